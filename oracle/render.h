@@ -1,0 +1,198 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see bits.h).
+// Render pipeline stages: restates libjxl v0.11.2 lib/jxl/{compressed_dc.cc (adaptive LF smoothing), epf.cc,
+// render_pipeline/stage_{gaborish,epf,xyb,from_linear,write}.cc, dec_xyb-inl.h, cms/transfer_functions-inl.h}.
+// SURVEY.md App. B.6 "Render constants [R]" — constants self-consistency-checked, operation order recalled:
+// PARITY UNPINNED against libjxl.  The integer write stage is [V] through the PNG goldens.
+#pragma once
+#include "headers.h"
+#include <cmath>
+
+namespace jxlo {
+
+struct Plane {
+  int w = 0, h = 0;
+  std::vector<float> d;
+  Plane() {}
+  Plane(int w_, int h_) : w(w_), h(h_), d((size_t)w_ * h_, 0.f) {}
+  float* row(int y) { return d.data() + (size_t)y * w; }
+  const float* row(int y) const { return d.data() + (size_t)y * w; }
+};
+struct Image3 { Plane p[3]; int w() const { return p[0].w; } int h() const { return p[0].h; } };
+
+inline int Mirror(int x, int size) {
+  while (x < 0 || x >= size) x = x < 0 ? -x - 1 : 2 * size - 1 - x;
+  return x;
+}
+
+// compressed_dc.cc AdaptiveDCSmoothing [R]
+inline void AdaptiveLFSmoothing(const float* lf_factors, Image3& lf) {
+  const int w = lf.w(), h = lf.h();
+  if (w <= 2 || h <= 2) return;
+  const float kW0 = 0.05226273532324128f, kW1 = 0.20345139757231578f, kW2 = 0.0334829185968739f;
+  Image3 out = lf;
+  for (int y = 1; y + 1 < h; y++) {
+    for (int x = 1; x + 1 < w; x++) {
+      float gap = 0.5f;
+      float mc[3], sm[3];
+      for (int c = 0; c < 3; c++) {
+        const float* t = lf.p[c].row(y - 1); const float* m = lf.p[c].row(y); const float* b = lf.p[c].row(y + 1);
+        float corner = (t[x - 1] + t[x + 1]) + (b[x - 1] + b[x + 1]);
+        float edge = (t[x] + m[x - 1]) + (m[x + 1] + b[x]);
+        mc[c] = m[x];
+        sm[c] = std::fmaf(corner, kW2, std::fmaf(edge, kW1, mc[c] * kW0));
+        gap = std::max(gap, std::fabs((mc[c] - sm[c]) / lf_factors[c]));
+      }
+      float factor = std::max(0.0f, std::fmaf(-4.0f, gap, 3.0f));
+      for (int c = 0; c < 3; c++) out.p[c].row(y)[x] = std::fmaf(sm[c] - mc[c], factor, mc[c]);
+    }
+  }
+  lf = out;
+}
+
+// stage_gaborish.cc [R]: 3x3 symmetric convolution, mirrored image borders
+inline void Gaborish(const LoopFilter& lf, Image3& img) {
+  const int w = img.w(), h = img.h();
+  for (int c = 0; c < 3; c++) {
+    float w1 = lf.gab_w[2 * c], w2 = lf.gab_w[2 * c + 1];
+    float div = 1.0f + 4.0f * (w1 + w2);
+    float n0 = 1.0f / div, n1 = w1 / div, n2 = w2 / div;
+    Plane out(w, h);
+    for (int y = 0; y < h; y++) {
+      const float* t = img.p[c].row(Mirror(y - 1, h));
+      const float* m = img.p[c].row(y);
+      const float* b = img.p[c].row(Mirror(y + 1, h));
+      float* o = out.row(y);
+      for (int x = 0; x < w; x++) {
+        int xl = Mirror(x - 1, w), xr = Mirror(x + 1, w);
+        float sum0 = m[x];
+        float sum1 = (m[xl] + m[xr]) + (t[x] + b[x]);
+        float sum2 = (t[xl] + t[xr]) + (b[xl] + b[xr]);
+        o[x] = std::fmaf(sum2, n2, std::fmaf(sum1, n1, sum0 * n0));
+      }
+    }
+    img.p[c] = out;
+  }
+}
+
+static const float kInvSigmaNum = -1.1715728752538099024f;
+static const float kMinSigma = -3.90524291751269967465540850526868f;
+
+// epf.cc ComputeSigma [R]: per-8x8-block inverse sigma. hf_mul/sharpness are per 8x8 block maps of the frame.
+inline void ComputeInvSigma(const LoopFilter& lf, float quant_scale, const std::vector<int32_t>& hf_mul,
+                            const std::vector<uint8_t>& sharpness, int bw, int bh, std::vector<float>& inv_sigma) {
+  inv_sigma.assign((size_t)bw * bh, 0.f);
+  for (int i = 0; i < bw * bh; i++) {
+    float sigma_quant = lf.quant_mul / (quant_scale * (float)hf_mul[i] * kInvSigmaNum);
+    float sigma = sigma_quant * lf.sharp_lut[sharpness[i]];
+    sigma = std::min(-1e-4f, sigma);
+    inv_sigma[i] = 1.0f / sigma;
+  }
+}
+
+// stage_epf.cc [R]. pass: 0 (12 taps, plus-SAD), 1 (4 taps, plus-SAD), 2 (4 taps, point-SAD)
+inline void EPFPass(const LoopFilter& lf, int pass, const std::vector<float>& inv_sigma, int bw, Image3& img) {
+  const int w = img.w(), h = img.h();
+  Image3 out = img;
+  float sigma_scale = pass == 0 ? lf.pass0_sigma_scale : pass == 2 ? lf.pass2_sigma_scale : 1.0f;
+  const float sm = sigma_scale * 1.65f;
+  const float bsm = sm * lf.border_sad_mul;
+  static const int taps0[12][2] = {{0, -2}, {-1, -1}, {0, -1}, {1, -1}, {-2, 0}, {-1, 0}, {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {0, 2}};
+  static const int taps1[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  static const int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  auto px = [&](int c, int x, int y) -> float { return img.p[c].row(Mirror(y, h))[Mirror(x, w)]; };
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      float is = inv_sigma[(size_t)(y / 8) * bw + x / 8];
+      if (is < kMinSigma) continue;  // copy
+      bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
+      float sad_mul = border ? bsm : sm;
+      float vmul = is * sad_mul;
+      float wsum = 1.0f;
+      float acc[3] = {px(0, x, y), px(1, x, y), px(2, x, y)};
+      const int ntaps = pass == 0 ? 12 : 4;
+      for (int t = 0; t < ntaps; t++) {
+        int dx = pass == 0 ? taps0[t][0] : taps1[t][0];
+        int dy = pass == 0 ? taps0[t][1] : taps1[t][1];
+        float sad = 0.f;
+        if (pass == 2) {
+          for (int c = 0; c < 3; c++) sad = std::fmaf(std::fabs(px(c, x + dx, y + dy) - px(c, x, y)), lf.channel_scale[c], sad);
+        } else {
+          for (int c = 0; c < 3; c++) {
+            float s = 0.f;
+            for (int k = 0; k < 5; k++) s += std::fabs(px(c, x + dx + plus[k][0], y + dy + plus[k][1]) - px(c, x + plus[k][0], y + plus[k][1]));
+            sad = std::fmaf(s, lf.channel_scale[c], sad);
+          }
+        }
+        float wgt = std::max(0.0f, std::fmaf(sad, vmul, 1.0f));
+        wsum += wgt;
+        for (int c = 0; c < 3; c++) acc[c] = std::fmaf(wgt, px(c, x + dx, y + dy), acc[c]);
+      }
+      float inv = 1.0f / wsum;
+      for (int c = 0; c < 3; c++) out.p[c].row(y)[x] = acc[c] * inv;
+    }
+  }
+  img = out;
+}
+
+// dec_xyb-inl.h XybToRgb + opsin_params.cc [R]
+struct OpsinParams {
+  float inv[9];
+  float neg_bias[3];       // -bias
+  float neg_bias_cbrt[3];  // cbrt(-bias)
+};
+inline OpsinParams MakeOpsin(const ImageMetadata& m, float intensity_target) {
+  OpsinParams o;
+  float s = 255.0f / intensity_target;
+  for (int i = 0; i < 9; i++) o.inv[i] = m.opsin_inv[i] * s;
+  for (int i = 0; i < 3; i++) { o.neg_bias[i] = m.opsin_bias[i]; o.neg_bias_cbrt[i] = std::cbrt(m.opsin_bias[i]); }
+  return o;
+}
+inline void XybToLinear(const OpsinParams& o, float X, float Y, float B, float* r, float* g, float* b) {
+  float gr = (Y + X) - o.neg_bias_cbrt[0];
+  float gg = (Y - X) - o.neg_bias_cbrt[1];
+  float gb = B - o.neg_bias_cbrt[2];
+  float mr = std::fmaf(gr * gr, gr, o.neg_bias[0]);
+  float mg = std::fmaf(gg * gg, gg, o.neg_bias[1]);
+  float mb = std::fmaf(gb * gb, gb, o.neg_bias[2]);
+  *r = std::fmaf(o.inv[2], mb, std::fmaf(o.inv[1], mg, o.inv[0] * mr));
+  *g = std::fmaf(o.inv[5], mb, std::fmaf(o.inv[4], mg, o.inv[3] * mr));
+  *b = std::fmaf(o.inv[8], mb, std::fmaf(o.inv[7], mg, o.inv[6] * mr));
+}
+
+// transfer_functions-inl.h TF_SRGB::EncodedFromDisplay [R] (rational polynomial in sqrt(x))
+inline float LinearToSRGB(float v) {
+  static const float p[5] = {-5.135152395e-4f, 5.287254571e-3f, 3.903842876e-1f, 1.474205315f, 7.352629620e-1f};
+  static const float q[5] = {1.004519624e-2f, 3.036675394e-1f, 1.340816930f, 9.258482155e-1f, 2.424867759e-2f};
+  float x = std::fabs(v);
+  float lin = x * 12.92f;
+  float s = std::sqrt(x);
+  float yp = p[4], yq = q[4];
+  for (int i = 3; i >= 0; i--) { yp = std::fmaf(yp, s, p[i]); yq = std::fmaf(yq, s, q[i]); }
+  float poly = yp / yq;
+  float r = x > 0.0031308f ? poly : lin;
+  return std::copysign(r, v);
+}
+
+inline uint16_t FloatToHalf(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000;
+  int32_t exp = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+  uint32_t mant = x & 0x7FFFFF;
+  if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00 | (mant ? 0x200 : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7C00);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    mant |= 0x800000;
+    int shift = 14 - exp;
+    uint32_t m = mant >> shift;
+    uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (m & 1))) m++;
+    return (uint16_t)(sign | m);
+  }
+  uint32_t m = mant >> 13, rem = mant & 0x1FFF;
+  uint32_t r = (uint32_t)(exp << 10) | m;
+  if (rem > 0x1000 || (rem == 0x1000 && (m & 1))) r++;
+  return (uint16_t)(sign | r);
+}
+
+}  // namespace jxlo
