@@ -1,0 +1,83 @@
+"""ctypes binding of tools/_build/libjxlsynth.so — deterministic JPEG XL bit-stream synthesiser (fixture generator)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOLS_DIR = os.path.join(ROOT, "tools")
+LIB_PATH = os.path.join(TOOLS_DIR, "_build", "libjxlsynth.so")
+
+
+class Params(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("distance", C.c_float), ("epf_iters", C.c_int32), ("gab", C.c_int32),
+                ("strategy_mix", C.c_int32), ("out_bits", C.c_int32), ("hdr", C.c_int32), ("skip_lf_smoothing", C.c_int32),
+                ("custom_orders", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", TOOLS_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.jxlsynth_last_error.restype = C.c_char_p
+        L.jxlsynth_free.argtypes = [C.c_void_p]
+        L.jxlsynth_image.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.jxlsynth_vardct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.jxlsynth_modular.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        _lib = L
+    return _lib
+
+
+def synthetic_image(seed, w, h):
+    """Seeded synthetic sRGB u8 image: low-frequency cosines + soft rectangles + noise."""
+    out = np.empty((h, w, 3), np.uint8)
+    lib().jxlsynth_image(seed, w, h, out.ctypes.data)
+    return out
+
+
+def _take(out, n):
+    data = C.string_at(out.value, n.value)
+    lib().jxlsynth_free(out)
+    return data
+
+
+def encode_vardct(rgb, seed=1, distance=1.0, epf_iters=1, gab=1, strategy_mix=1, out_bits=8, hdr=0, skip_lf_smoothing=0):
+    """rgb: (h,w,3) uint8 sRGB, or float32 linear when hdr=1.  Returns codestream bytes."""
+    L = lib()
+    h, w = rgb.shape[:2]
+    p = Params(seed=seed, distance=distance, epf_iters=epf_iters, gab=gab, strategy_mix=strategy_mix, out_bits=out_bits,
+               hdr=hdr, skip_lf_smoothing=skip_lf_smoothing)
+    out = C.c_void_p(); n = C.c_size_t()
+    if rgb.dtype == np.uint8:
+        a = np.ascontiguousarray(rgb)
+        rc = L.jxlsynth_vardct(a.ctypes.data, None, w, h, C.byref(p), C.byref(out), C.byref(n))
+    else:
+        a = np.ascontiguousarray(rgb, dtype=np.float32)
+        rc = L.jxlsynth_vardct(None, a.ctypes.data, w, h, C.byref(p), C.byref(out), C.byref(n))
+    if rc:
+        raise RuntimeError(L.jxlsynth_last_error().decode())
+    return _take(out, n)
+
+
+def encode_modular(img, bits=8, rct=False):
+    """img: (h,w,C) integer array, C in {1,2,3,4} (2/4 = with alpha).  Lossless Modular codestream."""
+    L = lib()
+    h, w, c = img.shape
+    has_alpha = c in (2, 4)
+    nchan = c - (1 if has_alpha else 0)
+    planes = [np.ascontiguousarray(img[..., i].astype(np.int32)) for i in range(c)]
+    arr = (C.c_void_p * c)(*[p.ctypes.data for p in planes])
+    out = C.c_void_p(); n = C.c_size_t()
+    rc = L.jxlsynth_modular(arr, nchan, 1 if has_alpha else 0, w, h, bits, 1 if rct else 0, C.byref(out), C.byref(n))
+    if rc:
+        raise RuntimeError(L.jxlsynth_last_error().decode())
+    return _take(out, n)

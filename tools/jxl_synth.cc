@@ -1,0 +1,748 @@
+// jxlsynth — deterministic JPEG XL bit-stream synthesiser.
+// Produces conformant VarDCT (XYB, ANS, variable block sizes, gaborish/EPF flags) and Modular-lossless streams from
+// seeded synthetic images, because the reference ships no `cjxl -d 1` fixture and no encoder exists in this image.
+// Fixture/bench input generator only: NOT on the product decode path, independent of oracle/.
+#include "synth_dct.h"
+#include <map>
+
+namespace synth {
+
+// ---- PRNG + synthetic image (SURVEY §8d "Concrete synthetic inputs") ------------------------------------------------
+struct Pcg32 {
+  uint64_t state, inc;
+  explicit Pcg32(uint64_t seed, uint64_t seq = 54) { state = 0; inc = (seq << 1) | 1; next(); state += seed; next(); }
+  uint32_t next() {
+    uint64_t old = state;
+    state = old * 6364136223846793005ULL + inc;
+    uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+    return (xs >> rot) | (xs << ((32 - rot) & 31));
+  }
+  float uniform() { return (next() >> 8) * (1.0f / 16777216.0f); }
+  float gauss() { float u1 = std::max(uniform(), 1e-7f), u2 = uniform(); return std::sqrt(-2.0f * std::log(u1)) * std::cos(6.2831853f * u2); }
+};
+
+static void SyntheticImage(uint32_t seed, int w, int h, uint8_t* rgb) {
+  Pcg32 r1(seed * 4 + 1), r2(seed * 4 + 2), r3(seed * 4 + 3);
+  struct Cosine { float fx, fy, ph, amp[3]; } cs[8];
+  for (auto& c : cs) {
+    c.fx = (r1.uniform() * 2 - 1) * 6.0f / w * 6.2831853f; c.fy = (r1.uniform() * 2 - 1) * 6.0f / h * 6.2831853f;
+    c.ph = r1.uniform() * 6.2831853f;
+    for (float& a : c.amp) a = (r1.uniform() * 2 - 1) * 0.12f;
+  }
+  struct Rect { float x0, y0, x1, y1, soft, col[3], alpha; } rs[64];
+  for (auto& r : rs) {
+    float cx = r2.uniform() * w, cy = r2.uniform() * h, rw = (0.02f + r2.uniform() * 0.2f) * w, rh = (0.02f + r2.uniform() * 0.2f) * h;
+    r.x0 = cx - rw / 2; r.x1 = cx + rw / 2; r.y0 = cy - rh / 2; r.y1 = cy + rh / 2;
+    r.soft = 0.5f + r2.uniform() * 6.0f;
+    for (float& c : r.col) c = r2.uniform();
+    r.alpha = 0.3f + 0.7f * r2.uniform();
+  }
+  std::vector<float> fx(8 * w);
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      float v[3] = {0.5f, 0.5f, 0.5f};
+      for (auto& c : cs) { float s = std::cos(c.fx * x + c.fy * y + c.ph); for (int k = 0; k < 3; k++) v[k] += c.amp[k] * s; }
+      for (auto& r : rs) {
+        if (x < r.x0 - 3 * r.soft || x > r.x1 + 3 * r.soft || y < r.y0 - 3 * r.soft || y > r.y1 + 3 * r.soft) continue;
+        float dx = std::min(x - r.x0, r.x1 - x), dy = std::min(y - r.y0, r.y1 - y);
+        float d = std::min(dx, dy) / r.soft;
+        float a = r.alpha / (1.0f + std::exp(-2.0f * d));
+        for (int k = 0; k < 3; k++) v[k] = v[k] * (1 - a) + r.col[k] * a;
+      }
+      for (int k = 0; k < 3; k++) {
+        float t = v[k] + r3.gauss() * (2.0f / 255.0f);
+        int q = (int)std::lrintf(std::min(1.0f, std::max(0.0f, t)) * 255.0f);
+        rgb[((size_t)y * w + x) * 3 + k] = (uint8_t)q;
+      }
+    }
+  }
+}
+
+// ---- colour ----------------------------------------------------------------------------------------------------
+static inline float SrgbToLinear(float v) { return v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f); }
+static void LinearToXYB(float r, float g, float b, float* X, float* Y, float* B) {
+  const float bias = 0.0037930732552754493f;
+  float mr = 0.30f * r + 0.622f * g + 0.078f * b + bias;
+  float mg = 0.23f * r + 0.692f * g + 0.078f * b + bias;
+  float mb = 0.24342268924547819f * r + 0.20476744424496821f * g + 0.55180986650955360f * b + bias;
+  float cb = std::cbrt(bias);
+  float gr = std::cbrt(std::max(0.0f, mr)) - cb, gg = std::cbrt(std::max(0.0f, mg)) - cb, gb = std::cbrt(std::max(0.0f, mb)) - cb;
+  *X = 0.5f * (gr - gg); *Y = 0.5f * (gr + gg); *B = gb;
+}
+
+struct Params {
+  uint32_t seed = 1;
+  float distance = 1.0f;
+  int epf_iters = 1;
+  int gab = 1;
+  int strategy_mix = 1;   // 0 DCT8 only, 1 SURVEY mix, 2 + large blocks / exotic small ones
+  int out_bits = 8;       // 8 | 16 | 32 (float, linear, intensity_target 1000 when hdr)
+  int hdr = 0;
+  int skip_lf_smoothing = 0;
+  int custom_orders = 0;  // reserved
+  int reserved[8] = {0};
+};
+
+// ---- modular sub-stream tokenisation with the fixed global tree --------------------------------------------------
+// Tree (decode rule: property > split ? left : right):
+//  root: stream_id(prop1) > nLF ? HFMETA : LFCOEF
+//  LFCOEF: channel(prop0) > 0 ? (channel > 1 ? B : X) : Y ; each a balanced tree over prop 9 (W+N-NW) cutoffs,
+//          leaves = gradient predictor (5)
+//  HFMETA: channel > 1 ? (channel > 2 ? SHARP(pred W) : (y > 0 ? HFMUL(pred W) : STRATEGY(pred W))) : CFL (pred zero)
+struct TNode { int prop; int split; int l, r; int pred; int ctx; };
+struct GTree {
+  std::vector<TNode> nodes;
+  int num_leaves = 0;
+  int add_leaf(int pred) { nodes.push_back({-1, 0, -1, -1, pred, 0}); return (int)nodes.size() - 1; }
+  int add_inner(int prop, int split, int l, int r) { nodes.push_back({prop, split, l, r, 0, 0}); return (int)nodes.size() - 1; }
+};
+static int BuildCutoffTree(GTree& t, int prop, const std::vector<int>& cut, int lo, int hi, int pred) {
+  // values v with cut[i-1] < v <= cut[i] ... ; build balanced tree over cut[lo..hi)
+  if (lo >= hi) return t.add_leaf(pred);
+  int mid = (lo + hi) / 2;
+  int l = BuildCutoffTree(t, prop, cut, mid + 1, hi, pred);  // prop > cut[mid]
+  int r = BuildCutoffTree(t, prop, cut, lo, mid, pred);
+  return t.add_inner(prop, cut[mid], l, r);
+}
+static GTree MakeGlobalTree(int nlf, std::vector<int>* bfs_order) {
+  GTree t;
+  static const int cuts[] = {-255, -127, -63, -31, -15, -7, -3, -1, 0, 1, 3, 7, 15, 31, 63, 127, 255};
+  std::vector<int> cut(cuts, cuts + sizeof(cuts) / sizeof(cuts[0]));
+  int ty = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
+  int tx = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
+  int tb = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
+  int lf_c = t.add_inner(0, 1, tb, tx);
+  int lf = t.add_inner(0, 0, lf_c, ty);
+  int sharp = t.add_leaf(1), hfmul = t.add_leaf(1), strat = t.add_leaf(1), cfl = t.add_leaf(0);
+  int blk = t.add_inner(2, 0, hfmul, strat);
+  int c23 = t.add_inner(0, 2, sharp, blk);
+  int meta = t.add_inner(0, 1, c23, cfl);
+  int root = t.add_inner(1, nlf, meta, lf);
+  // BFS numbering (that is the order nodes are written / leaf contexts are assigned)
+  std::vector<int> order{root};
+  for (size_t i = 0; i < order.size(); i++) {
+    const TNode& n = t.nodes[order[i]];
+    if (n.prop >= 0) { order.push_back(n.l); order.push_back(n.r); }
+  }
+  int leaf = 0;
+  for (int id : order) if (t.nodes[id].prop < 0) t.nodes[id].ctx = leaf++;
+  t.num_leaves = leaf;
+  *bfs_order = order;
+  // move root to a known place: remember it as last node
+  return t;
+}
+
+static void TreeTokens(const GTree& t, const std::vector<int>& bfs, std::vector<Token>& tok) {
+  for (int id : bfs) {
+    const TNode& n = t.nodes[id];
+    if (n.prop < 0) {
+      tok.push_back({1, 0});
+      tok.push_back({2, (uint32_t)n.pred});
+      tok.push_back({3, 0});  // offset
+      tok.push_back({4, 0});  // mul_log
+      tok.push_back({5, 0});  // mul_bits
+    } else {
+      tok.push_back({1, (uint32_t)n.prop + 1});
+      tok.push_back({0, PackSigned(n.split)});
+    }
+  }
+}
+
+// tokenises channels (each w x h ints) of one modular sub-stream under the global tree
+struct ChanRef { const int32_t* d; int w, h; };
+static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& chans, int stream_id, std::vector<Token>& tok) {
+  for (size_t ci = 0; ci < chans.size(); ci++) {
+    const ChanRef& ch = chans[ci];
+    for (int y = 0; y < ch.h; y++) {
+      const int32_t* p = ch.d + (size_t)y * ch.w;
+      const int32_t* pn = y ? p - ch.w : nullptr;
+      for (int x = 0; x < ch.w; x++) {
+        int64_t W = x ? p[x - 1] : (y ? pn[x] : 0);
+        int64_t N = y ? pn[x] : W;
+        int64_t NW = (x && y) ? pn[x - 1] : W;
+        int props[10] = {(int)ci, stream_id, y, x, 0, 0, 0, 0, 0, (int)(W + N - NW)};
+        int pos = root;
+        while (t.nodes[pos].prop >= 0) pos = props[t.nodes[pos].prop] > t.nodes[pos].split ? t.nodes[pos].l : t.nodes[pos].r;
+        const TNode& leaf = t.nodes[pos];
+        int64_t guess;
+        if (leaf.pred == 0) guess = 0;
+        else if (leaf.pred == 1) guess = W;
+        else { int64_t m = std::min(N, W), M = std::max(N, W), g = N + W - NW; guess = NW < m ? M : (NW > M ? m : g); }
+        tok.push_back({(uint32_t)leaf.ctx, PackSigned((int32_t)(p[x] - guess))});
+      }
+    }
+  }
+}
+
+// ---- image / frame headers -------------------------------------------------------------------------------------
+static void WriteSize(BitWriter& w, uint32_t xs, uint32_t ys) {
+  w.put(0, 1);  // small = 0
+  WriteU32(w, ys, {9, 1}, {13, 1}, {18, 1}, {30, 1});
+  w.put(0, 3);  // ratio 0
+  WriteU32(w, xs, {9, 1}, {13, 1}, {18, 1}, {30, 1});
+}
+
+static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool xyb, int bits, bool has_alpha, bool gray) {
+  w.put(0xFF, 8); w.put(0x0A, 8);
+  WriteSize(w, xs, ys);
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray;
+  w.put(all_default, 1);
+  if (!all_default) {
+    bool extra_fields = p.hdr;
+    w.put(extra_fields, 1);
+    if (extra_fields) {
+      w.put(0, 3);  // orientation 1
+      w.put(0, 1); w.put(0, 1); w.put(0, 1);  // no intrinsic size / preview / animation
+    }
+    // BitDepth
+    if (p.out_bits == 32) { w.put(1, 1); WriteU32(w, 32, {0, 32}, {0, 16}, {0, 24}, {6, 1}); w.put(8 - 1, 4); }
+    else { w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1}); }
+    w.put(1, 1);  // modular_16bit_buffers
+    WriteU32(w, has_alpha ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {12, 1});
+    if (has_alpha) {
+      if (bits == 8) w.put(1, 1);  // d_alpha
+      else {
+        w.put(0, 1);
+        WriteU32(w, 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});  // type alpha
+        w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1});
+        WriteU32(w, 0, {0, 0}, {0, 3}, {0, 4}, {3, 1});  // dim_shift
+        WriteU32(w, 0, {0, 0}, {4, 0}, {5, 16}, {10, 48});  // name
+        w.put(0, 1);  // alpha_associated
+      }
+    }
+    w.put(xyb, 1);
+    // ColorEncoding
+    bool ce_default = !p.hdr && !gray;
+    w.put(ce_default, 1);
+    if (!ce_default) {
+      w.put(0, 1);  // want_icc
+      WriteU32(w, gray ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});   // colour space
+      WriteU32(w, 1, {0, 0}, {0, 1}, {4, 2}, {6, 18});              // white point D65
+      if (!gray) WriteU32(w, 1, {0, 0}, {0, 1}, {4, 2}, {6, 18});   // primaries sRGB
+      w.put(0, 1);                                                  // have_gamma = 0
+      WriteU32(w, p.hdr ? 8 : 13, {0, 0}, {0, 1}, {4, 2}, {6, 18}); // tf linear | sRGB
+      WriteU32(w, 1, {0, 0}, {0, 1}, {4, 2}, {6, 18});              // rendering intent relative
+    }
+    if (extra_fields) {
+      w.put(0, 1);  // tone mapping not default
+      WriteF16(w, 1000.0f); WriteF16(w, 0.0f); w.put(0, 1); WriteF16(w, 0.0f);
+    }
+    WriteU64(w, 0);  // extensions
+  }
+  w.put(1, 1);  // default_m
+  w.align();
+}
+
+static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool xyb, int num_extra, int group_shift, bool lf_default) {
+  w.put(0, 1);  // all_default
+  w.put(0, 2);  // regular frame
+  w.put(modular ? 1 : 0, 1);
+  WriteU64(w, (!modular && p.skip_lf_smoothing) ? 0x80 : 0);
+  if (!xyb) w.put(0, 1);  // do_YCbCr
+  w.put(0, 2);            // upsampling 1
+  for (int i = 0; i < num_extra; i++) w.put(0, 2);
+  if (modular) w.put(group_shift, 2);
+  if (!modular && xyb) { w.put(3, 3); w.put(2, 3); }
+  w.put(0, 2);  // num_passes = 1
+  w.put(0, 1);  // have_crop
+  // blending info (+ one per extra channel)
+  for (int i = 0; i < 1 + num_extra; i++) w.put(0, 2);  // mode Replace
+  w.put(1, 1);  // is_last
+  w.put(0, 2);  // name length 0
+  // RestorationFilter
+  if (lf_default) w.put(1, 1);
+  else {
+    w.put(0, 1);
+    w.put(p.gab ? 1 : 0, 1);
+    if (p.gab) w.put(0, 1);  // gab_custom
+    w.put(p.epf_iters, 2);
+    if (p.epf_iters > 0) {
+      if (!modular) w.put(0, 1);  // sharp_custom
+      w.put(0, 1);                // weight_custom
+      w.put(0, 1);                // sigma_custom
+      if (modular) WriteF16(w, 1.0f);
+    }
+    WriteU64(w, 0);
+  }
+  WriteU64(w, 0);  // frame extensions
+}
+
+static void WriteTOCAndSections(BitWriter& out, const std::vector<BitWriter>& sections, bool single) {
+  out.put(0, 1);  // not permuted
+  out.align();
+  if (single) {
+    BitWriter all;
+    for (auto& s : sections) all.append(s);
+    all.align();
+    WriteU32(out, (uint32_t)all.bytes.size(), {10, 0}, {14, 1024}, {22, 17408}, {30, 4211712});
+    out.align();
+    for (uint8_t b : all.bytes) out.bytes.push_back(b);
+    return;
+  }
+  std::vector<BitWriter> al = sections;
+  for (auto& s : al) s.align();
+  for (auto& s : al) WriteU32(out, (uint32_t)s.bytes.size(), {10, 0}, {14, 1024}, {22, 17408}, {30, 4211712});
+  out.align();
+  for (auto& s : al) out.bytes.insert(out.bytes.end(), s.bytes.begin(), s.bytes.end());
+}
+
+// ---- VarDCT encoder ----------------------------------------------------------------------------------------------
+static const uint16_t kFreqCtx[64] = {0xBAD, 0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 15, 16, 16, 17, 17,
+                                      18,    18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23, 23, 23, 24, 24, 24, 24, 25, 25, 25, 25,
+                                      26,    26, 26, 26, 27, 27, 27, 27, 28, 28, 28, 28, 29, 29, 29, 29, 30, 30, 30, 30};
+static const uint16_t kNzCtx[64] = {0xBAD, 0,   31,  62,  62,  93,  93,  93,  93,  123, 123, 123, 123, 152, 152, 152,
+                                    152,   152, 152, 152, 152, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180,
+                                    180,   206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
+                                    206,   206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206};
+static const uint8_t kDefaultBlockCtx[39] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14,
+                                             7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
+
+static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p) {
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8;
+  const int pw = bw * 8, ph = bh * 8;
+  const int xg = (w + 255) / 256, yg = (h + 255) / 256, ngroups = xg * yg;
+  const int xlg = (w + 2047) / 2048, ylg = (h + 2047) / 2048, nlf = xlg * ylg;
+  const int cw = (bw + 7) / 8, chh = (bh + 7) / 8;
+  Pcg32 rng(p.seed * 977 + 4);
+  // padded planes (edge replicate)
+  std::vector<float> pl[3];
+  for (int c = 0; c < 3; c++) {
+    pl[c].resize((size_t)pw * ph);
+    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) pl[c][(size_t)y * pw + x] = xyb_planes[c][(size_t)std::min(y, h - 1) * w + std::min(x, w - 1)];
+  }
+  // --- strategy map
+  std::vector<int8_t> strat((size_t)bw * bh, -1);
+  std::vector<uint8_t> first((size_t)bw * bh, 0);
+  struct Cand { int s; float prob; };
+  std::vector<Cand> cands;
+  if (p.strategy_mix == 1) cands = {{S_DCT32X32, 0.05f}, {S_DCT16X16, 0.10f}, {S_DCT16X8, 0.075f}, {S_DCT8X16, 0.075f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.04f}};
+  else if (p.strategy_mix >= 2) cands = {{S_DCT64X64, 0.02f}, {S_DCT64X32, 0.01f}, {S_DCT32X64, 0.01f}, {S_DCT32X32, 0.04f}, {S_DCT32X16, 0.02f}, {S_DCT16X32, 0.02f}, {S_DCT32X8, 0.02f},
+                                         {S_DCT8X32, 0.02f}, {S_DCT16X16, 0.08f}, {S_DCT16X8, 0.06f}, {S_DCT8X16, 0.06f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.03f},
+                                         {S_DCT2X2, 0.02f}, {S_IDENTITY, 0.02f}};
+  if (p.strategy_mix >= 100) cands = {{p.strategy_mix - 100, 1.0f}};  // force one strategy wherever it fits
+  for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
+    if (strat[(size_t)by * bw + bx] >= 0) continue;
+    int chosen = S_DCT;
+    float r = rng.uniform(), acc = 0;
+    for (auto& c : cands) {
+      acc += c.prob * (float)(kCovX[c.s] * kCovY[c.s]);  // weight by area so that *pixel* share matches prob
+      if (r >= acc) continue;
+      int cx = kCovX[c.s], cy = kCovY[c.s];
+      bool ok = (bx % cx == 0) && (by % cy == 0) && bx + cx <= bw && by + cy <= bh && (bx % 32) + cx <= 32 && (by % 32) + cy <= 32;
+      for (int iy = 0; ok && iy < cy; iy++) for (int ix = 0; ix < cx; ix++) if (strat[(size_t)(by + iy) * bw + bx + ix] >= 0) ok = false;
+      if (ok) chosen = c.s;
+      break;
+    }
+    int cx = kCovX[chosen], cy = kCovY[chosen];
+    for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) strat[(size_t)(by + iy) * bw + bx + ix] = (int8_t)chosen;
+    first[(size_t)by * bw + bx] = 1;
+  }
+  // --- quantisation parameters
+  const uint32_t global_scale = (uint32_t)std::min(65535.0f, std::max(1.0f, 4587.0f / p.distance));
+  const uint32_t quant_lf = 16;
+  const float inv_gs = 65536.0f / (float)global_scale;
+  const float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
+  const float x_dm = 0.8f, b_dm = 1.0f;  // x_qm_scale 3, b_qm_scale 2
+  std::vector<int32_t> hf_mul((size_t)bw * bh, 1);
+  std::vector<int32_t> sharp((size_t)bw * bh, 0);
+  for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
+    size_t o = (size_t)by * bw + bx;
+    if (first[o]) {
+      int q = 14 + (int)(rng.next() % 12);
+      int s = strat[o];
+      for (int iy = 0; iy < kCovY[s]; iy++) for (int ix = 0; ix < kCovX[s]; ix++) hf_mul[o + (size_t)iy * bw + ix] = q;
+    }
+    uint32_t r = rng.next() % 100;
+    sharp[o] = r < 10 ? 0 : r < 70 ? 4 : (int)(r % 8);
+  }
+  // quant tables for used kinds
+  bool used_kind[17] = {false};
+  for (size_t o = 0; o < strat.size(); o++) used_kind[kKind[strat[o]]] = true;
+  QuantSpec specs[17];
+  std::vector<float> table[17][3];
+  for (int k = 0; k < 17; k++) {
+    if (!used_kind[k]) { specs[k].mode = 0; continue; }
+    specs[k] = DefaultSpec(k);
+    for (int c = 0; c < 3; c++) ComputeTable(specs[k], k, c, table[k][c]);
+  }
+  // --- forward transforms, LF extraction
+  std::vector<float> lf[3];
+  for (int c = 0; c < 3; c++) lf[c].assign((size_t)bw * bh, 0.f);
+  // coefficient storage per varblock: offset table
+  std::vector<size_t> coff((size_t)bw * bh, 0);
+  size_t total_coef = 0;
+  for (size_t o = 0; o < strat.size(); o++) if (first[o]) { coff[o] = total_coef; total_coef += (size_t)kCovX[strat[o]] * kCovY[strat[o]] * 64; }
+  std::vector<float> coef[3];
+  for (int c = 0; c < 3; c++) coef[c].assign(total_coef, 0.f);
+  for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
+    size_t o = (size_t)by * bw + bx;
+    if (!first[o]) continue;
+    int s = strat[o];
+    for (int c = 0; c < 3; c++) {
+      float* cf = coef[c].data() + coff[o];
+      ForwardTransform(s, pl[c].data() + (size_t)by * 8 * pw + bx * 8, pw, cf);
+      LFFromLowestFrequencies(s, cf, lf[c].data() + o, bw);
+    }
+  }
+  // --- quantise LF (Y first; X and B coded relative to dequantised Y: default cfl for LF = (0, 1))
+  std::vector<int32_t> lfq[3];
+  for (int c = 0; c < 3; c++) lfq[c].assign((size_t)bw * bh, 0);
+  float lfstep[3];
+  for (int c = 0; c < 3; c++) lfstep[c] = m_lf[c] * inv_gs / (float)quant_lf;
+  for (size_t o = 0; o < (size_t)bw * bh; o++) {
+    int32_t qy = (int32_t)std::lrintf(lf[1][o] / lfstep[1]);
+    float dy = qy * lfstep[1];
+    lfq[1][o] = qy;
+    lfq[0][o] = (int32_t)std::lrintf(lf[0][o] / lfstep[0]);
+    lfq[2][o] = (int32_t)std::lrintf((lf[2][o] - dy) / lfstep[2]);
+  }
+  // --- chroma-from-luma factors per 64x64 tile: X uses 0, B least-squares around base 1.0
+  std::vector<int32_t> ytox((size_t)cw * chh, 0), ytob((size_t)cw * chh, 0);
+  {
+    std::vector<double> num((size_t)cw * chh, 0.0), den((size_t)cw * chh, 0.0);
+    for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
+      size_t o = (size_t)by * bw + bx;
+      if (!first[o]) continue;
+      int s = strat[o];
+      size_t n = (size_t)kCovX[s] * kCovY[s] * 64;
+      size_t tile = (size_t)(by / 8) * cw + bx / 8;
+      const float* y = coef[1].data() + coff[o]; const float* b = coef[2].data() + coff[o];
+      for (size_t k = 1; k < n; k++) { num[tile] += (double)y[k] * (b[k] - y[k]); den[tile] += (double)y[k] * y[k]; }
+    }
+    for (size_t t = 0; t < num.size(); t++) {
+      double f = den[t] > 1e-12 ? num[t] / den[t] : 0.0;
+      int v = (int)std::lrint(f * 84.0);
+      ytob[t] = std::max(-128, std::min(127, v));
+      ytox[t] = 0;
+    }
+  }
+  // --- quantise AC
+  std::vector<int32_t> qc[3];
+  for (int c = 0; c < 3; c++) qc[c].assign(total_coef, 0);
+  const float bias[4] = {1.0f - 0.05465007330715401f, 1.0f - 0.07005449891748593f, 1.0f - 0.049935103337343655f, 0.145f};
+  auto quant = [](float v) -> int32_t {
+    float a = std::fabs(v);
+    if (a < 0.58f) return 0;
+    int32_t q = (int32_t)(a + 0.5f);
+    return v < 0 ? -q : q;
+  };
+  for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
+    size_t o = (size_t)by * bw + bx;
+    if (!first[o]) continue;
+    int s = strat[o], kind = kKind[s];
+    int cx = kCovX[s], cy = kCovY[s];
+    size_t n = (size_t)cx * cy * 64;
+    float sd = inv_gs / (float)hf_mul[o];
+    float sdc[3] = {sd * x_dm, sd, sd * b_dm};
+    size_t tile = (size_t)(by / 8) * cw + bx / 8;
+    float kx = 0.0f + ytox[tile] / 84.0f, kb = 1.0f + ytob[tile] / 84.0f;
+    const float* ty = table[kind][1].data(); const float* tx = table[kind][0].data(); const float* tb = table[kind][2].data();
+    float* fy = coef[1].data() + coff[o]; float* fx = coef[0].data() + coff[o]; float* fb = coef[2].data() + coff[o];
+    int32_t* qy = qc[1].data() + coff[o]; int32_t* qx = qc[0].data() + coff[o]; int32_t* qb = qc[2].data() + coff[o];
+    // LLF slots are not coded: zero them (they are positions (v<cy,u<cx) of the stored layout)
+    std::vector<uint8_t> is_llf(n, 0);
+    { int R = 8 * cy, C = 8 * cx; for (int v = 0; v < cy; v++) for (int u = 0; u < cx; u++) is_llf[StoredIdx(R, C, v, u)] = 1; }
+    for (size_t k = 0; k < n; k++) {
+      if (is_llf[k]) continue;
+      int32_t q = quant(fy[k] / (ty[k] * sdc[1]));
+      qy[k] = q;
+      float adj = q == 0 ? 0.f : (q == 1 ? bias[1] : q == -1 ? -bias[1] : (float)q - bias[3] / (float)q);
+      float dy = adj * (ty[k] * sdc[1]);
+      qx[k] = quant((fx[k] - kx * dy) / (tx[k] * sdc[0]));
+      qb[k] = quant((fb[k] - kb * dy) / (tb[k] * sdc[2]));
+    }
+  }
+  // --- tokens: modular streams (LF coefficients + HF metadata) under the global tree
+  std::vector<int> bfs;
+  GTree gt = MakeGlobalTree(nlf, &bfs);
+  const int root = bfs[0];
+  std::vector<Token> tree_tokens;
+  TreeTokens(gt, bfs, tree_tokens);
+  struct LfGroupData { std::vector<int32_t> ch[3]; std::vector<int32_t> m[4]; int gbw, gbh, nb; std::vector<Token> lf_tok, meta_tok; };
+  std::vector<LfGroupData> lgd(nlf);
+  for (int g = 0; g < nlf; g++) {
+    LfGroupData& d = lgd[g];
+    int gx = g % xlg, gy = g / xlg, bx0 = gx * 256, by0 = gy * 256;
+    d.gbw = std::min(256, bw - bx0); d.gbh = std::min(256, bh - by0);
+    static const int order[3] = {1, 0, 2};  // Y, X, B
+    for (int i = 0; i < 3; i++) {
+      d.ch[i].resize((size_t)d.gbw * d.gbh);
+      for (int y = 0; y < d.gbh; y++) for (int x = 0; x < d.gbw; x++) d.ch[i][(size_t)y * d.gbw + x] = lfq[order[i]][(size_t)(by0 + y) * bw + bx0 + x];
+    }
+    std::vector<ChanRef> cr;
+    for (int i = 0; i < 3; i++) cr.push_back({d.ch[i].data(), d.gbw, d.gbh});
+    ModularTokens(gt, root, cr, 1 + g, d.lf_tok);
+    // HF metadata
+    int mcw = (d.gbw + 7) / 8, mch = (d.gbh + 7) / 8;
+    d.m[0].resize((size_t)mcw * mch); d.m[1].resize((size_t)mcw * mch);
+    for (int y = 0; y < mch; y++) for (int x = 0; x < mcw; x++) {
+      d.m[0][(size_t)y * mcw + x] = ytox[(size_t)(gy * 32 + y) * cw + gx * 32 + x];
+      d.m[1][(size_t)y * mcw + x] = ytob[(size_t)(gy * 32 + y) * cw + gx * 32 + x];
+    }
+    std::vector<int32_t> st, hm;
+    for (int y = 0; y < d.gbh; y++) for (int x = 0; x < d.gbw; x++) {
+      size_t o = (size_t)(by0 + y) * bw + bx0 + x;
+      if (first[o]) { st.push_back(strat[o]); hm.push_back(hf_mul[o] - 1); }
+    }
+    d.nb = (int)st.size();
+    d.m[2] = st; d.m[2].insert(d.m[2].end(), hm.begin(), hm.end());
+    d.m[3].resize((size_t)d.gbw * d.gbh);
+    for (int y = 0; y < d.gbh; y++) for (int x = 0; x < d.gbw; x++) d.m[3][(size_t)y * d.gbw + x] = sharp[(size_t)(by0 + y) * bw + bx0 + x];
+    std::vector<ChanRef> mr{{d.m[0].data(), mcw, mch}, {d.m[1].data(), mcw, mch}, {d.m[2].data(), d.nb, 2}, {d.m[3].data(), d.gbw, d.gbh}};
+    ModularTokens(gt, root, mr, 1 + 2 * nlf + g, d.meta_tok);
+  }
+  // --- tokens: AC per group
+  const int nctx = 15;
+  std::vector<std::vector<Token>> ac_tok(ngroups);
+  std::vector<uint32_t> natural[13];
+  static const int bucket_rep[13] = {S_DCT, S_IDENTITY, S_DCT16X16, S_DCT32X32, S_DCT16X8, S_DCT32X8, S_DCT32X16, S_DCT64X64, S_DCT64X32, 21, 22, 24, 25};
+  for (int b = 0; b < 9; b++) natural[b] = NaturalOrder(bucket_rep[b]);
+  for (int g = 0; g < ngroups; g++) {
+    int gx = g % xg, gy = g / xg, bx0 = gx * 32, by0 = gy * 32;
+    int gbw = std::min(32, bw - bx0), gbh = std::min(32, bh - by0);
+    uint8_t nzmap[3][1024];
+    memset(nzmap, 0, sizeof(nzmap));
+    std::vector<Token>& tk = ac_tok[g];
+    for (int by = 0; by < gbh; by++) for (int bx = 0; bx < gbw; bx++) {
+      size_t o = (size_t)(by0 + by) * bw + bx0 + bx;
+      if (!first[o]) continue;
+      int s = strat[o], cx = kCovX[s], cy = kCovY[s], covered = cx * cy, l2 = ILog2(covered), size = covered * 64, ord = kBucket[s];
+      const std::vector<uint32_t>& order = natural[ord];
+      static const int chan[3] = {1, 0, 2};
+      for (int ci = 0; ci < 3; ci++) {
+        int c = chan[ci];
+        int idx = (c < 2 ? (c ^ 1) : 2) * 13 + ord;
+        int block_ctx = kDefaultBlockCtx[idx];
+        const int32_t* q = qc[c].data() + coff[o];
+        int nz = 0;
+        for (int k = covered; k < size; k++) nz += q[order[k]] != 0;
+        int pred;
+        if (bx == 0) pred = by == 0 ? 32 : nzmap[c][(by - 1) * 32 + bx];
+        else if (by == 0) pred = nzmap[c][by * 32 + bx - 1];
+        else pred = (nzmap[c][(by - 1) * 32 + bx] + nzmap[c][by * 32 + bx - 1] + 1) / 2;
+        int pc = std::min(pred, 64);
+        uint32_t nzctx = pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2);
+        tk.push_back({nzctx, (uint32_t)nz});
+        uint8_t nzm = (uint8_t)((nz + covered - 1) >> l2);
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzmap[c][(by + iy) * 32 + bx + ix] = nzm;
+        uint32_t histo = 37 * nctx + 458 * block_ctx;
+        int left = nz;
+        uint32_t prev = nz > size / 16 ? 0 : 1;
+        for (int k = covered; k < size && left != 0; k++) {
+          uint32_t nzl = (left + covered - 1) >> l2, kk = (uint32_t)k >> l2;
+          uint32_t ctx = histo + (kNzCtx[nzl] + kFreqCtx[kk]) * 2 + prev;
+          uint32_t u = PackSigned(q[order[k]]);
+          tk.push_back({ctx, u});
+          prev = u != 0;
+          left -= prev;
+        }
+      }
+    }
+  }
+  // --- entropy codes
+  EntropyCoder tree_code, mod_code, ac_code;
+  { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
+  { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); }
+    BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 64, mod_code); }
+  { std::vector<const std::vector<Token>*> s; for (auto& t : ac_tok) s.push_back(&t);
+    BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_code); }
+  // --- sections
+  std::vector<BitWriter> sections;
+  {  // LfGlobal
+    BitWriter s;
+    s.put(1, 1);  // LfChannelDequantization all_default
+    WriteU32(s, global_scale, {11, 1}, {11, 2049}, {12, 4097}, {16, 8193});
+    WriteU32(s, quant_lf, {0, 16}, {5, 1}, {8, 1}, {16, 1});
+    s.put(1, 1);  // default BlockCtxMap
+    s.put(1, 1);  // default LfChannelCorrelation
+    s.put(1, 1);  // GlobalModular: has_tree
+    WriteEntropyCode(s, tree_code);
+    EncodeTokens(s, tree_code, tree_tokens);
+    WriteEntropyCode(s, mod_code);
+    sections.push_back(s);
+  }
+  for (int g = 0; g < nlf; g++) {  // LfGroup
+    BitWriter s;
+    LfGroupData& d = lgd[g];
+    s.put(0, 2);  // extra_precision
+    s.put(1, 1); s.put(1, 1); s.put(0, 2);  // GroupHeader: use_global_tree, default WP, 0 transforms
+    EncodeTokens(s, mod_code, d.lf_tok);
+    // (ModularLfGroup: no channels -> nothing)
+    s.put(d.nb - 1, CeilLog2((uint32_t)(d.gbw * d.gbh)));
+    s.put(1, 1); s.put(1, 1); s.put(0, 2);
+    EncodeTokens(s, mod_code, d.meta_tok);
+    sections.push_back(s);
+  }
+  {  // HfGlobal
+    BitWriter s;
+    s.put(0, 1);  // dequant matrices not all default
+    for (int k = 0; k < 17; k++) {
+      const QuantSpec& q = specs[k];
+      s.put(q.mode, 3);
+      auto write_bands = [&](const Bands& b) {
+        s.put(b.n - 1, 4);
+        for (int c = 0; c < 3; c++) for (int i = 0; i < b.n; i++) WriteF16(s, i == 0 ? b.v[c][i] / 64.0f : b.v[c][i]);
+      };
+      switch (q.mode) {
+        case 0: break;
+        case 1: for (int c = 0; c < 3; c++) for (int i = 0; i < 3; i++) WriteF16(s, q.idw[c][i] / 64.0f); break;
+        case 2: for (int c = 0; c < 3; c++) for (int i = 0; i < 6; i++) WriteF16(s, q.dct2w[c][i] / 64.0f); break;
+        case 3: for (int c = 0; c < 3; c++) for (int i = 0; i < 2; i++) WriteF16(s, q.dct4mul[c][i]); write_bands(q.dct); break;
+        case 4: for (int c = 0; c < 3; c++) WriteF16(s, q.dct4x8mul[c]); write_bands(q.dct); break;
+        case 6: write_bands(q.dct); break;
+      }
+    }
+    s.put(0, CeilLog2((uint32_t)ngroups));  // num_hf_presets - 1
+    s.put(2, 2);                            // used_orders = Val(0)
+    WriteEntropyCode(s, ac_code);
+    sections.push_back(s);
+  }
+  for (int g = 0; g < ngroups; g++) {  // PassGroup
+    BitWriter s;
+    // preset: ceil_log2(1) = 0 bits
+    EncodeTokens(s, ac_code, ac_tok[g]);
+    sections.push_back(s);
+  }
+  BitWriter out;
+  WriteImageHeader(out, w, h, p, true, p.out_bits == 16 ? 16 : 8, false, false);
+  bool lf_default = p.gab == 1 && p.epf_iters == 2;
+  WriteFrameHeader(out, p, false, true, 0, 1, lf_default);
+  WriteTOCAndSections(out, sections, ngroups == 1);
+  out.align();
+  return out.bytes;
+}
+
+// ---- Modular lossless encoder (gradient predictor, fixed global tree, 256x256 groups) ---------------------------
+static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int nchan, int w, int h, int bits, bool has_alpha, bool rct) {
+  // channels: nchan colour (1 or 3) [+1 alpha].  Optional RCT type 6 (YCgCo) signalled as a global transform.
+  const int group_shift = 1, gd = 256;
+  const int xg = (w + gd - 1) / gd, yg = (h + gd - 1) / gd, ngroups = xg * yg;
+  const int xlg = (w + 2047) / 2048, ylg = (h + 2047) / 2048, nlf = xlg * ylg;
+  const int ntot = nchan + (has_alpha ? 1 : 0);
+  std::vector<std::vector<int32_t>> ch(ntot);
+  for (int c = 0; c < ntot; c++) ch[c].assign(planes[c], planes[c] + (size_t)w * h);
+  if (rct && nchan == 3) {
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+      int32_t R = ch[0][i], G = ch[1][i], B = ch[2][i];
+      int32_t co = R - B, tmp = B + (co >> 1), cg = G - tmp, y = tmp + (cg >> 1);
+      ch[0][i] = y; ch[1][i] = co; ch[2][i] = cg;
+    }
+  }
+  // tree: channel split, then prop 9 cutoffs, gradient predictor
+  GTree t;
+  static const int cuts[] = {-1023, -255, -63, -15, -3, 0, 3, 15, 63, 255, 1023};
+  std::vector<int> cut(cuts, cuts + 11);
+  std::vector<int> sub(ntot);
+  for (int c = 0; c < ntot; c++) sub[c] = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
+  int root = sub[ntot - 1];
+  for (int c = ntot - 2; c >= 0; c--) root = t.add_inner(0, c, root, sub[c]);  // channel > c ? (higher channels) : channel c
+  std::vector<int> bfs{root};
+  for (size_t i = 0; i < bfs.size(); i++) { const TNode& n = t.nodes[bfs[i]]; if (n.prop >= 0) { bfs.push_back(n.l); bfs.push_back(n.r); } }
+  int leaf = 0;
+  for (int id : bfs) if (t.nodes[id].prop < 0) t.nodes[id].ctx = leaf++;
+  t.num_leaves = leaf;
+  std::vector<Token> tree_tokens;
+  TreeTokens(t, bfs, tree_tokens);
+  bool single = ngroups == 1;
+  bool all_global = w <= gd && h <= gd;  // every channel decoded in GlobalModular
+  std::vector<std::vector<Token>> gtok(ngroups);
+  std::vector<Token> global_tok;
+  std::vector<std::vector<std::vector<int32_t>>> gdata(ngroups);
+  if (all_global) {
+    std::vector<ChanRef> cr;
+    for (int c = 0; c < ntot; c++) cr.push_back({ch[c].data(), w, h});
+    ModularTokens(t, root, cr, 0, global_tok);
+  } else {
+    for (int g = 0; g < ngroups; g++) {
+      int gx = g % xg, gy = g / xg, x0 = gx * gd, y0 = gy * gd, gw = std::min(gd, w - x0), gh = std::min(gd, h - y0);
+      gdata[g].resize(ntot);
+      std::vector<ChanRef> cr;
+      for (int c = 0; c < ntot; c++) {
+        gdata[g][c].resize((size_t)gw * gh);
+        for (int y = 0; y < gh; y++) memcpy(&gdata[g][c][(size_t)y * gw], &ch[c][(size_t)(y0 + y) * w + x0], sizeof(int32_t) * gw);
+        cr.push_back({gdata[g][c].data(), gw, gh});
+      }
+      ModularTokens(t, root, cr, 1 + 3 * nlf + 17 + g, gtok[g]);
+    }
+  }
+  EntropyCoder tree_code, code;
+  { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
+  { std::vector<const std::vector<Token>*> s{&global_tok}; for (auto& g : gtok) s.push_back(&g); BuildEntropyCoder(s, t.num_leaves, UintConfig{4, 2, 0}, 64, code); }
+  std::vector<BitWriter> sections;
+  {
+    BitWriter s;
+    s.put(1, 1);  // LfChannelDequantization default
+    s.put(1, 1);  // has_tree
+    WriteEntropyCode(s, tree_code);
+    EncodeTokens(s, tree_code, tree_tokens);
+    WriteEntropyCode(s, code);
+    // global GroupHeader
+    s.put(1, 1); s.put(1, 1);
+    if (rct && nchan == 3) { WriteU32(s, 1, {0, 0}, {0, 1}, {4, 2}, {8, 18}); s.put(0, 2); WriteU32(s, 0, {3, 0}, {6, 8}, {10, 72}, {13, 1096}); WriteU32(s, 6, {0, 6}, {2, 0}, {4, 2}, {6, 10}); }
+    else s.put(0, 2);
+    EncodeTokens(s, code, global_tok);  // (ANS state is written even when no channel is decodable globally)
+    sections.push_back(s);
+  }
+  for (int g = 0; g < nlf; g++) sections.push_back(BitWriter());  // LfGroups: nothing (no squeezed channels)
+  if (!single || true) {
+    // HfGlobal is absent for modular frames but still has a TOC slot
+    sections.push_back(BitWriter());
+    for (int g = 0; g < ngroups; g++) {
+      BitWriter s;
+      if (!all_global) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, code, gtok[g]); }
+      sections.push_back(s);
+    }
+  }
+  BitWriter out;
+  Params p; p.out_bits = bits; p.gab = 0; p.epf_iters = 0;  // lossless: no restoration filters
+  WriteImageHeader(out, w, h, p, false, bits, has_alpha, nchan == 1);
+  WriteFrameHeader(out, p, true, false, has_alpha ? 1 : 0, group_shift, false);
+  WriteTOCAndSections(out, sections, single);
+  out.align();
+  return out.bytes;
+}
+
+}  // namespace synth
+
+// ---- C API ---------------------------------------------------------------------------------------------------------
+extern "C" {
+struct jxlsynth_params {
+  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders; int32_t reserved[8];
+};
+static thread_local std::string g_err;
+const char* jxlsynth_last_error() { return g_err.c_str(); }
+void jxlsynth_free(uint8_t* p) { free(p); }
+void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::SyntheticImage(seed, w, h, rgb); }
+
+static int finish(const std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
+  *out = (uint8_t*)malloc(v.size());
+  memcpy(*out, v.data(), v.size());
+  *n = v.size();
+  return 0;
+}
+// rgb8: interleaved sRGB u8 (w*h*3).  For hdr: rgb_lin (float, linear, w*h*3) is used instead.
+int jxlsynth_vardct(const uint8_t* rgb8, const float* rgb_lin, int w, int h, const jxlsynth_params* pp, uint8_t** out, size_t* n) {
+  try {
+    synth::Params p;
+    p.seed = pp->seed; p.distance = pp->distance; p.epf_iters = pp->epf_iters; p.gab = pp->gab; p.strategy_mix = pp->strategy_mix;
+    p.out_bits = pp->out_bits; p.hdr = pp->hdr; p.skip_lf_smoothing = pp->skip_lf_smoothing;
+    std::vector<float> pl[3];
+    for (auto& v : pl) v.resize((size_t)w * h);
+    const float scale = p.hdr ? 255.0f / 1000.0f : 1.0f;  // intensity_target 1000: linear 1.0 == 1000 nits
+    (void)scale;
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+      float r, g, b;
+      if (rgb_lin) { r = rgb_lin[3 * i]; g = rgb_lin[3 * i + 1]; b = rgb_lin[3 * i + 2]; if (p.hdr) { r *= 1000.f / 255.f; g *= 1000.f / 255.f; b *= 1000.f / 255.f; } }
+      else { r = synth::SrgbToLinear(rgb8[3 * i] / 255.0f); g = synth::SrgbToLinear(rgb8[3 * i + 1] / 255.0f); b = synth::SrgbToLinear(rgb8[3 * i + 2] / 255.0f); }
+      synth::LinearToXYB(r, g, b, &pl[0][i], &pl[1][i], &pl[2][i]);
+    }
+    const float* planes[3] = {pl[0].data(), pl[1].data(), pl[2].data()};
+    return finish(synth::EncodeVarDCT(planes, w, h, p), out, n);
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+// planes: nchan (+alpha) pointers to w*h int32 samples
+int jxlsynth_modular(const int32_t* const* planes, int nchan, int has_alpha, int w, int h, int bits, int rct, uint8_t** out, size_t* n) {
+  try { return finish(synth::EncodeModular(planes, nchan, w, h, bits, has_alpha != 0, rct != 0), out, n); }
+  catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+}
