@@ -1,0 +1,152 @@
+/* jxl_hip.h — C ABI of the MI355X-native JPEG XL decode path.
+ *
+ * This is the drop-in boundary: the symbols below are exactly the libjxl / libjxl_threads entry points that
+ * inflation/jpegxl-rs binds through jpegxl-sys (extern "C-unwind"), with identical names, argument meaning, struct
+ * layouts and status codes, exported from libjxl.so / libjxl_threads.so look-alikes so that
+ * `DEP_JXL_LIB=<dir> cargo build -p jpegxl-rs` links against this implementation with zero Rust changes
+ * (jpegxl-sys/build.rs:30-34).  Each declaration cites the reference line it replaces.
+ * The second part (JxlHip*) is an extension without reference counterpart: a device-resident batch decode used by
+ * bench.py and by batch users — the reference decodes batches by looping decode_with (jpegxl-rs/benches/decode.rs:16-19).
+ */
+#ifndef JXL_HIP_H_
+#define JXL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- common types (jpegxl-sys/src/common/types.rs:25-148) -------------------------------------------------------- */
+typedef int JXL_BOOL;                                                     /* types.rs:25-31 */
+typedef enum { JXL_TYPE_FLOAT = 0, JXL_TYPE_UINT8 = 2, JXL_TYPE_UINT16 = 3, JXL_TYPE_FLOAT16 = 5 } JxlDataType;   /* types.rs:40-55 */
+typedef enum { JXL_NATIVE_ENDIAN = 0, JXL_LITTLE_ENDIAN = 1, JXL_BIG_ENDIAN = 2 } JxlEndianness;                  /* types.rs:60-72 */
+typedef struct { uint32_t num_channels; JxlDataType data_type; JxlEndianness endianness; size_t align; } JxlPixelFormat; /* types.rs:83-103 */
+
+/* jpegxl-sys/src/common/memory_manager.rs:22-64 */
+typedef void* (*jpegxl_alloc_func)(void* opaque, size_t size);
+typedef void (*jpegxl_free_func)(void* opaque, void* address);
+typedef struct { void* opaque; jpegxl_alloc_func alloc; jpegxl_free_func free; } JxlMemoryManager;
+
+/* jpegxl-sys/src/metadata/codestream_header.rs:38-241 (204 bytes) */
+typedef enum { JXL_ORIENT_IDENTITY = 1 } JxlOrientation;
+typedef struct { uint32_t xsize, ysize; } JxlPreviewHeader;
+typedef struct { uint32_t tps_numerator, tps_denominator, num_loops; JXL_BOOL have_timecodes; } JxlAnimationHeader;
+typedef struct {
+  JXL_BOOL have_container;
+  uint32_t xsize, ysize, bits_per_sample, exponent_bits_per_sample;
+  float intensity_target, min_nits;
+  JXL_BOOL relative_to_max_display;
+  float linear_below;
+  JXL_BOOL uses_original_profile, have_preview, have_animation;
+  int32_t orientation;
+  uint32_t num_color_channels, num_extra_channels, alpha_bits, alpha_exponent_bits;
+  JXL_BOOL alpha_premultiplied;
+  JxlPreviewHeader preview;
+  JxlAnimationHeader animation;
+  uint32_t intrinsic_xsize, intrinsic_ysize;
+  uint8_t padding[100];
+} JxlBasicInfo;
+
+/* jpegxl-sys/src/decode.rs:43-54, 84-247, 284-287 */
+typedef enum { JXL_SIG_NOT_ENOUGH_BYTES = 0, JXL_SIG_INVALID = 1, JXL_SIG_CODESTREAM = 2, JXL_SIG_CONTAINER = 3 } JxlSignature;
+typedef enum {
+  JXL_DEC_SUCCESS = 0, JXL_DEC_ERROR = 1, JXL_DEC_NEED_MORE_INPUT = 2, JXL_DEC_NEED_PREVIEW_OUT_BUFFER = 3,
+  JXL_DEC_NEED_IMAGE_OUT_BUFFER = 5, JXL_DEC_JPEG_NEED_MORE_OUTPUT = 6, JXL_DEC_BOX_NEED_MORE_OUTPUT = 7,
+  JXL_DEC_BASIC_INFO = 0x40, JXL_DEC_COLOR_ENCODING = 0x100, JXL_DEC_PREVIEW_IMAGE = 0x200, JXL_DEC_FRAME = 0x400,
+  JXL_DEC_FULL_IMAGE = 0x1000, JXL_DEC_JPEG_RECONSTRUCTION = 0x2000, JXL_DEC_BOX = 0x4000, JXL_DEC_FRAME_PROGRESSION = 0x8000,
+  JXL_DEC_BOX_COMPLETE = 0x10000
+} JxlDecoderStatus;
+typedef enum { JXL_COLOR_PROFILE_TARGET_ORIGINAL = 0, JXL_COLOR_PROFILE_TARGET_DATA = 1 } JxlColorProfileTarget;
+
+typedef struct JxlDecoderStruct JxlDecoder;
+
+/* jpegxl-sys/src/threads/parallel_runner.rs:46-122 */
+typedef int JxlParallelRetCode;
+typedef JxlParallelRetCode (*JxlParallelRunInit)(void* jpegxl_opaque, size_t num_threads);
+typedef void (*JxlParallelRunFunction)(void* jpegxl_opaque, uint32_t value, size_t thread_id);
+typedef JxlParallelRetCode (*JxlParallelRunner)(void* runner_opaque, void* jpegxl_opaque, JxlParallelRunInit init,
+                                                JxlParallelRunFunction func, uint32_t start_range, uint32_t end_range);
+
+/* ---- live decoder entry points (the 22 symbols jpegxl-rs/src/decode.rs calls) ----------------- */
+uint32_t JxlDecoderVersion(void);                                                             /* decode.rs:370 -> 11002 */
+JxlSignature JxlSignatureCheck(const uint8_t* buf, size_t len);                               /* decode.rs:385 */
+JxlDecoder* JxlDecoderCreate(const JxlMemoryManager* memory_manager);                         /* decode.rs:400 */
+void JxlDecoderReset(JxlDecoder* dec);                                                        /* decode.rs:408 */
+void JxlDecoderDestroy(JxlDecoder* dec);                                                      /* decode.rs:414 */
+JxlDecoderStatus JxlDecoderSetParallelRunner(JxlDecoder* dec, JxlParallelRunner runner, void* opaque);   /* decode.rs:487 */
+JxlDecoderStatus JxlDecoderSubscribeEvents(JxlDecoder* dec, int events_wanted);               /* decode.rs:525 */
+JxlDecoderStatus JxlDecoderSetKeepOrientation(JxlDecoder* dec, JXL_BOOL skip_reorientation);  /* decode.rs:563 */
+JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* dec, JXL_BOOL unpremul_alpha);   /* decode.rs:585 */
+JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* dec, JXL_BOOL render_spotcolors);  /* decode.rs:602 */
+JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* dec, JXL_BOOL coalescing);               /* decode.rs:622 */
+JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* dec);                                     /* decode.rs:662 — runs the HIP hot path */
+JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* dec, const uint8_t* data, size_t size);       /* decode.rs:680 */
+void JxlDecoderCloseInput(JxlDecoder* dec);                                                   /* decode.rs:724 */
+JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* dec, JxlBasicInfo* info);           /* decode.rs:738 */
+JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* dec, JxlColorProfileTarget target, size_t* size);              /* decode.rs:862 */
+JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* dec, JxlColorProfileTarget target, uint8_t* icc, size_t size); /* decode.rs:884 */
+JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* dec, float desired_intensity_target);                         /* decode.rs:921 */
+JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size);              /* decode.rs:1100 */
+JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* dec, const JxlPixelFormat* format, void* buffer, size_t size);        /* decode.rs:1123 */
+JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* dec, uint8_t* data, size_t size);        /* decode.rs:1283 */
+size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* dec);                                          /* decode.rs:1305 */
+
+/* ---- libjxl_threads (threads/thread_parallel_runner.rs:44-65, resizable_parallel_runner.rs:42-67) ---------------- */
+JxlParallelRetCode JxlThreadParallelRunner(void* runner_opaque, void* jpegxl_opaque, JxlParallelRunInit init, JxlParallelRunFunction func,
+                                           uint32_t start_range, uint32_t end_range);
+void* JxlThreadParallelRunnerCreate(const JxlMemoryManager* memory_manager, size_t num_worker_threads);
+void JxlThreadParallelRunnerDestroy(void* runner_opaque);
+size_t JxlThreadParallelRunnerDefaultNumWorkerThreads(void);
+JxlParallelRetCode JxlResizableParallelRunner(void* runner_opaque, void* jpegxl_opaque, JxlParallelRunInit init, JxlParallelRunFunction func,
+                                              uint32_t start_range, uint32_t end_range);
+void* JxlResizableParallelRunnerCreate(const JxlMemoryManager* memory_manager);
+void JxlResizableParallelRunnerSetThreads(void* runner_opaque, size_t num_threads);
+uint32_t JxlResizableParallelRunnerSuggestThreads(uint64_t xsize, uint64_t ysize);
+void JxlResizableParallelRunnerDestroy(void* runner_opaque);
+
+/* The remaining 89 symbols declared by jpegxl-sys (encoder, box API, CMS, gain map ...) are exported as
+ * error-returning stubs so the Rust crate links (csrc/jxl_stubs.cc, generated by tools/gen_stubs.py). */
+
+/* ---- extension: device-resident batch decode ------------------------------------------------------------------- */
+typedef struct JxlHipBatchStruct JxlHipBatch;
+typedef struct {
+  float lf_ms, lfpost_ms, hf_ms, idct_ms, filter_ms, out_ms, total_ms;
+} JxlHipStageTimes;
+
+/* Last error message of the calling thread ("" if none). */
+const char* JxlHipLastError(void);
+/* Creates a batch bound to HIP device `device`. */
+JxlHipBatch* JxlHipBatchCreate(int device);
+void JxlHipBatchDestroy(JxlHipBatch* batch);
+/* Parses one image (headers, TOC, global tables) and appends it; returns its index or -1. */
+int JxlHipBatchAddImage(JxlHipBatch* batch, const uint8_t* data, size_t size);
+/* Basic info / required output size of image `index` for `format`. */
+JxlDecoderStatus JxlHipBatchGetBasicInfo(const JxlHipBatch* batch, int index, JxlBasicInfo* info);
+JxlDecoderStatus JxlHipBatchOutBufferSize(const JxlHipBatch* batch, int index, const JxlPixelFormat* format, size_t* size);
+/* Output format (and optional caller-owned *device* destination; NULL = batch-owned) of image `index`. */
+JxlDecoderStatus JxlHipBatchSetOutput(JxlHipBatch* batch, int index, const JxlPixelFormat* format, void* device_buffer);
+/* Decode-thread packing: lanes between active entropy-decode threads (64 = one stream per wavefront, 1 = 64 per wavefront). */
+void JxlHipBatchSetLaneStride(JxlHipBatch* batch, int lf, int hf);
+/* Uploads streams and tables (inputs become HBM-resident) and allocates work buffers.  hip_stream: hipStream_t or NULL. */
+JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* batch, void* hip_stream);
+/* Enqueues the decode of the whole batch on hip_stream (no host sync). */
+JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* batch, void* hip_stream);
+/* Same, with HIP events around every stage on hip_stream; synchronises. */
+JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* batch, void* hip_stream, JxlHipStageTimes* times);
+/* Waits for completion and checks per-frame device status. */
+JxlDecoderStatus JxlHipBatchFinish(JxlHipBatch* batch, void* hip_stream);
+/* Device pointer of the decoded pixels of image `index`; copy to host. */
+void* JxlHipBatchDeviceOutput(const JxlHipBatch* batch, int index);
+JxlDecoderStatus JxlHipBatchCopyOutput(JxlHipBatch* batch, int index, void* host_dst, size_t size, void* hip_stream);
+/* Accounting for roofline reports. */
+uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* batch);
+uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* batch);
+uint64_t JxlHipBatchAlgorithmicBytesHF(const JxlHipBatch* batch);
+uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_HIP_H_ */

@@ -1,0 +1,491 @@
+// jxl-hip: batch decoder (see decoder.h).
+#include "decoder.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace jxlhip {
+
+#define HIP_CHECK(expr)                                                                                    \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess) throw ParseError(std::string("HIP error: ") + hipGetErrorString(e_) + " in " #expr, false); \
+  } while (0)
+
+namespace {
+size_t Align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct ConstOffsets {
+  size_t cs = 0, sec_off = 0, sec_size = 0, tree = 0, bcm = 0;
+  size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0;
+  size_t ac_ctx = 0, ac_cfg = 0, ac_alias = 0, ac_pc = 0, ac_po = 0, ac_ps = 0;
+  size_t orders[39] = {0};
+  size_t qtable[17 * 3] = {0};
+  bool has_qtable[17] = {false};
+};
+
+struct Arena {
+  std::vector<uint8_t>& buf;
+  explicit Arena(std::vector<uint8_t>& b) : buf(b) {}
+  size_t Put(const void* src, size_t n, size_t align = 256) {
+    size_t off = Align(buf.size(), align);
+    buf.resize(off + std::max<size_t>(n, 4), 0);
+    if (n) memcpy(buf.data() + off, src, n);
+    return off;
+  }
+};
+
+void PutCode(Arena& a, const HostCode& c, size_t* ctx, size_t* cfg, size_t* alias, size_t* pc, size_t* po, size_t* ps) {
+  *ctx = a.Put(c.ctx_map.data(), c.ctx_map.size());
+  *cfg = a.Put(c.cfg.data(), c.cfg.size() * 4);
+  *alias = a.Put(c.alias.data(), c.alias.size() * 8);
+  *pc = a.Put(c.pfx_count.data(), c.pfx_count.size() * 2);
+  *po = a.Put(c.pfx_sym_off.data(), c.pfx_sym_off.size() * 4);
+  *ps = a.Put(c.pfx_syms.data(), c.pfx_syms.size() * 2);
+}
+DevCode ViewCode(const HostCode& c, const uint8_t* base, size_t ctx, size_t cfg, size_t alias, size_t pc, size_t po, size_t ps) {
+  DevCode d;
+  d.ctx_map = base + ctx; d.cfg = (const uint32_t*)(base + cfg); d.alias = (const uint64_t*)(base + alias);
+  d.pfx_count = (const uint16_t*)(base + pc); d.pfx_sym_off = (const uint32_t*)(base + po); d.pfx_syms = (const uint16_t*)(base + ps);
+  d.num_ctx = c.num_ctx; d.num_clusters = c.num_clusters; d.log_alpha = c.log_alpha; d.use_prefix = c.use_prefix;
+  return d;
+}
+}  // namespace
+
+Batch::Batch(int device) : device_(device) {
+  HIP_CHECK(hipSetDevice(device_));
+}
+Batch::~Batch() {
+  if (dconst_) (void)hipFree(dconst_);
+  if (dwork_) (void)hipFree(dwork_);
+  if (dframes_) (void)hipFree(dframes_);
+}
+
+int Batch::AddImage(const uint8_t* data, size_t size) {
+  std::unique_ptr<ImageEntry> e(new ImageEntry());
+  bool have_container = false;
+  if (!ExtractCodestream(data, size, &e->cs, &have_container, &e->has_jbrd)) throw ParseError("truncated", false);
+  ParseImageHeader(e->cs, &e->ih, &e->frame_bitpos);
+  e->ih.have_container = have_container;
+  ParseFrameStart(e->cs, e->ih, e->frame_bitpos, &e->plan);
+  const FramePlan& p = e->plan;
+  if (!p.modular && !e->ih.extra.empty()) throw ParseError("unsupported: extra channels in a VarDCT frame", true);
+  if (p.modular && e->ih.xyb_encoded) throw ParseError("unsupported: XYB Modular frame", true);
+  if (p.modular && e->ih.depth.is_float) throw ParseError("unsupported: float Modular samples", true);
+  if (p.modular && p.gchannels.size() > 8) throw ParseError("unsupported: more than 8 modular channels", true);
+  if (!p.modular && e->ih.xyb_encoded) {
+    const bool srgb = e->ih.color_default || (!e->ih.have_gamma && e->ih.tf == 13);
+    const bool linear = !e->ih.color_default && !e->ih.have_gamma && e->ih.tf == 8;
+    if (!srgb && !linear) throw ParseError("unsupported: output transfer function", true);
+  }
+  if (e->ih.orientation != 1) throw ParseError("unsupported: orientation", true);
+  images_.push_back(std::move(e));
+  prepared_ = false;
+  return (int)images_.size() - 1;
+}
+
+size_t Batch::OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t* channels) {
+  uint32_t nc = o.num_channels;
+  bool alpha = false;
+  for (auto& e : ih.extra) if (e.type == 0) alpha = true;
+  if (nc == 0) nc = (ih.color_space == 1 ? 1 : 3) + (alpha ? 1 : 0);
+  if (channels) *channels = nc;
+  const size_t bps = o.type == 0 ? 1 : o.type == 2 ? 4 : 2;
+  size_t stride = (size_t)ih.xsize * nc * bps;
+  if (o.align > 1) stride = (stride + o.align - 1) / o.align * o.align;
+  return stride;
+}
+size_t Batch::OutputSize(const ImageHeader& ih, const OutputSpec& o) {
+  // jpegxl-sys decode.rs:1100 JxlDecoderImageOutBufferSize: stride * (h - 1) + w * C * bytes
+  uint32_t nc;
+  const size_t stride = OutputStride(ih, o, &nc);
+  const size_t bps = o.type == 0 ? 1 : o.type == 2 ? 4 : 2;
+  return stride * (ih.ysize - 1) + (size_t)ih.xsize * nc * bps;
+}
+void Batch::SetOutput(int i, const OutputSpec& o) {
+  ImageEntry& e = *images_[i];
+  e.out = o;
+  uint32_t nc;
+  e.out_stride = OutputStride(e.ih, o, &nc);
+  e.out.num_channels = nc;
+  e.out_size = OutputSize(e.ih, o);
+  prepared_ = false;
+}
+
+uint64_t Batch::total_pixels() const { uint64_t n = 0; for (auto& e : images_) n += (uint64_t)e->ih.xsize * e->ih.ysize; return n; }
+uint64_t Batch::compressed_bytes() const { uint64_t n = 0; for (auto& e : images_) n += e->cs.size; return n; }
+uint64_t Batch::algorithmic_bytes_hf() const {
+  // K_hf: reads the PassGroup sections once, writes the quantised coefficients once (int32, 3 channels) — SURVEY §8d
+  uint64_t n = 0;
+  for (auto& e : images_) {
+    const FramePlan& p = e->plan;
+    if (p.modular) continue;
+    if (p.single_section) n += e->cs.size; else for (size_t s = 2 + p.num_lf_groups; s < p.sections.size(); s++) n += p.sections[s].size;
+    n += (uint64_t)p.bw * p.bh * 64 * 3 * 4;
+  }
+  return n;
+}
+
+void* Batch::device_output(int i) const {
+  const ImageEntry& e = *images_[i];
+  return e.out.device_ptr ? e.out.device_ptr : (void*)(dwork_ + e.off_out);
+}
+
+void Batch::Prepare(void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  HIP_CHECK(hipSetDevice(device_));
+  InitDeviceTables(stream_v);
+  if (dconst_) { (void)hipFree(dconst_); dconst_ = nullptr; }
+  if (dwork_) { (void)hipFree(dwork_); dwork_ = nullptr; }
+  if (dframes_) { (void)hipFree(dframes_); dframes_ = nullptr; }
+  const int n = (int)images_.size();
+  hconst_.clear();
+  Arena arena(hconst_);
+  std::vector<ConstOffsets> co(n);
+  // natural coefficient orders (shared)
+  size_t natural_off[13];
+  for (int b = 0; b < 13; b++) { auto v = NaturalCoeffOrder(kBucketStrategy[b]); natural_off[b] = arena.Put(v.data(), v.size() * 2); }
+  // quant tables are shared between frames with identical specs
+  struct QCache { const QuantTableSpec* spec; int kind; size_t off[3]; };
+  std::vector<QCache> qcache;
+  auto spec_equal = [](const QuantTableSpec& a, const QuantTableSpec& b) {
+    if (a.mode != b.mode || a.num_bands != b.num_bands || a.num_bands4 != b.num_bands4) return false;
+    if (memcmp(a.bands, b.bands, sizeof(a.bands)) || memcmp(a.idw, b.idw, sizeof(a.idw)) || memcmp(a.dct2w, b.dct2w, sizeof(a.dct2w))) return false;
+    if (memcmp(a.dct4mul, b.dct4mul, sizeof(a.dct4mul)) || memcmp(a.dct4x8mul, b.dct4x8mul, sizeof(a.dct4x8mul))) return false;
+    return true;
+  };
+  max_lf_groups_ = max_groups_ = max_w_ = max_h_ = max_bw_ = max_bh_ = max_epf_ = 0;
+  any_gab_ = any_vardct_ = any_modular_ = false;
+  for (int i = 0; i < n; i++) {
+    ImageEntry& e = *images_[i];
+    FramePlan& p = e.plan;
+    ConstOffsets& c = co[i];
+    if (e.out_size == 0) SetOutput(i, e.out);
+    c.cs = arena.Put(e.cs.data(), e.cs.padded_size());
+    std::vector<uint64_t> so, ss;
+    for (auto& s : p.sections) { so.push_back(s.offset); ss.push_back(s.size); }
+    c.sec_off = arena.Put(so.data(), so.size() * 8);
+    c.sec_size = arena.Put(ss.data(), ss.size() * 8);
+    if (p.has_global_tree) {
+      c.tree = arena.Put(p.tree.nodes.data(), p.tree.nodes.size() * sizeof(TreeNode));
+      PutCode(arena, p.tree_code, &c.mod_ctx, &c.mod_cfg, &c.mod_alias, &c.mod_pc, &c.mod_po, &c.mod_ps);
+    }
+    c.bcm = arena.Put(&p.bcm, sizeof(p.bcm));
+    if (!p.modular) {
+      any_vardct_ = true;
+      // (single-section frames: HfGlobal is parsed in the pre-run below; reserve nothing here)
+    } else any_modular_ = true;
+    max_lf_groups_ = std::max<int>(max_lf_groups_, p.num_lf_groups);
+    max_groups_ = std::max<int>(max_groups_, p.num_groups);
+    max_w_ = std::max<int>(max_w_, p.width); max_h_ = std::max<int>(max_h_, p.height);
+    max_bw_ = std::max<int>(max_bw_, p.bw); max_bh_ = std::max<int>(max_bh_, p.bh);
+    if (!p.modular) { max_epf_ = std::max<int>(max_epf_, p.lf.epf_iters); any_gab_ |= p.lf.gab != 0; }
+  }
+  // ---- work arena layout
+  size_t w = 0;
+  auto take = [&](size_t bytes) { size_t off = Align(w); w = off + bytes; return off; };
+  struct WorkOffsets {
+    size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
+        mod_scratch;
+    size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride;
+  };
+  std::vector<WorkOffsets> wo(n);
+  mod_plane_offsets_.assign(n, {});
+  status_off_ = take((size_t)n * 4);
+  // coefficient buffers of all frames are contiguous so that one memset clears them
+  coeff_off_ = Align(w);
+  for (int i = 0; i < n; i++) {
+    const FramePlan& p = images_[i]->plan;
+    if (p.modular) continue;
+    for (int c = 0; c < 3; c++) wo[i].coeff[c] = take((size_t)p.num_groups * 65536 * 4);
+  }
+  coeff_bytes_ = w - coeff_off_;
+  for (int i = 0; i < n; i++) {
+    ImageEntry& e = *images_[i];
+    const FramePlan& p = e.plan;
+    WorkOffsets& o = wo[i];
+    o.end_bitpos = take(16);
+    if (!e.out.device_ptr) e.off_out = take(e.out_size + 64);
+    if (!p.modular) {
+      const size_t nb = (size_t)p.bw * p.bh;
+      for (int c = 0; c < 3; c++) { o.lfq[c] = take(nb * 4); o.lf[c] = take(nb * 4); o.lf_tmp[c] = take(nb * 4); o.llf[c] = take(nb * 4); }
+      o.blk_info = take(nb * 4); o.coef_off = take(nb * 4); o.inv_sigma = take(nb * 4);
+      const size_t ntile = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8);
+      o.ytox = take(ntile); o.ytob = take(ntile);
+      const size_t plane = (size_t)p.bw * 8 * p.bh * 8 * 4;
+      for (int c = 0; c < 3; c++) { o.plane_a[c] = take(plane); o.plane_b[c] = take(plane); }
+      o.lf_scratch_stride = 16 + 2 * 1024 + 3 * 65536;
+      o.lf_scratch = take(o.lf_scratch_stride * 4 * p.num_lf_groups);
+      o.wp_scratch_stride = 10 * (256 + 2);
+      o.wp_scratch = take(o.wp_scratch_stride * 4 * p.num_lf_groups);
+    } else {
+      // full-frame planes for every channel of the global image + spares for palette expansion
+      std::vector<size_t>& mp = mod_plane_offsets_[i];
+      for (auto& ch : p.gchannels) mp.push_back(take((size_t)ch.w * ch.h * 4 + 64));
+      size_t spare = 0;
+      for (auto& t : p.gtransforms) if (t.id == 1) spare += t.num_c - 1;
+      for (size_t k = 0; k < spare; k++) mp.push_back(take((size_t)p.width * p.height * 4 + 64));
+      const size_t gd = p.group_dim;
+      o.mod_scratch_stride = (p.gchannels.size() + 4) * gd * gd + 4 * 65536;
+      o.mod_scratch = take(o.mod_scratch_stride * 4 * p.num_groups);
+      o.wp_scratch_stride = p.tree.uses_wp ? 10 * (65536 + 2) : 16;
+      o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.num_groups));
+    }
+  }
+  work_size_ = Align(w);
+  HIP_CHECK(hipMalloc((void**)&dwork_, work_size_));
+  HIP_CHECK(hipMemsetAsync(dwork_, 0, work_size_, stream));
+  HIP_CHECK(hipMalloc((void**)&dframes_, sizeof(FrameDev) * std::max(n, 1)));
+
+  // ---- single-section VarDCT frames: HfGlobal starts where the device-decoded LfGroup ends.  Pre-run the LF stage
+  // for those frames now, read the end position back and parse HfGlobal on the host.
+  frames_host_.assign(n, FrameDev());
+  auto fill_frame = [&](int i, const uint8_t* cbase) {
+    ImageEntry& e = *images_[i];
+    const FramePlan& p = e.plan;
+    const ConstOffsets& c = co[i];
+    const WorkOffsets& o = wo[i];
+    FrameDev& f = frames_host_[i];
+    memset(&f, 0, sizeof(f));
+    f.width = p.width; f.height = p.height; f.bw = p.bw; f.bh = p.bh; f.xgroups = p.xgroups; f.ygroups = p.ygroups; f.num_groups = p.num_groups;
+    f.xlfgroups = p.xlfgroups; f.num_lf_groups = p.num_lf_groups; f.cw = (p.bw + 7) / 8; f.ch = (p.bh + 7) / 8;
+    f.group_dim = p.group_dim; f.is_modular = p.modular; f.plane_stride = p.bw * 8; f.plane_rows = p.bh * 8;
+    f.cs = cbase + c.cs; f.cs_size = e.cs.size;
+    f.sec_off = (const uint64_t*)(cbase + c.sec_off); f.sec_size = (const uint64_t*)(cbase + c.sec_size);
+    f.single_section = p.single_section;
+    f.lf_start_bitpos = p.global_data_bitpos;  // VarDCT without extra channels: LfGroup follows LfGlobal directly
+    f.stream_end_bitpos = (uint64_t*)(dwork_ + o.end_bitpos);
+    if (p.has_global_tree) {
+      f.tree = (const TreeNode*)(cbase + c.tree);
+      f.mod_code = ViewCode(p.tree_code, cbase, c.mod_ctx, c.mod_cfg, c.mod_alias, c.mod_pc, c.mod_po, c.mod_ps);
+    }
+    f.uses_wp = p.tree.uses_wp; f.gwp = p.gwp;
+    f.bcm = (const BlockCtxDev*)(cbase + c.bcm);
+    f.status = (uint32_t*)(dwork_ + status_off_) + i;
+    f.out = (uint8_t*)(e.out.device_ptr ? e.out.device_ptr : dwork_ + e.off_out);
+    f.out_stride = e.out_stride; f.out_channels = e.out.num_channels; f.out_type = e.out.type; f.out_big_endian = e.out.big_endian;
+    f.is_gray = e.ih.color_space == 1;
+    f.wp_scratch = (int32_t*)(dwork_ + o.wp_scratch); f.wp_scratch_stride = o.wp_scratch_stride;
+    if (!p.modular) {
+      const float inv_gs = 65536.0f / (float)p.global_scale;
+      const float inv_quant_lf = inv_gs / (float)p.quant_lf;
+      for (int k = 0; k < 3; k++) f.lf_fac[k] = p.m_lf[k] * inv_quant_lf;
+      f.cfl_lf_x = p.base_x + (float)p.ytox_lf * (1.0f / (float)p.color_factor);
+      f.cfl_lf_b = p.base_b + (float)p.ytob_lf * (1.0f / (float)p.color_factor);
+      f.inv_global_scale = inv_gs;
+      f.x_dm = std::pow(0.8f, (float)p.x_qm_scale - 2.0f); f.b_dm = std::pow(0.8f, (float)p.b_qm_scale - 2.0f);
+      for (int k = 0; k < 4; k++) f.quant_bias[k] = e.ih.quant_bias[k];
+      f.color_scale = 1.0f / (float)p.color_factor; f.base_x = p.base_x; f.base_b = p.base_b;
+      f.skip_lf_smoothing = (p.flags & 128) != 0;
+      f.gab = p.lf.gab; f.epf_iters = p.lf.epf_iters;
+      for (int k = 0; k < 3; k++) {
+        const float w1 = p.lf.gab_w[2 * k], w2 = p.lf.gab_w[2 * k + 1];
+        const float div = 1.0f + 4.0f * (w1 + w2);
+        f.gab_w[3 * k] = 1.0f / div; f.gab_w[3 * k + 1] = w1 / div; f.gab_w[3 * k + 2] = w2 / div;
+      }
+      for (int k = 0; k < 8; k++) f.epf_sharp_lut[k] = p.lf.sharp_lut[k];
+      for (int k = 0; k < 3; k++) f.epf_channel_scale[k] = p.lf.channel_scale[k];
+      f.epf_quant_mul = p.lf.quant_mul; f.epf_quant_scale = (float)p.global_scale / 65536.0f;
+      const float scales[3] = {p.lf.pass0_sigma_scale, 1.0f, p.lf.pass2_sigma_scale};
+      for (int k = 0; k < 3; k++) { f.epf_sm[k] = scales[k] * 1.65f; f.epf_bsm[k] = f.epf_sm[k] * p.lf.border_sad_mul; }
+      const float s = 255.0f / e.ih.intensity_target;
+      for (int k = 0; k < 9; k++) f.opsin_inv[k] = e.ih.opsin_inv[k] * s;
+      for (int k = 0; k < 3; k++) { f.neg_bias[k] = e.ih.opsin_bias[k]; f.neg_bias_cbrt[k] = std::cbrt(e.ih.opsin_bias[k]); }
+      if (e.ih.xyb_encoded) f.color_mode = (!e.ih.color_default && !e.ih.have_gamma && e.ih.tf == 8) ? 1 : 0;
+      else f.color_mode = p.do_ycbcr ? 2 : 3;
+      for (int k = 0; k < 3; k++) {
+        f.lfq[k] = (int32_t*)(dwork_ + o.lfq[k]); f.lf[k] = (float*)(dwork_ + o.lf[k]); f.lf_tmp[k] = (float*)(dwork_ + o.lf_tmp[k]);
+        f.llf[k] = (float*)(dwork_ + o.llf[k]); f.coeff[k] = (int32_t*)(dwork_ + o.coeff[k]);
+        f.plane_a[k] = (float*)(dwork_ + o.plane_a[k]); f.plane_b[k] = (float*)(dwork_ + o.plane_b[k]);
+      }
+      f.blk_info = (uint32_t*)(dwork_ + o.blk_info); f.coef_off = (uint32_t*)(dwork_ + o.coef_off);
+      f.ytox = (int8_t*)(dwork_ + o.ytox); f.ytob = (int8_t*)(dwork_ + o.ytob);
+      f.inv_sigma = (float*)(dwork_ + o.inv_sigma);
+      f.lf_scratch = (int32_t*)(dwork_ + o.lf_scratch); f.lf_scratch_stride = o.lf_scratch_stride;
+      // HfGlobal-derived fields (present once parsed)
+      if (!p.ac_code.empty()) {
+        f.ac_code = ViewCode(p.ac_code[0], cbase, c.ac_ctx, c.ac_cfg, c.ac_alias, c.ac_pc, c.ac_po, c.ac_ps);
+        for (int k = 0; k < 39; k++) f.orders[k] = (const uint16_t*)(cbase + c.orders[k]);
+        for (int k = 0; k < 17 * 3; k++) f.qtable[k] = c.has_qtable[k / 3] ? (const float*)(cbase + c.qtable[k]) : nullptr;
+        f.num_hf_presets = p.num_hf_presets;
+        uint32_t bits = 0; while ((1u << bits) < p.num_hf_presets) bits++;
+        f.preset_bits = bits;
+        f.hf_start_bitpos = p.end_bitpos;
+      }
+    } else {
+      const std::vector<size_t>& mp = mod_plane_offsets_[i];
+      f.mod_nchan = (uint32_t)p.gchannels.size(); f.mod_nb_meta = p.nb_meta_channels;
+      for (size_t k = 0; k < p.gchannels.size(); k++) { f.mod_plane[k] = (int32_t*)(dwork_ + mp[k]); f.mod_w[k] = p.gchannels[k].w; f.mod_h[k] = p.gchannels[k].h; }
+      f.mod_global_decodable = p.global_decodable; f.mod_global_bitpos = p.global_data_bitpos;
+      f.mod_group_scratch = (int32_t*)(dwork_ + o.mod_scratch); f.mod_group_scratch_stride = o.mod_scratch_stride;
+      f.mod_bits = e.ih.depth.bits;
+      f.hf_start_bitpos = 0;
+    }
+  };
+
+  std::vector<int> single;
+  for (int i = 0; i < n; i++) if (images_[i]->plan.single_section && !images_[i]->plan.modular) single.push_back(i);
+  if (!single.empty()) {
+    // temporary upload of what exists so far
+    uint8_t* tmpc = nullptr;
+    HIP_CHECK(hipMalloc((void**)&tmpc, Align(hconst_.size())));
+    HIP_CHECK(hipMemcpyAsync(tmpc, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
+    std::vector<FrameDev> tmpf;
+    for (int i : single) { fill_frame(i, tmpc); tmpf.push_back(frames_host_[i]); }
+    HIP_CHECK(hipMemcpyAsync(dframes_, tmpf.data(), sizeof(FrameDev) * tmpf.size(), hipMemcpyHostToDevice, stream));
+    LaunchLfDecode(dframes_, (int)tmpf.size(), 1, cfg, stream_v);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (size_t k = 0; k < single.size(); k++) {
+      const int i = single[k];
+      uint32_t status = 0;
+      uint64_t endpos[2] = {0, 0};
+      HIP_CHECK(hipMemcpy(&status, tmpf[k].status, 4, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(endpos, tmpf[k].stream_end_bitpos, 16, hipMemcpyDeviceToHost));
+      if (status) { (void)hipFree(tmpc); throw ParseError(status & kErrUnsupported ? "unsupported: stream feature (LF stage)" : "corrupt LF group stream", (status & kErrUnsupported) != 0); }
+      ParseHfGlobal(images_[i]->cs, images_[i]->ih, endpos[0], &images_[i]->plan);
+    }
+    HIP_CHECK(hipMemsetAsync(dwork_ + status_off_, 0, (size_t)n * 4, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    (void)hipFree(tmpc);
+  }
+  // ---- HfGlobal tables (now available for every VarDCT frame)
+  for (int i = 0; i < n; i++) {
+    ImageEntry& e = *images_[i];
+    FramePlan& p = e.plan;
+    ConstOffsets& c = co[i];
+    if (p.modular) continue;
+    PutCode(arena, p.ac_code[0], &c.ac_ctx, &c.ac_cfg, &c.ac_alias, &c.ac_pc, &c.ac_po, &c.ac_ps);
+    for (int b = 0; b < 13; b++) for (int ch = 0; ch < 3; ch++) {
+      const auto& cu = p.custom_order[b * 3 + ch];
+      c.orders[b * 3 + ch] = cu.empty() ? natural_off[b] : arena.Put(cu.data(), cu.size() * 2);
+    }
+    for (int k = 0; k <= 12; k++) {  // kinds above 64x64 are not supported by the IDCT kernel
+      if (k == 10) continue;         // AFV
+      int hit = -1;
+      for (size_t q = 0; q < qcache.size(); q++) if (qcache[q].kind == k && spec_equal(*qcache[q].spec, p.qspec[k])) { hit = (int)q; break; }
+      if (hit < 0) {
+        QCache qc; qc.spec = &p.qspec[k]; qc.kind = k;
+        for (int ch = 0; ch < 3; ch++) { std::vector<float> t; ComputeQuantTable(p.qspec[k], k, ch, &t); qc.off[ch] = arena.Put(t.data(), t.size() * 4); }
+        qcache.push_back(qc); hit = (int)qcache.size() - 1;
+      }
+      for (int ch = 0; ch < 3; ch++) c.qtable[k * 3 + ch] = qcache[hit].off[ch];
+      c.has_qtable[k] = true;
+    }
+  }
+  const_size_ = Align(hconst_.size());
+  HIP_CHECK(hipMalloc((void**)&dconst_, const_size_));
+  HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
+  for (int i = 0; i < n; i++) fill_frame(i, dconst_);
+  HIP_CHECK(hipMemcpyAsync(dframes_, frames_host_.data(), sizeof(FrameDev) * n, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  prepared_ = true;
+}
+
+void Batch::Run(void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!prepared_) Prepare(stream_v);
+  const int n = (int)images_.size();
+  if (any_vardct_) {
+    HIP_CHECK(hipMemsetAsync(dwork_ + coeff_off_, 0, coeff_bytes_, stream));
+    LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
+    LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
+    LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
+    LaunchIdct(dframes_, n, max_groups_, stream_v);
+    LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
+    LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
+  }
+  if (any_modular_) {
+    LaunchModularGlobal(dframes_, n, stream_v);
+    LaunchModularGroups(dframes_, n, max_groups_, stream_v);
+    for (int i = 0; i < n; i++) {
+      const ImageEntry& e = *images_[i];
+      const FramePlan& p = e.plan;
+      if (!p.modular) continue;
+      // undo global transforms on the host-tracked channel list (transform.cc), reverse order
+      const std::vector<size_t>& mp = mod_plane_offsets_[i];
+      std::vector<int32_t*> list;
+      for (size_t k = 0; k < p.gchannels.size(); k++) list.push_back((int32_t*)(dwork_ + mp[k]));
+      size_t spare = p.gchannels.size();
+      const size_t npx = (size_t)p.width * p.height;
+      for (int t = (int)p.gtransforms.size() - 1; t >= 0; t--) {
+        const TransformDesc& td = p.gtransforms[t];
+        if (td.id == 0) LaunchModRct(list[td.begin_c], list[td.begin_c + 1], list[td.begin_c + 2], npx, td.rct_type, stream_v);
+        else {
+          int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
+          outs[0] = list[td.begin_c + 1];
+          for (uint32_t c = 1; c < td.num_c; c++) outs[c] = (int32_t*)(dwork_ + mp[spare++]);
+          LaunchModPalette(list[0], outs, td.nb_colors, td.num_c, std::min<uint32_t>(e.ih.depth.bits, 24), npx, stream_v);
+          std::vector<int32_t*> nl;
+          for (size_t k = 1; k < list.size(); k++) { if (k - 1 == td.begin_c) { for (uint32_t c = 0; c < td.num_c; c++) nl.push_back(outs[c]); } else nl.push_back(list[k]); }
+          list.swap(nl);
+        }
+      }
+      ModOutputArgs a;
+      memset(&a, 0, sizeof(a));
+      a.ncolor = p.nb_color_channels;
+      if (list.size() < a.ncolor) throw ParseError("modular channel list", false);
+      for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = list[c];
+      a.color_factor = 1.0f / (float)((1u << e.ih.depth.bits) - 1);
+      a.alpha = nullptr; a.alpha_factor = 1.0f;
+      for (size_t k = 0; k < e.ih.extra.size(); k++) if (e.ih.extra[k].type == 0) {
+        a.alpha = list[a.ncolor + k];
+        a.alpha_factor = 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);
+        break;
+      }
+      LaunchModOutput(dframes_, i, a, p.width, p.height, stream_v);
+    }
+  }
+}
+
+StageTimes Batch::RunTimed(void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!prepared_) Prepare(stream_v);
+  const int n = (int)images_.size();
+  StageTimes t;
+  if (!any_vardct_) { Run(stream_v); return t; }
+  hipEvent_t ev[8];
+  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipEventRecord(ev[0], stream));
+  HIP_CHECK(hipMemsetAsync(dwork_ + coeff_off_, 0, coeff_bytes_, stream));
+  LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
+  HIP_CHECK(hipEventRecord(ev[1], stream));
+  LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
+  HIP_CHECK(hipEventRecord(ev[2], stream));
+  LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
+  HIP_CHECK(hipEventRecord(ev[3], stream));
+  LaunchIdct(dframes_, n, max_groups_, stream_v);
+  HIP_CHECK(hipEventRecord(ev[4], stream));
+  LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
+  HIP_CHECK(hipEventRecord(ev[5], stream));
+  LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
+  HIP_CHECK(hipEventRecord(ev[6], stream));
+  HIP_CHECK(hipEventSynchronize(ev[6]));
+  float* dst[6] = {&t.lf_ms, &t.lfpost_ms, &t.hf_ms, &t.idct_ms, &t.filter_ms, &t.out_ms};
+  for (int i = 0; i < 6; i++) HIP_CHECK(hipEventElapsedTime(dst[i], ev[i], ev[i + 1]));
+  HIP_CHECK(hipEventElapsedTime(&t.total_ms, ev[0], ev[6]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return t;
+}
+
+void Batch::Finish(void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  HIP_CHECK(hipStreamSynchronize(stream));
+  const int n = (int)images_.size();
+  std::vector<uint32_t> status(n, 0);
+  HIP_CHECK(hipMemcpy(status.data(), dwork_ + status_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    if (!status[i]) continue;
+    HIP_CHECK(hipMemset(dwork_ + status_off_, 0, (size_t)n * 4));
+    if (status[i] & kErrUnsupported) throw ParseError("unsupported: stream feature on the device path (frame " + std::to_string(i) + ")", true);
+    throw ParseError("corrupt stream (device status " + std::to_string(status[i]) + ", frame " + std::to_string(i) + ")", false);
+  }
+}
+
+void Batch::CopyOutputToHost(int i, void* dst, size_t size, void* stream_v) {
+  const ImageEntry& e = *images_[i];
+  HIP_CHECK(hipMemcpyAsync(dst, device_output(i), std::min(size, e.out_size), hipMemcpyDeviceToHost, (hipStream_t)stream_v));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_v));
+}
+
+}  // namespace jxlhip

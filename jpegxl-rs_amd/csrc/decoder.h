@@ -1,0 +1,84 @@
+// jxl-hip: batch decoder — owns device memory for a batch of frames and enqueues the kernel pipeline.
+// A batch of one frame backs the libjxl-compatible JxlDecoder ABI (jxl_abi.cc); larger batches back the resident
+// batch API used by bench.py (include/jxl_hip.h).
+#pragma once
+#include "host_parse.h"
+#include "kernels.h"
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace jxlhip {
+
+struct OutputSpec {
+  uint32_t num_channels = 0;   // 0 = colour + alpha
+  uint32_t type = 0;           // 0 u8, 1 u16, 2 f32, 3 f16
+  uint32_t big_endian = 0;
+  size_t align = 0;
+  void* device_ptr = nullptr;  // optional caller-owned device destination
+};
+
+struct ImageEntry {
+  Codestream cs;
+  ImageHeader ih;
+  FramePlan plan;
+  uint64_t frame_bitpos = 0;
+  OutputSpec out;
+  size_t out_stride = 0, out_size = 0;
+  bool has_jbrd = false;
+  // arena offsets
+  size_t off_cs = 0, off_sec = 0, off_tree = 0, off_bcm = 0;
+  size_t off_out = 0;
+};
+
+struct StageTimes { float lf_ms = 0, lfpost_ms = 0, hf_ms = 0, idct_ms = 0, filter_ms = 0, out_ms = 0, total_ms = 0; };
+
+class Batch {
+ public:
+  explicit Batch(int device);
+  ~Batch();
+  // Parses headers (container, image header, frame header, TOC, global sections).  Throws ParseError.
+  int AddImage(const uint8_t* data, size_t size);
+  size_t size() const { return images_.size(); }
+  ImageEntry& image(int i) { return *images_[i]; }
+  static size_t OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t* channels);
+  static size_t OutputSize(const ImageHeader& ih, const OutputSpec& o);
+  void SetOutput(int i, const OutputSpec& o);
+  // Allocates device memory, uploads streams + tables (inputs become HBM-resident).  stream: hipStream_t.
+  void Prepare(void* stream);
+  // Enqueues the whole decode of every frame of the batch.  No host synchronisation inside.
+  void Run(void* stream);
+  // Waits, checks device status words; throws ParseError on stream errors.
+  void Finish(void* stream);
+  // Copies frame i's pixels to host memory (after Finish).
+  void CopyOutputToHost(int i, void* dst, size_t size, void* stream);
+  void* device_output(int i) const;
+  // Timed run with per-stage HIP events on `stream` (used by bench.py for the roofline block).
+  StageTimes RunTimed(void* stream);
+  LaunchCfg cfg;
+  size_t const_bytes() const { return const_size_; }
+  size_t work_bytes() const { return work_size_; }
+  uint64_t algorithmic_bytes_hf() const;   // compressed AC bytes + coefficient bytes written (K_hf roofline)
+  uint64_t total_pixels() const;
+  uint64_t compressed_bytes() const;
+
+ private:
+  void BuildFrameDev(int i, FrameDev* fd, uint8_t* hconst, size_t* const_off, bool measure_only);
+  void UploadFrames(void* stream);
+  void EnqueueVarDCTFront(void* stream);
+  int device_;
+  std::vector<std::unique_ptr<ImageEntry>> images_;
+  std::vector<FrameDev> frames_host_;
+  std::vector<uint8_t> hconst_;
+  uint8_t* dconst_ = nullptr; size_t const_size_ = 0;
+  uint8_t* dwork_ = nullptr; size_t work_size_ = 0;
+  FrameDev* dframes_ = nullptr;
+  size_t coeff_off_ = 0, coeff_bytes_ = 0, status_off_ = 0, modplane_off_ = 0, modplane_bytes_ = 0;
+  bool prepared_ = false;
+  int max_lf_groups_ = 0, max_groups_ = 0, max_w_ = 0, max_h_ = 0, max_bw_ = 0, max_bh_ = 0, max_epf_ = 0;
+  bool any_gab_ = false, any_vardct_ = false, any_modular_ = false;
+  struct ModFinish { int frame; std::vector<int> planes; };  // host-side channel lists for modular frames
+  std::vector<std::vector<size_t>> mod_plane_offsets_;       // per frame: work-arena offsets of planes (incl. spare)
+};
+
+}  // namespace jxlhip

@@ -1,0 +1,941 @@
+// jxl-hip: host-side header parser (see host_parse.h).  Field layouts: SURVEY.md App. B.1-B.6.
+#include "host_parse.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace jxlhip {
+
+namespace {
+
+[[noreturn]] void Fail(const char* msg) { throw ParseError(msg, false); }
+[[noreturn]] void Unsupported(const char* msg) { throw ParseError(std::string("unsupported: ") + msg, true); }
+
+struct Reader {
+  BitReader br;
+  uint64_t limit_bits;
+  Reader(const Codestream& cs, uint64_t bitpos) {
+    br.Init(cs.data(), bitpos, cs.size);
+    limit_bits = cs.size * 8;
+  }
+  uint32_t u(int n) {
+    uint32_t v = n ? br.Read(n) : 0;
+    if (br.BitPos() > limit_bits) throw ParseError("truncated", false);
+    return v;
+  }
+  bool b() { return u(1) != 0; }
+  uint64_t pos() const { return br.BitPos(); }
+  void align() { int r = (int)(pos() & 7); if (r) u(8 - r); }
+  struct D { int bits; uint32_t off; };
+  uint32_t U32(D d0, D d1, D d2, D d3) {
+    uint32_t s = u(2);
+    D d = s == 0 ? d0 : s == 1 ? d1 : s == 2 ? d2 : d3;
+    return d.off + u(d.bits);
+  }
+  uint64_t U64() {
+    uint32_t s = u(2);
+    if (s == 0) return 0;
+    if (s == 1) return 1 + u(4);
+    if (s == 2) return 17 + u(8);
+    uint64_t v = u(12);
+    int shift = 12;
+    while (u(1)) {
+      if (shift == 60) { v |= (uint64_t)u(4) << shift; break; }
+      v |= (uint64_t)u(8) << shift;
+      shift += 8;
+    }
+    return v;
+  }
+  float F16() {
+    uint32_t h = u(16);
+    uint32_t sign = h >> 15, e = (h >> 10) & 31, m = h & 1023;
+    if (e == 31) Fail("F16 is inf/nan");
+    float v = e == 0 ? std::ldexp((float)m, -24) : std::ldexp((float)(m + 1024), (int)e - 25);
+    return sign ? -v : v;
+  }
+  uint32_t Enum() { return U32({0, 0}, {0, 1}, {4, 2}, {6, 18}); }
+  void SkipExtensions() {
+    uint64_t ext = U64();
+    if (!ext) return;
+    uint64_t total = 0;
+    for (int i = 0; i < 64; i++) if (ext >> i & 1) total += U64();
+    while (total > 0) { int n = (int)std::min<uint64_t>(total, 32); u(n); total -= n; }
+  }
+};
+
+int CeilLog2(uint32_t x) { int r = 0; while ((1ull << r) < x) r++; return r; }
+int FloorLog2(uint32_t x) { int r = 0; while (x >>= 1) r++; return r; }
+
+// ---- entropy code header -----------------------------------------------------------------------------------------
+uint32_t VarLenUint8(Reader& r) { if (!r.u(1)) return 0; int n = r.u(3); return n ? r.u(n) + (1u << n) : 1; }
+uint32_t VarLenUint16(Reader& r) { if (!r.u(1)) return 0; int n = r.u(4); return n ? r.u(n) + (1u << n) : 1; }
+
+uint32_t ReadUintConfig(Reader& r, int log_alpha) {
+  uint32_t split = r.u(CeilLog2(log_alpha + 1)), msb = 0, lsb = 0;
+  if (split != (uint32_t)log_alpha) {
+    msb = r.u(CeilLog2(split + 1));
+    if (msb > split) Fail("hybrid uint: msb_in_token");
+    lsb = r.u(CeilLog2(split - msb + 1));
+  }
+  if (lsb + msb > split) Fail("hybrid uint: lsb_in_token");
+  return split | (msb << 8) | (lsb << 16);
+}
+
+void ReadHistogram(Reader& r, std::vector<int>& counts) {
+  counts.clear();
+  if (r.u(1)) {
+    int ns = r.u(1) + 1;
+    uint32_t s0 = VarLenUint8(r);
+    if (ns == 1) { counts.assign(s0 + 1, 0); counts[s0] = 4096; return; }
+    uint32_t s1 = VarLenUint8(r);
+    if (s0 == s1) Fail("ANS: duplicate symbol");
+    counts.assign(std::max(s0, s1) + 1, 0);
+    counts[s0] = r.u(12);
+    counts[s1] = 4096 - counts[s0];
+    return;
+  }
+  if (r.u(1)) {
+    int n = VarLenUint8(r) + 1;
+    counts.assign(n, 4096 / n);
+    for (int i = 0; i < 4096 % n; i++) counts[i]++;
+    return;
+  }
+  int len = 0;
+  while (len < 3 && r.u(1)) len++;
+  int shift = (int)(r.u(len) | (1u << len)) - 1;
+  if (shift > 13) Fail("ANS: shift");
+  int length = VarLenUint8(r) + 3;
+  // 7-bit peek LUT of the log-count prefix code: entries {nbits, value}
+  static const uint8_t base[16][2] = {{3, 10}, {7, 12}, {3, 7}, {4, 3}, {3, 6}, {3, 8}, {3, 9}, {4, 5}, {3, 10}, {4, 4}, {3, 7}, {4, 1}, {3, 6}, {3, 8}, {3, 9}, {4, 2}};
+  static const uint8_t odd[8][2] = {{7, 12}, {5, 0}, {6, 11}, {5, 0}, {7, 13}, {5, 0}, {6, 11}, {5, 0}};
+  std::vector<int> logc(length, 0), same(length, 0);
+  int omit_log = -1, omit_pos = -1;
+  for (int i = 0; i < length; i++) {
+    r.br.Refill();
+    uint32_t idx = r.br.Peek(7);
+    const uint8_t* e = (idx & 15) == 1 ? odd[idx >> 4] : base[idx & 15];
+    r.u(e[0]);
+    logc[i] = e[1];
+    if (logc[i] == 13) {
+      int rl = VarLenUint8(r);
+      same[i] = rl + 5;
+      i += rl + 3;
+      continue;
+    }
+    if (logc[i] > omit_log) { omit_log = logc[i]; omit_pos = i; }
+  }
+  if (omit_pos < 0) Fail("ANS: no omit position");
+  if (omit_pos + 1 < length && logc[omit_pos + 1] == 13) Fail("ANS: RLE after omit position");
+  counts.assign(length, 0);
+  int total = 0, prev = 0, numsame = 0;
+  for (int i = 0; i < length; i++) {
+    if (same[i]) { numsame = same[i] - 1; prev = i > 0 ? counts[i - 1] : 0; }
+    if (numsame > 0) { counts[i] = prev; numsame--; }
+    else {
+      int code = logc[i];
+      if (i == omit_pos || code == 0) continue;
+      if (code == 1) counts[i] = 1;
+      else {
+        int bitcount = std::min(std::max(0, shift - ((12 - code + 1) >> 1)), code - 1);
+        counts[i] = (1 << (code - 1)) + (r.u(bitcount) << (code - 1 - bitcount));
+      }
+    }
+    total += counts[i];
+  }
+  counts[omit_pos] = 4096 - total;
+  if (counts[omit_pos] <= 0) Fail("ANS: omitted count <= 0");
+}
+
+void BuildAlias(std::vector<int> dist, int log_alpha, uint64_t* out) {
+  const int T = 1 << log_alpha, B = 4096 >> log_alpha;
+  while (!dist.empty() && dist.back() == 0) dist.pop_back();
+  if (dist.empty()) dist.assign(1, 4096);
+  if ((int)dist.size() > T) Fail("ANS: alphabet larger than table");
+  for (size_t s = 0; s < dist.size(); s++) {
+    if (dist[s] == 4096) {
+      for (int i = 0; i < T; i++) out[i] = PackAlias(0, (uint32_t)s, 0, (uint32_t)(B * i), 4096);
+      return;
+    }
+  }
+  std::vector<int> cut(T, 0), right(T, 0), offs1(T, 0), over, under;
+  for (size_t i = 0; i < dist.size(); i++) cut[i] = dist[i];
+  for (int i = 0; i < T; i++) { if (cut[i] > B) over.push_back(i); else if (cut[i] < B) under.push_back(i); }
+  while (!over.empty()) {
+    if (under.empty()) Fail("ANS: alias construction");
+    int o = over.back(); over.pop_back();
+    int u = under.back(); under.pop_back();
+    cut[o] -= B - cut[u];
+    right[u] = o; offs1[u] = cut[o];
+    if (cut[o] < B) under.push_back(o); else if (cut[o] > B) over.push_back(o);
+  }
+  for (int i = 0; i < T; i++) {
+    if (cut[i] == B) { right[i] = i; offs1[i] = 0; cut[i] = 0; } else offs1[i] -= cut[i];
+    uint32_t f0 = i < (int)dist.size() ? dist[i] : 0, f1 = right[i] < (int)dist.size() ? dist[right[i]] : 0;
+    out[i] = PackAlias((uint32_t)cut[i], (uint32_t)right[i], f0, (uint32_t)offs1[i], f1);
+  }
+}
+
+// Brotli-style prefix code → canonical (count per length, symbols sorted by (length, value))
+void ReadPrefixCode(Reader& r, int alphabet, uint16_t* count16, std::vector<uint16_t>& syms) {
+  for (int i = 0; i < 16; i++) count16[i] = 0;
+  std::vector<uint8_t> lens(alphabet, 0);
+  auto finish = [&]() {
+    int nonzero = 0, last = 0;
+    for (int i = 0; i < alphabet; i++) if (lens[i]) { nonzero++; last = i; }
+    if (nonzero <= 1) { count16[0] = 1; syms.push_back((uint16_t)(nonzero ? last : 0)); return; }
+    for (int len = 1; len <= 15; len++) for (int i = 0; i < alphabet; i++) if (lens[i] == len) { count16[len]++; syms.push_back((uint16_t)i); }
+  };
+  if (alphabet == 1) { finish(); return; }
+  int hskip = r.u(2);
+  if (hskip == 1) {
+    int max_bits = 0;
+    for (int v = alphabet - 1; v; v >>= 1) max_bits++;
+    int n = r.u(2) + 1, s[4];
+    for (int i = 0; i < n; i++) { s[i] = r.u(max_bits); if (s[i] >= alphabet) Fail("prefix: symbol out of range"); }
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) if (s[i] == s[j]) Fail("prefix: duplicate symbol");
+    if (n == 1) { count16[0] = 1; syms.push_back((uint16_t)s[0]); return; }
+    if (n == 2) { lens[s[0]] = 1; lens[s[1]] = 1; }
+    else if (n == 3) { lens[s[0]] = 1; lens[s[1]] = 2; lens[s[2]] = 2; }
+    else if (r.u(1)) { lens[s[0]] = 1; lens[s[1]] = 2; lens[s[2]] = 3; lens[s[3]] = 3; }
+    else for (int i = 0; i < 4; i++) lens[s[i]] = 2;
+    finish();
+    return;
+  }
+  static const uint8_t kOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+  static const uint8_t kLen[16] = {2, 2, 2, 3, 2, 2, 2, 4, 2, 2, 2, 3, 2, 2, 2, 4};
+  static const uint8_t kVal[16] = {0, 4, 3, 2, 0, 4, 3, 1, 0, 4, 3, 2, 0, 4, 3, 5};
+  uint8_t cl[18] = {0};
+  int space = 32, ncodes = 0;
+  for (int i = hskip; i < 18 && space > 0; i++) {
+    r.br.Refill();
+    uint32_t p = r.br.Peek(4);
+    r.u(kLen[p]);
+    cl[kOrder[i]] = kVal[p];
+    if (kVal[p]) { space -= 32 >> kVal[p]; ncodes++; }
+  }
+  if (ncodes != 1 && space != 0) Fail("prefix: code length code");
+  // canonical decode table for the code-length code (max length 5)
+  int cl_single = -1;
+  if (ncodes == 1) for (int i = 0; i < 18; i++) if (cl[i]) cl_single = i;
+  uint8_t lut_sym[32], lut_len[32];
+  if (cl_single < 0) {
+    uint32_t code = 0;
+    for (int len = 1; len <= 5; len++) {
+      for (int s = 0; s < 18; s++) {
+        if (cl[s] != len) continue;
+        uint32_t rev = 0;
+        for (int b = 0; b < len; b++) if (code >> b & 1) rev |= 1u << (len - 1 - b);
+        for (uint32_t k = rev; k < 32; k += 1u << len) { lut_sym[k] = (uint8_t)s; lut_len[k] = (uint8_t)len; }
+        code++;
+      }
+      code <<= 1;
+    }
+  }
+  int symbol = 0, prev_len = 8, repeat = 0, repeat_len = 0, sp = 32768;
+  while (symbol < alphabet && sp > 0) {
+    int v;
+    if (cl_single >= 0) v = cl_single;
+    else { r.br.Refill(); uint32_t p = r.br.Peek(5); v = lut_sym[p]; r.u(lut_len[p]); }
+    if (v < 16) {
+      repeat = 0;
+      lens[symbol++] = (uint8_t)v;
+      if (v) { prev_len = v; sp -= 32768 >> v; }
+    } else {
+      int extra = v == 16 ? 2 : 3, new_len = v == 16 ? prev_len : 0;
+      if (repeat_len != new_len) { repeat = 0; repeat_len = new_len; }
+      int old = repeat;
+      if (repeat > 0) { repeat -= 2; repeat <<= extra; }
+      repeat += r.u(extra) + 3;
+      int delta = repeat - old;
+      if (symbol + delta > alphabet) Fail("prefix: repeat overflow");
+      for (int i = 0; i < delta; i++) lens[symbol++] = (uint8_t)repeat_len;
+      if (repeat_len) sp -= delta << (15 - repeat_len);
+    }
+  }
+  if (sp != 0) Fail("prefix: incomplete code");
+  finish();
+}
+
+void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77 = true);
+
+struct HostSymbolReader {  // symbol reader over a HostCode, for the small global streams parsed on the host
+  Reader& r; const HostCode& hc; DevCode view; AnsReader ans;
+  HostSymbolReader(Reader& rr, const HostCode& c) : r(rr), hc(c), view(c.View()) { ans.Init(r.br, view); }
+  uint32_t Read(uint32_t ctx) {
+    uint32_t v = ReadHybridUint(r.br, ans, view, ctx);
+    if (r.pos() > r.limit_bits) throw ParseError("truncated", false);
+    return v;
+  }
+  void CheckFinal() { if (!ans.FinalOk(view)) Fail("ANS final state"); }
+};
+
+void ReadContextMap(Reader& r, uint32_t num_ctx, std::vector<uint8_t>& map, uint32_t* num_clusters) {
+  map.assign(num_ctx, 0);
+  if (r.b()) {
+    int bits = r.u(2);
+    for (auto& m : map) m = (uint8_t)r.u(bits);
+  } else {
+    bool mtf = r.b();
+    HostCode nested;
+    ReadEntropyCode(r, 1, &nested, num_ctx > 2);
+    if (nested.lz77) Unsupported("LZ77 in context map");
+    HostSymbolReader sr(r, nested);
+    for (auto& m : map) { uint32_t v = sr.Read(0); if (v > 255) Fail("context map value"); m = (uint8_t)v; }
+    sr.CheckFinal();
+    if (mtf) {
+      uint8_t t[256];
+      for (int i = 0; i < 256; i++) t[i] = (uint8_t)i;
+      for (auto& m : map) {
+        uint8_t idx = m, v = t[idx];
+        m = v;
+        for (int j = idx; j > 0; j--) t[j] = t[j - 1];
+        t[0] = v;
+      }
+    }
+  }
+  uint32_t mx = 0;
+  for (auto m : map) mx = std::max<uint32_t>(mx, m);
+  std::vector<bool> used(mx + 1, false);
+  for (auto m : map) used[m] = true;
+  for (bool u : used) if (!u) Fail("context map skips a cluster");
+  *num_clusters = mx + 1;
+}
+
+void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77) {
+  *hc = HostCode();
+  hc->lz77 = r.b();
+  if (hc->lz77) {
+    if (!allow_lz77) Fail("LZ77 not allowed");
+    Unsupported("LZ77-coded stream");
+  }
+  hc->num_ctx = num_ctx;
+  if (num_ctx > 1) ReadContextMap(r, num_ctx, hc->ctx_map, &hc->num_clusters);
+  else { hc->ctx_map.assign(1, 0); hc->num_clusters = 1; }
+  hc->use_prefix = r.b();
+  hc->log_alpha = hc->use_prefix ? 15 : 5 + r.u(2);
+  hc->cfg.resize(hc->num_clusters);
+  for (auto& c : hc->cfg) c = ReadUintConfig(r, hc->log_alpha);
+  if (hc->use_prefix) {
+    std::vector<int> asz(hc->num_clusters);
+    for (auto& a : asz) { a = VarLenUint16(r) + 1; if (a > (1 << 15)) Fail("prefix alphabet too large"); }
+    hc->pfx_count.assign(hc->num_clusters * 16, 0);
+    hc->pfx_sym_off.resize(hc->num_clusters);
+    for (uint32_t c = 0; c < hc->num_clusters; c++) {
+      hc->pfx_sym_off[c] = (uint32_t)hc->pfx_syms.size();
+      ReadPrefixCode(r, asz[c], &hc->pfx_count[c * 16], hc->pfx_syms);
+    }
+    hc->alias.assign(1, 0);
+  } else {
+    hc->alias.assign((size_t)hc->num_clusters << hc->log_alpha, 0);
+    std::vector<int> dist;
+    for (uint32_t c = 0; c < hc->num_clusters; c++) {
+      ReadHistogram(r, dist);
+      BuildAlias(dist, hc->log_alpha, &hc->alias[(size_t)c << hc->log_alpha]);
+    }
+    hc->pfx_count.assign(16, 0); hc->pfx_sym_off.assign(1, 0); hc->pfx_syms.assign(1, 0);
+  }
+}
+
+void ReadTree(Reader& r, HostTree* t, size_t limit) {
+  HostCode code;
+  ReadEntropyCode(r, 6, &code);
+  HostSymbolReader sr(r, code);
+  t->nodes.clear(); t->num_leaves = 0; t->uses_wp = false; t->max_prop = 0;
+  size_t pending = 1;
+  while (pending > 0) {
+    if (t->nodes.size() > limit) Fail("MA tree too large");
+    pending--;
+    int prop = (int)sr.Read(1) - 1;
+    TreeNode n;
+    if (prop < 0) {
+      uint32_t predictor = sr.Read(2);
+      if (predictor >= 14) Fail("MA tree predictor");
+      int32_t offset = UnpackSigned(sr.Read(3));
+      uint32_t mul_log = sr.Read(4);
+      if (mul_log >= 31) Fail("MA tree mul_log");
+      uint32_t mul_bits = sr.Read(5);
+      if (mul_bits + 1 >= (1u << (31 - mul_log))) Fail("MA tree mul_bits");
+      if (t->num_leaves >= (1u << 24)) Fail("MA tree leaves");
+      n.prop = -1; n.val = offset; n.a = predictor | (t->num_leaves << 8); n.b = (mul_bits + 1u) << mul_log;
+      t->num_leaves++;
+      if (predictor == 6) t->uses_wp = true;
+    } else {
+      if (prop > 255) Fail("MA tree property");
+      n.prop = prop; n.val = UnpackSigned(sr.Read(0));
+      n.a = (uint32_t)(t->nodes.size() + pending + 1); n.b = (uint32_t)(t->nodes.size() + pending + 2);
+      if (prop == 15) t->uses_wp = true;
+      t->max_prop = std::max(t->max_prop, prop);
+      pending += 2;
+    }
+    t->nodes.push_back(n);
+  }
+  sr.CheckFinal();
+}
+
+void ReadSizeHeader(Reader& r, uint32_t* xs, uint32_t* ys) {
+  bool small = r.b();
+  *ys = small ? (r.u(5) + 1) * 8 : r.U32({9, 1}, {13, 1}, {18, 1}, {30, 1});
+  uint32_t ratio = r.u(3);
+  if (ratio == 0) *xs = small ? (r.u(5) + 1) * 8 : r.U32({9, 1}, {13, 1}, {18, 1}, {30, 1});
+  else {
+    static const uint32_t num[8] = {0, 1, 12, 4, 3, 16, 5, 2}, den[8] = {1, 1, 10, 3, 2, 9, 4, 1};
+    *xs = (uint32_t)((uint64_t)*ys * num[ratio] / den[ratio]);
+  }
+}
+void ReadBitDepth(Reader& r, BitDepthInfo* d) {
+  d->is_float = r.b();
+  if (!d->is_float) { d->bits = r.U32({0, 8}, {0, 10}, {0, 12}, {6, 1}); d->exp_bits = 0; }
+  else { d->bits = r.U32({0, 32}, {0, 16}, {0, 24}, {6, 1}); d->exp_bits = r.u(4) + 1; }
+}
+void SkipName(Reader& r) {
+  uint32_t n = r.U32({0, 0}, {4, 0}, {5, 16}, {10, 48});
+  for (uint32_t i = 0; i < n; i++) r.u(8);
+}
+void SkipCustomXY(Reader& r) { for (int i = 0; i < 2; i++) r.U32({19, 0}, {19, 524288}, {20, 1048576}, {21, 2097152}); }
+
+void ReadTransform(Reader& r, TransformDesc* t) {
+  t->id = r.u(2);
+  if (t->id == 3) Fail("transform id");
+  if (t->id != 2) t->begin_c = r.U32({3, 0}, {6, 8}, {10, 72}, {13, 1096});
+  if (t->id == 0) { t->rct_type = r.U32({0, 6}, {2, 0}, {4, 2}, {6, 10}); if (t->rct_type >= 42) Fail("rct type"); }
+  else if (t->id == 1) {
+    t->num_c = r.U32({0, 1}, {0, 3}, {0, 4}, {13, 1});
+    t->nb_colors = r.U32({8, 0}, {10, 256}, {12, 1280}, {16, 5376});
+    t->nb_deltas = r.U32({0, 0}, {8, 1}, {10, 257}, {16, 1281});
+    t->predictor = r.u(4);
+    if (t->predictor >= 14) Fail("palette predictor");
+  } else {
+    uint32_t n = r.U32({0, 0}, {4, 1}, {6, 9}, {8, 41});
+    t->squeeze.resize(n);
+    for (auto& s : t->squeeze) { s.horizontal = r.b(); s.in_place = r.b(); s.begin_c = r.U32({3, 0}, {6, 8}, {10, 72}, {13, 1096}); s.num_c = r.U32({0, 1}, {0, 2}, {0, 3}, {4, 4}); }
+  }
+}
+
+}  // namespace
+
+// ---- public ------------------------------------------------------------------------------------------------------------
+SigResult CheckSignature(const uint8_t* buf, size_t len) {
+  // jpegxl-sys decode.rs:385 JxlSignatureCheck; utils.rs:25-33
+  if (len == 0) return kSigNotEnoughBytes;
+  if (buf[0] == 0xFF) {
+    if (len < 2) return kSigNotEnoughBytes;
+    return buf[1] == 0x0A ? kSigCodestream : kSigInvalid;
+  }
+  static const uint8_t sig[12] = {0, 0, 0, 0xC, 'J', 'X', 'L', ' ', 0xD, 0xA, 0x87, 0xA};
+  size_t n = std::min<size_t>(len, 12);
+  if (memcmp(buf, sig, n) != 0) return kSigInvalid;
+  return len < 12 ? kSigNotEnoughBytes : kSigContainer;
+}
+
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd) {
+  *have_container = false; *has_jbrd = false;
+  std::vector<uint8_t> tmp;
+  const uint8_t* src = data; size_t n = size;
+  bool complete = true;
+  if (!(size >= 2 && data[0] == 0xFF && data[1] == 0x0A)) {
+    *have_container = true;
+    size_t pos = 0;
+    bool found = false, last_unbounded = false;
+    while (pos + 8 <= size) {
+      uint64_t bs = ((uint64_t)data[pos] << 24) | ((uint64_t)data[pos + 1] << 16) | ((uint64_t)data[pos + 2] << 8) | data[pos + 3];
+      const uint8_t* type = data + pos + 4;
+      size_t hdr = 8;
+      if (bs == 1) {
+        if (pos + 16 > size) { complete = false; break; }
+        bs = 0;
+        for (int i = 0; i < 8; i++) bs = (bs << 8) | data[pos + 8 + i];
+        hdr = 16;
+      }
+      size_t end;
+      if (bs == 0) { end = size; last_unbounded = true; }
+      else {
+        if (bs < hdr) Fail("bad box size");
+        end = pos + bs;
+        if (end > size) { complete = false; end = size; }
+      }
+      if (!memcmp(type, "jxlc", 4)) { tmp.insert(tmp.end(), data + pos + hdr, data + end); found = true; }
+      else if (!memcmp(type, "jxlp", 4)) { if (end >= pos + hdr + 4) { tmp.insert(tmp.end(), data + pos + hdr + 4, data + end); found = true; } }
+      else if (!memcmp(type, "jbrd", 4)) *has_jbrd = true;
+      pos = end;
+    }
+    (void)last_unbounded;
+    if (!found) complete = false;
+    src = tmp.data(); n = tmp.size();
+  }
+  cs->size = n;
+  cs->storage.assign((n + 3) / 4 + 4, 0);
+  if (n) memcpy(cs->data(), src, n);
+  return complete;
+}
+
+void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bitpos) {
+  Reader r(cs, 0);
+  if (r.u(16) != 0x0AFF) Fail("not a JPEG XL codestream");
+  ReadSizeHeader(r, &ih->xsize, &ih->ysize);
+  bool all_default = r.b();
+  bool extra_fields = false;
+  if (!all_default) {
+    extra_fields = r.b();
+    if (extra_fields) {
+      ih->orientation = r.u(3) + 1;
+      if (r.b()) ReadSizeHeader(r, &ih->intrinsic_x, &ih->intrinsic_y);
+      ih->have_preview = r.b();
+      if (ih->have_preview) Unsupported("preview frame");
+      ih->have_animation = r.b();
+      if (ih->have_animation) {
+        ih->tps_num = r.U32({0, 100}, {0, 1000}, {10, 1}, {30, 1});
+        ih->tps_den = r.U32({0, 1}, {0, 1001}, {8, 1}, {10, 1});
+        ih->num_loops = r.U32({0, 0}, {3, 0}, {16, 0}, {32, 0});
+        ih->have_timecodes = r.b();
+      }
+    }
+    ReadBitDepth(r, &ih->depth);
+    r.b();  // modular_16bit_buffers
+    uint32_t nextra = r.U32({0, 0}, {0, 1}, {4, 2}, {12, 1});
+    ih->extra.resize(nextra);
+    for (auto& e : ih->extra) {
+      if (r.b()) continue;  // default 8-bit alpha
+      e.type = r.Enum();
+      ReadBitDepth(r, &e.depth);
+      e.dim_shift = r.U32({0, 0}, {0, 3}, {0, 4}, {3, 1});
+      SkipName(r);
+      if (e.type == 0) e.alpha_associated = r.b();
+      if (e.type == 2) for (int i = 0; i < 4; i++) r.F16();
+      if (e.type == 5) r.U32({0, 1}, {2, 0}, {4, 3}, {8, 19});
+    }
+    ih->xyb_encoded = r.b();
+    ih->color_default = r.b();
+    if (!ih->color_default) {
+      ih->want_icc = r.b();
+      ih->color_space = r.Enum();
+      if (!ih->want_icc) {
+        if (ih->color_space != 2) { ih->white_point = r.Enum(); if (ih->white_point == 2) SkipCustomXY(r); }
+        if (ih->color_space != 2 && ih->color_space != 1) { ih->primaries = r.Enum(); if (ih->primaries == 2) for (int i = 0; i < 3; i++) SkipCustomXY(r); }
+        if (ih->color_space != 2) { ih->have_gamma = r.b(); if (ih->have_gamma) ih->gamma = r.u(24); else ih->tf = r.Enum(); }
+        ih->rendering_intent = r.Enum();
+      }
+    }
+    if (extra_fields && !r.b()) {
+      ih->intensity_target = r.F16(); ih->min_nits = r.F16(); ih->relative_to_max_display = r.b(); ih->linear_below = r.F16();
+    }
+    r.SkipExtensions();
+  }
+  static const float kInv[9] = {11.031566901960783f,  -9.866943921568629f, -0.16462299647058826f, -3.254147380392157f, 4.418770392156863f,
+                                -0.16462299647058826f, -3.6588512862745097f, 2.7129230470588235f, 1.9459282392156863f};
+  for (int i = 0; i < 9; i++) ih->opsin_inv[i] = kInv[i];
+  for (int i = 0; i < 3; i++) ih->opsin_bias[i] = -0.0037930732552754493f;
+  ih->quant_bias[0] = 1.0f - 0.05465007330715401f; ih->quant_bias[1] = 1.0f - 0.07005449891748593f;
+  ih->quant_bias[2] = 1.0f - 0.049935103337343655f; ih->quant_bias[3] = 0.145f;
+  if (!r.b()) {  // default_m == false
+    if (ih->xyb_encoded && !r.b()) {
+      for (int i = 0; i < 9; i++) ih->opsin_inv[i] = r.F16();
+      for (int i = 0; i < 3; i++) ih->opsin_bias[i] = r.F16();
+      for (int i = 0; i < 4; i++) ih->quant_bias[i] = r.F16();
+    }
+    uint32_t cw = r.u(3);
+    if (cw & 1) for (int i = 0; i < 15; i++) r.F16();
+    if (cw & 2) for (int i = 0; i < 55; i++) r.F16();
+    if (cw & 4) for (int i = 0; i < 210; i++) r.F16();
+  }
+  if (ih->want_icc) Unsupported("embedded ICC profile");
+  r.align();
+  *frame_bitpos = r.pos();
+}
+
+static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p);
+
+void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* p) {
+  Reader r(cs, frame_bitpos);
+  const size_t num_extra = ih.extra.size();
+  const bool xyb = ih.xyb_encoded;
+  uint32_t fx = ih.xsize, fy = ih.ysize;
+  std::vector<uint32_t> ec_ups(num_extra, 1);
+  bool all_default = r.b();
+  if (!xyb) { p->x_qm_scale = 2; p->b_qm_scale = 2; }
+  if (!all_default) {
+    p->frame_type = r.u(2);
+    p->modular = r.u(1) != 0;
+    p->flags = r.U64();
+    if (!xyb) p->do_ycbcr = r.b();
+    const bool use_lf_frame = (p->flags & 32) != 0;
+    uint32_t jpeg_ups[3] = {0, 0, 0};
+    if (p->do_ycbcr && !use_lf_frame) for (int i = 0; i < 3; i++) jpeg_ups[i] = r.u(2);
+    if (!use_lf_frame) {
+      p->upsampling = r.U32({0, 1}, {0, 2}, {0, 4}, {0, 8});
+      for (auto& e : ec_ups) e = r.U32({0, 1}, {0, 2}, {0, 4}, {0, 8});
+    }
+    if (p->modular) p->group_size_shift = r.u(2);
+    if (!p->modular && xyb) { p->x_qm_scale = r.u(3); p->b_qm_scale = r.u(3); }
+    if (p->frame_type != 2) {
+      p->num_passes = r.U32({0, 1}, {0, 2}, {0, 3}, {3, 4});
+      if (p->num_passes != 1) {
+        uint32_t nds = r.U32({0, 0}, {0, 1}, {0, 2}, {1, 3});
+        for (uint32_t i = 0; i + 1 < p->num_passes; i++) p->pass_shift[i] = r.u(2);
+        for (uint32_t i = 0; i < nds; i++) r.U32({0, 1}, {0, 2}, {0, 4}, {0, 8});
+        for (uint32_t i = 0; i < nds; i++) r.U32({0, 0}, {0, 1}, {0, 2}, {3, 0});
+      }
+    }
+    bool partial = false;
+    uint32_t lf_level = 0;
+    if (p->frame_type == 1) lf_level = r.U32({0, 1}, {0, 2}, {0, 3}, {0, 4});
+    else if (r.b()) {
+      int32_t x0 = 0, y0 = 0;
+      if (p->frame_type != 2) {
+        x0 = UnpackSigned(r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688}));
+        y0 = UnpackSigned(r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688}));
+      }
+      fx = r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688});
+      fy = r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688});
+      partial = x0 > 0 || y0 > 0 || (int64_t)fx + x0 < (int64_t)ih.xsize || (int64_t)fy + y0 < (int64_t)ih.ysize;
+      if (x0 != 0 || y0 != 0 || fx != ih.xsize || fy != ih.ysize) Unsupported("cropped frame");
+    }
+    uint32_t blend_mode = 0, duration = 0, save_as_ref = 0;
+    if (p->frame_type == 0 || p->frame_type == 3) {
+      for (size_t i = 0; i < 1 + num_extra; i++) {
+        uint32_t mode = r.U32({0, 0}, {0, 1}, {0, 2}, {2, 3});
+        if (i == 0) blend_mode = mode;
+        if (num_extra > 0 && (mode == 2 || mode == 3)) r.U32({0, 0}, {0, 1}, {0, 2}, {3, 3});
+        if (num_extra > 0 && (mode == 2 || mode == 3 || mode == 4)) r.b();
+        if (mode != 0 || partial) r.u(2);
+      }
+      if (ih.have_animation) { duration = r.U32({0, 0}, {0, 1}, {8, 0}, {32, 0}); if (ih.have_timecodes) r.u(32); }
+      p->is_last = r.b();
+    } else p->is_last = false;
+    if (p->frame_type != 1 && !p->is_last) save_as_ref = r.u(2);
+    bool can_ref = !p->is_last && p->frame_type != 1 && (duration == 0 || save_as_ref != 0);
+    bool full_replace = (p->frame_type == 0 || p->frame_type == 3) && blend_mode == 0 && !partial;
+    if (p->frame_type == 2 || (can_ref && full_replace)) r.b();
+    SkipName(r);
+    if (!r.b()) {  // RestorationFilter not all_default
+      LoopFilterParams& lf = p->lf;
+      lf.gab = r.b();
+      if (lf.gab && r.b()) for (int i = 0; i < 6; i++) lf.gab_w[i] = r.F16();
+      lf.epf_iters = r.u(2);
+      if (lf.epf_iters > 0) {
+        if (!p->modular && r.b()) for (int i = 0; i < 8; i++) lf.sharp_lut[i] = r.F16();
+        if (r.b()) { for (int i = 0; i < 3; i++) lf.channel_scale[i] = r.F16(); r.F16(); r.F16(); }
+        if (r.b()) { if (!p->modular) lf.quant_mul = r.F16(); lf.pass0_sigma_scale = r.F16(); lf.pass2_sigma_scale = r.F16(); lf.border_sad_mul = r.F16(); }
+        if (p->modular) r.F16();
+      }
+      r.SkipExtensions();
+    }
+    r.SkipExtensions();
+    if (p->frame_type != 0) Unsupported("non-regular frame (reference / LF / skip-progressive)");
+    if (!p->is_last) Unsupported("multi-frame image");
+    if (p->upsampling != 1) Unsupported("upsampling");
+    for (auto e : ec_ups) if (e != 1) Unsupported("extra-channel upsampling");
+    for (int i = 0; i < 3; i++) if (jpeg_ups[i]) Unsupported("chroma subsampling");
+    if (use_lf_frame) Unsupported("LF frame");
+    (void)lf_level;
+  }
+  if (p->flags & 2) Unsupported("patches");
+  if (p->flags & 16) Unsupported("splines");
+  if (p->flags & 1) Unsupported("noise");
+  if (p->num_passes != 1) Unsupported("multiple passes");
+  p->width = fx; p->height = fy;
+  p->group_dim = p->modular ? (128u << p->group_size_shift) : 256u;
+  p->xgroups = (fx + p->group_dim - 1) / p->group_dim; p->ygroups = (fy + p->group_dim - 1) / p->group_dim;
+  p->num_groups = p->xgroups * p->ygroups;
+  p->xlfgroups = (fx + p->group_dim * 8 - 1) / (p->group_dim * 8); p->ylfgroups = (fy + p->group_dim * 8 - 1) / (p->group_dim * 8);
+  p->num_lf_groups = p->xlfgroups * p->ylfgroups;
+  p->bw = (fx + 7) / 8; p->bh = (fy + 7) / 8;
+  // ---- TOC
+  p->single_section = p->num_groups == 1 && p->num_passes == 1;
+  size_t n = p->single_section ? 1 : 1 + p->num_lf_groups + 1 + (size_t)p->num_groups * p->num_passes;
+  if (r.b()) Unsupported("permuted TOC");
+  r.align();
+  std::vector<uint64_t> sizes(n);
+  for (auto& s : sizes) s = r.U32({10, 0}, {14, 1024}, {22, 17408}, {30, 4211712});
+  r.align();
+  uint64_t off = r.pos() / 8;
+  p->sections.resize(n);
+  for (size_t i = 0; i < n; i++) { p->sections[i] = {off, sizes[i]}; off += sizes[i]; }
+  if (off > cs.size) throw ParseError("truncated", false);
+  // ---- LfGlobal
+  Reader rg(cs, p->sections[0].offset * 8);
+  rg.limit_bits = (p->sections[0].offset + p->sections[0].size) * 8;
+  ParseLfGlobal(rg, ih, p);
+  p->end_bitpos = rg.pos();
+  if (!p->single_section && !p->modular) ParseHfGlobal(cs, ih, p->sections[1 + p->num_lf_groups].offset * 8, p);
+}
+
+static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
+  if (!r.b()) for (int c = 0; c < 3; c++) p->m_lf[c] = r.F16() * (1.0f / 128.0f);
+  BlockCtxDev& b = p->bcm;
+  memset(&b, 0, sizeof(b));
+  if (!p->modular) {
+    p->global_scale = r.U32({11, 1}, {11, 2049}, {12, 4097}, {16, 8193});
+    p->quant_lf = r.U32({0, 16}, {5, 1}, {8, 1}, {16, 1});
+    static const uint8_t kDefault[39] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
+    b.num_lf_ctxs = 1; b.num_ctxs = 15;
+    memcpy(b.ctx_map, kDefault, 39);
+    if (!r.b()) {
+      for (int j = 0; j < 3; j++) {
+        b.n_lf_thr[j] = r.u(4);
+        for (uint32_t i = 0; i < b.n_lf_thr[j]; i++) b.lf_thr[j][i] = UnpackSigned(r.U32({4, 0}, {8, 16}, {16, 272}, {32, 65808}));
+      }
+      b.n_qf_thr = r.u(4);
+      for (uint32_t i = 0; i < b.n_qf_thr; i++) b.qf_thr[i] = r.U32({2, 0}, {3, 4}, {5, 12}, {8, 44}) + 1;
+      b.num_lf_ctxs = (b.n_lf_thr[0] + 1) * (b.n_lf_thr[1] + 1) * (b.n_lf_thr[2] + 1);
+      size_t n = (size_t)39 * b.num_lf_ctxs * (b.n_qf_thr + 1);
+      if (n > sizeof(b.ctx_map)) Fail("block context map too large");
+      std::vector<uint8_t> map; uint32_t nc = 0;
+      ReadContextMap(r, (uint32_t)n, map, &nc);
+      if (nc > 16) Fail("too many block contexts");
+      memcpy(b.ctx_map, map.data(), n);
+      b.num_ctxs = nc;
+    }
+    if (!r.b()) {
+      p->color_factor = r.U32({0, 84}, {0, 256}, {8, 2}, {16, 258});
+      p->base_x = r.F16(); p->base_b = r.F16();
+      p->ytox_lf = (int32_t)r.u(8) - 128; p->ytob_lf = (int32_t)r.u(8) - 128;
+    }
+  }
+  // GlobalModular (dec_modular.cc DecodeGlobalInfo)
+  p->has_global_tree = r.b();
+  uint32_t nb_color = 0;
+  if (p->modular) nb_color = (ih.color_space == 1 && !ih.xyb_encoded && !p->do_ycbcr) ? 1 : 3;
+  p->nb_color_channels = nb_color;
+  if (p->has_global_tree) {
+    size_t limit = std::min<size_t>(1u << 22, 1024 + (size_t)p->width * p->height * (nb_color + ih.extra.size()) / 16);
+    ReadTree(r, &p->tree, limit);
+    ReadEntropyCode(r, p->tree.num_leaves, &p->tree_code);
+    if (p->tree.max_prop >= 16) Unsupported("MA tree referencing previous channels (property >= 16)");
+  }
+  p->gchannels.clear();
+  for (uint32_t c = 0; c < nb_color + ih.extra.size(); c++) p->gchannels.push_back({p->width, p->height, 0, 0});
+  p->nb_meta_channels = 0;
+  p->global_decodable = 0;
+  p->gwp = WPHeader{16, 10, {7, 7, 7, 0, 0}, {13, 12, 12, 12}};
+  if (p->gchannels.empty()) { p->global_data_bitpos = r.pos(); return; }
+  // GroupHeader
+  p->g_use_global_tree = r.b();
+  if (!r.b()) {
+    p->gwp.p1 = r.u(5); p->gwp.p2 = r.u(5);
+    for (int i = 0; i < 5; i++) p->gwp.p3[i] = r.u(5);
+    for (int i = 0; i < 4; i++) p->gwp.w[i] = r.u(4);
+  }
+  uint32_t nt = r.U32({0, 0}, {0, 1}, {4, 2}, {8, 18});
+  p->gtransforms.resize(nt);
+  for (auto& t : p->gtransforms) {
+    ReadTransform(r, &t);
+    // apply to the channel list (transform.cc MetaApply)
+    auto& ch = p->gchannels;
+    if (t.id == 0) { if (t.begin_c + 3 > ch.size()) Fail("rct range"); }
+    else if (t.id == 1) {
+      uint32_t endc = t.begin_c + t.num_c - 1;
+      if (endc >= ch.size()) Fail("palette range");
+      if (t.begin_c < p->nb_meta_channels) Unsupported("palette over meta channels");
+      p->nb_meta_channels += 1;
+      ch.erase(ch.begin() + t.begin_c + 1, ch.begin() + endc + 1);
+      ch.insert(ch.begin(), FramePlan::ModChannel{t.nb_colors, t.num_c, -1, 0});
+    } else Unsupported("global squeeze transform");
+  }
+  if (!p->g_use_global_tree) Unsupported("local MA tree in the global modular stream");
+  if (!p->has_global_tree) Fail("global tree missing");
+  uint32_t end = (uint32_t)p->gchannels.size();
+  for (uint32_t i = 0; i < p->gchannels.size(); i++) {
+    const auto& c = p->gchannels[i];
+    if (i >= p->nb_meta_channels && (c.w > p->group_dim || c.h > p->group_dim)) { end = i; break; }
+  }
+  p->global_decodable = end;
+  p->global_data_bitpos = r.pos();
+}
+
+void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos, FramePlan* p) {
+  (void)ih;
+  Reader r(cs, bitpos);
+  for (int k = 0; k < 17; k++) p->qspec[k] = QuantTableSpec();
+  if (!r.b()) {
+    for (int k = 0; k < 17; k++) {
+      QuantTableSpec& q = p->qspec[k];
+      q.mode = r.u(3);
+      auto bands = [&](uint32_t* n, float (*v)[17]) {
+        *n = r.u(4) + 1;
+        for (int c = 0; c < 3; c++) for (uint32_t i = 0; i < *n; i++) v[c][i] = r.F16();
+        for (int c = 0; c < 3; c++) v[c][0] *= 64.0f;
+      };
+      switch (q.mode) {
+        case 0: break;
+        case 1: if (k != 1) Fail("quant mode/table mismatch"); for (int c = 0; c < 3; c++) for (int i = 0; i < 3; i++) q.idw[c][i] = r.F16() * 64.0f; break;
+        case 2: if (k != 2) Fail("quant mode/table mismatch"); for (int c = 0; c < 3; c++) for (int i = 0; i < 6; i++) q.dct2w[c][i] = r.F16() * 64.0f; break;
+        case 3: if (k != 3) Fail("quant mode/table mismatch"); for (int c = 0; c < 3; c++) for (int i = 0; i < 2; i++) q.dct4mul[c][i] = r.F16(); bands(&q.num_bands, q.bands); break;
+        case 4: if (k != 9) Fail("quant mode/table mismatch"); for (int c = 0; c < 3; c++) q.dct4x8mul[c] = r.F16(); bands(&q.num_bands, q.bands); break;
+        case 5:
+          if (k != 10) Fail("quant mode/table mismatch");
+          for (int c = 0; c < 3; c++) for (int i = 0; i < 9; i++) { q.afvw[c][i] = r.F16(); if (i < 6) q.afvw[c][i] *= 64.0f; }
+          bands(&q.num_bands, q.bands); bands(&q.num_bands4, q.bands4);
+          break;
+        case 6: bands(&q.num_bands, q.bands); break;
+        case 7: Unsupported("RAW quantisation tables");
+      }
+    }
+  }
+  p->num_hf_presets = 1 + r.u(CeilLog2(p->num_groups));
+  p->used_orders.assign(p->num_passes, 0);
+  p->custom_order.assign((size_t)p->num_passes * 39, {});
+  p->ac_code.resize(p->num_passes);
+  for (uint32_t ps = 0; ps < p->num_passes; ps++) {
+    uint32_t used = r.U32({0, 0x5F}, {0, 0x13}, {0, 0}, {13, 0});
+    p->used_orders[ps] = used;
+    if (used) {
+      HostCode oc;
+      ReadEntropyCode(r, 8, &oc);
+      HostSymbolReader sr(r, oc);
+      auto ctxof = [](uint32_t v) { uint32_t t = v == 0 ? 0 : 1 + FloorLog2(v); return std::min<uint32_t>(t, 7); };
+      for (int b = 0; b < 13; b++) {
+        if (!(used & (1u << b))) continue;
+        std::vector<uint16_t> natural = NaturalCoeffOrder(kBucketStrategy[b]);
+        const size_t size = natural.size(), skip = size / 64;
+        for (int c = 0; c < 3; c++) {
+          std::vector<uint32_t> lehmer(size, 0);
+          uint32_t end = sr.Read(ctxof((uint32_t)size)) + (uint32_t)skip;
+          if (end > size) Fail("permutation size");
+          uint32_t last = 0;
+          for (size_t i = skip; i < end; i++) { lehmer[i] = sr.Read(ctxof(last)); last = lehmer[i]; if (lehmer[i] >= size - i) Fail("lehmer code"); }
+          std::vector<uint32_t> temp(size);
+          for (size_t i = 0; i < size; i++) temp[i] = (uint32_t)i;
+          std::vector<uint16_t>& o = p->custom_order[(size_t)ps * 39 + b * 3 + c];
+          o.resize(size);
+          for (size_t i = 0; i < size; i++) { o[i] = natural[temp[lehmer[i]]]; temp.erase(temp.begin() + lehmer[i]); }
+        }
+      }
+      sr.CheckFinal();
+    }
+    ReadEntropyCode(r, 495 * p->bcm.num_ctxs * p->num_hf_presets, &p->ac_code[ps]);
+  }
+  p->end_bitpos = r.pos();
+}
+
+// ---- tables ---------------------------------------------------------------------------------------------------------------
+const uint8_t kBucketStrategy[13] = {0, 1, 4, 5, 6, 8, 10, 18, 19, 21, 22, 24, 25};
+const uint8_t kKindRows[17] = {1, 1, 1, 1, 2, 4, 1, 1, 2, 1, 1, 8, 4, 16, 8, 32, 16};
+const uint8_t kKindCols[17] = {1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32};
+
+std::vector<uint16_t> NaturalCoeffOrder(int strategy) {
+  int cx = (int)CoveredX(strategy), cy = (int)CoveredY(strategy);
+  if (cy > cx) std::swap(cx, cy);
+  const int xs = cx * 8, ratio = cx / cy, mask = ratio - 1;
+  int lr = 0; while ((1 << lr) < ratio) lr++;
+  std::vector<uint16_t> out((size_t)cx * cy * 64);
+  size_t cur = (size_t)cx * cy;
+  auto emit = [&](int x, int y, bool first_half) {
+    if (y & mask) return;
+    y >>= lr;
+    size_t k = (first_half && x < cx && y < cy) ? (size_t)y * cx + x : cur++;
+    out[k] = (uint16_t)(y * xs + x);
+  };
+  for (int i = 0; i < xs; i++) for (int j = 0; j <= i; j++) { int x = j, y = i - j; if (i & 1) std::swap(x, y); emit(x, y, true); }
+  for (int i = xs - 2; i >= 0; i--) for (int j = 0; j <= i; j++) { int x = xs - 1 - (i - j), y = xs - 1 - j; if (i & 1) std::swap(x, y); emit(x, y, false); }
+  return out;
+}
+
+static QuantTableSpec LibrarySpec(int kind) {
+  // quant_weights.cc library defaults [R]: only band-parameterised kinds are reproduced
+  QuantTableSpec q;
+  auto set = [&](int n, std::initializer_list<float> x, std::initializer_list<float> y, std::initializer_list<float> b) {
+    q.mode = 6; q.num_bands = n;
+    int i = 0; for (float v : x) q.bands[0][i++] = v;
+    i = 0; for (float v : y) q.bands[1][i++] = v;
+    i = 0; for (float v : b) q.bands[2][i++] = v;
+  };
+  switch (kind) {
+    case 0: set(6, {3150.0f, 0.0f, -0.4f, -0.4f, -0.4f, -2.0f}, {560.0f, 0.0f, -0.3f, -0.3f, -0.3f, -0.3f}, {512.0f, -2.0f, -1.0f, 0.0f, -1.0f, -2.0f}); break;
+    case 1: { q.mode = 1; float w[3][3] = {{280.0f, 3160.0f, 3160.0f}, {60.0f, 864.0f, 864.0f}, {18.0f, 200.0f, 200.0f}}; memcpy(q.idw, w, sizeof(w)); break; }
+    case 2: { q.mode = 2; float w[3][6] = {{3840.0f, 2560.0f, 1280.0f, 640.0f, 480.0f, 300.0f}, {960.0f, 640.0f, 320.0f, 180.0f, 140.0f, 120.0f}, {640.0f, 320.0f, 128.0f, 64.0f, 32.0f, 16.0f}}; memcpy(q.dct2w, w, sizeof(w)); break; }
+    case 3: set(4, {2200.0f, 0.0f, 0.0f, 0.0f}, {392.0f, 0.0f, 0.0f, 0.0f}, {112.0f, -0.25f, -0.25f, -0.5f}); q.mode = 3; for (int c = 0; c < 3; c++) q.dct4mul[c][0] = q.dct4mul[c][1] = 1.0f; break;
+    case 4: set(7, {8996.8725711814115328f, -1.3000777393353804f, -0.49424529824571225f, -0.439093774457103443f, -0.6350101832695744f, -0.90177264050827612f, -1.6162099239887414f},
+                {3191.48366296844234752f, -0.67424582104194355f, -0.80745813428471001f, -0.44925837484843441f, -0.35865440981033403f, -0.31322389111877305f, -0.37615025315725483f},
+                {1157.50408145487200256f, -2.0531423165804414f, -1.4f, -0.50687130033378396f, -0.42708730624733904f, -1.4856834539296244f, -4.9209142884401604f}); break;
+    case 5: set(8, {15718.40830982518931456f, -1.025f, -0.98f, -0.9012f, -0.4f, -0.48819395464f, -0.421064f, -0.27f},
+                {7305.7636810695983104f, -0.8041958212306401f, -0.7633036457487539f, -0.55660379990111464f, -0.49785304658857626f, -0.43699592683512467f, -0.40180866526242109f, -0.27321683125358037f},
+                {3803.53173721215041536f, -3.060733579805728f, -2.0413270132490346f, -2.0235650159727417f, -0.5495389509954993f, -0.4f, -0.4f, -0.3f}); break;
+    case 6: set(7, {7240.7734393502f, -0.7f, -0.7f, -0.2f, -0.2f, -0.2f, -0.5f}, {1448.15468787004f, -0.5f, -0.5f, -0.5f, -0.2f, -0.2f, -0.2f}, {506.854140754517f, -1.4f, -0.2f, -0.5f, -0.5f, -1.5f, -3.6f}); break;
+    case 7: set(8, {16283.2494710648897f, -1.7812845336559429f, -1.6309059012653515f, -1.0382179034313539f, -0.85f, -0.7f, -0.9f, -1.2360638576849587f},
+                {5089.15750884921511936f, -0.320049391452786891f, -0.35362849922161446f, -0.30340000000000003f, -0.61f, -0.5f, -0.5f, -0.6f},
+                {3397.77603275308720128f, -0.321327362693153371f, -0.34507619223117997f, -0.70340000000000003f, -0.9f, -1.0f, -1.0f, -1.1754605576265209f}); break;
+    case 8: set(8, {13844.97076442300573f, -0.97113799999999995f, -0.658f, -0.42026f, -0.22712f, -0.2206f, -0.226f, -0.6f},
+                {4798.964084220744293f, -0.61125308982767057f, -0.83770786552491361f, -0.79014862079498627f, -0.2692727459704829f, -0.38272769465388551f, -0.22924222653091453f, -0.20719098826199578f},
+                {1807.236946760964614f, -1.2f, -1.2f, -0.7f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
+    case 9: set(4, {2198.050556016380522f, -0.96269623020744692f, -0.76194253026666783f, -0.6551140670773547f}, {764.3655248643528689f, -0.92630200888366945f, -0.9675229603596517f, -0.27845290869168118f},
+                {527.107573587542228f, -1.4594385811273854f, -1.450082094097871593f, -1.5843722511996204f}); q.mode = 4; for (int c = 0; c < 3; c++) q.dct4x8mul[c] = 1.0f; break;
+    case 10: q.mode = 5; break;
+    default: {
+      static const float k64[3] = {26629.073922049845f, 9311.3238710010046f, 4992.2486445538634f}, k32[3] = {23629.073922049845f, 8611.3238710010046f, 4492.2486445538634f};
+      float mul; const float* base;
+      switch (kind) { case 11: mul = 0.9f; base = k64; break; case 12: mul = 0.65f; base = k32; break; case 13: mul = 1.8f; base = k64; break;
+                      case 14: mul = 1.3f; base = k32; break; case 15: mul = 3.6f; base = k64; break; default: mul = 2.6f; base = k32; break; }
+      set(8, {mul * base[0], -1.025f, -0.78f, -0.65012f, -0.19041574084286472f, -0.20819395464f, -0.421064f, -0.32733845535848671f},
+          {mul * base[1], -0.3041958212306401f, -0.3633036457487539f, -0.35660379990111464f, -0.3443074455424403f, -0.33699592683512467f, -0.30180866526242109f, -0.27321683125358037f},
+          {mul * base[2], -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f});
+    }
+  }
+  return q;
+}
+
+static void BandWeights(uint32_t nb, const float (*bands_in)[17], int c, int ROWS, int COLS, float* out) {
+  float bands[17];
+  bands[0] = bands_in[c][0];
+  if (!(bands[0] >= 1e-8f)) Fail("quant band");
+  for (uint32_t i = 1; i < nb; i++) {
+    float v = bands_in[c][i];
+    bands[i] = bands[i - 1] * (v > 0 ? 1.0f + v : 1.0f / (1.0f - v));
+    if (!(bands[i] >= 1e-8f)) Fail("quant band");
+  }
+  const float kSqrt2 = 1.41421356237309504880f;
+  float scale = (nb - 1) / (kSqrt2 + 1e-6f), rcpcol = scale / (COLS - 1), rcprow = scale / (ROWS - 1);
+  for (int y = 0; y < ROWS; y++) {
+    float dy = y * rcprow, dy2 = dy * dy;
+    for (int x = 0; x < COLS; x++) {
+      float dx = x * rcpcol;
+      float dist = std::sqrt(std::fmaf(dx, dx, dy2));
+      float w;
+      if (nb == 1) w = bands[0];
+      else {
+        int idx = (int)dist;
+        if (idx + 1 >= (int)nb) idx = (int)nb - 2;
+        float frac = dist - idx;
+        w = bands[idx] * std::pow(bands[idx + 1] / bands[idx], frac);
+      }
+      out[y * COLS + x] = w;
+    }
+  }
+}
+
+void ComputeQuantTable(const QuantTableSpec& spec0, int kind, int c, std::vector<float>* out) {
+  QuantTableSpec lib;
+  const QuantTableSpec* q = &spec0;
+  if (spec0.mode == 0) { lib = LibrarySpec(kind); q = &lib; }
+  const int ROWS = 8 * kKindRows[kind], COLS = 8 * kKindCols[kind];
+  const size_t n = (size_t)ROWS * COLS;
+  std::vector<float> w(n, 1.0f);
+  switch (q->mode) {
+    case 6: BandWeights(q->num_bands, q->bands, c, ROWS, COLS, w.data()); break;
+    case 1: for (auto& v : w) v = q->idw[c][0]; w[1] = w[8] = q->idw[c][1]; w[9] = q->idw[c][2]; break;
+    case 2: {
+      const float* d = q->dct2w[c];
+      w[0] = 1e6f; w[1] = w[8] = d[0]; w[9] = d[1];
+      for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { w[y * 8 + x + 2] = d[2]; w[(y + 2) * 8 + x] = d[2]; w[(y + 2) * 8 + x + 2] = d[3]; }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { w[y * 8 + x + 4] = d[4]; w[(y + 4) * 8 + x] = d[4]; w[(y + 4) * 8 + x + 4] = d[5]; }
+      break;
+    }
+    case 3: {
+      float w4[16]; BandWeights(q->num_bands, q->bands, c, 4, 4, w4);
+      for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[y * 8 + x] = w4[(y / 2) * 4 + x / 2];
+      w[1] /= q->dct4mul[c][0]; w[8] /= q->dct4mul[c][0]; w[9] /= q->dct4mul[c][1];
+      break;
+    }
+    case 4: {
+      float w48[32]; BandWeights(q->num_bands, q->bands, c, 4, 8, w48);
+      for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[y * 8 + x] = w48[(y / 2) * 8 + x];
+      w[8] /= q->dct4x8mul[c];
+      break;
+    }
+    case 5: break;  // AFV weights not reproduced; AFV blocks are rejected by the LF stage
+    default: Fail("quant mode");
+  }
+  out->resize(n);
+  for (size_t i = 0; i < n; i++) { if (!(w[i] > 0) || !std::isfinite(w[i])) Fail("quant weight"); (*out)[i] = 1.0f / w[i]; }
+}
+
+}  // namespace jxlhip

@@ -1,0 +1,161 @@
+// jxl-hip: host-side header parser.  Parses only the *structural* parts of a codestream — container, image and frame
+// headers, TOC and the two global sections' tables (MA tree, entropy-code histograms → alias tables, quantisation
+// parameters, coefficient orders).  Every O(pixels)/O(tokens) stream (LF coefficients, HF metadata, AC coefficients,
+// modular channels) is left for the HIP kernels.  Replaces the header side of libjxl's decode.cc / headers.cc /
+// frame_header.cc / toc.cc / dec_ans.cc(DecodeHistograms) / quant_weights.cc, reached by the reference through
+// JxlDecoderProcessInput (jpegxl-rs/src/decode.rs:238) and JxlDecoderGetBasicInfo (decode.rs:246).
+#pragma once
+#include "jxl_dev.h"
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+namespace jxlhip {
+
+struct ParseError : std::runtime_error {
+  bool unsupported;
+  ParseError(const std::string& s, bool unsup = false) : std::runtime_error(s), unsupported(unsup) {}
+};
+
+struct HostCode {  // entropy code in host memory, device-layout tables
+  std::vector<uint8_t> ctx_map;
+  std::vector<uint32_t> cfg;
+  std::vector<uint64_t> alias;
+  std::vector<uint16_t> pfx_count, pfx_syms;
+  std::vector<uint32_t> pfx_sym_off;
+  uint32_t num_ctx = 0, num_clusters = 0, log_alpha = 0, use_prefix = 0;
+  bool lz77 = false;
+  DevCode View() const {
+    DevCode d;
+    d.ctx_map = ctx_map.data(); d.cfg = cfg.data(); d.alias = alias.data();
+    d.pfx_count = pfx_count.data(); d.pfx_sym_off = pfx_sym_off.data(); d.pfx_syms = pfx_syms.data();
+    d.num_ctx = num_ctx; d.num_clusters = num_clusters; d.log_alpha = log_alpha; d.use_prefix = use_prefix;
+    return d;
+  }
+};
+
+struct HostTree {
+  std::vector<TreeNode> nodes;
+  uint32_t num_leaves = 0;
+  bool uses_wp = false;
+  int max_prop = 0;
+};
+
+struct BitDepthInfo { bool is_float = false; uint32_t bits = 8, exp_bits = 0; };
+struct ExtraChannel { uint32_t type = 0; BitDepthInfo depth; uint32_t dim_shift = 0; bool alpha_associated = false; };
+
+struct ImageHeader {
+  uint32_t xsize = 0, ysize = 0;
+  uint32_t orientation = 1;
+  uint32_t intrinsic_x = 0, intrinsic_y = 0;
+  bool have_preview = false, have_animation = false, have_timecodes = false;
+  uint32_t tps_num = 0, tps_den = 0, num_loops = 0;
+  BitDepthInfo depth;
+  std::vector<ExtraChannel> extra;
+  bool xyb_encoded = true;
+  // colour encoding
+  bool color_default = true, want_icc = false;
+  uint32_t color_space = 0, white_point = 1, primaries = 1, tf = 13, rendering_intent = 1;
+  bool have_gamma = false; uint32_t gamma = 0;
+  float intensity_target = 255.f, min_nits = 0.f, linear_below = 0.f;
+  bool relative_to_max_display = false;
+  float opsin_inv[9]; float opsin_bias[3]; float quant_bias[4];
+  bool have_container = false;
+};
+
+struct SqueezeStep { uint32_t horizontal, in_place, begin_c, num_c; };
+struct TransformDesc {
+  uint32_t id = 0, begin_c = 0, rct_type = 0, num_c = 0, nb_colors = 0, nb_deltas = 0, predictor = 0;
+  std::vector<SqueezeStep> squeeze;
+};
+
+struct LoopFilterParams {
+  uint32_t gab = 1, epf_iters = 2;
+  float gab_w[6] = {0.115169525f, 0.061248592f, 0.115169525f, 0.061248592f, 0.115169525f, 0.061248592f};
+  float sharp_lut[8] = {0.f, 1.f / 7, 2.f / 7, 3.f / 7, 4.f / 7, 5.f / 7, 6.f / 7, 1.f};
+  float channel_scale[3] = {40.0f, 5.0f, 3.5f};
+  float quant_mul = 0.46f, pass0_sigma_scale = 0.9f, pass2_sigma_scale = 6.5f, border_sad_mul = 2.0f / 3.0f;
+};
+
+struct QuantTableSpec {
+  uint32_t mode = 0;
+  uint32_t num_bands = 0; float bands[3][17];
+  uint32_t num_bands4 = 0; float bands4[3][17];
+  float idw[3][3], dct2w[3][6], dct4mul[3][2], dct4x8mul[3], afvw[3][9];
+  float raw_den = 0; std::vector<int32_t> raw[3];
+};
+
+struct Section { uint64_t offset, size; };
+
+struct FramePlan {
+  // frame header
+  uint32_t frame_type = 0; bool modular = false; uint64_t flags = 0; bool do_ycbcr = false;
+  uint32_t upsampling = 1, group_size_shift = 1, x_qm_scale = 3, b_qm_scale = 2;
+  uint32_t num_passes = 1; uint32_t pass_shift[11] = {0};
+  bool is_last = true;
+  LoopFilterParams lf;
+  // geometry
+  uint32_t width = 0, height = 0, group_dim = 256;
+  uint32_t xgroups = 0, ygroups = 0, num_groups = 0, xlfgroups = 0, ylfgroups = 0, num_lf_groups = 0;
+  uint32_t bw = 0, bh = 0;  // 8x8 blocks
+  // TOC
+  std::vector<Section> sections;   // byte offsets into the codestream buffer
+  bool single_section = false;
+  // LfGlobal
+  float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
+  uint32_t global_scale = 1, quant_lf = 1;
+  BlockCtxDev bcm;
+  uint32_t color_factor = 84; float base_x = 0.f, base_b = 1.f; int32_t ytox_lf = 0, ytob_lf = 0;
+  bool has_global_tree = false;
+  HostTree tree;
+  HostCode tree_code;       // code of the global-tree streams
+  // GlobalModular: channel list after global transforms; channel data starts at global_data_bitpos
+  struct ModChannel { uint32_t w, h; int32_t hshift, vshift; };
+  std::vector<ModChannel> gchannels;
+  uint32_t nb_meta_channels = 0;
+  std::vector<TransformDesc> gtransforms;
+  WPHeader gwp;
+  bool g_use_global_tree = true;
+  uint64_t global_data_bitpos = 0;   // absolute bit position (codestream) where the global stream's ANS state starts
+  uint32_t global_decodable = 0;     // number of leading channels decoded in the global section
+  uint32_t nb_color_channels = 0;    // colour channels held in the modular image (0 for VarDCT)
+  // HfGlobal
+  QuantTableSpec qspec[17];
+  uint32_t num_hf_presets = 1;
+  std::vector<uint32_t> used_orders;                // per pass
+  std::vector<std::vector<uint16_t>> custom_order;  // [pass*39 + bucket*3 + c] (empty = natural)
+  std::vector<HostCode> ac_code;                    // per pass
+  uint64_t end_bitpos = 0;                          // where parsing of the last host-parsed section stopped
+};
+
+// Aligned, padded copy of the codestream (container stripped) — also the H2D staging buffer
+struct Codestream {
+  std::vector<uint32_t> storage;
+  size_t size = 0;
+  const uint8_t* data() const { return reinterpret_cast<const uint8_t*>(storage.data()); }
+  uint8_t* data() { return reinterpret_cast<uint8_t*>(storage.data()); }
+  size_t padded_size() const { return storage.size() * 4; }
+};
+
+enum SigResult { kSigNotEnoughBytes = 0, kSigInvalid = 1, kSigCodestream = 2, kSigContainer = 3 };
+SigResult CheckSignature(const uint8_t* buf, size_t len);
+
+// Extracts the codestream; returns false if more input is needed (truncated container).
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd);
+
+// Parses the image header; *frame_bitpos receives the bit position of the first frame header.
+void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bitpos);
+
+// Parses frame header + TOC + LfGlobal (tables only).  On return plan->sections is filled and, for multi-section
+// frames, HfGlobal has been parsed too.  For single-section frames HfGlobal must be parsed later with ParseHfGlobal
+// at the bit position where the device-decoded LfGroup streams end.
+void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* plan);
+void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos, FramePlan* plan);
+
+// Dequantisation table (1/weight) of quant kind `kind`, channel c; natural coefficient order of a strategy.
+void ComputeQuantTable(const QuantTableSpec& spec, int kind, int c, std::vector<float>* out);
+std::vector<uint16_t> NaturalCoeffOrder(int strategy);
+extern const uint8_t kBucketStrategy[13];
+extern const uint8_t kKindRows[17], kKindCols[17];
+
+}  // namespace jxlhip

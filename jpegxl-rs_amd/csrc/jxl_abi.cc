@@ -1,0 +1,276 @@
+// jxl-hip: libjxl-compatible decoder C ABI (include/jxl_hip.h) on top of the HIP batch decoder.
+// Event state machine as exercised by jpegxl-rs/src/decode.rs:207-325 and jpegxl-sys/src/lib.rs:85-171.
+#include "../../include/jxl_hip.h"
+#include "decoder.h"
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace jxlhip;
+
+static thread_local std::string g_last_error;
+static void SetLastError(const std::string& s) { g_last_error = s; }
+
+struct JxlDecoderStruct {
+  JxlMemoryManager mm;
+  bool has_mm;
+  // settings (cleared by Reset)
+  int events_wanted;
+  bool keep_orientation, unpremul_alpha, render_spotcolors, coalescing;
+  float desired_intensity_target;
+  JxlParallelRunner runner; void* runner_opaque;
+  const uint8_t* input; size_t input_size; bool input_set, input_closed;
+  void* out_buffer; size_t out_size; JxlPixelFormat out_format; bool out_set;
+  uint8_t* jpeg_buffer; size_t jpeg_size; bool jpeg_set;
+  // progress
+  enum Stage { kInit, kHeaders, kFrame, kDone } stage;
+  int events_emitted;
+  bool started, need_out_reported;
+  Batch* batch;
+  int device;
+};
+
+static int DefaultDevice() {
+  const char* e = getenv("JXL_HIP_DEVICE");
+  return e ? atoi(e) : 0;
+}
+
+static void ClearState(JxlDecoder* d) {
+  d->events_wanted = 0;
+  d->keep_orientation = d->unpremul_alpha = false; d->render_spotcolors = true; d->coalescing = true;
+  d->desired_intensity_target = 0;
+  d->runner = nullptr; d->runner_opaque = nullptr;
+  d->input = nullptr; d->input_size = 0; d->input_set = d->input_closed = false;
+  d->out_buffer = nullptr; d->out_size = 0; d->out_set = false;
+  d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
+  d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
+  delete d->batch; d->batch = nullptr;
+}
+
+extern "C" {
+
+const char* JxlHipLastError(void) { return g_last_error.c_str(); }
+
+uint32_t JxlDecoderVersion(void) { return 11002; }  // libjxl 0.11.2 — jpegxl-sys/src/lib.rs:79
+
+JxlSignature JxlSignatureCheck(const uint8_t* buf, size_t len) { return (JxlSignature)CheckSignature(buf, len); }
+
+JxlDecoder* JxlDecoderCreate(const JxlMemoryManager* mm) {
+  // The memory manager struct is a temporary on the caller side: copy it (jpegxl-sys decode.rs:394-395).  alloc may
+  // unwind (jpegxl-rs/src/memory.rs:140-145): nothing here catches.
+  void* mem;
+  JxlMemoryManager copy = {nullptr, nullptr, nullptr};
+  bool has = false;
+  if (mm) {
+    if (!!mm->alloc != !!mm->free) return nullptr;
+    if (mm->alloc) { copy = *mm; has = true; }
+  }
+  mem = has ? copy.alloc(copy.opaque, sizeof(JxlDecoderStruct)) : malloc(sizeof(JxlDecoderStruct));
+  if (!mem) return nullptr;
+  JxlDecoder* d = new (mem) JxlDecoderStruct();
+  d->mm = copy; d->has_mm = has; d->batch = nullptr; d->device = DefaultDevice();
+  ClearState(d);
+  return d;
+}
+void JxlDecoderReset(JxlDecoder* d) { if (d) ClearState(d); }
+void JxlDecoderDestroy(JxlDecoder* d) {
+  if (!d) return;
+  ClearState(d);
+  JxlMemoryManager mm = d->mm; bool has = d->has_mm;
+  d->~JxlDecoderStruct();
+  if (has) mm.free(mm.opaque, d); else free(d);
+}
+JxlDecoderStatus JxlDecoderSetParallelRunner(JxlDecoder* d, JxlParallelRunner runner, void* opaque) {
+  if (d->started) return JXL_DEC_ERROR;
+  d->runner = runner; d->runner_opaque = opaque;  // accepted; the GPU path does not need host worker threads
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSubscribeEvents(JxlDecoder* d, int events) {
+  if (d->started) return JXL_DEC_ERROR;
+  if (events & 63) return JXL_DEC_ERROR;  // only informative events (>= 0x40) may be subscribed
+  d->events_wanted = events;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetKeepOrientation(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->keep_orientation = !!v; return JXL_DEC_SUCCESS; }
+JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->unpremul_alpha = !!v; return JXL_DEC_SUCCESS; }
+JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->render_spotcolors = !!v; return JXL_DEC_SUCCESS; }
+JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->coalescing = !!v; return JXL_DEC_SUCCESS; }
+JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* d, float v) { if (v < 0) return JXL_DEC_ERROR; d->desired_intensity_target = v; return JXL_DEC_SUCCESS; }
+
+JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t size) {
+  if (d->input_set) return JXL_DEC_ERROR;  // libjxl: "already set input, use JxlDecoderReleaseInput first"
+  d->input = data; d->input_size = size; d->input_set = true;
+  return JXL_DEC_SUCCESS;
+}
+void JxlDecoderCloseInput(JxlDecoder* d) { d->input_closed = true; }
+
+static void FillBasicInfo(const ImageHeader& ih, JxlBasicInfo* info) {
+  memset(info, 0, sizeof(*info));
+  info->have_container = ih.have_container;
+  info->xsize = ih.xsize; info->ysize = ih.ysize;
+  info->bits_per_sample = ih.depth.bits; info->exponent_bits_per_sample = ih.depth.exp_bits;
+  info->intensity_target = ih.intensity_target; info->min_nits = ih.min_nits;
+  info->relative_to_max_display = ih.relative_to_max_display; info->linear_below = ih.linear_below;
+  info->uses_original_profile = !ih.xyb_encoded;
+  info->have_preview = ih.have_preview; info->have_animation = ih.have_animation;
+  info->orientation = (int32_t)ih.orientation;
+  info->num_color_channels = ih.color_space == 1 ? 1 : 3;
+  info->num_extra_channels = (uint32_t)ih.extra.size();
+  for (auto& e : ih.extra) if (e.type == 0) { info->alpha_bits = e.depth.bits; info->alpha_exponent_bits = e.depth.exp_bits; info->alpha_premultiplied = e.alpha_associated; break; }
+  info->animation.tps_numerator = ih.tps_num; info->animation.tps_denominator = ih.tps_den; info->animation.num_loops = ih.num_loops;
+  info->animation.have_timecodes = ih.have_timecodes;
+  info->intrinsic_xsize = ih.intrinsic_x ? ih.intrinsic_x : ih.xsize; info->intrinsic_ysize = ih.intrinsic_y ? ih.intrinsic_y : ih.ysize;
+}
+
+static bool FormatToSpec(const JxlPixelFormat* f, OutputSpec* o) {
+  if (!f || f->num_channels > 4) return false;
+  switch (f->data_type) {
+    case JXL_TYPE_UINT8: o->type = 0; break;
+    case JXL_TYPE_UINT16: o->type = 1; break;
+    case JXL_TYPE_FLOAT: o->type = 2; break;
+    case JXL_TYPE_FLOAT16: o->type = 3; break;
+    default: return false;
+  }
+  o->num_channels = f->num_channels;
+  o->big_endian = f->endianness == JXL_BIG_ENDIAN;  // native == little on every supported host
+  o->align = f->align;
+  return true;
+}
+
+JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* d, JxlBasicInfo* info) {
+  if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_NEED_MORE_INPUT;
+  if (info) FillBasicInfo(d->batch->image(0).ih, info);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* format, size_t* size) {
+  if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_NEED_MORE_INPUT;
+  OutputSpec o;
+  if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  *size = Batch::OutputSize(d->batch->image(0).ih, o);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat* format, void* buffer, size_t size) {
+  if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_ERROR;
+  OutputSpec o;
+  if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  if (size < Batch::OutputSize(d->batch->image(0).ih, o)) return JXL_DEC_ERROR;
+  d->out_buffer = buffer; d->out_size = size; d->out_format = *format; d->out_set = true;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* d, uint8_t* data, size_t size) {
+  if (d->jpeg_set) return JXL_DEC_ERROR;
+  d->jpeg_buffer = data; d->jpeg_size = size; d->jpeg_set = true;
+  return JXL_DEC_SUCCESS;
+}
+size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* d) {
+  // returns the bytes NOT yet written; JPEG bit-stream reconstruction is not implemented, nothing is ever written
+  size_t r = d->jpeg_set ? d->jpeg_size : 0;
+  d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
+  return r;
+}
+
+// ICC synthesis is a "next" row: report the failure instead of fabricating a profile.
+JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder*, JxlColorProfileTarget, size_t* size) { if (size) *size = 0; SetLastError("unsupported: ICC profile synthesis"); return JXL_DEC_ERROR; }
+JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder*, JxlColorProfileTarget, uint8_t*, size_t) { SetLastError("unsupported: ICC profile synthesis"); return JXL_DEC_ERROR; }
+
+JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
+  d->started = true;
+  if (!d->input_set) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
+  try {
+    if (d->stage == JxlDecoderStruct::kInit) {
+      JxlSignature sig = JxlSignatureCheck(d->input, d->input_size);
+      if (sig == JXL_SIG_INVALID) { SetLastError("invalid signature"); return JXL_DEC_ERROR; }
+      if (sig == JXL_SIG_NOT_ENOUGH_BYTES) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
+      if (hipSetDevice(d->device) != hipSuccess) { SetLastError("no usable HIP device: the JPEG XL decode path requires an MI355X-class GPU (no CPU fallback)"); return JXL_DEC_ERROR; }
+      d->batch = new Batch(d->device);
+      d->batch->AddImage(d->input, d->input_size);
+      d->stage = JxlDecoderStruct::kHeaders;
+    }
+    if (d->stage == JxlDecoderStruct::kHeaders) {
+      if ((d->events_wanted & JXL_DEC_BASIC_INFO) && !(d->events_emitted & JXL_DEC_BASIC_INFO)) { d->events_emitted |= JXL_DEC_BASIC_INFO; return JXL_DEC_BASIC_INFO; }
+      if ((d->events_wanted & JXL_DEC_COLOR_ENCODING) && !(d->events_emitted & JXL_DEC_COLOR_ENCODING)) { d->events_emitted |= JXL_DEC_COLOR_ENCODING; return JXL_DEC_COLOR_ENCODING; }
+      // JPEG reconstruction (jbrd) is not implemented: the decoder falls through to pixel output
+      d->stage = JxlDecoderStruct::kFrame;
+    }
+    if (d->stage == JxlDecoderStruct::kFrame) {
+      if ((d->events_wanted & JXL_DEC_FRAME) && !(d->events_emitted & JXL_DEC_FRAME)) { d->events_emitted |= JXL_DEC_FRAME; return JXL_DEC_FRAME; }
+      if (!(d->events_wanted & JXL_DEC_FULL_IMAGE)) { d->stage = JxlDecoderStruct::kDone; return JXL_DEC_SUCCESS; }
+      if (!d->out_set) return JXL_DEC_NEED_IMAGE_OUT_BUFFER;
+      OutputSpec o;
+      FormatToSpec(&d->out_format, &o);
+      d->batch->SetOutput(0, o);
+      d->batch->Prepare(nullptr);
+      d->batch->Run(nullptr);       // ══► the HIP hot path
+      d->batch->Finish(nullptr);
+      d->batch->CopyOutputToHost(0, d->out_buffer, d->batch->image(0).out_size, nullptr);
+      d->stage = JxlDecoderStruct::kDone;
+      d->events_emitted |= JXL_DEC_FULL_IMAGE;
+      return JXL_DEC_FULL_IMAGE;
+    }
+    return JXL_DEC_SUCCESS;
+  } catch (const ParseError& e) {
+    SetLastError(e.what());
+    if (!d->input_closed && !strcmp(e.what(), "truncated")) return JXL_DEC_NEED_MORE_INPUT;
+    return JXL_DEC_ERROR;
+  } catch (const std::bad_alloc&) {
+    SetLastError("out of memory");
+    return JXL_DEC_ERROR;
+  }
+}
+
+// ---- batch extension ---------------------------------------------------------------------------------------------------
+struct JxlHipBatchStruct { Batch* b; };
+
+JxlHipBatch* JxlHipBatchCreate(int device) {
+  try {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device >= count) { SetLastError("no usable HIP device (no CPU fallback exists)"); return nullptr; }
+    JxlHipBatch* h = new JxlHipBatchStruct();
+    h->b = new Batch(device);
+    return h;
+  } catch (const std::exception& e) { SetLastError(e.what()); return nullptr; }
+}
+void JxlHipBatchDestroy(JxlHipBatch* h) { if (h) { delete h->b; delete h; } }
+int JxlHipBatchAddImage(JxlHipBatch* h, const uint8_t* data, size_t size) {
+  try { return h->b->AddImage(data, size); } catch (const std::exception& e) { SetLastError(e.what()); return -1; }
+}
+JxlDecoderStatus JxlHipBatchGetBasicInfo(const JxlHipBatch* h, int i, JxlBasicInfo* info) {
+  if (i < 0 || (size_t)i >= h->b->size()) return JXL_DEC_ERROR;
+  FillBasicInfo(h->b->image(i).ih, info);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlHipBatchOutBufferSize(const JxlHipBatch* h, int i, const JxlPixelFormat* format, size_t* size) {
+  OutputSpec o;
+  if (i < 0 || (size_t)i >= h->b->size() || !FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  *size = Batch::OutputSize(h->b->image(i).ih, o);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlHipBatchSetOutput(JxlHipBatch* h, int i, const JxlPixelFormat* format, void* device_buffer) {
+  OutputSpec o;
+  if (i < 0 || (size_t)i >= h->b->size() || !FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  o.device_ptr = device_buffer;
+  h->b->SetOutput(i, o);
+  return JXL_DEC_SUCCESS;
+}
+void JxlHipBatchSetLaneStride(JxlHipBatch* h, int lf, int hf) {
+  auto ok = [](int v) { return v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
+  if (ok(lf)) h->b->cfg.lane_stride_lf = lf;
+  if (ok(hf)) h->b->cfg.lane_stride_hf = hf;
+}
+#define BATCH_TRY(stmt) try { stmt; return JXL_DEC_SUCCESS; } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
+JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Prepare(s)) }
+JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Run(s)) }
+JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* h, void* s, JxlHipStageTimes* t) {
+  BATCH_TRY({ StageTimes st = h->b->RunTimed(s); t->lf_ms = st.lf_ms; t->lfpost_ms = st.lfpost_ms; t->hf_ms = st.hf_ms; t->idct_ms = st.idct_ms; t->filter_ms = st.filter_ms; t->out_ms = st.out_ms; t->total_ms = st.total_ms; })
+}
+JxlDecoderStatus JxlHipBatchFinish(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Finish(s)) }
+void* JxlHipBatchDeviceOutput(const JxlHipBatch* h, int i) { return h->b->device_output(i); }
+JxlDecoderStatus JxlHipBatchCopyOutput(JxlHipBatch* h, int i, void* dst, size_t size, void* s) { BATCH_TRY(h->b->CopyOutputToHost(i, dst, size, s)) }
+uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* h) { return h->b->total_pixels(); }
+uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* h) { return h->b->compressed_bytes(); }
+uint64_t JxlHipBatchAlgorithmicBytesHF(const JxlHipBatch* h) { return h->b->algorithmic_bytes_hf(); }
+uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* h) { return h->b->const_bytes() + h->b->work_bytes(); }
+
+}  // extern "C"

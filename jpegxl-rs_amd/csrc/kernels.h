@@ -1,0 +1,108 @@
+// jxl-hip: device-side frame descriptor + kernel launch interface (implemented in kernels.hip).
+#pragma once
+#include "jxl_dev.h"
+
+namespace jxlhip {
+
+struct ModGroupXform {  // global transform applied after all groups (RCT / palette), parsed on the host
+  uint32_t id, begin_c, rct_type, num_c, nb_colors;
+};
+
+// One per frame of a batch; array lives in device memory.  All pointers are device pointers.
+struct FrameDev {
+  // geometry
+  uint32_t width, height, bw, bh, xgroups, ygroups, num_groups, xlfgroups, num_lf_groups, cw, ch;
+  uint32_t group_dim, is_modular, plane_stride, plane_rows;
+  // codestream + sections (byte offsets); for single-section frames the *_bitpos fields are used instead
+  const uint8_t* cs;
+  uint64_t cs_size;
+  const uint64_t* sec_off;
+  const uint64_t* sec_size;
+  uint32_t single_section;
+  uint64_t lf_start_bitpos;      // single-section: where LfGroup starts
+  uint64_t hf_start_bitpos;      // single-section: where PassGroup starts
+  uint64_t* stream_end_bitpos;   // [0] = end of LfGroup stream (single-section), [1] = end of global modular stream
+  // entropy codes / tree
+  const TreeNode* tree;
+  DevCode mod_code;
+  uint32_t uses_wp;
+  WPHeader gwp;
+  DevCode ac_code;
+  const uint16_t* orders[39];
+  const BlockCtxDev* bcm;
+  uint32_t num_hf_presets, preset_bits;
+  // dequant
+  float lf_fac[3], cfl_lf_x, cfl_lf_b;
+  float inv_global_scale, x_dm, b_dm, quant_bias[4], color_scale, base_x, base_b;
+  const float* qtable[17 * 3];
+  uint32_t skip_lf_smoothing;
+  // loop filter + colour
+  uint32_t gab, epf_iters;
+  float gab_w[9];                 // per channel: n0, n1, n2 (normalised)
+  float epf_sharp_lut[8], epf_channel_scale[3], epf_quant_mul, epf_quant_scale;
+  float epf_sm[3], epf_bsm[3];    // per pass sad multipliers (normal, border)
+  float opsin_inv[9], neg_bias[3], neg_bias_cbrt[3];
+  uint32_t color_mode;            // 0: XYB->sRGB, 1: XYB->linear, 2: YCbCr->RGB, 3: none (RGB as is)
+  uint32_t is_gray;
+  // VarDCT buffers
+  int32_t* lfq[3];
+  float* lf[3];
+  float* lf_tmp[3];
+  float* llf[3];
+  uint32_t* blk_info;
+  uint32_t* coef_off;
+  int8_t* ytox; int8_t* ytob;
+  int32_t* coeff[3];
+  float* plane_a[3];
+  float* plane_b[3];
+  float* inv_sigma;
+  int32_t* lf_scratch;            // per LF group scratch (HF metadata channels)
+  uint64_t lf_scratch_stride;     // ints per LF group
+  int32_t* wp_scratch;            // per stream WP state
+  uint64_t wp_scratch_stride;
+  // modular buffers
+  int32_t* mod_plane[8];          // full-frame channel planes (after global transforms are undone: colour + extra)
+  uint32_t mod_nchan;             // channels in the global image *before* undoing global transforms
+  uint32_t mod_nb_meta;
+  uint32_t mod_w[8], mod_h[8];    // dims of each global channel (meta channels first)
+  uint32_t mod_global_decodable;
+  uint64_t mod_global_bitpos;
+  int32_t* mod_group_scratch;     // per group scratch
+  uint64_t mod_group_scratch_stride;
+  uint32_t mod_ngt;               // global transforms
+  ModGroupXform mod_gt[4];
+  uint32_t mod_bits, mod_color_channels, mod_alpha_channel /* index in mod_plane or 0xFFFFFFFF */, mod_alpha_bits;
+  // output
+  uint8_t* out;
+  uint64_t out_stride;            // bytes per row
+  uint32_t out_channels, out_type /*0 u8 1 u16 2 f32 3 f16*/, out_big_endian;
+  uint32_t* status;
+};
+
+struct LaunchCfg {
+  int lane_stride_lf = 64;   // lanes between active decode threads (64 = one stream per wave, 1 = one per lane)
+  int lane_stride_hf = 64;
+  int lane_stride_mod = 64;
+};
+
+void InitDeviceTables(void* stream);
+
+// VarDCT stages.  max_* are maxima over the batch (grid sizing); nframes = frames in batch.
+void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream);
+void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream);
+void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream);
+void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, void* stream);
+void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, int max_bw, int max_bh, bool any_gab, int max_epf, void* stream);
+void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, void* stream);
+// Modular stages
+struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; };
+void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream);
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_groups, void* stream);
+void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);
+void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, size_t n, void* stream);
+void LaunchModOutput(const FrameDev* frames, int fidx, const ModOutputArgs& a, int w, int h, void* stream);
+
+// names of the kernels (for profiling summaries)
+extern const char* const kKernelNames[];
+
+}  // namespace jxlhip

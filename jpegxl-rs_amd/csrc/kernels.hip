@@ -1,0 +1,1087 @@
+// jxl-hip: hand-written HIP kernels for gfx950 (MI355X) — the JPEG XL decode hot path.
+// Stages: K_lf (LF coefficients + HF metadata entropy decode, b3/b4), K_lfpost (LF dequant, adaptive
+// smoothing, LLF, b6), K_hf (ANS coefficient decode, b3/b7), K_idct (dequant + CfL + variable-block IDCT, b8/b9),
+// K_gab (b11), K_epf (b12), K_out (XYB -> linear -> sRGB -> interleaved write, b15-b17), K_mod* (Modular, b4/b5).
+// Compiled with -ffp-contract=off: every fused multiply-add is an explicit fmaf so results are bit-identical to the
+// CPU oracle's (and to what libjxl's MulAdd does on FMA hardware).
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <algorithm>
+
+namespace jxlhip {
+
+__constant__ float d_wc[9][128];       // WcMultipliers<N>[i] = 1 / (2 cos((i + 0.5) pi / N)), row = log2 N
+__constant__ float d_resample[4][8];   // DCTTotalResampleScale<N, 8N>(k), row = log2 N
+
+__device__ __forceinline__ void SetError(const FrameDev& f, uint32_t e) { atomicOr(f.status, e); }
+
+// =====================================================================================================================
+// small device-side field readers (GroupHeader / transforms of modular sub-streams)
+// =====================================================================================================================
+struct U32D { int bits; uint32_t off; };
+__device__ __forceinline__ uint32_t ReadU32(BitReader& br, U32D d0, U32D d1, U32D d2, U32D d3) {
+  const uint32_t s = br.Read(2);
+  const U32D d = s == 0 ? d0 : s == 1 ? d1 : s == 2 ? d2 : d3;
+  return d.off + (d.bits ? br.Read(d.bits) : 0);
+}
+__device__ __forceinline__ int CeilLog2D(uint32_t x) { return x <= 1 ? 0 : 32 - __clz((int)(x - 1)); }
+
+struct GroupHeaderD {
+  uint32_t use_global_tree;
+  WPHeader wp;
+  uint32_t ntransforms;
+  struct { uint32_t id, begin_c, rct_type, num_c, nb_colors, nb_deltas, predictor; } t[8];
+};
+
+__device__ bool ReadGroupHeader(BitReader& br, GroupHeaderD& gh) {
+  gh.use_global_tree = br.Read(1);
+  gh.wp = WPHeader{16, 10, {7, 7, 7, 0, 0}, {13, 12, 12, 12}};
+  if (!br.Read(1)) {
+    gh.wp.p1 = br.Read(5); gh.wp.p2 = br.Read(5);
+    for (int i = 0; i < 5; i++) gh.wp.p3[i] = br.Read(5);
+    for (int i = 0; i < 4; i++) gh.wp.w[i] = br.Read(4);
+  }
+  gh.ntransforms = ReadU32(br, {0, 0}, {0, 1}, {4, 2}, {8, 18});
+  if (gh.ntransforms > 8) return false;
+  for (uint32_t i = 0; i < gh.ntransforms; i++) {
+    auto& t = gh.t[i];
+    t.id = br.Read(2);
+    if (t.id >= 2) return false;  // squeeze / invalid: unsupported on device
+    t.begin_c = ReadU32(br, {3, 0}, {6, 8}, {10, 72}, {13, 1096});
+    if (t.id == 0) { t.rct_type = ReadU32(br, {0, 6}, {2, 0}, {4, 2}, {6, 10}); if (t.rct_type >= 42) return false; }
+    else {
+      t.num_c = ReadU32(br, {0, 1}, {0, 3}, {0, 4}, {13, 1});
+      t.nb_colors = ReadU32(br, {8, 0}, {10, 256}, {12, 1280}, {16, 5376});
+      t.nb_deltas = ReadU32(br, {0, 0}, {8, 1}, {10, 257}, {16, 1281});
+      t.predictor = br.Read(4);
+      if (t.nb_deltas != 0 || t.predictor != 0) return false;  // delta palettes: unsupported on device
+    }
+  }
+  return true;
+}
+
+// =====================================================================================================================
+// K_lf: one decode thread per LF group — LF coefficients (3 channels, order Y,X,B) + HF metadata, then varblock placement
+// =====================================================================================================================
+__global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular) return;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid % lane_stride) return;
+  const uint32_t g = tid / lane_stride;
+  if (g >= f.num_lf_groups) return;
+  const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
+  const uint32_t bx0 = gx * 256, by0 = gy * 256;
+  const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
+  BitReader br;
+  if (f.single_section) br.Init(f.cs, f.lf_start_bitpos, f.cs_size);
+  else { const uint64_t off = f.sec_off[1 + g]; br.Init(f.cs, off * 8, off + f.sec_size[1 + g]); }
+  const uint64_t limit = f.single_section ? f.cs_size * 8 : (f.sec_off[1 + g] + f.sec_size[1 + g]) * 8;
+
+  ModularCtx mc;
+  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp;
+  mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride;
+
+  // ---- LF coefficients
+  const uint32_t extra_precision = br.Read(2);
+  GroupHeaderD gh;
+  if (!ReadGroupHeader(br, gh) || !gh.use_global_tree || gh.ntransforms != 0) { SetError(f, kErrUnsupported); return; }
+  mc.wp = gh.wp; mc.stream_id = 1 + g;
+  {
+    AnsReader ans; ans.Init(br, f.mod_code);
+    const int chan_to_plane[3] = {1, 0, 2};  // stream channel order is Y, X, B
+    for (int c = 0; c < 3; c++) {
+      ChannelDesc ch;
+      ch.data = f.lfq[chan_to_plane[c]] + (size_t)by0 * f.bw + bx0;
+      ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)f.bw;
+      DecodeModularChannel(br, ans, mc, ch, c);
+    }
+    if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); return; }
+  }
+  // extra_precision is folded into the dequant factor by LfPost: store it in the scratch header
+  int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
+  scratch[0] = (int32_t)extra_precision;
+  // ---- HF metadata: 4 channels {ytox, ytob, (strategy,hf_mul-1) x nb_blocks, sharpness}
+  const uint32_t nb_blocks = 1 + br.Read(CeilLog2D(gbw * gbh));
+  if (!ReadGroupHeader(br, gh) || !gh.use_global_tree || gh.ntransforms != 0) { SetError(f, kErrUnsupported); return; }
+  mc.wp = gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
+  const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
+  int32_t* m_ytox = scratch + 16;
+  int32_t* m_ytob = m_ytox + mcw * mch;
+  int32_t* m_blk = m_ytob + mcw * mch;
+  int32_t* m_sharp = m_blk + 2 * nb_blocks;
+  {
+    AnsReader ans; ans.Init(br, f.mod_code);
+    ChannelDesc ch;
+    ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; DecodeModularChannel(br, ans, mc, ch, 0);
+    ch.data = m_ytob; DecodeModularChannel(br, ans, mc, ch, 1);
+    ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeModularChannel(br, ans, mc, ch, 2);
+    ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeModularChannel(br, ans, mc, ch, 3);
+    if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); return; }
+  }
+  if (br.BitPos() > limit) { SetError(f, kErrOverrun); return; }
+  if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
+  // ---- chroma-from-luma maps
+  for (uint32_t y = 0; y < mch; y++) for (uint32_t x = 0; x < mcw; x++) {
+    const int a = m_ytox[y * mcw + x], b = m_ytob[y * mcw + x];
+    if (a < -128 || a > 127 || b < -128 || b > 127) { SetError(f, kErrBadValue); return; }
+    const size_t o = (size_t)(gy * 32 + y) * f.cw + gx * 32 + x;
+    f.ytox[o] = (int8_t)a; f.ytob[o] = (int8_t)b;
+  }
+  // ---- varblock placement (raster order, first not-yet-covered block); coefficient offsets per 256x256 group
+  for (uint32_t y = 0; y < gbh; y++) for (uint32_t x = 0; x < gbw; x++) f.blk_info[(size_t)(by0 + y) * f.bw + bx0 + x] = 0xFFFFFFFFu;
+  uint32_t goff[64];
+  for (int i = 0; i < 64; i++) goff[i] = 0;
+  uint32_t num = 0;
+  for (uint32_t y = 0; y < gbh; y++) {
+    for (uint32_t x = 0; x < gbw; x++) {
+      const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
+      if (f.blk_info[o] != 0xFFFFFFFFu) continue;
+      if (num >= nb_blocks) { SetError(f, kErrVarblock); return; }
+      const int32_t s = m_blk[num], q = m_blk[nb_blocks + num];
+      num++;
+      if (s < 0 || s >= 27 || q < 0 || q > 255) { SetError(f, kErrBadValue); return; }
+      if (s >= 14 && s <= 17) { SetError(f, kErrUnsupported); return; }  // AFV
+      const uint32_t cx = CoveredX(s), cy = CoveredY(s);
+      if (cx > 8 || cy > 8) { SetError(f, kErrUnsupported); return; }  // transforms larger than 64x64
+      if (x + cx > gbw || y + cy > gbh || (x % 32) + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); return; }
+      const uint32_t gi = (y / 32) * 8 + (x / 32);
+      f.coef_off[o] = goff[gi];
+      goff[gi] += cx * cy * 64;
+      for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++) {
+        const size_t oo = o + (size_t)iy * f.bw + ix;
+        if (f.blk_info[oo] != 0xFFFFFFFFu) { SetError(f, kErrVarblock); return; }
+        const int32_t sh = m_sharp[(y + iy) * gbw + x + ix];
+        if (sh < 0 || sh > 7) { SetError(f, kErrBadValue); return; }
+        f.blk_info[oo] = PackBlockInfo((uint32_t)s, ix == 0 && iy == 0, (uint32_t)q, ix, iy, (uint32_t)sh);
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// K_lfpost: LF dequant (+CfL), adaptive smoothing, LLF (lowest frequencies from LF), per-block EPF sigma
+// =====================================================================================================================
+__global__ void LfDequantKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular) return;
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= f.bw || y >= f.bh) return;
+  const uint32_t g = (y / 256) * f.xlfgroups + x / 256;
+  const int32_t extra_precision = f.lf_scratch[(uint64_t)g * f.lf_scratch_stride];
+  const float mul = 1.0f / (float)(1 << extra_precision);
+  const size_t o = (size_t)y * f.bw + x;
+  const float vy = (float)f.lfq[1][o] * (f.lf_fac[1] * mul);
+  const float vx = (float)f.lfq[0][o] * (f.lf_fac[0] * mul);
+  const float vb = (float)f.lfq[2][o] * (f.lf_fac[2] * mul);
+  f.lf[1][o] = vy;
+  f.lf[0][o] = fmaf(vy, f.cfl_lf_x, vx);
+  f.lf[2][o] = fmaf(vy, f.cfl_lf_b, vb);
+}
+
+__global__ void LfSmoothKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  const int w = (int)f.bw, h = (int)f.bh;
+  if (x >= w || y >= h) return;
+  const size_t o = (size_t)y * w + x;
+  const bool interior = !f.skip_lf_smoothing && w > 2 && h > 2 && x >= 1 && y >= 1 && x + 1 < w && y + 1 < h;
+  if (!interior) { for (int c = 0; c < 3; c++) f.lf_tmp[c][o] = f.lf[c][o]; return; }
+  const float kW0 = 0.05226273532324128f, kW1 = 0.20345139757231578f, kW2 = 0.0334829185968739f;
+  float gap = 0.5f, mc[3], sm[3];
+  for (int c = 0; c < 3; c++) {
+    const float* t = f.lf[c] + o - w; const float* m = f.lf[c] + o; const float* b = f.lf[c] + o + w;
+    const float corner = (t[-1] + t[1]) + (b[-1] + b[1]);
+    const float edge = (t[0] + m[-1]) + (m[1] + b[0]);
+    mc[c] = m[0];
+    sm[c] = fmaf(corner, kW2, fmaf(edge, kW1, mc[c] * kW0));
+    gap = fmaxf(gap, fabsf((mc[c] - sm[c]) / f.lf_fac[c]));
+  }
+  const float factor = fmaxf(0.0f, fmaf(-4.0f, gap, 3.0f));
+  for (int c = 0; c < 3; c++) f.lf_tmp[c][o] = fmaf(sm[c] - mc[c], factor, mc[c]);
+}
+
+template <int N> __device__ __forceinline__ void FDct1D(float (&v)[N]) {  // unscaled forward DCT (dct-inl.h DCT1DImpl)
+  if constexpr (N == 2) { const float a = v[0], b = v[1]; v[0] = a + b; v[1] = a - b; }
+  else if constexpr (N > 2) {
+    constexpr int H = N / 2;
+    float e[H], o[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) e[i] = v[i] + v[N - 1 - i];
+    FDct1D<H>(e);
+    constexpr int L = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+#pragma unroll
+    for (int i = 0; i < H; i++) o[i] = (v[i] - v[N - 1 - i]) * d_wc[L][i];
+    FDct1D<H>(o);
+    o[0] = fmaf(o[0], 1.41421356237309504880f, o[1]);
+#pragma unroll
+    for (int i = 1; i + 1 < H; i++) o[i] = o[i] + o[i + 1];
+#pragma unroll
+    for (int i = 0; i < H; i++) { v[2 * i] = e[i]; v[2 * i + 1] = o[i]; }
+  }
+}
+__device__ void FDctDyn(float* v, int n) {  // n in {1,2,4,8}
+  if (n == 2) { float t[2] = {v[0], v[1]}; FDct1D<2>(t); v[0] = t[0]; v[1] = t[1]; }
+  else if (n == 4) { float t[4]; for (int i = 0; i < 4; i++) t[i] = v[i]; FDct1D<4>(t); for (int i = 0; i < 4; i++) v[i] = t[i]; }
+  else if (n == 8) { float t[8]; for (int i = 0; i < 8; i++) t[i] = v[i]; FDct1D<8>(t); for (int i = 0; i < 8; i++) v[i] = t[i]; }
+}
+__device__ __forceinline__ int Log2Small(int n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3; }
+
+// one thread per 8x8 block: first blocks compute the LLF coefficients of their varblock from the (smoothed) LF; every
+// block computes its EPF inverse sigma
+__global__ void LlfSigmaKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular) return;
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= f.bw || y >= f.bh) return;
+  const size_t o = (size_t)y * f.bw + x;
+  const uint32_t info = f.blk_info[o];
+  {  // epf.cc ComputeSigma
+    const float sigma_quant = f.epf_quant_mul / ((f.epf_quant_scale * (float)BI_HfMul(info)) * -1.1715728752538099024f);
+    float sigma = sigma_quant * f.epf_sharp_lut[BI_Sharp(info)];
+    sigma = fminf(-1e-4f, sigma);
+    f.inv_sigma[o] = 1.0f / sigma;
+  }
+  if (!BI_First(info)) return;
+  const uint32_t s = BI_Strategy(info);
+  const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
+  if (cx == 1 && cy == 1) { for (int c = 0; c < 3; c++) f.llf[c][o] = f.lf_tmp[c][o]; return; }
+  const float sr = 1.0f / (float)cy, sc = 1.0f / (float)cx;
+  const int lx = Log2Small(cx), ly = Log2Small(cy);
+  for (int c = 0; c < 3; c++) {
+    float buf[64], col[8];
+    const float* src = f.lf_tmp[c] + o;
+    for (int xx = 0; xx < cx; xx++) {
+      for (int yy = 0; yy < cy; yy++) col[yy] = src[(size_t)yy * f.bw + xx];
+      FDctDyn(col, cy);
+      for (int v = 0; v < cy; v++) buf[v * cx + xx] = col[v] * sr;
+    }
+    for (int v = 0; v < cy; v++) {
+      float row[8];
+      for (int u = 0; u < cx; u++) row[u] = buf[v * cx + u];
+      FDctDyn(row, cx);
+      for (int u = 0; u < cx; u++) f.llf[c][o + (size_t)v * f.bw + u] = ((row[u] * sc) * d_resample[ly][v]) * d_resample[lx][u];
+    }
+  }
+}
+
+// =====================================================================================================================
+// K_hf: one decode thread per 256x256 group — ANS coefficient decode (dec_group.cc DecodeACVarBlock)
+// =====================================================================================================================
+__device__ static const uint8_t kFreqCtx[64] = {0,  0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 15, 16, 16, 17, 17,
+                                                18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23, 23, 23, 24, 24, 24, 24, 25, 25, 25, 25,
+                                                26, 26, 26, 26, 27, 27, 27, 27, 28, 28, 28, 28, 29, 29, 29, 29, 30, 30, 30, 30};
+__device__ static const uint8_t kNzCtx[64] = {0,   0,   31,  62,  62,  93,  93,  93,  93,  123, 123, 123, 123, 152, 152, 152,
+                                              152, 152, 152, 152, 152, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180,
+                                              180, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
+                                              206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206};
+
+__global__ __launch_bounds__(64) void HfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular) return;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid % lane_stride) return;
+  const uint32_t g = tid / lane_stride;
+  if (g >= f.num_groups) return;
+  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
+  const uint32_t bx0 = gx * 32, by0 = gy * 32;
+  const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
+  BitReader br;
+  uint64_t limit;
+  if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
+  else { const uint32_t si = 2 + f.num_lf_groups + g; const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
+  const BlockCtxDev& bcm = *f.bcm;
+  const uint32_t nctx = bcm.num_ctxs;
+  const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
+  if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); return; }
+  const uint32_t ctx_offset = 495u * nctx * preset;
+  const DevCode& code = f.ac_code;
+  AnsReader ans; ans.Init(br, code);
+  uint8_t nzrow[3][32];
+  for (int c = 0; c < 3; c++) for (int i = 0; i < 32; i++) nzrow[c][i] = 0;
+  int32_t* cbase[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
+  for (uint32_t by = 0; by < gbh; by++) {
+    for (uint32_t bx = 0; bx < gbw; bx++) {
+      const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+      const uint32_t info = f.blk_info[o];
+      if (!BI_First(info)) continue;
+      const uint32_t s = BI_Strategy(info);
+      const uint32_t cx = CoveredX(s), cy = CoveredY(s), covered = cx * cy;
+      const uint32_t l2 = 31 - __clz((int)covered), size = covered * 64, ord = OrderBucket(s);
+      const uint32_t qf = BI_HfMul(info);
+      uint32_t qf_idx = 0;
+      for (uint32_t i = 0; i < bcm.n_qf_thr; i++) qf_idx += qf > bcm.qf_thr[i];
+      uint32_t lf_idx = 0;
+      if (bcm.num_lf_ctxs > 1) {
+        uint32_t b0 = 0, b1 = 0, b2 = 0;
+        for (uint32_t i = 0; i < bcm.n_lf_thr[0]; i++) b0 += f.lfq[0][o] > bcm.lf_thr[0][i];
+        for (uint32_t i = 0; i < bcm.n_lf_thr[1]; i++) b1 += f.lfq[1][o] > bcm.lf_thr[1][i];
+        for (uint32_t i = 0; i < bcm.n_lf_thr[2]; i++) b2 += f.lfq[2][o] > bcm.lf_thr[2][i];
+        lf_idx = (b0 * (bcm.n_lf_thr[2] + 1) + b2) * (bcm.n_lf_thr[1] + 1) + b1;
+      }
+      const uint32_t coff = f.coef_off[o];
+#pragma unroll 1
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
+        uint32_t idx = (uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord;
+        idx = idx * (bcm.n_qf_thr + 1) + qf_idx;
+        idx = idx * bcm.num_lf_ctxs + lf_idx;
+        const uint32_t block_ctx = bcm.ctx_map[idx];
+        uint32_t pred;
+        if (bx == 0) pred = by == 0 ? 32 : nzrow[c][bx];
+        else if (by == 0) pred = nzrow[c][bx - 1];
+        else pred = (nzrow[c][bx] + nzrow[c][bx - 1] + 1) / 2;
+        const uint32_t pc = pred > 64 ? 64 : pred;
+        const uint32_t nz_ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
+        uint32_t nzeros = ReadHybridUint(br, ans, code, nz_ctx);
+        if (nzeros + covered > size) { SetError(f, kErrNzeros); return; }
+        const uint8_t nzm = (uint8_t)((nzeros + covered - 1) >> l2);
+        for (uint32_t ix = 0; ix < cx; ix++) nzrow[c][bx + ix] = nzm;
+        const uint32_t histo = ctx_offset + 37 * nctx + 458 * block_ctx;
+        const uint16_t* order = f.orders[ord * 3 + c];
+        int32_t* blk = cbase[c] + coff;
+        uint32_t prev = nzeros > size / 16 ? 0 : 1;
+        for (uint32_t k = covered; k < size && nzeros != 0; k++) {
+          const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
+          const uint32_t ctx = histo + ((uint32_t)kNzCtx[nzl] + kFreqCtx[kk]) * 2 + prev;
+          const uint32_t u = ReadHybridUint(br, ans, code, ctx);
+          prev = u != 0;
+          nzeros -= prev;
+          if (u) blk[order[k]] = UnpackSigned(u);
+        }
+        if (nzeros != 0) { SetError(f, kErrNzeros); return; }
+      }
+    }
+  }
+  if (!ans.FinalOk(code)) { SetError(f, kErrAnsFinalState); return; }
+  if (br.BitPos() > limit) { SetError(f, kErrOverrun); return; }
+}
+
+// =====================================================================================================================
+// K_idct: dequant + chroma-from-luma + LLF + inverse transforms.  One 256-thread workgroup per 256x256 group.
+// Pass 1 (rows): horizontal 1-D IDCT of every coefficient row, written into the pixel plane as an intermediate;
+// 8x8 "special" transforms are completed here.  Pass 2 (columns): vertical 1-D IDCT in place.
+// =====================================================================================================================
+template <int N> __device__ __forceinline__ void IDct1D(float (&v)[N]) {  // dct-inl.h IDCT1DImpl
+  if constexpr (N == 2) { const float a = v[0], b = v[1]; v[0] = a + b; v[1] = a - b; }
+  else if constexpr (N > 2) {
+    constexpr int H = N / 2;
+    float e[H], o[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    IDct1D<H>(e);
+#pragma unroll
+    for (int i = H - 1; i > 0; i--) o[i] = o[i] + o[i - 1];
+    o[0] = o[0] * 1.41421356237309504880f;
+    IDct1D<H>(o);
+    constexpr int L = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : N == 32 ? 5 : 6;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      const float mul = d_wc[L][i];
+      v[i] = fmaf(mul, o[i], e[i]);
+      v[N - 1 - i] = fmaf(-mul, o[i], e[i]);
+    }
+  }
+}
+
+__device__ __forceinline__ float AdjustQuantBias(int32_t q, float bias_c, float bias3) {
+  if (q == 0) return 0.0f;
+  if (q == 1) return bias_c;
+  if (q == -1) return -bias_c;
+  const float fq = (float)q;
+  return fq - bias3 / fq;
+}
+
+struct BlockDequant {
+  const int32_t* q[3];      // quantised coefficients of the varblock (Y used for CfL)
+  const float* table[3];
+  float sdc[3];             // per-channel scaled dequant
+  float kx, kb;             // CfL multipliers
+  float bias[4];
+};
+
+// dequantised coefficient k of channel c (0=X,1=Y,2=B) incl. chroma-from-luma (dec_group.cc DequantLane)
+__device__ __forceinline__ float DequantCoef(const BlockDequant& d, int c, uint32_t k) {
+  const float y = AdjustQuantBias(d.q[1][k], d.bias[1], d.bias[3]) * (d.table[1][k] * d.sdc[1]);
+  if (c == 1) return y;
+  const float v = AdjustQuantBias(d.q[c][k], d.bias[c], d.bias[3]) * (d.table[c][k] * d.sdc[c]);
+  return fmaf(c == 0 ? d.kx : d.kb, y, v);
+}
+
+template <int C> __device__ __forceinline__ void RowPass(const BlockDequant& d, int c, int R, int v, int cy, int cx, const float* llf, size_t llf_stride,
+                                                         float* dst /* row start in plane */) {
+  float row[C];
+#pragma unroll
+  for (int u = 0; u < C; u++) {
+    const uint32_t k = R >= C ? (uint32_t)(u * R + v) : (uint32_t)(v * C + u);
+    row[u] = DequantCoef(d, c, k);
+  }
+  if (v < cy) {
+#pragma unroll
+    for (int u = 0; u < C / 8; u++) if (u < cx) row[u] = llf[(size_t)v * llf_stride + u];
+  }
+  IDct1D<C>(row);
+#pragma unroll
+  for (int u = 0; u < C; u++) dst[u] = row[u];
+}
+
+template <int R> __device__ __forceinline__ void ColPass(float* col0 /* top of column */, size_t stride) {
+  float col[R];
+#pragma unroll
+  for (int v = 0; v < R; v++) col[v] = col0[(size_t)v * stride];
+  IDct1D<R>(col);
+#pragma unroll
+  for (int v = 0; v < R; v++) col0[(size_t)v * stride] = col[v];
+}
+
+// 2-D IDCT of a small block held in `sem` (semantic layout [v*C+u]), horizontal first then vertical
+template <int R, int C> __device__ __forceinline__ void SmallIdct2D(const float* sem, float* out, size_t stride) {
+  float buf[R * C];
+#pragma unroll
+  for (int v = 0; v < R; v++) {
+    float row[C];
+#pragma unroll
+    for (int u = 0; u < C; u++) row[u] = sem[v * C + u];
+    IDct1D<C>(row);
+#pragma unroll
+    for (int u = 0; u < C; u++) buf[v * C + u] = row[u];
+  }
+#pragma unroll
+  for (int x = 0; x < C; x++) {
+    float col[R];
+#pragma unroll
+    for (int v = 0; v < R; v++) col[v] = buf[v * C + x];
+    IDct1D<R>(col);
+#pragma unroll
+    for (int y = 0; y < R; y++) out[(size_t)y * stride + x] = col[y];
+  }
+}
+
+// dec_transforms-inl.h: IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4 on one 8x8 block (coefficients in `cf`, stored layout)
+__device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t stride) {
+  if (s == 1) {  // IDENTITY
+    float dcs[4];
+    const float b00 = cf[0], b01 = cf[1], b10 = cf[8], b11 = cf[9];
+    dcs[0] = b00 + b01 + b10 + b11; dcs[1] = b00 + b01 - b10 - b11; dcs[2] = b00 - b01 + b10 - b11; dcs[3] = b00 - b01 - b10 + b11;
+    for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) {
+      const float block_dc = dcs[y * 2 + x];
+      float residual_sum = 0;
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (ix == 0 && iy == 0) continue; residual_sum += cf[(y + iy * 2) * 8 + x + ix * 2]; }
+      const float p11 = block_dc - residual_sum * (1.0f / 16);
+      out[(size_t)(4 * y + 1) * stride + 4 * x + 1] = p11;
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (ix == 1 && iy == 1) continue; out[(size_t)(y * 4 + iy) * stride + x * 4 + ix] = cf[(y + iy * 2) * 8 + x + ix * 2] + p11; }
+      out[(size_t)(y * 4) * stride + x * 4] = cf[(y + 2) * 8 + x + 2] + p11;
+    }
+  } else if (s == 2) {  // DCT2X2
+    float a[64], b[64];
+    for (int i = 0; i < 64; i++) a[i] = cf[i];
+    for (int S = 2; S <= 8; S *= 2) {
+      const int n = S / 2;
+      for (int i = 0; i < 64; i++) b[i] = a[i];
+      for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) {
+        const float c00 = a[y * 8 + x], c01 = a[y * 8 + n + x], c10 = a[(y + n) * 8 + x], c11 = a[(y + n) * 8 + n + x];
+        b[y * 2 * 8 + x * 2] = c00 + c01 + c10 + c11; b[y * 2 * 8 + x * 2 + 1] = c00 + c01 - c10 - c11;
+        b[(y * 2 + 1) * 8 + x * 2] = c00 - c01 + c10 - c11; b[(y * 2 + 1) * 8 + x * 2 + 1] = c00 - c01 - c10 + c11;
+      }
+      for (int i = 0; i < 64; i++) a[i] = b[i];
+    }
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) out[(size_t)y * stride + x] = a[y * 8 + x];
+  } else if (s == 3) {  // DCT4X4
+    float dcs[4];
+    const float b00 = cf[0], b01 = cf[1], b10 = cf[8], b11 = cf[9];
+    dcs[0] = b00 + b01 + b10 + b11; dcs[1] = b00 + b01 - b10 - b11; dcs[2] = b00 - b01 + b10 - b11; dcs[3] = b00 - b01 - b10 + b11;
+    for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) {
+      float sem[16];  // sem[v*4+u] = stored[u*4+v]
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? dcs[y * 2 + x] : cf[(y + iy * 2) * 8 + x + ix * 2];
+      SmallIdct2D<4, 4>(sem, out + (size_t)(y * 4) * stride + x * 4, stride);
+    }
+  } else if (s == 12) {  // DCT4X8: two 4x8 halves stacked vertically
+    const float b0 = cf[0], b1 = cf[8];
+    const float dcs[2] = {b0 + b1, b0 - b1};
+    for (int y = 0; y < 2; y++) {
+      float sem[32];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) sem[iy * 8 + ix] = (iy == 0 && ix == 0) ? dcs[y] : cf[(y + iy * 2) * 8 + ix];
+      SmallIdct2D<4, 8>(sem, out + (size_t)(y * 4) * stride, stride);
+    }
+  } else {  // s == 13, DCT8X4: two 8x4 halves side by side
+    const float b0 = cf[0], b1 = cf[8];
+    const float dcs[2] = {b0 + b1, b0 - b1};
+    for (int x = 0; x < 2; x++) {
+      float sem[32];  // sem[v*4+u] = stored[u*8+v]
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? dcs[x] : cf[(x + iy * 2) * 8 + ix];
+      SmallIdct2D<8, 4>(sem, out + x * 4, stride);
+    }
+  }
+}
+
+__device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || s == 12 || s == 13; }
+
+__global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular) return;
+  const uint32_t g = blockIdx.x;
+  if (g >= f.num_groups) return;
+  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
+  const uint32_t bx0 = gx * 32, by0 = gy * 32;
+  const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
+  const size_t stride = f.plane_stride;
+  // ---- pass 1: rows
+  for (uint32_t t = threadIdx.x; t < gbw * gbh * 8; t += blockDim.x) {
+    const uint32_t r = t & 7, bi = t >> 3;
+    const uint32_t bx = bi % gbw, by = bi / gbw;
+    const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+    const uint32_t info = f.blk_info[o];
+    if (BI_Ix(info) != 0) continue;                    // rows are owned by the first block column of the varblock
+    const uint32_t s = BI_Strategy(info);
+    const uint32_t iy = BI_Iy(info);
+    const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
+    const size_t o_first = o - (size_t)iy * f.bw;      // top-left block of the varblock
+    const uint32_t kind = QuantKind(s);
+    BlockDequant d;
+    const uint32_t coff = f.coef_off[o_first];
+    for (int c = 0; c < 3; c++) { d.q[c] = f.coeff[c] + (size_t)g * 65536 + coff; d.table[c] = f.qtable[kind * 3 + c]; }
+    const float sd = f.inv_global_scale / (float)BI_HfMul(info);
+    d.sdc[0] = sd * f.x_dm; d.sdc[1] = sd; d.sdc[2] = sd * f.b_dm;
+    const size_t tile = (size_t)((by0 + by - iy) / 8) * f.cw + (bx0 + bx) / 8;
+    d.kx = f.base_x + (float)f.ytox[tile] * f.color_scale;
+    d.kb = f.base_b + (float)f.ytob[tile] * f.color_scale;
+    for (int i = 0; i < 4; i++) d.bias[i] = f.quant_bias[i];
+    const int R = cy * 8, C = cx * 8;
+    const int v = (int)(iy * 8 + r);
+    if (IsSpecial(s)) {
+      if (r != 0) continue;
+      for (int c = 0; c < 3; c++) {
+        float cf[64];
+        for (uint32_t k = 0; k < 64; k++) cf[k] = DequantCoef(d, c, k);
+        cf[0] = f.llf[c][o_first];
+        SpecialTransform(s, cf, f.plane_a[c] + (size_t)(by0 + by) * 8 * stride + (bx0 + bx) * 8, stride);
+      }
+      continue;
+    }
+    for (int c = 0; c < 3; c++) {
+      float* dst = f.plane_a[c] + ((size_t)(by0 + by - iy) * 8 + v) * stride + (size_t)(bx0 + bx) * 8;
+      const float* llf = f.llf[c] + o_first;
+      switch (C) {
+        case 8: RowPass<8>(d, c, R, v, cy, cx, llf, f.bw, dst); break;
+        case 16: RowPass<16>(d, c, R, v, cy, cx, llf, f.bw, dst); break;
+        case 32: RowPass<32>(d, c, R, v, cy, cx, llf, f.bw, dst); break;
+        default: RowPass<64>(d, c, R, v, cy, cx, llf, f.bw, dst); break;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: columns
+  for (uint32_t t = threadIdx.x; t < gbw * gbh * 8; t += blockDim.x) {
+    const uint32_t xx = t & 7, bi = t >> 3;
+    const uint32_t bx = bi % gbw, by = bi / gbw;
+    const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+    const uint32_t info = f.blk_info[o];
+    if (BI_Iy(info) != 0) continue;                    // columns are owned by the first block row of the varblock
+    const uint32_t s = BI_Strategy(info);
+    if (IsSpecial(s)) continue;
+    const int R = (int)CoveredY(s) * 8;
+    for (int c = 0; c < 3; c++) {
+      float* col0 = f.plane_a[c] + (size_t)(by0 + by) * 8 * stride + (size_t)(bx0 + bx) * 8 + xx;
+      switch (R) {
+        case 8: ColPass<8>(col0, stride); break;
+        case 16: ColPass<16>(col0, stride); break;
+        case 32: ColPass<32>(col0, stride); break;
+        default: ColPass<64>(col0, stride); break;
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// K_gab / K_epf: loop restoration filters on the (w x h) image with mirrored borders
+// =====================================================================================================================
+__device__ __forceinline__ int MirrorD(int x, int size) {
+  while (x < 0 || x >= size) x = x < 0 ? -x - 1 : 2 * size - 1 - x;
+  return x;
+}
+__device__ __forceinline__ int FilterStagesBefore(const FrameDev& f, int stage) {  // stage: 0 gab, 1 epf0, 2 epf1, 3 epf2
+  int n = 0;
+  if (stage > 0 && f.gab) n++;
+  if (stage > 1 && f.epf_iters >= 3) n++;
+  if (stage > 2 && f.epf_iters >= 1) n++;
+  if (stage > 3 && f.epf_iters >= 2) n++;
+  return n;
+}
+__device__ __forceinline__ bool FilterStageActive(const FrameDev& f, int stage) {
+  return stage == 0 ? f.gab != 0 : stage == 1 ? f.epf_iters >= 3 : stage == 2 ? f.epf_iters >= 1 : f.epf_iters >= 2;
+}
+
+__global__ void GaborishKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular || !f.gab) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  const int w = (int)f.width, h = (int)f.height;
+  if (x >= w || y >= h) return;
+  const size_t stride = f.plane_stride;
+  const int yt = MirrorD(y - 1, h), yb = MirrorD(y + 1, h), xl = MirrorD(x - 1, w), xr = MirrorD(x + 1, w);
+  for (int c = 0; c < 3; c++) {
+    const float* src = f.plane_a[c];
+    const float* t = src + (size_t)yt * stride; const float* m = src + (size_t)y * stride; const float* b = src + (size_t)yb * stride;
+    const float sum0 = m[x];
+    const float sum1 = (m[xl] + m[xr]) + (t[x] + b[x]);
+    const float sum2 = (t[xl] + t[xr]) + (b[xl] + b[xr]);
+    f.plane_b[c][(size_t)y * stride + x] = fmaf(sum2, f.gab_w[c * 3 + 2], fmaf(sum1, f.gab_w[c * 3 + 1], sum0 * f.gab_w[c * 3 + 0]));
+  }
+}
+
+template <int PASS> __global__ void EpfKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  constexpr int stage = PASS + 1;
+  if (f.is_modular || !FilterStageActive(f, stage)) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  const int w = (int)f.width, h = (int)f.height;
+  if (x >= w || y >= h) return;
+  const bool src_is_a = (FilterStagesBefore(f, stage) & 1) == 0;
+  const size_t stride = f.plane_stride;
+  const float* src[3]; float* dst[3];
+  for (int c = 0; c < 3; c++) { src[c] = src_is_a ? f.plane_a[c] : f.plane_b[c]; dst[c] = src_is_a ? f.plane_b[c] : f.plane_a[c]; }
+  const size_t o = (size_t)y * stride + x;
+  const float is = f.inv_sigma[(size_t)(y / 8) * f.bw + x / 8];
+  if (is < -3.90524291751269967465540850526868f) { for (int c = 0; c < 3; c++) dst[c][o] = src[c][o]; return; }
+  const bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
+  const float vmul = is * (border ? f.epf_bsm[PASS] : f.epf_sm[PASS]);
+  auto px = [&](int c, int xx, int yy) -> float { return src[c][(size_t)MirrorD(yy, h) * stride + MirrorD(xx, w)]; };
+  float wsum = 1.0f;
+  float acc[3] = {src[0][o], src[1][o], src[2][o]};
+  constexpr int ntaps = PASS == 0 ? 12 : 4;
+  const int taps0[12][2] = {{0, -2}, {-1, -1}, {0, -1}, {1, -1}, {-2, 0}, {-1, 0}, {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {0, 2}};
+  const int taps1[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  const int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+#pragma unroll
+  for (int t = 0; t < ntaps; t++) {
+    const int dx = PASS == 0 ? taps0[t][0] : taps1[t][0], dy = PASS == 0 ? taps0[t][1] : taps1[t][1];
+    float sad = 0.f;
+    if (PASS == 2) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) sad = fmaf(fabsf(px(c, x + dx, y + dy) - src[c][o]), f.epf_channel_scale[c], sad);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) s += fabsf(px(c, x + dx + plus[k][0], y + dy + plus[k][1]) - px(c, x + plus[k][0], y + plus[k][1]));
+        sad = fmaf(s, f.epf_channel_scale[c], sad);
+      }
+    }
+    const float wgt = fmaxf(0.0f, fmaf(sad, vmul, 1.0f));
+    wsum += wgt;
+#pragma unroll
+    for (int c = 0; c < 3; c++) acc[c] = fmaf(wgt, px(c, x + dx, y + dy), acc[c]);
+  }
+  const float inv = 1.0f / wsum;
+  for (int c = 0; c < 3; c++) dst[c][o] = acc[c] * inv;
+}
+
+// =====================================================================================================================
+// K_out: XYB -> linear -> sRGB -> clamp/scale/round -> interleaved caller layout (stage_xyb/from_linear/write)
+// =====================================================================================================================
+__device__ __forceinline__ float LinearToSrgb(float v) {
+  const float x = fabsf(v);
+  const float lin = x * 12.92f;
+  const float s = sqrtf(x);
+  float yp = 7.352629620e-1f, yq = 2.424867759e-2f;
+  yp = fmaf(yp, s, 1.474205315f); yq = fmaf(yq, s, 9.258482155e-1f);
+  yp = fmaf(yp, s, 3.903842876e-1f); yq = fmaf(yq, s, 1.340816930f);
+  yp = fmaf(yp, s, 5.287254571e-3f); yq = fmaf(yq, s, 3.036675394e-1f);
+  yp = fmaf(yp, s, -5.135152395e-4f); yq = fmaf(yq, s, 1.004519624e-2f);
+  const float poly = yp / yq;
+  return copysignf(x > 0.0031308f ? poly : lin, v);
+}
+
+__device__ __forceinline__ uint16_t FloatToHalfBits(float fv) {
+  const uint32_t x = __float_as_uint(fv);
+  const uint32_t sign = (x >> 16) & 0x8000;
+  const int32_t exp = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+  uint32_t mant = x & 0x7FFFFF;
+  if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00 | (mant ? 0x200 : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7C00);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    mant |= 0x800000;
+    const int shift = 14 - exp;
+    uint32_t m = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (m & 1))) m++;
+    return (uint16_t)(sign | m);
+  }
+  const uint32_t m = mant >> 13, rem = mant & 0x1FFF;
+  uint32_t r = (uint32_t)(exp << 10) | m;
+  if (rem > 0x1000 || (rem == 0x1000 && (m & 1))) r++;
+  return (uint16_t)(sign | r);
+}
+
+__device__ __forceinline__ void StoreSample(const FrameDev& f, uint8_t* p, float v) {
+  if (f.out_type == 0) {
+    p[0] = (uint8_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * 255.0f);
+  } else if (f.out_type == 1) {
+    const uint32_t u = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * 65535.0f);
+    if (f.out_big_endian) { p[0] = (uint8_t)(u >> 8); p[1] = (uint8_t)u; } else { p[0] = (uint8_t)u; p[1] = (uint8_t)(u >> 8); }
+  } else if (f.out_type == 2) {
+    const uint32_t u = __float_as_uint(v);
+    if (f.out_big_endian) { p[0] = (uint8_t)(u >> 24); p[1] = (uint8_t)(u >> 16); p[2] = (uint8_t)(u >> 8); p[3] = (uint8_t)u; }
+    else { p[0] = (uint8_t)u; p[1] = (uint8_t)(u >> 8); p[2] = (uint8_t)(u >> 16); p[3] = (uint8_t)(u >> 24); }
+  } else {
+    const uint32_t u = FloatToHalfBits(v);
+    if (f.out_big_endian) { p[0] = (uint8_t)(u >> 8); p[1] = (uint8_t)u; } else { p[0] = (uint8_t)u; p[1] = (uint8_t)(u >> 8); }
+  }
+}
+
+__device__ __forceinline__ void StorePixel(const FrameDev& f, int x, int y, float r, float g, float b, float a) {
+  const uint32_t bps = f.out_type == 0 ? 1 : f.out_type == 2 ? 4 : 2;
+  uint8_t* p = f.out + (size_t)y * f.out_stride + (size_t)x * f.out_channels * bps;
+  const uint32_t nc = f.out_channels;
+  if (nc <= 2) {
+    StoreSample(f, p, f.is_gray ? r : g);  // gray images carry the same value in all channels; otherwise take G
+    if (nc == 2) StoreSample(f, p + bps, a);
+  } else {
+    StoreSample(f, p, r); StoreSample(f, p + bps, g); StoreSample(f, p + 2 * bps, b);
+    if (nc == 4) StoreSample(f, p + 3 * bps, a);
+  }
+}
+
+__global__ void OutputKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= (int)f.width || y >= (int)f.height) return;
+  const bool src_is_a = (FilterStagesBefore(f, 4) & 1) == 0;
+  const size_t o = (size_t)y * f.plane_stride + x;
+  const float X = (src_is_a ? f.plane_a[0] : f.plane_b[0])[o];
+  const float Y = (src_is_a ? f.plane_a[1] : f.plane_b[1])[o];
+  const float B = (src_is_a ? f.plane_a[2] : f.plane_b[2])[o];
+  float r, g, b;
+  if (f.color_mode <= 1) {
+    const float gr = (Y + X) - f.neg_bias_cbrt[0];
+    const float gg = (Y - X) - f.neg_bias_cbrt[1];
+    const float gb = B - f.neg_bias_cbrt[2];
+    const float mr = fmaf(gr * gr, gr, f.neg_bias[0]);
+    const float mg = fmaf(gg * gg, gg, f.neg_bias[1]);
+    const float mb = fmaf(gb * gb, gb, f.neg_bias[2]);
+    r = fmaf(f.opsin_inv[2], mb, fmaf(f.opsin_inv[1], mg, f.opsin_inv[0] * mr));
+    g = fmaf(f.opsin_inv[5], mb, fmaf(f.opsin_inv[4], mg, f.opsin_inv[3] * mr));
+    b = fmaf(f.opsin_inv[8], mb, fmaf(f.opsin_inv[7], mg, f.opsin_inv[6] * mr));
+    if (f.color_mode == 0) { r = LinearToSrgb(r); g = LinearToSrgb(g); b = LinearToSrgb(b); }
+  } else if (f.color_mode == 2) {
+    const float c128 = 128.0f / 255, crcr = 1.402f, cgcb = -0.114f * 1.772f / 0.587f, cgcr = -0.299f * 1.402f / 0.587f, cbcb = 1.772f;
+    const float yb = Y + c128;
+    r = fmaf(crcr, B, yb);
+    g = fmaf(cgcr, B, fmaf(cgcb, X, yb));
+    b = fmaf(cbcb, X, yb);
+  } else { r = X; g = Y; b = B; }
+  if (f.is_gray) r = g;
+  StorePixel(f, x, y, r, g, b, 1.0f);
+}
+
+// =====================================================================================================================
+// K_mod*: Modular frames.  Global stream (channels that fit a group), per-group streams with local palette / RCT,
+// global inverse transforms, integer -> sample conversion.
+// =====================================================================================================================
+__device__ void InvRctD(int32_t* c0, int32_t* c1, int32_t* c2, size_t n, uint32_t rct_type, size_t tid0, size_t tstride) {
+  const uint32_t perm = rct_type / 7, kind = rct_type % 7;
+  for (size_t i = tid0; i < n; i += tstride) {
+    const int32_t a = c0[i], b = c1[i], c = c2[i];
+    int32_t o0, o1, o2;
+    if (kind == 6) {
+      const int32_t tmp = (int32_t)((uint32_t)a - (uint32_t)(c >> 1));
+      o1 = (int32_t)((uint32_t)c + (uint32_t)tmp);
+      o2 = (int32_t)((uint32_t)tmp - (uint32_t)(b >> 1));
+      o0 = (int32_t)((uint32_t)o2 + (uint32_t)b);
+    } else {
+      int32_t first = a, second = b, third = c;
+      if (kind & 1) third = (int32_t)((uint32_t)third + (uint32_t)first);
+      if ((kind >> 1) == 1) second = (int32_t)((uint32_t)second + (uint32_t)first);
+      else if ((kind >> 1) == 2) second = (int32_t)((uint32_t)second + (uint32_t)(((int64_t)first + third) >> 1));
+      o0 = first; o1 = second; o2 = third;
+    }
+    int32_t res[3];
+    res[perm % 3] = o0; res[(perm + 1 + perm / 3) % 3] = o1; res[(perm + 2 - perm / 3) % 3] = o2;
+    c0[i] = res[0]; c1[i] = res[1]; c2[i] = res[2];
+  }
+}
+
+__device__ __forceinline__ int32_t PaletteValue(const int32_t* pal, int pal_w, int index, int c, int bit_depth) {
+  // palette.h GetPaletteValue (no delta entries: index < 0 only reachable with nb_deltas > 0, rejected)
+  if (index < 0) return 0;
+  if (index < pal_w) return pal[(size_t)c * pal_w + index];
+  if (c >= 3) return 0;
+  if (index < pal_w + 64) {
+    int i = (index - pal_w) >> (c * 2);
+    return (int32_t)(((int64_t)(i % 4) * ((1 << bit_depth) - 1)) / 4 + (1 << max(0, bit_depth - 3)));
+  }
+  int i = index - pal_w - 64;
+  for (int k = 0; k < c; k++) i /= 5;
+  return (int32_t)(((int64_t)(i % 5) * ((1 << bit_depth) - 1)) / 4);
+}
+
+// global stream: channels 0..mod_global_decodable-1 of the global image (meta channels + small channels)
+__global__ __launch_bounds__(64) void ModularGlobalKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.x];
+  if (!f.is_modular || threadIdx.x != 0) return;
+  BitReader br;
+  br.Init(f.cs, f.mod_global_bitpos, f.cs_size);
+  ModularCtx mc;
+  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0;
+  mc.wp_scratch = f.wp_scratch;
+  AnsReader ans; ans.Init(br, f.mod_code);
+  for (uint32_t c = 0; c < f.mod_global_decodable; c++) {
+    ChannelDesc ch;
+    ch.data = f.mod_plane[c]; ch.w = (int)f.mod_w[c]; ch.h = (int)f.mod_h[c]; ch.stride = (int)f.mod_w[c];
+    DecodeModularChannel(br, ans, mc, ch, (int)c);
+  }
+  if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); return; }
+  if (br.BitPos() > f.cs_size * 8) { SetError(f, kErrOverrun); return; }
+  f.stream_end_bitpos[1] = br.BitPos();
+}
+
+// per-group stream (dec_modular.cc DecodeGroup, shift range 0..2): one 64-thread block per group; thread 0 decodes,
+// then all lanes undo the local transforms and copy the rectangle into the frame planes
+__global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (!f.is_modular) return;
+  const uint32_t g = blockIdx.x;
+  if (g >= f.num_groups) return;
+  // channels decoded per group: those after the globally decoded ones
+  const uint32_t first = f.mod_global_decodable;
+  if (first >= f.mod_nchan) return;
+  const uint32_t gd = f.group_dim;
+  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
+  const uint32_t x0 = gx * gd, y0 = gy * gd;
+  __shared__ int s_ok;
+  __shared__ int s_nch;
+  __shared__ unsigned long long s_used;
+  __shared__ ChannelDesc s_ch[12];
+  __shared__ GroupHeaderD s_gh;
+  int32_t* scratch = f.mod_group_scratch + (uint64_t)g * f.mod_group_scratch_stride;
+  if (threadIdx.x == 0) {
+    s_ok = 0;
+    const uint32_t si = f.single_section ? 0 : 2 + f.num_lf_groups + g;
+    BitReader br;
+    uint64_t limit;
+    if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
+    else { const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
+    // channel list of this group (cropped rectangles)
+    int nch = 0;
+    uint64_t used = 0;
+    bool ok = true;
+    uint32_t gw = 0, gh = 0;
+    for (uint32_t c = first; c < f.mod_nchan && ok; c++) {
+      const uint32_t cw_ = f.mod_w[c], chh = f.mod_h[c];
+      if (x0 >= cw_ || y0 >= chh) continue;
+      const uint32_t rw = min(gd, cw_ - x0), rh = min(gd, chh - y0);
+      if (nch >= 8) { ok = false; break; }
+      s_ch[nch].data = scratch + used; s_ch[nch].w = (int)rw; s_ch[nch].h = (int)rh; s_ch[nch].stride = (int)rw;
+      used += (uint64_t)rw * rh;
+      gw = rw; gh = rh;
+      nch++;
+    }
+    int nmeta = 0;
+    if (ok && nch > 0) {
+      ok = ReadGroupHeader(br, s_gh) && s_gh.use_global_tree;
+      // apply local transforms to the channel list (MetaApply)
+      for (uint32_t i = 0; ok && i < s_gh.ntransforms; i++) {
+        auto& t = s_gh.t[i];
+        if (t.id == 0) { if (t.begin_c + 3 > (uint32_t)nch) ok = false; }
+        else {
+          const uint32_t endc = t.begin_c + t.num_c - 1;
+          if (endc >= (uint32_t)nch || (int)t.begin_c < nmeta || nch + 1 - (int)(t.num_c - 1) > 12 || t.nb_colors > 65536) { ok = false; break; }
+          // remove channels begin_c+1..endc, insert palette channel at 0
+          for (uint32_t k = endc + 1; k < (uint32_t)nch; k++) s_ch[k - (t.num_c - 1)] = s_ch[k];
+          nch -= (int)(t.num_c - 1);
+          for (int k = nch; k > 0; k--) s_ch[k] = s_ch[k - 1];
+          nch++;
+          s_ch[0].data = scratch + used; s_ch[0].w = (int)t.nb_colors; s_ch[0].h = (int)t.num_c; s_ch[0].stride = (int)t.nb_colors;
+          used += (uint64_t)t.nb_colors * t.num_c;
+          nmeta++;
+          // (after the inverse, begin_c indexes the channel list without the palette channel)
+        }
+      }
+      if (used > f.mod_group_scratch_stride) ok = false;
+      if (ok) {
+        ModularCtx mc;
+        mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
+        mc.stream_id = 1 + 3 * f.num_lf_groups + 17 + g;
+        mc.wp_scratch = f.wp_scratch + (uint64_t)(1 + g) * f.wp_scratch_stride;
+        AnsReader ans; ans.Init(br, f.mod_code);
+        for (int c = 0; c < nch; c++) DecodeModularChannel(br, ans, mc, s_ch[c], c);
+        if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); ok = false; }
+        else if (br.BitPos() > limit) { SetError(f, kErrOverrun); ok = false; }
+      } else SetError(f, kErrUnsupported);
+    }
+    s_nch = nch; s_ok = ok && nch > 0; s_used = used;
+    (void)gw; (void)gh;
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  // ---- undo local transforms (reverse order), all lanes
+  int nch = s_nch;
+  for (int i = (int)s_gh.ntransforms - 1; i >= 0; i--) {
+    const auto t = s_gh.t[i];
+    if (t.id == 0) {
+      const ChannelDesc a = s_ch[t.begin_c], b = s_ch[t.begin_c + 1], c = s_ch[t.begin_c + 2];
+      InvRctD(a.data, b.data, c.data, (size_t)a.w * a.h, t.rct_type, threadIdx.x, blockDim.x);
+      __syncthreads();
+    } else {
+      // inverse palette: channel 0 = palette, channel begin_c+1 = indices -> num_c channels
+      const ChannelDesc pal = s_ch[0];
+      const ChannelDesc idx = s_ch[t.begin_c + 1];
+      const size_t n = (size_t)idx.w * idx.h;
+      // new channels are carved from the palette's scratch tail: allocate after current usage is unknown here, so
+      // expand in place: channel c>0 gets fresh storage following the palette storage
+      __shared__ ChannelDesc s_new[4];
+      if (threadIdx.x == 0) {
+        if (s_used + (unsigned long long)(t.num_c - 1) * n > f.mod_group_scratch_stride) { SetError(f, kErrUnsupported); s_ok = 0; }
+        else {
+          int32_t* tail = scratch + s_used;
+          for (uint32_t c = 1; c < t.num_c; c++) { s_new[c] = idx; s_new[c].data = tail + (size_t)(c - 1) * n; }
+          s_new[0] = idx;
+          s_used += (unsigned long long)(t.num_c - 1) * n;
+        }
+      }
+      __syncthreads();
+      if (!s_ok) return;
+      const int bit_depth = min((int)f.mod_bits, 24);
+      for (size_t k = threadIdx.x; k < n; k += blockDim.x) {
+        const int index = idx.data[k];
+        for (int c = (int)t.num_c - 1; c >= 0; c--) s_new[c].data[k] = PaletteValue(pal.data, pal.w, index, c, bit_depth);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        // channel list: drop palette (0), replace index channel by num_c channels
+        ChannelDesc tmp[12];
+        int m = 0;
+        for (int k = 1; k < nch; k++) {
+          if ((uint32_t)(k - 1) == t.begin_c) { for (uint32_t c = 0; c < t.num_c; c++) tmp[m++] = s_new[c]; }
+          else tmp[m++] = s_ch[k];
+        }
+        for (int k = 0; k < m; k++) s_ch[k] = tmp[k];
+        s_nch = m;
+      }
+      __syncthreads();
+      nch = s_nch;
+    }
+  }
+  // ---- copy into the frame planes
+  int k = 0;
+  for (uint32_t c = first; c < f.mod_nchan; c++) {
+    const uint32_t cw_ = f.mod_w[c], chh = f.mod_h[c];
+    if (x0 >= cw_ || y0 >= chh) continue;
+    const ChannelDesc d = s_ch[k++];
+    int32_t* dst = f.mod_plane[c] + (size_t)y0 * cw_ + x0;
+    for (size_t i = threadIdx.x; i < (size_t)d.w * d.h; i += blockDim.x) {
+      const size_t yy = i / d.w, xx = i % d.w;
+      dst[yy * cw_ + xx] = d.data[i];
+    }
+  }
+}
+
+// ---- global inverse transforms and the integer write stage (explicit arguments; launched per frame by the host) ----
+__global__ void ModRctKernel(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type) {
+  InvRctD(a, b, c, n, rct_type, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+}
+
+struct ModPaletteArgs { const int32_t* pal; int32_t* out[4]; uint32_t nb_colors, num_c, bit_depth; size_t n; };
+__global__ void ModPaletteKernel(ModPaletteArgs a) {
+  const size_t ts = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += ts) {
+    const int index = a.out[0][i];
+    for (int c = (int)a.num_c - 1; c >= 0; c--) a.out[c][i] = PaletteValue(a.pal, (int)a.nb_colors, index, c, (int)a.bit_depth);
+  }
+}
+
+__global__ void ModularOutputKernel(const FrameDev* __restrict__ frames, int fidx, ModOutputArgs a) {
+  const FrameDev& f = frames[fidx];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= (int)f.width || y >= (int)f.height) return;
+  const size_t o = (size_t)y * f.width + x;
+  float r, g, b;
+  if (a.ncolor == 1) { r = g = b = (float)a.color[0][o] * a.color_factor; }
+  else { r = (float)a.color[0][o] * a.color_factor; g = (float)a.color[1][o] * a.color_factor; b = (float)a.color[2][o] * a.color_factor; }
+  const float al = a.alpha ? (float)a.alpha[o] * a.alpha_factor : 1.0f;
+  // StorePixel picks r for gray output of gray images and g otherwise
+  const uint32_t bps = f.out_type == 0 ? 1 : f.out_type == 2 ? 4 : 2;
+  uint8_t* p = f.out + (size_t)y * f.out_stride + (size_t)x * f.out_channels * bps;
+  const uint32_t nc = f.out_channels;
+  if (nc <= 2) { StoreSample(f, p, a.ncolor == 1 ? r : g); if (nc == 2) StoreSample(f, p + bps, al); }
+  else { StoreSample(f, p, r); StoreSample(f, p + bps, g); StoreSample(f, p + 2 * bps, b); if (nc == 4) StoreSample(f, p + 3 * bps, al); }
+}
+
+// =====================================================================================================================
+// launchers
+// =====================================================================================================================
+const char* const kKernelNames[] = {"LfDecodeKernel", "LfDequantKernel", "LfSmoothKernel", "LlfSigmaKernel", "HfDecodeKernel", "IdctKernel",
+                                    "GaborishKernel", "EpfKernel", "OutputKernel", "ModularGlobalKernel", "ModularGroupKernel", nullptr};
+
+static bool g_tables_ready = false;
+void InitDeviceTables(void* stream) {
+  if (g_tables_ready) return;
+  static float wc[9][128];
+  static float rs[4][8];
+  for (int l = 1; l <= 8; l++) { const int N = 1 << l; for (int i = 0; i < N / 2; i++) wc[l][i] = (float)(1.0 / (2.0 * cos((i + 0.5) * M_PI / N))); }
+  for (int l = 0; l < 4; l++) { const int N = 1 << l; for (int k = 0; k < N; k++) rs[l][k] = k == 0 ? 1.0f : (float)(sin(k * M_PI / (2.0 * N)) / sin(k * M_PI / (16.0 * N)) / 8.0); }
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_wc), wc, sizeof(wc), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_resample), rs, sizeof(rs), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  g_tables_ready = true;
+}
+
+static inline int DivUp(int a, int b) { return (a + b - 1) / b; }
+
+void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream) {
+  const int per_block = 64 / cfg.lane_stride_lf;
+  dim3 grid(DivUp(max_lf_groups, per_block), nframes);
+  hipLaunchKernelGGL(LfDecodeKernel, grid, dim3(64), 0, (hipStream_t)stream, frames, cfg.lane_stride_lf);
+}
+void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
+  dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
+  hipLaunchKernelGGL(LfDequantKernel, grid, block, 0, (hipStream_t)stream, frames);
+  hipLaunchKernelGGL(LfSmoothKernel, grid, block, 0, (hipStream_t)stream, frames);
+  hipLaunchKernelGGL(LlfSigmaKernel, grid, block, 0, (hipStream_t)stream, frames);
+}
+void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
+  const int per_block = 64 / cfg.lane_stride_hf;
+  dim3 grid(DivUp(max_groups, per_block), nframes);
+  hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(64), 0, (hipStream_t)stream, frames, cfg.lane_stride_hf);
+}
+void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, void* stream) {
+  hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
+}
+void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, int max_bw, int max_bh, bool any_gab, int max_epf, void* stream) {
+  (void)max_bw; (void)max_bh;
+  dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);
+  if (any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames);
+  if (max_epf >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames);
+  if (max_epf >= 1) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames);
+  if (max_epf >= 2) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames);
+}
+void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, void* stream) {
+  dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);
+  hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames);
+}
+void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream) {
+  hipLaunchKernelGGL(ModularGlobalKernel, dim3(nframes), dim3(64), 0, (hipStream_t)stream, frames);
+}
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_groups, void* stream) {
+  hipLaunchKernelGGL(ModularGroupKernel, dim3(max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames);
+}
+void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream) {
+  hipLaunchKernelGGL(ModRctKernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n, rct_type);
+}
+void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, size_t n, void* stream) {
+  ModPaletteArgs a;
+  a.pal = pal; a.nb_colors = nb_colors; a.num_c = num_c; a.bit_depth = bit_depth; a.n = n;
+  for (uint32_t c = 0; c < 4; c++) a.out[c] = c < num_c ? out[c] : nullptr;
+  hipLaunchKernelGGL(ModPaletteKernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+}
+void LaunchModOutput(const FrameDev* frames, int fidx, const ModOutputArgs& a, int w, int h, void* stream) {
+  dim3 block(64, 4), grid(DivUp(w, 64), DivUp(h, 4));
+  hipLaunchKernelGGL(ModularOutputKernel, grid, block, 0, (hipStream_t)stream, frames, fidx, a);
+}
+
+}  // namespace jxlhip
