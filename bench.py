@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixel/s of JPEG XL VarDCT (d1) decode of 3840x2160 frames on MI355X (BASELINE.json metric).
+
+A "step" decodes one batch of B synthetic 4K VarDCT frames per GPU (u8 RGB out) through the C-ABI batch API
+(include/jxl_hip.h): compressed streams and tables are HBM-resident before the timed region, decoded pixels stay in
+HBM (a torch tensor).  With N > 1 ranks every rank decodes its own shard of the batch (weak scaling, no data-path
+collective) and the decoded pixels are gathered to rank 0 over RCCL (BASELINE.json north_star).
+
+Contract: python bench.py --gpus N --steps K --warmup W  → rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
+
+
+def make_streams(distinct, width, height, epf, seed0=1000):
+    """Seeded synthetic frames encoded by tools/jxlsynth.  Returns list of bytes."""
+    import synth_lib as S
+    out = []
+    for i in range(distinct):
+        img = S.synthetic_image(seed0 + i, width, height)
+        out.append(S.encode_vardct(img, seed=seed0 + i, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1))
+    return out
+
+
+def _oracle_decode_worker(data):
+    import oracle_lib as O
+    t = time.time()
+    d = O.decode(data)
+    px = d.pixels("u8", 3)
+    return time.time() - t, int(px[:: 4097].sum())
+
+
+def cpu_baseline(streams, width, height, target_seconds=15.0):
+    """The CPU oracle (a scalar port of the libjxl algorithm: kind "port") timed on the host cores: one process per
+    core, each decoding whole frames of the same workload.  Bounded sample (~10-30 s of CPU work per core)."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    dt, _ = _oracle_decode_worker(streams[0])           # calibrate
+    per_core = max(1, min(4, int(target_seconds / max(dt, 1e-3))))
+    jobs = [streams[i % len(streams)] for i in range(cores * per_core)]
+    t0 = time.time()
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_oracle_decode_worker, jobs)
+    wall = time.time() - t0
+    mpx = len(jobs) * width * height / 1e6
+    return {"value": round(mpx / wall, 3), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "sample": f"{len(jobs)} decodes of {width}x{height} VarDCT d1 frames by oracle/libjxl_oracle.so ({per_core} per core, {cores} processes), "
+                      f"single-core rate {width * height / 1e6 / dt:.2f} Mpixel/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "64")), help="frames per GPU per step")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames (cycled to fill the batch)")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--epf", type=int, default=1)
+    ap.add_argument("--lane-stride-lf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_LF", "64")))
+    ap.add_argument("--lane-stride-hf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_HF", "64")))
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="compare frame 0 with the CPU oracle after the run")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    W, H = args.width, args.height
+
+    streams = make_streams(args.distinct, W, H, args.epf, seed0=1000 + 100 * rank)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(streams, W, H)   # before any GPU runtime is initialised in this process (fork safety)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import jpegxl_rs_amd as jx
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decode path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    B = args.batch
+    frame_bytes = W * H * 3
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+    batch = jx.BatchDecoder(local_rank)
+    for i in range(B):
+        batch.add(streams[i % len(streams)], "uint8", 3, device_ptr=out.data_ptr() + i * frame_bytes)
+    batch.set_lane_stride(args.lane_stride_lf, args.lane_stride_hf)
+    stream = torch.cuda.current_stream().cuda_stream
+    batch.prepare(stream)
+    gather_list = None
+    do_gather = world > 1 and not args.no_gather
+    if do_gather and rank == 0:
+        gather_list = [torch.empty_like(out) for _ in range(world)]
+
+    def step(timed):
+        if timed:
+            batch.decode_timed(stream)
+        else:
+            batch.decode(stream)
+        if do_gather:
+            dist.gather(out, gather_list, dst=0)
+
+    for _ in range(args.warmup):
+        step(False)
+    batch.finish(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    batch.finish(stream)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    times, runs = batch.collect_times()
+    stage_bytes = batch.stage_bytes
+    if rank == 0:
+        total_px = world * B * W * H * args.steps
+        value = total_px / elapsed / 1e6
+        # dominant kernel = stage with the largest device time; roofline from its ALGORITHMIC bytes per launch
+        stage_ms = {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"}
+        dom = max(stage_ms, key=stage_ms.get)
+        kernel_of = {"lf": "LfDecodeKernel", "lfpost": "LfDequant/LfSmooth/LlfSigma", "hf": "HfDecodeKernel", "idct": "IdctKernel",
+                     "filter": "Gaborish/Epf", "out": "OutputKernel"}
+        achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(kernel_of[dom])
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mpixel/s decode (4K VarDCT d1)", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": f"synthetic ({args.distinct} distinct seeded frames per GPU cycled over the batch, tools/jxlsynth)",
+            "config": {"workload": f"batch of {B} x {W}x{H} VarDCT d1 frames per GPU (XYB, ANS, var-block DCT8..32 mix, gaborish, EPF {args.epf}), u8 RGB out, "
+                                   "inputs and outputs resident in HBM",
+                       "frames_per_gpu": B, "width": W, "height": H, "compressed_bytes_per_frame": int(batch.compressed_bytes // B),
+                       "lane_stride_lf": args.lane_stride_lf, "lane_stride_hf": args.lane_stride_hf,
+                       "gather": bool(do_gather), "parallelism": f"frame-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_ms": round(stage_ms[dom], 4)},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_gbs": {k: round(stage_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2) if stage_ms[k] > 0 else None for k in stage_ms},
+            "device_bytes": batch.device_bytes,
+        }
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+        if args.verify:
+            import oracle_lib as O
+            got = batch.output(0)
+            ref = O.decode(streams[0]).pixels("u8", 3)
+            result["verified_vs_oracle"] = bool(np.array_equal(got, ref))
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

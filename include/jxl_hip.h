@@ -133,8 +133,10 @@ void JxlHipBatchSetLaneStride(JxlHipBatch* batch, int lf, int hf);
 JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* batch, void* hip_stream);
 /* Enqueues the decode of the whole batch on hip_stream (no host sync). */
 JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* batch, void* hip_stream);
-/* Same, with HIP events around every stage on hip_stream; synchronises. */
-JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* batch, void* hip_stream, JxlHipStageTimes* times);
+/* Same, bracketing every stage with HIP events recorded on hip_stream (still no host sync). */
+JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* batch, void* hip_stream);
+/* Waits for all timed decodes so far; returns per-stage sums in ms and the number of timed decodes. */
+JxlDecoderStatus JxlHipBatchCollectTimes(JxlHipBatch* batch, JxlHipStageTimes* times, int* runs);
 /* Waits for completion and checks per-frame device status. */
 JxlDecoderStatus JxlHipBatchFinish(JxlHipBatch* batch, void* hip_stream);
 /* Device pointer of the decoded pixels of image `index`; copy to host. */
@@ -143,7 +145,8 @@ JxlDecoderStatus JxlHipBatchCopyOutput(JxlHipBatch* batch, int index, void* host
 /* Accounting for roofline reports. */
 uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* batch);
 uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* batch);
-uint64_t JxlHipBatchAlgorithmicBytesHF(const JxlHipBatch* batch);
+/* Algorithmic (compulsory) HBM bytes of one decode per stage: lf, lfpost, hf, idct, filters, out. */
+void JxlHipBatchStageBytes(const JxlHipBatch* batch, uint64_t out[6]);
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* batch);
 
 #ifdef __cplusplus

@@ -98,10 +98,11 @@ def libjxl():
             "JxlHipBatchSetOutput": (C.c_int, [vp, C.c_int, C.POINTER(JxlPixelFormat), vp]),
             "JxlHipBatchSetLaneStride": (None, [vp, C.c_int, C.c_int]),
             "JxlHipBatchPrepare": (C.c_int, [vp, vp]), "JxlHipBatchDecode": (C.c_int, [vp, vp]),
-            "JxlHipBatchDecodeTimed": (C.c_int, [vp, vp, C.POINTER(JxlHipStageTimes)]), "JxlHipBatchFinish": (C.c_int, [vp, vp]),
+            "JxlHipBatchDecodeTimed": (C.c_int, [vp, vp]), "JxlHipBatchFinish": (C.c_int, [vp, vp]),
+            "JxlHipBatchCollectTimes": (C.c_int, [vp, C.POINTER(JxlHipStageTimes), C.POINTER(C.c_int)]),
             "JxlHipBatchDeviceOutput": (vp, [vp, C.c_int]), "JxlHipBatchCopyOutput": (C.c_int, [vp, C.c_int, vp, sz, vp]),
             "JxlHipBatchTotalPixels": (C.c_uint64, [vp]), "JxlHipBatchCompressedBytes": (C.c_uint64, [vp]),
-            "JxlHipBatchAlgorithmicBytesHF": (C.c_uint64, [vp]), "JxlHipBatchDeviceBytes": (C.c_uint64, [vp]),
+            "JxlHipBatchStageBytes": (None, [vp, C.POINTER(C.c_uint64 * 6)]), "JxlHipBatchDeviceBytes": (C.c_uint64, [vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -496,10 +497,14 @@ class BatchDecoder:
     def decode(self, stream=None):
         self._chk(libjxl().JxlHipBatchDecode(self._h, stream))
 
-    def decode_timed(self, stream=None) -> JxlHipStageTimes:
-        t = JxlHipStageTimes()
-        self._chk(libjxl().JxlHipBatchDecodeTimed(self._h, stream, C.byref(t)))
-        return t
+    def decode_timed(self, stream=None):
+        self._chk(libjxl().JxlHipBatchDecodeTimed(self._h, stream))
+
+    def collect_times(self):
+        """-> (dict stage -> summed ms, number of timed decodes)"""
+        t = JxlHipStageTimes(); runs = C.c_int()
+        self._chk(libjxl().JxlHipBatchCollectTimes(self._h, C.byref(t), C.byref(runs)))
+        return {n: getattr(t, n) for n, _ in JxlHipStageTimes._fields_}, runs.value
 
     def finish(self, stream=None):
         self._chk(libjxl().JxlHipBatchFinish(self._h, stream))
@@ -522,8 +527,11 @@ class BatchDecoder:
         return libjxl().JxlHipBatchCompressedBytes(self._h)
 
     @property
-    def algorithmic_bytes_hf(self):
-        return libjxl().JxlHipBatchAlgorithmicBytesHF(self._h)
+    def stage_bytes(self):
+        """Algorithmic HBM bytes of one decode of the batch per stage (lf, lfpost, hf, idct, filters, out)."""
+        a = (C.c_uint64 * 6)()
+        libjxl().JxlHipBatchStageBytes(self._h, C.byref(a))
+        return dict(zip(("lf", "lfpost", "hf", "idct", "filter", "out"), [int(v) for v in a]))
 
     @property
     def device_bytes(self):

@@ -115,16 +115,28 @@ void Batch::SetOutput(int i, const OutputSpec& o) {
 
 uint64_t Batch::total_pixels() const { uint64_t n = 0; for (auto& e : images_) n += (uint64_t)e->ih.xsize * e->ih.ysize; return n; }
 uint64_t Batch::compressed_bytes() const { uint64_t n = 0; for (auto& e : images_) n += e->cs.size; return n; }
-uint64_t Batch::algorithmic_bytes_hf() const {
-  // K_hf: reads the PassGroup sections once, writes the quantised coefficients once (int32, 3 channels) — SURVEY §8d
-  uint64_t n = 0;
+void Batch::StageBytes(uint64_t out[6]) const {
+  // Compulsory HBM traffic of each stage: every input read once, every output written once.
+  for (int i = 0; i < 6; i++) out[i] = 0;
   for (auto& e : images_) {
     const FramePlan& p = e->plan;
     if (p.modular) continue;
-    if (p.single_section) n += e->cs.size; else for (size_t s = 2 + p.num_lf_groups; s < p.sections.size(); s++) n += p.sections[s].size;
-    n += (uint64_t)p.bw * p.bh * 64 * 3 * 4;
+    const uint64_t nblk = (uint64_t)p.bw * p.bh, npx = (uint64_t)p.width * p.height;
+    uint64_t lf_sec = 0, hf_sec = 0;
+    if (p.single_section) { lf_sec = e->cs.size / 4; hf_sec = e->cs.size; }
+    else {
+      for (uint32_t s = 1; s < 1 + p.num_lf_groups; s++) lf_sec += p.sections[s].size;
+      for (size_t s = 2 + p.num_lf_groups; s < p.sections.size(); s++) hf_sec += p.sections[s].size;
+    }
+    out[0] += lf_sec + nblk * (3 * 4 + 4 + 4);                 // LF sections -> lfq (3 x i32) + blk_info + coef_off
+    out[1] += nblk * (12 + 12 + 12 + 12 + 12 + 16);            // dequant r/w, smooth r/w, llf r + (llf, sigma) w
+    out[2] += hf_sec + nblk * 64 * 3 * 4;                      // PassGroup sections -> i32 coefficients
+    out[3] += npx * (12 + 12);                                 // coefficients -> f32 planes
+    uint32_t nstages = (p.lf.gab ? 1 : 0) + (p.lf.epf_iters >= 3 ? 3 : p.lf.epf_iters);
+    out[4] += npx * 24 * nstages;                              // each filter stage reads and writes 3 f32 planes
+    const uint64_t bps = e->out.type == 0 ? 1 : e->out.type == 2 ? 4 : 2;
+    out[5] += npx * (12 + e->out.num_channels * bps);
   }
-  return n;
 }
 
 void* Batch::device_output(int i) const {
@@ -438,33 +450,42 @@ void Batch::Run(void* stream_v) {
   }
 }
 
-StageTimes Batch::RunTimed(void* stream_v) {
+void Batch::RunTimed(void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
-  StageTimes t;
-  if (!any_vardct_) { Run(stream_v); return t; }
-  hipEvent_t ev[8];
-  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
-  HIP_CHECK(hipEventRecord(ev[0], stream));
+  if (!any_vardct_) { Run(stream_v); return; }
+  std::vector<void*> evs(7);
+  for (auto& e : evs) { hipEvent_t ev; HIP_CHECK(hipEventCreate(&ev)); e = ev; }
+  auto rec = [&](int i) { HIP_CHECK(hipEventRecord((hipEvent_t)evs[i], stream)); };
+  rec(0);
   HIP_CHECK(hipMemsetAsync(dwork_ + coeff_off_, 0, coeff_bytes_, stream));
   LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
-  HIP_CHECK(hipEventRecord(ev[1], stream));
+  rec(1);
   LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
-  HIP_CHECK(hipEventRecord(ev[2], stream));
+  rec(2);
   LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
-  HIP_CHECK(hipEventRecord(ev[3], stream));
+  rec(3);
   LaunchIdct(dframes_, n, max_groups_, stream_v);
-  HIP_CHECK(hipEventRecord(ev[4], stream));
+  rec(4);
   LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
-  HIP_CHECK(hipEventRecord(ev[5], stream));
+  rec(5);
   LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
-  HIP_CHECK(hipEventRecord(ev[6], stream));
-  HIP_CHECK(hipEventSynchronize(ev[6]));
-  float* dst[6] = {&t.lf_ms, &t.lfpost_ms, &t.hf_ms, &t.idct_ms, &t.filter_ms, &t.out_ms};
-  for (int i = 0; i < 6; i++) HIP_CHECK(hipEventElapsedTime(dst[i], ev[i], ev[i + 1]));
-  HIP_CHECK(hipEventElapsedTime(&t.total_ms, ev[0], ev[6]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
+  rec(6);
+  timed_events_.push_back(evs);
+}
+
+StageTimes Batch::CollectTimes(int* runs) {
+  StageTimes t;
+  *runs = (int)timed_events_.size();
+  for (auto& evs : timed_events_) {
+    HIP_CHECK(hipEventSynchronize((hipEvent_t)evs[6]));
+    float* dst[6] = {&t.lf_ms, &t.lfpost_ms, &t.hf_ms, &t.idct_ms, &t.filter_ms, &t.out_ms};
+    for (int i = 0; i < 6; i++) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)evs[i], (hipEvent_t)evs[i + 1])); *dst[i] += ms; }
+    float tot = 0; HIP_CHECK(hipEventElapsedTime(&tot, (hipEvent_t)evs[0], (hipEvent_t)evs[6])); t.total_ms += tot;
+    for (auto e : evs) (void)hipEventDestroy((hipEvent_t)e);
+  }
+  timed_events_.clear();
   return t;
 }
 

@@ -53,12 +53,15 @@ class Batch {
   // Copies frame i's pixels to host memory (after Finish).
   void CopyOutputToHost(int i, void* dst, size_t size, void* stream);
   void* device_output(int i) const;
-  // Timed run with per-stage HIP events on `stream` (used by bench.py for the roofline block).
-  StageTimes RunTimed(void* stream);
+  // Same as Run but brackets every stage with HIP events recorded on `stream` (no host sync).  CollectTimes() waits for
+  // all recorded runs and returns the per-stage sums (ms) and the number of runs; used by bench.py for the roofline.
+  void RunTimed(void* stream);
+  StageTimes CollectTimes(int* runs);
+  // ALGORITHMIC bytes per stage for one Run of the batch: 0 lf, 1 lfpost, 2 hf, 3 idct, 4 filters, 5 out
+  void StageBytes(uint64_t out[6]) const;
   LaunchCfg cfg;
   size_t const_bytes() const { return const_size_; }
   size_t work_bytes() const { return work_size_; }
-  uint64_t algorithmic_bytes_hf() const;   // compressed AC bytes + coefficient bytes written (K_hf roofline)
   uint64_t total_pixels() const;
   uint64_t compressed_bytes() const;
 
@@ -78,7 +81,8 @@ class Batch {
   int max_lf_groups_ = 0, max_groups_ = 0, max_w_ = 0, max_h_ = 0, max_bw_ = 0, max_bh_ = 0, max_epf_ = 0;
   bool any_gab_ = false, any_vardct_ = false, any_modular_ = false;
   struct ModFinish { int frame; std::vector<int> planes; };  // host-side channel lists for modular frames
-  std::vector<std::vector<size_t>> mod_plane_offsets_;       // per frame: work-arena offsets of planes (incl. spare)
+  std::vector<std::vector<size_t>> mod_plane_offsets_;
+  std::vector<std::vector<void*>> timed_events_;       // per frame: work-arena offsets of planes (incl. spare)
 };
 
 }  // namespace jxlhip

@@ -262,15 +262,16 @@ void JxlHipBatchSetLaneStride(JxlHipBatch* h, int lf, int hf) {
 #define BATCH_TRY(stmt) try { stmt; return JXL_DEC_SUCCESS; } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
 JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Prepare(s)) }
 JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Run(s)) }
-JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* h, void* s, JxlHipStageTimes* t) {
-  BATCH_TRY({ StageTimes st = h->b->RunTimed(s); t->lf_ms = st.lf_ms; t->lfpost_ms = st.lfpost_ms; t->hf_ms = st.hf_ms; t->idct_ms = st.idct_ms; t->filter_ms = st.filter_ms; t->out_ms = st.out_ms; t->total_ms = st.total_ms; })
+JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->RunTimed(s)) }
+JxlDecoderStatus JxlHipBatchCollectTimes(JxlHipBatch* h, JxlHipStageTimes* t, int* runs) {
+  BATCH_TRY({ StageTimes st = h->b->CollectTimes(runs); t->lf_ms = st.lf_ms; t->lfpost_ms = st.lfpost_ms; t->hf_ms = st.hf_ms; t->idct_ms = st.idct_ms; t->filter_ms = st.filter_ms; t->out_ms = st.out_ms; t->total_ms = st.total_ms; })
 }
 JxlDecoderStatus JxlHipBatchFinish(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Finish(s)) }
 void* JxlHipBatchDeviceOutput(const JxlHipBatch* h, int i) { return h->b->device_output(i); }
 JxlDecoderStatus JxlHipBatchCopyOutput(JxlHipBatch* h, int i, void* dst, size_t size, void* s) { BATCH_TRY(h->b->CopyOutputToHost(i, dst, size, s)) }
 uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* h) { return h->b->total_pixels(); }
 uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* h) { return h->b->compressed_bytes(); }
-uint64_t JxlHipBatchAlgorithmicBytesHF(const JxlHipBatch* h) { return h->b->algorithmic_bytes_hf(); }
+void JxlHipBatchStageBytes(const JxlHipBatch* h, uint64_t out[6]) { h->b->StageBytes(out); }
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* h) { return h->b->const_bytes() + h->b->work_bytes(); }
 
 }  // extern "C"

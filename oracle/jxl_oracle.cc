@@ -119,6 +119,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
           std::vector<int32_t>& v = out.dump.ints[std::string("coeff") + char('0' + c)];
           for (auto& g : f.coeffs[c]) v.insert(v.end(), g.begin(), g.end());
         }
+        for (int c = 0; c < 3; c++) out.dump.ints[std::string("lfq") + char('0' + c)] = f.lfq[c];
         std::vector<int32_t>& st = out.dump.ints["strategy"];
         std::vector<int32_t>& hm = out.dump.ints["hf_mul"];
         std::vector<int32_t>& sh = out.dump.ints["sharpness"];

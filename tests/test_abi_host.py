@@ -1,0 +1,179 @@
+"""CPU tests of the drop-in boundary: the look-alike libjxl.so / libjxl_threads.so load and export every symbol
+jpegxl-sys declares, struct layouts match, and the host-side logic of the jpegxl-rs mirror behaves like the reference
+(no compute calls: there is no GPU here, and the product has no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, fixture_bytes
+
+
+@pytest.fixture(scope="module")
+def jx(built):
+    import jpegxl_rs_amd as jx
+    return jx
+
+
+def test_every_declared_symbol_is_exported(jx):
+    L = jx.libjxl()
+    T = jx.libjxl_threads()
+    header = open(os.path.join(ROOT, "include", "jxl_hip.h")).read()
+    declared = set(re.findall(r"\b(Jxl\w+)\s*\((?!\*)", header))
+    assert len(declared) >= 45
+    for name in declared:
+        lib = T if re.match(r"Jxl(Thread|Resizable)ParallelRunner", name) else L
+        assert hasattr(lib, name), name
+    stubs = re.findall(r"^\w[\w\*]*\s+(Jxl\w+)\(void\)", open(os.path.join(ROOT, "jpegxl-rs_amd", "csrc", "jxl_stubs.cc")).read(), re.M)
+    assert len(stubs) == 89                      # 120 declared by jpegxl-sys - 31 live ones
+    for name in stubs:
+        assert hasattr(L, name), name
+    assert not (set(stubs) & declared)
+
+
+def test_struct_layouts_and_version(jx):
+    assert C.sizeof(jx.JxlBasicInfo) == 204          # jpegxl-sys codestream_header.rs:108-241
+    assert jx.JxlBasicInfo.orientation.offset == 48 and jx.JxlBasicInfo.intrinsic_xsize.offset == 96 and jx.JxlBasicInfo.padding.offset == 104
+    assert C.sizeof(jx.JxlPixelFormat) == 24 and jx.JxlPixelFormat.align.offset == 16
+    assert C.sizeof(jx.JxlMemoryManager) == 24
+    assert jx.libjxl().JxlDecoderVersion() == 11002  # jpegxl-sys/src/lib.rs:79
+
+
+def test_signature_check(jx):
+    """utils.rs:42-47 and jpegxl-sys/src/lib.rs:98-99 (2 bytes are enough for a bare codestream)."""
+    s = fixture_bytes("sample.jxl")
+    assert jx.check_valid_signature(b"") is None
+    assert jx.check_valid_signature(bytes(64)) is False
+    assert jx.check_valid_signature(s) is True
+    assert jx.libjxl().JxlSignatureCheck(s, 2) == 2
+    assert jx.libjxl().JxlSignatureCheck(fixture_bytes("sample_jpg.jxl"), 12) == 3
+    assert jx.libjxl().JxlSignatureCheck(fixture_bytes("sample_jpg.jxl"), 5) == 0
+
+
+def test_invalid_input_errors(jx):
+    """tests/decode.rs:33-42, errors.rs:109-137: [] and zeros are InvalidInput before any library state is touched."""
+    dec = jx.decoder_builder()
+    for bad in (b"", b"\x00\x00", bytes(64)):
+        with pytest.raises(jx.InvalidInput):
+            dec.decode(bad)
+
+
+def test_raw_state_machine_without_gpu(jx):
+    """The event order of jpegxl-sys/src/lib.rs:85-171 up to the point where pixels are needed; on a box without a GPU
+    the hot path must fail loudly (JXL_DEC_ERROR), never fall back to a CPU decoder."""
+    import torch
+    L = jx.libjxl()
+    dec = L.JxlDecoderCreate(None)
+    assert dec
+    data = np.frombuffer(fixture_bytes("sample.jxl"), np.uint8)
+    assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_FULL_IMAGE) == 0
+    assert L.JxlDecoderSubscribeEvents(dec, 1) == 1                       # non-event bits are rejected
+    assert L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_NEED_MORE_INPUT    # no input yet
+    L.JxlDecoderReset(dec)
+    assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_FULL_IMAGE) == 0
+    assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+    assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 1    # input already set (decode.rs:680)
+    st = L.JxlDecoderProcessInput(dec)
+    if torch.cuda.is_available():
+        assert st == jx.JXL_DEC_BASIC_INFO
+    else:
+        assert st == jx.JXL_DEC_ERROR and "no CPU fallback" in jx.last_error()
+    L.JxlDecoderDestroy(dec)
+
+
+def test_memory_manager_is_copied_and_used(jx):
+    """memory.rs:24-39: alloc/free go through the caller's manager; the struct itself is a temporary (copied)."""
+    L = jx.libjxl()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    calls = {"alloc": 0, "free": 0}
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+    def alloc(opaque, size):
+        calls["alloc"] += 1
+        return libc.malloc(size)
+
+    def free(opaque, ptr):
+        calls["free"] += 1
+        libc.free(ptr)
+    a, f = ALLOC(alloc), FREE(free)
+    mm = jx.JxlMemoryManager(None, C.cast(a, C.c_void_p), C.cast(f, C.c_void_p))
+    dec = L.JxlDecoderCreate(C.byref(mm))
+    mm.alloc = None; mm.free = None     # the caller's struct may die right after Create
+    assert dec and calls["alloc"] == 1
+    L.JxlDecoderDestroy(dec)
+    assert calls["free"] == 1
+    half = jx.JxlMemoryManager(None, C.cast(a, C.c_void_p), None)
+    assert not L.JxlDecoderCreate(C.byref(half))   # alloc without free is rejected
+    null_alloc = ALLOC(lambda o, s: None)
+    oom = jx.JxlMemoryManager(None, C.cast(null_alloc, C.c_void_p), C.cast(f, C.c_void_p))
+    assert not L.JxlDecoderCreate(C.byref(oom))    # -> DecodeError::CannotCreateDecoder (decode.rs:184-186)
+
+
+def test_threads_runner_contract(jx):
+    """parallel_runner.rs:55-122: init once on the calling thread, func for every i in [start, end), return codes."""
+    T = jx.libjxl_threads()
+    INIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
+    FUNC = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_size_t)
+    T.JxlThreadParallelRunner.restype = C.c_int
+    T.JxlThreadParallelRunner.argtypes = [C.c_void_p, C.c_void_p, INIT, FUNC, C.c_uint32, C.c_uint32]
+    T.JxlResizableParallelRunner.restype = C.c_int
+    T.JxlResizableParallelRunner.argtypes = [C.c_void_p, C.c_void_p, INIT, FUNC, C.c_uint32, C.c_uint32]
+    seen, inits, tids = [], [], set()
+    init = INIT(lambda o, n: inits.append(n) or 0)
+    func = FUNC(lambda o, i, t: (seen.append(i), tids.add(t)) and None)
+    r = T.JxlThreadParallelRunnerCreate(None, 4)
+    assert T.JxlThreadParallelRunner(r, None, init, func, 5, 105) == 0
+    assert sorted(seen) == list(range(5, 105)) and inits == [4] and tids <= {0, 1, 2, 3}
+    assert T.JxlThreadParallelRunner(r, None, init, func, 7, 7) == 0 and inits == [4]      # empty range: no init
+    assert T.JxlThreadParallelRunner(r, None, INIT(lambda o, n: 42), func, 0, 3) == 42       # init failure propagates
+    assert T.JxlThreadParallelRunner(r, None, init, func, 3, 2) == -1
+    T.JxlThreadParallelRunnerDestroy(r)
+    seen.clear()
+    rr = T.JxlResizableParallelRunnerCreate(None)
+    assert T.JxlResizableParallelRunner(rr, None, init, func, 0, 10) == 0 and sorted(seen) == list(range(10))   # 0 workers: inline
+    T.JxlResizableParallelRunnerSetThreads(rr, T.JxlResizableParallelRunnerSuggestThreads(3840, 2160))
+    seen.clear()
+    assert T.JxlResizableParallelRunner(rr, None, init, func, 0, 1000) == 0 and sorted(seen) == list(range(1000))
+    T.JxlResizableParallelRunnerDestroy(rr)
+    assert T.JxlThreadParallelRunnerDefaultNumWorkerThreads() >= 1
+
+
+def test_runner_objects_are_small(jx):
+    """threads_runner.rs:97-102 / resizable_runner.rs:96-102: the runner object itself costs < 1 KiB from the custom allocator."""
+    T = jx.libjxl_threads()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]; libc.free.argtypes = [C.c_void_p]
+    total = []
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+    a = ALLOC(lambda o, s: total.append(s) or libc.malloc(s))
+    f = FREE(lambda o, p: libc.free(p))
+    mm = jx.JxlMemoryManager(None, C.cast(a, C.c_void_p), C.cast(f, C.c_void_p))
+    r = T.JxlThreadParallelRunnerCreate(C.byref(mm), 10)
+    assert r and sum(total) < 1024
+    T.JxlThreadParallelRunnerDestroy(r)
+
+
+def test_builder_fields_are_public_and_mutable(jx):
+    """decode.rs:85-154 + tests/decode.rs:167-173: options can be changed between decodes of one decoder object."""
+    dec = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3, endianness=jx.Endianness.Big, align=10), icc_profile=False, init_jpeg_buffer=512)
+    assert dec.pixel_format.align == 10 and dec.init_jpeg_buffer == 512
+    dec.pixel_format = None
+    dec.skip_reorientation = True
+    dec.unpremul_alpha = True
+    assert dec.pixel_format is None
+
+
+def test_sharding_plan():
+    from jpegxl_rs_amd.sharding import shard_range, shard_sizes
+    assert shard_sizes(1024, 8) == [128] * 8            # BASELINE config 3
+    assert shard_sizes(10, 4) == [3, 3, 2, 2]
+    assert [shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_sizes(3, 8) == [1, 1, 1, 0, 0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)

@@ -1,0 +1,232 @@
+"""GPU parity tests (-m gpu): the HIP decode path, called through the libjxl-compatible C ABI exactly like
+jpegxl-rs/src/decode.rs drives libjxl, must reproduce the CPU oracle bit-exactly for integer outputs and (so far also)
+exactly for f32 — tolerance: u8/u16 exact, f32 <= 1 ULP (BASELINE.json north_star).  Mirrors the reference's decode tests
+(jpegxl-rs/src/tests/decode.rs, errors.rs, image.rs) plus synthesised VarDCT streams for the path north_star names."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, GOLDEN, fixture_bytes, read_png16
+import oracle_lib as O
+import synth_lib as S
+
+pytestmark = pytest.mark.gpu
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+@pytest.fixture(scope="module")
+def jx(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import jpegxl_rs_amd as jx
+    return jx
+
+
+def ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64); bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai); bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi).max() if a.size else 0
+
+
+def check_against_oracle(jx, data, dtype, nch=0, **fmt):
+    meta, px = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=nch, **fmt)).decode_with(data, dtype)
+    kind = {"uint8": "u8", "uint16": "u16", "float32": "f32", "float16": "f16"}[np.dtype(dtype).name]
+    ref = O.decode(data).pixels(kind, nch, big_endian=fmt.get("endianness", 0) == 2, align=fmt.get("align", 0))
+    order = ">" if fmt.get("endianness", 0) == 2 else "<"
+    ref = ref.view(np.dtype(order + np.dtype(dtype).str[1:])).astype(dtype)
+    assert px.shape == ref.shape
+    if np.dtype(dtype) == np.float32:
+        assert ulp_diff(px, ref) <= 1
+    else:
+        assert np.array_equal(px, ref), f"{int((px != ref).sum())} of {px.size} samples differ"
+    return meta, px
+
+
+# ---- the reference's own fixtures and tests -------------------------------------------------------------------------
+def test_sample_jxl_equals_sample_png(jx):
+    """image.rs:157-172 through the HIP path: RGBA16 == sample.png."""
+    meta, px = jx.decoder_builder(parallel_runner=jx.ThreadsRunner()).decode_with(fixture_bytes("sample.jxl"), np.uint16)
+    assert (meta.width, meta.height, meta.num_color_channels, meta.has_alpha_channel) == (40, 50, 3, True)
+    png = read_png16(os.path.join(FIXTURES, "sample.png"))
+    assert np.array_equal(px.reshape(50, 40, 4), png)
+    assert hashlib.sha256(px.astype(">u2").tobytes()).hexdigest() == MANIFEST["reference_fixtures"]["sample.jxl"]["sha256_rgba16_be"]
+
+
+def test_decode_simple_and_pixel_types(jx):
+    """tests/decode.rs:45-67,96-120: inferred type Uint16, len == w*h*4; every pixel type and endianness succeeds."""
+    data = fixture_bytes("sample.jxl")
+    meta, px = jx.decoder_builder().decode(data)
+    assert px.dtype == np.uint16 and len(px) == meta.width * meta.height * 4
+    for dt in (np.float32, np.uint8, np.uint16, np.float16):
+        for en in (jx.Endianness.Big, jx.Endianness.Little, jx.Endianness.Native):
+            _, p = jx.decoder_builder(pixel_format=jx.PixelFormat(endianness=en)).decode_with(data, dt)
+            assert len(p) == 40 * 50 * 4 and p.dtype == np.dtype(dt)
+    check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.uint8, 4)
+    check_against_oracle(jx, data, np.uint16, 4, endianness=2)
+    check_against_oracle(jx, data, np.float32, 2)
+    check_against_oracle(jx, data, np.uint16, 1)
+
+
+def test_builder_reuse(jx):
+    """tests/decode.rs:142-180: one decoder object re-used with mutated options; f32 RGB big-endian align 10 then RGBA."""
+    data = fixture_bytes("sample.jxl")
+    dec = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3, endianness=jx.Endianness.Big, align=10), skip_reorientation=True,
+                             unpremul_alpha=True, render_spotcolors=True, coalescing=True, desired_intensity_target=0.5, decompress=True,
+                             init_jpeg_buffer=512, parallel_runner=jx.ResizableRunner())
+    meta, px = dec.decode_with(data, np.float32)
+    assert len(px) == meta.width * meta.height * 3
+    dec.pixel_format = None
+    dec.parallel_runner = jx.ThreadsRunner()
+    meta, px = dec.decode_with(data, np.float32)
+    assert len(px) == meta.width * meta.height * 4
+    meta, px = dec.decode(data)
+    assert px.dtype == np.uint16
+
+
+def test_decode_errors(jx):
+    """errors.rs:109-137: truncated input after CloseInput -> GenericError; garbage -> InvalidInput."""
+    dec = jx.decoder_builder()
+    with pytest.raises(jx.InvalidInput):
+        dec.decode(b"")
+    with pytest.raises(jx.InvalidInput):
+        dec.decode(bytes(64))
+    with pytest.raises(jx.GenericError):
+        jx.decoder_builder().decode(fixture_bytes("sample.jxl")[:100])
+    data = bytearray(S.encode_vardct(S.synthetic_image(1, 64, 64), strategy_mix=0))
+    data[len(data) // 2] ^= 0xFF                      # corrupt the token stream: ANS final-state / range checks must fire
+    with pytest.raises(jx.GenericError):
+        jx.decoder_builder().decode_with(bytes(data), np.uint8)
+
+
+def test_unsupported_fixtures_fail_cleanly(jx):
+    """sample_grey.jxl (patches, AFV), 2bit.jxl (splines) are 'next' rows: JXL_DEC_ERROR, never garbage."""
+    for name in ("sample_grey.jxl", "2bit.jxl"):
+        with pytest.raises(jx.GenericError) as e:
+            jx.decoder_builder().decode(fixture_bytes(name))
+        assert "unsupported" in str(e.value)
+
+
+def test_raw_ffi_sequence(jx):
+    """jpegxl-sys/src/lib.rs:85-171: raw state machine without CloseInput / Reset, u8 x 3 channels, 40 x 50."""
+    L = jx.libjxl()
+    dec = L.JxlDecoderCreate(None)
+    data = np.frombuffer(fixture_bytes("sample.jxl"), np.uint8)
+    assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_FULL_IMAGE) == 0
+    assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+    info = jx.JxlBasicInfo()
+    fmt = jx.JxlPixelFormat(3, jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+    buf = None
+    events = []
+    while True:
+        st = L.JxlDecoderProcessInput(dec)
+        events.append(st)
+        if st == jx.JXL_DEC_BASIC_INFO:
+            assert L.JxlDecoderGetBasicInfo(dec, C.byref(info)) == 0
+            assert (info.xsize, info.ysize) == (40, 50)
+        elif st == jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+            size = C.c_size_t()
+            assert L.JxlDecoderImageOutBufferSize(dec, C.byref(fmt), C.byref(size)) == 0
+            assert size.value == 40 * 50 * 3
+            buf = np.zeros(size.value, np.uint8)
+            assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), buf.ctypes.data, size.value - 1) == 1   # too small
+            assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), buf.ctypes.data, size.value) == 0
+        elif st == jx.JXL_DEC_FULL_IMAGE:
+            continue
+        elif st == jx.JXL_DEC_SUCCESS:
+            break
+        else:
+            raise AssertionError(st)
+    assert events == [jx.JXL_DEC_BASIC_INFO, jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER, jx.JXL_DEC_FULL_IMAGE, jx.JXL_DEC_SUCCESS]
+    L.JxlDecoderDestroy(dec)
+    assert np.array_equal(buf, O.decode(fixture_bytes("sample.jxl")).pixels("u8", 3))
+
+
+def test_bench_jxl_modular_groups(jx):
+    """benches/decode.rs:10 input: 54 groups, global MA tree with weighted predictor, per-group palettes and RCTs."""
+    meta, px = jx.decoder_builder().decode_with(fixture_bytes("bench.jxl"), np.uint8)
+    assert (meta.width, meta.height) == (2122, 1433)
+    assert hashlib.sha256(px.tobytes()).hexdigest() == MANIFEST["reference_fixtures"]["bench.jxl"]["sha256_rgba8"]
+
+
+# ---- VarDCT (the path north_star names) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct")])
+def test_vardct_golden_streams(jx, name):
+    data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+    _, px = jx.decoder_builder().decode_with(data, np.uint8)
+    assert hashlib.sha256(px.tobytes()).hexdigest() == MANIFEST[name]["sha256_u8_rgb"]
+    _, pf = jx.decoder_builder().decode_with(data, np.float32)
+    ref = O.decode(data).pixels("f32", 3).view(np.float32)
+    assert ulp_diff(pf, ref) <= 1
+
+
+@pytest.mark.parametrize("s", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20])
+def test_vardct_every_strategy(jx, s):
+    img = S.synthetic_image(7, 256, 128)
+    data = S.encode_vardct(img, seed=5, strategy_mix=100 + s, epf_iters=1, gab=1)
+    check_against_oracle(jx, data, np.float32, 3)
+    check_against_oracle(jx, data, np.uint8, 3)
+
+
+@pytest.mark.parametrize("w,h,mix,epf,gab,skip", [(8, 8, 0, 0, 0, 0), (9, 17, 0, 1, 1, 0), (64, 64, 0, 2, 1, 1), (100, 37, 1, 1, 1, 0), (256, 256, 1, 3, 1, 0),
+                                                  (257, 255, 2, 1, 0, 0), (300, 200, 2, 2, 1, 0), (520, 300, 2, 3, 1, 0), (2100, 300, 2, 1, 1, 0), (130, 2060, 1, 0, 1, 0)])
+def test_vardct_shapes_and_filters(jx, w, h, mix, epf, gab, skip):
+    """Ragged sizes (non-multiples of 8 / 256 / 2048), single-section and multi-LF-group frames, every filter combination."""
+    img = np.ascontiguousarray(S.synthetic_image(21, max(w, 8), max(h, 8))[:h, :w])
+    data = S.encode_vardct(img, seed=6, strategy_mix=mix, epf_iters=epf, gab=gab, skip_lf_smoothing=skip)
+    check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.uint16, 4, align=32)
+    check_against_oracle(jx, data, np.float32, 3)
+    check_against_oracle(jx, data, np.float16, 1)
+
+
+def test_hdr_float_stream(jx):
+    """Config-5 style: f32 samples, linear transfer, intensity_target 1000, EPF 3."""
+    lin = ((S.synthetic_image(9, 320, 200).astype(np.float32) / 255.0) ** 2.2) * 2.0
+    data = S.encode_vardct(lin, seed=4, strategy_mix=2, epf_iters=3, gab=1, out_bits=32, hdr=1)
+    meta, px = check_against_oracle(jx, data, np.float32, 3)
+    assert abs(meta.intensity_target - 1000.0) < 1e-3
+    m, p2 = jx.decoder_builder().decode(data)
+    assert p2.dtype == np.float32
+
+
+@pytest.mark.parametrize("h,w,c,bits,rct", [(50, 40, 3, 8, False), (300, 520, 4, 8, True), (64, 64, 1, 16, False), (257, 255, 3, 16, True), (700, 300, 2, 8, False)])
+def test_modular_synth(jx, h, w, c, bits, rct):
+    base = S.synthetic_image(3, w, h).astype(np.int32)
+    img = np.stack([base[..., i % 3] * ((1 << bits) - 1) // 255 for i in range(c)], -1)
+    _, px = jx.decoder_builder().decode_with(S.encode_modular(img, bits, rct), np.uint16 if bits == 16 else np.uint8)
+    assert np.array_equal(px.reshape(h, w, c), img)
+
+
+def test_full_size_4k_frame(jx):
+    """BASELINE config 2: one 3840x2160 VarDCT d1 frame, u8 output, bit-exact vs the CPU decode."""
+    img = S.synthetic_image(1000, 3840, 2160)
+    data = S.encode_vardct(img, seed=1000, strategy_mix=1, epf_iters=1, gab=1)
+    _, px = check_against_oracle(jx, data, np.uint8, 3)
+    err = px.reshape(2160, 3840, 3).astype(np.float64) - img
+    assert 10 * np.log10(255.0 ** 2 / (err ** 2).mean()) > 36.0     # size-independent property: decodes to the source picture
+
+
+def test_batch_api_mixed_sizes_and_lane_strides(jx):
+    """Resident batch decode (include/jxl_hip.h JxlHipBatch*): frames of different sizes, several decode-thread packings,
+    repeated decodes of the same prepared batch (idempotence)."""
+    streams = []
+    for i, (w, h, mix) in enumerate([(320, 200, 2), (64, 64, 0), (600, 520, 1), (320, 200, 1), (1030, 270, 2)]):
+        streams.append(S.encode_vardct(S.synthetic_image(30 + i, w, h), seed=30 + i, strategy_mix=mix, epf_iters=i % 4, gab=i % 2))
+    refs = [O.decode(s).pixels("u8", 3) for s in streams]
+    for lf, hf in [(64, 64), (1, 1), (8, 16)]:
+        b = jx.BatchDecoder(0)
+        for s in streams:
+            b.add(s, "uint8", 3)
+        b.set_lane_stride(lf, hf)
+        b.prepare()
+        for _ in range(2):
+            b.decode()
+            b.finish()
+            for i, r in enumerate(refs):
+                assert np.array_equal(b.output(i), r), (lf, hf, i)
+        assert b.total_pixels == sum(len(r) // 3 for r in refs)

@@ -1,0 +1,134 @@
+"""CPU tests: the oracle against every golden the reference's fixtures offer and against the
+committed regression vectors.  The oracle is the parity checker for the HIP path, so it is pinned first."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, GOLDEN, fixture_bytes, read_png16
+import oracle_lib as O
+
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+def test_sample_jxl_equals_sample_png_rgba16():
+    """The reference's only pixel-exact assertion: jpegxl-rs/src/image.rs:169 (sample.jxl == sample.png as RGBA16)."""
+    dec = O.decode(fixture_bytes("sample.jxl"))
+    assert (dec.info.xsize, dec.info.ysize, dec.info.bits_per_sample, dec.info.alpha_bits) == (40, 50, 16, 16)
+    got = dec.image("u16", 4)
+    png = read_png16(os.path.join(FIXTURES, "sample.png"))
+    assert png.shape == (50, 40, 4) and png.dtype == np.uint16
+    assert np.array_equal(got, png)
+    assert hashlib.sha256(got.astype(">u2").tobytes()).hexdigest() == MANIFEST["reference_fixtures"]["sample.jxl"]["sha256_rgba16_be"]
+    assert tuple(got[0, 1]) == (61466, 64019, 63957, 65535)  # SURVEY App. C spot value
+
+
+def test_sample_jxl_u8_derivation():
+    """u8 output = round(v * 255 / 65535) = (v + 128) // 257 (no ties — SURVEY App. C)."""
+    dec = O.decode(fixture_bytes("sample.jxl"))
+    u16 = dec.image("u16", 4).astype(np.int64)
+    assert np.array_equal(dec.image("u8", 4), ((u16 + 128) // 257).astype(np.uint8))
+    assert np.array_equal(dec.image("u8", 3), ((u16[..., :3] + 128) // 257).astype(np.uint8))
+
+
+def test_bench_jxl_rgba8_hash():
+    """samples/bench.jxl (54 groups, weighted predictor, per-group palettes + RCT) == bench.png, via its raw hash."""
+    dec = O.decode(fixture_bytes("bench.jxl"))
+    assert (dec.info.xsize, dec.info.ysize) == (2122, 1433)
+    assert hashlib.sha256(dec.image("u8", 4).tobytes()).hexdigest() == MANIFEST["reference_fixtures"]["bench.jxl"]["sha256_rgba8"]
+
+
+def test_sample_jpg_jxl_coefficients_match_the_jpeg():
+    """VarDCT syntax / context model known answer: the quantised coefficients decoded from sample_jpg.jxl are those of
+    samples/sample.jpg (Huffman-decoded independently by tests/golden/make_golden.py), chroma after the integer
+    chroma-from-luma of SURVEY App. B.6."""
+    g = np.load(os.path.join(GOLDEN, "sample_jpg_coefficients.npz"))
+    coefs, qt = g["coefficients"].astype(np.int64), g["qtables"].astype(np.int64)
+    dec = O.decode(fixture_bytes("sample_jpg.jxl"), dump=True)
+    assert dec.info.have_container == 1 and dec.info.has_jbrd == 1 and dec.info.xyb_encoded == 0
+    bw, bh = 5, 7
+    planes = [dec.ints("coeff%d" % c)[: bw * bh * 64].reshape(bh, bw, 8, 8).transpose(0, 1, 3, 2).reshape(bh, bw, 64) for c in range(3)]  # libjxl layout = JPEG^T
+    Y, Cb, Cr = planes[1].astype(np.int64), planes[0].astype(np.int64), planes[2].astype(np.int64)
+    ytox, ytob = [int(v) for v in dec.ints("cfl")[:2]]
+    assert (ytox, ytob) == (-15, 47)
+    assert np.array_equal(Y[..., 1:], coefs[0][..., 1:])
+
+    def undo(res, f, qc):
+        out = res.copy()
+        ff = (f * 2048) // 84 if f >= 0 else -((-f * 2048) // 84)
+        for k in range(1, 64):
+            scale = (2048 * qt[0][k] // qc[k]) * ff
+            out[..., k] = res[..., k] + ((Y[..., k] * ((scale + 1024) >> 11) + 1024) >> 11)
+        return out
+    assert np.array_equal(undo(Cb, ytox, qt[1])[..., 1:], coefs[1][..., 1:])
+    assert np.array_equal(undo(Cr, ytob, qt[2])[..., 1:], coefs[2][..., 1:])
+    # LF = JPEG DC unchanged
+    lfq = [dec.ints("lfq%d" % c).reshape(bh, bw) for c in range(3)]
+    assert np.array_equal(lfq[1], coefs[0][..., 0]) and np.array_equal(lfq[0], coefs[1][..., 0]) and np.array_equal(lfq[2], coefs[2][..., 0])
+
+
+@pytest.mark.parametrize("name,feature", [("sample_grey.jxl", "non-regular frame"), ("2bit.jxl", "splines")])
+def test_unsupported_fixtures_fail_cleanly(name, feature):
+    """sample_grey.jxl needs patches + AFV, 2bit.jxl needs splines: 'next' rows of SURVEY §8f — must be rejected, not mis-decoded."""
+    with pytest.raises(O.OracleError) as e:
+        O.decode(fixture_bytes(name))
+    assert "unsupported" in str(e.value) and feature in str(e.value)
+
+
+def test_invalid_and_truncated_inputs():
+    for bad in (b"", b"\x00\x00", bytes(64), fixture_bytes("sample.jxl")[:100]):
+        with pytest.raises(O.OracleError):
+            O.decode(bad)
+
+
+@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct")])
+def test_vardct_regression_vectors(name):
+    """Committed synthesised streams: the oracle's float pipeline output is pinned by hash (regression, not libjxl parity)."""
+    m = MANIFEST[name]
+    data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+    assert hashlib.sha256(data).hexdigest() == m["sha256_stream"]
+    dec = O.decode(data)
+    assert (dec.info.xsize, dec.info.ysize) == (m["width"], m["height"])
+    assert hashlib.sha256(dec.pixels("u8", 3).tobytes()).hexdigest() == m["sha256_u8_rgb"]
+    assert hashlib.sha256(dec.pixels("f32", 3).tobytes()).hexdigest() == m["sha256_f32_rgb"]
+
+
+def test_modular_regression_vector():
+    m = MANIFEST["modular_300x280_rgba16_rct"]
+    data = open(os.path.join(GOLDEN, "modular_300x280_rgba16_rct.jxl"), "rb").read()
+    dec = O.decode(data)
+    assert hashlib.sha256(dec.image("u16", 4).astype("<u2").tobytes()).hexdigest() == m["sha256_u16_rgba_le"]
+
+
+def test_output_layout_rules():
+    """Buffer layout contract of decode.rs:387-434: stride rounded up to align, size = stride*(h-1)+w*C*bytes, big endian."""
+    dec = O.decode(fixture_bytes("sample.jxl"))
+    base = dec.pixels("f32", 3, big_endian=True, align=10)
+    assert len(base) == 480 * 49 + 40 * 3 * 4                    # tests/decode.rs:164 (stride 480 is a multiple of 10)
+    al = dec.pixels("u16", 3, align=64)
+    stride = (40 * 3 * 2 + 63) // 64 * 64
+    assert len(al) == stride * 49 + 40 * 3 * 2
+    le = dec.pixels("u16", 4).view("<u2")
+    be = dec.pixels("u16", 4, big_endian=True).view(">u2")
+    assert np.array_equal(le.astype(np.uint16), be.astype(np.uint16))
+
+
+def test_idct_matches_direct_formula():
+    """The recursive IDCT of the oracle against the defining sum f(n) = F0 + sqrt2 * sum F_k cos((2n+1) k pi / 2N)."""
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    for strategy, (R, Cc) in {0: (8, 8), 4: (16, 16), 6: (16, 8), 7: (8, 16), 5: (32, 32), 18: (64, 64)}.items():
+        sem = rng.standard_normal((R, Cc)).astype(np.float32)
+        stored = (sem.T if R >= Cc else sem).reshape(-1).copy()
+        out = np.zeros((R, Cc), np.float32)
+        O.lib().jxlo_idct(strategy, stored.ctypes.data, out.ctypes.data, Cc)
+
+        def basis(N):
+            n = np.arange(N)[:, None]; k = np.arange(N)[None, :]
+            b = np.cos((2 * n + 1) * k * np.pi / (2 * N)) * np.sqrt(2.0)
+            b[:, 0] = 1.0
+            return b
+        ref = basis(R) @ sem.astype(np.float64) @ basis(Cc).T
+        assert np.abs(out - ref).max() < 2e-4 * max(R, Cc)
