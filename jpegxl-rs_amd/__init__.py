@@ -96,7 +96,7 @@ def libjxl():
             "JxlHipBatchAddImage": (C.c_int, [vp, vp, sz]), "JxlHipBatchGetBasicInfo": (C.c_int, [vp, C.c_int, C.POINTER(JxlBasicInfo)]),
             "JxlHipBatchOutBufferSize": (C.c_int, [vp, C.c_int, C.POINTER(JxlPixelFormat), C.POINTER(sz)]),
             "JxlHipBatchSetOutput": (C.c_int, [vp, C.c_int, C.POINTER(JxlPixelFormat), vp]),
-            "JxlHipBatchSetLaneStride": (None, [vp, C.c_int, C.c_int]),
+            "JxlHipBatchSetLaneStride": (None, [vp, C.c_int, C.c_int]), "JxlHipBatchSetOption": (None, [vp, C.c_char_p, C.c_int]),
             "JxlHipBatchPrepare": (C.c_int, [vp, vp]), "JxlHipBatchDecode": (C.c_int, [vp, vp]),
             "JxlHipBatchDecodeTimed": (C.c_int, [vp, vp]), "JxlHipBatchFinish": (C.c_int, [vp, vp]),
             "JxlHipBatchCollectTimes": (C.c_int, [vp, C.POINTER(JxlHipStageTimes), C.POINTER(C.c_int)]),
@@ -490,6 +490,9 @@ class BatchDecoder:
 
     def set_lane_stride(self, lf=64, hf=64):
         libjxl().JxlHipBatchSetLaneStride(self._h, lf, hf)
+
+    def set_option(self, name: str, value: int):
+        libjxl().JxlHipBatchSetOption(self._h, name.encode(), int(value))
 
     def prepare(self, stream=None):
         self._chk(libjxl().JxlHipBatchPrepare(self._h, stream))

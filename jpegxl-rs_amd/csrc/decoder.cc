@@ -205,6 +205,7 @@ void Batch::Prepare(void* stream_v) {
   std::vector<WorkOffsets> wo(n);
   mod_plane_offsets_.assign(n, {});
   status_off_ = take((size_t)n * 4);
+  const size_t flags_off = take((size_t)n * 4);
   // coefficient buffers of all frames are contiguous so that one memset clears them
   coeff_off_ = Align(w);
   for (int i = 0; i < n; i++) {
@@ -270,11 +271,13 @@ void Batch::Prepare(void* stream_v) {
     f.stream_end_bitpos = (uint64_t*)(dwork_ + o.end_bitpos);
     if (p.has_global_tree) {
       f.tree = (const TreeNode*)(cbase + c.tree);
+      f.tree_nodes = (uint32_t)p.tree.nodes.size();
       f.mod_code = ViewCode(p.tree_code, cbase, c.mod_ctx, c.mod_cfg, c.mod_alias, c.mod_pc, c.mod_po, c.mod_ps);
     }
     f.uses_wp = p.tree.uses_wp; f.gwp = p.gwp;
     f.bcm = (const BlockCtxDev*)(cbase + c.bcm);
     f.status = (uint32_t*)(dwork_ + status_off_) + i;
+    f.frame_flags = (uint32_t*)(dwork_ + flags_off) + i;
     f.out = (uint8_t*)(e.out.device_ptr ? e.out.device_ptr : dwork_ + e.off_out);
     f.out_stride = e.out_stride; f.out_channels = e.out.num_channels; f.out_type = e.out.type; f.out_big_endian = e.out.big_endian;
     f.is_gray = e.ih.color_space == 1;
@@ -403,7 +406,7 @@ void Batch::Run(void* stream_v) {
     LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
-    LaunchIdct(dframes_, n, max_groups_, stream_v);
+    LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
     LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
   }
@@ -466,7 +469,7 @@ void Batch::RunTimed(void* stream_v) {
   rec(2);
   LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
   rec(3);
-  LaunchIdct(dframes_, n, max_groups_, stream_v);
+  LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
   rec(4);
   LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
   rec(5);

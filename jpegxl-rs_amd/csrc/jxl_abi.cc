@@ -269,6 +269,12 @@ JxlDecoderStatus JxlHipBatchCollectTimes(JxlHipBatch* h, JxlHipStageTimes* t, in
 JxlDecoderStatus JxlHipBatchFinish(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Finish(s)) }
 void* JxlHipBatchDeviceOutput(const JxlHipBatch* h, int i) { return h->b->device_output(i); }
 JxlDecoderStatus JxlHipBatchCopyOutput(JxlHipBatch* h, int i, void* dst, size_t size, void* s) { BATCH_TRY(h->b->CopyOutputToHost(i, dst, size, s)) }
+void JxlHipBatchSetOption(JxlHipBatch* h, const char* name, int value) {
+  std::string n(name);
+  if (n == "force_generic_idct") h->b->cfg.force_generic_idct = value;
+  else if (n == "hf_block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) h->b->cfg.hf_block_threads = value;
+  else if (n == "lds_code_budget" && value >= 0 && value <= 128 * 1024) h->b->cfg.lds_code_budget = value;
+}
 uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* h) { return h->b->total_pixels(); }
 uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* h) { return h->b->compressed_bytes(); }
 void JxlHipBatchStageBytes(const JxlHipBatch* h, uint64_t out[6]) { h->b->StageBytes(out); }

@@ -24,6 +24,7 @@ struct FrameDev {
   uint64_t* stream_end_bitpos;   // [0] = end of LfGroup stream (single-section), [1] = end of global modular stream
   // entropy codes / tree
   const TreeNode* tree;
+  uint32_t tree_nodes;
   DevCode mod_code;
   uint32_t uses_wp;
   WPHeader gwp;
@@ -77,12 +78,16 @@ struct FrameDev {
   uint64_t out_stride;            // bytes per row
   uint32_t out_channels, out_type /*0 u8 1 u16 2 f32 3 f16*/, out_big_endian;
   uint32_t* status;
+  uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
 };
 
 struct LaunchCfg {
   int lane_stride_lf = 64;   // lanes between active decode threads (64 = one stream per wave, 1 = one per lane)
   int lane_stride_hf = 64;
   int lane_stride_mod = 64;
+  int force_generic_idct = 0;        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames
+  int hf_block_threads = 512;        // threads per HF-decode block (streams per block = threads / lane_stride_hf)
+  int lds_code_budget = 48 * 1024;   // bytes of LDS the entropy-code tables (cfg, ctx map, alias) may take per block
 };
 
 void InitDeviceTables(void* stream);
@@ -91,7 +96,7 @@ void InitDeviceTables(void* stream);
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream);
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream);
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream);
-void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, void* stream);
+void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream);
 void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, int max_bw, int max_bh, bool any_gab, int max_epf, void* stream);
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, void* stream);
 // Modular stages

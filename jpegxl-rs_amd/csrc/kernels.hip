@@ -62,101 +62,468 @@ __device__ bool ReadGroupHeader(BitReader& br, GroupHeaderD& gh) {
 }
 
 // =====================================================================================================================
-// K_lf: one decode thread per LF group — LF coefficients (3 channels, order Y,X,B) + HF metadata, then varblock placement
+// Fast serial entropy decode: LDS-resident tables + prefetching bit reader.
+// Pointers loaded from the frame descriptor are generic, which would make every access a FLAT instruction (LDS and
+// global sharing both wait counters).  The helpers below pin the address space: LdG/StG = global_load/global_store,
+// LdS = ds_read at a byte offset of the block's dynamic LDS.
 // =====================================================================================================================
-__global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride) {
+extern __shared__ __align__(16) uint8_t g_dyn_lds[];
+
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T> __device__ __forceinline__ T LdG(const T* p) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+template <> __device__ __forceinline__ uint4 LdG<uint4>(const uint4* p) {
+  typedef uint32_t __attribute__((ext_vector_type(4))) v4;
+  const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <typename T> __device__ __forceinline__ void StG(T* p, T v) {
+  *reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p)) = v;
+}
+#else   // host pass of hipcc only needs the declarations to parse
+template <typename T> __device__ __forceinline__ T LdG(const T* p) { return *p; }
+template <typename T> __device__ __forceinline__ void StG(T* p, T v) { *p = v; }
+#endif
+template <typename T> __device__ __forceinline__ T LdS(uint32_t byte_off) { return *reinterpret_cast<const T*>(g_dyn_lds + byte_off); }
+template <typename T> __device__ __forceinline__ void StS(uint32_t byte_off, T v) { *reinterpret_cast<T*>(g_dyn_lds + byte_off) = v; }
+constexpr uint32_t kNotInLds = 0xFFFFFFFFu;
+
+// Bit reader whose next 32-bit word is always already in flight: the refill never waits on global-memory latency.
+struct BitReaderP {
+  const uint32_t* words;
+  uint32_t wpos, wend, nextw;
+  uint64_t buf;
+  int avail;
+  __device__ __forceinline__ uint32_t Load(uint32_t i) const { return i < wend ? LdG(words + i) : 0u; }
+  __device__ __forceinline__ void Init(const uint8_t* base, uint64_t bit_pos, uint64_t byte_end) {
+    words = reinterpret_cast<const uint32_t*>(base);
+    wpos = (uint32_t)(bit_pos >> 5);
+    wend = (uint32_t)((byte_end + 3) >> 2);
+    buf = (uint64_t)Load(wpos) | ((uint64_t)Load(wpos + 1) << 32);
+    wpos += 2;
+    nextw = Load(wpos);
+    avail = 64;
+    const int skip = (int)(bit_pos & 31);
+    buf >>= skip; avail -= skip;
+    Refill();
+  }
+  __device__ __forceinline__ void Refill() {
+    if (avail <= 32) {
+      buf |= (uint64_t)nextw << avail;
+      avail += 32;
+      wpos++;
+      nextw = Load(wpos);
+    }
+  }
+  __device__ __forceinline__ uint32_t Read(int n) {  // n <= 32
+    Refill();
+    const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
+    buf >>= n; avail -= n;
+    return v;
+  }
+  __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)wpos * 32 - (uint64_t)avail; }
+};
+
+// Entropy-code tables as seen by the fast decoders: LDS byte offsets when staged, global pointers otherwise.
+struct FastCode {
+  const uint8_t* ctx_map_g;
+  const uint32_t* cfg_g;
+  const uint64_t* alias_g;
+  uint32_t ctx_map_off, cfg_off, alias_off;   // kNotInLds if the table stayed in global memory
+  uint32_t log_alpha;
+  __device__ __forceinline__ uint32_t Cluster(uint32_t ctx) const { return ctx_map_off != kNotInLds ? LdS<uint8_t>(ctx_map_off + ctx) : LdG(ctx_map_g + ctx); }
+  __device__ __forceinline__ uint32_t Cfg(uint32_t cl) const { return cfg_off != kNotInLds ? LdS<uint32_t>(cfg_off + cl * 4) : LdG(cfg_g + cl); }
+  __device__ __forceinline__ uint64_t Alias(uint32_t i) const { return alias_off != kNotInLds ? LdS<uint64_t>(alias_off + i * 8) : LdG(alias_g + i); }
+};
+
+__device__ __forceinline__ uint32_t FastSymbol(BitReaderP& br, uint32_t& state, const FastCode& c, uint32_t cluster) {
+  const uint32_t la = c.log_alpha;
+  const uint32_t res = state & 0xFFF;
+  const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
+  const uint64_t e = c.Alias((cluster << la) + i);
+  const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+  const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+  const bool hit = pos >= cutoff;
+  const uint32_t sym = hit ? right : i;
+  const uint32_t off = hit ? offs1 + pos : pos;
+  const uint32_t freq = hit ? freq1 : freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | br.Read(16);
+  return sym;
+}
+__device__ __forceinline__ uint32_t FastHybrid(BitReaderP& br, uint32_t& state, const FastCode& c, uint32_t cluster) {
+  const uint32_t cfg = c.Cfg(cluster);
+  uint32_t tok = FastSymbol(br, state, c, cluster);
+  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+  const uint32_t split = 1u << split_exp;
+  if (tok < split) return tok;
+  uint32_t nbits = split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb));
+  nbits &= 31;
+  const uint32_t low = tok & ((1u << lsb) - 1);
+  tok >>= lsb;
+  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
+  const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+  return (((hi << nbits) | bits) << lsb) | low;
+}
+
+// Cooperative copy of an entropy code into LDS (all threads of the block) starting at byte offset `base`; tables
+// that do not fit in [base, base + budget) stay in global memory.  Returns the bytes used.
+__device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget, bool with_ctx_map) {
+  uint32_t used = 0;
+  fc.log_alpha = g.log_alpha;
+  fc.ctx_map_g = g.ctx_map; fc.cfg_g = g.cfg; fc.alias_g = g.alias;
+  fc.ctx_map_off = fc.cfg_off = fc.alias_off = kNotInLds;
+  const uint32_t cfg_bytes = (g.num_clusters * 4 + 15) & ~15u;
+  if (used + cfg_bytes <= budget) {
+    for (uint32_t i = threadIdx.x; i < g.num_clusters; i += blockDim.x) StS<uint32_t>(base + used + i * 4, LdG(g.cfg + i));
+    fc.cfg_off = base + used; used += cfg_bytes;
+  }
+  if (with_ctx_map) {
+    const uint32_t n = (g.num_ctx + 15) & ~15u;
+    if (used + n <= budget) {
+      for (uint32_t i = threadIdx.x; i < g.num_ctx; i += blockDim.x) StS<uint8_t>(base + used + i, LdG(g.ctx_map + i));
+      fc.ctx_map_off = base + used; used += n;
+    }
+  }
+  const uint32_t n_alias = g.num_clusters << g.log_alpha;
+  if (used + n_alias * 8 <= budget) {
+    for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) StS<uint64_t>(base + used + i * 8, LdG(g.alias + i));
+    fc.alias_off = base + used; used += n_alias * 8;
+  }
+  return used;
+}
+
+// ---- Modular channel decode, cooperative version ------------------------------------------------------------------------
+constexpr int kLdsTreeMax = 1024;   // nodes copied to LDS (16 KiB); larger trees are walked in global memory
+constexpr uint32_t kLutOff = 0, kWorkOff = 2048, kTreeOff = 3072;
+constexpr uint32_t kModLdsFixed = kTreeOff + kLdsTreeMax * 16;
+struct ModTables {
+  const TreeNode* tree_g;
+  bool tree_in_lds;         // LDS copy at kTreeOff (leaves rewritten: a = predictor | cluster << 8)
+  FastCode code;
+  __device__ __forceinline__ TreeNode Node(uint32_t i) const {
+    if (tree_in_lds) {
+      const uint4 v = LdS<uint4>(kTreeOff + i * 16);
+      return TreeNode{(int32_t)v.x, (int32_t)v.y, v.z, v.w};
+    }
+    const uint4 v = LdG(reinterpret_cast<const uint4*>(tree_g + i));
+    return TreeNode{(int32_t)v.x, (int32_t)v.y, v.z, v.w};
+  }
+};
+
+__device__ __forceinline__ int32_t PropValue(int p, int chan, uint32_t stream_id, int x, int y, int32_t W, int32_t N, int32_t NW, int32_t NE, int32_t NN, int32_t WW,
+                                             int32_t prev9, int32_t wp_err) {
+  switch (p) {
+    case 0: return chan;
+    case 1: return (int32_t)stream_id;
+    case 2: return y;
+    case 3: return x;
+    case 4: return N < 0 ? (int32_t)(0u - (uint32_t)N) : N;
+    case 5: return W < 0 ? (int32_t)(0u - (uint32_t)W) : W;
+    case 6: return N;
+    case 7: return W;
+    case 8: return (int32_t)((uint32_t)W - (uint32_t)prev9);
+    case 9: return (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+    case 10: return (int32_t)((uint32_t)W - (uint32_t)NW);
+    case 11: return (int32_t)((uint32_t)NW - (uint32_t)N);
+    case 12: return (int32_t)((uint32_t)N - (uint32_t)NE);
+    case 13: return (int32_t)((uint32_t)N - (uint32_t)NN);
+    case 14: return (int32_t)((uint32_t)W - (uint32_t)WW);
+    default: return wp_err;
+  }
+}
+
+// Prediction in 32-bit wrap-around arithmetic where that is exact (the final sample is truncated to int32 anyway and
+// the clamped gradient only uses N+W-NW when it lies between N and W), 64-bit for the averaging predictors.
+__device__ __forceinline__ int32_t Predict(uint32_t predictor, int32_t W, int32_t N, int32_t NW, int32_t NE, int32_t NN, int32_t WW, int32_t NEE, int64_t wp_pred) {
+  switch (predictor) {
+    case 0: return 0;
+    case 1: return W;
+    case 2: return N;
+    case 3: return (int32_t)(((int64_t)W + N) / 2);
+    case 4: { const int64_t pp = (int64_t)W + N - NW; return Abs64(pp - W) < Abs64(pp - N) ? W : N; }
+    case 5: { const int32_t m = min(N, W), M = max(N, W); return NW < m ? M : (NW > M ? m : (int32_t)((uint32_t)N + (uint32_t)W - (uint32_t)NW)); }
+    case 6: return (int32_t)((wp_pred + 3) >> 3);
+    case 7: return NE;
+    case 8: return NW;
+    case 9: return WW;
+    case 10: return (int32_t)(((int64_t)W + NW) / 2);
+    case 11: return (int32_t)(((int64_t)N + NW) / 2);
+    case 12: return (int32_t)(((int64_t)N + NE) / 2);
+    default: return (int32_t)((6 * (int64_t)N - 2 * (int64_t)NN + 7 * (int64_t)W + WW + NEE + 3 * (int64_t)NE + 8) / 16);
+  }
+}
+
+// All threads of the block call this (contains barriers).  Thread 0 decodes; the others help build the LUT.
+// Semantics identical to DecodeModularChannel (jxl_dev.h).
+__device__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
+  if (ch.w == 0 || ch.h == 0) return;
+  // ---- thread 0: resolve static properties (channel, stream id) and analyse the remaining subtree
+  if (threadIdx.x == 0) {
+    uint32_t pos = 0;
+    TreeNode n = T.Node(0);
+    while (n.prop == 0 || n.prop == 1) {
+      const int32_t v = n.prop == 0 ? chan : (int32_t)mc.stream_id;
+      pos = v > n.val ? n.a : n.b;
+      n = T.Node(pos);
+    }
+    int mode = 1, prop = -1, count = 0;
+    int sp = 0;   // iterative DFS with a bounded stack at kWorkOff + 32
+    StS<int>(kWorkOff + 32 + 4 * sp++, (int)pos);
+    while (sp > 0 && mode == 1) {
+      const TreeNode m = T.Node((uint32_t)LdS<int>(kWorkOff + 32 + 4 * --sp));
+      if (++count > 600) { mode = 0; break; }
+      if (m.prop < 0) { if ((m.a & 0xFF) == 6) mode = 0; continue; }        // weighted predictor: general path
+      if (m.prop == 15 || m.prop >= 16 || m.prop <= 1) { mode = 0; break; }
+      if (prop < 0) prop = m.prop; else if (prop != m.prop) { mode = 0; break; }
+      if (m.val < -512 || m.val > 510 || sp + 2 > 200) { mode = 0; break; }
+      StS<int>(kWorkOff + 32 + 4 * sp++, (int)m.a); StS<int>(kWorkOff + 32 + 4 * sp++, (int)m.b);
+    }
+    if (!T.tree_in_lds) mode = 0;
+    StS<int>(kWorkOff + 0, mode); StS<int>(kWorkOff + 4, prop); StS<int>(kWorkOff + 8, (int)pos);
+  }
+  __syncthreads();
+  const int mode = LdS<int>(kWorkOff + 0), prop = LdS<int>(kWorkOff + 4);
+  const uint32_t subroot = (uint32_t)LdS<int>(kWorkOff + 8);
+  if (mode == 1) {
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+      const int32_t v = i - 512;
+      uint32_t pos = subroot;
+      TreeNode n = T.Node(pos);
+      while (n.prop >= 0) { pos = v > n.val ? n.a : n.b; n = T.Node(pos); }
+      StS<uint16_t>(kLutOff + 2 * i, (uint16_t)pos);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int w = ch.w, h = ch.h;
+    const FastCode& code = T.code;
+    WPState wps;
+    const bool use_wp = mc.uses_wp != 0 && mode == 0;
+    if (use_wp) wps.Init(mc.wp_scratch, w);
+    for (int y = 0; y < h; y++) {
+      int32_t* p = ch.data + (size_t)y * ch.stride;
+      const int32_t* pn = p - ch.stride;
+      const int32_t* pnn = pn - ch.stride;
+      // sliding window over the row above (loads issued ahead of use) and the row above that
+      int32_t up1 = 0, up2 = 0, up3 = 0, up0 = 0, nn1 = 0, nn2 = 0;
+      if (y > 0) { up1 = LdG(pn); up2 = w > 1 ? LdG(pn + 1) : 0; up3 = w > 2 ? LdG(pn + 2) : 0; }
+      if (y > 1) { nn1 = LdG(pnn); nn2 = w > 1 ? LdG(pnn + 1) : 0; }
+      int32_t left = 0, left2 = 0, prev9 = 0;
+      for (int x = 0; x < w; x++) {
+        const int32_t up4 = (y > 0 && x + 3 < w) ? LdG(pn + x + 3) : 0;     // prefetch for iteration x+1
+        const int32_t nn3 = (y > 1 && x + 2 < w) ? LdG(pnn + x + 2) : 0;
+        const int32_t W = x ? left : (y ? up1 : 0);
+        const int32_t N = y ? up1 : W;
+        const int32_t NW = (x && y) ? up0 : W;
+        const int32_t NE = (x + 1 < w && y) ? up2 : N;
+        const int32_t WW = x > 1 ? left2 : W;
+        const int32_t NN = y > 1 ? nn1 : N;
+        const int32_t NEE = (x + 2 < w && y) ? up3 : NE;
+        int64_t wp_pred = 0;
+        int32_t wp_err = 0;
+        if (use_wp) wp_pred = wps.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
+        TreeNode n;
+        if (mode == 1) {
+          int32_t v = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
+          v = v < -512 ? -512 : (v > 511 ? 511 : v);
+          n = T.Node(LdS<uint16_t>(kLutOff + 2 * (uint32_t)(v + 512)));
+        } else {
+          uint32_t pos = subroot;
+          n = T.Node(pos);
+          while (n.prop >= 0) {
+            const int32_t v = PropValue(n.prop & 15, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, wp_err);
+            pos = v > n.val ? n.a : n.b;
+            n = T.Node(pos);
+          }
+        }
+        prev9 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+        const uint32_t predictor = n.a & 0xFF;
+        const uint32_t cluster = T.tree_in_lds ? (n.a >> 8) : code.Cluster(n.a >> 8);
+        const int32_t guess = Predict(predictor, W, N, NW, NE, NN, WW, NEE, wp_pred);
+        const uint32_t tok = FastHybrid(br, state, code, cluster);
+        const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) * n.b + (uint32_t)n.val + (uint32_t)guess);
+        StG(p + x, val);
+        if (use_wp) wps.Update(val, x, y);
+        left2 = left; left = val;
+        up0 = up1; up1 = up2; up2 = up3; up3 = up4;
+        nn1 = nn2; nn2 = nn3;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Stages tree + code into LDS for the modular decoders.  The block's dynamic LDS must hold kModLdsFixed + code budget.
+__device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTables& T, uint32_t lds_bytes) {
+  const uint32_t budget = lds_bytes > kModLdsFixed ? lds_bytes - kModLdsFixed : 0;
+  StageCode(f.mod_code, T.code, kModLdsFixed, budget, /*with_ctx_map=*/false);
+  T.tree_g = f.tree;
+  T.tree_in_lds = num_tree_nodes <= (uint32_t)kLdsTreeMax;
+  if (T.tree_in_lds) {
+    for (uint32_t i = threadIdx.x; i < num_tree_nodes; i += blockDim.x) {
+      uint4 v = LdG(reinterpret_cast<const uint4*>(f.tree + i));
+      if ((int32_t)v.x < 0) v.z = (v.z & 0xFF) | ((uint32_t)LdG(f.mod_code.ctx_map + (v.z >> 8)) << 8);   // leaf: context -> cluster
+      StS<uint4>(kTreeOff + i * 16, v);
+    }
+  }
+  __syncthreads();
+}
+
+// =====================================================================================================================
+// K_lf: one 64-thread block per LF group — LF coefficients (3 channels, order Y,X,B) + HF metadata, varblock placement
+// =====================================================================================================================
+__global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid % lane_stride) return;
-  const uint32_t g = tid / lane_stride;
+  const uint32_t g = blockIdx.x;
   if (g >= f.num_lf_groups) return;
   const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
   const uint32_t bx0 = gx * 256, by0 = gy * 256;
   const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
-  BitReader br;
+  ModTables T;
+  StageModular(f, f.tree_nodes, T, lds_bytes);
+  BitReaderP br;
   if (f.single_section) br.Init(f.cs, f.lf_start_bitpos, f.cs_size);
   else { const uint64_t off = f.sec_off[1 + g]; br.Init(f.cs, off * 8, off + f.sec_size[1 + g]); }
   const uint64_t limit = f.single_section ? f.cs_size * 8 : (f.sec_off[1 + g] + f.sec_size[1 + g]) * 8;
+  __shared__ int s_fail;
+  __shared__ GroupHeaderD s_gh;
+  __shared__ uint32_t s_u[4];
+  if (threadIdx.x == 0) s_fail = 0;
 
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp;
   mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride;
+  uint32_t state = 0;
+  int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
 
   // ---- LF coefficients
-  const uint32_t extra_precision = br.Read(2);
-  GroupHeaderD gh;
-  if (!ReadGroupHeader(br, gh) || !gh.use_global_tree || gh.ntransforms != 0) { SetError(f, kErrUnsupported); return; }
-  mc.wp = gh.wp; mc.stream_id = 1 + g;
+  if (threadIdx.x == 0) {
+    s_u[0] = br.Read(2);  // extra_precision
+    BitReader tmp;        // GroupHeader parsing reuses the generic reader type: re-sync positions around it
+    tmp.Init(f.cs, br.BitPos(), f.cs_size);
+    if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree || s_gh.ntransforms != 0) { SetError(f, kErrUnsupported); s_fail = 1; }
+    br.Init(f.cs, tmp.BitPos(), f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g]);
+    state = br.Read(32);
+    scratch[0] = (int32_t)s_u[0];
+  }
+  __syncthreads();
+  if (s_fail) return;
+  mc.wp = s_gh.wp; mc.stream_id = 1 + g;
   {
-    AnsReader ans; ans.Init(br, f.mod_code);
     const int chan_to_plane[3] = {1, 0, 2};  // stream channel order is Y, X, B
     for (int c = 0; c < 3; c++) {
       ChannelDesc ch;
       ch.data = f.lfq[chan_to_plane[c]] + (size_t)by0 * f.bw + bx0;
       ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)f.bw;
-      DecodeModularChannel(br, ans, mc, ch, c);
+      DecodeChannelCoop(br, state, T, mc, ch, c);
     }
-    if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); return; }
   }
-  // extra_precision is folded into the dequant factor by LfPost: store it in the scratch header
-  int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
-  scratch[0] = (int32_t)extra_precision;
   // ---- HF metadata: 4 channels {ytox, ytob, (strategy,hf_mul-1) x nb_blocks, sharpness}
-  const uint32_t nb_blocks = 1 + br.Read(CeilLog2D(gbw * gbh));
-  if (!ReadGroupHeader(br, gh) || !gh.use_global_tree || gh.ntransforms != 0) { SetError(f, kErrUnsupported); return; }
-  mc.wp = gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
+  if (threadIdx.x == 0) {
+    if (state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
+    s_u[1] = 1 + br.Read(CeilLog2D(gbw * gbh));
+    BitReader tmp;
+    tmp.Init(f.cs, br.BitPos(), f.cs_size);
+    if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree || s_gh.ntransforms != 0) { SetError(f, kErrUnsupported); s_fail = 1; }
+    br.Init(f.cs, tmp.BitPos(), f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g]);
+    state = br.Read(32);
+  }
+  __syncthreads();
+  if (s_fail) return;
+  const uint32_t nb_blocks = s_u[1];
+  mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
   const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
   int32_t* m_ytox = scratch + 16;
   int32_t* m_ytob = m_ytox + mcw * mch;
   int32_t* m_blk = m_ytob + mcw * mch;
   int32_t* m_sharp = m_blk + 2 * nb_blocks;
   {
-    AnsReader ans; ans.Init(br, f.mod_code);
     ChannelDesc ch;
-    ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; DecodeModularChannel(br, ans, mc, ch, 0);
-    ch.data = m_ytob; DecodeModularChannel(br, ans, mc, ch, 1);
-    ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeModularChannel(br, ans, mc, ch, 2);
-    ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeModularChannel(br, ans, mc, ch, 3);
-    if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); return; }
+    ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; DecodeChannelCoop(br, state, T, mc, ch, 0);
+    ch.data = m_ytob; DecodeChannelCoop(br, state, T, mc, ch, 1);
+    ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeChannelCoop(br, state, T, mc, ch, 2);
+    ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeChannelCoop(br, state, T, mc, ch, 3);
   }
-  if (br.BitPos() > limit) { SetError(f, kErrOverrun); return; }
-  if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
-  // ---- chroma-from-luma maps
-  for (uint32_t y = 0; y < mch; y++) for (uint32_t x = 0; x < mcw; x++) {
-    const int a = m_ytox[y * mcw + x], b = m_ytob[y * mcw + x];
-    if (a < -128 || a > 127 || b < -128 || b > 127) { SetError(f, kErrBadValue); return; }
+  if (threadIdx.x == 0) {
+    if (state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
+    else if (br.BitPos() > limit) { SetError(f, kErrOverrun); s_fail = 1; }
+    else if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
+  }
+  __syncthreads();
+  if (s_fail) return;
+  // make thread 0's global stores (metadata channels) visible to the whole block
+  __threadfence_block();
+  // ---- chroma-from-luma maps (all threads)
+  for (uint32_t i = threadIdx.x; i < mcw * mch; i += blockDim.x) {
+    const uint32_t y = i / mcw, x = i % mcw;
+    const int a = m_ytox[i], b = m_ytob[i];
+    if (a < -128 || a > 127 || b < -128 || b > 127) { SetError(f, kErrBadValue); s_fail = 1; }
     const size_t o = (size_t)(gy * 32 + y) * f.cw + gx * 32 + x;
     f.ytox[o] = (int8_t)a; f.ytob[o] = (int8_t)b;
   }
-  // ---- varblock placement (raster order, first not-yet-covered block); coefficient offsets per 256x256 group
-  for (uint32_t y = 0; y < gbh; y++) for (uint32_t x = 0; x < gbw; x++) f.blk_info[(size_t)(by0 + y) * f.bw + bx0 + x] = 0xFFFFFFFFu;
-  uint32_t goff[64];
-  for (int i = 0; i < 64; i++) goff[i] = 0;
-  uint32_t num = 0;
-  for (uint32_t y = 0; y < gbh; y++) {
-    for (uint32_t x = 0; x < gbw; x++) {
-      const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
-      if (f.blk_info[o] != 0xFFFFFFFFu) continue;
-      if (num >= nb_blocks) { SetError(f, kErrVarblock); return; }
-      const int32_t s = m_blk[num], q = m_blk[nb_blocks + num];
-      num++;
-      if (s < 0 || s >= 27 || q < 0 || q > 255) { SetError(f, kErrBadValue); return; }
-      if (s >= 14 && s <= 17) { SetError(f, kErrUnsupported); return; }  // AFV
-      const uint32_t cx = CoveredX(s), cy = CoveredY(s);
-      if (cx > 8 || cy > 8) { SetError(f, kErrUnsupported); return; }  // transforms larger than 64x64
-      if (x + cx > gbw || y + cy > gbh || (x % 32) + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); return; }
-      const uint32_t gi = (y / 32) * 8 + (x / 32);
-      f.coef_off[o] = goff[gi];
-      goff[gi] += cx * cy * 64;
-      for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++) {
-        const size_t oo = o + (size_t)iy * f.bw + ix;
-        if (f.blk_info[oo] != 0xFFFFFFFFu) { SetError(f, kErrVarblock); return; }
-        const int32_t sh = m_sharp[(y + iy) * gbw + x + ix];
-        if (sh < 0 || sh > 7) { SetError(f, kErrBadValue); return; }
-        f.blk_info[oo] = PackBlockInfo((uint32_t)s, ix == 0 && iy == 0, (uint32_t)q, ix, iy, (uint32_t)sh);
+  // ---- varblock placement (raster order, first not-yet-covered block) with an LDS coverage bitmap; coefficient
+  // offsets per 256x256 group.  Blocks never cross a 32-block boundary, hence never a 64-bit word of the bitmap.
+  __shared__ unsigned long long s_cover[256 * 4];
+  for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
+    const uint32_t y = i >> 2, wx = (i & 3) * 64;
+    unsigned long long m = 0;   // bits outside the LF group are pre-set
+    if (y >= gbh || wx >= gbw) m = ~0ull;
+    else if (gbw - wx < 64) m = ~0ull << (gbw - wx);
+    s_cover[i] = m;
+  }
+  __syncthreads();
+  if (s_fail) return;
+  if (threadIdx.x == 0) {
+    uint32_t goff[64];
+    for (int i = 0; i < 64; i++) goff[i] = 0;
+    uint32_t num = 0;
+    int32_t s_next = LdG(m_blk), q_next = LdG(m_blk + nb_blocks);
+    bool bad = false;
+    for (uint32_t y = 0; y < gbh && !bad; y++) {
+      for (uint32_t wi = 0; wi < 4 && !bad; wi++) {
+        while (true) {
+          const unsigned long long cov = s_cover[y * 4 + wi];
+          if (cov == ~0ull) break;
+          const uint32_t x = wi * 64 + (uint32_t)__ffsll((long long)~cov) - 1;
+          if (num >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
+          const int32_t s = s_next, q = q_next;
+          num++;
+          if (num < nb_blocks) { s_next = LdG(m_blk + num); q_next = LdG(m_blk + nb_blocks + num); }
+          if (s < 0 || s >= 27 || q < 0 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }
+          if ((s >= 14 && s <= 17)) { SetError(f, kErrUnsupported); bad = true; break; }  // AFV
+          const uint32_t cx = CoveredX(s), cy = CoveredY(s);
+          if (cx > 8 || cy > 8) { SetError(f, kErrUnsupported); bad = true; break; }      // transforms larger than 64x64
+          if (x + cx > gbw || y + cy > gbh || (x % 32) + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
+          const unsigned long long bits = ((cx == 64 ? 0ull : (1ull << cx)) - 1ull) << (x & 63);
+          for (uint32_t iy = 0; iy < cy; iy++) {
+            unsigned long long& wv = s_cover[(y + iy) * 4 + wi];
+            if (wv & bits) { SetError(f, kErrVarblock); bad = true; }
+            wv |= bits;
+          }
+          if (bad) break;
+          if ((x % 8) + cx > 8 || (y % 8) + cy > 8) *f.frame_flags = 1;   // varblock not contained in a 64x64 tile: generic IDCT
+          const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
+          const uint32_t gi = (y / 32) * 8 + (x / 32);
+          StG(f.coef_off + o, goff[gi]);
+          goff[gi] += cx * cy * 64;
+          for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++)
+            StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo((uint32_t)s, ix == 0 && iy == 0, (uint32_t)q, ix, iy, 0));
+        }
       }
     }
+    if (bad) s_fail = 1;
+  }
+  __syncthreads();
+  if (s_fail) return;
+  __threadfence_block();
+  // ---- merge the sharpness map into the block info words (all threads)
+  for (uint32_t i = threadIdx.x; i < gbw * gbh; i += blockDim.x) {
+    const int32_t sh = m_sharp[i];
+    if (sh < 0 || sh > 7) { SetError(f, kErrBadValue); continue; }
+    f.blk_info[(size_t)(by0 + i / gbw) * f.bw + bx0 + i % gbw] |= (uint32_t)sh << 26;
   }
 }
 
@@ -278,9 +645,14 @@ __device__ static const uint8_t kNzCtx[64] = {0,   0,   31,  62,  62,  93,  93, 
                                               180, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
                                               206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206};
 
-__global__ __launch_bounds__(64) void HfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride) {
+__global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
+  // ---- stage the AC entropy code (cfg, context map, alias tables if they fit) and the two context LUTs into LDS
+  FastCode code;
+  if (threadIdx.x < 64) { StS<uint8_t>(threadIdx.x, kNzCtx[threadIdx.x]); StS<uint8_t>(64 + threadIdx.x, kFreqCtx[threadIdx.x]); }
+  StageCode(f.ac_code, code, 128, lds_bytes > 128 ? lds_bytes - 128 : 0, /*with_ctx_map=*/true);
+  __syncthreads();
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid % lane_stride) return;
   const uint32_t g = tid / lane_stride;
@@ -288,7 +660,7 @@ __global__ __launch_bounds__(64) void HfDecodeKernel(const FrameDev* __restrict_
   const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
   const uint32_t bx0 = gx * 32, by0 = gy * 32;
   const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
-  BitReader br;
+  BitReaderP br;
   uint64_t limit;
   if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
   else { const uint32_t si = 2 + f.num_lf_groups + g; const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
@@ -297,15 +669,27 @@ __global__ __launch_bounds__(64) void HfDecodeKernel(const FrameDev* __restrict_
   const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
   if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); return; }
   const uint32_t ctx_offset = 495u * nctx * preset;
-  const DevCode& code = f.ac_code;
-  AnsReader ans; ans.Init(br, code);
-  uint8_t nzrow[3][32];
-  for (int c = 0; c < 3; c++) for (int i = 0; i < 32; i++) nzrow[c][i] = 0;
+  uint32_t state = br.Read(32);
+  uint32_t nzrow[3][8];   // 32 bytes per channel packed in 8 words (kept in registers)
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) nzrow[c][i] = 0;
+  auto nz_get = [&](int c, uint32_t x) -> uint32_t {
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if ((x >> 2) == (uint32_t)i) w = nzrow[c][i];
+    return (w >> ((x & 3) * 8)) & 0xFF;
+  };
+  auto nz_set = [&](int c, uint32_t x, uint32_t v) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) if ((x >> 2) == (uint32_t)i) nzrow[c][i] = (nzrow[c][i] & ~(0xFFu << ((x & 3) * 8))) | (v << ((x & 3) * 8));
+  };
   int32_t* cbase[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
   for (uint32_t by = 0; by < gbh; by++) {
     for (uint32_t bx = 0; bx < gbw; bx++) {
       const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
-      const uint32_t info = f.blk_info[o];
+      const uint32_t info = LdG(f.blk_info + o);
       if (!BI_First(info)) continue;
       const uint32_t s = BI_Strategy(info);
       const uint32_t cx = CoveredX(s), cy = CoveredY(s), covered = cx * cy;
@@ -330,32 +714,35 @@ __global__ __launch_bounds__(64) void HfDecodeKernel(const FrameDev* __restrict_
         idx = idx * bcm.num_lf_ctxs + lf_idx;
         const uint32_t block_ctx = bcm.ctx_map[idx];
         uint32_t pred;
-        if (bx == 0) pred = by == 0 ? 32 : nzrow[c][bx];
-        else if (by == 0) pred = nzrow[c][bx - 1];
-        else pred = (nzrow[c][bx] + nzrow[c][bx - 1] + 1) / 2;
+        if (bx == 0) pred = by == 0 ? 32 : nz_get(c, bx);
+        else if (by == 0) pred = nz_get(c, bx - 1);
+        else pred = (nz_get(c, bx) + nz_get(c, bx - 1) + 1) / 2;
         const uint32_t pc = pred > 64 ? 64 : pred;
         const uint32_t nz_ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
-        uint32_t nzeros = ReadHybridUint(br, ans, code, nz_ctx);
+        uint32_t nzeros = FastHybrid(br, state, code, code.Cluster(nz_ctx));
         if (nzeros + covered > size) { SetError(f, kErrNzeros); return; }
-        const uint8_t nzm = (uint8_t)((nzeros + covered - 1) >> l2);
-        for (uint32_t ix = 0; ix < cx; ix++) nzrow[c][bx + ix] = nzm;
+        const uint32_t nzm = (nzeros + covered - 1) >> l2;
+        for (uint32_t ix = 0; ix < cx; ix++) nz_set(c, bx + ix, nzm);
         const uint32_t histo = ctx_offset + 37 * nctx + 458 * block_ctx;
         const uint16_t* order = f.orders[ord * 3 + c];
         int32_t* blk = cbase[c] + coff;
         uint32_t prev = nzeros > size / 16 ? 0 : 1;
+        uint32_t next_pos = LdG(order + covered);         // coefficient position for k, loaded one step ahead
         for (uint32_t k = covered; k < size && nzeros != 0; k++) {
+          const uint32_t pos = next_pos;
+          next_pos = k + 1 < size ? LdG(order + k + 1) : 0;
           const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
-          const uint32_t ctx = histo + ((uint32_t)kNzCtx[nzl] + kFreqCtx[kk]) * 2 + prev;
-          const uint32_t u = ReadHybridUint(br, ans, code, ctx);
+          const uint32_t ctx = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + kk)) * 2 + prev;
+          const uint32_t u = FastHybrid(br, state, code, code.Cluster(ctx));
           prev = u != 0;
           nzeros -= prev;
-          if (u) blk[order[k]] = UnpackSigned(u);
+          if (u) StG(blk + pos, UnpackSigned(u));
         }
         if (nzeros != 0) { SetError(f, kErrNzeros); return; }
       }
     }
   }
-  if (!ans.FinalOk(code)) { SetError(f, kErrAnsFinalState); return; }
+  if (state != 0x130000u) { SetError(f, kErrAnsFinalState); return; }
   if (br.BitPos() > limit) { SetError(f, kErrOverrun); return; }
 }
 
@@ -518,9 +905,9 @@ __device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t
 
 __device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || s == 12 || s == 13; }
 
-__global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ frames) {
+__global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ frames, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
+  if (f.is_modular || (*f.frame_flags == 0 && !force_generic)) return;   // regular frames take IdctTileKernel
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
@@ -590,6 +977,139 @@ __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ f
         case 32: ColPass<32>(col0, stride); break;
         default: ColPass<64>(col0, stride); break;
       }
+    }
+  }
+}
+
+// ---- fast path: one 256-thread workgroup per 64x64-pixel tile (8x8 blocks), all three channels staged in LDS ----------
+// Requires every varblock to lie inside one tile (true for naturally aligned blocks, i.e. everything encoders emit);
+// frames violating that are flagged by the LF stage and use IdctKernel above.  Same arithmetic, same operation order.
+constexpr int kTilePitch = 65;                     // floats per LDS tile row (64 + 1: conflict-free column access)
+constexpr int kTilePlane = 64 * kTilePitch;
+
+template <int C> __device__ __forceinline__ void TileRowPass(const BlockDequant& d, int R, int v, int cy, int cx, const FrameDev& f, size_t o_first,
+                                                             float* tile /* LDS, channel 0 */, int ty, int tx0) {
+  float yrow[C], row[C];
+  // Y: dequantise once, keep the pre-transform values for chroma-from-luma
+#pragma unroll
+  for (int u = 0; u < C; u++) {
+    const uint32_t k = R >= C ? (uint32_t)(u * R + v) : (uint32_t)(v * C + u);
+    yrow[u] = AdjustQuantBias(d.q[1][k], d.bias[1], d.bias[3]) * (d.table[1][k] * d.sdc[1]);
+  }
+#pragma unroll 1
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+    if (c == 1) {
+#pragma unroll
+      for (int u = 0; u < C; u++) row[u] = yrow[u];
+    } else {
+      const float kc = c == 0 ? d.kx : d.kb;
+#pragma unroll
+      for (int u = 0; u < C; u++) {
+        const uint32_t k = R >= C ? (uint32_t)(u * R + v) : (uint32_t)(v * C + u);
+        const float val = AdjustQuantBias(d.q[c][k], d.bias[c], d.bias[3]) * (d.table[c][k] * d.sdc[c]);
+        row[u] = fmaf(kc, yrow[u], val);
+      }
+    }
+    if (v < cy) {
+      const float* llf = f.llf[c] + o_first + (size_t)v * f.bw;
+#pragma unroll
+      for (int u = 0; u < C / 8; u++) if (u < cx) row[u] = llf[u];
+    }
+    IDct1D<C>(row);
+    float* dst = tile + c * kTilePlane + ty * kTilePitch + tx0;
+#pragma unroll
+    for (int u = 0; u < C; u++) dst[u] = row[u];
+  }
+}
+
+template <int R> __device__ __forceinline__ void TileColPass(float* col0) {
+  float col[R];
+#pragma unroll
+  for (int v = 0; v < R; v++) col[v] = col0[v * kTilePitch];
+  IDct1D<R>(col);
+#pragma unroll
+  for (int v = 0; v < R; v++) col0[v * kTilePitch] = col[v];
+}
+
+__global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular || *f.frame_flags != 0 || force_generic) return;
+  const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  if (tx * 8 >= f.bw || ty * 8 >= f.bh) return;
+  extern __shared__ __align__(16) float s_tile[];   // 3 * kTilePlane floats
+  const uint32_t bx0 = tx * 8, by0 = ty * 8;
+  const uint32_t tbw = min(8u, f.bw - bx0), tbh = min(8u, f.bh - by0);
+  const uint32_t g = (by0 / 32) * f.xgroups + bx0 / 32;
+  // ---- pass 1: horizontal 1-D IDCT of every coefficient row (dequantised on the fly) into the LDS tile
+  for (uint32_t t = threadIdx.x; t < 512; t += blockDim.x) {
+    const uint32_t r = t & 7, bi = t >> 3;
+    const uint32_t bx = bi & 7, by = bi >> 3;
+    if (bx >= tbw || by >= tbh) continue;
+    const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+    const uint32_t info = f.blk_info[o];
+    if (BI_Ix(info) != 0) continue;
+    const uint32_t s = BI_Strategy(info), iy = BI_Iy(info);
+    const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
+    const size_t o_first = o - (size_t)iy * f.bw;
+    const uint32_t kind = QuantKind(s);
+    BlockDequant d;
+    const uint32_t coff = f.coef_off[o_first];
+    for (int c = 0; c < 3; c++) { d.q[c] = f.coeff[c] + (size_t)g * 65536 + coff; d.table[c] = f.qtable[kind * 3 + c]; }
+    const float sd = f.inv_global_scale / (float)BI_HfMul(info);
+    d.sdc[0] = sd * f.x_dm; d.sdc[1] = sd; d.sdc[2] = sd * f.b_dm;
+    const size_t tile_i = (size_t)((by0 + by - iy) / 8) * f.cw + (bx0 + bx) / 8;
+    d.kx = f.base_x + (float)f.ytox[tile_i] * f.color_scale;
+    d.kb = f.base_b + (float)f.ytob[tile_i] * f.color_scale;
+    for (int i = 0; i < 4; i++) d.bias[i] = f.quant_bias[i];
+    const int R = cy * 8, C = cx * 8;
+    const int v = (int)(iy * 8 + r);
+    const int trow = (int)((by - iy) * 8) + v, tcol = (int)bx * 8;
+    if (IsSpecial(s)) {
+      if (r != 0) continue;
+      for (int c = 0; c < 3; c++) {
+        float cf[64];
+        for (uint32_t k = 0; k < 64; k++) cf[k] = DequantCoef(d, c, k);
+        cf[0] = f.llf[c][o_first];
+        SpecialTransform(s, cf, s_tile + c * kTilePlane + (by * 8) * kTilePitch + tcol, kTilePitch);
+      }
+      continue;
+    }
+    switch (C) {
+      case 8: TileRowPass<8>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
+      case 16: TileRowPass<16>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
+      case 32: TileRowPass<32>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
+      default: TileRowPass<64>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: vertical 1-D IDCT in LDS
+  for (uint32_t t = threadIdx.x; t < 512 * 3; t += blockDim.x) {
+    const uint32_t c = t / 512, tt = t % 512;
+    const uint32_t xx = tt & 7, bi = tt >> 3;
+    const uint32_t bx = bi & 7, by = bi >> 3;
+    if (bx >= tbw || by >= tbh) continue;
+    const uint32_t info = f.blk_info[(size_t)(by0 + by) * f.bw + bx0 + bx];
+    if (BI_Iy(info) != 0) continue;
+    const uint32_t s = BI_Strategy(info);
+    if (IsSpecial(s)) continue;
+    float* col0 = s_tile + c * kTilePlane + (by * 8) * kTilePitch + bx * 8 + xx;
+    switch ((int)CoveredY(s) * 8) {
+      case 8: TileColPass<8>(col0); break;
+      case 16: TileColPass<16>(col0); break;
+      case 32: TileColPass<32>(col0); break;
+      default: TileColPass<64>(col0); break;
+    }
+  }
+  __syncthreads();
+  // ---- pass 3: coalesced write of the tile into the planes
+  const uint32_t tw = tbw * 8, th = tbh * 8;
+  for (uint32_t c = 0; c < 3; c++) {
+    float* dst = f.plane_a[c] + (size_t)(by0 * 8) * f.plane_stride + bx0 * 8;
+    const float* src = s_tile + c * kTilePlane;
+    for (uint32_t i = threadIdx.x; i < 64 * th; i += blockDim.x) {
+      const uint32_t y = i >> 6, x = i & 63;
+      if (x < tw) dst[(size_t)y * f.plane_stride + x] = src[y * kTilePitch + x];
     }
   }
 }
@@ -1034,9 +1554,11 @@ void InitDeviceTables(void* stream) {
 static inline int DivUp(int a, int b) { return (a + b - 1) / b; }
 
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream) {
-  const int per_block = 64 / cfg.lane_stride_lf;
-  dim3 grid(DivUp(max_lf_groups, per_block), nframes);
-  hipLaunchKernelGGL(LfDecodeKernel, grid, dim3(64), 0, (hipStream_t)stream, frames, cfg.lane_stride_lf);
+  // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as the budget allows
+  const uint32_t lds_bytes = kModLdsFixed + (uint32_t)cfg.lds_code_budget;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  hipLaunchKernelGGL(LfDecodeKernel, dim3(max_lf_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, lds_bytes);
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
@@ -1045,12 +1567,18 @@ void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, v
   hipLaunchKernelGGL(LlfSigmaKernel, grid, block, 0, (hipStream_t)stream, frames);
 }
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
-  const int per_block = 64 / cfg.lane_stride_hf;
+  const int threads = cfg.hf_block_threads;
+  const int per_block = threads / cfg.lane_stride_hf;
+  const uint32_t lds_bytes = 128 + (uint32_t)cfg.lds_code_budget;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)HfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
   dim3 grid(DivUp(max_groups, per_block), nframes);
-  hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(64), 0, (hipStream_t)stream, frames, cfg.lane_stride_hf);
+  hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(threads), lds_bytes, (hipStream_t)stream, frames, cfg.lane_stride_hf, lds_bytes);
 }
-void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, void* stream) {
-  hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
+void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream) {
+  const int tiles_x = DivUp(max_bw, 8), tiles_y = DivUp(max_bh, 8);
+  hipLaunchKernelGGL(IdctTileKernel, dim3(tiles_x * tiles_y, nframes), dim3(256), 3 * kTilePlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+  hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
 }
 void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, int max_bw, int max_bh, bool any_gab, int max_epf, void* stream) {
   (void)max_bw; (void)max_bh;

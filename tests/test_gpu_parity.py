@@ -184,6 +184,23 @@ def test_vardct_shapes_and_filters(jx, w, h, mix, epf, gab, skip):
     check_against_oracle(jx, data, np.float16, 1)
 
 
+def test_unaligned_varblocks_and_generic_idct(jx):
+    """Varblocks that are not contained in a 64x64 tile (legal, never produced by encoders) take the generic IDCT kernel;
+    forcing the generic kernel on a regular stream must give the same pixels as the tiled kernel."""
+    img = S.synthetic_image(17, 520, 300)
+    data = S.encode_vardct(img, seed=8, strategy_mix=3, epf_iters=1, gab=1)
+    check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.float32, 3)
+    regular = S.encode_vardct(img, seed=8, strategy_mix=2, epf_iters=1, gab=1)
+    ref = O.decode(regular).pixels("f32", 3).view(np.float32)
+    for force in (0, 1):
+        b = jx.BatchDecoder(0)
+        b.add(regular, "float32", 3)
+        b.set_option("force_generic_idct", force)
+        b.prepare(); b.decode(); b.finish()
+        assert ulp_diff(b.output(0), ref) <= 1
+
+
 def test_hdr_float_stream(jx):
     """Config-5 style: f32 samples, linear transfer, intensity_target 1000, EPF 3."""
     lin = ((S.synthetic_image(9, 320, 200).astype(np.float32) / 255.0) ** 2.2) * 2.0

@@ -316,22 +316,21 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   struct Cand { int s; float prob; };
   std::vector<Cand> cands;
   if (p.strategy_mix == 1) cands = {{S_DCT32X32, 0.05f}, {S_DCT16X16, 0.10f}, {S_DCT16X8, 0.075f}, {S_DCT8X16, 0.075f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.04f}};
-  else if (p.strategy_mix >= 2) cands = {{S_DCT64X64, 0.02f}, {S_DCT64X32, 0.01f}, {S_DCT32X64, 0.01f}, {S_DCT32X32, 0.04f}, {S_DCT32X16, 0.02f}, {S_DCT16X32, 0.02f}, {S_DCT32X8, 0.02f},
+  else if (p.strategy_mix >= 2 && p.strategy_mix < 100) cands = {{S_DCT64X64, 0.02f}, {S_DCT64X32, 0.01f}, {S_DCT32X64, 0.01f}, {S_DCT32X32, 0.04f}, {S_DCT32X16, 0.02f}, {S_DCT16X32, 0.02f}, {S_DCT32X8, 0.02f},
                                          {S_DCT8X32, 0.02f}, {S_DCT16X16, 0.08f}, {S_DCT16X8, 0.06f}, {S_DCT8X16, 0.06f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.03f},
                                          {S_DCT2X2, 0.02f}, {S_IDENTITY, 0.02f}};
   if (p.strategy_mix >= 100) cands = {{p.strategy_mix - 100, 1.0f}};  // force one strategy wherever it fits
   for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
     if (strat[(size_t)by * bw + bx] >= 0) continue;
     int chosen = S_DCT;
-    float r = rng.uniform(), acc = 0;
-    for (auto& c : cands) {
-      acc += c.prob * (float)(kCovX[c.s] * kCovY[c.s]);  // weight by area so that *pixel* share matches prob
-      if (r >= acc) continue;
+    for (auto& c : cands) {   // largest first; a candidate that fits here is taken with its target area share
       int cx = kCovX[c.s], cy = kCovY[c.s];
-      bool ok = (bx % cx == 0) && (by % cy == 0) && bx + cx <= bw && by + cy <= bh && (bx % 32) + cx <= 32 && (by % 32) + cy <= 32;
+      bool ok = (p.strategy_mix == 3 || ((bx % cx == 0) && (by % cy == 0))) && bx + cx <= bw && by + cy <= bh && (bx % 32) + cx <= 32 && (by % 32) + cy <= 32;
       for (int iy = 0; ok && iy < cy; iy++) for (int ix = 0; ix < cx; ix++) if (strat[(size_t)(by + iy) * bw + bx + ix] >= 0) ok = false;
-      if (ok) chosen = c.s;
-      break;
+      if (!ok) continue;
+      float q = p.strategy_mix == 3 ? c.prob / (float)(cx * cy) * 2.0f : c.prob;
+      if (p.strategy_mix >= 100) q = 1.0f;
+      if (rng.uniform() < q) { chosen = c.s; break; }
     }
     int cx = kCovX[chosen], cy = kCovY[chosen];
     for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) strat[(size_t)(by + iy) * bw + bx + ix] = (int8_t)chosen;

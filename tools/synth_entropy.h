@@ -341,6 +341,11 @@ inline void BuildEntropyCoder(const std::vector<const std::vector<Token>*>& stre
   for (int i = 0; i < num_ctx; i++) ec.ctx_map[i] = (uint8_t)(assign[i] < 0 ? 0 : assign[i]);
   ec.cfg.assign(ch.size(), uc);
   ec.clusters.resize(ch.size());
+  {  // alias-table size like an encoder would pick it: smallest power of two holding the largest alphabet (>= 32)
+    size_t max_alpha = 1;
+    for (auto& hh : ch) { size_t n = hh.size(); while (n > 0 && hh[n - 1] == 0) n--; max_alpha = std::max(max_alpha, n); }
+    ec.log_alpha = std::min(8, std::max(5, CeilLog2((uint32_t)max_alpha)));
+  }
   for (size_t c = 0; c < ch.size(); c++) {
     if (ch[c].size() > 256) throw std::runtime_error("ANS alphabet > 256");
     Normalize(ch[c], ec.clusters[c].dist);
