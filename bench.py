@@ -63,14 +63,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "64")), help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "256")), help="frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames (cycled to fill the batch)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--epf", type=int, default=1)
     ap.add_argument("--lane-stride-lf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_LF", "64")))
-    ap.add_argument("--lane-stride-hf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_HF", "64")))
+    ap.add_argument("--lane-stride-hf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_HF", "1")),
+                    help="1 = SIMT HF decode (one group stream per lane), 64 = one stream per wavefront")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
+    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the LF stage of step k+1 with the rest of step k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="compare frame 0 with the CPU oracle after the run")
     args = ap.parse_args()
@@ -98,48 +100,100 @@ def main():
 
     B = args.batch
     frame_bytes = W * H * 3
-    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
-    batch = jx.BatchDecoder(local_rank)
-    for i in range(B):
-        batch.add(streams[i % len(streams)], "uint8", 3, device_ptr=out.data_ptr() + i * frame_bytes)
-    batch.set_lane_stride(args.lane_stride_lf, args.lane_stride_hf)
-    stream = torch.cuda.current_stream().cuda_stream
-    batch.prepare(stream)
+    pipeline = not args.no_pipeline
+    nbuf = 2 if pipeline else 1          # double-buffered batches: step k uses buffer set k % 2
+    outs, batches = [], []
+    main = torch.cuda.current_stream()
+    stream = main.cuda_stream
+    for b in range(nbuf):
+        out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+        batch = jx.BatchDecoder(local_rank)
+        for i in range(B):
+            batch.add(streams[i % len(streams)], "uint8", 3, device_ptr=out.data_ptr() + i * frame_bytes)
+        batch.set_lane_stride(args.lane_stride_lf, args.lane_stride_hf)
+        batch.prepare(stream)
+        outs.append(out); batches.append(batch)
+    batch, out = batches[0], outs[0]
     gather_list = None
     do_gather = world > 1 and not args.no_gather
     if do_gather and rank == 0:
         gather_list = [torch.empty_like(out) for _ in range(world)]
+    # LF ("front") parts run on a side stream so that step k+1's latency-bound LF decode overlaps step k's HF/IDCT/filter
+    # stages; events order front(k) -> rest(k) and rest(k) -> front(k+2) (same buffer set).
+    side = torch.cuda.Stream(device=dev, priority=-1) if pipeline else None   # LF blocks are few and long-running: dispatch them first
+    comm = torch.cuda.Stream(device=dev) if do_gather else None               # RCCL gather overlaps the next step's decode
+    front_done = [torch.cuda.Event() for _ in range(nbuf)]
+    rest_done = [torch.cuda.Event() for _ in range(nbuf)]
+    gather_done = [torch.cuda.Event() for _ in range(nbuf)]
+    state = {"k": 0, "front_issued": 0}
 
-    def step(timed):
-        if timed:
-            batch.decode_timed(stream)
+    def issue_front(k, timed):
+        b = k % nbuf
+        with torch.cuda.stream(side):
+            if k >= nbuf:
+                side.wait_event(rest_done[b])
+            batches[b].decode_part(1, side.cuda_stream, timed)
+            front_done[b].record(side)
+
+    def step(timed, last=False):
+        k = state["k"]
+        b = k % nbuf
+        if not pipeline:
+            if timed:
+                batches[0].decode_timed(stream)
+            else:
+                batches[0].decode(stream)
         else:
-            batch.decode(stream)
+            if state["front_issued"] <= k:
+                issue_front(k, timed); state["front_issued"] = k + 1
+            if not last and state["front_issued"] <= k + 1:
+                issue_front(k + 1, timed); state["front_issued"] = k + 2
+            main.wait_event(front_done[b])
+            if do_gather and k >= nbuf:
+                main.wait_event(gather_done[b])       # the previous gather of this buffer set must have read the pixels
+            batches[b].decode_part(2, stream, timed)
+            rest_done[b].record(main)
         if do_gather:
-            dist.gather(out, gather_list, dst=0)
+            if not pipeline:
+                rest_done[b].record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(rest_done[b])
+                dist.gather(outs[b], gather_list, dst=0)
+                gather_done[b].record(comm)
+            if not pipeline:
+                main.wait_event(gather_done[b])
+        state["k"] = k + 1
 
-    for _ in range(args.warmup):
-        step(False)
-    batch.finish(stream)
+    for i in range(args.warmup):
+        step(False, last=(i == args.warmup - 1))
     torch.cuda.synchronize()
+    for bt in batches:
+        bt.finish(stream)
+    state["k"] = 0; state["front_issued"] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(True, last=(i == args.steps - 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    batch.finish(stream)
+    for bt in batches:
+        bt.finish(stream)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    times, runs = batch.collect_times()
+    times, runs = {}, 0
+    for bt in batches:
+        t_, r_ = bt.collect_times()
+        runs += r_
+        for kk, vv in t_.items():
+            times[kk] = times.get(kk, 0.0) + vv
     stage_bytes = batch.stage_bytes
     if rank == 0:
         total_px = world * B * W * H * args.steps
@@ -165,13 +219,13 @@ def main():
                                    "inputs and outputs resident in HBM",
                        "frames_per_gpu": B, "width": W, "height": H, "compressed_bytes_per_frame": int(batch.compressed_bytes // B),
                        "lane_stride_lf": args.lane_stride_lf, "lane_stride_hf": args.lane_stride_hf,
-                       "gather": bool(do_gather), "parallelism": f"frame-sharded x{world}"},
+                       "gather": bool(do_gather), "pipelined_steps": bool(pipeline), "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_ms": round(stage_ms[dom], 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2) if stage_ms[k] > 0 else None for k in stage_ms},
-            "device_bytes": batch.device_bytes,
+            "device_bytes": sum(bt.device_bytes for bt in batches),
         }
         if cpu is not None:
             result["cpu_baseline"] = cpu

@@ -99,6 +99,7 @@ def libjxl():
             "JxlHipBatchSetLaneStride": (None, [vp, C.c_int, C.c_int]), "JxlHipBatchSetOption": (None, [vp, C.c_char_p, C.c_int]),
             "JxlHipBatchPrepare": (C.c_int, [vp, vp]), "JxlHipBatchDecode": (C.c_int, [vp, vp]),
             "JxlHipBatchDecodeTimed": (C.c_int, [vp, vp]), "JxlHipBatchFinish": (C.c_int, [vp, vp]),
+            "JxlHipBatchDecodePart": (C.c_int, [vp, vp, C.c_int, C.c_int]),
             "JxlHipBatchCollectTimes": (C.c_int, [vp, C.POINTER(JxlHipStageTimes), C.POINTER(C.c_int)]),
             "JxlHipBatchDeviceOutput": (vp, [vp, C.c_int]), "JxlHipBatchCopyOutput": (C.c_int, [vp, C.c_int, vp, sz, vp]),
             "JxlHipBatchTotalPixels": (C.c_uint64, [vp]), "JxlHipBatchCompressedBytes": (C.c_uint64, [vp]),
@@ -502,6 +503,10 @@ class BatchDecoder:
 
     def decode_timed(self, stream=None):
         self._chk(libjxl().JxlHipBatchDecodeTimed(self._h, stream))
+
+    def decode_part(self, part: int, stream=None, timed=False):
+        """part 1 = front (LF stage), 2 = rest (HF, IDCT, filters, output); see include/jxl_hip.h."""
+        self._chk(libjxl().JxlHipBatchDecodePart(self._h, stream, part, 1 if timed else 0))
 
     def collect_times(self):
         """-> (dict stage -> summed ms, number of timed decodes)"""

@@ -388,6 +388,15 @@ void Batch::Prepare(void* stream_v) {
       c.has_qtable[k] = true;
     }
   }
+  {  // LDS right-sizing for the decode kernels
+    auto code_bytes = [](const HostCode& c, bool ctx) { return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
+    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16;
+    for (int i = 0; i < n; i++) {
+      const FramePlan& p = images_[i]->plan;
+      if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); }
+      if (!p.modular) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(p.ac_code[0], true));
+    }
+  }
   const_size_ = Align(hconst_.size());
   HIP_CHECK(hipMalloc((void**)&dconst_, const_size_));
   HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
@@ -453,42 +462,65 @@ void Batch::Run(void* stream_v) {
   }
 }
 
-void Batch::RunTimed(void* stream_v) {
+void Batch::RunTimed(void* stream_v) { RunPart(stream_v, 0, true); }
+
+// part 0 = whole decode, 1 = front (coefficient clear + LF decode + LF post-processing), 2 = rest (HF decode, IDCT,
+// filters, output).  Front and rest of one decode may be enqueued on different streams (ordered by the caller with
+// events) so that the latency-bound LF stage of the next batch overlaps the bandwidth stages of the current one.
+void Batch::RunPart(void* stream_v, int part, bool timed) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
-  if (!any_vardct_) { Run(stream_v); return; }
-  std::vector<void*> evs(7);
-  for (auto& e : evs) { hipEvent_t ev; HIP_CHECK(hipEventCreate(&ev)); e = ev; }
-  auto rec = [&](int i) { HIP_CHECK(hipEventRecord((hipEvent_t)evs[i], stream)); };
-  rec(0);
-  HIP_CHECK(hipMemsetAsync(dwork_ + coeff_off_, 0, coeff_bytes_, stream));
-  LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
-  rec(1);
-  LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
-  rec(2);
-  LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
-  rec(3);
-  LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
-  rec(4);
-  LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
-  rec(5);
-  LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
-  rec(6);
-  timed_events_.push_back(evs);
+  if (!any_vardct_) { if (part != 1) Run(stream_v); return; }
+  std::vector<void*>* evs = nullptr;
+  if (timed) {
+    if (part != 2) { timed_events_.emplace_back(8, nullptr); }
+    if (timed_events_.empty()) timed_events_.emplace_back(8, nullptr);
+    evs = part == 2 ? &timed_events_[timed_rest_cursor_ < timed_events_.size() ? timed_rest_cursor_ : timed_events_.size() - 1] : &timed_events_.back();
+  }
+  auto rec = [&](int i) {
+    if (!evs) return;
+    hipEvent_t ev; HIP_CHECK(hipEventCreate(&ev)); (*evs)[i] = ev;
+    HIP_CHECK(hipEventRecord(ev, stream));
+  };
+  if (part != 2) {
+    rec(0);
+    HIP_CHECK(hipMemsetAsync(dwork_ + coeff_off_, 0, coeff_bytes_, stream));
+    LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
+    rec(1);
+    LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
+    if (part == 1) rec(2);
+  }
+  if (part != 1) {
+    rec(part == 2 ? 7 : 2);
+    LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
+    rec(3);
+    LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
+    rec(4);
+    LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
+    rec(5);
+    LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
+    rec(6);
+    if (timed && part == 2) timed_rest_cursor_++;
+  }
+  if (any_modular_ && part != 1) Run(stream_v);
 }
 
 StageTimes Batch::CollectTimes(int* runs) {
   StageTimes t;
   *runs = (int)timed_events_.size();
   for (auto& evs : timed_events_) {
+    bool complete = true;
+    for (size_t i = 0; i < 7; i++) if (!evs[i]) complete = false;
+    if (!complete) { for (auto e : evs) if (e) (void)hipEventDestroy((hipEvent_t)e); (*runs)--; continue; }
     HIP_CHECK(hipEventSynchronize((hipEvent_t)evs[6]));
     float* dst[6] = {&t.lf_ms, &t.lfpost_ms, &t.hf_ms, &t.idct_ms, &t.filter_ms, &t.out_ms};
-    for (int i = 0; i < 6; i++) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)evs[i], (hipEvent_t)evs[i + 1])); *dst[i] += ms; }
+    for (int i = 0; i < 6; i++) { float ms = 0; void* st = (i == 2 && evs[7]) ? evs[7] : evs[i]; HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)st, (hipEvent_t)evs[i + 1])); *dst[i] += ms; }
     float tot = 0; HIP_CHECK(hipEventElapsedTime(&tot, (hipEvent_t)evs[0], (hipEvent_t)evs[6])); t.total_ms += tot;
-    for (auto e : evs) (void)hipEventDestroy((hipEvent_t)e);
+    for (auto e : evs) if (e) (void)hipEventDestroy((hipEvent_t)e);
   }
   timed_events_.clear();
+  timed_rest_cursor_ = 0;
   return t;
 }
 

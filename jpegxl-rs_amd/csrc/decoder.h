@@ -56,6 +56,7 @@ class Batch {
   // Same as Run but brackets every stage with HIP events recorded on `stream` (no host sync).  CollectTimes() waits for
   // all recorded runs and returns the per-stage sums (ms) and the number of runs; used by bench.py for the roofline.
   void RunTimed(void* stream);
+  void RunPart(void* stream, int part, bool timed);
   StageTimes CollectTimes(int* runs);
   // ALGORITHMIC bytes per stage for one Run of the batch: 0 lf, 1 lfpost, 2 hf, 3 idct, 4 filters, 5 out
   void StageBytes(uint64_t out[6]) const;
@@ -82,7 +83,8 @@ class Batch {
   bool any_gab_ = false, any_vardct_ = false, any_modular_ = false;
   struct ModFinish { int frame; std::vector<int> planes; };  // host-side channel lists for modular frames
   std::vector<std::vector<size_t>> mod_plane_offsets_;
-  std::vector<std::vector<void*>> timed_events_;       // per frame: work-arena offsets of planes (incl. spare)
+  std::vector<std::vector<void*>> timed_events_;
+  size_t timed_rest_cursor_ = 0;       // per frame: work-arena offsets of planes (incl. spare)
 };
 
 }  // namespace jxlhip

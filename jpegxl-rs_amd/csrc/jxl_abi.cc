@@ -263,6 +263,10 @@ void JxlHipBatchSetLaneStride(JxlHipBatch* h, int lf, int hf) {
 JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Prepare(s)) }
 JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Run(s)) }
 JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->RunTimed(s)) }
+JxlDecoderStatus JxlHipBatchDecodePart(JxlHipBatch* h, void* s, int part, int timed) {
+  if (part < 0 || part > 2) return JXL_DEC_ERROR;
+  BATCH_TRY(h->b->RunPart(s, part, timed != 0))
+}
 JxlDecoderStatus JxlHipBatchCollectTimes(JxlHipBatch* h, JxlHipStageTimes* t, int* runs) {
   BATCH_TRY({ StageTimes st = h->b->CollectTimes(runs); t->lf_ms = st.lf_ms; t->lfpost_ms = st.lfpost_ms; t->hf_ms = st.hf_ms; t->idct_ms = st.idct_ms; t->filter_ms = st.filter_ms; t->out_ms = st.out_ms; t->total_ms = st.total_ms; })
 }

@@ -85,6 +85,8 @@ struct LaunchCfg {
   int lane_stride_lf = 64;   // lanes between active decode threads (64 = one stream per wave, 1 = one per lane)
   int lane_stride_hf = 64;
   int lane_stride_mod = 64;
+  // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
+  int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;
   int force_generic_idct = 0;        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames
   int hf_block_threads = 512;        // threads per HF-decode block (streams per block = threads / lane_stride_hf)
   int lds_code_budget = 48 * 1024;   // bytes of LDS the entropy-code tables (cfg, ctx map, alias) may take per block

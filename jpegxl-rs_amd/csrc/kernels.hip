@@ -88,6 +88,7 @@ template <typename T> __device__ __forceinline__ void StG(T* p, T v) { *p = v; }
 template <typename T> __device__ __forceinline__ T LdS(uint32_t byte_off) { return *reinterpret_cast<const T*>(g_dyn_lds + byte_off); }
 template <typename T> __device__ __forceinline__ void StS(uint32_t byte_off, T v) { *reinterpret_cast<T*>(g_dyn_lds + byte_off) = v; }
 constexpr uint32_t kNotInLds = 0xFFFFFFFFu;
+constexpr uint32_t kWinOffC = 3072;   // = kWinOff (bit-stream window of the modular fast path)
 
 // Bit reader whose next 32-bit word is always already in flight: the refill never waits on global-memory latency.
 struct BitReaderP {
@@ -167,6 +168,84 @@ __device__ __forceinline__ uint32_t FastHybrid(BitReaderP& br, uint32_t& state, 
   return (((hi << nbits) | bits) << lsb) | low;
 }
 
+// Compile-time selection of the table location (ALL_LDS = every table of the code was staged): keeps vmcnt waits out
+// of the LDS variant.
+template <bool ALL_LDS> __device__ __forceinline__ uint32_t ClusterT(const FastCode& c, uint32_t ctx) {
+  if (ALL_LDS) return LdS<uint8_t>(c.ctx_map_off + ctx);
+  return c.Cluster(ctx);
+}
+template <bool ALL_LDS> __device__ __forceinline__ uint32_t FastHybridT(BitReaderP& br, uint32_t& state, const FastCode& c, uint32_t cluster) {
+  if (!ALL_LDS) return FastHybrid(br, state, c, cluster);
+  const uint32_t la = c.log_alpha;
+  const uint32_t cfg = LdS<uint32_t>(c.cfg_off + cluster * 4);
+  const uint32_t res = state & 0xFFF;
+  const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
+  const uint64_t e = LdS<uint64_t>(c.alias_off + (((cluster << la) + i) << 3));
+  const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+  const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+  const bool hit = pos >= cutoff;
+  uint32_t tok = hit ? right : i;
+  const uint32_t off = hit ? offs1 + pos : pos;
+  const uint32_t freq = hit ? freq1 : freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | br.Read(16);
+  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+  const uint32_t split = 1u << split_exp;
+  if (tok < split) return tok;
+  uint32_t nbits = split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb));
+  nbits &= 31;
+  const uint32_t low = tok & ((1u << lsb) - 1);
+  tok >>= lsb;
+  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
+  const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+  return (((hi << nbits) | bits) << lsb) | low;
+}
+
+// LDS-only variants used by the serial fast path: no vector-memory instruction, hence no vmcnt wait, in the token loop.
+struct BitReaderW {      // reads 32-bit words from the LDS window [kWinOff, ...) holding words win_base.. of the stream
+  uint32_t wpos, win_base;
+  uint64_t buf;
+  int avail;
+  __device__ __forceinline__ void Refill() {
+    if (avail <= 32) {
+      buf |= (uint64_t)LdS<uint32_t>(kWinOffC + ((wpos - win_base) << 2)) << avail;
+      avail += 32;
+      wpos++;
+    }
+  }
+  __device__ __forceinline__ uint32_t Read(int n) {
+    Refill();
+    const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
+    buf >>= n; avail -= n;
+    return v;
+  }
+  __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)wpos * 32 - (uint64_t)avail; }
+};
+__device__ __forceinline__ uint32_t HybridLds(BitReaderW& br, uint32_t& state, uint32_t cfg_off, uint32_t alias_off, uint32_t la, uint32_t cluster) {
+  const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
+  const uint32_t res = state & 0xFFF;
+  const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
+  const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
+  const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+  const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+  const bool hit = pos >= cutoff;
+  uint32_t tok = hit ? right : i;
+  const uint32_t off = hit ? offs1 + pos : pos;
+  const uint32_t freq = hit ? freq1 : freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | br.Read(16);
+  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+  const uint32_t split = 1u << split_exp;
+  if (tok < split) return tok;
+  uint32_t nbits = split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb));
+  nbits &= 31;
+  const uint32_t low = tok & ((1u << lsb) - 1);
+  tok >>= lsb;
+  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
+  const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+  return (((hi << nbits) | bits) << lsb) | low;
+}
+
 // Cooperative copy of an entropy code into LDS (all threads of the block) starting at byte offset `base`; tables
 // that do not fit in [base, base + budget) stay in global memory.  Returns the bytes used.
 __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget, bool with_ctx_map) {
@@ -196,11 +275,15 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
 
 // ---- Modular channel decode, cooperative version ------------------------------------------------------------------------
 constexpr int kLdsTreeMax = 1024;   // nodes copied to LDS (16 KiB); larger trees are walked in global memory
-constexpr uint32_t kLutOff = 0, kWorkOff = 2048, kTreeOff = 3072;
-constexpr uint32_t kModLdsFixed = kTreeOff + kLdsTreeMax * 16;
+constexpr uint32_t kLutOff = 0, kWorkOff = 2048;
+constexpr uint32_t kWinOff = 3072, kWinWords = 528;                 // bit-stream window: 2112 B (>= 256 samples x 48 bits + slack)
+constexpr uint32_t kRowOff = kWinOff + kWinWords * 4, kRowMax = 1024; // two sample rows (current / previous) of up to 1024 ints
+constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;            // 256-sample staging buffer for wider channels
+constexpr uint32_t kTreeOff = kChunkOff + 256 * 4;
 struct ModTables {
   const TreeNode* tree_g;
   bool tree_in_lds;         // LDS copy at kTreeOff (leaves rewritten: a = predictor | cluster << 8)
+  uint32_t tree_cap;
   FastCode code;
   __device__ __forceinline__ TreeNode Node(uint32_t i) const {
     if (tree_in_lds) {
@@ -257,7 +340,7 @@ __device__ __forceinline__ int32_t Predict(uint32_t predictor, int32_t W, int32_
 
 // All threads of the block call this (contains barriers).  Thread 0 decodes; the others help build the LUT.
 // Semantics identical to DecodeModularChannel (jxl_dev.h).
-__device__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
+__device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
   if (ch.w == 0 || ch.h == 0) return;
   // ---- thread 0: resolve static properties (channel, stream id) and analyse the remaining subtree
   if (threadIdx.x == 0) {
@@ -269,33 +352,120 @@ __device__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTabl
       n = T.Node(pos);
     }
     int mode = 1, prop = -1, count = 0;
+    int upred = -1;   // predictor shared by all leaves with offset 0 / multiplier 1 (-2: not uniform / not simple)
     int sp = 0;   // iterative DFS with a bounded stack at kWorkOff + 32
     StS<int>(kWorkOff + 32 + 4 * sp++, (int)pos);
     while (sp > 0 && mode == 1) {
       const TreeNode m = T.Node((uint32_t)LdS<int>(kWorkOff + 32 + 4 * --sp));
       if (++count > 600) { mode = 0; break; }
-      if (m.prop < 0) { if ((m.a & 0xFF) == 6) mode = 0; continue; }        // weighted predictor: general path
+      if (m.prop < 0) {
+        if ((m.a & 0xFF) == 6) mode = 0;                                     // weighted predictor: general path
+        if (m.val != 0 || m.b != 1) upred = -2;
+        else if (upred == -1) upred = (int)(m.a & 0xFF);
+        else if (upred != (int)(m.a & 0xFF)) upred = -2;
+        continue;
+      }
       if (m.prop == 15 || m.prop >= 16 || m.prop <= 1) { mode = 0; break; }
       if (prop < 0) prop = m.prop; else if (prop != m.prop) { mode = 0; break; }
       if (m.val < -512 || m.val > 510 || sp + 2 > 200) { mode = 0; break; }
       StS<int>(kWorkOff + 32 + 4 * sp++, (int)m.a); StS<int>(kWorkOff + 32 + 4 * sp++, (int)m.b);
     }
     if (!T.tree_in_lds) mode = 0;
-    StS<int>(kWorkOff + 0, mode); StS<int>(kWorkOff + 4, prop); StS<int>(kWorkOff + 8, (int)pos);
+    StS<int>(kWorkOff + 0, mode); StS<int>(kWorkOff + 4, prop); StS<int>(kWorkOff + 8, (int)pos); StS<int>(kWorkOff + 12, upred);
   }
   __syncthreads();
   const int mode = LdS<int>(kWorkOff + 0), prop = LdS<int>(kWorkOff + 4);
   const uint32_t subroot = (uint32_t)LdS<int>(kWorkOff + 8);
+  const int upred = LdS<int>(kWorkOff + 12);
+  // fast rows: leaves are (predictor p, offset 0, multiplier 1) with p in {0 zero, 1 W, 5 gradient}; the LUT then maps
+  // the property value straight to the cluster
+  const bool need_n = upred == 5 || prop == 9;    // previous row needed
+  const bool fast = mode == 1 && (upred == 0 || upred == 1 || upred == 5) && (prop < 0 || prop == 2 || prop == 9) &&
+                    T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && ((uint32_t)ch.w <= kRowMax || !need_n);
   if (mode == 1) {
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
       const int32_t v = i - 512;
       uint32_t pos = subroot;
       TreeNode n = T.Node(pos);
       while (n.prop >= 0) { pos = v > n.val ? n.a : n.b; n = T.Node(pos); }
-      StS<uint16_t>(kLutOff + 2 * i, (uint16_t)pos);
+      StS<uint16_t>(kLutOff + 2 * i, fast ? (uint16_t)(n.a >> 8) : (uint16_t)pos);   // fast: cluster, else leaf node index
     }
   }
   __syncthreads();
+  if (fast) {
+    // ---- LDS-only serial loop.  Thread 0 decodes 256 samples at a time from a bit-stream window in LDS, reading the
+    // previous row from LDS and writing into LDS; the other lanes load the window and flush finished rows / chunks with
+    // coalesced global accesses.
+    const int w = ch.w, h = ch.h;
+    const bool row_in_lds = (uint32_t)w <= kRowMax;
+    const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
+    const uint32_t wend = br.wend;
+    BitReaderW bw;
+    bw.wpos = 0; bw.win_base = 0; bw.buf = 0; bw.avail = 0;
+    uint32_t skip_bits = 0;
+    if (threadIdx.x == 0) { const uint64_t bp = br.BitPos(); bw.wpos = (uint32_t)(bp >> 5); skip_bits = (uint32_t)(bp & 31); }
+    int32_t left = 0, nw = 0;
+    uint32_t cur = kRowOff, prev = kRowOff + kRowMax * 4;
+    for (int y = 0; y < h; y++) {
+      int32_t* p = ch.data + (size_t)y * ch.stride;
+      uint32_t cl_row = 0;
+      if (prop != 9) { int32_t v = prop == 2 ? y : 0; v = v > 511 ? 511 : v; cl_row = LdS<uint16_t>(kLutOff + 2 * (uint32_t)(v + 512)); }
+      for (int x0 = 0; x0 < w; x0 += 256) {
+        if (threadIdx.x == 0) StS<uint32_t>(kWorkOff + 16, bw.wpos);
+        __syncthreads();
+        const uint32_t wbase = LdS<uint32_t>(kWorkOff + 16);
+        for (uint32_t i = threadIdx.x; i < kWinWords; i += blockDim.x) StS<uint32_t>(kWinOff + i * 4, wbase + i < wend ? LdG(br.words + wbase + i) : 0u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          bw.win_base = wbase;
+          if (skip_bits != 0xFFFFFFFFu) {   // first chunk of the channel: establish the bit buffer
+            bw.buf = 0; bw.avail = 0;
+            bw.Refill(); bw.buf >>= skip_bits; bw.avail -= (int)skip_bits;
+            skip_bits = 0xFFFFFFFFu;
+          }
+          const int x1 = min(w, x0 + 256);
+          const uint32_t obase = row_in_lds ? cur : kChunkOff - (uint32_t)x0 * 4;
+          for (int x = x0; x < x1; x++) {
+            int32_t W, N, NW;
+            if (y == 0) { W = x ? left : 0; N = W; NW = W; }
+            else if (need_n) { N = LdS<int32_t>(prev + 4 * x); W = x ? left : N; NW = x ? nw : W; nw = N; }
+            else { W = x ? left : LdS<int32_t>(kWorkOff + 24); N = W; NW = W; }
+            uint32_t cluster = cl_row;
+            if (prop == 9) {
+              int32_t v = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+              v = v < -512 ? -512 : (v > 511 ? 511 : v);
+              cluster = LdS<uint16_t>(kLutOff + 2 * (uint32_t)(v + 512));
+            }
+            int32_t guess;
+            if (upred == 0) guess = 0;
+            else if (upred == 1) guess = W;
+            else { const int32_t m = min(N, W), M = max(N, W); guess = NW < m ? M : (NW > M ? m : (int32_t)((uint32_t)N + (uint32_t)W - (uint32_t)NW)); }
+            const uint32_t tok = HybridLds(bw, state, cfg_off, alias_off, la, cluster);
+            const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) + (uint32_t)guess);
+            StS<int32_t>(obase + 4 * x, val);
+            if (x == 0) StS<int32_t>(kWorkOff + 24, val);   // W of the next row's first sample when the row is not kept in LDS
+            left = val;
+          }
+        }
+        __syncthreads();
+        if (!row_in_lds) {
+          const int n = min(256, w - x0);
+          for (int i = threadIdx.x; i < n; i += blockDim.x) StG(p + x0 + i, LdS<int32_t>(kChunkOff + 4 * i));
+        }
+      }
+      if (row_in_lds) {
+        for (int i = threadIdx.x; i < w; i += blockDim.x) StG(p + i, LdS<int32_t>(cur + 4 * i));
+        const uint32_t t = cur; cur = prev; prev = t;
+      }
+    }
+    // hand the bit position back to the generic reader
+    if (threadIdx.x == 0) StS<uint64_t>(kWorkOff + 32, bw.BitPos());
+    __syncthreads();
+    const uint64_t endpos = LdS<uint64_t>(kWorkOff + 32);
+    br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
+    __syncthreads();
+    return;
+  }
   if (threadIdx.x == 0) {
     const int w = ch.w, h = ch.h;
     const FastCode& code = T.code;
@@ -356,11 +526,13 @@ __device__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTabl
 }
 
 // Stages tree + code into LDS for the modular decoders.  The block's dynamic LDS must hold kModLdsFixed + code budget.
-__device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTables& T, uint32_t lds_bytes) {
-  const uint32_t budget = lds_bytes > kModLdsFixed ? lds_bytes - kModLdsFixed : 0;
-  StageCode(f.mod_code, T.code, kModLdsFixed, budget, /*with_ctx_map=*/false);
+__device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTables& T, uint32_t tree_cap, uint32_t lds_bytes) {
+  const uint32_t code_base = kTreeOff + tree_cap * 16;
+  const uint32_t budget = lds_bytes > code_base ? lds_bytes - code_base : 0;
+  StageCode(f.mod_code, T.code, code_base, budget, /*with_ctx_map=*/false);
   T.tree_g = f.tree;
-  T.tree_in_lds = num_tree_nodes <= (uint32_t)kLdsTreeMax;
+  T.tree_cap = tree_cap;
+  T.tree_in_lds = num_tree_nodes <= tree_cap;
   if (T.tree_in_lds) {
     for (uint32_t i = threadIdx.x; i < num_tree_nodes; i += blockDim.x) {
       uint4 v = LdG(reinterpret_cast<const uint4*>(f.tree + i));
@@ -374,7 +546,7 @@ __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTabl
 // =====================================================================================================================
 // K_lf: one 64-thread block per LF group — LF coefficients (3 channels, order Y,X,B) + HF metadata, varblock placement
 // =====================================================================================================================
-__global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes) {
+__global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   const uint32_t g = blockIdx.x;
@@ -383,7 +555,7 @@ __global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict_
   const uint32_t bx0 = gx * 256, by0 = gy * 256;
   const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
   ModTables T;
-  StageModular(f, f.tree_nodes, T, lds_bytes);
+  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
   BitReaderP br;
   if (f.single_section) br.Init(f.cs, f.lf_start_bitpos, f.cs_size);
   else { const uint64_t off = f.sec_off[1 + g]; br.Init(f.cs, off * 8, off + f.sec_size[1 + g]); }
@@ -746,6 +918,134 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   if (br.BitPos() > limit) { SetError(f, kErrOverrun); return; }
 }
 
+// ---- SIMT variant: every lane decodes the stream of its own group; one token per lane per loop iteration -------------
+// The per-token work (context → cluster → alias lookup → state update → refill → hybrid bits → store) is the same
+// straight-line code for the "number of non-zeros" token and the coefficient tokens, so lanes stay converged; block
+// set-up is a separate, rarer, state.  All groups of a block belong to one frame and share its tables in LDS.
+constexpr uint32_t kSimtThreads = 256;
+constexpr uint32_t kSimtNzOff = 128;                                   // per-thread nzeros row buffers: 96 B each
+constexpr uint32_t kSimtBcmOff = kSimtNzOff + kSimtThreads * 96;       // copy of the BlockCtxDev
+constexpr uint32_t kSimtCodeOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;
+
+template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular) return;
+  if (blockIdx.x * kSimtThreads >= f.num_groups) return;
+  FastCode code;
+  if (threadIdx.x < 64) { StS<uint8_t>(threadIdx.x, kNzCtx[threadIdx.x]); StS<uint8_t>(64 + threadIdx.x, kFreqCtx[threadIdx.x]); }
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(f.bcm);
+    for (uint32_t i = threadIdx.x; i < sizeof(BlockCtxDev) / 4; i += blockDim.x) StS<uint32_t>(kSimtBcmOff + i * 4, LdG(src + i));
+  }
+  StageCode(f.ac_code, code, kSimtCodeOff, lds_bytes > kSimtCodeOff ? lds_bytes - kSimtCodeOff : 0, /*with_ctx_map=*/true);
+  __syncthreads();
+  if (ALL_LDS && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
+  const uint32_t g = blockIdx.x * kSimtThreads + threadIdx.x;
+  bool done = g >= f.num_groups;
+  const uint32_t nz_base = kSimtNzOff + threadIdx.x * 96;
+  for (uint32_t i = 0; i < 24; i++) StS<uint32_t>(nz_base + i * 4, 0u);
+  // BlockCtxDev field offsets inside the LDS copy
+  constexpr uint32_t oNLf = kSimtBcmOff + offsetof(BlockCtxDev, n_lf_thr), oQf = kSimtBcmOff + offsetof(BlockCtxDev, qf_thr);
+  constexpr uint32_t oLf = kSimtBcmOff + offsetof(BlockCtxDev, lf_thr), oMap = kSimtBcmOff + offsetof(BlockCtxDev, ctx_map);
+  const uint32_t n_qf = LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, n_qf_thr));
+  const uint32_t num_lf_ctxs = LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, num_lf_ctxs));
+  const uint32_t nctx = LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, num_ctxs));
+  const uint32_t gsafe = done ? 0 : g;
+  const uint32_t gx = gsafe % f.xgroups, gy = gsafe / f.xgroups;
+  const uint32_t bx0 = gx * 32, by0 = gy * 32;
+  const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
+  BitReaderP br;
+  uint64_t limit;
+  if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
+  else { const uint32_t si = 2 + f.num_lf_groups + gsafe; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); br.Init(f.cs, off * 8, off + sz); limit = (off + sz) * 8; }
+  uint32_t ctx_offset = 0, state = 0;
+  if (!done) {
+    const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
+    if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); done = true; }
+    ctx_offset = 495u * nctx * preset;
+    state = br.Read(32);
+  }
+  const uint32_t nblocks = gbw * gbh;
+  uint32_t pos = 0;                       // next block position to visit (raster within the group)
+  uint32_t phase = 0;                     // 0: find next varblock, 1: read nzeros, 2: read a coefficient
+  uint32_t bx = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, cx = 1, coff = 0, qf_idx = 0, lf_idx = 0;
+  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, by = 0;
+  const uint16_t* order = f.orders[0];
+  int32_t* blk = f.coeff[0];
+  while (__ballot(!done) != 0ull) {
+    if (!done && phase == 0) {
+      if (pos >= nblocks) {
+        if (state != 0x130000u) SetError(f, kErrAnsFinalState);
+        else if (br.BitPos() > limit) SetError(f, kErrOverrun);
+        done = true;
+      } else {
+        bx = pos % gbw; by = pos / gbw; pos++;
+        const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+        const uint32_t info = LdG(f.blk_info + o);
+        if (BI_First(info)) {
+          const uint32_t s = BI_Strategy(info);
+          cx = CoveredX(s); covered = cx * CoveredY(s);
+          l2 = 31 - __clz((int)covered); size = covered * 64; ord = OrderBucket(s);
+          const uint32_t qf = BI_HfMul(info);
+          qf_idx = 0;
+          for (uint32_t i = 0; i < n_qf; i++) qf_idx += qf > LdS<uint32_t>(oQf + i * 4);
+          lf_idx = 0;
+          if (num_lf_ctxs > 1) {
+            const uint32_t n0 = LdS<uint32_t>(oNLf), n1 = LdS<uint32_t>(oNLf + 4), n2 = LdS<uint32_t>(oNLf + 8);
+            uint32_t b0 = 0, b1 = 0, b2 = 0;
+            const int32_t q0 = LdG(f.lfq[0] + o), q1 = LdG(f.lfq[1] + o), q2 = LdG(f.lfq[2] + o);
+            for (uint32_t i = 0; i < n0; i++) b0 += q0 > LdS<int32_t>(oLf + i * 4);
+            for (uint32_t i = 0; i < n1; i++) b1 += q1 > LdS<int32_t>(oLf + 64 + i * 4);
+            for (uint32_t i = 0; i < n2; i++) b2 += q2 > LdS<int32_t>(oLf + 128 + i * 4);
+            lf_idx = (b0 * (n2 + 1) + b2) * (n1 + 1) + b1;
+          }
+          coff = LdG(f.coef_off + o);
+          ci = 0; phase = 1;
+        }
+      }
+    } else if (!done) {
+      const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
+      uint32_t ctx;
+      if (phase == 1) {
+        uint32_t idx = (uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord;
+        idx = idx * (n_qf + 1) + qf_idx;
+        idx = idx * num_lf_ctxs + lf_idx;
+        const uint32_t block_ctx = LdS<uint8_t>(oMap + idx);
+        uint32_t pred;
+        const uint32_t top = LdS<uint8_t>(nz_base + c * 32 + bx), left = bx ? LdS<uint8_t>(nz_base + c * 32 + bx - 1) : 0;
+        if (bx == 0) pred = by == 0 ? 32 : top;
+        else if (by == 0) pred = left;
+        else pred = (top + left + 1) / 2;
+        const uint32_t pc = pred > 64 ? 64 : pred;
+        ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
+        histo = ctx_offset + 37 * nctx + 458 * block_ctx;
+      } else {
+        const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
+        ctx = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + kk)) * 2 + prev;
+      }
+      const uint32_t u = FastHybridT<ALL_LDS>(br, state, code, ClusterT<ALL_LDS>(code, ctx));
+      if (phase == 1) {
+        nzeros = u;
+        if (nzeros + covered > size) { SetError(f, kErrNzeros); done = true; }
+        const uint32_t nzm = (nzeros + covered - 1) >> l2;
+        for (uint32_t ix = 0; ix < cx; ix++) StS<uint8_t>(nz_base + c * 32 + bx + ix, (uint8_t)nzm);
+        order = f.orders[ord * 3 + c];
+        blk = f.coeff[c] + (size_t)g * 65536 + coff;
+        prev = nzeros > size / 16 ? 0 : 1;
+        k = covered;
+        phase = 2;
+      } else {
+        if (u) StG(blk + LdG(order + k), UnpackSigned(u));
+        prev = u != 0;
+        nzeros -= prev;
+        k++;
+        if (nzeros != 0 && k >= size) { SetError(f, kErrNzeros); done = true; }
+      }
+      if (phase == 2 && nzeros == 0) { ci++; phase = ci == 3 ? 0 : 1; }
+    }
+  }
+}
+
 // =====================================================================================================================
 // K_idct: dequant + chroma-from-luma + LLF + inverse transforms.  One 256-thread workgroup per 256x256 group.
 // Pass 1 (rows): horizontal 1-D IDCT of every coefficient row, written into the pixel plane as an intermediate;
@@ -984,43 +1284,24 @@ __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ f
 // ---- fast path: one 256-thread workgroup per 64x64-pixel tile (8x8 blocks), all three channels staged in LDS ----------
 // Requires every varblock to lie inside one tile (true for naturally aligned blocks, i.e. everything encoders emit);
 // frames violating that are flagged by the LF stage and use IdctKernel above.  Same arithmetic, same operation order.
+//  pass 0: coalesced read of the quantised coefficients (consecutive lanes = consecutive coefficients), dequant + CfL,
+//          scatter into the LDS tile at the coefficient's (vertical, horizontal) frequency position
+//  pass 1: LLF substitution + horizontal 1-D IDCT per row (in LDS)     pass 2: vertical 1-D IDCT per column (in LDS)
+//  pass 3: coalesced write of the finished 64x64 tile to the three planes
 constexpr int kTilePitch = 65;                     // floats per LDS tile row (64 + 1: conflict-free column access)
 constexpr int kTilePlane = 64 * kTilePitch;
 
-template <int C> __device__ __forceinline__ void TileRowPass(const BlockDequant& d, int R, int v, int cy, int cx, const FrameDev& f, size_t o_first,
-                                                             float* tile /* LDS, channel 0 */, int ty, int tx0) {
-  float yrow[C], row[C];
-  // Y: dequantise once, keep the pre-transform values for chroma-from-luma
+template <int C> __device__ __forceinline__ void TileRowPass(float* row0 /* LDS row start */, int v, int cy, int cx, const float* llf /* global, row v of the LLF block */) {
+  float row[C];
 #pragma unroll
-  for (int u = 0; u < C; u++) {
-    const uint32_t k = R >= C ? (uint32_t)(u * R + v) : (uint32_t)(v * C + u);
-    yrow[u] = AdjustQuantBias(d.q[1][k], d.bias[1], d.bias[3]) * (d.table[1][k] * d.sdc[1]);
+  for (int u = 0; u < C; u++) row[u] = row0[u];
+  if (v < cy) {
+#pragma unroll
+    for (int u = 0; u < C / 8; u++) if (u < cx) row[u] = LdG(llf + u);
   }
-#pragma unroll 1
-  for (int ci = 0; ci < 3; ci++) {
-    const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-    if (c == 1) {
+  IDct1D<C>(row);
 #pragma unroll
-      for (int u = 0; u < C; u++) row[u] = yrow[u];
-    } else {
-      const float kc = c == 0 ? d.kx : d.kb;
-#pragma unroll
-      for (int u = 0; u < C; u++) {
-        const uint32_t k = R >= C ? (uint32_t)(u * R + v) : (uint32_t)(v * C + u);
-        const float val = AdjustQuantBias(d.q[c][k], d.bias[c], d.bias[3]) * (d.table[c][k] * d.sdc[c]);
-        row[u] = fmaf(kc, yrow[u], val);
-      }
-    }
-    if (v < cy) {
-      const float* llf = f.llf[c] + o_first + (size_t)v * f.bw;
-#pragma unroll
-      for (int u = 0; u < C / 8; u++) if (u < cx) row[u] = llf[u];
-    }
-    IDct1D<C>(row);
-    float* dst = tile + c * kTilePlane + ty * kTilePitch + tx0;
-#pragma unroll
-    for (int u = 0; u < C; u++) dst[u] = row[u];
-  }
+  for (int u = 0; u < C; u++) row0[u] = row[u];
 }
 
 template <int R> __device__ __forceinline__ void TileColPass(float* col0) {
@@ -1038,61 +1319,94 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
   const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   if (tx * 8 >= f.bw || ty * 8 >= f.bh) return;
   extern __shared__ __align__(16) float s_tile[];   // 3 * kTilePlane floats
+  __shared__ uint32_t s_info[64];
+  __shared__ uint32_t s_coff[64];
   const uint32_t bx0 = tx * 8, by0 = ty * 8;
   const uint32_t tbw = min(8u, f.bw - bx0), tbh = min(8u, f.bh - by0);
   const uint32_t g = (by0 / 32) * f.xgroups + bx0 / 32;
-  // ---- pass 1: horizontal 1-D IDCT of every coefficient row (dequantised on the fly) into the LDS tile
-  for (uint32_t t = threadIdx.x; t < 512; t += blockDim.x) {
-    const uint32_t r = t & 7, bi = t >> 3;
-    const uint32_t bx = bi & 7, by = bi >> 3;
-    if (bx >= tbw || by >= tbh) continue;
-    const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
-    const uint32_t info = f.blk_info[o];
-    if (BI_Ix(info) != 0) continue;
+  if (threadIdx.x < 64) {
+    const uint32_t bx = threadIdx.x & 7, by = threadIdx.x >> 3;
+    uint32_t info = 0xFFFFFFFFu, coff = 0;
+    if (bx < tbw && by < tbh) {
+      const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+      info = LdG(f.blk_info + o);
+      coff = LdG(f.coef_off + o - (size_t)BI_Iy(info) * f.bw - BI_Ix(info));   // offset of the covering varblock
+    }
+    s_info[threadIdx.x] = info; s_coff[threadIdx.x] = coff;
+  }
+  __syncthreads();
+  const int32_t* cq[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
+  const float bias0 = f.quant_bias[0], bias1 = f.quant_bias[1], bias2 = f.quant_bias[2], bias3 = f.quant_bias[3];
+  // ---- pass 0: stage dequantised coefficients.  Task = (block of the tile, one of its 64 coefficient slots).
+  for (uint32_t t = threadIdx.x; t < 4096; t += blockDim.x) {
+    const uint32_t bi = t >> 6, j = t & 63;
+    const uint32_t info = s_info[bi];
+    if (info == 0xFFFFFFFFu) continue;
+    const uint32_t s = BI_Strategy(info), ix = BI_Ix(info), iy = BI_Iy(info);
+    const uint32_t cx = CoveredX(s), cy = CoveredY(s);
+    const uint32_t R = cy * 8, C = cx * 8;
+    const uint32_t k = (iy * cx + ix) * 64 + j;               // this block's share of the varblock's coefficients
+    const uint32_t kind = QuantKind(s);
+    const uint32_t base = s_coff[bi] + k;
+    const int32_t qy = LdG(cq[1] + base), qx = LdG(cq[0] + base), qb = LdG(cq[2] + base);
+    const float sd = f.inv_global_scale / (float)BI_HfMul(info);
+    const float ydq = AdjustQuantBias(qy, bias1, bias3) * (LdG(f.qtable[kind * 3 + 1] + k) * sd);
+    const float xv = AdjustQuantBias(qx, bias0, bias3) * (LdG(f.qtable[kind * 3 + 0] + k) * (sd * f.x_dm));
+    const float bv = AdjustQuantBias(qb, bias2, bias3) * (LdG(f.qtable[kind * 3 + 2] + k) * (sd * f.b_dm));
+    const uint32_t vbx = (bi & 7) - ix, vby = (bi >> 3) - iy;   // varblock origin inside the tile (blocks)
+    const size_t tile_i = (size_t)((by0 + vby) / 8) * f.cw + (bx0 + vbx) / 8;
+    const float kx = f.base_x + (float)LdG(f.ytox + tile_i) * f.color_scale;
+    const float kb = f.base_b + (float)LdG(f.ytob + tile_i) * f.color_scale;
+    uint32_t v, u;
+    if (IsSpecial(s)) { v = k >> 3; u = k & 7; }            // kept in stored order for SpecialTransform
+    else if (R >= C) { v = k % R; u = k / R; }
+    else { v = k / C; u = k % C; }
+    const uint32_t lo = (vby * 8 + v) * kTilePitch + vbx * 8 + u;
+    s_tile[lo] = fmaf(kx, ydq, xv);
+    s_tile[kTilePlane + lo] = ydq;
+    s_tile[2 * kTilePlane + lo] = fmaf(kb, ydq, bv);
+  }
+  __syncthreads();
+  // ---- pass 1: rows (3 channels x up to 512 rows)
+  for (uint32_t t = threadIdx.x; t < 512 * 3; t += blockDim.x) {
+    const uint32_t c = t / 512, tt = t % 512;
+    const uint32_t r = tt & 7, bi = tt >> 3;
+    const uint32_t info = s_info[bi];
+    if (info == 0xFFFFFFFFu || BI_Ix(info) != 0) continue;
     const uint32_t s = BI_Strategy(info), iy = BI_Iy(info);
     const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
-    const size_t o_first = o - (size_t)iy * f.bw;
-    const uint32_t kind = QuantKind(s);
-    BlockDequant d;
-    const uint32_t coff = f.coef_off[o_first];
-    for (int c = 0; c < 3; c++) { d.q[c] = f.coeff[c] + (size_t)g * 65536 + coff; d.table[c] = f.qtable[kind * 3 + c]; }
-    const float sd = f.inv_global_scale / (float)BI_HfMul(info);
-    d.sdc[0] = sd * f.x_dm; d.sdc[1] = sd; d.sdc[2] = sd * f.b_dm;
-    const size_t tile_i = (size_t)((by0 + by - iy) / 8) * f.cw + (bx0 + bx) / 8;
-    d.kx = f.base_x + (float)f.ytox[tile_i] * f.color_scale;
-    d.kb = f.base_b + (float)f.ytob[tile_i] * f.color_scale;
-    for (int i = 0; i < 4; i++) d.bias[i] = f.quant_bias[i];
-    const int R = cy * 8, C = cx * 8;
-    const int v = (int)(iy * 8 + r);
-    const int trow = (int)((by - iy) * 8) + v, tcol = (int)bx * 8;
+    const uint32_t bx = bi & 7, by = bi >> 3;
+    const size_t o_first = (size_t)(by0 + by - iy) * f.bw + bx0 + bx;
+    float* blk0 = s_tile + c * kTilePlane + ((by - iy) * 8) * kTilePitch + bx * 8;
     if (IsSpecial(s)) {
       if (r != 0) continue;
-      for (int c = 0; c < 3; c++) {
-        float cf[64];
-        for (uint32_t k = 0; k < 64; k++) cf[k] = DequantCoef(d, c, k);
-        cf[0] = f.llf[c][o_first];
-        SpecialTransform(s, cf, s_tile + c * kTilePlane + (by * 8) * kTilePitch + tcol, kTilePitch);
-      }
+      float cf[64];
+#pragma unroll
+      for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
+      cf[0] = LdG(f.llf[c] + o_first);
+      SpecialTransform(s, cf, blk0, kTilePitch);
       continue;
     }
-    switch (C) {
-      case 8: TileRowPass<8>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
-      case 16: TileRowPass<16>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
-      case 32: TileRowPass<32>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
-      default: TileRowPass<64>(d, R, v, cy, cx, f, o_first, s_tile, trow, tcol); break;
+    const int v = (int)(iy * 8 + r);
+    float* row0 = blk0 + v * kTilePitch;
+    const float* llf = f.llf[c] + o_first + (size_t)v * f.bw;
+    switch (cx * 8) {
+      case 8: TileRowPass<8>(row0, v, cy, cx, llf); break;
+      case 16: TileRowPass<16>(row0, v, cy, cx, llf); break;
+      case 32: TileRowPass<32>(row0, v, cy, cx, llf); break;
+      default: TileRowPass<64>(row0, v, cy, cx, llf); break;
     }
   }
   __syncthreads();
-  // ---- pass 2: vertical 1-D IDCT in LDS
+  // ---- pass 2: columns
   for (uint32_t t = threadIdx.x; t < 512 * 3; t += blockDim.x) {
     const uint32_t c = t / 512, tt = t % 512;
     const uint32_t xx = tt & 7, bi = tt >> 3;
-    const uint32_t bx = bi & 7, by = bi >> 3;
-    if (bx >= tbw || by >= tbh) continue;
-    const uint32_t info = f.blk_info[(size_t)(by0 + by) * f.bw + bx0 + bx];
-    if (BI_Iy(info) != 0) continue;
+    const uint32_t info = s_info[bi];
+    if (info == 0xFFFFFFFFu || BI_Iy(info) != 0) continue;
     const uint32_t s = BI_Strategy(info);
     if (IsSpecial(s)) continue;
+    const uint32_t bx = bi & 7, by = bi >> 3;
     float* col0 = s_tile + c * kTilePlane + (by * 8) * kTilePitch + bx * 8 + xx;
     switch ((int)CoveredY(s) * 8) {
       case 8: TileColPass<8>(col0); break;
@@ -1109,7 +1423,7 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
     const float* src = s_tile + c * kTilePlane;
     for (uint32_t i = threadIdx.x; i < 64 * th; i += blockDim.x) {
       const uint32_t y = i >> 6, x = i & 63;
-      if (x < tw) dst[(size_t)y * f.plane_stride + x] = src[y * kTilePitch + x];
+      if (x < tw) StG(dst + (size_t)y * f.plane_stride + x, src[y * kTilePitch + x]);
     }
   }
 }
@@ -1554,11 +1868,13 @@ void InitDeviceTables(void* stream) {
 static inline int DivUp(int a, int b) { return (a + b - 1) / b; }
 
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream) {
-  // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as the budget allows
-  const uint32_t lds_bytes = kModLdsFixed + (uint32_t)cfg.lds_code_budget;
+  // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
+  // that several LF groups fit one CU)
+  const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
+  const uint32_t lds_bytes = kTreeOff + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
-  hipLaunchKernelGGL(LfDecodeKernel, dim3(max_lf_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, lds_bytes);
+  hipLaunchKernelGGL(LfDecodeKernel, dim3(max_lf_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
@@ -1567,9 +1883,23 @@ void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, v
   hipLaunchKernelGGL(LlfSigmaKernel, grid, block, 0, (hipStream_t)stream, frames);
 }
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
+  if (cfg.lane_stride_hf == 1) {   // SIMT: one group stream per lane
+    const bool all_lds = cfg.ac_code_bytes <= cfg.lds_code_budget;     // every frame's AC code fits the LDS budget
+    const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      attr = true;
+    }
+    const dim3 grid(DivUp(max_groups, (int)kSimtThreads), nframes);
+    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(kSimtThreads), lds, (hipStream_t)stream, frames, lds);
+    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(kSimtThreads), lds, (hipStream_t)stream, frames, lds);
+    return;
+  }
   const int threads = cfg.hf_block_threads;
   const int per_block = threads / cfg.lane_stride_hf;
-  const uint32_t lds_bytes = 128 + (uint32_t)cfg.lds_code_budget;
+  const uint32_t lds_bytes = 128 + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)HfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
   dim3 grid(DivUp(max_groups, per_block), nframes);

@@ -542,7 +542,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   EntropyCoder tree_code, mod_code, ac_code;
   { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
   { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); }
-    BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 64, mod_code); }
+    BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 32, mod_code); }
   { std::vector<const std::vector<Token>*> s; for (auto& t : ac_tok) s.push_back(&t);
     BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_code); }
   // --- sections
