@@ -201,14 +201,15 @@ def main():
         # dominant kernel = stage with the largest device time; roofline from its ALGORITHMIC bytes per launch
         stage_ms = {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"}
         dom = max(stage_ms, key=stage_ms.get)
-        kernel_of = {"lf": "LfDecodeKernel", "lfpost": "LfDequant/LfSmooth/LlfSigma", "hf": "HfDecodeKernel", "idct": "IdctKernel",
-                     "filter": "Gaborish/Epf", "out": "OutputKernel"}
+        kernel_of = {"lf": "LfDecodeKernel", "lfpost": "LlfSigmaKernel", "hf": "HfDecodeSimtKernel" if args.lane_stride_hf == 1 else "HfDecodeKernel",
+                     "idct": "IdctTileKernel", "filter": "EpfKernel", "out": "OutputKernel"}
         achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(kernel_of[dom])
+            try:   # HBM bytes per frame of that kernel from the PMC passes (profiles/r01b_pmc_traffic.md) x frames per launch
+                per_frame = json.load(open(pmc))["per_kernel"].get(kernel_of[dom])
+                traffic = int(per_frame * B) if per_frame is not None else None
             except Exception:
                 traffic = None
         result = {
