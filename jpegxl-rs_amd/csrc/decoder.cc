@@ -169,6 +169,7 @@ void Batch::Prepare(void* stream_v) {
   };
   max_lf_groups_ = max_groups_ = max_w_ = max_h_ = max_bw_ = max_bh_ = max_epf_ = 0;
   any_gab_ = any_vardct_ = any_modular_ = false;
+  fplan_ = FilterPlan();
   for (int i = 0; i < n; i++) {
     ImageEntry& e = *images_[i];
     FramePlan& p = e.plan;
@@ -192,13 +193,18 @@ void Batch::Prepare(void* stream_v) {
     max_groups_ = std::max<int>(max_groups_, p.num_groups);
     max_w_ = std::max<int>(max_w_, p.width); max_h_ = std::max<int>(max_h_, p.height);
     max_bw_ = std::max<int>(max_bw_, p.bw); max_bh_ = std::max<int>(max_bh_, p.bh);
-    if (!p.modular) { max_epf_ = std::max<int>(max_epf_, p.lf.epf_iters); any_gab_ |= p.lf.gab != 0; }
+    if (!p.modular) {
+      max_epf_ = std::max<int>(max_epf_, p.lf.epf_iters); any_gab_ |= p.lf.gab != 0;
+      const bool fusable = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded;
+      fplan_.any_fused |= fusable; fplan_.any_unfused |= !fusable;
+      fplan_.any_gab |= p.lf.gab != 0; fplan_.max_epf = std::max<int>(fplan_.max_epf, p.lf.epf_iters);
+    }
   }
   // ---- work arena layout
   size_t w = 0;
   auto take = [&](size_t bytes) { size_t off = Align(w); w = off + bytes; return off; };
   struct WorkOffsets {
-    size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
+    size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, vb_list, vb_count, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
         mod_scratch;
     size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride;
   };
@@ -224,6 +230,7 @@ void Batch::Prepare(void* stream_v) {
       const size_t nb = (size_t)p.bw * p.bh;
       for (int c = 0; c < 3; c++) { o.lfq[c] = take(nb * 4); o.lf[c] = take(nb * 4); o.lf_tmp[c] = take(nb * 4); o.llf[c] = take(nb * 4); }
       o.blk_info = take(nb * 4); o.coef_off = take(nb * 4); o.inv_sigma = take(nb * 4);
+      o.vb_list = take((size_t)p.num_groups * 1024 * 8); o.vb_count = take((size_t)p.num_groups * 4);
       const size_t ntile = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8);
       o.ytox = take(ntile); o.ytob = take(ntile);
       const size_t plane = (size_t)p.bw * 8 * p.bh * 8 * 4;
@@ -315,6 +322,7 @@ void Batch::Prepare(void* stream_v) {
         f.plane_a[k] = (float*)(dwork_ + o.plane_a[k]); f.plane_b[k] = (float*)(dwork_ + o.plane_b[k]);
       }
       f.blk_info = (uint32_t*)(dwork_ + o.blk_info); f.coef_off = (uint32_t*)(dwork_ + o.coef_off);
+      f.vb_list = (uint2*)(dwork_ + o.vb_list); f.vb_count = (uint32_t*)(dwork_ + o.vb_count);
       f.ytox = (int8_t*)(dwork_ + o.ytox); f.ytob = (int8_t*)(dwork_ + o.ytob);
       f.inv_sigma = (float*)(dwork_ + o.inv_sigma);
       f.lf_scratch = (int32_t*)(dwork_ + o.lf_scratch); f.lf_scratch_stride = o.lf_scratch_stride;
@@ -416,8 +424,8 @@ void Batch::Run(void* stream_v) {
     LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
-    LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
-    LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
+    LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
+    LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
   }
   if (any_modular_) {
     LaunchModularGlobal(dframes_, n, stream_v);
@@ -497,9 +505,9 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     rec(3);
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     rec(4);
-    LaunchFilters(dframes_, n, max_w_, max_h_, max_bw_, max_bh_, any_gab_, max_epf_, stream_v);
+    LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     rec(5);
-    LaunchOutput(dframes_, n, max_w_, max_h_, stream_v);
+    LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     rec(6);
     if (timed && part == 2) timed_rest_cursor_++;
   }

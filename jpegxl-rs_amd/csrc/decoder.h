@@ -81,6 +81,7 @@ class Batch {
   bool prepared_ = false;
   int max_lf_groups_ = 0, max_groups_ = 0, max_w_ = 0, max_h_ = 0, max_bw_ = 0, max_bh_ = 0, max_epf_ = 0;
   bool any_gab_ = false, any_vardct_ = false, any_modular_ = false;
+  FilterPlan fplan_;
   struct ModFinish { int frame; std::vector<int> planes; };  // host-side channel lists for modular frames
   std::vector<std::vector<size_t>> mod_plane_offsets_;
   std::vector<std::vector<void*>> timed_events_;

@@ -52,6 +52,8 @@ struct FrameDev {
   float* llf[3];
   uint32_t* blk_info;
   uint32_t* coef_off;
+  uint2* vb_list;                 // per group: up to 1024 {strategy | hf_mul-1 << 8 | x << 16 | y << 21, coefficient offset}
+  uint32_t* vb_count;             // per group: number of varblocks
   int8_t* ytox; int8_t* ytob;
   int32_t* coeff[3];
   float* plane_a[3];
@@ -87,9 +89,10 @@ struct LaunchCfg {
   int lane_stride_mod = 64;
   // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
   int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;
-  int force_generic_idct = 0;        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames
+  int force_generic_idct = 0;
+  int force_unfused_filters = 0;     // testing: stage-by-stage gaborish / EPF / output kernels even for fusable frames        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames
   int hf_block_threads = 512;        // threads per HF-decode block (streams per block = threads / lane_stride_hf)
-  int lds_code_budget = 48 * 1024;   // bytes of LDS the entropy-code tables (cfg, ctx map, alias) may take per block
+  int lds_code_budget = 64 * 1024;   // bytes of LDS the entropy-code tables (cfg, ctx map, alias) may take per block
 };
 
 void InitDeviceTables(void* stream);
@@ -99,8 +102,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream);
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream);
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream);
-void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, int max_bw, int max_bh, bool any_gab, int max_epf, void* stream);
-void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, void* stream);
+struct FilterPlan { bool any_fused = false, any_unfused = false, any_gab = false; int max_epf = 0; };   // over the VarDCT frames of a batch
+void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream);
+void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream);
 // Modular stages
 struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; };
 void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream);

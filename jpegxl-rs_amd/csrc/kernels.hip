@@ -78,8 +78,18 @@ template <> __device__ __forceinline__ uint4 LdG<uint4>(const uint4* p) {
   const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+template <> __device__ __forceinline__ uint2 LdG<uint2>(const uint2* p) {
+  typedef uint32_t __attribute__((ext_vector_type(2))) v2;
+  const v2 v = *reinterpret_cast<const __attribute__((address_space(1))) v2*>(reinterpret_cast<uintptr_t>(p));
+  return make_uint2(v.x, v.y);
+}
 template <typename T> __device__ __forceinline__ void StG(T* p, T v) {
   *reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p)) = v;
+}
+template <> __device__ __forceinline__ void StG<uint2>(uint2* p, uint2 v) {
+  typedef uint32_t __attribute__((ext_vector_type(2))) v2;
+  v2 t; t.x = v.x; t.y = v.y;
+  *reinterpret_cast<__attribute__((address_space(1))) v2*>(reinterpret_cast<uintptr_t>(p)) = t;
 }
 #else   // host pass of hipcc only needs the declarations to parse
 template <typename T> __device__ __forceinline__ T LdG(const T* p) { return *p; }
@@ -88,7 +98,6 @@ template <typename T> __device__ __forceinline__ void StG(T* p, T v) { *p = v; }
 template <typename T> __device__ __forceinline__ T LdS(uint32_t byte_off) { return *reinterpret_cast<const T*>(g_dyn_lds + byte_off); }
 template <typename T> __device__ __forceinline__ void StS(uint32_t byte_off, T v) { *reinterpret_cast<T*>(g_dyn_lds + byte_off) = v; }
 constexpr uint32_t kNotInLds = 0xFFFFFFFFu;
-constexpr uint32_t kWinOffC = 3072;   // = kWinOff (bit-stream window of the modular fast path)
 
 // Bit reader whose next 32-bit word is always already in flight: the refill never waits on global-memory latency.
 struct BitReaderP {
@@ -202,13 +211,13 @@ template <bool ALL_LDS> __device__ __forceinline__ uint32_t FastHybridT(BitReade
 }
 
 // LDS-only variants used by the serial fast path: no vector-memory instruction, hence no vmcnt wait, in the token loop.
-struct BitReaderW {      // reads 32-bit words from the LDS window [kWinOff, ...) holding words win_base.. of the stream
-  uint32_t wpos, win_base;
+struct BitReaderW {      // reads 32-bit words from an LDS window at win_off holding words win_base.. of the stream
+  uint32_t wpos, win_base, win_off;
   uint64_t buf;
   int avail;
   __device__ __forceinline__ void Refill() {
     if (avail <= 32) {
-      buf |= (uint64_t)LdS<uint32_t>(kWinOffC + ((wpos - win_base) << 2)) << avail;
+      buf |= (uint64_t)LdS<uint32_t>(win_off + ((wpos - win_base) << 2)) << avail;
       avail += 32;
       wpos++;
     }
@@ -273,17 +282,32 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
   return used;
 }
 
-// ---- Modular channel decode, cooperative version ------------------------------------------------------------------------
+// ---- Modular channel decode, cooperative version -------------------------------------------------------------------------
+// One wavefront decodes one sub-stream: lane 0 runs the serial chain, the other 63 lanes build LUTs and move data.
+// Several wavefronts (= several LF groups of one frame) share a workgroup and therefore one LDS copy of the MA tree and
+// the entropy code; everything else is per wavefront at `wb` and synchronised with wave-level fences only.
 constexpr int kLdsTreeMax = 1024;   // nodes copied to LDS (16 KiB); larger trees are walked in global memory
+// per-wavefront LDS region
 constexpr uint32_t kLutOff = 0, kWorkOff = 2048;
-constexpr uint32_t kWinOff = 3072, kWinWords = 528;                 // bit-stream window: 2112 B (>= 256 samples x 48 bits + slack)
-constexpr uint32_t kRowOff = kWinOff + kWinWords * 4, kRowMax = 1024; // two sample rows (current / previous) of up to 1024 ints
-constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;            // 256-sample staging buffer for wider channels
-constexpr uint32_t kTreeOff = kChunkOff + 256 * 4;
+constexpr uint32_t kWinOff = 3072, kWinWords = 528;                   // bit-stream window: 2112 B (>= 256 samples x 48 bits + slack)
+constexpr uint32_t kRowOff = kWinOff + kWinWords * 4, kRowMax = 256;  // two sample rows (current / previous) of up to 256 ints
+constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;             // 256-sample staging buffer for wider channels
+constexpr uint32_t kWaveLds = 8448;                                   // >= kChunkOff + 1024 and >= the 8 KiB placement bitmap
+static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
+constexpr uint32_t kLfWaves = 4;
+constexpr uint32_t kTreeOff = kLfWaves * kWaveLds;                    // shared: tree copy, then the entropy code
+
+__device__ __forceinline__ void WaveSync() {   // orders LDS/global accesses between the lanes of ONE wavefront
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct ModTables {
   const TreeNode* tree_g;
   bool tree_in_lds;         // LDS copy at kTreeOff (leaves rewritten: a = predictor | cluster << 8)
   uint32_t tree_cap;
+  uint32_t wb;              // base of this wavefront's private LDS region
   FastCode code;
   __device__ __forceinline__ TreeNode Node(uint32_t i) const {
     if (tree_in_lds) {
@@ -338,12 +362,13 @@ __device__ __forceinline__ int32_t Predict(uint32_t predictor, int32_t W, int32_
   }
 }
 
-// All threads of the block call this (contains barriers).  Thread 0 decodes; the others help build the LUT.
+// All 64 lanes of the wavefront call this.  Lane 0 decodes; the others help with LUT, bit-stream window and row I/O.
 // Semantics identical to DecodeModularChannel (jxl_dev.h).
 __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
   if (ch.w == 0 || ch.h == 0) return;
-  // ---- thread 0: resolve static properties (channel, stream id) and analyse the remaining subtree
-  if (threadIdx.x == 0) {
+  const uint32_t lane = threadIdx.x & 63, wb = T.wb;
+  // ---- lane 0: resolve static properties (channel, stream id) and analyse the remaining subtree
+  if (lane == 0) {
     uint32_t pos = 0;
     TreeNode n = T.Node(0);
     while (n.prop == 0 || n.prop == 1) {
@@ -353,10 +378,10 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     }
     int mode = 1, prop = -1, count = 0;
     int upred = -1;   // predictor shared by all leaves with offset 0 / multiplier 1 (-2: not uniform / not simple)
-    int sp = 0;   // iterative DFS with a bounded stack at kWorkOff + 32
-    StS<int>(kWorkOff + 32 + 4 * sp++, (int)pos);
+    int sp = 0;       // iterative DFS with a bounded stack at kWorkOff + 64
+    StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)pos);
     while (sp > 0 && mode == 1) {
-      const TreeNode m = T.Node((uint32_t)LdS<int>(kWorkOff + 32 + 4 * --sp));
+      const TreeNode m = T.Node((uint32_t)LdS<int>(wb + kWorkOff + 64 + 4 * --sp));
       if (++count > 600) { mode = 0; break; }
       if (m.prop < 0) {
         if ((m.a & 0xFF) == 6) mode = 0;                                     // weighted predictor: general path
@@ -368,32 +393,32 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       if (m.prop == 15 || m.prop >= 16 || m.prop <= 1) { mode = 0; break; }
       if (prop < 0) prop = m.prop; else if (prop != m.prop) { mode = 0; break; }
       if (m.val < -512 || m.val > 510 || sp + 2 > 200) { mode = 0; break; }
-      StS<int>(kWorkOff + 32 + 4 * sp++, (int)m.a); StS<int>(kWorkOff + 32 + 4 * sp++, (int)m.b);
+      StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.a); StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.b);
     }
     if (!T.tree_in_lds) mode = 0;
-    StS<int>(kWorkOff + 0, mode); StS<int>(kWorkOff + 4, prop); StS<int>(kWorkOff + 8, (int)pos); StS<int>(kWorkOff + 12, upred);
+    StS<int>(wb + kWorkOff + 0, mode); StS<int>(wb + kWorkOff + 4, prop); StS<int>(wb + kWorkOff + 8, (int)pos); StS<int>(wb + kWorkOff + 12, upred);
   }
-  __syncthreads();
-  const int mode = LdS<int>(kWorkOff + 0), prop = LdS<int>(kWorkOff + 4);
-  const uint32_t subroot = (uint32_t)LdS<int>(kWorkOff + 8);
-  const int upred = LdS<int>(kWorkOff + 12);
+  WaveSync();
+  const int mode = LdS<int>(wb + kWorkOff + 0), prop = LdS<int>(wb + kWorkOff + 4);
+  const uint32_t subroot = (uint32_t)LdS<int>(wb + kWorkOff + 8);
+  const int upred = LdS<int>(wb + kWorkOff + 12);
   // fast rows: leaves are (predictor p, offset 0, multiplier 1) with p in {0 zero, 1 W, 5 gradient}; the LUT then maps
   // the property value straight to the cluster
   const bool need_n = upred == 5 || prop == 9;    // previous row needed
   const bool fast = mode == 1 && (upred == 0 || upred == 1 || upred == 5) && (prop < 0 || prop == 2 || prop == 9) &&
                     T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && ((uint32_t)ch.w <= kRowMax || !need_n);
   if (mode == 1) {
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+    for (int i = (int)lane; i < 1024; i += 64) {
       const int32_t v = i - 512;
       uint32_t pos = subroot;
       TreeNode n = T.Node(pos);
       while (n.prop >= 0) { pos = v > n.val ? n.a : n.b; n = T.Node(pos); }
-      StS<uint16_t>(kLutOff + 2 * i, fast ? (uint16_t)(n.a >> 8) : (uint16_t)pos);   // fast: cluster, else leaf node index
+      StS<uint16_t>(wb + kLutOff + 2 * i, fast ? (uint16_t)(n.a >> 8) : (uint16_t)pos);   // fast: cluster, else leaf node index
     }
   }
-  __syncthreads();
+  WaveSync();
   if (fast) {
-    // ---- LDS-only serial loop.  Thread 0 decodes 256 samples at a time from a bit-stream window in LDS, reading the
+    // ---- LDS-only serial loop.  Lane 0 decodes 256 samples at a time from a bit-stream window in LDS, reading the
     // previous row from LDS and writing into LDS; the other lanes load the window and flush finished rows / chunks with
     // coalesced global accesses.
     const int w = ch.w, h = ch.h;
@@ -401,22 +426,22 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
     const uint32_t wend = br.wend;
     BitReaderW bw;
-    bw.wpos = 0; bw.win_base = 0; bw.buf = 0; bw.avail = 0;
+    bw.wpos = 0; bw.win_base = 0; bw.buf = 0; bw.avail = 0; bw.win_off = wb + kWinOff;
     uint32_t skip_bits = 0;
-    if (threadIdx.x == 0) { const uint64_t bp = br.BitPos(); bw.wpos = (uint32_t)(bp >> 5); skip_bits = (uint32_t)(bp & 31); }
+    if (lane == 0) { const uint64_t bp = br.BitPos(); bw.wpos = (uint32_t)(bp >> 5); skip_bits = (uint32_t)(bp & 31); }
     int32_t left = 0, nw = 0;
-    uint32_t cur = kRowOff, prev = kRowOff + kRowMax * 4;
+    uint32_t cur = wb + kRowOff, prev = wb + kRowOff + kRowMax * 4;
     for (int y = 0; y < h; y++) {
       int32_t* p = ch.data + (size_t)y * ch.stride;
       uint32_t cl_row = 0;
-      if (prop != 9) { int32_t v = prop == 2 ? y : 0; v = v > 511 ? 511 : v; cl_row = LdS<uint16_t>(kLutOff + 2 * (uint32_t)(v + 512)); }
+      if (prop != 9) { int32_t v = prop == 2 ? y : 0; v = v > 511 ? 511 : v; cl_row = LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)); }
       for (int x0 = 0; x0 < w; x0 += 256) {
-        if (threadIdx.x == 0) StS<uint32_t>(kWorkOff + 16, bw.wpos);
-        __syncthreads();
-        const uint32_t wbase = LdS<uint32_t>(kWorkOff + 16);
-        for (uint32_t i = threadIdx.x; i < kWinWords; i += blockDim.x) StS<uint32_t>(kWinOff + i * 4, wbase + i < wend ? LdG(br.words + wbase + i) : 0u);
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        if (lane == 0) StS<uint32_t>(wb + kWorkOff + 16, bw.wpos);
+        WaveSync();
+        const uint32_t wbase = LdS<uint32_t>(wb + kWorkOff + 16);
+        for (uint32_t i = lane; i < kWinWords; i += 64) StS<uint32_t>(wb + kWinOff + i * 4, wbase + i < wend ? LdG(br.words + wbase + i) : 0u);
+        WaveSync();
+        if (lane == 0) {
           bw.win_base = wbase;
           if (skip_bits != 0xFFFFFFFFu) {   // first chunk of the channel: establish the bit buffer
             bw.buf = 0; bw.avail = 0;
@@ -424,17 +449,17 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
             skip_bits = 0xFFFFFFFFu;
           }
           const int x1 = min(w, x0 + 256);
-          const uint32_t obase = row_in_lds ? cur : kChunkOff - (uint32_t)x0 * 4;
+          const uint32_t obase = row_in_lds ? cur : wb + kChunkOff - (uint32_t)x0 * 4;
           for (int x = x0; x < x1; x++) {
             int32_t W, N, NW;
             if (y == 0) { W = x ? left : 0; N = W; NW = W; }
             else if (need_n) { N = LdS<int32_t>(prev + 4 * x); W = x ? left : N; NW = x ? nw : W; nw = N; }
-            else { W = x ? left : LdS<int32_t>(kWorkOff + 24); N = W; NW = W; }
+            else { W = x ? left : LdS<int32_t>(wb + kWorkOff + 24); N = W; NW = W; }
             uint32_t cluster = cl_row;
             if (prop == 9) {
               int32_t v = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
               v = v < -512 ? -512 : (v > 511 ? 511 : v);
-              cluster = LdS<uint16_t>(kLutOff + 2 * (uint32_t)(v + 512));
+              cluster = LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512));
             }
             int32_t guess;
             if (upred == 0) guess = 0;
@@ -443,30 +468,30 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
             const uint32_t tok = HybridLds(bw, state, cfg_off, alias_off, la, cluster);
             const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) + (uint32_t)guess);
             StS<int32_t>(obase + 4 * x, val);
-            if (x == 0) StS<int32_t>(kWorkOff + 24, val);   // W of the next row's first sample when the row is not kept in LDS
+            if (x == 0) StS<int32_t>(wb + kWorkOff + 24, val);   // W of the next row's first sample when the row is not kept in LDS
             left = val;
           }
         }
-        __syncthreads();
+        WaveSync();
         if (!row_in_lds) {
           const int n = min(256, w - x0);
-          for (int i = threadIdx.x; i < n; i += blockDim.x) StG(p + x0 + i, LdS<int32_t>(kChunkOff + 4 * i));
+          for (int i = (int)lane; i < n; i += 64) StG(p + x0 + i, LdS<int32_t>(wb + kChunkOff + 4 * i));
         }
       }
       if (row_in_lds) {
-        for (int i = threadIdx.x; i < w; i += blockDim.x) StG(p + i, LdS<int32_t>(cur + 4 * i));
+        for (int i = (int)lane; i < w; i += 64) StG(p + i, LdS<int32_t>(cur + 4 * i));
         const uint32_t t = cur; cur = prev; prev = t;
       }
     }
     // hand the bit position back to the generic reader
-    if (threadIdx.x == 0) StS<uint64_t>(kWorkOff + 32, bw.BitPos());
-    __syncthreads();
-    const uint64_t endpos = LdS<uint64_t>(kWorkOff + 32);
+    if (lane == 0) StS<uint64_t>(wb + kWorkOff + 32, bw.BitPos());
+    WaveSync();
+    const uint64_t endpos = LdS<uint64_t>(wb + kWorkOff + 32);
     br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
-    __syncthreads();
+    WaveSync();
     return;
   }
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     const int w = ch.w, h = ch.h;
     const FastCode& code = T.code;
     WPState wps;
@@ -498,7 +523,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
         if (mode == 1) {
           int32_t v = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
           v = v < -512 ? -512 : (v > 511 ? 511 : v);
-          n = T.Node(LdS<uint16_t>(kLutOff + 2 * (uint32_t)(v + 512)));
+          n = T.Node(LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)));
         } else {
           uint32_t pos = subroot;
           n = T.Node(pos);
@@ -522,10 +547,10 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       }
     }
   }
-  __syncthreads();
+  WaveSync();
 }
 
-// Stages tree + code into LDS for the modular decoders.  The block's dynamic LDS must hold kModLdsFixed + code budget.
+// Stages tree + code into the shared part of the LDS (all threads of the block; one block barrier).
 __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTables& T, uint32_t tree_cap, uint32_t lds_bytes) {
   const uint32_t code_base = kTreeOff + tree_cap * 16;
   const uint32_t budget = lds_bytes > code_base ? lds_bytes - code_base : 0;
@@ -533,6 +558,7 @@ __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTabl
   T.tree_g = f.tree;
   T.tree_cap = tree_cap;
   T.tree_in_lds = num_tree_nodes <= tree_cap;
+  T.wb = (threadIdx.x >> 6) * kWaveLds;
   if (T.tree_in_lds) {
     for (uint32_t i = threadIdx.x; i < num_tree_nodes; i += blockDim.x) {
       uint4 v = LdG(reinterpret_cast<const uint4*>(f.tree + i));
@@ -544,26 +570,34 @@ __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTabl
 }
 
 // =====================================================================================================================
-// K_lf: one 64-thread block per LF group — LF coefficients (3 channels, order Y,X,B) + HF metadata, varblock placement
+// K_lf: one wavefront per LF group (four per workgroup, sharing the tables) — LF coefficients (3 channels, order Y,X,B)
+// + HF metadata, then varblock placement
 // =====================================================================================================================
-__global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
+__global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
-  const uint32_t g = blockIdx.x;
-  if (g >= f.num_lf_groups) return;
+  if (blockIdx.x * kLfWaves >= f.num_lf_groups) return;
+  __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves: issue ahead of co-resident bandwidth kernels
+  ModTables T;
+  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wb = T.wb;
+  const uint32_t g = blockIdx.x * kLfWaves + wave;
+  if (g >= f.num_lf_groups) return;             // (no block-wide barrier after this point)
   const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
   const uint32_t bx0 = gx * 256, by0 = gy * 256;
   const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
-  ModTables T;
-  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
   BitReaderP br;
+  const uint64_t sec_end = f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g];
   if (f.single_section) br.Init(f.cs, f.lf_start_bitpos, f.cs_size);
-  else { const uint64_t off = f.sec_off[1 + g]; br.Init(f.cs, off * 8, off + f.sec_size[1 + g]); }
-  const uint64_t limit = f.single_section ? f.cs_size * 8 : (f.sec_off[1 + g] + f.sec_size[1 + g]) * 8;
-  __shared__ int s_fail;
-  __shared__ GroupHeaderD s_gh;
-  __shared__ uint32_t s_u[4];
-  if (threadIdx.x == 0) s_fail = 0;
+  else br.Init(f.cs, f.sec_off[1 + g] * 8, sec_end);
+  const uint64_t limit = sec_end * 8;
+  __shared__ int s_fail_w[kLfWaves];
+  __shared__ GroupHeaderD s_gh_w[kLfWaves];
+  __shared__ uint32_t s_u_w[kLfWaves][4];
+  int& s_fail = s_fail_w[wave];
+  GroupHeaderD& s_gh = s_gh_w[wave];
+  uint32_t* s_u = s_u_w[wave];
+  if (lane == 0) s_fail = 0;
 
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp;
@@ -572,16 +606,16 @@ __global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict_
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
 
   // ---- LF coefficients
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     s_u[0] = br.Read(2);  // extra_precision
     BitReader tmp;        // GroupHeader parsing reuses the generic reader type: re-sync positions around it
     tmp.Init(f.cs, br.BitPos(), f.cs_size);
     if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree || s_gh.ntransforms != 0) { SetError(f, kErrUnsupported); s_fail = 1; }
-    br.Init(f.cs, tmp.BitPos(), f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g]);
+    br.Init(f.cs, tmp.BitPos(), sec_end);
     state = br.Read(32);
     scratch[0] = (int32_t)s_u[0];
   }
-  __syncthreads();
+  WaveSync();
   if (s_fail) return;
   mc.wp = s_gh.wp; mc.stream_id = 1 + g;
   {
@@ -594,16 +628,16 @@ __global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict_
     }
   }
   // ---- HF metadata: 4 channels {ytox, ytob, (strategy,hf_mul-1) x nb_blocks, sharpness}
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     if (state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
     s_u[1] = 1 + br.Read(CeilLog2D(gbw * gbh));
     BitReader tmp;
     tmp.Init(f.cs, br.BitPos(), f.cs_size);
     if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree || s_gh.ntransforms != 0) { SetError(f, kErrUnsupported); s_fail = 1; }
-    br.Init(f.cs, tmp.BitPos(), f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g]);
+    br.Init(f.cs, tmp.BitPos(), sec_end);
     state = br.Read(32);
   }
-  __syncthreads();
+  WaveSync();
   if (s_fail) return;
   const uint32_t nb_blocks = s_u[1];
   mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
@@ -619,17 +653,15 @@ __global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict_
     ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeChannelCoop(br, state, T, mc, ch, 2);
     ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeChannelCoop(br, state, T, mc, ch, 3);
   }
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     if (state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
     else if (br.BitPos() > limit) { SetError(f, kErrOverrun); s_fail = 1; }
     else if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
   }
-  __syncthreads();
+  WaveSync();
   if (s_fail) return;
-  // make thread 0's global stores (metadata channels) visible to the whole block
-  __threadfence_block();
-  // ---- chroma-from-luma maps (all threads)
-  for (uint32_t i = threadIdx.x; i < mcw * mch; i += blockDim.x) {
+  // ---- chroma-from-luma maps (all lanes)
+  for (uint32_t i = lane; i < mcw * mch; i += 64) {
     const uint32_t y = i / mcw, x = i % mcw;
     const int a = m_ytox[i], b = m_ytob[i];
     if (a < -128 || a > 127 || b < -128 || b > 127) { SetError(f, kErrBadValue); s_fail = 1; }
@@ -638,26 +670,26 @@ __global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict_
   }
   // ---- varblock placement (raster order, first not-yet-covered block) with an LDS coverage bitmap; coefficient
   // offsets per 256x256 group.  Blocks never cross a 32-block boundary, hence never a 64-bit word of the bitmap.
-  __shared__ unsigned long long s_cover[256 * 4];
-  for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) {
+  const uint32_t cover_off = wb;   // 8 KiB, reuses this wavefront's private region
+  for (uint32_t i = lane; i < 1024; i += 64) {
     const uint32_t y = i >> 2, wx = (i & 3) * 64;
     unsigned long long m = 0;   // bits outside the LF group are pre-set
     if (y >= gbh || wx >= gbw) m = ~0ull;
     else if (gbw - wx < 64) m = ~0ull << (gbw - wx);
-    s_cover[i] = m;
+    StS<unsigned long long>(cover_off + i * 8, m);
   }
-  __syncthreads();
+  WaveSync();
   if (s_fail) return;
-  if (threadIdx.x == 0) {
-    uint32_t goff[64];
-    for (int i = 0; i < 64; i++) goff[i] = 0;
+  if (lane == 0) {
+    uint32_t goff[64], gcnt[64];
+    for (int i = 0; i < 64; i++) { goff[i] = 0; gcnt[i] = 0; }
     uint32_t num = 0;
     int32_t s_next = LdG(m_blk), q_next = LdG(m_blk + nb_blocks);
     bool bad = false;
     for (uint32_t y = 0; y < gbh && !bad; y++) {
       for (uint32_t wi = 0; wi < 4 && !bad; wi++) {
         while (true) {
-          const unsigned long long cov = s_cover[y * 4 + wi];
+          const unsigned long long cov = LdS<unsigned long long>(cover_off + (y * 4 + wi) * 8);
           if (cov == ~0ull) break;
           const uint32_t x = wi * 64 + (uint32_t)__ffsll((long long)~cov) - 1;
           if (num >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
@@ -671,15 +703,21 @@ __global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict_
           if (x + cx > gbw || y + cy > gbh || (x % 32) + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
           const unsigned long long bits = ((cx == 64 ? 0ull : (1ull << cx)) - 1ull) << (x & 63);
           for (uint32_t iy = 0; iy < cy; iy++) {
-            unsigned long long& wv = s_cover[(y + iy) * 4 + wi];
+            const uint32_t co = cover_off + ((y + iy) * 4 + wi) * 8;
+            const unsigned long long wv = LdS<unsigned long long>(co);
             if (wv & bits) { SetError(f, kErrVarblock); bad = true; }
-            wv |= bits;
+            StS<unsigned long long>(co, wv | bits);
           }
           if (bad) break;
           if ((x % 8) + cx > 8 || (y % 8) + cy > 8) *f.frame_flags = 1;   // varblock not contained in a 64x64 tile: generic IDCT
           const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
           const uint32_t gi = (y / 32) * 8 + (x / 32);
           StG(f.coef_off + o, goff[gi]);
+          {  // per-group varblock list for the HF decoder: {strategy | hf_mul-1 << 8 | x << 16 | y << 21, coefficient offset}
+            const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
+            StG(f.vb_list + (size_t)gg * 1024 + gcnt[gi], make_uint2((uint32_t)s | ((uint32_t)q << 8) | ((x % 32) << 16) | ((y % 32) << 21), goff[gi]));
+            gcnt[gi]++;
+          }
           goff[gi] += cx * cy * 64;
           for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++)
             StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo((uint32_t)s, ix == 0 && iy == 0, (uint32_t)q, ix, iy, 0));
@@ -687,12 +725,15 @@ __global__ __launch_bounds__(64) void LfDecodeKernel(const FrameDev* __restrict_
       }
     }
     if (bad) s_fail = 1;
+    else for (uint32_t gi = 0; gi < 64; gi++) {
+      const uint32_t ly = gi / 8, lx = gi % 8;
+      if (ly * 32 < gbh && lx * 32 < gbw) StG(f.vb_count + (gy * 8 + ly) * f.xgroups + gx * 8 + lx, gcnt[gi]);
+    }
   }
-  __syncthreads();
+  WaveSync();
   if (s_fail) return;
-  __threadfence_block();
-  // ---- merge the sharpness map into the block info words (all threads)
-  for (uint32_t i = threadIdx.x; i < gbw * gbh; i += blockDim.x) {
+  // ---- merge the sharpness map into the block info words (all lanes)
+  for (uint32_t i = lane; i < gbw * gbh; i += 64) {
     const int32_t sh = m_sharp[i];
     if (sh < 0 || sh > 7) { SetError(f, kErrBadValue); continue; }
     f.blk_info[(size_t)(by0 + i / gbw) * f.bw + bx0 + i % gbw] |= (uint32_t)sh << 26;
@@ -919,13 +960,69 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
 }
 
 // ---- SIMT variant: every lane decodes the stream of its own group; one token per lane per loop iteration -------------
-// The per-token work (context → cluster → alias lookup → state update → refill → hybrid bits → store) is the same
-// straight-line code for the "number of non-zeros" token and the coefficient tokens, so lanes stay converged; block
-// set-up is a separate, rarer, state.  All groups of a block belong to one frame and share its tables in LDS.
+// The per-token work (context -> cluster -> alias lookup -> state update -> refill -> hybrid bits -> store) is the same
+// straight-line code for the "number of non-zeros" token and the coefficient tokens, so lanes stay converged.  Nothing in
+// the loop waits on global memory: tables, the per-lane bit-stream ring and the non-zero row buffers live in LDS, the
+// varblock list entry of the next block and the next coefficient position are loaded one step ahead, and the bit-stream
+// rings are topped up every fourth iteration with loads issued four iterations earlier.
 constexpr uint32_t kSimtThreads = 256;
 constexpr uint32_t kSimtNzOff = 128;                                   // per-thread nzeros row buffers: 96 B each
-constexpr uint32_t kSimtBcmOff = kSimtNzOff + kSimtThreads * 96;       // copy of the BlockCtxDev
-constexpr uint32_t kSimtCodeOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;
+constexpr uint32_t kSimtRingOff = kSimtNzOff + kSimtThreads * 96;      // per-thread bit-stream ring: 16 words
+constexpr uint32_t kSimtBcmOff = kSimtRingOff + kSimtThreads * 64;     // copy of the BlockCtxDev
+constexpr uint32_t kSimtOrdOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;   // natural orders of buckets 0..8 (u16)
+constexpr uint32_t kSimtOrdEntries = 64 + 64 + 256 + 1024 + 128 + 256 + 512 + 4096 + 2048;
+constexpr uint32_t kSimtCodeOff = kSimtOrdOff;   // (orders stay in global memory: staging them in LDS bought nothing)
+__device__ __forceinline__ uint32_t OrderLdsOffset(uint32_t bucket) {   // byte offset of a bucket's order table inside the LDS copy
+  const uint32_t e = bucket == 0 ? 0 : bucket == 1 ? 64 : bucket == 2 ? 128 : bucket == 3 ? 384 : bucket == 4 ? 1408 : bucket == 5 ? 1536 : bucket == 6 ? 1792 : bucket == 7 ? 2304 : 6400;
+  return kSimtOrdOff + e * 2;
+}
+
+struct BitReaderRing {   // per-lane ring of 16 words in LDS; absolute word index w lives at slot w & 15
+  uint32_t wpos, ring_off;
+  uint64_t buf;
+  int avail;
+  __device__ __forceinline__ void Refill() {
+    if (avail <= 32) {
+      buf |= (uint64_t)LdS<uint32_t>(ring_off + ((wpos & 15) << 2)) << avail;
+      avail += 32;
+      wpos++;
+    }
+  }
+  __device__ __forceinline__ uint32_t Read(int n) {
+    Refill();
+    const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
+    buf >>= n; avail -= n;
+    return v;
+  }
+  __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)wpos * 32 - (uint64_t)avail; }
+};
+
+template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridSimt(BR& br, uint32_t& state, const FastCode& c, uint32_t ctx) {
+  const uint32_t cluster = ALL_LDS ? LdS<uint8_t>(c.ctx_map_off + ctx) : c.Cluster(ctx);
+  const uint32_t la = c.log_alpha;
+  const uint32_t cfg = ALL_LDS ? LdS<uint32_t>(c.cfg_off + cluster * 4) : c.Cfg(cluster);
+  const uint32_t res = state & 0xFFF;
+  const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
+  const uint64_t e = ALL_LDS ? LdS<uint64_t>(c.alias_off + (((cluster << la) + i) << 3)) : c.Alias((cluster << la) + i);
+  const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+  const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+  const bool hit = pos >= cutoff;
+  uint32_t tok = hit ? right : i;
+  const uint32_t off = hit ? offs1 + pos : pos;
+  const uint32_t freq = hit ? freq1 : freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | br.Read(16);
+  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+  const uint32_t split = 1u << split_exp;
+  if (tok < split) return tok;
+  uint32_t nbits = split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb));
+  nbits &= 31;
+  const uint32_t low = tok & ((1u << lsb) - 1);
+  tok >>= lsb;
+  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
+  const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+  return (((hi << nbits) | bits) << lsb) | low;
+}
 
 template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
@@ -938,13 +1035,14 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     for (uint32_t i = threadIdx.x; i < sizeof(BlockCtxDev) / 4; i += blockDim.x) StS<uint32_t>(kSimtBcmOff + i * 4, LdG(src + i));
   }
   StageCode(f.ac_code, code, kSimtCodeOff, lds_bytes > kSimtCodeOff ? lds_bytes - kSimtCodeOff : 0, /*with_ctx_map=*/true);
+  const bool ord_lds = false;
+  int32_t* const cbase0 = f.coeff[0]; int32_t* const cbase1 = f.coeff[1]; int32_t* const cbase2 = f.coeff[2];
   __syncthreads();
   if (ALL_LDS && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
   const uint32_t g = blockIdx.x * kSimtThreads + threadIdx.x;
   bool done = g >= f.num_groups;
   const uint32_t nz_base = kSimtNzOff + threadIdx.x * 96;
   for (uint32_t i = 0; i < 24; i++) StS<uint32_t>(nz_base + i * 4, 0u);
-  // BlockCtxDev field offsets inside the LDS copy
   constexpr uint32_t oNLf = kSimtBcmOff + offsetof(BlockCtxDev, n_lf_thr), oQf = kSimtBcmOff + offsetof(BlockCtxDev, qf_thr);
   constexpr uint32_t oLf = kSimtBcmOff + offsetof(BlockCtxDev, lf_thr), oMap = kSimtBcmOff + offsetof(BlockCtxDev, ctx_map);
   const uint32_t n_qf = LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, n_qf_thr));
@@ -953,11 +1051,28 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   const uint32_t gsafe = done ? 0 : g;
   const uint32_t gx = gsafe % f.xgroups, gy = gsafe / f.xgroups;
   const uint32_t bx0 = gx * 32, by0 = gy * 32;
-  const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
-  BitReaderP br;
-  uint64_t limit;
-  if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
-  else { const uint32_t si = 2 + f.num_lf_groups + gsafe; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); br.Init(f.cs, off * 8, off + sz); limit = (off + sz) * 8; }
+  // ---- per-lane bit-stream ring
+  uint64_t bit0, byte_end;
+  if (f.single_section) { bit0 = f.hf_start_bitpos; byte_end = f.cs_size; }
+  else { const uint32_t si = 2 + f.num_lf_groups + gsafe; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); bit0 = off * 8; byte_end = off + sz; }
+  const uint64_t limit = byte_end * 8;
+  const uint32_t* words = reinterpret_cast<const uint32_t*>(f.cs);
+  const uint32_t wend = (uint32_t)((byte_end + 3) >> 2);
+  BitReaderRing br;
+  br.ring_off = kSimtRingOff + threadIdx.x * 64;
+  br.wpos = (uint32_t)(bit0 >> 5);
+  br.buf = 0; br.avail = 0;
+  uint32_t wload = br.wpos & ~3u;             // next absolute word index to fetch (multiple of 4: 16-byte loads)
+  auto fetch4 = [&](uint32_t w) -> uint4 { return w + 3 < wend ? LdG(reinterpret_cast<const uint4*>(words + w)) : make_uint4(w < wend ? LdG(words + w) : 0u, w + 1 < wend ? LdG(words + w + 1) : 0u, w + 2 < wend ? LdG(words + w + 2) : 0u, 0u); };
+  auto put4 = [&](uint32_t w, const uint4& v) { StS<uint4>(br.ring_off + ((w & 15) << 2), v); };
+  for (int i = 0; i < 4; i++) { put4(wload, fetch4(wload)); wload += 4; }   // 16 words ahead
+  uint4 pend0 = make_uint4(0, 0, 0, 0), pend1 = pend0;
+  bool pending = false;
+  {
+    br.Refill();
+    const int skip = (int)(bit0 & 31);
+    br.buf >>= skip; br.avail -= skip;
+  }
   uint32_t ctx_offset = 0, state = 0;
   if (!done) {
     const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
@@ -965,43 +1080,54 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     ctx_offset = 495u * nctx * preset;
     state = br.Read(32);
   }
-  const uint32_t nblocks = gbw * gbh;
-  uint32_t pos = 0;                       // next block position to visit (raster within the group)
-  uint32_t phase = 0;                     // 0: find next varblock, 1: read nzeros, 2: read a coefficient
-  uint32_t bx = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, cx = 1, coff = 0, qf_idx = 0, lf_idx = 0;
-  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, by = 0;
+  // ---- varblock list of this group, one entry loaded ahead
+  const uint2* vbl = f.vb_list + (size_t)gsafe * 1024;
+  const uint32_t nvb = done ? 0 : LdG(f.vb_count + gsafe);
+  uint32_t vi = 0;
+  uint2 ent_next = nvb ? LdG(vbl) : make_uint2(0, 0);
+  uint32_t phase = 0;                     // 0: start next varblock, 1: read nzeros, 2: read a coefficient
+  uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, cx = 1, coff = 0, qf_idx = 0, lf_idx = 0;
+  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, order_off = 0;
   const uint16_t* order = f.orders[0];
-  int32_t* blk = f.coeff[0];
+  int32_t* blk = cbase0;
+  uint32_t iter = 0;
   while (__ballot(!done) != 0ull) {
+    // ---- bit-stream top-up, every 2nd iteration (<= 3 words consumed in between): store what was requested 2 iterations
+    // ago, request the next 8 words when at most 8 are buffered (ring of 16: never overwritten, never empty)
+    if ((iter & 1) == 0) {
+      if (pending) { put4(wload - 8, pend0); put4(wload - 4, pend1); pending = false; }
+      if (!done && wload - br.wpos <= 8) { pend0 = fetch4(wload); pend1 = fetch4(wload + 4); wload += 8; pending = true; }
+    }
+    iter++;
     if (!done && phase == 0) {
-      if (pos >= nblocks) {
+      if (vi >= nvb) {
         if (state != 0x130000u) SetError(f, kErrAnsFinalState);
         else if (br.BitPos() > limit) SetError(f, kErrOverrun);
         done = true;
       } else {
-        bx = pos % gbw; by = pos / gbw; pos++;
-        const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
-        const uint32_t info = LdG(f.blk_info + o);
-        if (BI_First(info)) {
-          const uint32_t s = BI_Strategy(info);
-          cx = CoveredX(s); covered = cx * CoveredY(s);
-          l2 = 31 - __clz((int)covered); size = covered * 64; ord = OrderBucket(s);
-          const uint32_t qf = BI_HfMul(info);
-          qf_idx = 0;
-          for (uint32_t i = 0; i < n_qf; i++) qf_idx += qf > LdS<uint32_t>(oQf + i * 4);
-          lf_idx = 0;
-          if (num_lf_ctxs > 1) {
-            const uint32_t n0 = LdS<uint32_t>(oNLf), n1 = LdS<uint32_t>(oNLf + 4), n2 = LdS<uint32_t>(oNLf + 8);
-            uint32_t b0 = 0, b1 = 0, b2 = 0;
-            const int32_t q0 = LdG(f.lfq[0] + o), q1 = LdG(f.lfq[1] + o), q2 = LdG(f.lfq[2] + o);
-            for (uint32_t i = 0; i < n0; i++) b0 += q0 > LdS<int32_t>(oLf + i * 4);
-            for (uint32_t i = 0; i < n1; i++) b1 += q1 > LdS<int32_t>(oLf + 64 + i * 4);
-            for (uint32_t i = 0; i < n2; i++) b2 += q2 > LdS<int32_t>(oLf + 128 + i * 4);
-            lf_idx = (b0 * (n2 + 1) + b2) * (n1 + 1) + b1;
-          }
-          coff = LdG(f.coef_off + o);
-          ci = 0; phase = 1;
+        const uint2 ent = ent_next;
+        vi++;
+        if (vi < nvb) ent_next = LdG(vbl + vi);
+        const uint32_t s = ent.x & 31;
+        bx = (ent.x >> 16) & 31; by = (ent.x >> 21) & 31;
+        cx = CoveredX(s); covered = cx * CoveredY(s);
+        l2 = 31 - __clz((int)covered); size = covered * 64; ord = OrderBucket(s);
+        const uint32_t qf = ((ent.x >> 8) & 0xFF) + 1;
+        qf_idx = 0;
+        for (uint32_t i = 0; i < n_qf; i++) qf_idx += qf > LdS<uint32_t>(oQf + i * 4);
+        lf_idx = 0;
+        if (num_lf_ctxs > 1) {
+          const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+          const uint32_t n0 = LdS<uint32_t>(oNLf), n1 = LdS<uint32_t>(oNLf + 4), n2 = LdS<uint32_t>(oNLf + 8);
+          uint32_t b0 = 0, b1 = 0, b2 = 0;
+          const int32_t q0 = LdG(f.lfq[0] + o), q1 = LdG(f.lfq[1] + o), q2 = LdG(f.lfq[2] + o);
+          for (uint32_t i = 0; i < n0; i++) b0 += q0 > LdS<int32_t>(oLf + i * 4);
+          for (uint32_t i = 0; i < n1; i++) b1 += q1 > LdS<int32_t>(oLf + 64 + i * 4);
+          for (uint32_t i = 0; i < n2; i++) b2 += q2 > LdS<int32_t>(oLf + 128 + i * 4);
+          lf_idx = (b0 * (n2 + 1) + b2) * (n1 + 1) + b1;
         }
+        coff = ent.y;
+        ci = 0; phase = 1;
       }
     } else if (!done) {
       const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
@@ -1023,19 +1149,23 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
         const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
         ctx = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + kk)) * 2 + prev;
       }
-      const uint32_t u = FastHybridT<ALL_LDS>(br, state, code, ClusterT<ALL_LDS>(code, ctx));
+      const uint32_t u = HybridSimt<ALL_LDS>(br, state, code, ctx);
       if (phase == 1) {
         nzeros = u;
         if (nzeros + covered > size) { SetError(f, kErrNzeros); done = true; }
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
         for (uint32_t ix = 0; ix < cx; ix++) StS<uint8_t>(nz_base + c * 32 + bx + ix, (uint8_t)nzm);
-        order = f.orders[ord * 3 + c];
-        blk = f.coeff[c] + (size_t)g * 65536 + coff;
+        blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + (size_t)g * 65536 + coff;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
+        if (ord_lds) order_off = OrderLdsOffset(ord);
+        else { order = f.orders[ord * 3 + c]; next_pos = LdG(order + k); }
         phase = 2;
       } else {
-        if (u) StG(blk + LdG(order + k), UnpackSigned(u));
+        uint32_t pos;
+        if (ord_lds) pos = LdS<uint16_t>(order_off + 2 * k);
+        else { pos = next_pos; if (k + 1 < size) next_pos = LdG(order + k + 1); }
+        if (u) StG(blk + pos, UnpackSigned(u));
         prev = u != 0;
         nzeros -= prev;
         k++;
@@ -1447,9 +1577,13 @@ __device__ __forceinline__ bool FilterStageActive(const FrameDev& f, int stage) 
   return stage == 0 ? f.gab != 0 : stage == 1 ? f.epf_iters >= 3 : stage == 2 ? f.epf_iters >= 1 : f.epf_iters >= 2;
 }
 
-__global__ void GaborishKernel(const FrameDev* __restrict__ frames) {
+// Frames with the common restoration setting (gaborish + one EPF pass, XYB colour) take the fused tile kernel
+// FusedGabEpf1OutKernel; everything else runs the stage-by-stage kernels.
+__device__ __forceinline__ bool FusedEligible(const FrameDev& f, int unfused) { return !unfused && f.gab && f.epf_iters == 1 && f.color_mode <= 1; }
+
+__global__ void GaborishKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular || !f.gab) return;
+  if (f.is_modular || !f.gab || FusedEligible(f, unfused)) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   const int w = (int)f.width, h = (int)f.height;
   if (x >= w || y >= h) return;
@@ -1465,10 +1599,10 @@ __global__ void GaborishKernel(const FrameDev* __restrict__ frames) {
   }
 }
 
-template <int PASS> __global__ void EpfKernel(const FrameDev* __restrict__ frames) {
+template <int PASS> __global__ void EpfKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
   constexpr int stage = PASS + 1;
-  if (f.is_modular || !FilterStageActive(f, stage)) return;
+  if (f.is_modular || !FilterStageActive(f, stage) || FusedEligible(f, unfused)) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   const int w = (int)f.width, h = (int)f.height;
   if (x >= w || y >= h) return;
@@ -1580,9 +1714,9 @@ __device__ __forceinline__ void StorePixel(const FrameDev& f, int x, int y, floa
   }
 }
 
-__global__ void OutputKernel(const FrameDev* __restrict__ frames) {
+__global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular) return;
+  if (f.is_modular || FusedEligible(f, unfused)) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= (int)f.width || y >= (int)f.height) return;
   const bool src_is_a = (FilterStagesBefore(f, 4) & 1) == 0;
@@ -1611,6 +1745,114 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames) {
   } else { r = X; g = Y; b = B; }
   if (f.is_gray) r = g;
   StorePixel(f, x, y, r, g, b, 1.0f);
+}
+
+// =====================================================================================================================
+// Fused restoration + colour + write: gaborish -> EPF pass 1 -> XYB -> (s)RGB -> interleaved samples, one 64x32 pixel
+// tile per 256-thread workgroup.  The XYB planes are read once (with a 3-pixel mirrored halo) into LDS, the gaborish
+// result (tile + 2-pixel halo) lives in LDS, pixels go straight to the caller layout: 12 + C*bytes B/px of HBM traffic
+// instead of 63.  Arithmetic and operation order are those of GaborishKernel / EpfKernel<1> / OutputKernel (mirroring
+// the inputs of the symmetric 3x3 kernel gives exactly the gaborish value at the mirrored coordinate).
+// =====================================================================================================================
+constexpr int kFtW = 64, kFtH = 32;
+constexpr int kFinW = kFtW + 6, kFinH = kFtH + 6, kFinP = kFinW + 1;      // input region incl. halo 3, padded pitch
+constexpr int kFgW = kFtW + 4, kFgH = kFtH + 4, kFgP = kFgW + 1;          // gaborish region incl. halo 2
+constexpr size_t kFusedLds = (size_t)(3 * kFinH * kFinP + 3 * kFgH * kFgP) * sizeof(float);
+
+__global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __restrict__ frames, int unfused) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular || !FusedEligible(f, unfused)) return;
+  const int w = (int)f.width, h = (int)f.height;
+  const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * kFtH;
+  if (x0 >= w || y0 >= h) return;
+  extern __shared__ __align__(16) float s_f[];
+  float* s_in = s_f;                              // [3][kFinH][kFinP]
+  float* s_gab = s_f + 3 * kFinH * kFinP;         // [3][kFgH][kFgP]
+  const size_t stride = f.plane_stride;
+  // ---- load input tile (+3 halo) with image-border mirroring
+  for (int i = threadIdx.x; i < kFinW * kFinH; i += blockDim.x) {
+    const int ly = i / kFinW, lx = i % kFinW;
+    const int gx = MirrorD(x0 + lx - 3, w), gy = MirrorD(y0 + ly - 3, h);
+    const size_t o = (size_t)gy * stride + gx;
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_in[(c * kFinH + ly) * kFinP + lx] = LdG(f.plane_a[c] + o);
+  }
+  __syncthreads();
+  // ---- gaborish on tile + halo 2
+  for (int i = threadIdx.x; i < kFgW * kFgH; i += blockDim.x) {
+    const int ly = i / kFgW, lx = i % kFgW;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float* t = s_in + (c * kFinH + ly) * kFinP + lx;        // row above (input coords are +1 relative to gab coords)
+      const float* m = t + kFinP;
+      const float* b = m + kFinP;
+      const float sum0 = m[1];
+      const float sum1 = (m[0] + m[2]) + (t[1] + b[1]);
+      const float sum2 = (t[0] + t[2]) + (b[0] + b[2]);
+      s_gab[(c * kFgH + ly) * kFgP + lx] = fmaf(sum2, f.gab_w[c * 3 + 2], fmaf(sum1, f.gab_w[c * 3 + 1], sum0 * f.gab_w[c * 3 + 0]));
+    }
+  }
+  __syncthreads();
+  // ---- EPF pass 1 + colour + store
+  const float sm = f.epf_sm[1], bsm = f.epf_bsm[1];
+  const float cs0 = f.epf_channel_scale[0], cs1 = f.epf_channel_scale[1], cs2 = f.epf_channel_scale[2];
+  for (int i = threadIdx.x; i < kFtW * kFtH; i += blockDim.x) {
+    const int ly = i / kFtW, lx = i % kFtW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) continue;
+    const float* g0 = s_gab + (0 * kFgH + ly + 2) * kFgP + lx + 2;
+    const float* g1 = g0 + kFgH * kFgP;
+    const float* g2 = g1 + kFgH * kFgP;
+    float X = g0[0], Y = g1[0], B = g2[0];
+    const float is = LdG(f.inv_sigma + (size_t)(y / 8) * f.bw + x / 8);
+    if (!(is < -3.90524291751269967465540850526868f)) {
+      const bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
+      const float vmul = is * (border ? bsm : sm);
+      float wsum = 1.0f;
+      float a0 = X, a1 = Y, a2 = B;
+      const int taps[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+      const int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int dx = taps[t][0], dy = taps[t][1];
+        float sad = 0.f;
+        {
+          float s_ = 0.f;
+#pragma unroll
+          for (int k = 0; k < 5; k++) s_ += fabsf(g0[(dy + plus[k][1]) * kFgP + dx + plus[k][0]] - g0[plus[k][1] * kFgP + plus[k][0]]);
+          sad = fmaf(s_, cs0, sad);
+          s_ = 0.f;
+#pragma unroll
+          for (int k = 0; k < 5; k++) s_ += fabsf(g1[(dy + plus[k][1]) * kFgP + dx + plus[k][0]] - g1[plus[k][1] * kFgP + plus[k][0]]);
+          sad = fmaf(s_, cs1, sad);
+          s_ = 0.f;
+#pragma unroll
+          for (int k = 0; k < 5; k++) s_ += fabsf(g2[(dy + plus[k][1]) * kFgP + dx + plus[k][0]] - g2[plus[k][1] * kFgP + plus[k][0]]);
+          sad = fmaf(s_, cs2, sad);
+        }
+        const float wgt = fmaxf(0.0f, fmaf(sad, vmul, 1.0f));
+        wsum += wgt;
+        a0 = fmaf(wgt, g0[dy * kFgP + dx], a0);
+        a1 = fmaf(wgt, g1[dy * kFgP + dx], a1);
+        a2 = fmaf(wgt, g2[dy * kFgP + dx], a2);
+      }
+      const float inv = 1.0f / wsum;
+      X = a0 * inv; Y = a1 * inv; B = a2 * inv;
+    }
+    // XYB -> linear -> sRGB (OutputKernel)
+    const float gr = (Y + X) - f.neg_bias_cbrt[0];
+    const float gg = (Y - X) - f.neg_bias_cbrt[1];
+    const float gb = B - f.neg_bias_cbrt[2];
+    const float mr = fmaf(gr * gr, gr, f.neg_bias[0]);
+    const float mg = fmaf(gg * gg, gg, f.neg_bias[1]);
+    const float mb = fmaf(gb * gb, gb, f.neg_bias[2]);
+    float r = fmaf(f.opsin_inv[2], mb, fmaf(f.opsin_inv[1], mg, f.opsin_inv[0] * mr));
+    float g = fmaf(f.opsin_inv[5], mb, fmaf(f.opsin_inv[4], mg, f.opsin_inv[3] * mr));
+    float b = fmaf(f.opsin_inv[8], mb, fmaf(f.opsin_inv[7], mg, f.opsin_inv[6] * mr));
+    if (f.color_mode == 0) { r = LinearToSrgb(r); g = LinearToSrgb(g); b = LinearToSrgb(b); }
+    if (f.is_gray) r = g;
+    StorePixel(f, x, y, r, g, b, 1.0f);
+  }
 }
 
 // =====================================================================================================================
@@ -1874,7 +2116,7 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   const uint32_t lds_bytes = kTreeOff + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
-  hipLaunchKernelGGL(LfDecodeKernel, dim3(max_lf_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
+  hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)kLfWaves), nframes), dim3(64 * kLfWaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
@@ -1910,17 +2152,24 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
   hipLaunchKernelGGL(IdctTileKernel, dim3(tiles_x * tiles_y, nframes), dim3(256), 3 * kTilePlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
   hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
 }
-void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, int max_bw, int max_bh, bool any_gab, int max_epf, void* stream) {
-  (void)max_bw; (void)max_bh;
+void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);
-  if (any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames);
-  if (max_epf >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames);
-  if (max_epf >= 1) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames);
-  if (max_epf >= 2) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames);
+  const int unfused = cfg.force_unfused_filters;
+  if (fp.any_fused && !unfused) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)FusedGabEpf1OutKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds); attr = true; }
+    hipLaunchKernelGGL(FusedGabEpf1OutKernel, dim3(DivUp(max_w, kFtW), DivUp(max_h, kFtH), nframes), dim3(256), kFusedLds, (hipStream_t)stream, frames, unfused);
+  }
+  if (!fp.any_unfused && !unfused) return;
+  if (fp.any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  if (fp.max_epf >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  if (fp.max_epf >= 1) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  if (fp.max_epf >= 2) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames, unfused);
 }
-void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, void* stream) {
+void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
+  if (!fp.any_unfused && !cfg.force_unfused_filters) return;
   dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);
-  hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames);
+  hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters);
 }
 void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream) {
   hipLaunchKernelGGL(ModularGlobalKernel, dim3(nframes), dim3(64), 0, (hipStream_t)stream, frames);

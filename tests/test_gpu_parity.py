@@ -201,6 +201,25 @@ def test_unaligned_varblocks_and_generic_idct(jx):
         assert ulp_diff(b.output(0), ref) <= 1
 
 
+def test_fused_and_unfused_filter_paths_agree(jx):
+    """gaborish + EPF 1 frames take the fused LDS-tiled kernel; the stage-by-stage kernels must give the same bits."""
+    img = S.synthetic_image(19, 330, 150)
+    data = S.encode_vardct(img, seed=12, strategy_mix=2, epf_iters=1, gab=1)
+    ref = O.decode(data)
+    for force in (0, 1):
+        for dt, kind in (("uint8", "u8"), ("float32", "f32")):
+            b = jx.BatchDecoder(0)
+            b.add(data, dt, 3)
+            b.set_option("force_unfused_filters", force)
+            b.prepare(); b.decode(); b.finish()
+            want = ref.pixels(kind, 3).view(np.dtype(dt))
+            got = b.output(0)
+            if dt == "uint8":
+                assert np.array_equal(got, want), force
+            else:
+                assert ulp_diff(got, want) <= 1, force
+
+
 def test_hdr_float_stream(jx):
     """Config-5 style: f32 samples, linear transfer, intensity_target 1000, EPF 3."""
     lin = ((S.synthetic_image(9, 320, 200).astype(np.float32) / 255.0) ** 2.2) * 2.0
