@@ -78,6 +78,16 @@ template <> __device__ __forceinline__ uint4 LdG<uint4>(const uint4* p) {
   const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+template <> __device__ __forceinline__ int4 LdG<int4>(const int4* p) {
+  typedef int32_t __attribute__((ext_vector_type(4))) v4;
+  const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+template <> __device__ __forceinline__ float4 LdG<float4>(const float4* p) {
+  typedef float __attribute__((ext_vector_type(4))) v4;
+  const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 template <> __device__ __forceinline__ uint2 LdG<uint2>(const uint2* p) {
   typedef uint32_t __attribute__((ext_vector_type(2))) v2;
   const v2 v = *reinterpret_cast<const __attribute__((address_space(1))) v2*>(reinterpret_cast<uintptr_t>(p));
@@ -142,6 +152,7 @@ struct FastCode {
   const uint64_t* alias_g;
   uint32_t ctx_map_off, cfg_off, alias_off;   // kNotInLds if the table stayed in global memory
   uint32_t log_alpha;
+  uint32_t cfg_uniform;                       // the hybrid-uint config shared by every cluster, or 0xFFFFFFFF
   __device__ __forceinline__ uint32_t Cluster(uint32_t ctx) const { return ctx_map_off != kNotInLds ? LdS<uint8_t>(ctx_map_off + ctx) : LdG(ctx_map_g + ctx); }
   __device__ __forceinline__ uint32_t Cfg(uint32_t cl) const { return cfg_off != kNotInLds ? LdS<uint32_t>(cfg_off + cl * 4) : LdG(cfg_g + cl); }
   __device__ __forceinline__ uint64_t Alias(uint32_t i) const { return alias_off != kNotInLds ? LdS<uint64_t>(alias_off + i * 8) : LdG(alias_g + i); }
@@ -262,6 +273,12 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
   fc.log_alpha = g.log_alpha;
   fc.ctx_map_g = g.ctx_map; fc.cfg_g = g.cfg; fc.alias_g = g.alias;
   fc.ctx_map_off = fc.cfg_off = fc.alias_off = kNotInLds;
+  {
+    const uint32_t c0 = LdG(g.cfg);
+    bool same = true;
+    for (uint32_t i = threadIdx.x; i < g.num_clusters; i += blockDim.x) same = same && LdG(g.cfg + i) == c0;
+    fc.cfg_uniform = __syncthreads_and(same) ? c0 : 0xFFFFFFFFu;
+  }
   const uint32_t cfg_bytes = (g.num_clusters * 4 + 15) & ~15u;
   if (used + cfg_bytes <= budget) {
     for (uint32_t i = threadIdx.x; i < g.num_clusters; i += blockDim.x) StS<uint32_t>(base + used + i * 4, LdG(g.cfg + i));
@@ -362,6 +379,68 @@ __device__ __forceinline__ int32_t Predict(uint32_t predictor, int32_t W, int32_
   }
 }
 
+// Serial inner loop of the LDS-only fast path, specialised at compile time:
+//   ROWMODE 0: first row (N = NW = W), 1: previous row needed (read from LDS, next value prefetched), 2: W-only rows
+//   PROP9: context from W+N-NW through the LUT (else one cluster per row);  UPRED: 0 zero, 1 W, 5 clamped gradient
+struct ChunkState { BitReaderW bw; uint32_t state; int32_t left, nw; };
+template <int ROWMODE, bool PROP9, int UPRED>
+__device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, uint32_t prev, uint32_t obase, uint32_t lut_off, uint32_t first_off, uint32_t cl_row,
+                                               uint32_t cfg_off, uint32_t cfg_uniform, uint32_t alias_off, uint32_t la) {
+  BitReaderW bw = st.bw;
+  uint32_t state = st.state;
+  int32_t left = st.left, nw = st.nw;
+  int32_t n_next = ROWMODE == 1 ? LdS<int32_t>(prev + 4 * x0) : 0;
+  for (int x = x0; x < x1; x++) {
+    int32_t W, N, NW;
+    if (ROWMODE == 0) { W = x ? left : 0; N = W; NW = W; }
+    else if (ROWMODE == 1) {
+      N = n_next;
+      n_next = LdS<int32_t>(prev + 4 * (x + 1));     // one slot of slack exists past the row (kRowMax + chunk buffers follow)
+      W = x ? left : N; NW = x ? nw : W; nw = N;
+    } else { W = x ? left : LdS<int32_t>(first_off); N = W; NW = W; }
+    uint32_t cluster = cl_row;
+    if (PROP9) {
+      int32_t v = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+      v = v < -512 ? -512 : (v > 511 ? 511 : v);
+      cluster = LdS<uint16_t>(lut_off + 2 * (uint32_t)(v + 512));
+    }
+    int32_t guess;
+    if (UPRED == 0) guess = 0;
+    else if (UPRED == 1) guess = W;
+    else { const int32_t m = min(N, W), M = max(N, W); guess = NW < m ? M : (NW > M ? m : (int32_t)((uint32_t)N + (uint32_t)W - (uint32_t)NW)); }
+    // --- ANS symbol + hybrid integer (dec_ans.h), tables in LDS
+    const uint32_t res = state & 0xFFF;
+    const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
+    const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
+    const uint32_t cfg = cfg_uniform != 0xFFFFFFFFu ? cfg_uniform : LdS<uint32_t>(cfg_off + cluster * 4);
+    const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+    const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+    const bool hit = pos >= cutoff;
+    uint32_t tok = hit ? right : i;
+    const uint32_t off = hit ? offs1 + pos : pos;
+    const uint32_t freq = hit ? freq1 : freq0;
+    state = freq * (state >> 12) + off;
+    if (state < (1u << 16)) state = (state << 16) | bw.Read(16);
+    const uint32_t split_exp = cfg & 0xFF;
+    const uint32_t split = 1u << split_exp;
+    if (tok >= split) {
+      const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+      uint32_t nbits = split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb));
+      nbits &= 31;
+      const uint32_t low = tok & ((1u << lsb) - 1);
+      tok >>= lsb;
+      const uint32_t bits = nbits ? bw.Read((int)nbits) : 0;
+      const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+      tok = (((hi << nbits) | bits) << lsb) | low;
+    }
+    const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) + (uint32_t)guess);
+    StS<int32_t>(obase + 4 * x, val);
+    if (x == 0) StS<int32_t>(first_off, val);   // W of the next row's first sample
+    left = val;
+  }
+  st.bw = bw; st.state = state; st.left = left; st.nw = nw;
+}
+
 // All 64 lanes of the wavefront call this.  Lane 0 decodes; the others help with LUT, bit-stream window and row I/O.
 // Semantics identical to DecodeModularChannel (jxl_dev.h).
 __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
@@ -424,6 +503,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     const int w = ch.w, h = ch.h;
     const bool row_in_lds = (uint32_t)w <= kRowMax;
     const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
+    const uint32_t cfg_uniform = T.code.cfg_uniform;
     const uint32_t wend = br.wend;
     BitReaderW bw;
     bw.wpos = 0; bw.win_base = 0; bw.buf = 0; bw.avail = 0; bw.win_off = wb + kWinOff;
@@ -450,27 +530,22 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
           }
           const int x1 = min(w, x0 + 256);
           const uint32_t obase = row_in_lds ? cur : wb + kChunkOff - (uint32_t)x0 * 4;
-          for (int x = x0; x < x1; x++) {
-            int32_t W, N, NW;
-            if (y == 0) { W = x ? left : 0; N = W; NW = W; }
-            else if (need_n) { N = LdS<int32_t>(prev + 4 * x); W = x ? left : N; NW = x ? nw : W; nw = N; }
-            else { W = x ? left : LdS<int32_t>(wb + kWorkOff + 24); N = W; NW = W; }
-            uint32_t cluster = cl_row;
-            if (prop == 9) {
-              int32_t v = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
-              v = v < -512 ? -512 : (v > 511 ? 511 : v);
-              cluster = LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512));
-            }
-            int32_t guess;
-            if (upred == 0) guess = 0;
-            else if (upred == 1) guess = W;
-            else { const int32_t m = min(N, W), M = max(N, W); guess = NW < m ? M : (NW > M ? m : (int32_t)((uint32_t)N + (uint32_t)W - (uint32_t)NW)); }
-            const uint32_t tok = HybridLds(bw, state, cfg_off, alias_off, la, cluster);
-            const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) + (uint32_t)guess);
-            StS<int32_t>(obase + 4 * x, val);
-            if (x == 0) StS<int32_t>(wb + kWorkOff + 24, val);   // W of the next row's first sample when the row is not kept in LDS
-            left = val;
+          ChunkState st;
+          st.bw = bw; st.state = state; st.left = left; st.nw = nw;
+          const uint32_t lut_off = wb + kLutOff, first_off = wb + kWorkOff + 24;
+#define JXL_CHUNK(RM, P9, UP) DecodeChunkLds<RM, P9, UP>(st, x0, x1, prev, obase, lut_off, first_off, cl_row, cfg_off, cfg_uniform, alias_off, la)
+          const int rm = y == 0 ? 0 : (need_n ? 1 : 2);
+          if (prop == 9) {
+            if (upred == 5) { if (rm == 0) JXL_CHUNK(0, true, 5); else JXL_CHUNK(1, true, 5); }
+            else if (upred == 1) { if (rm == 0) JXL_CHUNK(0, true, 1); else JXL_CHUNK(1, true, 1); }
+            else { if (rm == 0) JXL_CHUNK(0, true, 0); else JXL_CHUNK(1, true, 0); }
+          } else {
+            if (upred == 5) { if (rm == 0) JXL_CHUNK(0, false, 5); else JXL_CHUNK(1, false, 5); }
+            else if (upred == 1) { if (rm == 0) JXL_CHUNK(0, false, 1); else JXL_CHUNK(2, false, 1); }
+            else { if (rm == 0) JXL_CHUNK(0, false, 0); else JXL_CHUNK(2, false, 0); }
           }
+#undef JXL_CHUNK
+          bw = st.bw; state = st.state; left = st.left; nw = st.nw;
         }
         WaveSync();
         if (!row_in_lds) {
@@ -1467,34 +1542,48 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
   __syncthreads();
   const int32_t* cq[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
   const float bias0 = f.quant_bias[0], bias1 = f.quant_bias[1], bias2 = f.quant_bias[2], bias3 = f.quant_bias[3];
-  // ---- pass 0: stage dequantised coefficients.  Task = (block of the tile, one of its 64 coefficient slots).
-  for (uint32_t t = threadIdx.x; t < 4096; t += blockDim.x) {
-    const uint32_t bi = t >> 6, j = t & 63;
+  // ---- pass 0: stage dequantised coefficients.  Task = (block of the tile, four of its 64 coefficient slots): 16-byte
+  // loads, consecutive lanes read consecutive 16-byte chunks.  The tile is exactly one chroma-from-luma tile.
+  const size_t cfl_i = (size_t)ty * f.cw + tx;
+  const float kx = f.base_x + (float)LdG(f.ytox + cfl_i) * f.color_scale;
+  const float kb = f.base_b + (float)LdG(f.ytob + cfl_i) * f.color_scale;
+  for (uint32_t t = threadIdx.x; t < 1024; t += blockDim.x) {
+    const uint32_t bi = t >> 4, j = (t & 15) * 4;
     const uint32_t info = s_info[bi];
     if (info == 0xFFFFFFFFu) continue;
     const uint32_t s = BI_Strategy(info), ix = BI_Ix(info), iy = BI_Iy(info);
     const uint32_t cx = CoveredX(s), cy = CoveredY(s);
     const uint32_t R = cy * 8, C = cx * 8;
-    const uint32_t k = (iy * cx + ix) * 64 + j;               // this block's share of the varblock's coefficients
+    const uint32_t k0 = (iy * cx + ix) * 64 + j;              // this block's share of the varblock's coefficients
     const uint32_t kind = QuantKind(s);
-    const uint32_t base = s_coff[bi] + k;
-    const int32_t qy = LdG(cq[1] + base), qx = LdG(cq[0] + base), qb = LdG(cq[2] + base);
+    const uint32_t base = s_coff[bi] + k0;
+    const int4 qy4 = LdG(reinterpret_cast<const int4*>(cq[1] + base));
+    const int4 qx4 = LdG(reinterpret_cast<const int4*>(cq[0] + base));
+    const int4 qb4 = LdG(reinterpret_cast<const int4*>(cq[2] + base));
+    const float4 ty4 = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 1] + k0));
+    const float4 tx4 = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 0] + k0));
+    const float4 tb4 = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 2] + k0));
     const float sd = f.inv_global_scale / (float)BI_HfMul(info);
-    const float ydq = AdjustQuantBias(qy, bias1, bias3) * (LdG(f.qtable[kind * 3 + 1] + k) * sd);
-    const float xv = AdjustQuantBias(qx, bias0, bias3) * (LdG(f.qtable[kind * 3 + 0] + k) * (sd * f.x_dm));
-    const float bv = AdjustQuantBias(qb, bias2, bias3) * (LdG(f.qtable[kind * 3 + 2] + k) * (sd * f.b_dm));
+    const float sdx = sd * f.x_dm, sdb = sd * f.b_dm;
+    const int32_t qy[4] = {qy4.x, qy4.y, qy4.z, qy4.w}, qx[4] = {qx4.x, qx4.y, qx4.z, qx4.w}, qb[4] = {qb4.x, qb4.y, qb4.z, qb4.w};
+    const float wy[4] = {ty4.x, ty4.y, ty4.z, ty4.w}, wx[4] = {tx4.x, tx4.y, tx4.z, tx4.w}, wbl[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
     const uint32_t vbx = (bi & 7) - ix, vby = (bi >> 3) - iy;   // varblock origin inside the tile (blocks)
-    const size_t tile_i = (size_t)((by0 + vby) / 8) * f.cw + (bx0 + vbx) / 8;
-    const float kx = f.base_x + (float)LdG(f.ytox + tile_i) * f.color_scale;
-    const float kb = f.base_b + (float)LdG(f.ytob + tile_i) * f.color_scale;
-    uint32_t v, u;
-    if (IsSpecial(s)) { v = k >> 3; u = k & 7; }            // kept in stored order for SpecialTransform
-    else if (R >= C) { v = k % R; u = k / R; }
-    else { v = k / C; u = k % C; }
-    const uint32_t lo = (vby * 8 + v) * kTilePitch + vbx * 8 + u;
-    s_tile[lo] = fmaf(kx, ydq, xv);
-    s_tile[kTilePlane + lo] = ydq;
-    s_tile[2 * kTilePlane + lo] = fmaf(kb, ydq, bv);
+    const bool special = IsSpecial(s);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t k = k0 + e;
+      const float ydq = AdjustQuantBias(qy[e], bias1, bias3) * (wy[e] * sd);
+      const float xv = AdjustQuantBias(qx[e], bias0, bias3) * (wx[e] * sdx);
+      const float bv = AdjustQuantBias(qb[e], bias2, bias3) * (wbl[e] * sdb);
+      uint32_t v, u;
+      if (special) { v = k >> 3; u = k & 7; }                 // kept in stored order for SpecialTransform
+      else if (R >= C) { v = k % R; u = k / R; }
+      else { v = k / C; u = k % C; }
+      const uint32_t lo = (vby * 8 + v) * kTilePitch + vbx * 8 + u;
+      s_tile[lo] = fmaf(kx, ydq, xv);
+      s_tile[kTilePlane + lo] = ydq;
+      s_tile[2 * kTilePlane + lo] = fmaf(kb, ydq, bv);
+    }
   }
   __syncthreads();
   // ---- pass 1: rows (3 channels x up to 512 rows)
