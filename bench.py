@@ -202,7 +202,7 @@ def main():
         stage_ms = {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"}
         dom = max(stage_ms, key=stage_ms.get)
         kernel_of = {"lf": "LfDecodeKernel", "lfpost": "LlfSigmaKernel", "hf": "HfDecodeSimtKernel" if args.lane_stride_hf == 1 else "HfDecodeKernel",
-                     "idct": "IdctTileKernel", "filter": "EpfKernel", "out": "OutputKernel"}
+                     "idct": "IdctTileKernel", "filter": "FusedGabEpf1OutKernel" if args.epf == 1 else "EpfKernel", "out": "OutputKernel"}
         achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
