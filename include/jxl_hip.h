@@ -117,6 +117,9 @@ typedef struct {
 
 /* Last error message of the calling thread ("" if none). */
 const char* JxlHipLastError(void);
+/* Host-only: parses the signature/container and image header of `data` and writes the ICC profile JxlDecoderGetColorAsICCProfile
+ * would return (pass icc_out == NULL to query *icc_size).  Needs no GPU.  Returns 0 on success. */
+int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc_out, size_t* icc_size);
 /* Creates a batch bound to HIP device `device`. */
 JxlHipBatch* JxlHipBatchCreate(int device);
 void JxlHipBatchDestroy(JxlHipBatch* batch);

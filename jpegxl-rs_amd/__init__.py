@@ -187,6 +187,20 @@ def check_valid_signature(buf: bytes) -> Optional[bool]:
 
 
 # ---- common (jpegxl-rs/src/common.rs) -----------------------------------------------------------------------------------
+def icc_profile_from_headers(buf: bytes) -> bytes:
+    """Extension (host-only, no GPU): the ICC profile JxlDecoderGetColorAsICCProfile reports for this file (decode.rs:368-385)."""
+    L = libjxl()
+    L.JxlHipColorProfileFromHeaders.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.JxlHipColorProfileFromHeaders.restype = C.c_int
+    size = C.c_size_t(0)
+    if L.JxlHipColorProfileFromHeaders(buf, len(buf), None, C.byref(size)):
+        raise GenericError(last_error())
+    out = (C.c_uint8 * size.value)()
+    if L.JxlHipColorProfileFromHeaders(buf, len(buf), out, C.byref(size)):
+        raise GenericError(last_error())
+    return bytes(out)
+
+
 class Endianness:
     Native, Little, Big = JXL_NATIVE_ENDIAN, JXL_LITTLE_ENDIAN, JXL_BIG_ENDIAN
 

@@ -165,6 +165,7 @@ void Batch::Prepare(void* stream_v) {
     if (a.mode != b.mode || a.num_bands != b.num_bands || a.num_bands4 != b.num_bands4) return false;
     if (memcmp(a.bands, b.bands, sizeof(a.bands)) || memcmp(a.idw, b.idw, sizeof(a.idw)) || memcmp(a.dct2w, b.dct2w, sizeof(a.dct2w))) return false;
     if (memcmp(a.dct4mul, b.dct4mul, sizeof(a.dct4mul)) || memcmp(a.dct4x8mul, b.dct4x8mul, sizeof(a.dct4x8mul))) return false;
+    if (a.mode == 7 && (a.raw_den != b.raw_den || a.raw[0] != b.raw[0] || a.raw[1] != b.raw[1] || a.raw[2] != b.raw[2])) return false;
     return true;
   };
   max_lf_groups_ = max_groups_ = max_w_ = max_h_ = max_bw_ = max_bh_ = max_epf_ = 0;

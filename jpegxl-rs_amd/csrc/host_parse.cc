@@ -391,7 +391,12 @@ void SkipName(Reader& r) {
   uint32_t n = r.U32({0, 0}, {4, 0}, {5, 16}, {10, 48});
   for (uint32_t i = 0; i < n; i++) r.u(8);
 }
-void SkipCustomXY(Reader& r) { for (int i = 0; i < 2; i++) r.U32({19, 0}, {19, 524288}, {20, 1048576}, {21, 2097152}); }
+void ReadCustomXY(Reader& r, double* xy) {
+  for (int i = 0; i < 2; i++) {
+    const uint32_t u = r.U32({19, 0}, {19, 524288}, {20, 1048576}, {21, 2097152});
+    xy[i] = (double)((u & 1) ? -(int32_t)((u + 1) >> 1) : (int32_t)(u >> 1)) * 1e-6;
+  }
+}
 
 void ReadTransform(Reader& r, TransformDesc* t) {
   t->id = r.u(2);
@@ -509,8 +514,8 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
       ih->want_icc = r.b();
       ih->color_space = r.Enum();
       if (!ih->want_icc) {
-        if (ih->color_space != 2) { ih->white_point = r.Enum(); if (ih->white_point == 2) SkipCustomXY(r); }
-        if (ih->color_space != 2 && ih->color_space != 1) { ih->primaries = r.Enum(); if (ih->primaries == 2) for (int i = 0; i < 3; i++) SkipCustomXY(r); }
+        if (ih->color_space != 2) { ih->white_point = r.Enum(); if (ih->white_point == 2) ReadCustomXY(r, ih->white_xy); }
+        if (ih->color_space != 2 && ih->color_space != 1) { ih->primaries = r.Enum(); if (ih->primaries == 2) for (int i = 0; i < 3; i++) ReadCustomXY(r, ih->prim_xy + 2 * i); }
         if (ih->color_space != 2) { ih->have_gamma = r.b(); if (ih->have_gamma) ih->gamma = r.u(24); else ih->tf = r.Enum(); }
         ih->rendering_intent = r.Enum();
       }
@@ -767,7 +772,33 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
           bands(&q.num_bands, q.bands); bands(&q.num_bands4, q.bands4);
           break;
         case 6: bands(&q.num_bands, q.bands); break;
-        case 7: Unsupported("RAW quantisation tables");
+        case 7: {
+          // RAW table: F16 denominator + a 3-channel Modular image (X, Y, B; libjxl coefficient layout) coded with the
+          // global MA tree — a few hundred samples, decoded here with the same per-thread decoder the kernels use.
+          q.raw_den = r.F16();
+          const int rows = 8 * kKindRows[k], cols = 8 * kKindCols[k];
+          if (!p->has_global_tree) Fail("RAW quant table without global tree");
+          const bool use_global = r.b();
+          WPHeader wp{16, 10, {7, 7, 7, 0, 0}, {13, 12, 12, 12}};
+          if (!r.b()) { wp.p1 = r.u(5); wp.p2 = r.u(5); for (int i = 0; i < 5; i++) wp.p3[i] = r.u(5); for (int i = 0; i < 4; i++) wp.w[i] = r.u(4); }
+          const uint32_t nt = r.U32({0, 0}, {0, 1}, {4, 2}, {8, 18});
+          if (!use_global || nt != 0) Unsupported("RAW quant table with local tree / transforms");
+          const DevCode view = p->tree_code.View();
+          ModularCtx mc;
+          mc.tree = p->tree.nodes.data(); mc.code = &view; mc.wp = wp; mc.uses_wp = p->tree.uses_wp;
+          std::vector<int32_t> wps(10 * (cols + 2), 0);
+          mc.wp_scratch = wps.data();
+          mc.stream_id = 1 + 3 * p->num_lf_groups + k;
+          AnsReader ans; ans.Init(r.br, view);
+          for (int c = 0; c < 3; c++) {
+            q.raw[c].assign((size_t)rows * cols, 0);
+            ChannelDesc ch; ch.data = q.raw[c].data(); ch.w = cols; ch.h = rows; ch.stride = cols;
+            DecodeModularChannel(r.br, ans, mc, ch, c);
+          }
+          if (!ans.FinalOk(view)) Fail("RAW quant table ANS final state");
+          if (r.pos() > r.limit_bits) throw ParseError("truncated", false);
+          break;
+        }
       }
     }
   }
@@ -932,6 +963,11 @@ void ComputeQuantTable(const QuantTableSpec& spec0, int kind, int c, std::vector
       break;
     }
     case 5: break;  // AFV weights not reproduced; AFV blocks are rejected by the LF stage
+    case 7:
+      if (q->raw[c].size() != n) Fail("RAW quant table size");
+      out->resize(n);
+      for (size_t i = 0; i < n; i++) { if (q->raw[c][i] <= 0) Fail("RAW quant value"); (*out)[i] = 1.0f / (1.0f / (q->raw_den * (float)q->raw[c][i])); }
+      return;
     default: Fail("quant mode");
   }
   out->resize(n);

@@ -57,6 +57,7 @@ struct ImageHeader {
   bool color_default = true, want_icc = false;
   uint32_t color_space = 0, white_point = 1, primaries = 1, tf = 13, rendering_intent = 1;
   bool have_gamma = false; uint32_t gamma = 0;
+  double white_xy[2] = {0.3127, 0.3290}, prim_xy[6] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204};  // custom CIE xy
   float intensity_target = 255.f, min_nits = 0.f, linear_below = 0.f;
   bool relative_to_max_display = false;
   float opsin_inv[9]; float opsin_bias[3]; float quant_bias[4];
@@ -155,6 +156,9 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
 // Dequantisation table (1/weight) of quant kind `kind`, channel c; natural coefficient order of a strategy.
 void ComputeQuantTable(const QuantTableSpec& spec, int kind, int c, std::vector<float>* out);
 std::vector<uint16_t> NaturalCoeffOrder(int strategy);
+// ICC v4.4 matrix/TRC profile of the enumerated colour encoding (icc_profile.cc); throws ParseError.
+std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih);
+std::string ColorDescription(const ImageHeader& ih);
 extern const uint8_t kBucketStrategy[13];
 extern const uint8_t kKindRows[17], kKindCols[17];
 

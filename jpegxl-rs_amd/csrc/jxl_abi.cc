@@ -171,9 +171,27 @@ size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* d) {
   return r;
 }
 
-// ICC synthesis is a "next" row: report the failure instead of fabricating a profile.
-JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder*, JxlColorProfileTarget, size_t* size) { if (size) *size = 0; SetLastError("unsupported: ICC profile synthesis"); return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder*, JxlColorProfileTarget, uint8_t*, size_t) { SetLastError("unsupported: ICC profile synthesis"); return JXL_DEC_ERROR; }
+// ICC profile of the enumerated colour encoding (icc_profile.cc).  Both targets describe the same encoding: the pixels
+// this decoder hands out are always in the codestream's tagged colour space (no preferred-profile conversion).
+static JxlDecoderStatus IccOf(const JxlDecoder* d, std::vector<uint8_t>* icc) {
+  if (!d || !d->batch || d->stage < JxlDecoderStruct::kHeaders) { SetLastError("ICC profile requested before the headers were decoded"); return JXL_DEC_ERROR; }
+  try { *icc = SynthesizeIcc(d->batch->image(0).ih); } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* d, JxlColorProfileTarget, size_t* size) {
+  std::vector<uint8_t> icc;
+  if (size) *size = 0;
+  if (IccOf(d, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  if (size) *size = icc.size();
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorProfileTarget, uint8_t* out, size_t size) {
+  std::vector<uint8_t> icc;
+  if (IccOf(d, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  if (!out || size < icc.size()) { SetLastError("ICC output buffer too small"); return JXL_DEC_ERROR; }
+  memcpy(out, icc.data(), icc.size());
+  return JXL_DEC_SUCCESS;
+}
 
 JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
   d->started = true;
@@ -284,5 +302,19 @@ uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* h) { return h->b->total_pixel
 uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* h) { return h->b->compressed_bytes(); }
 void JxlHipBatchStageBytes(const JxlHipBatch* h, uint64_t out[6]) { h->b->StageBytes(out); }
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* h) { return h->b->const_bytes() + h->b->work_bytes(); }
+
+int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc_out, size_t* icc_size) {
+  try {
+    Codestream cs; bool container = false, jbrd = false;
+    if (!ExtractCodestream(data, size, &cs, &container, &jbrd)) { SetLastError("truncated input"); return 1; }
+    ImageHeader ih; uint64_t frame_bitpos = 0;
+    ParseImageHeader(cs, &ih, &frame_bitpos);
+    const std::vector<uint8_t> icc = SynthesizeIcc(ih);
+    const size_t cap = icc_size ? *icc_size : 0;
+    if (icc_size) *icc_size = icc.size();
+    if (icc_out) { if (cap < icc.size()) { SetLastError("ICC output buffer too small"); return 1; } memcpy(icc_out, icc.data(), icc.size()); }
+    return 0;
+  } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
+}
 
 }  // extern "C"

@@ -169,6 +169,37 @@ def test_builder_fields_are_public_and_mutable(jx):
     assert dec.pixel_format is None
 
 
+def test_icc_profile_synthesis(jx):
+    """tests/decode.rs:45-67 asks for icc_profile(true) and requires lcms2 to accept the result.  The profile is built from
+    the image header alone (host code): parse it with lcms2 (PIL.ImageCms), check the ICC header, the MD5 profile ID, the
+    D50-adapted sRGB colorants and that an sRGB -> profile transform is the identity for an sRGB-tagged file."""
+    import hashlib, io, struct
+    from PIL import Image, ImageCms
+    fixtures = os.path.join(ROOT, "tests", "fixtures")
+    icc = jx.icc_profile_from_headers(open(os.path.join(fixtures, "bench.jxl"), "rb").read())
+    assert struct.unpack(">I", icc[:4])[0] == len(icc) and icc[36:40] == b"acsp" and icc[12:20] == b"mntrRGB " and icc[8:12] == bytes([4, 0x40, 0, 0])
+    zeroed = bytearray(icc)
+    zeroed[44:48] = bytes(4); zeroed[64:68] = bytes(4); zeroed[84:100] = bytes(16)
+    assert hashlib.md5(bytes(zeroed)).digest() == icc[84:100]
+    prof = ImageCms.ImageCmsProfile(io.BytesIO(icc))
+    assert ImageCms.getProfileDescription(prof).strip() == "RGB_D65_SRG_Rel_SRG"
+    want = ((0.4360, 0.2225, 0.0139), (0.3851, 0.7169, 0.0971), (0.1431, 0.0606, 0.7141))  # sRGB colorants adapted to D50
+    for got, ref in zip((prof.profile.red_colorant, prof.profile.green_colorant, prof.profile.blue_colorant), want):
+        assert np.abs(np.array(got[0]) - np.array(ref)).max() < 6e-4
+    ramp = np.arange(256, dtype=np.uint8)
+    img = Image.fromarray(np.stack([np.tile(ramp, (4, 1)), np.tile(ramp[::-1], (4, 1)), np.full((4, 256), 77, np.uint8)], -1), "RGB")
+    out = ImageCms.profileToProfile(img, ImageCms.createProfile("sRGB"), prof, renderingIntent=1)
+    assert np.abs(np.asarray(out).astype(int) - np.asarray(img).astype(int)).max() <= 1
+    # gamma-tagged RGBA16 file and a grey file: still valid profiles; the grey one has a kTRC and no colorants
+    g = jx.icc_profile_from_headers(open(os.path.join(fixtures, "sample.jxl"), "rb").read())
+    assert "g0.45455" in ImageCms.getProfileDescription(ImageCms.ImageCmsProfile(io.BytesIO(g)))
+    k = jx.icc_profile_from_headers(open(os.path.join(fixtures, "sample_grey.jxl"), "rb").read())
+    assert k[16:20] == b"GRAY" and b"kTRC" in k and b"rXYZ" not in k
+    assert ImageCms.ImageCmsProfile(io.BytesIO(k)).profile.xcolor_space.strip() == "GRAY"
+    with pytest.raises(jx.GenericError):
+        jx.icc_profile_from_headers(b"\xff\x0a")
+
+
 def test_sharding_plan():
     from jpegxl_rs_amd.sharding import shard_range, shard_sizes
     assert shard_sizes(1024, 8) == [128] * 8            # BASELINE config 3

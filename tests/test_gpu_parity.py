@@ -60,7 +60,13 @@ def test_decode_simple_and_pixel_types(jx):
     """tests/decode.rs:45-67,96-120: inferred type Uint16, len == w*h*4; every pixel type and endianness succeeds."""
     data = fixture_bytes("sample.jxl")
     meta, px = jx.decoder_builder().decode(data)
-    assert px.dtype == np.uint16 and len(px) == meta.width * meta.height * 4
+    assert px.dtype == np.uint16 and len(px) == meta.width * meta.height * 4 and meta.icc_profile is None
+    # decode.rs:46,64: icc_profile(true) -> a profile lcms2 accepts (PIL.ImageCms is an lcms2 binding)
+    import io
+    from PIL import ImageCms
+    meta, px2 = jx.decoder_builder(icc_profile=True).decode(data)
+    assert np.array_equal(px, px2) and meta.icc_profile == jx.icc_profile_from_headers(data)
+    assert ImageCms.ImageCmsProfile(io.BytesIO(meta.icc_profile)).profile.xcolor_space.strip() == "RGB"
     for dt in (np.float32, np.uint8, np.uint16, np.float16):
         for en in (jx.Endianness.Big, jx.Endianness.Little, jx.Endianness.Native):
             _, p = jx.decoder_builder(pixel_format=jx.PixelFormat(endianness=en)).decode_with(data, dt)
@@ -144,6 +150,20 @@ def test_raw_ffi_sequence(jx):
     assert events == [jx.JXL_DEC_BASIC_INFO, jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER, jx.JXL_DEC_FULL_IMAGE, jx.JXL_DEC_SUCCESS]
     L.JxlDecoderDestroy(dec)
     assert np.array_equal(buf, O.decode(fixture_bytes("sample.jxl")).pixels("u8", 3))
+
+
+def test_sample_jpg_jxl_pixels(jx):
+    """tests/decode.rs:123-139 input: a JPEG-transcoded VarDCT frame (YCbCr, RAW quant tables, custom block contexts and
+    coefficient order).  JPEG bit-stream reconstruction is a 'next' row, so reconstruct() yields pixels; they must equal the
+    oracle's and be close to what libjpeg makes of samples/sample.jpg."""
+    from PIL import Image
+    data = fixture_bytes("sample_jpg.jxl")
+    meta, px = check_against_oracle(jx, data, np.uint8, 3)
+    assert (meta.width, meta.height) == (40, 50)
+    jpg = np.array(Image.open(os.path.join(FIXTURES, "sample.jpg")).convert("RGB")).astype(np.int32)
+    assert np.abs(px.reshape(50, 40, 3).astype(np.int32) - jpg).mean() < 3.0
+    meta, (kind, val) = jx.decoder_builder(init_jpeg_buffer=512).reconstruct(data)
+    assert kind == "pixels" and len(val) == 40 * 50 * 3
 
 
 def test_bench_jxl_modular_groups(jx):

@@ -69,6 +69,32 @@ def test_sample_jpg_jxl_coefficients_match_the_jpeg():
     assert np.array_equal(lfq[1], coefs[0][..., 0]) and np.array_equal(lfq[0], coefs[1][..., 0]) and np.array_equal(lfq[2], coefs[2][..., 0])
 
 
+def test_sample_jpg_jxl_planes_match_an_independent_float_decode():
+    """RAW quant tables (layout and 1/(den*v) scaling), smart-dequant bias, float chroma-from-luma and the 8x8 IDCT, checked
+    against scipy's orthonormal IDCT on the golden JPEG quant tables: the oracle's pre-colour-transform planes must equal
+    idct(adj(q) * qtable [+ ratio * Y]) to float accuracy."""
+    from scipy.fft import idctn
+    g = np.load(os.path.join(GOLDEN, "sample_jpg_coefficients.npz"))
+    qt = g["qtables"].astype(np.float64)
+    dec = O.decode(fixture_bytes("sample_jpg.jxl"), dump=True)
+    bw, bh = 5, 7
+    q = [dec.ints("coeff%d" % c)[: bw * bh * 64].reshape(bh, bw, 8, 8).transpose(0, 1, 3, 2).astype(np.float64) for c in range(3)]
+    lfq = [dec.ints("lfq%d" % c).reshape(bh, bw).astype(np.float64) for c in range(3)]
+    bias, comp = [1 - 0.05465007330715401, 1 - 0.07005449891748593, 1 - 0.049935103337343655], [1, 0, 2]  # jxl channel -> JPEG component
+
+    def adj(c, v):
+        return np.where(np.abs(v) < 1.125, np.sign(v) * bias[c], v - 0.145 / np.where(v == 0, 1, v))
+    deq = [adj(c, q[c]) * qt[comp[c]].reshape(8, 8) for c in range(3)]
+    deq[0] = deq[0] + (-15 / 84.0) * deq[1]
+    deq[2] = deq[2] + (47 / 84.0) * deq[1]
+    for c in range(3):
+        k = deq[c].copy()
+        k[..., 0, 0] = lfq[c] * qt[comp[c]][0]
+        want = idctn(k, axes=(2, 3), norm="ortho").transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8)
+        got = dec.plane("idct%d" % c)[: bh * 8, : bw * 8] * 255.0
+        assert np.abs(got - want).max() < 0.01
+
+
 @pytest.mark.parametrize("name,feature", [("sample_grey.jxl", "non-regular frame"), ("2bit.jxl", "splines")])
 def test_unsupported_fixtures_fail_cleanly(name, feature):
     """sample_grey.jxl needs patches + AFV, 2bit.jxl needs splines: 'next' rows of SURVEY §8f — must be rejected, not mis-decoded."""
