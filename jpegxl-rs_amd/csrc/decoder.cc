@@ -18,7 +18,7 @@ size_t Align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct ConstOffsets {
   size_t cs = 0, sec_off = 0, sec_size = 0, tree = 0, bcm = 0;
-  size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0;
+  size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0, mod_chan = 0;
   size_t ac_ctx = 0, ac_cfg = 0, ac_alias = 0, ac_pc = 0, ac_po = 0, ac_ps = 0;
   size_t orders[39] = {0};
   size_t qtable[17 * 3] = {0};
@@ -73,7 +73,6 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
   if (!p.modular && !e->ih.extra.empty()) throw ParseError("unsupported: extra channels in a VarDCT frame", true);
   if (p.modular && e->ih.xyb_encoded) throw ParseError("unsupported: XYB Modular frame", true);
   if (p.modular && e->ih.depth.is_float) throw ParseError("unsupported: float Modular samples", true);
-  if (p.modular && p.gchannels.size() > 8) throw ParseError("unsupported: more than 8 modular channels", true);
   if (!p.modular && e->ih.xyb_encoded) {
     const bool srgb = e->ih.color_default || (!e->ih.have_gamma && e->ih.tf == 13);
     const bool linear = !e->ih.color_default && !e->ih.have_gamma && e->ih.tf == 8;
@@ -211,6 +210,7 @@ void Batch::Prepare(void* stream_v) {
   };
   std::vector<WorkOffsets> wo(n);
   mod_plane_offsets_.assign(n, {});
+  mod_ops_.assign(n, {});
   status_off_ = take((size_t)n * 4);
   const size_t flags_off = take((size_t)n * 4);
   // coefficient buffers of all frames are contiguous so that one memset clears them
@@ -241,17 +241,18 @@ void Batch::Prepare(void* stream_v) {
       o.wp_scratch_stride = 10 * (256 + 2);
       o.wp_scratch = take(o.wp_scratch_stride * 4 * p.num_lf_groups);
     } else {
-      // full-frame planes for every channel of the global image + spares for palette expansion
+      // planes for every channel of the global image, then the plan that undoes the global transforms
       std::vector<size_t>& mp = mod_plane_offsets_[i];
       for (auto& ch : p.gchannels) mp.push_back(take((size_t)ch.w * ch.h * 4 + 64));
-      size_t spare = 0;
-      for (auto& t : p.gtransforms) if (t.id == 1) spare += t.num_c - 1;
-      for (size_t k = 0; k < spare; k++) mp.push_back(take((size_t)p.width * p.height * 4 + 64));
+      PlanModularUndo(i, take);
+      std::vector<ModChanDev> table;
+      for (size_t k = 0; k < p.gchannels.size(); k++) table.push_back(ModChanDev{mp[k], p.gchannels[k].w, p.gchannels[k].h, p.gchannels[k].hshift, p.gchannels[k].vshift});
+      co[i].mod_chan = arena.Put(table.data(), table.size() * sizeof(ModChanDev));
       const size_t gd = p.group_dim;
-      o.mod_scratch_stride = (p.gchannels.size() + 4) * gd * gd + 4 * 65536;
-      o.mod_scratch = take(o.mod_scratch_stride * 4 * p.num_groups);
+      o.mod_scratch_stride = (8 + 4) * gd * gd + 4 * 65536;
+      o.mod_scratch = take(o.mod_scratch_stride * 4 * (p.num_lf_groups + p.num_groups));
       o.wp_scratch_stride = p.tree.uses_wp ? 10 * (65536 + 2) : 16;
-      o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.num_groups));
+      o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.num_lf_groups + p.num_groups));
     }
   }
   work_size_ = Align(w);
@@ -338,9 +339,8 @@ void Batch::Prepare(void* stream_v) {
         f.hf_start_bitpos = p.end_bitpos;
       }
     } else {
-      const std::vector<size_t>& mp = mod_plane_offsets_[i];
       f.mod_nchan = (uint32_t)p.gchannels.size(); f.mod_nb_meta = p.nb_meta_channels;
-      for (size_t k = 0; k < p.gchannels.size(); k++) { f.mod_plane[k] = (int32_t*)(dwork_ + mp[k]); f.mod_w[k] = p.gchannels[k].w; f.mod_h[k] = p.gchannels[k].h; }
+      f.mod_chan = (const ModChanDev*)(cbase + c.mod_chan); f.mod_base = dwork_;
       f.mod_global_decodable = p.global_decodable; f.mod_global_bitpos = p.global_data_bitpos;
       f.mod_group_scratch = (int32_t*)(dwork_ + o.mod_scratch); f.mod_group_scratch_stride = o.mod_scratch_stride;
       f.mod_bits = e.ih.depth.bits;
@@ -430,45 +430,104 @@ void Batch::Run(void* stream_v) {
   }
   if (any_modular_) {
     LaunchModularGlobal(dframes_, n, stream_v);
-    LaunchModularGroups(dframes_, n, max_groups_, stream_v);
+    LaunchModularGroups(dframes_, n, max_lf_groups_, max_groups_, stream_v);
     for (int i = 0; i < n; i++) {
-      const ImageEntry& e = *images_[i];
-      const FramePlan& p = e.plan;
-      if (!p.modular) continue;
-      // undo global transforms on the host-tracked channel list (transform.cc), reverse order
-      const std::vector<size_t>& mp = mod_plane_offsets_[i];
-      std::vector<int32_t*> list;
-      for (size_t k = 0; k < p.gchannels.size(); k++) list.push_back((int32_t*)(dwork_ + mp[k]));
-      size_t spare = p.gchannels.size();
-      const size_t npx = (size_t)p.width * p.height;
-      for (int t = (int)p.gtransforms.size() - 1; t >= 0; t--) {
-        const TransformDesc& td = p.gtransforms[t];
-        if (td.id == 0) LaunchModRct(list[td.begin_c], list[td.begin_c + 1], list[td.begin_c + 2], npx, td.rct_type, stream_v);
-        else {
-          int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
-          outs[0] = list[td.begin_c + 1];
-          for (uint32_t c = 1; c < td.num_c; c++) outs[c] = (int32_t*)(dwork_ + mp[spare++]);
-          LaunchModPalette(list[0], outs, td.nb_colors, td.num_c, std::min<uint32_t>(e.ih.depth.bits, 24), npx, stream_v);
-          std::vector<int32_t*> nl;
-          for (size_t k = 1; k < list.size(); k++) { if (k - 1 == td.begin_c) { for (uint32_t c = 0; c < td.num_c; c++) nl.push_back(outs[c]); } else nl.push_back(list[k]); }
-          list.swap(nl);
+      if (!images_[i]->plan.modular) continue;
+      for (const ModOp& op : mod_ops_[i]) {
+        auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
+        switch (op.kind) {
+          case ModOp::kRct: LaunchModRct(P(op.in[0]), P(op.in[1]), P(op.in[2]), op.n, op.param, stream_v); break;
+          case ModOp::kPalette: {
+            int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (uint32_t c = 0; c < op.num_c; c++) outs[c] = P(op.out[c]);
+            LaunchModPalette(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.n, stream_v);
+            break;
+          }
+          case ModOp::kSqueeze: LaunchModInvSqueeze(P(op.in[0]), P(op.in[1]), P(op.out[0]), op.param, op.aw, op.ah, op.rw, op.rh, stream_v); break;
+          case ModOp::kOutput: {
+            ModOutputArgs a;
+            memset(&a, 0, sizeof(a));
+            a.ncolor = op.num_c;
+            for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = P(op.in[c]);
+            a.color_factor = op.color_factor;
+            a.alpha = op.has_alpha ? P(op.in[3]) : nullptr; a.alpha_factor = op.alpha_factor;
+            LaunchModOutput(dframes_, i, a, images_[i]->plan.width, images_[i]->plan.height, stream_v);
+            break;
+          }
         }
       }
-      ModOutputArgs a;
-      memset(&a, 0, sizeof(a));
-      a.ncolor = p.nb_color_channels;
-      if (list.size() < a.ncolor) throw ParseError("modular channel list", false);
-      for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = list[c];
-      a.color_factor = 1.0f / (float)((1u << e.ih.depth.bits) - 1);
-      a.alpha = nullptr; a.alpha_factor = 1.0f;
-      for (size_t k = 0; k < e.ih.extra.size(); k++) if (e.ih.extra[k].type == 0) {
-        a.alpha = list[a.ncolor + k];
-        a.alpha_factor = 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);
-        break;
-      }
-      LaunchModOutput(dframes_, i, a, p.width, p.height, stream_v);
     }
   }
+}
+
+// Builds the list of kernels that undo the global transforms of Modular image i (transform.cc, reverse order) and feed
+// the write stage, tracking the channel list on the host exactly as MetaApply built it; `take` reserves work-arena bytes.
+void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
+  const ImageEntry& e = *images_[i];
+  const FramePlan& p = e.plan;
+  struct HC { size_t off; uint32_t w, h; };
+  std::vector<HC> list;
+  for (size_t k = 0; k < p.gchannels.size(); k++) list.push_back({mod_plane_offsets_[i][k], p.gchannels[k].w, p.gchannels[k].h});
+  std::vector<ModOp>& ops = mod_ops_[i];
+  ops.clear();
+  for (int t = (int)p.gtransforms.size() - 1; t >= 0; t--) {
+    const TransformDesc& td = p.gtransforms[t];
+    if (td.id == 0) {
+      if (td.begin_c + 3 > list.size()) throw ParseError("rct range", false);
+      const HC &a = list[td.begin_c], &b = list[td.begin_c + 1], &c = list[td.begin_c + 2];
+      if (a.w != b.w || a.w != c.w || a.h != b.h || a.h != c.h) throw ParseError("rct over channels of different size", false);
+      ModOp op; op.kind = ModOp::kRct; op.in[0] = a.off; op.in[1] = b.off; op.in[2] = c.off; op.n = (size_t)a.w * a.h; op.param = td.rct_type;
+      ops.push_back(op);
+    } else if (td.id == 1) {
+      // list[0] = palette, list[begin_c + 1] = index channel -> num_c channels in its place
+      if (td.begin_c + 1 >= list.size()) throw ParseError("palette range", false);
+      const HC idx = list[td.begin_c + 1];
+      ModOp op; op.kind = ModOp::kPalette; op.in[0] = list[0].off; op.num_c = td.num_c; op.param = td.nb_colors;
+      op.bits = std::min<uint32_t>(e.ih.depth.bits, 24); op.n = (size_t)idx.w * idx.h;
+      if (td.num_c > 4) throw ParseError("unsupported: palette with more than 4 channels", true);
+      op.out[0] = idx.off;
+      for (uint32_t c = 1; c < td.num_c; c++) op.out[c] = take(op.n * 4 + 64);
+      ops.push_back(op);
+      std::vector<HC> nl;
+      for (size_t k = 1; k < list.size(); k++) {
+        if (k - 1 == td.begin_c) { for (uint32_t c = 0; c < td.num_c; c++) nl.push_back({op.out[c], idx.w, idx.h}); }
+        else nl.push_back(list[k]);
+      }
+      list.swap(nl);
+    } else {
+      for (int q = (int)td.squeeze.size() - 1; q >= 0; q--) {
+        const SqueezeStep& sq = td.squeeze[q];
+        const uint32_t endc = sq.begin_c + sq.num_c - 1;
+        const uint32_t offset = sq.in_place ? endc + 1 : (uint32_t)(list.size() + sq.begin_c - endc - 1);
+        if (offset + sq.num_c > list.size() || endc >= offset) throw ParseError("squeeze range", false);
+        for (uint32_t c = sq.begin_c; c <= endc; c++) {
+          const HC avg = list[c], res = list[offset + c - sq.begin_c];
+          ModOp op; op.kind = ModOp::kSqueeze; op.param = sq.horizontal; op.in[0] = avg.off; op.in[1] = res.off;
+          op.aw = avg.w; op.ah = avg.h; op.rw = res.w; op.rh = res.h;
+          HC out;
+          if (sq.horizontal) { if (avg.h != res.h) throw ParseError("squeeze dims", false); out = {0, avg.w + res.w, avg.h}; }
+          else { if (avg.w != res.w) throw ParseError("squeeze dims", false); out = {0, avg.w, avg.h + res.h}; }
+          out.off = take((size_t)out.w * out.h * 4 + 64);
+          op.out[0] = out.off;
+          ops.push_back(op);
+          list[c] = out;
+        }
+        list.erase(list.begin() + offset, list.begin() + offset + sq.num_c);
+      }
+    }
+  }
+  ModOp op; op.kind = ModOp::kOutput; op.num_c = p.nb_color_channels;
+  if (list.size() < op.num_c + e.ih.extra.size()) throw ParseError("modular channel list", false);
+  for (size_t k = 0; k < op.num_c + e.ih.extra.size(); k++)
+    if (list[k].w != p.width || list[k].h != p.height) throw ParseError("unsupported: channel of a different size than the image (dim_shift)", true);
+  for (uint32_t c = 0; c < op.num_c; c++) op.in[c] = list[c].off;
+  op.color_factor = 1.0f / (float)((1u << e.ih.depth.bits) - 1);
+  for (size_t k = 0; k < e.ih.extra.size(); k++) if (e.ih.extra[k].type == 0) {
+    op.has_alpha = true; op.in[3] = list[op.num_c + k].off;
+    op.alpha_factor = 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);
+    break;
+  }
+  ops.push_back(op);
 }
 
 void Batch::RunTimed(void* stream_v) { RunPart(stream_v, 0, true); }

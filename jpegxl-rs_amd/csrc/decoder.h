@@ -6,6 +6,7 @@
 #include "kernels.h"
 #include <memory>
 #include <string>
+#include <functional>
 #include <vector>
 
 namespace jxlhip {
@@ -84,6 +85,17 @@ class Batch {
   FilterPlan fplan_;
   struct ModFinish { int frame; std::vector<int> planes; };  // host-side channel lists for modular frames
   std::vector<std::vector<size_t>> mod_plane_offsets_;
+  // one kernel launch of the host-planned tail of a Modular image: inverse global transforms, then the write stage
+  struct ModOp {
+    enum Kind { kRct, kPalette, kSqueeze, kOutput } kind = kRct;
+    size_t in[4] = {0, 0, 0, 0}, out[4] = {0, 0, 0, 0};   // work-arena offsets
+    size_t n = 0;
+    uint32_t param = 0, num_c = 0, bits = 0, aw = 0, ah = 0, rw = 0, rh = 0;
+    bool has_alpha = false;
+    float color_factor = 1.0f, alpha_factor = 1.0f;
+  };
+  std::vector<std::vector<ModOp>> mod_ops_;
+  void PlanModularUndo(int i, const std::function<size_t(size_t)>& take);
   std::vector<std::vector<void*>> timed_events_;
   size_t timed_rest_cursor_ = 0;       // per frame: work-arena offsets of planes (incl. spare)
 };

@@ -734,7 +734,36 @@ static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
       p->nb_meta_channels += 1;
       ch.erase(ch.begin() + t.begin_c + 1, ch.begin() + endc + 1);
       ch.insert(ch.begin(), FramePlan::ModChannel{t.nb_colors, t.num_c, -1, 0});
-    } else Unsupported("global squeeze transform");
+    } else {
+      // Squeeze (squeeze.cc MetaSqueeze): zero explicit steps = the default chain derived from the channel sizes
+      if (t.squeeze.empty()) {
+        const uint32_t first = p->nb_meta_channels;
+        if (first >= ch.size()) Fail("squeeze without channels");
+        const uint32_t nb = (uint32_t)ch.size() - first;
+        uint32_t w = ch[first].w, h = ch[first].h;
+        if (nb > 2 && ch[first + 1].w == w && ch[first + 1].h == h) { t.squeeze.push_back({1, 0, first + 1, 2}); t.squeeze.push_back({0, 0, first + 1, 2}); }
+        if (w <= h && h > 8) { t.squeeze.push_back({0, 1, first, nb}); h = (h + 1) / 2; }
+        while (w > 8 || h > 8) {
+          if (w > 8) { t.squeeze.push_back({1, 1, first, nb}); w = (w + 1) / 2; }
+          if (h > 8) { t.squeeze.push_back({0, 1, first, nb}); h = (h + 1) / 2; }
+        }
+      }
+      for (const SqueezeStep& q : t.squeeze) {
+        const uint32_t endc = q.begin_c + q.num_c - 1;
+        if (endc >= ch.size()) Fail("squeeze range");
+        if (q.begin_c < p->nb_meta_channels) Unsupported("squeeze over meta channels");
+        const uint32_t offset = q.in_place ? endc + 1 : (uint32_t)ch.size();
+        for (uint32_t c = q.begin_c; c <= endc; c++) {
+          FramePlan::ModChannel& a = ch[c];
+          if (a.hshift > 30 || a.vshift > 30) Fail("squeeze depth");
+          FramePlan::ModChannel res = a;
+          if (q.horizontal) { res.w = a.w - (a.w + 1) / 2; a.w = (a.w + 1) / 2; a.hshift++; res.hshift = a.hshift; }
+          else { res.h = a.h - (a.h + 1) / 2; a.h = (a.h + 1) / 2; a.vshift++; res.vshift = a.vshift; }
+          ch.insert(ch.begin() + offset + (c - q.begin_c), res);
+        }
+        if (ch.size() > 4096) Fail("too many squeezed channels");
+      }
+    }
   }
   if (!p->g_use_global_tree) Unsupported("local MA tree in the global modular stream");
   if (!p->has_global_tree) Fail("global tree missing");

@@ -4,9 +4,9 @@
 
 namespace jxlhip {
 
-struct ModGroupXform {  // global transform applied after all groups (RCT / palette), parsed on the host
-  uint32_t id, begin_c, rct_type, num_c, nb_colors;
-};
+// One channel of a Modular frame's global image as the sub-streams see it (after the global transforms' MetaApply):
+// plane location in the work arena, dimensions and the squeeze shifts that decide which section carries it.
+struct ModChanDev { uint64_t off; uint32_t w, h; int32_t hshift, vshift; };
 
 // One per frame of a batch; array lives in device memory.  All pointers are device pointers.
 struct FrameDev {
@@ -64,17 +64,15 @@ struct FrameDev {
   int32_t* wp_scratch;            // per stream WP state
   uint64_t wp_scratch_stride;
   // modular buffers
-  int32_t* mod_plane[8];          // full-frame channel planes (after global transforms are undone: colour + extra)
-  uint32_t mod_nchan;             // channels in the global image *before* undoing global transforms
+  const ModChanDev* mod_chan;     // channel table of the global image *before* undoing global transforms (meta channels first)
+  uint8_t* mod_base;              // work arena base the table's offsets refer to
+  uint32_t mod_nchan;
   uint32_t mod_nb_meta;
-  uint32_t mod_w[8], mod_h[8];    // dims of each global channel (meta channels first)
   uint32_t mod_global_decodable;
   uint64_t mod_global_bitpos;
   int32_t* mod_group_scratch;     // per group scratch
   uint64_t mod_group_scratch_stride;
-  uint32_t mod_ngt;               // global transforms
-  ModGroupXform mod_gt[4];
-  uint32_t mod_bits, mod_color_channels, mod_alpha_channel /* index in mod_plane or 0xFFFFFFFF */, mod_alpha_bits;
+  uint32_t mod_bits;
   // output
   uint8_t* out;
   uint64_t out_stride;            // bytes per row
@@ -108,7 +106,9 @@ void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, con
 // Modular stages
 struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; };
 void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream);
-void LaunchModularGroups(const FrameDev* frames, int nframes, int max_groups, void* stream);
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, void* stream);
+// inverse Squeeze of one channel: (avg, res) -> out; horizontal: avg aw x h, res rw x h, out (aw+rw) x h; vertical: avg w x ah, res w x rh
+void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);
 void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, size_t n, void* stream);
 void LaunchModOutput(const FrameDev* frames, int fidx, const ModOutputArgs& a, int w, int h, void* stream);

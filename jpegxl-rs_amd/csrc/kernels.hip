@@ -1045,7 +1045,6 @@ constexpr uint32_t kSimtNzOff = 128;                                   // per-th
 constexpr uint32_t kSimtRingOff = kSimtNzOff + kSimtThreads * 96;      // per-thread bit-stream ring: 16 words
 constexpr uint32_t kSimtBcmOff = kSimtRingOff + kSimtThreads * 64;     // copy of the BlockCtxDev
 constexpr uint32_t kSimtOrdOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;   // natural orders of buckets 0..8 (u16)
-constexpr uint32_t kSimtOrdEntries = 64 + 64 + 256 + 1024 + 128 + 256 + 512 + 4096 + 2048;
 constexpr uint32_t kSimtCodeOff = kSimtOrdOff;   // (orders stay in global memory: staging them in LDS bought nothing)
 __device__ __forceinline__ uint32_t OrderLdsOffset(uint32_t bucket) {   // byte offset of a bucket's order table inside the LDS copy
   const uint32_t e = bucket == 0 ? 0 : bucket == 1 ? 64 : bucket == 2 ? 128 : bucket == 3 ? 384 : bucket == 4 ? 1408 : bucket == 5 ? 1536 : bucket == 6 ? 1792 : bucket == 7 ? 2304 : 6400;
@@ -1985,6 +1984,8 @@ __device__ __forceinline__ int32_t PaletteValue(const int32_t* pal, int pal_w, i
   return (int32_t)(((int64_t)(i % 5) * ((1 << bit_depth) - 1)) / 4);
 }
 
+__device__ __forceinline__ int32_t* ModPlane(const FrameDev& f, const ModChanDev& c) { return (int32_t*)(f.mod_base + c.off); }
+
 // global stream: channels 0..mod_global_decodable-1 of the global image (meta channels + small channels)
 __global__ __launch_bounds__(64) void ModularGlobalKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.x];
@@ -1996,8 +1997,10 @@ __global__ __launch_bounds__(64) void ModularGlobalKernel(const FrameDev* __rest
   mc.wp_scratch = f.wp_scratch;
   AnsReader ans; ans.Init(br, f.mod_code);
   for (uint32_t c = 0; c < f.mod_global_decodable; c++) {
+    const ModChanDev mcd = f.mod_chan[c];
+    if (mcd.w == 0 || mcd.h == 0) continue;  // (empty channels keep their index: property 0 is the position in the list)
     ChannelDesc ch;
-    ch.data = f.mod_plane[c]; ch.w = (int)f.mod_w[c]; ch.h = (int)f.mod_h[c]; ch.stride = (int)f.mod_w[c];
+    ch.data = ModPlane(f, mcd); ch.w = (int)mcd.w; ch.h = (int)mcd.h; ch.stride = (int)mcd.w;
     DecodeModularChannel(br, ans, mc, ch, (int)c);
   }
   if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); return; }
@@ -2005,82 +2008,110 @@ __global__ __launch_bounds__(64) void ModularGlobalKernel(const FrameDev* __rest
   f.stream_end_bitpos[1] = br.BitPos();
 }
 
-// per-group stream (dec_modular.cc DecodeGroup, shift range 0..2): one 64-thread block per group; thread 0 decodes,
-// then all lanes undo the local transforms and copy the rectangle into the frame planes
+// Per-section Modular sub-streams (dec_modular.cc DecodeGroup): blockIdx.x < num_lf_groups → the ModularLfGroup stream
+// of that LF group (channels squeezed by >= 3 in both directions, stream id 1+nlf+g); otherwise the pass-group stream
+// (shift 0..2, stream id 1+3nlf+17+g).  One 64-thread block per stream; thread 0 decodes — straight into the frame
+// planes when the stream has no local transforms — then all lanes undo local transforms and copy the rectangles.
 __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.y];
   if (!f.is_modular) return;
-  const uint32_t g = blockIdx.x;
-  if (g >= f.num_groups) return;
-  // channels decoded per group: those after the globally decoded ones
+  const uint32_t unit = blockIdx.x;
+  const bool is_lf = unit < f.num_lf_groups;
+  const uint32_t g = is_lf ? unit : unit - f.num_lf_groups;
+  if (!is_lf && g >= f.num_groups) return;
+  // channels decoded per section: those after the globally decoded ones
   const uint32_t first = f.mod_global_decodable;
   if (first >= f.mod_nchan) return;
-  const uint32_t gd = f.group_dim;
-  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
-  const uint32_t x0 = gx * gd, y0 = gy * gd;
+  const uint32_t dim = is_lf ? f.group_dim * 8 : f.group_dim;
+  const uint32_t cols = is_lf ? f.xlfgroups : f.xgroups;
+  const uint32_t x0 = (g % cols) * dim, y0 = (g / cols) * dim;
+  const int min_shift = is_lf ? 3 : 0, max_shift = is_lf ? 1000 : 2;
+  constexpr int kMaxXformChan = 8;
   __shared__ int s_ok;
   __shared__ int s_nch;
   __shared__ unsigned long long s_used;
   __shared__ ChannelDesc s_ch[12];
+  __shared__ ChannelDesc s_dst[kMaxXformChan];
   __shared__ GroupHeaderD s_gh;
-  int32_t* scratch = f.mod_group_scratch + (uint64_t)g * f.mod_group_scratch_stride;
+  int32_t* scratch = f.mod_group_scratch + (uint64_t)unit * f.mod_group_scratch_stride;
+  // rectangle of channel c in this section (false: not part of it)
+  auto rect_of = [&](uint32_t c, ChannelDesc* d) -> bool {
+    const ModChanDev m = f.mod_chan[c];
+    if (m.w == 0 || m.h == 0) return false;
+    const int shift = min(m.hshift, m.vshift);
+    if (shift < min_shift || shift > max_shift) return false;
+    const uint32_t rx = x0 >> m.hshift, ry = y0 >> m.vshift;
+    if (rx >= m.w || ry >= m.h) return false;
+    const uint32_t rw = min(dim >> m.hshift, m.w - rx), rh = min(dim >> m.vshift, m.h - ry);
+    if (rw == 0 || rh == 0) return false;
+    d->data = ModPlane(f, m) + (size_t)ry * m.w + rx; d->w = (int)rw; d->h = (int)rh; d->stride = (int)m.w;
+    return true;
+  };
   if (threadIdx.x == 0) {
     s_ok = 0;
-    const uint32_t si = f.single_section ? 0 : 2 + f.num_lf_groups + g;
-    BitReader br;
-    uint64_t limit;
-    if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
-    else { const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
-    // channel list of this group (cropped rectangles)
     int nch = 0;
-    uint64_t used = 0;
     bool ok = true;
-    uint32_t gw = 0, gh = 0;
-    for (uint32_t c = first; c < f.mod_nchan && ok; c++) {
-      const uint32_t cw_ = f.mod_w[c], chh = f.mod_h[c];
-      if (x0 >= cw_ || y0 >= chh) continue;
-      const uint32_t rw = min(gd, cw_ - x0), rh = min(gd, chh - y0);
-      if (nch >= 8) { ok = false; break; }
-      s_ch[nch].data = scratch + used; s_ch[nch].w = (int)rw; s_ch[nch].h = (int)rh; s_ch[nch].stride = (int)rw;
-      used += (uint64_t)rw * rh;
-      gw = rw; gh = rh;
-      nch++;
-    }
-    int nmeta = 0;
-    if (ok && nch > 0) {
-      ok = ReadGroupHeader(br, s_gh) && s_gh.use_global_tree;
-      // apply local transforms to the channel list (MetaApply)
-      for (uint32_t i = 0; ok && i < s_gh.ntransforms; i++) {
-        auto& t = s_gh.t[i];
-        if (t.id == 0) { if (t.begin_c + 3 > (uint32_t)nch) ok = false; }
-        else {
-          const uint32_t endc = t.begin_c + t.num_c - 1;
-          if (endc >= (uint32_t)nch || (int)t.begin_c < nmeta || nch + 1 - (int)(t.num_c - 1) > 12 || t.nb_colors > 65536) { ok = false; break; }
-          // remove channels begin_c+1..endc, insert palette channel at 0
-          for (uint32_t k = endc + 1; k < (uint32_t)nch; k++) s_ch[k - (t.num_c - 1)] = s_ch[k];
-          nch -= (int)(t.num_c - 1);
-          for (int k = nch; k > 0; k--) s_ch[k] = s_ch[k - 1];
-          nch++;
-          s_ch[0].data = scratch + used; s_ch[0].w = (int)t.nb_colors; s_ch[0].h = (int)t.num_c; s_ch[0].stride = (int)t.nb_colors;
-          used += (uint64_t)t.nb_colors * t.num_c;
-          nmeta++;
-          // (after the inverse, begin_c indexes the channel list without the palette channel)
-        }
-      }
-      if (used > f.mod_group_scratch_stride) ok = false;
-      if (ok) {
-        ModularCtx mc;
-        mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
-        mc.stream_id = 1 + 3 * f.num_lf_groups + 17 + g;
-        mc.wp_scratch = f.wp_scratch + (uint64_t)(1 + g) * f.wp_scratch_stride;
+    ChannelDesc d;
+    for (uint32_t c = first; c < f.mod_nchan; c++) nch += rect_of(c, &d) ? 1 : 0;
+    unsigned long long used = 0;
+    if (nch > 0) {
+      if (f.single_section) ok = false;  // a one-group frame decodes every channel globally
+      const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + g;
+      BitReader br;
+      uint64_t limit = 0;
+      if (ok) { const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
+      ok = ok && ReadGroupHeader(br, s_gh) && s_gh.use_global_tree;
+      ModularCtx mc;
+      mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
+      mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + g;
+      mc.wp_scratch = f.wp_scratch + (uint64_t)(1 + unit) * f.wp_scratch_stride;
+      if (ok && s_gh.ntransforms == 0) {
+        // direct: decode every rectangle in place
         AnsReader ans; ans.Init(br, f.mod_code);
-        for (int c = 0; c < nch; c++) DecodeModularChannel(br, ans, mc, s_ch[c], c);
+        int k = 0;
+        for (uint32_t c = first; c < f.mod_nchan; c++) if (rect_of(c, &d)) DecodeModularChannel(br, ans, mc, d, k++);
         if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); ok = false; }
         else if (br.BitPos() > limit) { SetError(f, kErrOverrun); ok = false; }
+        nch = 0;  // nothing left to do for the other lanes
+      } else if (ok) {
+        // local transforms: decode into scratch, undo, then copy (at most kMaxXformChan channels)
+        if (nch > kMaxXformChan) ok = false;
+        int k = 0;
+        for (uint32_t c = first; ok && c < f.mod_nchan; c++) if (rect_of(c, &d)) {
+          s_dst[k] = d;
+          s_ch[k].data = scratch + used; s_ch[k].w = d.w; s_ch[k].h = d.h; s_ch[k].stride = d.w;
+          used += (unsigned long long)d.w * d.h;
+          k++;
+        }
+        int nmeta = 0;
+        // apply local transforms to the channel list (MetaApply)
+        for (uint32_t i = 0; ok && i < s_gh.ntransforms; i++) {
+          auto& t = s_gh.t[i];
+          if (t.id == 0) { if (t.begin_c + 3 > (uint32_t)nch) ok = false; }
+          else {
+            const uint32_t endc = t.begin_c + t.num_c - 1;
+            if (endc >= (uint32_t)nch || (int)t.begin_c < nmeta || nch + 1 - (int)(t.num_c - 1) > 12 || t.nb_colors > 65536) { ok = false; break; }
+            // remove channels begin_c+1..endc, insert palette channel at 0
+            for (uint32_t q = endc + 1; q < (uint32_t)nch; q++) s_ch[q - (t.num_c - 1)] = s_ch[q];
+            nch -= (int)(t.num_c - 1);
+            for (int q = nch; q > 0; q--) s_ch[q] = s_ch[q - 1];
+            nch++;
+            s_ch[0].data = scratch + used; s_ch[0].w = (int)t.nb_colors; s_ch[0].h = (int)t.num_c; s_ch[0].stride = (int)t.nb_colors;
+            used += (unsigned long long)t.nb_colors * t.num_c;
+            nmeta++;
+            // (after the inverse, begin_c indexes the channel list without the palette channel)
+          }
+        }
+        if (used > f.mod_group_scratch_stride) ok = false;
+        if (ok) {
+          AnsReader ans; ans.Init(br, f.mod_code);
+          for (int c = 0; c < nch; c++) DecodeModularChannel(br, ans, mc, s_ch[c], c);
+          if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); ok = false; }
+          else if (br.BitPos() > limit) { SetError(f, kErrOverrun); ok = false; }
+        } else SetError(f, kErrUnsupported);
       } else SetError(f, kErrUnsupported);
     }
     s_nch = nch; s_ok = ok && nch > 0; s_used = used;
-    (void)gw; (void)gh;
   }
   __syncthreads();
   if (!s_ok) return;
@@ -2097,8 +2128,7 @@ __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restr
       const ChannelDesc pal = s_ch[0];
       const ChannelDesc idx = s_ch[t.begin_c + 1];
       const size_t n = (size_t)idx.w * idx.h;
-      // new channels are carved from the palette's scratch tail: allocate after current usage is unknown here, so
-      // expand in place: channel c>0 gets fresh storage following the palette storage
+      // the num_c-1 new channels get fresh storage at the scratch tail
       __shared__ ChannelDesc s_new[4];
       if (threadIdx.x == 0) {
         if (s_used + (unsigned long long)(t.num_c - 1) * n > f.mod_group_scratch_stride) { SetError(f, kErrUnsupported); s_ok = 0; }
@@ -2133,17 +2163,66 @@ __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restr
     }
   }
   // ---- copy into the frame planes
-  int k = 0;
-  for (uint32_t c = first; c < f.mod_nchan; c++) {
-    const uint32_t cw_ = f.mod_w[c], chh = f.mod_h[c];
-    if (x0 >= cw_ || y0 >= chh) continue;
-    const ChannelDesc d = s_ch[k++];
-    int32_t* dst = f.mod_plane[c] + (size_t)y0 * cw_ + x0;
+  for (int k = 0; k < nch && k < kMaxXformChan; k++) {
+    const ChannelDesc d = s_ch[k], dst = s_dst[k];
     for (size_t i = threadIdx.x; i < (size_t)d.w * d.h; i += blockDim.x) {
       const size_t yy = i / d.w, xx = i % d.w;
-      dst[yy * cw_ + xx] = d.data[i];
+      dst.data[yy * dst.stride + xx] = d.data[i];
     }
   }
+}
+
+// ---- inverse Squeeze (squeeze.cc InvHSqueeze / InvVSqueeze; ISO/IEC 18181-1 "smooth tendency") ----------------------
+__device__ __forceinline__ int64_t SqueezeTendency(int64_t B, int64_t a, int64_t n) {
+  int64_t diff = 0;
+  if (B >= a && a >= n) {
+    diff = (4 * B - 3 * n - a + 6) / 12;
+    if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+    if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+  } else if (B <= a && a <= n) {
+    diff = (4 * B - 3 * n - a - 6) / 12;
+    if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+    if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+  }
+  return diff;
+}
+__device__ __forceinline__ void SqueezePair(int64_t prev, int64_t a, int64_t next, int64_t dmt, int32_t* o0, int32_t* o1) {
+  const int64_t diff = dmt + SqueezeTendency(prev, a, next);
+  const int64_t A = ((a * 2) + diff + (diff > 0 ? -(diff & 1) : (diff & 1))) >> 1;
+  *o0 = (int32_t)A; *o1 = (int32_t)(A - diff);
+}
+// horizontal: the recurrence runs along x, so one thread owns one row
+__global__ __launch_bounds__(64) void ModInvSqueezeHKernel(const int32_t* __restrict__ avg, const int32_t* __restrict__ res, int32_t* __restrict__ out,
+                                                           uint32_t aw, uint32_t rw, uint32_t h) {
+  const uint32_t y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= h) return;
+  const int32_t* pa = avg + (size_t)y * aw;
+  const int32_t* pr = res + (size_t)y * rw;
+  int32_t* po = out + (size_t)y * (aw + rw);
+  int64_t a = aw ? pa[0] : 0, left = a;
+  for (uint32_t x = 0; x < rw; x++) {
+    const int64_t next = x + 1 < aw ? pa[x + 1] : a;
+    int32_t o0, o1;
+    SqueezePair(left, a, next, pr[x], &o0, &o1);
+    po[2 * x] = o0; po[2 * x + 1] = o1;
+    left = o1; a = next;
+  }
+  if (aw > rw) po[2 * rw] = pa[rw];
+}
+// vertical: one thread per column, rows top to bottom (coalesced across the wave)
+__global__ __launch_bounds__(256) void ModInvSqueezeVKernel(const int32_t* __restrict__ avg, const int32_t* __restrict__ res, int32_t* __restrict__ out,
+                                                            uint32_t w, uint32_t ah, uint32_t rh) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= w) return;
+  int64_t a = ah ? avg[x] : 0, top = a;
+  for (uint32_t y = 0; y < rh; y++) {
+    const int64_t next = y + 1 < ah ? avg[(size_t)(y + 1) * w + x] : a;
+    int32_t o0, o1;
+    SqueezePair(top, a, next, res[(size_t)y * w + x], &o0, &o1);
+    out[(size_t)(2 * y) * w + x] = o0; out[(size_t)(2 * y + 1) * w + x] = o1;
+    top = o1; a = next;
+  }
+  if (ah > rh) out[(size_t)(2 * rh) * w + x] = avg[(size_t)rh * w + x];
 }
 
 // ---- global inverse transforms and the integer write stage (explicit arguments; launched per frame by the host) ----
@@ -2263,8 +2342,12 @@ void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, con
 void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream) {
   hipLaunchKernelGGL(ModularGlobalKernel, dim3(nframes), dim3(64), 0, (hipStream_t)stream, frames);
 }
-void LaunchModularGroups(const FrameDev* frames, int nframes, int max_groups, void* stream) {
-  hipLaunchKernelGGL(ModularGroupKernel, dim3(max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames);
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, void* stream) {
+  hipLaunchKernelGGL(ModularGroupKernel, dim3(max_lf_groups + max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames);
+}
+void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream) {
+  if (horizontal) { if (ah) hipLaunchKernelGGL(ModInvSqueezeHKernel, dim3((ah + 63) / 64), dim3(64), 0, (hipStream_t)stream, avg, res, out, aw, rw, ah); }
+  else if (aw) hipLaunchKernelGGL(ModInvSqueezeVKernel, dim3((aw + 255) / 256), dim3(256), 0, (hipStream_t)stream, avg, res, out, aw, ah, rh);
 }
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream) {
   hipLaunchKernelGGL(ModRctKernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n, rct_type);

@@ -258,7 +258,8 @@ inline void ReadLfGroup(BitReader& br, Frame& f, int g) {
     }
   }
   // ModularLfGroup
-  DecodeModularGroup(br, f, gx * 2048, gy * 2048, 2048, 2048, 3, 1000, 1 + nlf + g);
+  const int lfd = (int)f.fh.group_dim * 8;
+  DecodeModularGroup(br, f, gx * lfd, gy * lfd, lfd, lfd, 3, 1000, 1 + nlf + g);
   if (f.fh.modular) return;
   // HfMetadata (dec_frame.cc / ac_strategy / DecodeAcMetadata)
   uint32_t nb_blocks = 1 + br.u(CeilLog2((uint32_t)(gbw * gbh)));

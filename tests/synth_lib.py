@@ -33,6 +33,7 @@ def lib():
         L.jxlsynth_image.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.jxlsynth_vardct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.jxlsynth_modular.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.jxlsynth_modular2.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -68,8 +69,9 @@ def encode_vardct(rgb, seed=1, distance=1.0, epf_iters=1, gab=1, strategy_mix=1,
     return _take(out, n)
 
 
-def encode_modular(img, bits=8, rct=False):
-    """img: (h,w,C) integer array, C in {1,2,3,4} (2/4 = with alpha).  Lossless Modular codestream."""
+def encode_modular(img, bits=8, rct=False, squeeze=0):
+    """img: (h,w,C) integer array, C in {1,2,3,4} (2/4 = with alpha).  Lossless Modular codestream.
+    squeeze: 0 none, 1 default Squeeze chain (what `cjxl -d 0 -R 1` signals), 2 short explicit chain."""
     L = lib()
     h, w, c = img.shape
     has_alpha = c in (2, 4)
@@ -77,7 +79,7 @@ def encode_modular(img, bits=8, rct=False):
     planes = [np.ascontiguousarray(img[..., i].astype(np.int32)) for i in range(c)]
     arr = (C.c_void_p * c)(*[p.ctypes.data for p in planes])
     out = C.c_void_p(); n = C.c_size_t()
-    rc = L.jxlsynth_modular(arr, nchan, 1 if has_alpha else 0, w, h, bits, 1 if rct else 0, C.byref(out), C.byref(n))
+    rc = L.jxlsynth_modular2(arr, nchan, 1 if has_alpha else 0, w, h, bits, 1 if rct else 0, int(squeeze), C.byref(out), C.byref(n))
     if rc:
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)

@@ -258,6 +258,37 @@ def test_modular_synth(jx, h, w, c, bits, rct):
     assert np.array_equal(px.reshape(h, w, c), img)
 
 
+def _smooth_image(seed, h, w, c, bits):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = ((np.sin(xx / 37.0) + np.cos(yy / 23.0)) * 0.25 + 0.5) * ((1 << bits) - 1)
+    noise = rng.normal(0, (1 << bits) / 1024.0, (h, w, c)).astype(np.float32)
+    return np.clip(base[..., None] + noise, 0, (1 << bits) - 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("h,w,c,bits,rct,squeeze", [(50, 40, 1, 8, 0, 1), (280, 300, 3, 8, 1, 1), (280, 300, 4, 16, 1, 2), (520, 700, 1, 16, 0, 1),
+                                                   (2070, 2100, 1, 16, 0, 1), (600, 2300, 3, 8, 0, 1), (777, 333, 2, 8, 0, 2), (9, 1, 1, 8, 0, 1)])
+def test_modular_squeeze(jx, h, w, c, bits, rct, squeeze):
+    """Lossless Modular with the Squeeze transform (default chain as `cjxl -d 0 -R 1` signals it, and explicit chains with
+    appended residuals): residual channels ride in GlobalModular / LfGroup (shift >= 3) / PassGroup sections; the decode
+    must return the source samples exactly and agree with the oracle."""
+    img = _smooth_image(5, h, w, c, bits)
+    data = S.encode_modular(img, bits, bool(rct), squeeze)
+    dt = np.uint16 if bits == 16 else np.uint8
+    _, px = jx.decoder_builder().decode_with(data, dt)
+    assert np.array_equal(px.reshape(h, w, c), img)
+    assert np.array_equal(px, O.decode(data).pixels("u16" if bits == 16 else "u8", c).view(dt))
+
+
+def test_full_size_8k_modular_squeeze(jx):
+    """BASELINE config 4: lossless Modular (Squeeze) 8192x8192 u16 on one GPU, bit-exact (lossless round trip of the source)."""
+    img = _smooth_image(6, 8192, 8192, 1, 16)
+    data = S.encode_modular(img, 16, False, 1)
+    meta, px = jx.decoder_builder().decode_with(data, np.uint16)
+    assert (meta.width, meta.height, meta.num_color_channels) == (8192, 8192, 1)
+    assert np.array_equal(px.reshape(8192, 8192), img[..., 0])
+
+
 def test_full_size_4k_frame(jx):
     """BASELINE config 2: one 3840x2160 VarDCT d1 frame, u8 output, bit-exact vs the CPU decode."""
     img = S.synthetic_image(1000, 3840, 2160)

@@ -611,30 +611,120 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   return out.bytes;
 }
 
-// ---- Modular lossless encoder (gradient predictor, fixed global tree, 256x256 groups) ---------------------------
-static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int nchan, int w, int h, int bits, bool has_alpha, bool rct) {
-  // channels: nchan colour (1 or 3) [+1 alpha].  Optional RCT type 6 (YCgCo) signalled as a global transform.
-  const int group_shift = 1, gd = 256;
-  const int xg = (w + gd - 1) / gd, yg = (h + gd - 1) / gd, ngroups = xg * yg;
-  const int xlg = (w + 2047) / 2048, ylg = (h + 2047) / 2048, nlf = xlg * ylg;
-  const int ntot = nchan + (has_alpha ? 1 : 0);
-  std::vector<std::vector<int32_t>> ch(ntot);
-  for (int c = 0; c < ntot; c++) ch[c].assign(planes[c], planes[c] + (size_t)w * h);
-  if (rct && nchan == 3) {
-    for (size_t i = 0; i < (size_t)w * h; i++) {
-      int32_t R = ch[0][i], G = ch[1][i], B = ch[2][i];
-      int32_t co = R - B, tmp = B + (co >> 1), cg = G - tmp, y = tmp + (cg >> 1);
-      ch[0][i] = y; ch[1][i] = co; ch[2][i] = cg;
+// ---- Modular lossless encoder (gradient predictor, fixed global tree, 256x256 groups, optional RCT + Squeeze) -----
+struct SChan { std::vector<int32_t> d; int w, h, hs, vs; };
+struct SqStep { bool horizontal, in_place; int begin_c, num_c; };
+
+// ISO/IEC 18181-1 squeeze "smooth tendency" (the decoder adds it back, so both sides must agree exactly)
+static int64_t SqTendency(int64_t B, int64_t a, int64_t n) {
+  int64_t diff = 0;
+  if (B >= a && a >= n) {
+    diff = (4 * B - 3 * n - a + 6) / 12;
+    if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+    if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+  } else if (B <= a && a <= n) {
+    diff = (4 * B - 3 * n - a - 6) / 12;
+    if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+    if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+  }
+  return diff;
+}
+static void FwdSqueeze(const SChan& in, bool horizontal, SChan& avg, SChan& res) {
+  const int w = in.w, h = in.h;
+  if (horizontal) {
+    avg = SChan{{}, (w + 1) / 2, h, in.hs + 1, in.vs};
+    res = SChan{{}, w - (w + 1) / 2, h, in.hs + 1, in.vs};
+    avg.d.resize((size_t)avg.w * h); res.d.resize((size_t)res.w * h);
+    for (int y = 0; y < h; y++) {
+      const int32_t* p = &in.d[(size_t)y * w];
+      int32_t* pa = avg.d.data() + (size_t)y * avg.w;
+      int32_t* pr = res.d.data() + (size_t)y * res.w;
+      for (int x = 0; x < res.w; x++) { int64_t A = p[2 * x], B = p[2 * x + 1]; pa[x] = (int32_t)((A + B + (A > B)) >> 1); }
+      if (avg.w > res.w) pa[res.w] = p[w - 1];
+      for (int x = 0; x < res.w; x++) {
+        int64_t a = pa[x], next = x + 1 < avg.w ? pa[x + 1] : a, left = x ? p[2 * x - 1] : a;
+        pr[x] = (int32_t)((int64_t)p[2 * x] - p[2 * x + 1] - SqTendency(left, a, next));
+      }
+    }
+  } else {
+    avg = SChan{{}, w, (h + 1) / 2, in.hs, in.vs + 1};
+    res = SChan{{}, w, h - (h + 1) / 2, in.hs, in.vs + 1};
+    avg.d.resize((size_t)w * avg.h); res.d.resize((size_t)w * res.h);
+    for (int y = 0; y < res.h; y++)
+      for (int x = 0; x < w; x++) { int64_t A = in.d[(size_t)(2 * y) * w + x], B = in.d[(size_t)(2 * y + 1) * w + x]; avg.d[(size_t)y * w + x] = (int32_t)((A + B + (A > B)) >> 1); }
+    if (avg.h > res.h) for (int x = 0; x < w; x++) avg.d[(size_t)res.h * w + x] = in.d[(size_t)(h - 1) * w + x];
+    for (int y = 0; y < res.h; y++)
+      for (int x = 0; x < w; x++) {
+        int64_t a = avg.d[(size_t)y * w + x], next = y + 1 < avg.h ? avg.d[(size_t)(y + 1) * w + x] : a, top = y ? in.d[(size_t)(2 * y - 1) * w + x] : a;
+        res.d[(size_t)y * w + x] = (int32_t)((int64_t)in.d[(size_t)(2 * y) * w + x] - in.d[(size_t)(2 * y + 1) * w + x] - SqTendency(top, a, next));
+      }
+  }
+}
+// the default chain a decoder derives when the stream carries zero explicit steps (no meta channels here)
+static std::vector<SqStep> DefaultSqueezeSteps(const std::vector<SChan>& ch) {
+  std::vector<SqStep> p;
+  const int nb = (int)ch.size();
+  int w = ch[0].w, h = ch[0].h;
+  if (nb > 2 && ch[1].w == w && ch[1].h == h) { p.push_back({true, false, 1, 2}); p.push_back({false, false, 1, 2}); }
+  if (w <= h && h > 8) { p.push_back({false, true, 0, nb}); h = (h + 1) / 2; }
+  while (w > 8 || h > 8) {
+    if (w > 8) { p.push_back({true, true, 0, nb}); w = (w + 1) / 2; }
+    if (h > 8) { p.push_back({false, true, 0, nb}); h = (h + 1) / 2; }
+  }
+  return p;
+}
+static void ApplySqueeze(std::vector<SChan>& ch, const std::vector<SqStep>& steps) {
+  for (const SqStep& s : steps) {
+    const int endc = s.begin_c + s.num_c - 1;
+    if (endc >= (int)ch.size()) throw std::runtime_error("squeeze step out of range");
+    const int offset = s.in_place ? endc + 1 : (int)ch.size();
+    for (int c = s.begin_c; c <= endc; c++) {
+      SChan avg, res;
+      FwdSqueeze(ch[c], s.horizontal, avg, res);
+      ch[c] = std::move(avg);
+      ch.insert(ch.begin() + offset + (c - s.begin_c), std::move(res));
     }
   }
-  // tree: channel split, then prop 9 cutoffs, gradient predictor
+}
+
+// squeeze: 0 = none, 1 = default chain (signalled with zero explicit steps), 2 = short explicit chain mixing in-place and appended residuals
+static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int nchan, int w, int h, int bits, bool has_alpha, bool rct, int squeeze) {
+  // channels: nchan colour (1 or 3) [+1 alpha].  Optional RCT type 6 (YCgCo) signalled as a global transform.
+  const int group_shift = 1, gd = 256, lfd = gd * 8;
+  const int xg = (w + gd - 1) / gd, yg = (h + gd - 1) / gd, ngroups = xg * yg;
+  const int xlg = (w + lfd - 1) / lfd, ylg = (h + lfd - 1) / lfd, nlf = xlg * ylg;
+  const int ntot = nchan + (has_alpha ? 1 : 0);
+  std::vector<SChan> ch(ntot);
+  for (int c = 0; c < ntot; c++) { ch[c].d.assign(planes[c], planes[c] + (size_t)w * h); ch[c].w = w; ch[c].h = h; ch[c].hs = ch[c].vs = 0; }
+  if (rct && nchan == 3) {
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+      int32_t R = ch[0].d[i], G = ch[1].d[i], B = ch[2].d[i];
+      int32_t co = R - B, tmp = B + (co >> 1), cg = G - tmp, y = tmp + (cg >> 1);
+      ch[0].d[i] = y; ch[1].d[i] = co; ch[2].d[i] = cg;
+    }
+  }
+  std::vector<SqStep> steps;
+  if (squeeze == 1) steps = DefaultSqueezeSteps(ch);
+  else if (squeeze == 2) {
+    steps.push_back({true, true, 0, ntot});
+    steps.push_back({false, true, 0, ntot});
+    steps.push_back({true, false, 0, 1});
+    if (ntot > 1) steps.push_back({false, false, ntot - 1, 1});
+  }
+  if (squeeze) ApplySqueeze(ch, steps);
+  const int nfinal = (int)ch.size();
+  // tree: channel split (unsqueezed only: squeezed sub-streams have varying channel lists), then prop 9 cutoffs, gradient predictor
   GTree t;
   static const int cuts[] = {-1023, -255, -63, -15, -3, 0, 3, 15, 63, 255, 1023};
   std::vector<int> cut(cuts, cuts + 11);
-  std::vector<int> sub(ntot);
-  for (int c = 0; c < ntot; c++) sub[c] = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
-  int root = sub[ntot - 1];
-  for (int c = ntot - 2; c >= 0; c--) root = t.add_inner(0, c, root, sub[c]);  // channel > c ? (higher channels) : channel c
+  int root;
+  if (squeeze) root = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
+  else {
+    std::vector<int> sub(ntot);
+    for (int c = 0; c < ntot; c++) sub[c] = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
+    root = sub[ntot - 1];
+    for (int c = ntot - 2; c >= 0; c--) root = t.add_inner(0, c, root, sub[c]);  // channel > c ? (higher channels) : channel c
+  }
   std::vector<int> bfs{root};
   for (size_t i = 0; i < bfs.size(); i++) { const TNode& n = t.nodes[bfs[i]]; if (n.prop >= 0) { bfs.push_back(n.l); bfs.push_back(n.r); } }
   int leaf = 0;
@@ -643,30 +733,45 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
   std::vector<Token> tree_tokens;
   TreeTokens(t, bfs, tree_tokens);
   bool single = ngroups == 1;
-  bool all_global = w <= gd && h <= gd;  // every channel decoded in GlobalModular
-  std::vector<std::vector<Token>> gtok(ngroups);
+  // GlobalModular takes the leading channels that fit a group; the others go to LfGroups (shift >= 3) or PassGroups
+  int nglobal = 0;
+  while (nglobal < nfinal && ch[nglobal].w <= gd && ch[nglobal].h <= gd) nglobal++;
   std::vector<Token> global_tok;
-  std::vector<std::vector<std::vector<int32_t>>> gdata(ngroups);
-  if (all_global) {
+  std::vector<std::vector<Token>> lftok(nlf), gtok(ngroups);
+  std::vector<char> lf_has(nlf, 0), g_has(ngroups, 0);
+  {
     std::vector<ChanRef> cr;
-    for (int c = 0; c < ntot; c++) cr.push_back({ch[c].data(), w, h});
+    for (int c = 0; c < nglobal; c++) if (ch[c].w && ch[c].h) cr.push_back({ch[c].d.data(), ch[c].w, ch[c].h});
     ModularTokens(t, root, cr, 0, global_tok);
-  } else {
-    for (int g = 0; g < ngroups; g++) {
-      int gx = g % xg, gy = g / xg, x0 = gx * gd, y0 = gy * gd, gw = std::min(gd, w - x0), gh = std::min(gd, h - y0);
-      gdata[g].resize(ntot);
-      std::vector<ChanRef> cr;
-      for (int c = 0; c < ntot; c++) {
-        gdata[g][c].resize((size_t)gw * gh);
-        for (int y = 0; y < gh; y++) memcpy(&gdata[g][c][(size_t)y * gw], &ch[c][(size_t)(y0 + y) * w + x0], sizeof(int32_t) * gw);
-        cr.push_back({gdata[g][c].data(), gw, gh});
-      }
-      ModularTokens(t, root, cr, 1 + 3 * nlf + 17 + g, gtok[g]);
+  }
+  auto group_stream = [&](int x0, int y0, int dim, int min_shift, int max_shift, int stream_id, std::vector<Token>& out) -> bool {
+    std::vector<std::vector<int32_t>> store;
+    std::vector<ChanRef> cr;
+    for (int c = nglobal; c < nfinal; c++) {
+      const SChan& sc = ch[c];
+      if (!sc.w || !sc.h) continue;
+      const int shift = std::min(sc.hs, sc.vs);
+      if (shift < min_shift || shift > max_shift) continue;
+      const int rx = x0 >> sc.hs, ry = y0 >> sc.vs;
+      if (rx >= sc.w || ry >= sc.h) continue;
+      const int rw = std::min(dim >> sc.hs, sc.w - rx), rh = std::min(dim >> sc.vs, sc.h - ry);
+      if (rw <= 0 || rh <= 0) continue;
+      store.emplace_back((size_t)rw * rh);
+      for (int y = 0; y < rh; y++) memcpy(&store.back()[(size_t)y * rw], &sc.d[(size_t)(ry + y) * sc.w + rx], sizeof(int32_t) * rw);
+      cr.push_back({nullptr, rw, rh});
     }
+    for (size_t i = 0; i < cr.size(); i++) cr[i].d = store[i].data();
+    if (cr.empty()) return false;
+    ModularTokens(t, root, cr, stream_id, out);
+    return true;
+  };
+  if (nglobal < nfinal) {
+    for (int g = 0; g < nlf; g++) lf_has[g] = group_stream((g % xlg) * lfd, (g / xlg) * lfd, lfd, 3, 1000, 1 + nlf + g, lftok[g]);
+    for (int g = 0; g < ngroups; g++) g_has[g] = group_stream((g % xg) * gd, (g / xg) * gd, gd, 0, 2, 1 + 3 * nlf + 17 + g, gtok[g]);
   }
   EntropyCoder tree_code, code;
   { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
-  { std::vector<const std::vector<Token>*> s{&global_tok}; for (auto& g : gtok) s.push_back(&g); BuildEntropyCoder(s, t.num_leaves, UintConfig{4, 2, 0}, 64, code); }
+  { std::vector<const std::vector<Token>*> s{&global_tok}; for (auto& g : lftok) s.push_back(&g); for (auto& g : gtok) s.push_back(&g); BuildEntropyCoder(s, t.num_leaves, UintConfig{4, 2, 0}, 64, code); }
   std::vector<BitWriter> sections;
   {
     BitWriter s;
@@ -677,20 +782,34 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
     WriteEntropyCode(s, code);
     // global GroupHeader
     s.put(1, 1); s.put(1, 1);
-    if (rct && nchan == 3) { WriteU32(s, 1, {0, 0}, {0, 1}, {4, 2}, {8, 18}); s.put(0, 2); WriteU32(s, 0, {3, 0}, {6, 8}, {10, 72}, {13, 1096}); WriteU32(s, 6, {0, 6}, {2, 0}, {4, 2}, {6, 10}); }
-    else s.put(0, 2);
+    const bool has_rct = rct && nchan == 3;
+    WriteU32(s, (has_rct ? 1 : 0) + (squeeze ? 1 : 0), {0, 0}, {0, 1}, {4, 2}, {8, 18});
+    if (has_rct) { s.put(0, 2); WriteU32(s, 0, {3, 0}, {6, 8}, {10, 72}, {13, 1096}); WriteU32(s, 6, {0, 6}, {2, 0}, {4, 2}, {6, 10}); }
+    if (squeeze) {
+      s.put(2, 2);
+      const std::vector<SqStep> none;
+      const std::vector<SqStep>& sig = squeeze == 1 ? none : steps;
+      WriteU32(s, (uint32_t)sig.size(), {0, 0}, {4, 1}, {6, 9}, {8, 41});
+      for (const SqStep& q : sig) {
+        s.put(q.horizontal, 1); s.put(q.in_place, 1);
+        WriteU32(s, (uint32_t)q.begin_c, {3, 0}, {6, 8}, {10, 72}, {13, 1096});
+        WriteU32(s, (uint32_t)q.num_c, {0, 1}, {0, 2}, {0, 3}, {4, 4});
+      }
+    }
     EncodeTokens(s, code, global_tok);  // (ANS state is written even when no channel is decodable globally)
     sections.push_back(s);
   }
-  for (int g = 0; g < nlf; g++) sections.push_back(BitWriter());  // LfGroups: nothing (no squeezed channels)
-  if (!single || true) {
-    // HfGlobal is absent for modular frames but still has a TOC slot
-    sections.push_back(BitWriter());
-    for (int g = 0; g < ngroups; g++) {
-      BitWriter s;
-      if (!all_global) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, code, gtok[g]); }
-      sections.push_back(s);
-    }
+  for (int g = 0; g < nlf; g++) {  // LfGroups: the squeezed channels with shift >= 3
+    BitWriter s;
+    if (lf_has[g]) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, code, lftok[g]); }
+    sections.push_back(s);
+  }
+  // HfGlobal is absent for modular frames but still has a TOC slot
+  sections.push_back(BitWriter());
+  for (int g = 0; g < ngroups; g++) {
+    BitWriter s;
+    if (g_has[g]) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, code, gtok[g]); }
+    sections.push_back(s);
   }
   BitWriter out;
   Params p; p.out_bits = bits; p.gab = 0; p.epf_iters = 0;  // lossless: no restoration filters
@@ -740,8 +859,12 @@ int jxlsynth_vardct(const uint8_t* rgb8, const float* rgb_lin, int w, int h, con
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 // planes: nchan (+alpha) pointers to w*h int32 samples
+int jxlsynth_modular2(const int32_t* const* planes, int nchan, int has_alpha, int w, int h, int bits, int rct, int squeeze, uint8_t** out, size_t* n) {
+  try { return finish(synth::EncodeModular(planes, nchan, w, h, bits, has_alpha != 0, rct != 0, squeeze), out, n); }
+  catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 int jxlsynth_modular(const int32_t* const* planes, int nchan, int has_alpha, int w, int h, int bits, int rct, uint8_t** out, size_t* n) {
-  try { return finish(synth::EncodeModular(planes, nchan, w, h, bits, has_alpha != 0, rct != 0), out, n); }
+  try { return finish(synth::EncodeModular(planes, nchan, w, h, bits, has_alpha != 0, rct != 0, 0), out, n); }
   catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 }
