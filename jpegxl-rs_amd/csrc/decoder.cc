@@ -1,5 +1,6 @@
 // jxl-hip: batch decoder (see decoder.h).
 #include "decoder.h"
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -156,7 +157,16 @@ void Batch::Prepare(void* stream_v) {
   std::vector<ConstOffsets> co(n);
   // natural coefficient orders (shared)
   size_t natural_off[13];
-  for (int b = 0; b < 13; b++) { auto v = NaturalCoeffOrder(kBucketStrategy[b]); natural_off[b] = arena.Put(v.data(), v.size() * 2); }
+  {
+    // (process-wide: the orders of the DCT128/256 buckets are 16K..64K entries each)
+    static std::mutex mu;
+    static std::vector<uint16_t> natural[13];
+    std::lock_guard<std::mutex> lock(mu);
+    for (int b = 0; b < 13; b++) {
+      if (natural[b].empty()) natural[b] = NaturalCoeffOrder(kBucketStrategy[b]);
+      natural_off[b] = arena.Put(natural[b].data(), natural[b].size() * 2);
+    }
+  }
   // quant tables are shared between frames with identical specs
   struct QCache { const QuantTableSpec* spec; int kind; size_t off[3]; };
   std::vector<QCache> qcache;
@@ -384,13 +394,33 @@ void Batch::Prepare(void* stream_v) {
       const auto& cu = p.custom_order[b * 3 + ch];
       c.orders[b * 3 + ch] = cu.empty() ? natural_off[b] : arena.Put(cu.data(), cu.size() * 2);
     }
-    for (int k = 0; k <= 12; k++) {  // kinds above 64x64 are not supported by the IDCT kernel
+    for (int k = 0; k < 17; k++) {
       if (k == 10) continue;         // AFV
       int hit = -1;
       for (size_t q = 0; q < qcache.size(); q++) if (qcache[q].kind == k && spec_equal(*qcache[q].spec, p.qspec[k])) { hit = (int)q; break; }
       if (hit < 0) {
         QCache qc; qc.spec = &p.qspec[k]; qc.kind = k;
-        for (int ch = 0; ch < 3; ch++) { std::vector<float> t; ComputeQuantTable(p.qspec[k], k, ch, &t); qc.off[ch] = arena.Put(t.data(), t.size() * 4); }
+        for (int ch = 0; ch < 3; ch++) {
+          // the DCT128/256 tables are large (up to 64K weights per channel): computed once per process and spec
+          struct Big { QuantTableSpec spec; int kind, ch; std::vector<float> t; };
+          static std::mutex mu;
+          static std::vector<Big> big;
+          std::vector<float> local;
+          const std::vector<float>* t = &local;
+          if (k >= 13) {
+            std::lock_guard<std::mutex> lock(mu);
+            const Big* found = nullptr;
+            for (const Big& b : big) if (b.kind == k && b.ch == ch && spec_equal(b.spec, p.qspec[k])) { found = &b; break; }
+            if (!found) {
+              if (big.size() >= 48) big.clear();
+              big.push_back(Big{p.qspec[k], k, ch, {}});
+              ComputeQuantTable(p.qspec[k], k, ch, &big.back().t);
+              found = &big.back();
+            }
+            local = found->t;
+          } else ComputeQuantTable(p.qspec[k], k, ch, &local);
+          qc.off[ch] = arena.Put(t->data(), t->size() * 4);
+        }
         qcache.push_back(qc); hit = (int)qcache.size() - 1;
       }
       for (int ch = 0; ch < 3; ch++) c.qtable[k * 3 + ch] = qcache[hit].off[ch];

@@ -12,7 +12,7 @@
 namespace jxlhip {
 
 __constant__ float d_wc[9][128];       // WcMultipliers<N>[i] = 1 / (2 cos((i + 0.5) pi / N)), row = log2 N
-__constant__ float d_resample[4][8];   // DCTTotalResampleScale<N, 8N>(k), row = log2 N
+__constant__ float d_resample[6][32];  // DCTTotalResampleScale<N, 8N>(k), row = log2 N
 
 __device__ __forceinline__ void SetError(const FrameDev& f, uint32_t e) { atomicOr(f.status, e); }
 
@@ -774,7 +774,6 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
           if (s < 0 || s >= 27 || q < 0 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }
           if ((s >= 14 && s <= 17)) { SetError(f, kErrUnsupported); bad = true; break; }  // AFV
           const uint32_t cx = CoveredX(s), cy = CoveredY(s);
-          if (cx > 8 || cy > 8) { SetError(f, kErrUnsupported); bad = true; break; }      // transforms larger than 64x64
           if (x + cx > gbw || y + cy > gbh || (x % 32) + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
           const unsigned long long bits = ((cx == 64 ? 0ull : (1ull << cx)) - 1ull) << (x & 63);
           for (uint32_t iy = 0; iy < cy; iy++) {
@@ -784,7 +783,10 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
             StS<unsigned long long>(co, wv | bits);
           }
           if (bad) break;
-          if ((x % 8) + cx > 8 || (y % 8) + cy > 8) *f.frame_flags = 1;   // varblock not contained in a 64x64 tile: generic IDCT
+          if (cx > 8 || cy > 8) {
+            // DCT128/256 family: BigIdctKernel; whole 64x64 tiles when aligned, else the frame takes the generic path
+            atomicOr(f.frame_flags, (x % 8) || (y % 8) ? 3u : 2u);
+          } else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) atomicOr(f.frame_flags, 1u);   // varblock not contained in a 64x64 tile: generic IDCT
           const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
           const uint32_t gi = (y / 32) * 8 + (x / 32);
           StG(f.coef_off + o, goff[gi]);
@@ -867,6 +869,7 @@ template <int N> __device__ __forceinline__ void FDct1D(float (&v)[N]) {  // uns
     for (int i = 0; i < H; i++) e[i] = v[i] + v[N - 1 - i];
     FDct1D<H>(e);
     constexpr int L = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+    static_assert(N <= 32, "FDct1D: LLF blocks are at most 32 wide");
 #pragma unroll
     for (int i = 0; i < H; i++) o[i] = (v[i] - v[N - 1 - i]) * d_wc[L][i];
     FDct1D<H>(o);
@@ -902,6 +905,7 @@ __global__ void LlfSigmaKernel(const FrameDev* __restrict__ frames) {
   if (!BI_First(info)) return;
   const uint32_t s = BI_Strategy(info);
   const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
+  if (cx > 8 || cy > 8) return;                       // BigIdctKernel derives the LLF of DCT128/256 varblocks itself
   if (cx == 1 && cy == 1) { for (int c = 0; c < 3; c++) f.llf[c][o] = f.lf_tmp[c][o]; return; }
   const float sr = 1.0f / (float)cy, sc = 1.0f / (float)cx;
   const int lx = Log2Small(cx), ly = Log2Small(cy);
@@ -1408,10 +1412,11 @@ __device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t
 }
 
 __device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || s == 12 || s == 13; }
+__device__ __forceinline__ bool IsBig(uint32_t s) { return s >= 21; }   // DCT128x128 ... DCT128x256: larger than a 64x64 tile
 
 __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ frames, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || (*f.frame_flags == 0 && !force_generic)) return;   // regular frames take IdctTileKernel
+  if (f.is_modular || ((*f.frame_flags & 1) == 0 && !force_generic)) return;   // regular frames take IdctTileKernel
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
@@ -1426,6 +1431,7 @@ __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ f
     const uint32_t info = f.blk_info[o];
     if (BI_Ix(info) != 0) continue;                    // rows are owned by the first block column of the varblock
     const uint32_t s = BI_Strategy(info);
+    if (IsBig(s)) continue;                            // BigIdctKernel
     const uint32_t iy = BI_Iy(info);
     const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
     const size_t o_first = o - (size_t)iy * f.bw;      // top-left block of the varblock
@@ -1471,7 +1477,7 @@ __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ f
     const uint32_t info = f.blk_info[o];
     if (BI_Iy(info) != 0) continue;                    // columns are owned by the first block row of the varblock
     const uint32_t s = BI_Strategy(info);
-    if (IsSpecial(s)) continue;
+    if (IsSpecial(s) || IsBig(s)) continue;
     const int R = (int)CoveredY(s) * 8;
     for (int c = 0; c < 3; c++) {
       float* col0 = f.plane_a[c] + (size_t)(by0 + by) * 8 * stride + (size_t)(bx0 + bx) * 8 + xx;
@@ -1481,6 +1487,139 @@ __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ f
         case 32: ColPass<32>(col0, stride); break;
         default: ColPass<64>(col0, stride); break;
       }
+    }
+  }
+}
+
+// ---- DCT128 / DCT256 family (strategies 21..26): one workgroup per 256x256 group walks its big varblocks.  The 1-D
+// transforms are too long for registers, so each wavefront runs one transform level-parallel in LDS: the recursion of
+// IDct1D (even/odd split, adjacent-add of the odd half, half-size transforms, butterflies) is unrolled into log2 N
+// split levels and log2 N merge levels that each touch all N elements at once — the same floating-point operations in
+// the same order per element as the recursive form, hence bit-identical to it.
+constexpr uint32_t kBigWaveFloats = 2 * 256;                  // ping-pong buffers of one wavefront
+constexpr uint32_t kBigLlfFloats = 3 * 32 * 32;               // LLF of the current varblock, 3 channels
+constexpr uint32_t kBigLds = (kBigLlfFloats + 4 * kBigWaveFloats) * 4;
+
+__device__ __forceinline__ float* WaveIdctLevels(float* a, float* b, int N, int lane) {
+  float* src = a; float* dst = b;
+  for (int n = N; n >= 4; n >>= 1) {              // split levels
+    const int H = n >> 1;
+    for (int j = lane; j < N; j += 64) {
+      const int base = j & ~(n - 1), r = j & (n - 1);
+      float val;
+      if (r < H) val = src[base + 2 * r];
+      else { const int i = r - H; const float o = src[base + 2 * i + 1]; val = i > 0 ? o + src[base + 2 * i - 1] : o * 1.41421356237309504880f; }
+      dst[j] = val;
+    }
+    WaveSync();
+    float* t = src; src = dst; dst = t;
+  }
+  for (int j = lane; j < N; j += 64) {            // N = 2 leaves
+    const float p = src[j & ~1], q = src[j | 1];
+    dst[j] = (j & 1) ? p - q : p + q;
+  }
+  WaveSync();
+  { float* t = src; src = dst; dst = t; }
+  int L = 2;
+  for (int n = 4; n <= N; n <<= 1, L++) {         // merge levels
+    const int H = n >> 1;
+    for (int j = lane; j < N; j += 64) {
+      const int base = j & ~(n - 1), r = j & (n - 1);
+      const int i = r < H ? r : n - 1 - r;
+      const float e = src[base + i], o = src[base + H + i], mul = d_wc[L][i];
+      dst[j] = r < H ? fmaf(mul, o, e) : fmaf(-mul, o, e);
+    }
+    WaveSync();
+    float* t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
+__device__ void FDctDynBig(float* v, int n) {  // n in {1,2,4,8,16,32}; in-register transforms of the small LLF block
+  if (n == 2) { float t[2]; for (int i = 0; i < 2; i++) t[i] = v[i]; FDct1D<2>(t); for (int i = 0; i < 2; i++) v[i] = t[i]; }
+  else if (n == 4) { float t[4]; for (int i = 0; i < 4; i++) t[i] = v[i]; FDct1D<4>(t); for (int i = 0; i < 4; i++) v[i] = t[i]; }
+  else if (n == 8) { float t[8]; for (int i = 0; i < 8; i++) t[i] = v[i]; FDct1D<8>(t); for (int i = 0; i < 8; i++) v[i] = t[i]; }
+  else if (n == 16) { float t[16]; for (int i = 0; i < 16; i++) t[i] = v[i]; FDct1D<16>(t); for (int i = 0; i < 16; i++) v[i] = t[i]; }
+  else if (n == 32) { float t[32]; for (int i = 0; i < 32; i++) t[i] = v[i]; FDct1D<32>(t); for (int i = 0; i < 32; i++) v[i] = t[i]; }
+}
+__device__ __forceinline__ int Log2Cov(int n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5; }
+
+__global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular || (*f.frame_flags & 2) == 0) return;
+  const uint32_t g = blockIdx.x;
+  if (g >= f.num_groups) return;
+  extern __shared__ __align__(16) float s_big[];
+  float* s_llf = s_big;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wa = s_big + kBigLlfFloats + wave * kBigWaveFloats;
+  float* wbuf = wa + 256;
+  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
+  const size_t stride = f.plane_stride;
+  const uint32_t count = f.vb_count[g];
+  for (uint32_t e = 0; e < count; e++) {
+    const uint2 ent = f.vb_list[(size_t)g * 1024 + e];
+    const uint32_t s = ent.x & 0xFF;
+    if (!IsBig(s)) continue;
+    const uint32_t hf_mul = ((ent.x >> 8) & 0xFF) + 1, bx = gx * 32 + ((ent.x >> 16) & 31), by = gy * 32 + ((ent.x >> 21) & 31);
+    const int cx = (int)CoveredX(s), cy = (int)CoveredY(s), R = cy * 8, C = cx * 8;
+    const size_t o_first = (size_t)by * f.bw + bx;
+    // ---- LLF: scaled forward DCT of the varblock's LF samples (columns, then rows — LlfSigmaKernel's order)
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 3u * cx; t += blockDim.x) {
+      const uint32_t c = t / cx, xx = t % cx;
+      float col[32];
+      for (int yy = 0; yy < cy; yy++) col[yy] = f.lf_tmp[c][o_first + (size_t)yy * f.bw + xx];
+      FDctDynBig(col, cy);
+      const float sr = 1.0f / (float)cy;
+      for (int v = 0; v < cy; v++) s_llf[c * 1024 + v * 32 + xx] = col[v] * sr;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 3u * cy; t += blockDim.x) {
+      const uint32_t c = t / cy, v = t % cy;
+      float row[32];
+      for (int u = 0; u < cx; u++) row[u] = s_llf[c * 1024 + v * 32 + u];
+      FDctDynBig(row, cx);
+      const float sc = 1.0f / (float)cx;
+      const int lx = Log2Cov(cx), ly = Log2Cov(cy);
+      for (int u = 0; u < cx; u++) s_llf[c * 1024 + v * 32 + u] = ((row[u] * sc) * d_resample[ly][v]) * d_resample[lx][u];
+    }
+    __syncthreads();
+    // ---- pass 1: rows — dequant + chroma-from-luma + LLF substitution, horizontal transform, row written to the plane
+    BlockDequant d;
+    const uint32_t kind = QuantKind(s);
+    for (int c = 0; c < 3; c++) { d.q[c] = f.coeff[c] + (size_t)g * 65536 + ent.y; d.table[c] = f.qtable[kind * 3 + c]; }
+    const float sd = f.inv_global_scale / (float)hf_mul;
+    d.sdc[0] = sd * f.x_dm; d.sdc[1] = sd; d.sdc[2] = sd * f.b_dm;
+    for (int i = 0; i < 4; i++) d.bias[i] = f.quant_bias[i];
+    {  // chroma-from-luma factors of the tile holding the varblock's first block (dec_group.cc)
+      const size_t t0 = (size_t)(by / 8) * f.cw + bx / 8;
+      d.kx = f.base_x + (float)f.ytox[t0] * f.color_scale;
+      d.kb = f.base_b + (float)f.ytob[t0] * f.color_scale;
+    }
+    for (uint32_t task = wave; task < 3u * R; task += 4) {
+      const int c = (int)(task / R), v = (int)(task % R);
+      for (int u = (int)lane; u < C; u += 64) {
+        const uint32_t k = R >= C ? (uint32_t)(u * R + v) : (uint32_t)(v * C + u);
+        wa[u] = (v < cy && u < cx) ? s_llf[c * 1024 + v * 32 + u] : DequantCoef(d, c, k);
+      }
+      WaveSync();
+      const float* res = WaveIdctLevels(wa, wbuf, C, (int)lane);
+      float* dst = f.plane_a[c] + ((size_t)by * 8 + v) * stride + (size_t)bx * 8;
+      for (int u = (int)lane; u < C; u += 64) dst[u] = res[u];
+      WaveSync();
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- pass 2: columns in place
+    for (uint32_t task = wave; task < 3u * C; task += 4) {
+      const int c = (int)(task / C), xx = (int)(task % C);
+      float* col0 = f.plane_a[c] + (size_t)by * 8 * stride + (size_t)bx * 8 + xx;
+      for (int v = (int)lane; v < R; v += 64) wa[v] = col0[(size_t)v * stride];
+      WaveSync();
+      const float* res = WaveIdctLevels(wa, wbuf, R, (int)lane);
+      for (int v = (int)lane; v < R; v += 64) col0[(size_t)v * stride] = res[v];
+      WaveSync();
     }
   }
 }
@@ -1519,7 +1658,7 @@ template <int R> __device__ __forceinline__ void TileColPass(float* col0) {
 
 __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || *f.frame_flags != 0 || force_generic) return;
+  if (f.is_modular || (*f.frame_flags & 1) != 0 || force_generic) return;
   const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   if (tx * 8 >= f.bw || ty * 8 >= f.bh) return;
   extern __shared__ __align__(16) float s_tile[];   // 3 * kTilePlane floats
@@ -1539,6 +1678,7 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
     s_info[threadIdx.x] = info; s_coff[threadIdx.x] = coff;
   }
   __syncthreads();
+  if (IsBig(BI_Strategy(s_info[0]))) return;   // aligned DCT128/256 varblocks cover whole tiles: BigIdctKernel owns them
   const int32_t* cq[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
   const float bias0 = f.quant_bias[0], bias1 = f.quant_bias[1], bias2 = f.quant_bias[2], bias3 = f.quant_bias[3];
   // ---- pass 0: stage dequantised coefficients.  Task = (block of the tile, four of its 64 coefficient slots): 16-byte
@@ -2266,9 +2406,9 @@ static bool g_tables_ready = false;
 void InitDeviceTables(void* stream) {
   if (g_tables_ready) return;
   static float wc[9][128];
-  static float rs[4][8];
+  static float rs[6][32];
   for (int l = 1; l <= 8; l++) { const int N = 1 << l; for (int i = 0; i < N / 2; i++) wc[l][i] = (float)(1.0 / (2.0 * cos((i + 0.5) * M_PI / N))); }
-  for (int l = 0; l < 4; l++) { const int N = 1 << l; for (int k = 0; k < N; k++) rs[l][k] = k == 0 ? 1.0f : (float)(sin(k * M_PI / (2.0 * N)) / sin(k * M_PI / (16.0 * N)) / 8.0); }
+  for (int l = 0; l < 6; l++) { const int N = 1 << l; for (int k = 0; k < N; k++) rs[l][k] = k == 0 ? 1.0f : (float)(sin(k * M_PI / (2.0 * N)) / sin(k * M_PI / (16.0 * N)) / 8.0); }
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_wc), wc, sizeof(wc), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_resample), rs, sizeof(rs), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
   (void)hipStreamSynchronize((hipStream_t)stream);
@@ -2319,6 +2459,7 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
   const int tiles_x = DivUp(max_bw, 8), tiles_y = DivUp(max_bh, 8);
   hipLaunchKernelGGL(IdctTileKernel, dim3(tiles_x * tiles_y, nframes), dim3(256), 3 * kTilePlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
   hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
+  hipLaunchKernelGGL(BigIdctKernel, dim3(max_groups, nframes), dim3(256), kBigLds, (hipStream_t)stream, frames);                  // frames with DCT128/256 varblocks only
 }
 void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);

@@ -184,9 +184,9 @@ def test_vardct_golden_streams(jx, name):
     assert ulp_diff(pf, ref) <= 1
 
 
-@pytest.mark.parametrize("s", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20])
+@pytest.mark.parametrize("s", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 22, 23, 24, 25, 26])
 def test_vardct_every_strategy(jx, s):
-    img = S.synthetic_image(7, 256, 128)
+    img = S.synthetic_image(7, 256, 128) if s < 21 else S.synthetic_image(7, 520, 300)   # DCT128/256 need room; 520x300 leaves ragged edges
     data = S.encode_vardct(img, seed=5, strategy_mix=100 + s, epf_iters=1, gab=1)
     check_against_oracle(jx, data, np.float32, 3)
     check_against_oracle(jx, data, np.uint8, 3)
@@ -216,6 +216,23 @@ def test_unaligned_varblocks_and_generic_idct(jx):
     for force in (0, 1):
         b = jx.BatchDecoder(0)
         b.add(regular, "float32", 3)
+        b.set_option("force_generic_idct", force)
+        b.prepare(); b.decode(); b.finish()
+        assert ulp_diff(b.output(0), ref) <= 1
+
+
+@pytest.mark.parametrize("mix", [4, 5])
+def test_dct128_256_family_in_mixed_streams(jx, mix):
+    """north_star's "variable-block IDCT 2x2...256x256": DCT128x128 ... DCT256x256 varblocks mixed with every smaller strategy,
+    tile-aligned (mix 4: wave-per-row LDS transforms next to the tiled kernel) and at arbitrary positions (mix 5: generic path),
+    across several groups and with ragged right/bottom edges; forcing the generic small-block kernel must not change a bit."""
+    img = S.synthetic_image(11, 1100, 800)
+    data = S.encode_vardct(img, seed=5, strategy_mix=mix, epf_iters=2, gab=1)
+    check_against_oracle(jx, data, np.uint8, 3)
+    ref = O.decode(data).pixels("f32", 3).view(np.float32)
+    for force in (0, 1):
+        b = jx.BatchDecoder(0)
+        b.add(data, "float32", 3)
         b.set_option("force_generic_idct", force)
         b.prepare(); b.decode(); b.finish()
         assert ulp_diff(b.output(0), ref) <= 1
@@ -287,6 +304,16 @@ def test_full_size_8k_modular_squeeze(jx):
     meta, px = jx.decoder_builder().decode_with(data, np.uint16)
     assert (meta.width, meta.height, meta.num_color_channels) == (8192, 8192, 1)
     assert np.array_equal(px.reshape(8192, 8192), img[..., 0])
+
+
+def test_full_size_8k_hdr_frame(jx):
+    """BASELINE config 5: 7680x4320 f32 HDR VarDCT (linear, values up to 4.0, intensity_target 1000), EPF 3, <= 1 ULP vs the CPU decode."""
+    lin = ((S.synthetic_image(6, 7680, 4320).astype(np.float32) / 255.0) ** 2.2) * 4.0
+    data = S.encode_vardct(lin, seed=6, strategy_mix=1, epf_iters=3, gab=1, out_bits=32, hdr=1)
+    meta, px = check_against_oracle(jx, data, np.float32, 3)
+    assert (meta.width, meta.height) == (7680, 4320) and abs(meta.intensity_target - 1000.0) < 1e-3
+    err = px.reshape(4320, 7680, 3) - lin
+    assert float(np.sqrt((err.astype(np.float64) ** 2).mean())) < 0.05   # decodes to the source picture (size-independent property)
 
 
 def test_full_size_4k_frame(jx):

@@ -145,7 +145,8 @@ def test_idct_matches_direct_formula():
     """The recursive IDCT of the oracle against the defining sum f(n) = F0 + sqrt2 * sum F_k cos((2n+1) k pi / 2N)."""
     import ctypes as C
     rng = np.random.default_rng(1)
-    for strategy, (R, Cc) in {0: (8, 8), 4: (16, 16), 6: (16, 8), 7: (8, 16), 5: (32, 32), 18: (64, 64)}.items():
+    for strategy, (R, Cc) in {0: (8, 8), 4: (16, 16), 6: (16, 8), 7: (8, 16), 5: (32, 32), 18: (64, 64), 19: (64, 32), 21: (128, 128),
+                              22: (128, 64), 23: (64, 128), 24: (256, 256), 25: (256, 128), 26: (128, 256)}.items():
         sem = rng.standard_normal((R, Cc)).astype(np.float32)
         stored = (sem.T if R >= Cc else sem).reshape(-1).copy()
         out = np.zeros((R, Cc), np.float32)

@@ -75,7 +75,7 @@ struct Params {
   float distance = 1.0f;
   int epf_iters = 1;
   int gab = 1;
-  int strategy_mix = 1;   // 0 DCT8 only, 1 SURVEY mix, 2 + large blocks / exotic small ones
+  int strategy_mix = 1;   // 0 DCT8 only, 1 SURVEY mix, 2 + large blocks / exotic small ones, 3 = 2 unaligned, 4 = 2 + DCT128/256, 5 = 4 unaligned
   int out_bits = 8;       // 8 | 16 | 32 (float, linear, intensity_target 1000 when hdr)
   int hdr = 0;
   int skip_lf_smoothing = 0;
@@ -319,16 +319,21 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   else if (p.strategy_mix >= 2 && p.strategy_mix < 100) cands = {{S_DCT64X64, 0.02f}, {S_DCT64X32, 0.01f}, {S_DCT32X64, 0.01f}, {S_DCT32X32, 0.04f}, {S_DCT32X16, 0.02f}, {S_DCT16X32, 0.02f}, {S_DCT32X8, 0.02f},
                                          {S_DCT8X32, 0.02f}, {S_DCT16X16, 0.08f}, {S_DCT16X8, 0.06f}, {S_DCT8X16, 0.06f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.03f},
                                          {S_DCT2X2, 0.02f}, {S_IDENTITY, 0.02f}};
+  if (p.strategy_mix == 4 || p.strategy_mix == 5) {  // + the DCT128/256 family (5: also at unaligned positions)
+    const std::vector<Cand> big = {{24, 0.15f}, {25, 0.1f}, {26, 0.1f}, {21, 0.1f}, {22, 0.05f}, {23, 0.05f}};
+    cands.insert(cands.begin(), big.begin(), big.end());
+  }
+  const bool unaligned = p.strategy_mix == 3 || p.strategy_mix == 5;
   if (p.strategy_mix >= 100) cands = {{p.strategy_mix - 100, 1.0f}};  // force one strategy wherever it fits
   for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
     if (strat[(size_t)by * bw + bx] >= 0) continue;
     int chosen = S_DCT;
     for (auto& c : cands) {   // largest first; a candidate that fits here is taken with its target area share
       int cx = kCovX[c.s], cy = kCovY[c.s];
-      bool ok = (p.strategy_mix == 3 || ((bx % cx == 0) && (by % cy == 0))) && bx + cx <= bw && by + cy <= bh && (bx % 32) + cx <= 32 && (by % 32) + cy <= 32;
+      bool ok = (unaligned || ((bx % cx == 0) && (by % cy == 0))) && bx + cx <= bw && by + cy <= bh && (bx % 32) + cx <= 32 && (by % 32) + cy <= 32;
       for (int iy = 0; ok && iy < cy; iy++) for (int ix = 0; ix < cx; ix++) if (strat[(size_t)(by + iy) * bw + bx + ix] >= 0) ok = false;
       if (!ok) continue;
-      float q = p.strategy_mix == 3 ? c.prob / (float)(cx * cy) * 2.0f : c.prob;
+      float q = unaligned ? std::max(c.prob / (float)(cx * cy) * 2.0f, cx * cy >= 128 ? 0.002f : 0.0f) : c.prob;
       if (p.strategy_mix >= 100) q = 1.0f;
       if (rng.uniform() < q) { chosen = c.s; break; }
     }
@@ -495,7 +500,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   std::vector<std::vector<Token>> ac_tok(ngroups);
   std::vector<uint32_t> natural[13];
   static const int bucket_rep[13] = {S_DCT, S_IDENTITY, S_DCT16X16, S_DCT32X32, S_DCT16X8, S_DCT32X8, S_DCT32X16, S_DCT64X64, S_DCT64X32, 21, 22, 24, 25};
-  for (int b = 0; b < 9; b++) natural[b] = NaturalOrder(bucket_rep[b]);
+  for (int b = 0; b < 13; b++) natural[b] = NaturalOrder(bucket_rep[b]);
   for (int g = 0; g < ngroups; g++) {
     int gx = g % xg, gy = g / xg, bx0 = gx * 32, by0 = gy * 32;
     int gbw = std::min(32, bw - bx0), gbh = std::min(32, bh - by0);

@@ -267,6 +267,10 @@ inline QuantSpec DefaultSpec(int kind) {
       break;
     case 11: q.mode = 6; B(8, {0.9f * 26629.07f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {0.9f * 9311.32f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {0.9f * 4992.25f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
     case 12: q.mode = 6; B(8, {0.65f * 23629.07f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {0.65f * 8611.32f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {0.65f * 4492.25f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
+    case 13: q.mode = 6; B(8, {1.8f * 23966.17f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {1.8f * 8380.19f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {1.8f * 4493.02f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
+    case 14: q.mode = 6; B(8, {1.3f * 15358.9f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {1.3f * 5597.36f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {1.3f * 2919.96f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
+    case 15: q.mode = 6; B(8, {3.6f * 23966.17f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {3.6f * 8380.19f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {3.6f * 4493.02f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
+    case 16: q.mode = 6; B(8, {2.6f * 15358.9f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {2.6f * 5597.36f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {2.6f * 2919.96f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
     default: q.mode = 0; break;
   }
   return q;
