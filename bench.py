@@ -111,6 +111,8 @@ def main():
         for i in range(B):
             batch.add(streams[i % len(streams)], "uint8", 3, device_ptr=out.data_ptr() + i * frame_bytes)
         batch.set_lane_stride(args.lane_stride_lf, args.lane_stride_hf)
+        if b > 0:
+            batch.share_buffers(batches[0])     # the rest halves run one after the other: one set of coefficient/pixel planes
         batch.prepare(stream)
         outs.append(out); batches.append(batch)
     batch, out = batches[0], outs[0]

@@ -117,6 +117,10 @@ typedef struct {
 
 /* Last error message of the calling thread ("" if none). */
 const char* JxlHipLastError(void);
+/* Lets `batch` use `owner`'s coefficient and pixel planes instead of allocating its own (they are only touched by part 2 of a
+ * decode, so two batches whose part-2 halves run one after the other on one stream can share them: halves device memory of a
+ * double-buffered pipeline).  Call before JxlHipBatchPrepare(batch); owner must be prepared, at least as large, and outlive batch. */
+int JxlHipBatchShareBuffers(JxlHipBatch* batch, JxlHipBatch* owner);
 /* Host-only: parses the signature/container and image header of `data` and writes the ICC profile JxlDecoderGetColorAsICCProfile
  * would return (pass icc_out == NULL to query *icc_size).  Needs no GPU.  Returns 0 on success. */
 int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc_out, size_t* icc_size);

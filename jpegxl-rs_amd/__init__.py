@@ -104,6 +104,7 @@ def libjxl():
             "JxlHipBatchDeviceOutput": (vp, [vp, C.c_int]), "JxlHipBatchCopyOutput": (C.c_int, [vp, C.c_int, vp, sz, vp]),
             "JxlHipBatchTotalPixels": (C.c_uint64, [vp]), "JxlHipBatchCompressedBytes": (C.c_uint64, [vp]),
             "JxlHipBatchStageBytes": (None, [vp, C.POINTER(C.c_uint64 * 6)]), "JxlHipBatchDeviceBytes": (C.c_uint64, [vp]),
+            "JxlHipBatchShareBuffers": (C.c_int, [vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -508,6 +509,11 @@ class BatchDecoder:
 
     def set_option(self, name: str, value: int):
         libjxl().JxlHipBatchSetOption(self._h, name.encode(), int(value))
+
+    def share_buffers(self, owner: "BatchDecoder"):
+        """Use `owner`'s coefficient / pixel planes (call before prepare; see include/jxl_hip.h JxlHipBatchShareBuffers)."""
+        self._chk(libjxl().JxlHipBatchShareBuffers(self._h, owner._h))
+        self._owner = owner   # keep it alive
 
     def prepare(self, stream=None):
         self._chk(libjxl().JxlHipBatchPrepare(self._h, stream))

@@ -60,7 +60,16 @@ Batch::Batch(int device) : device_(device) {
 Batch::~Batch() {
   if (dconst_) (void)hipFree(dconst_);
   if (dwork_) (void)hipFree(dwork_);
+  if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   if (dframes_) (void)hipFree(dframes_);
+}
+
+// The coefficient and pixel planes are only touched by the "rest" half of a decode (HF decode ... write), which a caller
+// that pipelines two batches runs strictly one after the other on one stream: the second batch may therefore use the
+// first one's buffers.  Must be called before Prepare(); `owner` must already be prepared and stay alive.
+void Batch::ShareBigArena(Batch* owner) {
+  if (prepared_) throw ParseError("ShareBigArena after Prepare", false);
+  big_owner_ = owner;
 }
 
 int Batch::AddImage(const uint8_t* data, size_t size) {
@@ -150,6 +159,8 @@ void Batch::Prepare(void* stream_v) {
   InitDeviceTables(stream_v);
   if (dconst_) { (void)hipFree(dconst_); dconst_ = nullptr; }
   if (dwork_) { (void)hipFree(dwork_); dwork_ = nullptr; }
+  if (dbig_ && !big_owner_) (void)hipFree(dbig_);
+  dbig_ = nullptr;
   if (dframes_) { (void)hipFree(dframes_); dframes_ = nullptr; }
   const int n = (int)images_.size();
   hconst_.clear();
@@ -210,9 +221,12 @@ void Batch::Prepare(void* stream_v) {
       fplan_.any_gab |= p.lf.gab != 0; fplan_.max_epf = std::max<int>(fplan_.max_epf, p.lf.epf_iters);
     }
   }
-  // ---- work arena layout
-  size_t w = 0;
+  // ---- work arena layout: `take` = the per-batch arena (everything the LF stage writes, scratch, status, outputs);
+  // `take_big` = coefficient and pixel planes, only touched between HF decode and the write stage (shareable)
+  size_t w = 0, wbig = 0;
   auto take = [&](size_t bytes) { size_t off = Align(w); w = off + bytes; return off; };
+  auto take_big = [&](size_t bytes) { size_t off = Align(wbig); wbig = off + bytes; return off; };
+  const bool need_plane_b = fplan_.any_unfused || cfg.force_unfused_filters;
   struct WorkOffsets {
     size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, vb_list, vb_count, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
         mod_scratch;
@@ -224,13 +238,13 @@ void Batch::Prepare(void* stream_v) {
   status_off_ = take((size_t)n * 4);
   const size_t flags_off = take((size_t)n * 4);
   // coefficient buffers of all frames are contiguous so that one memset clears them
-  coeff_off_ = Align(w);
+  coeff_off_ = Align(wbig);
   for (int i = 0; i < n; i++) {
     const FramePlan& p = images_[i]->plan;
     if (p.modular) continue;
-    for (int c = 0; c < 3; c++) wo[i].coeff[c] = take((size_t)p.num_groups * 65536 * 4);
+    for (int c = 0; c < 3; c++) wo[i].coeff[c] = take_big((size_t)p.num_groups * 65536 * 4);
   }
-  coeff_bytes_ = w - coeff_off_;
+  coeff_bytes_ = wbig - coeff_off_;
   for (int i = 0; i < n; i++) {
     ImageEntry& e = *images_[i];
     const FramePlan& p = e.plan;
@@ -245,7 +259,7 @@ void Batch::Prepare(void* stream_v) {
       const size_t ntile = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8);
       o.ytox = take(ntile); o.ytob = take(ntile);
       const size_t plane = (size_t)p.bw * 8 * p.bh * 8 * 4;
-      for (int c = 0; c < 3; c++) { o.plane_a[c] = take(plane); o.plane_b[c] = take(plane); }
+      for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big(plane); o.plane_b[c] = need_plane_b ? take_big(plane) : (size_t)-1; }
       o.lf_scratch_stride = 16 + 2 * 1024 + 3 * 65536;
       o.lf_scratch = take(o.lf_scratch_stride * 4 * p.num_lf_groups);
       o.wp_scratch_stride = 10 * (256 + 2);
@@ -268,6 +282,15 @@ void Batch::Prepare(void* stream_v) {
   work_size_ = Align(w);
   HIP_CHECK(hipMalloc((void**)&dwork_, work_size_));
   HIP_CHECK(hipMemsetAsync(dwork_, 0, work_size_, stream));
+  big_size_ = Align(wbig);
+  has_plane_b_ = need_plane_b;
+  if (big_owner_) {
+    if (!big_owner_->dbig_ || big_owner_->big_size_ < big_size_) throw ParseError("ShareBigArena: the owner's buffers are missing or smaller than this batch needs", false);
+    dbig_ = big_owner_->dbig_;
+  } else {
+    HIP_CHECK(hipMalloc((void**)&dbig_, std::max<size_t>(big_size_, 256)));
+    HIP_CHECK(hipMemsetAsync(dbig_, 0, std::max<size_t>(big_size_, 256), stream));
+  }
   HIP_CHECK(hipMalloc((void**)&dframes_, sizeof(FrameDev) * std::max(n, 1)));
 
   // ---- single-section VarDCT frames: HfGlobal starts where the device-decoded LfGroup ends.  Pre-run the LF stage
@@ -330,8 +353,8 @@ void Batch::Prepare(void* stream_v) {
       else f.color_mode = p.do_ycbcr ? 2 : 3;
       for (int k = 0; k < 3; k++) {
         f.lfq[k] = (int32_t*)(dwork_ + o.lfq[k]); f.lf[k] = (float*)(dwork_ + o.lf[k]); f.lf_tmp[k] = (float*)(dwork_ + o.lf_tmp[k]);
-        f.llf[k] = (float*)(dwork_ + o.llf[k]); f.coeff[k] = (int32_t*)(dwork_ + o.coeff[k]);
-        f.plane_a[k] = (float*)(dwork_ + o.plane_a[k]); f.plane_b[k] = (float*)(dwork_ + o.plane_b[k]);
+        f.llf[k] = (float*)(dwork_ + o.llf[k]); f.coeff[k] = (int32_t*)(dbig_ + o.coeff[k]);
+        f.plane_a[k] = (float*)(dbig_ + o.plane_a[k]); f.plane_b[k] = o.plane_b[k] == (size_t)-1 ? nullptr : (float*)(dbig_ + o.plane_b[k]);
       }
       f.blk_info = (uint32_t*)(dwork_ + o.blk_info); f.coef_off = (uint32_t*)(dwork_ + o.coef_off);
       f.vb_list = (uint2*)(dwork_ + o.vb_list); f.vb_count = (uint32_t*)(dwork_ + o.vb_count);
@@ -450,9 +473,11 @@ void Batch::Run(void* stream_v) {
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
   if (any_vardct_) {
-    HIP_CHECK(hipMemsetAsync(dwork_ + coeff_off_, 0, coeff_bytes_, stream));
+    CheckFilterBuffers();
     LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
+    // the HF decoder only writes non-zero coefficients
+    HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, stream));
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
@@ -560,6 +585,11 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
   ops.push_back(op);
 }
 
+void Batch::CheckFilterBuffers() const {
+  if ((fplan_.any_unfused || cfg.force_unfused_filters) && !has_plane_b_)
+    throw ParseError("force_unfused_filters must be set before Prepare (the second pixel plane is only allocated when a frame needs it)", false);
+}
+
 void Batch::RunTimed(void* stream_v) { RunPart(stream_v, 0, true); }
 
 // part 0 = whole decode, 1 = front (coefficient clear + LF decode + LF post-processing), 2 = rest (HF decode, IDCT,
@@ -570,6 +600,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
   if (!any_vardct_) { if (part != 1) Run(stream_v); return; }
+  CheckFilterBuffers();
   std::vector<void*>* evs = nullptr;
   if (timed) {
     if (part != 2) { timed_events_.emplace_back(8, nullptr); }
@@ -583,13 +614,15 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   };
   if (part != 2) {
     rec(0);
-    HIP_CHECK(hipMemsetAsync(dwork_ + coeff_off_, 0, coeff_bytes_, stream));
     LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     rec(1);
     LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
     if (part == 1) rec(2);
   }
   if (part != 1) {
+    // the HF decoder only writes non-zero coefficients: clear the planes first (outside the per-stage brackets when the
+    // halves are timed separately; the planes may be shared with another batch, so this belongs to the rest half)
+    HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, stream));
     rec(part == 2 ? 7 : 2);
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     rec(3);

@@ -63,7 +63,8 @@ class Batch {
   void StageBytes(uint64_t out[6]) const;
   LaunchCfg cfg;
   size_t const_bytes() const { return const_size_; }
-  size_t work_bytes() const { return work_size_; }
+  size_t work_bytes() const { return work_size_ + (big_owner_ ? 0 : big_size_); }
+  void ShareBigArena(Batch* owner);
   uint64_t total_pixels() const;
   uint64_t compressed_bytes() const;
 
@@ -77,6 +78,10 @@ class Batch {
   std::vector<uint8_t> hconst_;
   uint8_t* dconst_ = nullptr; size_t const_size_ = 0;
   uint8_t* dwork_ = nullptr; size_t work_size_ = 0;
+  uint8_t* dbig_ = nullptr; size_t big_size_ = 0;   // coefficient + pixel planes (rest half only); may alias big_owner_'s
+  Batch* big_owner_ = nullptr;
+  bool has_plane_b_ = false;
+  void CheckFilterBuffers() const;
   FrameDev* dframes_ = nullptr;
   size_t coeff_off_ = 0, coeff_bytes_ = 0, status_off_ = 0, modplane_off_ = 0, modplane_bytes_ = 0;
   bool prepared_ = false;

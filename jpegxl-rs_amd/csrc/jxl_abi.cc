@@ -302,6 +302,9 @@ uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* h) { return h->b->total_pixel
 uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* h) { return h->b->compressed_bytes(); }
 void JxlHipBatchStageBytes(const JxlHipBatch* h, uint64_t out[6]) { h->b->StageBytes(out); }
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* h) { return h->b->const_bytes() + h->b->work_bytes(); }
+int JxlHipBatchShareBuffers(JxlHipBatch* h, JxlHipBatch* owner) {
+  try { h->b->ShareBigArena(owner ? owner->b : nullptr); return 0; } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
+}
 
 int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc_out, size_t* icc_size) {
   try {

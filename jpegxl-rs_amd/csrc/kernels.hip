@@ -155,14 +155,17 @@ struct FastCode {
   uint32_t cfg_uniform;                       // the hybrid-uint config shared by every cluster, or 0xFFFFFFFF
   __device__ __forceinline__ uint32_t Cluster(uint32_t ctx) const { return ctx_map_off != kNotInLds ? LdS<uint8_t>(ctx_map_off + ctx) : LdG(ctx_map_g + ctx); }
   __device__ __forceinline__ uint32_t Cfg(uint32_t cl) const { return cfg_off != kNotInLds ? LdS<uint32_t>(cfg_off + cl * 4) : LdG(cfg_g + cl); }
-  __device__ __forceinline__ uint64_t Alias(uint32_t i) const { return alias_off != kNotInLds ? LdS<uint64_t>(alias_off + i * 8) : LdG(alias_g + i); }
+  __device__ __forceinline__ uint64_t Alias(uint32_t cluster, uint32_t slot) const {
+    if (alias_off == kNotInLds) return LdG(alias_g + (cluster << log_alpha) + slot);
+    return LdS<uint64_t>(alias_off + (((cluster << log_alpha) + slot) << 3));
+  }
 };
 
 __device__ __forceinline__ uint32_t FastSymbol(BitReaderP& br, uint32_t& state, const FastCode& c, uint32_t cluster) {
   const uint32_t la = c.log_alpha;
   const uint32_t res = state & 0xFFF;
   const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
-  const uint64_t e = c.Alias((cluster << la) + i);
+  const uint64_t e = c.Alias(cluster, i);
   const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
   const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
   const bool hit = pos >= cutoff;
@@ -241,31 +244,6 @@ struct BitReaderW {      // reads 32-bit words from an LDS window at win_off hol
   }
   __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)wpos * 32 - (uint64_t)avail; }
 };
-__device__ __forceinline__ uint32_t HybridLds(BitReaderW& br, uint32_t& state, uint32_t cfg_off, uint32_t alias_off, uint32_t la, uint32_t cluster) {
-  const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
-  const uint32_t res = state & 0xFFF;
-  const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
-  const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
-  const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
-  const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
-  const bool hit = pos >= cutoff;
-  uint32_t tok = hit ? right : i;
-  const uint32_t off = hit ? offs1 + pos : pos;
-  const uint32_t freq = hit ? freq1 : freq0;
-  state = freq * (state >> 12) + off;
-  if (state < (1u << 16)) state = (state << 16) | br.Read(16);
-  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
-  const uint32_t split = 1u << split_exp;
-  if (tok < split) return tok;
-  uint32_t nbits = split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb));
-  nbits &= 31;
-  const uint32_t low = tok & ((1u << lsb) - 1);
-  tok >>= lsb;
-  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
-  const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
-  return (((hi << nbits) | bits) << lsb) | low;
-}
-
 // Cooperative copy of an entropy code into LDS (all threads of the block) starting at byte offset `base`; tables
 // that do not fit in [base, base + budget) stay in global memory.  Returns the bytes used.
 __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget, bool with_ctx_map) {
@@ -383,9 +361,14 @@ __device__ __forceinline__ int32_t Predict(uint32_t predictor, int32_t W, int32_
 //   ROWMODE 0: first row (N = NW = W), 1: previous row needed (read from LDS, next value prefetched), 2: W-only rows
 //   PROP9: context from W+N-NW through the LUT (else one cluster per row);  UPRED: 0 zero, 1 W, 5 clamped gradient
 struct ChunkState { BitReaderW bw; uint32_t state; int32_t left, nw; };
-template <int ROWMODE, bool PROP9, int UPRED>
+__device__ __forceinline__ uint32_t Uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <int ROWMODE, bool PROP9, int UPRED, bool UCFG>
 __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, uint32_t prev, uint32_t obase, uint32_t lut_off, uint32_t first_off, uint32_t cl_row,
                                                uint32_t cfg_off, uint32_t cfg_uniform, uint32_t alias_off, uint32_t la) {
+  // loop invariants into scalar registers (they come out of LDS-resident tables, i.e. vector registers)
+  prev = Uniform(prev); obase = Uniform(obase); lut_off = Uniform(lut_off); first_off = Uniform(first_off); cl_row = Uniform(cl_row);
+  cfg_off = Uniform(cfg_off); cfg_uniform = Uniform(cfg_uniform); alias_off = Uniform(alias_off); la = Uniform(la);
+  x0 = (int)Uniform((uint32_t)x0); x1 = (int)Uniform((uint32_t)x1);
   BitReaderW bw = st.bw;
   uint32_t state = st.state;
   int32_t left = st.left, nw = st.nw;
@@ -412,7 +395,7 @@ __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, u
     const uint32_t res = state & 0xFFF;
     const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
     const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
-    const uint32_t cfg = cfg_uniform != 0xFFFFFFFFu ? cfg_uniform : LdS<uint32_t>(cfg_off + cluster * 4);
+    const uint32_t cfg = UCFG ? cfg_uniform : LdS<uint32_t>(cfg_off + cluster * 4);
     const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
     const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
     const bool hit = pos >= cutoff;
@@ -528,24 +511,33 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
             bw.Refill(); bw.buf >>= skip_bits; bw.avail -= (int)skip_bits;
             skip_bits = 0xFFFFFFFFu;
           }
+        }
+        {
           const int x1 = min(w, x0 + 256);
           const uint32_t obase = row_in_lds ? cur : wb + kChunkOff - (uint32_t)x0 * 4;
           ChunkState st;
           st.bw = bw; st.state = state; st.left = left; st.nw = nw;
           const uint32_t lut_off = wb + kLutOff, first_off = wb + kWorkOff + 24;
-#define JXL_CHUNK(RM, P9, UP) DecodeChunkLds<RM, P9, UP>(st, x0, x1, prev, obase, lut_off, first_off, cl_row, cfg_off, cfg_uniform, alias_off, la)
           const int rm = y == 0 ? 0 : (need_n ? 1 : 2);
-          if (prop == 9) {
-            if (upred == 5) { if (rm == 0) JXL_CHUNK(0, true, 5); else JXL_CHUNK(1, true, 5); }
-            else if (upred == 1) { if (rm == 0) JXL_CHUNK(0, true, 1); else JXL_CHUNK(1, true, 1); }
-            else { if (rm == 0) JXL_CHUNK(0, true, 0); else JXL_CHUNK(1, true, 0); }
-          } else {
-            if (upred == 5) { if (rm == 0) JXL_CHUNK(0, false, 5); else JXL_CHUNK(1, false, 5); }
-            else if (upred == 1) { if (rm == 0) JXL_CHUNK(0, false, 1); else JXL_CHUNK(2, false, 1); }
-            else { if (rm == 0) JXL_CHUNK(0, false, 0); else JXL_CHUNK(2, false, 0); }
+#define JXL_CHUNK_ARGS st, x0, x1, prev, obase, lut_off, first_off, cl_row, cfg_off, cfg_uniform, alias_off, la
+#define JXL_DISPATCH                                                                              \
+          if (prop == 9) {                                                                        \
+            if (upred == 5) { if (rm == 0) JXL_CHUNK(0, true, 5); else JXL_CHUNK(1, true, 5); }   \
+            else if (upred == 1) { if (rm == 0) JXL_CHUNK(0, true, 1); else JXL_CHUNK(1, true, 1); } \
+            else { if (rm == 0) JXL_CHUNK(0, true, 0); else JXL_CHUNK(1, true, 0); }              \
+          } else {                                                                                \
+            if (upred == 5) { if (rm == 0) JXL_CHUNK(0, false, 5); else JXL_CHUNK(1, false, 5); } \
+            else if (upred == 1) { if (rm == 0) JXL_CHUNK(0, false, 1); else JXL_CHUNK(2, false, 1); } \
+            else { if (rm == 0) JXL_CHUNK(0, false, 0); else JXL_CHUNK(2, false, 0); }            \
           }
+          if (lane == 0) {
+#define JXL_CHUNK(RM, P9, UP) do { if (cfg_uniform != 0xFFFFFFFFu) DecodeChunkLds<RM, P9, UP, true>(JXL_CHUNK_ARGS); else DecodeChunkLds<RM, P9, UP, false>(JXL_CHUNK_ARGS); } while (0)
+            JXL_DISPATCH
 #undef JXL_CHUNK
-          bw = st.bw; state = st.state; left = st.left; nw = st.nw;
+            bw = st.bw; state = st.state; left = st.left; nw = st.nw;
+          }
+#undef JXL_DISPATCH
+#undef JXL_CHUNK_ARGS
         }
         WaveSync();
         if (!row_in_lds) {
@@ -1081,7 +1073,7 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   const uint32_t cfg = ALL_LDS ? LdS<uint32_t>(c.cfg_off + cluster * 4) : c.Cfg(cluster);
   const uint32_t res = state & 0xFFF;
   const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
-  const uint64_t e = ALL_LDS ? LdS<uint64_t>(c.alias_off + (((cluster << la) + i) << 3)) : c.Alias((cluster << la) + i);
+  const uint64_t e = ALL_LDS ? LdS<uint64_t>(c.alias_off + (((cluster << la) + i) << 3)) : c.Alias(cluster, i);
   const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
   const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
   const bool hit = pos >= cutoff;
