@@ -88,7 +88,6 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
     const bool linear = !e->ih.color_default && !e->ih.have_gamma && e->ih.tf == 8;
     if (!srgb && !linear) throw ParseError("unsupported: output transfer function", true);
   }
-  if (e->ih.orientation != 1) throw ParseError("unsupported: orientation", true);
   images_.push_back(std::move(e));
   prepared_ = false;
   return (int)images_.size() - 1;
@@ -101,16 +100,19 @@ size_t Batch::OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t*
   if (nc == 0) nc = (ih.color_space == 1 ? 1 : 3) + (alpha ? 1 : 0);
   if (channels) *channels = nc;
   const size_t bps = o.type == 0 ? 1 : o.type == 2 ? 4 : 2;
-  size_t stride = (size_t)ih.xsize * nc * bps;
+  size_t stride = (size_t)OrientedWidth(ih, o) * nc * bps;
   if (o.align > 1) stride = (stride + o.align - 1) / o.align * o.align;
   return stride;
 }
+// Orientations 5..8 transpose the image (codestream_header.rs JxlOrientation); applied unless the caller keeps it.
+uint32_t Batch::OrientedWidth(const ImageHeader& ih, const OutputSpec& o) { return (!o.keep_orientation && ih.orientation > 4) ? ih.ysize : ih.xsize; }
+uint32_t Batch::OrientedHeight(const ImageHeader& ih, const OutputSpec& o) { return (!o.keep_orientation && ih.orientation > 4) ? ih.xsize : ih.ysize; }
 size_t Batch::OutputSize(const ImageHeader& ih, const OutputSpec& o) {
   // jpegxl-sys decode.rs:1100 JxlDecoderImageOutBufferSize: stride * (h - 1) + w * C * bytes
   uint32_t nc;
   const size_t stride = OutputStride(ih, o, &nc);
   const size_t bps = o.type == 0 ? 1 : o.type == 2 ? 4 : 2;
-  return stride * (ih.ysize - 1) + (size_t)ih.xsize * nc * bps;
+  return stride * (OrientedHeight(ih, o) - 1) + (size_t)OrientedWidth(ih, o) * nc * bps;
 }
 void Batch::SetOutput(int i, const OutputSpec& o) {
   ImageEntry& e = *images_[i];
@@ -322,6 +324,7 @@ void Batch::Prepare(void* stream_v) {
     f.frame_flags = (uint32_t*)(dwork_ + flags_off) + i;
     f.out = (uint8_t*)(e.out.device_ptr ? e.out.device_ptr : dwork_ + e.off_out);
     f.out_stride = e.out_stride; f.out_channels = e.out.num_channels; f.out_type = e.out.type; f.out_big_endian = e.out.big_endian;
+    f.out_orient = e.out.keep_orientation ? 1 : e.ih.orientation;
     f.is_gray = e.ih.color_space == 1;
     f.wp_scratch = (int32_t*)(dwork_ + o.wp_scratch); f.wp_scratch_stride = o.wp_scratch_stride;
     if (!p.modular) {

@@ -17,6 +17,7 @@ struct OutputSpec {
   uint32_t big_endian = 0;
   size_t align = 0;
   void* device_ptr = nullptr;  // optional caller-owned device destination
+  bool keep_orientation = false;  // false: the header's orientation is applied to the output (libjxl's default)
 };
 
 struct ImageEntry {
@@ -43,6 +44,8 @@ class Batch {
   size_t size() const { return images_.size(); }
   ImageEntry& image(int i) { return *images_[i]; }
   static size_t OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t* channels);
+  static uint32_t OrientedWidth(const ImageHeader& ih, const OutputSpec& o);
+  static uint32_t OrientedHeight(const ImageHeader& ih, const OutputSpec& o);
   static size_t OutputSize(const ImageHeader& ih, const OutputSpec& o);
   void SetOutput(int i, const OutputSpec& o);
   // Allocates device memory, uploads streams + tables (inputs become HBM-resident).  stream: hipStream_t.

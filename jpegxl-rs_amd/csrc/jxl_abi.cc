@@ -106,22 +106,24 @@ JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t s
 }
 void JxlDecoderCloseInput(JxlDecoder* d) { d->input_closed = true; }
 
-static void FillBasicInfo(const ImageHeader& ih, JxlBasicInfo* info) {
+static void FillBasicInfo(const ImageHeader& ih, JxlBasicInfo* info, bool keep_orientation) {
   memset(info, 0, sizeof(*info));
   info->have_container = ih.have_container;
-  info->xsize = ih.xsize; info->ysize = ih.ysize;
+  // the orientation is applied by the write stage unless the caller keeps it: report the dimensions of what comes out
+  const bool transposed = !keep_orientation && ih.orientation > 4;
+  info->xsize = transposed ? ih.ysize : ih.xsize; info->ysize = transposed ? ih.xsize : ih.ysize;
   info->bits_per_sample = ih.depth.bits; info->exponent_bits_per_sample = ih.depth.exp_bits;
   info->intensity_target = ih.intensity_target; info->min_nits = ih.min_nits;
   info->relative_to_max_display = ih.relative_to_max_display; info->linear_below = ih.linear_below;
   info->uses_original_profile = !ih.xyb_encoded;
   info->have_preview = ih.have_preview; info->have_animation = ih.have_animation;
-  info->orientation = (int32_t)ih.orientation;
+  info->orientation = keep_orientation ? (int32_t)ih.orientation : 1;
   info->num_color_channels = ih.color_space == 1 ? 1 : 3;
   info->num_extra_channels = (uint32_t)ih.extra.size();
   for (auto& e : ih.extra) if (e.type == 0) { info->alpha_bits = e.depth.bits; info->alpha_exponent_bits = e.depth.exp_bits; info->alpha_premultiplied = e.alpha_associated; break; }
   info->animation.tps_numerator = ih.tps_num; info->animation.tps_denominator = ih.tps_den; info->animation.num_loops = ih.num_loops;
   info->animation.have_timecodes = ih.have_timecodes;
-  info->intrinsic_xsize = ih.intrinsic_x ? ih.intrinsic_x : ih.xsize; info->intrinsic_ysize = ih.intrinsic_y ? ih.intrinsic_y : ih.ysize;
+  info->intrinsic_xsize = ih.intrinsic_x ? ih.intrinsic_x : info->xsize; info->intrinsic_ysize = ih.intrinsic_y ? ih.intrinsic_y : info->ysize;
 }
 
 static bool FormatToSpec(const JxlPixelFormat* f, OutputSpec* o) {
@@ -141,13 +143,14 @@ static bool FormatToSpec(const JxlPixelFormat* f, OutputSpec* o) {
 
 JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* d, JxlBasicInfo* info) {
   if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_NEED_MORE_INPUT;
-  if (info) FillBasicInfo(d->batch->image(0).ih, info);
+  if (info) FillBasicInfo(d->batch->image(0).ih, info, d->keep_orientation);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* format, size_t* size) {
   if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_NEED_MORE_INPUT;
   OutputSpec o;
   if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  o.keep_orientation = d->keep_orientation;
   *size = Batch::OutputSize(d->batch->image(0).ih, o);
   return JXL_DEC_SUCCESS;
 }
@@ -155,6 +158,7 @@ JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat
   if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_ERROR;
   OutputSpec o;
   if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  o.keep_orientation = d->keep_orientation;
   if (size < Batch::OutputSize(d->batch->image(0).ih, o)) return JXL_DEC_ERROR;
   d->out_buffer = buffer; d->out_size = size; d->out_format = *format; d->out_set = true;
   return JXL_DEC_SUCCESS;
@@ -218,6 +222,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       if (!d->out_set) return JXL_DEC_NEED_IMAGE_OUT_BUFFER;
       OutputSpec o;
       FormatToSpec(&d->out_format, &o);
+      o.keep_orientation = d->keep_orientation;
       d->batch->SetOutput(0, o);
       d->batch->Prepare(nullptr);
       d->batch->Run(nullptr);       // ══► the HIP hot path
@@ -239,7 +244,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
 }
 
 // ---- batch extension ---------------------------------------------------------------------------------------------------
-struct JxlHipBatchStruct { Batch* b; };
+struct JxlHipBatchStruct { Batch* b; bool keep_orientation = false; };
 
 JxlHipBatch* JxlHipBatchCreate(int device) {
   try {
@@ -256,12 +261,13 @@ int JxlHipBatchAddImage(JxlHipBatch* h, const uint8_t* data, size_t size) {
 }
 JxlDecoderStatus JxlHipBatchGetBasicInfo(const JxlHipBatch* h, int i, JxlBasicInfo* info) {
   if (i < 0 || (size_t)i >= h->b->size()) return JXL_DEC_ERROR;
-  FillBasicInfo(h->b->image(i).ih, info);
+  FillBasicInfo(h->b->image(i).ih, info, h->keep_orientation);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlHipBatchOutBufferSize(const JxlHipBatch* h, int i, const JxlPixelFormat* format, size_t* size) {
   OutputSpec o;
   if (i < 0 || (size_t)i >= h->b->size() || !FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  o.keep_orientation = h->keep_orientation;
   *size = Batch::OutputSize(h->b->image(i).ih, o);
   return JXL_DEC_SUCCESS;
 }
@@ -269,6 +275,7 @@ JxlDecoderStatus JxlHipBatchSetOutput(JxlHipBatch* h, int i, const JxlPixelForma
   OutputSpec o;
   if (i < 0 || (size_t)i >= h->b->size() || !FormatToSpec(format, &o)) return JXL_DEC_ERROR;
   o.device_ptr = device_buffer;
+  o.keep_orientation = h->keep_orientation;
   h->b->SetOutput(i, o);
   return JXL_DEC_SUCCESS;
 }
@@ -295,6 +302,7 @@ void JxlHipBatchSetOption(JxlHipBatch* h, const char* name, int value) {
   std::string n(name);
   if (n == "force_generic_idct") h->b->cfg.force_generic_idct = value;
   else if (n == "force_unfused_filters") h->b->cfg.force_unfused_filters = value;
+  else if (n == "keep_orientation") h->keep_orientation = value != 0;   // applies to outputs set afterwards
   else if (n == "hf_block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) h->b->cfg.hf_block_threads = value;
   else if (n == "lds_code_budget" && value >= 0 && value <= 128 * 1024) h->b->cfg.lds_code_budget = value;
 }

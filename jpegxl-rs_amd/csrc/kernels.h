@@ -77,6 +77,7 @@ struct FrameDev {
   uint8_t* out;
   uint64_t out_stride;            // bytes per row
   uint32_t out_channels, out_type /*0 u8 1 u16 2 f32 3 f16*/, out_big_endian;
+  uint32_t out_orient;            // 1..8: orientation applied while writing (1 = none)
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
 };

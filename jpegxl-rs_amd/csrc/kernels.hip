@@ -1921,9 +1921,28 @@ __device__ __forceinline__ void StoreSample(const FrameDev& f, uint8_t* p, float
   }
 }
 
+// Position of image sample (x, y) in the output buffer: the header's orientation (1..8, EXIF numbering as in
+// codestream_header.rs JxlOrientation) is applied by the write stage — 2 flip-h, 3 rotate 180, 4 flip-v, 5 transpose,
+// 6 rotate 90 cw, 7 anti-transpose, 8 rotate 90 ccw; out_stride already refers to the oriented width.
+__device__ __forceinline__ uint8_t* OutPixelPtr(const FrameDev& f, int x, int y, uint32_t bps) {
+  const int w = (int)f.width, h = (int)f.height;
+  int ox = x, oy = y;
+  switch (f.out_orient) {
+    case 2: ox = w - 1 - x; break;
+    case 3: ox = w - 1 - x; oy = h - 1 - y; break;
+    case 4: oy = h - 1 - y; break;
+    case 5: ox = y; oy = x; break;
+    case 6: ox = h - 1 - y; oy = x; break;
+    case 7: ox = h - 1 - y; oy = w - 1 - x; break;
+    case 8: ox = y; oy = w - 1 - x; break;
+    default: break;
+  }
+  return f.out + (size_t)oy * f.out_stride + (size_t)ox * f.out_channels * bps;
+}
+
 __device__ __forceinline__ void StorePixel(const FrameDev& f, int x, int y, float r, float g, float b, float a) {
   const uint32_t bps = f.out_type == 0 ? 1 : f.out_type == 2 ? 4 : 2;
-  uint8_t* p = f.out + (size_t)y * f.out_stride + (size_t)x * f.out_channels * bps;
+  uint8_t* p = OutPixelPtr(f, x, y, bps);
   const uint32_t nc = f.out_channels;
   if (nc <= 2) {
     StoreSample(f, p, f.is_gray ? r : g);  // gray images carry the same value in all channels; otherwise take G
@@ -2382,7 +2401,7 @@ __global__ void ModularOutputKernel(const FrameDev* __restrict__ frames, int fid
   const float al = a.alpha ? (float)a.alpha[o] * a.alpha_factor : 1.0f;
   // StorePixel picks r for gray output of gray images and g otherwise
   const uint32_t bps = f.out_type == 0 ? 1 : f.out_type == 2 ? 4 : 2;
-  uint8_t* p = f.out + (size_t)y * f.out_stride + (size_t)x * f.out_channels * bps;
+  uint8_t* p = OutPixelPtr(f, x, y, bps);
   const uint32_t nc = f.out_channels;
   if (nc <= 2) { StoreSample(f, p, a.ncolor == 1 ? r : g); if (nc == 2) StoreSample(f, p + bps, al); }
   else { StoreSample(f, p, r); StoreSample(f, p + bps, g); StoreSample(f, p + 2 * bps, b); if (nc == 4) StoreSample(f, p + 3 * bps, al); }

@@ -306,6 +306,35 @@ def test_full_size_8k_modular_squeeze(jx):
     assert np.array_equal(px.reshape(8192, 8192), img[..., 0])
 
 
+def _orient(a, o):
+    """EXIF-style orientation o applied to an (h, w, c) array (codestream_header.rs JxlOrientation)."""
+    return {1: lambda v: v, 2: lambda v: v[:, ::-1], 3: lambda v: v[::-1, ::-1], 4: lambda v: v[::-1], 5: lambda v: v.transpose(1, 0, 2),
+            6: lambda v: v.transpose(1, 0, 2)[:, ::-1], 7: lambda v: v[::-1, ::-1].transpose(1, 0, 2), 8: lambda v: v.transpose(1, 0, 2)[::-1]}[o](a)
+
+
+@pytest.mark.parametrize("o", [2, 3, 4, 5, 6, 7, 8])
+def test_orientation_is_applied_by_the_write_stage(jx, o):
+    """JxlBasicInfo.orientation / skip_reorientation (decode.rs:340-346): by default the decoder hands out the oriented image
+    (dimensions swapped for 5..8, orientation reported as 1); with skip_reorientation the stored raster and the header value."""
+    img = S.synthetic_image(40 + o, 200, 136)
+    data = S.encode_vardct(img, seed=3, strategy_mix=2, epf_iters=1, gab=1, orientation=o)
+    stored = O.decode(data).pixels("u8", 3).reshape(136, 200, 3)
+    meta, px = jx.decoder_builder().decode_with(data, np.uint8)
+    want = _orient(stored, o)
+    assert (meta.height, meta.width) == want.shape[:2] and meta.orientation == 1
+    assert np.array_equal(px.reshape(want.shape), want)
+    meta, px = jx.decoder_builder(skip_reorientation=True).decode_with(data, np.uint8)
+    assert (meta.width, meta.height, meta.orientation) == (200, 136, o)
+    assert np.array_equal(px.reshape(136, 200, 3), stored)
+    # float output with row alignment goes through the unfused write kernel
+    _, pf = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3, align=64)).decode_with(data, np.float32)
+    ref = O.decode(data).pixels("f32", 3).view(np.float32).reshape(136, 200, 3)
+    wantf = _orient(ref, o)
+    stride = (wantf.shape[1] * 12 + 63) // 64 * 64 // 4
+    rows = np.stack([pf[r * stride: r * stride + wantf.shape[1] * 3] for r in range(wantf.shape[0])]).reshape(wantf.shape)
+    assert ulp_diff(rows, wantf) <= 1
+
+
 def test_full_size_8k_hdr_frame(jx):
     """BASELINE config 5: 7680x4320 f32 HDR VarDCT (linear, values up to 4.0, intensity_target 1000), EPF 3, <= 1 ULP vs the CPU decode."""
     lin = ((S.synthetic_image(6, 7680, 4320).astype(np.float32) / 255.0) ** 2.2) * 4.0

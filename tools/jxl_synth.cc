@@ -80,7 +80,8 @@ struct Params {
   int hdr = 0;
   int skip_lf_smoothing = 0;
   int custom_orders = 0;  // reserved
-  int reserved[8] = {0};
+  int orientation = 1;    // EXIF-style 1..8, written to the image header
+  int reserved[7] = {0};
 };
 
 // ---- modular sub-stream tokenisation with the fixed global tree --------------------------------------------------
@@ -185,13 +186,13 @@ static void WriteSize(BitWriter& w, uint32_t xs, uint32_t ys) {
 static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool xyb, int bits, bool has_alpha, bool gray) {
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
-  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray;
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1;
   w.put(all_default, 1);
   if (!all_default) {
-    bool extra_fields = p.hdr;
+    bool extra_fields = p.hdr || p.orientation != 1;
     w.put(extra_fields, 1);
     if (extra_fields) {
-      w.put(0, 3);  // orientation 1
+      w.put((uint32_t)(p.orientation - 1), 3);
       w.put(0, 1); w.put(0, 1); w.put(0, 1);  // no intrinsic size / preview / animation
     }
     // BitDepth
@@ -224,8 +225,8 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
       WriteU32(w, 1, {0, 0}, {0, 1}, {4, 2}, {6, 18});              // rendering intent relative
     }
     if (extra_fields) {
-      w.put(0, 1);  // tone mapping not default
-      WriteF16(w, 1000.0f); WriteF16(w, 0.0f); w.put(0, 1); WriteF16(w, 0.0f);
+      if (p.hdr) { w.put(0, 1); WriteF16(w, 1000.0f); WriteF16(w, 0.0f); w.put(0, 1); WriteF16(w, 0.0f); }   // tone mapping: intensity_target 1000
+      else w.put(1, 1);                                                                                      // tone mapping all default
     }
     WriteU64(w, 0);  // extensions
   }
@@ -830,7 +831,7 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
 // ---- C API ---------------------------------------------------------------------------------------------------------
 extern "C" {
 struct jxlsynth_params {
-  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders; int32_t reserved[8];
+  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation; int32_t reserved[7];
 };
 static thread_local std::string g_err;
 const char* jxlsynth_last_error() { return g_err.c_str(); }
@@ -849,6 +850,7 @@ int jxlsynth_vardct(const uint8_t* rgb8, const float* rgb_lin, int w, int h, con
     synth::Params p;
     p.seed = pp->seed; p.distance = pp->distance; p.epf_iters = pp->epf_iters; p.gab = pp->gab; p.strategy_mix = pp->strategy_mix;
     p.out_bits = pp->out_bits; p.hdr = pp->hdr; p.skip_lf_smoothing = pp->skip_lf_smoothing;
+    p.orientation = pp->orientation >= 1 && pp->orientation <= 8 ? pp->orientation : 1;
     std::vector<float> pl[3];
     for (auto& v : pl) v.resize((size_t)w * h);
     const float scale = p.hdr ? 255.0f / 1000.0f : 1.0f;  // intensity_target 1000: linear 1.0 == 1000 nits
