@@ -80,7 +80,10 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
   e->ih.have_container = have_container;
   ParseFrameStart(e->cs, e->ih, e->frame_bitpos, &e->plan);
   const FramePlan& p = e->plan;
-  if (!p.modular && !e->ih.extra.empty()) throw ParseError("unsupported: extra channels in a VarDCT frame", true);
+  if (!p.modular) {
+    for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
+    for (auto& x : e->ih.extra) if (x.dim_shift != 0 || x.depth.is_float) throw ParseError("unsupported: subsampled / float extra channel", true);
+  }
   if (p.modular && e->ih.xyb_encoded) throw ParseError("unsupported: XYB Modular frame", true);
   if (p.modular && e->ih.depth.is_float) throw ParseError("unsupported: float Modular samples", true);
   if (!p.modular && e->ih.xyb_encoded) {
@@ -191,7 +194,7 @@ void Batch::Prepare(void* stream_v) {
     return true;
   };
   max_lf_groups_ = max_groups_ = max_w_ = max_h_ = max_bw_ = max_bh_ = max_epf_ = 0;
-  any_gab_ = any_vardct_ = any_modular_ = false;
+  any_gab_ = any_vardct_ = any_modular_ = any_modchan_ = false;
   fplan_ = FilterPlan();
   for (int i = 0; i < n; i++) {
     ImageEntry& e = *images_[i];
@@ -231,12 +234,13 @@ void Batch::Prepare(void* stream_v) {
   const bool need_plane_b = fplan_.any_unfused || cfg.force_unfused_filters;
   struct WorkOffsets {
     size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, vb_list, vb_count, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
-        mod_scratch;
-    size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride;
+        mod_scratch, hf_end = 0, mod_wp = 0;
+    size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0;
   };
   std::vector<WorkOffsets> wo(n);
   mod_plane_offsets_.assign(n, {});
   mod_ops_.assign(n, {});
+  vardct_alpha_.assign(n, VarDctAlpha());
   status_off_ = take((size_t)n * 4);
   const size_t flags_off = take((size_t)n * 4);
   // coefficient buffers of all frames are contiguous so that one memset clears them
@@ -266,7 +270,25 @@ void Batch::Prepare(void* stream_v) {
       o.lf_scratch = take(o.lf_scratch_stride * 4 * p.num_lf_groups);
       o.wp_scratch_stride = 10 * (256 + 2);
       o.wp_scratch = take(o.wp_scratch_stride * 4 * p.num_lf_groups);
+      if (!p.gchannels.empty()) {
+        // extra channels (alpha, ...) ride in the frame's Modular sub-streams: planes, channel table, undo plan
+        any_modchan_ = true;
+        std::vector<size_t>& mp = mod_plane_offsets_[i];
+        for (auto& ch : p.gchannels) mp.push_back(take((size_t)ch.w * ch.h * 4 + 64));
+        PlanModularUndo(i, take);
+        std::vector<ModChanDev> table;
+        for (size_t k = 0; k < p.gchannels.size(); k++) table.push_back(ModChanDev{mp[k], p.gchannels[k].w, p.gchannels[k].h, p.gchannels[k].hshift, p.gchannels[k].vshift});
+        co[i].mod_chan = arena.Put(table.data(), table.size() * sizeof(ModChanDev));
+        const size_t gd = p.group_dim;
+        o.mod_scratch_stride = (8 + 4) * gd * gd + 4 * 65536;
+        o.mod_scratch = take(o.mod_scratch_stride * 4 * (p.num_lf_groups + p.num_groups));
+        o.hf_end = take((size_t)p.num_groups * 8);
+        // the Modular streams keep their WP state apart from the LF streams'
+        o.mod_wp_stride = p.tree.uses_wp ? 10 * (65536 + 2) : 16;
+        o.mod_wp = take(o.mod_wp_stride * 4 * (1 + p.num_lf_groups + p.num_groups));
+      }
     } else {
+      any_modchan_ = true;
       // planes for every channel of the global image, then the plan that undoes the global transforms
       std::vector<size_t>& mp = mod_plane_offsets_[i];
       for (auto& ch : p.gchannels) mp.push_back(take((size_t)ch.w * ch.h * 4 + 64));
@@ -375,12 +397,21 @@ void Batch::Prepare(void* stream_v) {
         f.hf_start_bitpos = p.end_bitpos;
       }
     } else {
+      f.hf_start_bitpos = 0;
+      f.mod_wp_scratch = f.wp_scratch; f.mod_wp_stride = f.wp_scratch_stride;
+    }
+    if (!p.gchannels.empty()) {
       f.mod_nchan = (uint32_t)p.gchannels.size(); f.mod_nb_meta = p.nb_meta_channels;
       f.mod_chan = (const ModChanDev*)(cbase + c.mod_chan); f.mod_base = dwork_;
       f.mod_global_decodable = p.global_decodable; f.mod_global_bitpos = p.global_data_bitpos;
       f.mod_group_scratch = (int32_t*)(dwork_ + o.mod_scratch); f.mod_group_scratch_stride = o.mod_scratch_stride;
       f.mod_bits = e.ih.depth.bits;
-      f.hf_start_bitpos = 0;
+      if (!p.modular) {
+        f.hf_end_bitpos = (uint64_t*)(dwork_ + o.hf_end);
+        f.mod_wp_scratch = (int32_t*)(dwork_ + o.mod_wp); f.mod_wp_stride = o.mod_wp_stride;
+        f.alpha_plane = vardct_alpha_[i].has ? (const int32_t*)(dwork_ + vardct_alpha_[i].off) : nullptr;
+        f.alpha_factor = vardct_alpha_[i].factor;
+      }
     }
   };
 
@@ -394,6 +425,7 @@ void Batch::Prepare(void* stream_v) {
     std::vector<FrameDev> tmpf;
     for (int i : single) { fill_frame(i, tmpc); tmpf.push_back(frames_host_[i]); }
     HIP_CHECK(hipMemcpyAsync(dframes_, tmpf.data(), sizeof(FrameDev) * tmpf.size(), hipMemcpyHostToDevice, stream));
+    if (any_modchan_) LaunchModularGlobal(dframes_, (int)tmpf.size(), stream_v);   // extra channels of a one-group frame precede the LfGroup
     LaunchLfDecode(dframes_, (int)tmpf.size(), 1, cfg, stream_v);
     HIP_CHECK(hipStreamSynchronize(stream));
     for (size_t k = 0; k < single.size(); k++) {
@@ -471,47 +503,34 @@ void Batch::Prepare(void* stream_v) {
   prepared_ = true;
 }
 
-void Batch::Run(void* stream_v) {
-  hipStream_t stream = (hipStream_t)stream_v;
-  if (!prepared_) Prepare(stream_v);
+void Batch::Run(void* stream_v) { RunPart(stream_v, 0, false); }
+
+// Everything Modular after the entropy decode of the global stream: the LfGroup / PassGroup sub-streams, then the
+// host-planned inverse transforms (and, for Modular frames, the write stage).
+void Batch::EnqueueModularTail(void* stream_v) {
   const int n = (int)images_.size();
-  if (any_vardct_) {
-    CheckFilterBuffers();
-    LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
-    LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
-    // the HF decoder only writes non-zero coefficients
-    HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, stream));
-    LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
-    LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
-    LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
-    LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
-  }
-  if (any_modular_) {
-    LaunchModularGlobal(dframes_, n, stream_v);
-    LaunchModularGroups(dframes_, n, max_lf_groups_, max_groups_, stream_v);
-    for (int i = 0; i < n; i++) {
-      if (!images_[i]->plan.modular) continue;
-      for (const ModOp& op : mod_ops_[i]) {
-        auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
-        switch (op.kind) {
-          case ModOp::kRct: LaunchModRct(P(op.in[0]), P(op.in[1]), P(op.in[2]), op.n, op.param, stream_v); break;
-          case ModOp::kPalette: {
-            int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
-            for (uint32_t c = 0; c < op.num_c; c++) outs[c] = P(op.out[c]);
-            LaunchModPalette(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.n, stream_v);
-            break;
-          }
-          case ModOp::kSqueeze: LaunchModInvSqueeze(P(op.in[0]), P(op.in[1]), P(op.out[0]), op.param, op.aw, op.ah, op.rw, op.rh, stream_v); break;
-          case ModOp::kOutput: {
-            ModOutputArgs a;
-            memset(&a, 0, sizeof(a));
-            a.ncolor = op.num_c;
-            for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = P(op.in[c]);
-            a.color_factor = op.color_factor;
-            a.alpha = op.has_alpha ? P(op.in[3]) : nullptr; a.alpha_factor = op.alpha_factor;
-            LaunchModOutput(dframes_, i, a, images_[i]->plan.width, images_[i]->plan.height, stream_v);
-            break;
-          }
+  LaunchModularGroups(dframes_, n, max_lf_groups_, max_groups_, stream_v);
+  for (int i = 0; i < n; i++) {
+    for (const ModOp& op : mod_ops_[i]) {
+      auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
+      switch (op.kind) {
+        case ModOp::kRct: LaunchModRct(P(op.in[0]), P(op.in[1]), P(op.in[2]), op.n, op.param, stream_v); break;
+        case ModOp::kPalette: {
+          int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
+          for (uint32_t c = 0; c < op.num_c; c++) outs[c] = P(op.out[c]);
+          LaunchModPalette(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.n, stream_v);
+          break;
+        }
+        case ModOp::kSqueeze: LaunchModInvSqueeze(P(op.in[0]), P(op.in[1]), P(op.out[0]), op.param, op.aw, op.ah, op.rw, op.rh, stream_v); break;
+        case ModOp::kOutput: {
+          ModOutputArgs a;
+          memset(&a, 0, sizeof(a));
+          a.ncolor = op.num_c;
+          for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = P(op.in[c]);
+          a.color_factor = op.color_factor;
+          a.alpha = op.has_alpha ? P(op.in[3]) : nullptr; a.alpha_factor = op.alpha_factor;
+          LaunchModOutput(dframes_, i, a, images_[i]->plan.width, images_[i]->plan.height, stream_v);
+          break;
         }
       }
     }
@@ -574,7 +593,7 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
       }
     }
   }
-  ModOp op; op.kind = ModOp::kOutput; op.num_c = p.nb_color_channels;
+  ModOp op; op.kind = ModOp::kOutput; op.num_c = p.nb_color_channels;   // (0 for VarDCT frames: only extra channels are Modular)
   if (list.size() < op.num_c + e.ih.extra.size()) throw ParseError("modular channel list", false);
   for (size_t k = 0; k < op.num_c + e.ih.extra.size(); k++)
     if (list[k].w != p.width || list[k].h != p.height) throw ParseError("unsupported: channel of a different size than the image (dim_shift)", true);
@@ -585,7 +604,8 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
     op.alpha_factor = 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);
     break;
   }
-  ops.push_back(op);
+  if (p.modular) ops.push_back(op);
+  else vardct_alpha_[i] = VarDctAlpha{op.has_alpha, op.in[3], op.alpha_factor};   // the VarDCT write stage reads the plane itself
 }
 
 void Batch::CheckFilterBuffers() const {
@@ -602,8 +622,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
-  if (!any_vardct_) { if (part != 1) Run(stream_v); return; }
-  CheckFilterBuffers();
+  if (any_vardct_) CheckFilterBuffers();
   std::vector<void*>* evs = nullptr;
   if (timed) {
     if (part != 2) { timed_events_.emplace_back(8, nullptr); }
@@ -617,17 +636,24 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   };
   if (part != 2) {
     rec(0);
-    LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
+    if (any_modchan_) LaunchModularGlobal(dframes_, n, stream_v);   // Modular frames; extra channels of VarDCT frames
+    if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     rec(1);
-    LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
+    if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
     if (part == 1) rec(2);
   }
-  if (part != 1) {
+  if (part != 1 && !any_vardct_) {
+    rec(part == 2 ? 7 : 2); rec(3); rec(4); rec(5);
+    if (any_modchan_) EnqueueModularTail(stream_v);
+    rec(6);
+    if (timed && part == 2) timed_rest_cursor_++;
+  } else if (part != 1) {
     // the HF decoder only writes non-zero coefficients: clear the planes first (outside the per-stage brackets when the
     // halves are timed separately; the planes may be shared with another batch, so this belongs to the rest half)
     HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, stream));
     rec(part == 2 ? 7 : 2);
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
+    if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
     rec(3);
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     rec(4);
@@ -637,7 +663,6 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     rec(6);
     if (timed && part == 2) timed_rest_cursor_++;
   }
-  if (any_modular_ && part != 1) Run(stream_v);
 }
 
 StageTimes Batch::CollectTimes(int* runs) {

@@ -103,6 +103,10 @@ class Batch {
     float color_factor = 1.0f, alpha_factor = 1.0f;
   };
   std::vector<std::vector<ModOp>> mod_ops_;
+  struct VarDctAlpha { bool has = false; size_t off = 0; float factor = 1.0f; };
+  std::vector<VarDctAlpha> vardct_alpha_;
+  bool any_modchan_ = false;      // some frame carries Modular channels (Modular frames, VarDCT frames with extra channels)
+  void EnqueueModularTail(void* stream);
   void PlanModularUndo(int i, const std::function<size_t(size_t)>& take);
   std::vector<std::vector<void*>> timed_events_;
   size_t timed_rest_cursor_ = 0;       // per frame: work-arena offsets of planes (incl. spare)

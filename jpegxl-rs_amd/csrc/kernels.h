@@ -73,6 +73,11 @@ struct FrameDev {
   int32_t* mod_group_scratch;     // per group scratch
   uint64_t mod_group_scratch_stride;
   uint32_t mod_bits;
+  int32_t* mod_wp_scratch;        // weighted-predictor state of the Modular sub-streams: global, then one per LfGroup / PassGroup unit
+  uint64_t mod_wp_stride;
+  uint64_t* hf_end_bitpos;        // VarDCT frames with extra channels: where each group's HF coefficient stream ended (its Modular part starts there)
+  const int32_t* alpha_plane;     // VarDCT frames: decoded alpha extra channel (image-sized), or null
+  float alpha_factor;             // 1 / (2^bits - 1)
   // output
   uint8_t* out;
   uint64_t out_stride;            // bytes per row

@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
   const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
   BitReaderP br;
   const uint64_t sec_end = f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g];
-  if (f.single_section) br.Init(f.cs, f.lf_start_bitpos, f.cs_size);
+  if (f.single_section) br.Init(f.cs, f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos, f.cs_size);   // (after the global Modular stream, if any)
   else br.Init(f.cs, f.sec_off[1 + g] * 8, sec_end);
   const uint64_t limit = sec_end * 8;
   __shared__ int s_fail_w[kLfWaves];
@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   }
   if (state != 0x130000u) { SetError(f, kErrAnsFinalState); return; }
   if (br.BitPos() > limit) { SetError(f, kErrOverrun); return; }
+  if (f.hf_end_bitpos) f.hf_end_bitpos[g] = br.BitPos();
 }
 
 // ---- SIMT variant: every lane decodes the stream of its own group; one token per lane per loop iteration -------------
@@ -1173,6 +1174,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
       if (vi >= nvb) {
         if (state != 0x130000u) SetError(f, kErrAnsFinalState);
         else if (br.BitPos() > limit) SetError(f, kErrOverrun);
+        else if (f.hf_end_bitpos) f.hf_end_bitpos[g] = br.BitPos();
         done = true;
       } else {
         const uint2 ent = ent_next;
@@ -1983,7 +1985,7 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
     b = fmaf(cbcb, X, yb);
   } else { r = X; g = Y; b = B; }
   if (f.is_gray) r = g;
-  StorePixel(f, x, y, r, g, b, 1.0f);
+  StorePixel(f, x, y, r, g, b, f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f);
 }
 
 // =====================================================================================================================
@@ -2090,7 +2092,7 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
     float b = fmaf(f.opsin_inv[8], mb, fmaf(f.opsin_inv[7], mg, f.opsin_inv[6] * mr));
     if (f.color_mode == 0) { r = LinearToSrgb(r); g = LinearToSrgb(g); b = LinearToSrgb(b); }
     if (f.is_gray) r = g;
-    StorePixel(f, x, y, r, g, b, 1.0f);
+    StorePixel(f, x, y, r, g, b, f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f);
   }
 }
 
@@ -2140,12 +2142,12 @@ __device__ __forceinline__ int32_t* ModPlane(const FrameDev& f, const ModChanDev
 // global stream: channels 0..mod_global_decodable-1 of the global image (meta channels + small channels)
 __global__ __launch_bounds__(64) void ModularGlobalKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.x];
-  if (!f.is_modular || threadIdx.x != 0) return;
+  if (f.mod_nchan == 0 || threadIdx.x != 0) return;   // Modular frames and VarDCT frames with extra channels
   BitReader br;
   br.Init(f.cs, f.mod_global_bitpos, f.cs_size);
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0;
-  mc.wp_scratch = f.wp_scratch;
+  mc.wp_scratch = f.mod_wp_scratch;
   AnsReader ans; ans.Init(br, f.mod_code);
   for (uint32_t c = 0; c < f.mod_global_decodable; c++) {
     const ModChanDev mcd = f.mod_chan[c];
@@ -2165,11 +2167,12 @@ __global__ __launch_bounds__(64) void ModularGlobalKernel(const FrameDev* __rest
 // planes when the stream has no local transforms — then all lanes undo local transforms and copy the rectangles.
 __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.y];
-  if (!f.is_modular) return;
+  if (f.mod_nchan == 0) return;
   const uint32_t unit = blockIdx.x;
   const bool is_lf = unit < f.num_lf_groups;
   const uint32_t g = is_lf ? unit : unit - f.num_lf_groups;
   if (!is_lf && g >= f.num_groups) return;
+  if (!f.is_modular && is_lf) return;   // VarDCT: extra channels are never squeezed here, so ModularLfGroup is empty
   // channels decoded per section: those after the globally decoded ones
   const uint32_t first = f.mod_global_decodable;
   if (first >= f.mod_nchan) return;
@@ -2210,12 +2213,17 @@ __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restr
       const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + g;
       BitReader br;
       uint64_t limit = 0;
-      if (ok) { const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
+      if (ok) {
+        const uint64_t off = f.sec_off[si];
+        // VarDCT PassGroup: the Modular part follows the HF coefficients of the group
+        br.Init(f.cs, f.is_modular ? off * 8 : f.hf_end_bitpos[g], off + f.sec_size[si]);
+        limit = (off + f.sec_size[si]) * 8;
+      }
       ok = ok && ReadGroupHeader(br, s_gh) && s_gh.use_global_tree;
       ModularCtx mc;
       mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
       mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + g;
-      mc.wp_scratch = f.wp_scratch + (uint64_t)(1 + unit) * f.wp_scratch_stride;
+      mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
       if (ok && s_gh.ntransforms == 0) {
         // direct: decode every rectangle in place
         AnsReader ans; ans.Init(br, f.mod_code);

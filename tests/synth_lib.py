@@ -32,6 +32,7 @@ def lib():
         L.jxlsynth_free.argtypes = [C.c_void_p]
         L.jxlsynth_image.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.jxlsynth_vardct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.jxlsynth_vardct2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.jxlsynth_modular.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.jxlsynth_modular2.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _lib = L
@@ -51,19 +52,22 @@ def _take(out, n):
     return data
 
 
-def encode_vardct(rgb, seed=1, distance=1.0, epf_iters=1, gab=1, strategy_mix=1, out_bits=8, hdr=0, skip_lf_smoothing=0, orientation=1):
-    """rgb: (h,w,3) uint8 sRGB, or float32 linear when hdr=1.  Returns codestream bytes."""
+def encode_vardct(rgb, seed=1, distance=1.0, epf_iters=1, gab=1, strategy_mix=1, out_bits=8, hdr=0, skip_lf_smoothing=0, orientation=1, alpha=None):
+    """rgb: (h,w,3) uint8 sRGB, or float32 linear when hdr=1; alpha: optional (h,w) uint8 plane carried as a lossless
+    extra channel.  Returns codestream bytes."""
     L = lib()
     h, w = rgb.shape[:2]
     p = Params(seed=seed, distance=distance, epf_iters=epf_iters, gab=gab, strategy_mix=strategy_mix, out_bits=out_bits,
                hdr=hdr, skip_lf_smoothing=skip_lf_smoothing, orientation=orientation)
     out = C.c_void_p(); n = C.c_size_t()
+    alpha_arr = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.uint8)
+    al = None if alpha_arr is None else alpha_arr.ctypes.data
     if rgb.dtype == np.uint8:
         a = np.ascontiguousarray(rgb)
-        rc = L.jxlsynth_vardct(a.ctypes.data, None, w, h, C.byref(p), C.byref(out), C.byref(n))
+        rc = L.jxlsynth_vardct2(a.ctypes.data, None, al, w, h, C.byref(p), C.byref(out), C.byref(n))
     else:
         a = np.ascontiguousarray(rgb, dtype=np.float32)
-        rc = L.jxlsynth_vardct(None, a.ctypes.data, w, h, C.byref(p), C.byref(out), C.byref(n))
+        rc = L.jxlsynth_vardct2(None, a.ctypes.data, al, w, h, C.byref(p), C.byref(out), C.byref(n))
     if rc:
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)

@@ -306,6 +306,26 @@ def test_full_size_8k_modular_squeeze(jx):
     assert np.array_equal(px.reshape(8192, 8192), img[..., 0])
 
 
+@pytest.mark.parametrize("w,h", [(200, 136), (256, 256), (600, 400), (1030, 270)])
+def test_vardct_with_alpha_extra_channel(jx, w, h):
+    """VarDCT colour + a lossless 8-bit alpha extra channel in the frame's Modular sub-streams: GlobalModular for one-group
+    images (the LfGroup then starts where that stream ends), else the Modular tail of every PassGroup (starting where the
+    group's HF coefficients end).  RGBA / RGB / grey+alpha outputs, u8 and f32."""
+    img = S.synthetic_image(50, w, h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    al = ((np.sin(xx / 17.0) * np.cos(yy / 11.0) * 0.5 + 0.5) * 255).astype(np.uint8)
+    data = S.encode_vardct(img, seed=9, strategy_mix=2, epf_iters=1, gab=1, alpha=al)
+    meta, px = jx.decoder_builder().decode_with(data, np.uint8)
+    assert meta.has_alpha_channel and len(px) == w * h * 4
+    assert np.array_equal(px.reshape(h, w, 4)[..., 3], al)
+    check_against_oracle(jx, data, np.uint8, 4)
+    check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.float32, 4)
+    check_against_oracle(jx, data, np.uint16, 2)
+    data = S.encode_vardct(img, seed=9, strategy_mix=1, epf_iters=3, gab=0, alpha=al)   # unfused filter path
+    check_against_oracle(jx, data, np.uint8, 4)
+
+
 def _orient(a, o):
     """EXIF-style orientation o applied to an (h, w, c) array (codestream_header.rs JxlOrientation)."""
     return {1: lambda v: v, 2: lambda v: v[:, ::-1], 3: lambda v: v[::-1, ::-1], 4: lambda v: v[::-1], 5: lambda v: v.transpose(1, 0, 2),

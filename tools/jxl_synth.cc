@@ -298,7 +298,7 @@ static const uint16_t kNzCtx[64] = {0xBAD, 0,   31,  62,  62,  93,  93,  93,  93
 static const uint8_t kDefaultBlockCtx[39] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14,
                                              7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
 
-static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p) {
+static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr) {
   const int bw = (w + 7) / 8, bh = (h + 7) / 8;
   const int pw = bw * 8, ph = bh * 8;
   const int xg = (w + 255) / 256, yg = (h + 255) / 256, ngroups = xg * yg;
@@ -544,10 +544,32 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
       }
     }
   }
+  // --- optional alpha: one 8-bit extra channel coded losslessly by the frame's Modular sub-streams (GlobalModular when
+  // the image fits one group, else the modular part of every PassGroup), under the same global tree
+  std::vector<Token> alpha_global_tok;
+  std::vector<std::vector<Token>> alpha_tok(ngroups);
+  const bool alpha_global = alpha && w <= 256 && h <= 256;
+  if (alpha) {
+    std::vector<int32_t> a32((size_t)w * h);
+    for (size_t i = 0; i < a32.size(); i++) a32[i] = alpha[i];
+    if (alpha_global) {
+      std::vector<ChanRef> cr{{a32.data(), w, h}};
+      ModularTokens(gt, root, cr, 0, alpha_global_tok);
+    } else {
+      for (int g = 0; g < ngroups; g++) {
+        const int x0 = (g % xg) * 256, y0 = (g / xg) * 256, gw = std::min(256, w - x0), gh = std::min(256, h - y0);
+        std::vector<int32_t> rect((size_t)gw * gh);
+        for (int y = 0; y < gh; y++) memcpy(&rect[(size_t)y * gw], &a32[(size_t)(y0 + y) * w + x0], sizeof(int32_t) * gw);
+        std::vector<ChanRef> cr{{rect.data(), gw, gh}};
+        ModularTokens(gt, root, cr, 1 + 3 * nlf + 17 + g, alpha_tok[g]);
+      }
+    }
+  }
   // --- entropy codes
   EntropyCoder tree_code, mod_code, ac_code;
   { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
   { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); }
+    s.push_back(&alpha_global_tok); for (auto& t : alpha_tok) s.push_back(&t);
     BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 32, mod_code); }
   { std::vector<const std::vector<Token>*> s; for (auto& t : ac_tok) s.push_back(&t);
     BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_code); }
@@ -564,6 +586,10 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     WriteEntropyCode(s, tree_code);
     EncodeTokens(s, tree_code, tree_tokens);
     WriteEntropyCode(s, mod_code);
+    if (alpha) {  // the global Modular image has a channel: GroupHeader + whatever is decodable globally
+      s.put(1, 1); s.put(1, 1); s.put(0, 2);
+      EncodeTokens(s, mod_code, alpha_global_tok);
+    }
     sections.push_back(s);
   }
   for (int g = 0; g < nlf; g++) {  // LfGroup
@@ -606,12 +632,13 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     BitWriter s;
     // preset: ceil_log2(1) = 0 bits
     EncodeTokens(s, ac_code, ac_tok[g]);
+    if (alpha && !alpha_global) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, mod_code, alpha_tok[g]); }
     sections.push_back(s);
   }
   BitWriter out;
-  WriteImageHeader(out, w, h, p, true, p.out_bits == 16 ? 16 : 8, false, false);
+  WriteImageHeader(out, w, h, p, true, p.out_bits == 16 ? 16 : 8, alpha != nullptr, false);
   bool lf_default = p.gab == 1 && p.epf_iters == 2;
-  WriteFrameHeader(out, p, false, true, 0, 1, lf_default);
+  WriteFrameHeader(out, p, false, true, alpha ? 1 : 0, 1, lf_default);
   WriteTOCAndSections(out, sections, ngroups == 1);
   out.align();
   return out.bytes;
@@ -845,7 +872,12 @@ static int finish(const std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
   return 0;
 }
 // rgb8: interleaved sRGB u8 (w*h*3).  For hdr: rgb_lin (float, linear, w*h*3) is used instead.
+int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* alpha8, int w, int h, const jxlsynth_params* pp, uint8_t** out, size_t* n);
 int jxlsynth_vardct(const uint8_t* rgb8, const float* rgb_lin, int w, int h, const jxlsynth_params* pp, uint8_t** out, size_t* n) {
+  return jxlsynth_vardct2(rgb8, rgb_lin, nullptr, w, h, pp, out, n);
+}
+// alpha8: optional w*h 8-bit alpha plane carried as an extra channel of the VarDCT frame
+int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* alpha8, int w, int h, const jxlsynth_params* pp, uint8_t** out, size_t* n) {
   try {
     synth::Params p;
     p.seed = pp->seed; p.distance = pp->distance; p.epf_iters = pp->epf_iters; p.gab = pp->gab; p.strategy_mix = pp->strategy_mix;
@@ -862,7 +894,7 @@ int jxlsynth_vardct(const uint8_t* rgb8, const float* rgb_lin, int w, int h, con
       synth::LinearToXYB(r, g, b, &pl[0][i], &pl[1][i], &pl[2][i]);
     }
     const float* planes[3] = {pl[0].data(), pl[1].data(), pl[2].data()};
-    return finish(synth::EncodeVarDCT(planes, w, h, p), out, n);
+    return finish(synth::EncodeVarDCT(planes, w, h, p, alpha8), out, n);
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 // planes: nchan (+alpha) pointers to w*h int32 samples
