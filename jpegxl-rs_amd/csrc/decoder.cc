@@ -19,7 +19,7 @@ size_t Align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct ConstOffsets {
   size_t cs = 0, sec_off = 0, sec_size = 0, tree = 0, bcm = 0;
-  size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0, mod_chan = 0;
+  size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0, mod_chan = 0, up_weights = 0;
   size_t ac_ctx = 0, ac_cfg = 0, ac_alias = 0, ac_pc = 0, ac_po = 0, ac_ps = 0;
   size_t orders[39] = {0};
   size_t qtable[17 * 3] = {0};
@@ -221,7 +221,8 @@ void Batch::Prepare(void* stream_v) {
     max_bw_ = std::max<int>(max_bw_, p.bw); max_bh_ = std::max<int>(max_bh_, p.bh);
     if (!p.modular) {
       max_epf_ = std::max<int>(max_epf_, p.lf.epf_iters); any_gab_ |= p.lf.gab != 0;
-      const bool fusable = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded;
+      const bool fusable = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && p.upsampling == 1;
+      if (p.upsampling > 1) { fplan_.any_upsampled = true; fplan_.max_out_w = std::max<int>(fplan_.max_out_w, e.ih.xsize); fplan_.max_out_h = std::max<int>(fplan_.max_out_h, e.ih.ysize); }
       fplan_.any_fused |= fusable; fplan_.any_unfused |= !fusable;
       fplan_.any_gab |= p.lf.gab != 0; fplan_.max_epf = std::max<int>(fplan_.max_epf, p.lf.epf_iters);
     }
@@ -234,7 +235,7 @@ void Batch::Prepare(void* stream_v) {
   const bool need_plane_b = fplan_.any_unfused || cfg.force_unfused_filters;
   struct WorkOffsets {
     size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, vb_list, vb_count, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
-        mod_scratch, hf_end = 0, mod_wp = 0;
+        mod_scratch, hf_end = 0, mod_wp = 0, up_plane[4] = {0, 0, 0, 0};
     size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0;
   };
   std::vector<WorkOffsets> wo(n);
@@ -266,6 +267,13 @@ void Batch::Prepare(void* stream_v) {
       o.ytox = take(ntile); o.ytob = take(ntile);
       const size_t plane = (size_t)p.bw * 8 * p.bh * 8 * 4;
       for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big(plane); o.plane_b[c] = need_plane_b ? take_big(plane) : (size_t)-1; }
+      if (p.upsampling > 1) {
+        for (int c = 0; c < 4; c++) o.up_plane[c] = take_big((size_t)e.ih.xsize * e.ih.ysize * 4);
+        static const float kUp2[15] = {-0.01716200f, -0.03452303f, -0.04022174f, -0.02921014f, -0.00624645f, 0.14111091f, 0.28896755f, 0.00278718f,
+                                       -0.01610267f, 0.56661550f,  0.03777607f,  -0.01986694f, -0.03144731f, -0.01185068f, -0.00213539f};   // library default, 2x only (oracle/render.h)
+        const std::vector<float>& cw = e.ih.up_weights[p.upsampling == 2 ? 0 : p.upsampling == 4 ? 1 : 2];
+        co[i].up_weights = cw.empty() ? arena.Put(kUp2, sizeof(kUp2)) : arena.Put(cw.data(), cw.size() * 4);
+      }
       o.lf_scratch_stride = 16 + 2 * 1024 + 3 * 65536;
       o.lf_scratch = take(o.lf_scratch_stride * 4 * p.num_lf_groups);
       o.wp_scratch_stride = 10 * (256 + 2);
@@ -347,6 +355,8 @@ void Batch::Prepare(void* stream_v) {
     f.out = (uint8_t*)(e.out.device_ptr ? e.out.device_ptr : dwork_ + e.off_out);
     f.out_stride = e.out_stride; f.out_channels = e.out.num_channels; f.out_type = e.out.type; f.out_big_endian = e.out.big_endian;
     f.out_orient = e.out.keep_orientation ? 1 : e.ih.orientation;
+    f.upsampling = p.upsampling; f.img_w = e.ih.xsize; f.img_h = e.ih.ysize;
+    if (p.upsampling > 1) { f.up_weights = (const float*)(cbase + c.up_weights); for (int k = 0; k < 4; k++) f.up_plane[k] = (float*)(dbig_ + o.up_plane[k]); }
     f.is_gray = e.ih.color_space == 1;
     f.wp_scratch = (int32_t*)(dwork_ + o.wp_scratch); f.wp_scratch_stride = o.wp_scratch_stride;
     if (!p.modular) {

@@ -538,9 +538,8 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
       for (int i = 0; i < 4; i++) ih->quant_bias[i] = r.F16();
     }
     uint32_t cw = r.u(3);
-    if (cw & 1) for (int i = 0; i < 15; i++) r.F16();
-    if (cw & 2) for (int i = 0; i < 55; i++) r.F16();
-    if (cw & 4) for (int i = 0; i < 210; i++) r.F16();
+    static const int kCount[3] = {15, 55, 210};
+    for (int k = 0; k < 3; k++) if (cw >> k & 1) { ih->up_weights[k].resize(kCount[k]); for (float& v : ih->up_weights[k]) v = r.F16(); }
   }
   if (ih->want_icc) Unsupported("embedded ICC profile");
   r.align();
@@ -627,8 +626,13 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     r.SkipExtensions();
     if (p->frame_type != 0) Unsupported("non-regular frame (reference / LF / skip-progressive)");
     if (!p->is_last) Unsupported("multi-frame image");
-    if (p->upsampling != 1) Unsupported("upsampling");
-    for (auto e : ec_ups) if (e != 1) Unsupported("extra-channel upsampling");
+    for (auto e : ec_ups) if (e != p->upsampling) Unsupported("extra-channel upsampling different from the colour upsampling");
+    if (p->upsampling != 1) {
+      if (p->modular) Unsupported("upsampling of a Modular frame");
+      const int k = p->upsampling == 2 ? 0 : p->upsampling == 4 ? 1 : 2;
+      if (k > 0 && ih.up_weights[k].empty()) Unsupported("default 4x / 8x upsampling weights (tables not reproducible offline)");
+      fx = (fx + p->upsampling - 1) / p->upsampling; fy = (fy + p->upsampling - 1) / p->upsampling;   // coded size
+    }
     for (int i = 0; i < 3; i++) if (jpeg_ups[i]) Unsupported("chroma subsampling");
     if (use_lf_frame) Unsupported("LF frame");
     (void)lf_level;

@@ -61,6 +61,7 @@ struct ImageHeader {
   float intensity_target = 255.f, min_nits = 0.f, linear_below = 0.f;
   bool relative_to_max_display = false;
   float opsin_inv[9]; float opsin_bias[3]; float quant_bias[4];
+  std::vector<float> up_weights[3];   // custom upsampling weights for 2x / 4x / 8x (15 / 55 / 210 values); empty = library default
   bool have_container = false;
 };
 

@@ -83,6 +83,10 @@ struct FrameDev {
   uint64_t out_stride;            // bytes per row
   uint32_t out_channels, out_type /*0 u8 1 u16 2 f32 3 f16*/, out_big_endian;
   uint32_t out_orient;            // 1..8: orientation applied while writing (1 = none)
+  // upsampling (frame coded at 1/upsampling of the image size): width/height above are the CODED size
+  uint32_t upsampling, img_w, img_h;   // img_*: image size the write stage covers (= width/height when upsampling == 1)
+  const float* up_weights;        // 15 / 55 / 210 coefficients of the symmetric (5N x 5N) kernel matrix, N = upsampling / 2
+  float* up_plane[4];             // upsampled X, Y, B (and alpha as float) planes, img_w x img_h
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
 };
@@ -106,7 +110,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream);
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream);
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream);
-struct FilterPlan { bool any_fused = false, any_unfused = false, any_gab = false; int max_epf = 0; };   // over the VarDCT frames of a batch
+struct FilterPlan {
+  bool any_upsampled = false;    // some frame needs UpsampleKernel before the write stage
+  int max_out_w = 0, max_out_h = 0; bool any_fused = false, any_unfused = false, any_gab = false; int max_epf = 0; };   // over the VarDCT frames of a batch
 void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream);
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream);
 // Modular stages

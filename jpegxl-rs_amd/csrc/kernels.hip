@@ -1801,7 +1801,7 @@ __device__ __forceinline__ bool FilterStageActive(const FrameDev& f, int stage) 
 
 // Frames with the common restoration setting (gaborish + one EPF pass, XYB colour) take the fused tile kernel
 // FusedGabEpf1OutKernel; everything else runs the stage-by-stage kernels.
-__device__ __forceinline__ bool FusedEligible(const FrameDev& f, int unfused) { return !unfused && f.gab && f.epf_iters == 1 && f.color_mode <= 1; }
+__device__ __forceinline__ bool FusedEligible(const FrameDev& f, int unfused) { return !unfused && f.gab && f.epf_iters == 1 && f.color_mode <= 1 && f.upsampling == 1; }
 
 __global__ void GaborishKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
@@ -1927,7 +1927,7 @@ __device__ __forceinline__ void StoreSample(const FrameDev& f, uint8_t* p, float
 // codestream_header.rs JxlOrientation) is applied by the write stage — 2 flip-h, 3 rotate 180, 4 flip-v, 5 transpose,
 // 6 rotate 90 cw, 7 anti-transpose, 8 rotate 90 ccw; out_stride already refers to the oriented width.
 __device__ __forceinline__ uint8_t* OutPixelPtr(const FrameDev& f, int x, int y, uint32_t bps) {
-  const int w = (int)f.width, h = (int)f.height;
+  const int w = (int)f.img_w, h = (int)f.img_h;
   int ox = x, oy = y;
   switch (f.out_orient) {
     case 2: ox = w - 1 - x; break;
@@ -1955,16 +1955,59 @@ __device__ __forceinline__ void StorePixel(const FrameDev& f, int x, int y, floa
   }
 }
 
+// Non-separable 2x / 4x / 8x upsampling of the restored planes (stage_upsampling.cc; same definition and accumulation order
+// as oracle/render.h UpsamplePlane): one thread per output sample and channel, 25 taps, result clamped to the window's range.
+// Channel 3 = the alpha extra channel (int samples scaled to float first).
+__global__ void UpsampleKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular || f.upsampling == 1) return;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (ox >= (int)f.img_w || oy >= (int)f.img_h) return;
+  const int up = (int)f.upsampling, N = up / 2;
+  const int w = (int)f.width, h = (int)f.height;
+  const int x = ox / up, sx = ox % up, y = oy / up, sy = oy % up;
+  const int ky = sy < N ? sy : up - 1 - sy, kx = sx < N ? sx : up - 1 - sx;
+  const bool fy = sy >= N, fx = sx >= N;
+  const bool src_is_a = (FilterStagesBefore(f, 4) & 1) == 0;
+  const int nch = f.alpha_plane ? 4 : 3;
+  for (int c = 0; c < nch; c++) {
+    const float* src = c == 3 ? nullptr : (src_is_a ? f.plane_a[c] : f.plane_b[c]);
+    float sum = 0.0f, mn = 0.0f, mx = 0.0f;
+    for (int iy = 0; iy < 5; iy++) {
+      const int yy = MirrorD(y + iy - 2, h);
+      const int mi = 5 * ky + (fy ? 4 - iy : iy);
+      for (int ix = 0; ix < 5; ix++) {
+        const int xx = MirrorD(x + ix - 2, w);
+        const float v = c == 3 ? (float)f.alpha_plane[(size_t)yy * w + xx] * f.alpha_factor : src[(size_t)yy * f.plane_stride + xx];
+        const int mj = 5 * kx + (fx ? 4 - ix : ix);
+        const int lo = mi < mj ? mi : mj, hi = mi < mj ? mj : mi;
+        const float k = f.up_weights[5 * N * lo - lo * (lo - 1) / 2 + hi - lo];
+        sum = fmaf(k, v, sum);
+        if (iy == 0 && ix == 0) { mn = v; mx = v; } else { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+      }
+    }
+    f.up_plane[c][(size_t)oy * f.img_w + ox] = sum < mn ? mn : (sum > mx ? mx : sum);
+  }
+}
+
 __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
   if (f.is_modular || FusedEligible(f, unfused)) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= (int)f.width || y >= (int)f.height) return;
-  const bool src_is_a = (FilterStagesBefore(f, 4) & 1) == 0;
-  const size_t o = (size_t)y * f.plane_stride + x;
-  const float X = (src_is_a ? f.plane_a[0] : f.plane_b[0])[o];
-  const float Y = (src_is_a ? f.plane_a[1] : f.plane_b[1])[o];
-  const float B = (src_is_a ? f.plane_a[2] : f.plane_b[2])[o];
+  if (x >= (int)f.img_w || y >= (int)f.img_h) return;
+  float X, Y, B, A = 1.0f;
+  if (f.upsampling > 1) {
+    const size_t o = (size_t)y * f.img_w + x;
+    X = f.up_plane[0][o]; Y = f.up_plane[1][o]; B = f.up_plane[2][o];
+    if (f.alpha_plane) A = f.up_plane[3][o];
+  } else {
+    const bool src_is_a = (FilterStagesBefore(f, 4) & 1) == 0;
+    const size_t o = (size_t)y * f.plane_stride + x;
+    X = (src_is_a ? f.plane_a[0] : f.plane_b[0])[o];
+    Y = (src_is_a ? f.plane_a[1] : f.plane_b[1])[o];
+    B = (src_is_a ? f.plane_a[2] : f.plane_b[2])[o];
+    if (f.alpha_plane) A = (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor;
+  }
   float r, g, b;
   if (f.color_mode <= 1) {
     const float gr = (Y + X) - f.neg_bias_cbrt[0];
@@ -1985,7 +2028,7 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
     b = fmaf(cbcb, X, yb);
   } else { r = X; g = Y; b = B; }
   if (f.is_gray) r = g;
-  StorePixel(f, x, y, r, g, b, f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f);
+  StorePixel(f, x, y, r, g, b, A);
 }
 
 // =====================================================================================================================
@@ -2496,7 +2539,9 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
 }
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   if (!fp.any_unfused && !cfg.force_unfused_filters) return;
-  dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);
+  const int ow = std::max(max_w, fp.max_out_w), oh = std::max(max_h, fp.max_out_h);   // upsampled frames write more pixels than they code
+  dim3 block(64, 4), grid(DivUp(ow, 64), DivUp(oh, 4), nframes);
+  if (fp.any_upsampled) hipLaunchKernelGGL(UpsampleKernel, grid, block, 0, (hipStream_t)stream, frames);
   hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters);
 }
 void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream) {

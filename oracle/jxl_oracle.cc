@@ -89,7 +89,15 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     Frame f;
     ReadFrameHeader(br, m, f.fh);
     if (f.fh.type != kRegular) JXLO_FAIL("unsupported: non-regular frame (reference / LF / skip-progressive frames)");
-    if (f.fh.upsampling != 1) JXLO_FAIL("unsupported: upsampling");
+    const int up = (int)f.fh.upsampling;
+    const float* up_weights = nullptr;
+    if (up > 1) {
+      if (f.fh.modular) JXLO_FAIL("unsupported: upsampling of a Modular frame");
+      const std::vector<float>& cw = up == 2 ? m.up2 : up == 4 ? m.up4 : m.up8;
+      if (!cw.empty()) up_weights = cw.data();
+      else if (up == 2) up_weights = kDefaultUp2Weights;
+      else JXLO_FAIL("unsupported: default 4x / 8x upsampling weights (tables not reproducible offline)");
+    }
     if (f.fh.have_crop && (f.fh.x0 != 0 || f.fh.y0 != 0 || f.fh.xsize != m.xsize || f.fh.ysize != m.ysize)) JXLO_FAIL("unsupported: cropped frame");
     if (!f.fh.is_last) JXLO_FAIL("unsupported: multi-frame image");
     if (f.fh.do_ycbcr) for (int i = 0; i < 3; i++) if (f.fh.jpeg_upsampling[i]) JXLO_FAIL("unsupported: chroma subsampling");
@@ -99,7 +107,8 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     out.tokens_lf = f.tokens_lf; out.tokens_hf = f.tokens_hf; out.tokens_modular = f.tokens_modular;
     // undo global modular transforms
     if (!f.gimg.channel.empty()) UndoTransforms(f.gimg, f.gimg_header.wp);
-    const int w = f.w, h = f.h;
+    const int cw_ = f.w, ch_ = f.h;                         // coded size
+    const int w = up > 1 ? out.w : f.w, h = up > 1 ? out.h : f.h;   // size after upsampling
     const bool gray = m.color.color_space == 1;
     out.num_color = gray ? 1 : 3;
     Image3 rgb;
@@ -129,7 +138,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
       }
       DequantAndIDCT(f);
       if (want_dump) StorePlanes(out.dump, "idct", f.xyb);
-      Image3 img = CropImage(f.xyb, w, h);
+      Image3 img = CropImage(f.xyb, cw_, ch_);
       if (f.fh.lf.gab) Gaborish(f.fh.lf, img);
       if (want_dump) StorePlanes(out.dump, "gab", img);
       if (f.fh.lf.epf_iters > 0) {
@@ -140,6 +149,10 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
         if (f.fh.lf.epf_iters >= 2) EPFPass(f.fh.lf, 2, inv_sigma, f.bw, img);
       }
       if (want_dump) StorePlanes(out.dump, "epf", img);
+      if (up > 1) {   // stage_upsampling.cc: XYB planes, before the colour transform
+        for (int c = 0; c < 3; c++) img.p[c] = UpsamplePlane(img.p[c], up, up_weights, out.w, out.h);
+        if (want_dump) StorePlanes(out.dump, "ups", img);
+      }
       rgb = img;
       if (m.xyb_encoded) {
         OpsinParams op = MakeOpsin(m, m.intensity_target);
@@ -189,10 +202,11 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     for (size_t e = 0; e < m.extra.size(); e++) {
       if (m.extra[e].type != 0) continue;
       const Channel& ch = f.gimg.channel[first_extra + e];
-      JXLO_CHECK(ch.w == w && ch.h == h);
+      JXLO_CHECK(ch.w == cw_ && ch.h == ch_);
       const float factor = 1.0f / (float)((1u << m.extra[e].depth.bits) - 1);
-      out.alpha = Plane(w, h);
-      for (size_t i = 0; i < (size_t)w * h; i++) out.alpha.d[i] = (float)ch.data[i] * factor;
+      out.alpha = Plane(cw_, ch_);
+      for (size_t i = 0; i < (size_t)cw_ * ch_; i++) out.alpha.d[i] = (float)ch.data[i] * factor;
+      if (up > 1) out.alpha = UpsamplePlane(out.alpha, up, up_weights, out.w, out.h);   // ec_upsampling == upsampling (checked at parse)
       if (want_dump) out.dump.ints["alpha"].assign(ch.data.begin(), ch.data.end());
       out.has_alpha = true;
       break;

@@ -24,6 +24,41 @@ inline int Mirror(int x, int size) {
   return x;
 }
 
+// ---- non-separable upsampling 2x / 4x / 8x (stage_upsampling.cc [R]; ISO/IEC 18181-1 "upsampling") -------------------
+// weights: the 15 / 55 / 210 stored coefficients of the symmetric (5N x 5N) matrix, N = up / 2.  Sub-pixel (sy, sx) of an
+// input sample uses the 5x5 kernel K[ky][kx][jy][jx] = M[5 ky + jy][5 kx + jx] with ky = min(sy, up-1-sy) and the window
+// mirrored (jy = 4 - iy) for the lower / right half; the result is clamped to the range of the 25 input samples.
+// Accumulation order (this restatement's choice, shared with the HIP kernel): row-major over the window, fused multiply-add.
+// Default 2x weights: recalled from the standard (they sum to 1 over the kernel, see tests); the 4x / 8x default tables are
+// not reproducible here — streams relying on them are rejected, streams carrying custom weights decode.
+static const float kDefaultUp2Weights[15] = {-0.01716200f, -0.03452303f, -0.04022174f, -0.02921014f, -0.00624645f, 0.14111091f, 0.28896755f, 0.00278718f,
+                                             -0.01610267f, 0.56661550f,  0.03777607f,  -0.01986694f, -0.03144731f, -0.01185068f, -0.00213539f};
+inline Plane UpsamplePlane(const Plane& in, int up, const float* weights, int out_w, int out_h) {
+  const int N = up / 2;
+  auto M = [&](int i, int j) { const int y = i < j ? i : j, x = i < j ? j : i; return weights[5 * N * y - y * (y - 1) / 2 + x - y]; };
+  Plane out(out_w, out_h);
+  for (int oy = 0; oy < out_h; oy++) {
+    const int y = oy / up, sy = oy % up, ky = sy < N ? sy : up - 1 - sy;
+    const bool fy = sy >= N;
+    for (int ox = 0; ox < out_w; ox++) {
+      const int x = ox / up, sx = ox % up, kx = sx < N ? sx : up - 1 - sx;
+      const bool fx = sx >= N;
+      float sum = 0.0f, mn = 0.0f, mx = 0.0f;
+      for (int iy = 0; iy < 5; iy++) {
+        const float* row = in.row(Mirror(y + iy - 2, in.h));
+        for (int ix = 0; ix < 5; ix++) {
+          const float v = row[Mirror(x + ix - 2, in.w)];
+          const float k = M(5 * ky + (fy ? 4 - iy : iy), 5 * kx + (fx ? 4 - ix : ix));
+          sum = std::fmaf(k, v, sum);
+          if (iy == 0 && ix == 0) { mn = v; mx = v; } else { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        }
+      }
+      out.row(oy)[ox] = sum < mn ? mn : (sum > mx ? mx : sum);
+    }
+  }
+  return out;
+}
+
 // compressed_dc.cc AdaptiveDCSmoothing [R]
 inline void AdaptiveLFSmoothing(const float* lf_factors, Image3& lf) {
   const int w = lf.w(), h = lf.h();

@@ -326,6 +326,32 @@ def test_vardct_with_alpha_extra_channel(jx, w, h):
     check_against_oracle(jx, data, np.uint8, 4)
 
 
+@pytest.mark.parametrize("up,custom,with_alpha", [(2, 0, False), (2, 1, False), (4, 1, False), (8, 1, False), (2, 0, True), (4, 1, True)])
+def test_upsampled_frames(jx, up, custom, with_alpha):
+    """north_star's "upsampling": frames coded at 1/2, 1/4, 1/8 of the image size and brought back by the non-separable 5x5
+    kernels (explicit weights from the image header; library default for 2x), alpha upsampled alongside, ragged sizes."""
+    w, h = 333, 201
+    img = S.synthetic_image(60 + up, w, h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    al = ((np.sin(xx / 17.0) * np.cos(yy / 11.0) * 0.5 + 0.5) * 255).astype(np.uint8) if with_alpha else None
+    data = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=2, gab=1, upsampling=up, custom_up_weights=custom, alpha=al)
+    nch = 4 if with_alpha else 3
+    meta, px = check_against_oracle(jx, data, np.uint8, nch)
+    assert (meta.width, meta.height) == (w, h)
+    check_against_oracle(jx, data, np.float32, nch)
+    err = px.reshape(h, w, nch)[..., :3].astype(np.float64) - img
+    assert 10 * np.log10(255.0 ** 2 / (err ** 2).mean()) > (33.0, 28.0, 23.0)[(2, 4, 8).index(up)]   # still the source picture
+    _, po = jx.decoder_builder().decode_with(S.encode_vardct(img, seed=4, upsampling=up, custom_up_weights=1, orientation=6), np.uint8)
+    assert len(po) == w * h * 3
+
+
+def test_default_4x_8x_upsampling_weights_are_rejected(jx):
+    """The 55 / 210 default weights of the 4x / 8x kernels are not reproducible offline: such streams must fail cleanly."""
+    data = S.encode_vardct(S.synthetic_image(3, 96, 64), upsampling=4, custom_up_weights=0)
+    with pytest.raises(jx.DecodeError):
+        jx.decoder_builder().decode_with(data, np.uint8)
+
+
 def _orient(a, o):
     """EXIF-style orientation o applied to an (h, w, c) array (codestream_header.rs JxlOrientation)."""
     return {1: lambda v: v, 2: lambda v: v[:, ::-1], 3: lambda v: v[::-1, ::-1], 4: lambda v: v[::-1], 5: lambda v: v.transpose(1, 0, 2),

@@ -141,6 +141,23 @@ def test_output_layout_rules():
     assert np.array_equal(le.astype(np.uint16), be.astype(np.uint16))
 
 
+def test_default_2x_upsampling_weights_are_a_partition_of_unity():
+    """The recalled default 2x weights (oracle/render.h kDefaultUp2Weights) must behave like an interpolation kernel: the
+    25 taps of every sub-pixel sum to 1, so a constant image stays constant; checked through a synthetic stream."""
+    w = np.array([-0.01716200, -0.03452303, -0.04022174, -0.02921014, -0.00624645, 0.14111091, 0.28896755, 0.00278718,
+                  -0.01610267, 0.56661550, 0.03777607, -0.01986694, -0.03144731, -0.01185068, -0.00213539])
+    m = np.zeros((5, 5))
+    k = 0
+    for y in range(5):
+        for x in range(y, 5):
+            m[y, x] = m[x, y] = w[k]; k += 1
+    assert abs(m.sum() - 1.0) < 1e-6
+    import synth_lib as S
+    flat = np.full((40, 56, 3), 128, np.uint8)
+    px = O.decode(S.encode_vardct(flat, upsampling=2, epf_iters=0, gab=0)).pixels("u8", 3)
+    assert np.abs(px.astype(int) - 128).max() <= 1
+
+
 def test_idct_matches_direct_formula():
     """The recursive IDCT of the oracle against the defining sum f(n) = F0 + sqrt2 * sum F_k cos((2n+1) k pi / 2N)."""
     import ctypes as C

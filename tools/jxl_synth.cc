@@ -81,7 +81,9 @@ struct Params {
   int skip_lf_smoothing = 0;
   int custom_orders = 0;  // reserved
   int orientation = 1;    // EXIF-style 1..8, written to the image header
-  int reserved[7] = {0};
+  int upsampling = 1;     // 1 | 2 | 4 | 8: the frame is coded at 1/upsampling of the image size
+  int custom_up_weights = 0;  // 1: the image header carries explicit upsampling weights (required for 4x / 8x here)
+  int reserved[5] = {0};
 };
 
 // ---- modular sub-stream tokenisation with the fixed global tree --------------------------------------------------
@@ -183,10 +185,28 @@ static void WriteSize(BitWriter& w, uint32_t xs, uint32_t ys) {
   WriteU32(w, xs, {9, 1}, {13, 1}, {18, 1}, {30, 1});
 }
 
+// Explicit upsampling weights for factor `up`: products of a Catmull-Rom kernel sampled at the sub-pixel centres, stored as
+// the upper triangle of the symmetric (5N x 5N) matrix (N = up / 2), every value rounded to F16 like the stream stores it.
+static std::vector<float> CustomUpWeights(int up) {
+  const int N = up / 2;
+  std::vector<double> a(5 * N);
+  auto cr = [](double t) { t = std::fabs(t); return t < 1 ? 1.5 * t * t * t - 2.5 * t * t + 1 : (t < 2 ? -0.5 * t * t * t + 2.5 * t * t - 4 * t + 2 : 0.0); };
+  for (int k = 0; k < N; k++) {
+    const double d = (k + 0.5) / up - 0.5;   // sub-pixel centre relative to the input sample
+    double sum = 0;
+    for (int j = 0; j < 5; j++) { a[5 * k + j] = cr((j - 2) - d); sum += a[5 * k + j]; }
+    for (int j = 0; j < 5; j++) a[5 * k + j] /= sum;
+  }
+  std::vector<float> wts;
+  for (int y = 0; y < 5 * N; y++) for (int x = y; x < 5 * N; x++) wts.push_back(RoundToHalf((float)(a[y] * a[x])));
+  return wts;
+}
+
 static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool xyb, int bits, bool has_alpha, bool gray) {
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
-  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1;
+  const bool custom_up = p.upsampling > 1 && p.custom_up_weights;
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up;
   w.put(all_default, 1);
   if (!all_default) {
     bool extra_fields = p.hdr || p.orientation != 1;
@@ -230,7 +250,13 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
     }
     WriteU64(w, 0);  // extensions
   }
-  w.put(1, 1);  // default_m
+  if (!custom_up) w.put(1, 1);  // default_m
+  else {
+    w.put(0, 1);
+    if (xyb) w.put(1, 1);   // OpsinInverseMatrix all_default
+    w.put(p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : 4, 3);   // cw_mask
+    for (float v : CustomUpWeights(p.upsampling)) WriteF16(w, v);
+  }
   w.align();
 }
 
@@ -240,8 +266,9 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   w.put(modular ? 1 : 0, 1);
   WriteU64(w, (!modular && p.skip_lf_smoothing) ? 0x80 : 0);
   if (!xyb) w.put(0, 1);  // do_YCbCr
-  w.put(0, 2);            // upsampling 1
-  for (int i = 0; i < num_extra; i++) w.put(0, 2);
+  const uint32_t ups_sel = p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : p.upsampling == 8 ? 3 : 0;
+  w.put(ups_sel, 2);      // upsampling
+  for (int i = 0; i < num_extra; i++) w.put(ups_sel, 2);   // ec_upsampling: same factor
   if (modular) w.put(group_shift, 2);
   if (!modular && xyb) { w.put(3, 3); w.put(2, 3); }
   w.put(0, 2);  // num_passes = 1
@@ -298,7 +325,8 @@ static const uint16_t kNzCtx[64] = {0xBAD, 0,   31,  62,  62,  93,  93,  93,  93
 static const uint8_t kDefaultBlockCtx[39] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14,
                                              7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
 
-static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr) {
+static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr, int img_w = 0, int img_h = 0) {
+  if (img_w == 0) { img_w = w; img_h = h; }   // (w, h) = coded size; (img_w, img_h) = image size when the frame is upsampled
   const int bw = (w + 7) / 8, bh = (h + 7) / 8;
   const int pw = bw * 8, ph = bh * 8;
   const int xg = (w + 255) / 256, yg = (h + 255) / 256, ngroups = xg * yg;
@@ -636,7 +664,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     sections.push_back(s);
   }
   BitWriter out;
-  WriteImageHeader(out, w, h, p, true, p.out_bits == 16 ? 16 : 8, alpha != nullptr, false);
+  WriteImageHeader(out, img_w, img_h, p, true, p.out_bits == 16 ? 16 : 8, alpha != nullptr, false);
   bool lf_default = p.gab == 1 && p.epf_iters == 2;
   WriteFrameHeader(out, p, false, true, alpha ? 1 : 0, 1, lf_default);
   WriteTOCAndSections(out, sections, ngroups == 1);
@@ -858,7 +886,7 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
 // ---- C API ---------------------------------------------------------------------------------------------------------
 extern "C" {
 struct jxlsynth_params {
-  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation; int32_t reserved[7];
+  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation, upsampling, custom_up_weights; int32_t reserved[5];
 };
 static thread_local std::string g_err;
 const char* jxlsynth_last_error() { return g_err.c_str(); }
@@ -883,6 +911,8 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
     p.seed = pp->seed; p.distance = pp->distance; p.epf_iters = pp->epf_iters; p.gab = pp->gab; p.strategy_mix = pp->strategy_mix;
     p.out_bits = pp->out_bits; p.hdr = pp->hdr; p.skip_lf_smoothing = pp->skip_lf_smoothing;
     p.orientation = pp->orientation >= 1 && pp->orientation <= 8 ? pp->orientation : 1;
+    p.upsampling = (pp->upsampling == 2 || pp->upsampling == 4 || pp->upsampling == 8) ? pp->upsampling : 1;
+    p.custom_up_weights = pp->custom_up_weights;
     std::vector<float> pl[3];
     for (auto& v : pl) v.resize((size_t)w * h);
     const float scale = p.hdr ? 255.0f / 1000.0f : 1.0f;  // intensity_target 1000: linear 1.0 == 1000 nits
@@ -892,6 +922,23 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
       if (rgb_lin) { r = rgb_lin[3 * i]; g = rgb_lin[3 * i + 1]; b = rgb_lin[3 * i + 2]; if (p.hdr) { r *= 1000.f / 255.f; g *= 1000.f / 255.f; b *= 1000.f / 255.f; } }
       else { r = synth::SrgbToLinear(rgb8[3 * i] / 255.0f); g = synth::SrgbToLinear(rgb8[3 * i + 1] / 255.0f); b = synth::SrgbToLinear(rgb8[3 * i + 2] / 255.0f); }
       synth::LinearToXYB(r, g, b, &pl[0][i], &pl[1][i], &pl[2][i]);
+    }
+    if (p.upsampling > 1) {
+      // code the frame at 1/upsampling of the image size: box-filtered XYB, alpha point-sampled
+      const int up = p.upsampling, cw = (w + up - 1) / up, ch = (h + up - 1) / up;
+      std::vector<float> small[3];
+      for (int c = 0; c < 3; c++) {
+        small[c].resize((size_t)cw * ch);
+        for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) {
+          double acc = 0; int cnt = 0;
+          for (int yy = y * up; yy < std::min(h, (y + 1) * up); yy++) for (int xx = x * up; xx < std::min(w, (x + 1) * up); xx++) { acc += pl[c][(size_t)yy * w + xx]; cnt++; }
+          small[c][(size_t)y * cw + x] = (float)(acc / cnt);
+        }
+      }
+      std::vector<uint8_t> small_a;
+      if (alpha8) { small_a.resize((size_t)cw * ch); for (int y = 0; y < ch; y++) for (int x = 0; x < cw; x++) small_a[(size_t)y * cw + x] = alpha8[(size_t)std::min(h - 1, y * up + up / 2) * w + std::min(w - 1, x * up + up / 2)]; }
+      const float* planes[3] = {small[0].data(), small[1].data(), small[2].data()};
+      return finish(synth::EncodeVarDCT(planes, cw, ch, p, alpha8 ? small_a.data() : nullptr, w, h), out, n);
     }
     const float* planes[3] = {pl[0].data(), pl[1].data(), pl[2].data()};
     return finish(synth::EncodeVarDCT(planes, w, h, p, alpha8), out, n);
