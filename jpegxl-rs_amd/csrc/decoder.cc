@@ -435,7 +435,7 @@ void Batch::Prepare(void* stream_v) {
     std::vector<FrameDev> tmpf;
     for (int i : single) { fill_frame(i, tmpc); tmpf.push_back(frames_host_[i]); }
     HIP_CHECK(hipMemcpyAsync(dframes_, tmpf.data(), sizeof(FrameDev) * tmpf.size(), hipMemcpyHostToDevice, stream));
-    if (any_modchan_) LaunchModularGlobal(dframes_, (int)tmpf.size(), stream_v);   // extra channels of a one-group frame precede the LfGroup
+    if (any_modchan_) LaunchModularGlobal(dframes_, (int)tmpf.size(), cfg, stream_v);   // extra channels of a one-group frame precede the LfGroup
     LaunchLfDecode(dframes_, (int)tmpf.size(), 1, cfg, stream_v);
     HIP_CHECK(hipStreamSynchronize(stream));
     for (size_t k = 0; k < single.size(); k++) {
@@ -519,7 +519,7 @@ void Batch::Run(void* stream_v) { RunPart(stream_v, 0, false); }
 // host-planned inverse transforms (and, for Modular frames, the write stage).
 void Batch::EnqueueModularTail(void* stream_v) {
   const int n = (int)images_.size();
-  LaunchModularGroups(dframes_, n, max_lf_groups_, max_groups_, stream_v);
+  LaunchModularGroups(dframes_, n, max_lf_groups_, max_groups_, cfg, stream_v);
   for (int i = 0; i < n; i++) {
     for (const ModOp& op : mod_ops_[i]) {
       auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
@@ -646,7 +646,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   };
   if (part != 2) {
     rec(0);
-    if (any_modchan_) LaunchModularGlobal(dframes_, n, stream_v);   // Modular frames; extra channels of VarDCT frames
+    if (any_modchan_) LaunchModularGlobal(dframes_, n, cfg, stream_v);   // Modular frames; extra channels of VarDCT frames
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     rec(1);
     if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);

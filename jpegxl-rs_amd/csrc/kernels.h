@@ -117,8 +117,8 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream);
 // Modular stages
 struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; };
-void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream);
-void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, void* stream);
+void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream);
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, const LaunchCfg& cfg, void* stream);
 // inverse Squeeze of one channel: (avg, res) -> out; horizontal: avg aw x h, res rw x h, out (aw+rw) x h; vertical: avg w x ah, res w x rh
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);

@@ -360,12 +360,19 @@ __device__ __forceinline__ int32_t Predict(uint32_t predictor, int32_t W, int32_
 // Serial inner loop of the LDS-only fast path, specialised at compile time:
 //   ROWMODE 0: first row (N = NW = W), 1: previous row needed (read from LDS, next value prefetched), 2: W-only rows
 //   PROP9: context from W+N-NW through the LUT (else one cluster per row);  UPRED: 0 zero, 1 W, 5 clamped gradient
+// cluster of property value v under the LDS copy of the (single-property) subtree at `pos` (leaves: a = predictor | cluster << 8)
+__device__ __forceinline__ uint32_t WalkCluster(uint32_t pos, int32_t v) {
+  uint4 n = LdS<uint4>(kTreeOff + pos * 16);
+  while ((int32_t)n.x >= 0) { pos = v > (int32_t)n.y ? n.z : n.w; n = LdS<uint4>(kTreeOff + pos * 16); }
+  return n.z >> 8;
+}
 struct ChunkState { BitReaderW bw; uint32_t state; int32_t left, nw; };
 __device__ __forceinline__ uint32_t Uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 template <int ROWMODE, bool PROP9, int UPRED, bool UCFG>
 __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, uint32_t prev, uint32_t obase, uint32_t lut_off, uint32_t first_off, uint32_t cl_row,
-                                               uint32_t cfg_off, uint32_t cfg_uniform, uint32_t alias_off, uint32_t la) {
+                                               uint32_t cfg_off, uint32_t cfg_uniform, uint32_t alias_off, uint32_t la, uint32_t wide_subroot) {
   // loop invariants into scalar registers (they come out of LDS-resident tables, i.e. vector registers)
+  wide_subroot = Uniform(wide_subroot);
   prev = Uniform(prev); obase = Uniform(obase); lut_off = Uniform(lut_off); first_off = Uniform(first_off); cl_row = Uniform(cl_row);
   cfg_off = Uniform(cfg_off); cfg_uniform = Uniform(cfg_uniform); alias_off = Uniform(alias_off); la = Uniform(la);
   x0 = (int)Uniform((uint32_t)x0); x1 = (int)Uniform((uint32_t)x1);
@@ -383,9 +390,10 @@ __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, u
     } else { W = x ? left : LdS<int32_t>(first_off); N = W; NW = W; }
     uint32_t cluster = cl_row;
     if (PROP9) {
-      int32_t v = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
-      v = v < -512 ? -512 : (v > 511 ? 511 : v);
+      const int32_t v0 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+      const int32_t v = v0 < -512 ? -512 : (v0 > 511 ? 511 : v0);
       cluster = LdS<uint16_t>(lut_off + 2 * (uint32_t)(v + 512));
+      if (__builtin_expect(wide_subroot != 0xFFFFFFFFu && v != v0, 0)) cluster = WalkCluster(wide_subroot, v0);   // rare: beyond the LUT
     }
     int32_t guess;
     if (UPRED == 0) guess = 0;
@@ -438,7 +446,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       pos = v > n.val ? n.a : n.b;
       n = T.Node(pos);
     }
-    int mode = 1, prop = -1, count = 0;
+    int mode = 1, prop = -1, count = 0, wide = 0;
     int upred = -1;   // predictor shared by all leaves with offset 0 / multiplier 1 (-2: not uniform / not simple)
     int sp = 0;       // iterative DFS with a bounded stack at kWorkOff + 64
     StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)pos);
@@ -454,16 +462,19 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       }
       if (m.prop == 15 || m.prop >= 16 || m.prop <= 1) { mode = 0; break; }
       if (prop < 0) prop = m.prop; else if (prop != m.prop) { mode = 0; break; }
-      if (m.val < -512 || m.val > 510 || sp + 2 > 200) { mode = 0; break; }
+      if (sp + 2 > 200) { mode = 0; break; }
+      if (m.val < -512 || m.val > 510) wide = 1;      // split outside the LUT's range: such property values walk the subtree
       StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.a); StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.b);
     }
     if (!T.tree_in_lds) mode = 0;
     StS<int>(wb + kWorkOff + 0, mode); StS<int>(wb + kWorkOff + 4, prop); StS<int>(wb + kWorkOff + 8, (int)pos); StS<int>(wb + kWorkOff + 12, upred);
+    StS<int>(wb + kWorkOff + 20, wide);
   }
   WaveSync();
   const int mode = LdS<int>(wb + kWorkOff + 0), prop = LdS<int>(wb + kWorkOff + 4);
   const uint32_t subroot = (uint32_t)LdS<int>(wb + kWorkOff + 8);
   const int upred = LdS<int>(wb + kWorkOff + 12);
+  const uint32_t wide_subroot = LdS<int>(wb + kWorkOff + 20) ? subroot : 0xFFFFFFFFu;
   // fast rows: leaves are (predictor p, offset 0, multiplier 1) with p in {0 zero, 1 W, 5 gradient}; the LUT then maps
   // the property value straight to the cluster
   const bool need_n = upred == 5 || prop == 9;    // previous row needed
@@ -497,7 +508,11 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     for (int y = 0; y < h; y++) {
       int32_t* p = ch.data + (size_t)y * ch.stride;
       uint32_t cl_row = 0;
-      if (prop != 9) { int32_t v = prop == 2 ? y : 0; v = v > 511 ? 511 : v; cl_row = LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)); }
+      if (prop != 9) {
+        const int32_t v0 = prop == 2 ? y : 0;
+        const int32_t v = v0 > 511 ? 511 : v0;
+        cl_row = (wide_subroot != 0xFFFFFFFFu && v != v0) ? WalkCluster(wide_subroot, v0) : LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512));
+      }
       for (int x0 = 0; x0 < w; x0 += 256) {
         if (lane == 0) StS<uint32_t>(wb + kWorkOff + 16, bw.wpos);
         WaveSync();
@@ -519,7 +534,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
           st.bw = bw; st.state = state; st.left = left; st.nw = nw;
           const uint32_t lut_off = wb + kLutOff, first_off = wb + kWorkOff + 24;
           const int rm = y == 0 ? 0 : (need_n ? 1 : 2);
-#define JXL_CHUNK_ARGS st, x0, x1, prev, obase, lut_off, first_off, cl_row, cfg_off, cfg_uniform, alias_off, la
+#define JXL_CHUNK_ARGS st, x0, x1, prev, obase, lut_off, first_off, cl_row, cfg_off, cfg_uniform, alias_off, la, wide_subroot
 #define JXL_DISPATCH                                                                              \
           if (prop == 9) {                                                                        \
             if (upred == 5) { if (rm == 0) JXL_CHUNK(0, true, 5); else JXL_CHUNK(1, true, 5); }   \
@@ -2182,26 +2197,109 @@ __device__ __forceinline__ int32_t PaletteValue(const int32_t* pal, int pal_w, i
 
 __device__ __forceinline__ int32_t* ModPlane(const FrameDev& f, const ModChanDev& c) { return (int32_t*)(f.mod_base + c.off); }
 
-// global stream: channels 0..mod_global_decodable-1 of the global image (meta channels + small channels)
-__global__ __launch_bounds__(64) void ModularGlobalKernel(const FrameDev* __restrict__ frames) {
+// Rectangle of global-image channel c inside the section unit (x0, y0, dim) for the shift range [min_shift, max_shift]
+// (dec_modular.cc DecodeGroup); false: the channel is not part of that sub-stream.
+__device__ __forceinline__ bool ModUnitRect(const FrameDev& f, uint32_t c, uint32_t x0, uint32_t y0, uint32_t dim, int min_shift, int max_shift, ChannelDesc* d) {
+  const ModChanDev m = f.mod_chan[c];
+  if (m.w == 0 || m.h == 0) return false;
+  const int shift = min(m.hshift, m.vshift);
+  if (shift < min_shift || shift > max_shift) return false;
+  const uint32_t rx = x0 >> m.hshift, ry = y0 >> m.vshift;
+  if (rx >= m.w || ry >= m.h) return false;
+  const uint32_t rw = min(dim >> m.hshift, m.w - rx), rh = min(dim >> m.vshift, m.h - ry);
+  if (rw == 0 || rh == 0) return false;
+  d->data = ModPlane(f, m) + (size_t)ry * m.w + rx; d->w = (int)rw; d->h = (int)rh; d->stride = (int)m.w;
+  return true;
+}
+
+// The global stream (meta channels + every channel that fits one group) with the same cooperative decoder: one wavefront
+// per frame.  Replaces the one-thread ModularGlobalKernel whenever the stream uses the global tree.
+__global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.x];
-  if (f.mod_nchan == 0 || threadIdx.x != 0) return;   // Modular frames and VarDCT frames with extra channels
-  BitReader br;
+  if (f.mod_nchan == 0) return;
+  ModTables T;
+  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  const uint32_t lane = threadIdx.x & 63;
+  BitReaderP br;
   br.Init(f.cs, f.mod_global_bitpos, f.cs_size);
+  uint32_t state = 0;
+  if (lane == 0) state = br.Read(32);
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0;
   mc.wp_scratch = f.mod_wp_scratch;
-  AnsReader ans; ans.Init(br, f.mod_code);
   for (uint32_t c = 0; c < f.mod_global_decodable; c++) {
     const ModChanDev mcd = f.mod_chan[c];
     if (mcd.w == 0 || mcd.h == 0) continue;  // (empty channels keep their index: property 0 is the position in the list)
     ChannelDesc ch;
     ch.data = ModPlane(f, mcd); ch.w = (int)mcd.w; ch.h = (int)mcd.h; ch.stride = (int)mcd.w;
-    DecodeModularChannel(br, ans, mc, ch, (int)c);
+    DecodeChannelCoop(br, state, T, mc, ch, (int)c);
   }
-  if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); return; }
-  if (br.BitPos() > f.cs_size * 8) { SetError(f, kErrOverrun); return; }
-  f.stream_end_bitpos[1] = br.BitPos();
+  if (lane == 0) {
+    if (state != 0x130000u) SetError(f, kErrAnsFinalState);
+    else if (br.BitPos() > f.cs_size * 8) SetError(f, kErrOverrun);
+    else f.stream_end_bitpos[1] = br.BitPos();
+  }
+}
+
+// Sub-streams without local transforms (the common case: squeezed / plain channels, alpha of VarDCT frames) through the
+// cooperative wavefront decoder of the LF stage: one wavefront per LfGroup / PassGroup unit, four per workgroup sharing
+// the LDS copy of the MA tree and the entropy code, samples decoded straight into the frame planes.
+__global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.mod_nchan == 0 || f.single_section) return;
+  const uint32_t total = f.num_lf_groups + f.num_groups;
+  if (blockIdx.x * kLfWaves >= total) return;
+  const uint32_t first = f.mod_global_decodable;
+  if (first >= f.mod_nchan) return;
+  ModTables T;
+  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t unit = blockIdx.x * kLfWaves + wave;
+  if (unit >= total) return;                     // (no block-wide barrier after this point)
+  const bool is_lf = unit < f.num_lf_groups;
+  if (!f.is_modular && is_lf) return;
+  const uint32_t g = is_lf ? unit : unit - f.num_lf_groups;
+  const uint32_t dim = is_lf ? f.group_dim * 8 : f.group_dim;
+  const uint32_t cols = is_lf ? f.xlfgroups : f.xgroups;
+  const uint32_t x0 = (g % cols) * dim, y0 = (g / cols) * dim;
+  const int min_shift = is_lf ? 3 : 0, max_shift = is_lf ? 1000 : 2;
+  __shared__ int s_go_w[kLfWaves];
+  __shared__ GroupHeaderD s_gh_w[kLfWaves];
+  int& s_go = s_go_w[wave];
+  GroupHeaderD& s_gh = s_gh_w[wave];
+  const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + g;
+  const uint64_t sec_end = f.sec_off[si] + f.sec_size[si];
+  BitReaderP br;
+  br.Init(f.cs, f.sec_off[si] * 8, sec_end);
+  uint32_t state = 0;
+  ChannelDesc d;
+  if (lane == 0) {
+    int nch = 0;
+    for (uint32_t c = first; c < f.mod_nchan; c++) nch += ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d) ? 1 : 0;
+    s_go = 0;
+    if (nch > 0) {
+      BitReader tmp;
+      tmp.Init(f.cs, f.is_modular ? f.sec_off[si] * 8 : f.hf_end_bitpos[g], f.cs_size);
+      if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree) SetError(f, kErrUnsupported);
+      else if (s_gh.ntransforms == 0) {            // (streams with local palettes / RCTs: ModularGroupKernel)
+        br.Init(f.cs, tmp.BitPos(), sec_end);
+        state = br.Read(32);
+        s_go = 1;
+      }
+    }
+  }
+  WaveSync();
+  if (!s_go) return;
+  ModularCtx mc;
+  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
+  mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + g;
+  mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
+  int k = 0;
+  for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) DecodeChannelCoop(br, state, T, mc, d, k++);
+  if (lane == 0) {
+    if (state != 0x130000u) SetError(f, kErrAnsFinalState);
+    else if (br.BitPos() > sec_end * 8) SetError(f, kErrOverrun);
+  }
 }
 
 // Per-section Modular sub-streams (dec_modular.cc DecodeGroup): blockIdx.x < num_lf_groups → the ModularLfGroup stream
@@ -2268,13 +2366,7 @@ __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restr
       mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + g;
       mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
       if (ok && s_gh.ntransforms == 0) {
-        // direct: decode every rectangle in place
-        AnsReader ans; ans.Init(br, f.mod_code);
-        int k = 0;
-        for (uint32_t c = first; c < f.mod_nchan; c++) if (rect_of(c, &d)) DecodeModularChannel(br, ans, mc, d, k++);
-        if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); ok = false; }
-        else if (br.BitPos() > limit) { SetError(f, kErrOverrun); ok = false; }
-        nch = 0;  // nothing left to do for the other lanes
+        nch = 0;   // no local transforms: ModularGroupFastKernel decodes these sub-streams in place
       } else if (ok) {
         // local transforms: decode into scratch, undo, then copy (at most kMaxXformChan channels)
         if (nch > kMaxXformChan) ok = false;
@@ -2462,7 +2554,7 @@ __global__ void ModularOutputKernel(const FrameDev* __restrict__ frames, int fid
 // launchers
 // =====================================================================================================================
 const char* const kKernelNames[] = {"LfDecodeKernel", "LfDequantKernel", "LfSmoothKernel", "LlfSigmaKernel", "HfDecodeKernel", "IdctKernel",
-                                    "GaborishKernel", "EpfKernel", "OutputKernel", "ModularGlobalKernel", "ModularGroupKernel", nullptr};
+                                    "GaborishKernel", "EpfKernel", "OutputKernel", "ModularGlobalFastKernel", "ModularGroupFastKernel", "ModularGroupKernel", nullptr};
 
 static bool g_tables_ready = false;
 void InitDeviceTables(void* stream) {
@@ -2544,10 +2636,21 @@ void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, con
   if (fp.any_upsampled) hipLaunchKernelGGL(UpsampleKernel, grid, block, 0, (hipStream_t)stream, frames);
   hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters);
 }
-void LaunchModularGlobal(const FrameDev* frames, int nframes, void* stream) {
-  hipLaunchKernelGGL(ModularGlobalKernel, dim3(nframes), dim3(64), 0, (hipStream_t)stream, frames);
+void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream) {
+  const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
+  const uint32_t lds_bytes = kTreeOff + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGlobalFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  hipLaunchKernelGGL(ModularGlobalFastKernel, dim3(nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
 }
-void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, void* stream) {
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, const LaunchCfg& cfg, void* stream) {
+  {
+    const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
+    const uint32_t lds_bytes = kTreeOff + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGroupFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+    hipLaunchKernelGGL(ModularGroupFastKernel, dim3(DivUp(max_lf_groups + max_groups, (int)kLfWaves), nframes), dim3(64 * kLfWaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
+  }
   hipLaunchKernelGGL(ModularGroupKernel, dim3(max_lf_groups + max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames);
 }
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream) {
