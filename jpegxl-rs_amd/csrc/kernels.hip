@@ -1421,7 +1421,8 @@ __device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t
 }
 
 __device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || s == 12 || s == 13; }
-__device__ __forceinline__ bool IsBig(uint32_t s) { return s >= 21; }   // DCT128x128 ... DCT128x256: larger than a 64x64 tile
+__device__ __forceinline__ bool IsBig(uint32_t s) { return s >= 21; }
+__device__ __forceinline__ uint32_t Log2Cov8(uint32_t n) { return n == 1 ? 0u : n == 2 ? 1u : n == 4 ? 2u : 3u; }   // covered blocks 1, 2, 4, 8   // DCT128x128 ... DCT128x256: larger than a 64x64 tile
 
 __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ frames, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
@@ -1688,6 +1689,44 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
   }
   __syncthreads();
   if (IsBig(BI_Strategy(s_info[0]))) return;   // aligned DCT128/256 varblocks cover whole tiles: BigIdctKernel owns them
+  // ---- row / column task lists sorted by transform length.  A tile mixes 8-, 16-, 32- and 64-point rows; taken in
+  // raster order every wavefront would run all four unrolled transforms one after the other (divergence), sorted by
+  // length a wavefront runs one.  Classes 0..3 = 8 << class points, class 4 = the 8x8 "special" transforms.
+  __shared__ uint32_t s_cnt[16];                 // [0..4] row counts, [5..8] column counts, then running cursors
+  __shared__ uint16_t s_rtask[512], s_ctask[512];
+  if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t my_rclass[2], my_cclass[2];
+  for (int q = 0; q < 2; q++) {
+    const uint32_t tt = threadIdx.x + q * 256, info = s_info[tt >> 3];
+    my_rclass[q] = my_cclass[q] = 0xFFu;
+    if (info == 0xFFFFFFFFu) continue;
+    const uint32_t st = BI_Strategy(info);
+    if (IsSpecial(st)) { if ((tt & 7) == 0) my_rclass[q] = 4; continue; }   // one task per special block (rows pass only)
+    if (BI_Ix(info) == 0) my_rclass[q] = Log2Cov8(CoveredX(st));
+    if (BI_Iy(info) == 0) my_cclass[q] = Log2Cov8(CoveredY(st));
+  }
+  for (int q = 0; q < 2; q++) {
+    if (my_rclass[q] != 0xFFu) atomicAdd(&s_cnt[my_rclass[q]], 1u);
+    if (my_cclass[q] != 0xFFu) atomicAdd(&s_cnt[5 + my_cclass[q]], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = 0;
+    for (int k = 0; k < 5; k++) { s_cnt[9 + k] = a; a += s_cnt[k]; }          // row cursors (exclusive prefix)
+    // column cursors share the tail of the array: classes 0..3 only; class index 5..8 counts
+  }
+  __shared__ uint32_t s_ccur[4];
+  if (threadIdx.x == 0) { uint32_t a = 0; for (int k = 0; k < 4; k++) { s_ccur[k] = a; a += s_cnt[5 + k]; } }
+  __syncthreads();
+  const uint32_t r_begin[6] = {s_cnt[9], s_cnt[10], s_cnt[11], s_cnt[12], s_cnt[13], s_cnt[13] + s_cnt[4]};
+  const uint32_t c_begin[5] = {s_ccur[0], s_ccur[1], s_ccur[2], s_ccur[3], s_ccur[3] + s_cnt[8]};
+  __syncthreads();
+  for (int q = 0; q < 2; q++) {
+    const uint32_t tt = threadIdx.x + q * 256;
+    if (my_rclass[q] != 0xFFu) s_rtask[atomicAdd(&s_cnt[9 + my_rclass[q]], 1u)] = (uint16_t)tt;
+    if (my_cclass[q] != 0xFFu) s_ctask[atomicAdd(&s_ccur[my_cclass[q]], 1u)] = (uint16_t)tt;
+  }
   const int32_t* cq[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
   const float bias0 = f.quant_bias[0], bias1 = f.quant_bias[1], bias2 = f.quant_bias[2], bias3 = f.quant_bias[3];
   // ---- pass 0: stage dequantised coefficients.  Task = (block of the tile, four of its 64 coefficient slots): 16-byte
@@ -1702,6 +1741,7 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
     const uint32_t s = BI_Strategy(info), ix = BI_Ix(info), iy = BI_Iy(info);
     const uint32_t cx = CoveredX(s), cy = CoveredY(s);
     const uint32_t R = cy * 8, C = cx * 8;
+    const uint32_t lr = 3 + Log2Cov8(cy), lc = 3 + Log2Cov8(cx);
     const uint32_t k0 = (iy * cx + ix) * 64 + j;              // this block's share of the varblock's coefficients
     const uint32_t kind = QuantKind(s);
     const uint32_t base = s_coff[bi] + k0;
@@ -1725,8 +1765,8 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
       const float bv = AdjustQuantBias(qb[e], bias2, bias3) * (wbl[e] * sdb);
       uint32_t v, u;
       if (special) { v = k >> 3; u = k & 7; }                 // kept in stored order for SpecialTransform
-      else if (R >= C) { v = k % R; u = k / R; }
-      else { v = k / C; u = k % C; }
+      else if (R >= C) { v = k & (R - 1); u = k >> lr; }      // (R, C are powers of two)
+      else { v = k >> lc; u = k & (C - 1); }
       const uint32_t lo = (vby * 8 + v) * kTilePitch + vbx * 8 + u;
       s_tile[lo] = fmaf(kx, ydq, xv);
       s_tile[kTilePlane + lo] = ydq;
@@ -1734,52 +1774,48 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
     }
   }
   __syncthreads();
-  // ---- pass 1: rows (3 channels x up to 512 rows)
-  for (uint32_t t = threadIdx.x; t < 512 * 3; t += blockDim.x) {
-    const uint32_t c = t / 512, tt = t % 512;
-    const uint32_t r = tt & 7, bi = tt >> 3;
-    const uint32_t info = s_info[bi];
-    if (info == 0xFFFFFFFFu || BI_Ix(info) != 0) continue;
-    const uint32_t s = BI_Strategy(info), iy = BI_Iy(info);
-    const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
-    const uint32_t bx = bi & 7, by = bi >> 3;
-    const size_t o_first = (size_t)(by0 + by - iy) * f.bw + bx0 + bx;
-    float* blk0 = s_tile + c * kTilePlane + ((by - iy) * 8) * kTilePitch + bx * 8;
-    if (IsSpecial(s)) {
-      if (r != 0) continue;
-      float cf[64];
+  // ---- pass 1: rows, one transform length at a time (3 channels x the class's task list)
+  for (int cls = 0; cls < 5; cls++) {
+    const uint32_t n = r_begin[cls + 1] - r_begin[cls];
+    for (uint32_t t = threadIdx.x; t < n * 3; t += blockDim.x) {
+      const uint32_t c = t / n, tt = s_rtask[r_begin[cls] + (t - c * n)];
+      const uint32_t r = tt & 7, bi = tt >> 3;
+      const uint32_t info = s_info[bi];
+      const uint32_t s = BI_Strategy(info), iy = BI_Iy(info);
+      const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
+      const uint32_t bx = bi & 7, by = bi >> 3;
+      const size_t o_first = (size_t)(by0 + by - iy) * f.bw + bx0 + bx;
+      float* blk0 = s_tile + c * kTilePlane + ((by - iy) * 8) * kTilePitch + bx * 8;
+      if (cls == 4) {
+        float cf[64];
 #pragma unroll
-      for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
-      cf[0] = LdG(f.llf[c] + o_first);
-      SpecialTransform(s, cf, blk0, kTilePitch);
-      continue;
-    }
-    const int v = (int)(iy * 8 + r);
-    float* row0 = blk0 + v * kTilePitch;
-    const float* llf = f.llf[c] + o_first + (size_t)v * f.bw;
-    switch (cx * 8) {
-      case 8: TileRowPass<8>(row0, v, cy, cx, llf); break;
-      case 16: TileRowPass<16>(row0, v, cy, cx, llf); break;
-      case 32: TileRowPass<32>(row0, v, cy, cx, llf); break;
-      default: TileRowPass<64>(row0, v, cy, cx, llf); break;
+        for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
+        cf[0] = LdG(f.llf[c] + o_first);
+        SpecialTransform(s, cf, blk0, kTilePitch);
+        continue;
+      }
+      const int v = (int)(iy * 8 + r);
+      float* row0 = blk0 + v * kTilePitch;
+      const float* llf = f.llf[c] + o_first + (size_t)v * f.bw;
+      if (cls == 0) TileRowPass<8>(row0, v, cy, cx, llf);
+      else if (cls == 1) TileRowPass<16>(row0, v, cy, cx, llf);
+      else if (cls == 2) TileRowPass<32>(row0, v, cy, cx, llf);
+      else TileRowPass<64>(row0, v, cy, cx, llf);
     }
   }
   __syncthreads();
   // ---- pass 2: columns
-  for (uint32_t t = threadIdx.x; t < 512 * 3; t += blockDim.x) {
-    const uint32_t c = t / 512, tt = t % 512;
-    const uint32_t xx = tt & 7, bi = tt >> 3;
-    const uint32_t info = s_info[bi];
-    if (info == 0xFFFFFFFFu || BI_Iy(info) != 0) continue;
-    const uint32_t s = BI_Strategy(info);
-    if (IsSpecial(s)) continue;
-    const uint32_t bx = bi & 7, by = bi >> 3;
-    float* col0 = s_tile + c * kTilePlane + (by * 8) * kTilePitch + bx * 8 + xx;
-    switch ((int)CoveredY(s) * 8) {
-      case 8: TileColPass<8>(col0); break;
-      case 16: TileColPass<16>(col0); break;
-      case 32: TileColPass<32>(col0); break;
-      default: TileColPass<64>(col0); break;
+  for (int cls = 0; cls < 4; cls++) {
+    const uint32_t n = c_begin[cls + 1] - c_begin[cls];
+    for (uint32_t t = threadIdx.x; t < n * 3; t += blockDim.x) {
+      const uint32_t c = t / n, tt = s_ctask[c_begin[cls] + (t - c * n)];
+      const uint32_t xx = tt & 7, bi = tt >> 3;
+      const uint32_t bx = bi & 7, by = bi >> 3;
+      float* col0 = s_tile + c * kTilePlane + (by * 8) * kTilePitch + bx * 8 + xx;
+      if (cls == 0) TileColPass<8>(col0);
+      else if (cls == 1) TileColPass<16>(col0);
+      else if (cls == 2) TileColPass<32>(col0);
+      else TileColPass<64>(col0);
     }
   }
   __syncthreads();
