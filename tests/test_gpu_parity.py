@@ -352,6 +352,36 @@ def test_default_4x_8x_upsampling_weights_are_rejected(jx):
         jx.decoder_builder().decode_with(data, np.uint8)
 
 
+def test_corrupted_streams_fail_cleanly_or_decode(jx):
+    """Robustness: random byte corruption in the section payloads (VarDCT and Modular streams) must end in a DecodeError or
+    a decode of the right size — never a crash or a hang (the kernels bound every loop by the frame geometry and read
+    zeros past the end of a section)."""
+    rng = np.random.default_rng(123)
+    img = S.synthetic_image(70, 300, 280)
+    al = (np.arange(300 * 280) % 251).astype(np.uint8).reshape(280, 300)
+    streams = [S.encode_vardct(img, seed=2, strategy_mix=2, epf_iters=2, gab=1, alpha=al),
+               S.encode_modular(_smooth_image(8, 280, 300, 3, 8), 8, True, 1),
+               S.encode_vardct(img, seed=2, strategy_mix=4, upsampling=2)]
+    outcomes = {"error": 0, "decoded": 0}
+    for data in streams:
+        for trial in range(24):
+            bad = bytearray(data)
+            n = 1 + trial % 4
+            for pos in rng.integers(24, len(bad), n):        # keep the signature / size header so the decode reaches the GPU
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if trial % 6 == 5:
+                bad = bad[: int(rng.integers(len(bad) // 2, len(bad)))]   # truncation
+            try:
+                meta, px = jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+                assert len(px) == meta.width * meta.height * (4 if meta.has_alpha_channel else 3)
+                outcomes["decoded"] += 1
+            except jx.DecodeError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 0 and outcomes["error"] + outcomes["decoded"] == 72
+    # the decoder is still healthy afterwards
+    check_against_oracle(jx, streams[0], np.uint8, 4)
+
+
 def _orient(a, o):
     """EXIF-style orientation o applied to an (h, w, c) array (codestream_header.rs JxlOrientation)."""
     return {1: lambda v: v, 2: lambda v: v[:, ::-1], 3: lambda v: v[::-1, ::-1], 4: lambda v: v[::-1], 5: lambda v: v.transpose(1, 0, 2),
