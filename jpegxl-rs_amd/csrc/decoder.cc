@@ -20,8 +20,8 @@ size_t Align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 struct ConstOffsets {
   size_t cs = 0, sec_off = 0, sec_size = 0, tree = 0, bcm = 0;
   size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0, mod_chan = 0, up_weights = 0;
-  size_t ac_ctx = 0, ac_cfg = 0, ac_alias = 0, ac_pc = 0, ac_po = 0, ac_ps = 0;
-  size_t orders[39] = {0};
+  struct Pass { size_t ac_ctx = 0, ac_cfg = 0, ac_alias = 0, ac_pc = 0, ac_po = 0, ac_ps = 0; size_t orders[39] = {0}; };
+  std::vector<Pass> pass;
   size_t qtable[17 * 3] = {0};
   bool has_qtable[17] = {false};
 };
@@ -62,6 +62,7 @@ Batch::~Batch() {
   if (dwork_) (void)hipFree(dwork_);
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   if (dframes_) (void)hipFree(dframes_);
+  if (dpasses_) (void)hipFree(dpasses_);
 }
 
 // The coefficient and pixel planes are only touched by the "rest" half of a decode (HF decode ... write), which a caller
@@ -194,7 +195,7 @@ void Batch::Prepare(void* stream_v) {
     return true;
   };
   max_lf_groups_ = max_groups_ = max_w_ = max_h_ = max_bw_ = max_bh_ = max_epf_ = 0;
-  any_gab_ = any_vardct_ = any_modular_ = any_modchan_ = false;
+  any_gab_ = any_vardct_ = any_modular_ = any_modchan_ = any_multipass_ = false;
   fplan_ = FilterPlan();
   for (int i = 0; i < n; i++) {
     ImageEntry& e = *images_[i];
@@ -398,8 +399,17 @@ void Batch::Prepare(void* stream_v) {
       f.lf_scratch = (int32_t*)(dwork_ + o.lf_scratch); f.lf_scratch_stride = o.lf_scratch_stride;
       // HfGlobal-derived fields (present once parsed)
       if (!p.ac_code.empty()) {
-        f.ac_code = ViewCode(p.ac_code[0], cbase, c.ac_ctx, c.ac_cfg, c.ac_alias, c.ac_pc, c.ac_po, c.ac_ps);
-        for (int k = 0; k < 39; k++) f.orders[k] = (const uint16_t*)(cbase + c.orders[k]);
+        f.num_passes = p.num_passes;
+        f.passes = dpasses_ + pass_first_[i];
+        for (uint32_t ps = 0; ps < p.num_passes; ps++) {
+          const ConstOffsets::Pass& cp = c.pass[ps];
+          PassDev& pd = passes_host_[pass_first_[i] + ps];
+          pd.code = ViewCode(p.ac_code[ps], cbase, cp.ac_ctx, cp.ac_cfg, cp.ac_alias, cp.ac_pc, cp.ac_po, cp.ac_ps);
+          for (int k = 0; k < 39; k++) pd.orders[k] = (const uint16_t*)(cbase + cp.orders[k]);
+          pd.shift = ps + 1 < p.num_passes ? p.pass_shift[ps] : 0; pd.pad = 0;
+        }
+        f.ac_code = passes_host_[pass_first_[i]].code;
+        for (int k = 0; k < 39; k++) f.orders[k] = passes_host_[pass_first_[i]].orders[k];
         for (int k = 0; k < 17 * 3; k++) f.qtable[k] = c.has_qtable[k / 3] ? (const float*)(cbase + c.qtable[k]) : nullptr;
         f.num_hf_presets = p.num_hf_presets;
         uint32_t bits = 0; while ((1u << bits) < p.num_hf_presets) bits++;
@@ -457,11 +467,16 @@ void Batch::Prepare(void* stream_v) {
     FramePlan& p = e.plan;
     ConstOffsets& c = co[i];
     if (p.modular) continue;
-    PutCode(arena, p.ac_code[0], &c.ac_ctx, &c.ac_cfg, &c.ac_alias, &c.ac_pc, &c.ac_po, &c.ac_ps);
-    for (int b = 0; b < 13; b++) for (int ch = 0; ch < 3; ch++) {
-      const auto& cu = p.custom_order[b * 3 + ch];
-      c.orders[b * 3 + ch] = cu.empty() ? natural_off[b] : arena.Put(cu.data(), cu.size() * 2);
+    c.pass.assign(p.num_passes, ConstOffsets::Pass());
+    for (uint32_t ps = 0; ps < p.num_passes; ps++) {
+      ConstOffsets::Pass& cp = c.pass[ps];
+      PutCode(arena, p.ac_code[ps], &cp.ac_ctx, &cp.ac_cfg, &cp.ac_alias, &cp.ac_pc, &cp.ac_po, &cp.ac_ps);
+      for (int b = 0; b < 13; b++) for (int ch = 0; ch < 3; ch++) {
+        const auto& cu = p.custom_order[(size_t)ps * 39 + b * 3 + ch];
+        cp.orders[b * 3 + ch] = cu.empty() ? natural_off[b] : arena.Put(cu.data(), cu.size() * 2);
+      }
     }
+    if (p.num_passes > 1) any_multipass_ = true;
     for (int k = 0; k < 17; k++) {
       if (k == 10) continue;         // AFV
       int hit = -1;
@@ -501,15 +516,25 @@ void Batch::Prepare(void* stream_v) {
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
       if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); }
-      if (!p.modular) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(p.ac_code[0], true));
+      if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
     }
+  }
+  {  // per-pass table descriptors (device array next to the frame descriptors)
+    pass_first_.assign(n, 0);
+    size_t total = 0;
+    for (int i = 0; i < n; i++) { pass_first_[i] = total; total += images_[i]->plan.modular ? 0 : images_[i]->plan.num_passes; }
+    passes_host_.assign(std::max<size_t>(total, 1), PassDev());
+    if (dpasses_) { (void)hipFree(dpasses_); dpasses_ = nullptr; }
+    HIP_CHECK(hipMalloc((void**)&dpasses_, sizeof(PassDev) * passes_host_.size()));
   }
   const_size_ = Align(hconst_.size());
   HIP_CHECK(hipMalloc((void**)&dconst_, const_size_));
   HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
   for (int i = 0; i < n; i++) fill_frame(i, dconst_);
   HIP_CHECK(hipMemcpyAsync(dframes_, frames_host_.data(), sizeof(FrameDev) * n, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipMemcpyAsync(dpasses_, passes_host_.data(), sizeof(PassDev) * passes_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
+  if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
   prepared_ = true;
 }
 

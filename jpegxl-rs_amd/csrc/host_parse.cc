@@ -640,7 +640,8 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   if (p->flags & 2) Unsupported("patches");
   if (p->flags & 16) Unsupported("splines");
   if (p->flags & 1) Unsupported("noise");
-  if (p->num_passes != 1) Unsupported("multiple passes");
+  if (p->num_passes != 1 && p->modular) Unsupported("multi-pass Modular frame");
+  if (p->num_passes > 11) Fail("number of passes");
   p->width = fx; p->height = fy;
   p->group_dim = p->modular ? (128u << p->group_size_shift) : 256u;
   p->xgroups = (fx + p->group_dim - 1) / p->group_dim; p->ygroups = (fy + p->group_dim - 1) / p->group_dim;

@@ -8,6 +8,9 @@ namespace jxlhip {
 // plane location in the work arena, dimensions and the squeeze shifts that decide which section carries it.
 struct ModChanDev { uint64_t off; uint32_t w, h; int32_t hshift, vshift; };
 
+// Per-pass tables of a VarDCT frame (HfPass in the codestream): entropy code, coefficient orders, left shift of the values.
+struct PassDev { DevCode code; const uint16_t* orders[39]; uint32_t shift; uint32_t pad; };
+
 // One per frame of a batch; array lives in device memory.  All pointers are device pointers.
 struct FrameDev {
   // geometry
@@ -32,6 +35,8 @@ struct FrameDev {
   const uint16_t* orders[39];
   const BlockCtxDev* bcm;
   uint32_t num_hf_presets, preset_bits;
+  uint32_t num_passes;            // progressive passes: PassGroup section (p, g) adds value << passes[p].shift to the coefficients
+  const PassDev* passes;          // [num_passes]; ac_code / orders above are pass 0's
   // dequant
   float lf_fac[3], cfl_lf_x, cfl_lf_b;
   float inv_global_scale, x_dm, b_dm, quant_bias[4], color_scale, base_x, base_b;

@@ -963,6 +963,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   uint64_t limit;
   if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
   else { const uint32_t si = 2 + f.num_lf_groups + g; const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
+  if (f.num_passes != 1) { SetError(f, kErrUnsupported); return; }   // progressive frames go through the SIMT kernel (the host forces it)
   const BlockCtxDev& bcm = *f.bcm;
   const uint32_t nctx = bcm.num_ctxs;
   const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
@@ -1120,14 +1121,21 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     const uint32_t* src = reinterpret_cast<const uint32_t*>(f.bcm);
     for (uint32_t i = threadIdx.x; i < sizeof(BlockCtxDev) / 4; i += blockDim.x) StS<uint32_t>(kSimtBcmOff + i * 4, LdG(src + i));
   }
-  StageCode(f.ac_code, code, kSimtCodeOff, lds_bytes > kSimtCodeOff ? lds_bytes - kSimtCodeOff : 0, /*with_ctx_map=*/true);
   const bool ord_lds = false;
   int32_t* const cbase0 = f.coeff[0]; int32_t* const cbase1 = f.coeff[1]; int32_t* const cbase2 = f.coeff[2];
+  const uint32_t g = blockIdx.x * kSimtThreads + threadIdx.x;
+  bool dead = g >= f.num_groups;                       // no stream, or a stream that failed in an earlier pass
+  const uint32_t nz_base = kSimtNzOff + threadIdx.x * 96;
+  // Progressive frames: PassGroup section (pass, g) carries value >> shift of every coefficient under the pass's own code
+  // and orders; the values accumulate.  The tables are re-staged per pass (block-wide), the lanes restart their streams.
+  for (uint32_t pass = 0; pass < f.num_passes; pass++) {
+  const PassDev& pd = f.passes[pass];
+  const uint32_t shift = pd.shift;
+  if (pass) __syncthreads();                           // every lane is done with the previous pass's tables
+  StageCode(pd.code, code, kSimtCodeOff, lds_bytes > kSimtCodeOff ? lds_bytes - kSimtCodeOff : 0, /*with_ctx_map=*/true);
   __syncthreads();
   if (ALL_LDS && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
-  const uint32_t g = blockIdx.x * kSimtThreads + threadIdx.x;
-  bool done = g >= f.num_groups;
-  const uint32_t nz_base = kSimtNzOff + threadIdx.x * 96;
+  bool done = dead;
   for (uint32_t i = 0; i < 24; i++) StS<uint32_t>(nz_base + i * 4, 0u);
   constexpr uint32_t oNLf = kSimtBcmOff + offsetof(BlockCtxDev, n_lf_thr), oQf = kSimtBcmOff + offsetof(BlockCtxDev, qf_thr);
   constexpr uint32_t oLf = kSimtBcmOff + offsetof(BlockCtxDev, lf_thr), oMap = kSimtBcmOff + offsetof(BlockCtxDev, ctx_map);
@@ -1140,7 +1148,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   // ---- per-lane bit-stream ring
   uint64_t bit0, byte_end;
   if (f.single_section) { bit0 = f.hf_start_bitpos; byte_end = f.cs_size; }
-  else { const uint32_t si = 2 + f.num_lf_groups + gsafe; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); bit0 = off * 8; byte_end = off + sz; }
+  else { const uint32_t si = 2 + f.num_lf_groups + pass * f.num_groups + gsafe; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); bit0 = off * 8; byte_end = off + sz; }
   const uint64_t limit = byte_end * 8;
   const uint32_t* words = reinterpret_cast<const uint32_t*>(f.cs);
   const uint32_t wend = (uint32_t)((byte_end + 3) >> 2);
@@ -1162,7 +1170,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   uint32_t ctx_offset = 0, state = 0;
   if (!done) {
     const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
-    if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); done = true; }
+    if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); done = true; dead = true; }
     ctx_offset = 495u * nctx * preset;
     state = br.Read(32);
   }
@@ -1174,7 +1182,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   uint32_t phase = 0;                     // 0: start next varblock, 1: read nzeros, 2: read a coefficient
   uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, cx = 1, coff = 0, qf_idx = 0, lf_idx = 0;
   uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, order_off = 0;
-  const uint16_t* order = f.orders[0];
+  const uint16_t* order = pd.orders[0];
   int32_t* blk = cbase0;
   uint32_t iter = 0;
   while (__ballot(!done) != 0ull) {
@@ -1187,9 +1195,9 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     iter++;
     if (!done && phase == 0) {
       if (vi >= nvb) {
-        if (state != 0x130000u) SetError(f, kErrAnsFinalState);
-        else if (br.BitPos() > limit) SetError(f, kErrOverrun);
-        else if (f.hf_end_bitpos) f.hf_end_bitpos[g] = br.BitPos();
+        if (state != 0x130000u) { SetError(f, kErrAnsFinalState); dead = true; }
+        else if (br.BitPos() > limit) { SetError(f, kErrOverrun); dead = true; }
+        else if (f.hf_end_bitpos && pass + 1 == f.num_passes) f.hf_end_bitpos[g] = br.BitPos();   // the Modular part follows the last pass
         done = true;
       } else {
         const uint2 ent = ent_next;
@@ -1239,28 +1247,33 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
       const uint32_t u = HybridSimt<ALL_LDS>(br, state, code, ctx);
       if (phase == 1) {
         nzeros = u;
-        if (nzeros + covered > size) { SetError(f, kErrNzeros); done = true; }
+        if (nzeros + covered > size) { SetError(f, kErrNzeros); done = true; dead = true; }
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
         for (uint32_t ix = 0; ix < cx; ix++) StS<uint8_t>(nz_base + c * 32 + bx + ix, (uint8_t)nzm);
         blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + (size_t)g * 65536 + coff;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
         if (ord_lds) order_off = OrderLdsOffset(ord);
-        else { order = f.orders[ord * 3 + c]; next_pos = LdG(order + k); }
+        else { order = pd.orders[ord * 3 + c]; next_pos = LdG(order + k); }
         phase = 2;
       } else {
         uint32_t pos;
         if (ord_lds) pos = LdS<uint16_t>(order_off + 2 * k);
         else { pos = next_pos; if (k + 1 < size) next_pos = LdG(order + k + 1); }
-        if (u) StG(blk + pos, UnpackSigned(u));
+        if (u) {
+          int32_t val = (int32_t)((uint32_t)UnpackSigned(u) << shift);
+          if (pass) val = (int32_t)((uint32_t)val + (uint32_t)LdG(blk + pos));
+          StG(blk + pos, val);
+        }
         prev = u != 0;
         nzeros -= prev;
         k++;
-        if (nzeros != 0 && k >= size) { SetError(f, kErrNzeros); done = true; }
+        if (nzeros != 0 && k >= size) { SetError(f, kErrNzeros); done = true; dead = true; }
       }
       if (phase == 2 && nzeros == 0) { ci++; phase = ci == 3 ? 0 : 1; }
     }
   }
+  }  // passes
 }
 
 // =====================================================================================================================
@@ -2303,7 +2316,8 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   __shared__ GroupHeaderD s_gh_w[kLfWaves];
   int& s_go = s_go_w[wave];
   GroupHeaderD& s_gh = s_gh_w[wave];
-  const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + g;
+  const uint32_t last_pass = f.is_modular ? 0 : f.num_passes - 1;       // VarDCT: extra channels ride in the last pass
+  const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + last_pass * f.num_groups + g;
   const uint64_t sec_end = f.sec_off[si] + f.sec_size[si];
   BitReaderP br;
   br.Init(f.cs, f.sec_off[si] * 8, sec_end);
@@ -2328,7 +2342,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   if (!s_go) return;
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
-  mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + g;
+  mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
   mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
   int k = 0;
   for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) DecodeChannelCoop(br, state, T, mc, d, k++);
@@ -2387,7 +2401,8 @@ __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restr
     unsigned long long used = 0;
     if (nch > 0) {
       if (f.single_section) ok = false;  // a one-group frame decodes every channel globally
-      const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + g;
+      const uint32_t last_pass = f.is_modular ? 0 : f.num_passes - 1;
+      const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + last_pass * f.num_groups + g;
       BitReader br;
       uint64_t limit = 0;
       if (ok) {
@@ -2399,7 +2414,7 @@ __global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restr
       ok = ok && ReadGroupHeader(br, s_gh) && s_gh.use_global_tree;
       ModularCtx mc;
       mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
-      mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + g;
+      mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
       mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
       if (ok && s_gh.ntransforms == 0) {
         nch = 0;   // no local transforms: ModularGroupFastKernel decodes these sub-streams in place

@@ -486,7 +486,7 @@ inline void ReadPassGroup(BitReader& br, Frame& f, int pass_idx, int g) {
   int min_shift = 0, max_shift = 2;
   if (f.fh.passes.num_passes > 1) {
     // dec_frame.cc: per-pass shift ranges derived from downsampling
-    int maxs = 2, mins = 0;
+    int maxs = 2, mins = 3;   // passes.h GetDownsamplingBracket: maxShift = 2, minShift = 3 to start with
     uint32_t np = f.fh.passes.num_passes;
     // passes.GetDownsamplingBracket
     for (uint32_t i = 0;; i++) {

@@ -352,6 +352,23 @@ def test_default_4x_8x_upsampling_weights_are_rejected(jx):
         jx.decoder_builder().decode_with(data, np.uint8)
 
 
+@pytest.mark.parametrize("npass,with_alpha,w,h", [(2, False, 200, 136), (3, False, 600, 400), (2, True, 600, 400), (3, True, 1030, 270)])
+def test_progressive_passes(jx, npass, with_alpha, w, h):
+    """Multi-pass (progressive) VarDCT frames: every PassGroup section (pass, group) adds value << shift under the pass's own
+    entropy code; alpha rides in the last pass.  The pixels must equal the single-pass encoding of the same coefficients."""
+    img = S.synthetic_image(80, w, h)
+    al = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8) if with_alpha else None
+    data = S.encode_vardct(img, seed=6, strategy_mix=2, epf_iters=1, gab=1, num_passes=npass, alpha=al)
+    nch = 4 if with_alpha else 3
+    _, px = check_against_oracle(jx, data, np.uint8, nch)
+    check_against_oracle(jx, data, np.float32, nch)
+    _, one = jx.decoder_builder().decode_with(S.encode_vardct(img, seed=6, strategy_mix=2, epf_iters=1, gab=1, alpha=al), np.uint8)
+    assert np.array_equal(px, one)
+    b = jx.BatchDecoder(0)            # a lane-stride setting that would pick the per-wavefront HF kernel is overridden
+    b.add(data, "uint8", nch); b.set_lane_stride(64, 64); b.prepare(); b.decode(); b.finish()
+    assert np.array_equal(b.output(0), px)
+
+
 def test_corrupted_streams_fail_cleanly_or_decode(jx):
     """Robustness: random byte corruption in the section payloads (VarDCT and Modular streams) must end in a DecodeError or
     a decode of the right size — never a crash or a hang (the kernels bound every loop by the frame geometry and read

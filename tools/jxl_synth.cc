@@ -83,7 +83,8 @@ struct Params {
   int orientation = 1;    // EXIF-style 1..8, written to the image header
   int upsampling = 1;     // 1 | 2 | 4 | 8: the frame is coded at 1/upsampling of the image size
   int custom_up_weights = 0;  // 1: the image header carries explicit upsampling weights (required for 4x / 8x here)
-  int reserved[5] = {0};
+  int num_passes = 1;     // 1..3: coefficients split into bit planes (pass p carries value >> shift[p], the last pass the remainder)
+  int reserved[4] = {0};
 };
 
 // ---- modular sub-stream tokenisation with the fixed global tree --------------------------------------------------
@@ -260,6 +261,9 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
   w.align();
 }
 
+// bit-plane split of the passes: 2 passes -> shifts {2, 0}; 3 passes -> {3, 1, 0}
+static int PassShift(int num_passes, int pass) { return pass + 1 == num_passes ? 0 : (num_passes == 2 ? 2 : (pass == 0 ? 3 : 1)); }
+
 static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool xyb, int num_extra, int group_shift, bool lf_default) {
   w.put(0, 1);  // all_default
   w.put(0, 2);  // regular frame
@@ -271,7 +275,12 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   for (int i = 0; i < num_extra; i++) w.put(ups_sel, 2);   // ec_upsampling: same factor
   if (modular) w.put(group_shift, 2);
   if (!modular && xyb) { w.put(3, 3); w.put(2, 3); }
-  w.put(0, 2);  // num_passes = 1
+  const int np = modular ? 1 : p.num_passes;
+  w.put((uint32_t)(np - 1), 2);  // num_passes (1, 2, 3)
+  if (np != 1) {
+    w.put(0, 2);                                         // num_downsample = 0
+    for (int i = 0; i + 1 < np; i++) w.put((uint32_t)PassShift(np, i), 2);   // shift of every pass but the last
+  }
   w.put(0, 1);  // have_crop
   // blending info (+ one per extra channel)
   for (int i = 0; i < 1 + num_extra; i++) w.put(0, 2);  // mode Replace
@@ -526,7 +535,21 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   }
   // --- tokens: AC per group
   const int nctx = 15;
-  std::vector<std::vector<Token>> ac_tok(ngroups);
+  const int np = p.num_passes;
+  // per-pass coefficient planes: pass p carries (remainder >> shift[p]); the decoder adds value << shift
+  std::vector<std::vector<int32_t>> qpass[3];
+  for (int c = 0; c < 3; c++) {
+    qpass[c].assign(np, std::vector<int32_t>());
+    std::vector<int32_t> rem = qc[c];
+    for (int ps = 0; ps < np; ps++) {
+      const int sh = PassShift(np, ps);
+      qpass[c][ps].resize(rem.size());
+      for (size_t i = 0; i < rem.size(); i++) { const int32_t a = rem[i] >> sh; qpass[c][ps][i] = a; rem[i] -= a * (1 << sh); }
+    }
+  }
+  std::vector<std::vector<Token>> ac_tok_all((size_t)ngroups * np);
+  for (int ps = 0; ps < np; ps++) {
+  std::vector<Token>* ac_tok = &ac_tok_all[(size_t)ps * ngroups];
   std::vector<uint32_t> natural[13];
   static const int bucket_rep[13] = {S_DCT, S_IDENTITY, S_DCT16X16, S_DCT32X32, S_DCT16X8, S_DCT32X8, S_DCT32X16, S_DCT64X64, S_DCT64X32, 21, 22, 24, 25};
   for (int b = 0; b < 13; b++) natural[b] = NaturalOrder(bucket_rep[b]);
@@ -546,7 +569,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
         int c = chan[ci];
         int idx = (c < 2 ? (c ^ 1) : 2) * 13 + ord;
         int block_ctx = kDefaultBlockCtx[idx];
-        const int32_t* q = qc[c].data() + coff[o];
+        const int32_t* q = qpass[c][ps].data() + coff[o];
         int nz = 0;
         for (int k = covered; k < size; k++) nz += q[order[k]] != 0;
         int pred;
@@ -572,6 +595,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
       }
     }
   }
+  }  // passes
   // --- optional alpha: one 8-bit extra channel coded losslessly by the frame's Modular sub-streams (GlobalModular when
   // the image fits one group, else the modular part of every PassGroup), under the same global tree
   std::vector<Token> alpha_global_tok;
@@ -589,18 +613,21 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
         std::vector<int32_t> rect((size_t)gw * gh);
         for (int y = 0; y < gh; y++) memcpy(&rect[(size_t)y * gw], &a32[(size_t)(y0 + y) * w + x0], sizeof(int32_t) * gw);
         std::vector<ChanRef> cr{{rect.data(), gw, gh}};
-        ModularTokens(gt, root, cr, 1 + 3 * nlf + 17 + g, alpha_tok[g]);
+        ModularTokens(gt, root, cr, 1 + 3 * nlf + 17 + ngroups * (p.num_passes - 1) + g, alpha_tok[g]);
       }
     }
   }
   // --- entropy codes
-  EntropyCoder tree_code, mod_code, ac_code;
+  EntropyCoder tree_code, mod_code;
+  std::vector<EntropyCoder> ac_codes(np);
   { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
   { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); }
     s.push_back(&alpha_global_tok); for (auto& t : alpha_tok) s.push_back(&t);
     BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 32, mod_code); }
-  { std::vector<const std::vector<Token>*> s; for (auto& t : ac_tok) s.push_back(&t);
-    BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_code); }
+  for (int ps = 0; ps < np; ps++) {
+    std::vector<const std::vector<Token>*> s; for (int g = 0; g < ngroups; g++) s.push_back(&ac_tok_all[(size_t)ps * ngroups + g]);
+    BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_codes[ps]);
+  }
   // --- sections
   std::vector<BitWriter> sections;
   {  // LfGlobal
@@ -652,22 +679,25 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
       }
     }
     s.put(0, CeilLog2((uint32_t)ngroups));  // num_hf_presets - 1
-    s.put(2, 2);                            // used_orders = Val(0)
-    WriteEntropyCode(s, ac_code);
+    for (int ps = 0; ps < np; ps++) {       // HfPass: natural orders, one entropy code per pass
+      s.put(2, 2);                          // used_orders = Val(0)
+      WriteEntropyCode(s, ac_codes[ps]);
+    }
     sections.push_back(s);
   }
-  for (int g = 0; g < ngroups; g++) {  // PassGroup
+  for (int ps = 0; ps < np; ps++) for (int g = 0; g < ngroups; g++) {  // PassGroup, pass-major
     BitWriter s;
     // preset: ceil_log2(1) = 0 bits
-    EncodeTokens(s, ac_code, ac_tok[g]);
-    if (alpha && !alpha_global) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, mod_code, alpha_tok[g]); }
+    EncodeTokens(s, ac_codes[ps], ac_tok_all[(size_t)ps * ngroups + g]);
+    // extra channels (shift 0..2) ride in the last pass (Passes::GetDownsamplingBracket without downsampling entries)
+    if (alpha && !alpha_global && ps == np - 1) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, mod_code, alpha_tok[g]); }
     sections.push_back(s);
   }
   BitWriter out;
   WriteImageHeader(out, img_w, img_h, p, true, p.out_bits == 16 ? 16 : 8, alpha != nullptr, false);
   bool lf_default = p.gab == 1 && p.epf_iters == 2;
   WriteFrameHeader(out, p, false, true, alpha ? 1 : 0, 1, lf_default);
-  WriteTOCAndSections(out, sections, ngroups == 1);
+  WriteTOCAndSections(out, sections, ngroups == 1 && np == 1);
   out.align();
   return out.bytes;
 }
@@ -886,7 +916,7 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
 // ---- C API ---------------------------------------------------------------------------------------------------------
 extern "C" {
 struct jxlsynth_params {
-  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation, upsampling, custom_up_weights; int32_t reserved[5];
+  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation, upsampling, custom_up_weights, num_passes; int32_t reserved[4];
 };
 static thread_local std::string g_err;
 const char* jxlsynth_last_error() { return g_err.c_str(); }
@@ -913,6 +943,7 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
     p.orientation = pp->orientation >= 1 && pp->orientation <= 8 ? pp->orientation : 1;
     p.upsampling = (pp->upsampling == 2 || pp->upsampling == 4 || pp->upsampling == 8) ? pp->upsampling : 1;
     p.custom_up_weights = pp->custom_up_weights;
+    p.num_passes = pp->num_passes >= 1 && pp->num_passes <= 3 ? pp->num_passes : 1;
     std::vector<float> pl[3];
     for (auto& v : pl) v.resize((size_t)w * h);
     const float scale = p.hdr ? 255.0f / 1000.0f : 1.0f;  // intensity_target 1000: linear 1.0 == 1000 nits
