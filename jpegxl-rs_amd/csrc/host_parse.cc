@@ -652,14 +652,32 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   // ---- TOC
   p->single_section = p->num_groups == 1 && p->num_passes == 1;
   size_t n = p->single_section ? 1 : 1 + p->num_lf_groups + 1 + (size_t)p->num_groups * p->num_passes;
-  if (r.b()) Unsupported("permuted TOC");
+  // toc.cc ReadToc: an optional Lehmer-coded permutation says where logical section i is stored
+  std::vector<uint32_t> perm;
+  if (r.b()) {
+    HostCode pc;
+    ReadEntropyCode(r, 8, &pc);
+    HostSymbolReader sr(r, pc);
+    auto ctxof = [](uint32_t v) { uint32_t t = v == 0 ? 0 : 1 + FloorLog2(v); return std::min<uint32_t>(t, 7); };
+    const uint32_t end = sr.Read(ctxof((uint32_t)n));
+    if (end > n) Fail("TOC permutation size");
+    std::vector<uint32_t> lehmer(n, 0), temp(n);
+    uint32_t last = 0;
+    for (size_t i = 0; i < end; i++) { lehmer[i] = sr.Read(ctxof(last)); last = lehmer[i]; if (lehmer[i] >= n - i) Fail("TOC lehmer code"); }
+    sr.CheckFinal();
+    for (size_t i = 0; i < n; i++) temp[i] = (uint32_t)i;
+    perm.resize(n);
+    for (size_t i = 0; i < n; i++) { perm[i] = temp[lehmer[i]]; temp.erase(temp.begin() + lehmer[i]); }
+  }
   r.align();
   std::vector<uint64_t> sizes(n);
   for (auto& s : sizes) s = r.U32({10, 0}, {14, 1024}, {22, 17408}, {30, 4211712});
   r.align();
   uint64_t off = r.pos() / 8;
+  std::vector<Section> phys(n);
+  for (size_t i = 0; i < n; i++) { phys[i] = {off, sizes[i]}; off += sizes[i]; }
   p->sections.resize(n);
-  for (size_t i = 0; i < n; i++) { p->sections[i] = {off, sizes[i]}; off += sizes[i]; }
+  for (size_t i = 0; i < n; i++) p->sections[i] = perm.empty() ? phys[i] : phys[perm[i]];
   if (off > cs.size) throw ParseError("truncated", false);
   // ---- LfGlobal
   Reader rg(cs, p->sections[0].offset * 8);

@@ -369,6 +369,19 @@ def test_progressive_passes(jx, npass, with_alpha, w, h):
     assert np.array_equal(b.output(0), px)
 
 
+def test_permuted_toc(jx):
+    """Sections stored in a shuffled order with the Lehmer-coded permutation in the TOC (what cjxl emits for centre-first /
+    progressive orderings): same pixels as the in-order stream."""
+    img = S.synthetic_image(81, 600, 400)
+    plain = S.encode_vardct(img, seed=7, strategy_mix=2)
+    _, want = jx.decoder_builder().decode_with(plain, np.uint8)
+    for kw in ({"permute_toc": 7}, {"permute_toc": 9, "num_passes": 2}):
+        data = S.encode_vardct(img, seed=7, strategy_mix=2, **kw)
+        assert data != plain
+        _, px = check_against_oracle(jx, data, np.uint8, 3)
+        assert np.array_equal(px, want)
+
+
 def test_corrupted_streams_fail_cleanly_or_decode(jx):
     """Robustness: random byte corruption in the section payloads (VarDCT and Modular streams) must end in a DecodeError or
     a decode of the right size — never a crash or a hang (the kernels bound every loop by the frame geometry and read

@@ -84,7 +84,8 @@ struct Params {
   int upsampling = 1;     // 1 | 2 | 4 | 8: the frame is coded at 1/upsampling of the image size
   int custom_up_weights = 0;  // 1: the image header carries explicit upsampling weights (required for 4x / 8x here)
   int num_passes = 1;     // 1..3: coefficients split into bit planes (pass p carries value >> shift[p], the last pass the remainder)
-  int reserved[4] = {0};
+  int permute_toc = 0;    // != 0: sections stored in a shuffled order (seed), TOC carries the permutation
+  int reserved[3] = {0};
 };
 
 // ---- modular sub-stream tokenisation with the fixed global tree --------------------------------------------------
@@ -304,7 +305,39 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   WriteU64(w, 0);  // frame extensions
 }
 
-static void WriteTOCAndSections(BitWriter& out, const std::vector<BitWriter>& sections, bool single) {
+static void WriteTOCAndSections(BitWriter& out, const std::vector<BitWriter>& sections, bool single, uint32_t permute_seed = 0) {
+  if (!single && permute_seed) {
+    // permuted TOC (toc.cc): logical section i is stored at position perm[i]; here the storage order is a seeded shuffle
+    const size_t n = sections.size();
+    std::vector<uint32_t> store(n);                 // store[j] = logical index kept at storage position j
+    for (size_t i = 0; i < n; i++) store[i] = (uint32_t)i;
+    Pcg32 rng(permute_seed);
+    for (size_t i = n - 1; i > 0; i--) std::swap(store[i], store[rng.next() % (i + 1)]);
+    std::vector<uint32_t> perm(n);
+    for (size_t j = 0; j < n; j++) perm[store[j]] = (uint32_t)j;
+    std::vector<uint32_t> temp(n), lehmer(n);
+    for (size_t i = 0; i < n; i++) temp[i] = (uint32_t)i;
+    for (size_t i = 0; i < n; i++) { const auto it = std::find(temp.begin(), temp.end(), perm[i]); lehmer[i] = (uint32_t)(it - temp.begin()); temp.erase(it); }
+    size_t end = n;
+    while (end > 0 && lehmer[end - 1] == 0) end--;
+    auto ctxof = [](uint32_t v) { uint32_t t = 0; while (v) { t++; v >>= 1; } return std::min<uint32_t>(t, 7); };
+    std::vector<Token> tok;
+    tok.push_back({ctxof((uint32_t)n), (uint32_t)end});
+    uint32_t last = 0;
+    for (size_t i = 0; i < end; i++) { tok.push_back({ctxof(last), lehmer[i]}); last = lehmer[i]; }
+    EntropyCoder code;
+    { std::vector<const std::vector<Token>*> ts{&tok}; BuildEntropyCoder(ts, 8, UintConfig{4, 2, 0}, 8, code); }
+    out.put(1, 1);
+    WriteEntropyCode(out, code);
+    EncodeTokens(out, code, tok);
+    out.align();
+    std::vector<BitWriter> al(n);
+    for (size_t j = 0; j < n; j++) { al[j] = sections[store[j]]; al[j].align(); }
+    for (auto& s : al) WriteU32(out, (uint32_t)s.bytes.size(), {10, 0}, {14, 1024}, {22, 17408}, {30, 4211712});
+    out.align();
+    for (auto& s : al) out.bytes.insert(out.bytes.end(), s.bytes.begin(), s.bytes.end());
+    return;
+  }
   out.put(0, 1);  // not permuted
   out.align();
   if (single) {
@@ -697,7 +730,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   WriteImageHeader(out, img_w, img_h, p, true, p.out_bits == 16 ? 16 : 8, alpha != nullptr, false);
   bool lf_default = p.gab == 1 && p.epf_iters == 2;
   WriteFrameHeader(out, p, false, true, alpha ? 1 : 0, 1, lf_default);
-  WriteTOCAndSections(out, sections, ngroups == 1 && np == 1);
+  WriteTOCAndSections(out, sections, ngroups == 1 && np == 1, (uint32_t)p.permute_toc);
   out.align();
   return out.bytes;
 }
@@ -916,7 +949,7 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
 // ---- C API ---------------------------------------------------------------------------------------------------------
 extern "C" {
 struct jxlsynth_params {
-  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation, upsampling, custom_up_weights, num_passes; int32_t reserved[4];
+  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation, upsampling, custom_up_weights, num_passes, permute_toc; int32_t reserved[3];
 };
 static thread_local std::string g_err;
 const char* jxlsynth_last_error() { return g_err.c_str(); }
@@ -944,6 +977,7 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
     p.upsampling = (pp->upsampling == 2 || pp->upsampling == 4 || pp->upsampling == 8) ? pp->upsampling : 1;
     p.custom_up_weights = pp->custom_up_weights;
     p.num_passes = pp->num_passes >= 1 && pp->num_passes <= 3 ? pp->num_passes : 1;
+    p.permute_toc = pp->permute_toc;
     std::vector<float> pl[3];
     for (auto& v : pl) v.resize((size_t)w * h);
     const float scale = p.hdr ? 255.0f / 1000.0f : 1.0f;  // intensity_target 1000: linear 1.0 == 1000 nits
