@@ -245,6 +245,8 @@ void Batch::Prepare(void* stream_v) {
   vardct_alpha_.assign(n, VarDctAlpha());
   status_off_ = take((size_t)n * 4);
   const size_t flags_off = take((size_t)n * 4);
+  flags_off_ = flags_off;
+  cfg.idct_flags_known = 0; ran_once_ = false;
   // coefficient buffers of all frames are contiguous so that one memset clears them
   coeff_off_ = Align(wbig);
   for (int i = 0; i < n; i++) {
@@ -658,6 +660,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
   if (any_vardct_) CheckFilterBuffers();
+  if (part != 1) ran_once_ = true;
   std::vector<void*>* evs = nullptr;
   if (timed) {
     if (part != 2) { timed_events_.emplace_back(8, nullptr); }
@@ -729,6 +732,14 @@ void Batch::Finish(void* stream_v) {
     HIP_CHECK(hipMemset(dwork_ + status_off_, 0, (size_t)n * 4));
     if (status[i] & kErrUnsupported) throw ParseError("unsupported: stream feature on the device path (frame " + std::to_string(i) + ")", true);
     throw ParseError("corrupt stream (device status " + std::to_string(status[i]) + ", frame " + std::to_string(i) + ")", false);
+  }
+  if (any_vardct_ && !cfg.idct_flags_known && ran_once_) {
+    // the LF stage has classified every frame's varblock placement: later decodes of this batch skip the kernels nobody needs
+    std::vector<uint32_t> flags(n, 0);
+    HIP_CHECK(hipMemcpy(flags.data(), dwork_ + flags_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
+    cfg.any_irregular_blocks = cfg.any_big_blocks = 0;
+    for (uint32_t v : flags) { cfg.any_irregular_blocks |= (v & 1) != 0; cfg.any_big_blocks |= (v & 2) != 0; }
+    cfg.idct_flags_known = 1;
   }
 }
 

@@ -90,6 +90,8 @@ class Batch {
   std::vector<PassDev> passes_host_;
   std::vector<size_t> pass_first_;
   bool any_multipass_ = false;
+  size_t flags_off_ = 0;
+  bool ran_once_ = false;         // a complete decode (incl. the LF stage) has been enqueued since Prepare
   size_t coeff_off_ = 0, coeff_bytes_ = 0, status_off_ = 0, modplane_off_ = 0, modplane_bytes_ = 0;
   bool prepared_ = false;
   int max_lf_groups_ = 0, max_groups_ = 0, max_w_ = 0, max_h_ = 0, max_bw_ = 0, max_bh_ = 0, max_epf_ = 0;

@@ -2663,8 +2663,10 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream) {
   const int tiles_x = DivUp(max_bw, 8), tiles_y = DivUp(max_bh, 8);
   hipLaunchKernelGGL(IdctTileKernel, dim3(tiles_x * tiles_y, nframes), dim3(256), 3 * kTilePlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
-  hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
-  hipLaunchKernelGGL(BigIdctKernel, dim3(max_groups, nframes), dim3(256), kBigLds, (hipStream_t)stream, frames);                  // frames with DCT128/256 varblocks only
+  if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
+    hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
+  if (!cfg.idct_flags_known || cfg.any_big_blocks)
+    hipLaunchKernelGGL(BigIdctKernel, dim3(max_groups, nframes), dim3(256), kBigLds, (hipStream_t)stream, frames);                  // frames with DCT128/256 varblocks only
 }
 void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);
