@@ -2102,7 +2102,7 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
 // instead of 63.  Arithmetic and operation order are those of GaborishKernel / EpfKernel<1> / OutputKernel (mirroring
 // the inputs of the symmetric 3x3 kernel gives exactly the gaborish value at the mirrored coordinate).
 // =====================================================================================================================
-constexpr int kFtW = 64, kFtH = 32;
+constexpr int kFtW = 32, kFtH = 24;
 constexpr int kFinW = kFtW + 6, kFinH = kFtH + 6, kFinP = kFinW + 1;      // input region incl. halo 3, padded pitch
 constexpr int kFgW = kFtW + 4, kFgH = kFtH + 4, kFgP = kFgW + 1;          // gaborish region incl. halo 2
 constexpr size_t kFusedLds = (size_t)(3 * kFinH * kFinP + 3 * kFgH * kFgP) * sizeof(float);
