@@ -790,6 +790,7 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
             StS<unsigned long long>(co, wv | bits);
           }
           if (bad) break;
+          if ((x % 4) + cx > 4 || (y % 4) + cy > 4) atomicOr(f.frame_flags, 4u);   // not inside one 32x32 tile: the IDCT uses 64x64 tiles
           if (cx > 8 || cy > 8) {
             // DCT128/256 family: BigIdctKernel; whole 64x64 tiles when aligned, else the frame takes the generic path
             atomicOr(f.frame_flags, (x % 8) || (y % 8) ? 3u : 2u);
@@ -1654,8 +1655,9 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
 //          scatter into the LDS tile at the coefficient's (vertical, horizontal) frequency position
 //  pass 1: LLF substitution + horizontal 1-D IDCT per row (in LDS)     pass 2: vertical 1-D IDCT per column (in LDS)
 //  pass 3: coalesced write of the finished 64x64 tile to the three planes
-constexpr int kTilePitch = 65;                     // floats per LDS tile row (64 + 1: conflict-free column access)
-constexpr int kTilePlane = 64 * kTilePitch;
+// TB = tile side in 8x8 blocks: 8 (64x64 pixels, any varblock up to 64x64) or 4 (32x32 pixels: frames whose varblocks are at
+// most 32x32 — a quarter of the LDS per workgroup, four times the workgroups in flight to cover barrier waits)
+template <int TB> struct TileGeom { static constexpr int kPx = TB * 8, kPitch = TB * 8 + 1, kPlane = TB * 8 * (TB * 8 + 1); };
 
 template <int C> __device__ __forceinline__ void TileRowPass(float* row0 /* LDS row start */, int v, int cy, int cx, const float* llf /* global, row v of the LLF block */) {
   float row[C];
@@ -1670,28 +1672,30 @@ template <int C> __device__ __forceinline__ void TileRowPass(float* row0 /* LDS 
   for (int u = 0; u < C; u++) row0[u] = row[u];
 }
 
-template <int R> __device__ __forceinline__ void TileColPass(float* col0) {
+template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* col0) {
   float col[R];
 #pragma unroll
-  for (int v = 0; v < R; v++) col[v] = col0[v * kTilePitch];
+  for (int v = 0; v < R; v++) col[v] = col0[v * PITCH];
   IDct1D<R>(col);
 #pragma unroll
-  for (int v = 0; v < R; v++) col0[v * kTilePitch] = col[v];
+  for (int v = 0; v < R; v++) col0[v * PITCH] = col[v];
 }
 
-__global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+  constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || (*f.frame_flags & 1) != 0 || force_generic) return;
+  if (((*f.frame_flags & 4) != 0) != (TB == 8)) return;     // frames with a varblock that no 32x32 tile contains take the 64x64 tiles
   const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  if (tx * 8 >= f.bw || ty * 8 >= f.bh) return;
+  if (tx * TB >= f.bw || ty * TB >= f.bh) return;
   extern __shared__ __align__(16) float s_tile[];   // 3 * kTilePlane floats
-  __shared__ uint32_t s_info[64];
-  __shared__ uint32_t s_coff[64];
-  const uint32_t bx0 = tx * 8, by0 = ty * 8;
-  const uint32_t tbw = min(8u, f.bw - bx0), tbh = min(8u, f.bh - by0);
+  __shared__ uint32_t s_info[kNB];
+  __shared__ uint32_t s_coff[kNB];
+  const uint32_t bx0 = tx * TB, by0 = ty * TB;
+  const uint32_t tbw = min((uint32_t)TB, f.bw - bx0), tbh = min((uint32_t)TB, f.bh - by0);
   const uint32_t g = (by0 / 32) * f.xgroups + bx0 / 32;
-  if (threadIdx.x < 64) {
-    const uint32_t bx = threadIdx.x & 7, by = threadIdx.x >> 3;
+  if (threadIdx.x < kNB) {
+    const uint32_t bx = threadIdx.x % TB, by = threadIdx.x / TB;
     uint32_t info = 0xFFFFFFFFu, coff = 0;
     if (bx < tbw && by < tbh) {
       const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
@@ -1706,12 +1710,13 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
   // raster order every wavefront would run all four unrolled transforms one after the other (divergence), sorted by
   // length a wavefront runs one.  Classes 0..3 = 8 << class points, class 4 = the 8x8 "special" transforms.
   __shared__ uint32_t s_cnt[16];                 // [0..4] row counts, [5..8] column counts, then running cursors
-  __shared__ uint16_t s_rtask[512], s_ctask[512];
+  __shared__ uint16_t s_rtask[kNB * 8], s_ctask[kNB * 8];
   if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t my_rclass[2], my_cclass[2];
-  for (int q = 0; q < 2; q++) {
-    const uint32_t tt = threadIdx.x + q * 256, info = s_info[tt >> 3];
+  constexpr int kQ = kNB * 8 / (TB == 8 ? 256 : 128);   // candidate row/column tasks per thread
+  uint32_t my_rclass[kQ], my_cclass[kQ];
+  for (int q = 0; q < kQ; q++) {
+    const uint32_t tt = threadIdx.x + q * blockDim.x, info = s_info[tt >> 3];
     my_rclass[q] = my_cclass[q] = 0xFFu;
     if (info == 0xFFFFFFFFu) continue;
     const uint32_t st = BI_Strategy(info);
@@ -1719,7 +1724,7 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
     if (BI_Ix(info) == 0) my_rclass[q] = Log2Cov8(CoveredX(st));
     if (BI_Iy(info) == 0) my_cclass[q] = Log2Cov8(CoveredY(st));
   }
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < kQ; q++) {
     if (my_rclass[q] != 0xFFu) atomicAdd(&s_cnt[my_rclass[q]], 1u);
     if (my_cclass[q] != 0xFFu) atomicAdd(&s_cnt[5 + my_cclass[q]], 1u);
   }
@@ -1735,8 +1740,8 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
   const uint32_t r_begin[6] = {s_cnt[9], s_cnt[10], s_cnt[11], s_cnt[12], s_cnt[13], s_cnt[13] + s_cnt[4]};
   const uint32_t c_begin[5] = {s_ccur[0], s_ccur[1], s_ccur[2], s_ccur[3], s_ccur[3] + s_cnt[8]};
   __syncthreads();
-  for (int q = 0; q < 2; q++) {
-    const uint32_t tt = threadIdx.x + q * 256;
+  for (int q = 0; q < kQ; q++) {
+    const uint32_t tt = threadIdx.x + q * blockDim.x;
     if (my_rclass[q] != 0xFFu) s_rtask[atomicAdd(&s_cnt[9 + my_rclass[q]], 1u)] = (uint16_t)tt;
     if (my_cclass[q] != 0xFFu) s_ctask[atomicAdd(&s_ccur[my_cclass[q]], 1u)] = (uint16_t)tt;
   }
@@ -1744,10 +1749,10 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
   const float bias0 = f.quant_bias[0], bias1 = f.quant_bias[1], bias2 = f.quant_bias[2], bias3 = f.quant_bias[3];
   // ---- pass 0: stage dequantised coefficients.  Task = (block of the tile, four of its 64 coefficient slots): 16-byte
   // loads, consecutive lanes read consecutive 16-byte chunks.  The tile is exactly one chroma-from-luma tile.
-  const size_t cfl_i = (size_t)ty * f.cw + tx;
+  const size_t cfl_i = (size_t)(by0 / 8) * f.cw + bx0 / 8;   // chroma-from-luma factors are per 64x64 pixels
   const float kx = f.base_x + (float)LdG(f.ytox + cfl_i) * f.color_scale;
   const float kb = f.base_b + (float)LdG(f.ytob + cfl_i) * f.color_scale;
-  for (uint32_t t = threadIdx.x; t < 1024; t += blockDim.x) {
+  for (uint32_t t = threadIdx.x; t < kNB * 16; t += blockDim.x) {
     const uint32_t bi = t >> 4, j = (t & 15) * 4;
     const uint32_t info = s_info[bi];
     if (info == 0xFFFFFFFFu) continue;
@@ -1768,7 +1773,7 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
     const float sdx = sd * f.x_dm, sdb = sd * f.b_dm;
     const int32_t qy[4] = {qy4.x, qy4.y, qy4.z, qy4.w}, qx[4] = {qx4.x, qx4.y, qx4.z, qx4.w}, qb[4] = {qb4.x, qb4.y, qb4.z, qb4.w};
     const float wy[4] = {ty4.x, ty4.y, ty4.z, ty4.w}, wx[4] = {tx4.x, tx4.y, tx4.z, tx4.w}, wbl[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
-    const uint32_t vbx = (bi & 7) - ix, vby = (bi >> 3) - iy;   // varblock origin inside the tile (blocks)
+    const uint32_t vbx = (bi % TB) - ix, vby = (bi / TB) - iy;   // varblock origin inside the tile (blocks)
     const bool special = IsSpecial(s);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -1796,7 +1801,7 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
       const uint32_t info = s_info[bi];
       const uint32_t s = BI_Strategy(info), iy = BI_Iy(info);
       const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
-      const uint32_t bx = bi & 7, by = bi >> 3;
+      const uint32_t bx = bi % TB, by = bi / TB;
       const size_t o_first = (size_t)(by0 + by - iy) * f.bw + bx0 + bx;
       float* blk0 = s_tile + c * kTilePlane + ((by - iy) * 8) * kTilePitch + bx * 8;
       if (cls == 4) {
@@ -1813,7 +1818,7 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
       if (cls == 0) TileRowPass<8>(row0, v, cy, cx, llf);
       else if (cls == 1) TileRowPass<16>(row0, v, cy, cx, llf);
       else if (cls == 2) TileRowPass<32>(row0, v, cy, cx, llf);
-      else TileRowPass<64>(row0, v, cy, cx, llf);
+      else if (TB == 8) TileRowPass<64>(row0, v, cy, cx, llf);
     }
   }
   __syncthreads();
@@ -1823,12 +1828,12 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
     for (uint32_t t = threadIdx.x; t < n * 3; t += blockDim.x) {
       const uint32_t c = t / n, tt = s_ctask[c_begin[cls] + (t - c * n)];
       const uint32_t xx = tt & 7, bi = tt >> 3;
-      const uint32_t bx = bi & 7, by = bi >> 3;
+      const uint32_t bx = bi % TB, by = bi / TB;
       float* col0 = s_tile + c * kTilePlane + (by * 8) * kTilePitch + bx * 8 + xx;
-      if (cls == 0) TileColPass<8>(col0);
-      else if (cls == 1) TileColPass<16>(col0);
-      else if (cls == 2) TileColPass<32>(col0);
-      else TileColPass<64>(col0);
+      if (cls == 0) TileColPass<8, kTilePitch>(col0);
+      else if (cls == 1) TileColPass<16, kTilePitch>(col0);
+      else if (cls == 2) TileColPass<32, kTilePitch>(col0);
+      else if (TB == 8) TileColPass<64, kTilePitch>(col0);
     }
   }
   __syncthreads();
@@ -1837,8 +1842,8 @@ __global__ __launch_bounds__(256) void IdctTileKernel(const FrameDev* __restrict
   for (uint32_t c = 0; c < 3; c++) {
     float* dst = f.plane_a[c] + (size_t)(by0 * 8) * f.plane_stride + bx0 * 8;
     const float* src = s_tile + c * kTilePlane;
-    for (uint32_t i = threadIdx.x; i < 64 * th; i += blockDim.x) {
-      const uint32_t y = i >> 6, x = i & 63;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(TB * 8) * th; i += blockDim.x) {
+      const uint32_t y = i / (TB * 8), x = i % (TB * 8);
       if (x < tw) StG(dst + (size_t)y * f.plane_stride + x, src[y * kTilePitch + x]);
     }
   }
@@ -2661,8 +2666,15 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
   hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(threads), lds_bytes, (hipStream_t)stream, frames, cfg.lane_stride_hf, lds_bytes);
 }
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream) {
-  const int tiles_x = DivUp(max_bw, 8), tiles_y = DivUp(max_bh, 8);
-  hipLaunchKernelGGL(IdctTileKernel, dim3(tiles_x * tiles_y, nframes), dim3(256), 3 * kTilePlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+  // 64x64 tiles for frames with varblocks beyond 32x32, 32x32 tiles (a quarter of the LDS) for the others
+  if (!cfg.idct_flags_known || cfg.any_wide_blocks) {
+    const int tiles_x = DivUp(max_bw, 8), tiles_y = DivUp(max_bh, 8);
+    hipLaunchKernelGGL(IdctTileKernel<8>, dim3(tiles_x * tiles_y, nframes), dim3(256), 3 * TileGeom<8>::kPlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+  }
+  if (!cfg.idct_flags_known || cfg.any_narrow_frames) {
+    const int tiles_x = DivUp(max_bw, 4), tiles_y = DivUp(max_bh, 4);
+    hipLaunchKernelGGL(IdctTileKernel<4>, dim3(tiles_x * tiles_y, nframes), dim3(128), 3 * TileGeom<4>::kPlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+  }
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
   if (!cfg.idct_flags_known || cfg.any_big_blocks)
