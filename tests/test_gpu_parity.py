@@ -382,6 +382,52 @@ def test_permuted_toc(jx):
         assert np.array_equal(px, want)
 
 
+def test_mixed_batch_in_two_halves_on_two_streams(jx):
+    """The pipelined use of the batch API (bench.py): part 1 (global Modular streams + LF stage) on a side stream, part 2 on the
+    main stream, for a batch mixing Modular frames, VarDCT frames with alpha, progressive and upsampled frames; two batches
+    sharing one set of coefficient / pixel planes; repeated to cover the cached varblock-flag paths."""
+    import torch
+    img = S.synthetic_image(90, 600, 400)
+    al = (np.add.outer(np.arange(400), np.arange(600)) % 256).astype(np.uint8)
+    streams = [(S.encode_vardct(img, seed=1, strategy_mix=2, alpha=al), 4), (S.encode_modular(_smooth_image(9, 280, 300, 3, 8), 8, True, 1), 3),
+               (S.encode_vardct(img, seed=2, strategy_mix=4, num_passes=2), 3), (S.encode_vardct(img, seed=3, strategy_mix=1, upsampling=2), 3),
+               (S.encode_vardct(S.synthetic_image(91, 200, 136), seed=4, strategy_mix=3, epf_iters=3), 3)]
+    want = [O.decode(d).pixels("u8", n) for d, n in streams]
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    batches = []
+    for k in range(2):
+        b = jx.BatchDecoder(0)
+        for d, n in streams:
+            b.add(d, "uint8", n)
+        if k:
+            b.share_buffers(batches[0])
+        b.prepare(main.cuda_stream)
+        batches.append(b)
+    torch.cuda.synchronize()
+    ev_front = [torch.cuda.Event() for _ in range(2)]
+    ev_rest = [torch.cuda.Event() for _ in range(2)]
+    for step in range(5):
+        k = step % 2
+        with torch.cuda.stream(side):
+            if step >= 2:
+                side.wait_event(ev_rest[k])
+            batches[k].decode_part(1, side.cuda_stream)
+            ev_front[k].record(side)
+        main.wait_event(ev_front[k])
+        batches[k].decode_part(2, main.cuda_stream)
+        ev_rest[k].record(main)
+        if step == 1:
+            torch.cuda.synchronize()
+            for b in batches:
+                b.finish(main.cuda_stream)     # reads the varblock flags: later steps skip the kernels nobody needs
+    torch.cuda.synchronize()
+    for b in batches:
+        b.finish(main.cuda_stream)
+        for i in range(len(streams)):
+            assert np.array_equal(b.output(i), want[i]), i
+
+
 def test_corrupted_streams_fail_cleanly_or_decode(jx):
     """Robustness: random byte corruption in the section payloads (VarDCT and Modular streams) must end in a DecodeError or
     a decode of the right size — never a crash or a hang (the kernels bound every loop by the frame geometry and read
