@@ -514,10 +514,10 @@ void Batch::Prepare(void* stream_v) {
   }
   {  // LDS right-sizing for the decode kernels
     auto code_bytes = [](const HostCode& c, bool ctx) { return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
-    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16;
+    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0;
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
-      if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); }
+      if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); cfg.any_wp |= p.tree.uses_wp ? 1 : 0; }
       if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
     }
   }

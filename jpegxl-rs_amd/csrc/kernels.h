@@ -100,6 +100,7 @@ struct LaunchCfg {
   int lane_stride_lf = 64;   // lanes between active decode threads (64 = one stream per wave, 1 = one per lane)
   int lane_stride_hf = 64;
   int lane_stride_mod = 64;
+  int any_wp = 0;            // some MA tree of the batch uses the weighted predictor (the Modular kernels then reserve LDS for its state)
   // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
   int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;
   int force_generic_idct = 0;

@@ -290,7 +290,7 @@ constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;             // 256-sam
 constexpr uint32_t kWaveLds = 8448;                                   // >= kChunkOff + 1024 and >= the 8 KiB placement bitmap
 static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
 constexpr uint32_t kLfWaves = 4;
-constexpr uint32_t kTreeOff = kLfWaves * kWaveLds;                    // shared: tree copy, then the entropy code
+// the shared part of the LDS (tree copy or per-wavefront pruned slices, then the entropy code) follows the per-wavefront regions
 
 __device__ __forceinline__ void WaveSync() {   // orders LDS/global accesses between the lanes of ONE wavefront
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -298,15 +298,91 @@ __device__ __forceinline__ void WaveSync() {   // orders LDS/global accesses bet
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+
+// Weighted-predictor state (context_predict.h weighted::State) held in LDS: same arithmetic as WPState (jxl_dev.h), the
+// five error arrays (2 rows of xsize + 2 ints each) at a byte offset of the dynamic LDS instead of global scratch.
+struct WPStateLds {
+  uint32_t base;            // byte offset; layout [error | pe0 | pe1 | pe2 | pe3], each 2 * (xsize + 2) ints
+  int32_t xsize;
+  int64_t prediction[4];
+  int64_t pred;
+  __device__ __forceinline__ uint32_t Arr(int a) const { return base + (uint32_t)a * (uint32_t)(xsize + 2) * 8u; }
+  __device__ __forceinline__ int32_t Ld(int a, int32_t i) const { return LdS<int32_t>(Arr(a) + (uint32_t)i * 4u); }
+  __device__ __forceinline__ void St(int a, int32_t i, int32_t v) const { StS<int32_t>(Arr(a) + (uint32_t)i * 4u, v); }
+  static constexpr uint32_t Bytes(int32_t xs) { return 5u * 2u * (uint32_t)(xs + 2) * 4u; }
+  __device__ __forceinline__ void Init(uint32_t base_off, int32_t xs, uint32_t lane) {   // all lanes of the wavefront
+    base = base_off; xsize = xs;
+    for (uint32_t i = lane; i < Bytes(xs) / 4; i += 64) StS<int32_t>(base + i * 4, 0);
+  }
+  __device__ __forceinline__ int64_t Predict(const WPHeader& hdr, int x, int y, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN, int32_t* max_err) {
+    const int32_t cur_row = (y & 1) ? 0 : (xsize + 2);
+    const int32_t prev_row = (y & 1) ? (xsize + 2) : 0;
+    const int32_t pos_N = prev_row + x;
+    const int32_t pos_NE = x < xsize - 1 ? pos_N + 1 : pos_N;
+    const int32_t pos_NW = x > 0 ? pos_N - 1 : pos_N;
+    uint32_t weights[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      weights[i] = WPState::ErrorWeight((uint64_t)(uint32_t)Ld(1 + i, pos_N) + (uint32_t)Ld(1 + i, pos_NE) + (uint32_t)Ld(1 + i, pos_NW), (uint32_t)hdr.w[i]);
+    N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
+    const int64_t teW = x == 0 ? 0 : Ld(0, cur_row + x - 1);
+    const int64_t teN = Ld(0, pos_N);
+    const int64_t teNW = Ld(0, pos_NW);
+    const int64_t sumWN = teN + teW;
+    const int64_t teNE = Ld(0, pos_NE);
+    int64_t p = teW;
+    if (Abs64(teN) > Abs64(p)) p = teN;
+    if (Abs64(teNW) > Abs64(p)) p = teNW;
+    if (Abs64(teNE) > Abs64(p)) p = teNE;
+    *max_err = (int32_t)p;
+    prediction[0] = W + NE - N;
+    prediction[1] = N - (((sumWN + teNE) * hdr.p1) >> 5);
+    prediction[2] = W - (((sumWN + teNW) * hdr.p2) >> 5);
+    prediction[3] = N - ((teNW * hdr.p3[0] + teN * hdr.p3[1] + teNE * hdr.p3[2] + (NN - N) * hdr.p3[3] + (NW - W) * hdr.p3[4]) >> 5);
+    uint32_t wsum = weights[0] + weights[1] + weights[2] + weights[3];
+    const int lw = FloorLog2u64(wsum);
+    wsum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { weights[i] >>= (lw - 4); wsum += weights[i]; }
+    int64_t sum = (int64_t)(wsum >> 1) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) sum += prediction[i] * (int64_t)weights[i];
+    pred = (sum * (int64_t)WPState::DivLookup(wsum - 1)) >> 24;
+    if (((teN ^ teW) | (teN ^ teNW)) > 0) return pred;
+    const int64_t mx = Max64(W, Max64(NE, N)), mn = Min64(W, Min64(NE, N));
+    pred = Max64(mn, Min64(mx, pred));
+    return pred;
+  }
+  __device__ __forceinline__ void Update(int64_t val, int x, int y) {
+    const int32_t cur_row = (y & 1) ? 0 : (xsize + 2);
+    const int32_t prev_row = (y & 1) ? (xsize + 2) : 0;
+    val *= 8;
+    St(0, cur_row + x, (int32_t)(pred - val));
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int32_t err = (int32_t)((Abs64(prediction[i] - val) + 3) >> 3);
+      St(1 + i, cur_row + x, err);
+      St(1 + i, prev_row + x + 1, Ld(1 + i, prev_row + x + 1) + err);
+    }
+  }
+};
+constexpr int32_t kWpLdsMaxW = 256;                                   // channel widths whose WP state fits the per-wavefront LDS slot
+constexpr uint32_t kWpLdsBytes = WPStateLds::Bytes(kWpLdsMaxW);       // 10 320 B
+
 struct ModTables {
   const TreeNode* tree_g;
-  bool tree_in_lds;         // LDS copy at kTreeOff (leaves rewritten: a = predictor | cluster << 8)
+  bool tree_in_lds;         // LDS copy at node_base (leaves rewritten: a = predictor | cluster << 8)
   uint32_t tree_cap;
+  uint32_t node_base;       // LDS byte offset of the node array Node() reads when tree_in_lds
+  uint32_t prune_off, prune_cap;   // this wavefront's slice of the tree region for a pruned per-(stream, channel) subtree of a
+                                   // tree too large to copy whole (prune_cap nodes; 0 = none)
+  const uint8_t* ctx_map_g;
   uint32_t wb;              // base of this wavefront's private LDS region
+  uint32_t wp_off;          // this wavefront's LDS slot for the weighted-predictor state (kWpLdsBytes), or 0xFFFFFFFF: global scratch
   FastCode code;
   __device__ __forceinline__ TreeNode Node(uint32_t i) const {
     if (tree_in_lds) {
-      const uint4 v = LdS<uint4>(kTreeOff + i * 16);
+      const uint4 v = LdS<uint4>(node_base + i * 16);
       return TreeNode{(int32_t)v.x, (int32_t)v.y, v.z, v.w};
     }
     const uint4 v = LdG(reinterpret_cast<const uint4*>(tree_g + i));
@@ -361,18 +437,18 @@ __device__ __forceinline__ int32_t Predict(uint32_t predictor, int32_t W, int32_
 //   ROWMODE 0: first row (N = NW = W), 1: previous row needed (read from LDS, next value prefetched), 2: W-only rows
 //   PROP9: context from W+N-NW through the LUT (else one cluster per row);  UPRED: 0 zero, 1 W, 5 clamped gradient
 // cluster of property value v under the LDS copy of the (single-property) subtree at `pos` (leaves: a = predictor | cluster << 8)
-__device__ __forceinline__ uint32_t WalkCluster(uint32_t pos, int32_t v) {
-  uint4 n = LdS<uint4>(kTreeOff + pos * 16);
-  while ((int32_t)n.x >= 0) { pos = v > (int32_t)n.y ? n.z : n.w; n = LdS<uint4>(kTreeOff + pos * 16); }
+__device__ __forceinline__ uint32_t WalkCluster(uint32_t node_base, uint32_t pos, int32_t v) {
+  uint4 n = LdS<uint4>(node_base + pos * 16);
+  while ((int32_t)n.x >= 0) { pos = v > (int32_t)n.y ? n.z : n.w; n = LdS<uint4>(node_base + pos * 16); }
   return n.z >> 8;
 }
 struct ChunkState { BitReaderW bw; uint32_t state; int32_t left, nw; };
 __device__ __forceinline__ uint32_t Uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 template <int ROWMODE, bool PROP9, int UPRED, bool UCFG>
 __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, uint32_t prev, uint32_t obase, uint32_t lut_off, uint32_t first_off, uint32_t cl_row,
-                                               uint32_t cfg_off, uint32_t cfg_uniform, uint32_t alias_off, uint32_t la, uint32_t wide_subroot) {
+                                               uint32_t cfg_off, uint32_t cfg_uniform, uint32_t alias_off, uint32_t la, uint32_t wide_subroot, uint32_t node_base) {
   // loop invariants into scalar registers (they come out of LDS-resident tables, i.e. vector registers)
-  wide_subroot = Uniform(wide_subroot);
+  wide_subroot = Uniform(wide_subroot); node_base = Uniform(node_base);
   prev = Uniform(prev); obase = Uniform(obase); lut_off = Uniform(lut_off); first_off = Uniform(first_off); cl_row = Uniform(cl_row);
   cfg_off = Uniform(cfg_off); cfg_uniform = Uniform(cfg_uniform); alias_off = Uniform(alias_off); la = Uniform(la);
   x0 = (int)Uniform((uint32_t)x0); x1 = (int)Uniform((uint32_t)x1);
@@ -393,7 +469,7 @@ __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, u
       const int32_t v0 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
       const int32_t v = v0 < -512 ? -512 : (v0 > 511 ? 511 : v0);
       cluster = LdS<uint16_t>(lut_off + 2 * (uint32_t)(v + 512));
-      if (__builtin_expect(wide_subroot != 0xFFFFFFFFu && v != v0, 0)) cluster = WalkCluster(wide_subroot, v0);   // rare: beyond the LUT
+      if (__builtin_expect(wide_subroot != 0xFFFFFFFFu && v != v0, 0)) cluster = WalkCluster(node_base, wide_subroot, v0);   // rare: beyond the LUT
     }
     int32_t guess;
     if (UPRED == 0) guess = 0;
@@ -434,9 +510,47 @@ __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, u
 
 // All 64 lanes of the wavefront call this.  Lane 0 decodes; the others help with LUT, bit-stream window and row I/O.
 // Semantics identical to DecodeModularChannel (jxl_dev.h).
-__device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
+__device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T_in, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
   if (ch.w == 0 || ch.h == 0) return;
-  const uint32_t lane = threadIdx.x & 63, wb = T.wb;
+  const uint32_t lane = threadIdx.x & 63, wb = T_in.wb;
+  ModTables T = T_in;
+  if (!T.tree_in_lds && T.prune_cap) {
+    // The tree does not fit the LDS whole (bench.jxl: 6643 nodes, most of them splits on the stream id): copy only what
+    // this (stream, channel) can reach — static splits resolved, nodes re-indexed depth-first — into this wavefront's slice.
+    if (lane == 0) {
+      const uint32_t stack = wb + kWorkOff + 64;          // entries: source node, parent slot | child << 31
+      int sp = 0, ok = 1;
+      uint32_t count = 0;
+      StS<uint32_t>(stack, 0u); StS<uint32_t>(stack + 4, 0xFFFFFFFFu); sp = 1;
+      while (sp > 0) {
+        sp--;
+        uint32_t src = LdS<uint32_t>(stack + 8 * sp);
+        const uint32_t link = LdS<uint32_t>(stack + 8 * sp + 4);
+        uint4 v = LdG(reinterpret_cast<const uint4*>(T.tree_g + src));
+        uint32_t guard = 0;
+        while ((int32_t)v.x == 0 || (int32_t)v.x == 1) {   // static properties: channel index, stream id
+          const int32_t pv = (int32_t)v.x == 0 ? chan : (int32_t)mc.stream_id;
+          src = pv > (int32_t)v.y ? v.z : v.w;
+          v = LdG(reinterpret_cast<const uint4*>(T.tree_g + src));
+          if (++guard > 4096) { ok = 0; break; }
+        }
+        if (!ok || count >= T.prune_cap) { ok = 0; break; }
+        const uint32_t dst = count++;
+        if ((int32_t)v.x < 0) v.z = (v.z & 0xFF) | ((uint32_t)LdG(T.ctx_map_g + (v.z >> 8)) << 8);   // leaf: context -> cluster
+        StS<uint4>(T.prune_off + dst * 16, v);
+        if (link != 0xFFFFFFFFu) StS<uint32_t>(T.prune_off + (link & 0x7FFFFFFFu) * 16 + ((link >> 31) ? 12 : 8), dst);   // parent's b / a
+        if ((int32_t)v.x >= 0) {
+          if (sp + 2 > 60) { ok = 0; break; }
+          StS<uint32_t>(stack + 8 * sp, v.w); StS<uint32_t>(stack + 8 * sp + 4, dst | 0x80000000u); sp++;
+          StS<uint32_t>(stack + 8 * sp, v.z); StS<uint32_t>(stack + 8 * sp + 4, dst); sp++;
+        }
+      }
+      StS<int>(wb + kWorkOff + 28, ok);
+    }
+    WaveSync();
+    if (LdS<int>(wb + kWorkOff + 28)) { T.tree_in_lds = true; T.node_base = T.prune_off; }
+    WaveSync();
+  }
   // ---- lane 0: resolve static properties (channel, stream id) and analyse the remaining subtree
   if (lane == 0) {
     uint32_t pos = 0;
@@ -511,7 +625,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       if (prop != 9) {
         const int32_t v0 = prop == 2 ? y : 0;
         const int32_t v = v0 > 511 ? 511 : v0;
-        cl_row = (wide_subroot != 0xFFFFFFFFu && v != v0) ? WalkCluster(wide_subroot, v0) : LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512));
+        cl_row = (wide_subroot != 0xFFFFFFFFu && v != v0) ? WalkCluster(T.node_base, wide_subroot, v0) : LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512));
       }
       for (int x0 = 0; x0 < w; x0 += 256) {
         if (lane == 0) StS<uint32_t>(wb + kWorkOff + 16, bw.wpos);
@@ -534,7 +648,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
           st.bw = bw; st.state = state; st.left = left; st.nw = nw;
           const uint32_t lut_off = wb + kLutOff, first_off = wb + kWorkOff + 24;
           const int rm = y == 0 ? 0 : (need_n ? 1 : 2);
-#define JXL_CHUNK_ARGS st, x0, x1, prev, obase, lut_off, first_off, cl_row, cfg_off, cfg_uniform, alias_off, la, wide_subroot
+#define JXL_CHUNK_ARGS st, x0, x1, prev, obase, lut_off, first_off, cl_row, cfg_off, cfg_uniform, alias_off, la, wide_subroot, T.node_base
 #define JXL_DISPATCH                                                                              \
           if (prop == 9) {                                                                        \
             if (upred == 5) { if (rm == 0) JXL_CHUNK(0, true, 5); else JXL_CHUNK(1, true, 5); }   \
@@ -573,12 +687,15 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     WaveSync();
     return;
   }
+  const bool use_wp = mc.uses_wp != 0 && mode == 0;
+  const bool wp_in_lds = use_wp && T.wp_off != 0xFFFFFFFFu && ch.w <= kWpLdsMaxW;
+  WPStateLds wpl;
+  if (wp_in_lds) { wpl.Init(T.wp_off, ch.w, lane); WaveSync(); }
   if (lane == 0) {
     const int w = ch.w, h = ch.h;
     const FastCode& code = T.code;
     WPState wps;
-    const bool use_wp = mc.uses_wp != 0 && mode == 0;
-    if (use_wp) wps.Init(mc.wp_scratch, w);
+    if (use_wp && !wp_in_lds) wps.Init(mc.wp_scratch, w);
     for (int y = 0; y < h; y++) {
       int32_t* p = ch.data + (size_t)y * ch.stride;
       const int32_t* pn = p - ch.stride;
@@ -600,7 +717,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
         const int32_t NEE = (x + 2 < w && y) ? up3 : NE;
         int64_t wp_pred = 0;
         int32_t wp_err = 0;
-        if (use_wp) wp_pred = wps.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
+        if (use_wp) wp_pred = wp_in_lds ? wpl.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err) : wps.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
         TreeNode n;
         if (mode == 1) {
           int32_t v = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
@@ -622,7 +739,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
         const uint32_t tok = FastHybrid(br, state, code, cluster);
         const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) * n.b + (uint32_t)n.val + (uint32_t)guess);
         StG(p + x, val);
-        if (use_wp) wps.Update(val, x, y);
+        if (use_wp) { if (wp_in_lds) wpl.Update(val, x, y); else wps.Update(val, x, y); }
         left2 = left; left = val;
         up0 = up1; up1 = up2; up2 = up3; up3 = up4;
         nn1 = nn2; nn2 = nn3;
@@ -634,18 +751,27 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
 
 // Stages tree + code into the shared part of the LDS (all threads of the block; one block barrier).
 __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTables& T, uint32_t tree_cap, uint32_t lds_bytes) {
-  const uint32_t code_base = kTreeOff + tree_cap * 16;
+  const uint32_t tree_off = (blockDim.x >> 6) * kWaveLds;   // shared part starts after the per-wavefront regions
+  const uint32_t code_base = tree_off + tree_cap * 16;
   const uint32_t budget = lds_bytes > code_base ? lds_bytes - code_base : 0;
   StageCode(f.mod_code, T.code, code_base, budget, /*with_ctx_map=*/false);
   T.tree_g = f.tree;
   T.tree_cap = tree_cap;
   T.tree_in_lds = num_tree_nodes <= tree_cap;
+  T.node_base = tree_off;
+  T.ctx_map_g = f.mod_code.ctx_map;
+  {  // larger trees: every wavefront of the workgroup gets a slice of the region for a pruned subtree
+    const uint32_t nw = blockDim.x >> 6;
+    T.prune_cap = T.tree_in_lds ? 0 : tree_cap / nw;
+    T.prune_off = tree_off + (threadIdx.x >> 6) * T.prune_cap * 16;
+  }
   T.wb = (threadIdx.x >> 6) * kWaveLds;
+  T.wp_off = 0xFFFFFFFFu;
   if (T.tree_in_lds) {
     for (uint32_t i = threadIdx.x; i < num_tree_nodes; i += blockDim.x) {
       uint4 v = LdG(reinterpret_cast<const uint4*>(f.tree + i));
       if ((int32_t)v.x < 0) v.z = (v.z & 0xFF) | ((uint32_t)LdG(f.mod_code.ctx_map + (v.z >> 8)) << 8);   // leaf: context -> cluster
-      StS<uint4>(kTreeOff + i * 16, v);
+      StS<uint4>(tree_off + i * 16, v);
     }
   }
   __syncthreads();
@@ -2268,11 +2394,12 @@ __device__ __forceinline__ bool ModUnitRect(const FrameDev& f, uint32_t c, uint3
 
 // The global stream (meta channels + every channel that fits one group) with the same cooperative decoder: one wavefront
 // per frame.  Replaces the one-thread ModularGlobalKernel whenever the stream uses the global tree.
-__global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
+__global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base) {
   const FrameDev& f = frames[blockIdx.x];
   if (f.mod_nchan == 0) return;
   ModTables T;
   StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  if (wp_base) T.wp_off = wp_base;
   const uint32_t lane = threadIdx.x & 63;
   BitReaderP br;
   br.Init(f.cs, f.mod_global_bitpos, f.cs_size);
@@ -2295,32 +2422,42 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
   }
 }
 
-// Sub-streams without local transforms (the common case: squeezed / plain channels, alpha of VarDCT frames) through the
-// cooperative wavefront decoder of the LF stage: one wavefront per LfGroup / PassGroup unit, four per workgroup sharing
-// the LDS copy of the MA tree and the entropy code, samples decoded straight into the frame planes.
-__global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
+// Per-section Modular sub-streams (dec_modular.cc DecodeGroup) through the cooperative wavefront decoder of the LF stage:
+// unit < num_lf_groups → the ModularLfGroup stream of that LF group (channels squeezed by >= 3 in both directions, stream
+// id 1+nlf+g); otherwise the pass-group stream (shift 0..2, stream id 1+3nlf+17+g).  One wavefront per unit, four per
+// workgroup sharing the LDS copy of the MA tree and the entropy code.  Streams without local transforms (squeezed / plain
+// channels, alpha of VarDCT frames) are decoded straight into the frame planes; streams with local palettes / RCTs
+// (bench.jxl) go through a per-unit scratch, the wavefront undoes the transforms and copies the rectangles out.
+constexpr int kMaxXformChan = 8;
+struct ModUnitShared {
+  int go, nch, direct;
+  unsigned long long used;
+  GroupHeaderD gh;
+  ChannelDesc ch[12], dst[kMaxXformChan], fresh[4];
+};
+__global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.mod_nchan == 0 || f.single_section) return;
   const uint32_t total = f.num_lf_groups + f.num_groups;
-  if (blockIdx.x * kLfWaves >= total) return;
+  const uint32_t nwaves = blockDim.x >> 6;          // 4, or 2 when every wavefront needs a large pruned-tree slice
+  if (blockIdx.x * nwaves >= total) return;
   const uint32_t first = f.mod_global_decodable;
   if (first >= f.mod_nchan) return;
   ModTables T;
   StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t unit = blockIdx.x * kLfWaves + wave;
+  if (wp_base) T.wp_off = wp_base + wave * kWpLdsBytes;
+  const uint32_t unit = blockIdx.x * nwaves + wave;
   if (unit >= total) return;                     // (no block-wide barrier after this point)
   const bool is_lf = unit < f.num_lf_groups;
-  if (!f.is_modular && is_lf) return;
+  if (!f.is_modular && is_lf) return;            // VarDCT: extra channels are never squeezed here, so ModularLfGroup is empty
   const uint32_t g = is_lf ? unit : unit - f.num_lf_groups;
   const uint32_t dim = is_lf ? f.group_dim * 8 : f.group_dim;
   const uint32_t cols = is_lf ? f.xlfgroups : f.xgroups;
   const uint32_t x0 = (g % cols) * dim, y0 = (g / cols) * dim;
   const int min_shift = is_lf ? 3 : 0, max_shift = is_lf ? 1000 : 2;
-  __shared__ int s_go_w[kLfWaves];
-  __shared__ GroupHeaderD s_gh_w[kLfWaves];
-  int& s_go = s_go_w[wave];
-  GroupHeaderD& s_gh = s_gh_w[wave];
+  __shared__ ModUnitShared s_unit[kLfWaves];
+  ModUnitShared& U = s_unit[wave];
   const uint32_t last_pass = f.is_modular ? 0 : f.num_passes - 1;       // VarDCT: extra channels ride in the last pass
   const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + last_pass * f.num_groups + g;
   const uint64_t sec_end = f.sec_off[si] + f.sec_size[si];
@@ -2328,196 +2465,126 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   br.Init(f.cs, f.sec_off[si] * 8, sec_end);
   uint32_t state = 0;
   ChannelDesc d;
+  int32_t* scratch = f.mod_group_scratch + (uint64_t)unit * f.mod_group_scratch_stride;
   if (lane == 0) {
     int nch = 0;
     for (uint32_t c = first; c < f.mod_nchan; c++) nch += ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d) ? 1 : 0;
-    s_go = 0;
+    U.go = 0; U.nch = 0; U.direct = 1; U.used = 0;
     if (nch > 0) {
       BitReader tmp;
       tmp.Init(f.cs, f.is_modular ? f.sec_off[si] * 8 : f.hf_end_bitpos[g], f.cs_size);
-      if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree) SetError(f, kErrUnsupported);
-      else if (s_gh.ntransforms == 0) {            // (streams with local palettes / RCTs: ModularGroupKernel)
-        br.Init(f.cs, tmp.BitPos(), sec_end);
-        state = br.Read(32);
-        s_go = 1;
-      }
-    }
-  }
-  WaveSync();
-  if (!s_go) return;
-  ModularCtx mc;
-  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
-  mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
-  mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
-  int k = 0;
-  for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) DecodeChannelCoop(br, state, T, mc, d, k++);
-  if (lane == 0) {
-    if (state != 0x130000u) SetError(f, kErrAnsFinalState);
-    else if (br.BitPos() > sec_end * 8) SetError(f, kErrOverrun);
-  }
-}
-
-// Per-section Modular sub-streams (dec_modular.cc DecodeGroup): blockIdx.x < num_lf_groups → the ModularLfGroup stream
-// of that LF group (channels squeezed by >= 3 in both directions, stream id 1+nlf+g); otherwise the pass-group stream
-// (shift 0..2, stream id 1+3nlf+17+g).  One 64-thread block per stream; thread 0 decodes — straight into the frame
-// planes when the stream has no local transforms — then all lanes undo local transforms and copy the rectangles.
-__global__ __launch_bounds__(64) void ModularGroupKernel(const FrameDev* __restrict__ frames) {
-  const FrameDev& f = frames[blockIdx.y];
-  if (f.mod_nchan == 0) return;
-  const uint32_t unit = blockIdx.x;
-  const bool is_lf = unit < f.num_lf_groups;
-  const uint32_t g = is_lf ? unit : unit - f.num_lf_groups;
-  if (!is_lf && g >= f.num_groups) return;
-  if (!f.is_modular && is_lf) return;   // VarDCT: extra channels are never squeezed here, so ModularLfGroup is empty
-  // channels decoded per section: those after the globally decoded ones
-  const uint32_t first = f.mod_global_decodable;
-  if (first >= f.mod_nchan) return;
-  const uint32_t dim = is_lf ? f.group_dim * 8 : f.group_dim;
-  const uint32_t cols = is_lf ? f.xlfgroups : f.xgroups;
-  const uint32_t x0 = (g % cols) * dim, y0 = (g / cols) * dim;
-  const int min_shift = is_lf ? 3 : 0, max_shift = is_lf ? 1000 : 2;
-  constexpr int kMaxXformChan = 8;
-  __shared__ int s_ok;
-  __shared__ int s_nch;
-  __shared__ unsigned long long s_used;
-  __shared__ ChannelDesc s_ch[12];
-  __shared__ ChannelDesc s_dst[kMaxXformChan];
-  __shared__ GroupHeaderD s_gh;
-  int32_t* scratch = f.mod_group_scratch + (uint64_t)unit * f.mod_group_scratch_stride;
-  // rectangle of channel c in this section (false: not part of it)
-  auto rect_of = [&](uint32_t c, ChannelDesc* d) -> bool {
-    const ModChanDev m = f.mod_chan[c];
-    if (m.w == 0 || m.h == 0) return false;
-    const int shift = min(m.hshift, m.vshift);
-    if (shift < min_shift || shift > max_shift) return false;
-    const uint32_t rx = x0 >> m.hshift, ry = y0 >> m.vshift;
-    if (rx >= m.w || ry >= m.h) return false;
-    const uint32_t rw = min(dim >> m.hshift, m.w - rx), rh = min(dim >> m.vshift, m.h - ry);
-    if (rw == 0 || rh == 0) return false;
-    d->data = ModPlane(f, m) + (size_t)ry * m.w + rx; d->w = (int)rw; d->h = (int)rh; d->stride = (int)m.w;
-    return true;
-  };
-  if (threadIdx.x == 0) {
-    s_ok = 0;
-    int nch = 0;
-    bool ok = true;
-    ChannelDesc d;
-    for (uint32_t c = first; c < f.mod_nchan; c++) nch += rect_of(c, &d) ? 1 : 0;
-    unsigned long long used = 0;
-    if (nch > 0) {
-      if (f.single_section) ok = false;  // a one-group frame decodes every channel globally
-      const uint32_t last_pass = f.is_modular ? 0 : f.num_passes - 1;
-      const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + last_pass * f.num_groups + g;
-      BitReader br;
-      uint64_t limit = 0;
-      if (ok) {
-        const uint64_t off = f.sec_off[si];
-        // VarDCT PassGroup: the Modular part follows the HF coefficients of the group
-        br.Init(f.cs, f.is_modular ? off * 8 : f.hf_end_bitpos[g], off + f.sec_size[si]);
-        limit = (off + f.sec_size[si]) * 8;
-      }
-      ok = ok && ReadGroupHeader(br, s_gh) && s_gh.use_global_tree;
-      ModularCtx mc;
-      mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = s_gh.wp;
-      mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
-      mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
-      if (ok && s_gh.ntransforms == 0) {
-        nch = 0;   // no local transforms: ModularGroupFastKernel decodes these sub-streams in place
-      } else if (ok) {
-        // local transforms: decode into scratch, undo, then copy (at most kMaxXformChan channels)
+      bool ok = ReadGroupHeader(tmp, U.gh) && U.gh.use_global_tree;
+      if (ok && U.gh.ntransforms != 0) {
+        // local transforms: channels are decoded into the unit's scratch (at most kMaxXformChan of them)
+        U.direct = 0;
         if (nch > kMaxXformChan) ok = false;
+        unsigned long long used = 0;
         int k = 0;
-        for (uint32_t c = first; ok && c < f.mod_nchan; c++) if (rect_of(c, &d)) {
-          s_dst[k] = d;
-          s_ch[k].data = scratch + used; s_ch[k].w = d.w; s_ch[k].h = d.h; s_ch[k].stride = d.w;
+        for (uint32_t c = first; ok && c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) {
+          U.dst[k] = d;
+          U.ch[k].data = scratch + used; U.ch[k].w = d.w; U.ch[k].h = d.h; U.ch[k].stride = d.w;
           used += (unsigned long long)d.w * d.h;
           k++;
         }
         int nmeta = 0;
-        // apply local transforms to the channel list (MetaApply)
-        for (uint32_t i = 0; ok && i < s_gh.ntransforms; i++) {
-          auto& t = s_gh.t[i];
+        for (uint32_t i = 0; ok && i < U.gh.ntransforms; i++) {           // MetaApply on the channel list
+          auto& t = U.gh.t[i];
           if (t.id == 0) { if (t.begin_c + 3 > (uint32_t)nch) ok = false; }
-          else {
+          else if (t.id == 1) {
             const uint32_t endc = t.begin_c + t.num_c - 1;
-            if (endc >= (uint32_t)nch || (int)t.begin_c < nmeta || nch + 1 - (int)(t.num_c - 1) > 12 || t.nb_colors > 65536) { ok = false; break; }
-            // remove channels begin_c+1..endc, insert palette channel at 0
-            for (uint32_t q = endc + 1; q < (uint32_t)nch; q++) s_ch[q - (t.num_c - 1)] = s_ch[q];
+            if (endc >= (uint32_t)nch || (int)t.begin_c < nmeta || nch + 1 - (int)(t.num_c - 1) > 12 || t.nb_colors > 65536 || t.num_c > 4) { ok = false; break; }
+            for (uint32_t q = endc + 1; q < (uint32_t)nch; q++) U.ch[q - (t.num_c - 1)] = U.ch[q];     // drop channels begin_c+1..endc
             nch -= (int)(t.num_c - 1);
-            for (int q = nch; q > 0; q--) s_ch[q] = s_ch[q - 1];
+            for (int q = nch; q > 0; q--) U.ch[q] = U.ch[q - 1];                                         // palette channel at index 0
             nch++;
-            s_ch[0].data = scratch + used; s_ch[0].w = (int)t.nb_colors; s_ch[0].h = (int)t.num_c; s_ch[0].stride = (int)t.nb_colors;
+            U.ch[0].data = scratch + used; U.ch[0].w = (int)t.nb_colors; U.ch[0].h = (int)t.num_c; U.ch[0].stride = (int)t.nb_colors;
             used += (unsigned long long)t.nb_colors * t.num_c;
             nmeta++;
-            // (after the inverse, begin_c indexes the channel list without the palette channel)
-          }
+          } else ok = false;                                               // local squeeze
         }
         if (used > f.mod_group_scratch_stride) ok = false;
-        if (ok) {
-          AnsReader ans; ans.Init(br, f.mod_code);
-          for (int c = 0; c < nch; c++) DecodeModularChannel(br, ans, mc, s_ch[c], c);
-          if (!ans.FinalOk(f.mod_code)) { SetError(f, kErrAnsFinalState); ok = false; }
-          else if (br.BitPos() > limit) { SetError(f, kErrOverrun); ok = false; }
-        } else SetError(f, kErrUnsupported);
-      } else SetError(f, kErrUnsupported);
+        U.used = used;
+      }
+      if (!ok) SetError(f, kErrUnsupported);
+      else {
+        br.Init(f.cs, tmp.BitPos(), sec_end);
+        state = br.Read(32);
+        U.nch = nch;
+        U.go = 1;
+      }
     }
-    s_nch = nch; s_ok = ok && nch > 0; s_used = used;
   }
-  __syncthreads();
-  if (!s_ok) return;
-  // ---- undo local transforms (reverse order), all lanes
-  int nch = s_nch;
-  for (int i = (int)s_gh.ntransforms - 1; i >= 0; i--) {
-    const auto t = s_gh.t[i];
+  WaveSync();
+  if (!U.go) return;
+  ModularCtx mc;
+  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = U.gh.wp;
+  mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
+  mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
+  if (U.direct) {
+    int k = 0;
+    for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) DecodeChannelCoop(br, state, T, mc, d, k++);
+  } else {
+    const int nch = U.nch;
+    for (int c = 0; c < nch; c++) { const ChannelDesc cd = U.ch[c]; DecodeChannelCoop(br, state, T, mc, cd, c); }
+  }
+  int fail = 0;
+  if (lane == 0) {
+    if (state != 0x130000u) { SetError(f, kErrAnsFinalState); fail = 1; }
+    else if (br.BitPos() > sec_end * 8) { SetError(f, kErrOverrun); fail = 1; }
+    U.go = !fail;
+  }
+  WaveSync();
+  if (U.direct || !U.go) return;
+  // ---- undo the local transforms (reverse order), the whole wavefront
+  int nch = U.nch;
+  for (int i = (int)U.gh.ntransforms - 1; i >= 0; i--) {
+    const auto t = U.gh.t[i];
     if (t.id == 0) {
-      const ChannelDesc a = s_ch[t.begin_c], b = s_ch[t.begin_c + 1], c = s_ch[t.begin_c + 2];
-      InvRctD(a.data, b.data, c.data, (size_t)a.w * a.h, t.rct_type, threadIdx.x, blockDim.x);
-      __syncthreads();
+      const ChannelDesc a = U.ch[t.begin_c], b = U.ch[t.begin_c + 1], c = U.ch[t.begin_c + 2];
+      InvRctD(a.data, b.data, c.data, (size_t)a.w * a.h, t.rct_type, lane, 64);
+      WaveSync();
     } else {
-      // inverse palette: channel 0 = palette, channel begin_c+1 = indices -> num_c channels
-      const ChannelDesc pal = s_ch[0];
-      const ChannelDesc idx = s_ch[t.begin_c + 1];
+      // inverse palette: channel 0 = palette, channel begin_c+1 = indices -> num_c channels (fresh storage at the scratch tail)
+      const ChannelDesc pal = U.ch[0];
+      const ChannelDesc idx = U.ch[t.begin_c + 1];
       const size_t n = (size_t)idx.w * idx.h;
-      // the num_c-1 new channels get fresh storage at the scratch tail
-      __shared__ ChannelDesc s_new[4];
-      if (threadIdx.x == 0) {
-        if (s_used + (unsigned long long)(t.num_c - 1) * n > f.mod_group_scratch_stride) { SetError(f, kErrUnsupported); s_ok = 0; }
+      if (lane == 0) {
+        if (U.used + (unsigned long long)(t.num_c - 1) * n > f.mod_group_scratch_stride) { SetError(f, kErrUnsupported); U.go = 0; }
         else {
-          int32_t* tail = scratch + s_used;
-          for (uint32_t c = 1; c < t.num_c; c++) { s_new[c] = idx; s_new[c].data = tail + (size_t)(c - 1) * n; }
-          s_new[0] = idx;
-          s_used += (unsigned long long)(t.num_c - 1) * n;
+          int32_t* tail = scratch + U.used;
+          for (uint32_t c = 1; c < t.num_c; c++) { U.fresh[c] = idx; U.fresh[c].data = tail + (size_t)(c - 1) * n; }
+          U.fresh[0] = idx;
+          U.used += (unsigned long long)(t.num_c - 1) * n;
         }
       }
-      __syncthreads();
-      if (!s_ok) return;
+      WaveSync();
+      if (!U.go) return;
       const int bit_depth = min((int)f.mod_bits, 24);
-      for (size_t k = threadIdx.x; k < n; k += blockDim.x) {
+      for (size_t k = lane; k < n; k += 64) {
         const int index = idx.data[k];
-        for (int c = (int)t.num_c - 1; c >= 0; c--) s_new[c].data[k] = PaletteValue(pal.data, pal.w, index, c, bit_depth);
+        for (int c = (int)t.num_c - 1; c >= 0; c--) U.fresh[c].data[k] = PaletteValue(pal.data, pal.w, index, c, bit_depth);
       }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        // channel list: drop palette (0), replace index channel by num_c channels
+      WaveSync();
+      if (lane == 0) {   // channel list: drop the palette (0), replace the index channel by num_c channels
         ChannelDesc tmp[12];
         int m = 0;
         for (int k = 1; k < nch; k++) {
-          if ((uint32_t)(k - 1) == t.begin_c) { for (uint32_t c = 0; c < t.num_c; c++) tmp[m++] = s_new[c]; }
-          else tmp[m++] = s_ch[k];
+          if ((uint32_t)(k - 1) == t.begin_c) { for (uint32_t c = 0; c < t.num_c; c++) tmp[m++] = U.fresh[c]; }
+          else tmp[m++] = U.ch[k];
         }
-        for (int k = 0; k < m; k++) s_ch[k] = tmp[k];
-        s_nch = m;
+        for (int k = 0; k < m; k++) U.ch[k] = tmp[k];
+        U.nch = m;
       }
-      __syncthreads();
-      nch = s_nch;
+      WaveSync();
+      nch = U.nch;
     }
   }
   // ---- copy into the frame planes
   for (int k = 0; k < nch && k < kMaxXformChan; k++) {
-    const ChannelDesc d = s_ch[k], dst = s_dst[k];
-    for (size_t i = threadIdx.x; i < (size_t)d.w * d.h; i += blockDim.x) {
-      const size_t yy = i / d.w, xx = i % d.w;
-      dst.data[yy * dst.stride + xx] = d.data[i];
+    const ChannelDesc cd = U.ch[k], dst = U.dst[k];
+    for (size_t i = lane; i < (size_t)cd.w * cd.h; i += 64) {
+      const size_t yy = i / cd.w, xx = i % cd.w;
+      dst.data[yy * dst.stride + xx] = cd.data[i];
     }
   }
 }
@@ -2610,7 +2677,7 @@ __global__ void ModularOutputKernel(const FrameDev* __restrict__ frames, int fid
 // launchers
 // =====================================================================================================================
 const char* const kKernelNames[] = {"LfDecodeKernel", "LfDequantKernel", "LfSmoothKernel", "LlfSigmaKernel", "HfDecodeKernel", "IdctKernel",
-                                    "GaborishKernel", "EpfKernel", "OutputKernel", "ModularGlobalFastKernel", "ModularGroupFastKernel", "ModularGroupKernel", nullptr};
+                                    "GaborishKernel", "EpfKernel", "OutputKernel", "ModularGlobalFastKernel", "ModularGroupFastKernel", nullptr};
 
 static bool g_tables_ready = false;
 void InitDeviceTables(void* stream) {
@@ -2631,7 +2698,7 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
   const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
-  const uint32_t lds_bytes = kTreeOff + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  const uint32_t lds_bytes = kLfWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
   hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)kLfWaves), nframes), dim3(64 * kLfWaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
@@ -2701,22 +2768,41 @@ void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, con
   if (fp.any_upsampled) hipLaunchKernelGGL(UpsampleKernel, grid, block, 0, (hipStream_t)stream, frames);
   hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters);
 }
-void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream) {
-  const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
-  const uint32_t lds_bytes = kTreeOff + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGlobalFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
-  hipLaunchKernelGGL(ModularGlobalFastKernel, dim3(nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
+void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream);
+// LDS plan of the Modular kernels: per-wavefront regions, tree region (whole tree or pruned per-wavefront slices), the
+// entropy code, and — for weighted-predictor trees — one WP-state slot per wavefront.  Everything should be LDS-resident
+// (a lookup in global memory costs ~10x); when it does not all fit, the tree region shrinks first (large trees are pruned
+// per stream anyway), then the code falls back to the shared budget.
+static void PlanModularLds(const LaunchCfg& cfg, uint32_t* nwaves_io, uint32_t* tree_cap, uint32_t* lds_tables, uint32_t* wp_base, uint32_t* lds_total) {
+  const uint32_t limit = 160 * 1024 - 4096;
+  uint32_t nwaves = *nwaves_io;
+  const bool pruned = cfg.max_tree_nodes > kLdsTreeMax;          // the tree is copied per wavefront, reduced to what its stream can reach
+  uint32_t cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
+  if (pruned && nwaves > 1) { nwaves = 2; cap = 2 * kLdsTreeMax; }   // two wavefronts, 1024 nodes each
+  uint32_t code = (uint32_t)std::min(cfg.mod_code_bytes, 96 * 1024);
+  auto wp = [&]() { return cfg.any_wp ? nwaves * kWpLdsBytes : 0u; };
+  auto total = [&]() { return nwaves * kWaveLds + cap * 16 + code + 16 + wp(); };
+  while (total() > limit && pruned && cap > 512) cap /= 2;
+  if (total() > limit) code = (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  *nwaves_io = nwaves;
+  *tree_cap = cap;
+  *lds_tables = nwaves * kWaveLds + cap * 16 + code;
+  if (wp() && total() <= limit) { *wp_base = (*lds_tables + 15) & ~15u; *lds_total = *wp_base + wp(); }
+  else { *wp_base = 0; *lds_total = *lds_tables; }
 }
 void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, const LaunchCfg& cfg, void* stream) {
-  {
-    const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
-    const uint32_t lds_bytes = kTreeOff + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGroupFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
-    hipLaunchKernelGGL(ModularGroupFastKernel, dim3(DivUp(max_lf_groups + max_groups, (int)kLfWaves), nframes), dim3(64 * kLfWaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
-  }
-  hipLaunchKernelGGL(ModularGroupKernel, dim3(max_lf_groups + max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames);
+  uint32_t nwaves = kLfWaves, tree_cap, lds_tables, wp_base, lds_bytes;
+  PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGroupFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  hipLaunchKernelGGL(ModularGroupFastKernel, dim3(DivUp(max_lf_groups + max_groups, (int)nwaves), nframes), dim3(64 * nwaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base);
+}
+void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream) {
+  uint32_t nwaves = 1, tree_cap, lds_tables, wp_base, lds_bytes;
+  PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGlobalFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  hipLaunchKernelGGL(ModularGlobalFastKernel, dim3(nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base);
 }
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream) {
   if (horizontal) { if (ah) hipLaunchKernelGGL(ModInvSqueezeHKernel, dim3((ah + 63) / 64), dim3(64), 0, (hipStream_t)stream, avg, res, out, aw, rw, ah); }
