@@ -101,7 +101,8 @@ def main():
     B = args.batch
     frame_bytes = W * H * 3
     pipeline = not args.no_pipeline
-    nbuf = 2 if pipeline else 1          # double-buffered batches: step k uses buffer set k % 2
+    nbuf = int(os.environ.get("JXL_BENCH_NBUF", "2")) if pipeline else 1   # double-buffered batches: step k uses buffer set k % nbuf
+    ahead = nbuf - 1                     # LF stages issued ahead of the step being finished
     outs, batches = [], []
     main = torch.cuda.current_stream()
     stream = main.cuda_stream
@@ -127,7 +128,7 @@ def main():
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
     rest_done = [torch.cuda.Event() for _ in range(nbuf)]
     gather_done = [torch.cuda.Event() for _ in range(nbuf)]
-    state = {"k": 0, "front_issued": 0}
+    state = {"k": 0, "front_issued": 0, "limit": args.warmup}
 
     def issue_front(k, timed):
         b = k % nbuf
@@ -148,8 +149,9 @@ def main():
         else:
             if state["front_issued"] <= k:
                 issue_front(k, timed); state["front_issued"] = k + 1
-            if not last and state["front_issued"] <= k + 1:
-                issue_front(k + 1, timed); state["front_issued"] = k + 2
+            for j in range(1, ahead + 1):
+                if k + j < state["limit"] and state["front_issued"] <= k + j:
+                    issue_front(k + j, timed); state["front_issued"] = k + j + 1
             main.wait_event(front_done[b])
             if do_gather and k >= nbuf:
                 main.wait_event(gather_done[b])       # the previous gather of this buffer set must have read the pixels
@@ -171,7 +173,7 @@ def main():
     torch.cuda.synchronize()
     for bt in batches:
         bt.finish(stream)
-    state["k"] = 0; state["front_issued"] = 0
+    state["k"] = 0; state["front_issued"] = 0; state["limit"] = args.steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
