@@ -63,3 +63,53 @@ def test_hdr_float_stream_roundtrip():
     assert dec.info.bits_per_sample == 32 and dec.info.exponent_bits == 8 and abs(dec.info.intensity_target - 1000.0) < 1e-3
     out = dec.image("f32", 3)
     assert np.abs(out - lin).mean() < 0.02
+
+
+# ---- stream features added later in the round: synthesiser x oracle on the CPU (the GPU suite repeats them through the C ABI) --
+def _smooth(seed, h, w, c, bits):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = ((np.sin(xx / 37.0) + np.cos(yy / 23.0)) * 0.25 + 0.5) * ((1 << bits) - 1)
+    return np.clip(base[..., None] + rng.normal(0, (1 << bits) / 1024.0, (h, w, c)).astype(np.float32), 0, (1 << bits) - 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("h,w,c,bits,rct,squeeze", [(50, 40, 1, 8, 0, 1), (280, 300, 3, 8, 1, 1), (280, 300, 4, 16, 1, 2), (2070, 2100, 1, 16, 0, 1), (9, 1, 1, 8, 0, 1)])
+def test_squeeze_lossless_roundtrip(h, w, c, bits, rct, squeeze):
+    """Default Squeeze chain (zero explicit steps in the stream) and explicit chains: residual channels in GlobalModular,
+    LfGroup (shift >= 3) and PassGroup sections; the oracle's inverse must return the source samples exactly."""
+    img = _smooth(5, h, w, c, bits)
+    out = O.decode(S.encode_modular(img, bits, bool(rct), squeeze)).image("u16" if bits == 16 else "u8", c)
+    assert np.array_equal(out, img)
+
+
+@pytest.mark.parametrize("strategy", [21, 22, 23, 24, 25, 26])
+def test_dct128_256_family_roundtrip(strategy):
+    img = S.synthetic_image(7, 520, 300)
+    out = O.decode(S.encode_vardct(img, seed=5, strategy_mix=100 + strategy, epf_iters=0, gab=0, distance=0.1, skip_lf_smoothing=1)).image("u8", 3)
+    assert psnr(out, img) > 41.0
+
+
+def test_alpha_passes_permuted_toc_and_orientation_streams():
+    img = S.synthetic_image(42, 600, 400)
+    al = (np.add.outer(np.arange(400), np.arange(600)) % 256).astype(np.uint8)
+    ref = O.decode(S.encode_vardct(img, seed=3, strategy_mix=2, alpha=al)).image("u8", 4)
+    assert np.array_equal(ref[..., 3], al) and psnr(ref[..., :3], img) > 33.0
+    for kw in ({"num_passes": 2}, {"num_passes": 3}, {"permute_toc": 7}, {"num_passes": 2, "permute_toc": 9}):
+        out = O.decode(S.encode_vardct(img, seed=3, strategy_mix=2, alpha=al, **kw)).image("u8", 4)
+        assert np.array_equal(out, ref), kw          # bit planes / section order do not change the decoded picture
+    d = O.decode(S.encode_vardct(img, seed=3, strategy_mix=2, orientation=6))
+    assert d.info.orientation == 6 and (d.info.xsize, d.info.ysize) == (600, 400)    # the oracle reports the stored raster
+
+
+@pytest.mark.parametrize("up,custom,floor", [(2, 0, 33.0), (2, 1, 33.0), (4, 1, 28.0), (8, 1, 23.0)])
+def test_upsampled_streams_roundtrip(up, custom, floor):
+    img = S.synthetic_image(62, 333, 201)
+    d = O.decode(S.encode_vardct(img, seed=4, strategy_mix=2, upsampling=up, custom_up_weights=custom))
+    assert (d.info.xsize, d.info.ysize) == (333, 201)
+    assert psnr(d.image("u8", 3), img) > floor
+
+
+def test_default_4x_upsampling_weights_rejected_by_the_oracle():
+    with pytest.raises(O.OracleError) as e:
+        O.decode(S.encode_vardct(S.synthetic_image(3, 96, 64), upsampling=4, custom_up_weights=0))
+    assert "unsupported" in str(e.value)
