@@ -122,6 +122,26 @@ def main():
         d = O.decode(data)
         manifest[name] = {"sha256_stream": hashlib.sha256(data).hexdigest(), "sha256_u8_rgb": hashlib.sha256(d.pixels("u8", 3).tobytes()).hexdigest(),
                           "sha256_f32_rgb": hashlib.sha256(d.pixels("f32", 3).tobytes()).hexdigest(), "width": c["w"], "height": c["h"]}
+    # streams exercising the features added later in the round (alpha extra channel, progressive passes + permuted TOC,
+    # upsampling with the default 2x weights, DCT128/256 varblocks at arbitrary positions, orientation); hashes are of the
+    # stored raster as the oracle renders it
+    img = S.synthetic_image(44, 520, 300)
+    al = (np.add.outer(np.arange(300), np.arange(520)) % 256).astype(np.uint8)
+    extra = [("vardct2_520x300_alpha_passes3_toc", dict(strategy_mix=2, epf_iters=1, gab=1, alpha=al, num_passes=3, permute_toc=5), 4),
+             ("vardct2_520x300_ups2_default", dict(strategy_mix=2, epf_iters=2, gab=1, upsampling=2), 3),
+             ("vardct2_520x300_ups4_custom_alpha", dict(strategy_mix=1, epf_iters=1, gab=1, upsampling=4, custom_up_weights=1, alpha=al), 4),
+             ("vardct2_520x300_mix5_orient7", dict(strategy_mix=5, epf_iters=3, gab=1, orientation=7), 3)]
+    for name, kw, nch in extra:
+        data = S.encode_vardct(img, seed=10, **kw)
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        d = O.decode(data)
+        manifest[name] = {"sha256_stream": hashlib.sha256(data).hexdigest(), "channels": nch, "sha256_u8": hashlib.sha256(d.pixels("u8", nch).tobytes()).hexdigest(),
+                          "sha256_f32": hashlib.sha256(d.pixels("f32", nch).tobytes()).hexdigest(), "width": 520, "height": 300}
+    yy, xx = np.mgrid[0:300, 0:333].astype(np.float32)
+    sq = np.clip((((np.sin(xx / 37.0) + np.cos(yy / 23.0)) * 0.25 + 0.5) * 65535)[..., None] + np.random.default_rng(3).normal(0, 64, (300, 333, 2)), 0, 65535).astype(np.int32)
+    data = S.encode_modular(sq, 16, False, 1)
+    open(os.path.join(HERE, "modular2_333x300_ga16_squeeze.jxl"), "wb").write(data)
+    manifest["modular2_333x300_ga16_squeeze"] = {"sha256_stream": hashlib.sha256(data).hexdigest(), "sha256_u16_ga_le": hashlib.sha256(sq.astype("<u2").tobytes()).hexdigest(), "width": 333, "height": 300}
     img = S.synthetic_image(43, 300, 280).astype(np.int32)
     rgba = np.concatenate([img * 257, (65535 - img[..., :1] * 257)], -1)
     data = S.encode_modular(rgba, 16, True)

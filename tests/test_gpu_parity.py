@@ -174,7 +174,7 @@ def test_bench_jxl_modular_groups(jx):
 
 
 # ---- VarDCT (the path north_star names) ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct")])
+@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct_")])
 def test_vardct_golden_streams(jx, name):
     data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
     _, px = jx.decoder_builder().decode_with(data, np.uint8)
@@ -182,6 +182,22 @@ def test_vardct_golden_streams(jx, name):
     _, pf = jx.decoder_builder().decode_with(data, np.float32)
     ref = O.decode(data).pixels("f32", 3).view(np.float32)
     assert ulp_diff(pf, ref) <= 1
+
+
+@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct2_") or k.startswith("modular2_")])
+def test_feature_golden_streams(jx, name):
+    """The committed feature streams through the C ABI (orientation kept as stored: the hashes are of the stored raster)."""
+    m = MANIFEST[name]
+    data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+    if name.startswith("modular2_"):
+        _, px = jx.decoder_builder().decode_with(data, np.uint16)
+        assert hashlib.sha256(px.astype("<u2").tobytes()).hexdigest() == m["sha256_u16_ga_le"]
+        return
+    dec = jx.decoder_builder(skip_reorientation=True, pixel_format=jx.PixelFormat(num_channels=m["channels"]))
+    _, px = dec.decode_with(data, np.uint8)
+    assert hashlib.sha256(px.tobytes()).hexdigest() == m["sha256_u8"]
+    _, pf = dec.decode_with(data, np.float32)
+    assert ulp_diff(pf, O.decode(data).pixels("f32", m["channels"]).view(np.float32)) <= 1
 
 
 @pytest.mark.parametrize("s", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 22, 23, 24, 25, 26])

@@ -109,7 +109,7 @@ def test_invalid_and_truncated_inputs():
             O.decode(bad)
 
 
-@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct")])
+@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct_")])
 def test_vardct_regression_vectors(name):
     """Committed synthesised streams: the oracle's float pipeline output is pinned by hash (regression, not libjxl parity)."""
     m = MANIFEST[name]
@@ -156,6 +156,26 @@ def test_default_2x_upsampling_weights_are_a_partition_of_unity():
     flat = np.full((40, 56, 3), 128, np.uint8)
     px = O.decode(S.encode_vardct(flat, upsampling=2, epf_iters=0, gab=0)).pixels("u8", 3)
     assert np.abs(px.astype(int) - 128).max() <= 1
+
+
+@pytest.mark.parametrize("name", [k for k in MANIFEST if k.startswith("vardct2_")])
+def test_feature_regression_vectors(name):
+    """Committed streams for alpha + progressive passes + permuted TOC, upsampling (default 2x / custom 4x weights), unaligned
+    DCT128/256 varblocks and orientation: the oracle's output is pinned by hash (regression, not libjxl parity)."""
+    m = MANIFEST[name]
+    data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+    assert hashlib.sha256(data).hexdigest() == m["sha256_stream"]
+    dec = O.decode(data)
+    assert (dec.info.xsize, dec.info.ysize) == (m["width"], m["height"])
+    assert hashlib.sha256(dec.pixels("u8", m["channels"]).tobytes()).hexdigest() == m["sha256_u8"]
+    assert hashlib.sha256(dec.pixels("f32", m["channels"]).tobytes()).hexdigest() == m["sha256_f32"]
+
+
+def test_squeeze_golden_stream_is_lossless():
+    m = MANIFEST["modular2_333x300_ga16_squeeze"]
+    data = open(os.path.join(GOLDEN, "modular2_333x300_ga16_squeeze.jxl"), "rb").read()
+    assert hashlib.sha256(data).hexdigest() == m["sha256_stream"]
+    assert hashlib.sha256(O.decode(data).pixels("u16", 2).tobytes()).hexdigest() == m["sha256_u16_ga_le"]
 
 
 def test_idct_matches_direct_formula():
