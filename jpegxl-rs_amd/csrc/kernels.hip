@@ -303,6 +303,7 @@ __device__ __forceinline__ void WaveSync() {   // orders LDS/global accesses bet
 // five error arrays (2 rows of xsize + 2 ints each) at a byte offset of the dynamic LDS instead of global scratch.
 struct WPStateLds {
   uint32_t base;            // byte offset; layout [error | pe0 | pe1 | pe2 | pe3], each 2 * (xsize + 2) ints
+  uint32_t div_off;         // 64-entry table of (1 << 24) / (i + 1) (context_predict.h kDivLookup) instead of a division per use
   int32_t xsize;
   int64_t prediction[4];
   int64_t pred;
@@ -310,9 +311,16 @@ struct WPStateLds {
   __device__ __forceinline__ int32_t Ld(int a, int32_t i) const { return LdS<int32_t>(Arr(a) + (uint32_t)i * 4u); }
   __device__ __forceinline__ void St(int a, int32_t i, int32_t v) const { StS<int32_t>(Arr(a) + (uint32_t)i * 4u, v); }
   static constexpr uint32_t Bytes(int32_t xs) { return 5u * 2u * (uint32_t)(xs + 2) * 4u; }
-  __device__ __forceinline__ void Init(uint32_t base_off, int32_t xs, uint32_t lane) {   // all lanes of the wavefront
-    base = base_off; xsize = xs;
+  __device__ __forceinline__ void Init(uint32_t base_off, uint32_t div_table_off, int32_t xs, uint32_t lane) {   // all lanes of the wavefront
+    base = base_off; xsize = xs; div_off = div_table_off;
     for (uint32_t i = lane; i < Bytes(xs) / 4; i += 64) StS<int32_t>(base + i * 4, 0);
+    StS<uint32_t>(div_off + lane * 4, (1u << 24) / (lane + 1));
+  }
+  __device__ __forceinline__ uint32_t Div(uint32_t i) const { return LdS<uint32_t>(div_off + i * 4); }
+  __device__ __forceinline__ uint32_t ErrorWeight(uint64_t x, uint32_t maxweight) const {
+    int shift = FloorLog2u64(x + 1) - 5;
+    if (shift < 0) shift = 0;
+    return 4 + ((maxweight * Div((uint32_t)(x >> shift))) >> shift);
   }
   __device__ __forceinline__ int64_t Predict(const WPHeader& hdr, int x, int y, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN, int32_t* max_err) {
     const int32_t cur_row = (y & 1) ? 0 : (xsize + 2);
@@ -323,7 +331,7 @@ struct WPStateLds {
     uint32_t weights[4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
-      weights[i] = WPState::ErrorWeight((uint64_t)(uint32_t)Ld(1 + i, pos_N) + (uint32_t)Ld(1 + i, pos_NE) + (uint32_t)Ld(1 + i, pos_NW), (uint32_t)hdr.w[i]);
+      weights[i] = ErrorWeight((uint64_t)(uint32_t)Ld(1 + i, pos_N) + (uint32_t)Ld(1 + i, pos_NE) + (uint32_t)Ld(1 + i, pos_NW), (uint32_t)hdr.w[i]);
     N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
     const int64_t teW = x == 0 ? 0 : Ld(0, cur_row + x - 1);
     const int64_t teN = Ld(0, pos_N);
@@ -347,7 +355,7 @@ struct WPStateLds {
     int64_t sum = (int64_t)(wsum >> 1) - 1;
 #pragma unroll
     for (int i = 0; i < 4; i++) sum += prediction[i] * (int64_t)weights[i];
-    pred = (sum * (int64_t)WPState::DivLookup(wsum - 1)) >> 24;
+    pred = (sum * (int64_t)Div(wsum - 1)) >> 24;
     if (((teN ^ teW) | (teN ^ teNW)) > 0) return pred;
     const int64_t mx = Max64(W, Max64(NE, N)), mn = Min64(W, Min64(NE, N));
     pred = Max64(mn, Min64(mx, pred));
@@ -367,7 +375,7 @@ struct WPStateLds {
   }
 };
 constexpr int32_t kWpLdsMaxW = 256;                                   // channel widths whose WP state fits the per-wavefront LDS slot
-constexpr uint32_t kWpLdsBytes = WPStateLds::Bytes(kWpLdsMaxW);       // 10 320 B
+constexpr uint32_t kWpLdsBytes = WPStateLds::Bytes(kWpLdsMaxW) + 256;   // 10 320 B of error rows + the 64-entry division table
 
 struct ModTables {
   const TreeNode* tree_g;
@@ -690,7 +698,101 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
   const bool use_wp = mc.uses_wp != 0 && mode == 0;
   const bool wp_in_lds = use_wp && T.wp_off != 0xFFFFFFFFu && ch.w <= kWpLdsMaxW;
   WPStateLds wpl;
-  if (wp_in_lds) { wpl.Init(T.wp_off, ch.w, lane); WaveSync(); }
+  if (wp_in_lds) { wpl.Init(T.wp_off, T.wp_off + kWpLdsBytes - 256, ch.w, lane); WaveSync(); }
+  // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
+  // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
+  // and predictors read, the WP state.  Rows up to kRowMax samples; wider channels take the loop below.
+  const bool lds_generic = T.tree_in_lds && T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
+  if (lds_generic) {
+    const int w = ch.w, h = ch.h;
+    const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
+    const uint32_t wend = br.wend;
+    BitReaderW bw;
+    bw.wpos = 0; bw.win_base = 0; bw.buf = 0; bw.avail = 0; bw.win_off = wb + kWinOff;
+    uint32_t skip_bits = 0;
+    if (lane == 0) { const uint64_t bp = br.BitPos(); bw.wpos = (uint32_t)(bp >> 5); skip_bits = (uint32_t)(bp & 31); }
+    uint32_t cur = wb + kRowOff, prev = wb + kRowOff + kRowMax * 4, prev2 = wb + kChunkOff;   // three row buffers, rotated
+    for (int y = 0; y < h; y++) {
+      int32_t* p = ch.data + (size_t)y * ch.stride;
+      if (lane == 0) StS<uint32_t>(wb + kWorkOff + 16, bw.wpos);
+      WaveSync();
+      const uint32_t wbase = LdS<uint32_t>(wb + kWorkOff + 16);
+      for (uint32_t i = lane; i < kWinWords; i += 64) StS<uint32_t>(wb + kWinOff + i * 4, wbase + i < wend ? LdG(br.words + wbase + i) : 0u);
+      WaveSync();
+      if (lane == 0) {
+        bw.win_base = wbase;
+        if (skip_bits != 0xFFFFFFFFu) { bw.buf = 0; bw.avail = 0; bw.Refill(); bw.buf >>= skip_bits; bw.avail -= (int)skip_bits; skip_bits = 0xFFFFFFFFu; }
+        int32_t left = 0, left2 = 0, prev9 = 0;
+        int32_t up0 = 0, up1 = 0, up2 = 0, up3 = 0;
+        if (y > 0) { up1 = LdS<int32_t>(prev); up2 = w > 1 ? LdS<int32_t>(prev + 4) : 0; up3 = w > 2 ? LdS<int32_t>(prev + 8) : 0; }
+        for (int x = 0; x < w; x++) {
+          const int32_t up4 = (y > 0 && x + 3 < w) ? LdS<int32_t>(prev + 4 * (x + 3)) : 0;
+          const int32_t W = x ? left : (y ? up1 : 0);
+          const int32_t N = y ? up1 : W;
+          const int32_t NW = (x && y) ? up0 : W;
+          const int32_t NE = (x + 1 < w && y) ? up2 : N;
+          const int32_t WW = x > 1 ? left2 : W;
+          const int32_t NN = y > 1 ? LdS<int32_t>(prev2 + 4 * x) : N;
+          const int32_t NEE = (x + 2 < w && y) ? up3 : NE;
+          int64_t wp_pred = 0;
+          int32_t wp_err = 0;
+          if (use_wp) wp_pred = wpl.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
+          TreeNode n;
+          if (mode == 1) {
+            int32_t v = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
+            v = v < -512 ? -512 : (v > 511 ? 511 : v);
+            n = T.Node(LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)));
+          } else {
+            uint32_t pos = subroot;
+            n = T.Node(pos);
+            while (n.prop >= 0) {
+              const int32_t v = PropValue(n.prop & 15, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, wp_err);
+              pos = v > n.val ? n.a : n.b;
+              n = T.Node(pos);
+            }
+          }
+          prev9 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+          const uint32_t cluster = n.a >> 8;
+          const int32_t guess = Predict(n.a & 0xFF, W, N, NW, NE, NN, WW, NEE, wp_pred);
+          // ANS symbol + hybrid integer out of LDS (same as DecodeChunkLds)
+          const uint32_t res = state & 0xFFF;
+          const uint32_t i = res >> (12 - la), pos_ = res & ((1u << (12 - la)) - 1);
+          const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
+          const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
+          const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+          const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+          const bool hit = pos_ >= cutoff;
+          uint32_t tok = hit ? right : i;
+          state = (hit ? freq1 : freq0) * (state >> 12) + (hit ? offs1 + pos_ : pos_);
+          if (state < (1u << 16)) state = (state << 16) | bw.Read(16);
+          const uint32_t split_exp = cfg & 0xFF;
+          if (tok >= (1u << split_exp)) {
+            const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+            const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - (1u << split_exp)) >> (msb + lsb))) & 31;
+            const uint32_t low = tok & ((1u << lsb) - 1);
+            tok >>= lsb;
+            const uint32_t bits = nbits ? bw.Read((int)nbits) : 0;
+            const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+            tok = (((hi << nbits) | bits) << lsb) | low;
+          }
+          const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) * n.b + (uint32_t)n.val + (uint32_t)guess);
+          StS<int32_t>(cur + 4 * x, val);
+          if (use_wp) wpl.Update(val, x, y);
+          left2 = left; left = val;
+          up0 = up1; up1 = up2; up2 = up3; up3 = up4;
+        }
+      }
+      WaveSync();
+      for (int i = (int)lane; i < w; i += 64) StG(p + i, LdS<int32_t>(cur + 4 * i));
+      const uint32_t t = prev2; prev2 = prev; prev = cur; cur = t;
+    }
+    if (lane == 0) StS<uint64_t>(wb + kWorkOff + 32, bw.BitPos());
+    WaveSync();
+    const uint64_t endpos = LdS<uint64_t>(wb + kWorkOff + 32);
+    br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
+    WaveSync();
+    return;
+  }
   if (lane == 0) {
     const int w = ch.w, h = ch.h;
     const FastCode& code = T.code;
