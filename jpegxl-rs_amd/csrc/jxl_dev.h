@@ -241,6 +241,7 @@ struct ModularCtx {
   uint32_t uses_wp;     // tree uses predictor 6 or property 15
   int32_t* wp_scratch;  // 5 * 2 * (max_w + 2) ints (only if uses_wp)
   uint32_t stream_id;
+  uint32_t narrow_wp = 0;  // device fast path: 32-bit weighted-predictor intermediates are exact (samples of at most 12 bits)
 };
 
 // Decodes channel `chan` (index within the sub-stream, = property 0) — encoding.cc DecodeModularChannelMAANS.

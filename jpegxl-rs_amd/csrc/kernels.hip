@@ -305,14 +305,16 @@ struct WPStateLds {
   uint32_t base;            // byte offset; layout [error | pe0 | pe1 | pe2 | pe3], each 2 * (xsize + 2) ints
   uint32_t div_off;         // 64-entry table of (1 << 24) / (i + 1) (context_predict.h kDivLookup) instead of a division per use
   int32_t xsize;
-  int64_t prediction[4];
+  bool narrow;              // 32-bit intermediates are exact for this image (samples of at most 12 bits)
+  int64_t prediction_store[4];
   int64_t pred;
+  template <typename WI> static __device__ __forceinline__ WI AbsT(WI v) { return v < 0 ? -v : v; }
   __device__ __forceinline__ uint32_t Arr(int a) const { return base + (uint32_t)a * (uint32_t)(xsize + 2) * 8u; }
   __device__ __forceinline__ int32_t Ld(int a, int32_t i) const { return LdS<int32_t>(Arr(a) + (uint32_t)i * 4u); }
   __device__ __forceinline__ void St(int a, int32_t i, int32_t v) const { StS<int32_t>(Arr(a) + (uint32_t)i * 4u, v); }
   static constexpr uint32_t Bytes(int32_t xs) { return 5u * 2u * (uint32_t)(xs + 2) * 4u; }
-  __device__ __forceinline__ void Init(uint32_t base_off, uint32_t div_table_off, int32_t xs, uint32_t lane) {   // all lanes of the wavefront
-    base = base_off; xsize = xs; div_off = div_table_off;
+  __device__ __forceinline__ void Init(uint32_t base_off, uint32_t div_table_off, int32_t xs, uint32_t lane, bool narrow_ok) {   // all lanes of the wavefront
+    base = base_off; xsize = xs; div_off = div_table_off; narrow = narrow_ok;
     for (uint32_t i = lane; i < Bytes(xs) / 4; i += 64) StS<int32_t>(base + i * 4, 0);
     StS<uint32_t>(div_off + lane * 4, (1u << 24) / (lane + 1));
   }
@@ -322,7 +324,11 @@ struct WPStateLds {
     if (shift < 0) shift = 0;
     return 4 + ((maxweight * Div((uint32_t)(x >> shift))) >> shift);
   }
-  __device__ __forceinline__ int64_t Predict(const WPHeader& hdr, int x, int y, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN, int32_t* max_err) {
+  // WI = int64_t (reference arithmetic) or int32_t: identical results whenever no intermediate exceeds 31 bits, which holds
+  // for samples of at most 12 bits (values * 8, errors and the weighted sums stay below 2^28); only the final product with
+  // the division table needs 64 bits.
+  template <typename WI> __device__ __forceinline__ int64_t PredictT(const WPHeader& hdr, int x, int y, WI N, WI W, WI NE, WI NW, WI NN, int32_t* max_err) {
+    WI* prediction = reinterpret_cast<WI*>(prediction_store);
     const int32_t cur_row = (y & 1) ? 0 : (xsize + 2);
     const int32_t prev_row = (y & 1) ? (xsize + 2) : 0;
     const int32_t pos_N = prev_row + x;
@@ -333,15 +339,15 @@ struct WPStateLds {
     for (int i = 0; i < 4; i++)
       weights[i] = ErrorWeight((uint64_t)(uint32_t)Ld(1 + i, pos_N) + (uint32_t)Ld(1 + i, pos_NE) + (uint32_t)Ld(1 + i, pos_NW), (uint32_t)hdr.w[i]);
     N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
-    const int64_t teW = x == 0 ? 0 : Ld(0, cur_row + x - 1);
-    const int64_t teN = Ld(0, pos_N);
-    const int64_t teNW = Ld(0, pos_NW);
-    const int64_t sumWN = teN + teW;
-    const int64_t teNE = Ld(0, pos_NE);
-    int64_t p = teW;
-    if (Abs64(teN) > Abs64(p)) p = teN;
-    if (Abs64(teNW) > Abs64(p)) p = teNW;
-    if (Abs64(teNE) > Abs64(p)) p = teNE;
+    const WI teW = x == 0 ? 0 : Ld(0, cur_row + x - 1);
+    const WI teN = Ld(0, pos_N);
+    const WI teNW = Ld(0, pos_NW);
+    const WI sumWN = teN + teW;
+    const WI teNE = Ld(0, pos_NE);
+    WI p = teW;
+    if (AbsT(teN) > AbsT(p)) p = teN;
+    if (AbsT(teNW) > AbsT(p)) p = teNW;
+    if (AbsT(teNE) > AbsT(p)) p = teNE;
     *max_err = (int32_t)p;
     prediction[0] = W + NE - N;
     prediction[1] = N - (((sumWN + teNE) * hdr.p1) >> 5);
@@ -352,27 +358,33 @@ struct WPStateLds {
     wsum = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) { weights[i] >>= (lw - 4); wsum += weights[i]; }
-    int64_t sum = (int64_t)(wsum >> 1) - 1;
+    WI sum = (WI)(wsum >> 1) - 1;
 #pragma unroll
-    for (int i = 0; i < 4; i++) sum += prediction[i] * (int64_t)weights[i];
-    pred = (sum * (int64_t)Div(wsum - 1)) >> 24;
+    for (int i = 0; i < 4; i++) sum += prediction[i] * (WI)weights[i];
+    pred = ((int64_t)sum * (int64_t)Div(wsum - 1)) >> 24;
     if (((teN ^ teW) | (teN ^ teNW)) > 0) return pred;
     const int64_t mx = Max64(W, Max64(NE, N)), mn = Min64(W, Min64(NE, N));
     pred = Max64(mn, Min64(mx, pred));
     return pred;
   }
-  __device__ __forceinline__ void Update(int64_t val, int x, int y) {
+  __device__ __forceinline__ int64_t Predict(const WPHeader& hdr, int x, int y, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN, int32_t* max_err) {
+    if (narrow) return PredictT<int32_t>(hdr, x, y, (int32_t)N, (int32_t)W, (int32_t)NE, (int32_t)NW, (int32_t)NN, max_err);
+    return PredictT<int64_t>(hdr, x, y, N, W, NE, NW, NN, max_err);
+  }
+  template <typename WI> __device__ __forceinline__ void UpdateT(WI val, int x, int y) {
+    const WI* prediction = reinterpret_cast<const WI*>(prediction_store);
     const int32_t cur_row = (y & 1) ? 0 : (xsize + 2);
     const int32_t prev_row = (y & 1) ? (xsize + 2) : 0;
     val *= 8;
-    St(0, cur_row + x, (int32_t)(pred - val));
+    St(0, cur_row + x, (int32_t)((WI)pred - val));
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int32_t err = (int32_t)((Abs64(prediction[i] - val) + 3) >> 3);
+      const int32_t err = (int32_t)((AbsT(prediction[i] - val) + 3) >> 3);
       St(1 + i, cur_row + x, err);
       St(1 + i, prev_row + x + 1, Ld(1 + i, prev_row + x + 1) + err);
     }
   }
+  __device__ __forceinline__ void Update(int64_t val, int x, int y) { if (narrow) UpdateT<int32_t>((int32_t)val, x, y); else UpdateT<int64_t>(val, x, y); }
 };
 constexpr int32_t kWpLdsMaxW = 256;                                   // channel widths whose WP state fits the per-wavefront LDS slot
 constexpr uint32_t kWpLdsBytes = WPStateLds::Bytes(kWpLdsMaxW) + 256;   // 10 320 B of error rows + the 64-entry division table
@@ -698,7 +710,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
   const bool use_wp = mc.uses_wp != 0 && mode == 0;
   const bool wp_in_lds = use_wp && T.wp_off != 0xFFFFFFFFu && ch.w <= kWpLdsMaxW;
   WPStateLds wpl;
-  if (wp_in_lds) { wpl.Init(T.wp_off, T.wp_off + kWpLdsBytes - 256, ch.w, lane); WaveSync(); }
+  if (wp_in_lds) { wpl.Init(T.wp_off, T.wp_off + kWpLdsBytes - 256, ch.w, lane, mc.narrow_wp != 0); WaveSync(); }
   // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
   // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
   // and predictors read, the WP state.  Rows up to kRowMax samples; wider channels take the loop below.
@@ -743,10 +755,18 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
             v = v < -512 ? -512 : (v > 511 ? 511 : v);
             n = T.Node(LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)));
           } else {
+            // all 16 properties of the sample once, into LDS; every tree level then costs a node read and one indexed read
+            // instead of a 16-way select over recomputed values
+            const uint32_t pv = wb + kWorkOff + 896;
+            const int32_t grad = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+            StS<int4>(pv, make_int4(chan, (int32_t)mc.stream_id, y, x));
+            StS<int4>(pv + 16, make_int4(N < 0 ? (int32_t)(0u - (uint32_t)N) : N, W < 0 ? (int32_t)(0u - (uint32_t)W) : W, N, W));
+            StS<int4>(pv + 32, make_int4((int32_t)((uint32_t)W - (uint32_t)prev9), grad, (int32_t)((uint32_t)W - (uint32_t)NW), (int32_t)((uint32_t)NW - (uint32_t)N)));
+            StS<int4>(pv + 48, make_int4((int32_t)((uint32_t)N - (uint32_t)NE), (int32_t)((uint32_t)N - (uint32_t)NN), (int32_t)((uint32_t)W - (uint32_t)WW), wp_err));
             uint32_t pos = subroot;
             n = T.Node(pos);
             while (n.prop >= 0) {
-              const int32_t v = PropValue(n.prop & 15, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, wp_err);
+              const int32_t v = LdS<int32_t>(pv + 4 * (uint32_t)(n.prop & 15));
               pos = v > n.val ? n.a : n.b;
               n = T.Node(pos);
             }
@@ -2508,7 +2528,7 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
   uint32_t state = 0;
   if (lane == 0) state = br.Read(32);
   ModularCtx mc;
-  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0;
+  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0; mc.narrow_wp = f.mod_bits <= 12;
   mc.wp_scratch = f.mod_wp_scratch;
   for (uint32_t c = 0; c < f.mod_global_decodable; c++) {
     const ModChanDev mcd = f.mod_chan[c];
@@ -2619,7 +2639,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   WaveSync();
   if (!U.go) return;
   ModularCtx mc;
-  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = U.gh.wp;
+  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = U.gh.wp; mc.narrow_wp = f.mod_bits <= 12;
   mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
   mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
   if (U.direct) {
