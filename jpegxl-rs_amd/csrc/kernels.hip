@@ -998,70 +998,109 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
     const size_t o = (size_t)(gy * 32 + y) * f.cw + gx * 32 + x;
     f.ytox[o] = (int8_t)a; f.ytob[o] = (int8_t)b;
   }
-  // ---- varblock placement (raster order, first not-yet-covered block) with an LDS coverage bitmap; coefficient
-  // offsets per 256x256 group.  Blocks never cross a 32-block boundary, hence never a 64-bit word of the bitmap.
-  const uint32_t cover_off = wb;   // 8 KiB, reuses this wavefront's private region
-  for (uint32_t i = lane; i < 1024; i += 64) {
-    const uint32_t y = i >> 2, wx = (i & 3) * 64;
-    unsigned long long m = 0;   // bits outside the LF group are pre-set
-    if (y >= gbh || wx >= gbw) m = ~0ull;
-    else if (gbw - wx < 64) m = ~0ull << (gbw - wx);
-    StS<unsigned long long>(cover_off + i * 8, m);
+  // ---- varblock placement (raster order, first not-yet-covered block).  Inherently sequential, so lane 0 walks it — but
+  // out of LDS only: 64 (strategy, hf_mul) pairs are staged per round by all lanes, the coverage bitmap is a ring of 64
+  // rows (a varblock reaches at most 32 rows down and rows above the scan line are never looked at again), the running
+  // coefficient offsets / varblock counts of the 64 groups live in LDS, and lane 0 only emits one 16-byte record per
+  // varblock; the wavefront then writes coef_off, the per-group varblock lists and the block-info words of all covered
+  // blocks in parallel.  (The one-lane version with global loads and stores in the loop took 44 % of this kernel.)
+  // Blocks never cross a 32-block boundary, hence never a 64-bit word of the bitmap.
+  const uint32_t ring_off = wb, goff_off = wb + 2048, gcnt_off = wb + 2304, in_off = wb + 2560, rec_off = wb + 3072, cnt_off = wb + 4096;
+  const uint32_t pat_off = wb + 4128, geo_off = wb + 4160;   // row pattern (8 words), per-strategy {cx | cy << 8} (27 halfwords)
+  // bitmap: 32-bit words, one per 32-block column of the LF group (8 per row); bits outside the group are pre-set
+  if (lane < 8) StS<uint32_t>(pat_off + lane * 4, lane * 32 >= gbw ? ~0u : (gbw - lane * 32 < 32 ? ~0u << (gbw - lane * 32) : 0u));
+  if (lane < 27) StS<uint16_t>(geo_off + lane * 2, (uint16_t)(CoveredX(lane) | (CoveredY(lane) << 8)));
+  WaveSync();
+  for (uint32_t i = lane; i < 512; i += 64) {
+    const uint32_t y = i >> 3, wi = i & 7;
+    StS<uint32_t>(ring_off + i * 4, y >= gbh ? ~0u : LdS<uint32_t>(pat_off + wi * 4));
   }
+  StS<uint32_t>(goff_off + lane * 4, 0u); StS<uint32_t>(gcnt_off + lane * 4, 0u);
+  if (lane == 0) { StS<uint32_t>(cnt_off + 4, 0u); StS<uint32_t>(cnt_off + 8, 0u); }
   WaveSync();
   if (s_fail) return;
-  if (lane == 0) {
-    uint32_t goff[64], gcnt[64];
-    for (int i = 0; i < 64; i++) { goff[i] = 0; gcnt[i] = 0; }
-    uint32_t num = 0;
-    int32_t s_next = LdG(m_blk), q_next = LdG(m_blk + nb_blocks);
-    bool bad = false;
-    for (uint32_t y = 0; y < gbh && !bad; y++) {
-      for (uint32_t wi = 0; wi < 4 && !bad; wi++) {
-        while (true) {
-          const unsigned long long cov = LdS<unsigned long long>(cover_off + (y * 4 + wi) * 8);
-          if (cov == ~0ull) break;
-          const uint32_t x = wi * 64 + (uint32_t)__ffsll((long long)~cov) - 1;
-          if (num >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
-          const int32_t s = s_next, q = q_next;
-          num++;
-          if (num < nb_blocks) { s_next = LdG(m_blk + num); q_next = LdG(m_blk + nb_blocks + num); }
-          if (s < 0 || s >= 27 || q < 0 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }
-          if ((s >= 14 && s <= 17)) { SetError(f, kErrUnsupported); bad = true; break; }  // AFV
-          const uint32_t cx = CoveredX(s), cy = CoveredY(s);
-          if (x + cx > gbw || y + cy > gbh || (x % 32) + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
-          const unsigned long long bits = ((cx == 64 ? 0ull : (1ull << cx)) - 1ull) << (x & 63);
-          for (uint32_t iy = 0; iy < cy; iy++) {
-            const uint32_t co = cover_off + ((y + iy) * 4 + wi) * 8;
-            const unsigned long long wv = LdS<unsigned long long>(co);
-            if (wv & bits) { SetError(f, kErrVarblock); bad = true; }
-            StS<unsigned long long>(co, wv | bits);
+  uint32_t num0 = 0, flags_acc = 0;
+  while (true) {
+    {  // stage the next 64 (strategy, hf_mul - 1) pairs
+      const uint32_t idx = num0 + lane;
+      int2 sq = make_int2(-1, -1);
+      if (idx < nb_blocks) sq = make_int2(LdG(m_blk + idx), LdG(m_blk + nb_blocks + idx));
+      StS<int2>(in_off + lane * 8, sq);
+    }
+    WaveSync();
+    if (lane == 0) {
+      uint32_t count = 0;
+      bool bad = false;
+      uint32_t y = LdS<uint32_t>(cnt_off + 4), wi = LdS<uint32_t>(cnt_off + 8);   // scan position: row, 32-block column
+      while (count < 64 && y < gbh) {
+        const uint32_t row = ring_off + (y & 63) * 32;
+        const uint32_t cov = LdS<uint32_t>(row + wi * 4);
+        if (cov == ~0u) {
+          // the first uncovered block of a row only moves right: next column; after the last one the ring slot becomes row y + 64
+          if (++wi == 8) {
+            const bool past = y + 64 >= gbh;
+            for (uint32_t k = 0; k < 8; k++) StS<uint32_t>(row + k * 4, past ? ~0u : LdS<uint32_t>(pat_off + k * 4));
+            y++; wi = 0;
           }
-          if (bad) break;
-          if ((x % 4) + cx > 4 || (y % 4) + cy > 4) atomicOr(f.frame_flags, 4u);   // not inside one 32x32 tile: the IDCT uses 64x64 tiles
-          if (cx > 8 || cy > 8) {
-            // DCT128/256 family: BigIdctKernel; whole 64x64 tiles when aligned, else the frame takes the generic path
-            atomicOr(f.frame_flags, (x % 8) || (y % 8) ? 3u : 2u);
-          } else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) atomicOr(f.frame_flags, 1u);   // varblock not contained in a 64x64 tile: generic IDCT
-          const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
-          const uint32_t gi = (y / 32) * 8 + (x / 32);
-          StG(f.coef_off + o, goff[gi]);
-          {  // per-group varblock list for the HF decoder: {strategy | hf_mul-1 << 8 | x << 16 | y << 21, coefficient offset}
-            const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
-            StG(f.vb_list + (size_t)gg * 1024 + gcnt[gi], make_uint2((uint32_t)s | ((uint32_t)q << 8) | ((x % 32) << 16) | ((y % 32) << 21), goff[gi]));
-            gcnt[gi]++;
-          }
-          goff[gi] += cx * cy * 64;
-          for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++)
-            StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo((uint32_t)s, ix == 0 && iy == 0, (uint32_t)q, ix, iy, 0));
+          continue;
         }
+        const uint32_t xb = (uint32_t)__ffs((int)~cov) - 1, x = wi * 32 + xb;
+        const int2 sq = LdS<int2>(in_off + count * 8);
+        const uint32_t s = (uint32_t)sq.x, q = (uint32_t)sq.y;
+        if (num0 + count >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
+        if (s >= 27 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }       // (negative values wrap to large ones)
+        if (s >= 14 && s <= 17) { SetError(f, kErrUnsupported); bad = true; break; }   // AFV
+        const uint32_t geo = LdS<uint16_t>(geo_off + s * 2), cx = geo & 0xFF, cy = geo >> 8;
+        if (x + cx > gbw || y + cy > gbh || xb + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
+        const uint32_t bits = (cx == 32 ? ~0u : (1u << cx) - 1u) << xb;
+        uint32_t clash = 0;
+        for (uint32_t iy = 0; iy < cy; iy++) {
+          const uint32_t co = ring_off + ((y + iy) & 63) * 32 + wi * 4;
+          const uint32_t wv = LdS<uint32_t>(co);
+          clash |= wv & bits;
+          StS<uint32_t>(co, wv | bits);
+        }
+        if (clash) { SetError(f, kErrVarblock); bad = true; break; }
+        if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;      // not inside one 32x32 tile: the IDCT uses 64x64 tiles
+        if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;   // DCT128/256 family: BigIdctKernel (+ generic path if unaligned)
+        else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;  // varblock not contained in a 64x64 tile: generic IDCT
+        const uint32_t gi = (y / 32) * 8 + wi;
+        const uint32_t go = LdS<uint32_t>(goff_off + gi * 4), gc = LdS<uint32_t>(gcnt_off + gi * 4);
+        StS<uint32_t>(goff_off + gi * 4, go + cx * cy * 64);
+        StS<uint32_t>(gcnt_off + gi * 4, gc + 1);
+        // record: {x | y << 8 | s << 16 | q << 24, coefficient offset, index in the group's list, cx | cy << 8}
+        StS<uint4>(rec_off + count * 16, make_uint4(x | (y << 8) | (s << 16) | (q << 24), go, gc, geo));
+        count++;
       }
+      if (bad) s_fail = 1;
+      StS<uint32_t>(cnt_off, count);
+      StS<uint32_t>(cnt_off + 4, y);
+      StS<uint32_t>(cnt_off + 8, wi);
     }
-    if (bad) s_fail = 1;
-    else for (uint32_t gi = 0; gi < 64; gi++) {
-      const uint32_t ly = gi / 8, lx = gi % 8;
-      if (ly * 32 < gbh && lx * 32 < gbw) StG(f.vb_count + (gy * 8 + ly) * f.xgroups + gx * 8 + lx, gcnt[gi]);
+    WaveSync();
+    if (s_fail) return;
+    const uint32_t count = LdS<uint32_t>(cnt_off);
+    const uint32_t scan_y = LdS<uint32_t>(cnt_off + 4);
+    if (lane < count) {
+      const uint4 r = LdS<uint4>(rec_off + lane * 16);
+      const uint32_t x = r.x & 0xFF, y = (r.x >> 8) & 0xFF, s = (r.x >> 16) & 0xFF, q = r.x >> 24;
+      const uint32_t cx = r.w & 0xFF, cy = r.w >> 8;
+      const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
+      StG(f.coef_off + o, r.y);
+      // per-group varblock list for the HF decoder: {strategy | hf_mul-1 << 8 | x << 16 | y << 21, coefficient offset}
+      const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
+      StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (q << 8) | ((x % 32) << 16) | ((y % 32) << 21), r.y));
+      for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++)
+        StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, 0));
     }
+    num0 += count;
+    if (scan_y >= gbh) break;
+    WaveSync();   // records consumed before the next round overwrites them
+  }
+  if (lane == 0 && flags_acc) atomicOr(f.frame_flags, flags_acc);
+  {
+    const uint32_t gi = lane, ly = gi / 8, lx = gi % 8;
+    if (ly * 32 < gbh && lx * 32 < gbw) StG(f.vb_count + (gy * 8 + ly) * f.xgroups + gx * 8 + lx, LdS<uint32_t>(gcnt_off + gi * 4));
   }
   WaveSync();
   if (s_fail) return;
