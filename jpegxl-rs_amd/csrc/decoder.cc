@@ -520,6 +520,7 @@ void Batch::Prepare(void* stream_v) {
       if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); cfg.any_wp |= p.tree.uses_wp ? 1 : 0; }
       if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
     }
+    if (getenv("JXL_HIP_DEBUG_LDS")) fprintf(stderr, "[jxl-hip] LDS sizing: tree nodes %d, modular code %d B, AC code %d B, BlockCtxDev %zu B\n", cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.ac_code_bytes, sizeof(BlockCtxDev));
   }
   {  // per-pass table descriptors (device array next to the frame descriptors)
     pass_first_.assign(n, 0);

@@ -323,56 +323,34 @@ JXL_HD_NOINLINE void DecodeModularChannel(BitReader& br, AnsReader& ans, const M
 #define JXL_TABLE static const
 #endif
 
-JXL_HD uint32_t CoveredX(uint32_t s) {
-  switch (s) {
-    case 4: case 7: case 10: return 2;
-    case 5: case 9: case 11: case 19: return 4;
-    case 18: case 20: case 22: return 8;
-    case 21: case 23: case 25: return 16;
-    case 24: case 26: return 32;
-    default: return 1;
-  }
+// Per-strategy tables packed as 4-bit fields of two 64-bit immediates (strategies 0..15 / 16..31): the lookups are
+// branch-free — the switch statements these replace compiled into long chains of divergent branches on the GPU.
+namespace strat {
+constexpr uint8_t kLog2Cx[32] = {0, 0, 0, 0, 1, 2, 0, 1, 0, 2, 1, 2, 0, 0, 0, 0, 0, 0, 3, 2, 3, 4, 3, 4, 5, 4, 5};
+constexpr uint8_t kLog2Cy[32] = {0, 0, 0, 0, 1, 2, 1, 0, 2, 0, 2, 1, 0, 0, 0, 0, 0, 0, 3, 3, 2, 4, 4, 3, 5, 5, 4};
+constexpr uint8_t kOrder[32] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+constexpr uint8_t kQuant[32] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+constexpr uint64_t Pack(const uint8_t (&t)[32], int lo, int bits) {
+  uint64_t r = 0;
+  for (int i = 0; i < 64 / bits; i++) if (lo + i < 32) r |= (uint64_t)t[lo + i] << (bits * i);
+  return r;
 }
-JXL_HD uint32_t CoveredY(uint32_t s) {
-  switch (s) {
-    case 4: case 6: case 11: return 2;
-    case 5: case 8: case 10: case 20: return 4;
-    case 18: case 19: case 23: return 8;
-    case 21: case 22: case 26: return 16;
-    case 24: case 25: return 32;
-    default: return 1;
-  }
-}
-JXL_HD uint32_t OrderBucket(uint32_t s) {
-  // {0,1,1,1,2,3,4,4,5,5,6,6,1,1,1,1,1,1,7,8,8,9,10,10,11,12,12}
-  if (s == 0) return 0;
-  if (s <= 3 || (s >= 12 && s <= 17)) return 1;
-  if (s == 4) return 2;
-  if (s == 5) return 3;
-  if (s <= 7) return 4;
-  if (s <= 9) return 5;
-  if (s <= 11) return 6;
-  if (s == 18) return 7;
-  if (s <= 20) return 8;
-  if (s == 21) return 9;
-  if (s <= 23) return 10;
-  if (s == 24) return 11;
-  return 12;
-}
+constexpr uint64_t kCxLo = Pack(kLog2Cx, 0, 4), kCxHi = Pack(kLog2Cx, 16, 4);
+constexpr uint64_t kCyLo = Pack(kLog2Cy, 0, 4), kCyHi = Pack(kLog2Cy, 16, 4);
+constexpr uint64_t kOrdLo = Pack(kOrder, 0, 4), kOrdHi = Pack(kOrder, 16, 4);
+// quant kinds reach 16: 5-bit fields, 12 per word
+constexpr uint64_t kQk0 = Pack(kQuant, 0, 5), kQk1 = Pack(kQuant, 12, 5), kQk2 = Pack(kQuant, 24, 5);
+}  // namespace strat
+JXL_HD uint32_t StratNibble(uint64_t lo, uint64_t hi, uint32_t s) { return (uint32_t)((s & 16 ? hi : lo) >> ((s & 15) * 4)) & 15u; }
+JXL_HD uint32_t Log2CoveredX(uint32_t s) { return StratNibble(strat::kCxLo, strat::kCxHi, s); }
+JXL_HD uint32_t Log2CoveredY(uint32_t s) { return StratNibble(strat::kCyLo, strat::kCyHi, s); }
+JXL_HD uint32_t CoveredX(uint32_t s) { return 1u << Log2CoveredX(s); }
+JXL_HD uint32_t CoveredY(uint32_t s) { return 1u << Log2CoveredY(s); }
+JXL_HD uint32_t OrderBucket(uint32_t s) { return StratNibble(strat::kOrdLo, strat::kOrdHi, s); }
 JXL_HD uint32_t QuantKind(uint32_t s) {
-  // {0,1,2,3,4,5,6,6,7,7,8,8,9,9,10,10,10,10,11,12,12,13,14,14,15,16,16}
-  if (s <= 5) return s;
-  if (s <= 7) return 6;
-  if (s <= 9) return 7;
-  if (s <= 11) return 8;
-  if (s <= 13) return 9;
-  if (s <= 17) return 10;
-  if (s == 18) return 11;
-  if (s <= 20) return 12;
-  if (s == 21) return 13;
-  if (s <= 23) return 14;
-  if (s == 24) return 15;
-  return 16;
+  const uint64_t w = s < 12 ? strat::kQk0 : s < 24 ? strat::kQk1 : strat::kQk2;
+  const uint32_t i = s < 12 ? s : s < 24 ? s - 12 : s - 24;
+  return (uint32_t)(w >> (i * 5)) & 31u;
 }
 
 // per-8x8-block info word written by the LF stage:

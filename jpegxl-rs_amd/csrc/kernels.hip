@@ -1087,9 +1087,24 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
       const uint32_t cx = r.w & 0xFF, cy = r.w >> 8;
       const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
       StG(f.coef_off + o, r.y);
-      // per-group varblock list for the HF decoder: {strategy | hf_mul-1 << 8 | x << 16 | y << 21, coefficient offset}
+      // block-context inputs of the HF stage (ac_context.h): quant-field and LF-value buckets of the varblock's first block,
+      // folded into qf_idx * num_lf_ctxs + lf_idx (< 64) here so that the HF decoder's loop has no threshold searches
+      const BlockCtxDev& bcm = *f.bcm;
+      uint32_t qf_idx = 0;
+      for (uint32_t i = 0; i < bcm.n_qf_thr; i++) qf_idx += q + 1 > bcm.qf_thr[i];
+      uint32_t lf_idx = 0;
+      if (bcm.num_lf_ctxs > 1) {
+        const int32_t q0 = LdG(f.lfq[0] + o), q1 = LdG(f.lfq[1] + o), q2 = LdG(f.lfq[2] + o);
+        uint32_t b0 = 0, b1 = 0, b2 = 0;
+        for (uint32_t i = 0; i < bcm.n_lf_thr[0]; i++) b0 += q0 > bcm.lf_thr[0][i];
+        for (uint32_t i = 0; i < bcm.n_lf_thr[1]; i++) b1 += q1 > bcm.lf_thr[1][i];
+        for (uint32_t i = 0; i < bcm.n_lf_thr[2]; i++) b2 += q2 > bcm.lf_thr[2][i];
+        lf_idx = (b0 * (bcm.n_lf_thr[2] + 1) + b2) * (bcm.n_lf_thr[1] + 1) + b1;
+      }
+      const uint32_t qlf = (qf_idx * bcm.num_lf_ctxs + lf_idx) & 63u;
+      // per-group varblock list for the HF decoder: {strategy | hf_mul-1 << 8 | x << 16 | y << 21 | qlf << 26, coefficient offset}
       const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
-      StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (q << 8) | ((x % 32) << 16) | ((y % 32) << 21), r.y));
+      StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (q << 8) | ((x % 32) << 16) | ((y % 32) << 21) | (qlf << 26), r.y));
       for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++)
         StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, 0));
     }
@@ -1346,12 +1361,7 @@ constexpr uint32_t kSimtNzOff = 128;                                   // per-th
 constexpr uint32_t kSimtRingOff = kSimtNzOff + kSimtThreads * 96;      // per-thread bit-stream ring: 16 words
 constexpr uint32_t kSimtBcmOff = kSimtRingOff + kSimtThreads * 64;     // copy of the BlockCtxDev
 constexpr uint32_t kSimtOrdOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;   // natural orders of buckets 0..8 (u16)
-constexpr uint32_t kSimtCodeOff = kSimtOrdOff;   // (orders stay in global memory: staging them in LDS bought nothing)
-__device__ __forceinline__ uint32_t OrderLdsOffset(uint32_t bucket) {   // byte offset of a bucket's order table inside the LDS copy
-  const uint32_t e = bucket == 0 ? 0 : bucket == 1 ? 64 : bucket == 2 ? 128 : bucket == 3 ? 384 : bucket == 4 ? 1408 : bucket == 5 ? 1536 : bucket == 6 ? 1792 : bucket == 7 ? 2304 : 6400;
-  return kSimtOrdOff + e * 2;
-}
-
+constexpr uint32_t kSimtCodeOff = kSimtOrdOff + 320;   // 39 order-table pointers of the pass (the tables stay in global memory)
 struct BitReaderRing {   // per-lane ring of 16 words in LDS; absolute word index w lives at slot w & 15
   uint32_t wpos, ring_off;
   uint64_t buf;
@@ -1409,11 +1419,11 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     const uint32_t* src = reinterpret_cast<const uint32_t*>(f.bcm);
     for (uint32_t i = threadIdx.x; i < sizeof(BlockCtxDev) / 4; i += blockDim.x) StS<uint32_t>(kSimtBcmOff + i * 4, LdG(src + i));
   }
-  const bool ord_lds = false;
   int32_t* const cbase0 = f.coeff[0]; int32_t* const cbase1 = f.coeff[1]; int32_t* const cbase2 = f.coeff[2];
   const uint32_t g = blockIdx.x * kSimtThreads + threadIdx.x;
   bool dead = g >= f.num_groups;                       // no stream, or a stream that failed in an earlier pass
   const uint32_t nz_base = kSimtNzOff + threadIdx.x * 96;
+  const uint32_t wend_all = (uint32_t)((f.cs_size + 3) >> 2);   // 16-byte loads stay inside the codestream buffer
   // Progressive frames: PassGroup section (pass, g) carries value >> shift of every coefficient under the pass's own code
   // and orders; the values accumulate.  The tables are re-staged per pass (block-wide), the lanes restart their streams.
   for (uint32_t pass = 0; pass < f.num_passes; pass++) {
@@ -1421,31 +1431,32 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   const uint32_t shift = pd.shift;
   if (pass) __syncthreads();                           // every lane is done with the previous pass's tables
   StageCode(pd.code, code, kSimtCodeOff, lds_bytes > kSimtCodeOff ? lds_bytes - kSimtCodeOff : 0, /*with_ctx_map=*/true);
+  if (threadIdx.x < 39) StS<uint64_t>(kSimtOrdOff + threadIdx.x * 8, (uint64_t)(uintptr_t)pd.orders[threadIdx.x]);
   __syncthreads();
   if (ALL_LDS && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
   bool done = dead;
+  uint32_t err = 0;                                    // first error of this lane's stream (reported after the loop)
   for (uint32_t i = 0; i < 24; i++) StS<uint32_t>(nz_base + i * 4, 0u);
-  constexpr uint32_t oNLf = kSimtBcmOff + offsetof(BlockCtxDev, n_lf_thr), oQf = kSimtBcmOff + offsetof(BlockCtxDev, qf_thr);
-  constexpr uint32_t oLf = kSimtBcmOff + offsetof(BlockCtxDev, lf_thr), oMap = kSimtBcmOff + offsetof(BlockCtxDev, ctx_map);
+  constexpr uint32_t oMap = kSimtBcmOff + offsetof(BlockCtxDev, ctx_map);
   const uint32_t n_qf = LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, n_qf_thr));
   const uint32_t num_lf_ctxs = LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, num_lf_ctxs));
   const uint32_t nctx = LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, num_ctxs));
+  const uint32_t qlf_stride = (n_qf + 1) * num_lf_ctxs;   // the LF stage stored qf_idx * num_lf_ctxs + lf_idx per varblock
   const uint32_t gsafe = done ? 0 : g;
-  const uint32_t gx = gsafe % f.xgroups, gy = gsafe / f.xgroups;
-  const uint32_t bx0 = gx * 32, by0 = gy * 32;
   // ---- per-lane bit-stream ring
   uint64_t bit0, byte_end;
   if (f.single_section) { bit0 = f.hf_start_bitpos; byte_end = f.cs_size; }
   else { const uint32_t si = 2 + f.num_lf_groups + pass * f.num_groups + gsafe; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); bit0 = off * 8; byte_end = off + sz; }
   const uint64_t limit = byte_end * 8;
   const uint32_t* words = reinterpret_cast<const uint32_t*>(f.cs);
-  const uint32_t wend = (uint32_t)((byte_end + 3) >> 2);
   BitReaderRing br;
   br.ring_off = kSimtRingOff + threadIdx.x * 64;
   br.wpos = (uint32_t)(bit0 >> 5);
   br.buf = 0; br.avail = 0;
   uint32_t wload = br.wpos & ~3u;             // next absolute word index to fetch (multiple of 4: 16-byte loads)
-  auto fetch4 = [&](uint32_t w) -> uint4 { return w + 3 < wend ? LdG(reinterpret_cast<const uint4*>(words + w)) : make_uint4(w < wend ? LdG(words + w) : 0u, w + 1 < wend ? LdG(words + w + 1) : 0u, w + 2 < wend ? LdG(words + w + 2) : 0u, 0u); };
+  // (words past the end of a section are the next section's, not zeros: a valid stream never consumes them — the ring only
+  // prefetches them — and an invalid one fails the final-state / overrun checks either way)
+  auto fetch4 = [&](uint32_t w) -> uint4 { return w + 3 < wend_all ? LdG(reinterpret_cast<const uint4*>(words + w)) : make_uint4(w < wend_all ? LdG(words + w) : 0u, w + 1 < wend_all ? LdG(words + w + 1) : 0u, w + 2 < wend_all ? LdG(words + w + 2) : 0u, 0u); };
   auto put4 = [&](uint32_t w, const uint4& v) { StS<uint4>(br.ring_off + ((w & 15) << 2), v); };
   for (int i = 0; i < 4; i++) { put4(wload, fetch4(wload)); wload += 4; }   // 16 words ahead
   uint4 pend0 = make_uint4(0, 0, 0, 0), pend1 = pend0;
@@ -1458,18 +1469,20 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   uint32_t ctx_offset = 0, state = 0;
   if (!done) {
     const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
-    if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); done = true; dead = true; }
+    if (preset >= f.num_hf_presets) { err = kErrBadValue; done = true; }
     ctx_offset = 495u * nctx * preset;
     state = br.Read(32);
   }
   // ---- varblock list of this group, one entry loaded ahead
   const uint2* vbl = f.vb_list + (size_t)gsafe * 1024;
   const uint32_t nvb = done ? 0 : LdG(f.vb_count + gsafe);
+  const uint32_t gbase = gsafe * 65536u;
   uint32_t vi = 0;
   uint2 ent_next = nvb ? LdG(vbl) : make_uint2(0, 0);
   uint32_t phase = 0;                     // 0: start next varblock, 1: read nzeros, 2: read a coefficient
-  uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, cx = 1, coff = 0, qf_idx = 0, lf_idx = 0;
-  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, order_off = 0;
+  uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, lcx = 0, coff = 0, qlf = 0;
+  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0;
+  uint64_t end_bitpos = 0;
   const uint16_t* order = pd.orders[0];
   int32_t* blk = cbase0;
   uint32_t iter = 0;
@@ -1483,48 +1496,29 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     iter++;
     if (!done && phase == 0) {
       if (vi >= nvb) {
-        if (state != 0x130000u) { SetError(f, kErrAnsFinalState); dead = true; }
-        else if (br.BitPos() > limit) { SetError(f, kErrOverrun); dead = true; }
-        else if (f.hf_end_bitpos && pass + 1 == f.num_passes) f.hf_end_bitpos[g] = br.BitPos();   // the Modular part follows the last pass
+        if (state != 0x130000u) err = kErrAnsFinalState;
+        else if (br.BitPos() > limit) err = kErrOverrun;
+        end_bitpos = br.BitPos();
         done = true;
       } else {
         const uint2 ent = ent_next;
         vi++;
         if (vi < nvb) ent_next = LdG(vbl + vi);
         const uint32_t s = ent.x & 31;
-        bx = (ent.x >> 16) & 31; by = (ent.x >> 21) & 31;
-        cx = CoveredX(s); covered = cx * CoveredY(s);
-        l2 = 31 - __clz((int)covered); size = covered * 64; ord = OrderBucket(s);
-        const uint32_t qf = ((ent.x >> 8) & 0xFF) + 1;
-        qf_idx = 0;
-        for (uint32_t i = 0; i < n_qf; i++) qf_idx += qf > LdS<uint32_t>(oQf + i * 4);
-        lf_idx = 0;
-        if (num_lf_ctxs > 1) {
-          const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
-          const uint32_t n0 = LdS<uint32_t>(oNLf), n1 = LdS<uint32_t>(oNLf + 4), n2 = LdS<uint32_t>(oNLf + 8);
-          uint32_t b0 = 0, b1 = 0, b2 = 0;
-          const int32_t q0 = LdG(f.lfq[0] + o), q1 = LdG(f.lfq[1] + o), q2 = LdG(f.lfq[2] + o);
-          for (uint32_t i = 0; i < n0; i++) b0 += q0 > LdS<int32_t>(oLf + i * 4);
-          for (uint32_t i = 0; i < n1; i++) b1 += q1 > LdS<int32_t>(oLf + 64 + i * 4);
-          for (uint32_t i = 0; i < n2; i++) b2 += q2 > LdS<int32_t>(oLf + 128 + i * 4);
-          lf_idx = (b0 * (n2 + 1) + b2) * (n1 + 1) + b1;
-        }
-        coff = ent.y;
+        bx = (ent.x >> 16) & 31; by = (ent.x >> 21) & 31; qlf = ent.x >> 26;
+        lcx = Log2CoveredX(s); l2 = lcx + Log2CoveredY(s);
+        covered = 1u << l2; size = covered * 64; ord = OrderBucket(s);
+        coff = gbase + ent.y;
         ci = 0; phase = 1;
       }
     } else if (!done) {
       const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
       uint32_t ctx;
       if (phase == 1) {
-        uint32_t idx = (uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord;
-        idx = idx * (n_qf + 1) + qf_idx;
-        idx = idx * num_lf_ctxs + lf_idx;
+        const uint32_t idx = ((uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord) * qlf_stride + qlf;
         const uint32_t block_ctx = LdS<uint8_t>(oMap + idx);
-        uint32_t pred;
         const uint32_t top = LdS<uint8_t>(nz_base + c * 32 + bx), left = bx ? LdS<uint8_t>(nz_base + c * 32 + bx - 1) : 0;
-        if (bx == 0) pred = by == 0 ? 32 : top;
-        else if (by == 0) pred = left;
-        else pred = (top + left + 1) / 2;
+        const uint32_t pred = bx == 0 ? (by == 0 ? 32 : top) : by == 0 ? left : (top + left + 1) / 2;
         const uint32_t pc = pred > 64 ? 64 : pred;
         ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
         histo = ctx_offset + 37 * nctx + 458 * block_ctx;
@@ -1535,19 +1529,25 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
       const uint32_t u = HybridSimt<ALL_LDS>(br, state, code, ctx);
       if (phase == 1) {
         nzeros = u;
-        if (nzeros + covered > size) { SetError(f, kErrNzeros); done = true; dead = true; }
+        if (nzeros + covered > size) { err = kErrNzeros; done = true; }
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
-        for (uint32_t ix = 0; ix < cx; ix++) StS<uint8_t>(nz_base + c * 32 + bx + ix, (uint8_t)nzm);
-        blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + (size_t)g * 65536 + coff;
+        {  // the varblock's columns of the "non-zeros above" row
+          const uint32_t a = nz_base + c * 32 + bx, v4 = nzm * 0x01010101u;
+          if (lcx == 0) StS<uint8_t>(a, (uint8_t)nzm);
+          else if (lcx == 1 && !(bx & 1)) StS<uint16_t>(a, (uint16_t)v4);
+          else if (lcx == 2 && !(bx & 3)) StS<uint32_t>(a, v4);
+          else if (lcx == 3 && !(bx & 7)) StS<uint2>(a, make_uint2(v4, v4));
+          else for (uint32_t ix = 0; ix < (1u << lcx); ix++) StS<uint8_t>(a + ix, (uint8_t)nzm);
+        }
+        blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + coff;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
-        if (ord_lds) order_off = OrderLdsOffset(ord);
-        else { order = pd.orders[ord * 3 + c]; next_pos = LdG(order + k); }
+        order = reinterpret_cast<const uint16_t*>((uintptr_t)LdS<uint64_t>(kSimtOrdOff + (ord * 3 + c) * 8));
+        next_pos = LdG(order + k);
         phase = 2;
       } else {
-        uint32_t pos;
-        if (ord_lds) pos = LdS<uint16_t>(order_off + 2 * k);
-        else { pos = next_pos; if (k + 1 < size) next_pos = LdG(order + k + 1); }
+        const uint32_t pos = next_pos;
+        if (k + 1 < size) next_pos = LdG(order + k + 1);
         if (u) {
           int32_t val = (int32_t)((uint32_t)UnpackSigned(u) << shift);
           if (pass) val = (int32_t)((uint32_t)val + (uint32_t)LdG(blk + pos));
@@ -1556,11 +1556,13 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
         prev = u != 0;
         nzeros -= prev;
         k++;
-        if (nzeros != 0 && k >= size) { SetError(f, kErrNzeros); done = true; dead = true; }
+        if (nzeros != 0 && k >= size) { err = kErrNzeros; done = true; }
       }
       if (phase == 2 && nzeros == 0) { ci++; phase = ci == 3 ? 0 : 1; }
     }
   }
+  if (err) { SetError(f, err); dead = true; }
+  else if (!dead && f.hf_end_bitpos && pass + 1 == f.num_passes) f.hf_end_bitpos[g] = end_bitpos;   // the Modular part follows the last pass
   }  // passes
 }
 
