@@ -61,8 +61,8 @@ def cpu_baseline(streams, width, height, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "256")), help="frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames (cycled to fill the batch)")
     ap.add_argument("--width", type=int, default=3840)
@@ -101,7 +101,7 @@ def main():
     B = args.batch
     frame_bytes = W * H * 3
     pipeline = not args.no_pipeline
-    nbuf = int(os.environ.get("JXL_BENCH_NBUF", "2")) if pipeline else 1   # double-buffered batches: step k uses buffer set k % nbuf
+    nbuf = int(os.environ.get("JXL_BENCH_NBUF", "3")) if pipeline else 1   # batches in flight: step k uses buffer set k % nbuf
     ahead = nbuf - 1                     # LF stages issued ahead of the step being finished
     outs, batches = [], []
     main = torch.cuda.current_stream()
@@ -123,7 +123,9 @@ def main():
         gather_list = [torch.empty_like(out) for _ in range(world)]
     # LF ("front") parts run on a side stream so that step k+1's latency-bound LF decode overlaps step k's HF/IDCT/filter
     # stages; events order front(k) -> rest(k) and rest(k) -> front(k+2) (same buffer set).
-    side = torch.cuda.Stream(device=dev, priority=-1) if pipeline else None   # LF blocks are few and long-running: dispatch them first
+    # (LF blocks are few and long-running: dispatch them first.)  With three buffer sets two LF stages are in flight, each on
+    # its own stream: an LF workgroup holds 35 KB of LDS, so two of them and an HF workgroup share a CU
+    sides = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, nbuf - 1))] if pipeline else []
     comm = torch.cuda.Stream(device=dev) if do_gather else None               # RCCL gather overlaps the next step's decode
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
     rest_done = [torch.cuda.Event() for _ in range(nbuf)]
@@ -132,6 +134,7 @@ def main():
 
     def issue_front(k, timed):
         b = k % nbuf
+        side = sides[k % len(sides)]
         with torch.cuda.stream(side):
             if k >= nbuf:
                 side.wait_event(rest_done[b])

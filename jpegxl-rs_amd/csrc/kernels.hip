@@ -289,7 +289,8 @@ constexpr uint32_t kRowOff = kWinOff + kWinWords * 4, kRowMax = 256;  // two sam
 constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;             // 256-sample staging buffer for wider channels
 constexpr uint32_t kWaveLds = 8448;                                   // >= kChunkOff + 1024 and >= the 8 KiB placement bitmap
 static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
-constexpr uint32_t kLfWaves = 4;
+constexpr uint32_t kLfWaves = 4;                                         // wavefronts per workgroup of the Modular group kernels
+constexpr uint32_t kLfDecWaves = 2, kLfDecGroups = 4;                    // LfDecodeKernel: two wavefronts share four LF groups
 // the shared part of the LDS (tree copy or per-wavefront pruned slices, then the entropy code) follows the per-wavefront regions
 
 __device__ __forceinline__ void WaveSync() {   // orders LDS/global accesses between the lanes of ONE wavefront
@@ -903,16 +904,8 @@ __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTabl
 // K_lf: one wavefront per LF group (four per workgroup, sharing the tables) — LF coefficients (3 channels, order Y,X,B)
 // + HF metadata, then varblock placement
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
-  const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
-  if (blockIdx.x * kLfWaves >= f.num_lf_groups) return;
-  __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves: issue ahead of co-resident bandwidth kernels
-  ModTables T;
-  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wb = T.wb;
-  const uint32_t g = blockIdx.x * kLfWaves + wave;
-  if (g >= f.num_lf_groups) return;             // (no block-wide barrier after this point)
+__device__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T, int& s_fail, GroupHeaderD& s_gh, uint32_t* s_u) {
+  const uint32_t lane = threadIdx.x & 63, wb = T.wb;
   const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
   const uint32_t bx0 = gx * 256, by0 = gy * 256;
   const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
@@ -921,13 +914,8 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
   if (f.single_section) br.Init(f.cs, f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos, f.cs_size);   // (after the global Modular stream, if any)
   else br.Init(f.cs, f.sec_off[1 + g] * 8, sec_end);
   const uint64_t limit = sec_end * 8;
-  __shared__ int s_fail_w[kLfWaves];
-  __shared__ GroupHeaderD s_gh_w[kLfWaves];
-  __shared__ uint32_t s_u_w[kLfWaves][4];
-  int& s_fail = s_fail_w[wave];
-  GroupHeaderD& s_gh = s_gh_w[wave];
-  uint32_t* s_u = s_u_w[wave];
   if (lane == 0) s_fail = 0;
+  WaveSync();
 
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp;
@@ -1124,6 +1112,30 @@ __global__ __launch_bounds__(256) void LfDecodeKernel(const FrameDev* __restrict
     const int32_t sh = m_sharp[i];
     if (sh < 0 || sh > 7) { SetError(f, kErrBadValue); continue; }
     f.blk_info[(size_t)(by0 + i / gbw) * f.bw + bx0 + i % gbw] |= (uint32_t)sh << 26;
+  }
+}
+
+// Two wavefronts per workgroup share four consecutive LF groups: wavefront w decodes groups w and 3 - w one after the
+// other.  A 3840x2160 frame has two large LF groups (256x256 and 224x256 blocks) and two slivers (14 rows): with one
+// wavefront per group the sliver wavefronts were done after 5 % of the kernel while their LDS stayed allocated; paired
+// like this both wavefronts carry about the same load and a frame holds 36 KB of LDS instead of 52 KB, so that the LF
+// workgroups of two batches in flight (2 x 36 KB) and an HF workgroup (80 KB) fit one CU.  (The kernel needs 272 VGPRs,
+// one wavefront per SIMD: a CU never hosts more than two of these workgroups, whatever the dispatcher would like.)
+__global__ __launch_bounds__(64 * kLfDecWaves) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular) return;
+  const uint32_t first = blockIdx.x * kLfDecGroups;
+  if (first >= f.num_lf_groups) return;
+  __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves: issue ahead of co-resident bandwidth kernels
+  ModTables T;
+  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  __shared__ int s_fail_w[kLfDecWaves];
+  __shared__ GroupHeaderD s_gh_w[kLfDecWaves];
+  __shared__ uint32_t s_u_w[kLfDecWaves][4];
+  const uint32_t wave = threadIdx.x >> 6;
+  for (uint32_t turn = 0; turn < kLfDecGroups / kLfDecWaves; turn++) {   // (no block-wide barrier after this point)
+    const uint32_t local = turn & 1 ? kLfDecGroups - 1 - (turn / 2) * kLfDecWaves - wave : (turn / 2) * kLfDecWaves + wave;
+    if (first + local < f.num_lf_groups) LfDecodeGroup(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
   }
 }
 
@@ -1356,12 +1368,11 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
 // the loop waits on global memory: tables, the per-lane bit-stream ring and the non-zero row buffers live in LDS, the
 // varblock list entry of the next block and the next coefficient position are loaded one step ahead, and the bit-stream
 // rings are topped up every fourth iteration with loads issued four iterations earlier.
-constexpr uint32_t kSimtThreads = 256;
-constexpr uint32_t kSimtNzOff = 128;                                   // per-thread nzeros row buffers: 96 B each
-constexpr uint32_t kSimtRingOff = kSimtNzOff + kSimtThreads * 96;      // per-thread bit-stream ring: 16 words
-constexpr uint32_t kSimtBcmOff = kSimtRingOff + kSimtThreads * 64;     // copy of the BlockCtxDev
-constexpr uint32_t kSimtOrdOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;   // natural orders of buckets 0..8 (u16)
-constexpr uint32_t kSimtCodeOff = kSimtOrdOff + 320;   // 39 order-table pointers of the pass (the tables stay in global memory)
+constexpr uint32_t kSimtMaxThreads = 256;                              // lanes (= group streams) per workgroup: 64 .. 256, right-sized per batch
+constexpr uint32_t kSimtBcmOff = 128;                                  // [0, 128): the two 64-entry context tables; then a copy of the BlockCtxDev
+constexpr uint32_t kSimtOrdOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;   // 39 order-table pointers of the pass
+constexpr uint32_t kSimtCodeOff = kSimtOrdOff + 320;                   // the AC code of the pass (cfg, context map, alias tables)
+constexpr uint32_t kSimtLaneBytes = 96 + 64;                           // per lane, after the code: nzeros row buffers (96 B) + 16-word bit-stream ring
 struct BitReaderRing {   // per-lane ring of 16 words in LDS; absolute word index w lives at slot w & 15
   uint32_t wpos, ring_off;
   uint64_t buf;
@@ -1409,10 +1420,13 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   return (((hi << nbits) | bits) << lsb) | low;
 }
 
-template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes) {
+template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
-  if (blockIdx.x * kSimtThreads >= f.num_groups) return;
+  if (blockIdx.x * lanes >= f.num_groups) return;
+  // per-lane regions sit at the end of the dynamic LDS: `lanes` real ones + one scratch region that all stream-less
+  // lanes of the last wavefront share (they only ever write zeros / prefetched words there and read nothing back)
+  const uint32_t lane_off = lds_bytes - (lanes + 1) * kSimtLaneBytes;
   FastCode code;
   if (threadIdx.x < 64) { StS<uint8_t>(threadIdx.x, kNzCtx[threadIdx.x]); StS<uint8_t>(64 + threadIdx.x, kFreqCtx[threadIdx.x]); }
   {
@@ -1420,9 +1434,10 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     for (uint32_t i = threadIdx.x; i < sizeof(BlockCtxDev) / 4; i += blockDim.x) StS<uint32_t>(kSimtBcmOff + i * 4, LdG(src + i));
   }
   int32_t* const cbase0 = f.coeff[0]; int32_t* const cbase1 = f.coeff[1]; int32_t* const cbase2 = f.coeff[2];
-  const uint32_t g = blockIdx.x * kSimtThreads + threadIdx.x;
-  bool dead = g >= f.num_groups;                       // no stream, or a stream that failed in an earlier pass
-  const uint32_t nz_base = kSimtNzOff + threadIdx.x * 96;
+  const uint32_t g = blockIdx.x * lanes + threadIdx.x;   // (`lanes` group streams per workgroup, whole wavefronts of threads)
+  bool dead = threadIdx.x >= lanes || g >= f.num_groups;   // no stream, or a stream that failed in an earlier pass
+  const uint32_t lane_slot = dead ? lanes : threadIdx.x;
+  const uint32_t nz_base = lane_off + lane_slot * 96;
   const uint32_t wend_all = (uint32_t)((f.cs_size + 3) >> 2);   // 16-byte loads stay inside the codestream buffer
   // Progressive frames: PassGroup section (pass, g) carries value >> shift of every coefficient under the pass's own code
   // and orders; the values accumulate.  The tables are re-staged per pass (block-wide), the lanes restart their streams.
@@ -1430,7 +1445,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   const PassDev& pd = f.passes[pass];
   const uint32_t shift = pd.shift;
   if (pass) __syncthreads();                           // every lane is done with the previous pass's tables
-  StageCode(pd.code, code, kSimtCodeOff, lds_bytes > kSimtCodeOff ? lds_bytes - kSimtCodeOff : 0, /*with_ctx_map=*/true);
+  StageCode(pd.code, code, kSimtCodeOff, lane_off > kSimtCodeOff ? lane_off - kSimtCodeOff : 0, /*with_ctx_map=*/true);
   if (threadIdx.x < 39) StS<uint64_t>(kSimtOrdOff + threadIdx.x * 8, (uint64_t)(uintptr_t)pd.orders[threadIdx.x]);
   __syncthreads();
   if (ALL_LDS && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
@@ -1450,7 +1465,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
   const uint64_t limit = byte_end * 8;
   const uint32_t* words = reinterpret_cast<const uint32_t*>(f.cs);
   BitReaderRing br;
-  br.ring_off = kSimtRingOff + threadIdx.x * 64;
+  br.ring_off = lane_off + (lanes + 1) * 96 + lane_slot * 64;
   br.wpos = (uint32_t)(bit0 >> 5);
   br.buf = 0; br.avail = 0;
   uint32_t wload = br.wpos & ~3u;             // next absolute word index to fetch (multiple of 4: 16-byte loads)
@@ -2861,10 +2876,10 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
   const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
-  const uint32_t lds_bytes = kLfWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  const uint32_t lds_bytes = kLfDecWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
-  hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)kLfWaves), nframes), dim3(64 * kLfWaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
+  hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)kLfDecGroups), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
@@ -2875,16 +2890,21 @@ void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, v
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
   if (cfg.lane_stride_hf == 1) {   // SIMT: one group stream per lane
     const bool all_lds = cfg.ac_code_bytes <= cfg.lds_code_budget;     // every frame's AC code fits the LDS budget
-    const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes);
+    // lanes per workgroup: the groups of a frame spread evenly over as few workgroups as possible, whole wavefronts (a
+    // 3840x2160 frame has 135 groups: 192 threads, 136 lane regions, 80 KB of LDS instead of 99 KB — which is what lets two
+    // LF workgroups share the CU with it)
+    const int nblk = DivUp(max_groups, (int)kSimtMaxThreads);
+    const uint32_t lanes = (uint32_t)DivUp(max_groups, nblk), threads = (uint32_t)DivUp((int)lanes, 64) * 64;
+    const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes) + (lanes + 1) * kSimtLaneBytes;
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
       (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
       attr = true;
     }
-    const dim3 grid(DivUp(max_groups, (int)kSimtThreads), nframes);
-    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(kSimtThreads), lds, (hipStream_t)stream, frames, lds);
-    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(kSimtThreads), lds, (hipStream_t)stream, frames, lds);
+    const dim3 grid(nblk, nframes);
+    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes);
+    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes);
     return;
   }
   const int threads = cfg.hf_block_threads;
