@@ -58,6 +58,9 @@ Batch::Batch(int device) : device_(device) {
   HIP_CHECK(hipSetDevice(device_));
 }
 Batch::~Batch() {
+  if (clear_stream_) { (void)hipStreamSynchronize((hipStream_t)clear_stream_); (void)hipStreamDestroy((hipStream_t)clear_stream_); }
+  if (clear_event_) (void)hipEventDestroy((hipEvent_t)clear_event_);
+  if (idct_event_) (void)hipEventDestroy((hipEvent_t)idct_event_);
   if (dconst_) (void)hipFree(dconst_);
   if (dwork_) (void)hipFree(dwork_);
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
@@ -165,6 +168,8 @@ void Batch::Prepare(void* stream_v) {
   InitDeviceTables(stream_v);
   if (dconst_) { (void)hipFree(dconst_); dconst_ = nullptr; }
   if (dwork_) { (void)hipFree(dwork_); dwork_ = nullptr; }
+  if (clear_stream_) (void)hipStreamSynchronize((hipStream_t)clear_stream_);   // a pending clear of the old coefficient planes
+  clear_pending_ = false;
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   dbig_ = nullptr;
   if (dframes_) { (void)hipFree(dframes_); dframes_ = nullptr; }
@@ -646,6 +651,32 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
   else vardct_alpha_[i] = VarDctAlpha{op.has_alpha, op.in[3], op.alpha_factor};   // the VarDCT write stage reads the plane itself
 }
 
+void Batch::ClearCoefficientsBeforeHf(void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  Batch* o = big_owner_ ? big_owner_ : this;
+  bool clean = false;
+  if (o->clear_pending_) {   // whatever was cleared, the clear must have finished before anything else touches the buffers
+    HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)o->clear_event_, 0));
+    clean = o->clear_off_ == coeff_off_ && o->clear_bytes_ >= coeff_bytes_;
+    o->clear_pending_ = false;
+  }
+  if (!clean) HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, stream));
+}
+void Batch::ClearCoefficientsAfterIdct(void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  Batch* o = big_owner_ ? big_owner_ : this;
+  if (!o->clear_stream_) {
+    hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); o->clear_stream_ = s;
+    hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); o->clear_event_ = e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); o->idct_event_ = e;
+  }
+  HIP_CHECK(hipEventRecord((hipEvent_t)o->idct_event_, stream));
+  HIP_CHECK(hipStreamWaitEvent((hipStream_t)o->clear_stream_, (hipEvent_t)o->idct_event_, 0));
+  HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, (hipStream_t)o->clear_stream_));
+  HIP_CHECK(hipEventRecord((hipEvent_t)o->clear_event_, (hipStream_t)o->clear_stream_));
+  o->clear_pending_ = true; o->clear_off_ = coeff_off_; o->clear_bytes_ = coeff_bytes_;
+}
+
 void Batch::CheckFilterBuffers() const {
   if ((fplan_.any_unfused || cfg.force_unfused_filters) && !has_plane_b_)
     throw ParseError("force_unfused_filters must be set before Prepare (the second pixel plane is only allocated when a frame needs it)", false);
@@ -689,12 +720,13 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   } else if (part != 1) {
     // the HF decoder only writes non-zero coefficients: clear the planes first (outside the per-stage brackets when the
     // halves are timed separately; the planes may be shared with another batch, so this belongs to the rest half)
-    HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, stream));
+    ClearCoefficientsBeforeHf(stream_v);
     rec(part == 2 ? 7 : 2);
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
     rec(3);
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
+    ClearCoefficientsAfterIdct(stream_v);   // (for the next decode on these buffers; runs under the filter stage)
     rec(4);
     LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     rec(5);

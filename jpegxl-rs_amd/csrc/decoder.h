@@ -83,6 +83,14 @@ class Batch {
   uint8_t* dwork_ = nullptr; size_t work_size_ = 0;
   uint8_t* dbig_ = nullptr; size_t big_size_ = 0;   // coefficient + pixel planes (rest half only); may alias big_owner_'s
   Batch* big_owner_ = nullptr;
+  // The coefficient planes must be zero when the HF stage starts.  Instead of clearing them at the start of a decode's
+  // second half (7 ms per 256 4K frames, nothing else running), the half that just consumed them clears them again on an
+  // internal stream as soon as its IDCT is done, under its own filter stage; the next second half on these buffers (this
+  // batch's or one sharing them) only waits for that.  State lives in the batch that owns the buffers.
+  void* clear_stream_ = nullptr; void* clear_event_ = nullptr; void* idct_event_ = nullptr;
+  bool clear_pending_ = false; size_t clear_off_ = 0, clear_bytes_ = 0;
+  void ClearCoefficientsBeforeHf(void* stream);
+  void ClearCoefficientsAfterIdct(void* stream);
   bool has_plane_b_ = false;
   void CheckFilterBuffers() const;
   FrameDev* dframes_ = nullptr;

@@ -1121,10 +1121,11 @@ __device__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T,
 // like this both wavefronts carry about the same load and a frame holds 36 KB of LDS instead of 52 KB, so that the LF
 // workgroups of two batches in flight (2 x 36 KB) and an HF workgroup (80 KB) fit one CU.  (The kernel needs 272 VGPRs,
 // one wavefront per SIMD: a CU never hosts more than two of these workgroups, whatever the dispatcher would like.)
-__global__ __launch_bounds__(64 * kLfDecWaves) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes) {
+// Small launches (single images) take one group per wavefront instead: latency over LDS economy.
+__global__ __launch_bounds__(64 * kLfDecWaves) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
-  const uint32_t first = blockIdx.x * kLfDecGroups;
+  const uint32_t first = blockIdx.x * groups_per_block;
   if (first >= f.num_lf_groups) return;
   __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves: issue ahead of co-resident bandwidth kernels
   ModTables T;
@@ -1133,8 +1134,8 @@ __global__ __launch_bounds__(64 * kLfDecWaves) void LfDecodeKernel(const FrameDe
   __shared__ GroupHeaderD s_gh_w[kLfDecWaves];
   __shared__ uint32_t s_u_w[kLfDecWaves][4];
   const uint32_t wave = threadIdx.x >> 6;
-  for (uint32_t turn = 0; turn < kLfDecGroups / kLfDecWaves; turn++) {   // (no block-wide barrier after this point)
-    const uint32_t local = turn & 1 ? kLfDecGroups - 1 - (turn / 2) * kLfDecWaves - wave : (turn / 2) * kLfDecWaves + wave;
+  for (uint32_t turn = 0; turn < groups_per_block / kLfDecWaves; turn++) {   // (no block-wide barrier after this point)
+    const uint32_t local = turn & 1 ? groups_per_block - 1 - (turn / 2) * kLfDecWaves - wave : (turn / 2) * kLfDecWaves + wave;
     if (first + local < f.num_lf_groups) LfDecodeGroup(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
   }
 }
@@ -1420,7 +1421,7 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   return (((hi << nbits) | bits) << lsb) | low;
 }
 
-template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes) {
+template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   if (blockIdx.x * lanes >= f.num_groups) return;
@@ -1434,9 +1435,15 @@ template <bool ALL_LDS> __global__ __launch_bounds__(256) void HfDecodeSimtKerne
     for (uint32_t i = threadIdx.x; i < sizeof(BlockCtxDev) / 4; i += blockDim.x) StS<uint32_t>(kSimtBcmOff + i * 4, LdG(src + i));
   }
   int32_t* const cbase0 = f.coeff[0]; int32_t* const cbase1 = f.coeff[1]; int32_t* const cbase2 = f.coeff[2];
-  const uint32_t g = blockIdx.x * lanes + threadIdx.x;   // (`lanes` group streams per workgroup, whole wavefronts of threads)
-  bool dead = threadIdx.x >= lanes || g >= f.num_groups;   // no stream, or a stream that failed in an earlier pass
-  const uint32_t lane_slot = dead ? lanes : threadIdx.x;
+  // `lanes` group streams per workgroup, `lanes_per_wave` of them on the first lanes of each wavefront.  Sparse wavefronts
+  // on purpose: every lane state that any lane of a wavefront is in costs the whole wavefront its instructions (block
+  // start, nzeros token, coefficient token, bit-stream refills ...), and with 64 streams per wavefront every iteration
+  // runs every path; 16 streams per wavefront skip most of them, and the 2-3 wavefronts a SIMD then holds fill each
+  // other's issue gaps (the per-lane LDS regions — the binding resource — do not change).
+  const uint32_t slot = (threadIdx.x >> 6) * lanes_per_wave + (threadIdx.x & 63);
+  const uint32_t g = blockIdx.x * lanes + slot;
+  bool dead = (threadIdx.x & 63) >= lanes_per_wave || slot >= lanes || g >= f.num_groups;   // no stream, or a stream that failed in an earlier pass
+  const uint32_t lane_slot = dead ? lanes : slot;
   const uint32_t nz_base = lane_off + lane_slot * 96;
   const uint32_t wend_all = (uint32_t)((f.cs_size + 3) >> 2);   // 16-byte loads stay inside the codestream buffer
   // Progressive frames: PassGroup section (pass, g) carries value >> shift of every coefficient under the pass's own code
@@ -2414,7 +2421,7 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
 constexpr int kFtW = 32, kFtH = 24;
 constexpr int kFinW = kFtW + 6, kFinH = kFtH + 6, kFinP = kFinW + 1;      // input region incl. halo 3, padded pitch
 constexpr int kFgW = kFtW + 4, kFgH = kFtH + 4, kFgP = kFgW + 1;          // gaborish region incl. halo 2
-constexpr size_t kFusedLds = (size_t)(3 * kFinH * kFinP + 3 * kFgH * kFgP) * sizeof(float);
+constexpr size_t kFusedLds = (size_t)(3 * kFinH * kFinP) * sizeof(float);   // the gaborish tile reuses the input tile's LDS (14 KB)
 
 __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
@@ -2424,7 +2431,7 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
   if (x0 >= w || y0 >= h) return;
   extern __shared__ __align__(16) float s_f[];
   float* s_in = s_f;                              // [3][kFinH][kFinP]
-  float* s_gab = s_f + 3 * kFinH * kFinP;         // [3][kFgH][kFgP]
+  float* s_gab = s_f;                             // [3][kFgH][kFgP] — overwrites the input tile (values pass through registers)
   const size_t stride = f.plane_stride;
   // ---- load input tile (+3 halo) with image-border mirroring
   for (int i = threadIdx.x; i < kFinW * kFinH; i += blockDim.x) {
@@ -2435,8 +2442,13 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
     for (int c = 0; c < 3; c++) s_in[(c * kFinH + ly) * kFinP + lx] = LdG(f.plane_a[c] + o);
   }
   __syncthreads();
-  // ---- gaborish on tile + halo 2
-  for (int i = threadIdx.x; i < kFgW * kFgH; i += blockDim.x) {
+  // ---- gaborish on tile + halo 2: every thread keeps its results in registers until all inputs have been read
+  constexpr int kGabPerThread = (kFgW * kFgH + 255) / 256;
+  float gv[kGabPerThread][3];
+#pragma unroll
+  for (int q = 0; q < kGabPerThread; q++) {
+    const int i = (int)threadIdx.x + q * 256;
+    if (i >= kFgW * kFgH) continue;
     const int ly = i / kFgW, lx = i % kFgW;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -2446,8 +2458,17 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
       const float sum0 = m[1];
       const float sum1 = (m[0] + m[2]) + (t[1] + b[1]);
       const float sum2 = (t[0] + t[2]) + (b[0] + b[2]);
-      s_gab[(c * kFgH + ly) * kFgP + lx] = fmaf(sum2, f.gab_w[c * 3 + 2], fmaf(sum1, f.gab_w[c * 3 + 1], sum0 * f.gab_w[c * 3 + 0]));
+      gv[q][c] = fmaf(sum2, f.gab_w[c * 3 + 2], fmaf(sum1, f.gab_w[c * 3 + 1], sum0 * f.gab_w[c * 3 + 0]));
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kGabPerThread; q++) {
+    const int i = (int)threadIdx.x + q * 256;
+    if (i >= kFgW * kFgH) continue;
+    const int ly = i / kFgW, lx = i % kFgW;
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_gab[(c * kFgH + ly) * kFgP + lx] = gv[q][c];
   }
   __syncthreads();
   // ---- EPF pass 1 + colour + store
@@ -2879,7 +2900,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   const uint32_t lds_bytes = kLfDecWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
-  hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)kLfDecGroups), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_bytes);
+  // batches that fill the GPU: four groups per workgroup (two per wavefront, paired large + small); otherwise one per wavefront
+  const uint32_t gpb = (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128 ? kLfDecGroups : kLfDecWaves;
+  hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
@@ -2894,7 +2917,13 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     // 3840x2160 frame has 135 groups: 192 threads, 136 lane regions, 80 KB of LDS instead of 99 KB — which is what lets two
     // LF workgroups share the CU with it)
     const int nblk = DivUp(max_groups, (int)kSimtMaxThreads);
-    const uint32_t lanes = (uint32_t)DivUp(max_groups, nblk), threads = (uint32_t)DivUp((int)lanes, 64) * 64;
+    const uint32_t lanes = (uint32_t)DivUp(max_groups, nblk);
+    static const int lpw_env = getenv("JXL_HIP_HF_LANES") ? atoi(getenv("JXL_HIP_HF_LANES")) : 0;
+    // streams per wavefront: five wavefronts per workgroup (one or two per SIMD next to the LF wavefronts, whose 272 VGPRs
+    // leave room for two of these)
+    uint32_t lpw = lpw_env >= 1 && lpw_env <= 64 ? (uint32_t)lpw_env : (uint32_t)DivUp((int)lanes, 5);
+    lpw = std::max(lpw, (uint32_t)DivUp((int)lanes, 16));                        // at most 16 wavefronts per workgroup
+    const uint32_t threads = (uint32_t)DivUp((int)lanes, (int)lpw) * 64;
     const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes) + (lanes + 1) * kSimtLaneBytes;
     static bool attr = false;
     if (!attr) {
@@ -2903,8 +2932,8 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
       attr = true;
     }
     const dim3 grid(nblk, nframes);
-    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes);
-    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes);
+    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw);
+    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw);
     return;
   }
   const int threads = cfg.hf_block_threads;
