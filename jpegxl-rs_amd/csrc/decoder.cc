@@ -63,6 +63,7 @@ Batch::~Batch() {
   if (idct_event_) (void)hipEventDestroy((hipEvent_t)idct_event_);
   if (dconst_) (void)hipFree(dconst_);
   if (dwork_) (void)hipFree(dwork_);
+  if (dcoef_) (void)hipFree(dcoef_);
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   if (dframes_) (void)hipFree(dframes_);
   if (dpasses_) (void)hipFree(dpasses_);
@@ -170,6 +171,7 @@ void Batch::Prepare(void* stream_v) {
   if (dwork_) { (void)hipFree(dwork_); dwork_ = nullptr; }
   if (clear_stream_) (void)hipStreamSynchronize((hipStream_t)clear_stream_);   // a pending clear of the old coefficient planes
   clear_pending_ = false;
+  if (dcoef_) { (void)hipFree(dcoef_); dcoef_ = nullptr; }
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   dbig_ = nullptr;
   if (dframes_) { (void)hipFree(dframes_); dframes_ = nullptr; }
@@ -253,13 +255,15 @@ void Batch::Prepare(void* stream_v) {
   flags_off_ = flags_off;
   cfg.idct_flags_known = 0; ran_once_ = false;
   // coefficient buffers of all frames are contiguous so that one memset clears them
-  coeff_off_ = Align(wbig);
+  // quantised coefficients: an arena of this batch's own (never shared: it is cleared for the batch's next decode on an
+  // internal stream while the next batch's HF stage runs, see ClearCoefficients*)
+  size_t wcoef = 0;
   for (int i = 0; i < n; i++) {
     const FramePlan& p = images_[i]->plan;
     if (p.modular) continue;
-    for (int c = 0; c < 3; c++) wo[i].coeff[c] = take_big((size_t)p.num_groups * 65536 * 4);
+    for (int c = 0; c < 3; c++) { wo[i].coeff[c] = Align(wcoef); wcoef = wo[i].coeff[c] + (size_t)p.num_groups * 65536 * 4; }
   }
-  coeff_bytes_ = wbig - coeff_off_;
+  coeff_bytes_ = Align(wcoef);
   for (int i = 0; i < n; i++) {
     ImageEntry& e = *images_[i];
     const FramePlan& p = e.plan;
@@ -331,6 +335,8 @@ void Batch::Prepare(void* stream_v) {
     HIP_CHECK(hipMalloc((void**)&dbig_, std::max<size_t>(big_size_, 256)));
     HIP_CHECK(hipMemsetAsync(dbig_, 0, std::max<size_t>(big_size_, 256), stream));
   }
+  HIP_CHECK(hipMalloc((void**)&dcoef_, std::max<size_t>(coeff_bytes_, 256)));
+  coef_dirty_ = true;                                  // first decode clears the planes in its own stream
   HIP_CHECK(hipMalloc((void**)&dframes_, sizeof(FrameDev) * std::max(n, 1)));
 
   // ---- single-section VarDCT frames: HfGlobal starts where the device-decoded LfGroup ends.  Pre-run the LF stage
@@ -396,7 +402,7 @@ void Batch::Prepare(void* stream_v) {
       else f.color_mode = p.do_ycbcr ? 2 : 3;
       for (int k = 0; k < 3; k++) {
         f.lfq[k] = (int32_t*)(dwork_ + o.lfq[k]); f.lf[k] = (float*)(dwork_ + o.lf[k]); f.lf_tmp[k] = (float*)(dwork_ + o.lf_tmp[k]);
-        f.llf[k] = (float*)(dwork_ + o.llf[k]); f.coeff[k] = (int32_t*)(dbig_ + o.coeff[k]);
+        f.llf[k] = (float*)(dwork_ + o.llf[k]); f.coeff[k] = (int32_t*)(dcoef_ + o.coeff[k]);
         f.plane_a[k] = (float*)(dbig_ + o.plane_a[k]); f.plane_b[k] = o.plane_b[k] == (size_t)-1 ? nullptr : (float*)(dbig_ + o.plane_b[k]);
       }
       f.blk_info = (uint32_t*)(dwork_ + o.blk_info); f.coef_off = (uint32_t*)(dwork_ + o.coef_off);
@@ -653,28 +659,22 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
 
 void Batch::ClearCoefficientsBeforeHf(void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
-  Batch* o = big_owner_ ? big_owner_ : this;
-  bool clean = false;
-  if (o->clear_pending_) {   // whatever was cleared, the clear must have finished before anything else touches the buffers
-    HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)o->clear_event_, 0));
-    clean = o->clear_off_ == coeff_off_ && o->clear_bytes_ >= coeff_bytes_;
-    o->clear_pending_ = false;
-  }
-  if (!clean) HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, stream));
+  if (clear_pending_) { HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)clear_event_, 0)); clear_pending_ = false; }
+  else if (coef_dirty_) HIP_CHECK(hipMemsetAsync(dcoef_, 0, coeff_bytes_, stream));
+  coef_dirty_ = true;
 }
-void Batch::ClearCoefficientsAfterIdct(void* stream_v) {
+void Batch::ClearCoefficientsAfterDecode(void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
-  Batch* o = big_owner_ ? big_owner_ : this;
-  if (!o->clear_stream_) {
-    hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); o->clear_stream_ = s;
-    hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); o->clear_event_ = e;
-    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); o->idct_event_ = e;
+  if (!clear_stream_) {
+    hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); clear_stream_ = s;
+    hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); clear_event_ = e;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); idct_event_ = e;
   }
-  HIP_CHECK(hipEventRecord((hipEvent_t)o->idct_event_, stream));
-  HIP_CHECK(hipStreamWaitEvent((hipStream_t)o->clear_stream_, (hipEvent_t)o->idct_event_, 0));
-  HIP_CHECK(hipMemsetAsync(dbig_ + coeff_off_, 0, coeff_bytes_, (hipStream_t)o->clear_stream_));
-  HIP_CHECK(hipEventRecord((hipEvent_t)o->clear_event_, (hipStream_t)o->clear_stream_));
-  o->clear_pending_ = true; o->clear_off_ = coeff_off_; o->clear_bytes_ = coeff_bytes_;
+  HIP_CHECK(hipEventRecord((hipEvent_t)idct_event_, stream));
+  HIP_CHECK(hipStreamWaitEvent((hipStream_t)clear_stream_, (hipEvent_t)idct_event_, 0));
+  HIP_CHECK(hipMemsetAsync(dcoef_, 0, coeff_bytes_, (hipStream_t)clear_stream_));
+  HIP_CHECK(hipEventRecord((hipEvent_t)clear_event_, (hipStream_t)clear_stream_));
+  clear_pending_ = true;
 }
 
 void Batch::CheckFilterBuffers() const {
@@ -726,12 +726,12 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
     rec(3);
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
-    ClearCoefficientsAfterIdct(stream_v);   // (for the next decode on these buffers; runs under the filter stage)
     rec(4);
     LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     rec(5);
     LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     rec(6);
+    ClearCoefficientsAfterDecode(stream_v);   // for this batch's next decode; runs under whatever the caller enqueues next
     if (timed && part == 2) timed_rest_cursor_++;
   }
 }

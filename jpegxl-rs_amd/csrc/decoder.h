@@ -66,7 +66,7 @@ class Batch {
   void StageBytes(uint64_t out[6]) const;
   LaunchCfg cfg;
   size_t const_bytes() const { return const_size_; }
-  size_t work_bytes() const { return work_size_ + (big_owner_ ? 0 : big_size_); }
+  size_t work_bytes() const { return work_size_ + coeff_bytes_ + (big_owner_ ? 0 : big_size_); }
   void ShareBigArena(Batch* owner);
   uint64_t total_pixels() const;
   uint64_t compressed_bytes() const;
@@ -83,14 +83,15 @@ class Batch {
   uint8_t* dwork_ = nullptr; size_t work_size_ = 0;
   uint8_t* dbig_ = nullptr; size_t big_size_ = 0;   // coefficient + pixel planes (rest half only); may alias big_owner_'s
   Batch* big_owner_ = nullptr;
-  // The coefficient planes must be zero when the HF stage starts.  Instead of clearing them at the start of a decode's
-  // second half (7 ms per 256 4K frames, nothing else running), the half that just consumed them clears them again on an
-  // internal stream as soon as its IDCT is done, under its own filter stage; the next second half on these buffers (this
-  // batch's or one sharing them) only waits for that.  State lives in the batch that owns the buffers.
+  // The coefficient planes must be zero when the HF stage starts.  A 7 ms memset per 256 4K frames with nothing else
+  // running is avoided like this: every batch has coefficient planes of its own (288 GB of HBM: three batches in flight
+  // hold 82 GB of them), and a decode that is done with them clears them again on an internal stream — which the GPU
+  // runs under the next batch's latency-bound HF stage.  The next decode of this batch only waits for that event.
+  uint8_t* dcoef_ = nullptr;
   void* clear_stream_ = nullptr; void* clear_event_ = nullptr; void* idct_event_ = nullptr;
-  bool clear_pending_ = false; size_t clear_off_ = 0, clear_bytes_ = 0;
+  bool clear_pending_ = false, coef_dirty_ = true;
   void ClearCoefficientsBeforeHf(void* stream);
-  void ClearCoefficientsAfterIdct(void* stream);
+  void ClearCoefficientsAfterDecode(void* stream);
   bool has_plane_b_ = false;
   void CheckFilterBuffers() const;
   FrameDev* dframes_ = nullptr;

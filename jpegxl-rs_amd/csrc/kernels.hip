@@ -1122,12 +1122,11 @@ __device__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T,
 // workgroups of two batches in flight (2 x 36 KB) and an HF workgroup (80 KB) fit one CU.  (The kernel needs 272 VGPRs,
 // one wavefront per SIMD: a CU never hosts more than two of these workgroups, whatever the dispatcher would like.)
 // Small launches (single images) take one group per wavefront instead: latency over LDS economy.
-__global__ __launch_bounds__(64 * kLfDecWaves) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
+__global__ __launch_bounds__(64 * kLfDecWaves, 4) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   const uint32_t first = blockIdx.x * groups_per_block;
   if (first >= f.num_lf_groups) return;
-  __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves: issue ahead of co-resident bandwidth kernels
   ModTables T;
   StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
   __shared__ int s_fail_w[kLfDecWaves];
@@ -1425,6 +1424,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   if (blockIdx.x * lanes >= f.num_groups) return;
+  __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of the co-resident LF waves
   // per-lane regions sit at the end of the dynamic LDS: `lanes` real ones + one scratch region that all stream-less
   // lanes of the last wavefront share (they only ever write zeros / prefetched words there and read nothing back)
   const uint32_t lane_off = lds_bytes - (lanes + 1) * kSimtLaneBytes;
@@ -1992,7 +1992,7 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
   for (int v = 0; v < R; v++) col0[v * PITCH] = col[v];
 }
 
-template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : 4) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || (*f.frame_flags & 1) != 0 || force_generic) return;
@@ -2919,9 +2919,9 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     const int nblk = DivUp(max_groups, (int)kSimtMaxThreads);
     const uint32_t lanes = (uint32_t)DivUp(max_groups, nblk);
     static const int lpw_env = getenv("JXL_HIP_HF_LANES") ? atoi(getenv("JXL_HIP_HF_LANES")) : 0;
-    // streams per wavefront: five wavefronts per workgroup (one or two per SIMD next to the LF wavefronts, whose 272 VGPRs
-    // leave room for two of these)
-    uint32_t lpw = lpw_env >= 1 && lpw_env <= 64 ? (uint32_t)lpw_env : (uint32_t)DivUp((int)lanes, 5);
+    // streams per wavefront: four wavefronts per workgroup, one per SIMD (two of these on one SIMD slow each other down
+    // more than the sparser lanes gain: 5 wavefronts 64 ms, 4: 49 ms, 3: 53 ms per 256 4K frames)
+    uint32_t lpw = lpw_env >= 1 && lpw_env <= 64 ? (uint32_t)lpw_env : (uint32_t)DivUp((int)lanes, 4);
     lpw = std::max(lpw, (uint32_t)DivUp((int)lanes, 16));                        // at most 16 wavefronts per workgroup
     const uint32_t threads = (uint32_t)DivUp((int)lanes, (int)lpw) * 64;
     const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes) + (lanes + 1) * kSimtLaneBytes;
