@@ -289,6 +289,12 @@ constexpr uint32_t kRowOff = kWinOff + kWinWords * 4, kRowMax = 256;  // two sam
 constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;             // 256-sample staging buffer for wider channels
 constexpr uint32_t kWaveLds = 8448;                                   // >= kChunkOff + 1024 and >= the 8 KiB placement bitmap
 static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
+#ifndef JXL_LF_MINW
+#define JXL_LF_MINW 4      // LfDecodeKernel: VGPR budget 512 / JXL_LF_MINW per lane
+#endif
+#ifndef JXL_IDCT_MINW
+#define JXL_IDCT_MINW 4    // IdctTileKernel<4>: likewise
+#endif
 constexpr uint32_t kLfWaves = 4;                                         // wavefronts per workgroup of the Modular group kernels
 constexpr uint32_t kLfDecWaves = 2, kLfDecGroups = 4;                    // LfDecodeKernel: two wavefronts share four LF groups
 // the shared part of the LDS (tree copy or per-wavefront pruned slices, then the entropy code) follows the per-wavefront regions
@@ -1122,7 +1128,7 @@ __device__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T,
 // workgroups of two batches in flight (2 x 36 KB) and an HF workgroup (80 KB) fit one CU.  (The kernel needs 272 VGPRs,
 // one wavefront per SIMD: a CU never hosts more than two of these workgroups, whatever the dispatcher would like.)
 // Small launches (single images) take one group per wavefront instead: latency over LDS economy.
-__global__ __launch_bounds__(64 * kLfDecWaves, 4) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
+__global__ __launch_bounds__(64 * kLfDecWaves, JXL_LF_MINW) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   const uint32_t first = blockIdx.x * groups_per_block;
@@ -1535,8 +1541,10 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
       }
     } else if (!done) {
       const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
-      uint32_t ctx;
+      uint32_t ctx, fetched = 0;     // coefficient position after the current one: requested before the token is decoded
       if (phase == 1) {
+        order = reinterpret_cast<const uint16_t*>((uintptr_t)LdS<uint64_t>(kSimtOrdOff + (ord * 3 + c) * 8));
+        fetched = LdG(order + covered);
         const uint32_t idx = ((uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord) * qlf_stride + qlf;
         const uint32_t block_ctx = LdS<uint8_t>(oMap + idx);
         const uint32_t top = LdS<uint8_t>(nz_base + c * 32 + bx), left = bx ? LdS<uint8_t>(nz_base + c * 32 + bx - 1) : 0;
@@ -1545,6 +1553,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
         histo = ctx_offset + 37 * nctx + 458 * block_ctx;
       } else {
+        if (k + 1 < size) fetched = LdG(order + k + 1);
         const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
         ctx = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + kk)) * 2 + prev;
       }
@@ -1564,12 +1573,11 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + coff;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
-        order = reinterpret_cast<const uint16_t*>((uintptr_t)LdS<uint64_t>(kSimtOrdOff + (ord * 3 + c) * 8));
-        next_pos = LdG(order + k);
+        next_pos = fetched;
         phase = 2;
       } else {
         const uint32_t pos = next_pos;
-        if (k + 1 < size) next_pos = LdG(order + k + 1);
+        next_pos = fetched;
         if (u) {
           int32_t val = (int32_t)((uint32_t)UnpackSigned(u) << shift);
           if (pass) val = (int32_t)((uint32_t)val + (uint32_t)LdG(blk + pos));
@@ -1992,7 +2000,7 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
   for (int v = 0; v < R; v++) col0[v * PITCH] = col[v];
 }
 
-template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : 4) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || (*f.frame_flags & 1) != 0 || force_generic) return;
