@@ -1529,22 +1529,27 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         end_bitpos = br.BitPos();
         done = true;
       } else {
-        const uint2 ent = ent_next;
-        vi++;
-        if (vi < nvb) ent_next = LdG(vbl + vi);
-        const uint32_t s = ent.x & 31;
-        bx = (ent.x >> 16) & 31; by = (ent.x >> 21) & 31; qlf = ent.x >> 26;
+        const uint32_t ex = ent_next.x, ey = ent_next.y;
+        const uint32_t s = ex & 31;
+        bx = (ex >> 16) & 31; by = (ex >> 21) & 31; qlf = ex >> 26;
         lcx = Log2CoveredX(s); l2 = lcx + Log2CoveredY(s);
         covered = 1u << l2; size = covered * 64; ord = OrderBucket(s);
-        coff = gbase + ent.y;
+        coff = gbase + ey;
         ci = 0; phase = 1;
+        vi++;
       }
     } else if (!done) {
       const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
-      uint32_t ctx, fetched = 0;     // coefficient position after the current one: requested before the token is decoded
+      // coefficient position after the current one: requested before the token is decoded, as the aligned 32-bit word that
+      // holds it (the 16-bit field is only extracted where it is used, so nothing waits for the load up here)
+      uint32_t ctx, fetched = 0, fetched_sh = 0;
+      auto fetch_pos = [&](uint32_t kk) { fetched = LdG(reinterpret_cast<const uint32_t*>(order + (kk & ~1u))); fetched_sh = (kk & 1u) << 4; };
       if (phase == 1) {
+        // the next varblock's list entry is requested while the last channel of this one is decoded (the old entry is dead
+        // by now, so the load lands in its registers and nothing waits for it before the next block start)
+        if (ci == 2 && vi < nvb) ent_next = LdG(vbl + vi);
         order = reinterpret_cast<const uint16_t*>((uintptr_t)LdS<uint64_t>(kSimtOrdOff + (ord * 3 + c) * 8));
-        fetched = LdG(order + covered);
+        fetch_pos(covered);
         const uint32_t idx = ((uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord) * qlf_stride + qlf;
         const uint32_t block_ctx = LdS<uint8_t>(oMap + idx);
         const uint32_t top = LdS<uint8_t>(nz_base + c * 32 + bx), left = bx ? LdS<uint8_t>(nz_base + c * 32 + bx - 1) : 0;
@@ -1553,7 +1558,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
         histo = ctx_offset + 37 * nctx + 458 * block_ctx;
       } else {
-        if (k + 1 < size) fetched = LdG(order + k + 1);
+        if (k + 1 < size) fetch_pos(k + 1);
         const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
         ctx = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + kk)) * 2 + prev;
       }
@@ -1573,11 +1578,11 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + coff;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
-        next_pos = fetched;
+        next_pos = (fetched >> fetched_sh) & 0xFFFFu;
         phase = 2;
       } else {
         const uint32_t pos = next_pos;
-        next_pos = fetched;
+        next_pos = (fetched >> fetched_sh) & 0xFFFFu;
         if (u) {
           int32_t val = (int32_t)((uint32_t)UnpackSigned(u) << shift);
           if (pass) val = (int32_t)((uint32_t)val + (uint32_t)LdG(blk + pos));
