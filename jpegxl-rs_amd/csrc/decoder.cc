@@ -770,12 +770,15 @@ void Batch::Finish(void* stream_v) {
     // the LF stage has classified every frame's varblock placement: later decodes of this batch skip the kernels nobody needs
     std::vector<uint32_t> flags(n, 0);
     HIP_CHECK(hipMemcpy(flags.data(), dwork_ + flags_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
-    cfg.any_irregular_blocks = cfg.any_big_blocks = cfg.any_wide_blocks = cfg.any_narrow_frames = 0;
+    cfg.any_irregular_blocks = cfg.any_big_blocks = 0;
+    cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = 0;
     for (int i = 0; i < n; i++) {
       if (images_[i]->plan.modular) continue;
       const uint32_t v = flags[i];
       cfg.any_irregular_blocks |= (v & 1) != 0; cfg.any_big_blocks |= (v & 2) != 0;
-      if (v & 4) cfg.any_wide_blocks = 1; else cfg.any_narrow_frames = 1;
+      if (v & 1) continue;                                  // generic IdctKernel frame
+      if (v & 4) { if (v & 8) cfg.need_tile8_special = 1; else cfg.need_tile8_plain = 1; }
+      else { if (v & 8) cfg.need_tile4_special = 1; else cfg.need_tile4_plain = 1; }
     }
     cfg.idct_flags_known = 1;
   }

@@ -1056,6 +1056,7 @@ __device__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T,
         }
         if (clash) { SetError(f, kErrVarblock); bad = true; break; }
         if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;      // not inside one 32x32 tile: the IDCT uses 64x64 tiles
+        if (s == 1 || s == 2 || s == 3 || s == 12 || s == 13) flags_acc |= 8u;   // IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4: the tile kernel variant that carries them
         if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;   // DCT128/256 family: BigIdctKernel (+ generic path if unaligned)
         else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;  // varblock not contained in a 64x64 tile: generic IDCT
         const uint32_t gi = (y / 32) * 8 + wi;
@@ -2005,11 +2006,15 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
   for (int v = 0; v < R; v++) col0[v * PITCH] = col[v];
 }
 
-template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+// SPECIAL = the variant for frames that contain the 8x8 "special" transforms (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4):
+// their 64-coefficient register blocks cost 30 VGPRs that the plain variant does not have to carry (the LF stage flags
+// the frames; which variants a batch needs is known after its first decode).
+template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || (*f.frame_flags & 1) != 0 || force_generic) return;
   if (((*f.frame_flags & 4) != 0) != (TB == 8)) return;     // frames with a varblock that no 32x32 tile contains take the 64x64 tiles
+  if (((*f.frame_flags & 8) != 0) != SPECIAL) return;
   const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   if (tx * TB >= f.bw || ty * TB >= f.bh) return;
   extern __shared__ __align__(16) float s_tile[];   // 3 * kTilePlane floats
@@ -2040,11 +2045,13 @@ template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 
   constexpr int kQ = kNB * 8 / (TB == 8 ? 256 : 128);   // candidate row/column tasks per thread
   uint32_t my_rclass[kQ], my_cclass[kQ];
   for (int q = 0; q < kQ; q++) {
-    const uint32_t tt = threadIdx.x + q * blockDim.x, info = s_info[tt >> 3];
+    const uint32_t tt = threadIdx.x + q * blockDim.x;
     my_rclass[q] = my_cclass[q] = 0xFFu;
+    if (tt >= (uint32_t)kNB * 8) continue;
+    const uint32_t info = s_info[tt >> 3];
     if (info == 0xFFFFFFFFu) continue;
     const uint32_t st = BI_Strategy(info);
-    if (IsSpecial(st)) { if ((tt & 7) == 0) my_rclass[q] = 4; continue; }   // one task per special block (rows pass only)
+    if (SPECIAL && IsSpecial(st)) { if ((tt & 7) == 0) my_rclass[q] = 4; continue; }   // one task per special block (rows pass only)
     if (BI_Ix(info) == 0) my_rclass[q] = Log2Cov8(CoveredX(st));
     if (BI_Iy(info) == 0) my_cclass[q] = Log2Cov8(CoveredY(st));
   }
@@ -2098,7 +2105,7 @@ template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 
     const int32_t qy[4] = {qy4.x, qy4.y, qy4.z, qy4.w}, qx[4] = {qx4.x, qx4.y, qx4.z, qx4.w}, qb[4] = {qb4.x, qb4.y, qb4.z, qb4.w};
     const float wy[4] = {ty4.x, ty4.y, ty4.z, ty4.w}, wx[4] = {tx4.x, tx4.y, tx4.z, tx4.w}, wbl[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
     const uint32_t vbx = (bi % TB) - ix, vby = (bi / TB) - iy;   // varblock origin inside the tile (blocks)
-    const bool special = IsSpecial(s);
+    const bool special = SPECIAL && IsSpecial(s);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const uint32_t k = k0 + e;
@@ -2128,13 +2135,15 @@ template <int TB> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 
       const uint32_t bx = bi % TB, by = bi / TB;
       const size_t o_first = (size_t)(by0 + by - iy) * f.bw + bx0 + bx;
       float* blk0 = s_tile + c * kTilePlane + ((by - iy) * 8) * kTilePitch + bx * 8;
-      if (cls == 4) {
-        float cf[64];
+      if constexpr (SPECIAL) {
+        if (cls == 4) {
+          float cf[64];
 #pragma unroll
-        for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
-        cf[0] = LdG(f.llf[c] + o_first);
-        SpecialTransform(s, cf, blk0, kTilePitch);
-        continue;
+          for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
+          cf[0] = LdG(f.llf[c] + o_first);
+          SpecialTransform(s, cf, blk0, kTilePitch);
+          continue;
+        }
       }
       const int v = (int)(iy * 8 + r);
       float* row0 = blk0 + v * kTilePitch;
@@ -2963,14 +2972,22 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
   hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(threads), lds_bytes, (hipStream_t)stream, frames, cfg.lane_stride_hf, lds_bytes);
 }
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream) {
-  // 64x64 tiles for frames with varblocks beyond 32x32, 32x32 tiles (a quarter of the LDS) for the others
-  if (!cfg.idct_flags_known || cfg.any_wide_blocks) {
+  // 64x64 tiles for frames with varblocks beyond 32x32, 32x32 tiles (a quarter of the LDS) for the others; each in a
+  // variant with and without the 8x8 special transforms.  Every frame is taken by exactly one of the four.
+  const bool all = !cfg.idct_flags_known;
+  {
     const int tiles_x = DivUp(max_bw, 8), tiles_y = DivUp(max_bh, 8);
-    hipLaunchKernelGGL(IdctTileKernel<8>, dim3(tiles_x * tiles_y, nframes), dim3(256), 3 * TileGeom<8>::kPlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+    const dim3 grid(tiles_x * tiles_y, nframes);
+    const size_t lds = 3 * TileGeom<8>::kPlane * sizeof(float);
+    if (all || cfg.need_tile8_plain) hipLaunchKernelGGL((IdctTileKernel<8, false>), grid, dim3(256), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+    if (all || cfg.need_tile8_special) hipLaunchKernelGGL((IdctTileKernel<8, true>), grid, dim3(256), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
   }
-  if (!cfg.idct_flags_known || cfg.any_narrow_frames) {
+  {
     const int tiles_x = DivUp(max_bw, 4), tiles_y = DivUp(max_bh, 4);
-    hipLaunchKernelGGL(IdctTileKernel<4>, dim3(tiles_x * tiles_y, nframes), dim3(128), 3 * TileGeom<4>::kPlane * sizeof(float), (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+    const dim3 grid(tiles_x * tiles_y, nframes);
+    const size_t lds = 3 * TileGeom<4>::kPlane * sizeof(float);
+    if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+    if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
   }
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
