@@ -910,7 +910,7 @@ __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTabl
 // K_lf: one wavefront per LF group (four per workgroup, sharing the tables) — LF coefficients (3 channels, order Y,X,B)
 // + HF metadata, then varblock placement
 // =====================================================================================================================
-__device__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T, int& s_fail, GroupHeaderD& s_gh, uint32_t* s_u) {
+__device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T, int& s_fail, GroupHeaderD& s_gh, uint32_t* s_u) {
   const uint32_t lane = threadIdx.x & 63, wb = T.wb;
   const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
   const uint32_t bx0 = gx * 256, by0 = gy * 256;
