@@ -61,7 +61,7 @@ def cpu_baseline(streams, width, height, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "256")), help="frames per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames (cycled to fill the batch)")
