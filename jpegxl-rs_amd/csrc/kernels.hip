@@ -2175,9 +2175,10 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
   for (uint32_t c = 0; c < 3; c++) {
     float* dst = f.plane_a[c] + (size_t)(by0 * 8) * f.plane_stride + bx0 * 8;
     const float* src = s_tile + c * kTilePlane;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(TB * 8) * th; i += blockDim.x) {
-      const uint32_t y = i / (TB * 8), x = i % (TB * 8);
-      if (x < tw) StG(dst + (size_t)y * f.plane_stride + x, src[y * kTilePitch + x]);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(TB * 2) * th; i += blockDim.x) {   // 16 bytes per store (rows are 32-byte aligned)
+      const uint32_t y = i / (TB * 2), x = (i % (TB * 2)) * 4;
+      const float* sp = src + y * kTilePitch + x;
+      if (x < tw) StG(reinterpret_cast<float4*>(dst + (size_t)y * f.plane_stride + x), make_float4(sp[0], sp[1], sp[2], sp[3]));
     }
   }
 }
