@@ -2040,7 +2040,9 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
   // length a wavefront runs one.  Classes 0..3 = 8 << class points, class 4 = the 8x8 "special" transforms.
   __shared__ uint32_t s_cnt[16];                 // [0..4] row counts, [5..8] column counts, then running cursors
   __shared__ uint16_t s_rtask[kNB * 8], s_ctask[kNB * 8];
+  __shared__ uint32_t s_next;                    // next unassigned row task of pass 1
   if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_next = 0;
   __syncthreads();
   constexpr int kQ = kNB * 8 / (TB == 8 ? 256 : 128);   // candidate row/column tasks per thread
   uint32_t my_rclass[kQ], my_cclass[kQ];
@@ -2123,29 +2125,47 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     }
   }
   __syncthreads();
-  // ---- pass 1: rows, one transform length at a time (3 channels x the class's task list)
-  for (int cls = 0; cls < 5; cls++) {
-    const uint32_t n = r_begin[cls + 1] - r_begin[cls];
-    for (uint32_t t = threadIdx.x; t < n * 3; t += blockDim.x) {
-      const uint32_t c = t / n, tt = s_rtask[r_begin[cls] + (t - c * n)];
-      const uint32_t r = tt & 7, bi = tt >> 3;
-      const uint32_t info = s_info[bi];
-      const uint32_t s = BI_Strategy(info), iy = BI_Iy(info);
-      const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
+  // ---- pass 1: rows.  The regular row tasks (sorted by transform length, x 3 channels) are handed out in chunks of 64
+  // from a counter in LDS; the 8x8 special transforms — one lane per (block, channel), ~10 times the work of a row — are
+  // taken first by the last wavefront while the others already pull rows (run after the rows they doubled this phase).
+  {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    auto block_of = [&](uint32_t tt, uint32_t c, uint32_t& s, uint32_t& iy, size_t& o_first) -> float* {
+      const uint32_t bi = tt >> 3, info = s_info[bi];
+      s = BI_Strategy(info); iy = BI_Iy(info);
       const uint32_t bx = bi % TB, by = bi / TB;
-      const size_t o_first = (size_t)(by0 + by - iy) * f.bw + bx0 + bx;
-      float* blk0 = s_tile + c * kTilePlane + ((by - iy) * 8) * kTilePitch + bx * 8;
-      if constexpr (SPECIAL) {
-        if (cls == 4) {
+      o_first = (size_t)(by0 + by - iy) * f.bw + bx0 + bx;
+      return s_tile + c * kTilePlane + ((by - iy) * 8) * kTilePitch + bx * 8;
+    };
+    if constexpr (SPECIAL) {
+      const uint32_t n4 = r_begin[5] - r_begin[4];
+      if (n4 && wave == nwaves - 1) {
+        for (uint32_t t = lane; t < n4 * 3; t += 64) {
+          const uint32_t c = t / n4, tt = s_rtask[r_begin[4] + (t - c * n4)];
+          uint32_t s, iy; size_t o_first;
+          float* blk0 = block_of(tt, c, s, iy, o_first);
           float cf[64];
 #pragma unroll
           for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
           cf[0] = LdG(f.llf[c] + o_first);
           SpecialTransform(s, cf, blk0, kTilePitch);
-          continue;
         }
       }
-      const int v = (int)(iy * 8 + r);
+    }
+    const uint32_t b1 = r_begin[1] - r_begin[0], b2 = r_begin[2] - r_begin[0], b3 = r_begin[3] - r_begin[0], nreg = r_begin[4] - r_begin[0];
+    while (true) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&s_next, 64u);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (base >= nreg * 3) break;
+      const uint32_t t = base + lane;
+      if (t >= nreg * 3) continue;
+      const uint32_t c = t / nreg, idx = t - c * nreg, tt = s_rtask[r_begin[0] + idx];
+      const uint32_t cls = idx < b1 ? 0 : idx < b2 ? 1 : idx < b3 ? 2 : 3;
+      uint32_t s, iy; size_t o_first;
+      float* blk0 = block_of(tt, c, s, iy, o_first);
+      const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
+      const int v = (int)(iy * 8 + (tt & 7));
       float* row0 = blk0 + v * kTilePitch;
       const float* llf = f.llf[c] + o_first + (size_t)v * f.bw;
       if (cls == 0) TileRowPass<8>(row0, v, cy, cx, llf);
