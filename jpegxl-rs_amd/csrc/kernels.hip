@@ -2175,11 +2175,12 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     }
   }
   __syncthreads();
-  // ---- pass 2: columns
-  for (int cls = 0; cls < 4; cls++) {
-    const uint32_t n = c_begin[cls + 1] - c_begin[cls];
-    for (uint32_t t = threadIdx.x; t < n * 3; t += blockDim.x) {
-      const uint32_t c = t / n, tt = s_ctask[c_begin[cls] + (t - c * n)];
+  // ---- pass 2: columns (one list over all transform lengths x 3 channels: no partly filled pass per length)
+  {
+    const uint32_t b1 = c_begin[1] - c_begin[0], b2 = c_begin[2] - c_begin[0], b3 = c_begin[3] - c_begin[0], ncol = c_begin[4] - c_begin[0];
+    for (uint32_t t = threadIdx.x; t < ncol * 3; t += blockDim.x) {
+      const uint32_t c = t / ncol, idx = t - c * ncol, tt = s_ctask[c_begin[0] + idx];
+      const uint32_t cls = idx < b1 ? 0 : idx < b2 ? 1 : idx < b3 ? 2 : 3;
       const uint32_t xx = tt & 7, bi = tt >> 3;
       const uint32_t bx = bi % TB, by = bi / TB;
       float* col0 = s_tile + c * kTilePlane + (by * 8) * kTilePitch + bx * 8 + xx;
