@@ -127,17 +127,25 @@ def main():
     # its own stream: an LF workgroup holds 35 KB of LDS, so two of them and an HF workgroup share a CU
     sides = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, nbuf - 1))] if pipeline else []
     comm = torch.cuda.Stream(device=dev) if do_gather else None               # RCCL gather overlaps the next step's decode
+    # What the LF stage of the batch two steps ahead waits for.  "rest" (default) = the end of the previous step, i.e. it starts
+    # together with this step's HF stage: the HF workgroups (80 KB of LDS on every CU) then force the dispatcher to spread the LF
+    # workgroups one per CU.  "hf" = the end of this step's HF stage (experiment: the LF workgroups then land next to pixel-kernel
+    # workgroups, pile up on some CUs, and the next HF stage waits for those CUs: 89 instead of 47 ms).
+    front_gate = os.environ.get("JXL_BENCH_FRONT_GATE", "rest")
+    hf_done = [torch.cuda.Event() for _ in range(nbuf)]
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
     rest_done = [torch.cuda.Event() for _ in range(nbuf)]
     gather_done = [torch.cuda.Event() for _ in range(nbuf)]
     state = {"k": 0, "front_issued": 0, "limit": args.warmup}
 
-    def issue_front(k, timed):
+    def issue_front(k, timed, gate=None):
         b = k % nbuf
         side = sides[k % len(sides)]
         with torch.cuda.stream(side):
             if k >= nbuf:
                 side.wait_event(rest_done[b])
+            if gate is not None:
+                side.wait_event(gate)
             batches[b].decode_part(1, side.cuda_stream, timed)
             front_done[b].record(side)
 
@@ -150,15 +158,20 @@ def main():
             else:
                 batches[0].decode(stream)
         else:
+            late = ahead if (front_gate == "hf" and ahead >= 2) else None
             if state["front_issued"] <= k:
                 issue_front(k, timed); state["front_issued"] = k + 1
             for j in range(1, ahead + 1):
-                if k + j < state["limit"] and state["front_issued"] <= k + j:
+                if j != late and k + j < state["limit"] and state["front_issued"] <= k + j:
                     issue_front(k + j, timed); state["front_issued"] = k + j + 1
             main.wait_event(front_done[b])
             if do_gather and k >= nbuf:
                 main.wait_event(gather_done[b])       # the previous gather of this buffer set must have read the pixels
-            batches[b].decode_part(2, stream, timed)
+            batches[b].decode_part(3, stream, timed)
+            hf_done[b].record(main)
+            if late is not None and k + late < state["limit"] and state["front_issued"] <= k + late:
+                issue_front(k + late, timed, gate=hf_done[b]); state["front_issued"] = k + late + 1
+            batches[b].decode_part(4, stream, timed)
             rest_done[b].record(main)
         if do_gather:
             if not pipeline:

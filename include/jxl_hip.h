@@ -144,9 +144,10 @@ JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* batch, void* hip_stream);
 JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* batch, void* hip_stream);
 /* Same, bracketing every stage with HIP events recorded on hip_stream (still no host sync). */
 JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* batch, void* hip_stream);
-/* Enqueues one part of a decode: 0 = everything, 1 = front (coefficient clear, LF decode, LF post-processing), 2 = rest (HF
- * decode, IDCT, filters, output).  Front and rest may go to different streams; the caller orders them with events, which lets
- * the latency-bound LF stage of the next batch overlap the bandwidth-bound stages of the current one. */
+/* Enqueues one part of a decode: 0 = everything, 1 = front (LF decode, LF post-processing), 2 = rest (HF decode, IDCT,
+ * filters, output); the rest may also be enqueued in two pieces, 3 = HF decode, 4 = IDCT, filters, output.  Front and rest may
+ * go to different streams; the caller orders them with events, which lets the latency-bound LF stage of later batches overlap
+ * the other stages of the current one (bench.py: three batches in flight, LF stages on two side streams). */
 JxlDecoderStatus JxlHipBatchDecodePart(JxlHipBatch* batch, void* hip_stream, int part, int timed);
 /* Waits for all timed decodes so far; returns per-stage sums in ms and the number of timed decodes. */
 JxlDecoderStatus JxlHipBatchCollectTimes(JxlHipBatch* batch, JxlHipStageTimes* times, int* runs);

@@ -525,7 +525,7 @@ class BatchDecoder:
         self._chk(libjxl().JxlHipBatchDecodeTimed(self._h, stream))
 
     def decode_part(self, part: int, stream=None, timed=False):
-        """part 1 = front (LF stage), 2 = rest (HF, IDCT, filters, output); see include/jxl_hip.h."""
+        """part 1 = front (LF stage), 2 = rest (HF, IDCT, filters, output) — or 3 = HF only, 4 = IDCT, filters, output; see include/jxl_hip.h."""
         self._chk(libjxl().JxlHipBatchDecodePart(self._h, stream, part, 1 if timed else 0))
 
     def collect_times(self):

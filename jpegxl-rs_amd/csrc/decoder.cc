@@ -688,23 +688,28 @@ void Batch::RunTimed(void* stream_v) { RunPart(stream_v, 0, true); }
 // filters, output).  Front and rest of one decode may be enqueued on different streams (ordered by the caller with
 // events) so that the latency-bound LF stage of the next batch overlaps the bandwidth stages of the current one.
 void Batch::RunPart(void* stream_v, int part, bool timed) {
+  // part 0 = whole decode, 1 = front (LF decode + LF post-processing), 2 = rest (HF decode, IDCT, filters, output);
+  // the rest can be enqueued in two pieces, 3 = HF decode only, 4 = everything after it, so that a caller can record an
+  // event between them (bench.py starts the LF stage of a later batch when an HF stage has ended, not when it starts).
   hipStream_t stream = (hipStream_t)stream_v;
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
   if (any_vardct_) CheckFilterBuffers();
-  if (part != 1) ran_once_ = true;
+  const bool do_front = part == 0 || part == 1, do_hf = part == 0 || part == 2 || part == 3, do_tail = part == 0 || part == 2 || part == 4;
+  const bool split = part != 0;                       // halves timed separately
+  if (do_hf || do_tail) ran_once_ = true;
   std::vector<void*>* evs = nullptr;
   if (timed) {
-    if (part != 2) { timed_events_.emplace_back(8, nullptr); }
+    if (do_front) { timed_events_.emplace_back(8, nullptr); }
     if (timed_events_.empty()) timed_events_.emplace_back(8, nullptr);
-    evs = part == 2 ? &timed_events_[timed_rest_cursor_ < timed_events_.size() ? timed_rest_cursor_ : timed_events_.size() - 1] : &timed_events_.back();
+    evs = !do_front ? &timed_events_[timed_rest_cursor_ < timed_events_.size() ? timed_rest_cursor_ : timed_events_.size() - 1] : &timed_events_.back();
   }
   auto rec = [&](int i) {
     if (!evs) return;
     hipEvent_t ev; HIP_CHECK(hipEventCreate(&ev)); (*evs)[i] = ev;
     HIP_CHECK(hipEventRecord(ev, stream));
   };
-  if (part != 2) {
+  if (do_front) {
     rec(0);
     if (any_modchan_) LaunchModularGlobal(dframes_, n, cfg, stream_v);   // Modular frames; extra channels of VarDCT frames
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
@@ -712,19 +717,26 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
     if (part == 1) rec(2);
   }
-  if (part != 1 && !any_vardct_) {
-    rec(part == 2 ? 7 : 2); rec(3); rec(4); rec(5);
-    if (any_modchan_) EnqueueModularTail(stream_v);
-    rec(6);
-    if (timed && part == 2) timed_rest_cursor_++;
-  } else if (part != 1) {
-    // the HF decoder only writes non-zero coefficients: clear the planes first (outside the per-stage brackets when the
-    // halves are timed separately; the planes may be shared with another batch, so this belongs to the rest half)
+  if (!any_vardct_) {
+    if (do_hf) { rec(split ? 7 : 2); rec(3); }
+    if (do_tail) {
+      rec(4); rec(5);
+      if (any_modchan_) EnqueueModularTail(stream_v);
+      rec(6);
+      if (timed && split) timed_rest_cursor_++;
+    }
+    return;
+  }
+  if (do_hf) {
+    // the HF decoder only writes non-zero coefficients into cleared planes (outside the per-stage brackets when the
+    // halves are timed separately)
     ClearCoefficientsBeforeHf(stream_v);
-    rec(part == 2 ? 7 : 2);
+    rec(split ? 7 : 2);
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
     rec(3);
+  }
+  if (do_tail) {
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     rec(4);
     LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
@@ -732,7 +744,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     rec(6);
     ClearCoefficientsAfterDecode(stream_v);   // for this batch's next decode; runs under whatever the caller enqueues next
-    if (timed && part == 2) timed_rest_cursor_++;
+    if (timed && split) timed_rest_cursor_++;
   }
 }
 
