@@ -2085,27 +2085,34 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
   const size_t cfl_i = (size_t)(by0 / 8) * f.cw + bx0 / 8;   // chroma-from-luma factors are per 64x64 pixels
   const float kx = f.base_x + (float)LdG(f.ytox + cfl_i) * f.color_scale;
   const float kb = f.base_b + (float)LdG(f.ytob + cfl_i) * f.color_scale;
-  for (uint32_t t = threadIdx.x; t < kNB * 16; t += blockDim.x) {
-    const uint32_t bi = t >> 4, j = (t & 15) * 4;
-    const uint32_t info = s_info[bi];
-    if (info == 0xFFFFFFFFu) continue;
+  struct Pass0Task { uint32_t info, bi, k0; int4 qy, qx, qb; float4 ty, tx, tb; };
+  auto p0_load = [&](uint32_t t, Pass0Task& p) {   // issues the six 16-byte loads of task t (if it exists)
+    p.info = 0xFFFFFFFFu;
+    if (t >= (uint32_t)kNB * 16) return;
+    p.bi = t >> 4;
+    p.info = s_info[p.bi];
+    if (p.info == 0xFFFFFFFFu) return;
+    const uint32_t s = BI_Strategy(p.info), ix = BI_Ix(p.info), iy = BI_Iy(p.info);
+    p.k0 = (iy * CoveredX(s) + ix) * 64 + (t & 15) * 4;      // this block's share of the varblock's coefficients
+    const uint32_t kind = QuantKind(s), base = s_coff[p.bi] + p.k0;
+    p.qy = LdG(reinterpret_cast<const int4*>(cq[1] + base));
+    p.qx = LdG(reinterpret_cast<const int4*>(cq[0] + base));
+    p.qb = LdG(reinterpret_cast<const int4*>(cq[2] + base));
+    p.ty = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 1] + p.k0));
+    p.tx = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 0] + p.k0));
+    p.tb = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 2] + p.k0));
+  };
+  auto p0_store = [&](const Pass0Task& p) {        // dequant + chroma-from-luma + scatter to (v, u)
+    if (p.info == 0xFFFFFFFFu) return;
+    const uint32_t info = p.info, bi = p.bi, k0 = p.k0;
     const uint32_t s = BI_Strategy(info), ix = BI_Ix(info), iy = BI_Iy(info);
     const uint32_t cx = CoveredX(s), cy = CoveredY(s);
     const uint32_t R = cy * 8, C = cx * 8;
     const uint32_t lr = 3 + Log2Cov8(cy), lc = 3 + Log2Cov8(cx);
-    const uint32_t k0 = (iy * cx + ix) * 64 + j;              // this block's share of the varblock's coefficients
-    const uint32_t kind = QuantKind(s);
-    const uint32_t base = s_coff[bi] + k0;
-    const int4 qy4 = LdG(reinterpret_cast<const int4*>(cq[1] + base));
-    const int4 qx4 = LdG(reinterpret_cast<const int4*>(cq[0] + base));
-    const int4 qb4 = LdG(reinterpret_cast<const int4*>(cq[2] + base));
-    const float4 ty4 = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 1] + k0));
-    const float4 tx4 = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 0] + k0));
-    const float4 tb4 = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 2] + k0));
     const float sd = f.inv_global_scale / (float)BI_HfMul(info);
     const float sdx = sd * f.x_dm, sdb = sd * f.b_dm;
-    const int32_t qy[4] = {qy4.x, qy4.y, qy4.z, qy4.w}, qx[4] = {qx4.x, qx4.y, qx4.z, qx4.w}, qb[4] = {qb4.x, qb4.y, qb4.z, qb4.w};
-    const float wy[4] = {ty4.x, ty4.y, ty4.z, ty4.w}, wx[4] = {tx4.x, tx4.y, tx4.z, tx4.w}, wbl[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
+    const int32_t qy[4] = {p.qy.x, p.qy.y, p.qy.z, p.qy.w}, qx[4] = {p.qx.x, p.qx.y, p.qx.z, p.qx.w}, qb[4] = {p.qb.x, p.qb.y, p.qb.z, p.qb.w};
+    const float wy[4] = {p.ty.x, p.ty.y, p.ty.z, p.ty.w}, wx[4] = {p.tx.x, p.tx.y, p.tx.z, p.tx.w}, wbl[4] = {p.tb.x, p.tb.y, p.tb.z, p.tb.w};
     const uint32_t vbx = (bi % TB) - ix, vby = (bi / TB) - iy;   // varblock origin inside the tile (blocks)
     const bool special = SPECIAL && IsSpecial(s);
 #pragma unroll
@@ -2123,6 +2130,14 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
       s_tile[kTilePlane + lo] = ydq;
       s_tile[2 * kTilePlane + lo] = fmaf(kb, ydq, bv);
     }
+  };
+  // two tasks per thread in flight: the loads of the second are issued before the first is dequantised
+  for (uint32_t t = threadIdx.x; t < (uint32_t)kNB * 16; t += 2 * blockDim.x) {
+    Pass0Task pa, pb;
+    p0_load(t, pa);
+    p0_load(t + blockDim.x, pb);
+    p0_store(pa);
+    p0_store(pb);
   }
   __syncthreads();
   // ---- pass 1: rows.  The regular row tasks (sorted by transform length, x 3 channels) are handed out in chunks of 64
