@@ -2020,6 +2020,10 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
   extern __shared__ __align__(16) float s_tile[];   // 3 * kTilePlane floats
   __shared__ uint32_t s_info[kNB];
   __shared__ uint32_t s_coff[kNB];
+  // bias[3] / |q| for |q| < 128: the smart dequantisation bias needs one correctly rounded division per non-trivial
+  // coefficient (12 per task, ~10 instructions each); the same quotients come out of a table filled by 128 divisions per tile
+  __shared__ float s_bias_q[128];
+  if (threadIdx.x < 128) s_bias_q[threadIdx.x] = threadIdx.x ? f.quant_bias[3] / (float)threadIdx.x : 0.0f;
   const uint32_t bx0 = tx * TB, by0 = ty * TB;
   const uint32_t tbw = min((uint32_t)TB, f.bw - bx0), tbh = min((uint32_t)TB, f.bh - by0);
   const uint32_t g = (by0 / 32) * f.xgroups + bx0 / 32;
@@ -2085,6 +2089,15 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
   const size_t cfl_i = (size_t)(by0 / 8) * f.cw + bx0 / 8;   // chroma-from-luma factors are per 64x64 pixels
   const float kx = f.base_x + (float)LdG(f.ytox + cfl_i) * f.color_scale;
   const float kb = f.base_b + (float)LdG(f.ytob + cfl_i) * f.color_scale;
+  auto adjust = [&](int32_t q, float bias_c) -> float {   // AdjustQuantBias with the quotient from the table (x / -y == -(x / y) exactly)
+    if (q == 0) return 0.0f;
+    const uint32_t aq = (uint32_t)(q < 0 ? -q : q);
+    if (aq == 1) return q < 0 ? -bias_c : bias_c;
+    const float fq = (float)q;
+    float d;
+    if (aq < 128) d = copysignf(s_bias_q[aq], fq); else d = bias3 / fq;
+    return fq - d;
+  };
   struct Pass0Task { uint32_t info, bi, k0; int4 qy, qx, qb; float4 ty, tx, tb; };
   auto p0_load = [&](uint32_t t, Pass0Task& p) {   // issues the six 16-byte loads of task t (if it exists)
     p.info = 0xFFFFFFFFu;
@@ -2118,9 +2131,9 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const uint32_t k = k0 + e;
-      const float ydq = AdjustQuantBias(qy[e], bias1, bias3) * (wy[e] * sd);
-      const float xv = AdjustQuantBias(qx[e], bias0, bias3) * (wx[e] * sdx);
-      const float bv = AdjustQuantBias(qb[e], bias2, bias3) * (wbl[e] * sdb);
+      const float ydq = adjust(qy[e], bias1) * (wy[e] * sd);
+      const float xv = adjust(qx[e], bias0) * (wx[e] * sdx);
+      const float bv = adjust(qb[e], bias2) * (wbl[e] * sdb);
       uint32_t v, u;
       if (special) { v = k >> 3; u = k & 7; }                 // kept in stored order for SpecialTransform
       else if (R >= C) { v = k & (R - 1); u = k >> lr; }      // (R, C are powers of two)
