@@ -2505,13 +2505,27 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
   float* s_in = s_f;                              // [3][kFinH][kFinP]
   float* s_gab = s_f;                             // [3][kFgH][kFgP] — overwrites the input tile (values pass through registers)
   const size_t stride = f.plane_stride;
-  // ---- load input tile (+3 halo) with image-border mirroring
-  for (int i = threadIdx.x; i < kFinW * kFinH; i += blockDim.x) {
-    const int ly = i / kFinW, lx = i % kFinW;
-    const int gx = MirrorD(x0 + lx - 3, w), gy = MirrorD(y0 + ly - 3, h);
-    const size_t o = (size_t)gy * stride + gx;
+  // ---- load input tile (+3 halo).  Tiles whose halo lies inside the image (all but the border ones) read aligned
+  // 16-byte chunks — columns x0-4 .. x0+35, ten per row — and drop the two outer samples; the others mirror per sample.
+  if (x0 >= 4 && y0 >= 3 && x0 + kFtW + 4 <= w && y0 + kFtH + 3 <= h) {
+    constexpr int kV = (kFinW + 2) / 4;
+    static_assert(kV * 4 == kFinW + 2 && kFtW % 4 == 0, "tile width");
+    for (int i = threadIdx.x; i < kV * kFinH * 3; i += blockDim.x) {
+      const int c = i / (kV * kFinH), r = i - c * (kV * kFinH), ly = r / kV, v = r - ly * kV;
+      const float4 q = LdG(reinterpret_cast<const float4*>(f.plane_a[c] + (size_t)(y0 + ly - 3) * stride + (x0 - 4 + v * 4)));
+      float* d = s_in + (c * kFinH + ly) * kFinP + v * 4 - 1;      // q.x is the sample left of local column v * 4
+      if (v > 0) d[0] = q.x;
+      d[1] = q.y; d[2] = q.z;
+      if (v < kV - 1) d[3] = q.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < kFinW * kFinH; i += blockDim.x) {
+      const int ly = i / kFinW, lx = i % kFinW;
+      const int gx = MirrorD(x0 + lx - 3, w), gy = MirrorD(y0 + ly - 3, h);
+      const size_t o = (size_t)gy * stride + gx;
 #pragma unroll
-    for (int c = 0; c < 3; c++) s_in[(c * kFinH + ly) * kFinP + lx] = LdG(f.plane_a[c] + o);
+      for (int c = 0; c < 3; c++) s_in[(c * kFinH + ly) * kFinP + lx] = LdG(f.plane_a[c] + o);
+    }
   }
   __syncthreads();
   // ---- gaborish on tile + halo 2: every thread keeps its results in registers until all inputs have been read
