@@ -57,7 +57,7 @@ struct FrameDev {
   float* llf[3];
   uint32_t* blk_info;
   uint32_t* coef_off;
-  uint2* vb_list;                 // per group: up to 1024 {strategy | hf_mul-1 << 8 | x << 16 | y << 21, coefficient offset}
+  uint2* vb_list;                 // per group: up to 1024 {strategy | log2 cx << 5 | log2 cx cy << 8 | order bucket << 12 | x << 16 | y << 21 | block-context bucket << 26, coefficient offset}
   uint32_t* vb_count;             // per group: number of varblocks
   int8_t* ytox; int8_t* ytob;
   int32_t* coeff[3];

@@ -1000,10 +1000,10 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   // blocks in parallel.  (The one-lane version with global loads and stores in the loop took 44 % of this kernel.)
   // Blocks never cross a 32-block boundary, hence never a 64-bit word of the bitmap.
   const uint32_t ring_off = wb, goff_off = wb + 2048, gcnt_off = wb + 2304, in_off = wb + 2560, rec_off = wb + 3072, cnt_off = wb + 4096;
-  const uint32_t pat_off = wb + 4128, geo_off = wb + 4160;   // row pattern (8 words), per-strategy {cx | cy << 8} (27 halfwords)
+  const uint32_t pat_off = wb + 4128, geo_off = wb + 4160;   // row pattern (8 words), per-strategy {cx | cy << 8 | HF entry fields << 16} (27 words)
   // bitmap: 32-bit words, one per 32-block column of the LF group (8 per row); bits outside the group are pre-set
   if (lane < 8) StS<uint32_t>(pat_off + lane * 4, lane * 32 >= gbw ? ~0u : (gbw - lane * 32 < 32 ? ~0u << (gbw - lane * 32) : 0u));
-  if (lane < 27) StS<uint16_t>(geo_off + lane * 2, (uint16_t)(CoveredX(lane) | (CoveredY(lane) << 8)));
+  if (lane < 27) StS<uint32_t>(geo_off + lane * 4, CoveredX(lane) | (CoveredY(lane) << 8) | (((Log2CoveredX(lane) << 5) | ((Log2CoveredX(lane) + Log2CoveredY(lane)) << 8) | (OrderBucket(lane) << 12)) << 16));
   WaveSync();
   for (uint32_t i = lane; i < 512; i += 64) {
     const uint32_t y = i >> 3, wi = i & 7;
@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
         if (num0 + count >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
         if (s >= 27 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }       // (negative values wrap to large ones)
         if (s >= 14 && s <= 17) { SetError(f, kErrUnsupported); bad = true; break; }   // AFV
-        const uint32_t geo = LdS<uint16_t>(geo_off + s * 2), cx = geo & 0xFF, cy = geo >> 8;
+        const uint32_t geo = LdS<uint32_t>(geo_off + s * 4), cx = geo & 0xFF, cy = (geo >> 8) & 0xFF;
         if (x + cx > gbw || y + cy > gbh || xb + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
         const uint32_t bits = (cx == 32 ? ~0u : (1u << cx) - 1u) << xb;
         uint32_t clash = 0;
@@ -1079,7 +1079,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     if (lane < count) {
       const uint4 r = LdS<uint4>(rec_off + lane * 16);
       const uint32_t x = r.x & 0xFF, y = (r.x >> 8) & 0xFF, s = (r.x >> 16) & 0xFF, q = r.x >> 24;
-      const uint32_t cx = r.w & 0xFF, cy = r.w >> 8;
+      const uint32_t cx = r.w & 0xFF, cy = (r.w >> 8) & 0xFF;
       const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
       StG(f.coef_off + o, r.y);
       // block-context inputs of the HF stage (ac_context.h): quant-field and LF-value buckets of the varblock's first block,
@@ -1097,9 +1097,10 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
         lf_idx = (b0 * (bcm.n_lf_thr[2] + 1) + b2) * (bcm.n_lf_thr[1] + 1) + b1;
       }
       const uint32_t qlf = (qf_idx * bcm.num_lf_ctxs + lf_idx) & 63u;
-      // per-group varblock list for the HF decoder: {strategy | hf_mul-1 << 8 | x << 16 | y << 21 | qlf << 26, coefficient offset}
+      // per-group varblock list for the HF decoder (everything its block start needs, ready to unpack):
+      // {strategy | log2 cx << 5 | log2 (cx cy) << 8 | order bucket << 12 | x << 16 | y << 21 | qlf << 26, coefficient offset}
       const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
-      StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (q << 8) | ((x % 32) << 16) | ((y % 32) << 21) | (qlf << 26), r.y));
+      StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (r.w >> 16) | ((x % 32) << 16) | ((y % 32) << 21) | (qlf << 26), r.y));
       for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++)
         StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, 0));
     }
@@ -1531,10 +1532,9 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         done = true;
       } else {
         const uint32_t ex = ent_next.x, ey = ent_next.y;
-        const uint32_t s = ex & 31;
         bx = (ex >> 16) & 31; by = (ex >> 21) & 31; qlf = ex >> 26;
-        lcx = Log2CoveredX(s); l2 = lcx + Log2CoveredY(s);
-        covered = 1u << l2; size = covered * 64; ord = OrderBucket(s);
+        lcx = (ex >> 5) & 7; l2 = (ex >> 8) & 15; ord = (ex >> 12) & 15;
+        covered = 1u << l2; size = covered * 64;
         coff = gbase + ey;
         ci = 0; phase = 1;
         vi++;
@@ -1568,13 +1568,18 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         nzeros = u;
         if (nzeros + covered > size) { err = kErrNzeros; done = true; }
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
-        {  // the varblock's columns of the "non-zeros above" row
-          const uint32_t a = nz_base + c * 32 + bx, v4 = nzm * 0x01010101u;
-          if (lcx == 0) StS<uint8_t>(a, (uint8_t)nzm);
-          else if (lcx == 1 && !(bx & 1)) StS<uint16_t>(a, (uint16_t)v4);
-          else if (lcx == 2 && !(bx & 3)) StS<uint32_t>(a, v4);
-          else if (lcx == 3 && !(bx & 7)) StS<uint2>(a, make_uint2(v4, v4));
-          else for (uint32_t ix = 0; ix < (1u << lcx); ix++) StS<uint8_t>(a + ix, (uint8_t)nzm);
+        {  // the varblock's columns of the "non-zeros above" row: one masked read-modify-write of the aligned 8 bytes that
+           // hold them (varblocks of up to 8 columns sit on multiples of their width); wider or unaligned ones byte by byte
+          const uint32_t cxw = 1u << lcx, sh = (bx & 7) * 8;
+          if ((bx & 7) + cxw <= 8) {
+            const uint32_t a8 = nz_base + c * 32 + (bx & ~7u);
+            const uint64_t mask = (cxw == 8 ? ~0ull : ((1ull << (8 * cxw)) - 1ull)) << sh;
+            const uint64_t val = (uint64_t)nzm * 0x0101010101010101ull;
+            const uint64_t old = LdS<uint64_t>(a8);
+            StS<uint64_t>(a8, (old & ~mask) | (val & mask));
+          } else {
+            for (uint32_t ix = 0; ix < cxw; ix++) StS<uint8_t>(nz_base + c * 32 + bx + ix, (uint8_t)nzm);
+          }
         }
         blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + coff;
         prev = nzeros > size / 16 ? 0 : 1;
@@ -1908,9 +1913,10 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
   const uint32_t count = f.vb_count[g];
   for (uint32_t e = 0; e < count; e++) {
     const uint2 ent = f.vb_list[(size_t)g * 1024 + e];
-    const uint32_t s = ent.x & 0xFF;
+    const uint32_t s = ent.x & 31;
     if (!IsBig(s)) continue;
-    const uint32_t hf_mul = ((ent.x >> 8) & 0xFF) + 1, bx = gx * 32 + ((ent.x >> 16) & 31), by = gy * 32 + ((ent.x >> 21) & 31);
+    const uint32_t bx = gx * 32 + ((ent.x >> 16) & 31), by = gy * 32 + ((ent.x >> 21) & 31);
+    const uint32_t hf_mul = BI_HfMul(f.blk_info[(size_t)by * f.bw + bx]);
     const int cx = (int)CoveredX(s), cy = (int)CoveredY(s), R = cy * 8, C = cx * 8;
     const size_t o_first = (size_t)by * f.bw + bx;
     // ---- LLF: scaled forward DCT of the varblock's LF samples (columns, then rows — LlfSigmaKernel's order)
