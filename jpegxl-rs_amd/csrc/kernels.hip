@@ -211,7 +211,8 @@ template <bool ALL_LDS> __device__ __forceinline__ uint32_t FastHybridT(BitReade
   const uint32_t off = hit ? offs1 + pos : pos;
   const uint32_t freq = hit ? freq1 : freq0;
   state = freq * (state >> 12) + off;
-  if (state < (1u << 16)) state = (state << 16) | br.Read(16);
+  // (the caller refilled: at least 33 bits are buffered, 17 after the renormalisation — enough for most extra-bit fields)
+  if (state < (1u << 16)) { state = (state << 16) | (uint32_t)(br.buf & 0xFFFFu); br.buf >>= 16; br.avail -= 16; }
   const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
   const uint32_t split = 1u << split_exp;
   if (tok < split) return tok;
@@ -219,7 +220,9 @@ template <bool ALL_LDS> __device__ __forceinline__ uint32_t FastHybridT(BitReade
   nbits &= 31;
   const uint32_t low = tok & ((1u << lsb) - 1);
   tok >>= lsb;
-  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
+  if ((int)nbits > br.avail) br.Refill();
+  const uint32_t bits = (uint32_t)(br.buf & ((1ull << nbits) - 1));
+  br.buf >>= nbits; br.avail -= (int)nbits;
   const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
   return (((hi << nbits) | bits) << lsb) | low;
 }
@@ -1402,6 +1405,7 @@ struct BitReaderRing {   // per-lane ring of 16 words in LDS; absolute word inde
 };
 
 template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridSimt(BR& br, uint32_t& state, const FastCode& c, uint32_t ctx) {
+  br.Refill();   // one refill point per token instead of one per field
   const uint32_t cluster = ALL_LDS ? LdS<uint8_t>(c.ctx_map_off + ctx) : c.Cluster(ctx);
   const uint32_t la = c.log_alpha;
   const uint32_t cfg = ALL_LDS ? LdS<uint32_t>(c.cfg_off + cluster * 4) : c.Cfg(cluster);
@@ -1415,7 +1419,8 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   const uint32_t off = hit ? offs1 + pos : pos;
   const uint32_t freq = hit ? freq1 : freq0;
   state = freq * (state >> 12) + off;
-  if (state < (1u << 16)) state = (state << 16) | br.Read(16);
+  // (the caller refilled: at least 33 bits are buffered, 17 after the renormalisation — enough for most extra-bit fields)
+  if (state < (1u << 16)) { state = (state << 16) | (uint32_t)(br.buf & 0xFFFFu); br.buf >>= 16; br.avail -= 16; }
   const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
   const uint32_t split = 1u << split_exp;
   if (tok < split) return tok;
@@ -1423,7 +1428,9 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   nbits &= 31;
   const uint32_t low = tok & ((1u << lsb) - 1);
   tok >>= lsb;
-  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
+  if ((int)nbits > br.avail) br.Refill();
+  const uint32_t bits = (uint32_t)(br.buf & ((1ull << nbits) - 1));
+  br.buf >>= nbits; br.avail -= (int)nbits;
   const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
   return (((hi << nbits) | bits) << lsb) | low;
 }
