@@ -1084,7 +1084,6 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
       const uint32_t x = r.x & 0xFF, y = (r.x >> 8) & 0xFF, s = (r.x >> 16) & 0xFF, q = r.x >> 24;
       const uint32_t cx = r.w & 0xFF, cy = (r.w >> 8) & 0xFF;
       const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
-      StG(f.coef_off + o, r.y);
       // block-context inputs of the HF stage (ac_context.h): quant-field and LF-value buckets of the varblock's first block,
       // folded into qf_idx * num_lf_ctxs + lf_idx (< 64) here so that the HF decoder's loop has no threshold searches
       const BlockCtxDev& bcm = *f.bcm;
@@ -1104,8 +1103,10 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
       // {strategy | log2 cx << 5 | log2 (cx cy) << 8 | order bucket << 12 | x << 16 | y << 21 | qlf << 26, coefficient offset}
       const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
       StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (r.w >> 16) | ((x % 32) << 16) | ((y % 32) << 21) | (qlf << 26), r.y));
-      for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++)
+      for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++) {
         StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, 0));
+        StG(f.coef_off + o + (size_t)iy * f.bw + ix, r.y);   // (every covered block: the IDCT reads info and offset side by side)
+      }
     }
     num0 += count;
     if (scan_y >= gbh) break;
@@ -2046,7 +2047,7 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     if (bx < tbw && by < tbh) {
       const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
       info = LdG(f.blk_info + o);
-      coff = LdG(f.coef_off + o - (size_t)BI_Iy(info) * f.bw - BI_Ix(info));   // offset of the covering varblock
+      coff = LdG(f.coef_off + o);                   // offset of the covering varblock (stored for all of its blocks)
     }
     s_info[threadIdx.x] = info; s_coff[threadIdx.x] = coff;
   }
