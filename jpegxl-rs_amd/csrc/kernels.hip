@@ -1998,14 +1998,10 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
 // most 32x32 — a quarter of the LDS per workgroup, four times the workgroups in flight to cover barrier waits)
 template <int TB> struct TileGeom { static constexpr int kPx = TB * 8, kPitch = TB * 8 + 1, kPlane = TB * 8 * (TB * 8 + 1); };
 
-template <int C> __device__ __forceinline__ void TileRowPass(float* row0 /* LDS row start */, int v, int cy, int cx, const float* llf /* global, row v of the LLF block */) {
+template <int C> __device__ __forceinline__ void TileRowPass(float* row0 /* LDS row start; the LLF samples are already in place */) {
   float row[C];
 #pragma unroll
   for (int u = 0; u < C; u++) row[u] = row0[u];
-  if (v < cy) {
-#pragma unroll
-    for (int u = 0; u < C / 8; u++) if (u < cx) row[u] = LdG(llf + u);
-  }
   IDct1D<C>(row);
 #pragma unroll
   for (int u = 0; u < C; u++) row0[u] = row[u];
@@ -2034,6 +2030,7 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
   extern __shared__ __align__(16) float s_tile[];   // 3 * kTilePlane floats
   __shared__ uint32_t s_info[kNB];
   __shared__ uint32_t s_coff[kNB];
+  __shared__ float s_llf[3 * kNB];
   // bias[3] / |q| for |q| < 128: the smart dequantisation bias needs one correctly rounded division per non-trivial
   // coefficient (12 per task, ~10 instructions each); the same quotients come out of a table filled by 128 divisions per tile
   __shared__ float s_bias_q[128];
@@ -2048,6 +2045,8 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
       const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
       info = LdG(f.blk_info + o);
       coff = LdG(f.coef_off + o);                   // offset of the covering varblock (stored for all of its blocks)
+      // the LLF plane holds one sample per 8x8 block: sample (iy, ix) of the covering varblock's low-frequency corner
+      for (int c = 0; c < 3; c++) s_llf[c * kNB + threadIdx.x] = LdG(f.llf[c] + o);
     }
     s_info[threadIdx.x] = info; s_coff[threadIdx.x] = coff;
   }
@@ -2167,6 +2166,15 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     p0_store(pb);
   }
   __syncthreads();
+  // ---- the lowest frequencies come from the LF image: every block of the tile puts its LLF sample where its varblock's
+  // coefficient (iy, ix) sits (special 8x8 transforms: their single one at the block origin)
+  for (uint32_t t = threadIdx.x; t < 3u * kNB; t += blockDim.x) {
+    const uint32_t c = t / kNB, bi = t - c * kNB, info = s_info[bi];
+    if (info == 0xFFFFFFFFu) continue;
+    const uint32_t ix = BI_Ix(info), iy = BI_Iy(info), bx = bi % TB, by = bi / TB;
+    s_tile[c * kTilePlane + ((by - iy) * 8 + iy) * kTilePitch + (bx - ix) * 8 + ix] = s_llf[t];
+  }
+  __syncthreads();
   // ---- pass 1: rows.  The regular row tasks (sorted by transform length, x 3 channels) are handed out in chunks of 64
   // from a counter in LDS; the 8x8 special transforms — one lane per (block, channel), ~10 times the work of a row — are
   // taken first by the last wavefront while the others already pull rows (run after the rows they doubled this phase).
@@ -2189,7 +2197,6 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
           float cf[64];
 #pragma unroll
           for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
-          cf[0] = LdG(f.llf[c] + o_first);
           SpecialTransform(s, cf, blk0, kTilePitch);
         }
       }
@@ -2206,14 +2213,11 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
       const uint32_t cls = idx < b1 ? 0 : idx < b2 ? 1 : idx < b3 ? 2 : 3;
       uint32_t s, iy; size_t o_first;
       float* blk0 = block_of(tt, c, s, iy, o_first);
-      const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
-      const int v = (int)(iy * 8 + (tt & 7));
-      float* row0 = blk0 + v * kTilePitch;
-      const float* llf = f.llf[c] + o_first + (size_t)v * f.bw;
-      if (cls == 0) TileRowPass<8>(row0, v, cy, cx, llf);
-      else if (cls == 1) TileRowPass<16>(row0, v, cy, cx, llf);
-      else if (cls == 2) TileRowPass<32>(row0, v, cy, cx, llf);
-      else if (TB == 8) TileRowPass<64>(row0, v, cy, cx, llf);
+      float* row0 = blk0 + (iy * 8 + (tt & 7)) * kTilePitch;
+      if (cls == 0) TileRowPass<8>(row0);
+      else if (cls == 1) TileRowPass<16>(row0);
+      else if (cls == 2) TileRowPass<32>(row0);
+      else if (TB == 8) TileRowPass<64>(row0);
     }
   }
   __syncthreads();
