@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 
 namespace jxlhip {
 
@@ -1436,7 +1437,11 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   return (((hi << nbits) | bits) << lsb) | low;
 }
 
-template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave) {
+template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave,
+                                                                                 uint32_t* __restrict__ sync, uint32_t epoch) {
+  // sync[0]: workgroups of this launch that have started, sync[1]: number of the last HF launch whose workgroups all have
+  // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
+  if (sync && threadIdx.x == 0 && atomicAdd(sync, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(sync, 0u); __threadfence(); atomicMax(sync + 1, epoch); }
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   if (blockIdx.x * lanes >= f.num_groups) return;
@@ -3002,6 +3007,32 @@ void InitDeviceTables(void* stream) {
 
 static inline int DivUp(int a, int b) { return (a + b - 1) / b; }
 
+// Pipelined callers make the LF stage of a later batch runnable at the same moment as the HF stage of the current one (both
+// wait for the previous step's end).  If the LF workgroups are dispatched first they pile up three per CU, the HF
+// workgroups (80 KB of LDS) do not fit there until an LF workgroup ends, and that HF stage takes 82 instead of 44 ms (seen
+// in one step out of three in a kernel trace).  So a large LF launch is preceded by this one-wavefront kernel, which
+// holds the stream until an HF launch enqueued after it... (numbered `epoch` or later) has all its workgroups resident —
+// with an HF workgroup on every CU only one more LF workgroup fits, and the dispatcher has to spread the launch — or,
+// when no such launch shows up (different calling pattern), for 2 ms.
+__global__ void HeadStartKernel(const uint32_t* __restrict__ sync, uint32_t epoch, uint64_t timeout_ticks) {
+  const uint64_t t0 = wall_clock64();   // 100 MHz
+  while ((int32_t)(__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0 && wall_clock64() - t0 < timeout_ticks) __builtin_amdgcn_s_sleep(32);
+}
+// {workgroups started, last fully resident HF launch} per device + the number of HF launches enqueued so far
+static std::mutex g_hf_sync_mu;
+static uint32_t* g_hf_sync[64] = {nullptr};
+static uint32_t g_hf_enqueued[64] = {0};
+static uint32_t* HfSyncWords(int* dev_out) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  *dev_out = dev;
+  if (!g_hf_sync[dev]) {
+    if (hipMalloc((void**)&g_hf_sync[dev], 2 * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    (void)hipMemset(g_hf_sync[dev], 0, 2 * sizeof(uint32_t));
+  }
+  return g_hf_sync[dev];
+}
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream) {
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
@@ -3010,7 +3041,14 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
   // batches that fill the GPU: four groups per workgroup (two per wavefront, paired large + small); otherwise one per wavefront
-  const uint32_t gpb = (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128 ? kLfDecGroups : kLfDecWaves;
+  const bool big = (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128;
+  const uint32_t gpb = big ? kLfDecGroups : kLfDecWaves;
+  if (big) {
+    std::lock_guard<std::mutex> lock(g_hf_sync_mu);
+    int dev;
+    if (uint32_t* sync = HfSyncWords(&dev))
+      hipLaunchKernelGGL(HeadStartKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sync, g_hf_enqueued[dev] + 1, (uint64_t)200000);   // the next HF launch, or 2 ms
+  }
   hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
@@ -3041,8 +3079,14 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
       attr = true;
     }
     const dim3 grid(nblk, nframes);
-    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw);
-    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw);
+    uint32_t* sync = nullptr; uint32_t epoch = 0;
+    {
+      std::lock_guard<std::mutex> lock(g_hf_sync_mu);
+      int dev;
+      if ((sync = HfSyncWords(&dev)) != nullptr) epoch = ++g_hf_enqueued[dev];
+    }
+    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
     return;
   }
   const int threads = cfg.hf_block_threads;
