@@ -1135,7 +1135,9 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
 // workgroups of two batches in flight (2 x 36 KB) and an HF workgroup (80 KB) fit one CU.  (The kernel needs 272 VGPRs,
 // one wavefront per SIMD: a CU never hosts more than two of these workgroups, whatever the dispatcher would like.)
 // Small launches (single images) take one group per wavefront instead: latency over LDS economy.
-__global__ __launch_bounds__(64 * kLfDecWaves, JXL_LF_MINW) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
+// CAPPED: 128 VGPRs (with spills) so that pixel-kernel wavefronts of the batch on the main stream fit the same SIMDs — the
+// variant for large pipelined batches; single images take the uncapped one (267 VGPRs, LF stage 20 % shorter).
+template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? JXL_LF_MINW : 1) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   const uint32_t first = blockIdx.x * groups_per_block;
@@ -3039,7 +3041,11 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
   const uint32_t lds_bytes = kLfDecWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)LfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)LfDecodeKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    (void)hipFuncSetAttribute((const void*)LfDecodeKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    attr_set = true;
+  }
   // batches that fill the GPU: four groups per workgroup (two per wavefront, paired large + small); otherwise one per wavefront
   const bool big = (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128;
   const uint32_t gpb = big ? kLfDecGroups : kLfDecWaves;
@@ -3049,7 +3055,11 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     if (uint32_t* sync = HfSyncWords(&dev))
       hipLaunchKernelGGL(HeadStartKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sync, g_hf_enqueued[dev] + 1, (uint64_t)200000);   // the next HF launch, or 2 ms
   }
-  hipLaunchKernelGGL(LfDecodeKernel, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
+  if (big) {
+    hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
+  } else {
+    hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
+  }
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
