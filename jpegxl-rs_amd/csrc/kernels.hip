@@ -2148,17 +2148,18 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     const float wy[4] = {p.ty.x, p.ty.y, p.ty.z, p.ty.w}, wx[4] = {p.tx.x, p.tx.y, p.tx.z, p.tx.w}, wbl[4] = {p.tb.x, p.tb.y, p.tb.z, p.tb.w};
     const uint32_t vbx = (bi % TB) - ix, vby = (bi / TB) - iy;   // varblock origin inside the tile (blocks)
     const bool special = SPECIAL && IsSpecial(s);
+    // the four coefficients k0 .. k0+3 (k0 a multiple of 4) are neighbours along one axis of the (v, u) grid
+    uint32_t v0, u0, step;
+    if (special) { v0 = k0 >> 3; u0 = k0 & 7; step = 1; }                        // kept in stored order for SpecialTransform
+    else if (R >= C) { v0 = k0 & (R - 1); u0 = k0 >> lr; step = kTilePitch; }    // (R, C are powers of two)
+    else { v0 = k0 >> lc; u0 = k0 & (C - 1); step = 1; }
+    const uint32_t lo0 = (vby * 8 + v0) * kTilePitch + vbx * 8 + u0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const uint32_t k = k0 + e;
       const float ydq = adjust(qy[e], bias1) * (wy[e] * sd);
       const float xv = adjust(qx[e], bias0) * (wx[e] * sdx);
       const float bv = adjust(qb[e], bias2) * (wbl[e] * sdb);
-      uint32_t v, u;
-      if (special) { v = k >> 3; u = k & 7; }                 // kept in stored order for SpecialTransform
-      else if (R >= C) { v = k & (R - 1); u = k >> lr; }      // (R, C are powers of two)
-      else { v = k >> lc; u = k & (C - 1); }
-      const uint32_t lo = (vby * 8 + v) * kTilePitch + vbx * 8 + u;
+      const uint32_t lo = lo0 + (uint32_t)e * step;
       s_tile[lo] = fmaf(kx, ydq, xv);
       s_tile[kTilePlane + lo] = ydq;
       s_tile[2 * kTilePlane + lo] = fmaf(kb, ydq, bv);
