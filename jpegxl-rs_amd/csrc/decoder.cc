@@ -712,6 +712,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   if (do_front) {
     rec(0);
     if (any_modchan_) LaunchModularGlobal(dframes_, n, cfg, stream_v);   // Modular frames; extra channels of VarDCT frames
+    cfg.lf_head_start = part == 1;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     rec(1);
     if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);

@@ -106,6 +106,7 @@ struct LaunchCfg {
   int force_generic_idct = 0;
   // filled by Batch::Finish from the per-frame flags the LF stage sets (deterministic per stream): once known, the
   // kernels for varblocks outside a 64x64 tile / the DCT128-256 family are only launched when some frame needs them
+  int lf_head_start = 0;             // the LF launch waits until the next HF launch is resident (set for pipelined front-only calls)
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
   int need_tile4_plain = 1, need_tile4_special = 1, need_tile8_plain = 1, need_tile8_special = 1;   // IdctTileKernel<TB, SPECIAL> variants some frame takes
   int force_unfused_filters = 0;     // testing: stage-by-stage gaborish / EPF / output kernels even for fusable frames        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames

@@ -3050,7 +3050,7 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   // batches that fill the GPU: four groups per workgroup (two per wavefront, paired large + small); otherwise one per wavefront
   const bool big = (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128;
   const uint32_t gpb = big ? kLfDecGroups : kLfDecWaves;
-  if (big) {
+  if (big && cfg.lf_head_start) {
     std::lock_guard<std::mutex> lock(g_hf_sync_mu);
     int dev;
     if (uint32_t* sync = HfSyncWords(&dev))
