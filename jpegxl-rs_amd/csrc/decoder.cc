@@ -715,7 +715,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     cfg.lf_head_start = part == 1;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     rec(1);
-    if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, stream_v);
+    if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, max_groups_, stream_v);
     if (part == 1) rec(2);
   }
   if (!any_vardct_) {
@@ -784,12 +784,13 @@ void Batch::Finish(void* stream_v) {
     std::vector<uint32_t> flags(n, 0);
     HIP_CHECK(hipMemcpy(flags.data(), dwork_ + flags_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
     cfg.any_irregular_blocks = cfg.any_big_blocks = 0;
-    cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = 0;
+    cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = cfg.need_rare_special = 0;
     for (int i = 0; i < n; i++) {
       if (images_[i]->plan.modular) continue;
       const uint32_t v = flags[i];
       cfg.any_irregular_blocks |= (v & 1) != 0; cfg.any_big_blocks |= (v & 2) != 0;
       if (v & 1) continue;                                  // generic IdctKernel frame
+      if (v & 16) cfg.need_rare_special = 1;
       if (v & 4) { if (v & 8) cfg.need_tile8_special = 1; else cfg.need_tile8_plain = 1; }
       else { if (v & 8) cfg.need_tile4_special = 1; else cfg.need_tile4_plain = 1; }
     }

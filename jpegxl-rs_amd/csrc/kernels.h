@@ -109,6 +109,7 @@ struct LaunchCfg {
   int lf_head_start = 0;             // the LF launch waits until the next HF launch is resident (set for pipelined front-only calls)
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
   int need_tile4_plain = 1, need_tile4_special = 1, need_tile8_plain = 1, need_tile8_special = 1;   // IdctTileKernel<TB, SPECIAL> variants some frame takes
+  int need_rare_special = 1;         // some tile-kernel frame has IDENTITY / DCT2X2 blocks (IdctRareSpecialKernel)
   int force_unfused_filters = 0;     // testing: stage-by-stage gaborish / EPF / output kernels even for fusable frames        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames
   int hf_block_threads = 512;        // threads per HF-decode block (streams per block = threads / lane_stride_hf)
   int lds_code_budget = 64 * 1024;   // bytes of LDS the entropy-code tables (cfg, ctx map, alias) may take per block
@@ -118,7 +119,7 @@ void InitDeviceTables(void* stream);
 
 // VarDCT stages.  max_* are maxima over the batch (grid sizing); nframes = frames in batch.
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream);
-void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream);
+void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, int max_groups, void* stream);
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream);
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream);
 struct FilterPlan {

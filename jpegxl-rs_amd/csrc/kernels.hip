@@ -1061,6 +1061,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
         if (clash) { SetError(f, kErrVarblock); bad = true; break; }
         if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;      // not inside one 32x32 tile: the IDCT uses 64x64 tiles
         if (s == 1 || s == 2 || s == 3 || s == 12 || s == 13) flags_acc |= 8u;   // IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4: the tile kernel variant that carries them
+        if (s == 1 || s == 2) flags_acc |= 16u;                                   // IDENTITY / DCT2X2 (rare): redone by IdctRareSpecialKernel after the tile kernel
         if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;   // DCT128/256 family: BigIdctKernel (+ generic path if unaligned)
         else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;  // varblock not contained in a 64x64 tile: generic IDCT
         const uint32_t gi = (y / 32) * 8 + wi;
@@ -1224,8 +1225,36 @@ __device__ void FDctDyn(float* v, int n) {  // n in {1,2,4,8}
 }
 __device__ __forceinline__ int Log2Small(int n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : 3; }
 
-// one thread per 8x8 block: first blocks compute the LLF coefficients of their varblock from the (smoothed) LF; every
-// block computes its EPF inverse sigma
+// LLF coefficients of one varblock of CX x CY blocks: scaled forward DCT of its LF samples, columns first
+// (dec_group.cc / dct_scales.h)
+template <int CX, int CY> __device__ __forceinline__ void LlfBlock(const FrameDev& f, size_t o) {
+  constexpr float sr = 1.0f / (float)CY, sc = 1.0f / (float)CX;
+  constexpr int lx = CX == 1 ? 0 : CX == 2 ? 1 : CX == 4 ? 2 : 3, ly = CY == 1 ? 0 : CY == 2 ? 1 : CY == 4 ? 2 : 3;
+#pragma unroll 1
+  for (int c = 0; c < 3; c++) {
+    float buf[CY][CX];
+    const float* src = f.lf_tmp[c] + o;
+#pragma unroll
+    for (int xx = 0; xx < CX; xx++) {
+      float col[CY];
+#pragma unroll
+      for (int yy = 0; yy < CY; yy++) col[yy] = src[(size_t)yy * f.bw + xx];
+      FDct1D<CY>(col);
+#pragma unroll
+      for (int v = 0; v < CY; v++) buf[v][xx] = col[v] * sr;
+    }
+#pragma unroll
+    for (int v = 0; v < CY; v++) {
+      float row[CX];
+#pragma unroll
+      for (int u = 0; u < CX; u++) row[u] = buf[v][u];
+      FDct1D<CX>(row);
+#pragma unroll
+      for (int u = 0; u < CX; u++) f.llf[c][o + (size_t)v * f.bw + u] = ((row[u] * sc) * d_resample[ly][v]) * d_resample[lx][u];
+    }
+  }
+}
+// one thread per 8x8 block: EPF inverse sigma; blocks that are a whole varblock copy their LF sample as the LLF coefficient
 __global__ void LlfSigmaKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.z];
   if (f.is_modular) return;
@@ -1239,26 +1268,37 @@ __global__ void LlfSigmaKernel(const FrameDev* __restrict__ frames) {
     sigma = fminf(-1e-4f, sigma);
     f.inv_sigma[o] = 1.0f / sigma;
   }
-  if (!BI_First(info)) return;
   const uint32_t s = BI_Strategy(info);
-  const int cx = (int)CoveredX(s), cy = (int)CoveredY(s);
-  if (cx > 8 || cy > 8) return;                       // BigIdctKernel derives the LLF of DCT128/256 varblocks itself
-  if (cx == 1 && cy == 1) { for (int c = 0; c < 3; c++) f.llf[c][o] = f.lf_tmp[c][o]; return; }
-  const float sr = 1.0f / (float)cy, sc = 1.0f / (float)cx;
-  const int lx = Log2Small(cx), ly = Log2Small(cy);
-  for (int c = 0; c < 3; c++) {
-    float buf[64], col[8];
-    const float* src = f.lf_tmp[c] + o;
-    for (int xx = 0; xx < cx; xx++) {
-      for (int yy = 0; yy < cy; yy++) col[yy] = src[(size_t)yy * f.bw + xx];
-      FDctDyn(col, cy);
-      for (int v = 0; v < cy; v++) buf[v * cx + xx] = col[v] * sr;
-    }
-    for (int v = 0; v < cy; v++) {
-      float row[8];
-      for (int u = 0; u < cx; u++) row[u] = buf[v * cx + u];
-      FDctDyn(row, cx);
-      for (int u = 0; u < cx; u++) f.llf[c][o + (size_t)v * f.bw + u] = ((row[u] * sc) * d_resample[ly][v]) * d_resample[lx][u];
+  if (CoveredX(s) == 1 && CoveredY(s) == 1) { for (int c = 0; c < 3; c++) f.llf[c][o] = f.lf_tmp[c][o]; }
+}
+// LLF coefficients of the larger varblocks, one thread per entry of the per-group varblock lists (every lane has a varblock;
+// one thread per 8x8 block left 90 % of the lanes idle while the others ran the transforms of half a dozen shapes one after
+// the other).  One instantiation per shape: static loops, everything in registers.
+__global__ __launch_bounds__(256) void LlfKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular) return;
+  const uint32_t g = blockIdx.x;
+  if (g >= f.num_groups) return;
+  const uint32_t bx0 = (g % f.xgroups) * 32, by0 = (g / f.xgroups) * 32;
+  const uint32_t count = f.vb_count[g];
+  for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) {
+    const uint32_t ex = f.vb_list[(size_t)g * 1024 + e].x;
+    const uint32_t s = ex & 31, cx = CoveredX(s), cy = CoveredY(s);
+    if (cx > 8 || cy > 8 || (cx == 1 && cy == 1)) continue;   // BigIdctKernel derives the LLF of DCT128/256 varblocks itself
+    const size_t o = (size_t)(by0 + ((ex >> 21) & 31)) * f.bw + bx0 + ((ex >> 16) & 31);
+    switch (cy * 16 + cx) {
+      case 0x12: LlfBlock<2, 1>(f, o); break;
+      case 0x21: LlfBlock<1, 2>(f, o); break;
+      case 0x22: LlfBlock<2, 2>(f, o); break;
+      case 0x14: LlfBlock<4, 1>(f, o); break;
+      case 0x41: LlfBlock<1, 4>(f, o); break;
+      case 0x24: LlfBlock<4, 2>(f, o); break;
+      case 0x42: LlfBlock<2, 4>(f, o); break;
+      case 0x44: LlfBlock<4, 4>(f, o); break;
+      case 0x48: LlfBlock<8, 4>(f, o); break;
+      case 0x84: LlfBlock<4, 8>(f, o); break;
+      case 0x88: LlfBlock<8, 8>(f, o); break;
+      default: break;   // (no other shape among the 27 strategies)
     }
   }
 }
@@ -1779,6 +1819,51 @@ __device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t
   }
 }
 
+// DCT4X4 / DCT4X8 / DCT8X4 on an 8x8 block that sits in an LDS tile in stored order, one HALF per lane (two adjacent lanes of
+// a wavefront per block and channel): half h needs the stored rows h, h + 2, h + 4, h + 6 (plus the two or four DC-mix
+// inputs of rows 0 / 1) and produces rows 4h..4h+3 (DCT4X4, DCT4X8) or columns 4h..4h+3 (DCT8X4).  Outputs overwrite the
+// partner's inputs, so every lane reads first and all lanes write afterwards (lock-step inside the wavefront + a wave
+// fence).  Same arithmetic as SpecialTransform, 32 instead of 64 live coefficients per lane.
+template <int PITCH> __device__ __forceinline__ void SpecialHalfLoad(uint32_t s, const float* blk, uint32_t h, float (&in)[32], float (&dc)[4]) {
+#pragma unroll
+  for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+    for (int ix = 0; ix < 8; ix++) in[iy * 8 + ix] = blk[(h + iy * 2) * PITCH + ix];
+  dc[0] = blk[0]; dc[1] = blk[1]; dc[2] = blk[PITCH]; dc[3] = blk[PITCH + 1];   // stored (0,0), (0,1), (1,0), (1,1)
+}
+template <int PITCH> __device__ __forceinline__ void SpecialHalfStore(uint32_t s, float* blk, uint32_t h, const float (&in)[32], const float (&dc)[4]) {
+  if (s == 3) {  // DCT4X4: quadrants (y = h, x = 0, 1)
+    const float b00 = dc[0], b01 = dc[1], b10 = dc[2], b11 = dc[3];
+    float dcs[4];
+    dcs[0] = b00 + b01 + b10 + b11; dcs[1] = b00 + b01 - b10 - b11; dcs[2] = b00 - b01 + b10 - b11; dcs[3] = b00 - b01 - b10 + b11;
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      float sem[16];  // sem[v*4+u] = stored[u*4+v]
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? (h == 0 ? dcs[x] : dcs[2 + x]) : in[iy * 8 + x + ix * 2];
+      SmallIdct2D<4, 4>(sem, blk + (h * 4) * PITCH + x * 4, PITCH);
+    }
+  } else if (s == 12) {  // DCT4X8: half y = h
+    const float b0 = dc[0], b1 = dc[2];
+    float sem[32];
+#pragma unroll
+    for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+      for (int ix = 0; ix < 8; ix++) sem[iy * 8 + ix] = (iy == 0 && ix == 0) ? (h == 0 ? b0 + b1 : b0 - b1) : in[iy * 8 + ix];
+    SmallIdct2D<4, 8>(sem, blk + (h * 4) * PITCH, PITCH);
+  } else {  // s == 13, DCT8X4: half x = h
+    const float b0 = dc[0], b1 = dc[2];
+    float sem[32];  // sem[v*4+u] = stored[u*8+v]
+#pragma unroll
+    for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+      for (int ix = 0; ix < 8; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? (h == 0 ? b0 + b1 : b0 - b1) : in[iy * 8 + ix];
+    SmallIdct2D<8, 4>(sem, blk + h * 4, PITCH);
+  }
+}
+
 __device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || s == 12 || s == 13; }
 __device__ __forceinline__ bool IsBig(uint32_t s) { return s >= 21; }
 __device__ __forceinline__ uint32_t Log2Cov8(uint32_t n) { return n == 1 ? 0u : n == 2 ? 1u : n == 4 ? 2u : 3u; }   // covered blocks 1, 2, 4, 8   // DCT128x128 ... DCT128x256: larger than a 64x64 tile
@@ -1994,6 +2079,52 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
   }
 }
 
+// ---- IDENTITY and DCT2X2 blocks (rare; 64 live coefficients per lane) of frames that take the tile kernels: the tile
+// kernel leaves them alone and this kernel, launched after it for the frames the LF stage flagged, writes their pixels.
+// The group's blocks are compacted first so that every lane has a (block, channel) of its own.  Same arithmetic as
+// IdctKernel's special path (DequantCoef + SpecialTransform).
+__global__ __launch_bounds__(256) void IdctRareSpecialKernel(const FrameDev* __restrict__ frames, int force_generic) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular || force_generic) return;
+  const uint32_t flags = *f.frame_flags;
+  if ((flags & 1) != 0 || (flags & 16) == 0) return;    // generic frames do their own; no such block in this frame
+  const uint32_t g = blockIdx.x;
+  if (g >= f.num_groups) return;
+  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
+  const uint32_t bx0 = gx * 32, by0 = gy * 32;
+  const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
+  const size_t stride = f.plane_stride;
+  __shared__ uint16_t s_list[1024];
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < gbw * gbh; t += blockDim.x) {
+    const uint32_t st = BI_Strategy(LdG(f.blk_info + (size_t)(by0 + t / gbw) * f.bw + bx0 + t % gbw));
+    if (st == 1 || st == 2) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)t;
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  for (uint32_t task = threadIdx.x; task < n * 3; task += blockDim.x) {
+    const uint32_t c = task / n, t = s_list[task - c * n];
+    const uint32_t bx = t % gbw, by = t / gbw;
+    const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
+    const uint32_t info = LdG(f.blk_info + o), s = BI_Strategy(info), kind = QuantKind(s);
+    BlockDequant d;
+    const uint32_t coff = LdG(f.coef_off + o);
+    for (int k = 0; k < 3; k++) { d.q[k] = f.coeff[k] + (size_t)g * 65536 + coff; d.table[k] = f.qtable[kind * 3 + k]; }
+    const float sd = f.inv_global_scale / (float)BI_HfMul(info);
+    d.sdc[0] = sd * f.x_dm; d.sdc[1] = sd; d.sdc[2] = sd * f.b_dm;
+    const size_t tile = (size_t)((by0 + by) / 8) * f.cw + (bx0 + bx) / 8;
+    d.kx = f.base_x + (float)f.ytox[tile] * f.color_scale;
+    d.kb = f.base_b + (float)f.ytob[tile] * f.color_scale;
+    for (int i = 0; i < 4; i++) d.bias[i] = f.quant_bias[i];
+    float cf[64];
+    for (uint32_t k = 0; k < 64; k++) cf[k] = DequantCoef(d, (int)c, k);
+    cf[0] = LdG(f.llf[c] + o);
+    SpecialTransform(s, cf, f.plane_a[c] + (size_t)(by0 + by) * 8 * stride + (bx0 + bx) * 8, stride);
+  }
+}
+
 // ---- fast path: one 256-thread workgroup per 64x64-pixel tile (8x8 blocks), all three channels staged in LDS ----------
 // Requires every varblock to lie inside one tile (true for naturally aligned blocks, i.e. everything encoders emit);
 // frames violating that are flagged by the LF stage and use IdctKernel above.  Same arithmetic, same operation order.
@@ -2198,14 +2329,18 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     if constexpr (SPECIAL) {
       const uint32_t n4 = r_begin[5] - r_begin[4];
       if (n4 && wave == nwaves - 1) {
-        for (uint32_t t = lane; t < n4 * 3; t += 64) {
-          const uint32_t c = t / n4, tt = s_rtask[r_begin[4] + (t - c * n4)];
+        for (uint32_t t0 = 0; t0 < n4 * 6; t0 += 64) {     // (block, channel, half) per lane; both halves in adjacent lanes
+          const uint32_t t = t0 + lane;
+          const bool live = t < n4 * 6;
+          const uint32_t task = live ? t >> 1 : 0, h = t & 1;
+          const uint32_t c = task / n4, tt = s_rtask[r_begin[4] + (task - c * n4)];
           uint32_t s, iy; size_t o_first;
           float* blk0 = block_of(tt, c, s, iy, o_first);
-          float cf[64];
-#pragma unroll
-          for (int k = 0; k < 64; k++) cf[k] = blk0[(k >> 3) * kTilePitch + (k & 7)];
-          SpecialTransform(s, cf, blk0, kTilePitch);
+          const bool mine = live && s != 1 && s != 2;        // IDENTITY / DCT2X2 are left to IdctRareSpecialKernel
+          float in[32], dc[4];
+          if (mine) SpecialHalfLoad<kTilePitch>(s, blk0, h, in, dc);
+          WaveSync();                                        // every lane has read its inputs before any lane writes
+          if (mine) SpecialHalfStore<kTilePitch>(s, blk0, h, in, dc);
         }
       }
     }
@@ -3062,11 +3197,12 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
   }
 }
-void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, void* stream) {
+void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, int max_groups, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
   hipLaunchKernelGGL(LfDequantKernel, grid, block, 0, (hipStream_t)stream, frames);
   hipLaunchKernelGGL(LfSmoothKernel, grid, block, 0, (hipStream_t)stream, frames);
   hipLaunchKernelGGL(LlfSigmaKernel, grid, block, 0, (hipStream_t)stream, frames);
+  hipLaunchKernelGGL(LlfKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
 }
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
   if (cfg.lane_stride_hf == 1) {   // SIMT: one group stream per lane
@@ -3126,6 +3262,7 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
     if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
   }
+  if (all || cfg.need_rare_special) hipLaunchKernelGGL(IdctRareSpecialKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
   if (!cfg.idct_flags_known || cfg.any_big_blocks)
