@@ -294,7 +294,7 @@ constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;             // 256-sam
 constexpr uint32_t kWaveLds = 8448;                                   // >= kChunkOff + 1024 and >= the 8 KiB placement bitmap
 static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
 #ifndef JXL_LF_MINW
-#define JXL_LF_MINW 4      // LfDecodeKernel: VGPR budget 512 / JXL_LF_MINW per lane
+#define JXL_LF_MINW 3      // LfDecodeKernel<true>: VGPR budget 512 / JXL_LF_MINW per lane (170: three IDCT or six filter wavefronts fit beside it)
 #endif
 #ifndef JXL_IDCT_MINW
 #define JXL_IDCT_MINW 4    // IdctTileKernel<4>: likewise
@@ -1136,7 +1136,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
 // workgroups of two batches in flight (2 x 36 KB) and an HF workgroup (80 KB) fit one CU.  (The kernel needs 272 VGPRs,
 // one wavefront per SIMD: a CU never hosts more than two of these workgroups, whatever the dispatcher would like.)
 // Small launches (single images) take one group per wavefront instead: latency over LDS economy.
-// CAPPED: 128 VGPRs (with spills) so that pixel-kernel wavefronts of the batch on the main stream fit the same SIMDs — the
+// CAPPED: at most 170 VGPRs (with spills) so that pixel-kernel wavefronts of the batch on the main stream fit the same SIMDs — the
 // variant for large pipelined batches; single images take the uncapped one (267 VGPRs, LF stage 20 % shorter).
 template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? JXL_LF_MINW : 1) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
