@@ -7,6 +7,7 @@
 #include "modular.h"
 #include "vardct.h"
 #include "render.h"
+#include "image_features.h"
 #include <map>
 
 namespace jxlo {
@@ -82,6 +83,10 @@ struct Frame {
   Image3 xyb;     // float planes (XYB, or RGB / YCbCr for non-XYB VarDCT)
   size_t tokens_lf = 0, tokens_hf = 0, tokens_modular = 0;
   Dump* dump = nullptr;
+  // image features (LfGlobal)
+  PatchDictionary patches;
+  Splines splines;
+  NoiseParams noise;
 };
 
 inline float InvGlobalScale(const Frame& f) { return 65536.0f / (float)f.global_scale; }
@@ -164,9 +169,10 @@ inline void ReadGlobalModular(BitReader& br, Frame& f) {
 }
 
 inline void ReadLfGlobal(BitReader& br, Frame& f) {
-  if (f.fh.flags & kPatches) JXLO_FAIL("unsupported: patches");
-  if (f.fh.flags & kSplines) JXLO_FAIL("unsupported: splines");
-  if (f.fh.flags & kNoise) JXLO_FAIL("unsupported: noise");
+  // dec_frame.cc ProcessDCGlobal: image features first (patches, splines, noise), in this order
+  if (f.fh.flags & kPatches) ReadPatches(br, f.m->extra.size(), (size_t)f.w * f.h, f.patches);
+  if (f.fh.flags & kSplines) ReadSplines(br, (size_t)f.w * f.h, f.splines);
+  if (f.fh.flags & kNoise) ReadNoise(br, f.noise);
   // LfChannelDequantization
   if (!br.Bool()) for (int c = 0; c < 3; c++) f.m_lf[c] = F16(br) * (1.0f / 128.0f);
   if (!f.fh.modular) {

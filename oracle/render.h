@@ -175,10 +175,25 @@ struct OpsinParams {
   float neg_bias[3];       // -bias
   float neg_bias_cbrt[3];  // cbrt(-bias)
 };
+// dec_cache.cc / dec_xyb.cc OutputEncodingInfo::SetColorEncoding: for a grey-scale image the three rows of the inverse
+// opsin matrix are replaced by their luminance-weighted sum (kSRGBLuminances), so R = G = B = luminance by construction;
+// Mul3x3Matrix accumulates each element in double.
 inline OpsinParams MakeOpsin(const ImageMetadata& m, float intensity_target) {
   OpsinParams o;
   float s = 255.0f / intensity_target;
-  for (int i = 0; i < 9; i++) o.inv[i] = m.opsin_inv[i] * s;
+  float inv[9];
+  for (int i = 0; i < 9; i++) inv[i] = m.opsin_inv[i];
+  if (m.color.color_space == 1) {
+    const float lum[3] = {0.2126f, 0.7152f, 0.0722f};
+    float folded[9];
+    for (int x = 0; x < 3; x++) for (int y = 0; y < 3; y++) {
+      double e = 0;
+      for (int z = 0; z < 3; z++) e += lum[z] * inv[z * 3 + x];
+      folded[y * 3 + x] = (float)e;
+    }
+    for (int i = 0; i < 9; i++) inv[i] = folded[i];
+  }
+  for (int i = 0; i < 9; i++) o.inv[i] = inv[i] * s;
   for (int i = 0; i < 3; i++) { o.neg_bias[i] = m.opsin_bias[i]; o.neg_bias_cbrt[i] = std::cbrt(m.opsin_bias[i]); }
   return o;
 }

@@ -3,7 +3,7 @@
 // dct-inl.h,dct_scales.h,dec_transforms-inl.h,dec_group.cc(dequant),compressed_dc.cc}.
 // context model / orders / RAW tables are [V]; the float pipeline (tables, op order) is [R]
 // — PARITY UNPINNED against libjxl for pixels; this file is the self-consistent definition both the
-// synthesiser and the HIP kernels are checked against.
+// synthesiser and the HIP kernels are checked against.  Round 2: AFV transforms + AFV weights, FastPowf band interpolation.
 #pragma once
 #include "bits.h"
 #include <algorithm>
@@ -170,6 +170,36 @@ inline void LowestFrequenciesFromLF(int strategy, const float* lf, int lf_stride
       block[StoredIndex(R, C, v, u)] = c[(size_t)v * cx + u] * ResampleScale(cy, v) * ResampleScale(cx, u);
 }
 
+
+// dec_transforms-inl.h AFVIDCT4x4: the 16 basis functions of the 4x4 "corner" transform (ISO/IEC 18181-1 AFV basis).
+// Recalled digits, verified: the 16x16 matrix is orthonormal to 1.5e-14 (tests/test_oracle_goldens.py), row 0 is the
+// constant function, every row is symmetric or antisymmetric under transposition of the 4x4 block.
+static const float k4x4AFVBasis[16][16] = {
+    {0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f},
+    {0.876902929799142f, 0.2206518106944235f, -0.10140050393753763f, -0.1014005039375375f, 0.2206518106944236f, -0.10140050393753777f, -0.10140050393753772f, -0.10140050393753763f, -0.10140050393753758f, -0.10140050393753769f, -0.1014005039375375f, -0.10140050393753768f, -0.10140050393753768f, -0.10140050393753759f, -0.10140050393753763f, -0.10140050393753741f},
+    {0.0f, 0.0f, 0.40670075830260755f, 0.44444816619734445f, 0.0f, 0.0f, 0.19574399372042936f, 0.2929100136981264f, -0.40670075830260716f, -0.19574399372042872f, 0.0f, 0.11379074460448091f, -0.44444816619734384f, -0.29291001369812636f, -0.1137907446044814f, 0.0f},
+    {0.0f, 0.0f, -0.21255748058288748f, 0.3085497062849767f, 0.0f, 0.4706702258572536f, -0.1621205195722993f, 0.0f, -0.21255748058287047f, -0.16212051957228327f, -0.47067022585725277f, -0.1464291867126764f, 0.3085497062849487f, 0.0f, -0.14642918671266536f, 0.4251149611657548f},
+    {0.0f, -0.7071067811865474f, 0.0f, 0.0f, 0.7071067811865476f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
+    {-0.4105377591765233f, 0.6235485373547691f, -0.06435071657946274f, -0.06435071657946266f, 0.6235485373547694f, -0.06435071657946284f, -0.0643507165794628f, -0.06435071657946274f, -0.06435071657946272f, -0.06435071657946279f, -0.06435071657946266f, -0.06435071657946277f, -0.06435071657946277f, -0.06435071657946273f, -0.06435071657946274f, -0.0643507165794626f},
+    {0.0f, 0.0f, -0.4517556589999482f, 0.15854503551840063f, 0.0f, -0.04038515160822202f, 0.0074182263792423875f, 0.39351034269210167f, -0.45175565899994635f, 0.007418226379244351f, 0.1107416575309343f, 0.08298163094882051f, 0.15854503551839705f, 0.3935103426921022f, 0.0829816309488214f, -0.45175565899994796f},
+    {0.0f, 0.0f, -0.304684750724869f, 0.5112616136591823f, 0.0f, 0.0f, -0.290480129728998f, -0.06578701549142804f, 0.304684750724884f, 0.2904801297290076f, 0.0f, -0.23889773523344604f, -0.5112616136592012f, 0.06578701549142545f, 0.23889773523345467f, 0.0f},
+    {0.0f, 0.0f, 0.3017929516615495f, 0.25792362796341184f, 0.0f, 0.16272340142866204f, 0.09520022653475037f, 0.0f, 0.3017929516615503f, 0.09520022653475055f, -0.16272340142866173f, -0.35312385449816297f, 0.25792362796341295f, 0.0f, -0.3531238544981624f, -0.6035859033230976f},
+    {0.0f, 0.0f, 0.40824829046386274f, 0.0f, 0.0f, 0.0f, 0.0f, -0.4082482904638628f, -0.4082482904638635f, 0.0f, 0.0f, -0.40824829046386296f, 0.0f, 0.4082482904638634f, 0.408248290463863f, 0.0f},
+    {0.0f, 0.0f, 0.1747866975480809f, 0.0812611176717539f, 0.0f, 0.0f, -0.3675398009862027f, -0.307882213957909f, -0.17478669754808135f, 0.3675398009862011f, 0.0f, 0.4826689115059883f, -0.08126111767175039f, 0.30788221395790305f, -0.48266891150598584f, 0.0f},
+    {0.0f, 0.0f, -0.21105601049335784f, 0.18567180916109802f, 0.0f, 0.0f, 0.49215859013738733f, -0.38525013709251915f, 0.21105601049335806f, -0.49215859013738905f, 0.0f, 0.17419412659916217f, -0.18567180916109904f, 0.3852501370925211f, -0.1741941265991621f, 0.0f},
+    {0.0f, 0.0f, -0.14266084808807264f, -0.3416446842253372f, 0.0f, 0.7367497537172237f, 0.24627107722075148f, -0.08574019035519306f, -0.14266084808807344f, 0.24627107722075137f, 0.14883399227113567f, -0.04768680350229251f, -0.3416446842253373f, -0.08574019035519267f, -0.047686803502292804f, -0.14266084808807242f},
+    {0.0f, 0.0f, -0.13813540350758585f, 0.3302282550303788f, 0.0f, 0.08755115000587084f, -0.07946706605909573f, -0.4613374887461511f, -0.13813540350758294f, -0.07946706605910261f, 0.49724647109535086f, 0.12538059448563663f, 0.3302282550303805f, -0.4613374887461554f, 0.12538059448564315f, -0.13813540350758452f},
+    {0.0f, 0.0f, -0.17437602599651067f, 0.0702790691196284f, 0.0f, -0.2921026642334881f, 0.3623817333531167f, 0.0f, -0.1743760259965108f, 0.36238173335311646f, 0.29210266423348785f, -0.4326608024727445f, 0.07027906911962818f, 0.0f, -0.4326608024727457f, 0.34875205199302267f},
+    {0.0f, 0.0f, 0.11354987314994337f, -0.07417504595810355f, 0.0f, 0.19402893032594343f, -0.435190496523228f, 0.21918684838857466f, 0.11354987314994257f, -0.4351904965232251f, 0.5550443808910661f, -0.25468277124066463f, -0.07417504595810233f, 0.2191868483885728f, -0.25468277124066413f, 0.1135498731499429f},
+};
+inline void AFVIDCT4x4(const float* coeffs, float* pixels) {
+  for (int i = 0; i < 16; i++) {
+    float px = 0.0f;
+    for (int j = 0; j < 16; j++) px = std::fmaf(coeffs[j], k4x4AFVBasis[j][i], px);
+    pixels[i] = px;
+  }
+}
+
 // dec_transforms-inl.h TransformToPixels. coeffs: stored layout, size covered*64; out: pixel block.
 inline void InverseTransform(int strategy, const float* coeffs, float* out, int stride) {
   const int cx = kCoveredX[strategy], cy = kCoveredY[strategy];
@@ -261,8 +291,30 @@ inline void InverseTransform(int strategy, const float* coeffs, float* out, int 
       }
       return;
     }
-    case AFV0: case AFV1: case AFV2: case AFV3:
-      JXLO_FAIL("unsupported: AFV transform (k4x4AFVBasis not reproducible here)");
+    case AFV0: case AFV1: case AFV2: case AFV3: {  // dec_transforms-inl.h AFVTransformToPixels<afv_kind>
+      const int afv_kind = strategy - AFV0, afv_x = afv_kind & 1, afv_y = afv_kind / 2;
+      const float block00 = coeffs[0], block01 = coeffs[1], block10 = coeffs[8];
+      const float dcs[3] = {(block00 + block10 + block01) * 4.0f, (block00 + block10 - block01), block00 - block10};
+      float coeff[16], block[32];
+      coeff[0] = dcs[0];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (ix == 0 && iy == 0) continue; coeff[iy * 4 + ix] = coeffs[iy * 2 * 8 + ix * 2]; }
+      AFVIDCT4x4(coeff, block);
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++)
+        out[(iy + afv_y * 4) * stride + afv_x * 4 + ix] = block[(afv_y == 1 ? 3 - iy : iy) * 4 + (afv_x == 1 ? 3 - ix : ix)];
+      // 4x4 DCT of the (even row, odd column) coefficients next to the corner
+      block[0] = dcs[1];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (ix == 0 && iy == 0) continue; block[iy * 4 + ix] = coeffs[iy * 2 * 8 + ix * 2 + 1]; }
+      {
+        float sem[16];
+        for (int v = 0; v < 4; v++) for (int u = 0; u < 4; u++) sem[v * 4 + u] = block[StoredIndex(4, 4, v, u)];
+        IDCT2D(sem, 4, 4, out + afv_y * 4 * stride + (afv_x == 1 ? 0 : 4), stride);
+      }
+      // 4x8 DCT of the odd rows in the other half
+      block[0] = dcs[2];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) { if (ix == 0 && iy == 0) continue; block[iy * 8 + ix] = coeffs[(1 + iy * 2) * 8 + ix]; }
+      IDCT2D(block, 4, 8, out + (afv_y == 1 ? 0 : 4) * stride, stride);
+      return;
+    }
     default: {
       std::vector<float> sem((size_t)R * C);
       for (int v = 0; v < R; v++) for (int u = 0; u < C; u++) sem[(size_t)v * C + u] = coeffs[StoredIndex(R, C, v, u)];
@@ -358,9 +410,16 @@ inline QuantEncoding LibraryQuant(int kind) {
                         {527.107573587542228f, -1.4594385811273854f, -1.450082094097871593f, -1.5843722511996204f});
       for (int c = 0; c < 3; c++) q.dct4x8multipliers[c] = 1.0f;
       break;
-    case QAFV:
-      q.mode = 5;  // numeric AFV weights are not reproduced; AFV blocks are rejected at transform time
+    case QAFV: {
+      q.mode = 5;
+      float w[3][9] = {{3072.0f, 3072.0f, 256.0f, 256.0f, 256.0f, 414.0f, 0.0f, 0.0f, 0.0f},
+                       {1024.0f, 1024.0f, 50.0f, 50.0f, 50.0f, 58.0f, 0.0f, 0.0f, 0.0f},
+                       {384.0f, 384.0f, 12.0f, 12.0f, 12.0f, 22.0f, -0.25f, -0.25f, -0.25f}};
+      memcpy(q.afv_weights, w, sizeof(w));
+      q.dct = LibraryQuant(QDCT4X8).dct;       // the 4x8 part uses the DCT4X8 bands
+      q.dct4x4 = LibraryQuant(QDCT4X4).dct;    // the 4x4 part uses the DCT4X4 bands
       break;
+    }
     default: {
       // 64x64 family: base bands scaled per size [R]
       static const float k64[3] = {26629.073922049845f, 9311.3238710010046f, 4992.2486445538634f};
@@ -385,6 +444,46 @@ inline QuantEncoding LibraryQuant(int kind) {
 
 inline float BandMult(float v) { return v > 0 ? 1.0f + v : 1.0f / (1.0f - v); }
 
+// base/fast_math-inl.h FastLog2f / FastPow2f / FastPowf: the rational approximations quant_weights.cc interpolates the
+// band weights with (NOT std::pow: the tables differ from an exact power by up to 3e-5 relative).  Constants recalled and
+// checked: |FastLog2f - log2| < 2.8e-6 on [0.01, 100], FastPow2f within 2.1e-7 relative on [-20, 20].
+inline float FastLog2f(float x) {
+  const float p[3] = {-1.8503833400518310E-06f, 1.4287160470083755E+00f, 7.4245873327820566E-01f};
+  const float q[3] = {9.9032814277590719E-01f, 1.0096718572241148E+00f, 1.7409343003366853E-01f};
+  int32_t x_bits; memcpy(&x_bits, &x, 4);
+  const int32_t exp_bits = x_bits - 0x3f2aaaab;   // = 2/3
+  const int32_t exp_shifted = exp_bits >> 23;
+  const int32_t m_bits = x_bits - (int32_t)((uint32_t)exp_shifted << 23);
+  float mantissa; memcpy(&mantissa, &m_bits, 4);
+  const float exp_val = (float)exp_shifted;
+  const float t = mantissa - 1.0f;
+  float yp = std::fmaf(p[2], t, p[1]); yp = std::fmaf(yp, t, p[0]);
+  float yq = std::fmaf(q[2], t, q[1]); yq = std::fmaf(yq, t, q[0]);
+  return yp / yq + exp_val;
+}
+inline float FastPow2f(float x) {
+  const float floorx = std::floor(x);
+  const int32_t e_bits = (int32_t)((uint32_t)((int32_t)floorx + 127) << 23);
+  float exp; memcpy(&exp, &e_bits, 4);
+  const float frac = x - floorx;
+  float num = frac + 1.01749063e+01f;
+  num = std::fmaf(num, frac, 4.88687798e+01f);
+  num = std::fmaf(num, frac, 9.85506591e+01f);
+  num = num * exp;
+  float den = std::fmaf(frac, 2.10242958e-01f, -2.22328856e-02f);
+  den = std::fmaf(den, frac, -1.94414990e+01f);
+  den = std::fmaf(den, frac, 9.85506633e+01f);
+  return num / den;
+}
+inline float FastPowf(float base, float exponent) { return FastPow2f(FastLog2f(base) * exponent); }
+// quant_weights.cc Interpolate
+inline float InterpolateBands(float pos, float max, const float* array, int len) {
+  const float scaled_pos = pos * (len - 1) / max;
+  const int idx = (int)scaled_pos;
+  const float a = array[idx], b = array[idx + 1];
+  return a * FastPowf(b / a, scaled_pos - idx);
+}
+
 // quant_weights.cc GetQuantWeights: weights (NOT inverted) for a ROWS x COLS table from band parameters
 inline void BandWeights(const DctBandParams& p, int c, int ROWS, int COLS, float* out) {
   float bands[17];
@@ -405,7 +504,7 @@ inline void BandWeights(const DctBandParams& p, int c, int ROWS, int COLS, float
         if (idx + 1 >= p.num_bands) idx = p.num_bands - 2;
         float frac = dist - idx;
         float a = bands[idx], b = bands[idx + 1];
-        w = a * std::pow(b / a, frac);
+        w = a * FastPowf(b / a, frac);
       }
       out[y * COLS + x] = w;
     }
@@ -464,10 +563,31 @@ inline void ComputeQuantTable(const QuantEncoding& q0, int kind, int c, std::vec
       w[8] /= q->dct4x8multipliers[c];
       break;
     }
-    case 5:
-      // AFV tables unsupported: fill with 1 so that non-AFV frames that merely declare the default set still decode
-      for (size_t i = 0; i < n; i++) w[i] = 1.0f;
+    case 5: {  // quant_weights.cc kQuantModeAFV
+      JXLO_CHECK(n == 64);
+      static const float kFreqs[16] = {0xBAD, 0xBAD, 0.8517778890324296f, 5.37778436506804f, 0xBAD, 0xBAD, 4.734747904497923f, 5.449245381693219f,
+                                       1.6598270267479331f, 4.0f, 7.275749096817861f, 10.423227632456525f, 2.662932286148962f, 7.630657783650829f,
+                                       8.962388608184032f, 12.97166202570235f};
+      float w48[32], w44[16];
+      BandWeights(q->dct, c, 4, 8, w48);
+      BandWeights(q->dct4x4, c, 4, 4, w44);
+      const float lo = 0.8517778890324296f, hi = 12.97166202570235f - lo + 1e-6f;
+      float bands[4];
+      bands[0] = q->afv_weights[c][5];
+      if (bands[0] < 1e-8f) JXLO_FAIL("bad AFV band");
+      for (int i = 1; i < 4; i++) { bands[i] = bands[i - 1] * BandMult(q->afv_weights[c][i + 5]); if (bands[i] < 1e-8f) JXLO_FAIL("bad AFV band"); }
+      auto set = [&](int x, int y, float v) { w[y * 8 + x] = v; };
+      w[0] = 1.0f;   // unused (LLF comes from the LF image)
+      set(0, 1, q->afv_weights[c][0]); set(1, 0, q->afv_weights[c][1]);
+      set(0, 2, q->afv_weights[c][2]); set(2, 0, q->afv_weights[c][3]); set(2, 2, q->afv_weights[c][4]);
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+        if (x < 2 && y < 2) continue;
+        set(2 * x, 2 * y, InterpolateBands(kFreqs[y * 4 + x] - lo, hi, bands, 4));
+      }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 8; x++) { if (x == 0 && y == 0) continue; w[(2 * y + 1) * 8 + x] = w48[y * 8 + x]; }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { if (x == 0 && y == 0) continue; w[(2 * y) * 8 + 2 * x + 1] = w44[y * 4 + x]; }
       break;
+    }
     default: JXLO_FAIL("bad quant mode");
   }
   out.resize(n);
