@@ -124,6 +124,9 @@ int JxlHipBatchShareBuffers(JxlHipBatch* batch, JxlHipBatch* owner);
 /* Host-only: parses the signature/container and image header of `data` and writes the ICC profile JxlDecoderGetColorAsICCProfile
  * would return (pass icc_out == NULL to query *icc_size).  Needs no GPU.  Returns 0 on success. */
 int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc_out, size_t* icc_size);
+/* Host-only (needs no GPU): the dequantisation table (1 / weight, libjxl's coefficient layout) the decoder uses for library-default
+ * quantisation kind `kind` (0..16, quant_weights.h), channel c (0 X, 1 Y, 2 B).  Writes min(n, cap) floats, returns n (0 on error). */
+size_t JxlHipLibraryQuantTable(int kind, int c, float* out, size_t cap);
 /* Creates a batch bound to HIP device `device`. */
 JxlHipBatch* JxlHipBatchCreate(int device);
 void JxlHipBatchDestroy(JxlHipBatch* batch);

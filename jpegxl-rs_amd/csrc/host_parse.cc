@@ -629,8 +629,6 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     for (auto e : ec_ups) if (e != p->upsampling) Unsupported("extra-channel upsampling different from the colour upsampling");
     if (p->upsampling != 1) {
       if (p->modular) Unsupported("upsampling of a Modular frame");
-      const int k = p->upsampling == 2 ? 0 : p->upsampling == 4 ? 1 : 2;
-      if (k > 0 && ih.up_weights[k].empty()) Unsupported("default 4x / 8x upsampling weights (tables not reproducible offline)");
       fx = (fx + p->upsampling - 1) / p->upsampling; fy = (fy + p->upsampling - 1) / p->upsampling;   // coded size
     }
     for (int i = 0; i < 3; i++) if (jpeg_ups[i]) Unsupported("chroma subsampling");
@@ -942,7 +940,16 @@ static QuantTableSpec LibrarySpec(int kind) {
                 {1807.236946760964614f, -1.2f, -1.2f, -0.7f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
     case 9: set(4, {2198.050556016380522f, -0.96269623020744692f, -0.76194253026666783f, -0.6551140670773547f}, {764.3655248643528689f, -0.92630200888366945f, -0.9675229603596517f, -0.27845290869168118f},
                 {527.107573587542228f, -1.4594385811273854f, -1.450082094097871593f, -1.5843722511996204f}); q.mode = 4; for (int c = 0; c < 3; c++) q.dct4x8mul[c] = 1.0f; break;
-    case 10: q.mode = 5; break;
+    case 10: {  // AFV: corner weights + the DCT4X8 and DCT4X4 band parameters
+      const QuantTableSpec q48 = LibrarySpec(9), q44 = LibrarySpec(3);
+      q.mode = 5;
+      const float w[3][9] = {{3072.0f, 3072.0f, 256.0f, 256.0f, 256.0f, 414.0f, 0.0f, 0.0f, 0.0f}, {1024.0f, 1024.0f, 50.0f, 50.0f, 50.0f, 58.0f, 0.0f, 0.0f, 0.0f},
+                             {384.0f, 384.0f, 12.0f, 12.0f, 12.0f, 22.0f, -0.25f, -0.25f, -0.25f}};
+      memcpy(q.afvw, w, sizeof(w));
+      q.num_bands = q48.num_bands; memcpy(q.bands, q48.bands, sizeof(q.bands));
+      q.num_bands4 = q44.num_bands; memcpy(q.bands4, q44.bands, sizeof(q.bands4));
+      break;
+    }
     default: {
       static const float k64[3] = {26629.073922049845f, 9311.3238710010046f, 4992.2486445538634f}, k32[3] = {23629.073922049845f, 8611.3238710010046f, 4492.2486445538634f};
       float mul; const float* base;
@@ -955,6 +962,35 @@ static QuantTableSpec LibrarySpec(int kind) {
   }
   return q;
 }
+
+// base/fast_math-inl.h FastLog2f / FastPow2f / FastPowf: the rational approximations libjxl interpolates quantisation bands with
+// (quant_weights.cc InterpolateVec) — not std::pow, the tables differ by up to 3e-5 relative.
+static float FastLog2f(float x) {
+  int32_t x_bits; memcpy(&x_bits, &x, 4);
+  const int32_t exp_bits = x_bits - 0x3f2aaaab;
+  const int32_t exp_shifted = exp_bits >> 23;
+  const int32_t m_bits = x_bits - (int32_t)((uint32_t)exp_shifted << 23);
+  float mantissa; memcpy(&mantissa, &m_bits, 4);
+  const float t = mantissa - 1.0f;
+  float yp = std::fmaf(7.4245873327820566E-01f, t, 1.4287160470083755E+00f); yp = std::fmaf(yp, t, -1.8503833400518310E-06f);
+  float yq = std::fmaf(1.7409343003366853E-01f, t, 1.0096718572241148E+00f); yq = std::fmaf(yq, t, 9.9032814277590719E-01f);
+  return yp / yq + (float)exp_shifted;
+}
+static float FastPow2f(float x) {
+  const float floorx = std::floor(x);
+  const int32_t e_bits = (int32_t)((uint32_t)((int32_t)floorx + 127) << 23);
+  float exp; memcpy(&exp, &e_bits, 4);
+  const float frac = x - floorx;
+  float num = frac + 1.01749063e+01f;
+  num = std::fmaf(num, frac, 4.88687798e+01f);
+  num = std::fmaf(num, frac, 9.85506591e+01f);
+  num = num * exp;
+  float den = std::fmaf(frac, 2.10242958e-01f, -2.22328856e-02f);
+  den = std::fmaf(den, frac, -1.94414990e+01f);
+  den = std::fmaf(den, frac, 9.85506633e+01f);
+  return num / den;
+}
+float FastPowf(float base, float exponent) { return FastPow2f(FastLog2f(base) * exponent); }
 
 static void BandWeights(uint32_t nb, const float (*bands_in)[17], int c, int ROWS, int COLS, float* out) {
   float bands[17];
@@ -978,7 +1014,7 @@ static void BandWeights(uint32_t nb, const float (*bands_in)[17], int c, int ROW
         int idx = (int)dist;
         if (idx + 1 >= (int)nb) idx = (int)nb - 2;
         float frac = dist - idx;
-        w = bands[idx] * std::pow(bands[idx + 1] / bands[idx], frac);
+        w = bands[idx] * FastPowf(bands[idx + 1] / bands[idx], frac);
       }
       out[y * COLS + x] = w;
     }
@@ -1014,7 +1050,31 @@ void ComputeQuantTable(const QuantTableSpec& spec0, int kind, int c, std::vector
       w[8] /= q->dct4x8mul[c];
       break;
     }
-    case 5: break;  // AFV weights not reproduced; AFV blocks are rejected by the LF stage
+    case 5: {  // quant_weights.cc kQuantModeAFV
+      static const float kFreqs[16] = {0, 0, 0.8517778890324296f, 5.37778436506804f, 0, 0, 4.734747904497923f, 5.449245381693219f,
+                                       1.6598270267479331f, 4.0f, 7.275749096817861f, 10.423227632456525f, 2.662932286148962f, 7.630657783650829f,
+                                       8.962388608184032f, 12.97166202570235f};
+      float w48[32], w44[16];
+      BandWeights(q->num_bands, q->bands, c, 4, 8, w48);
+      BandWeights(q->num_bands4, q->bands4, c, 4, 4, w44);
+      const float lo = 0.8517778890324296f, hi = 12.97166202570235f - lo + 1e-6f;
+      float bands[4];
+      bands[0] = q->afvw[c][5];
+      if (!(bands[0] >= 1e-8f)) Fail("AFV quant band");
+      for (int i = 1; i < 4; i++) { const float v = q->afvw[c][i + 5]; bands[i] = bands[i - 1] * (v > 0 ? 1.0f + v : 1.0f / (1.0f - v)); if (!(bands[i] >= 1e-8f)) Fail("AFV quant band"); }
+      w[0] = 1.0f;
+      w[1 * 8 + 0] = q->afvw[c][0]; w[0 * 8 + 1] = q->afvw[c][1];
+      w[2 * 8 + 0] = q->afvw[c][2]; w[0 * 8 + 2] = q->afvw[c][3]; w[2 * 8 + 2] = q->afvw[c][4];
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+        if (x < 2 && y < 2) continue;
+        const float scaled_pos = (kFreqs[y * 4 + x] - lo) * 3 / hi;
+        const int idx = (int)scaled_pos;
+        w[(2 * y) * 8 + 2 * x] = bands[idx] * FastPowf(bands[idx + 1] / bands[idx], scaled_pos - idx);
+      }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 8; x++) { if (x == 0 && y == 0) continue; w[(2 * y + 1) * 8 + x] = w48[y * 8 + x]; }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { if (x == 0 && y == 0) continue; w[(2 * y) * 8 + 2 * x + 1] = w44[y * 4 + x]; }
+      break;
+    }
     case 7:
       if (q->raw[c].size() != n) Fail("RAW quant table size");
       out->resize(n);

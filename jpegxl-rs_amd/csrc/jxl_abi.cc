@@ -314,6 +314,16 @@ int JxlHipBatchShareBuffers(JxlHipBatch* h, JxlHipBatch* owner) {
   try { h->b->ShareBigArena(owner ? owner->b : nullptr); return 0; } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
 }
 
+size_t JxlHipLibraryQuantTable(int kind, int c, float* out, size_t cap) {
+  try {
+    if (kind < 0 || kind >= 17 || c < 0 || c >= 3) return 0;
+    std::vector<float> t;
+    ComputeQuantTable(QuantTableSpec(), kind, c, &t);
+    for (size_t i = 0; i < t.size() && i < cap; i++) out[i] = t[i];
+    return t.size();
+  } catch (const std::exception& e) { SetLastError(e.what()); return 0; }
+}
+
 int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc_out, size_t* icc_size) {
   try {
     Codestream cs; bool container = false, jbrd = false;

@@ -14,6 +14,25 @@ namespace jxlhip {
 
 __constant__ float d_wc[9][128];       // WcMultipliers<N>[i] = 1 / (2 cos((i + 0.5) pi / N)), row = log2 N
 __constant__ float d_resample[6][32];  // DCTTotalResampleScale<N, 8N>(k), row = log2 N
+// dec_transforms-inl.h k4x4AFVBasis: the 16 orthonormal basis functions of the AFV 4x4 corner transform
+__constant__ float d_afv_basis[16][16] = {
+    {0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f},
+    {0.876902929799142f, 0.2206518106944235f, -0.10140050393753763f, -0.1014005039375375f, 0.2206518106944236f, -0.10140050393753777f, -0.10140050393753772f, -0.10140050393753763f, -0.10140050393753758f, -0.10140050393753769f, -0.1014005039375375f, -0.10140050393753768f, -0.10140050393753768f, -0.10140050393753759f, -0.10140050393753763f, -0.10140050393753741f},
+    {0.0f, 0.0f, 0.40670075830260755f, 0.44444816619734445f, 0.0f, 0.0f, 0.19574399372042936f, 0.2929100136981264f, -0.40670075830260716f, -0.19574399372042872f, 0.0f, 0.11379074460448091f, -0.44444816619734384f, -0.29291001369812636f, -0.1137907446044814f, 0.0f},
+    {0.0f, 0.0f, -0.21255748058288748f, 0.3085497062849767f, 0.0f, 0.4706702258572536f, -0.1621205195722993f, 0.0f, -0.21255748058287047f, -0.16212051957228327f, -0.47067022585725277f, -0.1464291867126764f, 0.3085497062849487f, 0.0f, -0.14642918671266536f, 0.4251149611657548f},
+    {0.0f, -0.7071067811865474f, 0.0f, 0.0f, 0.7071067811865476f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
+    {-0.4105377591765233f, 0.6235485373547691f, -0.06435071657946274f, -0.06435071657946266f, 0.6235485373547694f, -0.06435071657946284f, -0.0643507165794628f, -0.06435071657946274f, -0.06435071657946272f, -0.06435071657946279f, -0.06435071657946266f, -0.06435071657946277f, -0.06435071657946277f, -0.06435071657946273f, -0.06435071657946274f, -0.0643507165794626f},
+    {0.0f, 0.0f, -0.4517556589999482f, 0.15854503551840063f, 0.0f, -0.04038515160822202f, 0.0074182263792423875f, 0.39351034269210167f, -0.45175565899994635f, 0.007418226379244351f, 0.1107416575309343f, 0.08298163094882051f, 0.15854503551839705f, 0.3935103426921022f, 0.0829816309488214f, -0.45175565899994796f},
+    {0.0f, 0.0f, -0.304684750724869f, 0.5112616136591823f, 0.0f, 0.0f, -0.290480129728998f, -0.06578701549142804f, 0.304684750724884f, 0.2904801297290076f, 0.0f, -0.23889773523344604f, -0.5112616136592012f, 0.06578701549142545f, 0.23889773523345467f, 0.0f},
+    {0.0f, 0.0f, 0.3017929516615495f, 0.25792362796341184f, 0.0f, 0.16272340142866204f, 0.09520022653475037f, 0.0f, 0.3017929516615503f, 0.09520022653475055f, -0.16272340142866173f, -0.35312385449816297f, 0.25792362796341295f, 0.0f, -0.3531238544981624f, -0.6035859033230976f},
+    {0.0f, 0.0f, 0.40824829046386274f, 0.0f, 0.0f, 0.0f, 0.0f, -0.4082482904638628f, -0.4082482904638635f, 0.0f, 0.0f, -0.40824829046386296f, 0.0f, 0.4082482904638634f, 0.408248290463863f, 0.0f},
+    {0.0f, 0.0f, 0.1747866975480809f, 0.0812611176717539f, 0.0f, 0.0f, -0.3675398009862027f, -0.307882213957909f, -0.17478669754808135f, 0.3675398009862011f, 0.0f, 0.4826689115059883f, -0.08126111767175039f, 0.30788221395790305f, -0.48266891150598584f, 0.0f},
+    {0.0f, 0.0f, -0.21105601049335784f, 0.18567180916109802f, 0.0f, 0.0f, 0.49215859013738733f, -0.38525013709251915f, 0.21105601049335806f, -0.49215859013738905f, 0.0f, 0.17419412659916217f, -0.18567180916109904f, 0.3852501370925211f, -0.1741941265991621f, 0.0f},
+    {0.0f, 0.0f, -0.14266084808807264f, -0.3416446842253372f, 0.0f, 0.7367497537172237f, 0.24627107722075148f, -0.08574019035519306f, -0.14266084808807344f, 0.24627107722075137f, 0.14883399227113567f, -0.04768680350229251f, -0.3416446842253373f, -0.08574019035519267f, -0.047686803502292804f, -0.14266084808807242f},
+    {0.0f, 0.0f, -0.13813540350758585f, 0.3302282550303788f, 0.0f, 0.08755115000587084f, -0.07946706605909573f, -0.4613374887461511f, -0.13813540350758294f, -0.07946706605910261f, 0.49724647109535086f, 0.12538059448563663f, 0.3302282550303805f, -0.4613374887461554f, 0.12538059448564315f, -0.13813540350758452f},
+    {0.0f, 0.0f, -0.17437602599651067f, 0.0702790691196284f, 0.0f, -0.2921026642334881f, 0.3623817333531167f, 0.0f, -0.1743760259965108f, 0.36238173335311646f, 0.29210266423348785f, -0.4326608024727445f, 0.07027906911962818f, 0.0f, -0.4326608024727457f, 0.34875205199302267f},
+    {0.0f, 0.0f, 0.11354987314994337f, -0.07417504595810355f, 0.0f, 0.19402893032594343f, -0.435190496523228f, 0.21918684838857466f, 0.11354987314994257f, -0.4351904965232251f, 0.5550443808910661f, -0.25468277124066463f, -0.07417504595810233f, 0.2191868483885728f, -0.25468277124066413f, 0.1135498731499429f},
+};
 
 __device__ __forceinline__ void SetError(const FrameDev& f, uint32_t e) { atomicOr(f.status, e); }
 
@@ -1047,7 +1066,6 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
         const uint32_t s = (uint32_t)sq.x, q = (uint32_t)sq.y;
         if (num0 + count >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
         if (s >= 27 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }       // (negative values wrap to large ones)
-        if (s >= 14 && s <= 17) { SetError(f, kErrUnsupported); bad = true; break; }   // AFV
         const uint32_t geo = LdS<uint32_t>(geo_off + s * 4), cx = geo & 0xFF, cy = (geo >> 8) & 0xFF;
         if (x + cx > gbw || y + cy > gbh || xb + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
         const uint32_t bits = (cx == 32 ? ~0u : (1u << cx) - 1u) << xb;
@@ -1060,8 +1078,8 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
         }
         if (clash) { SetError(f, kErrVarblock); bad = true; break; }
         if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;      // not inside one 32x32 tile: the IDCT uses 64x64 tiles
-        if (s == 1 || s == 2 || s == 3 || s == 12 || s == 13) flags_acc |= 8u;   // IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4: the tile kernel variant that carries them
-        if (s == 1 || s == 2) flags_acc |= 16u;                                   // IDENTITY / DCT2X2 (rare): redone by IdctRareSpecialKernel after the tile kernel
+        if (s == 1 || s == 2 || s == 3 || (s >= 12 && s <= 17)) flags_acc |= 8u;  // IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4 / AFV0-3: the tile kernel variant that carries them
+        if (s == 1 || s == 2 || (s >= 14 && s <= 17)) flags_acc |= 16u;           // IDENTITY / DCT2X2 / AFV (64 live coefficients per lane): redone by IdctRareSpecialKernel after the tile kernel
         if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;   // DCT128/256 family: BigIdctKernel (+ generic path if unaligned)
         else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;  // varblock not contained in a 64x64 tile: generic IDCT
         const uint32_t gi = (y / 32) * 8 + wi;
@@ -1762,7 +1780,7 @@ template <int R, int C> __device__ __forceinline__ void SmallIdct2D(const float*
   }
 }
 
-// dec_transforms-inl.h: IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4 on one 8x8 block (coefficients in `cf`, stored layout)
+// dec_transforms-inl.h: IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3 on one 8x8 block (coefficients in `cf`, stored layout)
 __device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t stride) {
   if (s == 1) {  // IDENTITY
     float dcs[4];
@@ -1808,13 +1826,37 @@ __device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t
       for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) sem[iy * 8 + ix] = (iy == 0 && ix == 0) ? dcs[y] : cf[(y + iy * 2) * 8 + ix];
       SmallIdct2D<4, 8>(sem, out + (size_t)(y * 4) * stride, stride);
     }
-  } else {  // s == 13, DCT8X4: two 8x4 halves side by side
+  } else if (s == 13) {  // DCT8X4: two 8x4 halves side by side
     const float b0 = cf[0], b1 = cf[8];
     const float dcs[2] = {b0 + b1, b0 - b1};
     for (int x = 0; x < 2; x++) {
       float sem[32];  // sem[v*4+u] = stored[u*8+v]
       for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? dcs[x] : cf[(x + iy * 2) * 8 + ix];
       SmallIdct2D<8, 4>(sem, out + x * 4, stride);
+    }
+  } else {  // s == 14..17, AFV0-3 (AFVTransformToPixels): 4x4 corner in the AFV basis, a 4x4 DCT beside it, a 4x8 DCT in the other half
+    const uint32_t afv_x = (s - 14) & 1, afv_y = (s - 14) >> 1;
+    const float b00 = cf[0], b01 = cf[1], b10 = cf[8];
+    const float dcs[3] = {(b00 + b10 + b01) * 4.0f, (b00 + b10 - b01), b00 - b10};
+    {
+      float coeff[16];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) coeff[iy * 4 + ix] = (iy == 0 && ix == 0) ? dcs[0] : cf[iy * 2 * 8 + ix * 2];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) {
+        const int i = (afv_y == 1 ? 3 - iy : iy) * 4 + (afv_x == 1 ? 3 - ix : ix);
+        float px = 0.0f;
+        for (int j = 0; j < 16; j++) px = fmaf(coeff[j], d_afv_basis[j][i], px);
+        out[(size_t)(iy + afv_y * 4) * stride + afv_x * 4 + ix] = px;
+      }
+    }
+    {
+      float sem[16];  // sem[v*4+u] = stored[u*4+v]
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? dcs[1] : cf[iy * 2 * 8 + ix * 2 + 1];
+      SmallIdct2D<4, 4>(sem, out + (size_t)(afv_y * 4) * stride + (afv_x == 1 ? 0 : 4), stride);
+    }
+    {
+      float sem[32];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) sem[iy * 8 + ix] = (iy == 0 && ix == 0) ? dcs[2] : cf[(1 + iy * 2) * 8 + ix];
+      SmallIdct2D<4, 8>(sem, out + (size_t)(afv_y == 1 ? 0 : 4) * stride, stride);
     }
   }
 }
@@ -1864,7 +1906,8 @@ template <int PITCH> __device__ __forceinline__ void SpecialHalfStore(uint32_t s
   }
 }
 
-__device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || s == 12 || s == 13; }
+__device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || (s >= 12 && s <= 17); }
+__device__ __forceinline__ bool IsRareSpecial(uint32_t s) { return s == 1 || s == 2 || (s >= 14 && s <= 17); }   // IDENTITY, DCT2X2, AFV0-3
 __device__ __forceinline__ bool IsBig(uint32_t s) { return s >= 21; }
 __device__ __forceinline__ uint32_t Log2Cov8(uint32_t n) { return n == 1 ? 0u : n == 2 ? 1u : n == 4 ? 2u : 3u; }   // covered blocks 1, 2, 4, 8   // DCT128x128 ... DCT128x256: larger than a 64x64 tile
 
@@ -2079,7 +2122,7 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
   }
 }
 
-// ---- IDENTITY and DCT2X2 blocks (rare; 64 live coefficients per lane) of frames that take the tile kernels: the tile
+// ---- IDENTITY, DCT2X2 and AFV blocks (64 live coefficients per lane) of frames that take the tile kernels: the tile
 // kernel leaves them alone and this kernel, launched after it for the frames the LF stage flagged, writes their pixels.
 // The group's blocks are compacted first so that every lane has a (block, channel) of its own.  Same arithmetic as
 // IdctKernel's special path (DequantCoef + SpecialTransform).
@@ -2100,7 +2143,7 @@ __global__ __launch_bounds__(256) void IdctRareSpecialKernel(const FrameDev* __r
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < gbw * gbh; t += blockDim.x) {
     const uint32_t st = BI_Strategy(LdG(f.blk_info + (size_t)(by0 + t / gbw) * f.bw + bx0 + t % gbw));
-    if (st == 1 || st == 2) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)t;
+    if (IsRareSpecial(st)) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)t;
   }
   __syncthreads();
   const uint32_t n = s_n;
@@ -2336,7 +2379,7 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
           const uint32_t c = task / n4, tt = s_rtask[r_begin[4] + (task - c * n4)];
           uint32_t s, iy; size_t o_first;
           float* blk0 = block_of(tt, c, s, iy, o_first);
-          const bool mine = live && s != 1 && s != 2;        // IDENTITY / DCT2X2 are left to IdctRareSpecialKernel
+          const bool mine = live && !IsRareSpecial(s);       // IDENTITY / DCT2X2 / AFV are left to IdctRareSpecialKernel
           float in[32], dc[4];
           if (mine) SpecialHalfLoad<kTilePitch>(s, blk0, h, in, dc);
           WaveSync();                                        // every lane has read its inputs before any lane writes

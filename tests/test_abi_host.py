@@ -208,3 +208,27 @@ def test_sharding_plan():
     assert shard_sizes(3, 8) == [1, 1, 1, 0, 0, 0, 0, 0]
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_library_quant_tables_equal_the_oracle(jx):
+    """Host-side table parity (no GPU): every library-default dequantisation table (17 kinds x 3 channels, incl. the AFV table
+    and the FastPowf band interpolation of quant_weights.cc) the product computes is bit-identical to the oracle's."""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib as O
+    L = jx.libjxl()
+    L.JxlHipLibraryQuantTable.restype = C.c_size_t
+    L.JxlHipLibraryQuantTable.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    OL = O.lib()
+    OL.jxlo_library_qtable.restype = C.c_size_t
+    OL.jxlo_library_qtable.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    rows = [1, 1, 1, 1, 2, 4, 1, 1, 2, 1, 1, 8, 4, 16, 8, 32, 16]
+    cols = [1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32]
+    for kind in range(17):
+        n = rows[kind] * cols[kind] * 64
+        for c in range(3):
+            a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+            assert L.JxlHipLibraryQuantTable(kind, c, a.ctypes.data, n) == n
+            assert OL.jxlo_library_qtable(kind, c, b.ctypes.data, n) == n
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (kind, c)
+            assert np.all(a > 0) and np.all(np.isfinite(a))

@@ -386,10 +386,11 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   std::vector<uint8_t> first((size_t)bw * bh, 0);
   struct Cand { int s; float prob; };
   std::vector<Cand> cands;
-  if (p.strategy_mix == 1) cands = {{S_DCT32X32, 0.05f}, {S_DCT16X16, 0.10f}, {S_DCT16X8, 0.075f}, {S_DCT8X16, 0.075f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.04f}};
+  if (p.strategy_mix == 1) cands = {{S_DCT32X32, 0.05f}, {S_DCT16X16, 0.10f}, {S_DCT16X8, 0.075f}, {S_DCT8X16, 0.075f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.04f},
+                                     {S_AFV0, 0.006f}, {S_AFV1, 0.006f}, {S_AFV2, 0.006f}, {S_AFV3, 0.006f}};
   else if (p.strategy_mix >= 2 && p.strategy_mix < 100) cands = {{S_DCT64X64, 0.02f}, {S_DCT64X32, 0.01f}, {S_DCT32X64, 0.01f}, {S_DCT32X32, 0.04f}, {S_DCT32X16, 0.02f}, {S_DCT16X32, 0.02f}, {S_DCT32X8, 0.02f},
                                          {S_DCT8X32, 0.02f}, {S_DCT16X16, 0.08f}, {S_DCT16X8, 0.06f}, {S_DCT8X16, 0.06f}, {S_DCT4X8, 0.03f}, {S_DCT8X4, 0.03f}, {S_DCT4X4, 0.03f},
-                                         {S_DCT2X2, 0.02f}, {S_IDENTITY, 0.02f}};
+                                         {S_DCT2X2, 0.02f}, {S_IDENTITY, 0.02f}, {S_AFV0, 0.01f}, {S_AFV1, 0.01f}, {S_AFV2, 0.01f}, {S_AFV3, 0.01f}};
   if (p.strategy_mix == 4 || p.strategy_mix == 5) {  // + the DCT128/256 family (5: also at unaligned positions)
     const std::vector<Cand> big = {{24, 0.15f}, {25, 0.1f}, {26, 0.1f}, {21, 0.1f}, {22, 0.05f}, {23, 0.05f}};
     cands.insert(cands.begin(), big.begin(), big.end());
@@ -708,6 +709,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
         case 2: for (int c = 0; c < 3; c++) for (int i = 0; i < 6; i++) WriteF16(s, q.dct2w[c][i] / 64.0f); break;
         case 3: for (int c = 0; c < 3; c++) for (int i = 0; i < 2; i++) WriteF16(s, q.dct4mul[c][i]); write_bands(q.dct); break;
         case 4: for (int c = 0; c < 3; c++) WriteF16(s, q.dct4x8mul[c]); write_bands(q.dct); break;
+        case 5: for (int c = 0; c < 3; c++) for (int i = 0; i < 9; i++) WriteF16(s, i < 6 ? q.afvw[c][i] / 64.0f : q.afvw[c][i]); write_bands(q.dct); write_bands(q.dct4x4); break;
         case 6: write_bands(q.dct); break;
       }
     }

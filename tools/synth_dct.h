@@ -73,6 +73,26 @@ inline size_t StoredIdx(int R, int C, int v, int u) { return R >= C ? (size_t)u 
 inline float Resample(int N, int k) { return k == 0 ? 1.0f : (float)(std::sin(k * M_PI / (2.0 * N)) / std::sin(k * M_PI / (16.0 * N)) / 8.0); }
 
 // Forward transform of one varblock: pixels (stride) -> stored-layout coefficients (size covered*64)
+// AFV basis (dec_transforms-inl.h k4x4AFVBasis), orthonormal: the forward transform is its transpose
+static const float kAFVBasis[16][16] = {
+    {0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f, 0.25f},
+    {0.876902929799142f, 0.2206518106944235f, -0.10140050393753763f, -0.1014005039375375f, 0.2206518106944236f, -0.10140050393753777f, -0.10140050393753772f, -0.10140050393753763f, -0.10140050393753758f, -0.10140050393753769f, -0.1014005039375375f, -0.10140050393753768f, -0.10140050393753768f, -0.10140050393753759f, -0.10140050393753763f, -0.10140050393753741f},
+    {0.0f, 0.0f, 0.40670075830260755f, 0.44444816619734445f, 0.0f, 0.0f, 0.19574399372042936f, 0.2929100136981264f, -0.40670075830260716f, -0.19574399372042872f, 0.0f, 0.11379074460448091f, -0.44444816619734384f, -0.29291001369812636f, -0.1137907446044814f, 0.0f},
+    {0.0f, 0.0f, -0.21255748058288748f, 0.3085497062849767f, 0.0f, 0.4706702258572536f, -0.1621205195722993f, 0.0f, -0.21255748058287047f, -0.16212051957228327f, -0.47067022585725277f, -0.1464291867126764f, 0.3085497062849487f, 0.0f, -0.14642918671266536f, 0.4251149611657548f},
+    {0.0f, -0.7071067811865474f, 0.0f, 0.0f, 0.7071067811865476f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f},
+    {-0.4105377591765233f, 0.6235485373547691f, -0.06435071657946274f, -0.06435071657946266f, 0.6235485373547694f, -0.06435071657946284f, -0.0643507165794628f, -0.06435071657946274f, -0.06435071657946272f, -0.06435071657946279f, -0.06435071657946266f, -0.06435071657946277f, -0.06435071657946277f, -0.06435071657946273f, -0.06435071657946274f, -0.0643507165794626f},
+    {0.0f, 0.0f, -0.4517556589999482f, 0.15854503551840063f, 0.0f, -0.04038515160822202f, 0.0074182263792423875f, 0.39351034269210167f, -0.45175565899994635f, 0.007418226379244351f, 0.1107416575309343f, 0.08298163094882051f, 0.15854503551839705f, 0.3935103426921022f, 0.0829816309488214f, -0.45175565899994796f},
+    {0.0f, 0.0f, -0.304684750724869f, 0.5112616136591823f, 0.0f, 0.0f, -0.290480129728998f, -0.06578701549142804f, 0.304684750724884f, 0.2904801297290076f, 0.0f, -0.23889773523344604f, -0.5112616136592012f, 0.06578701549142545f, 0.23889773523345467f, 0.0f},
+    {0.0f, 0.0f, 0.3017929516615495f, 0.25792362796341184f, 0.0f, 0.16272340142866204f, 0.09520022653475037f, 0.0f, 0.3017929516615503f, 0.09520022653475055f, -0.16272340142866173f, -0.35312385449816297f, 0.25792362796341295f, 0.0f, -0.3531238544981624f, -0.6035859033230976f},
+    {0.0f, 0.0f, 0.40824829046386274f, 0.0f, 0.0f, 0.0f, 0.0f, -0.4082482904638628f, -0.4082482904638635f, 0.0f, 0.0f, -0.40824829046386296f, 0.0f, 0.4082482904638634f, 0.408248290463863f, 0.0f},
+    {0.0f, 0.0f, 0.1747866975480809f, 0.0812611176717539f, 0.0f, 0.0f, -0.3675398009862027f, -0.307882213957909f, -0.17478669754808135f, 0.3675398009862011f, 0.0f, 0.4826689115059883f, -0.08126111767175039f, 0.30788221395790305f, -0.48266891150598584f, 0.0f},
+    {0.0f, 0.0f, -0.21105601049335784f, 0.18567180916109802f, 0.0f, 0.0f, 0.49215859013738733f, -0.38525013709251915f, 0.21105601049335806f, -0.49215859013738905f, 0.0f, 0.17419412659916217f, -0.18567180916109904f, 0.3852501370925211f, -0.1741941265991621f, 0.0f},
+    {0.0f, 0.0f, -0.14266084808807264f, -0.3416446842253372f, 0.0f, 0.7367497537172237f, 0.24627107722075148f, -0.08574019035519306f, -0.14266084808807344f, 0.24627107722075137f, 0.14883399227113567f, -0.04768680350229251f, -0.3416446842253373f, -0.08574019035519267f, -0.047686803502292804f, -0.14266084808807242f},
+    {0.0f, 0.0f, -0.13813540350758585f, 0.3302282550303788f, 0.0f, 0.08755115000587084f, -0.07946706605909573f, -0.4613374887461511f, -0.13813540350758294f, -0.07946706605910261f, 0.49724647109535086f, 0.12538059448563663f, 0.3302282550303805f, -0.4613374887461554f, 0.12538059448564315f, -0.13813540350758452f},
+    {0.0f, 0.0f, -0.17437602599651067f, 0.0702790691196284f, 0.0f, -0.2921026642334881f, 0.3623817333531167f, 0.0f, -0.1743760259965108f, 0.36238173335311646f, 0.29210266423348785f, -0.4326608024727445f, 0.07027906911962818f, 0.0f, -0.4326608024727457f, 0.34875205199302267f},
+    {0.0f, 0.0f, 0.11354987314994337f, -0.07417504595810355f, 0.0f, 0.19402893032594343f, -0.435190496523228f, 0.21918684838857466f, 0.11354987314994257f, -0.4351904965232251f, 0.5550443808910661f, -0.25468277124066463f, -0.07417504595810233f, 0.2191868483885728f, -0.25468277124066413f, 0.1135498731499429f},
+};
+
 inline void ForwardTransform(int s, const float* px, int stride, float* coef) {
   const int cx = kCovX[s], cy = kCovY[s], R = 8 * cy, C = 8 * cx;
   switch (s) {
@@ -150,6 +170,27 @@ inline void ForwardTransform(int s, const float* px, int stride, float* coef) {
       coef[0] = (dcs[0] + dcs[1]) / 2; coef[8] = (dcs[0] - dcs[1]) / 2;
       return;
     }
+    case S_AFV0: case S_AFV1: case S_AFV2: case S_AFV3: {
+      // forward of dec_transforms-inl.h AFVTransformToPixels: 4x4 corner in the (orthonormal) AFV basis, 4x4 DCT beside it,
+      // 4x8 DCT of the other half; the three means are mixed into coefficients (0,0), (0,1), (1,0)
+      const int afv_x = (s - S_AFV0) & 1, afv_y = (s - S_AFV0) >> 1;
+      float pix[16], cf[16];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++)
+        pix[(afv_y == 1 ? 3 - iy : iy) * 4 + (afv_x == 1 ? 3 - ix : ix)] = px[(iy + afv_y * 4) * stride + afv_x * 4 + ix];
+      for (int j = 0; j < 16; j++) { float a = 0; for (int i = 0; i < 16; i++) a += kAFVBasis[j][i] * pix[i]; cf[j] = a; }
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) if (iy || ix) coef[iy * 2 * 8 + ix * 2] = cf[iy * 4 + ix];
+      const float a = cf[0] / 4.0f;
+      float sem[32];
+      FDCT2D(px + afv_y * 4 * stride + (afv_x == 1 ? 0 : 4), stride, 4, 4, sem);
+      const float m1 = sem[0];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) if (iy || ix) coef[iy * 2 * 8 + ix * 2 + 1] = sem[ix * 4 + iy];
+      FDCT2D(px + (afv_y == 1 ? 0 : 4) * stride, stride, 4, 8, sem);
+      const float m2 = sem[0];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) if (iy || ix) coef[(1 + iy * 2) * 8 + ix] = sem[iy * 8 + ix];
+      const float sum = (a + m1) / 2;             // = b00 + b10
+      coef[0] = (sum + m2) / 2; coef[8] = (sum - m2) / 2; coef[1] = (a - m1) / 2;
+      return;
+    }
     default: {
       std::vector<float> sem((size_t)R * C);
       FDCT2D(px, stride, R, C, sem.data());
@@ -205,6 +246,8 @@ struct QuantSpec {
   float dct2w[3][6];
   float dct4mul[3][2];
   float dct4x8mul[3];
+  float afvw[3][9];
+  Bands dct4x4;
 };
 
 inline float BandMul(float v) { return v > 0 ? 1.0f + v : 1.0f / (1.0f - v); }
@@ -265,6 +308,16 @@ inline QuantSpec DefaultSpec(int kind) {
       q.mode = 4; B(4, {2198.05f, -0.9627f, -0.7619f, -0.6551f}, {764.366f, -0.9263f, -0.9675f, -0.2785f}, {527.108f, -1.4594f, -1.4501f, -1.5844f});
       for (int c = 0; c < 3; c++) q.dct4x8mul[c] = 1.0f;
       break;
+    case 10: {  // AFV: corner weights, DCT4X8 bands, DCT4X4 bands
+      q.mode = 5;
+      const float w[3][9] = {{3072.0f, 3072.0f, 256.0f, 256.0f, 256.0f, 414.0f, 0.0f, 0.0f, 0.0f}, {1024.0f, 1024.0f, 50.0f, 50.0f, 50.0f, 58.0f, 0.0f, 0.0f, 0.0f},
+                             {384.0f, 384.0f, 12.0f, 12.0f, 12.0f, 22.0f, -0.25f, -0.25f, -0.25f}};
+      for (int c = 0; c < 3; c++) for (int i = 0; i < 9; i++) q.afvw[c][i] = i < 6 ? RoundToHalf(w[c][i] / 64.0f) * 64.0f : RoundToHalf(w[c][i]);
+      B(4, {2200.0f, 0.0f, 0.0f, 0.0f}, {392.0f, 0.0f, 0.0f, 0.0f}, {112.0f, -0.25f, -0.25f, -0.5f});
+      q.dct4x4 = q.dct;
+      B(4, {2198.05f, -0.9627f, -0.7619f, -0.6551f}, {764.366f, -0.9263f, -0.9675f, -0.2785f}, {527.108f, -1.4594f, -1.4501f, -1.5844f});
+      break;
+    }
     case 11: q.mode = 6; B(8, {0.9f * 26629.07f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {0.9f * 9311.32f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {0.9f * 4992.25f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
     case 12: q.mode = 6; B(8, {0.65f * 23629.07f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {0.65f * 8611.32f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {0.65f * 4492.25f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
     case 13: q.mode = 6; B(8, {1.8f * 23966.17f, -1.025f, -0.78f, -0.6501f, -0.1904f, -0.2082f, -0.4211f, -0.3273f}, {1.8f * 8380.19f, -0.3042f, -0.3633f, -0.3566f, -0.3443f, -0.337f, -0.3018f, -0.2732f}, {1.8f * 4493.02f, -1.2f, -1.2f, -0.8f, -0.7f, -0.7f, -0.4f, -0.5f}); break;
@@ -300,6 +353,26 @@ inline void ComputeTable(const QuantSpec& q, int kind, int c, std::vector<float>
       float w48[32]; BandWeights(q.dct, c, 4, 8, w48);
       for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[y * 8 + x] = w48[(y / 2) * 8 + x];
       w[8] /= q.dct4x8mul[c];
+      break;
+    }
+    case 5: {
+      static const float kFreqs[16] = {0, 0, 0.8517778890324296f, 5.37778436506804f, 0, 0, 4.734747904497923f, 5.449245381693219f, 1.6598270267479331f, 4.0f,
+                                       7.275749096817861f, 10.423227632456525f, 2.662932286148962f, 7.630657783650829f, 8.962388608184032f, 12.97166202570235f};
+      float w48[32], w44[16], bands[4];
+      BandWeights(q.dct, c, 4, 8, w48);
+      BandWeights(q.dct4x4, c, 4, 4, w44);
+      const float lo = 0.8517778890324296f, hi = 12.97166202570235f - lo + 1e-6f;
+      bands[0] = q.afvw[c][5];
+      for (int i = 1; i < 4; i++) bands[i] = bands[i - 1] * BandMul(q.afvw[c][i + 5]);
+      w[0] = 1.0f; w[8] = q.afvw[c][0]; w[1] = q.afvw[c][1]; w[16] = q.afvw[c][2]; w[2] = q.afvw[c][3]; w[18] = q.afvw[c][4];
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+        if (x < 2 && y < 2) continue;
+        const float sp = (kFreqs[y * 4 + x] - lo) * 3 / hi;
+        const int idx = (int)sp;
+        w[2 * y * 8 + 2 * x] = bands[idx] * std::pow(bands[idx + 1] / bands[idx], sp - idx);
+      }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 8; x++) if (x || y) w[(2 * y + 1) * 8 + x] = w48[y * 8 + x];
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) if (x || y) w[2 * y * 8 + 2 * x + 1] = w44[y * 4 + x];
       break;
     }
     default: throw std::runtime_error("quant kind without explicit spec used");
