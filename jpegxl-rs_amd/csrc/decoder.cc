@@ -17,6 +17,40 @@ namespace jxlhip {
 namespace {
 size_t Align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// library-default kernels (image_metadata.cc kWeights2 / 4 / 8): each sub-pixel kernel sums to 1
+static const float kUp2[15] = {-0.01716200f, -0.03452303f, -0.04022174f, -0.02921014f, -0.00624645f, 0.14111091f, 0.28896755f, 0.00278718f,
+                               -0.01610267f, 0.56661550f,  0.03777607f,  -0.01986694f, -0.03144731f, -0.01185068f, -0.00213539f};
+static const float kUp4[55] = {
+    -0.02419067f, -0.03491987f, -0.03693351f, -0.03094285f, -0.00529785f, -0.01663432f, -0.03556863f, -0.03888905f, -0.03516850f, -0.00989469f, 0.23651958f,
+    0.33392945f,  -0.01073543f, -0.01313181f, -0.03556694f, 0.13048175f,  0.40103025f,  0.03951150f,  -0.02077584f, 0.46914198f,  -0.00209270f, -0.01484589f,
+    -0.04064806f, 0.18942530f,  0.56279892f,  0.06674400f,  -0.02335494f, -0.03551682f, -0.00754830f, -0.02267919f, -0.02363578f, 0.00315804f,  -0.03399098f,
+    -0.01359519f, -0.00091653f, -0.00335467f, -0.01163294f, -0.01610294f, -0.00974088f, -0.00191622f, -0.01095446f, -0.03198464f, -0.04455121f, -0.02799790f,
+    -0.00645912f, 0.06390599f,  0.22963888f,  0.00630981f,  -0.01897349f, 0.67537268f,  0.08483369f,  -0.02534994f, -0.02205197f, -0.01667999f, -0.00384443f};
+static const float kUp8[210] = {
+    -0.02928613f, -0.03706353f, -0.03783812f, -0.03324558f, -0.00447632f, -0.02519406f, -0.03752601f, -0.03901508f, -0.03663285f, -0.00646649f,
+    -0.02066407f, -0.03838633f, -0.04002101f, -0.03900035f, -0.00901973f, -0.01626393f, -0.03954148f, -0.04046620f, -0.03979621f, -0.01224485f,
+    0.29895328f, 0.35757708f, -0.02447552f, -0.01081748f, -0.04314594f, 0.23903219f, 0.41119301f, -0.00573046f, -0.01450239f, -0.04246845f,
+    0.17567618f, 0.45220643f, 0.02287757f, -0.01936783f, -0.03583255f, 0.11572472f, 0.47416733f, 0.06284440f, -0.02685066f, 0.42720050f,
+    -0.02248939f, -0.01155273f, -0.04562755f, 0.28689496f, 0.49093869f, -0.00007891f, -0.01545926f, -0.04562659f, 0.21238920f, 0.53980934f,
+    0.03369474f, -0.02070211f, -0.03866988f, 0.14229550f, 0.56593398f, 0.08045181f, -0.02888298f, -0.03680918f, -0.00542229f, -0.02920477f,
+    -0.02788574f, -0.02118180f, -0.03942402f, -0.00775547f, -0.02433614f, -0.03193943f, -0.02030828f, -0.04044014f, -0.01074016f, -0.01930822f,
+    -0.03620399f, -0.01974125f, -0.03919545f, -0.01456093f, -0.00045072f, -0.00360110f, -0.01020207f, -0.01231907f, -0.00638988f, -0.00071592f,
+    -0.00279122f, -0.00957115f, -0.01288327f, -0.00730937f, -0.00107783f, -0.00210156f, -0.00890705f, -0.01317668f, -0.00813895f, -0.00153491f,
+    -0.02128481f, -0.04173044f, -0.04831487f, -0.03293190f, -0.00525260f, -0.01720322f, -0.04052736f, -0.05045706f, -0.03607317f, -0.00738030f,
+    -0.01341764f, -0.03965629f, -0.05151616f, -0.03814886f, -0.01005819f, 0.18968273f, 0.33063684f, -0.01300105f, -0.01372950f, -0.04017465f,
+    0.13727832f, 0.36402234f, 0.01027890f, -0.01832107f, -0.03365072f, 0.08734506f, 0.38194295f, 0.04338228f, -0.02525993f, 0.56408126f,
+    0.00458352f, -0.01648227f, -0.04887868f, 0.24585519f, 0.62026135f, 0.04314807f, -0.02213737f, -0.04158014f, 0.16637289f, 0.65027023f,
+    0.09621636f, -0.03101388f, -0.04082742f, -0.00904519f, -0.02790922f, -0.02117818f, 0.00798662f, -0.03995711f, -0.01243427f, -0.02231705f,
+    -0.02946266f, 0.00992055f, -0.03600283f, -0.01684920f, -0.00111684f, -0.00411204f, -0.01297130f, -0.01723725f, -0.01022545f, -0.00165306f,
+    -0.00313110f, -0.01218016f, -0.01763266f, -0.01125620f, -0.00231663f, -0.01374149f, -0.03797620f, -0.05142937f, -0.03117307f, -0.00581914f,
+    -0.01064003f, -0.03608089f, -0.05272168f, -0.03375670f, -0.00795586f, 0.09628104f, 0.27129991f, -0.00353779f, -0.01734151f, -0.03153981f,
+    0.05686230f, 0.28500998f, 0.02230594f, -0.02374955f, 0.68214326f, 0.05018048f, -0.02320852f, -0.04383616f, 0.18459474f, 0.71517975f,
+    0.10805613f, -0.03263677f, -0.03637639f, -0.01394373f, -0.02511203f, -0.01728636f, 0.05407331f, -0.02867568f, -0.01893131f, -0.00240854f,
+    -0.00446511f, -0.01636187f, -0.02377053f, -0.01522848f, -0.00333334f, -0.00819975f, -0.02964169f, -0.04499287f, -0.02745350f, -0.00612408f,
+    0.02727416f, 0.19446600f, 0.00159832f, -0.02232473f, 0.74982506f, 0.11452620f, -0.03348048f, -0.01605681f, -0.02070339f, -0.00458223f,
+};
+
+
 struct ConstOffsets {
   size_t cs = 0, sec_off = 0, sec_size = 0, tree = 0, bcm = 0;
   size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0, mod_chan = 0, up_weights = 0;
@@ -50,9 +84,41 @@ DevCode ViewCode(const HostCode& c, const uint8_t* base, size_t ctx, size_t cfg,
   d.ctx_map = base + ctx; d.cfg = (const uint32_t*)(base + cfg); d.alias = (const uint64_t*)(base + alias);
   d.pfx_count = (const uint16_t*)(base + pc); d.pfx_sym_off = (const uint32_t*)(base + po); d.pfx_syms = (const uint16_t*)(base + ps);
   d.num_ctx = c.num_ctx; d.num_clusters = c.num_clusters; d.log_alpha = c.log_alpha; d.use_prefix = c.use_prefix;
+  d.lz77 = c.lz77; d.lz_min_symbol = c.lz_min_symbol; d.lz_min_length = c.lz_min_length; d.lz_len_cfg = c.lz_len_cfg;
   return d;
 }
 }  // namespace
+
+// Colour-transform parameters of an image (stage_xyb.cc OpsinParams, dec_xyb.cc OutputEncodingInfo::SetColorEncoding):
+// inverse opsin matrix scaled to the intensity target — for grey-scale images its rows are replaced by their luminance-weighted
+// sum (kSRGBLuminances; Mul3x3Matrix accumulates in double), so R = G = B — and the output transfer function.
+static void FillColor(const ImageHeader& ih, bool do_ycbcr, FrameDev& f) {
+  float inv[9];
+  for (int k = 0; k < 9; k++) inv[k] = ih.opsin_inv[k];
+  if (ih.color_space == 1) {
+    const float lum[3] = {0.2126f, 0.7152f, 0.0722f};
+    float folded[9];
+    for (int x = 0; x < 3; x++) for (int y = 0; y < 3; y++) {
+      double e = 0;
+      for (int z = 0; z < 3; z++) e += lum[z] * inv[z * 3 + x];
+      folded[y * 3 + x] = (float)e;
+    }
+    for (int k = 0; k < 9; k++) inv[k] = folded[k];
+  }
+  const float s = 255.0f / ih.intensity_target;
+  for (int k = 0; k < 9; k++) f.opsin_inv[k] = inv[k] * s;
+  for (int k = 0; k < 3; k++) { f.neg_bias[k] = ih.opsin_bias[k]; f.neg_bias_cbrt[k] = std::cbrt(ih.opsin_bias[k]); }
+  f.inverse_gamma = 1.0f;
+  if (ih.xyb_encoded) {
+    f.color_mode = 0;
+    if (!ih.color_default) {
+      if (ih.have_gamma) { f.color_mode = 4; f.inverse_gamma = (float)ih.gamma * 1e-7f; }
+      else if (ih.tf == 8) f.color_mode = 1;
+      else if (ih.tf == 17) { f.color_mode = 4; f.inverse_gamma = 1.0f / 2.6f; }
+      else if (ih.tf == 1) f.color_mode = 5;
+    }
+  } else f.color_mode = do_ycbcr ? 2 : 3;
+}
 
 Batch::Batch(int device) : device_(device) {
   HIP_CHECK(hipSetDevice(device_));
@@ -78,27 +144,60 @@ void Batch::ShareBigArena(Batch* owner) {
 }
 
 int Batch::AddImage(const uint8_t* data, size_t size) {
-  std::unique_ptr<ImageEntry> e(new ImageEntry());
-  bool have_container = false;
-  if (!ExtractCodestream(data, size, &e->cs, &have_container, &e->has_jbrd)) throw ParseError("truncated", false);
-  ParseImageHeader(e->cs, &e->ih, &e->frame_bitpos);
-  e->ih.have_container = have_container;
-  ParseFrameStart(e->cs, e->ih, e->frame_bitpos, &e->plan);
-  const FramePlan& p = e->plan;
-  if (!p.modular) {
-    for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
-    for (auto& x : e->ih.extra) if (x.dim_shift != 0 || x.depth.is_float) throw ParseError("unsupported: subsampled / float extra channel", true);
+  std::shared_ptr<ImageShared> sh(new ImageShared());
+  bool have_container = false, has_jbrd = false;
+  if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd)) throw ParseError("truncated", false);
+  uint64_t bitpos = 0;
+  ParseImageHeader(sh->cs, &sh->ih, &bitpos);
+  sh->ih.have_container = have_container;
+  const ImageHeader& ih = sh->ih;
+  if (ih.xyb_encoded) {
+    // stage_from_linear.cc: sRGB, linear, pure gamma (incl. DCI) and Rec.709 are computed; PQ / HLG are not
+    const bool ok = ih.color_default || ih.have_gamma || ih.tf == 13 || ih.tf == 8 || ih.tf == 17 || ih.tf == 1;
+    if (!ok) throw ParseError("unsupported: output transfer function (PQ / HLG)", true);
   }
-  if (p.modular && e->ih.xyb_encoded) throw ParseError("unsupported: XYB Modular frame", true);
-  if (p.modular && e->ih.depth.is_float) throw ParseError("unsupported: float Modular samples", true);
-  if (!p.modular && e->ih.xyb_encoded) {
-    const bool srgb = e->ih.color_default || (!e->ih.have_gamma && e->ih.tf == 13);
-    const bool linear = !e->ih.color_default && !e->ih.have_gamma && e->ih.tf == 8;
-    if (!srgb && !linear) throw ParseError("unsupported: output transfer function", true);
+  // every frame of the image (frame_header.cc): reference-only / zero-duration layers first, the last one is displayed
+  std::vector<std::unique_ptr<ImageEntry>> units;
+  uint32_t visible = 0, nonvisible = 0;
+  for (int k = 0;; k++) {
+    if (k >= 256) throw ParseError("unsupported: more than 256 frames", true);
+    std::unique_ptr<ImageEntry> e(new ImageEntry(sh));
+    e->has_jbrd = has_jbrd;
+    e->frame_bitpos = bitpos;
+    e->frame_index = k;
+    e->pub_index = (int)pub_.size();
+    ParseFrameStart(sh->cs, ih, bitpos, &e->plan);
+    const FramePlan& p = e->plan;
+    if (p.frame_type == 0 || p.frame_type == 3) { visible++; nonvisible = 0; } else nonvisible++;
+    e->visible_frame_index = visible; e->nonvisible_frame_index = nonvisible;
+    if (!p.modular) {
+      for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
+      if (p.has_global_tree && (p.tree_code.use_prefix || p.tree_code.lz77)) throw ParseError("unsupported: prefix-coded / LZ77 LF streams of a VarDCT frame", true);
+    }
+    for (auto& x : ih.extra) if (x.dim_shift != 0 || x.depth.is_float) throw ParseError("unsupported: subsampled / float extra channel", true);
+    if (p.modular && ih.depth.is_float) throw ParseError("unsupported: float Modular samples", true);
+    if (p.feat.has_noise && !ih.xyb_encoded) throw ParseError("noise on a non-XYB frame", false);
+    const bool last = p.is_last;
+    bitpos = p.frame_end_bitpos;
+    units.push_back(std::move(e));
+    if (last) break;
   }
-  images_.push_back(std::move(e));
+  bool complex = units.size() > 1;
+  for (auto& u : units) {
+    const FramePlan& p = u->plan;
+    bool replace_all = p.blend.mode == 0;
+    for (auto& b : p.ec_blend) if (b.mode != 0) replace_all = false;
+    if ((p.flags & (1 | 2 | 16)) || p.have_crop || !replace_all || p.frame_type != 0) complex = true;
+    if (p.modular && ih.xyb_encoded) complex = true;      // XYB Modular frames go through the float planes
+    if (p.modular && p.upsampling != 1) complex = true;
+  }
+  if (complex && ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels in a multi-frame / feature image", true);
+  for (auto& u : units) u->complex = complex;
+  PubImage pi; pi.first_unit = (int)images_.size(); pi.num_units = (int)units.size(); pi.complex = complex;
+  for (auto& u : units) images_.push_back(std::move(u));
+  pub_.push_back(pi);
   prepared_ = false;
-  return (int)images_.size() - 1;
+  return (int)pub_.size() - 1;
 }
 
 size_t Batch::OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t* channels) {
@@ -123,7 +222,7 @@ size_t Batch::OutputSize(const ImageHeader& ih, const OutputSpec& o) {
   return stride * (OrientedHeight(ih, o) - 1) + (size_t)OrientedWidth(ih, o) * nc * bps;
 }
 void Batch::SetOutput(int i, const OutputSpec& o) {
-  ImageEntry& e = *images_[i];
+  ImageEntry& e = *images_[pub_[i].first_unit];
   e.out = o;
   uint32_t nc;
   e.out_stride = OutputStride(e.ih, o, &nc);
@@ -132,8 +231,8 @@ void Batch::SetOutput(int i, const OutputSpec& o) {
   prepared_ = false;
 }
 
-uint64_t Batch::total_pixels() const { uint64_t n = 0; for (auto& e : images_) n += (uint64_t)e->ih.xsize * e->ih.ysize; return n; }
-uint64_t Batch::compressed_bytes() const { uint64_t n = 0; for (auto& e : images_) n += e->cs.size; return n; }
+uint64_t Batch::total_pixels() const { uint64_t n = 0; for (auto& pi : pub_) { const ImageHeader& ih = images_[pi.first_unit]->ih; n += (uint64_t)ih.xsize * ih.ysize; } return n; }
+uint64_t Batch::compressed_bytes() const { uint64_t n = 0; for (auto& pi : pub_) n += images_[pi.first_unit]->cs.size; return n; }
 void Batch::StageBytes(uint64_t out[6]) const {
   // Compulsory HBM traffic of each stage: every input read once, every output written once.
   for (int i = 0; i < 6; i++) out[i] = 0;
@@ -159,7 +258,7 @@ void Batch::StageBytes(uint64_t out[6]) const {
 }
 
 void* Batch::device_output(int i) const {
-  const ImageEntry& e = *images_[i];
+  const ImageEntry& e = *images_[pub_[i].first_unit];
   return e.out.device_ptr ? e.out.device_ptr : (void*)(dwork_ + e.off_out);
 }
 
@@ -209,8 +308,8 @@ void Batch::Prepare(void* stream_v) {
     ImageEntry& e = *images_[i];
     FramePlan& p = e.plan;
     ConstOffsets& c = co[i];
-    if (e.out_size == 0) SetOutput(i, e.out);
-    c.cs = arena.Put(e.cs.data(), e.cs.padded_size());
+    if (e.frame_index == 0 && e.out_size == 0) SetOutput(e.pub_index, e.out);
+    if (e.frame_index == 0) c.cs = arena.Put(e.cs.data(), e.cs.padded_size()); else c.cs = co[i - e.frame_index].cs;   // frames share the codestream
     std::vector<uint64_t> so, ss;
     for (auto& s : p.sections) { so.push_back(s.offset); ss.push_back(s.size); }
     c.sec_off = arena.Put(so.data(), so.size() * 8);
@@ -230,8 +329,8 @@ void Batch::Prepare(void* stream_v) {
     max_bw_ = std::max<int>(max_bw_, p.bw); max_bh_ = std::max<int>(max_bh_, p.bh);
     if (!p.modular) {
       max_epf_ = std::max<int>(max_epf_, p.lf.epf_iters); any_gab_ |= p.lf.gab != 0;
-      const bool fusable = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && p.upsampling == 1;
-      if (p.upsampling > 1) { fplan_.any_upsampled = true; fplan_.max_out_w = std::max<int>(fplan_.max_out_w, e.ih.xsize); fplan_.max_out_h = std::max<int>(fplan_.max_out_h, e.ih.ysize); }
+      const bool fusable = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && p.upsampling == 1 && !e.complex;
+      if (p.upsampling > 1 && !e.complex) { fplan_.any_upsampled = true; fplan_.max_out_w = std::max<int>(fplan_.max_out_w, e.ih.xsize); fplan_.max_out_h = std::max<int>(fplan_.max_out_h, e.ih.ysize); }
       fplan_.any_fused |= fusable; fplan_.any_unfused |= !fusable;
       fplan_.any_gab |= p.lf.gab != 0; fplan_.max_epf = std::max<int>(fplan_.max_epf, p.lf.epf_iters);
     }
@@ -245,11 +344,15 @@ void Batch::Prepare(void* stream_v) {
   struct WorkOffsets {
     size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, vb_list, vb_count, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
         mod_scratch, hf_end = 0, mod_wp = 0, up_plane[4] = {0, 0, 0, 0};
-    size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0;
+    size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0, lz_window = (size_t)-1;
   };
   std::vector<WorkOffsets> wo(n);
   mod_plane_offsets_.assign(n, {});
   mod_ops_.assign(n, {});
+  cbufs_.assign(n, ComplexBufs());
+  for (auto& cb : cbufs_) for (size_t* a : {cb.ecf, cb.up_ec, cb.canvas_ec}) for (int k = 0; k < 4; k++) a[k] = (size_t)-1;
+  for (auto& cb : cbufs_) for (size_t* a : {cb.up, cb.noise, cb.rgb, cb.canvas, cb.pa, cb.pb, cb.color_int}) for (int k = 0; k < 3; k++) a[k] = (size_t)-1;
+  post_ops_.clear(); any_complex_ = false;
   vardct_alpha_.assign(n, VarDctAlpha());
   status_off_ = take((size_t)n * 4);
   const size_t flags_off = take((size_t)n * 4);
@@ -270,7 +373,14 @@ void Batch::Prepare(void* stream_v) {
     const FramePlan& p = e.plan;
     WorkOffsets& o = wo[i];
     o.end_bitpos = take(16);
-    if (!e.out.device_ptr) e.off_out = take(e.out_size + 64);
+    if (e.frame_index == 0 && !e.out.device_ptr) e.off_out = take(e.out_size + 64);
+  if (p.upsampling > 1) {   // kernel weights: custom (image header) or library default
+      const int upk = p.upsampling == 2 ? 0 : p.upsampling == 4 ? 1 : 2;
+      const float* const kDefault[3] = {kUp2, kUp4, kUp8};
+      static const size_t kCount[3] = {15, 55, 210};
+      const std::vector<float>& cw = e.ih.up_weights[upk];
+      co[i].up_weights = cw.empty() ? arena.Put(kDefault[upk], kCount[upk] * 4) : arena.Put(cw.data(), cw.size() * 4);
+    }
     if (!p.modular) {
       const size_t nb = (size_t)p.bw * p.bh;
       for (int c = 0; c < 3; c++) { o.lfq[c] = take(nb * 4); o.lf[c] = take(nb * 4); o.lf_tmp[c] = take(nb * 4); o.llf[c] = take(nb * 4); }
@@ -279,47 +389,8 @@ void Batch::Prepare(void* stream_v) {
       const size_t ntile = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8);
       o.ytox = take(ntile); o.ytob = take(ntile);
       const size_t plane = (size_t)p.bw * 8 * p.bh * 8 * 4;
-      for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big(plane); o.plane_b[c] = need_plane_b ? take_big(plane) : (size_t)-1; }
-      if (p.upsampling > 1) {
-        for (int c = 0; c < 4; c++) o.up_plane[c] = take_big((size_t)e.ih.xsize * e.ih.ysize * 4);
-        // library-default kernels (image_metadata.cc kWeights2 / 4 / 8): each sub-pixel kernel sums to 1
-        static const float kUp2[15] = {-0.01716200f, -0.03452303f, -0.04022174f, -0.02921014f, -0.00624645f, 0.14111091f, 0.28896755f, 0.00278718f,
-                                       -0.01610267f, 0.56661550f,  0.03777607f,  -0.01986694f, -0.03144731f, -0.01185068f, -0.00213539f};
-        static const float kUp4[55] = {
-    -0.02419067f, -0.03491987f, -0.03693351f, -0.03094285f, -0.00529785f, -0.01663432f, -0.03556863f, -0.03888905f, -0.03516850f, -0.00989469f, 0.23651958f,
-    0.33392945f,  -0.01073543f, -0.01313181f, -0.03556694f, 0.13048175f,  0.40103025f,  0.03951150f,  -0.02077584f, 0.46914198f,  -0.00209270f, -0.01484589f,
-    -0.04064806f, 0.18942530f,  0.56279892f,  0.06674400f,  -0.02335494f, -0.03551682f, -0.00754830f, -0.02267919f, -0.02363578f, 0.00315804f,  -0.03399098f,
-    -0.01359519f, -0.00091653f, -0.00335467f, -0.01163294f, -0.01610294f, -0.00974088f, -0.00191622f, -0.01095446f, -0.03198464f, -0.04455121f, -0.02799790f,
-    -0.00645912f, 0.06390599f,  0.22963888f,  0.00630981f,  -0.01897349f, 0.67537268f,  0.08483369f,  -0.02534994f, -0.02205197f, -0.01667999f, -0.00384443f};
-        static const float kUp8[210] = {
-    -0.02928613f, -0.03706353f, -0.03783812f, -0.03324558f, -0.00447632f, -0.02519406f, -0.03752601f, -0.03901508f, -0.03663285f, -0.00646649f,
-    -0.02066407f, -0.03838633f, -0.04002101f, -0.03900035f, -0.00901973f, -0.01626393f, -0.03954148f, -0.04046620f, -0.03979621f, -0.01224485f,
-    0.29895328f, 0.35757708f, -0.02447552f, -0.01081748f, -0.04314594f, 0.23903219f, 0.41119301f, -0.00573046f, -0.01450239f, -0.04246845f,
-    0.17567618f, 0.45220643f, 0.02287757f, -0.01936783f, -0.03583255f, 0.11572472f, 0.47416733f, 0.06284440f, -0.02685066f, 0.42720050f,
-    -0.02248939f, -0.01155273f, -0.04562755f, 0.28689496f, 0.49093869f, -0.00007891f, -0.01545926f, -0.04562659f, 0.21238920f, 0.53980934f,
-    0.03369474f, -0.02070211f, -0.03866988f, 0.14229550f, 0.56593398f, 0.08045181f, -0.02888298f, -0.03680918f, -0.00542229f, -0.02920477f,
-    -0.02788574f, -0.02118180f, -0.03942402f, -0.00775547f, -0.02433614f, -0.03193943f, -0.02030828f, -0.04044014f, -0.01074016f, -0.01930822f,
-    -0.03620399f, -0.01974125f, -0.03919545f, -0.01456093f, -0.00045072f, -0.00360110f, -0.01020207f, -0.01231907f, -0.00638988f, -0.00071592f,
-    -0.00279122f, -0.00957115f, -0.01288327f, -0.00730937f, -0.00107783f, -0.00210156f, -0.00890705f, -0.01317668f, -0.00813895f, -0.00153491f,
-    -0.02128481f, -0.04173044f, -0.04831487f, -0.03293190f, -0.00525260f, -0.01720322f, -0.04052736f, -0.05045706f, -0.03607317f, -0.00738030f,
-    -0.01341764f, -0.03965629f, -0.05151616f, -0.03814886f, -0.01005819f, 0.18968273f, 0.33063684f, -0.01300105f, -0.01372950f, -0.04017465f,
-    0.13727832f, 0.36402234f, 0.01027890f, -0.01832107f, -0.03365072f, 0.08734506f, 0.38194295f, 0.04338228f, -0.02525993f, 0.56408126f,
-    0.00458352f, -0.01648227f, -0.04887868f, 0.24585519f, 0.62026135f, 0.04314807f, -0.02213737f, -0.04158014f, 0.16637289f, 0.65027023f,
-    0.09621636f, -0.03101388f, -0.04082742f, -0.00904519f, -0.02790922f, -0.02117818f, 0.00798662f, -0.03995711f, -0.01243427f, -0.02231705f,
-    -0.02946266f, 0.00992055f, -0.03600283f, -0.01684920f, -0.00111684f, -0.00411204f, -0.01297130f, -0.01723725f, -0.01022545f, -0.00165306f,
-    -0.00313110f, -0.01218016f, -0.01763266f, -0.01125620f, -0.00231663f, -0.01374149f, -0.03797620f, -0.05142937f, -0.03117307f, -0.00581914f,
-    -0.01064003f, -0.03608089f, -0.05272168f, -0.03375670f, -0.00795586f, 0.09628104f, 0.27129991f, -0.00353779f, -0.01734151f, -0.03153981f,
-    0.05686230f, 0.28500998f, 0.02230594f, -0.02374955f, 0.68214326f, 0.05018048f, -0.02320852f, -0.04383616f, 0.18459474f, 0.71517975f,
-    0.10805613f, -0.03263677f, -0.03637639f, -0.01394373f, -0.02511203f, -0.01728636f, 0.05407331f, -0.02867568f, -0.01893131f, -0.00240854f,
-    -0.00446511f, -0.01636187f, -0.02377053f, -0.01522848f, -0.00333334f, -0.00819975f, -0.02964169f, -0.04499287f, -0.02745350f, -0.00612408f,
-    0.02727416f, 0.19446600f, 0.00159832f, -0.02232473f, 0.74982506f, 0.11452620f, -0.03348048f, -0.01605681f, -0.02070339f, -0.00458223f,
-        };
-        const int upk = p.upsampling == 2 ? 0 : p.upsampling == 4 ? 1 : 2;
-        const float* const kDefault[3] = {kUp2, kUp4, kUp8};
-        static const size_t kCount[3] = {15, 55, 210};
-        const std::vector<float>& cw = e.ih.up_weights[upk];
-        co[i].up_weights = cw.empty() ? arena.Put(kDefault[upk], kCount[upk] * 4) : arena.Put(cw.data(), cw.size() * 4);
-      }
+      for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big(plane); o.plane_b[c] = (need_plane_b || e.complex) ? take_big(plane) : (size_t)-1; }
+      if (p.upsampling > 1 && !e.complex) for (int c = 0; c < 4; c++) o.up_plane[c] = take_big((size_t)e.ih.xsize * e.ih.ysize * 4);
       o.lf_scratch_stride = 16 + 2 * 1024 + 3 * 65536;
       o.lf_scratch = take(o.lf_scratch_stride * 4 * p.num_lf_groups);
       o.wp_scratch_stride = 10 * (256 + 2);
@@ -355,6 +426,29 @@ void Batch::Prepare(void* stream_v) {
       o.mod_scratch = take(o.mod_scratch_stride * 4 * (p.num_lf_groups + p.num_groups));
       o.wp_scratch_stride = p.tree.uses_wp ? 10 * (65536 + 2) : 16;
       o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.num_lf_groups + p.num_groups));
+      if (e.complex) for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big((size_t)p.bw * 8 * p.bh * 8 * 4); o.plane_b[c] = (size_t)-1; }
+    }
+    if (!p.gchannels.empty() && p.has_global_tree && p.tree_code.lz77)   // LZ77 windows of the Modular streams (4 MiB each)
+      o.lz_window = take((size_t)(1 + p.num_lf_groups + p.num_groups) * (4u << 20));
+    if (e.complex) {
+      // buffers of the frame tail (PlanPostOps): float extra channels, upsampled planes, noise planes, colour-transformed planes
+      // (only when the untransformed ones must survive as a reference frame), canvas (only when the frame is blended)
+      any_complex_ = true;
+      ComplexBufs& cb = cbufs_[i];
+      const size_t ne = e.ih.extra.size();
+      const size_t coded = (size_t)p.width * p.height * 4, full = (size_t)p.frame_w * p.frame_h * 4, img = (size_t)e.ih.xsize * e.ih.ysize * 4;
+      for (size_t k = 0; k < ne; k++) cb.ecf[k] = take_big(coded);
+      if (p.upsampling > 1) { for (int c = 0; c < 3; c++) cb.up[c] = take_big(full); for (size_t k = 0; k < ne; k++) cb.up_ec[k] = take_big(full); }
+      if (p.feat.has_noise) for (int c = 0; c < 3; c++) cb.noise[c] = take_big(full);
+      const bool can_ref = !p.is_last && p.frame_type != 1 && (p.duration == 0 || p.save_as_reference != 0);
+      bool replace_all = p.blend.mode == 0;
+      for (auto& b : p.ec_blend) if (b.mode != 0) replace_all = false;
+      const bool needs_blending = p.have_crop || !replace_all;
+      if (p.frame_type != 2) {
+        if (can_ref && p.save_before_ct) for (int c = 0; c < 3; c++) cb.rgb[c] = take_big(full);
+        if (needs_blending) { for (int c = 0; c < 3; c++) cb.canvas[c] = take_big(img); for (size_t k = 0; k < ne; k++) cb.canvas_ec[k] = take_big(img); }
+      }
+      for (int c = 0; c < 3; c++) { cb.pa[c] = o.plane_a[c]; cb.pb[c] = o.plane_b[c]; }
     }
   }
   work_size_ = Align(w);
@@ -406,6 +500,8 @@ void Batch::Prepare(void* stream_v) {
     f.upsampling = p.upsampling; f.img_w = e.ih.xsize; f.img_h = e.ih.ysize;
     if (p.upsampling > 1) { f.up_weights = (const float*)(cbase + c.up_weights); for (int k = 0; k < 4; k++) f.up_plane[k] = (float*)(dbig_ + o.up_plane[k]); }
     f.is_gray = e.ih.color_space == 1;
+    f.post_mode = e.complex ? 1 : 0;
+    f.lz_window = o.lz_window == (size_t)-1 ? nullptr : (uint32_t*)(dwork_ + o.lz_window);
     f.wp_scratch = (int32_t*)(dwork_ + o.wp_scratch); f.wp_scratch_stride = o.wp_scratch_stride;
     if (!p.modular) {
       const float inv_gs = 65536.0f / (float)p.global_scale;
@@ -429,11 +525,7 @@ void Batch::Prepare(void* stream_v) {
       f.epf_quant_mul = p.lf.quant_mul; f.epf_quant_scale = (float)p.global_scale / 65536.0f;
       const float scales[3] = {p.lf.pass0_sigma_scale, 1.0f, p.lf.pass2_sigma_scale};
       for (int k = 0; k < 3; k++) { f.epf_sm[k] = scales[k] * 1.65f; f.epf_bsm[k] = f.epf_sm[k] * p.lf.border_sad_mul; }
-      const float s = 255.0f / e.ih.intensity_target;
-      for (int k = 0; k < 9; k++) f.opsin_inv[k] = e.ih.opsin_inv[k] * s;
-      for (int k = 0; k < 3; k++) { f.neg_bias[k] = e.ih.opsin_bias[k]; f.neg_bias_cbrt[k] = std::cbrt(e.ih.opsin_bias[k]); }
-      if (e.ih.xyb_encoded) f.color_mode = (!e.ih.color_default && !e.ih.have_gamma && e.ih.tf == 8) ? 1 : 0;
-      else f.color_mode = p.do_ycbcr ? 2 : 3;
+      FillColor(e.ih, p.do_ycbcr, f);
       for (int k = 0; k < 3; k++) {
         f.lfq[k] = (int32_t*)(dwork_ + o.lfq[k]); f.lf[k] = (float*)(dwork_ + o.lf[k]); f.lf_tmp[k] = (float*)(dwork_ + o.lf_tmp[k]);
         f.llf[k] = (float*)(dwork_ + o.llf[k]); f.coeff[k] = (int32_t*)(dcoef_ + o.coeff[k]);
@@ -574,6 +666,11 @@ void Batch::Prepare(void* stream_v) {
     if (dpasses_) { (void)hipFree(dpasses_); dpasses_ = nullptr; }
     HIP_CHECK(hipMalloc((void**)&dpasses_, sizeof(PassDev) * passes_host_.size()));
   }
+  if (any_complex_) {
+    std::vector<size_t> upw(n, 0);
+    for (int i = 0; i < n; i++) upw[i] = co[i].up_weights;
+    PlanPostOps(hconst_, upw);
+  }
   const_size_ = Align(hconst_.size());
   HIP_CHECK(hipMalloc((void**)&dconst_, const_size_));
   HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
@@ -686,9 +783,245 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
     op.alpha_factor = 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);
     break;
   }
+  if (e.complex) {
+    // frames of complex images end in float planes: the tail converts these integer planes itself (PlanPostOps)
+    ComplexBufs& cb = cbufs_[i];
+    cb.nb_color_int = op.num_c;
+    for (uint32_t c = 0; c < op.num_c; c++) cb.color_int[c] = list[c].off;
+    cb.ec_int.clear();
+    for (size_t k = 0; k < e.ih.extra.size(); k++) cb.ec_int.push_back(list[op.num_c + k].off);
+    return;
+  }
   if (p.modular) ops.push_back(op);
   else vardct_alpha_[i] = VarDctAlpha{op.has_alpha, op.in[3], op.alpha_factor};   // the VarDCT write stage reads the plane itself
 }
+
+// ---- frame tail of complex images -------------------------------------------------------------------------------------------------
+// Walks the frames of every complex image in codestream order and records, as closures over device addresses, the kernels
+// that turn each frame's planes into the image: dec_cache.cc PreparePipeline's stage order (patches, splines, upsampling,
+// noise | save as reference before the colour transform | XYB / YCbCr -> output colour space | blending onto the canvas |
+// save as reference | write).  Reference slots are tracked here (frame_header.cc save_as_reference / CanBeReferenced).
+void Batch::PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>& up_weights_off) {
+  Arena arena(hconst);
+  struct Slot { bool valid = false, before_ct = false; size_t p[3] = {0, 0, 0}; uint32_t stride = 0; size_t ec[4] = {0, 0, 0, 0}; uint32_t ec_stride = 0; uint32_t w = 0, h = 0; };
+  auto B = [this](size_t off) { return (float*)(dbig_ + off); };
+  for (const PubImage& pi : pub_) {
+    if (!pi.complex) continue;
+    Slot slots[4];
+    const ImageEntry& first = *images_[pi.first_unit];
+    const ImageHeader& ih = first.ih;
+    const uint32_t ne = (uint32_t)ih.extra.size();
+    uint32_t premul_mask = 0;
+    for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].alpha_associated) premul_mask |= 1u << k;
+    for (int u = pi.first_unit; u < pi.first_unit + pi.num_units; u++) {
+      const ImageEntry& e = *images_[u];
+      const FramePlan& p = e.plan;
+      const ComplexBufs& cb = cbufs_[u];
+      const uint32_t cw = p.width, ch = p.height, fw = p.frame_w, fh = p.frame_h;
+      // current planes of the frame: after the restoration filters (VarDCT) / the int -> float conversion (Modular)
+      const uint32_t nstages = p.modular ? 0 : (p.lf.gab ? 1 : 0) + (p.lf.epf_iters >= 3 ? 3 : p.lf.epf_iters);
+      size_t cur[3]; uint32_t cur_stride = p.bw * 8;
+      for (int c = 0; c < 3; c++) cur[c] = (nstages & 1) ? cb.pb[c] : cb.pa[c];
+      size_t cur_ec[4] = {0, 0, 0, 0}; uint32_t cur_ec_stride = cw;
+      if (p.modular) {
+        const uint32_t bits = ih.depth.bits;
+        if (ih.xyb_encoded) {
+          if (cb.nb_color_int != 3) throw ParseError("XYB Modular frame without three colour channels", false);
+          const size_t cy = cb.color_int[0], cx = cb.color_int[1], cbb = cb.color_int[2];
+          const float fac[3] = {p.m_lf[0], p.m_lf[1], p.m_lf[2]};
+          post_ops_.push_back([=](void* st) {
+            float* dst[3] = {B(cur[0]), B(cur[1]), B(cur[2])};
+            LaunchXybModToFloat((const int32_t*)(dwork_ + cy), (const int32_t*)(dwork_ + cx), (const int32_t*)(dwork_ + cbb), cw, dst, cur_stride, cw, ch, fac, st);
+          });
+        } else {
+          const float factor = (float)(1.0 / (double)((1u << bits) - 1));
+          for (int c = 0; c < 3; c++) {
+            const size_t src = cb.color_int[cb.nb_color_int == 1 ? 0 : c], dst = cur[c];
+            post_ops_.push_back([=](void* st) { LaunchIntToFloat((const int32_t*)(dwork_ + src), cw, B(dst), cur_stride, cw, ch, factor, st); });
+          }
+        }
+      }
+      for (uint32_t k = 0; k < ne; k++) {
+        if (k >= cb.ec_int.size()) throw ParseError("missing extra channel", false);
+        const size_t src = cb.ec_int[k], dst = cb.ecf[k];
+        const float factor = 1.0f / (float)((1u << ih.extra[k].depth.bits) - 1);
+        post_ops_.push_back([=](void* st) { LaunchIntToFloat((const int32_t*)(dwork_ + src), cw, B(dst), cw, cw, ch, factor, st); });
+        cur_ec[k] = dst;
+      }
+      // ---- patches
+      if (p.flags & 2) {
+        std::vector<PatchEntryDev> entries;
+        for (const PatchRefH& pr : p.feat.patches) {
+          const Slot& sl = slots[pr.ref];
+          if (!sl.valid) throw ParseError("patch refers to an empty reference slot", false);
+          if (!sl.before_ct) throw ParseError("patch refers to a frame saved after the colour transform", false);
+          if ((uint64_t)pr.x0 + pr.xsize > sl.w || (uint64_t)pr.y0 + pr.ysize > sl.h) throw ParseError("patch exceeds its reference frame", false);
+          for (const PatchPosH& pp : pr.pos) {
+            if (pp.x + pr.xsize > cw || pp.y + pr.ysize > ch) throw ParseError("patch exceeds the frame", false);
+            PatchEntryDev en;
+            memset(&en, 0, sizeof(en));
+            for (int c = 0; c < 3; c++) en.src[c] = B(sl.p[c]) + (size_t)pr.y0 * sl.stride + pr.x0;
+            for (uint32_t k = 0; k < ne; k++) en.esrc[k] = B(sl.ec[k]) + (size_t)pr.y0 * sl.ec_stride + pr.x0;
+            en.src_stride = sl.stride; en.esrc_stride = sl.ec_stride;
+            en.x = (int32_t)pp.x; en.y = (int32_t)pp.y; en.xs = pr.xsize; en.ys = pr.ysize;
+            for (uint32_t k = 0; k < 1 + ne; k++) en.mode[k] = pp.blend[k].mode | (pp.blend[k].alpha_channel << 8) | (pp.blend[k].clamp << 16);
+            entries.push_back(en);
+          }
+        }
+        if (!entries.empty()) {
+          // per 32x32 tile: the placements touching it, in dictionary order
+          const uint32_t tx = (cw + 31) / 32, ty = (ch + 31) / 32;
+          std::vector<std::vector<uint32_t>> lists((size_t)tx * ty);
+          for (uint32_t k = 0; k < entries.size(); k++) {
+            const PatchEntryDev& en = entries[k];
+            for (uint32_t yy = (uint32_t)en.y / 32; yy <= ((uint32_t)en.y + en.ys - 1) / 32; yy++)
+              for (uint32_t xx = (uint32_t)en.x / 32; xx <= ((uint32_t)en.x + en.xs - 1) / 32; xx++) lists[(size_t)yy * tx + xx].push_back(k);
+          }
+          std::vector<uint32_t> start(lists.size() + 1, 0), flat;
+          for (size_t t = 0; t < lists.size(); t++) { start[t + 1] = start[t] + (uint32_t)lists[t].size(); flat.insert(flat.end(), lists[t].begin(), lists[t].end()); }
+          if (flat.empty()) flat.push_back(0);
+          const size_t o_e = arena.Put(entries.data(), entries.size() * sizeof(PatchEntryDev)), o_s = arena.Put(start.data(), start.size() * 4), o_l = arena.Put(flat.data(), flat.size() * 4);
+          PatchFrameArgs pa;
+          memset(&pa, 0, sizeof(pa));
+          for (int c = 0; c < 3; c++) pa.p[c] = B(cur[c]);
+          for (uint32_t k = 0; k < ne; k++) pa.ec[k] = B(cur_ec[k]);
+          pa.stride = cur_stride; pa.ec_stride = cur_ec_stride; pa.w = cw; pa.h = ch; pa.num_extra = ne; pa.premul_mask = premul_mask;
+          post_ops_.push_back([=](void* st) { LaunchPatches(pa, (const PatchEntryDev*)(dconst_ + o_e), (const uint32_t*)(dconst_ + o_s), (const uint32_t*)(dconst_ + o_l), st); });
+        }
+      }
+      // ---- splines (segments from the host, host_features.cc)
+      if (p.flags & 16) {
+        SplineDrawList dl;
+        BuildSplineDrawList(p.feat, p.base_x, p.base_b, ch, &dl);
+        if (!dl.segments.empty() && !dl.indices.empty()) {
+          const size_t o_g = arena.Put(dl.segments.data(), dl.segments.size() * sizeof(SplineSegmentDev)), o_r = arena.Put(dl.row_start.data(), dl.row_start.size() * 4),
+                       o_i = arena.Put(dl.indices.data(), dl.indices.size() * 4);
+          post_ops_.push_back([=](void* st) {
+            float* pl[3] = {B(cur[0]), B(cur[1]), B(cur[2])};
+            LaunchSplines(pl, cur_stride, cw, ch, (const SplineSegmentDev*)(dconst_ + o_g), (const uint32_t*)(dconst_ + o_r), (const uint32_t*)(dconst_ + o_i), st);
+          });
+        }
+      }
+      // ---- upsampling to the frame size
+      if (p.upsampling > 1) {
+        const size_t o_w = up_weights_off[u];
+        const uint32_t up = p.upsampling;
+        for (int c = 0; c < 3; c++) {
+          const size_t src = cur[c], dst = cb.up[c]; const uint32_t ss = cur_stride;
+          post_ops_.push_back([=](void* st) { LaunchUpsamplePlane(B(src), ss, cw, ch, B(dst), fw, fw, fh, up, (const float*)(dconst_ + o_w), st); });
+          cur[c] = dst;
+        }
+        for (uint32_t k = 0; k < ne; k++) {
+          const size_t src = cur_ec[k], dst = cb.up_ec[k];
+          post_ops_.push_back([=](void* st) { LaunchUpsamplePlane(B(src), cw, cw, ch, B(dst), fw, fw, fh, up, (const float*)(dconst_ + o_w), st); });
+          cur_ec[k] = dst;
+        }
+        cur_stride = fw; cur_ec_stride = fw;
+      }
+      // ---- noise
+      if (p.feat.has_noise) {
+        NoiseArgs na;
+        memset(&na, 0, sizeof(na));
+        for (int c = 0; c < 3; c++) { na.p[c] = B(cur[c]); na.noise[c] = B(cb.noise[c]); }
+        na.stride = cur_stride; na.w = fw; na.h = fh; na.noise_stride = fw; na.group_dim = p.group_dim;
+        na.visible_frame_index = e.visible_frame_index; na.nonvisible_frame_index = e.nonvisible_frame_index;
+        for (int k = 0; k < 8; k++) na.lut[k] = p.feat.noise_lut[k];
+        na.ytox = p.base_x; na.ytob = p.base_b;
+        post_ops_.push_back([=](void* st) { LaunchNoise(na, st); });
+      }
+      const bool can_ref = !p.is_last && p.frame_type != 1 && (p.duration == 0 || p.save_as_reference != 0);
+      if (can_ref && p.save_before_ct) {
+        Slot& sl = slots[p.save_as_reference];
+        sl.valid = true; sl.before_ct = true; sl.stride = cur_stride; sl.ec_stride = cur_ec_stride; sl.w = fw; sl.h = fh;
+        for (int c = 0; c < 3; c++) sl.p[c] = cur[c];
+        for (uint32_t k = 0; k < ne; k++) sl.ec[k] = cur_ec[k];
+      }
+      if (p.frame_type == 2) continue;    // reference-only frames are not displayed
+      // ---- colour transform into the output space
+      {
+        ColorArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.w = fw; ca.h = fh; ca.src_stride = cur_stride;
+        ca.mode = ih.xyb_encoded ? 0 : p.do_ycbcr ? 1 : 2;
+        const bool separate = cb.rgb[0] != (size_t)-1;
+        if (ca.mode != 2 || separate) {
+          for (int c = 0; c < 3; c++) { ca.src[c] = B(cur[c]); ca.dst[c] = separate ? B(cb.rgb[c]) : B(cur[c]); }
+          ca.dst_stride = separate ? fw : cur_stride;
+          FrameDev fd;
+          FillColor(ih, p.do_ycbcr, fd);
+          for (int k = 0; k < 9; k++) ca.opsin_inv[k] = fd.opsin_inv[k];
+          for (int k = 0; k < 3; k++) { ca.neg_bias[k] = fd.neg_bias[k]; ca.neg_bias_cbrt[k] = fd.neg_bias_cbrt[k]; }
+          ca.tf_kind = fd.color_mode == 0 ? 0 : fd.color_mode == 1 ? 1 : fd.color_mode == 4 ? 2 : 3;
+          ca.inverse_gamma = fd.inverse_gamma;
+          post_ops_.push_back([=](void* st) { LaunchColor(ca, st); });
+          if (separate) { for (int c = 0; c < 3; c++) cur[c] = cb.rgb[c]; cur_stride = fw; }
+        }
+      }
+      // ---- blending onto the canvas
+      bool replace_all = p.blend.mode == 0;
+      for (auto& b : p.ec_blend) if (b.mode != 0) replace_all = false;
+      const bool needs_blending = p.have_crop || !replace_all;
+      size_t canvas[3], canvas_ec[4] = {0, 0, 0, 0}; uint32_t canvas_stride, canvas_ec_stride;
+      if (!needs_blending) {
+        if (fw != ih.xsize || fh != ih.ysize) throw ParseError("frame size differs from the image size without a crop", false);
+        for (int c = 0; c < 3; c++) canvas[c] = cur[c];
+        for (uint32_t k = 0; k < ne; k++) canvas_ec[k] = cur_ec[k];
+        canvas_stride = cur_stride; canvas_ec_stride = cur_ec_stride;
+      } else {
+        auto source = [&](uint32_t idx) -> const Slot* {
+          const Slot& sl = slots[idx];
+          if (!sl.valid) return nullptr;
+          if (sl.before_ct) throw ParseError("blending source was saved before the colour transform", false);
+          if (sl.w != ih.xsize || sl.h != ih.ysize) throw ParseError("blending source has the wrong size", false);
+          return &sl;
+        };
+        BlendArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        for (int c = 0; c < 3; c++) { ba.fg[c] = B(cur[c]); ba.canvas[c] = B(cb.canvas[c]); }
+        for (uint32_t k = 0; k < ne; k++) { ba.fg_ec[k] = B(cur_ec[k]); ba.canvas_ec[k] = B(cb.canvas_ec[k]); }
+        ba.fg_stride = cur_stride; ba.fg_ec_stride = cur_ec_stride; ba.fw = fw; ba.fh = fh; ba.x0 = p.x0; ba.y0 = p.y0;
+        ba.canvas_stride = ih.xsize; ba.canvas_ec_stride = ih.xsize; ba.img_w = ih.xsize; ba.img_h = ih.ysize; ba.num_extra = ne; ba.premul_mask = premul_mask;
+        const Slot* bg = source(p.blend.source);
+        if (bg) { for (int c = 0; c < 3; c++) ba.bg[c] = B(bg->p[c]); ba.bg_stride = bg->stride; }
+        ba.mode[0] = p.blend.mode | (p.blend.alpha_channel << 8) | ((uint32_t)p.blend.clamp << 16);
+        if (p.blend.mode == 2 || p.blend.mode == 3) {
+          if (ne == 0) throw ParseError("alpha blending without extra channels", false);
+          if (bg) { ba.bg_alpha = B(bg->ec[p.blend.alpha_channel]); ba.bg_alpha_stride = bg->ec_stride; }
+        }
+        for (uint32_t k = 0; k < ne; k++) {
+          const BlendInfoH& bi = p.ec_blend[k];
+          ba.mode[1 + k] = bi.mode | (bi.alpha_channel << 8) | ((uint32_t)bi.clamp << 16);
+          const Slot* eb = source(bi.source);
+          if (eb) { ba.bg_ec[k] = B(eb->ec[k]); ba.bg_ec_alpha[k] = B(eb->ec[bi.alpha_channel]); ba.bg_ec_stride[k] = eb->ec_stride; }
+        }
+        post_ops_.push_back([=](void* st) { LaunchBlend(ba, st); });
+        for (int c = 0; c < 3; c++) canvas[c] = cb.canvas[c];
+        for (uint32_t k = 0; k < ne; k++) canvas_ec[k] = cb.canvas_ec[k];
+        canvas_stride = ih.xsize; canvas_ec_stride = ih.xsize;
+      }
+      if (can_ref && !p.save_before_ct) {
+        Slot& sl = slots[p.save_as_reference];
+        sl.valid = true; sl.before_ct = false; sl.stride = canvas_stride; sl.ec_stride = canvas_ec_stride; sl.w = ih.xsize; sl.h = ih.ysize;
+        for (int c = 0; c < 3; c++) sl.p[c] = canvas[c];
+        for (uint32_t k = 0; k < ne; k++) sl.ec[k] = canvas_ec[k];
+      }
+      if (!p.is_last) continue;   // coalescing: the composite of the last frame is what the caller receives
+      // ---- write stage
+      WriteArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      for (int c = 0; c < 3; c++) wa.p[c] = B(canvas[c]);
+      wa.stride = canvas_stride;
+      for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].type == 0) { wa.alpha = B(canvas_ec[k]); wa.alpha_stride = canvas_ec_stride; break; }
+      wa.img_w = ih.xsize; wa.img_h = ih.ysize;
+      wa.out = (uint8_t*)(first.out.device_ptr ? first.out.device_ptr : dwork_ + first.off_out);
+      wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian;
+      wa.out_orient = first.out.keep_orientation ? 1 : ih.orientation; wa.is_gray = ih.color_space == 1;
+      post_ops_.push_back([=](void* st) { LaunchWrite(wa, st); });
+    }
+  }
+}
+
+void Batch::EnqueuePostOps(void* stream) { for (auto& op : post_ops_) op(stream); }
 
 void Batch::ClearCoefficientsBeforeHf(void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
@@ -756,6 +1089,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     if (do_tail) {
       rec(4); rec(5);
       if (any_modchan_) EnqueueModularTail(stream_v);
+      if (any_complex_) EnqueuePostOps(stream_v);
       rec(6);
       if (timed && split) timed_rest_cursor_++;
     }
@@ -776,6 +1110,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     rec(5);
     LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
+    if (any_complex_) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
     rec(6);
     ClearCoefficientsAfterDecode(stream_v);   // for this batch's next decode; runs under whatever the caller enqueues next
     if (timed && split) timed_rest_cursor_++;
@@ -832,7 +1167,7 @@ void Batch::Finish(void* stream_v) {
 }
 
 void Batch::CopyOutputToHost(int i, void* dst, size_t size, void* stream_v) {
-  const ImageEntry& e = *images_[i];
+  const ImageEntry& e = *images_[pub_[i].first_unit];
   HIP_CHECK(hipMemcpyAsync(dst, device_output(i), std::min(size, e.out_size), hipMemcpyDeviceToHost, (hipStream_t)stream_v));
   HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_v));
 }

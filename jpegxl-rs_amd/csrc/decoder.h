@@ -20,17 +20,28 @@ struct OutputSpec {
   bool keep_orientation = false;  // false: the header's orientation is applied to the output (libjxl's default)
 };
 
+// What the frames of one image share: the codestream and the image header.
+struct ImageShared { Codestream cs; ImageHeader ih; };
+
+// One *frame* of an image: the unit the decode stages work on (one FrameDev each).  A single-frame image without image
+// features is one unit that writes its pixels itself; the frames of other ("complex") images end in float planes and a
+// host-planned tail (patches, splines, noise, colour transform, blending, write) composes them (Batch::PlanPostOps).
 struct ImageEntry {
-  Codestream cs;
-  ImageHeader ih;
+  std::shared_ptr<ImageShared> shared;
+  Codestream& cs;
+  ImageHeader& ih;
   FramePlan plan;
   uint64_t frame_bitpos = 0;
-  OutputSpec out;
+  OutputSpec out;                      // (first unit of the image)
   size_t out_stride = 0, out_size = 0;
   bool has_jbrd = false;
+  int pub_index = 0, frame_index = 0;  // image the frame belongs to, position among its frames
+  bool complex = false;                // frame of a complex image
+  uint32_t visible_frame_index = 0, nonvisible_frame_index = 0;   // noise seeds (dec_frame.cc)
   // arena offsets
   size_t off_cs = 0, off_sec = 0, off_tree = 0, off_bcm = 0;
   size_t off_out = 0;
+  explicit ImageEntry(std::shared_ptr<ImageShared> s) : shared(std::move(s)), cs(shared->cs), ih(shared->ih) {}
 };
 
 struct StageTimes { float lf_ms = 0, lfpost_ms = 0, hf_ms = 0, idct_ms = 0, filter_ms = 0, out_ms = 0, total_ms = 0; };
@@ -41,8 +52,8 @@ class Batch {
   ~Batch();
   // Parses headers (container, image header, frame header, TOC, global sections).  Throws ParseError.
   int AddImage(const uint8_t* data, size_t size);
-  size_t size() const { return images_.size(); }
-  ImageEntry& image(int i) { return *images_[i]; }
+  size_t size() const { return pub_.size(); }
+  ImageEntry& image(int i) { return *images_[pub_[i].first_unit]; }
   static size_t OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t* channels);
   static uint32_t OrientedWidth(const ImageHeader& ih, const OutputSpec& o);
   static uint32_t OrientedHeight(const ImageHeader& ih, const OutputSpec& o);
@@ -76,7 +87,21 @@ class Batch {
   void UploadFrames(void* stream);
   void EnqueueVarDCTFront(void* stream);
   int device_;
-  std::vector<std::unique_ptr<ImageEntry>> images_;
+  std::vector<std::unique_ptr<ImageEntry>> images_;   // decode units (frames), in image order
+  struct PubImage { int first_unit = 0, num_units = 1; bool complex = false; };
+  std::vector<PubImage> pub_;                          // images as the caller counts them
+  // ---- frame tail of complex images
+  struct ComplexBufs {      // big-arena offsets of one complex unit ((size_t)-1: not allocated)
+    size_t ecf[4], up[3], up_ec[4], noise[3], rgb[3], canvas[3], canvas_ec[4], pa[3], pb[3];
+    std::vector<size_t> ec_int;     // work-arena offsets of the decoded extra channels (int32, coded size)
+    size_t color_int[3];            // Modular frames: work-arena offsets of the colour channels after the inverse transforms
+    uint32_t nb_color_int = 0;
+  };
+  std::vector<ComplexBufs> cbufs_;
+  std::vector<std::function<void(void*)>> post_ops_;
+  bool any_complex_ = false;
+  void PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>& up_weights_off);
+  void EnqueuePostOps(void* stream);
   std::vector<FrameDev> frames_host_;
   std::vector<uint8_t> hconst_;
   uint8_t* dconst_ = nullptr; size_t const_size_ = 0;

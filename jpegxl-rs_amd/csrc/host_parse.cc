@@ -260,9 +260,17 @@ void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77 
 
 struct HostSymbolReader {  // symbol reader over a HostCode, for the small global streams parsed on the host
   Reader& r; const HostCode& hc; DevCode view; AnsReader ans;
-  HostSymbolReader(Reader& rr, const HostCode& c) : r(rr), hc(c), view(c.View()) { ans.Init(r.br, view); }
+  std::vector<uint32_t> window; Lz77State lz;
+  HostSymbolReader(Reader& rr, const HostCode& c, uint32_t dist_multiplier = 0) : r(rr), hc(c), view(c.View()) {
+    ans.Init(r.br, view);
+    if (hc.lz77) { window.assign(Lz77State::kWindow, 0); lz.Init(window.data(), dist_multiplier); }
+  }
   uint32_t Read(uint32_t ctx) {
-    uint32_t v = ReadHybridUint(r.br, ans, view, ctx);
+    uint32_t v;
+    if (!hc.lz77) v = ReadHybridUint(r.br, ans, view, ctx);
+    else v = Lz77Read(r.br, lz, ctx, hc.num_ctx, hc.lz_min_symbol, hc.lz_min_length, hc.lz_len_cfg,
+                      [&](uint32_t c) { return (uint32_t)view.ctx_map[c]; }, [&](uint32_t cl) { return ReadSymbol(r.br, ans, view, cl); },
+                      [&](uint32_t cl) { return view.cfg[cl]; });
     if (r.pos() > r.limit_bits) throw ParseError("truncated", false);
     return v;
   }
@@ -278,7 +286,6 @@ void ReadContextMap(Reader& r, uint32_t num_ctx, std::vector<uint8_t>& map, uint
     bool mtf = r.b();
     HostCode nested;
     ReadEntropyCode(r, 1, &nested, num_ctx > 2);
-    if (nested.lz77) Unsupported("LZ77 in context map");
     HostSymbolReader sr(r, nested);
     for (auto& m : map) { uint32_t v = sr.Read(0); if (v > 255) Fail("context map value"); m = (uint8_t)v; }
     sr.CheckFinal();
@@ -306,9 +313,12 @@ void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77)
   hc->lz77 = r.b();
   if (hc->lz77) {
     if (!allow_lz77) Fail("LZ77 not allowed");
-    Unsupported("LZ77-coded stream");
+    hc->lz_min_symbol = r.U32({0, 224}, {0, 512}, {0, 4096}, {15, 8});
+    hc->lz_min_length = r.U32({0, 3}, {0, 4}, {2, 5}, {8, 9});
+    hc->lz_len_cfg = ReadUintConfig(r, 8);
   }
   hc->num_ctx = num_ctx;
+  if (hc->lz77) num_ctx += 1;            // the distance context (last entry of the context map)
   if (num_ctx > 1) ReadContextMap(r, num_ctx, hc->ctx_map, &hc->num_clusters);
   else { hc->ctx_map.assign(1, 0); hc->num_clusters = 1; }
   hc->use_prefix = r.b();
@@ -583,32 +593,34 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     uint32_t lf_level = 0;
     if (p->frame_type == 1) lf_level = r.U32({0, 1}, {0, 2}, {0, 3}, {0, 4});
     else if (r.b()) {
-      int32_t x0 = 0, y0 = 0;
+      p->have_crop = true;
       if (p->frame_type != 2) {
-        x0 = UnpackSigned(r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688}));
-        y0 = UnpackSigned(r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688}));
+        p->x0 = UnpackSigned(r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688}));
+        p->y0 = UnpackSigned(r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688}));
       }
       fx = r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688});
       fy = r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688});
-      partial = x0 > 0 || y0 > 0 || (int64_t)fx + x0 < (int64_t)ih.xsize || (int64_t)fy + y0 < (int64_t)ih.ysize;
-      if (x0 != 0 || y0 != 0 || fx != ih.xsize || fy != ih.ysize) Unsupported("cropped frame");
+      if (fx == 0 || fy == 0) Fail("empty frame");
+      partial = p->x0 > 0 || p->y0 > 0 || (int64_t)fx + p->x0 < (int64_t)ih.xsize || (int64_t)fy + p->y0 < (int64_t)ih.ysize;
     }
-    uint32_t blend_mode = 0, duration = 0, save_as_ref = 0;
+    p->ec_blend.assign(num_extra, BlendInfoH());
     if (p->frame_type == 0 || p->frame_type == 3) {
       for (size_t i = 0; i < 1 + num_extra; i++) {
-        uint32_t mode = r.U32({0, 0}, {0, 1}, {0, 2}, {2, 3});
-        if (i == 0) blend_mode = mode;
-        if (num_extra > 0 && (mode == 2 || mode == 3)) r.U32({0, 0}, {0, 1}, {0, 2}, {3, 3});
-        if (num_extra > 0 && (mode == 2 || mode == 3 || mode == 4)) r.b();
-        if (mode != 0 || partial) r.u(2);
+        BlendInfoH& b = i == 0 ? p->blend : p->ec_blend[i - 1];
+        b.mode = r.U32({0, 0}, {0, 1}, {0, 2}, {2, 3});
+        if (b.mode > 4) Fail("blend mode");
+        if (num_extra > 0 && (b.mode == 2 || b.mode == 3)) b.alpha_channel = r.U32({0, 0}, {0, 1}, {0, 2}, {3, 3});
+        if (num_extra > 0 && (b.mode == 2 || b.mode == 3 || b.mode == 4)) b.clamp = r.b();
+        if (b.mode != 0 || partial) b.source = r.u(2);
+        if (b.alpha_channel >= std::max<size_t>(num_extra, 1)) Fail("blend alpha channel");
       }
-      if (ih.have_animation) { duration = r.U32({0, 0}, {0, 1}, {8, 0}, {32, 0}); if (ih.have_timecodes) r.u(32); }
+      if (ih.have_animation) { p->duration = r.U32({0, 0}, {0, 1}, {8, 0}, {32, 0}); if (ih.have_timecodes) r.u(32); }
       p->is_last = r.b();
     } else p->is_last = false;
-    if (p->frame_type != 1 && !p->is_last) save_as_ref = r.u(2);
-    bool can_ref = !p->is_last && p->frame_type != 1 && (duration == 0 || save_as_ref != 0);
-    bool full_replace = (p->frame_type == 0 || p->frame_type == 3) && blend_mode == 0 && !partial;
-    if (p->frame_type == 2 || (can_ref && full_replace)) r.b();
+    if (p->frame_type != 1 && !p->is_last) p->save_as_reference = r.u(2);
+    bool can_ref = !p->is_last && p->frame_type != 1 && (p->duration == 0 || p->save_as_reference != 0);
+    bool full_replace = (p->frame_type == 0 || p->frame_type == 3) && p->blend.mode == 0 && !partial;
+    if (p->frame_type == 2 || (can_ref && full_replace)) p->save_before_ct = r.b();
     SkipName(r);
     if (!r.b()) {  // RestorationFilter not all_default
       LoopFilterParams& lf = p->lf;
@@ -619,25 +631,19 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
         if (!p->modular && r.b()) for (int i = 0; i < 8; i++) lf.sharp_lut[i] = r.F16();
         if (r.b()) { for (int i = 0; i < 3; i++) lf.channel_scale[i] = r.F16(); r.F16(); r.F16(); }
         if (r.b()) { if (!p->modular) lf.quant_mul = r.F16(); lf.pass0_sigma_scale = r.F16(); lf.pass2_sigma_scale = r.F16(); lf.border_sad_mul = r.F16(); }
-        if (p->modular) r.F16();
+        if (p->modular) p->sigma_for_modular = r.F16();
       }
       r.SkipExtensions();
     }
     r.SkipExtensions();
-    if (p->frame_type != 0) Unsupported("non-regular frame (reference / LF / skip-progressive)");
-    if (!p->is_last) Unsupported("multi-frame image");
+    if (p->frame_type == 1 || use_lf_frame) Unsupported("LF frame");
     for (auto e : ec_ups) if (e != p->upsampling) Unsupported("extra-channel upsampling different from the colour upsampling");
-    if (p->upsampling != 1) {
-      if (p->modular) Unsupported("upsampling of a Modular frame");
-      fx = (fx + p->upsampling - 1) / p->upsampling; fy = (fy + p->upsampling - 1) / p->upsampling;   // coded size
-    }
     for (int i = 0; i < 3; i++) if (jpeg_ups[i]) Unsupported("chroma subsampling");
-    if (use_lf_frame) Unsupported("LF frame");
     (void)lf_level;
   }
-  if (p->flags & 2) Unsupported("patches");
-  if (p->flags & 16) Unsupported("splines");
-  if (p->flags & 1) Unsupported("noise");
+  p->frame_w = fx; p->frame_h = fy;
+  if (p->upsampling != 1) { fx = (fx + p->upsampling - 1) / p->upsampling; fy = (fy + p->upsampling - 1) / p->upsampling; }   // coded size
+  if (p->modular && (p->lf.gab || p->lf.epf_iters)) Unsupported("restoration filters on a Modular frame");
   if (p->num_passes != 1 && p->modular) Unsupported("multi-pass Modular frame");
   if (p->num_passes > 11) Fail("number of passes");
   p->width = fx; p->height = fy;
@@ -677,6 +683,7 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   p->sections.resize(n);
   for (size_t i = 0; i < n; i++) p->sections[i] = perm.empty() ? phys[i] : phys[perm[i]];
   if (off > cs.size) throw ParseError("truncated", false);
+  p->frame_end_bitpos = off * 8;
   // ---- LfGlobal
   Reader rg(cs, p->sections[0].offset * 8);
   rg.limit_bits = (p->sections[0].offset + p->sections[0].size) * 8;
@@ -685,7 +692,86 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   if (!p->single_section && !p->modular) ParseHfGlobal(cs, ih, p->sections[1 + p->num_lf_groups].offset * 8, p);
 }
 
+// dec_patch_dictionary.cc PatchDictionary::Decode — contexts {0 #refs, 1 reference frame, 2 size - 1, 3 position in the reference,
+// 4 first position, 5 blend mode, 6 position delta, 7 count - 1, 8 alpha channel, 9 clamp}
+static void ParsePatches(Reader& r, size_t num_extra, size_t frame_pixels, FrameFeatures* f) {
+  HostCode code;
+  ReadEntropyCode(r, 10, &code);
+  HostSymbolReader sr(r, code);
+  const uint32_t num = sr.Read(0);
+  if ((uint64_t)num > frame_pixels + 1024) Fail("too many patches");
+  f->patches.resize(num);
+  size_t total = 0;
+  for (PatchRefH& pr : f->patches) {
+    pr.ref = sr.Read(1);
+    if (pr.ref >= 4) Fail("patch reference frame");
+    pr.x0 = sr.Read(3); pr.y0 = sr.Read(3);
+    pr.xsize = sr.Read(2) + 1; pr.ysize = sr.Read(2) + 1;
+    const uint32_t count = sr.Read(7) + 1;
+    total += count;
+    if (total > frame_pixels + 1024) Fail("too many patch positions");
+    pr.pos.resize(count);
+    for (uint32_t i = 0; i < count; i++) {
+      PatchPosH& pp = pr.pos[i];
+      if (i == 0) { pp.x = sr.Read(4); pp.y = sr.Read(4); }
+      else { pp.x = pr.pos[i - 1].x + UnpackSigned(sr.Read(6)); pp.y = pr.pos[i - 1].y + UnpackSigned(sr.Read(6)); }
+      if (pp.x < 0 || pp.y < 0) Fail("patch position");
+      pp.blend.resize(1 + num_extra);
+      for (PatchBlendH& b : pp.blend) {
+        b.mode = sr.Read(5);
+        if (b.mode >= 8) Fail("patch blend mode");
+        const bool uses_alpha = b.mode >= 4;
+        if (uses_alpha && num_extra > 1) { b.alpha_channel = sr.Read(8); if (b.alpha_channel >= num_extra) Fail("patch alpha channel"); }
+        if (uses_alpha || b.mode == 3) b.clamp = sr.Read(9) != 0;
+        if (uses_alpha && num_extra == 0) Fail("alpha patch blending without extra channels");
+      }
+    }
+  }
+  sr.CheckFinal();
+}
+
+// splines.cc Splines::Decode — contexts {0 quantisation adjustment, 1 starting position, 2 #splines - 1, 3 #control points,
+// 4 control point double deltas, 5 DCT coefficients}
+static void ParseSplines(Reader& r, size_t num_pixels, FrameFeatures* f) {
+  HostCode code;
+  ReadEntropyCode(r, 6, &code);
+  HostSymbolReader sr(r, code);
+  const size_t num = 1 + (size_t)sr.Read(2);
+  const size_t max_cp = std::min<size_t>(1u << 20, num_pixels / 2);
+  if (num > max_cp) Fail("too many splines");
+  f->spline_start.resize(num);
+  int64_t lx = 0, ly = 0;
+  for (size_t i = 0; i < num; i++) {
+    int64_t x, y;
+    if (i == 0) { x = sr.Read(1); y = sr.Read(1); }
+    else { x = lx + UnpackSigned(sr.Read(1)); y = ly + UnpackSigned(sr.Read(1)); }
+    if (std::llabs(x) >= (1 << 23) || std::llabs(y) >= (1 << 23)) Fail("spline starting point");
+    f->spline_start[i] = {x, y};
+    lx = x; ly = y;
+  }
+  f->spline_quant_adjust = UnpackSigned(sr.Read(0));
+  f->splines.resize(num);
+  size_t total = 0;
+  for (SplineH& q : f->splines) {
+    const size_t n = sr.Read(3);
+    total += n;
+    if (total > max_cp) Fail("too many spline control points");
+    q.control_points.resize(n);
+    for (auto& cp : q.control_points) {
+      cp.first = UnpackSigned(sr.Read(4)); cp.second = UnpackSigned(sr.Read(4));
+      if (std::llabs(cp.first) >= (1 << 30) || std::llabs(cp.second) >= (1 << 30)) Fail("spline delta");
+    }
+    for (int c = 0; c < 3; c++) for (int i = 0; i < 32; i++) q.color_dct[c][i] = UnpackSigned(sr.Read(5));
+    for (int i = 0; i < 32; i++) q.sigma_dct[i] = UnpackSigned(sr.Read(5));
+  }
+  sr.CheckFinal();
+}
+
 static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
+  // dec_frame.cc ProcessDCGlobal: image features first — patches, splines, noise parameters
+  if (p->flags & 2) ParsePatches(r, ih.extra.size(), (size_t)p->width * p->height, &p->feat);
+  if (p->flags & 16) ParseSplines(r, (size_t)p->width * p->height, &p->feat);
+  if (p->flags & 1) { p->feat.has_noise = true; for (float& v : p->feat.noise_lut) v = (float)r.u(10) * (1.0f / 1024.0f); }
   if (!r.b()) for (int c = 0; c < 3; c++) p->m_lf[c] = r.F16() * (1.0f / 128.0f);
   BlockCtxDev& b = p->bcm;
   memset(&b, 0, sizeof(b));
@@ -884,6 +970,7 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
       sr.CheckFinal();
     }
     ReadEntropyCode(r, 495 * p->bcm.num_ctxs * p->num_hf_presets, &p->ac_code[ps]);
+    if (p->ac_code[ps].use_prefix || p->ac_code[ps].lz77) Unsupported("prefix-coded / LZ77 AC coefficient stream");
   }
   p->end_bitpos = r.pos();
 }

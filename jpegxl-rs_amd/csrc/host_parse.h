@@ -23,13 +23,15 @@ struct HostCode {  // entropy code in host memory, device-layout tables
   std::vector<uint64_t> alias;
   std::vector<uint16_t> pfx_count, pfx_syms;
   std::vector<uint32_t> pfx_sym_off;
-  uint32_t num_ctx = 0, num_clusters = 0, log_alpha = 0, use_prefix = 0;
+  uint32_t num_ctx = 0, num_clusters = 0, log_alpha = 0, use_prefix = 0;   // num_ctx: without the LZ77 distance context
   bool lz77 = false;
+  uint32_t lz_min_symbol = 0, lz_min_length = 0, lz_len_cfg = 0;
   DevCode View() const {
     DevCode d;
     d.ctx_map = ctx_map.data(); d.cfg = cfg.data(); d.alias = alias.data();
     d.pfx_count = pfx_count.data(); d.pfx_sym_off = pfx_sym_off.data(); d.pfx_syms = pfx_syms.data();
     d.num_ctx = num_ctx; d.num_clusters = num_clusters; d.log_alpha = log_alpha; d.use_prefix = use_prefix;
+    d.lz77 = lz77; d.lz_min_symbol = lz_min_symbol; d.lz_min_length = lz_min_length; d.lz_len_cfg = lz_len_cfg;
     return d;
   }
 };
@@ -89,6 +91,26 @@ struct QuantTableSpec {
 
 struct Section { uint64_t offset, size; };
 
+// ---- image features and frame compositing (LfGlobal / frame header), host-parsed: dec_patch_dictionary.cc, splines.cc, dec_noise.cc
+struct BlendInfoH { uint32_t mode = 0, alpha_channel = 0, source = 0; bool clamp = false; };   // BlendMode: 0 replace, 1 add, 2 blend, 3 mul-add, 4 mul
+struct PatchBlendH { uint32_t mode = 0, alpha_channel = 0, clamp = 0; };                        // PatchBlendMode 0..7
+struct PatchPosH { int64_t x = 0, y = 0; std::vector<PatchBlendH> blend; };                      // blend[0] colour, blend[1 + e] extra channel e
+struct PatchRefH { uint32_t ref = 0, x0 = 0, y0 = 0, xsize = 0, ysize = 0; std::vector<PatchPosH> pos; };
+struct SplineH { std::vector<std::pair<int64_t, int64_t>> control_points; int32_t color_dct[3][32]; int32_t sigma_dct[32]; };
+struct FrameFeatures {
+  std::vector<PatchRefH> patches;
+  int32_t spline_quant_adjust = 0;
+  std::vector<SplineH> splines;
+  std::vector<std::pair<int64_t, int64_t>> spline_start;
+  bool has_noise = false;
+  float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+// One rendered spline sample (splines.cc SplineSegment) and the per-row draw lists built on the host (host_features.cc)
+struct SplineSegmentDev { float center_x, center_y, maximum_distance, inv_sigma, sigma_over_4_times_intensity, color[3]; };
+struct SplineDrawList { std::vector<SplineSegmentDev> segments; std::vector<uint32_t> row_start; std::vector<uint32_t> indices; };
+void BuildSplineDrawList(const FrameFeatures& f, float y_to_x, float y_to_b, uint32_t height, SplineDrawList* out);
+float FastPowf(float base, float exponent);   // base/fast_math-inl.h (host_parse.cc)
+
 struct FramePlan {
   // frame header
   uint32_t frame_type = 0; bool modular = false; uint64_t flags = 0; bool do_ycbcr = false;
@@ -96,6 +118,14 @@ struct FramePlan {
   uint32_t num_passes = 1; uint32_t pass_shift[11] = {0};
   bool is_last = true;
   LoopFilterParams lf;
+  // compositing: position / size of the frame on the image canvas, blending, reference slots (frame_header.cc)
+  bool have_crop = false; int32_t x0 = 0, y0 = 0;
+  uint32_t frame_w = 0, frame_h = 0;       // frame size after upsampling (width / height below are the coded size)
+  BlendInfoH blend; std::vector<BlendInfoH> ec_blend;
+  uint32_t duration = 0, save_as_reference = 0; bool save_before_ct = false;
+  float sigma_for_modular = 1.0f;
+  FrameFeatures feat;
+  uint64_t frame_end_bitpos = 0;           // first bit after the frame's last section (= next frame header)
   // geometry
   uint32_t width = 0, height = 0, group_dim = 256;
   uint32_t xgroups = 0, ygroups = 0, num_groups = 0, xlfgroups = 0, ylfgroups = 0, num_lf_groups = 0;

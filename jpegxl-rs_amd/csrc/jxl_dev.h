@@ -80,6 +80,8 @@ struct DevCode {
   const uint32_t* pfx_sym_off; // [cluster] offset into pfx_syms
   const uint16_t* pfx_syms;
   uint32_t num_ctx, num_clusters, log_alpha, use_prefix;
+  // LZ77 (dec_ans.h): tokens >= lz_min_symbol start a copy; ctx_map then holds one more entry (the distance context, last)
+  uint32_t lz77, lz_min_symbol, lz_min_length, lz_len_cfg;
 };
 
 struct AnsReader {
@@ -88,7 +90,7 @@ struct AnsReader {
   JXL_HD bool FinalOk(const DevCode& code) const { return code.use_prefix || state == 0x130000u; }
 };
 
-JXL_HD uint32_t ReadSymbol(BitReader& br, AnsReader& ans, const DevCode& code, uint32_t cluster) {
+template <typename BR> JXL_HD uint32_t ReadSymbol(BR& br, AnsReader& ans, const DevCode& code, uint32_t cluster) {
   if (code.use_prefix) {
     const uint16_t* cnt = code.pfx_count + cluster * 16;
     const uint16_t* syms = code.pfx_syms + code.pfx_sym_off[cluster];
@@ -135,6 +137,74 @@ JXL_HD uint32_t ReadHybridUint(BitReader& br, AnsReader& ans, const DevCode& cod
 }
 
 JXL_HD int32_t UnpackSigned(uint32_t u) { return (int32_t)((u >> 1) ^ (~(u & 1) + 1)); }
+
+// ---- LZ77 over decoded values (dec_ans.h ANSSymbolReader::ReadHybridUintClustered with lz77 enabled) ------------------------
+// window: 2^20 entries of scratch owned by the stream (only positions < num_decoded are ever read)
+template <typename BR> JXL_HD uint32_t HybridFromToken(BR& br, uint32_t cfg, uint32_t tok) {
+  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+  const uint32_t split = 1u << split_exp;
+  if (tok < split) return tok;
+  uint32_t nbits = split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb));
+  nbits &= 31;
+  const uint32_t low = tok & ((1u << lsb) - 1);
+  tok >>= lsb;
+  const uint32_t bits = nbits ? br.Read((int)nbits) : 0;
+  const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+  return (((hi << nbits) | bits) << lsb) | low;
+}
+struct Lz77State {
+  uint32_t* window;          // kWindow entries
+  uint32_t num_to_copy, copy_pos, num_decoded, dist_multiplier;
+  static constexpr uint32_t kWindow = 1u << 20, kMask = kWindow - 1;
+  JXL_HD void Init(uint32_t* w, uint32_t dist_mult) { window = w; num_to_copy = copy_pos = num_decoded = 0; dist_multiplier = dist_mult; }
+};
+JXL_HD int32_t Lz77SpecialDistance(uint32_t i, uint32_t mult) {   // kSpecialDistances[i][0] + mult * kSpecialDistances[i][1]
+  // the 120 WebP-lossless-style neighbour offsets (dx in -7..8, dy in 0..7), packed as (dx + 7) | dy << 4
+  const uint8_t t[120] = {
+      0x17, 0x08, 0x18, 0x16, 0x27, 0x09, 0x28, 0x26, 0x19, 0x15, 0x29, 0x25, 0x37, 0x0A, 0x38, 0x36, 0x1A, 0x14, 0x39, 0x35,
+      0x2A, 0x24, 0x47, 0x0B, 0x48, 0x46, 0x1B, 0x13, 0x3A, 0x34, 0x49, 0x45, 0x2B, 0x23, 0x57, 0x4A, 0x44, 0x3B, 0x33, 0x0C,
+      0x58, 0x56, 0x1C, 0x12, 0x59, 0x55, 0x2C, 0x22, 0x4B, 0x43, 0x5A, 0x54, 0x3C, 0x32, 0x67, 0x0D, 0x68, 0x66, 0x1D, 0x11,
+      0x69, 0x65, 0x2D, 0x21, 0x5B, 0x53, 0x4C, 0x42, 0x6A, 0x64, 0x3D, 0x31, 0x77, 0x0E, 0x78, 0x76, 0x5C, 0x52, 0x1E, 0x10,
+      0x6B, 0x63, 0x4D, 0x41, 0x79, 0x75, 0x2E, 0x20, 0x7A, 0x74, 0x3E, 0x30, 0x6C, 0x62, 0x5D, 0x51, 0x0F, 0x7B, 0x73, 0x4E,
+      0x40, 0x1F, 0x2F, 0x6D, 0x61, 0x3F, 0x7C, 0x72, 0x5E, 0x50, 0x4F, 0x7D, 0x71, 0x6E, 0x60, 0x5F, 0x7E, 0x70, 0x6F, 0x7F,
+  };
+  const int first = (int)(t[i] & 15) - 7, second = (int)(t[i] >> 4);
+  return first + (int32_t)mult * second;
+}
+// One value of an LZ77-coded stream: `cluster_of(ctx)` / `read_symbol(cluster)` are supplied by the caller (alias tables or
+// prefix codes, wherever they live).
+template <typename BR, typename ClusterFn, typename SymbolFn, typename CfgFn>
+JXL_HD uint32_t Lz77Read(BR& br, Lz77State& lz, uint32_t ctx, uint32_t dist_ctx, uint32_t min_symbol, uint32_t min_length, uint32_t len_cfg,
+                         ClusterFn cluster_of, SymbolFn read_symbol, CfgFn cfg_of) {   // cluster_of maps the two "contexts" the caller passes to clusters
+  for (;;) {
+    if (lz.num_to_copy > 0) {
+      const uint32_t v = lz.window[(lz.copy_pos++) & Lz77State::kMask];
+      lz.num_to_copy--;
+      lz.window[(lz.num_decoded++) & Lz77State::kMask] = v;
+      return v;
+    }
+    const uint32_t cl = cluster_of(ctx);
+    const uint32_t tok = read_symbol(cl);
+    if (tok >= min_symbol) {
+      lz.num_to_copy = HybridFromToken(br, len_cfg, tok - min_symbol) + min_length;
+      const uint32_t dcl = cluster_of(dist_ctx);
+      const uint32_t dtok = read_symbol(dcl);
+      uint32_t distance = HybridFromToken(br, cfg_of(dcl), dtok);
+      const uint32_t nspecial = lz.dist_multiplier == 0 ? 0u : 120u;
+      if (distance < nspecial) { const int32_t d = Lz77SpecialDistance(distance, lz.dist_multiplier); distance = d < 1 ? 1u : (uint32_t)d; }
+      else distance = distance + 1 - nspecial;
+      if (distance > lz.num_decoded) distance = lz.num_decoded;
+      if (distance > Lz77State::kWindow) distance = Lz77State::kWindow;
+      lz.copy_pos = lz.num_decoded - distance;
+      if (distance == 0) { const uint32_t n = lz.num_to_copy < Lz77State::kWindow ? lz.num_to_copy : Lz77State::kWindow; for (uint32_t i = 0; i < n; i++) lz.window[i] = 0; }
+      if (lz.num_to_copy < min_length) return 0;   // (length overflow: libjxl bails out with 0)
+      continue;
+    }
+    const uint32_t v = HybridFromToken(br, cfg_of(cl), tok);
+    lz.window[(lz.num_decoded++) & Lz77State::kMask] = v;
+    return v;
+  }
+}
 
 // ---- MA tree -----------------------------------------------------------------------------------------------------------
 // inner node: prop >= 0, val = split value, a = left child (prop > val), b = right child
@@ -242,6 +312,8 @@ struct ModularCtx {
   int32_t* wp_scratch;  // 5 * 2 * (max_w + 2) ints (only if uses_wp)
   uint32_t stream_id;
   uint32_t narrow_wp = 0;  // device fast path: 32-bit weighted-predictor intermediates are exact (samples of at most 12 bits)
+  uint32_t slow = 0;       // the code uses prefix codes and / or LZ77: symbols are read by the general reader (tables in global memory)
+  Lz77State* lz = nullptr; // LZ77 state of the stream (slow && code->lz77)
 };
 
 // Decodes channel `chan` (index within the sub-stream, = property 0) — encoding.cc DecodeModularChannelMAANS.

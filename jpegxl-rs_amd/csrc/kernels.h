@@ -48,7 +48,7 @@ struct FrameDev {
   float epf_sharp_lut[8], epf_channel_scale[3], epf_quant_mul, epf_quant_scale;
   float epf_sm[3], epf_bsm[3];    // per pass sad multipliers (normal, border)
   float opsin_inv[9], neg_bias[3], neg_bias_cbrt[3];
-  uint32_t color_mode;            // 0: XYB->sRGB, 1: XYB->linear, 2: YCbCr->RGB, 3: none (RGB as is)
+  uint32_t color_mode;            // 0: XYB->sRGB, 1: XYB->linear, 2: YCbCr->RGB, 3: none (RGB as is), 4: XYB->gamma (FastPowf), 5: XYB->Rec.709
   uint32_t is_gray;
   // VarDCT buffers
   int32_t* lfq[3];
@@ -94,6 +94,10 @@ struct FrameDev {
   float* up_plane[4];             // upsampled X, Y, B (and alpha as float) planes, img_w x img_h
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
+  uint32_t* lz_window;            // LZ77-coded Modular streams: 2^20-entry windows, one per stream (global, then LfGroup / PassGroup units)
+  uint32_t post_mode;             // 1: the frame ends in its float planes (after the restoration filters); upsampling, colour transform and the
+                                  // write stage are done by the host-planned frame tail (kernels_features.hip) — multi-frame images, image features
+  float inverse_gamma;            // colour modes 4 / 5 (XYB -> gamma / Rec.709 transfer)
 };
 
 struct LaunchCfg {
@@ -136,6 +140,34 @@ void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, i
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);
 void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, size_t n, void* stream);
 void LaunchModOutput(const FrameDev* frames, int fidx, const ModOutputArgs& a, int w, int h, void* stream);
+
+// ---- frame tail of images with several frames or image features (kernels_features.hip); explicit arguments, device pointers ----
+struct SplineSegmentDev;   // host_parse.h
+// One placement of a patch: source rectangle (pointers already at its top-left sample) -> frame position (x, y).
+// mode[k] = PatchBlendMode | alpha channel << 8 | clamp << 16 for k = 0 (colour), 1 + e (extra channel e)
+struct PatchEntryDev { const float* src[3]; const float* esrc[4]; uint32_t src_stride, esrc_stride; int32_t x, y; uint32_t xs, ys; uint32_t mode[5]; uint32_t pad; };
+struct PatchFrameArgs { float* p[3]; float* ec[4]; uint32_t stride, ec_stride, w, h, num_extra, premul_mask; };
+struct NoiseArgs { float* p[3]; uint32_t stride, w, h; float* noise[3]; uint32_t noise_stride, group_dim, visible_frame_index, nonvisible_frame_index; float lut[8]; float ytox, ytob; };
+// mode: 0 XYB -> linear -> transfer function (tf_kind 0 sRGB, 1 linear, 2 gamma, 3 Rec.709), 1 YCbCr -> RGB, 2 copy
+struct ColorArgs { const float* src[3]; float* dst[3]; uint32_t src_stride, dst_stride, w, h, mode, tf_kind; float inverse_gamma, opsin_inv[9], neg_bias[3], neg_bias_cbrt[3]; };
+// mode[k] = BlendMode | alpha channel << 8 | clamp << 16; bg pointers are null when the source slot is empty (treated as zeros)
+struct BlendArgs {
+  const float* fg[3]; const float* fg_ec[4]; uint32_t fg_stride, fg_ec_stride, fw, fh; int32_t x0, y0;
+  const float* bg[3]; uint32_t bg_stride; const float* bg_alpha; uint32_t bg_alpha_stride;
+  const float* bg_ec[4]; const float* bg_ec_alpha[4]; uint32_t bg_ec_stride[4];
+  float* canvas[3]; float* canvas_ec[4]; uint32_t canvas_stride, canvas_ec_stride, img_w, img_h, num_extra, premul_mask; uint32_t mode[5];
+};
+struct WriteArgs { const float* p[3]; const float* alpha; uint32_t stride, alpha_stride, img_w, img_h; uint8_t* out; uint64_t out_stride; uint32_t out_channels, out_type, out_big_endian, out_orient, is_gray; };
+void LaunchIntToFloat(const int32_t* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor, void* stream);
+void LaunchXybModToFloat(const int32_t* cy, const int32_t* cx, const int32_t* cb, uint32_t src_stride, float* const dst[3], uint32_t dst_stride, uint32_t w, uint32_t h, const float fac[3], void* stream);
+void LaunchPatches(const PatchFrameArgs& a, const PatchEntryDev* entries, const uint32_t* tile_start, const uint32_t* tile_list, void* stream);
+void LaunchSplines(float* const p[3], uint32_t stride, uint32_t w, uint32_t h, const SplineSegmentDev* segs, const uint32_t* row_start, const uint32_t* indices, void* stream);
+void LaunchUpsamplePlane(const float* src, uint32_t src_stride, uint32_t w, uint32_t h, float* dst, uint32_t dst_stride, uint32_t ow, uint32_t oh, uint32_t up, const float* weights, void* stream);
+void LaunchNoise(const NoiseArgs& a, void* stream);
+void LaunchColor(const ColorArgs& a, void* stream);
+void LaunchBlend(const BlendArgs& a, void* stream);
+void LaunchWrite(const WriteArgs& a, void* stream);
+void LaunchCopyPlane(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, void* stream);
 
 // names of the kernels (for profiling summaries)
 extern const char* const kKernelNames[];

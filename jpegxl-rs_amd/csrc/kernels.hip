@@ -635,7 +635,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     StS<int>(wb + kWorkOff + 20, wide);
   }
   WaveSync();
-  const int mode = LdS<int>(wb + kWorkOff + 0), prop = LdS<int>(wb + kWorkOff + 4);
+  const int mode = mc.slow ? 0 : LdS<int>(wb + kWorkOff + 0), prop = LdS<int>(wb + kWorkOff + 4);   // prefix / LZ77 streams: general loop only
   const uint32_t subroot = (uint32_t)LdS<int>(wb + kWorkOff + 8);
   const int upred = LdS<int>(wb + kWorkOff + 12);
   const uint32_t wide_subroot = LdS<int>(wb + kWorkOff + 20) ? subroot : 0xFFFFFFFFu;
@@ -744,7 +744,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
   // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
   // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
   // and predictors read, the WP state.  Rows up to kRowMax samples; wider channels take the loop below.
-  const bool lds_generic = T.tree_in_lds && T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
+  const bool lds_generic = !mc.slow && T.tree_in_lds && T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
   if (lds_generic) {
     const int w = ch.w, h = ch.h;
     const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
@@ -888,7 +888,17 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
         const uint32_t predictor = n.a & 0xFF;
         const uint32_t cluster = T.tree_in_lds ? (n.a >> 8) : code.Cluster(n.a >> 8);
         const int32_t guess = Predict(predictor, W, N, NW, NE, NN, WW, NEE, wp_pred);
-        const uint32_t tok = FastHybrid(br, state, code, cluster);
+        uint32_t tok;
+        if (!mc.slow) tok = FastHybrid(br, state, code, cluster);
+        else {
+          // prefix codes / LZ77 (dec_ans.h): general symbol reader over the tables in global memory
+          const DevCode& dc = *mc.code;
+          AnsReader ans; ans.state = state;
+          if (!dc.lz77) tok = HybridFromToken(br, dc.cfg[cluster], ReadSymbol(br, ans, dc, cluster));
+          else tok = Lz77Read(br, *mc.lz, cluster, (uint32_t)dc.ctx_map[dc.num_ctx], dc.lz_min_symbol, dc.lz_min_length, dc.lz_len_cfg,
+                              [](uint32_t c) { return c; }, [&](uint32_t cl) { return ReadSymbol(br, ans, dc, cl); }, [&](uint32_t cl) { return dc.cfg[cl]; });
+          state = ans.state;
+        }
         const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) * n.b + (uint32_t)n.val + (uint32_t)guess);
         StG(p + x, val);
         if (use_wp) { if (wp_in_lds) wpl.Update(val, x, y); else wps.Update(val, x, y); }
@@ -2457,7 +2467,7 @@ __device__ __forceinline__ bool FilterStageActive(const FrameDev& f, int stage) 
 
 // Frames with the common restoration setting (gaborish + one EPF pass, XYB colour) take the fused tile kernel
 // FusedGabEpf1OutKernel; everything else runs the stage-by-stage kernels.
-__device__ __forceinline__ bool FusedEligible(const FrameDev& f, int unfused) { return !unfused && f.gab && f.epf_iters == 1 && f.color_mode <= 1 && f.upsampling == 1; }
+__device__ __forceinline__ bool FusedEligible(const FrameDev& f, int unfused) { return !unfused && f.gab && f.epf_iters == 1 && f.color_mode <= 1 && f.upsampling == 1 && f.post_mode == 0; }
 
 __global__ void GaborishKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
@@ -2541,6 +2551,29 @@ __device__ __forceinline__ float LinearToSrgb(float v) {
   return copysignf(x > 0.0031308f ? poly : lin, v);
 }
 
+// base/fast_math-inl.h FastLog2f / FastPow2f / FastPowf and the transfer functions built on them (stage_from_linear.cc OpGamma, TF_709)
+__device__ __forceinline__ float FastPowfDev(float base, float exponent) {
+  const int32_t x_bits = __float_as_int(base);
+  const int32_t exp_shifted = (x_bits - 0x3f2aaaab) >> 23;
+  const float t = __int_as_float(x_bits - (int32_t)((uint32_t)exp_shifted << 23)) - 1.0f;
+  float yp = fmaf(7.4245873327820566E-01f, t, 1.4287160470083755E+00f); yp = fmaf(yp, t, -1.8503833400518310E-06f);
+  float yq = fmaf(1.7409343003366853E-01f, t, 1.0096718572241148E+00f); yq = fmaf(yq, t, 9.9032814277590719E-01f);
+  const float x = (yp / yq + (float)exp_shifted) * exponent;
+  const float floorx = floorf(x);
+  const float exp = __int_as_float((int32_t)((uint32_t)((int32_t)floorx + 127) << 23));
+  const float frac = x - floorx;
+  float num = frac + 1.01749063e+01f;
+  num = fmaf(num, frac, 4.88687798e+01f);
+  num = fmaf(num, frac, 9.85506591e+01f);
+  num = num * exp;
+  float den = fmaf(frac, 2.10242958e-01f, -2.22328856e-02f);
+  den = fmaf(den, frac, -1.94414990e+01f);
+  den = fmaf(den, frac, 9.85506633e+01f);
+  return num / den;
+}
+__device__ __forceinline__ float GammaFromLinear(float v, float inverse_gamma) { return v <= 1e-5f ? 0.0f : FastPowfDev(v, inverse_gamma); }
+__device__ __forceinline__ float Rec709FromLinear(float v) { return v <= 0.018f ? 4.5f * v : fmaf(1.099f, FastPowfDev(v, 0.45f), -0.099f); }
+
 __device__ __forceinline__ uint16_t FloatToHalfBits(float fv) {
   const uint32_t x = __float_as_uint(fv);
   const uint32_t sign = (x >> 16) & 0x8000;
@@ -2616,7 +2649,7 @@ __device__ __forceinline__ void StorePixel(const FrameDev& f, int x, int y, floa
 // Channel 3 = the alpha extra channel (int samples scaled to float first).
 __global__ void UpsampleKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular || f.upsampling == 1) return;
+  if (f.is_modular || f.upsampling == 1 || f.post_mode) return;
   const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
   if (ox >= (int)f.img_w || oy >= (int)f.img_h) return;
   const int up = (int)f.upsampling, N = up / 2;
@@ -2648,7 +2681,7 @@ __global__ void UpsampleKernel(const FrameDev* __restrict__ frames) {
 
 __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
   const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular || FusedEligible(f, unfused)) return;
+  if (f.is_modular || f.post_mode || FusedEligible(f, unfused)) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= (int)f.img_w || y >= (int)f.img_h) return;
   float X, Y, B, A = 1.0f;
@@ -2665,7 +2698,7 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
     if (f.alpha_plane) A = (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor;
   }
   float r, g, b;
-  if (f.color_mode <= 1) {
+  if (f.color_mode <= 1 || f.color_mode >= 4) {
     const float gr = (Y + X) - f.neg_bias_cbrt[0];
     const float gg = (Y - X) - f.neg_bias_cbrt[1];
     const float gb = B - f.neg_bias_cbrt[2];
@@ -2676,6 +2709,8 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
     g = fmaf(f.opsin_inv[5], mb, fmaf(f.opsin_inv[4], mg, f.opsin_inv[3] * mr));
     b = fmaf(f.opsin_inv[8], mb, fmaf(f.opsin_inv[7], mg, f.opsin_inv[6] * mr));
     if (f.color_mode == 0) { r = LinearToSrgb(r); g = LinearToSrgb(g); b = LinearToSrgb(b); }
+    else if (f.color_mode == 4) { r = GammaFromLinear(r, f.inverse_gamma); g = GammaFromLinear(g, f.inverse_gamma); b = GammaFromLinear(b, f.inverse_gamma); }
+    else if (f.color_mode == 5) { r = Rec709FromLinear(r); g = Rec709FromLinear(g); b = Rec709FromLinear(b); }
   } else if (f.color_mode == 2) {
     const float c128 = 128.0f / 255, crcr = 1.402f, cgcb = -0.114f * 1.772f / 0.587f, cgcr = -0.299f * 1.402f / 0.587f, cbcb = 1.772f;
     const float yb = Y + c128;
@@ -2897,11 +2932,19 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
   const uint32_t lane = threadIdx.x & 63;
   BitReaderP br;
   br.Init(f.cs, f.mod_global_bitpos, f.cs_size);
-  uint32_t state = 0;
-  if (lane == 0) state = br.Read(32);
+  uint32_t state = 0x130000u;
+  if (lane == 0 && !f.mod_code.use_prefix) state = br.Read(32);
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0; mc.narrow_wp = f.mod_bits <= 12;
   mc.wp_scratch = f.mod_wp_scratch;
+  mc.slow = f.mod_code.use_prefix || f.mod_code.lz77;
+  Lz77State lz;
+  if (f.mod_code.lz77) {
+    uint32_t dist_mult = 0;
+    for (uint32_t c = 0; c < f.mod_global_decodable; c++) dist_mult = max(dist_mult, f.mod_chan[c].w);
+    lz.Init(f.lz_window, dist_mult);
+    mc.lz = &lz;
+  }
   for (uint32_t c = 0; c < f.mod_global_decodable; c++) {
     const ModChanDev mcd = f.mod_chan[c];
     if (mcd.w == 0 || mcd.h == 0) continue;  // (empty channels keep their index: property 0 is the position in the list)
@@ -3002,7 +3045,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
       if (!ok) SetError(f, kErrUnsupported);
       else {
         br.Init(f.cs, tmp.BitPos(), sec_end);
-        state = br.Read(32);
+        state = f.mod_code.use_prefix ? 0x130000u : br.Read(32);
         U.nch = nch;
         U.go = 1;
       }
@@ -3014,6 +3057,15 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = U.gh.wp; mc.narrow_wp = f.mod_bits <= 12;
   mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
   mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
+  mc.slow = f.mod_code.use_prefix || f.mod_code.lz77;
+  Lz77State lz;
+  if (f.mod_code.lz77) {
+    uint32_t dist_mult = 0;     // widest channel of the stream (modular/encoding/encoding.cc)
+    if (U.direct) { for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) dist_mult = max(dist_mult, (uint32_t)d.w); }
+    else for (int c = 0; c < U.nch; c++) dist_mult = max(dist_mult, (uint32_t)U.ch[c].w);
+    lz.Init(f.lz_window + (uint64_t)(1 + unit) * Lz77State::kWindow, dist_mult);
+    mc.lz = &lz;
+  }
   if (U.direct) {
     int k = 0;
     for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) DecodeChannelCoop(br, state, T, mc, d, k++);
