@@ -16,6 +16,25 @@ class Params(C.Structure):
                 ("num_passes", C.c_int32), ("permute_toc", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
+class Frame(C.Structure):
+    """Frame control of the synthesiser (tools/jxl_synth.cc jxlsynth_frame)."""
+    _fields_ = [("noise", C.c_int32), ("noise_lut", C.c_uint32 * 8)] + [(n, C.c_int32) for n in (
+        "frame_type", "have_crop", "crop_x0", "crop_y0", "canvas_w", "canvas_h", "blend_mode", "blend_source", "blend_clamp", "is_last",
+        "save_as_reference", "save_before_ct", "emit", "num_extra_hdr", "xyb_image")]
+
+
+def frame(**kw):
+    f = Frame(is_last=1, num_extra_hdr=-1)
+    lut = kw.pop("noise_lut", None)
+    if lut is not None:
+        f.noise = 1
+        for i, v in enumerate(lut):
+            f.noise_lut[i] = int(v)
+    for k, v in kw.items():
+        setattr(f, k, int(v))
+    return f
+
+
 _lib = None
 
 
@@ -36,6 +55,8 @@ def lib():
         L.jxlsynth_vardct2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.jxlsynth_modular.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.jxlsynth_modular2.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.jxlsynth_vardct3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(Frame), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.jxlsynth_modular3.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Frame), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -86,5 +107,32 @@ def encode_modular(img, bits=8, rct=False, squeeze=0):
     out = C.c_void_p(); n = C.c_size_t()
     rc = L.jxlsynth_modular2(arr, nchan, 1 if has_alpha else 0, w, h, bits, 1 if rct else 0, int(squeeze), C.byref(out), C.byref(n))
     if rc:
+        raise RuntimeError(L.jxlsynth_last_error().decode())
+    return _take(out, n)
+
+
+def encode_vardct_frame(rgb, fx, seed=1, distance=1.0, epf_iters=1, gab=1, strategy_mix=1, alpha=None):
+    """One VarDCT frame under frame control `fx` (see frame()): emit 0 = image header + frame, 1 = frame only."""
+    L = lib()
+    h, w = rgb.shape[:2]
+    p = Params(seed=seed, distance=distance, epf_iters=epf_iters, gab=gab, strategy_mix=strategy_mix, out_bits=8, orientation=1, upsampling=1, num_passes=1)
+    out = C.c_void_p(); n = C.c_size_t()
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    alpha_arr = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.uint8)
+    if L.jxlsynth_vardct3(a.ctypes.data, None if alpha_arr is None else alpha_arr.ctypes.data, w, h, C.byref(p), C.byref(fx), C.byref(out), C.byref(n)):
+        raise RuntimeError(L.jxlsynth_last_error().decode())
+    return _take(out, n)
+
+
+def encode_modular_frame(img, fx, bits=8, rct=False, squeeze=0):
+    """One lossless Modular frame under frame control `fx`."""
+    L = lib()
+    h, w, c = img.shape
+    has_alpha = c in (2, 4)
+    nchan = c - (1 if has_alpha else 0)
+    planes = [np.ascontiguousarray(img[..., i].astype(np.int32)) for i in range(c)]
+    arr = (C.c_void_p * c)(*[p.ctypes.data for p in planes])
+    out = C.c_void_p(); n = C.c_size_t()
+    if L.jxlsynth_modular3(arr, nchan, 1 if has_alpha else 0, w, h, bits, 1 if rct else 0, int(squeeze), C.byref(fx), C.byref(out), C.byref(n)):
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)

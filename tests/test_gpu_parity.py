@@ -561,3 +561,43 @@ def test_batch_api_mixed_sizes_and_lane_strides(jx):
             for i, r in enumerate(refs):
                 assert np.array_equal(b.output(i), r), (lf, hf, i)
         assert b.total_pixels == sum(len(r) // 3 for r in refs)
+
+
+# ---- multi-frame images and image features (round 2): frame tail kernels vs the oracle -----------------------------------------------
+def _stream_cases():
+    img = S.synthetic_image(5, 200, 136)
+    small = S.synthetic_image(9, 64, 48)
+    big = S.synthetic_image(6, 600, 400)
+    cases = {}
+    m0 = S.encode_modular_frame(img, S.frame(is_last=0, save_as_reference=1), bits=8)
+    for mode in (0, 1, 4):
+        cases["modular_layer_mode%d" % mode] = m0 + S.encode_modular_frame(small, S.frame(emit=1, have_crop=1, crop_x0=40, crop_y0=30, canvas_w=200, canvas_h=136, blend_mode=mode, blend_source=1), bits=8)
+    cases["modular_layer_offscreen"] = m0 + S.encode_modular_frame(small, S.frame(emit=1, have_crop=1, crop_x0=-20, crop_y0=100, canvas_w=200, canvas_h=136, blend_source=1), bits=8)
+    al = np.full((136, 200, 1), 200, np.uint8)
+    m0a = S.encode_modular_frame(np.dstack([img, al]), S.frame(is_last=0, save_as_reference=2), bits=8)
+    sa = np.dstack([small, (np.add.outer(np.arange(48), np.arange(64)) * 3 % 256).astype(np.uint8)])
+    for mode in (2, 3):
+        cases["modular_alpha_mode%d" % mode] = m0a + S.encode_modular_frame(sa, S.frame(emit=1, have_crop=1, crop_x0=10, crop_y0=20, canvas_w=200, canvas_h=136, blend_mode=mode, blend_source=2, blend_clamp=mode == 3), bits=8)
+    g0 = S.encode_vardct_frame(big, S.frame(is_last=0, save_as_reference=1), seed=3, strategy_mix=2)
+    cases["vardct_overlay"] = g0 + S.encode_vardct_frame(small, S.frame(emit=1, have_crop=1, crop_x0=300, crop_y0=160, canvas_w=600, canvas_h=400, blend_source=1), seed=4)
+    g1 = S.encode_vardct_frame(small, S.frame(emit=1, is_last=0, have_crop=1, crop_x0=100, crop_y0=60, canvas_w=600, canvas_h=400, blend_source=1), seed=4)
+    cases["vardct_three_layers_add"] = g0 + g1 + S.encode_vardct_frame(img, S.frame(emit=1, have_crop=1, crop_x0=-30, crop_y0=300, canvas_w=600, canvas_h=400, blend_mode=1, blend_source=0), seed=5, epf_iters=2)
+    cases["vardct_noise"] = S.encode_vardct_frame(big, S.frame(noise_lut=[30, 60, 90, 120, 150, 180, 210, 240]), seed=3, strategy_mix=2)
+    cases["vardct_noise_small_epf3"] = S.encode_vardct_frame(small, S.frame(noise_lut=[200] * 8), seed=3, epf_iters=3)
+    alpha = (np.add.outer(np.arange(400), np.arange(600)) % 256).astype(np.uint8)
+    v0a = S.encode_vardct_frame(big, S.frame(is_last=0, save_as_reference=3), seed=3, alpha=alpha)
+    cases["vardct_alpha_blend"] = v0a + S.encode_vardct_frame(img, S.frame(emit=1, have_crop=1, crop_x0=50, crop_y0=70, canvas_w=600, canvas_h=400, blend_mode=2, blend_source=3), seed=7,
+                                                            alpha=(np.add.outer(np.arange(136), np.arange(200)) * 2 % 256).astype(np.uint8))
+    return cases
+
+
+@pytest.mark.parametrize("name", ["modular_layer_mode0", "modular_layer_mode1", "modular_layer_mode4", "modular_layer_offscreen", "modular_alpha_mode2", "modular_alpha_mode3",
+                                  "vardct_overlay", "vardct_three_layers_add", "vardct_noise", "vardct_noise_small_epf3", "vardct_alpha_blend"])
+def test_multi_frame_and_feature_streams(jx, name):
+    """Reference / zero-duration layers, cropped frames (also partly outside the canvas), every frame blend mode, alpha, noise:
+    the frame tail of the HIP path against the oracle (u8 exact, f32 <= 1 ULP)."""
+    data = _stream_cases()[name]
+    nch = 4 if "alpha" in name else 3
+    check_against_oracle(jx, data, np.uint8, nch)
+    check_against_oracle(jx, data, np.float32, nch)
+    check_against_oracle(jx, data, np.uint16, 3)

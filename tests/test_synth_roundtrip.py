@@ -117,3 +117,55 @@ def test_default_4x_8x_upsampling_weights_decode():
         d = O.decode(S.encode_vardct(img, upsampling=up, custom_up_weights=0))
         assert (d.info.xsize, d.info.ysize) == (96, 64)
         assert psnr(d.image("u8", 3), img) > floor
+
+# ---- multi-frame images, blending, crops, noise (round 2) ------------------------------------------------------------------------
+def _layers():
+    img = S.synthetic_image(5, 200, 136)
+    small = S.synthetic_image(9, 64, 48)
+    return img, small
+
+
+@pytest.mark.parametrize("mode", [0, 1, 4])
+def test_layered_modular_frames_blend_like_the_arithmetic_says(mode):
+    """frame_header.cc BlendingInfo / blending.cc: a cropped lossless layer over a saved frame — replace, add, mul."""
+    img, small = _layers()
+    f0 = S.encode_modular_frame(img, S.frame(is_last=0, save_as_reference=1), bits=8)
+    f1 = S.encode_modular_frame(small, S.frame(emit=1, have_crop=1, crop_x0=40, crop_y0=30, canvas_w=200, canvas_h=136, blend_mode=mode, blend_source=1), bits=8)
+    px = O.decode(f0 + f1).image("u8", 3).astype(float)
+    exp = img.astype(float)
+    roi = exp[30:78, 40:104]
+    exp[30:78, 40:104] = small if mode == 0 else np.clip(roi + small, 0, 255) if mode == 1 else roi * small / 255.0
+    assert np.abs(px - exp).max() <= 0.5
+
+
+def test_layer_partly_outside_the_canvas_and_alpha_blending():
+    img, small = _layers()
+    f0 = S.encode_modular_frame(img, S.frame(is_last=0, save_as_reference=1), bits=8)
+    f1 = S.encode_modular_frame(small, S.frame(emit=1, have_crop=1, crop_x0=-20, crop_y0=100, canvas_w=200, canvas_h=136, blend_source=1), bits=8)
+    exp = img.copy(); exp[100:136, 0:44] = small[0:36, 20:64]
+    assert np.array_equal(O.decode(f0 + f1).image("u8", 3), exp)
+    al = np.full((136, 200, 1), 255, np.uint8)
+    f0a = S.encode_modular_frame(np.dstack([img, al]), S.frame(is_last=0, save_as_reference=2), bits=8)
+    sa = np.dstack([small, (np.add.outer(np.arange(48), np.arange(64)) * 3 % 256).astype(np.uint8)])
+    a = sa[..., 3:4] / 255.0
+    for mode in (2, 3):
+        f1a = S.encode_modular_frame(sa, S.frame(emit=1, have_crop=1, crop_x0=10, crop_y0=20, canvas_w=200, canvas_h=136, blend_mode=mode, blend_source=2), bits=8)
+        px = O.decode(f0a + f1a).image("u8", 4)
+        exp = img.astype(float)
+        roi = exp[20:68, 10:74]
+        exp[20:68, 10:74] = small * a + roi * (1 - a) if mode == 2 else np.clip(roi + small * a, 0, 255)
+        assert np.abs(px[..., :3] - exp).max() <= 0.5 and px[..., 3].min() == 255
+
+
+def test_vardct_layers_and_noise():
+    img, small = _layers()
+    base = O.decode(S.encode_vardct_frame(img, S.frame(), seed=3)).image("u8", 3)
+    ov = O.decode(S.encode_vardct_frame(small, S.frame(), seed=4)).image("u8", 3)
+    g0 = S.encode_vardct_frame(img, S.frame(is_last=0, save_as_reference=1), seed=3)
+    g1 = S.encode_vardct_frame(small, S.frame(emit=1, have_crop=1, crop_x0=100, crop_y0=60, canvas_w=200, canvas_h=136, blend_source=1), seed=4)
+    exp = base.copy(); exp[60:108, 100:164] = ov
+    assert np.array_equal(O.decode(g0 + g1).image("u8", 3), exp)
+    # noise: zero-mean, strength follows the LUT
+    weak = O.decode(S.encode_vardct_frame(img, S.frame(noise_lut=[10] * 8), seed=3)).image("u8", 3).astype(float)
+    strong = O.decode(S.encode_vardct_frame(img, S.frame(noise_lut=[120] * 8), seed=3)).image("u8", 3).astype(float)
+    assert 0.2 < np.abs(weak - base).mean() < np.abs(strong - base).mean() and abs((weak - base).mean()) < 0.3

@@ -86,6 +86,16 @@ struct Params {
   int num_passes = 1;     // 1..3: coefficients split into bit planes (pass p carries value >> shift[p], the last pass the remainder)
   int permute_toc = 0;    // != 0: sections stored in a shuffled order (seed), TOC carries the permutation
   int reserved[3] = {0};
+  // ---- frame control (multi-frame streams are assembled by concatenating the pieces): noise, frame type, crop, blending, slots
+  int noise = 0; uint32_t noise_lut[8] = {0};     // flag kNoise + 8 x u(10)
+  int frame_type = 0;                             // 0 regular, 2 reference only, 3 skip progressive
+  int have_crop = 0, crop_x0 = 0, crop_y0 = 0;    // frame size = the planes' size; image size = canvas_w x canvas_h
+  int canvas_w = 0, canvas_h = 0;                 // image size when it differs from the frame (crop) — 0: same
+  int blend_mode = 0, blend_source = 0, blend_clamp = 0;   // colour and every extra channel use the same blending info
+  int is_last = 1, save_as_reference = 0, save_before_ct = 0;
+  int emit = 0;                                   // 0 image header + frame, 1 frame only, 2 image header only
+  int num_extra_hdr = -1;                         // extra channels announced by the image header (-1: as the frame has)
+  int xyb_image = 0;                              // Modular frames: the image is XYB encoded (samples are Y, X, B - Y scaled by the LF factors)
 };
 
 // ---- modular sub-stream tokenisation with the fixed global tree --------------------------------------------------
@@ -265,27 +275,55 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
 // bit-plane split of the passes: 2 passes -> shifts {2, 0}; 3 passes -> {3, 1, 0}
 static int PassShift(int num_passes, int pass) { return pass + 1 == num_passes ? 0 : (num_passes == 2 ? 2 : (pass == 0 ? 3 : 1)); }
 
-static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool xyb, int num_extra, int group_shift, bool lf_default) {
+static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool xyb, int num_extra, int group_shift, bool lf_default, int frame_w = 0, int frame_h = 0) {
   w.put(0, 1);  // all_default
-  w.put(0, 2);  // regular frame
+  w.put((uint32_t)p.frame_type, 2);
   w.put(modular ? 1 : 0, 1);
-  WriteU64(w, (!modular && p.skip_lf_smoothing) ? 0x80 : 0);
+  WriteU64(w, ((!modular && p.skip_lf_smoothing) ? 0x80 : 0) | (p.noise ? 1 : 0));
   if (!xyb) w.put(0, 1);  // do_YCbCr
   const uint32_t ups_sel = p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : p.upsampling == 8 ? 3 : 0;
   w.put(ups_sel, 2);      // upsampling
   for (int i = 0; i < num_extra; i++) w.put(ups_sel, 2);   // ec_upsampling: same factor
   if (modular) w.put(group_shift, 2);
   if (!modular && xyb) { w.put(3, 3); w.put(2, 3); }
-  const int np = modular ? 1 : p.num_passes;
-  w.put((uint32_t)(np - 1), 2);  // num_passes (1, 2, 3)
-  if (np != 1) {
-    w.put(0, 2);                                         // num_downsample = 0
-    for (int i = 0; i + 1 < np; i++) w.put((uint32_t)PassShift(np, i), 2);   // shift of every pass but the last
+  if (p.frame_type != 2) {
+    const int np = modular ? 1 : p.num_passes;
+    w.put((uint32_t)(np - 1), 2);  // num_passes (1, 2, 3)
+    if (np != 1) {
+      w.put(0, 2);                                         // num_downsample = 0
+      for (int i = 0; i + 1 < np; i++) w.put((uint32_t)PassShift(np, i), 2);   // shift of every pass but the last
+    }
   }
-  w.put(0, 1);  // have_crop
-  // blending info (+ one per extra channel)
-  for (int i = 0; i < 1 + num_extra; i++) w.put(0, 2);  // mode Replace
-  w.put(1, 1);  // is_last
+  bool partial = false;
+  w.put(p.have_crop ? 1 : 0, 1);  // have_crop
+  if (p.have_crop) {
+    auto pack = [](int32_t v) { return v >= 0 ? (uint32_t)v * 2 : (uint32_t)(-v) * 2 - 1; };
+    if (p.frame_type != 2) {
+      WriteU32(w, pack(p.crop_x0), {8, 0}, {11, 256}, {14, 2304}, {30, 18688});
+      WriteU32(w, pack(p.crop_y0), {8, 0}, {11, 256}, {14, 2304}, {30, 18688});
+    }
+    WriteU32(w, (uint32_t)frame_w, {8, 0}, {11, 256}, {14, 2304}, {30, 18688});
+    WriteU32(w, (uint32_t)frame_h, {8, 0}, {11, 256}, {14, 2304}, {30, 18688});
+    const int cw = p.canvas_w ? p.canvas_w : frame_w, ch = p.canvas_h ? p.canvas_h : frame_h;
+    partial = p.crop_x0 > 0 || p.crop_y0 > 0 || frame_w + p.crop_x0 < cw || frame_h + p.crop_y0 < ch;
+  }
+  if (p.frame_type == 0 || p.frame_type == 3) {
+    // blending info (+ one per extra channel)
+    for (int i = 0; i < 1 + num_extra; i++) {
+      if (p.blend_mode < 3) w.put((uint32_t)p.blend_mode, 2); else { w.put(3, 2); w.put((uint32_t)p.blend_mode - 3, 2); }
+      if (num_extra > 0 && (p.blend_mode == 2 || p.blend_mode == 3)) w.put(0, 2);   // alpha channel 0
+      if (num_extra > 0 && (p.blend_mode == 2 || p.blend_mode == 3 || p.blend_mode == 4)) w.put(p.blend_clamp ? 1 : 0, 1);
+      if (p.blend_mode != 0 || partial) w.put((uint32_t)p.blend_source, 2);
+    }
+    w.put(p.is_last ? 1 : 0, 1);  // is_last
+  }
+  const bool is_last = (p.frame_type == 0 || p.frame_type == 3) ? p.is_last != 0 : false;
+  if (!is_last) w.put((uint32_t)p.save_as_reference, 2);
+  {
+    const bool can_ref = !is_last;      // (no animation: duration 0)
+    const bool full_replace = (p.frame_type == 0 || p.frame_type == 3) && p.blend_mode == 0 && !partial;
+    if (p.frame_type == 2 || (can_ref && full_replace)) w.put(p.save_before_ct ? 1 : 0, 1);
+  }
   w.put(0, 2);  // name length 0
   // RestorationFilter
   if (lf_default) w.put(1, 1);
@@ -666,6 +704,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   std::vector<BitWriter> sections;
   {  // LfGlobal
     BitWriter s;
+    if (p.noise) for (int i = 0; i < 8; i++) s.put(p.noise_lut[i] & 1023, 10);   // NoiseParams
     s.put(1, 1);  // LfChannelDequantization all_default
     WriteU32(s, global_scale, {11, 1}, {11, 2049}, {12, 4097}, {16, 8193});
     WriteU32(s, quant_lf, {0, 16}, {5, 1}, {8, 1}, {16, 1});
@@ -729,9 +768,11 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     sections.push_back(s);
   }
   BitWriter out;
-  WriteImageHeader(out, img_w, img_h, p, true, p.out_bits == 16 ? 16 : 8, alpha != nullptr, false);
+  const bool hdr_alpha = p.num_extra_hdr >= 0 ? p.num_extra_hdr > 0 : alpha != nullptr;
+  if (p.emit != 1) WriteImageHeader(out, p.canvas_w ? p.canvas_w : img_w, p.canvas_h ? p.canvas_h : img_h, p, true, p.out_bits == 16 ? 16 : 8, hdr_alpha, false);
+  if (p.emit == 2) return out.bytes;
   bool lf_default = p.gab == 1 && p.epf_iters == 2;
-  WriteFrameHeader(out, p, false, true, alpha ? 1 : 0, 1, lf_default);
+  WriteFrameHeader(out, p, false, true, alpha ? 1 : 0, 1, lf_default, img_w, img_h);
   WriteTOCAndSections(out, sections, ngroups == 1 && np == 1, (uint32_t)p.permute_toc);
   out.align();
   return out.bytes;
@@ -814,7 +855,7 @@ static void ApplySqueeze(std::vector<SChan>& ch, const std::vector<SqStep>& step
 }
 
 // squeeze: 0 = none, 1 = default chain (signalled with zero explicit steps), 2 = short explicit chain mixing in-place and appended residuals
-static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int nchan, int w, int h, int bits, bool has_alpha, bool rct, int squeeze) {
+static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int nchan, int w, int h, int bits, bool has_alpha, bool rct, int squeeze, const Params* fx = nullptr) {
   // channels: nchan colour (1 or 3) [+1 alpha].  Optional RCT type 6 (YCgCo) signalled as a global transform.
   const int group_shift = 1, gd = 256, lfd = gd * 8;
   const int xg = (w + gd - 1) / gd, yg = (h + gd - 1) / gd, ngroups = xg * yg;
@@ -938,9 +979,12 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
     sections.push_back(s);
   }
   BitWriter out;
-  Params p; p.out_bits = bits; p.gab = 0; p.epf_iters = 0;  // lossless: no restoration filters
-  WriteImageHeader(out, w, h, p, false, bits, has_alpha, nchan == 1);
-  WriteFrameHeader(out, p, true, false, has_alpha ? 1 : 0, group_shift, false);
+  Params p;
+  if (fx) p = *fx;
+  p.out_bits = bits; p.gab = 0; p.epf_iters = 0; p.noise = 0; p.upsampling = 1; p.num_passes = 1; p.skip_lf_smoothing = 0;  // lossless: no restoration filters
+  if (p.emit != 1) WriteImageHeader(out, p.canvas_w ? p.canvas_w : w, p.canvas_h ? p.canvas_h : h, p, p.xyb_image != 0, bits, has_alpha, nchan == 1);
+  if (p.emit == 2) return out.bytes;
+  WriteFrameHeader(out, p, true, p.xyb_image != 0, has_alpha ? 1 : 0, group_shift, false, w, h);
   WriteTOCAndSections(out, sections, single);
   out.align();
   return out.bytes;
@@ -1009,6 +1053,40 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
     }
     const float* planes[3] = {pl[0].data(), pl[1].data(), pl[2].data()};
     return finish(synth::EncodeVarDCT(planes, w, h, p, alpha8), out, n);
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+// Frame control for multi-frame / feature streams: a stream is the concatenation of one image header (emit = 2, or the first
+// frame emitted with emit = 0) and any number of frames (emit = 1), the last one with is_last = 1.
+struct jxlsynth_frame {
+  int32_t noise; uint32_t noise_lut[8];
+  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image;
+};
+static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
+  if (!fx) return;
+  p.noise = fx->noise; for (int i = 0; i < 8; i++) p.noise_lut[i] = fx->noise_lut[i];
+  p.frame_type = fx->frame_type; p.have_crop = fx->have_crop; p.crop_x0 = fx->crop_x0; p.crop_y0 = fx->crop_y0; p.canvas_w = fx->canvas_w; p.canvas_h = fx->canvas_h;
+  p.blend_mode = fx->blend_mode; p.blend_source = fx->blend_source; p.blend_clamp = fx->blend_clamp; p.is_last = fx->is_last; p.save_as_reference = fx->save_as_reference;
+  p.save_before_ct = fx->save_before_ct; p.emit = fx->emit; p.num_extra_hdr = fx->num_extra_hdr; p.xyb_image = fx->xyb_image;
+}
+int jxlsynth_vardct3(const uint8_t* rgb8, const uint8_t* alpha8, int w, int h, const jxlsynth_params* pp, const jxlsynth_frame* fx, uint8_t** out, size_t* n) {
+  try {
+    synth::Params p;
+    p.seed = pp->seed; p.distance = pp->distance; p.epf_iters = pp->epf_iters; p.gab = pp->gab; p.strategy_mix = pp->strategy_mix;
+    p.out_bits = pp->out_bits; p.skip_lf_smoothing = pp->skip_lf_smoothing;
+    ApplyFrame(p, fx);
+    std::vector<float> pl[3];
+    for (auto& v : pl) v.resize((size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; i++)
+      synth::LinearToXYB(synth::SrgbToLinear(rgb8[3 * i] / 255.0f), synth::SrgbToLinear(rgb8[3 * i + 1] / 255.0f), synth::SrgbToLinear(rgb8[3 * i + 2] / 255.0f), &pl[0][i], &pl[1][i], &pl[2][i]);
+    const float* planes[3] = {pl[0].data(), pl[1].data(), pl[2].data()};
+    return finish(synth::EncodeVarDCT(planes, w, h, p, alpha8), out, n);
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+int jxlsynth_modular3(const int32_t* const* planes, int nchan, int has_alpha, int w, int h, int bits, int rct, int squeeze, const jxlsynth_frame* fx, uint8_t** out, size_t* n) {
+  try {
+    synth::Params p;
+    ApplyFrame(p, fx);
+    return finish(synth::EncodeModular(planes, nchan, w, h, bits, has_alpha != 0, rct != 0, squeeze, &p), out, n);
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 // planes: nchan (+alpha) pointers to w*h int32 samples
