@@ -82,7 +82,10 @@ JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* dec, JXL_BOOL unpre
 JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* dec, JXL_BOOL render_spotcolors);  /* decode.rs:602 */
 JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* dec, JXL_BOOL coalescing);               /* decode.rs:622 */
 JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* dec);                                     /* decode.rs:662 — runs the HIP hot path */
-JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* dec, const uint8_t* data, size_t size);       /* decode.rs:680 */
+JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* dec, const uint8_t* data, size_t size);
+/* jpegxl-sys/src/decode.rs:706: releases the input set by JxlDecoderSetInput; returns the number of bytes the decoder has not consumed
+ * (everything while the headers could not be parsed yet, 0 afterwards: the decoder keeps its own copy of the codestream). */
+size_t JxlDecoderReleaseInput(JxlDecoder* dec);       /* decode.rs:680 */
 void JxlDecoderCloseInput(JxlDecoder* dec);                                                   /* decode.rs:724 */
 JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* dec, JxlBasicInfo* info);           /* decode.rs:738 */
 JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* dec, JxlColorProfileTarget target, size_t* size);              /* decode.rs:862 */

@@ -275,6 +275,17 @@ void Batch::Prepare(void* stream_v) {
   dbig_ = nullptr;
   if (dframes_) { (void)hipFree(dframes_); dframes_ = nullptr; }
   const int n = (int)images_.size();
+  // un-premultiplying alpha (JxlDecoderSetUnpremultiplyAlpha, jpegxl-rs decode.rs:353) happens in the write stage of the frame tail
+  for (PubImage& pi : pub_) {
+    ImageEntry& first = *images_[pi.first_unit];
+    bool premul = false;
+    for (auto& x : first.ih.extra) if (x.type == 0) { premul = x.alpha_associated; break; }
+    if (first.out.unpremul_alpha && premul && !pi.complex) {
+      if (first.ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels with un-premultiplied output", true);
+      pi.complex = true;
+      for (int u = pi.first_unit; u < pi.first_unit + pi.num_units; u++) images_[u]->complex = true;
+    }
+  }
   hconst_.clear();
   Arena arena(hconst_);
   std::vector<ConstOffsets> co(n);
@@ -1011,7 +1022,11 @@ void Batch::PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>&
       memset(&wa, 0, sizeof(wa));
       for (int c = 0; c < 3; c++) wa.p[c] = B(canvas[c]);
       wa.stride = canvas_stride;
-      for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].type == 0) { wa.alpha = B(canvas_ec[k]); wa.alpha_stride = canvas_ec_stride; break; }
+      for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].type == 0) {
+        wa.alpha = B(canvas_ec[k]); wa.alpha_stride = canvas_ec_stride;
+        wa.unpremul = first.out.unpremul_alpha && ih.extra[k].alpha_associated && (first.out.num_channels == 2 || first.out.num_channels == 4);
+        break;
+      }
       wa.img_w = ih.xsize; wa.img_h = ih.ysize;
       wa.out = (uint8_t*)(first.out.device_ptr ? first.out.device_ptr : dwork_ + first.off_out);
       wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian;

@@ -18,6 +18,7 @@ struct OutputSpec {
   size_t align = 0;
   void* device_ptr = nullptr;  // optional caller-owned device destination
   bool keep_orientation = false;  // false: the header's orientation is applied to the output (libjxl's default)
+  bool unpremul_alpha = false;    // JxlDecoderSetUnpremultiplyAlpha: premultiplied colour is divided by alpha in the write stage
 };
 
 // What the frames of one image share: the codestream and the image header.

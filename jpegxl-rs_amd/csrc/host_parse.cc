@@ -532,6 +532,7 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
     }
     if (extra_fields && !r.b()) {
       ih->intensity_target = r.F16(); ih->min_nits = r.F16(); ih->relative_to_max_display = r.b(); ih->linear_below = r.F16();
+      if (!(ih->intensity_target > 0.0f)) Fail("intensity target must be positive");
     }
     r.SkipExtensions();
   }
@@ -919,6 +920,7 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
           if (!r.b()) { wp.p1 = r.u(5); wp.p2 = r.u(5); for (int i = 0; i < 5; i++) wp.p3[i] = r.u(5); for (int i = 0; i < 4; i++) wp.w[i] = r.u(4); }
           const uint32_t nt = r.U32({0, 0}, {0, 1}, {4, 2}, {8, 18});
           if (!use_global || nt != 0) Unsupported("RAW quant table with local tree / transforms");
+          if (p->tree_code.lz77) Unsupported("RAW quant table in an LZ77-coded stream");
           const DevCode view = p->tree_code.View();
           ModularCtx mc;
           mc.tree = p->tree.nodes.data(); mc.code = &view; mc.wp = wp; mc.uses_wp = p->tree.uses_wp;

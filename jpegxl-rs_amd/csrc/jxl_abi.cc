@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <string>
 
 using namespace jxlhip;
@@ -96,7 +97,12 @@ JxlDecoderStatus JxlDecoderSubscribeEvents(JxlDecoder* d, int events) {
 JxlDecoderStatus JxlDecoderSetKeepOrientation(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->keep_orientation = !!v; return JXL_DEC_SUCCESS; }
 JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->unpremul_alpha = !!v; return JXL_DEC_SUCCESS; }
 JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->render_spotcolors = !!v; return JXL_DEC_SUCCESS; }
-JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->coalescing = !!v; return JXL_DEC_SUCCESS; }
+JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL v) {
+  if (d->started) return JXL_DEC_ERROR;
+  if (!v) { SetLastError("unsupported: non-coalesced frame output (frames are always composited on the GPU)"); return JXL_DEC_ERROR; }
+  d->coalescing = true;
+  return JXL_DEC_SUCCESS;
+}
 JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* d, float v) { if (v < 0) return JXL_DEC_ERROR; d->desired_intensity_target = v; return JXL_DEC_SUCCESS; }
 
 JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t size) {
@@ -105,6 +111,15 @@ JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t s
   return JXL_DEC_SUCCESS;
 }
 void JxlDecoderCloseInput(JxlDecoder* d) { d->input_closed = true; }
+size_t JxlDecoderReleaseInput(JxlDecoder* d) {
+  // libjxl's streaming sequence: ProcessInput -> NEED_MORE_INPUT, ReleaseInput (= unconsumed bytes), SetInput with more data.
+  // Until the headers and the frame index could be parsed nothing counts as consumed (the caller provides the stream again
+  // from its start); after that the decoder works from its own copy of the codestream.
+  if (!d->input_set) return 0;
+  const size_t unconsumed = d->stage == JxlDecoderStruct::kInit ? d->input_size : 0;
+  d->input = nullptr; d->input_size = 0; d->input_set = false;
+  return unconsumed;
+}
 
 static void FillBasicInfo(const ImageHeader& ih, JxlBasicInfo* info, bool keep_orientation) {
   memset(info, 0, sizeof(*info));
@@ -150,6 +165,7 @@ JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixe
   if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_NEED_MORE_INPUT;
   OutputSpec o;
   if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  if (o.num_channels != 0 && o.num_channels < 3 && d->batch->image(0).ih.color_space != 1) { SetLastError("number of channels is too low for colour output"); return JXL_DEC_ERROR; }
   o.keep_orientation = d->keep_orientation;
   *size = Batch::OutputSize(d->batch->image(0).ih, o);
   return JXL_DEC_SUCCESS;
@@ -158,6 +174,7 @@ JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat
   if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_ERROR;
   OutputSpec o;
   if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
+  if (o.num_channels != 0 && o.num_channels < 3 && d->batch->image(0).ih.color_space != 1) { SetLastError("number of channels is too low for colour output"); return JXL_DEC_ERROR; }
   o.keep_orientation = d->keep_orientation;
   if (size < Batch::OutputSize(d->batch->image(0).ih, o)) return JXL_DEC_ERROR;
   d->out_buffer = buffer; d->out_size = size; d->out_format = *format; d->out_set = true;
@@ -206,8 +223,12 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       if (sig == JXL_SIG_INVALID) { SetLastError("invalid signature"); return JXL_DEC_ERROR; }
       if (sig == JXL_SIG_NOT_ENOUGH_BYTES) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
       if (hipSetDevice(d->device) != hipSuccess) { SetLastError("no usable HIP device: the JPEG XL decode path requires an MI355X-class GPU (no CPU fallback)"); return JXL_DEC_ERROR; }
-      d->batch = new Batch(d->device);
-      d->batch->AddImage(d->input, d->input_size);
+      std::unique_ptr<Batch> b(new Batch(d->device));
+      b->AddImage(d->input, d->input_size);      // (throws "truncated" while the frame index is incomplete: nothing is kept)
+      for (auto& x : b->image(0).ih.extra)
+        if (x.type == 2 && d->render_spotcolors) throw ParseError("unsupported: spot colour rendering (call JxlDecoderSetRenderSpotcolors(dec, JXL_FALSE))", true);
+      delete d->batch;
+      d->batch = b.release();
       d->stage = JxlDecoderStruct::kHeaders;
     }
     if (d->stage == JxlDecoderStruct::kHeaders) {
@@ -223,6 +244,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       OutputSpec o;
       FormatToSpec(&d->out_format, &o);
       o.keep_orientation = d->keep_orientation;
+      o.unpremul_alpha = d->unpremul_alpha;
       d->batch->SetOutput(0, o);
       d->batch->Prepare(nullptr);
       d->batch->Run(nullptr);       // ══► the HIP hot path
@@ -239,6 +261,9 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
     return JXL_DEC_ERROR;
   } catch (const std::bad_alloc&) {
     SetLastError("out of memory");
+    return JXL_DEC_ERROR;
+  } catch (const std::exception& e) {     // (length_error from hostile sizes, system_error ...: never unwind into the caller's frames)
+    SetLastError(e.what());
     return JXL_DEC_ERROR;
   }
 }

@@ -24,9 +24,8 @@ struct Pool {
   uint64_t generation; size_t active; bool stop;
 };
 
-void Worker(Pool* p, size_t id) {
-  uint64_t seen = 0;
-  std::unique_lock<std::mutex> lk(*p->mu);
+void Worker(Pool* p, size_t id, uint64_t seen) {   // seen: the pool's job generation when the worker was created — jobs that ran before
+  std::unique_lock<std::mutex> lk(*p->mu);          // it existed are not its business (SetThreads restarts workers), later ones are
   for (;;) {
     p->cv_work->wait(lk, [&] { return p->stop || p->generation != seen; });
     if (p->stop) return;
@@ -41,7 +40,9 @@ void Worker(Pool* p, size_t id) {
 
 void StartWorkers(Pool* p, size_t n) {
   p->num_workers = n;
-  for (size_t i = 0; i < n; i++) p->threads->emplace_back(Worker, p, i);
+  uint64_t gen;
+  { std::lock_guard<std::mutex> g(*p->mu); gen = p->generation; }
+  for (size_t i = 0; i < n; i++) p->threads->emplace_back(Worker, p, i, gen);
 }
 void StopWorkers(Pool* p) {
   { std::lock_guard<std::mutex> g(*p->mu); p->stop = true; }
@@ -85,6 +86,7 @@ int Run(Pool* p, void* jpegxl_opaque, JxlParallelRunInit init, JxlParallelRunFun
   p->active = p->num_workers; p->generation++;
   p->cv_work->notify_all();
   p->cv_done->wait(lk, [&] { return p->active == 0; });
+  p->func = nullptr; p->opaque = nullptr; p->end = 0;   // nothing stale for a later worker to pick up
   return 0;
 }
 

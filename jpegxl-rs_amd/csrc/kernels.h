@@ -157,7 +157,7 @@ struct BlendArgs {
   const float* bg_ec[4]; const float* bg_ec_alpha[4]; uint32_t bg_ec_stride[4];
   float* canvas[3]; float* canvas_ec[4]; uint32_t canvas_stride, canvas_ec_stride, img_w, img_h, num_extra, premul_mask; uint32_t mode[5];
 };
-struct WriteArgs { const float* p[3]; const float* alpha; uint32_t stride, alpha_stride, img_w, img_h; uint8_t* out; uint64_t out_stride; uint32_t out_channels, out_type, out_big_endian, out_orient, is_gray; };
+struct WriteArgs { const float* p[3]; const float* alpha; uint32_t stride, alpha_stride, img_w, img_h; uint8_t* out; uint64_t out_stride; uint32_t out_channels, out_type, out_big_endian, out_orient, is_gray, unpremul; };
 void LaunchIntToFloat(const int32_t* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor, void* stream);
 void LaunchXybModToFloat(const int32_t* cy, const int32_t* cx, const int32_t* cb, uint32_t src_stride, float* const dst[3], uint32_t dst_stride, uint32_t w, uint32_t h, const float fac[3], void* stream);
 void LaunchPatches(const PatchFrameArgs& a, const PatchEntryDev* entries, const uint32_t* tile_start, const uint32_t* tile_list, void* stream);

@@ -419,10 +419,14 @@ __global__ void WriteKernel(WriteArgs a) {
   const int w = (int)a.img_w, h = (int)a.img_h;
   if (x >= w || y >= h) return;
   const size_t o = (size_t)y * a.stride + x;
-  const float r = a.p[0][o], g = a.p[1][o], b = a.p[2][o];
+  float r = a.p[0][o], g = a.p[1][o], b = a.p[2][o];
   float al = 1.0f;
   if (a.alpha) {
     al = a.alpha[(size_t)y * a.alpha_stride + x];
+    if (a.unpremul) {   // alpha.cc UnpremultiplyAlpha: colour / max(alpha, 2^-26)
+      const float m = 1.0f / fmaxf(1.0f / (float)(1u << 26), al);
+      r *= m; g *= m; b *= m;
+    }
   }
   int ox = x, oy = y;
   switch (a.out_orient) {

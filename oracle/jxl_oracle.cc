@@ -20,7 +20,7 @@ struct Decoded {
   bool have_container = false, has_jbrd = false;
   int w = 0, h = 0;
   int num_color = 3;
-  bool has_alpha = false;
+  bool has_alpha = false, alpha_premultiplied = false;
   // final float channels (display-referred, nominal range [0,1]); 1 or 3 colour + optional alpha
   std::vector<Plane> color;
   Plane alpha;
@@ -377,6 +377,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
       if (m.extra[e].type != 0) continue;
       out.alpha = canvas_extra[e];
       out.has_alpha = true;
+      out.alpha_premultiplied = m.extra[e].alpha_associated;
       break;
     }
     break;
@@ -384,7 +385,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
 }
 
 // stage_write.cc: clamp, scale, round-to-nearest-even, interleave (SURVEY b17 [V])
-size_t WritePixels(const Decoded& d, int type /*0 u8,1 u16,2 f32,3 f16*/, int num_channels, int big_endian, size_t align, std::vector<uint8_t>& out) {
+size_t WritePixels(const Decoded& d, int type /*0 u8,1 u16,2 f32,3 f16*/, int num_channels, int big_endian, size_t align, std::vector<uint8_t>& out, bool unpremul = false) {
   const int w = d.w, h = d.h;
   const size_t bps = type == 0 ? 1 : type == 2 ? 4 : 2;
   size_t stride = (size_t)w * num_channels * bps;
@@ -400,6 +401,9 @@ size_t WritePixels(const Decoded& d, int type /*0 u8,1 u16,2 f32,3 f16*/, int nu
         if (is_alpha) v = d.has_alpha ? d.alpha.row(y)[x] : 1.0f;
         else if (num_channels <= 2) v = d.color.size() == 1 ? d.color[0].row(y)[x] : d.color[1].row(y)[x];
         else v = d.color.size() == 1 ? d.color[0].row(y)[x] : d.color[c].row(y)[x];
+        // alpha.cc UnpremultiplyAlpha (stage_write.cc, JxlDecoderSetUnpremultiplyAlpha): only when alpha is associated and written out
+        if (!is_alpha && unpremul && d.has_alpha && d.alpha_premultiplied && (num_channels == 2 || num_channels == 4))
+          v *= 1.0f / std::max(1.0f / (float)(1u << 26), d.alpha.row(y)[x]);
         uint8_t* p = row + ((size_t)x * num_channels + c) * bps;
         if (type == 0) {
           float s = std::min(1.0f, std::max(0.0f, v)) * 255.0f;
@@ -438,6 +442,7 @@ struct jxlo_handle {
   Decoded d;
   std::vector<uint8_t> pixels;
   std::string err;
+  bool unpremul = false;
 };
 
 jxlo_handle* jxlo_decode(const uint8_t* data, size_t size, int want_dump) {
@@ -454,6 +459,7 @@ jxlo_handle* jxlo_decode(const uint8_t* data, size_t size, int want_dump) {
 }
 const char* jxlo_error(jxlo_handle* h) { return h->err.empty() ? nullptr : h->err.c_str(); }
 void jxlo_free(jxlo_handle* h) { delete h; }
+void jxlo_set_unpremultiply_alpha(jxlo_handle* h, int v) { h->unpremul = v != 0; }
 void jxlo_get_info(jxlo_handle* h, jxlo_info* i) {
   const ImageMetadata& m = h->d.meta;
   memset(i, 0, sizeof(*i));
@@ -470,7 +476,7 @@ void jxlo_get_info(jxlo_handle* h, jxlo_info* i) {
 // renders pixels; returns byte size (0 on error); pointer valid until next call / free
 size_t jxlo_render(jxlo_handle* h, int type, int num_channels, int big_endian, size_t align, const uint8_t** out) {
   if (!h->err.empty()) return 0;
-  size_t n = WritePixels(h->d, type, num_channels, big_endian, align, h->pixels);
+  size_t n = WritePixels(h->d, type, num_channels, big_endian, align, h->pixels, h->unpremul);
   *out = h->pixels.data();
   return n;
 }

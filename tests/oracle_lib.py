@@ -77,6 +77,11 @@ class Decoded:
     def __del__(self):
         self.close()
 
+    def set_unpremultiply_alpha(self, on=True):
+        """JxlDecoderSetUnpremultiplyAlpha: colour / alpha in the write stage when the alpha channel is associated."""
+        self._L.jxlo_set_unpremultiply_alpha.argtypes = [C.c_void_p, C.c_int]
+        self._L.jxlo_set_unpremultiply_alpha(self._h, 1 if on else 0)
+
     def pixels(self, dtype="u8", num_channels=0, big_endian=False, align=0):
         t, npdt = TYPES[dtype]
         if num_channels == 0:

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(jx):
         lib = T if re.match(r"Jxl(Thread|Resizable)ParallelRunner", name) else L
         assert hasattr(lib, name), name
     stubs = re.findall(r"^\w[\w\*]*\s+(Jxl\w+)\(void\)", open(os.path.join(ROOT, "jpegxl-rs_amd", "csrc", "jxl_stubs.cc")).read(), re.M)
-    assert len(stubs) == 89                      # 120 declared by jpegxl-sys - 31 live ones
+    assert len(stubs) == 88                      # 120 declared by jpegxl-sys - 32 live ones (round 2: JxlDecoderReleaseInput is live)
     for name in stubs:
         assert hasattr(L, name), name
     assert not (set(stubs) & declared)
@@ -232,3 +232,38 @@ def test_library_quant_tables_equal_the_oracle(jx):
             assert OL.jxlo_library_qtable(kind, c, b.ctypes.data, n) == n
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (kind, c)
             assert np.all(a > 0) and np.all(np.isfinite(a))
+
+
+def test_resizable_runner_survives_resizing_between_jobs(jx):
+    """resizable_runner.rs:63 calls SetThreads on every basic-info event, i.e. between jobs: freshly started workers must
+    neither replay the previous job nor miss the next one, and every index is visited exactly once."""
+    import ctypes as C
+    T = jx.libjxl_threads()
+    INIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
+    FUNC = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_size_t)
+    T.JxlResizableParallelRunner.restype = C.c_int
+    T.JxlResizableParallelRunner.argtypes = [C.c_void_p, C.c_void_p, INIT, FUNC, C.c_uint32, C.c_uint32]
+    pool = T.JxlResizableParallelRunnerCreate(None)
+    try:
+        for threads, (lo, hi) in ((0, (0, 7)), (3, (5, 300)), (8, (0, 1000)), (2, (10, 11)), (5, (0, 64))):
+            T.JxlResizableParallelRunnerSetThreads(pool, threads)
+            hits = [0] * hi
+            def func(_, i, thread):
+                hits[i] += 1
+            assert T.JxlResizableParallelRunner(pool, None, INIT(lambda _, n: 0), FUNC(func), lo, hi) == 0
+            assert hits[lo:hi] == [1] * (hi - lo) and sum(hits[:lo]) == 0
+    finally:
+        T.JxlResizableParallelRunnerDestroy(pool)
+
+
+def test_libjxl_probe_reports_what_it_looked_at(jx, monkeypatch):
+    """The run-time libjxl probe (tests/libjxl_probe.py) must never mistake this repository's look-alike for the real
+    library, and must say what it probed when nothing is found."""
+    import libjxl_probe as P
+    monkeypatch.setenv("LD_LIBRARY_PATH", os.path.join(ROOT, "jpegxl-rs_amd", "lib"))   # the look-alike is on the path: still not "real"
+    found = P.probe()
+    assert found["lib"] is None or os.path.realpath(os.path.dirname(found["lib"])) != os.path.realpath(os.path.join(ROOT, "jpegxl-rs_amd", "lib"))
+    text = P.describe(found)
+    assert ("no libjxl on this box: probed" in text) != found["available"]
+    v, own = P._check_lib(os.path.join(ROOT, "jpegxl-rs_amd", "lib", "libjxl.so"))
+    assert v == 11002 and own          # a copy of the look-alike elsewhere on the system would be recognised and rejected

@@ -74,8 +74,8 @@ def test_decode_simple_and_pixel_types(jx):
     check_against_oracle(jx, data, np.uint8, 3)
     check_against_oracle(jx, data, np.uint8, 4)
     check_against_oracle(jx, data, np.uint16, 4, endianness=2)
-    check_against_oracle(jx, data, np.float32, 2)
-    check_against_oracle(jx, data, np.uint16, 1)
+    check_against_oracle(jx, data, np.float32, 3)
+    check_against_oracle(jx, data, np.uint16, 4)
 
 
 def test_builder_reuse(jx):
@@ -236,7 +236,7 @@ def test_vardct_shapes_and_filters(jx, w, h, mix, epf, gab, skip):
     check_against_oracle(jx, data, np.uint8, 3)
     check_against_oracle(jx, data, np.uint16, 4, align=32)
     check_against_oracle(jx, data, np.float32, 3)
-    check_against_oracle(jx, data, np.float16, 1)
+    check_against_oracle(jx, data, np.float16, 3)
 
 
 def test_unaligned_varblocks_and_generic_idct(jx):
@@ -356,7 +356,7 @@ def test_vardct_with_alpha_extra_channel(jx, w, h):
     check_against_oracle(jx, data, np.uint8, 4)
     check_against_oracle(jx, data, np.uint8, 3)
     check_against_oracle(jx, data, np.float32, 4)
-    check_against_oracle(jx, data, np.uint16, 2)
+    check_against_oracle(jx, data, np.uint16, 4)
     data = S.encode_vardct(img, seed=9, strategy_mix=1, epf_iters=3, gab=0, alpha=al)   # unfused filter path
     check_against_oracle(jx, data, np.uint8, 4)
 
@@ -601,3 +601,81 @@ def test_multi_frame_and_feature_streams(jx, name):
     check_against_oracle(jx, data, np.uint8, nch)
     check_against_oracle(jx, data, np.float32, nch)
     check_against_oracle(jx, data, np.uint16, 3)
+
+
+def test_unpremultiply_alpha_setter(jx):
+    """decode.rs:353 JxlDecoderSetUnpremultiplyAlpha: an image whose alpha is associated comes out divided by alpha (alpha.cc
+    UnpremultiplyAlpha) when RGBA is requested, untouched otherwise."""
+    img = S.synthetic_image(5, 200, 136)
+    alpha = (64 + np.add.outer(np.arange(136), np.arange(200)) % 192).astype(np.uint8)
+    data = S.encode_vardct_frame(img, S.frame(alpha_premultiplied=1), seed=3, alpha=alpha)
+    ref = O.decode(data)
+    plain = ref.pixels("u8", 4).copy()
+    ref.set_unpremultiply_alpha(True)
+    want = ref.pixels("u8", 4).copy()
+    assert not np.array_equal(plain, want)
+    _, px = jx.decoder_builder(unpremul_alpha=True).decode_with(data, np.uint8)
+    assert np.array_equal(px, want)
+    _, px = jx.decoder_builder(unpremul_alpha=False).decode_with(data, np.uint8)
+    assert np.array_equal(px, plain)
+    _, pf = jx.decoder_builder(unpremul_alpha=True).decode_with(data, np.float32)
+    assert ulp_diff(pf, ref.pixels("f32", 4).view(np.float32)) <= 1
+    _, p3 = jx.decoder_builder(unpremul_alpha=True, pixel_format=jx.PixelFormat(num_channels=3)).decode_with(data, np.uint8)
+    assert np.array_equal(p3, ref.pixels("u8", 3))          # no alpha requested: nothing to divide by
+
+
+def test_streaming_input_sequence(jx):
+    """libjxl's streaming protocol (jpegxl-sys decode.rs:664-706): ProcessInput -> NEED_MORE_INPUT, ReleaseInput returns the
+    unconsumed bytes, SetInput again with more data."""
+    L = jx.libjxl()
+    L.JxlDecoderReleaseInput.restype = C.c_size_t
+    L.JxlDecoderReleaseInput.argtypes = [C.c_void_p]
+    data = fixture_bytes("sample.jxl")
+    dec = L.JxlDecoderCreate(None)
+    try:
+        assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_FULL_IMAGE) == 0
+        buf = np.frombuffer(data, np.uint8)
+        for cut in (1, 100, 2000):
+            assert L.JxlDecoderSetInput(dec, buf.ctypes.data, cut) == 0
+            assert L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_NEED_MORE_INPUT
+            assert L.JxlDecoderReleaseInput(dec) == cut
+        assert L.JxlDecoderSetInput(dec, buf.ctypes.data, len(data)) == 0
+        L.JxlDecoderCloseInput(dec)
+        assert L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_BASIC_INFO
+        assert L.JxlDecoderReleaseInput(dec) == 0
+    finally:
+        L.JxlDecoderDestroy(dec)
+    with pytest.raises(jx.GenericError):       # two channels of a colour image: libjxl's "number of channels is too low"
+        jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=2)).decode_with(data, np.uint8)
+
+
+def test_against_real_libjxl_when_the_box_has_one(jx, capsys):
+    """SURVEY §8c run-time oracle adapter: probe (in a subprocess — the soname collides with the look-alike) for a system
+    libjxl.so*, djxl / cjxl and Python JXL plugins.  If one exists, every committed stream and every reference fixture is decoded
+    with it and compared with the HIP path: u8 / u16 exact, f32 <= 1 ULP (BASELINE north_star).  If none exists the test says
+    exactly what was probed and skips — the float pipeline then stays PARITY-UNPINNED against libjxl."""
+    import libjxl_probe as P
+    found = P.probe()
+    with capsys.disabled():
+        print("\n[libjxl probe] " + P.describe(found))
+    if not found["available"]:
+        pytest.skip(P.describe(found))
+    names = [os.path.join(FIXTURES, n) for n in ("sample.jxl", "sample_grey.jxl", "2bit.jxl", "sample_jpg.jxl", "bench.jxl")]
+    names += sorted(os.path.join(GOLDEN, n) for n in os.listdir(GOLDEN) if n.endswith(".jxl"))
+    checked = 0
+    for path in names:
+        data = open(path, "rb").read()
+        info = O.decode(data).info
+        nch = 1 if info.num_color_channels == 1 else 3
+        for dtype, npdt in (("u8", np.uint8), ("u16", np.uint16), ("f32", np.float32)):
+            ref = P.decode(found, data, dtype, nch)
+            if ref is None:
+                continue
+            _, px = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=nch)).decode_with(data, npdt)
+            assert px.shape == ref.shape, path
+            if dtype == "f32":
+                assert ulp_diff(px, ref.astype(np.float32)) <= 1, (path, dtype)
+            else:
+                assert np.array_equal(px, ref), (path, dtype, int((px != ref).sum()))
+            checked += 1
+    assert checked > 0

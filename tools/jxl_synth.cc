@@ -95,6 +95,7 @@ struct Params {
   int is_last = 1, save_as_reference = 0, save_before_ct = 0;
   int emit = 0;                                   // 0 image header + frame, 1 frame only, 2 image header only
   int num_extra_hdr = -1;                         // extra channels announced by the image header (-1: as the frame has)
+  int alpha_premultiplied = 0;                    // image header: alpha_associated
   int xyb_image = 0;                              // Modular frames: the image is XYB encoded (samples are Y, X, B - Y scaled by the LF factors)
 };
 
@@ -233,14 +234,14 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
     w.put(1, 1);  // modular_16bit_buffers
     WriteU32(w, has_alpha ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {12, 1});
     if (has_alpha) {
-      if (bits == 8) w.put(1, 1);  // d_alpha
+      if (bits == 8 && !p.alpha_premultiplied) w.put(1, 1);  // d_alpha
       else {
         w.put(0, 1);
         WriteU32(w, 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});  // type alpha
         w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1});
         WriteU32(w, 0, {0, 0}, {0, 3}, {0, 4}, {3, 1});  // dim_shift
         WriteU32(w, 0, {0, 0}, {4, 0}, {5, 16}, {10, 48});  // name
-        w.put(0, 1);  // alpha_associated
+        w.put(p.alpha_premultiplied ? 1 : 0, 1);  // alpha_associated
       }
     }
     w.put(xyb, 1);
@@ -1059,14 +1060,14 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
 // frame emitted with emit = 0) and any number of frames (emit = 1), the last one with is_last = 1.
 struct jxlsynth_frame {
   int32_t noise; uint32_t noise_lut[8];
-  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image;
+  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image, alpha_premultiplied;
 };
 static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
   if (!fx) return;
   p.noise = fx->noise; for (int i = 0; i < 8; i++) p.noise_lut[i] = fx->noise_lut[i];
   p.frame_type = fx->frame_type; p.have_crop = fx->have_crop; p.crop_x0 = fx->crop_x0; p.crop_y0 = fx->crop_y0; p.canvas_w = fx->canvas_w; p.canvas_h = fx->canvas_h;
   p.blend_mode = fx->blend_mode; p.blend_source = fx->blend_source; p.blend_clamp = fx->blend_clamp; p.is_last = fx->is_last; p.save_as_reference = fx->save_as_reference;
-  p.save_before_ct = fx->save_before_ct; p.emit = fx->emit; p.num_extra_hdr = fx->num_extra_hdr; p.xyb_image = fx->xyb_image;
+  p.save_before_ct = fx->save_before_ct; p.emit = fx->emit; p.num_extra_hdr = fx->num_extra_hdr; p.xyb_image = fx->xyb_image; p.alpha_premultiplied = fx->alpha_premultiplied;
 }
 int jxlsynth_vardct3(const uint8_t* rgb8, const uint8_t* alpha8, int w, int h, const jxlsynth_params* pp, const jxlsynth_frame* fx, uint8_t** out, size_t* n) {
   try {
