@@ -5,6 +5,13 @@ A "step" decodes one batch of B synthetic 4K VarDCT frames per GPU (u8 RGB out) 
 (include/jxl_hip.h): compressed streams and tables are HBM-resident before the timed region, decoded pixels stay in
 HBM (a torch tensor).  With N > 1 ranks every rank decodes its own shard of the batch (weak scaling, no data-path
 collective) and the decoded pixels are gathered to rank 0 over RCCL (BASELINE.json north_star).
+--scaling strong --total-frames T fixes the job instead (BASELINE config 3: 1024 frames over the node): every rank decodes
+T / N frames per step, in chunks of at most --batch.
+
+Besides the headline (steady state, three batches in flight) the N = 1 line reports what a caller of the drop-in API sees:
+single_frame_ms (config 2: one 4K frame through decode_with, host to host), one_pass (config-3 shape: a fresh batch of 128
+frames decoded once, cold, no pipelining, with and without the host-side parse + upload), pcie_inclusive (the same pass plus
+the copy of the pixels back to host memory) and verified_vs_oracle (pixels of the timed batches against the CPU oracle).
 
 Contract: python bench.py --gpus N --steps K --warmup W  → rank 0 prints ONE JSON line.
 """
@@ -21,14 +28,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
 
 
-def make_streams(distinct, width, height, epf, seed0=1000):
-    """Seeded synthetic frames encoded by tools/jxlsynth.  Returns list of bytes."""
+def _make_stream(args):
     import synth_lib as S
-    out = []
-    for i in range(distinct):
-        img = S.synthetic_image(seed0 + i, width, height)
-        out.append(S.encode_vardct(img, seed=seed0 + i, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1))
-    return out
+    seed, width, height, epf = args
+    img = S.synthetic_image(seed, width, height)
+    return S.encode_vardct(img, seed=seed, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1)
+
+
+def make_streams(distinct, width, height, epf, seed0=1000):
+    """Seeded synthetic frames encoded by tools/jxlsynth, one per seed (different content, different
+    varblock maps and token counts).  Generated on the host cores in parallel (4.6 s per 4K frame).  Returns list of bytes."""
+    import multiprocessing as mp
+    jobs = [(seed0 + i, width, height, epf) for i in range(distinct)]
+    workers = max(1, min(len(jobs), os.cpu_count() or 1, 64))
+    if workers == 1:
+        return [_make_stream(j) for j in jobs]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_make_stream, jobs)
 
 
 def _oracle_decode_worker(data):
@@ -39,10 +55,41 @@ def _oracle_decode_worker(data):
     return time.time() - t, int(px[:: 4097].sum())
 
 
+def libjxl_baseline(found, streams, width, height, target_seconds=15.0):
+    """Real libjxl (if the box has one, tests/libjxl_probe.py): the decode loop of jpegxl-rs/benches/decode.rs:16-37, one process
+    per core, in subprocesses (the soname collides with this repository's look-alike)."""
+    import concurrent.futures as cf
+    import libjxl_probe as P
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    if P.decode(found, streams[0], "u8", 3) is None:
+        return None
+    dt = time.time() - t0
+    per_core = max(1, min(4, int(target_seconds / max(dt, 1e-3))))
+    jobs = [streams[i % len(streams)] for i in range(cores * per_core)]
+    t0 = time.time()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda d: P.decode(found, d, "u8", 3) is not None, jobs))
+    wall = time.time() - t0
+    return {"value": round(len(jobs) * width * height / 1e6 / wall, 3), "unit": "Mpixel/s", "cores": cores, "kind": "libjxl",
+            "sample": f"{len(jobs)} decodes of {width}x{height} VarDCT d1 frames by {found.get('lib') or found.get('djxl')} (version {found.get('lib_version')}), "
+                      f"one subprocess per decode incl. start-up, {cores} at a time"}
+
+
 def cpu_baseline(streams, width, height, target_seconds=15.0):
     """The CPU oracle (a scalar port of the libjxl algorithm: kind "port") timed on the host cores: one process per
-    core, each decoding whole frames of the same workload.  Bounded sample (~10-30 s of CPU work per core)."""
+    core, each decoding whole frames of the same workload.  Bounded sample (~10-30 s of CPU work per core).  A real libjxl
+    found by the run-time probe takes precedence (kind "libjxl")."""
     import multiprocessing as mp
+    try:
+        import libjxl_probe as P
+        found = P.probe()
+        if found["available"]:
+            r = libjxl_baseline(found, streams, width, height, target_seconds)
+            if r is not None:
+                return r
+    except Exception:
+        pass
     cores = max(1, min(os.cpu_count() or 1, 64))
     t0 = time.time()
     dt, _ = _oracle_decode_worker(streams[0])           # calibrate
@@ -58,13 +105,61 @@ def cpu_baseline(streams, width, height, target_seconds=15.0):
                       f"single-core rate {width * height / 1e6 / dt:.2f} Mpixel/s"}
 
 
+def extras(jx, torch, streams, W, H, device):
+    """What a caller of the drop-in API sees, measured after the timed region (N = 1): see the module docstring."""
+    import numpy as np
+    out = {}
+    dec = jx.decoder_builder()
+    ts = []
+    for i in range(6):
+        t0 = time.perf_counter()
+        dec.decode_with(streams[i % len(streams)], np.uint8)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    out["single_frame_ms"] = {"value": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "what": f"one {W}x{H} frame through decoder_builder().decode_with(u8): host bytes in, host pixels out "
+                              "(parse, device allocation, upload, decode, copy back); median of 5 after one warm-up", "mpixel_per_s": round(W * H / 1e6 / (sorted(ts[1:])[2] * 1e-3), 1)}
+    # BASELINE config 3 per-GPU shape: 128 frames, one pass, nothing resident beforehand, no pipelining
+    n = 128
+    torch.cuda.synchronize()
+    dst = torch.empty((n, H, W, 3), dtype=torch.uint8, device=torch.device("cuda", device))
+    host = torch.empty((n, H, W, 3), dtype=torch.uint8, pin_memory=True)
+    stream = torch.cuda.current_stream().cuda_stream
+    t0 = time.perf_counter()
+    b = jx.BatchDecoder(device)
+    for i in range(n):
+        b.add(streams[i % len(streams)], "uint8", 3, device_ptr=dst.data_ptr() + i * W * H * 3)
+    b.set_lane_stride(64, 1)
+    b.prepare(stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    b.decode(stream)
+    b.finish(stream)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    host.copy_(dst, non_blocking=True)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    mpx = n * W * H / 1e6
+    out["one_pass_128"] = {"decode_ms": round((t2 - t1) * 1e3, 2), "prepare_ms": round((t1 - t0) * 1e3, 2), "mpixel_per_s_decode_only": round(mpx / (t2 - t1), 1),
+                           "mpixel_per_s_with_prepare": round(mpx / (t2 - t0), 1),
+                           "what": "fresh batch of 128 frames (BASELINE config 3 per-GPU share), decoded once: prepare = host parse of headers / TOC / entropy tables + device "
+                                   "allocation + upload of the compressed streams; decode = every kernel, no overlap between batches"}
+    out["pcie_inclusive"] = {"mpixel_per_s": round(mpx / (t3 - t0), 1), "d2h_ms": round((t3 - t2) * 1e3, 2), "d2h_gbs": round(n * W * H * 3 / 1e9 / (t3 - t2), 1),
+                             "what": "the same pass plus the copy of the decoded pixels to pinned host memory (compressed input up, 24.9 MB per frame down)"}
+    del b
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "256")), help="frames per GPU per step")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames (cycled to fill the batch)")
+    ap.add_argument("--distinct", type=int, default=int(os.environ.get("JXL_BENCH_DISTINCT", "32")), help="distinct synthetic frames (cycled to fill the batch)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: --batch frames per GPU per step; strong: --total-frames per step over all GPUs")
+    ap.add_argument("--total-frames", type=int, default=1024, help="frames per step of the whole job with --scaling strong (BASELINE config 3)")
+    ap.add_argument("--no-extras", action="store_true", help="skip single_frame_ms / one_pass / pcie_inclusive (N = 1 only anyway)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of decoded frames with the CPU oracle after the run")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--epf", type=int, default=1)
@@ -74,7 +169,6 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the LF stage of step k+1 with the rest of step k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="compare frame 0 with the CPU oracle after the run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +193,11 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     B = args.batch
+    inner = 1                       # pipeline iterations per step
+    if args.scaling == "strong":
+        per_rank = max(1, args.total_frames // world)
+        B = min(args.batch, per_rank)
+        inner = max(1, per_rank // B)
     frame_bytes = W * H * 3
     pipeline = not args.no_pipeline
     nbuf = int(os.environ.get("JXL_BENCH_NBUF", "3")) if pipeline else 1   # batches in flight: step k uses buffer set k % nbuf
@@ -136,7 +235,7 @@ def main():
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
     rest_done = [torch.cuda.Event() for _ in range(nbuf)]
     gather_done = [torch.cuda.Event() for _ in range(nbuf)]
-    state = {"k": 0, "front_issued": 0, "limit": args.warmup}
+    state = {"k": 0, "front_issued": 0, "limit": args.warmup * inner}
 
     def issue_front(k, timed, gate=None):
         b = k % nbuf
@@ -184,18 +283,18 @@ def main():
                 main.wait_event(gather_done[b])
         state["k"] = k + 1
 
-    for i in range(args.warmup):
-        step(False, last=(i == args.warmup - 1))
+    for i in range(args.warmup * inner):
+        step(False, last=(i == args.warmup * inner - 1))
     torch.cuda.synchronize()
     for bt in batches:
         bt.finish(stream)
-    state["k"] = 0; state["front_issued"] = 0; state["limit"] = args.steps
+    state["k"] = 0; state["front_issued"] = 0; state["limit"] = args.steps * inner
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(True, last=(i == args.steps - 1))
+    for i in range(args.steps * inner):
+        step(True, last=(i == args.steps * inner - 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -216,7 +315,7 @@ def main():
             times[kk] = times.get(kk, 0.0) + vv
     stage_bytes = batch.stage_bytes
     if rank == 0:
-        total_px = world * B * W * H * args.steps
+        total_px = world * B * inner * W * H * args.steps
         value = total_px / elapsed / 1e6
         # dominant kernel = stage with the largest device time; roofline from its ALGORITHMIC bytes per launch
         stage_ms = {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"}
@@ -234,11 +333,11 @@ def main():
                 traffic = None
         result = {
             "metric": "Mpixel/s decode (4K VarDCT d1)", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": f"synthetic ({args.distinct} distinct seeded frames per GPU cycled over the batch, tools/jxlsynth)",
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": f"synthetic ({args.distinct} distinct seeded frames per GPU cycled over the batch, tools/jxlsynth; own synthesiser, 0.8 bpp — real d1 photographs run 1.5-2.5 bpp)",
             "config": {"workload": f"batch of {B} x {W}x{H} VarDCT d1 frames per GPU (XYB, ANS, var-block DCT8..32 mix, gaborish, EPF {args.epf}), u8 RGB out, "
                                    "inputs and outputs resident in HBM",
-                       "frames_per_gpu": B, "width": W, "height": H, "compressed_bytes_per_frame": int(batch.compressed_bytes // B),
+                       "frames_per_gpu": B * inner, "frames_per_launch": B, "width": W, "height": H, "compressed_bytes_per_frame": int(batch.compressed_bytes // B),
                        "lane_stride_lf": args.lane_stride_lf, "lane_stride_hf": args.lane_stride_hf,
                        "gather": bool(do_gather), "pipelined_steps": bool(pipeline), "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -250,11 +349,20 @@ def main():
         }
         if cpu is not None:
             result["cpu_baseline"] = cpu
-        if args.verify:
+        if not args.no_verify:
+            # outside the timed region: decoded frames of the batches the timed steps wrote, against the CPU oracle
             import oracle_lib as O
-            got = batch.output(0)
-            ref = O.decode(streams[0]).pixels("u8", 3)
-            result["verified_vs_oracle"] = bool(np.array_equal(got, ref))
+            ok, checked = True, []
+            for bi, bt in enumerate(batches):
+                for fi in sorted({0, B // 2, B - 1}):
+                    got = outs[bi][fi].cpu().numpy().reshape(-1)
+                    ref = O.decode(streams[fi % len(streams)]).pixels("u8", 3)
+                    ok = ok and bool(np.array_equal(got, ref))
+                    checked.append(f"{bi}:{fi}")
+            result["verified_vs_oracle"] = ok
+            result["verified_frames"] = checked
+        if world == 1 and not args.no_extras:
+            result.update(extras(jx, torch, streams, W, H, local_rank))
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

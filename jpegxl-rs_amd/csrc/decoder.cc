@@ -234,26 +234,40 @@ void Batch::SetOutput(int i, const OutputSpec& o) {
 uint64_t Batch::total_pixels() const { uint64_t n = 0; for (auto& pi : pub_) { const ImageHeader& ih = images_[pi.first_unit]->ih; n += (uint64_t)ih.xsize * ih.ysize; } return n; }
 uint64_t Batch::compressed_bytes() const { uint64_t n = 0; for (auto& pi : pub_) n += images_[pi.first_unit]->cs.size; return n; }
 void Batch::StageBytes(uint64_t out[6]) const {
-  // Compulsory HBM traffic of each stage: every input read once, every output written once.
+  // Compulsory (ALGORITHMIC) HBM traffic of each stage as the kernels are actually structured — every input the stage cannot avoid
+  // reading once, every output written once:
+  //  lf     LfGroup sections -> quantised LF (3 x i32) + block info + coefficient offset per 8x8 block
+  //  lfpost LF dequantisation, smoothing, LLF, EPF sigma: 76 B per block
+  //  hf     PassGroup sections -> the non-zero coefficients (i32 each; counted by the kernel, known after the first Finish)
+  //  idct   coefficient planes as stored (dense i32: 12 B/px) -> 3 f32 planes (12 B/px)
+  //  filter fused gaborish + EPF + colour + write: 12 B/px in, C x bytes out.  Stage-by-stage: 24 B/px per filter pass
+  //  out    stage-by-stage frames only: 12 B/px in, C x bytes out (the fused kernel has written the pixels already)
   for (int i = 0; i < 6; i++) out[i] = 0;
-  for (auto& e : images_) {
-    const FramePlan& p = e->plan;
+  for (size_t u = 0; u < images_.size(); u++) {
+    const ImageEntry& e = *images_[u];
+    const FramePlan& p = e.plan;
     if (p.modular) continue;
+    const ImageEntry& first = *images_[pub_[e.pub_index].first_unit];
     const uint64_t nblk = (uint64_t)p.bw * p.bh, npx = (uint64_t)p.width * p.height;
     uint64_t lf_sec = 0, hf_sec = 0;
-    if (p.single_section) { lf_sec = e->cs.size / 4; hf_sec = e->cs.size; }
+    if (p.single_section) { lf_sec = e.cs.size / 4; hf_sec = e.cs.size; }
     else {
       for (uint32_t s = 1; s < 1 + p.num_lf_groups; s++) lf_sec += p.sections[s].size;
       for (size_t s = 2 + p.num_lf_groups; s < p.sections.size(); s++) hf_sec += p.sections[s].size;
     }
-    out[0] += lf_sec + nblk * (3 * 4 + 4 + 4);                 // LF sections -> lfq (3 x i32) + blk_info + coef_off
-    out[1] += nblk * (12 + 12 + 12 + 12 + 12 + 16);            // dequant r/w, smooth r/w, llf r + (llf, sigma) w
-    out[2] += hf_sec + nblk * 64 * 3 * 4;                      // PassGroup sections -> i32 coefficients
-    out[3] += npx * (12 + 12);                                 // coefficients -> f32 planes
-    uint32_t nstages = (p.lf.gab ? 1 : 0) + (p.lf.epf_iters >= 3 ? 3 : p.lf.epf_iters);
-    out[4] += npx * 24 * nstages;                              // each filter stage reads and writes 3 f32 planes
-    const uint64_t bps = e->out.type == 0 ? 1 : e->out.type == 2 ? 4 : 2;
-    out[5] += npx * (12 + e->out.num_channels * bps);
+    const uint64_t bps = first.out.type == 0 ? 1 : first.out.type == 2 ? 4 : 2;
+    const uint64_t out_px = (uint64_t)first.out.num_channels * bps;
+    out[0] += lf_sec + nblk * (3 * 4 + 4 + 4);
+    out[1] += nblk * (12 + 12 + 12 + 12 + 12 + 16);
+    out[2] += hf_sec + (u < hf_written_.size() ? (uint64_t)hf_written_[u] * 4 : 0);
+    out[3] += npx * (12 + 12);
+    const bool fused = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && p.upsampling == 1 && !e.complex && !cfg.force_unfused_filters;
+    if (fused) out[4] += npx * (12 + out_px);
+    else {
+      const uint32_t nstages = (p.lf.gab ? 1 : 0) + (p.lf.epf_iters >= 3 ? 3 : p.lf.epf_iters);
+      out[4] += npx * 24 * nstages;
+      out[5] += npx * (12 + out_px);
+    }
   }
 }
 
@@ -368,6 +382,8 @@ void Batch::Prepare(void* stream_v) {
   status_off_ = take((size_t)n * 4);
   const size_t flags_off = take((size_t)n * 4);
   flags_off_ = flags_off;
+  hfw_off_ = take((size_t)n * 4);
+  hf_written_.assign(n, 0); decodes_since_finish_ = 0;
   cfg.idct_flags_known = 0; ran_once_ = false;
   // coefficient buffers of all frames are contiguous so that one memset clears them
   // quantised coefficients: an arena of this batch's own (never shared: it is cleared for the batch's next decode on an
@@ -505,6 +521,7 @@ void Batch::Prepare(void* stream_v) {
     f.bcm = (const BlockCtxDev*)(cbase + c.bcm);
     f.status = (uint32_t*)(dwork_ + status_off_) + i;
     f.frame_flags = (uint32_t*)(dwork_ + flags_off) + i;
+    f.hf_written = (uint32_t*)(dwork_ + hfw_off_) + i;
     f.out = (uint8_t*)(e.out.device_ptr ? e.out.device_ptr : dwork_ + e.off_out);
     f.out_stride = e.out_stride; f.out_channels = e.out.num_channels; f.out_type = e.out.type; f.out_big_endian = e.out.big_endian;
     f.out_orient = e.out.keep_orientation ? 1 : e.ih.orientation;
@@ -1079,6 +1096,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   const bool do_front = part == 0 || part == 1, do_hf = part == 0 || part == 2 || part == 3, do_tail = part == 0 || part == 2 || part == 4;
   const bool split = part != 0;                       // halves timed separately
   if (do_hf || do_tail) ran_once_ = true;
+  if (do_hf) decodes_since_finish_++;
   std::vector<void*>* evs = nullptr;
   if (timed) {
     if (do_front) { timed_events_.emplace_back(8, nullptr); }
@@ -1161,6 +1179,14 @@ void Batch::Finish(void* stream_v) {
     HIP_CHECK(hipMemset(dwork_ + status_off_, 0, (size_t)n * 4));
     if (status[i] & kErrUnsupported) throw ParseError("unsupported: stream feature on the device path (frame " + std::to_string(i) + ")", true);
     throw ParseError("corrupt stream (device status " + std::to_string(status[i]) + ", frame " + std::to_string(i) + ")", false);
+  }
+  if (any_vardct_ && decodes_since_finish_ > 0) {
+    // non-zero coefficients per decode of every frame (deterministic per stream): the HF stage's written bytes for StageBytes
+    std::vector<uint32_t> cnt(n, 0);
+    HIP_CHECK(hipMemcpy(cnt.data(), dwork_ + hfw_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) hf_written_[i] = cnt[i] / decodes_since_finish_;
+    HIP_CHECK(hipMemset(dwork_ + hfw_off_, 0, (size_t)n * 4));
+    decodes_since_finish_ = 0;
   }
   if (any_vardct_ && !cfg.idct_flags_known && ran_once_) {
     // the LF stage has classified every frame's varblock placement: later decodes of this batch skip the kernels nobody needs

@@ -125,7 +125,9 @@ class Batch {
   std::vector<PassDev> passes_host_;
   std::vector<size_t> pass_first_;
   bool any_multipass_ = false;
-  size_t flags_off_ = 0;
+  size_t flags_off_ = 0, hfw_off_ = 0;
+  std::vector<uint32_t> hf_written_;   // per unit: non-zero AC coefficients per decode (from the device counter, read by Finish)
+  uint32_t decodes_since_finish_ = 0;
   bool ran_once_ = false;         // a complete decode (incl. the LF stage) has been enqueued since Prepare
   size_t coeff_off_ = 0, coeff_bytes_ = 0, status_off_ = 0, modplane_off_ = 0, modplane_bytes_ = 0;
   bool prepared_ = false;

@@ -94,6 +94,7 @@ struct FrameDev {
   float* up_plane[4];             // upsampled X, Y, B (and alpha as float) planes, img_w x img_h
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
+  uint32_t* hf_written;           // running count of non-zero AC coefficients the HF stage wrote for this frame (bench accounting)
   uint32_t* lz_window;            // LZ77-coded Modular streams: 2^20-entry windows, one per stream (global, then LfGroup / PassGroup units)
   uint32_t post_mode;             // 1: the frame ends in its float planes (after the restoration filters); upsampling, colour transform and the
                                   // write stage are done by the host-planned frame tail (kernels_features.hip) — multi-frame images, image features

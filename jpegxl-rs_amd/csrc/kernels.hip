@@ -1384,6 +1384,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
     for (int i = 0; i < 8; i++) if ((x >> 2) == (uint32_t)i) nzrow[c][i] = (nzrow[c][i] & ~(0xFFu << ((x & 3) * 8))) | (v << ((x & 3) * 8));
   };
   int32_t* cbase[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
+  uint32_t nz_written = 0;                           // (bench accounting: coefficients this stream writes)
   for (uint32_t by = 0; by < gbh; by++) {
     for (uint32_t bx = 0; bx < gbw; bx++) {
       const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
@@ -1419,6 +1420,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
         const uint32_t nz_ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
         uint32_t nzeros = FastHybrid(br, state, code, code.Cluster(nz_ctx));
         if (nzeros + covered > size) { SetError(f, kErrNzeros); return; }
+        nz_written += nzeros;
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
         for (uint32_t ix = 0; ix < cx; ix++) nz_set(c, bx + ix, nzm);
         const uint32_t histo = ctx_offset + 37 * nctx + 458 * block_ctx;
@@ -1443,6 +1445,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   if (state != 0x130000u) { SetError(f, kErrAnsFinalState); return; }
   if (br.BitPos() > limit) { SetError(f, kErrOverrun); return; }
   if (f.hf_end_bitpos) f.hf_end_bitpos[g] = br.BitPos();
+  if (nz_written) atomicAdd(f.hf_written, nz_written);
 }
 
 // ---- SIMT variant: every lane decodes the stream of its own group; one token per lane per loop iteration -------------
@@ -1594,7 +1597,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
   uint2 ent_next = nvb ? LdG(vbl) : make_uint2(0, 0);
   uint32_t phase = 0;                     // 0: start next varblock, 1: read nzeros, 2: read a coefficient
   uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, lcx = 0, coff = 0, qlf = 0;
-  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0;
+  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, nz_total = 0;
   uint64_t end_bitpos = 0;
   const uint16_t* order = pd.orders[0];
   int32_t* blk = cbase0;
@@ -1649,6 +1652,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
       const uint32_t u = HybridSimt<ALL_LDS>(br, state, code, ctx);
       if (phase == 1) {
         nzeros = u;
+        nz_total += u;                               // (bench accounting: coefficients this stream writes)
         if (nzeros + covered > size) { err = kErrNzeros; done = true; }
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
         {  // the varblock's columns of the "non-zeros above" row: one masked read-modify-write of the aligned 8 bytes that
@@ -1687,6 +1691,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
   }
   if (err) { SetError(f, err); dead = true; }
   else if (!dead && f.hf_end_bitpos && pass + 1 == f.num_passes) f.hf_end_bitpos[g] = end_bitpos;   // the Modular part follows the last pass
+  if (!dead && nz_total) { atomicAdd(f.hf_written, nz_total); nz_total = 0; }
   }  // passes
 }
 

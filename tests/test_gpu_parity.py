@@ -171,18 +171,57 @@ def test_raw_ffi_sequence(jx):
     assert np.array_equal(buf, O.decode(fixture_bytes("sample.jxl")).pixels("u8", 3))
 
 
+def independent_float_decode_of_sample_jpg():
+    """Float decode of samples/sample.jpg that shares NO code with the oracle or the product: the Huffman-decoded JPEG coefficients
+    and quant tables (tests/golden/sample_jpg_coefficients.npz, made by make_golden.py's own JPEG parser), the integer
+    chroma-from-luma residual of SURVEY App. B.6, libjxl's dequantisation bias (dec_group.cc AdjustQuantBias: |q| = 1 ->
+    bias_c, else q - 0.145 / q), scipy's orthonormal IDCT and the JFIF YCbCr matrix — in float64."""
+    from scipy.fft import idctn
+    g = np.load(os.path.join(GOLDEN, "sample_jpg_coefficients.npz"))
+    co, qt = g["coefficients"].astype(np.int64), g["qtables"].astype(np.float64)
+    bh, bw = 7, 5
+    bias = [1 - 0.07005449891748593, 1 - 0.05465007330715401, 1 - 0.049935103337343655]       # Y, Cb (X slot), Cr (B slot)
+
+    def adj(b, v):
+        return np.where(v == 0, 0.0, np.where(np.abs(v) == 1, np.sign(v) * b, v - 0.145 / np.where(v == 0, 1, v)))
+
+    def residual(cq, f, qc):       # what the codestream stores for a chroma coefficient (ytox = -15, ytob = 47 in this file)
+        out = cq.copy()
+        ff = (f * 2048) // 84 if f >= 0 else -((-f * 2048) // 84)
+        for k in range(1, 64):
+            scale = (2048 * int(qt[0][k]) // int(qc[k])) * ff
+            out[..., k] = cq[..., k] - ((co[0][..., k] * ((scale + 1024) >> 11) + 1024) >> 11)
+        return out
+    dy = adj(bias[0], co[0]) * qt[0]
+    dcb = adj(bias[1], residual(co[1], -15, qt[1])) * qt[1] + (-15 / 84.0) * dy
+    dcr = adj(bias[2], residual(co[2], 47, qt[2])) * qt[2] + (47 / 84.0) * dy
+    for d, c in ((dy, 0), (dcb, 1), (dcr, 2)):
+        d[..., 0] = co[c][..., 0] * qt[c][0]                                                   # DC is not biased (it is the LF image)
+    Y, Cb, Cr = [idctn(k.reshape(bh, bw, 8, 8), axes=(2, 3), norm="ortho").transpose(0, 2, 1, 3).reshape(bh * 8, bw * 8) / 255.0 for k in (dy, dcb, dcr)]
+    yb = Y + 128 / 255
+    rgb = np.stack([yb + 1.402 * Cr, yb + (-0.114 * 1.772 / 0.587) * Cb + (-0.299 * 1.402 / 0.587) * Cr, yb + 1.772 * Cb], -1)
+    return rgb[:50, :40]
+
+
 def test_sample_jpg_jxl_pixels(jx):
-    """tests/decode.rs:123-139 input: a JPEG-transcoded VarDCT frame (YCbCr, RAW quant tables, custom block contexts and
-    coefficient order).  JPEG bit-stream reconstruction is a 'next' row, so reconstruct() yields pixels; they must equal the
-    oracle's and be close to what libjpeg makes of samples/sample.jpg."""
+    """tests/decode.rs:123-139 input: a JPEG-transcoded VarDCT frame written by the real encoder (YCbCr, RAW quant tables, custom
+    block contexts and coefficient order).  The HIP path's float output must equal an independent float64 decode of sample.jpg
+    (see above) to 0.01 of an 8-bit step — this pins RAW-table layout and scaling, the dequantisation bias, float chroma-from-luma,
+    the 8x8 IDCT, the YCbCr stage and the write stage ON THE GPU without the oracle.  (Against a *plain* JPEG decode the bound
+    would be 22 steps: libjxl's bias moves every |q| = 1 coefficient by 5-7 % of its quantisation step.)"""
     from PIL import Image
     data = fixture_bytes("sample_jpg.jxl")
     meta, px = check_against_oracle(jx, data, np.uint8, 3)
     assert (meta.width, meta.height) == (40, 50)
+    want = independent_float_decode_of_sample_jpg()
+    _, pf = jx.decoder_builder().decode_with(data, np.float32)
+    assert np.abs(pf.reshape(50, 40, 3).astype(np.float64) - want).max() * 255 < 0.01
+    q = np.clip(want, 0, 1) * 255
+    sure = np.abs(q - np.round(q)) < 0.49                                   # away from rounding ties
+    assert np.array_equal(px.reshape(50, 40, 3)[sure], np.round(q)[sure].astype(np.uint8))
     jpg = np.array(Image.open(os.path.join(FIXTURES, "sample.jpg")).convert("RGB")).astype(np.int32)
-    assert np.abs(px.reshape(50, 40, 3).astype(np.int32) - jpg).mean() < 3.0
-    meta, (kind, val) = jx.decoder_builder(init_jpeg_buffer=512).reconstruct(data)
-    assert kind == "pixels" and len(val) == 40 * 50 * 3
+    diff = np.abs(px.reshape(50, 40, 3).astype(np.int32) - jpg)
+    assert diff.mean() < 2.5 and diff.max() <= 24                          # libjpeg (integer IDCT, no bias): sanity only
 
 
 def test_bench_jxl_modular_groups(jx):
