@@ -130,6 +130,11 @@ int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc
 /* Host-only (needs no GPU): the dequantisation table (1 / weight, libjxl's coefficient layout) the decoder uses for library-default
  * quantisation kind `kind` (0..16, quant_weights.h), channel c (0 X, 1 Y, 2 B).  Writes min(n, cap) floats, returns n (0 on error). */
 size_t JxlHipLibraryQuantTable(int kind, int c, float* out, size_t cap);
+/* Host-only (needs no GPU): the serialisation half of JPEG reconstruction — parses a `jbrd` box payload and writes the JPEG file from
+ * quantised coefficients (components x blocks x 64 int16, natural order, 4:4:4) and quantisation tables (components x 64, natural order).
+ * *out_size: capacity in, bytes needed / written out.  Returns 0 on success, 2 if the buffer is too small, 1 on error. */
+int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const int16_t* coefficients, const int32_t* quant_tables,
+                         uint8_t* out, size_t* out_size);
 /* Creates a batch bound to HIP device `device`. */
 JxlHipBatch* JxlHipBatchCreate(int device);
 void JxlHipBatchDestroy(JxlHipBatch* batch);

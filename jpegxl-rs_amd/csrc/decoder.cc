@@ -146,7 +146,7 @@ void Batch::ShareBigArena(Batch* owner) {
 int Batch::AddImage(const uint8_t* data, size_t size) {
   std::shared_ptr<ImageShared> sh(new ImageShared());
   bool have_container = false, has_jbrd = false;
-  if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd)) throw ParseError("truncated", false);
+  if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, &sh->jbrd)) throw ParseError("truncated", false);
   uint64_t bitpos = 0;
   ParseImageHeader(sh->cs, &sh->ih, &bitpos);
   sh->ih.have_container = have_container;
@@ -1205,6 +1205,73 @@ void Batch::Finish(void* stream_v) {
     }
     cfg.idct_flags_known = 1;
   }
+}
+
+// ---- JPEG reconstruction -----------------------------------------------------------------------------------------------------------------
+bool Batch::CanReconstructJpeg(int i, std::string* why) {
+  auto no = [&](const char* m) { if (why) *why = m; return false; };
+  const PubImage& pi = pub_[i];
+  const ImageEntry& e = *images_[pi.first_unit];
+  if (e.shared->jbrd.empty()) return no("no jbrd box");
+  const FramePlan& p = e.plan;
+  if (pi.num_units != 1 || pi.complex || p.modular || e.ih.xyb_encoded || !p.do_ycbcr && e.ih.color_space != 1) return no("not a plain JPEG-transcoded frame");
+  if (p.upsampling != 1 || p.num_passes != 1 || !e.ih.extra.empty()) return no("not a plain JPEG-transcoded frame");
+  if (jpeg_data_.size() < pub_.size()) jpeg_data_.resize(pub_.size());
+  if (!jpeg_data_[i]) {
+    std::unique_ptr<JpegData> jd(new JpegData());
+    std::string err;
+    if (!ParseJbrd(e.shared->jbrd.data(), e.shared->jbrd.size(), jd.get(), &err)) { if (why) *why = err; return false; }
+    if (jd->components.size() != 3 && jd->components.size() != 1) return no("component count");
+    for (auto& s : jd->scan_info) if (!(s.Ss == 0 && s.Se == 63 && s.Al == 0 && s.Ah == 0)) return no("unsupported: progressive JPEG scan script");
+    for (uint8_t m : jd->marker_order) if (m == 0xC2 || m == 0xCA) return no("unsupported: progressive JPEG");
+    jpeg_data_[i] = std::move(jd);
+  }
+  return true;
+}
+
+std::vector<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
+  std::string why;
+  if (!CanReconstructJpeg(i, &why)) throw ParseError("JPEG reconstruction: " + why, true);
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!prepared_) Prepare(stream_v);
+  const int u = pub_[i].first_unit;
+  const ImageEntry& e = *images_[u];
+  const FramePlan& p = e.plan;
+  JpegData& jd = *jpeg_data_[i];
+  {
+    // quantisation tables from the frame's RAW table (HfGlobal; for one-group frames known only after Prepare): jxl channels X, Y, B
+    // = Cb, Y, Cr, and libjxl's coefficient layout is the transpose of JPEG's
+    const QuantTableSpec& q = p.qspec[0];
+    if (q.mode != 7) throw ParseError("JPEG reconstruction: quantisation table is not a RAW (JPEG) table", true);
+    for (size_t c = 0; c < jd.components.size(); c++) {
+      const int ch = jd.components.size() == 1 ? 1 : (c == 0 ? 1 : c == 1 ? 0 : 2);
+      if (q.raw[ch].size() != 64) throw ParseError("JPEG reconstruction: RAW table size", true);
+      JpegQuantTable& t = jd.quant[jd.components[c].quant_idx];
+      for (int v = 0; v < 8; v++) for (int u = 0; u < 8; u++) t.values[v * 8 + u] = q.raw[ch][u * 8 + v];
+    }
+  }
+  // entropy decode only: LF stage (LF coefficients = JPEG DC, block metadata) and HF stage (AC coefficients)
+  RunPart(stream_v, 1, false);
+  RunPart(stream_v, 3, false);
+  const size_t nblk = (size_t)p.bw * p.bh, ncomp = jd.components.size();
+  int16_t* dcoef = nullptr;
+  HIP_CHECK(hipMalloc((void**)&dcoef, ncomp * nblk * 64 * sizeof(int16_t)));
+  JpegCoefArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ncomp = (uint32_t)ncomp;
+  for (size_t c = 0; c < ncomp; c++) for (int k = 0; k < 64; k++) a.qt[c][k] = jd.quant[jd.components[c].quant_idx].values[k];
+  a.out = dcoef;
+  LaunchJpegCoefficients(dframes_, u, a, p.bw, p.bh, stream_v);
+  std::vector<int16_t> host(ncomp * nblk * 64);
+  hipError_t err = hipMemcpyAsync(host.data(), dcoef, host.size() * sizeof(int16_t), hipMemcpyDeviceToHost, stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(stream);
+  (void)hipFree(dcoef);
+  if (err != hipSuccess) throw ParseError(std::string("HIP error: ") + hipGetErrorString(err), false);
+  Finish(stream_v);
+  const int16_t* planes[3] = {host.data(), host.data() + (ncomp > 1 ? nblk * 64 : 0), host.data() + (ncomp > 2 ? 2 * nblk * 64 : 0)};
+  std::vector<uint8_t> out;
+  if (!WriteJpeg(jd, e.ih.xsize, e.ih.ysize, planes, &out, &why)) throw ParseError(why, true);
+  return out;
 }
 
 void Batch::CopyOutputToHost(int i, void* dst, size_t size, void* stream_v) {

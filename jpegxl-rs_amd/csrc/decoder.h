@@ -4,6 +4,7 @@
 #pragma once
 #include "host_parse.h"
 #include "kernels.h"
+#include "jpeg_recon.h"
 #include <memory>
 #include <string>
 #include <functional>
@@ -22,7 +23,7 @@ struct OutputSpec {
 };
 
 // What the frames of one image share: the codestream and the image header.
-struct ImageShared { Codestream cs; ImageHeader ih; };
+struct ImageShared { Codestream cs; ImageHeader ih; std::vector<uint8_t> jbrd; };   // jbrd: payload of the JPEG-reconstruction box, if any
 
 // One *frame* of an image: the unit the decode stages work on (one FrameDev each).  A single-frame image without image
 // features is one unit that writes its pixels itself; the frames of other ("complex") images end in float planes and a
@@ -66,6 +67,11 @@ class Batch {
   void Run(void* stream);
   // Waits, checks device status words; throws ParseError on stream errors.
   void Finish(void* stream);
+  // JPEG bit-stream reconstruction of image i (decode.rs:493 reconstruct): true if the image carries a usable `jbrd` box and is a plain
+  // single-frame JPEG transcode (DCT8 only, RAW quant table, 4:4:4).  ReconstructJpeg runs the entropy-decode stages on the GPU, gathers
+  // the quantised coefficients in JPEG layout and serialises the file on the host; throws ParseError if something does not fit.
+  bool CanReconstructJpeg(int i, std::string* why = nullptr);
+  std::vector<uint8_t> ReconstructJpeg(int i, void* stream);
   // Copies frame i's pixels to host memory (after Finish).
   void CopyOutputToHost(int i, void* dst, size_t size, void* stream);
   void* device_output(int i) const;
@@ -100,6 +106,7 @@ class Batch {
   };
   std::vector<ComplexBufs> cbufs_;
   std::vector<std::function<void(void*)>> post_ops_;
+  std::vector<std::unique_ptr<JpegData>> jpeg_data_;   // per image, parsed lazily by CanReconstructJpeg
   bool any_complex_ = false;
   void PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>& up_weights_off);
   void EnqueuePostOps(void* stream);

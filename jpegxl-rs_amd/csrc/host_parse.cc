@@ -442,7 +442,7 @@ SigResult CheckSignature(const uint8_t* buf, size_t len) {
   return len < 12 ? kSigNotEnoughBytes : kSigContainer;
 }
 
-bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd) {
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, std::vector<uint8_t>* jbrd) {
   *have_container = false; *has_jbrd = false;
   std::vector<uint8_t> tmp;
   const uint8_t* src = data; size_t n = size;
@@ -470,7 +470,7 @@ bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* h
       }
       if (!memcmp(type, "jxlc", 4)) { tmp.insert(tmp.end(), data + pos + hdr, data + end); found = true; }
       else if (!memcmp(type, "jxlp", 4)) { if (end >= pos + hdr + 4) { tmp.insert(tmp.end(), data + pos + hdr + 4, data + end); found = true; } }
-      else if (!memcmp(type, "jbrd", 4)) *has_jbrd = true;
+      else if (!memcmp(type, "jbrd", 4)) { *has_jbrd = true; if (jbrd) jbrd->assign(data + pos + hdr, data + end); }
       pos = end;
     }
     (void)last_unbounded;

@@ -173,7 +173,7 @@ enum SigResult { kSigNotEnoughBytes = 0, kSigInvalid = 1, kSigCodestream = 2, kS
 SigResult CheckSignature(const uint8_t* buf, size_t len);
 
 // Extracts the codestream; returns false if more input is needed (truncated container).
-bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd);
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, std::vector<uint8_t>* jbrd = nullptr);
 
 // Parses the image header; *frame_bitpos receives the bit position of the first frame header.
 void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bitpos);

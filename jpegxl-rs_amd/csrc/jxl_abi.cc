@@ -25,6 +25,7 @@ struct JxlDecoderStruct {
   const uint8_t* input; size_t input_size; bool input_set, input_closed;
   void* out_buffer; size_t out_size; JxlPixelFormat out_format; bool out_set;
   uint8_t* jpeg_buffer; size_t jpeg_size; bool jpeg_set;
+  bool jpeg_available; size_t jpeg_written; std::vector<uint8_t> jpeg_bytes;   // JPEG bit-stream reconstruction (jbrd)
   // progress
   enum Stage { kInit, kHeaders, kFrame, kDone } stage;
   int events_emitted;
@@ -46,6 +47,7 @@ static void ClearState(JxlDecoder* d) {
   d->input = nullptr; d->input_size = 0; d->input_set = d->input_closed = false;
   d->out_buffer = nullptr; d->out_size = 0; d->out_set = false;
   d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
+  d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
   delete d->batch; d->batch = nullptr;
 }
@@ -186,9 +188,10 @@ JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* d, uint8_t* data, size_t si
   return JXL_DEC_SUCCESS;
 }
 size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* d) {
-  // returns the bytes NOT yet written; JPEG bit-stream reconstruction is not implemented, nothing is ever written
-  size_t r = d->jpeg_set ? d->jpeg_size : 0;
-  d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
+  // jpegxl-sys decode.rs: returns the bytes of the buffer NOT written to.  Like libjxl (JxlToJpegDecoder::WriteOutput) the file is
+  // written in one piece: after JXL_DEC_JPEG_NEED_MORE_OUTPUT nothing has been consumed and the whole buffer counts as unused.
+  size_t r = d->jpeg_set ? d->jpeg_size - d->jpeg_written : 0;
+  d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false; d->jpeg_written = 0;
   return r;
 }
 
@@ -234,12 +237,40 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
     if (d->stage == JxlDecoderStruct::kHeaders) {
       if ((d->events_wanted & JXL_DEC_BASIC_INFO) && !(d->events_emitted & JXL_DEC_BASIC_INFO)) { d->events_emitted |= JXL_DEC_BASIC_INFO; return JXL_DEC_BASIC_INFO; }
       if ((d->events_wanted & JXL_DEC_COLOR_ENCODING) && !(d->events_emitted & JXL_DEC_COLOR_ENCODING)) { d->events_emitted |= JXL_DEC_COLOR_ENCODING; return JXL_DEC_COLOR_ENCODING; }
-      // JPEG reconstruction (jbrd) is not implemented: the decoder falls through to pixel output
+      // JPEG reconstruction (decode.rs:258-269): announced when the container carries a usable jbrd box; otherwise pixels
+      if ((d->events_wanted & JXL_DEC_JPEG_RECONSTRUCTION) && !(d->events_emitted & JXL_DEC_JPEG_RECONSTRUCTION)) {
+        d->events_emitted |= JXL_DEC_JPEG_RECONSTRUCTION;
+        std::string why;
+        if (d->batch->CanReconstructJpeg(0, &why)) { d->jpeg_available = true; return JXL_DEC_JPEG_RECONSTRUCTION; }
+        if (d->batch->image(0).has_jbrd) SetLastError("JPEG reconstruction unavailable, decoding to pixels: " + why);
+      }
       d->stage = JxlDecoderStruct::kFrame;
     }
     if (d->stage == JxlDecoderStruct::kFrame) {
       if ((d->events_wanted & JXL_DEC_FRAME) && !(d->events_emitted & JXL_DEC_FRAME)) { d->events_emitted |= JXL_DEC_FRAME; return JXL_DEC_FRAME; }
       if (!(d->events_wanted & JXL_DEC_FULL_IMAGE)) { d->stage = JxlDecoderStruct::kDone; return JXL_DEC_SUCCESS; }
+      if (d->jpeg_available && d->jpeg_set) {
+        // the caller asked for the JPEG file: entropy decode on the GPU, Huffman re-encode on the host, written in one piece
+        if (d->jpeg_bytes.empty()) {
+          try {
+            OutputSpec o; o.type = 0; o.num_channels = 3;
+            d->batch->SetOutput(0, o);
+            d->jpeg_bytes = d->batch->ReconstructJpeg(0, nullptr);
+          } catch (const ParseError& e) {
+            if (!e.unsupported) throw;
+            SetLastError(std::string(e.what()) + " (decoding to pixels instead)");
+            d->jpeg_available = false;
+          }
+        }
+        if (d->jpeg_available) {
+          if (d->jpeg_bytes.size() > d->jpeg_size) return JXL_DEC_JPEG_NEED_MORE_OUTPUT;
+          memcpy(d->jpeg_buffer, d->jpeg_bytes.data(), d->jpeg_bytes.size());
+          d->jpeg_written = d->jpeg_bytes.size();
+          d->stage = JxlDecoderStruct::kDone;
+          d->events_emitted |= JXL_DEC_FULL_IMAGE;
+          return JXL_DEC_FULL_IMAGE;
+        }
+      }
       if (!d->out_set) return JXL_DEC_NEED_IMAGE_OUT_BUFFER;
       OutputSpec o;
       FormatToSpec(&d->out_format, &o);
@@ -337,6 +368,25 @@ void JxlHipBatchStageBytes(const JxlHipBatch* h, uint64_t out[6]) { h->b->StageB
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* h) { return h->b->const_bytes() + h->b->work_bytes(); }
 int JxlHipBatchShareBuffers(JxlHipBatch* h, JxlHipBatch* owner) {
   try { h->b->ShareBigArena(owner ? owner->b : nullptr); return 0; } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
+}
+
+int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const int16_t* coefficients, const int32_t* quant_tables,
+                         uint8_t* out, size_t* out_size) {
+  try {
+    JpegData jd;
+    std::string err;
+    if (!ParseJbrd(jbrd, jbrd_size, &jd, &err)) { SetLastError(err); return 1; }
+    const size_t nblk = (size_t)((width + 7) / 8) * ((height + 7) / 8), nc = jd.components.size();
+    for (size_t c = 0; c < nc; c++) for (int k = 0; k < 64; k++) jd.quant[jd.components[c].quant_idx].values[k] = quant_tables[c * 64 + k];
+    const int16_t* planes[3] = {coefficients, coefficients + (nc > 1 ? nblk * 64 : 0), coefficients + (nc > 2 ? 2 * nblk * 64 : 0)};
+    std::vector<uint8_t> bytes;
+    if (!WriteJpeg(jd, width, height, planes, &bytes, &err)) { SetLastError(err); return 1; }
+    const size_t cap = *out_size;
+    *out_size = bytes.size();
+    if (cap < bytes.size()) { SetLastError("output buffer too small"); return 2; }
+    memcpy(out, bytes.data(), bytes.size());
+    return 0;
+  } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
 }
 
 size_t JxlHipLibraryQuantTable(int kind, int c, float* out, size_t cap) {

@@ -168,6 +168,11 @@ void LaunchNoise(const NoiseArgs& a, void* stream);
 void LaunchColor(const ColorArgs& a, void* stream);
 void LaunchBlend(const BlendArgs& a, void* stream);
 void LaunchWrite(const WriteArgs& a, void* stream);
+// JPEG reconstruction: quantised coefficients of a JPEG-transcoded frame in JPEG layout — component c (0 Y, 1 Cb, 2 Cr), block raster
+// order, 64 coefficients in natural (row-major) order: DC from the quantised LF image, AC from the coefficient planes with the integer
+// chroma-from-luma of the transcoder undone (dec_group.cc, jpeg branch).  qt: the JPEG quantisation tables, natural order.
+struct JpegCoefArgs { int16_t* out; uint32_t ncomp; int32_t qt[3][64]; };
+void LaunchJpegCoefficients(const FrameDev* frames, int fidx, const JpegCoefArgs& a, uint32_t bw, uint32_t bh, void* stream);
 void LaunchCopyPlane(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, void* stream);
 
 // names of the kernels (for profiling summaries)

@@ -452,6 +452,35 @@ __global__ void CopyPlaneKernel(const float* __restrict__ src, uint32_t src_stri
   dst[(size_t)y * dst_stride + x] = src[(size_t)y * src_stride + x];
 }
 
+// ---- JPEG reconstruction: coefficients back into JPEG layout --------------------------------------------------------------------------
+__global__ void JpegCoefKernel(const FrameDev* __restrict__ frames, int fidx, JpegCoefArgs a) {
+  const FrameDev& f = frames[fidx];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;       // (block, natural coefficient index)
+  const uint32_t nblk = f.bw * f.bh;
+  if (t >= nblk * 64) return;
+  const uint32_t o = t >> 6, i = t & 63, v = i >> 3, u = i & 7;
+  const uint32_t bx = o % f.bw, by = o / f.bw;
+  const uint32_t g = (by / 32) * f.xgroups + bx / 32;
+  const size_t base = (size_t)g * 65536 + f.coef_off[o] + (u * 8 + v);   // libjxl stores the transpose of JPEG's (v, u) layout
+  const int32_t y = i == 0 ? f.lfq[1][o] : f.coeff[1][base];
+  if (a.ncomp == 1) { a.out[(size_t)o * 64 + i] = (int16_t)y; return; }
+  a.out[(size_t)o * 64 + i] = (int16_t)y;
+  const size_t tile = (size_t)(by / 8) * f.cw + bx / 8;
+  for (int c = 1; c < 3; c++) {
+    const int ch = c == 1 ? 0 : 2;                                    // Cb rides in the X slot, Cr in the B slot
+    int32_t val;
+    if (i == 0) val = f.lfq[ch][o];
+    else {
+      const int32_t fac = c == 1 ? (int32_t)f.ytox[tile] : (int32_t)f.ytob[tile];
+      const int32_t ff = fac * 2048 / 84;                             // (C++ division: truncates toward zero)
+      const int32_t scale = (2048 * a.qt[0][i] / a.qt[c][i]) * ff;
+      const int32_t cfl = (y * ((scale + 1024) >> 11) + 1024) >> 11;
+      val = f.coeff[ch][base] + cfl;
+    }
+    a.out[((size_t)c * nblk + o) * 64 + i] = (int16_t)val;
+  }
+}
+
 inline dim3 Grid2(uint32_t w, uint32_t h) { return dim3((w + 31) / 32, (h + 7) / 8); }
 const dim3 kBlock2(32, 8);
 
@@ -484,6 +513,10 @@ void LaunchNoise(const NoiseArgs& a, void* stream) {
 void LaunchColor(const ColorArgs& a, void* stream) { hipLaunchKernelGGL(ColorKernel, Grid2(a.w, a.h), kBlock2, 0, (hipStream_t)stream, a); }
 void LaunchBlend(const BlendArgs& a, void* stream) { hipLaunchKernelGGL(BlendKernel, Grid2(a.img_w, a.img_h), kBlock2, 0, (hipStream_t)stream, a); }
 void LaunchWrite(const WriteArgs& a, void* stream) { hipLaunchKernelGGL(WriteKernel, Grid2(a.img_w, a.img_h), kBlock2, 0, (hipStream_t)stream, a); }
+void LaunchJpegCoefficients(const FrameDev* frames, int fidx, const JpegCoefArgs& a, uint32_t bw, uint32_t bh, void* stream) {
+  const uint32_t n = bw * bh * 64;
+  hipLaunchKernelGGL(JpegCoefKernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, frames, fidx, a);
+}
 void LaunchCopyPlane(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, void* stream) {
   hipLaunchKernelGGL(CopyPlaneKernel, Grid2(w, h), kBlock2, 0, (hipStream_t)stream, src, src_stride, dst, dst_stride, w, h);
 }

@@ -267,3 +267,35 @@ def test_libjxl_probe_reports_what_it_looked_at(jx, monkeypatch):
     assert ("no libjxl on this box: probed" in text) != found["available"]
     v, own = P._check_lib(os.path.join(ROOT, "jpegxl-rs_amd", "lib", "libjxl.so"))
     assert v == 11002 and own          # a copy of the look-alike elsewhere on the system would be recognised and rejected
+
+
+def test_jpeg_writer_reproduces_sample_jpg(jx):
+    """Host half of reconstruct() (decode.rs:493-514; reference test tests/decode.rs:123-139), no GPU needed: the jbrd box of
+    samples/sample_jpg.jxl plus the JPEG's quantised coefficients (Huffman-decoded independently by tests/golden/make_golden.py)
+    must serialise to samples/sample.jpg byte for byte (sha256 d28d532e...)."""
+    import ctypes as C
+    import hashlib
+    import struct
+    import numpy as np
+    from conftest import FIXTURES, GOLDEN
+    data = open(os.path.join(FIXTURES, "sample_jpg.jxl"), "rb").read()
+    pos, jbrd = 0, None
+    while pos < len(data):
+        n, t = struct.unpack(">I4s", data[pos:pos + 8])
+        if t == b"jbrd":
+            jbrd = data[pos + 8:pos + n]
+        pos += n
+    assert jbrd is not None and len(jbrd) == 162
+    g = np.load(os.path.join(GOLDEN, "sample_jpg_coefficients.npz"))
+    coef = np.ascontiguousarray(g["coefficients"].astype(np.int16))          # [3][7][5][64] natural order
+    qt = np.ascontiguousarray(g["qtables"].astype(np.int32))
+    L = jx.libjxl()
+    L.JxlHipDebugWriteJpeg.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    out = np.zeros(1 << 16, np.uint8)
+    n = C.c_size_t(10)
+    assert L.JxlHipDebugWriteJpeg(jbrd, len(jbrd), 40, 50, coef.ctypes.data, qt.ctypes.data, out.ctypes.data, C.byref(n)) == 2 and n.value == 1779
+    n = C.c_size_t(len(out))
+    assert L.JxlHipDebugWriteJpeg(jbrd, len(jbrd), 40, 50, coef.ctypes.data, qt.ctypes.data, out.ctypes.data, C.byref(n)) == 0, jx.last_error()
+    want = open(os.path.join(FIXTURES, "sample.jpg"), "rb").read()
+    assert out[:n.value].tobytes() == want
+    assert hashlib.sha256(want).hexdigest().startswith("d28d532e")

@@ -718,3 +718,23 @@ def test_against_real_libjxl_when_the_box_has_one(jx, capsys):
                 assert np.array_equal(px, ref), (path, dtype, int((px != ref).sum()))
             checked += 1
     assert checked > 0
+
+
+def test_jpeg_reconstruction(jx):
+    """tests/decode.rs:123-139 (`jpeg`): reconstruct() of the JPEG-transcoded fixture yields Data::Jpeg — here byte-identical to
+    samples/sample.jpg — growing the caller's buffer from 512 bytes through JXL_DEC_JPEG_NEED_MORE_OUTPUT; a file without a jbrd box
+    falls back to Data::Pixels(Uint16)."""
+    want = open(os.path.join(FIXTURES, "sample.jpg"), "rb").read()
+    dec = jx.decoder_builder(init_jpeg_buffer=512)
+    meta, (kind, val) = dec.reconstruct(fixture_bytes("sample_jpg.jxl"))
+    assert kind == "jpeg" and val == want
+    assert (meta.width, meta.height) == (40, 50)
+    from PIL import Image
+    import io
+    assert Image.open(io.BytesIO(val)).size == (40, 50)
+    meta, (kind, val) = dec.reconstruct(fixture_bytes("sample.jxl"))      # same decoder object again (Reset on success)
+    assert kind == "pixels" and val.dtype == np.uint16 and len(val) == 40 * 50 * 4
+    meta, (kind, val) = jx.decoder_builder().reconstruct(fixture_bytes("sample_jpg.jxl"))   # default 512 KiB buffer: one shot
+    assert kind == "jpeg" and val == want
+    # the pixel path of the same file is unaffected
+    check_against_oracle(jx, fixture_bytes("sample_jpg.jxl"), np.uint8, 3)
