@@ -55,14 +55,14 @@ struct ConstOffsets {
   size_t cs = 0, sec_off = 0, sec_size = 0, tree = 0, bcm = 0;
   size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0, mod_chan = 0, up_weights = 0;
   struct Pass { size_t ac_ctx = 0, ac_cfg = 0, ac_alias = 0, ac_pc = 0, ac_po = 0, ac_ps = 0; size_t orders[39] = {0}; };
-  std::vector<Pass> pass;
+  vec<Pass> pass;
   size_t qtable[17 * 3] = {0};
   bool has_qtable[17] = {false};
 };
 
 struct Arena {
-  std::vector<uint8_t>& buf;
-  explicit Arena(std::vector<uint8_t>& b) : buf(b) {}
+  vec<uint8_t>& buf;
+  explicit Arena(vec<uint8_t>& b) : buf(b) {}
   size_t Put(const void* src, size_t n, size_t align = 256) {
     size_t off = Align(buf.size(), align);
     buf.resize(off + std::max<size_t>(n, 4), 0);
@@ -157,7 +157,7 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
     if (!ok) throw ParseError("unsupported: output transfer function (PQ / HLG)", true);
   }
   // every frame of the image (frame_header.cc): reference-only / zero-duration layers first, the last one is displayed
-  std::vector<std::unique_ptr<ImageEntry>> units;
+  vec<std::unique_ptr<ImageEntry>> units;
   uint32_t visible = 0, nonvisible = 0;
   for (int k = 0;; k++) {
     if (k >= 256) throw ParseError("unsupported: more than 256 frames", true);
@@ -302,22 +302,22 @@ void Batch::Prepare(void* stream_v) {
   }
   hconst_.clear();
   Arena arena(hconst_);
-  std::vector<ConstOffsets> co(n);
+  vec<ConstOffsets> co(n);
   // natural coefficient orders (shared)
   size_t natural_off[13];
   {
     // (process-wide: the orders of the DCT128/256 buckets are 16K..64K entries each)
     static std::mutex mu;
-    static std::vector<uint16_t> natural[13];
+    static std::vector<uint16_t> natural[13];   // process-lifetime cache: never through a caller's allocator
     std::lock_guard<std::mutex> lock(mu);
     for (int b = 0; b < 13; b++) {
-      if (natural[b].empty()) natural[b] = NaturalCoeffOrder(kBucketStrategy[b]);
+      if (natural[b].empty()) { const vec<uint16_t> v = NaturalCoeffOrder(kBucketStrategy[b]); natural[b].assign(v.begin(), v.end()); }
       natural_off[b] = arena.Put(natural[b].data(), natural[b].size() * 2);
     }
   }
   // quant tables are shared between frames with identical specs
   struct QCache { const QuantTableSpec* spec; int kind; size_t off[3]; };
-  std::vector<QCache> qcache;
+  vec<QCache> qcache;
   auto spec_equal = [](const QuantTableSpec& a, const QuantTableSpec& b) {
     if (a.mode != b.mode || a.num_bands != b.num_bands || a.num_bands4 != b.num_bands4) return false;
     if (memcmp(a.bands, b.bands, sizeof(a.bands)) || memcmp(a.idw, b.idw, sizeof(a.idw)) || memcmp(a.dct2w, b.dct2w, sizeof(a.dct2w))) return false;
@@ -335,7 +335,7 @@ void Batch::Prepare(void* stream_v) {
     ConstOffsets& c = co[i];
     if (e.frame_index == 0 && e.out_size == 0) SetOutput(e.pub_index, e.out);
     if (e.frame_index == 0) c.cs = arena.Put(e.cs.data(), e.cs.padded_size()); else c.cs = co[i - e.frame_index].cs;   // frames share the codestream
-    std::vector<uint64_t> so, ss;
+    vec<uint64_t> so, ss;
     for (auto& s : p.sections) { so.push_back(s.offset); ss.push_back(s.size); }
     c.sec_off = arena.Put(so.data(), so.size() * 8);
     c.sec_size = arena.Put(ss.data(), ss.size() * 8);
@@ -371,7 +371,7 @@ void Batch::Prepare(void* stream_v) {
         mod_scratch, hf_end = 0, mod_wp = 0, up_plane[4] = {0, 0, 0, 0};
     size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0, lz_window = (size_t)-1;
   };
-  std::vector<WorkOffsets> wo(n);
+  vec<WorkOffsets> wo(n);
   mod_plane_offsets_.assign(n, {});
   mod_ops_.assign(n, {});
   cbufs_.assign(n, ComplexBufs());
@@ -405,7 +405,7 @@ void Batch::Prepare(void* stream_v) {
       const int upk = p.upsampling == 2 ? 0 : p.upsampling == 4 ? 1 : 2;
       const float* const kDefault[3] = {kUp2, kUp4, kUp8};
       static const size_t kCount[3] = {15, 55, 210};
-      const std::vector<float>& cw = e.ih.up_weights[upk];
+      const vec<float>& cw = e.ih.up_weights[upk];
       co[i].up_weights = cw.empty() ? arena.Put(kDefault[upk], kCount[upk] * 4) : arena.Put(cw.data(), cw.size() * 4);
     }
     if (!p.modular) {
@@ -425,10 +425,10 @@ void Batch::Prepare(void* stream_v) {
       if (!p.gchannels.empty()) {
         // extra channels (alpha, ...) ride in the frame's Modular sub-streams: planes, channel table, undo plan
         any_modchan_ = true;
-        std::vector<size_t>& mp = mod_plane_offsets_[i];
+        vec<size_t>& mp = mod_plane_offsets_[i];
         for (auto& ch : p.gchannels) mp.push_back(take((size_t)ch.w * ch.h * 4 + 64));
         PlanModularUndo(i, take);
-        std::vector<ModChanDev> table;
+        vec<ModChanDev> table;
         for (size_t k = 0; k < p.gchannels.size(); k++) table.push_back(ModChanDev{mp[k], p.gchannels[k].w, p.gchannels[k].h, p.gchannels[k].hshift, p.gchannels[k].vshift});
         co[i].mod_chan = arena.Put(table.data(), table.size() * sizeof(ModChanDev));
         const size_t gd = p.group_dim;
@@ -442,10 +442,10 @@ void Batch::Prepare(void* stream_v) {
     } else {
       any_modchan_ = true;
       // planes for every channel of the global image, then the plan that undoes the global transforms
-      std::vector<size_t>& mp = mod_plane_offsets_[i];
+      vec<size_t>& mp = mod_plane_offsets_[i];
       for (auto& ch : p.gchannels) mp.push_back(take((size_t)ch.w * ch.h * 4 + 64));
       PlanModularUndo(i, take);
-      std::vector<ModChanDev> table;
+      vec<ModChanDev> table;
       for (size_t k = 0; k < p.gchannels.size(); k++) table.push_back(ModChanDev{mp[k], p.gchannels[k].w, p.gchannels[k].h, p.gchannels[k].hshift, p.gchannels[k].vshift});
       co[i].mod_chan = arena.Put(table.data(), table.size() * sizeof(ModChanDev));
       const size_t gd = p.group_dim;
@@ -602,14 +602,14 @@ void Batch::Prepare(void* stream_v) {
     }
   };
 
-  std::vector<int> single;
+  vec<int> single;
   for (int i = 0; i < n; i++) if (images_[i]->plan.single_section && !images_[i]->plan.modular) single.push_back(i);
   if (!single.empty()) {
     // temporary upload of what exists so far
     uint8_t* tmpc = nullptr;
     HIP_CHECK(hipMalloc((void**)&tmpc, Align(hconst_.size())));
     HIP_CHECK(hipMemcpyAsync(tmpc, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
-    std::vector<FrameDev> tmpf;
+    vec<FrameDev> tmpf;
     for (int i : single) { fill_frame(i, tmpc); tmpf.push_back(frames_host_[i]); }
     HIP_CHECK(hipMemcpyAsync(dframes_, tmpf.data(), sizeof(FrameDev) * tmpf.size(), hipMemcpyHostToDevice, stream));
     if (any_modchan_) LaunchModularGlobal(dframes_, (int)tmpf.size(), cfg, stream_v);   // extra channels of a one-group frame precede the LfGroup
@@ -651,11 +651,11 @@ void Batch::Prepare(void* stream_v) {
         QCache qc; qc.spec = &p.qspec[k]; qc.kind = k;
         for (int ch = 0; ch < 3; ch++) {
           // the DCT128/256 tables are large (up to 64K weights per channel): computed once per process and spec
-          struct Big { QuantTableSpec spec; int kind, ch; std::vector<float> t; };
+          struct Big { QuantTableSpec spec; int kind, ch; std::vector<float> t; };   // process-lifetime cache: plain allocator
           static std::mutex mu;
           static std::vector<Big> big;
-          std::vector<float> local;
-          const std::vector<float>* t = &local;
+          vec<float> local;
+          const vec<float>* t = &local;
           if (k >= 13) {
             std::lock_guard<std::mutex> lock(mu);
             const Big* found = nullptr;
@@ -663,10 +663,10 @@ void Batch::Prepare(void* stream_v) {
             if (!found) {
               if (big.size() >= 48) big.clear();
               big.push_back(Big{p.qspec[k], k, ch, {}});
-              ComputeQuantTable(p.qspec[k], k, ch, &big.back().t);
+              { vec<float> tmp; ComputeQuantTable(p.qspec[k], k, ch, &tmp); big.back().t.assign(tmp.begin(), tmp.end()); }
               found = &big.back();
             }
-            local = found->t;
+            local.assign(found->t.begin(), found->t.end());
           } else ComputeQuantTable(p.qspec[k], k, ch, &local);
           qc.off[ch] = arena.Put(t->data(), t->size() * 4);
         }
@@ -695,7 +695,7 @@ void Batch::Prepare(void* stream_v) {
     HIP_CHECK(hipMalloc((void**)&dpasses_, sizeof(PassDev) * passes_host_.size()));
   }
   if (any_complex_) {
-    std::vector<size_t> upw(n, 0);
+    vec<size_t> upw(n, 0);
     for (int i = 0; i < n; i++) upw[i] = co[i].up_weights;
     PlanPostOps(hconst_, upw);
   }
@@ -750,9 +750,9 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
   const ImageEntry& e = *images_[i];
   const FramePlan& p = e.plan;
   struct HC { size_t off; uint32_t w, h; };
-  std::vector<HC> list;
+  vec<HC> list;
   for (size_t k = 0; k < p.gchannels.size(); k++) list.push_back({mod_plane_offsets_[i][k], p.gchannels[k].w, p.gchannels[k].h});
-  std::vector<ModOp>& ops = mod_ops_[i];
+  vec<ModOp>& ops = mod_ops_[i];
   ops.clear();
   for (int t = (int)p.gtransforms.size() - 1; t >= 0; t--) {
     const TransformDesc& td = p.gtransforms[t];
@@ -772,7 +772,7 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
       op.out[0] = idx.off;
       for (uint32_t c = 1; c < td.num_c; c++) op.out[c] = take(op.n * 4 + 64);
       ops.push_back(op);
-      std::vector<HC> nl;
+      vec<HC> nl;
       for (size_t k = 1; k < list.size(); k++) {
         if (k - 1 == td.begin_c) { for (uint32_t c = 0; c < td.num_c; c++) nl.push_back({op.out[c], idx.w, idx.h}); }
         else nl.push_back(list[k]);
@@ -829,7 +829,7 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
 // that turn each frame's planes into the image: dec_cache.cc PreparePipeline's stage order (patches, splines, upsampling,
 // noise | save as reference before the colour transform | XYB / YCbCr -> output colour space | blending onto the canvas |
 // save as reference | write).  Reference slots are tracked here (frame_header.cc save_as_reference / CanBeReferenced).
-void Batch::PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>& up_weights_off) {
+void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off) {
   Arena arena(hconst);
   struct Slot { bool valid = false, before_ct = false; size_t p[3] = {0, 0, 0}; uint32_t stride = 0; size_t ec[4] = {0, 0, 0, 0}; uint32_t ec_stride = 0; uint32_t w = 0, h = 0; };
   auto B = [this](size_t off) { return (float*)(dbig_ + off); };
@@ -878,7 +878,7 @@ void Batch::PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>&
       }
       // ---- patches
       if (p.flags & 2) {
-        std::vector<PatchEntryDev> entries;
+        vec<PatchEntryDev> entries;
         for (const PatchRefH& pr : p.feat.patches) {
           const Slot& sl = slots[pr.ref];
           if (!sl.valid) throw ParseError("patch refers to an empty reference slot", false);
@@ -899,13 +899,13 @@ void Batch::PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>&
         if (!entries.empty()) {
           // per 32x32 tile: the placements touching it, in dictionary order
           const uint32_t tx = (cw + 31) / 32, ty = (ch + 31) / 32;
-          std::vector<std::vector<uint32_t>> lists((size_t)tx * ty);
+          vec<vec<uint32_t>> lists((size_t)tx * ty);
           for (uint32_t k = 0; k < entries.size(); k++) {
             const PatchEntryDev& en = entries[k];
             for (uint32_t yy = (uint32_t)en.y / 32; yy <= ((uint32_t)en.y + en.ys - 1) / 32; yy++)
               for (uint32_t xx = (uint32_t)en.x / 32; xx <= ((uint32_t)en.x + en.xs - 1) / 32; xx++) lists[(size_t)yy * tx + xx].push_back(k);
           }
-          std::vector<uint32_t> start(lists.size() + 1, 0), flat;
+          vec<uint32_t> start(lists.size() + 1, 0), flat;
           for (size_t t = 0; t < lists.size(); t++) { start[t + 1] = start[t] + (uint32_t)lists[t].size(); flat.insert(flat.end(), lists[t].begin(), lists[t].end()); }
           if (flat.empty()) flat.push_back(0);
           const size_t o_e = arena.Put(entries.data(), entries.size() * sizeof(PatchEntryDev)), o_s = arena.Put(start.data(), start.size() * 4), o_l = arena.Put(flat.data(), flat.size() * 4);
@@ -1097,7 +1097,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   const bool split = part != 0;                       // halves timed separately
   if (do_hf || do_tail) ran_once_ = true;
   if (do_hf) decodes_since_finish_++;
-  std::vector<void*>* evs = nullptr;
+  vec<void*>* evs = nullptr;
   if (timed) {
     if (do_front) { timed_events_.emplace_back(8, nullptr); }
     if (timed_events_.empty()) timed_events_.emplace_back(8, nullptr);
@@ -1172,7 +1172,7 @@ void Batch::Finish(void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   HIP_CHECK(hipStreamSynchronize(stream));
   const int n = (int)images_.size();
-  std::vector<uint32_t> status(n, 0);
+  vec<uint32_t> status(n, 0);
   HIP_CHECK(hipMemcpy(status.data(), dwork_ + status_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
   for (int i = 0; i < n; i++) {
     if (!status[i]) continue;
@@ -1182,7 +1182,7 @@ void Batch::Finish(void* stream_v) {
   }
   if (any_vardct_ && decodes_since_finish_ > 0) {
     // non-zero coefficients per decode of every frame (deterministic per stream): the HF stage's written bytes for StageBytes
-    std::vector<uint32_t> cnt(n, 0);
+    vec<uint32_t> cnt(n, 0);
     HIP_CHECK(hipMemcpy(cnt.data(), dwork_ + hfw_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) hf_written_[i] = cnt[i] / decodes_since_finish_;
     HIP_CHECK(hipMemset(dwork_ + hfw_off_, 0, (size_t)n * 4));
@@ -1190,7 +1190,7 @@ void Batch::Finish(void* stream_v) {
   }
   if (any_vardct_ && !cfg.idct_flags_known && ran_once_) {
     // the LF stage has classified every frame's varblock placement: later decodes of this batch skip the kernels nobody needs
-    std::vector<uint32_t> flags(n, 0);
+    vec<uint32_t> flags(n, 0);
     HIP_CHECK(hipMemcpy(flags.data(), dwork_ + flags_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
     cfg.any_irregular_blocks = cfg.any_big_blocks = 0;
     cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = cfg.need_rare_special = 0;
@@ -1229,7 +1229,7 @@ bool Batch::CanReconstructJpeg(int i, std::string* why) {
   return true;
 }
 
-std::vector<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
+vec<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
   std::string why;
   if (!CanReconstructJpeg(i, &why)) throw ParseError("JPEG reconstruction: " + why, true);
   hipStream_t stream = (hipStream_t)stream_v;
@@ -1262,14 +1262,14 @@ std::vector<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
   for (size_t c = 0; c < ncomp; c++) for (int k = 0; k < 64; k++) a.qt[c][k] = jd.quant[jd.components[c].quant_idx].values[k];
   a.out = dcoef;
   LaunchJpegCoefficients(dframes_, u, a, p.bw, p.bh, stream_v);
-  std::vector<int16_t> host(ncomp * nblk * 64);
+  vec<int16_t> host(ncomp * nblk * 64);
   hipError_t err = hipMemcpyAsync(host.data(), dcoef, host.size() * sizeof(int16_t), hipMemcpyDeviceToHost, stream);
   if (err == hipSuccess) err = hipStreamSynchronize(stream);
   (void)hipFree(dcoef);
   if (err != hipSuccess) throw ParseError(std::string("HIP error: ") + hipGetErrorString(err), false);
   Finish(stream_v);
   const int16_t* planes[3] = {host.data(), host.data() + (ncomp > 1 ? nblk * 64 : 0), host.data() + (ncomp > 2 ? 2 * nblk * 64 : 0)};
-  std::vector<uint8_t> out;
+  vec<uint8_t> out;
   if (!WriteJpeg(jd, e.ih.xsize, e.ih.ysize, planes, &out, &why)) throw ParseError(why, true);
   return out;
 }

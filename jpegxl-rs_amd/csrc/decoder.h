@@ -23,7 +23,7 @@ struct OutputSpec {
 };
 
 // What the frames of one image share: the codestream and the image header.
-struct ImageShared { Codestream cs; ImageHeader ih; std::vector<uint8_t> jbrd; };   // jbrd: payload of the JPEG-reconstruction box, if any
+struct ImageShared { Codestream cs; ImageHeader ih; vec<uint8_t> jbrd; };   // jbrd: payload of the JPEG-reconstruction box, if any
 
 // One *frame* of an image: the unit the decode stages work on (one FrameDev each).  A single-frame image without image
 // features is one unit that writes its pixels itself; the frames of other ("complex") images end in float planes and a
@@ -71,7 +71,7 @@ class Batch {
   // single-frame JPEG transcode (DCT8 only, RAW quant table, 4:4:4).  ReconstructJpeg runs the entropy-decode stages on the GPU, gathers
   // the quantised coefficients in JPEG layout and serialises the file on the host; throws ParseError if something does not fit.
   bool CanReconstructJpeg(int i, std::string* why = nullptr);
-  std::vector<uint8_t> ReconstructJpeg(int i, void* stream);
+  vec<uint8_t> ReconstructJpeg(int i, void* stream);
   // Copies frame i's pixels to host memory (after Finish).
   void CopyOutputToHost(int i, void* dst, size_t size, void* stream);
   void* device_output(int i) const;
@@ -94,24 +94,24 @@ class Batch {
   void UploadFrames(void* stream);
   void EnqueueVarDCTFront(void* stream);
   int device_;
-  std::vector<std::unique_ptr<ImageEntry>> images_;   // decode units (frames), in image order
+  vec<std::unique_ptr<ImageEntry>> images_;   // decode units (frames), in image order
   struct PubImage { int first_unit = 0, num_units = 1; bool complex = false; };
-  std::vector<PubImage> pub_;                          // images as the caller counts them
+  vec<PubImage> pub_;                          // images as the caller counts them
   // ---- frame tail of complex images
   struct ComplexBufs {      // big-arena offsets of one complex unit ((size_t)-1: not allocated)
     size_t ecf[4], up[3], up_ec[4], noise[3], rgb[3], canvas[3], canvas_ec[4], pa[3], pb[3];
-    std::vector<size_t> ec_int;     // work-arena offsets of the decoded extra channels (int32, coded size)
+    vec<size_t> ec_int;     // work-arena offsets of the decoded extra channels (int32, coded size)
     size_t color_int[3];            // Modular frames: work-arena offsets of the colour channels after the inverse transforms
     uint32_t nb_color_int = 0;
   };
-  std::vector<ComplexBufs> cbufs_;
-  std::vector<std::function<void(void*)>> post_ops_;
-  std::vector<std::unique_ptr<JpegData>> jpeg_data_;   // per image, parsed lazily by CanReconstructJpeg
+  vec<ComplexBufs> cbufs_;
+  vec<std::function<void(void*)>> post_ops_;
+  vec<std::unique_ptr<JpegData>> jpeg_data_;   // per image, parsed lazily by CanReconstructJpeg
   bool any_complex_ = false;
-  void PlanPostOps(std::vector<uint8_t>& hconst, const std::vector<size_t>& up_weights_off);
+  void PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off);
   void EnqueuePostOps(void* stream);
-  std::vector<FrameDev> frames_host_;
-  std::vector<uint8_t> hconst_;
+  vec<FrameDev> frames_host_;
+  vec<uint8_t> hconst_;
   uint8_t* dconst_ = nullptr; size_t const_size_ = 0;
   uint8_t* dwork_ = nullptr; size_t work_size_ = 0;
   uint8_t* dbig_ = nullptr; size_t big_size_ = 0;   // coefficient + pixel planes (rest half only); may alias big_owner_'s
@@ -129,11 +129,11 @@ class Batch {
   void CheckFilterBuffers() const;
   FrameDev* dframes_ = nullptr;
   PassDev* dpasses_ = nullptr;
-  std::vector<PassDev> passes_host_;
-  std::vector<size_t> pass_first_;
+  vec<PassDev> passes_host_;
+  vec<size_t> pass_first_;
   bool any_multipass_ = false;
   size_t flags_off_ = 0, hfw_off_ = 0;
-  std::vector<uint32_t> hf_written_;   // per unit: non-zero AC coefficients per decode (from the device counter, read by Finish)
+  vec<uint32_t> hf_written_;   // per unit: non-zero AC coefficients per decode (from the device counter, read by Finish)
   uint32_t decodes_since_finish_ = 0;
   bool ran_once_ = false;         // a complete decode (incl. the LF stage) has been enqueued since Prepare
   size_t coeff_off_ = 0, coeff_bytes_ = 0, status_off_ = 0, modplane_off_ = 0, modplane_bytes_ = 0;
@@ -141,8 +141,8 @@ class Batch {
   int max_lf_groups_ = 0, max_groups_ = 0, max_w_ = 0, max_h_ = 0, max_bw_ = 0, max_bh_ = 0, max_epf_ = 0;
   bool any_gab_ = false, any_vardct_ = false, any_modular_ = false;
   FilterPlan fplan_;
-  struct ModFinish { int frame; std::vector<int> planes; };  // host-side channel lists for modular frames
-  std::vector<std::vector<size_t>> mod_plane_offsets_;
+  struct ModFinish { int frame; vec<int> planes; };  // host-side channel lists for modular frames
+  vec<vec<size_t>> mod_plane_offsets_;
   // one kernel launch of the host-planned tail of a Modular image: inverse global transforms, then the write stage
   struct ModOp {
     enum Kind { kRct, kPalette, kSqueeze, kOutput } kind = kRct;
@@ -152,13 +152,13 @@ class Batch {
     bool has_alpha = false;
     float color_factor = 1.0f, alpha_factor = 1.0f;
   };
-  std::vector<std::vector<ModOp>> mod_ops_;
+  vec<vec<ModOp>> mod_ops_;
   struct VarDctAlpha { bool has = false; size_t off = 0; float factor = 1.0f; };
-  std::vector<VarDctAlpha> vardct_alpha_;
+  vec<VarDctAlpha> vardct_alpha_;
   bool any_modchan_ = false;      // some frame carries Modular channels (Modular frames, VarDCT frames with extra channels)
   void EnqueueModularTail(void* stream);
   void PlanModularUndo(int i, const std::function<size_t(size_t)>& take);
-  std::vector<std::vector<void*>> timed_events_;
+  vec<vec<void*>> timed_events_;
   size_t timed_rest_cursor_ = 0;       // per frame: work-arena offsets of planes (incl. spare)
 };
 

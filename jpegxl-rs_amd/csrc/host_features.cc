@@ -48,7 +48,7 @@ float ContinuousIDCT(const float dct[32], float t) {
   return result;
 }
 
-void CatmullRom(std::vector<Pt> points, std::vector<Pt>& result) {
+void CatmullRom(vec<Pt> points, vec<Pt>& result) {
   if (points.empty()) return;
   if (points.size() == 1) { result.push_back(points[0]); return; }
   const int kNumPoints = 16;
@@ -75,7 +75,7 @@ void CatmullRom(std::vector<Pt> points, std::vector<Pt>& result) {
   result.push_back(points[points.size() - 2]);
 }
 
-void EquallySpaced(const std::vector<Pt>& points, std::vector<std::pair<Pt, float>>& out) {
+void EquallySpaced(const vec<Pt>& points, vec<std::pair<Pt, float>>& out) {
   const float kDist = 1.0f;
   if (points.empty()) return;
   Pt current = points.front();
@@ -106,13 +106,13 @@ void BuildSplineDrawList(const FrameFeatures& f, float y_to_x, float y_to_b, uin
   out->segments.clear(); out->row_start.clear(); out->indices.clear();
   static const float kChannelWeight[4] = {0.0042f, 0.075f, 0.07f, 0.3333f};
   const float kSqrt0_5 = 0.70710678118654752440f;
-  std::vector<std::pair<uint32_t, uint32_t>> by_y;
+  vec<std::pair<uint32_t, uint32_t>> by_y;
   const int32_t adj = f.spline_quant_adjust;
   const float inv_quant = adj >= 0 ? 1.0f / (1.0f + 0.125f * adj) : 1.0f - 0.125f * adj;
   for (size_t si = 0; si < f.splines.size(); si++) {
     const SplineH& q = f.splines[si];
     // QuantizedSpline::Dequantize
-    std::vector<Pt> cps;
+    vec<Pt> cps;
     int cx = (int)std::roundf((float)f.spline_start[si].first), cy = (int)std::roundf((float)f.spline_start[si].second);
     cps.push_back({(float)cx, (float)cy});
     int dx = 0, dy = 0;
@@ -137,9 +137,9 @@ void BuildSplineDrawList(const FrameFeatures& f, float y_to_x, float y_to_b, uin
       const float inv_dct_factor = i == 0 ? kSqrt0_5 : 1.0f;
       sigma_dct[i] = q.sigma_dct[i] * inv_dct_factor * kChannelWeight[3] * inv_quant;
     }
-    std::vector<Pt> inter;
+    vec<Pt> inter;
     CatmullRom(cps, inter);
-    std::vector<std::pair<Pt, float>> pts;
+    vec<std::pair<Pt, float>> pts;
     EquallySpaced(inter, pts);
     if (pts.size() > (1u << 24)) throw ParseError("spline too long", false);
     const float arc_length = (float)((double)pts.size() - 2) * 1.0f + pts.back().second;

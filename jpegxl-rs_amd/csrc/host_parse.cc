@@ -81,7 +81,7 @@ uint32_t ReadUintConfig(Reader& r, int log_alpha) {
   return split | (msb << 8) | (lsb << 16);
 }
 
-void ReadHistogram(Reader& r, std::vector<int>& counts) {
+void ReadHistogram(Reader& r, vec<int>& counts) {
   counts.clear();
   if (r.u(1)) {
     int ns = r.u(1) + 1;
@@ -108,7 +108,7 @@ void ReadHistogram(Reader& r, std::vector<int>& counts) {
   // 7-bit peek LUT of the log-count prefix code: entries {nbits, value}
   static const uint8_t base[16][2] = {{3, 10}, {7, 12}, {3, 7}, {4, 3}, {3, 6}, {3, 8}, {3, 9}, {4, 5}, {3, 10}, {4, 4}, {3, 7}, {4, 1}, {3, 6}, {3, 8}, {3, 9}, {4, 2}};
   static const uint8_t odd[8][2] = {{7, 12}, {5, 0}, {6, 11}, {5, 0}, {7, 13}, {5, 0}, {6, 11}, {5, 0}};
-  std::vector<int> logc(length, 0), same(length, 0);
+  vec<int> logc(length, 0), same(length, 0);
   int omit_log = -1, omit_pos = -1;
   for (int i = 0; i < length; i++) {
     r.br.Refill();
@@ -146,7 +146,7 @@ void ReadHistogram(Reader& r, std::vector<int>& counts) {
   if (counts[omit_pos] <= 0) Fail("ANS: omitted count <= 0");
 }
 
-void BuildAlias(std::vector<int> dist, int log_alpha, uint64_t* out) {
+void BuildAlias(vec<int> dist, int log_alpha, uint64_t* out) {
   const int T = 1 << log_alpha, B = 4096 >> log_alpha;
   while (!dist.empty() && dist.back() == 0) dist.pop_back();
   if (dist.empty()) dist.assign(1, 4096);
@@ -157,7 +157,7 @@ void BuildAlias(std::vector<int> dist, int log_alpha, uint64_t* out) {
       return;
     }
   }
-  std::vector<int> cut(T, 0), right(T, 0), offs1(T, 0), over, under;
+  vec<int> cut(T, 0), right(T, 0), offs1(T, 0), over, under;
   for (size_t i = 0; i < dist.size(); i++) cut[i] = dist[i];
   for (int i = 0; i < T; i++) { if (cut[i] > B) over.push_back(i); else if (cut[i] < B) under.push_back(i); }
   while (!over.empty()) {
@@ -176,9 +176,9 @@ void BuildAlias(std::vector<int> dist, int log_alpha, uint64_t* out) {
 }
 
 // Brotli-style prefix code → canonical (count per length, symbols sorted by (length, value))
-void ReadPrefixCode(Reader& r, int alphabet, uint16_t* count16, std::vector<uint16_t>& syms) {
+void ReadPrefixCode(Reader& r, int alphabet, uint16_t* count16, vec<uint16_t>& syms) {
   for (int i = 0; i < 16; i++) count16[i] = 0;
-  std::vector<uint8_t> lens(alphabet, 0);
+  vec<uint8_t> lens(alphabet, 0);
   auto finish = [&]() {
     int nonzero = 0, last = 0;
     for (int i = 0; i < alphabet; i++) if (lens[i]) { nonzero++; last = i; }
@@ -260,7 +260,7 @@ void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77 
 
 struct HostSymbolReader {  // symbol reader over a HostCode, for the small global streams parsed on the host
   Reader& r; const HostCode& hc; DevCode view; AnsReader ans;
-  std::vector<uint32_t> window; Lz77State lz;
+  vec<uint32_t> window; Lz77State lz;
   HostSymbolReader(Reader& rr, const HostCode& c, uint32_t dist_multiplier = 0) : r(rr), hc(c), view(c.View()) {
     ans.Init(r.br, view);
     if (hc.lz77) { window.assign(Lz77State::kWindow, 0); lz.Init(window.data(), dist_multiplier); }
@@ -277,7 +277,7 @@ struct HostSymbolReader {  // symbol reader over a HostCode, for the small globa
   void CheckFinal() { if (!ans.FinalOk(view)) Fail("ANS final state"); }
 };
 
-void ReadContextMap(Reader& r, uint32_t num_ctx, std::vector<uint8_t>& map, uint32_t* num_clusters) {
+void ReadContextMap(Reader& r, uint32_t num_ctx, vec<uint8_t>& map, uint32_t* num_clusters) {
   map.assign(num_ctx, 0);
   if (r.b()) {
     int bits = r.u(2);
@@ -302,7 +302,7 @@ void ReadContextMap(Reader& r, uint32_t num_ctx, std::vector<uint8_t>& map, uint
   }
   uint32_t mx = 0;
   for (auto m : map) mx = std::max<uint32_t>(mx, m);
-  std::vector<bool> used(mx + 1, false);
+  vec<bool> used(mx + 1, false);
   for (auto m : map) used[m] = true;
   for (bool u : used) if (!u) Fail("context map skips a cluster");
   *num_clusters = mx + 1;
@@ -326,7 +326,7 @@ void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77)
   hc->cfg.resize(hc->num_clusters);
   for (auto& c : hc->cfg) c = ReadUintConfig(r, hc->log_alpha);
   if (hc->use_prefix) {
-    std::vector<int> asz(hc->num_clusters);
+    vec<int> asz(hc->num_clusters);
     for (auto& a : asz) { a = VarLenUint16(r) + 1; if (a > (1 << 15)) Fail("prefix alphabet too large"); }
     hc->pfx_count.assign(hc->num_clusters * 16, 0);
     hc->pfx_sym_off.resize(hc->num_clusters);
@@ -337,7 +337,7 @@ void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77)
     hc->alias.assign(1, 0);
   } else {
     hc->alias.assign((size_t)hc->num_clusters << hc->log_alpha, 0);
-    std::vector<int> dist;
+    vec<int> dist;
     for (uint32_t c = 0; c < hc->num_clusters; c++) {
       ReadHistogram(r, dist);
       BuildAlias(dist, hc->log_alpha, &hc->alias[(size_t)c << hc->log_alpha]);
@@ -442,9 +442,9 @@ SigResult CheckSignature(const uint8_t* buf, size_t len) {
   return len < 12 ? kSigNotEnoughBytes : kSigContainer;
 }
 
-bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, std::vector<uint8_t>* jbrd) {
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, vec<uint8_t>* jbrd) {
   *have_container = false; *has_jbrd = false;
-  std::vector<uint8_t> tmp;
+  vec<uint8_t> tmp;
   const uint8_t* src = data; size_t n = size;
   bool complete = true;
   if (!(size >= 2 && data[0] == 0xFF && data[1] == 0x0A)) {
@@ -564,7 +564,7 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   const size_t num_extra = ih.extra.size();
   const bool xyb = ih.xyb_encoded;
   uint32_t fx = ih.xsize, fy = ih.ysize;
-  std::vector<uint32_t> ec_ups(num_extra, 1);
+  vec<uint32_t> ec_ups(num_extra, 1);
   bool all_default = r.b();
   if (!xyb) { p->x_qm_scale = 2; p->b_qm_scale = 2; }
   if (!all_default) {
@@ -658,7 +658,7 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   p->single_section = p->num_groups == 1 && p->num_passes == 1;
   size_t n = p->single_section ? 1 : 1 + p->num_lf_groups + 1 + (size_t)p->num_groups * p->num_passes;
   // toc.cc ReadToc: an optional Lehmer-coded permutation says where logical section i is stored
-  std::vector<uint32_t> perm;
+  vec<uint32_t> perm;
   if (r.b()) {
     HostCode pc;
     ReadEntropyCode(r, 8, &pc);
@@ -666,7 +666,7 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     auto ctxof = [](uint32_t v) { uint32_t t = v == 0 ? 0 : 1 + FloorLog2(v); return std::min<uint32_t>(t, 7); };
     const uint32_t end = sr.Read(ctxof((uint32_t)n));
     if (end > n) Fail("TOC permutation size");
-    std::vector<uint32_t> lehmer(n, 0), temp(n);
+    vec<uint32_t> lehmer(n, 0), temp(n);
     uint32_t last = 0;
     for (size_t i = 0; i < end; i++) { lehmer[i] = sr.Read(ctxof(last)); last = lehmer[i]; if (lehmer[i] >= n - i) Fail("TOC lehmer code"); }
     sr.CheckFinal();
@@ -675,11 +675,11 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     for (size_t i = 0; i < n; i++) { perm[i] = temp[lehmer[i]]; temp.erase(temp.begin() + lehmer[i]); }
   }
   r.align();
-  std::vector<uint64_t> sizes(n);
+  vec<uint64_t> sizes(n);
   for (auto& s : sizes) s = r.U32({10, 0}, {14, 1024}, {22, 17408}, {30, 4211712});
   r.align();
   uint64_t off = r.pos() / 8;
-  std::vector<Section> phys(n);
+  vec<Section> phys(n);
   for (size_t i = 0; i < n; i++) { phys[i] = {off, sizes[i]}; off += sizes[i]; }
   p->sections.resize(n);
   for (size_t i = 0; i < n; i++) p->sections[i] = perm.empty() ? phys[i] : phys[perm[i]];
@@ -792,7 +792,7 @@ static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
       b.num_lf_ctxs = (b.n_lf_thr[0] + 1) * (b.n_lf_thr[1] + 1) * (b.n_lf_thr[2] + 1);
       size_t n = (size_t)39 * b.num_lf_ctxs * (b.n_qf_thr + 1);
       if (n > sizeof(b.ctx_map)) Fail("block context map too large");
-      std::vector<uint8_t> map; uint32_t nc = 0;
+      vec<uint8_t> map; uint32_t nc = 0;
       ReadContextMap(r, (uint32_t)n, map, &nc);
       if (nc > 16) Fail("too many block contexts");
       memcpy(b.ctx_map, map.data(), n);
@@ -924,7 +924,7 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
           const DevCode view = p->tree_code.View();
           ModularCtx mc;
           mc.tree = p->tree.nodes.data(); mc.code = &view; mc.wp = wp; mc.uses_wp = p->tree.uses_wp;
-          std::vector<int32_t> wps(10 * (cols + 2), 0);
+          vec<int32_t> wps(10 * (cols + 2), 0);
           mc.wp_scratch = wps.data();
           mc.stream_id = 1 + 3 * p->num_lf_groups + k;
           AnsReader ans; ans.Init(r.br, view);
@@ -954,17 +954,17 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
       auto ctxof = [](uint32_t v) { uint32_t t = v == 0 ? 0 : 1 + FloorLog2(v); return std::min<uint32_t>(t, 7); };
       for (int b = 0; b < 13; b++) {
         if (!(used & (1u << b))) continue;
-        std::vector<uint16_t> natural = NaturalCoeffOrder(kBucketStrategy[b]);
+        vec<uint16_t> natural = NaturalCoeffOrder(kBucketStrategy[b]);
         const size_t size = natural.size(), skip = size / 64;
         for (int c = 0; c < 3; c++) {
-          std::vector<uint32_t> lehmer(size, 0);
+          vec<uint32_t> lehmer(size, 0);
           uint32_t end = sr.Read(ctxof((uint32_t)size)) + (uint32_t)skip;
           if (end > size) Fail("permutation size");
           uint32_t last = 0;
           for (size_t i = skip; i < end; i++) { lehmer[i] = sr.Read(ctxof(last)); last = lehmer[i]; if (lehmer[i] >= size - i) Fail("lehmer code"); }
-          std::vector<uint32_t> temp(size);
+          vec<uint32_t> temp(size);
           for (size_t i = 0; i < size; i++) temp[i] = (uint32_t)i;
-          std::vector<uint16_t>& o = p->custom_order[(size_t)ps * 39 + b * 3 + c];
+          vec<uint16_t>& o = p->custom_order[(size_t)ps * 39 + b * 3 + c];
           o.resize(size);
           for (size_t i = 0; i < size; i++) { o[i] = natural[temp[lehmer[i]]]; temp.erase(temp.begin() + lehmer[i]); }
         }
@@ -982,12 +982,12 @@ const uint8_t kBucketStrategy[13] = {0, 1, 4, 5, 6, 8, 10, 18, 19, 21, 22, 24, 2
 const uint8_t kKindRows[17] = {1, 1, 1, 1, 2, 4, 1, 1, 2, 1, 1, 8, 4, 16, 8, 32, 16};
 const uint8_t kKindCols[17] = {1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32};
 
-std::vector<uint16_t> NaturalCoeffOrder(int strategy) {
+vec<uint16_t> NaturalCoeffOrder(int strategy) {
   int cx = (int)CoveredX(strategy), cy = (int)CoveredY(strategy);
   if (cy > cx) std::swap(cx, cy);
   const int xs = cx * 8, ratio = cx / cy, mask = ratio - 1;
   int lr = 0; while ((1 << lr) < ratio) lr++;
-  std::vector<uint16_t> out((size_t)cx * cy * 64);
+  vec<uint16_t> out((size_t)cx * cy * 64);
   size_t cur = (size_t)cx * cy;
   auto emit = [&](int x, int y, bool first_half) {
     if (y & mask) return;
@@ -1110,13 +1110,13 @@ static void BandWeights(uint32_t nb, const float (*bands_in)[17], int c, int ROW
   }
 }
 
-void ComputeQuantTable(const QuantTableSpec& spec0, int kind, int c, std::vector<float>* out) {
+void ComputeQuantTable(const QuantTableSpec& spec0, int kind, int c, vec<float>* out) {
   QuantTableSpec lib;
   const QuantTableSpec* q = &spec0;
   if (spec0.mode == 0) { lib = LibrarySpec(kind); q = &lib; }
   const int ROWS = 8 * kKindRows[kind], COLS = 8 * kKindCols[kind];
   const size_t n = (size_t)ROWS * COLS;
-  std::vector<float> w(n, 1.0f);
+  vec<float> w(n, 1.0f);
   switch (q->mode) {
     case 6: BandWeights(q->num_bands, q->bands, c, ROWS, COLS, w.data()); break;
     case 1: for (auto& v : w) v = q->idw[c][0]; w[1] = w[8] = q->idw[c][1]; w[9] = q->idw[c][2]; break;

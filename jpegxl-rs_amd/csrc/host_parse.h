@@ -6,6 +6,7 @@
 // JxlDecoderProcessInput (jpegxl-rs/src/decode.rs:238) and JxlDecoderGetBasicInfo (decode.rs:246).
 #pragma once
 #include "jxl_dev.h"
+#include "mm_alloc.h"
 #include <string>
 #include <vector>
 #include <stdexcept>
@@ -18,11 +19,11 @@ struct ParseError : std::runtime_error {
 };
 
 struct HostCode {  // entropy code in host memory, device-layout tables
-  std::vector<uint8_t> ctx_map;
-  std::vector<uint32_t> cfg;
-  std::vector<uint64_t> alias;
-  std::vector<uint16_t> pfx_count, pfx_syms;
-  std::vector<uint32_t> pfx_sym_off;
+  vec<uint8_t> ctx_map;
+  vec<uint32_t> cfg;
+  vec<uint64_t> alias;
+  vec<uint16_t> pfx_count, pfx_syms;
+  vec<uint32_t> pfx_sym_off;
   uint32_t num_ctx = 0, num_clusters = 0, log_alpha = 0, use_prefix = 0;   // num_ctx: without the LZ77 distance context
   bool lz77 = false;
   uint32_t lz_min_symbol = 0, lz_min_length = 0, lz_len_cfg = 0;
@@ -37,7 +38,7 @@ struct HostCode {  // entropy code in host memory, device-layout tables
 };
 
 struct HostTree {
-  std::vector<TreeNode> nodes;
+  vec<TreeNode> nodes;
   uint32_t num_leaves = 0;
   bool uses_wp = false;
   int max_prop = 0;
@@ -53,7 +54,7 @@ struct ImageHeader {
   bool have_preview = false, have_animation = false, have_timecodes = false;
   uint32_t tps_num = 0, tps_den = 0, num_loops = 0;
   BitDepthInfo depth;
-  std::vector<ExtraChannel> extra;
+  vec<ExtraChannel> extra;
   bool xyb_encoded = true;
   // colour encoding
   bool color_default = true, want_icc = false;
@@ -63,14 +64,14 @@ struct ImageHeader {
   float intensity_target = 255.f, min_nits = 0.f, linear_below = 0.f;
   bool relative_to_max_display = false;
   float opsin_inv[9]; float opsin_bias[3]; float quant_bias[4];
-  std::vector<float> up_weights[3];   // custom upsampling weights for 2x / 4x / 8x (15 / 55 / 210 values); empty = library default
+  vec<float> up_weights[3];   // custom upsampling weights for 2x / 4x / 8x (15 / 55 / 210 values); empty = library default
   bool have_container = false;
 };
 
 struct SqueezeStep { uint32_t horizontal, in_place, begin_c, num_c; };
 struct TransformDesc {
   uint32_t id = 0, begin_c = 0, rct_type = 0, num_c = 0, nb_colors = 0, nb_deltas = 0, predictor = 0;
-  std::vector<SqueezeStep> squeeze;
+  vec<SqueezeStep> squeeze;
 };
 
 struct LoopFilterParams {
@@ -86,7 +87,7 @@ struct QuantTableSpec {
   uint32_t num_bands = 0; float bands[3][17];
   uint32_t num_bands4 = 0; float bands4[3][17];
   float idw[3][3], dct2w[3][6], dct4mul[3][2], dct4x8mul[3], afvw[3][9];
-  float raw_den = 0; std::vector<int32_t> raw[3];
+  float raw_den = 0; vec<int32_t> raw[3];
 };
 
 struct Section { uint64_t offset, size; };
@@ -94,20 +95,20 @@ struct Section { uint64_t offset, size; };
 // ---- image features and frame compositing (LfGlobal / frame header), host-parsed: dec_patch_dictionary.cc, splines.cc, dec_noise.cc
 struct BlendInfoH { uint32_t mode = 0, alpha_channel = 0, source = 0; bool clamp = false; };   // BlendMode: 0 replace, 1 add, 2 blend, 3 mul-add, 4 mul
 struct PatchBlendH { uint32_t mode = 0, alpha_channel = 0, clamp = 0; };                        // PatchBlendMode 0..7
-struct PatchPosH { int64_t x = 0, y = 0; std::vector<PatchBlendH> blend; };                      // blend[0] colour, blend[1 + e] extra channel e
-struct PatchRefH { uint32_t ref = 0, x0 = 0, y0 = 0, xsize = 0, ysize = 0; std::vector<PatchPosH> pos; };
-struct SplineH { std::vector<std::pair<int64_t, int64_t>> control_points; int32_t color_dct[3][32]; int32_t sigma_dct[32]; };
+struct PatchPosH { int64_t x = 0, y = 0; vec<PatchBlendH> blend; };                      // blend[0] colour, blend[1 + e] extra channel e
+struct PatchRefH { uint32_t ref = 0, x0 = 0, y0 = 0, xsize = 0, ysize = 0; vec<PatchPosH> pos; };
+struct SplineH { vec<std::pair<int64_t, int64_t>> control_points; int32_t color_dct[3][32]; int32_t sigma_dct[32]; };
 struct FrameFeatures {
-  std::vector<PatchRefH> patches;
+  vec<PatchRefH> patches;
   int32_t spline_quant_adjust = 0;
-  std::vector<SplineH> splines;
-  std::vector<std::pair<int64_t, int64_t>> spline_start;
+  vec<SplineH> splines;
+  vec<std::pair<int64_t, int64_t>> spline_start;
   bool has_noise = false;
   float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 // One rendered spline sample (splines.cc SplineSegment) and the per-row draw lists built on the host (host_features.cc)
 struct SplineSegmentDev { float center_x, center_y, maximum_distance, inv_sigma, sigma_over_4_times_intensity, color[3]; };
-struct SplineDrawList { std::vector<SplineSegmentDev> segments; std::vector<uint32_t> row_start; std::vector<uint32_t> indices; };
+struct SplineDrawList { vec<SplineSegmentDev> segments; vec<uint32_t> row_start; vec<uint32_t> indices; };
 void BuildSplineDrawList(const FrameFeatures& f, float y_to_x, float y_to_b, uint32_t height, SplineDrawList* out);
 float FastPowf(float base, float exponent);   // base/fast_math-inl.h (host_parse.cc)
 
@@ -121,7 +122,7 @@ struct FramePlan {
   // compositing: position / size of the frame on the image canvas, blending, reference slots (frame_header.cc)
   bool have_crop = false; int32_t x0 = 0, y0 = 0;
   uint32_t frame_w = 0, frame_h = 0;       // frame size after upsampling (width / height below are the coded size)
-  BlendInfoH blend; std::vector<BlendInfoH> ec_blend;
+  BlendInfoH blend; vec<BlendInfoH> ec_blend;
   uint32_t duration = 0, save_as_reference = 0; bool save_before_ct = false;
   float sigma_for_modular = 1.0f;
   FrameFeatures feat;
@@ -131,7 +132,7 @@ struct FramePlan {
   uint32_t xgroups = 0, ygroups = 0, num_groups = 0, xlfgroups = 0, ylfgroups = 0, num_lf_groups = 0;
   uint32_t bw = 0, bh = 0;  // 8x8 blocks
   // TOC
-  std::vector<Section> sections;   // byte offsets into the codestream buffer
+  vec<Section> sections;   // byte offsets into the codestream buffer
   bool single_section = false;
   // LfGlobal
   float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
@@ -143,9 +144,9 @@ struct FramePlan {
   HostCode tree_code;       // code of the global-tree streams
   // GlobalModular: channel list after global transforms; channel data starts at global_data_bitpos
   struct ModChannel { uint32_t w, h; int32_t hshift, vshift; };
-  std::vector<ModChannel> gchannels;
+  vec<ModChannel> gchannels;
   uint32_t nb_meta_channels = 0;
-  std::vector<TransformDesc> gtransforms;
+  vec<TransformDesc> gtransforms;
   WPHeader gwp;
   bool g_use_global_tree = true;
   uint64_t global_data_bitpos = 0;   // absolute bit position (codestream) where the global stream's ANS state starts
@@ -154,15 +155,15 @@ struct FramePlan {
   // HfGlobal
   QuantTableSpec qspec[17];
   uint32_t num_hf_presets = 1;
-  std::vector<uint32_t> used_orders;                // per pass
-  std::vector<std::vector<uint16_t>> custom_order;  // [pass*39 + bucket*3 + c] (empty = natural)
-  std::vector<HostCode> ac_code;                    // per pass
+  vec<uint32_t> used_orders;                // per pass
+  vec<vec<uint16_t>> custom_order;  // [pass*39 + bucket*3 + c] (empty = natural)
+  vec<HostCode> ac_code;                    // per pass
   uint64_t end_bitpos = 0;                          // where parsing of the last host-parsed section stopped
 };
 
 // Aligned, padded copy of the codestream (container stripped) — also the H2D staging buffer
 struct Codestream {
-  std::vector<uint32_t> storage;
+  vec<uint32_t> storage;
   size_t size = 0;
   const uint8_t* data() const { return reinterpret_cast<const uint8_t*>(storage.data()); }
   uint8_t* data() { return reinterpret_cast<uint8_t*>(storage.data()); }
@@ -173,7 +174,7 @@ enum SigResult { kSigNotEnoughBytes = 0, kSigInvalid = 1, kSigCodestream = 2, kS
 SigResult CheckSignature(const uint8_t* buf, size_t len);
 
 // Extracts the codestream; returns false if more input is needed (truncated container).
-bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, std::vector<uint8_t>* jbrd = nullptr);
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, vec<uint8_t>* jbrd = nullptr);
 
 // Parses the image header; *frame_bitpos receives the bit position of the first frame header.
 void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bitpos);
@@ -185,10 +186,10 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
 void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos, FramePlan* plan);
 
 // Dequantisation table (1/weight) of quant kind `kind`, channel c; natural coefficient order of a strategy.
-void ComputeQuantTable(const QuantTableSpec& spec, int kind, int c, std::vector<float>* out);
-std::vector<uint16_t> NaturalCoeffOrder(int strategy);
+void ComputeQuantTable(const QuantTableSpec& spec, int kind, int c, vec<float>* out);
+vec<uint16_t> NaturalCoeffOrder(int strategy);
 // ICC v4.4 matrix/TRC profile of the enumerated colour encoding (icc_profile.cc); throws ParseError.
-std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih);
+vec<uint8_t> SynthesizeIcc(const ImageHeader& ih);
 std::string ColorDescription(const ImageHeader& ih);
 extern const uint8_t kBucketStrategy[13];
 extern const uint8_t kKindRows[17], kKindCols[17];

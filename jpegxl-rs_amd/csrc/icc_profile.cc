@@ -37,8 +37,8 @@ struct Md5 {
     }
     a += A; b += B; c += C; d += D;
   }
-  void Digest(const std::vector<uint8_t>& msg, uint8_t out[16]) {
-    std::vector<uint8_t> v(msg);
+  void Digest(const vec<uint8_t>& msg, uint8_t out[16]) {
+    vec<uint8_t> v(msg);
     const uint64_t bits = (uint64_t)msg.size() * 8;
     v.push_back(0x80);
     while (v.size() % 64 != 56) v.push_back(0);
@@ -49,11 +49,11 @@ struct Md5 {
   }
 };
 
-void Put32(std::vector<uint8_t>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s)); }
-void Put16(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
-void PutTag(std::vector<uint8_t>& v, const char* t) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)t[i]); }
-void PutS15(std::vector<uint8_t>& v, double x) { Put32(v, (uint32_t)(int32_t)std::lround(x * 65536.0)); }
-void Set32(std::vector<uint8_t>& v, size_t pos, uint32_t x) { for (int i = 0; i < 4; i++) v[pos + i] = (uint8_t)(x >> (24 - 8 * i)); }
+void Put32(vec<uint8_t>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s)); }
+void Put16(vec<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+void PutTag(vec<uint8_t>& v, const char* t) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)t[i]); }
+void PutS15(vec<uint8_t>& v, double x) { Put32(v, (uint32_t)(int32_t)std::lround(x * 65536.0)); }
+void Set32(vec<uint8_t>& v, size_t pos, uint32_t x) { for (int i = 0; i < 4; i++) v[pos + i] = (uint8_t)(x >> (24 - 8 * i)); }
 
 struct Mat3 { double m[3][3]; };
 Mat3 Mul(const Mat3& a, const Mat3& b) {
@@ -90,12 +90,12 @@ Mat3 AdaptToD50(const double white[3]) {
   return Mul(Inv(brad), Mul(scale, brad));
 }
 
-void Mluc(std::vector<uint8_t>& v, const std::string& text) {
+void Mluc(vec<uint8_t>& v, const std::string& text) {
   PutTag(v, "mluc"); Put32(v, 0); Put32(v, 1); Put32(v, 12); PutTag(v, "enUS"); Put32(v, (uint32_t)text.size() * 2); Put32(v, 28);
   for (char ch : text) Put16(v, (uint8_t)ch);
 }
-void Xyz(std::vector<uint8_t>& v, const double p[3]) { PutTag(v, "XYZ "); Put32(v, 0); for (int i = 0; i < 3; i++) PutS15(v, p[i]); }
-void Para(std::vector<uint8_t>& v, int type, std::initializer_list<double> params) {
+void Xyz(vec<uint8_t>& v, const double p[3]) { PutTag(v, "XYZ "); Put32(v, 0); for (int i = 0; i < 3; i++) PutS15(v, p[i]); }
+void Para(vec<uint8_t>& v, int type, std::initializer_list<double> params) {
   PutTag(v, "para"); Put32(v, 0); Put16(v, (uint32_t)type); Put16(v, 0);
   for (double p : params) PutS15(v, p);
 }
@@ -114,7 +114,7 @@ std::string ColorDescription(const ImageHeader& ih) {
   return s;
 }
 
-std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
+vec<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
   if (ih.want_icc) throw ParseError("unsupported: embedded ICC profile", true);
   if (ih.color_space > 1) throw ParseError("unsupported: ICC profile for XYB / unknown colour space", true);
   const bool grey = ih.color_space == 1;
@@ -149,7 +149,7 @@ std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
     for (int c = 0; c < 3; c++) for (int i = 0; i < 3; i++) col[c][i] = a.m[i][c];
   }
 
-  std::vector<uint8_t> trc;
+  vec<uint8_t> trc;
   if (ih.have_gamma) {
     if (ih.gamma == 0 || ih.gamma > 10000000) throw ParseError("colour encoding: gamma", false);
     Para(trc, 0, {1.0 / (ih.gamma * 1e-7)});
@@ -164,8 +164,8 @@ std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
     }
   }
 
-  struct Tag { const char* sig; std::vector<uint8_t> data; int alias; };
-  std::vector<Tag> tags;
+  struct Tag { const char* sig; vec<uint8_t> data; int alias; };
+  vec<Tag> tags;
   { Tag t{"desc", {}, -1}; Mluc(t.data, ColorDescription(ih)); tags.push_back(std::move(t)); }
   { Tag t{"cprt", {}, -1}; Mluc(t.data, "CC0"); tags.push_back(std::move(t)); }
   { Tag t{"wtpt", {}, -1}; Xyz(t.data, kD50); tags.push_back(std::move(t)); }
@@ -181,7 +181,7 @@ std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
     tags.push_back(Tag{"kTRC", trc, -1});
   }
 
-  std::vector<uint8_t> out;
+  vec<uint8_t> out;
   Put32(out, 0);                      // size, patched below
   PutTag(out, "jxl ");                // preferred CMM
   Put32(out, 0x04400000);             // version 4.4
@@ -201,7 +201,7 @@ std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
   Put32(out, (uint32_t)tags.size());
   const size_t table = out.size();
   out.resize(table + 12 * tags.size(), 0);
-  std::vector<std::pair<uint32_t, uint32_t>> where(tags.size());
+  vec<std::pair<uint32_t, uint32_t>> where(tags.size());
   for (size_t i = 0; i < tags.size(); i++) {
     if (tags[i].alias >= 0) { where[i] = where[tags[i].alias]; continue; }
     where[i] = {(uint32_t)out.size(), (uint32_t)tags[i].data.size()};
@@ -215,7 +215,7 @@ std::vector<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
   }
   Set32(out, 0, (uint32_t)out.size());
   // profile ID: MD5 with flags, rendering intent and the ID field zeroed
-  std::vector<uint8_t> z(out);
+  vec<uint8_t> z(out);
   memset(&z[44], 0, 4); memset(&z[64], 0, 4); memset(&z[84], 0, 16);
   Md5().Digest(z, &out[84]);
   return out;

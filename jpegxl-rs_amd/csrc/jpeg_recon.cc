@@ -133,7 +133,7 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
     }
     if (r.bad) return fail("truncated");
   }
-  std::vector<uint32_t> inter_sizes(num_inter);
+  vec<uint32_t> inter_sizes(num_inter);
   for (auto& v : inter_sizes) v = r.u(16);
   const uint32_t tail_len = r.U32({0, 0}, {8, 1}, {16, 257}, {22, 65793});
   jd->has_zero_padding_bit = r.b();
@@ -156,7 +156,7 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
   for (auto& d : jd->inter_marker_data) total += d.size();
   total += jd->tail_data.size();
   const size_t off = (r.p + 7) / 8;
-  std::vector<uint8_t> plain(total + 1);
+  vec<uint8_t> plain(total + 1);
   if (total > 0) {
     BrotliDecompressFn brotli = LoadBrotli();
     if (!brotli) return fail("libbrotlidec.so.1 not available");
@@ -164,7 +164,7 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
     if (off >= size || brotli(size - off, data + off, &got, plain.data()) != 1 || got != total) return fail("Brotli stream does not match the announced sizes");
   }
   size_t pos = 0;
-  auto take = [&](std::vector<uint8_t>& v) { if (!v.empty()) memcpy(v.data(), plain.data() + pos, v.size()); pos += v.size(); };
+  auto take = [&](vec<uint8_t>& v) { if (!v.empty()) memcpy(v.data(), plain.data() + pos, v.size()); pos += v.size(); };
   for (auto& a : jd->app_data) { take(a); if ((size_t)a[1] * 256u + a[2] + 1u != a.size()) return fail("APP marker length mismatch"); }
   for (auto& c : jd->com_data) { take(c); if ((size_t)c[1] * 256u + c[2] + 1u != c.size()) return fail("COM marker length mismatch"); }
   for (auto& d : jd->inter_marker_data) take(d);
@@ -195,7 +195,7 @@ bool BuildHuffTable(const JpegHuffmanCode& h, HuffTable* t) {
 }
 
 struct BitWriter {
-  std::vector<uint8_t>* out;
+  vec<uint8_t>* out;
   uint64_t acc = 0; int nbits = 0;   // bits pending (MSB-first)
   bool ok = true;
   void Put(uint32_t v, int n) {
@@ -225,7 +225,7 @@ struct BitWriter {
 
 }  // namespace
 
-bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, std::vector<uint8_t>* out, std::string* err) {
+bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, vec<uint8_t>* out, std::string* err) {
   auto fail = [&](const char* m) { if (err) *err = std::string("JPEG writer: ") + m; return false; };
   out->clear();
   out->push_back(0xFF); out->push_back(0xD8);

@@ -8,31 +8,32 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include "mm_alloc.h"
 
 namespace jxlhip {
 
-struct JpegHuffmanCode { uint32_t slot_id = 0; bool is_last = true; uint32_t counts[17] = {0}; std::vector<uint32_t> values; };
+struct JpegHuffmanCode { uint32_t slot_id = 0; bool is_last = true; uint32_t counts[17] = {0}; vec<uint32_t> values; };
 struct JpegScanComponent { uint32_t comp_idx = 0, ac_tbl_idx = 0, dc_tbl_idx = 0; };
 struct JpegScanInfo {
   uint32_t num_components = 1, Ss = 0, Se = 63, Al = 0, Ah = 0, last_needed_pass = 0;
   JpegScanComponent components[4];
-  std::vector<uint32_t> reset_points;
-  std::vector<std::pair<uint32_t, uint32_t>> extra_zero_runs;   // (block index, number of extra 0xF0 symbols)
+  vec<uint32_t> reset_points;
+  vec<std::pair<uint32_t, uint32_t>> extra_zero_runs;   // (block index, number of extra 0xF0 symbols)
 };
 struct JpegQuantTable { uint32_t precision = 0, index = 0; bool is_last = true; int32_t values[64] = {0}; };   // values: natural (row-major) order
 struct JpegComponentInfo { uint32_t id = 0, quant_idx = 0, h_samp = 1, v_samp = 1; };
 struct JpegData {
-  std::vector<uint8_t> marker_order;
-  std::vector<std::vector<uint8_t>> app_data; std::vector<uint32_t> app_marker_type;
-  std::vector<std::vector<uint8_t>> com_data, inter_marker_data;
-  std::vector<uint8_t> tail_data;
-  std::vector<JpegQuantTable> quant;
-  std::vector<JpegComponentInfo> components;
-  std::vector<JpegHuffmanCode> huffman_code;
-  std::vector<JpegScanInfo> scan_info;
+  vec<uint8_t> marker_order;
+  vec<vec<uint8_t>> app_data; vec<uint32_t> app_marker_type;
+  vec<vec<uint8_t>> com_data, inter_marker_data;
+  vec<uint8_t> tail_data;
+  vec<JpegQuantTable> quant;
+  vec<JpegComponentInfo> components;
+  vec<JpegHuffmanCode> huffman_code;
+  vec<JpegScanInfo> scan_info;
   uint32_t restart_interval = 0;
   bool has_zero_padding_bit = false;
-  std::vector<uint8_t> padding_bits;
+  vec<uint8_t> padding_bits;
 };
 
 // Parses the payload of a `jbrd` box (bit-packed JPEGData bundle, then one Brotli stream with the marker payloads; Brotli comes
@@ -43,6 +44,6 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
 // Serialises the JPEG: markers in jbrd order, quantisation tables as filled in by the caller (jd.quant[i].values), entropy-coded
 // scans from the quantised coefficients.  coeffs[c]: blocks_h x blocks_w x 64 int16 in natural order for component c (4:4:4 only).
 // Sequential (baseline / extended) scans are supported; progressive scan scripts return false.
-bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, std::vector<uint8_t>* out, std::string* err);
+bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, vec<uint8_t>* out, std::string* err);
 
 }  // namespace jxlhip

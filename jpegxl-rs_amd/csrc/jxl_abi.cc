@@ -17,6 +17,7 @@ static void SetLastError(const std::string& s) { g_last_error = s; }
 struct JxlDecoderStruct {
   JxlMemoryManager mm;
   bool has_mm;
+  MmHooks hooks;        // the same three pointers in the form mm_alloc.h scopes take
   // settings (cleared by Reset)
   int events_wanted;
   bool keep_orientation, unpremul_alpha, render_spotcolors, coalescing;
@@ -25,7 +26,7 @@ struct JxlDecoderStruct {
   const uint8_t* input; size_t input_size; bool input_set, input_closed;
   void* out_buffer; size_t out_size; JxlPixelFormat out_format; bool out_set;
   uint8_t* jpeg_buffer; size_t jpeg_size; bool jpeg_set;
-  bool jpeg_available; size_t jpeg_written; std::vector<uint8_t> jpeg_bytes;   // JPEG bit-stream reconstruction (jbrd)
+  bool jpeg_available; size_t jpeg_written; vec<uint8_t> jpeg_bytes;   // JPEG bit-stream reconstruction (jbrd)
   // progress
   enum Stage { kInit, kHeaders, kFrame, kDone } stage;
   int events_emitted;
@@ -39,6 +40,11 @@ static int DefaultDevice() {
   return e ? atoi(e) : 0;
 }
 
+// host allocations made on behalf of decoder `d` (parser, tables, staging buffers, the Batch object) go through its memory manager
+#define JXL_MM_SCOPE(d) MmScope mm_scope_((d) && (d)->has_mm ? &(d)->hooks : nullptr)
+static Batch* NewBatch(int device) { void* mem = MmAllocate(sizeof(Batch)); try { return new (mem) Batch(device); } catch (...) { MmDeallocate(mem); throw; } }
+static void DeleteBatch(Batch* b) { if (b) { b->~Batch(); MmDeallocate(b); } }
+
 static void ClearState(JxlDecoder* d) {
   d->events_wanted = 0;
   d->keep_orientation = d->unpremul_alpha = false; d->render_spotcolors = true; d->coalescing = true;
@@ -49,7 +55,7 @@ static void ClearState(JxlDecoder* d) {
   d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
-  delete d->batch; d->batch = nullptr;
+  DeleteBatch(d->batch); d->batch = nullptr;
 }
 
 extern "C" {
@@ -74,6 +80,7 @@ JxlDecoder* JxlDecoderCreate(const JxlMemoryManager* mm) {
   if (!mem) return nullptr;
   JxlDecoder* d = new (mem) JxlDecoderStruct();
   d->mm = copy; d->has_mm = has; d->batch = nullptr; d->device = DefaultDevice();
+  d->hooks.opaque = copy.opaque; d->hooks.alloc = copy.alloc; d->hooks.free = copy.free;
   ClearState(d);
   return d;
 }
@@ -197,20 +204,21 @@ size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* d) {
 
 // ICC profile of the enumerated colour encoding (icc_profile.cc).  Both targets describe the same encoding: the pixels
 // this decoder hands out are always in the codestream's tagged colour space (no preferred-profile conversion).
-static JxlDecoderStatus IccOf(const JxlDecoder* d, std::vector<uint8_t>* icc) {
+static JxlDecoderStatus IccOf(const JxlDecoder* d, vec<uint8_t>* icc) {
+  JXL_MM_SCOPE(d);
   if (!d || !d->batch || d->stage < JxlDecoderStruct::kHeaders) { SetLastError("ICC profile requested before the headers were decoded"); return JXL_DEC_ERROR; }
   try { *icc = SynthesizeIcc(d->batch->image(0).ih); } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* d, JxlColorProfileTarget, size_t* size) {
-  std::vector<uint8_t> icc;
+  vec<uint8_t> icc;
   if (size) *size = 0;
   if (IccOf(d, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
   if (size) *size = icc.size();
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorProfileTarget, uint8_t* out, size_t size) {
-  std::vector<uint8_t> icc;
+  vec<uint8_t> icc;
   if (IccOf(d, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
   if (!out || size < icc.size()) { SetLastError("ICC output buffer too small"); return JXL_DEC_ERROR; }
   memcpy(out, icc.data(), icc.size());
@@ -218,6 +226,7 @@ JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorPro
 }
 
 JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
+  JXL_MM_SCOPE(d);
   d->started = true;
   if (!d->input_set) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
   try {
@@ -226,12 +235,12 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       if (sig == JXL_SIG_INVALID) { SetLastError("invalid signature"); return JXL_DEC_ERROR; }
       if (sig == JXL_SIG_NOT_ENOUGH_BYTES) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
       if (hipSetDevice(d->device) != hipSuccess) { SetLastError("no usable HIP device: the JPEG XL decode path requires an MI355X-class GPU (no CPU fallback)"); return JXL_DEC_ERROR; }
-      std::unique_ptr<Batch> b(new Batch(d->device));
-      b->AddImage(d->input, d->input_size);      // (throws "truncated" while the frame index is incomplete: nothing is kept)
-      for (auto& x : b->image(0).ih.extra)
+      struct Holder { Batch* b; ~Holder() { DeleteBatch(b); } } hold{NewBatch(d->device)};
+      hold.b->AddImage(d->input, d->input_size);      // (throws "truncated" while the frame index is incomplete: nothing is kept)
+      for (auto& x : hold.b->image(0).ih.extra)
         if (x.type == 2 && d->render_spotcolors) throw ParseError("unsupported: spot colour rendering (call JxlDecoderSetRenderSpotcolors(dec, JXL_FALSE))", true);
-      delete d->batch;
-      d->batch = b.release();
+      DeleteBatch(d->batch);
+      d->batch = hold.b; hold.b = nullptr;
       d->stage = JxlDecoderStruct::kHeaders;
     }
     if (d->stage == JxlDecoderStruct::kHeaders) {
@@ -379,7 +388,7 @@ int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, 
     const size_t nblk = (size_t)((width + 7) / 8) * ((height + 7) / 8), nc = jd.components.size();
     for (size_t c = 0; c < nc; c++) for (int k = 0; k < 64; k++) jd.quant[jd.components[c].quant_idx].values[k] = quant_tables[c * 64 + k];
     const int16_t* planes[3] = {coefficients, coefficients + (nc > 1 ? nblk * 64 : 0), coefficients + (nc > 2 ? 2 * nblk * 64 : 0)};
-    std::vector<uint8_t> bytes;
+    vec<uint8_t> bytes;
     if (!WriteJpeg(jd, width, height, planes, &bytes, &err)) { SetLastError(err); return 1; }
     const size_t cap = *out_size;
     *out_size = bytes.size();
@@ -392,7 +401,7 @@ int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, 
 size_t JxlHipLibraryQuantTable(int kind, int c, float* out, size_t cap) {
   try {
     if (kind < 0 || kind >= 17 || c < 0 || c >= 3) return 0;
-    std::vector<float> t;
+    vec<float> t;
     ComputeQuantTable(QuantTableSpec(), kind, c, &t);
     for (size_t i = 0; i < t.size() && i < cap; i++) out[i] = t[i];
     return t.size();
@@ -405,7 +414,7 @@ int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc
     if (!ExtractCodestream(data, size, &cs, &container, &jbrd)) { SetLastError("truncated input"); return 1; }
     ImageHeader ih; uint64_t frame_bitpos = 0;
     ParseImageHeader(cs, &ih, &frame_bitpos);
-    const std::vector<uint8_t> icc = SynthesizeIcc(ih);
+    const vec<uint8_t> icc = SynthesizeIcc(ih);
     const size_t cap = icc_size ? *icc_size : 0;
     if (icc_size) *icc_size = icc.size();
     if (icc_out) { if (cap < icc.size()) { SetLastError("ICC output buffer too small"); return 1; } memcpy(icc_out, icc.data(), icc.size()); }

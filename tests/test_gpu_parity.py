@@ -738,3 +738,49 @@ def test_jpeg_reconstruction(jx):
     assert kind == "jpeg" and val == want
     # the pixel path of the same file is unaffected
     check_against_oracle(jx, fixture_bytes("sample_jpg.jxl"), np.uint8, 3)
+
+
+def _bump(tmp_path, size):
+    import subprocess
+    so = str(tmp_path / "libbump.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", so, os.path.join(os.path.dirname(__file__), "bump_alloc.c")])
+    B = C.CDLL(so)
+    B.bump_create.restype = C.c_void_p; B.bump_create.argtypes = [C.c_size_t]
+    B.bump_destroy.argtypes = [C.c_void_p]
+    B.bump_stats.argtypes = [C.c_void_p, C.POINTER(C.c_size_t * 5)]
+    return B, B.bump_create(size)
+
+
+def test_memory_manager_bump_arena(jx, tmp_path):
+    """memory.rs:128-138 (`test_mm`): a whole decode of sample.jxl through a 50 MiB bump allocator that never frees.  Every host
+    allocation the decoder makes for this image (decoder object, Batch, parser state, tables, staging) comes out of the caller's
+    arena, the cumulative total stays far below the arena size, and every block is handed back by Destroy."""
+    B, arena = _bump(tmp_path, 50 << 20)
+    mm = jx.JxlMemoryManager(arena, C.cast(B.bump_alloc, C.c_void_p), C.cast(B.bump_free, C.c_void_p))
+    dec = jx.decoder_builder(memory_manager=mm, icc_profile=True)
+    meta, px = dec.decode_with(fixture_bytes("sample.jxl"), np.uint8)
+    assert np.array_equal(np.frombuffer(px, np.uint8), O.decode(fixture_bytes("sample.jxl")).pixels("u8", meta.num_color_channels + (1 if meta.has_alpha_channel else 0)))
+    st = (C.c_size_t * 5)()
+    B.bump_stats(arena, C.byref(st))
+    used, allocs, frees, failed, largest = list(st)
+    print(f"bump arena: {used} bytes in {allocs} allocations ({frees} freed so far), largest {largest}")
+    assert failed == 0 and allocs > 20 and 64 << 10 < used < 50 << 20
+    meta, (kind, val) = dec.reconstruct(fixture_bytes("sample_jpg.jxl"))        # JPEG path through the same arena
+    assert kind == "jpeg" and val == open(os.path.join(FIXTURES, "sample.jpg"), "rb").read()
+    del dec
+    import gc
+    gc.collect()
+    B.bump_stats(arena, C.byref(st))
+    assert st[3] == 0 and st[1] == st[2], list(st)      # balanced: nothing allocated through the manager is leaked or freed elsewhere
+    B.bump_destroy(arena)
+
+
+def test_memory_manager_out_of_memory_is_an_error_not_a_crash(jx, tmp_path):
+    """An arena too small for the decode: allocation failure surfaces as JXL_DEC_ERROR (DecodeError::GenericError), not a crash."""
+    B, arena = _bump(tmp_path, 16 << 10)
+    mm = jx.JxlMemoryManager(arena, C.cast(B.bump_alloc, C.c_void_p), C.cast(B.bump_free, C.c_void_p))
+    dec = jx.decoder_builder(memory_manager=mm)
+    with pytest.raises(jx.DecodeError):
+        dec.decode_with(fixture_bytes("sample.jxl"), np.uint8)
+    del dec
+    B.bump_destroy(arena)
