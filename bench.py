@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--lane-stride-hf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_HF", "1")),
                     help="1 = SIMT HF decode (one group stream per lane), 64 = one stream per wavefront")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
+    ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the LF stage of step k+1 with the rest of step k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -216,10 +217,11 @@ def main():
         batch.prepare(stream)
         outs.append(out); batches.append(batch)
     batch, out = batches[0], outs[0]
-    gather_list = None
+    gathered = None
     do_gather = world > 1 and not args.no_gather
     if do_gather and rank == 0:
-        gather_list = [torch.empty_like(out) for _ in range(world)]
+        gathered = torch.empty((world, inner * B, H, W, 3), dtype=torch.uint8, device=dev)     # where the consumer rank sees the whole job's pixels (one step)
+    from jpegxl_rs_amd.sharding import gather_frames_chunked
     # LF ("front") parts run on a side stream so that step k+1's latency-bound LF decode overlaps step k's HF/IDCT/filter
     # stages; events order front(k) -> rest(k) and rest(k) -> front(k+2) (same buffer set).
     # (LF blocks are few and long-running: dispatch them first.)  With three buffer sets two LF stages are in flight, each on
@@ -231,6 +233,13 @@ def main():
     # workgroups one per CU.  "hf" = the end of this step's HF stage (experiment: the LF workgroups then land next to pixel-kernel
     # workgroups, pile up on some CUs, and the next HF stage waits for those CUs: 89 instead of 47 ms).
     front_gate = os.environ.get("JXL_BENCH_FRONT_GATE", "rest")
+    # "deep" (experiment, off): the HF stage on a stream of its own as well, so that HF(k+1) overlaps the IDCT / filter stages of
+    # step k (coefficients are per batch, the shared pixel planes are only touched by the IDCT / filter stages, which stay in order
+    # on the main stream).  Measured (r02b, 256 frames): 119 ms per step instead of 105 — the 1024-thread HF workgroups wait for
+    # whole CUs to drain and the single-lane LF wavefronts already take VALU slots from the pixel kernels: HF 46 -> 79 ms,
+    # IDCT 21 -> 34 ms.  More batches in flight (4, 5) make it worse (136, 135 ms).
+    deep = pipeline and os.environ.get("JXL_BENCH_DEEP", "0") == "1"
+    hf_stream = torch.cuda.Stream(device=dev, priority=-1) if deep else None
     hf_done = [torch.cuda.Event() for _ in range(nbuf)]
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
     rest_done = [torch.cuda.Event() for _ in range(nbuf)]
@@ -263,11 +272,19 @@ def main():
             for j in range(1, ahead + 1):
                 if j != late and k + j < state["limit"] and state["front_issued"] <= k + j:
                     issue_front(k + j, timed); state["front_issued"] = k + j + 1
-            main.wait_event(front_done[b])
+            if deep:
+                with torch.cuda.stream(hf_stream):
+                    hf_stream.wait_event(front_done[b])
+                    batches[b].decode_part(3, hf_stream.cuda_stream, timed)
+                    hf_done[b].record(hf_stream)
+                main.wait_event(hf_done[b])
+            else:
+                main.wait_event(front_done[b])
             if do_gather and k >= nbuf:
                 main.wait_event(gather_done[b])       # the previous gather of this buffer set must have read the pixels
-            batches[b].decode_part(3, stream, timed)
-            hf_done[b].record(main)
+            if not deep:
+                batches[b].decode_part(3, stream, timed)
+                hf_done[b].record(main)
             if late is not None and k + late < state["limit"] and state["front_issued"] <= k + late:
                 issue_front(k + late, timed, gate=hf_done[b]); state["front_issued"] = k + late + 1
             batches[b].decode_part(4, stream, timed)
@@ -277,7 +294,9 @@ def main():
                 rest_done[b].record(main)
             with torch.cuda.stream(comm):
                 comm.wait_event(rest_done[b])
-                dist.gather(outs[b], gather_list, dst=0)
+                # per-chunk point-to-point transfers straight into their final place (all peers at once, one xGMI link each)
+                j = k % inner
+                gather_frames_chunked(outs[b], gathered[:, j * B:(j + 1) * B] if rank == 0 else None, dst=0, chunk_frames=args.gather_chunk)
                 gather_done[b].record(comm)
             if not pipeline:
                 main.wait_event(gather_done[b])

@@ -1099,8 +1099,8 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   if (do_hf) decodes_since_finish_++;
   vec<void*>* evs = nullptr;
   if (timed) {
-    if (do_front) { timed_events_.emplace_back(8, nullptr); }
-    if (timed_events_.empty()) timed_events_.emplace_back(8, nullptr);
+    if (do_front) { timed_events_.emplace_back(9, nullptr); }
+    if (timed_events_.empty()) timed_events_.emplace_back(9, nullptr);
     evs = !do_front ? &timed_events_[timed_rest_cursor_ < timed_events_.size() ? timed_rest_cursor_ : timed_events_.size() - 1] : &timed_events_.back();
   }
   auto rec = [&](int i) {
@@ -1138,6 +1138,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     rec(3);
   }
   if (do_tail) {
+    if (split) rec(8);                        // the tail may sit on another stream than the HF stage: its own start mark
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     rec(4);
     LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
@@ -1159,7 +1160,7 @@ StageTimes Batch::CollectTimes(int* runs) {
     if (!complete) { for (auto e : evs) if (e) (void)hipEventDestroy((hipEvent_t)e); (*runs)--; continue; }
     HIP_CHECK(hipEventSynchronize((hipEvent_t)evs[6]));
     float* dst[6] = {&t.lf_ms, &t.lfpost_ms, &t.hf_ms, &t.idct_ms, &t.filter_ms, &t.out_ms};
-    for (int i = 0; i < 6; i++) { float ms = 0; void* st = (i == 2 && evs[7]) ? evs[7] : evs[i]; HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)st, (hipEvent_t)evs[i + 1])); *dst[i] += ms; }
+    for (int i = 0; i < 6; i++) { float ms = 0; void* st = (i == 2 && evs[7]) ? evs[7] : (i == 3 && evs[8]) ? evs[8] : evs[i]; HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)st, (hipEvent_t)evs[i + 1])); *dst[i] += ms; }
     float tot = 0; HIP_CHECK(hipEventElapsedTime(&tot, (hipEvent_t)evs[0], (hipEvent_t)evs[6])); t.total_ms += tot;
     for (auto e : evs) if (e) (void)hipEventDestroy((hipEvent_t)e);
   }

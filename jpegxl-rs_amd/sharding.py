@@ -26,3 +26,34 @@ def gather_frames(local, dst: int = 0, group=None):
     out = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local, out, dst=dst, group=group)
     return out
+
+
+def gather_frames_chunked(local, out=None, dst: int = 0, chunk_frames: int = 32, group=None):
+    """Gathers [frames, ...] tensors of equal shape to rank `dst` as point-to-point transfers of `chunk_frames` frames each,
+    placed directly at their final position in `out` ([world, frames, ...] on dst; allocated when None).  One group of
+    sends/receives per chunk: on GPUs (RCCL) every peer's chunk travels over its own xGMI link at the same time, a chunk is at
+    most world x chunk_frames x frame bytes in flight, and the first chunks can leave while later work is still queued
+    behind them on the compute stream.  Returns `out` on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = local.shape[0]
+    chunk_frames = max(1, int(chunk_frames))
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        if tuple(out.shape) != (world,) + tuple(local.shape) or out.dtype != local.dtype:
+            raise ValueError("gather destination must be [world, *local.shape] of the same dtype")
+        if out[dst].data_ptr() != local.data_ptr():
+            out[dst].copy_(local, non_blocking=True)
+    for c0 in range(0, n, chunk_frames):
+        c1 = min(n, c0 + chunk_frames)
+        if rank == dst:
+            ops = [dist.P2POp(dist.irecv, out[r][c0:c1], r, group) for r in range(world) if r != dst]
+        else:
+            ops = [dist.P2POp(dist.isend, local[c0:c1], dst, group)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()       # (RCCL: orders the current stream after the transfer, does not block the host)
+    return out if rank == dst else None

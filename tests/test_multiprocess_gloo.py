@@ -19,7 +19,7 @@ def _worker(rank, world, port, nframes, tmp):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import oracle_lib as O
     import synth_lib as S
-    from jpegxl_rs_amd.sharding import shard_range, gather_frames
+    from jpegxl_rs_amd.sharding import shard_range, gather_frames, gather_frames_chunked
     b, e = shard_range(nframes, world, rank)
     frames = []
     for i in range(b, e):
@@ -31,10 +31,22 @@ def _worker(rank, world, port, nframes, tmp):
     assert t.item() == world
     dist.barrier()
     out = gather_frames(local, dst=0)
+    # the chunked point-to-point form bench.py uses (direct placement, ragged last chunk, a view of a larger job buffer as target)
+    job = torch.zeros((world, 3 * local.shape[0]) + tuple(local.shape[1:]), dtype=local.dtype) if rank == 0 else None
+    n = local.shape[0]
+    for j in range(3):
+        res = gather_frames_chunked(local + j, job[:, j * n:(j + 1) * n] if rank == 0 else None, dst=0, chunk_frames=1 + j)
+        assert (res is None) == (rank != 0)
+    alloc = gather_frames_chunked(local, None, dst=0, chunk_frames=5)
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), torch.cat(out).numpy())
+        for j in range(3):
+            assert torch.equal(job[:, j * n:(j + 1) * n].reshape((-1,) + tuple(local.shape[1:])), torch.cat(out) + j)
+        assert torch.equal(alloc.reshape((-1,) + tuple(local.shape[1:])), torch.cat(out))
+        with pytest.raises(ValueError):
+            gather_frames_chunked(local, torch.zeros((world, n + 1) + tuple(local.shape[1:]), dtype=local.dtype), dst=0)
     else:
-        assert out is None
+        assert out is None and alloc is None
     dist.destroy_process_group()
 
 
