@@ -56,6 +56,8 @@ struct ConstOffsets {
   size_t mod_ctx = 0, mod_cfg = 0, mod_alias = 0, mod_pc = 0, mod_po = 0, mod_ps = 0, mod_chan = 0, up_weights = 0;
   struct Pass { size_t ac_ctx = 0, ac_cfg = 0, ac_alias = 0, ac_pc = 0, ac_po = 0, ac_ps = 0; size_t orders[39] = {0}; };
   vec<Pass> pass;
+  struct Local { uint32_t unit = 0; size_t tree = 0, ctx = 0, cfg = 0, alias = 0, pc = 0, po = 0, ps = 0; };   // sub-streams with their own tree / code
+  vec<Local> local;
   size_t qtable[17 * 3] = {0};
   bool has_qtable[17] = {false};
 };
@@ -133,6 +135,7 @@ Batch::~Batch() {
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   if (dframes_) (void)hipFree(dframes_);
   if (dpasses_) (void)hipFree(dpasses_);
+  if (dlocal_) (void)hipFree(dlocal_);
 }
 
 // The coefficient and pixel planes are only touched by the "rest" half of a decode (HF decode ... write), which a caller
@@ -173,6 +176,8 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
     if (!p.modular) {
       for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
       if (p.has_global_tree && (p.tree_code.use_prefix || p.tree_code.lz77)) throw ParseError("unsupported: prefix-coded / LZ77 LF streams of a VarDCT frame", true);
+      if (p.max_prop >= 16) throw ParseError("unsupported: previous-channel MA properties in a VarDCT frame", true);
+      if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
     }
     for (auto& x : ih.extra) if (x.dim_shift != 0 || x.depth.is_float) throw ParseError("unsupported: subsampled / float extra channel", true);
     if (p.modular && ih.depth.is_float) throw ParseError("unsupported: float Modular samples", true);
@@ -342,6 +347,13 @@ void Batch::Prepare(void* stream_v) {
     if (p.has_global_tree) {
       c.tree = arena.Put(p.tree.nodes.data(), p.tree.nodes.size() * sizeof(TreeNode));
       PutCode(arena, p.tree_code, &c.mod_ctx, &c.mod_cfg, &c.mod_alias, &c.mod_pc, &c.mod_po, &c.mod_ps);
+    }
+    for (auto& ls : p.local_streams) {
+      ConstOffsets::Local l;
+      l.unit = ls.unit;
+      l.tree = arena.Put(ls.tree.nodes.data(), ls.tree.nodes.size() * sizeof(TreeNode));
+      PutCode(arena, ls.code, &l.ctx, &l.cfg, &l.alias, &l.pc, &l.po, &l.ps);
+      c.local.push_back(l);
     }
     c.bcm = arena.Put(&p.bcm, sizeof(p.bcm));
     if (!p.modular) {
@@ -518,6 +530,20 @@ void Batch::Prepare(void* stream_v) {
       f.mod_code = ViewCode(p.tree_code, cbase, c.mod_ctx, c.mod_cfg, c.mod_alias, c.mod_pc, c.mod_po, c.mod_ps);
     }
     f.uses_wp = p.tree.uses_wp; f.gwp = p.gwp;
+    f.tree_max_prop = (uint32_t)p.tree.max_prop;
+    if (!c.local.empty()) {
+      // descriptor table of the frame's units (0 = global stream), zero = "uses the frame's tree"
+      ModLocalDev* table = &local_host_[local_first_[i]];
+      f.mod_local = dlocal_ + local_first_[i];
+      for (size_t k = 0; k < c.local.size(); k++) {
+        const ConstOffsets::Local& l = c.local[k];
+        const FramePlan::LocalStream& ls = p.local_streams[k];
+        ModLocalDev& d = table[l.unit];
+        d.tree = (const TreeNode*)(cbase + l.tree); d.tree_nodes = (uint32_t)ls.tree.nodes.size(); d.uses_wp = ls.tree.uses_wp; d.max_prop = (uint32_t)ls.tree.max_prop;
+        d.data_bitpos = ls.data_bitpos;
+        d.code = ViewCode(ls.code, cbase, l.ctx, l.cfg, l.alias, l.pc, l.po, l.ps);
+      }
+    }
     f.bcm = (const BlockCtxDev*)(cbase + c.bcm);
     f.status = (uint32_t*)(dwork_ + status_off_) + i;
     f.frame_flags = (uint32_t*)(dwork_ + flags_off) + i;
@@ -678,10 +704,14 @@ void Batch::Prepare(void* stream_v) {
   }
   {  // LDS right-sizing for the decode kernels
     auto code_bytes = [](const HostCode& c, bool ctx) { return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
-    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0;
+    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0; cfg.any_local_trees = 0;
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
       if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); cfg.any_wp |= p.tree.uses_wp ? 1 : 0; }
+      for (auto& ls : p.local_streams) {
+        cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)ls.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(ls.code, false)); cfg.any_wp |= ls.tree.uses_wp ? 1 : 0;
+        if (ls.unit != 0) cfg.any_local_trees = 1;
+      }
       if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
     }
     if (getenv("JXL_HIP_DEBUG_LDS")) fprintf(stderr, "[jxl-hip] LDS sizing: tree nodes %d, modular code %d B, AC code %d B, BlockCtxDev %zu B\n", cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.ac_code_bytes, sizeof(BlockCtxDev));
@@ -694,6 +724,19 @@ void Batch::Prepare(void* stream_v) {
     if (dpasses_) { (void)hipFree(dpasses_); dpasses_ = nullptr; }
     HIP_CHECK(hipMalloc((void**)&dpasses_, sizeof(PassDev) * passes_host_.size()));
   }
+  {  // descriptors of the sub-streams with their own tree / code: one table per frame that has any
+    local_first_.assign(n, 0);
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+      const FramePlan& p = images_[i]->plan;
+      local_first_[i] = total;
+      if (!p.local_streams.empty()) total += 1 + (size_t)p.num_lf_groups + p.num_groups;
+    }
+    local_host_.assign(std::max<size_t>(total, 1), ModLocalDev());
+    for (auto& d : local_host_) memset(&d, 0, sizeof(d));
+    if (dlocal_) { (void)hipFree(dlocal_); dlocal_ = nullptr; }
+    HIP_CHECK(hipMalloc((void**)&dlocal_, sizeof(ModLocalDev) * local_host_.size()));
+  }
   if (any_complex_) {
     vec<size_t> upw(n, 0);
     for (int i = 0; i < n; i++) upw[i] = co[i].up_weights;
@@ -705,6 +748,7 @@ void Batch::Prepare(void* stream_v) {
   for (int i = 0; i < n; i++) fill_frame(i, dconst_);
   HIP_CHECK(hipMemcpyAsync(dframes_, frames_host_.data(), sizeof(FrameDev) * n, hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipMemcpyAsync(dpasses_, passes_host_.data(), sizeof(PassDev) * passes_host_.size(), hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipMemcpyAsync(dlocal_, local_host_.data(), sizeof(ModLocalDev) * local_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
   prepared_ = true;
@@ -725,7 +769,9 @@ void Batch::EnqueueModularTail(void* stream_v) {
         case ModOp::kPalette: {
           int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
           for (uint32_t c = 0; c < op.num_c; c++) outs[c] = P(op.out[c]);
-          LaunchModPalette(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.n, stream_v);
+          if (op.nb_deltas == 0 && op.predictor == 0) LaunchModPalette(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.n, stream_v);
+          else LaunchModPaletteDelta(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.nb_deltas, op.predictor, op.aw, op.ah, images_[i]->plan.gwp,
+                                     op.predictor == 6 ? P(op.wp_scratch) : nullptr, op.wp_stride, stream_v);
           break;
         }
         case ModOp::kSqueeze: LaunchModInvSqueeze(P(op.in[0]), P(op.in[1]), P(op.out[0]), op.param, op.aw, op.ah, op.rw, op.rh, stream_v); break;
@@ -771,6 +817,8 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
       if (td.num_c > 4) throw ParseError("unsupported: palette with more than 4 channels", true);
       op.out[0] = idx.off;
       for (uint32_t c = 1; c < td.num_c; c++) op.out[c] = take(op.n * 4 + 64);
+      op.nb_deltas = td.nb_deltas; op.predictor = td.predictor; op.aw = idx.w; op.ah = idx.h;
+      if (td.predictor == 6) { op.wp_stride = 10 * (idx.w + 2); op.wp_scratch = take((size_t)op.wp_stride * 4 * td.num_c); }   // weighted-predictor state per output channel
       ops.push_back(op);
       vec<HC> nl;
       for (size_t k = 1; k < list.size(); k++) {

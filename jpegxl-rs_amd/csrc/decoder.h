@@ -131,6 +131,9 @@ class Batch {
   PassDev* dpasses_ = nullptr;
   vec<PassDev> passes_host_;
   vec<size_t> pass_first_;
+  ModLocalDev* dlocal_ = nullptr;      // descriptors of Modular sub-streams with their own tree / code (FrameDev::mod_local)
+  vec<ModLocalDev> local_host_;
+  vec<size_t> local_first_;
   bool any_multipass_ = false;
   size_t flags_off_ = 0, hfw_off_ = 0;
   vec<uint32_t> hf_written_;   // per unit: non-zero AC coefficients per decode (from the device counter, read by Finish)
@@ -149,6 +152,7 @@ class Batch {
     size_t in[4] = {0, 0, 0, 0}, out[4] = {0, 0, 0, 0};   // work-arena offsets
     size_t n = 0;
     uint32_t param = 0, num_c = 0, bits = 0, aw = 0, ah = 0, rw = 0, rh = 0;
+    uint32_t nb_deltas = 0, predictor = 0, wp_stride = 0; size_t wp_scratch = 0;   // palette with delta entries / a predictor
     bool has_alpha = false;
     float color_factor = 1.0f, alpha_factor = 1.0f;
   };

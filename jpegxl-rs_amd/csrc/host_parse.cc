@@ -558,6 +558,7 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
 }
 
 static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p);
+static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p);
 
 void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* p) {
   Reader r(cs, frame_bitpos);
@@ -690,6 +691,8 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   rg.limit_bits = (p->sections[0].offset + p->sections[0].size) * 8;
   ParseLfGlobal(rg, ih, p);
   p->end_bitpos = rg.pos();
+  ParseLocalModularStreams(cs, p);
+  if (p->max_prop >= 16 + 4 * kMaxModRefs) Unsupported("MA tree property beyond the supported previous-channel references");
   if (!p->single_section && !p->modular) ParseHfGlobal(cs, ih, p->sections[1 + p->num_lf_groups].offset * 8, p);
 }
 
@@ -813,8 +816,9 @@ static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
     size_t limit = std::min<size_t>(1u << 22, 1024 + (size_t)p->width * p->height * (nb_color + ih.extra.size()) / 16);
     ReadTree(r, &p->tree, limit);
     ReadEntropyCode(r, p->tree.num_leaves, &p->tree_code);
-    if (p->tree.max_prop >= 16) Unsupported("MA tree referencing previous channels (property >= 16)");
+    p->max_prop = p->tree.max_prop;
   }
+  p->local_streams.clear();
   p->gchannels.clear();
   for (uint32_t c = 0; c < nb_color + ih.extra.size(); c++) p->gchannels.push_back({p->width, p->height, 0, 0});
   p->nb_meta_channels = 0;
@@ -873,8 +877,17 @@ static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
       }
     }
   }
-  if (!p->g_use_global_tree) Unsupported("local MA tree in the global modular stream");
-  if (!p->has_global_tree) Fail("global tree missing");
+  if (!p->g_use_global_tree) {
+    // the global stream brings its own tree and code (encoding.cc ModularDecode)
+    FramePlan::LocalStream ls;
+    size_t pixels = 0;
+    for (auto& c : p->gchannels) pixels += (size_t)c.w * c.h;
+    ReadTree(r, &ls.tree, std::min<size_t>(1u << 22, 1024 + pixels));
+    ReadEntropyCode(r, ls.tree.num_leaves, &ls.code);
+    ls.unit = 0;
+    p->max_prop = std::max(p->max_prop, ls.tree.max_prop);
+    p->local_streams.push_back(std::move(ls));
+  } else if (!p->has_global_tree) Fail("global tree missing");
   uint32_t end = (uint32_t)p->gchannels.size();
   for (uint32_t i = 0; i < p->gchannels.size(); i++) {
     const auto& c = p->gchannels[i];
@@ -882,6 +895,47 @@ static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
   }
   p->global_decodable = end;
   p->global_data_bitpos = r.pos();
+  if (!p->local_streams.empty()) p->local_streams[0].data_bitpos = r.pos();
+}
+
+// Sections of a Modular frame start with their Modular sub-stream: read the GroupHeader of every LfGroup / PassGroup unit that
+// holds channels and, where it says use_global_tree = 0, the stream's own tree and code (dec_modular.cc DecodeGroup,
+// encoding.cc ModularDecode).  VarDCT frames keep such streams behind data only the device decodes: not parsed here.
+static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p) {
+  if (!p->modular || p->single_section || p->global_decodable >= p->gchannels.size()) return;
+  const uint32_t total = p->num_lf_groups + p->num_groups;
+  for (uint32_t unit = 0; unit < total; unit++) {
+    const bool is_lf = unit < p->num_lf_groups;
+    const uint32_t g = is_lf ? unit : unit - p->num_lf_groups;
+    const uint32_t dim = is_lf ? p->group_dim * 8 : p->group_dim, cols = is_lf ? p->xlfgroups : p->xgroups;
+    const uint32_t x0 = (g % cols) * dim, y0 = (g / cols) * dim;
+    const int min_shift = is_lf ? 3 : 0, max_shift = is_lf ? 1000 : 2;
+    size_t pixels = 0;
+    for (size_t c = p->global_decodable; c < p->gchannels.size(); c++) {
+      const auto& m = p->gchannels[c];
+      if (m.w == 0 || m.h == 0) continue;
+      const int shift = std::min(m.hshift, m.vshift);
+      if (shift < min_shift || shift > max_shift) continue;
+      const uint32_t rx = x0 >> m.hshift, ry = y0 >> m.vshift;
+      if (rx >= m.w || ry >= m.h) continue;
+      pixels += (size_t)std::min(dim >> m.hshift, m.w - rx) * std::min(dim >> m.vshift, m.h - ry);
+    }
+    if (pixels == 0) continue;
+    const Section& sec = p->sections[is_lf ? 1 + g : 2 + p->num_lf_groups + g];
+    Reader r(cs, sec.offset * 8);
+    r.limit_bits = (sec.offset + sec.size) * 8;
+    if (r.b()) { if (!p->has_global_tree) Fail("global tree missing"); continue; }
+    if (!r.b()) { r.u(5); r.u(5); for (int i = 0; i < 5; i++) r.u(5); for (int i = 0; i < 4; i++) r.u(4); }   // WPHeader (read again on the device)
+    const uint32_t nt = r.U32({0, 0}, {0, 1}, {4, 2}, {8, 18});
+    for (uint32_t i = 0; i < nt; i++) { TransformDesc t; ReadTransform(r, &t); }
+    FramePlan::LocalStream ls;
+    ReadTree(r, &ls.tree, std::min<size_t>(1u << 20, 1024 + pixels));
+    ReadEntropyCode(r, ls.tree.num_leaves, &ls.code);
+    ls.unit = 1 + unit;
+    ls.data_bitpos = r.pos();
+    p->max_prop = std::max(p->max_prop, ls.tree.max_prop);
+    p->local_streams.push_back(std::move(ls));
+  }
 }
 
 void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos, FramePlan* p) {

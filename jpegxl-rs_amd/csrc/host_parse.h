@@ -149,6 +149,12 @@ struct FramePlan {
   vec<TransformDesc> gtransforms;
   WPHeader gwp;
   bool g_use_global_tree = true;
+  // Modular sub-streams with an MA tree and an entropy code of their own (GroupHeader.use_global_tree = 0): unit 0 = the global
+  // stream, 1 + u = LfGroup / PassGroup unit u (LF groups first).  Parsed on the host for Modular frames, whose sections start
+  // with their stream; data_bitpos = absolute bit position of the stream's ANS state.
+  struct LocalStream { uint32_t unit = 0; HostTree tree; HostCode code; uint64_t data_bitpos = 0; };
+  vec<LocalStream> local_streams;
+  int max_prop = 0;                  // largest property index any MA tree of the frame tests
   uint64_t global_data_bitpos = 0;   // absolute bit position (codestream) where the global stream's ANS state starts
   uint32_t global_decodable = 0;     // number of leading channels decoded in the global section
   uint32_t nb_color_channels = 0;    // colour channels held in the modular image (0 for VarDCT)

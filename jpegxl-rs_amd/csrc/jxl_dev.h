@@ -217,7 +217,13 @@ struct ChannelDesc {
   int32_t* data;   // top-left sample
   int32_t w, h;
   int32_t stride;  // in samples
+  int32_t hs, vs;           // subsampling shifts (only compared: previous-channel properties need channels of identical geometry)
 };
+
+// Previous channels of the same sub-stream with the geometry of the one being decoded, nearest first (context_predict.h
+// PrecomputeReferences): what properties 16 + 4r .. 19 + 4r look at.
+constexpr int kMaxModRefs = 8;
+struct ModRefs { int32_t n; int32_t stride[kMaxModRefs]; const int32_t* data[kMaxModRefs]; };
 
 JXL_HD int FloorLog2u64(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -314,7 +320,26 @@ struct ModularCtx {
   uint32_t narrow_wp = 0;  // device fast path: 32-bit weighted-predictor intermediates are exact (samples of at most 12 bits)
   uint32_t slow = 0;       // the code uses prefix codes and / or LZ77: symbols are read by the general reader (tables in global memory)
   Lz77State* lz = nullptr; // LZ77 state of the stream (slow && code->lz77)
+  uint32_t max_prop = 0;   // largest property index in the tree (>= 16: previous-channel properties, evaluated from `refs`)
+  const ModRefs* refs = nullptr;
 };
+
+// properties 16.. (context_predict.h): |v|, v, |v - g|, v - g of the r-th reference channel at (x, y), g = clamped gradient of its W / N / NW
+JXL_HD int32_t RefPropValue(const ModRefs* refs, int prop, int x, int y) {
+  const int r = (prop - 16) >> 2, k = (prop - 16) & 3;
+  if (!refs || r >= refs->n) return 0;
+  const int32_t* rp = refs->data[r] + (size_t)y * refs->stride[r];
+  const int64_t v = rp[x];
+  if (k == 0) return (int32_t)(v < 0 ? -v : v);
+  if (k == 1) return (int32_t)v;
+  const int64_t rl = x ? rp[x - 1] : 0;
+  const int64_t rt = y ? rp[x - refs->stride[r]] : rl;
+  const int64_t rtl = (x && y) ? rp[x - 1 - refs->stride[r]] : rl;
+  const int64_t m = rt < rl ? rt : rl, M = rt < rl ? rl : rt;
+  const int64_t g = rtl < m ? M : (rtl > M ? m : rt + rl - rtl);
+  const int64_t d = v - g;
+  return k == 2 ? (int32_t)(d < 0 ? -d : d) : (int32_t)d;
+}
 
 // Decodes channel `chan` (index within the sub-stream, = property 0) — encoding.cc DecodeModularChannelMAANS.
 // Properties >= 16 (previous-channel references) are rejected by the host before launch.

@@ -12,6 +12,10 @@ struct ModChanDev { uint64_t off; uint32_t w, h; int32_t hshift, vshift; };
 struct PassDev { DevCode code; const uint16_t* orders[39]; uint32_t shift; uint32_t pad; };
 
 // One per frame of a batch; array lives in device memory.  All pointers are device pointers.
+// A Modular sub-stream that carries its own MA tree and entropy code (GroupHeader.use_global_tree = 0, parsed on the host for
+// Modular frames, where every section starts with its stream).
+struct ModLocalDev { const TreeNode* tree; uint32_t tree_nodes, uses_wp, max_prop, pad; uint64_t data_bitpos; DevCode code; };
+
 struct FrameDev {
   // geometry
   uint32_t width, height, bw, bh, xgroups, ygroups, num_groups, xlfgroups, num_lf_groups, cw, ch;
@@ -31,6 +35,9 @@ struct FrameDev {
   DevCode mod_code;
   uint32_t uses_wp;
   WPHeader gwp;
+  uint32_t tree_max_prop;         // largest property index in any MA tree of the frame (>= 16: previous-channel properties)
+  const ModLocalDev* mod_local;   // Modular sub-streams with a tree and code of their own, indexed 0 = global stream, 1 + unit = LfGroup /
+                                  // PassGroup unit (entries with tree == nullptr use the frame's tree); nullptr: none in this frame
   DevCode ac_code;
   const uint16_t* orders[39];
   const BlockCtxDev* bcm;
@@ -106,6 +113,7 @@ struct LaunchCfg {
   int lane_stride_hf = 64;
   int lane_stride_mod = 64;
   int any_wp = 0;            // some MA tree of the batch uses the weighted predictor (the Modular kernels then reserve LDS for its state)
+  int any_local_trees = 0;   // some Modular sub-stream carries its own MA tree / code (second launch of the group kernel)
   // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
   int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;
   int force_generic_idct = 0;
@@ -140,6 +148,8 @@ void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups,
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);
 void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, size_t n, void* stream);
+void LaunchModPaletteDelta(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, uint32_t nb_deltas, uint32_t predictor,
+                           uint32_t w, uint32_t h, const WPHeader& wp, int32_t* wp_scratch, uint32_t wp_stride, void* stream);
 void LaunchModOutput(const FrameDev* frames, int fidx, const ModOutputArgs& a, int w, int h, void* stream);
 
 // ---- frame tail of images with several frames or image features (kernels_features.hip); explicit arguments, device pointers ----

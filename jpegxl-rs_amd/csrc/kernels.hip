@@ -414,7 +414,14 @@ struct WPStateLds {
       St(1 + i, prev_row + x + 1, Ld(1 + i, prev_row + x + 1) + err);
     }
   }
-  __device__ __forceinline__ void Update(int64_t val, int x, int y) { if (narrow) UpdateT<int32_t>((int32_t)val, x, y); else UpdateT<int64_t>(val, x, y); }
+  // The 32-bit variant is only exact while every sample seen so far is small.  The image's bit depth promises that for plain
+  // streams, but residual channels (RCT, squeeze) or a hostile stream may exceed it: the first sample outside +-4095 switches
+  // this channel to the 64-bit arithmetic for good (the state arrays are the same in both variants; all inputs of the
+  // predictions made so far were within the bound).
+  __device__ __forceinline__ void Update(int64_t val, int x, int y) {
+    if (narrow) { UpdateT<int32_t>((int32_t)val, x, y); if ((uint64_t)(val + 4095) > 8190ull) narrow = false; }
+    else UpdateT<int64_t>(val, x, y);
+  }
 };
 constexpr int32_t kWpLdsMaxW = 256;                                   // channel widths whose WP state fits the per-wavefront LDS slot
 constexpr uint32_t kWpLdsBytes = WPStateLds::Bytes(kWpLdsMaxW) + 256;   // 10 320 B of error rows + the 64-entry division table
@@ -744,7 +751,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
   // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
   // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
   // and predictors read, the WP state.  Rows up to kRowMax samples; wider channels take the loop below.
-  const bool lds_generic = !mc.slow && T.tree_in_lds && T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
+  const bool lds_generic = !mc.slow && mc.max_prop < 16 && T.tree_in_lds && T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
   if (lds_generic) {
     const int w = ch.w, h = ch.h;
     const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
@@ -879,7 +886,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
           uint32_t pos = subroot;
           n = T.Node(pos);
           while (n.prop >= 0) {
-            const int32_t v = PropValue(n.prop & 15, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, wp_err);
+            const int32_t v = n.prop < 16 ? PropValue(n.prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, wp_err) : RefPropValue(mc.refs, n.prop, x, y);
             pos = v > n.val ? n.a : n.b;
             n = T.Node(pos);
           }
@@ -912,16 +919,16 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
 }
 
 // Stages tree + code into the shared part of the LDS (all threads of the block; one block barrier).
-__device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTables& T, uint32_t tree_cap, uint32_t lds_bytes) {
+__device__ void StageModular(const TreeNode* tree, uint32_t num_tree_nodes, const DevCode& code, ModTables& T, uint32_t tree_cap, uint32_t lds_bytes) {
   const uint32_t tree_off = (blockDim.x >> 6) * kWaveLds;   // shared part starts after the per-wavefront regions
   const uint32_t code_base = tree_off + tree_cap * 16;
   const uint32_t budget = lds_bytes > code_base ? lds_bytes - code_base : 0;
-  StageCode(f.mod_code, T.code, code_base, budget, /*with_ctx_map=*/false);
-  T.tree_g = f.tree;
+  StageCode(code, T.code, code_base, budget, /*with_ctx_map=*/false);
+  T.tree_g = tree;
   T.tree_cap = tree_cap;
   T.tree_in_lds = num_tree_nodes <= tree_cap;
   T.node_base = tree_off;
-  T.ctx_map_g = f.mod_code.ctx_map;
+  T.ctx_map_g = code.ctx_map;
   {  // larger trees: every wavefront of the workgroup gets a slice of the region for a pruned subtree
     const uint32_t nw = blockDim.x >> 6;
     T.prune_cap = T.tree_in_lds ? 0 : tree_cap / nw;
@@ -931,8 +938,8 @@ __device__ void StageModular(const FrameDev& f, uint32_t num_tree_nodes, ModTabl
   T.wp_off = 0xFFFFFFFFu;
   if (T.tree_in_lds) {
     for (uint32_t i = threadIdx.x; i < num_tree_nodes; i += blockDim.x) {
-      uint4 v = LdG(reinterpret_cast<const uint4*>(f.tree + i));
-      if ((int32_t)v.x < 0) v.z = (v.z & 0xFF) | ((uint32_t)LdG(f.mod_code.ctx_map + (v.z >> 8)) << 8);   // leaf: context -> cluster
+      uint4 v = LdG(reinterpret_cast<const uint4*>(tree + i));
+      if ((int32_t)v.x < 0) v.z = (v.z & 0xFF) | ((uint32_t)LdG(code.ctx_map + (v.z >> 8)) << 8);   // leaf: context -> cluster
       StS<uint4>(tree_off + i * 16, v);
     }
   }
@@ -1172,7 +1179,7 @@ template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? J
   const uint32_t first = blockIdx.x * groups_per_block;
   if (first >= f.num_lf_groups) return;
   ModTables T;
-  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  StageModular(f.tree, f.tree_nodes, f.mod_code, T, tree_cap, lds_bytes);
   __shared__ int s_fail_w[kLfDecWaves];
   __shared__ GroupHeaderD s_gh_w[kLfDecWaves];
   __shared__ uint32_t s_u_w[kLfDecWaves][4];
@@ -2895,9 +2902,28 @@ __device__ void InvRctD(int32_t* c0, int32_t* c1, int32_t* c2, size_t n, uint32_
   }
 }
 
+// palette.h kDeltaPalette: the implicit delta entries negative indices select (index -> entry (i + 1) / 2, sign by parity)
+__constant__ int16_t d_delta_palette[72][3] = {
+    {0, 0, 0},       {4, 4, 4},       {11, 0, 0},      {0, 0, -13},     {0, -12, 0},     {-10, -10, -10}, {-18, -18, -18}, {-27, -27, -27},
+    {-18, -18, 0},   {0, 0, -32},     {-32, 0, 0},     {-37, -37, -37}, {0, -32, -32},   {24, 24, 45},    {50, 50, 50},    {-45, -24, -24},
+    {-24, -45, -45}, {0, -24, -24},   {-34, -34, 0},   {-24, 0, -24},   {-45, -45, -24}, {64, 64, 64},    {-32, 0, -32},   {0, -32, 0},
+    {-32, 0, 32},    {-24, -45, -24}, {45, 24, 45},    {24, -24, -45},  {-45, -24, 24},  {80, 80, 80},    {64, 0, 0},      {0, 0, -64},
+    {0, -64, -64},   {-24, -24, 45},  {96, 96, 96},    {64, 64, 0},     {45, -24, -24},  {34, -34, 0},    {112, 112, 112}, {24, -45, -45},
+    {45, 45, -24},   {0, -32, 32},    {24, -24, 45},   {0, 96, 96},     {45, -24, 24},   {24, -45, -24},  {-24, -45, 24},  {0, -64, 0},
+    {96, 0, 0},      {128, 128, 128}, {64, 0, 64},     {144, 144, 144}, {96, 96, 0},     {-36, -36, 36},  {45, -24, -45},  {45, -45, -24},
+    {0, 0, -96},     {0, 128, 128},   {0, 96, 0},      {45, 24, -45},   {-128, 0, 0},    {24, -45, 24},   {-45, 24, -45},  {64, 0, -64},
+    {64, -64, -64},  {96, 0, 96},     {45, -45, 24},   {24, 45, -45},   {64, 64, -64},   {128, 128, 0},   {0, 0, -128},    {-24, 45, -45}};
+
 __device__ __forceinline__ int32_t PaletteValue(const int32_t* pal, int pal_w, int index, int c, int bit_depth) {
-  // palette.h GetPaletteValue (no delta entries: index < 0 only reachable with nb_deltas > 0, rejected)
-  if (index < 0) return 0;
+  // palette.h GetPaletteValue
+  if (index < 0) {
+    if (c >= 3) return 0;
+    index = -(index + 1);
+    index %= 1 + 2 * (72 - 1);
+    int32_t r = (int32_t)d_delta_palette[(index + 1) >> 1][c] * ((index & 1) ? 1 : -1);
+    if (bit_depth > 8) r *= 1 << (bit_depth - 8);
+    return r;
+  }
   if (index < pal_w) return pal[(size_t)c * pal_w + index];
   if (c >= 3) return 0;
   if (index < pal_w + 64) {
@@ -2922,7 +2948,7 @@ __device__ __forceinline__ bool ModUnitRect(const FrameDev& f, uint32_t c, uint3
   if (rx >= m.w || ry >= m.h) return false;
   const uint32_t rw = min(dim >> m.hshift, m.w - rx), rh = min(dim >> m.vshift, m.h - ry);
   if (rw == 0 || rh == 0) return false;
-  d->data = ModPlane(f, m) + (size_t)ry * m.w + rx; d->w = (int)rw; d->h = (int)rh; d->stride = (int)m.w;
+  d->data = ModPlane(f, m) + (size_t)ry * m.w + rx; d->w = (int)rw; d->h = (int)rh; d->stride = (int)m.w; d->hs = m.hshift; d->vs = m.vshift;
   return true;
 }
 
@@ -2932,19 +2958,27 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
   const FrameDev& f = frames[blockIdx.x];
   if (f.mod_nchan == 0) return;
   ModTables T;
-  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  // the global stream may carry a tree and a code of its own (GroupHeader.use_global_tree = 0; f.mod_global_bitpos is then past them)
+  const ModLocalDev* local = f.mod_local && f.mod_local[0].tree ? &f.mod_local[0] : nullptr;
+  const TreeNode* const tree = local ? local->tree : f.tree;
+  const uint32_t tree_nodes = local ? local->tree_nodes : f.tree_nodes;
+  const DevCode& code = local ? local->code : f.mod_code;
+  StageModular(tree, tree_nodes, code, T, tree_cap, lds_bytes);
   if (wp_base) T.wp_off = wp_base;
   const uint32_t lane = threadIdx.x & 63;
   BitReaderP br;
   br.Init(f.cs, f.mod_global_bitpos, f.cs_size);
   uint32_t state = 0x130000u;
-  if (lane == 0 && !f.mod_code.use_prefix) state = br.Read(32);
+  if (lane == 0 && !code.use_prefix) state = br.Read(32);
   ModularCtx mc;
-  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0; mc.narrow_wp = f.mod_bits <= 12;
+  mc.tree = tree; mc.code = &code; mc.uses_wp = local ? local->uses_wp : f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0; mc.narrow_wp = f.mod_bits <= 12;
+  mc.max_prop = local ? local->max_prop : f.tree_max_prop;
   mc.wp_scratch = f.mod_wp_scratch;
-  mc.slow = f.mod_code.use_prefix || f.mod_code.lz77;
+  mc.slow = code.use_prefix || code.lz77;
+  __shared__ ModRefs s_refs;
+  mc.refs = &s_refs;
   Lz77State lz;
-  if (f.mod_code.lz77) {
+  if (code.lz77) {
     uint32_t dist_mult = 0;
     for (uint32_t c = 0; c < f.mod_global_decodable; c++) dist_mult = max(dist_mult, f.mod_chan[c].w);
     lz.Init(f.lz_window, dist_mult);
@@ -2955,6 +2989,18 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
     if (mcd.w == 0 || mcd.h == 0) continue;  // (empty channels keep their index: property 0 is the position in the list)
     ChannelDesc ch;
     ch.data = ModPlane(f, mcd); ch.w = (int)mcd.w; ch.h = (int)mcd.h; ch.stride = (int)mcd.w;
+    if (mc.max_prop >= 16) {   // reference channels: earlier channels of this stream with the same geometry, nearest first
+      if (lane == 0) {
+        int n = 0;
+        for (int j = (int)c - 1; j >= 0 && n < kMaxModRefs; j--) {
+          const ModChanDev r = f.mod_chan[j];
+          if (r.w != mcd.w || r.h != mcd.h || r.hshift != mcd.hshift || r.vshift != mcd.vshift) continue;
+          s_refs.data[n] = ModPlane(f, r); s_refs.stride[n] = (int)r.w; n++;
+        }
+        s_refs.n = n;
+      }
+      WaveSync();
+    }
     DecodeChannelCoop(br, state, T, mc, ch, (int)c);
   }
   if (lane == 0) {
@@ -2977,20 +3023,29 @@ struct ModUnitShared {
   GroupHeaderD gh;
   ChannelDesc ch[12], dst[kMaxXformChan], fresh[4];
 };
-__global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base) {
+// local_pass = 1: the launch for units whose stream carries a tree / code of its own (f.mod_local) — one wavefront per workgroup,
+// each staging its unit's tables; the regular launch (0) skips those units.
+__global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base, uint32_t local_pass) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.mod_nchan == 0 || f.single_section) return;
+  if (local_pass ? !f.mod_local : !f.tree) return;   // (a frame without a global tree: every unit is decoded by the local pass)
   const uint32_t total = f.num_lf_groups + f.num_groups;
-  const uint32_t nwaves = blockDim.x >> 6;          // 4, or 2 when every wavefront needs a large pruned-tree slice
+  const uint32_t nwaves = blockDim.x >> 6;          // 4, or 2 when every wavefront needs a large pruned-tree slice; 1 in the local pass
   if (blockIdx.x * nwaves >= total) return;
   const uint32_t first = f.mod_global_decodable;
   if (first >= f.mod_nchan) return;
+  const ModLocalDev* local = nullptr;
+  if (local_pass) { local = &f.mod_local[1 + blockIdx.x]; if (!local->tree) return; }
+  const TreeNode* const tree = local ? local->tree : f.tree;
+  const uint32_t tree_nodes = local ? local->tree_nodes : f.tree_nodes;
+  const DevCode& code = local ? local->code : f.mod_code;
   ModTables T;
-  StageModular(f, f.tree_nodes, T, tree_cap, lds_bytes);
+  StageModular(tree, tree_nodes, code, T, tree_cap, lds_bytes);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wp_base) T.wp_off = wp_base + wave * kWpLdsBytes;
   const uint32_t unit = blockIdx.x * nwaves + wave;
   if (unit >= total) return;                     // (no block-wide barrier after this point)
+  if (!local_pass && f.mod_local && f.mod_local[1 + unit].tree) return;   // decoded by the local pass
   const bool is_lf = unit < f.num_lf_groups;
   if (!f.is_modular && is_lf) return;            // VarDCT: extra channels are never squeezed here, so ModularLfGroup is empty
   const uint32_t g = is_lf ? unit : unit - f.num_lf_groups;
@@ -3015,7 +3070,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
     if (nch > 0) {
       BitReader tmp;
       tmp.Init(f.cs, f.is_modular ? f.sec_off[si] * 8 : f.hf_end_bitpos[g], f.cs_size);
-      bool ok = ReadGroupHeader(tmp, U.gh) && U.gh.use_global_tree;
+      bool ok = ReadGroupHeader(tmp, U.gh) && (U.gh.use_global_tree ? local == nullptr : local != nullptr);   // (a local tree the host has not parsed: VarDCT frames)
       if (ok && U.gh.ntransforms != 0) {
         // local transforms: channels are decoded into the unit's scratch (at most kMaxXformChan of them)
         U.direct = 0;
@@ -3024,7 +3079,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
         int k = 0;
         for (uint32_t c = first; ok && c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) {
           U.dst[k] = d;
-          U.ch[k].data = scratch + used; U.ch[k].w = d.w; U.ch[k].h = d.h; U.ch[k].stride = d.w;
+          U.ch[k].data = scratch + used; U.ch[k].w = d.w; U.ch[k].h = d.h; U.ch[k].stride = d.w; U.ch[k].hs = d.hs; U.ch[k].vs = d.vs;
           used += (unsigned long long)d.w * d.h;
           k++;
         }
@@ -3039,7 +3094,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
             nch -= (int)(t.num_c - 1);
             for (int q = nch; q > 0; q--) U.ch[q] = U.ch[q - 1];                                         // palette channel at index 0
             nch++;
-            U.ch[0].data = scratch + used; U.ch[0].w = (int)t.nb_colors; U.ch[0].h = (int)t.num_c; U.ch[0].stride = (int)t.nb_colors;
+            U.ch[0].data = scratch + used; U.ch[0].w = (int)t.nb_colors; U.ch[0].h = (int)t.num_c; U.ch[0].stride = (int)t.nb_colors; U.ch[0].hs = -1; U.ch[0].vs = 0;
             used += (unsigned long long)t.nb_colors * t.num_c;
             nmeta++;
           } else ok = false;                                               // local squeeze
@@ -3049,8 +3104,8 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
       }
       if (!ok) SetError(f, kErrUnsupported);
       else {
-        br.Init(f.cs, tmp.BitPos(), sec_end);
-        state = f.mod_code.use_prefix ? 0x130000u : br.Read(32);
+        br.Init(f.cs, local ? local->data_bitpos : tmp.BitPos(), sec_end);   // (local: past the stream's own tree and code)
+        state = code.use_prefix ? 0x130000u : br.Read(32);
         U.nch = nch;
         U.go = 1;
       }
@@ -3059,12 +3114,16 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   WaveSync();
   if (!U.go) return;
   ModularCtx mc;
-  mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp; mc.wp = U.gh.wp; mc.narrow_wp = f.mod_bits <= 12;
+  mc.tree = tree; mc.code = &code; mc.uses_wp = local ? local->uses_wp : f.uses_wp; mc.wp = U.gh.wp; mc.narrow_wp = f.mod_bits <= 12;
+  mc.max_prop = local ? local->max_prop : f.tree_max_prop;
   mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
   mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
-  mc.slow = f.mod_code.use_prefix || f.mod_code.lz77;
+  mc.slow = code.use_prefix || code.lz77;
+  __shared__ ModRefs s_refs_w[kLfWaves];
+  ModRefs& refs = s_refs_w[wave];
+  mc.refs = &refs;
   Lz77State lz;
-  if (f.mod_code.lz77) {
+  if (code.lz77) {
     uint32_t dist_mult = 0;     // widest channel of the stream (modular/encoding/encoding.cc)
     if (U.direct) { for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) dist_mult = max(dist_mult, (uint32_t)d.w); }
     else for (int c = 0; c < U.nch; c++) dist_mult = max(dist_mult, (uint32_t)U.ch[c].w);
@@ -3073,10 +3132,40 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   }
   if (U.direct) {
     int k = 0;
-    for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) DecodeChannelCoop(br, state, T, mc, d, k++);
+    for (uint32_t c = first; c < f.mod_nchan; c++) if (ModUnitRect(f, c, x0, y0, dim, min_shift, max_shift, &d)) {
+      if (mc.max_prop >= 16) {   // reference channels: earlier channels of this stream with the same geometry, nearest first
+        if (lane == 0) {
+          int n = 0;
+          ChannelDesc r;
+          for (int j = (int)c - 1; j >= (int)first && n < kMaxModRefs; j--) {
+            if (!ModUnitRect(f, (uint32_t)j, x0, y0, dim, min_shift, max_shift, &r)) continue;
+            if (r.w != d.w || r.h != d.h || r.hs != d.hs || r.vs != d.vs) continue;
+            refs.data[n] = r.data; refs.stride[n] = r.stride; n++;
+          }
+          refs.n = n;
+        }
+        WaveSync();
+      }
+      DecodeChannelCoop(br, state, T, mc, d, k++);
+    }
   } else {
     const int nch = U.nch;
-    for (int c = 0; c < nch; c++) { const ChannelDesc cd = U.ch[c]; DecodeChannelCoop(br, state, T, mc, cd, c); }
+    for (int c = 0; c < nch; c++) {
+      const ChannelDesc cd = U.ch[c];
+      if (mc.max_prop >= 16) {
+        if (lane == 0) {
+          int n = 0;
+          for (int j = c - 1; j >= 0 && n < kMaxModRefs; j--) {
+            const ChannelDesc r = U.ch[j];
+            if (r.w != cd.w || r.h != cd.h || r.hs != cd.hs || r.vs != cd.vs) continue;
+            refs.data[n] = r.data; refs.stride[n] = r.stride; n++;
+          }
+          refs.n = n;
+        }
+        WaveSync();
+      }
+      DecodeChannelCoop(br, state, T, mc, cd, c);
+    }
   }
   int fail = 0;
   if (lane == 0) {
@@ -3204,6 +3293,63 @@ __global__ void ModPaletteKernel(ModPaletteArgs a) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += ts) {
     const int index = a.out[0][i];
     for (int c = (int)a.num_c - 1; c >= 0; c--) a.out[c][i] = PaletteValue(a.pal, (int)a.nb_colors, index, c, (int)a.bit_depth);
+  }
+}
+
+// Palettes with delta entries / a predictor (palette.h InvPalette, the nb_deltas / predictor branch): entries below nb_deltas and
+// the implicit negative ones are added to a prediction from the already reconstructed neighbours of the same output channel, so
+// a channel is a serial raster scan.  Lane c of one wavefront owns channel c; the lanes walk the pixels together because
+// channel 0 is written over the index plane.
+struct ModPaletteDeltaArgs { const int32_t* pal; int32_t* out[4]; uint32_t nb_colors, num_c, bit_depth, nb_deltas, predictor, w, h; WPHeader wp; int32_t* wp_scratch; uint32_t wp_stride; };
+__global__ __launch_bounds__(64) void ModPaletteDeltaKernel(ModPaletteDeltaArgs a) {
+  const uint32_t c = threadIdx.x;
+  const bool active = c < a.num_c;
+  int32_t* p = a.out[active ? c : 0];
+  WPState wps;
+  if (active && a.predictor == 6) wps.Init(a.wp_scratch + (size_t)c * a.wp_stride, (int32_t)a.w);
+  const int w = (int)a.w, h = (int)a.h;
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      const size_t i = (size_t)y * w + x;
+      const int index = a.out[0][i];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();           // every lane has the index before lane 0 replaces it
+      if (active) {
+        int32_t val = PaletteValue(a.pal, (int)a.nb_colors, index, (int)c, (int)a.bit_depth);
+        const int64_t W = x ? p[i - 1] : (y ? p[i - w] : 0);
+        const int64_t N = y ? p[i - w] : W;
+        const int64_t NW = (x && y) ? p[i - w - 1] : W;
+        const int64_t NE = (x + 1 < w && y) ? p[i - w + 1] : N;
+        const int64_t WW = x > 1 ? p[i - 2] : W;
+        const int64_t NN = y > 1 ? p[i - 2 * (size_t)w] : N;
+        const int64_t NEE = (x + 2 < w && y) ? p[i - w + 2] : NE;
+        int64_t wp_pred = 0;
+        int32_t unused;
+        if (a.predictor == 6) wp_pred = wps.Predict(a.wp, x, y, N, W, NE, NW, NN, &unused);
+        if (index < (int)a.nb_deltas) {
+          int64_t guess;
+          switch (a.predictor) {
+            case 0: guess = 0; break;
+            case 1: guess = W; break;
+            case 2: guess = N; break;
+            case 3: guess = (W + N) / 2; break;
+            case 4: { const int64_t pp = W + N - NW; guess = Abs64(pp - W) < Abs64(pp - N) ? W : N; break; }
+            case 5: { const int64_t m = Min64(N, W), M = Max64(N, W); guess = NW < m ? M : (NW > M ? m : N + W - NW); break; }
+            case 6: guess = (wp_pred + 3) >> 3; break;
+            case 7: guess = NE; break;
+            case 8: guess = NW; break;
+            case 9: guess = WW; break;
+            case 10: guess = (W + NW) / 2; break;
+            case 11: guess = (N + NW) / 2; break;
+            case 12: guess = (N + NE) / 2; break;
+            default: guess = (6 * N - 2 * NN + 7 * W + WW + NEE + 3 * NE + 8) / 16; break;
+          }
+          val = (int32_t)((int64_t)val + guess);
+        }
+        p[i] = val;
+        if (a.predictor == 6) wps.Update(val, x, y);
+      }
+    }
   }
 }
 
@@ -3416,7 +3562,12 @@ void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups,
   PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGroupFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
-  hipLaunchKernelGGL(ModularGroupFastKernel, dim3(DivUp(max_lf_groups + max_groups, (int)nwaves), nframes), dim3(64 * nwaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base);
+  hipLaunchKernelGGL(ModularGroupFastKernel, dim3(DivUp(max_lf_groups + max_groups, (int)nwaves), nframes), dim3(64 * nwaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 0u);
+  if (cfg.any_local_trees) {   // units with a tree / code of their own: one wavefront per workgroup, each staging its own tables
+    nwaves = 1;
+    PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
+    hipLaunchKernelGGL(ModularGroupFastKernel, dim3(max_lf_groups + max_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 1u);
+  }
 }
 void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream) {
   uint32_t nwaves = 1, tree_cap, lds_tables, wp_base, lds_bytes;
@@ -3437,6 +3588,14 @@ void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_color
   a.pal = pal; a.nb_colors = nb_colors; a.num_c = num_c; a.bit_depth = bit_depth; a.n = n;
   for (uint32_t c = 0; c < 4; c++) a.out[c] = c < num_c ? out[c] : nullptr;
   hipLaunchKernelGGL(ModPaletteKernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+}
+void LaunchModPaletteDelta(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, uint32_t nb_deltas, uint32_t predictor,
+                           uint32_t w, uint32_t h, const WPHeader& wp, int32_t* wp_scratch, uint32_t wp_stride, void* stream) {
+  ModPaletteDeltaArgs a;
+  a.pal = pal; a.nb_colors = nb_colors; a.num_c = num_c; a.bit_depth = bit_depth; a.nb_deltas = nb_deltas; a.predictor = predictor; a.w = w; a.h = h;
+  a.wp = wp; a.wp_scratch = wp_scratch; a.wp_stride = wp_stride;
+  for (uint32_t c = 0; c < 4; c++) a.out[c] = c < num_c ? out[c] : nullptr;
+  hipLaunchKernelGGL(ModPaletteDeltaKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
 }
 void LaunchModOutput(const FrameDev* frames, int fidx, const ModOutputArgs& a, int w, int h, void* stream) {
   dim3 block(64, 4), grid(DivUp(w, 64), DivUp(h, 4));

@@ -136,3 +136,26 @@ def encode_modular_frame(img, fx, bits=8, rct=False, squeeze=0):
     if L.jxlsynth_modular3(arr, nchan, 1 if has_alpha else 0, w, h, bits, 1 if rct else 0, int(squeeze), C.byref(fx), C.byref(out), C.byref(n)):
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)
+
+
+class FreeParams(C.Structure):
+    """tools/jxl_synth.cc jxlsynth_free_params (tools/synth_free.h FreeParams)."""
+    _fields_ = [("seed", C.c_uint32)] + [(n, C.c_int) for n in ("w", "h", "nchan", "has_alpha", "bits", "tree_flags", "tree_depth", "local_trees", "lz77",
+                                                                 "palette", "nb_colors", "nb_deltas", "pal_pred")]
+
+
+TREE_WP, TREE_PREV_CHANNELS, TREE_MULTIPLIERS, TREE_ALL_PREDICTORS, TREE_CUSTOM_WP = 1, 2, 4, 8, 16
+
+
+def encode_modular_free(seed=1, w=64, h=64, nchan=3, has_alpha=False, bits=8, tree_flags=0, tree_depth=5, local_trees=0, lz77=False,
+                        palette=False, nb_colors=16, nb_deltas=0, pal_pred=0):
+    """Free-running Modular stream (tools/synth_free.h): random MA trees / predictors / properties, local trees, LZ77, delta
+    palettes.  The pixels are whatever a decoder makes of the token stream — for decoder-vs-decoder parity only."""
+    L = lib()
+    L.jxlsynth_modular_free.argtypes = [C.POINTER(FreeParams), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    p = FreeParams(seed, w, h, nchan, 1 if has_alpha else 0, bits, tree_flags, tree_depth, local_trees, 1 if lz77 else 0,
+                   1 if palette else 0, nb_colors, nb_deltas, pal_pred)
+    out = C.c_void_p(); n = C.c_size_t()
+    if L.jxlsynth_modular_free(C.byref(p), C.byref(out), C.byref(n)):
+        raise RuntimeError(L.jxlsynth_last_error().decode())
+    return _take(out, n)

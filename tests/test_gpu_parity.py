@@ -784,3 +784,27 @@ def test_memory_manager_out_of_memory_is_an_error_not_a_crash(jx, tmp_path):
         dec.decode_with(fixture_bytes("sample.jxl"), np.uint8)
     del dec
     B.bump_destroy(arena)
+
+
+from free_cases import FREE_CASES
+
+
+@pytest.mark.parametrize("name", sorted(FREE_CASES))
+def test_free_running_modular_streams(jx, name):
+    """Modular features no encoder run is available for (SURVEY.md B.5 [R] rows): random MA trees over every property incl. the
+    weighted predictor's error (15) and previous-channel properties (>= 16), all 14 predictors with offsets / multipliers, custom
+    WP headers, per-section local trees, LZ77 with special distances, palettes with delta entries and a predictor.  The streams
+    come from tools/synth_free.h (one shared histogram, so any token sequence is a valid stream); the pixels are whatever a
+    decoder makes of them and the HIP path must make the same of them as the oracle, at 16 bits so that little is clamped."""
+    kw = dict(FREE_CASES[name])
+    kw.setdefault("bits", 16)
+    data = S.encode_modular_free(**kw)
+    nch = (kw.get("nchan", 3)) + (1 if kw.get("has_alpha") else 0)
+    check_against_oracle(jx, data, np.uint16, nch)
+    # float output is not clamped: every decoded integer takes part (sample / 65535 in both decoders)
+    _, pf = check_against_oracle(jx, data, np.float32, nch)
+    assert np.unique(pf).size > (20 if "palette" in name else 200)
+    if "palette_delta_every" in name:
+        for pred in range(14):
+            d2 = S.encode_modular_free(**dict(kw, pal_pred=pred, seed=100 + pred))
+            check_against_oracle(jx, d2, np.float32, nch)

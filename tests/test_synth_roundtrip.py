@@ -3,6 +3,9 @@ VarDCT round trips within the expected quantisation error for every supported bl
 import numpy as np
 import pytest
 
+import os
+
+from conftest import GOLDEN
 import oracle_lib as O
 import synth_lib as S
 
@@ -169,3 +172,20 @@ def test_vardct_layers_and_noise():
     weak = O.decode(S.encode_vardct_frame(img, S.frame(noise_lut=[10] * 8), seed=3)).image("u8", 3).astype(float)
     strong = O.decode(S.encode_vardct_frame(img, S.frame(noise_lut=[120] * 8), seed=3)).image("u8", 3).astype(float)
     assert 0.2 < np.abs(weak - base).mean() < np.abs(strong - base).mean() and abs((weak - base).mean()) < 0.3
+
+
+def test_free_running_streams_are_stable_under_the_oracle():
+    """tools/synth_free.h streams (random MA trees, all predictors / properties, local trees, LZ77, delta palettes): the synthesiser
+    is deterministic and the oracle's rendering of them is pinned by hash (tests/golden/free_streams.json, written by this same
+    code path) — a change of either shows up here before the GPU parity test compares the HIP path with the oracle."""
+    import hashlib
+    import json
+    from free_cases import FREE_CASES
+    man = json.load(open(os.path.join(GOLDEN, "free_streams.json")))
+    assert sorted(man) == sorted(FREE_CASES)
+    for name, kw in sorted(FREE_CASES.items()):
+        kw = dict(kw); kw.setdefault("bits", 16)
+        data = S.encode_modular_free(**kw)
+        assert hashlib.sha256(data).hexdigest() == man[name]["sha256_stream"], name
+        px = O.decode(data).pixels("f32", man[name]["channels"])
+        assert hashlib.sha256(px.tobytes()).hexdigest() == man[name]["sha256_f32"], name

@@ -105,7 +105,7 @@ struct Params {
 //  LFCOEF: channel(prop0) > 0 ? (channel > 1 ? B : X) : Y ; each a balanced tree over prop 9 (W+N-NW) cutoffs,
 //          leaves = gradient predictor (5)
 //  HFMETA: channel > 1 ? (channel > 2 ? SHARP(pred W) : (y > 0 ? HFMUL(pred W) : STRATEGY(pred W))) : CFL (pred zero)
-struct TNode { int prop; int split; int l, r; int pred; int ctx; };
+struct TNode { int prop; int split; int l, r; int pred; int ctx; int off = 0, mul_log = 0, mul_bits = 0; };
 struct GTree {
   std::vector<TNode> nodes;
   int num_leaves = 0;
@@ -154,9 +154,9 @@ static void TreeTokens(const GTree& t, const std::vector<int>& bfs, std::vector<
     if (n.prop < 0) {
       tok.push_back({1, 0});
       tok.push_back({2, (uint32_t)n.pred});
-      tok.push_back({3, 0});  // offset
-      tok.push_back({4, 0});  // mul_log
-      tok.push_back({5, 0});  // mul_bits
+      tok.push_back({3, PackSigned(n.off)});        // offset
+      tok.push_back({4, (uint32_t)n.mul_log});      // multiplier = (mul_bits + 1) << mul_log
+      tok.push_back({5, (uint32_t)n.mul_bits});
     } else {
       tok.push_back({1, (uint32_t)n.prop + 1});
       tok.push_back({0, PackSigned(n.split)});
@@ -993,6 +993,8 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
 
 }  // namespace synth
 
+#include "synth_free.h"
+
 // ---- C API ---------------------------------------------------------------------------------------------------------
 extern "C" {
 struct jxlsynth_params {
@@ -1098,5 +1100,17 @@ int jxlsynth_modular2(const int32_t* const* planes, int nchan, int has_alpha, in
 int jxlsynth_modular(const int32_t* const* planes, int nchan, int has_alpha, int w, int h, int bits, int rct, uint8_t** out, size_t* n) {
   try { return finish(synth::EncodeModular(planes, nchan, w, h, bits, has_alpha != 0, rct != 0, 0), out, n); }
   catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// Free-running Modular stream (tools/synth_free.h): feature coverage without an encoder-side simulation of the decoder.
+struct jxlsynth_free_params { uint32_t seed; int w, h, nchan, has_alpha, bits, tree_flags, tree_depth, local_trees, lz77, palette, nb_colors, nb_deltas, pal_pred; };
+int jxlsynth_modular_free(const jxlsynth_free_params* pp, uint8_t** out, size_t* n) {
+  try {
+    synth::FreeParams p;
+    p.seed = pp->seed; p.w = pp->w; p.h = pp->h; p.nchan = pp->nchan; p.has_alpha = pp->has_alpha; p.bits = pp->bits;
+    p.tree_flags = pp->tree_flags; p.tree_depth = pp->tree_depth; p.local_trees = pp->local_trees; p.lz77 = pp->lz77;
+    p.palette = pp->palette; p.nb_colors = pp->nb_colors; p.nb_deltas = pp->nb_deltas; p.pal_pred = pp->pal_pred;
+    return finish(synth::EncodeModularFree(p), out, n);
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 }

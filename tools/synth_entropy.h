@@ -91,7 +91,8 @@ inline float RoundToHalf(float f) { return HalfBitsToFloat(FloatToHalfBits(f)); 
 inline void WriteF16(BitWriter& w, float f) { w.put(FloatToHalfBits(f), 16); }
 
 // ---- tokens ---------------------------------------------------------------------------------------------------------
-struct Token { uint32_t ctx; uint32_t value; };
+// raw = 1: `value` is the entropy-coded symbol itself, followed by `nb` literal bits `bits` (LZ77 length symbols)
+struct Token { uint32_t ctx; uint32_t value; uint8_t raw = 0; uint8_t nb = 0; uint32_t bits = 0; };
 
 struct UintConfig { int split_exponent, msb, lsb; };
 
@@ -103,6 +104,11 @@ inline void EncodeHybrid(const UintConfig& c, uint32_t v, uint32_t* tok, uint32_
   *tok = split + ((n - c.split_exponent) << (c.msb + c.lsb)) + ((m >> (n - c.msb)) << c.lsb) + (m & ((1u << c.lsb) - 1));
   *nbits = n - c.msb - c.lsb;
   *bits = (m >> c.lsb) & ((1u << *nbits) - 1);
+}
+
+inline void TokenSymbol(const UintConfig& c, const Token& t, uint32_t* tok, uint32_t* nbits, uint32_t* bits) {
+  if (t.raw) { *tok = t.value; *nbits = t.nb; *bits = t.bits; return; }
+  EncodeHybrid(c, t.value, tok, nbits, bits);
 }
 
 // ---- ANS ---------------------------------------------------------------------------------------------------------
@@ -257,6 +263,11 @@ struct EntropyCoder {
   std::vector<UintConfig> cfg;       // per cluster
   std::vector<ClusterCode> clusters;
   int num_ctx = 0;
+  // LZ77 (dec_ans.h): symbols >= lz_min_symbol are copy lengths (hybrid uint under lz_len_cfg, + lz_min_length), each followed
+  // by a distance token in the extra context num_ctx - 1
+  bool lz77 = false;
+  uint32_t lz_min_symbol = 224, lz_min_length = 3;
+  UintConfig lz_len_cfg{4, 0, 0};
 };
 
 inline double HistoCost(const std::vector<uint32_t>& h, uint64_t total) {
@@ -277,7 +288,7 @@ inline void BuildEntropyCoder(const std::vector<const std::vector<Token>*>& stre
   for (auto* ts : streams)
     for (const Token& t : *ts) {
       uint32_t tok, nb, bits;
-      EncodeHybrid(uc, t.value, &tok, &nb, &bits);
+      TokenSymbol(uc, t, &tok, &nb, &bits);
       if (t.ctx >= (uint32_t)num_ctx) throw std::runtime_error("token ctx out of range");
       auto& hh = h[t.ctx];
       if (hh.size() <= tok) hh.resize(tok + 1, 0);
@@ -408,7 +419,13 @@ inline void WriteContextMap(BitWriter& w, const std::vector<uint8_t>& map, int n
 }
 
 inline void WriteEntropyCode(BitWriter& w, const EntropyCoder& ec) {
-  w.put(0, 1);  // no lz77
+  if (!ec.lz77) w.put(0, 1);
+  else {
+    w.put(1, 1);
+    WriteU32(w, ec.lz_min_symbol, {0, 224}, {0, 512}, {0, 4096}, {15, 8});
+    WriteU32(w, ec.lz_min_length, {0, 3}, {0, 4}, {2, 5}, {8, 9});
+    WriteUintConfig(w, ec.lz_len_cfg, 8);
+  }
   if (ec.num_ctx > 1) WriteContextMap(w, ec.ctx_map, (int)ec.clusters.size());
   w.put(0, 1);  // ANS (no prefix codes)
   w.put(ec.log_alpha - 5, 2);
@@ -426,7 +443,7 @@ inline void EncodeTokens(BitWriter& w, const EntropyCoder& ec, const std::vector
     const Token& t = tokens[ii];
     int cl = ec.ctx_map[t.ctx];
     uint32_t tok, nb, bits;
-    EncodeHybrid(ec.cfg[cl], t.value, &tok, &nb, &bits);
+    TokenSymbol(ec.cfg[cl], t, &tok, &nb, &bits);
     const ClusterCode& cc = ec.clusters[cl];
     if (tok >= cc.dist.size() || cc.dist[tok] == 0) throw std::runtime_error("symbol with zero probability");
     uint32_t freq = cc.dist[tok];
@@ -438,7 +455,7 @@ inline void EncodeTokens(BitWriter& w, const EntropyCoder& ec, const std::vector
     const Token& t = tokens[i];
     int cl = ec.ctx_map[t.ctx];
     uint32_t tok, nb, bits;
-    EncodeHybrid(ec.cfg[cl], t.value, &tok, &nb, &bits);
+    TokenSymbol(ec.cfg[cl], t, &tok, &nb, &bits);
     if (has_refill[i]) w.put(refill[i], 16);
     if (nb > 24) { w.put(bits & 0xFFFF, 16); w.put(bits >> 16, nb - 16); } else w.put(bits, nb);
   }
