@@ -418,10 +418,9 @@ struct WPStateLds {
   // streams, but residual channels (RCT, squeeze) or a hostile stream may exceed it: the first sample outside +-4095 switches
   // this channel to the 64-bit arithmetic for good (the state arrays are the same in both variants; all inputs of the
   // predictions made so far were within the bound).
-  __device__ __forceinline__ void Update(int64_t val, int x, int y) {
-    if (narrow) { UpdateT<int32_t>((int32_t)val, x, y); if ((uint64_t)(val + 4095) > 8190ull) narrow = false; }
-    else UpdateT<int64_t>(val, x, y);
-  }
+  __device__ __forceinline__ void UpdateStores(int64_t val, int x, int y) { if (narrow) UpdateT<int32_t>((int32_t)val, x, y); else UpdateT<int64_t>(val, x, y); }
+  __device__ __forceinline__ void NoteSample(int64_t val) { if (narrow && (uint64_t)(val + 4095) > 8190ull) narrow = false; }
+  __device__ __forceinline__ void Update(int64_t val, int x, int y) { UpdateStores(val, x, y); NoteSample(val); }
 };
 constexpr int32_t kWpLdsMaxW = 256;                                   // channel widths whose WP state fits the per-wavefront LDS slot
 constexpr uint32_t kWpLdsBytes = WPStateLds::Bytes(kWpLdsMaxW) + 256;   // 10 320 B of error rows + the 64-entry division table
@@ -567,6 +566,9 @@ __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, u
 
 // All 64 lanes of the wavefront call this.  Lane 0 decodes; the others help with LUT, bit-stream window and row I/O.
 // Semantics identical to DecodeModularChannel (jxl_dev.h).
+// BALLOT: general trees are evaluated by the whole wavefront (see the "ballot" path below) — the Modular kernels; the LF kernel
+// of the VarDCT path keeps the single-lane loops (register budget).
+template <bool BALLOT = false>
 __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T_in, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
   if (ch.w == 0 || ch.h == 0) return;
   const uint32_t lane = threadIdx.x & 63, wb = T_in.wb;
@@ -752,6 +754,149 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
   // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
   // and predictors read, the WP state.  Rows up to kRowMax samples; wider channels take the loop below.
   const bool lds_generic = !mc.slow && mc.max_prop < 16 && T.tree_in_lds && T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
+  // ---- "ballot" path: the whole wavefront decodes the channel together.  Every value of the serial chain (neighbours, ANS state,
+  // bit buffer, weighted-predictor arithmetic) is computed redundantly by all 64 lanes — that costs nothing, a wavefront
+  // instruction takes the same time for one active lane as for 64 — and the part that used to be a pointer chase through LDS is
+  // spread over the lanes: lane j owns inner node j of the channel's subtree (at most 64 inner nodes and 64 leaves after the
+  // static splits are resolved), evaluates that node's property and comparison, one ballot yields all decisions of the tree as
+  // a 64-bit scalar, and the walk from the root is a few scalar bit tests with the child tables read across lanes
+  // (v_readlane) — no LDS round trip per tree level (the single-lane loop paid two).  Channels whose subtree never looks at the
+  // weighted predictor (no predictor 6 leaf, no property 15 split) skip its arithmetic altogether.
+#ifndef JXL_NO_BALLOT
+  if (BALLOT && lds_generic && mode == 0) {
+    const uint32_t qi_off = wb + kLutOff, ql_off = wb + kLutOff + 256, pair_off = wb + kLutOff + 512;
+    if (lane == 0) {
+      uint32_t ni = 0, nl = 0;
+      int ok = 1;
+      auto resolve = [&](uint32_t pos) {     // follow static splits (channel index, stream id)
+        TreeNode n = T.Node(pos);
+        uint32_t guard = 0;
+        while ((n.prop == 0 || n.prop == 1) && ++guard < 4096) { pos = (n.prop == 0 ? chan : (int32_t)mc.stream_id) > n.val ? n.a : n.b; n = T.Node(pos); }
+        return pos;
+      };
+      const uint32_t root = resolve(subroot);
+      uint32_t root_code;
+      if (T.Node(root).prop < 0) { StS<uint32_t>(ql_off, root); nl = 1; root_code = 0x80; }
+      else { StS<uint32_t>(qi_off, root); ni = 1; root_code = 0; }
+      for (uint32_t i = 0; i < ni && ok; i++) {
+        const TreeNode n = T.Node(LdS<uint32_t>(qi_off + 4 * i));
+        uint32_t codes[2];
+        for (int k = 0; k < 2; k++) {
+          const uint32_t c = resolve(k == 0 ? n.a : n.b);
+          if (T.Node(c).prop < 0) { if (nl >= 64) { ok = 0; break; } StS<uint32_t>(ql_off + 4 * nl, c); codes[k] = 0x80 | nl++; }
+          else { if (ni >= 64) { ok = 0; break; } StS<uint32_t>(qi_off + 4 * ni, c); codes[k] = ni++; }
+        }
+        if (ok) StS<uint16_t>(pair_off + 2 * i, (uint16_t)(codes[0] | (codes[1] << 8)));
+      }
+      StS<int>(wb + kWorkOff + 40, ok); StS<uint32_t>(wb + kWorkOff + 44, ni); StS<uint32_t>(wb + kWorkOff + 48, nl); StS<uint32_t>(wb + kWorkOff + 52, root_code);
+    }
+    WaveSync();
+    if (LdS<int>(wb + kWorkOff + 40)) {
+      const uint32_t ni = LdS<uint32_t>(wb + kWorkOff + 44), nl = LdS<uint32_t>(wb + kWorkOff + 48);
+      const uint32_t root_code = Uniform(LdS<uint32_t>(wb + kWorkOff + 52));
+      int32_t my_prop = -1, my_val = 0x7FFFFFFF;
+      uint32_t my_pair = 0, leaf_a = 0, leaf_b = 1;
+      int32_t leaf_val = 0;
+      if (lane < ni) { const TreeNode n = T.Node(LdS<uint32_t>(qi_off + 4 * lane)); my_prop = n.prop; my_val = n.val; my_pair = LdS<uint16_t>(pair_off + 2 * lane); }
+      if (lane < nl) { const TreeNode n = T.Node(LdS<uint32_t>(ql_off + 4 * lane)); leaf_a = n.a; leaf_b = n.b; leaf_val = n.val; }
+      uint32_t used = 0;
+      for (int k = 0; k < 16; k++) if (__ballot(my_prop == k)) used |= 1u << k;
+      used = Uniform(used);
+      const bool wp_here = use_wp && (((used >> 15) & 1) || __ballot(lane < nl && (leaf_a & 0xFF) == 6) != 0);
+      WaveSync();
+      const int w = ch.w, h = ch.h;
+      const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
+      const uint32_t wend = br.wend;
+      // the incoming ANS state and bit position live in lane 0
+      state = Uniform(state);
+      const uint64_t bp = br.BitPos();
+      const uint64_t bp0 = ((uint64_t)Uniform((uint32_t)(bp >> 32)) << 32) | Uniform((uint32_t)bp);
+      BitReaderW bw;
+      bw.wpos = (uint32_t)(bp0 >> 5); bw.win_base = 0; bw.buf = 0; bw.avail = 0; bw.win_off = wb + kWinOff;
+      uint32_t skip_bits = (uint32_t)(bp0 & 31);
+      uint32_t cur = wb + kRowOff, prev = wb + kRowOff + kRowMax * 4, prev2 = wb + kChunkOff;   // three row buffers, rotated
+      for (int y = 0; y < h; y++) {
+        int32_t* p = ch.data + (size_t)y * ch.stride;
+        const uint32_t wbase = bw.wpos;
+        WaveSync();    // (the previous row's window reads are done)
+        for (uint32_t i = lane; i < kWinWords; i += 64) StS<uint32_t>(wb + kWinOff + i * 4, wbase + i < wend ? LdG(br.words + wbase + i) : 0u);
+        WaveSync();
+        bw.win_base = wbase;
+        if (skip_bits != 0xFFFFFFFFu) { bw.buf = 0; bw.avail = 0; bw.Refill(); bw.buf >>= skip_bits; bw.avail -= (int)skip_bits; skip_bits = 0xFFFFFFFFu; }
+        int32_t left = 0, left2 = 0, prev9 = 0;
+        int32_t up0 = 0, up1 = 0, up2 = 0, up3 = 0;
+        if (y > 0) { up1 = LdS<int32_t>(prev); up2 = w > 1 ? LdS<int32_t>(prev + 4) : 0; up3 = w > 2 ? LdS<int32_t>(prev + 8) : 0; }
+        for (int x = 0; x < w; x++) {
+          const int32_t up4 = (y > 0 && x + 3 < w) ? LdS<int32_t>(prev + 4 * (x + 3)) : 0;
+          const int32_t W = x ? left : (y ? up1 : 0);
+          const int32_t N = y ? up1 : W;
+          const int32_t NW = (x && y) ? up0 : W;
+          const int32_t NE = (x + 1 < w && y) ? up2 : N;
+          const int32_t WW = x > 1 ? left2 : W;
+          const int32_t NN = y > 1 ? LdS<int32_t>(prev2 + 4 * x) : N;
+          const int32_t NEE = (x + 2 < w && y) ? up3 : NE;
+          int64_t wp_pred = 0;
+          int32_t wp_err = 0;
+          if (wp_here) wp_pred = wpl.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
+          // this lane's node: its property out of the ones the subtree uses
+          int32_t pv = 0;
+#define JXL_SEL(k, expr) if (used & (1u << (k))) pv = my_prop == (k) ? (int32_t)(expr) : pv;
+          JXL_SEL(0, chan) JXL_SEL(1, mc.stream_id) JXL_SEL(2, y) JXL_SEL(3, x)
+          JXL_SEL(4, N < 0 ? 0u - (uint32_t)N : (uint32_t)N) JXL_SEL(5, W < 0 ? 0u - (uint32_t)W : (uint32_t)W) JXL_SEL(6, N) JXL_SEL(7, W)
+          JXL_SEL(8, (uint32_t)W - (uint32_t)prev9) JXL_SEL(9, (uint32_t)W + (uint32_t)N - (uint32_t)NW) JXL_SEL(10, (uint32_t)W - (uint32_t)NW)
+          JXL_SEL(11, (uint32_t)NW - (uint32_t)N) JXL_SEL(12, (uint32_t)N - (uint32_t)NE) JXL_SEL(13, (uint32_t)N - (uint32_t)NN)
+          JXL_SEL(14, (uint32_t)W - (uint32_t)WW) JXL_SEL(15, wp_err)
+#undef JXL_SEL
+          const uint64_t decisions = __ballot(pv > my_val);
+          uint32_t code = root_code;
+          while (!(code & 0x80)) {
+            const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)my_pair, (int)code);
+            code = ((decisions >> code) & 1) ? (pair & 0xFF) : (pair >> 8);
+          }
+          const int leaf = (int)(code & 0x7F);
+          const uint32_t n_a = (uint32_t)__builtin_amdgcn_readlane((int)leaf_a, leaf), n_b = (uint32_t)__builtin_amdgcn_readlane((int)leaf_b, leaf);
+          const int32_t n_val = __builtin_amdgcn_readlane(leaf_val, leaf);
+          prev9 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+          const uint32_t cluster = n_a >> 8;
+          const int32_t guess = Predict(n_a & 0xFF, W, N, NW, NE, NN, WW, NEE, wp_pred);
+          // ANS symbol + hybrid integer out of LDS (all lanes read the same addresses: broadcasts)
+          const uint32_t res = state & 0xFFF;
+          const uint32_t i = res >> (12 - la), pos_ = res & ((1u << (12 - la)) - 1);
+          const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
+          const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
+          const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+          const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+          const bool hit = pos_ >= cutoff;
+          uint32_t tok = hit ? right : i;
+          state = (hit ? freq1 : freq0) * (state >> 12) + (hit ? offs1 + pos_ : pos_);
+          if (state < (1u << 16)) state = (state << 16) | bw.Read(16);
+          const uint32_t split_exp = cfg & 0xFF;
+          if (tok >= (1u << split_exp)) {
+            const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+            const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - (1u << split_exp)) >> (msb + lsb))) & 31;
+            const uint32_t low = tok & ((1u << lsb) - 1);
+            tok >>= lsb;
+            const uint32_t bits = nbits ? bw.Read((int)nbits) : 0;
+            const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+            tok = (((hi << nbits) | bits) << lsb) | low;
+          }
+          const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) * n_b + (uint32_t)n_val + (uint32_t)guess);
+          if (lane == 0) StS<int32_t>(cur + 4 * x, val);
+          if (wp_here) { if (lane == 0) wpl.UpdateStores(val, x, y); wpl.NoteSample(val); }
+          left2 = left; left = val;
+          up0 = up1; up1 = up2; up2 = up3; up3 = up4;
+        }
+        WaveSync();
+        for (int i = (int)lane; i < w; i += 64) StG(p + i, LdS<int32_t>(cur + 4 * i));
+        const uint32_t t = prev2; prev2 = prev; prev = cur; cur = t;
+      }
+      const uint64_t endpos = bw.BitPos();
+      br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
+      WaveSync();
+      return;
+    }
+  }
+#endif
   if (lds_generic) {
     const int w = ch.w, h = ch.h;
     const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
@@ -3001,7 +3146,7 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
       }
       WaveSync();
     }
-    DecodeChannelCoop(br, state, T, mc, ch, (int)c);
+    DecodeChannelCoop<true>(br, state, T, mc, ch, (int)c);
   }
   if (lane == 0) {
     if (state != 0x130000u) SetError(f, kErrAnsFinalState);
@@ -3146,7 +3291,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
         }
         WaveSync();
       }
-      DecodeChannelCoop(br, state, T, mc, d, k++);
+      DecodeChannelCoop<true>(br, state, T, mc, d, k++);
     }
   } else {
     const int nch = U.nch;
@@ -3164,7 +3309,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
         }
         WaveSync();
       }
-      DecodeChannelCoop(br, state, T, mc, cd, c);
+      DecodeChannelCoop<true>(br, state, T, mc, cd, c);
     }
   }
   int fail = 0;

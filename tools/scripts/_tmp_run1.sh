@@ -1,15 +1,9 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-run() { name=$1; shift; env "$@" python bench.py --steps 12 --warmup 3 --no-extras --no-cpu-baseline --no-verify > gpurun_out/deep_$name.json 2> gpurun_out/deep_$name.err; }
-run base JXL_BENCH_DEEP=0
-run deep3 JXL_BENCH_DEEP=1
-run deep4 JXL_BENCH_DEEP=1 JXL_BENCH_NBUF=4
-run deep5 JXL_BENCH_DEEP=1 JXL_BENCH_NBUF=5
-python - <<'PY'
-import json
-for b in ("base","deep3","deep4","deep5"):
-    try:
-        r=json.loads(open(f"gpurun_out/deep_{b}.json").read().strip().splitlines()[-1])
-        print(b, r["value"], r["ms_per_step"], r["stage_ms"], round(r["device_bytes"]/2**30,1))
-    except Exception as e: print(b, "ERR", e, open(f"gpurun_out/deep_{b}.err").read()[-800:])
-PY
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bj
+mkdir -p $OUT
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/$tag -o p --output-format csv -- python $GRAFT_REPO_ROOT/tests/gpu_benchjxl.py 1 > /tmp/pmc_$tag.log 2>&1 < /dev/null
+  tail -1 /tmp/pmc_$tag.log
+done
+find $OUT -name "*.csv" | head -20
