@@ -1103,25 +1103,14 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
 
 void Batch::EnqueuePostOps(void* stream) { for (auto& op : post_ops_) op(stream); }
 
+// The HF stage only writes non-zero coefficients into zeroed planes.  The IDCT kernels zero what they consumed (kernels.hip,
+// IdctTileKernel pass 0), so a batch that is decoded again and again never clears its planes as a whole; only a decode whose
+// tail did not run over them (first decode, JPEG reconstruction, a failed stream) leaves them dirty.
 void Batch::ClearCoefficientsBeforeHf(void* stream_v) {
-  hipStream_t stream = (hipStream_t)stream_v;
-  if (clear_pending_) { HIP_CHECK(hipStreamWaitEvent(stream, (hipEvent_t)clear_event_, 0)); clear_pending_ = false; }
-  else if (coef_dirty_) HIP_CHECK(hipMemsetAsync(dcoef_, 0, coeff_bytes_, stream));
+  if (coef_dirty_) HIP_CHECK(hipMemsetAsync(dcoef_, 0, coeff_bytes_, (hipStream_t)stream_v));
   coef_dirty_ = true;
 }
-void Batch::ClearCoefficientsAfterDecode(void* stream_v) {
-  hipStream_t stream = (hipStream_t)stream_v;
-  if (!clear_stream_) {
-    hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); clear_stream_ = s;
-    hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); clear_event_ = e;
-    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); idct_event_ = e;
-  }
-  HIP_CHECK(hipEventRecord((hipEvent_t)idct_event_, stream));
-  HIP_CHECK(hipStreamWaitEvent((hipStream_t)clear_stream_, (hipEvent_t)idct_event_, 0));
-  HIP_CHECK(hipMemsetAsync(dcoef_, 0, coeff_bytes_, (hipStream_t)clear_stream_));
-  HIP_CHECK(hipEventRecord((hipEvent_t)clear_event_, (hipStream_t)clear_stream_));
-  clear_pending_ = true;
-}
+void Batch::ClearCoefficientsAfterDecode(void*) { coef_dirty_ = false; }
 
 void Batch::CheckFilterBuffers() const {
   if ((fplan_.any_unfused || cfg.force_unfused_filters) && !has_plane_b_)
@@ -1194,7 +1183,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     if (any_complex_) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
     rec(6);
-    ClearCoefficientsAfterDecode(stream_v);   // for this batch's next decode; runs under whatever the caller enqueues next
+    ClearCoefficientsAfterDecode(stream_v);   // (the IDCT kernels zeroed what they read)
     if (timed && split) timed_rest_cursor_++;
   }
 }
@@ -1226,6 +1215,7 @@ void Batch::Finish(void* stream_v) {
   for (int i = 0; i < n; i++) {
     if (!status[i]) continue;
     HIP_CHECK(hipMemset(dwork_ + status_off_, 0, (size_t)n * 4));
+    coef_dirty_ = true;                                  // (a failed stream may have written where no IDCT looked)
     if (status[i] & kErrUnsupported) throw ParseError("unsupported: stream feature on the device path (frame " + std::to_string(i) + ")", true);
     throw ParseError("corrupt stream (device status " + std::to_string(status[i]) + ", frame " + std::to_string(i) + ")", false);
   }

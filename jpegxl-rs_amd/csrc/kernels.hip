@@ -2153,6 +2153,16 @@ __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ f
       }
     }
   }
+  // the group's coefficients (all but those of DCT128/256 varblocks, which BigIdctKernel reads after this kernel) have been
+  // consumed by pass 1: zero them for the batch's next decode (see IdctTileKernel pass 0)
+  const uint32_t count = f.vb_count[g];
+  for (uint32_t e = 0; e < count; e++) {
+    const uint2 ent = f.vb_list[(size_t)g * 1024 + e];
+    const uint32_t s = ent.x & 31;
+    if (IsBig(s)) continue;
+    const uint32_t n = CoveredX(s) * CoveredY(s) * 64;
+    for (uint32_t i = threadIdx.x; i < 3 * n; i += blockDim.x) f.coeff[i / n][(size_t)g * 65536 + ent.y + i % n] = 0;
+  }
 }
 
 // ---- DCT128 / DCT256 family (strategies 21..26): one workgroup per 256x256 group walks its big varblocks.  The 1-D
@@ -2276,6 +2286,7 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
     }
     __threadfence();
     __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 3u * R * C; i += blockDim.x) f.coeff[i / (R * C)][(size_t)g * 65536 + ent.y + i % (R * C)] = 0;   // consumed: zero for the next decode
     // ---- pass 2: columns in place
     for (uint32_t task = wave; task < 3u * C; task += 4) {
       const int c = (int)(task / C), xx = (int)(task % C);
@@ -2332,6 +2343,13 @@ __global__ __launch_bounds__(256) void IdctRareSpecialKernel(const FrameDev* __r
     for (uint32_t k = 0; k < 64; k++) cf[k] = DequantCoef(d, (int)c, k);
     cf[0] = LdG(f.llf[c] + o);
     SpecialTransform(s, cf, f.plane_a[c] + (size_t)(by0 + by) * 8 * stride + (bx0 + bx) * 8, stride);
+  }
+  __syncthreads();
+  // these blocks' coefficients have been consumed: zero them for the batch's next decode (see IdctTileKernel pass 0)
+  for (uint32_t i = threadIdx.x; i < n * 192; i += blockDim.x) {
+    const uint32_t t = s_list[i / 192], r = i % 192;
+    const size_t o = (size_t)(by0 + t / gbw) * f.bw + bx0 + t % gbw;
+    f.coeff[r / 64][(size_t)g * 65536 + LdG(f.coef_off + o) + r % 64] = 0;
   }
 }
 
@@ -2443,7 +2461,7 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     if (my_rclass[q] != 0xFFu) s_rtask[atomicAdd(&s_cnt[9 + my_rclass[q]], 1u)] = (uint16_t)tt;
     if (my_cclass[q] != 0xFFu) s_ctask[atomicAdd(&s_ccur[my_cclass[q]], 1u)] = (uint16_t)tt;
   }
-  const int32_t* cq[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
+  int32_t* cq[3] = {f.coeff[0] + (size_t)g * 65536, f.coeff[1] + (size_t)g * 65536, f.coeff[2] + (size_t)g * 65536};
   const float bias0 = f.quant_bias[0], bias1 = f.quant_bias[1], bias2 = f.quant_bias[2], bias3 = f.quant_bias[3];
   // ---- pass 0: stage dequantised coefficients.  Task = (block of the tile, four of its 64 coefficient slots): 16-byte
   // loads, consecutive lanes read consecutive 16-byte chunks.  The tile is exactly one chroma-from-luma tile.
@@ -2472,6 +2490,15 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     p.qy = LdG(reinterpret_cast<const int4*>(cq[1] + base));
     p.qx = LdG(reinterpret_cast<const int4*>(cq[0] + base));
     p.qb = LdG(reinterpret_cast<const int4*>(cq[2] + base));
+    // The HF stage only writes non-zero coefficients, so the planes must be zero again before the batch's next decode: every
+    // kernel that consumes a block's coefficients for good puts zeros back where it found something else (a few MB per frame
+    // instead of a 100 MB memset; IDENTITY / DCT2X2 / AFV blocks are read again, and cleared, by IdctRareSpecialKernel).
+    if (!(SPECIAL && IsRareSpecial(s))) {
+      const int4 z = make_int4(0, 0, 0, 0);
+      if (p.qy.x | p.qy.y | p.qy.z | p.qy.w) StG(reinterpret_cast<int4*>(cq[1] + base), z);
+      if (p.qx.x | p.qx.y | p.qx.z | p.qx.w) StG(reinterpret_cast<int4*>(cq[0] + base), z);
+      if (p.qb.x | p.qb.y | p.qb.z | p.qb.w) StG(reinterpret_cast<int4*>(cq[2] + base), z);
+    }
     p.ty = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 1] + p.k0));
     p.tx = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 0] + p.k0));
     p.tb = LdG(reinterpret_cast<const float4*>(f.qtable[kind * 3 + 2] + p.k0));
