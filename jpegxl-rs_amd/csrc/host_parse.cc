@@ -346,6 +346,198 @@ void ReadEntropyCode(Reader& r, uint32_t num_ctx, HostCode* hc, bool allow_lz77)
   }
 }
 
+// ---- embedded ICC profile (icc_codec.cc ICCReader + UnpredictICC) ----------------------------------------------------------------------
+// The codestream carries the profile as an entropy-coded byte stream (41 contexts chosen from the two previous bytes) of a
+// *predicted* form: varint output size, varint command-stream size, commands, then data.  The 128-byte header is coded as
+// differences from a template, the tag table as one command per tag, the tag contents as insert / shuffle / N-th order
+// prediction runs.
+namespace {
+uint32_t IccContext(size_t i, uint32_t b1, uint32_t b2) {
+  if (i <= 128) return 0;
+  auto letter = [](uint32_t b) { return (b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z'); };
+  auto digit = [](uint32_t b) { return (b >= '0' && b <= '9') || b == '.' || b == ','; };
+  uint32_t k1, k2;
+  if (letter(b1)) k1 = 0; else if (digit(b1)) k1 = 1; else if (b1 <= 1) k1 = 2 + b1; else if (b1 < 16) k1 = 4; else if (b1 > 240 && b1 < 255) k1 = 5; else if (b1 == 255) k1 = 6; else k1 = 7;
+  if (letter(b2)) k2 = 0; else if (digit(b2)) k2 = 1; else if (b2 < 16) k2 = 2; else if (b2 > 240) k2 = 3; else k2 = 4;
+  return 1 + k1 + k2 * 8;
+}
+struct IccIn {
+  const vec<uint8_t>& e; size_t size;
+  uint64_t VarInt(size_t* pos) const {
+    uint64_t v = 0; int shift = 0;
+    for (;;) {
+      if (*pos >= size || shift > 63) Fail("ICC varint");
+      const uint8_t b = e[(*pos)++];
+      v |= (uint64_t)(b & 127) << shift;
+      if (!(b & 128)) return v;
+      shift += 7;
+    }
+  }
+};
+void IccShuffle(uint8_t* data, size_t size, size_t width) {
+  const size_t height = (size + width - 1) / width;
+  vec<uint8_t> out(size);
+  size_t s = 0, j = 0;
+  for (size_t i = 0; i < size; i++) { out[i] = data[j]; j += height; if (j >= size) j = ++s; }
+  memcpy(data, out.data(), size);
+}
+void Put32(vec<uint8_t>& v, uint64_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+void PutTag(vec<uint8_t>& v, const char* t) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)t[i]); }
+uint8_t IccPredict(const vec<uint8_t>& d, size_t start, size_t i, size_t stride, size_t width, int order) {
+  auto pr = [&](uint64_t p1, uint64_t p2, uint64_t p3) -> uint64_t { return order == 0 ? p1 : order == 1 ? 2 * p1 - p2 : 3 * p1 - 3 * p2 + p3; };
+  if (width == 1) { const size_t pos = start + i; return (uint8_t)pr(d[pos - stride], d[pos - stride * 2], d[pos - stride * 3]); }
+  if (width == 2) {
+    const size_t p = start + (i & ~(size_t)1);
+    auto rd = [&](size_t o) -> uint64_t { return ((uint64_t)d[o] << 8) | d[o + 1]; };
+    const uint64_t v = pr(rd(p - stride), rd(p - stride * 2), rd(p - stride * 3)) & 0xFFFF;
+    return (i & 1) ? (uint8_t)(v & 255) : (uint8_t)(v >> 8);
+  }
+  const size_t p = start + (i & ~(size_t)3);
+  auto rd = [&](size_t o) -> uint64_t { return ((uint64_t)d[o] << 24) | ((uint64_t)d[o + 1] << 16) | ((uint64_t)d[o + 2] << 8) | d[o + 3]; };
+  const uint64_t v = pr(rd(p - stride), rd(p - stride * 2), rd(p - stride * 3)) & 0xFFFFFFFFull;
+  return (uint8_t)(v >> ((3 - (i & 3)) * 8));
+}
+}  // namespace
+
+void UnpredictIcc(const vec<uint8_t>& enc, vec<uint8_t>* out) {
+  const IccIn in{enc, enc.size()};
+  const size_t size = enc.size();
+  vec<uint8_t>& res = *out;
+  res.clear();
+  size_t pos = 0;
+  const uint64_t osize = in.VarInt(&pos);
+  if (osize >> 32) Fail("ICC size");
+  const uint64_t csize = in.VarInt(&pos);
+  if (csize >> 32) Fail("ICC command size");
+  size_t cpos = pos;
+  if (csize > size - pos) Fail("ICC command stream out of bounds");
+  const size_t cend = cpos + csize;
+  pos = cend;
+  // header: differences from the predicted header (template + profile size; a few fields copy earlier ones)
+  uint8_t header[128] = {0};
+  header[8] = 4;
+  memcpy(header + 12, "mntr", 4); memcpy(header + 16, "RGB ", 4); memcpy(header + 20, "XYZ ", 4); memcpy(header + 36, "acsp", 4);
+  header[70] = 246; header[71] = 214; header[73] = 1; header[78] = 211; header[79] = 45;
+  header[0] = (uint8_t)(osize >> 24); header[1] = (uint8_t)(osize >> 16); header[2] = (uint8_t)(osize >> 8); header[3] = (uint8_t)osize;
+  for (size_t i = 0; i <= 128; i++) {
+    if (res.size() == osize) { if (cpos != cend || pos != size) Fail("ICC: data left after the profile"); return; }
+    if (i == 128) break;
+    if (i == 8 && res.size() >= 8) { header[80] = res[4]; header[81] = res[5]; header[82] = res[6]; header[83] = res[7]; }
+    if (i == 41 && res.size() >= 41) {
+      if (res[40] == 'A') { header[41] = 'P'; header[42] = 'P'; header[43] = 'L'; }
+      if (res[40] == 'M') { header[41] = 'S'; header[42] = 'F'; header[43] = 'T'; }
+    }
+    if (i == 42 && res.size() >= 42) {
+      if (res[40] == 'S' && res[41] == 'G') { header[42] = 'I'; header[43] = ' '; }
+      if (res[40] == 'S' && res[41] == 'U') { header[42] = 'N'; header[43] = 'W'; }
+    }
+    if (pos >= size) Fail("ICC header out of bounds");
+    res.push_back((uint8_t)(enc[pos++] + header[i]));
+  }
+  if (cpos >= cend) Fail("ICC commands out of bounds");
+  // tag table
+  static const char* const kTagStrings[17] = {"cprt", "wtpt", "bkpt", "rXYZ", "gXYZ", "bXYZ", "kXYZ", "rTRC", "gTRC", "bTRC", "kTRC", "chad", "desc", "chrm", "dmnd", "dmdd", "lumi"};
+  uint64_t numtags = in.VarInt(&cpos);
+  if (numtags != 0) {
+    numtags--;
+    if (numtags >> 32) Fail("ICC tag count");
+    Put32(res, numtags);
+    uint64_t prevtagstart = 128 + numtags * 12, prevtagsize = 0;
+    for (;;) {
+      if (res.size() > osize || cpos > cend) Fail("ICC tag list out of bounds");
+      if (cpos == cend) break;
+      const uint8_t command = enc[cpos++];
+      const uint8_t tagcode = command & 63;
+      char tag[4];
+      if (tagcode == 0) break;
+      else if (tagcode == 1) { if (size - pos < 4) Fail("ICC tag out of bounds"); memcpy(tag, &enc[pos], 4); pos += 4; }
+      else if (tagcode == 2) memcpy(tag, "rTRC", 4);
+      else if (tagcode == 3) memcpy(tag, "rXYZ", 4);
+      else { if (tagcode - 4 >= 17) Fail("ICC tag code"); memcpy(tag, kTagStrings[tagcode - 4], 4); }
+      for (int i = 0; i < 4; i++) res.push_back((uint8_t)tag[i]);
+      uint64_t tagstart, tagsize = prevtagsize;
+      auto is = [&](const char* t) { return memcmp(tag, t, 4) == 0; };
+      if (is("rXYZ") || is("gXYZ") || is("bXYZ") || is("kXYZ") || is("wtpt") || is("bkpt") || is("lumi")) tagsize = 20;
+      if (command & 64) { if (cpos >= cend) Fail("ICC commands out of bounds"); tagstart = in.VarInt(&cpos); }
+      else tagstart = prevtagstart + prevtagsize;
+      if (tagstart >> 32) Fail("ICC tag offset");
+      Put32(res, tagstart);
+      if (command & 128) { if (cpos >= cend) Fail("ICC commands out of bounds"); tagsize = in.VarInt(&cpos); }
+      if (tagsize >> 32) Fail("ICC tag size");
+      Put32(res, tagsize);
+      prevtagstart = tagstart; prevtagsize = tagsize;
+      if (tagcode == 2) { PutTag(res, "gTRC"); Put32(res, tagstart); Put32(res, tagsize); PutTag(res, "bTRC"); Put32(res, tagstart); Put32(res, tagsize); }
+      if (tagcode == 3) {
+        if ((tagstart + tagsize * 2) >> 32) Fail("ICC tag offset");
+        PutTag(res, "gXYZ"); Put32(res, tagstart + tagsize); Put32(res, tagsize);
+        PutTag(res, "bXYZ"); Put32(res, tagstart + tagsize * 2); Put32(res, tagsize);
+      }
+    }
+  }
+  // main content
+  static const char* const kTypeStrings[8] = {"XYZ ", "desc", "text", "mluc", "para", "curv", "sf32", "gbd "};
+  for (;;) {
+    if (res.size() > osize || cpos > cend) Fail("ICC content out of bounds");
+    if (cpos == cend) break;
+    const uint8_t command = enc[cpos++];
+    if (command == 1) {
+      if (cpos >= cend) Fail("ICC commands out of bounds");
+      const uint64_t num = in.VarInt(&cpos);
+      if (num > size - pos) Fail("ICC insert out of bounds");
+      res.insert(res.end(), enc.begin() + pos, enc.begin() + pos + num); pos += num;
+    } else if (command == 2 || command == 3) {
+      if (cpos >= cend) Fail("ICC commands out of bounds");
+      const uint64_t num = in.VarInt(&cpos);
+      if (num > size - pos) Fail("ICC shuffle out of bounds");
+      vec<uint8_t> sh(enc.begin() + pos, enc.begin() + pos + num);
+      if (num) IccShuffle(sh.data(), num, command == 2 ? 2 : 4);
+      res.insert(res.end(), sh.begin(), sh.end()); pos += num;
+    } else if (command == 4) {
+      if (cend - cpos < 2) Fail("ICC commands out of bounds");
+      const uint8_t flags = enc[cpos++];
+      const size_t width = (flags & 3) + 1;
+      if (width == 3) Fail("ICC predictor width");
+      const int order = (flags & 12) >> 2;
+      if (order == 3) Fail("ICC predictor order");
+      uint64_t stride = width;
+      if (flags & 16) { if (cpos >= cend) Fail("ICC commands out of bounds"); stride = in.VarInt(&cpos); if (stride < width) Fail("ICC predictor stride"); }
+      if (res.empty() || ((res.size() - 1u) >> 2u) < stride) Fail("ICC predictor stride too large");
+      if (cpos >= cend) Fail("ICC commands out of bounds");
+      const uint64_t num = in.VarInt(&cpos);
+      if (num > size - pos) Fail("ICC predict out of bounds");
+      vec<uint8_t> sh(enc.begin() + pos, enc.begin() + pos + num);
+      if (width > 1 && num) IccShuffle(sh.data(), num, width);
+      const size_t start = res.size();
+      for (size_t i = 0; i < num; i++) res.push_back((uint8_t)(IccPredict(res, start, i, stride, width, order) + sh[i]));
+      pos += num;
+    } else if (command == 10) {
+      PutTag(res, "XYZ "); for (int i = 0; i < 4; i++) res.push_back(0);
+      if (size - pos < 12) Fail("ICC XYZ out of bounds");
+      res.insert(res.end(), enc.begin() + pos, enc.begin() + pos + 12); pos += 12;
+    } else if (command >= 16 && command < 24) {
+      PutTag(res, kTypeStrings[command - 16]); for (int i = 0; i < 4; i++) res.push_back(0);
+    } else Fail("ICC command");
+  }
+  if (pos != size) Fail("ICC: not all data used");
+  if (res.size() != osize) Fail("ICC: result size");
+}
+
+static void ReadEmbeddedIcc(Reader& r, vec<uint8_t>* icc) {
+  const uint64_t enc_size = r.U64();
+  if (enc_size > (1u << 28)) Fail("ICC stream too large");
+  HostCode code;
+  ReadEntropyCode(r, 41, &code);
+  HostSymbolReader sr(r, code);
+  vec<uint8_t> enc((size_t)enc_size);
+  for (size_t i = 0; i < enc.size(); i++) {
+    const uint32_t v = sr.Read(IccContext(i, i > 0 ? enc[i - 1] : 0, i > 1 ? enc[i - 2] : 0));
+    if (v >= 256) Fail("ICC byte");
+    enc[i] = (uint8_t)v;
+  }
+  sr.CheckFinal();
+  UnpredictIcc(enc, icc);
+}
+
 void ReadTree(Reader& r, HostTree* t, size_t limit) {
   HostCode code;
   ReadEntropyCode(r, 6, &code);
@@ -552,7 +744,7 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
     static const int kCount[3] = {15, 55, 210};
     for (int k = 0; k < 3; k++) if (cw >> k & 1) { ih->up_weights[k].resize(kCount[k]); for (float& v : ih->up_weights[k]) v = r.F16(); }
   }
-  if (ih->want_icc) Unsupported("embedded ICC profile");
+  if (ih->want_icc) ReadEmbeddedIcc(r, &ih->icc);
   r.align();
   *frame_bitpos = r.pos();
 }

@@ -66,6 +66,7 @@ struct ImageHeader {
   float opsin_inv[9]; float opsin_bias[3]; float quant_bias[4];
   vec<float> up_weights[3];   // custom upsampling weights for 2x / 4x / 8x (15 / 55 / 210 values); empty = library default
   bool have_container = false;
+  vec<uint8_t> icc;          // embedded ICC profile (want_icc), decoded
 };
 
 struct SqueezeStep { uint32_t horizontal, in_place, begin_c, num_c; };

@@ -202,24 +202,31 @@ size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* d) {
   return r;
 }
 
-// ICC profile of the enumerated colour encoding (icc_profile.cc).  Both targets describe the same encoding: the pixels
-// this decoder hands out are always in the codestream's tagged colour space (no preferred-profile conversion).
-static JxlDecoderStatus IccOf(const JxlDecoder* d, vec<uint8_t>* icc) {
+// ICC profile of the image.  Enumerated colour encodings: synthesised (icc_profile.cc); both targets describe the same encoding,
+// the pixels this decoder hands out are always in the codestream's tagged colour space.  Embedded profiles (want_icc): the
+// original profile is the decoded one; the pixel data of an XYB image comes out as sRGB (libjxl without a CMS converts to sRGB
+// when it cannot target the profile's space), non-XYB samples are in the profile's own space.
+static JxlDecoderStatus IccOf(const JxlDecoder* d, JxlColorProfileTarget target, vec<uint8_t>* icc) {
   JXL_MM_SCOPE(d);
   if (!d || !d->batch || d->stage < JxlDecoderStruct::kHeaders) { SetLastError("ICC profile requested before the headers were decoded"); return JXL_DEC_ERROR; }
-  try { *icc = SynthesizeIcc(d->batch->image(0).ih); } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
+  const ImageHeader& ih = d->batch->image(0).ih;
+  try {
+    if (ih.want_icc && (target == JXL_COLOR_PROFILE_TARGET_ORIGINAL || !ih.xyb_encoded)) *icc = ih.icc;
+    else if (ih.want_icc) { ImageHeader srgb = ih; srgb.want_icc = false; srgb.icc.clear(); *icc = SynthesizeIcc(srgb); }   // XYB pixel data: rendered to sRGB (grey: same curve)
+    else *icc = SynthesizeIcc(ih);
+  } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* d, JxlColorProfileTarget, size_t* size) {
+JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* d, JxlColorProfileTarget target, size_t* size) {
   vec<uint8_t> icc;
   if (size) *size = 0;
-  if (IccOf(d, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  if (IccOf(d, target, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
   if (size) *size = icc.size();
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorProfileTarget, uint8_t* out, size_t size) {
+JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorProfileTarget target, uint8_t* out, size_t size) {
   vec<uint8_t> icc;
-  if (IccOf(d, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  if (IccOf(d, target, &icc) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
   if (!out || size < icc.size()) { SetLastError("ICC output buffer too small"); return JXL_DEC_ERROR; }
   memcpy(out, icc.data(), icc.size());
   return JXL_DEC_SUCCESS;
@@ -414,7 +421,7 @@ int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc
     if (!ExtractCodestream(data, size, &cs, &container, &jbrd)) { SetLastError("truncated input"); return 1; }
     ImageHeader ih; uint64_t frame_bitpos = 0;
     ParseImageHeader(cs, &ih, &frame_bitpos);
-    const vec<uint8_t> icc = SynthesizeIcc(ih);
+    const vec<uint8_t> icc = ih.want_icc ? ih.icc : SynthesizeIcc(ih);   // (embedded profile: the original one)
     const size_t cap = icc_size ? *icc_size : 0;
     if (icc_size) *icc_size = icc.size();
     if (icc_out) { if (cap < icc.size()) { SetLastError("ICC output buffer too small"); return 1; } memcpy(icc_out, icc.data(), icc.size()); }

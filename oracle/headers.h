@@ -48,8 +48,190 @@ struct ImageMetadata {
   float quant_bias[4];
   uint32_t cw_mask = 0;
   std::vector<float> up2, up4, up8;
+  std::vector<uint8_t> icc;   // embedded ICC profile (color.want_icc), decoded
   int num_color_channels() const { return color.color_space == 1 ? 1 : 3; }
 };
+
+// ---- embedded ICC profile: icc_codec.cc (ICCReader + UnpredictICC) [R] -----------------------------------------------
+// Byte stream under 41 contexts (kind of the previous byte x kind of the one before), then the "predicted ICC" container:
+// varint(size of the profile) varint(size of the command stream) commands data.
+namespace icc_detail {
+inline int ByteKind1(int b) {
+  if (('a' <= b && b <= 'z') || ('A' <= b && b <= 'Z')) return 0;
+  if (('0' <= b && b <= '9') || b == '.' || b == ',') return 1;
+  if (b <= 1) return 2 + b;
+  if (b < 16) return 4;
+  if (b > 240 && b < 255) return 5;
+  if (b == 255) return 6;
+  return 7;
+}
+inline int ByteKind2(int b) {
+  if (('a' <= b && b <= 'z') || ('A' <= b && b <= 'Z')) return 0;
+  if (('0' <= b && b <= '9') || b == '.' || b == ',') return 1;
+  if (b < 16) return 2;
+  if (b > 240) return 3;
+  return 4;
+}
+inline int Context(size_t i, int b1, int b2) { return i <= 128 ? 0 : 1 + ByteKind1(b1) + 8 * ByteKind2(b2); }
+
+struct Cursor {
+  const std::vector<uint8_t>& v;
+  uint64_t varint(size_t& at) const {
+    uint64_t r = 0;
+    for (int k = 0; k < 10; k++) {
+      if (at >= v.size()) JXLO_FAIL("ICC: varint out of bounds");
+      uint8_t b = v[at++];
+      r |= (uint64_t)(b & 0x7F) << (7 * k);
+      if (b < 0x80) return r;
+    }
+    JXLO_FAIL("ICC: varint too long");
+  }
+};
+inline void be32(std::vector<uint8_t>& o, uint64_t x) { for (int s = 24; s >= 0; s -= 8) o.push_back((uint8_t)(x >> s)); }
+inline void word(std::vector<uint8_t>& o, const std::string& w) { o.insert(o.end(), w.begin(), w.end()); }
+// transposes a (width x ceil(n / width)) layout back: output i takes input i / width + (i % width) * rows, ragged last column
+inline std::vector<uint8_t> Unshuffled(const uint8_t* in, size_t n, size_t width) {
+  std::vector<uint8_t> out(n);
+  size_t rows = (n + width - 1) / width, start = 0, j = 0;
+  for (size_t i = 0; i < n; i++) { out[i] = in[j]; j += rows; if (j >= n) j = ++start; }
+  return out;
+}
+inline uint64_t Extrapolate(int order, uint64_t a, uint64_t b, uint64_t c) { return order == 0 ? a : order == 1 ? 2 * a - b : 3 * a - 3 * b + c; }
+}  // namespace icc_detail
+
+inline std::vector<uint8_t> UnpredictICC(const std::vector<uint8_t>& enc) {
+  using namespace icc_detail;
+  Cursor cur{enc};
+  const size_t n = enc.size();
+  size_t data = 0;
+  const uint64_t out_size = cur.varint(data);
+  const uint64_t cmd_size = cur.varint(data);
+  if (out_size > 0xFFFFFFFFull || cmd_size > 0xFFFFFFFFull || cmd_size > n - data) JXLO_FAIL("ICC: sizes");
+  size_t cmd = data;
+  const size_t cmd_end = data + (size_t)cmd_size;
+  data = cmd_end;
+  std::vector<uint8_t> icc;
+  // 128-byte header as differences from a guess
+  std::vector<uint8_t> guess(128, 0);
+  guess[0] = (uint8_t)(out_size >> 24); guess[1] = (uint8_t)(out_size >> 16); guess[2] = (uint8_t)(out_size >> 8); guess[3] = (uint8_t)out_size;
+  guess[8] = 4;
+  const char* fixed[4] = {"mntr", "RGB ", "XYZ ", "acsp"};
+  const int fixed_at[4] = {12, 16, 20, 36};
+  for (int k = 0; k < 4; k++) memcpy(&guess[fixed_at[k]], fixed[k], 4);
+  const uint8_t d50[12] = {0, 0, 246, 214, 0, 1, 0, 0, 0, 0, 211, 45};
+  memcpy(&guess[68], d50, 12);
+  for (size_t i = 0;; i++) {
+    if (icc.size() == out_size) { if (cmd != cmd_end || data != n) JXLO_FAIL("ICC: trailing data"); return icc; }
+    if (i == 128) break;
+    if (i == 8) memcpy(&guess[80], &icc[4], 4);                                     // creator guess = preferred CMM
+    if (i == 41) { if (icc[40] == 'A') memcpy(&guess[41], "PPL", 3); else if (icc[40] == 'M') memcpy(&guess[41], "SFT", 3); }
+    if (i == 42) { if (icc[40] == 'S' && icc[41] == 'G') memcpy(&guess[42], "I ", 2); else if (icc[40] == 'S' && icc[41] == 'U') memcpy(&guess[42], "NW", 2); }
+    if (data >= n) JXLO_FAIL("ICC: header data missing");
+    icc.push_back((uint8_t)(enc[data++] + guess[i]));
+  }
+  if (cmd >= cmd_end) JXLO_FAIL("ICC: commands missing");
+  // tag table
+  static const char* kKnownTags[17] = {"cprt", "wtpt", "bkpt", "rXYZ", "gXYZ", "bXYZ", "kXYZ", "rTRC", "gTRC", "bTRC", "kTRC", "chad", "desc", "chrm", "dmnd", "dmdd", "lumi"};
+  uint64_t ntags_plus1 = cur.varint(cmd);
+  if (ntags_plus1) {
+    const uint64_t ntags = ntags_plus1 - 1;
+    if (ntags > 0xFFFFFFFFull) JXLO_FAIL("ICC: tag count");
+    be32(icc, ntags);
+    uint64_t last_start = 128 + 12 * ntags, last_size = 0;
+    while (true) {
+      if (icc.size() > out_size || cmd > cmd_end) JXLO_FAIL("ICC: tag table overrun");
+      if (cmd == cmd_end) break;
+      const int c = enc[cmd++], code = c & 63;
+      if (code == 0) break;
+      std::string name;
+      if (code == 1) { if (n - data < 4) JXLO_FAIL("ICC: tag name missing"); name.assign((const char*)&enc[data], 4); data += 4; }
+      else if (code == 2) name = "rTRC";
+      else if (code == 3) name = "rXYZ";
+      else if (code - 4 < 17) name = kKnownTags[code - 4];
+      else JXLO_FAIL("ICC: tag code");
+      word(icc, name);
+      uint64_t size = last_size;
+      if (name == "rXYZ" || name == "gXYZ" || name == "bXYZ" || name == "kXYZ" || name == "wtpt" || name == "bkpt" || name == "lumi") size = 20;
+      uint64_t start = last_start + last_size;
+      if (c & 64) { if (cmd >= cmd_end) JXLO_FAIL("ICC: tag offset missing"); start = cur.varint(cmd); }
+      if (start > 0xFFFFFFFFull) JXLO_FAIL("ICC: tag offset");
+      be32(icc, start);
+      if (c & 128) { if (cmd >= cmd_end) JXLO_FAIL("ICC: tag size missing"); size = cur.varint(cmd); }
+      if (size > 0xFFFFFFFFull) JXLO_FAIL("ICC: tag size");
+      be32(icc, size);
+      last_start = start; last_size = size;
+      if (code == 2) for (const char* t : {"gTRC", "bTRC"}) { word(icc, t); be32(icc, start); be32(icc, size); }
+      if (code == 3) {
+        if (start + 2 * size > 0xFFFFFFFFull) JXLO_FAIL("ICC: tag offset");
+        word(icc, "gXYZ"); be32(icc, start + size); be32(icc, size);
+        word(icc, "bXYZ"); be32(icc, start + 2 * size); be32(icc, size);
+      }
+    }
+  }
+  // tag data
+  static const char* kKnownTypes[8] = {"XYZ ", "desc", "text", "mluc", "para", "curv", "sf32", "gbd "};
+  while (true) {
+    if (icc.size() > out_size || cmd > cmd_end) JXLO_FAIL("ICC: content overrun");
+    if (cmd == cmd_end) break;
+    const int c = enc[cmd++];
+    if (c == 1 || c == 2 || c == 3) {
+      if (cmd >= cmd_end) JXLO_FAIL("ICC: count missing");
+      const uint64_t count = cur.varint(cmd);
+      if (count > n - data) JXLO_FAIL("ICC: data missing");
+      if (c == 1) icc.insert(icc.end(), enc.begin() + data, enc.begin() + data + count);
+      else { auto u = Unshuffled(&enc[data], (size_t)count, c == 2 ? 2 : 4); icc.insert(icc.end(), u.begin(), u.end()); }
+      data += (size_t)count;
+    } else if (c == 4) {
+      if (cmd_end - cmd < 2) JXLO_FAIL("ICC: predictor flags missing");
+      const int flags = enc[cmd++];
+      const size_t width = (flags & 3) + 1;
+      const int order = (flags >> 2) & 3;
+      if (width == 3 || order == 3) JXLO_FAIL("ICC: predictor parameters");
+      uint64_t stride = width;
+      if (flags & 16) { if (cmd >= cmd_end) JXLO_FAIL("ICC: stride missing"); stride = cur.varint(cmd); if (stride < width) JXLO_FAIL("ICC: stride"); }
+      if (icc.empty() || ((icc.size() - 1) >> 2) < stride) JXLO_FAIL("ICC: stride too large");
+      if (cmd >= cmd_end) JXLO_FAIL("ICC: count missing");
+      const uint64_t count = cur.varint(cmd);
+      if (count > n - data) JXLO_FAIL("ICC: data missing");
+      std::vector<uint8_t> res(enc.begin() + data, enc.begin() + data + count);
+      if (width > 1) res = Unshuffled(res.data(), res.size(), width);
+      const size_t base = icc.size();
+      for (size_t i = 0; i < res.size(); i++) {
+        const size_t unit = base + i - i % width;       // first byte of the big-endian value this byte belongs to
+        uint64_t past[3];
+        for (int k = 0; k < 3; k++) { uint64_t v = 0; for (size_t b = 0; b < width; b++) v = (v << 8) | icc[unit - (size_t)stride * (k + 1) + b]; past[k] = v; }
+        const uint64_t pred = Extrapolate(order, past[0], past[1], past[2]);
+        const int shift = (int)(8 * (width - 1 - i % width));
+        icc.push_back((uint8_t)((pred >> shift) + res[i]));
+      }
+      data += (size_t)count;
+    } else if (c == 10) {
+      word(icc, "XYZ "); be32(icc, 0);
+      if (n - data < 12) JXLO_FAIL("ICC: XYZ data missing");
+      icc.insert(icc.end(), enc.begin() + data, enc.begin() + data + 12); data += 12;
+    } else if (c >= 16 && c < 24) { word(icc, kKnownTypes[c - 16]); be32(icc, 0); }
+    else JXLO_FAIL("ICC: unknown command");
+  }
+  if (data != n || icc.size() != out_size) JXLO_FAIL("ICC: size mismatch");
+  return icc;
+}
+
+inline void ReadEmbeddedICC(BitReader& br, std::vector<uint8_t>& icc) {
+  const uint64_t enc_size = U64(br);
+  if (enc_size > (1ull << 28)) JXLO_FAIL("ICC: encoded size");
+  EntropyCode ec;
+  ReadEntropyCode(br, 41, ec);
+  SymbolReader sr;
+  sr.Init(&ec, br);
+  std::vector<uint8_t> enc((size_t)enc_size);
+  for (size_t i = 0; i < enc.size(); i++) {
+    const uint32_t v = sr.Read(br, icc_detail::Context(i, i ? enc[i - 1] : 0, i > 1 ? enc[i - 2] : 0));
+    if (v > 255) JXLO_FAIL("ICC: byte out of range");
+    enc[i] = (uint8_t)v;
+  }
+  if (!sr.CheckFinal()) JXLO_FAIL("ICC: ANS final state");
+  icc = UnpredictICC(enc);
+}
 
 inline void ReadSize(BitReader& br, uint32_t& xs, uint32_t& ys) {
   bool small = br.Bool();
@@ -179,7 +361,7 @@ inline void ReadImageHeaders(BitReader& br, ImageMetadata& m) {
     if (m.cw_mask & 2) { m.up4.resize(55); for (auto& v : m.up4) v = F16(br); }
     if (m.cw_mask & 4) { m.up8.resize(210); for (auto& v : m.up8) v = F16(br); }
   }
-  if (m.color.want_icc) JXLO_FAIL("unsupported: embedded ICC profile");
+  if (m.color.want_icc) ReadEmbeddedICC(br, m.icc);
   br.byte_align();
 }
 

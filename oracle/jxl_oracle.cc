@@ -460,6 +460,8 @@ jxlo_handle* jxlo_decode(const uint8_t* data, size_t size, int want_dump) {
 const char* jxlo_error(jxlo_handle* h) { return h->err.empty() ? nullptr : h->err.c_str(); }
 void jxlo_free(jxlo_handle* h) { delete h; }
 void jxlo_set_unpremultiply_alpha(jxlo_handle* h, int v) { h->unpremul = v != 0; }
+// embedded ICC profile of the image (empty when the colour encoding is enumerated)
+size_t jxlo_icc(jxlo_handle* h, uint8_t* out, size_t cap) { const auto& v = h->d.meta.icc; if (out && cap >= v.size() && !v.empty()) memcpy(out, v.data(), v.size()); return v.size(); }
 void jxlo_get_info(jxlo_handle* h, jxlo_info* i) {
   const ImageMetadata& m = h->d.meta;
   memset(i, 0, sizeof(*i));

@@ -82,6 +82,15 @@ class Decoded:
         self._L.jxlo_set_unpremultiply_alpha.argtypes = [C.c_void_p, C.c_int]
         self._L.jxlo_set_unpremultiply_alpha(self._h, 1 if on else 0)
 
+    def icc(self) -> bytes:
+        """The embedded ICC profile (b"" when the colour encoding is enumerated)."""
+        self._L.jxlo_icc.restype = C.c_size_t
+        self._L.jxlo_icc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        n = self._L.jxlo_icc(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.jxlo_icc(self._h, buf, n)
+        return buf.raw[:n]
+
     def pixels(self, dtype="u8", num_channels=0, big_endian=False, align=0):
         t, npdt = TYPES[dtype]
         if num_channels == 0:

@@ -159,3 +159,10 @@ def encode_modular_free(seed=1, w=64, h=64, nchan=3, has_alpha=False, bits=8, tr
     if L.jxlsynth_modular_free(C.byref(p), C.byref(out), C.byref(n)):
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)
+
+
+def set_icc(icc: bytes = b""):
+    """Embed `icc` (an ICC profile) in the image headers written from now on (b"" = back to enumerated colour encodings)."""
+    L = lib()
+    L.jxlsynth_set_icc.argtypes = [C.c_char_p, C.c_size_t]
+    L.jxlsynth_set_icc(icc, len(icc))

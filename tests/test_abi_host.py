@@ -299,3 +299,49 @@ def test_jpeg_writer_reproduces_sample_jpg(jx):
     want = open(os.path.join(FIXTURES, "sample.jpg"), "rb").read()
     assert out[:n.value].tobytes() == want
     assert hashlib.sha256(want).hexdigest().startswith("d28d532e")
+
+
+def test_embedded_icc_profile_round_trip(jx):
+    """SURVEY §8f.3 "decode the ANS-coded embedded ICC": image headers with want_icc carry the profile as an entropy-coded,
+    predicted byte stream (icc_codec.cc).  tools/jxl_synth.cc writes one (header differences, tag commands incl. the TRC / XYZ
+    triples and implicit offsets, insert / shuffle / predict content commands of every width and order); the product's host
+    parser and the oracle — written separately — must both give back the exact profile.  Profiles: lcms2's sRGB / Lab / XYZ
+    (PIL.ImageCms) and this library's own synthesised one.  (libjxl itself is not available: the stream syntax is [R].)"""
+    import numpy as np
+    import oracle_lib as O
+    import synth_lib as S
+    from PIL import ImageCms
+    img = np.random.default_rng(1).integers(0, 255, (40, 50, 3)).astype(np.int32)
+    plain = S.encode_modular(img, 8, False, 0)
+    profiles = {n: ImageCms.ImageCmsProfile(ImageCms.createProfile(n)).tobytes() for n in ("sRGB", "LAB", "XYZ")}
+    profiles["own"] = jx.icc_profile_from_headers(plain)
+    want_px = O.decode(plain).pixels("u8", 3)
+    for name, icc in profiles.items():
+        S.set_icc(icc)
+        try:
+            data = S.encode_modular(img, 8, False, 0)
+            xyb = S.encode_vardct(S.synthetic_image(3, 64, 48), seed=1)
+        finally:
+            S.set_icc(b"")
+        assert len(data) > len(plain) + 100
+        assert jx.icc_profile_from_headers(data) == icc, name
+        assert jx.icc_profile_from_headers(xyb) == icc, name
+        ref = O.decode(data)
+        assert ref.icc() == icc, name
+        assert np.array_equal(ref.pixels("u8", 3), want_px)          # the samples are untouched by the profile
+        assert O.decode(xyb).icc() == icc
+    # damaged stream: an error, not a crash / wrong profile
+    S.set_icc(profiles["sRGB"])
+    try:
+        data = bytearray(S.encode_modular(img, 8, False, 0))
+    finally:
+        S.set_icc(b"")
+    bad = 0
+    for pos in range(20, 200, 7):
+        d2 = bytearray(data); d2[pos] ^= 0x5A
+        try:
+            got = jx.icc_profile_from_headers(bytes(d2))
+            bad += got != profiles["sRGB"]
+        except jx.DecodeError:
+            bad += 1
+    assert bad >= 20

@@ -838,3 +838,23 @@ def test_repeated_decodes_leave_clean_coefficient_planes(jx):
                 b.finish()
                 for i, r in enumerate(refs):
                     assert np.array_equal(b.output(i), r), (name, force, rep, i)
+
+
+def test_images_with_an_embedded_icc_profile(jx):
+    """decode.rs:368-385 with icc_profile(true) on files whose colour encoding is an embedded ICC profile: non-XYB samples are
+    handed out untouched with the embedded profile; XYB images are rendered to sRGB (libjxl without a CMS) and report the sRGB
+    profile for the pixel data.  Pixels equal the oracle's either way."""
+    from PIL import ImageCms
+    icc = ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes()
+    img = S.synthetic_image(8, 300, 200).astype(np.int32)
+    S.set_icc(icc)
+    try:
+        lossless = S.encode_modular(np.dstack([img, 255 - img[..., :1]]), 8, True)
+        lossy = S.encode_vardct(S.synthetic_image(8, 300, 200), seed=2, strategy_mix=2)
+    finally:
+        S.set_icc(b"")
+    meta, px = jx.decoder_builder(icc_profile=True).decode_with(lossless, np.uint8)
+    assert meta.icc_profile == icc and np.array_equal(px, O.decode(lossless).pixels("u8", 4))
+    meta, px = jx.decoder_builder(icc_profile=True).decode_with(lossy, np.uint8)
+    assert meta.icc_profile == jx.icc_profile_from_headers(S.encode_vardct(S.synthetic_image(8, 64, 64), seed=2))    # the enumerated sRGB profile
+    assert np.array_equal(px, O.decode(lossy).pixels("u8", 3))

@@ -215,11 +215,131 @@ static std::vector<float> CustomUpWeights(int up) {
   return wts;
 }
 
+// ---- embedded ICC profile, encoder side (the inverse of icc_codec.cc UnpredictICC): header as differences from the predicted
+// header, one command per tag (known names, implicit offsets / sizes, TRC and XYZ triples where they apply), tag data as a mix
+// of insert / shuffle / predict commands chosen to exercise the decoder rather than to compress.
+static thread_local std::vector<uint8_t> g_icc;
+static void IccVarint(std::vector<uint8_t>& v, uint64_t x) { while (x > 127) { v.push_back((uint8_t)(x | 128)); x >>= 7; } v.push_back((uint8_t)x); }
+static std::vector<uint8_t> IccShuffleFwd(const std::vector<uint8_t>& in, size_t width) {   // decoder: out[i] = in[j], j walking columns
+  const size_t n = in.size(), rows = (n + width - 1) / width;
+  std::vector<uint8_t> out(n);
+  size_t start = 0, j = 0;
+  for (size_t i = 0; i < n; i++) { out[j] = in[i]; j += rows; if (j >= n) j = ++start; }
+  return out;
+}
+static std::vector<uint8_t> EncodeIccBytes(const std::vector<uint8_t>& icc) {
+  std::vector<uint8_t> cmds, data;
+  const size_t n = icc.size();
+  // header
+  uint8_t guess[128] = {0};
+  guess[0] = (uint8_t)(n >> 24); guess[1] = (uint8_t)(n >> 16); guess[2] = (uint8_t)(n >> 8); guess[3] = (uint8_t)n;
+  guess[8] = 4; memcpy(guess + 12, "mntr", 4); memcpy(guess + 16, "RGB ", 4); memcpy(guess + 20, "XYZ ", 4); memcpy(guess + 36, "acsp", 4);
+  guess[70] = 246; guess[71] = 214; guess[73] = 1; guess[78] = 211; guess[79] = 45;
+  for (size_t i = 0; i < 128 && i < n; i++) {
+    if (i == 8) memcpy(guess + 80, &icc[4], 4);
+    if (i == 41) { if (icc[40] == 'A') memcpy(guess + 41, "PPL", 3); else if (icc[40] == 'M') memcpy(guess + 41, "SFT", 3); }
+    if (i == 42) { if (icc[40] == 'S' && icc[41] == 'G') memcpy(guess + 42, "I ", 2); else if (icc[40] == 'S' && icc[41] == 'U') memcpy(guess + 42, "NW", 2); }
+    data.push_back((uint8_t)(icc[i] - guess[i]));
+  }
+  size_t pos = std::min<size_t>(128, n);
+  if (n >= 132) {
+    auto rd32 = [&](size_t o) { return ((uint32_t)icc[o] << 24) | ((uint32_t)icc[o + 1] << 16) | ((uint32_t)icc[o + 2] << 8) | icc[o + 3]; };
+    const uint32_t ntags = rd32(128);
+    if (132 + (size_t)ntags * 12 > n) throw std::runtime_error("ICC tag table out of bounds");
+    IccVarint(cmds, (uint64_t)ntags + 1);
+    static const char* kKnown[17] = {"cprt", "wtpt", "bkpt", "rXYZ", "gXYZ", "bXYZ", "kXYZ", "rTRC", "gTRC", "bTRC", "kTRC", "chad", "desc", "chrm", "dmnd", "dmdd", "lumi"};
+    uint64_t last_start = 128 + 12ull * ntags, last_size = 0;
+    for (uint32_t t = 0; t < ntags;) {
+      const size_t o = 132 + 12 * (size_t)t;
+      const std::string name((const char*)&icc[o], 4);
+      const uint32_t start = rd32(o + 4), size = rd32(o + 8);
+      auto same = [&](uint32_t k, const char* nm, uint32_t st, uint32_t sz) {
+        return t + k < ntags && memcmp(&icc[132 + 12 * (size_t)(t + k)], nm, 4) == 0 && rd32(132 + 12 * (size_t)(t + k) + 4) == st && rd32(132 + 12 * (size_t)(t + k) + 8) == sz;
+      };
+      int code = 1, span = 1;
+      if (name == "rTRC" && same(1, "gTRC", start, size) && same(2, "bTRC", start, size)) { code = 2; span = 3; }
+      else if (name == "rXYZ" && same(1, "gXYZ", start + size, size) && same(2, "bXYZ", start + 2 * size, size)) { code = 3; span = 3; }
+      else for (int k = 0; k < 17; k++) if (name == kKnown[k]) code = 4 + k;
+      uint64_t implied_size = last_size;
+      if (name == "rXYZ" || name == "gXYZ" || name == "bXYZ" || name == "kXYZ" || name == "wtpt" || name == "bkpt" || name == "lumi") implied_size = 20;
+      int c = code;
+      if (start != last_start + last_size) c |= 64;
+      if (size != implied_size) c |= 128;
+      cmds.push_back((uint8_t)c);
+      if (code == 1) data.insert(data.end(), name.begin(), name.end());
+      if (c & 64) IccVarint(cmds, start);
+      if (c & 128) IccVarint(cmds, size);
+      last_start = start; last_size = size;
+      t += span;
+    }
+    cmds.push_back(0);     // end of the tag list
+    pos = 132 + 12 * (size_t)ntags;
+  }
+  // tag data: cycle through the content commands
+  int turn = 0;
+  while (pos < n) {
+    size_t len = std::min<size_t>(n - pos, 24 + 37 * (size_t)(turn % 5));
+    const int kind = turn++ % 6;
+    if (kind == 5 && n - pos >= 20 && memcmp(&icc[pos], "XYZ \0\0\0\0", 8) == 0) { cmds.push_back(10); data.insert(data.end(), icc.begin() + pos + 8, icc.begin() + pos + 20); pos += 20; continue; }
+    if (kind == 0 || kind == 5) { cmds.push_back(1); IccVarint(cmds, len); data.insert(data.end(), icc.begin() + pos, icc.begin() + pos + len); }
+    else if (kind == 1 || kind == 2) {
+      const size_t width = kind == 1 ? 2 : 4;
+      cmds.push_back((uint8_t)(kind == 1 ? 2 : 3)); IccVarint(cmds, len);
+      const std::vector<uint8_t> sh = IccShuffleFwd(std::vector<uint8_t>(icc.begin() + pos, icc.begin() + pos + len), width);
+      data.insert(data.end(), sh.begin(), sh.end());
+    } else {
+      // predict: width 1 / 2 / 4, order 0..2, explicit stride now and then
+      const size_t width = kind == 3 ? 1 : (turn % 2 ? 2 : 4);
+      const int order = turn % 3;
+      const bool explicit_stride = turn % 4 == 0;
+      const uint64_t stride = explicit_stride ? width * 2 : width;
+      if (pos == 0 || ((pos - 1) >> 2) < stride) { cmds.push_back(1); IccVarint(cmds, len); data.insert(data.end(), icc.begin() + pos, icc.begin() + pos + len); pos += len; continue; }
+      cmds.push_back(4);
+      cmds.push_back((uint8_t)((width - 1) | (order << 2) | (explicit_stride ? 16 : 0)));
+      if (explicit_stride) IccVarint(cmds, stride);
+      IccVarint(cmds, len);
+      std::vector<uint8_t> res(len);
+      for (size_t i = 0; i < len; i++) {
+        const size_t unit = pos + i - i % width;
+        uint64_t past[3];
+        for (int k = 0; k < 3; k++) { uint64_t v = 0; for (size_t b = 0; b < width; b++) v = (v << 8) | icc[unit - (size_t)stride * (k + 1) + b]; past[k] = v; }
+        const uint64_t pred = order == 0 ? past[0] : order == 1 ? 2 * past[0] - past[1] : 3 * past[0] - 3 * past[1] + past[2];
+        res[i] = (uint8_t)(icc[pos + i] - (uint8_t)(pred >> (8 * (width - 1 - i % width))));
+      }
+      if (width > 1) res = IccShuffleFwd(res, width);
+      data.insert(data.end(), res.begin(), res.end());
+    }
+    pos += len;
+  }
+  std::vector<uint8_t> out;
+  IccVarint(out, n);
+  IccVarint(out, cmds.size());
+  out.insert(out.end(), cmds.begin(), cmds.end());
+  out.insert(out.end(), data.begin(), data.end());
+  return out;
+}
+static void WriteIccStream(BitWriter& w, const std::vector<uint8_t>& icc) {
+  const std::vector<uint8_t> enc = EncodeIccBytes(icc);
+  auto kind1 = [](int b) { if ((b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z')) return 0; if ((b >= '0' && b <= '9') || b == '.' || b == ',') return 1; if (b <= 1) return 2 + b; if (b < 16) return 4; if (b > 240 && b < 255) return 5; if (b == 255) return 6; return 7; };
+  auto kind2 = [](int b) { if ((b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z')) return 0; if ((b >= '0' && b <= '9') || b == '.' || b == ',') return 1; if (b < 16) return 2; if (b > 240) return 3; return 4; };
+  std::vector<Token> tok;
+  for (size_t i = 0; i < enc.size(); i++) {
+    const int b1 = i ? enc[i - 1] : 0, b2 = i > 1 ? enc[i - 2] : 0;
+    tok.push_back({(uint32_t)(i <= 128 ? 0 : 1 + kind1(b1) + 8 * kind2(b2)), enc[i]});
+  }
+  WriteU64(w, enc.size());
+  EntropyCoder code;
+  std::vector<const std::vector<Token>*> ss{&tok};
+  BuildEntropyCoder(ss, 41, UintConfig{4, 2, 0}, 6, code);
+  WriteEntropyCode(w, code);
+  EncodeTokens(w, code, tok);
+}
+
 static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool xyb, int bits, bool has_alpha, bool gray) {
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
   const bool custom_up = p.upsampling > 1 && p.custom_up_weights;
-  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up;
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty();
   w.put(all_default, 1);
   if (!all_default) {
     bool extra_fields = p.hdr || p.orientation != 1;
@@ -246,9 +366,12 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
     }
     w.put(xyb, 1);
     // ColorEncoding
-    bool ce_default = !p.hdr && !gray;
+    bool ce_default = !p.hdr && !gray && g_icc.empty();
     w.put(ce_default, 1);
-    if (!ce_default) {
+    if (!g_icc.empty()) {
+      w.put(1, 1);                                                  // want_icc: only the colour space follows
+      WriteU32(w, gray ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});
+    } else if (!ce_default) {
       w.put(0, 1);  // want_icc
       WriteU32(w, gray ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});   // colour space
       WriteU32(w, 1, {0, 0}, {0, 1}, {4, 2}, {6, 18});              // white point D65
@@ -270,6 +393,7 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
     w.put(p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : 4, 3);   // cw_mask
     for (float v : CustomUpWeights(p.upsampling)) WriteF16(w, v);
   }
+  if (!g_icc.empty()) WriteIccStream(w, g_icc);
   w.align();
 }
 
@@ -1004,6 +1128,8 @@ static thread_local std::string g_err;
 const char* jxlsynth_last_error() { return g_err.c_str(); }
 void jxlsynth_free(uint8_t* p) { free(p); }
 void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::SyntheticImage(seed, w, h, rgb); }
+// ICC profile embedded by the image headers written from now on in this thread (size 0: none, enumerated colour encoding)
+void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
 
 static int finish(const std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
   *out = (uint8_t*)malloc(v.size());
