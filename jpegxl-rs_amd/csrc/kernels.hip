@@ -364,16 +364,29 @@ struct WPStateLds {
     const int32_t pos_N = prev_row + x;
     const int32_t pos_NE = x < xsize - 1 ? pos_N + 1 : pos_N;
     const int32_t pos_NW = x > 0 ? pos_N - 1 : pos_N;
-    uint32_t weights[4];
+    // all sixteen state reads are issued before anything waits for one of them (one LDS round trip instead of eight)
+    uint32_t e0[4], e1[4], e2[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      weights[i] = ErrorWeight((uint64_t)(uint32_t)Ld(1 + i, pos_N) + (uint32_t)Ld(1 + i, pos_NE) + (uint32_t)Ld(1 + i, pos_NW), (uint32_t)hdr.w[i]);
-    N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
+    for (int i = 0; i < 4; i++) { e0[i] = (uint32_t)Ld(1 + i, pos_N); e1[i] = (uint32_t)Ld(1 + i, pos_NE); e2[i] = (uint32_t)Ld(1 + i, pos_NW); }
     const WI teW = x == 0 ? 0 : Ld(0, cur_row + x - 1);
     const WI teN = Ld(0, pos_N);
     const WI teNW = Ld(0, pos_NW);
-    const WI sumWN = teN + teW;
     const WI teNE = Ld(0, pos_NE);
+    // error weights: the four division-table reads likewise go out together
+    int shift[4];
+    uint32_t quot[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint64_t sum = (uint64_t)e0[i] + e1[i] + e2[i];
+      shift[i] = FloorLog2u64(sum + 1) - 5;
+      if (shift[i] < 0) shift[i] = 0;
+      quot[i] = Div((uint32_t)(sum >> shift[i]));
+    }
+    uint32_t weights[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) weights[i] = 4 + (((uint32_t)hdr.w[i] * quot[i]) >> shift[i]);
+    N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
+    const WI sumWN = teN + teW;
     WI p = teW;
     if (AbsT(teN) > AbsT(p)) p = teN;
     if (AbsT(teNW) > AbsT(p)) p = teNW;
@@ -388,10 +401,11 @@ struct WPStateLds {
     wsum = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) { weights[i] >>= (lw - 4); wsum += weights[i]; }
+    const uint32_t inv = Div(wsum - 1);
     WI sum = (WI)(wsum >> 1) - 1;
 #pragma unroll
     for (int i = 0; i < 4; i++) sum += prediction[i] * (WI)weights[i];
-    pred = ((int64_t)sum * (int64_t)Div(wsum - 1)) >> 24;
+    pred = ((int64_t)sum * (int64_t)inv) >> 24;
     if (((teN ^ teW) | (teN ^ teNW)) > 0) return pred;
     const int64_t mx = Max64(W, Max64(NE, N)), mn = Min64(W, Min64(NE, N));
     pred = Max64(mn, Min64(mx, pred));
@@ -406,12 +420,15 @@ struct WPStateLds {
     const int32_t cur_row = (y & 1) ? 0 : (xsize + 2);
     const int32_t prev_row = (y & 1) ? (xsize + 2) : 0;
     val *= 8;
+    int32_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = Ld(1 + i, prev_row + x + 1);       // (read together, ahead of the stores)
     St(0, cur_row + x, (int32_t)((WI)pred - val));
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int32_t err = (int32_t)((AbsT(prediction[i] - val) + 3) >> 3);
       St(1 + i, cur_row + x, err);
-      St(1 + i, prev_row + x + 1, Ld(1 + i, prev_row + x + 1) + err);
+      St(1 + i, prev_row + x + 1, acc[i] + err);
     }
   }
   // The 32-bit variant is only exact while every sample seen so far is small.  The image's bit depth promises that for plain
@@ -566,6 +583,158 @@ __device__ __forceinline__ void DecodeChunkLds(ChunkState& st, int x0, int x1, u
 
 // All 64 lanes of the wavefront call this.  Lane 0 decodes; the others help with LUT, bit-stream window and row I/O.
 // Semantics identical to DecodeModularChannel (jxl_dev.h).
+// ---- "ballot" decode of a channel under a general MA tree: the whole wavefront decodes the channel together.  Every value of the
+// serial chain (neighbours, ANS state, bit buffer, weighted-predictor arithmetic) is computed redundantly by all 64 lanes — that
+// costs nothing, a wavefront instruction takes the same time for one active lane as for 64 — and the part that used to be a
+// pointer chase through LDS is spread over the lanes: lane j owns the inner nodes j, 64 + j, ... of the channel's subtree (R
+// register rows, at most 64 R inner nodes and leaves after the static splits are resolved), evaluates their properties and
+// comparisons, R ballots yield all decisions of the tree as 64-bit scalars, and the walk from the root is scalar bit tests with
+// the child tables read across lanes (v_readlane) — no LDS round trip per tree level (the single-lane loop pays two).
+// R == 1: the lane's property comes out of a select chain over the properties the subtree uses; R > 1: lane 0 puts the 16
+// property values into LDS and every lane fetches those of its nodes (one LDS round trip for the whole tree).  Channels whose
+// subtree never looks at the weighted predictor (no predictor 6 leaf, no property 15 split) skip its arithmetic altogether.
+constexpr uint32_t kBallotMax = 512;
+struct BallotArgs { uint32_t qi_off, ql_off, pair_off, ni, nl, root_code; bool use_wp; };
+template <int R>
+__device__ __forceinline__ void DecodeRowsBallot(BitReaderP& br, uint32_t& state, const ModTables& T, const ModularCtx& mc, const ChannelDesc& ch, int chan, WPStateLds& wpl, const BallotArgs& ba) {
+  const uint32_t lane = threadIdx.x & 63, wb = T.wb;
+  const uint32_t root_code = ba.root_code;
+  int32_t my_prop[R], my_val[R], leaf_val[R];
+  uint32_t my_pair[R], leaf_a[R], leaf_b[R];
+  uint32_t used = 0;
+  bool wp_leaf = false;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const uint32_t idx = (uint32_t)r * 64 + lane;
+    my_prop[r] = R == 1 ? -1 : 0; my_val[r] = 0x7FFFFFFF; my_pair[r] = 0; leaf_a[r] = 0; leaf_b[r] = 1; leaf_val[r] = 0;
+    if (idx < ba.ni) { const TreeNode n = T.Node(LdS<uint16_t>(ba.qi_off + 2 * idx)); my_prop[r] = n.prop & 15; my_val[r] = n.val; my_pair[r] = LdS<uint32_t>(ba.pair_off + 4 * idx); }
+    if (idx < ba.nl) { const TreeNode n = T.Node(LdS<uint16_t>(ba.ql_off + 2 * idx)); leaf_a[r] = n.a; leaf_b[r] = n.b; leaf_val[r] = n.val; }
+    for (int k = 0; k < 16; k++) if (__ballot(idx < ba.ni && my_prop[r] == k)) used |= 1u << k;
+    wp_leaf |= __ballot(idx < ba.nl && (leaf_a[r] & 0xFF) == 6) != 0;
+  }
+  used = Uniform(used);
+  const bool wp_here = ba.use_wp && (((used >> 15) & 1) || wp_leaf);
+  WaveSync();     // the tables have been read: the window region may be overwritten
+  const int w = ch.w, h = ch.h;
+  const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
+  const uint32_t wend = br.wend;
+  const uint32_t pv = wb + kWorkOff + 896;
+  // the incoming ANS state and bit position live in lane 0
+  state = Uniform(state);
+  const uint64_t bp = br.BitPos();
+  const uint64_t bp0 = ((uint64_t)Uniform((uint32_t)(bp >> 32)) << 32) | Uniform((uint32_t)bp);
+  BitReaderW bw;
+  bw.wpos = (uint32_t)(bp0 >> 5); bw.win_base = 0; bw.buf = 0; bw.avail = 0; bw.win_off = wb + kWinOff;
+  uint32_t skip_bits = (uint32_t)(bp0 & 31);
+  uint32_t cur = wb + kRowOff, prev = wb + kRowOff + kRowMax * 4, prev2 = wb + kChunkOff;   // three row buffers, rotated
+  for (int y = 0; y < h; y++) {
+    int32_t* p = ch.data + (size_t)y * ch.stride;
+    const uint32_t wbase = bw.wpos;
+    WaveSync();    // (the previous row's window reads are done)
+    for (uint32_t i = lane; i < kWinWords; i += 64) StS<uint32_t>(wb + kWinOff + i * 4, wbase + i < wend ? LdG(br.words + wbase + i) : 0u);
+    WaveSync();
+    bw.win_base = wbase;
+    if (skip_bits != 0xFFFFFFFFu) { bw.buf = 0; bw.avail = 0; bw.Refill(); bw.buf >>= skip_bits; bw.avail -= (int)skip_bits; skip_bits = 0xFFFFFFFFu; }
+    int32_t left = 0, left2 = 0, prev9 = 0;
+    int32_t up0 = 0, up1 = 0, up2 = 0, up3 = 0;
+    if (y > 0) { up1 = LdS<int32_t>(prev); up2 = w > 1 ? LdS<int32_t>(prev + 4) : 0; up3 = w > 2 ? LdS<int32_t>(prev + 8) : 0; }
+    for (int x = 0; x < w; x++) {
+      const int32_t up4 = (y > 0 && x + 3 < w) ? LdS<int32_t>(prev + 4 * (x + 3)) : 0;
+      const int32_t W = x ? left : (y ? up1 : 0);
+      const int32_t N = y ? up1 : W;
+      const int32_t NW = (x && y) ? up0 : W;
+      const int32_t NE = (x + 1 < w && y) ? up2 : N;
+      const int32_t WW = x > 1 ? left2 : W;
+      const int32_t NN = y > 1 ? LdS<int32_t>(prev2 + 4 * x) : N;
+      const int32_t NEE = (x + 2 < w && y) ? up3 : NE;
+      int64_t wp_pred = 0;
+      int32_t wp_err = 0;
+      if (wp_here) wp_pred = wpl.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
+      uint64_t decisions[R];
+      if constexpr (R == 1) {
+        // this lane's node: its property out of the ones the subtree uses
+        int32_t v = 0;
+#define JXL_SEL(k, expr) if (used & (1u << (k))) v = my_prop[0] == (k) ? (int32_t)(expr) : v;
+        JXL_SEL(2, y) JXL_SEL(3, x)
+        JXL_SEL(4, N < 0 ? 0u - (uint32_t)N : (uint32_t)N) JXL_SEL(5, W < 0 ? 0u - (uint32_t)W : (uint32_t)W) JXL_SEL(6, N) JXL_SEL(7, W)
+        JXL_SEL(8, (uint32_t)W - (uint32_t)prev9) JXL_SEL(9, (uint32_t)W + (uint32_t)N - (uint32_t)NW) JXL_SEL(10, (uint32_t)W - (uint32_t)NW)
+        JXL_SEL(11, (uint32_t)NW - (uint32_t)N) JXL_SEL(12, (uint32_t)N - (uint32_t)NE) JXL_SEL(13, (uint32_t)N - (uint32_t)NN)
+        JXL_SEL(14, (uint32_t)W - (uint32_t)WW) JXL_SEL(15, wp_err)
+#undef JXL_SEL
+        decisions[0] = __ballot(v > my_val[0]);
+      } else {
+        if (lane == 0) {
+          const int32_t grad = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+          StS<int4>(pv, make_int4(chan, (int32_t)mc.stream_id, y, x));
+          StS<int4>(pv + 16, make_int4(N < 0 ? (int32_t)(0u - (uint32_t)N) : N, W < 0 ? (int32_t)(0u - (uint32_t)W) : W, N, W));
+          StS<int4>(pv + 32, make_int4((int32_t)((uint32_t)W - (uint32_t)prev9), grad, (int32_t)((uint32_t)W - (uint32_t)NW), (int32_t)((uint32_t)NW - (uint32_t)N)));
+          StS<int4>(pv + 48, make_int4((int32_t)((uint32_t)N - (uint32_t)NE), (int32_t)((uint32_t)N - (uint32_t)NN), (int32_t)((uint32_t)W - (uint32_t)WW), wp_err));
+        }
+        int32_t v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = LdS<int32_t>(pv + 4 * (uint32_t)my_prop[r]);
+#pragma unroll
+        for (int r = 0; r < R; r++) decisions[r] = __ballot(v[r] > my_val[r]);
+      }
+      uint32_t code = root_code;
+      while (!(code & 0x8000)) {
+        const int l = (int)(code & 63);
+        const uint32_t row = code >> 6;
+        uint32_t pair = 0;
+        uint64_t d = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) if (row == (uint32_t)r) { pair = (uint32_t)__builtin_amdgcn_readlane((int)my_pair[r], l); d = decisions[r]; }
+        code = ((d >> l) & 1) ? (pair & 0xFFFF) : (pair >> 16);
+      }
+      uint32_t n_a = 0, n_b = 1;
+      int32_t n_val = 0;
+      {
+        const int l = (int)(code & 63);
+        const uint32_t row = (code & 0x7FFF) >> 6;
+#pragma unroll
+        for (int r = 0; r < R; r++) if (row == (uint32_t)r) {
+          n_a = (uint32_t)__builtin_amdgcn_readlane((int)leaf_a[r], l); n_b = (uint32_t)__builtin_amdgcn_readlane((int)leaf_b[r], l); n_val = __builtin_amdgcn_readlane(leaf_val[r], l);
+        }
+      }
+      prev9 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+      const uint32_t cluster = n_a >> 8;
+      const int32_t guess = Predict(n_a & 0xFF, W, N, NW, NE, NN, WW, NEE, wp_pred);
+      // ANS symbol + hybrid integer out of LDS (all lanes read the same addresses: broadcasts)
+      const uint32_t res = state & 0xFFF;
+      const uint32_t i = res >> (12 - la), pos_ = res & ((1u << (12 - la)) - 1);
+      const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
+      const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
+      const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+      const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+      const bool hit = pos_ >= cutoff;
+      uint32_t tok = hit ? right : i;
+      state = (hit ? freq1 : freq0) * (state >> 12) + (hit ? offs1 + pos_ : pos_);
+      if (state < (1u << 16)) state = (state << 16) | bw.Read(16);
+      const uint32_t split_exp = cfg & 0xFF;
+      if (tok >= (1u << split_exp)) {
+        const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+        const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - (1u << split_exp)) >> (msb + lsb))) & 31;
+        const uint32_t low = tok & ((1u << lsb) - 1);
+        tok >>= lsb;
+        const uint32_t bits = nbits ? bw.Read((int)nbits) : 0;
+        const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+        tok = (((hi << nbits) | bits) << lsb) | low;
+      }
+      const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) * n_b + (uint32_t)n_val + (uint32_t)guess);
+      if (lane == 0) StS<int32_t>(cur + 4 * x, val);
+      if (wp_here) { if (lane == 0) wpl.UpdateStores(val, x, y); wpl.NoteSample(val); }
+      left2 = left; left = val;
+      up0 = up1; up1 = up2; up2 = up3; up3 = up4;
+    }
+    WaveSync();
+    for (int i = (int)lane; i < w; i += 64) StG(p + i, LdS<int32_t>(cur + 4 * i));
+    const uint32_t t = prev2; prev2 = prev; prev = cur; cur = t;
+  }
+  const uint64_t endpos = bw.BitPos();
+  br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
+  WaveSync();
+}
+
 // BALLOT: general trees are evaluated by the whole wavefront (see the "ballot" path below) — the Modular kernels; the LF kernel
 // of the VarDCT path keeps the single-lane loops (register budget).
 template <bool BALLOT = false>
@@ -764,7 +933,8 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
   // weighted predictor (no predictor 6 leaf, no property 15 split) skip its arithmetic altogether.
 #ifndef JXL_NO_BALLOT
   if (BALLOT && lds_generic && mode == 0) {
-    const uint32_t qi_off = wb + kLutOff, ql_off = wb + kLutOff + 256, pair_off = wb + kLutOff + 512;
+    // breadth-first numbering of the channel's subtree (static splits resolved): inner node i -> lane i % 64, register row i / 64
+    const uint32_t qi_off = wb + kLutOff, ql_off = wb + kLutOff + 1024, pair_off = wb + kWinOff;   // u16[512], u16[512], u32[512] (the window is loaded later)
     if (lane == 0) {
       uint32_t ni = 0, nl = 0;
       int ok = 1;
@@ -776,123 +946,31 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       };
       const uint32_t root = resolve(subroot);
       uint32_t root_code;
-      if (T.Node(root).prop < 0) { StS<uint32_t>(ql_off, root); nl = 1; root_code = 0x80; }
-      else { StS<uint32_t>(qi_off, root); ni = 1; root_code = 0; }
+      if (root > 0xFFFFu) ok = 0;
+      if (T.Node(root).prop < 0) { StS<uint16_t>(ql_off, (uint16_t)root); nl = 1; root_code = 0x8000; }
+      else { StS<uint16_t>(qi_off, (uint16_t)root); ni = 1; root_code = 0; }
       for (uint32_t i = 0; i < ni && ok; i++) {
-        const TreeNode n = T.Node(LdS<uint32_t>(qi_off + 4 * i));
+        const TreeNode n = T.Node(LdS<uint16_t>(qi_off + 2 * i));
         uint32_t codes[2];
         for (int k = 0; k < 2; k++) {
           const uint32_t c = resolve(k == 0 ? n.a : n.b);
-          if (T.Node(c).prop < 0) { if (nl >= 64) { ok = 0; break; } StS<uint32_t>(ql_off + 4 * nl, c); codes[k] = 0x80 | nl++; }
-          else { if (ni >= 64) { ok = 0; break; } StS<uint32_t>(qi_off + 4 * ni, c); codes[k] = ni++; }
+          if (c > 0xFFFFu) { ok = 0; break; }
+          if (T.Node(c).prop < 0) { if (nl >= kBallotMax) { ok = 0; break; } StS<uint16_t>(ql_off + 2 * nl, (uint16_t)c); codes[k] = 0x8000 | nl++; }
+          else { if (ni >= kBallotMax) { ok = 0; break; } StS<uint16_t>(qi_off + 2 * ni, (uint16_t)c); codes[k] = ni++; }
         }
-        if (ok) StS<uint16_t>(pair_off + 2 * i, (uint16_t)(codes[0] | (codes[1] << 8)));
+        if (ok) StS<uint32_t>(pair_off + 4 * i, codes[0] | (codes[1] << 16));
       }
       StS<int>(wb + kWorkOff + 40, ok); StS<uint32_t>(wb + kWorkOff + 44, ni); StS<uint32_t>(wb + kWorkOff + 48, nl); StS<uint32_t>(wb + kWorkOff + 52, root_code);
     }
     WaveSync();
     if (LdS<int>(wb + kWorkOff + 40)) {
       const uint32_t ni = LdS<uint32_t>(wb + kWorkOff + 44), nl = LdS<uint32_t>(wb + kWorkOff + 48);
-      const uint32_t root_code = Uniform(LdS<uint32_t>(wb + kWorkOff + 52));
-      int32_t my_prop = -1, my_val = 0x7FFFFFFF;
-      uint32_t my_pair = 0, leaf_a = 0, leaf_b = 1;
-      int32_t leaf_val = 0;
-      if (lane < ni) { const TreeNode n = T.Node(LdS<uint32_t>(qi_off + 4 * lane)); my_prop = n.prop; my_val = n.val; my_pair = LdS<uint16_t>(pair_off + 2 * lane); }
-      if (lane < nl) { const TreeNode n = T.Node(LdS<uint32_t>(ql_off + 4 * lane)); leaf_a = n.a; leaf_b = n.b; leaf_val = n.val; }
-      uint32_t used = 0;
-      for (int k = 0; k < 16; k++) if (__ballot(my_prop == k)) used |= 1u << k;
-      used = Uniform(used);
-      const bool wp_here = use_wp && (((used >> 15) & 1) || __ballot(lane < nl && (leaf_a & 0xFF) == 6) != 0);
-      WaveSync();
-      const int w = ch.w, h = ch.h;
-      const uint32_t cfg_off = T.code.cfg_off, alias_off = T.code.alias_off, la = T.code.log_alpha;
-      const uint32_t wend = br.wend;
-      // the incoming ANS state and bit position live in lane 0
-      state = Uniform(state);
-      const uint64_t bp = br.BitPos();
-      const uint64_t bp0 = ((uint64_t)Uniform((uint32_t)(bp >> 32)) << 32) | Uniform((uint32_t)bp);
-      BitReaderW bw;
-      bw.wpos = (uint32_t)(bp0 >> 5); bw.win_base = 0; bw.buf = 0; bw.avail = 0; bw.win_off = wb + kWinOff;
-      uint32_t skip_bits = (uint32_t)(bp0 & 31);
-      uint32_t cur = wb + kRowOff, prev = wb + kRowOff + kRowMax * 4, prev2 = wb + kChunkOff;   // three row buffers, rotated
-      for (int y = 0; y < h; y++) {
-        int32_t* p = ch.data + (size_t)y * ch.stride;
-        const uint32_t wbase = bw.wpos;
-        WaveSync();    // (the previous row's window reads are done)
-        for (uint32_t i = lane; i < kWinWords; i += 64) StS<uint32_t>(wb + kWinOff + i * 4, wbase + i < wend ? LdG(br.words + wbase + i) : 0u);
-        WaveSync();
-        bw.win_base = wbase;
-        if (skip_bits != 0xFFFFFFFFu) { bw.buf = 0; bw.avail = 0; bw.Refill(); bw.buf >>= skip_bits; bw.avail -= (int)skip_bits; skip_bits = 0xFFFFFFFFu; }
-        int32_t left = 0, left2 = 0, prev9 = 0;
-        int32_t up0 = 0, up1 = 0, up2 = 0, up3 = 0;
-        if (y > 0) { up1 = LdS<int32_t>(prev); up2 = w > 1 ? LdS<int32_t>(prev + 4) : 0; up3 = w > 2 ? LdS<int32_t>(prev + 8) : 0; }
-        for (int x = 0; x < w; x++) {
-          const int32_t up4 = (y > 0 && x + 3 < w) ? LdS<int32_t>(prev + 4 * (x + 3)) : 0;
-          const int32_t W = x ? left : (y ? up1 : 0);
-          const int32_t N = y ? up1 : W;
-          const int32_t NW = (x && y) ? up0 : W;
-          const int32_t NE = (x + 1 < w && y) ? up2 : N;
-          const int32_t WW = x > 1 ? left2 : W;
-          const int32_t NN = y > 1 ? LdS<int32_t>(prev2 + 4 * x) : N;
-          const int32_t NEE = (x + 2 < w && y) ? up3 : NE;
-          int64_t wp_pred = 0;
-          int32_t wp_err = 0;
-          if (wp_here) wp_pred = wpl.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
-          // this lane's node: its property out of the ones the subtree uses
-          int32_t pv = 0;
-#define JXL_SEL(k, expr) if (used & (1u << (k))) pv = my_prop == (k) ? (int32_t)(expr) : pv;
-          JXL_SEL(0, chan) JXL_SEL(1, mc.stream_id) JXL_SEL(2, y) JXL_SEL(3, x)
-          JXL_SEL(4, N < 0 ? 0u - (uint32_t)N : (uint32_t)N) JXL_SEL(5, W < 0 ? 0u - (uint32_t)W : (uint32_t)W) JXL_SEL(6, N) JXL_SEL(7, W)
-          JXL_SEL(8, (uint32_t)W - (uint32_t)prev9) JXL_SEL(9, (uint32_t)W + (uint32_t)N - (uint32_t)NW) JXL_SEL(10, (uint32_t)W - (uint32_t)NW)
-          JXL_SEL(11, (uint32_t)NW - (uint32_t)N) JXL_SEL(12, (uint32_t)N - (uint32_t)NE) JXL_SEL(13, (uint32_t)N - (uint32_t)NN)
-          JXL_SEL(14, (uint32_t)W - (uint32_t)WW) JXL_SEL(15, wp_err)
-#undef JXL_SEL
-          const uint64_t decisions = __ballot(pv > my_val);
-          uint32_t code = root_code;
-          while (!(code & 0x80)) {
-            const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)my_pair, (int)code);
-            code = ((decisions >> code) & 1) ? (pair & 0xFF) : (pair >> 8);
-          }
-          const int leaf = (int)(code & 0x7F);
-          const uint32_t n_a = (uint32_t)__builtin_amdgcn_readlane((int)leaf_a, leaf), n_b = (uint32_t)__builtin_amdgcn_readlane((int)leaf_b, leaf);
-          const int32_t n_val = __builtin_amdgcn_readlane(leaf_val, leaf);
-          prev9 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
-          const uint32_t cluster = n_a >> 8;
-          const int32_t guess = Predict(n_a & 0xFF, W, N, NW, NE, NN, WW, NEE, wp_pred);
-          // ANS symbol + hybrid integer out of LDS (all lanes read the same addresses: broadcasts)
-          const uint32_t res = state & 0xFFF;
-          const uint32_t i = res >> (12 - la), pos_ = res & ((1u << (12 - la)) - 1);
-          const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
-          const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
-          const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
-          const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
-          const bool hit = pos_ >= cutoff;
-          uint32_t tok = hit ? right : i;
-          state = (hit ? freq1 : freq0) * (state >> 12) + (hit ? offs1 + pos_ : pos_);
-          if (state < (1u << 16)) state = (state << 16) | bw.Read(16);
-          const uint32_t split_exp = cfg & 0xFF;
-          if (tok >= (1u << split_exp)) {
-            const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
-            const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - (1u << split_exp)) >> (msb + lsb))) & 31;
-            const uint32_t low = tok & ((1u << lsb) - 1);
-            tok >>= lsb;
-            const uint32_t bits = nbits ? bw.Read((int)nbits) : 0;
-            const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
-            tok = (((hi << nbits) | bits) << lsb) | low;
-          }
-          const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) * n_b + (uint32_t)n_val + (uint32_t)guess);
-          if (lane == 0) StS<int32_t>(cur + 4 * x, val);
-          if (wp_here) { if (lane == 0) wpl.UpdateStores(val, x, y); wpl.NoteSample(val); }
-          left2 = left; left = val;
-          up0 = up1; up1 = up2; up2 = up3; up3 = up4;
-        }
-        WaveSync();
-        for (int i = (int)lane; i < w; i += 64) StG(p + i, LdS<int32_t>(cur + 4 * i));
-        const uint32_t t = prev2; prev2 = prev; prev = cur; cur = t;
-      }
-      const uint64_t endpos = bw.BitPos();
-      br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
-      WaveSync();
+      const uint32_t rows = (max(ni, nl) + 63) / 64;
+      const BallotArgs ba{qi_off, ql_off, pair_off, ni, nl, Uniform(LdS<uint32_t>(wb + kWorkOff + 52)), use_wp};
+      if (rows <= 1) DecodeRowsBallot<1>(br, state, T, mc, ch, chan, wpl, ba);
+      else if (rows <= 2) DecodeRowsBallot<2>(br, state, T, mc, ch, chan, wpl, ba);
+      else if (rows <= 4) DecodeRowsBallot<4>(br, state, T, mc, ch, chan, wpl, ba);
+      else DecodeRowsBallot<8>(br, state, T, mc, ch, chan, wpl, ba);
       return;
     }
   }

@@ -1,9 +1,8 @@
-cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
-timeout 600 python bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline > gpurun_out/selfclean.json 2> gpurun_out/selfclean.err < /dev/null
-python - <<'PY'
-import json
-try:
-    r=json.loads(open("gpurun_out/selfclean.json").read().strip().splitlines()[-1]); print(r["value"], r["ms_per_step"], r["stage_ms"], r.get("verified_vs_oracle"))
-except Exception as e: print("ERR", e, open("gpurun_out/selfclean.err").read()[-1500:])
-PY
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bj2
+rm -rf $OUT; mkdir -p $OUT
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d $OUT/$tag -o p --output-format csv -- python $GRAFT_REPO_ROOT/tests/gpu_benchjxl.py 1 > /tmp/pmc_$tag.log 2>&1 < /dev/null
+  tail -1 /tmp/pmc_$tag.log
+done
