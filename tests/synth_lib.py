@@ -166,3 +166,34 @@ def set_icc(icc: bytes = b""):
     L = lib()
     L.jxlsynth_set_icc.argtypes = [C.c_char_p, C.c_size_t]
     L.jxlsynth_set_icc(icc, len(icc))
+
+
+def set_features(patches=None, splines=None, num_extra=0):
+    """Patch dictionary / splines of the frames written from now on (tools/jxl_synth.cc WriteFeatures); call without arguments to clear.
+    patches: list of (ref, x0, y0, xsize, ysize, [(x, y, [(mode, alpha_channel, clamp)] * (1 + num_extra)), ...])
+    splines: (quant_adjust, [(start_x, start_y, [(ddx, ddy), ...], colour_dct[3][32], sigma_dct[32]), ...])"""
+    L = lib()
+    L.jxlsynth_set_features.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t, C.c_int]
+    pf, sf = [], []
+    for ref, x0, y0, xs, ys, positions in (patches or []):
+        pf += [ref, x0, y0, xs, ys, len(positions)]
+        for x, y, blends in positions:
+            assert len(blends) == 1 + num_extra
+            pf += [x, y]
+            for mode, alpha, clamp in blends:
+                pf += [mode, alpha, clamp]
+    if splines:
+        adjust, items = splines
+        sf += [adjust, len(items)]
+        for sx, sy, cps, colour, sigma in items:
+            sf += [sx, sy, len(cps)]
+            for dx, dy in cps:
+                sf += [dx, dy]
+            for c in range(3):
+                assert len(colour[c]) == 32
+                sf += [int(v) for v in colour[c]]
+            assert len(sigma) == 32
+            sf += [int(v) for v in sigma]
+    pa = (C.c_int32 * max(1, len(pf)))(*pf)
+    sa = (C.c_int32 * max(1, len(sf)))(*sf)
+    L.jxlsynth_set_features(pa, len(pf), sa, len(sf), num_extra)

@@ -858,3 +858,57 @@ def test_images_with_an_embedded_icc_profile(jx):
     meta, px = jx.decoder_builder(icc_profile=True).decode_with(lossy, np.uint8)
     assert meta.icc_profile == jx.icc_profile_from_headers(S.encode_vardct(S.synthetic_image(8, 64, 64), seed=2))    # the enumerated sRGB profile
     assert np.array_equal(px, O.decode(lossy).pixels("u8", 3))
+
+
+def _feature_streams():
+    """Synthetic patch dictionaries and splines (tools/jxl_synth.cc WriteFeatures): every patch blend mode (none, replace, add,
+    multiply, blend above / below, alpha-weighted add above / below), clamping, several reference frames, patches touching the
+    frame edges, splines of one and several control points with colour and sigma DCTs, alone and together with noise."""
+    ref_a = S.synthetic_image(50, 64, 48)
+    ref_b = S.synthetic_image(52, 40, 72)
+    main = S.synthetic_image(51, 200, 136)
+    colour = [[0] * 32 for _ in range(3)]
+    colour[1][0] = 300; colour[0][0] = 40; colour[2][1] = -60; colour[1][3] = 25
+    sigma = [0] * 32
+    sigma[0] = 30; sigma[2] = 4
+    splines = (1, [(20, 30, [(15, 5), (2, -3), (-4, 6)], colour, sigma), (150, 20, [(-10, 20)], colour, sigma), (100, 100, [], colour, sigma)])
+    cases = {}
+    hdr = dict(frame_type=2, is_last=0, save_before_ct=1, have_crop=1, canvas_w=200, canvas_h=136)
+    ra = S.encode_vardct_frame(ref_a, S.frame(save_as_reference=1, **hdr), seed=3)
+    rb = S.encode_vardct_frame(ref_b, S.frame(emit=1, save_as_reference=2, **hdr), seed=5)
+    patches = [(1, 4, 6, 20, 16, [(10, 12, [(1, 0, 0)]), (100, 50, [(2, 0, 0)]), (150, 100, [(3, 0, 1)]), (180, 120, [(2, 0, 0)]), (0, 0, [(0, 0, 0)])]),
+               (2, 3, 20, 8, 8, [(0, 128, [(1, 0, 0)]), (192, 0, [(3, 0, 0)]), (96, 64, [(2, 0, 0)])]),
+               (1, 0, 0, 64, 48, [(70, 80, [(2, 0, 0)])])]
+
+    def with_features(fn, **feat):
+        S.set_features(**feat)
+        try:
+            return fn()
+        finally:
+            S.set_features()
+    cases["patches"] = ra + rb + with_features(lambda: S.encode_vardct_frame(main, S.frame(emit=1), seed=4), patches=patches)
+    cases["splines"] = with_features(lambda: S.encode_vardct_frame(main, S.frame(), seed=4), splines=splines)
+    cases["patches_splines_noise"] = ra + rb + with_features(lambda: S.encode_vardct_frame(main, S.frame(emit=1, noise_lut=[40, 80, 120, 160, 200, 240, 280, 320]), seed=4, epf_iters=2),
+                                                            patches=patches, splines=splines)
+    # alpha blend modes: image with alpha; the reference frame carries alpha too
+    al_ref = (np.add.outer(np.arange(48), np.arange(64)) * 3 % 256).astype(np.uint8)
+    al_main = (64 + np.add.outer(np.arange(136), np.arange(200)) % 192).astype(np.uint8)
+    raa = S.encode_vardct_frame(ref_a, S.frame(save_as_reference=1, **hdr), seed=3, alpha=al_ref)
+    pa = [(1, 2, 2, 24, 20, [(5, 5, [(4, 0, 0), (1, 0, 0)]), (60, 10, [(5, 0, 1), (2, 0, 0)]), (120, 40, [(6, 0, 0), (0, 0, 0)]), (30, 90, [(7, 0, 1), (3, 0, 1)]), (170, 110, [(4, 0, 1), (4, 0, 1)])])]
+    cases["patches_alpha_modes"] = raa + with_features(lambda: S.encode_vardct_frame(main, S.frame(emit=1), seed=4, alpha=al_main), patches=pa, num_extra=1)
+    # Modular main frame with patches from a Modular reference frame (integer samples through the same tail)
+    mref = S.encode_modular_frame(ref_a, S.frame(frame_type=2, is_last=0, save_as_reference=3, save_before_ct=1, have_crop=1, canvas_w=200, canvas_h=136), bits=8)
+    cases["patches_modular"] = mref + with_features(lambda: S.encode_modular_frame(main, S.frame(emit=1), bits=8), patches=[(3, 8, 8, 30, 30, [(20, 20, [(1, 0, 0)]), (100, 60, [(2, 0, 0)])])])
+    return cases
+
+
+@pytest.mark.parametrize("name", ["patches", "splines", "patches_splines_noise", "patches_alpha_modes", "patches_modular"])
+def test_synthetic_patches_and_splines(jx, name):
+    """The two real-encoder fixtures exercise one patch blend mode and one spline each; these streams cover the rest of
+    dec_patch_dictionary.cc / splines.cc as the oracle restates them, HIP frame tail against oracle."""
+    data = _feature_streams()[name]
+    nch = 4 if "alpha" in name else 3
+    assert np.unique(O.decode(data).pixels("u8", nch)).size > 50
+    check_against_oracle(jx, data, np.uint8, nch)
+    check_against_oracle(jx, data, np.float32, nch)
+    check_against_oracle(jx, data, np.uint16, 3)

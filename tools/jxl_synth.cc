@@ -215,6 +215,83 @@ static std::vector<float> CustomUpWeights(int up) {
   return wts;
 }
 
+// ---- image features of the next frame(s): patch dictionary and splines, written at the head of LfGlobal (dec_patch_dictionary.cc,
+// splines.cc).  Set through jxlsynth_set_features as flat integer scripts:
+//   patches: { ref, x0, y0, xsize, ysize, count, count x { x, y, (1 + num_extra) x { mode, alpha_channel, clamp } } } ...
+//   splines: { quant_adjust, num, num x { start_x, start_y, ncp, ncp x { dx, dy } (double deltas), 3 x 32 colour DCT, 32 sigma DCT } }
+static thread_local std::vector<int32_t> g_patches, g_splines;
+static thread_local int g_feature_extra = 0;      // number of extra channels the patch blending entries cover
+static void WriteFeatures(BitWriter& s) {
+  if (!g_patches.empty()) {
+    std::vector<Token> tok;
+    size_t i = 0;
+    std::vector<Token> body;
+    uint32_t nrefs = 0;
+    while (i < g_patches.size()) {
+      const int32_t* r = &g_patches[i];
+      nrefs++;
+      body.push_back({1, (uint32_t)r[0]});
+      body.push_back({3, (uint32_t)r[1]}); body.push_back({3, (uint32_t)r[2]});
+      body.push_back({2, (uint32_t)r[3] - 1}); body.push_back({2, (uint32_t)r[4] - 1});
+      const int count = r[5];
+      body.push_back({7, (uint32_t)count - 1});
+      i += 6;
+      int px = 0, py = 0;
+      for (int k = 0; k < count; k++) {
+        const int x = g_patches[i], y = g_patches[i + 1];
+        i += 2;
+        if (k == 0) { body.push_back({4, (uint32_t)x}); body.push_back({4, (uint32_t)y}); }
+        else { body.push_back({6, PackSigned(x - px)}); body.push_back({6, PackSigned(y - py)}); }
+        px = x; py = y;
+        for (int e = 0; e < 1 + g_feature_extra; e++) {
+          const int mode = g_patches[i], alpha = g_patches[i + 1], clamp = g_patches[i + 2];
+          i += 3;
+          body.push_back({5, (uint32_t)mode});
+          if (mode >= 4 && g_feature_extra > 1) body.push_back({8, (uint32_t)alpha});
+          if (mode >= 3) body.push_back({9, (uint32_t)clamp});
+        }
+      }
+    }
+    tok.push_back({0, nrefs});
+    tok.insert(tok.end(), body.begin(), body.end());
+    EntropyCoder code;
+    std::vector<const std::vector<Token>*> ss{&tok};
+    BuildEntropyCoder(ss, 10, UintConfig{4, 2, 0}, 4, code);
+    WriteEntropyCode(s, code);
+    EncodeTokens(s, code, tok);
+  }
+  if (!g_splines.empty()) {
+    std::vector<Token> tok;
+    const int32_t* v = g_splines.data();
+    const int adjust = v[0], num = v[1];
+    tok.push_back({2, (uint32_t)num - 1});
+    // starting points first, then the quantisation adjustment, then the splines
+    std::vector<size_t> at;
+    size_t i = 2;
+    for (int k = 0; k < num; k++) { at.push_back(i); const int ncp = g_splines[i + 2]; i += 3 + 2 * (size_t)ncp + 128; }
+    int lx = 0, ly = 0;
+    for (int k = 0; k < num; k++) {
+      const int x = g_splines[at[k]], y = g_splines[at[k] + 1];
+      if (k == 0) { tok.push_back({1, (uint32_t)x}); tok.push_back({1, (uint32_t)y}); }
+      else { tok.push_back({1, PackSigned(x - lx)}); tok.push_back({1, PackSigned(y - ly)}); }
+      lx = x; ly = y;
+    }
+    tok.push_back({0, PackSigned(adjust)});
+    for (int k = 0; k < num; k++) {
+      const int32_t* q = &g_splines[at[k]];
+      const int ncp = q[2];
+      tok.push_back({3, (uint32_t)ncp});
+      for (int c = 0; c < 2 * ncp; c++) tok.push_back({4, PackSigned(q[3 + c])});
+      for (int c = 0; c < 128; c++) tok.push_back({5, PackSigned(q[3 + 2 * ncp + c])});
+    }
+    EntropyCoder code;
+    std::vector<const std::vector<Token>*> ss{&tok};
+    BuildEntropyCoder(ss, 6, UintConfig{4, 2, 0}, 4, code);
+    WriteEntropyCode(s, code);
+    EncodeTokens(s, code, tok);
+  }
+}
+
 // ---- embedded ICC profile, encoder side (the inverse of icc_codec.cc UnpredictICC): header as differences from the predicted
 // header, one command per tag (known names, implicit offsets / sizes, TRC and XYZ triples where they apply), tag data as a mix
 // of insert / shuffle / predict commands chosen to exercise the decoder rather than to compress.
@@ -404,7 +481,7 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   w.put(0, 1);  // all_default
   w.put((uint32_t)p.frame_type, 2);
   w.put(modular ? 1 : 0, 1);
-  WriteU64(w, ((!modular && p.skip_lf_smoothing) ? 0x80 : 0) | (p.noise ? 1 : 0));
+  WriteU64(w, ((!modular && p.skip_lf_smoothing) ? 0x80 : 0) | (p.noise ? 1 : 0) | (g_patches.empty() ? 0 : 2) | (g_splines.empty() ? 0 : 16));
   if (!xyb) w.put(0, 1);  // do_YCbCr
   const uint32_t ups_sel = p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : p.upsampling == 8 ? 3 : 0;
   w.put(ups_sel, 2);      // upsampling
@@ -829,6 +906,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   std::vector<BitWriter> sections;
   {  // LfGlobal
     BitWriter s;
+    WriteFeatures(s);                                                             // patch dictionary, splines
     if (p.noise) for (int i = 0; i < 8; i++) s.put(p.noise_lut[i] & 1023, 10);   // NoiseParams
     s.put(1, 1);  // LfChannelDequantization all_default
     WriteU32(s, global_scale, {11, 1}, {11, 2049}, {12, 4097}, {16, 8193});
@@ -1067,6 +1145,7 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
   std::vector<BitWriter> sections;
   {
     BitWriter s;
+    WriteFeatures(s);
     s.put(1, 1);  // LfChannelDequantization default
     s.put(1, 1);  // has_tree
     WriteEntropyCode(s, tree_code);
@@ -1130,6 +1209,10 @@ void jxlsynth_free(uint8_t* p) { free(p); }
 void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::SyntheticImage(seed, w, h, rgb); }
 // ICC profile embedded by the image headers written from now on in this thread (size 0: none, enumerated colour encoding)
 void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
+// patch dictionary / splines of the frames written from now on in this thread (see WriteFeatures; n = 0 clears)
+void jxlsynth_set_features(const int32_t* patches, size_t npatch, const int32_t* splines, size_t nspline, int num_extra) {
+  synth::g_patches.assign(patches, patches + npatch); synth::g_splines.assign(splines, splines + nspline); synth::g_feature_extra = num_extra;
+}
 
 static int finish(const std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
   *out = (uint8_t*)malloc(v.size());
