@@ -176,6 +176,7 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
     if (!p.modular) {
       for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
       if (p.has_global_tree && (p.tree_code.use_prefix || p.tree_code.lz77)) throw ParseError("unsupported: prefix-coded / LZ77 LF streams of a VarDCT frame", true);
+      if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
       if (p.max_prop >= 16) throw ParseError("unsupported: previous-channel MA properties in a VarDCT frame", true);
       if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
     }
@@ -754,6 +755,15 @@ void Batch::Prepare(void* stream_v) {
   prepared_ = true;
 }
 
+// JXL_HIP_DEBUG_SYNC=1: name every stage on stderr and wait for it (finding the kernel behind a device fault)
+static void DebugSync(const char* what, void* stream) {
+  static const bool on = getenv("JXL_HIP_DEBUG_SYNC") != nullptr;
+  if (!on) return;
+  fprintf(stderr, "[jxl-hip] %s ...", what); fflush(stderr);
+  const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  fprintf(stderr, " %s\n", hipGetErrorString(e)); fflush(stderr);
+}
+
 void Batch::Run(void* stream_v) { RunPart(stream_v, 0, false); }
 
 // Everything Modular after the entropy decode of the global stream: the LfGroup / PassGroup sub-streams, then the
@@ -1147,11 +1157,15 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   };
   if (do_front) {
     rec(0);
+    DebugSync("start", stream_v);
     if (any_modchan_) LaunchModularGlobal(dframes_, n, cfg, stream_v);   // Modular frames; extra channels of VarDCT frames
+    DebugSync("modular global", stream_v);
     cfg.lf_head_start = part == 1;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
+    DebugSync("LF decode", stream_v);
     rec(1);
     if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, max_groups_, stream_v);
+    DebugSync("LF post", stream_v);
     if (part == 1) rec(2);
   }
   if (!any_vardct_) {
@@ -1171,17 +1185,21 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     ClearCoefficientsBeforeHf(stream_v);
     rec(split ? 7 : 2);
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
+    DebugSync("HF decode", stream_v);
     if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
     rec(3);
   }
   if (do_tail) {
     if (split) rec(8);                        // the tail may sit on another stream than the HF stage: its own start mark
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
+    DebugSync("IDCT", stream_v);
     rec(4);
     LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
+    DebugSync("filters", stream_v);
     rec(5);
     LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     if (any_complex_) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
+    DebugSync("output / frame tail", stream_v);
     rec(6);
     ClearCoefficientsAfterDecode(stream_v);   // (the IDCT kernels zeroed what they read)
     if (timed && split) timed_rest_cursor_++;
@@ -1301,6 +1319,7 @@ vec<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
   for (size_t c = 0; c < ncomp; c++) for (int k = 0; k < 64; k++) a.qt[c][k] = jd.quant[jd.components[c].quant_idx].values[k];
   a.out = dcoef;
   LaunchJpegCoefficients(dframes_, u, a, p.bw, p.bh, stream_v);
+  DebugSync("JPEG coefficients", stream_v);
   vec<int16_t> host(ncomp * nblk * 64);
   hipError_t err = hipMemcpyAsync(host.data(), dcoef, host.size() * sizeof(int16_t), hipMemcpyDeviceToHost, stream);
   if (err == hipSuccess) err = hipStreamSynchronize(stream);

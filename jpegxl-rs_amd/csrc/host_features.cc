@@ -168,7 +168,8 @@ void BuildSplineDrawList(const FrameFeatures& f, float y_to_x, float y_to_b, uin
       const long long y0 = std::llround(pt.first.y - maximum_distance), y1 = std::llround(pt.first.y + maximum_distance) + 1;
       for (long long y = std::max<long long>(y0, 0); y < y1 && y < (long long)height; y++) by_y.push_back({(uint32_t)y, (uint32_t)out->segments.size()});
       out->segments.push_back(seg);
-      if (by_y.size() > (1u << 28)) throw ParseError("splines cover too large an area", false);
+      // (row, segment) pairs: bounded by the frame, like splines.cc bounds the estimated area the segments may touch
+      if (by_y.size() > ((size_t)height << 14) + (1u << 20)) throw ParseError("splines cover too large an area", false);
     }
   }
   std::sort(by_y.begin(), by_y.end());

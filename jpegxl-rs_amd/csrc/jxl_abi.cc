@@ -276,6 +276,11 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
             if (!e.unsupported) throw;
             SetLastError(std::string(e.what()) + " (decoding to pixels instead)");
             d->jpeg_available = false;
+            // the batch was prepared for the JPEG path (output format, buffers): start over for the pixel decode
+            struct Holder { Batch* b; ~Holder() { DeleteBatch(b); } } hold{NewBatch(d->device)};
+            hold.b->AddImage(d->input, d->input_size);
+            DeleteBatch(d->batch);
+            d->batch = hold.b; hold.b = nullptr;
           }
         }
         if (d->jpeg_available) {

@@ -912,3 +912,44 @@ def test_synthetic_patches_and_splines(jx, name):
     check_against_oracle(jx, data, np.uint8, nch)
     check_against_oracle(jx, data, np.float32, nch)
     check_against_oracle(jx, data, np.uint16, 3)
+
+
+def test_corrupted_feature_streams_fail_cleanly_or_decode(jx):
+    """Same robustness bar as test_corrupted_streams_fail_cleanly_or_decode for what round 2 added: the two real-encoder fixtures
+    (patches, splines, noise, AFV, prefix codes), multi-frame / patch / spline synth streams, free-running Modular streams with
+    LZ77, local trees, weighted predictor, delta palettes, an embedded ICC profile, and the JPEG reconstruction path."""
+    from free_cases import FREE_CASES
+    rng = np.random.default_rng(321)
+    feats = _feature_streams()
+    streams = [fixture_bytes("sample_grey.jxl"), fixture_bytes("2bit.jxl"), feats["patches_splines_noise"], feats["patches_alpha_modes"], feats["patches_modular"]]
+    for name in ("gray_alpha_16bit_everything", "lz77_local_trees", "palette_delta_wp_sections", "previous_channel_properties_groups", "local_tree_everywhere"):
+        streams.append(S.encode_modular_free(**dict(FREE_CASES[name], bits=16)))
+    outcomes = {"error": 0, "decoded": 0}
+    for data in streams:
+        for trial in range(16):
+            bad = bytearray(data)
+            for pos in rng.integers(12, len(bad), 1 + trial % 3):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if trial % 8 == 7:
+                bad = bad[: int(rng.integers(len(bad) // 2, len(bad)))]
+            try:
+                meta, px = jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+                assert len(px) == meta.width * meta.height * (meta.num_color_channels + (1 if meta.has_alpha_channel else 0))
+                outcomes["decoded"] += 1
+            except jx.DecodeError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 0 and outcomes["error"] + outcomes["decoded"] == 16 * len(streams)
+    # JPEG reconstruction with a damaged jbrd box / codestream: JPEG bytes, pixels or an error
+    data = fixture_bytes("sample_jpg.jxl")
+    for trial in range(24):
+        bad = bytearray(data)
+        for pos in rng.integers(40, len(bad), 1 + trial % 2):
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            meta, (kind, val) = jx.decoder_builder().reconstruct(bytes(bad))
+            assert kind in ("jpeg", "pixels") and len(val) > 0
+        except jx.DecodeError:
+            pass
+    check_against_oracle(jx, fixture_bytes("sample_grey.jxl"), np.uint8, 3)
+    meta, (kind, val) = jx.decoder_builder().reconstruct(data)
+    assert kind == "jpeg" and val == open(os.path.join(FIXTURES, "sample.jpg"), "rb").read()
