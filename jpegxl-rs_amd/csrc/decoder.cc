@@ -123,7 +123,7 @@ static void FillColor(const ImageHeader& ih, bool do_ycbcr, FrameDev& f) {
 }
 
 Batch::Batch(int device) : device_(device) {
-  HIP_CHECK(hipSetDevice(device_));
+  if (device_ >= 0) HIP_CHECK(hipSetDevice(device_));      // (-1: host-side parsing only, JxlHipDebugDescribe)
 }
 Batch::~Batch() {
   if (clear_stream_) { (void)hipStreamSynchronize((hipStream_t)clear_stream_); (void)hipStreamDestroy((hipStream_t)clear_stream_); }

@@ -56,6 +56,8 @@ class Batch {
   int AddImage(const uint8_t* data, size_t size);
   size_t size() const { return pub_.size(); }
   ImageEntry& image(int i) { return *images_[pub_[i].first_unit]; }
+  int num_units() const { return (int)images_.size(); }          // frames of all images, in decode order
+  const ImageEntry& unit(int i) const { return *images_[i]; }
   static size_t OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t* channels);
   static uint32_t OrientedWidth(const ImageHeader& ih, const OutputSpec& o);
   static uint32_t OrientedHeight(const ImageHeader& ih, const OutputSpec& o);

@@ -410,6 +410,32 @@ int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, 
   } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
 }
 
+// Host-only (no GPU): parses the container, the image header and every frame header / TOC / LfGlobal / local Modular stream the host
+// side handles, and writes a one-line-per-frame description into `out` (NUL-terminated, truncated to cap).  Returns 0, or 1 with
+// JxlHipLastError() set when the file is rejected — the host half of AddImage, for tests and triage without a device.
+int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap) {
+  try {
+    Batch b(-1);
+    b.AddImage(data, size);
+    std::string s;
+    char line[512];
+    const ImageHeader& ih = b.image(0).ih;
+    snprintf(line, sizeof line, "image %ux%u bits=%u extra=%zu xyb=%d gray=%d icc=%zu frames=%d\n", ih.xsize, ih.ysize, ih.depth.bits, ih.extra.size(), (int)ih.xyb_encoded,
+             (int)(ih.color_space == 1), ih.icc.size(), b.num_units());
+    s += line;
+    for (int i = 0; i < b.num_units(); i++) {
+      const FramePlan& p = b.unit(i).plan;
+      snprintf(line, sizeof line, "frame %d %s type=%u %ux%u at (%d,%d) groups=%u lf_groups=%u passes=%u upsampling=%u patches=%zu splines=%zu noise=%d blend=%u last=%d "
+               "tree_nodes=%zu max_prop=%d wp=%d prefix=%d lz77=%d local_streams=%zu transforms=%zu sections=%zu\n", i, p.modular ? "modular" : "vardct", p.frame_type, p.width, p.height,
+               p.x0, p.y0, p.num_groups, p.num_lf_groups, p.num_passes, p.upsampling, p.feat.patches.size(), p.feat.splines.size(), (int)p.feat.has_noise, p.blend.mode, (int)p.is_last,
+               p.tree.nodes.size(), p.max_prop, (int)p.tree.uses_wp, (int)p.tree_code.use_prefix, (int)p.tree_code.lz77, p.local_streams.size(), p.gtransforms.size(), p.sections.size());
+      s += line;
+    }
+    if (out && cap) { const size_t n = std::min(cap - 1, s.size()); memcpy(out, s.data(), n); out[n] = 0; }
+    return 0;
+  } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
+}
+
 size_t JxlHipLibraryQuantTable(int kind, int c, float* out, size_t cap) {
   try {
     if (kind < 0 || kind >= 17 || c < 0 || c >= 3) return 0;

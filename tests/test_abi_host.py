@@ -345,3 +345,99 @@ def test_embedded_icc_profile_round_trip(jx):
         except jx.DecodeError:
             bad += 1
     assert bad >= 20
+
+
+def _describe(jx, data):
+    import ctypes as C
+    L = jx.libjxl()
+    L.JxlHipDebugDescribe.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(1 << 16)
+    if L.JxlHipDebugDescribe(data, len(data), buf, len(buf)):
+        raise jx.GenericError(jx.last_error())
+    lines = buf.value.decode().strip().split("\n")
+    rows = []
+    for l in lines:
+        kv = dict(t.split("=") for t in l.split() if "=" in t)
+        kv["kind"] = l.split()[0] + (" " + l.split()[2] if l.startswith("frame") else "")
+        kv["raw"] = l
+        rows.append(kv)
+    return rows
+
+
+def test_host_parser_on_fixtures_and_synthetic_streams(jx):
+    """The host half of the decode (container, image header, frame headers, TOC, LfGlobal incl. patches / splines / noise, local
+    Modular streams, embedded ICC) runs without a GPU through JxlHipDebugDescribe: what it finds in the reference's fixtures and
+    in the synthesiser's streams is checked here, so that parser regressions show up in the CPU suite."""
+    import numpy as np
+    import synth_lib as S
+    from conftest import fixture_bytes
+    from free_cases import FREE_CASES
+    d = _describe(jx, fixture_bytes("sample_grey.jxl"))
+    assert d[0]["frames"] == "2" and d[0]["gray"] == "1" and d[0]["xyb"] == "1"
+    assert d[1]["kind"] == "frame modular" and d[1]["type"] == "2" and d[2]["kind"] == "frame vardct" and d[2]["patches"] == "1"
+    d = _describe(jx, fixture_bytes("2bit.jxl"))
+    assert d[0]["bits"] == "2" and d[1]["splines"] == "28" and d[1]["prefix"] == "1" and d[1]["kind"] == "frame modular"
+    d = _describe(jx, fixture_bytes("bench.jxl"))
+    assert d[1]["groups"] == "54" and d[1]["tree_nodes"] == "6643" and d[1]["wp"] == "1" and d[1]["sections"] == "58"
+    d = _describe(jx, fixture_bytes("sample_jpg.jxl"))
+    assert d[1]["kind"] == "frame vardct" and d[0]["xyb"] == "0"
+    for name, kw in FREE_CASES.items():
+        kw = dict(kw); kw.setdefault("bits", 16)
+        d = _describe(jx, S.encode_modular_free(**kw))
+        f = d[1]
+        groups = int(f["groups"])
+        if kw.get("local_trees") == 2:
+            assert int(f["local_streams"]) == (1 + groups if groups > 1 else 1) and f["tree_nodes"] == "0", name
+        elif kw.get("local_trees") == 1:
+            assert int(f["local_streams"]) == (groups if groups > 1 else 0), name
+        else:
+            assert f["local_streams"] == "0", name
+        assert (f["lz77"] == "1") == bool(kw.get("lz77")) or kw.get("local_trees") == 2, name
+        if name.startswith("previous_channel_properties"):
+            assert int(f["max_prop"]) >= 16, name
+        assert int(f["transforms"]) == (1 if kw.get("palette") else 0), name
+    # multi-frame stream with crop + blending, noise
+    img = S.synthetic_image(5, 200, 136)
+    small = S.synthetic_image(9, 64, 48)
+    two = S.encode_vardct_frame(img, S.frame(is_last=0, save_as_reference=1), seed=3) + \
+        S.encode_vardct_frame(small, S.frame(emit=1, have_crop=1, crop_x0=40, crop_y0=30, canvas_w=200, canvas_h=136, blend_mode=2, blend_source=1, noise_lut=[100] * 8), seed=4)
+    d = _describe(jx, two)
+    assert d[0]["frames"] == "2" and "at (40,30)" in d[2]["raw"] and d[2]["blend"] == "2" and d[2]["noise"] == "1" and d[2]["last"] == "1"
+    # rejected inputs say why
+    with pytest.raises(jx.GenericError, match="truncated|unsupported|corrupt|signature|header"):
+        _describe(jx, fixture_bytes("bench.jxl")[:1000])
+
+
+def test_host_parser_survives_corrupted_input(jx):
+    """Memory safety of the host half: a few thousand single- and multi-bit corruptions and truncations of every kind of stream
+    (fixtures incl. the jbrd container, multi-frame / feature streams, free-running Modular streams with local trees and LZ77,
+    an embedded ICC profile) must end in a description or a clean rejection."""
+    import numpy as np
+    import synth_lib as S
+    from conftest import fixture_bytes
+    from free_cases import FREE_CASES
+    from PIL import ImageCms
+    rng = np.random.default_rng(99)
+    streams = [fixture_bytes(n) for n in ("sample.jxl", "sample_grey.jxl", "2bit.jxl", "sample_jpg.jxl")]
+    streams += [S.encode_modular_free(**dict(FREE_CASES[n], bits=16)) for n in ("lz77_local_trees", "local_tree_single_group", "palette_delta_gradient", "previous_channel_properties_global")]
+    S.set_icc(ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes())
+    try:
+        streams.append(S.encode_vardct(S.synthetic_image(3, 64, 48), seed=1))
+    finally:
+        S.set_icc(b"")
+    streams.append(S.encode_vardct(S.synthetic_image(4, 300, 280), seed=2, strategy_mix=2, num_passes=3, permute_toc=3))
+    accepted = rejected = 0
+    for data in streams:
+        for trial in range(300):
+            bad = bytearray(data)
+            hi = len(bad) if trial % 3 else min(len(bad), 300)
+            for pos in rng.integers(2, hi, 1 + trial % 4):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if trial % 10 == 9:
+                bad = bad[: int(rng.integers(8, len(bad)))]
+            try:
+                _describe(jx, bytes(bad))
+                accepted += 1
+            except jx.GenericError:
+                rejected += 1
+    assert accepted > 100 and rejected > 100

@@ -916,7 +916,7 @@ def test_synthetic_patches_and_splines(jx, name):
 
 def test_corrupted_feature_streams_fail_cleanly_or_decode(jx):
     """Same robustness bar as test_corrupted_streams_fail_cleanly_or_decode for what round 2 added: the two real-encoder fixtures
-    (patches, splines, noise, AFV, prefix codes), multi-frame / patch / spline synth streams, free-running Modular streams with
+    (patches, splines, AFV, prefix codes), multi-frame / patch / spline synth streams, free-running Modular streams with
     LZ77, local trees, weighted predictor, delta palettes, an embedded ICC profile, and the JPEG reconstruction path."""
     from free_cases import FREE_CASES
     rng = np.random.default_rng(321)

@@ -55,7 +55,7 @@ struct TreeGen {
   }
   // random subtree; `ranges` = the interval each property is known to lie in on this path (dec_ma.cc rejects splits outside it)
   int Random(int depth, std::vector<Range> ranges, int w, int h) {
-    if (depth <= 0 || rng.next() % 5 == 0) return Leaf(RandPred());
+    if (depth <= 0 || (depth < p.tree_depth && rng.next() % 5 == 0)) return Leaf(RandPred());   // (never a leaf at the root of a random subtree)
     std::vector<int> props = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14};
     if (p.tree_flags & 1) { props.push_back(15); props.push_back(15); }
     if (p.tree_flags & 2) for (int k = 16; k < 24; k++) props.push_back(k);
