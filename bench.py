@@ -366,6 +366,17 @@ def main():
             "stage_gbs": {k: round(stage_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2) if stage_ms[k] > 0 else None for k in stage_ms},
             "device_bytes": sum(bt.device_bytes for bt in batches),
         }
+        if world == 1:
+            # practical HBM ceiling next to the spec peak: a device-to-device copy of 4 GiB, read + write counted
+            a = torch.empty(1 << 30, dtype=torch.int32, device=dev); bcopy = torch.empty_like(a)
+            bcopy.copy_(a); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                bcopy.copy_(a)
+            e1.record(); torch.cuda.synchronize()
+            result["roofline"]["measured_copy_gbs"] = round(5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del a, bcopy
         if cpu is not None:
             result["cpu_baseline"] = cpu
         if not args.no_verify:

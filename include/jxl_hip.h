@@ -93,6 +93,10 @@ JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* dec, JxlColorP
 JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* dec, float desired_intensity_target);                         /* decode.rs:921 */
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size);              /* decode.rs:1100 */
 JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* dec, const JxlPixelFormat* format, void* buffer, size_t size);        /* decode.rs:1123 */
+/* Pixel output through a callback instead of a buffer (decode.rs:289-309, :1172): called once per row (x = 0, num_pixels = xsize) from
+ * the thread inside JxlDecoderProcessInput after the image has been decoded; the row memory is only valid during the call. */
+typedef void (*JxlImageOutCallback)(void* opaque, size_t x, size_t y, size_t num_pixels, const void* pixels);
+JxlDecoderStatus JxlDecoderSetImageOutCallback(JxlDecoder* dec, const JxlPixelFormat* format, JxlImageOutCallback callback, void* opaque);   /* decode.rs:1172 */
 JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* dec, uint8_t* data, size_t size);        /* decode.rs:1283 */
 size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* dec);                                          /* decode.rs:1305 */
 

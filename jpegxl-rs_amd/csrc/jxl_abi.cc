@@ -25,6 +25,7 @@ struct JxlDecoderStruct {
   JxlParallelRunner runner; void* runner_opaque;
   const uint8_t* input; size_t input_size; bool input_set, input_closed;
   void* out_buffer; size_t out_size; JxlPixelFormat out_format; bool out_set;
+  JxlImageOutCallback out_callback; void* out_callback_opaque;   // alternative to out_buffer (rows are handed out after the decode)
   uint8_t* jpeg_buffer; size_t jpeg_size; bool jpeg_set;
   bool jpeg_available; size_t jpeg_written; vec<uint8_t> jpeg_bytes;   // JPEG bit-stream reconstruction (jbrd)
   // progress
@@ -51,7 +52,7 @@ static void ClearState(JxlDecoder* d) {
   d->desired_intensity_target = 0;
   d->runner = nullptr; d->runner_opaque = nullptr;
   d->input = nullptr; d->input_size = 0; d->input_set = d->input_closed = false;
-  d->out_buffer = nullptr; d->out_size = 0; d->out_set = false;
+  d->out_buffer = nullptr; d->out_size = 0; d->out_set = false; d->out_callback = nullptr; d->out_callback_opaque = nullptr;
   d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
@@ -181,12 +182,22 @@ JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixe
 }
 JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat* format, void* buffer, size_t size) {
   if (!d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_ERROR;
+  if (d->out_callback) { SetLastError("an output callback is already set"); return JXL_DEC_ERROR; }
   OutputSpec o;
   if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
   if (o.num_channels != 0 && o.num_channels < 3 && d->batch->image(0).ih.color_space != 1) { SetLastError("number of channels is too low for colour output"); return JXL_DEC_ERROR; }
   o.keep_orientation = d->keep_orientation;
   if (size < Batch::OutputSize(d->batch->image(0).ih, o)) return JXL_DEC_ERROR;
   d->out_buffer = buffer; d->out_size = size; d->out_format = *format; d->out_set = true;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetImageOutCallback(JxlDecoder* d, const JxlPixelFormat* format, JxlImageOutCallback callback, void* opaque) {
+  if (!d || !format || !callback || !d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_ERROR;
+  if (d->out_set) { SetLastError("an output buffer or callback is already set"); return JXL_DEC_ERROR; }
+  size_t need = 0;
+  if (JxlDecoderImageOutBufferSize(d, format, &need) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  d->out_format = *format; d->out_buffer = nullptr; d->out_size = need; d->out_set = true;
+  d->out_callback = callback; d->out_callback_opaque = opaque;
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* d, uint8_t* data, size_t size) {
@@ -301,7 +312,15 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       d->batch->Prepare(nullptr);
       d->batch->Run(nullptr);       // ══► the HIP hot path
       d->batch->Finish(nullptr);
-      d->batch->CopyOutputToHost(0, d->out_buffer, d->batch->image(0).out_size, nullptr);
+      if (d->out_callback) {
+        // callback output: the image is decoded as a whole on the device, then handed out row by row
+        vec<uint8_t> host(d->batch->image(0).out_size);
+        d->batch->CopyOutputToHost(0, host.data(), host.size(), nullptr);
+        JxlBasicInfo info;
+        FillBasicInfo(d->batch->image(0).ih, &info, d->keep_orientation);
+        const size_t stride = d->batch->image(0).out_stride;
+        for (size_t y = 0; y < info.ysize; y++) d->out_callback(d->out_callback_opaque, 0, y, info.xsize, host.data() + y * stride);
+      } else d->batch->CopyOutputToHost(0, d->out_buffer, d->batch->image(0).out_size, nullptr);
       d->stage = JxlDecoderStruct::kDone;
       d->events_emitted |= JXL_DEC_FULL_IMAGE;
       return JXL_DEC_FULL_IMAGE;

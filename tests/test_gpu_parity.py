@@ -953,3 +953,41 @@ def test_corrupted_feature_streams_fail_cleanly_or_decode(jx):
     check_against_oracle(jx, fixture_bytes("sample_grey.jxl"), np.uint8, 3)
     meta, (kind, val) = jx.decoder_builder().reconstruct(data)
     assert kind == "jpeg" and val == open(os.path.join(FIXTURES, "sample.jpg"), "rb").read()
+
+
+def test_image_out_callback(jx):
+    """jpegxl-sys decode.rs:289-309, :1172 JxlDecoderSetImageOutCallback: rows arrive through the callback (x = 0, one row each, in
+    order) and add up to the same pixels as the buffer API; a buffer and a callback exclude each other."""
+    L = jx.libjxl()
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p)
+    L.JxlDecoderSetImageOutCallback.restype = C.c_int
+    L.JxlDecoderSetImageOutCallback.argtypes = [C.c_void_p, C.c_void_p, CB, C.c_void_p]
+    data = S.encode_vardct(S.synthetic_image(12, 300, 200), seed=3, strategy_mix=2)
+    buf = np.frombuffer(data, np.uint8)
+    rows = {}
+
+    def cb(opaque, x, y, n, pixels):
+        assert x == 0 and y not in rows
+        rows[y] = np.ctypeslib.as_array(C.cast(pixels, C.POINTER(C.c_uint16)), shape=(n * 3,)).copy()
+    cbf = CB(cb)
+    dec = L.JxlDecoderCreate(None)
+    assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_FULL_IMAGE) == 0
+    assert L.JxlDecoderSetInput(dec, buf.ctypes.data, len(buf)) == 0
+    L.JxlDecoderCloseInput(dec)
+    fmt = jx.JxlPixelFormat(3, jx.JXL_TYPE_UINT16, jx.JXL_NATIVE_ENDIAN, 0)
+    events = []
+    while True:
+        st = L.JxlDecoderProcessInput(dec)
+        events.append(st)
+        if st == jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+            assert L.JxlDecoderSetImageOutCallback(dec, C.byref(fmt), cbf, None) == 0
+            dummy = np.zeros(16, np.uint8)
+            assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), dummy.ctypes.data, 16) == 1      # already set
+        elif st in (jx.JXL_DEC_SUCCESS, jx.JXL_DEC_ERROR):
+            break
+    assert events[-1] == jx.JXL_DEC_SUCCESS, jx.last_error()
+    L.JxlDecoderDestroy(dec)
+    ref = O.decode(data)
+    want = ref.pixels("u16", 3).view(np.uint16)
+    got = np.concatenate([rows[y] for y in range(len(rows))])
+    assert len(rows) == 200 and np.array_equal(got, want)
