@@ -55,6 +55,10 @@ struct Frame {
   FrameHeader fh;
   // geometry
   int w = 0, h = 0, bw = 0, bh = 0;  // pixels, 8x8 blocks
+  // chroma subsampling (frame_header.h YCbCrChromaSubsampling): channel c lives on a grid of (bw >> hs[c]) x (bh >> vs[c]) blocks, kept
+  // in the top-left corner of the full-size LF / coefficient / pixel arrays
+  int hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0};
+  bool subsampled = false;
   // LfGlobal
   float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
   uint32_t global_scale = 1, quant_lf = 1;
@@ -237,9 +241,25 @@ inline void ReadLfGroup(BitReader& br, Frame& f, int g) {
     uint32_t extra_precision = br.u(2);
     ModularImage img;
     img.bitdepth = 16;
-    for (int c = 0; c < 3; c++) img.channel.emplace_back(gbw, gbh);
+    static const int kChanOfStream[3] = {1, 0, 2};        // the stream's channels are Y, X, B
+    for (int i = 0; i < 3; i++) img.channel.emplace_back(gbw >> f.hs[kChanOfStream[i]], gbh >> f.vs[kChanOfStream[i]]);   // (dec_modular.cc DecodeVarDCTDC)
     img.w = gbw; img.h = gbh;
     ModularDecode(br, img, 1 + g, &f.gtree, 0, true, &f.tokens_lf);
+    if (f.subsampled) {
+      // compressed_dc.cc DequantDC, the branch without chroma-from-luma: every channel on its own grid
+      const float mul = 1.0f / (float)(1 << extra_precision);
+      const float inv_quant_lf = InvGlobalScale(f) / (float)f.quant_lf;
+      for (int i = 0; i < 3; i++) {
+        const int c = kChanOfStream[i];
+        const float fac = (f.m_lf[c] * inv_quant_lf) * mul;
+        const Channel& ch = img.channel[i];
+        for (int y = 0; y < ch.h; y++) for (int x = 0; x < ch.w; x++) {
+          const size_t o = (size_t)((by0 >> f.vs[c]) + y) * f.bw + (bx0 >> f.hs[c]) + x;
+          f.lfq[c][o] = ch.row(y)[x];
+          f.lf.p[c].d[o] = (float)ch.row(y)[x] * fac;
+        }
+      }
+    } else {
     // dequant: compressed_dc.cc DequantDC; modular channel order is Y, X, B
     const float mul = 1.0f / (float)(1 << extra_precision);
     const float inv_quant_lf = InvGlobalScale(f) / (float)f.quant_lf;
@@ -261,6 +281,7 @@ inline void ReadLfGroup(BitReader& br, Frame& f, int g) {
         f.lf.p[0].d[o] = std::fmaf(vy, cfl_x, vx);
         f.lf.p[2].d[o] = std::fmaf(vy, cfl_b, vb);
       }
+    }
     }
   }
   // ModularLfGroup
@@ -445,17 +466,28 @@ inline void ReadPassGroup(BitReader& br, Frame& f, int pass_idx, int g) {
         int lf_idx = 0;
         if (f.bcm.num_lf_ctxs > 1) {
           int bX = 0, bY = 0, bB = 0;
-          for (int32_t t : f.bcm.lf_thresholds[0]) if (f.lfq[0][o] > t) bX++;
-          for (int32_t t : f.bcm.lf_thresholds[1]) if (f.lfq[1][o] > t) bY++;
-          for (int32_t t : f.bcm.lf_thresholds[2]) if (f.lfq[2][o] > t) bB++;
+          auto at = [&](int c) { return f.lfq[c][(size_t)((by0 + by) >> f.vs[c]) * f.bw + ((bx0 + bx) >> f.hs[c])]; };   // (quant_dc is kept at full resolution)
+          for (int32_t t : f.bcm.lf_thresholds[0]) if (at(0) > t) bX++;
+          for (int32_t t : f.bcm.lf_thresholds[1]) if (at(1) > t) bY++;
+          for (int32_t t : f.bcm.lf_thresholds[2]) if (at(2) > t) bB++;
           lf_idx = (bX * ((int)f.bcm.lf_thresholds[2].size() + 1) + bB) * ((int)f.bcm.lf_thresholds[1].size() + 1) + bY;
         }
         static const int chan_order[3] = {1, 0, 2};
         for (int ci = 0; ci < 3; ci++) {
           const int c = chan_order[ci];
+          // dec_group.cc: a subsampled channel only has a block where the block starts one of its cells; its "non-zeros"
+          // neighbourhood lives on its own grid
+          const int sbx = bx >> f.hs[c], sby = by >> f.vs[c];
+          if ((sbx << f.hs[c]) != bx || (sby << f.vs[c]) != by) continue;
+          if (f.subsampled && s != 0) JXLO_FAIL("unsupported: chroma subsampling with a transform other than DCT8");
           const int block_ctx = f.bcm.Context(lf_idx, (uint32_t)f.hf_mul[o], ord, c);
           // predicted nzeros
           int pred;
+          if (f.subsampled) {
+            if (sbx == 0) pred = sby == 0 ? 32 : nzmap[c][(sby - 1) * 32 + sbx];
+            else if (sby == 0) pred = nzmap[c][sby * 32 + sbx - 1];
+            else pred = (nzmap[c][(sby - 1) * 32 + sbx] + nzmap[c][sby * 32 + sbx - 1] + 1) / 2;
+          } else
           if (bx == 0) pred = by == 0 ? 32 : nzmap[c][(by - 1) * 32 + bx];
           else if (by == 0) pred = nzmap[c][by * 32 + bx - 1];
           else pred = (nzmap[c][(by - 1) * 32 + bx] + nzmap[c][by * 32 + bx - 1] + 1) / 2;
@@ -464,7 +496,8 @@ inline void ReadPassGroup(BitReader& br, Frame& f, int pass_idx, int g) {
           uint32_t nzeros = sr.Read(br, (int)nz_ctx);
           if (nzeros + covered > (uint32_t)size) JXLO_FAIL("nzeros too large");
           uint8_t nzm = (uint8_t)((nzeros + covered - 1) >> log2cov);
-          for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzmap[c][(by + iy) * 32 + bx + ix] = nzm;
+          if (f.subsampled) nzmap[c][sby * 32 + sbx] = nzm;
+          else for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzmap[c][(by + iy) * 32 + bx + ix] = nzm;
           const size_t histo_offset = ctx_offset + (size_t)37 * nctx + (size_t)458 * block_ctx;
           const std::vector<uint32_t>& order = ps.order[ord * 3 + c];
           int32_t* blk = f.coeffs[c][g].data() + offset;
@@ -529,6 +562,23 @@ inline void DequantAndIDCT(Frame& f) {
       const int kind = kQuantKind[s];
       const float sd = inv_gs / (float)f.hf_mul[o];
       const float sdc[3] = {sd * x_dm, sd, sd * b_dm};
+      if (f.subsampled) {
+        // every channel on its own grid, 8x8 DCT only, no chroma-from-luma (JPEG transcodes never carry any)
+        const size_t tile = (size_t)((by0 + by) / 8) * f.cw + (bx0 + bx) / 8;
+        if (f.base_x != 0.f || f.base_b != 0.f || f.ytox_map[tile] != 0 || f.ytob_map[tile] != 0) JXLO_FAIL("unsupported: chroma from luma in a chroma-subsampled frame");
+        for (int c = 0; c < 3; c++) {
+          const int sbx = (bx0 + bx) >> f.hs[c], sby = (by0 + by) >> f.vs[c];
+          if ((sbx << f.hs[c]) != bx0 + bx || (sby << f.vs[c]) != by0 + by) continue;
+          blk[c].assign(size, 0.f);
+          const std::vector<float>& table = EnsureQuantTable(f, kind, c);
+          const int32_t* q = f.coeffs[c][g].data() + offset;
+          for (int k = 0; k < size; k++) blk[c][k] = AdjustQuantBias(c, q[k], m.quant_bias) * (table[k] * sdc[c]);
+          LowestFrequenciesFromLF(s, &f.lf.p[c].d[(size_t)sby * f.bw + sbx], f.bw, blk[c].data());
+          InverseTransform(s, blk[c].data(), f.xyb.p[c].row(sby * 8) + sbx * 8, f.xyb.p[c].w);
+        }
+        offset += size;
+        continue;
+      }
       for (int c = 0; c < 3; c++) {
         blk[c].assign(size, 0.f);
         const std::vector<float>& table = EnsureQuantTable(f, kind, c);
@@ -550,6 +600,50 @@ inline void DequantAndIDCT(Frame& f) {
       }
       offset += size;
     }
+  }
+}
+
+// stage_chroma_upsampling.cc: horizontal, then vertical 2x upsampling of a subsampled channel with the (1/4, 3/4) kernel,
+// out[2x] = 0.25 in[x-1] + 0.75 in[x], out[2x+1] = 0.25 in[x+1] + 0.75 in[x], neighbours mirrored at the channel's own edges
+// (the channel covers ceil(size / 2) samples of the image) [R]
+inline void UpsampleChroma(Frame& f) {
+  for (int c = 0; c < 3; c++) {
+    if (f.hs[c] == 0 && f.vs[c] == 0) continue;
+    int cw = (f.w + (1 << f.hs[c]) - 1) >> f.hs[c], ch = (f.h + (1 << f.vs[c]) - 1) >> f.vs[c];
+    Plane cur(cw, ch);
+    for (int y = 0; y < ch; y++) memcpy(cur.row(y), f.xyb.p[c].row(y), sizeof(float) * cw);
+    if (f.hs[c]) {
+      Plane out(2 * cw, ch);
+      for (int y = 0; y < ch; y++) {
+        const float* in = cur.row(y);
+        float* o = out.row(y);
+        for (int x = 0; x < cw; x++) {
+          const float mid = in[x] * 0.75f, prev = in[x ? x - 1 : 0], next = in[x + 1 < cw ? x + 1 : cw - 1];
+          o[2 * x] = std::fmaf(0.25f, prev, mid);
+          o[2 * x + 1] = std::fmaf(0.25f, next, mid);
+        }
+      }
+      cur = out; cw *= 2;
+    }
+    if (f.vs[c]) {
+      Plane out(cw, 2 * ch);
+      for (int y = 0; y < ch; y++) {
+        const float* in = cur.row(y);
+        const float* up = cur.row(y ? y - 1 : 0);
+        const float* down = cur.row(y + 1 < ch ? y + 1 : ch - 1);
+        float* o0 = out.row(2 * y);
+        float* o1 = out.row(2 * y + 1);
+        for (int x = 0; x < cw; x++) {
+          const float mid = in[x] * 0.75f;
+          o0[x] = std::fmaf(0.25f, up[x], mid);
+          o1[x] = std::fmaf(0.25f, down[x], mid);
+        }
+      }
+      cur = out; ch *= 2;
+    }
+    Plane full(f.bw * 8, f.bh * 8);
+    for (int y = 0; y < std::min(ch, f.bh * 8); y++) memcpy(full.row(y), cur.row(y), sizeof(float) * std::min(cw, f.bw * 8));
+    f.xyb.p[c] = full;
   }
 }
 

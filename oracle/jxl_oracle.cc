@@ -34,6 +34,15 @@ void InitFrame(Frame& f, const ImageMetadata& m) {
   f.m = &m;
   f.w = (int)f.fh.width; f.h = (int)f.fh.height;
   f.bw = (f.w + 7) / 8; f.bh = (f.h + 7) / 8;
+  if (f.fh.do_ycbcr && !f.fh.modular) {
+    // frame_header.h YCbCrChromaSubsampling: sampling-factor modes per channel -> shifts relative to the largest factor; the block
+    // grid is padded to whole cells of the coarsest channel (frame_dimensions: xsize_blocks = DivCeil(xsize, 8 << maxhs) << maxhs)
+    static const int kH[4] = {0, 1, 1, 0}, kV[4] = {0, 1, 0, 1};
+    int maxhs = 0, maxvs = 0;
+    for (int c = 0; c < 3; c++) { maxhs = std::max(maxhs, kH[f.fh.jpeg_upsampling[c]]); maxvs = std::max(maxvs, kV[f.fh.jpeg_upsampling[c]]); }
+    for (int c = 0; c < 3; c++) { f.hs[c] = maxhs - kH[f.fh.jpeg_upsampling[c]]; f.vs[c] = maxvs - kV[f.fh.jpeg_upsampling[c]]; f.subsampled |= f.hs[c] || f.vs[c]; }
+    f.bw = ((f.w + (8 << maxhs) - 1) / (8 << maxhs)) << maxhs; f.bh = ((f.h + (8 << maxvs) - 1) / (8 << maxvs)) << maxvs;
+  }
   f.cw = (f.bw + 7) / 8; f.chh = (f.bh + 7) / 8;
   if (!f.fh.modular) {
     size_t nb = (size_t)f.bw * f.bh;
@@ -169,8 +178,11 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
       else if (up == 4) up_weights = kDefaultUp4Weights;
       else up_weights = kDefaultUp8Weights;
     }
-    if (fh.do_ycbcr) for (int i = 0; i < 3; i++) if (fh.jpeg_upsampling[i]) JXLO_FAIL("unsupported: chroma subsampling");
     InitFrame(f, m);
+    if (f.subsampled) {
+      if (!(fh.flags & kSkipAdaptiveLFSmoothing) || fh.lf.gab || fh.lf.epf_iters || fh.upsampling != 1 || fh.passes.num_passes != 1)
+        JXLO_FAIL("unsupported: chroma subsampling together with LF smoothing / restoration filters / upsampling / passes");
+    }
     f.dump = want_dump ? &out.dump : nullptr;
     DecodeFrameSections(cs.data(), cs.size(), br, f);
     out.tokens_lf += f.tokens_lf; out.tokens_hf += f.tokens_hf; out.tokens_modular += f.tokens_modular;
@@ -206,6 +218,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
         for (size_t i = 0; i < f.ytox_map.size(); i++) { cf.push_back(f.ytox_map[i]); cf.push_back(f.ytob_map[i]); }
       }
       DequantAndIDCT(f);
+      if (f.subsampled) UpsampleChroma(f);
       if (want_dump) StorePlanes(out.dump, "idct", f.xyb);
       img = CropImage(f.xyb, cw_, ch_);
       if (fh.lf.epf_iters > 0) ComputeInvSigma(fh.lf, (float)f.global_scale / 65536.0f, f.hf_mul, f.sharpness, f.bw, f.bh, inv_sigma);

@@ -197,3 +197,20 @@ def set_features(patches=None, splines=None, num_extra=0):
     pa = (C.c_int32 * max(1, len(pf)))(*pf)
     sa = (C.c_int32 * max(1, len(sf)))(*sf)
     L.jxlsynth_set_features(pa, len(pf), sa, len(sf), num_extra)
+
+
+SUBSAMPLING = {"444": (0, 0, 0), "420": (0, 1, 0), "422": (0, 2, 0), "440": (0, 3, 0), "mixed": (2, 1, 0)}
+
+
+def encode_ycbcr(rgb, subsampling="420", seed=1, distance=1.0):
+    """YCbCr VarDCT frame with chroma subsampling (tools/synth_ycbcr.h): rgb (h,w,3) uint8; subsampling a key of SUBSAMPLING or a
+    (Cb, Y, Cr) tuple of sampling-factor modes (0 = 1x1, 1 = 2x2, 2 = 2x1, 3 = 1x2)."""
+    L = lib()
+    L.jxlsynth_ycbcr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_uint32, C.c_float, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    h, w = rgb.shape[:2]
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    modes = (C.c_int32 * 3)(*(SUBSAMPLING[subsampling] if isinstance(subsampling, str) else subsampling))
+    out = C.c_void_p(); n = C.c_size_t()
+    if L.jxlsynth_ycbcr(a.ctypes.data, w, h, modes, seed, distance, C.byref(out), C.byref(n)):
+        raise RuntimeError(L.jxlsynth_last_error().decode())
+    return _take(out, n)

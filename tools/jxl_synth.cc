@@ -97,6 +97,7 @@ struct Params {
   int num_extra_hdr = -1;                         // extra channels announced by the image header (-1: as the frame has)
   int alpha_premultiplied = 0;                    // image header: alpha_associated
   int xyb_image = 0;                              // Modular frames: the image is XYB encoded (samples are Y, X, B - Y scaled by the LF factors)
+  int do_ycbcr = 0; int jpeg_upsampling[3] = {0, 0, 0};   // non-XYB VarDCT frames: YCbCr with per-channel sampling-factor modes (tools/synth_ycbcr.h)
 };
 
 // ---- modular sub-stream tokenisation with the fixed global tree --------------------------------------------------
@@ -482,7 +483,10 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   w.put((uint32_t)p.frame_type, 2);
   w.put(modular ? 1 : 0, 1);
   WriteU64(w, ((!modular && p.skip_lf_smoothing) ? 0x80 : 0) | (p.noise ? 1 : 0) | (g_patches.empty() ? 0 : 2) | (g_splines.empty() ? 0 : 16));
-  if (!xyb) w.put(0, 1);  // do_YCbCr
+  if (!xyb) {
+    w.put(p.do_ycbcr ? 1 : 0, 1);
+    if (p.do_ycbcr) for (int c = 0; c < 3; c++) w.put((uint32_t)p.jpeg_upsampling[c], 2);   // YCbCrChromaSubsampling, channels Cb, Y, Cr
+  }
   const uint32_t ups_sel = p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : p.upsampling == 8 ? 3 : 0;
   w.put(ups_sel, 2);      // upsampling
   for (int i = 0; i < num_extra; i++) w.put(ups_sel, 2);   // ec_upsampling: same factor
@@ -1197,6 +1201,7 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
 }  // namespace synth
 
 #include "synth_free.h"
+#include "synth_ycbcr.h"
 
 // ---- C API ---------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -1311,6 +1316,14 @@ int jxlsynth_modular(const int32_t* const* planes, int nchan, int has_alpha, int
   catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// YCbCr VarDCT frame with chroma subsampling (tools/synth_ycbcr.h); modes = sampling-factor modes of Cb, Y, Cr (0 1x1, 1 2x2, 2 2x1, 3 1x2)
+int jxlsynth_ycbcr(const uint8_t* rgb8, int w, int h, const int32_t* modes, uint32_t seed, float distance, uint8_t** out, size_t* n) {
+  try {
+    synth::Params p; p.seed = seed; p.distance = distance;
+    const int m[3] = {modes[0], modes[1], modes[2]};
+    return finish(synth::EncodeYCbCr(rgb8, w, h, m, p), out, n);
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 // Free-running Modular stream (tools/synth_free.h): feature coverage without an encoder-side simulation of the decoder.
 struct jxlsynth_free_params { uint32_t seed; int w, h, nchan, has_alpha, bits, tree_flags, tree_depth, local_trees, lz77, palette, nb_colors, nb_deltas, pal_pred; };
 int jxlsynth_modular_free(const jxlsynth_free_params* pp, uint8_t** out, size_t* n) {
