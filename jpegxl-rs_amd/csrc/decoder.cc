@@ -177,6 +177,7 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
       for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
       if (p.has_global_tree && (p.tree_code.use_prefix || p.tree_code.lz77)) throw ParseError("unsupported: prefix-coded / LZ77 LF streams of a VarDCT frame", true);
       if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
+      if (p.subsampled && (p.base_x != 0.f || p.base_b != 0.f)) throw ParseError("unsupported: chroma from luma in a chroma-subsampled frame", true);
       if (p.max_prop >= 16) throw ParseError("unsupported: previous-channel MA properties in a VarDCT frame", true);
       if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
     }
@@ -196,6 +197,7 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
     if ((p.flags & (1 | 2 | 16)) || p.have_crop || !replace_all || p.frame_type != 0) complex = true;
     if (p.modular && ih.xyb_encoded) complex = true;      // XYB Modular frames go through the float planes
     if (p.modular && p.upsampling != 1) complex = true;
+    if (p.subsampled) complex = true;                     // chroma planes are upsampled in the frame tail
   }
   if (complex && ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels in a multi-frame / feature image", true);
   for (auto& u : units) u->complex = complex;
@@ -532,6 +534,8 @@ void Batch::Prepare(void* stream_v) {
     }
     f.uses_wp = p.tree.uses_wp; f.gwp = p.gwp;
     f.tree_max_prop = (uint32_t)p.tree.max_prop;
+    for (int k = 0; k < 3; k++) { f.hs[k] = p.hs[k]; f.vs[k] = p.vs[k]; }
+    f.subsampled = p.subsampled;
     if (!c.local.empty()) {
       // descriptor table of the frame's units (0 = global stream), zero = "uses the frame's tree"
       ModLocalDev* table = &local_host_[local_first_[i]];
@@ -705,7 +709,7 @@ void Batch::Prepare(void* stream_v) {
   }
   {  // LDS right-sizing for the decode kernels
     auto code_bytes = [](const HostCode& c, bool ctx) { return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
-    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0; cfg.any_local_trees = 0;
+    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0; cfg.any_local_trees = 0; cfg.any_subsampled = 0;
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
       if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); cfg.any_wp |= p.tree.uses_wp ? 1 : 0; }
@@ -714,6 +718,7 @@ void Batch::Prepare(void* stream_v) {
         if (ls.unit != 0) cfg.any_local_trees = 1;
       }
       if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
+      if (p.subsampled) cfg.any_subsampled = 1;
     }
     if (getenv("JXL_HIP_DEBUG_LDS")) fprintf(stderr, "[jxl-hip] LDS sizing: tree nodes %d, modular code %d B, AC code %d B, BlockCtxDev %zu B\n", cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.ac_code_bytes, sizeof(BlockCtxDev));
   }
@@ -752,6 +757,7 @@ void Batch::Prepare(void* stream_v) {
   HIP_CHECK(hipMemcpyAsync(dlocal_, local_host_.data(), sizeof(ModLocalDev) * local_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
+  if (cfg.any_subsampled) cfg.lane_stride_hf = 1;   // so do chroma-subsampled frames (per-channel block grids)
   prepared_ = true;
 }
 
@@ -909,6 +915,17 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
       size_t cur[3]; uint32_t cur_stride = p.bw * 8;
       for (int c = 0; c < 3; c++) cur[c] = (nstages & 1) ? cb.pb[c] : cb.pa[c];
       size_t cur_ec[4] = {0, 0, 0, 0}; uint32_t cur_ec_stride = cw;
+      if (p.subsampled) {
+        // the subsampled channels sit in the top-left corner of their planes: bring them to full resolution (plane b)
+        for (int c = 0; c < 3; c++) {
+          if (!p.hs[c] && !p.vs[c]) continue;
+          if (cb.pb[c] == (size_t)-1) throw ParseError("chroma upsampling needs the second plane set", false);
+          const size_t src = cur[c], dst = cb.pb[c];
+          const uint32_t ccw = (cw + (1u << p.hs[c]) - 1) >> p.hs[c], cch = (ch + (1u << p.vs[c]) - 1) >> p.vs[c], chs = p.hs[c], cvs = p.vs[c];
+          post_ops_.push_back([=](void* st) { LaunchChromaUpsample(B(src), cur_stride, B(dst), cur_stride, ccw, cch, chs, cvs, cw, ch, st); });
+          cur[c] = dst;
+        }
+      }
       if (p.modular) {
         const uint32_t bits = ih.depth.bits;
         if (ih.xyb_encoded) {
@@ -1273,6 +1290,7 @@ bool Batch::CanReconstructJpeg(int i, std::string* why) {
   const FramePlan& p = e.plan;
   if (pi.num_units != 1 || pi.complex || p.modular || e.ih.xyb_encoded || !p.do_ycbcr && e.ih.color_space != 1) return no("not a plain JPEG-transcoded frame");
   if (p.upsampling != 1 || p.num_passes != 1 || !e.ih.extra.empty()) return no("not a plain JPEG-transcoded frame");
+  if (p.subsampled) return no("unsupported: JPEG reconstruction of chroma-subsampled frames");
   if (jpeg_data_.size() < pub_.size()) jpeg_data_.resize(pub_.size());
   if (!jpeg_data_[i]) {
     std::unique_ptr<JpegData> jd(new JpegData());

@@ -766,8 +766,7 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     p->flags = r.U64();
     if (!xyb) p->do_ycbcr = r.b();
     const bool use_lf_frame = (p->flags & 32) != 0;
-    uint32_t jpeg_ups[3] = {0, 0, 0};
-    if (p->do_ycbcr && !use_lf_frame) for (int i = 0; i < 3; i++) jpeg_ups[i] = r.u(2);
+    if (p->do_ycbcr && !use_lf_frame) for (int i = 0; i < 3; i++) p->jpeg_upsampling[i] = r.u(2);
     if (!use_lf_frame) {
       p->upsampling = r.U32({0, 1}, {0, 2}, {0, 4}, {0, 8});
       for (auto& e : ec_ups) e = r.U32({0, 1}, {0, 2}, {0, 4}, {0, 8});
@@ -832,7 +831,6 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     r.SkipExtensions();
     if (p->frame_type == 1 || use_lf_frame) Unsupported("LF frame");
     for (auto e : ec_ups) if (e != p->upsampling) Unsupported("extra-channel upsampling different from the colour upsampling");
-    for (int i = 0; i < 3; i++) if (jpeg_ups[i]) Unsupported("chroma subsampling");
     (void)lf_level;
   }
   p->frame_w = fx; p->frame_h = fy;
@@ -847,6 +845,17 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   p->xlfgroups = (fx + p->group_dim * 8 - 1) / (p->group_dim * 8); p->ylfgroups = (fy + p->group_dim * 8 - 1) / (p->group_dim * 8);
   p->num_lf_groups = p->xlfgroups * p->ylfgroups;
   p->bw = (fx + 7) / 8; p->bh = (fy + 7) / 8;
+  if (p->do_ycbcr && !p->modular) {
+    static const uint32_t kH[4] = {0, 1, 1, 0}, kV[4] = {0, 1, 0, 1};
+    uint32_t maxhs = 0, maxvs = 0;
+    for (int c = 0; c < 3; c++) { maxhs = std::max(maxhs, kH[p->jpeg_upsampling[c]]); maxvs = std::max(maxvs, kV[p->jpeg_upsampling[c]]); }
+    for (int c = 0; c < 3; c++) { p->hs[c] = maxhs - kH[p->jpeg_upsampling[c]]; p->vs[c] = maxvs - kV[p->jpeg_upsampling[c]]; p->subsampled |= p->hs[c] || p->vs[c]; }
+    if (p->subsampled) {
+      p->bw = ((fx + (8u << maxhs) - 1) / (8u << maxhs)) << maxhs; p->bh = ((fy + (8u << maxvs) - 1) / (8u << maxvs)) << maxvs;
+      if (!(p->flags & 128) || p->lf.gab || p->lf.epf_iters || p->upsampling != 1 || p->num_passes != 1)
+        Unsupported("chroma subsampling together with LF smoothing / restoration filters / upsampling / progressive passes");
+    }
+  } else if (p->do_ycbcr) for (int c = 0; c < 3; c++) if (p->jpeg_upsampling[c]) Unsupported("chroma subsampling in a Modular frame");
   // ---- TOC
   p->single_section = p->num_groups == 1 && p->num_passes == 1;
   size_t n = p->single_section ? 1 : 1 + p->num_lf_groups + 1 + (size_t)p->num_groups * p->num_passes;

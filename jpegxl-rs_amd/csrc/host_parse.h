@@ -132,6 +132,10 @@ struct FramePlan {
   uint32_t width = 0, height = 0, group_dim = 256;
   uint32_t xgroups = 0, ygroups = 0, num_groups = 0, xlfgroups = 0, ylfgroups = 0, num_lf_groups = 0;
   uint32_t bw = 0, bh = 0;  // 8x8 blocks
+  // chroma subsampling of YCbCr frames (frame_header.h YCbCrChromaSubsampling): sampling-factor mode per channel (Cb, Y, Cr) and the
+  // shifts relative to the largest factor; bw / bh are padded to whole cells of the coarsest channel
+  uint32_t jpeg_upsampling[3] = {0, 0, 0}, hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0};
+  bool subsampled = false;
   // TOC
   vec<Section> sections;   // byte offsets into the codestream buffer
   bool single_section = false;

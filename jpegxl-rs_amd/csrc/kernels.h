@@ -35,6 +35,9 @@ struct FrameDev {
   DevCode mod_code;
   uint32_t uses_wp;
   WPHeader gwp;
+  // chroma subsampling (YCbCr JPEG transcodes): channel c lives on a grid of (bw >> hs[c]) x (bh >> vs[c]) blocks, packed into the
+  // top-left corner of the frame-sized LF / pixel planes; coefficients keep the offsets of the full-resolution block a cell starts at
+  uint32_t hs[3], vs[3], subsampled;
   uint32_t tree_max_prop;         // largest property index in any MA tree of the frame (>= 16: previous-channel properties)
   const ModLocalDev* mod_local;   // Modular sub-streams with a tree and code of their own, indexed 0 = global stream, 1 + unit = LfGroup /
                                   // PassGroup unit (entries with tree == nullptr use the frame's tree); nullptr: none in this frame
@@ -113,6 +116,7 @@ struct LaunchCfg {
   int lane_stride_hf = 64;
   int lane_stride_mod = 64;
   int any_wp = 0;            // some MA tree of the batch uses the weighted predictor (the Modular kernels then reserve LDS for its state)
+  int any_subsampled = 0;    // some frame is chroma-subsampled (its own IDCT kernel; the SIMT HF kernel only)
   int any_local_trees = 0;   // some Modular sub-stream carries its own MA tree / code (second launch of the group kernel)
   // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
   int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;
@@ -148,6 +152,7 @@ void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups,
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);
 void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, size_t n, void* stream);
+void LaunchChromaUpsample(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t cw, uint32_t ch, uint32_t hs, uint32_t vs, uint32_t out_w, uint32_t out_h, void* stream);
 void LaunchModPaletteDelta(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, uint32_t nb_deltas, uint32_t predictor,
                            uint32_t w, uint32_t h, const WPHeader& wp, int32_t* wp_scratch, uint32_t wp_stride, void* stream);
 void LaunchModOutput(const FrameDev* frames, int fidx, const ModOutputArgs& a, int w, int h, void* stream);

@@ -1209,8 +1209,9 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     const int chan_to_plane[3] = {1, 0, 2};  // stream channel order is Y, X, B
     for (int c = 0; c < 3; c++) {
       ChannelDesc ch;
-      ch.data = f.lfq[chan_to_plane[c]] + (size_t)by0 * f.bw + bx0;
-      ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)f.bw;
+      const int pl = chan_to_plane[c];       // (subsampled channels: their own, smaller grid — dec_modular.cc DecodeVarDCTDC)
+      ch.data = f.lfq[pl] + (size_t)(by0 >> f.vs[pl]) * f.bw + (bx0 >> f.hs[pl]);
+      ch.w = (int)(gbw >> f.hs[pl]); ch.h = (int)(gbh >> f.vs[pl]); ch.stride = (int)f.bw;
       DecodeChannelCoop(br, state, T, mc, ch, c);
     }
   }
@@ -1252,6 +1253,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     const uint32_t y = i / mcw, x = i % mcw;
     const int a = m_ytox[i], b = m_ytob[i];
     if (a < -128 || a > 127 || b < -128 || b > 127) { SetError(f, kErrBadValue); s_fail = 1; }
+    if (f.subsampled && (a | b)) { SetError(f, kErrUnsupported); s_fail = 1; }      // chroma from luma across different block grids
     const size_t o = (size_t)(gy * 32 + y) * f.cw + gx * 32 + x;
     f.ytox[o] = (int8_t)a; f.ytob[o] = (int8_t)b;
   }
@@ -1306,6 +1308,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
         const uint32_t s = (uint32_t)sq.x, q = (uint32_t)sq.y;
         if (num0 + count >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
         if (s >= 27 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }       // (negative values wrap to large ones)
+        if (f.subsampled && s != 0) { SetError(f, kErrUnsupported); bad = true; break; }   // chroma-subsampled frames: 8x8 DCT only
         const uint32_t geo = LdS<uint32_t>(geo_off + s * 4), cx = geo & 0xFF, cy = (geo >> 8) & 0xFF;
         if (x + cx > gbw || y + cy > gbh || xb + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
         const uint32_t bits = (cx == 32 ? ~0u : (1u << cx) - 1u) << xb;
@@ -1351,7 +1354,8 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
       for (uint32_t i = 0; i < bcm.n_qf_thr; i++) qf_idx += q + 1 > bcm.qf_thr[i];
       uint32_t lf_idx = 0;
       if (bcm.num_lf_ctxs > 1) {
-        const int32_t q0 = LdG(f.lfq[0] + o), q1 = LdG(f.lfq[1] + o), q2 = LdG(f.lfq[2] + o);
+        auto lfq_at = [&](int c) { return LdG(f.lfq[c] + (size_t)((by0 + y) >> f.vs[c]) * f.bw + ((bx0 + x) >> f.hs[c])); };   // (quant_dc is kept at full resolution)
+        const int32_t q0 = lfq_at(0), q1 = lfq_at(1), q2 = lfq_at(2);
         uint32_t b0 = 0, b1 = 0, b2 = 0;
         for (uint32_t i = 0; i < bcm.n_lf_thr[0]; i++) b0 += q0 > bcm.lf_thr[0][i];
         for (uint32_t i = 0; i < bcm.n_lf_thr[1]; i++) b1 += q1 > bcm.lf_thr[1][i];
@@ -1421,6 +1425,17 @@ __global__ void LfDequantKernel(const FrameDev* __restrict__ frames) {
   if (f.is_modular) return;
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= f.bw || y >= f.bh) return;
+  if (f.subsampled) {
+    // compressed_dc.cc DequantDC without chroma-from-luma: every channel on its own grid (packed top-left in the planes)
+    for (int c = 0; c < 3; c++) {
+      if (x >= (f.bw >> f.hs[c]) || y >= (f.bh >> f.vs[c])) continue;
+      const uint32_t gc = ((y << f.vs[c]) / 256) * f.xlfgroups + (x << f.hs[c]) / 256;
+      const float mulc = 1.0f / (float)(1 << f.lf_scratch[(uint64_t)gc * f.lf_scratch_stride]);
+      const size_t oc = (size_t)y * f.bw + x;
+      f.lf[c][oc] = (float)f.lfq[c][oc] * (f.lf_fac[c] * mulc);
+    }
+    return;
+  }
   const uint32_t g = (y / 256) * f.xlfgroups + x / 256;
   const int32_t extra_precision = f.lf_scratch[(uint64_t)g * f.lf_scratch_stride];
   const float mul = 1.0f / (float)(1 << extra_precision);
@@ -1825,6 +1840,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
   const uint32_t gbase = gsafe * 65536u;
   uint32_t vi = 0;
   uint2 ent_next = nvb ? LdG(vbl) : make_uint2(0, 0);
+  const uint32_t sub_pack = f.hs[0] | (f.vs[0] << 1) | (f.hs[1] << 2) | (f.vs[1] << 3) | (f.hs[2] << 4) | (f.vs[2] << 5);   // chroma subsampling shifts (0 / 1)
   uint32_t phase = 0;                     // 0: start next varblock, 1: read nzeros, 2: read a coefficient
   uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, lcx = 0, coff = 0, qlf = 0;
   uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, nz_total = 0;
@@ -1857,20 +1873,27 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
       }
     } else if (!done) {
       const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
+      // chroma-subsampled frames (dec_group.cc): a channel has a block only where the block starts one of its cells, and its
+      // "non-zeros" neighbourhood lives on its own grid (nbx / nby)
+      const uint32_t hsc = (sub_pack >> (2 * c)) & 1u, vsc = (sub_pack >> (2 * c + 1)) & 1u;
+      const uint32_t nbx = bx >> hsc, nby = by >> vsc;
       // coefficient position after the current one: requested before the token is decoded, as the aligned 32-bit word that
       // holds it (the 16-bit field is only extracted where it is used, so nothing waits for the load up here)
       uint32_t ctx, fetched = 0, fetched_sh = 0;
       auto fetch_pos = [&](uint32_t kk) { fetched = LdG(reinterpret_cast<const uint32_t*>(order + (kk & ~1u))); fetched_sh = (kk & 1u) << 4; };
+      // the next varblock's list entry is requested while the last channel of this one is decoded (the old entry is dead
+      // by now, so the load lands in its registers and nothing waits for it before the next block start)
+      if (phase == 1 && ci == 2 && vi < nvb) ent_next = LdG(vbl + vi);
+      if (phase == 1 && ((bx & hsc) | (by & vsc)) != 0) {
+        ci++; phase = ci == 3 ? 0 : 1;             // this channel has no block here
+      } else {
       if (phase == 1) {
-        // the next varblock's list entry is requested while the last channel of this one is decoded (the old entry is dead
-        // by now, so the load lands in its registers and nothing waits for it before the next block start)
-        if (ci == 2 && vi < nvb) ent_next = LdG(vbl + vi);
         order = reinterpret_cast<const uint16_t*>((uintptr_t)LdS<uint64_t>(kSimtOrdOff + (ord * 3 + c) * 8));
         fetch_pos(covered);
         const uint32_t idx = ((uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord) * qlf_stride + qlf;
         const uint32_t block_ctx = LdS<uint8_t>(oMap + idx);
-        const uint32_t top = LdS<uint8_t>(nz_base + c * 32 + bx), left = bx ? LdS<uint8_t>(nz_base + c * 32 + bx - 1) : 0;
-        const uint32_t pred = bx == 0 ? (by == 0 ? 32 : top) : by == 0 ? left : (top + left + 1) / 2;
+        const uint32_t top = LdS<uint8_t>(nz_base + c * 32 + nbx), left = nbx ? LdS<uint8_t>(nz_base + c * 32 + nbx - 1) : 0;
+        const uint32_t pred = nbx == 0 ? (nby == 0 ? 32 : top) : nby == 0 ? left : (top + left + 1) / 2;
         const uint32_t pc = pred > 64 ? 64 : pred;
         ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
         histo = ctx_offset + 37 * nctx + 458 * block_ctx;
@@ -1887,15 +1910,15 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
         {  // the varblock's columns of the "non-zeros above" row: one masked read-modify-write of the aligned 8 bytes that
            // hold them (varblocks of up to 8 columns sit on multiples of their width); wider or unaligned ones byte by byte
-          const uint32_t cxw = 1u << lcx, sh = (bx & 7) * 8;
-          if ((bx & 7) + cxw <= 8) {
-            const uint32_t a8 = nz_base + c * 32 + (bx & ~7u);
+          const uint32_t cxw = 1u << lcx, sh = (nbx & 7) * 8;
+          if ((nbx & 7) + cxw <= 8) {
+            const uint32_t a8 = nz_base + c * 32 + (nbx & ~7u);
             const uint64_t mask = (cxw == 8 ? ~0ull : ((1ull << (8 * cxw)) - 1ull)) << sh;
             const uint64_t val = (uint64_t)nzm * 0x0101010101010101ull;
             const uint64_t old = LdS<uint64_t>(a8);
             StS<uint64_t>(a8, (old & ~mask) | (val & mask));
           } else {
-            for (uint32_t ix = 0; ix < cxw; ix++) StS<uint8_t>(nz_base + c * 32 + bx + ix, (uint8_t)nzm);
+            for (uint32_t ix = 0; ix < cxw; ix++) StS<uint8_t>(nz_base + c * 32 + nbx + ix, (uint8_t)nzm);
           }
         }
         blk = (c == 0 ? cbase0 : c == 1 ? cbase1 : cbase2) + coff;
@@ -1917,6 +1940,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         if (nzeros != 0 && k >= size) { err = kErrNzeros; done = true; }
       }
       if (phase == 2 && nzeros == 0) { ci++; phase = ci == 3 ? 0 : 1; }
+      }
     }
   }
   if (err) { SetError(f, err); dead = true; }
@@ -2158,7 +2182,7 @@ __device__ __forceinline__ uint32_t Log2Cov8(uint32_t n) { return n == 1 ? 0u : 
 
 __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ frames, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || ((*f.frame_flags & 1) == 0 && !force_generic)) return;   // regular frames take IdctTileKernel
+  if (f.is_modular || f.subsampled || ((*f.frame_flags & 1) == 0 && !force_generic)) return;   // regular frames take IdctTileKernel
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
@@ -2298,7 +2322,7 @@ __device__ __forceinline__ int Log2Cov(int n) { return n == 1 ? 0 : n == 2 ? 1 :
 
 __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || (*f.frame_flags & 2) == 0) return;
+  if (f.is_modular || f.subsampled || (*f.frame_flags & 2) == 0) return;
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   extern __shared__ __align__(16) float s_big[];
@@ -2378,13 +2402,50 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
   }
 }
 
+// ---- chroma-subsampled frames (YCbCr JPEG transcodes; dec_group.cc with !Is444()): 8x8 DCT only, no chroma-from-luma, every channel on
+// its own block grid.  One thread per (block, channel) of a 256x256 group; a channel takes part in a block only where the block starts
+// one of its cells, and writes its 8x8 pixels at the cell's position of the packed (top-left) subsampled plane; the chroma planes are
+// brought to full resolution afterwards (ChromaUpsampleKernel).  Same arithmetic as the 8x8 path of IdctKernel (rows, then columns).
+__global__ __launch_bounds__(256) void IdctSubsampledKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular || !f.subsampled) return;
+  const uint32_t g = blockIdx.x;
+  if (g >= f.num_groups) return;
+  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
+  const uint32_t bx0 = gx * 32, by0 = gy * 32;
+  const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
+  const size_t stride = f.plane_stride;
+  for (uint32_t t = threadIdx.x; t < gbw * gbh * 3; t += blockDim.x) {
+    const uint32_t c = t / (gbw * gbh), bi = t - c * gbw * gbh;
+    const uint32_t X = bx0 + bi % gbw, Y = by0 + bi / gbw;
+    if ((X & ((1u << f.hs[c]) - 1u)) | (Y & ((1u << f.vs[c]) - 1u))) continue;
+    const size_t o = (size_t)Y * f.bw + X;
+    const uint32_t info = LdG(f.blk_info + o);
+    if (BI_Strategy(info) != 0) continue;                      // (rejected by the LF stage)
+    int32_t* q = f.coeff[c] + (size_t)g * 65536 + LdG(f.coef_off + o);
+    const float* table = f.qtable[c];                          // kind 0 (DCT8), channel c
+    const float sd = f.inv_global_scale / (float)BI_HfMul(info);
+    const float sdc = c == 0 ? sd * f.x_dm : c == 2 ? sd * f.b_dm : sd;
+    const float bias_c = f.quant_bias[c], bias3 = f.quant_bias[3];
+    float sem[64];
+    for (uint32_t k = 0; k < 64; k++) {
+      const int32_t v = q[k];
+      if (v) q[k] = 0;                                         // consumed: the planes stay clean for the next decode
+      sem[(k & 7) * 8 + (k >> 3)] = AdjustQuantBias(v, bias_c, bias3) * (table[k] * sdc);   // stored layout is the transpose of (v, u)
+    }
+    const uint32_t sx = X >> f.hs[c], sy = Y >> f.vs[c];
+    sem[0] = LdG(f.lf[c] + (size_t)sy * f.bw + sx);            // the lowest frequency of an 8x8 DCT is the LF sample
+    SmallIdct2D<8, 8>(sem, f.plane_a[c] + (size_t)sy * 8 * stride + (size_t)sx * 8, stride);
+  }
+}
+
 // ---- IDENTITY, DCT2X2 and AFV blocks (64 live coefficients per lane) of frames that take the tile kernels: the tile
 // kernel leaves them alone and this kernel, launched after it for the frames the LF stage flagged, writes their pixels.
 // The group's blocks are compacted first so that every lane has a (block, channel) of its own.  Same arithmetic as
 // IdctKernel's special path (DequantCoef + SpecialTransform).
 __global__ __launch_bounds__(256) void IdctRareSpecialKernel(const FrameDev* __restrict__ frames, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || force_generic) return;
+  if (f.is_modular || f.subsampled || force_generic) return;
   const uint32_t flags = *f.frame_flags;
   if ((flags & 1) != 0 || (flags & 16) == 0) return;    // generic frames do their own; no such block in this frame
   const uint32_t g = blockIdx.x;
@@ -2466,7 +2527,7 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
 template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || (*f.frame_flags & 1) != 0 || force_generic) return;
+  if (f.is_modular || f.subsampled || (*f.frame_flags & 1) != 0 || force_generic) return;
   if (((*f.frame_flags & 4) != 0) != (TB == 8)) return;     // frames with a varblock that no 32x32 tile contains take the 64x64 tiles
   if (((*f.frame_flags & 8) != 0) != SPECIAL) return;
   const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -3758,6 +3819,7 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
     if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
   }
+  if (cfg.any_subsampled) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
   if (all || cfg.need_rare_special) hipLaunchKernelGGL(IdctRareSpecialKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only

@@ -323,6 +323,32 @@ __global__ void ColorKernel(ColorArgs a) {
   a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
 }
 
+// ---- chroma upsampling of subsampled YCbCr frames (stage_chroma_upsampling.cc): horizontal, then vertical, each with the (1/4, 3/4)
+// kernel — out[2x] = 0.25 in[x-1] + 0.75 in[x], out[2x+1] = 0.25 in[x+1] + 0.75 in[x] — neighbours clamped at the channel's own edges.
+// One thread per output sample; the vertical step works on horizontally upsampled rows, exactly as two stages would.
+struct ChromaUpArgs { const float* src; float* dst; uint32_t src_stride, dst_stride, cw, ch, hs, vs, out_w, out_h; };
+__global__ void ChromaUpsampleKernel(ChromaUpArgs a) {
+  const uint32_t X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (X >= a.out_w || Y >= a.out_h) return;
+  const uint32_t sx = X >> a.hs, sy = Y >> a.vs;
+  if (sx >= a.cw || sy >= a.ch) return;
+  auto hval = [&](uint32_t row) -> float {
+    const float* in = a.src + (size_t)row * a.src_stride;
+    if (!a.hs) return in[X];
+    const float mid = in[sx] * 0.75f;
+    const uint32_t nb = (X & 1) ? min(sx + 1, a.cw - 1) : (sx ? sx - 1 : 0);
+    return fmaf(0.25f, in[nb], mid);
+  };
+  float v;
+  if (!a.vs) v = hval(sy);
+  else {
+    const float mid = hval(sy) * 0.75f;
+    const uint32_t nb = (Y & 1) ? min(sy + 1, a.ch - 1) : (sy ? sy - 1 : 0);
+    v = fmaf(0.25f, hval(nb), mid);
+  }
+  a.dst[(size_t)Y * a.dst_stride + X] = v;
+}
+
 // ---- blending of a frame onto the image canvas (stage_blending.cc; blending.cc) ----------------------------------------------
 __device__ __forceinline__ float FrameBlendSampleD(uint32_t mode, bool clamp, bool premultiplied, float bg, float fg, float bga, float fga) {
   switch (mode) {
@@ -519,6 +545,11 @@ void LaunchJpegCoefficients(const FrameDev* frames, int fidx, const JpegCoefArgs
 }
 void LaunchCopyPlane(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, void* stream) {
   hipLaunchKernelGGL(CopyPlaneKernel, Grid2(w, h), kBlock2, 0, (hipStream_t)stream, src, src_stride, dst, dst_stride, w, h);
+}
+
+void LaunchChromaUpsample(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t cw, uint32_t ch, uint32_t hs, uint32_t vs, uint32_t out_w, uint32_t out_h, void* stream) {
+  ChromaUpArgs a{src, dst, src_stride, dst_stride, cw, ch, hs, vs, out_w, out_h};
+  hipLaunchKernelGGL(ChromaUpsampleKernel, Grid2(out_w, out_h), kBlock2, 0, (hipStream_t)stream, a);
 }
 
 }  // namespace jxlhip

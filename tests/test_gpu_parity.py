@@ -991,3 +991,20 @@ def test_image_out_callback(jx):
     want = ref.pixels("u16", 3).view(np.uint16)
     got = np.concatenate([rows[y] for y in range(len(rows))])
     assert len(rows) == 200 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("sub", ["420", "422", "440", "mixed", "444"])
+@pytest.mark.parametrize("w,h", [(200, 136), (203, 139), (64, 48), (530, 300), (2100, 270)])
+def test_chroma_subsampled_ycbcr_frames(jx, sub, w, h):
+    """SURVEY row b10 (stage_chroma_upsampling.cc, dec_group.cc with !Is444()): YCbCr VarDCT frames whose chroma (or luma, "mixed")
+    channels live on coarser block grids — what a 4:2:0 / 4:2:2 / 4:4:0 JPEG becomes.  Streams from tools/synth_ycbcr.h (the encoder
+    and the oracle's decoder were written separately and reproduce the source image); the HIP path — per-channel LF grids in the
+    LF kernel, the skip rule and per-channel non-zero contexts in the HF kernel, IdctSubsampledKernel, ChromaUpsampleKernel —
+    must match the oracle bit for bit, odd sizes (padding to whole cells, clamped upsampling taps) and several groups included."""
+    img = S.synthetic_image(60 + w % 7, w, h)
+    data = S.encode_ycbcr(img, sub, seed=w + h, distance=0.7)
+    ref = O.decode(data).image("u8", 3)
+    assert np.abs(ref.astype(int) - img.astype(int)).mean() < 6          # the stream does describe the source image
+    check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.float32, 3)
+    check_against_oracle(jx, data, np.uint16, 4 if False else 3)
