@@ -16,7 +16,8 @@ def streams():
     feats = T._feature_streams()
     img = S.synthetic_image(70, 300, 280)
     out = [fixture_bytes("sample_grey.jxl"), fixture_bytes("2bit.jxl"), feats["patches_splines_noise"], feats["patches_alpha_modes"], feats["patches_modular"],
-           fixture_bytes("sample.jxl"), fixture_bytes("sample_jpg.jxl"), S.encode_vardct(img, seed=2, strategy_mix=2, epf_iters=2, gab=1, num_passes=2), S.encode_vardct(img, seed=2, strategy_mix=4, upsampling=2)]
+           fixture_bytes("sample.jxl"), fixture_bytes("sample_jpg.jxl"), S.encode_vardct(img, seed=2, strategy_mix=2, epf_iters=2, gab=1, num_passes=2), S.encode_vardct(img, seed=2, strategy_mix=4, upsampling=2),
+           S.encode_ycbcr(img, "420", seed=3), S.encode_ycbcr(S.synthetic_image(71, 203, 139), "mixed", seed=4)]
     for name in ("gray_alpha_16bit_everything", "lz77_local_trees", "palette_delta_wp_sections", "previous_channel_properties_groups", "local_tree_everywhere"):
         out.append(S.encode_modular_free(**dict(FREE_CASES[name], bits=16)))
     return out

@@ -924,6 +924,7 @@ def test_corrupted_feature_streams_fail_cleanly_or_decode(jx):
     streams = [fixture_bytes("sample_grey.jxl"), fixture_bytes("2bit.jxl"), feats["patches_splines_noise"], feats["patches_alpha_modes"], feats["patches_modular"]]
     for name in ("gray_alpha_16bit_everything", "lz77_local_trees", "palette_delta_wp_sections", "previous_channel_properties_groups", "local_tree_everywhere"):
         streams.append(S.encode_modular_free(**dict(FREE_CASES[name], bits=16)))
+    streams += [S.encode_ycbcr(S.synthetic_image(70, 300, 280), "420", seed=3), S.encode_ycbcr(S.synthetic_image(71, 203, 139), "mixed", seed=4)]
     outcomes = {"error": 0, "decoded": 0}
     for data in streams:
         for trial in range(16):
