@@ -139,6 +139,10 @@ size_t JxlHipLibraryQuantTable(int kind, int c, float* out, size_t cap);
  * *out_size: capacity in, bytes needed / written out.  Returns 0 on success, 2 if the buffer is too small, 1 on error. */
 int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const int16_t* coefficients, const int32_t* quant_tables,
                          uint8_t* out, size_t* out_size);
+/* Same with JPEG sampling factors: sampling = (h, v) per component (NULL = all 1x1); the component planes follow one another, each
+ * (mcu_rows * v) x (mcu_cols * h) blocks, the MCU grid being ceil(size / (8 * max factor)). */
+int JxlHipDebugWriteJpegSampled(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const uint32_t* sampling, const int16_t* coefficients,
+                                const int32_t* quant_tables, uint8_t* out, size_t* out_size);
 /* Host-only (no GPU): parse everything the host side parses and describe the image / its frames, one line each, into out
    (NUL-terminated, truncated to cap).  0 = accepted, 1 = rejected (JxlHipLastError()). */
 int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap);

@@ -1288,9 +1288,9 @@ bool Batch::CanReconstructJpeg(int i, std::string* why) {
   const ImageEntry& e = *images_[pi.first_unit];
   if (e.shared->jbrd.empty()) return no("no jbrd box");
   const FramePlan& p = e.plan;
-  if (pi.num_units != 1 || pi.complex || p.modular || e.ih.xyb_encoded || !p.do_ycbcr && e.ih.color_space != 1) return no("not a plain JPEG-transcoded frame");
+  if (pi.num_units != 1 || (pi.complex && !p.subsampled) || p.modular || e.ih.xyb_encoded || !p.do_ycbcr && e.ih.color_space != 1) return no("not a plain JPEG-transcoded frame");
   if (p.upsampling != 1 || p.num_passes != 1 || !e.ih.extra.empty()) return no("not a plain JPEG-transcoded frame");
-  if (p.subsampled) return no("unsupported: JPEG reconstruction of chroma-subsampled frames");
+  if (p.subsampled && ((p.flags & (1 | 2 | 16)) || p.have_crop || p.frame_type != 0)) return no("not a plain JPEG-transcoded frame");
   if (jpeg_data_.size() < pub_.size()) jpeg_data_.resize(pub_.size());
   if (!jpeg_data_[i]) {
     std::unique_ptr<JpegData> jd(new JpegData());
@@ -1328,23 +1328,39 @@ vec<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
   // entropy decode only: LF stage (LF coefficients = JPEG DC, block metadata) and HF stage (AC coefficients)
   RunPart(stream_v, 1, false);
   RunPart(stream_v, 3, false);
-  const size_t nblk = (size_t)p.bw * p.bh, ncomp = jd.components.size();
+  const size_t ncomp = jd.components.size();
+  // component planes: the frame's (padded) block grid shifted by the channel's subsampling; sampling factors for the SOF marker from
+  // the frame header (libjxl dec_frame.cc: h_samp_factor = 1 << (max shift - shift), JPEG components Y, Cb, Cr = channels 1, 0, 2)
+  size_t comp_blocks[3] = {0, 0, 0}, comp_first[3] = {0, 0, 0}, nblk = 0;
+  {
+    int max_hs = 0, max_vs = 0;
+    for (int c = 0; c < 3; c++) { max_hs = std::max(max_hs, (int)p.hs[c]); max_vs = std::max(max_vs, (int)p.vs[c]); }
+    for (size_t c = 0; c < ncomp; c++) {
+      const int ch = ncomp == 1 ? 1 : (c == 0 ? 1 : c == 1 ? 0 : 2);
+      jd.components[c].h_samp = 1u << (max_hs - p.hs[ch]);
+      jd.components[c].v_samp = 1u << (max_vs - p.vs[ch]);
+      comp_blocks[c] = (size_t)(p.bw >> p.hs[ch]) * (p.bh >> p.vs[ch]);
+      comp_first[c] = nblk;
+      nblk += comp_blocks[c];
+    }
+  }
   int16_t* dcoef = nullptr;
-  HIP_CHECK(hipMalloc((void**)&dcoef, ncomp * nblk * 64 * sizeof(int16_t)));
+  HIP_CHECK(hipMalloc((void**)&dcoef, nblk * 64 * sizeof(int16_t)));
   JpegCoefArgs a;
   memset(&a, 0, sizeof(a));
   a.ncomp = (uint32_t)ncomp;
+  for (size_t c = 0; c < ncomp; c++) a.comp_off[c] = (uint32_t)comp_first[c];
   for (size_t c = 0; c < ncomp; c++) for (int k = 0; k < 64; k++) a.qt[c][k] = jd.quant[jd.components[c].quant_idx].values[k];
   a.out = dcoef;
   LaunchJpegCoefficients(dframes_, u, a, p.bw, p.bh, stream_v);
   DebugSync("JPEG coefficients", stream_v);
-  vec<int16_t> host(ncomp * nblk * 64);
+  vec<int16_t> host(nblk * 64);
   hipError_t err = hipMemcpyAsync(host.data(), dcoef, host.size() * sizeof(int16_t), hipMemcpyDeviceToHost, stream);
   if (err == hipSuccess) err = hipStreamSynchronize(stream);
   (void)hipFree(dcoef);
   if (err != hipSuccess) throw ParseError(std::string("HIP error: ") + hipGetErrorString(err), false);
   Finish(stream_v);
-  const int16_t* planes[3] = {host.data(), host.data() + (ncomp > 1 ? nblk * 64 : 0), host.data() + (ncomp > 2 ? 2 * nblk * 64 : 0)};
+  const int16_t* planes[3] = {host.data(), host.data() + comp_first[1] * 64, host.data() + comp_first[2] * 64};
   vec<uint8_t> out;
   if (!WriteJpeg(jd, e.ih.xsize, e.ih.ysize, planes, &out, &why)) throw ParseError(why, true);
   return out;

@@ -4,6 +4,7 @@
 // byte-identical to it (tests/test_abi_host.py, tests/test_gpu_parity.py).
 #include "jpeg_recon.h"
 #include <dlfcn.h>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -231,7 +232,10 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
   out->push_back(0xFF); out->push_back(0xD8);
   size_t app_i = 0, com_i = 0, inter_i = 0, dqt_i = 0, dht_i = 0, scan_i = 0, pad_pos = 0;
   HuffTable dc_tab[4], ac_tab[4];
-  const uint32_t bw = (width + 7) / 8, bh = (height + 7) / 8;
+  // component planes: MCU grid x sampling factors (jpeg_data.h JPEGComponent::width_in_blocks / height_in_blocks)
+  uint32_t max_h = 1, max_v = 1;
+  for (auto& c : jd.components) { if (c.h_samp < 1 || c.h_samp > 4 || c.v_samp < 1 || c.v_samp > 4) return fail("bad sampling factor"); max_h = std::max(max_h, c.h_samp); max_v = std::max(max_v, c.v_samp); }
+  const uint32_t mcu_cols = (width + 8 * max_h - 1) / (8 * max_h), mcu_rows = (height + 8 * max_v - 1) / (8 * max_v);
   bool seen_dri = false;
   for (uint8_t m : jd.marker_order) {
     if (m == 0xC0 || m == 0xC1 || m == 0xC2 || m == 0xC9 || m == 0xCA) {
@@ -240,7 +244,7 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
       const uint8_t hdr[9] = {0xFF, m, (uint8_t)(len >> 8), (uint8_t)len, 8, (uint8_t)(height >> 8), (uint8_t)height, (uint8_t)(width >> 8), (uint8_t)width};
       out->insert(out->end(), hdr, hdr + 9);
       out->push_back((uint8_t)n);
-      for (auto& c : jd.components) { out->push_back((uint8_t)c.id); out->push_back((uint8_t)((c.h_samp << 4) | c.v_samp)); out->push_back((uint8_t)c.quant_idx); }
+      for (auto& c : jd.components) { out->push_back((uint8_t)c.id); out->push_back((uint8_t)((c.h_samp << 4) | c.v_samp)); out->push_back((uint8_t)jd.quant[c.quant_idx].index); }
     } else if (m == 0xC4) {
       size_t len = 2, last = dht_i;
       for (size_t i = dht_i; i < jd.huffman_code.size(); i++) { len += 16; for (uint32_t c : jd.huffman_code[i].counts) len += c; last = i; if (jd.huffman_code[i].is_last) break; }
@@ -296,13 +300,22 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
         out->push_back((uint8_t)((s.components[i].dc_tbl_idx << 4) | s.components[i].ac_tbl_idx));
       }
       out->push_back((uint8_t)s.Ss); out->push_back((uint8_t)s.Se); out->push_back((uint8_t)((s.Ah << 4) | s.Al));
-      // ---- entropy-coded segment (EncodeScan, sequential mode; 4:4:4: an MCU is one block of every scan component)
+      // ---- entropy-coded segment (EncodeScan, sequential mode).  Interleaved scans: an MCU holds v_samp x h_samp blocks of every scan
+      // component and the MCU grid covers the padded image; a single-component scan walks that component's own blocks, one per MCU,
+      // over ceil(size * samp / (8 * max_samp)) of them (the blocks that hold image data).
       BitWriter w; w.out = out;
       int last_dc[4] = {0, 0, 0, 0};
       const uint32_t restart_interval = seen_dri ? jd.restart_interval : 0;
       uint32_t restarts_to_go = restart_interval, next_restart = 0, block_scan_index = 0;
       size_t ezr_pos = 0, reset_pos = 0;
-      for (uint32_t my = 0; my < bh; my++) for (uint32_t mx = 0; mx < bw; mx++) {
+      const bool interleaved = s.num_components > 1;
+      uint32_t scan_cols = mcu_cols, scan_rows = mcu_rows;
+      if (!interleaved) {
+        const JpegComponentInfo& c0 = jd.components[s.components[0].comp_idx];
+        scan_cols = (width * c0.h_samp + 8 * max_h - 1) / (8 * max_h);
+        scan_rows = (height * c0.v_samp + 8 * max_v - 1) / (8 * max_v);
+      }
+      for (uint32_t my = 0; my < scan_rows; my++) for (uint32_t mx = 0; mx < scan_cols; mx++) {
         if (restart_interval > 0 && restarts_to_go == 0) {
           if (!w.Pad(jd, &pad_pos)) return fail("padding bits exhausted");
           out->push_back(0xFF); out->push_back((uint8_t)(0xD0 + next_restart));
@@ -312,13 +325,16 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
         }
         for (uint32_t i = 0; i < s.num_components; i++) {
           const JpegScanComponent& sc = s.components[i];
+          const JpegComponentInfo& comp = jd.components[sc.comp_idx];
+          const uint32_t nby = interleaved ? comp.v_samp : 1, nbx = interleaved ? comp.h_samp : 1, comp_bw = mcu_cols * comp.h_samp;
+          for (uint32_t iy = 0; iy < nby; iy++) for (uint32_t ix = 0; ix < nbx; ix++) {
           const HuffTable& dct = dc_tab[sc.dc_tbl_idx & 3];
           const HuffTable& act = ac_tab[sc.ac_tbl_idx & 3];
           if (!dct.init || !act.init) return fail("scan uses an undefined Huffman table");
           if (reset_pos < s.reset_points.size() && s.reset_points[reset_pos] == block_scan_index) reset_pos++;   // (only matters for progressive EOB runs)
           int num_zero_runs = 0;
           if (ezr_pos < s.extra_zero_runs.size() && s.extra_zero_runs[ezr_pos].first == block_scan_index) num_zero_runs = (int)s.extra_zero_runs[ezr_pos++].second;
-          const int16_t* c = coeffs[sc.comp_idx] + ((size_t)my * bw + mx) * 64;
+          const int16_t* c = coeffs[sc.comp_idx] + ((size_t)(my * nby + iy) * comp_bw + (mx * nbx + ix)) * 64;
           // EncodeDCTBlockSequential
           int temp2 = c[0], temp = temp2 - last_dc[sc.comp_idx];
           last_dc[sc.comp_idx] = temp2;
@@ -346,6 +362,7 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
           if (r > 0) w.Symbol(0, act);
           if (!w.ok) return fail("symbol without a Huffman code");
           block_scan_index++;
+          }
         }
         if (restart_interval > 0) restarts_to_go--;
       }

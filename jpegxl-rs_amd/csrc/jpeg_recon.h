@@ -42,7 +42,8 @@ struct JpegData {
 bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err);
 
 // Serialises the JPEG: markers in jbrd order, quantisation tables as filled in by the caller (jd.quant[i].values), entropy-coded
-// scans from the quantised coefficients.  coeffs[c]: blocks_h x blocks_w x 64 int16 in natural order for component c (4:4:4 only).
+// scans from the quantised coefficients.  coeffs[c]: (mcu_rows * v_samp) x (mcu_cols * h_samp) x 64 int16 in natural order for component
+// c, the MCU grid being ceil(size / (8 * max sampling factor)); sampling factors from jd.components (set by the caller from the frame header).
 // Sequential (baseline / extended) scans are supported; progressive scan scripts return false.
 bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, vec<uint8_t>* out, std::string* err);
 

@@ -410,15 +410,27 @@ int JxlHipBatchShareBuffers(JxlHipBatch* h, JxlHipBatch* owner) {
   try { h->b->ShareBigArena(owner ? owner->b : nullptr); return 0; } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
 }
 
-int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const int16_t* coefficients, const int32_t* quant_tables,
-                         uint8_t* out, size_t* out_size) {
+int JxlHipDebugWriteJpegSampled(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const uint32_t* sampling, const int16_t* coefficients,
+                                const int32_t* quant_tables, uint8_t* out, size_t* out_size) {
   try {
     JpegData jd;
     std::string err;
     if (!ParseJbrd(jbrd, jbrd_size, &jd, &err)) { SetLastError(err); return 1; }
-    const size_t nblk = (size_t)((width + 7) / 8) * ((height + 7) / 8), nc = jd.components.size();
-    for (size_t c = 0; c < nc; c++) for (int k = 0; k < 64; k++) jd.quant[jd.components[c].quant_idx].values[k] = quant_tables[c * 64 + k];
-    const int16_t* planes[3] = {coefficients, coefficients + (nc > 1 ? nblk * 64 : 0), coefficients + (nc > 2 ? 2 * nblk * 64 : 0)};
+    const size_t nc = jd.components.size();
+    uint32_t max_h = 1, max_v = 1;
+    for (size_t c = 0; c < nc; c++) {
+      jd.components[c].h_samp = sampling ? sampling[2 * c] : 1; jd.components[c].v_samp = sampling ? sampling[2 * c + 1] : 1;
+      if (jd.components[c].h_samp < 1 || jd.components[c].h_samp > 4 || jd.components[c].v_samp < 1 || jd.components[c].v_samp > 4) { SetLastError("bad sampling factor"); return 1; }
+      max_h = std::max(max_h, jd.components[c].h_samp); max_v = std::max(max_v, jd.components[c].v_samp);
+    }
+    const size_t mcu_cols = (width + 8 * max_h - 1) / (8 * max_h), mcu_rows = (height + 8 * max_v - 1) / (8 * max_v);
+    const int16_t* planes[3] = {coefficients, coefficients, coefficients};
+    size_t first = 0;
+    for (size_t c = 0; c < nc; c++) {
+      for (int k = 0; k < 64; k++) jd.quant[jd.components[c].quant_idx].values[k] = quant_tables[c * 64 + k];
+      planes[c] = coefficients + first * 64;
+      first += mcu_cols * jd.components[c].h_samp * mcu_rows * jd.components[c].v_samp;
+    }
     vec<uint8_t> bytes;
     if (!WriteJpeg(jd, width, height, planes, &bytes, &err)) { SetLastError(err); return 1; }
     const size_t cap = *out_size;
@@ -427,6 +439,10 @@ int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, 
     memcpy(out, bytes.data(), bytes.size());
     return 0;
   } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
+}
+int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const int16_t* coefficients, const int32_t* quant_tables,
+                         uint8_t* out, size_t* out_size) {
+  return JxlHipDebugWriteJpegSampled(jbrd, jbrd_size, width, height, nullptr, coefficients, quant_tables, out, out_size);
 }
 
 // Host-only (no GPU): parses the container, the image header and every frame header / TOC / LfGlobal / local Modular stream the host
@@ -449,6 +465,13 @@ int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap)
                p.x0, p.y0, p.num_groups, p.num_lf_groups, p.num_passes, p.upsampling, p.feat.patches.size(), p.feat.splines.size(), (int)p.feat.has_noise, p.blend.mode, (int)p.is_last,
                p.tree.nodes.size(), p.max_prop, (int)p.tree.uses_wp, (int)p.tree_code.use_prefix, (int)p.tree_code.lz77, p.local_streams.size(), p.gtransforms.size(), p.sections.size());
       s += line;
+      if (!p.modular) {
+        snprintf(line, sizeof line, "  quantizer global_scale=%u quant_lf=%u m_lf=%g,%g,%g x_qm=%u b_qm=%u cfl_base=%g,%g colour_factor=%u ycbcr=%d sampling=%u,%u,%u flags=%llu\n", p.global_scale, p.quant_lf,
+                 p.m_lf[0], p.m_lf[1], p.m_lf[2], p.x_qm_scale, p.b_qm_scale, p.base_x, p.base_b, p.color_factor, (int)p.do_ycbcr, p.jpeg_upsampling[0], p.jpeg_upsampling[1], p.jpeg_upsampling[2],
+                 (unsigned long long)p.flags);
+        s += line;
+        for (int k = 0; k < 17; k++) if (p.qspec[k].mode != 0) { snprintf(line, sizeof line, "  qtable kind=%d mode=%u raw_den=%g\n", k, p.qspec[k].mode, p.qspec[k].raw_den); s += line; }
+      }
     }
     if (out && cap) { const size_t n = std::min(cap - 1, s.size()); memcpy(out, s.data(), n); out[n] = 0; }
     return 0;

@@ -186,7 +186,7 @@ void LaunchWrite(const WriteArgs& a, void* stream);
 // JPEG reconstruction: quantised coefficients of a JPEG-transcoded frame in JPEG layout — component c (0 Y, 1 Cb, 2 Cr), block raster
 // order, 64 coefficients in natural (row-major) order: DC from the quantised LF image, AC from the coefficient planes with the integer
 // chroma-from-luma of the transcoder undone (dec_group.cc, jpeg branch).  qt: the JPEG quantisation tables, natural order.
-struct JpegCoefArgs { int16_t* out; uint32_t ncomp; int32_t qt[3][64]; };
+struct JpegCoefArgs { int16_t* out; uint32_t ncomp; int32_t qt[3][64]; uint32_t comp_off[3]; };   // comp_off: first block of a component's plane (subsampled frames)
 void LaunchJpegCoefficients(const FrameDev* frames, int fidx, const JpegCoefArgs& a, uint32_t bw, uint32_t bh, void* stream);
 void LaunchCopyPlane(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, void* stream);
 

@@ -488,6 +488,19 @@ __global__ void JpegCoefKernel(const FrameDev* __restrict__ frames, int fidx, Jp
   const uint32_t bx = o % f.bw, by = o / f.bw;
   const uint32_t g = (by / 32) * f.xgroups + bx / 32;
   const size_t base = (size_t)g * 65536 + f.coef_off[o] + (u * 8 + v);   // libjxl stores the transpose of JPEG's (v, u) layout
+  if (f.subsampled) {
+    // chroma-subsampled frames carry no chroma-from-luma (the LF stage rejects it); a channel's block (sx, sy) keeps its coefficients at
+    // the slot of block (sx << hs, sy << vs) and its LF sample at (sx, sy) of the padded grid; component planes are packed one after another
+    for (uint32_t c = 0; c < a.ncomp; c++) {
+      const int ch = c == 0 ? 1 : c == 1 ? 0 : 2;
+      const uint32_t hs = f.hs[ch], vs = f.vs[ch];
+      if ((bx & ((1u << hs) - 1u)) | (by & ((1u << vs) - 1u))) continue;
+      const uint32_t sx = bx >> hs, sy = by >> vs, cw = f.bw >> hs;
+      const int32_t val = i == 0 ? f.lfq[ch][(size_t)sy * f.bw + sx] : f.coeff[ch][base];
+      a.out[((size_t)a.comp_off[c] + (size_t)sy * cw + sx) * 64 + i] = (int16_t)val;
+    }
+    return;
+  }
   const int32_t y = i == 0 ? f.lfq[1][o] : f.coeff[1][base];
   if (a.ncomp == 1) { a.out[(size_t)o * 64 + i] = (int16_t)y; return; }
   a.out[(size_t)o * 64 + i] = (int16_t)y;

@@ -214,3 +214,18 @@ def encode_ycbcr(rgb, subsampling="420", seed=1, distance=1.0):
     if L.jxlsynth_ycbcr(a.ctypes.data, w, h, modes, seed, distance, C.byref(out), C.byref(n)):
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)
+
+
+def jpeg_transcode_codestream(w, h, modes, planes, qts):
+    """Codestream of a lossless JPEG transcode (tools/synth_ycbcr.h EncodeJpegTranscode).  modes / planes / qts per jxl channel (Cb, Y, Cr):
+    sampling-factor mode as in SUBSAMPLING, quantised coefficients int16 [blocks, 64] in JPEG natural order over the component's block
+    grid (MCU grid x sampling factor), quantisation table int32 [64] natural order."""
+    L = lib()
+    L.jxlsynth_jpeg_transcode.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    m = (C.c_int32 * 3)(*modes)
+    pl = [np.ascontiguousarray(p, dtype=np.int16) for p in planes]
+    q = np.ascontiguousarray(qts, dtype=np.int32)
+    out = C.c_void_p(); n = C.c_size_t()
+    if L.jxlsynth_jpeg_transcode(w, h, m, pl[0].ctypes.data, pl[1].ctypes.data, pl[2].ctypes.data, q.ctypes.data, C.byref(out), C.byref(n)):
+        raise RuntimeError(L.jxlsynth_last_error().decode())
+    return _take(out, n)

@@ -1009,3 +1009,27 @@ def test_chroma_subsampled_ycbcr_frames(jx, sub, w, h):
     check_against_oracle(jx, data, np.uint8, 3)
     check_against_oracle(jx, data, np.float32, 3)
     check_against_oracle(jx, data, np.uint16, 4 if False else 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", __import__("jpeg_cases").CASES, ids=lambda c: "%dx%d_ss%d_q%d" % c[:4])
+def test_jpeg_transcodes_of_real_jpegs(jx, case):
+    """decode.rs:493-514 `reconstruct` on JPEG XL files that stand for lossless transcodes of real JPEGs: Pillow's libjpeg writes the
+    JPEG (4:4:4 / 4:2:2 / 4:2:0, optimised tables, restart intervals, COM marker), tests/jpeg_tools.py turns it into jbrd box + VarDCT
+    codestream (RAW quantisation tables, subsampled chroma grids).  reconstruct() must give back the JPEG byte for byte — entropy stages
+    on the GPU, per-component coefficient planes (JpegCoefKernel), MCU interleave with the sampling factors from the frame header — and
+    the pixel path must match the oracle bit for bit and libjpeg's own decode of the JPEG within integer-IDCT distance."""
+    import jpeg_cases as JC
+    import jpeg_tools as J
+    data = JC.jpeg_bytes(case)
+    jxl = J.transcode(data)
+    meta, (kind, val) = jx.decoder_builder().reconstruct(jxl)
+    assert kind == "jpeg" and val == data
+    assert (meta.width, meta.height) == case[:2]
+    check_against_oracle(jx, jxl, np.uint8, 3)
+    check_against_oracle(jx, jxl, np.float32, 3)
+    res = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3)).decode_with(jxl, np.uint8)[1]
+    d = np.abs(np.asarray(res).reshape(case[1], case[0], 3).astype(int) - JC.pil_pixels(data))
+    assert d.max() <= 6 and d.mean() < 0.7
+    meta, (kind, val) = jx.decoder_builder(init_jpeg_buffer=256).reconstruct(jxl)      # grown through JXL_DEC_JPEG_NEED_MORE_OUTPUT
+    assert kind == "jpeg" and val == data

@@ -1,0 +1,64 @@
+"""JPEG transcodes anchored on real JPEG files (`-m "not gpu"` half).  Pillow's libjpeg writes baseline JPEGs (4:4:4 / 4:2:2 / 4:2:0,
+optimised Huffman tables, restart intervals, COM markers); tests/jpeg_tools.py Huffman-decodes them and writes the JPEG XL file of the
+lossless transcode (jbrd box + VarDCT codestream with RAW quantisation tables and chroma subsampling, tools/synth_ycbcr.h).  Checked here:
+ * the serialisation half of reconstruct() (csrc/jpeg_recon.cc, no GPU needed) reproduces every file byte for byte from its jbrd box and
+   coefficients — interleaved MCUs with sampling factors, restart markers, padding bits;
+ * a file re-serialised with one scan per component (the other MCU geometry of the writer) decodes in libjpeg to the same pixels;
+ * the oracle's pixels for the transcode agree with libjpeg's decode of the JPEG within integer-IDCT / rounding distance — an anchor for
+   the oracle's YCbCr, RAW-table, subsampled-grid and chroma-upsampling arithmetic that owes nothing to this repository's encoders.
+The GPU half (reconstruct() == the JPEG's bytes, pixels == oracle) is tests/test_gpu_parity.py::test_jpeg_transcodes_of_real_jpegs."""
+import ctypes as C
+import io
+
+import numpy as np
+import pytest
+
+import jpeg_cases as JC
+import jpeg_tools as J
+import oracle_lib as O
+
+
+@pytest.fixture(scope="module")
+def jx():
+    import jpegxl_rs_amd as jx
+    return jx
+
+
+def _write(jx, j, jbrd):
+    L = jx.libjxl()
+    L.JxlHipDebugWriteJpegSampled.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    samp = np.array([[c["h"], c["v"]] for c in j.components], np.uint32)
+    coef = np.concatenate([c.reshape(-1) for c in j.coef]).astype(np.int16)
+    qt = np.array([j.qt[c["tq"]] for c in j.components], np.int32)
+    out = np.zeros(coef.size * 4 + (1 << 16), np.uint8)
+    n = C.c_size_t(len(out))
+    assert L.JxlHipDebugWriteJpegSampled(jbrd, len(jbrd), j.width, j.height, samp.ctypes.data, coef.ctypes.data, qt.ctypes.data, out.ctypes.data, C.byref(n)) == 0, jx.last_error()
+    return out[:n.value].tobytes()
+
+
+@pytest.mark.parametrize("case", JC.CASES, ids=lambda c: "%dx%d_ss%d_q%d" % c[:4])
+def test_writer_reproduces_libjpeg_files(jx, case):
+    data = JC.jpeg_bytes(case)
+    j = J.parse_jpeg(data)
+    assert _write(jx, j, J.build_jbrd(j)) == data
+    if case[4].get("optimize"):
+        return                                               # (tables optimised for the interleaved scan lack codes other DC differences need)
+    # one scan per component: blocks of the component's own grid, only those that hold image data (T.81 A.2.4)
+    first = j.marker_order.index(0xDA)
+    j.marker_order[first:first + 1] = [0xDA] * 3
+    comps = j.scans[0]["comps"]
+    j.scans = [dict(comps=[c]) for c in comps]
+    j.padding_bits = []                                      # (ones; the three scans pad on their own)
+    split = _write(jx, j, J.build_jbrd(j))
+    assert split != data and split.count(b"\xff\xda") >= 3
+    assert np.array_equal(JC.pil_pixels(split), JC.pil_pixels(data))
+
+
+@pytest.mark.parametrize("case", JC.CASES, ids=lambda c: "%dx%d_ss%d_q%d" % c[:4])
+def test_oracle_pixels_of_transcode_match_libjpeg(case):
+    data = JC.jpeg_bytes(case)
+    w, h = case[:2]
+    px = np.frombuffer(O.decode(J.transcode(data)).pixels("u8", 3), np.uint8).reshape(h, w, 3).astype(int)
+    ref = JC.pil_pixels(data)
+    d = np.abs(px - ref)
+    assert d.max() <= 6 and d.mean() < 0.7, (int(d.max()), float(d.mean()))      # float IDCT + one rounding vs libjpeg's integer pipeline

@@ -1324,6 +1324,15 @@ int jxlsynth_ycbcr(const uint8_t* rgb8, int w, int h, const int32_t* modes, uint
     return finish(synth::EncodeYCbCr(rgb8, w, h, m, p), out, n);
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
+// Codestream of a JPEG transcode (tools/synth_ycbcr.h EncodeJpegTranscode): planes / qt per jxl channel (Cb, Y, Cr), JPEG natural order
+int jxlsynth_jpeg_transcode(int w, int h, const int32_t* modes, const int16_t* cb, const int16_t* y, const int16_t* cr, const int32_t* qt, uint8_t** out, size_t* n) {
+  try {
+    synth::Params p;
+    const int m[3] = {modes[0], modes[1], modes[2]};
+    const int16_t* planes[3] = {cb, y, cr};
+    return finish(synth::EncodeJpegTranscode(w, h, m, planes, qt, p), out, n);
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 // Free-running Modular stream (tools/synth_free.h): feature coverage without an encoder-side simulation of the decoder.
 struct jxlsynth_free_params { uint32_t seed; int w, h, nchan, has_alpha, bits, tree_flags, tree_depth, local_trees, lz77, palette, nb_colors, nb_deltas, pal_pred; };
 int jxlsynth_modular_free(const jxlsynth_free_params* pp, uint8_t** out, size_t* n) {

@@ -7,63 +7,36 @@
 
 namespace synth {
 
-// sampling-factor modes per jxl channel (0 = Cb, 1 = Y, 2 = Cr): 0 = 1x1, 1 = 2x2, 2 = 2x1 (horizontal factor 2), 3 = 1x2
-static std::vector<uint8_t> EncodeYCbCr(const uint8_t* rgb8, int w, int h, const int mode[3], const Params& p) {
+struct YCbCrQuantised {
+  int w, h; int mode[3];
+  std::vector<int32_t> lfq[3], qc[3];     // per channel: (bh >> vs) x (bw >> hs) LF values / x 64 coefficients in libjxl's (transposed) layout
+  std::vector<int32_t> hf_mul;            // bw x bh
+  uint32_t global_scale = 1, quant_lf = 16;
+  bool custom_m_lf = false; float m_lf[3] = {0, 0, 0};
+  const int32_t* raw_table = nullptr; float raw_den = 0;   // 3 x 64 (channel, libjxl layout) when the 8x8 DCT uses a RAW table
+};
+
+static void YCbCrGeometry(int w, int h, const int mode[3], int hs[3], int vs[3], int* bw, int* bh) {
   static const int kH[4] = {0, 1, 1, 0}, kV[4] = {0, 1, 0, 1};
-  int maxhs = 0, maxvs = 0, hs[3], vs[3];
+  int maxhs = 0, maxvs = 0;
   for (int c = 0; c < 3; c++) { maxhs = std::max(maxhs, kH[mode[c]]); maxvs = std::max(maxvs, kV[mode[c]]); }
   for (int c = 0; c < 3; c++) { hs[c] = maxhs - kH[mode[c]]; vs[c] = maxvs - kV[mode[c]]; }
-  const int bw = ((w + (8 << maxhs) - 1) / (8 << maxhs)) << maxhs, bh = ((h + (8 << maxvs) - 1) / (8 << maxvs)) << maxvs;
+  *bw = ((w + (8 << maxhs) - 1) / (8 << maxhs)) << maxhs; *bh = ((h + (8 << maxvs) - 1) / (8 << maxvs)) << maxvs;
+}
+
+static std::vector<uint8_t> WriteYCbCrFrame(const YCbCrQuantised& in, const Params& p) {
+  const int w = in.w, h = in.h;
+  const int* mode = in.mode;
+  int hs[3], vs[3], bw, bh;
+  YCbCrGeometry(w, h, mode, hs, vs, &bw, &bh);
   const int xg = (w + 255) / 256, yg = (h + 255) / 256, ngroups = xg * yg;
   const int xlg = (w + 2047) / 2048, ylg = (h + 2047) / 2048, nlf = xlg * ylg;
   int bwc[3], bhc[3];
   for (int c = 0; c < 3; c++) { bwc[c] = bw >> hs[c]; bhc[c] = bh >> vs[c]; }
-  Pcg32 rng(p.seed * 613 + 11);
-  // ---- planes: YCbCr (JPEG matrix, Y centred like the decoder expects), chroma box-averaged, edge-replicated to whole blocks
-  std::vector<float> full[3];
-  for (auto& v : full) v.resize((size_t)w * h);
-  for (size_t i = 0; i < (size_t)w * h; i++) {
-    const float R = rgb8[3 * i] / 255.0f, G = rgb8[3 * i + 1] / 255.0f, B = rgb8[3 * i + 2] / 255.0f;
-    full[1][i] = 0.299f * R + 0.587f * G + 0.114f * B - 128.0f / 255.0f;
-    full[0][i] = -0.168736f * R - 0.331264f * G + 0.5f * B;
-    full[2][i] = 0.5f * R - 0.418688f * G - 0.081312f * B;
-  }
-  std::vector<float> pl[3];
-  for (int c = 0; c < 3; c++) {
-    const int pw = bwc[c] * 8, ph = bhc[c] * 8, fx = 1 << hs[c], fy = 1 << vs[c];
-    pl[c].resize((size_t)pw * ph);
-    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
-      float acc = 0;
-      for (int dy = 0; dy < fy; dy++) for (int dx = 0; dx < fx; dx++) acc += full[c][(size_t)std::min(y * fy + dy, h - 1) * w + std::min(x * fx + dx, w - 1)];
-      pl[c][(size_t)y * pw + x] = acc / (float)(fx * fy);
-    }
-  }
-  // ---- quantisation
-  const uint32_t global_scale = (uint32_t)std::min(65535.0f, std::max(1.0f, 4587.0f / p.distance));
-  const uint32_t quant_lf = 16;
-  const float inv_gs = 65536.0f / (float)global_scale;
-  const float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
-  std::vector<int32_t> hf_mul((size_t)bw * bh);
-  for (auto& v : hf_mul) v = 3 + (int)(rng.next() % 6);
-  std::vector<float> table[3];
-  { const QuantSpec spec = DefaultSpec(0); for (int c = 0; c < 3; c++) ComputeTable(spec, 0, c, table[c]); }
-  std::vector<int32_t> qc[3], lfq[3];
-  auto quant = [](float v) -> int32_t { const float a = std::fabs(v); if (a < 0.58f) return 0; const int32_t q = (int32_t)(a + 0.5f); return v < 0 ? -q : q; };
-  for (int c = 0; c < 3; c++) {
-    qc[c].assign((size_t)bwc[c] * bhc[c] * 64, 0);
-    lfq[c].assign((size_t)bwc[c] * bhc[c], 0);
-    const int pw = bwc[c] * 8;
-    for (int by = 0; by < bhc[c]; by++) for (int bx = 0; bx < bwc[c]; bx++) {
-      float cf[64], lf = 0;
-      ForwardTransform(S_DCT, pl[c].data() + (size_t)by * 8 * pw + bx * 8, pw, cf);
-      LFFromLowestFrequencies(S_DCT, cf, &lf, 1);
-      lfq[c][(size_t)by * bwc[c] + bx] = (int32_t)std::lrintf(lf / (m_lf[c] * inv_gs / (float)quant_lf));
-      // the block's quantisation multiplier is the one of the full-resolution block it starts at
-      const float sd = inv_gs / (float)hf_mul[(size_t)(by << vs[c]) * bw + (bx << hs[c])];
-      int32_t* q = qc[c].data() + ((size_t)by * bwc[c] + bx) * 64;
-      for (int k = 1; k < 64; k++) q[k] = quant(cf[k] / (table[c][k] * sd));
-    }
-  }
+  const std::vector<int32_t>* lfq = in.lfq;
+  const std::vector<int32_t>* qc = in.qc;
+  const std::vector<int32_t>& hf_mul = in.hf_mul;
+  const uint32_t global_scale = in.global_scale, quant_lf = in.quant_lf;
   // ---- Modular streams: LF coefficients (per-channel size) + HF metadata under the fixed global tree
   std::vector<int> bfs;
   GTree gt = MakeGlobalTree(nlf, &bfs);
@@ -134,14 +107,23 @@ static std::vector<uint8_t> EncodeYCbCr(const uint8_t* rgb8, int w, int h, const
       }
     }
   }
+  // RAW quantisation table of the 8x8 DCT (quant_weights.cc kQuantModeRAW): a 3-channel 8x8 Modular image under the global tree,
+  // stream id 1 + 3 * nlf + kind
+  std::vector<Token> raw_tok;
+  if (in.raw_table) {
+    std::vector<ChanRef> cr;
+    for (int c = 0; c < 3; c++) cr.push_back({in.raw_table + 64 * c, 8, 8});
+    ModularTokens(gt, root, cr, 1 + 3 * nlf + 0, raw_tok);
+  }
   EntropyCoder tree_code, mod_code, ac_code;
   { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
-  { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); } BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 32, mod_code); }
+  { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); } s.push_back(&raw_tok); BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 32, mod_code); }
   { std::vector<const std::vector<Token>*> s; for (auto& t : ac_tok) s.push_back(&t); BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_code); }
   std::vector<BitWriter> sections;
   {  // LfGlobal
     BitWriter s;
-    s.put(1, 1);  // LfChannelDequantization all_default
+    if (!in.custom_m_lf) s.put(1, 1);  // LfChannelDequantization all_default
+    else { s.put(0, 1); for (int c = 0; c < 3; c++) WriteF16(s, in.m_lf[c] * 128.0f); }
     WriteU32(s, global_scale, {11, 1}, {11, 2049}, {12, 4097}, {16, 8193});
     WriteU32(s, quant_lf, {0, 16}, {5, 1}, {8, 1}, {16, 1});
     s.put(1, 1);  // default BlockCtxMap
@@ -164,9 +146,19 @@ static std::vector<uint8_t> EncodeYCbCr(const uint8_t* rgb8, int w, int h, const
     EncodeTokens(s, mod_code, d.meta_tok);
     sections.push_back(s);
   }
-  {  // HfGlobal: library default dequantisation matrices, one preset, natural orders
+  {  // HfGlobal: library default dequantisation matrices (or a RAW table for the 8x8 DCT: JPEG transcodes), one preset, natural orders
     BitWriter s;
-    s.put(1, 1);
+    if (!in.raw_table) s.put(1, 1);
+    else {
+      s.put(0, 1);
+      for (int k = 0; k < 17; k++) {
+        if (k != 0) { s.put(0, 3); continue; }                     // library default for everything but kind 0
+        s.put(7, 3);                                                // kQuantModeRAW
+        WriteF16(s, in.raw_den);
+        s.put(1, 1); s.put(1, 1); s.put(0, 2);                      // GroupHeader: global tree, default WP, no transforms
+        EncodeTokens(s, mod_code, raw_tok);
+      }
+    }
     s.put(0, CeilLog2((uint32_t)ngroups));
     s.put(2, 2);
     WriteEntropyCode(s, ac_code);
@@ -182,6 +174,100 @@ static std::vector<uint8_t> EncodeYCbCr(const uint8_t* rgb8, int w, int h, const
   WriteTOCAndSections(out, sections, ngroups == 1, 0);
   out.align();
   return out.bytes;
+}
+
+
+// sampling-factor modes per jxl channel (0 = Cb, 1 = Y, 2 = Cr): 0 = 1x1, 1 = 2x2, 2 = 2x1 (horizontal factor 2), 3 = 1x2
+static std::vector<uint8_t> EncodeYCbCr(const uint8_t* rgb8, int w, int h, const int mode[3], const Params& p) {
+  static const int kH[4] = {0, 1, 1, 0}, kV[4] = {0, 1, 0, 1};
+  int maxhs = 0, maxvs = 0, hs[3], vs[3];
+  for (int c = 0; c < 3; c++) { maxhs = std::max(maxhs, kH[mode[c]]); maxvs = std::max(maxvs, kV[mode[c]]); }
+  for (int c = 0; c < 3; c++) { hs[c] = maxhs - kH[mode[c]]; vs[c] = maxvs - kV[mode[c]]; }
+  const int bw = ((w + (8 << maxhs) - 1) / (8 << maxhs)) << maxhs, bh = ((h + (8 << maxvs) - 1) / (8 << maxvs)) << maxvs;
+  const int xg = (w + 255) / 256, yg = (h + 255) / 256, ngroups = xg * yg;
+  const int xlg = (w + 2047) / 2048, ylg = (h + 2047) / 2048, nlf = xlg * ylg;
+  int bwc[3], bhc[3];
+  for (int c = 0; c < 3; c++) { bwc[c] = bw >> hs[c]; bhc[c] = bh >> vs[c]; }
+  Pcg32 rng(p.seed * 613 + 11);
+  // ---- planes: YCbCr (JPEG matrix, Y centred like the decoder expects), chroma box-averaged, edge-replicated to whole blocks
+  std::vector<float> full[3];
+  for (auto& v : full) v.resize((size_t)w * h);
+  for (size_t i = 0; i < (size_t)w * h; i++) {
+    const float R = rgb8[3 * i] / 255.0f, G = rgb8[3 * i + 1] / 255.0f, B = rgb8[3 * i + 2] / 255.0f;
+    full[1][i] = 0.299f * R + 0.587f * G + 0.114f * B - 128.0f / 255.0f;
+    full[0][i] = -0.168736f * R - 0.331264f * G + 0.5f * B;
+    full[2][i] = 0.5f * R - 0.418688f * G - 0.081312f * B;
+  }
+  std::vector<float> pl[3];
+  for (int c = 0; c < 3; c++) {
+    const int pw = bwc[c] * 8, ph = bhc[c] * 8, fx = 1 << hs[c], fy = 1 << vs[c];
+    pl[c].resize((size_t)pw * ph);
+    for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
+      float acc = 0;
+      for (int dy = 0; dy < fy; dy++) for (int dx = 0; dx < fx; dx++) acc += full[c][(size_t)std::min(y * fy + dy, h - 1) * w + std::min(x * fx + dx, w - 1)];
+      pl[c][(size_t)y * pw + x] = acc / (float)(fx * fy);
+    }
+  }
+  // ---- quantisation
+  const uint32_t global_scale = (uint32_t)std::min(65535.0f, std::max(1.0f, 4587.0f / p.distance));
+  const uint32_t quant_lf = 16;
+  const float inv_gs = 65536.0f / (float)global_scale;
+  const float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
+  std::vector<int32_t> hf_mul((size_t)bw * bh);
+  for (auto& v : hf_mul) v = 3 + (int)(rng.next() % 6);
+  std::vector<float> table[3];
+  { const QuantSpec spec = DefaultSpec(0); for (int c = 0; c < 3; c++) ComputeTable(spec, 0, c, table[c]); }
+  std::vector<int32_t> qc[3], lfq[3];
+  auto quant = [](float v) -> int32_t { const float a = std::fabs(v); if (a < 0.58f) return 0; const int32_t q = (int32_t)(a + 0.5f); return v < 0 ? -q : q; };
+  for (int c = 0; c < 3; c++) {
+    qc[c].assign((size_t)bwc[c] * bhc[c] * 64, 0);
+    lfq[c].assign((size_t)bwc[c] * bhc[c], 0);
+    const int pw = bwc[c] * 8;
+    for (int by = 0; by < bhc[c]; by++) for (int bx = 0; bx < bwc[c]; bx++) {
+      float cf[64], lf = 0;
+      ForwardTransform(S_DCT, pl[c].data() + (size_t)by * 8 * pw + bx * 8, pw, cf);
+      LFFromLowestFrequencies(S_DCT, cf, &lf, 1);
+      lfq[c][(size_t)by * bwc[c] + bx] = (int32_t)std::lrintf(lf / (m_lf[c] * inv_gs / (float)quant_lf));
+      // the block's quantisation multiplier is the one of the full-resolution block it starts at
+      const float sd = inv_gs / (float)hf_mul[(size_t)(by << vs[c]) * bw + (bx << hs[c])];
+      int32_t* q = qc[c].data() + ((size_t)by * bwc[c] + bx) * 64;
+      for (int k = 1; k < 64; k++) q[k] = quant(cf[k] / (table[c][k] * sd));
+    }
+  }
+  YCbCrQuantised in;
+  in.w = w; in.h = h; for (int c = 0; c < 3; c++) { in.mode[c] = mode[c]; in.lfq[c] = lfq[c]; in.qc[c] = qc[c]; }
+  in.hf_mul = hf_mul; in.global_scale = global_scale; in.quant_lf = quant_lf;
+  return WriteYCbCrFrame(in, p);
+}
+
+// JPEG transcode (what libjxl's lossless JPEG recompression writes, enc_frame.cc with jpeg_data): the JPEG's quantised coefficients as
+// they are — DC as the LF image, AC transposed into libjxl's layout — quantiser at unity (global_scale 65536, quant_lf 1, hf_mul 1),
+// LF factors qt[0] / (8 * 255) per channel, the JPEG quantisation tables as a RAW table with denominator 1 / (8 * 255).
+// planes: per jxl channel (Cb, Y, Cr) the component's blocks x 64 coefficients in JPEG natural (row-major) order; qt: 3 x 64, same order.
+static std::vector<uint8_t> EncodeJpegTranscode(int w, int h, const int mode[3], const int16_t* const planes[3], const int32_t* qt, const Params& p) {
+  YCbCrQuantised in;
+  in.w = w; in.h = h;
+  int hs[3], vs[3], bw, bh;
+  YCbCrGeometry(w, h, mode, hs, vs, &bw, &bh);
+  static std::vector<int32_t> raw;
+  raw.assign(3 * 64, 1);
+  for (int c = 0; c < 3; c++) {
+    in.mode[c] = mode[c];
+    const int bwc = bw >> hs[c], bhc = bh >> vs[c];
+    in.lfq[c].resize((size_t)bwc * bhc); in.qc[c].assign((size_t)bwc * bhc * 64, 0);
+    for (size_t b = 0; b < (size_t)bwc * bhc; b++) {
+      const int16_t* src = planes[c] + b * 64;
+      in.lfq[c][b] = src[0];
+      for (int v = 0; v < 8; v++) for (int u = 0; u < 8; u++) if (u | v) in.qc[c][b * 64 + u * 8 + v] = src[v * 8 + u];
+    }
+    for (int v = 0; v < 8; v++) for (int u = 0; u < 8; u++) raw[c * 64 + u * 8 + v] = qt[c * 64 + v * 8 + u];
+    in.m_lf[c] = (float)qt[c * 64] / 2040.0f;
+  }
+  in.custom_m_lf = true;
+  in.hf_mul.assign((size_t)bw * bh, 1);
+  in.global_scale = 65536; in.quant_lf = 1;
+  in.raw_table = raw.data(); in.raw_den = 1.0f / 2040.0f;
+  return WriteYCbCrFrame(in, p);
 }
 
 }  // namespace synth
