@@ -357,6 +357,9 @@ def _describe(jx, data):
     lines = buf.value.decode().strip().split("\n")
     rows = []
     for l in lines:
+        if l.startswith("  quantizer"):                      # detail line of the VarDCT frame above it
+            rows[-1]["quantizer"] = dict(t.split("=") for t in l.split() if "=" in t)
+            continue
         kv = dict(t.split("=") for t in l.split() if "=" in t)
         kv["kind"] = l.split()[0] + (" " + l.split()[2] if l.startswith("frame") else "")
         kv["raw"] = l
@@ -403,6 +406,9 @@ def test_host_parser_on_fixtures_and_synthetic_streams(jx):
         S.encode_vardct_frame(small, S.frame(emit=1, have_crop=1, crop_x0=40, crop_y0=30, canvas_w=200, canvas_h=136, blend_mode=2, blend_source=1, noise_lut=[100] * 8), seed=4)
     d = _describe(jx, two)
     assert d[0]["frames"] == "2" and "at (40,30)" in d[2]["raw"] and d[2]["blend"] == "2" and d[2]["noise"] == "1" and d[2]["last"] == "1"
+    # the JPEG transcode of the reference: JPEG-style quantiser set-up (what tools/synth_ycbcr.h's transcodes copy)
+    q = _describe(jx, fixture_bytes("sample_jpg.jxl"))[1]["quantizer"]
+    assert (q["global_scale"], q["quant_lf"], q["ycbcr"], q["sampling"], q["cfl_base"]) == ("65536", "1", "1", "0,0,0", "0,0")
     # rejected inputs say why
     with pytest.raises(jx.GenericError, match="truncated|unsupported|corrupt|signature|header"):
         _describe(jx, fixture_bytes("bench.jxl")[:1000])
