@@ -3,7 +3,12 @@ import os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-data = open(os.path.join(ROOT, "tests", "fixtures", "sample_jpg.jxl"), "rb").read()
+if os.environ.get("FUZZ_CASE"):                    # a transcode of a libjpeg-written JPEG (tests/jpeg_cases.py) instead of the fixture
+    import jpeg_cases as JC
+    import jpeg_tools as J
+    data = J.transcode(JC.jpeg_bytes(JC.CASES[int(os.environ["FUZZ_CASE"])]))
+else:
+    data = open(os.path.join(ROOT, "tests", "fixtures", "sample_jpg.jxl"), "rb").read()
 
 
 def mutate(t, seed):

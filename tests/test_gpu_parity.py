@@ -941,16 +941,19 @@ def test_corrupted_feature_streams_fail_cleanly_or_decode(jx):
                 outcomes["error"] += 1
     assert outcomes["error"] > 0 and outcomes["error"] + outcomes["decoded"] == 16 * len(streams)
     # JPEG reconstruction with a damaged jbrd box / codestream: JPEG bytes, pixels or an error
+    import jpeg_cases as JC
+    import jpeg_tools as J
     data = fixture_bytes("sample_jpg.jxl")
-    for trial in range(24):
-        bad = bytearray(data)
-        for pos in rng.integers(40, len(bad), 1 + trial % 2):
-            bad[pos] ^= 1 << int(rng.integers(0, 8))
-        try:
-            meta, (kind, val) = jx.decoder_builder().reconstruct(bytes(bad))
-            assert kind in ("jpeg", "pixels") and len(val) > 0
-        except jx.DecodeError:
-            pass
+    for src in (data, J.transcode(JC.jpeg_bytes(JC.CASES[4])), J.transcode(JC.jpeg_bytes(JC.CASES[5]))):   # + 4:2:0 / 4:2:2 with restart markers
+        for trial in range(24):
+            bad = bytearray(src)
+            for pos in rng.integers(40, len(bad), 1 + trial % 2):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            try:
+                meta, (kind, val) = jx.decoder_builder().reconstruct(bytes(bad))
+                assert kind in ("jpeg", "pixels") and len(val) > 0
+            except jx.DecodeError:
+                pass
     check_against_oracle(jx, fixture_bytes("sample_grey.jxl"), np.uint8, 3)
     meta, (kind, val) = jx.decoder_builder().reconstruct(data)
     assert kind == "jpeg" and val == open(os.path.join(FIXTURES, "sample.jpg"), "rb").read()
