@@ -149,7 +149,7 @@ void Batch::ShareBigArena(Batch* owner) {
 int Batch::AddImage(const uint8_t* data, size_t size) {
   std::shared_ptr<ImageShared> sh(new ImageShared());
   bool have_container = false, has_jbrd = false;
-  if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, &sh->jbrd)) throw ParseError("truncated", false);
+  if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, &sh->boxes)) throw ParseError("truncated", false);
   uint64_t bitpos = 0;
   ParseImageHeader(sh->cs, &sh->ih, &bitpos);
   sh->ih.have_container = have_container;
@@ -1286,7 +1286,7 @@ bool Batch::CanReconstructJpeg(int i, std::string* why) {
   auto no = [&](const char* m) { if (why) *why = m; return false; };
   const PubImage& pi = pub_[i];
   const ImageEntry& e = *images_[pi.first_unit];
-  if (e.shared->jbrd.empty()) return no("no jbrd box");
+  if (e.shared->boxes.jbrd.empty()) return no("no jbrd box");
   const FramePlan& p = e.plan;
   if (pi.num_units != 1 || (pi.complex && !p.subsampled) || p.modular || e.ih.xyb_encoded || !p.do_ycbcr && e.ih.color_space != 1) return no("not a plain JPEG-transcoded frame");
   if (p.upsampling != 1 || p.num_passes != 1 || !e.ih.extra.empty()) return no("not a plain JPEG-transcoded frame");
@@ -1295,7 +1295,13 @@ bool Batch::CanReconstructJpeg(int i, std::string* why) {
   if (!jpeg_data_[i]) {
     std::unique_ptr<JpegData> jd(new JpegData());
     std::string err;
-    if (!ParseJbrd(e.shared->jbrd.data(), e.shared->jbrd.size(), jd.get(), &err)) { if (why) *why = err; return false; }
+    const MetadataBoxes& bx = e.shared->boxes;
+    if (!ParseJbrd(bx.jbrd.data(), bx.jbrd.size(), jd.get(), &err)) { if (why) *why = err; return false; }
+    JpegMetadataSources src;
+    src.icc = e.ih.icc.data(); src.icc_size = e.ih.icc.size();
+    src.exif = bx.have_exif ? bx.exif.data() : nullptr; src.exif_size = bx.exif.size(); src.exif_brob = bx.exif_brob;
+    src.xml = bx.have_xml ? bx.xml.data() : nullptr; src.xml_size = bx.xml.size(); src.xml_brob = bx.xml_brob;
+    if (!FillJpegMetadata(jd.get(), src, &err)) { if (why) *why = err; return false; }
     if (jd->components.size() != 3 && jd->components.size() != 1) return no("component count");
     for (auto& s : jd->scan_info) if (!(s.Ss == 0 && s.Se == 63 && s.Al == 0 && s.Ah == 0)) return no("unsupported: progressive JPEG scan script");
     for (uint8_t m : jd->marker_order) if (m == 0xC2 || m == 0xCA) return no("unsupported: progressive JPEG");

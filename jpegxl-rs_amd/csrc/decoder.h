@@ -23,7 +23,7 @@ struct OutputSpec {
 };
 
 // What the frames of one image share: the codestream and the image header.
-struct ImageShared { Codestream cs; ImageHeader ih; vec<uint8_t> jbrd; };   // jbrd: payload of the JPEG-reconstruction box, if any
+struct ImageShared { Codestream cs; ImageHeader ih; MetadataBoxes boxes; };   // jbrd: payload of the JPEG-reconstruction box, if any
 
 // One *frame* of an image: the unit the decode stages work on (one FrameDev each).  A single-frame image without image
 // features is one unit that writes its pixels itself; the frames of other ("complex") images end in float planes and a

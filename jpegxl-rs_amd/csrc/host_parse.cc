@@ -634,7 +634,7 @@ SigResult CheckSignature(const uint8_t* buf, size_t len) {
   return len < 12 ? kSigNotEnoughBytes : kSigContainer;
 }
 
-bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, vec<uint8_t>* jbrd) {
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, MetadataBoxes* boxes) {
   *have_container = false; *has_jbrd = false;
   vec<uint8_t> tmp;
   const uint8_t* src = data; size_t n = size;
@@ -662,7 +662,15 @@ bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* h
       }
       if (!memcmp(type, "jxlc", 4)) { tmp.insert(tmp.end(), data + pos + hdr, data + end); found = true; }
       else if (!memcmp(type, "jxlp", 4)) { if (end >= pos + hdr + 4) { tmp.insert(tmp.end(), data + pos + hdr + 4, data + end); found = true; } }
-      else if (!memcmp(type, "jbrd", 4)) { *has_jbrd = true; if (jbrd) jbrd->assign(data + pos + hdr, data + end); }
+      else if (!memcmp(type, "jbrd", 4)) { *has_jbrd = true; if (boxes) boxes->jbrd.assign(data + pos + hdr, data + end); }
+      else if (boxes) {
+        // metadata a reconstructed JPEG gets its APP1 markers from (decode.cc box handling: the first box of a kind counts)
+        const bool brob = !memcmp(type, "brob", 4) && end >= pos + hdr + 4;
+        const uint8_t* real = brob ? data + pos + hdr : type;
+        const size_t body = pos + hdr + (brob ? 4 : 0);
+        if (!memcmp(real, "Exif", 4) && !boxes->have_exif) { boxes->have_exif = true; boxes->exif_brob = brob; boxes->exif.assign(data + body, data + end); }
+        else if (!memcmp(real, "xml ", 4) && !boxes->have_xml) { boxes->have_xml = true; boxes->xml_brob = brob; boxes->xml.assign(data + body, data + end); }
+      }
       pos = end;
     }
     (void)last_unbounded;

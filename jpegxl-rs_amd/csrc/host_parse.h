@@ -185,7 +185,10 @@ enum SigResult { kSigNotEnoughBytes = 0, kSigInvalid = 1, kSigCodestream = 2, kS
 SigResult CheckSignature(const uint8_t* buf, size_t len);
 
 // Extracts the codestream; returns false if more input is needed (truncated container).
-bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, vec<uint8_t>* jbrd = nullptr);
+// container boxes JPEG reconstruction draws on: `jbrd`, the first `Exif` and the first `xml ` box; *_brob: the payload is still the Brotli
+// stream of a `brob` box (decompressed where it is used, jpeg_recon.cc)
+struct MetadataBoxes { vec<uint8_t> jbrd, exif, xml; bool have_exif = false, have_xml = false, exif_brob = false, xml_brob = false; };
+bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, MetadataBoxes* boxes = nullptr);
 
 // Parses the image header; *frame_bitpos receives the bit position of the first frame header.
 void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bitpos);

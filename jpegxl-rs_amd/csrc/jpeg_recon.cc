@@ -41,6 +41,10 @@ BrotliDecompressFn LoadBrotli() {
   return fn;
 }
 
+const uint8_t kIccTag[12] = {'I', 'C', 'C', '_', 'P', 'R', 'O', 'F', 'I', 'L', 'E', 0};
+const uint8_t kExifTag[6] = {'E', 'x', 'i', 'f', 0, 0};
+const uint8_t kXmpTag[29] = {'h', 't', 't', 'p', ':', '/', '/', 'n', 's', '.', 'a', 'd', 'o', 'b', 'e', '.', 'c', 'o', 'm', '/', 'x', 'a', 'p', '/', '1', '.', '0', '/', 0};
+
 const uint8_t kNaturalOrder[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
                                    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
@@ -149,10 +153,7 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
   for (uint32_t v : inter_sizes) jd->inter_marker_data.emplace_back(v);
   // ---- Brotli stream: unknown-type APPn markers, COM markers, inter-marker data, tail data, back to back
   size_t total = 0;
-  for (size_t i = 0; i < num_app; i++) {
-    if (jd->app_marker_type[i] != 0) return fail("unsupported: ICC / Exif / XMP markers rebuilt from other boxes");
-    total += jd->app_data[i].size();
-  }
+  for (size_t i = 0; i < num_app; i++) if (jd->app_marker_type[i] == 0) total += jd->app_data[i].size();
   for (auto& c : jd->com_data) total += c.size();
   for (auto& d : jd->inter_marker_data) total += d.size();
   total += jd->tail_data.size();
@@ -166,10 +167,66 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
   }
   size_t pos = 0;
   auto take = [&](vec<uint8_t>& v) { if (!v.empty()) memcpy(v.data(), plain.data() + pos, v.size()); pos += v.size(); };
-  for (auto& a : jd->app_data) { take(a); if ((size_t)a[1] * 256u + a[2] + 1u != a.size()) return fail("APP marker length mismatch"); }
+  uint32_t num_icc = 0;
+  for (size_t i = 0; i < num_app; i++) {
+    auto& a = jd->app_data[i];
+    const uint32_t type = jd->app_marker_type[i];
+    if (type == 0) { take(a); if ((size_t)a[1] * 256u + a[2] + 1u != a.size()) return fail("APP marker length mismatch"); continue; }
+    // dec_jpeg_data.cc: marker byte, length and tag of the markers whose payload lives elsewhere in the file
+    const size_t tag_len = type == 1 ? sizeof(kIccTag) : type == 2 ? sizeof(kExifTag) : sizeof(kXmpTag);
+    if (a.size() < 3 + tag_len + (type == 1 ? 2 : 0)) return fail("metadata marker too short");
+    a[0] = type == 1 ? 0xE2 : 0xE1;
+    a[1] = (uint8_t)((a.size() - 1) >> 8); a[2] = (uint8_t)(a.size() - 1);
+    memcpy(&a[3], type == 1 ? kIccTag : type == 2 ? kExifTag : kXmpTag, tag_len);
+    if (type == 1) a[15] = (uint8_t)++num_icc;
+  }
+  for (size_t i = 0; i < num_app; i++) if (jd->app_marker_type[i] == 1) jd->app_data[i][16] = (uint8_t)num_icc;
   for (auto& c : jd->com_data) { take(c); if ((size_t)c[1] * 256u + c[2] + 1u != c.size()) return fail("COM marker length mismatch"); }
   for (auto& d : jd->inter_marker_data) take(d);
   take(jd->tail_data);
+  return true;
+}
+
+bool FillJpegMetadata(JpegData* jd, const JpegMetadataSources& src, std::string* err) {
+  auto fail = [&](const char* m) { if (err) *err = std::string("JPEG metadata: ") + m; return false; };
+  // a box payload of known size, through Brotli when it came in a `brob` box
+  auto payload = [&](const uint8_t* data, size_t size, bool brob, size_t want, vec<uint8_t>* out) {
+    if (!brob) { if (size != want) return false; out->assign(data, data + size); return true; }
+    BrotliDecompressFn brotli = LoadBrotli();
+    if (!brotli) return false;
+    out->resize(want + 1);
+    size_t got = out->size();
+    if (brotli(size, data, &got, out->data()) != 1 || got != want) return false;
+    out->resize(want);
+    return true;
+  };
+  size_t icc_pos = 0;
+  bool exif_done = false, xmp_done = false;
+  for (size_t i = 0; i < jd->app_data.size(); i++) {
+    auto& a = jd->app_data[i];
+    const uint32_t type = jd->app_marker_type[i];
+    if (type == 1) {
+      const size_t len = a.size() - 17;
+      if (icc_pos + len > src.icc_size) return fail("ICC profile shorter than the APP2 markers");
+      memcpy(a.data() + 17, src.icc + icc_pos, len);
+      icc_pos += len;
+    } else if (type == 2 && !exif_done) {
+      if (!src.exif) return fail("Exif marker without an Exif box");
+      const size_t want = a.size() - 3 - sizeof(kExifTag) + 4;     // the box starts with the 4-byte TIFF header offset
+      vec<uint8_t> box;
+      if (!payload(src.exif, src.exif_size, src.exif_brob, want, &box)) return fail("Exif size mismatch");
+      memcpy(a.data() + 3 + sizeof(kExifTag), box.data() + 4, want - 4);
+      exif_done = true;
+    } else if (type == 3 && !xmp_done) {
+      if (!src.xml) return fail("XMP marker without an xml box");
+      const size_t want = a.size() - 3 - sizeof(kXmpTag);
+      vec<uint8_t> box;
+      if (!payload(src.xml, src.xml_size, src.xml_brob, want, &box)) return fail("XMP size mismatch");
+      if (want) memcpy(a.data() + 3 + sizeof(kXmpTag), box.data(), want);
+      xmp_done = true;
+    } else if (type != 0) return fail("more than one Exif / XMP marker");
+  }
+  if (icc_pos != src.icc_size && icc_pos != 0) return fail("ICC profile longer than the APP2 markers");
   return true;
 }
 

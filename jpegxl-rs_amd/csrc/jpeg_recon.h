@@ -37,9 +37,20 @@ struct JpegData {
 };
 
 // Parses the payload of a `jbrd` box (bit-packed JPEGData bundle, then one Brotli stream with the marker payloads; Brotli comes
-// from the system's libbrotlidec.so.1, loaded at run time).  Returns false with *err set when the data is malformed, needs something
-// this implementation does not do (ICC / Exif / XMP markers rebuilt from other boxes) or Brotli is unavailable.
+// from the system's libbrotlidec.so.1, loaded at run time).  Returns false with *err set when the data is malformed or Brotli is
+// unavailable.  APPn markers of type ICC / Exif / XMP come back sized, with marker byte, length and tag in place (dec_jpeg_data.cc) and
+// their payload still to be filled by FillJpegMetadata.
 bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err);
+
+// The payloads jbrd leaves out because the JPEG XL file holds them elsewhere: the ICC profile of the codestream, spread over the APP2
+// chunks in order (decode.cc SetJPEGDataFromICC), the `Exif` box minus its 4-byte TIFF offset and the `xml ` box (decode_to_jpeg.cc
+// SetExif / SetXmp); sizes must match what the markers announce.  *_brob: the box arrived Brotli-compressed (`brob`).
+struct JpegMetadataSources {
+  const uint8_t* icc = nullptr; size_t icc_size = 0;
+  const uint8_t* exif = nullptr; size_t exif_size = 0; bool exif_brob = false;
+  const uint8_t* xml = nullptr; size_t xml_size = 0; bool xml_brob = false;
+};
+bool FillJpegMetadata(JpegData* jd, const JpegMetadataSources& src, std::string* err);
 
 // Serialises the JPEG: markers in jbrd order, quantisation tables as filled in by the caller (jd.quant[i].values), entropy-coded
 // scans from the quantised coefficients.  coeffs[c]: (mcu_rows * v_samp) x (mcu_cols * h_samp) x 64 int16 in natural order for component

@@ -473,6 +473,12 @@ int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap)
         for (int k = 0; k < 17; k++) if (p.qspec[k].mode != 0) { snprintf(line, sizeof line, "  qtable kind=%d mode=%u raw_den=%g\n", k, p.qspec[k].mode, p.qspec[k].raw_den); s += line; }
       }
     }
+    if (b.image(0).has_jbrd) {
+      // the host half of the JPEG-reconstruction check: jbrd parses, the ICC / Exif / XMP markers find their payloads
+      std::string why;
+      const bool ok = b.CanReconstructJpeg(0, &why);
+      s += ok ? std::string("jpeg_reconstruction=1\n") : "jpeg_reconstruction=0 reason: " + why + "\n";
+    }
     if (out && cap) { const size_t n = std::min(cap - 1, s.size()); memcpy(out, s.data(), n); out[n] = 0; }
     return 0;
   } catch (const std::exception& e) { SetLastError(e.what()); return 1; }

@@ -202,7 +202,7 @@ def brotli_compress(data: bytes) -> bytes:
     return out.raw[:cap.value]
 
 
-def build_jbrd(j: Jpeg) -> bytes:
+def build_jbrd(j: Jpeg, typed_metadata=False) -> bytes:
     """jbrd box payload for a parsed JPEG (field order of JPEGData::VisitFields; validated against the parser of the product, which in
     turn reads the reference's samples/sample_jpg.jxl)."""
     b = _Bits()
@@ -211,7 +211,8 @@ def build_jbrd(j: Jpeg) -> bytes:
     for m in j.marker_order:
         b.u(m - 0xC0, 6)
     for a in j.app_data:
-        b.u32(0, [(0, 0), (0, 1), (1, 2), (2, 4)])        # unknown type: the payload travels in the Brotli stream
+        # type 0: the payload travels in the Brotli stream; 1 / 2 / 3: ICC chunk / Exif / XMP, kept in the codestream / `Exif` / `xml ` box
+        b.u32(app_type(a) if typed_metadata else 0, [(0, 0), (0, 1), (1, 2), (2, 4)])
         b.u(len(a) - 1, 16)
     for c in j.com_data:
         b.u(len(c) - 1, 16)
@@ -261,20 +262,52 @@ def build_jbrd(j: Jpeg) -> bytes:
         b.u(len(j.padding_bits), 24)
         for bit in j.padding_bits:
             b.u(bit, 1)
-    plain = b"".join(j.app_data) + b"".join(j.com_data) + j.tail_data
+    plain = b"".join(a for a in j.app_data if not (typed_metadata and app_type(a))) + b"".join(j.com_data) + j.tail_data
     return b.bytes() + (brotli_compress(plain) if plain else b"")
 
 
-def container(jbrd: bytes, codestream: bytes) -> bytes:
+ICC_TAG, EXIF_TAG, XMP_TAG = b"ICC_PROFILE\0", b"Exif\0\0", b"http://ns.adobe.com/xap/1.0/\0"
+
+
+def app_type(a: bytes) -> int:
+    """jpeg_data.h AppMarkerType of an APPn marker (marker byte, length, payload): 1 ICC chunk, 2 Exif, 3 XMP, 0 anything else."""
+    if a[0] == 0xE2 and a[3:3 + len(ICC_TAG)] == ICC_TAG and len(a) >= 17:
+        return 1
+    if a[0] == 0xE1 and a[3:3 + len(EXIF_TAG)] == EXIF_TAG:
+        return 2
+    if a[0] == 0xE1 and a[3:3 + len(XMP_TAG)] == XMP_TAG:
+        return 3
+    return 0
+
+
+def container(jbrd: bytes, codestream: bytes, exif: bytes = None, xmp: bytes = None, compress_boxes=False, jbrd_last=False) -> bytes:
+    """ISO BMFF container as cjxl lays a JPEG transcode out; exif = TIFF data (the box adds the 4-byte offset), xmp = the packet;
+    compress_boxes wraps them in `brob` boxes (cjxl's default)."""
     def box(t, payload):
         return struct.pack(">I4s", 8 + len(payload), t) + payload
-    return b"\x00\x00\x00\x0cJXL \r\n\x87\n" + box(b"ftyp", b"jxl \x00\x00\x00\x00jxl ") + box(b"jbrd", jbrd) + box(b"jxlc", codestream)
+
+    def meta(t, payload):
+        return box(b"brob", t + brotli_compress(payload)) if compress_boxes else box(t, payload)
+    out = b"\x00\x00\x00\x0cJXL \r\n\x87\n" + box(b"ftyp", b"jxl \x00\x00\x00\x00jxl ")
+    boxes = []
+    if exif is not None:
+        boxes.append(meta(b"Exif", b"\0\0\0\0" + exif))
+    if xmp is not None:
+        boxes.append(meta(b"xml ", xmp))
+    if jbrd_last:
+        return out + box(b"jxlc", codestream) + b"".join(boxes) + box(b"jbrd", jbrd)
+    return out + b"".join(boxes) + box(b"jbrd", jbrd) + box(b"jxlc", codestream)
 
 
-def transcode(jpeg_bytes: bytes) -> bytes:
-    """JPEG file -> the JPEG XL file of its lossless transcode (container with jbrd + VarDCT codestream)."""
+def transcode(jpeg_bytes: bytes, typed_metadata=False, compress_boxes=False, jbrd_last=False) -> bytes:
+    """JPEG file -> the JPEG XL file of its lossless transcode (container with jbrd + VarDCT codestream).  typed_metadata: the way
+    cjxl stores ICC / Exif / XMP — the ICC profile in the codestream's image header, Exif / XMP in their own boxes, and only their
+    marker sizes in jbrd (otherwise all APPn payloads ride in jbrd's Brotli stream)."""
     import synth_lib as S
     j = parse_jpeg(jpeg_bytes)
+    icc = b"".join(a[17:] for a in j.app_data if app_type(a) == 1) if typed_metadata else b""
+    exif = next((a[3 + len(EXIF_TAG):] for a in j.app_data if app_type(a) == 2), None) if typed_metadata else None
+    xmp = next((a[3 + len(XMP_TAG):] for a in j.app_data if app_type(a) == 3), None) if typed_metadata else None
     assert len(j.components) == 3, "colour JPEGs only"
     maxh = max(c["h"] for c in j.components); maxv = max(c["v"] for c in j.components)
     mode_of = {(1, 1): 0, (2, 2): 1, (2, 1): 2, (1, 2): 3}
@@ -283,4 +316,9 @@ def transcode(jpeg_bytes: bytes) -> bytes:
     modes = [mode_of[(j.components[i]["h"], j.components[i]["v"])] for i in order]
     planes = [np.ascontiguousarray(j.coef[i].reshape(-1, 64)) for i in order]
     qts = np.ascontiguousarray(np.array([j.qt[j.components[i]["tq"]] for i in order], np.int32))
-    return container(build_jbrd(j), S.jpeg_transcode_codestream(j.width, j.height, modes, planes, qts))
+    S.set_icc(icc)
+    try:
+        cs = S.jpeg_transcode_codestream(j.width, j.height, modes, planes, qts)
+    finally:
+        S.set_icc(b"")
+    return container(build_jbrd(j, typed_metadata), cs, exif, xmp, compress_boxes, jbrd_last)

@@ -1036,3 +1036,46 @@ def test_jpeg_transcodes_of_real_jpegs(jx, case):
     assert d.max() <= 6 and d.mean() < 0.7
     meta, (kind, val) = jx.decoder_builder(init_jpeg_buffer=256).reconstruct(jxl)      # grown through JXL_DEC_JPEG_NEED_MORE_OUTPUT
     assert kind == "jpeg" and val == data
+
+
+@pytest.mark.gpu
+def test_jpeg_transcode_metadata_from_boxes(jx):
+    """The layout cjxl gives a transcoded photo: the ICC profile travels in the codestream's image header, Exif and XMP in their own
+    boxes (Brotli-compressed `brob` boxes by default), and jbrd only records the sizes of the APP1 / APP2 markers (jpeg_data.h
+    AppMarkerType kICC / kExif / kXMP; decode.cc SetJPEGDataFromICC, decode_to_jpeg.cc SetExif / SetXmp).  reconstruct() has to put
+    the markers back — a 150 KB profile spans three APP2 chunks — and give the libjpeg-written file back byte for byte; a file whose
+    boxes do not match what jbrd announces falls back to pixels (decode.rs:507-513) instead of emitting a damaged JPEG."""
+    import io
+    import struct
+    from PIL import Image, ImageCms
+    import jpeg_cases as JC
+    import jpeg_tools as J
+    icc = ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes()
+    icc += bytes(np.random.default_rng(1).integers(0, 255, 150000).astype(np.uint8))
+    ex = Image.Exif()
+    ex[0x010E] = "a test image"
+    ex[0x0131] = "jxl-hip tests"
+    buf = io.BytesIO()
+    Image.fromarray(JC.photo(67, 45)).save(buf, "JPEG", quality=85, subsampling=2, icc_profile=icc, exif=ex.tobytes(),
+                                           xmp=b"<x:xmpmeta xmlns:x='adobe:ns:meta/'><!-- packet --></x:xmpmeta>")
+    data = buf.getvalue()
+    kinds = [J.app_type(a) for a in J.parse_jpeg(data).app_data]
+    assert kinds.count(1) == 3 and 2 in kinds and 3 in kinds
+    for kw in (dict(), dict(compress_boxes=True), dict(compress_boxes=True, jbrd_last=True)):
+        jxl = J.transcode(data, typed_metadata=True, **kw)
+        meta, (kind, val) = jx.decoder_builder().reconstruct(jxl)
+        assert kind == "jpeg" and val == data, kw
+        assert jx.decoder_builder(icc_profile=True).decode_with(jxl, np.uint8)[0].icc_profile == icc
+    check_against_oracle(jx, jxl, np.uint8, 3)
+    # damaged metadata: drop the Exif box / change the size of the xml box -> pixels
+    jxl = J.transcode(data, typed_metadata=True)
+    pos, boxes = 12, []
+    while pos < len(jxl):
+        n, t = struct.unpack(">I4s", jxl[pos:pos + 8])
+        boxes.append((t, jxl[pos:pos + n]))
+        pos += n
+    no_exif = jxl[:12] + b"".join(b for t, b in boxes if t != b"Exif")
+    longer = jxl[:12] + b"".join(struct.pack(">I4s", len(b) + 1, t) + b[8:] + b" " if t == b"xml " else b for t, b in boxes)
+    for bad in (no_exif, longer):
+        meta, (kind, val) = jx.decoder_builder().reconstruct(bad)
+        assert kind == "pixels" and val.dtype == np.uint8 and len(val) == 67 * 45 * 3

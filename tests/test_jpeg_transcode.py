@@ -62,3 +62,35 @@ def test_oracle_pixels_of_transcode_match_libjpeg(case):
     ref = JC.pil_pixels(data)
     d = np.abs(px - ref)
     assert d.max() <= 6 and d.mean() < 0.7, (int(d.max()), float(d.mean()))      # float IDCT + one rounding vs libjpeg's integer pipeline
+
+
+def test_metadata_markers_from_boxes_host_half(jx):
+    """cjxl's layout for ICC / Exif / XMP (profile in the image header, `Exif` / `xml ` boxes, plain or `brob`): the host half of
+    reconstruct() — jbrd parse + marker rebuild — accepts matching boxes and names the reason when they do not match."""
+    import struct
+    from PIL import Image, ImageCms
+    icc = ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes() + bytes(range(256)) * 300
+    ex = Image.Exif()
+    ex[0x010E] = "a test image"
+    buf = io.BytesIO()
+    Image.fromarray(JC.photo(40, 50)).save(buf, "JPEG", quality=85, subsampling=2, icc_profile=icc, exif=ex.tobytes(), xmp=b"<x:xmpmeta xmlns:x='adobe:ns:meta/'/>")
+    data = buf.getvalue()
+
+    def describe(jxl):
+        L = jx.libjxl()
+        L.JxlHipDebugDescribe.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        out = C.create_string_buffer(1 << 16)
+        assert L.JxlHipDebugDescribe(jxl, len(jxl), out, len(out)) == 0, jx.last_error()
+        return out.value.decode()
+    for kw in (dict(), dict(compress_boxes=True), dict(jbrd_last=True)):
+        d = describe(J.transcode(data, typed_metadata=True, **kw))
+        assert "jpeg_reconstruction=1" in d and "icc=%d" % len(icc) in d, d
+    assert "jpeg_reconstruction=1" in describe(J.transcode(data))          # everything inside jbrd
+    jxl = J.transcode(data, typed_metadata=True)
+    pos, boxes = 12, []
+    while pos < len(jxl):
+        n, t = struct.unpack(">I4s", jxl[pos:pos + 8])
+        boxes.append((t, jxl[pos:pos + n]))
+        pos += n
+    assert "Exif marker without an Exif box" in describe(jxl[:12] + b"".join(b for t, b in boxes if t != b"Exif"))
+    assert "XMP size mismatch" in describe(jxl[:12] + b"".join(struct.pack(">I4s", len(b) + 1, t) + b[8:] + b" " if t == b"xml " else b for t, b in boxes))
