@@ -1303,8 +1303,7 @@ bool Batch::CanReconstructJpeg(int i, std::string* why) {
     src.xml = bx.have_xml ? bx.xml.data() : nullptr; src.xml_size = bx.xml.size(); src.xml_brob = bx.xml_brob;
     if (!FillJpegMetadata(jd.get(), src, &err)) { if (why) *why = err; return false; }
     if (jd->components.size() != 3 && jd->components.size() != 1) return no("component count");
-    for (auto& s : jd->scan_info) if (!(s.Ss == 0 && s.Se == 63 && s.Al == 0 && s.Ah == 0)) return no("unsupported: progressive JPEG scan script");
-    for (uint8_t m : jd->marker_order) if (m == 0xC2 || m == 0xCA) return no("unsupported: progressive JPEG");
+    for (uint8_t m : jd->marker_order) if (m == 0xC9 || m == 0xCA) return no("unsupported: arithmetic-coded JPEG");
     jpeg_data_[i] = std::move(jd);
   }
   return true;

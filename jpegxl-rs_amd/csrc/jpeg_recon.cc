@@ -281,6 +281,111 @@ struct BitWriter {
   }
 };
 
+// dec_jpeg_data_writer.cc DCTCodingState: the end-of-band run and the correction bits waiting for it (progressive scans)
+struct EobState {
+  uint32_t eob_run = 0;
+  const HuffTable* ac = nullptr;
+  vec<uint8_t> bits;
+  void Flush(BitWriter& w) {
+    if (eob_run > 0) {
+      int nbits = 0;
+      while ((eob_run >> (nbits + 1)) != 0) nbits++;
+      w.Symbol(nbits << 4, *ac);
+      if (nbits > 0) w.Put(eob_run & ((1u << nbits) - 1), nbits);
+      eob_run = 0;
+    }
+    for (uint8_t b : bits) w.Put(b, 1);
+    bits.clear();
+  }
+  void BufferEndOfBand(BitWriter& w, const HuffTable* table, const vec<uint8_t>* new_bits) {
+    if (eob_run == 0) ac = table;
+    eob_run++;
+    if (new_bits) bits.insert(bits.end(), new_bits->begin(), new_bits->end());
+    if (eob_run == 0x7FFF || bits.size() > (1u << 16) - 64 + 1) Flush(w);
+  }
+};
+
+// EncodeDCTBlockProgressive: first pass over a spectral band at precision Al (DC difference when the band starts at 0)
+bool EncodeBlockProgressive(const int16_t* c, const HuffTable& dct, const HuffTable& act, int Ss, int Se, int Al, int num_zero_runs, EobState& st, int* last_dc, BitWriter& w) {
+  const bool eob_run_allowed = Ss > 0;
+  if (Ss == 0) {
+    int temp2 = c[0] >> Al, temp = temp2 - *last_dc;
+    *last_dc = temp2;
+    temp2 = temp;
+    if (temp < 0) { temp = -temp; temp2--; }
+    int nbits = 0;
+    while ((temp >> nbits) != 0) nbits++;
+    if (nbits >= 13) return false;
+    w.Symbol(nbits, dct);
+    if (nbits > 0) w.Put((uint32_t)temp2 & ((1u << nbits) - 1), nbits);
+    Ss++;
+  }
+  if (Ss > Se) return true;
+  int r = 0;
+  for (int k = Ss; k <= Se; k++) {
+    int temp = c[kNaturalOrder[k]], temp2;
+    if (temp == 0) { r++; continue; }
+    if (temp < 0) { temp = -temp; temp >>= Al; temp2 = ~temp; } else { temp >>= Al; temp2 = temp; }
+    if (temp == 0) { r++; continue; }
+    st.Flush(w);
+    while (r > 15) { w.Symbol(0xF0, act); r -= 16; }
+    int nbits = 0;
+    while ((temp >> nbits) != 0) nbits++;
+    if (nbits >= 16) return false;
+    w.Symbol((r << 4) + nbits, act);
+    w.Put((uint32_t)temp2 & ((1u << nbits) - 1), nbits);
+    r = 0;
+  }
+  if (num_zero_runs > 0) {
+    st.Flush(w);
+    for (int i = 0; i < num_zero_runs; i++) { w.Symbol(0xF0, act); r -= 16; }
+  }
+  if (r > 0) {
+    st.BufferEndOfBand(w, &act, nullptr);
+    if (!eob_run_allowed) st.Flush(w);
+  }
+  return true;
+}
+
+// EncodeRefinementBits: one more bit of precision for a band (successive approximation, Ah > 0)
+bool EncodeBlockRefinement(const int16_t* c, const HuffTable& act, int Ss, int Se, int Al, EobState& st, BitWriter& w) {
+  const bool eob_run_allowed = Ss > 0;
+  if (Ss == 0) { w.Put((uint32_t)(c[0] >> Al) & 1u, 1); Ss++; }
+  if (Ss > Se) return true;
+  int abs_values[64];
+  int eob = 0;
+  for (int k = Ss; k <= Se; k++) {
+    const int v = c[kNaturalOrder[k]];
+    abs_values[k] = (v < 0 ? -v : v) >> Al;
+    if (abs_values[k] == 1) eob = k;
+  }
+  int r = 0;
+  vec<uint8_t> refinement;
+  refinement.reserve(64);
+  for (int k = Ss; k <= Se; k++) {
+    if (abs_values[k] == 0) { r++; continue; }
+    while (r > 15 && k <= eob) {
+      st.Flush(w);
+      w.Symbol(0xF0, act);
+      r -= 16;
+      for (uint8_t b : refinement) w.Put(b, 1);
+      refinement.clear();
+    }
+    if (abs_values[k] > 1) { refinement.push_back((uint8_t)(abs_values[k] & 1)); continue; }
+    st.Flush(w);
+    w.Symbol((r << 4) + 1, act);
+    w.Put(c[kNaturalOrder[k]] < 0 ? 0u : 1u, 1);
+    for (uint8_t b : refinement) w.Put(b, 1);
+    refinement.clear();
+    r = 0;
+  }
+  if (r > 0 || !refinement.empty()) {
+    st.BufferEndOfBand(w, &act, &refinement);
+    if (!eob_run_allowed) st.Flush(w);
+  }
+  return true;
+}
+
 }  // namespace
 
 bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, vec<uint8_t>* out, std::string* err) {
@@ -293,10 +398,11 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
   uint32_t max_h = 1, max_v = 1;
   for (auto& c : jd.components) { if (c.h_samp < 1 || c.h_samp > 4 || c.v_samp < 1 || c.v_samp > 4) return fail("bad sampling factor"); max_h = std::max(max_h, c.h_samp); max_v = std::max(max_v, c.v_samp); }
   const uint32_t mcu_cols = (width + 8 * max_h - 1) / (8 * max_h), mcu_rows = (height + 8 * max_v - 1) / (8 * max_v);
-  bool seen_dri = false;
+  bool seen_dri = false, is_progressive = false;
   for (uint8_t m : jd.marker_order) {
     if (m == 0xC0 || m == 0xC1 || m == 0xC2 || m == 0xC9 || m == 0xCA) {
-      if (m == 0xC2 || m == 0xCA) return fail("unsupported: progressive JPEG");
+      if (m == 0xC9 || m == 0xCA) return fail("unsupported: arithmetic-coded JPEG");
+      is_progressive = m == 0xC2;
       const size_t n = jd.components.size(), len = 8 + 3 * n;
       const uint8_t hdr[9] = {0xFF, m, (uint8_t)(len >> 8), (uint8_t)len, 8, (uint8_t)(height >> 8), (uint8_t)height, (uint8_t)(width >> 8), (uint8_t)width};
       out->insert(out->end(), hdr, hdr + 9);
@@ -349,7 +455,10 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
     } else if (m == 0xDA) {
       if (scan_i >= jd.scan_info.size()) return fail("SOS marker without scan info");
       const JpegScanInfo& s = jd.scan_info[scan_i++];
-      if (!(s.Ss == 0 && s.Se == 63 && s.Al == 0 && s.Ah == 0)) return fail("unsupported: progressive scan script");
+      if (s.Ss > s.Se || s.Se > 63 || s.Al > 13 || s.Ah > 13) return fail("bad scan parameters");
+      if (!is_progressive && !(s.Ss == 0 && s.Se == 63 && s.Al == 0 && s.Ah == 0)) return fail("spectral selection in a sequential JPEG");
+      const int mode = s.Ah != 0 ? 2 : is_progressive ? 1 : 0;    // EncodeScan<kMode>: sequential, progressive first pass, refinement
+      EobState eob_state;
       const size_t len = 6 + 2 * s.num_components;
       out->push_back(0xFF); out->push_back(0xDA); out->push_back((uint8_t)(len >> 8)); out->push_back((uint8_t)len); out->push_back((uint8_t)s.num_components);
       for (uint32_t i = 0; i < s.num_components; i++) {
@@ -374,6 +483,7 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
       }
       for (uint32_t my = 0; my < scan_rows; my++) for (uint32_t mx = 0; mx < scan_cols; mx++) {
         if (restart_interval > 0 && restarts_to_go == 0) {
+          eob_state.Flush(w);
           if (!w.Pad(jd, &pad_pos)) return fail("padding bits exhausted");
           out->push_back(0xFF); out->push_back((uint8_t)(0xD0 + next_restart));
           next_restart = (next_restart + 1) & 7;
@@ -387,11 +497,19 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
           for (uint32_t iy = 0; iy < nby; iy++) for (uint32_t ix = 0; ix < nbx; ix++) {
           const HuffTable& dct = dc_tab[sc.dc_tbl_idx & 3];
           const HuffTable& act = ac_tab[sc.ac_tbl_idx & 3];
-          if (!dct.init || !act.init) return fail("scan uses an undefined Huffman table");
-          if (reset_pos < s.reset_points.size() && s.reset_points[reset_pos] == block_scan_index) reset_pos++;   // (only matters for progressive EOB runs)
+          if ((s.Ss == 0 && s.Ah == 0 && !dct.init) || (s.Se > 0 && !act.init)) return fail("scan uses an undefined Huffman table");
+          if (reset_pos < s.reset_points.size() && s.reset_points[reset_pos] == block_scan_index) { eob_state.Flush(w); reset_pos++; }   // the original file ended its EOB run here
           int num_zero_runs = 0;
           if (ezr_pos < s.extra_zero_runs.size() && s.extra_zero_runs[ezr_pos].first == block_scan_index) num_zero_runs = (int)s.extra_zero_runs[ezr_pos++].second;
           const int16_t* c = coeffs[sc.comp_idx] + ((size_t)(my * nby + iy) * comp_bw + (mx * nbx + ix)) * 64;
+          if (mode != 0) {
+            const bool ok = mode == 1 ? EncodeBlockProgressive(c, dct, act, (int)s.Ss, (int)s.Se, (int)s.Al, num_zero_runs, eob_state, &last_dc[sc.comp_idx], w)
+                                      : EncodeBlockRefinement(c, act, (int)s.Ss, (int)s.Se, (int)s.Al, eob_state, w);
+            if (!ok) return fail("coefficient out of range");
+            if (!w.ok) return fail("symbol without a Huffman code");
+            block_scan_index++;
+            continue;
+          }
           // EncodeDCTBlockSequential
           int temp2 = c[0], temp = temp2 - last_dc[sc.comp_idx];
           last_dc[sc.comp_idx] = temp2;
@@ -423,6 +541,8 @@ bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_
         }
         if (restart_interval > 0) restarts_to_go--;
       }
+      eob_state.Flush(w);
+      if (!w.ok) return fail("symbol without a Huffman code");
       if (!w.Pad(jd, &pad_pos)) return fail("padding bits exhausted");
     } else if (m == 0xD9) {
       out->push_back(0xFF); out->push_back(0xD9);

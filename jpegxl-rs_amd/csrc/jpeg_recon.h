@@ -55,7 +55,7 @@ bool FillJpegMetadata(JpegData* jd, const JpegMetadataSources& src, std::string*
 // Serialises the JPEG: markers in jbrd order, quantisation tables as filled in by the caller (jd.quant[i].values), entropy-coded
 // scans from the quantised coefficients.  coeffs[c]: (mcu_rows * v_samp) x (mcu_cols * h_samp) x 64 int16 in natural order for component
 // c, the MCU grid being ceil(size / (8 * max sampling factor)); sampling factors from jd.components (set by the caller from the frame header).
-// Sequential (baseline / extended) scans are supported; progressive scan scripts return false.
+// Sequential (baseline / extended) and progressive (spectral selection, successive approximation, EOB runs) Huffman scans.
 bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, vec<uint8_t>* out, std::string* err);
 
 }  // namespace jxlhip

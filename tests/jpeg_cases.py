@@ -15,6 +15,24 @@ CASES = [
     (2100, 24, 2, 70, {}),                      # two LF groups wide
 ]
 
+# progressive files (libjpeg's default scan script: spectral selection + successive approximation, 10 scans); "gratings" is built so
+# that whole rows of blocks only carry correction bits in the refinement scans: libjpeg ends its end-of-band runs after 937 such bits,
+# which the reconstruction data records as reset points
+PROGRESSIVE = [
+    (67, 45, 2, 85, dict(progressive=True)),
+    (64, 64, 0, 75, dict(progressive=True)),
+    (130, 77, 1, 95, dict(progressive=True, optimize=True)),
+    (100, 60, 2, 80, dict(progressive=True, restart_marker_blocks=3)),
+    (300, 280, 2, 88, dict(progressive=True)),
+    (1024, 256, 0, 90, dict(progressive=True, image="gratings")),
+]
+
+
+def gratings(w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    g = 128 + 60 * np.cos((2 * x + 1) * np.pi / 16) + 40 * np.cos((2 * x + 1) * 3 * np.pi / 16) + 30 * np.cos((2 * y + 1) * 2 * np.pi / 16)
+    return np.clip(np.stack([g, g, g], -1), 0, 255).astype(np.uint8)
+
 
 def photo(w, h, seed=3):
     rng = np.random.default_rng(seed)
@@ -26,8 +44,10 @@ def photo(w, h, seed=3):
 def jpeg_bytes(case):
     from PIL import Image
     w, h, ss, q, kw = case
+    kw = dict(kw)
+    img = gratings(w, h) if kw.pop("image", None) == "gratings" else photo(w, h, seed=w + h)
     buf = io.BytesIO()
-    Image.fromarray(photo(w, h, seed=w + h)).save(buf, "JPEG", quality=q, subsampling=ss, **kw)
+    Image.fromarray(img).save(buf, "JPEG", quality=q, subsampling=ss, **kw)
     return buf.getvalue()
 
 

@@ -62,7 +62,7 @@ def parse_jpeg(data: bytes) -> Jpeg:
                 j.huff.append(dict(is_ac=cls, id=idx, is_last=False, counts=counts, values=vals))
                 p += 17 + n
             j.huff[-1]["is_last"] = True
-        elif m in (0xC0, 0xC1):
+        elif m in (0xC0, 0xC1, 0xC2):
             prec, j.height, j.width, nc = struct.unpack(">BHHB", seg[:6])
             assert prec == 8
             j.components = [dict(id=seg[6 + 3 * i], h=seg[7 + 3 * i] >> 4, v=seg[7 + 3 * i] & 15, tq=seg[8 + 3 * i]) for i in range(nc)]
@@ -76,9 +76,11 @@ def parse_jpeg(data: bytes) -> Jpeg:
                 cid, tabs = seg[1 + 2 * i], seg[2 + 2 * i]
                 comps.append(([c["id"] for c in j.components].index(cid), tabs >> 4, tabs & 15))
             ss, se, ahal = seg[1 + 2 * ns:4 + 2 * ns]
-            assert (ss, se, ahal) == (0, 63, 0), "progressive scans are not handled"
-            end = _decode_scan(j, data, pos + 2 + ln, comps, dc_tab, ac_tab)
-            j.scans.append(dict(comps=comps))
+            scan = dict(comps=comps, ss=ss, se=se, ah=ahal >> 4, al=ahal & 15, reset_points=[])
+            if j.sof != 0xC2:
+                assert (ss, se, ahal) == (0, 63, 0)
+            end = _decode_scan(j, data, pos + 2 + ln, scan, dc_tab, ac_tab)
+            j.scans.append(scan)
             pos = end
             continue
         else:
@@ -98,7 +100,9 @@ def _huff_lut(counts, vals):
     return lut
 
 
-def _decode_scan(j, data, pos, comps, dc_tab, ac_tab):
+def _decode_scan(j, data, pos, scan, dc_tab, ac_tab):
+    comps, ss, se, ah, al = scan["comps"], scan["ss"], scan["se"], scan["ah"], scan["al"]
+    progressive = j.sof == 0xC2
     maxh = max(c["h"] for c in j.components); maxv = max(c["v"] for c in j.components)
     mcux = -(-j.width // (8 * maxh)); mcuy = -(-j.height // (8 * maxv))
     if not hasattr(j, "coef"):
@@ -140,6 +144,106 @@ def _decode_scan(j, data, pos, comps, dc_tab, ac_tab):
         return v if n == 0 or v >= (1 << (n - 1)) else v - (1 << n) + 1
     last_dc = [0] * len(j.components)
     togo = j.restart_interval
+    # progressive scans (T.81 G.1.2; jdphuff.c) + what the canonical writer of the reconstruction side (dec_jpeg_data_writer.cc) would have
+    # pending at every block: its end-of-band run and correction bits — where the file starts a new run although that writer would
+    # have extended the old one (libjpeg flushes after 937 correction bits, the canonical writer after 65473), jbrd gets a reset point
+    eobrun = [0]
+    canon = dict(run=0, bits=0)
+    block_index = [0]
+
+    def canon_flush():
+        canon["run"] = 0; canon["bits"] = 0
+
+    def canon_end_of_band(nbits):
+        canon["run"] += 1; canon["bits"] += nbits
+        if canon["run"] == 0x7FFF or canon["bits"] > (1 << 16) - 64 + 1:
+            canon_flush()
+
+    def prog_block(blk, ci, dct, act):
+        p1 = 1 << al
+        if ss == 0:
+            if ah == 0:
+                s = decode(dc_tab[dct])
+                last_dc[ci] += extend(receive(s), s)
+                blk[0] = last_dc[ci] * p1
+            elif getbit():
+                blk[0] |= p1
+            assert se == 0, "progressive DC scans carry no AC coefficients"
+            return
+        k = ss
+        symbols = 0                                           # coefficient / ZRL symbols of this block so far
+        tail_bits = 0                                         # correction bits since the last symbol
+        if ah == 0:
+            if eobrun[0] > 0:
+                eobrun[0] -= 1
+                canon_end_of_band(0)
+                return
+            while k <= se:
+                rs = decode(ac_tab[act]); r, s = rs >> 4, rs & 15
+                if s == 0 and r < 15:
+                    if symbols == 0 and canon["run"] > 0:
+                        scan["reset_points"].append(block_index[0]); canon_flush()
+                    eobrun[0] = (1 << r) + (receive(r) if r else 0) - 1
+                    break
+                if symbols == 0:
+                    canon_flush()
+                symbols += 1
+                if s == 0:
+                    k += 16; continue
+                k += r
+                blk[ZIGZAG[k]] = extend(receive(s), s) * p1
+                k += 1
+            assert k <= se + 1
+            if k <= se:
+                canon_end_of_band(0)
+            return
+        m1 = -p1
+        if eobrun[0] == 0:
+            while k <= se:
+                rs = decode(ac_tab[act]); r, s = rs >> 4, rs & 15
+                val = 0
+                if s:
+                    assert s == 1
+                    val = p1 if getbit() else m1
+                elif r < 15:
+                    if symbols == 0 and canon["run"] > 0:
+                        scan["reset_points"].append(block_index[0]); canon_flush()
+                    eobrun[0] = (1 << r) + (receive(r) if r else 0)
+                    break
+                if symbols == 0:
+                    canon_flush()
+                symbols += 1
+                tail_bits = 0
+                while k <= se:
+                    c = int(blk[ZIGZAG[k]])
+                    if c != 0:
+                        tail_bits += 1
+                        if getbit() and (c & p1) == 0:
+                            blk[ZIGZAG[k]] = c + (p1 if c >= 0 else m1)
+                    else:
+                        if r == 0:
+                            break
+                        r -= 1
+                    k += 1
+                # (the correction bits read while skipping belong to this symbol: the writer emits them right after it)
+                tail_bits = 0
+                if s:
+                    blk[ZIGZAG[k]] = val
+                k += 1
+        ended_in_run = False
+        if eobrun[0] > 0:
+            while k <= se:
+                c = int(blk[ZIGZAG[k]])
+                if c != 0:
+                    tail_bits += 1
+                    if getbit() and (c & p1) == 0:
+                        blk[ZIGZAG[k]] = c + (p1 if c >= 0 else m1)
+                k += 1
+            eobrun[0] -= 1
+            ended_in_run = True
+        if ended_in_run:
+            canon_end_of_band(tail_bits)
+
     for my in range(rows):
         for mx in range(cols):
             if j.restart_interval and togo == 0:
@@ -147,13 +251,21 @@ def _decode_scan(j, data, pos, comps, dc_tab, ac_tab):
                     j.padding_bits.append(getbit())
                 assert data[state["pos"]] == 0xFF and 0xD0 <= data[state["pos"] + 1] <= 0xD7
                 state["pos"] += 2; state["n"] = 0
-                last_dc = [0] * len(j.components); togo = j.restart_interval
+                for i in range(len(last_dc)):
+                    last_dc[i] = 0
+                togo = j.restart_interval
+                assert eobrun[0] == 0
+                canon_flush()
             for ci, dct, act in comps:
                 c = j.components[ci]
                 for iy in range(c["v"] if inter else 1):
                     for ix in range(c["h"] if inter else 1):
                         by = my * (c["v"] if inter else 1) + iy; bx = mx * (c["h"] if inter else 1) + ix
                         blk = j.coef[ci][by, bx]
+                        if progressive:
+                            prog_block(blk, ci, dct, act)
+                            block_index[0] += 1
+                            continue
                         s = decode(dc_tab[dct])
                         last_dc[ci] += extend(receive(s), s)
                         blk[0] = last_dc[ci]
@@ -168,6 +280,7 @@ def _decode_scan(j, data, pos, comps, dc_tab, ac_tab):
                             k += r
                             blk[ZIGZAG[k]] = extend(receive(s), s)
                             k += 1
+                        assert k <= 64, "zero run past the block (extra zero runs are not handled)"
             if j.restart_interval:
                 togo -= 1
     for _ in range(state["n"]):
@@ -245,15 +358,20 @@ def build_jbrd(j: Jpeg, typed_metadata=False) -> bytes:
             b.u32(v, [(2, 0), (2, 4), (4, 8), (8, 1)])
     for s in j.scans:
         b.u32(len(s["comps"]), [(0, 1), (0, 2), (0, 3), (0, 4)])
-        b.u(0, 6); b.u(63, 6); b.u(0, 4); b.u(0, 4)
+        b.u(s.get("ss", 0), 6); b.u(s.get("se", 63), 6); b.u(s.get("al", 0), 4); b.u(s.get("ah", 0), 4)
         for ci, dct, act in s["comps"]:
             b.u(ci, 2); b.u(act, 2); b.u(dct, 2)
         b.u32(0, [(0, 0), (0, 1), (0, 2), (3, 3)])          # last_needed_pass
     if 0xDD in j.marker_order:
         b.u(j.restart_interval, 16)
     for s in j.scans:
-        b.u32(0, [(0, 0), (2, 1), (4, 4), (16, 20)])        # reset points
-        b.u32(0, [(0, 0), (2, 1), (4, 4), (16, 20)])        # extra zero runs
+        rp = s.get("reset_points", [])
+        b.u32(len(rp), [(0, 0), (2, 1), (4, 4), (16, 20)])  # reset points: blocks before which the file's writer ended an end-of-band run
+        last = -1
+        for x in rp:
+            b.u32(x - last - 1, [(0, 0), (3, 1), (5, 9), (28, 41)])
+            last = x
+        b.u32(0, [(0, 0), (2, 1), (4, 4), (16, 20)])        # extra zero runs (libjpeg writes none)
     # (no inter-marker data)
     b.u32(len(j.tail_data), [(0, 0), (8, 1), (16, 257), (22, 65793)])
     zero_pad = any(bit == 0 for bit in j.padding_bits)

@@ -1015,10 +1015,12 @@ def test_chroma_subsampled_ycbcr_frames(jx, sub, w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", __import__("jpeg_cases").CASES, ids=lambda c: "%dx%d_ss%d_q%d" % c[:4])
+@pytest.mark.parametrize("case", __import__("jpeg_cases").CASES + __import__("jpeg_cases").PROGRESSIVE,
+                         ids=lambda c: "%dx%d_ss%d_q%d%s" % (c[:4] + ("_progressive" if c[4].get("progressive") else "",)))
 def test_jpeg_transcodes_of_real_jpegs(jx, case):
     """decode.rs:493-514 `reconstruct` on JPEG XL files that stand for lossless transcodes of real JPEGs: Pillow's libjpeg writes the
-    JPEG (4:4:4 / 4:2:2 / 4:2:0, optimised tables, restart intervals, COM marker), tests/jpeg_tools.py turns it into jbrd box + VarDCT
+    JPEG (4:4:4 / 4:2:2 / 4:2:0, optimised tables, restart intervals, COM marker; baseline and progressive scan scripts), tests/jpeg_tools.py
+    turns it into jbrd box + VarDCT
     codestream (RAW quantisation tables, subsampled chroma grids).  reconstruct() must give back the JPEG byte for byte — entropy stages
     on the GPU, per-component coefficient planes (JpegCoefKernel), MCU interleave with the sampling factors from the frame header — and
     the pixel path must match the oracle bit for bit and libjpeg's own decode of the JPEG within integer-IDCT distance."""
