@@ -54,3 +54,11 @@ def jpeg_bytes(case):
 def pil_pixels(data):
     from PIL import Image
     return np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)
+
+
+def grey_jpeg_bytes(w, h, quality, **kw):
+    """One-component JPEG of the first channel of photo()."""
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(photo(w, h, seed=w + h)[:, :, 0]).save(buf, "JPEG", quality=quality, **kw)
+    return buf.getvalue()

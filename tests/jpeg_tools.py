@@ -426,7 +426,16 @@ def transcode(jpeg_bytes: bytes, typed_metadata=False, compress_boxes=False, jbr
     icc = b"".join(a[17:] for a in j.app_data if app_type(a) == 1) if typed_metadata else b""
     exif = next((a[3 + len(EXIF_TAG):] for a in j.app_data if app_type(a) == 2), None) if typed_metadata else None
     xmp = next((a[3 + len(XMP_TAG):] for a in j.app_data if app_type(a) == 3), None) if typed_metadata else None
-    assert len(j.components) == 3, "colour JPEGs only"
+    if len(j.components) == 1:
+        # a grey JPEG: grey image header over a three-channel YCbCr frame whose chroma channels are empty (enc_jpeg_data.cc)
+        S.set_icc(icc)
+        try:
+            qt = np.array([j.qt[j.components[0]["tq"]]] * 3, np.int32)
+            cs = S.jpeg_transcode_codestream(j.width, j.height, [0, 0, 0], [None, j.coef[0].reshape(-1, 64), None], qt)
+        finally:
+            S.set_icc(b"")
+        return container(build_jbrd(j, typed_metadata), cs, exif, xmp, compress_boxes, jbrd_last)
+    assert len(j.components) == 3
     maxh = max(c["h"] for c in j.components); maxv = max(c["v"] for c in j.components)
     mode_of = {(1, 1): 0, (2, 2): 1, (2, 1): 2, (1, 2): 3}
     # jxl channel order is Cb, Y, Cr = JPEG components 1, 0, 2; a channel's mode is its sampling factor relative to the others

@@ -223,9 +223,10 @@ def jpeg_transcode_codestream(w, h, modes, planes, qts):
     L = lib()
     L.jxlsynth_jpeg_transcode.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     m = (C.c_int32 * 3)(*modes)
-    pl = [np.ascontiguousarray(p, dtype=np.int16) for p in planes]
+    pl = [None if p is None else np.ascontiguousarray(p, dtype=np.int16) for p in planes]     # Cb = Cr = None: a grey JPEG
     q = np.ascontiguousarray(qts, dtype=np.int32)
     out = C.c_void_p(); n = C.c_size_t()
-    if L.jxlsynth_jpeg_transcode(w, h, m, pl[0].ctypes.data, pl[1].ctypes.data, pl[2].ctypes.data, q.ctypes.data, C.byref(out), C.byref(n)):
+    ptr = [None if p is None else p.ctypes.data for p in pl]
+    if L.jxlsynth_jpeg_transcode(w, h, m, ptr[0], ptr[1], ptr[2], q.ctypes.data, C.byref(out), C.byref(n)):
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)

@@ -1081,3 +1081,23 @@ def test_jpeg_transcode_metadata_from_boxes(jx):
     for bad in (no_exif, longer):
         meta, (kind, val) = jx.decoder_builder().reconstruct(bad)
         assert kind == "pixels" and val.dtype == np.uint8 and len(val) == 67 * 45 * 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(progressive=True), dict(restart_marker_rows=1)], ids=["baseline", "progressive", "restarts"])
+def test_grey_jpeg_transcodes(jx, kw):
+    """One-component JPEGs written by libjpeg: reconstruct() == the file, grey pixels == oracle (and within 2 of libjpeg's decode)."""
+    import io
+    from PIL import Image
+    import jpeg_cases as JC
+    import jpeg_tools as J
+    for (w, h) in ((75, 52), (300, 270)):
+        data = JC.grey_jpeg_bytes(w, h, 85, **kw)
+        jxl = J.transcode(data)
+        meta, (kind, val) = jx.decoder_builder().reconstruct(jxl)
+        assert kind == "jpeg" and val == data
+        check_against_oracle(jx, jxl, np.uint8, 1)
+        check_against_oracle(jx, jxl, np.float32, 1)
+        res = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=1)).decode_with(jxl, np.uint8)[1]
+        d = np.abs(np.asarray(res).reshape(h, w).astype(int) - np.asarray(Image.open(io.BytesIO(data))).astype(int))
+        assert d.max() <= 2 and d.mean() < 0.5

@@ -115,3 +115,16 @@ def test_metadata_markers_from_boxes_host_half(jx):
         pos += n
     assert "Exif marker without an Exif box" in describe(jxl[:12] + b"".join(b for t, b in boxes if t != b"Exif"))
     assert "XMP size mismatch" in describe(jxl[:12] + b"".join(struct.pack(">I4s", len(b) + 1, t) + b[8:] + b" " if t == b"xml " else b for t, b in boxes))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(progressive=True), dict(restart_marker_rows=1)], ids=["baseline", "progressive", "restarts"])
+def test_grey_jpegs(jx, kw):
+    """One-component JPEGs: a grey image header over a YCbCr frame whose chroma channels are empty; the writer takes component 0 from
+    the Y channel.  Bytes back from the host writer; the oracle's grey pixels against libjpeg's."""
+    from PIL import Image
+    data = JC.grey_jpeg_bytes(75, 52, 85, **kw)
+    j = J.parse_jpeg(data)
+    assert len(j.components) == 1 and _write(jx, j, J.build_jbrd(j)) == data
+    px = np.frombuffer(O.decode(J.transcode(data)).pixels("u8", 1), np.uint8).reshape(52, 75).astype(int)
+    d = np.abs(px - np.asarray(Image.open(io.BytesIO(data))).astype(int))
+    assert d.max() <= 2 and d.mean() < 0.5

@@ -1330,7 +1330,10 @@ int jxlsynth_jpeg_transcode(int w, int h, const int32_t* modes, const int16_t* c
     synth::Params p;
     const int m[3] = {modes[0], modes[1], modes[2]};
     const int16_t* planes[3] = {cb, y, cr};
-    return finish(synth::EncodeJpegTranscode(w, h, m, planes, qt, p), out, n);
+    std::vector<int16_t> zero;
+    const bool gray = !cb && !cr;                       // one-component JPEG: grey image header, empty chroma channels
+    if (gray) { zero.assign((size_t)((w + 7) / 8) * ((h + 7) / 8) * 64, 0); planes[0] = planes[2] = zero.data(); }
+    return finish(synth::EncodeJpegTranscode(w, h, m, planes, qt, p, gray), out, n);
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 // Free-running Modular stream (tools/synth_free.h): feature coverage without an encoder-side simulation of the decoder.

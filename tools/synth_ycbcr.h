@@ -14,6 +14,7 @@ struct YCbCrQuantised {
   uint32_t global_scale = 1, quant_lf = 16;
   bool custom_m_lf = false; float m_lf[3] = {0, 0, 0};
   const int32_t* raw_table = nullptr; float raw_den = 0;   // 3 x 64 (channel, libjxl layout) when the 8x8 DCT uses a RAW table
+  bool gray = false;                      // grey image header (a one-component JPEG: the frame still has three channels, Cb = Cr = 0)
 };
 
 static void YCbCrGeometry(int w, int h, const int mode[3], int hs[3], int vs[3], int* bw, int* bh) {
@@ -169,7 +170,7 @@ static std::vector<uint8_t> WriteYCbCrFrame(const YCbCrQuantised& in, const Para
   Params q = p;
   q.gab = 0; q.epf_iters = 0; q.noise = 0; q.upsampling = 1; q.num_passes = 1; q.skip_lf_smoothing = 1; q.out_bits = 8; q.hdr = 0;
   q.do_ycbcr = 1; for (int c = 0; c < 3; c++) q.jpeg_upsampling[c] = mode[c];
-  WriteImageHeader(out, w, h, q, false, 8, false, false);
+  WriteImageHeader(out, w, h, q, false, 8, false, in.gray);
   WriteFrameHeader(out, q, false, false, 0, 1, false, w, h);
   WriteTOCAndSections(out, sections, ngroups == 1, 0);
   out.align();
@@ -244,9 +245,9 @@ static std::vector<uint8_t> EncodeYCbCr(const uint8_t* rgb8, int w, int h, const
 // they are — DC as the LF image, AC transposed into libjxl's layout — quantiser at unity (global_scale 65536, quant_lf 1, hf_mul 1),
 // LF factors qt[0] / (8 * 255) per channel, the JPEG quantisation tables as a RAW table with denominator 1 / (8 * 255).
 // planes: per jxl channel (Cb, Y, Cr) the component's blocks x 64 coefficients in JPEG natural (row-major) order; qt: 3 x 64, same order.
-static std::vector<uint8_t> EncodeJpegTranscode(int w, int h, const int mode[3], const int16_t* const planes[3], const int32_t* qt, const Params& p) {
+static std::vector<uint8_t> EncodeJpegTranscode(int w, int h, const int mode[3], const int16_t* const planes[3], const int32_t* qt, const Params& p, bool gray = false) {
   YCbCrQuantised in;
-  in.w = w; in.h = h;
+  in.w = w; in.h = h; in.gray = gray;
   int hs[3], vs[3], bw, bh;
   YCbCrGeometry(w, h, mode, hs, vs, &bw, &bh);
   static std::vector<int32_t> raw;
