@@ -94,9 +94,26 @@ DevCode ViewCode(const HostCode& c, const uint8_t* base, size_t ctx, size_t cfg,
 // Colour-transform parameters of an image (stage_xyb.cc OpsinParams, dec_xyb.cc OutputEncodingInfo::SetColorEncoding):
 // inverse opsin matrix scaled to the intensity target — for grey-scale images its rows are replaced by their luminance-weighted
 // sum (kSRGBLuminances; Mul3x3Matrix accumulates in double), so R = G = B — and the output transfer function.
+// sRGB or linear output (colour modes 0 / 1): what the fused gaborish + EPF + output kernel computes; other transfer functions take the
+// unfused filter kernels and OutputKernel
+static bool SimpleTransfer(const ImageHeader& ih) { return ih.color_default || (!ih.have_gamma && (ih.tf == 13 || ih.tf == 8)); }
+
 static void FillColor(const ImageHeader& ih, bool do_ycbcr, FrameDev& f) {
   float inv[9];
   for (int k = 0; k < 9; k++) inv[k] = ih.opsin_inv[k];
+  // images whose header names other primaries / another white point than sRGB / D65: XYB decodes to linear sRGB, the matrix takes it on
+  // to the image's own primaries (icc_profile.cc SrgbToOriginalPrimaries)
+  float luminances[3];
+  double to_original[9];
+  if (SrgbToOriginalPrimaries(ih, to_original, luminances) && ih.xyb_encoded) {
+    float adapted[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+      double e = 0;
+      for (int k = 0; k < 3; k++) e += to_original[i * 3 + k] * (double)inv[k * 3 + j];
+      adapted[i * 3 + j] = (float)e;
+    }
+    for (int k = 0; k < 9; k++) inv[k] = adapted[k];
+  }
   if (ih.color_space == 1) {
     const float lum[3] = {0.2126f, 0.7152f, 0.0722f};
     float folded[9];
@@ -118,6 +135,15 @@ static void FillColor(const ImageHeader& ih, bool do_ycbcr, FrameDev& f) {
       else if (ih.tf == 8) f.color_mode = 1;
       else if (ih.tf == 17) { f.color_mode = 4; f.inverse_gamma = 1.0f / 2.6f; }
       else if (ih.tf == 1) f.color_mode = 5;
+      else if (ih.tf == 16) { f.color_mode = 6; f.hdr_par[0] = ih.intensity_target * (1.0f / 10000.0f); }   // TF_PQ(intensity_target)
+      else if (ih.tf == 18) {
+        // stage_from_linear.cc OpHlg: HlgOOTF::ToSceneLight(display_luminance = intensity target, luminances of the output primaries)
+        f.color_mode = 7;
+        const float gamma = (1 / 1.2f) * std::pow(1.111f, -std::log2(ih.intensity_target / 1000.f));
+        f.hdr_par[0] = gamma - 1;
+        f.hdr_par[1] = (f.hdr_par[0] < -0.01f || 0.01f < f.hdr_par[0]) ? 1.0f : 0.0f;
+        for (int k = 0; k < 3; k++) f.hdr_par[2 + k] = luminances[k];
+      }
     }
   } else f.color_mode = do_ycbcr ? 2 : 3;
 }
@@ -155,9 +181,9 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
   sh->ih.have_container = have_container;
   const ImageHeader& ih = sh->ih;
   if (ih.xyb_encoded) {
-    // stage_from_linear.cc: sRGB, linear, pure gamma (incl. DCI) and Rec.709 are computed; PQ / HLG are not
-    const bool ok = ih.color_default || ih.have_gamma || ih.tf == 13 || ih.tf == 8 || ih.tf == 17 || ih.tf == 1;
-    if (!ok) throw ParseError("unsupported: output transfer function (PQ / HLG)", true);
+    // stage_from_linear.cc: sRGB, linear, pure gamma (incl. DCI), Rec.709, PQ and HLG
+    const bool ok = ih.color_default || ih.want_icc || ih.have_gamma || ih.tf == 13 || ih.tf == 8 || ih.tf == 17 || ih.tf == 1 || ih.tf == 16 || ih.tf == 18;
+    if (!ok) throw ParseError("unsupported: output transfer function", true);
   }
   // every frame of the image (frame_header.cc): reference-only / zero-duration layers first, the last one is displayed
   vec<std::unique_ptr<ImageEntry>> units;
@@ -269,7 +295,7 @@ void Batch::StageBytes(uint64_t out[6]) const {
     out[1] += nblk * (12 + 12 + 12 + 12 + 12 + 16);
     out[2] += hf_sec + (u < hf_written_.size() ? (uint64_t)hf_written_[u] * 4 : 0);
     out[3] += npx * (12 + 12);
-    const bool fused = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && p.upsampling == 1 && !e.complex && !cfg.force_unfused_filters;
+    const bool fused = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && SimpleTransfer(e.ih) && p.upsampling == 1 && !e.complex && !cfg.force_unfused_filters;
     if (fused) out[4] += npx * (12 + out_px);
     else {
       const uint32_t nstages = (p.lf.gab ? 1 : 0) + (p.lf.epf_iters >= 3 ? 3 : p.lf.epf_iters);
@@ -369,7 +395,7 @@ void Batch::Prepare(void* stream_v) {
     max_bw_ = std::max<int>(max_bw_, p.bw); max_bh_ = std::max<int>(max_bh_, p.bh);
     if (!p.modular) {
       max_epf_ = std::max<int>(max_epf_, p.lf.epf_iters); any_gab_ |= p.lf.gab != 0;
-      const bool fusable = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && p.upsampling == 1 && !e.complex;
+      const bool fusable = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && SimpleTransfer(e.ih) && p.upsampling == 1 && !e.complex;
       if (p.upsampling > 1 && !e.complex) { fplan_.any_upsampled = true; fplan_.max_out_w = std::max<int>(fplan_.max_out_w, e.ih.xsize); fplan_.max_out_h = std::max<int>(fplan_.max_out_h, e.ih.ysize); }
       fplan_.any_fused |= fusable; fplan_.any_unfused |= !fusable;
       fplan_.any_gab |= p.lf.gab != 0; fplan_.max_epf = std::max<int>(fplan_.max_epf, p.lf.epf_iters);
@@ -1054,7 +1080,8 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
           FillColor(ih, p.do_ycbcr, fd);
           for (int k = 0; k < 9; k++) ca.opsin_inv[k] = fd.opsin_inv[k];
           for (int k = 0; k < 3; k++) { ca.neg_bias[k] = fd.neg_bias[k]; ca.neg_bias_cbrt[k] = fd.neg_bias_cbrt[k]; }
-          ca.tf_kind = fd.color_mode == 0 ? 0 : fd.color_mode == 1 ? 1 : fd.color_mode == 4 ? 2 : 3;
+          ca.tf_kind = fd.color_mode == 0 ? 0 : fd.color_mode == 1 ? 1 : fd.color_mode == 4 ? 2 : fd.color_mode == 5 ? 3 : fd.color_mode == 6 ? 4 : 5;
+          for (int k = 0; k < 5; k++) ca.hdr_par[k] = fd.hdr_par[k];
           ca.inverse_gamma = fd.inverse_gamma;
           post_ops_.push_back([=](void* st) { LaunchColor(ca, st); });
           if (separate) { for (int c = 0; c < 3; c++) cur[c] = cb.rgb[c]; cur_stride = fw; }

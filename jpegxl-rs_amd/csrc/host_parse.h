@@ -205,6 +205,10 @@ vec<uint16_t> NaturalCoeffOrder(int strategy);
 // ICC v4.4 matrix/TRC profile of the enumerated colour encoding (icc_profile.cc); throws ParseError.
 vec<uint8_t> SynthesizeIcc(const ImageHeader& ih);
 std::string ColorDescription(const ImageHeader& ih);
+// dec_xyb.cc OutputEncodingInfo::SetColorEncoding: linear sRGB -> the image's own primaries / white point (row-major 3x3, through XYZ D50
+// with linear Bradford adaptation) and the luminance weights of those primaries.  Returns false — identity, sRGB luminances — for
+// sRGB / D65, grey images and images that carry an ICC profile.
+bool SrgbToOriginalPrimaries(const ImageHeader& ih, double m[9], float luminances[3]);
 extern const uint8_t kBucketStrategy[13];
 extern const uint8_t kKindRows[17], kKindCols[17];
 

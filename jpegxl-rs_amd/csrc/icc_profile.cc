@@ -114,11 +114,8 @@ std::string ColorDescription(const ImageHeader& ih) {
   return s;
 }
 
-vec<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
-  if (ih.want_icc) throw ParseError("unsupported: embedded ICC profile", true);
-  if (ih.color_space > 1) throw ParseError("unsupported: ICC profile for XYB / unknown colour space", true);
-  const bool grey = ih.color_space == 1;
-  double wxy[2];
+namespace {
+void WhiteXy(const ImageHeader& ih, double wxy[2]) {
   switch (ih.white_point) {
     case 1: wxy[0] = 0.3127; wxy[1] = 0.3290; break;
     case 2: wxy[0] = ih.white_xy[0]; wxy[1] = ih.white_xy[1]; break;
@@ -126,14 +123,71 @@ vec<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
     case 11: wxy[0] = 0.314; wxy[1] = 0.351; break;
     default: throw ParseError("colour encoding: white point enum", false);
   }
-  double pxy[6];
+}
+const double kSrgbPrimaries[6] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204};
+void PrimariesXy(const ImageHeader& ih, double pxy[6]) {
   switch (ih.primaries) {
-    case 1: { const double p[6] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204}; memcpy(pxy, p, sizeof p); break; }
+    case 1: memcpy(pxy, kSrgbPrimaries, sizeof kSrgbPrimaries); break;
     case 2: for (int i = 0; i < 6; i++) pxy[i] = ih.prim_xy[i]; break;
     case 9: { const double p[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046}; memcpy(pxy, p, sizeof p); break; }
     case 11: { const double p[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060}; memcpy(pxy, p, sizeof p); break; }
     default: throw ParseError("colour encoding: primaries enum", false);
   }
+}
+// cms PrimariesToXYZ: columns = the primaries' XYZ scaled so that they add up to the white point
+Mat3 PrimariesToXyz(const double pxy[6], const double wxy[2]) {
+  if (!(wxy[1] > 1e-9)) throw ParseError("colour encoding: white point with y <= 0", false);
+  Mat3 prim;
+  for (int c = 0; c < 3; c++) { prim.m[0][c] = pxy[2 * c]; prim.m[1][c] = pxy[2 * c + 1]; prim.m[2][c] = 1.0 - pxy[2 * c] - pxy[2 * c + 1]; }
+  const Mat3 pinv = Inv(prim);
+  const double wxyz[3] = {wxy[0] / wxy[1], 1.0, (1.0 - wxy[0] - wxy[1]) / wxy[1]};
+  Mat3 r;
+  for (int c = 0; c < 3; c++) {
+    double scale = 0;
+    for (int k = 0; k < 3; k++) scale += pinv.m[c][k] * wxyz[k];
+    for (int i = 0; i < 3; i++) r.m[i][c] = prim.m[i][c] * scale;
+  }
+  return r;
+}
+// cms AdaptToXYZD50 (its own D50 and inverse Bradford constants, not the ICC header's)
+Mat3 AdaptToXyzD50(const double wxy[2]) {
+  if (!(wxy[1] > 1e-9)) throw ParseError("colour encoding: white point with y <= 0", false);
+  const Mat3 brad = {{{0.8951, 0.2664, -0.1614}, {-0.7502, 1.7135, 0.0367}, {0.0389, -0.0685, 1.0296}}};
+  const Mat3 brad_inv = {{{0.9869929, -0.1470543, 0.1599627}, {0.4323053, 0.5183603, 0.0492912}, {-0.0085287, 0.0400428, 0.9684867}}};
+  const double wxyz[3] = {wxy[0] / wxy[1], 1.0, (1.0 - wxy[0] - wxy[1]) / wxy[1]}, w50[3] = {0.96422, 1.0, 0.82521};
+  Mat3 scaled = brad;
+  for (int i = 0; i < 3; i++) {
+    double lms = 0, lms50 = 0;
+    for (int k = 0; k < 3; k++) { lms += brad.m[i][k] * wxyz[k]; lms50 += brad.m[i][k] * w50[k]; }
+    for (int k = 0; k < 3; k++) scaled.m[i][k] = brad.m[i][k] * (lms50 / lms);
+  }
+  return Mul(brad_inv, scaled);
+}
+}  // namespace
+
+bool SrgbToOriginalPrimaries(const ImageHeader& ih, double m[9], float luminances[3]) {
+  for (int i = 0; i < 9; i++) m[i] = i % 4 == 0 ? 1.0 : 0.0;
+  luminances[0] = 0.2126f; luminances[1] = 0.7152f; luminances[2] = 0.0722f;
+  if (ih.color_default || ih.want_icc || ih.color_space != 0 || (ih.primaries == 1 && ih.white_point == 1)) return false;
+  double w[2], p[6];
+  const double w65[2] = {0.3127, 0.3290};
+  WhiteXy(ih, w); PrimariesXy(ih, p);
+  const Mat3 srgb_to_xyzd50 = Mul(AdaptToXyzD50(w65), PrimariesToXyz(kSrgbPrimaries, w65));
+  const Mat3 original_to_xyz = PrimariesToXyz(p, w);
+  for (int i = 0; i < 3; i++) luminances[i] = (float)original_to_xyz.m[1][i];
+  const Mat3 srgb_to_original = Mul(Inv(Mul(AdaptToXyzD50(w), original_to_xyz)), srgb_to_xyzd50);
+  for (int i = 0; i < 9; i++) m[i] = srgb_to_original.m[i / 3][i % 3];
+  return true;
+}
+
+vec<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
+  if (ih.want_icc) throw ParseError("unsupported: embedded ICC profile", true);
+  if (ih.color_space > 1) throw ParseError("unsupported: ICC profile for XYB / unknown colour space", true);
+  const bool grey = ih.color_space == 1;
+  double wxy[2];
+  WhiteXy(ih, wxy);
+  double pxy[6];
+  PrimariesXy(ih, pxy);
   double white[3];
   XyToXyz(wxy[0], wxy[1], white);
   const Mat3 chad = AdaptToD50(white);

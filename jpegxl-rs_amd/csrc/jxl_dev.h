@@ -472,4 +472,35 @@ struct BlockCtxDev {
   uint8_t ctx_map[3 * 13 * 64];
 };
 
+// ---- HDR transfer functions of the output stage (stage_from_linear.cc OpPq / OpHlg) ----------------------------------------------------
+// TF_PQ::EncodedFromDisplay: 4-over-4 rational polynomials in x^(1/4) (a second pair below 1e-4), x = linear value x intensity_target / 10000
+JXL_HD float PqFromLinear(float v, float scale) {
+  const float xs = fabsf(v) * scale;
+  const float t = sqrtf(sqrtf(xs));
+  float yp, yq;
+  if (xs < 1e-4f) {
+    yp = fmaf(fmaf(fmaf(fmaf(-2.864824e+05f, t, 6.889862e+04f), t, 1.352821e+02f), t, 3.881234e-01f), t, 9.863406e-06f);
+    yq = fmaf(fmaf(fmaf(fmaf(-2.072546e+05f, t, -4.389884e+04f), t, 1.608477e+04f), t, 1.477719e+03f), t, 3.371868e+01f);
+  } else {
+    yp = fmaf(fmaf(fmaf(fmaf(4.838434e+01f, t, 1.492516e+02f), t, 5.522776e+01f), t, -1.095778e+00f), t, 1.351392e-02f);
+    yq = fmaf(fmaf(fmaf(fmaf(2.590418e+01f, t, 1.120607e+02f), t, 9.263710e+01f), t, 2.016708e+01f), t, 1.012416e+00f);
+  }
+  return copysignf(yp / yq, v);
+}
+// TF_HLG_Base::EncodedFromDisplay (scalar double in libjxl: OpHlg goes lane by lane)
+JXL_HD float HlgFromLinear(float v) {
+  const double kA = 0.17883277, kB = 1 - 4 * kA, kC = 0.5599107295, kDiv12 = 1.0 / 12;
+  const double s = fabs((double)v);
+  if (s == 0.0) return 0.0f;
+  const double e = s <= kDiv12 ? sqrt(3.0 * s) : kA * log(12 * s - kB) + kC;
+  return (float)copysign(e, (double)v);
+}
+// HlgOOTF::Apply (cms/tone_mapping-inl.h): display light -> scene light; par = {exponent, apply?, luminances of the output primaries}
+template <typename PowFn> JXL_HD void HlgInverseOotf(const float* par, float& r, float& g, float& b, PowFn fast_powf) {
+  if (par[1] == 0.0f) return;
+  const float luminance = fmaf(par[2], r, fmaf(par[3], g, par[4] * b));
+  const float ratio = fminf(fast_powf(luminance, par[0]), 1e9f);
+  r *= ratio; g *= ratio; b *= ratio;
+}
+
 }  // namespace jxlhip

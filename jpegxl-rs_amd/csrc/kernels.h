@@ -58,7 +58,7 @@ struct FrameDev {
   float epf_sharp_lut[8], epf_channel_scale[3], epf_quant_mul, epf_quant_scale;
   float epf_sm[3], epf_bsm[3];    // per pass sad multipliers (normal, border)
   float opsin_inv[9], neg_bias[3], neg_bias_cbrt[3];
-  uint32_t color_mode;            // 0: XYB->sRGB, 1: XYB->linear, 2: YCbCr->RGB, 3: none (RGB as is), 4: XYB->gamma (FastPowf), 5: XYB->Rec.709
+  uint32_t color_mode;            // 0: XYB->sRGB, 1: XYB->linear, 2: YCbCr->RGB, 3: none (RGB as is), 4: XYB->gamma (FastPowf), 5: XYB->Rec.709, 6: XYB->PQ, 7: XYB->HLG
   uint32_t is_gray;
   // VarDCT buffers
   int32_t* lfq[3];
@@ -109,6 +109,7 @@ struct FrameDev {
   uint32_t post_mode;             // 1: the frame ends in its float planes (after the restoration filters); upsampling, colour transform and the
                                   // write stage are done by the host-planned frame tail (kernels_features.hip) — multi-frame images, image features
   float inverse_gamma;            // colour modes 4 / 5 (XYB -> gamma / Rec.709 transfer)
+  float hdr_par[5];               // colour mode 6 (PQ): [0] intensity_target / 10000; 7 (HLG): [0] OOTF exponent, [1] apply it, [2..4] luminances
 };
 
 struct LaunchCfg {
@@ -164,8 +165,8 @@ struct SplineSegmentDev;   // host_parse.h
 struct PatchEntryDev { const float* src[3]; const float* esrc[4]; uint32_t src_stride, esrc_stride; int32_t x, y; uint32_t xs, ys; uint32_t mode[5]; uint32_t pad; };
 struct PatchFrameArgs { float* p[3]; float* ec[4]; uint32_t stride, ec_stride, w, h, num_extra, premul_mask; };
 struct NoiseArgs { float* p[3]; uint32_t stride, w, h; float* noise[3]; uint32_t noise_stride, group_dim, visible_frame_index, nonvisible_frame_index; float lut[8]; float ytox, ytob; };
-// mode: 0 XYB -> linear -> transfer function (tf_kind 0 sRGB, 1 linear, 2 gamma, 3 Rec.709), 1 YCbCr -> RGB, 2 copy
-struct ColorArgs { const float* src[3]; float* dst[3]; uint32_t src_stride, dst_stride, w, h, mode, tf_kind; float inverse_gamma, opsin_inv[9], neg_bias[3], neg_bias_cbrt[3]; };
+// mode: 0 XYB -> linear -> transfer function (tf_kind 0 sRGB, 1 linear, 2 gamma, 3 Rec.709, 4 PQ, 5 HLG), 1 YCbCr -> RGB, 2 copy
+struct ColorArgs { const float* src[3]; float* dst[3]; uint32_t src_stride, dst_stride, w, h, mode, tf_kind; float inverse_gamma, opsin_inv[9], neg_bias[3], neg_bias_cbrt[3], hdr_par[5]; };
 // mode[k] = BlendMode | alpha channel << 8 | clamp << 16; bg pointers are null when the source slot is empty (treated as zeros)
 struct BlendArgs {
   const float* fg[3]; const float* fg_ec[4]; uint32_t fg_stride, fg_ec_stride, fw, fh; int32_t x0, y0;

@@ -3034,6 +3034,11 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
     if (f.color_mode == 0) { r = LinearToSrgb(r); g = LinearToSrgb(g); b = LinearToSrgb(b); }
     else if (f.color_mode == 4) { r = GammaFromLinear(r, f.inverse_gamma); g = GammaFromLinear(g, f.inverse_gamma); b = GammaFromLinear(b, f.inverse_gamma); }
     else if (f.color_mode == 5) { r = Rec709FromLinear(r); g = Rec709FromLinear(g); b = Rec709FromLinear(b); }
+    else if (f.color_mode == 6) { r = PqFromLinear(r, f.hdr_par[0]); g = PqFromLinear(g, f.hdr_par[0]); b = PqFromLinear(b, f.hdr_par[0]); }
+    else if (f.color_mode == 7) {
+      HlgInverseOotf(f.hdr_par, r, g, b, [](float x, float e) { return FastPowfDev(x, e); });
+      r = HlgFromLinear(r); g = HlgFromLinear(g); b = HlgFromLinear(b);
+    }
   } else if (f.color_mode == 2) {
     const float c128 = 128.0f / 255, crcr = 1.402f, cgcb = -0.114f * 1.772f / 0.587f, cgcr = -0.299f * 1.402f / 0.587f, cbcb = 1.772f;
     const float yb = Y + c128;

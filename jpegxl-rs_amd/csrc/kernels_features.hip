@@ -293,6 +293,8 @@ __device__ __forceinline__ float TransferD(uint32_t kind, float inverse_gamma, f
     case 0: return LinearToSrgbF(v);
     case 1: return v;
     case 2: return v <= 1e-5f ? 0.0f : FastPowfD(v, inverse_gamma);
+    case 4: return PqFromLinear(v, inverse_gamma);          // (inverse_gamma carries intensity_target / 10000 here)
+    case 5: return HlgFromLinear(v);
     default: return v <= 0.018f ? 4.5f * v : fmaf(1.099f, FastPowfD(v, 0.45f), -0.099f);
   }
 }
@@ -312,7 +314,9 @@ __global__ void ColorKernel(ColorArgs a) {
     r = fmaf(a.opsin_inv[2], mb, fmaf(a.opsin_inv[1], mg, a.opsin_inv[0] * mr));
     g = fmaf(a.opsin_inv[5], mb, fmaf(a.opsin_inv[4], mg, a.opsin_inv[3] * mr));
     b = fmaf(a.opsin_inv[8], mb, fmaf(a.opsin_inv[7], mg, a.opsin_inv[6] * mr));
-    r = TransferD(a.tf_kind, a.inverse_gamma, r); g = TransferD(a.tf_kind, a.inverse_gamma, g); b = TransferD(a.tf_kind, a.inverse_gamma, b);
+    if (a.tf_kind == 5) HlgInverseOotf(a.hdr_par, r, g, b, [](float x, float e) { return FastPowfD(x, e); });
+    const float tf_par = a.tf_kind == 4 ? a.hdr_par[0] : a.inverse_gamma;
+    r = TransferD(a.tf_kind, tf_par, r); g = TransferD(a.tf_kind, tf_par, g); b = TransferD(a.tf_kind, tf_par, b);
   } else if (a.mode == 1) {   // YCbCr (planes Cb, Y, Cr) -> RGB
     const float c128 = 128.0f / 255, crcr = 1.402f, cgcb = -0.114f * 1.772f / 0.587f, cgcr = -0.299f * 1.402f / 0.587f, cbcb = 1.772f;
     const float yb = Y + c128;

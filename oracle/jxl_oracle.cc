@@ -284,28 +284,36 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     // ---- colour transform to the output space (stage_xyb.cc, stage_from_linear.cc, stage_ycbcr.cc)
     Image3 rgb = img;
     if (m.xyb_encoded) {
-      OpsinParams op = MakeOpsin(m, m.intensity_target);
-      // stage_from_linear.cc: 0 sRGB, 1 linear, 2 gamma (OpGamma: FastPowf, zero below 1e-5), 3 Rec.709
+      float luminances[3];
+      OpsinParams op = MakeOpsin(m, m.intensity_target, luminances);
+      // stage_from_linear.cc: 0 sRGB, 1 linear, 2 gamma (OpGamma: FastPowf, zero below 1e-5), 3 Rec.709, 4 PQ, 5 HLG (inverse OOTF first)
       int tf_kind = 0; float inverse_gamma = 1.0f;
+      HlgOotf ootf;
       if (!m.color.all_default) {
         if (m.color.have_gamma) { tf_kind = 2; inverse_gamma = (float)m.color.gamma * 1e-7f; }
         else if (m.color.tf == 13) tf_kind = 0;
         else if (m.color.tf == 8) tf_kind = 1;
         else if (m.color.tf == 17) { tf_kind = 2; inverse_gamma = 1.0f / 2.6f; }   // DCI
         else if (m.color.tf == 1) tf_kind = 3;
-        else JXLO_FAIL("unsupported: output transfer function (PQ / HLG)");
+        else if (m.color.tf == 16) tf_kind = 4;
+        else if (m.color.tf == 18) { tf_kind = 5; ootf = HlgOotf(m.intensity_target, luminances); }
+        else JXLO_FAIL("unsupported: output transfer function");
       }
+      const float pq_scale = m.intensity_target * (1.0f / 10000.0f);
       auto tf = [&](float v) -> float {
         switch (tf_kind) {
           case 0: return LinearToSRGB(v);
           case 1: return v;
           case 2: return v <= 1e-5f ? 0.0f : FastPowf(v, inverse_gamma);
+          case 4: return PqFromLinear(v, pq_scale);
+          case 5: return HlgFromLinear(v);
           default: return v <= 0.018f ? 4.5f * v : std::fmaf(1.099f, FastPowf(v, 0.45f), -0.099f);
         }
       };
       for (int y = 0; y < fhh; y++) for (int x = 0; x < fw; x++) {
         float r, g, b;
         XybToLinear(op, img.p[0].row(y)[x], img.p[1].row(y)[x], img.p[2].row(y)[x], &r, &g, &b);
+        if (tf_kind == 5) ootf.Apply(&r, &g, &b);
         r = tf(r); g = tf(g); b = tf(b);
         rgb.p[0].row(y)[x] = r; rgb.p[1].row(y)[x] = g; rgb.p[2].row(y)[x] = b;
       }

@@ -178,11 +178,95 @@ struct OpsinParams {
 // dec_cache.cc / dec_xyb.cc OutputEncodingInfo::SetColorEncoding: for a grey-scale image the three rows of the inverse
 // opsin matrix are replaced by their luminance-weighted sum (kSRGBLuminances), so R = G = B = luminance by construction;
 // Mul3x3Matrix accumulates each element in double.
-inline OpsinParams MakeOpsin(const ImageMetadata& m, float intensity_target) {
+// ---- output primaries / white point (dec_xyb.cc OutputEncodingInfo::SetColorEncoding; cms/jxl_cms_internal.h PrimariesToXYZ,
+// AdaptToXYZD50 — [R]: formulas restated, intermediate precision (double here) not checkable against libjxl).  XYB decodes to linear
+// sRGB; an image whose header names other primaries or another white point gets the inverse opsin matrix multiplied by
+// (linear sRGB -> its own primaries), going through XYZ D50 with linear Bradford adaptation on both sides.
+struct Mat3d { double m[3][3]; };
+inline Mat3d Mul3(const Mat3d& a, const Mat3d& b) {
+  Mat3d r;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double e = 0; for (int k = 0; k < 3; k++) e += a.m[i][k] * b.m[k][j]; r.m[i][j] = e; }
+  return r;
+}
+inline Mat3d Inv3(const Mat3d& a) {
+  const double (*m)[3] = a.m;
+  const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+  JXLO_CHECK(std::fabs(det) > 1e-12);
+  Mat3d r;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    r.m[j][i] = (m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1]) / det;
+  }
+  return r;
+}
+inline Mat3d PrimariesToXYZ(const double p[6], const double w[2]) {
+  JXLO_CHECK(w[1] > 1e-9);
+  Mat3d prim;
+  for (int c = 0; c < 3; c++) { prim.m[0][c] = p[2 * c]; prim.m[1][c] = p[2 * c + 1]; prim.m[2][c] = 1.0 - p[2 * c] - p[2 * c + 1]; }
+  const Mat3d pinv = Inv3(prim);
+  const double wxyz[3] = {w[0] / w[1], 1.0, (1.0 - w[0] - w[1]) / w[1]};
+  Mat3d r;
+  for (int c = 0; c < 3; c++) {
+    double scale = 0;
+    for (int k = 0; k < 3; k++) scale += pinv.m[c][k] * wxyz[k];
+    for (int i = 0; i < 3; i++) r.m[i][c] = prim.m[i][c] * scale;
+  }
+  return r;
+}
+inline Mat3d AdaptToXYZD50(const double w[2]) {
+  JXLO_CHECK(w[1] > 1e-9);
+  const Mat3d brad = {{{0.8951, 0.2664, -0.1614}, {-0.7502, 1.7135, 0.0367}, {0.0389, -0.0685, 1.0296}}};
+  const Mat3d brad_inv = {{{0.9869929, -0.1470543, 0.1599627}, {0.4323053, 0.5183603, 0.0492912}, {-0.0085287, 0.0400428, 0.9684867}}};
+  const double wxyz[3] = {w[0] / w[1], 1.0, (1.0 - w[0] - w[1]) / w[1]}, w50[3] = {0.96422, 1.0, 0.82521};
+  Mat3d scaled = brad;
+  for (int i = 0; i < 3; i++) {
+    double lms = 0, lms50 = 0;
+    for (int k = 0; k < 3; k++) { lms += brad.m[i][k] * wxyz[k]; lms50 += brad.m[i][k] * w50[k]; }
+    for (int k = 0; k < 3; k++) scaled.m[i][k] = brad.m[i][k] * (lms50 / lms);
+  }
+  return Mul3(brad_inv, scaled);
+}
+// xy of the enumerated white points / primaries (color_encoding_internal.h)
+inline void WhiteXY(const ColorEncoding& c, double w[2]) {
+  switch (c.white_point) {
+    case 1: w[0] = 0.3127; w[1] = 0.3290; break;
+    case 2: w[0] = c.custom_xy[0] * 1e-6; w[1] = c.custom_xy[1] * 1e-6; break;
+    case 10: w[0] = w[1] = 1.0 / 3; break;
+    case 11: w[0] = 0.314; w[1] = 0.351; break;
+    default: JXLO_FAIL("white point enum");
+  }
+}
+inline void PrimariesXY(const ColorEncoding& c, double p[6]) {
+  static const double srgb[6] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204};
+  static const double bt2100[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046}, p3[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060};
+  switch (c.primaries) {
+    case 1: for (int i = 0; i < 6; i++) p[i] = srgb[i]; break;
+    case 2: for (int i = 0; i < 6; i++) p[i] = c.custom_xy[2 + i] * 1e-6; break;
+    case 9: for (int i = 0; i < 6; i++) p[i] = bt2100[i]; break;
+    case 11: for (int i = 0; i < 6; i++) p[i] = p3[i]; break;
+    default: JXLO_FAIL("primaries enum");
+  }
+}
+
+inline OpsinParams MakeOpsin(const ImageMetadata& m, float intensity_target, float luminances[3] = nullptr) {
   OpsinParams o;
   float s = 255.0f / intensity_target;
   float inv[9];
   for (int i = 0; i < 9; i++) inv[i] = m.opsin_inv[i];
+  if (luminances) { luminances[0] = 0.2126f; luminances[1] = 0.7152f; luminances[2] = 0.0722f; }
+  if (!m.color.all_default && !m.color.want_icc && m.color.color_space == 0 && (m.color.primaries != 1 || m.color.white_point != 1)) {
+    double w[2], p[6], w65[2] = {0.3127, 0.3290}, psrgb[6];
+    ColorEncoding srgb; srgb.white_point = 1; srgb.primaries = 1;
+    WhiteXY(m.color, w); PrimariesXY(m.color, p); PrimariesXY(srgb, psrgb);
+    const Mat3d srgb_to_xyzd50 = Mul3(AdaptToXYZD50(w65), PrimariesToXYZ(psrgb, w65));
+    const Mat3d original_to_xyz = PrimariesToXYZ(p, w);
+    if (luminances) for (int i = 0; i < 3; i++) luminances[i] = (float)original_to_xyz.m[1][i];
+    const Mat3d srgb_to_original = Mul3(Inv3(Mul3(AdaptToXYZD50(w), original_to_xyz)), srgb_to_xyzd50);
+    Mat3d oi;
+    for (int i = 0; i < 9; i++) oi.m[i / 3][i % 3] = inv[i];
+    const Mat3d adapted = Mul3(srgb_to_original, oi);
+    for (int i = 0; i < 9; i++) inv[i] = (float)adapted.m[i / 3][i % 3];
+  }
   if (m.color.color_space == 1) {
     const float lum[3] = {0.2126f, 0.7152f, 0.0722f};
     float folded[9];
@@ -222,6 +306,50 @@ inline float LinearToSRGB(float v) {
   float r = x > 0.0031308f ? poly : lin;
   return std::copysign(r, v);
 }
+
+// transfer_functions-inl.h TF_PQ::EncodedFromDisplay [R]: 4-over-4 rational polynomials in x^(1/4), one for small values; x = linear
+// value (1.0 = intensity target), scale = intensity_target / 10000.  The coefficients reproduce SMPTE ST 2084 to 7e-7 (1.7e-6 below
+// 1e-4), which is how their recollection was checked (tests/test_oracle_goldens.py).
+inline float PqFromLinear(float v, float scale) {
+  static const float p[5] = {1.351392e-02f, -1.095778e+00f, 5.522776e+01f, 1.492516e+02f, 4.838434e+01f};
+  static const float q[5] = {1.012416e+00f, 2.016708e+01f, 9.263710e+01f, 1.120607e+02f, 2.590418e+01f};
+  static const float plo[5] = {9.863406e-06f, 3.881234e-01f, 1.352821e+02f, 6.889862e+04f, -2.864824e+05f};
+  static const float qlo[5] = {3.371868e+01f, 1.477719e+03f, 1.608477e+04f, -4.389884e+04f, -2.072546e+05f};
+  const float xs = std::fabs(v) * scale;
+  const float t = std::sqrt(std::sqrt(xs));
+  const bool small = xs < 1e-4f;
+  const float* pp = small ? plo : p;
+  const float* qq = small ? qlo : q;
+  float yp = pp[4], yq = qq[4];
+  for (int i = 3; i >= 0; i--) { yp = std::fmaf(yp, t, pp[i]); yq = std::fmaf(yq, t, qq[i]); }
+  return std::copysign(yp / yq, v);
+}
+// transfer_functions-inl.h TF_HLG_Base::EncodedFromDisplay (scalar, double; stage_from_linear.cc OpHlg applies it lane by lane)
+inline float HlgFromLinear(float v) {
+  const double kA = 0.17883277, kB = 1 - 4 * kA, kC = 0.5599107295, kDiv12 = 1.0 / 12;
+  double s = std::fabs((double)v);
+  if (s == 0.0) return 0.0f;
+  const double e = s <= kDiv12 ? std::sqrt(3.0 * s) : kA * std::log(12 * s - kB) + kC;
+  return (float)std::copysign(e, (double)v);
+}
+// cms/tone_mapping-inl.h HlgOOTF::ToSceneLight(display_luminance = intensity target, luminances of the output primaries): display
+// light -> scene light before the HLG OETF; skipped when the exponent is within 0.01 of zero
+struct HlgOotf {
+  float exponent = 0, lum[3] = {0, 0, 0}; bool apply = false;
+  HlgOotf() {}
+  HlgOotf(float display_luminance, const float luminances[3]) {
+    const float gamma = (1 / 1.2f) * std::pow(1.111f, -std::log2(display_luminance / 1000.f));
+    exponent = gamma - 1;
+    apply = exponent < -0.01f || 0.01f < exponent;
+    for (int i = 0; i < 3; i++) lum[i] = luminances[i];
+  }
+  void Apply(float* r, float* g, float* b) const {
+    if (!apply) return;
+    const float luminance = std::fmaf(lum[0], *r, std::fmaf(lum[1], *g, lum[2] * *b));
+    const float ratio = std::min(FastPowf(luminance, exponent), 1e9f);
+    *r *= ratio; *g *= ratio; *b *= ratio;
+  }
+};
 
 inline uint16_t FloatToHalf(float f) {
   uint32_t x; memcpy(&x, &f, 4);

@@ -230,3 +230,15 @@ def jpeg_transcode_codestream(w, h, modes, planes, qts):
     if L.jxlsynth_jpeg_transcode(w, h, m, ptr[0], ptr[1], ptr[2], q.ctypes.data, C.byref(out), C.byref(n)):
         raise RuntimeError(L.jxlsynth_last_error().decode())
     return _take(out, n)
+
+
+def set_color(white_point=None, primaries=1, tf=13, gamma=0.0, intensity_target=255.0):
+    """Enumerated colour encoding of the image headers written from now on (color_encoding_internal.h enums: white point 1 D65 / 10 E /
+    11 DCI, primaries 1 sRGB / 9 BT.2100 / 11 P3, tf 1 Rec.709 / 8 linear / 13 sRGB / 16 PQ / 17 DCI / 18 HLG; gamma != 0 replaces tf)
+    and the intensity target in nits; call without arguments to clear."""
+    L = lib()
+    L.jxlsynth_set_color.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_float]
+    if white_point is None:
+        L.jxlsynth_set_color(-1, 1, 13, 0, 255.0)
+    else:
+        L.jxlsynth_set_color(white_point, primaries, tf, int(round(gamma * 1e7)), intensity_target)

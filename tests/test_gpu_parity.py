@@ -1101,3 +1101,39 @@ def test_grey_jpeg_transcodes(jx, kw):
         res = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=1)).decode_with(jxl, np.uint8)[1]
         d = np.abs(np.asarray(res).reshape(h, w).astype(int) - np.asarray(Image.open(io.BytesIO(data))).astype(int))
         assert d.max() <= 2 and d.mean() < 0.5
+
+
+COLOUR_ENCODINGS = {
+    "p3_srgb_tf": dict(white_point=1, primaries=11, tf=13),
+    "bt2100_pq_1000": dict(white_point=1, primaries=9, tf=16, intensity_target=1000.0),
+    "bt2100_hlg_1000": dict(white_point=1, primaries=9, tf=18, intensity_target=1000.0),
+    "srgb_pq_255": dict(white_point=1, primaries=1, tf=16),
+    "srgb_hlg_300": dict(white_point=1, primaries=1, tf=18, intensity_target=300.0),
+    "dci_white_p3_gamma26": dict(white_point=11, primaries=11, tf=17),
+    "bt2100_rec709_tf": dict(white_point=1, primaries=9, tf=1),
+    "white_e_gamma22": dict(white_point=10, primaries=1, gamma=1 / 2.2),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(COLOUR_ENCODINGS))
+def test_output_colour_encodings(jx, name):
+    """XYB images that name their own primaries, white point and transfer function (dec_xyb.cc SetColorEncoding: inverse opsin matrix
+    times linear-sRGB -> own primaries; stage_from_linear.cc: sRGB, Rec.709, gamma, PQ, HLG with the inverse OOTF): the fast path (default
+    filters, OutputKernel), the feature path (ColorKernel, a frame with patches-style tail: two frames blended) and an upsampled frame
+    against the oracle, all output types.  The oracle's side of these encodings is pinned by tests/test_oracle_goldens.py."""
+    img = S.synthetic_image(31, 200, 136)
+    S.set_color(**COLOUR_ENCODINGS[name])
+    try:
+        plain = S.encode_vardct(img, seed=5, strategy_mix=2)                                  # gaborish + EPF 1: unfused filters + OutputKernel
+        nofilter = S.encode_vardct(img, seed=6, gab=0, epf_iters=0)
+        layered = S.encode_vardct_frame(img, S.frame(is_last=0, save_as_reference=1), seed=3) + \
+            S.encode_vardct_frame(S.synthetic_image(9, 64, 48), S.frame(emit=1, have_crop=1, crop_x0=40, crop_y0=30, canvas_w=200, canvas_h=136, blend_mode=2, blend_source=1), seed=4)
+    finally:
+        S.set_color()
+    for data in (plain, nofilter, layered):
+        check_against_oracle(jx, data, np.uint8, 3)
+        check_against_oracle(jx, data, np.uint16, 3)
+        check_against_oracle(jx, data, np.float32, 3)
+    srgb = O.decode(S.encode_vardct(img, seed=5, strategy_mix=2)).image("u8", 3).astype(int)
+    assert np.abs(O.decode(plain).image("u8", 3).astype(int) - srgb).max() > 8                 # (the encoding does change the pixels)

@@ -295,3 +295,64 @@ def test_idct_matches_direct_formula():
             return b
         ref = basis(R) @ sem.astype(np.float64) @ basis(Cc).T
         assert np.abs(out - ref).max() < 2e-4 * max(R, Cc)
+
+
+def test_output_colour_encodings_against_independent_colour_science():
+    """XYB images whose header names other primaries / a PQ or HLG transfer function (dec_xyb.cc OutputEncodingInfo::SetColorEncoding,
+    stage_from_linear.cc OpPq / OpHlg incl. the inverse OOTF): the oracle's pixels, taken back to linear sRGB with textbook float64
+    formulas (RGB -> XYZ matrices from the xy chromaticities, sRGB / ST 2084 / BT.2100 HLG EOTFs, OOTF gamma 1.2 at 1000 nits), must
+    equal the oracle's linear-sRGB decode of the same codestream.  Pins the primaries adaptation (its D50 detour cancels), the recalled
+    PQ rational-polynomial coefficients (they reproduce ST 2084 to 7e-7) and the HLG + OOTF chain."""
+    import synth_lib as S
+    img = S.synthetic_image(5, 96, 64)
+
+    def dec(**kw):
+        S.set_color(**kw)
+        try:
+            data = S.encode_vardct(img, seed=1)
+        finally:
+            S.set_color()
+        return np.frombuffer(O.decode(data).pixels("f32", 3), np.float32).reshape(64, 96, 3).astype(np.float64)
+
+    def rgb_to_xyz(prim, white):
+        P = np.array([[prim[0], prim[2], prim[4]], [prim[1], prim[3], prim[5]], [1 - prim[0] - prim[1], 1 - prim[2] - prim[3], 1 - prim[4] - prim[5]]])
+        W = np.array([white[0] / white[1], 1, (1 - white[0] - white[1]) / white[1]])
+        return P * np.linalg.solve(P, W)
+    srgb, p3, bt2020, d65 = (0.64, 0.33, 0.30, 0.60, 0.15, 0.06), (0.680, 0.320, 0.265, 0.690, 0.150, 0.060), (0.708, 0.292, 0.170, 0.797, 0.131, 0.046), (0.3127, 0.3290)
+
+    def to_srgb(x, prim):
+        return x @ (np.linalg.inv(rgb_to_xyz(srgb, d65)) @ rgb_to_xyz(prim, d65)).T
+
+    def srgb_eotf(v):
+        return np.where(v <= 0.04045, v / 12.92, ((np.abs(v) + 0.055) / 1.055) ** 2.4)
+
+    def pq_eotf(e):
+        m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+        p = np.abs(e) ** (1 / m2)
+        return (np.maximum(p - c1, 0) / (c2 - c3 * p)) ** (1 / m1)
+
+    def hlg_inverse_oetf(e):
+        a = 0.17883277
+        return np.where(e <= 0.5, e * e / 3, (np.exp((e - 0.5599107295) / a) + 1 - 4 * a) / 12)
+    lin255 = dec(white_point=1, primaries=1, tf=8)
+    lin1000 = dec(white_point=1, primaries=1, tf=8, intensity_target=1000.0)
+    assert np.abs(to_srgb(srgb_eotf(dec(white_point=1, primaries=11, tf=13)), p3) - lin255).max() < 5e-5
+    assert np.abs(to_srgb(srgb_eotf(dec(white_point=1, primaries=9, tf=13)), bt2020) - lin255).max() < 5e-5
+    assert np.abs(to_srgb(pq_eotf(dec(white_point=1, primaries=9, tf=16, intensity_target=1000.0)) * 10, bt2020) - lin1000).max() < 2e-5
+    assert np.abs(pq_eotf(dec(white_point=1, primaries=1, tf=16)) * (10000 / 255) - lin255).max() < 1e-4
+    scene = hlg_inverse_oetf(dec(white_point=1, primaries=9, tf=18, intensity_target=1000.0))
+    display = scene * ((scene @ rgb_to_xyz(bt2020, d65)[1]) ** 0.2)[..., None]
+    assert np.abs(to_srgb(display, bt2020) - lin1000).max() < 2e-5
+    # 300 nits: the system gamma is 0.9995, within the 0.01 band where libjxl skips the OOTF
+    scene = hlg_inverse_oetf(dec(white_point=1, primaries=1, tf=18, intensity_target=300.0))
+    assert np.abs(scene - dec(white_point=1, primaries=1, tf=8, intensity_target=300.0)).max() < 1e-5
+    # PQ coefficients against ST 2084 itself
+    import ctypes as C
+    x = np.concatenate([np.logspace(-9, 0, 4000), [0.0]])
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    exact = ((c1 + c2 * x ** m1) / (1 + c3 * x ** m1)) ** m2
+    p, q = [1.351392e-02, -1.095778e+00, 5.522776e+01, 1.492516e+02, 4.838434e+01], [1.012416e+00, 2.016708e+01, 9.263710e+01, 1.120607e+02, 2.590418e+01]
+    plo, qlo = [9.863406e-06, 3.881234e-01, 1.352821e+02, 6.889862e+04, -2.864824e+05], [3.371868e+01, 1.477719e+03, 1.608477e+04, -4.389884e+04, -2.072546e+05]
+    t = x ** 0.25
+    approx = np.where(x < 1e-4, np.polyval(plo[::-1], t) / np.polyval(qlo[::-1], t), np.polyval(p[::-1], t) / np.polyval(q[::-1], t))
+    assert np.abs(approx - exact).max() < 2e-6

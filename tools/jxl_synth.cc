@@ -297,6 +297,10 @@ static void WriteFeatures(BitWriter& s) {
 // header, one command per tag (known names, implicit offsets / sizes, TRC and XYZ triples where they apply), tag data as a mix
 // of insert / shuffle / predict commands chosen to exercise the decoder rather than to compress.
 static thread_local std::vector<uint8_t> g_icc;
+// enumerated colour encoding of the image headers written from now on (jxlsynth_set_color): white point / primaries / transfer function
+// enums of color_encoding_internal.h, gamma in 1e-7 units (0 = use tf), intensity target in nits
+struct ColorOverride { bool set = false; int white_point = 1, primaries = 1, tf = 13; uint32_t gamma = 0; float intensity_target = 255.0f; };
+static thread_local ColorOverride g_color;
 static void IccVarint(std::vector<uint8_t>& v, uint64_t x) { while (x > 127) { v.push_back((uint8_t)(x | 128)); x >>= 7; } v.push_back((uint8_t)x); }
 static std::vector<uint8_t> IccShuffleFwd(const std::vector<uint8_t>& in, size_t width) {   // decoder: out[i] = in[j], j walking columns
   const size_t n = in.size(), rows = (n + width - 1) / width;
@@ -417,10 +421,11 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
   const bool custom_up = p.upsampling > 1 && p.custom_up_weights;
-  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty();
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set;
   w.put(all_default, 1);
   if (!all_default) {
-    bool extra_fields = p.hdr || p.orientation != 1;
+    const bool custom_target = g_color.set && g_color.intensity_target != 255.0f;
+    bool extra_fields = p.hdr || p.orientation != 1 || custom_target;
     w.put(extra_fields, 1);
     if (extra_fields) {
       w.put((uint32_t)(p.orientation - 1), 3);
@@ -444,11 +449,19 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
     }
     w.put(xyb, 1);
     // ColorEncoding
-    bool ce_default = !p.hdr && !gray && g_icc.empty();
+    bool ce_default = !p.hdr && !gray && g_icc.empty() && !g_color.set;
     w.put(ce_default, 1);
     if (!g_icc.empty()) {
       w.put(1, 1);                                                  // want_icc: only the colour space follows
       WriteU32(w, gray ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});
+    } else if (g_color.set) {
+      w.put(0, 1);  // want_icc
+      WriteU32(w, gray ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});
+      WriteU32(w, (uint32_t)g_color.white_point, {0, 0}, {0, 1}, {4, 2}, {6, 18});
+      if (!gray) WriteU32(w, (uint32_t)g_color.primaries, {0, 0}, {0, 1}, {4, 2}, {6, 18});
+      if (g_color.gamma) { w.put(1, 1); w.put(g_color.gamma, 24); }
+      else { w.put(0, 1); WriteU32(w, (uint32_t)g_color.tf, {0, 0}, {0, 1}, {4, 2}, {6, 18}); }
+      WriteU32(w, 1, {0, 0}, {0, 1}, {4, 2}, {6, 18});              // rendering intent relative
     } else if (!ce_default) {
       w.put(0, 1);  // want_icc
       WriteU32(w, gray ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});   // colour space
@@ -459,7 +472,7 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
       WriteU32(w, 1, {0, 0}, {0, 1}, {4, 2}, {6, 18});              // rendering intent relative
     }
     if (extra_fields) {
-      if (p.hdr) { w.put(0, 1); WriteF16(w, 1000.0f); WriteF16(w, 0.0f); w.put(0, 1); WriteF16(w, 0.0f); }   // tone mapping: intensity_target 1000
+      if (p.hdr || custom_target) { w.put(0, 1); WriteF16(w, custom_target ? g_color.intensity_target : 1000.0f); WriteF16(w, 0.0f); w.put(0, 1); WriteF16(w, 0.0f); }   // tone mapping: intensity_target
       else w.put(1, 1);                                                                                      // tone mapping all default
     }
     WriteU64(w, 0);  // extensions
@@ -1214,6 +1227,13 @@ void jxlsynth_free(uint8_t* p) { free(p); }
 void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::SyntheticImage(seed, w, h, rgb); }
 // ICC profile embedded by the image headers written from now on in this thread (size 0: none, enumerated colour encoding)
 void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
+// white_point < 0 clears the override
+void jxlsynth_set_color(int white_point, int primaries, int tf, uint32_t gamma_1e7, float intensity_target) {
+  synth::g_color = synth::ColorOverride();
+  if (white_point < 0) return;
+  synth::g_color.set = true; synth::g_color.white_point = white_point; synth::g_color.primaries = primaries; synth::g_color.tf = tf;
+  synth::g_color.gamma = gamma_1e7; synth::g_color.intensity_target = intensity_target;
+}
 // patch dictionary / splines of the frames written from now on in this thread (see WriteFeatures; n = 0 clears)
 void jxlsynth_set_features(const int32_t* patches, size_t npatch, const int32_t* splines, size_t nspline, int num_extra) {
   synth::g_patches.assign(patches, patches + npatch); synth::g_splines.assign(splines, splines + nspline); synth::g_feature_extra = num_extra;
