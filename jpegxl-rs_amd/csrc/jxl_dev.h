@@ -6,6 +6,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <math.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>

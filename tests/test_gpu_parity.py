@@ -1128,7 +1128,7 @@ def test_output_colour_encodings(jx, name):
         plain = S.encode_vardct(img, seed=5, strategy_mix=2)                                  # gaborish + EPF 1: unfused filters + OutputKernel
         nofilter = S.encode_vardct(img, seed=6, gab=0, epf_iters=0)
         layered = S.encode_vardct_frame(img, S.frame(is_last=0, save_as_reference=1), seed=3) + \
-            S.encode_vardct_frame(S.synthetic_image(9, 64, 48), S.frame(emit=1, have_crop=1, crop_x0=40, crop_y0=30, canvas_w=200, canvas_h=136, blend_mode=2, blend_source=1), seed=4)
+            S.encode_vardct_frame(S.synthetic_image(9, 64, 48), S.frame(emit=1, have_crop=1, crop_x0=40, crop_y0=30, canvas_w=200, canvas_h=136, blend_mode=1, blend_source=1), seed=4)
     finally:
         S.set_color()
     for data in (plain, nofilter, layered):
