@@ -6,7 +6,21 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 if os.environ.get("FUZZ_CASE"):                    # a transcode of a libjpeg-written JPEG (tests/jpeg_cases.py) instead of the fixture
     import jpeg_cases as JC
     import jpeg_tools as J
-    data = J.transcode(JC.jpeg_bytes(JC.CASES[int(os.environ["FUZZ_CASE"])]))
+    sel = os.environ["FUZZ_CASE"]
+    if sel.startswith("p"):                        # progressive file
+        data = J.transcode(JC.jpeg_bytes(JC.PROGRESSIVE[int(sel[1:])]))
+    elif sel.startswith("g"):                      # grey, progressive
+        data = J.transcode(JC.grey_jpeg_bytes(75, 52, 85, progressive=True))
+    elif sel.startswith("m"):                      # ICC / Exif / XMP in the codestream / boxes (brob)
+        import io
+        from PIL import Image, ImageCms
+        icc = ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes()
+        ex = Image.Exif(); ex[0x010E] = "a test image"
+        buf = io.BytesIO()
+        Image.fromarray(JC.photo(67, 45)).save(buf, "JPEG", quality=85, subsampling=2, icc_profile=icc, exif=ex.tobytes(), xmp=b"<x:xmpmeta xmlns:x='adobe:ns:meta/'/>", progressive=True)
+        data = J.transcode(buf.getvalue(), typed_metadata=True, compress_boxes=True)
+    else:
+        data = J.transcode(JC.jpeg_bytes(JC.CASES[int(sel)]))
 else:
     data = open(os.path.join(ROOT, "tests", "fixtures", "sample_jpg.jxl"), "rb").read()
 

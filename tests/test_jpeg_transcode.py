@@ -128,3 +128,33 @@ def test_grey_jpegs(jx, kw):
     px = np.frombuffer(O.decode(J.transcode(data)).pixels("u8", 1), np.uint8).reshape(52, 75).astype(int)
     d = np.abs(px - np.asarray(Image.open(io.BytesIO(data))).astype(int))
     assert d.max() <= 2 and d.mean() < 0.5
+
+
+def test_writer_survives_damaged_reconstruction_data(jx):
+    """Robustness of the host half of reconstruct(): bit flips in the jbrd bundle (marker order, table definitions, scan scripts,
+    reset points) and wild coefficients give an error or some byte string, never a crash or an out-of-bounds access."""
+    L = jx.libjxl()
+    L.JxlHipDebugWriteJpegSampled.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    rng = np.random.default_rng(5)
+    outcomes = [0, 0]
+    for case in (JC.PROGRESSIVE[0], JC.PROGRESSIVE[3], JC.CASES[4]):
+        data = JC.jpeg_bytes(case)
+        j = J.parse_jpeg(data)
+        jbrd = J.build_jbrd(j)
+        samp = np.array([[c["h"], c["v"]] for c in j.components], np.uint32)
+        coef = np.concatenate([c.reshape(-1) for c in j.coef]).astype(np.int16)
+        qt = np.array([j.qt[c["tq"]] for c in j.components], np.int32)
+        out = np.zeros(len(data) * 8 + 65536, np.uint8)
+        for trial in range(500):
+            bad = bytearray(jbrd)
+            for pos in rng.integers(0, min(len(bad), 120), 1 + trial % 3):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            cf = coef
+            if trial % 5 == 0:
+                cf = coef.copy()
+                cf[rng.integers(0, len(cf), 20)] = rng.integers(-32768, 32767, 20)
+            n = C.c_size_t(len(out))
+            rc = L.JxlHipDebugWriteJpegSampled(bytes(bad), len(bad), j.width, j.height, samp.ctypes.data, cf.ctypes.data, qt.ctypes.data, out.ctypes.data, C.byref(n))
+            assert rc in (0, 1, 2)
+            outcomes[rc == 0] += 1
+    assert outcomes[0] > 0 and outcomes[1] > 0
