@@ -188,10 +188,18 @@ def main():
     import jpegxl_rs_amd as jx
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path is HIP-only (no CPU fallback)")
+    # JXL_BENCH_SHARE_GPU=1 + JXL_BENCH_BACKEND=gloo: several ranks on one GPU — a functional check of the N > 1 control flow on a
+    # one-GPU box (RCCL refuses two ranks per device); never the configuration a result is quoted on
+    if os.environ.get("JXL_BENCH_SHARE_GPU") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("JXL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     B = args.batch
     inner = 1                       # pipeline iterations per step
