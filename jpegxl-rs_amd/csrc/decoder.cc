@@ -208,7 +208,11 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
       if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
     }
     for (auto& x : ih.extra) if (x.dim_shift != 0 || x.depth.is_float) throw ParseError("unsupported: subsampled / float extra channel", true);
-    if (p.modular && ih.depth.is_float) throw ParseError("unsupported: float Modular samples", true);
+    if (p.modular && ih.depth.is_float && !ih.xyb_encoded) {
+      // dec_modular.cc int_to_float: the sample's bit pattern, exp_bits of exponent; what the format allows and a binary32 can hold
+      const uint32_t b = ih.depth.bits, eb = ih.depth.exp_bits;
+      if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) throw ParseError("unsupported: float sample layout", true);
+    }
     if (p.feat.has_noise && !ih.xyb_encoded) throw ParseError("noise on a non-XYB frame", false);
     const bool last = p.is_last;
     bitpos = p.frame_end_bitpos;
@@ -822,7 +826,7 @@ void Batch::EnqueueModularTail(void* stream_v) {
           memset(&a, 0, sizeof(a));
           a.ncolor = op.num_c;
           for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = P(op.in[c]);
-          a.color_factor = op.color_factor;
+          a.color_factor = op.color_factor; a.float_bits = op.float_bits; a.float_exp_bits = op.float_exp_bits;
           a.alpha = op.has_alpha ? P(op.in[3]) : nullptr; a.alpha_factor = op.alpha_factor;
           LaunchModOutput(dframes_, i, a, images_[i]->plan.width, images_[i]->plan.height, stream_v);
           break;
@@ -895,7 +899,8 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
   for (size_t k = 0; k < op.num_c + e.ih.extra.size(); k++)
     if (list[k].w != p.width || list[k].h != p.height) throw ParseError("unsupported: channel of a different size than the image (dim_shift)", true);
   for (uint32_t c = 0; c < op.num_c; c++) op.in[c] = list[c].off;
-  op.color_factor = 1.0f / (float)((1u << e.ih.depth.bits) - 1);
+  op.color_factor = e.ih.depth.is_float ? 1.0f : 1.0f / (float)((1u << e.ih.depth.bits) - 1);
+  op.float_bits = e.ih.depth.is_float ? e.ih.depth.bits : 0; op.float_exp_bits = e.ih.depth.exp_bits;
   for (size_t k = 0; k < e.ih.extra.size(); k++) if (e.ih.extra[k].type == 0) {
     op.has_alpha = true; op.in[3] = list[op.num_c + k].off;
     op.alpha_factor = 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);
@@ -963,10 +968,12 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
             LaunchXybModToFloat((const int32_t*)(dwork_ + cy), (const int32_t*)(dwork_ + cx), (const int32_t*)(dwork_ + cbb), cw, dst, cur_stride, cw, ch, fac, st);
           });
         } else {
-          const float factor = (float)(1.0 / (double)((1u << bits) - 1));
+          const bool fl = ih.depth.is_float;
+          const float factor = fl ? 1.0f : (float)(1.0 / (double)((1u << bits) - 1));
+          const uint32_t fbits = fl ? ih.depth.bits : 0, febits = ih.depth.exp_bits;
           for (int c = 0; c < 3; c++) {
             const size_t src = cb.color_int[cb.nb_color_int == 1 ? 0 : c], dst = cur[c];
-            post_ops_.push_back([=](void* st) { LaunchIntToFloat((const int32_t*)(dwork_ + src), cw, B(dst), cur_stride, cw, ch, factor, st); });
+            post_ops_.push_back([=](void* st) { LaunchIntToFloat((const int32_t*)(dwork_ + src), cw, B(dst), cur_stride, cw, ch, factor, st, fbits, febits); });
           }
         }
       }

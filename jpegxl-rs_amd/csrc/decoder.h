@@ -157,6 +157,7 @@ class Batch {
     uint32_t nb_deltas = 0, predictor = 0, wp_stride = 0; size_t wp_scratch = 0;   // palette with delta entries / a predictor
     bool has_alpha = false;
     float color_factor = 1.0f, alpha_factor = 1.0f;
+    uint32_t float_bits = 0, float_exp_bits = 0;          // float samples: IntToFloatSample instead of the factor
   };
   vec<vec<ModOp>> mod_ops_;
   struct VarDctAlpha { bool has = false; size_t off = 0; float factor = 1.0f; };

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -472,6 +473,29 @@ struct BlockCtxDev {
   uint32_t num_lf_ctxs, num_ctxs;
   uint8_t ctx_map[3 * 13 * 64];
 };
+
+// ---- float samples of Modular images (dec_modular.cc int_to_float): the integer holds the bits of a float with `exp_bits` exponent
+// bits out of `bits`; repacked into binary32 (subnormals of the narrow format are normalised, bits == 32 is a plain reinterpretation)
+JXL_HD float IntToFloatSample(int32_t v, uint32_t bits, uint32_t exp_bits) {
+  uint32_t f = (uint32_t)v;
+  if (bits == 32) { float r; memcpy(&r, &f, 4); return r; }
+  const int exp_bias = (1 << (exp_bits - 1)) - 1;
+  const uint32_t sign_shift = bits - 1, mant_bits = bits - exp_bits - 1, mant_shift = 23 - mant_bits;
+  const uint32_t signbit = (f >> sign_shift) & 1u;
+  f &= (1u << sign_shift) - 1u;
+  if (f == 0) return signbit ? -0.0f : 0.0f;
+  int exp = (int)(f >> mant_bits);
+  uint32_t mantissa = (f & ((1u << mant_bits) - 1u)) << mant_shift;
+  if (exp == 0 && exp_bits < 8) {                 // subnormal of the narrow format: normalise, the leading 1 becomes implicit
+    while ((mantissa & 0x800000u) == 0) { mantissa <<= 1; exp--; }
+    exp++;
+    mantissa &= 0x7FFFFFu;
+  }
+  exp = exp - exp_bias + 127;
+  const uint32_t out = (signbit ? 0x80000000u : 0u) | ((uint32_t)exp << 23) | mantissa;
+  float r; memcpy(&r, &out, 4);
+  return r;
+}
 
 // ---- HDR transfer functions of the output stage (stage_from_linear.cc OpPq / OpHlg) ----------------------------------------------------
 // TF_PQ::EncodedFromDisplay: 4-over-4 rational polynomials in x^(1/4) (a second pair below 1e-4), x = linear value x intensity_target / 10000

@@ -146,7 +146,7 @@ struct FilterPlan {
 void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream);
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream);
 // Modular stages
-struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; };
+struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; uint32_t float_bits, float_exp_bits; };   // float_bits != 0: colour samples are float bit patterns
 void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream);
 void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, const LaunchCfg& cfg, void* stream);
 // inverse Squeeze of one channel: (avg, res) -> out; horizontal: avg aw x h, res rw x h, out (aw+rw) x h; vertical: avg w x ah, res w x rh
@@ -175,7 +175,8 @@ struct BlendArgs {
   float* canvas[3]; float* canvas_ec[4]; uint32_t canvas_stride, canvas_ec_stride, img_w, img_h, num_extra, premul_mask; uint32_t mode[5];
 };
 struct WriteArgs { const float* p[3]; const float* alpha; uint32_t stride, alpha_stride, img_w, img_h; uint8_t* out; uint64_t out_stride; uint32_t out_channels, out_type, out_big_endian, out_orient, is_gray, unpremul; };
-void LaunchIntToFloat(const int32_t* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor, void* stream);
+void LaunchIntToFloat(const int32_t* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor, void* stream, uint32_t float_bits = 0,
+                      uint32_t float_exp_bits = 0);   // float_bits != 0: the integers are float bit patterns (IntToFloatSample)
 void LaunchXybModToFloat(const int32_t* cy, const int32_t* cx, const int32_t* cb, uint32_t src_stride, float* const dst[3], uint32_t dst_stride, uint32_t w, uint32_t h, const float fac[3], void* stream);
 void LaunchPatches(const PatchFrameArgs& a, const PatchEntryDev* entries, const uint32_t* tile_start, const uint32_t* tile_list, void* stream);
 void LaunchSplines(float* const p[3], uint32_t stride, uint32_t w, uint32_t h, const SplineSegmentDev* segs, const uint32_t* row_start, const uint32_t* indices, void* stream);

@@ -3685,8 +3685,9 @@ __global__ void ModularOutputKernel(const FrameDev* __restrict__ frames, int fid
   if (x >= (int)f.width || y >= (int)f.height) return;
   const size_t o = (size_t)y * f.width + x;
   float r, g, b;
-  if (a.ncolor == 1) { r = g = b = (float)a.color[0][o] * a.color_factor; }
-  else { r = (float)a.color[0][o] * a.color_factor; g = (float)a.color[1][o] * a.color_factor; b = (float)a.color[2][o] * a.color_factor; }
+  auto sample = [&](int c) { const int32_t v = a.color[c][o]; return a.float_bits ? IntToFloatSample(v, a.float_bits, a.float_exp_bits) : (float)v * a.color_factor; };
+  if (a.ncolor == 1) { r = g = b = sample(0); }
+  else { r = sample(0); g = sample(1); b = sample(2); }
   const float al = a.alpha ? (float)a.alpha[o] * a.alpha_factor : 1.0f;
   // StorePixel picks r for gray output of gray images and g otherwise
   const uint32_t bps = f.out_type == 0 ? 1 : f.out_type == 2 ? 4 : 2;

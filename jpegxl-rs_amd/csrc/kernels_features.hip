@@ -70,10 +70,12 @@ __device__ __forceinline__ float LinearToSrgbF(float v) {   // cms/transfer_func
 }
 
 // ---- integer Modular planes -> float planes (dec_modular.cc ModularImageToDecodedRect) ---------------------------------
-__global__ void IntToFloatKernel(const int32_t* __restrict__ src, uint32_t src_stride, float* __restrict__ dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor) {
+__global__ void IntToFloatKernel(const int32_t* __restrict__ src, uint32_t src_stride, float* __restrict__ dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor,
+                                 uint32_t float_bits, uint32_t float_exp_bits) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= w || y >= h) return;
-  dst[(size_t)y * dst_stride + x] = (float)src[(size_t)y * src_stride + x] * factor;
+  const int32_t v = src[(size_t)y * src_stride + x];
+  dst[(size_t)y * dst_stride + x] = float_bits ? IntToFloatSample(v, float_bits, float_exp_bits) : (float)v * factor;
 }
 // XYB Modular frames code Y, X, B - Y; factors = the LF dequantisation factors (DequantMatrices::DCQuants)
 __global__ void XybModToFloatKernel(const int32_t* __restrict__ cy, const int32_t* __restrict__ cx, const int32_t* __restrict__ cb, uint32_t src_stride,
@@ -529,8 +531,9 @@ const dim3 kBlock2(32, 8);
 
 }  // namespace
 
-void LaunchIntToFloat(const int32_t* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor, void* stream) {
-  hipLaunchKernelGGL(IntToFloatKernel, Grid2(w, h), kBlock2, 0, (hipStream_t)stream, src, src_stride, dst, dst_stride, w, h, factor);
+void LaunchIntToFloat(const int32_t* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor, void* stream, uint32_t float_bits,
+                      uint32_t float_exp_bits) {
+  hipLaunchKernelGGL(IntToFloatKernel, Grid2(w, h), kBlock2, 0, (hipStream_t)stream, src, src_stride, dst, dst_stride, w, h, factor, float_bits, float_exp_bits);
 }
 void LaunchXybModToFloat(const int32_t* cy, const int32_t* cx, const int32_t* cb, uint32_t src_stride, float* const dst[3], uint32_t dst_stride, uint32_t w, uint32_t h,
                          const float fac[3], void* stream) {

@@ -122,12 +122,41 @@ static const float kDefaultUp8Weights[210] = {
     0.02727416f, 0.19446600f, 0.00159832f, -0.02232473f, 0.74982506f, 0.11452620f, -0.03348048f, -0.01605681f, -0.02070339f, -0.00458223f,
 };
 
+// dec_modular.cc int_to_float: a float sample's bit pattern (sign, exp_bits of exponent, the rest mantissa) -> binary32
+static float IntToFloatSample(int32_t in, uint32_t bits, uint32_t exp_bits) {
+  uint32_t f = (uint32_t)in;
+  float out;
+  if (bits == 32) { memcpy(&out, &f, 4); return out; }
+  const int exp_bias = (1 << (exp_bits - 1)) - 1;
+  const int sign_shift = (int)bits - 1, mant_bits = (int)bits - (int)exp_bits - 1, mant_shift = 23 - mant_bits;
+  const int signbit = (int)((f >> sign_shift) & 1u);
+  f &= (1u << sign_shift) - 1;
+  if (f == 0) return signbit ? -0.f : 0.f;
+  int exp = (int)(f >> mant_bits);
+  int mantissa = (int)(f & ((1u << mant_bits) - 1));
+  mantissa <<= mant_shift;
+  if (exp == 0 && exp_bits < 8) {          // subnormal number: normalise, then drop the leading 1 (implicit from now on)
+    while ((mantissa & 0x800000) == 0) { mantissa <<= 1; exp--; }
+    exp++;
+    mantissa &= 0x7fffff;
+  }
+  exp -= exp_bias;
+  exp += 127;
+  JXLO_CHECK(exp >= 0);
+  f = (signbit ? 0x80000000u : 0u) | ((uint32_t)exp << 23) | (uint32_t)mantissa;
+  memcpy(&out, &f, 4);
+  return out;
+}
+
 // dec_modular.cc ModularImageToDecodedRect: integer channels of the frame's Modular image -> float planes
 void ModularToFloat(const Frame& f, const ImageMetadata& m, Image3& img) {
   const bool gray = m.color.color_space == 1;
   const int w = f.w, h = f.h;
   for (int c = 0; c < 3; c++) img.p[c] = Plane(w, h);
-  if (m.depth.float_sample && !m.xyb_encoded) JXLO_FAIL("unsupported: float modular samples");
+  if (m.depth.float_sample && !m.xyb_encoded) {
+    const uint32_t b = m.depth.bits, eb = m.depth.exp_bits;
+    if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) JXLO_FAIL("unsupported: float sample layout");
+  }
   if (m.xyb_encoded) {
     // XYB is coded as Y, X, B - Y and scaled by the LF dequantisation factors (DequantMatrices::DCQuants)
     if (f.gimg.channel.size() < 3) JXLO_FAIL("missing colour channels");
@@ -142,11 +171,13 @@ void ModularToFloat(const Frame& f, const ImageMetadata& m, Image3& img) {
   }
   const int nb = (gray && !f.fh.do_ycbcr) ? 1 : 3;
   if ((int)f.gimg.channel.size() < nb) JXLO_FAIL("missing colour channels");
-  const float factor = (float)(1.0 / (double)((1u << m.depth.bits) - 1));
+  const bool fl = m.depth.float_sample;
+  const float factor = fl ? 1.0f : (float)(1.0 / (double)((1u << m.depth.bits) - 1));
   for (int c = 0; c < 3; c++) {
     const Channel& ch = f.gimg.channel[nb == 1 ? 0 : c];
     JXLO_CHECK(ch.w == w && ch.h == h);
-    for (size_t i = 0; i < (size_t)w * h; i++) img.p[c].d[i] = (float)ch.data[i] * factor;
+    if (fl) for (size_t i = 0; i < (size_t)w * h; i++) img.p[c].d[i] = IntToFloatSample(ch.data[i], m.depth.bits, m.depth.exp_bits);
+    else for (size_t i = 0; i < (size_t)w * h; i++) img.p[c].d[i] = (float)ch.data[i] * factor;
   }
 }
 

@@ -242,3 +242,11 @@ def set_color(white_point=None, primaries=1, tf=13, gamma=0.0, intensity_target=
         L.jxlsynth_set_color(-1, 1, 13, 0, 255.0)
     else:
         L.jxlsynth_set_color(white_point, primaries, tf, int(round(gamma * 1e7)), intensity_target)
+
+
+def set_float(exp_bits=0):
+    """Float samples in the image headers written from now on: the Modular integers are bit patterns of floats with `exp_bits` exponent
+    bits out of the `bits` the encoder is called with (0 = integer samples again)."""
+    L = lib()
+    L.jxlsynth_set_float.argtypes = [C.c_int]
+    L.jxlsynth_set_float(int(exp_bits))

@@ -1137,3 +1137,35 @@ def test_output_colour_encodings(jx, name):
         check_against_oracle(jx, data, np.float32, 3)
     srgb = O.decode(S.encode_vardct(img, seed=5, strategy_mix=2)).image("u8", 3).astype(int)
     assert np.abs(O.decode(plain).image("u8", 3).astype(int) - srgb).max() > 8                 # (the encoding does change the pixels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,exp_bits", [(16, 5), (32, 8), (24, 7)])
+def test_float_modular_samples(jx, bits, exp_bits):
+    """Lossless float images (BitDepth.float_sample; dec_modular.cc int_to_float): binary16 / binary32 / 24-bit samples through the plain
+    Modular output kernel and — two frames, the second blended on — through the float planes of the frame tail; f32 output is the exact
+    float, integer outputs clamp and scale.  decode() hands out Float16 / Float pixels for such files (result.rs:65-72)."""
+    rng = np.random.default_rng(bits)
+    h, w = 70, 90
+    if bits == 16:
+        vals = np.concatenate([np.arange(0, 0x3C01), np.arange(0x8000, 0xBC01)]).astype(np.uint16)       # [-1, 1] incl. subnormals, -0
+        ints = rng.choice(vals, (h, w, 3)).astype(np.int32)
+    elif bits == 32:
+        ints = (rng.random((h, w, 3), dtype=np.float32) * 1.25 - 0.125).view(np.int32).copy()
+        ints &= 0x7FFFFFFF                                                                                 # (keeps the synthesiser's residuals in 32 bits)
+    else:
+        ints = rng.integers(0, 64 << 16, (h, w, 3)).astype(np.int32)                                       # up to 2.0 in 1 + 7 + 16 bits
+    S.set_float(exp_bits)
+    try:
+        plain = S.encode_modular(ints, bits, False, 0)
+        layered = S.encode_modular_frame(ints, S.frame(is_last=0, save_as_reference=1), bits) + \
+            S.encode_modular_frame(ints[:32, :40], S.frame(emit=1, have_crop=1, crop_x0=10, crop_y0=20, canvas_w=w, canvas_h=h, blend_mode=1, blend_source=1), bits)
+    finally:
+        S.set_float(0)
+    for data in (plain, layered):
+        for dtype in (np.float32, np.uint8, np.uint16):
+            check_against_oracle(jx, data, dtype, 3)
+    meta, px = jx.decoder_builder().decode(plain)
+    assert px.dtype == (np.float16 if bits == 16 else np.float32)
+    if bits == 16:
+        assert np.array_equal(np.asarray(px).view(np.uint16).reshape(h, w, 3), ints.astype(np.uint16))       # the file's halves, bit for bit

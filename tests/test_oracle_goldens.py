@@ -356,3 +356,29 @@ def test_output_colour_encodings_against_independent_colour_science():
     t = x ** 0.25
     approx = np.where(x < 1e-4, np.polyval(plo[::-1], t) / np.polyval(qlo[::-1], t), np.polyval(p[::-1], t) / np.polyval(q[::-1], t))
     assert np.abs(approx - exact).max() < 2e-6
+
+
+def test_float_samples_against_numpy():
+    """Modular images with float samples (dec_modular.cc int_to_float): binary16 — every finite pattern incl. subnormals and -0 —, binary32
+    and a 24-bit layout (1 + 7 + 16) come out of the oracle as exactly the floats numpy reads from the same bits."""
+    import synth_lib as S
+    rng = np.random.default_rng(3)
+    h, w = 64, 96
+
+    def dec(ints, bits, exp_bits):
+        S.set_float(exp_bits)
+        try:
+            data = S.encode_modular(ints, bits, False, 0)
+        finally:
+            S.set_float(0)
+        return np.frombuffer(O.decode(data).pixels("f32", 3), np.float32).reshape(h, w, 3)
+    vals = np.concatenate([np.arange(0, 0x7C00), np.arange(0x8000, 0xFC00)]).astype(np.uint16)
+    pat = rng.choice(vals, (h, w, 3))
+    pat[0, :8, 0] = [0, 0x8000, 1, 0x8001, 0x03FF, 0x0400, 0x7BFF, 0xFBFF]
+    assert np.array_equal(dec(pat.astype(np.int32), 16, 5).view(np.uint32), pat.view(np.float16).astype(np.float32).view(np.uint32))
+    f = rng.random((h, w, 3), dtype=np.float32)
+    f[0, :3, 0] = [0.0, 1.0, 1e-40]
+    assert np.array_equal(dec(f.view(np.int32), 32, 8).view(np.uint32), f.view(np.uint32))
+    pat24 = rng.integers(0, 1 << 23, (h, w, 3)).astype(np.int32)
+    e, m = pat24 >> 16, pat24 & 0xFFFF
+    assert np.array_equal(dec(pat24, 24, 7).astype(np.float64), np.where(e == 0, m * 2.0 ** (-62 - 16), (1 + m / 65536.0) * 2.0 ** (e - 63.0)))

@@ -301,6 +301,7 @@ static thread_local std::vector<uint8_t> g_icc;
 // enums of color_encoding_internal.h, gamma in 1e-7 units (0 = use tf), intensity target in nits
 struct ColorOverride { bool set = false; int white_point = 1, primaries = 1, tf = 13; uint32_t gamma = 0; float intensity_target = 255.0f; };
 static thread_local ColorOverride g_color;
+static thread_local int g_float_exp_bits = 0;     // != 0: the image's samples are floats with this many exponent bits (jxlsynth_set_float)
 static void IccVarint(std::vector<uint8_t>& v, uint64_t x) { while (x > 127) { v.push_back((uint8_t)(x | 128)); x >>= 7; } v.push_back((uint8_t)x); }
 static std::vector<uint8_t> IccShuffleFwd(const std::vector<uint8_t>& in, size_t width) {   // decoder: out[i] = in[j], j walking columns
   const size_t n = in.size(), rows = (n + width - 1) / width;
@@ -421,7 +422,7 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
   const bool custom_up = p.upsampling > 1 && p.custom_up_weights;
-  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set;
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set && !g_float_exp_bits;
   w.put(all_default, 1);
   if (!all_default) {
     const bool custom_target = g_color.set && g_color.intensity_target != 255.0f;
@@ -433,6 +434,7 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
     }
     // BitDepth
     if (p.out_bits == 32) { w.put(1, 1); WriteU32(w, 32, {0, 32}, {0, 16}, {0, 24}, {6, 1}); w.put(8 - 1, 4); }
+    else if (g_float_exp_bits) { w.put(1, 1); WriteU32(w, bits, {0, 32}, {0, 16}, {0, 24}, {6, 1}); w.put((uint32_t)g_float_exp_bits - 1, 4); }
     else { w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1}); }
     w.put(1, 1);  // modular_16bit_buffers
     WriteU32(w, has_alpha ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {12, 1});
@@ -1227,6 +1229,7 @@ void jxlsynth_free(uint8_t* p) { free(p); }
 void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::SyntheticImage(seed, w, h, rgb); }
 // ICC profile embedded by the image headers written from now on in this thread (size 0: none, enumerated colour encoding)
 void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
+void jxlsynth_set_float(int exp_bits) { synth::g_float_exp_bits = exp_bits; }
 // white_point < 0 clears the override
 void jxlsynth_set_color(int white_point, int primaries, int tf, uint32_t gamma_1e7, float intensity_target) {
   synth::g_color = synth::ColorOverride();
