@@ -25,7 +25,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-LIBJXL_PATH = os.path.join(LIB_DIR, "libjxl.so")
+LIBJXL_PATH = os.environ.get("JXL_HIP_LIBJXL") or os.path.join(LIB_DIR, "libjxl.so")      # (override: A/B runs of kernel variants)
 LIBTHREADS_PATH = os.path.join(LIB_DIR, "libjxl_threads.so")
 
 # ---- C types (include/jxl_hip.h) ------------------------------------------------------------------------------------
