@@ -1841,13 +1841,34 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
   uint32_t vi = 0;
   uint2 ent_next = nvb ? LdG(vbl) : make_uint2(0, 0);
   const uint32_t sub_pack = f.hs[0] | (f.vs[0] << 1) | (f.hs[1] << 2) | (f.vs[1] << 3) | (f.hs[2] << 4) | (f.vs[2] << 5);   // chroma subsampling shifts (0 / 1)
-  uint32_t phase = 0;                     // 0: start next varblock, 1: read nzeros, 2: read a coefficient
+  uint32_t phase = 1;                     // 1: read nzeros, 2: read a coefficient (varblock starts ride on the iteration that ends the previous one)
   uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, lcx = 0, coff = 0, qlf = 0;
   uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, nz_total = 0;
   uint64_t end_bitpos = 0;
   const uint16_t* order = pd.orders[0];
   int32_t* blk = cbase0;
   uint32_t iter = 0;
+  // Start of the next varblock, or the end of the stream.  Runs in the iteration that finishes the previous varblock (a lane used to
+  // spend an iteration of its own in a "block start" phase without decoding a token: one in about twelve); the entry after the one
+  // consumed here is requested right away, so its load has the whole varblock (at least three tokens) to arrive.
+  auto block_start = [&]() {
+    if (vi >= nvb) {
+      if (state != 0x130000u) err = kErrAnsFinalState;
+      else if (br.BitPos() > limit) err = kErrOverrun;
+      end_bitpos = br.BitPos();
+      done = true;
+    } else {
+      const uint32_t ex = ent_next.x, ey = ent_next.y;
+      bx = (ex >> 16) & 31; by = (ex >> 21) & 31; qlf = ex >> 26;
+      lcx = (ex >> 5) & 7; l2 = (ex >> 8) & 15; ord = (ex >> 12) & 15;
+      covered = 1u << l2; size = covered * 64;
+      coff = gbase + ey;
+      ci = 0; phase = 1;
+      vi++;
+      if (vi < nvb) ent_next = LdG(vbl + vi);
+    }
+  };
+  if (!done) block_start();
   while (__ballot(!done) != 0ull) {
     // ---- bit-stream top-up, every 2nd iteration (<= 3 words consumed in between): store what was requested 2 iterations
     // ago, request the next 8 words when at most 8 are buffered (ring of 16: never overwritten, never empty)
@@ -1856,22 +1877,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
       if (!done && wload - br.wpos <= 8) { pend0 = fetch4(wload); pend1 = fetch4(wload + 4); wload += 8; pending = true; }
     }
     iter++;
-    if (!done && phase == 0) {
-      if (vi >= nvb) {
-        if (state != 0x130000u) err = kErrAnsFinalState;
-        else if (br.BitPos() > limit) err = kErrOverrun;
-        end_bitpos = br.BitPos();
-        done = true;
-      } else {
-        const uint32_t ex = ent_next.x, ey = ent_next.y;
-        bx = (ex >> 16) & 31; by = (ex >> 21) & 31; qlf = ex >> 26;
-        lcx = (ex >> 5) & 7; l2 = (ex >> 8) & 15; ord = (ex >> 12) & 15;
-        covered = 1u << l2; size = covered * 64;
-        coff = gbase + ey;
-        ci = 0; phase = 1;
-        vi++;
-      }
-    } else if (!done) {
+    if (!done) {
       const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
       // chroma-subsampled frames (dec_group.cc): a channel has a block only where the block starts one of its cells, and its
       // "non-zeros" neighbourhood lives on its own grid (nbx / nby)
@@ -1881,11 +1887,9 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
       // holds it (the 16-bit field is only extracted where it is used, so nothing waits for the load up here)
       uint32_t ctx, fetched = 0, fetched_sh = 0;
       auto fetch_pos = [&](uint32_t kk) { fetched = LdG(reinterpret_cast<const uint32_t*>(order + (kk & ~1u))); fetched_sh = (kk & 1u) << 4; };
-      // the next varblock's list entry is requested while the last channel of this one is decoded (the old entry is dead
-      // by now, so the load lands in its registers and nothing waits for it before the next block start)
-      if (phase == 1 && ci == 2 && vi < nvb) ent_next = LdG(vbl + vi);
       if (phase == 1 && ((bx & hsc) | (by & vsc)) != 0) {
-        ci++; phase = ci == 3 ? 0 : 1;             // this channel has no block here
+        ci++;                                      // this channel has no block here
+        if (ci == 3) block_start(); else phase = 1;
       } else {
       if (phase == 1) {
         order = reinterpret_cast<const uint16_t*>((uintptr_t)LdS<uint64_t>(kSimtOrdOff + (ord * 3 + c) * 8));
@@ -1939,7 +1943,7 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
         k++;
         if (nzeros != 0 && k >= size) { err = kErrNzeros; done = true; }
       }
-      if (phase == 2 && nzeros == 0) { ci++; phase = ci == 3 ? 0 : 1; }
+      if (phase == 2 && nzeros == 0) { ci++; if (ci == 3) block_start(); else phase = 1; }
       }
     }
   }
