@@ -678,7 +678,7 @@ bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* h
     src = tmp.data(); n = tmp.size();
   }
   cs->size = n;
-  cs->storage.assign((n + 3) / 4 + 4, 0);
+  cs->storage.assign((n + 3) / 4 + 20, 0);     // 80 zero bytes after the stream: the HF kernel's bit-stream ring prefetches up to 64 bytes ahead
   if (n) memcpy(cs->data(), src, n);
   return complete;
 }

@@ -1755,7 +1755,7 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   return (((hi << nbits) | bits) << lsb) | low;
 }
 
-template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave,
+template <bool ALL_LDS, bool SUB> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave,
                                                                                  uint32_t* __restrict__ sync, uint32_t epoch) {
   // sync[0]: workgroups of this launch that have started, sync[1]: number of the last HF launch whose workgroups all have
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
@@ -1817,7 +1817,10 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
   uint32_t wload = br.wpos & ~3u;             // next absolute word index to fetch (multiple of 4: 16-byte loads)
   // (words past the end of a section are the next section's, not zeros: a valid stream never consumes them — the ring only
   // prefetches them — and an invalid one fails the final-state / overrun checks either way)
-  auto fetch4 = [&](uint32_t w) -> uint4 { return w + 3 < wend_all ? LdG(reinterpret_cast<const uint4*>(words + w)) : make_uint4(w < wend_all ? LdG(words + w) : 0u, w + 1 < wend_all ? LdG(words + w + 1) : 0u, w + 2 < wend_all ? LdG(words + w + 2) : 0u, 0u); };
+  // (the codestream is followed by 80 zero bytes, host_parse.cc ExtractCodestream: the prefetch of a valid stream ends inside them; a
+  // damaged stream that runs past its section keeps re-reading the last words — it fails the final-state / overrun checks either way)
+  const uint32_t wmax = (wend_all + 12) & ~3u;
+  auto fetch4 = [&](uint32_t w) -> uint4 { return LdG(reinterpret_cast<const uint4*>(words + min(w, wmax))); };
   auto put4 = [&](uint32_t w, const uint4& v) { StS<uint4>(br.ring_off + ((w & 15) << 2), v); };
   for (int i = 0; i < 4; i++) { put4(wload, fetch4(wload)); wload += 4; }   // 16 words ahead
   uint4 pend0 = make_uint4(0, 0, 0, 0), pend1 = pend0;
@@ -1840,7 +1843,8 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
   const uint32_t gbase = gsafe * 65536u;
   uint32_t vi = 0;
   uint2 ent_next = nvb ? LdG(vbl) : make_uint2(0, 0);
-  const uint32_t sub_pack = f.hs[0] | (f.vs[0] << 1) | (f.hs[1] << 2) | (f.vs[1] << 3) | (f.hs[2] << 4) | (f.vs[2] << 5);   // chroma subsampling shifts (0 / 1)
+  // chroma subsampling shifts (0 / 1); SUB = false: a launch without subsampled frames, the lock-step loop does not carry their bookkeeping
+  const uint32_t sub_pack = SUB ? (f.hs[0] | (f.vs[0] << 1) | (f.hs[1] << 2) | (f.vs[1] << 3) | (f.hs[2] << 4) | (f.vs[2] << 5)) : 0u;
   uint32_t phase = 1;                     // 1: read nzeros, 2: read a coefficient (varblock starts ride on the iteration that ends the previous one)
   uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, lcx = 0, coff = 0, qlf = 0;
   uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, nz_total = 0;
@@ -1881,13 +1885,13 @@ template <bool ALL_LDS> __global__ __launch_bounds__(1024) void HfDecodeSimtKern
       const uint32_t c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y, X, B
       // chroma-subsampled frames (dec_group.cc): a channel has a block only where the block starts one of its cells, and its
       // "non-zeros" neighbourhood lives on its own grid (nbx / nby)
-      const uint32_t hsc = (sub_pack >> (2 * c)) & 1u, vsc = (sub_pack >> (2 * c + 1)) & 1u;
+      const uint32_t hsc = SUB ? (sub_pack >> (2 * c)) & 1u : 0u, vsc = SUB ? (sub_pack >> (2 * c + 1)) & 1u : 0u;
       const uint32_t nbx = bx >> hsc, nby = by >> vsc;
       // coefficient position after the current one: requested before the token is decoded, as the aligned 32-bit word that
       // holds it (the 16-bit field is only extracted where it is used, so nothing waits for the load up here)
       uint32_t ctx, fetched = 0, fetched_sh = 0;
       auto fetch_pos = [&](uint32_t kk) { fetched = LdG(reinterpret_cast<const uint32_t*>(order + (kk & ~1u))); fetched_sh = (kk & 1u) << 4; };
-      if (phase == 1 && ((bx & hsc) | (by & vsc)) != 0) {
+      if (SUB && phase == 1 && ((bx & hsc) | (by & vsc)) != 0) {
         ci++;                                      // this channel has no block here
         if (ci == 3) block_start(); else phase = 1;
       } else {
@@ -3798,8 +3802,10 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes) + (lanes + 1) * kSimtLaneBytes;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
       attr = true;
     }
     const dim3 grid(nblk, nframes);
@@ -3809,8 +3815,13 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
       int dev;
       if ((sync = HfSyncWords(&dev)) != nullptr) epoch = ++g_hf_enqueued[dev];
     }
-    if (all_lds) hipLaunchKernelGGL(HfDecodeSimtKernel<true>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
-    else hipLaunchKernelGGL(HfDecodeSimtKernel<false>, grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+    if (cfg.any_subsampled) {
+      if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+      else hipLaunchKernelGGL((HfDecodeSimtKernel<false, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+    } else {
+      if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+      else hipLaunchKernelGGL((HfDecodeSimtKernel<false, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+    }
     return;
   }
   const int threads = cfg.hf_block_threads;
