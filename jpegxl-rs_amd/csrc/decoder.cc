@@ -786,6 +786,7 @@ void Batch::Prepare(void* stream_v) {
   HIP_CHECK(hipMemcpyAsync(dpasses_, passes_host_.data(), sizeof(PassDev) * passes_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipMemcpyAsync(dlocal_, local_host_.data(), sizeof(ModLocalDev) * local_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
+  cfg.any_multipass = any_multipass_ ? 1 : 0;
   if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
   if (cfg.any_subsampled) cfg.lane_stride_hf = 1;   // so do chroma-subsampled frames (per-channel block grids)
   prepared_ = true;

@@ -1755,7 +1755,7 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   return (((hi << nbits) | bits) << lsb) | low;
 }
 
-template <bool ALL_LDS, bool SUB> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave,
+template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave,
                                                                                  uint32_t* __restrict__ sync, uint32_t epoch) {
   // sync[0]: workgroups of this launch that have started, sync[1]: number of the last HF launch whose workgroups all have
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
@@ -1787,9 +1787,10 @@ template <bool ALL_LDS, bool SUB> __global__ __launch_bounds__(1024) void HfDeco
   const uint32_t wend_all = (uint32_t)((f.cs_size + 3) >> 2);   // 16-byte loads stay inside the codestream buffer
   // Progressive frames: PassGroup section (pass, g) carries value >> shift of every coefficient under the pass's own code
   // and orders; the values accumulate.  The tables are re-staged per pass (block-wide), the lanes restart their streams.
-  for (uint32_t pass = 0; pass < f.num_passes; pass++) {
+  // MULTI = false: a launch without progressive frames — one pass, no shift, no accumulation in the loop
+  for (uint32_t pass = 0; pass < (MULTI ? f.num_passes : 1u); pass++) {
   const PassDev& pd = f.passes[pass];
-  const uint32_t shift = pd.shift;
+  const uint32_t shift = MULTI ? pd.shift : 0u;
   if (pass) __syncthreads();                           // every lane is done with the previous pass's tables
   StageCode(pd.code, code, kSimtCodeOff, lane_off > kSimtCodeOff ? lane_off - kSimtCodeOff : 0, /*with_ctx_map=*/true);
   if (threadIdx.x < 39) StS<uint64_t>(kSimtOrdOff + threadIdx.x * 8, (uint64_t)(uintptr_t)pd.orders[threadIdx.x]);
@@ -1847,7 +1848,8 @@ template <bool ALL_LDS, bool SUB> __global__ __launch_bounds__(1024) void HfDeco
   const uint32_t sub_pack = SUB ? (f.hs[0] | (f.vs[0] << 1) | (f.hs[1] << 2) | (f.vs[1] << 3) | (f.hs[2] << 4) | (f.vs[2] << 5)) : 0u;
   uint32_t phase = 1;                     // 1: read nzeros, 2: read a coefficient (varblock starts ride on the iteration that ends the previous one)
   uint32_t bx = 0, by = 0, ci = 0, covered = 1, l2 = 0, size = 64, ord = 0, lcx = 0, coff = 0, qlf = 0;
-  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, nz_total = 0;
+  uint32_t nzeros = 0, prev = 0, k = 0, histo = 0, next_pos = 0, nz_total = 0, bctx_idx = 0;
+  const uint32_t bctx_step = 13u * qlf_stride;
   uint64_t end_bitpos = 0;
   const uint16_t* order = pd.orders[0];
   int32_t* blk = cbase0;
@@ -1867,6 +1869,7 @@ template <bool ALL_LDS, bool SUB> __global__ __launch_bounds__(1024) void HfDeco
       lcx = (ex >> 5) & 7; l2 = (ex >> 8) & 15; ord = (ex >> 12) & 15;
       covered = 1u << l2; size = covered * 64;
       coff = gbase + ey;
+      bctx_idx = ord * qlf_stride + qlf;             // block-context index of channel ci = this + ci * 13 * qlf_stride
       ci = 0; phase = 1;
       vi++;
       if (vi < nvb) ent_next = LdG(vbl + vi);
@@ -1898,8 +1901,7 @@ template <bool ALL_LDS, bool SUB> __global__ __launch_bounds__(1024) void HfDeco
       if (phase == 1) {
         order = reinterpret_cast<const uint16_t*>((uintptr_t)LdS<uint64_t>(kSimtOrdOff + (ord * 3 + c) * 8));
         fetch_pos(covered);
-        const uint32_t idx = ((uint32_t)(c < 2 ? (c ^ 1) : 2) * 13 + ord) * qlf_stride + qlf;
-        const uint32_t block_ctx = LdS<uint8_t>(oMap + idx);
+        const uint32_t block_ctx = LdS<uint8_t>(oMap + bctx_idx + ci * bctx_step);   // ((c < 2 ? c ^ 1 : 2) == ci) * 13 + ord) * qlf_stride + qlf
         const uint32_t top = LdS<uint8_t>(nz_base + c * 32 + nbx), left = nbx ? LdS<uint8_t>(nz_base + c * 32 + nbx - 1) : 0;
         const uint32_t pred = nbx == 0 ? (nby == 0 ? 32 : top) : nby == 0 ? left : (top + left + 1) / 2;
         const uint32_t pc = pred > 64 ? 64 : pred;
@@ -1939,7 +1941,7 @@ template <bool ALL_LDS, bool SUB> __global__ __launch_bounds__(1024) void HfDeco
         next_pos = (fetched >> fetched_sh) & 0xFFFFu;
         if (u) {
           int32_t val = (int32_t)((uint32_t)UnpackSigned(u) << shift);
-          if (pass) val = (int32_t)((uint32_t)val + (uint32_t)LdG(blk + pos));
+          if (MULTI && pass) val = (int32_t)((uint32_t)val + (uint32_t)LdG(blk + pos));
           StG(blk + pos, val);
         }
         prev = u != 0;
@@ -3802,10 +3804,9 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes) + (lanes + 1) * kSimtLaneBytes;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
       attr = true;
     }
     const dim3 grid(nblk, nframes);
@@ -3815,13 +3816,12 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
       int dev;
       if ((sync = HfSyncWords(&dev)) != nullptr) epoch = ++g_hf_enqueued[dev];
     }
-    if (cfg.any_subsampled) {
-      if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
-      else hipLaunchKernelGGL((HfDecodeSimtKernel<false, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
-    } else {
-      if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
-      else hipLaunchKernelGGL((HfDecodeSimtKernel<false, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
-    }
+    // the common case gets its own instantiation: tables in LDS, no chroma subsampling, no progressive passes (every instruction of
+    // the lock-step loop is paid by all ~37 000 iterations of a frame); everything else takes the general one
+    const bool plain = all_lds && !cfg.any_subsampled && !cfg.any_multipass;
+    if (plain) hipLaunchKernelGGL((HfDecodeSimtKernel<true, false, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+    else if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+    else hipLaunchKernelGGL((HfDecodeSimtKernel<false, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
     return;
   }
   const int threads = cfg.hf_block_threads;
