@@ -250,6 +250,10 @@ def main():
     hf_stream = torch.cuda.Stream(device=dev, priority=-1) if deep else None
     hf_done = [torch.cuda.Event() for _ in range(nbuf)]
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
+    lf_done = [torch.cuda.Event() for _ in range(nbuf)]
+    # the HF stage of a batch waits for its LF decode only, the IDCT for the LF post-processing (JXL_BENCH_SPLIT_FRONT=0: the HF stage
+    # waits for both, as before)
+    split_front = pipeline and not deep and os.environ.get("JXL_BENCH_SPLIT_FRONT", "1") != "0"
     rest_done = [torch.cuda.Event() for _ in range(nbuf)]
     gather_done = [torch.cuda.Event() for _ in range(nbuf)]
     state = {"k": 0, "front_issued": 0, "limit": args.warmup * inner}
@@ -262,7 +266,12 @@ def main():
                 side.wait_event(rest_done[b])
             if gate is not None:
                 side.wait_event(gate)
-            batches[b].decode_part(1, side.cuda_stream, timed)
+            if split_front:
+                batches[b].decode_part(5, side.cuda_stream, timed)      # LF decode: all the HF stage waits for
+                lf_done[b].record(side)
+                batches[b].decode_part(6, side.cuda_stream, timed)      # LF post-processing: needed by the IDCT only
+            else:
+                batches[b].decode_part(1, side.cuda_stream, timed)
             front_done[b].record(side)
 
     def step(timed, last=False):
@@ -287,7 +296,7 @@ def main():
                     hf_done[b].record(hf_stream)
                 main.wait_event(hf_done[b])
             else:
-                main.wait_event(front_done[b])
+                main.wait_event(lf_done[b] if split_front else front_done[b])
             if do_gather and k >= nbuf:
                 main.wait_event(gather_done[b])       # the previous gather of this buffer set must have read the pixels
             if not deep:
@@ -295,6 +304,8 @@ def main():
                 hf_done[b].record(main)
             if late is not None and k + late < state["limit"] and state["front_issued"] <= k + late:
                 issue_front(k + late, timed, gate=hf_done[b]); state["front_issued"] = k + late + 1
+            if split_front:
+                main.wait_event(front_done[b])
             batches[b].decode_part(4, stream, timed)
             rest_done[b].record(main)
         if do_gather:

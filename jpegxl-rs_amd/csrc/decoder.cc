@@ -1192,13 +1192,18 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   if (!prepared_) Prepare(stream_v);
   const int n = (int)images_.size();
   if (any_vardct_) CheckFilterBuffers();
-  const bool do_front = part == 0 || part == 1, do_hf = part == 0 || part == 2 || part == 3, do_tail = part == 0 || part == 2 || part == 4;
+  // The front, too, comes in two pieces: 5 = LF decode (what the HF stage needs: block info, varblock lists, coefficient offsets),
+  // 6 = LF post-processing (dequantised LF, LLF, EPF sigma: what the IDCT and the filters need) — a pipelined caller lets the HF stage
+  // wait for piece 5 only, so that the post-processing kernels, which wait for wavefront slots beside the pixel kernels of the batch
+  // before, are off the critical path.
+  const bool do_lf = part == 0 || part == 1 || part == 5, do_lfpost = part == 0 || part == 1 || part == 6, do_front = do_lf || do_lfpost;
+  const bool do_hf = part == 0 || part == 2 || part == 3, do_tail = part == 0 || part == 2 || part == 4;
   const bool split = part != 0;                       // halves timed separately
   if (do_hf || do_tail) ran_once_ = true;
   if (do_hf) decodes_since_finish_++;
   vec<void*>* evs = nullptr;
   if (timed) {
-    if (do_front) { timed_events_.emplace_back(9, nullptr); }
+    if (do_lf) { timed_events_.emplace_back(9, nullptr); }
     if (timed_events_.empty()) timed_events_.emplace_back(9, nullptr);
     evs = !do_front ? &timed_events_[timed_rest_cursor_ < timed_events_.size() ? timed_rest_cursor_ : timed_events_.size() - 1] : &timed_events_.back();
   }
@@ -1207,18 +1212,20 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     hipEvent_t ev; HIP_CHECK(hipEventCreate(&ev)); (*evs)[i] = ev;
     HIP_CHECK(hipEventRecord(ev, stream));
   };
-  if (do_front) {
+  if (do_lf) {
     rec(0);
     DebugSync("start", stream_v);
     if (any_modchan_) LaunchModularGlobal(dframes_, n, cfg, stream_v);   // Modular frames; extra channels of VarDCT frames
     DebugSync("modular global", stream_v);
-    cfg.lf_head_start = part == 1;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
+    cfg.lf_head_start = part == 1 || part == 5;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
     DebugSync("LF decode", stream_v);
     rec(1);
+  }
+  if (do_lfpost) {
     if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, max_groups_, stream_v);
     DebugSync("LF post", stream_v);
-    if (part == 1) rec(2);
+    if (part == 1 || part == 6) rec(2);
   }
   if (!any_vardct_) {
     if (do_hf) { rec(split ? 7 : 2); rec(3); }
