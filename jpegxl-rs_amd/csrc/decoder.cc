@@ -103,9 +103,9 @@ static void FillColor(const ImageHeader& ih, bool do_ycbcr, FrameDev& f) {
   for (int k = 0; k < 9; k++) inv[k] = ih.opsin_inv[k];
   // images whose header names other primaries / another white point than sRGB / D65: XYB decodes to linear sRGB, the matrix takes it on
   // to the image's own primaries (icc_profile.cc SrgbToOriginalPrimaries)
-  float luminances[3];
+  float luminances[3] = {0.2126f, 0.7152f, 0.0722f};
   double to_original[9];
-  if (SrgbToOriginalPrimaries(ih, to_original, luminances) && ih.xyb_encoded) {
+  if (ih.xyb_encoded && SrgbToOriginalPrimaries(ih, to_original, luminances)) {   // (not for other images: their samples are in that space already)
     float adapted[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
       double e = 0;
