@@ -28,6 +28,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
 
 
+def _pmc_bytes(kernels, frames):
+    """HBM bytes of `frames` frames through the named kernels from the PMC passes (profiles/pmc_traffic.json), or None."""
+    try:
+        per = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_kernel"]
+        return int(sum(per[k] for k in kernels) * frames)
+    except Exception:
+        return None
+
+
 def _make_stream(args):
     import synth_lib as S
     seed, width, height, epf = args
@@ -381,6 +390,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_ms": round(stage_ms[dom], 4)},
+            # the entropy stages above are serial chains (HBM fraction ~ 0 by construction); the stage that IS bound by HBM is the IDCT:
+            # the same figures for it (stage = IdctTileKernel + IdctRareSpecialKernel, measured while the LF stages of two other batches run)
+            "roofline_hbm_stage": (lambda ms, by, pf: {"bound": "hbm", "kernel": "IdctTileKernel (+ IdctRareSpecialKernel)", "achieved": round(by / (ms * 1e-3) / 1e9, 3) if ms > 0 else None,
+                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
+                                                     "traffic": pf, "algorithmic_bytes_per_launch": by, "avg_launch_ms": round(ms, 4)})(
+                stage_ms.get("idct", 0.0), stage_bytes.get("idct", 0), _pmc_bytes(("IdctTileKernel<4, true>", "IdctRareSpecialKernel"), B)),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_gbs": {k: round(stage_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2) if stage_ms[k] > 0 else None for k in stage_ms},
             "device_bytes": sum(bt.device_bytes for bt in batches),
