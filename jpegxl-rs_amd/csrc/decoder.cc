@@ -332,6 +332,14 @@ void Batch::Prepare(void* stream_v) {
     ImageEntry& first = *images_[pi.first_unit];
     bool premul = false;
     for (auto& x : first.ih.extra) if (x.type == 0) { premul = x.alpha_associated; break; }
+    bool spot = false;
+    for (auto& x : first.ih.extra) if (x.type == 2) spot = true;
+    if (spot && first.out.render_spotcolors) {
+      // stage_spot.cc runs in the frame tail; grey images keep one colour plane there (not handled)
+      if (first.ih.color_space == 1) throw ParseError("unsupported: spot colours on a grey image", true);
+      if (first.ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels with spot colours", true);
+      if (!pi.complex) { pi.complex = true; for (int u = pi.first_unit; u < pi.first_unit + pi.num_units; u++) images_[u]->complex = true; }
+    }
     if (first.out.unpremul_alpha && premul && !pi.complex) {
       if (first.ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels with un-premultiplied output", true);
       pi.complex = true;
@@ -1075,6 +1083,14 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
       }
       if (p.frame_type == 2) continue;    // reference-only frames are not displayed
       // ---- colour transform into the output space
+      bool has_spot = false;
+      for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].type == 2) has_spot = true;
+      bool blends = p.have_crop || p.blend.mode != 0;
+      for (auto& b : p.ec_blend) if (b.mode != 0) blends = true;
+      const bool spot_after_linear = has_spot && first.out.render_spotcolors && p.is_last && !blends;
+      ColorArgs deferred_tf;
+      memset(&deferred_tf, 0, sizeof(deferred_tf));
+      bool have_deferred_tf = false;
       {
         ColorArgs ca;
         memset(&ca, 0, sizeof(ca));
@@ -1091,6 +1107,9 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
           ca.tf_kind = fd.color_mode == 0 ? 0 : fd.color_mode == 1 ? 1 : fd.color_mode == 4 ? 2 : fd.color_mode == 5 ? 3 : fd.color_mode == 6 ? 4 : 5;
           for (int k = 0; k < 5; k++) ca.hdr_par[k] = fd.hdr_par[k];
           ca.inverse_gamma = fd.inverse_gamma;
+          // spot colours are mixed in linear light when the frame goes straight to the output (dec_cache.cc PreparePipeline: XYB stage,
+          // [from-linear + blending], spot stage, from-linear): the transfer function then follows the spot stage
+          if (spot_after_linear && ca.mode == 0) { deferred_tf = ca; deferred_tf.mode = 3; ca.tf_kind = 1; have_deferred_tf = true; }
           post_ops_.push_back([=](void* st) { LaunchColor(ca, st); });
           if (separate) { for (int c = 0; c < 3; c++) cur[c] = cb.rgb[c]; cur_stride = fw; }
         }
@@ -1144,6 +1163,22 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
         for (uint32_t k = 0; k < ne; k++) sl.ec[k] = canvas_ec[k];
       }
       if (!p.is_last) continue;   // coalescing: the composite of the last frame is what the caller receives
+      // ---- spot colours (stage_spot.cc): colour = mix * spot + (1 - mix) * colour with mix = solidity * channel, channel by channel
+      if (first.out.render_spotcolors) {
+        for (uint32_t k = 0; k < ne; k++) {
+          if (ih.extra[k].type != 2) continue;
+          SpotArgs sa;
+          for (int c = 0; c < 3; c++) { sa.p[c] = B(canvas[c]); sa.color[c] = ih.extra[k].spot[c]; }
+          sa.stride = canvas_stride; sa.spot = B(canvas_ec[k]); sa.spot_stride = canvas_ec_stride; sa.scale = ih.extra[k].spot[3]; sa.w = ih.xsize; sa.h = ih.ysize;
+          post_ops_.push_back([=](void* st) { LaunchSpot(sa, st); });
+        }
+      }
+      if (have_deferred_tf) {
+        ColorArgs ta = deferred_tf;
+        for (int c = 0; c < 3; c++) { ta.src[c] = B(canvas[c]); ta.dst[c] = B(canvas[c]); }
+        ta.src_stride = ta.dst_stride = canvas_stride; ta.w = ih.xsize; ta.h = ih.ysize;
+        post_ops_.push_back([=](void* st) { LaunchColor(ta, st); });
+      }
       // ---- write stage
       WriteArgs wa;
       memset(&wa, 0, sizeof(wa));

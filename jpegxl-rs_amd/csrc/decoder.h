@@ -20,6 +20,7 @@ struct OutputSpec {
   void* device_ptr = nullptr;  // optional caller-owned device destination
   bool keep_orientation = false;  // false: the header's orientation is applied to the output (libjxl's default)
   bool unpremul_alpha = false;    // JxlDecoderSetUnpremultiplyAlpha: premultiplied colour is divided by alpha in the write stage
+  bool render_spotcolors = true;  // JxlDecoderSetRenderSpotcolors: spot-colour extra channels are mixed into the colour channels (stage_spot.cc)
 };
 
 // What the frames of one image share: the codestream and the image header.

@@ -715,7 +715,7 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
       e.dim_shift = r.U32({0, 0}, {0, 3}, {0, 4}, {3, 1});
       SkipName(r);
       if (e.type == 0) e.alpha_associated = r.b();
-      if (e.type == 2) for (int i = 0; i < 4; i++) r.F16();
+      if (e.type == 2) for (int i = 0; i < 4; i++) e.spot[i] = r.F16();
       if (e.type == 5) r.U32({0, 1}, {2, 0}, {4, 3}, {8, 19});
     }
     ih->xyb_encoded = r.b();

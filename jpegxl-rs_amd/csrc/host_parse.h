@@ -45,7 +45,7 @@ struct HostTree {
 };
 
 struct BitDepthInfo { bool is_float = false; uint32_t bits = 8, exp_bits = 0; };
-struct ExtraChannel { uint32_t type = 0; BitDepthInfo depth; uint32_t dim_shift = 0; bool alpha_associated = false; };
+struct ExtraChannel { uint32_t type = 0; BitDepthInfo depth; uint32_t dim_shift = 0; bool alpha_associated = false; float spot[4] = {0, 0, 0, 0}; };   // spot: colour + solidity of a spot-colour channel (type 2)
 
 struct ImageHeader {
   uint32_t xsize = 0, ysize = 0;

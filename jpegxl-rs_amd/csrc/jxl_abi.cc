@@ -255,8 +255,6 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       if (hipSetDevice(d->device) != hipSuccess) { SetLastError("no usable HIP device: the JPEG XL decode path requires an MI355X-class GPU (no CPU fallback)"); return JXL_DEC_ERROR; }
       struct Holder { Batch* b; ~Holder() { DeleteBatch(b); } } hold{NewBatch(d->device)};
       hold.b->AddImage(d->input, d->input_size);      // (throws "truncated" while the frame index is incomplete: nothing is kept)
-      for (auto& x : hold.b->image(0).ih.extra)
-        if (x.type == 2 && d->render_spotcolors) throw ParseError("unsupported: spot colour rendering (call JxlDecoderSetRenderSpotcolors(dec, JXL_FALSE))", true);
       DeleteBatch(d->batch);
       d->batch = hold.b; hold.b = nullptr;
       d->stage = JxlDecoderStruct::kHeaders;
@@ -308,6 +306,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       FormatToSpec(&d->out_format, &o);
       o.keep_orientation = d->keep_orientation;
       o.unpremul_alpha = d->unpremul_alpha;
+      o.render_spotcolors = d->render_spotcolors;
       d->batch->SetOutput(0, o);
       d->batch->Prepare(nullptr);
       d->batch->Run(nullptr);       // ══► the HIP hot path

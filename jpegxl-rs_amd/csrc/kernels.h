@@ -166,7 +166,7 @@ struct SplineSegmentDev;   // host_parse.h
 struct PatchEntryDev { const float* src[3]; const float* esrc[4]; uint32_t src_stride, esrc_stride; int32_t x, y; uint32_t xs, ys; uint32_t mode[5]; uint32_t pad; };
 struct PatchFrameArgs { float* p[3]; float* ec[4]; uint32_t stride, ec_stride, w, h, num_extra, premul_mask; };
 struct NoiseArgs { float* p[3]; uint32_t stride, w, h; float* noise[3]; uint32_t noise_stride, group_dim, visible_frame_index, nonvisible_frame_index; float lut[8]; float ytox, ytob; };
-// mode: 0 XYB -> linear -> transfer function (tf_kind 0 sRGB, 1 linear, 2 gamma, 3 Rec.709, 4 PQ, 5 HLG), 1 YCbCr -> RGB, 2 copy
+// mode: 3 = transfer function only (after a spot-colour stage in linear light); 0 XYB -> linear -> transfer function (tf_kind 0 sRGB, 1 linear, 2 gamma, 3 Rec.709, 4 PQ, 5 HLG), 1 YCbCr -> RGB, 2 copy
 struct ColorArgs { const float* src[3]; float* dst[3]; uint32_t src_stride, dst_stride, w, h, mode, tf_kind; float inverse_gamma, opsin_inv[9], neg_bias[3], neg_bias_cbrt[3], hdr_par[5]; };
 // mode[k] = BlendMode | alpha channel << 8 | clamp << 16; bg pointers are null when the source slot is empty (treated as zeros)
 struct BlendArgs {
@@ -184,6 +184,9 @@ void LaunchSplines(float* const p[3], uint32_t stride, uint32_t w, uint32_t h, c
 void LaunchUpsamplePlane(const float* src, uint32_t src_stride, uint32_t w, uint32_t h, float* dst, uint32_t dst_stride, uint32_t ow, uint32_t oh, uint32_t up, const float* weights, void* stream);
 void LaunchNoise(const NoiseArgs& a, void* stream);
 void LaunchColor(const ColorArgs& a, void* stream);
+// stage_spot.cc: p[c] = mix * color[c] + (1 - mix) * p[c], mix = scale * spot
+struct SpotArgs { float* p[3]; const float* spot; uint32_t stride, spot_stride, w, h; float color[3], scale; };
+void LaunchSpot(const SpotArgs& a, void* stream);
 void LaunchBlend(const BlendArgs& a, void* stream);
 void LaunchWrite(const WriteArgs& a, void* stream);
 // JPEG reconstruction: quantised coefficients of a JPEG-transcoded frame in JPEG layout — component c (0 Y, 1 Cb, 2 Cr), block raster

@@ -325,8 +325,22 @@ __global__ void ColorKernel(ColorArgs a) {
     r = fmaf(crcr, B, yb);
     g = fmaf(cgcr, B, fmaf(cgcb, X, yb));
     b = fmaf(cbcb, X, yb);
+  } else if (a.mode == 3) {   // transfer function only: the planes hold linear light (a spot-colour stage came in between)
+    r = X; g = Y; b = B;
+    if (a.tf_kind == 5) HlgInverseOotf(a.hdr_par, r, g, b, [](float x, float e) { return FastPowfD(x, e); });
+    const float tf_par = a.tf_kind == 4 ? a.hdr_par[0] : a.inverse_gamma;
+    r = TransferD(a.tf_kind, tf_par, r); g = TransferD(a.tf_kind, tf_par, g); b = TransferD(a.tf_kind, tf_par, b);
   } else { r = X; g = Y; b = B; }
   a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
+}
+
+__global__ void SpotKernel(SpotArgs a) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= a.w || y >= a.h) return;
+  const float mix = a.scale * a.spot[(size_t)y * a.spot_stride + x];
+  const size_t o = (size_t)y * a.stride + x;
+#pragma unroll
+  for (int c = 0; c < 3; c++) a.p[c][o] = mix * a.color[c] + (1.0f - mix) * a.p[c][o];
 }
 
 // ---- chroma upsampling of subsampled YCbCr frames (stage_chroma_upsampling.cc): horizontal, then vertical, each with the (1/4, 3/4)
@@ -556,6 +570,7 @@ void LaunchNoise(const NoiseArgs& a, void* stream) {
                      a.visible_frame_index, a.nonvisible_frame_index);
   hipLaunchKernelGGL(NoiseAddKernel, Grid2(a.w, a.h), kBlock2, 0, (hipStream_t)stream, a);
 }
+void LaunchSpot(const SpotArgs& a, void* stream) { hipLaunchKernelGGL(SpotKernel, Grid2(a.w, a.h), kBlock2, 0, (hipStream_t)stream, a); }
 void LaunchColor(const ColorArgs& a, void* stream) { hipLaunchKernelGGL(ColorKernel, Grid2(a.w, a.h), kBlock2, 0, (hipStream_t)stream, a); }
 void LaunchBlend(const BlendArgs& a, void* stream) { hipLaunchKernelGGL(BlendKernel, Grid2(a.img_w, a.img_h), kBlock2, 0, (hipStream_t)stream, a); }
 void LaunchWrite(const WriteArgs& a, void* stream) { hipLaunchKernelGGL(WriteKernel, Grid2(a.img_w, a.img_h), kBlock2, 0, (hipStream_t)stream, a); }

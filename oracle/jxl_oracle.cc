@@ -122,6 +122,19 @@ static const float kDefaultUp8Weights[210] = {
     0.02727416f, 0.19446600f, 0.00159832f, -0.02232473f, 0.74982506f, 0.11452620f, -0.03348048f, -0.01605681f, -0.02070339f, -0.00458223f,
 };
 
+static thread_local bool g_render_spot = true;   // JxlDecoderSetRenderSpotcolors (default on)
+
+// stage_spot.cc: every spot-colour extra channel in turn, p = mix * spot + (1 - mix) * p with mix = solidity * channel value
+static void SpotMix(const ImageMetadata& m, const std::vector<Plane>& extra, int x, int y, float* r, float* g, float* b) {
+  for (size_t e = 0; e < extra.size() && e < m.extra.size(); e++) {
+    if (m.extra[e].type != 2) continue;
+    const float mix = m.extra[e].spot[3] * extra[e].row(y)[x];
+    *r = mix * m.extra[e].spot[0] + (1.0f - mix) * *r;
+    *g = mix * m.extra[e].spot[1] + (1.0f - mix) * *g;
+    *b = mix * m.extra[e].spot[2] + (1.0f - mix) * *b;
+  }
+}
+
 // dec_modular.cc int_to_float: a float sample's bit pattern (sign, exp_bits of exponent, the rest mantissa) -> binary32
 static float IntToFloatSample(int32_t in, uint32_t bits, uint32_t exp_bits) {
   uint32_t f = (uint32_t)in;
@@ -313,6 +326,15 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     }
     if (fh.type == kReferenceOnly) continue;
     // ---- colour transform to the output space (stage_xyb.cc, stage_from_linear.cc, stage_ycbcr.cc)
+    // spot colours (dec_cache.cc PreparePipeline: XYB stage, [from-linear + blending], spot stage, from-linear): mixed in linear light
+    // when an XYB frame goes straight to the output, in the output space otherwise; only what is handed out gets them
+    bool has_spot = false;
+    for (size_t e = 0; e < num_extra; e++) if (m.extra[e].type == 2) has_spot = true;
+    has_spot = has_spot && g_render_spot && fh.is_last;
+    if (has_spot && gray) JXLO_FAIL("unsupported: spot colours on a grey image");
+    bool frame_blends = fh.have_crop || fh.blend.mode != 0;
+    for (auto& b : fh.ec_blend) if (b.mode != 0) frame_blends = true;
+    const bool spot_in_linear = has_spot && m.xyb_encoded && !frame_blends;
     Image3 rgb = img;
     if (m.xyb_encoded) {
       float luminances[3];
@@ -344,6 +366,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
       for (int y = 0; y < fhh; y++) for (int x = 0; x < fw; x++) {
         float r, g, b;
         XybToLinear(op, img.p[0].row(y)[x], img.p[1].row(y)[x], img.p[2].row(y)[x], &r, &g, &b);
+        if (spot_in_linear) SpotMix(m, extra, x, y, &r, &g, &b);       // stage_spot.cc between the XYB stage and the transfer function
         if (tf_kind == 5) ootf.Apply(&r, &g, &b);
         r = tf(r); g = tf(g); b = tf(b);
         rgb.p[0].row(y)[x] = r; rgb.p[1].row(y)[x] = g; rgb.p[2].row(y)[x] = b;
@@ -421,6 +444,8 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
       r.valid = true; r.is_xyb = false; r.w = out.w; r.h = out.h; r.color = canvas; r.extra = canvas_extra;
     }
     if (!fh.is_last) continue;   // coalescing: only the composite of the last frame is handed out (animation frames: last wins)
+    if (has_spot && !spot_in_linear)
+      for (int y = 0; y < out.h; y++) for (int x = 0; x < out.w; x++) SpotMix(m, canvas_extra, x, y, &canvas.p[0].row(y)[x], &canvas.p[1].row(y)[x], &canvas.p[2].row(y)[x]);
     out.color.clear();
     if (gray) out.color.push_back(canvas.p[0]);
     else for (int c = 0; c < 3; c++) out.color.push_back(canvas.p[c]);
@@ -512,6 +537,7 @@ jxlo_handle* jxlo_decode(const uint8_t* data, size_t size, int want_dump) {
 const char* jxlo_error(jxlo_handle* h) { return h->err.empty() ? nullptr : h->err.c_str(); }
 void jxlo_free(jxlo_handle* h) { delete h; }
 void jxlo_set_unpremultiply_alpha(jxlo_handle* h, int v) { h->unpremul = v != 0; }
+void jxlo_set_render_spotcolors(int v) { g_render_spot = v != 0; }   // applies to the decodes started afterwards on this thread
 // embedded ICC profile of the image (empty when the colour encoding is enumerated)
 size_t jxlo_icc(jxlo_handle* h, uint8_t* out, size_t cap) { const auto& v = h->d.meta.icc; if (out && cap >= v.size() && !v.empty()) memcpy(out, v.data(), v.size()); return v.size(); }
 void jxlo_get_info(jxlo_handle* h, jxlo_info* i) {

@@ -122,3 +122,10 @@ class Decoded:
 
 def decode(data: bytes, dump=False) -> Decoded:
     return Decoded(data, dump)
+
+
+def set_render_spotcolors(on=True):
+    """JxlDecoderSetRenderSpotcolors for the oracle decodes started afterwards (default on)."""
+    L = lib()
+    L.jxlo_set_render_spotcolors.argtypes = [C.c_int]
+    L.jxlo_set_render_spotcolors(1 if on else 0)

@@ -250,3 +250,11 @@ def set_float(exp_bits=0):
     L = lib()
     L.jxlsynth_set_float.argtypes = [C.c_int]
     L.jxlsynth_set_float(int(exp_bits))
+
+
+def set_spot(rgba=None):
+    """The extra channel of the images written from now on is a spot colour (r, g, b, solidity — half-float precision) instead of alpha;
+    call without arguments to go back to alpha."""
+    L = lib()
+    L.jxlsynth_set_spot.argtypes = [C.POINTER(C.c_float)]
+    L.jxlsynth_set_spot(None if rgba is None else (C.c_float * 4)(*rgba))

@@ -1173,3 +1173,46 @@ def test_float_modular_samples(jx, bits, exp_bits):
     assert px.dtype == (np.float16 if bits == 16 else np.float32)
     if bits == 16:
         assert np.array_equal(np.asarray(px).view(np.uint16).reshape(h, w, 3), ints.astype(np.uint16))       # the file's halves, bit for bit
+
+
+@pytest.mark.gpu
+def test_spot_colour_channels(jx):
+    """JxlDecoderSetRenderSpotcolors (decode.rs:350-362) / stage_spot.cc: a spot-colour extra channel is mixed into the colour channels —
+    colour = mix * spot + (1 - mix) * colour, mix = solidity * channel — in linear light when an XYB frame goes straight to the output, in
+    the output space otherwise (after blending); render_spotcolors(false) hands out the plain image.  Lossless RGB + spot (the mixing
+    formula checked with numpy), XYB VarDCT + spot with sRGB and PQ output, and a two-frame image with blending."""
+    rng = np.random.default_rng(4)
+    h, w = 72, 104
+    img = rng.integers(0, 256, (h, w, 4)).astype(np.int32)
+    spot = (1.0, 0.25, 0.125, 0.75)
+    S.set_spot(spot)
+    try:
+        lossless = S.encode_modular(img, 8, False, 0)
+        lossy = S.encode_vardct(S.synthetic_image(3, w, h), seed=5, alpha=img[..., 3].astype(np.uint8))
+        S.set_color(white_point=1, primaries=9, tf=16, intensity_target=1000.0)
+        lossy_pq = S.encode_vardct(S.synthetic_image(3, w, h), seed=5, alpha=img[..., 3].astype(np.uint8))
+        S.set_color()
+        layered = S.encode_vardct_frame(S.synthetic_image(3, w, h), S.frame(is_last=0, save_as_reference=1), seed=3, alpha=img[..., 3].astype(np.uint8)) + \
+            S.encode_vardct_frame(S.synthetic_image(9, 40, 32), S.frame(emit=1, have_crop=1, crop_x0=10, crop_y0=20, canvas_w=w, canvas_h=h, blend_mode=1, blend_source=1), seed=4,
+                                  alpha=img[:32, :40, 3].astype(np.uint8))
+    finally:
+        S.set_spot()
+        S.set_color()
+    for data in (lossless, lossy, lossy_pq, layered):
+        for dtype in (np.float32, np.uint8, np.uint16):
+            check_against_oracle(jx, data, dtype, 3)
+    px = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3)).decode_with(lossless, np.float32)[1].reshape(h, w, 3)
+    rgb, s = img[..., :3].astype(np.float32) / np.float32(255), img[..., 3].astype(np.float32) / np.float32(255)
+    mix = np.float32(spot[3]) * s
+    want = mix[..., None] * np.array(spot[:3], np.float32) + (np.float32(1) - mix)[..., None] * rgb
+    assert np.abs(px - want).max() < 1e-6
+    plain = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3), render_spotcolors=False).decode_with(lossless, np.uint8)[1].reshape(h, w, 3)
+    assert np.array_equal(plain, img[..., :3].astype(np.uint8))
+    O.set_render_spotcolors(False)
+    try:
+        for data in (lossy, layered):
+            ref = O.decode(data).pixels("u8", 3)
+            got = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3), render_spotcolors=False).decode_with(data, np.uint8)[1]
+            assert np.array_equal(np.asarray(got).ravel(), np.frombuffer(ref, np.uint8))
+    finally:
+        O.set_render_spotcolors(True)

@@ -382,3 +382,27 @@ def test_float_samples_against_numpy():
     pat24 = rng.integers(0, 1 << 23, (h, w, 3)).astype(np.int32)
     e, m = pat24 >> 16, pat24 & 0xFFFF
     assert np.array_equal(dec(pat24, 24, 7).astype(np.float64), np.where(e == 0, m * 2.0 ** (-62 - 16), (1 + m / 65536.0) * 2.0 ** (e - 63.0)))
+
+
+def test_spot_colour_mixing_against_numpy():
+    """stage_spot.cc in the oracle: colour = mix * spot + (1 - mix) * colour with mix = solidity * channel, on a lossless RGB image with a
+    spot-colour extra channel; with rendering switched off the plain image comes out."""
+    import synth_lib as S
+    rng = np.random.default_rng(4)
+    h, w = 40, 56
+    img = rng.integers(0, 256, (h, w, 4)).astype(np.int32)
+    spot = (1.0, 0.25, 0.125, 0.75)
+    S.set_spot(spot)
+    try:
+        data = S.encode_modular(img, 8, False, 0)
+    finally:
+        S.set_spot()
+    px = np.frombuffer(O.decode(data).pixels("f32", 3), np.float32).reshape(h, w, 3)
+    rgb, s = img[..., :3].astype(np.float32) / np.float32(255), img[..., 3].astype(np.float32) / np.float32(255)
+    mix = np.float32(spot[3]) * s
+    assert np.abs(px - (mix[..., None] * np.array(spot[:3], np.float32) + (np.float32(1) - mix)[..., None] * rgb)).max() < 1e-6
+    O.set_render_spotcolors(False)
+    try:
+        assert np.array_equal(np.frombuffer(O.decode(data).pixels("u8", 3), np.uint8).reshape(h, w, 3), img[..., :3].astype(np.uint8))
+    finally:
+        O.set_render_spotcolors(True)

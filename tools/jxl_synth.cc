@@ -301,6 +301,8 @@ static thread_local std::vector<uint8_t> g_icc;
 // enums of color_encoding_internal.h, gamma in 1e-7 units (0 = use tf), intensity target in nits
 struct ColorOverride { bool set = false; int white_point = 1, primaries = 1, tf = 13; uint32_t gamma = 0; float intensity_target = 255.0f; };
 static thread_local ColorOverride g_color;
+static thread_local bool g_spot_set = false;          // the image's extra channel is a spot colour (jxlsynth_set_spot) instead of alpha
+static thread_local float g_spot[4] = {0, 0, 0, 0};   // its colour and solidity
 static thread_local int g_float_exp_bits = 0;     // != 0: the image's samples are floats with this many exponent bits (jxlsynth_set_float)
 static void IccVarint(std::vector<uint8_t>& v, uint64_t x) { while (x > 127) { v.push_back((uint8_t)(x | 128)); x >>= 7; } v.push_back((uint8_t)x); }
 static std::vector<uint8_t> IccShuffleFwd(const std::vector<uint8_t>& in, size_t width) {   // decoder: out[i] = in[j], j walking columns
@@ -438,7 +440,14 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
     else { w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1}); }
     w.put(1, 1);  // modular_16bit_buffers
     WriteU32(w, has_alpha ? 1 : 0, {0, 0}, {0, 1}, {4, 2}, {12, 1});
-    if (has_alpha) {
+    if (has_alpha && g_spot_set) {
+      w.put(0, 1);                                         // not the default 8-bit alpha
+      WriteU32(w, 2, {0, 0}, {0, 1}, {4, 2}, {6, 18});     // type kSpotColor
+      w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1});
+      WriteU32(w, 0, {0, 0}, {0, 3}, {0, 4}, {3, 1});      // dim_shift
+      WriteU32(w, 0, {0, 0}, {4, 0}, {5, 16}, {10, 48});   // name
+      for (int i = 0; i < 4; i++) WriteF16(w, g_spot[i]);  // spot colour, solidity
+    } else if (has_alpha) {
       if (bits == 8 && !p.alpha_premultiplied) w.put(1, 1);  // d_alpha
       else {
         w.put(0, 1);
@@ -1230,6 +1239,8 @@ void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::Syntheti
 // ICC profile embedded by the image headers written from now on in this thread (size 0: none, enumerated colour encoding)
 void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
 void jxlsynth_set_float(int exp_bits) { synth::g_float_exp_bits = exp_bits; }
+// rgba == NULL: the extra channel is alpha again
+void jxlsynth_set_spot(const float* rgba) { synth::g_spot_set = rgba != nullptr; if (rgba) for (int i = 0; i < 4; i++) synth::g_spot[i] = rgba[i]; }
 // white_point < 0 clears the override
 void jxlsynth_set_color(int white_point, int primaries, int tf, uint32_t gamma_1e7, float intensity_target) {
   synth::g_color = synth::ColorOverride();
