@@ -207,7 +207,13 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
       if (p.max_prop >= 16) throw ParseError("unsupported: previous-channel MA properties in a VarDCT frame", true);
       if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
     }
-    for (auto& x : ih.extra) if (x.dim_shift != 0 || x.depth.is_float) throw ParseError("unsupported: subsampled / float extra channel", true);
+    for (auto& x : ih.extra) {
+      if (x.dim_shift != 0) throw ParseError("unsupported: subsampled extra channel", true);
+      if (x.depth.is_float) {
+        const uint32_t b = x.depth.bits, eb = x.depth.exp_bits;
+        if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) throw ParseError("unsupported: float sample layout", true);
+      }
+    }
     if (p.modular && ih.depth.is_float && !ih.xyb_encoded) {
       // dec_modular.cc int_to_float: the sample's bit pattern, exp_bits of exponent; what the format allows and a binary32 can hold
       const uint32_t b = ih.depth.bits, eb = ih.depth.exp_bits;
@@ -229,6 +235,7 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
     if (p.modular && p.upsampling != 1) complex = true;
     if (p.subsampled) complex = true;                     // chroma planes are upsampled in the frame tail
   }
+  for (auto& x : ih.extra) if (x.depth.is_float) complex = true;   // float extra channels are converted in the frame tail (IntToFloatSample)
   if (complex && ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels in a multi-frame / feature image", true);
   for (auto& u : units) u->complex = complex;
   PubImage pi; pi.first_unit = (int)images_.size(); pi.num_units = (int)units.size(); pi.complex = complex;
@@ -912,7 +919,7 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
   op.float_bits = e.ih.depth.is_float ? e.ih.depth.bits : 0; op.float_exp_bits = e.ih.depth.exp_bits;
   for (size_t k = 0; k < e.ih.extra.size(); k++) if (e.ih.extra[k].type == 0) {
     op.has_alpha = true; op.in[3] = list[op.num_c + k].off;
-    op.alpha_factor = 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);
+    op.alpha_factor = e.ih.extra[k].depth.is_float ? 1.0f : 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);   // (float alpha: converted in the frame tail)
     break;
   }
   if (e.complex) {
@@ -989,8 +996,10 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
       for (uint32_t k = 0; k < ne; k++) {
         if (k >= cb.ec_int.size()) throw ParseError("missing extra channel", false);
         const size_t src = cb.ec_int[k], dst = cb.ecf[k];
-        const float factor = 1.0f / (float)((1u << ih.extra[k].depth.bits) - 1);
-        post_ops_.push_back([=](void* st) { LaunchIntToFloat((const int32_t*)(dwork_ + src), cw, B(dst), cw, cw, ch, factor, st); });
+        const bool efl = ih.extra[k].depth.is_float;
+        const float factor = efl ? 1.0f : 1.0f / (float)((1u << ih.extra[k].depth.bits) - 1);
+        const uint32_t ebits = efl ? ih.extra[k].depth.bits : 0, eexp = ih.extra[k].depth.exp_bits;
+        post_ops_.push_back([=](void* st) { LaunchIntToFloat((const int32_t*)(dwork_ + src), cw, B(dst), cw, cw, ch, factor, st, ebits, eexp); });
         cur_ec[k] = dst;
       }
       // ---- patches

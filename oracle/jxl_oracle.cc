@@ -290,13 +290,18 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     std::vector<Plane> extra(num_extra);
     for (size_t e = 0; e < num_extra; e++) {
       if (m.extra[e].dim_shift != 0) JXLO_FAIL("unsupported: subsampled extra channel");
-      if (m.extra[e].depth.float_sample) JXLO_FAIL("unsupported: float extra channel");
+      const bool efl = m.extra[e].depth.float_sample;
+      if (efl) {
+        const uint32_t b = m.extra[e].depth.bits, eb = m.extra[e].depth.exp_bits;
+        if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) JXLO_FAIL("unsupported: float sample layout");
+      }
       if (first_extra + e >= f.gimg.channel.size()) JXLO_FAIL("missing extra channel");
       const Channel& ch = f.gimg.channel[first_extra + e];
       JXLO_CHECK(ch.w == cw_ && ch.h == ch_);
-      const float factor = 1.0f / (float)((1u << m.extra[e].depth.bits) - 1);
+      const float factor = efl ? 1.0f : 1.0f / (float)((1u << m.extra[e].depth.bits) - 1);
       extra[e] = Plane(cw_, ch_);
-      for (size_t i = 0; i < (size_t)cw_ * ch_; i++) extra[e].d[i] = (float)ch.data[i] * factor;
+      if (efl) for (size_t i = 0; i < (size_t)cw_ * ch_; i++) extra[e].d[i] = IntToFloatSample(ch.data[i], m.extra[e].depth.bits, m.extra[e].depth.exp_bits);
+      else for (size_t i = 0; i < (size_t)cw_ * ch_; i++) extra[e].d[i] = (float)ch.data[i] * factor;
       if (want_dump && m.extra[e].type == 0 && !out.dump.ints.count("alpha")) out.dump.ints["alpha"].assign(ch.data.begin(), ch.data.end());
     }
     // image features (dec_cache.cc PreparePipeline order): patches, splines, upsampling, noise

@@ -1216,3 +1216,22 @@ def test_spot_colour_channels(jx):
             assert np.array_equal(np.asarray(got).ravel(), np.frombuffer(ref, np.uint8))
     finally:
         O.set_render_spotcolors(True)
+
+
+@pytest.mark.gpu
+def test_float_alpha_channel(jx):
+    """Float extra channels (BitDepth.float_sample of an ExtraChannelInfo): a binary16 RGBA image, colour and alpha both bit patterns of
+    halves; they take the frame tail (IntToFloatSample per plane).  Exact halves back in f32, the usual clamping for integer outputs."""
+    rng = np.random.default_rng(16)
+    h, w = 50, 70
+    vals = np.concatenate([np.arange(0, 0x3C01), np.arange(0x8000, 0xBC01)]).astype(np.uint16)
+    ints = rng.choice(vals, (h, w, 4)).astype(np.int32)
+    S.set_float(5)
+    try:
+        data = S.encode_modular(ints, 16, False, 0)
+    finally:
+        S.set_float(0)
+    for dtype in (np.float32, np.uint8, np.uint16):
+        check_against_oracle(jx, data, dtype, 4)
+    px = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=4)).decode_with(data, np.float32)[1].reshape(h, w, 4)
+    assert np.array_equal(px.view(np.uint32), ints.astype(np.uint16).view(np.float16).astype(np.float32).view(np.uint32))

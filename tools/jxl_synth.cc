@@ -452,7 +452,8 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
       else {
         w.put(0, 1);
         WriteU32(w, 0, {0, 0}, {0, 1}, {4, 2}, {6, 18});  // type alpha
-        w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1});
+        if (g_float_exp_bits) { w.put(1, 1); WriteU32(w, bits, {0, 32}, {0, 16}, {0, 24}, {6, 1}); w.put((uint32_t)g_float_exp_bits - 1, 4); }   // float samples: alpha as well
+        else { w.put(0, 1); WriteU32(w, bits, {0, 8}, {0, 10}, {0, 12}, {6, 1}); }
         WriteU32(w, 0, {0, 0}, {0, 3}, {0, 4}, {3, 1});  // dim_shift
         WriteU32(w, 0, {0, 0}, {4, 0}, {5, 16}, {10, 48});  // name
         w.put(p.alpha_premultiplied ? 1 : 0, 1);  // alpha_associated
