@@ -3851,7 +3851,9 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
   }
   if (cfg.any_subsampled) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
-  if (all || cfg.need_rare_special) hipLaunchKernelGGL(IdctRareSpecialKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);
+  // one wavefront per group: a group holds a few dozen of these blocks (x 3 channels, one lane each), three more wavefronts per workgroup
+  // only occupied slots (256 threads: 26.4 ms for the IDCT stage of the bench batch, 64 or 128 threads: 25.0 ms)
+  if (all || cfg.need_rare_special) hipLaunchKernelGGL(IdctRareSpecialKernel, dim3(max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
   if (!cfg.idct_flags_known || cfg.any_big_blocks)
