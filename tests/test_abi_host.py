@@ -447,3 +447,17 @@ def test_host_parser_survives_corrupted_input(jx):
             except jx.GenericError:
                 rejected += 1
     assert accepted > 100 and rejected > 100
+
+
+def test_xcd_contiguous_tile_mapping_is_a_bijection():
+    """kernels.hip XcdContiguous (workgroup id -> tile of FusedGabEpf1OutKernel): every XCD (id mod 8) gets a contiguous run of tiles and
+    every tile is visited exactly once, for any tile count — restated here in Python, the kernel's outputs are checked by the GPU tests."""
+    def xcd_contiguous(bid, nwg):
+        q, r, c = nwg >> 3, nwg & 7, bid & 7
+        return (c * (q + 1) if c < r else r * (q + 1) + (c - r) * q) + (bid >> 3)
+    for nwg in list(range(1, 200)) + [10800, 10801, 10807, 43200, 65535]:
+        tiles = [xcd_contiguous(b, nwg) for b in range(nwg)]
+        assert sorted(tiles) == list(range(nwg)), nwg
+        for c in range(min(8, nwg)):
+            run = [tiles[b] for b in range(c, nwg, 8)]
+            assert run == list(range(run[0], run[0] + len(run))), (nwg, c)
