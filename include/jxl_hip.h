@@ -185,6 +185,9 @@ uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* batch);
 /* Algorithmic (compulsory) HBM bytes of one decode per stage: lf, lfpost, hf, idct, filters, out. */
 void JxlHipBatchStageBytes(const JxlHipBatch* batch, uint64_t out[6]);
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* batch);
+/* Facts about a prepared batch, by name (-1: unknown name): "lf_simt_frames" / "lf_legacy_frames" = VarDCT frames whose LF-group streams
+ * take the SIMT kernel (one stream per lane, lane stride < 64) / the one-wavefront-per-stream kernel, "lf_simt_lanes", "lf_simt_waves". */
+int64_t JxlHipBatchGetInfo(const JxlHipBatch* batch, const char* name);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,7 @@ def libjxl():
             "JxlHipBatchDeviceOutput": (vp, [vp, C.c_int]), "JxlHipBatchCopyOutput": (C.c_int, [vp, C.c_int, vp, sz, vp]),
             "JxlHipBatchTotalPixels": (C.c_uint64, [vp]), "JxlHipBatchCompressedBytes": (C.c_uint64, [vp]),
             "JxlHipBatchStageBytes": (None, [vp, C.POINTER(C.c_uint64 * 6)]), "JxlHipBatchDeviceBytes": (C.c_uint64, [vp]),
+            "JxlHipBatchGetInfo": (C.c_int64, [vp, C.c_char_p]),
             "JxlHipBatchShareBuffers": (C.c_int, [vp, vp]),
         }
         for name, (res, args) in sig.items():
@@ -545,6 +546,10 @@ class BatchDecoder:
         out = np.empty(n, dtype=np.uint8)
         self._chk(libjxl().JxlHipBatchCopyOutput(self._h, i, out.ctypes.data, n, stream))
         return JxlDecoder._convert(out, self._fmt[i])
+
+    def info_value(self, name: str) -> int:
+        """Facts about the prepared batch by name (include/jxl_hip.h JxlHipBatchGetInfo), e.g. "lf_simt_frames"."""
+        return int(libjxl().JxlHipBatchGetInfo(self._h, name.encode()))
 
     @property
     def total_pixels(self):

@@ -1,6 +1,8 @@
 // jxl-hip: batch decoder (see decoder.h).
 #include "decoder.h"
 #include <mutex>
+#include <map>
+#include <queue>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -81,6 +83,55 @@ void PutCode(Arena& a, const HostCode& c, size_t* ctx, size_t* cfg, size_t* alia
   *po = a.Put(c.pfx_sym_off.data(), c.pfx_sym_off.size() * 4);
   *ps = a.Put(c.pfx_syms.data(), c.pfx_syms.size() * 2);
 }
+// ---- SIMT LF decode: channel classes (kernels.h LfSimtPlan) -----------------------------------------------------------------------------
+// Walks the part of the MA tree channel `chan` of sub-stream `stream_id` can reach (static splits on the channel index / stream id are
+// followed wherever they occur).  Eligible: at most one other property, the row (2) or the gradient W + N - NW (9), with splits inside
+// the table's range; leaves with one common predictor out of zero / W / clamped gradient, offset 0, multiplier 1.  Fills the 1024-entry
+// property value -> cluster table (value v at index v + 512).
+struct LfChanClass { uint32_t kind = 0, pred = 0, cluster = 0; uint8_t lut[1024]; };
+bool ClassifyLfChannel(const HostTree& tree, const HostCode& code, int chan, uint32_t stream_id, LfChanClass* out) {
+  const vec<TreeNode>& nd = tree.nodes;
+  if (nd.empty()) return false;
+  int prop = -1, pred = -1;
+  {  // reachable subtree: properties, predictors, split range
+    vec<uint32_t> stack{0};
+    size_t visited = 0;
+    while (!stack.empty()) {
+      const uint32_t pos = stack.back(); stack.pop_back();
+      if (pos >= nd.size() || ++visited > 8192) return false;
+      const TreeNode& n = nd[pos];
+      if (n.prop < 0) {
+        const int p = (int)(n.a & 0xFF);
+        if ((p != 0 && p != 1 && p != 5) || n.val != 0 || n.b != 1) return false;
+        if (pred < 0) pred = p; else if (pred != p) return false;
+        if ((n.a >> 8) >= code.ctx_map.size()) return false;
+        continue;
+      }
+      if (n.prop == 0 || n.prop == 1) { stack.push_back((n.prop == 0 ? chan : (int32_t)stream_id) > n.val ? n.a : n.b); continue; }
+      if (n.prop != 2 && n.prop != 9) return false;
+      if (prop < 0) prop = n.prop; else if (prop != n.prop) return false;
+      if (n.val < -512 || n.val > 510) return false;
+      stack.push_back(n.a); stack.push_back(n.b);
+    }
+  }
+  if (pred < 0) return false;
+  for (int i = 0; i < 1024; i++) {
+    const int32_t v = i - 512;
+    uint32_t pos = 0;
+    for (;;) {
+      const TreeNode& n = nd[pos];
+      if (n.prop < 0) break;
+      const int32_t pv = n.prop == 0 ? chan : n.prop == 1 ? (int32_t)stream_id : v;
+      pos = pv > n.val ? n.a : n.b;
+    }
+    out->lut[i] = code.ctx_map[nd[pos].a >> 8];
+  }
+  out->kind = prop < 0 ? 0 : prop == 2 ? 1 : 2;
+  out->pred = (uint32_t)pred;
+  out->cluster = out->lut[512];
+  return true;
+}
+
 DevCode ViewCode(const HostCode& c, const uint8_t* base, size_t ctx, size_t cfg, size_t alias, size_t pc, size_t po, size_t ps) {
   DevCode d;
   d.ctx_map = base + ctx; d.cfg = (const uint32_t*)(base + cfg); d.alias = (const uint64_t*)(base + alias);
@@ -314,6 +365,17 @@ void Batch::StageBytes(uint64_t out[6]) const {
       out[5] += npx * (12 + out_px);
     }
   }
+}
+
+int64_t Batch::Info(const std::string& name) const {
+  if (name == "lf_simt_frames" || name == "lf_legacy_frames") {
+    int64_t simt = 0, legacy = 0;
+    for (size_t i = 0; i < frames_host_.size() && i < images_.size(); i++) if (!images_[i]->plan.modular) (frames_host_[i].lf_simt ? simt : legacy)++;
+    return name == "lf_simt_frames" ? simt : legacy;
+  }
+  if (name == "lf_simt_lanes") return lf_simt_.num_lanes;
+  if (name == "lf_simt_waves") return lf_simt_.num_lanes ? (lf_simt_.num_lanes + lf_simt_.lanes_per_wave - 1) / lf_simt_.lanes_per_wave : 0;
+  return -1;
 }
 
 void* Batch::device_output(int i) const {
@@ -576,6 +638,8 @@ void Batch::Prepare(void* stream_v) {
       f.tree = (const TreeNode*)(cbase + c.tree);
       f.tree_nodes = (uint32_t)p.tree.nodes.size();
       f.mod_code = ViewCode(p.tree_code, cbase, c.mod_ctx, c.mod_cfg, c.mod_alias, c.mod_pc, c.mod_po, c.mod_ps);
+      f.mod_cfg_uniform = p.tree_code.cfg.empty() ? 0xFFFFFFFFu : p.tree_code.cfg[0];
+      for (uint32_t v : p.tree_code.cfg) if (v != p.tree_code.cfg[0]) f.mod_cfg_uniform = 0xFFFFFFFFu;
     }
     f.uses_wp = p.tree.uses_wp; f.gwp = p.gwp;
     f.tree_max_prop = (uint32_t)p.tree.max_prop;
@@ -793,10 +857,77 @@ void Batch::Prepare(void* stream_v) {
     for (int i = 0; i < n; i++) upw[i] = co[i].up_weights;
     PlanPostOps(hconst_, upw);
   }
+  // ---- SIMT LF decode plan (cfg.lane_stride_lf < 64): streams of eligible frames, spread over lanes of about equal work
+  lf_simt_ = LfSimtPlan();
+  vec<uint8_t> simt_frame(n, 0);
+  size_t simt_streams_off = 0, simt_lanes_off = 0, simt_luts_off = 0;
+  if (any_vardct_ && cfg.lane_stride_lf < 64) {
+    vec<LfSimtStream> streams;
+    vec<uint64_t> cost;
+    vec<uint8_t> luts;
+    std::map<std::string, uint32_t> lut_of;       // table content -> offset in the blob (frames of one encoder share most tables)
+    for (int i = 0; i < n; i++) {
+      const FramePlan& p = images_[i]->plan;
+      if (p.modular || !p.has_global_tree || p.tree_code.use_prefix || p.tree_code.lz77 || p.tree_code.log_alpha > 8 || p.tree_code.num_clusters > 256) continue;
+      vec<LfSimtStream> mine;
+      bool ok = true;
+      for (uint32_t g = 0; g < p.num_lf_groups && ok; g++) {
+        LfSimtStream st;
+        memset(&st, 0, sizeof(st));
+        st.frame = (uint32_t)i; st.group = g;
+        for (int c = 0; c < 7 && ok; c++) {
+          LfChanClass cl;
+          ok = ClassifyLfChannel(p.tree, p.tree_code, c < 3 ? c : c - 3, c < 3 ? 1 + g : 1 + 2 * p.num_lf_groups + g, &cl);
+          if (!ok) break;
+          const std::string key((const char*)cl.lut, sizeof(cl.lut));
+          auto it = lut_of.find(key);
+          if (it == lut_of.end()) { it = lut_of.emplace(key, (uint32_t)luts.size()).first; luts.insert(luts.end(), cl.lut, cl.lut + 1024); }
+          st.chan[c].lut_off = it->second;
+          st.chan[c].info = cl.kind | (cl.pred << 2) | (cl.cluster << 8);
+        }
+        if (ok) mine.push_back(st);
+      }
+      if (!ok) continue;
+      simt_frame[i] = 1;
+      for (auto& st : mine) {
+        const uint32_t gx = st.group % p.xlfgroups, gy = st.group / p.xlfgroups;
+        const uint64_t gbw = std::min<uint32_t>(256, p.bw - gx * 256), gbh = std::min<uint32_t>(256, p.bh - gy * 256);
+        streams.push_back(st); cost.push_back(gbw * gbh * 5 + 2048);
+      }
+    }
+    if (!streams.empty()) {
+      // longest-processing-time-first onto as many lanes as the longest stream allows
+      uint64_t total = 0, longest = 0;
+      for (uint64_t cst : cost) { total += cst; longest = std::max(longest, cst); }
+      const size_t nlanes = std::max<size_t>(1, std::min<size_t>(streams.size(), (size_t)((total + longest - 1) / longest)));
+      vec<uint32_t> order(streams.size());
+      for (size_t k = 0; k < order.size(); k++) order[k] = (uint32_t)k;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+      vec<vec<uint32_t>> lane_streams(nlanes);
+      std::priority_queue<std::pair<uint64_t, uint32_t>, std::vector<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> pq;
+      for (size_t l = 0; l < nlanes; l++) pq.push({0, (uint32_t)l});
+      for (uint32_t k : order) { auto top = pq.top(); pq.pop(); lane_streams[top.second].push_back(k); pq.push({top.first + cost[k], top.second}); }
+      // lanes of the same frames next to each other (they read the same tables)
+      std::stable_sort(lane_streams.begin(), lane_streams.end(), [&](const vec<uint32_t>& a, const vec<uint32_t>& b) { return streams[a[0]].frame < streams[b[0]].frame; });
+      vec<LfSimtStream> flat;
+      vec<LfSimtLane> lanes;
+      for (auto& ls : lane_streams) { lanes.push_back(LfSimtLane{(uint32_t)flat.size(), (uint32_t)ls.size()}); for (uint32_t k : ls) flat.push_back(streams[k]); }
+      simt_streams_off = arena.Put(flat.data(), flat.size() * sizeof(LfSimtStream));
+      simt_lanes_off = arena.Put(lanes.data(), lanes.size() * sizeof(LfSimtLane));
+      simt_luts_off = arena.Put(luts.data(), luts.size());
+      lf_simt_.num_lanes = (uint32_t)lanes.size();
+      lf_simt_.lanes_per_wave = (uint32_t)std::max(1, 64 / std::max(1, cfg.lane_stride_lf));
+      lf_simt_.any_legacy = 0;
+      for (int i = 0; i < n; i++) if (!images_[i]->plan.modular && !simt_frame[i]) lf_simt_.any_legacy = 1;
+    }
+  }
   const_size_ = Align(hconst_.size());
   HIP_CHECK(hipMalloc((void**)&dconst_, const_size_));
   HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
-  for (int i = 0; i < n; i++) fill_frame(i, dconst_);
+  for (int i = 0; i < n; i++) { fill_frame(i, dconst_); frames_host_[i].lf_simt = lf_simt_.num_lanes ? simt_frame[i] : 0; }
+  if (lf_simt_.num_lanes) {
+    lf_simt_.streams = (const LfSimtStream*)(dconst_ + simt_streams_off); lf_simt_.lanes = (const LfSimtLane*)(dconst_ + simt_lanes_off); lf_simt_.luts = dconst_ + simt_luts_off;
+  }
   HIP_CHECK(hipMemcpyAsync(dframes_, frames_host_.data(), sizeof(FrameDev) * n, hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipMemcpyAsync(dpasses_, passes_host_.data(), sizeof(PassDev) * passes_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipMemcpyAsync(dlocal_, local_host_.data(), sizeof(ModLocalDev) * local_host_.size(), hipMemcpyHostToDevice, stream));
@@ -1262,7 +1393,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     if (any_modchan_) LaunchModularGlobal(dframes_, n, cfg, stream_v);   // Modular frames; extra channels of VarDCT frames
     DebugSync("modular global", stream_v);
     cfg.lf_head_start = part == 1 || part == 5;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
-    if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v);
+    if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v, &lf_simt_);
     DebugSync("LF decode", stream_v);
     rec(1);
   }

@@ -89,6 +89,7 @@ class Batch {
   size_t const_bytes() const { return const_size_; }
   size_t work_bytes() const { return work_size_ + coeff_bytes_ + (big_owner_ ? 0 : big_size_); }
   void ShareBigArena(Batch* owner);
+  int64_t Info(const std::string& name) const;
   uint64_t total_pixels() const;
   uint64_t compressed_bytes() const;
 
@@ -147,6 +148,7 @@ class Batch {
   int max_lf_groups_ = 0, max_groups_ = 0, max_w_ = 0, max_h_ = 0, max_bw_ = 0, max_bh_ = 0, max_epf_ = 0;
   bool any_gab_ = false, any_vardct_ = false, any_modular_ = false;
   FilterPlan fplan_;
+  LfSimtPlan lf_simt_;            // SIMT LF decode: device descriptors of the eligible frames' LF-group streams (cfg.lane_stride_lf < 64)
   struct ModFinish { int frame; vec<int> planes; };  // host-side channel lists for modular frames
   vec<vec<size_t>> mod_plane_offsets_;
   // one kernel launch of the host-planned tail of a Modular image: inverse global transforms, then the write stage

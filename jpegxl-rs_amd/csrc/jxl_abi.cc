@@ -401,6 +401,9 @@ void JxlHipBatchSetOption(JxlHipBatch* h, const char* name, int value) {
   else if (n == "hf_block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) h->b->cfg.hf_block_threads = value;
   else if (n == "lds_code_budget" && value >= 0 && value <= 128 * 1024) h->b->cfg.lds_code_budget = value;
 }
+int64_t JxlHipBatchGetInfo(const JxlHipBatch* h, const char* name) {
+  try { return h->b->Info(name ? name : ""); } catch (const std::exception& e) { SetLastError(e.what()); return -1; }
+}
 uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* h) { return h->b->total_pixels(); }
 uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* h) { return h->b->compressed_bytes(); }
 void JxlHipBatchStageBytes(const JxlHipBatch* h, uint64_t out[6]) { h->b->StageBytes(out); }

@@ -102,6 +102,8 @@ struct FrameDev {
   uint32_t upsampling, img_w, img_h;   // img_*: image size the write stage covers (= width/height when upsampling == 1)
   const float* up_weights;        // 15 / 55 / 210 coefficients of the symmetric (5N x 5N) kernel matrix, N = upsampling / 2
   float* up_plane[4];             // upsampled X, Y, B (and alpha as float) planes, img_w x img_h
+  uint32_t mod_cfg_uniform;       // the hybrid-integer configuration shared by every cluster of mod_code, or 0xFFFFFFFF
+  uint32_t lf_simt;               // the LF-group streams of this frame are decoded by LfDecodeSimtKernel (one stream per lane), placement by LfPlaceKernel
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
   uint32_t* hf_written;           // running count of non-zero AC coefficients the HF stage wrote for this frame (bench accounting)
@@ -136,8 +138,24 @@ struct LaunchCfg {
 
 void InitDeviceTables(void* stream);
 
+// ---- SIMT LF decode (LfDecodeSimtKernel): one LF-group stream (three LF coefficient channels + four HF-metadata channels, ~275 000 tokens
+// for a 2048x2048 region) per LANE instead of per wavefront.  The host classifies every channel of every stream from the frame's MA tree
+// (Batch::PlanLfSimt): after the static splits (channel index, stream id) the subtree must test at most one property — none, the row
+// (property 2) or the gradient W + N - NW (property 9) —, with leaves of predictor zero / W / clamped gradient, offset 0, multiplier 1.
+// Such a channel is described by a 1024-entry property -> cluster table (values clamped to [-512, 511]; splits outside that range make
+// the frame ineligible), which the lanes read through the L2 like the alias tables: nothing about a stream lives in LDS.
+struct LfSimtChan { uint32_t lut_off; uint32_t info; };    // lut_off: byte offset in the batch's LUT blob; info = kind | predictor << 2 | cluster << 8
+                                                           // kind 0: one cluster for the channel (`cluster`), 1: per row (table indexed by y), 2: per sample (property 9)
+struct LfSimtStream { uint32_t frame, group; LfSimtChan chan[7]; };   // channels: LF Y, X, B, then ytox, ytob, block info, sharpness
+struct LfSimtLane { uint32_t first, count; };               // a lane decodes streams [first, first + count) one after the other
+struct LfSimtPlan {
+  const LfSimtStream* streams = nullptr; const LfSimtLane* lanes = nullptr; const uint8_t* luts = nullptr;   // device pointers
+  uint32_t num_lanes = 0, lanes_per_wave = 16;
+  int any_legacy = 1;          // some VarDCT frame of the batch still takes LfDecodeKernel (one wavefront per stream)
+};
+
 // VarDCT stages.  max_* are maxima over the batch (grid sizing); nframes = frames in batch.
-void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream);
+void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream, const LfSimtPlan* simt = nullptr);
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, int max_groups, void* stream);
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream);
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream);

@@ -1173,6 +1173,9 @@ __device__ void StageModular(const TreeNode* tree, uint32_t num_tree_nodes, cons
 // K_lf: one wavefront per LF group (four per workgroup, sharing the tables) — LF coefficients (3 channels, order Y,X,B)
 // + HF metadata, then varblock placement
 // =====================================================================================================================
+// PLACE_ONLY: the seven channels have been decoded by LfDecodeSimtKernel (samples in the LF planes / the group's scratch, block count in
+// scratch[1]); only the part after the entropy decode runs — chroma-from-luma maps, varblock placement, sharpness merge.
+template <bool PLACE_ONLY>
 __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T, int& s_fail, GroupHeaderD& s_gh, uint32_t* s_u) {
   const uint32_t lane = threadIdx.x & 63, wb = T.wb;
   const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
@@ -1180,8 +1183,10 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
   BitReaderP br;
   const uint64_t sec_end = f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g];
-  if (f.single_section) br.Init(f.cs, f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos, f.cs_size);   // (after the global Modular stream, if any)
-  else br.Init(f.cs, f.sec_off[1 + g] * 8, sec_end);
+  if (!PLACE_ONLY) {
+    if (f.single_section) br.Init(f.cs, f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos, f.cs_size);   // (after the global Modular stream, if any)
+    else br.Init(f.cs, f.sec_off[1 + g] * 8, sec_end);
+  }
   const uint64_t limit = sec_end * 8;
   if (lane == 0) s_fail = 0;
   WaveSync();
@@ -1191,7 +1196,12 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride;
   uint32_t state = 0;
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
-
+  if (PLACE_ONLY) {
+    if (lane == 0) { s_u[1] = (uint32_t)LdG(scratch + 1); if (LdG(f.status) != 0 || s_u[1] == 0 || s_u[1] > gbw * gbh) s_fail = 1; }   // (a failed stream leaves no usable block count)
+    WaveSync();
+    if (s_fail) return;
+  }
+  if (!PLACE_ONLY) {
   // ---- LF coefficients
   if (lane == 0) {
     s_u[0] = br.Read(2);  // extra_precision
@@ -1227,24 +1237,25 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   }
   WaveSync();
   if (s_fail) return;
+  }
   const uint32_t nb_blocks = s_u[1];
-  mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
   const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
   int32_t* m_ytox = scratch + 16;
   int32_t* m_ytob = m_ytox + mcw * mch;
   int32_t* m_blk = m_ytob + mcw * mch;
   int32_t* m_sharp = m_blk + 2 * nb_blocks;
-  {
+  if (!PLACE_ONLY) {
+    mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
     ChannelDesc ch;
     ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; DecodeChannelCoop(br, state, T, mc, ch, 0);
     ch.data = m_ytob; DecodeChannelCoop(br, state, T, mc, ch, 1);
     ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeChannelCoop(br, state, T, mc, ch, 2);
     ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeChannelCoop(br, state, T, mc, ch, 3);
-  }
-  if (lane == 0) {
-    if (state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
-    else if (br.BitPos() > limit) { SetError(f, kErrOverrun); s_fail = 1; }
-    else if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
+    if (lane == 0) {
+      if (state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
+      else if (br.BitPos() > limit) { SetError(f, kErrOverrun); s_fail = 1; }
+      else if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
+    }
   }
   WaveSync();
   if (s_fail) return;
@@ -1402,7 +1413,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
 // variant for large pipelined batches; single images take the uncapped one (267 VGPRs, LF stage 20 % shorter).
 template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? JXL_LF_MINW : 1) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
+  if (f.is_modular || f.lf_simt) return;
   const uint32_t first = blockIdx.x * groups_per_block;
   if (first >= f.num_lf_groups) return;
   ModTables T;
@@ -1413,8 +1424,233 @@ template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? J
   const uint32_t wave = threadIdx.x >> 6;
   for (uint32_t turn = 0; turn < groups_per_block / kLfDecWaves; turn++) {   // (no block-wide barrier after this point)
     const uint32_t local = turn & 1 ? groups_per_block - 1 - (turn / 2) * kLfDecWaves - wave : (turn / 2) * kLfDecWaves + wave;
-    if (first + local < f.num_lf_groups) LfDecodeGroup(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
+    if (first + local < f.num_lf_groups) LfDecodeGroup<false>(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
   }
+}
+
+// =====================================================================================================================
+// K_lf, SIMT form: one LF-group stream per LANE (LfSimtPlan, kernels.h).  An LF group of a 4K frame is one rANS stream of ~275 000
+// tokens whose every context depends on the sample before it: one wavefront per stream (LfDecodeKernel above) keeps 1024 wavefronts
+// with one busy lane each, 170 VGPRs and 18 KB of LDS apiece, on the chip for the whole stage.  Here a wavefront carries up to 64
+// streams in lock step — one token per lane per iteration — so that a batch of 256 frames needs a few dozen wavefronts, no LDS and
+// ~50 VGPRs: the stage's latency grows (every iteration pays two dependent L2 round trips: property -> cluster table, alias table),
+// its footprint shrinks by more than an order of magnitude, and the stages of other batches get the CUs.
+// Per lane: the bit reader (next word always in flight), the rANS state, the position in the channel, W / NW and three prefetched
+// samples of the row above (loaded three iterations ahead, across the row boundary), pointers to the tables of its frame.
+// Everything else (geometry, sub-stream headers, channel classes) is recomputed from the descriptors in the rare path that
+// runs when a lane reaches the end of a row.  Semantics = DecodeChannelCoop's fast path (= jxl_dev.h DecodeModularChannel).
+// =====================================================================================================================
+// Bit reader of a SIMT lane: as BitReaderP (next word always in flight), but the refill load is unconditional — the word index is
+// clamped to the end of the CODESTREAM, which is followed by 80 zero bytes (Codestream::storage) — so that the loaded word lands in
+// `nextw` without a select (a select would make every refill wait for its own load).  A reader that runs past its section reads the
+// bytes of the next one instead of zeros; that only happens on damaged streams, which the end-of-stream position check rejects.
+struct BitReaderQ {
+  const uint32_t* words;
+  uint32_t wpos, wlast, nextw;
+  uint64_t buf;
+  int avail;
+  __device__ __forceinline__ uint32_t Load(uint32_t i) const { return LdG(words + min(i, wlast)); }
+  __device__ __forceinline__ void Init(const uint8_t* base, uint64_t bit_pos, uint64_t cs_size) {
+    words = reinterpret_cast<const uint32_t*>(base);
+    wpos = (uint32_t)(bit_pos >> 5);
+    wlast = (uint32_t)((cs_size + 3) >> 2);        // first word of the zero padding
+    buf = (uint64_t)Load(wpos) | ((uint64_t)Load(wpos + 1) << 32);
+    wpos += 2;
+    nextw = Load(wpos);
+    avail = 64;
+    const int skip = (int)(bit_pos & 31);
+    buf >>= skip; avail -= skip;
+    Refill();
+  }
+  __device__ __forceinline__ void Refill() {
+    if (avail <= 32) {
+      buf |= (uint64_t)nextw << avail;
+      avail += 32;
+      wpos++;
+      nextw = Load(wpos);
+    }
+  }
+  __device__ __forceinline__ uint32_t Read(int n) {  // n <= 32
+    Refill();
+    const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
+    buf >>= n; avail -= n;
+    return v;
+  }
+  __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)wpos * 32 - (uint64_t)avail; }
+};
+__device__ __forceinline__ bool SkipGroupHeaderSimt(BitReaderQ& br) {   // GroupHeader of an eligible stream: global tree, no transforms
+  const uint32_t use_global_tree = br.Read(1);
+  if (!br.Read(1)) { br.Read(10); br.Read(25); br.Read(16); }          // explicit weighted-predictor parameters: not used by eligible trees
+  const uint32_t sel = br.Read(2);
+  const uint32_t ntr = sel == 0 ? 0u : sel == 1 ? 1u : sel == 2 ? 2u + br.Read(4) : 18u + br.Read(8);
+  return use_global_tree && ntr == 0;
+}
+
+__global__ __launch_bounds__(64) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
+                                                        const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave) {
+  const uint32_t li = blockIdx.x * lanes_per_wave + threadIdx.x;
+  if (threadIdx.x >= lanes_per_wave || li >= num_lanes) return;
+  uint32_t cur, end;
+  { const uint2 ln = LdG(reinterpret_cast<const uint2*>(lanes + li)); cur = ln.x; end = ln.x + ln.y; }
+  BitReaderQ br;
+  br.words = nullptr; br.wpos = br.wlast = br.nextw = 0; br.buf = 0; br.avail = 0;
+  uint32_t state = 0;
+  int32_t* out = nullptr;                 // current row of the current channel
+  uint32_t x = 0, w = 0, y = 0, h = 0;
+  int32_t stride = 0;
+  int32_t left = 0, nw = 0, up0 = 0, up1 = 0, up2 = 0;
+  const uint8_t* lut = luts;
+  const uint64_t* alias = nullptr;
+  const uint32_t* cfgp = nullptr;
+  uint32_t cfgu = 0, la = 0, kind = 0, pred = 0, row_cluster = 0, const_cluster = 0;
+  bool hp = false, roll_next = false;     // a row above exists; the prefetch may run on into the next row (it exists and the row is >= 4 wide)
+  int c = 7;                              // channel of the stream; 7: start the next stream
+  for (;;) {
+    if (__builtin_expect(x >= w, 0)) {
+      // ---- rare path: next row, channel, sub-stream or stream
+      bool more = true;
+      for (;;) {
+        if (c < 7 && y + 1 < h) { y++; out += stride; break; }
+        const LfSimtStream* st = streams + cur;
+        if (c == 6) {   // the stream's last channel is complete
+          const FrameDev& f = frames[LdG(&st->frame)];
+          const uint32_t g = LdG(&st->group);
+          const uint64_t limit = (f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g]) * 8;
+          if (state != 0x130000u) SetError(f, kErrAnsFinalState);
+          else if (br.BitPos() > limit) SetError(f, kErrOverrun);
+          else if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
+          cur++; st++; c = 7;
+        }
+        if (c >= 7) {
+          if (cur >= end) { more = false; break; }
+          const FrameDev& f = frames[LdG(&st->frame)];
+          const uint32_t g = LdG(&st->group);
+          br.Init(f.cs, f.single_section ? (f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos) : f.sec_off[1 + g] * 8, f.cs_size);
+          int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
+          scratch[0] = (int32_t)br.Read(2);      // extra_precision
+          scratch[1] = 0;
+          if (!SkipGroupHeaderSimt(br)) { SetError(f, kErrUnsupported); cur++; continue; }   // (c stays 7: the next stream)
+          state = br.Read(32);
+          alias = f.mod_code.alias; cfgp = f.mod_code.cfg; la = f.mod_code.log_alpha; cfgu = f.mod_cfg_uniform;
+          c = -1;
+        }
+        c++;
+        const FrameDev& f = frames[LdG(&st->frame)];
+        const uint32_t g = LdG(&st->group);
+        const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
+        const uint32_t bx0 = gx * 256, by0 = gy * 256;
+        const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
+        int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
+        if (c == 3) {   // HF metadata sub-stream
+          bool ok = true;
+          if (state != 0x130000u) { SetError(f, kErrAnsFinalState); ok = false; }
+          const uint32_t nb = 1 + br.Read(CeilLog2D(gbw * gbh));
+          if (ok && !SkipGroupHeaderSimt(br)) { SetError(f, kErrUnsupported); ok = false; }
+          if (!ok) { cur++; c = 7; continue; }
+          scratch[1] = (int32_t)nb;
+          state = br.Read(32);
+        }
+        uint32_t nw_ = 0, nh_ = 0;
+        int32_t* data;
+        if (c < 3) {
+          const int pl = c == 0 ? 1 : c == 1 ? 0 : 2;          // stream channel order is Y, X, B
+          data = f.lfq[pl] + (size_t)(by0 >> f.vs[pl]) * f.bw + (bx0 >> f.hs[pl]);
+          nw_ = gbw >> f.hs[pl]; nh_ = gbh >> f.vs[pl]; stride = (int32_t)f.bw;
+        } else {
+          const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8, nb = (uint32_t)scratch[1];
+          int32_t* m_ytox = scratch + 16;
+          if (c == 3) { data = m_ytox; nw_ = mcw; nh_ = mch; }
+          else if (c == 4) { data = m_ytox + mcw * mch; nw_ = mcw; nh_ = mch; }
+          else if (c == 5) { data = m_ytox + 2 * mcw * mch; nw_ = nb; nh_ = 2; }
+          else { data = m_ytox + 2 * mcw * mch + 2 * nb; nw_ = gbw; nh_ = gbh; }
+          stride = (int32_t)nw_;
+        }
+        const uint2 cls = LdG(reinterpret_cast<const uint2*>(&st->chan[c]));
+        lut = luts + cls.x; kind = cls.y & 3; pred = (cls.y >> 2) & 7; const_cluster = cls.y >> 8;
+        y = 0; out = data;
+        if (nw_ == 0 || nh_ == 0) { w = 0; h = 0; continue; }      // empty channel: on to the next one
+        w = nw_; h = nh_;
+        break;
+      }
+      if (!more) break;
+      x = 0;
+      hp = y > 0;
+      roll_next = y + 1 < h && w >= 4;
+      row_cluster = kind == 1 ? (uint32_t)LdG(lut + 512 + min(y, 511u)) : const_cluster;
+      if (hp && w < 4) {                 // narrow rows: the rolling prefetch could run ahead of the stores
+        up0 = LdG(out - stride); up1 = w > 1 ? LdG(out - stride + 1) : 0; up2 = w > 2 ? LdG(out - stride + 2) : 0;
+      }
+      // everything this branch loaded has arrived before the branch ends: the common path below then starts without a wait for it
+      asm volatile("" : "+v"(up0), "+v"(up1), "+v"(up2), "+v"(row_cluster));
+    }
+    // ---- one sample.  All loads that do not depend on this sample's context go out first (bit-stream refill, the sample three
+    // positions ahead in the row above); the two that do (cluster, alias entry) are the iteration's two L2 round trips.
+    br.Refill();
+    int32_t up3 = 0;
+    {
+      const uint32_t j = x + 3;
+      const bool nxt = j >= w;
+      if (nxt ? roll_next : hp) up3 = LdG(out + (nxt ? (int32_t)(j - w) : (int32_t)j - stride));   // row above, or the start of this row for the row below
+    }
+    const int32_t n_raw = up0;
+    const int32_t W = x ? left : (hp ? n_raw : 0);
+    const int32_t N = hp ? n_raw : W;
+    const int32_t NW = (x && hp) ? nw : W;
+    nw = n_raw;
+    const int32_t grad = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+    uint32_t cluster = row_cluster;
+    if (kind == 2) cluster = LdG(lut + (uint32_t)(min(max(grad, -512), 511) + 512));
+    const int32_t mn = min(N, W), mx = max(N, W);
+    const int32_t g5 = NW < mn ? mx : (NW > mx ? mn : grad);
+    const int32_t guess = pred == 0 ? 0 : (pred == 1 ? W : g5);
+    // rANS symbol + hybrid integer (dec_ans.h), tables through the L2
+    const uint32_t res = state & 0xFFF;
+    const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
+    const uint64_t e = LdG(alias + ((cluster << la) + i));
+    const uint32_t cfg = cfgu != 0xFFFFFFFFu ? cfgu : LdG(cfgp + cluster);
+    const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+    const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+    const bool hit = pos >= cutoff;
+    uint32_t tok = hit ? right : i;
+    state = (hit ? freq1 : freq0) * (state >> 12) + (hit ? offs1 + pos : pos);
+    // (the alias entry has arrived, hence every load issued before it: rotate the window over the row above now, not at the top of the
+    // next iteration, where the move would wait for whatever the end of this iteration has in flight)
+    up0 = up1; up1 = up2; up2 = up3;
+    if (state < (1u << 16)) { state = (state << 16) | (uint32_t)(br.buf & 0xFFFFu); br.buf >>= 16; br.avail -= 16; }   // (>= 33 bits were buffered)
+    const uint32_t split_exp = cfg & 0xFF;
+    if (tok >= (1u << split_exp)) {
+      const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+      const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - (1u << split_exp)) >> (msb + lsb))) & 31;
+      const uint32_t low = tok & ((1u << lsb) - 1);
+      tok >>= lsb;
+      if ((int)nbits > br.avail) br.Refill();
+      const uint32_t bits = (uint32_t)(br.buf & ((1ull << nbits) - 1));
+      br.buf >>= nbits; br.avail -= (int)nbits;
+      const uint32_t hi = (1u << msb) | (tok & ((1u << msb) - 1));
+      tok = (((hi << nbits) | bits) << lsb) | low;
+    }
+    const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) + (uint32_t)guess);
+    StG(out + x, val);
+    left = val;
+    x++;
+  }
+}
+
+// What follows the entropy decode of an LF group whose channels LfDecodeSimtKernel has decoded: chroma-from-luma maps, varblock
+// placement, block-info words (LfDecodeGroup<true>) — one wavefront per LF group, 4.3 KB of LDS each, nothing staged.
+constexpr uint32_t kLfPlaceWaves = 4, kLfPlaceLds = 4352;
+__global__ __launch_bounds__(64 * kLfPlaceWaves) void LfPlaceKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular || !f.lf_simt) return;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t g = blockIdx.x * kLfPlaceWaves + wave;
+  if (g >= f.num_lf_groups) return;
+  __shared__ int s_fail_w[kLfPlaceWaves];
+  __shared__ GroupHeaderD s_gh_w[1];
+  __shared__ uint32_t s_u_w[kLfPlaceWaves][4];
+  ModTables T;
+  T.wb = wave * kLfPlaceLds;
+  LfDecodeGroup<true>(f, g, T, s_fail_w[wave], s_gh_w[0], s_u_w[wave]);
 }
 
 // =====================================================================================================================
@@ -3754,7 +3990,15 @@ static uint32_t* HfSyncWords(int* dev_out) {
   }
   return g_hf_sync[dev];
 }
-void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream) {
+void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream, const LfSimtPlan* simt) {
+  if (simt && simt->num_lanes) {
+    // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane), then one short wavefront per LF group for the
+    // varblock placement
+    const uint32_t lpw = std::min(64u, std::max(1u, simt->lanes_per_wave));
+    hipLaunchKernelGGL(LfDecodeSimtKernel, dim3(DivUp((int)simt->num_lanes, (int)lpw)), dim3(64), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw);
+    hipLaunchKernelGGL(LfPlaceKernel, dim3(DivUp(max_lf_groups, (int)kLfPlaceWaves), nframes), dim3(64 * kLfPlaceWaves), kLfPlaceWaves * kLfPlaceLds, (hipStream_t)stream, frames);
+    if (!simt->any_legacy) return;
+  }
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
   const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
