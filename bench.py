@@ -172,12 +172,16 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--epf", type=int, default=1)
-    ap.add_argument("--lane-stride-lf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_LF", "64")))
+    ap.add_argument("--lane-stride-lf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_LF", "2")),
+                    help="< 64: SIMT LF decode, 64 / value LF-group streams per wavefront; 64 = one stream per wavefront")
     ap.add_argument("--lane-stride-hf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_HF", "1")),
                     help="1 = SIMT HF decode (one group stream per lane), 64 = one stream per wavefront")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
-    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the LF stage of step k+1 with the rest of step k")
+    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
+    ap.add_argument("--in-flight", type=int, default=8, help="batch objects in flight (pipelined): LF stages run this many steps ahead, minus one")
+    ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
+    ap.add_argument("--out-buffers", type=int, default=2, help="output buffer sets the batches in flight cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -191,6 +195,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(streams, W, H)   # before any GPU runtime is initialised in this process (fork safety)
 
+    # the pipeline keeps ~10 HIP streams busy at once (main, HF, LF side streams, gather); the runtime maps streams onto 4 hardware
+    # queues by default and kernels of streams that share a queue serialise
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -218,70 +225,72 @@ def main():
         inner = max(1, per_rank // B)
     frame_bytes = W * H * 3
     pipeline = not args.no_pipeline
-    nbuf = int(os.environ.get("JXL_BENCH_NBUF", "3")) if pipeline else 1   # batches in flight: step k uses buffer set k % nbuf
+    # Pipeline (one MI355X): a decode is LF (entropy decode of the LF groups: a serial chain per stream, ~250 ms per launch
+    # whatever the batch size, a few dozen wavefronts in the SIMT form) -> LF post-processing -> HF (entropy decode of the coefficients,
+    # ~40 ms, one sparse workgroup per frame) -> IDCT -> filters + write (the HBM-bound part).  Throughput comes from batches in flight:
+    # step k runs the tail of batch k on the main stream, the HF stage of batch k + 1 on a stream of its own ("deep"), and the LF stages
+    # of batches k + 1 .. k + ahead on side streams.  A batch object (its LF outputs: 12 MB per 4K frame) is busy from its LF stage to
+    # its tail; the coefficient planes (106 MB per frame) exist twice (HF of k + 1 beside the IDCT of k), the pixel planes and the
+    # outputs as often as --out-buffers says.
+    deep = pipeline and os.environ.get("JXL_BENCH_DEEP", "1") == "1"
+    nbuf = int(os.environ.get("JXL_BENCH_NBUF", str(args.in_flight))) if pipeline else 1   # batches in flight: step k uses batch object k % nbuf
+    if deep and nbuf % 2:
+        nbuf += 1                        # (the two coefficient sets alternate with k; batch objects must keep their parity)
     ahead = nbuf - 1                     # LF stages issued ahead of the step being finished
+    nout = min(nbuf, max(1, args.out_buffers))
     outs, batches = [], []
     main = torch.cuda.current_stream()
     stream = main.cuda_stream
+    for j in range(nout):
+        outs.append(torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev))
     for b in range(nbuf):
-        out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+        out = outs[b % nout]
         batch = jx.BatchDecoder(local_rank)
         for i in range(B):
-            batch.add(streams[i % len(streams)], "uint8", 3, device_ptr=out.data_ptr() + i * frame_bytes)
+            batch.add(streams[(i + b * B) % len(streams)], "uint8", 3, device_ptr=out.data_ptr() + i * frame_bytes)
         batch.set_lane_stride(args.lane_stride_lf, args.lane_stride_hf)
         if b > 0:
-            batch.share_buffers(batches[0])     # the rest halves run one after the other: one set of coefficient/pixel planes
+            batch.share_buffers(batches[0])     # the tails run one after the other on the main stream: one set of pixel planes
+        if b >= (2 if deep else 1):
+            batch.share_coefficients(batches[b % 2 if deep else 0])
         batch.prepare(stream)
-        outs.append(out); batches.append(batch)
+        batches.append(batch)
     batch, out = batches[0], outs[0]
     gathered = None
     do_gather = world > 1 and not args.no_gather
     if do_gather and rank == 0:
         gathered = torch.empty((world, inner * B, H, W, 3), dtype=torch.uint8, device=dev)     # where the consumer rank sees the whole job's pixels (one step)
     from jpegxl_rs_amd.sharding import gather_frames_chunked
-    # LF ("front") parts run on a side stream so that step k+1's latency-bound LF decode overlaps step k's HF/IDCT/filter
-    # stages; events order front(k) -> rest(k) and rest(k) -> front(k+2) (same buffer set).
-    # (LF blocks are few and long-running: dispatch them first.)  With three buffer sets two LF stages are in flight, each on
-    # its own stream: an LF workgroup holds 35 KB of LDS, so two of them and an HF workgroup share a CU
-    sides = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, nbuf - 1))] if pipeline else []
+    sides = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, min(ahead, args.lf_streams)))] if pipeline else []
     comm = torch.cuda.Stream(device=dev) if do_gather else None               # RCCL gather overlaps the next step's decode
-    # What the LF stage of the batch two steps ahead waits for.  "rest" (default) = the end of the previous step, i.e. it starts
-    # together with this step's HF stage: the HF workgroups (80 KB of LDS on every CU) then force the dispatcher to spread the LF
-    # workgroups one per CU.  "hf" = the end of this step's HF stage (experiment: the LF workgroups then land next to pixel-kernel
-    # workgroups, pile up on some CUs, and the next HF stage waits for those CUs: 89 instead of 47 ms).
-    front_gate = os.environ.get("JXL_BENCH_FRONT_GATE", "rest")
-    # "deep" (experiment, off): the HF stage on a stream of its own as well, so that HF(k+1) overlaps the IDCT / filter stages of
-    # step k (coefficients are per batch, the shared pixel planes are only touched by the IDCT / filter stages, which stay in order
-    # on the main stream).  Measured (r02b, 256 frames): 119 ms per step instead of 105 — the 1024-thread HF workgroups wait for
-    # whole CUs to drain and the single-lane LF wavefronts already take VALU slots from the pixel kernels: HF 46 -> 79 ms,
-    # IDCT 21 -> 34 ms.  More batches in flight (4, 5) make it worse (136, 135 ms).
-    deep = pipeline and os.environ.get("JXL_BENCH_DEEP", "0") == "1"
     hf_stream = torch.cuda.Stream(device=dev, priority=-1) if deep else None
     hf_done = [torch.cuda.Event() for _ in range(nbuf)]
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
     lf_done = [torch.cuda.Event() for _ in range(nbuf)]
-    # the HF stage of a batch waits for its LF decode only, the IDCT for the LF post-processing (JXL_BENCH_SPLIT_FRONT=0: the HF stage
-    # waits for both, as before)
-    split_front = pipeline and not deep and os.environ.get("JXL_BENCH_SPLIT_FRONT", "1") != "0"
     rest_done = [torch.cuda.Event() for _ in range(nbuf)]
-    gather_done = [torch.cuda.Event() for _ in range(nbuf)]
-    state = {"k": 0, "front_issued": 0, "limit": args.warmup * inner}
+    out_free = [torch.cuda.Event() for _ in range(nout)]      # the gather of the step that used this output buffer last has read it
+    state = {"k": 0, "front_issued": 0, "hf_issued": 0, "limit": args.warmup * inner, "gathers": 0}
 
-    def issue_front(k, timed, gate=None):
+    def issue_front(k, timed):
         b = k % nbuf
         side = sides[k % len(sides)]
         with torch.cuda.stream(side):
             if k >= nbuf:
-                side.wait_event(rest_done[b])
-            if gate is not None:
-                side.wait_event(gate)
-            if split_front:
-                batches[b].decode_part(5, side.cuda_stream, timed)      # LF decode: all the HF stage waits for
-                lf_done[b].record(side)
-                batches[b].decode_part(6, side.cuda_stream, timed)      # LF post-processing: needed by the IDCT only
-            else:
-                batches[b].decode_part(1, side.cuda_stream, timed)
+                side.wait_event(rest_done[b])                       # the batch object's previous decode is complete
+            batches[b].decode_part(5, side.cuda_stream, timed)      # LF decode: all the HF stage waits for
+            lf_done[b].record(side)
+            batches[b].decode_part(6, side.cuda_stream, timed)      # LF post-processing: needed by the IDCT only
             front_done[b].record(side)
+
+    def issue_hf(k, timed):
+        b = k % nbuf
+        s_ = hf_stream if deep else main
+        with torch.cuda.stream(s_):
+            s_.wait_event(lf_done[b])
+            if deep and k >= 2:
+                s_.wait_event(rest_done[(k - 2) % nbuf])            # the coefficient set's previous user has consumed (and zeroed) it
+            batches[b].decode_part(3, s_.cuda_stream, timed)
+            hf_done[b].record(s_)
 
     def step(timed, last=False):
         k = state["k"]
@@ -291,43 +300,31 @@ def main():
                 batches[0].decode_timed(stream)
             else:
                 batches[0].decode(stream)
+            rest_done[b].record(main)
         else:
-            late = ahead if (front_gate == "hf" and ahead >= 2) else None
-            if state["front_issued"] <= k:
-                issue_front(k, timed); state["front_issued"] = k + 1
-            for j in range(1, ahead + 1):
-                if j != late and k + j < state["limit"] and state["front_issued"] <= k + j:
+            for j in range(0, ahead + 1):
+                if k + j < state["limit"] and state["front_issued"] <= k + j:
                     issue_front(k + j, timed); state["front_issued"] = k + j + 1
+            for j in range(0, 2 if deep else 1):
+                if k + j < state["limit"] and state["hf_issued"] <= k + j:
+                    issue_hf(k + j, timed); state["hf_issued"] = k + j + 1
             if deep:
-                with torch.cuda.stream(hf_stream):
-                    hf_stream.wait_event(front_done[b])
-                    batches[b].decode_part(3, hf_stream.cuda_stream, timed)
-                    hf_done[b].record(hf_stream)
                 main.wait_event(hf_done[b])
-            else:
-                main.wait_event(lf_done[b] if split_front else front_done[b])
-            if do_gather and k >= nbuf:
-                main.wait_event(gather_done[b])       # the previous gather of this buffer set must have read the pixels
-            if not deep:
-                batches[b].decode_part(3, stream, timed)
-                hf_done[b].record(main)
-            if late is not None and k + late < state["limit"] and state["front_issued"] <= k + late:
-                issue_front(k + late, timed, gate=hf_done[b]); state["front_issued"] = k + late + 1
-            if split_front:
-                main.wait_event(front_done[b])
+            main.wait_event(front_done[b])
+            if do_gather and state["gathers"] >= nout:
+                main.wait_event(out_free[k % nout])   # the previous gather of this output buffer must have read the pixels
             batches[b].decode_part(4, stream, timed)
             rest_done[b].record(main)
         if do_gather:
-            if not pipeline:
-                rest_done[b].record(main)
             with torch.cuda.stream(comm):
                 comm.wait_event(rest_done[b])
                 # per-chunk point-to-point transfers straight into their final place (all peers at once, one xGMI link each)
                 j = k % inner
-                gather_frames_chunked(outs[b], gathered[:, j * B:(j + 1) * B] if rank == 0 else None, dst=0, chunk_frames=args.gather_chunk)
-                gather_done[b].record(comm)
+                gather_frames_chunked(outs[k % nout] if pipeline else outs[0], gathered[:, j * B:(j + 1) * B] if rank == 0 else None, dst=0, chunk_frames=args.gather_chunk)
+                out_free[k % nout].record(comm)
+            state["gathers"] += 1
             if not pipeline:
-                main.wait_event(gather_done[b])
+                main.wait_event(out_free[k % nout])
         state["k"] = k + 1
 
     for i in range(args.warmup * inner):
@@ -335,7 +332,7 @@ def main():
     torch.cuda.synchronize()
     for bt in batches:
         bt.finish(stream)
-    state["k"] = 0; state["front_issued"] = 0; state["limit"] = args.steps * inner
+    state["k"] = 0; state["front_issued"] = 0; state["hf_issued"] = 0; state["limit"] = args.steps * inner
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -367,7 +364,7 @@ def main():
         # dominant kernel = stage with the largest device time; roofline from its ALGORITHMIC bytes per launch
         stage_ms = {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"}
         dom = max(stage_ms, key=stage_ms.get)
-        kernel_of = {"lf": "LfDecodeKernel", "lfpost": "LlfSigmaKernel", "hf": "HfDecodeSimtKernel" if args.lane_stride_hf == 1 else "HfDecodeKernel",
+        kernel_of = {"lf": "LfDecodeSimtKernel" if args.lane_stride_lf < 64 else "LfDecodeKernel", "lfpost": "LlfSigmaKernel", "hf": "HfDecodeSimtKernel" if args.lane_stride_hf == 1 else "HfDecodeKernel",
                      "idct": "IdctTileKernel", "filter": "FusedGabEpf1OutKernel" if args.epf == 1 else "EpfKernel", "out": "OutputKernel"}
         achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
         traffic = None
@@ -417,10 +414,15 @@ def main():
             # outside the timed region: decoded frames of the batches the timed steps wrote, against the CPU oracle
             import oracle_lib as O
             ok, checked = True, []
-            for bi, bt in enumerate(batches):
+            total_steps = args.steps * inner
+            for oj in range(len(outs)):
+                ks = [k for k in range(total_steps) if (k % len(outs) if pipeline else 0) == oj]
+                if not ks:
+                    continue
+                bi = ks[-1] % nbuf                    # the batch object whose tail wrote this output buffer last
                 for fi in sorted({0, B // 2, B - 1}):
-                    got = outs[bi][fi].cpu().numpy().reshape(-1)
-                    ref = O.decode(streams[fi % len(streams)]).pixels("u8", 3)
+                    got = outs[oj][fi].cpu().numpy().reshape(-1)
+                    ref = O.decode(streams[(fi + bi * B) % len(streams)]).pixels("u8", 3)
                     ok = ok and bool(np.array_equal(got, ref))
                     checked.append(f"{bi}:{fi}")
             result["verified_vs_oracle"] = ok

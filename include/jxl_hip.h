@@ -128,6 +128,11 @@ const char* JxlHipLastError(void);
  * decode, so two batches whose part-2 halves run one after the other on one stream can share them: halves device memory of a
  * double-buffered pipeline).  Call before JxlHipBatchPrepare(batch); owner must be prepared, at least as large, and outlive batch. */
 int JxlHipBatchShareBuffers(JxlHipBatch* batch, JxlHipBatch* owner);
+/* The same for the quantised-coefficient planes (written by the HF stage of a decode, consumed and zeroed again by its IDCT stage): batches
+ * whose [HF ... IDCT] intervals never overlap may use one set.  A deep pipeline alternates between two owners, so that the HF stage of
+ * batch k + 1 runs beside the IDCT of batch k.  Call before JxlHipBatchPrepare(batch); owner must be prepared, at least as large, and
+ * outlive batch.  Without it every batch holds planes of its own (106 MB per 4K frame). */
+int JxlHipBatchShareCoefficients(JxlHipBatch* batch, JxlHipBatch* owner);
 /* Host-only: parses the signature/container and image header of `data` and writes the ICC profile JxlDecoderGetColorAsICCProfile
  * would return (pass icc_out == NULL to query *icc_size).  Needs no GPU.  Returns 0 on success. */
 int JxlHipColorProfileFromHeaders(const uint8_t* data, size_t size, uint8_t* icc_out, size_t* icc_size);

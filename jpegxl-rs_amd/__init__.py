@@ -105,7 +105,7 @@ def libjxl():
             "JxlHipBatchTotalPixels": (C.c_uint64, [vp]), "JxlHipBatchCompressedBytes": (C.c_uint64, [vp]),
             "JxlHipBatchStageBytes": (None, [vp, C.POINTER(C.c_uint64 * 6)]), "JxlHipBatchDeviceBytes": (C.c_uint64, [vp]),
             "JxlHipBatchGetInfo": (C.c_int64, [vp, C.c_char_p]),
-            "JxlHipBatchShareBuffers": (C.c_int, [vp, vp]),
+            "JxlHipBatchShareBuffers": (C.c_int, [vp, vp]), "JxlHipBatchShareCoefficients": (C.c_int, [vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -515,6 +515,11 @@ class BatchDecoder:
         """Use `owner`'s coefficient / pixel planes (call before prepare; see include/jxl_hip.h JxlHipBatchShareBuffers)."""
         self._chk(libjxl().JxlHipBatchShareBuffers(self._h, owner._h))
         self._owner = owner   # keep it alive
+
+    def share_coefficients(self, owner: "BatchDecoder"):
+        """Use `owner`'s quantised-coefficient planes (call before prepare; include/jxl_hip.h JxlHipBatchShareCoefficients)."""
+        self._chk(libjxl().JxlHipBatchShareCoefficients(self._h, owner._h))
+        self._coef_owner = owner
 
     def prepare(self, stream=None):
         self._chk(libjxl().JxlHipBatchPrepare(self._h, stream))

@@ -208,7 +208,7 @@ Batch::~Batch() {
   if (idct_event_) (void)hipEventDestroy((hipEvent_t)idct_event_);
   if (dconst_) (void)hipFree(dconst_);
   if (dwork_) (void)hipFree(dwork_);
-  if (dcoef_) (void)hipFree(dcoef_);
+  if (dcoef_ && !coef_owner_) (void)hipFree(dcoef_);
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   if (dframes_) (void)hipFree(dframes_);
   if (dpasses_) (void)hipFree(dpasses_);
@@ -221,6 +221,13 @@ Batch::~Batch() {
 void Batch::ShareBigArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareBigArena after Prepare", false);
   big_owner_ = owner;
+}
+// Likewise for the quantised-coefficient planes (written by the HF stage, consumed — and zeroed again — by the IDCT of the same decode):
+// batches whose [HF ... IDCT] intervals never overlap may use one set.  A deep pipeline alternates between two owners so that the HF
+// stage of batch k + 1 can run beside the IDCT of batch k.
+void Batch::ShareCoefArena(Batch* owner) {
+  if (prepared_) throw ParseError("ShareCoefArena after Prepare", false);
+  coef_owner_ = owner;
 }
 
 int Batch::AddImage(const uint8_t* data, size_t size) {
@@ -391,7 +398,8 @@ void Batch::Prepare(void* stream_v) {
   if (dwork_) { (void)hipFree(dwork_); dwork_ = nullptr; }
   if (clear_stream_) (void)hipStreamSynchronize((hipStream_t)clear_stream_);   // a pending clear of the old coefficient planes
   clear_pending_ = false;
-  if (dcoef_) { (void)hipFree(dcoef_); dcoef_ = nullptr; }
+  if (dcoef_ && !coef_owner_) (void)hipFree(dcoef_);
+  dcoef_ = nullptr;
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
   dbig_ = nullptr;
   if (dframes_) { (void)hipFree(dframes_); dframes_ = nullptr; }
@@ -612,8 +620,13 @@ void Batch::Prepare(void* stream_v) {
     HIP_CHECK(hipMalloc((void**)&dbig_, std::max<size_t>(big_size_, 256)));
     HIP_CHECK(hipMemsetAsync(dbig_, 0, std::max<size_t>(big_size_, 256), stream));
   }
-  HIP_CHECK(hipMalloc((void**)&dcoef_, std::max<size_t>(coeff_bytes_, 256)));
-  coef_dirty_ = true;                                  // first decode clears the planes in its own stream
+  if (coef_owner_) {
+    if (!coef_owner_->dcoef_ || coef_owner_->coeff_bytes_ < coeff_bytes_) throw ParseError("ShareCoefArena: the owner's planes are missing or smaller than this batch needs", false);
+    dcoef_ = coef_owner_->dcoef_;                      // (whether they are clean is the owner's knowledge: CoefDirty())
+  } else {
+    HIP_CHECK(hipMalloc((void**)&dcoef_, std::max<size_t>(coeff_bytes_, 256)));
+    coef_dirty_ = true;                                // first decode clears the planes in its own stream
+  }
   HIP_CHECK(hipMalloc((void**)&dframes_, sizeof(FrameDev) * std::max(n, 1)));
 
   // ---- single-section VarDCT frames: HfGlobal starts where the device-decoded LfGroup ends.  Pre-run the LF stage
@@ -896,17 +909,22 @@ void Batch::Prepare(void* stream_v) {
       }
     }
     if (!streams.empty()) {
-      // longest-processing-time-first onto as many lanes as the longest stream allows
+      // longest-processing-time-first; the number of lanes grows from the lower bound (total work / longest stream) until no lane carries
+      // noticeably more than the longest stream: a lane more costs nothing, a lane with two long streams doubles the stage's latency
       uint64_t total = 0, longest = 0;
       for (uint64_t cst : cost) { total += cst; longest = std::max(longest, cst); }
-      const size_t nlanes = std::max<size_t>(1, std::min<size_t>(streams.size(), (size_t)((total + longest - 1) / longest)));
       vec<uint32_t> order(streams.size());
       for (size_t k = 0; k < order.size(); k++) order[k] = (uint32_t)k;
       std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-      vec<vec<uint32_t>> lane_streams(nlanes);
-      std::priority_queue<std::pair<uint64_t, uint32_t>, std::vector<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> pq;
-      for (size_t l = 0; l < nlanes; l++) pq.push({0, (uint32_t)l});
-      for (uint32_t k : order) { auto top = pq.top(); pq.pop(); lane_streams[top.second].push_back(k); pq.push({top.first + cost[k], top.second}); }
+      vec<vec<uint32_t>> lane_streams;
+      for (size_t nlanes = std::max<size_t>(1, std::min<size_t>(streams.size(), (size_t)((total + longest - 1) / longest)));; nlanes = std::min(streams.size(), nlanes + std::max<size_t>(1, nlanes / 64))) {
+        lane_streams.assign(nlanes, vec<uint32_t>());
+        std::priority_queue<std::pair<uint64_t, uint32_t>, std::vector<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> pq;
+        for (size_t l = 0; l < nlanes; l++) pq.push({0, (uint32_t)l});
+        uint64_t makespan = 0;
+        for (uint32_t k : order) { auto top = pq.top(); pq.pop(); lane_streams[top.second].push_back(k); makespan = std::max(makespan, top.first + cost[k]); pq.push({top.first + cost[k], top.second}); }
+        if (makespan <= longest + longest / 16 || nlanes >= streams.size()) break;
+      }
       // lanes of the same frames next to each other (they read the same tables)
       std::stable_sort(lane_streams.begin(), lane_streams.end(), [&](const vec<uint32_t>& a, const vec<uint32_t>& b) { return streams[a[0]].frame < streams[b[0]].frame; });
       vec<LfSimtStream> flat;
@@ -1344,10 +1362,10 @@ void Batch::EnqueuePostOps(void* stream) { for (auto& op : post_ops_) op(stream)
 // IdctTileKernel pass 0), so a batch that is decoded again and again never clears its planes as a whole; only a decode whose
 // tail did not run over them (first decode, JPEG reconstruction, a failed stream) leaves them dirty.
 void Batch::ClearCoefficientsBeforeHf(void* stream_v) {
-  if (coef_dirty_) HIP_CHECK(hipMemsetAsync(dcoef_, 0, coeff_bytes_, (hipStream_t)stream_v));
-  coef_dirty_ = true;
+  if (CoefDirty()) HIP_CHECK(hipMemsetAsync(dcoef_, 0, coef_owner_ ? coef_owner_->coeff_bytes_ : coeff_bytes_, (hipStream_t)stream_v));
+  CoefDirty() = true;
 }
-void Batch::ClearCoefficientsAfterDecode(void*) { coef_dirty_ = false; }
+void Batch::ClearCoefficientsAfterDecode(void*) { CoefDirty() = false; }
 
 void Batch::CheckFilterBuffers() const {
   if ((fplan_.any_unfused || cfg.force_unfused_filters) && !has_plane_b_)
@@ -1467,7 +1485,7 @@ void Batch::Finish(void* stream_v) {
   for (int i = 0; i < n; i++) {
     if (!status[i]) continue;
     HIP_CHECK(hipMemset(dwork_ + status_off_, 0, (size_t)n * 4));
-    coef_dirty_ = true;                                  // (a failed stream may have written where no IDCT looked)
+    CoefDirty() = true;                                  // (a failed stream may have written where no IDCT looked)
     if (status[i] & kErrUnsupported) throw ParseError("unsupported: stream feature on the device path (frame " + std::to_string(i) + ")", true);
     throw ParseError("corrupt stream (device status " + std::to_string(status[i]) + ", frame " + std::to_string(i) + ")", false);
   }

@@ -87,8 +87,9 @@ class Batch {
   void StageBytes(uint64_t out[6]) const;
   LaunchCfg cfg;
   size_t const_bytes() const { return const_size_; }
-  size_t work_bytes() const { return work_size_ + coeff_bytes_ + (big_owner_ ? 0 : big_size_); }
+  size_t work_bytes() const { return work_size_ + (coef_owner_ ? 0 : coeff_bytes_) + (big_owner_ ? 0 : big_size_); }
   void ShareBigArena(Batch* owner);
+  void ShareCoefArena(Batch* owner);
   int64_t Info(const std::string& name) const;
   uint64_t total_pixels() const;
   uint64_t compressed_bytes() const;
@@ -127,6 +128,8 @@ class Batch {
   uint8_t* dcoef_ = nullptr;
   void* clear_stream_ = nullptr; void* clear_event_ = nullptr; void* idct_event_ = nullptr;
   bool clear_pending_ = false, coef_dirty_ = true;
+  Batch* coef_owner_ = nullptr;
+  bool& CoefDirty() { return coef_owner_ ? coef_owner_->coef_dirty_ : coef_dirty_; }
   void ClearCoefficientsBeforeHf(void* stream);
   void ClearCoefficientsAfterDecode(void* stream);
   bool has_plane_b_ = false;

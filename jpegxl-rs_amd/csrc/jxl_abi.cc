@@ -408,6 +408,9 @@ uint64_t JxlHipBatchTotalPixels(const JxlHipBatch* h) { return h->b->total_pixel
 uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* h) { return h->b->compressed_bytes(); }
 void JxlHipBatchStageBytes(const JxlHipBatch* h, uint64_t out[6]) { h->b->StageBytes(out); }
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* h) { return h->b->const_bytes() + h->b->work_bytes(); }
+int JxlHipBatchShareCoefficients(JxlHipBatch* h, JxlHipBatch* owner) {
+  try { h->b->ShareCoefArena(owner ? owner->b : nullptr); return 0; } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
+}
 int JxlHipBatchShareBuffers(JxlHipBatch* h, JxlHipBatch* owner) {
   try { h->b->ShareBigArena(owner ? owner->b : nullptr); return 0; } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
 }
@@ -473,6 +476,12 @@ int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap)
                  (unsigned long long)p.flags);
         s += line;
         for (int k = 0; k < 17; k++) if (p.qspec[k].mode != 0) { snprintf(line, sizeof line, "  qtable kind=%d mode=%u raw_den=%g\n", k, p.qspec[k].mode, p.qspec[k].raw_den); s += line; }
+        snprintf(line, sizeof line, "  lf_code contexts=%u clusters=%u log_alpha=%u alias_bytes=%zu\n", p.tree_code.num_ctx, p.tree_code.num_clusters, p.tree_code.log_alpha, p.tree_code.alias.size() * 8);
+        s += line;
+        for (size_t ps = 0; ps < p.ac_code.size(); ps++) {
+          snprintf(line, sizeof line, "  ac_code pass=%zu contexts=%u clusters=%u log_alpha=%u alias_bytes=%zu\n", ps, p.ac_code[ps].num_ctx, p.ac_code[ps].num_clusters, p.ac_code[ps].log_alpha, p.ac_code[ps].alias.size() * 8);
+          s += line;
+        }
       }
     }
     if (b.image(0).has_jbrd) {

@@ -1173,20 +1173,18 @@ __device__ void StageModular(const TreeNode* tree, uint32_t num_tree_nodes, cons
 // K_lf: one wavefront per LF group (four per workgroup, sharing the tables) — LF coefficients (3 channels, order Y,X,B)
 // + HF metadata, then varblock placement
 // =====================================================================================================================
-// PLACE_ONLY: the seven channels have been decoded by LfDecodeSimtKernel (samples in the LF planes / the group's scratch, block count in
-// scratch[1]); only the part after the entropy decode runs — chroma-from-luma maps, varblock placement, sharpness merge.
-template <bool PLACE_ONLY>
+// Entropy decode of one LF group by one wavefront (DecodeChannelCoop): three LF coefficient channels into the quantised LF planes, four
+// HF-metadata channels and the block count (scratch[1]) into the group's scratch.  What follows — chroma-from-luma maps, varblock
+// placement, block-info words — is LfPlaceKernel's, for this kernel's frames and the SIMT kernel's alike.
 __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t g, ModTables& T, int& s_fail, GroupHeaderD& s_gh, uint32_t* s_u) {
-  const uint32_t lane = threadIdx.x & 63, wb = T.wb;
+  const uint32_t lane = threadIdx.x & 63;
   const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
   const uint32_t bx0 = gx * 256, by0 = gy * 256;
   const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
   BitReaderP br;
   const uint64_t sec_end = f.single_section ? f.cs_size : f.sec_off[1 + g] + f.sec_size[1 + g];
-  if (!PLACE_ONLY) {
-    if (f.single_section) br.Init(f.cs, f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos, f.cs_size);   // (after the global Modular stream, if any)
-    else br.Init(f.cs, f.sec_off[1 + g] * 8, sec_end);
-  }
+  if (f.single_section) br.Init(f.cs, f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos, f.cs_size);   // (after the global Modular stream, if any)
+  else br.Init(f.cs, f.sec_off[1 + g] * 8, sec_end);
   const uint64_t limit = sec_end * 8;
   if (lane == 0) s_fail = 0;
   WaveSync();
@@ -1196,12 +1194,6 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride;
   uint32_t state = 0;
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
-  if (PLACE_ONLY) {
-    if (lane == 0) { s_u[1] = (uint32_t)LdG(scratch + 1); if (LdG(f.status) != 0 || s_u[1] == 0 || s_u[1] > gbw * gbh) s_fail = 1; }   // (a failed stream leaves no usable block count)
-    WaveSync();
-    if (s_fail) return;
-  }
-  if (!PLACE_ONLY) {
   // ---- LF coefficients
   if (lane == 0) {
     s_u[0] = br.Read(2);  // extra_precision
@@ -1211,6 +1203,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     br.Init(f.cs, tmp.BitPos(), sec_end);
     state = br.Read(32);
     scratch[0] = (int32_t)s_u[0];
+    scratch[1] = 0;
   }
   WaveSync();
   if (s_fail) return;
@@ -1237,30 +1230,57 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   }
   WaveSync();
   if (s_fail) return;
-  }
   const uint32_t nb_blocks = s_u[1];
   const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
   int32_t* m_ytox = scratch + 16;
   int32_t* m_ytob = m_ytox + mcw * mch;
   int32_t* m_blk = m_ytob + mcw * mch;
   int32_t* m_sharp = m_blk + 2 * nb_blocks;
-  if (!PLACE_ONLY) {
-    mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
-    ChannelDesc ch;
-    ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; DecodeChannelCoop(br, state, T, mc, ch, 0);
-    ch.data = m_ytob; DecodeChannelCoop(br, state, T, mc, ch, 1);
-    ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeChannelCoop(br, state, T, mc, ch, 2);
-    ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeChannelCoop(br, state, T, mc, ch, 3);
-    if (lane == 0) {
-      if (state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
-      else if (br.BitPos() > limit) { SetError(f, kErrOverrun); s_fail = 1; }
-      else if (f.single_section) f.stream_end_bitpos[0] = br.BitPos();
-    }
+  mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
+  ChannelDesc ch;
+  ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; DecodeChannelCoop(br, state, T, mc, ch, 0);
+  ch.data = m_ytob; DecodeChannelCoop(br, state, T, mc, ch, 1);
+  ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeChannelCoop(br, state, T, mc, ch, 2);
+  ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeChannelCoop(br, state, T, mc, ch, 3);
+  if (lane == 0) {
+    if (state != 0x130000u) SetError(f, kErrAnsFinalState);
+    else if (br.BitPos() > limit) SetError(f, kErrOverrun);
+    else { if (f.single_section) f.stream_end_bitpos[0] = br.BitPos(); scratch[1] = (int32_t)nb_blocks; }
   }
   WaveSync();
+}
+
+// ---- varblock placement of one BAND (32 block rows) of an LF group, by one wavefront -----------------------------------------------------
+// The varblocks of an LF group arrive as one list in raster order of their top-left blocks ("the next entry goes to the first block no
+// earlier entry covers").  That is sequential — but varblocks never cross a 32-row band (they stay inside a 256x256-pixel group), so a
+// band is complete before the scan enters the next one and the list index at which a band starts is where the running sum of block areas
+// reaches (rows above) x (group width): a prefix sum.  Every band therefore goes to a wavefront of its own — eight per 2048x2048 LF
+// group instead of one —, which first finds its start index with wave-wide scans over the strategy list and then walks its band.
+// The walk itself: lane 0 follows the scan out of LDS only — 64 (strategy, hf_mul) pairs staged per round by all lanes, coverage bitmap
+// as a ring of 64 rows x 8 words, running coefficient offsets / varblock counts of the band's eight groups — and emits one 16-byte record
+// per varblock; the wavefront then writes coefficient offsets, per-group varblock lists (incl. the HF block-context bucket) and block-info
+// words of all covered blocks in parallel.  The band's rows of the chroma-from-luma maps and of the sharpness map are its as well.
+constexpr uint32_t kLfPlaceWaves = 4, kLfPlaceLds = 4352;
+__device__ __forceinline__ void LfPlaceBand(const FrameDev& f, const uint32_t g, const uint32_t band, const uint32_t wb, int& s_fail, uint32_t* s_u) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
+  const uint32_t bx0 = gx * 256, by0 = gy * 256;
+  const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
+  const uint32_t y_begin = band * 32;
+  if (y_begin >= gbh) return;
+  const uint32_t y_end = min(gbh, y_begin + 32);
+  int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
+  const uint32_t nb_blocks = (uint32_t)LdG(scratch + 1);
+  if (lane == 0) s_fail = (LdG(f.status) != 0 || nb_blocks == 0 || nb_blocks > gbw * gbh) ? 1 : 0;   // (a failed stream leaves no usable block count)
+  WaveSync();
   if (s_fail) return;
-  // ---- chroma-from-luma maps (all lanes)
-  for (uint32_t i = lane; i < mcw * mch; i += 64) {
+  const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
+  int32_t* m_ytox = scratch + 16;
+  int32_t* m_ytob = m_ytox + mcw * mch;
+  int32_t* m_blk = m_ytob + mcw * mch;
+  int32_t* m_sharp = m_blk + 2 * nb_blocks;
+  // ---- chroma-from-luma maps: the band's four tile rows (all lanes)
+  for (uint32_t i = band * 4 * mcw + lane; i < min(mch, band * 4 + 4) * mcw; i += 64) {
     const uint32_t y = i / mcw, x = i % mcw;
     const int a = m_ytox[i], b = m_ytob[i];
     if (a < -128 || a > 127 || b < -128 || b > 127) { SetError(f, kErrBadValue); s_fail = 1; }
@@ -1268,28 +1288,47 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     const size_t o = (size_t)(gy * 32 + y) * f.cw + gx * 32 + x;
     f.ytox[o] = (int8_t)a; f.ytob[o] = (int8_t)b;
   }
-  // ---- varblock placement (raster order, first not-yet-covered block).  Inherently sequential, so lane 0 walks it — but
-  // out of LDS only: 64 (strategy, hf_mul) pairs are staged per round by all lanes, the coverage bitmap is a ring of 64
-  // rows (a varblock reaches at most 32 rows down and rows above the scan line are never looked at again), the running
-  // coefficient offsets / varblock counts of the 64 groups live in LDS, and lane 0 only emits one 16-byte record per
-  // varblock; the wavefront then writes coef_off, the per-group varblock lists and the block-info words of all covered
-  // blocks in parallel.  (The one-lane version with global loads and stores in the loop took 44 % of this kernel.)
-  // Blocks never cross a 32-block boundary, hence never a 64-bit word of the bitmap.
   const uint32_t ring_off = wb, goff_off = wb + 2048, gcnt_off = wb + 2304, in_off = wb + 2560, rec_off = wb + 3072, cnt_off = wb + 4096;
   const uint32_t pat_off = wb + 4128, geo_off = wb + 4160;   // row pattern (8 words), per-strategy {cx | cy << 8 | HF entry fields << 16} (27 words)
   // bitmap: 32-bit words, one per 32-block column of the LF group (8 per row); bits outside the group are pre-set
   if (lane < 8) StS<uint32_t>(pat_off + lane * 4, lane * 32 >= gbw ? ~0u : (gbw - lane * 32 < 32 ? ~0u << (gbw - lane * 32) : 0u));
   if (lane < 27) StS<uint32_t>(geo_off + lane * 4, CoveredX(lane) | (CoveredY(lane) << 8) | (((Log2CoveredX(lane) << 5) | ((Log2CoveredX(lane) + Log2CoveredY(lane)) << 8) | (OrderBucket(lane) << 12)) << 16));
   WaveSync();
+  // ---- where the band starts in the list: first index whose preceding areas add up to (rows above) x width
+  uint32_t num0 = 0;
+  if (band > 0) {
+    const uint32_t target = y_begin * gbw;
+    uint32_t cum = 0, found = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < nb_blocks; base += 64) {
+      const uint32_t idx = base + lane;
+      uint32_t area = 0;
+      if (idx < nb_blocks) { const uint32_t st = (uint32_t)LdG(m_blk + idx); if (st < 27) { const uint32_t geo = LdS<uint32_t>(geo_off + st * 4); area = (geo & 0xFF) * ((geo >> 8) & 0xFF); } }
+      uint32_t incl = area;       // inclusive prefix sum over the wavefront
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
+      const uint32_t total = __shfl(incl, 63, 64);
+      if (cum + total < target) { cum += total; continue; }
+      const uint64_t reach = __ballot(cum + incl - area >= target && idx < nb_blocks);   // lanes whose entry starts at or past the band's first block
+      if (reach) {
+        const int l0 = __ffsll((long long)reach) - 1;
+        const uint32_t at = __shfl(cum + incl - area, l0, 64);
+        found = at == target ? base + (uint32_t)l0 : 0xFFFFFFFEu;    // (not exactly there: a varblock straddles the band's top — damaged list)
+        break;
+      }
+      cum += total;
+    }
+    if (found >= 0xFFFFFFFEu) { if (lane == 0) { SetError(f, kErrVarblock); s_fail = 1; } WaveSync(); return; }
+    num0 = found;
+  }
   for (uint32_t i = lane; i < 512; i += 64) {
-    const uint32_t y = i >> 3, wi = i & 7;
-    StS<uint32_t>(ring_off + i * 4, y >= gbh ? ~0u : LdS<uint32_t>(pat_off + wi * 4));
+    const uint32_t y = y_begin + (i >> 3), wi = i & 7;                  // ring slot (y & 63) holds row y; the band's 32 rows + what lies below (pre-set)
+    StS<uint32_t>(ring_off + ((y & 63) * 8 + wi) * 4, y >= y_end ? ~0u : LdS<uint32_t>(pat_off + wi * 4));
   }
   StS<uint32_t>(goff_off + lane * 4, 0u); StS<uint32_t>(gcnt_off + lane * 4, 0u);
-  if (lane == 0) { StS<uint32_t>(cnt_off + 4, 0u); StS<uint32_t>(cnt_off + 8, 0u); }
+  if (lane == 0) { StS<uint32_t>(cnt_off + 4, y_begin); StS<uint32_t>(cnt_off + 8, 0u); }
   WaveSync();
   if (s_fail) return;
-  uint32_t num0 = 0, flags_acc = 0;
+  uint32_t flags_acc = 0;
   while (true) {
     {  // stage the next 64 (strategy, hf_mul - 1) pairs
       const uint32_t idx = num0 + lane;
@@ -1302,14 +1341,13 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
       uint32_t count = 0;
       bool bad = false;
       uint32_t y = LdS<uint32_t>(cnt_off + 4), wi = LdS<uint32_t>(cnt_off + 8);   // scan position: row, 32-block column
-      while (count < 64 && y < gbh) {
+      while (count < 64 && y < y_end) {
         const uint32_t row = ring_off + (y & 63) * 32;
         const uint32_t cov = LdS<uint32_t>(row + wi * 4);
         if (cov == ~0u) {
           // the first uncovered block of a row only moves right: next column; after the last one the ring slot becomes row y + 64
           if (++wi == 8) {
-            const bool past = y + 64 >= gbh;
-            for (uint32_t k = 0; k < 8; k++) StS<uint32_t>(row + k * 4, past ? ~0u : LdS<uint32_t>(pat_off + k * 4));
+            for (uint32_t k = 0; k < 8; k++) StS<uint32_t>(row + k * 4, ~0u);    // (row y + 64 is past the band)
             y++; wi = 0;
           }
           continue;
@@ -1379,27 +1417,19 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
       const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
       StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (r.w >> 16) | ((x % 32) << 16) | ((y % 32) << 21) | (qlf << 26), r.y));
       for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++) {
-        StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, 0));
+        // (the sharpness map is merged here: every covered block's word is written exactly once)
+        const int32_t sh = LdG(m_sharp + (size_t)(y + iy) * gbw + x + ix);
+        if (sh < 0 || sh > 7) SetError(f, kErrBadValue);
+        StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, (uint32_t)sh & 7u));
         StG(f.coef_off + o + (size_t)iy * f.bw + ix, r.y);   // (every covered block: the IDCT reads info and offset side by side)
       }
     }
     num0 += count;
-    if (scan_y >= gbh) break;
+    if (scan_y >= y_end) break;
     WaveSync();   // records consumed before the next round overwrites them
   }
   if (lane == 0 && flags_acc) atomicOr(f.frame_flags, flags_acc);
-  {
-    const uint32_t gi = lane, ly = gi / 8, lx = gi % 8;
-    if (ly * 32 < gbh && lx * 32 < gbw) StG(f.vb_count + (gy * 8 + ly) * f.xgroups + gx * 8 + lx, LdS<uint32_t>(gcnt_off + gi * 4));
-  }
-  WaveSync();
-  if (s_fail) return;
-  // ---- merge the sharpness map into the block info words (all lanes)
-  for (uint32_t i = lane; i < gbw * gbh; i += 64) {
-    const int32_t sh = m_sharp[i];
-    if (sh < 0 || sh > 7) { SetError(f, kErrBadValue); continue; }
-    f.blk_info[(size_t)(by0 + i / gbw) * f.bw + bx0 + i % gbw] |= (uint32_t)sh << 26;
-  }
+  if (lane < 8 && lane * 32 < gbw) StG(f.vb_count + (gy * 8 + band) * f.xgroups + gx * 8 + lane, LdS<uint32_t>(gcnt_off + (band * 8 + lane) * 4));
 }
 
 // Two wavefronts per workgroup share four consecutive LF groups: wavefront w decodes groups w and 3 - w one after the
@@ -1424,7 +1454,7 @@ template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? J
   const uint32_t wave = threadIdx.x >> 6;
   for (uint32_t turn = 0; turn < groups_per_block / kLfDecWaves; turn++) {   // (no block-wide barrier after this point)
     const uint32_t local = turn & 1 ? groups_per_block - 1 - (turn / 2) * kLfDecWaves - wave : (turn / 2) * kLfDecWaves + wave;
-    if (first + local < f.num_lf_groups) LfDecodeGroup<false>(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
+    if (first + local < f.num_lf_groups) LfDecodeGroup(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
   }
 }
 
@@ -1487,9 +1517,10 @@ __device__ __forceinline__ bool SkipGroupHeaderSimt(BitReaderQ& br) {   // Group
 }
 
 __global__ __launch_bounds__(64) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
-                                                        const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave) {
+                                                        const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority) {
   const uint32_t li = blockIdx.x * lanes_per_wave + threadIdx.x;
   if (threadIdx.x >= lanes_per_wave || li >= num_lanes) return;
+  if (high_priority) __builtin_amdgcn_s_setprio(3);
   uint32_t cur, end;
   { const uint2 ln = LdG(reinterpret_cast<const uint2*>(lanes + li)); cur = ln.x; end = ln.x + ln.y; }
   BitReaderQ br;
@@ -1636,21 +1667,16 @@ __global__ __launch_bounds__(64) void LfDecodeSimtKernel(const FrameDev* __restr
   }
 }
 
-// What follows the entropy decode of an LF group whose channels LfDecodeSimtKernel has decoded: chroma-from-luma maps, varblock
-// placement, block-info words (LfDecodeGroup<true>) — one wavefront per LF group, 4.3 KB of LDS each, nothing staged.
-constexpr uint32_t kLfPlaceWaves = 4, kLfPlaceLds = 4352;
+// What follows the entropy decode of the LF groups (either kernel): LfPlaceBand, one wavefront per 32-row band of an LF group.
 __global__ __launch_bounds__(64 * kLfPlaceWaves) void LfPlaceKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || !f.lf_simt) return;
+  if (f.is_modular) return;
   const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t g = blockIdx.x * kLfPlaceWaves + wave;
-  if (g >= f.num_lf_groups) return;
+  const uint32_t unit = blockIdx.x * kLfPlaceWaves + wave;      // (LF group, band)
+  if (unit / 8 >= f.num_lf_groups) return;
   __shared__ int s_fail_w[kLfPlaceWaves];
-  __shared__ GroupHeaderD s_gh_w[1];
   __shared__ uint32_t s_u_w[kLfPlaceWaves][4];
-  ModTables T;
-  T.wb = wave * kLfPlaceLds;
-  LfDecodeGroup<true>(f, g, T, s_fail_w[wave], s_gh_w[0], s_u_w[wave]);
+  LfPlaceBand(f, unit / 8, unit % 8, wave * kLfPlaceLds, s_fail_w[wave], s_u_w[wave]);
 }
 
 // =====================================================================================================================
@@ -3991,13 +4017,26 @@ static uint32_t* HfSyncWords(int* dev_out) {
   return g_hf_sync[dev];
 }
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream, const LfSimtPlan* simt) {
+  static const bool time_it = getenv("JXL_HIP_TIME_LF") != nullptr;     // experiments: blocking per-kernel times on stderr
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  if (time_it) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], (hipStream_t)stream); }
+  auto place = [&]() {
+    // varblock placement, one wavefront per 32-row band of an LF group
+    if (time_it) (void)hipEventRecord(ev[1], (hipStream_t)stream);
+    hipLaunchKernelGGL(LfPlaceKernel, dim3(DivUp(max_lf_groups * 8, (int)kLfPlaceWaves), nframes), dim3(64 * kLfPlaceWaves), kLfPlaceWaves * kLfPlaceLds, (hipStream_t)stream, frames);
+    if (time_it) {
+      (void)hipEventRecord(ev[2], (hipStream_t)stream); (void)hipEventSynchronize(ev[2]);
+      float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+      fprintf(stderr, "[jxl-hip] LF stage: %d frames, SIMT %u lanes / %u per wavefront: decode %.2f ms, placement %.2f ms\n", nframes, simt ? simt->num_lanes : 0u, simt ? simt->lanes_per_wave : 0u, a, b);
+      for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+  };
   if (simt && simt->num_lanes) {
-    // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane), then one short wavefront per LF group for the
-    // varblock placement
+    // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane)
     const uint32_t lpw = std::min(64u, std::max(1u, simt->lanes_per_wave));
-    hipLaunchKernelGGL(LfDecodeSimtKernel, dim3(DivUp((int)simt->num_lanes, (int)lpw)), dim3(64), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw);
-    hipLaunchKernelGGL(LfPlaceKernel, dim3(DivUp(max_lf_groups, (int)kLfPlaceWaves), nframes), dim3(64 * kLfPlaceWaves), kLfPlaceWaves * kLfPlaceLds, (hipStream_t)stream, frames);
-    if (!simt->any_legacy) return;
+    static const int lf_prio = getenv("JXL_HIP_LF_PRIO") ? atoi(getenv("JXL_HIP_LF_PRIO")) : 0;
+    hipLaunchKernelGGL(LfDecodeSimtKernel, dim3(DivUp((int)simt->num_lanes, (int)lpw)), dim3(64), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_prio);
+    if (!simt->any_legacy) { place(); return; }
   }
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
@@ -4023,6 +4062,7 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   } else {
     hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
   }
+  place();
 }
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, int max_groups, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_bw, 64), DivUp(max_bh, 4), nframes);
