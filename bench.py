@@ -249,6 +249,8 @@ def main():
         for i in range(B):
             batch.add(streams[(i + b * B) % len(streams)], "uint8", 3, device_ptr=out.data_ptr() + i * frame_bytes)
         batch.set_lane_stride(args.lane_stride_lf, args.lane_stride_hf)
+        if os.environ.get("JXL_BENCH_LDS_BUDGET"):
+            batch.set_option("lds_code_budget", int(os.environ["JXL_BENCH_LDS_BUDGET"]))   # experiment: entropy-code tables of the HF stage through the L2
         if b > 0:
             batch.share_buffers(batches[0])     # the tails run one after the other on the main stream: one set of pixel planes
         if b >= (2 if deep else 1):

@@ -206,6 +206,8 @@ Batch::~Batch() {
   if (clear_stream_) { (void)hipStreamSynchronize((hipStream_t)clear_stream_); (void)hipStreamDestroy((hipStream_t)clear_stream_); }
   if (clear_event_) (void)hipEventDestroy((hipEvent_t)clear_event_);
   if (idct_event_) (void)hipEventDestroy((hipEvent_t)idct_event_);
+  if (flags_event_) (void)hipEventDestroy((hipEvent_t)flags_event_);
+  if (flags_pinned_) (void)hipHostFree(flags_pinned_);
   if (dconst_) (void)hipFree(dconst_);
   if (dwork_) (void)hipFree(dwork_);
   if (dcoef_ && !coef_owner_) (void)hipFree(dcoef_);
@@ -514,7 +516,7 @@ void Batch::Prepare(void* stream_v) {
   flags_off_ = flags_off;
   hfw_off_ = take((size_t)n * 4);
   hf_written_.assign(n, 0); decodes_since_finish_ = 0;
-  cfg.idct_flags_known = 0; ran_once_ = false;
+  cfg.idct_flags_known = 0; ran_once_ = false; flags_pending_ = false;
   // coefficient buffers of all frames are contiguous so that one memset clears them
   // quantised coefficients: an arena of this batch's own (never shared: it is cleared for the batch's next decode on an
   // internal stream while the next batch's HF stage runs, see ClearCoefficients*)
@@ -1158,6 +1160,7 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
           const Slot& sl = slots[pr.ref];
           if (!sl.valid) throw ParseError("patch refers to an empty reference slot", false);
           if (!sl.before_ct) throw ParseError("patch refers to a frame saved after the colour transform", false);
+          if (pr.xsize == 0 || pr.ysize == 0) throw ParseError("empty patch", false);
           if ((uint64_t)pr.x0 + pr.xsize > sl.w || (uint64_t)pr.y0 + pr.ysize > sl.h) throw ParseError("patch exceeds its reference frame", false);
           for (const PatchPosH& pp : pr.pos) {
             if (pp.x + pr.xsize > cw || pp.y + pr.ysize > ch) throw ParseError("patch exceeds the frame", false);
@@ -1177,8 +1180,10 @@ void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off)
           vec<vec<uint32_t>> lists((size_t)tx * ty);
           for (uint32_t k = 0; k < entries.size(); k++) {
             const PatchEntryDev& en = entries[k];
-            for (uint32_t yy = (uint32_t)en.y / 32; yy <= ((uint32_t)en.y + en.ys - 1) / 32; yy++)
-              for (uint32_t xx = (uint32_t)en.x / 32; xx <= ((uint32_t)en.x + en.xs - 1) / 32; xx++) lists[(size_t)yy * tx + xx].push_back(k);
+            // (sizes are >= 1 and the placement lies inside the frame — checked above; clamped all the same: the lists must not be overrun)
+            const uint32_t y1 = std::min(ty - 1, ((uint32_t)en.y + std::max(en.ys, 1u) - 1) / 32), x1 = std::min(tx - 1, ((uint32_t)en.x + std::max(en.xs, 1u) - 1) / 32);
+            for (uint32_t yy = (uint32_t)en.y / 32; yy <= y1; yy++)
+              for (uint32_t xx = (uint32_t)en.x / 32; xx <= x1; xx++) lists[(size_t)yy * tx + xx].push_back(k);
           }
           vec<uint32_t> start(lists.size() + 1, 0), flat;
           for (size_t t = 0; t < lists.size(); t++) { start[t + 1] = start[t] + (uint32_t)lists[t].size(); flat.insert(flat.end(), lists[t].begin(), lists[t].end()); }
@@ -1413,6 +1418,19 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     cfg.lf_head_start = part == 1 || part == 5;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v, &lf_simt_);
     DebugSync("LF decode", stream_v);
+    if (any_vardct_ && !cfg.idct_flags_known && part != 0) {
+      // a caller that enqueues the stages separately: the placement flags travel to pinned host memory behind the LF stage, and the tail —
+      // enqueued steps later — waits for that copy (long done by then) instead of launching every IDCT kernel variant
+      if (!flags_pinned_ || flags_pinned_n_ < (size_t)n) {
+        if (flags_pinned_) (void)hipHostFree(flags_pinned_);
+        HIP_CHECK(hipHostMalloc((void**)&flags_pinned_, (size_t)std::max(n, 1) * 4));
+        flags_pinned_n_ = (size_t)n;
+      }
+      if (!flags_event_) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); flags_event_ = ev; }
+      HIP_CHECK(hipMemcpyAsync(flags_pinned_, dwork_ + flags_off_, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipEventRecord((hipEvent_t)flags_event_, stream));
+      flags_pending_ = true;
+    }
     rec(1);
   }
   if (do_lfpost) {
@@ -1442,6 +1460,11 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     rec(3);
   }
   if (do_tail) {
+    if (!cfg.idct_flags_known && flags_pending_ && part != 0) {
+      HIP_CHECK(hipEventSynchronize((hipEvent_t)flags_event_));
+      ApplyIdctFlags(flags_pinned_);
+      flags_pending_ = false;
+    }
     if (split) rec(8);                        // the tail may sit on another stream than the HF stage: its own start mark
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     DebugSync("IDCT", stream_v);
@@ -1501,19 +1524,25 @@ void Batch::Finish(void* stream_v) {
     // the LF stage has classified every frame's varblock placement: later decodes of this batch skip the kernels nobody needs
     vec<uint32_t> flags(n, 0);
     HIP_CHECK(hipMemcpy(flags.data(), dwork_ + flags_off_, (size_t)n * 4, hipMemcpyDeviceToHost));
-    cfg.any_irregular_blocks = cfg.any_big_blocks = 0;
-    cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = cfg.need_rare_special = 0;
-    for (int i = 0; i < n; i++) {
-      if (images_[i]->plan.modular) continue;
-      const uint32_t v = flags[i];
-      cfg.any_irregular_blocks |= (v & 1) != 0; cfg.any_big_blocks |= (v & 2) != 0;
-      if (v & 1) continue;                                  // generic IdctKernel frame
-      if (v & 16) cfg.need_rare_special = 1;
-      if (v & 4) { if (v & 8) cfg.need_tile8_special = 1; else cfg.need_tile8_plain = 1; }
-      else { if (v & 8) cfg.need_tile4_special = 1; else cfg.need_tile4_plain = 1; }
-    }
-    cfg.idct_flags_known = 1;
+    ApplyIdctFlags(flags.data());
   }
+}
+
+// Per-frame flags of the varblock placement (LfPlaceBand) -> which IDCT kernels a decode of this batch needs.
+void Batch::ApplyIdctFlags(const uint32_t* flags) {
+  const int n = (int)images_.size();
+  cfg.any_irregular_blocks = cfg.any_big_blocks = 0;
+  cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = cfg.need_rare_special = 0;
+  for (int i = 0; i < n; i++) {
+    if (images_[i]->plan.modular) continue;
+    const uint32_t v = flags[i];
+    cfg.any_irregular_blocks |= (v & 1) != 0; cfg.any_big_blocks |= (v & 2) != 0;
+    if (v & 1) continue;                                  // generic IdctKernel frame
+    if (v & 16) cfg.need_rare_special = 1;
+    if (v & 4) { if (v & 8) cfg.need_tile8_special = 1; else cfg.need_tile8_plain = 1; }
+    else { if (v & 8) cfg.need_tile4_special = 1; else cfg.need_tile4_plain = 1; }
+  }
+  cfg.idct_flags_known = 1;
 }
 
 // ---- JPEG reconstruction -----------------------------------------------------------------------------------------------------------------
@@ -1586,6 +1615,7 @@ vec<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
   }
   int16_t* dcoef = nullptr;
   HIP_CHECK(hipMalloc((void**)&dcoef, nblk * 64 * sizeof(int16_t)));
+  struct DevFree { int16_t* p; ~DevFree() { if (p) (void)hipFree(p); } } dcoef_guard{dcoef};   // (released on every exit, incl. exceptions below)
   JpegCoefArgs a;
   memset(&a, 0, sizeof(a));
   a.ncomp = (uint32_t)ncomp;
@@ -1597,7 +1627,6 @@ vec<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
   vec<int16_t> host(nblk * 64);
   hipError_t err = hipMemcpyAsync(host.data(), dcoef, host.size() * sizeof(int16_t), hipMemcpyDeviceToHost, stream);
   if (err == hipSuccess) err = hipStreamSynchronize(stream);
-  (void)hipFree(dcoef);
   if (err != hipSuccess) throw ParseError(std::string("HIP error: ") + hipGetErrorString(err), false);
   Finish(stream_v);
   const int16_t* planes[3] = {host.data(), host.data() + comp_first[1] * 64, host.data() + comp_first[2] * 64};

@@ -133,6 +133,8 @@ class Batch {
   void ClearCoefficientsBeforeHf(void* stream);
   void ClearCoefficientsAfterDecode(void* stream);
   bool has_plane_b_ = false;
+  uint32_t* flags_pinned_ = nullptr; size_t flags_pinned_n_ = 0; void* flags_event_ = nullptr; bool flags_pending_ = false;   // placement flags on their way to the host
+  void ApplyIdctFlags(const uint32_t* flags);
   void CheckFilterBuffers() const;
   FrameDev* dframes_ = nullptr;
   PassDev* dpasses_ = nullptr;

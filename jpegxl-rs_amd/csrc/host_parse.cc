@@ -657,9 +657,11 @@ bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* h
       if (bs == 0) { end = size; last_unbounded = true; }
       else {
         if (bs < hdr) Fail("bad box size");
-        end = pos + bs;
-        if (end > size) { complete = false; end = size; }
+        // (compared without forming pos + bs: an extended size near 2^64 must not wrap to a position before this box)
+        if (bs > (uint64_t)(size - pos)) { complete = false; end = size; }
+        else end = pos + (size_t)bs;
       }
+      if (end < pos + hdr) { complete = false; break; }     // the box header itself is cut off: nothing of the payload is there
       if (!memcmp(type, "jxlc", 4)) { tmp.insert(tmp.end(), data + pos + hdr, data + end); found = true; }
       else if (!memcmp(type, "jxlp", 4)) { if (end >= pos + hdr + 4) { tmp.insert(tmp.end(), data + pos + hdr + 4, data + end); found = true; } }
       else if (!memcmp(type, "jbrd", 4)) { *has_jbrd = true; if (boxes) boxes->jbrd.assign(data + pos + hdr, data + end); }
@@ -919,7 +921,11 @@ static void ParsePatches(Reader& r, size_t num_extra, size_t frame_pixels, Frame
     pr.ref = sr.Read(1);
     if (pr.ref >= 4) Fail("patch reference frame");
     pr.x0 = sr.Read(3); pr.y0 = sr.Read(3);
-    pr.xsize = sr.Read(2) + 1; pr.ysize = sr.Read(2) + 1;
+    // (sizes in 64 bits: a 0xFFFFFFFF token must not wrap to an empty patch — dec_patch_dictionary.cc computes in size_t and rejects
+    // patches larger than the reference frame; no frame is larger than 2^30 in either direction)
+    const uint64_t xs = (uint64_t)sr.Read(2) + 1, ys = (uint64_t)sr.Read(2) + 1;
+    if (xs > (1u << 30) || ys > (1u << 30) || (uint64_t)pr.x0 + xs > (1ull << 31) || (uint64_t)pr.y0 + ys > (1ull << 31)) Fail("patch size");
+    pr.xsize = (uint32_t)xs; pr.ysize = (uint32_t)ys;
     const uint32_t count = sr.Read(7) + 1;
     total += count;
     if (total > frame_pixels + 1024) Fail("too many patch positions");

@@ -149,6 +149,15 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
     for (auto& b : jd->padding_bits) b = (uint8_t)r.u(1);
   }
   if (r.bad) return fail("truncated");
+  {
+    // the announced sizes are checked against what the Brotli stream behind them can plausibly hold before anything of that size is
+    // allocated (a 45 KB box may announce 1 GiB of inter-marker data): three orders of magnitude of compression is beyond any JPEG's markers
+    uint64_t announced = tail_len;
+    for (uint32_t v : inter_sizes) announced += v;
+    const size_t off0 = (r.p + 7) / 8;
+    const uint64_t brotli_bytes = off0 < size ? size - off0 : 0;
+    if (announced > brotli_bytes * 1024 + 65536) return fail("announced marker data exceeds what the box can hold");
+  }
   jd->tail_data.resize(tail_len);
   for (uint32_t v : inter_sizes) jd->inter_marker_data.emplace_back(v);
   // ---- Brotli stream: unknown-type APPn markers, COM markers, inter-marker data, tail data, back to back

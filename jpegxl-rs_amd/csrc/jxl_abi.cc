@@ -246,7 +246,9 @@ JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorPro
 JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
   JXL_MM_SCOPE(d);
   d->started = true;
-  if (!d->input_set) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
+  // (input is only demanded until the headers have been parsed: the decoder works from its own copy of the codestream afterwards, so a
+  // caller may release its buffer — JxlDecoderReleaseInput — and go on)
+  if (!d->input_set && d->stage == JxlDecoderStruct::kInit) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
   try {
     if (d->stage == JxlDecoderStruct::kInit) {
       JxlSignature sig = JxlSignatureCheck(d->input, d->input_size);
@@ -286,6 +288,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
             SetLastError(std::string(e.what()) + " (decoding to pixels instead)");
             d->jpeg_available = false;
             // the batch was prepared for the JPEG path (output format, buffers): start over for the pixel decode
+            if (!d->input_set) throw ParseError("the input was released before the pixel decode could start over", false);
             struct Holder { Batch* b; ~Holder() { DeleteBatch(b); } } hold{NewBatch(d->device)};
             hold.b->AddImage(d->input, d->input_size);
             DeleteBatch(d->batch);
