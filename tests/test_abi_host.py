@@ -360,6 +360,9 @@ def _describe(jx, data):
         if l.startswith("  quantizer"):                      # detail line of the VarDCT frame above it
             rows[-1]["quantizer"] = dict(t.split("=") for t in l.split() if "=" in t)
             continue
+        if l.startswith(("  lf_code", "  ac_code")):          # entropy-code sizes of the VarDCT frame above it
+            rows[-1].setdefault("codes", []).append(dict([("which", l.split()[0])] + [t.split("=") for t in l.split() if "=" in t]))
+            continue
         kv = dict(t.split("=") for t in l.split() if "=" in t)
         kv["kind"] = l.split()[0] + (" " + l.split()[2] if l.startswith("frame") else "")
         kv["raw"] = l
