@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
     ap.add_argument("--in-flight", type=int, default=8, help="batch objects in flight (pipelined): LF stages run this many steps ahead, minus one")
     ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
+    ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current step (deep pipeline), one stream and one coefficient set each")
+    ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "2")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
     ap.add_argument("--out-buffers", type=int, default=2, help="output buffer sets the batches in flight cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -234,8 +236,10 @@ def main():
     # outputs as often as --out-buffers says.
     deep = pipeline and os.environ.get("JXL_BENCH_DEEP", "1") == "1"
     nbuf = int(os.environ.get("JXL_BENCH_NBUF", str(args.in_flight))) if pipeline else 1   # batches in flight: step k uses batch object k % nbuf
-    if deep and nbuf % 2:
-        nbuf += 1                        # (the two coefficient sets alternate with k; batch objects must keep their parity)
+    nhf = max(1, args.hf_streams) if deep else 0     # HF stages in flight beside the tail of the step (each on its own stream)
+    ncoef = nhf + 1                      # coefficient sets: one per HF stage in flight + the one the tail is consuming
+    if deep and nbuf % ncoef:
+        nbuf += ncoef - nbuf % ncoef     # (the coefficient sets rotate with k; batch object k % nbuf must always meet set k % ncoef)
     ahead = nbuf - 1                     # LF stages issued ahead of the step being finished
     nout = min(nbuf, max(1, args.out_buffers))
     outs, batches = [], []
@@ -253,8 +257,8 @@ def main():
             batch.set_option("lds_code_budget", int(os.environ["JXL_BENCH_LDS_BUDGET"]))   # experiment: entropy-code tables of the HF stage through the L2
         if b > 0:
             batch.share_buffers(batches[0])     # the tails run one after the other on the main stream: one set of pixel planes
-        if b >= (2 if deep else 1):
-            batch.share_coefficients(batches[b % 2 if deep else 0])
+        if b >= ncoef:
+            batch.share_coefficients(batches[b % ncoef])
         batch.prepare(stream)
         batches.append(batch)
     batch, out = batches[0], outs[0]
@@ -265,7 +269,7 @@ def main():
     from jpegxl_rs_amd.sharding import gather_frames_chunked
     sides = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(max(1, min(ahead, args.lf_streams)))] if pipeline else []
     comm = torch.cuda.Stream(device=dev) if do_gather else None               # RCCL gather overlaps the next step's decode
-    hf_stream = torch.cuda.Stream(device=dev, priority=-1) if deep else None
+    hf_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(nhf)]
     hf_done = [torch.cuda.Event() for _ in range(nbuf)]
     front_done = [torch.cuda.Event() for _ in range(nbuf)]
     lf_done = [torch.cuda.Event() for _ in range(nbuf)]
@@ -279,6 +283,8 @@ def main():
         with torch.cuda.stream(side):
             if k >= nbuf:
                 side.wait_event(rest_done[b])                       # the batch object's previous decode is complete
+            if k < args.wide_first and args.lane_stride_lf < 64:
+                batches[b].set_option("lf_wide_once", 1)            # cold pipeline, idle GPU: the wide LF kernel (100 instead of 250 ms until step 0 can go on)
             batches[b].decode_part(5, side.cuda_stream, timed)      # LF decode: all the HF stage waits for
             lf_done[b].record(side)
             batches[b].decode_part(6, side.cuda_stream, timed)      # LF post-processing: needed by the IDCT only
@@ -286,11 +292,11 @@ def main():
 
     def issue_hf(k, timed):
         b = k % nbuf
-        s_ = hf_stream if deep else main
+        s_ = hf_streams[k % nhf] if deep else main
         with torch.cuda.stream(s_):
             s_.wait_event(lf_done[b])
-            if deep and k >= 2:
-                s_.wait_event(rest_done[(k - 2) % nbuf])            # the coefficient set's previous user has consumed (and zeroed) it
+            if deep and k >= ncoef:
+                s_.wait_event(rest_done[(k - ncoef) % nbuf])        # the coefficient set's previous user has consumed (and zeroed) it
             batches[b].decode_part(3, s_.cuda_stream, timed)
             hf_done[b].record(s_)
 
@@ -307,7 +313,7 @@ def main():
             for j in range(0, ahead + 1):
                 if k + j < state["limit"] and state["front_issued"] <= k + j:
                     issue_front(k + j, timed); state["front_issued"] = k + j + 1
-            for j in range(0, 2 if deep else 1):
+            for j in range(0, nhf + 1 if deep else 1):
                 if k + j < state["limit"] and state["hf_issued"] <= k + j:
                     issue_hf(k + j, timed); state["hf_issued"] = k + j + 1
             if deep:

@@ -163,7 +163,8 @@ JxlDecoderStatus JxlHipBatchOutBufferSize(const JxlHipBatch* batch, int index, c
 JxlDecoderStatus JxlHipBatchSetOutput(JxlHipBatch* batch, int index, const JxlPixelFormat* format, void* device_buffer);
 /* Decode-thread packing: lanes between active entropy-decode threads (64 = one stream per wavefront, 1 = 64 per wavefront). */
 void JxlHipBatchSetLaneStride(JxlHipBatch* batch, int lf, int hf);
-/* Tuning / testing knobs: "force_generic_idct", "hf_block_threads", "lds_code_budget". Unknown names are ignored. */
+/* Tuning / testing knobs: "force_generic_idct", "hf_block_threads", "lds_code_budget", "lf_wide_once" (the next LF stage of the batch takes the
+ * one-wavefront-per-stream kernel whatever the lane stride: shorter latency on an idle GPU). Unknown names are ignored. */
 void JxlHipBatchSetOption(JxlHipBatch* batch, const char* name, int value);
 /* Uploads streams and tables (inputs become HBM-resident) and allocates work buffers.  hip_stream: hipStream_t or NULL. */
 JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* batch, void* hip_stream);

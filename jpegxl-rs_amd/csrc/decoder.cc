@@ -500,6 +500,7 @@ void Batch::Prepare(void* stream_v) {
   const bool need_plane_b = fplan_.any_unfused || cfg.force_unfused_filters;
   struct WorkOffsets {
     size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, vb_list, vb_count, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
+        place_rec = 0, place_cnt = 0, band_start = 0,
         mod_scratch, hf_end = 0, mod_wp = 0, up_plane[4] = {0, 0, 0, 0};
     size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0, lz_window = (size_t)-1;
   };
@@ -545,6 +546,7 @@ void Batch::Prepare(void* stream_v) {
       for (int c = 0; c < 3; c++) { o.lfq[c] = take(nb * 4); o.lf[c] = take(nb * 4); o.lf_tmp[c] = take(nb * 4); o.llf[c] = take(nb * 4); }
       o.blk_info = take(nb * 4); o.coef_off = take(nb * 4); o.inv_sigma = take(nb * 4);
       o.vb_list = take((size_t)p.num_groups * 1024 * 8); o.vb_count = take((size_t)p.num_groups * 4);
+      o.place_rec = take(nb * 16); o.place_cnt = take((size_t)p.num_lf_groups * 8 * 4); o.band_start = take((size_t)p.num_lf_groups * 8 * 4);
       const size_t ntile = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8);
       o.ytox = take(ntile); o.ytob = take(ntile);
       const size_t plane = (size_t)p.bw * 8 * p.bh * 8 * 4;
@@ -716,6 +718,7 @@ void Batch::Prepare(void* stream_v) {
       }
       f.blk_info = (uint32_t*)(dwork_ + o.blk_info); f.coef_off = (uint32_t*)(dwork_ + o.coef_off);
       f.vb_list = (uint2*)(dwork_ + o.vb_list); f.vb_count = (uint32_t*)(dwork_ + o.vb_count);
+      f.place_rec = (uint4*)(dwork_ + o.place_rec); f.place_cnt = (uint32_t*)(dwork_ + o.place_cnt); f.band_start = (uint32_t*)(dwork_ + o.band_start);
       f.ytox = (int8_t*)(dwork_ + o.ytox); f.ytob = (int8_t*)(dwork_ + o.ytob);
       f.inv_sigma = (float*)(dwork_ + o.inv_sigma);
       f.lf_scratch = (int32_t*)(dwork_ + o.lf_scratch); f.lf_scratch_stride = o.lf_scratch_stride;
@@ -872,8 +875,31 @@ void Batch::Prepare(void* stream_v) {
     for (int i = 0; i < n; i++) upw[i] = co[i].up_weights;
     PlanPostOps(hconst_, upw);
   }
-  // ---- SIMT LF decode plan (cfg.lane_stride_lf < 64): streams of eligible frames, spread over lanes of about equal work
   lf_simt_ = LfSimtPlan();
+  // ---- varblock placement units: every 32-row band of every LF group of every VarDCT frame, the tallest / widest first (the lanes of a
+  // wavefront then carry bands of similar length)
+  size_t place_units_off = 0;
+  {
+    vec<uint2> units;
+    vec<uint32_t> ucost;
+    for (int i = 0; i < n; i++) {
+      const FramePlan& p = images_[i]->plan;
+      if (p.modular) continue;
+      for (uint32_t g = 0; g < p.num_lf_groups; g++) {
+        const uint32_t gx = g % p.xlfgroups, gy = g / p.xlfgroups;
+        const uint32_t gbw = std::min<uint32_t>(256, p.bw - gx * 256), gbh = std::min<uint32_t>(256, p.bh - gy * 256);
+        for (uint32_t band = 0; band * 32 < gbh; band++) { units.push_back(make_uint2((uint32_t)i, g | (band << 16))); ucost.push_back(std::min<uint32_t>(32, gbh - band * 32) * gbw); }
+      }
+    }
+    vec<uint32_t> order(units.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = (uint32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ucost[a] > ucost[b]; });
+    vec<uint2> sorted;
+    for (uint32_t k : order) sorted.push_back(units[k]);
+    place_units_off = arena.Put(sorted.data(), sorted.size() * sizeof(uint2));
+    lf_simt_.num_units = (uint32_t)sorted.size();
+  }
+  // ---- SIMT LF decode plan (cfg.lane_stride_lf < 64): streams of eligible frames, spread over lanes of about equal work
   vec<uint8_t> simt_frame(n, 0);
   size_t simt_streams_off = 0, simt_lanes_off = 0, simt_luts_off = 0;
   if (any_vardct_ && cfg.lane_stride_lf < 64) {
@@ -945,6 +971,7 @@ void Batch::Prepare(void* stream_v) {
   HIP_CHECK(hipMalloc((void**)&dconst_, const_size_));
   HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
   for (int i = 0; i < n; i++) { fill_frame(i, dconst_); frames_host_[i].lf_simt = lf_simt_.num_lanes ? simt_frame[i] : 0; }
+  lf_simt_.units = (const uint2*)(dconst_ + place_units_off);
   if (lf_simt_.num_lanes) {
     lf_simt_.streams = (const LfSimtStream*)(dconst_ + simt_streams_off); lf_simt_.lanes = (const LfSimtLane*)(dconst_ + simt_lanes_off); lf_simt_.luts = dconst_ + simt_luts_off;
   }
@@ -1417,6 +1444,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     DebugSync("modular global", stream_v);
     cfg.lf_head_start = part == 1 || part == 5;   // front enqueued on its own: a pipelined caller, the HF stage of another batch is about to start
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v, &lf_simt_);
+    cfg.lf_wide_once = 0;
     DebugSync("LF decode", stream_v);
     if (any_vardct_ && !cfg.idct_flags_known && part != 0) {
       // a caller that enqueues the stages separately: the placement flags travel to pinned host memory behind the LF stage, and the tail —

@@ -400,6 +400,7 @@ void JxlHipBatchSetOption(JxlHipBatch* h, const char* name, int value) {
   std::string n(name);
   if (n == "force_generic_idct") h->b->cfg.force_generic_idct = value;
   else if (n == "force_unfused_filters") h->b->cfg.force_unfused_filters = value;
+  else if (n == "lf_wide_once") h->b->cfg.lf_wide_once = value != 0;
   else if (n == "keep_orientation") h->keep_orientation = value != 0;   // applies to outputs set afterwards
   else if (n == "hf_block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) h->b->cfg.hf_block_threads = value;
   else if (n == "lds_code_budget" && value >= 0 && value <= 128 * 1024) h->b->cfg.lds_code_budget = value;

@@ -103,6 +103,9 @@ struct FrameDev {
   const float* up_weights;        // 15 / 55 / 210 coefficients of the symmetric (5N x 5N) kernel matrix, N = upsampling / 2
   float* up_plane[4];             // upsampled X, Y, B (and alpha as float) planes, img_w x img_h
   uint32_t mod_cfg_uniform;       // the hybrid-integer configuration shared by every cluster of mod_code, or 0xFFFFFFFF
+  uint4* place_rec;               // varblock placement records (one per varblock, grouped per band: BandRecordBase), bw x bh entries
+  uint32_t* place_cnt;            // [LF group * 8 + band] records of the band
+  uint32_t* band_start;           // [LF group * 8 + band] index of the band's first entry in the LF group's strategy list (0xFFFFFFFF: damaged)
   uint32_t lf_simt;               // the LF-group streams of this frame are decoded by LfDecodeSimtKernel (one stream per lane), placement by LfPlaceKernel
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
@@ -127,6 +130,8 @@ struct LaunchCfg {
   int force_generic_idct = 0;
   // filled by Batch::Finish from the per-frame flags the LF stage sets (deterministic per stream): once known, the
   // kernels for varblocks outside a 64x64 tile / the DCT128-256 family are only launched when some frame needs them
+  int lf_wide_once = 0;              // the next LF launch takes the one-wavefront-per-stream kernel for every frame, SIMT-eligible or not (a pipeline that starts
+                                     // on an idle GPU: 100 instead of 250 ms until the first batch can go on); reset by the launch
   int lf_head_start = 0;             // the LF launch waits until the next HF launch is resident (set for pipelined front-only calls)
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
   int need_tile4_plain = 1, need_tile4_special = 1, need_tile8_plain = 1, need_tile8_special = 1;   // IdctTileKernel<TB, SPECIAL> variants some frame takes
@@ -150,6 +155,7 @@ struct LfSimtStream { uint32_t frame, group; LfSimtChan chan[7]; };   // channel
 struct LfSimtLane { uint32_t first, count; };               // a lane decodes streams [first, first + count) one after the other
 struct LfSimtPlan {
   const LfSimtStream* streams = nullptr; const LfSimtLane* lanes = nullptr; const uint8_t* luts = nullptr;   // device pointers
+  const uint2* units = nullptr; uint32_t num_units = 0;     // varblock placement: {frame, LF group | band << 16} of every 32-row band of every VarDCT frame, longest first
   uint32_t num_lanes = 0, lanes_per_wave = 16;
   int any_legacy = 1;          // some VarDCT frame of the batch still takes LfDecodeKernel (one wavefront per stream)
 };

@@ -1250,186 +1250,185 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   WaveSync();
 }
 
-// ---- varblock placement of one BAND (32 block rows) of an LF group, by one wavefront -----------------------------------------------------
+// ---- varblock placement -----------------------------------------------------------------------------------------------------------------
 // The varblocks of an LF group arrive as one list in raster order of their top-left blocks ("the next entry goes to the first block no
 // earlier entry covers").  That is sequential — but varblocks never cross a 32-row band (they stay inside a 256x256-pixel group), so a
-// band is complete before the scan enters the next one and the list index at which a band starts is where the running sum of block areas
-// reaches (rows above) x (group width): a prefix sum.  Every band therefore goes to a wavefront of its own — eight per 2048x2048 LF
-// group instead of one —, which first finds its start index with wave-wide scans over the strategy list and then walks its band.
-// The walk itself: lane 0 follows the scan out of LDS only — 64 (strategy, hf_mul) pairs staged per round by all lanes, coverage bitmap
-// as a ring of 64 rows x 8 words, running coefficient offsets / varblock counts of the band's eight groups — and emits one 16-byte record
-// per varblock; the wavefront then writes coefficient offsets, per-group varblock lists (incl. the HF block-context bucket) and block-info
-// words of all covered blocks in parallel.  The band's rows of the chroma-from-luma maps and of the sharpness map are its as well.
-constexpr uint32_t kLfPlaceWaves = 4, kLfPlaceLds = 4352;
-__device__ __forceinline__ void LfPlaceBand(const FrameDev& f, const uint32_t g, const uint32_t band, const uint32_t wb, int& s_fail, uint32_t* s_u) {
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
-  const uint32_t bx0 = gx * 256, by0 = gy * 256;
-  const uint32_t gbw = min(256u, f.bw - bx0), gbh = min(256u, f.bh - by0);
-  const uint32_t y_begin = band * 32;
-  if (y_begin >= gbh) return;
-  const uint32_t y_end = min(gbh, y_begin + 32);
+// band is complete before the scan enters the next one, and the list index at which a band starts is where the running sum of block areas
+// reaches (rows above) x (group width): a prefix sum.  Three kernels:
+//   LfBandStartKernel   one wavefront per LF group: wave-wide scans over the strategy list -> start index of each of its (up to 8) bands
+//   LfPlaceSimtKernel   one band per LANE, 16 lanes per wavefront: every lane walks its band's scan (coverage bitmap of 32 rows x 256
+//                       blocks = 1 KB of LDS per lane) and emits one 16-byte record per varblock; the walk is a serial chain per band, so
+//                       like the entropy decode it runs in lock step on a few hundred wavefronts instead of one wavefront per chain
+//   LfPlaceExpandKernel one workgroup per band: records -> coefficient offsets, per-group varblock lists (incl. the HF block-context
+//                       bucket), block-info words of all covered blocks (sharpness merged), the band's rows of the chroma-from-luma maps
+struct BandGeom { uint32_t gx, gy, bx0, by0, gbw, gbh, y_begin, y_end; };
+__device__ __forceinline__ BandGeom BandGeometry(const FrameDev& f, uint32_t g, uint32_t band) {
+  BandGeom b;
+  b.gx = g % f.xlfgroups; b.gy = g / f.xlfgroups;
+  b.bx0 = b.gx * 256; b.by0 = b.gy * 256;
+  b.gbw = min(256u, f.bw - b.bx0); b.gbh = min(256u, f.bh - b.by0);
+  b.y_begin = band * 32; b.y_end = min(b.gbh, b.y_begin + 32);
+  return b;
+}
+// records of a band: a region of (rows x width) entries at (blocks of the LF groups above) + (of those to the left) + (of the bands above)
+__device__ __forceinline__ size_t BandRecordBase(const FrameDev& f, const BandGeom& b) { return (size_t)b.by0 * f.bw + (size_t)b.bx0 * b.gbh + (size_t)b.y_begin * b.gbw; }
+__device__ __forceinline__ uint32_t StrategyGeo(uint32_t s) {   // cx | cy << 8 | {log2 cx << 5 | log2 (cx cy) << 8 | order bucket << 12} << 16
+  return CoveredX(s) | (CoveredY(s) << 8) | (((Log2CoveredX(s) << 5) | ((Log2CoveredX(s) + Log2CoveredY(s)) << 8) | (OrderBucket(s) << 12)) << 16);
+}
+
+__global__ __launch_bounds__(256) void LfBandStartKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular) return;
+  const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= f.num_lf_groups) return;
+  const BandGeom bg = BandGeometry(f, g, 0);
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
   const uint32_t nb_blocks = (uint32_t)LdG(scratch + 1);
-  if (lane == 0) s_fail = (LdG(f.status) != 0 || nb_blocks == 0 || nb_blocks > gbw * gbh) ? 1 : 0;   // (a failed stream leaves no usable block count)
-  WaveSync();
-  if (s_fail) return;
-  const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
-  int32_t* m_ytox = scratch + 16;
-  int32_t* m_ytob = m_ytox + mcw * mch;
-  int32_t* m_blk = m_ytob + mcw * mch;
-  int32_t* m_sharp = m_blk + 2 * nb_blocks;
-  // ---- chroma-from-luma maps: the band's four tile rows (all lanes)
-  for (uint32_t i = band * 4 * mcw + lane; i < min(mch, band * 4 + 4) * mcw; i += 64) {
+  uint32_t* starts = f.band_start + g * 8;
+  if (LdG(f.status) != 0 || nb_blocks == 0 || nb_blocks > bg.gbw * bg.gbh) { if (lane < 8) StG(starts + lane, 0xFFFFFFFFu); return; }   // (a failed stream leaves no usable block count)
+  const uint32_t mcw = (bg.gbw + 7) / 8, mch = (bg.gbh + 7) / 8;
+  const int32_t* m_blk = scratch + 16 + 2 * mcw * mch;
+  const uint32_t nbands = (bg.gbh + 31) / 32;
+  if (lane == 0) StG(starts, 0u);
+  uint32_t next = 1, cum = 0;                     // next band whose start is looked for; areas of the entries before `base`
+  for (uint32_t base = 0; base < nb_blocks && next < nbands; base += 64) {
+    const uint32_t idx = base + lane;
+    uint32_t area = 0;
+    if (idx < nb_blocks) { const uint32_t st = (uint32_t)LdG(m_blk + idx); if (st < 27) area = CoveredX(st) * CoveredY(st); }
+    uint32_t incl = area;                         // inclusive prefix sum over the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
+    const uint32_t total = __shfl(incl, 63, 64);
+    while (next < nbands) {                       // (several bands may start inside one chunk of 64 entries)
+      const uint32_t target = next * 32 * bg.gbw;
+      if (cum + total < target) break;
+      const uint64_t reach = __ballot(cum + incl - area >= target && idx < nb_blocks);   // entries that start at or past the band's first block
+      if (!reach) break;                          // the band starts exactly where this chunk ends (or the list does)
+      const int l0 = __ffsll((long long)reach) - 1;
+      const uint32_t at = __shfl(cum + incl - area, l0, 64);
+      if (lane == 0) StG(starts + next, at == target ? base + (uint32_t)l0 : 0xFFFFFFFFu);   // not exactly there: a varblock straddles the band's top (damaged list)
+      next++;
+    }
+    cum += total;
+  }
+  if (lane == 0) for (uint32_t k = next; k < 8; k++) StG(starts + k, k < nbands ? 0xFFFFFFFFu : 0u);     // bands the list never reaches
+}
+
+constexpr uint32_t kPlaceLanes = 16, kPlaceLaneWords = 256 + 17;          // per lane: 32 rows x 8 words of coverage, 8 group offsets, 8 group counts (odd stride: no bank conflicts)
+__global__ __launch_bounds__(64) void LfPlaceSimtKernel(const FrameDev* __restrict__ frames, const uint2* __restrict__ units, uint32_t num_units) {
+  __shared__ uint32_t s_lds[kPlaceLanes * kPlaceLaneWords];
+  const uint32_t u = blockIdx.x * kPlaceLanes + threadIdx.x;
+  if (threadIdx.x >= kPlaceLanes || u >= num_units) return;
+  const uint2 unit = LdG(units + u);
+  const FrameDev& f = frames[unit.x];
+  const uint32_t g = unit.y & 0xFFFF, band = unit.y >> 16;
+  const BandGeom bg = BandGeometry(f, g, band);
+  uint32_t* cnt_out = f.place_cnt + g * 8 + band;
+  uint32_t k = LdG(f.band_start + g * 8 + band);
+  if (k == 0xFFFFFFFFu) { if (LdG(f.status) == 0) SetError(f, kErrVarblock); StG(cnt_out, 0u); return; }
+  int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
+  const uint32_t nb_blocks = (uint32_t)LdG(scratch + 1);
+  const uint32_t mcw = (bg.gbw + 7) / 8, mch = (bg.gbh + 7) / 8;
+  const int32_t* m_blk = scratch + 16 + 2 * mcw * mch;
+  uint4* rec = f.place_rec + BandRecordBase(f, bg);
+  uint32_t* ring = s_lds + threadIdx.x * kPlaceLaneWords;
+  uint32_t* goff = ring + 256;
+  uint32_t* gcnt = ring + 264;
+  for (uint32_t i = 0; i < 256; i++) { const uint32_t wi = i & 7; ring[i] = wi * 32 >= bg.gbw ? ~0u : (bg.gbw - wi * 32 < 32 ? ~0u << (bg.gbw - wi * 32) : 0u); }   // bits outside the group are pre-set
+  for (uint32_t i = 0; i < 8; i++) { goff[i] = 0; gcnt[i] = 0; }
+  uint32_t y = bg.y_begin, wi = 0, count = 0, flags_acc = 0, err = 0;
+  int2 sq_next = k < nb_blocks ? make_int2(LdG(m_blk + k), LdG(m_blk + nb_blocks + k)) : make_int2(-1, -1);
+  while (y < bg.y_end) {
+    const uint32_t row = (y & 31) * 8;
+    const uint32_t cov = ring[row + wi];
+    if (cov == ~0u) { if (++wi == 8) { wi = 0; y++; } continue; }     // the first uncovered block of a row only moves right
+    const uint32_t xb = (uint32_t)__ffs((int)~cov) - 1, x = wi * 32 + xb;
+    if (k >= nb_blocks) { err = kErrVarblock; break; }
+    const uint32_t s = (uint32_t)sq_next.x, q = (uint32_t)sq_next.y;
+    k++;
+    if (k < nb_blocks) sq_next = make_int2(LdG(m_blk + k), LdG(m_blk + nb_blocks + k));     // (arrives while this varblock is placed)
+    if (s >= 27 || q > 255) { err = kErrBadValue; break; }           // (negative values wrap to large ones)
+    if (f.subsampled && s != 0) { err = kErrUnsupported; break; }    // chroma-subsampled frames: 8x8 DCT only
+    const uint32_t geo = StrategyGeo(s), cx = geo & 0xFF, cy = (geo >> 8) & 0xFF;
+    if (x + cx > bg.gbw || y + cy > bg.gbh || xb + cx > 32 || (y % 32) + cy > 32) { err = kErrVarblock; break; }
+    const uint32_t bits = (cx == 32 ? ~0u : (1u << cx) - 1u) << xb;
+    uint32_t clash = 0;
+    for (uint32_t iy = 0; iy < cy; iy++) { const uint32_t o = ((y + iy) & 31) * 8 + wi; const uint32_t wv = ring[o]; clash |= wv & bits; ring[o] = wv | bits; }
+    if (clash) { err = kErrVarblock; break; }
+    if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;      // not inside one 32x32 tile: the IDCT uses 64x64 tiles
+    if (s == 1 || s == 2 || s == 3 || (s >= 12 && s <= 17)) flags_acc |= 8u;  // IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4 / AFV0-3: the tile kernel variant that carries them
+    if (s == 1 || s == 2 || (s >= 14 && s <= 17)) flags_acc |= 16u;           // IDENTITY / DCT2X2 / AFV: redone by IdctRareSpecialKernel after the tile kernel
+    if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;   // DCT128/256 family: BigIdctKernel (+ generic path if unaligned)
+    else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;  // varblock not contained in a 64x64 tile: generic IDCT
+    const uint32_t go = goff[wi], gc = gcnt[wi];
+    goff[wi] = go + cx * cy * 64;
+    gcnt[wi] = gc + 1;
+    // record: {x | y << 8 | s << 16 | q << 24, coefficient offset, index in the group's list, geometry word}
+    StG(rec + count, make_uint4(x | (y << 8) | (s << 16) | (q << 24), go, gc, geo));
+    count++;
+  }
+  if (err) { SetError(f, err); count = 0; }
+  if (flags_acc) atomicOr(f.frame_flags, flags_acc);
+  StG(cnt_out, count);
+  for (uint32_t i = 0; i < 8; i++) if (i * 32 < bg.gbw) StG(f.vb_count + (bg.gy * 8 + band) * f.xgroups + bg.gx * 8 + i, err ? 0u : gcnt[i]);
+}
+
+__global__ __launch_bounds__(256) void LfPlaceExpandKernel(const FrameDev* __restrict__ frames, const uint2* __restrict__ units, uint32_t num_units) {
+  const uint2 unit = LdG(units + blockIdx.x);
+  const FrameDev& f = frames[unit.x];
+  const uint32_t g = unit.y & 0xFFFF, band = unit.y >> 16;
+  const BandGeom bg = BandGeometry(f, g, band);
+  int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
+  const uint32_t nb_blocks = (uint32_t)LdG(scratch + 1);
+  if (LdG(f.status) != 0 || nb_blocks == 0 || nb_blocks > bg.gbw * bg.gbh) return;
+  const uint32_t mcw = (bg.gbw + 7) / 8, mch = (bg.gbh + 7) / 8;
+  const int32_t* m_ytox = scratch + 16;
+  const int32_t* m_ytob = m_ytox + mcw * mch;
+  const int32_t* m_sharp = m_ytob + mcw * mch + 2 * nb_blocks;
+  // ---- chroma-from-luma maps: the band's four tile rows
+  for (uint32_t i = band * 4 * mcw + threadIdx.x; i < min(mch, band * 4 + 4) * mcw; i += blockDim.x) {
     const uint32_t y = i / mcw, x = i % mcw;
     const int a = m_ytox[i], b = m_ytob[i];
-    if (a < -128 || a > 127 || b < -128 || b > 127) { SetError(f, kErrBadValue); s_fail = 1; }
-    if (f.subsampled && (a | b)) { SetError(f, kErrUnsupported); s_fail = 1; }      // chroma from luma across different block grids
-    const size_t o = (size_t)(gy * 32 + y) * f.cw + gx * 32 + x;
+    if (a < -128 || a > 127 || b < -128 || b > 127) SetError(f, kErrBadValue);
+    if (f.subsampled && (a | b)) SetError(f, kErrUnsupported);      // chroma from luma across different block grids
+    const size_t o = (size_t)(bg.gy * 32 + y) * f.cw + bg.gx * 32 + x;
     f.ytox[o] = (int8_t)a; f.ytob[o] = (int8_t)b;
   }
-  const uint32_t ring_off = wb, goff_off = wb + 2048, gcnt_off = wb + 2304, in_off = wb + 2560, rec_off = wb + 3072, cnt_off = wb + 4096;
-  const uint32_t pat_off = wb + 4128, geo_off = wb + 4160;   // row pattern (8 words), per-strategy {cx | cy << 8 | HF entry fields << 16} (27 words)
-  // bitmap: 32-bit words, one per 32-block column of the LF group (8 per row); bits outside the group are pre-set
-  if (lane < 8) StS<uint32_t>(pat_off + lane * 4, lane * 32 >= gbw ? ~0u : (gbw - lane * 32 < 32 ? ~0u << (gbw - lane * 32) : 0u));
-  if (lane < 27) StS<uint32_t>(geo_off + lane * 4, CoveredX(lane) | (CoveredY(lane) << 8) | (((Log2CoveredX(lane) << 5) | ((Log2CoveredX(lane) + Log2CoveredY(lane)) << 8) | (OrderBucket(lane) << 12)) << 16));
-  WaveSync();
-  // ---- where the band starts in the list: first index whose preceding areas add up to (rows above) x width
-  uint32_t num0 = 0;
-  if (band > 0) {
-    const uint32_t target = y_begin * gbw;
-    uint32_t cum = 0, found = 0xFFFFFFFFu;
-    for (uint32_t base = 0; base < nb_blocks; base += 64) {
-      const uint32_t idx = base + lane;
-      uint32_t area = 0;
-      if (idx < nb_blocks) { const uint32_t st = (uint32_t)LdG(m_blk + idx); if (st < 27) { const uint32_t geo = LdS<uint32_t>(geo_off + st * 4); area = (geo & 0xFF) * ((geo >> 8) & 0xFF); } }
-      uint32_t incl = area;       // inclusive prefix sum over the wavefront
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
-      const uint32_t total = __shfl(incl, 63, 64);
-      if (cum + total < target) { cum += total; continue; }
-      const uint64_t reach = __ballot(cum + incl - area >= target && idx < nb_blocks);   // lanes whose entry starts at or past the band's first block
-      if (reach) {
-        const int l0 = __ffsll((long long)reach) - 1;
-        const uint32_t at = __shfl(cum + incl - area, l0, 64);
-        found = at == target ? base + (uint32_t)l0 : 0xFFFFFFFEu;    // (not exactly there: a varblock straddles the band's top — damaged list)
-        break;
-      }
-      cum += total;
+  const uint32_t count = LdG(f.place_cnt + g * 8 + band);
+  const uint4* rec = f.place_rec + BandRecordBase(f, bg);
+  const BlockCtxDev& bcm = *f.bcm;
+  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+    const uint4 r = LdG(rec + i);
+    const uint32_t x = r.x & 0xFF, y = (r.x >> 8) & 0xFF, s = (r.x >> 16) & 0xFF, q = r.x >> 24;
+    const uint32_t cx = r.w & 0xFF, cy = (r.w >> 8) & 0xFF;
+    const size_t o = (size_t)(bg.by0 + y) * f.bw + bg.bx0 + x;
+    // block-context inputs of the HF stage (ac_context.h): quant-field and LF-value buckets of the varblock's first block,
+    // folded into qf_idx * num_lf_ctxs + lf_idx (< 64) here so that the HF decoder's loop has no threshold searches
+    uint32_t qf_idx = 0;
+    for (uint32_t t = 0; t < bcm.n_qf_thr; t++) qf_idx += q + 1 > bcm.qf_thr[t];
+    uint32_t lf_idx = 0;
+    if (bcm.num_lf_ctxs > 1) {
+      auto lfq_at = [&](int c) { return LdG(f.lfq[c] + (size_t)((bg.by0 + y) >> f.vs[c]) * f.bw + ((bg.bx0 + x) >> f.hs[c])); };   // (quant_dc is kept at full resolution)
+      const int32_t q0 = lfq_at(0), q1 = lfq_at(1), q2 = lfq_at(2);
+      uint32_t b0 = 0, b1 = 0, b2 = 0;
+      for (uint32_t t = 0; t < bcm.n_lf_thr[0]; t++) b0 += q0 > bcm.lf_thr[0][t];
+      for (uint32_t t = 0; t < bcm.n_lf_thr[1]; t++) b1 += q1 > bcm.lf_thr[1][t];
+      for (uint32_t t = 0; t < bcm.n_lf_thr[2]; t++) b2 += q2 > bcm.lf_thr[2][t];
+      lf_idx = (b0 * (bcm.n_lf_thr[2] + 1) + b2) * (bcm.n_lf_thr[1] + 1) + b1;
     }
-    if (found >= 0xFFFFFFFEu) { if (lane == 0) { SetError(f, kErrVarblock); s_fail = 1; } WaveSync(); return; }
-    num0 = found;
+    const uint32_t qlf = (qf_idx * bcm.num_lf_ctxs + lf_idx) & 63u;
+    // per-group varblock list for the HF decoder (everything its block start needs, ready to unpack):
+    // {strategy | log2 cx << 5 | log2 (cx cy) << 8 | order bucket << 12 | x << 16 | y << 21 | qlf << 26, coefficient offset}
+    const uint32_t gg = (bg.gy * 8 + y / 32) * f.xgroups + bg.gx * 8 + x / 32;
+    StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (r.w >> 16) | ((x % 32) << 16) | ((y % 32) << 21) | (qlf << 26), r.y));
+    for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++) {
+      // (the sharpness map is merged here: every covered block's word is written exactly once)
+      const int32_t sh = LdG(m_sharp + (size_t)(y + iy) * bg.gbw + x + ix);
+      if (sh < 0 || sh > 7) SetError(f, kErrBadValue);
+      StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, (uint32_t)sh & 7u));
+      StG(f.coef_off + o + (size_t)iy * f.bw + ix, r.y);   // (every covered block: the IDCT reads info and offset side by side)
+    }
   }
-  for (uint32_t i = lane; i < 512; i += 64) {
-    const uint32_t y = y_begin + (i >> 3), wi = i & 7;                  // ring slot (y & 63) holds row y; the band's 32 rows + what lies below (pre-set)
-    StS<uint32_t>(ring_off + ((y & 63) * 8 + wi) * 4, y >= y_end ? ~0u : LdS<uint32_t>(pat_off + wi * 4));
-  }
-  StS<uint32_t>(goff_off + lane * 4, 0u); StS<uint32_t>(gcnt_off + lane * 4, 0u);
-  if (lane == 0) { StS<uint32_t>(cnt_off + 4, y_begin); StS<uint32_t>(cnt_off + 8, 0u); }
-  WaveSync();
-  if (s_fail) return;
-  uint32_t flags_acc = 0;
-  while (true) {
-    {  // stage the next 64 (strategy, hf_mul - 1) pairs
-      const uint32_t idx = num0 + lane;
-      int2 sq = make_int2(-1, -1);
-      if (idx < nb_blocks) sq = make_int2(LdG(m_blk + idx), LdG(m_blk + nb_blocks + idx));
-      StS<int2>(in_off + lane * 8, sq);
-    }
-    WaveSync();
-    if (lane == 0) {
-      uint32_t count = 0;
-      bool bad = false;
-      uint32_t y = LdS<uint32_t>(cnt_off + 4), wi = LdS<uint32_t>(cnt_off + 8);   // scan position: row, 32-block column
-      while (count < 64 && y < y_end) {
-        const uint32_t row = ring_off + (y & 63) * 32;
-        const uint32_t cov = LdS<uint32_t>(row + wi * 4);
-        if (cov == ~0u) {
-          // the first uncovered block of a row only moves right: next column; after the last one the ring slot becomes row y + 64
-          if (++wi == 8) {
-            for (uint32_t k = 0; k < 8; k++) StS<uint32_t>(row + k * 4, ~0u);    // (row y + 64 is past the band)
-            y++; wi = 0;
-          }
-          continue;
-        }
-        const uint32_t xb = (uint32_t)__ffs((int)~cov) - 1, x = wi * 32 + xb;
-        const int2 sq = LdS<int2>(in_off + count * 8);
-        const uint32_t s = (uint32_t)sq.x, q = (uint32_t)sq.y;
-        if (num0 + count >= nb_blocks) { SetError(f, kErrVarblock); bad = true; break; }
-        if (s >= 27 || q > 255) { SetError(f, kErrBadValue); bad = true; break; }       // (negative values wrap to large ones)
-        if (f.subsampled && s != 0) { SetError(f, kErrUnsupported); bad = true; break; }   // chroma-subsampled frames: 8x8 DCT only
-        const uint32_t geo = LdS<uint32_t>(geo_off + s * 4), cx = geo & 0xFF, cy = (geo >> 8) & 0xFF;
-        if (x + cx > gbw || y + cy > gbh || xb + cx > 32 || (y % 32) + cy > 32) { SetError(f, kErrVarblock); bad = true; break; }
-        const uint32_t bits = (cx == 32 ? ~0u : (1u << cx) - 1u) << xb;
-        uint32_t clash = 0;
-        for (uint32_t iy = 0; iy < cy; iy++) {
-          const uint32_t co = ring_off + ((y + iy) & 63) * 32 + wi * 4;
-          const uint32_t wv = LdS<uint32_t>(co);
-          clash |= wv & bits;
-          StS<uint32_t>(co, wv | bits);
-        }
-        if (clash) { SetError(f, kErrVarblock); bad = true; break; }
-        if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;      // not inside one 32x32 tile: the IDCT uses 64x64 tiles
-        if (s == 1 || s == 2 || s == 3 || (s >= 12 && s <= 17)) flags_acc |= 8u;  // IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4 / AFV0-3: the tile kernel variant that carries them
-        if (s == 1 || s == 2 || (s >= 14 && s <= 17)) flags_acc |= 16u;           // IDENTITY / DCT2X2 / AFV (64 live coefficients per lane): redone by IdctRareSpecialKernel after the tile kernel
-        if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;   // DCT128/256 family: BigIdctKernel (+ generic path if unaligned)
-        else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;  // varblock not contained in a 64x64 tile: generic IDCT
-        const uint32_t gi = (y / 32) * 8 + wi;
-        const uint32_t go = LdS<uint32_t>(goff_off + gi * 4), gc = LdS<uint32_t>(gcnt_off + gi * 4);
-        StS<uint32_t>(goff_off + gi * 4, go + cx * cy * 64);
-        StS<uint32_t>(gcnt_off + gi * 4, gc + 1);
-        // record: {x | y << 8 | s << 16 | q << 24, coefficient offset, index in the group's list, cx | cy << 8}
-        StS<uint4>(rec_off + count * 16, make_uint4(x | (y << 8) | (s << 16) | (q << 24), go, gc, geo));
-        count++;
-      }
-      if (bad) s_fail = 1;
-      StS<uint32_t>(cnt_off, count);
-      StS<uint32_t>(cnt_off + 4, y);
-      StS<uint32_t>(cnt_off + 8, wi);
-    }
-    WaveSync();
-    if (s_fail) return;
-    const uint32_t count = LdS<uint32_t>(cnt_off);
-    const uint32_t scan_y = LdS<uint32_t>(cnt_off + 4);
-    if (lane < count) {
-      const uint4 r = LdS<uint4>(rec_off + lane * 16);
-      const uint32_t x = r.x & 0xFF, y = (r.x >> 8) & 0xFF, s = (r.x >> 16) & 0xFF, q = r.x >> 24;
-      const uint32_t cx = r.w & 0xFF, cy = (r.w >> 8) & 0xFF;
-      const size_t o = (size_t)(by0 + y) * f.bw + bx0 + x;
-      // block-context inputs of the HF stage (ac_context.h): quant-field and LF-value buckets of the varblock's first block,
-      // folded into qf_idx * num_lf_ctxs + lf_idx (< 64) here so that the HF decoder's loop has no threshold searches
-      const BlockCtxDev& bcm = *f.bcm;
-      uint32_t qf_idx = 0;
-      for (uint32_t i = 0; i < bcm.n_qf_thr; i++) qf_idx += q + 1 > bcm.qf_thr[i];
-      uint32_t lf_idx = 0;
-      if (bcm.num_lf_ctxs > 1) {
-        auto lfq_at = [&](int c) { return LdG(f.lfq[c] + (size_t)((by0 + y) >> f.vs[c]) * f.bw + ((bx0 + x) >> f.hs[c])); };   // (quant_dc is kept at full resolution)
-        const int32_t q0 = lfq_at(0), q1 = lfq_at(1), q2 = lfq_at(2);
-        uint32_t b0 = 0, b1 = 0, b2 = 0;
-        for (uint32_t i = 0; i < bcm.n_lf_thr[0]; i++) b0 += q0 > bcm.lf_thr[0][i];
-        for (uint32_t i = 0; i < bcm.n_lf_thr[1]; i++) b1 += q1 > bcm.lf_thr[1][i];
-        for (uint32_t i = 0; i < bcm.n_lf_thr[2]; i++) b2 += q2 > bcm.lf_thr[2][i];
-        lf_idx = (b0 * (bcm.n_lf_thr[2] + 1) + b2) * (bcm.n_lf_thr[1] + 1) + b1;
-      }
-      const uint32_t qlf = (qf_idx * bcm.num_lf_ctxs + lf_idx) & 63u;
-      // per-group varblock list for the HF decoder (everything its block start needs, ready to unpack):
-      // {strategy | log2 cx << 5 | log2 (cx cy) << 8 | order bucket << 12 | x << 16 | y << 21 | qlf << 26, coefficient offset}
-      const uint32_t gg = (gy * 8 + y / 32) * f.xgroups + gx * 8 + x / 32;
-      StG(f.vb_list + (size_t)gg * 1024 + r.z, make_uint2(s | (r.w >> 16) | ((x % 32) << 16) | ((y % 32) << 21) | (qlf << 26), r.y));
-      for (uint32_t iy = 0; iy < cy; iy++) for (uint32_t ix = 0; ix < cx; ix++) {
-        // (the sharpness map is merged here: every covered block's word is written exactly once)
-        const int32_t sh = LdG(m_sharp + (size_t)(y + iy) * gbw + x + ix);
-        if (sh < 0 || sh > 7) SetError(f, kErrBadValue);
-        StG(f.blk_info + o + (size_t)iy * f.bw + ix, PackBlockInfo(s, ix == 0 && iy == 0, q, ix, iy, (uint32_t)sh & 7u));
-        StG(f.coef_off + o + (size_t)iy * f.bw + ix, r.y);   // (every covered block: the IDCT reads info and offset side by side)
-      }
-    }
-    num0 += count;
-    if (scan_y >= y_end) break;
-    WaveSync();   // records consumed before the next round overwrites them
-  }
-  if (lane == 0 && flags_acc) atomicOr(f.frame_flags, flags_acc);
-  if (lane < 8 && lane * 32 < gbw) StG(f.vb_count + (gy * 8 + band) * f.xgroups + gx * 8 + lane, LdS<uint32_t>(gcnt_off + (band * 8 + lane) * 4));
 }
 
 // Two wavefronts per workgroup share four consecutive LF groups: wavefront w decodes groups w and 3 - w one after the
@@ -1441,9 +1440,9 @@ __device__ __forceinline__ void LfPlaceBand(const FrameDev& f, const uint32_t g,
 // Small launches (single images) take one group per wavefront instead: latency over LDS economy.
 // CAPPED: at most 170 VGPRs (with spills) so that pixel-kernel wavefronts of the batch on the main stream fit the same SIMDs — the
 // variant for large pipelined batches; single images take the uncapped one (267 VGPRs, LF stage 20 % shorter).
-template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? JXL_LF_MINW : 1) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes) {
+template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? JXL_LF_MINW : 1) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes, int take_simt_frames) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || f.lf_simt) return;
+  if (f.is_modular || (f.lf_simt && !take_simt_frames)) return;
   const uint32_t first = blockIdx.x * groups_per_block;
   if (first >= f.num_lf_groups) return;
   ModTables T;
@@ -1665,18 +1664,6 @@ __global__ __launch_bounds__(64) void LfDecodeSimtKernel(const FrameDev* __restr
     left = val;
     x++;
   }
-}
-
-// What follows the entropy decode of the LF groups (either kernel): LfPlaceBand, one wavefront per 32-row band of an LF group.
-__global__ __launch_bounds__(64 * kLfPlaceWaves) void LfPlaceKernel(const FrameDev* __restrict__ frames) {
-  const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t unit = blockIdx.x * kLfPlaceWaves + wave;      // (LF group, band)
-  if (unit / 8 >= f.num_lf_groups) return;
-  __shared__ int s_fail_w[kLfPlaceWaves];
-  __shared__ uint32_t s_u_w[kLfPlaceWaves][4];
-  LfPlaceBand(f, unit / 8, unit % 8, wave * kLfPlaceLds, s_fail_w[wave], s_u_w[wave]);
 }
 
 // =====================================================================================================================
@@ -2018,14 +2005,14 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
 }
 
 template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024) void HfDecodeSimtKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes, uint32_t lanes, uint32_t lanes_per_wave,
-                                                                                 uint32_t* __restrict__ sync, uint32_t epoch) {
+                                                                                 uint32_t* __restrict__ sync, uint32_t epoch, int prio) {
   // sync[0]: workgroups of this launch that have started, sync[1]: number of the last HF launch whose workgroups all have
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
   if (sync && threadIdx.x == 0 && atomicAdd(sync, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(sync, 0u); __threadfence(); atomicMax(sync + 1, epoch); }
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
   if (blockIdx.x * lanes >= f.num_groups) return;
-  __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of the co-resident LF waves
+  if (prio) __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of co-resident waves
   // per-lane regions sit at the end of the dynamic LDS: `lanes` real ones + one scratch region that all stream-less
   // lanes of the last wavefront share (they only ever write zeros / prefetched words there and read nothing back)
   const uint32_t lane_off = lds_bytes - (lanes + 1) * kSimtLaneBytes;
@@ -4021,9 +4008,13 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   if (time_it) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], (hipStream_t)stream); }
   auto place = [&]() {
-    // varblock placement, one wavefront per 32-row band of an LF group
+    // varblock placement: band starts (prefix sums), the walk of every band (one per lane), records -> block info / varblock lists
     if (time_it) (void)hipEventRecord(ev[1], (hipStream_t)stream);
-    hipLaunchKernelGGL(LfPlaceKernel, dim3(DivUp(max_lf_groups * 8, (int)kLfPlaceWaves), nframes), dim3(64 * kLfPlaceWaves), kLfPlaceWaves * kLfPlaceLds, (hipStream_t)stream, frames);
+    hipLaunchKernelGGL(LfBandStartKernel, dim3(DivUp(max_lf_groups, 4), nframes), dim3(256), 0, (hipStream_t)stream, frames);
+    if (simt && simt->num_units) {
+      hipLaunchKernelGGL(LfPlaceSimtKernel, dim3(DivUp((int)simt->num_units, (int)kPlaceLanes)), dim3(64), 0, (hipStream_t)stream, frames, simt->units, simt->num_units);
+      hipLaunchKernelGGL(LfPlaceExpandKernel, dim3(simt->num_units), dim3(256), 0, (hipStream_t)stream, frames, simt->units, simt->num_units);
+    }
     if (time_it) {
       (void)hipEventRecord(ev[2], (hipStream_t)stream); (void)hipEventSynchronize(ev[2]);
       float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev[0], ev[1]); (void)hipEventElapsedTime(&b, ev[1], ev[2]);
@@ -4031,7 +4022,8 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
       for (auto& e : ev) (void)hipEventDestroy(e);
     }
   };
-  if (simt && simt->num_lanes) {
+  const int wide = cfg.lf_wide_once;      // this launch: one wavefront per stream for every frame (shorter latency, the whole GPU's SIMDs)
+  if (simt && simt->num_lanes && !wide) {
     // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane)
     const uint32_t lpw = std::min(64u, std::max(1u, simt->lanes_per_wave));
     static const int lf_prio = getenv("JXL_HIP_LF_PRIO") ? atoi(getenv("JXL_HIP_LF_PRIO")) : 0;
@@ -4058,9 +4050,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
       hipLaunchKernelGGL(HeadStartKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sync, g_hf_enqueued[dev] + 1, (uint64_t)200000);   // the next HF launch, or 2 ms
   }
   if (big) {
-    hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
+    hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, wide);
   } else {
-    hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes);
+    hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, wide);
   }
   place();
 }
@@ -4102,10 +4094,11 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     }
     // the common case gets its own instantiation: tables in LDS, no chroma subsampling, no progressive passes (every instruction of
     // the lock-step loop is paid by all ~37 000 iterations of a frame); everything else takes the general one
+    static const int hf_prio = getenv("JXL_HIP_HF_PRIO") ? atoi(getenv("JXL_HIP_HF_PRIO")) : 1;
     const bool plain = all_lds && !cfg.any_subsampled && !cfg.any_multipass;
-    if (plain) hipLaunchKernelGGL((HfDecodeSimtKernel<true, false, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
-    else if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
-    else hipLaunchKernelGGL((HfDecodeSimtKernel<false, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch);
+    if (plain) hipLaunchKernelGGL((HfDecodeSimtKernel<true, false, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch, hf_prio);
+    else if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch, hf_prio);
+    else hipLaunchKernelGGL((HfDecodeSimtKernel<false, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch, hf_prio);
     return;
   }
   const int threads = cfg.hf_block_threads;
