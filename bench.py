@@ -172,15 +172,15 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--epf", type=int, default=1)
-    ap.add_argument("--lane-stride-lf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_LF", "2")),
+    ap.add_argument("--lane-stride-lf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_LF", "8")),
                     help="< 64: SIMT LF decode, 64 / value LF-group streams per wavefront; 64 = one stream per wavefront")
     ap.add_argument("--lane-stride-hf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_HF", "1")),
                     help="1 = SIMT HF decode (one group stream per lane), 64 = one stream per wavefront")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
-    ap.add_argument("--in-flight", type=int, default=8, help="batch objects in flight (pipelined): LF stages run this many steps ahead, minus one")
-    ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
+    ap.add_argument("--in-flight", type=int, default=10, help="batch objects in flight (pipelined): LF stages run this many steps ahead, minus one")
+    ap.add_argument("--lf-streams", type=int, default=9, help="side streams the LF stages of the batches ahead are spread over")
     ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current step (deep pipeline), one stream and one coefficient set each")
     ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "2")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
     ap.add_argument("--out-buffers", type=int, default=2, help="output buffer sets the batches in flight cycle through")
@@ -345,8 +345,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_start = torch.cuda.Event(enable_timing=True); t_start.record(main)
+    step_marks = []
     for i in range(args.steps * inner):
         step(True, last=(i == args.steps * inner - 1))
+        ev = torch.cuda.Event(enable_timing=True); ev.record(main); step_marks.append(ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -402,6 +405,8 @@ def main():
                                                      "traffic": pf, "algorithmic_bytes_per_launch": by, "avg_launch_ms": round(ms, 4)})(
                 stage_ms.get("idct", 0.0), stage_bytes.get("idct", 0), _pmc_bytes(("IdctTileKernel<4, true>", "IdctRareSpecialKernel"), B)),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            # when the tail of every timed step had completed (ms after the start of the timed region): pipeline fill, then the steady state
+            "step_end_ms": [round(t_start.elapsed_time(e), 1) for e in step_marks],
             "stage_gbs": {k: round(stage_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2) if stage_ms[k] > 0 else None for k in stage_ms},
             "device_bytes": sum(bt.device_bytes for bt in batches),
         }

@@ -98,16 +98,36 @@ template <> __device__ __forceinline__ uint4 LdG<uint4>(const uint4* p) {
   const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+// JXL_NT16 (experiment): the 16-byte accesses of coefficient / pixel planes — data that is touched once per decode — carry the non-temporal
+// hint, so that they leave the L2 to what is re-read (entropy-code tables of the SIMT decoders, halo rows of the filter tiles)
+#ifdef JXL_NT16
+#define JXL_LD16(T, ptr) __builtin_nontemporal_load(ptr)
+#else
+#define JXL_LD16(T, ptr) (*(ptr))
+#endif
 template <> __device__ __forceinline__ int4 LdG<int4>(const int4* p) {
   typedef int32_t __attribute__((ext_vector_type(4))) v4;
-  const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
+  const v4 v = JXL_LD16(v4, reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p)));
   return make_int4(v.x, v.y, v.z, v.w);
 }
 template <> __device__ __forceinline__ float4 LdG<float4>(const float4* p) {
   typedef float __attribute__((ext_vector_type(4))) v4;
-  const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
+  const v4 v = JXL_LD16(v4, reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p)));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+#ifdef JXL_NT16
+template <typename T> __device__ __forceinline__ void StG(T* p, T v);
+template <> __device__ __forceinline__ void StG<float4>(float4* p, float4 v) {
+  typedef float __attribute__((ext_vector_type(4))) v4;
+  v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<__attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p)));
+}
+template <> __device__ __forceinline__ void StG<int4>(int4* p, int4 v) {
+  typedef int32_t __attribute__((ext_vector_type(4))) v4;
+  v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<__attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p)));
+}
+#endif
 template <> __device__ __forceinline__ uint2 LdG<uint2>(const uint2* p) {
   typedef uint32_t __attribute__((ext_vector_type(2))) v2;
   const v2 v = *reinterpret_cast<const __attribute__((address_space(1))) v2*>(reinterpret_cast<uintptr_t>(p));
@@ -1515,11 +1535,15 @@ __device__ __forceinline__ bool SkipGroupHeaderSimt(BitReaderQ& br) {   // Group
   return use_global_tree && ntr == 0;
 }
 
-__global__ __launch_bounds__(64) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
-                                                        const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority) {
-  const uint32_t li = blockIdx.x * lanes_per_wave + threadIdx.x;
-  if (threadIdx.x >= lanes_per_wave || li >= num_lanes) return;
-  if (high_priority) __builtin_amdgcn_s_setprio(3);
+// Workgroups of up to 16 wavefronts: the stage's few wavefronts then sit on a handful of CUs (4 per SIMD, filling each other's issue gaps)
+// instead of one on each of a hundred CUs, where every one of them would share — and evict — the instruction cache and L1 of that
+// CU's pixel-kernel wavefronts.
+__global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
+                                                          const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority) {
+  const uint32_t li = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * lanes_per_wave + (threadIdx.x & 63);
+  if ((threadIdx.x & 63) >= lanes_per_wave || li >= num_lanes) return;
+  if (high_priority & 1) __builtin_amdgcn_s_setprio(3);
+  const int xp = high_priority;     // experiments (JXL_HIP_LF_PRIO bits 2, 4: drop the sample stores / the row-above prefetch — wrong pixels, timing only)
   uint32_t cur, end;
   { const uint2 ln = LdG(reinterpret_cast<const uint2*>(lanes + li)); cur = ln.x; end = ln.x + ln.y; }
   BitReaderQ br;
@@ -1620,7 +1644,7 @@ __global__ __launch_bounds__(64) void LfDecodeSimtKernel(const FrameDev* __restr
     {
       const uint32_t j = x + 3;
       const bool nxt = j >= w;
-      if (nxt ? roll_next : hp) up3 = LdG(out + (nxt ? (int32_t)(j - w) : (int32_t)j - stride));   // row above, or the start of this row for the row below
+      if ((nxt ? roll_next : hp) && !(xp & 4)) up3 = LdG(out + (nxt ? (int32_t)(j - w) : (int32_t)j - stride));   // row above, or the start of this row for the row below
     }
     const int32_t n_raw = up0;
     const int32_t W = x ? left : (hp ? n_raw : 0);
@@ -1660,7 +1684,7 @@ __global__ __launch_bounds__(64) void LfDecodeSimtKernel(const FrameDev* __restr
       tok = (((hi << nbits) | bits) << lsb) | low;
     }
     const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) + (uint32_t)guess);
-    StG(out + x, val);
+    if (!(xp & 2)) StG(out + x, val);
     left = val;
     x++;
   }
@@ -4027,7 +4051,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane)
     const uint32_t lpw = std::min(64u, std::max(1u, simt->lanes_per_wave));
     static const int lf_prio = getenv("JXL_HIP_LF_PRIO") ? atoi(getenv("JXL_HIP_LF_PRIO")) : 0;
-    hipLaunchKernelGGL(LfDecodeSimtKernel, dim3(DivUp((int)simt->num_lanes, (int)lpw)), dim3(64), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_prio);
+    static const int wpb_env = getenv("JXL_HIP_LF_WAVES_PER_WG") ? atoi(getenv("JXL_HIP_LF_WAVES_PER_WG")) : 1;
+    const int nwaves = DivUp((int)simt->num_lanes, (int)lpw), wpb = std::max(1, std::min(4, wpb_env));
+    hipLaunchKernelGGL(LfDecodeSimtKernel, dim3(DivUp(nwaves, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_prio);
     if (!simt->any_legacy) { place(); return; }
   }
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
