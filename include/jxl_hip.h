@@ -156,6 +156,13 @@ JxlHipBatch* JxlHipBatchCreate(int device);
 void JxlHipBatchDestroy(JxlHipBatch* batch);
 /* Parses one image (headers, TOC, global tables) and appends it; returns its index or -1. */
 int JxlHipBatchAddImage(JxlHipBatch* batch, const uint8_t* data, size_t size);
+/* The same for `n` images at once, parsed on `num_threads` host threads (the per-image work — container, headers, TOC, entropy-code tables
+ * of the global sections — is independent) and appended in order.  Returns the index of the first image, -1 on error (nothing is appended
+ * then).  What a streaming caller feeds fresh compressed frames with, step after step. */
+int JxlHipBatchAddImages(JxlHipBatch* batch, const uint8_t* const* datas, const size_t* sizes, int n, int num_threads);
+/* Forgets the images of the batch but keeps its device arenas, its pinned staging buffer and the sharing set up with JxlHipBatchShare*:
+ * the object can be filled (AddImage(s), SetOutput) and prepared again without allocating.  No decode of the old content may be in flight. */
+void JxlHipBatchReset(JxlHipBatch* batch);
 /* Basic info / required output size of image `index` for `format`. */
 JxlDecoderStatus JxlHipBatchGetBasicInfo(const JxlHipBatch* batch, int index, JxlBasicInfo* info);
 JxlDecoderStatus JxlHipBatchOutBufferSize(const JxlHipBatch* batch, int index, const JxlPixelFormat* format, size_t* size);

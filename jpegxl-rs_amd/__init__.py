@@ -104,7 +104,8 @@ def libjxl():
             "JxlHipBatchDeviceOutput": (vp, [vp, C.c_int]), "JxlHipBatchCopyOutput": (C.c_int, [vp, C.c_int, vp, sz, vp]),
             "JxlHipBatchTotalPixels": (C.c_uint64, [vp]), "JxlHipBatchCompressedBytes": (C.c_uint64, [vp]),
             "JxlHipBatchStageBytes": (None, [vp, C.POINTER(C.c_uint64 * 6)]), "JxlHipBatchDeviceBytes": (C.c_uint64, [vp]),
-            "JxlHipBatchGetInfo": (C.c_int64, [vp, C.c_char_p]),
+            "JxlHipBatchGetInfo": (C.c_int64, [vp, C.c_char_p]), "JxlHipBatchReset": (None, [vp]),
+            "JxlHipBatchAddImages": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_int, C.c_int]),
             "JxlHipBatchShareBuffers": (C.c_int, [vp, vp]), "JxlHipBatchShareCoefficients": (C.c_int, [vp, vp]),
         }
         for name, (res, args) in sig.items():
@@ -494,6 +495,29 @@ class BatchDecoder:
         self._fmt.append(fmt)
         self._n += 1
         return i
+
+    def add_many(self, datas, dtype="uint8", num_channels=0, device_ptrs=None, threads=4, endianness=Endianness.Native, align=0) -> int:
+        """Parses the images of `datas` (bytes objects) on `threads` host threads and appends them in order (JxlHipBatchAddImages);
+        device_ptrs: optional caller-owned device destination per image.  Returns the index of the first one."""
+        L = libjxl()
+        n = len(datas)
+        ptrs = (C.c_char_p * n)(*datas)
+        sizes = (C.c_size_t * n)(*[len(d) for d in datas])
+        first = L.JxlHipBatchAddImages(self._h, ptrs, sizes, n, int(threads))
+        if first < 0:
+            raise GenericError(last_error())
+        fmt = JxlPixelFormat(num_channels, _PIXEL_TYPES[np.dtype(dtype).name][0], endianness, align)
+        for k in range(n):
+            self._chk(L.JxlHipBatchSetOutput(self._h, first + k, C.byref(fmt), device_ptrs[k] if device_ptrs is not None else None))
+            self._fmt.append(fmt)
+        self._n += n
+        return first
+
+    def reset(self):
+        """Forgets the images, keeps the device arenas and buffer sharing (JxlHipBatchReset): fill and prepare again."""
+        libjxl().JxlHipBatchReset(self._h)
+        self._n = 0
+        self._fmt = []
 
     def info(self, i) -> JxlBasicInfo:
         info = JxlBasicInfo()

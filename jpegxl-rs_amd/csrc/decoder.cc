@@ -1,6 +1,9 @@
 // jxl-hip: batch decoder (see decoder.h).
 #include "decoder.h"
+#include <atomic>
+#include <exception>
 #include <mutex>
+#include <thread>
 #include <map>
 #include <queue>
 #include <hip/hip_runtime.h>
@@ -15,6 +18,33 @@ namespace jxlhip {
     hipError_t e_ = (expr);                                                                                \
     if (e_ != hipSuccess) throw ParseError(std::string("HIP error: ") + hipGetErrorString(e_) + " in " #expr, false); \
   } while (0)
+
+// Growable byte buffer in pinned host memory — what Prepare assembles the constant arena in and uploads from.  Pinned: the upload is a
+// DMA at link speed (57 GB/s) instead of a staged copy, and can overlap the GPU's work.  The capacity survives clear(): a batch object that is
+// refilled step after step (JxlHipBatchReset) allocates once.  Falls back to pageable memory when pinning fails (no GPU: host-only describe).
+HostStage::~HostStage() { Release(); }
+void HostStage::Release() {
+  if (!p_) return;
+  if (pinned_) (void)hipHostFree(p_); else std::free(p_);
+  p_ = nullptr; n_ = cap_ = 0;
+}
+void HostStage::Resize(size_t n) {
+  if (n > cap_) {
+    const size_t cap = std::max<size_t>(n + n / 2, 1 << 20);
+    uint8_t* q = nullptr;
+    bool pinned = hipHostMalloc((void**)&q, cap, hipHostMallocDefault) == hipSuccess && q;
+    if (!pinned) { (void)hipGetLastError(); q = (uint8_t*)std::malloc(cap); if (!q) throw std::bad_alloc(); }
+    const size_t keep = n_;
+    if (keep) memcpy(q, p_, keep);
+    Release();
+    p_ = q; cap_ = cap; pinned_ = pinned; n_ = keep;
+  }
+  if (n > n_) {   // zero what Put does not overwrite: alignment gaps (< 256 B) — the payload is copied over right after
+    const size_t gap_end = std::min(n, n_ + 512);
+    memset(p_ + n_, 0, gap_end - n_);
+  }
+  n_ = n;
+}
 
 namespace {
 size_t Align(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -65,11 +95,11 @@ struct ConstOffsets {
 };
 
 struct Arena {
-  vec<uint8_t>& buf;
-  explicit Arena(vec<uint8_t>& b) : buf(b) {}
+  HostStage& buf;
+  explicit Arena(HostStage& b) : buf(b) {}
   size_t Put(const void* src, size_t n, size_t align = 256) {
-    size_t off = Align(buf.size(), align);
-    buf.resize(off + std::max<size_t>(n, 4), 0);
+    const size_t off = Align(buf.size(), align), end = off + std::max<size_t>(n, 4);
+    buf.Resize(end);                                   // (the gap before `off` and a short tail are zeroed)
     if (n) memcpy(buf.data() + off, src, n);
     return off;
   }
@@ -222,17 +252,91 @@ Batch::~Batch() {
 // first one's buffers.  Must be called before Prepare(); `owner` must already be prepared and stay alive.
 void Batch::ShareBigArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareBigArena after Prepare", false);
+  if (big_owner_ == owner) return;
+  if (big_owner_) big_owner_->big_sharers_--;
+  if (dbig_ && !big_owner_) { (void)hipFree(dbig_); dbig_ = nullptr; big_cap_ = 0; }
   big_owner_ = owner;
+  if (owner) owner->big_sharers_++;
 }
 // Likewise for the quantised-coefficient planes (written by the HF stage, consumed — and zeroed again — by the IDCT of the same decode):
 // batches whose [HF ... IDCT] intervals never overlap may use one set.  A deep pipeline alternates between two owners so that the HF
 // stage of batch k + 1 can run beside the IDCT of batch k.
 void Batch::ShareCoefArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareCoefArena after Prepare", false);
+  if (coef_owner_ == owner) return;
+  if (dcoef_ && !coef_owner_) { (void)hipFree(dcoef_); dcoef_ = nullptr; coef_cap_ = 0; }
   coef_owner_ = owner;
 }
 
+// Makes *ptr a device allocation of at least `bytes` (kept if it already is; grown with 1/8 of slack otherwise).  Returns true if the
+// memory is new.
+bool Batch::DevReserve(void** ptr, size_t* cap, size_t bytes) {
+  if (*ptr && *cap >= bytes) return false;
+  if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *cap = 0; }
+  const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+  if (hipMalloc(ptr, want) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipMalloc(ptr, std::max<size_t>(bytes, 256))); *cap = std::max<size_t>(bytes, 256); }
+  else *cap = want;
+  return true;
+}
+
+// Forgets the images (and everything derived from them) but keeps the device arenas, the pinned staging buffer and the sharing set up with
+// ShareBigArena / ShareCoefArena: the batch object can be filled again.  The caller makes sure no decode of the old content is in flight.
+void Batch::Reset() {
+  images_.clear(); pub_.clear(); cbufs_.clear(); post_ops_.clear(); jpeg_data_.clear();
+  frames_host_.clear(); passes_host_.clear(); pass_first_.clear(); local_host_.clear(); local_first_.clear();
+  mod_plane_offsets_.clear(); mod_ops_.clear(); vardct_alpha_.clear(); hf_written_.clear();
+  any_complex_ = false;       // (stage timings recorded so far stay: CollectTimes sums over the object's life) prepared_ = false; ran_once_ = false; flags_pending_ = false; decodes_since_finish_ = 0;
+  cfg.idct_flags_known = 0;
+  lf_simt_ = LfSimtPlan();
+}
+
+// Parses `n` images on `threads` host threads (the per-image work of AddImage — container, image and frame headers, TOC, the global
+// sections' tables — is independent) and appends them in order.  Returns the index of the first one; throws what the first failing
+// image threw.
+int Batch::AddImages(const uint8_t* const* datas, const size_t* sizes, int n, int threads) {
+  if (n <= 0) return (int)pub_.size();
+  vec<ParsedImage> parsed((size_t)n);
+  vec<std::exception_ptr> errors((size_t)n);
+  const int nt = std::max(1, std::min(threads, n));
+  std::atomic<int> next{0};
+  const MmHooks* hooks = MmCurrent();
+  auto work = [&]() {
+    MmScope scope(hooks);                  // (worker threads allocate through the caller's memory manager, too)
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      try { ParseImage(datas[i], sizes[i], &parsed[i]); } catch (...) { errors[i] = std::current_exception(); }
+    }
+  };
+  if (nt == 1) work();
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) pool.emplace_back(work);
+    for (auto& t : pool) t.join();
+  }
+  const int first = (int)pub_.size();
+  for (int i = 0; i < n; i++) {
+    if (errors[i]) std::rethrow_exception(errors[i]);
+    Append(std::move(parsed[i]));
+  }
+  return first;
+}
+
 int Batch::AddImage(const uint8_t* data, size_t size) {
+  ParsedImage pi;
+  ParseImage(data, size, &pi);
+  return Append(std::move(pi));
+}
+
+int Batch::Append(ParsedImage&& im) {
+  PubImage pi; pi.first_unit = (int)images_.size(); pi.num_units = (int)im.units.size(); pi.complex = im.complex;
+  for (auto& u : im.units) { u->pub_index = (int)pub_.size(); images_.push_back(std::move(u)); }
+  pub_.push_back(pi);
+  prepared_ = false;
+  return (int)pub_.size() - 1;
+}
+
+void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
   std::shared_ptr<ImageShared> sh(new ImageShared());
   bool have_container = false, has_jbrd = false;
   if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, &sh->boxes)) throw ParseError("truncated", false);
@@ -254,7 +358,7 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
     e->has_jbrd = has_jbrd;
     e->frame_bitpos = bitpos;
     e->frame_index = k;
-    e->pub_index = (int)pub_.size();
+    e->pub_index = 0;                     // (set when the image is appended)
     ParseFrameStart(sh->cs, ih, bitpos, &e->plan);
     const FramePlan& p = e->plan;
     if (p.frame_type == 0 || p.frame_type == 3) { visible++; nonvisible = 0; } else nonvisible++;
@@ -298,11 +402,8 @@ int Batch::AddImage(const uint8_t* data, size_t size) {
   for (auto& x : ih.extra) if (x.depth.is_float) complex = true;   // float extra channels are converted in the frame tail (IntToFloatSample)
   if (complex && ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels in a multi-frame / feature image", true);
   for (auto& u : units) u->complex = complex;
-  PubImage pi; pi.first_unit = (int)images_.size(); pi.num_units = (int)units.size(); pi.complex = complex;
-  for (auto& u : units) images_.push_back(std::move(u));
-  pub_.push_back(pi);
-  prepared_ = false;
-  return (int)pub_.size() - 1;
+  out->units = std::move(units);
+  out->complex = complex;
 }
 
 size_t Batch::OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t* channels) {
@@ -396,15 +497,13 @@ void Batch::Prepare(void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   HIP_CHECK(hipSetDevice(device_));
   InitDeviceTables(stream_v);
-  if (dconst_) { (void)hipFree(dconst_); dconst_ = nullptr; }
-  if (dwork_) { (void)hipFree(dwork_); dwork_ = nullptr; }
+  // Device allocations are kept from one Prepare to the next and only replaced when they are too small (DevReserve): a batch object
+  // that is refilled step after step (JxlHipBatchReset + AddImages + Prepare, the streaming loop of bench.py) allocates once —
+  // hipFree synchronises the device, hipMalloc of gigabytes takes milliseconds.
   if (clear_stream_) (void)hipStreamSynchronize((hipStream_t)clear_stream_);   // a pending clear of the old coefficient planes
   clear_pending_ = false;
-  if (dcoef_ && !coef_owner_) (void)hipFree(dcoef_);
-  dcoef_ = nullptr;
-  if (dbig_ && !big_owner_) (void)hipFree(dbig_);
-  dbig_ = nullptr;
-  if (dframes_) { (void)hipFree(dframes_); dframes_ = nullptr; }
+  if (coef_owner_) dcoef_ = nullptr;
+  if (big_owner_) dbig_ = nullptr;
   const int n = (int)images_.size();
   // un-premultiplying alpha (JxlDecoderSetUnpremultiplyAlpha, jpegxl-rs decode.rs:353) happens in the write stage of the frame tail
   for (PubImage& pi : pub_) {
@@ -613,25 +712,26 @@ void Batch::Prepare(void* stream_v) {
     }
   }
   work_size_ = Align(w);
-  HIP_CHECK(hipMalloc((void**)&dwork_, work_size_));
+  DevReserve((void**)&dwork_, &work_cap_, work_size_);
   HIP_CHECK(hipMemsetAsync(dwork_, 0, work_size_, stream));
   big_size_ = Align(wbig);
   has_plane_b_ = need_plane_b;
   if (big_owner_) {
-    if (!big_owner_->dbig_ || big_owner_->big_size_ < big_size_) throw ParseError("ShareBigArena: the owner's buffers are missing or smaller than this batch needs", false);
+    if (!big_owner_->dbig_ || big_owner_->big_cap_ < big_size_) throw ParseError("ShareBigArena: the owner's buffers are missing or smaller than this batch needs", false);
     dbig_ = big_owner_->dbig_;
-  } else {
-    HIP_CHECK(hipMalloc((void**)&dbig_, std::max<size_t>(big_size_, 256)));
-    HIP_CHECK(hipMemsetAsync(dbig_, 0, std::max<size_t>(big_size_, 256), stream));
+  } else if (DevReserve((void**)&dbig_, &big_cap_, std::max<size_t>(big_size_, 256)) || big_sharers_ == 0) {
+    // (planes other batches share are not cleared again when this object is refilled: their decodes may be using them — every sharer,
+    // like a refilled owner, then starts from what the decode before left, which plain frames overwrite completely)
+    HIP_CHECK(hipMemsetAsync(dbig_, 0, big_cap_, stream));
   }
   if (coef_owner_) {
-    if (!coef_owner_->dcoef_ || coef_owner_->coeff_bytes_ < coeff_bytes_) throw ParseError("ShareCoefArena: the owner's planes are missing or smaller than this batch needs", false);
+    if (!coef_owner_->dcoef_ || coef_owner_->coef_cap_ < coeff_bytes_) throw ParseError("ShareCoefArena: the owner's planes are missing or smaller than this batch needs", false);
     dcoef_ = coef_owner_->dcoef_;                      // (whether they are clean is the owner's knowledge: CoefDirty())
-  } else {
-    HIP_CHECK(hipMalloc((void**)&dcoef_, std::max<size_t>(coeff_bytes_, 256)));
-    coef_dirty_ = true;                                // first decode clears the planes in its own stream
+  } else if (DevReserve((void**)&dcoef_, &coef_cap_, std::max<size_t>(coeff_bytes_, 256)) || coeff_bytes_ != coef_laid_out_) {
+    coef_dirty_ = true;                                // new planes, or another layout of them: the first decode clears them in its own stream
   }
-  HIP_CHECK(hipMalloc((void**)&dframes_, sizeof(FrameDev) * std::max(n, 1)));
+  coef_laid_out_ = coeff_bytes_;
+  DevReserve((void**)&dframes_, &frames_cap_, sizeof(FrameDev) * std::max(n, 1));
 
   // ---- single-section VarDCT frames: HfGlobal starts where the device-decoded LfGroup ends.  Pre-run the LF stage
   // for those frames now, read the end position back and parse HfGlobal on the host.
@@ -854,8 +954,7 @@ void Batch::Prepare(void* stream_v) {
     size_t total = 0;
     for (int i = 0; i < n; i++) { pass_first_[i] = total; total += images_[i]->plan.modular ? 0 : images_[i]->plan.num_passes; }
     passes_host_.assign(std::max<size_t>(total, 1), PassDev());
-    if (dpasses_) { (void)hipFree(dpasses_); dpasses_ = nullptr; }
-    HIP_CHECK(hipMalloc((void**)&dpasses_, sizeof(PassDev) * passes_host_.size()));
+    DevReserve((void**)&dpasses_, &passes_cap_, sizeof(PassDev) * passes_host_.size());
   }
   {  // descriptors of the sub-streams with their own tree / code: one table per frame that has any
     local_first_.assign(n, 0);
@@ -867,8 +966,7 @@ void Batch::Prepare(void* stream_v) {
     }
     local_host_.assign(std::max<size_t>(total, 1), ModLocalDev());
     for (auto& d : local_host_) memset(&d, 0, sizeof(d));
-    if (dlocal_) { (void)hipFree(dlocal_); dlocal_ = nullptr; }
-    HIP_CHECK(hipMalloc((void**)&dlocal_, sizeof(ModLocalDev) * local_host_.size()));
+    DevReserve((void**)&dlocal_, &local_cap_, sizeof(ModLocalDev) * local_host_.size());
   }
   if (any_complex_) {
     vec<size_t> upw(n, 0);
@@ -968,7 +1066,7 @@ void Batch::Prepare(void* stream_v) {
     }
   }
   const_size_ = Align(hconst_.size());
-  HIP_CHECK(hipMalloc((void**)&dconst_, const_size_));
+  DevReserve((void**)&dconst_, &const_cap_, const_size_);
   HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
   for (int i = 0; i < n; i++) { fill_frame(i, dconst_); frames_host_[i].lf_simt = lf_simt_.num_lanes ? simt_frame[i] : 0; }
   lf_simt_.units = (const uint2*)(dconst_ + place_units_off);
@@ -1118,7 +1216,7 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
 // that turn each frame's planes into the image: dec_cache.cc PreparePipeline's stage order (patches, splines, upsampling,
 // noise | save as reference before the colour transform | XYB / YCbCr -> output colour space | blending onto the canvas |
 // save as reference | write).  Reference slots are tracked here (frame_header.cc save_as_reference / CanBeReferenced).
-void Batch::PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off) {
+void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
   Arena arena(hconst);
   struct Slot { bool valid = false, before_ct = false; size_t p[3] = {0, 0, 0}; uint32_t stride = 0; size_t ec[4] = {0, 0, 0, 0}; uint32_t ec_stride = 0; uint32_t w = 0, h = 0; };
   auto B = [this](size_t off) { return (float*)(dbig_ + off); };

@@ -47,6 +47,24 @@ struct ImageEntry {
   explicit ImageEntry(std::shared_ptr<ImageShared> s) : shared(std::move(s)), cs(shared->cs), ih(shared->ih) {}
 };
 
+// growable byte buffer in pinned host memory: the constant arena is assembled in it and uploaded from it (decoder.cc)
+class HostStage {
+ public:
+  HostStage() = default;
+  HostStage(const HostStage&) = delete;
+  HostStage& operator=(const HostStage&) = delete;
+  ~HostStage();
+  size_t size() const { return n_; }
+  uint8_t* data() { return p_; }
+  const uint8_t* data() const { return p_; }
+  void clear() { n_ = 0; }
+  void Resize(size_t n);
+  bool pinned() const { return pinned_; }
+ private:
+  void Release();
+  uint8_t* p_ = nullptr; size_t n_ = 0, cap_ = 0; bool pinned_ = false;
+};
+
 struct StageTimes { float lf_ms = 0, lfpost_ms = 0, hf_ms = 0, idct_ms = 0, filter_ms = 0, out_ms = 0, total_ms = 0; };
 
 class Batch {
@@ -55,6 +73,10 @@ class Batch {
   ~Batch();
   // Parses headers (container, image header, frame header, TOC, global sections).  Throws ParseError.
   int AddImage(const uint8_t* data, size_t size);
+  // The same for n images, parsed on `threads` host threads and appended in order; returns the index of the first.
+  int AddImages(const uint8_t* const* datas, const size_t* sizes, int n, int threads);
+  // Forgets the images, keeps device arenas / staging buffer / buffer sharing: the object can be filled and prepared again.
+  void Reset();
   size_t size() const { return pub_.size(); }
   ImageEntry& image(int i) { return *images_[pub_[i].first_unit]; }
   int num_units() const { return (int)images_.size(); }          // frames of all images, in decode order
@@ -113,14 +135,19 @@ class Batch {
   vec<std::function<void(void*)>> post_ops_;
   vec<std::unique_ptr<JpegData>> jpeg_data_;   // per image, parsed lazily by CanReconstructJpeg
   bool any_complex_ = false;
-  void PlanPostOps(vec<uint8_t>& hconst, const vec<size_t>& up_weights_off);
+  void PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off);
   void EnqueuePostOps(void* stream);
   vec<FrameDev> frames_host_;
-  vec<uint8_t> hconst_;
+  HostStage hconst_;
+  struct ParsedImage { vec<std::unique_ptr<ImageEntry>> units; bool complex = false; };
+  static void ParseImage(const uint8_t* data, size_t size, ParsedImage* out);
+  int Append(ParsedImage&& im);
+  static bool DevReserve(void** ptr, size_t* cap, size_t bytes);
+  size_t const_cap_ = 0, work_cap_ = 0, big_cap_ = 0, coef_cap_ = 0, coef_laid_out_ = 0, frames_cap_ = 0, passes_cap_ = 0, local_cap_ = 0;
   uint8_t* dconst_ = nullptr; size_t const_size_ = 0;
   uint8_t* dwork_ = nullptr; size_t work_size_ = 0;
   uint8_t* dbig_ = nullptr; size_t big_size_ = 0;   // coefficient + pixel planes (rest half only); may alias big_owner_'s
-  Batch* big_owner_ = nullptr;
+  Batch* big_owner_ = nullptr; int big_sharers_ = 0;
   // The coefficient planes must be zero when the HF stage starts.  A 7 ms memset per 256 4K frames with nothing else
   // running is avoided like this: every batch has coefficient planes of its own (288 GB of HBM: three batches in flight
   // hold 82 GB of them), and a decode that is done with them clears them again on an internal stream — which the GPU

@@ -357,6 +357,10 @@ void JxlHipBatchDestroy(JxlHipBatch* h) { if (h) { delete h->b; delete h; } }
 int JxlHipBatchAddImage(JxlHipBatch* h, const uint8_t* data, size_t size) {
   try { return h->b->AddImage(data, size); } catch (const std::exception& e) { SetLastError(e.what()); return -1; }
 }
+int JxlHipBatchAddImages(JxlHipBatch* h, const uint8_t* const* datas, const size_t* sizes, int n, int num_threads) {
+  try { return h->b->AddImages(datas, sizes, n, num_threads); } catch (const std::exception& e) { SetLastError(e.what()); return -1; }
+}
+void JxlHipBatchReset(JxlHipBatch* h) { h->b->Reset(); }
 JxlDecoderStatus JxlHipBatchGetBasicInfo(const JxlHipBatch* h, int i, JxlBasicInfo* info) {
   if (i < 0 || (size_t)i >= h->b->size()) return JXL_DEC_ERROR;
   FillBasicInfo(h->b->image(i).ih, info, h->keep_orientation);

@@ -602,6 +602,37 @@ def test_batch_api_mixed_sizes_and_lane_strides(jx):
         assert b.total_pixels == sum(len(r) // 3 for r in refs)
 
 
+def test_batch_objects_are_refilled_without_reallocating(jx):
+    """The streaming loop of bench.py: JxlHipBatchReset + JxlHipBatchAddImages (parser threads) + JxlHipBatchPrepare on one batch object,
+    again and again with other images (other sizes, other counts), a second object sharing its pixel and coefficient planes; SIMT LF decode
+    and the one-wavefront-per-stream kernel ("lf_wide_once") alike.  Every refill decodes bit-exactly."""
+    sets = []
+    for r, shapes in enumerate([[(320, 200, 2), (600, 520, 1), (64, 64, 0)], [(600, 520, 2), (200, 136, 1)], [(1030, 270, 2), (320, 200, 0), (600, 520, 0), (24, 17, 1)]]):
+        streams = [S.encode_vardct(S.synthetic_image(70 + 10 * r + i, w, h), seed=70 + 10 * r + i, strategy_mix=mix, epf_iters=(i + r) % 3, gab=(i + r) % 2) for i, (w, h, mix) in enumerate(shapes)]
+        sets.append((streams, [O.decode(s).pixels("u8", 3) for s in streams]))
+    big = max(sets, key=lambda t: sum(len(r) for r in t[1]))
+    owner = jx.BatchDecoder(0); owner.set_lane_stride(4, 1)
+    owner.add_many(big[0], "uint8", 3, threads=3); owner.prepare()
+    sharer = jx.BatchDecoder(0); sharer.set_lane_stride(4, 1)
+    sharer.share_buffers(owner); sharer.share_coefficients(owner)
+    for rnd in range(5):
+        for bi, b in enumerate((owner, sharer)):
+            streams, refs = sets[(rnd + bi) % len(sets)]
+            if b is sharer and sum(len(r) for r in refs) > sum(len(r) for r in big[1]):
+                continue
+            b.reset()
+            assert b.add_many(streams, "uint8", 3, threads=1 + rnd % 3) == 0
+            b.prepare()
+            assert b.info_value("lf_simt_frames") == len(streams)
+            if rnd % 2:
+                b.set_option("lf_wide_once", 1)
+            b.decode(); b.finish()
+            for i, r in enumerate(refs):
+                assert np.array_equal(b.output(i), r), (rnd, bi, i)
+    with pytest.raises(jx.GenericError):                        # a bad image among many: nothing is appended
+        owner.reset(); owner.add_many([sets[0][0][0], b"\xff\x0a" + bytes(40)], "uint8", 3, threads=2)
+
+
 # ---- multi-frame images and image features (round 2): frame tail kernels vs the oracle -----------------------------------------------
 def _stream_cases():
     img = S.synthetic_image(5, 200, 136)
