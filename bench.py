@@ -37,18 +37,33 @@ def _pmc_bytes(kernels, frames):
         return None
 
 
+def _textured(img, amp, seed):
+    """Photograph-like detail on top of the smooth synthetic picture: fine grain plus 4x4-pixel texture, `amp` sRGB levels strong, correlated
+    between the channels.  amp 5 takes a 4K frame from 0.8 to about 2 bits per pixel at distance 1 — what real `cjxl -d 1` photographs run."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    h, w, _ = img.shape
+    n = rng.standard_normal((h, w)).astype(np.float32)
+    n = (n + np.roll(n, 1, 0) + np.roll(n, 1, 1) + np.roll(n, (1, 1), (0, 1))) / 2
+    m = np.kron(rng.standard_normal((h // 4 + 1, w // 4 + 1)).astype(np.float32), np.ones((4, 4), np.float32))[:h, :w]
+    t = (0.7 * n + 0.7 * m) * amp
+    return np.clip(img.astype(np.float32) + t[:, :, None] * np.array([1.0, 0.9, 0.8], np.float32), 0, 255).astype(np.uint8)
+
+
 def _make_stream(args):
     import synth_lib as S
-    seed, width, height, epf = args
+    seed, width, height, epf, texture = args
     img = S.synthetic_image(seed, width, height)
+    if texture:
+        img = _textured(img, texture, seed)
     return S.encode_vardct(img, seed=seed, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1)
 
 
-def make_streams(distinct, width, height, epf, seed0=1000):
+def make_streams(distinct, width, height, epf, seed0=1000, texture=0.0):
     """Seeded synthetic frames encoded by tools/jxlsynth, one per seed (different content, different
     varblock maps and token counts).  Generated on the host cores in parallel (4.6 s per 4K frame).  Returns list of bytes."""
     import multiprocessing as mp
-    jobs = [(seed0 + i, width, height, epf) for i in range(distinct)]
+    jobs = [(seed0 + i, width, height, epf, texture) for i in range(distinct)]
     workers = max(1, min(len(jobs), os.cpu_count() or 1, 64))
     if workers == 1:
         return [_make_stream(j) for j in jobs]
@@ -398,6 +413,9 @@ def main():
     ap.add_argument("--out-buffers", type=int, default=2, help="output buffer sets the batches in flight cycle through")
     ap.add_argument("--prepare-threads", type=int, default=int(os.environ.get("JXL_BENCH_PREPARE_THREADS", "3")), help="streaming: host threads that each parse + prepare + upload one batch at a time")
     ap.add_argument("--parse-threads", type=int, default=int(os.environ.get("JXL_BENCH_PARSE_THREADS", "8")), help="host threads JxlHipBatchAddImages parses the frames of one batch on")
+    ap.add_argument("--texture", type=float, default=5.0, help="strength (sRGB levels) of the texture of the realistic-bit-rate workload (0: skip it)")
+    ap.add_argument("--realistic-distinct", type=int, default=64, help="distinct frames of the realistic-bit-rate workload")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the second workload (textured frames, ~2 bpp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -407,6 +425,8 @@ def main():
     W, H = args.width, args.height
 
     streams = make_streams(args.distinct, W, H, args.epf, seed0=1000 + 1000 * rank)
+    # the same frames with photograph-like texture: ~2 bpp at distance 1 instead of 0.8 (second workload of the line, fewer distinct frames)
+    realistic_streams = make_streams(min(args.distinct, args.realistic_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture) if args.texture > 0 and not args.no_realistic else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(streams, W, H)   # before any GPU runtime is initialised in this process (fork safety)
@@ -440,7 +460,7 @@ def main():
         B = min(args.batch, per_rank)
         inner = max(1, per_rank // B)
 
-    def measure(streaming):
+    def measure(streaming, streams=streams):
         """one mode: W untimed warm-up steps, then exactly K timed steps from an empty pipeline, bracketed by barrier + synchronize"""
         p = Pipeline(args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming)
         p.run(args.warmup * inner, False)
@@ -462,7 +482,8 @@ def main():
                 times[kk] = times.get(kk, 0.0) + vv
         r = {"elapsed": elapsed, "t_decode": t_decode, "step_end": step_end, "stage_ms": {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"},
              "stage_bytes": p.batches[0].stage_bytes, "device_bytes": sum(bt.device_bytes for bt in p.batches), "compressed": int(p.batches[0].compressed_bytes // B),
-             "nbuf": p.nbuf, "prepare_s": list(p.prepare_s), "gather": bool(p.do_gather), "pipelined": bool(p.pipeline)}
+             "nbuf": p.nbuf, "prepare_s": list(p.prepare_s), "gather": bool(p.do_gather), "pipelined": bool(p.pipeline),
+             "nonzeros": p.batches[0].info_value("hf_nonzeros") // B}
         if not args.no_verify and rank == 0:
             import oracle_lib as O
             r["verified"], r["verified_frames"] = p.verify(args.steps * inner, O, np)
@@ -474,6 +495,9 @@ def main():
     modes = ["streaming", "resident"] if args.mode == "both" else [args.mode]
     res = {m: measure(m == "streaming") for m in modes}
     head = res[modes[0]]
+    realistic = None
+    if args.texture > 0 and not args.no_realistic and realistic_streams:
+        realistic = measure(modes[0] == "streaming", realistic_streams)
     if rank == 0:
         total_px = world * B * inner * W * H * args.steps
         rate = lambda r: total_px / r["elapsed"] / 1e6
@@ -531,6 +555,17 @@ def main():
             result["resident_mpixel_per_s"] = round(rate(rr), 2)
             result["resident"] = {"ms_per_step": round(rr["elapsed"] / args.steps * 1e3, 3), "stage_ms": {k: round(v, 4) for k, v in rr["stage_ms"].items()}, "step_end_ms": rr["step_end"],
                                   "verified_vs_oracle": rr.get("verified"), "streaming_over_resident": round(rate(head) / rate(rr), 4)}
+        result["config"]["nonzero_coefficients_per_frame"] = head["nonzeros"]
+        result["config"]["bits_per_pixel"] = round(head["compressed"] * 8 / (W * H), 3)
+        if realistic is not None:
+            re_ = realistic["step_end"]; n_r = len(re_)
+            result["config"]["workload_realistic"] = {
+                "what": f"the same pipeline and mode on frames with photograph-like texture (bench.py _textured, {args.texture:g} sRGB levels): the bit rate of real cjxl -d 1 photographs",
+                "value": round(rate(realistic), 2), "unit": "Mpixel/s", "ms_per_step": round(realistic["elapsed"] / args.steps * 1e3, 3),
+                "steady_state_ms_per_step": round((re_[n_r * 2 // 3] - re_[n_r // 5]) / max(1, n_r * 2 // 3 - n_r // 5), 2) if n_r >= 10 else None,
+                "stage_ms": {k: round(v, 4) for k, v in realistic["stage_ms"].items()}, "compressed_bytes_per_frame": realistic["compressed"],
+                "bits_per_pixel": round(realistic["compressed"] * 8 / (W * H), 3), "nonzero_coefficients_per_frame": realistic["nonzeros"],
+                "distinct_frames": len(realistic_streams), "verified_vs_oracle": realistic.get("verified")}
         if world > 1:
             result["decode_only_mpixel_per_s"] = round(total_px / head["t_decode"] / 1e6, 2)     # until every rank's own decode work was done
             result["gather_ms"] = round((head["elapsed"] - head["t_decode"]) * 1e3, 2)             # what the pixel gather added after that

@@ -170,7 +170,7 @@ JxlDecoderStatus JxlHipBatchOutBufferSize(const JxlHipBatch* batch, int index, c
 JxlDecoderStatus JxlHipBatchSetOutput(JxlHipBatch* batch, int index, const JxlPixelFormat* format, void* device_buffer);
 /* Decode-thread packing: lanes between active entropy-decode threads (64 = one stream per wavefront, 1 = 64 per wavefront). */
 void JxlHipBatchSetLaneStride(JxlHipBatch* batch, int lf, int hf);
-/* Tuning / testing knobs: "force_generic_idct", "hf_block_threads", "lds_code_budget", "lf_wide_once" (the next LF stage of the batch takes the
+/* Tuning / testing knobs: "force_generic_idct", "hf_block_threads", "lds_code_budget", "debug_stop_after", "lf_wide_once" (the next LF stage of the batch takes the
  * one-wavefront-per-stream kernel whatever the lane stride: shorter latency on an idle GPU). Unknown names are ignored. */
 void JxlHipBatchSetOption(JxlHipBatch* batch, const char* name, int value);
 /* Uploads streams and tables (inputs become HBM-resident) and allocates work buffers.  hip_stream: hipStream_t or NULL. */
@@ -199,8 +199,15 @@ uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* batch);
 void JxlHipBatchStageBytes(const JxlHipBatch* batch, uint64_t out[6]);
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* batch);
 /* Facts about a prepared batch, by name (-1: unknown name): "lf_simt_frames" / "lf_legacy_frames" = VarDCT frames whose LF-group streams
- * take the SIMT kernel (one stream per lane, lane stride < 64) / the one-wavefront-per-stream kernel, "lf_simt_lanes", "lf_simt_waves". */
+ * take the SIMT kernel (one stream per lane, lane stride < 64) / the one-wavefront-per-stream kernel, "lf_simt_lanes", "lf_simt_waves", "hf_nonzeros" = non-zero AC coefficients of one decode of the batch (after a Finish). */
 int64_t JxlHipBatchGetInfo(const JxlHipBatch* batch, const char* name);
+/* Testing: after a decode, copies a device buffer of image `index`'s first (VarDCT) frame to the host — "plane_a" / "plane_b" (the padded
+ * float XYB planes the stages ping-pong between, 8 bw x 8 bh samples per channel), "lf" / "llf" / "lfq", "inv_sigma", "blk_info", "coef_off" (one
+ * value per 8x8 block), "coeff" (dense quantised coefficients, 65536 per group), "ytox" / "ytob".  With JxlHipBatchSetOption("debug_stop_after", s)
+ * the tail of the decode stops after stage s (1 IDCT, 2 gaborish, 3 / 4 / 5 EPF pass 0 / 1 / 2; stage-by-stage filters: "force_unfused_filters"),
+ * which is how tests/test_stage_formulas.py compares single stages with float64 restatements of their defining formulas.
+ * Returns the size of the buffer in bytes (0 on error), copies min(size, cap). */
+size_t JxlHipBatchDebugRead(JxlHipBatch* batch, int index, const char* name, int channel, void* dst, size_t cap, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,7 @@ def libjxl():
             "JxlHipBatchTotalPixels": (C.c_uint64, [vp]), "JxlHipBatchCompressedBytes": (C.c_uint64, [vp]),
             "JxlHipBatchStageBytes": (None, [vp, C.POINTER(C.c_uint64 * 6)]), "JxlHipBatchDeviceBytes": (C.c_uint64, [vp]),
             "JxlHipBatchGetInfo": (C.c_int64, [vp, C.c_char_p]), "JxlHipBatchReset": (None, [vp]),
+            "JxlHipBatchDebugRead": (sz, [vp, C.c_int, C.c_char_p, C.c_int, vp, sz, vp]),
             "JxlHipBatchAddImages": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_int, C.c_int]),
             "JxlHipBatchShareBuffers": (C.c_int, [vp, vp]), "JxlHipBatchShareCoefficients": (C.c_int, [vp, vp]),
         }
@@ -575,6 +576,16 @@ class BatchDecoder:
         out = np.empty(n, dtype=np.uint8)
         self._chk(libjxl().JxlHipBatchCopyOutput(self._h, i, out.ctypes.data, n, stream))
         return JxlDecoder._convert(out, self._fmt[i])
+
+    def debug_read(self, i: int, name: str, channel: int = 0, dtype=np.float32) -> np.ndarray:
+        """Testing: a device buffer of image i's first frame after a decode (include/jxl_hip.h JxlHipBatchDebugRead), as a flat array."""
+        L = libjxl()
+        n = L.JxlHipBatchDebugRead(self._h, i, name.encode(), channel, None, 0, None)
+        if n == 0:
+            raise GenericError(last_error())
+        out = np.empty(n // np.dtype(dtype).itemsize, dtype=dtype)
+        L.JxlHipBatchDebugRead(self._h, i, name.encode(), channel, out.ctypes.data, n, None)
+        return out
 
     def info_value(self, name: str) -> int:
         """Facts about the prepared batch by name (include/jxl_hip.h JxlHipBatchGetInfo), e.g. "lf_simt_frames"."""

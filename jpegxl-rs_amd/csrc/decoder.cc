@@ -477,13 +477,50 @@ void Batch::StageBytes(uint64_t out[6]) const {
   }
 }
 
+// Testing: copies one of the device buffers of image i's first frame to the host (after a decode, JxlHipBatchDebugRead): the planes
+// between the stages ("debug_stop_after") and the inputs of the pixel stages.  Returns the bytes the buffer holds; copies min(that, cap).
+size_t Batch::DebugRead(int i, const std::string& name, int c, void* dst, size_t cap, void* stream_v) {
+  if (!prepared_ || i < 0 || (size_t)i >= pub_.size() || c < 0 || c > 2) throw ParseError("DebugRead: no such image / channel", false);
+  const int u = pub_[i].first_unit;
+  const FrameDev& f = frames_host_[u];
+  const FramePlan& p = images_[u]->plan;
+  if (p.modular) throw ParseError("DebugRead: not a VarDCT frame", false);
+  const size_t nb = (size_t)p.bw * p.bh, npx = nb * 64;
+  const void* src = nullptr; size_t bytes = 0;
+  if (name == "plane_a") { src = f.plane_a[c]; bytes = npx * 4; }
+  else if (name == "plane_b") { src = f.plane_b[c]; bytes = npx * 4; }
+  else if (name == "lf") { src = f.lf[c]; bytes = nb * 4; }
+  else if (name == "llf") { src = f.llf[c]; bytes = nb * 4; }
+  else if (name == "lfq") { src = f.lfq[c]; bytes = nb * 4; }
+  else if (name == "inv_sigma") { src = f.inv_sigma; bytes = nb * 4; }
+  else if (name == "blk_info") { src = f.blk_info; bytes = nb * 4; }
+  else if (name == "coef_off") { src = f.coef_off; bytes = nb * 4; }
+  else if (name == "coeff") { src = f.coeff[c]; bytes = (size_t)p.num_groups * 65536 * 4; }
+  else if (name == "ytox") { src = f.ytox; bytes = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8); }
+  else if (name == "ytob") { src = f.ytob; bytes = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8); }
+  else throw ParseError("DebugRead: unknown buffer " + name, false);
+  if (!src) throw ParseError("DebugRead: buffer " + name + " is not allocated for this batch", false);
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_v));
+  if (dst && cap) HIP_CHECK(hipMemcpy(dst, src, std::min(bytes, cap), hipMemcpyDeviceToHost));
+  return bytes;
+}
+
 int64_t Batch::Info(const std::string& name) const {
   if (name == "lf_simt_frames" || name == "lf_legacy_frames") {
     int64_t simt = 0, legacy = 0;
     for (size_t i = 0; i < frames_host_.size() && i < images_.size(); i++) if (!images_[i]->plan.modular) (frames_host_[i].lf_simt ? simt : legacy)++;
     return name == "lf_simt_frames" ? simt : legacy;
   }
+  if (name == "hf_nonzeros") { int64_t t = 0; for (uint32_t v : hf_written_) t += v; return t; }   // non-zero AC coefficients per decode of the batch (known after a Finish)
   if (name == "lf_simt_lanes") return lf_simt_.num_lanes;
+  if (!images_.empty() && !images_[0]->plan.modular) {   // geometry / quantiser of the first frame (tests that restate a stage from its defining formula)
+    const FramePlan& p = images_[0]->plan;
+    if (name == "frame0_bw") return p.bw;
+    if (name == "frame0_bh") return p.bh;
+    if (name == "frame0_global_scale") return p.global_scale;
+    if (name == "frame0_quant_lf") return p.quant_lf;
+    if (name == "frame0_color_factor") return p.color_factor;
+  }
   if (name == "lf_simt_waves") return lf_simt_.num_lanes ? (lf_simt_.num_lanes + lf_simt_.lanes_per_wave - 1) / lf_simt_.lanes_per_wave : 0;
   return -1;
 }
@@ -1595,11 +1632,11 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
     DebugSync("IDCT", stream_v);
     rec(4);
-    LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
+    if (cfg.debug_stop_after != 1) LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
     DebugSync("filters", stream_v);
     rec(5);
-    LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
-    if (any_complex_) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
+    if (!cfg.debug_stop_after) LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
+    if (any_complex_ && !cfg.debug_stop_after) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
     DebugSync("output / frame tail", stream_v);
     rec(6);
     ClearCoefficientsAfterDecode(stream_v);   // (the IDCT kernels zeroed what they read)

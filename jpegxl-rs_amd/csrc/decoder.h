@@ -113,6 +113,7 @@ class Batch {
   void ShareBigArena(Batch* owner);
   void ShareCoefArena(Batch* owner);
   int64_t Info(const std::string& name) const;
+  size_t DebugRead(int i, const std::string& name, int c, void* dst, size_t cap, void* stream);
   uint64_t total_pixels() const;
   uint64_t compressed_bytes() const;
 

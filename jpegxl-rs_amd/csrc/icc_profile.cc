@@ -213,7 +213,26 @@ vec<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
       case 8: Para(trc, 0, {1.0}); break;
       case 1: Para(trc, 3, {1.0 / 0.45, 1.0 / 1.099, 0.099 / 1.099, 1.0 / 4.5, 0.081}); break;
       case 17: Para(trc, 0, {2.6}); break;
-      case 16: case 18: throw ParseError("unsupported: ICC profile for PQ / HLG transfer functions", true);
+      case 16: case 18: {
+        // HDR transfer functions have no parametric ICC form: a sampled curve (encoded value -> display / scene light, both normalised to
+        // [0, 1]) carries what a v4 CMM can use, the `cicp` tag below what an HDR-aware one wants (ITU-T H.273 code points)
+        const int n = 4096;
+        PutTag(trc, "curv"); Put32(trc, 0); Put32(trc, (uint32_t)n);
+        for (int i = 0; i < n; i++) {
+          const double e = (double)i / (n - 1);
+          double l;
+          if (ih.tf == 16) {          // SMPTE ST 2084 EOTF, 1.0 = 10000 cd/m2
+            const double m1 = 2610.0 / 16384, m2 = 2523.0 / 4096 * 128, c1 = 3424.0 / 4096, c2 = 2413.0 / 4096 * 32, c3 = 2392.0 / 4096 * 32;
+            const double p = std::pow(e, 1.0 / m2);
+            l = std::pow(std::max(p - c1, 0.0) / (c2 - c3 * p), 1.0 / m1);
+          } else {                    // ARIB STD-B67 inverse OETF (scene light, 1.0 at signal 1.0)
+            const double a = 0.17883277, b = 1 - 4 * a, c = 0.5 - a * std::log(4 * a);
+            l = e <= 0.5 ? e * e / 3.0 : (std::exp((e - c) / a) + b) / 12.0;
+          }
+          Put16(trc, (uint32_t)std::lround(std::min(1.0, std::max(0.0, l)) * 65535.0));
+        }
+        break;
+      }
       default: throw ParseError("colour encoding: transfer function enum", false);
     }
   }
@@ -233,6 +252,15 @@ vec<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
     tags.push_back(Tag{"bTRC", {}, first});
   } else {
     tags.push_back(Tag{"kTRC", trc, -1});
+  }
+  if (!ih.have_gamma && (ih.tf == 16 || ih.tf == 18) && !grey) {
+    // cicp (ICC v4.4): colour primaries, transfer characteristics, matrix coefficients (0: RGB), full range — where H.273 names the primaries
+    int prim = -1;
+    if (ih.primaries == 1 && ih.white_point == 1) prim = 1;            // BT.709 / sRGB
+    else if (ih.primaries == 9 && ih.white_point == 1) prim = 9;       // BT.2020 / BT.2100
+    else if (ih.primaries == 11 && ih.white_point == 11) prim = 11;    // SMPTE RP 431-2 (DCI white)
+    else if (ih.primaries == 11 && ih.white_point == 1) prim = 12;     // SMPTE EG 432-1 (P3 D65)
+    if (prim >= 0) { Tag t{"cicp", {}, -1}; PutTag(t.data, "cicp"); Put32(t.data, 0); t.data.push_back((uint8_t)prim); t.data.push_back((uint8_t)ih.tf); t.data.push_back(0); t.data.push_back(1); tags.push_back(std::move(t)); }
   }
 
   vec<uint8_t> out;

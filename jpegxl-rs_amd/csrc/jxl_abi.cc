@@ -405,9 +405,13 @@ void JxlHipBatchSetOption(JxlHipBatch* h, const char* name, int value) {
   if (n == "force_generic_idct") h->b->cfg.force_generic_idct = value;
   else if (n == "force_unfused_filters") h->b->cfg.force_unfused_filters = value;
   else if (n == "lf_wide_once") h->b->cfg.lf_wide_once = value != 0;
+  else if (n == "debug_stop_after" && value >= 0 && value <= 5) h->b->cfg.debug_stop_after = value;
   else if (n == "keep_orientation") h->keep_orientation = value != 0;   // applies to outputs set afterwards
   else if (n == "hf_block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) h->b->cfg.hf_block_threads = value;
   else if (n == "lds_code_budget" && value >= 0 && value <= 128 * 1024) h->b->cfg.lds_code_budget = value;
+}
+size_t JxlHipBatchDebugRead(JxlHipBatch* h, int index, const char* name, int channel, void* dst, size_t cap, void* s) {
+  try { return h->b->DebugRead(index, name ? name : "", channel, dst, cap, s); } catch (const std::exception& e) { SetLastError(e.what()); return 0; }
 }
 int64_t JxlHipBatchGetInfo(const JxlHipBatch* h, const char* name) {
   try { return h->b->Info(name ? name : ""); } catch (const std::exception& e) { SetLastError(e.what()); return -1; }

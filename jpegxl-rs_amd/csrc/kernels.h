@@ -136,6 +136,7 @@ struct LaunchCfg {
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
   int need_tile4_plain = 1, need_tile4_special = 1, need_tile8_plain = 1, need_tile8_special = 1;   // IdctTileKernel<TB, SPECIAL> variants some frame takes
   int need_rare_special = 1;         // some tile-kernel frame has IDENTITY / DCT2X2 blocks (IdctRareSpecialKernel)
+  int debug_stop_after = 0;          // testing: the tail of a decode stops after 1 = IDCT, 2 = gaborish, 3 / 4 / 5 = EPF pass 0 / 1 / 2 (stage-by-stage filters only)
   int force_unfused_filters = 0;     // testing: stage-by-stage gaborish / EPF / output kernels even for fusable frames        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames
   int hf_block_threads = 512;        // threads per HF-decode block (streams per block = threads / lane_stride_hf)
   int lds_code_budget = 64 * 1024;   // bytes of LDS the entropy-code tables (cfg, ctx map, alias) may take per block

@@ -4173,10 +4173,12 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
     hipLaunchKernelGGL(FusedGabEpf1OutKernel, dim3(tiles_x * DivUp(max_h, kFtH), 1, nframes), dim3(256), kFusedLds, (hipStream_t)stream, frames, unfused, tiles_x, swizzle);
   }
   if (!fp.any_unfused && !unfused) return;
+  // (cfg.debug_stop_after, testing: 2 = stop after gaborish, 3 / 4 / 5 = after EPF pass 0 / 1 / 2 — the planes are then read back, JxlHipBatchDebugRead)
+  const int stop = cfg.debug_stop_after ? cfg.debug_stop_after : 99;
   if (fp.any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames, unfused);
-  if (fp.max_epf >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames, unfused);
-  if (fp.max_epf >= 1) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames, unfused);
-  if (fp.max_epf >= 2) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  if (fp.max_epf >= 1 && stop >= 4) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  if (fp.max_epf >= 2 && stop >= 5) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames, unfused);
 }
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   if (!fp.any_unfused && !cfg.force_unfused_filters) return;

@@ -301,6 +301,42 @@ def test_jpeg_writer_reproduces_sample_jpg(jx):
     assert hashlib.sha256(want).hexdigest().startswith("d28d532e")
 
 
+def test_icc_profile_for_pq_and_hlg_images(jx):
+    """decode.rs:368-385 (icc_profile(true)) on HDR images: PQ / HLG have no parametric ICC curve — the profile carries a sampled one (checked
+    against SMPTE ST 2084 / ARIB STD-B67 in float64) and the H.273 code points in a `cicp` tag; lcms2 accepts it."""
+    import io, struct
+    import synth_lib as S
+    from PIL import ImageCms
+    img = S.synthetic_image(3, 64, 48)
+    for tf, prim_enum, cicp_prim in ((16, 9, 9), (18, 9, 9), (16, 1, 1), (18, 11, 12)):
+        S.set_color(1, prim_enum, tf, intensity_target=1000.0)
+        try:
+            data = S.encode_vardct(img, seed=3)
+        finally:
+            S.set_color()
+        icc = jx.icc_profile_from_headers(data)
+        assert struct.unpack(">I", icc[:4])[0] == len(icc)
+        prof = ImageCms.ImageCmsProfile(io.BytesIO(icc))                 # lcms2 parses it
+        assert ("PeQ" if tf == 16 else "HLG") in ImageCms.getProfileDescription(prof)
+        ntags = struct.unpack(">I", icc[128:132])[0]
+        tags = {icc[132 + 12 * i:136 + 12 * i]: struct.unpack(">II", icc[136 + 12 * i:144 + 12 * i]) for i in range(ntags)}
+        off, size = tags[b"cicp"]
+        assert icc[off:off + 4] == b"cicp" and tuple(icc[off + 8:off + 12]) == (cicp_prim, tf, 0, 1) and size == 12
+        off, size = tags[b"rTRC"]
+        assert tags[b"gTRC"] == tags[b"rTRC"] == tags[b"bTRC"] and icc[off:off + 4] == b"curv"
+        n = struct.unpack(">I", icc[off + 8:off + 12])[0]
+        curve = np.frombuffer(icc[off + 12:off + 12 + 2 * n], ">u2").astype(np.float64) / 65535
+        e = np.linspace(0, 1, n)
+        if tf == 16:
+            m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+            p = e ** (1 / m2)
+            want = (np.maximum(p - c1, 0) / (c2 - c3 * p)) ** (1 / m1)
+        else:
+            a = 0.17883277; b = 1 - 4 * a; c = 0.5 - a * np.log(4 * a)
+            want = np.where(e <= 0.5, e * e / 3, (np.exp((e - c) / a) + b) / 12)
+        assert np.abs(curve - want).max() < 1e-5 and curve[0] == 0 and abs(curve[-1] - 1) < 1e-4 and np.all(np.diff(curve) >= 0)
+
+
 def test_embedded_icc_profile_round_trip(jx):
     """SURVEY §8f.3 "decode the ANS-coded embedded ICC": image headers with want_icc carry the profile as an entropy-coded,
     predicted byte stream (icc_codec.cc).  tools/jxl_synth.cc writes one (header differences, tag commands incl. the TRC / XYZ
