@@ -373,6 +373,18 @@ class Pipeline:
                 got = self.outs[oj][fi].cpu().numpy().reshape(-1)
                 ok = ok and bool(np.array_equal(got, O.decode(frames[fi]).pixels("u8", 3)))
                 checked.append(f"{ks[-1]}:{fi}")
+        if self.gathered is not None and self.rank == 0:
+            # what the consumer rank holds of the other ranks' shards after the last step's gather (their frames are regenerated here: seeds are per rank)
+            self.torch.cuda.synchronize()
+            k = nsteps - 1
+            n, B = len(self.streams), self.B
+            off = (k * 37 if self.streaming else k * B) % n
+            for r in range(1, self.world):
+                for fi in sorted({0, B - 1}):
+                    data = _make_stream((1000 + 1000 * r + (off + fi) % n, self.args.width, self.args.height, self.args.epf, 0.0))
+                    got = self.gathered[r][(k % self.inner) * B + fi].cpu().numpy().reshape(-1)
+                    ok = ok and bool(np.array_equal(got, O.decode(data).pixels("u8", 3)))
+                    checked.append(f"rank{r}:{k}:{fi}")
         return ok, checked
 
     def close(self):

@@ -47,13 +47,22 @@ def gather_frames_chunked(local, out=None, dst: int = 0, chunk_frames: int = 32,
             raise ValueError("gather destination must be [world, *local.shape] of the same dtype")
         if out[dst].data_ptr() != local.data_ptr():
             out[dst].copy_(local, non_blocking=True)
+    # gloo moves host memory only: device tensors (the one-GPU functional check of bench.py's N > 1 flow, JXL_BENCH_BACKEND=gloo) are staged
+    staged = local.is_cuda and dist.get_backend(group) == "gloo"
     for c0 in range(0, n, chunk_frames):
         c1 = min(n, c0 + chunk_frames)
         if rank == dst:
-            ops = [dist.P2POp(dist.irecv, out[r][c0:c1], r, group) for r in range(world) if r != dst]
+            peers = [r for r in range(world) if r != dst]
+            bufs = [torch.empty(out[r][c0:c1].shape, dtype=local.dtype) if staged else out[r][c0:c1] for r in peers]
+            ops = [dist.P2POp(dist.irecv, b, r, group) for b, r in zip(bufs, peers)]
         else:
-            ops = [dist.P2POp(dist.isend, local[c0:c1], dst, group)]
+            if staged:
+                torch.cuda.current_stream().synchronize()
+            ops = [dist.P2POp(dist.isend, local[c0:c1].cpu() if staged else local[c0:c1], dst, group)]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()       # (RCCL: orders the current stream after the transfer, does not block the host)
+        if staged and rank == dst:
+            for b, r in zip(bufs, peers):
+                out[r][c0:c1].copy_(b)
     return out if rank == dst else None
