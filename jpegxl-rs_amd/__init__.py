@@ -451,12 +451,59 @@ class JxlDecoder:
         meta, fmt, pixels, _ = self._decode_internal(data, _PIXEL_TYPES[name][0], self.icc_profile, False)
         return meta, self._convert(pixels, fmt)
 
+    # ---- image.rs:32-132, the `image` crate integration (trait ToDynamic): the decoded buffer as an image object, None when the combination
+    # of sample type and channel count has no DynamicImage variant.  The stand-in for DynamicImage here is a (height, width, channels) numpy
+    # array tagged with the variant's name.
+    _DYNAMIC = {("float32", 3): "ImageRgb32F", ("float32", 4): "ImageRgba32F", ("uint8", 1): "ImageLuma8", ("uint8", 2): "ImageLumaA8",
+                ("uint8", 3): "ImageRgb8", ("uint8", 4): "ImageRgba8", ("uint16", 1): "ImageLuma16", ("uint16", 2): "ImageLumaA16",
+                ("uint16", 3): "ImageRgb16", ("uint16", 4): "ImageRgba16"}
+
+    def _to_image(self, meta, fmt, pixels):
+        arr = self._convert(pixels, fmt)
+        variant = self._DYNAMIC.get((arr.dtype.name, fmt.num_channels))
+        if variant is None or arr.size != meta.width * meta.height * fmt.num_channels:     # (ImageBuffer::from_raw: the buffer must hold the image exactly)
+            return None
+        return DynamicImage(variant, arr.reshape(meta.height, meta.width, fmt.num_channels))
+
+    def decode_to_image(self, data: bytes):
+        """image.rs:53-66 — decode with the sample type the header asks for; Optional[DynamicImage]."""
+        meta, fmt, pixels, _ = self._decode_internal(data, None, False, False)
+        return self._to_image(meta, fmt, pixels)
+
+    def decode_to_image_with(self, data: bytes, dtype):
+        """image.rs:68-86 — decode_to_image_with::<T>."""
+        name = np.dtype(dtype).name
+        if name not in _PIXEL_TYPES:
+            raise UnsupportedBitWidth(name)
+        meta, fmt, pixels, _ = self._decode_internal(data, _PIXEL_TYPES[name][0], False, False)
+        return self._to_image(meta, fmt, pixels)
+
     def reconstruct(self, data: bytes):
         """decode.rs:493-514 — returns (Metadata, ('jpeg', bytes) | ('pixels', ndarray))."""
         meta, fmt, pixels, jpeg = self._decode_internal(data, None, self.icc_profile, True)
         if jpeg is not None and len(jpeg):
             return meta, ("jpeg", jpeg.tobytes())
         return meta, ("pixels", self._convert(pixels, fmt))
+
+
+class DynamicImage:
+    """Stand-in for image::DynamicImage (image.rs:88-132): `variant` names the enum variant, `pixels` is (height, width, channels)."""
+
+    def __init__(self, variant: str, pixels: np.ndarray):
+        self.variant, self.pixels = variant, pixels
+
+    def to_rgba16(self) -> np.ndarray:
+        """DynamicImage::to_rgba16 as the reference's test uses it (image.rs:169): grey is replicated, alpha defaults to opaque, 8-bit samples
+        scale by 257, float samples by 65535 (clamped)."""
+        p = self.pixels
+        if p.dtype == np.uint8:
+            p = p.astype(np.uint16) * 257
+        elif p.dtype == np.float32:
+            p = np.rint(np.clip(p, 0.0, 1.0) * 65535.0).astype(np.uint16)
+        c = p.shape[2]
+        rgb = np.repeat(p[:, :, :1], 3, axis=2) if c <= 2 else p[:, :, :3]
+        alpha = p[:, :, c - 1:c] if c in (2, 4) else np.full(p.shape[:2] + (1,), 65535, np.uint16)
+        return np.concatenate([rgb, alpha], axis=2).astype(np.uint16)
 
 
 def decoder_builder(**options) -> JxlDecoder:

@@ -56,6 +56,27 @@ def test_sample_jxl_equals_sample_png(jx):
     assert hashlib.sha256(px.astype(">u2").tobytes()).hexdigest() == MANIFEST["reference_fixtures"]["sample.jxl"]["sha256_rgba16_be"]
 
 
+def test_image_integration(jx):
+    """jpegxl-rs/src/image.rs:145-225 (tests invalid / simple / pixel_type of the `image` integration): decode_to_image(SAMPLE_JXL).to_rgba16()
+    == sample.png as RGBA16; which (sample type, channel count) pairs have a DynamicImage variant."""
+    dec = jx.decoder_builder(parallel_runner=jx.ThreadsRunner())
+    for bad_call in (lambda: dec.decode_to_image(b""), lambda: dec.decode_to_image_with(b"", np.float32)):
+        with pytest.raises(jx.DecodeError):
+            bad_call()
+    sample, grey = fixture_bytes("sample.jxl"), fixture_bytes("sample_grey.jxl")
+    img = dec.decode_to_image(sample)
+    assert img is not None
+    assert np.array_equal(img.to_rgba16(), read_png16(os.path.join(FIXTURES, "sample.png")))
+    assert dec.decode_to_image_with(sample, np.float16) is None
+    for nch, data, f32_ok in ((1, grey, False), (2, grey, False), (3, sample, True), (4, sample, True)):
+        d = jx.decoder_builder(parallel_runner=jx.ThreadsRunner(), pixel_format=jx.PixelFormat(num_channels=nch))
+        for t, ok in ((np.uint8, True), (np.uint16, True), (np.float32, f32_ok)):
+            got = d.decode_to_image_with(data, t)
+            assert (got is not None) == ok, (nch, t)
+            if ok:
+                assert got.pixels.shape[2] == nch and got.pixels.dtype == np.dtype(t)
+
+
 def test_decode_simple_and_pixel_types(jx):
     """tests/decode.rs:45-67,96-120: inferred type Uint16, len == w*h*4; every pixel type and endianness succeeds."""
     data = fixture_bytes("sample.jxl")
