@@ -234,7 +234,7 @@ class Pipeline:
         self.comm = S("comm", 0) if self.do_gather else None            # RCCL gather overlaps the next step's decode
         self.hf_streams = [S("hf", i, -1) for i in range(self.nhf)]
         self.copy_streams = [S("copy", i) for i in range(max(1, args.prepare_threads))] if streaming else []
-        self.hf_done, self.front_done, self.lf_done, self.rest_done = ([E() for _ in range(nbuf)] for _ in range(4))
+        self.hf_done, self.front_done, self.lf_done, self.rest_done, self.idct_done = ([E() for _ in range(nbuf)] for _ in range(5))
         self.out_free = [E() for _ in range(self.nout)]               # the gather of the step that used this output buffer last has read it
         self.pool = None
         if streaming:
@@ -290,7 +290,7 @@ class Pipeline:
         with self.torch.cuda.stream(s_):
             s_.wait_event(self.lf_done[b])
             if self.deep and k >= self.ncoef:
-                s_.wait_event(self.rest_done[(k - self.ncoef) % self.nbuf])   # the coefficient set's previous user has consumed (and zeroed) it
+                s_.wait_event(self.idct_done[(k - self.ncoef) % self.nbuf])   # the coefficient set's previous user has consumed (and zeroed) it
             self.batches[b].decode_part(3, s_.cuda_stream, timed)
             self.hf_done[b].record(s_)
 
@@ -323,7 +323,9 @@ class Pipeline:
             main.wait_event(self.front_done[b])
             if self.do_gather and st["gathers"] >= self.nout:
                 main.wait_event(self.out_free[k % self.nout])   # the previous gather of this output buffer must have read the pixels
-            self.batches[b].decode_part(4, self.stream, timed)
+            self.batches[b].decode_part(7, self.stream, timed)     # IDCT
+            self.idct_done[b].record(main)
+            self.batches[b].decode_part(8, self.stream, timed)     # restoration filters, colour, write
             self.rest_done[b].record(main)
         if self.do_gather:
             from jpegxl_rs_amd.sharding import gather_frames_chunked

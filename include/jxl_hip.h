@@ -181,7 +181,8 @@ JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* batch, void* hip_stream);
 JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* batch, void* hip_stream);
 /* Enqueues one part of a decode: 0 = everything, 1 = front (LF decode, LF post-processing), 2 = rest (HF decode, IDCT,
  * filters, output); the rest may also be enqueued in two pieces, 3 = HF decode, 4 = IDCT, filters, output, and so may the front,
- * 5 = LF decode (all the HF decode needs), 6 = LF post-processing (needed by piece 4 only).  Front and rest may
+ * 5 = LF decode (all the HF decode needs), 6 = LF post-processing (needed by piece 4 only); piece 4 in turn as 7 = IDCT (the last stage
+ * that touches the coefficient planes) and 8 = restoration filters, colour, write.  Front and rest may
  * go to different streams; the caller orders them with events, which lets the latency-bound LF stage of later batches overlap
  * the other stages of the current one (bench.py: three batches in flight, LF stages on two side streams). */
 JxlDecoderStatus JxlHipBatchDecodePart(JxlHipBatch* batch, void* hip_stream, int part, int timed);

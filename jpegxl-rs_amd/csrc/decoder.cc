@@ -365,7 +365,7 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
     e->visible_frame_index = visible; e->nonvisible_frame_index = nonvisible;
     if (!p.modular) {
       for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
-      if (p.has_global_tree && (p.tree_code.use_prefix || p.tree_code.lz77)) throw ParseError("unsupported: prefix-coded / LZ77 LF streams of a VarDCT frame", true);
+      if (p.has_global_tree && p.tree_code.lz77) throw ParseError("unsupported: LZ77 in the LF streams of a VarDCT frame", true);
       if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
       if (p.subsampled && (p.base_x != 0.f || p.base_b != 0.f)) throw ParseError("unsupported: chroma from luma in a chroma-subsampled frame", true);
       if (p.max_prop >= 16) throw ParseError("unsupported: previous-channel MA properties in a VarDCT frame", true);
@@ -972,8 +972,9 @@ void Batch::Prepare(void* stream_v) {
     }
   }
   {  // LDS right-sizing for the decode kernels
-    auto code_bytes = [](const HostCode& c, bool ctx) { return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
-    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0; cfg.any_local_trees = 0; cfg.any_subsampled = 0;
+    auto code_bytes = [](const HostCode& c, bool ctx) { if (c.use_prefix) return 16;   /* prefix codes are read from global memory: nothing to size the LDS for */
+      return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
+    cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0; cfg.any_local_trees = 0; cfg.any_subsampled = 0; cfg.any_prefix_ac = 0;
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
       if (p.has_global_tree) { cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)p.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(p.tree_code, false)); cfg.any_wp |= p.tree.uses_wp ? 1 : 0; }
@@ -983,6 +984,7 @@ void Batch::Prepare(void* stream_v) {
       }
       if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
       if (p.subsampled) cfg.any_subsampled = 1;
+      if (!p.modular) for (auto& code : p.ac_code) if (code.use_prefix) cfg.any_prefix_ac = 1;
     }
     if (getenv("JXL_HIP_DEBUG_LDS")) fprintf(stderr, "[jxl-hip] LDS sizing: tree nodes %d, modular code %d B, AC code %d B, BlockCtxDev %zu B\n", cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.ac_code_bytes, sizeof(BlockCtxDev));
   }
@@ -1557,7 +1559,10 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   // wait for piece 5 only, so that the post-processing kernels, which wait for wavefront slots beside the pixel kernels of the batch
   // before, are off the critical path.
   const bool do_lf = part == 0 || part == 1 || part == 5, do_lfpost = part == 0 || part == 1 || part == 6, do_front = do_lf || do_lfpost;
-  const bool do_hf = part == 0 || part == 2 || part == 3, do_tail = part == 0 || part == 2 || part == 4;
+  // ... and so may the tail: 7 = IDCT (the last stage that touches the coefficient planes: a caller that rotates coefficient sets lets the next
+  // HF stage of that set start behind it), 8 = restoration filters, colour, write
+  const bool do_hf = part == 0 || part == 2 || part == 3, do_tail = part == 0 || part == 2 || part == 4 || part == 7 || part == 8;
+  const bool do_idct = do_tail && part != 8, do_post = do_tail && part != 7;
   const bool split = part != 0;                       // halves timed separately
   if (do_hf || do_tail) ran_once_ = true;
   if (do_hf) decodes_since_finish_++;
@@ -1604,11 +1609,14 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   if (!any_vardct_) {
     if (do_hf) { rec(split ? 7 : 2); rec(3); }
     if (do_tail) {
-      rec(4); rec(5);
-      if (any_modchan_) EnqueueModularTail(stream_v);
-      if (any_complex_) EnqueuePostOps(stream_v);
-      rec(6);
-      if (timed && split) timed_rest_cursor_++;
+      if (do_idct) rec(4);
+      if (do_post) {
+        rec(5);
+        if (any_modchan_) EnqueueModularTail(stream_v);
+        if (any_complex_) EnqueuePostOps(stream_v);
+        rec(6);
+        if (timed && split) timed_rest_cursor_++;
+      }
     }
     return;
   }
@@ -1628,19 +1636,23 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
       ApplyIdctFlags(flags_pinned_);
       flags_pending_ = false;
     }
-    if (split) rec(8);                        // the tail may sit on another stream than the HF stage: its own start mark
-    LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
-    DebugSync("IDCT", stream_v);
-    rec(4);
-    if (cfg.debug_stop_after != 1) LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
-    DebugSync("filters", stream_v);
-    rec(5);
-    if (!cfg.debug_stop_after) LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
-    if (any_complex_ && !cfg.debug_stop_after) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
-    DebugSync("output / frame tail", stream_v);
-    rec(6);
-    ClearCoefficientsAfterDecode(stream_v);   // (the IDCT kernels zeroed what they read)
-    if (timed && split) timed_rest_cursor_++;
+    if (do_idct) {
+      if (split) rec(8);                        // the tail may sit on another stream than the HF stage: its own start mark
+      LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
+      DebugSync("IDCT", stream_v);
+      rec(4);
+      ClearCoefficientsAfterDecode(stream_v);   // (the IDCT kernels zeroed what they read)
+    }
+    if (do_post) {
+      if (cfg.debug_stop_after != 1) LaunchFilters(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
+      DebugSync("filters", stream_v);
+      rec(5);
+      if (!cfg.debug_stop_after) LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
+      if (any_complex_ && !cfg.debug_stop_after) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
+      DebugSync("output / frame tail", stream_v);
+      rec(6);
+      if (timed && split) timed_rest_cursor_++;
+    }
   }
 }
 

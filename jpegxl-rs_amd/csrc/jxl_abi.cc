@@ -391,7 +391,7 @@ JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->P
 JxlDecoderStatus JxlHipBatchDecode(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->Run(s)) }
 JxlDecoderStatus JxlHipBatchDecodeTimed(JxlHipBatch* h, void* s) { BATCH_TRY(h->b->RunTimed(s)) }
 JxlDecoderStatus JxlHipBatchDecodePart(JxlHipBatch* h, void* s, int part, int timed) {
-  if (part < 0 || part > 6) return JXL_DEC_ERROR;
+  if (part < 0 || part > 8) return JXL_DEC_ERROR;
   BATCH_TRY(h->b->RunPart(s, part, timed != 0))
 }
 JxlDecoderStatus JxlHipBatchCollectTimes(JxlHipBatch* h, JxlHipStageTimes* t, int* runs) {

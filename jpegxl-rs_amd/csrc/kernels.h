@@ -124,6 +124,7 @@ struct LaunchCfg {
   int any_wp = 0;            // some MA tree of the batch uses the weighted predictor (the Modular kernels then reserve LDS for its state)
   int any_subsampled = 0;    // some frame is chroma-subsampled (its own IDCT kernel; the SIMT HF kernel only)
   int any_multipass = 0;     // some frame has progressive passes (the general instantiation of the SIMT HF kernel)
+  int any_prefix_ac = 0;     // some VarDCT frame's AC code is a prefix code (HfDecodeKernel beside the SIMT kernel)
   int any_local_trees = 0;   // some Modular sub-stream carries its own MA tree / code (second launch of the group kernel)
   // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
   int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;

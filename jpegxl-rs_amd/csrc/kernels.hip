@@ -145,6 +145,12 @@ template <> __device__ __forceinline__ void StG<uint2>(uint2* p, uint2 v) {
 template <typename T> __device__ __forceinline__ T LdG(const T* p) { return *p; }
 template <typename T> __device__ __forceinline__ void StG(T* p, T v) { *p = v; }
 #endif
+// 16-byte load WITHOUT the non-temporal hint: plane rows a filter tile shares with its neighbours (halo) should stay in the L2 for them
+__device__ __forceinline__ float4 LdGKeep(const float4* p) {
+  typedef float __attribute__((ext_vector_type(4))) v4;
+  const v4 v = *reinterpret_cast<const __attribute__((address_space(1))) v4*>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 template <typename T> __device__ __forceinline__ T LdS(uint32_t byte_off) { return *reinterpret_cast<const T*>(g_dyn_lds + byte_off); }
 template <typename T> __device__ __forceinline__ void StS(uint32_t byte_off, T v) { *reinterpret_cast<T*>(g_dyn_lds + byte_off) = v; }
 constexpr uint32_t kNotInLds = 0xFFFFFFFFu;
@@ -1212,6 +1218,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp;
   mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride;
+  mc.slow = f.mod_code.use_prefix;       // prefix-coded LF streams (cjxl's fast efforts): the general symbol reader
   uint32_t state = 0;
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
   // ---- LF coefficients
@@ -1221,7 +1228,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     tmp.Init(f.cs, br.BitPos(), f.cs_size);
     if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree || s_gh.ntransforms != 0) { SetError(f, kErrUnsupported); s_fail = 1; }
     br.Init(f.cs, tmp.BitPos(), sec_end);
-    state = br.Read(32);
+    state = f.mod_code.use_prefix ? 0x130000u : br.Read(32);     // (prefix codes carry no ANS state)
     scratch[0] = (int32_t)s_u[0];
     scratch[1] = 0;
   }
@@ -1246,7 +1253,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     tmp.Init(f.cs, br.BitPos(), f.cs_size);
     if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree || s_gh.ntransforms != 0) { SetError(f, kErrUnsupported); s_fail = 1; }
     br.Init(f.cs, tmp.BitPos(), sec_end);
-    state = br.Read(32);
+    state = f.mod_code.use_prefix ? 0x130000u : br.Read(32);
   }
   WaveSync();
   if (s_fail) return;
@@ -1860,9 +1867,13 @@ __device__ static const uint8_t kNzCtx[64] = {0,   0,   31,  62,  62,  93,  93, 
                                               180, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
                                               206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206};
 
-__global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride, uint32_t lds_bytes) {
+// only_prefix: the launch beside the SIMT kernel that takes the frames whose AC code is a prefix (Huffman) code — what cjxl's fast efforts
+// write; symbols are then read bit by bit through the canonical-code tables in global memory (jxl_dev.h ReadSymbol)
+__global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride, uint32_t lds_bytes, int only_prefix) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
+  const bool pfx = f.ac_code.use_prefix != 0;
+  if (only_prefix && !pfx) return;
   // ---- stage the AC entropy code (cfg, context map, alias tables if they fit) and the two context LUTs into LDS
   FastCode code;
   if (threadIdx.x < 64) { StS<uint8_t>(threadIdx.x, kNzCtx[threadIdx.x]); StS<uint8_t>(64 + threadIdx.x, kFreqCtx[threadIdx.x]); }
@@ -1885,7 +1896,13 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
   if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); return; }
   const uint32_t ctx_offset = 495u * nctx * preset;
-  uint32_t state = br.Read(32);
+  uint32_t state = pfx ? 0x130000u : br.Read(32);
+  auto read_hybrid = [&](uint32_t ctx) -> uint32_t {
+    if (!pfx) return FastHybrid(br, state, code, code.Cluster(ctx));
+    const uint32_t cl = LdG(f.ac_code.ctx_map + ctx);
+    AnsReader ans; ans.state = state;
+    return HybridFromToken(br, LdG(f.ac_code.cfg + cl), ReadSymbol(br, ans, f.ac_code, cl));
+  };
   uint32_t nzrow[3][8];   // 32 bytes per channel packed in 8 words (kept in registers)
 #pragma unroll
   for (int c = 0; c < 3; c++)
@@ -1936,7 +1953,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
         else pred = (nz_get(c, bx) + nz_get(c, bx - 1) + 1) / 2;
         const uint32_t pc = pred > 64 ? 64 : pred;
         const uint32_t nz_ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
-        uint32_t nzeros = FastHybrid(br, state, code, code.Cluster(nz_ctx));
+        uint32_t nzeros = read_hybrid(nz_ctx);
         if (nzeros + covered > size) { SetError(f, kErrNzeros); return; }
         nz_written += nzeros;
         const uint32_t nzm = (nzeros + covered - 1) >> l2;
@@ -1951,7 +1968,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
           next_pos = k + 1 < size ? LdG(order + k + 1) : 0;
           const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
           const uint32_t ctx = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + kk)) * 2 + prev;
-          const uint32_t u = FastHybrid(br, state, code, code.Cluster(ctx));
+          const uint32_t u = read_hybrid(ctx);
           prev = u != 0;
           nzeros -= prev;
           if (u) StG(blk + pos, UnpackSigned(u));
@@ -2034,7 +2051,7 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
   if (sync && threadIdx.x == 0 && atomicAdd(sync, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(sync, 0u); __threadfence(); atomicMax(sync + 1, epoch); }
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
+  if (f.is_modular || f.ac_code.use_prefix) return;            // (prefix-coded frames: HfDecodeKernel, launched beside this one)
   if (blockIdx.x * lanes >= f.num_groups) return;
   if (prio) __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of co-resident waves
   // per-lane regions sit at the end of the dynamic LDS: `lanes` real ones + one scratch region that all stream-less
@@ -3372,7 +3389,7 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
     static_assert(kV * 4 == kFinW + 2 && kFtW % 4 == 0, "tile width");
     for (int i = threadIdx.x; i < kV * kFinH * 3; i += blockDim.x) {
       const int c = i / (kV * kFinH), r = i - c * (kV * kFinH), ly = r / kV, v = r - ly * kV;
-      const float4 q = LdG(reinterpret_cast<const float4*>(f.plane_a[c] + (size_t)(y0 + ly - 3) * stride + (x0 - 4 + v * 4)));
+      const float4 q = LdGKeep(reinterpret_cast<const float4*>(f.plane_a[c] + (size_t)(y0 + ly - 3) * stride + (x0 - 4 + v * 4)));
       float* d = s_in + (c * kFinH + ly) * kFinP + v * 4 - 1;      // q.x is the sample left of local column v * 4
       if (v > 0) d[0] = q.x;
       d[1] = q.y; d[2] = q.z;
@@ -4125,6 +4142,11 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     if (plain) hipLaunchKernelGGL((HfDecodeSimtKernel<true, false, false>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch, hf_prio);
     else if (all_lds) hipLaunchKernelGGL((HfDecodeSimtKernel<true, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch, hf_prio);
     else hipLaunchKernelGGL((HfDecodeSimtKernel<false, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch, hf_prio);
+    if (cfg.any_prefix_ac) {   // frames with a prefix-coded AC stream: one group stream per wavefront lane 0, tables in global memory
+      static bool attr2 = false;
+      if (!attr2) { (void)hipFuncSetAttribute((const void*)HfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr2 = true; }
+      hipLaunchKernelGGL(HfDecodeKernel, dim3(DivUp(max_groups, 512 / 64), nframes), dim3(512), 128, (hipStream_t)stream, frames, 64, 128u, 1);
+    }
     return;
   }
   const int threads = cfg.hf_block_threads;
@@ -4133,7 +4155,7 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)HfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
   dim3 grid(DivUp(max_groups, per_block), nframes);
-  hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(threads), lds_bytes, (hipStream_t)stream, frames, cfg.lane_stride_hf, lds_bytes);
+  hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(threads), lds_bytes, (hipStream_t)stream, frames, cfg.lane_stride_hf, lds_bytes, 0);
 }
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream) {
   // 64x64 tiles for frames with varblocks beyond 32x32, 32x32 tiles (a quarter of the LDS) for the others; each in a

@@ -244,6 +244,13 @@ def set_color(white_point=None, primaries=1, tf=13, gamma=0.0, intensity_target=
         L.jxlsynth_set_color(white_point, primaries, tf, int(round(gamma * 1e7)), intensity_target)
 
 
+def set_prefix(on=False):
+    """Streams written from now on use prefix (Huffman) codes instead of ANS (cjxl -e 1..3); call without arguments to go back."""
+    L = lib()
+    L.jxlsynth_set_prefix.argtypes = [C.c_int]
+    L.jxlsynth_set_prefix(1 if on else 0)
+
+
 def set_float(exp_bits=0):
     """Float samples in the image headers written from now on: the Modular integers are bit patterns of floats with `exp_bits` exponent
     bits out of the `bits` the encoder is called with (0 = integer samples again)."""

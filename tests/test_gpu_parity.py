@@ -623,6 +623,33 @@ def test_batch_api_mixed_sizes_and_lane_strides(jx):
         assert b.total_pixels == sum(len(r) // 3 for r in refs)
 
 
+@pytest.mark.parametrize("w,h,mix,epf", [(320, 200, 2, 1), (64, 64, 0, 0), (600, 520, 1, 2), (2100, 300, 1, 1)])
+def test_prefix_coded_vardct_streams(jx, w, h, mix, epf):
+    """What `cjxl -e 1..3` writes: LF (Modular) and AC streams under prefix (Huffman) codes instead of ANS.  The synthesiser's
+    prefix writer and the oracle agree with the ANS form of the same frame (test_synth_roundtrip.py); here the HIP path — general symbol
+    reader in the LF kernel, HfDecodeKernel for the AC streams — against the oracle, alone and in a batch beside ANS-coded frames."""
+    img = S.synthetic_image(40 + w % 7, w, h)
+    ans = S.encode_vardct(img, seed=5, strategy_mix=mix, epf_iters=epf, gab=1)
+    S.set_prefix(True)
+    try:
+        pfx = S.encode_vardct(img, seed=5, strategy_mix=mix, epf_iters=epf, gab=1)
+    finally:
+        S.set_prefix(False)
+    assert pfx != ans
+    _, px = check_against_oracle(jx, pfx, np.uint8, 3)
+    check_against_oracle(jx, pfx, np.float32, 3)
+    ref = O.decode(ans).pixels("u8", 3)
+    assert np.array_equal(px.reshape(-1), ref)                     # the same coefficients either way
+    for lf_stride in (64, 4):
+        b = jx.BatchDecoder(0)
+        for s_ in (ans, pfx, pfx, ans):
+            b.add(s_, "uint8", 3)
+        b.set_lane_stride(lf_stride, 1)
+        b.prepare(); b.decode(); b.finish()
+        for i in range(4):
+            assert np.array_equal(b.output(i), ref), (lf_stride, i)
+
+
 def test_batch_objects_are_refilled_without_reallocating(jx):
     """The streaming loop of bench.py: JxlHipBatchReset + JxlHipBatchAddImages (parser threads) + JxlHipBatchPrepare on one batch object,
     again and again with other images (other sizes, other counts), a second object sharing its pixel and coefficient planes; SIMT LF decode

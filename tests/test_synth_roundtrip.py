@@ -189,3 +189,24 @@ def test_free_running_streams_are_stable_under_the_oracle():
         assert hashlib.sha256(data).hexdigest() == man[name]["sha256_stream"], name
         px = O.decode(data).pixels("f32", man[name]["channels"])
         assert hashlib.sha256(px.tobytes()).hexdigest() == man[name]["sha256_f32"], name
+
+
+def test_prefix_coded_streams_decode_like_their_ans_twins():
+    """tools/synth_entropy.h writes prefix (Huffman) codes when asked (length-limited Huffman, Brotli-style code description, canonical codes
+    most significant bit first): the oracle must decode such streams to exactly what the ANS-coded twin of the same image gives — VarDCT
+    (lossy: same quantised coefficients) and Modular (lossless: the source samples)."""
+    import numpy as np
+    import oracle_lib as O
+    import synth_lib as S
+    for seed, (w, h) in enumerate([(320, 200), (64, 48), (520, 300)]):
+        img = S.synthetic_image(60 + seed, w, h)
+        ans = S.encode_vardct(img, seed=seed, strategy_mix=seed % 3)
+        S.set_prefix(True)
+        try:
+            pfx = S.encode_vardct(img, seed=seed, strategy_mix=seed % 3)
+            mod = S.encode_modular(img, bits=8)
+        finally:
+            S.set_prefix(False)
+        assert pfx != ans
+        assert np.array_equal(O.decode(pfx).pixels("u8", 3), O.decode(ans).pixels("u8", 3))
+        assert np.array_equal(O.decode(mod).pixels("u8", 3), img.reshape(-1))

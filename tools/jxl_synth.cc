@@ -1240,6 +1240,8 @@ void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::Syntheti
 // ICC profile embedded by the image headers written from now on in this thread (size 0: none, enumerated colour encoding)
 void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
 void jxlsynth_set_float(int exp_bits) { synth::g_float_exp_bits = exp_bits; }
+// entropy-coded streams written from now on in this thread use prefix (Huffman) codes instead of ANS — what cjxl's fast efforts emit
+void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 // rgba == NULL: the extra channel is alpha again
 void jxlsynth_set_spot(const float* rgba) { synth::g_spot_set = rgba != nullptr; if (rgba) for (int i = 0; i < 4; i++) synth::g_spot[i] = rgba[i]; }
 // white_point < 0 clears the override

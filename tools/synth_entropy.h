@@ -256,8 +256,16 @@ struct ClusterCode {
   std::vector<std::vector<uint16_t>> reverse;
 };
 
+// prefix (Huffman) code of one cluster: code lengths (<= 15), canonical codes by (length, symbol)
+struct PrefixCode { std::vector<uint8_t> len; std::vector<uint16_t> code; bool single = false; };   // single: one used symbol, coded in zero bits
+// streams written from now on in this thread use prefix codes instead of ANS (what cjxl's fast efforts emit); the nested code of a
+// context map stays ANS
+inline bool& UsePrefixCodes() { static thread_local bool v = false; return v; }
+
 struct EntropyCoder {
   // configuration
+  bool use_prefix = false;
+  std::vector<PrefixCode> prefix;    // per cluster (use_prefix)
   int log_alpha = 8;
   std::vector<uint8_t> ctx_map;      // ctx -> cluster
   std::vector<UintConfig> cfg;       // per cluster
@@ -270,6 +278,7 @@ struct EntropyCoder {
   UintConfig lz_len_cfg{4, 0, 0};
 };
 
+inline void MakePrefixCodes(EntropyCoder& ec);
 inline double HistoCost(const std::vector<uint32_t>& h, uint64_t total) {
   if (total == 0) return 0;
   double c = 0;
@@ -376,6 +385,108 @@ inline void BuildEntropyCoder(const std::vector<const std::vector<Token>*>& stre
       cc.reverse[sym][off] = (uint16_t)v;
     }
   }
+  if (UsePrefixCodes() && !ec.lz77) MakePrefixCodes(ec);
+}
+
+// Huffman code lengths (<= max_len) for counts (0 = unused symbol): plain Huffman, flattened (counts halved towards 1) until it fits
+inline std::vector<uint8_t> HuffmanLengths(std::vector<uint32_t> counts, int max_len) {
+  const size_t n = counts.size();
+  std::vector<uint8_t> len(n, 0);
+  size_t used = 0;
+  for (uint32_t c : counts) used += c != 0;
+  if (used == 0) return len;
+  if (used == 1) { for (size_t i = 0; i < n; i++) if (counts[i]) len[i] = 1; return len; }
+  for (;;) {
+    struct Node { uint64_t w; int l, r; };
+    std::vector<Node> nodes;
+    std::vector<int> live;
+    for (size_t i = 0; i < n; i++) if (counts[i]) { nodes.push_back({counts[i], -1, (int)i}); live.push_back((int)nodes.size() - 1); }
+    while (live.size() > 1) {
+      std::sort(live.begin(), live.end(), [&](int a, int b) { return nodes[a].w > nodes[b].w || (nodes[a].w == nodes[b].w && a < b); });
+      const int a = live.back(); live.pop_back();
+      const int b = live.back(); live.pop_back();
+      nodes.push_back({nodes[a].w + nodes[b].w, a, b});
+      live.push_back((int)nodes.size() - 1);
+    }
+    std::fill(len.begin(), len.end(), 0);
+    int deepest = 0;
+    std::vector<std::pair<int, int>> stack{{live[0], 0}};
+    while (!stack.empty()) {
+      auto [id, d] = stack.back(); stack.pop_back();
+      if (nodes[id].l < 0) { len[nodes[id].r] = (uint8_t)d; deepest = std::max(deepest, d); }
+      else { stack.push_back({nodes[id].l, d + 1}); stack.push_back({nodes[id].r, d + 1}); }
+    }
+    if (deepest <= max_len) return len;
+    for (auto& c : counts) if (c) c = c / 2 + 1;
+  }
+}
+inline std::vector<uint16_t> CanonicalCodes(const std::vector<uint8_t>& len) {
+  std::vector<uint16_t> code(len.size(), 0);
+  uint32_t next = 0;
+  for (int l = 1; l <= 15; l++) {
+    for (size_t s = 0; s < len.size(); s++) if (len[s] == l) code[s] = (uint16_t)next++;
+    next <<= 1;
+  }
+  return code;
+}
+inline void PutCodeMsbFirst(BitWriter& w, uint32_t code, int len) { for (int b = len - 1; b >= 0; b--) w.put((code >> b) & 1, 1); }
+// Brotli-style description of a prefix code over `alphabet` symbols (dec_huffman.cc ReadHuffmanCode): the simple form for one or two
+// used symbols, else the complex form — code-length code over the lengths that occur (no repeat symbols), then one length per symbol up
+// to the last used one.
+inline void WritePrefixCodeDescription(BitWriter& w, const std::vector<uint8_t>& len, int alphabet) {
+  if (alphabet == 1) return;
+  std::vector<int> used;
+  for (int i = 0; i < alphabet; i++) if (len[i]) used.push_back(i);
+  int max_bits = 0;
+  for (int v = alphabet - 1; v; v >>= 1) max_bits++;
+  if (used.size() <= 2) {
+    w.put(1, 2);                                  // simple
+    w.put((uint32_t)std::max<size_t>(used.size(), 1) - 1, 2);
+    if (used.empty()) w.put(0, max_bits);
+    for (int sym : used) w.put((uint32_t)sym, max_bits);
+    return;
+  }
+  w.put(0, 2);                                    // complex, no skipped code-length-code entries
+  std::vector<uint32_t> freq(18, 0);
+  for (int i = 0; i <= used.back(); i++) freq[len[i]]++;
+  std::vector<uint8_t> cl = HuffmanLengths(freq, 5);
+  int distinct = 0;
+  for (int i = 0; i < 18; i++) distinct += cl[i] != 0;
+  static const uint8_t kOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+  // fixed code of the code-length-code lengths: 0 -> 00, 4 -> 10 (first bit 1), 3 -> 01, 2 -> 110, 1 -> 1110, 5 -> 1111 (bits in stream order)
+  auto put_cl = [&](int v) {
+    switch (v) { case 0: w.put(0, 2); break; case 4: w.put(1, 2); break; case 3: w.put(2, 2); break; case 2: w.put(3, 3); break; case 1: w.put(7, 4); break; default: w.put(15, 4); break; }
+  };
+  int space = 32;
+  for (int i = 0; i < 18 && space > 0; i++) {
+    const int v = cl[kOrder[i]];
+    put_cl(v);
+    if (v) space -= 32 >> v;
+  }
+  if (distinct != 1 && space != 0) throw std::runtime_error("prefix writer: incomplete code-length code");
+  if (distinct == 1) return;                      // every symbol up to the end has that one length: nothing more is read... (only valid if complete)
+  const std::vector<uint16_t> clcode = CanonicalCodes(cl);
+  int sp = 32768;
+  for (int i = 0; i <= used.back() && sp > 0; i++) {
+    PutCodeMsbFirst(w, clcode[len[i]], cl[len[i]]);
+    if (len[i]) sp -= 32768 >> len[i];
+  }
+  if (sp != 0) throw std::runtime_error("prefix writer: incomplete code");
+}
+inline void MakePrefixCodes(EntropyCoder& ec) {
+  ec.use_prefix = true;
+  ec.log_alpha = 15;
+  ec.prefix.resize(ec.clusters.size());
+  for (size_t c = 0; c < ec.clusters.size(); c++) {
+    std::vector<uint32_t> counts(ec.clusters[c].dist.begin(), ec.clusters[c].dist.end());
+    while (!counts.empty() && counts.back() == 0) counts.pop_back();
+    if (counts.empty()) counts.push_back(1);
+    ec.prefix[c].len = HuffmanLengths(counts, 15);
+    size_t used = 0;
+    for (uint8_t l : ec.prefix[c].len) used += l != 0;
+    ec.prefix[c].single = used <= 1;                            // a single symbol costs no bits (ReadSymbol: count[0] flags it)
+    ec.prefix[c].code = CanonicalCodes(ec.prefix[c].len);
+  }
 }
 
 inline void WriteUintConfig(BitWriter& w, const UintConfig& c, int log_alpha) {
@@ -413,7 +524,10 @@ inline void WriteContextMap(BitWriter& w, const std::vector<uint8_t>& map, int n
   w.put(1, 1);  // use_mtf
   EntropyCoder nested;
   std::vector<const std::vector<Token>*> ss{&toks};
+  const bool outer_prefix = UsePrefixCodes();
+  UsePrefixCodes() = false;
   BuildEntropyCoder(ss, 1, UintConfig{4, 2, 0}, 1, nested);
+  UsePrefixCodes() = outer_prefix;
   WriteEntropyCode(w, nested);
   EncodeTokens(w, nested, toks);
 }
@@ -427,6 +541,13 @@ inline void WriteEntropyCode(BitWriter& w, const EntropyCoder& ec) {
     WriteUintConfig(w, ec.lz_len_cfg, 8);
   }
   if (ec.num_ctx > 1) WriteContextMap(w, ec.ctx_map, (int)ec.clusters.size());
+  if (ec.use_prefix) {
+    w.put(1, 1);  // prefix codes: log_alpha_size is 15
+    for (size_t c = 0; c < ec.clusters.size(); c++) WriteUintConfig(w, ec.cfg[c], 15);
+    for (size_t c = 0; c < ec.clusters.size(); c++) WriteVarLenUint16(w, (uint32_t)ec.prefix[c].len.size() - 1);
+    for (size_t c = 0; c < ec.clusters.size(); c++) WritePrefixCodeDescription(w, ec.prefix[c].len, (int)ec.prefix[c].len.size());
+    return;
+  }
   w.put(0, 1);  // ANS (no prefix codes)
   w.put(ec.log_alpha - 5, 2);
   for (size_t c = 0; c < ec.clusters.size(); c++) WriteUintConfig(w, ec.cfg[c], ec.log_alpha);
@@ -436,6 +557,19 @@ inline void WriteEntropyCode(BitWriter& w, const EntropyCoder& ec) {
 // rANS encode one stream: [state32] then per token (refill16?) + extra bits, in decode order
 inline void EncodeTokens(BitWriter& w, const EntropyCoder& ec, const std::vector<Token>& tokens) {
   const size_t n = tokens.size();
+  if (ec.use_prefix) {   // no state: per token its code (first bit = most significant), then the extra bits
+    for (size_t i = 0; i < n; i++) {
+      const Token& t = tokens[i];
+      const int cl = ec.ctx_map[t.ctx];
+      uint32_t tok, nb, bits;
+      TokenSymbol(ec.cfg[cl], t, &tok, &nb, &bits);
+      const PrefixCode& pc = ec.prefix[cl];
+      if (tok >= pc.len.size()) throw std::runtime_error("prefix: symbol outside the alphabet");
+      if (!pc.single) { if (!pc.len[tok]) throw std::runtime_error("prefix: symbol without a code"); PutCodeMsbFirst(w, pc.code[tok], pc.len[tok]); }
+      if (nb > 24) { w.put(bits & 0xFFFF, 16); w.put(bits >> 16, nb - 16); } else w.put(bits, nb);
+    }
+    return;
+  }
   std::vector<uint16_t> refill(n, 0);
   std::vector<uint8_t> has_refill(n, 0);
   uint32_t state = 0x130000;
