@@ -60,6 +60,12 @@ typedef enum {
 } JxlDecoderStatus;
 typedef enum { JXL_COLOR_PROFILE_TARGET_ORIGINAL = 0, JXL_COLOR_PROFILE_TARGET_DATA = 1 } JxlColorProfileTarget;
 
+/* jpegxl-sys/src/metadata/codestream_header.rs:286-388 (frame header of a displayed frame or non-coalesced layer) */
+typedef enum { JXL_BLEND_REPLACE = 0, JXL_BLEND_ADD = 1, JXL_BLEND_BLEND = 2, JXL_BLEND_MULADD = 3, JXL_BLEND_MUL = 4 } JxlBlendMode;
+typedef struct { JxlBlendMode blendmode; uint32_t source, alpha; JXL_BOOL clamp; } JxlBlendInfo;
+typedef struct { JXL_BOOL have_crop; int32_t crop_x0, crop_y0; uint32_t xsize, ysize; JxlBlendInfo blend_info; uint32_t save_as_reference; } JxlLayerInfo;
+typedef struct { uint32_t duration, timecode, name_length; JXL_BOOL is_last; JxlLayerInfo layer_info; } JxlFrameHeader;
+
 typedef struct JxlDecoderStruct JxlDecoder;
 
 /* jpegxl-sys/src/threads/parallel_runner.rs:46-122 */
@@ -80,7 +86,16 @@ JxlDecoderStatus JxlDecoderSubscribeEvents(JxlDecoder* dec, int events_wanted); 
 JxlDecoderStatus JxlDecoderSetKeepOrientation(JxlDecoder* dec, JXL_BOOL skip_reorientation);  /* decode.rs:563 */
 JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* dec, JXL_BOOL unpremul_alpha);   /* decode.rs:585 */
 JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* dec, JXL_BOOL render_spotcolors);  /* decode.rs:602 */
-JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* dec, JXL_BOOL coalescing);               /* decode.rs:622 */
+/* decode.rs:622.  coalescing = FALSE: every regular frame of the image arrives as coded — JXL_DEC_FRAME, JXL_DEC_NEED_IMAGE_OUT_BUFFER (a buffer of
+ * the FRAME's size: JxlDecoderImageOutBufferSize follows), JXL_DEC_FULL_IMAGE per frame — its pixels after the colour transform, not blended,
+ * cropped frames at their own size; JxlDecoderGetFrameHeader says where it goes and how it blends. */
+JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* dec, JXL_BOOL coalescing);
+void JxlDecoderRewind(JxlDecoder* dec);                                                       /* decode.rs:438: back to the start, settings kept; set the input again */
+void JxlDecoderSkipFrames(JxlDecoder* dec, size_t amount);                                    /* decode.rs:457: the next `amount` frames are not announced nor decoded */
+JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* dec);                                 /* decode.rs:472: after JXL_DEC_FRAME: do not decode this frame */
+JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* dec, JxlFrameHeader* header);     /* decode.rs:1040: valid after JXL_DEC_FRAME */
+JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* dec, char* name, size_t size);      /* decode.rs:1058 */
+JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* dec, size_t index, JxlBlendInfo* blend_info);   /* decode.rs:1077 */
 JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* dec);                                     /* decode.rs:662 — runs the HIP hot path */
 JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* dec, const uint8_t* data, size_t size);
 /* jpegxl-sys/src/decode.rs:706: releases the input set by JxlDecoderSetInput; returns the number of bytes the decoder has not consumed

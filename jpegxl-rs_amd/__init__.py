@@ -56,6 +56,22 @@ class JxlMemoryManager(C.Structure):
     _fields_ = [("opaque", C.c_void_p), ("alloc", C.c_void_p), ("free", C.c_void_p)]
 
 
+class JxlBlendInfo(C.Structure):
+    """jpegxl-sys/src/metadata/codestream_header.rs:305-315"""
+    _fields_ = [("blendmode", C.c_int), ("source", C.c_uint32), ("alpha", C.c_uint32), ("clamp", C.c_int)]
+
+
+class JxlLayerInfo(C.Structure):
+    """codestream_header.rs:323-353"""
+    _fields_ = [("have_crop", C.c_int), ("crop_x0", C.c_int32), ("crop_y0", C.c_int32), ("xsize", C.c_uint32), ("ysize", C.c_uint32),
+                ("blend_info", JxlBlendInfo), ("save_as_reference", C.c_uint32)]
+
+
+class JxlFrameHeader(C.Structure):
+    """codestream_header.rs:358-388"""
+    _fields_ = [("duration", C.c_uint32), ("timecode", C.c_uint32), ("name_length", C.c_uint32), ("is_last", C.c_int), ("layer_info", JxlLayerInfo)]
+
+
 class JxlHipStageTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lf_ms", "lfpost_ms", "hf_ms", "idct_ms", "filter_ms", "out_ms", "total_ms")]
 
@@ -92,6 +108,9 @@ def libjxl():
             "JxlDecoderImageOutBufferSize": (C.c_int, [vp, C.POINTER(JxlPixelFormat), C.POINTER(sz)]),
             "JxlDecoderSetImageOutBuffer": (C.c_int, [vp, C.POINTER(JxlPixelFormat), vp, sz]),
             "JxlDecoderSetJPEGBuffer": (C.c_int, [vp, vp, sz]), "JxlDecoderReleaseJPEGBuffer": (sz, [vp]),
+            "JxlDecoderGetFrameHeader": (C.c_int, [vp, C.POINTER(JxlFrameHeader)]), "JxlDecoderGetFrameName": (C.c_int, [vp, C.c_char_p, sz]),
+            "JxlDecoderGetExtraChannelBlendInfo": (C.c_int, [vp, sz, C.POINTER(JxlBlendInfo)]), "JxlDecoderSkipFrames": (None, [vp, sz]),
+            "JxlDecoderSkipCurrentFrame": (C.c_int, [vp]), "JxlDecoderRewind": (None, [vp]),
             "JxlHipLastError": (C.c_char_p, []), "JxlHipBatchCreate": (vp, [C.c_int]), "JxlHipBatchDestroy": (None, [vp]),
             "JxlHipBatchAddImage": (C.c_int, [vp, vp, sz]), "JxlHipBatchGetBasicInfo": (C.c_int, [vp, C.c_int, C.POINTER(JxlBasicInfo)]),
             "JxlHipBatchOutBufferSize": (C.c_int, [vp, C.c_int, C.POINTER(JxlPixelFormat), C.POINTER(sz)]),

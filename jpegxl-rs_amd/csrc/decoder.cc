@@ -427,13 +427,28 @@ size_t Batch::OutputSize(const ImageHeader& ih, const OutputSpec& o) {
   const size_t bps = o.type == 0 ? 1 : o.type == 2 ? 4 : 2;
   return stride * (OrientedHeight(ih, o) - 1) + (size_t)OrientedWidth(ih, o) * nc * bps;
 }
+void Batch::OutputDims(int i, const OutputSpec& o, uint32_t* w, uint32_t* h) const {
+  const ImageEntry& first = *images_[pub_[i].first_unit];
+  *w = first.ih.xsize; *h = first.ih.ysize;
+  if (o.only_frame >= 0 && o.only_frame < pub_[i].num_units) { const FramePlan& p = images_[pub_[i].first_unit + o.only_frame]->plan; *w = p.frame_w; *h = p.frame_h; }
+}
+size_t Batch::OutputSizeOf(int i, const OutputSpec& o) const {
+  ImageHeader dims = images_[pub_[i].first_unit]->ih;       // (OutputStride / OutputSize only look at the size, the orientation and the channel list)
+  OutputDims(i, o, &dims.xsize, &dims.ysize);
+  return OutputSize(dims, o);
+}
 void Batch::SetOutput(int i, const OutputSpec& o) {
   ImageEntry& e = *images_[pub_[i].first_unit];
   e.out = o;
+  if (o.only_frame >= pub_[i].num_units) throw ParseError("non-coalesced output: no such frame", false);
+  // (a lone frame that fills the image is the same either way: the plain path keeps it)
+  if (o.only_frame == 0 && pub_[i].num_units == 1 && !e.plan.have_crop) e.out.only_frame = -1;
+  ImageHeader dims = e.ih;
+  OutputDims(i, e.out, &dims.xsize, &dims.ysize);
   uint32_t nc;
-  e.out_stride = OutputStride(e.ih, o, &nc);
+  e.out_stride = OutputStride(dims, o, &nc);
   e.out.num_channels = nc;
-  e.out_size = OutputSize(e.ih, o);
+  e.out_size = OutputSize(dims, o);
   prepared_ = false;
 }
 
@@ -554,6 +569,11 @@ void Batch::Prepare(void* stream_v) {
       if (first.ih.color_space == 1) throw ParseError("unsupported: spot colours on a grey image", true);
       if (first.ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels with spot colours", true);
       if (!pi.complex) { pi.complex = true; for (int u = pi.first_unit; u < pi.first_unit + pi.num_units; u++) images_[u]->complex = true; }
+    }
+    if (first.out.only_frame >= 0 && !pi.complex) {     // a single frame as coded: written by the frame tail (its own size, no blending)
+      if (first.ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels with non-coalesced output", true);
+      pi.complex = true;
+      for (int u = pi.first_unit; u < pi.first_unit + pi.num_units; u++) images_[u]->complex = true;
     }
     if (first.out.unpremul_alpha && premul && !pi.complex) {
       if (first.ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels with un-premultiplied output", true);
@@ -898,7 +918,10 @@ void Batch::Prepare(void* stream_v) {
   };
 
   vec<int> single;
-  for (int i = 0; i < n; i++) if (images_[i]->plan.single_section && !images_[i]->plan.modular) single.push_back(i);
+  for (int i = 0; i < n; i++) if (images_[i]->plan.single_section && !images_[i]->plan.modular) {
+    single.push_back(i);
+    images_[i]->plan.ac_code.clear();      // (a batch that is prepared again: HfGlobal is parsed afresh below, fill_frame must not look for its tables yet)
+  }
   if (!single.empty()) {
     // temporary upload of what exists so far
     uint8_t* tmpc = nullptr;
@@ -1440,6 +1463,31 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
           post_ops_.push_back([=](void* st) { LaunchColor(ca, st); });
           if (separate) { for (int c = 0; c < 3; c++) cur[c] = cb.rgb[c]; cur_stride = fw; }
         }
+      }
+      if (first.out.only_frame >= 0 && u == pi.first_unit + first.out.only_frame) {
+        // ---- non-coalesced output (JxlDecoderSetCoalescing(false)): this frame's own pixels after the colour transform, frame-sized, not
+        // blended; the frames before it have been composed as usual (it may draw patches from them), the ones after it are not needed
+        WriteArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        for (int c = 0; c < 3; c++) wa.p[c] = B(cur[c]);
+        wa.stride = cur_stride;
+        for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].type == 0) {
+          wa.alpha = B(cur_ec[k]); wa.alpha_stride = cur_ec_stride;
+          wa.unpremul = first.out.unpremul_alpha && ih.extra[k].alpha_associated && (first.out.num_channels == 2 || first.out.num_channels == 4);
+          break;
+        }
+        wa.img_w = fw; wa.img_h = fh;
+        wa.out = (uint8_t*)(first.out.device_ptr ? first.out.device_ptr : dwork_ + first.off_out);
+        wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian;
+        wa.out_orient = first.out.keep_orientation ? 1 : ih.orientation; wa.is_gray = ih.color_space == 1;
+        if (have_deferred_tf) {          // (the transfer function had been put off for a spot-colour stage this output does not run)
+          ColorArgs ta = deferred_tf;
+          for (int c = 0; c < 3; c++) { ta.src[c] = B(cur[c]); ta.dst[c] = B(cur[c]); }
+          ta.src_stride = ta.dst_stride = cur_stride; ta.w = fw; ta.h = fh;
+          post_ops_.push_back([=](void* st) { LaunchColor(ta, st); });
+        }
+        post_ops_.push_back([=](void* st) { LaunchWrite(wa, st); });
+        break;
       }
       // ---- blending onto the canvas
       bool replace_all = p.blend.mode == 0;

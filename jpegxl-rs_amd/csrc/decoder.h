@@ -20,6 +20,8 @@ struct OutputSpec {
   void* device_ptr = nullptr;  // optional caller-owned device destination
   bool keep_orientation = false;  // false: the header's orientation is applied to the output (libjxl's default)
   bool unpremul_alpha = false;    // JxlDecoderSetUnpremultiplyAlpha: premultiplied colour is divided by alpha in the write stage
+  int only_frame = -1;            // >= 0: non-coalesced output (JxlDecoderSetCoalescing(false)) — frame `only_frame` of the image as coded: its own size, its own
+                                  // pixels after the colour transform, not blended onto the canvas
   bool render_spotcolors = true;  // JxlDecoderSetRenderSpotcolors: spot-colour extra channels are mixed into the colour channels (stage_spot.cc)
 };
 
@@ -85,6 +87,11 @@ class Batch {
   static uint32_t OrientedWidth(const ImageHeader& ih, const OutputSpec& o);
   static uint32_t OrientedHeight(const ImageHeader& ih, const OutputSpec& o);
   static size_t OutputSize(const ImageHeader& ih, const OutputSpec& o);
+  // size of the rectangle output `o` of image i covers: the image, or — non-coalesced output — frame o.only_frame as coded (before orientation)
+  void OutputDims(int i, const OutputSpec& o, uint32_t* w, uint32_t* h) const;
+  size_t OutputSizeOf(int i, const OutputSpec& o) const;
+  int num_frames(int i) const { return pub_[i].num_units; }
+  const ImageEntry& frame(int i, int k) const { return *images_[pub_[i].first_unit + k]; }
   void SetOutput(int i, const OutputSpec& o);
   // Allocates device memory, uploads streams + tables (inputs become HBM-resident).  stream: hipStream_t.
   void Prepare(void* stream);

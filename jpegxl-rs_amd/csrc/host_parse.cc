@@ -817,14 +817,18 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
         if (b.mode != 0 || partial) b.source = r.u(2);
         if (b.alpha_channel >= std::max<size_t>(num_extra, 1)) Fail("blend alpha channel");
       }
-      if (ih.have_animation) { p->duration = r.U32({0, 0}, {0, 1}, {8, 0}, {32, 0}); if (ih.have_timecodes) r.u(32); }
+      if (ih.have_animation) { p->duration = r.U32({0, 0}, {0, 1}, {8, 0}, {32, 0}); if (ih.have_timecodes) p->timecode = r.u(32); }
       p->is_last = r.b();
     } else p->is_last = false;
     if (p->frame_type != 1 && !p->is_last) p->save_as_reference = r.u(2);
     bool can_ref = !p->is_last && p->frame_type != 1 && (p->duration == 0 || p->save_as_reference != 0);
     bool full_replace = (p->frame_type == 0 || p->frame_type == 3) && p->blend.mode == 0 && !partial;
     if (p->frame_type == 2 || (can_ref && full_replace)) p->save_before_ct = r.b();
-    SkipName(r);
+    {  // frame name (JxlDecoderGetFrameName)
+      const uint32_t n = r.U32({0, 0}, {4, 0}, {5, 16}, {10, 48});
+      p->name.clear();
+      for (uint32_t i = 0; i < n; i++) p->name.push_back((char)r.u(8));
+    }
     if (!r.b()) {  // RestorationFilter not all_default
       LoopFilterParams& lf = p->lf;
       lf.gab = r.b();

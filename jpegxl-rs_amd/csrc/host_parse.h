@@ -124,7 +124,8 @@ struct FramePlan {
   bool have_crop = false; int32_t x0 = 0, y0 = 0;
   uint32_t frame_w = 0, frame_h = 0;       // frame size after upsampling (width / height below are the coded size)
   BlendInfoH blend; vec<BlendInfoH> ec_blend;
-  uint32_t duration = 0, save_as_reference = 0; bool save_before_ct = false;
+  uint32_t duration = 0, timecode = 0, save_as_reference = 0; bool save_before_ct = false;
+  vec<char> name;                          // frame name (UTF-8, no terminator)
   float sigma_for_modular = 1.0f;
   FrameFeatures feat;
   uint64_t frame_end_bitpos = 0;           // first bit after the frame's last section (= next frame header)

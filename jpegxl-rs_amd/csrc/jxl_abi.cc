@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <memory>
 #include <string>
@@ -32,6 +33,8 @@ struct JxlDecoderStruct {
   enum Stage { kInit, kHeaders, kFrame, kDone } stage;
   int events_emitted;
   bool started, need_out_reported;
+  // frames as the caller counts them: every regular frame when coalescing is off, the composite (= the last frame) otherwise
+  vec<int> frames; size_t frame_cursor, skip_frames; bool frame_announced;
   Batch* batch;
   int device;
 };
@@ -56,8 +59,17 @@ static void ClearState(JxlDecoder* d) {
   d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
+  d->frames.clear(); d->frame_cursor = 0; d->skip_frames = 0; d->frame_announced = false;
   DeleteBatch(d->batch); d->batch = nullptr;
 }
+// frames JXL_DEC_FRAME / JXL_DEC_FULL_IMAGE are reported for
+static void ListFrames(JxlDecoder* d) {
+  d->frames.clear();
+  const int n = d->batch->num_frames(0);
+  if (d->coalescing) { d->frames.push_back(n - 1); return; }
+  for (int k = 0; k < n; k++) { const uint32_t t = d->batch->frame(0, k).plan.frame_type; if (t == 0 || t == 3) d->frames.push_back(k); }
+}
+static int CurrentFrame(const JxlDecoder* d) { return d->batch && d->frame_cursor < d->frames.size() ? d->frames[d->frame_cursor] : -1; }
 
 extern "C" {
 
@@ -107,10 +119,58 @@ JxlDecoderStatus JxlDecoderSubscribeEvents(JxlDecoder* d, int events) {
 JxlDecoderStatus JxlDecoderSetKeepOrientation(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->keep_orientation = !!v; return JXL_DEC_SUCCESS; }
 JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->unpremul_alpha = !!v; return JXL_DEC_SUCCESS; }
 JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->render_spotcolors = !!v; return JXL_DEC_SUCCESS; }
-JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL v) {
-  if (d->started) return JXL_DEC_ERROR;
-  if (!v) { SetLastError("unsupported: non-coalesced frame output (frames are always composited on the GPU)"); return JXL_DEC_ERROR; }
-  d->coalescing = true;
+JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->coalescing = !!v; return JXL_DEC_SUCCESS; }
+void JxlDecoderSkipFrames(JxlDecoder* d, size_t amount) { d->skip_frames += amount; }
+JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* d) {
+  if (d->stage != JxlDecoderStruct::kFrame || !d->frame_announced) return JXL_DEC_ERROR;
+  d->frame_cursor++; d->frame_announced = false;
+  return JXL_DEC_SUCCESS;
+}
+void JxlDecoderRewind(JxlDecoder* d) {
+  JXL_MM_SCOPE(d);
+  // (libjxl: "resets the decoder like JxlDecoderReset, but keeps all settings"; the input has to be set again)
+  const int events = d->events_wanted; const bool ko = d->keep_orientation, up = d->unpremul_alpha, rs = d->render_spotcolors, co = d->coalescing;
+  const float it = d->desired_intensity_target; const JxlParallelRunner runner = d->runner; void* const ro = d->runner_opaque;
+  ClearState(d);
+  d->events_wanted = events; d->keep_orientation = ko; d->unpremul_alpha = up; d->render_spotcolors = rs; d->coalescing = co;
+  d->desired_intensity_target = it; d->runner = runner; d->runner_opaque = ro;
+}
+static void FillBlendInfo(const BlendInfoH& b, JxlBlendInfo* out) { out->blendmode = (JxlBlendMode)b.mode; out->source = b.source; out->alpha = b.alpha_channel; out->clamp = b.clamp ? 1 : 0; }
+JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h) {
+  const int k = CurrentFrame(d);
+  if (k < 0 || d->stage != JxlDecoderStruct::kFrame || !h) return JXL_DEC_ERROR;
+  const ImageEntry& e = d->batch->frame(0, k);
+  const FramePlan& p = e.plan;
+  memset(h, 0, sizeof(*h));
+  h->duration = p.duration; h->timecode = p.timecode; h->name_length = (uint32_t)p.name.size(); h->is_last = p.is_last ? 1 : 0;
+  if (d->coalescing) {                     // the composite: no crop, the image's size (jpegxl-sys codestream_header.rs:324-329)
+    h->layer_info.xsize = e.ih.xsize; h->layer_info.ysize = e.ih.ysize;
+    if (!d->keep_orientation && e.ih.orientation > 4) { h->layer_info.xsize = e.ih.ysize; h->layer_info.ysize = e.ih.xsize; }
+    h->is_last = 1;
+    return JXL_DEC_SUCCESS;
+  }
+  h->layer_info.have_crop = p.have_crop ? 1 : 0;
+  h->layer_info.crop_x0 = p.have_crop ? p.x0 : 0; h->layer_info.crop_y0 = p.have_crop ? p.y0 : 0;
+  h->layer_info.xsize = p.frame_w; h->layer_info.ysize = p.frame_h;
+  FillBlendInfo(p.blend, &h->layer_info.blend_info);
+  h->layer_info.save_as_reference = p.save_as_reference;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* d, char* name, size_t size) {
+  const int k = CurrentFrame(d);
+  if (k < 0 || d->stage != JxlDecoderStruct::kFrame || !name) return JXL_DEC_ERROR;
+  const vec<char>& n = d->batch->frame(0, k).plan.name;
+  if (size < n.size() + 1) return JXL_DEC_ERROR;
+  if (!n.empty()) memcpy(name, n.data(), n.size());
+  name[n.size()] = 0;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* d, size_t index, JxlBlendInfo* out) {
+  const int k = CurrentFrame(d);
+  if (k < 0 || d->stage != JxlDecoderStruct::kFrame || !out) return JXL_DEC_ERROR;
+  const FramePlan& p = d->batch->frame(0, k).plan;
+  if (index >= p.ec_blend.size()) return JXL_DEC_ERROR;
+  FillBlendInfo(p.ec_blend[index], out);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* d, float v) { if (v < 0) return JXL_DEC_ERROR; d->desired_intensity_target = v; return JXL_DEC_SUCCESS; }
@@ -177,7 +237,8 @@ JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixe
   if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
   if (o.num_channels != 0 && o.num_channels < 3 && d->batch->image(0).ih.color_space != 1) { SetLastError("number of channels is too low for colour output"); return JXL_DEC_ERROR; }
   o.keep_orientation = d->keep_orientation;
-  *size = Batch::OutputSize(d->batch->image(0).ih, o);
+  o.only_frame = d->coalescing ? -1 : CurrentFrame(d);
+  *size = d->batch->OutputSizeOf(0, o);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat* format, void* buffer, size_t size) {
@@ -187,7 +248,8 @@ JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat
   if (!FormatToSpec(format, &o)) return JXL_DEC_ERROR;
   if (o.num_channels != 0 && o.num_channels < 3 && d->batch->image(0).ih.color_space != 1) { SetLastError("number of channels is too low for colour output"); return JXL_DEC_ERROR; }
   o.keep_orientation = d->keep_orientation;
-  if (size < Batch::OutputSize(d->batch->image(0).ih, o)) return JXL_DEC_ERROR;
+  o.only_frame = d->coalescing ? -1 : CurrentFrame(d);
+  if (size < d->batch->OutputSizeOf(0, o)) return JXL_DEC_ERROR;
   d->out_buffer = buffer; d->out_size = size; d->out_format = *format; d->out_set = true;
   return JXL_DEC_SUCCESS;
 }
@@ -260,6 +322,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       DeleteBatch(d->batch);
       d->batch = hold.b; hold.b = nullptr;
       d->stage = JxlDecoderStruct::kHeaders;
+      ListFrames(d);
     }
     if (d->stage == JxlDecoderStruct::kHeaders) {
       if ((d->events_wanted & JXL_DEC_BASIC_INFO) && !(d->events_emitted & JXL_DEC_BASIC_INFO)) { d->events_emitted |= JXL_DEC_BASIC_INFO; return JXL_DEC_BASIC_INFO; }
@@ -273,9 +336,13 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       }
       d->stage = JxlDecoderStruct::kFrame;
     }
-    if (d->stage == JxlDecoderStruct::kFrame) {
-      if ((d->events_wanted & JXL_DEC_FRAME) && !(d->events_emitted & JXL_DEC_FRAME)) { d->events_emitted |= JXL_DEC_FRAME; return JXL_DEC_FRAME; }
-      if (!(d->events_wanted & JXL_DEC_FULL_IMAGE)) { d->stage = JxlDecoderStruct::kDone; return JXL_DEC_SUCCESS; }
+    while (d->stage == JxlDecoderStruct::kFrame) {
+      // one round per frame the caller sees: the composite (coalescing, one round) or every regular frame as coded
+      while (d->skip_frames > 0 && d->frame_cursor < d->frames.size() && !d->frame_announced) { d->frame_cursor++; d->skip_frames--; }
+      if (d->frame_cursor >= d->frames.size()) { d->stage = JxlDecoderStruct::kDone; return JXL_DEC_SUCCESS; }
+      if ((d->events_wanted & JXL_DEC_FRAME) && !d->frame_announced) { d->frame_announced = true; d->events_emitted |= JXL_DEC_FRAME; return JXL_DEC_FRAME; }
+      d->frame_announced = true;
+      if (!(d->events_wanted & JXL_DEC_FULL_IMAGE)) { d->frame_cursor++; d->frame_announced = false; continue; }
       if (d->jpeg_available && d->jpeg_set) {
         // the caller asked for the JPEG file: entropy decode on the GPU, Huffman re-encode on the host, written in one piece
         if (d->jpeg_bytes.empty()) {
@@ -310,7 +377,9 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       o.keep_orientation = d->keep_orientation;
       o.unpremul_alpha = d->unpremul_alpha;
       o.render_spotcolors = d->render_spotcolors;
+      o.only_frame = d->coalescing ? -1 : d->frames[d->frame_cursor];
       d->batch->SetOutput(0, o);
+      if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
       d->batch->Prepare(nullptr);
       d->batch->Run(nullptr);       // ══► the HIP hot path
       d->batch->Finish(nullptr);
@@ -318,13 +387,15 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         // callback output: the image is decoded as a whole on the device, then handed out row by row
         vec<uint8_t> host(d->batch->image(0).out_size);
         d->batch->CopyOutputToHost(0, host.data(), host.size(), nullptr);
-        JxlBasicInfo info;
-        FillBasicInfo(d->batch->image(0).ih, &info, d->keep_orientation);
+        uint32_t w = 0, h = 0;
+        d->batch->OutputDims(0, d->batch->image(0).out, &w, &h);
+        if (!d->keep_orientation && d->batch->image(0).ih.orientation > 4) std::swap(w, h);
         const size_t stride = d->batch->image(0).out_stride;
-        for (size_t y = 0; y < info.ysize; y++) d->out_callback(d->out_callback_opaque, 0, y, info.xsize, host.data() + y * stride);
+        for (size_t y = 0; y < h; y++) d->out_callback(d->out_callback_opaque, 0, y, w, host.data() + y * stride);
       } else d->batch->CopyOutputToHost(0, d->out_buffer, d->batch->image(0).out_size, nullptr);
-      d->stage = JxlDecoderStruct::kDone;
+      d->frame_cursor++; d->frame_announced = false;
       d->events_emitted |= JXL_DEC_FULL_IMAGE;
+      if (!d->coalescing) { d->out_set = false; d->out_buffer = nullptr; d->out_callback = nullptr; }     // every layer gets a buffer of its own size
       return JXL_DEC_FULL_IMAGE;
     }
     return JXL_DEC_SUCCESS;

@@ -192,6 +192,79 @@ def test_raw_ffi_sequence(jx):
     assert np.array_equal(buf, O.decode(fixture_bytes("sample.jxl")).pixels("u8", 3))
 
 
+def test_non_coalesced_frames_and_frame_headers(jx):
+    """JxlDecoderSetCoalescing(false) (jpegxl-sys decode.rs:622, forwarded by jpegxl-rs decode.rs:356-358): every regular frame arrives as coded —
+    JXL_DEC_FRAME (JxlDecoderGetFrameHeader: crop, size, blending, is_last), a buffer of the FRAME's size, its pixels un-blended — and equals
+    the decode of that frame written as an image of its own; reference-only frames are not delivered; SkipFrames / SkipCurrentFrame / Rewind."""
+    L = jx.libjxl()
+    big, small, img = S.synthetic_image(6, 600, 400), S.synthetic_image(9, 64, 48), S.synthetic_image(5, 200, 136)
+    stream = (S.encode_vardct_frame(big, S.frame(is_last=0, save_as_reference=1), seed=3, strategy_mix=2)
+              + S.encode_vardct_frame(img, S.frame(emit=1, is_last=0, frame_type=2, save_as_reference=2, save_before_ct=1, have_crop=1, canvas_w=600, canvas_h=400), seed=5)    # reference only: never delivered
+              + S.encode_vardct_frame(small, S.frame(emit=1, is_last=0, have_crop=1, crop_x0=300, crop_y0=160, canvas_w=600, canvas_h=400, blend_mode=1, blend_source=1), seed=4)
+              + S.encode_vardct_frame(img, S.frame(emit=1, have_crop=1, crop_x0=-30, crop_y0=300, canvas_w=600, canvas_h=400, blend_mode=0, blend_source=1), seed=5, epf_iters=2))
+    alone = [S.encode_vardct_frame(big, S.frame(), seed=3, strategy_mix=2), S.encode_vardct_frame(small, S.frame(), seed=4), S.encode_vardct_frame(img, S.frame(), seed=5, epf_iters=2)]
+    want = [O.decode(a).pixels("u8", 3) for a in alone]
+    geometry = [(0, 0, 0, 600, 400, 0, 0), (1, 300, 160, 64, 48, 1, 0), (1, -30, 300, 200, 136, 0, 1)]     # have_crop, x0, y0, w, h, blend mode, is_last
+    data = np.frombuffer(stream, np.uint8)
+    fmt = jx.JxlPixelFormat(3, jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+
+    def run(dec, expect_first):
+        got, headers, events, buf = [], [], [], None
+        while True:
+            st = L.JxlDecoderProcessInput(dec)
+            events.append(st)
+            if st == jx.JXL_DEC_FRAME:
+                fh = jx.JxlFrameHeader()
+                assert L.JxlDecoderGetFrameHeader(dec, C.byref(fh)) == 0
+                li = fh.layer_info
+                headers.append((li.have_crop, li.crop_x0, li.crop_y0, li.xsize, li.ysize, li.blend_info.blendmode, fh.is_last))
+                name = C.create_string_buffer(8)
+                assert L.JxlDecoderGetFrameName(dec, name, 8) == 0 and name.value == b"" and fh.name_length == 0
+            elif st == jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+                size = C.c_size_t()
+                assert L.JxlDecoderImageOutBufferSize(dec, C.byref(fmt), C.byref(size)) == 0
+                buf = np.zeros(size.value, np.uint8)
+                assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), buf.ctypes.data, size.value) == 0
+            elif st == jx.JXL_DEC_FULL_IMAGE:
+                got.append(buf)
+            elif st == jx.JXL_DEC_SUCCESS:
+                break
+            else:
+                assert st == jx.JXL_DEC_BASIC_INFO, (st, jx.last_error())
+        assert headers == geometry[expect_first:]
+        assert len(got) == len(want) - expect_first
+        for g, w_ in zip(got, want[expect_first:]):
+            assert np.array_equal(g, w_)
+        return events
+
+    dec = L.JxlDecoderCreate(None)
+    assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_FRAME | jx.JXL_DEC_FULL_IMAGE) == 0
+    assert L.JxlDecoderSetCoalescing(dec, 0) == 0
+    assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+    ev = run(dec, 0)
+    assert ev.count(jx.JXL_DEC_FRAME) == 3 and ev.count(jx.JXL_DEC_FULL_IMAGE) == 3
+    L.JxlDecoderRewind(dec)                                    # settings (events, coalescing off) stay; the input is set again
+    L.JxlDecoderSkipFrames(dec, 1)
+    assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+    run(dec, 1)
+    L.JxlDecoderDestroy(dec)
+    # the jpegxl-rs loop (decode.rs:207-325) with coalescing(false): one buffer, refilled per frame — the last layer is what is left in it
+    meta, px = jx.decoder_builder(coalescing=False, pixel_format=jx.PixelFormat(num_channels=3)).decode_with(stream, np.uint8)
+    assert (meta.width, meta.height) == (600, 400) and np.array_equal(px, want[2])
+    # coalesced (default): the composite, and a frame header that hides the layers
+    dec = L.JxlDecoderCreate(None)
+    assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_FRAME | jx.JXL_DEC_FULL_IMAGE) == 0
+    assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+    assert L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_FRAME
+    fh = jx.JxlFrameHeader()
+    assert L.JxlDecoderGetFrameHeader(dec, C.byref(fh)) == 0
+    assert (fh.layer_info.have_crop, fh.layer_info.xsize, fh.layer_info.ysize, fh.is_last) == (0, 600, 400, 1)
+    assert L.JxlDecoderSkipCurrentFrame(dec) == 0 and L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_SUCCESS
+    L.JxlDecoderDestroy(dec)
+    _, composite = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3)).decode_with(stream, np.uint8)
+    assert np.array_equal(composite, O.decode(stream).pixels("u8", 3))
+
+
 def independent_float_decode_of_sample_jpg():
     """Float decode of samples/sample.jpg that shares NO code with the oracle or the product: the Huffman-decoded JPEG coefficients
     and quant tables (tests/golden/sample_jpg_coefficients.npz, made by make_golden.py's own JPEG parser), the integer
