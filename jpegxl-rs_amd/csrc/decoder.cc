@@ -495,7 +495,15 @@ void Batch::StageBytes(uint64_t out[6]) const {
 // Testing: copies one of the device buffers of image i's first frame to the host (after a decode, JxlHipBatchDebugRead): the planes
 // between the stages ("debug_stop_after") and the inputs of the pixel stages.  Returns the bytes the buffer holds; copies min(that, cap).
 size_t Batch::DebugRead(int i, const std::string& name, int c, void* dst, size_t cap, void* stream_v) {
-  if (!prepared_ || i < 0 || (size_t)i >= pub_.size() || c < 0 || c > 2) throw ParseError("DebugRead: no such image / channel", false);
+  if (!prepared_ || i < 0 || (size_t)i >= pub_.size() || c < 0 || (c > 2 && name != "qtable") || c >= 51) throw ParseError("DebugRead: no such image / channel", false);
+  if (name == "qtable") {     // dequantisation table (1 / weight) of quant kind c / 3, channel c % 3: 64 x rows x cols floats (kKindRows / kKindCols)
+    const FrameDev& f0 = frames_host_[pub_[i].first_unit];
+    const size_t bytes = (size_t)64 * kKindRows[c / 3] * kKindCols[c / 3] * 4;
+    if (!f0.qtable[c]) throw ParseError("DebugRead: no such table", false);
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_v));
+    if (dst && cap) HIP_CHECK(hipMemcpy(dst, f0.qtable[c], std::min(bytes, cap), hipMemcpyDeviceToHost));
+    return bytes;
+  }
   const int u = pub_[i].first_unit;
   const FrameDev& f = frames_host_[u];
   const FramePlan& p = images_[u]->plan;
@@ -511,6 +519,7 @@ size_t Batch::DebugRead(int i, const std::string& name, int c, void* dst, size_t
   else if (name == "blk_info") { src = f.blk_info; bytes = nb * 4; }
   else if (name == "coef_off") { src = f.coef_off; bytes = nb * 4; }
   else if (name == "coeff") { src = f.coeff[c]; bytes = (size_t)p.num_groups * 65536 * 4; }
+  else if (name == "qtable") { throw ParseError("DebugRead: qtable takes kind * 3 + channel", false); }
   else if (name == "ytox") { src = f.ytox; bytes = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8); }
   else if (name == "ytob") { src = f.ytob; bytes = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8); }
   else throw ParseError("DebugRead: unknown buffer " + name, false);
@@ -535,6 +544,9 @@ int64_t Batch::Info(const std::string& name) const {
     if (name == "frame0_global_scale") return p.global_scale;
     if (name == "frame0_quant_lf") return p.quant_lf;
     if (name == "frame0_color_factor") return p.color_factor;
+    if (name == "frame0_x_qm_scale") return p.x_qm_scale;
+    if (name == "frame0_b_qm_scale") return p.b_qm_scale;
+    if (name == "frame0_xgroups") return p.xgroups;
   }
   if (name == "lf_simt_waves") return lf_simt_.num_lanes ? (lf_simt_.num_lanes + lf_simt_.lanes_per_wave - 1) / lf_simt_.lanes_per_wave : 0;
   return -1;

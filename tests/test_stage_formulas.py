@@ -152,3 +152,75 @@ def test_inverse_opsin_and_transfer_function(jx, tf):
     # the matrix rows sum terms of up to ~11 x the mixed values with cancellation: float32 leaves ~1e-6 absolute on values in [0, 1];
     # libjxl's sRGB curve is a rational approximation good to ~1e-6 as well
     assert np.abs(got - want).max() <= (4e-6 if tf == "linear" else 1.5e-5), float(np.abs(got - want).max())
+
+
+# ---- dequantisation + chroma from luma + inverse DCT -------------------------------------------------------------------------------------
+# covered blocks (columns, rows) and quantisation-table kind of the plain DCT strategies (ac_strategy.h; IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 /
+# AFV are transforms of their own and the 128 / 256 family is left out here)
+PLAIN = {0: (1, 1, 0), 4: (2, 2, 4), 5: (4, 4, 5), 6: (1, 2, 6), 7: (2, 1, 6), 8: (1, 4, 7), 9: (4, 1, 7), 10: (2, 4, 8), 11: (4, 2, 8), 18: (8, 8, 11), 19: (4, 8, 12), 20: (8, 4, 12)}
+
+
+@pytest.mark.parametrize("w,h,mix,seed", [(256, 192, 0, 11), (512, 384, 1, 12), (520, 300, 2, 13)])
+def test_dequantisation_cfl_and_idct_follow_their_definition(jx, w, h, mix, seed):
+    """dec_group.cc / quantizer.h / dct-inl.h restated: coefficient = AdjustQuantBias(q) x table[k] x (65536 / global_scale) / hf_mul (x 0.8^(qm_scale - 2)
+    for X, B), X and B plus (base + map / colour_factor) x Y, the lowest frequencies replaced by the LLF values, then the separable inverse DCT in
+    libjxl's normalisation (coefficient 0 = block mean: scipy's orthonormal idctn of coefficients x sqrt(rows x cols)).  Inputs off the device:
+    quantised coefficients, block info, LLF planes, tables, CfL maps; output: the planes after the IDCT stage."""
+    from scipy.fft import idctn
+    data = S.encode_vardct(S.synthetic_image(seed, w, h), seed=seed, strategy_mix=mix, epf_iters=0, gab=0)
+    got, b = planes_after(jx, data, 1, 0, 0)
+    bw, bh, xgroups = b.info_value("frame0_bw"), b.info_value("frame0_bh"), b.info_value("frame0_xgroups")
+    info = b.debug_read(0, "blk_info", dtype=np.uint32).reshape(bh, bw)
+    coef_off = b.debug_read(0, "coef_off", dtype=np.uint32).reshape(bh, bw)
+    # (the IDCT zeroes the coefficient planes it consumes: decode up to the HF stage again to read them)
+    b.decode_part(1); b.decode_part(3); b.finish()
+    coeff = [b.debug_read(0, "coeff", c, dtype=np.int32).astype(np.float64) for c in range(3)]
+    llf = [b.debug_read(0, "llf", c).reshape(bh, bw).astype(np.float64) for c in range(3)]
+    cw = (bw + 7) // 8
+    ytox = b.debug_read(0, "ytox", dtype=np.int8).astype(np.float64)
+    ytob = b.debug_read(0, "ytob", dtype=np.int8).astype(np.float64)
+    inv_global_scale = 65536.0 / b.info_value("frame0_global_scale")
+    colour_scale = 1.0 / b.info_value("frame0_color_factor")
+    dm = [0.8 ** (b.info_value("frame0_x_qm_scale") - 2.0), 1.0, 0.8 ** (b.info_value("frame0_b_qm_scale") - 2.0)]
+    bias = [1.0 - 0.05465007330715401, 1.0 - 0.07005449891748593, 1.0 - 0.049935103337343655, 0.145]
+    tables = {}
+    checked = worst = 0
+    scale = max(1e-3, float(np.abs(got).max()))
+    for by in range(bh):
+        for bx in range(bw):
+            word = int(info[by, bx])
+            if not (word >> 5) & 1:
+                continue                                     # not the first block of its varblock
+            s = word & 31
+            if s not in PLAIN or by * 8 >= h or bx * 8 >= w:
+                continue
+            cx, cy, kind = PLAIN[s]
+            R, Cc = cy * 8, cx * 8
+            hf_mul = ((word >> 8) & 0xFF) + 1
+            g = (by // 32) * xgroups + bx // 32
+            base = g * 65536 + int(coef_off[by, bx])
+            tile = (by // 8) * cw + bx // 8
+            k_cfl = [0.0 + ytox[tile] * colour_scale, 0.0, 1.0 + ytob[tile] * colour_scale]
+            # storage order of coefficient (v = vertical, u = horizontal frequency): transposed for blocks at least as tall as wide
+            vv, uu = np.mgrid[0:R, 0:Cc]
+            kidx = (uu * R + vv) if R >= Cc else (vv * Cc + uu)
+            deq = []
+            for c in range(3):
+                if (kind, c) not in tables:
+                    tables[(kind, c)] = b.debug_read(0, "qtable", kind * 3 + c).astype(np.float64)
+                q = coeff[c][base + kidx]
+                safe = np.where(q == 0, 1.0, q)
+                adj = np.where(q == 0, 0.0, np.where(np.abs(q) == 1, np.sign(q) * bias[c], q - bias[3] / safe))
+                deq.append(adj * tables[(kind, c)][kidx] * (inv_global_scale / hf_mul * dm[c]))
+            sem = [deq[0] + k_cfl[0] * deq[1], deq[1], deq[2] + k_cfl[2] * deq[1]]
+            for c in range(3):
+                sem[c][:cy, :cx] = llf[c][by:by + cy, bx:bx + cx]
+                want = idctn(sem[c] * np.sqrt(R * Cc), norm="ortho")
+                y0, x0 = by * 8, bx * 8
+                hh, ww = min(R, h - y0), min(Cc, w - x0)
+                err = float(np.abs(got[c][y0:y0 + hh, x0:x0 + ww] - want[:hh, :ww]).max())
+                worst = max(worst, err)
+            checked += 1
+    assert checked > (bw * bh) // 40, checked
+    # up to 64 x 64 terms summed in float32 against float64: a few 1e-6 of the largest values in play
+    assert worst <= 2e-5 * scale, (worst, scale)
