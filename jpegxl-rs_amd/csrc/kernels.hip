@@ -2827,7 +2827,7 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
 template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || f.subsampled || (*f.frame_flags & 1) != 0 || force_generic) return;
+  if (f.is_modular || f.subsampled || (*f.frame_flags & 1) != 0 || (force_generic & 3)) return;
   if (((*f.frame_flags & 4) != 0) != (TB == 8)) return;     // frames with a varblock that no 32x32 tile contains take the 64x64 tiles
   if (((*f.frame_flags & 8) != 0) != SPECIAL) return;
   const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -2926,9 +2926,13 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
     const uint32_t s = BI_Strategy(p.info), ix = BI_Ix(p.info), iy = BI_Iy(p.info);
     p.k0 = (iy * CoveredX(s) + ix) * 64 + (t & 15) * 4;      // this block's share of the varblock's coefficients
     const uint32_t kind = QuantKind(s), base = s_coff[p.bi] + p.k0;
+    if (force_generic & 4) {      // experiment (JXL_HIP_IDCT_NOCOEF, wrong pixels): what the stage would cost without the dense coefficient read
+      p.qy = p.qx = p.qb = make_int4(0, 0, 0, (int)(t & 1));
+    } else {
     p.qy = LdG(reinterpret_cast<const int4*>(cq[1] + base));
     p.qx = LdG(reinterpret_cast<const int4*>(cq[0] + base));
     p.qb = LdG(reinterpret_cast<const int4*>(cq[2] + base));
+    }
     // The HF stage only writes non-zero coefficients, so the planes must be zero again before the batch's next decode: every
     // kernel that consumes a block's coefficients for good puts zeros back where it found something else (a few MB per frame
     // instead of a 100 MB memset; IDENTITY / DCT2X2 / AFV blocks are read again, and cleared, by IdctRareSpecialKernel).
@@ -4161,6 +4165,7 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
   // 64x64 tiles for frames with varblocks beyond 32x32, 32x32 tiles (a quarter of the LDS) for the others; each in a
   // variant with and without the 8x8 special transforms.  Every frame is taken by exactly one of the four.
   const bool all = !cfg.idct_flags_known;
+  static const int nocoef = getenv("JXL_HIP_IDCT_NOCOEF") ? 4 : 0;
   {
     const int tiles_x = DivUp(max_bw, 8), tiles_y = DivUp(max_bh, 8);
     const dim3 grid(tiles_x * tiles_y, nframes);
@@ -4173,7 +4178,7 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     const dim3 grid(tiles_x * tiles_y, nframes);
     const size_t lds = 3 * TileGeom<4>::kPlane * sizeof(float);
     if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
-    if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+    if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct | nocoef);
   }
   if (cfg.any_subsampled) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
   // one wavefront per group: a group holds a few dozen of these blocks (x 3 channels, one lane each), three more wavefronts per workgroup
