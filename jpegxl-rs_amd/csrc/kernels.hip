@@ -3361,7 +3361,10 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
 // instead of 63.  Arithmetic and operation order are those of GaborishKernel / EpfKernel<1> / OutputKernel (mirroring
 // the inputs of the symmetric 3x3 kernel gives exactly the gaborish value at the mirrored coordinate).
 // =====================================================================================================================
-constexpr int kFtW = 32, kFtH = 24;
+#ifndef JXL_FTH
+#define JXL_FTH 24
+#endif
+constexpr int kFtW = 32, kFtH = JXL_FTH;   // (JXL_FTH: tile height, an A/B knob — 16 gives 10 KB of LDS per workgroup instead of 14)
 constexpr int kFinW = kFtW + 6, kFinH = kFtH + 6, kFinP = kFinW + 1;      // input region incl. halo 3, padded pitch
 constexpr int kFgW = kFtW + 4, kFgH = kFtH + 4, kFgP = kFgW + 1;          // gaborish region incl. halo 2
 constexpr size_t kFusedLds = (size_t)(3 * kFinH * kFinP) * sizeof(float);   // the gaborish tile reuses the input tile's LDS (14 KB)
