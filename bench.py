@@ -2,16 +2,26 @@
 """bench.py — Mpixel/s of JPEG XL VarDCT (d1) decode of 3840x2160 frames on MI355X (BASELINE.json metric).
 
 A "step" decodes one batch of B synthetic 4K VarDCT frames per GPU (u8 RGB out) through the C-ABI batch API
-(include/jxl_hip.h): compressed streams and tables are HBM-resident before the timed region, decoded pixels stay in
-HBM (a torch tensor).  With N > 1 ranks every rank decodes its own shard of the batch (weak scaling, no data-path
-collective) and the decoded pixels are gathered to rank 0 over RCCL (BASELINE.json north_star).
+(include/jxl_hip.h); decoded pixels stay in HBM (a torch tensor).  Two modes, both run by default:
+
+  streaming (the headline `value`): every step decodes a batch of FRESH inputs.  Prepare workers refill a ring of batch objects
+      (JxlHipBatchReset / AddImages: parse on host threads into pinned staging; Prepare: tables + upload on a copy stream) and
+      enqueue the latency-bound LF stage on side streams, ten or so batches ahead; the main thread issues HF decode, IDCT and the
+      filter / write stages of step k.  The host never holds a decoded stream longer than the ring.
+  resident (`resident_mpixel_per_s`): the same pipeline over batch objects prepared before the timed region — compressed streams
+      and tables are in HBM when the clock starts (the configuration round 2's number was quoted on).
+
+`workload_realistic` repeats the headline mode on frames with photograph-like texture (1.5 - 2.5 bits per pixel).
+With N > 1 ranks every rank decodes its own shard of the batch (weak scaling, no data-path collective) and the decoded pixels are
+gathered to rank 0 over RCCL (BASELINE.json north_star); `decode_only_mpixel_per_s` / `gather_ms` split the two.
 --scaling strong --total-frames T fixes the job instead (BASELINE config 3: 1024 frames over the node): every rank decodes
 T / N frames per step, in chunks of at most --batch.
 
-Besides the headline (steady state, three batches in flight) the N = 1 line reports what a caller of the drop-in API sees:
-single_frame_ms (config 2: one 4K frame through decode_with, host to host), one_pass (config-3 shape: a fresh batch of 128
-frames decoded once, cold, no pipelining, with and without the host-side parse + upload), pcie_inclusive (the same pass plus
-the copy of the pixels back to host memory) and verified_vs_oracle (pixels of the timed batches against the CPU oracle).
+Besides the headline the N = 1 line reports what a caller of the drop-in API sees: single_frame_ms (config 2: one 4K frame through
+decode_with, host to host), one_pass (config-3 shape: a fresh batch of 128 frames decoded once, cold, no pipelining, with and
+without the host-side parse + upload), pcie_inclusive (the same pass plus the copy of the pixels back to host memory),
+step_end_ms / steady_state_ms_per_step (the pipeline fill is inside the K timed steps) and verified_vs_oracle (pixels of the
+timed batches against the CPU oracle).
 
 Contract: python bench.py --gpus N --steps K --warmup W  → rank 0 prints ONE JSON line.
 """
