@@ -63,10 +63,21 @@ def _textured(img, amp, seed):
 def _make_stream(args):
     import synth_lib as S
     seed, width, height, epf, texture = args
+    # (JXL_BENCH_STREAM_CACHE=<dir>: keep the synthesised streams between runs of a parameter sweep on one box; unset in a plain run)
+    cache = os.environ.get("JXL_BENCH_STREAM_CACHE")
+    path = os.path.join(cache, f"s{seed}_{width}x{height}_e{epf}_t{texture}.jxl") if cache else None
+    if path and os.path.exists(path):
+        return open(path, "rb").read()
     img = S.synthetic_image(seed, width, height)
     if texture:
         img = _textured(img, texture, seed)
-    return S.encode_vardct(img, seed=seed, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1)
+    data = S.encode_vardct(img, seed=seed, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1)
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        with open(path + f".{os.getpid()}", "wb") as fh:
+            fh.write(data)
+        os.replace(path + f".{os.getpid()}", path)
+    return data
 
 
 def make_streams(distinct, width, height, epf, seed0=1000, texture=0.0):

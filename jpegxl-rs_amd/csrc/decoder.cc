@@ -4,6 +4,7 @@
 #include <exception>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <map>
 #include <queue>
 #include <hip/hip_runtime.h>
@@ -145,16 +146,18 @@ bool ClassifyLfChannel(const HostTree& tree, const HostCode& code, int chan, uin
     }
   }
   if (pred < 0) return false;
-  for (int i = 0; i < 1024; i++) {
-    const int32_t v = i - 512;
-    uint32_t pos = 0;
-    for (;;) {
-      const TreeNode& n = nd[pos];
-      if (n.prop < 0) break;
-      const int32_t pv = n.prop == 0 ? chan : n.prop == 1 ? (int32_t)stream_id : v;
-      pos = pv > n.val ? n.a : n.b;
+  {  // the table, by pushing the value range [-512, 511] down the tree (a split at `val` sends (val, hi] to child a, [lo, val] to child b):
+     // every reachable node once instead of a walk from the root per value — 7 tables per LF group of every frame add up in a streaming loop
+    struct Range { uint32_t pos; int32_t lo, hi; };
+    vec<Range> stack{Range{0, -512, 511}};
+    while (!stack.empty()) {
+      const Range r = stack.back(); stack.pop_back();
+      const TreeNode& n = nd[r.pos];
+      if (n.prop < 0) { memset(out->lut + (r.lo + 512), code.ctx_map[n.a >> 8], (size_t)(r.hi - r.lo + 1)); continue; }
+      if (n.prop == 0 || n.prop == 1) { stack.push_back(Range{(n.prop == 0 ? chan : (int32_t)stream_id) > n.val ? n.a : n.b, r.lo, r.hi}); continue; }
+      if (r.hi > n.val) stack.push_back(Range{n.a, std::max(r.lo, n.val + 1), r.hi});
+      if (r.lo <= n.val) stack.push_back(Range{n.b, r.lo, std::min(r.hi, n.val)});
     }
-    out->lut[i] = code.ctx_map[nd[pos].a >> 8];
   }
   out->kind = prop < 0 ? 0 : prop == 2 ? 1 : 2;
   out->pred = (uint32_t)pred;
@@ -569,6 +572,17 @@ void Batch::Prepare(void* stream_v) {
   if (coef_owner_) dcoef_ = nullptr;
   if (big_owner_) dbig_ = nullptr;
   const int n = (int)images_.size();
+  // JXL_HIP_TIME_PREPARE=1: host milliseconds of the phases of this function on stderr
+  const bool time_phases = getenv("JXL_HIP_TIME_PREPARE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  std::string t_report;
+  auto mark = [&](const char* what) {
+    if (!time_phases) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64];
+    snprintf(buf, sizeof buf, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_report += buf; t_last = now;
+  };
   // un-premultiplying alpha (JxlDecoderSetUnpremultiplyAlpha, jpegxl-rs decode.rs:353) happens in the write stage of the frame tail
   for (PubImage& pi : pub_) {
     ImageEntry& first = *images_[pi.first_unit];
@@ -660,6 +674,7 @@ void Batch::Prepare(void* stream_v) {
       fplan_.any_gab |= p.lf.gab != 0; fplan_.max_epf = std::max<int>(fplan_.max_epf, p.lf.epf_iters);
     }
   }
+  mark("tables1");
   // ---- work arena layout: `take` = the per-batch arena (everything the LF stage writes, scratch, status, outputs);
   // `take_big` = coefficient and pixel planes, only touched between HF decode and the write stage (shareable)
   size_t w = 0, wbig = 0;
@@ -781,8 +796,26 @@ void Batch::Prepare(void* stream_v) {
     }
   }
   work_size_ = Align(w);
-  DevReserve((void**)&dwork_, &work_cap_, work_size_);
-  HIP_CHECK(hipMemsetAsync(dwork_, 0, work_size_, stream));
+  {
+    // The arena is cleared when it is new.  A refilled batch of plain VarDCT frames (the streaming loop: 14 MB of LF-stage outputs per 4K frame, 3.6 GB per
+    // batch of 256) only gets its status / flag / counter words zeroed: every kernel of that path writes what it reads later (valid streams) or treats what it
+    // finds as it treats the content of a damaged stream.  JXL_HIP_POISON_WORK=1 (tests) fills the rest with 0xCD even when new, to prove exactly that.
+    const bool fresh = DevReserve((void**)&dwork_, &work_cap_, work_size_);
+    static const bool poison = getenv("JXL_HIP_POISON_WORK") != nullptr;
+    bool plain = n > 0, cautious = false;     // cautious: one-group frames (the LF stage runs ahead, in this function) and output buffers inside the arena (row padding)
+    for (int i = 0; i < n; i++) {
+      const ImageEntry& e = *images_[i];
+      if (e.plan.modular || !e.plan.gchannels.empty() || e.complex) plain = false;
+      if (e.plan.single_section || (e.frame_index == 0 && !e.out.device_ptr)) cautious = true;
+    }
+    const size_t head = std::min(work_size_, Align(hfw_off_ + (size_t)n * 4));
+    if (plain && poison) {
+      HIP_CHECK(hipMemsetAsync(dwork_ + head, 0xCD, work_size_ - head, stream));
+      HIP_CHECK(hipMemsetAsync(dwork_, 0, head, stream));
+      for (int i = 0; i < n; i++) { const ImageEntry& e = *images_[i]; if (e.frame_index == 0 && !e.out.device_ptr) HIP_CHECK(hipMemsetAsync(dwork_ + e.off_out, 0, e.out_size + 64, stream)); }
+    } else if (plain && !cautious && !fresh) HIP_CHECK(hipMemsetAsync(dwork_, 0, head, stream));
+    else HIP_CHECK(hipMemsetAsync(dwork_, 0, work_size_, stream));
+  }
   big_size_ = Align(wbig);
   has_plane_b_ = need_plane_b;
   if (big_owner_) {
@@ -800,6 +833,7 @@ void Batch::Prepare(void* stream_v) {
     coef_dirty_ = true;                                // new planes, or another layout of them: the first decode clears them in its own stream
   }
   coef_laid_out_ = coeff_bytes_;
+  mark("layout+reserve");
   DevReserve((void**)&dframes_, &frames_cap_, sizeof(FrameDev) * std::max(n, 1));
 
   // ---- single-section VarDCT frames: HfGlobal starts where the device-decoded LfGroup ends.  Pre-run the LF stage
@@ -1006,6 +1040,7 @@ void Batch::Prepare(void* stream_v) {
       c.has_qtable[k] = true;
     }
   }
+  mark("hf_tables");
   {  // LDS right-sizing for the decode kernels
     auto code_bytes = [](const HostCode& c, bool ctx) { if (c.use_prefix) return 16;   /* prefix codes are read from global memory: nothing to size the LDS for */
       return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
@@ -1047,6 +1082,7 @@ void Batch::Prepare(void* stream_v) {
     for (int i = 0; i < n; i++) upw[i] = co[i].up_weights;
     PlanPostOps(hconst_, upw);
   }
+  mark("misc");
   lf_simt_ = LfSimtPlan();
   // ---- varblock placement units: every 32-row band of every LF group of every VarDCT frame, the tallest / widest first (the lanes of a
   // wavefront then carry bands of similar length)
@@ -1139,6 +1175,7 @@ void Batch::Prepare(void* stream_v) {
       for (int i = 0; i < n; i++) if (!images_[i]->plan.modular && !simt_frame[i]) lf_simt_.any_legacy = 1;
     }
   }
+  mark("simt_plan");
   const_size_ = Align(hconst_.size());
   DevReserve((void**)&dconst_, &const_cap_, const_size_);
   HIP_CHECK(hipMemcpyAsync(dconst_, hconst_.data(), hconst_.size(), hipMemcpyHostToDevice, stream));
@@ -1147,10 +1184,13 @@ void Batch::Prepare(void* stream_v) {
   if (lf_simt_.num_lanes) {
     lf_simt_.streams = (const LfSimtStream*)(dconst_ + simt_streams_off); lf_simt_.lanes = (const LfSimtLane*)(dconst_ + simt_lanes_off); lf_simt_.luts = dconst_ + simt_luts_off;
   }
+  mark("fill_frames");
   HIP_CHECK(hipMemcpyAsync(dframes_, frames_host_.data(), sizeof(FrameDev) * n, hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipMemcpyAsync(dpasses_, passes_host_.data(), sizeof(PassDev) * passes_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipMemcpyAsync(dlocal_, local_host_.data(), sizeof(ModLocalDev) * local_host_.size(), hipMemcpyHostToDevice, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
+  mark("upload_wait");
+  if (time_phases) fprintf(stderr, "[jxl-hip] Prepare of %d frames (%.1f MB of tables and streams, %.1f MB work arena), ms:%s\n", n, hconst_.size() / 1e6, work_size_ / 1e6, t_report.c_str());
   cfg.any_multipass = any_multipass_ ? 1 : 0;
   if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
   if (cfg.any_subsampled) cfg.lane_stride_hf = 1;   // so do chroma-subsampled frames (per-channel block grids)
