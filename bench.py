@@ -251,7 +251,8 @@ class Pipeline:
             if key not in Pipeline._streams:
                 Pipeline._streams[key] = torch.cuda.Stream(device=dev, priority=priority)
             return Pipeline._streams[key]
-        self.sides = [S("lf", i, -1) for i in range(max(1, min(self.ahead, args.lf_streams)))] if self.pipeline else []
+        lf_prio = (lambda i: -1 if i == 0 else 0) if os.environ.get("JXL_BENCH_LF_PRIO") == "first" else (lambda i: -1)   # experiment: only the stream of the first cold LF stage is a high-priority one
+        self.sides = [S("lf", i, lf_prio(i)) for i in range(max(1, min(self.ahead, args.lf_streams)))] if self.pipeline else []
         self.comm = S("comm", 0) if self.do_gather else None            # RCCL gather overlaps the next step's decode
         self.hf_streams = [S("hf", i, -1) for i in range(self.nhf)]
         self.copy_streams = [S("copy", i) for i in range(max(1, args.prepare_threads))] if streaming else []

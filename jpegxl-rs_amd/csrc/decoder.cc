@@ -352,6 +352,16 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
     const bool ok = ih.color_default || ih.want_icc || ih.have_gamma || ih.tf == 13 || ih.tf == 8 || ih.tf == 17 || ih.tf == 1 || ih.tf == 16 || ih.tf == 18;
     if (!ok) throw ParseError("unsupported: output transfer function", true);
   }
+  if (ih.have_preview) {
+    // decode.cc: the preview is a frame of its own in front of the image's frames, its default size the PreviewHeader's.  It is decoded for callers that
+    // subscribe to JXL_DEC_PREVIEW_IMAGE only — jpegxl-rs never does (decode.rs:334-347) —, so the frame is stepped over: header + TOC say where it ends.
+    ImageHeader ph = ih;
+    ph.xsize = ih.preview_x; ph.ysize = ih.preview_y;
+    FramePlan pp;
+    ParseFrameStart(sh->cs, ph, bitpos, &pp, /*header_and_toc_only=*/true);
+    if (pp.frame_type != 0) throw ParseError("the preview must be a regular frame", false);
+    bitpos = pp.frame_end_bitpos;
+  }
   // every frame of the image (frame_header.cc): reference-only / zero-duration layers first, the last one is displayed
   vec<std::unique_ptr<ImageEntry>> units;
   uint32_t visible = 0, nonvisible = 0;

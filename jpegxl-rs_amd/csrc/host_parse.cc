@@ -697,7 +697,18 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
       ih->orientation = r.u(3) + 1;
       if (r.b()) ReadSizeHeader(r, &ih->intrinsic_x, &ih->intrinsic_y);
       ih->have_preview = r.b();
-      if (ih->have_preview) Unsupported("preview frame");
+      if (ih->have_preview) {   // headers.cc PreviewHeader
+        const bool div8 = r.b();
+        auto dim = [&]() { return div8 ? 8 * r.U32({0, 16}, {0, 32}, {5, 1}, {9, 33}) : r.U32({6, 1}, {8, 65}, {10, 321}, {12, 1345}); };
+        ih->preview_y = dim();
+        const uint32_t ratio = r.u(3);
+        if (ratio == 0) ih->preview_x = dim();
+        else {
+          static const uint32_t num[8] = {0, 1, 12, 4, 3, 16, 5, 2}, den[8] = {1, 1, 10, 3, 2, 9, 4, 1};
+          ih->preview_x = (uint32_t)((uint64_t)ih->preview_y * num[ratio] / den[ratio]);
+        }
+        if (ih->preview_x > 4096 || ih->preview_y > 4096) Fail("preview too large");
+      }
       ih->have_animation = r.b();
       if (ih->have_animation) {
         ih->tps_num = r.U32({0, 100}, {0, 1000}, {10, 1}, {30, 1});
@@ -762,7 +773,8 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
 static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p);
 static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p);
 
-void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* p) {
+void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* p, bool header_and_toc_only) {
+  const bool skip = header_and_toc_only;
   Reader r(cs, frame_bitpos);
   const size_t num_extra = ih.extra.size();
   const bool xyb = ih.xyb_encoded;
@@ -843,14 +855,14 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
       r.SkipExtensions();
     }
     r.SkipExtensions();
-    if (p->frame_type == 1 || use_lf_frame) Unsupported("LF frame");
-    for (auto e : ec_ups) if (e != p->upsampling) Unsupported("extra-channel upsampling different from the colour upsampling");
+    if (!skip && (p->frame_type == 1 || use_lf_frame)) Unsupported("LF frame");
+    if (!skip) for (auto e : ec_ups) if (e != p->upsampling) Unsupported("extra-channel upsampling different from the colour upsampling");
     (void)lf_level;
   }
   p->frame_w = fx; p->frame_h = fy;
   if (p->upsampling != 1) { fx = (fx + p->upsampling - 1) / p->upsampling; fy = (fy + p->upsampling - 1) / p->upsampling; }   // coded size
-  if (p->modular && (p->lf.gab || p->lf.epf_iters)) Unsupported("restoration filters on a Modular frame");
-  if (p->num_passes != 1 && p->modular) Unsupported("multi-pass Modular frame");
+  if (!skip && p->modular && (p->lf.gab || p->lf.epf_iters)) Unsupported("restoration filters on a Modular frame");
+  if (!skip && p->num_passes != 1 && p->modular) Unsupported("multi-pass Modular frame");
   if (p->num_passes > 11) Fail("number of passes");
   p->width = fx; p->height = fy;
   p->group_dim = p->modular ? (128u << p->group_size_shift) : 256u;
@@ -866,10 +878,10 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     for (int c = 0; c < 3; c++) { p->hs[c] = maxhs - kH[p->jpeg_upsampling[c]]; p->vs[c] = maxvs - kV[p->jpeg_upsampling[c]]; p->subsampled |= p->hs[c] || p->vs[c]; }
     if (p->subsampled) {
       p->bw = ((fx + (8u << maxhs) - 1) / (8u << maxhs)) << maxhs; p->bh = ((fy + (8u << maxvs) - 1) / (8u << maxvs)) << maxvs;
-      if (!(p->flags & 128) || p->lf.gab || p->lf.epf_iters || p->upsampling != 1 || p->num_passes != 1)
+      if (!skip && (!(p->flags & 128) || p->lf.gab || p->lf.epf_iters || p->upsampling != 1 || p->num_passes != 1))
         Unsupported("chroma subsampling together with LF smoothing / restoration filters / upsampling / progressive passes");
     }
-  } else if (p->do_ycbcr) for (int c = 0; c < 3; c++) if (p->jpeg_upsampling[c]) Unsupported("chroma subsampling in a Modular frame");
+  } else if (p->do_ycbcr && !skip) for (int c = 0; c < 3; c++) if (p->jpeg_upsampling[c]) Unsupported("chroma subsampling in a Modular frame");
   // ---- TOC
   p->single_section = p->num_groups == 1 && p->num_passes == 1;
   size_t n = p->single_section ? 1 : 1 + p->num_lf_groups + 1 + (size_t)p->num_groups * p->num_passes;
@@ -901,6 +913,7 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   for (size_t i = 0; i < n; i++) p->sections[i] = perm.empty() ? phys[i] : phys[perm[i]];
   if (off > cs.size) throw ParseError("truncated", false);
   p->frame_end_bitpos = off * 8;
+  if (skip) return;
   // ---- LfGlobal
   Reader rg(cs, p->sections[0].offset * 8);
   rg.limit_bits = (p->sections[0].offset + p->sections[0].size) * 8;

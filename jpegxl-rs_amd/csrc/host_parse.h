@@ -52,6 +52,7 @@ struct ImageHeader {
   uint32_t orientation = 1;
   uint32_t intrinsic_x = 0, intrinsic_y = 0;
   bool have_preview = false, have_animation = false, have_timecodes = false;
+  uint32_t preview_x = 0, preview_y = 0;     // headers.cc PreviewHeader (the preview frame itself is skipped: nothing in jpegxl-rs asks for it)
   uint32_t tps_num = 0, tps_den = 0, num_loops = 0;
   BitDepthInfo depth;
   vec<ExtraChannel> extra;
@@ -197,7 +198,8 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
 // Parses frame header + TOC + LfGlobal (tables only).  On return plan->sections is filled and, for multi-section
 // frames, HfGlobal has been parsed too.  For single-section frames HfGlobal must be parsed later with ParseHfGlobal
 // at the bit position where the device-decoded LfGroup streams end.
-void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* plan);
+// header_and_toc_only: the frame is only stepped over (the preview frame): frame header and TOC give plan->frame_end_bitpos, nothing else is looked at
+void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* plan, bool header_and_toc_only = false);
 void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos, FramePlan* plan);
 
 // Dequantisation table (1/weight) of quant kind `kind`, channel c; natural coefficient order of a strategy.

@@ -202,6 +202,7 @@ static void FillBasicInfo(const ImageHeader& ih, JxlBasicInfo* info, bool keep_o
   info->relative_to_max_display = ih.relative_to_max_display; info->linear_below = ih.linear_below;
   info->uses_original_profile = !ih.xyb_encoded;
   info->have_preview = ih.have_preview; info->have_animation = ih.have_animation;
+  info->preview.xsize = ih.preview_x; info->preview.ysize = ih.preview_y;
   info->orientation = keep_orientation ? (int32_t)ih.orientation : 1;
   info->num_color_channels = ih.color_space == 1 ? 1 : 3;
   info->num_extra_channels = (uint32_t)ih.extra.size();

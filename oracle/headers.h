@@ -33,6 +33,7 @@ struct ImageMetadata {
   uint32_t orientation = 1;
   bool have_intrinsic = false; uint32_t intrinsic_x = 0, intrinsic_y = 0;
   bool have_preview = false, have_animation = false;
+  uint32_t preview_x = 0, preview_y = 0;
   uint32_t tps_num = 0, tps_den = 0, num_loops = 0; bool have_timecodes = false;
   BitDepth depth;
   bool modular_16bit = true;
@@ -247,6 +248,22 @@ inline void ReadSize(BitReader& br, uint32_t& xs, uint32_t& ys) {
   }
 }
 
+// headers.cc PreviewHeader: the size of the preview frame that precedes the frames of the image (at most 4096 x 4096)
+inline void ReadPreviewSize(BitReader& br, uint32_t& xs, uint32_t& ys) {
+  const bool div8 = br.Bool();
+  if (div8) ys = 8 * U32(br, Val(16), Val(32), BitsOffset(5, 1), BitsOffset(9, 33));
+  else ys = U32(br, BitsOffset(6, 1), BitsOffset(8, 65), BitsOffset(10, 321), BitsOffset(12, 1345));
+  const uint32_t ratio = br.u(3);
+  if (ratio == 0) {
+    if (div8) xs = 8 * U32(br, Val(16), Val(32), BitsOffset(5, 1), BitsOffset(9, 33));
+    else xs = U32(br, BitsOffset(6, 1), BitsOffset(8, 65), BitsOffset(10, 321), BitsOffset(12, 1345));
+  } else {
+    static const uint32_t num[8] = {0, 1, 12, 4, 3, 16, 5, 2}, den[8] = {1, 1, 10, 3, 2, 9, 4, 1};
+    xs = (uint32_t)((uint64_t)ys * num[ratio] / den[ratio]);
+  }
+  if (xs > 4096 || ys > 4096) JXLO_FAIL("preview too large");
+}
+
 inline void ReadBitDepth(BitReader& br, BitDepth& d) {
   d.float_sample = br.Bool();
   if (!d.float_sample) { d.bits = U32(br, Val(8), Val(10), Val(12), BitsOffset(6, 1)); d.exp_bits = 0; }
@@ -305,7 +322,7 @@ inline void ReadImageHeaders(BitReader& br, ImageMetadata& m) {
       m.have_intrinsic = br.Bool();
       if (m.have_intrinsic) ReadSize(br, m.intrinsic_x, m.intrinsic_y);
       m.have_preview = br.Bool();
-      if (m.have_preview) JXLO_FAIL("unsupported: preview frame");
+      if (m.have_preview) ReadPreviewSize(br, m.preview_x, m.preview_y);
       m.have_animation = br.Bool();
       if (m.have_animation) {
         m.tps_num = U32(br, Val(100), Val(1000), BitsOffset(10, 1), BitsOffset(30, 1));

@@ -207,6 +207,19 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
   for (size_t e = 0; e < num_extra; e++) ec_premul[e] = m.extra[e].alpha_associated;
   RefFrame refs[4];
   uint32_t visible_frame_index = 0, nonvisible_frame_index = 0;
+  if (m.have_preview) {
+    // decode.cc: the preview is a frame of its own in front of the image's frames (frame_header.cc: its default size is the PreviewHeader's).  Only a caller
+    // that subscribes to JXL_DEC_PREVIEW_IMAGE gets it decoded (jpegxl-rs never does, decode.rs:334-347): header and TOC are read to find where it ends.
+    ImageMetadata pm = m;
+    pm.xsize = m.preview_x; pm.ysize = m.preview_y;
+    FrameHeader ph;
+    ReadFrameHeader(br, pm, ph);
+    if (ph.type != kRegular) JXLO_FAIL("the preview must be a regular frame");
+    std::vector<Section> sec;
+    ReadTOC(br, ph.toc_entries(), sec);
+    if (sec.back().offset > cs.size()) JXLO_FAIL("truncated preview frame");
+    br.pos = sec.back().offset * 8;
+  }
   for (;;) {
     Frame f;
     ReadFrameHeader(br, m, f.fh);

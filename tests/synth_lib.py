@@ -244,6 +244,12 @@ def set_color(white_point=None, primaries=1, tf=13, gamma=0.0, intensity_target=
         L.jxlsynth_set_color(white_point, primaries, tf, int(round(gamma * 1e7)), intensity_target)
 
 
+def set_preview(w=0, h=0):
+    """The image headers written from now on announce a preview frame of w x h (0: none): the caller puts a frame of that size (emit=1) in front of the
+    image's frames."""
+    lib().jxlsynth_set_preview(int(w), int(h))
+
+
 def set_prefix(on=False):
     """Streams written from now on use prefix (Huffman) codes instead of ANS (cjxl -e 1..3); call without arguments to go back."""
     L = lib()

@@ -192,6 +192,35 @@ def test_raw_ffi_sequence(jx):
     assert np.array_equal(buf, O.decode(fixture_bytes("sample.jxl")).pixels("u8", 3))
 
 
+def test_preview_frames_are_stepped_over(jx):
+    """An image with a preview (headers.cc PreviewHeader; a frame of that size in front of the image's frames): jpegxl-rs never subscribes to
+    JXL_DEC_PREVIEW_IMAGE (decode.rs:334-347), so the preview is stepped over and the image decodes to what it decodes to without one;
+    JxlBasicInfo reports have_preview and the preview's size (jpegxl-sys codestream_header.rs:38-241)."""
+    from test_synth_roundtrip import preview_streams
+    L = jx.libjxl()
+    cases = preview_streams()
+    for name, with_preview, plain, (pw, ph) in cases:
+        ref = O.decode(plain).pixels("u8", 3)
+        _, px = check_against_oracle(jx, with_preview, np.uint8, 3)
+        assert np.array_equal(px.reshape(-1), ref), name
+        check_against_oracle(jx, with_preview, np.float32, 3)
+        dec = L.JxlDecoderCreate(None)
+        data = np.frombuffer(with_preview, np.uint8)
+        assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO) == 0
+        assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+        assert L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_BASIC_INFO
+        info = jx.JxlBasicInfo()
+        assert L.JxlDecoderGetBasicInfo(dec, C.byref(info)) == 0
+        assert (info.have_preview, info.preview_xsize, info.preview_ysize, info.xsize, info.ysize) == (1, pw, ph, 300, 200), name
+        L.JxlDecoderDestroy(dec)
+    b = jx.BatchDecoder(0)
+    for name, with_preview, plain, _ in cases:
+        b.add(with_preview, "uint8", 3); b.add(plain, "uint8", 3)
+    b.prepare(); b.decode(); b.finish()
+    for i in range(len(cases)):
+        assert np.array_equal(b.output(2 * i), b.output(2 * i + 1))
+
+
 def test_non_coalesced_frames_and_frame_headers(jx):
     """JxlDecoderSetCoalescing(false) (jpegxl-sys decode.rs:622, forwarded by jpegxl-rs decode.rs:356-358): every regular frame arrives as coded —
     JXL_DEC_FRAME (JxlDecoderGetFrameHeader: crop, size, blending, is_last), a buffer of the FRAME's size, its pixels un-blended — and equals

@@ -210,3 +210,31 @@ def test_prefix_coded_streams_decode_like_their_ans_twins():
         assert pfx != ans
         assert np.array_equal(O.decode(pfx).pixels("u8", 3), O.decode(ans).pixels("u8", 3))
         assert np.array_equal(O.decode(mod).pixels("u8", 3), img.reshape(-1))
+
+
+def preview_streams():
+    """(name, stream with a preview frame in front, the same image without): the preview is a frame of the PreviewHeader's size — VarDCT or Modular, also of
+    several groups — that a decoder without a JXL_DEC_PREVIEW_IMAGE subscriber steps over"""
+    import synth_lib as S
+    out = []
+    main = S.synthetic_image(71, 300, 200)
+    for name, pw, ph, modular in [("vardct_div8", 64, 48, False), ("modular_odd", 37, 23, True), ("vardct_multigroup", 520, 300, False)]:
+        prev = S.synthetic_image(72, pw, ph)
+        S.set_preview(pw, ph)
+        try:
+            hdr = S.encode_vardct_frame(main, S.frame(emit=2), seed=3)
+        finally:
+            S.set_preview(0, 0)
+        pf = S.encode_modular_frame(prev, S.frame(emit=1), bits=8) if modular else S.encode_vardct_frame(prev, S.frame(emit=1), seed=5)
+        body = S.encode_vardct_frame(main, S.frame(emit=1), seed=3)
+        out.append((name, hdr + pf + body, S.encode_vardct_frame(main, S.frame(emit=0), seed=3), (pw, ph)))
+    return out
+
+
+def test_preview_frames_are_stepped_over():
+    """headers.cc PreviewHeader + the preview frame (decode.cc): the image decodes to what it decodes to without the preview"""
+    import numpy as np
+    import oracle_lib as O
+    for name, with_preview, plain, _ in preview_streams():
+        assert len(with_preview) > len(plain)
+        assert np.array_equal(O.decode(with_preview).pixels("u8", 3), O.decode(plain).pixels("u8", 3)), name

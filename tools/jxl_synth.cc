@@ -420,19 +420,36 @@ static void WriteIccStream(BitWriter& w, const std::vector<uint8_t>& icc) {
   EncodeTokens(w, code, tok);
 }
 
+static int g_preview_w = 0, g_preview_h = 0;   // jxlsynth_set_preview: the image header announces a preview frame of this size (the caller emits it first)
+// headers.cc PreviewHeader
+static void WritePreviewSize(BitWriter& w, int xs, int ys) {
+  const bool div8 = xs % 8 == 0 && ys % 8 == 0;
+  auto dim = [&](int v) {
+    if (div8) WriteU32(w, (uint32_t)(v / 8), {0, 16}, {0, 32}, {5, 1}, {9, 33});
+    else WriteU32(w, (uint32_t)v, {6, 1}, {8, 65}, {10, 321}, {12, 1345});
+  };
+  w.put(div8 ? 1 : 0, 1);
+  dim(ys);
+  w.put(0, 3);     // ratio 0: the width follows
+  dim(xs);
+}
 static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool xyb, int bits, bool has_alpha, bool gray) {
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
   const bool custom_up = p.upsampling > 1 && p.custom_up_weights;
-  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set && !g_float_exp_bits;
+  const bool preview = g_preview_w > 0 && g_preview_h > 0;
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set && !g_float_exp_bits && !preview;
   w.put(all_default, 1);
   if (!all_default) {
     const bool custom_target = g_color.set && g_color.intensity_target != 255.0f;
-    bool extra_fields = p.hdr || p.orientation != 1 || custom_target;
+    bool extra_fields = p.hdr || p.orientation != 1 || custom_target || preview;
     w.put(extra_fields, 1);
     if (extra_fields) {
       w.put((uint32_t)(p.orientation - 1), 3);
-      w.put(0, 1); w.put(0, 1); w.put(0, 1);  // no intrinsic size / preview / animation
+      w.put(0, 1);                                  // no intrinsic size
+      w.put(preview ? 1 : 0, 1);
+      if (preview) WritePreviewSize(w, g_preview_w, g_preview_h);
+      w.put(0, 1);                                  // no animation
     }
     // BitDepth
     if (p.out_bits == 32) { w.put(1, 1); WriteU32(w, 32, {0, 32}, {0, 16}, {0, 24}, {6, 1}); w.put(8 - 1, 4); }
@@ -1241,6 +1258,7 @@ void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::Syntheti
 void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
 void jxlsynth_set_float(int exp_bits) { synth::g_float_exp_bits = exp_bits; }
 // entropy-coded streams written from now on in this thread use prefix (Huffman) codes instead of ANS — what cjxl's fast efforts emit
+void jxlsynth_set_preview(int w, int h) { synth::g_preview_w = w; synth::g_preview_h = h; }
 void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 // rgba == NULL: the extra channel is alpha again
 void jxlsynth_set_spot(const float* rgba) { synth::g_spot_set = rgba != nullptr; if (rgba) for (int i = 0; i < 4; i++) synth::g_spot[i] = rgba[i]; }
