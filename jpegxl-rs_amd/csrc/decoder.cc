@@ -364,18 +364,26 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
   }
   // every frame of the image (frame_header.cc): reference-only / zero-duration layers first, the last one is displayed
   vec<std::unique_ptr<ImageEntry>> units;
+  std::shared_ptr<ImageEntry> lf_frames[5];     // dec_cache.h dc_frames: the latest LF frame of every level (1 .. 4)
   uint32_t visible = 0, nonvisible = 0;
   for (int k = 0;; k++) {
     if (k >= 256) throw ParseError("unsupported: more than 256 frames", true);
     std::unique_ptr<ImageEntry> e(new ImageEntry(sh));
     e->has_jbrd = has_jbrd;
     e->frame_bitpos = bitpos;
-    e->frame_index = k;
+    e->frame_index = (int)units.size();   // (position among the units of the image: LF frames are none)
     e->pub_index = 0;                     // (set when the image is appended)
     ParseFrameStart(sh->cs, ih, bitpos, &e->plan);
     const FramePlan& p = e->plan;
     if (p.frame_type == 0 || p.frame_type == 3) { visible++; nonvisible = 0; } else nonvisible++;
     e->visible_frame_index = visible; e->nonvisible_frame_index = nonvisible;
+    if (p.use_lf_frame) {
+      // frame_header.cc kUseDcFrame: the LF image is the LF frame of the next level's samples, one per 8x8 block of this frame
+      const std::shared_ptr<ImageEntry>& src = lf_frames[p.lf_level + 1];
+      if (!src) throw ParseError("the LF frame this frame refers to is not in the stream", false);
+      if (p.subsampled || src->plan.width != p.bw || src->plan.height != p.bh) throw ParseError("LF frame of the wrong size", false);
+      e->lf_source = src;
+    }
     if (!p.modular) {
       for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
       if (p.has_global_tree && p.tree_code.lz77) throw ParseError("unsupported: LZ77 in the LF streams of a VarDCT frame", true);
@@ -399,6 +407,11 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
     if (p.feat.has_noise && !ih.xyb_encoded) throw ParseError("noise on a non-XYB frame", false);
     const bool last = p.is_last;
     bitpos = p.frame_end_bitpos;
+    if (p.frame_type == 1) {              // an LF frame: kept aside for the frames that refer to it (decoded by Batch::lf_batch_), never displayed
+      if (!ih.extra.empty()) throw ParseError("unsupported: LF frame of an image with extra channels", true);
+      lf_frames[p.lf_level] = std::shared_ptr<ImageEntry>(e.release());
+      continue;
+    }
     units.push_back(std::move(e));
     if (last) break;
   }
@@ -911,7 +924,8 @@ void Batch::Prepare(void* stream_v) {
       f.x_dm = std::pow(0.8f, (float)p.x_qm_scale - 2.0f); f.b_dm = std::pow(0.8f, (float)p.b_qm_scale - 2.0f);
       for (int k = 0; k < 4; k++) f.quant_bias[k] = e.ih.quant_bias[k];
       f.color_scale = 1.0f / (float)p.color_factor; f.base_x = p.base_x; f.base_b = p.base_b;
-      f.skip_lf_smoothing = (p.flags & 128) != 0;
+      f.skip_lf_smoothing = (p.flags & 128) != 0 || p.use_lf_frame;     // (dec_frame.cc FinalizeDC: no adaptive smoothing of an LF frame's samples)
+      f.use_lf_frame = p.use_lf_frame ? 1 : 0;
       f.gab = p.lf.gab; f.epf_iters = p.lf.epf_iters;
       for (int k = 0; k < 3; k++) {
         const float w1 = p.lf.gab_w[2 * k], w2 = p.lf.gab_w[2 * k + 1];
@@ -1127,7 +1141,7 @@ void Batch::Prepare(void* stream_v) {
     std::map<std::string, uint32_t> lut_of;       // table content -> offset in the blob (frames of one encoder share most tables)
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
-      if (p.modular || !p.has_global_tree || p.tree_code.use_prefix || p.tree_code.lz77 || p.tree_code.log_alpha > 8 || p.tree_code.num_clusters > 256) continue;
+      if (p.modular || !p.has_global_tree || p.tree_code.use_prefix || p.tree_code.lz77 || p.tree_code.log_alpha > 8 || p.tree_code.num_clusters > 256 || p.use_lf_frame) continue;
       vec<LfSimtStream> mine;
       bool ok = true;
       for (uint32_t g = 0; g < p.num_lf_groups && ok; g++) {
@@ -1201,6 +1215,34 @@ void Batch::Prepare(void* stream_v) {
   HIP_CHECK(hipStreamSynchronize(stream));
   mark("upload_wait");
   if (time_phases) fprintf(stderr, "[jxl-hip] Prepare of %d frames (%.1f MB of tables and streams, %.1f MB work arena), ms:%s\n", n, hconst_.size() / 1e6, work_size_ / 1e6, t_report.c_str());
+  // ---- LF frames the units refer to: a batch of their own, every LF frame a one-frame image of its own size that ends in its XYB planes (PlanPostOps)
+  {
+    vec<int> users;
+    for (int i = 0; i < n; i++) if (images_[i]->lf_source) users.push_back(i);
+    if (users.empty()) lf_batch_.reset();
+    else {
+      if (!lf_batch_) lf_batch_.reset(new Batch(device_)); else lf_batch_->Reset();
+      lf_batch_->lf_targets_.assign(users.size(), LfTarget());
+      for (size_t k = 0; k < users.size(); k++) {
+        const ImageEntry& user = *images_[users[k]];
+        const ImageEntry& src = *user.lf_source;
+        std::shared_ptr<ImageShared> sh(new ImageShared());
+        sh->cs = src.cs; sh->ih = src.ih;
+        sh->ih.xsize = src.plan.width; sh->ih.ysize = src.plan.height; sh->ih.orientation = 1; sh->ih.intrinsic_x = sh->ih.intrinsic_y = 0; sh->ih.have_preview = false;
+        std::unique_ptr<ImageEntry> e(new ImageEntry(sh));
+        e->plan = src.plan; e->frame_bitpos = src.frame_bitpos; e->frame_index = 0; e->complex = true;
+        e->visible_frame_index = src.visible_frame_index; e->nonvisible_frame_index = src.nonvisible_frame_index;
+        e->lf_source = src.lf_source;                      // (an LF frame may itself sit on the LF frame of the next level)
+        ParsedImage pi; pi.complex = true; pi.units.push_back(std::move(e));
+        lf_batch_->Append(std::move(pi));
+        LfTarget& t = lf_batch_->lf_targets_[k];
+        for (int c = 0; c < 3; c++) t.dst[c] = frames_host_[users[k]].lf[c];
+        t.pitch = user.plan.bw; t.w = user.plan.bw; t.h = user.plan.bh;
+      }
+      lf_batch_->cfg.lane_stride_lf = 64;
+      lf_batch_->Prepare(stream_v);
+    }
+  }
   cfg.any_multipass = any_multipass_ ? 1 : 0;
   if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
   if (cfg.any_subsampled) cfg.lane_stride_hf = 1;   // so do chroma-subsampled frames (per-channel block grids)
@@ -1486,6 +1528,19 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
         na.ytox = p.base_x; na.ytob = p.base_b;
         post_ops_.push_back([=](void* st) { LaunchNoise(na, st); });
       }
+      if (p.frame_type == 1) {
+        // an LF frame (this batch is another batch's lf_batch_): its planes, before any colour transform, are the LF image of the frame that refers to it
+        const int pub = e.pub_index;
+        const size_t s0 = cur[0], s1 = cur[1], s2 = cur[2];
+        post_ops_.push_back([=](void* st) {
+          if ((size_t)pub >= lf_targets_.size() || !lf_targets_[pub].dst[0]) return;
+          const LfTarget& t = lf_targets_[pub];
+          const size_t src[3] = {s0, s1, s2};
+          for (int c = 0; c < 3; c++)
+            HIP_CHECK(hipMemcpy2DAsync(t.dst[c], (size_t)t.pitch * 4, B(src[c]), (size_t)cur_stride * 4, (size_t)t.w * 4, t.h, hipMemcpyDeviceToDevice, (hipStream_t)st));
+        });
+        continue;
+      }
       const bool can_ref = !p.is_last && p.frame_type != 1 && (p.duration == 0 || p.save_as_reference != 0);
       if (can_ref && p.save_before_ct) {
         Slot& sl = slots[p.save_as_reference];
@@ -1712,6 +1767,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     rec(1);
   }
   if (do_lfpost) {
+    if (lf_batch_) lf_batch_->RunPart(stream_v, 0, false);     // LF frames: decoded to the end, their planes copied into the LF planes of the units that refer to them
     if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, max_groups_, stream_v);
     DebugSync("LF post", stream_v);
     if (part == 1 || part == 6) rec(2);
@@ -1786,6 +1842,7 @@ StageTimes Batch::CollectTimes(int* runs) {
 
 void Batch::Finish(void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
+  if (lf_batch_) lf_batch_->Finish(stream_v);            // (a damaged LF frame fails the decode like a damaged frame)
   HIP_CHECK(hipStreamSynchronize(stream));
   const int n = (int)images_.size();
   vec<uint32_t> status(n, 0);

@@ -43,6 +43,7 @@ struct ImageEntry {
   int pub_index = 0, frame_index = 0;  // image the frame belongs to, position among its frames
   bool complex = false;                // frame of a complex image
   uint32_t visible_frame_index = 0, nonvisible_frame_index = 0;   // noise seeds (dec_frame.cc)
+  std::shared_ptr<ImageEntry> lf_source;   // the LF frame (frame type 1) a frame with use_lf_frame takes its LF image from; not a unit of the batch itself
   // arena offsets
   size_t off_cs = 0, off_sec = 0, off_tree = 0, off_bcm = 0;
   size_t off_out = 0;
@@ -141,6 +142,11 @@ class Batch {
   };
   vec<ComplexBufs> cbufs_;
   vec<std::function<void(void*)>> post_ops_;
+  // ---- LF frames: the frames that units of this batch take their LF image from are decoded by a batch of their own (each as a one-frame image that ends
+  // in its XYB planes), run in front of this batch's LF post-processing; its frame tail copies the planes into the referring unit's LF planes
+  struct LfTarget { float* dst[3] = {nullptr, nullptr, nullptr}; uint32_t pitch = 0, w = 0, h = 0; };
+  std::unique_ptr<Batch> lf_batch_;
+  vec<LfTarget> lf_targets_;                   // (of the batch that decodes LF frames: per image, where its planes go)
   vec<std::unique_ptr<JpegData>> jpeg_data_;   // per image, parsed lazily by CanReconstructJpeg
   bool any_complex_ = false;
   void PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off);

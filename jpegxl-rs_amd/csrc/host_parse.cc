@@ -805,9 +805,12 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
       }
     }
     bool partial = false;
-    uint32_t lf_level = 0;
-    if (p->frame_type == 1) lf_level = r.U32({0, 1}, {0, 2}, {0, 3}, {0, 4});
-    else if (r.b()) {
+    p->use_lf_frame = use_lf_frame;
+    if (p->frame_type == 1) {
+      p->lf_level = r.U32({0, 1}, {0, 2}, {0, 3}, {0, 4});
+      const uint32_t d = 1u << (3 * p->lf_level);      // (frame_header.cc ToFrameDimensions: the image size divided by 8^level, rounded up)
+      fx = (fx + d - 1) / d; fy = (fy + d - 1) / d;
+    } else if (r.b()) {
       p->have_crop = true;
       if (p->frame_type != 2) {
         p->x0 = UnpackSigned(r.U32({8, 0}, {11, 256}, {14, 2304}, {30, 18688}));
@@ -855,9 +858,10 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
       r.SkipExtensions();
     }
     r.SkipExtensions();
-    if (!skip && (p->frame_type == 1 || use_lf_frame)) Unsupported("LF frame");
+    if (use_lf_frame && p->modular) Fail("use_lf_frame on a Modular frame");
+    if (use_lf_frame && p->frame_type == 1 && p->lf_level >= 4) Fail("LF frame level");
+    if (p->frame_type == 1 && (p->upsampling != 1 || (p->flags & (1 | 2 | 16)))) Fail("LF frame with upsampling / image features");
     if (!skip) for (auto e : ec_ups) if (e != p->upsampling) Unsupported("extra-channel upsampling different from the colour upsampling");
-    (void)lf_level;
   }
   p->frame_w = fx; p->frame_h = fy;
   if (p->upsampling != 1) { fx = (fx + p->upsampling - 1) / p->upsampling; fy = (fy + p->upsampling - 1) / p->upsampling; }   // coded size

@@ -120,6 +120,9 @@ struct FramePlan {
   uint32_t upsampling = 1, group_size_shift = 1, x_qm_scale = 3, b_qm_scale = 2;
   uint32_t num_passes = 1; uint32_t pass_shift[11] = {0};
   bool is_last = true;
+  // LF frames (frame_header.cc kDCFrame / kUseDcFrame): a frame of type 1 is the LF image — one sample per 8x8 block — of the frames one level below it
+  // (lf_level 1: of the regular frames); a frame with use_lf_frame has no LF coefficients of its own and reads the LF frame of level lf_level + 1
+  uint32_t lf_level = 0; bool use_lf_frame = false;
   LoopFilterParams lf;
   // compositing: position / size of the frame on the image canvas, blending, reference slots (frame_header.cc)
   bool have_crop = false; int32_t x0 = 0, y0 = 0;

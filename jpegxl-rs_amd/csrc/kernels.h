@@ -106,6 +106,7 @@ struct FrameDev {
   uint4* place_rec;               // varblock placement records (one per varblock, grouped per band: BandRecordBase), bw x bh entries
   uint32_t* place_cnt;            // [LF group * 8 + band] records of the band
   uint32_t* band_start;           // [LF group * 8 + band] index of the band's first entry in the LF group's strategy list (0xFFFFFFFF: damaged)
+  uint32_t use_lf_frame;          // frame_header.cc kUseDcFrame: no LF coefficients in the LfGroups, the LF image is an LF frame's samples (no dequantisation, no smoothing, LF context 0)
   uint32_t lf_simt;               // the LF-group streams of this frame are decoded by LfDecodeSimtKernel (one stream per lane), placement by LfPlaceKernel
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)

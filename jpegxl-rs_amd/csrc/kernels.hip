@@ -1221,8 +1221,9 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   mc.slow = f.mod_code.use_prefix;       // prefix-coded LF streams (cjxl's fast efforts): the general symbol reader
   uint32_t state = 0;
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
-  // ---- LF coefficients
-  if (lane == 0) {
+  // ---- LF coefficients (not in the stream of a frame that takes its LF image from an LF frame: frame_header.cc kUseDcFrame)
+  const bool has_lf = !f.use_lf_frame;
+  if (lane == 0 && has_lf) {
     s_u[0] = br.Read(2);  // extra_precision
     BitReader tmp;        // GroupHeader parsing reuses the generic reader type: re-sync positions around it
     tmp.Init(f.cs, br.BitPos(), f.cs_size);
@@ -1232,10 +1233,11 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     scratch[0] = (int32_t)s_u[0];
     scratch[1] = 0;
   }
+  if (lane == 0 && !has_lf) { scratch[0] = 0; scratch[1] = 0; state = 0x130000u; }
   WaveSync();
   if (s_fail) return;
   mc.wp = s_gh.wp; mc.stream_id = 1 + g;
-  {
+  if (has_lf) {
     const int chan_to_plane[3] = {1, 0, 2};  // stream channel order is Y, X, B
     for (int c = 0; c < 3; c++) {
       ChannelDesc ch;
@@ -1434,7 +1436,7 @@ __global__ __launch_bounds__(256) void LfPlaceExpandKernel(const FrameDev* __res
     uint32_t qf_idx = 0;
     for (uint32_t t = 0; t < bcm.n_qf_thr; t++) qf_idx += q + 1 > bcm.qf_thr[t];
     uint32_t lf_idx = 0;
-    if (bcm.num_lf_ctxs > 1) {
+    if (bcm.num_lf_ctxs > 1 && !f.use_lf_frame) {      // (dec_cache.cc: quant_dc is zero-filled when the LF image is an LF frame's)
       auto lfq_at = [&](int c) { return LdG(f.lfq[c] + (size_t)((bg.by0 + y) >> f.vs[c]) * f.bw + ((bg.bx0 + x) >> f.hs[c])); };   // (quant_dc is kept at full resolution)
       const int32_t q0 = lfq_at(0), q1 = lfq_at(1), q2 = lfq_at(2);
       uint32_t b0 = 0, b1 = 0, b2 = 0;
@@ -1702,7 +1704,7 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
 // =====================================================================================================================
 __global__ void LfDequantKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular) return;
+  if (f.is_modular || f.use_lf_frame) return;      // (use_lf_frame: f.lf holds the samples of the LF frame, copied there before this stage)
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= f.bw || y >= f.bh) return;
   if (f.subsampled) {
@@ -1932,7 +1934,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
       uint32_t qf_idx = 0;
       for (uint32_t i = 0; i < bcm.n_qf_thr; i++) qf_idx += qf > bcm.qf_thr[i];
       uint32_t lf_idx = 0;
-      if (bcm.num_lf_ctxs > 1) {
+      if (bcm.num_lf_ctxs > 1 && !f.use_lf_frame) {
         uint32_t b0 = 0, b1 = 0, b2 = 0;
         for (uint32_t i = 0; i < bcm.n_lf_thr[0]; i++) b0 += f.lfq[0][o] > bcm.lf_thr[0][i];
         for (uint32_t i = 0; i < bcm.n_lf_thr[1]; i++) b1 += f.lfq[1][o] > bcm.lf_thr[1][i];

@@ -464,7 +464,7 @@ inline void ReadPassGroup(BitReader& br, Frame& f, int pass_idx, int g) {
         const int ord = kOrderBucket[s];
         // LF context index from quantised LF
         int lf_idx = 0;
-        if (f.bcm.num_lf_ctxs > 1) {
+        if (f.bcm.num_lf_ctxs > 1 && !(f.fh.flags & kUseLfFrame)) {     // (dec_cache.cc: a frame that takes its LF from an LF frame has quant_dc zero-filled)
           int bX = 0, bY = 0, bB = 0;
           auto at = [&](int c) { return f.lfq[c][(size_t)((by0 + by) >> f.vs[c]) * f.bw + ((bx0 + bx) >> f.hs[c])]; };   // (quant_dc is kept at full resolution)
           for (int32_t t : f.bcm.lf_thresholds[0]) if (at(0) > t) bX++;

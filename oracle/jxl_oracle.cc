@@ -206,6 +206,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
   std::vector<bool> ec_premul(num_extra, false);
   for (size_t e = 0; e < num_extra; e++) ec_premul[e] = m.extra[e].alpha_associated;
   RefFrame refs[4];
+  struct LfFrame { bool valid = false; Image3 img; } lf_frames[4];     // dec_cache.h PassesSharedState::dc_frames
   uint32_t visible_frame_index = 0, nonvisible_frame_index = 0;
   if (m.have_preview) {
     // decode.cc: the preview is a frame of its own in front of the image's frames (frame_header.cc: its default size is the PreviewHeader's).  Only a caller
@@ -224,7 +225,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     Frame f;
     ReadFrameHeader(br, m, f.fh);
     const FrameHeader& fh = f.fh;
-    if (fh.type == kLFFrame || (fh.flags & kUseLfFrame)) JXLO_FAIL("unsupported: LF frames");
+    if (fh.type == kLFFrame && (fh.upsampling != 1 || (fh.flags & (kPatches | kSplines | kNoise)))) JXLO_FAIL("LF frame with upsampling / image features");
     if (fh.type == kRegular || fh.type == kSkipProgressive) { visible_frame_index++; nonvisible_frame_index = 0; } else nonvisible_frame_index++;
     const int up = (int)fh.upsampling;
     const float* up_weights = nullptr;
@@ -240,6 +241,15 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
       if (!(fh.flags & kSkipAdaptiveLFSmoothing) || fh.lf.gab || fh.lf.epf_iters || fh.upsampling != 1 || fh.passes.num_passes != 1)
         JXLO_FAIL("unsupported: chroma subsampling together with LF smoothing / restoration filters / upsampling / passes");
     }
+    if (fh.flags & kUseLfFrame) {
+      // dec_cache.cc InitializePassesSharedState: the LF image is the one the LF frame of the next level left (dc_frames[lf_level]; a regular frame is level 0),
+      // no LF coefficients in the LfGroups, no dequantisation, no adaptive smoothing (dec_frame.cc FinalizeDC)
+      if (fh.modular) JXLO_FAIL("use_lf_frame on a Modular frame");
+      if (fh.lf_level >= 4 || !lf_frames[fh.lf_level].valid) JXLO_FAIL("the LF frame this frame refers to has not been decoded");
+      const Image3& src = lf_frames[fh.lf_level].img;
+      if (src.w() != f.bw || src.h() != f.bh || f.subsampled) JXLO_FAIL("LF frame of the wrong size");
+      f.lf = src;
+    }
     f.dump = want_dump ? &out.dump : nullptr;
     DecodeFrameSections(cs.data(), cs.size(), br, f);
     out.tokens_lf += f.tokens_lf; out.tokens_hf += f.tokens_hf; out.tokens_modular += f.tokens_modular;
@@ -252,7 +262,7 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
     std::vector<float> inv_sigma;
     if (!fh.modular) {
       // ---- VarDCT ----
-      if (!(fh.flags & kSkipAdaptiveLFSmoothing)) {
+      if (!(fh.flags & kSkipAdaptiveLFSmoothing) && !(fh.flags & kUseLfFrame)) {
         float fac[3];
         const float inv_quant_lf = InvGlobalScale(f) / (float)f.quant_lf;
         for (int c = 0; c < 3; c++) fac[c] = f.m_lf[c] * inv_quant_lf;
@@ -335,6 +345,13 @@ void DecodeImage(const uint8_t* data, size_t size, Decoded& out, bool want_dump)
       if (!m.xyb_encoded) JXLO_FAIL("noise on a non-XYB frame");
       AddNoise(f.noise, visible_frame_index, nonvisible_frame_index, (int)fh.group_dim, y_to_x, y_to_b, img);
       if (want_dump) StorePlanes(out.dump, "noise", img);
+    }
+    if (fh.type == kLFFrame) {
+      // dec_frame.cc: an LF frame ends here — its samples (XYB, or whatever the image is coded in) are the LF image of the frames one level down
+      if (fh.lf_level < 1 || fh.lf_level > 4) JXLO_FAIL("LF level");
+      lf_frames[fh.lf_level - 1].valid = true;
+      lf_frames[fh.lf_level - 1].img = img;
+      continue;
     }
     JXLO_CHECK(img.w() == fw && img.h() == fhh);
     const bool can_ref = !fh.is_last && fh.type != kLFFrame && (fh.duration == 0 || fh.save_as_reference != 0);

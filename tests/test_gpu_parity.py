@@ -221,6 +221,34 @@ def test_preview_frames_are_stepped_over(jx):
         assert np.array_equal(b.output(2 * i), b.output(2 * i + 1))
 
 
+def test_lf_frames(jx):
+    """LF frames (frame_header.cc kDCFrame / kUseDcFrame, what `cjxl --progressive_dc` writes): the LF image of a frame travels as a
+    frame of its own at 1/8 scale — VarDCT or Modular, possibly on an LF frame of the next level itself —, and the frame that refers to it has no
+    LF coefficients, no LF dequantisation and no adaptive smoothing.  The HIP path decodes the LF frames in a batch of their own in front of the
+    LF post-processing of the frames that use them; against the oracle, alone and in batches beside ordinary frames (both LF decode kernels)."""
+    from test_synth_roundtrip import lf_frame_streams
+    cases = lf_frame_streams()
+    plain = S.encode_vardct(S.synthetic_image(81, 300, 200), seed=3)
+    refs = {}
+    for name, stream, img, _ in cases:
+        _, px = check_against_oracle(jx, stream, np.uint8, 3)
+        refs[name] = px.reshape(-1)
+        check_against_oracle(jx, stream, np.float32, 3)
+    want_plain = O.decode(plain).pixels("u8", 3)
+    for lf_stride in (64, 8):
+        b = jx.BatchDecoder(0)
+        order = []
+        for name, stream, _, _ in cases:
+            b.add(stream, "uint8", 3); order.append(name)
+            b.add(plain, "uint8", 3); order.append(None)
+        b.set_lane_stride(lf_stride, 1)
+        b.prepare()
+        for _ in range(2):                    # (decoded twice: the LF frames' batch is run again with the batch)
+            b.decode(); b.finish()
+            for i, name in enumerate(order):
+                assert np.array_equal(b.output(i), want_plain if name is None else refs[name]), (lf_stride, i, name)
+
+
 def test_non_coalesced_frames_and_frame_headers(jx):
     """JxlDecoderSetCoalescing(false) (jpegxl-sys decode.rs:622, forwarded by jpegxl-rs decode.rs:356-358): every regular frame arrives as coded —
     JXL_DEC_FRAME (JxlDecoderGetFrameHeader: crop, size, blending, is_last), a buffer of the FRAME's size, its pixels un-blended — and equals

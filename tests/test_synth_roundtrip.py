@@ -238,3 +238,55 @@ def test_preview_frames_are_stepped_over():
     for name, with_preview, plain, _ in preview_streams():
         assert len(with_preview) > len(plain)
         assert np.array_equal(O.decode(with_preview).pixels("u8", 3), O.decode(plain).pixels("u8", 3)), name
+
+
+def _block_means(img):
+    """1/8-scale image: the mean of every 8x8 block (edge blocks: of what exists)"""
+    import numpy as np
+    h, w, c = img.shape
+    bh, bw = (h + 7) // 8, (w + 7) // 8
+    pad = np.pad(img.astype(np.float64), ((0, bh * 8 - h), (0, bw * 8 - w), (0, 0)), mode="edge")
+    return np.clip(np.rint(pad.reshape(bh, 8, bw, 8, c).mean(axis=(1, 3))), 0, 255).astype(np.uint8)
+
+
+def lf_frame_streams():
+    """(name, stream, source image): images whose LF image travels as an LF frame (frame_type 1, `cjxl --progressive_dc`): a 1/8-scale VarDCT or
+    Modular frame first, then the frame proper with flag use_lf_frame and no LF coefficients in its LfGroups; also two levels (1/64 -> 1/8 -> 1)."""
+    import numpy as np
+    import synth_lib as S
+    out = []
+    for name, (w, h), lf_modular, levels, mix, epf in [("vardct_lf", (300, 200), False, 1, 1, 1), ("modular_lf", (264, 136), True, 1, 2, 2),
+                                                       ("two_levels", (2100, 600), False, 2, 1, 1), ("multi_lf_group", (2300, 400), False, 1, 2, 0)]:
+        img = S.synthetic_image(81, w, h)
+        small = _block_means(img)
+        hdr = S.encode_vardct_frame(img, S.frame(emit=2), seed=3)
+        parts = [hdr]
+        if levels == 2:
+            parts.append(S.encode_vardct_frame(_block_means(small), S.frame(emit=1, is_last=0, frame_type=1, lf_level=2), seed=7, distance=0.3, epf_iters=0, gab=0))
+        fx = S.frame(emit=1, is_last=0, frame_type=1, lf_level=1, use_lf_frame=1 if levels == 2 else 0, xyb_image=1 if lf_modular else 0)
+        if lf_modular:
+            # XYB samples as integers (dec_modular.cc: Y, X, B - Y in units of the LF dequantisation steps): any smooth picture will do
+            ints = np.stack([small[..., 1].astype(np.int32) * 2, small[..., 0].astype(np.int32) // 8 - 16, small[..., 2].astype(np.int32) // 4 - 32], axis=-1)
+            parts.append(S.encode_modular_frame(ints, fx, bits=8))
+        else:
+            parts.append(S.encode_vardct_frame(small, fx, seed=5, distance=0.3, epf_iters=0, gab=0))
+        parts.append(S.encode_vardct_frame(img, S.frame(emit=1, use_lf_frame=1), seed=3, strategy_mix=mix, epf_iters=epf))
+        out.append((name, b"".join(parts), img, lf_modular))
+    return out
+
+
+def test_lf_frames_feed_the_frames_that_refer_to_them():
+    """frame_header.cc kLFFrame / kUseLfFrame, dec_cache.cc dc_frames: the decode of an image whose LF image comes from an LF frame is the picture
+    (within what a distance-1 VarDCT frame loses whose LF image was made from block means of the sRGB samples and coded at distance 0.3); the Modular LF frame's arbitrary samples show up as
+    the picture's low frequencies, i.e. the frame is used at all"""
+    import numpy as np
+    import oracle_lib as O
+    for name, stream, img, lf_modular in lf_frame_streams():
+        d = O.decode(stream)
+        px = d.pixels("u8", 3).reshape(img.shape).astype(np.int32)
+        err = np.abs(px - img.astype(np.int32))
+        if lf_modular:
+            assert err.mean() > 20, name                      # the low frequencies are someone else's
+        else:
+            # (a plain distance-1 frame of these pictures: mean 1.7 - 1.9; the LF image here is the block means of the sRGB samples, re-quantised)
+            assert err.mean() < 6 and np.percentile(err, 99.9) < 70, (name, float(err.mean()), float(err.max()))

@@ -94,6 +94,8 @@ struct Params {
   int blend_mode = 0, blend_source = 0, blend_clamp = 0;   // colour and every extra channel use the same blending info
   int is_last = 1, save_as_reference = 0, save_before_ct = 0;
   int emit = 0;                                   // 0 image header + frame, 1 frame only, 2 image header only
+  int use_lf_frame = 0;                           // VarDCT: the LF image comes from the LF frame written before (flag 32: no LF coefficients in the LfGroups)
+  int lf_level = 0;                               // frame_type 1 (LF frame): its level (1: the LF image of the regular frames)
   int num_extra_hdr = -1;                         // extra channels announced by the image header (-1: as the frame has)
   int alpha_premultiplied = 0;                    // image header: alpha_associated
   int xyb_image = 0;                              // Modular frames: the image is XYB encoded (samples are Y, X, B - Y scaled by the LF factors)
@@ -524,14 +526,16 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   w.put(0, 1);  // all_default
   w.put((uint32_t)p.frame_type, 2);
   w.put(modular ? 1 : 0, 1);
-  WriteU64(w, ((!modular && p.skip_lf_smoothing) ? 0x80 : 0) | (p.noise ? 1 : 0) | (g_patches.empty() ? 0 : 2) | (g_splines.empty() ? 0 : 16));
+  WriteU64(w, ((!modular && p.skip_lf_smoothing) ? 0x80 : 0) | (p.noise ? 1 : 0) | (g_patches.empty() ? 0 : 2) | (g_splines.empty() ? 0 : 16) | ((!modular && p.use_lf_frame) ? 32 : 0));
   if (!xyb) {
     w.put(p.do_ycbcr ? 1 : 0, 1);
     if (p.do_ycbcr) for (int c = 0; c < 3; c++) w.put((uint32_t)p.jpeg_upsampling[c], 2);   // YCbCrChromaSubsampling, channels Cb, Y, Cr
   }
   const uint32_t ups_sel = p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : p.upsampling == 8 ? 3 : 0;
-  w.put(ups_sel, 2);      // upsampling
-  for (int i = 0; i < num_extra; i++) w.put(ups_sel, 2);   // ec_upsampling: same factor
+  if (modular || !p.use_lf_frame) {
+    w.put(ups_sel, 2);      // upsampling
+    for (int i = 0; i < num_extra; i++) w.put(ups_sel, 2);   // ec_upsampling: same factor
+  }
   if (modular) w.put(group_shift, 2);
   if (!modular && xyb) { w.put(3, 3); w.put(2, 3); }
   if (p.frame_type != 2) {
@@ -543,8 +547,9 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
     }
   }
   bool partial = false;
-  w.put(p.have_crop ? 1 : 0, 1);  // have_crop
-  if (p.have_crop) {
+  if (p.frame_type == 1) w.put((uint32_t)(p.lf_level - 1), 2);   // lf_level 1..4 (an LF frame has no crop: its size is the image's / 8^level)
+  else w.put(p.have_crop ? 1 : 0, 1);  // have_crop
+  if (p.frame_type != 1 && p.have_crop) {
     auto pack = [](int32_t v) { return v >= 0 ? (uint32_t)v * 2 : (uint32_t)(-v) * 2 - 1; };
     if (p.frame_type != 2) {
       WriteU32(w, pack(p.crop_x0), {8, 0}, {11, 256}, {14, 2304}, {30, 18688});
@@ -566,9 +571,9 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
     w.put(p.is_last ? 1 : 0, 1);  // is_last
   }
   const bool is_last = (p.frame_type == 0 || p.frame_type == 3) ? p.is_last != 0 : false;
-  if (!is_last) w.put((uint32_t)p.save_as_reference, 2);
+  if (!is_last && p.frame_type != 1) w.put((uint32_t)p.save_as_reference, 2);
   {
-    const bool can_ref = !is_last;      // (no animation: duration 0)
+    const bool can_ref = !is_last && p.frame_type != 1;      // (no animation: duration 0)
     const bool full_replace = (p.frame_type == 0 || p.frame_type == 3) && p.blend_mode == 0 && !partial;
     if (p.frame_type == 2 || (can_ref && full_replace)) w.put(p.save_before_ct ? 1 : 0, 1);
   }
@@ -972,9 +977,11 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   for (int g = 0; g < nlf; g++) {  // LfGroup
     BitWriter s;
     LfGroupData& d = lgd[g];
-    s.put(0, 2);  // extra_precision
-    s.put(1, 1); s.put(1, 1); s.put(0, 2);  // GroupHeader: use_global_tree, default WP, 0 transforms
-    EncodeTokens(s, mod_code, d.lf_tok);
+    if (!p.use_lf_frame) {
+      s.put(0, 2);  // extra_precision
+      s.put(1, 1); s.put(1, 1); s.put(0, 2);  // GroupHeader: use_global_tree, default WP, 0 transforms
+      EncodeTokens(s, mod_code, d.lf_tok);
+    }
     // (ModularLfGroup: no channels -> nothing)
     s.put(d.nb - 1, CeilLog2((uint32_t)(d.gbw * d.gbh)));
     s.put(1, 1); s.put(1, 1); s.put(0, 2);
@@ -1331,7 +1338,7 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
 // frame emitted with emit = 0) and any number of frames (emit = 1), the last one with is_last = 1.
 struct jxlsynth_frame {
   int32_t noise; uint32_t noise_lut[8];
-  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image, alpha_premultiplied;
+  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image, alpha_premultiplied, use_lf_frame, lf_level;
 };
 static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
   if (!fx) return;
@@ -1339,6 +1346,7 @@ static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
   p.frame_type = fx->frame_type; p.have_crop = fx->have_crop; p.crop_x0 = fx->crop_x0; p.crop_y0 = fx->crop_y0; p.canvas_w = fx->canvas_w; p.canvas_h = fx->canvas_h;
   p.blend_mode = fx->blend_mode; p.blend_source = fx->blend_source; p.blend_clamp = fx->blend_clamp; p.is_last = fx->is_last; p.save_as_reference = fx->save_as_reference;
   p.save_before_ct = fx->save_before_ct; p.emit = fx->emit; p.num_extra_hdr = fx->num_extra_hdr; p.xyb_image = fx->xyb_image; p.alpha_premultiplied = fx->alpha_premultiplied;
+  p.use_lf_frame = fx->use_lf_frame; p.lf_level = fx->lf_level;
 }
 int jxlsynth_vardct3(const uint8_t* rgb8, const uint8_t* alpha8, int w, int h, const jxlsynth_params* pp, const jxlsynth_frame* fx, uint8_t** out, size_t* n) {
   try {
