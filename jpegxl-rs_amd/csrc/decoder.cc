@@ -773,11 +773,11 @@ void Batch::Prepare(void* stream_v) {
         co[i].mod_chan = arena.Put(table.data(), table.size() * sizeof(ModChanDev));
         const size_t gd = p.group_dim;
         o.mod_scratch_stride = (8 + 4) * gd * gd + 4 * 65536;
-        o.mod_scratch = take(o.mod_scratch_stride * 4 * (p.num_lf_groups + p.num_groups));
+        o.mod_scratch = take(o.mod_scratch_stride * 4 * p.NumModUnits());
         o.hf_end = take((size_t)p.num_groups * 8);
         // the Modular streams keep their WP state apart from the LF streams'
         o.mod_wp_stride = p.tree.uses_wp ? 10 * (65536 + 2) : 16;
-        o.mod_wp = take(o.mod_wp_stride * 4 * (1 + p.num_lf_groups + p.num_groups));
+        o.mod_wp = take(o.mod_wp_stride * 4 * (1 + p.NumModUnits()));
       }
     } else {
       any_modchan_ = true;
@@ -790,13 +790,13 @@ void Batch::Prepare(void* stream_v) {
       co[i].mod_chan = arena.Put(table.data(), table.size() * sizeof(ModChanDev));
       const size_t gd = p.group_dim;
       o.mod_scratch_stride = (8 + 4) * gd * gd + 4 * 65536;
-      o.mod_scratch = take(o.mod_scratch_stride * 4 * (p.num_lf_groups + p.num_groups));
+      o.mod_scratch = take(o.mod_scratch_stride * 4 * p.NumModUnits());
       o.wp_scratch_stride = p.tree.uses_wp ? 10 * (65536 + 2) : 16;
-      o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.num_lf_groups + p.num_groups));
+      o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.NumModUnits()));
       if (e.complex) for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big((size_t)p.bw * 8 * p.bh * 8 * 4); o.plane_b[c] = (size_t)-1; }
     }
     if (!p.gchannels.empty() && p.has_global_tree && p.tree_code.lz77)   // LZ77 windows of the Modular streams (4 MiB each)
-      o.lz_window = take((size_t)(1 + p.num_lf_groups + p.num_groups) * (4u << 20));
+      o.lz_window = take((size_t)(1 + p.NumModUnits()) * (4u << 20));
     if (e.complex) {
       // buffers of the frame tail (PlanPostOps): float extra channels, upsampled planes, noise planes, colour-transformed planes
       // (only when the untransformed ones must survive as a reference frame), canvas (only when the frame is blended)
@@ -885,6 +885,8 @@ void Batch::Prepare(void* stream_v) {
       for (uint32_t v : p.tree_code.cfg) if (v != p.tree_code.cfg[0]) f.mod_cfg_uniform = 0xFFFFFFFFu;
     }
     f.uses_wp = p.tree.uses_wp; f.gwp = p.gwp;
+    f.mod_unit_passes = p.ModUnitPasses(); f.mod_pass = p.mod_pass;
+    for (int k = 0; k < 11; k++) { f.pass_min_shift[k] = p.pass_min_shift[k]; f.pass_max_shift[k] = p.pass_max_shift[k]; }
     f.tree_max_prop = (uint32_t)p.tree.max_prop;
     for (int k = 0; k < 3; k++) { f.hs[k] = p.hs[k]; f.vs[k] = p.vs[k]; }
     f.subsampled = p.subsampled;
@@ -1095,7 +1097,7 @@ void Batch::Prepare(void* stream_v) {
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
       local_first_[i] = total;
-      if (!p.local_streams.empty()) total += 1 + (size_t)p.num_lf_groups + p.num_groups;
+      if (!p.local_streams.empty()) total += 1 + (size_t)p.NumModUnits();
     }
     local_host_.assign(std::max<size_t>(total, 1), ModLocalDev());
     for (auto& d : local_host_) memset(&d, 0, sizeof(d));
@@ -1264,7 +1266,9 @@ void Batch::Run(void* stream_v) { RunPart(stream_v, 0, false); }
 // host-planned inverse transforms (and, for Modular frames, the write stage).
 void Batch::EnqueueModularTail(void* stream_v) {
   const int n = (int)images_.size();
-  LaunchModularGroups(dframes_, n, max_lf_groups_, max_groups_, cfg, stream_v);
+  int max_units = 1;
+  for (auto& im : images_) max_units = std::max<int>(max_units, (int)im->plan.NumModUnits());
+  LaunchModularGroups(dframes_, n, max_units, cfg, stream_v);
   for (int i = 0; i < n; i++) {
     for (const ModOp& op : mod_ops_[i]) {
       auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };

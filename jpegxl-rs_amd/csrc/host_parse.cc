@@ -798,12 +798,25 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     if (p->frame_type != 2) {
       p->num_passes = r.U32({0, 1}, {0, 2}, {0, 3}, {3, 4});
       if (p->num_passes != 1) {
-        uint32_t nds = r.U32({0, 0}, {0, 1}, {0, 2}, {1, 3});
+        p->num_ds = r.U32({0, 0}, {0, 1}, {0, 2}, {1, 3});
         for (uint32_t i = 0; i + 1 < p->num_passes; i++) p->pass_shift[i] = r.u(2);
-        for (uint32_t i = 0; i < nds; i++) r.U32({0, 1}, {0, 2}, {0, 4}, {0, 8});
-        for (uint32_t i = 0; i < nds; i++) r.U32({0, 0}, {0, 1}, {0, 2}, {3, 0});
+        for (uint32_t i = 0; i < p->num_ds; i++) p->downsample[i] = r.U32({0, 1}, {0, 2}, {0, 4}, {0, 8});
+        for (uint32_t i = 0; i < p->num_ds; i++) p->ds_last_pass[i] = r.U32({0, 0}, {0, 1}, {0, 2}, {3, 0});
       }
     }
+    if (p->num_passes > 11) Fail("number of passes");
+    for (uint32_t pass = 0; pass < p->num_passes; pass++) {     // passes.h GetDownsamplingBracket
+      int32_t mins = 3, maxs = 2;
+      for (uint32_t i = 0;; i++) {
+        for (uint32_t j = 0; j < p->num_ds; j++) if (i == p->ds_last_pass[j]) mins = p->downsample[j] == 8 ? 3 : p->downsample[j] == 4 ? 2 : p->downsample[j] == 2 ? 1 : 0;
+        if (i + 1 == p->num_passes) mins = 0;
+        if (i == pass) break;
+        maxs = mins - 1;
+      }
+      p->pass_min_shift[pass] = mins; p->pass_max_shift[pass] = maxs;
+    }
+    p->mod_pass = p->num_passes - 1;
+    for (uint32_t pass = 0; pass < p->num_passes; pass++) if (p->pass_min_shift[pass] <= 0 && p->pass_max_shift[pass] >= 0) { p->mod_pass = pass; break; }
     bool partial = false;
     p->use_lf_frame = use_lf_frame;
     if (p->frame_type == 1) {
@@ -866,7 +879,6 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   p->frame_w = fx; p->frame_h = fy;
   if (p->upsampling != 1) { fx = (fx + p->upsampling - 1) / p->upsampling; fy = (fy + p->upsampling - 1) / p->upsampling; }   // coded size
   if (!skip && p->modular && (p->lf.gab || p->lf.epf_iters)) Unsupported("restoration filters on a Modular frame");
-  if (!skip && p->num_passes != 1 && p->modular) Unsupported("multi-pass Modular frame");
   if (p->num_passes > 11) Fail("number of passes");
   p->width = fx; p->height = fy;
   p->group_dim = p->modular ? (128u << p->group_size_shift) : 256u;
@@ -1139,13 +1151,14 @@ static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
 // encoding.cc ModularDecode).  VarDCT frames keep such streams behind data only the device decodes: not parsed here.
 static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p) {
   if (!p->modular || p->single_section || p->global_decodable >= p->gchannels.size()) return;
-  const uint32_t total = p->num_lf_groups + p->num_groups;
+  const uint32_t total = p->NumModUnits();
   for (uint32_t unit = 0; unit < total; unit++) {
     const bool is_lf = unit < p->num_lf_groups;
-    const uint32_t g = is_lf ? unit : unit - p->num_lf_groups;
+    const uint32_t pass = is_lf ? 0 : (unit - p->num_lf_groups) / p->num_groups;
+    const uint32_t g = is_lf ? unit : (unit - p->num_lf_groups) % p->num_groups;
     const uint32_t dim = is_lf ? p->group_dim * 8 : p->group_dim, cols = is_lf ? p->xlfgroups : p->xgroups;
     const uint32_t x0 = (g % cols) * dim, y0 = (g / cols) * dim;
-    const int min_shift = is_lf ? 3 : 0, max_shift = is_lf ? 1000 : 2;
+    const int min_shift = is_lf ? 3 : p->pass_min_shift[pass], max_shift = is_lf ? 1000 : p->pass_max_shift[pass];
     size_t pixels = 0;
     for (size_t c = p->global_decodable; c < p->gchannels.size(); c++) {
       const auto& m = p->gchannels[c];
@@ -1157,7 +1170,7 @@ static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p) {
       pixels += (size_t)std::min(dim >> m.hshift, m.w - rx) * std::min(dim >> m.vshift, m.h - ry);
     }
     if (pixels == 0) continue;
-    const Section& sec = p->sections[is_lf ? 1 + g : 2 + p->num_lf_groups + g];
+    const Section& sec = p->sections[is_lf ? 1 + g : 2 + p->num_lf_groups + pass * p->num_groups + g];
     Reader r(cs, sec.offset * 8);
     r.limit_bits = (sec.offset + sec.size) * 8;
     if (r.b()) { if (!p->has_global_tree) Fail("global tree missing"); continue; }

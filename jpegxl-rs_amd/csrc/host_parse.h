@@ -119,6 +119,12 @@ struct FramePlan {
   uint32_t frame_type = 0; bool modular = false; uint64_t flags = 0; bool do_ycbcr = false;
   uint32_t upsampling = 1, group_size_shift = 1, x_qm_scale = 3, b_qm_scale = 2;
   uint32_t num_passes = 1; uint32_t pass_shift[11] = {0};
+  // passes.h GetDownsamplingBracket: the Modular channels PassGroup (pass, g) carries are those with pass_min_shift <= min(hshift, vshift) <= pass_max_shift
+  uint32_t num_ds = 0, downsample[4] = {0}, ds_last_pass[4] = {0};
+  int32_t pass_min_shift[11] = {0}, pass_max_shift[11] = {2};
+  uint32_t mod_pass = 0;                   // VarDCT frames: the pass whose sections carry the (unsqueezed) extra channels
+  uint32_t ModUnitPasses() const { return modular ? num_passes : 1; }      // Modular sub-streams per group the device decodes
+  uint32_t NumModUnits() const { return num_lf_groups + num_groups * ModUnitPasses(); }
   bool is_last = true;
   // LF frames (frame_header.cc kDCFrame / kUseDcFrame): a frame of type 1 is the LF image — one sample per 8x8 block — of the frames one level below it
   // (lf_level 1: of the regular frames); a frame with use_lf_frame has no LF coefficients of its own and reads the LF frame of level lf_level + 1

@@ -106,6 +106,9 @@ struct FrameDev {
   uint4* place_rec;               // varblock placement records (one per varblock, grouped per band: BandRecordBase), bw x bh entries
   uint32_t* place_cnt;            // [LF group * 8 + band] records of the band
   uint32_t* band_start;           // [LF group * 8 + band] index of the band's first entry in the LF group's strategy list (0xFFFFFFFF: damaged)
+  uint32_t mod_unit_passes;       // Modular sub-streams per group: the frame's passes (Modular frames), 1 (VarDCT frames: the extra channels' pass only, mod_pass)
+  uint32_t mod_pass;
+  int32_t pass_min_shift[11], pass_max_shift[11];   // passes.h GetDownsamplingBracket per pass: the channels (by min(hshift, vshift)) a PassGroup of that pass carries
   uint32_t use_lf_frame;          // frame_header.cc kUseDcFrame: no LF coefficients in the LfGroups, the LF image is an LF frame's samples (no dequantisation, no smoothing, LF context 0)
   uint32_t lf_simt;               // the LF-group streams of this frame are decoded by LfDecodeSimtKernel (one stream per lane), placement by LfPlaceKernel
   uint32_t* status;
@@ -176,7 +179,7 @@ void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, con
 // Modular stages
 struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; uint32_t float_bits, float_exp_bits; };   // float_bits != 0: colour samples are float bit patterns
 void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream);
-void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, const LaunchCfg& cfg, void* stream);
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_units, const LaunchCfg& cfg, void* stream);   // max_units: most LF groups + groups x passes of a frame
 // inverse Squeeze of one channel: (avg, res) -> out; horizontal: avg aw x h, res rw x h, out (aw+rw) x h; vertical: avg w x ah, res w x rh
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);

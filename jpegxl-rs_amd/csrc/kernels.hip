@@ -2246,7 +2246,7 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
     }
   }
   if (err) { SetError(f, err); dead = true; }
-  else if (!dead && f.hf_end_bitpos && pass + 1 == f.num_passes) f.hf_end_bitpos[g] = end_bitpos;   // the Modular part follows the last pass
+  else if (!dead && f.hf_end_bitpos && pass == f.mod_pass) f.hf_end_bitpos[g] = end_bitpos;   // the Modular part of the extra channels' pass follows its coefficients
   if (!dead && nz_total) { atomicAdd(f.hf_written, nz_total); nz_total = 0; }
   }  // passes
 }
@@ -3664,7 +3664,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   const FrameDev& f = frames[blockIdx.y];
   if (f.mod_nchan == 0 || f.single_section) return;
   if (local_pass ? !f.mod_local : !f.tree) return;   // (a frame without a global tree: every unit is decoded by the local pass)
-  const uint32_t total = f.num_lf_groups + f.num_groups;
+  const uint32_t total = f.num_lf_groups + f.num_groups * f.mod_unit_passes;
   const uint32_t nwaves = blockDim.x >> 6;          // 4, or 2 when every wavefront needs a large pruned-tree slice; 1 in the local pass
   if (blockIdx.x * nwaves >= total) return;
   const uint32_t first = f.mod_global_decodable;
@@ -3683,14 +3683,15 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   if (!local_pass && f.mod_local && f.mod_local[1 + unit].tree) return;   // decoded by the local pass
   const bool is_lf = unit < f.num_lf_groups;
   if (!f.is_modular && is_lf) return;            // VarDCT: extra channels are never squeezed here, so ModularLfGroup is empty
-  const uint32_t g = is_lf ? unit : unit - f.num_lf_groups;
+  // units after the LF groups: PassGroup (pass, g), pass-major — Modular frames: every pass; VarDCT frames: the pass that carries the extra channels
+  const uint32_t last_pass = is_lf ? 0 : f.is_modular ? (unit - f.num_lf_groups) / f.num_groups : f.mod_pass;
+  const uint32_t g = is_lf ? unit : (unit - f.num_lf_groups) % f.num_groups;
   const uint32_t dim = is_lf ? f.group_dim * 8 : f.group_dim;
   const uint32_t cols = is_lf ? f.xlfgroups : f.xgroups;
   const uint32_t x0 = (g % cols) * dim, y0 = (g / cols) * dim;
-  const int min_shift = is_lf ? 3 : 0, max_shift = is_lf ? 1000 : 2;
+  const int min_shift = is_lf ? 3 : f.pass_min_shift[last_pass], max_shift = is_lf ? 1000 : f.pass_max_shift[last_pass];
   __shared__ ModUnitShared s_unit[kLfWaves];
   ModUnitShared& U = s_unit[wave];
-  const uint32_t last_pass = f.is_modular ? 0 : f.num_passes - 1;       // VarDCT: extra channels ride in the last pass
   const uint32_t si = is_lf ? 1 + g : 2 + f.num_lf_groups + last_pass * f.num_groups + g;
   const uint64_t sec_end = f.sec_off[si] + f.sec_size[si];
   BitReaderP br;
@@ -4241,7 +4242,8 @@ static void PlanModularLds(const LaunchCfg& cfg, uint32_t* nwaves_io, uint32_t* 
   if (wp() && total() <= limit) { *wp_base = (*lds_tables + 15) & ~15u; *lds_total = *wp_base + wp(); }
   else { *wp_base = 0; *lds_total = *lds_tables; }
 }
-void LaunchModularGroups(const FrameDev* frames, int nframes, int max_lf_groups, int max_groups, const LaunchCfg& cfg, void* stream) {
+void LaunchModularGroups(const FrameDev* frames, int nframes, int max_units, const LaunchCfg& cfg, void* stream) {
+  const int max_lf_groups = max_units, max_groups = 0;
   uint32_t nwaves = kLfWaves, tree_cap, lds_tables, wp_base, lds_bytes;
   PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
   static bool attr_set = false;

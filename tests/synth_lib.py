@@ -20,11 +20,11 @@ class Frame(C.Structure):
     """Frame control of the synthesiser (tools/jxl_synth.cc jxlsynth_frame)."""
     _fields_ = [("noise", C.c_int32), ("noise_lut", C.c_uint32 * 8)] + [(n, C.c_int32) for n in (
         "frame_type", "have_crop", "crop_x0", "crop_y0", "canvas_w", "canvas_h", "blend_mode", "blend_source", "blend_clamp", "is_last",
-        "save_as_reference", "save_before_ct", "emit", "num_extra_hdr", "xyb_image", "alpha_premultiplied", "use_lf_frame", "lf_level")]
+        "save_as_reference", "save_before_ct", "emit", "num_extra_hdr", "xyb_image", "alpha_premultiplied", "use_lf_frame", "lf_level", "mod_passes", "mod_ds")]
 
 
 def frame(**kw):
-    f = Frame(is_last=1, num_extra_hdr=-1)
+    f = Frame(is_last=1, num_extra_hdr=-1, mod_passes=1, mod_ds=1)
     lut = kw.pop("noise_lut", None)
     if lut is not None:
         f.noise = 1

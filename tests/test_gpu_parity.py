@@ -249,6 +249,26 @@ def test_lf_frames(jx):
                 assert np.array_equal(b.output(i), want_plain if name is None else refs[name]), (lf_stride, i, name)
 
 
+def test_multipass_modular_frames(jx):
+    """Modular frames in several passes (frame_header.cc Passes, passes.h GetDownsamplingBracket): PassGroup (pass, group) carries the
+    channels whose shift falls into the pass's bracket.  The HIP path decodes every (pass, group) sub-stream as a unit of its own; lossless against the
+    source samples and the oracle, alone and in one batch."""
+    from test_synth_roundtrip import multipass_modular_streams
+    cases = multipass_modular_streams()
+    for name, data, img, bits in cases:
+        dt = np.uint16 if bits > 8 else np.uint8
+        _, px = check_against_oracle(jx, data, dt, img.shape[2])
+        assert np.array_equal(px.reshape(img.shape), img), name
+    b = jx.BatchDecoder(0)
+    for name, data, img, bits in cases:
+        b.add(data, "uint16" if bits > 8 else "uint8", img.shape[2])
+    b.prepare(); b.decode(); b.finish()
+    for i, (name, data, img, bits) in enumerate(cases):
+        got = b.output(i)
+        got = got.view(np.uint16) if bits > 8 else got
+        assert np.array_equal(got.reshape(img.shape), img), name
+
+
 def test_non_coalesced_frames_and_frame_headers(jx):
     """JxlDecoderSetCoalescing(false) (jpegxl-sys decode.rs:622, forwarded by jpegxl-rs decode.rs:356-358): every regular frame arrives as coded —
     JXL_DEC_FRAME (JxlDecoderGetFrameHeader: crop, size, blending, is_last), a buffer of the FRAME's size, its pixels un-blended — and equals

@@ -290,3 +290,25 @@ def test_lf_frames_feed_the_frames_that_refer_to_them():
         else:
             # (a plain distance-1 frame of these pictures: mean 1.7 - 1.9; the LF image here is the block means of the sRGB samples, re-quantised)
             assert err.mean() < 6 and np.percentile(err, 99.9) < 70, (name, float(err.mean()), float(err.max()))
+
+
+def multipass_modular_streams():
+    """(name, stream, source samples, bits): Modular frames in several passes (frame_header.cc Passes; passes.h GetDownsamplingBracket): the squeezed
+    channels are spread over the PassGroups of the passes by their shift — "responsive" lossless files"""
+    import synth_lib as S
+    out = []
+    for name, (h, w, c, bits), squeeze, passes, ds in [("three_passes", (300, 520, 3, 8), 1, 3, 1), ("two_passes", (300, 520, 3, 8), 1, 2, 1),
+                                                      ("no_entries_explicit_chain", (300, 520, 3, 8), 2, 2, 0), ("grey16_three", (700, 900, 1, 16), 1, 3, 1),
+                                                      ("one_group", (100, 90, 3, 8), 1, 3, 1), ("alpha_two", (260, 300, 4, 8), 1, 2, 1), ("unsqueezed", (300, 280, 3, 8), 0, 3, 1)]:
+        img = _smooth(5, h, w, c, bits)
+        out.append((name, S.encode_modular_frame(img, S.frame(mod_passes=passes, mod_ds=ds), bits=bits, squeeze=squeeze), img, bits))
+    return out
+
+
+def test_multipass_modular_frames_are_lossless():
+    import numpy as np
+    import oracle_lib as O
+    for name, data, img, bits in multipass_modular_streams():
+        px = O.decode(data).pixels("u16" if bits > 8 else "u8", img.shape[2])
+        px = px.view(np.uint16) if bits > 8 else px
+        assert np.array_equal(px.reshape(img.shape), img), name

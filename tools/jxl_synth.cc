@@ -96,6 +96,9 @@ struct Params {
   int emit = 0;                                   // 0 image header + frame, 1 frame only, 2 image header only
   int use_lf_frame = 0;                           // VarDCT: the LF image comes from the LF frame written before (flag 32: no LF coefficients in the LfGroups)
   int lf_level = 0;                               // frame_type 1 (LF frame): its level (1: the LF image of the regular frames)
+  int mod_passes = 1;                             // Modular frames: passes (1 .. 3); the squeezed channels are spread over them by shift
+  int mod_ds = 1;                                 // ... with downsampling entries (passes.h GetDownsamplingBracket): pass i carries shift np - 1 - i (the first also 2);
+                                                  // 0: no entries — everything rides in the last pass, the others are empty
   int num_extra_hdr = -1;                         // extra channels announced by the image header (-1: as the frame has)
   int alpha_premultiplied = 0;                    // image header: alpha_associated
   int xyb_image = 0;                              // Modular frames: the image is XYB encoded (samples are Y, X, B - Y scaled by the LF factors)
@@ -539,11 +542,15 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   if (modular) w.put(group_shift, 2);
   if (!modular && xyb) { w.put(3, 3); w.put(2, 3); }
   if (p.frame_type != 2) {
-    const int np = modular ? 1 : p.num_passes;
+    const int np = modular ? p.mod_passes : p.num_passes;
     w.put((uint32_t)(np - 1), 2);  // num_passes (1, 2, 3)
     if (np != 1) {
-      w.put(0, 2);                                         // num_downsample = 0
-      for (int i = 0; i + 1 < np; i++) w.put((uint32_t)PassShift(np, i), 2);   // shift of every pass but the last
+      const int nds = modular && p.mod_ds ? np - 1 : 0;
+      w.put((uint32_t)nds, 2);                             // num_downsample (0 .. 2)
+      for (int i = 0; i + 1 < np; i++) w.put(modular ? 0u : (uint32_t)PassShift(np, i), 2);   // shift of every pass but the last
+      // entry i: "pass i completes the image at 1 / (2 << (nds - 1 - i))" -> downsample 4, 2 (np = 3) or 2 (np = 2); U32(Val 1, 2, 4, 8)
+      for (int i = 0; i < nds; i++) w.put((uint32_t)(nds - i), 2);
+      for (int i = 0; i < nds; i++) w.put((uint32_t)i, 2);    // last_pass: U32(Val 0, 1, 2, Bits(3))
     }
   }
   bool partial = false;
@@ -1155,13 +1162,26 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
   t.num_leaves = leaf;
   std::vector<Token> tree_tokens;
   TreeTokens(t, bfs, tree_tokens);
-  bool single = ngroups == 1;
+  const int np = fx ? std::max(1, std::min(3, fx->mod_passes)) : 1;
+  const bool with_ds = fx ? fx->mod_ds != 0 : true;
+  bool single = ngroups == 1 && np == 1;
+  // passes.h GetDownsamplingBracket for the pass layout WriteFrameHeader announces
+  auto bracket = [&](int pass, int* mins, int* maxs) {
+    int mn = 3, mx = 2;
+    for (int i = 0;; i++) {
+      if (with_ds && i + 1 < np) mn = np - 1 - i;      // downsample 2^(np - 1 - i) completes at pass i
+      if (i == np - 1) mn = 0;
+      if (i == pass) break;
+      mx = mn - 1;
+    }
+    *mins = mn; *maxs = mx;
+  };
   // GlobalModular takes the leading channels that fit a group; the others go to LfGroups (shift >= 3) or PassGroups
   int nglobal = 0;
   while (nglobal < nfinal && ch[nglobal].w <= gd && ch[nglobal].h <= gd) nglobal++;
   std::vector<Token> global_tok;
-  std::vector<std::vector<Token>> lftok(nlf), gtok(ngroups);
-  std::vector<char> lf_has(nlf, 0), g_has(ngroups, 0);
+  std::vector<std::vector<Token>> lftok(nlf), gtok((size_t)ngroups * np);
+  std::vector<char> lf_has(nlf, 0), g_has((size_t)ngroups * np, 0);
   {
     std::vector<ChanRef> cr;
     for (int c = 0; c < nglobal; c++) if (ch[c].w && ch[c].h) cr.push_back({ch[c].d.data(), ch[c].w, ch[c].h});
@@ -1190,7 +1210,11 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
   };
   if (nglobal < nfinal) {
     for (int g = 0; g < nlf; g++) lf_has[g] = group_stream((g % xlg) * lfd, (g / xlg) * lfd, lfd, 3, 1000, 1 + nlf + g, lftok[g]);
-    for (int g = 0; g < ngroups; g++) g_has[g] = group_stream((g % xg) * gd, (g / xg) * gd, gd, 0, 2, 1 + 3 * nlf + 17 + g, gtok[g]);
+    for (int ps = 0; ps < np; ps++) {
+      int mins, maxs;
+      bracket(ps, &mins, &maxs);
+      for (int g = 0; g < ngroups; g++) g_has[(size_t)ps * ngroups + g] = group_stream((g % xg) * gd, (g / xg) * gd, gd, mins, maxs, 1 + 3 * nlf + 17 + ps * ngroups + g, gtok[(size_t)ps * ngroups + g]);
+    }
   }
   EntropyCoder tree_code, code;
   { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
@@ -1230,14 +1254,15 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
   }
   // HfGlobal is absent for modular frames but still has a TOC slot
   sections.push_back(BitWriter());
-  for (int g = 0; g < ngroups; g++) {
+  for (int k = 0; k < ngroups * np; k++) {      // PassGroups, pass-major
     BitWriter s;
-    if (g_has[g]) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, code, gtok[g]); }
+    if (g_has[k]) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, code, gtok[k]); }
     sections.push_back(s);
   }
   BitWriter out;
   Params p;
   if (fx) p = *fx;
+  p.mod_passes = np;
   p.out_bits = bits; p.gab = 0; p.epf_iters = 0; p.noise = 0; p.upsampling = 1; p.num_passes = 1; p.skip_lf_smoothing = 0;  // lossless: no restoration filters
   if (p.emit != 1) WriteImageHeader(out, p.canvas_w ? p.canvas_w : w, p.canvas_h ? p.canvas_h : h, p, p.xyb_image != 0, bits, has_alpha, nchan == 1);
   if (p.emit == 2) return out.bytes;
@@ -1338,7 +1363,7 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
 // frame emitted with emit = 0) and any number of frames (emit = 1), the last one with is_last = 1.
 struct jxlsynth_frame {
   int32_t noise; uint32_t noise_lut[8];
-  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image, alpha_premultiplied, use_lf_frame, lf_level;
+  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image, alpha_premultiplied, use_lf_frame, lf_level, mod_passes, mod_ds;
 };
 static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
   if (!fx) return;
@@ -1347,6 +1372,7 @@ static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
   p.blend_mode = fx->blend_mode; p.blend_source = fx->blend_source; p.blend_clamp = fx->blend_clamp; p.is_last = fx->is_last; p.save_as_reference = fx->save_as_reference;
   p.save_before_ct = fx->save_before_ct; p.emit = fx->emit; p.num_extra_hdr = fx->num_extra_hdr; p.xyb_image = fx->xyb_image; p.alpha_premultiplied = fx->alpha_premultiplied;
   p.use_lf_frame = fx->use_lf_frame; p.lf_level = fx->lf_level;
+  p.mod_passes = fx->mod_passes > 0 ? fx->mod_passes : 1; p.mod_ds = fx->mod_ds;
 }
 int jxlsynth_vardct3(const uint8_t* rgb8, const uint8_t* alpha8, int w, int h, const jxlsynth_params* pp, const jxlsynth_frame* fx, uint8_t** out, size_t* n) {
   try {
