@@ -471,6 +471,8 @@ def test_host_parser_survives_corrupted_input(jx):
     finally:
         S.set_icc(b"")
     streams.append(S.encode_vardct(S.synthetic_image(4, 300, 280), seed=2, strategy_mix=2, num_passes=3, permute_toc=3))
+    from test_synth_roundtrip import preview_streams, lf_frame_streams, multipass_modular_streams       # round 3: preview frame, LF frames, Modular passes
+    streams += [preview_streams()[1][1], lf_frame_streams()[0][1], lf_frame_streams()[1][1], multipass_modular_streams()[0][1]]
     accepted = rejected = 0
     for data in streams:
         for trial in range(300):

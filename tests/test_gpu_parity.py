@@ -249,6 +249,37 @@ def test_lf_frames(jx):
                 assert np.array_equal(b.output(i), want_plain if name is None else refs[name]), (lf_stride, i, name)
 
 
+def test_corrupted_round3_streams_fail_cleanly_or_decode(jx):
+    """The robustness bar of test_corrupted_streams_fail_cleanly_or_decode for what round 3 added: images with a preview frame, LF frames (the nested
+    batch of LF frames fails like a frame), Modular frames in several passes, prefix-coded VarDCT frames."""
+    from test_synth_roundtrip import preview_streams, lf_frame_streams, multipass_modular_streams
+    rng = np.random.default_rng(321)
+    S.set_prefix(True)
+    try:
+        pfx = S.encode_vardct(S.synthetic_image(44, 320, 200), seed=5, strategy_mix=2, epf_iters=1, gab=1)
+    finally:
+        S.set_prefix(False)
+    lf = lf_frame_streams()
+    streams = [preview_streams()[1][1], lf[0][1], lf[1][1], lf[3][1], multipass_modular_streams()[0][1], multipass_modular_streams()[5][1], pfx]
+    outcomes = {"error": 0, "decoded": 0}
+    for data in streams:
+        for trial in range(20):
+            bad = bytearray(data)
+            for pos in rng.integers(16, len(bad), 1 + trial % 4):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if trial % 7 == 6:
+                bad = bad[: int(rng.integers(len(bad) // 2, len(bad)))]
+            try:
+                meta, px = jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+                assert len(px) == meta.width * meta.height * (4 if meta.has_alpha_channel else 3)
+                outcomes["decoded"] += 1
+            except jx.DecodeError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 0 and outcomes["error"] + outcomes["decoded"] == 20 * len(streams)
+    for data in (lf[0][1], streams[0]):                  # the decoder is still healthy afterwards
+        check_against_oracle(jx, data, np.uint8, 3)
+
+
 def test_multipass_modular_frames(jx):
     """Modular frames in several passes (frame_header.cc Passes, passes.h GetDownsamplingBracket): PassGroup (pass, group) carries the
     channels whose shift falls into the pass's bracket.  The HIP path decodes every (pass, group) sub-stream as a unit of its own; lossless against the
