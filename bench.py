@@ -442,10 +442,10 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
-    ap.add_argument("--in-flight", type=int, default=10, help="batches in flight on the GPU (pipelined): LF stages run this many steps ahead, minus one")
-    ap.add_argument("--lf-streams", type=int, default=6, help="side streams the LF stages of the batches ahead are spread over")
+    ap.add_argument("--in-flight", type=int, default=11, help="batches in flight on the GPU (pipelined): LF stages run this many steps ahead, minus one")
+    ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
     ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current step (deep pipeline), one stream and one coefficient set each")
-    ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "3")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
+    ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
     ap.add_argument("--out-buffers", type=int, default=2, help="output buffer sets the batches in flight cycle through")
     ap.add_argument("--prepare-threads", type=int, default=int(os.environ.get("JXL_BENCH_PREPARE_THREADS", "3")), help="streaming: host threads that each parse + prepare + upload one batch at a time")
     ap.add_argument("--parse-threads", type=int, default=int(os.environ.get("JXL_BENCH_PARSE_THREADS", "8")), help="host threads JxlHipBatchAddImages parses the frames of one batch on")

@@ -2055,7 +2055,7 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || f.ac_code.use_prefix) return;            // (prefix-coded frames: HfDecodeKernel, launched beside this one)
   if (blockIdx.x * lanes >= f.num_groups) return;
-  if (prio) __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of co-resident waves
+  if (prio & 1) __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of co-resident waves
   // per-lane regions sit at the end of the dynamic LDS: `lanes` real ones + one scratch region that all stream-less
   // lanes of the last wavefront share (they only ever write zeros / prefetched words there and read nothing back)
   const uint32_t lane_off = lds_bytes - (lanes + 1) * kSimtLaneBytes;
@@ -2234,7 +2234,8 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
         if (u) {
           int32_t val = (int32_t)((uint32_t)UnpackSigned(u) << shift);
           if (MULTI && pass) val = (int32_t)((uint32_t)val + (uint32_t)LdG(blk + pos));
-          StG(blk + pos, val);
+          if (!(prio & 4)) StG(blk + pos, val);       // (JXL_HIP_HF_PRIO bit 2: experiment — what the scattered stores cost the kernels beside this one; wrong pixels)
+          else if (prio & 8) StG(blk + (nz_total & 0xFFFFu), val);   // (bit 3: the same number of stores, but consecutive per lane)
         }
         prev = u != 0;
         nzeros -= prev;
