@@ -386,7 +386,6 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
     }
     if (!p.modular) {
       for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
-      if (p.has_global_tree && p.tree_code.lz77) throw ParseError("unsupported: LZ77 in the LF streams of a VarDCT frame", true);
       if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
       if (p.subsampled && (p.base_x != 0.f || p.base_b != 0.f)) throw ParseError("unsupported: chroma from luma in a chroma-subsampled frame", true);
       if (p.max_prop >= 16) throw ParseError("unsupported: previous-channel MA properties in a VarDCT frame", true);
@@ -795,8 +794,8 @@ void Batch::Prepare(void* stream_v) {
       o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.NumModUnits()));
       if (e.complex) for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big((size_t)p.bw * 8 * p.bh * 8 * 4); o.plane_b[c] = (size_t)-1; }
     }
-    if (!p.gchannels.empty() && p.has_global_tree && p.tree_code.lz77)   // LZ77 windows of the Modular streams (4 MiB each)
-      o.lz_window = take((size_t)(1 + p.NumModUnits()) * (4u << 20));
+    if (p.has_global_tree && p.tree_code.lz77 && (!p.gchannels.empty() || !p.modular))   // LZ77 windows of the Modular streams (4 MiB each); VarDCT: + one per LF group
+      o.lz_window = take((size_t)(1 + p.NumModUnits() + (p.modular ? 0 : p.num_lf_groups)) * (4u << 20));
     if (e.complex) {
       // buffers of the frame tail (PlanPostOps): float extra channels, upsampled planes, noise planes, colour-transformed planes
       // (only when the untransformed ones must survive as a reference frame), canvas (only when the frame is blended)
@@ -915,6 +914,7 @@ void Batch::Prepare(void* stream_v) {
     f.is_gray = e.ih.color_space == 1;
     f.post_mode = e.complex ? 1 : 0;
     f.lz_window = o.lz_window == (size_t)-1 ? nullptr : (uint32_t*)(dwork_ + o.lz_window);
+    f.lz_lf_base = 1 + p.NumModUnits();
     f.wp_scratch = (int32_t*)(dwork_ + o.wp_scratch); f.wp_scratch_stride = o.wp_scratch_stride;
     if (!p.modular) {
       const float inv_gs = 65536.0f / (float)p.global_scale;

@@ -109,6 +109,7 @@ struct FrameDev {
   uint32_t mod_unit_passes;       // Modular sub-streams per group: the frame's passes (Modular frames), 1 (VarDCT frames: the extra channels' pass only, mod_pass)
   uint32_t mod_pass;
   int32_t pass_min_shift[11], pass_max_shift[11];   // passes.h GetDownsamplingBracket per pass: the channels (by min(hshift, vshift)) a PassGroup of that pass carries
+  uint32_t lz_lf_base;            // LZ77-coded LF-group streams of a VarDCT frame: index of LF group 0's window in lz_window (the Modular units' windows come first)
   uint32_t use_lf_frame;          // frame_header.cc kUseDcFrame: no LF coefficients in the LfGroups, the LF image is an LF frame's samples (no dequantisation, no smoothing, LF context 0)
   uint32_t lf_simt;               // the LF-group streams of this frame are decoded by LfDecodeSimtKernel (one stream per lane), placement by LfPlaceKernel
   uint32_t* status;

@@ -1218,7 +1218,16 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp;
   mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride;
-  mc.slow = f.mod_code.use_prefix;       // prefix-coded LF streams (cjxl's fast efforts): the general symbol reader
+  mc.slow = f.mod_code.use_prefix || f.mod_code.lz77;       // prefix-coded LF streams (cjxl's fast efforts), LZ77 (its slowest): the general symbol reader
+  // LZ77 state in LDS (the rare path must not cost the common one registers); one window per LF group: its two streams — LF coefficients,
+  // HF metadata — use it one after the other
+  __shared__ Lz77State s_lz[kLfDecWaves];
+  Lz77State& lz = s_lz[(threadIdx.x >> 6) % kLfDecWaves];
+  if (f.mod_code.lz77) {
+    if (!f.lz_window) { if (lane == 0) SetError(f, kErrUnsupported); return; }
+    if (lane == 0) lz.Init(f.lz_window + (uint64_t)(f.lz_lf_base + g) * Lz77State::kWindow, gbw);   // dist_multiplier: the widest channel of the stream (modular/encoding/encoding.cc)
+    mc.lz = &lz;
+  }
   uint32_t state = 0;
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
   // ---- LF coefficients (not in the stream of a frame that takes its LF image from an LF frame: frame_header.cc kUseDcFrame)
@@ -1261,6 +1270,8 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   if (s_fail) return;
   const uint32_t nb_blocks = s_u[1];
   const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
+  if (f.mod_code.lz77 && lane == 0) lz.Init(lz.window, max(max(nb_blocks, gbw), mcw));
+  WaveSync();
   int32_t* m_ytox = scratch + 16;
   int32_t* m_ytob = m_ytox + mcw * mch;
   int32_t* m_blk = m_ytob + mcw * mch;

@@ -250,6 +250,12 @@ def set_preview(w=0, h=0):
     lib().jxlsynth_set_preview(int(w), int(h))
 
 
+def set_lz77_lf(on=False):
+    """VarDCT frames written from now on (this thread) code their LF-group Modular streams (LF coefficients, HF metadata) with LZ77: runs of equal
+    values and repeats of the row above become copies."""
+    lib().jxlsynth_set_lz77_lf(1 if on else 0)
+
+
 def set_prefix(on=False):
     """Streams written from now on use prefix (Huffman) codes instead of ANS (cjxl -e 1..3); call without arguments to go back."""
     L = lib()

@@ -280,6 +280,25 @@ def test_corrupted_round3_streams_fail_cleanly_or_decode(jx):
         check_against_oracle(jx, data, np.uint8, 3)
 
 
+def test_lz77_coded_lf_streams(jx):
+    """LZ77 in the LF-group Modular streams of VarDCT frames (dec_ans.h): the LF kernel's general symbol reader with one 4 MB window
+    per LF group; against the oracle and the ANS twin of the same frame, alone and in a batch beside plain frames (both LF decode kernels)."""
+    from test_synth_roundtrip import lz77_lf_streams
+    cases = lz77_lf_streams()
+    for name, lz, ans in cases:
+        _, px = check_against_oracle(jx, lz, np.uint8, 3)
+        assert np.array_equal(px.reshape(-1), O.decode(ans).pixels("u8", 3)), name
+        check_against_oracle(jx, lz, np.float32, 3)
+    for lf_stride in (64, 8):
+        b = jx.BatchDecoder(0)
+        for name, lz, ans in cases:
+            b.add(lz, "uint8", 3); b.add(ans, "uint8", 3)
+        b.set_lane_stride(lf_stride, 1)
+        b.prepare(); b.decode(); b.finish()
+        for i in range(len(cases)):
+            assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), (lf_stride, cases[i][0])
+
+
 def test_multipass_modular_frames(jx):
     """Modular frames in several passes (frame_header.cc Passes, passes.h GetDownsamplingBracket): PassGroup (pass, group) carries the
     channels whose shift falls into the pass's bracket.  The HIP path decodes every (pass, group) sub-stream as a unit of its own; lossless against the

@@ -312,3 +312,29 @@ def test_multipass_modular_frames_are_lossless():
         px = O.decode(data).pixels("u16" if bits > 8 else "u8", img.shape[2])
         px = px.view(np.uint16) if bits > 8 else px
         assert np.array_equal(px.reshape(img.shape), img), name
+
+
+def lz77_lf_streams():
+    """(name, LZ77-coded stream, ANS twin): VarDCT frames whose LF-group Modular streams (LF coefficients, HF metadata) are LZ77-coded — copies of the
+    value before (distance 1) and of the row above (special distance 0 = the stream's distance multiplier); flat areas make the runs"""
+    import synth_lib as S
+    out = []
+    for name, seed, (w, h), mix, epf in [("small", 1, (320, 200), 1, 1), ("one_group", 2, (64, 48), 0, 2), ("two_lf_groups", 3, (2300, 400), 2, 0)]:
+        img = S.synthetic_image(60 + seed, w, h)
+        img[: h // 2, : w // 2] = img[0, 0]
+        ans = S.encode_vardct(img, seed=seed, strategy_mix=mix, epf_iters=epf)
+        S.set_lz77_lf(True)
+        try:
+            lz = S.encode_vardct(img, seed=seed, strategy_mix=mix, epf_iters=epf)
+        finally:
+            S.set_lz77_lf(False)
+        out.append((name, lz, ans))
+    return out
+
+
+def test_lz77_coded_lf_streams_decode_like_their_ans_twins():
+    import numpy as np
+    import oracle_lib as O
+    for name, lz, ans in lz77_lf_streams():
+        assert lz != ans
+        assert np.array_equal(O.decode(lz).pixels("u8", 3), O.decode(ans).pixels("u8", 3)), name

@@ -196,6 +196,31 @@ static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& 
   }
 }
 
+// LZ77 over a finished token stream (dec_ans.h ANSSymbolReader: the window holds the decoded values of the whole stream, whatever their contexts): runs
+// that repeat the value before (distance 1: special distance code 1) or the value one row up (distance `row`: special distance code 0 = the stream's
+// distance multiplier, its widest channel) become a length symbol in the context of the run's first value + a distance token in the extra context
+static void ApplyLz77(std::vector<Token>& tok, uint32_t dist_ctx, const EntropyCoder& proto, size_t row) {
+  std::vector<Token> out;
+  const size_t n = tok.size();
+  size_t i = 0;
+  while (i < n) {
+    size_t l1 = 0, lr = 0;
+    if (i >= 1) while (i + l1 < n && tok[i + l1].value == tok[i + l1 - 1].value) l1++;
+    if (row > 1 && i >= row) while (i + lr < n && tok[i + lr].value == tok[i + lr - row].value) lr++;
+    const size_t len = std::max(l1, lr);
+    if (len >= std::max<size_t>(proto.lz_min_length, 6)) {
+      Token t; t.ctx = tok[i].ctx; t.raw = 1;
+      uint32_t sym, nb, bits;
+      EncodeHybrid(proto.lz_len_cfg, (uint32_t)len - proto.lz_min_length, &sym, &nb, &bits);
+      t.value = proto.lz_min_symbol + sym; t.nb = (uint8_t)nb; t.bits = bits;
+      out.push_back(t);
+      out.push_back(Token{dist_ctx, lr >= l1 ? 0u : 1u});      // (ties go to the row copy: flat areas then exercise both distance codes)
+      i += len;
+    } else out.push_back(tok[i++]);
+  }
+  tok.swap(out);
+}
+
 // ---- image / frame headers -------------------------------------------------------------------------------------
 static void WriteSize(BitWriter& w, uint32_t xs, uint32_t ys) {
   w.put(0, 1);  // small = 0
@@ -953,9 +978,16 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   EntropyCoder tree_code, mod_code;
   std::vector<EntropyCoder> ac_codes(np);
   { std::vector<const std::vector<Token>*> s{&tree_tokens}; BuildEntropyCoder(s, 6, UintConfig{4, 2, 0}, 6, tree_code); }
+  const bool lz77_lf = UseLz77Lf();
+  if (lz77_lf) {
+    EntropyCoder proto;
+    proto.lz_min_symbol = 224; proto.lz_min_length = 3; proto.lz_len_cfg = UintConfig{3, 0, 0};
+    for (auto& d : lgd) { ApplyLz77(d.lf_tok, (uint32_t)gt.num_leaves, proto, (size_t)d.gbw); ApplyLz77(d.meta_tok, (uint32_t)gt.num_leaves, proto, 0); }
+  }
   { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); }
     s.push_back(&alpha_global_tok); for (auto& t : alpha_tok) s.push_back(&t);
-    BuildEntropyCoder(s, gt.num_leaves, UintConfig{4, 2, 0}, 32, mod_code); }
+    BuildEntropyCoder(s, gt.num_leaves + (lz77_lf ? 1 : 0), UintConfig{4, 2, 0}, 32, mod_code);
+    if (lz77_lf) { mod_code.lz77 = true; mod_code.lz_min_symbol = 224; mod_code.lz_min_length = 3; mod_code.lz_len_cfg = UintConfig{3, 0, 0}; } }
   for (int ps = 0; ps < np; ps++) {
     std::vector<const std::vector<Token>*> s; for (int g = 0; g < ngroups; g++) s.push_back(&ac_tok_all[(size_t)ps * ngroups + g]);
     BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_codes[ps]);
@@ -1292,6 +1324,7 @@ void jxlsynth_set_float(int exp_bits) { synth::g_float_exp_bits = exp_bits; }
 // entropy-coded streams written from now on in this thread use prefix (Huffman) codes instead of ANS — what cjxl's fast efforts emit
 void jxlsynth_set_preview(int w, int h) { synth::g_preview_w = w; synth::g_preview_h = h; }
 void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
+void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 // rgba == NULL: the extra channel is alpha again
 void jxlsynth_set_spot(const float* rgba) { synth::g_spot_set = rgba != nullptr; if (rgba) for (int i = 0; i < 4; i++) synth::g_spot[i] = rgba[i]; }
 // white_point < 0 clears the override

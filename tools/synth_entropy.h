@@ -261,6 +261,8 @@ struct PrefixCode { std::vector<uint8_t> len; std::vector<uint16_t> code; bool s
 // streams written from now on in this thread use prefix codes instead of ANS (what cjxl's fast efforts emit); the nested code of a
 // context map stays ANS
 inline bool& UsePrefixCodes() { static thread_local bool v = false; return v; }
+// the Modular streams of VarDCT frames (LF coefficients, HF metadata) written from now on in this thread are LZ77-coded (what cjxl's slowest efforts may choose)
+inline bool& UseLz77Lf() { static thread_local bool v = false; return v; }
 
 struct EntropyCoder {
   // configuration
