@@ -388,7 +388,6 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
       for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
       if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
       if (p.subsampled && (p.base_x != 0.f || p.base_b != 0.f)) throw ParseError("unsupported: chroma from luma in a chroma-subsampled frame", true);
-      if (p.max_prop >= 16) throw ParseError("unsupported: previous-channel MA properties in a VarDCT frame", true);
       if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
     }
     for (auto& x : ih.extra) {

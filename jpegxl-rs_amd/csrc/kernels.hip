@@ -1228,6 +1228,29 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     if (lane == 0) lz.Init(f.lz_window + (uint64_t)(f.lz_lf_base + g) * Lz77State::kWindow, gbw);   // dist_multiplier: the widest channel of the stream (modular/encoding/encoding.cc)
     mc.lz = &lz;
   }
+  // previous-channel properties (16 + 4 r + k; cjxl -E): the earlier channels of the stream with the same size, nearest first (encoding.cc
+  // PrecomputeReferences) — kept in LDS, built by lane 0 in front of every channel
+  __shared__ ModRefs s_refs[kLfDecWaves];
+  __shared__ ChannelDesc s_done[kLfDecWaves][4];
+  const uint32_t wslot = (threadIdx.x >> 6) % kLfDecWaves;
+  const bool with_refs = f.tree_max_prop >= 16;
+  mc.max_prop = f.tree_max_prop;
+  if (with_refs) mc.refs = &s_refs[wslot];
+  auto before_channel = [&](const ChannelDesc& chd, int k) {      // k: index of the channel in its stream
+    if (!with_refs) return;
+    if (lane == 0) {
+      ModRefs& r = s_refs[wslot];
+      int n = 0;
+      for (int j = k - 1; j >= 0 && n < kMaxModRefs; j--) {
+        const ChannelDesc& d = s_done[wslot][j];
+        if (d.w != chd.w || d.h != chd.h) continue;
+        r.data[n] = d.data; r.stride[n] = d.stride; n++;
+      }
+      r.n = n;
+      s_done[wslot][k] = chd;
+    }
+    WaveSync();
+  };
   uint32_t state = 0;
   int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
   // ---- LF coefficients (not in the stream of a frame that takes its LF image from an LF frame: frame_header.cc kUseDcFrame)
@@ -1253,6 +1276,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
       const int pl = chan_to_plane[c];       // (subsampled channels: their own, smaller grid — dec_modular.cc DecodeVarDCTDC)
       ch.data = f.lfq[pl] + (size_t)(by0 >> f.vs[pl]) * f.bw + (bx0 >> f.hs[pl]);
       ch.w = (int)(gbw >> f.hs[pl]); ch.h = (int)(gbh >> f.vs[pl]); ch.stride = (int)f.bw;
+      before_channel(ch, c);
       DecodeChannelCoop(br, state, T, mc, ch, c);
     }
   }
@@ -1278,10 +1302,10 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   int32_t* m_sharp = m_blk + 2 * nb_blocks;
   mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
   ChannelDesc ch;
-  ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; DecodeChannelCoop(br, state, T, mc, ch, 0);
-  ch.data = m_ytob; DecodeChannelCoop(br, state, T, mc, ch, 1);
-  ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; DecodeChannelCoop(br, state, T, mc, ch, 2);
-  ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; DecodeChannelCoop(br, state, T, mc, ch, 3);
+  ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; before_channel(ch, 0); DecodeChannelCoop(br, state, T, mc, ch, 0);
+  ch.data = m_ytob; before_channel(ch, 1); DecodeChannelCoop(br, state, T, mc, ch, 1);
+  ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; before_channel(ch, 2); DecodeChannelCoop(br, state, T, mc, ch, 2);
+  ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; before_channel(ch, 3); DecodeChannelCoop(br, state, T, mc, ch, 3);
   if (lane == 0) {
     if (state != 0x130000u) SetError(f, kErrAnsFinalState);
     else if (br.BitPos() > limit) SetError(f, kErrOverrun);

@@ -256,6 +256,11 @@ def set_lz77_lf(on=False):
     lib().jxlsynth_set_lz77_lf(1 if on else 0)
 
 
+def set_prev_channel_props(on=False):
+    """VarDCT frames written from now on (this thread): the MA tree of their LF-group streams also splits on previous-channel properties."""
+    lib().jxlsynth_set_prev_channel_props(1 if on else 0)
+
+
 def set_prefix(on=False):
     """Streams written from now on use prefix (Huffman) codes instead of ANS (cjxl -e 1..3); call without arguments to go back."""
     L = lib()

@@ -299,6 +299,24 @@ def test_lz77_coded_lf_streams(jx):
             assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), (lf_stride, cases[i][0])
 
 
+def test_previous_channel_properties_in_lf_streams(jx):
+    """MA trees of the LF-group streams of VarDCT frames that split on previous-channel properties (16 + 4 r + k, `cjxl -E`): the LF
+    kernel's general tree walk with the earlier channels of the stream as references; against the oracle and the plain-tree twin, alone and batched."""
+    from test_synth_roundtrip import prev_channel_streams
+    cases = prev_channel_streams()
+    for name, pc, plain in cases:
+        _, px = check_against_oracle(jx, pc, np.uint8, 3)
+        assert np.array_equal(px.reshape(-1), O.decode(plain).pixels("u8", 3)), name
+    for lf_stride in (64, 8):
+        b = jx.BatchDecoder(0)
+        for name, pc, plain in cases:
+            b.add(pc, "uint8", 3); b.add(plain, "uint8", 3)
+        b.set_lane_stride(lf_stride, 1)
+        b.prepare(); b.decode(); b.finish()
+        for i in range(len(cases)):
+            assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), (lf_stride, cases[i][0])
+
+
 def test_multipass_modular_frames(jx):
     """Modular frames in several passes (frame_header.cc Passes, passes.h GetDownsamplingBracket): PassGroup (pass, group) carries the
     channels whose shift falls into the pass's bracket.  The HIP path decodes every (pass, group) sub-stream as a unit of its own; lossless against the

@@ -338,3 +338,28 @@ def test_lz77_coded_lf_streams_decode_like_their_ans_twins():
     for name, lz, ans in lz77_lf_streams():
         assert lz != ans
         assert np.array_equal(O.decode(lz).pixels("u8", 3), O.decode(ans).pixels("u8", 3)), name
+
+
+def prev_channel_streams():
+    """(name, stream whose LF-group MA tree splits on previous-channel properties, twin under the plain tree)"""
+    import synth_lib as S
+    out = []
+    for name, seed, (w, h), mix, epf in [("small", 1, (320, 200), 1, 1), ("one_group", 2, (64, 48), 0, 2), ("two_lf_groups", 3, (2300, 400), 2, 0)]:
+        img = S.synthetic_image(60 + seed, w, h)
+        plain = S.encode_vardct(img, seed=seed, strategy_mix=mix, epf_iters=epf)
+        S.set_prev_channel_props(True)
+        try:
+            pc = S.encode_vardct(img, seed=seed, strategy_mix=mix, epf_iters=epf)
+        finally:
+            S.set_prev_channel_props(False)
+        out.append((name, pc, plain))
+    return out
+
+
+def test_previous_channel_properties_in_lf_streams_decode_like_the_plain_tree():
+    """context_predict.h PrecomputeReferences inside the LF-group streams of VarDCT frames (cjxl -E): X conditioned on |Y|, B on X and Y, ytob on ytox"""
+    import numpy as np
+    import oracle_lib as O
+    for name, pc, plain in prev_channel_streams():
+        assert pc != plain
+        assert np.array_equal(O.decode(pc).pixels("u8", 3), O.decode(plain).pixels("u8", 3)), name

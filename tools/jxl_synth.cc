@@ -133,9 +133,16 @@ static GTree MakeGlobalTree(int nlf, std::vector<int>* bfs_order) {
   int ty = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
   int tx = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
   int tb = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
+  if (UsePrevChannelProps()) {
+    // X looks at |Y| here (property 16: nearest previous channel), B at the sign of X minus its gradient prediction (19) and at |Y| (20: the channel before that)
+    tx = t.add_inner(16, 2, BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5), tx);
+    const int tb2 = t.add_inner(20, 4, BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 1), BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5));
+    tb = t.add_inner(19, 0, tb2, tb);
+  }
   int lf_c = t.add_inner(0, 1, tb, tx);
   int lf = t.add_inner(0, 0, lf_c, ty);
   int sharp = t.add_leaf(1), hfmul = t.add_leaf(1), strat = t.add_leaf(1), cfl = t.add_leaf(0);
+  if (UsePrevChannelProps()) cfl = t.add_inner(17, 0, t.add_leaf(0), t.add_inner(17, -1, t.add_leaf(0), t.add_leaf(1)));   // ytob looks at ytox's value (ytox itself: no previous channel, property 0)
   int blk = t.add_inner(2, 0, hfmul, strat);
   int c23 = t.add_inner(0, 2, sharp, blk);
   int meta = t.add_inner(0, 1, c23, cfl);
@@ -182,7 +189,19 @@ static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& 
         int64_t W = x ? p[x - 1] : (y ? pn[x] : 0);
         int64_t N = y ? pn[x] : W;
         int64_t NW = (x && y) ? pn[x - 1] : W;
-        int props[10] = {(int)ci, stream_id, y, x, 0, 0, 0, 0, 0, (int)(W + N - NW)};
+        int props[16 + 4 * 4] = {(int)ci, stream_id, y, x, 0, 0, 0, 0, 0, (int)(W + N - NW)};
+        {  // encoding.cc PrecomputeReferences: earlier channels of this stream with the same size, nearest first
+          int r = 0;
+          for (int cj = (int)ci - 1; cj >= 0 && r < 4; cj--) {
+            const ChanRef& rc = chans[(size_t)cj];
+            if (rc.w != ch.w || rc.h != ch.h) continue;
+            const int32_t* rp = rc.d + (size_t)y * rc.w;
+            const int64_t v = rp[x], rl = x ? rp[x - 1] : 0, rt = y ? rp[x - rc.w] : rl, rtl = (x && y) ? rp[x - 1 - rc.w] : rl;
+            const int64_t m = std::min(rt, rl), M = std::max(rt, rl), g = rtl < m ? M : (rtl > M ? m : rt + rl - rtl);
+            props[16 + 4 * r] = (int)std::llabs(v); props[17 + 4 * r] = (int)v; props[18 + 4 * r] = (int)std::llabs(v - g); props[19 + 4 * r] = (int)(v - g);
+            r++;
+          }
+        }
         int pos = root;
         while (t.nodes[pos].prop >= 0) pos = props[t.nodes[pos].prop] > t.nodes[pos].split ? t.nodes[pos].l : t.nodes[pos].r;
         const TNode& leaf = t.nodes[pos];
@@ -1325,6 +1344,7 @@ void jxlsynth_set_float(int exp_bits) { synth::g_float_exp_bits = exp_bits; }
 void jxlsynth_set_preview(int w, int h) { synth::g_preview_w = w; synth::g_preview_h = h; }
 void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
+void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
 // rgba == NULL: the extra channel is alpha again
 void jxlsynth_set_spot(const float* rgba) { synth::g_spot_set = rgba != nullptr; if (rgba) for (int i = 0; i < 4; i++) synth::g_spot[i] = rgba[i]; }
 // white_point < 0 clears the override

@@ -262,6 +262,8 @@ struct PrefixCode { std::vector<uint8_t> len; std::vector<uint16_t> code; bool s
 // context map stays ANS
 inline bool& UsePrefixCodes() { static thread_local bool v = false; return v; }
 // the Modular streams of VarDCT frames (LF coefficients, HF metadata) written from now on in this thread are LZ77-coded (what cjxl's slowest efforts may choose)
+// ... their MA tree also splits on previous-channel properties (16 + 4 r + k: the sample of the r-th previous channel of equal size at this position, cjxl -E)
+inline bool& UsePrevChannelProps() { static thread_local bool v = false; return v; }
 inline bool& UseLz77Lf() { static thread_local bool v = false; return v; }
 
 struct EntropyCoder {
