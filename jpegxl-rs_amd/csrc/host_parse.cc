@@ -1276,7 +1276,6 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
     }
     ReadEntropyCode(r, 495 * p->bcm.num_ctxs * p->num_hf_presets, &p->ac_code[ps]);
     if (p->ac_code[ps].lz77) Unsupported("LZ77 in an AC coefficient stream");
-    if (p->ac_code[ps].use_prefix && (p->num_passes > 1 || p->subsampled)) Unsupported("prefix-coded AC coefficient stream of a progressive / chroma-subsampled frame");
   }
   p->end_bitpos = r.pos();
 }

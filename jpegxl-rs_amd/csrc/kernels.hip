@@ -1911,6 +1911,7 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   if (f.is_modular) return;
   const bool pfx = f.ac_code.use_prefix != 0;
   if (only_prefix && !pfx) return;
+  if (only_prefix && (f.num_passes != 1 || f.subsampled)) return;      // (progressive / chroma-subsampled prefix-coded frames: HfDecodeSimtKernel walks them)
   // ---- stage the AC entropy code (cfg, context map, alias tables if they fit) and the two context LUTs into LDS
   FastCode code;
   if (threadIdx.x < 64) { StS<uint8_t>(threadIdx.x, kNzCtx[threadIdx.x]); StS<uint8_t>(64 + threadIdx.x, kFreqCtx[threadIdx.x]); }
@@ -2088,7 +2089,12 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
   if (sync && threadIdx.x == 0 && atomicAdd(sync, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(sync, 0u); __threadfence(); atomicMax(sync + 1, epoch); }
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || f.ac_code.use_prefix) return;            // (prefix-coded frames: HfDecodeKernel, launched beside this one)
+  if (f.is_modular) return;
+  // prefix-coded frames: HfDecodeKernel, launched beside this one — unless they are progressive or chroma-subsampled: those are walked here (the
+  // general instantiation), their symbols read bit by bit through the canonical-code tables in global memory (jxl_dev.h ReadSymbol)
+  bool any_pfx = f.ac_code.use_prefix != 0;
+  for (uint32_t ps = 1; MULTI && ps < f.num_passes; ps++) any_pfx |= f.passes[ps].code.use_prefix != 0;
+  if (any_pfx && !((SUB && f.subsampled) || (MULTI && f.num_passes > 1))) return;
   if (blockIdx.x * lanes >= f.num_groups) return;
   if (prio & 1) __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of co-resident waves
   // per-lane regions sit at the end of the dynamic LDS: `lanes` real ones + one scratch region that all stream-less
@@ -2122,7 +2128,8 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   StageCode(pd.code, code, kSimtCodeOff, lane_off > kSimtCodeOff ? lane_off - kSimtCodeOff : 0, /*with_ctx_map=*/true);
   if (threadIdx.x < 39) StS<uint64_t>(kSimtOrdOff + threadIdx.x * 8, (uint64_t)(uintptr_t)pd.orders[threadIdx.x]);
   __syncthreads();
-  if (ALL_LDS && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
+  const bool pfx = (SUB || MULTI) && pd.code.use_prefix != 0;
+  if (ALL_LDS && !pfx && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
   bool done = dead;
   uint32_t err = 0;                                    // first error of this lane's stream (reported after the loop)
   for (uint32_t i = 0; i < 24; i++) StS<uint32_t>(nz_base + i * 4, 0u);
@@ -2163,7 +2170,7 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
     const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
     if (preset >= f.num_hf_presets) { err = kErrBadValue; done = true; }
     ctx_offset = 495u * nctx * preset;
-    state = br.Read(32);
+    state = pfx ? 0x130000u : br.Read(32);           // (prefix codes carry no ANS state)
   }
   // ---- varblock list of this group, one entry loaded ahead
   const uint2* vbl = f.vb_list + (size_t)gsafe * 1024;
@@ -2239,7 +2246,13 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
         const uint32_t nzl = (nzeros + covered - 1) >> l2, kk = k >> l2;
         ctx = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + kk)) * 2 + prev;
       }
-      const uint32_t u = HybridSimt<ALL_LDS>(br, state, code, ctx);
+      uint32_t u;
+      if ((SUB || MULTI) && pfx) {
+        br.Refill();
+        const uint32_t cl = LdG(pd.code.ctx_map + ctx);
+        AnsReader ans; ans.state = state;
+        u = HybridFromToken(br, LdG(pd.code.cfg + cl), ReadSymbol(br, ans, pd.code, cl));
+      } else u = HybridSimt<ALL_LDS>(br, state, code, ctx);
       if (phase == 1) {
         nzeros = u;
         nz_total += u;                               // (bench accounting: coefficients this stream writes)

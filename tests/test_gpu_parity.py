@@ -280,6 +280,33 @@ def test_corrupted_round3_streams_fail_cleanly_or_decode(jx):
         check_against_oracle(jx, data, np.uint8, 3)
 
 
+def test_prefix_coded_progressive_and_subsampled_frames(jx):
+    """Prefix-coded AC streams of progressive frames (several passes, each with its own code and orders) and of chroma-subsampled YCbCr frames (what a
+    fast-effort JPEG recompression looks like): walked by the general instantiation of HfDecodeSimtKernel with the bit-serial canonical-code reader.
+    Against the oracle and the ANS twin, alone and in a batch beside ANS-coded frames."""
+    img = S.synthetic_image(41, 520, 300)
+    pairs = []
+    for make in (lambda: S.encode_vardct(img, seed=5, strategy_mix=2, num_passes=3), lambda: S.encode_vardct(img, seed=5, strategy_mix=1, num_passes=2, permute_toc=3, epf_iters=2),
+                 lambda: S.encode_ycbcr(img, subsampling="420", seed=3), lambda: S.encode_ycbcr(img, subsampling="422", seed=3), lambda: S.encode_ycbcr(img, subsampling="444", seed=3)):
+        ans = make()
+        S.set_prefix(True)
+        try:
+            pfx = make()
+        finally:
+            S.set_prefix(False)
+        assert pfx != ans
+        pairs.append((pfx, ans))
+    for pfx, ans in pairs:
+        _, px = check_against_oracle(jx, pfx, np.uint8, 3)
+        assert np.array_equal(px.reshape(-1), O.decode(ans).pixels("u8", 3))
+    b = jx.BatchDecoder(0)
+    for pfx, ans in pairs:
+        b.add(pfx, "uint8", 3); b.add(ans, "uint8", 3)
+    b.prepare(); b.decode(); b.finish()
+    for i in range(len(pairs)):
+        assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), i
+
+
 def test_lz77_coded_lf_streams(jx):
     """LZ77 in the LF-group Modular streams of VarDCT frames (dec_ans.h): the LF kernel's general symbol reader with one 4 MB window
     per LF group; against the oracle and the ANS twin of the same frame, alone and in a batch beside plain frames (both LF decode kernels)."""
