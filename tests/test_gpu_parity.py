@@ -847,6 +847,23 @@ def test_full_size_4k_frame(jx):
     assert 10 * np.log10(255.0 ** 2 / (err ** 2).mean()) > 36.0     # size-independent property: decodes to the source picture
 
 
+def test_full_size_4k_frame_with_lf_frame_and_prefix_codes(jx):
+    """BASELINE config 2's size with what round 3 added: a 3840x2160 frame whose LF image is an LF frame (480x270, itself a VarDCT frame), both under
+    prefix codes.  Bit-exact vs the CPU decode; decodes to the source picture (size-independent property)."""
+    from test_synth_roundtrip import _block_means
+    img = S.synthetic_image(1001, 3840, 2160)
+    S.set_prefix(True)
+    try:
+        data = (S.encode_vardct_frame(img, S.frame(emit=2), seed=3)
+                + S.encode_vardct_frame(_block_means(img), S.frame(emit=1, is_last=0, frame_type=1, lf_level=1), seed=5, distance=0.3, epf_iters=0, gab=0)
+                + S.encode_vardct_frame(img, S.frame(emit=1, use_lf_frame=1), seed=1001, strategy_mix=1, epf_iters=1, gab=1))
+    finally:
+        S.set_prefix(False)
+    _, px = check_against_oracle(jx, data, np.uint8, 3)
+    err = px.reshape(2160, 3840, 3).astype(np.float64) - img
+    assert 10 * np.log10(255.0 ** 2 / (err ** 2).mean()) > 36.0
+
+
 def test_batch_api_mixed_sizes_and_lane_strides(jx):
     """Resident batch decode (include/jxl_hip.h JxlHipBatch*): frames of different sizes, several decode-thread packings,
     repeated decodes of the same prepared batch (idempotence)."""
