@@ -47,6 +47,21 @@ def _pmc_bytes(kernels, frames):
         return None
 
 
+def _valu_issue(frames, s_per_step, steady_ms):
+    """VALU issue rate of a step: wavefront-instructions per second over the chip's peak (1024 SIMDs, one wave64 FP32 instruction per 4 cycles, 2.4 GHz) — a lower bound of
+    how busy the vector ALUs are (transcendental and 64-bit operations take longer than 4 cycles).  Counts from the SQ counter passes of the round (profiles/sq_valu.json)."""
+    try:
+        per = json.load(open(os.path.join(ROOT, "profiles", "sq_valu.json")))["per_kernel"]
+        instr = sum(v["valu_wave_instr_per_frame"] for v in per.values() if v["calls"] == 2) * frames
+        peak = 256 * 4 * 2.4e9 / 4
+        out = {"wave_instr_per_step": int(instr), "peak_wave_instr_per_s": peak, "frac": round(instr / s_per_step / peak, 4)}
+        if steady_ms:
+            out["frac_steady_state"] = round(instr / (steady_ms * 1e-3) / peak, 4)
+        return out
+    except Exception:
+        return None
+
+
 def _textured(img, amp, seed):
     """Photograph-like detail on top of the smooth synthetic picture: fine grain plus 4x4-pixel texture, `amp` sRGB levels strong, correlated
     between the channels.  amp 5 takes a 4K frame from 0.8 to about 2 bits per pixel at distance 1 — what real `cjxl -d 1` photographs run."""
@@ -575,6 +590,9 @@ def main():
                                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
                                                      "traffic": pf, "algorithmic_bytes_per_launch": by, "avg_launch_ms": round(ms, 4)})(
                 stage_ms.get("idct", 0.0), stage_bytes.get("idct", 0), _pmc_bytes(("IdctTileKernel<4, true>", "IdctRareSpecialKernel"), B)),
+            # what the step as a whole runs into is neither HBM nor MFMA but vector-ALU issue (profiles/r03_notes.md): VALU wavefront-instructions of all kernels of a
+            # step (SQ_INSTS_VALU, profiles/sq_valu.json) against 256 CUs x 4 SIMDs issuing one wave64 FP32 instruction per 4 cycles at 2.4 GHz
+            "valu_issue": _valu_issue(B, head["elapsed"] / args.steps, steady),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             # when the tail of every timed step had completed (ms after the start of the timed region): pipeline fill, then the steady state
             "step_end_ms": e, "steady_state_ms_per_step": steady,
