@@ -100,7 +100,7 @@ def make_streams(distinct, width, height, epf, seed0=1000, texture=0.0):
     varblock maps and token counts).  Generated on the host cores in parallel (4.6 s per 4K frame).  Returns list of bytes."""
     import multiprocessing as mp
     jobs = [(seed0 + i, width, height, epf, texture) for i in range(distinct)]
-    workers = max(1, min(len(jobs), os.cpu_count() or 1, 64))
+    workers = max(1, min(len(jobs), int(os.environ.get("JXL_BENCH_SYNTH_WORKERS", "0")) or (os.cpu_count() or 1), 64))
     if workers == 1:
         return [_make_stream(j) for j in jobs]
     with mp.get_context("fork").Pool(workers) as pool:
@@ -439,7 +439,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "256")), help="frames per GPU per step")
-    ap.add_argument("--distinct", type=int, default=int(os.environ.get("JXL_BENCH_DISTINCT", "256")), help="distinct synthetic frames per GPU (cycled to fill the batches)")
+    ap.add_argument("--distinct", type=int, default=int(os.environ.get("JXL_BENCH_DISTINCT", "0")), help="distinct synthetic frames per GPU (cycled to fill the batches); default 256, 64 per GPU when N > 1 "
+                    "(the ranks of a node share its host cores for the synthesis: 4.6 s per frame)")
     ap.add_argument("--mode", choices=["streaming", "resident", "both"], default=os.environ.get("JXL_BENCH_MODE", "both"),
                     help="streaming (the headline): every step parses, prepares, uploads and decodes a fresh batch of compressed frames; resident: prepared "
                          "batches decoded again and again; both: streaming timed first, the resident figure reported beside it")
@@ -474,6 +475,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     W, H = args.width, args.height
+    if args.distinct <= 0:
+        args.distinct = 256 if world == 1 else 64
+    if world > 1:
+        args.realistic_distinct = min(args.realistic_distinct, 16)
+        os.environ.setdefault("JXL_BENCH_SYNTH_WORKERS", str(max(1, (os.cpu_count() or 1) // int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))))
 
     streams = make_streams(args.distinct, W, H, args.epf, seed0=1000 + 1000 * rank)
     # the same frames with photograph-like texture: ~2 bpp at distance 1 instead of 0.8 (second workload of the line, fewer distinct frames)
