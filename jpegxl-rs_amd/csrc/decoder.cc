@@ -467,6 +467,7 @@ void Batch::SetOutput(int i, const OutputSpec& o) {
   if (o.only_frame >= pub_[i].num_units) throw ParseError("non-coalesced output: no such frame", false);
   // (a lone frame that fills the image is the same either way: the plain path keeps it)
   if (o.only_frame == 0 && pub_[i].num_units == 1 && !e.plan.have_crop) e.out.only_frame = -1;
+  if (o.upto_frame >= pub_[i].num_units - 1 || o.only_frame >= 0) e.out.upto_frame = -1;     // (the last frame's composite is the image)
   ImageHeader dims = e.ih;
   OutputDims(i, e.out, &dims.xsize, &dims.ysize);
   uint32_t nc;
@@ -1657,7 +1658,9 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
         for (int c = 0; c < 3; c++) sl.p[c] = canvas[c];
         for (uint32_t k = 0; k < ne; k++) sl.ec[k] = canvas_ec[k];
       }
-      if (!p.is_last) continue;   // coalescing: the composite of the last frame is what the caller receives
+      // coalescing: the composite of the last frame is what the caller receives — or, for a frame of an animation, the canvas after that frame
+      const bool deliver = first.out.upto_frame >= 0 ? u == pi.first_unit + first.out.upto_frame : p.is_last;
+      if (!deliver) continue;
       // ---- spot colours (stage_spot.cc): colour = mix * spot + (1 - mix) * colour with mix = solidity * channel, channel by channel
       if (first.out.render_spotcolors) {
         for (uint32_t k = 0; k < ne; k++) {
@@ -1689,6 +1692,7 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
       wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian;
       wa.out_orient = first.out.keep_orientation ? 1 : ih.orientation; wa.is_gray = ih.color_space == 1;
       post_ops_.push_back([=](void* st) { LaunchWrite(wa, st); });
+      break;                      // (frames behind the delivered one: nothing of theirs is needed)
     }
   }
 }

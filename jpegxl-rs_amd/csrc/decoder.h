@@ -20,6 +20,7 @@ struct OutputSpec {
   void* device_ptr = nullptr;  // optional caller-owned device destination
   bool keep_orientation = false;  // false: the header's orientation is applied to the output (libjxl's default)
   bool unpremul_alpha = false;    // JxlDecoderSetUnpremultiplyAlpha: premultiplied colour is divided by alpha in the write stage
+  int upto_frame = -1;            // >= 0: coalesced output of an animation frame — the canvas as it stands after frame `upto_frame` has been blended (the frames behind it are not shown)
   int only_frame = -1;            // >= 0: non-coalesced output (JxlDecoderSetCoalescing(false)) — frame `only_frame` of the image as coded: its own size, its own
                                   // pixels after the colour transform, not blended onto the canvas
   bool render_spotcolors = true;  // JxlDecoderSetRenderSpotcolors: spot-colour extra channels are mixed into the colour channels (stage_spot.cc)

@@ -66,7 +66,14 @@ static void ClearState(JxlDecoder* d) {
 static void ListFrames(JxlDecoder* d) {
   d->frames.clear();
   const int n = d->batch->num_frames(0);
-  if (d->coalescing) { d->frames.push_back(n - 1); return; }
+  if (d->coalescing) {
+    // the composite after the last frame — or, for an animation, after every frame that is shown (frame_header.cc: a regular frame with a duration, or the last one;
+    // frames of duration 0 are layers of the frame that follows)
+    if (d->batch->image(0).ih.have_animation)
+      for (int k = 0; k + 1 < n; k++) { const FramePlan& p = d->batch->frame(0, k).plan; if ((p.frame_type == 0 || p.frame_type == 3) && p.duration > 0) d->frames.push_back(k); }
+    d->frames.push_back(n - 1);
+    return;
+  }
   for (int k = 0; k < n; k++) { const uint32_t t = d->batch->frame(0, k).plan.frame_type; if (t == 0 || t == 3) d->frames.push_back(k); }
 }
 static int CurrentFrame(const JxlDecoder* d) { return d->batch && d->frame_cursor < d->frames.size() ? d->frames[d->frame_cursor] : -1; }
@@ -146,7 +153,7 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
   if (d->coalescing) {                     // the composite: no crop, the image's size (jpegxl-sys codestream_header.rs:324-329)
     h->layer_info.xsize = e.ih.xsize; h->layer_info.ysize = e.ih.ysize;
     if (!d->keep_orientation && e.ih.orientation > 4) { h->layer_info.xsize = e.ih.ysize; h->layer_info.ysize = e.ih.xsize; }
-    h->is_last = 1;
+    h->is_last = d->frame_cursor + 1 >= d->frames.size() ? 1 : 0;      // (the only composite of a still image; the last shown frame of an animation)
     return JXL_DEC_SUCCESS;
   }
   h->layer_info.have_crop = p.have_crop ? 1 : 0;
@@ -379,6 +386,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       o.unpremul_alpha = d->unpremul_alpha;
       o.render_spotcolors = d->render_spotcolors;
       o.only_frame = d->coalescing ? -1 : d->frames[d->frame_cursor];
+      o.upto_frame = d->coalescing && d->frames.size() > 1 ? d->frames[d->frame_cursor] : -1;
       d->batch->SetOutput(0, o);
       if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
       d->batch->Prepare(nullptr);
@@ -396,7 +404,8 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       } else d->batch->CopyOutputToHost(0, d->out_buffer, d->batch->image(0).out_size, nullptr);
       d->frame_cursor++; d->frame_announced = false;
       d->events_emitted |= JXL_DEC_FULL_IMAGE;
-      if (!d->coalescing) { d->out_set = false; d->out_buffer = nullptr; d->out_callback = nullptr; }     // every layer gets a buffer of its own size
+      // every layer gets a buffer of its own size; every frame of an animation is asked for anew (decode.cc: the buffer is used up by a frame)
+      if (!d->coalescing || d->frame_cursor < d->frames.size()) { d->out_set = false; d->out_buffer = nullptr; d->out_callback = nullptr; }
       return JXL_DEC_FULL_IMAGE;
     }
     return JXL_DEC_SUCCESS;

@@ -20,7 +20,7 @@ class Frame(C.Structure):
     """Frame control of the synthesiser (tools/jxl_synth.cc jxlsynth_frame)."""
     _fields_ = [("noise", C.c_int32), ("noise_lut", C.c_uint32 * 8)] + [(n, C.c_int32) for n in (
         "frame_type", "have_crop", "crop_x0", "crop_y0", "canvas_w", "canvas_h", "blend_mode", "blend_source", "blend_clamp", "is_last",
-        "save_as_reference", "save_before_ct", "emit", "num_extra_hdr", "xyb_image", "alpha_premultiplied", "use_lf_frame", "lf_level", "mod_passes", "mod_ds")]
+        "save_as_reference", "save_before_ct", "emit", "num_extra_hdr", "xyb_image", "alpha_premultiplied", "use_lf_frame", "lf_level", "mod_passes", "mod_ds", "duration")]
 
 
 def frame(**kw):
@@ -242,6 +242,11 @@ def set_color(white_point=None, primaries=1, tf=13, gamma=0.0, intensity_target=
         L.jxlsynth_set_color(-1, 1, 13, 0, 255.0)
     else:
         L.jxlsynth_set_color(white_point, primaries, tf, int(round(gamma * 1e7)), intensity_target)
+
+
+def set_animation(tps_num=0, tps_den=1, loops=0):
+    """Image headers written from now on announce an animation (tps_num / tps_den ticks per second; 0: none); frames then carry frame(duration=...)."""
+    lib().jxlsynth_set_animation(int(tps_num), int(tps_den), int(loops))
 
 
 def set_preview(w=0, h=0):

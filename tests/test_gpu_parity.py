@@ -192,6 +192,69 @@ def test_raw_ffi_sequence(jx):
     assert np.array_equal(buf, O.decode(fixture_bytes("sample.jxl")).pixels("u8", 3))
 
 
+def test_coalesced_animation_frames(jx):
+    """An animation decoded with coalescing (the default): every frame that is shown arrives as JXL_DEC_FRAME (JxlDecoderGetFrameHeader: duration,
+    is_last, the image's size) -> JXL_DEC_NEED_IMAGE_OUT_BUFFER -> JXL_DEC_FULL_IMAGE with the canvas as it stands after that frame; frames of
+    duration 0 are layers of the frame behind them.  Expected canvases: the oracle's decode of the stream cut after the frame (the frame written as
+    the last one).  jpegxl-rs's loop (decode.rs:207-325) refills its buffer per frame and so returns the last canvas."""
+    L = jx.libjxl()
+    big, small, img = S.synthetic_image(6, 600, 400), S.synthetic_image(9, 64, 48), S.synthetic_image(5, 200, 136)
+    S.set_animation(100, 1, 0)
+    try:
+        def f0(last): return S.encode_vardct_frame(big, S.frame(is_last=last, save_as_reference=0 if last else 1, duration=10), seed=3, strategy_mix=2)
+        def f1(last, dur): return S.encode_vardct_frame(small, S.frame(emit=1, is_last=last, have_crop=1, crop_x0=300, crop_y0=160, canvas_w=600, canvas_h=400, blend_mode=1, blend_source=1,
+                                                                        save_as_reference=0 if last else 1, duration=dur), seed=4)
+        f2 = S.encode_vardct_frame(img, S.frame(emit=1, have_crop=1, crop_x0=-30, crop_y0=300, canvas_w=600, canvas_h=400, blend_mode=0, blend_source=1, duration=7), seed=5, epf_iters=2)
+        full, upto0, upto1 = f0(0) + f1(0, 5) + f2, f0(1), f0(0) + f1(1, 5)
+        layered = f0(0) + f1(0, 0) + f2                     # the middle frame is a layer of the last one: two frames are shown
+    finally:
+        S.set_animation(0)
+    want = [O.decode(s_).pixels("u8", 3) for s_ in (upto0, upto1, full)]
+    fmt = jx.JxlPixelFormat(3, jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+
+    def run(stream):
+        data = np.frombuffer(stream, np.uint8)
+        dec = L.JxlDecoderCreate(None)
+        assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_FRAME | jx.JXL_DEC_FULL_IMAGE) == 0
+        assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+        L.JxlDecoderCloseInput(dec)
+        got, headers, buf = [], [], None
+        while True:
+            st = L.JxlDecoderProcessInput(dec)
+            if st == jx.JXL_DEC_BASIC_INFO:
+                info = jx.JxlBasicInfo()
+                assert L.JxlDecoderGetBasicInfo(dec, C.byref(info)) == 0
+                assert info.have_animation == 1 and (info.xsize, info.ysize) == (600, 400)
+            elif st == jx.JXL_DEC_FRAME:
+                fh = jx.JxlFrameHeader()
+                assert L.JxlDecoderGetFrameHeader(dec, C.byref(fh)) == 0
+                headers.append((fh.duration, fh.is_last, fh.layer_info.xsize, fh.layer_info.ysize))
+            elif st == jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+                size = C.c_size_t()
+                assert L.JxlDecoderImageOutBufferSize(dec, C.byref(fmt), C.byref(size)) == 0 and size.value == 600 * 400 * 3
+                buf = np.zeros(size.value, np.uint8)
+                assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), buf.ctypes.data, size.value) == 0
+            elif st == jx.JXL_DEC_FULL_IMAGE:
+                got.append(buf); buf = None
+            elif st == jx.JXL_DEC_SUCCESS:
+                break
+            else:
+                raise AssertionError(st)
+        L.JxlDecoderDestroy(dec)
+        return got, headers
+
+    got, headers = run(full)
+    assert headers == [(10, 0, 600, 400), (5, 0, 600, 400), (7, 1, 600, 400)]
+    assert len(got) == 3
+    for k in range(3):
+        assert np.array_equal(got[k], want[k]), k
+    got, headers = run(layered)
+    assert headers == [(10, 0, 600, 400), (7, 1, 600, 400)] and len(got) == 2
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], O.decode(layered).pixels("u8", 3))
+    _, px = jx.decoder_builder().decode_with(full, np.uint8)
+    assert np.array_equal(px.reshape(-1), want[2])
+
+
 def test_preview_frames_are_stepped_over(jx):
     """An image with a preview (headers.cc PreviewHeader; a frame of that size in front of the image's frames): jpegxl-rs never subscribes to
     JXL_DEC_PREVIEW_IMAGE (decode.rs:334-347), so the preview is stepped over and the image decodes to what it decodes to without one;

@@ -96,6 +96,7 @@ struct Params {
   int emit = 0;                                   // 0 image header + frame, 1 frame only, 2 image header only
   int use_lf_frame = 0;                           // VarDCT: the LF image comes from the LF frame written before (flag 32: no LF coefficients in the LfGroups)
   int lf_level = 0;                               // frame_type 1 (LF frame): its level (1: the LF image of the regular frames)
+  int duration = 0;                               // animation (jxlsynth_set_animation): ticks this frame is shown
   int mod_passes = 1;                             // Modular frames: passes (1 .. 3); the squeezed channels are spread over them by shift
   int mod_ds = 1;                                 // ... with downsampling entries (passes.h GetDownsamplingBracket): pass i carries shift np - 1 - i (the first also 2);
                                                   // 0: no entries — everything rides in the last pass, the others are empty
@@ -469,6 +470,7 @@ static void WriteIccStream(BitWriter& w, const std::vector<uint8_t>& icc) {
   EncodeTokens(w, code, tok);
 }
 
+static int g_anim_num = 0, g_anim_den = 1, g_anim_loops = 0;   // jxlsynth_set_animation: ticks per second (0: no animation), loop count
 static int g_preview_w = 0, g_preview_h = 0;   // jxlsynth_set_preview: the image header announces a preview frame of this size (the caller emits it first)
 // headers.cc PreviewHeader
 static void WritePreviewSize(BitWriter& w, int xs, int ys) {
@@ -486,19 +488,25 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
   const bool custom_up = p.upsampling > 1 && p.custom_up_weights;
-  const bool preview = g_preview_w > 0 && g_preview_h > 0;
-  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set && !g_float_exp_bits && !preview;
+  const bool preview = g_preview_w > 0 && g_preview_h > 0, anim = g_anim_num > 0;
+  bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set && !g_float_exp_bits && !preview && !anim;
   w.put(all_default, 1);
   if (!all_default) {
     const bool custom_target = g_color.set && g_color.intensity_target != 255.0f;
-    bool extra_fields = p.hdr || p.orientation != 1 || custom_target || preview;
+    bool extra_fields = p.hdr || p.orientation != 1 || custom_target || preview || anim;
     w.put(extra_fields, 1);
     if (extra_fields) {
       w.put((uint32_t)(p.orientation - 1), 3);
       w.put(0, 1);                                  // no intrinsic size
       w.put(preview ? 1 : 0, 1);
       if (preview) WritePreviewSize(w, g_preview_w, g_preview_h);
-      w.put(0, 1);                                  // no animation
+      w.put(anim ? 1 : 0, 1);
+      if (anim) {                                   // headers.cc AnimationHeader
+        WriteU32(w, (uint32_t)g_anim_num, {0, 100}, {0, 1000}, {10, 1}, {30, 1});
+        WriteU32(w, (uint32_t)g_anim_den, {0, 1}, {0, 1001}, {8, 1}, {10, 1});
+        WriteU32(w, (uint32_t)g_anim_loops, {0, 0}, {3, 0}, {16, 0}, {32, 0});
+        w.put(0, 1);                                // have_timecodes
+      }
     }
     // BitDepth
     if (p.out_bits == 32) { w.put(1, 1); WriteU32(w, 32, {0, 32}, {0, 16}, {0, 24}, {6, 1}); w.put(8 - 1, 4); }
@@ -619,12 +627,14 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
       if (num_extra > 0 && (p.blend_mode == 2 || p.blend_mode == 3 || p.blend_mode == 4)) w.put(p.blend_clamp ? 1 : 0, 1);
       if (p.blend_mode != 0 || partial) w.put((uint32_t)p.blend_source, 2);
     }
+    if (g_anim_num > 0) WriteU32(w, (uint32_t)p.duration, {0, 0}, {0, 1}, {8, 0}, {32, 0});   // duration in ticks (no timecodes)
     w.put(p.is_last ? 1 : 0, 1);  // is_last
   }
   const bool is_last = (p.frame_type == 0 || p.frame_type == 3) ? p.is_last != 0 : false;
   if (!is_last && p.frame_type != 1) w.put((uint32_t)p.save_as_reference, 2);
   {
-    const bool can_ref = !is_last && p.frame_type != 1;      // (no animation: duration 0)
+    const int dur = g_anim_num > 0 && (p.frame_type == 0 || p.frame_type == 3) ? p.duration : 0;
+    const bool can_ref = !is_last && p.frame_type != 1 && (dur == 0 || p.save_as_reference != 0);
     const bool full_replace = (p.frame_type == 0 || p.frame_type == 3) && p.blend_mode == 0 && !partial;
     if (p.frame_type == 2 || (can_ref && full_replace)) w.put(p.save_before_ct ? 1 : 0, 1);
   }
@@ -1341,6 +1351,7 @@ void jxlsynth_image(uint32_t seed, int w, int h, uint8_t* rgb) { synth::Syntheti
 void jxlsynth_set_icc(const uint8_t* icc, size_t size) { synth::g_icc.assign(icc, icc + size); }
 void jxlsynth_set_float(int exp_bits) { synth::g_float_exp_bits = exp_bits; }
 // entropy-coded streams written from now on in this thread use prefix (Huffman) codes instead of ANS — what cjxl's fast efforts emit
+void jxlsynth_set_animation(int tps_num, int tps_den, int loops) { synth::g_anim_num = tps_num; synth::g_anim_den = tps_den > 0 ? tps_den : 1; synth::g_anim_loops = loops; }
 void jxlsynth_set_preview(int w, int h) { synth::g_preview_w = w; synth::g_preview_h = h; }
 void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
@@ -1416,7 +1427,7 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
 // frame emitted with emit = 0) and any number of frames (emit = 1), the last one with is_last = 1.
 struct jxlsynth_frame {
   int32_t noise; uint32_t noise_lut[8];
-  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image, alpha_premultiplied, use_lf_frame, lf_level, mod_passes, mod_ds;
+  int32_t frame_type, have_crop, crop_x0, crop_y0, canvas_w, canvas_h, blend_mode, blend_source, blend_clamp, is_last, save_as_reference, save_before_ct, emit, num_extra_hdr, xyb_image, alpha_premultiplied, use_lf_frame, lf_level, mod_passes, mod_ds, duration;
 };
 static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
   if (!fx) return;
@@ -1425,7 +1436,7 @@ static void ApplyFrame(synth::Params& p, const jxlsynth_frame* fx) {
   p.blend_mode = fx->blend_mode; p.blend_source = fx->blend_source; p.blend_clamp = fx->blend_clamp; p.is_last = fx->is_last; p.save_as_reference = fx->save_as_reference;
   p.save_before_ct = fx->save_before_ct; p.emit = fx->emit; p.num_extra_hdr = fx->num_extra_hdr; p.xyb_image = fx->xyb_image; p.alpha_premultiplied = fx->alpha_premultiplied;
   p.use_lf_frame = fx->use_lf_frame; p.lf_level = fx->lf_level;
-  p.mod_passes = fx->mod_passes > 0 ? fx->mod_passes : 1; p.mod_ds = fx->mod_ds;
+  p.mod_passes = fx->mod_passes > 0 ? fx->mod_passes : 1; p.mod_ds = fx->mod_ds; p.duration = fx->duration;
 }
 int jxlsynth_vardct3(const uint8_t* rgb8, const uint8_t* alpha8, int w, int h, const jxlsynth_params* pp, const jxlsynth_frame* fx, uint8_t** out, size_t* n) {
   try {
