@@ -108,6 +108,10 @@ JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* dec, JxlColorP
 JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* dec, float desired_intensity_target);                         /* decode.rs:921 */
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size);              /* decode.rs:1100 */
 JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* dec, const JxlPixelFormat* format, void* buffer, size_t size);        /* decode.rs:1123 */
+// jpegxl-sys/src/decode.rs:999-1025: the preview image (JXL_DEC_PREVIEW_IMAGE / JXL_DEC_NEED_PREVIEW_OUT_BUFFER; JxlBasicInfo.have_preview, .preview) — the preview frame is
+// decoded on the GPU like an image of its own.  jpegxl-rs itself never subscribes to it (decode.rs:334-347).
+JxlDecoderStatus JxlDecoderPreviewOutBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size);
+JxlDecoderStatus JxlDecoderSetPreviewOutBuffer(JxlDecoder* dec, const JxlPixelFormat* format, void* buffer, size_t size);
 /* Pixel output through a callback instead of a buffer (decode.rs:289-309, :1172): called once per row (x = 0, num_pixels = xsize) from
  * the thread inside JxlDecoderProcessInput after the image has been decoded; the row memory is only valid during the call. */
 typedef void (*JxlImageOutCallback)(void* opaque, size_t x, size_t y, size_t num_pixels, const void* pixels);

@@ -339,11 +339,67 @@ int Batch::Append(ParsedImage&& im) {
   return (int)pub_.size() - 1;
 }
 
+// what the device path cannot take of a frame that parsed (thrown as "unsupported: ...")
+static void CheckFrameSupported(const FramePlan& p, const ImageHeader& ih) {
+  if (!p.modular) {
+    for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
+    if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
+    if (p.subsampled && (p.base_x != 0.f || p.base_b != 0.f)) throw ParseError("unsupported: chroma from luma in a chroma-subsampled frame", true);
+    if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
+  }
+  for (auto& x : ih.extra) {
+    if (x.dim_shift != 0) throw ParseError("unsupported: subsampled extra channel", true);
+    if (x.depth.is_float) {
+      const uint32_t b = x.depth.bits, eb = x.depth.exp_bits;
+      if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) throw ParseError("unsupported: float sample layout", true);
+    }
+  }
+  if (p.modular && ih.depth.is_float && !ih.xyb_encoded) {
+    // dec_modular.cc int_to_float: the sample's bit pattern, exp_bits of exponent; what the format allows and a binary32 can hold
+    const uint32_t b = ih.depth.bits, eb = ih.depth.exp_bits;
+    if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) throw ParseError("unsupported: float sample layout", true);
+  }
+  if (p.feat.has_noise && !ih.xyb_encoded) throw ParseError("noise on a non-XYB frame", false);
+}
+
+// The preview of image i (headers.cc PreviewHeader; JXL_DEC_PREVIEW_IMAGE, jpegxl-sys decode.rs:999-1025): the preview frame decoded as a one-frame image of the
+// preview's size by a batch of its own — the same kernels, the frame tail for colour and write — and copied to `dst`.
+ImageHeader Batch::PreviewHeaderOf(int i) const {
+  const ImageEntry& e = *images_[pub_[i].first_unit];
+  if (!e.ih.have_preview) throw ParseError("the image has no preview", false);
+  ImageHeader ph = e.ih;
+  ph.xsize = e.ih.preview_x; ph.ysize = e.ih.preview_y; ph.have_preview = false; ph.intrinsic_x = ph.intrinsic_y = 0;
+  return ph;
+}
+size_t Batch::PreviewOutputSize(int i, const OutputSpec& o) const { return OutputSize(PreviewHeaderOf(i), o); }
+void Batch::DecodePreview(int i, const OutputSpec& o, void* dst, size_t cap, void* stream_v) {
+  const ImageEntry& e = *images_[pub_[i].first_unit];
+  std::shared_ptr<ImageShared> sh(new ImageShared());
+  sh->cs = e.cs; sh->ih = PreviewHeaderOf(i);
+  std::unique_ptr<ImageEntry> u(new ImageEntry(sh));
+  u->frame_bitpos = e.preview_bitpos; u->frame_index = 0; u->complex = true;
+  u->visible_frame_index = 1; u->nonvisible_frame_index = 0;
+  ParseFrameStart(sh->cs, sh->ih, u->frame_bitpos, &u->plan);
+  if (u->plan.frame_type != 0 || u->plan.use_lf_frame) throw ParseError("the preview must be a regular frame", false);
+  u->plan.is_last = true;                              // (whatever the frame says: nothing of the image follows it as far as the preview goes)
+  CheckFrameSupported(u->plan, sh->ih);
+  if (sh->ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels in a preview", true);
+  Batch tmp(device_);
+  ParsedImage pi; pi.complex = true; pi.units.push_back(std::move(u));
+  tmp.Append(std::move(pi));
+  tmp.SetOutput(0, o);
+  if (tmp.image(0).out_size > cap) throw ParseError("preview output buffer too small", false);
+  tmp.Prepare(stream_v);
+  tmp.Run(stream_v);
+  tmp.Finish(stream_v);
+  tmp.CopyOutputToHost(0, dst, tmp.image(0).out_size, stream_v);
+}
+
 void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
   std::shared_ptr<ImageShared> sh(new ImageShared());
   bool have_container = false, has_jbrd = false;
   if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, &sh->boxes)) throw ParseError("truncated", false);
-  uint64_t bitpos = 0;
+  uint64_t bitpos = 0, preview_bitpos = 0;
   ParseImageHeader(sh->cs, &sh->ih, &bitpos);
   sh->ih.have_container = have_container;
   const ImageHeader& ih = sh->ih;
@@ -360,6 +416,7 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
     FramePlan pp;
     ParseFrameStart(sh->cs, ph, bitpos, &pp, /*header_and_toc_only=*/true);
     if (pp.frame_type != 0) throw ParseError("the preview must be a regular frame", false);
+    preview_bitpos = bitpos;
     bitpos = pp.frame_end_bitpos;
   }
   // every frame of the image (frame_header.cc): reference-only / zero-duration layers first, the last one is displayed
@@ -384,25 +441,7 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
       if (p.subsampled || src->plan.width != p.bw || src->plan.height != p.bh) throw ParseError("LF frame of the wrong size", false);
       e->lf_source = src;
     }
-    if (!p.modular) {
-      for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
-      if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
-      if (p.subsampled && (p.base_x != 0.f || p.base_b != 0.f)) throw ParseError("unsupported: chroma from luma in a chroma-subsampled frame", true);
-      if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
-    }
-    for (auto& x : ih.extra) {
-      if (x.dim_shift != 0) throw ParseError("unsupported: subsampled extra channel", true);
-      if (x.depth.is_float) {
-        const uint32_t b = x.depth.bits, eb = x.depth.exp_bits;
-        if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) throw ParseError("unsupported: float sample layout", true);
-      }
-    }
-    if (p.modular && ih.depth.is_float && !ih.xyb_encoded) {
-      // dec_modular.cc int_to_float: the sample's bit pattern, exp_bits of exponent; what the format allows and a binary32 can hold
-      const uint32_t b = ih.depth.bits, eb = ih.depth.exp_bits;
-      if (b > 32 || eb < 2 || eb > 8 || b < eb + 2 || b - eb - 1 > 23 || (b == 32 && eb != 8)) throw ParseError("unsupported: float sample layout", true);
-    }
-    if (p.feat.has_noise && !ih.xyb_encoded) throw ParseError("noise on a non-XYB frame", false);
+    CheckFrameSupported(p, ih);
     const bool last = p.is_last;
     bitpos = p.frame_end_bitpos;
     if (p.frame_type == 1) {              // an LF frame: kept aside for the frames that refer to it (decoded by Batch::lf_batch_), never displayed
@@ -425,7 +464,7 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
   }
   for (auto& x : ih.extra) if (x.depth.is_float) complex = true;   // float extra channels are converted in the frame tail (IntToFloatSample)
   if (complex && ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels in a multi-frame / feature image", true);
-  for (auto& u : units) u->complex = complex;
+  for (auto& u : units) { u->complex = complex; u->preview_bitpos = preview_bitpos; }
   out->units = std::move(units);
   out->complex = complex;
 }

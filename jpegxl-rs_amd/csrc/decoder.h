@@ -44,6 +44,7 @@ struct ImageEntry {
   int pub_index = 0, frame_index = 0;  // image the frame belongs to, position among its frames
   bool complex = false;                // frame of a complex image
   uint32_t visible_frame_index = 0, nonvisible_frame_index = 0;   // noise seeds (dec_frame.cc)
+  uint64_t preview_bitpos = 0;             // where the preview frame starts (images with a preview: ih.have_preview)
   std::shared_ptr<ImageEntry> lf_source;   // the LF frame (frame type 1) a frame with use_lf_frame takes its LF image from; not a unit of the batch itself
   // arena offsets
   size_t off_cs = 0, off_sec = 0, off_tree = 0, off_bcm = 0;
@@ -108,6 +109,10 @@ class Batch {
   vec<uint8_t> ReconstructJpeg(int i, void* stream);
   // Copies frame i's pixels to host memory (after Finish).
   void CopyOutputToHost(int i, void* dst, size_t size, void* stream);
+  // the preview of image i (JXL_DEC_PREVIEW_IMAGE): its header (the image header with the preview's size), the size of its output, the decode into host memory
+  ImageHeader PreviewHeaderOf(int i) const;
+  size_t PreviewOutputSize(int i, const OutputSpec& o) const;
+  void DecodePreview(int i, const OutputSpec& o, void* dst, size_t cap, void* stream);
   void* device_output(int i) const;
   // Same as Run but brackets every stage with HIP events recorded on `stream` (no host sync).  CollectTimes() waits for
   // all recorded runs and returns the per-stage sums (ms) and the number of runs; used by bench.py for the roofline.

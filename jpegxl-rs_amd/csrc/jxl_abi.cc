@@ -27,6 +27,7 @@ struct JxlDecoderStruct {
   const uint8_t* input; size_t input_size; bool input_set, input_closed;
   void* out_buffer; size_t out_size; JxlPixelFormat out_format; bool out_set;
   JxlImageOutCallback out_callback; void* out_callback_opaque;   // alternative to out_buffer (rows are handed out after the decode)
+  void* preview_buffer; size_t preview_size; JxlPixelFormat preview_format; bool preview_set;   // JxlDecoderSetPreviewOutBuffer
   uint8_t* jpeg_buffer; size_t jpeg_size; bool jpeg_set;
   bool jpeg_available; size_t jpeg_written; vec<uint8_t> jpeg_bytes;   // JPEG bit-stream reconstruction (jbrd)
   // progress
@@ -56,6 +57,7 @@ static void ClearState(JxlDecoder* d) {
   d->runner = nullptr; d->runner_opaque = nullptr;
   d->input = nullptr; d->input_size = 0; d->input_set = d->input_closed = false;
   d->out_buffer = nullptr; d->out_size = 0; d->out_set = false; d->out_callback = nullptr; d->out_callback_opaque = nullptr;
+  d->preview_buffer = nullptr; d->preview_size = 0; d->preview_set = false;
   d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
@@ -261,6 +263,30 @@ JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat
   d->out_buffer = buffer; d->out_size = size; d->out_format = *format; d->out_set = true;
   return JXL_DEC_SUCCESS;
 }
+// The preview (jpegxl-sys decode.rs:999-1025): announced after the colour encoding when JXL_DEC_PREVIEW_IMAGE is subscribed and the image has one —
+// JXL_DEC_NEED_PREVIEW_OUT_BUFFER until a buffer is set, then decoded (a batch of its own for the preview frame) and reported as JXL_DEC_PREVIEW_IMAGE.
+static bool PreviewSpec(const JxlDecoder* d, const JxlPixelFormat* format, OutputSpec* o) {
+  if (!FormatToSpec(format, o)) return false;
+  if (o->num_channels != 0 && o->num_channels < 3 && d->batch->image(0).ih.color_space != 1) { SetLastError("number of channels is too low for colour output"); return false; }
+  o->keep_orientation = d->keep_orientation;
+  o->unpremul_alpha = d->unpremul_alpha;
+  return true;
+}
+JxlDecoderStatus JxlDecoderPreviewOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* format, size_t* size) {
+  if (!d->batch || d->stage < JxlDecoderStruct::kHeaders || !size) return JXL_DEC_ERROR;
+  try {
+    OutputSpec o;
+    if (!d->batch->image(0).ih.have_preview || !PreviewSpec(d, format, &o)) return JXL_DEC_ERROR;
+    *size = d->batch->PreviewOutputSize(0, o);
+    return JXL_DEC_SUCCESS;
+  } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
+}
+JxlDecoderStatus JxlDecoderSetPreviewOutBuffer(JxlDecoder* d, const JxlPixelFormat* format, void* buffer, size_t size) {
+  size_t need = 0;
+  if (!buffer || JxlDecoderPreviewOutBufferSize(d, format, &need) != JXL_DEC_SUCCESS || size < need) return JXL_DEC_ERROR;
+  d->preview_buffer = buffer; d->preview_size = size; d->preview_format = *format; d->preview_set = true;
+  return JXL_DEC_SUCCESS;
+}
 JxlDecoderStatus JxlDecoderSetImageOutCallback(JxlDecoder* d, const JxlPixelFormat* format, JxlImageOutCallback callback, void* opaque) {
   if (!d || !format || !callback || !d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_ERROR;
   if (d->out_set) { SetLastError("an output buffer or callback is already set"); return JXL_DEC_ERROR; }
@@ -335,6 +361,14 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
     if (d->stage == JxlDecoderStruct::kHeaders) {
       if ((d->events_wanted & JXL_DEC_BASIC_INFO) && !(d->events_emitted & JXL_DEC_BASIC_INFO)) { d->events_emitted |= JXL_DEC_BASIC_INFO; return JXL_DEC_BASIC_INFO; }
       if ((d->events_wanted & JXL_DEC_COLOR_ENCODING) && !(d->events_emitted & JXL_DEC_COLOR_ENCODING)) { d->events_emitted |= JXL_DEC_COLOR_ENCODING; return JXL_DEC_COLOR_ENCODING; }
+      if ((d->events_wanted & JXL_DEC_PREVIEW_IMAGE) && !(d->events_emitted & JXL_DEC_PREVIEW_IMAGE) && d->batch->image(0).ih.have_preview) {
+        if (!d->preview_set) return JXL_DEC_NEED_PREVIEW_OUT_BUFFER;
+        OutputSpec o;
+        if (!PreviewSpec(d, &d->preview_format, &o)) return JXL_DEC_ERROR;
+        d->batch->DecodePreview(0, o, d->preview_buffer, d->preview_size, nullptr);      // ══► the HIP hot path, on the preview frame
+        d->events_emitted |= JXL_DEC_PREVIEW_IMAGE;
+        return JXL_DEC_PREVIEW_IMAGE;
+      }
       // JPEG reconstruction (decode.rs:258-269): announced when the container carries a usable jbrd box; otherwise pixels
       if ((d->events_wanted & JXL_DEC_JPEG_RECONSTRUCTION) && !(d->events_emitted & JXL_DEC_JPEG_RECONSTRUCTION)) {
         d->events_emitted |= JXL_DEC_JPEG_RECONSTRUCTION;

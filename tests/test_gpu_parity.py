@@ -262,7 +262,7 @@ def test_preview_frames_are_stepped_over(jx):
     from test_synth_roundtrip import preview_streams
     L = jx.libjxl()
     cases = preview_streams()
-    for name, with_preview, plain, (pw, ph) in cases:
+    for name, with_preview, plain, (pw, ph), _ in cases:
         ref = O.decode(plain).pixels("u8", 3)
         _, px = check_against_oracle(jx, with_preview, np.uint8, 3)
         assert np.array_equal(px.reshape(-1), ref), name
@@ -277,7 +277,7 @@ def test_preview_frames_are_stepped_over(jx):
         assert (info.have_preview, info.preview_xsize, info.preview_ysize, info.xsize, info.ysize) == (1, pw, ph, 300, 200), name
         L.JxlDecoderDestroy(dec)
     b = jx.BatchDecoder(0)
-    for name, with_preview, plain, _ in cases:
+    for name, with_preview, plain, _, _ in cases:
         b.add(with_preview, "uint8", 3); b.add(plain, "uint8", 3)
     b.prepare(); b.decode(); b.finish()
     for i in range(len(cases)):
@@ -425,6 +425,49 @@ def test_multipass_modular_frames(jx):
         got = b.output(i)
         got = got.view(np.uint16) if bits > 8 else got
         assert np.array_equal(got.reshape(img.shape), img), name
+
+
+def test_preview_image_is_delivered_when_subscribed(jx):
+    """JXL_DEC_PREVIEW_IMAGE (jpegxl-sys decode.rs:999-1025, status 0x200): a caller that subscribes gets JXL_DEC_NEED_PREVIEW_OUT_BUFFER, sets a buffer of
+    JxlDecoderPreviewOutBufferSize bytes and receives the preview — the preview frame decoded on the GPU like an image of its own — before the frames of
+    the image; expected pixels: the oracle's decode of the preview written as an image of its own."""
+    from test_synth_roundtrip import preview_streams
+    L = jx.libjxl()
+    for name, with_preview, plain, (pw, ph), alone in preview_streams():
+        for dtype, jt, kind in ((np.uint8, jx.JXL_TYPE_UINT8, "u8"), (np.float32, jx.JXL_TYPE_FLOAT, "f32")):
+            fmt = jx.JxlPixelFormat(3, jt, jx.JXL_NATIVE_ENDIAN, 0)
+            data = np.frombuffer(with_preview, np.uint8)
+            dec = L.JxlDecoderCreate(None)
+            assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO | jx.JXL_DEC_PREVIEW_IMAGE | jx.JXL_DEC_FULL_IMAGE) == 0
+            assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+            L.JxlDecoderCloseInput(dec)
+            events, prev, buf = [], None, None
+            while True:
+                st = L.JxlDecoderProcessInput(dec)
+                events.append(st)
+                if st == jx.JXL_DEC_NEED_PREVIEW_OUT_BUFFER:
+                    size = C.c_size_t()
+                    assert L.JxlDecoderPreviewOutBufferSize(dec, C.byref(fmt), C.byref(size)) == 0
+                    assert size.value == pw * ph * 3 * np.dtype(dtype).itemsize
+                    prev = np.zeros(pw * ph * 3, dtype)
+                    assert L.JxlDecoderSetPreviewOutBuffer(dec, C.byref(fmt), prev.ctypes.data, size.value - 1) == 1     # too small
+                    assert L.JxlDecoderSetPreviewOutBuffer(dec, C.byref(fmt), prev.ctypes.data, size.value) == 0
+                elif st == jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+                    size = C.c_size_t()
+                    assert L.JxlDecoderImageOutBufferSize(dec, C.byref(fmt), C.byref(size)) == 0
+                    buf = np.zeros(300 * 200 * 3, dtype)
+                    assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), buf.ctypes.data, size.value) == 0
+                elif st == jx.JXL_DEC_SUCCESS:
+                    break
+                elif st not in (jx.JXL_DEC_BASIC_INFO, jx.JXL_DEC_PREVIEW_IMAGE, jx.JXL_DEC_FULL_IMAGE):
+                    raise AssertionError(st)
+            L.JxlDecoderDestroy(dec)
+            assert events == [jx.JXL_DEC_BASIC_INFO, jx.JXL_DEC_NEED_PREVIEW_OUT_BUFFER, jx.JXL_DEC_PREVIEW_IMAGE, jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER, jx.JXL_DEC_FULL_IMAGE, jx.JXL_DEC_SUCCESS], name
+            want_prev, want_img = O.decode(alone).pixels(kind, 3).view(dtype), O.decode(plain).pixels(kind, 3).view(dtype)
+            if dtype == np.float32:
+                assert ulp_diff(prev, want_prev) <= 1 and ulp_diff(buf, want_img) <= 1, name
+            else:
+                assert np.array_equal(prev, want_prev) and np.array_equal(buf, want_img), name
 
 
 def test_non_coalesced_frames_and_frame_headers(jx):

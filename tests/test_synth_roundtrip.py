@@ -227,7 +227,9 @@ def preview_streams():
             S.set_preview(0, 0)
         pf = S.encode_modular_frame(prev, S.frame(emit=1), bits=8) if modular else S.encode_vardct_frame(prev, S.frame(emit=1), seed=5)
         body = S.encode_vardct_frame(main, S.frame(emit=1), seed=3)
-        out.append((name, hdr + pf + body, S.encode_vardct_frame(main, S.frame(emit=0), seed=3), (pw, ph)))
+        # (the Modular preview of an XYB image is an XYB Modular frame: its samples are read as Y, X, B - Y whatever they were meant to be)
+        alone = S.encode_modular_frame(prev, S.frame(emit=0, xyb_image=1), bits=8) if modular else S.encode_vardct_frame(prev, S.frame(emit=0), seed=5)   # the preview as an image of its own
+        out.append((name, hdr + pf + body, S.encode_vardct_frame(main, S.frame(emit=0), seed=3), (pw, ph), alone))
     return out
 
 
@@ -235,7 +237,7 @@ def test_preview_frames_are_stepped_over():
     """headers.cc PreviewHeader + the preview frame (decode.cc): the image decodes to what it decodes to without the preview"""
     import numpy as np
     import oracle_lib as O
-    for name, with_preview, plain, _ in preview_streams():
+    for name, with_preview, plain, _, _ in preview_streams():
         assert len(with_preview) > len(plain)
         assert np.array_equal(O.decode(with_preview).pixels("u8", 3), O.decode(plain).pixels("u8", 3)), name
 
