@@ -108,6 +108,32 @@ JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* dec, JxlColorP
 JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* dec, float desired_intensity_target);                         /* decode.rs:921 */
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size);              /* decode.rs:1100 */
 JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* dec, const JxlPixelFormat* format, void* buffer, size_t size);        /* decode.rs:1123 */
+// jpegxl-sys/src/color/color_encoding.rs:125-159 and metadata/codestream_header.rs:247-279 (read-only descriptions of the image; jpegxl-rs itself reads JxlBasicInfo and the ICC profile only)
+typedef struct {
+  int color_space;                 // JxlColorSpace: 0 RGB, 1 grey, 2 XYB, 3 unknown
+  int white_point;                 // JxlWhitePoint: 1 D65, 2 custom, 10 E, 11 DCI
+  double white_point_xy[2];
+  int primaries;                   // JxlPrimaries: 1 sRGB, 2 custom, 9 BT.2100, 11 P3
+  double primaries_red_xy[2], primaries_green_xy[2], primaries_blue_xy[2];
+  int transfer_function;           // JxlTransferFunction: 1 BT.709, 2 unknown, 8 linear, 13 sRGB, 16 PQ, 17 DCI, 18 HLG, 65535 gamma
+  double gamma;
+  int rendering_intent;            // 0 perceptual, 1 relative, 2 saturation, 3 absolute
+} JxlColorEncoding;
+typedef struct {
+  int type;                        // JxlExtraChannelType: 0 alpha, 1 depth, 2 spot colour, 3 selection mask, 4 black, 5 CFA, 6 thermal, 15 unknown, 16 optional
+  uint32_t bits_per_sample, exponent_bits_per_sample, dim_shift, name_length;
+  JXL_BOOL alpha_premultiplied;
+  float spot_color[4];
+  uint32_t cfa_channel;
+} JxlExtraChannelInfo;
+// decode.rs:833: the colour encoding as enumerated values (error for images that carry an ICC profile instead: JxlDecoderGetColorAsICCProfile is the way then)
+JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* dec, JxlColorProfileTarget target, JxlColorEncoding* color_encoding);
+// decode.rs:756 / :777
+JxlDecoderStatus JxlDecoderGetExtraChannelInfo(const JxlDecoder* dec, size_t index, JxlExtraChannelInfo* info);
+JxlDecoderStatus JxlDecoderGetExtraChannelName(const JxlDecoder* dec, size_t index, char* name, size_t size);
+// decode.rs:509: bytes of input that make JxlDecoderGetBasicInfo likely to succeed; decode.rs:1495: the whole image is always decoded (ratio 1)
+size_t JxlDecoderSizeHintBasicInfo(const JxlDecoder* dec);
+size_t JxlDecoderGetIntendedDownsamplingRatio(const JxlDecoder* dec);
 // jpegxl-sys/src/decode.rs:999-1025: the preview image (JXL_DEC_PREVIEW_IMAGE / JXL_DEC_NEED_PREVIEW_OUT_BUFFER; JxlBasicInfo.have_preview, .preview) — the preview frame is
 // decoded on the GPU like an image of its own.  jpegxl-rs itself never subscribes to it (decode.rs:334-347).
 JxlDecoderStatus JxlDecoderPreviewOutBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size);

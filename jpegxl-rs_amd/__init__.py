@@ -56,6 +56,18 @@ class JxlMemoryManager(C.Structure):
     _fields_ = [("opaque", C.c_void_p), ("alloc", C.c_void_p), ("free", C.c_void_p)]
 
 
+class JxlColorEncoding(C.Structure):
+    """jpegxl-sys color/color_encoding.rs:125-159"""
+    _fields_ = [("color_space", C.c_int), ("white_point", C.c_int), ("white_point_xy", C.c_double * 2), ("primaries", C.c_int), ("primaries_red_xy", C.c_double * 2),
+                ("primaries_green_xy", C.c_double * 2), ("primaries_blue_xy", C.c_double * 2), ("transfer_function", C.c_int), ("gamma", C.c_double), ("rendering_intent", C.c_int)]
+
+
+class JxlExtraChannelInfo(C.Structure):
+    """jpegxl-sys metadata/codestream_header.rs:247-279"""
+    _fields_ = [("type", C.c_int), ("bits_per_sample", C.c_uint32), ("exponent_bits_per_sample", C.c_uint32), ("dim_shift", C.c_uint32), ("name_length", C.c_uint32),
+                ("alpha_premultiplied", C.c_int), ("spot_color", C.c_float * 4), ("cfa_channel", C.c_uint32)]
+
+
 class JxlBlendInfo(C.Structure):
     """jpegxl-sys/src/metadata/codestream_header.rs:305-315"""
     _fields_ = [("blendmode", C.c_int), ("source", C.c_uint32), ("alpha", C.c_uint32), ("clamp", C.c_int)]
@@ -107,6 +119,11 @@ def libjxl():
             "JxlDecoderSetDesiredIntensityTarget": (C.c_int, [vp, C.c_float]),
             "JxlDecoderImageOutBufferSize": (C.c_int, [vp, C.POINTER(JxlPixelFormat), C.POINTER(sz)]),
             "JxlDecoderSetImageOutBuffer": (C.c_int, [vp, C.POINTER(JxlPixelFormat), vp, sz]),
+            "JxlDecoderGetColorAsEncodedProfile": (C.c_int, [vp, C.c_int, C.POINTER(JxlColorEncoding)]),
+            "JxlDecoderGetExtraChannelInfo": (C.c_int, [vp, sz, C.POINTER(JxlExtraChannelInfo)]),
+            "JxlDecoderGetExtraChannelName": (C.c_int, [vp, sz, C.c_char_p, sz]),
+            "JxlDecoderSizeHintBasicInfo": (sz, [vp]),
+            "JxlDecoderGetIntendedDownsamplingRatio": (sz, [vp]),
             "JxlDecoderPreviewOutBufferSize": (C.c_int, [vp, C.POINTER(JxlPixelFormat), C.POINTER(sz)]),
             "JxlDecoderSetPreviewOutBuffer": (C.c_int, [vp, C.POINTER(JxlPixelFormat), vp, sz]),
             "JxlDecoderSetJPEGBuffer": (C.c_int, [vp, vp, sz]), "JxlDecoderReleaseJPEGBuffer": (sz, [vp]),

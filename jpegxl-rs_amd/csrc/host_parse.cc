@@ -726,10 +726,10 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
       e.type = r.Enum();
       ReadBitDepth(r, &e.depth);
       e.dim_shift = r.U32({0, 0}, {0, 3}, {0, 4}, {3, 1});
-      SkipName(r);
+      { const uint32_t n = r.U32({0, 0}, {4, 0}, {5, 16}, {10, 48}); for (uint32_t i = 0; i < n; i++) e.name.push_back((char)r.u(8)); }     // (JxlDecoderGetExtraChannelName)
       if (e.type == 0) e.alpha_associated = r.b();
       if (e.type == 2) for (int i = 0; i < 4; i++) e.spot[i] = r.F16();
-      if (e.type == 5) r.U32({0, 1}, {2, 0}, {4, 3}, {8, 19});
+      if (e.type == 5) e.cfa_channel = r.U32({0, 1}, {2, 0}, {4, 3}, {8, 19});
     }
     ih->xyb_encoded = r.b();
     ih->color_default = r.b();

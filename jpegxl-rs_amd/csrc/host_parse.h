@@ -45,7 +45,7 @@ struct HostTree {
 };
 
 struct BitDepthInfo { bool is_float = false; uint32_t bits = 8, exp_bits = 0; };
-struct ExtraChannel { uint32_t type = 0; BitDepthInfo depth; uint32_t dim_shift = 0; bool alpha_associated = false; float spot[4] = {0, 0, 0, 0}; };   // spot: colour + solidity of a spot-colour channel (type 2)
+struct ExtraChannel { uint32_t type = 0; BitDepthInfo depth; uint32_t dim_shift = 0; bool alpha_associated = false; float spot[4] = {0, 0, 0, 0}; uint32_t cfa_channel = 1; vec<char> name; };   // spot: colour + solidity of a spot-colour channel (type 2)
 
 struct ImageHeader {
   uint32_t xsize = 0, ysize = 0;
@@ -216,6 +216,8 @@ void ComputeQuantTable(const QuantTableSpec& spec, int kind, int c, vec<float>* 
 vec<uint16_t> NaturalCoeffOrder(int strategy);
 // ICC v4.4 matrix/TRC profile of the enumerated colour encoding (icc_profile.cc); throws ParseError.
 vec<uint8_t> SynthesizeIcc(const ImageHeader& ih);
+// CIE xy of the image's white point (2 values) and primaries (6: red, green, blue), enumerated or custom (JxlColorEncoding, jpegxl-sys color_encoding.rs:125-159)
+void ColorChromaticities(const ImageHeader& ih, double white_xy[2], double primaries_xy[6]);
 std::string ColorDescription(const ImageHeader& ih);
 // dec_xyb.cc OutputEncodingInfo::SetColorEncoding: linear sRGB -> the image's own primaries / white point (row-major 3x3, through XYZ D50
 // with linear Bradford adaptation) and the luminance weights of those primaries.  Returns false — identity, sRGB luminances — for

@@ -180,6 +180,13 @@ bool SrgbToOriginalPrimaries(const ImageHeader& ih, double m[9], float luminance
   return true;
 }
 
+void ColorChromaticities(const ImageHeader& ih, double white_xy[2], double primaries_xy[6]) {
+  ImageHeader h = ih;
+  if (h.color_default) { h.white_point = 1; h.primaries = 1; }
+  WhiteXy(h, white_xy);
+  if (h.color_space == 1) memcpy(primaries_xy, kSrgbPrimaries, sizeof kSrgbPrimaries); else PrimariesXy(h, primaries_xy);
+}
+
 vec<uint8_t> SynthesizeIcc(const ImageHeader& ih) {
   if (ih.want_icc) throw ParseError("unsupported: embedded ICC profile", true);
   if (ih.color_space > 1) throw ParseError("unsupported: ICC profile for XYB / unknown colour space", true);

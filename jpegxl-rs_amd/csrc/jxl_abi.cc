@@ -165,6 +165,47 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
   h->layer_info.save_as_reference = p.save_as_reference;
   return JXL_DEC_SUCCESS;
 }
+JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* d, JxlColorProfileTarget, JxlColorEncoding* out) {
+  if (!d->batch || d->stage < JxlDecoderStruct::kHeaders || !out) return JXL_DEC_ERROR;
+  const ImageHeader& ih = d->batch->image(0).ih;
+  if (ih.want_icc) { SetLastError("the image carries an ICC profile: no enumerated colour encoding"); return JXL_DEC_ERROR; }
+  try {
+    memset(out, 0, sizeof(*out));
+    out->color_space = ih.color_default ? 0 : (int)ih.color_space;
+    out->white_point = ih.color_default ? 1 : (int)ih.white_point;
+    out->primaries = ih.color_default || ih.color_space == 1 ? 1 : (int)ih.primaries;
+    double w[2], p[6];
+    ColorChromaticities(ih, w, p);
+    for (int i = 0; i < 2; i++) { out->white_point_xy[i] = w[i]; out->primaries_red_xy[i] = p[i]; out->primaries_green_xy[i] = p[2 + i]; out->primaries_blue_xy[i] = p[4 + i]; }
+    if (!ih.color_default && ih.have_gamma) { out->transfer_function = 65535; out->gamma = (double)ih.gamma * 1e-7; }
+    else out->transfer_function = ih.color_default ? 13 : (int)ih.tf;
+    out->rendering_intent = ih.color_default ? 1 : (int)ih.rendering_intent;
+    return JXL_DEC_SUCCESS;
+  } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
+}
+JxlDecoderStatus JxlDecoderGetExtraChannelInfo(const JxlDecoder* d, size_t index, JxlExtraChannelInfo* out) {
+  if (!d->batch || d->stage < JxlDecoderStruct::kHeaders || !out) return JXL_DEC_ERROR;
+  const ImageHeader& ih = d->batch->image(0).ih;
+  if (index >= ih.extra.size()) return JXL_DEC_ERROR;
+  const ExtraChannel& e = ih.extra[index];
+  memset(out, 0, sizeof(*out));
+  out->type = (int)e.type; out->bits_per_sample = e.depth.bits; out->exponent_bits_per_sample = e.depth.is_float ? e.depth.exp_bits : 0;
+  out->dim_shift = e.dim_shift; out->name_length = (uint32_t)e.name.size(); out->alpha_premultiplied = e.alpha_associated ? 1 : 0;
+  for (int i = 0; i < 4; i++) out->spot_color[i] = e.spot[i];
+  out->cfa_channel = e.cfa_channel;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetExtraChannelName(const JxlDecoder* d, size_t index, char* name, size_t size) {
+  if (!d->batch || d->stage < JxlDecoderStruct::kHeaders || !name) return JXL_DEC_ERROR;
+  const ImageHeader& ih = d->batch->image(0).ih;
+  if (index >= ih.extra.size() || size < ih.extra[index].name.size() + 1) return JXL_DEC_ERROR;
+  const vec<char>& n = ih.extra[index].name;
+  if (!n.empty()) memcpy(name, n.data(), n.size());
+  name[n.size()] = 0;
+  return JXL_DEC_SUCCESS;
+}
+size_t JxlDecoderSizeHintBasicInfo(const JxlDecoder* d) { return d->batch ? 0 : 98; }      // (decode.cc InitialBasicInfoSizeHint: container signature + box headers + the largest fixed headers)
+size_t JxlDecoderGetIntendedDownsamplingRatio(const JxlDecoder*) { return 1; }
 JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* d, char* name, size_t size) {
   const int k = CurrentFrame(d);
   if (k < 0 || d->stage != JxlDecoderStruct::kFrame || !name) return JXL_DEC_ERROR;

@@ -427,6 +427,71 @@ def test_multipass_modular_frames(jx):
         assert np.array_equal(got.reshape(img.shape), img), name
 
 
+def test_colour_encoding_and_extra_channel_info(jx):
+    """JxlDecoderGetColorAsEncodedProfile (jpegxl-sys decode.rs:833, color_encoding.rs:125-159) and JxlDecoderGetExtraChannelInfo / Name (decode.rs:756-782,
+    codestream_header.rs:247-279): the enumerated colour description and the extra channels as the image header states them."""
+    L = jx.libjxl()
+    img = S.synthetic_image(31, 104, 72)
+    rgba = np.dstack([img, (np.arange(104 * 72) % 251).astype(np.uint8).reshape(72, 104)]).astype(np.int32)
+
+    def headers(stream):
+        data = np.frombuffer(stream, np.uint8)
+        dec = L.JxlDecoderCreate(None)
+        assert L.JxlDecoderSizeHintBasicInfo(dec) > 0 and L.JxlDecoderGetIntendedDownsamplingRatio(dec) == 1
+        assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_BASIC_INFO) == 0
+        assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+        assert L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_BASIC_INFO
+        ce = jx.JxlColorEncoding()
+        st = L.JxlDecoderGetColorAsEncodedProfile(dec, 0, C.byref(ce))
+        extras = []
+        info = jx.JxlBasicInfo()
+        assert L.JxlDecoderGetBasicInfo(dec, C.byref(info)) == 0
+        for k in range(info.num_extra_channels):
+            ei = jx.JxlExtraChannelInfo()
+            assert L.JxlDecoderGetExtraChannelInfo(dec, k, C.byref(ei)) == 0
+            name = C.create_string_buffer(ei.name_length + 1)
+            assert L.JxlDecoderGetExtraChannelName(dec, k, name, ei.name_length + 1) == 0
+            extras.append((ei.type, ei.bits_per_sample, ei.alpha_premultiplied, [round(v, 4) for v in ei.spot_color], name.value))
+        ei = jx.JxlExtraChannelInfo()
+        assert L.JxlDecoderGetExtraChannelInfo(dec, info.num_extra_channels, C.byref(ei)) == 1
+        L.JxlDecoderDestroy(dec)
+        return st, ce, extras
+
+    st, ce, extras = headers(S.encode_vardct(img, seed=5))                                   # all defaults: sRGB
+    assert st == 0 and (ce.color_space, ce.white_point, ce.primaries, ce.transfer_function, ce.rendering_intent) == (0, 1, 1, 13, 1) and extras == []
+    assert abs(ce.white_point_xy[0] - 0.3127) < 1e-9 and abs(ce.primaries_red_xy[0] - 0.639998686) < 1e-9 and abs(ce.primaries_blue_xy[1] - 0.059997204) < 1e-9
+    S.set_color(white_point=1, primaries=9, tf=16, intensity_target=1000.0)
+    try:
+        pq = S.encode_vardct(img, seed=5)
+    finally:
+        S.set_color()
+    st, ce, _ = headers(pq)                                                                   # BT.2100 primaries, PQ
+    assert st == 0 and (ce.primaries, ce.transfer_function) == (9, 16) and abs(ce.primaries_green_xy[1] - 0.797) < 1e-9
+    S.set_color(white_point=11, primaries=11, tf=0, gamma=0.45455)
+    try:
+        g = S.encode_vardct(img, seed=5)
+    finally:
+        S.set_color()
+    st, ce, _ = headers(g)                                                                    # DCI white, P3, gamma
+    assert st == 0 and (ce.white_point, ce.primaries, ce.transfer_function) == (11, 11, 65535) and abs(ce.gamma - 0.45455) < 1e-6 and abs(ce.white_point_xy[1] - 0.351) < 1e-9
+    st, _, extras = headers(S.encode_vardct(img, seed=5, alpha=rgba[..., 3].astype(np.uint8)))
+    assert st == 0 and extras == [(0, 8, 0, [0.0, 0.0, 0.0, 0.0], b"")]
+    S.set_spot((1.0, 0.25, 0.125, 0.75))
+    try:
+        spot = S.encode_modular(rgba, 8, False, 0)
+    finally:
+        S.set_spot()
+    _, _, extras = headers(spot)
+    assert extras == [(2, 8, 0, [1.0, 0.25, 0.125, 0.75], b"")]
+    from PIL import ImageCms
+    S.set_icc(ImageCms.ImageCmsProfile(ImageCms.createProfile("sRGB")).tobytes())
+    try:
+        icc = S.encode_vardct(S.synthetic_image(3, 64, 48), seed=1)
+    finally:
+        S.set_icc(b"")
+    assert headers(icc)[0] == 1                                                               # an ICC profile: no enumerated description
+
+
 def test_preview_image_is_delivered_when_subscribed(jx):
     """JXL_DEC_PREVIEW_IMAGE (jpegxl-sys decode.rs:999-1025, status 0x200): a caller that subscribes gets JXL_DEC_NEED_PREVIEW_OUT_BUFFER, sets a buffer of
     JxlDecoderPreviewOutBufferSize bytes and receives the preview — the preview frame decoded on the GPU like an image of its own — before the frames of
