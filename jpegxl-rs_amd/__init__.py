@@ -623,12 +623,12 @@ class BatchDecoder:
 
     def share_buffers(self, owner: "BatchDecoder"):
         """Use `owner`'s coefficient / pixel planes (call before prepare; see include/jxl_hip.h JxlHipBatchShareBuffers)."""
-        self._chk(libjxl().JxlHipBatchShareBuffers(self._h, owner._h))
+        self._chk(libjxl().JxlHipBatchShareBuffers(self._h, owner._h if owner is not None else None))   # (None: planes of its own again)
         self._owner = owner   # keep it alive
 
     def share_coefficients(self, owner: "BatchDecoder"):
         """Use `owner`'s quantised-coefficient planes (call before prepare; include/jxl_hip.h JxlHipBatchShareCoefficients)."""
-        self._chk(libjxl().JxlHipBatchShareCoefficients(self._h, owner._h))
+        self._chk(libjxl().JxlHipBatchShareCoefficients(self._h, owner._h if owner is not None else None))
         self._coef_owner = owner
 
     def prepare(self, stream=None):

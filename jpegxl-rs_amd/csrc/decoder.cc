@@ -245,6 +245,7 @@ Batch::~Batch() {
   if (dwork_) (void)hipFree(dwork_);
   if (dcoef_ && !coef_owner_) (void)hipFree(dcoef_);
   if (dbig_ && !big_owner_) (void)hipFree(dbig_);
+  if (big_owner_) big_owner_->big_sharers_--;
   if (dframes_) (void)hipFree(dframes_);
   if (dpasses_) (void)hipFree(dpasses_);
   if (dlocal_) (void)hipFree(dlocal_);
@@ -256,8 +257,8 @@ Batch::~Batch() {
 void Batch::ShareBigArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareBigArena after Prepare", false);
   if (big_owner_ == owner) return;
-  if (big_owner_) big_owner_->big_sharers_--;
-  if (dbig_ && !big_owner_) { (void)hipFree(dbig_); dbig_ = nullptr; big_cap_ = 0; }
+  if (big_owner_) { big_owner_->big_sharers_--; dbig_ = nullptr; big_cap_ = 0; }       // (the pointer aliased the old owner's planes: not ours to free)
+  if (dbig_) { (void)hipFree(dbig_); dbig_ = nullptr; big_cap_ = 0; }
   big_owner_ = owner;
   if (owner) owner->big_sharers_++;
 }
@@ -267,7 +268,8 @@ void Batch::ShareBigArena(Batch* owner) {
 void Batch::ShareCoefArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareCoefArena after Prepare", false);
   if (coef_owner_ == owner) return;
-  if (dcoef_ && !coef_owner_) { (void)hipFree(dcoef_); dcoef_ = nullptr; coef_cap_ = 0; }
+  if (coef_owner_) { dcoef_ = nullptr; coef_cap_ = 0; coef_laid_out_ = 0; }            // (aliased the old owner's planes: not ours to free)
+  if (dcoef_) { (void)hipFree(dcoef_); dcoef_ = nullptr; coef_cap_ = 0; }
   coef_owner_ = owner;
 }
 
@@ -288,9 +290,12 @@ void Batch::Reset() {
   images_.clear(); pub_.clear(); cbufs_.clear(); post_ops_.clear(); jpeg_data_.clear();
   frames_host_.clear(); passes_host_.clear(); pass_first_.clear(); local_host_.clear(); local_first_.clear();
   mod_plane_offsets_.clear(); mod_ops_.clear(); vardct_alpha_.clear(); hf_written_.clear();
-  any_complex_ = false;       // (stage timings recorded so far stay: CollectTimes sums over the object's life) prepared_ = false; ran_once_ = false; flags_pending_ = false; decodes_since_finish_ = 0;
+  // (stage timings recorded so far stay: CollectTimes sums over the object's life)
+  any_complex_ = false; any_gab_ = any_vardct_ = any_modular_ = any_modchan_ = any_multipass_ = false;
+  prepared_ = false; ran_once_ = false; flags_pending_ = false; decodes_since_finish_ = 0;
   cfg.idct_flags_known = 0;
   lf_simt_ = LfSimtPlan();
+  if (lf_batch_) lf_batch_->Reset();     // (kept for its arenas; Prepare drops it when no unit refers to an LF frame)
 }
 
 // Parses `n` images on `threads` host threads (the per-image work of AddImage — container, image and frame headers, TOC, the global
@@ -890,8 +895,10 @@ void Batch::Prepare(void* stream_v) {
   if (coef_owner_) {
     if (!coef_owner_->dcoef_ || coef_owner_->coef_cap_ < coeff_bytes_) throw ParseError("ShareCoefArena: the owner's planes are missing or smaller than this batch needs", false);
     dcoef_ = coef_owner_->dcoef_;                      // (whether they are clean is the owner's knowledge: CoefDirty())
-  } else if (DevReserve((void**)&dcoef_, &coef_cap_, std::max<size_t>(coeff_bytes_, 256)) || coeff_bytes_ != coef_laid_out_) {
-    coef_dirty_ = true;                                // new planes, or another layout of them: the first decode clears them in its own stream
+  } else {
+    const bool fresh = DevReserve((void**)&dcoef_, &coef_cap_, std::max<size_t>(coeff_bytes_, 256));
+    if (fresh) coef_clean_extent_ = 0;                 // (a new allocation: nothing of it is known to be zero)
+    if (fresh || coeff_bytes_ != coef_laid_out_) coef_dirty_ = true;   // new planes, or another layout of them: the first decode clears them in its own stream
   }
   coef_laid_out_ = coeff_bytes_;
   mark("layout+reserve");
@@ -1742,7 +1749,15 @@ void Batch::EnqueuePostOps(void* stream) { for (auto& op : post_ops_) op(stream)
 // IdctTileKernel pass 0), so a batch that is decoded again and again never clears its planes as a whole; only a decode whose
 // tail did not run over them (first decode, JPEG reconstruction, a failed stream) leaves them dirty.
 void Batch::ClearCoefficientsBeforeHf(void* stream_v) {
-  if (CoefDirty()) HIP_CHECK(hipMemsetAsync(dcoef_, 0, coef_owner_ ? coef_owner_->coeff_bytes_ : coeff_bytes_, (hipStream_t)stream_v));
+  // The planes are known to be zero over [0, clean extent) of the owner: hipMalloc'd memory is not cleared, and a decode only puts zeros
+  // back inside its own layout — a sharer (or a refill) whose layout reaches further than anything cleared so far needs the dense clear too.
+  size_t& extent = coef_owner_ ? coef_owner_->coef_clean_extent_ : coef_clean_extent_;
+  if (CoefDirty() || coeff_bytes_ > extent) {
+    const size_t cap = coef_owner_ ? coef_owner_->coef_cap_ : coef_cap_;
+    const size_t bytes = std::min(cap, std::max(extent, coeff_bytes_));
+    HIP_CHECK(hipMemsetAsync(dcoef_, 0, bytes, (hipStream_t)stream_v));
+    extent = bytes;
+  }
   CoefDirty() = true;
 }
 void Batch::ClearCoefficientsAfterDecode(void*) { CoefDirty() = false; }

@@ -176,6 +176,7 @@ class Batch {
   void* clear_stream_ = nullptr; void* clear_event_ = nullptr; void* idct_event_ = nullptr;
   bool clear_pending_ = false, coef_dirty_ = true;
   Batch* coef_owner_ = nullptr;
+  size_t coef_clean_extent_ = 0;   // bytes of this object's own coefficient planes known to be zero after a completed decode
   bool& CoefDirty() { return coef_owner_ ? coef_owner_->coef_dirty_ : coef_dirty_; }
   void ClearCoefficientsBeforeHf(void* stream);
   void ClearCoefficientsAfterDecode(void* stream);

@@ -1114,6 +1114,46 @@ def test_batch_objects_are_refilled_without_reallocating(jx):
         owner.reset(); owner.add_many([sets[0][0][0], b"\xff\x0a" + bytes(40)], "uint8", 3, threads=2)
 
 
+def test_batch_reset_and_unsharing_leave_a_consistent_object(jx):
+    """Round-3 advisor findings on Batch::Reset / ShareCoefArena / ShareBigArena / ClearCoefficientsBeforeHf: (1) Reset() really forgets the
+    prepared state — sharing can be set up afterwards and a decode of the empty batch is a no-op; (2) leaving a sharing arrangement
+    (owner = NULL) gives the sharer planes of its own and never frees the owner's; (3) a sharer whose coefficient layout reaches
+    beyond what the owner's own content ever cleared starts from zeroed planes (hipMalloc'd memory is not)."""
+    small = [S.encode_vardct(S.synthetic_image(31 + i, 200, 136), seed=31 + i, strategy_mix=2, epf_iters=1, gab=1) for i in range(2)]
+    large = [S.encode_vardct(S.synthetic_image(41 + i, 600, 520), seed=41 + i, strategy_mix=2, epf_iters=1, gab=1) for i in range(3)]
+    ref_small = [O.decode(s).pixels("u8", 3) for s in small]
+    ref_large = [O.decode(s).pixels("u8", 3) for s in large]
+
+    def run(b, refs):
+        b.prepare(); b.decode(); b.finish()
+        for i, r in enumerate(refs):
+            assert np.array_equal(b.output(i), r), i
+
+    owner = jx.BatchDecoder(0)
+    owner.add_many(large, "uint8", 3); run(owner, ref_large)             # the owner's arenas get the size of the large set ...
+    owner.reset(); owner.add_many(small, "uint8", 3); run(owner, ref_small)   # ... but its current content only covers a corner of them
+    sharer = jx.BatchDecoder(0)
+    sharer.share_buffers(owner); sharer.share_coefficients(owner)
+    sharer.add_many(large, "uint8", 3); run(sharer, ref_large)           # (3): layout larger than the owner's current one
+    run(owner, ref_small)
+    # (1) after Reset the object is unprepared: sharing may change, an empty decode does nothing
+    sharer.reset()
+    sharer.share_coefficients(owner); sharer.share_buffers(owner)
+    sharer.decode(); sharer.finish()
+    assert sharer.total_pixels == 0
+    # (2) leave the arrangement: own planes again; the owner's planes are still there and still the owner's
+    sharer.share_coefficients(None); sharer.share_buffers(None)
+    sharer.add_many(large, "uint8", 3); run(sharer, ref_large)
+    run(owner, ref_small)
+    owner.reset(); owner.add_many(large, "uint8", 3); run(owner, ref_large)
+    del sharer                                                            # destruction of a former sharer does not touch the owner either
+    run(owner, ref_large)
+    third = jx.BatchDecoder(0); third.share_buffers(owner); third.share_coefficients(owner)
+    third.add_many(small, "uint8", 3); run(third, ref_small)
+    del third
+    owner.reset(); owner.add_many(small, "uint8", 3); run(owner, ref_small)
+
+
 # ---- multi-frame images and image features (round 2): frame tail kernels vs the oracle -----------------------------------------------
 def _stream_cases():
     img = S.synthetic_image(5, 200, 136)
