@@ -77,16 +77,20 @@ def _textured(img, amp, seed):
 
 def _make_stream(args):
     import synth_lib as S
-    seed, width, height, epf, texture = args
+    seed, width, height, epf, texture, tree_shape = args
     # (JXL_BENCH_STREAM_CACHE=<dir>: keep the synthesised streams between runs of a parameter sweep on one box; unset in a plain run)
     cache = os.environ.get("JXL_BENCH_STREAM_CACHE")
-    path = os.path.join(cache, f"s{seed}_{width}x{height}_e{epf}_t{texture}.jxl") if cache else None
+    path = os.path.join(cache, f"s{seed}_{width}x{height}_e{epf}_t{texture}_m{tree_shape}.jxl") if cache else None
     if path and os.path.exists(path):
         return open(path, "rb").read()
     img = S.synthetic_image(seed, width, height)
     if texture:
         img = _textured(img, texture, seed)
-    data = S.encode_vardct(img, seed=seed, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1)
+    S.set_lf_tree_shape(tree_shape)
+    try:
+        data = S.encode_vardct(img, seed=seed, distance=1.0, epf_iters=epf, gab=1, strategy_mix=1)
+    finally:
+        S.set_lf_tree_shape(0)
     if path:
         os.makedirs(cache, exist_ok=True)
         with open(path + f".{os.getpid()}", "wb") as fh:
@@ -95,11 +99,12 @@ def _make_stream(args):
     return data
 
 
-def make_streams(distinct, width, height, epf, seed0=1000, texture=0.0):
+def make_streams(distinct, width, height, epf, seed0=1000, texture=0.0, tree_shape=0):
     """Seeded synthetic frames encoded by tools/jxlsynth, one per seed (different content, different
-    varblock maps and token counts).  Generated on the host cores in parallel (4.6 s per 4K frame).  Returns list of bytes."""
+    varblock maps and token counts).  tree_shape 1: the MA tree of the LF-group streams has the shape a default-effort cjxl encode writes
+    (weighted predictor; tests/synth_lib.py set_lf_tree_shape).  Generated on the host cores in parallel (4.6 s per 4K frame).  Returns list of bytes."""
     import multiprocessing as mp
-    jobs = [(seed0 + i, width, height, epf, texture) for i in range(distinct)]
+    jobs = [(seed0 + i, width, height, epf, texture, tree_shape) for i in range(distinct)]
     workers = max(1, min(len(jobs), int(os.environ.get("JXL_BENCH_SYNTH_WORKERS", "0")) or (os.cpu_count() or 1), 64))
     if workers == 1:
         return [_make_stream(j) for j in jobs]
@@ -468,6 +473,8 @@ def main():
     ap.add_argument("--texture", type=float, default=5.0, help="strength (sRGB levels) of the texture of the realistic-bit-rate workload (0: skip it)")
     ap.add_argument("--realistic-distinct", type=int, default=64, help="distinct frames of the realistic-bit-rate workload")
     ap.add_argument("--no-realistic", action="store_true", help="skip the second workload (textured frames, ~2 bpp)")
+    ap.add_argument("--cjxl-distinct", type=int, default=32, help="distinct frames of the cjxl-shaped workload (textured frames whose LF-group streams use the MA-tree shape of a default-effort "
+                    "cjxl encode: weighted predictor); 0: skip it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -484,6 +491,7 @@ def main():
     streams = make_streams(args.distinct, W, H, args.epf, seed0=1000 + 1000 * rank)
     # the same frames with photograph-like texture: ~2 bpp at distance 1 instead of 0.8 (second workload of the line, fewer distinct frames)
     realistic_streams = make_streams(min(args.distinct, args.realistic_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture) if args.texture > 0 and not args.no_realistic else None
+    cjxl_streams = make_streams(min(args.distinct, args.cjxl_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture, tree_shape=1) if args.cjxl_distinct > 0 and not args.no_realistic else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(streams, W, H)   # before any GPU runtime is initialised in this process (fork safety)
@@ -540,7 +548,8 @@ def main():
         r = {"elapsed": elapsed, "t_decode": t_decode, "step_end": step_end, "stage_ms": {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"},
              "stage_bytes": p.batches[0].stage_bytes, "device_bytes": sum(bt.device_bytes for bt in p.batches), "compressed": int(p.batches[0].compressed_bytes // B),
              "nbuf": p.nbuf, "prepare_s": list(p.prepare_s), "gather": bool(p.do_gather), "pipelined": bool(p.pipeline),
-             "nonzeros": p.batches[0].info_value("hf_nonzeros") // B}
+             "nonzeros": p.batches[0].info_value("hf_nonzeros") // B,
+             "lf_simt": [p.batches[0].info_value(k) for k in ("lf_simt_frames", "lf_legacy_frames", "lf_simt_wp")]}
         if not args.no_verify and rank == 0:
             import oracle_lib as O
             r["verified"], r["verified_frames"] = p.verify(args.steps * inner, O, np)
@@ -555,6 +564,7 @@ def main():
     realistic = None
     if args.texture > 0 and not args.no_realistic and realistic_streams:
         realistic = measure(modes[0] == "streaming", realistic_streams)
+    cjxl = measure(modes[0] == "streaming", cjxl_streams) if cjxl_streams else None
     if rank == 0:
         total_px = world * B * inner * W * H * args.steps
         rate = lambda r: total_px / r["elapsed"] / 1e6
@@ -580,7 +590,8 @@ def main():
         result = {
             "metric": "Mpixel/s decode (4K VarDCT d1)", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(head["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": f"synthetic ({args.distinct} distinct seeded frames per GPU, tools/jxlsynth; own synthesiser, 0.8 bpp — real d1 photographs run 1.5-2.5 bpp)",
+            "vs_baseline": None, "dtype": "f32", "data": f"synthetic ({args.distinct} distinct seeded frames per GPU, tools/jxlsynth; own synthesiser, 0.8 bpp — real d1 photographs run 1.5-2.5 bpp: config.workload_realistic; the LF-group MA tree is the gradient tree the SIMT LF kernel is eligible for by "
+                                                        f"construction — a default-effort cjxl encode writes weighted-predictor trees: config.workload_cjxl_shape; cpu_baseline kind 'port' is the scalar oracle, not libjxl)",
             "config": {"workload": f"batch of {B} x {W}x{H} VarDCT d1 frames per GPU per step (XYB, ANS, var-block DCT8..32 mix, gaborish, EPF {args.epf}), u8 RGB out; "
                                    + ("streaming: every step's compressed frames come from host memory and are parsed, prepared and uploaded inside the timed region, outputs stay in HBM"
                                       if modes[0] == "streaming" else "inputs and outputs resident in HBM"),
@@ -626,6 +637,17 @@ def main():
                 "stage_ms": {k: round(v, 4) for k, v in realistic["stage_ms"].items()}, "compressed_bytes_per_frame": realistic["compressed"],
                 "bits_per_pixel": round(realistic["compressed"] * 8 / (W * H), 3), "nonzero_coefficients_per_frame": realistic["nonzeros"],
                 "distinct_frames": len(realistic_streams), "verified_vs_oracle": realistic.get("verified")}
+        if cjxl is not None:
+            ce_ = cjxl["step_end"]; n_c = len(ce_)
+            result["config"]["workload_cjxl_shape"] = {
+                "what": "the realistic-bit-rate frames with LF-group streams under the MA-tree shape of a default-effort cjxl encode (enc_modular.cc tree kinds 'WP fixed DC' + 'AC meta': "
+                        "weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients; row / N / W splits for the HF metadata) — the headline's and the realistic "
+                        "workload's LF trees are the gradient tree `cjxl --faster_decoding` picks, which the plain SIMT LF kernel was built around",
+                "value": round(rate(cjxl), 2), "unit": "Mpixel/s", "ms_per_step": round(cjxl["elapsed"] / args.steps * 1e3, 3),
+                "steady_state_ms_per_step": round((ce_[n_c * 2 // 3] - ce_[n_c // 5]) / max(1, n_c * 2 // 3 - n_c // 5), 2) if n_c >= 10 else None,
+                "stage_ms": {k: round(v, 4) for k, v in cjxl["stage_ms"].items()}, "compressed_bytes_per_frame": cjxl["compressed"],
+                "bits_per_pixel": round(cjxl["compressed"] * 8 / (W * H), 3), "lf_simt_frames": cjxl["lf_simt"][0], "lf_legacy_frames": cjxl["lf_simt"][1],
+                "lf_simt_weighted_predictor_kernel": bool(cjxl["lf_simt"][2]), "distinct_frames": len(cjxl_streams), "verified_vs_oracle": cjxl.get("verified")}
         if world > 1:
             result["decode_only_mpixel_per_s"] = round(total_px / head["t_decode"] / 1e6, 2)     # until every rank's own decode work was done
             result["gather_ms"] = round((head["elapsed"] - head["t_decode"]) * 1e3, 2)             # what the pixel gather added after that

@@ -216,7 +216,8 @@ JxlDecoderStatus JxlHipBatchSetOutput(JxlHipBatch* batch, int index, const JxlPi
 /* Decode-thread packing: lanes between active entropy-decode threads (64 = one stream per wavefront, 1 = 64 per wavefront). */
 void JxlHipBatchSetLaneStride(JxlHipBatch* batch, int lf, int hf);
 /* Tuning / testing knobs: "force_generic_idct", "hf_block_threads", "lds_code_budget", "debug_stop_after", "lf_wide_once" (the next LF stage of the batch takes the
- * one-wavefront-per-stream kernel whatever the lane stride: shorter latency on an idle GPU). Unknown names are ignored. */
+ * one-wavefront-per-stream kernel whatever the lane stride: shorter latency on an idle GPU), "lf_wp_narrow_test" (testing: the SIMT LF kernel's
+ * weighted-predictor lanes hand a stream back to the one-wavefront-per-stream kernel at |sample| > 16 instead of 2^20). Unknown names are ignored. */
 void JxlHipBatchSetOption(JxlHipBatch* batch, const char* name, int value);
 /* Uploads streams and tables (inputs become HBM-resident) and allocates work buffers.  hip_stream: hipStream_t or NULL. */
 JxlDecoderStatus JxlHipBatchPrepare(JxlHipBatch* batch, void* hip_stream);
@@ -245,7 +246,7 @@ uint64_t JxlHipBatchCompressedBytes(const JxlHipBatch* batch);
 void JxlHipBatchStageBytes(const JxlHipBatch* batch, uint64_t out[6]);
 uint64_t JxlHipBatchDeviceBytes(const JxlHipBatch* batch);
 /* Facts about a prepared batch, by name (-1: unknown name): "lf_simt_frames" / "lf_legacy_frames" = VarDCT frames whose LF-group streams
- * take the SIMT kernel (one stream per lane, lane stride < 64) / the one-wavefront-per-stream kernel, "lf_simt_lanes", "lf_simt_waves", "hf_nonzeros" = non-zero AC coefficients of one decode of the batch (after a Finish). */
+ * take the SIMT kernel (one stream per lane, lane stride < 64) / the one-wavefront-per-stream kernel, "lf_simt_lanes", "lf_simt_waves", "lf_simt_wp" (1: the SIMT launch is the instantiation with weighted-predictor state), "hf_nonzeros" = non-zero AC coefficients of one decode of the batch (after a Finish). */
 int64_t JxlHipBatchGetInfo(const JxlHipBatch* batch, const char* name);
 /* Testing: after a decode, copies a device buffer of image `index`'s first (VarDCT) frame to the host — "plane_a" / "plane_b" (the padded
  * float XYB planes the stages ping-pong between, 8 bw x 8 bh samples per channel), "lf" / "llf" / "lfq", "inv_sigma", "blk_info", "coef_off" (one

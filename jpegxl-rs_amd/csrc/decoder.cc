@@ -115,53 +115,135 @@ void PutCode(Arena& a, const HostCode& c, size_t* ctx, size_t* cfg, size_t* alia
   *ps = a.Put(c.pfx_syms.data(), c.pfx_syms.size() * 2);
 }
 // ---- SIMT LF decode: channel classes (kernels.h LfSimtPlan) -----------------------------------------------------------------------------
-// Walks the part of the MA tree channel `chan` of sub-stream `stream_id` can reach (static splits on the channel index / stream id are
-// followed wherever they occur).  Eligible: at most one other property, the row (2) or the gradient W + N - NW (9), with splits inside
-// the table's range; leaves with one common predictor out of zero / W / clamped gradient, offset 0, multiplier 1.  Fills the 1024-entry
-// property value -> cluster table (value v at index v + 512).
-struct LfChanClass { uint32_t kind = 0, pred = 0, cluster = 0; uint8_t lut[1024]; };
-bool ClassifyLfChannel(const HostTree& tree, const HostCode& code, int chan, uint32_t stream_id, LfChanClass* out) {
-  const vec<TreeNode>& nd = tree.nodes;
-  if (nd.empty()) return false;
-  int prop = -1, pred = -1;
-  {  // reachable subtree: properties, predictors, split range
+// Classifies the part of the MA tree channel `chan` of sub-stream `stream_id` can reach (static splits on the channel index / stream id are
+// followed wherever they occur; splits on the row — property 2 — partition the channel's rows into classes).  Within a row class the
+// subtree may test at most two of {W + N - NW (9), W (7), N (6), the weighted predictor's largest error (15)}: one property through a
+// 1024-entry value -> cluster table (splits inside [-512, 510]), two through a 32 x 32 table (splits inside [-16, 14]); its leaves share one
+// predictor out of zero / W / N / clamped gradient / weighted / (W + N) / 2 / select / NE, with offset 0 and multiplier 1.  That covers the
+// fixed trees libjxl's encoder writes for LF-group streams at its default and faster efforts (enc_modular.cc: "WP fixed DC", "gradient
+// fixed DC", "AC meta" and its variants); learned trees (slower efforts) usually test more properties and keep LfDecodeKernel.
+struct LfRowClass { uint32_t kind = 0, pred = 0, sel_a = 0, sel_b = 0, cluster = 0; vec<uint8_t> lut; };
+struct LfChanClass { bool uses_wp = false; vec<LfRowClass> rows; uint8_t row_to_class[512]; };
+namespace {
+struct LfClassifier {
+  const vec<TreeNode>& nd;
+  const HostCode& code;
+  int chan; int32_t stream_id;
+  LfClassifier(const HostTree& t, const HostCode& c, int ch, uint32_t sid) : nd(t.nodes), code(c), chan(ch), stream_id((int32_t)sid) {}
+  static int SelOf(int prop) { return prop == 9 ? 0 : prop == 7 ? 1 : prop == 6 ? 2 : prop == 15 ? 3 : -1; }
+  static int PredCode(int p) { static const int k[8] = {0, 1, 2, 5, 6, 3, 4, 7}; for (int i = 0; i < 8; i++) if (k[i] == p) return i; return -1; }
+  // child taken at a static node, or -1 for a dynamic one; y < 0: the row is not fixed (its splits count as dynamic)
+  int Static(const TreeNode& n, int y) const {
+    if (n.prop == 0) return chan > n.val ? (int)n.a : (int)n.b;
+    if (n.prop == 1) return stream_id > n.val ? (int)n.a : (int)n.b;
+    if (n.prop == 2 && y >= 0) return y > n.val ? (int)n.a : (int)n.b;
+    return -1;
+  }
+  // row thresholds and weighted-predictor use of the whole reachable subtree
+  bool Survey(vec<int32_t>* ysplits, bool* uses_wp) const {
     vec<uint32_t> stack{0};
     size_t visited = 0;
     while (!stack.empty()) {
       const uint32_t pos = stack.back(); stack.pop_back();
       if (pos >= nd.size() || ++visited > 8192) return false;
       const TreeNode& n = nd[pos];
-      if (n.prop < 0) {
-        const int p = (int)(n.a & 0xFF);
-        if ((p != 0 && p != 1 && p != 5) || n.val != 0 || n.b != 1) return false;
-        if (pred < 0) pred = p; else if (pred != p) return false;
-        if ((n.a >> 8) >= code.ctx_map.size()) return false;
-        continue;
-      }
-      if (n.prop == 0 || n.prop == 1) { stack.push_back((n.prop == 0 ? chan : (int32_t)stream_id) > n.val ? n.a : n.b); continue; }
-      if (n.prop != 2 && n.prop != 9) return false;
-      if (prop < 0) prop = n.prop; else if (prop != n.prop) return false;
-      if (n.val < -512 || n.val > 510) return false;
+      if (n.prop < 0) { if ((n.a & 0xFF) == 6) *uses_wp = true; continue; }
+      const int st = Static(n, -1);
+      if (st >= 0) { stack.push_back((uint32_t)st); continue; }
+      if (n.prop == 2) ysplits->push_back(n.val);
+      if (n.prop == 15) *uses_wp = true;
       stack.push_back(n.a); stack.push_back(n.b);
     }
+    return true;
   }
-  if (pred < 0) return false;
-  {  // the table, by pushing the value range [-512, 511] down the tree (a split at `val` sends (val, hi] to child a, [lo, val] to child b):
-     // every reachable node once instead of a walk from the root per value — 7 tables per LF group of every frame add up in a streaming loop
-    struct Range { uint32_t pos; int32_t lo, hi; };
-    vec<Range> stack{Range{0, -512, 511}};
-    while (!stack.empty()) {
-      const Range r = stack.back(); stack.pop_back();
-      const TreeNode& n = nd[r.pos];
-      if (n.prop < 0) { memset(out->lut + (r.lo + 512), code.ctx_map[n.a >> 8], (size_t)(r.hi - r.lo + 1)); continue; }
-      if (n.prop == 0 || n.prop == 1) { stack.push_back(Range{(n.prop == 0 ? chan : (int32_t)stream_id) > n.val ? n.a : n.b, r.lo, r.hi}); continue; }
-      if (r.hi > n.val) stack.push_back(Range{n.a, std::max(r.lo, n.val + 1), r.hi});
-      if (r.lo <= n.val) stack.push_back(Range{n.b, r.lo, std::min(r.hi, n.val)});
+  bool ClassifyRow(int y, LfRowClass* out) const {
+    int props[2] = {-1, -1}, np = 0, pred = -1;
+    int32_t lo_split = 0, hi_split = 0;
+    {
+      vec<uint32_t> stack{0};
+      size_t visited = 0;
+      while (!stack.empty()) {
+        const uint32_t pos = stack.back(); stack.pop_back();
+        if (pos >= nd.size() || ++visited > 8192) return false;
+        const TreeNode& n = nd[pos];
+        if (n.prop < 0) {
+          const int pc = PredCode((int)(n.a & 0xFF));
+          if (pc < 0 || n.val != 0 || n.b != 1) return false;
+          if (pred < 0) pred = pc; else if (pred != pc) return false;
+          if ((n.a >> 8) >= code.ctx_map.size()) return false;
+          continue;
+        }
+        const int st = Static(n, y);
+        if (st >= 0) { stack.push_back((uint32_t)st); continue; }
+        if (SelOf(n.prop) < 0) return false;
+        int k = 0;
+        while (k < np && props[k] != n.prop) k++;
+        if (k == np) { if (np == 2) return false; props[np++] = n.prop; }
+        lo_split = std::min(lo_split, n.val); hi_split = std::max(hi_split, n.val);
+        stack.push_back(n.a); stack.push_back(n.b);
+      }
     }
+    if (pred < 0) return false;
+    const int32_t lo = np == 2 ? -16 : -512, hi = np == 2 ? 15 : 511;
+    if (np && (lo_split < lo || hi_split > hi - 1)) return false;
+    out->kind = (uint32_t)np; out->pred = (uint32_t)pred;
+    out->sel_a = np > 0 ? (uint32_t)SelOf(props[0]) : 0; out->sel_b = np > 1 ? (uint32_t)SelOf(props[1]) : 0;
+    const int32_t span = hi - lo + 1;
+    out->lut.assign(np == 0 ? 1 : np == 1 ? (size_t)span : (size_t)span * span, 0);
+    // the table, by pushing the value box down the tree (a split at `val` sends (val, hi] to child a, [lo, val] to child b): every
+    // reachable node once instead of a walk from the root per value — 7 tables per LF group of every frame add up in a streaming loop
+    struct Box { uint32_t pos; int32_t lo[2], hi[2]; };
+    vec<Box> stack{Box{0, {lo, lo}, {hi, hi}}};
+    while (!stack.empty()) {
+      const Box r = stack.back(); stack.pop_back();
+      const TreeNode& n = nd[r.pos];
+      if (n.prop < 0) {
+        const uint8_t cl = code.ctx_map[n.a >> 8];
+        if (np == 0) out->lut[0] = cl;
+        else if (np == 1) memset(out->lut.data() + (r.lo[0] - lo), cl, (size_t)(r.hi[0] - r.lo[0] + 1));
+        else for (int32_t a = r.lo[0]; a <= r.hi[0]; a++) memset(out->lut.data() + (size_t)(a - lo) * span + (r.lo[1] - lo), cl, (size_t)(r.hi[1] - r.lo[1] + 1));
+        continue;
+      }
+      const int st = Static(n, y);
+      if (st >= 0) { Box b = r; b.pos = (uint32_t)st; stack.push_back(b); continue; }
+      const int k = n.prop == props[0] ? 0 : 1;
+      if (r.hi[k] > n.val) { Box b = r; b.pos = n.a; b.lo[k] = std::max(r.lo[k], n.val + 1); stack.push_back(b); }
+      if (r.lo[k] <= n.val) { Box b = r; b.pos = n.b; b.hi[k] = std::min(r.hi[k], n.val); stack.push_back(b); }
+    }
+    out->cluster = out->lut[0];
+    return true;
   }
-  out->kind = prop < 0 ? 0 : prop == 2 ? 1 : 2;
-  out->pred = (uint32_t)pred;
-  out->cluster = out->lut[512];
+};
+}  // namespace
+// whether channel `chan` of sub-stream `stream_id` can reach a weighted-predictor leaf or a split on its error (a damaged tree counts as yes)
+bool LfChannelUsesWp(const HostTree& tree, int chan, uint32_t stream_id) {
+  static const HostCode no_code;
+  vec<int32_t> ysplits;
+  bool uses = false;
+  return tree.nodes.empty() || !LfClassifier(tree, no_code, chan, stream_id).Survey(&ysplits, &uses) || uses;
+}
+bool ClassifyLfChannel(const HostTree& tree, const HostCode& code, int chan, uint32_t stream_id, LfChanClass* out) {
+  if (tree.nodes.empty()) return false;
+  LfClassifier cl(tree, code, chan, stream_id);
+  vec<int32_t> ysplits;
+  out->uses_wp = false;
+  if (!cl.Survey(&ysplits, &out->uses_wp)) return false;
+  // rows 0 ... 511 (the table's reach; LF-group channels have at most 256 rows): a class per interval between row thresholds
+  vec<int32_t> starts{0};
+  for (int32_t v : ysplits) if (v >= 0 && v < 511) starts.push_back(v + 1);
+  std::sort(starts.begin(), starts.end());
+  starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+  if (starts.size() > 64) return false;
+  out->rows.clear();
+  for (size_t k = 0; k < starts.size(); k++) {
+    LfRowClass rc;
+    if (!cl.ClassifyRow(starts[k], &rc)) return false;
+    size_t idx = 0;
+    while (idx < out->rows.size() && !(out->rows[idx].kind == rc.kind && out->rows[idx].pred == rc.pred && out->rows[idx].sel_a == rc.sel_a && out->rows[idx].sel_b == rc.sel_b && out->rows[idx].lut == rc.lut)) idx++;
+    if (idx == out->rows.size()) out->rows.push_back(std::move(rc));
+    const int32_t end = k + 1 < starts.size() ? starts[k + 1] : 512;
+    for (int32_t y = starts[k]; y < end; y++) out->row_to_class[y] = (uint8_t)idx;
+  }
   return true;
 }
 
@@ -606,6 +688,7 @@ int64_t Batch::Info(const std::string& name) const {
   }
   if (name == "hf_nonzeros") { int64_t t = 0; for (uint32_t v : hf_written_) t += v; return t; }   // non-zero AC coefficients per decode of the batch (known after a Finish)
   if (name == "lf_simt_lanes") return lf_simt_.num_lanes;
+  if (name == "lf_simt_wp") return lf_simt_.num_lanes ? lf_simt_.any_wp : 0;     // the SIMT launch is the weighted-predictor instantiation
   if (!images_.empty() && !images_[0]->plan.modular) {   // geometry / quantiser of the first frame (tests that restate a stage from its defining formula)
     const FramePlan& p = images_[0]->plan;
     if (name == "frame0_bw") return p.bw;
@@ -803,7 +886,12 @@ void Batch::Prepare(void* stream_v) {
       if (p.upsampling > 1 && !e.complex) for (int c = 0; c < 4; c++) o.up_plane[c] = take_big((size_t)e.ih.xsize * e.ih.ysize * 4);
       o.lf_scratch_stride = 16 + 2 * 1024 + 3 * 65536;
       o.lf_scratch = take(o.lf_scratch_stride * 4 * p.num_lf_groups);
-      o.wp_scratch_stride = 10 * (256 + 2);
+      // weighted-predictor state of an LF-group stream.  LfDecodeSimtKernel: two rows of 258 records of 32 bytes; LfDecodeKernel's global
+      // form (channels wider than its LDS slot — only the block-info rows, up to 65 536 wide, can be): five arrays of 2 x (width + 2) ints
+      bool wide_wp = false;
+      if (p.tree.uses_wp && p.has_global_tree)
+        for (uint32_t g = 0; g < p.num_lf_groups && !wide_wp; g++) wide_wp = LfChannelUsesWp(p.tree, 2, 1 + 2 * p.num_lf_groups + g);
+      o.wp_scratch_stride = wide_wp ? 10 * (65536 + 2) : kLfSimtWpInts;
       o.wp_scratch = take(o.wp_scratch_stride * 4 * p.num_lf_groups);
       if (!p.gchannels.empty()) {
         // extra channels (alpha, ...) ride in the frame's Modular sub-streams: planes, channel table, undo plan
@@ -1187,6 +1275,7 @@ void Batch::Prepare(void* stream_v) {
     vec<uint64_t> cost;
     vec<uint8_t> luts;
     std::map<std::string, uint32_t> lut_of;       // table content -> offset in the blob (frames of one encoder share most tables)
+    bool wp_streams = false;                      // some eligible stream keeps weighted-predictor state: the batch takes that instantiation of the kernel
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
       if (p.modular || !p.has_global_tree || p.tree_code.use_prefix || p.tree_code.lz77 || p.tree_code.log_alpha > 8 || p.tree_code.num_clusters > 256 || p.use_lf_frame) continue;
@@ -1199,12 +1288,29 @@ void Batch::Prepare(void* stream_v) {
         for (int c = 0; c < 7 && ok; c++) {
           LfChanClass cl;
           ok = ClassifyLfChannel(p.tree, p.tree_code, c < 3 ? c : c - 3, c < 3 ? 1 + g : 1 + 2 * p.num_lf_groups + g, &cl);
+          if (ok && cl.uses_wp && c == 5) ok = false;      // (the block-info rows are up to 65 536 wide: the per-lane weighted-predictor rows hold 256)
           if (!ok) break;
-          const std::string key((const char*)cl.lut, sizeof(cl.lut));
-          auto it = lut_of.find(key);
-          if (it == lut_of.end()) { it = lut_of.emplace(key, (uint32_t)luts.size()).first; luts.insert(luts.end(), cl.lut, cl.lut + 1024); }
-          st.chan[c].lut_off = it->second;
-          st.chan[c].info = cl.kind | (cl.pred << 2) | (cl.cluster << 8);
+          auto intern = [&](const uint8_t* bytes, size_t size) {      // table content -> offset in the blob (frames of one encoder share most tables)
+            const std::string key((const char*)bytes, size);
+            auto it = lut_of.find(key);
+            if (it == lut_of.end()) { it = lut_of.emplace(key, (uint32_t)luts.size()).first; luts.insert(luts.end(), bytes, bytes + size); }
+            return it->second;
+          };
+          auto word = [&](const LfRowClass& rc) { return rc.kind | (rc.pred << 2) | (rc.sel_a << 5) | (rc.sel_b << 7) | (cl.uses_wp ? kLfSimtWpLive : 0u) | (rc.cluster << 16); };
+          if (cl.rows.size() == 1) {
+            st.chan[c].lut_off = cl.rows[0].kind ? intern(cl.rows[0].lut.data(), cl.rows[0].lut.size()) : 0;
+            st.chan[c].info = word(cl.rows[0]);
+          } else {   // the class depends on the row: [512 bytes: row -> class][classes x {table offset, class word}]
+            vec<uint8_t> blob(512 + 8 * cl.rows.size());
+            memcpy(blob.data(), cl.row_to_class, 512);
+            for (size_t k = 0; k < cl.rows.size(); k++) {
+              const uint32_t e[2] = {cl.rows[k].kind ? intern(cl.rows[k].lut.data(), cl.rows[k].lut.size()) : 0u, word(cl.rows[k])};
+              memcpy(blob.data() + 512 + 8 * k, e, 8);
+            }
+            st.chan[c].lut_off = intern(blob.data(), blob.size());
+            st.chan[c].info = kLfSimtRows | (cl.uses_wp ? kLfSimtWpLive : 0u);
+          }
+          if (cl.uses_wp) wp_streams = true;
         }
         if (ok) mine.push_back(st);
       }
@@ -1243,7 +1349,7 @@ void Batch::Prepare(void* stream_v) {
       simt_luts_off = arena.Put(luts.data(), luts.size());
       lf_simt_.num_lanes = (uint32_t)lanes.size();
       lf_simt_.lanes_per_wave = (uint32_t)std::max(1, 64 / std::max(1, cfg.lane_stride_lf));
-      lf_simt_.any_legacy = 0;
+      lf_simt_.any_legacy = 0; lf_simt_.any_wp = wp_streams ? 1 : 0;
       for (int i = 0; i < n; i++) if (!images_[i]->plan.modular && !simt_frame[i]) lf_simt_.any_legacy = 1;
     }
   }

@@ -561,6 +561,7 @@ void JxlHipBatchSetOption(JxlHipBatch* h, const char* name, int value) {
   if (n == "force_generic_idct") h->b->cfg.force_generic_idct = value;
   else if (n == "force_unfused_filters") h->b->cfg.force_unfused_filters = value;
   else if (n == "lf_wide_once") h->b->cfg.lf_wide_once = value != 0;
+  else if (n == "lf_wp_narrow_test") h->b->cfg.lf_wp_narrow_test = value != 0;
   else if (n == "debug_stop_after" && value >= 0 && value <= 5) h->b->cfg.debug_stop_after = value;
   else if (n == "keep_orientation") h->keep_orientation = value != 0;   // applies to outputs set afterwards
   else if (n == "hf_block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) h->b->cfg.hf_block_threads = value;

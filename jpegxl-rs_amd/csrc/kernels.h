@@ -138,6 +138,7 @@ struct LaunchCfg {
   // kernels for varblocks outside a 64x64 tile / the DCT128-256 family are only launched when some frame needs them
   int lf_wide_once = 0;              // the next LF launch takes the one-wavefront-per-stream kernel for every frame, SIMT-eligible or not (a pipeline that starts
                                      // on an idle GPU: 100 instead of 250 ms until the first batch can go on); reset by the launch
+  int lf_wp_narrow_test = 0;         // testing: the SIMT LF kernel's weighted-predictor lanes hand a stream back at |sample| > 16 instead of 2^20
   int lf_head_start = 0;             // the LF launch waits until the next HF launch is resident (set for pipelined front-only calls)
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
   int need_tile4_plain = 1, need_tile4_special = 1, need_tile8_plain = 1, need_tile8_special = 1;   // IdctTileKernel<TB, SPECIAL> variants some frame takes
@@ -152,12 +153,19 @@ void InitDeviceTables(void* stream);
 
 // ---- SIMT LF decode (LfDecodeSimtKernel): one LF-group stream (three LF coefficient channels + four HF-metadata channels, ~275 000 tokens
 // for a 2048x2048 region) per LANE instead of per wavefront.  The host classifies every channel of every stream from the frame's MA tree
-// (Batch::PlanLfSimt): after the static splits (channel index, stream id) the subtree must test at most one property — none, the row
-// (property 2) or the gradient W + N - NW (property 9) —, with leaves of predictor zero / W / clamped gradient, offset 0, multiplier 1.
-// Such a channel is described by a 1024-entry property -> cluster table (values clamped to [-512, 511]; splits outside that range make
-// the frame ineligible), which the lanes read through the L2 like the alias tables: nothing about a stream lives in LDS.
-struct LfSimtChan { uint32_t lut_off; uint32_t info; };    // lut_off: byte offset in the batch's LUT blob; info = kind | predictor << 2 | cluster << 8
-                                                           // kind 0: one cluster for the channel (`cluster`), 1: per row (table indexed by y), 2: per sample (property 9)
+// (decoder.cc ClassifyLfChannel): after the static splits (channel index, stream id) and per class of rows (splits on the row, property 2)
+// the subtree may test at most two of {W + N - NW (9), W (7), N (6), largest weighted-predictor error (15)} and its leaves share one
+// predictor with offset 0, multiplier 1.  A row class is an 8-byte entry {table offset, class word}; its table — 1024 bytes either way —
+// maps the clamped property value(s) to the cluster and is read through the L2 like the alias tables: nothing about a stream lives in LDS.
+// Class word: bits 0-1 kind (0: one cluster, bits 16-23; 1: table over property A, value in [-512, 511]; 2: table over A x B, values in
+// [-16, 15]); bits 2-4 predictor (0 zero, 1 W, 2 N, 3 clamped gradient, 4 weighted, 5 (W + N) / 2, 6 select, 7 NE); bits 5-6 / 7-8
+// property A / B (0: W + N - NW, 1: W, 2: N, 3: weighted-predictor error); bit 10: the channel keeps weighted-predictor state.
+// Channel entry: a row class when every row of the channel has the same one; with bit 9 set, lut_off points at
+// [512 bytes: row (clamped to 511) -> index][8-byte row classes].
+constexpr uint32_t kLfSimtRows = 1u << 9, kLfSimtWpLive = 1u << 10;
+constexpr uint32_t kLfSimtWpInts = 2 * 258 * 8;            // ints of weighted-predictor state per stream: 2 rows x 258 records {four sub-predictor errors, true error, pad}
+constexpr int32_t kLfRedoMark = 0x5eed;                    // lf_scratch[2] of an LF group: the SIMT kernel handed the stream back (LfDecodeKernel decodes it again)
+struct LfSimtChan { uint32_t lut_off; uint32_t info; };    // lut_off: byte offset in the batch's table blob; info: class word
 struct LfSimtStream { uint32_t frame, group; LfSimtChan chan[7]; };   // channels: LF Y, X, B, then ytox, ytob, block info, sharpness
 struct LfSimtLane { uint32_t first, count; };               // a lane decodes streams [first, first + count) one after the other
 struct LfSimtPlan {
@@ -165,6 +173,7 @@ struct LfSimtPlan {
   const uint2* units = nullptr; uint32_t num_units = 0;     // varblock placement: {frame, LF group | band << 16} of every 32-row band of every VarDCT frame, longest first
   uint32_t num_lanes = 0, lanes_per_wave = 16;
   int any_legacy = 1;          // some VarDCT frame of the batch still takes LfDecodeKernel (one wavefront per stream)
+  int any_wp = 0;              // some SIMT stream keeps weighted-predictor state (the kernel's WP instantiation; LfDecodeKernel follows for the streams it hands back)
 };
 
 // VarDCT stages.  max_* are maxima over the batch (grid sizing); nframes = frames in batch.

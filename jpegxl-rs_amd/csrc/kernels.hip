@@ -1509,6 +1509,14 @@ template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? J
   if (f.is_modular || (f.lf_simt && !take_simt_frames)) return;
   const uint32_t first = blockIdx.x * groups_per_block;
   if (first >= f.num_lf_groups) return;
+  // take_simt_frames 2: of the SIMT kernel's frames only the streams it handed back (lf_scratch[2] == kLfRedoMark: values outside the range of its
+  // 32-bit weighted-predictor arithmetic, explicit predictor parameters) — normally none, and the workgroup ends before it stages anything
+  const bool redo_only = f.lf_simt && take_simt_frames == 2;
+  if (redo_only) {
+    bool any = false;
+    for (uint32_t k = 0; k < groups_per_block && first + k < f.num_lf_groups; k++) any |= LdG(f.lf_scratch + (uint64_t)(first + k) * f.lf_scratch_stride + 2) == kLfRedoMark;
+    if (!any) return;
+  }
   ModTables T;
   StageModular(f.tree, f.tree_nodes, f.mod_code, T, tree_cap, lds_bytes);
   __shared__ int s_fail_w[kLfDecWaves];
@@ -1517,7 +1525,9 @@ template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? J
   const uint32_t wave = threadIdx.x >> 6;
   for (uint32_t turn = 0; turn < groups_per_block / kLfDecWaves; turn++) {   // (no block-wide barrier after this point)
     const uint32_t local = turn & 1 ? groups_per_block - 1 - (turn / 2) * kLfDecWaves - wave : (turn / 2) * kLfDecWaves + wave;
-    if (first + local < f.num_lf_groups) LfDecodeGroup(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
+    if (first + local >= f.num_lf_groups) continue;
+    if (redo_only && LdG(f.lf_scratch + (uint64_t)(first + local) * f.lf_scratch_stride + 2) != kLfRedoMark) continue;
+    LfDecodeGroup(f, first + local, T, s_fail_w[wave], s_gh_w[wave], s_u_w[wave]);
   }
 }
 
@@ -1571,19 +1581,36 @@ struct BitReaderQ {
   }
   __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)wpos * 32 - (uint64_t)avail; }
 };
-__device__ __forceinline__ bool SkipGroupHeaderSimt(BitReaderQ& br) {   // GroupHeader of an eligible stream: global tree, no transforms
+__device__ __forceinline__ bool SkipGroupHeaderSimt(BitReaderQ& br, bool* default_wp) {   // GroupHeader of an eligible stream: global tree, no transforms
   const uint32_t use_global_tree = br.Read(1);
-  if (!br.Read(1)) { br.Read(10); br.Read(25); br.Read(16); }          // explicit weighted-predictor parameters: not used by eligible trees
+  *default_wp = br.Read(1) != 0;
+  if (!*default_wp) { br.Read(10); br.Read(25); br.Read(16); }         // explicit weighted-predictor parameters (streams that use the predictor go back to LfDecodeKernel)
   const uint32_t sel = br.Read(2);
   const uint32_t ntr = sel == 0 ? 0u : sel == 1 ? 1u : sel == 2 ? 2u + br.Read(4) : 18u + br.Read(8);
   return use_global_tree && ntr == 0;
 }
 
-// Workgroups of up to 16 wavefronts: the stage's few wavefronts then sit on a handful of CUs (4 per SIMD, filling each other's issue gaps)
-// instead of one on each of a hundred CUs, where every one of them would share — and evict — the instruction cache and L1 of that
-// CU's pixel-kernel wavefronts.
-__global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
+// ---- weighted predictor of a SIMT lane (context_predict.h weighted::State with the header's default parameters — p1 16, p2 10, p3 7 7 7 0 0,
+// weights 13 12 12 12; a stream whose group header carries other parameters is handed back to LfDecodeKernel).  The reference keeps, per
+// sub-predictor, error magnitudes of the row above and of this row: a sample's magnitude is stored at its own position and ADDED to the
+// position right of it in the row above, i.e. to what the next sample reads as "N".  Per lane that is a register chain — aN (stored value
+// + the left neighbour's magnitude), aNW (the aN of the sample before) — and the stored values of the row above arrive from the stream's
+// two rows of 32-byte records {four magnitudes, true error} in global memory, two positions ahead of their use; the sample's own record
+// goes out with one 16-byte and one 4-byte store.  32-bit arithmetic throughout, exact while |sample| <= 2^20 and |true error| <= 2^24
+// (products with the 5-bit weights stay below 2^31); the lane checks both per sample and hands the stream back otherwise.
+constexpr uint32_t kWpRecBytes = 32, kWpRowBytes = 258 * kWpRecBytes;
+struct WpLane {
+  uint32_t aN[4], aNW[4], mA[4], mB[4];     // mA: stored magnitudes of the row above at x + 1 (arrived), mB: at x + 2 (in flight)
+  int32_t teN, teNW, teW, eA, eB;           // true errors at N, NW, W; of the row above at x + 1 / x + 2
+  int32_t pr[4], avg;                       // this sample's sub-predictions and their weighted average (x 8)
+};
+
+// One LF-group stream per lane, `lanes_per_wave` lanes per wavefront.  WP: the instantiation whose lanes may keep weighted-predictor state
+// (any channel class with kLfSimtWpLive); the plain one costs 64 VGPRs and no LDS, this one a 256-byte division table and ~40 VGPRs more.
+template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
                                                           const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority) {
+  __shared__ uint32_t s_div[WP ? 64 : 1];   // (1 << 24) / (i + 1): context_predict.h kDivLookup
+  if (WP) { if (threadIdx.x < 64) s_div[threadIdx.x] = (1u << 24) / (threadIdx.x + 1); __syncthreads(); }
   const uint32_t li = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * lanes_per_wave + (threadIdx.x & 63);
   if ((threadIdx.x & 63) >= lanes_per_wave || li >= num_lanes) return;
   if (high_priority & 1) __builtin_amdgcn_s_setprio(3);
@@ -1600,13 +1627,24 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
   const uint8_t* lut = luts;
   const uint64_t* alias = nullptr;
   const uint32_t* cfgp = nullptr;
-  uint32_t cfgu = 0, la = 0, kind = 0, pred = 0, row_cluster = 0, const_cluster = 0;
+  uint32_t cfgu = 0, la = 0, cls = 0, const_cluster = 0;     // cls: class word of the current row (kernels.h)
   bool hp = false, roll_next = false;     // a row above exists; the prefetch may run on into the next row (it exists and the row is >= 4 wide)
   int c = 7;                              // channel of the stream; 7: start the next stream
+  WpLane wp;
+  uint8_t* wrows = nullptr;               // this stream's two rows of weighted-predictor records
+  uint8_t* wprev = nullptr; uint8_t* wcur = nullptr;
+  if (WP) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) wp.aN[i] = wp.aNW[i] = wp.mA[i] = wp.mB[i] = 0;
+    wp.teN = wp.teNW = wp.teW = wp.eA = wp.eB = 0; wp.avg = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) wp.pr[i] = 0;
+  }
   for (;;) {
     if (__builtin_expect(x >= w, 0)) {
       // ---- rare path: next row, channel, sub-stream or stream
       bool more = true;
+      bool new_channel = false;
       for (;;) {
         if (c < 7 && y + 1 < h) { y++; out += stride; break; }
         const LfSimtStream* st = streams + cur;
@@ -1626,13 +1664,17 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
           br.Init(f.cs, f.single_section ? (f.mod_nchan ? f.stream_end_bitpos[1] : f.lf_start_bitpos) : f.sec_off[1 + g] * 8, f.cs_size);
           int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
           scratch[0] = (int32_t)br.Read(2);      // extra_precision
-          scratch[1] = 0;
-          if (!SkipGroupHeaderSimt(br)) { SetError(f, kErrUnsupported); cur++; continue; }   // (c stays 7: the next stream)
+          scratch[1] = 0; scratch[2] = 0;
+          bool default_wp = true;
+          if (!SkipGroupHeaderSimt(br, &default_wp)) { SetError(f, kErrUnsupported); cur++; continue; }   // (c stays 7: the next stream)
+          if (WP && !default_wp) { scratch[2] = kLfRedoMark; cur++; continue; }
           state = br.Read(32);
           alias = f.mod_code.alias; cfgp = f.mod_code.cfg; la = f.mod_code.log_alpha; cfgu = f.mod_cfg_uniform;
+          if (WP) wrows = reinterpret_cast<uint8_t*>(f.wp_scratch + (uint64_t)g * f.wp_scratch_stride);
           c = -1;
         }
         c++;
+        new_channel = true;
         const FrameDev& f = frames[LdG(&st->frame)];
         const uint32_t g = LdG(&st->group);
         const uint32_t gx = g % f.xlfgroups, gy = g / f.xlfgroups;
@@ -1643,7 +1685,9 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
           bool ok = true;
           if (state != 0x130000u) { SetError(f, kErrAnsFinalState); ok = false; }
           const uint32_t nb = 1 + br.Read(CeilLog2D(gbw * gbh));
-          if (ok && !SkipGroupHeaderSimt(br)) { SetError(f, kErrUnsupported); ok = false; }
+          bool default_wp = true;
+          if (ok && !SkipGroupHeaderSimt(br, &default_wp)) { SetError(f, kErrUnsupported); ok = false; }
+          if (WP && ok && !default_wp) { scratch[2] = kLfRedoMark; ok = false; }
           if (!ok) { cur++; c = 7; continue; }
           scratch[1] = (int32_t)nb;
           state = br.Read(32);
@@ -1663,8 +1707,6 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
           else { data = m_ytox + 2 * mcw * mch + 2 * nb; nw_ = gbw; nh_ = gbh; }
           stride = (int32_t)nw_;
         }
-        const uint2 cls = LdG(reinterpret_cast<const uint2*>(&st->chan[c]));
-        lut = luts + cls.x; kind = cls.y & 3; pred = (cls.y >> 2) & 7; const_cluster = cls.y >> 8;
         y = 0; out = data;
         if (nw_ == 0 || nh_ == 0) { w = 0; h = 0; continue; }      // empty channel: on to the next one
         w = nw_; h = nh_;
@@ -1674,15 +1716,44 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
       x = 0;
       hp = y > 0;
       roll_next = y + 1 < h && w >= 4;
-      row_cluster = kind == 1 ? (uint32_t)LdG(lut + 512 + min(y, 511u)) : const_cluster;
+      {  // class of this row
+        uint2 e = LdG(reinterpret_cast<const uint2*>(&streams[cur].chan[c]));
+        if (e.y & kLfSimtRows) {
+          const uint32_t k = LdG(luts + e.x + min(y, 511u));
+          e = LdG(reinterpret_cast<const uint2*>(luts + e.x + 512 + 8 * k));
+        }
+        lut = luts + e.x; cls = e.y; const_cluster = e.y >> 16;
+      }
       if (hp && w < 4) {                 // narrow rows: the rolling prefetch could run ahead of the stores
         up0 = LdG(out - stride); up1 = w > 1 ? LdG(out - stride + 1) : 0; up2 = w > 2 ? LdG(out - stride + 2) : 0;
       }
+      if (WP && (cls & kLfSimtWpLive)) {
+        if (w > 256) {                   // (the host keeps such channels off this kernel; a damaged stream may still announce one)
+          const LfSimtStream* st = streams + cur;
+          const FrameDev& f = frames[LdG(&st->frame)];
+          (f.lf_scratch + (uint64_t)LdG(&st->group) * f.lf_scratch_stride)[2] = kLfRedoMark;
+          cur++; c = 7; w = 0; h = 0; x = 0; continue;
+        }
+        if (new_channel) {               // fresh state: the row "above" row 0 holds zeros
+          for (uint32_t k = 0; k < w; k++) { StG(reinterpret_cast<uint4*>(wrows + kWpRowBytes + k * kWpRecBytes), make_uint4(0, 0, 0, 0)); StG(reinterpret_cast<int32_t*>(wrows + kWpRowBytes + k * kWpRecBytes + 16), 0); }
+        }
+        wcur = wrows + (y & 1) * kWpRowBytes; wprev = wrows + ((y & 1) ^ 1) * kWpRowBytes;
+        const uint4 m0 = LdG(reinterpret_cast<const uint4*>(wprev));
+        const uint4 m1 = LdG(reinterpret_cast<const uint4*>(wprev + (w > 1 ? kWpRecBytes : 0)));
+        wp.teN = LdG(reinterpret_cast<const int32_t*>(wprev + 16));
+        wp.eA = LdG(reinterpret_cast<const int32_t*>(wprev + (w > 1 ? kWpRecBytes : 0) + 16));
+        wp.aN[0] = m0.x; wp.aN[1] = m0.y; wp.aN[2] = m0.z; wp.aN[3] = m0.w;
+        wp.mA[0] = m1.x; wp.mA[1] = m1.y; wp.mA[2] = m1.z; wp.mA[3] = m1.w;
+#pragma unroll
+        for (int i = 0; i < 4; i++) wp.aNW[i] = wp.aN[i];
+        wp.teNW = wp.teN; wp.teW = 0;
+      }
       // everything this branch loaded has arrived before the branch ends: the common path below then starts without a wait for it
-      asm volatile("" : "+v"(up0), "+v"(up1), "+v"(up2), "+v"(row_cluster));
+      asm volatile("" : "+v"(up0), "+v"(up1), "+v"(up2), "+v"(const_cluster));
     }
     // ---- one sample.  All loads that do not depend on this sample's context go out first (bit-stream refill, the sample three
-    // positions ahead in the row above); the two that do (cluster, alias entry) are the iteration's two L2 round trips.
+    // positions ahead in the row above, the weighted-predictor record two positions ahead); the two that do (cluster, alias entry)
+    // are the iteration's two L2 round trips.
     br.Refill();
     int32_t up3 = 0;
     {
@@ -1696,11 +1767,71 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
     const int32_t NW = (x && hp) ? nw : W;
     nw = n_raw;
     const int32_t grad = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
-    uint32_t cluster = row_cluster;
-    if (kind == 2) cluster = LdG(lut + (uint32_t)(min(max(grad, -512), 511) + 512));
+    const bool wp_live = WP && (cls & kLfSimtWpLive);
+    const bool last_col = x + 1 >= w;
+    const int32_t NE = (hp && !last_col) ? up1 : N;
+    int32_t wp_err = 0, teNE = 0;
+    uint32_t aNE[4] = {0, 0, 0, 0};
+    if (wp_live) {
+      const uint8_t* r = wprev + min(x + 2, w - 1) * kWpRecBytes;
+      const uint4 m = LdG(reinterpret_cast<const uint4*>(r));
+      wp.eB = LdG(reinterpret_cast<const int32_t*>(r + 16));
+      wp.mB[0] = m.x; wp.mB[1] = m.y; wp.mB[2] = m.z; wp.mB[3] = m.w;
+      teNE = last_col ? wp.teN : wp.eA;
+#pragma unroll
+      for (int i = 0; i < 4; i++) aNE[i] = last_col ? wp.aN[i] : wp.mA[i];
+      int32_t p = wp.teW;
+      if (abs(wp.teN) > abs(p)) p = wp.teN;
+      if (abs(wp.teNW) > abs(p)) p = wp.teNW;
+      if (abs(teNE) > abs(p)) p = teNE;
+      wp_err = p;
+    }
+    const uint32_t kind = cls & 3, pcode = (cls >> 2) & 7;
+    uint32_t cluster = const_cluster;
+    if (kind) {
+      const uint32_t sa = (cls >> 5) & 3, sb = (cls >> 7) & 3;
+      const int32_t va = sa == 0 ? grad : sa == 1 ? W : sa == 2 ? N : wp_err;
+      const int32_t vb = sb == 0 ? grad : sb == 1 ? W : sb == 2 ? N : wp_err;
+      const uint32_t i1 = (uint32_t)(min(max(va, -512), 511) + 512);
+      const uint32_t i2 = ((uint32_t)(min(max(va, -16), 15) + 16) << 5) | (uint32_t)(min(max(vb, -16), 15) + 16);
+      cluster = LdG(lut + (kind == 1 ? i1 : i2));
+    }
     const int32_t mn = min(N, W), mx = max(N, W);
     const int32_t g5 = NW < mn ? mx : (NW > mx ? mn : grad);
-    const int32_t guess = pred == 0 ? 0 : (pred == 1 ? W : g5);
+    int32_t guess = pcode == 0 ? 0 : (pcode == 1 ? W : (pcode == 2 ? N : g5));
+    if (__builtin_expect(pcode >= 5, 0)) {
+      if (pcode == 5) guess = (int32_t)(((int64_t)W + N) / 2);
+      else if (pcode == 6) { const int64_t pp = (int64_t)W + N - NW; guess = Abs64(pp - W) < Abs64(pp - N) ? W : N; }
+      else guess = NE;
+    }
+    if (wp_live) {
+      // sub-predictor weights from the error magnitudes around the sample
+      uint32_t wt[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t e = wp.aN[i] + aNE[i] + wp.aNW[i];
+        const int shift = max(0, 26 - (int)__clz((int)(e + 1)));
+        wt[i] = 4 + (((i == 0 ? 13u : 12u) * s_div[e >> shift]) >> shift);
+      }
+      const int32_t N8 = N << 3, W8 = W << 3, NE8 = NE << 3;
+      const int32_t sumWN = wp.teN + wp.teW;
+      wp.pr[0] = W8 + NE8 - N8;
+      wp.pr[1] = N8 - ((sumWN + teNE) >> 1);
+      wp.pr[2] = W8 - (((sumWN + wp.teNW) * 10) >> 5);
+      wp.pr[3] = N8 - (((wp.teNW + wp.teN + teNE) * 7) >> 5);
+      uint32_t total = wt[0] + wt[1] + wt[2] + wt[3];
+      const int lg = 31 - (int)__clz((int)total);
+#pragma unroll
+      for (int i = 0; i < 4; i++) wt[i] >>= (lg - 4);
+      total = wt[0] + wt[1] + wt[2] + wt[3];
+      int32_t acc = (int32_t)(total >> 1) - 1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc += wp.pr[i] * (int32_t)wt[i];
+      int32_t avg = (int32_t)(((int64_t)acc * (int64_t)s_div[total - 1]) >> 24);
+      if (((wp.teN ^ wp.teW) | (wp.teN ^ wp.teNW)) <= 0) avg = max(min(W8, min(NE8, N8)), min(max(W8, max(NE8, N8)), avg));
+      wp.avg = avg;
+      if (pcode == 4) guess = (avg + 3) >> 3;
+    }
     // rANS symbol + hybrid integer (dec_ans.h), tables through the L2
     const uint32_t res = state & 0xFFF;
     const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
@@ -1730,6 +1861,29 @@ __global__ __launch_bounds__(256, 8) void LfDecodeSimtKernel(const FrameDev* __r
     const int32_t val = (int32_t)((uint32_t)UnpackSigned(tok) + (uint32_t)guess);
     if (!(xp & 2)) StG(out + x, val);
     left = val;
+    if (wp_live) {
+      // what the sample turned out to be: true error, error magnitude of every sub-predictor -> this row's record; the chain for x + 1
+      const int32_t v8 = (int32_t)((uint32_t)val << 3);
+      const int32_t te = wp.avg - v8;
+      uint32_t em[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) em[i] = (uint32_t)(abs(wp.pr[i] - v8) + 3) >> 3;
+      uint8_t* rec = wcur + x * kWpRecBytes;
+      StG(reinterpret_cast<uint4*>(rec), make_uint4(em[0], em[1], em[2], em[3]));
+      StG(reinterpret_cast<int32_t*>(rec + 16), te);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { wp.aNW[i] = wp.aN[i]; wp.aN[i] = wp.mA[i] + em[i]; wp.mA[i] = wp.mB[i]; }
+      wp.teNW = wp.teN; wp.teN = wp.eA; wp.eA = wp.eB; wp.teW = te;
+      const uint32_t vmax = (xp & 8) ? 16u : (1u << 20);      // (bit 8 of the flags: testing, so that ordinary streams take the hand-back path)
+      if (__builtin_expect((uint32_t)val + vmax > 2 * vmax || (uint32_t)te + (1u << 24) > (2u << 24), 0)) {
+        // outside the range the 32-bit arithmetic is exact for: the one-wavefront-per-stream kernel decodes this stream again (64-bit)
+        const LfSimtStream* st = streams + cur;
+        const FrameDev& f = frames[LdG(&st->frame)];
+        (f.lf_scratch + (uint64_t)LdG(&st->group) * f.lf_scratch_stride)[2] = kLfRedoMark;
+        cur++; c = 7; w = 0; h = 0; x = 0;
+        continue;
+      }
+    }
     x++;
   }
 }
@@ -4123,14 +4277,18 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     }
   };
   const int wide = cfg.lf_wide_once;      // this launch: one wavefront per stream for every frame (shorter latency, the whole GPU's SIMDs)
+  int simt_mode = wide ? 1 : 0;           // LfDecodeKernel's take_simt_frames: 0 legacy frames only, 1 every frame, 2 legacy frames + the streams the SIMT kernel handed back
   if (simt && simt->num_lanes && !wide) {
     // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane)
     const uint32_t lpw = std::min(64u, std::max(1u, simt->lanes_per_wave));
     static const int lf_prio = getenv("JXL_HIP_LF_PRIO") ? atoi(getenv("JXL_HIP_LF_PRIO")) : 0;
     static const int wpb_env = getenv("JXL_HIP_LF_WAVES_PER_WG") ? atoi(getenv("JXL_HIP_LF_WAVES_PER_WG")) : 1;
     const int nwaves = DivUp((int)simt->num_lanes, (int)lpw), wpb = std::max(1, std::min(4, wpb_env));
-    hipLaunchKernelGGL(LfDecodeSimtKernel, dim3(DivUp(nwaves, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_prio);
-    if (!simt->any_legacy) { place(); return; }
+    const int lf_flags = lf_prio | (cfg.lf_wp_narrow_test ? 8 : 0);
+    if (simt->any_wp) hipLaunchKernelGGL(LfDecodeSimtKernel<true>, dim3(DivUp(nwaves, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags);
+    else hipLaunchKernelGGL(LfDecodeSimtKernel<false>, dim3(DivUp(nwaves, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags);
+    if (!simt->any_legacy && !simt->any_wp) { place(); return; }
+    simt_mode = simt->any_wp ? 2 : 0;         // the weighted-predictor lanes may hand streams back: LfDecodeKernel follows for those (and for the legacy frames)
   }
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
@@ -4152,9 +4310,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
       hipLaunchKernelGGL(HeadStartKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sync, g_hf_enqueued[dev] + 1, (uint64_t)200000);   // the next HF launch, or 2 ms
   }
   if (big) {
-    hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, wide);
+    hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, simt_mode);
   } else {
-    hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, wide);
+    hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, simt_mode);
   }
   place();
 }

@@ -261,6 +261,13 @@ def set_lz77_lf(on=False):
     lib().jxlsynth_set_lz77_lf(1 if on else 0)
 
 
+def set_lf_tree_shape(shape=0):
+    """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
+    weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;
+    0: the gradient tree (what `cjxl --faster_decoding` picks)."""
+    lib().jxlsynth_set_lf_tree_shape(int(shape))
+
+
 def set_prev_channel_props(on=False):
     """VarDCT frames written from now on (this thread): the MA tree of their LF-group streams also splits on previous-channel properties."""
     lib().jxlsynth_set_prev_channel_props(1 if on else 0)

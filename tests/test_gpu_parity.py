@@ -1114,6 +1114,52 @@ def test_batch_objects_are_refilled_without_reallocating(jx):
         owner.reset(); owner.add_many([sets[0][0][0], b"\xff\x0a" + bytes(40)], "uint8", 3, threads=2)
 
 
+def test_lf_simt_weighted_predictor_trees(jx):
+    """LF-group streams under the MA-tree shape of a default-effort cjxl encode (weighted-predictor leaves under a fixed tree over property 15;
+    HF metadata under the row / N / W tree) take the SIMT LF kernel's weighted-predictor instantiation: every frame SIMT, HIP == oracle.
+    Streams that spell out other predictor parameters, and — "lf_wp_narrow_test" — streams whose samples leave the range of the lanes'
+    32-bit arithmetic, are handed back to the one-wavefront-per-stream kernel on the device and still decode bit-exactly; so do batches that
+    mix tree shapes, single images (no SIMT) and the wide first launch of a pipeline."""
+    from test_synth_roundtrip import cjxl_shape_streams
+    cases = cjxl_shape_streams()
+    refs = {}
+    for name, shape, cj, plain in cases:
+        if name not in refs:
+            refs[name] = O.decode(plain).pixels("u8", 3)
+        _, px = jx.decoder_builder().decode_with(cj, np.uint8)             # single image: one wavefront per stream
+        assert np.array_equal(px.reshape(-1), refs[name].reshape(-1)), (name, shape)
+    for shape in (1, 2):
+        mine = [(n, cj) for n, sh, cj, _ in cases if sh == shape]
+        for lf_stride, narrow, wide in ((4, 0, 0), (8, 0, 0), (1, 0, 0), (4, 1, 0), (4, 0, 1)):
+            b = jx.BatchDecoder(0)
+            b.set_lane_stride(lf_stride, 1)
+            b.add_many([cj for _, cj in mine] * 2, "uint8", 3)
+            b.set_option("lf_wp_narrow_test", narrow)
+            b.prepare()
+            assert b.info_value("lf_simt_frames") == 2 * len(mine) and b.info_value("lf_simt_wp") == 1
+            if wide:
+                b.set_option("lf_wide_once", 1)
+            for _ in range(2):                                              # (decoded again: the hand-back marks are per decode)
+                b.decode(); b.finish()
+                for i, (n, _) in enumerate(mine * 2):
+                    assert np.array_equal(b.output(i).reshape(-1), refs[n].reshape(-1)), (shape, lf_stride, narrow, wide, n)
+    # mixed batch: weighted-predictor trees, gradient trees (SIMT without predictor state of their own), a prefix-coded frame (legacy kernel)
+    S.set_prefix(True)
+    try:
+        pfx = S.encode_vardct(S.synthetic_image(81, 320, 200), seed=1, strategy_mix=1, epf_iters=1)
+    finally:
+        S.set_prefix(False)
+    mixed = [(n, cj) for n, sh, cj, _ in cases if sh == 1][:3] + [(n, pl) for n, sh, _, pl in cases if sh == 2][:3] + [("small", pfx)]
+    b = jx.BatchDecoder(0)
+    b.set_lane_stride(4, 1)
+    b.add_many([d for _, d in mixed], "uint8", 3)
+    b.prepare()
+    assert b.info_value("lf_simt_frames") == 6 and b.info_value("lf_legacy_frames") == 1 and b.info_value("lf_simt_wp") == 1
+    b.decode(); b.finish()
+    for i, (n, _) in enumerate(mixed):
+        assert np.array_equal(b.output(i).reshape(-1), refs[n].reshape(-1)), (i, n)
+
+
 def test_batch_reset_and_unsharing_leave_a_consistent_object(jx):
     """Round-3 advisor findings on Batch::Reset / ShareCoefArena / ShareBigArena / ClearCoefficientsBeforeHf: (1) Reset() really forgets the
     prepared state — sharing can be set up afterwards and a decode of the empty batch is a no-op; (2) leaving a sharing arrangement
@@ -1141,6 +1187,7 @@ def test_batch_reset_and_unsharing_leave_a_consistent_object(jx):
     sharer.share_coefficients(owner); sharer.share_buffers(owner)
     sharer.decode(); sharer.finish()
     assert sharer.total_pixels == 0
+    sharer.reset()
     # (2) leave the arrangement: own planes again; the owner's planes are still there and still the owner's
     sharer.share_coefficients(None); sharer.share_buffers(None)
     sharer.add_many(large, "uint8", 3); run(sharer, ref_large)

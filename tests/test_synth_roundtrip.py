@@ -365,3 +365,32 @@ def test_previous_channel_properties_in_lf_streams_decode_like_the_plain_tree():
     for name, pc, plain in prev_channel_streams():
         assert pc != plain
         assert np.array_equal(O.decode(pc).pixels("u8", 3), O.decode(plain).pixels("u8", 3)), name
+
+
+def cjxl_shape_streams():
+    """(name, shape, stream under the MA-tree shape of a default-effort cjxl encode, twin under the gradient tree).  Shape 1: weighted-predictor
+    leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata, default predictor
+    parameters; shape 2: the same with the parameters spelt out (other values) in every LF-group header."""
+    import synth_lib as S
+    out = []
+    for name, seed, (w, h), mix, epf in [("small", 1, (320, 200), 1, 1), ("one_group", 2, (64, 48), 0, 2), ("two_lf_groups", 3, (2300, 400), 2, 0), ("tall", 4, (136, 2200), 1, 1)]:
+        img = S.synthetic_image(80 + seed, w, h)
+        plain = S.encode_vardct(img, seed=seed, strategy_mix=mix, epf_iters=epf)
+        for shape in (1, 2):
+            S.set_lf_tree_shape(shape)
+            try:
+                out.append((name, shape, S.encode_vardct(img, seed=seed, strategy_mix=mix, epf_iters=epf), plain))
+            finally:
+                S.set_lf_tree_shape(0)
+    return out
+
+
+def test_cjxl_shaped_lf_trees_decode_like_the_gradient_tree():
+    """The weighted predictor inside LF-group streams (what cjxl writes at its default effort): the synthesiser's encoder-side simulation of the
+    predictor (written from the format's definition) and the oracle's decoder agree — same pixels as the twin whose LF coefficients ride under
+    the gradient tree; explicit predictor parameters in the group headers included."""
+    import numpy as np
+    import oracle_lib as O
+    for name, shape, cj, plain in cjxl_shape_streams():
+        assert cj != plain
+        assert np.array_equal(O.decode(cj).pixels("u8", 3), O.decode(plain).pixels("u8", 3)), (name, shape)

@@ -129,6 +129,26 @@ static int BuildCutoffTree(GTree& t, int prop, const std::vector<int>& cut, int 
 }
 static GTree MakeGlobalTree(int nlf, std::vector<int>* bfs_order) {
   GTree t;
+  int root;
+  if (LfTreeShape() >= 1) {
+    // The tree shape of a default-effort encode (libjxl enc_modular.cc: tree kinds "WP fixed DC" for the LF coefficients, "AC meta" for the HF
+    // metadata), restated from the format's point of view: the LF channels look at the weighted predictor's largest neighbouring error
+    // (property 15) through 33 cut-offs, every leaf predicts with the weighted predictor (6); the HF-metadata channels: chroma-from-luma maps
+    // -> clamped gradient, the (strategy, quantiser) rows -> zero / W under splits on the row and on W, the sharpness map -> zero under N > 0, W > 0.
+    static const int wcuts[] = {-500, -392, -255, -191, -127, -95, -63, -47, -31, -23, -15, -11, -7, -4, -3, -1, 0, 1, 3, 5, 7, 11, 15, 23, 31, 47, 63, 95, 127, 191, 255, 392, 500};
+    std::vector<int> cut(wcuts, wcuts + sizeof(wcuts) / sizeof(wcuts[0]));
+    const int lf = BuildCutoffTree(t, 15, cut, 0, (int)cut.size(), 6);        // one subtree for the three channels (the real encoder does not split on the channel either)
+    auto w_split3 = [&](int pred) {   // W > 5 ? (W > 11 ? a : b) : (W > 3 ? c : d)
+      return t.add_inner(7, 5, t.add_inner(7, 11, t.add_leaf(pred), t.add_leaf(pred)), t.add_inner(7, 3, t.add_leaf(pred), t.add_leaf(pred)));
+    };
+    const int qf = w_split3(1), acs = w_split3(0);
+    const int blk = t.add_inner(2, 0, qf, acs);                                 // row 1: quantiser, row 0: strategy
+    const int epf = t.add_inner(6, 0, t.add_inner(7, 0, t.add_leaf(0), t.add_leaf(0)), t.add_inner(7, 0, t.add_leaf(0), t.add_leaf(0)));
+    const int c23 = t.add_inner(0, 2, epf, blk);
+    const int cfl = t.add_inner(0, 0, t.add_leaf(5), t.add_leaf(5));
+    const int meta = t.add_inner(0, 1, c23, cfl);
+    root = t.add_inner(1, nlf, meta, lf);
+  } else {
   static const int cuts[] = {-255, -127, -63, -31, -15, -7, -3, -1, 0, 1, 3, 7, 15, 31, 63, 127, 255};
   std::vector<int> cut(cuts, cuts + sizeof(cuts) / sizeof(cuts[0]));
   int ty = BuildCutoffTree(t, 9, cut, 0, (int)cut.size(), 5);
@@ -147,7 +167,8 @@ static GTree MakeGlobalTree(int nlf, std::vector<int>* bfs_order) {
   int blk = t.add_inner(2, 0, hfmul, strat);
   int c23 = t.add_inner(0, 2, sharp, blk);
   int meta = t.add_inner(0, 1, c23, cfl);
-  int root = t.add_inner(1, nlf, meta, lf);
+  root = t.add_inner(1, nlf, meta, lf);
+  }
   // BFS numbering (that is the order nodes are written / leaf contexts are assigned)
   std::vector<int> order{root};
   for (size_t i = 0; i < order.size(); i++) {
@@ -178,11 +199,92 @@ static void TreeTokens(const GTree& t, const std::vector<int>& bfs, std::vector<
   }
 }
 
+// The weighted predictor as the format defines it (ISO/IEC 18181-1 "self-correcting predictor"; default parameters): four sub-predictors whose
+// recent errors around the sample weight their average.  Encoder-side simulation for the fixed trees above: Predict() gives the prediction (x 8)
+// and the largest neighbouring error (property 15), Update() records what the sample turned out to be.
+struct WpParams { int p1 = 16, p2 = 10, p3[5] = {7, 7, 7, 0, 0}; uint32_t wmax[4] = {13, 12, 12, 12}; };
+// LfTreeShape() 2: the LF-group streams of VarDCT frames spell the predictor's parameters out in their group headers — these, not the defaults
+static WpParams LfWpParams() {
+  WpParams q;
+  if (LfTreeShape() == 2) { q.p1 = 20; q.p2 = 8; const int p3[5] = {5, 9, 6, 3, 2}; const uint32_t wm[4] = {10, 14, 9, 13}; for (int i = 0; i < 5; i++) q.p3[i] = p3[i]; for (int i = 0; i < 4; i++) q.wmax[i] = wm[i]; }
+  return q;
+}
+static void WriteGroupHeaderLf(BitWriter& s) {     // GroupHeader of an LfGroup sub-stream: global tree, predictor parameters, no transforms
+  s.put(1, 1);
+  if (LfTreeShape() == 2) {
+    const WpParams q = LfWpParams();
+    s.put(0, 1); s.put(q.p1, 5); s.put(q.p2, 5);
+    for (int i = 0; i < 5; i++) s.put(q.p3[i], 5);
+    for (int i = 0; i < 4; i++) s.put(q.wmax[i], 4);
+  } else s.put(1, 1);
+  s.put(0, 2);
+}
+struct WpSim {
+  WpParams par;
+  int w = 0;
+  std::vector<int32_t> err[2];            // true errors of the two rows in use
+  std::vector<uint32_t> sub[4][2];        // per sub-predictor: error magnitudes, (w + 2) entries per row
+  int64_t pred[4] = {0, 0, 0, 0}, avg = 0;
+  void Init(int width) { w = width; for (int r = 0; r < 2; r++) { err[r].assign((size_t)w + 2, 0); for (int i = 0; i < 4; i++) sub[i][r].assign((size_t)w + 2, 0); } }
+  static uint32_t Recip(uint32_t i) { return (1u << 24) / (i + 1); }
+  static int Log2Floor(uint64_t v) { int n = 0; while (v >>= 1) n++; return n; }
+  int64_t Predict(int x, int y, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN, int32_t* max_error) {
+    const uint32_t* kMaxWeight = par.wmax;
+    const int cur = y & 1, up = cur ^ 1;
+    const int n = x, ne = x + 1 < w ? x + 1 : x, nw = x > 0 ? x - 1 : x;
+    uint32_t wt[4];
+    for (int i = 0; i < 4; i++) {
+      const uint64_t e = (uint64_t)sub[i][up][n] + sub[i][up][ne] + sub[i][up][nw];
+      int shift = Log2Floor(e + 1) - 5;
+      if (shift < 0) shift = 0;
+      wt[i] = 4 + (uint32_t)(((uint64_t)kMaxWeight[i] * Recip((uint32_t)(e >> shift))) >> shift);
+    }
+    N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
+    const int64_t eW = x ? err[cur][x - 1] : 0, eN = err[up][n], eNW = err[up][nw], eNE = err[up][ne];
+    int64_t m = eW;
+    if (std::llabs(eN) > std::llabs(m)) m = eN;
+    if (std::llabs(eNW) > std::llabs(m)) m = eNW;
+    if (std::llabs(eNE) > std::llabs(m)) m = eNE;
+    *max_error = (int32_t)m;
+    pred[0] = W + NE - N;
+    pred[1] = N - (((eW + eN + eNE) * par.p1) >> 5);
+    pred[2] = W - (((eW + eN + eNW) * par.p2) >> 5);
+    pred[3] = N - ((eNW * par.p3[0] + eN * par.p3[1] + eNE * par.p3[2] + (NN - N) * par.p3[3] + (NW - W) * par.p3[4]) >> 5);
+    uint32_t total = wt[0] + wt[1] + wt[2] + wt[3];
+    const int lg = Log2Floor(total);
+    total = 0;
+    for (int i = 0; i < 4; i++) { wt[i] >>= lg - 4; total += wt[i]; }
+    int64_t acc = (int64_t)(total >> 1) - 1;
+    for (int i = 0; i < 4; i++) acc += pred[i] * (int64_t)wt[i];
+    avg = (acc * (int64_t)Recip(total - 1)) >> 24;
+    if (((eN ^ eW) | (eN ^ eNW)) <= 0) {
+      const int64_t hi = std::max(W, std::max(NE, N)), lo = std::min(W, std::min(NE, N));
+      avg = std::max(lo, std::min(hi, avg));
+    }
+    return avg;
+  }
+  void Update(int64_t sample, int x, int y) {
+    const int cur = y & 1, up = cur ^ 1;
+    sample *= 8;
+    err[cur][x] = (int32_t)(avg - sample);
+    for (int i = 0; i < 4; i++) {
+      const uint32_t e = (uint32_t)((std::llabs(pred[i] - sample) + 3) >> 3);
+      sub[i][cur][x] = e;
+      sub[i][up][x + 1] += e;
+    }
+  }
+};
+
 // tokenises channels (each w x h ints) of one modular sub-stream under the global tree
 struct ChanRef { const int32_t* d; int w, h; };
-static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& chans, int stream_id, std::vector<Token>& tok) {
+static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& chans, int stream_id, std::vector<Token>& tok, const WpParams& wpar = WpParams()) {
+  bool tree_wp = false;
+  for (const TNode& n : t.nodes) tree_wp |= n.prop == 15 || (n.prop < 0 && n.pred == 6);
+  WpSim wp;
+  wp.par = wpar;
   for (size_t ci = 0; ci < chans.size(); ci++) {
     const ChanRef& ch = chans[ci];
+    if (tree_wp) wp.Init(ch.w);
     for (int y = 0; y < ch.h; y++) {
       const int32_t* p = ch.d + (size_t)y * ch.w;
       const int32_t* pn = y ? p - ch.w : nullptr;
@@ -190,7 +292,14 @@ static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& 
         int64_t W = x ? p[x - 1] : (y ? pn[x] : 0);
         int64_t N = y ? pn[x] : W;
         int64_t NW = (x && y) ? pn[x - 1] : W;
-        int props[16 + 4 * 4] = {(int)ci, stream_id, y, x, 0, 0, 0, 0, 0, (int)(W + N - NW)};
+        int props[16 + 4 * 4] = {(int)ci, stream_id, y, x, 0, 0, (int)N, (int)W, 0, (int)(W + N - NW)};
+        int64_t wp_guess = 0;
+        if (tree_wp) {
+          const int64_t NE = (y && x + 1 < ch.w) ? pn[x + 1] : N, NN = y > 1 ? pn[x - ch.w] : N;
+          int32_t max_error = 0;
+          wp_guess = (wp.Predict(x, y, N, W, NE, NW, NN, &max_error) + 3) >> 3;
+          props[15] = max_error;
+        }
         {  // encoding.cc PrecomputeReferences: earlier channels of this stream with the same size, nearest first
           int r = 0;
           for (int cj = (int)ci - 1; cj >= 0 && r < 4; cj--) {
@@ -209,8 +318,10 @@ static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& 
         int64_t guess;
         if (leaf.pred == 0) guess = 0;
         else if (leaf.pred == 1) guess = W;
+        else if (leaf.pred == 6) guess = wp_guess;
         else { int64_t m = std::min(N, W), M = std::max(N, W), g = N + W - NW; guess = NW < m ? M : (NW > M ? m : g); }
         tok.push_back({(uint32_t)leaf.ctx, PackSigned((int32_t)(p[x] - guess))});
+        if (tree_wp) wp.Update(p[x], x, y);
       }
     }
   }
@@ -899,7 +1010,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     }
     std::vector<ChanRef> cr;
     for (int i = 0; i < 3; i++) cr.push_back({d.ch[i].data(), d.gbw, d.gbh});
-    ModularTokens(gt, root, cr, 1 + g, d.lf_tok);
+    ModularTokens(gt, root, cr, 1 + g, d.lf_tok, LfWpParams());
     // HF metadata
     int mcw = (d.gbw + 7) / 8, mch = (d.gbh + 7) / 8;
     d.m[0].resize((size_t)mcw * mch); d.m[1].resize((size_t)mcw * mch);
@@ -917,7 +1028,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     d.m[3].resize((size_t)d.gbw * d.gbh);
     for (int y = 0; y < d.gbh; y++) for (int x = 0; x < d.gbw; x++) d.m[3][(size_t)y * d.gbw + x] = sharp[(size_t)(by0 + y) * bw + bx0 + x];
     std::vector<ChanRef> mr{{d.m[0].data(), mcw, mch}, {d.m[1].data(), mcw, mch}, {d.m[2].data(), d.nb, 2}, {d.m[3].data(), d.gbw, d.gbh}};
-    ModularTokens(gt, root, mr, 1 + 2 * nlf + g, d.meta_tok);
+    ModularTokens(gt, root, mr, 1 + 2 * nlf + g, d.meta_tok, LfWpParams());
   }
   // --- tokens: AC per group
   const int nctx = 15;
@@ -1047,12 +1158,12 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     LfGroupData& d = lgd[g];
     if (!p.use_lf_frame) {
       s.put(0, 2);  // extra_precision
-      s.put(1, 1); s.put(1, 1); s.put(0, 2);  // GroupHeader: use_global_tree, default WP, 0 transforms
+      WriteGroupHeaderLf(s);
       EncodeTokens(s, mod_code, d.lf_tok);
     }
     // (ModularLfGroup: no channels -> nothing)
     s.put(d.nb - 1, CeilLog2((uint32_t)(d.gbw * d.gbh)));
-    s.put(1, 1); s.put(1, 1); s.put(0, 2);
+    WriteGroupHeaderLf(s);
     EncodeTokens(s, mod_code, d.meta_tok);
     sections.push_back(s);
   }
@@ -1356,6 +1467,7 @@ void jxlsynth_set_preview(int w, int h) { synth::g_preview_w = w; synth::g_previ
 void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
+void jxlsynth_set_lf_tree_shape(int shape) { synth::LfTreeShape() = shape; }
 // rgba == NULL: the extra channel is alpha again
 void jxlsynth_set_spot(const float* rgba) { synth::g_spot_set = rgba != nullptr; if (rgba) for (int i = 0; i < 4; i++) synth::g_spot[i] = rgba[i]; }
 // white_point < 0 clears the override
