@@ -318,6 +318,8 @@ struct ModularCtx {
   WPHeader wp;
   uint32_t uses_wp;     // tree uses predictor 6 or property 15
   int32_t* wp_scratch;  // 5 * 2 * (max_w + 2) ints (only if uses_wp)
+  uint32_t* status = nullptr;         // device: the frame's error word
+  uint64_t wp_scratch_ints = ~0ull;   // device: what the stream's slot really holds (a wider weighted-predictor channel is refused)
   uint32_t stream_id;
   uint32_t narrow_wp = 0;  // device fast path: 32-bit weighted-predictor intermediates are exact (samples of at most 12 bits)
   uint32_t slow = 0;       // the code uses prefix codes and / or LZ77: symbols are read by the general reader (tables in global memory)

@@ -835,6 +835,25 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.a); StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.b);
     }
     if (!T.tree_in_lds) mode = 0;
+    // whether the channel's subtree looks at the weighted predictor at all (a leaf with predictor 6, a split on property 15): its state is
+    // per channel, so a channel that never does skips the arithmetic — and the state rows, which for the widest channels (the block-info rows
+    // of an LF group: up to 65 536 samples) the host only provides when the subtree can get there (decoder.cc LfChannelUsesWp)
+    int sub_wp = 0;
+    if (mc.uses_wp && mode == 0) {
+      int visited = 0;
+      sp = 0;
+      StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)pos);
+      while (sp > 0 && !sub_wp) {
+        const TreeNode m = T.Node((uint32_t)LdS<int>(wb + kWorkOff + 64 + 4 * --sp));
+        if (++visited > 8192) { sub_wp = 1; break; }
+        if (m.prop < 0) { if ((m.a & 0xFF) == 6) sub_wp = 1; continue; }
+        if (m.prop == 15) { sub_wp = 1; break; }
+        if (m.prop == 0 || m.prop == 1) { StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)((m.prop == 0 ? chan : (int32_t)mc.stream_id) > m.val ? m.a : m.b)); continue; }
+        if (sp + 2 > 200) { sub_wp = 1; break; }
+        StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.a); StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.b);
+      }
+    }
+    StS<int>(wb + kWorkOff + 56, sub_wp);
     StS<int>(wb + kWorkOff + 0, mode); StS<int>(wb + kWorkOff + 4, prop); StS<int>(wb + kWorkOff + 8, (int)pos); StS<int>(wb + kWorkOff + 12, upred);
     StS<int>(wb + kWorkOff + 20, wide);
   }
@@ -941,8 +960,12 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     WaveSync();
     return;
   }
-  const bool use_wp = mc.uses_wp != 0 && mode == 0;
+  const bool use_wp = mc.uses_wp != 0 && mode == 0 && LdS<int>(wb + kWorkOff + 56) != 0;
   const bool wp_in_lds = use_wp && T.wp_off != 0xFFFFFFFFu && ch.w <= kWpLdsMaxW;
+  if (use_wp && !wp_in_lds && 10ull * ((uint64_t)ch.w + 2) > mc.wp_scratch_ints) {     // (a tree too large to survey: no state rows of that width)
+    if (lane == 0 && mc.status) atomicOr(mc.status, kErrUnsupported);
+    return;
+  }
   WPStateLds wpl;
   if (wp_in_lds) { wpl.Init(T.wp_off, T.wp_off + kWpLdsBytes - 256, ch.w, lane, mc.narrow_wp != 0); WaveSync(); }
   // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
@@ -1217,7 +1240,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
 
   ModularCtx mc;
   mc.tree = f.tree; mc.code = &f.mod_code; mc.uses_wp = f.uses_wp;
-  mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride;
+  mc.wp_scratch = f.wp_scratch + (uint64_t)g * f.wp_scratch_stride; mc.wp_scratch_ints = f.wp_scratch_stride; mc.status = f.status;
   mc.slow = f.mod_code.use_prefix || f.mod_code.lz77;       // prefix-coded LF streams (cjxl's fast efforts), LZ77 (its slowest): the general symbol reader
   // LZ77 state in LDS (the rare path must not cost the common one registers); one window per LF group: its two streams — LF coefficients,
   // HF metadata — use it one after the other
@@ -3811,7 +3834,7 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
   ModularCtx mc;
   mc.tree = tree; mc.code = &code; mc.uses_wp = local ? local->uses_wp : f.uses_wp; mc.wp = f.gwp; mc.stream_id = 0; mc.narrow_wp = f.mod_bits <= 12;
   mc.max_prop = local ? local->max_prop : f.tree_max_prop;
-  mc.wp_scratch = f.mod_wp_scratch;
+  mc.wp_scratch = f.mod_wp_scratch; mc.wp_scratch_ints = f.mod_wp_stride; mc.status = f.status;
   mc.slow = code.use_prefix || code.lz77;
   __shared__ ModRefs s_refs;
   mc.refs = &s_refs;
@@ -3956,7 +3979,7 @@ __global__ __launch_bounds__(256) void ModularGroupFastKernel(const FrameDev* __
   mc.tree = tree; mc.code = &code; mc.uses_wp = local ? local->uses_wp : f.uses_wp; mc.wp = U.gh.wp; mc.narrow_wp = f.mod_bits <= 12;
   mc.max_prop = local ? local->max_prop : f.tree_max_prop;
   mc.stream_id = is_lf ? 1 + f.num_lf_groups + g : 1 + 3 * f.num_lf_groups + 17 + last_pass * f.num_groups + g;
-  mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride;
+  mc.wp_scratch = f.mod_wp_scratch + (uint64_t)(1 + unit) * f.mod_wp_stride; mc.wp_scratch_ints = f.mod_wp_stride; mc.status = f.status;
   mc.slow = code.use_prefix || code.lz77;
   __shared__ ModRefs s_refs_w[kLfWaves];
   ModRefs& refs = s_refs_w[wave];

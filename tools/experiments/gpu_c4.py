@@ -1,7 +1,7 @@
 """Resident decode of BASELINE config 4 (8192x8192 Modular Squeeze u16) a few times — for rocprofv3 (not a pytest)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jpegxl_rs_amd as jx
 import synth_lib as S

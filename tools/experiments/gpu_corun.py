@@ -1,9 +1,9 @@
 """GPU helper: which shared resource are the pixel stages (IDCT, filters) short of when the HF stage of another batch runs beside them?
 The tail of a prepared batch (JxlHipBatchDecodePart 4) is timed alone, beside the real HF stage of a second batch, and beside synthetic
-co-runners (tools/microbench/spin.hip) that each exercise one resource.   usage: python tests/gpu_corun.py [frames]"""
+co-runners (tools/microbench/spin.hip) that each exercise one resource.   usage: python tools/experiments/gpu_corun.py [frames]"""
 import ctypes as C, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import jpegxl_rs_amd as jx

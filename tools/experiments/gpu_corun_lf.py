@@ -1,7 +1,7 @@
-"""GPU helper: cost of LF SIMT stages in flight for the pixel stages (tail) of another batch.  usage: python tests/gpu_corun_lf.py"""
+"""GPU helper: cost of LF SIMT stages in flight for the pixel stages (tail) of another batch.  usage: python tools/experiments/gpu_corun_lf.py"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import jpegxl_rs_amd as jx

@@ -1,7 +1,7 @@
 """Scratch: where does a free-running stream differ between the HIP path and the oracle (not a pytest)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jpegxl_rs_amd as jx
 import oracle_lib as O, synth_lib as S

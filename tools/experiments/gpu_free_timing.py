@@ -1,7 +1,7 @@
 """Times free-running Modular streams (general MA trees) through the one-shot API (not a pytest).  argv[1] = library path override."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jpegxl_rs_amd as jx
 if len(sys.argv) > 1:

@@ -3,7 +3,7 @@ usage: gpu_fuzz_dbg.py            -> runs all, prints the ones that do not end i
        gpu_fuzz_dbg.py <i> <t>    -> runs one and prints the outcome"""
 import os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 

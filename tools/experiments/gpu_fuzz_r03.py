@@ -3,7 +3,7 @@ subsampled frames, LZ77-coded LF streams, previous-channel properties, animation
 Not a pytest (run under gpurun, inside `timeout`)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth_lib as S
 import jpegxl_rs_amd as jx

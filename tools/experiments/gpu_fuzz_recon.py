@@ -1,7 +1,7 @@
 """Isolates crashing inputs of the JPEG-reconstruction corruption loop: every trial in a subprocess (not a pytest)."""
 import os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 if os.environ.get("FUZZ_CASE"):                    # a transcode of a libjpeg-written JPEG (tests/jpeg_cases.py) instead of the fixture
     import jpeg_cases as JC

@@ -1,7 +1,7 @@
 """Stage times of one resident 3840x2160 decode with the two HF kernels (not a pytest): lane stride 64 = one group stream per
 wavefront (default of the one-shot API: lowest latency), 1 = SIMT, one stream per lane (bench.py: highest throughput)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jpegxl_rs_amd as jx
 import synth_lib as S

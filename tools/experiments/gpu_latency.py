@@ -2,7 +2,7 @@
 through a resident one-image batch (device time only).  Prints one line per case."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jpegxl_rs_amd as jx
 import synth_lib as S

@@ -1,8 +1,8 @@
 """GPU helper: N LF stages (SIMT form) of N batches on N streams at once, nothing else running — does the LF launch time depend on its
-company?  usage: python tests/gpu_lf_conc.py [frames] [lane_stride]"""
+company?  usage: python tools/experiments/gpu_lf_conc.py [frames] [lane_stride]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import jpegxl_rs_amd as jx

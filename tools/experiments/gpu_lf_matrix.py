@@ -1,7 +1,7 @@
 """GPU helper: LF SIMT kernel time (JXL_HIP_TIME_LF=1 prints decode / placement per launch) over batch sizes and lanes per wavefront.
-usage: JXL_HIP_TIME_LF=1 python tests/gpu_lf_matrix.py"""
+usage: JXL_HIP_TIME_LF=1 python tools/experiments/gpu_lf_matrix.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import jpegxl_rs_amd as jx

@@ -1,8 +1,8 @@
 """GPU helper (not a pytest file): SIMT LF decode — parity against the oracle on a few shapes, then the LF stage's time for a batch
 of 4K frames at several lanes-per-wavefront settings next to the one-wavefront-per-stream kernel.
-usage: python tests/gpu_lf_simt.py [frames] [distinct]"""
+usage: python tools/experiments/gpu_lf_simt.py [frames] [distinct]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

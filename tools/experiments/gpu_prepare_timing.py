@@ -1,7 +1,7 @@
 """Where does the host-side preparation of a fresh batch go (not a pytest): add (parse) vs prepare (allocation, upload, LF pre-run)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import jpegxl_rs_amd as jx

@@ -1,4 +1,4 @@
-// Co-runner for interference experiments (tests/gpu_corun.py): long-lived wavefronts that do a configurable kind of work for a given time,
+// Co-runner for interference experiments (tools/experiments/gpu_corun.py): long-lived wavefronts that do a configurable kind of work for a given time,
 // launched beside a real decode stage to see which shared resource that stage is short of.
 //   mode 0: dependent VALU chain only            mode 1: + `lds` bytes of LDS held per workgroup
 //   mode 2: + one scattered 4-byte load per lane and round over `span` bytes (TLB / L2 pressure)      mode 3: scattered 4-byte stores instead
