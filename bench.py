@@ -425,7 +425,7 @@ class Pipeline:
             off = (k * 37 if self.streaming else k * B) % n
             for r in range(1, self.world):
                 for fi in sorted({0, B - 1}):
-                    data = _make_stream((1000 + 1000 * r + (off + fi) % n, self.args.width, self.args.height, self.args.epf, 0.0))
+                    data = _make_stream((1000 + 1000 * r + (off + fi) % n, self.args.width, self.args.height, self.args.epf, 0.0, 0))
                     got = self.gathered[r][(k % self.inner) * B + fi].cpu().numpy().reshape(-1)
                     ok = ok and bool(np.array_equal(got, O.decode(data).pixels("u8", 3)))
                     checked.append(f"rank{r}:{k}:{fi}")

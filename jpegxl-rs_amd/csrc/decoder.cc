@@ -1275,6 +1275,7 @@ void Batch::Prepare(void* stream_v) {
     vec<uint64_t> cost;
     vec<uint8_t> luts;
     std::map<std::string, uint32_t> lut_of;       // table content -> offset in the blob (frames of one encoder share most tables)
+    bool general_streams = false;                 // some eligible stream needs the instantiation with two-property tables / the rarer properties and predictors
     bool wp_streams = false;                      // some eligible stream keeps weighted-predictor state: the batch takes that instantiation of the kernel
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
@@ -1311,6 +1312,8 @@ void Batch::Prepare(void* stream_v) {
             st.chan[c].info = kLfSimtRows | (cl.uses_wp ? kLfSimtWpLive : 0u);
           }
           if (cl.uses_wp) wp_streams = true;
+          for (const LfRowClass& rc : cl.rows)      // beyond what the lean instantiation handles: one cluster per row or a table over W + N - NW; zero / W / clamped gradient
+            if (rc.kind == 2 || (rc.kind == 1 && rc.sel_a != 0) || !(rc.pred == 0 || rc.pred == 1 || rc.pred == 3)) general_streams = true;
         }
         if (ok) mine.push_back(st);
       }
@@ -1349,7 +1352,8 @@ void Batch::Prepare(void* stream_v) {
       simt_luts_off = arena.Put(luts.data(), luts.size());
       lf_simt_.num_lanes = (uint32_t)lanes.size();
       lf_simt_.lanes_per_wave = (uint32_t)std::max(1, 64 / std::max(1, cfg.lane_stride_lf));
-      lf_simt_.any_legacy = 0; lf_simt_.any_wp = wp_streams ? 1 : 0;
+      lf_simt_.any_legacy = 0; lf_simt_.any_wp = wp_streams ? 1 : 0; lf_simt_.any_general = general_streams || wp_streams ? 1 : 0;
+
       for (int i = 0; i < n; i++) if (!images_[i]->plan.modular && !simt_frame[i]) lf_simt_.any_legacy = 1;
     }
   }

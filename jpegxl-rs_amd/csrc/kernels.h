@@ -156,7 +156,9 @@ void InitDeviceTables(void* stream);
 // (decoder.cc ClassifyLfChannel): after the static splits (channel index, stream id) and per class of rows (splits on the row, property 2)
 // the subtree may test at most two of {W + N - NW (9), W (7), N (6), largest weighted-predictor error (15)} and its leaves share one
 // predictor with offset 0, multiplier 1.  A row class is an 8-byte entry {table offset, class word}; its table — 1024 bytes either way —
-// maps the clamped property value(s) to the cluster and is read through the L2 like the alias tables: nothing about a stream lives in LDS.
+// maps the clamped property value(s) to the cluster and is read through the L2 like the alias tables: nothing about a stream lives in LDS
+// (measured in round 4: even 2 KB of LDS per LF workgroup — resident for hundreds of milliseconds on every CU — fragments the LDS the 80 KB
+// HF workgroups need: HF stage 56 -> 71 ms, with the tables in LDS too 80 ms, although the LF stage itself got 12 % shorter).
 // Class word: bits 0-1 kind (0: one cluster, bits 16-23; 1: table over property A, value in [-512, 511]; 2: table over A x B, values in
 // [-16, 15]); bits 2-4 predictor (0 zero, 1 W, 2 N, 3 clamped gradient, 4 weighted, 5 (W + N) / 2, 6 select, 7 NE); bits 5-6 / 7-8
 // property A / B (0: W + N - NW, 1: W, 2: N, 3: weighted-predictor error); bit 10: the channel keeps weighted-predictor state.
@@ -173,6 +175,7 @@ struct LfSimtPlan {
   const uint2* units = nullptr; uint32_t num_units = 0;     // varblock placement: {frame, LF group | band << 16} of every 32-row band of every VarDCT frame, longest first
   uint32_t num_lanes = 0, lanes_per_wave = 16;
   int any_legacy = 1;          // some VarDCT frame of the batch still takes LfDecodeKernel (one wavefront per stream)
+  int any_general = 0;         // some SIMT stream needs more than the lean instantiation offers (kernels.hip LfDecodeSimtKernel<WP, GEN>)
   int any_wp = 0;              // some SIMT stream keeps weighted-predictor state (the kernel's WP instantiation; LfDecodeKernel follows for the streams it hands back)
 };
 

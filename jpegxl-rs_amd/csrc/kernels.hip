@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(256) void LfPlaceExpandKernel(const FrameDev* __res
 // Small launches (single images) take one group per wavefront instead: latency over LDS economy.
 // CAPPED: at most 170 VGPRs (with spills) so that pixel-kernel wavefronts of the batch on the main stream fit the same SIMDs — the
 // variant for large pipelined batches; single images take the uncapped one (267 VGPRs, LF stage 20 % shorter).
-template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? JXL_LF_MINW : 1) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes, int take_simt_frames) {
+template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? JXL_LF_MINW : 1) void LfDecodeKernel(const FrameDev* __restrict__ frames, uint32_t groups_per_block, uint32_t tree_cap, uint32_t lds_bytes, int take_simt_frames, uint32_t wp_base) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || (f.lf_simt && !take_simt_frames)) return;
   const uint32_t first = blockIdx.x * groups_per_block;
@@ -1542,6 +1542,7 @@ template <bool CAPPED> __global__ __launch_bounds__(64 * kLfDecWaves, CAPPED ? J
   }
   ModTables T;
   StageModular(f.tree, f.tree_nodes, f.mod_code, T, tree_cap, lds_bytes);
+  if (wp_base) T.wp_off = wp_base + (threadIdx.x >> 6) * kWpLdsBytes;      // weighted-predictor rows of this wavefront's stream (batches with such trees)
   __shared__ int s_fail_w[kLfDecWaves];
   __shared__ GroupHeaderD s_gh_w[kLfDecWaves];
   __shared__ uint32_t s_u_w[kLfDecWaves][4];
@@ -1628,12 +1629,15 @@ struct WpLane {
   int32_t pr[4], avg;                       // this sample's sub-predictions and their weighted average (x 8)
 };
 
-// One LF-group stream per lane, `lanes_per_wave` lanes per wavefront.  WP: the instantiation whose lanes may keep weighted-predictor state
-// (any channel class with kLfSimtWpLive); the plain one costs 64 VGPRs and no LDS, this one a 256-byte division table and ~40 VGPRs more.
-template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
-                                                          const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority) {
-  __shared__ uint32_t s_div[WP ? 64 : 1];   // (1 << 24) / (i + 1): context_predict.h kDivLookup
-  if (WP) { if (threadIdx.x < 64) s_div[threadIdx.x] = (1u << 24) / (threadIdx.x + 1); __syncthreads(); }
+// One LF-group stream per lane, `lanes_per_wave` lanes per wavefront.  Instantiations: <false, false> the lean one — a context per row or a table
+// over W + N - NW, predictors zero / W / clamped gradient (the gradient trees of `cjxl --faster_decoding`, the synthesiser's default): 64 VGPRs;
+// <false, true> adds tables over W / N and pairs of properties and the rarer predictors; <true, true> weighted-predictor state on top (any channel
+// class with kLfSimtWpLive): a 256-byte division table and ~50 VGPRs more.
+// No LDS in any of them (kernels.h: LF workgroups stay for hundreds of milliseconds and would fragment what the HF workgroups need): the
+// weighted predictor's 64-entry division table is read from global memory (g_wp_div: it stays in the vector L1, and its reads hang off
+// the prediction, which only meets the entropy chain when the token is there).
+template <bool WP, bool GEN> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
+                                                          const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority, const uint32_t* __restrict__ s_div) {
   const uint32_t li = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * lanes_per_wave + (threadIdx.x & 63);
   if ((threadIdx.x & 63) >= lanes_per_wave || li >= num_lanes) return;
   if (high_priority & 1) __builtin_amdgcn_s_setprio(3);
@@ -1647,7 +1651,7 @@ template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSi
   uint32_t x = 0, w = 0, y = 0, h = 0;
   int32_t stride = 0;
   int32_t left = 0, nw = 0, up0 = 0, up1 = 0, up2 = 0;
-  const uint8_t* lut = luts;
+  uint32_t lut_off = 0;                   // table of the current row's class (byte offset in the blob)
   const uint64_t* alias = nullptr;
   const uint32_t* cfgp = nullptr;
   uint32_t cfgu = 0, la = 0, cls = 0, const_cluster = 0;     // cls: class word of the current row (kernels.h)
@@ -1745,7 +1749,7 @@ template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSi
           const uint32_t k = LdG(luts + e.x + min(y, 511u));
           e = LdG(reinterpret_cast<const uint2*>(luts + e.x + 512 + 8 * k));
         }
-        lut = luts + e.x; cls = e.y; const_cluster = e.y >> 16;
+        lut_off = e.x; cls = e.y; const_cluster = (e.y >> 16) & 0xFF;
       }
       if (hp && w < 4) {                 // narrow rows: the rolling prefetch could run ahead of the stores
         up0 = LdG(out - stride); up1 = w > 1 ? LdG(out - stride + 1) : 0; up2 = w > 2 ? LdG(out - stride + 2) : 0;
@@ -1792,7 +1796,7 @@ template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSi
     const int32_t grad = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
     const bool wp_live = WP && (cls & kLfSimtWpLive);
     const bool last_col = x + 1 >= w;
-    const int32_t NE = (hp && !last_col) ? up1 : N;
+    const int32_t NE = GEN ? ((hp && !last_col) ? up1 : N) : 0;
     int32_t wp_err = 0, teNE = 0;
     uint32_t aNE[4] = {0, 0, 0, 0};
     if (wp_live) {
@@ -1812,20 +1816,27 @@ template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSi
     const uint32_t kind = cls & 3, pcode = (cls >> 2) & 7;
     uint32_t cluster = const_cluster;
     if (kind) {
-      const uint32_t sa = (cls >> 5) & 3, sb = (cls >> 7) & 3;
-      const int32_t va = sa == 0 ? grad : sa == 1 ? W : sa == 2 ? N : wp_err;
-      const int32_t vb = sb == 0 ? grad : sb == 1 ? W : sb == 2 ? N : wp_err;
-      const uint32_t i1 = (uint32_t)(min(max(va, -512), 511) + 512);
-      const uint32_t i2 = ((uint32_t)(min(max(va, -16), 15) + 16) << 5) | (uint32_t)(min(max(vb, -16), 15) + 16);
-      cluster = LdG(lut + (kind == 1 ? i1 : i2));
+      uint32_t idx = (uint32_t)(min(max(grad, -512), 511) + 512);
+      if (GEN) {
+        const uint32_t sa = (cls >> 5) & 3, sb = (cls >> 7) & 3;
+        const int32_t va = sa == 0 ? grad : sa == 1 ? W : sa == 2 ? N : wp_err;
+        const int32_t vb = sb == 0 ? grad : sb == 1 ? W : sb == 2 ? N : wp_err;
+        const uint32_t i1 = (uint32_t)(min(max(va, -512), 511) + 512);
+        const uint32_t i2 = ((uint32_t)(min(max(va, -16), 15) + 16) << 5) | (uint32_t)(min(max(vb, -16), 15) + 16);
+        idx = kind == 1 ? i1 : i2;
+      }
+      cluster = LdG(luts + lut_off + idx);
     }
     const int32_t mn = min(N, W), mx = max(N, W);
     const int32_t g5 = NW < mn ? mx : (NW > mx ? mn : grad);
-    int32_t guess = pcode == 0 ? 0 : (pcode == 1 ? W : (pcode == 2 ? N : g5));
-    if (__builtin_expect(pcode >= 5, 0)) {
-      if (pcode == 5) guess = (int32_t)(((int64_t)W + N) / 2);
-      else if (pcode == 6) { const int64_t pp = (int64_t)W + N - NW; guess = Abs64(pp - W) < Abs64(pp - N) ? W : N; }
-      else guess = NE;
+    int32_t guess = pcode == 0 ? 0 : (pcode == 1 ? W : g5);
+    if (GEN) {
+      if (pcode == 2) guess = N;
+      if (__builtin_expect(pcode >= 5, 0)) {
+        if (pcode == 5) guess = (int32_t)(((int64_t)W + N) / 2);
+        else if (pcode == 6) { const int64_t pp = (int64_t)W + N - NW; guess = Abs64(pp - W) < Abs64(pp - N) ? W : N; }
+        else guess = NE;
+      }
     }
     if (wp_live) {
       // sub-predictor weights from the error magnitudes around the sample
@@ -1834,7 +1845,7 @@ template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSi
       for (int i = 0; i < 4; i++) {
         const uint32_t e = wp.aN[i] + aNE[i] + wp.aNW[i];
         const int shift = max(0, 26 - (int)__clz((int)(e + 1)));
-        wt[i] = 4 + (((i == 0 ? 13u : 12u) * s_div[e >> shift]) >> shift);
+        wt[i] = 4 + (((i == 0 ? 13u : 12u) * LdG(s_div + (e >> shift))) >> shift);
       }
       const int32_t N8 = N << 3, W8 = W << 3, NE8 = NE << 3;
       const int32_t sumWN = wp.teN + wp.teW;
@@ -1850,7 +1861,7 @@ template <bool WP> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSi
       int32_t acc = (int32_t)(total >> 1) - 1;
 #pragma unroll
       for (int i = 0; i < 4; i++) acc += wp.pr[i] * (int32_t)wt[i];
-      int32_t avg = (int32_t)(((int64_t)acc * (int64_t)s_div[total - 1]) >> 24);
+      int32_t avg = (int32_t)(((int64_t)acc * (int64_t)LdG(s_div + (total - 1))) >> 24);
       if (((wp.teN ^ wp.teW) | (wp.teN ^ wp.teNW)) <= 0) avg = max(min(W8, min(NE8, N8)), min(max(W8, max(NE8, N8)), avg));
       wp.avg = avg;
       if (pcode == 4) guess = (avg + 3) >> 3;
@@ -4280,6 +4291,22 @@ static uint32_t* HfSyncWords(int* dev_out) {
   }
   return g_hf_sync[dev];
 }
+// (1 << 24) / (i + 1), i < 64 (context_predict.h kDivLookup), in device memory: the SIMT LF kernel's weighted-predictor lanes read it through the vector L1
+static const uint32_t* WpDivTable() {
+  static std::mutex mu;
+  static uint32_t* table[64] = {nullptr};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!table[dev]) {
+    uint32_t host[64];
+    for (uint32_t i = 0; i < 64; i++) host[i] = (1u << 24) / (i + 1);
+    if (hipMalloc((void**)&table[dev], sizeof(host)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(table[dev], host, sizeof(host), hipMemcpyHostToDevice);
+  }
+  return table[dev];
+}
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream, const LfSimtPlan* simt) {
   static const bool time_it = getenv("JXL_HIP_TIME_LF") != nullptr;     // experiments: blocking per-kernel times on stderr
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -4308,15 +4335,21 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     static const int wpb_env = getenv("JXL_HIP_LF_WAVES_PER_WG") ? atoi(getenv("JXL_HIP_LF_WAVES_PER_WG")) : 1;
     const int nwaves = DivUp((int)simt->num_lanes, (int)lpw), wpb = std::max(1, std::min(4, wpb_env));
     const int lf_flags = lf_prio | (cfg.lf_wp_narrow_test ? 8 : 0);
-    if (simt->any_wp) hipLaunchKernelGGL(LfDecodeSimtKernel<true>, dim3(DivUp(nwaves, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags);
-    else hipLaunchKernelGGL(LfDecodeSimtKernel<false>, dim3(DivUp(nwaves, wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags);
+    const dim3 grid(DivUp(nwaves, wpb)), block(64 * wpb);
+    const uint32_t* wp_div = WpDivTable();
+    if (simt->any_wp) hipLaunchKernelGGL((LfDecodeSimtKernel<true, true>), grid, block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags, wp_div);
+    else if (simt->any_general) hipLaunchKernelGGL((LfDecodeSimtKernel<false, true>), grid, block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags, wp_div);
+    else hipLaunchKernelGGL((LfDecodeSimtKernel<false, false>), grid, block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags, wp_div);
     if (!simt->any_legacy && !simt->any_wp) { place(); return; }
     simt_mode = simt->any_wp ? 2 : 0;         // the weighted-predictor lanes may hand streams back: LfDecodeKernel follows for those (and for the legacy frames)
   }
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
   const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
-  const uint32_t lds_bytes = kLfDecWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  const uint32_t lds_tables = kLfDecWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  // trees with the weighted predictor: its state rows (channels up to 256 wide — all but the block-info rows) in LDS, one slot per wavefront
+  const uint32_t wp_base = cfg.any_wp ? (lds_tables + 15) & ~15u : 0u;
+  const uint32_t lds_bytes = wp_base ? wp_base + kLfDecWaves * kWpLdsBytes : lds_tables;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)LfDecodeKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
@@ -4333,9 +4366,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
       hipLaunchKernelGGL(HeadStartKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sync, g_hf_enqueued[dev] + 1, (uint64_t)200000);   // the next HF launch, or 2 ms
   }
   if (big) {
-    hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, simt_mode);
+    hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_tables, simt_mode, wp_base);
   } else {
-    hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_bytes, simt_mode);
+    hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_tables, simt_mode, wp_base);
   }
   place();
 }
