@@ -233,6 +233,7 @@ class Pipeline:
     def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming):
         self.args, self.jx, self.torch, self.dist, self.streams = args, jx, torch, dist, streams
         self.dev, self.local_rank, self.rank, self.world, self.B, self.inner, self.streaming = dev, local_rank, rank, world, B, inner, streaming
+        self.stream_texture, self.stream_tree_shape = args.main_texture, args.main_tree_shape    # how `streams` were made (verify() regenerates other ranks' frames)
         W, H = args.width, args.height
         self.frame_bytes = W * H * 3
         self.pipeline = not args.no_pipeline
@@ -425,7 +426,7 @@ class Pipeline:
             off = (k * 37 if self.streaming else k * B) % n
             for r in range(1, self.world):
                 for fi in sorted({0, B - 1}):
-                    data = _make_stream((1000 + 1000 * r + (off + fi) % n, self.args.width, self.args.height, self.args.epf, 0.0, 0))
+                    data = _make_stream((1000 + 1000 * r + (off + fi) % n, self.args.width, self.args.height, self.args.epf, self.stream_texture, self.stream_tree_shape))
                     got = self.gathered[r][(k % self.inner) * B + fi].cpu().numpy().reshape(-1)
                     ok = ok and bool(np.array_equal(got, O.decode(data).pixels("u8", 3)))
                     checked.append(f"rank{r}:{k}:{fi}")
@@ -475,6 +476,8 @@ def main():
     ap.add_argument("--no-realistic", action="store_true", help="skip the second workload (textured frames, ~2 bpp)")
     ap.add_argument("--cjxl-distinct", type=int, default=32, help="distinct frames of the cjxl-shaped workload (textured frames whose LF-group streams use the MA-tree shape of a default-effort "
                     "cjxl encode: weighted predictor); 0: skip it")
+    ap.add_argument("--main-tree-shape", type=int, default=0, help="experiments: LF tree shape of the headline workload's frames (1: the cjxl default-effort shape)")
+    ap.add_argument("--main-texture", type=float, default=0.0, help="experiments: texture strength of the headline workload's frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -488,7 +491,7 @@ def main():
         args.realistic_distinct = min(args.realistic_distinct, 16)
         os.environ.setdefault("JXL_BENCH_SYNTH_WORKERS", str(max(1, (os.cpu_count() or 1) // int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))))
 
-    streams = make_streams(args.distinct, W, H, args.epf, seed0=1000 + 1000 * rank)
+    streams = make_streams(args.distinct, W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.main_texture, tree_shape=args.main_tree_shape)
     # the same frames with photograph-like texture: ~2 bpp at distance 1 instead of 0.8 (second workload of the line, fewer distinct frames)
     realistic_streams = make_streams(min(args.distinct, args.realistic_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture) if args.texture > 0 and not args.no_realistic else None
     cjxl_streams = make_streams(min(args.distinct, args.cjxl_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture, tree_shape=1) if args.cjxl_distinct > 0 and not args.no_realistic else None
@@ -525,9 +528,10 @@ def main():
         B = min(args.batch, per_rank)
         inner = max(1, per_rank // B)
 
-    def measure(streaming, streams=streams):
+    def measure(streaming, streams=streams, texture=args.main_texture, tree_shape=args.main_tree_shape):
         """one mode: W untimed warm-up steps, then exactly K timed steps from an empty pipeline, bracketed by barrier + synchronize"""
         p = Pipeline(args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming)
+        p.stream_texture, p.stream_tree_shape = texture, tree_shape
         p.run(args.warmup * inner, False)
         for bt in p.batches:
             bt.finish(p.stream)
@@ -563,8 +567,8 @@ def main():
     head = res[modes[0]]
     realistic = None
     if args.texture > 0 and not args.no_realistic and realistic_streams:
-        realistic = measure(modes[0] == "streaming", realistic_streams)
-    cjxl = measure(modes[0] == "streaming", cjxl_streams) if cjxl_streams else None
+        realistic = measure(modes[0] == "streaming", realistic_streams, args.texture, 0)
+    cjxl = measure(modes[0] == "streaming", cjxl_streams, args.texture, 1) if cjxl_streams else None
     if rank == 0:
         total_px = world * B * inner * W * H * args.steps
         rate = lambda r: total_px / r["elapsed"] / 1e6
