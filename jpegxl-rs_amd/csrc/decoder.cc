@@ -664,6 +664,7 @@ size_t Batch::DebugRead(int i, const std::string& name, int c, void* dst, size_t
   if (name == "plane_a") { src = f.plane_a[c]; bytes = npx * 4; }
   else if (name == "plane_b") { src = f.plane_b[c]; bytes = npx * 4; }
   else if (name == "lf") { src = f.lf[c]; bytes = nb * 4; }
+  else if (name == "lf_smooth") { src = f.lf_tmp[c]; bytes = nb * 4; }     // the LF samples after the adaptive smoothing
   else if (name == "llf") { src = f.llf[c]; bytes = nb * 4; }
   else if (name == "lfq") { src = f.lfq[c]; bytes = nb * 4; }
   else if (name == "inv_sigma") { src = f.inv_sigma; bytes = nb * 4; }
@@ -671,6 +672,7 @@ size_t Batch::DebugRead(int i, const std::string& name, int c, void* dst, size_t
   else if (name == "coef_off") { src = f.coef_off; bytes = nb * 4; }
   else if (name == "coeff") { src = f.coeff[c]; bytes = (size_t)p.num_groups * 65536 * 4; }
   else if (name == "qtable") { throw ParseError("DebugRead: qtable takes kind * 3 + channel", false); }
+  else if (name == "up_weights") { src = f.up_weights; bytes = p.upsampling == 2 ? 60 : p.upsampling == 4 ? 220 : p.upsampling == 8 ? 840 : 0; }   // the 15 / 55 / 210 stored upsampling weights in use
   else if (name == "ytox") { src = f.ytox; bytes = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8); }
   else if (name == "ytob") { src = f.ytob; bytes = (size_t)((p.bw + 7) / 8) * ((p.bh + 7) / 8); }
   else throw ParseError("DebugRead: unknown buffer " + name, false);

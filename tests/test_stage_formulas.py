@@ -5,6 +5,9 @@ field and the sharpness map, weights 1 + SAD * inv_sigma * scale clamped at 0, p
 transform (stage_xyb.cc: subtract cbrt(bias), cube, add bias, 3x3 matrix) and the sRGB transfer function (stage_from_linear.cc against the
 IEC 61966-2-1 formula).  The planes between the stages come off the device through JxlHipBatchSetOption("debug_stop_after") +
 JxlHipBatchDebugRead (include/jxl_hip.h); inputs of a stage are what the stage before left, so each test isolates one stage.
+Round 4 adds: the six 8x8 transforms that are not a plain DCT (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3: dec_transforms-inl.h), the
+DCT128 / 256 family against scipy's idctn, the lowest frequencies of multi-block transforms from the LF samples (the standard's product-of-
+cosines scale), the adaptive LF smoothing (compressed_dc.cc) and the 2x / 4x / 8x upsampling from the stored weights (stage_upsampling.cc).
 Tolerances: a few float32 ULPs of the magnitude of the values that enter a sum (stated per test)."""
 import numpy as np
 import pytest
@@ -160,14 +163,17 @@ def test_inverse_opsin_and_transfer_function(jx, tf):
 PLAIN = {0: (1, 1, 0), 4: (2, 2, 4), 5: (4, 4, 5), 6: (1, 2, 6), 7: (2, 1, 6), 8: (1, 4, 7), 9: (4, 1, 7), 10: (2, 4, 8), 11: (4, 2, 8), 18: (8, 8, 11), 19: (4, 8, 12), 20: (8, 4, 12)}
 
 
-@pytest.mark.parametrize("w,h,mix,seed", [(256, 192, 0, 11), (512, 384, 1, 12), (520, 300, 2, 13)])
-def test_dequantisation_cfl_and_idct_follow_their_definition(jx, w, h, mix, seed):
-    """dec_group.cc / quantizer.h / dct-inl.h restated: coefficient = AdjustQuantBias(q) x table[k] x (65536 / global_scale) / hf_mul (x 0.8^(qm_scale - 2)
-    for X, B), X and B plus (base + map / colour_factor) x Y, the lowest frequencies replaced by the LLF values, then the separable inverse DCT in
-    libjxl's normalisation (coefficient 0 = block mean: scipy's orthonormal idctn of coefficients x sqrt(rows x cols)).  Inputs off the device:
-    quantised coefficients, block info, LLF planes, tables, CfL maps; output: the planes after the IDCT stage."""
-    from scipy.fft import idctn
-    data = S.encode_vardct(S.synthetic_image(seed, w, h), seed=seed, strategy_mix=mix, epf_iters=0, gab=0)
+COVERED = {0: (1, 1), 1: (1, 1), 2: (1, 1), 3: (1, 1), 4: (2, 2), 5: (4, 4), 6: (1, 2), 7: (2, 1), 8: (1, 4), 9: (4, 1), 10: (2, 4), 11: (4, 2), 12: (1, 1), 13: (1, 1),
+           14: (1, 1), 15: (1, 1), 16: (1, 1), 17: (1, 1), 18: (8, 8), 19: (4, 8), 20: (8, 4), 21: (16, 16), 22: (8, 16), 23: (16, 8), 24: (32, 32), 25: (16, 32), 26: (32, 16)}
+QUANT_KIND = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 6, 7: 6, 8: 7, 9: 7, 10: 8, 11: 8, 12: 9, 13: 9, 14: 10, 15: 10, 16: 10, 17: 10, 18: 11, 19: 12, 20: 12,
+              21: 13, 22: 14, 23: 14, 24: 15, 25: 16, 26: 16}
+
+
+def dequantised_varblocks(jx, data, h, w):
+    """Decodes `data` up to the IDCT stage and yields, per varblock that starts inside the image: (strategy, by, bx, [three flat float64 arrays of
+    dequantised coefficients in STORAGE order, chroma from luma applied]), after the IDCT planes `got` and the batch.  Dequantisation as in
+    dec_group.cc / quantizer.h: AdjustQuantBias(q) x table[k] x (65536 / global_scale) / hf_mul (x 0.8^(qm_scale - 2) for X, B), X and B plus
+    (base + map / colour_factor) x Y.  Inputs off the device: quantised coefficients, block info, tables, CfL maps."""
     got, b = planes_after(jx, data, 1, 0, 0)
     bw, bh, xgroups = b.info_value("frame0_bw"), b.info_value("frame0_bh"), b.info_value("frame0_xgroups")
     info = b.debug_read(0, "blk_info", dtype=np.uint32).reshape(bh, bw)
@@ -175,7 +181,6 @@ def test_dequantisation_cfl_and_idct_follow_their_definition(jx, w, h, mix, seed
     # (the IDCT zeroes the coefficient planes it consumes: decode up to the HF stage again to read them)
     b.decode_part(1); b.decode_part(3); b.finish()
     coeff = [b.debug_read(0, "coeff", c, dtype=np.int32).astype(np.float64) for c in range(3)]
-    llf = [b.debug_read(0, "llf", c).reshape(bh, bw).astype(np.float64) for c in range(3)]
     cw = (bw + 7) // 8
     ytox = b.debug_read(0, "ytox", dtype=np.int8).astype(np.float64)
     ytob = b.debug_read(0, "ytob", dtype=np.int8).astype(np.float64)
@@ -184,43 +189,401 @@ def test_dequantisation_cfl_and_idct_follow_their_definition(jx, w, h, mix, seed
     dm = [0.8 ** (b.info_value("frame0_x_qm_scale") - 2.0), 1.0, 0.8 ** (b.info_value("frame0_b_qm_scale") - 2.0)]
     bias = [1.0 - 0.05465007330715401, 1.0 - 0.07005449891748593, 1.0 - 0.049935103337343655, 0.145]
     tables = {}
+
+    def blocks():
+        for by in range(bh):
+            for bx in range(bw):
+                word = int(info[by, bx])
+                if not (word >> 5) & 1 or by * 8 >= h or bx * 8 >= w:
+                    continue                                     # not the first block of its varblock / outside the image
+                s = word & 31
+                cx, cy = COVERED[s]
+                kind = QUANT_KIND[s]
+                n = 64 * cx * cy
+                hf_mul = ((word >> 8) & 0xFF) + 1
+                g = (by // 32) * xgroups + bx // 32
+                base = g * 65536 + int(coef_off[by, bx])
+                tile = (by // 8) * cw + bx // 8
+                k_cfl = [0.0 + ytox[tile] * colour_scale, 0.0, 1.0 + ytob[tile] * colour_scale]
+                deq = []
+                for c in range(3):
+                    if (kind, c) not in tables:
+                        tables[(kind, c)] = b.debug_read(0, "qtable", kind * 3 + c).astype(np.float64)
+                    q = coeff[c][base:base + n]
+                    safe = np.where(q == 0, 1.0, q)
+                    adj = np.where(q == 0, 0.0, np.where(np.abs(q) == 1, np.sign(q) * bias[c], q - bias[3] / safe))
+                    deq.append(adj * tables[(kind, c)][:n] * (inv_global_scale / hf_mul * dm[c]))
+                yield s, by, bx, [deq[0] + k_cfl[0] * deq[1], deq[1], deq[2] + k_cfl[2] * deq[1]]
+    return got, b, blocks()
+
+
+def semantic(stored, R, C):
+    """(R, C) array indexed (vertical, horizontal frequency) from the storage order: transposed for transforms at least as tall as wide"""
+    return stored.reshape(C, R).T if R >= C else stored.reshape(R, C)
+
+
+def idct_libjxl(sem):
+    """inverse DCT in libjxl's normalisation (coefficient (0, 0) = the mean of the block)"""
+    from scipy.fft import idctn
+    return idctn(sem * np.sqrt(sem.shape[0] * sem.shape[1]), norm="ortho")
+
+
+@pytest.mark.parametrize("w,h,mix,seed", [(256, 192, 0, 11), (512, 384, 1, 12), (520, 300, 2, 13)])
+def test_dequantisation_cfl_and_idct_follow_their_definition(jx, w, h, mix, seed):
+    """the lowest frequencies replaced by the LLF values, then the separable inverse DCT in libjxl's normalisation (coefficient 0 = block mean:
+    scipy's orthonormal idctn of coefficients x sqrt(rows x cols)); output: the planes after the IDCT stage."""
+    data = S.encode_vardct(S.synthetic_image(seed, w, h), seed=seed, strategy_mix=mix, epf_iters=0, gab=0)
+    got, b, blocks = dequantised_varblocks(jx, data, h, w)
+    bw, bh = b.info_value("frame0_bw"), b.info_value("frame0_bh")
+    llf = [b.debug_read(0, "llf", c).reshape(bh, bw).astype(np.float64) for c in range(3)]
     checked = worst = 0
     scale = max(1e-3, float(np.abs(got).max()))
+    for s, by, bx, deq in blocks:
+        if s not in PLAIN:
+            continue
+        cx, cy, _ = PLAIN[s]
+        R, Cc = cy * 8, cx * 8
+        for c in range(3):
+            sem = semantic(deq[c], R, Cc).copy()
+            sem[:cy, :cx] = llf[c][by:by + cy, bx:bx + cx]
+            want = idct_libjxl(sem)
+            y0, x0 = by * 8, bx * 8
+            hh, ww = min(R, h - y0), min(Cc, w - x0)
+            worst = max(worst, float(np.abs(got[c][y0:y0 + hh, x0:x0 + ww] - want[:hh, :ww]).max()))
+        checked += 1
+    assert checked > (bw * bh) // 40, checked
+    # up to 64 x 64 terms summed in float32 against float64: a few 1e-6 of the largest values in play
+    assert worst <= 2e-5 * scale, (worst, scale)
+
+
+# ---- the 8x8 transforms that are not a plain DCT (dec_transforms-inl.h TransformToPixels) ----------------------------------------------
+def hadamard4(a, b, c, d):
+    return a + b + c + d, a + b - c - d, a - b + c - d, a - b - c + d
+
+
+def inverse_identity(c):
+    """IDENTITY: four 4x4 quadrants, each a constant (its 'DC' from a 2x2 Hadamard of the four lowest coefficients, minus the mean of its residuals)
+    plus per-pixel residuals; the residual of pixel (1, 1) is implied, its slot carries pixel (0, 0)'s"""
+    out = np.zeros((8, 8))
+    dcs = hadamard4(c[0, 0], c[0, 1], c[1, 0], c[1, 1])
+    for y in range(2):
+        for x in range(2):
+            sub = c[y::2, x::2].copy()                     # sub[iy, ix] = c[y + 2 iy, x + 2 ix]
+            anchor = dcs[2 * y + x] - (sub.sum() - sub[0, 0]) / 16.0
+            blk = sub + anchor
+            blk[0, 0] = sub[1, 1] + anchor
+            blk[1, 1] = anchor
+            out[4 * y:4 * y + 4, 4 * x:4 * x + 4] = blk
+    return out
+
+
+def inverse_dct2x2(c):
+    """DCT2X2: three rounds of 2x2 Hadamard butterflies, each doubling the resolved top-left square (2, 4, 8)"""
+    a = c.copy()
+    for S_ in (2, 4, 8):
+        n = S_ // 2
+        r00, r01, r10, r11 = hadamard4(a[:n, :n].copy(), a[:n, n:S_].copy(), a[n:S_, :n].copy(), a[n:S_, n:S_].copy())
+        a[0:S_:2, 0:S_:2], a[0:S_:2, 1:S_:2], a[1:S_:2, 0:S_:2], a[1:S_:2, 1:S_:2] = r00, r01, r10, r11
+    return a
+
+
+def inverse_dct4x4(c):
+    out = np.zeros((8, 8))
+    dcs = hadamard4(c[0, 0], c[0, 1], c[1, 0], c[1, 1])
+    for y in range(2):
+        for x in range(2):
+            sub = c[y::2, x::2].copy()
+            sub[0, 0] = dcs[2 * y + x]
+            out[4 * y:4 * y + 4, 4 * x:4 * x + 4] = idct_libjxl(sub.T)    # a square block is stored transposed
+    return out
+
+
+def inverse_dct4x8(c):
+    """two 4-row x 8-column halves, one above the other; their means are sum and difference of coefficients (0, 0) and (1, 0)"""
+    out = np.zeros((8, 8))
+    dcs = (c[0, 0] + c[1, 0], c[0, 0] - c[1, 0])
+    for y in range(2):
+        blk = c[y::2, :].copy()
+        blk[0, 0] = dcs[y]
+        out[4 * y:4 * y + 4, :] = idct_libjxl(blk)
+    return out
+
+
+def inverse_dct8x4(c):
+    out = np.zeros((8, 8))
+    dcs = (c[0, 0] + c[1, 0], c[0, 0] - c[1, 0])
+    for x in range(2):
+        blk = c[x::2, :].copy()
+        blk[0, 0] = dcs[x]
+        out[:, 4 * x:4 * x + 4] = idct_libjxl(blk.T)                       # 8 rows x 4 columns: stored transposed
+    return out
+
+
+# the 16 basis functions of the AFV corner transform (ISO/IEC 18181-1; a table of constants like the opsin matrix — what can be checked without
+# libjxl is checked below: orthonormal, first row constant, every row symmetric or antisymmetric under transposition of the 4x4 block)
+AFV_BASIS = np.array([
+    [0.25] * 16,
+    [0.876902929799142, 0.2206518106944235, -0.10140050393753763, -0.1014005039375375, 0.2206518106944236, -0.10140050393753777, -0.10140050393753772, -0.10140050393753763,
+     -0.10140050393753758, -0.10140050393753769, -0.1014005039375375, -0.10140050393753768, -0.10140050393753768, -0.10140050393753759, -0.10140050393753763, -0.10140050393753741],
+    [0.0, 0.0, 0.40670075830260755, 0.44444816619734445, 0.0, 0.0, 0.19574399372042936, 0.2929100136981264, -0.40670075830260716, -0.19574399372042872, 0.0, 0.11379074460448091,
+     -0.44444816619734384, -0.29291001369812636, -0.1137907446044814, 0.0],
+    [0.0, 0.0, -0.21255748058288748, 0.3085497062849767, 0.0, 0.4706702258572536, -0.1621205195722993, 0.0, -0.21255748058287047, -0.16212051957228327, -0.47067022585725277,
+     -0.1464291867126764, 0.3085497062849487, 0.0, -0.14642918671266536, 0.4251149611657548],
+    [0.0, -0.7071067811865474, 0.0, 0.0, 0.7071067811865476, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+    [-0.4105377591765233, 0.6235485373547691, -0.06435071657946274, -0.06435071657946266, 0.6235485373547694, -0.06435071657946284, -0.0643507165794628, -0.06435071657946274,
+     -0.06435071657946272, -0.06435071657946279, -0.06435071657946266, -0.06435071657946277, -0.06435071657946277, -0.06435071657946273, -0.06435071657946274, -0.0643507165794626],
+    [0.0, 0.0, -0.4517556589999482, 0.15854503551840063, 0.0, -0.04038515160822202, 0.0074182263792423875, 0.39351034269210167, -0.45175565899994635, 0.007418226379244351,
+     0.1107416575309343, 0.08298163094882051, 0.15854503551839705, 0.3935103426921022, 0.0829816309488214, -0.45175565899994796],
+    [0.0, 0.0, -0.304684750724869, 0.5112616136591823, 0.0, 0.0, -0.290480129728998, -0.06578701549142804, 0.304684750724884, 0.2904801297290076, 0.0, -0.23889773523344604,
+     -0.5112616136592012, 0.06578701549142545, 0.23889773523345467, 0.0],
+    [0.0, 0.0, 0.3017929516615495, 0.25792362796341184, 0.0, 0.16272340142866204, 0.09520022653475037, 0.0, 0.3017929516615503, 0.09520022653475055, -0.16272340142866173,
+     -0.35312385449816297, 0.25792362796341295, 0.0, -0.3531238544981624, -0.6035859033230976],
+    [0.0, 0.0, 0.40824829046386274, 0.0, 0.0, 0.0, 0.0, -0.4082482904638628, -0.4082482904638635, 0.0, 0.0, -0.40824829046386296, 0.0, 0.4082482904638634, 0.408248290463863, 0.0],
+    [0.0, 0.0, 0.1747866975480809, 0.0812611176717539, 0.0, 0.0, -0.3675398009862027, -0.307882213957909, -0.17478669754808135, 0.3675398009862011, 0.0, 0.4826689115059883,
+     -0.08126111767175039, 0.30788221395790305, -0.48266891150598584, 0.0],
+    [0.0, 0.0, -0.21105601049335784, 0.18567180916109802, 0.0, 0.0, 0.49215859013738733, -0.38525013709251915, 0.21105601049335806, -0.49215859013738905, 0.0, 0.17419412659916217,
+     -0.18567180916109904, 0.3852501370925211, -0.1741941265991621, 0.0],
+    [0.0, 0.0, -0.14266084808807264, -0.3416446842253372, 0.0, 0.7367497537172237, 0.24627107722075148, -0.08574019035519306, -0.14266084808807344, 0.24627107722075137,
+     0.14883399227113567, -0.04768680350229251, -0.3416446842253373, -0.08574019035519267, -0.047686803502292804, -0.14266084808807242],
+    [0.0, 0.0, -0.13813540350758585, 0.3302282550303788, 0.0, 0.08755115000587084, -0.07946706605909573, -0.4613374887461511, -0.13813540350758294, -0.07946706605910261,
+     0.49724647109535086, 0.12538059448563663, 0.3302282550303805, -0.4613374887461554, 0.12538059448564315, -0.13813540350758452],
+    [0.0, 0.0, -0.17437602599651067, 0.0702790691196284, 0.0, -0.2921026642334881, 0.3623817333531167, 0.0, -0.1743760259965108, 0.36238173335311646, 0.29210266423348785,
+     -0.4326608024727445, 0.07027906911962818, 0.0, -0.4326608024727457, 0.34875205199302267],
+    [0.0, 0.0, 0.11354987314994337, -0.07417504595810355, 0.0, 0.19402893032594343, -0.435190496523228, 0.21918684838857466, 0.11354987314994257, -0.4351904965232251,
+     0.5550443808910661, -0.25468277124066463, -0.07417504595810233, 0.2191868483885728, -0.25468277124066413, 0.1135498731499429]])
+
+
+def inverse_afv(c, kind):
+    """AFV0-3: a 4x4 corner (which one: kind & 1 = right, kind >> 1 = bottom) in the AFV basis, a 4x4 DCT beside it, a 4x8 DCT in the other half"""
+    right, bottom = kind & 1, kind >> 1
+    out = np.zeros((8, 8))
+    c00, c01, c10 = c[0, 0], c[0, 1], c[1, 0]
+    corner = c[0::2, 0::2].copy()
+    corner[0, 0] = (c00 + c10 + c01) * 4.0
+    px = (corner.reshape(16) @ AFV_BASIS).reshape(4, 4)
+    if bottom:
+        px = px[::-1, :]
+    if right:
+        px = px[:, ::-1]
+    out[4 * bottom:4 * bottom + 4, 4 * right:4 * right + 4] = px
+    beside = c[0::2, 1::2].copy()
+    beside[0, 0] = c00 + c10 - c01
+    x0 = 0 if right else 4
+    out[4 * bottom:4 * bottom + 4, x0:x0 + 4] = idct_libjxl(beside.T)
+    half = c[1::2, :].copy()
+    half[0, 0] = c00 - c10
+    y0 = 0 if bottom else 4
+    out[y0:y0 + 4, :] = idct_libjxl(half)
+    return out
+
+
+SPECIAL = {1: inverse_identity, 2: inverse_dct2x2, 3: inverse_dct4x4, 12: inverse_dct4x8, 13: inverse_dct8x4,
+           14: lambda c: inverse_afv(c, 0), 15: lambda c: inverse_afv(c, 1), 16: lambda c: inverse_afv(c, 2), 17: lambda c: inverse_afv(c, 3)}
+
+
+def test_afv_basis_is_an_orthonormal_basis_with_the_expected_symmetries():
+    assert np.abs(AFV_BASIS @ AFV_BASIS.T - np.eye(16)).max() < 1e-13
+    for row in AFV_BASIS:
+        m = row.reshape(4, 4)
+        assert np.allclose(m, m.T, atol=1e-13) or np.allclose(m, -m.T, atol=1e-13)
+
+
+@pytest.mark.parametrize("s", sorted(SPECIAL))
+def test_special_8x8_transforms_follow_their_definition(jx, s):
+    w, h = 136, 104
+    data = S.encode_vardct(S.synthetic_image(20 + s, w, h), seed=20 + s, strategy_mix=100 + s, epf_iters=0, gab=0)
+    got, b, blocks = dequantised_varblocks(jx, data, h, w)
+    bw, bh = b.info_value("frame0_bw"), b.info_value("frame0_bh")
+    llf = [b.debug_read(0, "llf", c).reshape(bh, bw).astype(np.float64) for c in range(3)]
+    checked = worst = 0
+    scale = max(1e-3, float(np.abs(got).max()))
+    for bs, by, bx, deq in blocks:
+        if bs != s:
+            continue
+        for c in range(3):
+            blk = deq[c].reshape(8, 8).copy()
+            blk[0, 0] = llf[c][by, bx]
+            want = SPECIAL[s](blk)
+            y0, x0 = by * 8, bx * 8
+            hh, ww = min(8, h - y0), min(8, w - x0)
+            worst = max(worst, float(np.abs(got[c][y0:y0 + hh, x0:x0 + ww] - want[:hh, :ww]).max()))
+        checked += 1
+    assert checked >= (bw * bh) // 2, checked
+    assert worst <= 2e-5 * scale, (s, worst, scale)
+
+
+# ---- lowest frequencies of a multi-block transform from its LF samples (dec_transforms-inl.h LowestFrequenciesFromDC) -------------------
+def llf_from_lf(block):
+    """ISO/IEC 18181-1: the cy x cx LF samples are transformed by a DCT of their own size and coefficient (v, u) is scaled by
+    prod_{i < 3} cos(v pi 2^i / (16 cy)) x the same in u — cos(a) cos(2a) cos(4a) = sin(8a) / (8 sin a), dct_scales.h DCTTotalResampleScale<N, 8N>.
+    (Were the LF samples plain 8x8 means of a band-limited block, the exact relation would DIVIDE by that factor: the format defines the LF image
+    through this mapping instead — enc_transforms-inl.h DCFromLowestFrequencies applies the reciprocals — so the product is the definition.)"""
+    from scipy.fft import dctn
+    cy, cx = block.shape
+    coeff = dctn(block, norm="ortho") / np.sqrt(cy * cx)
+
+    def scale(n):
+        k = np.arange(n)
+        a = k * np.pi / (16.0 * n)
+        return np.cos(a) * np.cos(2 * a) * np.cos(4 * a)
+    return coeff * scale(cy)[:, None] * scale(cx)[None, :]
+
+
+@pytest.mark.parametrize("w,h,mix,seed", [(520, 300, 2, 31), (384, 256, 1, 32)])
+def test_lowest_frequencies_from_the_lf_samples(jx, w, h, mix, seed):
+    data = S.encode_vardct(S.synthetic_image(seed, w, h), seed=seed, strategy_mix=mix, epf_iters=0, gab=0)
+    _, b = planes_after(jx, data, 1, 0, 0)
+    bw, bh = b.info_value("frame0_bw"), b.info_value("frame0_bh")
+    info = b.debug_read(0, "blk_info", dtype=np.uint32).reshape(bh, bw)
+    lf = [b.debug_read(0, "lf_smooth", c).reshape(bh, bw).astype(np.float64) for c in range(3)]
+    llf = [b.debug_read(0, "llf", c).reshape(bh, bw).astype(np.float64) for c in range(3)]
+    shapes, worst = set(), 0.0
+    scale = max(1e-3, max(float(np.abs(p).max()) for p in lf))
     for by in range(bh):
         for bx in range(bw):
             word = int(info[by, bx])
             if not (word >> 5) & 1:
-                continue                                     # not the first block of its varblock
-            s = word & 31
-            if s not in PLAIN or by * 8 >= h or bx * 8 >= w:
                 continue
-            cx, cy, kind = PLAIN[s]
-            R, Cc = cy * 8, cx * 8
-            hf_mul = ((word >> 8) & 0xFF) + 1
-            g = (by // 32) * xgroups + bx // 32
-            base = g * 65536 + int(coef_off[by, bx])
-            tile = (by // 8) * cw + bx // 8
-            k_cfl = [0.0 + ytox[tile] * colour_scale, 0.0, 1.0 + ytob[tile] * colour_scale]
-            # storage order of coefficient (v = vertical, u = horizontal frequency): transposed for blocks at least as tall as wide
-            vv, uu = np.mgrid[0:R, 0:Cc]
-            kidx = (uu * R + vv) if R >= Cc else (vv * Cc + uu)
-            deq = []
+            cx, cy = COVERED[word & 31]
+            if cx > 8 or cy > 8:
+                continue
+            shapes.add((cy, cx))
             for c in range(3):
-                if (kind, c) not in tables:
-                    tables[(kind, c)] = b.debug_read(0, "qtable", kind * 3 + c).astype(np.float64)
-                q = coeff[c][base + kidx]
-                safe = np.where(q == 0, 1.0, q)
-                adj = np.where(q == 0, 0.0, np.where(np.abs(q) == 1, np.sign(q) * bias[c], q - bias[3] / safe))
-                deq.append(adj * tables[(kind, c)][kidx] * (inv_global_scale / hf_mul * dm[c]))
-            sem = [deq[0] + k_cfl[0] * deq[1], deq[1], deq[2] + k_cfl[2] * deq[1]]
-            for c in range(3):
-                sem[c][:cy, :cx] = llf[c][by:by + cy, bx:bx + cx]
-                want = idctn(sem[c] * np.sqrt(R * Cc), norm="ortho")
-                y0, x0 = by * 8, bx * 8
-                hh, ww = min(R, h - y0), min(Cc, w - x0)
-                err = float(np.abs(got[c][y0:y0 + hh, x0:x0 + ww] - want[:hh, :ww]).max())
-                worst = max(worst, err)
-            checked += 1
-    assert checked > (bw * bh) // 40, checked
-    # up to 64 x 64 terms summed in float32 against float64: a few 1e-6 of the largest values in play
-    assert worst <= 2e-5 * scale, (worst, scale)
+                want = llf_from_lf(lf[c][by:by + cy, bx:bx + cx])
+                worst = max(worst, float(np.abs(llf[c][by:by + cy, bx:bx + cx] - want).max()))
+    assert len(shapes) >= 6, shapes
+    assert worst <= 16 * EPS * scale, (worst, scale)
+
+
+# ---- DCT128 / DCT256 family: LLF from the smoothed LF samples, then scipy's idctn ------------------------------------------------------
+@pytest.mark.parametrize("s,w,h", [(21, 300, 264), (22, 264, 136), (23, 136, 264), (24, 520, 264), (25, 264, 264), (26, 264, 264)])
+def test_dct128_256_family_follows_its_definition(jx, s, w, h):
+    data = S.encode_vardct(S.synthetic_image(40 + s, w, h), seed=40 + s, strategy_mix=100 + s, epf_iters=0, gab=0)
+    got, b, blocks = dequantised_varblocks(jx, data, h, w)
+    bw, bh = b.info_value("frame0_bw"), b.info_value("frame0_bh")
+    lf = [b.debug_read(0, "lf_smooth", c).reshape(bh, bw).astype(np.float64) for c in range(3)]
+    checked = worst = 0
+    scale = max(1e-3, float(np.abs(got).max()))
+    for bs, by, bx, deq in blocks:
+        if bs != s:
+            continue
+        cx, cy = COVERED[s]
+        R, Cc = cy * 8, cx * 8
+        for c in range(3):
+            sem = semantic(deq[c], R, Cc).copy()
+            sem[:cy, :cx] = llf_from_lf(lf[c][by:by + cy, bx:bx + cx])
+            want = idct_libjxl(sem)
+            y0, x0 = by * 8, bx * 8
+            hh, ww = min(R, h - y0), min(Cc, w - x0)
+            worst = max(worst, float(np.abs(got[c][y0:y0 + hh, x0:x0 + ww] - want[:hh, :ww]).max()))
+        checked += 1
+    assert checked >= 1, checked
+    # 256 x 256 terms in float32 butterflies against float64
+    assert worst <= 4e-5 * scale, (s, worst, scale)
+
+
+# ---- adaptive LF smoothing (compressed_dc.cc AdaptiveDCSmoothing) ------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,seed", [(520, 300, 51), (136, 104, 52), (16, 16, 53)])
+def test_adaptive_lf_smoothing_follows_its_definition(jx, w, h, seed):
+    """interior samples: s = w0 c + w1 (4-neighbours) + w2 (diagonals) with w1 = 0.20345139757231578, w2 = 0.0334829185968739, w0 = 1 - 4 (w1 + w2);
+    gap = max(0.5, max_c |c - s| / LF step of the channel); result c + (s - c) max(0, 3 - 4 gap); the border row / column is kept.
+    The LF step of channel c = default LF dequantisation weight (1 / 4096, 1 / 512, 1 / 256) x 65536 / (global_scale x quant_lf)."""
+    data = S.encode_vardct(S.synthetic_image(seed, w, h), seed=seed, strategy_mix=1, epf_iters=0, gab=0)
+    _, b = planes_after(jx, data, 1, 0, 0)
+    bw, bh = b.info_value("frame0_bw"), b.info_value("frame0_bh")
+    before = np.stack([b.debug_read(0, "lf", c).reshape(bh, bw).astype(np.float64) for c in range(3)])
+    after = np.stack([b.debug_read(0, "lf_smooth", c).reshape(bh, bw).astype(np.float64) for c in range(3)])
+    lfq = np.stack([b.debug_read(0, "lfq", c, dtype=np.int32).reshape(bh, bw).astype(np.float64) for c in range(3)])
+    step = np.array([1 / 4096.0, 1 / 512.0, 1 / 256.0]) * 65536.0 / (b.info_value("frame0_global_scale") * b.info_value("frame0_quant_lf"))
+    # LF dequantisation of the luma channel (no chroma-from-luma term there): sample = quantised value x step
+    assert np.abs(before[1] - lfq[1] * step[1]).max() <= 2 * EPS * np.abs(before[1]).max()
+    w1, w2 = 0.20345139757231578, 0.0334829185968739
+    w0 = 1.0 - 4.0 * (w1 + w2)
+    want = before.copy()
+    if bw > 2 and bh > 2:
+        c_ = before[:, 1:-1, 1:-1]
+        edge = before[:, :-2, 1:-1] + before[:, 2:, 1:-1] + before[:, 1:-1, :-2] + before[:, 1:-1, 2:]
+        diag = before[:, :-2, :-2] + before[:, :-2, 2:] + before[:, 2:, :-2] + before[:, 2:, 2:]
+        sm = w0 * c_ + w1 * edge + w2 * diag
+        gap = np.maximum(0.5, (np.abs(c_ - sm) / step[:, None, None]).max(axis=0))
+        want[:, 1:-1, 1:-1] = c_ + (sm - c_) * np.maximum(0.0, 3.0 - 4.0 * gap)
+    scale = max(1e-3, float(np.abs(before).max()))
+    # |c - s| / step amplifies a float32 rounding of s by 1 / step (~1e2-1e3) into the blend factor: a few 1e-5 of the sample range
+    assert np.abs(after - want).max() <= 1e-5 * scale, float(np.abs(after - want).max())
+    if bw > 2 and bh > 2:
+        assert np.abs(after - before).max() > 0, "the smoothing moved nothing: the test image is too flat to say anything"
+
+
+# ---- 2x / 4x / 8x upsampling (stage_upsampling.cc) -------------------------------------------------------------------------------------------
+def upsample_float64(p, up, weights):
+    """every input sample becomes up x up output samples; output (sy, sx) of a sample is a 5x5 kernel over its neighbourhood (mirrored at the
+    borders), clamped to the range of those 25 samples.  Kernels: the stored 15 / 55 / 210 weights are the upper triangle of a symmetric
+    (5 up / 2)^2 matrix M, kernel[ky][kx][iy][ix] = M[5 ky + iy][5 kx + ix] for the top-left quadrant of sub-positions, mirrored for the others."""
+    n = up // 2
+    M = np.zeros((5 * n, 5 * n))
+    k = 0
+    for i in range(5 * n):
+        for j in range(i, 5 * n):
+            M[i, j] = M[j, i] = weights[k]
+            k += 1
+    assert k == len(weights)
+    h, w = p.shape
+    pad = np.pad(p, 2, mode="symmetric")
+    win = np.stack([pad[iy:iy + h, ix:ix + w] for iy in range(5) for ix in range(5)])     # (25, h, w)
+    lo, hi = win.min(axis=0), win.max(axis=0)
+    out = np.zeros((h * up, w * up))
+    for sy in range(up):
+        ky, flip_y = (sy, False) if sy < n else (up - 1 - sy, True)
+        for sx in range(up):
+            kx, flip_x = (sx, False) if sx < n else (up - 1 - sx, True)
+            kern = M[5 * ky:5 * ky + 5, 5 * kx:5 * kx + 5]
+            if flip_y:
+                kern = kern[::-1, :]
+            if flip_x:
+                kern = kern[:, ::-1]
+            v = np.tensordot(kern.reshape(25), win, axes=1)
+            out[sy::up, sx::up] = np.clip(v, lo, hi)
+    return out
+
+
+@pytest.mark.parametrize("up,custom", [(2, 0), (2, 1), (4, 1), (8, 1), (4, 0), (8, 0)])
+def test_upsampling_follows_its_definition(jx, up, custom):
+    """linear f32 output of an upsampled frame = inverse opsin (pinned above) of the float64 upsampling of the planes the filters left"""
+    S.set_color(1, 1, 8)
+    try:
+        data = S.encode_vardct(S.synthetic_image(60 + up, 96, 72), seed=60 + up, strategy_mix=1, epf_iters=0, gab=0, upsampling=up, custom_up_weights=custom)
+    finally:
+        S.set_color()
+    b = jx.BatchDecoder(0)
+    b.add(data, "float32", 3)
+    b.set_option("force_unfused_filters", 1)
+    b.prepare()
+    b.set_option("debug_stop_after", 1)
+    b.decode(); b.finish()
+    info = b.info(0)
+    W, H, bw, bh = info.xsize, info.ysize, b.info_value("frame0_bw"), b.info_value("frame0_bh")
+    w, h = (W + up - 1) // up, (H + up - 1) // up
+    xyb = np.stack([b.debug_read(0, "plane_a", c).reshape(bh * 8, bw * 8)[:h, :w] for c in range(3)]).astype(np.float64)
+    weights = b.debug_read(0, "up_weights").astype(np.float64)
+    assert len(weights) == {2: 15, 4: 55, 8: 210}[up]
+    if not custom:     # the library defaults: every kernel of a partition of unity sums to 1 (a constant image stays constant)
+        n = up // 2
+        M = np.zeros((5 * n, 5 * n)); k = 0
+        for i in range(5 * n):
+            for j in range(i, 5 * n):
+                M[i, j] = M[j, i] = weights[k]; k += 1
+        sums = M.reshape(n, 5, n, 5).sum(axis=(1, 3))
+        assert np.abs(sums - 1.0).max() < 2e-3, sums
+    X, Y, B = [upsample_float64(xyb[c], up, weights)[:H, :W] for c in range(3)]
+    b.set_option("debug_stop_after", 0)
+    b.decode(); b.finish()
+    got = b.output(0).reshape(H, W, 3).astype(np.float64)
+    bias = -0.0037930732552754493
+    cb = np.cbrt(bias)
+    mixed = [np.power(Y + X - cb, 3) + bias, np.power(Y - X - cb, 3) + bias, np.power(B - cb, 3) + bias]
+    inv = np.array([[11.031566901960783, -9.866943921568629, -0.16462299647058826],
+                    [-3.254147380392157, 4.418770392156863, -0.16462299647058826],
+                    [-3.6588512862745097, 2.7129230470588235, 1.9459282392156863]])
+    want = np.stack([sum(inv[r, k] * mixed[k] for k in range(3)) for r in range(3)], axis=-1)
+    # 25-term kernels in float32 (1e-7 relative on XYB values below 1) through the cube and a matrix with entries up to 11: ~1e-5 absolute
+    assert np.abs(got - want).max() <= 2e-5, float(np.abs(got - want).max())
