@@ -248,6 +248,12 @@ class Pipeline:
         if self.deep and nbuf % self.ncoef:
             nbuf += self.ncoef - nbuf % self.ncoef                     # (coefficient sets rotate with k: batch object k % nbuf must always meet set k % ncoef)
         self.nbuf = nbuf
+        # tails in flight: 1 = IDCT and filters of consecutive batches one after the other on the main stream; 2 = the filter stage on a stream of
+        # its own beside the IDCT of the next batch (two sets of pixel planes)
+        self.ntail = max(1, min(2, args.tail_streams)) if self.deep else 1
+        if self.ntail > 1 and nbuf % (self.ncoef * self.ntail):
+            nbuf += self.ncoef * self.ntail - nbuf % (self.ncoef * self.ntail)
+            self.nbuf = nbuf
         self.nout = min(nbuf, max(1, args.out_buffers))
         self.main = torch.cuda.current_stream()
         self.stream = self.main.cuda_stream
@@ -256,8 +262,8 @@ class Pipeline:
         for b in range(nbuf):
             bt = jx.BatchDecoder(local_rank)
             self.fill(bt, b)
-            if b > 0:
-                bt.share_buffers(self.batches[0])                  # the tails run one after the other on the main stream: one set of pixel planes
+            if b >= self.ntail:
+                bt.share_buffers(self.batches[b % self.ntail])     # one set of pixel planes per tail in flight (1: the tails run one after the other on the main stream)
             if b >= self.ncoef:
                 bt.share_coefficients(self.batches[b % self.ncoef])
             bt.prepare(self.stream)
@@ -276,6 +282,7 @@ class Pipeline:
         self.sides = [S("lf", i, lf_prio(i)) for i in range(max(1, min(self.ahead, args.lf_streams)))] if self.pipeline else []
         self.comm = S("comm", 0) if self.do_gather else None            # RCCL gather overlaps the next step's decode
         self.hf_streams = [S("hf", i, -1) for i in range(self.nhf)]
+        self.filter_stream = S("filter", 0) if self.ntail > 1 else None
         self.copy_streams = [S("copy", i) for i in range(max(1, args.prepare_threads))] if streaming else []
         self.hf_done, self.front_done, self.lf_done, self.rest_done, self.idct_done = ([E() for _ in range(nbuf)] for _ in range(5))
         self.out_free = [E() for _ in range(self.nout)]               # the gather of the step that used this output buffer last has read it
@@ -366,10 +373,21 @@ class Pipeline:
             main.wait_event(self.front_done[b])
             if self.do_gather and st["gathers"] >= self.nout:
                 main.wait_event(self.out_free[k % self.nout])   # the previous gather of this output buffer must have read the pixels
+            if self.ntail > 1 and k >= self.ntail:
+                main.wait_event(self.rest_done[(k - self.ntail) % self.nbuf])   # the plane set's previous user has written its pixels
             self.batches[b].decode_part(7, self.stream, timed)     # IDCT
             self.idct_done[b].record(main)
-            self.batches[b].decode_part(8, self.stream, timed)     # restoration filters, colour, write
-            self.rest_done[b].record(main)
+            if self.ntail > 1:
+                fs = self.filter_stream
+                with torch.cuda.stream(fs):
+                    fs.wait_event(self.idct_done[b])
+                    if self.do_gather and st["gathers"] >= self.nout:
+                        fs.wait_event(self.out_free[k % self.nout])
+                    self.batches[b].decode_part(8, fs.cuda_stream, timed)
+                    self.rest_done[b].record(fs)
+            else:
+                self.batches[b].decode_part(8, self.stream, timed)     # restoration filters, colour, write
+                self.rest_done[b].record(main)
         if self.do_gather:
             from jpegxl_rs_amd.sharding import gather_frames_chunked
             with torch.cuda.stream(self.comm):
@@ -396,8 +414,10 @@ class Pipeline:
         t0 = time.perf_counter()
         for k in range(nsteps):
             self.step(k, timed, st)
-            ev = torch.cuda.Event(enable_timing=True); ev.record(self.main); marks.append(ev)
+            ev = torch.cuda.Event(enable_timing=True); ev.record(self.filter_stream if self.filter_stream is not None else self.main); marks.append(ev)
         self.main.synchronize()
+        if self.filter_stream is not None:
+            self.filter_stream.synchronize()
         t_decode = time.perf_counter() - t0          # every rank's own decode work is done (the gather may still be running)
         torch.cuda.synchronize()
         if self.world > 1:
@@ -467,6 +487,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=11, help="batches in flight on the GPU (pipelined): LF stages run this many steps ahead, minus one")
     ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
     ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current step (deep pipeline), one stream and one coefficient set each")
+    ap.add_argument("--tail-streams", type=int, default=int(os.environ.get("JXL_BENCH_TAIL_STREAMS", "1")), help="2: the filter stage of a batch on its own stream beside the IDCT of the next (two sets of pixel planes)")
     ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
     ap.add_argument("--out-buffers", type=int, default=2, help="output buffer sets the batches in flight cycle through")
     ap.add_argument("--prepare-threads", type=int, default=int(os.environ.get("JXL_BENCH_PREPARE_THREADS", "3")), help="streaming: host threads that each parse + prepare + upload one batch at a time")

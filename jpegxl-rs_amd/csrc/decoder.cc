@@ -836,7 +836,7 @@ void Batch::Prepare(void* stream_v) {
     size_t lfq[3], lf[3], lf_tmp[3], llf[3], blk_info, coef_off, vb_list, vb_count, ytox, ytob, coeff[3], plane_a[3], plane_b[3], inv_sigma, lf_scratch, wp_scratch, end_bitpos,
         place_rec = 0, place_cnt = 0, band_start = 0,
         mod_scratch, hf_end = 0, mod_wp = 0, up_plane[4] = {0, 0, 0, 0};
-    size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0, lz_window = (size_t)-1;
+    size_t lf_scratch_stride, wp_scratch_stride, mod_scratch_stride, mod_wp_stride = 0, lz_window = (size_t)-1, lz_ac_window = (size_t)-1;
   };
   vec<WorkOffsets> wo(n);
   mod_plane_offsets_.assign(n, {});
@@ -930,6 +930,11 @@ void Batch::Prepare(void* stream_v) {
     }
     if (p.has_global_tree && p.tree_code.lz77 && (!p.gchannels.empty() || !p.modular))   // LZ77 windows of the Modular streams (4 MiB each); VarDCT: + one per LF group
       o.lz_window = take((size_t)(1 + p.NumModUnits() + (p.modular ? 0 : p.num_lf_groups)) * (4u << 20));
+    if (!p.modular) {   // LZ77-coded AC streams: a window per group stream (1 MiB each, only for the frames that use them)
+      bool lz_ac = p.single_section;    // (a one-section frame's AC code is only parsed once its LF streams have been decoded: always reserved, 1 MiB)
+      for (auto& code : p.ac_code) lz_ac |= code.lz77;
+      if (lz_ac) o.lz_ac_window = take((size_t)p.num_groups * kAcLzWindow * 4);
+    }
     if (e.complex) {
       // buffers of the frame tail (PlanPostOps): float extra channels, upsampled planes, noise planes, colour-transformed planes
       // (only when the untransformed ones must survive as a reference frame), canvas (only when the frame is blended)
@@ -1050,6 +1055,7 @@ void Batch::Prepare(void* stream_v) {
     f.is_gray = e.ih.color_space == 1;
     f.post_mode = e.complex ? 1 : 0;
     f.lz_window = o.lz_window == (size_t)-1 ? nullptr : (uint32_t*)(dwork_ + o.lz_window);
+    f.lz_ac_window = o.lz_ac_window == (size_t)-1 ? nullptr : (uint32_t*)(dwork_ + o.lz_ac_window);
     f.lz_lf_base = 1 + p.NumModUnits();
     f.wp_scratch = (int32_t*)(dwork_ + o.wp_scratch); f.wp_scratch_stride = o.wp_scratch_stride;
     if (!p.modular) {
@@ -1204,7 +1210,7 @@ void Batch::Prepare(void* stream_v) {
   }
   mark("hf_tables");
   {  // LDS right-sizing for the decode kernels
-    auto code_bytes = [](const HostCode& c, bool ctx) { if (c.use_prefix) return 16;   /* prefix codes are read from global memory: nothing to size the LDS for */
+    auto code_bytes = [](const HostCode& c, bool ctx) { if (c.use_prefix || c.lz77) return 16;   /* prefix codes / LZ77 streams are read through the tables in global memory: nothing to size the LDS for */
       return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
     cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0; cfg.any_local_trees = 0; cfg.any_subsampled = 0; cfg.any_prefix_ac = 0;
     for (int i = 0; i < n; i++) {
@@ -1216,7 +1222,7 @@ void Batch::Prepare(void* stream_v) {
       }
       if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
       if (p.subsampled) cfg.any_subsampled = 1;
-      if (!p.modular) for (auto& code : p.ac_code) if (code.use_prefix) cfg.any_prefix_ac = 1;
+      if (!p.modular) for (auto& code : p.ac_code) if (code.use_prefix || code.lz77) cfg.any_prefix_ac = 1;
     }
     if (getenv("JXL_HIP_DEBUG_LDS")) fprintf(stderr, "[jxl-hip] LDS sizing: tree nodes %d, modular code %d B, AC code %d B, BlockCtxDev %zu B\n", cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.ac_code_bytes, sizeof(BlockCtxDev));
   }

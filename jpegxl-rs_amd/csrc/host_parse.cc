@@ -1275,7 +1275,6 @@ void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos,
       sr.CheckFinal();
     }
     ReadEntropyCode(r, 495 * p->bcm.num_ctxs * p->num_hf_presets, &p->ac_code[ps]);
-    if (p->ac_code[ps].lz77) Unsupported("LZ77 in an AC coefficient stream");
   }
   p->end_bitpos = r.pos();
 }

@@ -155,11 +155,15 @@ template <typename BR> JXL_HD uint32_t HybridFromToken(BR& br, uint32_t cfg, uin
   return (((hi << nbits) | bits) << lsb) | low;
 }
 struct Lz77State {
-  uint32_t* window;          // kWindow entries
+  uint32_t* window;          // wmask + 1 entries
   uint32_t num_to_copy, copy_pos, num_decoded, dist_multiplier;
+  uint32_t wmask;            // window size - 1: kWindow - 1 (libjxl's 2^20) unless the stream is known to be shorter than a smaller power of two
   static constexpr uint32_t kWindow = 1u << 20, kMask = kWindow - 1;
-  JXL_HD void Init(uint32_t* w, uint32_t dist_mult) { window = w; num_to_copy = copy_pos = num_decoded = 0; dist_multiplier = dist_mult; }
+  JXL_HD void Init(uint32_t* w, uint32_t dist_mult, uint32_t entries = kWindow) { window = w; num_to_copy = copy_pos = num_decoded = 0; dist_multiplier = dist_mult; wmask = entries - 1; }
 };
+// AC coefficient streams (one per pass and group): at most 3 x (1024 + 65536) values, so a window of 2^18 entries never wraps and behaves
+// like libjxl's 2^20-entry one (distances are clamped to the number of decoded values)
+constexpr uint32_t kAcLzWindow = 1u << 18;
 JXL_HD int32_t Lz77SpecialDistance(uint32_t i, uint32_t mult) {   // kSpecialDistances[i][0] + mult * kSpecialDistances[i][1]
   // the 120 WebP-lossless-style neighbour offsets (dx in -7..8, dy in 0..7), packed as (dx + 7) | dy << 4
   const uint8_t t[120] = {
@@ -180,9 +184,9 @@ JXL_HD uint32_t Lz77Read(BR& br, Lz77State& lz, uint32_t ctx, uint32_t dist_ctx,
                          ClusterFn cluster_of, SymbolFn read_symbol, CfgFn cfg_of) {   // cluster_of maps the two "contexts" the caller passes to clusters
   for (;;) {
     if (lz.num_to_copy > 0) {
-      const uint32_t v = lz.window[(lz.copy_pos++) & Lz77State::kMask];
+      const uint32_t v = lz.window[(lz.copy_pos++) & lz.wmask];
       lz.num_to_copy--;
-      lz.window[(lz.num_decoded++) & Lz77State::kMask] = v;
+      lz.window[(lz.num_decoded++) & lz.wmask] = v;
       return v;
     }
     const uint32_t cl = cluster_of(ctx);
@@ -196,14 +200,14 @@ JXL_HD uint32_t Lz77Read(BR& br, Lz77State& lz, uint32_t ctx, uint32_t dist_ctx,
       if (distance < nspecial) { const int32_t d = Lz77SpecialDistance(distance, lz.dist_multiplier); distance = d < 1 ? 1u : (uint32_t)d; }
       else distance = distance + 1 - nspecial;
       if (distance > lz.num_decoded) distance = lz.num_decoded;
-      if (distance > Lz77State::kWindow) distance = Lz77State::kWindow;
+      if (distance > lz.wmask) distance = lz.wmask + 1;
       lz.copy_pos = lz.num_decoded - distance;
-      if (distance == 0) { const uint32_t n = lz.num_to_copy < Lz77State::kWindow ? lz.num_to_copy : Lz77State::kWindow; for (uint32_t i = 0; i < n; i++) lz.window[i] = 0; }
+      if (distance == 0) { const uint32_t n = lz.num_to_copy <= lz.wmask ? lz.num_to_copy : lz.wmask + 1; for (uint32_t i = 0; i < n; i++) lz.window[i] = 0; }
       if (lz.num_to_copy < min_length) return 0;   // (length overflow: libjxl bails out with 0)
       continue;
     }
     const uint32_t v = HybridFromToken(br, cfg_of(cl), tok);
-    lz.window[(lz.num_decoded++) & Lz77State::kMask] = v;
+    lz.window[(lz.num_decoded++) & lz.wmask] = v;
     return v;
   }
 }

@@ -115,6 +115,7 @@ struct FrameDev {
   uint32_t* status;
   uint32_t* frame_flags;          // [0] != 0: some varblock is not contained in a 64x64 tile (generic IDCT path)
   uint32_t* hf_written;           // running count of non-zero AC coefficients the HF stage wrote for this frame (bench accounting)
+  uint32_t* lz_ac_window;         // LZ77-coded AC streams: kAcLzWindow entries per group stream (reused pass after pass); null otherwise
   uint32_t* lz_window;            // LZ77-coded Modular streams: 2^20-entry windows, one per stream (global, then LfGroup / PassGroup units)
   uint32_t post_mode;             // 1: the frame ends in its float planes (after the restoration filters); upsampling, colour transform and the
                                   // write stage are done by the host-planned frame tail (kernels_features.hip) — multi-frame images, image features
@@ -129,7 +130,7 @@ struct LaunchCfg {
   int any_wp = 0;            // some MA tree of the batch uses the weighted predictor (the Modular kernels then reserve LDS for its state)
   int any_subsampled = 0;    // some frame is chroma-subsampled (its own IDCT kernel; the SIMT HF kernel only)
   int any_multipass = 0;     // some frame has progressive passes (the general instantiation of the SIMT HF kernel)
-  int any_prefix_ac = 0;     // some VarDCT frame's AC code is a prefix code (HfDecodeKernel beside the SIMT kernel)
+  int any_prefix_ac = 0;     // some VarDCT frame's AC code is a prefix code or LZ77-coded (HfDecodeKernel beside the SIMT kernel)
   int any_local_trees = 0;   // some Modular sub-stream carries its own MA tree / code (second launch of the group kernel)
   // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
   int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;

@@ -2097,9 +2097,10 @@ __device__ static const uint8_t kNzCtx[64] = {0,   0,   31,  62,  62,  93,  93, 
 __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride, uint32_t lds_bytes, int only_prefix) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular) return;
-  const bool pfx = f.ac_code.use_prefix != 0;
-  if (only_prefix && !pfx) return;
-  if (only_prefix && (f.num_passes != 1 || f.subsampled)) return;      // (progressive / chroma-subsampled prefix-coded frames: HfDecodeSimtKernel walks them)
+  const bool pfx = f.ac_code.use_prefix != 0, lz77 = f.ac_code.lz77 != 0;
+  const bool slow = pfx || lz77;                                       // symbols through the general reader (tables in global memory)
+  if (only_prefix && !slow) return;
+  if (only_prefix && (f.num_passes != 1 || f.subsampled)) return;      // (progressive / chroma-subsampled prefix- or LZ77-coded frames: HfDecodeSimtKernel walks them)
   // ---- stage the AC entropy code (cfg, context map, alias tables if they fit) and the two context LUTs into LDS
   FastCode code;
   if (threadIdx.x < 64) { StS<uint8_t>(threadIdx.x, kNzCtx[threadIdx.x]); StS<uint8_t>(64 + threadIdx.x, kFreqCtx[threadIdx.x]); }
@@ -2123,11 +2124,19 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   if (preset >= f.num_hf_presets) { SetError(f, kErrBadValue); return; }
   const uint32_t ctx_offset = 495u * nctx * preset;
   uint32_t state = pfx ? 0x130000u : br.Read(32);
+  Lz77State lz;                                      // LZ77 over the values of this group stream (dec_ans.h; distance multiplier 0: no special distances)
+  lz.Init(lz77 ? f.lz_ac_window + (size_t)g * kAcLzWindow : nullptr, 0, kAcLzWindow);
+  if (lz77 && !f.lz_ac_window) { SetError(f, kErrUnsupported); return; }
   auto read_hybrid = [&](uint32_t ctx) -> uint32_t {
-    if (!pfx) return FastHybrid(br, state, code, code.Cluster(ctx));
-    const uint32_t cl = LdG(f.ac_code.ctx_map + ctx);
+    if (!slow) return FastHybrid(br, state, code, code.Cluster(ctx));
     AnsReader ans; ans.state = state;
-    return HybridFromToken(br, LdG(f.ac_code.cfg + cl), ReadSymbol(br, ans, f.ac_code, cl));
+    uint32_t v;
+    if (!lz77) { const uint32_t cl = LdG(f.ac_code.ctx_map + ctx); v = HybridFromToken(br, LdG(f.ac_code.cfg + cl), ReadSymbol(br, ans, f.ac_code, cl)); }
+    else v = Lz77Read(br, lz, ctx, f.ac_code.num_ctx, f.ac_code.lz_min_symbol, f.ac_code.lz_min_length, f.ac_code.lz_len_cfg,
+                      [&](uint32_t c) { return (uint32_t)LdG(f.ac_code.ctx_map + c); }, [&](uint32_t cl) { return ReadSymbol(br, ans, f.ac_code, cl); },
+                      [&](uint32_t cl) { return LdG(f.ac_code.cfg + cl); });
+    state = ans.state;
+    return v;
   };
   uint32_t nzrow[3][8];   // 32 bytes per channel packed in 8 words (kept in registers)
 #pragma unroll
@@ -2280,8 +2289,8 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   if (f.is_modular) return;
   // prefix-coded frames: HfDecodeKernel, launched beside this one — unless they are progressive or chroma-subsampled: those are walked here (the
   // general instantiation), their symbols read bit by bit through the canonical-code tables in global memory (jxl_dev.h ReadSymbol)
-  bool any_pfx = f.ac_code.use_prefix != 0;
-  for (uint32_t ps = 1; MULTI && ps < f.num_passes; ps++) any_pfx |= f.passes[ps].code.use_prefix != 0;
+  bool any_pfx = f.ac_code.use_prefix != 0 || f.ac_code.lz77 != 0;     // (prefix codes or LZ77: the general symbol reader)
+  for (uint32_t ps = 1; MULTI && ps < f.num_passes; ps++) any_pfx |= f.passes[ps].code.use_prefix != 0 || f.passes[ps].code.lz77 != 0;
   if (any_pfx && !((SUB && f.subsampled) || (MULTI && f.num_passes > 1))) return;
   if (blockIdx.x * lanes >= f.num_groups) return;
   if (prio & 1) __builtin_amdgcn_s_setprio(3);   // few, long, latency-critical waves on the critical path of a batch: issue ahead of co-resident waves
@@ -2316,7 +2325,11 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   StageCode(pd.code, code, kSimtCodeOff, lane_off > kSimtCodeOff ? lane_off - kSimtCodeOff : 0, /*with_ctx_map=*/true);
   if (threadIdx.x < 39) StS<uint64_t>(kSimtOrdOff + threadIdx.x * 8, (uint64_t)(uintptr_t)pd.orders[threadIdx.x]);
   __syncthreads();
-  const bool pfx = (SUB || MULTI) && pd.code.use_prefix != 0;
+  const bool lz77 = (SUB || MULTI) && pd.code.lz77 != 0;
+  const bool pfx = (SUB || MULTI) && (pd.code.use_prefix != 0 || lz77);      // "slow" pass: symbols through the general reader
+  Lz77State lz;                                        // (one window per group stream, restarted pass after pass)
+  if (SUB || MULTI) lz.Init(lz77 && !dead ? f.lz_ac_window + (size_t)g * kAcLzWindow : nullptr, 0, kAcLzWindow);
+  if (lz77 && !f.lz_ac_window) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
   if (ALL_LDS && !pfx && (code.cfg_off == kNotInLds || code.ctx_map_off == kNotInLds || code.alias_off == kNotInLds)) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
   bool done = dead;
   uint32_t err = 0;                                    // first error of this lane's stream (reported after the loop)
@@ -2358,7 +2371,7 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
     const uint32_t preset = f.preset_bits ? br.Read((int)f.preset_bits) : 0;
     if (preset >= f.num_hf_presets) { err = kErrBadValue; done = true; }
     ctx_offset = 495u * nctx * preset;
-    state = pfx ? 0x130000u : br.Read(32);           // (prefix codes carry no ANS state)
+    state = (pfx && pd.code.use_prefix) ? 0x130000u : br.Read(32);           // (prefix codes carry no ANS state)
   }
   // ---- varblock list of this group, one entry loaded ahead
   const uint2* vbl = f.vb_list + (size_t)gsafe * 1024;
@@ -2437,9 +2450,12 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
       uint32_t u;
       if ((SUB || MULTI) && pfx) {
         br.Refill();
-        const uint32_t cl = LdG(pd.code.ctx_map + ctx);
         AnsReader ans; ans.state = state;
-        u = HybridFromToken(br, LdG(pd.code.cfg + cl), ReadSymbol(br, ans, pd.code, cl));
+        if (!lz77) { const uint32_t cl = LdG(pd.code.ctx_map + ctx); u = HybridFromToken(br, LdG(pd.code.cfg + cl), ReadSymbol(br, ans, pd.code, cl)); }
+        else u = Lz77Read(br, lz, ctx, pd.code.num_ctx, pd.code.lz_min_symbol, pd.code.lz_min_length, pd.code.lz_len_cfg,
+                          [&](uint32_t c2) { return (uint32_t)LdG(pd.code.ctx_map + c2); }, [&](uint32_t cl) { return ReadSymbol(br, ans, pd.code, cl); },
+                          [&](uint32_t cl) { return LdG(pd.code.cfg + cl); });
+        state = ans.state;
       } else u = HybridSimt<ALL_LDS>(br, state, code, ctx);
       if (phase == 1) {
         nzeros = u;

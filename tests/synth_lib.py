@@ -261,6 +261,12 @@ def set_lz77_lf(on=False):
     lib().jxlsynth_set_lz77_lf(1 if on else 0)
 
 
+def set_lz77_ac(on=False):
+    """VarDCT frames written from now on (this thread) code their AC coefficient streams with LZ77 (runs of zero coefficients, repeating pairs and
+    triples become copies; no special distances: the readers of these streams have no distance multiplier)"""
+    lib().jxlsynth_set_lz77_ac(1 if on else 0)
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

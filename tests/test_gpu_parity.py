@@ -389,6 +389,27 @@ def test_lz77_coded_lf_streams(jx):
             assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), (lf_stride, cases[i][0])
 
 
+def test_lz77_coded_ac_streams(jx):
+    """LZ77 in the AC coefficient streams (dec_ans.h): the general symbol reader of the HF kernels with a 1 MB window per group stream
+    in global memory — single-pass frames through HfDecodeKernel, progressive ones through the general HfDecodeSimtKernel instantiation; against the
+    oracle and the ANS twin, alone and in a batch beside plain frames."""
+    from test_synth_roundtrip import lz77_ac_streams
+    cases = lz77_ac_streams()
+    for name, lz, ans, nc in cases:
+        _, px = check_against_oracle(jx, lz, np.uint8, nc)
+        assert np.array_equal(px.reshape(-1), O.decode(ans).pixels("u8", nc)), name
+    check_against_oracle(jx, cases[0][1], np.float32, 3)
+    b = jx.BatchDecoder(0)
+    for name, lz, ans, nc in cases:
+        b.add(lz, "uint8", nc); b.add(ans, "uint8", nc)
+    b.prepare(); b.decode(); b.finish()
+    for i in range(len(cases)):
+        assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), cases[i][0]
+    b.decode(); b.finish()     # (a second decode of the prepared batch: the windows are scratch, nothing carries over)
+    for i in range(len(cases)):
+        assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), cases[i][0]
+
+
 def test_previous_channel_properties_in_lf_streams(jx):
     """MA trees of the LF-group streams of VarDCT frames that split on previous-channel properties (16 + 4 r + k, `cjxl -E`): the LF
     kernel's general tree walk with the earlier channels of the stream as references; against the oracle and the plain-tree twin, alone and batched."""

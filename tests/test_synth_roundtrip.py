@@ -342,6 +342,44 @@ def test_lz77_coded_lf_streams_decode_like_their_ans_twins():
         assert np.array_equal(O.decode(lz).pixels("u8", 3), O.decode(ans).pixels("u8", 3)), name
 
 
+def lz77_ac_streams():
+    """(name, stream whose AC coefficient streams are LZ77-coded, ANS twin): runs of zero coefficients, repeating pairs and triples of values become
+    copies (distance tokens without special codes: these readers have no distance multiplier); single-pass, progressive (every pass its own code
+    and window), with prefix codes under the LZ77 layer, with extra channels whose Modular part follows the coefficients"""
+    import numpy as np
+    import synth_lib as S
+    out = []
+    for name, seed, (w, h), kw in [("small", 1, (320, 200), dict(strategy_mix=1, epf_iters=1)), ("one_group", 2, (64, 48), dict(strategy_mix=0, epf_iters=2)),
+                                   ("many_groups_big_blocks", 3, (1100, 600), dict(strategy_mix=2, epf_iters=0)), ("three_passes", 4, (520, 300), dict(strategy_mix=2, num_passes=3)),
+                                   ("two_passes_permuted", 5, (300, 280), dict(strategy_mix=1, num_passes=2, permute_toc=3)), ("prefix", 6, (320, 200), dict(strategy_mix=1)),
+                                   ("alpha", 7, (300, 270), dict(strategy_mix=2))]:
+        img = S.synthetic_image(70 + seed, w, h)
+        img[: h // 3, : w // 2] = img[0, 0]
+        if name == "alpha":
+            kw = dict(kw, alpha=(np.arange(w * h, dtype=np.uint32).reshape(h, w) % 251).astype(np.uint8))
+        if name == "prefix":
+            S.set_prefix(True)
+        try:
+            ans = S.encode_vardct(img, seed=seed, **kw)
+            S.set_lz77_ac(True)
+            try:
+                lz = S.encode_vardct(img, seed=seed, **kw)
+            finally:
+                S.set_lz77_ac(False)
+        finally:
+            S.set_prefix(False)
+        out.append((name, lz, ans, 4 if name == "alpha" else 3))
+    return out
+
+
+def test_lz77_coded_ac_streams_decode_like_their_ans_twins():
+    import numpy as np
+    import oracle_lib as O
+    for name, lz, ans, nc in lz77_ac_streams():
+        assert lz != ans and len(lz) != len(ans), name
+        assert np.array_equal(O.decode(lz).pixels("u8", nc), O.decode(ans).pixels("u8", nc)), name
+
+
 def prev_channel_streams():
     """(name, stream whose LF-group MA tree splits on previous-channel properties, twin under the plain tree)"""
     import synth_lib as S

@@ -330,22 +330,27 @@ static void ModularTokens(const GTree& t, int root, const std::vector<ChanRef>& 
 // LZ77 over a finished token stream (dec_ans.h ANSSymbolReader: the window holds the decoded values of the whole stream, whatever their contexts): runs
 // that repeat the value before (distance 1: special distance code 1) or the value one row up (distance `row`: special distance code 0 = the stream's
 // distance multiplier, its widest channel) become a length symbol in the context of the run's first value + a distance token in the extra context
-static void ApplyLz77(std::vector<Token>& tok, uint32_t dist_ctx, const EntropyCoder& proto, size_t row) {
+// special = false: a stream without a distance multiplier (AC coefficients): no special distance codes, the distance token is distance - 1; copies at
+// distance 1 (runs), 2 and 3 (repeating pairs / triples)
+static void ApplyLz77(std::vector<Token>& tok, uint32_t dist_ctx, const EntropyCoder& proto, size_t row, bool special = true) {
   std::vector<Token> out;
   const size_t n = tok.size();
   size_t i = 0;
   while (i < n) {
-    size_t l1 = 0, lr = 0;
+    size_t l1 = 0, lr = 0, l2 = 0, l3 = 0;
     if (i >= 1) while (i + l1 < n && tok[i + l1].value == tok[i + l1 - 1].value) l1++;
     if (row > 1 && i >= row) while (i + lr < n && tok[i + lr].value == tok[i + lr - row].value) lr++;
-    const size_t len = std::max(l1, lr);
+    if (!special && i >= 2) while (i + l2 < n && tok[i + l2].value == tok[i + l2 - 2].value) l2++;
+    if (!special && i >= 3) while (i + l3 < n && tok[i + l3].value == tok[i + l3 - 3].value) l3++;
+    const size_t len = std::max(std::max(l1, lr), std::max(l2, l3));
     if (len >= std::max<size_t>(proto.lz_min_length, 6)) {
       Token t; t.ctx = tok[i].ctx; t.raw = 1;
       uint32_t sym, nb, bits;
       EncodeHybrid(proto.lz_len_cfg, (uint32_t)len - proto.lz_min_length, &sym, &nb, &bits);
       t.value = proto.lz_min_symbol + sym; t.nb = (uint8_t)nb; t.bits = bits;
       out.push_back(t);
-      out.push_back(Token{dist_ctx, lr >= l1 ? 0u : 1u});      // (ties go to the row copy: flat areas then exercise both distance codes)
+      if (special) out.push_back(Token{dist_ctx, lr >= l1 ? 0u : 1u});      // (ties go to the row copy: flat areas then exercise both distance codes)
+      else out.push_back(Token{dist_ctx, l3 == len ? 2u : l2 == len ? 1u : 0u});
       i += len;
     } else out.push_back(tok[i++]);
   }
@@ -1128,9 +1133,16 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     s.push_back(&alpha_global_tok); for (auto& t : alpha_tok) s.push_back(&t);
     BuildEntropyCoder(s, gt.num_leaves + (lz77_lf ? 1 : 0), UintConfig{4, 2, 0}, 32, mod_code);
     if (lz77_lf) { mod_code.lz77 = true; mod_code.lz_min_symbol = 224; mod_code.lz_min_length = 3; mod_code.lz_len_cfg = UintConfig{3, 0, 0}; } }
+  const bool lz77_ac = UseLz77Ac();
   for (int ps = 0; ps < np; ps++) {
+    if (lz77_ac) {   // LZ77 over every group's coefficient stream of the pass (dec_group.cc reads them with a reader without distance multiplier)
+      EntropyCoder proto;
+      proto.lz_min_symbol = 224; proto.lz_min_length = 3; proto.lz_len_cfg = UintConfig{3, 0, 0};
+      for (int g = 0; g < ngroups; g++) ApplyLz77(ac_tok_all[(size_t)ps * ngroups + g], (uint32_t)(495 * nctx), proto, 0, /*special=*/false);
+    }
     std::vector<const std::vector<Token>*> s; for (int g = 0; g < ngroups; g++) s.push_back(&ac_tok_all[(size_t)ps * ngroups + g]);
-    BuildEntropyCoder(s, 495 * nctx, UintConfig{4, 2, 0}, 96, ac_codes[ps]);
+    BuildEntropyCoder(s, 495 * nctx + (lz77_ac ? 1 : 0), UintConfig{4, 2, 0}, 96, ac_codes[ps]);
+    if (lz77_ac) { ac_codes[ps].lz77 = true; ac_codes[ps].lz_min_symbol = 224; ac_codes[ps].lz_min_length = 3; ac_codes[ps].lz_len_cfg = UintConfig{3, 0, 0}; }
   }
   // --- sections
   std::vector<BitWriter> sections;
@@ -1466,6 +1478,7 @@ void jxlsynth_set_animation(int tps_num, int tps_den, int loops) { synth::g_anim
 void jxlsynth_set_preview(int w, int h) { synth::g_preview_w = w; synth::g_preview_h = h; }
 void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
+void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
 void jxlsynth_set_lf_tree_shape(int shape) { synth::LfTreeShape() = shape; }
 // rgba == NULL: the extra channel is alpha again

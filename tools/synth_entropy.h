@@ -265,6 +265,8 @@ inline bool& UsePrefixCodes() { static thread_local bool v = false; return v; }
 // ... their MA tree also splits on previous-channel properties (16 + 4 r + k: the sample of the r-th previous channel of equal size at this position, cjxl -E)
 inline bool& UsePrevChannelProps() { static thread_local bool v = false; return v; }
 inline bool& UseLz77Lf() { static thread_local bool v = false; return v; }
+// ... and the AC coefficient streams of VarDCT frames
+inline bool& UseLz77Ac() { static thread_local bool v = false; return v; }
 // ... their MA tree has the shape cjxl writes at its default effort: the LF coefficients under a fixed tree over the weighted predictor's
 // maximum error (property 15) with weighted-predictor leaves, the HF metadata under the fixed tree over the row, N and W (0: the gradient tree)
 inline int& LfTreeShape() { static thread_local int v = 0; return v; }
