@@ -142,6 +142,36 @@ JxlDecoderStatus JxlDecoderSetPreviewOutBuffer(JxlDecoder* dec, const JxlPixelFo
  * the thread inside JxlDecoderProcessInput after the image has been decoded; the row memory is only valid during the call. */
 typedef void (*JxlImageOutCallback)(void* opaque, size_t x, size_t y, size_t num_pixels, const void* pixels);
 JxlDecoderStatus JxlDecoderSetImageOutCallback(JxlDecoder* dec, const JxlPixelFormat* format, JxlImageOutCallback callback, void* opaque);   /* decode.rs:1172 */
+/* decode.rs:1200 (callback types :324-361): the rows are handed out after the image has been decoded on the device — init(init_opaque, 1 thread,
+ * xsize pixels per call), run(..., thread 0, x = 0, y, xsize, row) for every row, destroy. */
+typedef void* (*JxlImageOutInitCallback)(void* init_opaque, size_t num_threads, size_t num_pixels_per_thread);
+typedef void (*JxlImageOutRunCallback)(void* run_opaque, size_t thread_id, size_t x, size_t y, size_t num_pixels, const void* pixels);
+typedef void (*JxlImageOutDestroyCallback)(void* run_opaque);
+JxlDecoderStatus JxlDecoderSetMultithreadedImageOutCallback(JxlDecoder* dec, const JxlPixelFormat* format, JxlImageOutInitCallback init_callback,
+                                                            JxlImageOutRunCallback run_callback, JxlImageOutDestroyCallback destroy_callback, void* init_opaque);
+/* decode.rs:1224 / :1258: a separate plane for an extra channel (one sample per pixel in `format`'s type, num_channels ignored).  The alpha channel — the
+ * one the interleaved 2 / 4 channel output carries — is supported; any other index is rejected with JXL_DEC_ERROR and a message (JxlHipLastError). */
+JxlDecoderStatus JxlDecoderExtraChannelBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size, uint32_t index);
+JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* dec, const JxlPixelFormat* format, void* buffer, size_t size, uint32_t index);
+/* decode.rs:1326-1470: the boxes of the container (JXL_DEC_BOX once per box, signature and codestream boxes included; contents through a caller buffer with
+ * JXL_DEC_BOX_NEED_MORE_OUTPUT when it is full; `brob` boxes decompressed on request when the system has libbrotlidec).  Boxes up to the first codestream
+ * box are announced before JXL_DEC_BASIC_INFO, the others after the last frame. */
+typedef struct { char type[4]; } JxlBoxType;                                                  /* types.rs:147 */
+JxlDecoderStatus JxlDecoderSetBoxBuffer(JxlDecoder* dec, uint8_t* data, size_t size);
+size_t JxlDecoderReleaseBoxBuffer(JxlDecoder* dec);
+JxlDecoderStatus JxlDecoderSetDecompressBoxes(JxlDecoder* dec, JXL_BOOL decompress);
+JxlDecoderStatus JxlDecoderGetBoxType(JxlDecoder* dec, JxlBoxType* type, JXL_BOOL decompressed);
+JxlDecoderStatus JxlDecoderGetBoxSizeRaw(JxlDecoder* dec, uint64_t* size);
+JxlDecoderStatus JxlDecoderGetBoxSizeContents(JxlDecoder* dec, uint64_t* size);
+/* decode.rs:1482: which JXL_DEC_FRAME_PROGRESSION events are wanted (0 frames, 1 DC, 2 last passes, 3 passes are accepted, the finer ones rejected like libjxl
+ * does); frames are decoded whole on the device, so no progression event is ever emitted.  decode.rs:1513: nothing partial exists to flush: JXL_DEC_ERROR
+ * ("no flush was done"), as libjxl answers when no new image data is available. */
+JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* dec, int detail);
+JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* dec);
+/* decode.rs:1528 (types.rs:111-144): integer output is scaled to the full range of the buffer's type (JXL_BIT_DEPTH_FROM_PIXEL_FORMAT = 0, the default).
+ * FROM_CODESTREAM (1) / CUSTOM (2) are accepted when they ask for exactly that (or the buffer is float) and rejected with a message otherwise. */
+typedef struct { int type; uint32_t bits_per_sample, exponent_bits_per_sample; } JxlBitDepth;
+JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* dec, const JxlBitDepth* bit_depth);
 JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* dec, uint8_t* data, size_t size);        /* decode.rs:1283 */
 size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* dec);                                          /* decode.rs:1305 */
 
@@ -158,7 +188,7 @@ void JxlResizableParallelRunnerSetThreads(void* runner_opaque, size_t num_thread
 uint32_t JxlResizableParallelRunnerSuggestThreads(uint64_t xsize, uint64_t ysize);
 void JxlResizableParallelRunnerDestroy(void* runner_opaque);
 
-/* The remaining 89 symbols declared by jpegxl-sys (encoder, box API, CMS, gain map ...) are exported as
+/* The remaining symbols declared by jpegxl-sys (encoder, CMS, gain map, output colour profile ...) are exported as
  * error-returning stubs so the Rust crate links (csrc/jxl_stubs.cc, generated by tools/gen_stubs.py). */
 
 /* ---- extension: device-resident batch decode ------------------------------------------------------------------- */

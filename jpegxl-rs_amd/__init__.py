@@ -94,6 +94,11 @@ _lib = None
 _threads = None
 
 
+class JxlBitDepth(C.Structure):
+    """jpegxl-sys/src/common/types.rs:133-144"""
+    _fields_ = [("type", C.c_int), ("bits_per_sample", C.c_uint32), ("exponent_bits_per_sample", C.c_uint32)]
+
+
 class NativeLibraryMissing(RuntimeError):
     pass
 
@@ -130,6 +135,14 @@ def libjxl():
             "JxlDecoderGetFrameHeader": (C.c_int, [vp, C.POINTER(JxlFrameHeader)]), "JxlDecoderGetFrameName": (C.c_int, [vp, C.c_char_p, sz]),
             "JxlDecoderGetExtraChannelBlendInfo": (C.c_int, [vp, sz, C.POINTER(JxlBlendInfo)]), "JxlDecoderSkipFrames": (None, [vp, sz]),
             "JxlDecoderSkipCurrentFrame": (C.c_int, [vp]), "JxlDecoderRewind": (None, [vp]),
+            "JxlDecoderSetMultithreadedImageOutCallback": (C.c_int, [vp, C.POINTER(JxlPixelFormat), vp, vp, vp, vp]),
+            "JxlDecoderExtraChannelBufferSize": (C.c_int, [vp, C.POINTER(JxlPixelFormat), C.POINTER(sz), C.c_uint32]),
+            "JxlDecoderSetExtraChannelBuffer": (C.c_int, [vp, C.POINTER(JxlPixelFormat), vp, sz, C.c_uint32]),
+            "JxlDecoderSetBoxBuffer": (C.c_int, [vp, vp, sz]), "JxlDecoderReleaseBoxBuffer": (sz, [vp]),
+            "JxlDecoderSetDecompressBoxes": (C.c_int, [vp, C.c_int]), "JxlDecoderGetBoxType": (C.c_int, [vp, C.c_char_p, C.c_int]),
+            "JxlDecoderGetBoxSizeRaw": (C.c_int, [vp, C.POINTER(C.c_uint64)]), "JxlDecoderGetBoxSizeContents": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+            "JxlDecoderSetProgressiveDetail": (C.c_int, [vp, C.c_int]), "JxlDecoderFlushImage": (C.c_int, [vp]),
+            "JxlDecoderSetImageOutBitDepth": (C.c_int, [vp, C.POINTER(JxlBitDepth)]),
             "JxlHipLastError": (C.c_char_p, []), "JxlHipBatchCreate": (vp, [C.c_int]), "JxlHipBatchDestroy": (None, [vp]),
             "JxlHipBatchAddImage": (C.c_int, [vp, vp, sz]), "JxlHipBatchGetBasicInfo": (C.c_int, [vp, C.c_int, C.POINTER(JxlBasicInfo)]),
             "JxlHipBatchOutBufferSize": (C.c_int, [vp, C.c_int, C.POINTER(JxlPixelFormat), C.POINTER(sz)]),

@@ -41,6 +41,19 @@ BrotliDecompressFn LoadBrotli() {
   return fn;
 }
 
+}  // namespace
+bool BrotliDecompressAll(const uint8_t* data, size_t size, size_t limit, vec<uint8_t>* out) {
+  BrotliDecompressFn brotli = LoadBrotli();
+  if (!brotli) return false;
+  for (size_t cap = std::max<size_t>(4096, size * 4); ; cap *= 4) {
+    if (cap > limit) cap = limit;
+    out->resize(cap);
+    size_t got = cap;
+    if (brotli(size, data, &got, out->data()) == 1) { out->resize(got); return true; }     // (the one-shot API reports "output full" and "damaged" alike)
+    if (cap >= limit) { out->clear(); return false; }
+  }
+}
+namespace {
 const uint8_t kIccTag[12] = {'I', 'C', 'C', '_', 'P', 'R', 'O', 'F', 'I', 'L', 'E', 0};
 const uint8_t kExifTag[6] = {'E', 'x', 'i', 'f', 0, 0};
 const uint8_t kXmpTag[29] = {'h', 't', 't', 'p', ':', '/', '/', 'n', 's', '.', 'a', 'd', 'o', 'b', 'e', '.', 'c', 'o', 'm', '/', 'x', 'a', 'p', '/', '1', '.', '0', '/', 0};
@@ -156,7 +169,9 @@ bool ParseJbrd(const uint8_t* data, size_t size, JpegData* jd, std::string* err)
     for (uint32_t v : inter_sizes) announced += v;
     const size_t off0 = (r.p + 7) / 8;
     const uint64_t brotli_bytes = off0 < size ? size - off0 : 0;
-    if (announced > brotli_bytes * 1024 + 65536) return fail("announced marker data exceeds what the box can hold");
+    // (Brotli reaches ratios far beyond 1000:1 on zero-filled tails, so no ratio is assumed: an absolute bound on what is allocated, and the
+    // decompressed size has to match exactly below)
+    if (announced > ((uint64_t)1 << 30) || (announced > 0 && brotli_bytes == 0)) return fail("announced marker data exceeds what the box can hold");
   }
   jd->tail_data.resize(tail_len);
   for (uint32_t v : inter_sizes) jd->inter_marker_data.emplace_back(v);

@@ -58,4 +58,8 @@ bool FillJpegMetadata(JpegData* jd, const JpegMetadataSources& src, std::string*
 // Sequential (baseline / extended) and progressive (spectral selection, successive approximation, EOB runs) Huffman scans.
 bool WriteJpeg(const JpegData& jd, uint32_t width, uint32_t height, const int16_t* const* coeffs, vec<uint8_t>* out, std::string* err);
 
+// One-shot Brotli decompression of a stream whose plain size is not announced (container `brob` boxes): the output buffer grows until the
+// stream fits or `limit` bytes are exceeded.  False when the system has no libbrotlidec or the stream is damaged.
+bool BrotliDecompressAll(const uint8_t* data, size_t size, size_t limit, vec<uint8_t>* out);
+
 }  // namespace jxlhip

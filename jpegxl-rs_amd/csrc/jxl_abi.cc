@@ -2,6 +2,7 @@
 // Event state machine as exercised by jpegxl-rs/src/decode.rs:207-325 and jpegxl-sys/src/lib.rs:85-171.
 #include "../../include/jxl_hip.h"
 #include "decoder.h"
+#include "jpeg_recon.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -30,12 +31,26 @@ struct JxlDecoderStruct {
   void* preview_buffer; size_t preview_size; JxlPixelFormat preview_format; bool preview_set;   // JxlDecoderSetPreviewOutBuffer
   uint8_t* jpeg_buffer; size_t jpeg_size; bool jpeg_set;
   bool jpeg_available; size_t jpeg_written; vec<uint8_t> jpeg_bytes;   // JPEG bit-stream reconstruction (jbrd)
+  // JxlDecoderSetMultithreadedImageOutCallback
+  JxlImageOutInitCallback mt_init; JxlImageOutRunCallback mt_run; JxlImageOutDestroyCallback mt_destroy; void* mt_opaque;
+  // JxlDecoderSetExtraChannelBuffer (one entry per call, used up by the frame they were set for)
+  struct EcBuffer { uint32_t index; void* buffer; size_t size; JxlPixelFormat format; };
+  vec<EcBuffer> ec_buffers;
+  int progressive_detail;
+  // box API: the container as handed in (kept only when JXL_DEC_BOX is subscribed), its boxes in file order
+  struct BoxRec { char type[4], real[4]; uint64_t raw_size; size_t body, body_size; bool brob; };
+  bool decompress_boxes;
+  vec<uint8_t> container; vec<BoxRec> boxes;
+  size_t box_next, box_split; int box_current; bool box_complete_pending;
+  vec<uint8_t> box_plain; bool box_plain_ready; size_t box_written;
+  uint8_t* box_buffer; size_t box_size, box_buffer_written; bool box_set;
   // progress
   enum Stage { kInit, kHeaders, kFrame, kDone } stage;
   int events_emitted;
   bool started, need_out_reported;
   // frames as the caller counts them: every regular frame when coalescing is off, the composite (= the last frame) otherwise
   vec<int> frames; size_t frame_cursor, skip_frames; bool frame_announced;
+  bool frame_done;     // JXL_DEC_FULL_IMAGE of frames[frame_cursor] has been returned: its header stays readable until the next JxlDecoderProcessInput moves on
   Batch* batch;
   int device;
 };
@@ -61,7 +76,11 @@ static void ClearState(JxlDecoder* d) {
   d->jpeg_buffer = nullptr; d->jpeg_size = 0; d->jpeg_set = false;
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
-  d->frames.clear(); d->frame_cursor = 0; d->skip_frames = 0; d->frame_announced = false;
+  d->frames.clear(); d->frame_cursor = 0; d->skip_frames = 0; d->frame_announced = false; d->frame_done = false;
+  d->mt_init = nullptr; d->mt_run = nullptr; d->mt_destroy = nullptr; d->mt_opaque = nullptr;
+  d->ec_buffers.clear(); d->progressive_detail = 0;
+  d->decompress_boxes = false; d->container.clear(); d->boxes.clear(); d->box_next = d->box_split = 0; d->box_current = -1; d->box_complete_pending = false;
+  d->box_plain.clear(); d->box_plain_ready = false; d->box_written = 0; d->box_buffer = nullptr; d->box_size = d->box_buffer_written = 0; d->box_set = false;
   DeleteBatch(d->batch); d->batch = nullptr;
 }
 // frames JXL_DEC_FRAME / JXL_DEC_FULL_IMAGE are reported for
@@ -131,7 +150,7 @@ JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* d, JXL_BOOL v) { if (
 JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL v) { if (d->started) return JXL_DEC_ERROR; d->coalescing = !!v; return JXL_DEC_SUCCESS; }
 void JxlDecoderSkipFrames(JxlDecoder* d, size_t amount) { d->skip_frames += amount; }
 JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* d) {
-  if (d->stage != JxlDecoderStruct::kFrame || !d->frame_announced) return JXL_DEC_ERROR;
+  if (d->stage != JxlDecoderStruct::kFrame || !d->frame_announced || d->frame_done) return JXL_DEC_ERROR;
   d->frame_cursor++; d->frame_announced = false;
   return JXL_DEC_SUCCESS;
 }
@@ -140,7 +159,9 @@ void JxlDecoderRewind(JxlDecoder* d) {
   // (libjxl: "resets the decoder like JxlDecoderReset, but keeps all settings"; the input has to be set again)
   const int events = d->events_wanted; const bool ko = d->keep_orientation, up = d->unpremul_alpha, rs = d->render_spotcolors, co = d->coalescing;
   const float it = d->desired_intensity_target; const JxlParallelRunner runner = d->runner; void* const ro = d->runner_opaque;
+  const bool db = d->decompress_boxes; const int pd = d->progressive_detail;
   ClearState(d);
+  d->decompress_boxes = db; d->progressive_detail = pd;
   d->events_wanted = events; d->keep_orientation = ko; d->unpremul_alpha = up; d->render_spotcolors = rs; d->coalescing = co;
   d->desired_intensity_target = it; d->runner = runner; d->runner_opaque = ro;
 }
@@ -223,7 +244,16 @@ JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* d, size_t 
   FillBlendInfo(p.ec_blend[index], out);
   return JXL_DEC_SUCCESS;
 }
+// decode.rs:360-362.  libjxl tone-maps (Rec. 2408, then gamut mapping) when the target is below the intensity target of a PQ image, and applies the inverse
+// HLG OOTF for the new peak when an HLG image is rendered to another transfer function; everything else is unaffected by the setting.  The tone mapper is not
+// built here: the setting is stored, and a decode that WOULD need it fails with a message instead of handing out pixels that were not tone-mapped (NeedsToneMapping).
 JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder* d, float v) { if (v < 0) return JXL_DEC_ERROR; d->desired_intensity_target = v; return JXL_DEC_SUCCESS; }
+static bool NeedsToneMapping(const JxlDecoder* d) {
+  if (!(d->desired_intensity_target > 0) || !d->batch) return false;
+  const ImageHeader& ih = d->batch->image(0).ih;
+  if (!ih.xyb_encoded || ih.want_icc || ih.color_default || ih.have_gamma) return false;    // (only XYB images pass through the stage; sRGB / gamma curves never need it)
+  return ih.tf == 16 && d->desired_intensity_target < ih.intensity_target;                   // PQ image towards a dimmer display (HLG images are handed out as HLG: no OOTF change)
+}
 
 JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t size) {
   if (d->input_set) return JXL_DEC_ERROR;  // libjxl: "already set input, use JxlDecoderReleaseInput first"
@@ -380,6 +410,179 @@ JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorPro
   return JXL_DEC_SUCCESS;
 }
 
+// ---- decode.rs:1200: rows through init / run / destroy callbacks (one "thread": the caller's, after the image has been decoded on the device)
+JxlDecoderStatus JxlDecoderSetMultithreadedImageOutCallback(JxlDecoder* d, const JxlPixelFormat* format, JxlImageOutInitCallback init_cb, JxlImageOutRunCallback run_cb,
+                                                            JxlImageOutDestroyCallback destroy_cb, void* init_opaque) {
+  if (!d || !format || !init_cb || !run_cb || !destroy_cb || !d->batch || d->stage < JxlDecoderStruct::kHeaders) return JXL_DEC_ERROR;
+  if (d->out_set) { SetLastError("an output buffer or callback is already set"); return JXL_DEC_ERROR; }
+  size_t need = 0;
+  if (JxlDecoderImageOutBufferSize(d, format, &need) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  d->out_format = *format; d->out_buffer = nullptr; d->out_size = need; d->out_set = true;
+  d->mt_init = init_cb; d->mt_run = run_cb; d->mt_destroy = destroy_cb; d->mt_opaque = init_opaque;
+  return JXL_DEC_SUCCESS;
+}
+
+// ---- decode.rs:1224 / :1258: extra channels as planes of their own
+static int AlphaIndex(const ImageHeader& ih) { for (size_t i = 0; i < ih.extra.size(); i++) if (ih.extra[i].type == 0) return (int)i; return -1; }
+static bool EcSpec(const JxlDecoder* d, const JxlPixelFormat* format, uint32_t index, OutputSpec* o) {
+  if (!d || !d->batch || d->stage < JxlDecoderStruct::kHeaders) { SetLastError("extra channel buffers need the basic info"); return false; }
+  const ImageHeader& ih = d->batch->image(0).ih;
+  if (index >= ih.extra.size()) { SetLastError("no such extra channel"); return false; }
+  JxlPixelFormat one = *format; one.num_channels = 1;       // (num_channels of the format is ignored: one sample per pixel)
+  if (!FormatToSpec(&one, o)) return false;
+  o->keep_orientation = d->keep_orientation;
+  o->only_frame = d->coalescing ? -1 : CurrentFrame(d);
+  return true;
+}
+JxlDecoderStatus JxlDecoderExtraChannelBufferSize(const JxlDecoder* d, const JxlPixelFormat* format, size_t* size, uint32_t index) {
+  OutputSpec o;
+  if (!format || !size || !EcSpec(d, format, index, &o)) return JXL_DEC_ERROR;
+  // rows x stride of a one-sample-per-pixel buffer of the (oriented) image size
+  uint32_t w = 0, h = 0;
+  d->batch->OutputDims(0, o, &w, &h);
+  if (!d->keep_orientation && d->batch->image(0).ih.orientation > 4) std::swap(w, h);
+  const size_t bps = o.type == 0 ? 1 : o.type == 2 ? 4 : 2;
+  size_t stride = (size_t)w * bps;
+  if (o.align > 1) stride = (stride + o.align - 1) / o.align * o.align;
+  *size = stride * h;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* d, const JxlPixelFormat* format, void* buffer, size_t size, uint32_t index) {
+  JXL_MM_SCOPE(d);
+  size_t need = 0;
+  if (!buffer || JxlDecoderExtraChannelBufferSize(d, format, &need, index) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  if (size < need) { SetLastError("extra channel buffer too small"); return JXL_DEC_ERROR; }
+  if ((int)index != AlphaIndex(d->batch->image(0).ih)) {
+    SetLastError("unsupported: only the alpha channel can be delivered as a separate plane (the other extra channels are decoded and blended, but not handed out)");
+    return JXL_DEC_ERROR;
+  }
+  for (auto& e : d->ec_buffers) if (e.index == index) { e.buffer = buffer; e.size = size; e.format = *format; return JXL_DEC_SUCCESS; }
+  d->ec_buffers.push_back(JxlDecoderStruct::EcBuffer{index, buffer, size, *format});
+  return JXL_DEC_SUCCESS;
+}
+
+// ---- decode.rs:1482 / :1513 / :1528
+JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* d, int detail) {
+  if (!d || detail < 0 || detail > 3) { SetLastError("unsupported progressive detail (kFrames, kDC, kLastPasses, kPasses are accepted)"); return JXL_DEC_ERROR; }
+  d->progressive_detail = detail;        // (no JXL_DEC_FRAME_PROGRESSION is ever emitted: a frame is decoded whole once its bytes are there)
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* d) {
+  (void)d;
+  SetLastError("nothing to flush: frames are decoded whole on the device once their bytes are available");
+  return JXL_DEC_ERROR;                  // libjxl's answer when no new image data could be flushed
+}
+JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* d, const JxlBitDepth* bd) {
+  if (!d || !bd || !d->out_set) { SetLastError("JxlDecoderSetImageOutBitDepth: no image out buffer is set"); return JXL_DEC_ERROR; }
+  if (bd->type == 0) return JXL_DEC_SUCCESS;                                    // from the pixel format: what the write stage does
+  const uint32_t type_bits = d->out_format.data_type == JXL_TYPE_UINT8 ? 8 : d->out_format.data_type == JXL_TYPE_UINT16 ? 16 : 0;
+  if (type_bits == 0) {                                                         // float output carries no integer range
+    if (bd->type == 1 || (bd->type == 2 && bd->exponent_bits_per_sample > 0)) return JXL_DEC_SUCCESS;
+    SetLastError("an integer bit depth for a float buffer"); return JXL_DEC_ERROR;
+  }
+  const ImageHeader& ih = d->batch->image(0).ih;
+  const uint32_t bits = bd->type == 1 ? ih.depth.bits : bd->bits_per_sample;
+  if (bd->type != 1 && bd->type != 2) return JXL_DEC_ERROR;
+  if (bits == 0 || bits > type_bits) { SetLastError("bit depth does not fit the buffer's sample type"); return JXL_DEC_ERROR; }
+  if (bits == type_bits && !(bd->type == 1 && ih.depth.exp_bits) && !(bd->type == 2 && bd->exponent_bits_per_sample)) return JXL_DEC_SUCCESS;
+  SetLastError("unsupported: integer output is scaled to the full range of the buffer's type; a narrower range (bit depth from the codestream / custom) is not implemented");
+  return JXL_DEC_ERROR;
+}
+
+// ---- decode.rs:1326-1470: container boxes
+static void ScanBoxes(JxlDecoder* d) {
+  d->boxes.clear(); d->box_next = 0; d->box_split = 0; d->box_current = -1;
+  const uint8_t* data = d->container.data(); const size_t size = d->container.size();
+  size_t pos = 0; bool seen_cs = false;
+  while (pos + 8 <= size) {
+    uint64_t bs = ((uint64_t)data[pos] << 24) | ((uint64_t)data[pos + 1] << 16) | ((uint64_t)data[pos + 2] << 8) | data[pos + 3];
+    size_t hdr = 8;
+    if (bs == 1) { if (pos + 16 > size) break; bs = 0; for (int i = 0; i < 8; i++) bs = (bs << 8) | data[pos + 8 + i]; hdr = 16; if (bs < 16) break; }
+    else if (bs != 0 && bs < 8) break;
+    const size_t end = (bs == 0 || bs > (uint64_t)(size - pos)) ? size : pos + (size_t)bs;
+    JxlDecoderStruct::BoxRec b;
+    memcpy(b.type, data + pos + 4, 4); memcpy(b.real, b.type, 4);
+    b.raw_size = bs; b.body = pos + hdr; b.body_size = end - (pos + hdr);
+    b.brob = !memcmp(b.type, "brob", 4) && b.body_size >= 4;
+    if (b.brob) memcpy(b.real, data + b.body, 4);
+    d->boxes.push_back(b);
+    if (!seen_cs && (!memcmp(b.type, "jxlc", 4) || !memcmp(b.type, "jxlp", 4))) { seen_cs = true; d->box_split = d->boxes.size(); }
+    pos = end;
+  }
+  if (!seen_cs) d->box_split = d->boxes.size();
+}
+// content of the current box as the caller gets it: the payload, or — `brob` box with decompression on — the decompressed payload behind the 4-byte type
+static bool BoxContent(JxlDecoder* d, const uint8_t** src, size_t* n) {
+  const JxlDecoderStruct::BoxRec& b = d->boxes[(size_t)d->box_current];
+  if (!(b.brob && d->decompress_boxes)) { *src = d->container.data() + b.body; *n = b.body_size; return true; }
+  if (!d->box_plain_ready) {
+    if (!BrotliDecompressAll(d->container.data() + b.body + 4, b.body_size - 4, (size_t)1 << 30, &d->box_plain)) { SetLastError("brob box: Brotli stream damaged or libbrotlidec.so.1 not available"); return false; }
+    d->box_plain_ready = true;
+  }
+  *src = d->box_plain.data(); *n = d->box_plain.size();
+  return true;
+}
+// finishes the output of the current box, then announces the next one below `upto`; JXL_DEC_SUCCESS: nothing (more) to report
+static JxlDecoderStatus PumpBoxes(JxlDecoder* d, size_t upto) {
+  if (!(d->events_wanted & (JXL_DEC_BOX | JXL_DEC_BOX_COMPLETE))) return JXL_DEC_SUCCESS;
+  for (;;) {
+    if (d->box_current >= 0) {
+      if (d->box_set) {
+        const uint8_t* src; size_t n;
+        if (!BoxContent(d, &src, &n)) return JXL_DEC_ERROR;
+        const size_t k = std::min(n - d->box_written, d->box_size - d->box_buffer_written);
+        if (k) memcpy(d->box_buffer + d->box_buffer_written, src + d->box_written, k);
+        d->box_written += k; d->box_buffer_written += k;
+        if (d->box_written < n) return JXL_DEC_BOX_NEED_MORE_OUTPUT;
+      }
+      d->box_current = -1; d->box_plain.clear(); d->box_plain_ready = false;
+      if (d->events_wanted & JXL_DEC_BOX_COMPLETE) return JXL_DEC_BOX_COMPLETE;
+    }
+    if (d->box_next >= upto || d->box_next >= d->boxes.size()) return JXL_DEC_SUCCESS;
+    d->box_current = (int)d->box_next++; d->box_written = 0;
+    if (d->events_wanted & JXL_DEC_BOX) return JXL_DEC_BOX;
+  }
+}
+JxlDecoderStatus JxlDecoderSetBoxBuffer(JxlDecoder* d, uint8_t* data, size_t size) {
+  if (!d || d->box_set) { SetLastError("a box buffer is already set: JxlDecoderReleaseBoxBuffer first"); return JXL_DEC_ERROR; }
+  d->box_buffer = data; d->box_size = size; d->box_buffer_written = 0; d->box_set = true;
+  return JXL_DEC_SUCCESS;
+}
+size_t JxlDecoderReleaseBoxBuffer(JxlDecoder* d) {
+  if (!d || !d->box_set) return 0;
+  const size_t unused = d->box_size - d->box_buffer_written;
+  d->box_buffer = nullptr; d->box_size = d->box_buffer_written = 0; d->box_set = false;
+  return unused;
+}
+JxlDecoderStatus JxlDecoderSetDecompressBoxes(JxlDecoder* d, JXL_BOOL decompress) {
+  if (!d) return JXL_DEC_ERROR;
+  if (decompress) {
+    JXL_MM_SCOPE(d);
+    vec<uint8_t> probe;
+    const uint8_t empty[1] = {0x06};      // the Brotli stream of an empty output (WBITS 16, ISLAST, ISLASTEMPTY)
+    if (!BrotliDecompressAll(empty, 1, 4096, &probe)) { SetLastError("brob boxes cannot be decompressed: libbrotlidec.so.1 not available"); return JXL_DEC_ERROR; }
+  }
+  d->decompress_boxes = !!decompress;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetBoxType(JxlDecoder* d, JxlBoxType* type, JXL_BOOL decompressed) {
+  if (!d || !type || d->box_current < 0) { SetLastError("no box: the file does not use the container format, or no JXL_DEC_BOX event is current"); return JXL_DEC_ERROR; }
+  const JxlDecoderStruct::BoxRec& b = d->boxes[(size_t)d->box_current];
+  memcpy(type->type, decompressed ? b.real : b.type, 4);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetBoxSizeRaw(JxlDecoder* d, uint64_t* size) {
+  if (!d || !size || d->box_current < 0) return JXL_DEC_ERROR;
+  *size = d->boxes[(size_t)d->box_current].raw_size;       // as coded: header included, 0 = "to the end of the file"
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetBoxSizeContents(JxlDecoder* d, uint64_t* size) {
+  if (!d || !size || d->box_current < 0) return JXL_DEC_ERROR;
+  const JxlDecoderStruct::BoxRec& b = d->boxes[(size_t)d->box_current];
+  *size = b.raw_size == 0 ? 0 : b.body_size;               // (libjxl: 0 for a box of unbounded size)
+  return JXL_DEC_SUCCESS;
+}
+
 JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
   JXL_MM_SCOPE(d);
   d->started = true;
@@ -398,8 +601,13 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       d->batch = hold.b; hold.b = nullptr;
       d->stage = JxlDecoderStruct::kHeaders;
       ListFrames(d);
+      if ((d->events_wanted & (JXL_DEC_BOX | JXL_DEC_BOX_COMPLETE)) && d->batch->image(0).ih.have_container) {
+        d->container.assign(d->input, d->input + d->input_size);
+        ScanBoxes(d);
+      }
     }
     if (d->stage == JxlDecoderStruct::kHeaders) {
+      if (!d->boxes.empty()) { const JxlDecoderStatus bs = PumpBoxes(d, d->box_split); if (bs != JXL_DEC_SUCCESS) return bs; }   // boxes up to the first codestream box
       if ((d->events_wanted & JXL_DEC_BASIC_INFO) && !(d->events_emitted & JXL_DEC_BASIC_INFO)) { d->events_emitted |= JXL_DEC_BASIC_INFO; return JXL_DEC_BASIC_INFO; }
       if ((d->events_wanted & JXL_DEC_COLOR_ENCODING) && !(d->events_emitted & JXL_DEC_COLOR_ENCODING)) { d->events_emitted |= JXL_DEC_COLOR_ENCODING; return JXL_DEC_COLOR_ENCODING; }
       if ((d->events_wanted & JXL_DEC_PREVIEW_IMAGE) && !(d->events_emitted & JXL_DEC_PREVIEW_IMAGE) && d->batch->image(0).ih.have_preview) {
@@ -421,8 +629,9 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
     }
     while (d->stage == JxlDecoderStruct::kFrame) {
       // one round per frame the caller sees: the composite (coalescing, one round) or every regular frame as coded
+      if (d->frame_done) { d->frame_cursor++; d->frame_announced = false; d->frame_done = false; }     // (the frame reported last stayed current until now)
       while (d->skip_frames > 0 && d->frame_cursor < d->frames.size() && !d->frame_announced) { d->frame_cursor++; d->skip_frames--; }
-      if (d->frame_cursor >= d->frames.size()) { d->stage = JxlDecoderStruct::kDone; return JXL_DEC_SUCCESS; }
+      if (d->frame_cursor >= d->frames.size()) { d->stage = JxlDecoderStruct::kDone; break; }
       if ((d->events_wanted & JXL_DEC_FRAME) && !d->frame_announced) { d->frame_announced = true; d->events_emitted |= JXL_DEC_FRAME; return JXL_DEC_FRAME; }
       d->frame_announced = true;
       if (!(d->events_wanted & JXL_DEC_FULL_IMAGE)) { d->frame_cursor++; d->frame_announced = false; continue; }
@@ -455,6 +664,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         }
       }
       if (!d->out_set) return JXL_DEC_NEED_IMAGE_OUT_BUFFER;
+      if (NeedsToneMapping(d)) throw ParseError("unsupported: desired_intensity_target below the intensity target of a PQ image asks for libjxl's tone mapping stage, which this decoder does not have (leave the target at 0 to get the untouched PQ pixels)", true);
       OutputSpec o;
       FormatToSpec(&d->out_format, &o);
       o.keep_orientation = d->keep_orientation;
@@ -467,7 +677,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       d->batch->Prepare(nullptr);
       d->batch->Run(nullptr);       // ══► the HIP hot path
       d->batch->Finish(nullptr);
-      if (d->out_callback) {
+      if (d->out_callback || d->mt_run) {
         // callback output: the image is decoded as a whole on the device, then handed out row by row
         vec<uint8_t> host(d->batch->image(0).out_size);
         d->batch->CopyOutputToHost(0, host.data(), host.size(), nullptr);
@@ -475,14 +685,48 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         d->batch->OutputDims(0, d->batch->image(0).out, &w, &h);
         if (!d->keep_orientation && d->batch->image(0).ih.orientation > 4) std::swap(w, h);
         const size_t stride = d->batch->image(0).out_stride;
-        for (size_t y = 0; y < h; y++) d->out_callback(d->out_callback_opaque, 0, y, w, host.data() + y * stride);
+        if (d->mt_run) {
+          void* run_opaque = d->mt_init(d->mt_opaque, 1, w);
+          if (!run_opaque) throw ParseError("the image out init callback failed", false);
+          for (size_t y = 0; y < h; y++) d->mt_run(run_opaque, 0, 0, y, w, host.data() + y * stride);
+          d->mt_destroy(run_opaque);
+        } else for (size_t y = 0; y < h; y++) d->out_callback(d->out_callback_opaque, 0, y, w, host.data() + y * stride);
       } else d->batch->CopyOutputToHost(0, d->out_buffer, d->batch->image(0).out_size, nullptr);
-      d->frame_cursor++; d->frame_announced = false;
+      if (!d->ec_buffers.empty()) {
+        // the alpha plane on its own (JxlDecoderSetExtraChannelBuffer): a second pass of the frame with interleaved alpha in the plane's sample type, de-interleaved here
+        for (auto& eb : d->ec_buffers) {
+          OutputSpec oe = o;
+          JxlPixelFormat one = eb.format; one.num_channels = 1;
+          FormatToSpec(&one, &oe);
+          const bool grey = d->batch->image(0).ih.color_space == 1;
+          oe.num_channels = grey ? 2 : 4; oe.align = 0; oe.device_ptr = nullptr;
+          oe.keep_orientation = o.keep_orientation; oe.unpremul_alpha = false; oe.render_spotcolors = o.render_spotcolors; oe.only_frame = o.only_frame; oe.upto_frame = o.upto_frame;
+          d->batch->SetOutput(0, oe);
+          d->batch->Prepare(nullptr); d->batch->Run(nullptr); d->batch->Finish(nullptr);
+          vec<uint8_t> host(d->batch->image(0).out_size);
+          d->batch->CopyOutputToHost(0, host.data(), host.size(), nullptr);
+          uint32_t w = 0, h = 0;
+          d->batch->OutputDims(0, d->batch->image(0).out, &w, &h);
+          if (!d->keep_orientation && d->batch->image(0).ih.orientation > 4) std::swap(w, h);
+          const size_t bps = oe.type == 0 ? 1 : oe.type == 2 ? 4 : 2, nc = oe.num_channels, src_stride = d->batch->image(0).out_stride;
+          size_t dst_stride = (size_t)w * bps;
+          if (eb.format.align > 1) dst_stride = (dst_stride + eb.format.align - 1) / eb.format.align * eb.format.align;
+          if (dst_stride * h > eb.size) throw ParseError("extra channel buffer too small for this frame", false);
+          for (size_t y = 0; y < h; y++) {
+            const uint8_t* sp = host.data() + y * src_stride + (nc - 1) * bps;
+            uint8_t* dp = (uint8_t*)eb.buffer + y * dst_stride;
+            for (size_t x = 0; x < w; x++) memcpy(dp + x * bps, sp + x * nc * bps, bps);
+          }
+        }
+        d->ec_buffers.clear();
+      }
+      d->frame_done = true;         // (the cursor moves on with the next call: the frame's header, name and blend info stay readable after JXL_DEC_FULL_IMAGE)
       d->events_emitted |= JXL_DEC_FULL_IMAGE;
       // every layer gets a buffer of its own size; every frame of an animation is asked for anew (decode.cc: the buffer is used up by a frame)
-      if (!d->coalescing || d->frame_cursor < d->frames.size()) { d->out_set = false; d->out_buffer = nullptr; d->out_callback = nullptr; }
+      if (!d->coalescing || d->frame_cursor + 1 < d->frames.size()) { d->out_set = false; d->out_buffer = nullptr; d->out_callback = nullptr; d->mt_run = nullptr; }
       return JXL_DEC_FULL_IMAGE;
     }
+    if (!d->boxes.empty()) { const JxlDecoderStatus bs = PumpBoxes(d, d->boxes.size()); if (bs != JXL_DEC_SUCCESS) return bs; }   // the boxes behind the first codestream box
     return JXL_DEC_SUCCESS;
   } catch (const ParseError& e) {
     SetLastError(e.what());
