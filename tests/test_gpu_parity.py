@@ -343,6 +343,42 @@ def test_corrupted_round3_streams_fail_cleanly_or_decode(jx):
         check_against_oracle(jx, data, np.uint8, 3)
 
 
+def test_corrupted_round4_streams_fail_cleanly_or_decode(jx):
+    """The same bar for what round 4 added: LZ77-coded AC streams (single pass -> HfDecodeKernel, progressive -> the general SIMT instantiation; copy lengths
+    and distances are attacker-controlled), cjxl-shaped weighted-predictor LF trees on the SIMT LF kernel, and a container walked through the box API."""
+    from test_synth_roundtrip import lz77_ac_streams, cjxl_shape_streams
+    rng = np.random.default_rng(4321)
+    lz = lz77_ac_streams()
+    streams = [lz[0][1], lz[2][1], lz[3][1], lz[5][1], cjxl_shape_streams()[0][2], cjxl_shape_streams()[4][2]]
+    outcomes = {"error": 0, "decoded": 0}
+    for data in streams:
+        for trial in range(24):
+            bad = bytearray(data)
+            lo = 16 if trial % 3 else len(bad) // 3          # (two thirds of the trials hit anywhere, one third only the group sections)
+            for pos in rng.integers(lo, len(bad), 1 + trial % 4):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if trial % 8 == 7:
+                bad = bad[: int(rng.integers(len(bad) // 2, len(bad)))]
+            try:
+                meta, px = jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+                assert len(px) == meta.width * meta.height * (4 if meta.has_alpha_channel else 3)
+                outcomes["decoded"] += 1
+            except jx.DecodeError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 0 and outcomes["error"] + outcomes["decoded"] == 24 * len(streams)
+    check_against_oracle(jx, lz[0][1], np.uint8, 3)          # the decoder is still healthy afterwards
+    # a batch in which one LZ77 frame is damaged: the others decode
+    bad = bytearray(lz[2][1]); bad[len(bad) * 2 // 3] ^= 0x55
+    b = jx.BatchDecoder(0)
+    b.add(lz[0][1], "uint8", 3); b.add(bytes(bad), "uint8", 3); b.add(lz[3][1], "uint8", 3)
+    b.prepare(); b.decode()
+    try:
+        b.finish()
+    except jx.DecodeError:
+        pass
+    assert np.array_equal(b.output(0), O.decode(lz[0][1]).pixels("u8", 3)) and np.array_equal(b.output(2), O.decode(lz[3][1]).pixels("u8", 3))
+
+
 def test_prefix_coded_progressive_and_subsampled_frames(jx):
     """Prefix-coded AC streams of progressive frames (several passes, each with its own code and orders) and of chroma-subsampled YCbCr frames (what a
     fast-effort JPEG recompression looks like): walked by the general instantiation of HfDecodeSimtKernel with the bit-serial canonical-code reader.
