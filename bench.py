@@ -230,8 +230,11 @@ class Pipeline:
 
     _streams = {}
 
-    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming):
+    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer="gather"):
         self.args, self.jx, self.torch, self.dist, self.streams = args, jx, torch, dist, streams
+        # who consumes the decoded pixels: "gather" = rank 0 (RCCL point-to-point gather, north_star's mode); "per_rank" = every rank its own frames, in place
+        # in HBM (a reduction over the pixels stands in for the consumer; the ranks only exchange the 8-byte checksums at the end of the run)
+        self.consumer = consumer
         self.dev, self.local_rank, self.rank, self.world, self.B, self.inner, self.streaming = dev, local_rank, rank, world, B, inner, streaming
         self.stream_texture, self.stream_tree_shape = args.main_texture, args.main_tree_shape    # how `streams` were made (verify() regenerates other ranks' frames)
         W, H = args.width, args.height
@@ -268,7 +271,9 @@ class Pipeline:
                 bt.share_coefficients(self.batches[b % self.ncoef])
             bt.prepare(self.stream)
             self.batches.append(bt)
-        self.do_gather = world > 1 and not args.no_gather
+        self.do_gather = world > 1 and not args.no_gather and consumer == "gather"
+        self.consume_local = consumer == "per_rank"
+        self.checksum = torch.zeros((), dtype=torch.int64, device=dev)
         self.gathered = torch.empty((world, inner * B, H, W, 3), dtype=torch.uint8, device=dev) if self.do_gather and rank == 0 else None
         E = torch.cuda.Event
         # (HIP streams are made once per process and handed to every pipeline: the runtime spreads streams over GPU_MAX_HW_QUEUES hardware
@@ -280,7 +285,7 @@ class Pipeline:
             return Pipeline._streams[key]
         lf_prio = (lambda i: -1 if i == 0 else 0) if os.environ.get("JXL_BENCH_LF_PRIO") == "first" else (lambda i: -1)   # experiment: only the stream of the first cold LF stage is a high-priority one
         self.sides = [S("lf", i, lf_prio(i)) for i in range(max(1, min(self.ahead, args.lf_streams)))] if self.pipeline else []
-        self.comm = S("comm", 0) if self.do_gather else None            # RCCL gather overlaps the next step's decode
+        self.comm = S("comm", 0) if (self.do_gather or self.consume_local) else None            # RCCL gather / local consumer overlaps the next step's decode
         self.hf_streams = [S("hf", i, -1) for i in range(self.nhf)]
         self.filter_stream = S("filter", 0) if self.ntail > 1 else None
         self.copy_streams = [S("copy", i) for i in range(max(1, args.prepare_threads))] if streaming else []
@@ -371,7 +376,7 @@ class Pipeline:
             if self.deep:
                 main.wait_event(self.hf_done[b])
             main.wait_event(self.front_done[b])
-            if self.do_gather and st["gathers"] >= self.nout:
+            if (self.do_gather or self.consume_local) and st["gathers"] >= self.nout:
                 main.wait_event(self.out_free[k % self.nout])   # the previous gather of this output buffer must have read the pixels
             if self.ntail > 1 and k >= self.ntail:
                 main.wait_event(self.rest_done[(k - self.ntail) % self.nbuf])   # the plane set's previous user has written its pixels
@@ -381,13 +386,21 @@ class Pipeline:
                 fs = self.filter_stream
                 with torch.cuda.stream(fs):
                     fs.wait_event(self.idct_done[b])
-                    if self.do_gather and st["gathers"] >= self.nout:
+                    if (self.do_gather or self.consume_local) and st["gathers"] >= self.nout:
                         fs.wait_event(self.out_free[k % self.nout])
                     self.batches[b].decode_part(8, fs.cuda_stream, timed)
                     self.rest_done[b].record(fs)
             else:
                 self.batches[b].decode_part(8, self.stream, timed)     # restoration filters, colour, write
                 self.rest_done[b].record(main)
+        if self.consume_local:
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.rest_done[b])
+                self.checksum += self.outs[k % self.nout].view(-1).view(torch.int32).sum(dtype=torch.int64)     # every decoded byte is read once, where it was written
+                self.out_free[k % self.nout].record(self.comm)
+            st["gathers"] += 1
+            if not self.pipeline:
+                main.wait_event(self.out_free[k % self.nout])
         if self.do_gather:
             from jpegxl_rs_amd.sharding import gather_frames_chunked
             with torch.cuda.stream(self.comm):
@@ -405,10 +418,12 @@ class Pipeline:
         torch, dist = self.torch, self.dist
         st = {"front_issued": 0, "hf_issued": 0, "prep_submitted": 0, "limit": nsteps, "gathers": 0, "futures": {}}
         self.prepare_s = []
+        self.checksum.zero_()
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        cpu0 = time.process_time()
         t_start = torch.cuda.Event(enable_timing=True); t_start.record(self.main)
         marks = []
         t0 = time.perf_counter()
@@ -419,11 +434,15 @@ class Pipeline:
         if self.filter_stream is not None:
             self.filter_stream.synchronize()
         t_decode = time.perf_counter() - t0          # every rank's own decode work is done (the gather may still be running)
+        if self.consume_local and self.world > 1:
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(self.checksum)         # checksum of checksums: the only bytes that cross xGMI in this mode
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        self.cpu_s = time.process_time() - cpu0       # host CPU seconds of this rank's process over the run (all threads: parse, prepare, enqueue)
         return elapsed, [round(t_start.elapsed_time(e), 1) for e in marks], t_decode
 
     def verify(self, nsteps, O, np):
@@ -482,6 +501,7 @@ def main():
     ap.add_argument("--lane-stride-hf", type=int, default=int(os.environ.get("JXL_LANE_STRIDE_HF", "1")),
                     help="1 = SIMT HF decode (one group stream per lane), 64 = one stream per wavefront")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
+    ap.add_argument("--per-rank-consumers", action="store_true", help="N = 1: also run the per-rank-consumer leg that N > 1 runs beside the gather (a reduction over the decoded pixels per step)")
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
     ap.add_argument("--in-flight", type=int, default=11, help="batches in flight on the GPU (pipelined): LF stages run this many steps ahead, minus one")
@@ -549,9 +569,9 @@ def main():
         B = min(args.batch, per_rank)
         inner = max(1, per_rank // B)
 
-    def measure(streaming, streams=streams, texture=args.main_texture, tree_shape=args.main_tree_shape):
+    def measure(streaming, streams=streams, texture=args.main_texture, tree_shape=args.main_tree_shape, consumer="gather"):
         """one mode: W untimed warm-up steps, then exactly K timed steps from an empty pipeline, bracketed by barrier + synchronize"""
-        p = Pipeline(args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming)
+        p = Pipeline(args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer)
         p.stream_texture, p.stream_tree_shape = texture, tree_shape
         p.run(args.warmup * inner, False)
         for bt in p.batches:
@@ -560,10 +580,14 @@ def main():
         elapsed, step_end, t_decode = p.run(args.steps * inner, True)
         for bt in p.batches:
             bt.finish(p.stream)
+        cpu_s = p.cpu_s
         if world > 1:
             t = torch.tensor([elapsed, t_decode], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, t_decode = float(t[0].item()), float(t[1].item())
+            c = torch.tensor([cpu_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)       # host CPU seconds of all ranks (they share one host)
+            cpu_s = float(c[0].item())
         times, runs = {}, 0
         for bt in p.batches:
             t_, r_ = bt.collect_times()
@@ -572,7 +596,7 @@ def main():
                 times[kk] = times.get(kk, 0.0) + vv
         r = {"elapsed": elapsed, "t_decode": t_decode, "step_end": step_end, "stage_ms": {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"},
              "stage_bytes": p.batches[0].stage_bytes, "device_bytes": sum(bt.device_bytes for bt in p.batches), "compressed": int(p.batches[0].compressed_bytes // B),
-             "nbuf": p.nbuf, "prepare_s": list(p.prepare_s), "gather": bool(p.do_gather), "pipelined": bool(p.pipeline),
+             "nbuf": p.nbuf, "prepare_s": list(p.prepare_s), "gather": bool(p.do_gather), "pipelined": bool(p.pipeline), "cpu_s": cpu_s, "checksum": int(p.checksum.item()),
              "nonzeros": p.batches[0].info_value("hf_nonzeros") // B,
              "lf_simt": [p.batches[0].info_value(k) for k in ("lf_simt_frames", "lf_legacy_frames", "lf_simt_wp")]}
         if not args.no_verify and rank == 0:
@@ -590,6 +614,8 @@ def main():
     if args.texture > 0 and not args.no_realistic and realistic_streams:
         realistic = measure(modes[0] == "streaming", realistic_streams, args.texture, 0)
     cjxl = measure(modes[0] == "streaming", cjxl_streams, args.texture, 1) if cjxl_streams else None
+    # N > 1: the same job with per-rank consumers beside the gather to rank 0 (7 peers x ~80 GB/s of pixels into one GPU's xGMI links bound the gather)
+    local_leg = measure(modes[0] == "streaming", consumer="per_rank") if (world > 1 or args.per_rank_consumers) and not args.no_gather else None
     if rank == 0:
         total_px = world * B * inner * W * H * args.steps
         rate = lambda r: total_px / r["elapsed"] / 1e6
@@ -673,6 +699,16 @@ def main():
                 "stage_ms": {k: round(v, 4) for k, v in cjxl["stage_ms"].items()}, "compressed_bytes_per_frame": cjxl["compressed"],
                 "bits_per_pixel": round(cjxl["compressed"] * 8 / (W * H), 3), "lf_simt_frames": cjxl["lf_simt"][0], "lf_legacy_frames": cjxl["lf_simt"][1],
                 "lf_simt_weighted_predictor_kernel": bool(cjxl["lf_simt"][2]), "distinct_frames": len(cjxl_streams), "verified_vs_oracle": cjxl.get("verified")}
+        frames_total = world * B * inner * args.steps
+        result["host_cpu"] = {"cpu_s_per_frame": round(head["cpu_s"] / frames_total, 6), "cores_busy": round(head["cpu_s"] / head["elapsed"], 2),
+                              "what": "process CPU time of all ranks over the timed steps (parse + prepare + upload + enqueue threads) per decoded frame; cores_busy = CPU seconds per wall second: "
+                                      "what one host has to supply for this rate (the ranks of a node share its cores)"}
+        if local_leg is not None:
+            result["per_rank_consumers"] = {
+                "what": "the same job with every rank consuming its own frames where they were decoded (a reduction over the pixels on a side stream stands in for the consumer; the ranks exchange "
+                        "only the 8-byte checksums at the end): the rate a sharded consumer sees, beside `value` = everything gathered into rank 0 over xGMI",
+                "value": round(rate(local_leg), 2), "unit": "Mpixel/s", "ms_per_step": round(local_leg["elapsed"] / args.steps * 1e3, 3), "checksum_of_checksums": local_leg["checksum"],
+                "verified_vs_oracle": local_leg.get("verified"), "host_cpu_s_per_frame": round(local_leg["cpu_s"] / frames_total, 6)}
         if world > 1:
             result["decode_only_mpixel_per_s"] = round(total_px / head["t_decode"] / 1e6, 2)     # until every rank's own decode work was done
             result["gather_ms"] = round((head["elapsed"] - head["t_decode"]) * 1e3, 2)             # what the pixel gather added after that

@@ -66,3 +66,51 @@ def gather_frames_chunked(local, out=None, dst: int = 0, chunk_frames: int = 32,
             for b, r in zip(bufs, peers):
                 out[r][c0:c1].copy_(b)
     return out if rank == dst else None
+
+
+def gather_frames_ragged(local, sizes, out=None, dst: int = 0, chunk_frames: int = 32, group=None):
+    """The gather for shards of unequal length (shard_sizes: 1024 frames over 3, 5, 6 or 7 GPUs): rank r holds `sizes[r]` frames, rank `dst` receives
+    them in rank order into `out` ([sum(sizes), ...]; allocated when None) — the frame order of the unsharded job.  Point-to-point chunks like
+    gather_frames_chunked; a peer whose shard is exhausted simply has no transfer in the later rounds.  Returns `out` on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [int(v) for v in sizes]
+    if len(sizes) != world or local.shape[0] != sizes[rank]:
+        raise ValueError("sizes must list every rank's shard length, and this rank's shard must have its length")
+    offs = [sum(sizes[:r]) for r in range(world)]
+    total = sum(sizes)
+    chunk_frames = max(1, int(chunk_frames))
+    if rank == dst:
+        if out is None:
+            out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        if tuple(out.shape) != (total,) + tuple(local.shape[1:]) or out.dtype != local.dtype:
+            raise ValueError("gather destination must be [sum(sizes), *frame shape] of the same dtype")
+        if sizes[dst]:
+            out[offs[dst]:offs[dst] + sizes[dst]].copy_(local, non_blocking=True)
+    staged = local.is_cuda and dist.get_backend(group) == "gloo"
+    for c0 in range(0, max(sizes) if sizes else 0, chunk_frames):
+        ops, bufs = [], []
+        if rank == dst:
+            for r in range(world):
+                c1 = min(sizes[r], c0 + chunk_frames)
+                if r == dst or c1 <= c0:
+                    continue
+                view = out[offs[r] + c0:offs[r] + c1]
+                buf = torch.empty(view.shape, dtype=local.dtype) if staged else view
+                bufs.append((buf, view))
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        else:
+            c1 = min(sizes[rank], c0 + chunk_frames)
+            if c1 > c0:
+                if staged:
+                    torch.cuda.current_stream().synchronize()
+                ops.append(dist.P2POp(dist.isend, local[c0:c1].cpu() if staged else local[c0:c1], dst, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if staged:
+            for buf, view in bufs:
+                view.copy_(buf)
+    return out if rank == dst else None

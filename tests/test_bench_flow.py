@@ -41,6 +41,10 @@ def test_two_ranks_share_one_gpu_and_gather(jx, mode):
     assert any(v.startswith("rank1:") for v in d["verified_frames"])           # pixels of the other rank's shard, as gathered at rank 0
     assert d["gather_ms"] >= 0 and d["decode_only_mpixel_per_s"] >= d["value"] > 0
     assert abs(d["value"] - 2 * 16 * 512 * 384 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) < 0.01 * d["value"]   # whole-job pixels over the max-over-ranks time
+    # the per-rank-consumer leg beside the gather: its own rate, the checksum of checksums of both ranks' pixels, and the host CPU budget of the job
+    pr = d["per_rank_consumers"]
+    assert pr["value"] > 0 and pr["verified_vs_oracle"] is True and pr["checksum_of_checksums"] != 0
+    assert d["host_cpu"]["cpu_s_per_frame"] > 0 and d["host_cpu"]["cores_busy"] > 0
 
 
 def test_config3_per_gpu_share(jx):

@@ -61,3 +61,51 @@ def test_two_rank_shard_and_gather(built, tmp_path):
         img = S.synthetic_image(100 + i, 64, 48)
         ref = O.decode(S.encode_vardct(img, seed=100 + i, strategy_mix=1)).image("u8", 3)
         assert np.array_equal(got[i], ref)
+
+
+def _worker4(rank, world, port, nframes, tmp):
+    """four ranks, ragged shards (10 frames -> 3, 3, 2, 2): the frame order of the unsharded job comes back at rank 0; the checksum of checksums of the
+    per-rank-consumer mode (bench.py Pipeline.consume_local) equals the checksum of the gathered job"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    import synth_lib as S
+    from jpegxl_rs_amd.sharding import shard_range, shard_sizes, gather_frames_ragged
+    sizes = shard_sizes(nframes, world)
+    b, e = shard_range(nframes, world, rank)
+    assert e - b == sizes[rank] and sum(sizes) == nframes
+    frames = [O.decode(S.encode_vardct(S.synthetic_image(300 + i, 48, 40), seed=300 + i, strategy_mix=0)).image("u8", 3) for i in range(b, e)]
+    local = torch.from_numpy(np.stack(frames))
+    for chunk in (1, 2, 8):
+        out = gather_frames_ragged(local, sizes, None, dst=0, chunk_frames=chunk)
+        assert (out is None) == (rank != 0)
+        if rank == 0:
+            np.save(os.path.join(tmp, "ragged%d.npy" % chunk), out.numpy())
+    with pytest.raises(ValueError):
+        gather_frames_ragged(local[:-1] if local.shape[0] > 1 else torch.cat([local, local]), sizes, None, dst=0)
+    # per-rank consumers: every rank reduces its own pixels, one all-reduce of the 8-byte checksums
+    padded = np.zeros((local.numel() + 3) // 4 * 4, np.uint8); padded[:local.numel()] = local.numpy().reshape(-1)
+    chk = torch.tensor(int(padded.view(np.int32).astype(np.int64).sum()), dtype=torch.int64)
+    dist.all_reduce(chk)
+    if rank == 0:
+        np.save(os.path.join(tmp, "checksum.npy"), np.array([chk.item()]))
+    dist.destroy_process_group()
+
+
+def test_four_ranks_ragged_shards_and_per_rank_checksums(built, tmp_path):
+    import oracle_lib as O
+    import synth_lib as S
+    from jpegxl_rs_amd.sharding import shard_range
+    world, nframes, port = 4, 10, 31500 + os.getpid() % 2000
+    mp.spawn(_worker4, args=(world, port, nframes, str(tmp_path)), nprocs=world, join=True)
+    ref = np.stack([O.decode(S.encode_vardct(S.synthetic_image(300 + i, 48, 40), seed=300 + i, strategy_mix=0)).image("u8", 3) for i in range(nframes)])
+    for chunk in (1, 2, 8):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "ragged%d.npy" % chunk)), ref), chunk
+    want = 0
+    for r in range(world):
+        b, e = shard_range(nframes, world, r)
+        flat = ref[b:e].reshape(-1)
+        padded = np.zeros((flat.size + 3) // 4 * 4, np.uint8); padded[:flat.size] = flat
+        want += int(padded.view(np.int32).astype(np.int64).sum())
+    assert int(np.load(os.path.join(str(tmp_path), "checksum.npy"))[0]) == want
