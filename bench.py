@@ -230,7 +230,7 @@ class Pipeline:
 
     _streams = {}
 
-    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer="gather"):
+    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer="gather", depth=None):
         self.args, self.jx, self.torch, self.dist, self.streams = args, jx, torch, dist, streams
         # who consumes the decoded pixels: "gather" = rank 0 (RCCL point-to-point gather, north_star's mode); "per_rank" = every rank its own frames, in place
         # in HBM (a reduction over the pixels stands in for the consumer; the ranks only exchange the 8-byte checksums at the end of the run)
@@ -241,7 +241,10 @@ class Pipeline:
         self.frame_bytes = W * H * 3
         self.pipeline = not args.no_pipeline
         self.deep = self.pipeline and os.environ.get("JXL_BENCH_DEEP", "1") == "1"
-        nbuf = int(os.environ.get("JXL_BENCH_NBUF", str(args.in_flight))) if self.pipeline else 1
+        # depth = (batches in flight, LF side streams): as many LF stages in flight as it takes to cover one LF launch with steps (weighted-predictor LF streams
+        # take ~2x the time per launch of gradient-tree ones: their pipeline is deeper)
+        in_flight, lf_streams = depth if depth else (args.in_flight, args.lf_streams)
+        nbuf = int(os.environ.get("JXL_BENCH_NBUF", str(in_flight))) if self.pipeline else 1
         self.nhf = max(1, args.hf_streams) if self.deep else 0        # HF stages in flight beside the tail of the step (each on its own stream)
         self.ncoef = self.nhf + 1                                      # coefficient sets: one per HF stage in flight + the one the tail is consuming
         self.ahead = nbuf - 1 if self.pipeline else 0                  # LF stages issued ahead of the step being finished
@@ -284,7 +287,7 @@ class Pipeline:
                 Pipeline._streams[key] = torch.cuda.Stream(device=dev, priority=priority)
             return Pipeline._streams[key]
         lf_prio = (lambda i: -1 if i == 0 else 0) if os.environ.get("JXL_BENCH_LF_PRIO") == "first" else (lambda i: -1)   # experiment: only the stream of the first cold LF stage is a high-priority one
-        self.sides = [S("lf", i, lf_prio(i)) for i in range(max(1, min(self.ahead, args.lf_streams)))] if self.pipeline else []
+        self.sides = [S("lf", i, lf_prio(i)) for i in range(max(1, min(self.ahead, lf_streams)))] if self.pipeline else []
         self.comm = S("comm", 0) if (self.do_gather or self.consume_local) else None            # RCCL gather / local consumer overlaps the next step's decode
         self.hf_streams = [S("hf", i, -1) for i in range(self.nhf)]
         self.filter_stream = S("filter", 0) if self.ntail > 1 else None
@@ -506,6 +509,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
     ap.add_argument("--in-flight", type=int, default=11, help="batches in flight on the GPU (pipelined): LF stages run this many steps ahead, minus one")
     ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
+    ap.add_argument("--wp-in-flight", type=int, default=14, help="batches in flight for workloads whose LF streams use the weighted predictor (LF stage ~700 ms per launch instead of ~370)")
+    ap.add_argument("--wp-lf-streams", type=int, default=10, help="LF side streams for those workloads")
     ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current step (deep pipeline), one stream and one coefficient set each")
     ap.add_argument("--tail-streams", type=int, default=int(os.environ.get("JXL_BENCH_TAIL_STREAMS", "1")), help="2: the filter stage of a batch on its own stream beside the IDCT of the next (two sets of pixel planes)")
     ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
@@ -571,7 +576,8 @@ def main():
 
     def measure(streaming, streams=streams, texture=args.main_texture, tree_shape=args.main_tree_shape, consumer="gather"):
         """one mode: W untimed warm-up steps, then exactly K timed steps from an empty pipeline, bracketed by barrier + synchronize"""
-        p = Pipeline(args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer)
+        depth = (args.wp_in_flight, args.wp_lf_streams) if tree_shape == 1 and not args.no_pipeline else None
+        p = Pipeline(args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer, depth)
         p.stream_texture, p.stream_tree_shape = texture, tree_shape
         p.run(args.warmup * inner, False)
         for bt in p.batches:
@@ -698,7 +704,8 @@ def main():
                 "steady_state_ms_per_step": round((ce_[n_c * 2 // 3] - ce_[n_c // 5]) / max(1, n_c * 2 // 3 - n_c // 5), 2) if n_c >= 10 else None,
                 "stage_ms": {k: round(v, 4) for k, v in cjxl["stage_ms"].items()}, "compressed_bytes_per_frame": cjxl["compressed"],
                 "bits_per_pixel": round(cjxl["compressed"] * 8 / (W * H), 3), "lf_simt_frames": cjxl["lf_simt"][0], "lf_legacy_frames": cjxl["lf_simt"][1],
-                "lf_simt_weighted_predictor_kernel": bool(cjxl["lf_simt"][2]), "distinct_frames": len(cjxl_streams), "verified_vs_oracle": cjxl.get("verified")}
+                "lf_simt_weighted_predictor_kernel": bool(cjxl["lf_simt"][2]), "distinct_frames": len(cjxl_streams), "verified_vs_oracle": cjxl.get("verified"),
+                "batches_in_flight": cjxl["nbuf"], "lf_streams": args.wp_lf_streams}
         frames_total = world * B * inner * args.steps
         result["host_cpu"] = {"cpu_s_per_frame": round(head["cpu_s"] / frames_total, 6), "cores_busy": round(head["cpu_s"] / head["elapsed"], 2),
                               "what": "process CPU time of all ranks over the timed steps (parse + prepare + upload + enqueue threads) per decoded frame; cores_busy = CPU seconds per wall second: "

@@ -341,6 +341,9 @@ static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
 #ifndef JXL_LF_MINW
 #define JXL_LF_MINW 3      // LfDecodeKernel<true>: VGPR budget 512 / JXL_LF_MINW per lane (170: three IDCT or six filter wavefronts fit beside it)
 #endif
+#ifndef JXL_IDCT_T4
+#define JXL_IDCT_T4 128   // threads of an IdctTileKernel<4> workgroup (A/B knob: 256 = four wavefronts share the 14 KB tile)
+#endif
 #ifndef JXL_IDCT_MINW
 #define JXL_IDCT_MINW 4    // IdctTileKernel<4>: likewise
 #endif
@@ -3079,7 +3082,7 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
 // SPECIAL = the variant for frames that contain the 8x8 "special" transforms (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4):
 // their 64-coefficient register blocks cost 30 VGPRs that the plain variant does not have to carry (the LF stage flags
 // the frames; which variants a batch needs is known after its first decode).
-template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL_IDCT_T4, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || f.subsampled || (*f.frame_flags & 1) != 0 || (force_generic & 3)) return;
@@ -3121,7 +3124,7 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : 128
   if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
   if (threadIdx.x == 0) s_next = 0;
   __syncthreads();
-  constexpr int kQ = kNB * 8 / (TB == 8 ? 256 : 128);   // candidate row/column tasks per thread
+  constexpr int kQ = (kNB * 8 + (TB == 8 ? 256 : JXL_IDCT_T4) - 1) / (TB == 8 ? 256 : JXL_IDCT_T4);   // candidate row/column tasks per thread
   uint32_t my_rclass[kQ], my_cclass[kQ];
   for (int q = 0; q < kQ; q++) {
     const uint32_t tt = threadIdx.x + q * blockDim.x;
@@ -4462,8 +4465,8 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     const int tiles_x = DivUp(max_bw, 4), tiles_y = DivUp(max_bh, 4);
     const dim3 grid(tiles_x * tiles_y, nframes);
     const size_t lds = 3 * TileGeom<4>::kPlane * sizeof(float);
-    if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
-    if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(128), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct | nocoef);
+    if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(JXL_IDCT_T4), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+    if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(JXL_IDCT_T4), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct | nocoef);
   }
   if (cfg.any_subsampled) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
   // one wavefront per group: a group holds a few dozen of these blocks (x 3 channels, one lane each), three more wavefronts per workgroup
