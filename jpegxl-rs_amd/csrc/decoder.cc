@@ -689,6 +689,7 @@ int64_t Batch::Info(const std::string& name) const {
     return name == "lf_simt_frames" ? simt : legacy;
   }
   if (name == "hf_nonzeros") { int64_t t = 0; for (uint32_t v : hf_written_) t += v; return t; }   // non-zero AC coefficients per decode of the batch (known after a Finish)
+  if (name == "mod_group_lds_bytes") return prepared_ ? (int64_t)ModularGroupLdsBytes(cfg) : -1;
   if (name == "lf_simt_lanes") return lf_simt_.num_lanes;
   if (name == "lf_simt_wp") return lf_simt_.num_lanes ? lf_simt_.any_wp : 0;     // the SIMT launch is the weighted-predictor instantiation
   if (!images_.empty() && !images_[0]->plan.modular) {   // geometry / quantiser of the first frame (tests that restate a stage from its defining formula)
@@ -1421,7 +1422,7 @@ static void DebugSync(const char* what, void* stream) {
   if (!on) return;
   fprintf(stderr, "[jxl-hip] %s ...", what); fflush(stderr);
   const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-  fprintf(stderr, " %s\n", hipGetErrorString(e)); fflush(stderr);
+  fprintf(stderr, " %s (launch status: %s)\n", hipGetErrorString(e), hipGetErrorString(hipPeekAtLastError())); fflush(stderr);
 }
 
 void Batch::Run(void* stream_v) { RunPart(stream_v, 0, false); }
@@ -1432,9 +1433,14 @@ void Batch::EnqueueModularTail(void* stream_v) {
   const int n = (int)images_.size();
   int max_units = 1;
   for (auto& im : images_) max_units = std::max<int>(max_units, (int)im->plan.NumModUnits());
+  static const bool dbg = getenv("JXL_HIP_DEBUG_SYNC") != nullptr;
+  auto check = [&](const char* what, int kind) { if (!dbg) return; const hipError_t e = hipGetLastError(); if (e != hipSuccess) fprintf(stderr, "[jxl-hip] launch of %s (%d) rejected: %s\n", what, kind, hipGetErrorString(e)); };
+  check("(before the Modular tail)", -1);
   LaunchModularGroups(dframes_, n, max_units, cfg, stream_v);
+  check("ModularGroupFastKernel", max_units);
   for (int i = 0; i < n; i++) {
     for (const ModOp& op : mod_ops_[i]) {
+      check("Modular tail op before", (int)op.kind);
       auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
       switch (op.kind) {
         case ModOp::kRct: LaunchModRct(P(op.in[0]), P(op.in[1]), P(op.in[2]), op.n, op.param, stream_v); break;
@@ -1890,12 +1896,20 @@ void Batch::RunTimed(void* stream_v) { RunPart(stream_v, 0, true); }
 // part 0 = whole decode, 1 = front (coefficient clear + LF decode + LF post-processing), 2 = rest (HF decode, IDCT,
 // filters, output).  Front and rest of one decode may be enqueued on different streams (ordered by the caller with
 // events) so that the latency-bound LF stage of the next batch overlaps the bandwidth stages of the current one.
+// A launch the runtime refuses (too much LDS, an empty grid ...) does not fail at the call site: it leaves an error code that the next runtime call of the thread
+// reports — possibly somebody else's.  Every enqueued part ends with this check, so that such a launch fails the decode it belongs to, by name.
+static void CheckLaunches(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw ParseError(std::string("kernel launch rejected by the runtime (") + what + "): " + hipGetErrorString(e), false);
+}
+
 void Batch::RunPart(void* stream_v, int part, bool timed) {
   // part 0 = whole decode, 1 = front (LF decode + LF post-processing), 2 = rest (HF decode, IDCT, filters, output);
   // the rest can be enqueued in two pieces, 3 = HF decode only, 4 = everything after it, so that a caller can record an
   // event between them (bench.py starts the LF stage of a later batch when an HF stage has ended, not when it starts).
   hipStream_t stream = (hipStream_t)stream_v;
   if (!prepared_) Prepare(stream_v);
+  (void)hipGetLastError();          // (whatever an earlier runtime call of this thread left unread is not this decode's)
   const int n = (int)images_.size();
   if (any_vardct_) CheckFilterBuffers();
   // The front, too, comes in two pieces: 5 = LF decode (what the HF stage needs: block info, varblock lists, coefficient offsets),
@@ -1930,6 +1944,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     if (any_vardct_) LaunchLfDecode(dframes_, n, max_lf_groups_, cfg, stream_v, &lf_simt_);
     cfg.lf_wide_once = 0;
     DebugSync("LF decode", stream_v);
+    CheckLaunches("LF stage");
     if (any_vardct_ && !cfg.idct_flags_known && part != 0) {
       // a caller that enqueues the stages separately: the placement flags travel to pinned host memory behind the LF stage, and the tail —
       // enqueued steps later — waits for that copy (long done by then) instead of launching every IDCT kernel variant
@@ -1949,6 +1964,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     if (lf_batch_) lf_batch_->RunPart(stream_v, 0, false);     // LF frames: decoded to the end, their planes copied into the LF planes of the units that refer to them
     if (any_vardct_) LaunchLfPost(dframes_, n, max_bw_, max_bh_, max_groups_, stream_v);
     DebugSync("LF post", stream_v);
+    CheckLaunches("LF post-processing");
     if (part == 1 || part == 6) rec(2);
   }
   if (!any_vardct_) {
@@ -1959,6 +1975,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
         rec(5);
         if (any_modchan_) EnqueueModularTail(stream_v);
         if (any_complex_) EnqueuePostOps(stream_v);
+        CheckLaunches("Modular sub-streams / frame tail");
         rec(6);
         if (timed && split) timed_rest_cursor_++;
       }
@@ -1973,6 +1990,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     DebugSync("HF decode", stream_v);
     if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
+    CheckLaunches("HF stage / Modular sub-streams");
     rec(3);
   }
   if (do_tail) {
@@ -1985,6 +2003,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
       if (split) rec(8);                        // the tail may sit on another stream than the HF stage: its own start mark
       LaunchIdct(dframes_, n, max_groups_, max_bw_, max_bh_, cfg, stream_v);
       DebugSync("IDCT", stream_v);
+      CheckLaunches("IDCT stage");
       rec(4);
       ClearCoefficientsAfterDecode(stream_v);   // (the IDCT kernels zeroed what they read)
     }
@@ -1995,6 +2014,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
       if (!cfg.debug_stop_after) LaunchOutput(dframes_, n, max_w_, max_h_, fplan_, cfg, stream_v);
       if (any_complex_ && !cfg.debug_stop_after) EnqueuePostOps(stream_v);   // frame tail of multi-frame / feature images
       DebugSync("output / frame tail", stream_v);
+      CheckLaunches("filters / output / frame tail");
       rec(6);
       if (timed && split) timed_rest_cursor_++;
     }

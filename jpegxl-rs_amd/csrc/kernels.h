@@ -193,6 +193,7 @@ void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, con
 // Modular stages
 struct ModOutputArgs { const int32_t* color[3]; const int32_t* alpha; uint32_t ncolor; float color_factor, alpha_factor; uint32_t float_bits, float_exp_bits; };   // float_bits != 0: colour samples are float bit patterns
 void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream);
+uint32_t ModularGroupLdsBytes(const LaunchCfg& cfg);
 void LaunchModularGroups(const FrameDev* frames, int nframes, int max_units, const LaunchCfg& cfg, void* stream);   // max_units: most LF groups + groups x passes of a frame
 // inverse Squeeze of one channel: (avg, res) -> out; horizontal: avg aw x h, res rw x h, out (aw+rw) x h; vertical: avg w x ah, res w x rh
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);

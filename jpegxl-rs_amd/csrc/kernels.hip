@@ -347,6 +347,12 @@ static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
 #ifndef JXL_IDCT_MINW
 #define JXL_IDCT_MINW 4    // IdctTileKernel<4>: likewise
 #endif
+// The dynamic-LDS ceiling of a kernel (static __shared__ arrays count against the same 160 KB): a refused request must not pass silently — launches above the
+// default 64 KB would then be refused one by one, each leaving an error code for some later runtime call to report.
+static void SetMaxDynamicLds(const void* func, int bytes, const char* name) {
+  const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "[jxl-hip] cannot raise the dynamic LDS limit of %s to %d bytes: %s\n", name, bytes, hipGetErrorString(e)); }
+}
 constexpr uint32_t kLfWaves = 4;                                         // wavefronts per workgroup of the Modular group kernels
 constexpr uint32_t kLfDecWaves = 2, kLfDecGroups = 4;                    // LfDecodeKernel: two wavefronts share four LF groups
 // the shared part of the LDS (tree copy or per-wavefront pruned slices, then the entropy code) follows the per-wavefront regions
@@ -4371,8 +4377,8 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   const uint32_t lds_bytes = wp_base ? wp_base + kLfDecWaves * kWpLdsBytes : lds_tables;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)LfDecodeKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-    (void)hipFuncSetAttribute((const void*)LfDecodeKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+    SetMaxDynamicLds((const void*)LfDecodeKernel<true>, 160 * 1024 - 2048, "LfDecodeKernel<true>");
+    SetMaxDynamicLds((const void*)LfDecodeKernel<false>, 160 * 1024 - 2048, "LfDecodeKernel<false>");
     attr_set = true;
   }
   // batches that fill the GPU: four groups per workgroup (two per wavefront, paired large + small); otherwise one per wavefront
@@ -4415,9 +4421,9 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes) + (lanes + 1) * kSimtLaneBytes;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      (void)hipFuncSetAttribute((const void*)HfDecodeSimtKernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      SetMaxDynamicLds((const void*)HfDecodeSimtKernel<true, false, false>, 160 * 1024 - 2048, "HfDecodeSimtKernel<true, false, false>");
+      SetMaxDynamicLds((const void*)HfDecodeSimtKernel<true, true, true>, 160 * 1024 - 2048, "HfDecodeSimtKernel<true, true, true>");
+      SetMaxDynamicLds((const void*)HfDecodeSimtKernel<false, true, true>, 160 * 1024 - 2048, "HfDecodeSimtKernel<false, true, true>");
       attr = true;
     }
     const dim3 grid(nblk, nframes);
@@ -4436,7 +4442,7 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     else hipLaunchKernelGGL((HfDecodeSimtKernel<false, true, true>), grid, dim3(threads), lds, (hipStream_t)stream, frames, lds, lanes, lpw, sync, epoch, hf_prio);
     if (cfg.any_prefix_ac) {   // frames with a prefix-coded AC stream: one group stream per wavefront lane 0, tables in global memory
       static bool attr2 = false;
-      if (!attr2) { (void)hipFuncSetAttribute((const void*)HfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr2 = true; }
+      if (!attr2) { SetMaxDynamicLds((const void*)HfDecodeKernel, 160 * 1024 - 2048, "HfDecodeKernel"); attr2 = true; }
       hipLaunchKernelGGL(HfDecodeKernel, dim3(DivUp(max_groups, 512 / 64), nframes), dim3(512), 128, (hipStream_t)stream, frames, 64, 128u, 1);
     }
     return;
@@ -4445,11 +4451,19 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
   const int per_block = threads / cfg.lane_stride_hf;
   const uint32_t lds_bytes = 128 + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes);
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)HfDecodeKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  if (!attr_set) { SetMaxDynamicLds((const void*)HfDecodeKernel, 160 * 1024 - 2048, "HfDecodeKernel"); attr_set = true; }
   dim3 grid(DivUp(max_groups, per_block), nframes);
   hipLaunchKernelGGL(HfDecodeKernel, grid, dim3(threads), lds_bytes, (hipStream_t)stream, frames, cfg.lane_stride_hf, lds_bytes, 0);
 }
+// JXL_HIP_DEBUG_SYNC: names the launch that the runtime rejected (a rejected launch leaves an error code behind that the next runtime call of the process would report)
+static void DebugLaunch(const char* what) {
+  static const bool on = getenv("JXL_HIP_DEBUG_SYNC") != nullptr;
+  if (!on) return;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "[jxl-hip] launch of %s rejected: %s\n", what, hipGetErrorString(e));
+}
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream) {
+  DebugLaunch("(something before the IDCT stage)");
   // 64x64 tiles for frames with varblocks beyond 32x32, 32x32 tiles (a quarter of the LDS) for the others; each in a
   // variant with and without the 8x8 special transforms.  Every frame is taken by exactly one of the four.
   const bool all = !cfg.idct_flags_known;
@@ -4460,6 +4474,7 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     const size_t lds = 3 * TileGeom<8>::kPlane * sizeof(float);
     if (all || cfg.need_tile8_plain) hipLaunchKernelGGL((IdctTileKernel<8, false>), grid, dim3(256), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
     if (all || cfg.need_tile8_special) hipLaunchKernelGGL((IdctTileKernel<8, true>), grid, dim3(256), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
+    DebugLaunch("IdctTileKernel<8>");
   }
   {
     const int tiles_x = DivUp(max_bw, 4), tiles_y = DivUp(max_bh, 4);
@@ -4467,22 +4482,25 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     const size_t lds = 3 * TileGeom<4>::kPlane * sizeof(float);
     if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(JXL_IDCT_T4), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
     if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(JXL_IDCT_T4), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct | nocoef);
+    DebugLaunch("IdctTileKernel<4>");
   }
   if (cfg.any_subsampled) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
   // one wavefront per group: a group holds a few dozen of these blocks (x 3 channels, one lane each), three more wavefronts per workgroup
   // only occupied slots (256 threads: 26.4 ms for the IDCT stage of the bench batch, 64 or 128 threads: 25.0 ms)
   if (all || cfg.need_rare_special) hipLaunchKernelGGL(IdctRareSpecialKernel, dim3(max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);
+  DebugLaunch("IdctSubsampledKernel / IdctRareSpecialKernel");
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
   if (!cfg.idct_flags_known || cfg.any_big_blocks)
     hipLaunchKernelGGL(BigIdctKernel, dim3(max_groups, nframes), dim3(256), kBigLds, (hipStream_t)stream, frames);                  // frames with DCT128/256 varblocks only
+  DebugLaunch("IdctKernel / BigIdctKernel");
 }
 void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   dim3 block(64, 4), grid(DivUp(max_w, 64), DivUp(max_h, 4), nframes);
   const int unfused = cfg.force_unfused_filters;
   if (fp.any_fused && !unfused) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)FusedGabEpf1OutKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds); attr = true; }
+    if (!attr) { SetMaxDynamicLds((const void*)FusedGabEpf1OutKernel, (int)kFusedLds, "FusedGabEpf1OutKernel"); attr = true; }
     static const int swizzle = getenv("JXL_HIP_NO_XCD_SWIZZLE") ? 0 : 1;
     const int tiles_x = DivUp(max_w, kFtW);
     hipLaunchKernelGGL(FusedGabEpf1OutKernel, dim3(tiles_x * DivUp(max_h, kFtH), 1, nframes), dim3(256), kFusedLds, (hipStream_t)stream, frames, unfused, tiles_x, swizzle);
@@ -4508,7 +4526,9 @@ void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& c
 // (a lookup in global memory costs ~10x); when it does not all fit, the tree region shrinks first (large trees are pruned
 // per stream anyway), then the code falls back to the shared budget.
 static void PlanModularLds(const LaunchCfg& cfg, uint32_t* nwaves_io, uint32_t* tree_cap, uint32_t* lds_tables, uint32_t* wp_base, uint32_t* lds_total) {
-  const uint32_t limit = 160 * 1024 - 4096;
+  // (the kernels' static __shared__ arrays — 5 KB in ModularGroupFastKernel — come on top of the dynamic part: a plan that ends above 160 KB in total is rejected by the
+  // runtime at launch.  Round 4: the limit was 156 KB of dynamic LDS, which a stream with large alias tables reached — the launch was refused and left its error code behind)
+  const uint32_t limit = 160 * 1024 - 8192;
   uint32_t nwaves = *nwaves_io;
   const bool pruned = cfg.max_tree_nodes > kLdsTreeMax;          // the tree is copied per wavefront, reduced to what its stream can reach
   uint32_t cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
@@ -4529,19 +4549,26 @@ void LaunchModularGroups(const FrameDev* frames, int nframes, int max_units, con
   uint32_t nwaves = kLfWaves, tree_cap, lds_tables, wp_base, lds_bytes;
   PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGroupFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  if (!attr_set) { SetMaxDynamicLds((const void*)ModularGroupFastKernel, 160 * 1024 - 8192, "ModularGroupFastKernel"); attr_set = true; }
   hipLaunchKernelGGL(ModularGroupFastKernel, dim3(DivUp(max_lf_groups + max_groups, (int)nwaves), nframes), dim3(64 * nwaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 0u);
+  if (getenv("JXL_HIP_DEBUG_SYNC")) fprintf(stderr, "[jxl-hip] ModularGroupFastKernel: grid %d x %d, %u threads, %u B of dynamic LDS (tree cap %u, tables %u, wp base %u; max nodes %d, code %d B, any_wp %d)\n",
+                                            DivUp(max_lf_groups + max_groups, (int)nwaves), nframes, 64 * nwaves, lds_bytes, tree_cap, lds_tables, wp_base, cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.any_wp);
   if (cfg.any_local_trees) {   // units with a tree / code of their own: one wavefront per workgroup, each staging its own tables
     nwaves = 1;
     PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
     hipLaunchKernelGGL(ModularGroupFastKernel, dim3(max_lf_groups + max_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 1u);
   }
 }
+uint32_t ModularGroupLdsBytes(const LaunchCfg& cfg) {   // dynamic LDS of the shared-tree launch of ModularGroupFastKernel (tests: plans above the 64 KB default)
+  uint32_t nwaves = kLfWaves, tree_cap, lds_tables, wp_base, lds_bytes;
+  PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
+  return lds_bytes;
+}
 void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream) {
   uint32_t nwaves = 1, tree_cap, lds_tables, wp_base, lds_bytes;
   PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ModularGlobalFastKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); attr_set = true; }
+  if (!attr_set) { SetMaxDynamicLds((const void*)ModularGlobalFastKernel, 160 * 1024 - 8192, "ModularGlobalFastKernel"); attr_set = true; }
   hipLaunchKernelGGL(ModularGlobalFastKernel, dim3(nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base);
 }
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream) {

@@ -1891,3 +1891,18 @@ def test_float_alpha_channel(jx):
         check_against_oracle(jx, data, dtype, 4)
     px = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=4)).decode_with(data, np.float32)[1].reshape(h, w, 4)
     assert np.array_equal(px.view(np.uint32), ints.astype(np.uint16).view(np.float16).astype(np.float32).view(np.uint32))
+
+
+def test_modular_group_streams_with_more_than_64k_of_lds_tables(jx):
+    """Round 4: the request for ModularGroupFastKernel's dynamic-LDS ceiling was refused by the runtime (static arrays + request > 160 KB) and the refusal ignored, so launches
+    that needed more than the default 64 KB would have been refused in turn.  Multi-group Modular streams with deep trees and wide alphabets (16-bit samples) plan more
+    than that; they must decode like the oracle — and a refused launch now fails the decode by name (Batch::RunPart CheckLaunches)."""
+    seen_big = 0
+    for seed, depth, flags in [(31, 9, S.TREE_ALL_PREDICTORS | S.TREE_MULTIPLIERS), (32, 10, S.TREE_WP | S.TREE_PREV_CHANNELS), (33, 10, 31)]:
+        data = S.encode_modular_free(seed=seed, w=700, h=560, nchan=3, bits=16, tree_flags=flags, tree_depth=depth)
+        b = jx.BatchDecoder(0)
+        b.add(data, "uint16", 3)
+        b.prepare(); b.decode(); b.finish()
+        seen_big += b.info_value("mod_group_lds_bytes") > 65536
+        assert np.array_equal(b.output(0).view(np.uint16).reshape(-1), O.decode(data).pixels("u16", 3).view(np.uint16)), seed
+    assert seen_big >= 1
