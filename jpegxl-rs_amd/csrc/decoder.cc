@@ -314,6 +314,54 @@ static void FillColor(const ImageHeader& ih, bool do_ycbcr, FrameDev& f) {
   } else f.color_mode = do_ycbcr ? 2 : 3;
 }
 
+// ---- device arena pool.  hipMalloc / hipFree of the multi-gigabyte arenas cost 0.5-3.5 s per batch object on the boxes measured (page tables of tens of GB set up and
+// torn down), which is what a "fresh batch" paid each time (bench.py one_pass_128: 92 ms here, 3.6 s on the driver's box in round 3).  Arenas that a batch lets go of are kept
+// in a process-wide free list (bounded: JXL_HIP_ARENA_POOL_MB, default 49 152; 0 turns the pool off) and handed to the next batch that asks for that much memory on that device.
+namespace {
+struct ArenaPool {
+  struct Block { void* p; size_t cap; int dev; };
+  std::mutex mu;
+  std::vector<Block> blocks;
+  size_t held = 0;
+  static size_t Limit() { static const size_t v = getenv("JXL_HIP_ARENA_POOL_MB") ? (size_t)atoll(getenv("JXL_HIP_ARENA_POOL_MB")) << 20 : (size_t)49152 << 20; return v; }
+  static constexpr size_t kMinBytes = (size_t)8 << 20;   // small allocations are cheap: not pooled
+  void* Take(size_t want, size_t* cap) {
+    if (want < kMinBytes || Limit() == 0) return nullptr;
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    int best = -1;
+    for (size_t i = 0; i < blocks.size(); i++)
+      if (blocks[i].dev == dev && blocks[i].cap >= want && blocks[i].cap <= want + want / 2 + ((size_t)64 << 20) && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
+    if (best < 0) return nullptr;
+    void* p = blocks[(size_t)best].p; *cap = blocks[(size_t)best].cap; held -= *cap;
+    blocks.erase(blocks.begin() + best);
+    return p;
+  }
+  void Give(void* p, size_t cap) {
+    if (!p) return;
+    int dev = 0;
+    const bool dev_ok = hipGetDevice(&dev) == hipSuccess;
+    if (!dev_ok) (void)hipGetLastError();
+    if (dev_ok && cap >= kMinBytes && Limit() != 0) {
+      std::lock_guard<std::mutex> lock(mu);
+      if (held + cap <= Limit() && blocks.size() < 32) {
+        (void)hipDeviceSynchronize();      // (what hipFree does implicitly: nothing in flight may still touch the block when somebody else gets it)
+        blocks.push_back(Block{p, cap, dev}); held += cap;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void Trim() {   // gives everything back to the runtime (an allocation failed: the pool may be what is in the way)
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& b : blocks) (void)hipFree(b.p);
+    blocks.clear(); held = 0;
+  }
+};
+ArenaPool& Pool() { static ArenaPool* pool = new ArenaPool(); return *pool; }     // (never destroyed: the runtime may be gone by then)
+}  // namespace
+void DeviceArenaPoolTrim() { Pool().Trim(); }
+
 Batch::Batch(int device) : device_(device) {
   if (device_ >= 0) HIP_CHECK(hipSetDevice(device_));      // (-1: host-side parsing only, JxlHipDebugDescribe)
 }
@@ -323,10 +371,11 @@ Batch::~Batch() {
   if (idct_event_) (void)hipEventDestroy((hipEvent_t)idct_event_);
   if (flags_event_) (void)hipEventDestroy((hipEvent_t)flags_event_);
   if (flags_pinned_) (void)hipHostFree(flags_pinned_);
-  if (dconst_) (void)hipFree(dconst_);
-  if (dwork_) (void)hipFree(dwork_);
-  if (dcoef_ && !coef_owner_) (void)hipFree(dcoef_);
-  if (dbig_ && !big_owner_) (void)hipFree(dbig_);
+  if (device_ >= 0 && (dconst_ || dwork_ || dcoef_ || dbig_)) (void)hipSetDevice(device_);
+  Pool().Give(dconst_, const_cap_);
+  Pool().Give(dwork_, work_cap_);
+  if (dcoef_ && !coef_owner_) Pool().Give(dcoef_, coef_cap_);
+  if (dbig_ && !big_owner_) Pool().Give(dbig_, big_cap_);
   if (big_owner_) big_owner_->big_sharers_--;
   if (dframes_) (void)hipFree(dframes_);
   if (dpasses_) (void)hipFree(dpasses_);
@@ -340,7 +389,7 @@ void Batch::ShareBigArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareBigArena after Prepare", false);
   if (big_owner_ == owner) return;
   if (big_owner_) { big_owner_->big_sharers_--; dbig_ = nullptr; big_cap_ = 0; }       // (the pointer aliased the old owner's planes: not ours to free)
-  if (dbig_) { (void)hipFree(dbig_); dbig_ = nullptr; big_cap_ = 0; }
+  if (dbig_) { Pool().Give(dbig_, big_cap_); dbig_ = nullptr; big_cap_ = 0; }
   big_owner_ = owner;
   if (owner) owner->big_sharers_++;
 }
@@ -351,18 +400,24 @@ void Batch::ShareCoefArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareCoefArena after Prepare", false);
   if (coef_owner_ == owner) return;
   if (coef_owner_) { dcoef_ = nullptr; coef_cap_ = 0; coef_laid_out_ = 0; }            // (aliased the old owner's planes: not ours to free)
-  if (dcoef_) { (void)hipFree(dcoef_); dcoef_ = nullptr; coef_cap_ = 0; }
+  if (dcoef_) { Pool().Give(dcoef_, coef_cap_); dcoef_ = nullptr; coef_cap_ = 0; }
   coef_owner_ = owner;
 }
 
-// Makes *ptr a device allocation of at least `bytes` (kept if it already is; grown with 1/8 of slack otherwise).  Returns true if the
-// memory is new.
+// Makes *ptr a device allocation of at least `bytes` (kept if it already is; grown with 1/8 of slack otherwise; taken from the arena pool when it has a block of
+// that size).  Returns true if the memory is new (contents undefined).
 bool Batch::DevReserve(void** ptr, size_t* cap, size_t bytes) {
   if (*ptr && *cap >= bytes) return false;
-  if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *cap = 0; }
+  if (*ptr) { Pool().Give(*ptr, *cap); *ptr = nullptr; *cap = 0; }
   const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
-  if (hipMalloc(ptr, want) != hipSuccess) { (void)hipGetLastError(); HIP_CHECK(hipMalloc(ptr, std::max<size_t>(bytes, 256))); *cap = std::max<size_t>(bytes, 256); }
-  else *cap = want;
+  if (void* p = Pool().Take(std::max<size_t>(bytes, 256), cap)) { *ptr = p; return true; }
+  if (hipMalloc(ptr, want) != hipSuccess) {
+    (void)hipGetLastError();
+    Pool().Trim();
+    if (hipMalloc(ptr, want) == hipSuccess) { *cap = want; return true; }
+    (void)hipGetLastError();
+    HIP_CHECK(hipMalloc(ptr, std::max<size_t>(bytes, 256))); *cap = std::max<size_t>(bytes, 256);
+  } else *cap = want;
   return true;
 }
 
