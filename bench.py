@@ -190,8 +190,7 @@ def extras(jx, torch, streams, W, H, device):
     stream = torch.cuda.current_stream().cuda_stream
     t0 = time.perf_counter()
     b = jx.BatchDecoder(device)
-    for i in range(n):
-        b.add(streams[i % len(streams)], "uint8", 3, device_ptr=dst.data_ptr() + i * W * H * 3)
+    b.add_many([streams[i % len(streams)] for i in range(n)], "uint8", 3, device_ptrs=[dst.data_ptr() + i * W * H * 3 for i in range(n)], threads=8)
     b.set_lane_stride(64, 1)
     b.prepare(stream)
     torch.cuda.synchronize()

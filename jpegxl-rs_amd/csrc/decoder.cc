@@ -316,14 +316,22 @@ static void FillColor(const ImageHeader& ih, bool do_ycbcr, FrameDev& f) {
 
 // ---- device arena pool.  hipMalloc / hipFree of the multi-gigabyte arenas cost 0.5-3.5 s per batch object on the boxes measured (page tables of tens of GB set up and
 // torn down), which is what a "fresh batch" paid each time (bench.py one_pass_128: 92 ms here, 3.6 s on the driver's box in round 3).  Arenas that a batch lets go of are kept
-// in a process-wide free list (bounded: JXL_HIP_ARENA_POOL_MB, default 49 152; 0 turns the pool off) and handed to the next batch that asks for that much memory on that device.
+// in a process-wide free list (bounded: JXL_HIP_ARENA_POOL_MB, default 60 % of the device's memory; 0 turns the pool off) and handed to the next batch that asks for that much memory on that device.
 namespace {
 struct ArenaPool {
   struct Block { void* p; size_t cap; int dev; };
   std::mutex mu;
   std::vector<Block> blocks;
   size_t held = 0;
-  static size_t Limit() { static const size_t v = getenv("JXL_HIP_ARENA_POOL_MB") ? (size_t)atoll(getenv("JXL_HIP_ARENA_POOL_MB")) << 20 : (size_t)49152 << 20; return v; }
+  static size_t Limit() {   // default: 60 % of the device's memory — what is handed back with hipFree is what the next hipMalloc (of any size) waits for: 2-3.5 s after a pipeline's 130 GB
+    static const size_t v = [] {
+      if (const char* e = getenv("JXL_HIP_ARENA_POOL_MB")) return (size_t)atoll(e) << 20;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)64 << 30; }
+      return total_b / 10 * 6;
+    }();
+    return v;
+  }
   static constexpr size_t kMinBytes = (size_t)8 << 20;   // small allocations are cheap: not pooled
   void* Take(size_t want, size_t* cap) {
     if (want < kMinBytes || Limit() == 0) return nullptr;
@@ -331,7 +339,7 @@ struct ArenaPool {
     std::lock_guard<std::mutex> lock(mu);
     int best = -1;
     for (size_t i = 0; i < blocks.size(); i++)
-      if (blocks[i].dev == dev && blocks[i].cap >= want && blocks[i].cap <= want + want / 2 + ((size_t)64 << 20) && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
+      if (blocks[i].dev == dev && blocks[i].cap >= want && blocks[i].cap <= 4 * want + ((size_t)64 << 20) && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
     if (best < 0) return nullptr;
     void* p = blocks[(size_t)best].p; *cap = blocks[(size_t)best].cap; held -= *cap;
     blocks.erase(blocks.begin() + best);
@@ -344,7 +352,7 @@ struct ArenaPool {
     if (!dev_ok) (void)hipGetLastError();
     if (dev_ok && cap >= kMinBytes && Limit() != 0) {
       std::lock_guard<std::mutex> lock(mu);
-      if (held + cap <= Limit() && blocks.size() < 32) {
+      if (held + cap <= Limit() && blocks.size() < 96) {
         (void)hipDeviceSynchronize();      // (what hipFree does implicitly: nothing in flight may still touch the block when somebody else gets it)
         blocks.push_back(Block{p, cap, dev}); held += cap;
         return;
