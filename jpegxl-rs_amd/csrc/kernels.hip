@@ -4351,7 +4351,10 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
       for (auto& e : ev) (void)hipEventDestroy(e);
     }
   };
-  const int wide = cfg.lf_wide_once;      // this launch: one wavefront per stream for every frame (shorter latency, the whole GPU's SIMDs)
+  // this launch: one wavefront per stream for every frame (shorter latency, the whole GPU's SIMDs) — not for batches whose SIMT launch is the weighted-predictor
+  // instantiation: per stream the lane-serial form is the faster one there (1.5 against 2.8 us per sample), four of these wide launches at the start of a cold
+  // pipeline took 1.0-2.3 s each (profiles/r04_notes.md)
+  const int wide = cfg.lf_wide_once && !(simt && simt->num_lanes && simt->any_wp);
   int simt_mode = wide ? 1 : 0;           // LfDecodeKernel's take_simt_frames: 0 legacy frames only, 1 every frame, 2 legacy frames + the streams the SIMT kernel handed back
   if (simt && simt->num_lanes && !wide) {
     // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane)
@@ -4371,7 +4374,10 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   // dynamic LDS: LUT + scratch + tree copy + as much of the entropy code as needed / the budget allows (right-sized so
   // that several LF groups fit one CU)
   const uint32_t tree_cap = (uint32_t)std::min(cfg.max_tree_nodes, kLdsTreeMax);
-  const uint32_t lds_tables = kLfDecWaves * kWaveLds + tree_cap * 16 + (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  // (the pass that only takes the streams the weighted-predictor SIMT lanes handed back — normally none — keeps the entropy code out of the LDS: its 256 workgroups
+  // have to find room on CUs that the HF stage and the pixel kernels fill, and the launch holds up the placement kernels behind it until the last one has been dispatched)
+  const bool redo_only_launch = simt_mode == 2 && simt && !simt->any_legacy;
+  const uint32_t lds_tables = kLfDecWaves * kWaveLds + tree_cap * 16 + (redo_only_launch ? 0u : (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes));
   // trees with the weighted predictor: its state rows (channels up to 256 wide — all but the block-info rows) in LDS, one slot per wavefront
   const uint32_t wp_base = cfg.any_wp ? (lds_tables + 15) & ~15u : 0u;
   const uint32_t lds_bytes = wp_base ? wp_base + kLfDecWaves * kWpLdsBytes : lds_tables;
