@@ -508,8 +508,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
     ap.add_argument("--in-flight", type=int, default=11, help="batches in flight on the GPU (pipelined): LF stages run this many steps ahead, minus one")
     ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
-    ap.add_argument("--wp-in-flight", type=int, default=14, help="batches in flight for workloads whose LF streams use the weighted predictor (LF stage ~700 ms per launch instead of ~370)")
-    ap.add_argument("--wp-lf-streams", type=int, default=10, help="LF side streams for those workloads")
+    ap.add_argument("--wp-in-flight", type=int, default=11, help="batches in flight for workloads whose LF streams use the weighted predictor (LF stage ~700 ms per launch instead of ~370)")
+    ap.add_argument("--wp-lf-streams", type=int, default=7, help="LF side streams for those workloads")
     ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current step (deep pipeline), one stream and one coefficient set each")
     ap.add_argument("--tail-streams", type=int, default=int(os.environ.get("JXL_BENCH_TAIL_STREAMS", "1")), help="2: the filter stage of a batch on its own stream beside the IDCT of the next (two sets of pixel planes)")
     ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
