@@ -1645,10 +1645,21 @@ struct WpLane {
 // No LDS in any of them (kernels.h: LF workgroups stay for hundreds of milliseconds and would fragment what the HF workgroups need): the
 // weighted predictor's 64-entry division table is read from global memory (g_wp_div: it stays in the vector L1, and its reads hang off
 // the prediction, which only meets the entropy chain when the token is there).
-template <bool WP, bool GEN> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
+// QUAD (weighted-predictor launches): four adjacent lanes carry ONE stream.  Everything but the weighted predictor is computed redundantly by the four (a wavefront
+// instruction costs the same for one or four active lanes); of the predictor, lane q owns sub-predictor q — its error magnitudes, weight, prediction — and the sums over
+// the four (weights, weighted predictions) are two DPP quad-permute additions each.  ~100 of the ~330 instructions per sample go away; 8 streams occupy 32 lanes.
+__device__ __forceinline__ int32_t QuadSum(int32_t v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+  return v;
+}
+template <bool WP, bool GEN, bool QUAD = false> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
                                                           const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority, const uint32_t* __restrict__ s_div) {
-  const uint32_t li = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * lanes_per_wave + (threadIdx.x & 63);
-  if ((threadIdx.x & 63) >= lanes_per_wave || li >= num_lanes) return;
+  static_assert(!QUAD || WP, "quads only pay for the weighted predictor");
+  const uint32_t lane_in_wave = QUAD ? (threadIdx.x & 63) >> 2 : (threadIdx.x & 63);
+  const uint32_t q = QUAD ? threadIdx.x & 3 : 0;              // which sub-predictor this lane owns
+  const uint32_t li = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * lanes_per_wave + lane_in_wave;
+  if (lane_in_wave >= lanes_per_wave || li >= num_lanes) return;
   if (high_priority & 1) __builtin_amdgcn_s_setprio(3);
   const int xp = high_priority;     // experiments (JXL_HIP_LF_PRIO bits 2, 4: drop the sample stores / the row-above prefetch — wrong pixels, timing only)
   uint32_t cur, end;
@@ -1774,14 +1785,20 @@ template <bool WP, bool GEN> __global__ __launch_bounds__(256, WP ? 4 : 8) void 
           for (uint32_t k = 0; k < w; k++) { StG(reinterpret_cast<uint4*>(wrows + kWpRowBytes + k * kWpRecBytes), make_uint4(0, 0, 0, 0)); StG(reinterpret_cast<int32_t*>(wrows + kWpRowBytes + k * kWpRecBytes + 16), 0); }
         }
         wcur = wrows + (y & 1) * kWpRowBytes; wprev = wrows + ((y & 1) ^ 1) * kWpRowBytes;
-        const uint4 m0 = LdG(reinterpret_cast<const uint4*>(wprev));
-        const uint4 m1 = LdG(reinterpret_cast<const uint4*>(wprev + (w > 1 ? kWpRecBytes : 0)));
         wp.teN = LdG(reinterpret_cast<const int32_t*>(wprev + 16));
         wp.eA = LdG(reinterpret_cast<const int32_t*>(wprev + (w > 1 ? kWpRecBytes : 0) + 16));
-        wp.aN[0] = m0.x; wp.aN[1] = m0.y; wp.aN[2] = m0.z; wp.aN[3] = m0.w;
-        wp.mA[0] = m1.x; wp.mA[1] = m1.y; wp.mA[2] = m1.z; wp.mA[3] = m1.w;
+        if constexpr (QUAD) {
+          wp.aN[0] = LdG(reinterpret_cast<const uint32_t*>(wprev) + q);
+          wp.mA[0] = LdG(reinterpret_cast<const uint32_t*>(wprev + (w > 1 ? kWpRecBytes : 0)) + q);
+          wp.aNW[0] = wp.aN[0];
+        } else {
+          const uint4 m0 = LdG(reinterpret_cast<const uint4*>(wprev));
+          const uint4 m1 = LdG(reinterpret_cast<const uint4*>(wprev + (w > 1 ? kWpRecBytes : 0)));
+          wp.aN[0] = m0.x; wp.aN[1] = m0.y; wp.aN[2] = m0.z; wp.aN[3] = m0.w;
+          wp.mA[0] = m1.x; wp.mA[1] = m1.y; wp.mA[2] = m1.z; wp.mA[3] = m1.w;
 #pragma unroll
-        for (int i = 0; i < 4; i++) wp.aNW[i] = wp.aN[i];
+          for (int i = 0; i < 4; i++) wp.aNW[i] = wp.aN[i];
+        }
         wp.teNW = wp.teN; wp.teW = 0;
       }
       // everything this branch loaded has arrived before the branch ends: the common path below then starts without a wait for it
@@ -1810,12 +1827,17 @@ template <bool WP, bool GEN> __global__ __launch_bounds__(256, WP ? 4 : 8) void 
     uint32_t aNE[4] = {0, 0, 0, 0};
     if (wp_live) {
       const uint8_t* r = wprev + min(x + 2, w - 1) * kWpRecBytes;
-      const uint4 m = LdG(reinterpret_cast<const uint4*>(r));
       wp.eB = LdG(reinterpret_cast<const int32_t*>(r + 16));
-      wp.mB[0] = m.x; wp.mB[1] = m.y; wp.mB[2] = m.z; wp.mB[3] = m.w;
-      teNE = last_col ? wp.teN : wp.eA;
+      if constexpr (QUAD) {
+        wp.mB[0] = LdG(reinterpret_cast<const uint32_t*>(r) + q);
+        aNE[0] = last_col ? wp.aN[0] : wp.mA[0];
+      } else {
+        const uint4 m = LdG(reinterpret_cast<const uint4*>(r));
+        wp.mB[0] = m.x; wp.mB[1] = m.y; wp.mB[2] = m.z; wp.mB[3] = m.w;
 #pragma unroll
-      for (int i = 0; i < 4; i++) aNE[i] = last_col ? wp.aN[i] : wp.mA[i];
+        for (int i = 0; i < 4; i++) aNE[i] = last_col ? wp.aN[i] : wp.mA[i];
+      }
+      teNE = last_col ? wp.teN : wp.eA;
       int32_t p = wp.teW;
       if (abs(wp.teN) > abs(p)) p = wp.teN;
       if (abs(wp.teNW) > abs(p)) p = wp.teNW;
@@ -1847,7 +1869,27 @@ template <bool WP, bool GEN> __global__ __launch_bounds__(256, WP ? 4 : 8) void 
         else guess = NE;
       }
     }
-    if (wp_live) {
+    if (QUAD && wp_live) {
+      // this lane's sub-predictor: weight from its error magnitudes around the sample, prediction = base - ((error sum x coefficient) >> 5)
+      const uint32_t e = wp.aN[0] + aNE[0] + wp.aNW[0];
+      const int shift = max(0, 26 - (int)__clz((int)(e + 1)));
+      uint32_t wt = 4 + (((q == 0 ? 13u : 12u) * LdG(s_div + (e >> shift))) >> shift);
+      const int32_t N8 = N << 3, W8 = W << 3, NE8 = NE << 3;
+      const int32_t sumWN = wp.teN + wp.teW;
+      const int32_t base = q == 0 ? W8 + NE8 - N8 : (q == 2 ? W8 : N8);
+      const int32_t tsum = q == 1 ? sumWN + teNE : (q == 2 ? sumWN + wp.teNW : wp.teNW + wp.teN + teNE);
+      const int32_t coef = q == 0 ? 0 : (q == 1 ? 16 : (q == 2 ? 10 : 7));      // ((x * 16) >> 5 == x >> 1: sub-predictor 1)
+      wp.pr[0] = base - ((tsum * coef) >> 5);
+      uint32_t total = (uint32_t)QuadSum((int32_t)wt);
+      const int lg = 31 - (int)__clz((int)total);
+      wt >>= (lg - 4);
+      total = (uint32_t)QuadSum((int32_t)wt);
+      const int32_t acc = QuadSum(wp.pr[0] * (int32_t)wt) + (int32_t)(total >> 1) - 1;
+      int32_t avg = (int32_t)(((int64_t)acc * (int64_t)LdG(s_div + (total - 1))) >> 24);
+      if (((wp.teN ^ wp.teW) | (wp.teN ^ wp.teNW)) <= 0) avg = max(min(W8, min(NE8, N8)), min(max(W8, max(NE8, N8)), avg));
+      wp.avg = avg;
+      if (pcode == 4) guess = (avg + 3) >> 3;
+    } else if (wp_live) {
       // sub-predictor weights from the error magnitudes around the sample
       uint32_t wt[4];
 #pragma unroll
@@ -1908,14 +1950,21 @@ template <bool WP, bool GEN> __global__ __launch_bounds__(256, WP ? 4 : 8) void 
       // what the sample turned out to be: true error, error magnitude of every sub-predictor -> this row's record; the chain for x + 1
       const int32_t v8 = (int32_t)((uint32_t)val << 3);
       const int32_t te = wp.avg - v8;
-      uint32_t em[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) em[i] = (uint32_t)(abs(wp.pr[i] - v8) + 3) >> 3;
       uint8_t* rec = wcur + x * kWpRecBytes;
-      StG(reinterpret_cast<uint4*>(rec), make_uint4(em[0], em[1], em[2], em[3]));
-      StG(reinterpret_cast<int32_t*>(rec + 16), te);
+      if constexpr (QUAD) {
+        const uint32_t em = (uint32_t)(abs(wp.pr[0] - v8) + 3) >> 3;
+        StG(reinterpret_cast<uint32_t*>(rec) + q, em);
+        StG(reinterpret_cast<int32_t*>(rec + 16), te);
+        wp.aNW[0] = wp.aN[0]; wp.aN[0] = wp.mA[0] + em; wp.mA[0] = wp.mB[0];
+      } else {
+        uint32_t em[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) { wp.aNW[i] = wp.aN[i]; wp.aN[i] = wp.mA[i] + em[i]; wp.mA[i] = wp.mB[i]; }
+        for (int i = 0; i < 4; i++) em[i] = (uint32_t)(abs(wp.pr[i] - v8) + 3) >> 3;
+        StG(reinterpret_cast<uint4*>(rec), make_uint4(em[0], em[1], em[2], em[3]));
+        StG(reinterpret_cast<int32_t*>(rec + 16), te);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { wp.aNW[i] = wp.aN[i]; wp.aN[i] = wp.mA[i] + em[i]; wp.mA[i] = wp.mB[i]; }
+      }
       wp.teNW = wp.teN; wp.teN = wp.eA; wp.eA = wp.eB; wp.teW = te;
       const uint32_t vmax = (xp & 8) ? 16u : (1u << 20);      // (bit 8 of the flags: testing, so that ordinary streams take the hand-back path)
       if (__builtin_expect((uint32_t)val + vmax > 2 * vmax || (uint32_t)te + (1u << 24) > (2u << 24), 0)) {
@@ -4365,7 +4414,13 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     const int lf_flags = lf_prio | (cfg.lf_wp_narrow_test ? 8 : 0);
     const dim3 grid(DivUp(nwaves, wpb)), block(64 * wpb);
     const uint32_t* wp_div = WpDivTable();
-    if (simt->any_wp) hipLaunchKernelGGL((LfDecodeSimtKernel<true, true>), grid, block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags, wp_div);
+    static const bool no_quad = getenv("JXL_HIP_LF_NOQUAD") != nullptr;      // A/B: the one-lane-per-stream weighted-predictor instantiation
+    if (simt->any_wp && !no_quad) {
+      // four lanes per stream: at most 16 streams per wavefront
+      const uint32_t lpq = std::min(16u, lpw);
+      const int nwq = DivUp((int)simt->num_lanes, (int)lpq);
+      hipLaunchKernelGGL((LfDecodeSimtKernel<true, true, true>), dim3(DivUp(nwq, wpb)), block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpq, lf_flags, wp_div);
+    } else if (simt->any_wp) hipLaunchKernelGGL((LfDecodeSimtKernel<true, true>), grid, block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags, wp_div);
     else if (simt->any_general) hipLaunchKernelGGL((LfDecodeSimtKernel<false, true>), grid, block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags, wp_div);
     else hipLaunchKernelGGL((LfDecodeSimtKernel<false, false>), grid, block, 0, (hipStream_t)stream, frames, simt->streams, simt->lanes, simt->luts, simt->num_lanes, lpw, lf_flags, wp_div);
     if (!simt->any_legacy && !simt->any_wp) { place(); return; }
