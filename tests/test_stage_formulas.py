@@ -587,3 +587,42 @@ def test_upsampling_follows_its_definition(jx, up, custom):
     want = np.stack([sum(inv[r, k] * mixed[k] for k in range(3)) for r in range(3)], axis=-1)
     # 25-term kernels in float32 (1e-7 relative on XYB values below 1) through the cube and a matrix with entries up to 11: ~1e-5 absolute
     assert np.abs(got - want).max() <= 2e-5, float(np.abs(got - want).max())
+
+
+# ---- frame blending (blending.cc PerformBlending) ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_blend_modes_follow_their_definition(jx, mode):
+    """A cropped RGBA layer over a saved RGBA frame, every blend mode, non-premultiplied alpha.  Inputs: the background frame decoded as an image of its own and the
+    layer as the non-coalesced decode hands it out (its own pixels after the colour transform); expected canvas in float64 from the definitions:
+    0 replace; 1 add; 2 blend: a = fa + ba (1 - fa), colour (fg fa + bg ba (1 - fa)) / a (0 where a = 0); 3 alpha-weighted add: colour bg + fg fa, alpha of the
+    background kept; 4 multiply: bg x fg.  No oracle code."""
+    w, h, cw, ch, x0, y0 = 200, 136, 64, 48, 10, 20
+    img, small = S.synthetic_image(5, w, h), S.synthetic_image(9, cw, ch)
+    bg_a = (np.add.outer(np.arange(h), np.arange(w)) * 5 % 256).astype(np.uint8)
+    fg_a = (np.add.outer(np.arange(ch), np.arange(cw)) * 3 % 256).astype(np.uint8)
+    f0 = np.dstack([img, bg_a]); f1 = np.dstack([small, fg_a])
+    alone = S.encode_modular_frame(f0, S.frame(), bits=8)
+    both = (S.encode_modular_frame(f0, S.frame(is_last=0, save_as_reference=2), bits=8)
+            + S.encode_modular_frame(f1, S.frame(emit=1, have_crop=1, crop_x0=x0, crop_y0=y0, canvas_w=w, canvas_h=h, blend_mode=mode, blend_source=2), bits=8))
+    _, bg = jx.decoder_builder().decode_with(alone, np.float32)
+    _, fg = jx.decoder_builder(coalescing=False).decode_with(both, np.float32)
+    _, got = jx.decoder_builder().decode_with(both, np.float32)
+    bg = bg.reshape(h, w, 4).astype(np.float64); fg = fg.reshape(ch, cw, 4).astype(np.float64); got = got.reshape(h, w, 4).astype(np.float64)
+    assert np.abs(bg * 255 - f0).max() < 1e-4      # (lossless 8-bit samples as floats)
+    want = bg.copy()
+    B, F = bg[y0:y0 + ch, x0:x0 + cw], fg
+    ba, fa = B[..., 3:], F[..., 3:]
+    if mode == 0:
+        out = F
+    elif mode == 1:
+        out = B + F
+    elif mode == 2:
+        a = fa + ba * (1 - fa)
+        col = np.where(a > 0, (F[..., :3] * fa + B[..., :3] * ba * (1 - fa)) / np.where(a > 0, a, 1), 0.0)
+        out = np.concatenate([col, a], axis=-1)
+    elif mode == 3:
+        out = np.concatenate([B[..., :3] + F[..., :3] * fa, ba], axis=-1)
+    else:
+        out = B * F
+    want[y0:y0 + ch, x0:x0 + cw] = out
+    assert np.abs(got - want).max() <= 4 * EPS * max(1.0, float(np.abs(want).max())), (mode, float(np.abs(got - want).max()))
