@@ -574,7 +574,7 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
   std::shared_ptr<ImageEntry> lf_frames[5];     // dec_cache.h dc_frames: the latest LF frame of every level (1 .. 4)
   uint32_t visible = 0, nonvisible = 0;
   for (int k = 0;; k++) {
-    if (k >= 256) throw ParseError("unsupported: more than 256 frames", true);
+    if (k >= 4096) throw ParseError("unsupported: more than 4096 frames", true);     // (a bound on what one image may make the host allocate; every frame is a unit of the batch)
     std::unique_ptr<ImageEntry> e(new ImageEntry(sh));
     e->has_jbrd = has_jbrd;
     e->frame_bitpos = bitpos;

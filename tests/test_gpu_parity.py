@@ -1906,3 +1906,23 @@ def test_modular_group_streams_with_more_than_64k_of_lds_tables(jx):
         seen_big += b.info_value("mod_group_lds_bytes") > 65536
         assert np.array_equal(b.output(0).view(np.uint16).reshape(-1), O.decode(data).pixels("u16", 3).view(np.uint16)), seed
     assert seen_big >= 1
+
+
+def test_animation_with_more_than_256_frames(jx):
+    """300 small frames (a long GIF turned into JPEG XL): the last canvas equals the oracle's; the frame count was capped at 256 until round 4"""
+    n, w, h = 300, 48, 40
+    base = S.synthetic_image(3, w, h)
+    S.set_animation(100, 1, 0)
+    try:
+        parts = [S.encode_vardct_frame(base, S.frame(is_last=0, save_as_reference=1, duration=1), seed=3, strategy_mix=0)]
+        for k in range(1, n):
+            tile = S.synthetic_image(100 + k % 7, 16, 16)
+            parts.append(S.encode_vardct_frame(tile, S.frame(emit=1, is_last=1 if k == n - 1 else 0, have_crop=1, crop_x0=(k * 5) % (w - 16), crop_y0=(k * 3) % (h - 16), canvas_w=w, canvas_h=h,
+                                                             blend_mode=0, blend_source=1, save_as_reference=0 if k == n - 1 else 1, duration=1), seed=k, strategy_mix=0))
+        data = b"".join(parts)
+    finally:
+        S.set_animation(0)
+    b = jx.BatchDecoder(0)
+    b.add(data, "uint8", 3)
+    b.prepare(); b.decode(); b.finish()
+    assert np.array_equal(b.output(0), O.decode(data).pixels("u8", 3))
