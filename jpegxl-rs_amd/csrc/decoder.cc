@@ -663,7 +663,17 @@ void Batch::SetOutput(int i, const OutputSpec& o) {
   e.out_stride = OutputStride(dims, o, &nc);
   e.out.num_channels = nc;
   e.out_size = OutputSize(dims, o);
+  e.deliver_frames.clear();
   prepared_ = false;
+}
+void Batch::SetOutputAllFrames(int i, const OutputSpec& o, const vec<int>& frames) {
+  if (o.device_ptr || o.only_frame >= 0 || frames.empty()) throw ParseError("SetOutputAllFrames: internal output buffers, coalesced frames only", false);
+  for (size_t k = 0; k < frames.size(); k++)
+    if (frames[k] < 0 || frames[k] >= pub_[i].num_units || (k && frames[k] <= frames[k - 1])) throw ParseError("SetOutputAllFrames: frame list must be ascending positions among the image's frames", false);
+  OutputSpec oo = o;
+  oo.upto_frame = -1;
+  SetOutput(i, oo);
+  images_[pub_[i].first_unit]->deliver_frames = frames;
 }
 
 uint64_t Batch::total_pixels() const { uint64_t n = 0; for (auto& pi : pub_) { const ImageHeader& ih = images_[pi.first_unit]->ih; n += (uint64_t)ih.xsize * ih.ysize; } return n; }
@@ -931,7 +941,7 @@ void Batch::Prepare(void* stream_v) {
     const FramePlan& p = e.plan;
     WorkOffsets& o = wo[i];
     o.end_bitpos = take(16);
-    if (e.frame_index == 0 && !e.out.device_ptr) e.off_out = take(e.out_size + 64);
+    if (e.frame_index == 0 && !e.out.device_ptr) e.off_out = take((e.out_size + 64) * std::max<size_t>(1, e.deliver_frames.size()));
   if (p.upsampling > 1) {   // kernel weights: custom (image header) or library default
       const int upk = p.upsampling == 2 ? 0 : p.upsampling == 4 ? 1 : 2;
       const float* const kDefault[3] = {kUp2, kUp4, kUp8};
@@ -1037,7 +1047,7 @@ void Batch::Prepare(void* stream_v) {
     if (plain && poison) {
       HIP_CHECK(hipMemsetAsync(dwork_ + head, 0xCD, work_size_ - head, stream));
       HIP_CHECK(hipMemsetAsync(dwork_, 0, head, stream));
-      for (int i = 0; i < n; i++) { const ImageEntry& e = *images_[i]; if (e.frame_index == 0 && !e.out.device_ptr) HIP_CHECK(hipMemsetAsync(dwork_ + e.off_out, 0, e.out_size + 64, stream)); }
+      for (int i = 0; i < n; i++) { const ImageEntry& e = *images_[i]; if (e.frame_index == 0 && !e.out.device_ptr) HIP_CHECK(hipMemsetAsync(dwork_ + e.off_out, 0, (e.out_size + 64) * std::max<size_t>(1, e.deliver_frames.size()), stream)); }
     } else if (plain && !cautious && !fresh) HIP_CHECK(hipMemsetAsync(dwork_, 0, head, stream));
     else HIP_CHECK(hipMemsetAsync(dwork_, 0, work_size_, stream));
   }
@@ -1892,8 +1902,17 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
         for (uint32_t k = 0; k < ne; k++) sl.ec[k] = canvas_ec[k];
       }
       // coalescing: the composite of the last frame is what the caller receives — or, for a frame of an animation, the canvas after that frame
-      const bool deliver = first.out.upto_frame >= 0 ? u == pi.first_unit + first.out.upto_frame : p.is_last;
+      // ... or, decoded once for all of them (SetOutputAllFrames), after every frame of the list, each canvas to its own slot of the output area
+      int slot = -1;
+      for (size_t k = 0; k < first.deliver_frames.size(); k++) if (first.deliver_frames[k] == u - pi.first_unit) slot = (int)k;
+      const bool all_frames = !first.deliver_frames.empty();
+      const bool deliver = all_frames ? slot >= 0 : (first.out.upto_frame >= 0 ? u == pi.first_unit + first.out.upto_frame : p.is_last);
       if (!deliver) continue;
+      if (all_frames) {   // (delivery must leave the canvas as it is: the frames behind blend onto it)
+        bool spot = false;
+        for (uint32_t k = 0; k < ne; k++) spot |= ih.extra[k].type == 2 && first.out.render_spotcolors;
+        if (spot || have_deferred_tf) throw ParseError("unsupported: all frames of an animation in one decode with spot colours to render", true);
+      }
       // ---- spot colours (stage_spot.cc): colour = mix * spot + (1 - mix) * colour with mix = solidity * channel, channel by channel
       if (first.out.render_spotcolors) {
         for (uint32_t k = 0; k < ne; k++) {
@@ -1921,10 +1940,11 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
         break;
       }
       wa.img_w = ih.xsize; wa.img_h = ih.ysize;
-      wa.out = (uint8_t*)(first.out.device_ptr ? first.out.device_ptr : dwork_ + first.off_out);
+      wa.out = (uint8_t*)(first.out.device_ptr ? first.out.device_ptr : dwork_ + first.off_out) + (all_frames ? (size_t)slot * (first.out_size + 64) : 0);
       wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian;
       wa.out_orient = first.out.keep_orientation ? 1 : ih.orientation; wa.is_gray = ih.color_space == 1;
       post_ops_.push_back([=](void* st) { LaunchWrite(wa, st); });
+      if (all_frames && slot + 1 < (int)first.deliver_frames.size()) continue;
       break;                      // (frames behind the delivered one: nothing of theirs is needed)
     }
   }
@@ -2239,6 +2259,12 @@ vec<uint8_t> Batch::ReconstructJpeg(int i, void* stream_v) {
   return out;
 }
 
+void Batch::CopyOutputSlotToHost(int i, int slot, void* dst, size_t size, void* stream_v) {
+  const ImageEntry& e = *images_[pub_[i].first_unit];
+  if (slot < 0 || (size_t)slot >= e.deliver_frames.size() || e.out.device_ptr) throw ParseError("CopyOutputSlotToHost: no such slot", false);
+  HIP_CHECK(hipMemcpyAsync(dst, dwork_ + e.off_out + (size_t)slot * (e.out_size + 64), std::min(size, e.out_size), hipMemcpyDeviceToHost, (hipStream_t)stream_v));
+  HIP_CHECK(hipStreamSynchronize((hipStream_t)stream_v));
+}
 void Batch::CopyOutputToHost(int i, void* dst, size_t size, void* stream_v) {
   const ImageEntry& e = *images_[pub_[i].first_unit];
   HIP_CHECK(hipMemcpyAsync(dst, device_output(i), std::min(size, e.out_size), hipMemcpyDeviceToHost, (hipStream_t)stream_v));

@@ -40,6 +40,7 @@ struct ImageEntry {
   uint64_t frame_bitpos = 0;
   OutputSpec out;                      // (first unit of the image)
   size_t out_stride = 0, out_size = 0;
+  vec<int> deliver_frames;             // (first unit) coalesced animation decoded once: the canvas after each of these frames goes to its own slot of the output area (SetOutputAllFrames)
   bool has_jbrd = false;
   int pub_index = 0, frame_index = 0;  // image the frame belongs to, position among its frames
   bool complex = false;                // frame of a complex image
@@ -93,6 +94,11 @@ class Batch {
   // size of the rectangle output `o` of image i covers: the image, or — non-coalesced output — frame o.only_frame as coded (before orientation)
   void OutputDims(int i, const OutputSpec& o, uint32_t* w, uint32_t* h) const;
   size_t OutputSizeOf(int i, const OutputSpec& o) const;
+  // Coalesced animation in one decode: the canvas as it stands after every frame of `frames` (ascending positions among the image's frames) is written to slot k of the
+  // image's output area in device memory (internal buffers only); CopyOutputSlotToHost hands them out.  Throws "unsupported" for what needs the canvas changed in place on
+  // delivery (spot colours, a transfer function deferred behind them): the caller then decodes frame by frame (OutputSpec::upto_frame).
+  void SetOutputAllFrames(int i, const OutputSpec& o, const vec<int>& frames);
+  void CopyOutputSlotToHost(int i, int slot, void* dst, size_t size, void* stream);
   int num_frames(int i) const { return pub_[i].num_units; }
   const ImageEntry& frame(int i, int k) const { return *images_[pub_[i].first_unit + k]; }
   void SetOutput(int i, const OutputSpec& o);

@@ -50,6 +50,8 @@ struct JxlDecoderStruct {
   bool started, need_out_reported;
   // frames as the caller counts them: every regular frame when coalescing is off, the composite (= the last frame) otherwise
   vec<int> frames; size_t frame_cursor, skip_frames; bool frame_announced;
+  // coalesced animation decoded once: the canvases after every shown frame wait in device memory, in the format of the first buffer the caller set
+  bool anim_cached, anim_cache_failed; JxlPixelFormat anim_format; bool anim_keep_orientation, anim_unpremul, anim_spot;
   bool frame_done;     // JXL_DEC_FULL_IMAGE of frames[frame_cursor] has been returned: its header stays readable until the next JxlDecoderProcessInput moves on
   Batch* batch;
   int device;
@@ -77,6 +79,7 @@ static void ClearState(JxlDecoder* d) {
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
   d->frames.clear(); d->frame_cursor = 0; d->skip_frames = 0; d->frame_announced = false; d->frame_done = false;
+  d->anim_cached = d->anim_cache_failed = false;
   d->mt_init = nullptr; d->mt_run = nullptr; d->mt_destroy = nullptr; d->mt_opaque = nullptr;
   d->ec_buffers.clear(); d->progressive_detail = 0;
   d->decompress_boxes = false; d->container.clear(); d->boxes.clear(); d->box_next = d->box_split = 0; d->box_current = -1; d->box_complete_pending = false;
@@ -672,15 +675,45 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       o.render_spotcolors = d->render_spotcolors;
       o.only_frame = d->coalescing ? -1 : d->frames[d->frame_cursor];
       o.upto_frame = d->coalescing && d->frames.size() > 1 ? d->frames[d->frame_cursor] : -1;
-      d->batch->SetOutput(0, o);
-      if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
-      d->batch->Prepare(nullptr);
-      d->batch->Run(nullptr);       // ══► the HIP hot path
-      d->batch->Finish(nullptr);
+      // Animations (coalescing): one decode serves every shown frame — the canvas after each of them is kept in device memory (Batch::SetOutputAllFrames) — as long as
+      // the caller keeps asking for the same format and no extra-channel planes; otherwise (and for what that mode cannot do) frame by frame, each replaying the frames before it
+      const bool same_format = d->anim_cached && !memcmp(&d->anim_format, &d->out_format, sizeof(JxlPixelFormat)) && d->anim_keep_orientation == d->keep_orientation &&
+                               d->anim_unpremul == d->unpremul_alpha && d->anim_spot == d->render_spotcolors;
+      int anim_slot = -1;
+      if (o.upto_frame >= 0 || (d->coalescing && d->frames.size() > 1)) {
+        if (!d->anim_cached && !d->anim_cache_failed && d->ec_buffers.empty()) {
+          try {
+            OutputSpec oa = o; oa.upto_frame = -1;
+            d->batch->SetOutputAllFrames(0, oa, d->frames);
+            if (d->batch->image(0).out_size * d->frames.size() > ((size_t)2 << 30)) throw ParseError("unsupported: too many canvases to keep", true);
+            if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
+            d->batch->Prepare(nullptr);
+            d->batch->Run(nullptr);       // ══► the HIP hot path, once for the whole animation
+            d->batch->Finish(nullptr);
+            d->anim_cached = true; d->anim_format = d->out_format; d->anim_keep_orientation = d->keep_orientation; d->anim_unpremul = d->unpremul_alpha; d->anim_spot = d->render_spotcolors;
+            anim_slot = (int)d->frame_cursor;
+          } catch (const ParseError& e) {
+            if (!e.unsupported) throw;
+            d->anim_cache_failed = true;
+          }
+        } else if (same_format && d->ec_buffers.empty()) anim_slot = (int)d->frame_cursor;
+      }
+      if (anim_slot < 0) {
+        d->anim_cached = false;           // (the batch is prepared for something else from here on)
+        d->batch->SetOutput(0, o);
+        if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
+        d->batch->Prepare(nullptr);
+        d->batch->Run(nullptr);       // ══► the HIP hot path
+        d->batch->Finish(nullptr);
+      } else if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
+      auto copy_out = [&](void* dst, size_t size) {
+        if (anim_slot >= 0) d->batch->CopyOutputSlotToHost(0, anim_slot, dst, size, nullptr);
+        else d->batch->CopyOutputToHost(0, dst, size, nullptr);
+      };
       if (d->out_callback || d->mt_run) {
         // callback output: the image is decoded as a whole on the device, then handed out row by row
         vec<uint8_t> host(d->batch->image(0).out_size);
-        d->batch->CopyOutputToHost(0, host.data(), host.size(), nullptr);
+        copy_out(host.data(), host.size());
         uint32_t w = 0, h = 0;
         d->batch->OutputDims(0, d->batch->image(0).out, &w, &h);
         if (!d->keep_orientation && d->batch->image(0).ih.orientation > 4) std::swap(w, h);
@@ -691,7 +724,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
           for (size_t y = 0; y < h; y++) d->mt_run(run_opaque, 0, 0, y, w, host.data() + y * stride);
           d->mt_destroy(run_opaque);
         } else for (size_t y = 0; y < h; y++) d->out_callback(d->out_callback_opaque, 0, y, w, host.data() + y * stride);
-      } else d->batch->CopyOutputToHost(0, d->out_buffer, d->batch->image(0).out_size, nullptr);
+      } else copy_out(d->out_buffer, d->batch->image(0).out_size);
       if (!d->ec_buffers.empty()) {
         // the alpha plane on its own (JxlDecoderSetExtraChannelBuffer): a second pass of the frame with interleaved alpha in the plane's sample type, de-interleaved here
         for (auto& eb : d->ec_buffers) {

@@ -1926,3 +1926,65 @@ def test_animation_with_more_than_256_frames(jx):
     b.add(data, "uint8", 3)
     b.prepare(); b.decode(); b.finish()
     assert np.array_equal(b.output(0), O.decode(data).pixels("u8", 3))
+
+
+def test_long_animation_is_decoded_once(jx):
+    """120 shown frames, coalesced, through the raw event loop: every canvas arrives (checked against the oracle at four places) and the whole animation costs one decode —
+    JXL_DEC_FULL_IMAGE after JXL_DEC_FULL_IMAGE comes out of the canvases kept in device memory (round 3: every frame replayed all frames before it).  A caller that changes
+    its buffer format half way gets the frame-by-frame path for the rest."""
+    import time
+    L = jx.libjxl()
+    n, w, h = 120, 96, 80
+    base = S.synthetic_image(3, w, h)
+
+    def frames(upto):
+        parts = [S.encode_vardct_frame(base, S.frame(is_last=1 if upto == 0 else 0, save_as_reference=0 if upto == 0 else 1, duration=2), seed=3, strategy_mix=0)]
+        for k in range(1, upto + 1):
+            tile = S.synthetic_image(100 + k % 5, 24, 16)
+            last = k == upto
+            parts.append(S.encode_vardct_frame(tile, S.frame(emit=1, is_last=1 if last else 0, have_crop=1, crop_x0=(k * 7) % (w - 24), crop_y0=(k * 5) % (h - 16), canvas_w=w, canvas_h=h,
+                                                             blend_mode=1 if k % 3 == 0 else 0, blend_source=1, save_as_reference=0 if last else 1, duration=1 + k % 3), seed=k, strategy_mix=0))
+        return b"".join(parts)
+    S.set_animation(100, 1, 0)
+    try:
+        full = frames(n - 1)
+        prefixes = {k: frames(k) for k in (0, 1, 57)}
+    finally:
+        S.set_animation(0)
+
+    def run(switch_at=None):
+        data = np.frombuffer(full, np.uint8)
+        dec = L.JxlDecoderCreate(None)
+        assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_FRAME | jx.JXL_DEC_FULL_IMAGE) == 0
+        assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+        L.JxlDecoderCloseInput(dec)
+        got, buf = [], None
+        while True:
+            st = L.JxlDecoderProcessInput(dec)
+            if st == jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+                nc = 4 if switch_at is not None and len(got) >= switch_at else 3
+                fmt = jx.JxlPixelFormat(nc, jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+                buf = np.zeros(w * h * nc, np.uint8)
+                assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), buf.ctypes.data, buf.size) == 0
+            elif st == jx.JXL_DEC_FULL_IMAGE:
+                got.append(buf); buf = None
+            elif st == jx.JXL_DEC_SUCCESS:
+                break
+            elif st != jx.JXL_DEC_FRAME:
+                raise AssertionError((st, jx.last_error()))
+        L.JxlDecoderDestroy(dec)
+        return got
+    run()                                   # (warm-up: first use of the kernels of the frame tail)
+    t0 = time.perf_counter()
+    got = run()
+    once = time.perf_counter() - t0
+    assert len(got) == n
+    for k, stream in prefixes.items():
+        assert np.array_equal(got[k], O.decode(stream).pixels("u8", 3)), k
+    assert np.array_equal(got[n - 1], O.decode(full).pixels("u8", 3))
+    t0 = time.perf_counter()
+    mixed = run(switch_at=100)              # RGBA from frame 100 on: those 20 frames replay their predecessors
+    per_frame_tail = time.perf_counter() - t0
+    assert len(mixed) == n and np.array_equal(mixed[57], got[57])
+    assert np.array_equal(mixed[n - 1].reshape(h, w, 4)[..., :3].reshape(-1), got[n - 1])
+    assert once < per_frame_tail, (once, per_frame_tail)      # 120 frames out of one decode take less than 100 + 20 replayed ones
