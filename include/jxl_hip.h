@@ -168,8 +168,9 @@ JxlDecoderStatus JxlDecoderGetBoxSizeContents(JxlDecoder* dec, uint64_t* size);
  * ("no flush was done"), as libjxl answers when no new image data is available. */
 JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* dec, int detail);
 JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* dec);
-/* decode.rs:1528 (types.rs:111-144): integer output is scaled to the full range of the buffer's type (JXL_BIT_DEPTH_FROM_PIXEL_FORMAT = 0, the default).
- * FROM_CODESTREAM (1) / CUSTOM (2) are accepted when they ask for exactly that (or the buffer is float) and rejected with a message otherwise. */
+/* decode.rs:1528 (types.rs:111-144): integer output is scaled to the full range of the buffer's type by default (JXL_BIT_DEPTH_FROM_PIXEL_FORMAT = 0); FROM_CODESTREAM (1) /
+ * CUSTOM (2): samples in [0, 2^bits - 1] (the write stage's multiplier), bits <= the sample type's; float buffers keep their values.  Call after the image out buffer is set;
+ * the setting lasts for that buffer. */
 typedef struct { int type; uint32_t bits_per_sample, exponent_bits_per_sample; } JxlBitDepth;
 JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* dec, const JxlBitDepth* bit_depth);
 JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* dec, uint8_t* data, size_t size);        /* decode.rs:1283 */

@@ -650,6 +650,7 @@ size_t Batch::OutputSizeOf(int i, const OutputSpec& o) const {
   OutputDims(i, o, &dims.xsize, &dims.ysize);
   return OutputSize(dims, o);
 }
+static float IntMul(const OutputSpec& o) { const uint32_t full = o.type == 0 ? 8 : 16; const uint32_t b = o.int_bits && o.int_bits < full ? o.int_bits : full; return (float)((1u << b) - 1); }
 void Batch::SetOutput(int i, const OutputSpec& o) {
   ImageEntry& e = *images_[pub_[i].first_unit];
   e.out = o;
@@ -1122,7 +1123,7 @@ void Batch::Prepare(void* stream_v) {
     f.frame_flags = (uint32_t*)(dwork_ + flags_off) + i;
     f.hf_written = (uint32_t*)(dwork_ + hfw_off_) + i;
     f.out = (uint8_t*)(e.out.device_ptr ? e.out.device_ptr : dwork_ + e.off_out);
-    f.out_stride = e.out_stride; f.out_channels = e.out.num_channels; f.out_type = e.out.type; f.out_big_endian = e.out.big_endian;
+    f.out_stride = e.out_stride; f.out_channels = e.out.num_channels; f.out_type = e.out.type; f.out_big_endian = e.out.big_endian; f.out_int_mul = IntMul(e.out);
     f.out_orient = e.out.keep_orientation ? 1 : e.ih.orientation;
     f.upsampling = p.upsampling; f.img_w = e.ih.xsize; f.img_h = e.ih.ysize;
     if (p.upsampling > 1) { f.up_weights = (const float*)(cbase + c.up_weights); for (int k = 0; k < 4; k++) f.up_plane[k] = (float*)(dbig_ + o.up_plane[k]); }
@@ -1842,7 +1843,7 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
         }
         wa.img_w = fw; wa.img_h = fh;
         wa.out = (uint8_t*)(first.out.device_ptr ? first.out.device_ptr : dwork_ + first.off_out);
-        wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian;
+        wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian; wa.out_int_mul = IntMul(first.out);
         wa.out_orient = first.out.keep_orientation ? 1 : ih.orientation; wa.is_gray = ih.color_space == 1;
         if (have_deferred_tf) {          // (the transfer function had been put off for a spot-colour stage this output does not run)
           ColorArgs ta = deferred_tf;
@@ -1941,7 +1942,7 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
       }
       wa.img_w = ih.xsize; wa.img_h = ih.ysize;
       wa.out = (uint8_t*)(first.out.device_ptr ? first.out.device_ptr : dwork_ + first.off_out) + (all_frames ? (size_t)slot * (first.out_size + 64) : 0);
-      wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian;
+      wa.out_stride = first.out_stride; wa.out_channels = first.out.num_channels; wa.out_type = first.out.type; wa.out_big_endian = first.out.big_endian; wa.out_int_mul = IntMul(first.out);
       wa.out_orient = first.out.keep_orientation ? 1 : ih.orientation; wa.is_gray = ih.color_space == 1;
       post_ops_.push_back([=](void* st) { LaunchWrite(wa, st); });
       if (all_frames && slot + 1 < (int)first.deliver_frames.size()) continue;

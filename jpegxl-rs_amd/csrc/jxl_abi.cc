@@ -37,6 +37,7 @@ struct JxlDecoderStruct {
   struct EcBuffer { uint32_t index; void* buffer; size_t size; JxlPixelFormat format; };
   vec<EcBuffer> ec_buffers;
   int progressive_detail;
+  uint32_t out_int_bits;     // JxlDecoderSetImageOutBitDepth: 0 = the range of the buffer's sample type
   // box API: the container as handed in (kept only when JXL_DEC_BOX is subscribed), its boxes in file order
   struct BoxRec { char type[4], real[4]; uint64_t raw_size; size_t body, body_size; bool brob; };
   bool decompress_boxes;
@@ -51,7 +52,7 @@ struct JxlDecoderStruct {
   // frames as the caller counts them: every regular frame when coalescing is off, the composite (= the last frame) otherwise
   vec<int> frames; size_t frame_cursor, skip_frames; bool frame_announced;
   // coalesced animation decoded once: the canvases after every shown frame wait in device memory, in the format of the first buffer the caller set
-  bool anim_cached, anim_cache_failed; JxlPixelFormat anim_format; bool anim_keep_orientation, anim_unpremul, anim_spot;
+  bool anim_cached, anim_cache_failed; JxlPixelFormat anim_format; bool anim_keep_orientation, anim_unpremul, anim_spot; uint32_t anim_int_bits;
   bool frame_done;     // JXL_DEC_FULL_IMAGE of frames[frame_cursor] has been returned: its header stays readable until the next JxlDecoderProcessInput moves on
   Batch* batch;
   int device;
@@ -81,7 +82,7 @@ static void ClearState(JxlDecoder* d) {
   d->frames.clear(); d->frame_cursor = 0; d->skip_frames = 0; d->frame_announced = false; d->frame_done = false;
   d->anim_cached = d->anim_cache_failed = false;
   d->mt_init = nullptr; d->mt_run = nullptr; d->mt_destroy = nullptr; d->mt_opaque = nullptr;
-  d->ec_buffers.clear(); d->progressive_detail = 0;
+  d->ec_buffers.clear(); d->progressive_detail = 0; d->out_int_bits = 0;
   d->decompress_boxes = false; d->container.clear(); d->boxes.clear(); d->box_next = d->box_split = 0; d->box_current = -1; d->box_complete_pending = false;
   d->box_plain.clear(); d->box_plain_ready = false; d->box_written = 0; d->box_buffer = nullptr; d->box_size = d->box_buffer_written = 0; d->box_set = false;
   DeleteBatch(d->batch); d->batch = nullptr;
@@ -477,19 +478,20 @@ JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* d) {
 }
 JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* d, const JxlBitDepth* bd) {
   if (!d || !bd || !d->out_set) { SetLastError("JxlDecoderSetImageOutBitDepth: no image out buffer is set"); return JXL_DEC_ERROR; }
-  if (bd->type == 0) return JXL_DEC_SUCCESS;                                    // from the pixel format: what the write stage does
+  if (bd->type == 0) { d->out_int_bits = 0; return JXL_DEC_SUCCESS; }           // from the pixel format: the full range of the sample type
+  if (bd->type != 1 && bd->type != 2) return JXL_DEC_ERROR;
   const uint32_t type_bits = d->out_format.data_type == JXL_TYPE_UINT8 ? 8 : d->out_format.data_type == JXL_TYPE_UINT16 ? 16 : 0;
-  if (type_bits == 0) {                                                         // float output carries no integer range
-    if (bd->type == 1 || (bd->type == 2 && bd->exponent_bits_per_sample > 0)) return JXL_DEC_SUCCESS;
-    SetLastError("an integer bit depth for a float buffer"); return JXL_DEC_ERROR;
-  }
   const ImageHeader& ih = d->batch->image(0).ih;
   const uint32_t bits = bd->type == 1 ? ih.depth.bits : bd->bits_per_sample;
-  if (bd->type != 1 && bd->type != 2) return JXL_DEC_ERROR;
+  const uint32_t exp_bits = bd->type == 1 ? (ih.depth.is_float ? ih.depth.exp_bits : 0) : bd->exponent_bits_per_sample;
+  if (type_bits == 0) {                                                         // float output carries no integer range: only a float depth makes sense
+    if (bd->type == 1 || exp_bits > 0) { d->out_int_bits = 0; return JXL_DEC_SUCCESS; }
+    SetLastError("an integer bit depth for a float buffer"); return JXL_DEC_ERROR;
+  }
+  if (exp_bits > 0) { SetLastError("a float bit depth for an integer buffer"); return JXL_DEC_ERROR; }
   if (bits == 0 || bits > type_bits) { SetLastError("bit depth does not fit the buffer's sample type"); return JXL_DEC_ERROR; }
-  if (bits == type_bits && !(bd->type == 1 && ih.depth.exp_bits) && !(bd->type == 2 && bd->exponent_bits_per_sample)) return JXL_DEC_SUCCESS;
-  SetLastError("unsupported: integer output is scaled to the full range of the buffer's type; a narrower range (bit depth from the codestream / custom) is not implemented");
-  return JXL_DEC_ERROR;
+  d->out_int_bits = bits == type_bits ? 0 : bits;                               // samples in [0, 2^bits - 1] (the write stage's multiplier)
+  return JXL_DEC_SUCCESS;
 }
 
 // ---- decode.rs:1326-1470: container boxes
@@ -673,12 +675,13 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       o.keep_orientation = d->keep_orientation;
       o.unpremul_alpha = d->unpremul_alpha;
       o.render_spotcolors = d->render_spotcolors;
+      o.int_bits = d->out_int_bits;
       o.only_frame = d->coalescing ? -1 : d->frames[d->frame_cursor];
       o.upto_frame = d->coalescing && d->frames.size() > 1 ? d->frames[d->frame_cursor] : -1;
       // Animations (coalescing): one decode serves every shown frame — the canvas after each of them is kept in device memory (Batch::SetOutputAllFrames) — as long as
       // the caller keeps asking for the same format and no extra-channel planes; otherwise (and for what that mode cannot do) frame by frame, each replaying the frames before it
       const bool same_format = d->anim_cached && !memcmp(&d->anim_format, &d->out_format, sizeof(JxlPixelFormat)) && d->anim_keep_orientation == d->keep_orientation &&
-                               d->anim_unpremul == d->unpremul_alpha && d->anim_spot == d->render_spotcolors;
+                               d->anim_unpremul == d->unpremul_alpha && d->anim_spot == d->render_spotcolors && d->anim_int_bits == d->out_int_bits;
       int anim_slot = -1;
       if (o.upto_frame >= 0 || (d->coalescing && d->frames.size() > 1)) {
         if (!d->anim_cached && !d->anim_cache_failed && d->ec_buffers.empty()) {
@@ -690,7 +693,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
             d->batch->Prepare(nullptr);
             d->batch->Run(nullptr);       // ══► the HIP hot path, once for the whole animation
             d->batch->Finish(nullptr);
-            d->anim_cached = true; d->anim_format = d->out_format; d->anim_keep_orientation = d->keep_orientation; d->anim_unpremul = d->unpremul_alpha; d->anim_spot = d->render_spotcolors;
+            d->anim_cached = true; d->anim_format = d->out_format; d->anim_keep_orientation = d->keep_orientation; d->anim_unpremul = d->unpremul_alpha; d->anim_spot = d->render_spotcolors; d->anim_int_bits = d->out_int_bits;
             anim_slot = (int)d->frame_cursor;
           } catch (const ParseError& e) {
             if (!e.unsupported) throw;
@@ -756,7 +759,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       d->frame_done = true;         // (the cursor moves on with the next call: the frame's header, name and blend info stay readable after JXL_DEC_FULL_IMAGE)
       d->events_emitted |= JXL_DEC_FULL_IMAGE;
       // every layer gets a buffer of its own size; every frame of an animation is asked for anew (decode.cc: the buffer is used up by a frame)
-      if (!d->coalescing || d->frame_cursor + 1 < d->frames.size()) { d->out_set = false; d->out_buffer = nullptr; d->out_callback = nullptr; d->mt_run = nullptr; }
+      if (!d->coalescing || d->frame_cursor + 1 < d->frames.size()) { d->out_set = false; d->out_buffer = nullptr; d->out_callback = nullptr; d->mt_run = nullptr; d->out_int_bits = 0; }
       return JXL_DEC_FULL_IMAGE;
     }
     if (!d->boxes.empty()) { const JxlDecoderStatus bs = PumpBoxes(d, d->boxes.size()); if (bs != JXL_DEC_SUCCESS) return bs; }   // the boxes behind the first codestream box

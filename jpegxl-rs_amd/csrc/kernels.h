@@ -97,6 +97,7 @@ struct FrameDev {
   uint8_t* out;
   uint64_t out_stride;            // bytes per row
   uint32_t out_channels, out_type /*0 u8 1 u16 2 f32 3 f16*/, out_big_endian;
+  float out_int_mul;              // integer output: sample = round(clamp(v, 0, 1) x this) — 255 / 65535, or 2^bits - 1 (JxlDecoderSetImageOutBitDepth)
   uint32_t out_orient;            // 1..8: orientation applied while writing (1 = none)
   // upsampling (frame coded at 1/upsampling of the image size): width/height above are the CODED size
   uint32_t upsampling, img_w, img_h;   // img_*: image size the write stage covers (= width/height when upsampling == 1)
@@ -220,7 +221,7 @@ struct BlendArgs {
   const float* bg_ec[4]; const float* bg_ec_alpha[4]; uint32_t bg_ec_stride[4];
   float* canvas[3]; float* canvas_ec[4]; uint32_t canvas_stride, canvas_ec_stride, img_w, img_h, num_extra, premul_mask; uint32_t mode[5];
 };
-struct WriteArgs { const float* p[3]; const float* alpha; uint32_t stride, alpha_stride, img_w, img_h; uint8_t* out; uint64_t out_stride; uint32_t out_channels, out_type, out_big_endian, out_orient, is_gray, unpremul; };
+struct WriteArgs { const float* p[3]; const float* alpha; uint32_t stride, alpha_stride, img_w, img_h; uint8_t* out; uint64_t out_stride; uint32_t out_channels, out_type, out_big_endian, out_orient, is_gray, unpremul; float out_int_mul; };
 void LaunchIntToFloat(const int32_t* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t w, uint32_t h, float factor, void* stream, uint32_t float_bits = 0,
                       uint32_t float_exp_bits = 0);   // float_bits != 0: the integers are float bit patterns (IntToFloatSample)
 void LaunchXybModToFloat(const int32_t* cy, const int32_t* cx, const int32_t* cb, uint32_t src_stride, float* const dst[3], uint32_t dst_stride, uint32_t w, uint32_t h, const float fac[3], void* stream);

@@ -3538,9 +3538,9 @@ __device__ __forceinline__ uint16_t FloatToHalfBits(float fv) {
 
 __device__ __forceinline__ void StoreSample(const FrameDev& f, uint8_t* p, float v) {
   if (f.out_type == 0) {
-    p[0] = (uint8_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * 255.0f);
+    p[0] = (uint8_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * f.out_int_mul);
   } else if (f.out_type == 1) {
-    const uint32_t u = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * 65535.0f);
+    const uint32_t u = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * f.out_int_mul);
     if (f.out_big_endian) { p[0] = (uint8_t)(u >> 8); p[1] = (uint8_t)u; } else { p[0] = (uint8_t)u; p[1] = (uint8_t)(u >> 8); }
   } else if (f.out_type == 2) {
     const uint32_t u = __float_as_uint(v);

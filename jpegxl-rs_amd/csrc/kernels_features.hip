@@ -447,9 +447,9 @@ __device__ __forceinline__ uint16_t HalfBits(float fv) {
   return (uint16_t)(sign | r);
 }
 __device__ __forceinline__ void StoreSampleW(const WriteArgs& a, uint8_t* p, float v) {
-  if (a.out_type == 0) p[0] = (uint8_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * 255.0f);
+  if (a.out_type == 0) p[0] = (uint8_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * a.out_int_mul);
   else if (a.out_type == 1) {
-    const uint32_t u = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * 65535.0f);
+    const uint32_t u = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, v)) * a.out_int_mul);
     if (a.out_big_endian) { p[0] = (uint8_t)(u >> 8); p[1] = (uint8_t)u; } else { p[0] = (uint8_t)u; p[1] = (uint8_t)(u >> 8); }
   } else if (a.out_type == 2) {
     const uint32_t u = __float_as_uint(v);

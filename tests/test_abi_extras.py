@@ -229,8 +229,8 @@ def test_bit_depth_progressive_detail_and_flush(jx):
         assert L.JxlDecoderSetImageOutBitDepth(dec, C.byref(jx.JxlBitDepth(0, 0, 0))) == 0      # from the pixel format
         assert L.JxlDecoderSetImageOutBitDepth(dec, C.byref(jx.JxlBitDepth(2, 16, 0))) == 0     # custom = the type's range
         assert L.JxlDecoderSetImageOutBitDepth(dec, C.byref(jx.JxlBitDepth(2, 17, 0))) == 1     # does not fit
-        assert L.JxlDecoderSetImageOutBitDepth(dec, C.byref(jx.JxlBitDepth(1, 0, 0))) == 1      # 8 bits from the codestream in a 16-bit buffer: not implemented, said so
-        assert b"not implemented" in L.JxlHipLastError()
+        assert L.JxlDecoderSetImageOutBitDepth(dec, C.byref(jx.JxlBitDepth(2, 8, 3))) == 1      # a float depth for an integer buffer
+        assert L.JxlDecoderSetImageOutBitDepth(dec, C.byref(jx.JxlBitDepth(0, 0, 0))) == 0
         assert L.JxlDecoderFlushImage(dec) == 1                                                 # nothing partial to flush
     _decode_loop(jx, L, dec, need)
     L.JxlDecoderDestroy(dec)
@@ -282,3 +282,40 @@ def test_tone_mapping_request_fails_loudly_instead_of_being_ignored(jx):
         jx.decoder_builder(desired_intensity_target=255.0).decode_with(data, np.float32)
     srgb = S.encode_vardct(S.synthetic_image(9, 96, 64), seed=3)
     jx.decoder_builder(desired_intensity_target=100.0).decode_with(srgb, np.uint8)      # an SDR image never passes through the stage
+
+
+@pytest.mark.parametrize("bits,mode", [(10, 1), (12, 1), (10, 2), (5, 2)])
+def test_image_out_bit_depth_from_the_codestream_gives_back_the_coded_integers(jx, bits, mode):
+    """decode.rs:1528 JxlDecoderSetImageOutBitDepth: a lossless 10 / 12-bit image decoded into a 16-bit buffer with the depth taken from the codestream (type 1) or given
+    (type 2) comes out as the integers that were coded (libjxl: sample = round(v x (2^bits - 1))); with the default the same buffer holds them scaled to 65535.
+    A custom depth of 5 bits on an 8-bit buffer: round(v x 31)."""
+    L = jx.libjxl()
+    rng = np.random.default_rng(bits)
+    w, h = 90, 70
+    src_bits = 8 if bits == 5 else bits
+    img = rng.integers(0, 1 << src_bits, (h, w, 3)).astype(np.int32)
+    data = np.frombuffer(S.encode_modular(img, src_bits, False, 0), np.uint8)
+    u16 = bits != 5
+    fmt = jx.JxlPixelFormat(3, jx.JXL_TYPE_UINT16 if u16 else jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+    out = {}
+    for name, depth in (("set", jx.JxlBitDepth(mode, bits if mode == 2 else 0, 0)), ("default", None)):
+        dec = L.JxlDecoderCreate(None)
+        assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_FULL_IMAGE) == 0
+        assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+        L.JxlDecoderCloseInput(dec)
+        px = np.zeros(w * h * 3, np.uint16 if u16 else np.uint8)
+
+        def need():
+            assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), px.ctypes.data, px.nbytes) == 0
+            if depth is not None:
+                assert L.JxlDecoderSetImageOutBitDepth(dec, C.byref(depth)) == 0, jx.last_error()
+        _decode_loop(jx, L, dec, need)
+        L.JxlDecoderDestroy(dec)
+        out[name] = px.reshape(h, w, 3).astype(np.int64)
+    full = 65535 if u16 else 255
+    v = img / float((1 << src_bits) - 1)
+    assert np.abs(out["default"] - np.rint(v * full).astype(np.int64)).max() <= 1      # (float32 sample x 65535 lands within one code of the float64 value)
+    if bits == 5:
+        assert np.array_equal(out["set"], np.rint(v.astype(np.float32) * np.float32(31)).astype(np.int64))
+    else:
+        assert np.array_equal(out["set"], img)
