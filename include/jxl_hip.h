@@ -149,8 +149,8 @@ typedef void (*JxlImageOutRunCallback)(void* run_opaque, size_t thread_id, size_
 typedef void (*JxlImageOutDestroyCallback)(void* run_opaque);
 JxlDecoderStatus JxlDecoderSetMultithreadedImageOutCallback(JxlDecoder* dec, const JxlPixelFormat* format, JxlImageOutInitCallback init_callback,
                                                             JxlImageOutRunCallback run_callback, JxlImageOutDestroyCallback destroy_callback, void* init_opaque);
-/* decode.rs:1224 / :1258: a separate plane for an extra channel (one sample per pixel in `format`'s type, num_channels ignored).  The alpha channel — the
- * one the interleaved 2 / 4 channel output carries — is supported; any other index is rejected with JXL_DEC_ERROR and a message (JxlHipLastError). */
+/* decode.rs:1224 / :1258: a separate plane for an extra channel (one sample per pixel in `format`'s type, num_channels ignored), any of the image's extra channels: each
+ * plane costs one more pass of the frame with that channel in the alpha slot of the interleaved output. */
 JxlDecoderStatus JxlDecoderExtraChannelBufferSize(const JxlDecoder* dec, const JxlPixelFormat* format, size_t* size, uint32_t index);
 JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* dec, const JxlPixelFormat* format, void* buffer, size_t size, uint32_t index);
 /* decode.rs:1326-1470: the boxes of the container (JXL_DEC_BOX once per box, signature and codestream boxes included; contents through a caller buffer with

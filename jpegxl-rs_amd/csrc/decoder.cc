@@ -623,6 +623,7 @@ size_t Batch::OutputStride(const ImageHeader& ih, const OutputSpec& o, uint32_t*
   uint32_t nc = o.num_channels;
   bool alpha = false;
   for (auto& e : ih.extra) if (e.type == 0) alpha = true;
+  if (o.alpha_from_extra >= 0 && (size_t)o.alpha_from_extra < ih.extra.size()) alpha = true;
   if (nc == 0) nc = (ih.color_space == 1 ? 1 : 3) + (alpha ? 1 : 0);
   if (channels) *channels = nc;
   const size_t bps = o.type == 0 ? 1 : o.type == 2 ? 4 : 2;
@@ -1607,7 +1608,8 @@ void Batch::PlanModularUndo(int i, const std::function<size_t(size_t)>& take) {
   for (uint32_t c = 0; c < op.num_c; c++) op.in[c] = list[c].off;
   op.color_factor = e.ih.depth.is_float ? 1.0f : 1.0f / (float)((1u << e.ih.depth.bits) - 1);
   op.float_bits = e.ih.depth.is_float ? e.ih.depth.bits : 0; op.float_exp_bits = e.ih.depth.exp_bits;
-  for (size_t k = 0; k < e.ih.extra.size(); k++) if (e.ih.extra[k].type == 0) {
+  const int alpha_pick = images_[pub_[e.pub_index].first_unit]->out.alpha_from_extra;
+  for (size_t k = 0; k < e.ih.extra.size(); k++) if (alpha_pick >= 0 ? (int)k == alpha_pick : e.ih.extra[k].type == 0) {
     op.has_alpha = true; op.in[3] = list[op.num_c + k].off;
     op.alpha_factor = e.ih.extra[k].depth.is_float ? 1.0f : 1.0f / (float)((1u << e.ih.extra[k].depth.bits) - 1);   // (float alpha: converted in the frame tail)
     break;
@@ -1836,7 +1838,7 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
         memset(&wa, 0, sizeof(wa));
         for (int c = 0; c < 3; c++) wa.p[c] = B(cur[c]);
         wa.stride = cur_stride;
-        for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].type == 0) {
+        for (uint32_t k = 0; k < ne; k++) if (first.out.alpha_from_extra >= 0 ? (int)k == first.out.alpha_from_extra : ih.extra[k].type == 0) {
           wa.alpha = B(cur_ec[k]); wa.alpha_stride = cur_ec_stride;
           wa.unpremul = first.out.unpremul_alpha && ih.extra[k].alpha_associated && (first.out.num_channels == 2 || first.out.num_channels == 4);
           break;
@@ -1935,7 +1937,7 @@ void Batch::PlanPostOps(HostStage& hconst, const vec<size_t>& up_weights_off) {
       memset(&wa, 0, sizeof(wa));
       for (int c = 0; c < 3; c++) wa.p[c] = B(canvas[c]);
       wa.stride = canvas_stride;
-      for (uint32_t k = 0; k < ne; k++) if (ih.extra[k].type == 0) {
+      for (uint32_t k = 0; k < ne; k++) if (first.out.alpha_from_extra >= 0 ? (int)k == first.out.alpha_from_extra : ih.extra[k].type == 0) {
         wa.alpha = B(canvas_ec[k]); wa.alpha_stride = canvas_ec_stride;
         wa.unpremul = first.out.unpremul_alpha && ih.extra[k].alpha_associated && (first.out.num_channels == 2 || first.out.num_channels == 4);
         break;

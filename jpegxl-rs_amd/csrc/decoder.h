@@ -23,6 +23,8 @@ struct OutputSpec {
   int upto_frame = -1;            // >= 0: coalesced output of an animation frame — the canvas as it stands after frame `upto_frame` has been blended (the frames behind it are not shown)
   int only_frame = -1;            // >= 0: non-coalesced output (JxlDecoderSetCoalescing(false)) — frame `only_frame` of the image as coded: its own size, its own
                                   // pixels after the colour transform, not blended onto the canvas
+  int alpha_from_extra = -1;      // which extra channel fills the alpha slot of 2 / 4-channel output: -1 = the first one of type alpha; >= 0: that extra channel, as it is
+                                  // (JxlDecoderSetExtraChannelBuffer hands out any extra channel through this slot)
   uint32_t int_bits = 0;          // integer output: 0 = the full range of the sample type, else samples in [0, 2^int_bits - 1] (JxlDecoderSetImageOutBitDepth)
   bool render_spotcolors = true;  // JxlDecoderSetRenderSpotcolors: spot-colour extra channels are mixed into the colour channels (stage_spot.cc)
 };

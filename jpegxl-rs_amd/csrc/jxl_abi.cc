@@ -456,10 +456,6 @@ JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* d, const JxlPixelFo
   size_t need = 0;
   if (!buffer || JxlDecoderExtraChannelBufferSize(d, format, &need, index) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
   if (size < need) { SetLastError("extra channel buffer too small"); return JXL_DEC_ERROR; }
-  if ((int)index != AlphaIndex(d->batch->image(0).ih)) {
-    SetLastError("unsupported: only the alpha channel can be delivered as a separate plane (the other extra channels are decoded and blended, but not handed out)");
-    return JXL_DEC_ERROR;
-  }
   for (auto& e : d->ec_buffers) if (e.index == index) { e.buffer = buffer; e.size = size; e.format = *format; return JXL_DEC_SUCCESS; }
   d->ec_buffers.push_back(JxlDecoderStruct::EcBuffer{index, buffer, size, *format});
   return JXL_DEC_SUCCESS;
@@ -729,13 +725,14 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         } else for (size_t y = 0; y < h; y++) d->out_callback(d->out_callback_opaque, 0, y, w, host.data() + y * stride);
       } else copy_out(d->out_buffer, d->batch->image(0).out_size);
       if (!d->ec_buffers.empty()) {
-        // the alpha plane on its own (JxlDecoderSetExtraChannelBuffer): a second pass of the frame with interleaved alpha in the plane's sample type, de-interleaved here
+        // an extra channel as a plane of its own (JxlDecoderSetExtraChannelBuffer): one more pass of the frame per plane with that channel in the alpha slot of the interleaved
+        // output (OutputSpec::alpha_from_extra), in the plane's sample type, de-interleaved here
         for (auto& eb : d->ec_buffers) {
           OutputSpec oe = o;
           JxlPixelFormat one = eb.format; one.num_channels = 1;
           FormatToSpec(&one, &oe);
           const bool grey = d->batch->image(0).ih.color_space == 1;
-          oe.num_channels = grey ? 2 : 4; oe.align = 0; oe.device_ptr = nullptr;
+          oe.num_channels = grey ? 2 : 4; oe.align = 0; oe.device_ptr = nullptr; oe.alpha_from_extra = (int)eb.index; oe.int_bits = 0;
           oe.keep_orientation = o.keep_orientation; oe.unpremul_alpha = false; oe.render_spotcolors = o.render_spotcolors; oe.only_frame = o.only_frame; oe.upto_frame = o.upto_frame;
           d->batch->SetOutput(0, oe);
           d->batch->Prepare(nullptr); d->batch->Run(nullptr); d->batch->Finish(nullptr);

@@ -319,3 +319,34 @@ def test_image_out_bit_depth_from_the_codestream_gives_back_the_coded_integers(j
         assert np.array_equal(out["set"], np.rint(v.astype(np.float32) * np.float32(31)).astype(np.int64))
     else:
         assert np.array_equal(out["set"], img)
+
+
+@pytest.mark.parametrize("lossy", [False, True])
+def test_a_spot_colour_channel_as_an_extra_channel_buffer(jx, lossy):
+    """an extra channel that is not alpha (a spot colour) handed out as a plane of its own: the coded samples, exactly (the extra channels of a VarDCT frame are lossless too);
+    the colour buffer of the same decode carries the image with the spot colour rendered, as without the request"""
+    L = jx.libjxl()
+    rng = np.random.default_rng(5)
+    w, h = 104, 72
+    img = rng.integers(0, 256, (h, w, 4)).astype(np.int32)
+    S.set_spot((1.0, 0.25, 0.125, 0.75))
+    try:
+        stream = S.encode_vardct(S.synthetic_image(3, w, h), seed=5, alpha=img[..., 3].astype(np.uint8)) if lossy else S.encode_modular(img, 8, False, 0)
+    finally:
+        S.set_spot()
+    data = np.frombuffer(stream, np.uint8)
+    fmt = jx.JxlPixelFormat(3, jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+    efmt = jx.JxlPixelFormat(1, jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+    dec = L.JxlDecoderCreate(None)
+    assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_FULL_IMAGE) == 0
+    assert L.JxlDecoderSetInput(dec, data.ctypes.data, len(data)) == 0
+    L.JxlDecoderCloseInput(dec)
+    px, plane = np.zeros(w * h * 3, np.uint8), np.zeros(w * h, np.uint8)
+
+    def need():
+        assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), px.ctypes.data, px.size) == 0
+        assert L.JxlDecoderSetExtraChannelBuffer(dec, C.byref(efmt), plane.ctypes.data, plane.size, 0) == 0, jx.last_error()
+    _decode_loop(jx, L, dec, need)
+    L.JxlDecoderDestroy(dec)
+    assert np.array_equal(plane.reshape(h, w), img[..., 3].astype(np.uint8))
+    assert np.array_equal(px, O.decode(stream).pixels("u8", 3))
