@@ -350,3 +350,55 @@ def test_a_spot_colour_channel_as_an_extra_channel_buffer(jx, lossy):
     L.JxlDecoderDestroy(dec)
     assert np.array_equal(plane.reshape(h, w), img[..., 3].astype(np.uint8))
     assert np.array_equal(px, O.decode(stream).pixels("u8", 3))
+
+
+def test_box_api_survives_damaged_containers(jx):
+    """bit flips and truncations anywhere in a container (box sizes, types, the brob payload, the codestream): the box walk ends in JXL_DEC_SUCCESS or a clean error,
+    never writes past a box buffer, and the decoder works afterwards"""
+    L = jx.libjxl()
+    rng = np.random.default_rng(77)
+    cs = S.encode_vardct(S.synthetic_image(3, 64, 48), seed=4)
+    outcomes = {"ok": 0, "error": 0}
+    for split in (False, True):
+        data, exif, xml = container(cs, split)
+        for trial in range(150):
+            bad = bytearray(data)
+            hi = len(bad) if trial % 2 else 120                   # half of the trials aim at the box headers in front
+            for pos in rng.integers(12, hi, 1 + trial % 3):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if trial % 9 == 8:
+                bad = bad[: int(rng.integers(40, len(bad)))]
+            raw = np.frombuffer(bytes(bad), np.uint8)
+            dec = L.JxlDecoderCreate(None)
+            assert L.JxlDecoderSubscribeEvents(dec, jx.JXL_DEC_FULL_IMAGE | jx.JXL_DEC_BOX | jx.JXL_DEC_BOX_COMPLETE) == 0
+            L.JxlDecoderSetDecompressBoxes(dec, 1)
+            assert L.JxlDecoderSetInput(dec, raw.ctypes.data, len(raw)) == 0
+            L.JxlDecoderCloseInput(dec)
+            guard = np.full(64 + 16, 0xA5, np.uint8)               # 64 bytes handed out, 16 bytes of canary behind them
+            px = np.zeros(64 * 48 * 3, np.uint8)
+            fmt = jx.JxlPixelFormat(3, jx.JXL_TYPE_UINT8, jx.JXL_NATIVE_ENDIAN, 0)
+            for _ in range(400):
+                st = L.JxlDecoderProcessInput(dec)
+                if st == jx.JXL_DEC_BOX:
+                    L.JxlDecoderReleaseBoxBuffer(dec)
+                    assert L.JxlDecoderSetBoxBuffer(dec, guard.ctypes.data, 64) == 0
+                elif st == jx.JXL_DEC_BOX_NEED_MORE_OUTPUT:
+                    L.JxlDecoderReleaseBoxBuffer(dec)
+                    assert L.JxlDecoderSetBoxBuffer(dec, guard.ctypes.data, 64) == 0
+                elif st == jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+                    if L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), px.ctypes.data, px.size) != 0:
+                        outcomes["error"] += 1
+                        break
+                elif st == jx.JXL_DEC_SUCCESS:
+                    outcomes["ok"] += 1
+                    break
+                elif st in (jx.JXL_DEC_ERROR, jx.JXL_DEC_NEED_MORE_INPUT):
+                    outcomes["error"] += 1
+                    break
+            else:
+                raise AssertionError("the event loop does not end")
+            assert (guard[64:] == 0xA5).all()
+            L.JxlDecoderDestroy(dec)
+    assert outcomes["ok"] > 20 and outcomes["error"] > 20, outcomes
+    _, px = jx.decoder_builder().decode_with(cs, np.uint8)
+    assert np.array_equal(px.reshape(-1), O.decode(cs).pixels("u8", 3))
