@@ -35,6 +35,10 @@ __constant__ float d_afv_basis[16][16] = {
 };
 
 __device__ __forceinline__ void SetError(const FrameDev& f, uint32_t e) { atomicOr(f.status, e); }
+// A frame whose LF stage failed has no usable block info, varblock lists or coefficient offsets — whatever the arena held before is still there (stale values of another
+// layout after a refill, anything after a pooled allocation) — so every stage behind the LF decode that indexes through them leaves such a frame alone (round 4: a damaged
+// LF stream + a poisoned arena made LlfKernel read a varblock count of 0xA5A5A5A5: memory fault).
+__device__ __forceinline__ bool FrameFailed(const FrameDev& f) { return __hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 
 // =====================================================================================================================
 // small device-side field readers (GroupHeader / transforms of modular sub-streams)
@@ -2093,7 +2097,7 @@ template <int CX, int CY> __device__ __forceinline__ void LlfBlock(const FrameDe
 // one thread per 8x8 block: EPF inverse sigma; blocks that are a whole varblock copy their LF sample as the LLF coefficient
 __global__ void LlfSigmaKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular) return;
+  if (f.is_modular || FrameFailed(f)) return;
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= f.bw || y >= f.bh) return;
   const size_t o = (size_t)y * f.bw + x;
@@ -2112,7 +2116,7 @@ __global__ void LlfSigmaKernel(const FrameDev* __restrict__ frames) {
 // the other).  One instantiation per shape: static loops, everything in registers.
 __global__ __launch_bounds__(256) void LlfKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
+  if (f.is_modular || FrameFailed(f)) return;
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   const uint32_t bx0 = (g % f.xgroups) * 32, by0 = (g / f.xgroups) * 32;
@@ -2154,7 +2158,7 @@ __device__ static const uint8_t kNzCtx[64] = {0,   0,   31,  62,  62,  93,  93, 
 // write; symbols are then read bit by bit through the canonical-code tables in global memory (jxl_dev.h ReadSymbol)
 __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict__ frames, int lane_stride, uint32_t lds_bytes, int only_prefix) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
+  if (f.is_modular || FrameFailed(f)) return;
   const bool pfx = f.ac_code.use_prefix != 0, lz77 = f.ac_code.lz77 != 0;
   const bool slow = pfx || lz77;                                       // symbols through the general reader (tables in global memory)
   if (only_prefix && !slow) return;
@@ -2344,7 +2348,7 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
   if (sync && threadIdx.x == 0 && atomicAdd(sync, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(sync, 0u); __threadfence(); atomicMax(sync + 1, epoch); }
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular) return;
+  if (f.is_modular || FrameFailed(f)) return;
   // prefix-coded frames: HfDecodeKernel, launched beside this one — unless they are progressive or chroma-subsampled: those are walked here (the
   // general instantiation), their symbols read bit by bit through the canonical-code tables in global memory (jxl_dev.h ReadSymbol)
   bool any_pfx = f.ac_code.use_prefix != 0 || f.ac_code.lz77 != 0;     // (prefix codes or LZ77: the general symbol reader)
@@ -2795,7 +2799,7 @@ __device__ __forceinline__ uint32_t Log2Cov8(uint32_t n) { return n == 1 ? 0u : 
 
 __global__ __launch_bounds__(256) void IdctKernel(const FrameDev* __restrict__ frames, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || f.subsampled || ((*f.frame_flags & 1) == 0 && !force_generic)) return;   // regular frames take IdctTileKernel
+  if (f.is_modular || f.subsampled || ((*f.frame_flags & 1) == 0 && !force_generic) || FrameFailed(f)) return;   // regular frames take IdctTileKernel
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
@@ -2935,7 +2939,7 @@ __device__ __forceinline__ int Log2Cov(int n) { return n == 1 ? 0 : n == 2 ? 1 :
 
 __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || f.subsampled || (*f.frame_flags & 2) == 0) return;
+  if (f.is_modular || f.subsampled || (*f.frame_flags & 2) == 0 || FrameFailed(f)) return;
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   extern __shared__ __align__(16) float s_big[];
@@ -3021,7 +3025,7 @@ __global__ __launch_bounds__(256) void BigIdctKernel(const FrameDev* __restrict_
 // brought to full resolution afterwards (ChromaUpsampleKernel).  Same arithmetic as the 8x8 path of IdctKernel (rows, then columns).
 __global__ __launch_bounds__(256) void IdctSubsampledKernel(const FrameDev* __restrict__ frames) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || !f.subsampled) return;
+  if (f.is_modular || !f.subsampled || FrameFailed(f)) return;
   const uint32_t g = blockIdx.x;
   if (g >= f.num_groups) return;
   const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
@@ -3058,7 +3062,7 @@ __global__ __launch_bounds__(256) void IdctSubsampledKernel(const FrameDev* __re
 // IdctKernel's special path (DequantCoef + SpecialTransform).
 __global__ __launch_bounds__(256) void IdctRareSpecialKernel(const FrameDev* __restrict__ frames, int force_generic) {
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || f.subsampled || force_generic) return;
+  if (f.is_modular || f.subsampled || force_generic || FrameFailed(f)) return;
   const uint32_t flags = *f.frame_flags;
   if ((flags & 1) != 0 || (flags & 16) == 0) return;    // generic frames do their own; no such block in this frame
   const uint32_t g = blockIdx.x;
@@ -3156,6 +3160,8 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL
   const uint32_t bx0 = tx * TB, by0 = ty * TB;
   const uint32_t tbw = min((uint32_t)TB, f.bw - bx0), tbh = min((uint32_t)TB, f.bh - by0);
   const uint32_t g = (by0 / 32) * f.xgroups + bx0 / 32;
+  __shared__ uint32_t s_failed;
+  if (threadIdx.x == blockDim.x - 1) s_failed = __hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (FrameFailed: read beside the block infos, looked at behind the barrier they need anyway)
   if (threadIdx.x < kNB) {
     const uint32_t bx = threadIdx.x % TB, by = threadIdx.x / TB;
     uint32_t info = 0xFFFFFFFFu, coff = 0;
@@ -3169,6 +3175,7 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL
     s_info[threadIdx.x] = info; s_coff[threadIdx.x] = coff;
   }
   __syncthreads();
+  if (s_failed) return;
   if (IsBig(BI_Strategy(s_info[0]))) return;   // aligned DCT128/256 varblocks cover whole tiles: BigIdctKernel owns them
   // ---- row / column task lists sorted by transform length.  A tile mixes 8-, 16-, 32- and 64-point rows; taken in
   // raster order every wavefront would run all four unrolled transforms one after the other (divergence), sorted by

@@ -503,7 +503,7 @@ __global__ void JpegCoefKernel(const FrameDev* __restrict__ frames, int fidx, Jp
   const FrameDev& f = frames[fidx];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;       // (block, natural coefficient index)
   const uint32_t nblk = f.bw * f.bh;
-  if (t >= nblk * 64) return;
+  if (t >= nblk * 64 || *f.status != 0) return;      // (a frame whose entropy stages failed has no usable coefficient offsets)
   const uint32_t o = t >> 6, i = t & 63, v = i >> 3, u = i & 7;
   const uint32_t bx = o % f.bw, by = o / f.bw;
   const uint32_t g = (by / 32) * f.xgroups + bx / 32;
