@@ -492,7 +492,11 @@ int Batch::Append(ParsedImage&& im) {
 // what the device path cannot take of a frame that parsed (thrown as "unsupported: ...")
 static void CheckFrameSupported(const FramePlan& p, const ImageHeader& ih) {
   if (!p.modular) {
-    for (auto& t : p.gtransforms) if (t.id == 2) throw ParseError("unsupported: squeezed extra channels in a VarDCT frame", true);
+    // squeezed extra channels (what a default cjxl encode does to the alpha of an RGBA picture): the sub-channels squeezed by >= 3 ride in the LfGroup sections — the LF
+    // kernel decodes them between the LF coefficients and the HF metadata —, the others in the PassGroup sections of ONE pass (ModularGroupFastKernel reads them behind that
+    // pass's coefficients); downsampling entries that spread them over several passes of a VarDCT frame are not handled
+    for (auto& t : p.gtransforms) if (t.id == 2 && p.num_passes > 1 && !(p.pass_min_shift[p.mod_pass] <= 0 && p.pass_max_shift[p.mod_pass] >= 2))
+      throw ParseError("unsupported: squeezed extra channels of a VarDCT frame spread over several passes", true);
     if (!p.has_global_tree) throw ParseError("unsupported: VarDCT frame without a global MA tree (its LF streams would need local trees)", true);
     if (p.subsampled && (p.base_x != 0.f || p.base_b != 0.f)) throw ParseError("unsupported: chroma from luma in a chroma-subsampled frame", true);
     if (!p.local_streams.empty()) throw ParseError("unsupported: local MA tree in the global Modular stream of a VarDCT frame", true);
@@ -1364,6 +1368,11 @@ void Batch::Prepare(void* stream_v) {
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
       if (p.modular || !p.has_global_tree || p.tree_code.use_prefix || p.tree_code.lz77 || p.tree_code.log_alpha > 8 || p.tree_code.num_clusters > 256 || p.use_lf_frame) continue;
+      {   // extra-channel sub-channels squeezed by >= 3 sit in the middle of the LfGroup sections: only the one-wavefront-per-stream kernel decodes those
+        bool lf_modular = false;
+        for (size_t c = p.global_decodable; c < p.gchannels.size(); c++) lf_modular |= p.gchannels[c].w && p.gchannels[c].h && std::min(p.gchannels[c].hshift, p.gchannels[c].vshift) >= 3;
+        if (lf_modular) continue;
+      }
       vec<LfSimtStream> mine;
       bool ok = true;
       for (uint32_t g = 0; g < p.num_lf_groups && ok; g++) {

@@ -1231,6 +1231,23 @@ __device__ void StageModular(const TreeNode* tree, uint32_t num_tree_nodes, cons
   __syncthreads();
 }
 
+__device__ __forceinline__ int32_t* ModPlane(const FrameDev& f, const ModChanDev& c) { return (int32_t*)(f.mod_base + c.off); }
+
+// Rectangle of global-image channel c inside the section unit (x0, y0, dim) for the shift range [min_shift, max_shift]
+// (dec_modular.cc DecodeGroup); false: the channel is not part of that sub-stream.
+__device__ __forceinline__ bool ModUnitRect(const FrameDev& f, uint32_t c, uint32_t x0, uint32_t y0, uint32_t dim, int min_shift, int max_shift, ChannelDesc* d) {
+  const ModChanDev m = f.mod_chan[c];
+  if (m.w == 0 || m.h == 0) return false;
+  const int shift = min(m.hshift, m.vshift);
+  if (shift < min_shift || shift > max_shift) return false;
+  const uint32_t rx = x0 >> m.hshift, ry = y0 >> m.vshift;
+  if (rx >= m.w || ry >= m.h) return false;
+  const uint32_t rw = min(dim >> m.hshift, m.w - rx), rh = min(dim >> m.vshift, m.h - ry);
+  if (rw == 0 || rh == 0) return false;
+  d->data = ModPlane(f, m) + (size_t)ry * m.w + rx; d->w = (int)rw; d->h = (int)rh; d->stride = (int)m.w; d->hs = m.hshift; d->vs = m.vshift;
+  return true;
+}
+
 // =====================================================================================================================
 // K_lf: one wavefront per LF group (four per workgroup, sharing the tables) — LF coefficients (3 channels, order Y,X,B)
 // + HF metadata, then varblock placement
@@ -1314,6 +1331,35 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
       ch.w = (int)(gbw >> f.hs[pl]); ch.h = (int)(gbh >> f.vs[pl]); ch.stride = (int)f.bw;
       before_channel(ch, c);
       DecodeChannelCoop(br, state, T, mc, ch, c);
+    }
+  }
+  // ---- ModularLfGroup (dec_frame.cc ProcessDCGroup: between the LF coefficients and the HF metadata): the sub-channels of the frame's extra channels that Squeeze
+  // halved three times or more in both directions (a default cjxl encode squeezes the alpha channel).  Nothing is in the stream when no channel falls in that range.
+  if (f.mod_nchan > f.mod_global_decodable) {
+    const uint32_t first_c = f.mod_global_decodable, px0 = bx0 * 8, py0 = by0 * 8;
+    ChannelDesc d;
+    uint32_t nch_lf = 0, widest = 0;
+    for (uint32_t c = first_c; c < f.mod_nchan; c++) if (ModUnitRect(f, c, px0, py0, 2048, 3, 1000, &d)) { nch_lf++; widest = max(widest, (uint32_t)d.w); }
+    if (nch_lf) {
+      if (lane == 0) {
+        if (has_lf && state != 0x130000u) { SetError(f, kErrAnsFinalState); s_fail = 1; }
+        BitReader tmp;
+        tmp.Init(f.cs, br.BitPos(), f.cs_size);
+        if (!ReadGroupHeader(tmp, s_gh) || !s_gh.use_global_tree || s_gh.ntransforms != 0 || (with_refs && nch_lf > 4)) { SetError(f, kErrUnsupported); s_fail = 1; }
+        br.Init(f.cs, tmp.BitPos(), sec_end);
+        state = f.mod_code.use_prefix ? 0x130000u : br.Read(32);
+      }
+      WaveSync();
+      if (s_fail) return;
+      mc.wp = s_gh.wp; mc.stream_id = 1 + f.num_lf_groups + g;
+      if (f.mod_code.lz77 && lane == 0) lz.Init(lz.window, widest);
+      WaveSync();
+      int k = 0;
+      for (uint32_t c = first_c; c < f.mod_nchan; c++) if (ModUnitRect(f, c, px0, py0, 2048, 3, 1000, &d)) {
+        before_channel(d, k);
+        DecodeChannelCoop(br, state, T, mc, d, k);
+        k++;
+      }
     }
   }
   // ---- HF metadata: 4 channels {ytox, ytob, (strategy,hf_mul-1) x nb_blocks, sharpness}
@@ -3886,23 +3932,6 @@ __device__ __forceinline__ int32_t PaletteValue(const int32_t* pal, int pal_w, i
   int i = index - pal_w - 64;
   for (int k = 0; k < c; k++) i /= 5;
   return (int32_t)(((int64_t)(i % 5) * ((1 << bit_depth) - 1)) / 4);
-}
-
-__device__ __forceinline__ int32_t* ModPlane(const FrameDev& f, const ModChanDev& c) { return (int32_t*)(f.mod_base + c.off); }
-
-// Rectangle of global-image channel c inside the section unit (x0, y0, dim) for the shift range [min_shift, max_shift]
-// (dec_modular.cc DecodeGroup); false: the channel is not part of that sub-stream.
-__device__ __forceinline__ bool ModUnitRect(const FrameDev& f, uint32_t c, uint32_t x0, uint32_t y0, uint32_t dim, int min_shift, int max_shift, ChannelDesc* d) {
-  const ModChanDev m = f.mod_chan[c];
-  if (m.w == 0 || m.h == 0) return false;
-  const int shift = min(m.hshift, m.vshift);
-  if (shift < min_shift || shift > max_shift) return false;
-  const uint32_t rx = x0 >> m.hshift, ry = y0 >> m.vshift;
-  if (rx >= m.w || ry >= m.h) return false;
-  const uint32_t rw = min(dim >> m.hshift, m.w - rx), rh = min(dim >> m.vshift, m.h - ry);
-  if (rw == 0 || rh == 0) return false;
-  d->data = ModPlane(f, m) + (size_t)ry * m.w + rx; d->w = (int)rw; d->h = (int)rh; d->stride = (int)m.w; d->hs = m.hshift; d->vs = m.vshift;
-  return true;
 }
 
 // The global stream (meta channels + every channel that fits one group) with the same cooperative decoder: one wavefront

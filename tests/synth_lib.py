@@ -267,6 +267,12 @@ def set_lz77_ac(on=False):
     lib().jxlsynth_set_lz77_ac(1 if on else 0)
 
 
+def set_alpha_squeeze(on=False):
+    """VarDCT frames written from now on (this thread) put their extra channel through the default Squeeze chain, like a default cjxl encode of an RGBA picture: its
+    sub-channels ride in GlobalModular, the LfGroup sections (between LF coefficients and HF metadata) and the PassGroup sections of the last pass"""
+    lib().jxlsynth_set_alpha_squeeze(1 if on else 0)
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

@@ -894,6 +894,49 @@ def test_vardct_with_alpha_extra_channel(jx, w, h):
     check_against_oracle(jx, data, np.uint8, 4)
 
 
+def test_vardct_with_squeezed_alpha(jx):
+    """The extra channel of a VarDCT frame under the default Squeeze chain (what cjxl does to the alpha of an RGBA picture): residual channels in GlobalModular,
+    in the LfGroup sections (shift >= 3: decoded by the LF kernel between the LF coefficients and the HF metadata) and in the PassGroup tails; inverse
+    Squeeze before the write stage.  Alone, batched beside plain frames, and with the stream cut / bit-flipped."""
+    from test_synth_roundtrip import squeezed_alpha_streams
+    cases = squeezed_alpha_streams()
+    for name, sq, plain, al in cases:
+        meta, px = jx.decoder_builder().decode_with(sq, np.uint8)
+        assert meta.has_alpha_channel, name
+        h, w = al.shape
+        assert np.array_equal(px.reshape(h, w, 4)[..., 3], al), name
+        check_against_oracle(jx, sq, np.uint8, 4)
+        check_against_oracle(jx, sq, np.float32, 4)
+        check_against_oracle(jx, sq, np.uint8, 3)
+    # one batch: squeezed frames beside their plain twins (the SIMT LF path for the twins, the cooperative kernel for the LfGroup sub-channels)
+    streams = [c[1] for c in cases] + [c[2] for c in cases]
+    b = jx.BatchDecoder(0)
+    for s in streams:
+        b.add(s, "uint8", 4)
+    b.prepare()
+    for _ in range(2):
+        b.decode()
+        b.finish()
+        for i, (name, sq, plain, al) in enumerate(cases):
+            assert np.array_equal(b.output(i), b.output(i + len(cases))), name
+            assert np.array_equal(np.asarray(b.output(i)).reshape(al.shape + (4,))[..., 3], al), name
+    rng = np.random.default_rng(12)
+    for name, sq, plain, al in cases[:3]:
+        for k in range(24):
+            bad = bytearray(sq)
+            if k % 3 == 0:
+                bad = bad[: int(rng.integers(40, len(bad)))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[int(rng.integers(30, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+            except Exception:
+                pass
+        meta, px = jx.decoder_builder().decode_with(sq, np.uint8)      # the decoder is still sound
+        assert np.array_equal(px.reshape(al.shape + (4,))[..., 3], al), name
+
+
 @pytest.mark.parametrize("up,custom,with_alpha", [(2, 0, False), (2, 1, False), (4, 1, False), (8, 1, False), (2, 0, True), (4, 1, True)])
 def test_upsampled_frames(jx, up, custom, with_alpha):
     """north_star's "upsampling": frames coded at 1/2, 1/4, 1/8 of the image size and brought back by the non-separable 5x5

@@ -141,6 +141,36 @@ def test_layered_modular_frames_blend_like_the_arithmetic_says(mode):
     assert np.abs(px - exp).max() <= 0.5
 
 
+def squeezed_alpha_streams():
+    """(name, squeezed stream, its unsqueezed twin, alpha plane): the extra channel of a VarDCT frame put through the default Squeeze chain, the way a default
+    cjxl encode of an RGBA picture stores it: one-group frame (everything in GlobalModular), several groups (PassGroup tails of every shift), a frame wider than
+    an LF group (shift >= 3 sub-channels in the LfGroup sections, between the LF coefficients and the HF metadata), three passes (all of it in the last one)."""
+    out = []
+    for name, (w, h), shape, kw in [("one_group", (200, 136), 0, {}), ("groups", (700, 560), 0, {}), ("lf_groups", (2300, 400), 0, {}),
+                                    ("three_passes", (520, 300), 0, dict(num_passes=3)), ("cjxl_shaped_lf", (700, 560), 1, {}), ("cjxl_shaped_lf_groups", (2100, 300), 1, {})]:
+        img = S.synthetic_image(31, w, h)
+        yy, xx = np.mgrid[0:h, 0:w]
+        al = ((np.sin(xx / 23.0) * np.cos(yy / 13.0) * 0.5 + 0.5) * 255).astype(np.uint8)
+        S.set_lf_tree_shape(shape)       # 1: weighted-predictor LF streams, the SIMT LF kernel's case
+        try:
+            plain = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1, alpha=al, **kw)
+            S.set_alpha_squeeze(True)
+            sq = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1, alpha=al, **kw)
+        finally:
+            S.set_alpha_squeeze(False)
+            S.set_lf_tree_shape(0)
+        out.append((name, sq, plain, al))
+    return out
+
+
+def test_squeezed_alpha_in_vardct_frames():
+    for name, sq, plain, al in squeezed_alpha_streams():
+        assert sq != plain, name
+        a, b = O.decode(sq).image("u8", 4), O.decode(plain).image("u8", 4)
+        assert np.array_equal(a[..., 3], al), name            # Squeeze is lossless
+        assert np.array_equal(a, b), name                      # and the colour channels do not notice
+
+
 def test_layer_partly_outside_the_canvas_and_alpha_blending():
     img, small = _layers()
     f0 = S.encode_modular_frame(img, S.frame(is_last=0, save_as_reference=1), bits=8)

@@ -835,6 +835,14 @@ static const uint16_t kNzCtx[64] = {0xBAD, 0,   31,  62,  62,  93,  93,  93,  93
 static const uint8_t kDefaultBlockCtx[39] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14,
                                              7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
 
+struct SChan { std::vector<int32_t> d; int w, h, hs, vs; };
+struct SqStep { bool horizontal, in_place; int begin_c, num_c; };
+static std::vector<SqStep> DefaultSqueezeSteps(const std::vector<SChan>& ch);
+static void ApplySqueeze(std::vector<SChan>& ch, const std::vector<SqStep>& steps);
+// the extra channel of the VarDCT frames written from now on (this thread) goes through the default Squeeze chain — what a default cjxl encode of an RGBA picture does
+// (its alpha is coded "lossy": squeezed, residuals quantised through the tree's multipliers): sub-channels squeezed by >= 3 ride in the LfGroup sections between the
+// LF coefficients and the HF metadata, the others in the PassGroup sections of the last pass, the small ones in GlobalModular
+static bool& AlphaSqueeze() { static thread_local bool v = false; return v; }
 static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr, int img_w = 0, int img_h = 0) {
   if (img_w == 0) { img_w = w; img_h = h; }   // (w, h) = coded size; (img_w, img_h) = image size when the frame is upsampled
   const int bw = (w + 7) / 8, bh = (h + 7) / 8;
@@ -1101,12 +1109,50 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   // --- optional alpha: one 8-bit extra channel coded losslessly by the frame's Modular sub-streams (GlobalModular when
   // the image fits one group, else the modular part of every PassGroup), under the same global tree
   std::vector<Token> alpha_global_tok;
-  std::vector<std::vector<Token>> alpha_tok(ngroups);
+  std::vector<std::vector<Token>> alpha_tok(ngroups), alpha_lf_tok;
+  std::vector<char> alpha_lf_has, alpha_has;          // squeezed alpha: which LfGroup / PassGroup sections carry a Modular sub-stream
+  const bool alpha_sq = alpha && AlphaSqueeze();
   const bool alpha_global = alpha && w <= 256 && h <= 256;
   if (alpha) {
     std::vector<int32_t> a32((size_t)w * h);
     for (size_t i = 0; i < a32.size(); i++) a32[i] = alpha[i];
-    if (alpha_global) {
+    if (AlphaSqueeze()) {
+      std::vector<SChan> ach(1);
+      ach[0].d = a32; ach[0].w = w; ach[0].h = h; ach[0].hs = ach[0].vs = 0;
+      ApplySqueeze(ach, DefaultSqueezeSteps(ach));
+      const int nfinal = (int)ach.size();
+      int nglobal = 0;
+      while (nglobal < nfinal && ach[nglobal].w <= 256 && ach[nglobal].h <= 256) nglobal++;
+      {
+        std::vector<ChanRef> cr;
+        for (int c = 0; c < nglobal; c++) if (ach[c].w && ach[c].h) cr.push_back({ach[c].d.data(), ach[c].w, ach[c].h});
+        ModularTokens(gt, root, cr, 0, alpha_global_tok);
+      }
+      auto group_stream = [&](int x0, int y0, int dim, int min_shift, int max_shift, int stream_id, std::vector<Token>& out) -> bool {
+        std::vector<std::vector<int32_t>> store;
+        std::vector<ChanRef> cr;
+        for (int c = nglobal; c < nfinal; c++) {
+          const SChan& sc = ach[c];
+          if (!sc.w || !sc.h) continue;
+          const int shift = std::min(sc.hs, sc.vs);
+          if (shift < min_shift || shift > max_shift) continue;
+          const int rx = x0 >> sc.hs, ry = y0 >> sc.vs;
+          if (rx >= sc.w || ry >= sc.h) continue;
+          const int rw = std::min(dim >> sc.hs, sc.w - rx), rh = std::min(dim >> sc.vs, sc.h - ry);
+          if (rw <= 0 || rh <= 0) continue;
+          store.emplace_back((size_t)rw * rh);
+          for (int y = 0; y < rh; y++) memcpy(&store.back()[(size_t)y * rw], &sc.d[(size_t)(ry + y) * sc.w + rx], sizeof(int32_t) * rw);
+          cr.push_back({nullptr, rw, rh});
+        }
+        for (size_t i = 0; i < cr.size(); i++) cr[i].d = store[i].data();
+        if (cr.empty()) return false;
+        ModularTokens(gt, root, cr, stream_id, out);
+        return true;
+      };
+      alpha_lf_tok.resize(nlf); alpha_lf_has.assign(nlf, 0); alpha_has.assign(ngroups, 0);
+      for (int g = 0; g < nlf; g++) alpha_lf_has[g] = group_stream((g % xlg) * 2048, (g / xlg) * 2048, 2048, 3, 1000, 1 + nlf + g, alpha_lf_tok[g]);
+      for (int g = 0; g < ngroups; g++) alpha_has[g] = group_stream((g % xg) * 256, (g / xg) * 256, 256, 0, 2, 1 + 3 * nlf + 17 + ngroups * (p.num_passes - 1) + g, alpha_tok[g]);
+    } else if (alpha_global) {
       std::vector<ChanRef> cr{{a32.data(), w, h}};
       ModularTokens(gt, root, cr, 0, alpha_global_tok);
     } else {
@@ -1117,6 +1163,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
         std::vector<ChanRef> cr{{rect.data(), gw, gh}};
         ModularTokens(gt, root, cr, 1 + 3 * nlf + 17 + ngroups * (p.num_passes - 1) + g, alpha_tok[g]);
       }
+      alpha_has.assign(ngroups, 1);
     }
   }
   // --- entropy codes
@@ -1130,7 +1177,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     for (auto& d : lgd) { ApplyLz77(d.lf_tok, (uint32_t)gt.num_leaves, proto, (size_t)d.gbw); ApplyLz77(d.meta_tok, (uint32_t)gt.num_leaves, proto, 0); }
   }
   { std::vector<const std::vector<Token>*> s; for (auto& d : lgd) { s.push_back(&d.lf_tok); s.push_back(&d.meta_tok); }
-    s.push_back(&alpha_global_tok); for (auto& t : alpha_tok) s.push_back(&t);
+    s.push_back(&alpha_global_tok); for (auto& t : alpha_tok) s.push_back(&t); for (auto& t : alpha_lf_tok) s.push_back(&t);
     BuildEntropyCoder(s, gt.num_leaves + (lz77_lf ? 1 : 0), UintConfig{4, 2, 0}, 32, mod_code);
     if (lz77_lf) { mod_code.lz77 = true; mod_code.lz_min_symbol = 224; mod_code.lz_min_length = 3; mod_code.lz_len_cfg = UintConfig{3, 0, 0}; } }
   const bool lz77_ac = UseLz77Ac();
@@ -1160,7 +1207,9 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     EncodeTokens(s, tree_code, tree_tokens);
     WriteEntropyCode(s, mod_code);
     if (alpha) {  // the global Modular image has a channel: GroupHeader + whatever is decodable globally
-      s.put(1, 1); s.put(1, 1); s.put(0, 2);
+      s.put(1, 1); s.put(1, 1);
+      if (alpha_sq) { s.put(1, 2); s.put(2, 2); WriteU32(s, 0, {0, 0}, {4, 1}, {6, 9}, {8, 41}); }    // one transform: Squeeze with the default chain (zero explicit steps)
+      else s.put(0, 2);
       EncodeTokens(s, mod_code, alpha_global_tok);
     }
     sections.push_back(s);
@@ -1173,7 +1222,8 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
       WriteGroupHeaderLf(s);
       EncodeTokens(s, mod_code, d.lf_tok);
     }
-    // (ModularLfGroup: no channels -> nothing)
+    // ModularLfGroup: the extra channel's sub-channels squeezed by >= 3 in both directions (none without Squeeze: nothing is written then)
+    if (alpha_sq && alpha_lf_has[g]) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, mod_code, alpha_lf_tok[g]); }
     s.put(d.nb - 1, CeilLog2((uint32_t)(d.gbw * d.gbh)));
     WriteGroupHeaderLf(s);
     EncodeTokens(s, mod_code, d.meta_tok);
@@ -1211,7 +1261,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     // preset: ceil_log2(1) = 0 bits
     EncodeTokens(s, ac_codes[ps], ac_tok_all[(size_t)ps * ngroups + g]);
     // extra channels (shift 0..2) ride in the last pass (Passes::GetDownsamplingBracket without downsampling entries)
-    if (alpha && !alpha_global && ps == np - 1) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, mod_code, alpha_tok[g]); }
+    if (alpha && (alpha_sq || !alpha_global) && ps == np - 1 && alpha_has[g]) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, mod_code, alpha_tok[g]); }
     sections.push_back(s);
   }
   BitWriter out;
@@ -1226,8 +1276,6 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
 }
 
 // ---- Modular lossless encoder (gradient predictor, fixed global tree, 256x256 groups, optional RCT + Squeeze) -----
-struct SChan { std::vector<int32_t> d; int w, h, hs, vs; };
-struct SqStep { bool horizontal, in_place; int begin_c, num_c; };
 
 // ISO/IEC 18181-1 squeeze "smooth tendency" (the decoder adds it back, so both sides must agree exactly)
 static int64_t SqTendency(int64_t B, int64_t a, int64_t n) {
@@ -1479,6 +1527,7 @@ void jxlsynth_set_preview(int w, int h) { synth::g_preview_w = w; synth::g_previ
 void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
+void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
 void jxlsynth_set_lf_tree_shape(int shape) { synth::LfTreeShape() = shape; }
 // rgba == NULL: the extra channel is alpha again
