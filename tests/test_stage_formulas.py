@@ -626,3 +626,94 @@ def test_blend_modes_follow_their_definition(jx, mode):
         out = B * F
     want[y0:y0 + ch, x0:x0 + cw] = out
     assert np.abs(got - want).max() <= 4 * EPS * max(1.0, float(np.abs(want).max())), (mode, float(np.abs(got - want).max()))
+
+
+# ---- noise synthesis -------------------------------------------------------------------------------------------------------------------
+M64 = (1 << 64) - 1
+
+
+def splitmix64(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def noise_planes(w, h, group_dim, visible, nonvisible):
+    """The three planes of uniform samples in [1, 2) (dec_noise.cc Random3Planes / base/random.h): per group of the frame, eight Xorshift128+
+    generators seeded by SplitMix64 chains from (visible frame index, non-visible frame index) and (x0, y0) of the group; a batch of eight 64-bit
+    words gives sixteen floats (low word first), mantissa = the top 23 bits of each 32-bit word; rows take whole batches, planes follow each other."""
+    out = np.zeros((3, h, w), np.float32)
+    golden = 0x9E3779B97F4A7C15
+    for gy0 in range(0, h, group_dim):
+        for gx0 in range(0, w, group_dim):
+            s0 = [splitmix64((((visible << 32) + nonvisible) + golden) & M64)]
+            s1 = [splitmix64((((gx0 << 32) + gy0) + golden) & M64)]
+            for _ in range(7):
+                s0.append(splitmix64(s0[-1])); s1.append(splitmix64(s1[-1]))
+            s0, s1 = np.array(s0, np.uint64), np.array(s1, np.uint64)
+            xs, ys = min(group_dim, w - gx0), min(group_dim, h - gy0)
+            nb = (xs + 15) // 16
+            for c in range(3):
+                words = np.empty((ys, nb, 8), np.uint64)
+                for y in range(ys):
+                    for k in range(nb):
+                        a, b = s0, s1
+                        words[y, k] = a + b
+                        s0 = b
+                        a = a ^ (a << np.uint64(23))
+                        s1 = a ^ b ^ (a >> np.uint64(18)) ^ (b >> np.uint64(5))
+                halves = words.view(np.uint32).reshape(ys, nb * 16)          # little endian: low word first
+                f = ((halves >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32)
+                out[c, gy0:gy0 + ys, gx0:gx0 + xs] = f[:, :xs]
+    return out
+
+
+def noise_strength(lut, v):
+    """stage_noise.cc: piecewise-linear LUT over eight points at intensity k / 6, clamped to [0, 1]; beyond the last point the last value"""
+    s = np.maximum(0.0, v * 6.0)
+    fl = np.floor(s)
+    frac = s - fl
+    over = s >= 7.0
+    fl = np.where(over, 6.0, fl); frac = np.where(over, 1.0, frac)
+    i = fl.astype(int)
+    return np.clip(lut[i] + (lut[i + 1] - lut[i]) * frac, 0.0, 1.0)
+
+
+@pytest.mark.parametrize("w,h,lut", [(300, 280, [30, 60, 90, 120, 150, 180, 210, 240]), (77, 61, [1023, 800, 600, 400, 300, 200, 100, 0])])
+def test_noise_synthesis_follows_its_definition(jx, w, h, lut):
+    """Noise (ISO/IEC 18181-1 noise synthesis; libjxl dec_noise.cc + stage_noise.cc): the pseudo-random planes, the 5x5 high-pass (centre -3.84, the other 24
+    taps 0.16, mirrored borders), the intensity-dependent strength from the frame's 8-point LUT, the correlated injection into X / Y / B with the frame's base
+    chroma-from-luma factors (0 and 1).  The decoder's linear f32 pixels of the noisy frame against inverse-opsin(float64) of (the XYB planes of the SAME
+    frame before noise, read off the device, + the noise restated here)."""
+    img = S.synthetic_image(19, w, h)
+    S.set_color(1, 1, 8)
+    try:
+        data = S.encode_vardct_frame(img, S.frame(noise_lut=lut), seed=3, strategy_mix=1, epf_iters=0, gab=0)
+    finally:
+        S.set_color()
+    xyb, _ = planes_after(jx, data, 1, 0, 0)
+    px, _ = planes_after(jx, data, 0, 0, 0)
+    rnd = noise_planes(w, h, 256, 1, 0).astype(np.float64)            # the first shown frame counts as visible frame 1 (dec_frame.cc InitFrame increments before the frame is decoded)
+    pad = np.pad(rnd, ((0, 0), (2, 2), (2, 2)), mode="symmetric")            # Mirror(): -1 -> 0, -2 -> 1
+    total = sum(pad[:, 2 + dy:2 + dy + h, 2 + dx:2 + dx + w] for dy in range(-2, 3) for dx in range(-2, 3))
+    conv = (total - rnd) * 0.16 + rnd * -3.84
+    X, Y, B = xyb
+    lutf = np.array(lut, np.float64) / 1024.0
+    sg, sr = noise_strength(lutf, (Y - X) * 0.5), noise_strength(lutf, (Y + X) * 0.5)
+    ar, ag, ac = conv * 0.22
+    red = sr * (0.0078125 * ar + 0.9921875 * ac)
+    green = sg * (0.0078125 * ag + 0.9921875 * ac)
+    rg = red + green
+    X2, Y2, B2 = X + 0.0 * rg + red - green, Y + rg, B + 1.0 * rg
+    assert np.abs(rg).max() > 0.02                                           # the noise is far above the tolerance below
+    bias = -0.0037930732552754493
+    cb = np.cbrt(bias)
+    mixed = [np.power(Y2 + X2 - cb, 3) + bias, np.power(Y2 - X2 - cb, 3) + bias, np.power(B2 - cb, 3) + bias]
+    inv = np.array([[11.031566901960783, -9.866943921568629, -0.16462299647058826],
+                    [-3.254147380392157, 4.418770392156863, -0.16462299647058826],
+                    [-3.6588512862745097, 2.7129230470588235, 1.9459282392156863]])
+    want = np.stack([sum(inv[r, k] * mixed[k] for k in range(3)) for r in range(3)], axis=-1)
+    got = px.astype(np.float64)
+    # 25 taps of values in [1, 2) cancel to a high-pass of a few units: ~25 x 2^-23 x 2 absolute on the convolution, x 0.22 x strength, then the inverse opsin's
+    # cancelling matrix rows (x ~11 x the slope of the cube): 2e-5 absolute on linear values in [0, 1]
+    assert np.abs(got - want).max() <= 2e-5, float(np.abs(got - want).max())
