@@ -7,7 +7,8 @@ IEC 61966-2-1 formula).  The planes between the stages come off the device throu
 JxlHipBatchDebugRead (include/jxl_hip.h); inputs of a stage are what the stage before left, so each test isolates one stage.
 Round 4 adds: the six 8x8 transforms that are not a plain DCT (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3: dec_transforms-inl.h), the
 DCT128 / 256 family against scipy's idctn, the lowest frequencies of multi-block transforms from the LF samples (the standard's product-of-
-cosines scale), the adaptive LF smoothing (compressed_dc.cc) and the 2x / 4x / 8x upsampling from the stored weights (stage_upsampling.cc).
+cosines scale), the adaptive LF smoothing (compressed_dc.cc), the 2x / 4x / 8x upsampling from the stored weights (stage_upsampling.cc), frame and
+patch blending (blending.cc), noise synthesis (dec_noise.cc, stage_noise.cc) and spline rendering (splines.cc).
 Tolerances: a few float32 ULPs of the magnitude of the values that enter a sum (stated per test)."""
 import numpy as np
 import pytest
@@ -628,6 +629,59 @@ def test_blend_modes_follow_their_definition(jx, mode):
     assert np.abs(got - want).max() <= 4 * EPS * max(1.0, float(np.abs(want).max())), (mode, float(np.abs(got - want).max()))
 
 
+# ---- patches (stage_patches.cc; blending.cc) ----------------------------------------------------------------------------------------------
+def test_patch_blend_modes_follow_their_definition(jx):
+    """Rectangles of a saved reference frame (RGBA, lossless Modular, kept before the colour transform) pasted into an RGBA frame under every patch blend mode,
+    colour and alpha each with the placement's own mode, non-premultiplied alpha: 1 replace; 2 add; 3 multiply; 4 blend above (patch over frame):
+    a = pa + fa (1 - pa), colour (patch pa + frame fa (1 - pa)) / a; 5 blend below (frame over patch); 6 alpha-weighted add above: frame + patch pa, alpha of the
+    frame kept; 7 alpha-weighted add below: patch + frame fa, alpha of the patch.  Inputs: the frame without patches and the reference picture, each decoded as an
+    image of its own; expected values in float64; no oracle code."""
+    w, h, rw, rh = 200, 136, 64, 48
+    main, ref = S.synthetic_image(51, w, h), S.synthetic_image(50, rw, rh)
+    al_main = (64 + np.add.outer(np.arange(h), np.arange(w)) % 192).astype(np.uint8)
+    al_ref = (np.add.outer(np.arange(rh), np.arange(rw)) * 3 % 256).astype(np.uint8)
+    f_main, f_ref = np.dstack([main, al_main]), np.dstack([ref, al_ref])
+    px0, py0, pw, ph = 2, 3, 24, 20                                            # the rectangle of the reference frame that is pasted
+    spots = {1: (5, 5), 2: (60, 10), 3: (120, 40), 4: (30, 90), 5: (170, 110), 6: (100, 100), 7: (150, 5)}      # mode -> where (non-overlapping; one runs off the right edge? no: all inside)
+    patches = [(1, px0, py0, pw, ph, [(x, y, [(m, 0, 0), (m, 0, 0)]) for m, (x, y) in spots.items()])]
+    plain = S.encode_modular_frame(f_main, S.frame(), bits=8)
+    ref_alone = S.encode_modular_frame(f_ref, S.frame(), bits=8)
+    ref_frame = S.encode_modular_frame(f_ref, S.frame(frame_type=2, is_last=0, save_as_reference=1, save_before_ct=1, have_crop=1, canvas_w=w, canvas_h=h), bits=8)
+    S.set_features(patches=patches, num_extra=1)
+    try:
+        with_patches = ref_frame + S.encode_modular_frame(f_main, S.frame(emit=1), bits=8)
+    finally:
+        S.set_features()
+    dec = lambda d, hh, ww: jx.decoder_builder().decode_with(d, np.float32)[1].reshape(hh, ww, 4).astype(np.float64)
+    frame, src, got = dec(plain, h, w), dec(ref_alone, rh, rw), dec(with_patches, h, w)
+    assert np.abs(frame * 255 - f_main).max() < 1e-4 and np.abs(src * 255 - f_ref).max() < 1e-4
+    P = src[py0:py0 + ph, px0:px0 + pw]
+    want = frame.copy()
+    for m, (x, y) in spots.items():
+        F = frame[y:y + ph, x:x + pw]
+        fa, pa = F[..., 3:], P[..., 3:]
+        if m == 1:
+            out = P
+        elif m == 2:
+            out = F + P
+        elif m == 3:
+            out = F * P
+        elif m in (4, 5):
+            fg, bg = (P, F) if m == 4 else (F, P)
+            ga, ba = fg[..., 3:], bg[..., 3:]
+            a = ga + ba * (1 - ga)
+            col = np.where(a > 0, (fg[..., :3] * ga + bg[..., :3] * ba * (1 - ga)) / np.where(a > 0, a, 1), 0.0)
+            out = np.concatenate([col, a], axis=-1)
+        elif m == 6:
+            out = np.concatenate([F[..., :3] + P[..., :3] * pa, fa], axis=-1)
+        else:
+            out = np.concatenate([P[..., :3] + F[..., :3] * fa, pa], axis=-1)
+        want[y:y + ph, x:x + pw] = out
+    assert np.abs(want - frame).max() > 0.2
+    err = np.abs(got - want)
+    assert err.max() <= 4 * EPS * max(1.0, float(np.abs(want).max())), {m: float(err[y:y + ph, x:x + pw].max()) for m, (x, y) in spots.items()}
+
+
 # ---- noise synthesis -------------------------------------------------------------------------------------------------------------------
 M64 = (1 << 64) - 1
 
@@ -717,3 +771,130 @@ def test_noise_synthesis_follows_its_definition(jx, w, h, lut):
     # 25 taps of values in [1, 2) cancel to a high-pass of a few units: ~25 x 2^-23 x 2 absolute on the convolution, x 0.22 x strength, then the inverse opsin's
     # cancelling matrix rows (x ~11 x the slope of the cube): 2e-5 absolute on linear values in [0, 1]
     assert np.abs(got - want).max() <= 2e-5, float(np.abs(got - want).max())
+
+
+# ---- splines -----------------------------------------------------------------------------------------------------------------------------
+def catmull_rom(points):
+    """Centripetal Catmull-Rom through the control points, 16 samples per span, the ends extended by reflection (splines.cc DrawCentripetalCatmullRomSpline)"""
+    pts = [np.array(p, np.float64) for p in points]
+    pts = [pts[0] + (pts[0] - pts[1])] + pts + [pts[-1] + (pts[-1] - pts[-2])]
+    out = []
+    for s in range(len(pts) - 3):
+        p = pts[s:s + 4]
+        out.append(p[1])
+        d = [np.sqrt(np.hypot(*(p[k + 1] - p[k]))) for k in range(3)]       # knot spacing |chord|^(1/2)
+        t = [0.0, d[0], d[0] + d[1], d[0] + d[1] + d[2]]
+        for i in range(1, 16):
+            tt = d[0] + i / 16 * d[1]
+            a = [p[k] + (tt - t[k]) / d[k] * (p[k + 1] - p[k]) for k in range(3)]
+            b = [a[k] + (tt - t[k]) / (d[k] + d[k + 1]) * (a[k + 1] - a[k]) for k in range(2)]
+            out.append(b[0] + (tt - t[1]) / d[1] * (b[1] - b[0]))
+    out.append(pts[-2])
+    return out
+
+
+def equally_spaced(points):
+    """Walk the polyline in steps of arc length 1 (splines.cc ForEachEquallySpacedPoint): (point, multiplier) with multiplier 1 except for the remainder at the end"""
+    out = [(points[0], 1.0)]
+    current, nxt = points[0], 0
+    while nxt < len(points):
+        previous, from_previous = current, 0.0
+        while True:
+            if nxt == len(points):
+                out.append((previous, from_previous))
+                return out
+            to_next = float(np.hypot(*(points[nxt] - previous)))
+            if from_previous + to_next >= 1.0:
+                current = previous + (1.0 - from_previous) / to_next * (points[nxt] - previous)
+                out.append((current, 1.0))
+                break
+            from_previous += to_next
+            previous = points[nxt]
+            nxt += 1
+    return out
+
+
+def fast_erf_rational(x):
+    """base/fast_math-inl.h FastErff: 1 - 1 / (1 + a1 x + a2 x^2 + a3 x^3 + a4 x^4)^4 (Abramowitz & Stegun 7.1.27 with refitted coefficients)"""
+    a = np.abs(x)
+    d = 1.0 + a * (2.77820801e-01 + a * (2.32120216e-01 + a * (2.05260015e-04 + a * 7.77394369e-02)))
+    r = 1.0 - 1.0 / d ** 4
+    return np.where(x <= 0, -r, r)
+
+
+def render_splines(w, h, quant_adjust, splines, erf_fn):
+    """(3, h, w) float64: what the splines add to X, Y, B (ISO/IEC 18181-1 splines; libjxl splines.cc): dequantised control points and 32-point DCTs of colour and
+    sigma along the arc, one Gaussian-profile dab per unit of arc length: colour(t) * sigma(t) / 4 * multiplier * (erf((d / 2 + sqrt(2) / 4) / sigma) - erf((d / 2 - sqrt(2) / 4) / sigma))^2"""
+    out = np.zeros((3, h, w))
+    inv_quant = 1.0 / (1.0 + 0.125 * quant_adjust) if quant_adjust >= 0 else 1.0 - 0.125 * quant_adjust
+    weight = [0.0042, 0.075, 0.07, 0.3333]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    for sx, sy, deltas, colour_q, sigma_q in splines:
+        cps, cx, cy, dx, dy = [(float(sx), float(sy))], sx, sy, 0, 0
+        for ddx, ddy in deltas:
+            dx += ddx; dy += ddy; cx += dx; cy += dy
+            cps.append((float(cx), float(cy)))
+        dct = np.array([np.array(colour_q[c], np.float64) * weight[c] for c in range(3)] + [np.array(sigma_q, np.float64) * weight[3]]) * inv_quant
+        dct[:, 0] *= np.sqrt(0.5)
+        dct[0] += 0.0 * dct[1]                                                # the frame's base chroma-from-luma factors: 0 for X ...
+        dct[2] += 1.0 * dct[1]                                                # ... and 1 for B
+        pts = equally_spaced(catmull_rom(cps))
+        arc = (len(pts) - 2) + pts[-1][1]
+        for k, (pt, mult) in enumerate(pts):
+            t = 31.0 * min(1.0, k / arc)
+            vals = np.sqrt(2.0) * (dct * np.cos(np.pi / 32 * np.arange(32) * (t + 0.5))).sum(axis=1)
+            colour, sigma = vals[:3], vals[3]
+            if sigma == 0 or not np.isfinite(1.0 / sigma):
+                continue
+            max_colour = max(0.01, float(np.abs(colour * mult).max()))
+            max_dist = np.sqrt(-2.0 * sigma * sigma * (np.log(0.1) * 5 - np.log(max_colour)))
+            y0, y1 = max(0, int(np.floor(pt[1] - max_dist + 0.5))), min(h, int(np.floor(pt[1] + max_dist + 0.5)) + 1)
+            x0, x1 = max(0, int(np.floor(pt[0] - max_dist + 0.5))), min(w, int(np.floor(pt[0] + max_dist + 0.5)) + 1)
+            if y0 >= y1 or x0 >= x1:
+                continue
+            d = np.hypot(xx[y0:y1, x0:x1] - pt[0], yy[y0:y1, x0:x1] - pt[1])
+            f = erf_fn((d * 0.5 + np.sqrt(2) / 4) / sigma) - erf_fn((d * 0.5 - np.sqrt(2) / 4) / sigma)
+            out[:, y0:y1, x0:x1] += colour[:, None, None] * (0.25 * sigma * mult * f * f)
+    return out
+
+
+def test_splines_follow_their_definition(jx):
+    """Splines: the XYB planes before the splines come off the device (stop after the IDCT; no filters), the decoder's linear f32 pixels go back to XYB through the
+    float64 forward opsin, and the difference is what the spline stage added.  Against the float64 rendering above, (1) with libjxl's rational erf (the curve, the
+    arc-length walk, the DCT evaluation with exact cosines, the dab formula, the order-independent sum: what is left is float32 rounding and FastCosf, 4e-6 of
+    its argument range) and (2) with the exact erf (the rational form is within 6e-4 of it: a looser bound that does not lean on the recalled coefficients)."""
+    from scipy.special import erf
+    w, h = 200, 136
+    img = S.synthetic_image(23, w, h)
+    colour = [[0] * 32 for _ in range(3)]
+    colour[1][0] = 24; colour[0][0] = 30; colour[2][1] = -12; colour[1][3] = 5; colour[0][2] = -9
+    sigma = [0] * 32
+    sigma[0] = 9; sigma[2] = 2
+    splines = [(20, 30, [(15, 5), (2, -3), (-4, 6)], colour, sigma), (150, 20, [(-10, 20)], colour, sigma), (60, 110, [(25, -7), (-3, -2)], colour, sigma)]
+    S.set_color(1, 1, 8)
+    S.set_features(splines=(1, splines))
+    try:
+        data = S.encode_vardct_frame(img, S.frame(), seed=4, strategy_mix=1, epf_iters=0, gab=0)
+    finally:
+        S.set_features()
+        S.set_color()
+    before, _ = planes_after(jx, data, 1, 0, 0)
+    px, _ = planes_after(jx, data, 0, 0, 0)
+    inv = np.array([[11.031566901960783, -9.866943921568629, -0.16462299647058826],
+                    [-3.254147380392157, 4.418770392156863, -0.16462299647058826],
+                    [-3.6588512862745097, 2.7129230470588235, 1.9459282392156863]])
+    bias = -0.0037930732552754493
+    mixed = np.einsum("rk,yxk->ryx", np.linalg.inv(inv), px.astype(np.float64))
+    gamma = np.cbrt(mixed - bias) + np.cbrt(bias)
+    after = np.stack([(gamma[0] - gamma[1]) / 2, (gamma[0] + gamma[1]) / 2, gamma[2]])
+    got = after - before
+    want = render_splines(w, h, 1, splines, fast_erf_rational)
+    peak = np.abs(want).max(axis=(1, 2))
+    assert peak.min() > 0.02, peak                                            # every channel carries a visible spline
+    touched = np.abs(want).sum(axis=0) > 0
+    assert 0.03 < touched.mean() < 0.6                                         # and most of the picture is left alone
+    err = np.abs(got - want).max(axis=(1, 2))
+    assert (err <= 2e-5 * peak + 4e-6).all(), (err, peak)
+    exact = render_splines(w, h, 1, splines, erf)
+    err = np.abs(got - exact).max(axis=(1, 2))
+    assert (err <= 5e-3 * peak).all(), (err, peak)
