@@ -492,7 +492,7 @@ int Batch::Append(ParsedImage&& im) {
 // what the device path cannot take of a frame that parsed (thrown as "unsupported: ...")
 static void CheckFrameSupported(const FramePlan& p, const ImageHeader& ih) {
   if (!p.modular) {
-    // squeezed extra channels (what a default cjxl encode does to the alpha of an RGBA picture): the sub-channels squeezed by >= 3 ride in the LfGroup sections — the LF
+    // squeezed extra channels (what cjxl does to a progressive or lossy alpha of an RGBA picture): the sub-channels squeezed by >= 3 ride in the LfGroup sections — the LF
     // kernel decodes them between the LF coefficients and the HF metadata —, the others in the PassGroup sections of ONE pass (ModularGroupFastKernel reads them behind that
     // pass's coefficients); downsampling entries that spread them over several passes of a VarDCT frame are not handled
     for (auto& t : p.gtransforms) if (t.id == 2 && p.num_passes > 1 && !(p.pass_min_shift[p.mod_pass] <= 0 && p.pass_max_shift[p.mod_pass] >= 2))

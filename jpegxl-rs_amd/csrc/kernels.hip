@@ -1334,7 +1334,7 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
     }
   }
   // ---- ModularLfGroup (dec_frame.cc ProcessDCGroup: between the LF coefficients and the HF metadata): the sub-channels of the frame's extra channels that Squeeze
-  // halved three times or more in both directions (a default cjxl encode squeezes the alpha channel).  Nothing is in the stream when no channel falls in that range.
+  // halved three times or more in both directions (cjxl squeezes a progressive or lossy alpha channel).  Nothing is in the stream when no channel falls in that range.
   if (f.mod_nchan > f.mod_global_decodable) {
     const uint32_t first_c = f.mod_global_decodable, px0 = bx0 * 8, py0 = by0 * 8;
     ChannelDesc d;

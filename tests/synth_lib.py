@@ -268,7 +268,7 @@ def set_lz77_ac(on=False):
 
 
 def set_alpha_squeeze(on=False):
-    """VarDCT frames written from now on (this thread) put their extra channel through the default Squeeze chain, like a default cjxl encode of an RGBA picture: its
+    """VarDCT frames written from now on (this thread) put their extra channel through the default Squeeze chain, like a cjxl encode of an RGBA picture with a progressive or lossy alpha: its
     sub-channels ride in GlobalModular, the LfGroup sections (between LF coefficients and HF metadata) and the PassGroup sections of the last pass"""
     lib().jxlsynth_set_alpha_squeeze(1 if on else 0)
 

@@ -895,7 +895,7 @@ def test_vardct_with_alpha_extra_channel(jx, w, h):
 
 
 def test_vardct_with_squeezed_alpha(jx):
-    """The extra channel of a VarDCT frame under the default Squeeze chain (what cjxl does to the alpha of an RGBA picture): residual channels in GlobalModular,
+    """The extra channel of a VarDCT frame under the default Squeeze chain (what cjxl does to a progressive or lossy alpha of an RGBA picture): residual channels in GlobalModular,
     in the LfGroup sections (shift >= 3: decoded by the LF kernel between the LF coefficients and the HF metadata) and in the PassGroup tails; inverse
     Squeeze before the write stage.  Alone, batched beside plain frames, and with the stream cut / bit-flipped."""
     from test_synth_roundtrip import squeezed_alpha_streams

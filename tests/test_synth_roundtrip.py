@@ -142,8 +142,8 @@ def test_layered_modular_frames_blend_like_the_arithmetic_says(mode):
 
 
 def squeezed_alpha_streams():
-    """(name, squeezed stream, its unsqueezed twin, alpha plane): the extra channel of a VarDCT frame put through the default Squeeze chain, the way a default
-    cjxl encode of an RGBA picture stores it: one-group frame (everything in GlobalModular), several groups (PassGroup tails of every shift), a frame wider than
+    """(name, squeezed stream, its unsqueezed twin, alpha plane): the extra channel of a VarDCT frame put through the default Squeeze chain, the way cjxl
+    stores a progressive or lossy alpha of an RGBA picture: one-group frame (everything in GlobalModular), several groups (PassGroup tails of every shift), a frame wider than
     an LF group (shift >= 3 sub-channels in the LfGroup sections, between the LF coefficients and the HF metadata), three passes (all of it in the last one)."""
     out = []
     for name, (w, h), shape, kw in [("one_group", (200, 136), 0, {}), ("groups", (700, 560), 0, {}), ("lf_groups", (2300, 400), 0, {}),

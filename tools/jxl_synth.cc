@@ -839,7 +839,7 @@ struct SChan { std::vector<int32_t> d; int w, h, hs, vs; };
 struct SqStep { bool horizontal, in_place; int begin_c, num_c; };
 static std::vector<SqStep> DefaultSqueezeSteps(const std::vector<SChan>& ch);
 static void ApplySqueeze(std::vector<SChan>& ch, const std::vector<SqStep>& steps);
-// the extra channel of the VarDCT frames written from now on (this thread) goes through the default Squeeze chain — what a default cjxl encode of an RGBA picture does
+// the extra channel of the VarDCT frames written from now on (this thread) goes through the default Squeeze chain — what a cjxl encode of an RGBA picture with a progressive or lossy alpha does
 // (its alpha is coded "lossy": squeezed, residuals quantised through the tree's multipliers): sub-channels squeezed by >= 3 ride in the LfGroup sections between the
 // LF coefficients and the HF metadata, the others in the PassGroup sections of the last pass, the small ones in GlobalModular
 static bool& AlphaSqueeze() { static thread_local bool v = false; return v; }
