@@ -599,7 +599,8 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
     const bool last = p.is_last;
     bitpos = p.frame_end_bitpos;
     if (p.frame_type == 1) {              // an LF frame: kept aside for the frames that refer to it (decoded by Batch::lf_batch_), never displayed
-      if (!ih.extra.empty()) throw ParseError("unsupported: LF frame of an image with extra channels", true);
+      // (every frame carries the image's extra channels, an LF frame too — libjxl's encoder fills them with zeros there; they are decoded with the frame and not looked at)
+      if (ih.extra.size() > 4) throw ParseError("unsupported: LF frame of an image with more than 4 extra channels", true);
       lf_frames[p.lf_level] = std::shared_ptr<ImageEntry>(e.release());
       continue;
     }

@@ -1118,6 +1118,17 @@ def test_full_size_4k_frame(jx):
     assert 10 * np.log10(255.0 ** 2 / (err ** 2).mean()) > 36.0     # size-independent property: decodes to the source picture
 
 
+def test_lf_frames_of_images_with_alpha(jx):
+    """An RGBA image whose LF image is an LF frame: the LF frame carries the image's extra channel as well (zeros at 1/8 scale in a `cjxl --progressive_dc` file); it is decoded
+    with the frame and ignored, the alpha comes from the frame proper — plain or squeezed."""
+    from test_synth_roundtrip import lf_frame_alpha_streams
+    for name, stream, al in lf_frame_alpha_streams():
+        meta, px = check_against_oracle(jx, stream, np.uint8, 4)
+        assert meta.has_alpha_channel and np.array_equal(px.reshape(al.shape + (4,))[..., 3], al), name
+        check_against_oracle(jx, stream, np.float32, 4)
+        check_against_oracle(jx, stream, np.uint8, 3)
+
+
 def test_full_size_4k_frame_with_lf_frame_and_prefix_codes(jx):
     """BASELINE config 2's size with what round 3 added: a 3840x2160 frame whose LF image is an LF frame (480x270, itself a VarDCT frame), both under
     prefix codes.  Bit-exact vs the CPU decode; decodes to the source picture (size-independent property)."""

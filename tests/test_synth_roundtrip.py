@@ -307,6 +307,41 @@ def lf_frame_streams():
     return out
 
 
+def lf_frame_alpha_streams():
+    """(name, stream, twin without the LF frame's detour, alpha): RGBA images whose LF image travels as an LF frame.  Every frame codes the image's extra channels, the LF
+    frame too (`cjxl --progressive_dc` on an RGBA picture writes a zero-filled one at 1/8 scale); a decoder reads past them and takes the alpha of the frame proper."""
+    import numpy as np
+    import synth_lib as S
+    out = []
+    for name, (w, h), lf_modular, squeeze in [("vardct_lf", (300, 200), False, False), ("modular_lf", (264, 136), True, False), ("vardct_lf_squeezed_alpha", (700, 560), False, True)]:
+        img = S.synthetic_image(83, w, h)
+        al = (np.add.outer(np.arange(h), np.arange(w)) * 3 % 256).astype(np.uint8)
+        small = _block_means(img)
+        sal = (np.add.outer(np.arange(small.shape[0]), np.arange(small.shape[1])) * 7 % 256).astype(np.uint8)       # (anything: it is not looked at)
+        parts = [S.encode_vardct_frame(img, S.frame(emit=2), seed=3, alpha=al)]
+        fx = S.frame(emit=1, is_last=0, frame_type=1, lf_level=1, xyb_image=1 if lf_modular else 0)
+        if lf_modular:
+            ints = np.stack([small[..., 1].astype(np.int32) * 2, small[..., 0].astype(np.int32) // 8 - 16, small[..., 2].astype(np.int32) // 4 - 32, sal.astype(np.int32)], axis=-1)
+            parts.append(S.encode_modular_frame(ints, fx, bits=8))
+        else:
+            parts.append(S.encode_vardct_frame(small, fx, seed=5, distance=0.3, epf_iters=0, gab=0, alpha=sal))
+        S.set_alpha_squeeze(squeeze)
+        try:
+            parts.append(S.encode_vardct_frame(img, S.frame(emit=1, use_lf_frame=1), seed=3, strategy_mix=2, epf_iters=1, alpha=al))
+        finally:
+            S.set_alpha_squeeze(False)
+        out.append((name, b"".join(parts), al))
+    return out
+
+
+def test_lf_frames_of_images_with_alpha():
+    import numpy as np
+    import oracle_lib as O
+    for name, stream, al in lf_frame_alpha_streams():
+        px = O.decode(stream).image("u8", 4)
+        assert np.array_equal(px[..., 3], al), name
+
+
 def test_lf_frames_feed_the_frames_that_refer_to_them():
     """frame_header.cc kLFFrame / kUseLfFrame, dec_cache.cc dc_frames: the decode of an image whose LF image comes from an LF frame is the picture
     (within what a distance-1 VarDCT frame loses whose LF image was made from block means of the sRGB samples and coded at distance 0.3); the Modular LF frame's arbitrary samples show up as
