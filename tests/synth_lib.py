@@ -273,6 +273,11 @@ def set_alpha_squeeze(on=False):
     lib().jxlsynth_set_alpha_squeeze(1 if on else 0)
 
 
+def set_hf_presets(n=1):
+    """VarDCT frames written from now on (this thread) carry n histogram sets for their AC coefficients (HfGlobal num_hf_presets); group g of every pass uses set g % n"""
+    lib().jxlsynth_set_hf_presets(int(n))
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

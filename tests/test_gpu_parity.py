@@ -894,6 +894,35 @@ def test_vardct_with_alpha_extra_channel(jx, w, h):
     check_against_oracle(jx, data, np.uint8, 4)
 
 
+def test_several_hf_histogram_sets(jx):
+    """HfGlobal num_hf_presets > 1 (what libjxl's encoder writes for larger pictures): every PassGroup picks one of several sets of AC histograms.  Alone (both HF kernels: the
+    SIMT one for ANS streams, HfDecodeKernel for prefix codes), in one batch beside their one-set twins, and with the selector damaged."""
+    from test_synth_roundtrip import hf_preset_streams
+    cases = hf_preset_streams()
+    for name, many, one in cases:
+        check_against_oracle(jx, many, np.uint8, 3)
+        check_against_oracle(jx, many, np.float32, 3)
+    b = jx.BatchDecoder(0)
+    for name, many, one in cases:
+        b.add(many, "uint8", 3); b.add(one, "uint8", 3)
+    b.prepare()
+    for _ in range(2):
+        b.decode(); b.finish()
+        for i, (name, many, one) in enumerate(cases):
+            assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), name
+    rng = np.random.default_rng(5)
+    for name, many, one in cases[:3]:
+        for k in range(30):
+            bad = bytearray(many)
+            for _ in range(1 + k % 3):
+                bad[int(rng.integers(len(bad) // 6, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+            except jx.DecodeError:
+                pass
+        check_against_oracle(jx, many, np.uint8, 3)
+
+
 def test_vardct_with_squeezed_alpha(jx):
     """The extra channel of a VarDCT frame under the default Squeeze chain (what cjxl does to a progressive or lossy alpha of an RGBA picture): residual channels in GlobalModular,
     in the LfGroup sections (shift >= 3: decoded by the LF kernel between the LF coefficients and the HF metadata) and in the PassGroup tails; inverse

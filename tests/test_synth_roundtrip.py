@@ -141,6 +141,33 @@ def test_layered_modular_frames_blend_like_the_arithmetic_says(mode):
     assert np.abs(px - exp).max() <= 0.5
 
 
+def hf_preset_streams():
+    """(name, stream with several histogram sets, its one-set twin): HfGlobal num_hf_presets > 1 — libjxl's encoder clusters the groups of a larger picture into several sets of AC
+    histograms; every PassGroup names its set, whose contexts follow those of the sets before it.  Single pass, progressive, > 1 LF group, prefix codes, LZ77."""
+    out = []
+    for name, (w, h), n, kw, opt in [("two_sets", (700, 560), 2, {}, None), ("five_sets_passes", (520, 300), 5, dict(num_passes=3), None), ("three_sets_lf_groups", (2300, 400), 3, {}, None),
+                                     ("prefix", (700, 560), 3, {}, "prefix"), ("lz77", (520, 300), 2, {}, "lz77")]:
+        img = S.synthetic_image(33, w, h)
+        if opt == "prefix":
+            S.set_prefix(True)
+        if opt == "lz77":
+            S.set_lz77_ac(True)
+        try:
+            one = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1, **kw)
+            S.set_hf_presets(n)
+            many = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1, **kw)
+        finally:
+            S.set_hf_presets(1); S.set_prefix(False); S.set_lz77_ac(False)
+        out.append((name, many, one))
+    return out
+
+
+def test_several_hf_histogram_sets():
+    for name, many, one in hf_preset_streams():
+        assert many != one, name
+        assert np.array_equal(O.decode(many).image("u8", 3), O.decode(one).image("u8", 3)), name
+
+
 def squeezed_alpha_streams():
     """(name, squeezed stream, its unsqueezed twin, alpha plane): the extra channel of a VarDCT frame put through the default Squeeze chain, the way cjxl
     stores a progressive or lossy alpha of an RGBA picture: one-group frame (everything in GlobalModular), several groups (PassGroup tails of every shift), a frame wider than

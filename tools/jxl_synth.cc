@@ -843,6 +843,9 @@ static void ApplySqueeze(std::vector<SChan>& ch, const std::vector<SqStep>& step
 // (its alpha is coded "lossy": squeezed, residuals quantised through the tree's multipliers): sub-channels squeezed by >= 3 ride in the LfGroup sections between the
 // LF coefficients and the HF metadata, the others in the PassGroup sections of the last pass, the small ones in GlobalModular
 static bool& AlphaSqueeze() { static thread_local bool v = false; return v; }
+// number of histogram sets ("HF presets", HfGlobal num_hf_presets) of the VarDCT frames written from now on (this thread): group g of every pass codes its coefficients
+// with set g % n — libjxl's encoder clusters the groups of a large picture into several sets
+static int& HfPresets() { static thread_local int v = 1; return v; }
 static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr, int img_w = 0, int img_h = 0) {
   if (img_w == 0) { img_w = w; img_h = h; }   // (w, h) = coded size; (img_w, img_h) = image size when the frame is upsampled
   const int bw = (w + 7) / 8, bh = (h + 7) / 8;
@@ -1181,14 +1184,17 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     BuildEntropyCoder(s, gt.num_leaves + (lz77_lf ? 1 : 0), UintConfig{4, 2, 0}, 32, mod_code);
     if (lz77_lf) { mod_code.lz77 = true; mod_code.lz_min_symbol = 224; mod_code.lz_min_length = 3; mod_code.lz_len_cfg = UintConfig{3, 0, 0}; } }
   const bool lz77_ac = UseLz77Ac();
+  const int npresets = std::max(1, std::min(HfPresets(), ngroups));
   for (int ps = 0; ps < np; ps++) {
+    if (npresets > 1)      // histogram set g % npresets: its contexts follow those of the sets before it (dec_group.cc: context offset = histo_selector * num AC contexts)
+      for (int g = 0; g < ngroups; g++) for (Token& t : ac_tok_all[(size_t)ps * ngroups + g]) t.ctx += (uint32_t)((g % npresets) * 495 * nctx);
     if (lz77_ac) {   // LZ77 over every group's coefficient stream of the pass (dec_group.cc reads them with a reader without distance multiplier)
       EntropyCoder proto;
       proto.lz_min_symbol = 224; proto.lz_min_length = 3; proto.lz_len_cfg = UintConfig{3, 0, 0};
-      for (int g = 0; g < ngroups; g++) ApplyLz77(ac_tok_all[(size_t)ps * ngroups + g], (uint32_t)(495 * nctx), proto, 0, /*special=*/false);
+      for (int g = 0; g < ngroups; g++) ApplyLz77(ac_tok_all[(size_t)ps * ngroups + g], (uint32_t)(495 * nctx * npresets), proto, 0, /*special=*/false);
     }
     std::vector<const std::vector<Token>*> s; for (int g = 0; g < ngroups; g++) s.push_back(&ac_tok_all[(size_t)ps * ngroups + g]);
-    BuildEntropyCoder(s, 495 * nctx + (lz77_ac ? 1 : 0), UintConfig{4, 2, 0}, 96, ac_codes[ps]);
+    BuildEntropyCoder(s, 495 * nctx * npresets + (lz77_ac ? 1 : 0), UintConfig{4, 2, 0}, 96, ac_codes[ps]);
     if (lz77_ac) { ac_codes[ps].lz77 = true; ac_codes[ps].lz_min_symbol = 224; ac_codes[ps].lz_min_length = 3; ac_codes[ps].lz_len_cfg = UintConfig{3, 0, 0}; }
   }
   // --- sections
@@ -1249,7 +1255,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
         case 6: write_bands(q.dct); break;
       }
     }
-    s.put(0, CeilLog2((uint32_t)ngroups));  // num_hf_presets - 1
+    s.put((uint32_t)(npresets - 1), CeilLog2((uint32_t)ngroups));  // num_hf_presets - 1
     for (int ps = 0; ps < np; ps++) {       // HfPass: natural orders, one entropy code per pass
       s.put(2, 2);                          // used_orders = Val(0)
       WriteEntropyCode(s, ac_codes[ps]);
@@ -1258,7 +1264,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   }
   for (int ps = 0; ps < np; ps++) for (int g = 0; g < ngroups; g++) {  // PassGroup, pass-major
     BitWriter s;
-    // preset: ceil_log2(1) = 0 bits
+    s.put((uint32_t)(g % npresets), CeilLog2((uint32_t)npresets));   // which histogram set (0 bits when there is one)
     EncodeTokens(s, ac_codes[ps], ac_tok_all[(size_t)ps * ngroups + g]);
     // extra channels (shift 0..2) ride in the last pass (Passes::GetDownsamplingBracket without downsampling entries)
     if (alpha && (alpha_sq || !alpha_global) && ps == np - 1 && alpha_has[g]) { s.put(1, 1); s.put(1, 1); s.put(0, 2); EncodeTokens(s, mod_code, alpha_tok[g]); }
@@ -1528,6 +1534,7 @@ void jxlsynth_set_prefix(int on) { synth::UsePrefixCodes() = on != 0; }
 void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
+void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
 void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
 void jxlsynth_set_lf_tree_shape(int shape) { synth::LfTreeShape() = shape; }
 // rgba == NULL: the extra channel is alpha again
