@@ -1073,9 +1073,12 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
           if (use_wp) wp_pred = wpl.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
           TreeNode n;
           if (mode == 1) {
-            int32_t v = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
-            v = v < -512 ? -512 : (v > 511 ? 511 : v);
-            n = T.Node(LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)));
+            const int32_t v0 = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
+            const int32_t v = v0 < -512 ? -512 : (v0 > 511 ? 511 : v0);
+            if (wide_subroot != 0xFFFFFFFFu && v != v0) {      // a split beyond the LUT's range and a value out there: walk the subtree
+              n = T.Node(wide_subroot);
+              while (n.prop >= 0) n = T.Node(v0 > n.val ? n.a : n.b);
+            } else n = T.Node(LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)));
           } else {
             // all 16 properties of the sample once, into LDS; every tree level then costs a node read and one indexed read
             // instead of a 16-way select over recomputed values
@@ -1164,9 +1167,12 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
         if (use_wp) wp_pred = wp_in_lds ? wpl.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err) : wps.Predict(mc.wp, x, y, N, W, NE, NW, NN, &wp_err);
         TreeNode n;
         if (mode == 1) {
-          int32_t v = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
-          v = v < -512 ? -512 : (v > 511 ? 511 : v);
-          n = T.Node(LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)));
+          const int32_t v0 = prop < 0 ? 0 : PropValue(prop, chan, mc.stream_id, x, y, W, N, NW, NE, NN, WW, prev9, 0);
+          const int32_t v = v0 < -512 ? -512 : (v0 > 511 ? 511 : v0);
+          if (wide_subroot != 0xFFFFFFFFu && v != v0) {      // a split beyond the LUT's range and a value out there: walk the subtree
+            n = T.Node(wide_subroot);
+            while (n.prop >= 0) n = T.Node(v0 > n.val ? n.a : n.b);
+          } else n = T.Node(LdS<uint16_t>(wb + kLutOff + 2 * (uint32_t)(v + 512)));
         } else {
           uint32_t pos = subroot;
           n = T.Node(pos);

@@ -278,6 +278,11 @@ def set_hf_presets(n=1):
     lib().jxlsynth_set_hf_presets(int(n))
 
 
+def set_modular_group_shift(shift=1):
+    """Modular frames written from now on (this thread) use groups of 128 << shift samples a side (frame header group_size_shift; 1 = 256 is the default)"""
+    lib().jxlsynth_set_modular_group_shift(int(shift))
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

@@ -894,6 +894,17 @@ def test_vardct_with_alpha_extra_channel(jx, w, h):
     check_against_oracle(jx, data, np.uint8, 4)
 
 
+def test_modular_group_sizes(jx):
+    """Modular frames with groups of 128, 512 and 1024 samples a side (frame header group_size_shift 0, 2, 3): the section grid, the LfGroup size (8 groups) and
+    which channels fit GlobalModular all follow the group size.  Lossless: the source samples come back; also against the oracle."""
+    from test_synth_roundtrip import modular_group_size_streams
+    for name, data, img, bits in modular_group_size_streams():
+        dtype = np.uint8 if bits == 8 else np.uint16
+        meta, px = jx.decoder_builder().decode_with(data, dtype)
+        assert np.array_equal(px.reshape(img.shape), img), name
+        check_against_oracle(jx, data, np.float32, img.shape[2])
+
+
 def test_several_hf_histogram_sets(jx):
     """HfGlobal num_hf_presets > 1 (what libjxl's encoder writes for larger pictures): every PassGroup picks one of several sets of AC histograms.  Alone (both HF kernels: the
     SIMT one for ANS streams, HfDecodeKernel for prefix codes), in one batch beside their one-set twins, and with the selector damaged."""

@@ -141,6 +141,28 @@ def test_layered_modular_frames_blend_like_the_arithmetic_says(mode):
     assert np.abs(px - exp).max() <= 0.5
 
 
+def modular_group_size_streams():
+    """(name, stream, samples, bits): Modular frames with group_size_shift 0, 2, 3 (groups of 128, 512, 1024 samples a side; `cjxl -g`), plain and squeezed, RGB / RGBA / grey"""
+    from test_gpu_parity import _smooth_image
+    out = []
+    for shift in (0, 2, 3):
+        for (w, h, nch, bits, sq) in [(700, 560, 3, 8, 0), (1300, 1100, 4, 16, 1), (333, 300, 1, 8, 0), (2300, 400, 3, 8, 1)]:
+            img = _smooth_image(7 + shift, h, w, nch, bits)
+            S.set_modular_group_shift(shift)
+            try:
+                data = S.encode_modular(img, bits, True, sq)
+            finally:
+                S.set_modular_group_shift(1)
+            out.append((f"shift{shift}_{w}x{h}x{nch}_{bits}b_sq{sq}", data, img, bits))
+    return out
+
+
+def test_modular_group_sizes():
+    for name, data, img, bits in modular_group_size_streams():
+        out = O.decode(data).image("u8" if bits == 8 else "u16", img.shape[2])
+        assert np.array_equal(out.reshape(img.shape), img), name
+
+
 def hf_preset_streams():
     """(name, stream with several histogram sets, its one-set twin): HfGlobal num_hf_presets > 1 — libjxl's encoder clusters the groups of a larger picture into several sets of AC
     histograms; every PassGroup names its set, whose contexts follow those of the sets before it.  Single pass, progressive, > 1 LF group, prefix codes, LZ77."""

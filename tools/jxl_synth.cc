@@ -846,6 +846,8 @@ static bool& AlphaSqueeze() { static thread_local bool v = false; return v; }
 // number of histogram sets ("HF presets", HfGlobal num_hf_presets) of the VarDCT frames written from now on (this thread): group g of every pass codes its coefficients
 // with set g % n — libjxl's encoder clusters the groups of a large picture into several sets
 static int& HfPresets() { static thread_local int v = 1; return v; }
+// group_size_shift of the Modular frames written from now on (this thread): groups of 128 << shift samples a side (frame_header.cc; 1 = 256 is what VarDCT frames always use)
+static int& ModularGroupShift() { static thread_local int v = 1; return v; }
 static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr, int img_w = 0, int img_h = 0) {
   if (img_w == 0) { img_w = w; img_h = h; }   // (w, h) = coded size; (img_w, img_h) = image size when the frame is upsampled
   const int bw = (w + 7) / 8, bh = (h + 7) / 8;
@@ -1358,7 +1360,7 @@ static void ApplySqueeze(std::vector<SChan>& ch, const std::vector<SqStep>& step
 // squeeze: 0 = none, 1 = default chain (signalled with zero explicit steps), 2 = short explicit chain mixing in-place and appended residuals
 static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int nchan, int w, int h, int bits, bool has_alpha, bool rct, int squeeze, const Params* fx = nullptr) {
   // channels: nchan colour (1 or 3) [+1 alpha].  Optional RCT type 6 (YCgCo) signalled as a global transform.
-  const int group_shift = 1, gd = 256, lfd = gd * 8;
+  const int group_shift = ModularGroupShift(), gd = 128 << group_shift, lfd = gd * 8;
   const int xg = (w + gd - 1) / gd, yg = (h + gd - 1) / gd, ngroups = xg * yg;
   const int xlg = (w + lfd - 1) / lfd, ylg = (h + lfd - 1) / lfd, nlf = xlg * ylg;
   const int ntot = nchan + (has_alpha ? 1 : 0);
@@ -1535,6 +1537,7 @@ void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
+void jxlsynth_set_modular_group_shift(int shift) { synth::ModularGroupShift() = shift < 0 || shift > 3 ? 1 : shift; }
 void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
 void jxlsynth_set_lf_tree_shape(int shape) { synth::LfTreeShape() = shape; }
 // rgba == NULL: the extra channel is alpha again
