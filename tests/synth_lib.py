@@ -283,6 +283,11 @@ def set_modular_group_shift(shift=1):
     lib().jxlsynth_set_modular_group_shift(int(shift))
 
 
+def set_custom_filters(on=False):
+    """VarDCT frames written from now on (this thread) carry custom gaborish weights, EPF sharpness LUT, channel scales and sigma parameters in their RestorationFilter bundle"""
+    lib().jxlsynth_set_custom_filters(1 if on else 0)
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

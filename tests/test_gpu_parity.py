@@ -894,6 +894,35 @@ def test_vardct_with_alpha_extra_channel(jx, w, h):
     check_against_oracle(jx, data, np.uint8, 4)
 
 
+@pytest.mark.parametrize("gab,epf", [(1, 0), (0, 1), (1, 1), (1, 2), (1, 3), (0, 3)])
+def test_custom_restoration_filter_parameters(jx, gab, epf):
+    """RestorationFilter with every custom field (loop_filter.cc): gaborish weights per channel, the EPF sharpness LUT, channel scales, quant_mul, pass 0 / 2 sigma scales,
+    border SAD multiplier.  The fused and the staged filter kernels take them from the frame, not from constants: HIP == oracle, and the picture differs from the
+    default-parameter twin."""
+    img = S.synthetic_image(12, 300, 280)
+    plain = S.encode_vardct(img, seed=3, strategy_mix=2, epf_iters=epf, gab=gab)
+    S.set_custom_filters(True)
+    try:
+        data = S.encode_vardct(img, seed=3, strategy_mix=2, epf_iters=epf, gab=gab)
+        big = S.encode_vardct(S.synthetic_image(13, 1030, 270), seed=5, strategy_mix=1, epf_iters=epf, gab=gab)
+    finally:
+        S.set_custom_filters(False)
+    _, a = check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.float32, 3)
+    check_against_oracle(jx, big, np.uint8, 3)
+    _, b = jx.decoder_builder().decode_with(plain, np.uint8)
+    assert not np.array_equal(a, b)
+    bd = jx.BatchDecoder(0)            # the unfused path and a batch mixing both kinds of frames
+    bd.add(data, "uint8", 3); bd.add(plain, "uint8", 3); bd.add(big, "uint8", 3)
+    bd.set_option("force_unfused_filters", 1)
+    bd.prepare(); bd.decode(); bd.finish()
+    assert np.array_equal(bd.output(0), a.reshape(-1)) and np.array_equal(bd.output(1), b.reshape(-1))
+    bd2 = jx.BatchDecoder(0)
+    bd2.add(plain, "uint8", 3); bd2.add(data, "uint8", 3)
+    bd2.prepare(); bd2.decode(); bd2.finish()
+    assert np.array_equal(bd2.output(1), a.reshape(-1)) and np.array_equal(bd2.output(0), b.reshape(-1))
+
+
 def test_modular_group_sizes(jx):
     """Modular frames with groups of 128, 512 and 1024 samples a side (frame header group_size_shift 0, 2, 3): the section grid, the LfGroup size (8 groups) and
     which channels fit GlobalModular all follow the group size.  Lossless: the source samples come back; also against the oracle."""

@@ -693,6 +693,9 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
 // bit-plane split of the passes: 2 passes -> shifts {2, 0}; 3 passes -> {3, 1, 0}
 static int PassShift(int num_passes, int pass) { return pass + 1 == num_passes ? 0 : (num_passes == 2 ? 2 : (pass == 0 ? 3 : 1)); }
 
+// VarDCT frames written from now on (this thread) carry a RestorationFilter bundle with every custom field set: gaborish weights, EPF sharpness LUT, channel scales,
+// sigma parameters (loop_filter.cc) — the encoder side does not look at them
+static bool& CustomFilters() { static thread_local bool v = false; return v; }
 static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool xyb, int num_extra, int group_shift, bool lf_default, int frame_w = 0, int frame_h = 0) {
   w.put(0, 1);  // all_default
   w.put((uint32_t)p.frame_type, 2);
@@ -756,16 +759,22 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
   }
   w.put(0, 2);  // name length 0
   // RestorationFilter
-  if (lf_default) w.put(1, 1);
+  const bool custom_lf = CustomFilters() && !modular;
+  if (lf_default && !custom_lf) w.put(1, 1);
   else {
     w.put(0, 1);
     w.put(p.gab ? 1 : 0, 1);
-    if (p.gab) w.put(0, 1);  // gab_custom
+    if (p.gab) {
+      w.put(custom_lf ? 1 : 0, 1);  // gab_custom
+      if (custom_lf) for (float v : {0.15f, 0.08f, 0.12f, 0.05f, 0.1f, 0.07f}) WriteF16(w, v);       // (x, y, b) x (weight of the 4 edge neighbours, of the 4 corners)
+    }
     w.put(p.epf_iters, 2);
     if (p.epf_iters > 0) {
-      if (!modular) w.put(0, 1);  // sharp_custom
-      w.put(0, 1);                // weight_custom
-      w.put(0, 1);                // sigma_custom
+      if (!modular) { w.put(custom_lf ? 1 : 0, 1); if (custom_lf) for (float v : {0.0f, 0.1f, 0.3f, 0.4f, 0.6f, 0.7f, 0.9f, 1.1f}) WriteF16(w, v); }   // sharp_custom + LUT
+      w.put(custom_lf ? 1 : 0, 1);                // weight_custom: channel scales, two reserved values
+      if (custom_lf) for (float v : {35.0f, 6.0f, 3.0f, 0.4f, 0.35f}) WriteF16(w, v);
+      w.put(custom_lf ? 1 : 0, 1);                // sigma_custom: quant_mul, pass0 / pass2 sigma scale, border SAD multiplier
+      if (custom_lf) for (float v : {0.5f, 0.8f, 7.0f, 0.7f}) WriteF16(w, v);
       if (modular) WriteF16(w, 1.0f);
     }
     WriteU64(w, 0);
@@ -1537,6 +1546,7 @@ void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
+void jxlsynth_set_custom_filters(int on) { synth::CustomFilters() = on != 0; }
 void jxlsynth_set_modular_group_shift(int shift) { synth::ModularGroupShift() = shift < 0 || shift > 3 ? 1 : shift; }
 void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
 void jxlsynth_set_lf_tree_shape(int shape) { synth::LfTreeShape() = shape; }
