@@ -288,6 +288,11 @@ def set_custom_filters(on=False):
     lib().jxlsynth_set_custom_filters(1 if on else 0)
 
 
+def set_custom_block_ctx(on=False):
+    """VarDCT frames written from now on (this thread) carry their own BlockCtxMap: thresholds on the quantised LF of the three channels and on the quantiser field, 1404 entries onto 16 block contexts"""
+    lib().jxlsynth_set_custom_block_ctx(1 if on else 0)
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

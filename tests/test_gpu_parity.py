@@ -934,6 +934,35 @@ def test_modular_group_sizes(jx):
         check_against_oracle(jx, data, np.float32, img.shape[2])
 
 
+def test_block_context_maps(jx):
+    """Frames with a BlockCtxMap of their own (LF and quantiser-field thresholds, 16 block contexts — what libjxl's encoder writes at default effort): both HF kernels,
+    alone, batched beside the default-map twins (per-frame context tables in one launch), damaged."""
+    from test_synth_roundtrip import block_ctx_map_streams
+    cases = block_ctx_map_streams()
+    for name, many, one in cases:
+        check_against_oracle(jx, many, np.uint8, 3)
+        check_against_oracle(jx, many, np.float32, 3)
+    b = jx.BatchDecoder(0)
+    for name, many, one in cases:
+        b.add(many, "uint8", 3); b.add(one, "uint8", 3)
+    b.prepare()
+    for _ in range(2):
+        b.decode(); b.finish()
+        for i, (name, many, one) in enumerate(cases):
+            assert np.array_equal(b.output(2 * i), b.output(2 * i + 1)), name
+    rng = np.random.default_rng(6)
+    for name, many, one in cases[:3]:
+        for k in range(30):
+            bad = bytearray(many)
+            for _ in range(1 + k % 3):
+                bad[int(rng.integers(20, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+            except jx.DecodeError:
+                pass
+        check_against_oracle(jx, many, np.uint8, 3)
+
+
 def test_several_hf_histogram_sets(jx):
     """HfGlobal num_hf_presets > 1 (what libjxl's encoder writes for larger pictures): every PassGroup picks one of several sets of AC histograms.  Alone (both HF kernels: the
     SIMT one for ANS streams, HfDecodeKernel for prefix codes), in one batch beside their one-set twins, and with the selector damaged."""

@@ -163,6 +163,45 @@ def test_modular_group_sizes():
         assert np.array_equal(out.reshape(img.shape), img), name
 
 
+def block_ctx_map_streams():
+    """(name, stream with a BlockCtxMap of its own, default-map twin): thresholds on the quantised LF of X / Y / B and on the quantiser field select among 16 block contexts
+    (ac_context.h BlockCtxMap; libjxl's encoder fits one per frame at default effort); the map itself travels MTF- and ANS-coded.  Also with several histogram sets,
+    progressive passes, prefix codes, and under an LF frame (no quantised LF of the frame's own: LF index 0)."""
+    from_lf = None
+    out = []
+    for name, (w, h), kw, presets, opt in [("small", (300, 280), {}, 1, None), ("groups", (700, 560), {}, 1, None), ("passes_presets", (520, 300), dict(num_passes=3), 3, None),
+                                           ("lf_groups", (2300, 400), {}, 2, None), ("prefix", (700, 560), {}, 1, "prefix")]:
+        img = S.synthetic_image(33, w, h)
+        if opt == "prefix":
+            S.set_prefix(True)
+        S.set_hf_presets(presets)
+        try:
+            one = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1, **kw)
+            S.set_custom_block_ctx(True)
+            many = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1, **kw)
+        finally:
+            S.set_custom_block_ctx(False); S.set_hf_presets(1); S.set_prefix(False)
+        out.append((name, many, one))
+    img = S.synthetic_image(81, 300, 200)
+    parts = {}
+    for custom in (False, True):
+        S.set_custom_block_ctx(custom)
+        try:
+            parts[custom] = (S.encode_vardct_frame(img, S.frame(emit=2), seed=3)
+                             + S.encode_vardct_frame(_block_means(img), S.frame(emit=1, is_last=0, frame_type=1, lf_level=1), seed=5, distance=0.3, epf_iters=0, gab=0)
+                             + S.encode_vardct_frame(img, S.frame(emit=1, use_lf_frame=1), seed=3, strategy_mix=2, epf_iters=1))
+        finally:
+            S.set_custom_block_ctx(False)
+    out.append(("under_lf_frame", parts[True], parts[False]))
+    return out
+
+
+def test_block_context_maps():
+    for name, many, one in block_ctx_map_streams():
+        assert many != one, name
+        assert np.array_equal(O.decode(many).image("u8", 3), O.decode(one).image("u8", 3)), name
+
+
 def hf_preset_streams():
     """(name, stream with several histogram sets, its one-set twin): HfGlobal num_hf_presets > 1 — libjxl's encoder clusters the groups of a larger picture into several sets of AC
     histograms; every PassGroup names its set, whose contexts follow those of the sets before it.  Single pass, progressive, > 1 LF group, prefix codes, LZ77."""

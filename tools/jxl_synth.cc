@@ -855,6 +855,9 @@ static bool& AlphaSqueeze() { static thread_local bool v = false; return v; }
 // number of histogram sets ("HF presets", HfGlobal num_hf_presets) of the VarDCT frames written from now on (this thread): group g of every pass codes its coefficients
 // with set g % n — libjxl's encoder clusters the groups of a large picture into several sets
 static int& HfPresets() { static thread_local int v = 1; return v; }
+// VarDCT frames written from now on (this thread) carry a BlockCtxMap of their own: thresholds on the quantised LF of X / Y / B (1 / 2 / 1 of them, at quantiles of the
+// frame) and two on the quantiser field, 39 x 12 x 3 entries onto 16 block contexts (ac_context.h; what libjxl's encoder fits at default effort)
+static bool& CustomBlockCtx() { static thread_local bool v = false; return v; }
 // group_size_shift of the Modular frames written from now on (this thread): groups of 128 << shift samples a side (frame_header.cc; 1 = 256 is what VarDCT frames always use)
 static int& ModularGroupShift() { static thread_local int v = 1; return v; }
 static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr, int img_w = 0, int img_h = 0) {
@@ -1058,7 +1061,24 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     ModularTokens(gt, root, mr, 1 + 2 * nlf + g, d.meta_tok, LfWpParams());
   }
   // --- tokens: AC per group
-  const int nctx = 15;
+  const bool custom_bcm = CustomBlockCtx();
+  std::vector<int32_t> lf_thr[3];
+  std::vector<uint32_t> qf_thr;
+  std::vector<uint8_t> bcm_map;
+  int num_lf_ctxs = 1;
+  if (custom_bcm) {
+    auto quantile = [&](int c, double q) { std::vector<int32_t> v(lfq[c]); std::sort(v.begin(), v.end()); return v[(size_t)(q * (double)(v.size() - 1))]; };
+    lf_thr[0] = {quantile(0, 0.5)}; lf_thr[1] = {quantile(1, 0.33), quantile(1, 0.66)}; lf_thr[2] = {quantile(2, 0.5)};
+    if (lf_thr[1][1] <= lf_thr[1][0]) lf_thr[1][1] = lf_thr[1][0] + 1;       // (strictly increasing is not required by the format; kept tidy)
+    qf_thr = {17, 21};
+    num_lf_ctxs = 2 * 3 * 2;
+    bcm_map.resize((size_t)39 * num_lf_ctxs * 3);
+    for (size_t i = 0; i < bcm_map.size(); i++) {
+      const int lf_idx = (int)(i % num_lf_ctxs), qf_idx = (int)((i / num_lf_ctxs) % 3), co = (int)(i / num_lf_ctxs / 3);
+      bcm_map[i] = (uint8_t)((kDefaultBlockCtx[co] + 5 * lf_idx + 3 * qf_idx) % 16);
+    }
+  }
+  const int nctx = custom_bcm ? 16 : 15;
   const int np = p.num_passes;
   // per-pass coefficient planes: pass p carries (remainder >> shift[p]); the decoder adds value << shift
   std::vector<std::vector<int32_t>> qpass[3];
@@ -1093,6 +1113,17 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
         int c = chan[ci];
         int idx = (c < 2 ? (c ^ 1) : 2) * 13 + ord;
         int block_ctx = kDefaultBlockCtx[idx];
+        if (custom_bcm) {
+          int lf_idx = 0;
+          if (!p.use_lf_frame) {       // (a frame whose LF comes from an LF frame has no quantised LF of its own: index 0)
+            int b3[3] = {0, 0, 0};
+            for (int cc = 0; cc < 3; cc++) for (int32_t t : lf_thr[cc]) if (lfq[cc][o] > t) b3[cc]++;
+            lf_idx = (b3[0] * ((int)lf_thr[2].size() + 1) + b3[2]) * ((int)lf_thr[1].size() + 1) + b3[1];
+          }
+          int qf_idx = 0;
+          for (uint32_t t : qf_thr) if ((uint32_t)hf_mul[o] > t) qf_idx++;
+          block_ctx = bcm_map[((size_t)idx * (qf_thr.size() + 1) + qf_idx) * num_lf_ctxs + lf_idx];
+        }
         const int32_t* q = qpass[c][ps].data() + coff[o];
         int nz = 0;
         for (int k = covered; k < size; k++) nz += q[order[k]] != 0;
@@ -1217,7 +1248,17 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     s.put(1, 1);  // LfChannelDequantization all_default
     WriteU32(s, global_scale, {11, 1}, {11, 2049}, {12, 4097}, {16, 8193});
     WriteU32(s, quant_lf, {0, 16}, {5, 1}, {8, 1}, {16, 1});
-    s.put(1, 1);  // default BlockCtxMap
+    if (!custom_bcm) s.put(1, 1);  // default BlockCtxMap
+    else {
+      s.put(0, 1);
+      for (int c = 0; c < 3; c++) {
+        s.put((uint32_t)lf_thr[c].size(), 4);
+        for (int32_t t : lf_thr[c]) WriteU32(s, PackSigned(t), {4, 0}, {8, 16}, {16, 272}, {32, 65808});
+      }
+      s.put((uint32_t)qf_thr.size(), 4);
+      for (uint32_t t : qf_thr) WriteU32(s, t - 1, {2, 0}, {3, 4}, {5, 12}, {8, 44});
+      WriteContextMap(s, bcm_map, 16);
+    }
     s.put(1, 1);  // default LfChannelCorrelation
     s.put(1, 1);  // GlobalModular: has_tree
     WriteEntropyCode(s, tree_code);
@@ -1546,6 +1587,7 @@ void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
+void jxlsynth_set_custom_block_ctx(int on) { synth::CustomBlockCtx() = on != 0; }
 void jxlsynth_set_custom_filters(int on) { synth::CustomFilters() = on != 0; }
 void jxlsynth_set_modular_group_shift(int shift) { synth::ModularGroupShift() = shift < 0 || shift > 3 ? 1 : shift; }
 void jxlsynth_set_prev_channel_props(int on) { synth::UsePrevChannelProps() = on != 0; }
