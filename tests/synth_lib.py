@@ -293,6 +293,11 @@ def set_custom_block_ctx(on=False):
     lib().jxlsynth_set_custom_block_ctx(1 if on else 0)
 
 
+def set_custom_lf_global(on=False):
+    """VarDCT frames written from now on (this thread) carry their own LF dequantisation steps and chroma-from-luma parameters (colour factor, base correlations, LF factors)"""
+    lib().jxlsynth_set_custom_lf_global(1 if on else 0)
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

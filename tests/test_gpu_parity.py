@@ -963,6 +963,24 @@ def test_block_context_maps(jx):
         check_against_oracle(jx, many, np.uint8, 3)
 
 
+def test_custom_lf_dequantisation_and_colour_correlation(jx):
+    """LfGlobal with its own LF dequantisation steps and chroma-from-luma parameters (colour factor, base correlations, LF factors): LF dequantisation, the LLF and the
+    dequantisation in the IDCT kernels take them from the frame.  Alone and in a batch beside default-parameter frames."""
+    from test_synth_roundtrip import custom_lf_global_streams
+    cases = custom_lf_global_streams()
+    for name, data, img in cases:
+        check_against_oracle(jx, data, np.uint8, 3)
+        check_against_oracle(jx, data, np.float32, 3)
+    b = jx.BatchDecoder(0)
+    plain = S.encode_vardct(cases[1][2], seed=4, strategy_mix=2, epf_iters=1, gab=1)
+    for name, data, img in cases:
+        b.add(data, "uint8", 3); b.add(plain, "uint8", 3)
+    b.prepare(); b.decode(); b.finish()
+    for i, (name, data, img) in enumerate(cases):
+        assert np.array_equal(b.output(2 * i), O.decode(data).pixels("u8", 3)), name
+        assert np.array_equal(b.output(2 * i + 1), O.decode(plain).pixels("u8", 3)), name
+
+
 def test_several_hf_histogram_sets(jx):
     """HfGlobal num_hf_presets > 1 (what libjxl's encoder writes for larger pictures): every PassGroup picks one of several sets of AC histograms.  Alone (both HF kernels: the
     SIMT one for ANS streams, HfDecodeKernel for prefix codes), in one batch beside their one-set twins, and with the selector damaged."""

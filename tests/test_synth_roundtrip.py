@@ -202,6 +202,26 @@ def test_block_context_maps():
         assert np.array_equal(O.decode(many).image("u8", 3), O.decode(one).image("u8", 3)), name
 
 
+def custom_lf_global_streams():
+    """(name, stream, source image): frames with their own LfChannelDequantization (LF steps 1 / 2048, 1 / 256, 1 / 128 instead of 1 / 4096, 1 / 512, 1 / 256) and
+    LfChannelCorrelation (colour factor 64, base correlations 0.125 / 0.75, LF factors +6 / -10) — libjxl's encoder writes fitted values at default effort"""
+    out = []
+    for name, (w, h), kw in [("small", (300, 280), {}), ("groups", (700, 560), {}), ("passes", (520, 300), dict(num_passes=3)), ("lf_groups", (2300, 400), {})]:
+        img = S.synthetic_image(33, w, h)
+        S.set_custom_lf_global(True)
+        try:
+            data = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1, **kw)
+        finally:
+            S.set_custom_lf_global(False)
+        out.append((name, data, img))
+    return out
+
+
+def test_custom_lf_dequantisation_and_colour_correlation():
+    for name, data, img in custom_lf_global_streams():
+        assert psnr(O.decode(data).image("u8", 3), img) > 37.0, name       # the decoder applies what the encoder assumed (default parameters: 40 dB; the LF steps here are twice as coarse)
+
+
 def hf_preset_streams():
     """(name, stream with several histogram sets, its one-set twin): HfGlobal num_hf_presets > 1 — libjxl's encoder clusters the groups of a larger picture into several sets of AC
     histograms; every PassGroup names its set, whose contexts follow those of the sets before it.  Single pass, progressive, > 1 LF group, prefix codes, LZ77."""

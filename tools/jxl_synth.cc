@@ -858,6 +858,9 @@ static int& HfPresets() { static thread_local int v = 1; return v; }
 // VarDCT frames written from now on (this thread) carry a BlockCtxMap of their own: thresholds on the quantised LF of X / Y / B (1 / 2 / 1 of them, at quantiles of the
 // frame) and two on the quantiser field, 39 x 12 x 3 entries onto 16 block contexts (ac_context.h; what libjxl's encoder fits at default effort)
 static bool& CustomBlockCtx() { static thread_local bool v = false; return v; }
+// VarDCT frames written from now on (this thread) carry their own LfChannelDequantization (1 / 2048, 1 / 256, 1 / 128) and LfChannelCorrelation (colour factor 64, base
+// correlations 0.125 / 0.75, LF factors +6 / -10): the encoder side quantises the LF with these steps and predicts X / B from Y with these factors
+static bool& CustomLfGlobal() { static thread_local bool v = false; return v; }
 // group_size_shift of the Modular frames written from now on (this thread): groups of 128 << shift samples a side (frame_header.cc; 1 = 256 is what VarDCT frames always use)
 static int& ModularGroupShift() { static thread_local int v = 1; return v; }
 static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int h, const Params& p, const uint8_t* alpha = nullptr, int img_w = 0, int img_h = 0) {
@@ -910,7 +913,10 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   const uint32_t global_scale = (uint32_t)std::min(65535.0f, std::max(1.0f, 4587.0f / p.distance));
   const uint32_t quant_lf = 16;
   const float inv_gs = 65536.0f / (float)global_scale;
-  const float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
+  const bool custom_lfg = CustomLfGlobal();
+  const float m_lf[3] = {custom_lfg ? 1.0f / 2048 : 1.0f / 4096, custom_lfg ? 1.0f / 256 : 1.0f / 512, custom_lfg ? 1.0f / 128 : 1.0f / 256};
+  const float cfl_factor = custom_lfg ? 64.0f : 84.0f, cfl_base_x = custom_lfg ? 0.125f : 0.0f, cfl_base_b = custom_lfg ? 0.75f : 1.0f;
+  const int cfl_x_lf = custom_lfg ? 6 : 0, cfl_b_lf = custom_lfg ? -10 : 0;
   const float x_dm = 0.8f, b_dm = 1.0f;  // x_qm_scale 3, b_qm_scale 2
   std::vector<int32_t> hf_mul((size_t)bw * bh, 1);
   std::vector<int32_t> sharp((size_t)bw * bh, 0);
@@ -962,8 +968,8 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     int32_t qy = (int32_t)std::lrintf(lf[1][o] / lfstep[1]);
     float dy = qy * lfstep[1];
     lfq[1][o] = qy;
-    lfq[0][o] = (int32_t)std::lrintf(lf[0][o] / lfstep[0]);
-    lfq[2][o] = (int32_t)std::lrintf((lf[2][o] - dy) / lfstep[2]);
+    lfq[0][o] = (int32_t)std::lrintf((lf[0][o] - (cfl_base_x + (float)cfl_x_lf / cfl_factor) * dy) / lfstep[0]);
+    lfq[2][o] = (int32_t)std::lrintf((lf[2][o] - (cfl_base_b + (float)cfl_b_lf / cfl_factor) * dy) / lfstep[2]);
   }
   // --- chroma-from-luma factors per 64x64 tile: X uses 0, B least-squares around base 1.0
   std::vector<int32_t> ytox((size_t)cw * chh, 0), ytob((size_t)cw * chh, 0);
@@ -976,11 +982,11 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
       size_t n = (size_t)kCovX[s] * kCovY[s] * 64;
       size_t tile = (size_t)(by / 8) * cw + bx / 8;
       const float* y = coef[1].data() + coff[o]; const float* b = coef[2].data() + coff[o];
-      for (size_t k = 1; k < n; k++) { num[tile] += (double)y[k] * (b[k] - y[k]); den[tile] += (double)y[k] * y[k]; }
+      for (size_t k = 1; k < n; k++) { num[tile] += (double)y[k] * (b[k] - cfl_base_b * y[k]); den[tile] += (double)y[k] * y[k]; }
     }
     for (size_t t = 0; t < num.size(); t++) {
       double f = den[t] > 1e-12 ? num[t] / den[t] : 0.0;
-      int v = (int)std::lrint(f * 84.0);
+      int v = (int)std::lrint(f * (double)cfl_factor);
       ytob[t] = std::max(-128, std::min(127, v));
       ytox[t] = 0;
     }
@@ -1004,7 +1010,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     float sd = inv_gs / (float)hf_mul[o];
     float sdc[3] = {sd * x_dm, sd, sd * b_dm};
     size_t tile = (size_t)(by / 8) * cw + bx / 8;
-    float kx = 0.0f + ytox[tile] / 84.0f, kb = 1.0f + ytob[tile] / 84.0f;
+    float kx = cfl_base_x + ytox[tile] / cfl_factor, kb = cfl_base_b + ytob[tile] / cfl_factor;
     const float* ty = table[kind][1].data(); const float* tx = table[kind][0].data(); const float* tb = table[kind][2].data();
     float* fy = coef[1].data() + coff[o]; float* fx = coef[0].data() + coff[o]; float* fb = coef[2].data() + coff[o];
     int32_t* qy = qc[1].data() + coff[o]; int32_t* qx = qc[0].data() + coff[o]; int32_t* qb = qc[2].data() + coff[o];
@@ -1245,7 +1251,8 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     BitWriter s;
     WriteFeatures(s);                                                             // patch dictionary, splines
     if (p.noise) for (int i = 0; i < 8; i++) s.put(p.noise_lut[i] & 1023, 10);   // NoiseParams
-    s.put(1, 1);  // LfChannelDequantization all_default
+    if (!custom_lfg) s.put(1, 1);  // LfChannelDequantization all_default
+    else { s.put(0, 1); for (int c = 0; c < 3; c++) WriteF16(s, m_lf[c] * 128.0f); }
     WriteU32(s, global_scale, {11, 1}, {11, 2049}, {12, 4097}, {16, 8193});
     WriteU32(s, quant_lf, {0, 16}, {5, 1}, {8, 1}, {16, 1});
     if (!custom_bcm) s.put(1, 1);  // default BlockCtxMap
@@ -1259,7 +1266,13 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
       for (uint32_t t : qf_thr) WriteU32(s, t - 1, {2, 0}, {3, 4}, {5, 12}, {8, 44});
       WriteContextMap(s, bcm_map, 16);
     }
-    s.put(1, 1);  // default LfChannelCorrelation
+    if (!custom_lfg) s.put(1, 1);  // default LfChannelCorrelation
+    else {
+      s.put(0, 1);
+      WriteU32(s, (uint32_t)cfl_factor, {0, 84}, {0, 256}, {8, 2}, {16, 258});
+      WriteF16(s, cfl_base_x); WriteF16(s, cfl_base_b);
+      s.put((uint32_t)(cfl_x_lf + 128), 8); s.put((uint32_t)(cfl_b_lf + 128), 8);
+    }
     s.put(1, 1);  // GlobalModular: has_tree
     WriteEntropyCode(s, tree_code);
     EncodeTokens(s, tree_code, tree_tokens);
@@ -1587,6 +1600,7 @@ void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
+void jxlsynth_set_custom_lf_global(int on) { synth::CustomLfGlobal() = on != 0; }
 void jxlsynth_set_custom_block_ctx(int on) { synth::CustomBlockCtx() = on != 0; }
 void jxlsynth_set_custom_filters(int on) { synth::CustomFilters() = on != 0; }
 void jxlsynth_set_modular_group_shift(int shift) { synth::ModularGroupShift() = shift < 0 || shift > 3 ? 1 : shift; }
