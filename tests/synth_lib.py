@@ -298,6 +298,11 @@ def set_custom_lf_global(on=False):
     lib().jxlsynth_set_custom_lf_global(1 if on else 0)
 
 
+def set_custom_opsin(on=False):
+    """XYB images written from now on (this thread) carry an OpsinInverseMatrix bundle of their own (matrix, opsin biases, quantisation biases as binary16 values)"""
+    lib().jxlsynth_set_custom_opsin(1 if on else 0)
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

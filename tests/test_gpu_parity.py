@@ -981,6 +981,32 @@ def test_custom_lf_dequantisation_and_colour_correlation(jx):
         assert np.array_equal(b.output(2 * i + 1), O.decode(plain).pixels("u8", 3)), name
 
 
+def test_custom_opsin_inverse_matrix_and_quant_biases(jx):
+    """Image header with an OpsinInverseMatrix bundle of its own (inverse matrix, opsin biases, quantisation biases; binary16 values close to the defaults): the dequantisation
+    bias in the IDCT kernels and the XYB stage of the fused and staged tails take them from the image.  u8 / f32, with custom upsampling weights in the same bundle, batched."""
+    img = S.synthetic_image(33, 300, 280)
+    plain = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1)
+    S.set_custom_opsin(True)
+    try:
+        data = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1)
+        ups = S.encode_vardct(S.synthetic_image(34, 520, 300), seed=4, strategy_mix=2, epf_iters=2, gab=1, upsampling=2, custom_up_weights=1)
+        staged = S.encode_vardct(img, seed=4, strategy_mix=1, epf_iters=3, gab=0)
+    finally:
+        S.set_custom_opsin(False)
+    _, a = check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.float32, 3)
+    check_against_oracle(jx, ups, np.uint8, 3)
+    check_against_oracle(jx, staged, np.uint8, 3)
+    _, b = jx.decoder_builder().decode_with(plain, np.uint8)
+    assert not np.array_equal(a, b) and np.abs(a.astype(int) - b.astype(int)).max() <= 3       # close to the default parameters, not equal to them
+    bd = jx.BatchDecoder(0)
+    for d in (plain, data, ups, staged, plain):
+        bd.add(d, "uint8", 3)
+    bd.prepare(); bd.decode(); bd.finish()
+    assert np.array_equal(bd.output(0), b.reshape(-1)) and np.array_equal(bd.output(1), a.reshape(-1)) and np.array_equal(bd.output(4), b.reshape(-1))
+    assert np.array_equal(bd.output(2), O.decode(ups).pixels("u8", 3)) and np.array_equal(bd.output(3), O.decode(staged).pixels("u8", 3))
+
+
 def test_several_hf_histogram_sets(jx):
     """HfGlobal num_hf_presets > 1 (what libjxl's encoder writes for larger pictures): every PassGroup picks one of several sets of AC histograms.  Alone (both HF kernels: the
     SIMT one for ANS streams, HfDecodeKernel for prefix codes), in one batch beside their one-set twins, and with the selector damaged."""

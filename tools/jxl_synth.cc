@@ -600,10 +600,14 @@ static void WritePreviewSize(BitWriter& w, int xs, int ys) {
   w.put(0, 3);     // ratio 0: the width follows
   dim(xs);
 }
+// XYB images written from now on (this thread) carry their own OpsinInverseMatrix bundle: the library's matrix, opsin biases and quantisation biases as binary16 values
+// (so a decoder that reads them computes with slightly different numbers than one that falls back to its defaults)
+static bool& CustomOpsin() { static thread_local bool v = false; return v; }
 static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool xyb, int bits, bool has_alpha, bool gray) {
   w.put(0xFF, 8); w.put(0x0A, 8);
   WriteSize(w, xs, ys);
-  const bool custom_up = p.upsampling > 1 && p.custom_up_weights;
+  const bool custom_opsin = xyb && CustomOpsin();
+  const bool custom_up = (p.upsampling > 1 && p.custom_up_weights) || custom_opsin;      // (either makes the transform-data bundle non-default)
   const bool preview = g_preview_w > 0 && g_preview_h > 0, anim = g_anim_num > 0;
   bool all_default = xyb && bits == 8 && !has_alpha && !p.hdr && p.out_bits != 32 && !gray && p.orientation == 1 && !custom_up && g_icc.empty() && !g_color.set && !g_float_exp_bits && !preview && !anim;
   w.put(all_default, 1);
@@ -682,9 +686,18 @@ static void WriteImageHeader(BitWriter& w, int xs, int ys, const Params& p, bool
   if (!custom_up) w.put(1, 1);  // default_m
   else {
     w.put(0, 1);
-    if (xyb) w.put(1, 1);   // OpsinInverseMatrix all_default
-    w.put(p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : 4, 3);   // cw_mask
-    for (float v : CustomUpWeights(p.upsampling)) WriteF16(w, v);
+    if (xyb) {
+      w.put(custom_opsin ? 0 : 1, 1);   // OpsinInverseMatrix all_default
+      if (custom_opsin) {
+        for (float v : {11.031566901960783f, -9.866943921568629f, -0.16462299647058826f, -3.254147380392157f, 4.418770392156863f, -0.16462299647058826f,
+                        -3.6588512862745097f, 2.7129230470588235f, 1.9459282392156863f}) WriteF16(w, v);
+        for (int i = 0; i < 3; i++) WriteF16(w, -0.0037930732552754493f);
+        for (float v : {1.0f - 0.05465007330715401f, 1.0f - 0.07005449891748593f, 1.0f - 0.049935103337343655f, 0.145f}) WriteF16(w, v);
+      }
+    }
+    const bool up_w = p.upsampling > 1 && p.custom_up_weights;
+    w.put(!up_w ? 0 : p.upsampling == 2 ? 1 : p.upsampling == 4 ? 2 : 4, 3);   // cw_mask
+    if (up_w) for (float v : CustomUpWeights(p.upsampling)) WriteF16(w, v);
   }
   if (!g_icc.empty()) WriteIccStream(w, g_icc);
   w.align();
@@ -1600,6 +1613,7 @@ void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
+void jxlsynth_set_custom_opsin(int on) { synth::CustomOpsin() = on != 0; }
 void jxlsynth_set_custom_lf_global(int on) { synth::CustomLfGlobal() = on != 0; }
 void jxlsynth_set_custom_block_ctx(int on) { synth::CustomBlockCtx() = on != 0; }
 void jxlsynth_set_custom_filters(int on) { synth::CustomFilters() = on != 0; }
