@@ -303,6 +303,16 @@ def set_custom_opsin(on=False):
     lib().jxlsynth_set_custom_opsin(1 if on else 0)
 
 
+def set_qm_scales(x=3, b=2):
+    """x_qm_scale / b_qm_scale (0..7) of the VarDCT frames written from now on (this thread): X / B quantisation steps times 0.8^(scale - 2)"""
+    lib().jxlsynth_set_qm_scales(int(x), int(b))
+
+
+def set_quant_lf(q=16):
+    """quant_lf (1..65536) of the VarDCT frames written from now on (this thread)"""
+    lib().jxlsynth_set_quant_lf(int(q))
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

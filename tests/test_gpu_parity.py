@@ -1007,6 +1007,35 @@ def test_custom_opsin_inverse_matrix_and_quant_biases(jx):
     assert np.array_equal(bd.output(2), O.decode(ups).pixels("u8", 3)) and np.array_equal(bd.output(3), O.decode(staged).pixels("u8", 3))
 
 
+@pytest.mark.parametrize("xq,bq", [(0, 0), (2, 4), (5, 2), (7, 7)])
+def test_qm_scales(jx, xq, bq):
+    """x_qm_scale / b_qm_scale other than the default 3 / 2 (libjxl's encoder raises x_qm_scale with the distance): X / B dequantisation steps times 0.8^(scale - 2)"""
+    img = S.synthetic_image(33, 300, 280)
+    S.set_qm_scales(xq, bq)
+    try:
+        data = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1)
+    finally:
+        S.set_qm_scales()
+    _, px = check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.float32, 3)
+    err = px.reshape(280, 300, 3).astype(np.float64) - img
+    assert 10 * np.log10(255.0 ** 2 / (err ** 2).mean()) > 37.5
+
+
+@pytest.mark.parametrize("q", [1, 7, 40, 300, 5000])
+def test_quant_lf_values(jx, q):
+    """quant_lf over its coded range (1, 1 + 5 bits, 1 + 8 bits, 1 + 16 bits): LF steps from a few per cent of the range down to 1e-6 — large quantised LF values, the
+    block-context LF thresholds with them, LF smoothing on fine steps"""
+    img = S.synthetic_image(33, 300, 280)
+    S.set_quant_lf(q); S.set_custom_block_ctx(True)
+    try:
+        data = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1)
+    finally:
+        S.set_quant_lf(); S.set_custom_block_ctx(False)
+    check_against_oracle(jx, data, np.uint8, 3)
+    check_against_oracle(jx, data, np.float32, 3)
+
+
 def test_several_hf_histogram_sets(jx):
     """HfGlobal num_hf_presets > 1 (what libjxl's encoder writes for larger pictures): every PassGroup picks one of several sets of AC histograms.  Alone (both HF kernels: the
     SIMT one for ANS streams, HfDecodeKernel for prefix codes), in one batch beside their one-set twins, and with the selector damaged."""

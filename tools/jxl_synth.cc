@@ -709,6 +709,10 @@ static int PassShift(int num_passes, int pass) { return pass + 1 == num_passes ?
 // VarDCT frames written from now on (this thread) carry a RestorationFilter bundle with every custom field set: gaborish weights, EPF sharpness LUT, channel scales,
 // sigma parameters (loop_filter.cc) — the encoder side does not look at them
 static bool& CustomFilters() { static thread_local bool v = false; return v; }
+// x_qm_scale / b_qm_scale of the VarDCT frames written from now on (this thread): the X / B quantisation steps are scaled by 0.8^(scale - 2) (frame_header.cc; 3 / 2 by default)
+static int* QmScales() { static thread_local int v[2] = {3, 2}; return v; }
+// quant_lf (LfGlobal Quantizer, 1..65536; 16 by default) of the VarDCT frames written from now on (this thread): the LF steps are the channel's LF factor * 65536 / global_scale / quant_lf
+static int& QuantLf() { static thread_local int v = 16; return v; }
 static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool xyb, int num_extra, int group_shift, bool lf_default, int frame_w = 0, int frame_h = 0) {
   w.put(0, 1);  // all_default
   w.put((uint32_t)p.frame_type, 2);
@@ -724,7 +728,7 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
     for (int i = 0; i < num_extra; i++) w.put(ups_sel, 2);   // ec_upsampling: same factor
   }
   if (modular) w.put(group_shift, 2);
-  if (!modular && xyb) { w.put(3, 3); w.put(2, 3); }
+  if (!modular && xyb) { w.put((uint32_t)QmScales()[0], 3); w.put((uint32_t)QmScales()[1], 3); }
   if (p.frame_type != 2) {
     const int np = modular ? p.mod_passes : p.num_passes;
     w.put((uint32_t)(np - 1), 2);  // num_passes (1, 2, 3)
@@ -924,13 +928,13 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   }
   // --- quantisation parameters
   const uint32_t global_scale = (uint32_t)std::min(65535.0f, std::max(1.0f, 4587.0f / p.distance));
-  const uint32_t quant_lf = 16;
+  const uint32_t quant_lf = (uint32_t)QuantLf();
   const float inv_gs = 65536.0f / (float)global_scale;
   const bool custom_lfg = CustomLfGlobal();
   const float m_lf[3] = {custom_lfg ? 1.0f / 2048 : 1.0f / 4096, custom_lfg ? 1.0f / 256 : 1.0f / 512, custom_lfg ? 1.0f / 128 : 1.0f / 256};
   const float cfl_factor = custom_lfg ? 64.0f : 84.0f, cfl_base_x = custom_lfg ? 0.125f : 0.0f, cfl_base_b = custom_lfg ? 0.75f : 1.0f;
   const int cfl_x_lf = custom_lfg ? 6 : 0, cfl_b_lf = custom_lfg ? -10 : 0;
-  const float x_dm = 0.8f, b_dm = 1.0f;  // x_qm_scale 3, b_qm_scale 2
+  const float x_dm = std::pow(0.8f, (float)(QmScales()[0] - 2)), b_dm = std::pow(0.8f, (float)(QmScales()[1] - 2));  // x_qm_scale 3, b_qm_scale 2 by default
   std::vector<int32_t> hf_mul((size_t)bw * bh, 1);
   std::vector<int32_t> sharp((size_t)bw * bh, 0);
   for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
@@ -1613,6 +1617,8 @@ void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
+void jxlsynth_set_quant_lf(int q) { synth::QuantLf() = q < 1 || q > 65536 ? 16 : q; }
+void jxlsynth_set_qm_scales(int x, int b) { synth::QmScales()[0] = x < 0 || x > 7 ? 3 : x; synth::QmScales()[1] = b < 0 || b > 7 ? 2 : b; }
 void jxlsynth_set_custom_opsin(int on) { synth::CustomOpsin() = on != 0; }
 void jxlsynth_set_custom_lf_global(int on) { synth::CustomLfGlobal() = on != 0; }
 void jxlsynth_set_custom_block_ctx(int on) { synth::CustomBlockCtx() = on != 0; }
