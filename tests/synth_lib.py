@@ -313,6 +313,11 @@ def set_quant_lf(q=16):
     lib().jxlsynth_set_quant_lf(int(q))
 
 
+def set_lf_extra_precision(e=0):
+    """extra_precision (0..3) of the LF groups of the VarDCT frames written from now on (this thread): LF coefficients in steps 2^e times finer"""
+    lib().jxlsynth_set_lf_extra_precision(int(e))
+
+
 def set_lf_tree_shape(shape=0):
     """1: the LF-group streams of VarDCT frames written from now on (in this thread) use the MA-tree shape of a default-effort cjxl encode —
     weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients, the fixed row / N / W tree for the HF metadata;

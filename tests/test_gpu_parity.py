@@ -1036,6 +1036,33 @@ def test_quant_lf_values(jx, q):
     check_against_oracle(jx, data, np.float32, 3)
 
 
+@pytest.mark.parametrize("e", [1, 2, 3])
+def test_lf_extra_precision(jx, e):
+    """LF groups with extra_precision 1..3 (LF coefficients in steps 2 / 4 / 8 times finer; libjxl's encoder uses it at low distances): the cooperative LF kernel and the
+    SIMT one (a batch of frames, gradient tree and weighted-predictor tree), several LF groups"""
+    img, wide = S.synthetic_image(33, 300, 280), S.synthetic_image(35, 2300, 400)
+    S.set_lf_extra_precision(e)
+    try:
+        small = S.encode_vardct(img, seed=4, strategy_mix=2, epf_iters=1, gab=1)
+        big = S.encode_vardct(wide, seed=5, strategy_mix=1, epf_iters=2, gab=1)
+        S.set_lf_tree_shape(1)
+        wp = S.encode_vardct(img, seed=6, strategy_mix=2, epf_iters=1, gab=1)
+    finally:
+        S.set_lf_extra_precision(); S.set_lf_tree_shape(0)
+    for d in (small, big, wp):
+        check_against_oracle(jx, d, np.uint8, 3)
+    check_against_oracle(jx, small, np.float32, 3)
+    for group in ([small, big] * 4, [wp] * 8):
+        b = jx.BatchDecoder(0)
+        b.set_lane_stride(4, 1)
+        for d in group:
+            b.add(d, "uint8", 3)
+        b.prepare(); b.decode(); b.finish()
+        assert b.info_value("lf_simt_frames") == len(group)
+        for i, d in enumerate(group):
+            assert np.array_equal(b.output(i), O.decode(d).pixels("u8", 3)), i
+
+
 def test_several_hf_histogram_sets(jx):
     """HfGlobal num_hf_presets > 1 (what libjxl's encoder writes for larger pictures): every PassGroup picks one of several sets of AC histograms.  Alone (both HF kernels: the
     SIMT one for ANS streams, HfDecodeKernel for prefix codes), in one batch beside their one-set twins, and with the selector damaged."""

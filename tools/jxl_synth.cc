@@ -713,6 +713,8 @@ static bool& CustomFilters() { static thread_local bool v = false; return v; }
 static int* QmScales() { static thread_local int v[2] = {3, 2}; return v; }
 // quant_lf (LfGlobal Quantizer, 1..65536; 16 by default) of the VarDCT frames written from now on (this thread): the LF steps are the channel's LF factor * 65536 / global_scale / quant_lf
 static int& QuantLf() { static thread_local int v = 16; return v; }
+// extra_precision (0..3) of the LF groups of the VarDCT frames written from now on (this thread): the LF coefficients are coded in steps 2^extra_precision times finer
+static int& LfExtraPrecision() { static thread_local int v = 0; return v; }
 static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool xyb, int num_extra, int group_shift, bool lf_default, int frame_w = 0, int frame_h = 0) {
   w.put(0, 1);  // all_default
   w.put((uint32_t)p.frame_type, 2);
@@ -980,7 +982,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   std::vector<int32_t> lfq[3];
   for (int c = 0; c < 3; c++) lfq[c].assign((size_t)bw * bh, 0);
   float lfstep[3];
-  for (int c = 0; c < 3; c++) lfstep[c] = m_lf[c] * inv_gs / (float)quant_lf;
+  for (int c = 0; c < 3; c++) lfstep[c] = m_lf[c] * inv_gs / (float)quant_lf / (float)(1 << LfExtraPrecision());
   for (size_t o = 0; o < (size_t)bw * bh; o++) {
     int32_t qy = (int32_t)std::lrintf(lf[1][o] / lfstep[1]);
     float dy = qy * lfstep[1];
@@ -1306,7 +1308,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
     BitWriter s;
     LfGroupData& d = lgd[g];
     if (!p.use_lf_frame) {
-      s.put(0, 2);  // extra_precision
+      s.put((uint32_t)LfExtraPrecision(), 2);  // extra_precision
       WriteGroupHeaderLf(s);
       EncodeTokens(s, mod_code, d.lf_tok);
     }
@@ -1617,6 +1619,7 @@ void jxlsynth_set_lz77_lf(int on) { synth::UseLz77Lf() = on != 0; }
 void jxlsynth_set_lz77_ac(int on) { synth::UseLz77Ac() = on != 0; }
 void jxlsynth_set_alpha_squeeze(int on) { synth::AlphaSqueeze() = on != 0; }
 void jxlsynth_set_hf_presets(int n) { synth::HfPresets() = n < 1 ? 1 : n; }
+void jxlsynth_set_lf_extra_precision(int e) { synth::LfExtraPrecision() = e < 0 || e > 3 ? 0 : e; }
 void jxlsynth_set_quant_lf(int q) { synth::QuantLf() = q < 1 || q > 65536 ? 16 : q; }
 void jxlsynth_set_qm_scales(int x, int b) { synth::QmScales()[0] = x < 0 || x > 7 ? 3 : x; synth::QmScales()[1] = b < 0 || b > 7 ? 2 : b; }
 void jxlsynth_set_custom_opsin(int on) { synth::CustomOpsin() = on != 0; }
