@@ -993,7 +993,7 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
   // --- chroma-from-luma factors per 64x64 tile: X uses 0, B least-squares around base 1.0
   std::vector<int32_t> ytox((size_t)cw * chh, 0), ytob((size_t)cw * chh, 0);
   {
-    std::vector<double> num((size_t)cw * chh, 0.0), den((size_t)cw * chh, 0.0);
+    std::vector<double> num((size_t)cw * chh, 0.0), den((size_t)cw * chh, 0.0), numx((size_t)cw * chh, 0.0);
     for (int by = 0; by < bh; by++) for (int bx = 0; bx < bw; bx++) {
       size_t o = (size_t)by * bw + bx;
       if (!first[o]) continue;
@@ -1001,13 +1001,16 @@ static std::vector<uint8_t> EncodeVarDCT(const float* xyb_planes[3], int w, int 
       size_t n = (size_t)kCovX[s] * kCovY[s] * 64;
       size_t tile = (size_t)(by / 8) * cw + bx / 8;
       const float* y = coef[1].data() + coff[o]; const float* b = coef[2].data() + coff[o];
-      for (size_t k = 1; k < n; k++) { num[tile] += (double)y[k] * (b[k] - cfl_base_b * y[k]); den[tile] += (double)y[k] * y[k]; }
+      const float* xc = coef[0].data() + coff[o];
+      for (size_t k = 1; k < n; k++) { num[tile] += (double)y[k] * (b[k] - cfl_base_b * y[k]); numx[tile] += (double)y[k] * (xc[k] - cfl_base_x * y[k]); den[tile] += (double)y[k] * y[k]; }
     }
     for (size_t t = 0; t < num.size(); t++) {
       double f = den[t] > 1e-12 ? num[t] / den[t] : 0.0;
       int v = (int)std::lrint(f * (double)cfl_factor);
       ytob[t] = std::max(-128, std::min(127, v));
+      // (X map: zero unless the frame carries its own colour-correlation parameters; then fitted like the B map, and never left at zero so that the term is exercised)
       ytox[t] = 0;
+      if (custom_lfg) { const int vx = (int)std::lrint((den[t] > 1e-12 ? numx[t] / den[t] : 0.0) * (double)cfl_factor); ytox[t] = std::max(-128, std::min(127, vx == 0 ? (t % 2 ? 3 : -2) : vx)); }
     }
   }
   // --- quantise AC
