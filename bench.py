@@ -213,6 +213,38 @@ def extras(jx, torch, streams, W, H, device):
     return out
 
 
+def _cu_mask(spec, ncu=256):
+    """CU mask of an experiment stream: 'first:N' (mask bits 0 .. N-1; the driver deals mask bits round-robin over the XCDs, so this is N / 8
+    CUs of every XCD), 'last:N', 'stride:K' (every K-th bit), 'not-first:N', or comma-separated 32-bit hex words.  '' = no mask."""
+    if not spec:
+        return None
+    kind, _, val = spec.partition(":")
+    if kind == "first":
+        bits = [i < int(val) for i in range(ncu)]
+    elif kind == "last":
+        bits = [i >= ncu - int(val) for i in range(ncu)]
+    elif kind == "not-first":
+        bits = [i >= int(val) for i in range(ncu)]
+    elif kind == "stride":
+        bits = [i % int(val) == 0 for i in range(ncu)]
+    else:
+        return [int(w, 16) for w in spec.split(",")]
+    return [sum(1 << b for b in range(32) if bits[w * 32 + b]) for w in range(ncu // 32)]
+
+
+def _masked_stream(torch, dev, mask):
+    """hipExtStreamCreateWithCUMask through the HIP runtime torch has loaded, wrapped as a torch stream (lives as long as the process)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * len(mask))(*mask)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(mask)), words)
+    if err != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {err}")
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 class Pipeline:
     """The decode pipeline of one GPU.  A decode is LF (entropy decode of the LF groups: a serial chain per stream, ~230 ms per
     launch whatever the batch size, a few dozen wavefronts in the SIMT form) -> varblock placement + LF post-processing -> HF (entropy decode of
@@ -260,6 +292,9 @@ class Pipeline:
             nbuf += self.ncoef * self.ntail - nbuf % (self.ncoef * self.ntail)
             self.nbuf = nbuf
         self.nout = min(nbuf, max(1, args.out_buffers))
+        if os.environ.get("JXL_BENCH_CUMASK_MAIN") and "main" not in Pipeline._streams:          # experiment: the tail's kernels on a CU-masked stream
+            Pipeline._streams["main"] = _masked_stream(torch, dev, _cu_mask(os.environ["JXL_BENCH_CUMASK_MAIN"]))
+            torch.cuda.set_stream(Pipeline._streams["main"])
         self.main = torch.cuda.current_stream()
         self.stream = self.main.cuda_stream
         self.outs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(self.nout)]
@@ -283,7 +318,8 @@ class Pipeline:
         def S(kind, i, priority=0):
             key = (kind, i)
             if key not in Pipeline._streams:
-                Pipeline._streams[key] = torch.cuda.Stream(device=dev, priority=priority)
+                mask = _cu_mask(os.environ.get("JXL_BENCH_CUMASK_" + kind.upper(), ""))    # experiment: confine the kernels of one kind of stream to a set of CUs
+                Pipeline._streams[key] = _masked_stream(torch, dev, mask) if mask else torch.cuda.Stream(device=dev, priority=priority)
             return Pipeline._streams[key]
         lf_prio = (lambda i: -1 if i == 0 else 0) if os.environ.get("JXL_BENCH_LF_PRIO") == "first" else (lambda i: -1)   # experiment: only the stream of the first cold LF stage is a high-priority one
         self.sides = [S("lf", i, lf_prio(i)) for i in range(max(1, min(self.ahead, lf_streams)))] if self.pipeline else []
