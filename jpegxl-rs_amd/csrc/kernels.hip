@@ -3630,6 +3630,15 @@ __device__ __forceinline__ uint8_t* OutPixelPtr(const FrameDev& f, int x, int y,
   return f.out + (size_t)oy * f.out_stride + (size_t)ox * f.out_channels * bps;
 }
 
+// a whole dword of output samples (JXL_PACKED_STORE_NT: with the non-temporal hint — nothing on the device reads decoded pixels again)
+__device__ __forceinline__ void StoreOut32(uint32_t* p, uint32_t v) {
+#ifdef JXL_PACKED_STORE_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 __device__ __forceinline__ void StorePixel(const FrameDev& f, int x, int y, float r, float g, float b, float a) {
   const uint32_t bps = f.out_type == 0 ? 1 : f.out_type == 2 ? 4 : 2;
   uint8_t* p = OutPixelPtr(f, x, y, bps);
@@ -3814,6 +3823,11 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
   }
   __syncthreads();
   // ---- EPF pass 1 + colour + store
+#ifndef JXL_NO_PACKED_STORE
+  // 1: u8 RGB, 2: u8 RGBA written as dwords (rows and buffer 4-byte aligned, width a multiple of 4 so that a quad of lanes is inside the image or outside it)
+  const int packed = (f.out_type == 0 && f.out_orient <= 1 && (w & 3) == 0 && ((uintptr_t)f.out & 3) == 0 && (f.out_stride & 3) == 0 && f.img_w == f.width && f.img_h == f.height)
+                         ? (f.out_channels == 3 ? 1 : f.out_channels == 4 ? 2 : 0) : 0;
+#endif
   const float sm = f.epf_sm[1], bsm = f.epf_bsm[1];
   const float cs0 = f.epf_channel_scale[0], cs1 = f.epf_channel_scale[1], cs2 = f.epf_channel_scale[2];
   for (int i = threadIdx.x; i < kFtW * kFtH; i += blockDim.x) {
@@ -3876,6 +3890,29 @@ __global__ __launch_bounds__(256) void FusedGabEpf1OutKernel(const FrameDev* __r
     float b = fmaf(f.opsin_inv[8], mb, fmaf(f.opsin_inv[7], mg, f.opsin_inv[6] * mr));
     if (f.color_mode == 0) { r = LinearToSrgb(r); g = LinearToSrgb(g); b = LinearToSrgb(b); }
     if (f.is_gray) r = g;
+#ifndef JXL_NO_PACKED_STORE
+    if (packed) {
+      // u8 RGB / RGBA in image orientation: whole dwords instead of three or four byte stores per pixel.  RGB: the four lanes of a quad hold 12 bytes = three
+      // dwords; lane j takes the rest of its own pixel and the head of its right neighbour's (DPP quad_perm [1, 2, 3, 3]) and lanes 0..2 store.  Same rounding
+      // as StoreSample.
+      const uint32_t pr = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, r)) * f.out_int_mul) & 0xFFu;
+      const uint32_t pg = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, g)) * f.out_int_mul) & 0xFFu;
+      const uint32_t pb = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, b)) * f.out_int_mul) & 0xFFu;
+      const uint32_t p = pr | (pg << 8) | (pb << 16);
+      uint8_t* const row = f.out + (size_t)y * f.out_stride;
+      if (packed == 2) {
+        const float a = f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f;
+        const uint32_t pa = (uint32_t)__float2int_rn(fminf(1.0f, fmaxf(0.0f, a)) * f.out_int_mul) & 0xFFu;
+        StoreOut32(reinterpret_cast<uint32_t*>(row + 4 * (size_t)x), p | (pa << 24));
+      } else {
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0xF9, 0xF, 0xF, false);
+        const uint32_t j = (uint32_t)lx & 3u;
+        const uint32_t d = (p >> (8u * j)) | (nx << (24u - 8u * j));
+        if (j != 3u) StoreOut32(reinterpret_cast<uint32_t*>(row + 3 * (size_t)x + j), d);
+      }
+      continue;
+    }
+#endif
     StorePixel(f, x, y, r, g, b, f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f);
   }
 }
