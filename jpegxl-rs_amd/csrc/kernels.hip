@@ -4619,7 +4619,8 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
   {
     const int tiles_x = DivUp(max_bw, 4), tiles_y = DivUp(max_bh, 4);
     const dim3 grid(tiles_x * tiles_y, nframes);
-    const size_t lds = 3 * TileGeom<4>::kPlane * sizeof(float);
+    static const size_t pad = getenv("JXL_HIP_PAD_LDS_IDCT") ? (size_t)atoi(getenv("JXL_HIP_PAD_LDS_IDCT")) : 0;   // (experiments, as JXL_HIP_PAD_LDS_FILTER; up to the 64 KB a launch gets without asking)
+    const size_t lds = 3 * TileGeom<4>::kPlane * sizeof(float) + pad;
     if (all || cfg.need_tile4_plain) hipLaunchKernelGGL((IdctTileKernel<4, false>), grid, dim3(JXL_IDCT_T4), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct);
     if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(JXL_IDCT_T4), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct | nocoef);
     DebugLaunch("IdctTileKernel<4>");
@@ -4640,10 +4641,12 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
   const int unfused = cfg.force_unfused_filters;
   if (fp.any_fused && !unfused) {
     static bool attr = false;
-    if (!attr) { SetMaxDynamicLds((const void*)FusedGabEpf1OutKernel, (int)kFusedLds, "FusedGabEpf1OutKernel"); attr = true; }
+    // (JXL_HIP_PAD_LDS_FILTER, experiments: bytes of LDS the launch asks for beyond what the kernel uses — occupancy as beside an HF workgroup, on an idle GPU)
+    static const size_t pad = getenv("JXL_HIP_PAD_LDS_FILTER") ? (size_t)atoi(getenv("JXL_HIP_PAD_LDS_FILTER")) : 0;
+    if (!attr) { SetMaxDynamicLds((const void*)FusedGabEpf1OutKernel, (int)(kFusedLds + pad), "FusedGabEpf1OutKernel"); attr = true; }
     static const int swizzle = getenv("JXL_HIP_NO_XCD_SWIZZLE") ? 0 : 1;
     const int tiles_x = DivUp(max_w, kFtW);
-    hipLaunchKernelGGL(FusedGabEpf1OutKernel, dim3(tiles_x * DivUp(max_h, kFtH), 1, nframes), dim3(256), kFusedLds, (hipStream_t)stream, frames, unfused, tiles_x, swizzle);
+    hipLaunchKernelGGL(FusedGabEpf1OutKernel, dim3(tiles_x * DivUp(max_h, kFtH), 1, nframes), dim3(256), kFusedLds + pad, (hipStream_t)stream, frames, unfused, tiles_x, swizzle);
   }
   if (!fp.any_unfused && !unfused) return;
   // (cfg.debug_stop_after, testing: 2 = stop after gaborish, 3 / 4 / 5 = after EPF pass 0 / 1 / 2 — the planes are then read back, JxlHipBatchDebugRead)
