@@ -1293,6 +1293,9 @@ void Batch::Prepare(void* stream_v) {
   {  // LDS right-sizing for the decode kernels
     auto code_bytes = [](const HostCode& c, bool ctx) { if (c.use_prefix || c.lz77) return 16;   /* prefix codes / LZ77 streams are read through the tables in global memory: nothing to size the LDS for */
       return (int)(((c.num_clusters * 4 + 15) & ~15u) + (ctx ? ((c.num_ctx + 15) & ~15u) : 0) + ((size_t)c.num_clusters << c.log_alpha) * 8); };
+    auto code_bytes_compact = [](const HostCode& c) { if (c.use_prefix || c.lz77) return 16;
+      return (int)(((c.num_clusters * 4 + 15) & ~15u) + ((c.num_ctx + 15) & ~15u) + (((((size_t)c.num_clusters << c.log_alpha) * 6) + 15) & ~(size_t)15)); };
+    cfg.ac_code_bytes_compact = 16;
     cfg.max_tree_nodes = 1; cfg.mod_code_bytes = 16; cfg.ac_code_bytes = 16; cfg.any_wp = 0; cfg.any_local_trees = 0; cfg.any_subsampled = 0; cfg.any_prefix_ac = 0;
     for (int i = 0; i < n; i++) {
       const FramePlan& p = images_[i]->plan;
@@ -1301,11 +1304,11 @@ void Batch::Prepare(void* stream_v) {
         cfg.max_tree_nodes = std::max<int>(cfg.max_tree_nodes, (int)ls.tree.nodes.size()); cfg.mod_code_bytes = std::max(cfg.mod_code_bytes, code_bytes(ls.code, false)); cfg.any_wp |= ls.tree.uses_wp ? 1 : 0;
         if (ls.unit != 0) cfg.any_local_trees = 1;
       }
-      if (!p.modular) for (auto& code : p.ac_code) cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true));
+      if (!p.modular) for (auto& code : p.ac_code) { cfg.ac_code_bytes = std::max(cfg.ac_code_bytes, code_bytes(code, true)); cfg.ac_code_bytes_compact = std::max(cfg.ac_code_bytes_compact, code_bytes_compact(code)); }
       if (p.subsampled) cfg.any_subsampled = 1;
       if (!p.modular) for (auto& code : p.ac_code) if (code.use_prefix || code.lz77) cfg.any_prefix_ac = 1;
     }
-    if (getenv("JXL_HIP_DEBUG_LDS")) fprintf(stderr, "[jxl-hip] LDS sizing: tree nodes %d, modular code %d B, AC code %d B, BlockCtxDev %zu B\n", cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.ac_code_bytes, sizeof(BlockCtxDev));
+    if (getenv("JXL_HIP_DEBUG_LDS")) fprintf(stderr, "[jxl-hip] LDS sizing: tree nodes %d, modular code %d B, AC code %d B (compact %d B), BlockCtxDev %zu B\n", cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.ac_code_bytes, cfg.ac_code_bytes_compact, sizeof(BlockCtxDev));
   }
   {  // per-pass table descriptors (device array next to the frame descriptors)
     pass_first_.assign(n, 0);

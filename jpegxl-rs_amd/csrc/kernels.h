@@ -134,7 +134,7 @@ struct LaunchCfg {
   int any_prefix_ac = 0;     // some VarDCT frame's AC code is a prefix code or LZ77-coded (HfDecodeKernel beside the SIMT kernel)
   int any_local_trees = 0;   // some Modular sub-stream carries its own MA tree / code (second launch of the group kernel)
   // filled by Batch::Prepare: LDS needs of the batch (bytes of cfg + ctx map + alias tables, MA-tree nodes)
-  int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20;
+  int max_tree_nodes = 1024, mod_code_bytes = 1 << 20, ac_code_bytes = 1 << 20, ac_code_bytes_compact = 1 << 20;   // (compact: 6 bytes per alias slot, StageCodeCompact)
   int force_generic_idct = 0;
   // filled by Batch::Finish from the per-frame flags the LF stage sets (deterministic per stream): once known, the
   // kernels for varblocks outside a 64x64 tile / the DCT128-256 family are only launched when some frame needs them

@@ -201,6 +201,7 @@ struct FastCode {
   const uint32_t* cfg_g;
   const uint64_t* alias_g;
   uint32_t ctx_map_off, cfg_off, alias_off;   // kNotInLds if the table stayed in global memory
+  uint32_t freq_off;                          // StageCodeCompact: per-symbol frequencies (u16) behind the 4-byte alias slots
   uint32_t log_alpha;
   uint32_t cfg_uniform;                       // the hybrid-uint config shared by every cluster, or 0xFFFFFFFF
   __device__ __forceinline__ uint32_t Cluster(uint32_t ctx) const { return ctx_map_off != kNotInLds ? LdS<uint8_t>(ctx_map_off + ctx) : LdG(ctx_map_g + ctx); }
@@ -328,6 +329,46 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
     fc.alias_off = base + used; used += n_alias * 8;
   }
   return used;
+}
+
+// The same for the SIMT HF kernel's all-in-LDS instantiations, with the alias table in 6 instead of 8 bytes per slot: a 4-byte slot
+// cutoff[0:8) right[8:16) offs1[16:29) and one u16 frequency per symbol — freq0 of slot i is the frequency of symbol i, freq1 that of symbol
+// `right` (host_parse.cc BuildAlias), so the reader looks the frequency up by the symbol it decoded (one more dependent LDS read per token; 57 -> 43 KB
+// for the bench's AC code: two more pixel workgroups beside an HF workgroup on every CU).  All or nothing: returns 0 and leaves alias_off = kNotInLds
+// if [base, base + budget) is too small.
+__device__ uint32_t StageCodeCompact(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget) {
+  fc.log_alpha = g.log_alpha;
+  fc.ctx_map_g = g.ctx_map; fc.cfg_g = g.cfg; fc.alias_g = g.alias;
+  fc.ctx_map_off = fc.cfg_off = fc.alias_off = fc.freq_off = kNotInLds;
+  {
+    const uint32_t c0 = LdG(g.cfg);
+    bool same = true;
+    for (uint32_t i = threadIdx.x; i < g.num_clusters; i += blockDim.x) same = same && LdG(g.cfg + i) == c0;
+    fc.cfg_uniform = __syncthreads_and(same) ? c0 : 0xFFFFFFFFu;
+  }
+  const uint32_t cfg_bytes = (g.num_clusters * 4 + 15) & ~15u, map_bytes = (g.num_ctx + 15) & ~15u;
+  const uint32_t n_alias = g.num_clusters << g.log_alpha;
+  const uint32_t total = cfg_bytes + map_bytes + ((n_alias * 6 + 15) & ~15u);
+  if (total > budget) return 0;
+  for (uint32_t i = threadIdx.x; i < g.num_clusters; i += blockDim.x) StS<uint32_t>(base + i * 4, LdG(g.cfg + i));
+  fc.cfg_off = base;
+  for (uint32_t i = threadIdx.x; i < g.num_ctx; i += blockDim.x) StS<uint8_t>(base + cfg_bytes + i, LdG(g.ctx_map + i));
+  fc.ctx_map_off = base + cfg_bytes;
+  const uint32_t slots = base + cfg_bytes + map_bytes, freqs = slots + n_alias * 4;
+  for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) {
+    const uint64_t e = LdG(g.alias + i);
+    StS<uint32_t>(slots + i * 4, (uint32_t)(e & 0xFFFF) | ((uint32_t)((e >> 29) & 0x1FFF) << 16));
+    StS<uint16_t>(freqs + i * 2, (uint16_t)((e >> 16) & 0x1FFF));            // freq0: symbol i of this cluster
+  }
+  __syncthreads();
+  // freq1 belongs to symbol `right` (equal to what the first pass wrote there, except in a one-symbol histogram, whose slots carry freq0 = 0)
+  for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) {
+    const uint64_t e = LdG(g.alias + i);
+    const uint32_t right = (uint32_t)((e >> 8) & 0xFF), cluster_base = i & ~((1u << g.log_alpha) - 1);
+    if (right < (1u << g.log_alpha)) StS<uint16_t>(freqs + (cluster_base + right) * 2, (uint16_t)((e >> 42) & 0x1FFF));
+  }
+  fc.alias_off = slots; fc.freq_off = freqs;
+  return total;
 }
 
 // ---- Modular channel decode, cooperative version -------------------------------------------------------------------------
@@ -2370,13 +2411,27 @@ template <bool ALL_LDS, typename BR> __device__ __forceinline__ uint32_t HybridS
   const uint32_t cfg = ALL_LDS ? LdS<uint32_t>(c.cfg_off + cluster * 4) : c.Cfg(cluster);
   const uint32_t res = state & 0xFFF;
   const uint32_t i = res >> (12 - la), pos = res & ((1u << (12 - la)) - 1);
-  const uint64_t e = ALL_LDS ? LdS<uint64_t>(c.alias_off + (((cluster << la) + i) << 3)) : c.Alias(cluster, i);
-  const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
-  const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
-  const bool hit = pos >= cutoff;
-  uint32_t tok = hit ? right : i;
-  const uint32_t off = hit ? offs1 + pos : pos;
-  const uint32_t freq = hit ? freq1 : freq0;
+  uint32_t tok, off, freq;
+#ifndef JXL_HF_WIDE_ALIAS
+  if (ALL_LDS) {      // StageCodeCompact: 4-byte slot, frequency by decoded symbol
+    const uint32_t cb = cluster << la;
+    const uint32_t e = LdS<uint32_t>(c.alias_off + ((cb + i) << 2));
+    const uint32_t cutoff = e & 0xFF, right = (e >> 8) & 0xFF, offs1 = e >> 16;
+    const bool hit = pos >= cutoff;
+    tok = hit ? right : i;
+    off = hit ? offs1 + pos : pos;
+    freq = LdS<uint16_t>(c.freq_off + ((cb + tok) << 1));
+  } else
+#endif
+  {
+    const uint64_t e = ALL_LDS ? LdS<uint64_t>(c.alias_off + (((cluster << la) + i) << 3)) : c.Alias(cluster, i);
+    const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+    const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+    const bool hit = pos >= cutoff;
+    tok = hit ? right : i;
+    off = hit ? offs1 + pos : pos;
+    freq = hit ? freq1 : freq0;
+  }
   state = freq * (state >> 12) + off;
   // (the caller refilled: at least 33 bits are buffered, 17 after the renormalisation — enough for most extra-bit fields)
   if (state < (1u << 16)) { state = (state << 16) | (uint32_t)(br.buf & 0xFFFFu); br.buf >>= 16; br.avail -= 16; }
@@ -2436,6 +2491,10 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   const PassDev& pd = f.passes[pass];
   const uint32_t shift = MULTI ? pd.shift : 0u;
   if (pass) __syncthreads();                           // every lane is done with the previous pass's tables
+#ifndef JXL_HF_WIDE_ALIAS
+  if (ALL_LDS && !(pd.code.use_prefix != 0 || pd.code.lz77 != 0)) StageCodeCompact(pd.code, code, kSimtCodeOff, lane_off > kSimtCodeOff ? lane_off - kSimtCodeOff : 0);
+  else
+#endif
   StageCode(pd.code, code, kSimtCodeOff, lane_off > kSimtCodeOff ? lane_off - kSimtCodeOff : 0, /*with_ctx_map=*/true);
   if (threadIdx.x < 39) StS<uint64_t>(kSimtOrdOff + threadIdx.x * 8, (uint64_t)(uintptr_t)pd.orders[threadIdx.x]);
   __syncthreads();
@@ -4546,7 +4605,12 @@ void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, i
 }
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
   if (cfg.lane_stride_hf == 1) {   // SIMT: one group stream per lane
-    const bool all_lds = cfg.ac_code_bytes <= cfg.lds_code_budget;     // every frame's AC code fits the LDS budget
+#ifndef JXL_HF_WIDE_ALIAS
+    const int code_lds = cfg.ac_code_bytes_compact;                    // the all-in-LDS instantiations stage the compact form (StageCodeCompact)
+#else
+    const int code_lds = cfg.ac_code_bytes;
+#endif
+    const bool all_lds = code_lds <= cfg.lds_code_budget;              // every frame's AC code fits the LDS budget
     // lanes per workgroup: the groups of a frame spread evenly over as few workgroups as possible, whole wavefronts (a
     // 3840x2160 frame has 135 groups: 192 threads, 136 lane regions, 80 KB of LDS instead of 99 KB — which is what lets two
     // LF workgroups share the CU with it)
@@ -4558,7 +4622,7 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     uint32_t lpw = lpw_env >= 1 && lpw_env <= 64 ? (uint32_t)lpw_env : (uint32_t)DivUp((int)lanes, 4);
     lpw = std::max(lpw, (uint32_t)DivUp((int)lanes, 16));                        // at most 16 wavefronts per workgroup
     const uint32_t threads = (uint32_t)DivUp((int)lanes, (int)lpw) * 64;
-    const uint32_t lds = kSimtCodeOff + (uint32_t)std::min(cfg.lds_code_budget, cfg.ac_code_bytes) + (lanes + 1) * kSimtLaneBytes;
+    const uint32_t lds = kSimtCodeOff + (uint32_t)(all_lds ? code_lds : std::min(cfg.lds_code_budget, cfg.ac_code_bytes)) + (lanes + 1) * kSimtLaneBytes;
     static bool attr = false;
     if (!attr) {
       SetMaxDynamicLds((const void*)HfDecodeSimtKernel<true, false, false>, 160 * 1024 - 2048, "HfDecodeSimtKernel<true, false, false>");
