@@ -3805,7 +3805,10 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
 #define JXL_FTH 24
 #endif
 constexpr int kFtW = 32, kFtH = JXL_FTH;   // (JXL_FTH: tile height, an A/B knob — 16 gives 10 KB of LDS per workgroup instead of 14)
-constexpr int kFinW = kFtW + 6, kFinH = kFtH + 6, kFinP = kFinW + 1;      // input region incl. halo 3, padded pitch
+#ifndef JXL_FPAD
+#define JXL_FPAD 1
+#endif
+constexpr int kFinW = kFtW + 6, kFinH = kFtH + 6, kFinP = kFinW + JXL_FPAD;      // input region incl. halo 3, padded pitch (JXL_FPAD 0: 13.4 instead of 13.7 KB per workgroup — a seventh one beside a 66 KB HF workgroup)
 constexpr int kFgW = kFtW + 4, kFgH = kFtH + 4, kFgP = kFgW + 1;          // gaborish region incl. halo 2
 constexpr size_t kFusedLds = (size_t)(3 * kFinH * kFinP) * sizeof(float);   // the gaborish tile reuses the input tile's LDS (14 KB)
 
