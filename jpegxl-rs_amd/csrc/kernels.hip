@@ -390,7 +390,7 @@ static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
 #define JXL_IDCT_T4 128   // threads of an IdctTileKernel<4> workgroup (A/B knob: 256 = four wavefronts share the 14 KB tile)
 #endif
 #ifndef JXL_IDCT_MINW
-#define JXL_IDCT_MINW 4    // IdctTileKernel<4>: likewise
+#define JXL_IDCT_MINW 5    // IdctTileKernel<4>: five wavefronts per SIMD = 96 VGPRs (24 dwords of scratch in the SPECIAL variant): four of them fit beside an HF wavefront (80 VGPRs) where 110 registers allowed three (r04: steady state 71.0 -> 69.7 ms per step, alone 19.2 -> 18.8)
 #endif
 // The dynamic-LDS ceiling of a kernel (static __shared__ arrays count against the same 160 KB): a refused request must not pass silently — launches above the
 // default 64 KB would then be refused one by one, each leaving an error code for some later runtime call to report.
@@ -3252,7 +3252,12 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
 // SPECIAL = the variant for frames that contain the 8x8 "special" transforms (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4):
 // their 64-coefficient register blocks cost 30 VGPRs that the plain variant does not have to carry (the LF stage flags
 // the frames; which variants a batch needs is known after its first decode).
-template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL_IDCT_T4, TB == 8 ? 2 : JXL_IDCT_MINW) void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
+#ifdef JXL_IDCT_NUM_VGPR   // (A/B knob: a register budget between what the waves-per-SIMD steps of __launch_bounds__ give — 128, 96)
+#define JXL_IDCT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(JXL_IDCT_NUM_VGPR)))
+#else
+#define JXL_IDCT_VGPR_ATTR
+#endif
+template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL_IDCT_T4, TB == 8 ? 2 : JXL_IDCT_MINW) JXL_IDCT_VGPR_ATTR void IdctTileKernel(const FrameDev* __restrict__ frames, int tiles_x, int force_generic) {
   constexpr int kTilePitch = TileGeom<TB>::kPitch, kTilePlane = TileGeom<TB>::kPlane, kNB = TB * TB;
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || f.subsampled || (*f.frame_flags & 1) != 0 || (force_generic & 3)) return;
