@@ -772,6 +772,36 @@ def test_vardct_shapes_and_filters(jx, w, h, mix, epf, gab, skip):
     check_against_oracle(jx, data, np.float16, 3)
 
 
+@pytest.mark.parametrize("w,h", [(64, 40), (68, 33), (66, 40), (70, 24), (260, 50), (1028, 70)])
+def test_fused_filter_dword_stores(jx, w, h):
+    """The fused filter kernel writes u8 RGB / RGBA as whole dwords (RGB: a DPP exchange inside every quad of lanes) when rows and buffer are 4-byte
+    aligned, the width is a multiple of 4 and the image is written in its own orientation; every other case keeps the byte stores.  Widths on both
+    sides of that condition, with and without an alpha plane, aligned and unaligned rows, a rotated image, sample types that never take the path."""
+    img = np.ascontiguousarray(S.synthetic_image(33, max(w, 8), max(h, 8))[:h, :w])
+    alpha = ((np.arange(h)[:, None] * 7 + np.arange(w)[None, :] * 3) % 256).astype(np.uint8)
+    data = S.encode_vardct(img, seed=9, strategy_mix=2, epf_iters=1, gab=1)
+    data_a = S.encode_vardct(img, seed=9, strategy_mix=2, epf_iters=1, gab=1, alpha=alpha)
+    for d in (data, data_a):
+        for nch in (3, 4):
+            check_against_oracle(jx, d, np.uint8, nch)
+            check_against_oracle(jx, d, np.uint8, nch, align=64)
+        check_against_oracle(jx, d, np.uint8, 1)
+        check_against_oracle(jx, d, np.uint8, 2)
+        check_against_oracle(jx, d, np.uint16, 3)
+    rotated = S.encode_vardct(img, seed=9, strategy_mix=2, epf_iters=1, gab=1, orientation=6)
+    check_against_oracle(jx, rotated, np.uint8, 3)
+    check_against_oracle(jx, rotated, np.uint8, 4)
+    # a batch writes frame after frame into one buffer: frames whose byte size is not a multiple of 4 leave the next one's rows unaligned
+    odd = np.ascontiguousarray(S.synthetic_image(34, 72, 24)[:21, :66])
+    streams = [S.encode_vardct(odd, seed=3, epf_iters=1, gab=1), data, S.encode_vardct(odd, seed=4, epf_iters=1, gab=1)]
+    b = jx.BatchDecoder(0)
+    for st in streams:
+        b.add(st, "uint8", 3)
+    b.prepare(); b.decode(); b.finish()
+    for i, st in enumerate(streams):
+        assert np.array_equal(b.output(i).reshape(-1), O.decode(st).pixels("u8", 3).reshape(-1)), i
+
+
 def test_unaligned_varblocks_and_generic_idct(jx):
     """Varblocks that are not contained in a 64x64 tile (legal, never produced by encoders) take the generic IDCT kernel;
     forcing the generic kernel on a regular stream must give the same pixels as the tiled kernel."""
