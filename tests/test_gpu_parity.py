@@ -802,6 +802,33 @@ def test_fused_filter_dword_stores(jx, w, h):
         assert np.array_equal(b.output(i).reshape(-1), O.decode(st).pixels("u8", 3).reshape(-1)), i
 
 
+@pytest.mark.parametrize("kind", ["flat", "one_edge", "dots"])
+def test_degenerate_ac_histograms(jx, kind):
+    """Pictures whose AC token statistics collapse — a constant colour (every block: zero non-zeros), one vertical edge, a few isolated dots — give AC
+    codes with one-symbol histograms (alias slots that all point at the symbol, frequency 4096) and clusters no token ever uses: the HF kernel's compact
+    alias tables (a u16 frequency per symbol, written in two passes) must decode them like the 8-byte slots did.  Alone and in one batch."""
+    w, h = 264, 200
+    img = np.full((h, w, 3), (90, 140, 200), dtype=np.uint8)
+    if kind == "one_edge":
+        img[:, w // 2:] = (200, 60, 30)
+    elif kind == "dots":
+        for (y, x) in [(13, 17), (100, 130), (190, 250), (64, 64)]:
+            img[y, x] = (255, 255, 255)
+    streams = []
+    for mix, epf in ((0, 0), (2, 1)):
+        data = S.encode_vardct(img, seed=5, strategy_mix=mix, epf_iters=epf, gab=epf)
+        check_against_oracle(jx, data, np.uint8, 3)
+        check_against_oracle(jx, data, np.float32, 3)
+        streams.append(data)
+    streams.append(S.encode_vardct(S.synthetic_image(12, w, h), seed=2, strategy_mix=2, epf_iters=1, gab=1))    # an ordinary frame in the same launch
+    b = jx.BatchDecoder(0)
+    for st in streams:
+        b.add(st, "uint8", 3)
+    b.prepare(); b.decode(); b.finish()
+    for i, st in enumerate(streams):
+        assert np.array_equal(b.output(i).reshape(-1), O.decode(st).pixels("u8", 3).reshape(-1)), i
+
+
 def test_unaligned_varblocks_and_generic_idct(jx):
     """Varblocks that are not contained in a 64x64 tile (legal, never produced by encoders) take the generic IDCT kernel;
     forcing the generic kernel on a regular stream must give the same pixels as the tiled kernel."""
