@@ -3252,7 +3252,7 @@ template <int R, int PITCH> __device__ __forceinline__ void TileColPass(float* c
 // SPECIAL = the variant for frames that contain the 8x8 "special" transforms (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4):
 // their 64-coefficient register blocks cost 30 VGPRs that the plain variant does not have to carry (the LF stage flags
 // the frames; which variants a batch needs is known after its first decode).
-#ifdef JXL_IDCT_NUM_VGPR   // (A/B knob: a register budget between what the waves-per-SIMD steps of __launch_bounds__ give — 128, 96)
+#ifdef JXL_IDCT_NUM_VGPR   // (A/B knob: a register budget between what the waves-per-SIMD steps of __launch_bounds__ give — 128, 96; hipcc 7.2 keeps 110 VGPRs for <4, true> under 104: not honoured)
 #define JXL_IDCT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(JXL_IDCT_NUM_VGPR)))
 #else
 #define JXL_IDCT_VGPR_ATTR
