@@ -1,0 +1,11 @@
+# --tail-streams 2 in the full bench process with more hardware queues (the extra stream collides with the copy streams at 16)
+cd $GRAFT_REPO_ROOT
+export JXL_BENCH_STREAM_CACHE=/tmp/jxl_streams
+one() { label="$1"; shift; timeout 700 python bench.py --no-cpu-baseline --no-extras "$@" 2>/dev/null | python -c "
+import sys,json
+try:
+    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']; print('$label', d['value'], d['ms_per_step'], d['steady_state_ms_per_step'], 'resident', d['resident_mpixel_per_s'], 'realistic', c['workload_realistic']['value'], 'cjxl', c['workload_cjxl_shape']['value'], d['stage_ms'])
+except Exception as e: print('$label', 'failed', e)"; }
+GPU_MAX_HW_QUEUES=24 one k20_tail2_q24 --gpus 1 --steps 20 --warmup 5 --tail-streams 2
+GPU_MAX_HW_QUEUES=32 one k20_tail2_q32 --gpus 1 --steps 20 --warmup 5 --tail-streams 2
+GPU_MAX_HW_QUEUES=24 one k20_base_q24 --gpus 1 --steps 20 --warmup 5
