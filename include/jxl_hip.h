@@ -287,6 +287,60 @@ int64_t JxlHipBatchGetInfo(const JxlHipBatch* batch, const char* name);
  * Returns the size of the buffer in bytes (0 on error), copies min(size, cap). */
 size_t JxlHipBatchDebugRead(JxlHipBatch* batch, int index, const char* name, int channel, void* dst, size_t cap, void* hip_stream);
 
+/* ---- extension: the streaming decode pipeline of one GPU ----------------------------------------------------------------------
+ * No counterpart in the reference: jpegxl-rs decodes batches by looping decode_with over files (jpegxl-rs/benches/decode.rs:16-19).  A pipeline object
+ * owns what keeps a GPU busy with a stream of compressed images: a ring of batch objects, the coefficient sets and pixel planes all jobs share, its own
+ * non-blocking HIP streams, the host threads that parse / build tables / upload / enqueue the latency-bound LF stage several jobs ahead, and the thread
+ * that issues HF stages and tails in submission order (csrc/pipeline.h).  bench.py's headline is produced by these calls.
+ * Concurrent callers of the libjxl API above share one such pipeline per device (csrc/scheduler.cc). */
+typedef struct JxlHipPipelineStruct JxlHipPipeline;
+typedef struct {
+  int32_t jobs_in_flight;    /* jobs in flight on the GPU; 0 = default (11) */
+  int32_t lf_streams;        /* side streams for the LF stages; 0 = default (7) */
+  int32_t hf_streams;        /* HF stages in flight beside the tail, one coefficient set each + one; 0 = default (1) */
+  int32_t prepare_threads;   /* host threads that each prepare one job at a time; 0 = default (3) */
+  int32_t parse_threads;     /* host threads one job's images are parsed on; 0 = default (8) */
+  int32_t lane_stride_lf, lane_stride_hf;   /* see JxlHipBatchSetLaneStride; 0 = defaults (8, 1) */
+  int32_t wide_first;        /* LF stages at the start of a cold pipeline that take the one-wavefront-per-stream kernel; < 0 = default (4) */
+  int32_t small_job_frames;  /* jobs of at most this many frames always take it (latency over occupancy); 0 = never */
+  int32_t timed;             /* bracket the stages with HIP events: JxlHipPipelineCollectTimes */
+  int32_t reserve_frames, reserve_width, reserve_height;   /* size the shared planes for jobs of this shape at creation (0: grown when the pipeline is idle) */
+} JxlHipPipelineOptions;
+JxlHipPipeline* JxlHipPipelineCreate(int device, const JxlHipPipelineOptions* options /* NULL = defaults */);
+void JxlHipPipelineDestroy(JxlHipPipeline* pipeline);
+/* Submits a job of n compressed images, all decoded to `format`.  Exactly one of device_out / host_out is given: n caller-owned destinations (device memory /
+ * host memory — pinned, JxlHipHostAlloc, for full-speed copies that overlap later jobs), each at least JxlHipImageOutSize bytes; out_capacity (optional) is
+ * checked per image.  The compressed bytes and the destinations must stay valid until JxlHipPipelineWait(ticket) returns.  Blocks while the ring is full.
+ * An image that does not parse or decode fails alone.  Returns the job's ticket (>= 0) or -1 (JxlHipLastError). */
+int64_t JxlHipPipelineSubmit(JxlHipPipeline* pipeline, const uint8_t* const* datas, const size_t* sizes, int n, const JxlPixelFormat* format, void* const* device_out,
+                             void* const* host_out, const size_t* out_capacity);
+/* Waits until the job has left the GPU (pixels written, host copies done).  image_status[i] (n entries, optional): 0 decoded, 1 failed; *end_ms (optional): when the
+ * job's last byte was written, ms after JxlHipPipelineResetClock.  JXL_DEC_SUCCESS if every image decoded, else JXL_DEC_ERROR (JxlHipLastError names the first).
+ * A ticket can be waited for once; jobs complete in submission order. */
+JxlDecoderStatus JxlHipPipelineWait(JxlHipPipeline* pipeline, int64_t ticket, int* image_status, int n, float* end_ms);
+JxlDecoderStatus JxlHipPipelineWaitAll(JxlHipPipeline* pipeline);        /* every job submitted so far has left the GPU (results stay collectable) */
+JxlDecoderStatus JxlHipPipelineResetClock(JxlHipPipeline* pipeline);     /* waits for idle; end_ms and the prepare-time counters start over */
+JxlDecoderStatus JxlHipPipelineCollectTimes(JxlHipPipeline* pipeline, JxlHipStageTimes* times, int* runs);   /* options.timed: per-stage sums (ms) over the jobs since the last call */
+void JxlHipPipelineStageBytes(JxlHipPipeline* pipeline, uint64_t out[6]);   /* algorithmic bytes per stage of the job prepared last (JxlHipBatchStageBytes) */
+/* "jobs", "slots", "coefficient_sets", "device_bytes", "shared_big_bytes", "shared_coef_bytes", "private_plane_jobs" (jobs that did not fit the shared planes),
+ * "prepare_us_total" / "prepared_jobs" (host time of the prepare threads since the last clock reset), and of the job prepared / finished last: "frames",
+ * "compressed_bytes", "total_pixels", "hf_nonzeros", "lf_simt_frames", "lf_legacy_frames", "lf_simt_wp".  -1: unknown name. */
+int64_t JxlHipPipelineGetInfo(JxlHipPipeline* pipeline, const char* name);
+/* Pinned host memory for host_out destinations (hipHostMalloc / hipHostFree). */
+void* JxlHipHostAlloc(size_t bytes);
+void JxlHipHostFree(void* p);
+/* Host-only (needs no GPU): basic info and output size of an image for `format` from its headers — what a caller of JxlHipPipelineSubmit sizes its buffers with. */
+JxlDecoderStatus JxlHipImageOutSize(const uint8_t* data, size_t size, const JxlPixelFormat* format, JxlBasicInfo* info, size_t* out_size);
+/* Device arenas that batches and pipelines let go of are pooled per process (hipMalloc / hipFree of tens of GB cost seconds): JXL_HIP_ARENA_POOL_MB bounds the pool
+ * (default 60 % of the device's memory, 0 = off); Trim hands every pooled block back to the runtime — for processes that share the GPU with another allocator —
+ * and returns the bytes released; Held = bytes pooled right now. */
+size_t JxlHipArenaPoolTrim(void);
+size_t JxlHipArenaPoolHeld(void);
+/* The scheduler behind the libjxl API (one shared pipeline per device; JXL_HIP_SCHEDULER=0 turns it off): jobs submitted / images decoded so far; Shutdown joins its
+ * threads and frees its pipelines (tests). */
+void JxlHipSchedulerStats(int device, int64_t* jobs, int64_t* images);
+void JxlHipSchedulerShutdown(void);
+
 #ifdef __cplusplus
 }
 #endif

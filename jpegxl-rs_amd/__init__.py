@@ -88,6 +88,12 @@ class JxlHipStageTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lf_ms", "lfpost_ms", "hf_ms", "idct_ms", "filter_ms", "out_ms", "total_ms")]
 
 
+class JxlHipPipelineOptions(C.Structure):
+    """include/jxl_hip.h JxlHipPipelineOptions (0 / negative = the library's default)"""
+    _fields_ = [(n, C.c_int32) for n in ("jobs_in_flight", "lf_streams", "hf_streams", "prepare_threads", "parse_threads", "lane_stride_lf", "lane_stride_hf", "wide_first",
+                                         "small_job_frames", "timed", "reserve_frames", "reserve_width", "reserve_height")]
+
+
 assert C.sizeof(JxlBasicInfo) == 204 and C.sizeof(JxlPixelFormat) == 24 and C.sizeof(JxlMemoryManager) == 24
 
 _lib = None
@@ -159,6 +165,16 @@ def libjxl():
             "JxlHipBatchDebugRead": (sz, [vp, C.c_int, C.c_char_p, C.c_int, vp, sz, vp]),
             "JxlHipBatchAddImages": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_int, C.c_int]),
             "JxlHipBatchShareBuffers": (C.c_int, [vp, vp]), "JxlHipBatchShareCoefficients": (C.c_int, [vp, vp]),
+            "JxlHipPipelineCreate": (vp, [C.c_int, C.POINTER(JxlHipPipelineOptions)]), "JxlHipPipelineDestroy": (None, [vp]),
+            "JxlHipPipelineSubmit": (C.c_int64, [vp, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_int, C.POINTER(JxlPixelFormat), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]),
+            "JxlHipPipelineWait": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_float)]),
+            "JxlHipPipelineWaitAll": (C.c_int, [vp]), "JxlHipPipelineResetClock": (C.c_int, [vp]),
+            "JxlHipPipelineCollectTimes": (C.c_int, [vp, C.POINTER(JxlHipStageTimes), C.POINTER(C.c_int)]),
+            "JxlHipPipelineStageBytes": (None, [vp, C.POINTER(C.c_uint64 * 6)]), "JxlHipPipelineGetInfo": (C.c_int64, [vp, C.c_char_p]),
+            "JxlHipHostAlloc": (vp, [sz]), "JxlHipHostFree": (None, [vp]),
+            "JxlHipImageOutSize": (C.c_int, [vp, sz, C.POINTER(JxlPixelFormat), C.POINTER(JxlBasicInfo), C.POINTER(sz)]),
+            "JxlHipArenaPoolTrim": (sz, []), "JxlHipArenaPoolHeld": (sz, []),
+            "JxlHipSchedulerStats": (None, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]), "JxlHipSchedulerShutdown": (None, []),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -707,3 +723,111 @@ class BatchDecoder:
     @property
     def device_bytes(self):
         return libjxl().JxlHipBatchDeviceBytes(self._h)
+
+
+def arena_pool_trim() -> int:
+    """Hands every pooled device arena back to the HIP runtime (JxlHipArenaPoolTrim); returns the bytes released."""
+    return int(libjxl().JxlHipArenaPoolTrim())
+
+
+def image_out_size(data: bytes, dtype="uint8", num_channels=0, endianness=Endianness.Native, align=0):
+    """(JxlBasicInfo, bytes of the decoded image in that format) from the headers alone — host-only (JxlHipImageOutSize)."""
+    fmt = JxlPixelFormat(num_channels, _PIXEL_TYPES[np.dtype(dtype).name][0], endianness, align)
+    info, size = JxlBasicInfo(), C.c_size_t()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    check_dec_status(libjxl().JxlHipImageOutSize(buf.ctypes.data, len(data), C.byref(fmt), C.byref(info), C.byref(size)))
+    return info, size.value
+
+
+class PinnedBuffer:
+    """Pinned host memory (JxlHipHostAlloc) as a numpy uint8 array: destination of a pipeline's host_out copies."""
+
+    def __init__(self, nbytes: int):
+        self._p = libjxl().JxlHipHostAlloc(max(1, int(nbytes)))
+        if not self._p:
+            raise MemoryError(last_error())
+        self.nbytes = int(nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(1, self.nbytes)).from_address(self._p))[: self.nbytes]
+
+    @property
+    def ptr(self) -> int:
+        return self._p
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            libjxl().JxlHipHostFree(self._p)
+            self._p = None
+
+
+class Pipeline:
+    """The streaming decode pipeline of one GPU (include/jxl_hip.h JxlHipPipeline*; csrc/pipeline.h): submit jobs of compressed images, the library overlaps
+    their stages — host parse / upload, LF, HF, IDCT, filters, copies — over its own streams and threads.  submit() returns a ticket, wait(ticket) the per-image
+    status once the pixels are where they were asked for."""
+
+    def __init__(self, device: int = 0, **options):
+        o = JxlHipPipelineOptions()
+        o.wide_first = -1
+        for k, v in options.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown pipeline option {k}")
+            setattr(o, k, int(v))
+        self._h = libjxl().JxlHipPipelineCreate(int(device), C.byref(o))
+        if not self._h:
+            raise CannotCreateDecoder(last_error())
+        self._keep = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            libjxl().JxlHipPipelineDestroy(self._h)
+            self._h = None
+            self._keep = {}
+
+    __del__ = close
+
+    def submit(self, datas, dtype="uint8", num_channels=0, device_ptrs=None, host_ptrs=None, capacities=None, endianness=Endianness.Native, align=0) -> int:
+        """Job of len(datas) images (bytes objects).  device_ptrs / host_ptrs: one destination address per image (exactly one of the two lists); the bytes objects and
+        the destinations are kept referenced until wait()."""
+        n = len(datas)
+        ptrs = (C.c_char_p * n)(*datas)
+        sizes = (C.c_size_t * n)(*[len(d) for d in datas])
+        fmt = JxlPixelFormat(num_channels, _PIXEL_TYPES[np.dtype(dtype).name][0], endianness, align)
+        dev = (C.c_void_p * n)(*device_ptrs) if device_ptrs is not None else None
+        host = (C.c_void_p * n)(*host_ptrs) if host_ptrs is not None else None
+        caps = (C.c_size_t * n)(*capacities) if capacities is not None else None
+        t = libjxl().JxlHipPipelineSubmit(self._h, ptrs, sizes, n, C.byref(fmt), dev, host, caps)
+        if t < 0:
+            raise GenericError(last_error())
+        self._keep[t] = (datas, ptrs, sizes, dev, host, caps, n)
+        return t
+
+    def wait(self, ticket: int, check=True):
+        """-> (per-image status list, end_ms).  check: raise GenericError if an image failed."""
+        n = self._keep[ticket][6] if ticket in self._keep else 0
+        st = (C.c_int * max(1, n))()
+        end = C.c_float()
+        rc = libjxl().JxlHipPipelineWait(self._h, int(ticket), st, n, C.byref(end))
+        self._keep.pop(ticket, None)
+        if rc != JXL_DEC_SUCCESS and check:
+            raise GenericError(last_error())
+        return list(st)[:n], float(end.value)
+
+    def wait_all(self):
+        check_dec_status(libjxl().JxlHipPipelineWaitAll(self._h))
+
+    def reset_clock(self):
+        check_dec_status(libjxl().JxlHipPipelineResetClock(self._h))
+
+    def collect_times(self):
+        t, runs = JxlHipStageTimes(), C.c_int()
+        check_dec_status(libjxl().JxlHipPipelineCollectTimes(self._h, C.byref(t), C.byref(runs)))
+        return {n: getattr(t, n) for n, _ in JxlHipStageTimes._fields_}, runs.value
+
+    @property
+    def stage_bytes(self):
+        out = (C.c_uint64 * 6)()
+        libjxl().JxlHipPipelineStageBytes(self._h, C.byref(out))
+        return dict(zip(("lf", "lfpost", "hf", "idct", "filter", "out"), [int(v) for v in out]))
+
+    def info(self, name: str) -> int:
+        return int(libjxl().JxlHipPipelineGetInfo(self._h, name.encode()))

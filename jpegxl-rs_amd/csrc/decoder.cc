@@ -333,9 +333,8 @@ struct ArenaPool {
     return v;
   }
   static constexpr size_t kMinBytes = (size_t)8 << 20;   // small allocations are cheap: not pooled
-  void* Take(size_t want, size_t* cap) {
+  void* Take(size_t want, size_t* cap, int dev) {
     if (want < kMinBytes || Limit() == 0) return nullptr;
-    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lock(mu);
     int best = -1;
     for (size_t i = 0; i < blocks.size(); i++)
@@ -345,49 +344,65 @@ struct ArenaPool {
     blocks.erase(blocks.begin() + best);
     return p;
   }
-  void Give(void* p, size_t cap) {
+  // `dev`: the device the block was allocated on (the owner's, not the calling thread's current one).  The device-wide wait — what hipFree does implicitly: nothing in
+  // flight may still touch the block when somebody else gets it — happens outside the pool's lock.
+  void Give(void* p, size_t cap, int dev) {
     if (!p) return;
-    int dev = 0;
-    const bool dev_ok = hipGetDevice(&dev) == hipSuccess;
-    if (!dev_ok) (void)hipGetLastError();
-    if (dev_ok && cap >= kMinBytes && Limit() != 0) {
-      std::lock_guard<std::mutex> lock(mu);
-      if (held + cap <= Limit() && blocks.size() < 96) {
-        (void)hipDeviceSynchronize();      // (what hipFree does implicitly: nothing in flight may still touch the block when somebody else gets it)
-        blocks.push_back(Block{p, cap, dev}); held += cap;
-        return;
+    if (dev >= 0 && cap >= kMinBytes && Limit() != 0) {
+      bool room;
+      { std::lock_guard<std::mutex> lock(mu); room = held + cap <= Limit() && blocks.size() < 96; }
+      if (room) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+        if (cur != dev) (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+        std::lock_guard<std::mutex> lock(mu);
+        if (held + cap <= Limit() && blocks.size() < 96) { blocks.push_back(Block{p, cap, dev}); held += cap; return; }
       }
     }
     (void)hipFree(p);
   }
-  void Trim() {   // gives everything back to the runtime (an allocation failed: the pool may be what is in the way)
-    std::lock_guard<std::mutex> lock(mu);
-    for (auto& b : blocks) (void)hipFree(b.p);
-    blocks.clear(); held = 0;
+  size_t Trim() {   // gives everything back to the runtime (an allocation failed: the pool may be what is in the way; or the caller asked: JxlHipArenaPoolTrim)
+    std::vector<Block> mine;
+    size_t bytes;
+    { std::lock_guard<std::mutex> lock(mu); mine.swap(blocks); bytes = held; held = 0; }
+    for (auto& b : mine) (void)hipFree(b.p);
+    return bytes;
   }
+  size_t Held() { std::lock_guard<std::mutex> lock(mu); return held; }
 };
 ArenaPool& Pool() { static ArenaPool* pool = new ArenaPool(); return *pool; }     // (never destroyed: the runtime may be gone by then)
 }  // namespace
-void DeviceArenaPoolTrim() { Pool().Trim(); }
+size_t DeviceArenaPoolTrim() { return Pool().Trim(); }
+size_t DeviceArenaPoolHeld() { return Pool().Held(); }
+void* DeviceArenaTake(size_t want, size_t* cap, int device) { return Pool().Take(want, cap, device); }
+void DeviceArenaGive(void* p, size_t cap, int device) { Pool().Give(p, cap, device); }
 
 Batch::Batch(int device) : device_(device) {
   if (device_ >= 0) HIP_CHECK(hipSetDevice(device_));      // (-1: host-side parsing only, JxlHipDebugDescribe)
 }
 Batch::~Batch() {
+  // (the calling thread's current device is left as it was found)
+  int cur = -1;
+  if (device_ >= 0 && hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+  if (device_ >= 0 && cur != device_) (void)hipSetDevice(device_);
   if (clear_stream_) { (void)hipStreamSynchronize((hipStream_t)clear_stream_); (void)hipStreamDestroy((hipStream_t)clear_stream_); }
   if (clear_event_) (void)hipEventDestroy((hipEvent_t)clear_event_);
   if (idct_event_) (void)hipEventDestroy((hipEvent_t)idct_event_);
   if (flags_event_) (void)hipEventDestroy((hipEvent_t)flags_event_);
   if (flags_pinned_) (void)hipHostFree(flags_pinned_);
-  if (device_ >= 0 && (dconst_ || dwork_ || dcoef_ || dbig_)) (void)hipSetDevice(device_);
-  Pool().Give(dconst_, const_cap_);
-  Pool().Give(dwork_, work_cap_);
-  if (dcoef_ && !coef_owner_) Pool().Give(dcoef_, coef_cap_);
-  if (dbig_ && !big_owner_) Pool().Give(dbig_, big_cap_);
+  if (status_event_) (void)hipEventDestroy((hipEvent_t)status_event_);
+  if (status_pinned_) (void)hipHostFree(status_pinned_);
+  Pool().Give(dconst_, const_cap_, device_);
+  Pool().Give(dwork_, work_cap_, device_);
+  if (dcoef_ && !coef_owner_ && !coef_is_ext_) Pool().Give(dcoef_, coef_cap_, device_);
+  if (dbig_ && !big_owner_ && !big_is_ext_) Pool().Give(dbig_, big_cap_, device_);
   if (big_owner_) big_owner_->big_sharers_--;
   if (dframes_) (void)hipFree(dframes_);
   if (dpasses_) (void)hipFree(dpasses_);
   if (dlocal_) (void)hipFree(dlocal_);
+  if (device_ >= 0 && cur >= 0 && cur != device_) (void)hipSetDevice(cur);
 }
 
 // The coefficient and pixel planes are only touched by the "rest" half of a decode (HF decode ... write), which a caller
@@ -397,7 +412,8 @@ void Batch::ShareBigArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareBigArena after Prepare", false);
   if (big_owner_ == owner) return;
   if (big_owner_) { big_owner_->big_sharers_--; dbig_ = nullptr; big_cap_ = 0; }       // (the pointer aliased the old owner's planes: not ours to free)
-  if (dbig_) { Pool().Give(dbig_, big_cap_); dbig_ = nullptr; big_cap_ = 0; }
+  if (dbig_ && !big_is_ext_) Pool().Give(dbig_, big_cap_, device_);
+  dbig_ = nullptr; big_cap_ = 0; big_is_ext_ = false;
   big_owner_ = owner;
   if (owner) owner->big_sharers_++;
 }
@@ -408,17 +424,59 @@ void Batch::ShareCoefArena(Batch* owner) {
   if (prepared_) throw ParseError("ShareCoefArena after Prepare", false);
   if (coef_owner_ == owner) return;
   if (coef_owner_) { dcoef_ = nullptr; coef_cap_ = 0; coef_laid_out_ = 0; }            // (aliased the old owner's planes: not ours to free)
-  if (dcoef_) { Pool().Give(dcoef_, coef_cap_); dcoef_ = nullptr; coef_cap_ = 0; }
+  if (dcoef_ && !coef_is_ext_) Pool().Give(dcoef_, coef_cap_, device_);
+  dcoef_ = nullptr; coef_cap_ = 0; coef_is_ext_ = false;
   coef_owner_ = owner;
+}
+
+void Batch::UseSharedPlanes(SharedPlanes* big, SharedPlanes* coef) {
+  if (big_owner_ || coef_owner_) throw ParseError("UseSharedPlanes: the batch shares another batch's arenas already", false);
+  ext_big_ = big; ext_coef_ = coef;
+  prepared_ = false;
+}
+
+// ---- stream-ordered completion (pipelined callers): the status words travel to pinned memory behind the decode, an event says when
+void Batch::EnqueueStatusReadback(void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  const size_t n = images_.size();
+  if (!status_pinned_ || status_pinned_n_ < 2 * n) {
+    if (status_pinned_) (void)hipHostFree(status_pinned_);
+    status_pinned_ = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&status_pinned_, std::max<size_t>(2 * n, 2) * 4));
+    status_pinned_n_ = std::max<size_t>(2 * n, 2);
+  }
+  if (!status_event_) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); status_event_ = ev; }
+  if (n) {
+    HIP_CHECK(hipMemcpyAsync(status_pinned_, dwork_ + status_off_, n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(status_pinned_ + n, dwork_ + hfw_off_, n * 4, hipMemcpyDeviceToHost, stream));
+  }
+  HIP_CHECK(hipEventRecord((hipEvent_t)status_event_, stream));
+  status_pending_ = true;
+  if (lf_batch_) lf_batch_->EnqueueStatusReadback(stream_v);
+}
+void Batch::HarvestStatus(vec<uint32_t>* per_unit) {
+  const size_t n = images_.size();
+  per_unit->assign(n, 0);
+  if (!status_pending_) throw ParseError("HarvestStatus without EnqueueStatusReadback", false);
+  HIP_CHECK(hipEventSynchronize((hipEvent_t)status_event_));
+  status_pending_ = false;
+  bool any = false;
+  for (size_t i = 0; i < n; i++) { (*per_unit)[i] = status_pinned_[i]; any |= status_pinned_[i] != 0; }
+  if (any_vardct_ && decodes_since_finish_ > 0) {
+    for (size_t i = 0; i < n; i++) hf_written_[i] = status_pinned_[n + i] / decodes_since_finish_;
+    decodes_since_finish_ = 0;
+  }
+  if (lf_batch_) { vec<uint32_t> lf; if (lf_batch_->status_pending_) { lf_batch_->HarvestStatus(&lf); for (uint32_t v : lf) if (v) for (auto& s : *per_unit) s |= v; } }
+  (void)any;    // (failed frames: ZeroFailedCoefficients has put zeros back on the device, the planes stay clean for the next user)
 }
 
 // Makes *ptr a device allocation of at least `bytes` (kept if it already is; grown with 1/8 of slack otherwise; taken from the arena pool when it has a block of
 // that size).  Returns true if the memory is new (contents undefined).
 bool Batch::DevReserve(void** ptr, size_t* cap, size_t bytes) {
   if (*ptr && *cap >= bytes) return false;
-  if (*ptr) { Pool().Give(*ptr, *cap); *ptr = nullptr; *cap = 0; }
+  if (*ptr) { Pool().Give(*ptr, *cap, device_); *ptr = nullptr; *cap = 0; }
   const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
-  if (void* p = Pool().Take(std::max<size_t>(bytes, 256), cap)) { *ptr = p; return true; }
+  if (void* p = Pool().Take(std::max<size_t>(bytes, 256), cap, device_)) { *ptr = p; return true; }
   if (hipMalloc(ptr, want) != hipSuccess) {
     (void)hipGetLastError();
     Pool().Trim();
@@ -448,6 +506,21 @@ void Batch::Reset() {
 // image threw.
 int Batch::AddImages(const uint8_t* const* datas, const size_t* sizes, int n, int threads) {
   if (n <= 0) return (int)pub_.size();
+  vec<int> index;
+  std::vector<std::string> errors;
+  return AddImagesImpl(datas, sizes, n, threads, /*tolerant=*/false, &index, &errors);
+}
+
+// The pipelined form: an image that does not parse (truncated, damaged headers, a feature the device path does not take) is left out instead of failing the call —
+// (*index)[i] = its index in the batch or -1, (*errors)[i] = what it threw ("" if it parsed).
+void Batch::AddImagesTolerant(const uint8_t* const* datas, const size_t* sizes, int n, int threads, vec<int>* index, std::vector<std::string>* errors) {
+  AddImagesImpl(datas, sizes, n, threads, /*tolerant=*/true, index, errors);
+}
+
+int Batch::AddImagesImpl(const uint8_t* const* datas, const size_t* sizes, int n, int threads, bool tolerant, vec<int>* index, std::vector<std::string>* errs) {
+  index->assign((size_t)std::max(n, 0), -1);
+  errs->assign((size_t)std::max(n, 0), std::string());
+  if (n <= 0) return (int)pub_.size();
   vec<ParsedImage> parsed((size_t)n);
   vec<std::exception_ptr> errors((size_t)n);
   const int nt = std::max(1, std::min(threads, n));
@@ -468,9 +541,14 @@ int Batch::AddImages(const uint8_t* const* datas, const size_t* sizes, int n, in
     for (auto& t : pool) t.join();
   }
   const int first = (int)pub_.size();
+  if (!tolerant) for (int i = 0; i < n; i++) if (errors[i]) std::rethrow_exception(errors[i]);
   for (int i = 0; i < n; i++) {
-    if (errors[i]) std::rethrow_exception(errors[i]);
-    Append(std::move(parsed[i]));
+    if (errors[i]) {
+      try { std::rethrow_exception(errors[i]); } catch (const std::exception& e) { (*errs)[i] = e.what(); } catch (...) { (*errs)[i] = "unknown error"; }
+      if ((*errs)[i].empty()) (*errs)[i] = "parse error";
+      continue;
+    }
+    (*index)[i] = Append(std::move(parsed[i]));
   }
   return first;
 }
@@ -803,6 +881,8 @@ void Batch::Prepare(void* stream_v) {
   clear_pending_ = false;
   if (coef_owner_) dcoef_ = nullptr;
   if (big_owner_) dbig_ = nullptr;
+  if (big_is_ext_) { dbig_ = nullptr; big_cap_ = 0; big_is_ext_ = false; }          // (pointers into the pipeline's planes: decided anew below)
+  if (coef_is_ext_) { dcoef_ = nullptr; coef_cap_ = 0; coef_laid_out_ = 0; coef_is_ext_ = false; }
   const int n = (int)images_.size();
   // JXL_HIP_TIME_PREPARE=1: host milliseconds of the phases of this function on stderr
   const bool time_phases = getenv("JXL_HIP_TIME_PREPARE") != nullptr;
@@ -1060,9 +1140,14 @@ void Batch::Prepare(void* stream_v) {
   }
   big_size_ = Align(wbig);
   has_plane_b_ = need_plane_b;
+  bool plain_planes = n > 0;      // plain VarDCT frames overwrite every sample of the pixel planes they read: they can take planes that hold another decode's leftovers
+  for (int i = 0; i < n; i++) { const ImageEntry& e = *images_[i]; if (e.plan.modular || e.complex || e.plan.upsampling > 1) plain_planes = false; }
   if (big_owner_) {
     if (!big_owner_->dbig_ || big_owner_->big_cap_ < big_size_) throw ParseError("ShareBigArena: the owner's buffers are missing or smaller than this batch needs", false);
     dbig_ = big_owner_->dbig_;
+  } else if (ext_big_ && ext_big_->p && ext_big_->cap >= big_size_ && plain_planes) {
+    if (dbig_) { Pool().Give(dbig_, big_cap_, device_); dbig_ = nullptr; big_cap_ = 0; }
+    dbig_ = ext_big_->p; big_is_ext_ = true;
   } else if (DevReserve((void**)&dbig_, &big_cap_, std::max<size_t>(big_size_, 256)) || big_sharers_ == 0) {
     // (planes other batches share are not cleared again when this object is refilled: their decodes may be using them — every sharer,
     // like a refilled owner, then starts from what the decode before left, which plain frames overwrite completely)
@@ -1071,6 +1156,9 @@ void Batch::Prepare(void* stream_v) {
   if (coef_owner_) {
     if (!coef_owner_->dcoef_ || coef_owner_->coef_cap_ < coeff_bytes_) throw ParseError("ShareCoefArena: the owner's planes are missing or smaller than this batch needs", false);
     dcoef_ = coef_owner_->dcoef_;                      // (whether they are clean is the owner's knowledge: CoefDirty())
+  } else if (ext_coef_ && ext_coef_->p && ext_coef_->cap >= coeff_bytes_ && any_vardct_) {
+    if (dcoef_) { Pool().Give(dcoef_, coef_cap_, device_); dcoef_ = nullptr; coef_cap_ = 0; }
+    dcoef_ = ext_coef_->p; coef_is_ext_ = true;        // (clean or not: ext_coef_->dirty / clean_extent, kept by the decodes that used the set before)
   } else {
     const bool fresh = DevReserve((void**)&dcoef_, &coef_cap_, std::max<size_t>(coeff_bytes_, 256));
     if (fresh) coef_clean_extent_ = 0;                 // (a new allocation: nothing of it is known to be zero)
@@ -1974,9 +2062,9 @@ void Batch::EnqueuePostOps(void* stream) { for (auto& op : post_ops_) op(stream)
 void Batch::ClearCoefficientsBeforeHf(void* stream_v) {
   // The planes are known to be zero over [0, clean extent) of the owner: hipMalloc'd memory is not cleared, and a decode only puts zeros
   // back inside its own layout — a sharer (or a refill) whose layout reaches further than anything cleared so far needs the dense clear too.
-  size_t& extent = coef_owner_ ? coef_owner_->coef_clean_extent_ : coef_clean_extent_;
+  size_t& extent = coef_is_ext_ ? ext_coef_->clean_extent : coef_owner_ ? coef_owner_->coef_clean_extent_ : coef_clean_extent_;
   if (CoefDirty() || coeff_bytes_ > extent) {
-    const size_t cap = coef_owner_ ? coef_owner_->coef_cap_ : coef_cap_;
+    const size_t cap = coef_is_ext_ ? ext_coef_->cap : coef_owner_ ? coef_owner_->coef_cap_ : coef_cap_;
     const size_t bytes = std::min(cap, std::max(extent, coeff_bytes_));
     HIP_CHECK(hipMemsetAsync(dcoef_, 0, bytes, (hipStream_t)stream_v));
     extent = bytes;
@@ -2089,6 +2177,7 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     DebugSync("HF decode", stream_v);
     if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
+    LaunchZeroFailedCoefficients(dframes_, n, stream_v);   // (frames that failed up to here are skipped by the IDCT kernels: their planes are zeroed now)
     CheckLaunches("HF stage / Modular sub-streams");
     rec(3);
   }

@@ -74,6 +74,10 @@ class HostStage {
   uint8_t* p_ = nullptr; size_t n_ = 0, cap_ = 0; bool pinned_ = false;
 };
 
+// Coefficient / pixel planes that belong to somebody else (a Pipeline): a batch whose layout fits uses them instead of arenas of its own (Batch::UseSharedPlanes).
+// `dirty` / `clean_extent` are the coefficient planes' bookkeeping (see Batch::ClearCoefficientsBeforeHf); the owner serialises the decodes that share one set.
+struct SharedPlanes { uint8_t* p = nullptr; size_t cap = 0; bool dirty = true; size_t clean_extent = 0; };
+
 struct StageTimes { float lf_ms = 0, lfpost_ms = 0, hf_ms = 0, idct_ms = 0, filter_ms = 0, out_ms = 0, total_ms = 0; };
 
 class Batch {
@@ -84,6 +88,8 @@ class Batch {
   int AddImage(const uint8_t* data, size_t size);
   // The same for n images, parsed on `threads` host threads and appended in order; returns the index of the first.
   int AddImages(const uint8_t* const* datas, const size_t* sizes, int n, int threads);
+  // Same, but an image that does not parse is left out instead of failing the call: (*index)[i] = its index in the batch or -1, (*errors)[i] = what it threw.
+  void AddImagesTolerant(const uint8_t* const* datas, const size_t* sizes, int n, int threads, vec<int>* index, std::vector<std::string>* errors);
   // Forgets the images, keeps device arenas / staging buffer / buffer sharing: the object can be filled and prepared again.
   void Reset();
   size_t size() const { return pub_.size(); }
@@ -132,9 +138,23 @@ class Batch {
   void StageBytes(uint64_t out[6]) const;
   LaunchCfg cfg;
   size_t const_bytes() const { return const_size_; }
-  size_t work_bytes() const { return work_size_ + (coef_owner_ ? 0 : coeff_bytes_) + (big_owner_ ? 0 : big_size_); }
+  size_t work_bytes() const { return work_size_ + (coef_owner_ || coef_is_ext_ ? 0 : coeff_bytes_) + (big_owner_ || big_is_ext_ ? 0 : big_size_); }
   void ShareBigArena(Batch* owner);
   void ShareCoefArena(Batch* owner);
+  // Planes owned by the caller (pipeline.cc): used by the next Prepare when they are large enough for the batch's layout, otherwise the batch falls back to arenas of
+  // its own (big_bytes_wanted / coef_bytes_wanted say what it would have taken).  nullptr = back to own arenas.  The caller orders the decodes that share a set.
+  void UseSharedPlanes(SharedPlanes* big, SharedPlanes* coef);
+  size_t big_bytes_wanted() const { return big_size_; }
+  size_t coef_bytes_wanted() const { return coeff_bytes_; }
+  bool uses_shared_big() const { return big_is_ext_; }
+  bool uses_shared_coef() const { return coef_is_ext_; }
+  // Stream-ordered form of Finish for pipelined callers: EnqueueStatusReadback copies the per-unit status words to pinned host memory behind whatever `stream` holds
+  // and records an event; HarvestStatus waits for that event only and returns the words (0 = decoded).  Nothing touches the legacy NULL stream.
+  void EnqueueStatusReadback(void* stream);
+  void HarvestStatus(vec<uint32_t>* per_unit);
+  int first_unit_of(int i) const { return pub_[i].first_unit; }
+  int num_units_of(int i) const { return pub_[i].num_units; }
+  int device() const { return device_; }
   int64_t Info(const std::string& name) const;
   size_t DebugRead(int i, const std::string& name, int c, void* dst, size_t cap, void* stream);
   uint64_t total_pixels() const;
@@ -170,8 +190,9 @@ class Batch {
   HostStage hconst_;
   struct ParsedImage { vec<std::unique_ptr<ImageEntry>> units; bool complex = false; };
   static void ParseImage(const uint8_t* data, size_t size, ParsedImage* out);
+  int AddImagesImpl(const uint8_t* const* datas, const size_t* sizes, int n, int threads, bool tolerant, vec<int>* index, std::vector<std::string>* errors);
   int Append(ParsedImage&& im);
-  static bool DevReserve(void** ptr, size_t* cap, size_t bytes);
+  bool DevReserve(void** ptr, size_t* cap, size_t bytes);
   size_t const_cap_ = 0, work_cap_ = 0, big_cap_ = 0, coef_cap_ = 0, coef_laid_out_ = 0, frames_cap_ = 0, passes_cap_ = 0, local_cap_ = 0;
   uint8_t* dconst_ = nullptr; size_t const_size_ = 0;
   uint8_t* dwork_ = nullptr; size_t work_size_ = 0;
@@ -186,7 +207,9 @@ class Batch {
   bool clear_pending_ = false, coef_dirty_ = true;
   Batch* coef_owner_ = nullptr;
   size_t coef_clean_extent_ = 0;   // bytes of this object's own coefficient planes known to be zero after a completed decode
-  bool& CoefDirty() { return coef_owner_ ? coef_owner_->coef_dirty_ : coef_dirty_; }
+  SharedPlanes* ext_big_ = nullptr; SharedPlanes* ext_coef_ = nullptr; bool big_is_ext_ = false, coef_is_ext_ = false;
+  uint32_t* status_pinned_ = nullptr; size_t status_pinned_n_ = 0; void* status_event_ = nullptr; bool status_pending_ = false;
+  bool& CoefDirty() { return coef_is_ext_ ? ext_coef_->dirty : coef_owner_ ? coef_owner_->coef_dirty_ : coef_dirty_; }
   void ClearCoefficientsBeforeHf(void* stream);
   void ClearCoefficientsAfterDecode(void* stream);
   bool has_plane_b_ = false;
@@ -233,5 +256,11 @@ class Batch {
   vec<vec<void*>> timed_events_;
   size_t timed_rest_cursor_ = 0;       // per frame: work-arena offsets of planes (incl. spare)
 };
+
+// device arena pool (decoder.cc): blocks a batch or a pipeline lets go of are kept for the next one that asks for that much memory on that device
+size_t DeviceArenaPoolTrim();      // gives every pooled block back to the runtime; returns the bytes released
+size_t DeviceArenaPoolHeld();
+void* DeviceArenaTake(size_t want, size_t* cap, int device);
+void DeviceArenaGive(void* p, size_t cap, int device);
 
 }  // namespace jxlhip

@@ -2,6 +2,7 @@
 // Event state machine as exercised by jpegxl-rs/src/decode.rs:207-325 and jpegxl-sys/src/lib.rs:85-171.
 #include "../../include/jxl_hip.h"
 #include "decoder.h"
+#include "pipeline.h"
 #include "jpeg_recon.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
@@ -56,7 +57,20 @@ struct JxlDecoderStruct {
   bool frame_done;     // JXL_DEC_FULL_IMAGE of frames[frame_cursor] has been returned: its header stays readable until the next JxlDecoderProcessInput moves on
   Batch* batch;
   int device;
+  void* stream;        // the decoder's own non-blocking HIP stream (SURVEY 8b "Threading"): created with the first decode, kept over Reset, destroyed with the decoder
 };
+
+// One-shot decodes of plain images go to the device's shared pipeline (scheduler.cc): concurrent decoders coalesce into jobs.  JXL_HIP_SCHEDULER=0: every decoder
+// runs its own batch of one on its own stream.
+static bool SchedulerEnabled() { static const bool on = [] { const char* e = getenv("JXL_HIP_SCHEDULER"); return !(e && e[0] == '0'); }(); return on; }
+static void* DecoderStream(JxlDecoder* d) {
+  if (!d->stream) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); throw ParseError("cannot create a HIP stream for the decoder", false); }
+    d->stream = s;
+  }
+  return d->stream;
+}
 
 static int DefaultDevice() {
   const char* e = getenv("JXL_HIP_DEVICE");
@@ -124,7 +138,7 @@ JxlDecoder* JxlDecoderCreate(const JxlMemoryManager* mm) {
   mem = has ? copy.alloc(copy.opaque, sizeof(JxlDecoderStruct)) : malloc(sizeof(JxlDecoderStruct));
   if (!mem) return nullptr;
   JxlDecoder* d = new (mem) JxlDecoderStruct();
-  d->mm = copy; d->has_mm = has; d->batch = nullptr; d->device = DefaultDevice();
+  d->mm = copy; d->has_mm = has; d->batch = nullptr; d->device = DefaultDevice(); d->stream = nullptr;
   d->hooks.opaque = copy.opaque; d->hooks.alloc = copy.alloc; d->hooks.free = copy.free;
   ClearState(d);
   return d;
@@ -133,6 +147,7 @@ void JxlDecoderReset(JxlDecoder* d) { if (d) ClearState(d); }
 void JxlDecoderDestroy(JxlDecoder* d) {
   if (!d) return;
   ClearState(d);
+  if (d->stream) { (void)hipStreamSynchronize((hipStream_t)d->stream); (void)hipStreamDestroy((hipStream_t)d->stream); d->stream = nullptr; }
   JxlMemoryManager mm = d->mm; bool has = d->has_mm;
   d->~JxlDecoderStruct();
   if (has) mm.free(mm.opaque, d); else free(d);
@@ -591,6 +606,10 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
   // caller may release its buffer — JxlDecoderReleaseInput — and go on)
   if (!d->input_set && d->stage == JxlDecoderStruct::kInit) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
   try {
+    if (d->stage == JxlDecoderStruct::kHeaders || d->stage == JxlDecoderStruct::kFrame) {
+      // (the current device is per thread, and a decoder may be called from another thread than last time)
+      if (hipSetDevice(d->device) != hipSuccess) { (void)hipGetLastError(); SetLastError("no usable HIP device"); return JXL_DEC_ERROR; }
+    }
     if (d->stage == JxlDecoderStruct::kInit) {
       JxlSignature sig = JxlSignatureCheck(d->input, d->input_size);
       if (sig == JXL_SIG_INVALID) { SetLastError("invalid signature"); return JXL_DEC_ERROR; }
@@ -615,7 +634,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         if (!d->preview_set) return JXL_DEC_NEED_PREVIEW_OUT_BUFFER;
         OutputSpec o;
         if (!PreviewSpec(d, &d->preview_format, &o)) return JXL_DEC_ERROR;
-        d->batch->DecodePreview(0, o, d->preview_buffer, d->preview_size, nullptr);      // ══► the HIP hot path, on the preview frame
+        d->batch->DecodePreview(0, o, d->preview_buffer, d->preview_size, DecoderStream(d));      // ══► the HIP hot path, on the preview frame
         d->events_emitted |= JXL_DEC_PREVIEW_IMAGE;
         return JXL_DEC_PREVIEW_IMAGE;
       }
@@ -642,7 +661,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
           try {
             OutputSpec o; o.type = 0; o.num_channels = 3;
             d->batch->SetOutput(0, o);
-            d->jpeg_bytes = d->batch->ReconstructJpeg(0, nullptr);
+            d->jpeg_bytes = d->batch->ReconstructJpeg(0, DecoderStream(d));
           } catch (const ParseError& e) {
             if (!e.unsupported) throw;
             SetLastError(std::string(e.what()) + " (decoding to pixels instead)");
@@ -679,6 +698,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       const bool same_format = d->anim_cached && !memcmp(&d->anim_format, &d->out_format, sizeof(JxlPixelFormat)) && d->anim_keep_orientation == d->keep_orientation &&
                                d->anim_unpremul == d->unpremul_alpha && d->anim_spot == d->render_spotcolors && d->anim_int_bits == d->out_int_bits;
       int anim_slot = -1;
+      bool scheduled = false;       // the pixels are in the caller's buffer already (shared pipeline)
       if (o.upto_frame >= 0 || (d->coalescing && d->frames.size() > 1)) {
         if (!d->anim_cached && !d->anim_cache_failed && d->ec_buffers.empty()) {
           try {
@@ -686,9 +706,9 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
             d->batch->SetOutputAllFrames(0, oa, d->frames);
             if (d->batch->image(0).out_size * d->frames.size() > ((size_t)2 << 30)) throw ParseError("unsupported: too many canvases to keep", true);
             if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
-            d->batch->Prepare(nullptr);
-            d->batch->Run(nullptr);       // ══► the HIP hot path, once for the whole animation
-            d->batch->Finish(nullptr);
+            d->batch->Prepare(DecoderStream(d));
+            d->batch->Run(DecoderStream(d));       // ══► the HIP hot path, once for the whole animation
+            d->batch->Finish(DecoderStream(d));
             d->anim_cached = true; d->anim_format = d->out_format; d->anim_keep_orientation = d->keep_orientation; d->anim_unpremul = d->unpremul_alpha; d->anim_spot = d->render_spotcolors; d->anim_int_bits = d->out_int_bits;
             anim_slot = (int)d->frame_cursor;
           } catch (const ParseError& e) {
@@ -701,13 +721,24 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         d->anim_cached = false;           // (the batch is prepared for something else from here on)
         d->batch->SetOutput(0, o);
         if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
-        d->batch->Prepare(nullptr);
-        d->batch->Run(nullptr);       // ══► the HIP hot path
-        d->batch->Finish(nullptr);
+        // A plain one-shot decode into the caller's buffer — what jpegxl-rs' decode_with does (decode.rs:461-484) — rides in a job of the device's shared pipeline:
+        // decoders that run on other threads at this moment share the job (scheduler.cc).  Everything else runs as a batch of one on the decoder's own stream.
+        const bool via_scheduler = SchedulerEnabled() && !d->has_mm && d->input_set && d->coalescing && d->frames.size() == 1 && o.only_frame < 0 && o.upto_frame < 0 &&
+                                   !d->out_callback && !d->mt_run && d->ec_buffers.empty() && d->out_buffer;
+        if (via_scheduler) {
+          std::string err;
+          if (SchedulerDecode(d->device, d->input, d->input_size, o, d->out_buffer, d->batch->image(0).out_size, &err)) throw ParseError(err, err.rfind("unsupported", 0) == 0);   // ══► the HIP hot path
+          scheduled = true;
+        } else {
+          d->batch->Prepare(DecoderStream(d));
+          d->batch->Run(DecoderStream(d));       // ══► the HIP hot path
+          d->batch->Finish(DecoderStream(d));
+        }
       } else if (d->batch->image(0).out_size > d->out_size) { SetLastError("output buffer too small for this frame"); return JXL_DEC_ERROR; }
       auto copy_out = [&](void* dst, size_t size) {
-        if (anim_slot >= 0) d->batch->CopyOutputSlotToHost(0, anim_slot, dst, size, nullptr);
-        else d->batch->CopyOutputToHost(0, dst, size, nullptr);
+        if (scheduled) return;
+        if (anim_slot >= 0) d->batch->CopyOutputSlotToHost(0, anim_slot, dst, size, DecoderStream(d));
+        else d->batch->CopyOutputToHost(0, dst, size, DecoderStream(d));
       };
       if (d->out_callback || d->mt_run) {
         // callback output: the image is decoded as a whole on the device, then handed out row by row
@@ -735,9 +766,9 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
           oe.num_channels = grey ? 2 : 4; oe.align = 0; oe.device_ptr = nullptr; oe.alpha_from_extra = (int)eb.index; oe.int_bits = 0;
           oe.keep_orientation = o.keep_orientation; oe.unpremul_alpha = false; oe.render_spotcolors = o.render_spotcolors; oe.only_frame = o.only_frame; oe.upto_frame = o.upto_frame;
           d->batch->SetOutput(0, oe);
-          d->batch->Prepare(nullptr); d->batch->Run(nullptr); d->batch->Finish(nullptr);
+          d->batch->Prepare(DecoderStream(d)); d->batch->Run(DecoderStream(d)); d->batch->Finish(DecoderStream(d));
           vec<uint8_t> host(d->batch->image(0).out_size);
-          d->batch->CopyOutputToHost(0, host.data(), host.size(), nullptr);
+          d->batch->CopyOutputToHost(0, host.data(), host.size(), DecoderStream(d));
           uint32_t w = 0, h = 0;
           d->batch->OutputDims(0, d->batch->image(0).out, &w, &h);
           if (!d->keep_orientation && d->batch->image(0).ih.orientation > 4) std::swap(w, h);
@@ -860,6 +891,98 @@ int JxlHipBatchShareCoefficients(JxlHipBatch* h, JxlHipBatch* owner) {
 int JxlHipBatchShareBuffers(JxlHipBatch* h, JxlHipBatch* owner) {
   try { h->b->ShareBigArena(owner ? owner->b : nullptr); return 0; } catch (const std::exception& e) { SetLastError(e.what()); return 1; }
 }
+
+// ---- streaming pipeline (pipeline.h) -----------------------------------------------------------------------------------------
+struct JxlHipPipelineStruct { Pipeline* p; };
+
+JxlHipPipeline* JxlHipPipelineCreate(int device, const JxlHipPipelineOptions* o) {
+  try {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); SetLastError("no usable HIP device (no CPU fallback exists)"); return nullptr; }
+    PipelineOptions po;
+    if (o) {
+      auto pick = [](int32_t v, int def) { return v > 0 ? (int)v : def; };
+      po.in_flight = pick(o->jobs_in_flight, po.in_flight); po.lf_streams = pick(o->lf_streams, po.lf_streams); po.hf_streams = pick(o->hf_streams, po.hf_streams);
+      po.prepare_threads = pick(o->prepare_threads, po.prepare_threads); po.parse_threads = pick(o->parse_threads, po.parse_threads);
+      po.lane_stride_lf = pick(o->lane_stride_lf, po.lane_stride_lf); po.lane_stride_hf = pick(o->lane_stride_hf, po.lane_stride_hf);
+      po.wide_first = o->wide_first >= 0 ? o->wide_first : po.wide_first; po.small_job_frames = o->small_job_frames > 0 ? o->small_job_frames : 0;
+      po.timed = o->timed != 0;
+      po.reserve_frames = o->reserve_frames; po.reserve_width = o->reserve_width; po.reserve_height = o->reserve_height;
+    }
+    auto ok = [](int v) { return v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
+    if (!ok(po.lane_stride_lf) || !ok(po.lane_stride_hf)) { SetLastError("lane strides must be powers of two up to 64"); return nullptr; }
+    JxlHipPipeline* h = new JxlHipPipelineStruct();
+    try { h->p = new Pipeline(device, po); } catch (...) { delete h; throw; }
+    return h;
+  } catch (const std::exception& e) { SetLastError(e.what()); return nullptr; }
+}
+void JxlHipPipelineDestroy(JxlHipPipeline* h) { if (h) { delete h->p; delete h; } }
+int64_t JxlHipPipelineSubmit(JxlHipPipeline* h, const uint8_t* const* datas, const size_t* sizes, int n, const JxlPixelFormat* format, void* const* device_out, void* const* host_out,
+                             const size_t* out_capacity) {
+  try {
+    OutputSpec o;
+    if (!h || !FormatToSpec(format, &o)) { SetLastError("JxlHipPipelineSubmit: bad pixel format"); return -1; }
+    return h->p->Submit(datas, sizes, n, o, device_out, host_out, out_capacity);
+  } catch (const std::exception& e) { SetLastError(e.what()); return -1; }
+}
+JxlDecoderStatus JxlHipPipelineWait(JxlHipPipeline* h, int64_t ticket, int* image_status, int n, float* end_ms) {
+  try {
+    PipelineJobResult r;
+    h->p->Wait(ticket, &r);
+    bool all_ok = true;
+    std::string first;
+    for (size_t i = 0; i < r.status.size(); i++) {
+      if (image_status && (int)i < n) image_status[i] = r.status[i];
+      if (r.status[i] != 0) { all_ok = false; if (first.empty()) first = "image " + std::to_string(i) + ": " + r.error[i]; }
+    }
+    if (end_ms) *end_ms = r.end_ms;
+    if (!all_ok) SetLastError(first);
+    return all_ok ? JXL_DEC_SUCCESS : JXL_DEC_ERROR;
+  } catch (const std::exception& e) { SetLastError(e.what()); if (image_status) for (int i = 0; i < n; i++) image_status[i] = 1; return JXL_DEC_ERROR; }
+}
+JxlDecoderStatus JxlHipPipelineWaitAll(JxlHipPipeline* h) { BATCH_TRY(h->p->WaitAll()) }
+JxlDecoderStatus JxlHipPipelineResetClock(JxlHipPipeline* h) { BATCH_TRY(h->p->ResetClock()) }
+JxlDecoderStatus JxlHipPipelineCollectTimes(JxlHipPipeline* h, JxlHipStageTimes* t, int* runs) {
+  BATCH_TRY({ StageTimes st = h->p->CollectTimes(runs); t->lf_ms = st.lf_ms; t->lfpost_ms = st.lfpost_ms; t->hf_ms = st.hf_ms; t->idct_ms = st.idct_ms; t->filter_ms = st.filter_ms; t->out_ms = st.out_ms; t->total_ms = st.total_ms; })
+}
+void JxlHipPipelineStageBytes(JxlHipPipeline* h, uint64_t out[6]) { h->p->StageBytes(out); }
+int64_t JxlHipPipelineGetInfo(JxlHipPipeline* h, const char* name) {
+  try {
+    const std::string n(name ? name : "");
+    if (n == "prepare_us_total") return (int64_t)(h->p->prepare_seconds_total() * 1e6);
+    if (n == "prepared_jobs") return h->p->prepared_jobs();
+    return h->p->Info(name);
+  } catch (const std::exception& e) { SetLastError(e.what()); return -1; }
+}
+void* JxlHipHostAlloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); SetLastError("hipHostMalloc failed"); return nullptr; }
+  return p;
+}
+void JxlHipHostFree(void* p) { if (p) (void)hipHostFree(p); }
+size_t JxlHipArenaPoolTrim(void) { return DeviceArenaPoolTrim(); }
+size_t JxlHipArenaPoolHeld(void) { return DeviceArenaPoolHeld(); }
+void JxlHipSchedulerStats(int device, int64_t* jobs, int64_t* images) { SchedulerStats(device, jobs, images); }
+void JxlHipSchedulerShutdown(void) { SchedulerShutdown(); }
+JxlDecoderStatus JxlHipImageOutSize(const uint8_t* data, size_t size, const JxlPixelFormat* format, JxlBasicInfo* info, size_t* out_size) {
+  try {
+    OutputSpec o;
+    if (!FormatToSpec(format, &o)) { SetLastError("bad pixel format"); return JXL_DEC_ERROR; }
+    std::shared_ptr<ImageShared> sh(new ImageShared());
+    bool have_container = false, has_jbrd = false;
+    if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, nullptr)) return JXL_DEC_NEED_MORE_INPUT;
+    uint64_t bitpos = 0;
+    ParseImageHeader(sh->cs, &sh->ih, &bitpos);
+    sh->ih.have_container = have_container;
+    if (info) FillBasicInfo(sh->ih, info, false);
+    if (out_size) *out_size = Batch::OutputSize(sh->ih, o);
+    return JXL_DEC_SUCCESS;
+  } catch (const std::exception& e) { SetLastError(e.what()); return JXL_DEC_ERROR; }
+}
+
+// the pipelines keep ~15 HIP streams busy at once; the runtime maps streams onto 4 hardware queues by default and kernels of streams that share a queue serialise.
+// Set (unless the caller chose a value) before the HIP runtime reads it, i.e. when this library is loaded.
+__attribute__((constructor)) static void JxlHipDefaultHwQueues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 int JxlHipDebugWriteJpegSampled(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const uint32_t* sampling, const int16_t* coefficients,
                                 const int32_t* quant_tables, uint8_t* out, size_t* out_size) {

@@ -185,6 +185,7 @@ struct LfSimtPlan {
 void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, const LaunchCfg& cfg, void* stream, const LfSimtPlan* simt = nullptr);
 void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, int max_groups, void* stream);
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream);
+void LaunchZeroFailedCoefficients(const FrameDev* frames, int nframes, void* stream);   // behind the HF stage: a failed frame's coefficient planes go back to zero
 void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw, int max_bh, const LaunchCfg& cfg, void* stream);
 struct FilterPlan {
   bool any_upsampled = false;    // some frame needs UpsampleKernel before the write stage

@@ -2455,7 +2455,11 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
   if (sync && threadIdx.x == 0 && atomicAdd(sync, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(sync, 0u); __threadfence(); atomicMax(sync + 1, epoch); }
   const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || FrameFailed(f)) return;
+  // (the status word is read once per workgroup — another workgroup of the launch may set it at any time, and wavefronts that disagreed about it
+  // would part ways in front of the barriers below; the 8 spare bytes behind the 39 order pointers carry it)
+  if (threadIdx.x == 0) StS<uint32_t>(kSimtOrdOff + 312, __hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  __syncthreads();
+  if (f.is_modular || LdS<uint32_t>(kSimtOrdOff + 312) != 0) return;
   // prefix-coded frames: HfDecodeKernel, launched beside this one — unless they are progressive or chroma-subsampled: those are walked here (the
   // general instantiation), their symbols read bit by bit through the canonical-code tables in global memory (jxl_dev.h ReadSymbol)
   bool any_pfx = f.ac_code.use_prefix != 0 || f.ac_code.lz77 != 0;     // (prefix codes or LZ77: the general symbol reader)
@@ -4470,9 +4474,15 @@ __global__ void ModularOutputKernel(const FrameDev* __restrict__ frames, int fid
 const char* const kKernelNames[] = {"LfDecodeKernel", "LfDequantKernel", "LfSmoothKernel", "LlfSigmaKernel", "HfDecodeKernel", "IdctKernel",
                                     "GaborishKernel", "EpfKernel", "OutputKernel", "ModularGlobalFastKernel", "ModularGroupFastKernel", nullptr};
 
-static bool g_tables_ready = false;
+// (per device, once; decoders of several host threads may get here at the same time)
+static std::mutex g_tables_mu;
+static bool g_tables_ready[64] = {false};
 void InitDeviceTables(void* stream) {
-  if (g_tables_ready) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(g_tables_mu);
+  if (g_tables_ready[dev]) return;
   static float wc[9][128];
   static float rs[6][32];
   for (int l = 1; l <= 8; l++) { const int N = 1 << l; for (int i = 0; i < N / 2; i++) wc[l][i] = (float)(1.0 / (2.0 * cos((i + 0.5) * M_PI / N))); }
@@ -4480,7 +4490,7 @@ void InitDeviceTables(void* stream) {
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_wc), wc, sizeof(wc), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
   (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_resample), rs, sizeof(rs), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
   (void)hipStreamSynchronize((hipStream_t)stream);
-  g_tables_ready = true;
+  g_tables_ready[dev] = true;
 }
 
 static inline int DivUp(int a, int b) { return (a + b - 1) / b; }
@@ -4610,6 +4620,21 @@ void LaunchLfPost(const FrameDev* frames, int nframes, int max_bw, int max_bh, i
   hipLaunchKernelGGL(LfSmoothKernel, grid, block, 0, (hipStream_t)stream, frames);
   hipLaunchKernelGGL(LlfSigmaKernel, grid, block, 0, (hipStream_t)stream, frames);
   hipLaunchKernelGGL(LlfKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
+}
+// Every IDCT kernel skips a frame whose status word is set, so nobody puts zeros back where that frame's HF stage wrote before it failed: this kernel does, right
+// behind the HF stage — the coefficient planes are clean again for whichever decode uses them next (pipelines rotate a few sets between many batches).
+__global__ __launch_bounds__(256) void ZeroFailedCoefKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular || !FrameFailed(f)) return;
+  const size_t n16 = (size_t)f.num_groups * 65536 / 4;
+  for (int c = 0; c < 3; c++) {
+    int4* p = reinterpret_cast<int4*>(f.coeff[c]);
+    if (!p) continue;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_int4(0, 0, 0, 0);
+  }
+}
+void LaunchZeroFailedCoefficients(const FrameDev* frames, int nframes, void* stream) {
+  if (nframes > 0) hipLaunchKernelGGL(ZeroFailedCoefKernel, dim3(32, nframes), dim3(256), 0, (hipStream_t)stream, frames);
 }
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
   if (cfg.lane_stride_hf == 1) {   // SIMT: one group stream per lane

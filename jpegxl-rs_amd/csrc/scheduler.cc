@@ -1,0 +1,231 @@
+// jxl-hip: one shared decode pipeline per device behind the libjxl-compatible API (pipeline.h: SchedulerDecode).
+//
+// jpegxl-rs callers decode one image per JxlDecoderProcessInput call, and many of them run at once on many threads — decoders are Send
+// (jpegxl-rs/src/decode.rs:523-532).  One image at a time leaves the GPU idle: a 4K frame is four serial LF chains and 135 group streams.  The
+// scheduler turns whatever requests are waiting into one job of the device's pipeline (requests that arrive while a job is being prepared ride in
+// the next one), jobs overlap in the pipeline, decoded pixels come back through pinned staging buffers and every caller copies its own image
+// into its own buffer.  A single caller sees the latency of a one-image job on streams of the pipeline's own (never the NULL stream).
+#include "pipeline.h"
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+namespace jxlhip {
+namespace {
+
+struct Request {
+  const uint8_t* data; size_t size; OutputSpec spec; void* dst; size_t dst_size;
+  void* staging = nullptr; size_t staging_cap = 0;
+  int status = -1; std::string error;
+  bool done = false, retried = false;
+  std::condition_variable cv;
+};
+
+bool SameSpec(const OutputSpec& a, const OutputSpec& b) {
+  return a.num_channels == b.num_channels && a.type == b.type && a.big_endian == b.big_endian && a.align == b.align && a.keep_orientation == b.keep_orientation &&
+         a.unpremul_alpha == b.unpremul_alpha && a.upto_frame == b.upto_frame && a.only_frame == b.only_frame && a.alpha_from_extra == b.alpha_from_extra &&
+         a.int_bits == b.int_bits && a.render_spotcolors == b.render_spotcolors;
+}
+
+int EnvInt(const char* name, int def) { const char* e = getenv(name); return e && *e ? atoi(e) : def; }
+
+class DeviceScheduler {
+ public:
+  explicit DeviceScheduler(int device) : device_(device) {
+    PipelineOptions o;
+    // latency mode: a handful of small jobs in flight; small jobs take the one-wavefront-per-stream LF kernel (a third of the SIMT kernel's latency on a GPU that has room)
+    o.in_flight = EnvInt("JXL_HIP_SCHED_IN_FLIGHT", 6);
+    o.lf_streams = EnvInt("JXL_HIP_SCHED_LF_STREAMS", 6);
+    o.hf_streams = 1;
+    o.prepare_threads = EnvInt("JXL_HIP_SCHED_PREPARE_THREADS", 3);
+    o.parse_threads = EnvInt("JXL_HIP_SCHED_PARSE_THREADS", 8);
+    o.wide_first = 0;
+    o.small_job_frames = EnvInt("JXL_HIP_SCHED_WIDE_BELOW", 48);
+    o.reserve_frames = EnvInt("JXL_HIP_SCHED_RESERVE_FRAMES", 16); o.reserve_width = 3840; o.reserve_height = 2160;
+    max_job_ = std::max(1, EnvInt("JXL_HIP_SCHED_MAX_JOB", 64));
+    coalesce_us_ = std::max(0, EnvInt("JXL_HIP_COALESCE_US", 150));
+    pipe_.reset(new Pipeline(device, o));
+    collector_ = std::thread([this] { CollectorLoop(); });
+    completer_ = std::thread([this] { CompleterLoop(); });
+  }
+  ~DeviceScheduler() {
+    { std::lock_guard<std::mutex> lock(mu_); shutdown_ = true; }
+    cv_.notify_all(); done_cv_.notify_all();
+    if (collector_.joinable()) collector_.join();
+    if (completer_.joinable()) completer_.join();
+    pipe_.reset();
+    (void)hipSetDevice(device_);
+    for (auto& b : free_staging_) (void)hipHostFree(b.first);
+  }
+
+  int Decode(const uint8_t* data, size_t size, const OutputSpec& spec, void* dst, size_t dst_size, std::string* error) {
+    Request r;
+    r.data = data; r.size = size; r.spec = spec; r.spec.device_ptr = nullptr; r.dst = dst; r.dst_size = dst_size;
+    {
+      std::unique_lock<std::mutex> lock(mu_);
+      if (shutdown_) { if (error) *error = "scheduler shut down"; return 1; }
+      pending_.push_back(&r);
+      cv_.notify_all();
+      r.cv.wait(lock, [&] { return r.done; });
+    }
+    int rc = r.status == 0 ? 0 : 1;
+    if (rc == 0 && r.staging) memcpy(dst, r.staging, dst_size);     // every caller copies its own pixels: T threads, T copies at once
+    if (r.staging) { std::lock_guard<std::mutex> lock(mu_); ReleaseStaging(r.staging, r.staging_cap); }
+    if (rc && error) *error = r.error.empty() ? "decode failed" : r.error;
+    return rc;
+  }
+  void Stats(int64_t* jobs, int64_t* images) { std::lock_guard<std::mutex> lock(mu_); if (jobs) *jobs = jobs_; if (images) *images = images_; }
+
+ private:
+  struct InFlight { int64_t ticket; std::vector<Request*> reqs; };
+
+  // pinned staging buffers, recycled by capacity (mu_ held)
+  void* TakeStaging(size_t bytes, size_t* cap) {
+    int best = -1;
+    for (size_t i = 0; i < free_staging_.size(); i++)
+      if (free_staging_[i].second >= bytes && free_staging_[i].second <= 2 * bytes + (1 << 20) && (best < 0 || free_staging_[i].second < free_staging_[(size_t)best].second)) best = (int)i;
+    if (best >= 0) { void* p = free_staging_[(size_t)best].first; *cap = free_staging_[(size_t)best].second; staging_held_ -= *cap; free_staging_.erase(free_staging_.begin() + best); return p; }
+    return nullptr;
+  }
+  void ReleaseStaging(void* p, size_t cap) {
+    static const size_t limit = (size_t)std::max(0, EnvInt("JXL_HIP_SCHED_PINNED_MB", 4096)) << 20;
+    if (staging_held_ + cap <= limit && free_staging_.size() < 256) { free_staging_.push_back({p, cap}); staging_held_ += cap; }
+    else { (void)hipSetDevice(device_); (void)hipHostFree(p); }
+  }
+
+  void Finish(Request* r, int status, const std::string& err) {     // (mu_ held)
+    r->status = status; r->error = err; r->done = true;
+    r->cv.notify_all();
+  }
+
+  void SubmitJob(std::vector<Request*>& reqs) {
+    // staging for every request (pinned: the copy engine writes it while later jobs decode)
+    std::vector<const uint8_t*> datas; std::vector<size_t> sizes, caps; std::vector<void*> outs;
+    for (Request* r : reqs) {
+      if (!r->staging) {
+        size_t cap = 0;
+        void* p;
+        { std::lock_guard<std::mutex> lock(mu_); p = TakeStaging(r->dst_size, &cap); }
+        if (!p) {
+          cap = (r->dst_size + 4095) & ~(size_t)4095;
+          if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+        }
+        r->staging = p; r->staging_cap = p ? cap : 0;
+      }
+      datas.push_back(r->data); sizes.push_back(r->size); outs.push_back(r->staging); caps.push_back(r->staging ? r->dst_size : 0);
+    }
+    int64_t ticket = -1;
+    std::string err;
+    try { ticket = pipe_->Submit(datas.data(), sizes.data(), (int)reqs.size(), reqs[0]->spec, nullptr, outs.data(), caps.data()); }
+    catch (const std::exception& e) { err = e.what(); }
+    std::lock_guard<std::mutex> lock(mu_);
+    if (ticket < 0) { for (Request* r : reqs) Finish(r, 1, err); return; }
+    jobs_++; images_ += (int64_t)reqs.size();
+    inflight_.push_back(InFlight{ticket, reqs});
+    done_cv_.notify_all();
+  }
+
+  void CollectorLoop() {
+    (void)hipSetDevice(device_);
+    for (;;) {
+      std::vector<Request*> reqs;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return shutdown_ || !pending_.empty(); });
+        if (shutdown_) { for (Request* r : pending_) Finish(r, 1, "scheduler shut down"); pending_.clear(); return; }
+        // a short window for company: threads that were released together by the job before come back together
+        if (coalesce_us_ > 0 && (int)pending_.size() < max_job_) {
+          const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(coalesce_us_);
+          size_t seen = pending_.size();
+          while (!shutdown_ && (int)pending_.size() < max_job_) {
+            if (cv_.wait_until(lock, until) == std::cv_status::timeout) break;
+            if (pending_.size() == seen) continue;
+            seen = pending_.size();
+          }
+        }
+        // the requests that share the first one's output format, in arrival order
+        const OutputSpec spec = pending_.front()->spec;
+        for (auto it = pending_.begin(); it != pending_.end() && (int)reqs.size() < max_job_;) {
+          if (SameSpec((*it)->spec, spec)) { reqs.push_back(*it); it = pending_.erase(it); } else ++it;
+        }
+      }
+      SubmitJob(reqs);
+    }
+  }
+
+  void CompleterLoop() {
+    (void)hipSetDevice(device_);
+    for (;;) {
+      InFlight job;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        done_cv_.wait(lock, [&] { return shutdown_ || !inflight_.empty(); });
+        if (inflight_.empty()) { if (shutdown_) return; continue; }
+        job = inflight_.front(); inflight_.pop_front();
+      }
+      PipelineJobResult res;
+      std::string err;
+      try { pipe_->Wait(job.ticket, &res); } catch (const std::exception& e) { err = e.what(); }
+      std::vector<Request*> retry;
+      {
+        std::lock_guard<std::mutex> lock(mu_);
+        for (size_t i = 0; i < job.reqs.size(); i++) {
+          Request* r = job.reqs[i];
+          if (!err.empty()) { Finish(r, 1, err); continue; }
+          if (res.status[i] == 0) { Finish(r, 0, std::string()); continue; }
+          // one image can fail a whole job in Prepare (a feature the device path refuses at that point): everybody gets a job of their own once
+          const bool whole_job = job.reqs.size() > 1 && !r->retried && [&] { for (size_t k = 0; k < res.status.size(); k++) if (res.status[k] == 0) return false; return true; }();
+          if (whole_job) { r->retried = true; retry.push_back(r); } else Finish(r, 1, res.error[i]);
+        }
+      }
+      for (Request* r : retry) { std::vector<Request*> one{r}; SubmitJob(one); }
+    }
+  }
+
+  const int device_;
+  std::unique_ptr<Pipeline> pipe_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::deque<Request*> pending_;
+  std::deque<InFlight> inflight_;
+  std::vector<std::pair<void*, size_t>> free_staging_;
+  size_t staging_held_ = 0;
+  int max_job_ = 64, coalesce_us_ = 150;
+  int64_t jobs_ = 0, images_ = 0;
+  bool shutdown_ = false;
+  std::thread collector_, completer_;
+};
+
+std::mutex g_sched_mu;
+DeviceScheduler* g_sched[64] = {nullptr};       // (never destroyed at exit: the HIP runtime may be gone by then; SchedulerShutdown for tests)
+
+DeviceScheduler* For(int device) {
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  if (!g_sched[device]) g_sched[device] = new DeviceScheduler(device);
+  return g_sched[device];
+}
+
+}  // namespace
+
+int SchedulerDecode(int device, const uint8_t* data, size_t size, const OutputSpec& spec, void* dst, size_t dst_size, std::string* error) {
+  DeviceScheduler* s = nullptr;
+  try { s = For(device); } catch (const std::exception& e) { if (error) *error = e.what(); return 1; }
+  if (!s) { if (error) *error = "no scheduler for this device"; return 1; }
+  return s->Decode(data, size, spec, dst, dst_size, error);
+}
+
+void SchedulerStats(int device, int64_t* jobs, int64_t* images) {
+  if (jobs) *jobs = 0;
+  if (images) *images = 0;
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  if (device >= 0 && device < 64 && g_sched[device]) g_sched[device]->Stats(jobs, images);
+}
+
+void SchedulerShutdown() {
+  std::lock_guard<std::mutex> lock(g_sched_mu);
+  for (auto& s : g_sched) { delete s; s = nullptr; }
+}
+
+}  // namespace jxlhip
