@@ -23,21 +23,35 @@ namespace jxlhip {
 // Growable byte buffer in pinned host memory — what Prepare assembles the constant arena in and uploads from.  Pinned: the upload is a
 // DMA at link speed (57 GB/s) instead of a staged copy, and can overlap the GPU's work.  The capacity survives clear(): a batch object that is
 // refilled step after step (JxlHipBatchReset) allocates once.  Falls back to pageable memory when pinning fails (no GPU: host-only describe).
-HostStage::~HostStage() { Release(); }
+HostStage::~HostStage() {
+  Release();
+  for (auto& r : retired_) { if (r.second) (void)hipHostFree(r.first); else std::free(r.first); }
+}
 void HostStage::Release() {
   if (!p_) return;
   if (pinned_) (void)hipHostFree(p_); else std::free(p_);
   p_ = nullptr; n_ = cap_ = 0;
 }
+void HostStage::Reserve(size_t n) {
+  if (n <= cap_) return;
+  const size_t keep = n_;
+  Resize(n);
+  n_ = keep;
+}
 void HostStage::Resize(size_t n) {
   if (n > cap_) {
-    const size_t cap = std::max<size_t>(n + n / 2, 1 << 20);
+    // (pinned allocations cost milliseconds each and serialise with the rest of the runtime: capacities double, so that an arena assembled piece by piece
+    // — or a batch object refilled with jobs of changing size — settles after a few)
+    size_t cap = std::max<size_t>(cap_ * 2, 1 << 20);
+    while (cap < n) cap *= 2;
     uint8_t* q = nullptr;
     bool pinned = hipHostMalloc((void**)&q, cap, hipHostMallocDefault) == hipSuccess && q;
     if (!pinned) { (void)hipGetLastError(); q = (uint8_t*)std::malloc(cap); if (!q) throw std::bad_alloc(); }
     const size_t keep = n_;
     if (keep) memcpy(q, p_, keep);
-    Release();
+    // (hipHostFree waits for the whole device — hundreds of milliseconds under a busy pipeline: the outgrown block is kept until the object dies; capacities
+    // double, so all of them together are smaller than the live one)
+    if (p_) retired_.push_back({p_, pinned_});
     p_ = q; cap_ = cap; pinned_ = pinned; n_ = keep;
   }
   if (n > n_) {   // zero what Put does not overwrite: alignment gaps (< 256 B) — the payload is copied over right after
@@ -346,12 +360,17 @@ struct ArenaPool {
   }
   // `dev`: the device the block was allocated on (the owner's, not the calling thread's current one).  The device-wide wait — what hipFree does implicitly: nothing in
   // flight may still touch the block when somebody else gets it — happens outside the pool's lock.
-  void Give(void* p, size_t cap, int dev) {
+  // idle: the caller knows that nothing on the device refers to the block any more (a batch object is only refilled after its last decode has left the GPU) — no
+  // device-wide wait, which under a busy pipeline takes as long as everything in flight (seen: 400 ms stalls of a prepare thread)
+  void Give(void* p, size_t cap, int dev, bool idle = false) {
     if (!p) return;
     if (dev >= 0 && cap >= kMinBytes && Limit() != 0) {
       bool room;
       { std::lock_guard<std::mutex> lock(mu); room = held + cap <= Limit() && blocks.size() < 96; }
-      if (room) {
+      if (room && idle) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (held + cap <= Limit() && blocks.size() < 96) { blocks.push_back(Block{p, cap, dev}); held += cap; return; }
+      } else if (room) {
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
         if (cur != dev) (void)hipSetDevice(dev);
@@ -377,7 +396,7 @@ ArenaPool& Pool() { static ArenaPool* pool = new ArenaPool(); return *pool; }   
 size_t DeviceArenaPoolTrim() { return Pool().Trim(); }
 size_t DeviceArenaPoolHeld() { return Pool().Held(); }
 void* DeviceArenaTake(size_t want, size_t* cap, int device) { return Pool().Take(want, cap, device); }
-void DeviceArenaGive(void* p, size_t cap, int device) { Pool().Give(p, cap, device); }
+void DeviceArenaGive(void* p, size_t cap, int device, bool idle) { Pool().Give(p, cap, device, idle); }
 
 Batch::Batch(int device) : device_(device) {
   if (device_ >= 0) HIP_CHECK(hipSetDevice(device_));      // (-1: host-side parsing only, JxlHipDebugDescribe)
@@ -442,8 +461,9 @@ void Batch::EnqueueStatusReadback(void* stream_v) {
   if (!status_pinned_ || status_pinned_n_ < 2 * n) {
     if (status_pinned_) (void)hipHostFree(status_pinned_);
     status_pinned_ = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&status_pinned_, std::max<size_t>(2 * n, 2) * 4));
-    status_pinned_n_ = std::max<size_t>(2 * n, 2);
+    const size_t cap = std::max<size_t>(8192, 4 * n);             // (hipHostFree waits for the device: generous, so that a refilled batch object rarely gets here)
+    HIP_CHECK(hipHostMalloc((void**)&status_pinned_, cap * 4));
+    status_pinned_n_ = cap;
   }
   if (!status_event_) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); status_event_ = ev; }
   if (n) {
@@ -474,8 +494,11 @@ void Batch::HarvestStatus(vec<uint32_t>* per_unit) {
 // that size).  Returns true if the memory is new (contents undefined).
 bool Batch::DevReserve(void** ptr, size_t* cap, size_t bytes) {
   if (*ptr && *cap >= bytes) return false;
-  if (*ptr) { Pool().Give(*ptr, *cap, device_); *ptr = nullptr; *cap = 0; }
-  const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+  // (no decode of this object is in flight when it is prepared again — the contract of Reset / Prepare —, so the outgrown block is idle unless other batches share it)
+  if (*ptr) { Pool().Give(*ptr, *cap, device_, /*idle=*/!(ptr == (void**)&dbig_ && big_sharers_ > 0)); *ptr = nullptr; *cap = 0; }
+  // below 4 GiB capacities are powers of two (a batch object refilled with jobs of changing size settles after a few allocations), above: 1/8 of slack
+  size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+  if (bytes < ((size_t)4 << 30)) { want = 1 << 16; while (want < bytes) want *= 2; }
   if (void* p = Pool().Take(std::max<size_t>(bytes, 256), cap, device_)) { *ptr = p; return true; }
   if (hipMalloc(ptr, want) != hipSuccess) {
     (void)hipGetLastError();
@@ -870,7 +893,7 @@ void* Batch::device_output(int i) const {
   return e.out.device_ptr ? e.out.device_ptr : (void*)(dwork_ + e.off_out);
 }
 
-void Batch::Prepare(void* stream_v) {
+void Batch::Prepare(void* stream_v, bool wait_upload) {
   hipStream_t stream = (hipStream_t)stream_v;
   HIP_CHECK(hipSetDevice(device_));
   InitDeviceTables(stream_v);
@@ -920,6 +943,11 @@ void Batch::Prepare(void* stream_v) {
     }
   }
   hconst_.clear();
+  {
+    size_t guess = (size_t)1 << 20;      // streams + tables: one allocation instead of a dozen doublings
+    for (auto& e : images_) { guess += sizeof(FrameDev) + 4 * sizeof(PassDev) + 1024; if (e->frame_index == 0) guess += e->cs.padded_size() + ((size_t)256 << 10); }
+    hconst_.Reserve(guess);
+  }
   Arena arena(hconst_);
   vec<ConstOffsets> co(n);
   // natural coefficient orders (shared)
@@ -1146,7 +1174,7 @@ void Batch::Prepare(void* stream_v) {
     if (!big_owner_->dbig_ || big_owner_->big_cap_ < big_size_) throw ParseError("ShareBigArena: the owner's buffers are missing or smaller than this batch needs", false);
     dbig_ = big_owner_->dbig_;
   } else if (ext_big_ && ext_big_->p && ext_big_->cap >= big_size_ && plain_planes) {
-    if (dbig_) { Pool().Give(dbig_, big_cap_, device_); dbig_ = nullptr; big_cap_ = 0; }
+    if (dbig_) { Pool().Give(dbig_, big_cap_, device_, /*idle=*/big_sharers_ == 0); dbig_ = nullptr; big_cap_ = 0; }
     dbig_ = ext_big_->p; big_is_ext_ = true;
   } else if (DevReserve((void**)&dbig_, &big_cap_, std::max<size_t>(big_size_, 256)) || big_sharers_ == 0) {
     // (planes other batches share are not cleared again when this object is refilled: their decodes may be using them — every sharer,
@@ -1157,7 +1185,7 @@ void Batch::Prepare(void* stream_v) {
     if (!coef_owner_->dcoef_ || coef_owner_->coef_cap_ < coeff_bytes_) throw ParseError("ShareCoefArena: the owner's planes are missing or smaller than this batch needs", false);
     dcoef_ = coef_owner_->dcoef_;                      // (whether they are clean is the owner's knowledge: CoefDirty())
   } else if (ext_coef_ && ext_coef_->p && ext_coef_->cap >= coeff_bytes_ && any_vardct_) {
-    if (dcoef_) { Pool().Give(dcoef_, coef_cap_, device_); dcoef_ = nullptr; coef_cap_ = 0; }
+    if (dcoef_) { Pool().Give(dcoef_, coef_cap_, device_, /*idle=*/true); dcoef_ = nullptr; coef_cap_ = 0; }
     dcoef_ = ext_coef_->p; coef_is_ext_ = true;        // (clean or not: ext_coef_->dirty / clean_extent, kept by the decodes that used the set before)
   } else {
     const bool fresh = DevReserve((void**)&dcoef_, &coef_cap_, std::max<size_t>(coeff_bytes_, 256));
@@ -1552,10 +1580,20 @@ void Batch::Prepare(void* stream_v) {
     lf_simt_.streams = (const LfSimtStream*)(dconst_ + simt_streams_off); lf_simt_.lanes = (const LfSimtLane*)(dconst_ + simt_lanes_off); lf_simt_.luts = dconst_ + simt_luts_off;
   }
   mark("fill_frames");
-  HIP_CHECK(hipMemcpyAsync(dframes_, frames_host_.data(), sizeof(FrameDev) * n, hipMemcpyHostToDevice, stream));
-  HIP_CHECK(hipMemcpyAsync(dpasses_, passes_host_.data(), sizeof(PassDev) * passes_host_.size(), hipMemcpyHostToDevice, stream));
-  HIP_CHECK(hipMemcpyAsync(dlocal_, local_host_.data(), sizeof(ModLocalDev) * local_host_.size(), hipMemcpyHostToDevice, stream));
-  HIP_CHECK(hipStreamSynchronize(stream));
+  {
+    // the descriptor arrays travel through the pinned staging buffer, too (a copy from pageable memory is staged by the runtime and holds the calling thread —
+    // and others — up for as long as the device is busy); appended behind the constant arena's content, which has been copied out of it above
+    const size_t o_frames = arena.Put(frames_host_.data(), sizeof(FrameDev) * (size_t)n);
+    const size_t o_passes = arena.Put(passes_host_.data(), sizeof(PassDev) * passes_host_.size());
+    const size_t o_local = arena.Put(local_host_.data(), sizeof(ModLocalDev) * local_host_.size());
+    HIP_CHECK(hipMemcpyAsync(dframes_, hconst_.data() + o_frames, sizeof(FrameDev) * (size_t)n, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dpasses_, hconst_.data() + o_passes, sizeof(PassDev) * passes_host_.size(), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(dlocal_, hconst_.data() + o_local, sizeof(ModLocalDev) * local_host_.size(), hipMemcpyHostToDevice, stream));
+  }
+  mark("h2d_enqueue");
+  // (a pipelined caller enqueues the LF stage on the same stream right behind the upload and never waits for it on the host: the pinned staging buffer is not touched
+  // again before the object's next Prepare, which comes after this decode has left the GPU)
+  if (wait_upload) HIP_CHECK(hipStreamSynchronize(stream));
   mark("upload_wait");
   if (time_phases) fprintf(stderr, "[jxl-hip] Prepare of %d frames (%.1f MB of tables and streams, %.1f MB work arena), ms:%s\n", n, hconst_.size() / 1e6, work_size_ / 1e6, t_report.c_str());
   // ---- LF frames the units refer to: a batch of their own, every LF frame a one-frame image of its own size that ends in its XYB planes (PlanPostOps)
@@ -1583,7 +1621,7 @@ void Batch::Prepare(void* stream_v) {
         t.pitch = user.plan.bw; t.w = user.plan.bw; t.h = user.plan.bh;
       }
       lf_batch_->cfg.lane_stride_lf = 64;
-      lf_batch_->Prepare(stream_v);
+      lf_batch_->Prepare(stream_v, wait_upload);
     }
   }
   cfg.any_multipass = any_multipass_ ? 1 : 0;
@@ -2132,13 +2170,15 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     cfg.lf_wide_once = 0;
     DebugSync("LF decode", stream_v);
     CheckLaunches("LF stage");
-    if (any_vardct_ && !cfg.idct_flags_known && part != 0) {
+    if (any_vardct_ && !cfg.idct_flags_known && part != 0 && !cfg.no_flag_wait) {
       // a caller that enqueues the stages separately: the placement flags travel to pinned host memory behind the LF stage, and the tail —
       // enqueued steps later — waits for that copy (long done by then) instead of launching every IDCT kernel variant
       if (!flags_pinned_ || flags_pinned_n_ < (size_t)n) {
-        if (flags_pinned_) (void)hipHostFree(flags_pinned_);
-        HIP_CHECK(hipHostMalloc((void**)&flags_pinned_, (size_t)std::max(n, 1) * 4));
-        flags_pinned_n_ = (size_t)n;
+        if (flags_pinned_) (void)hipHostFree(flags_pinned_);      // (waits for the device: the capacity is generous so that a refilled batch object rarely gets here)
+        flags_pinned_ = nullptr;
+        const size_t cap = std::max<size_t>(4096, 2 * (size_t)n);
+        HIP_CHECK(hipHostMalloc((void**)&flags_pinned_, cap * 4));
+        flags_pinned_n_ = cap;
       }
       if (!flags_event_) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); flags_event_ = ev; }
       HIP_CHECK(hipMemcpyAsync(flags_pinned_, dwork_ + flags_off_, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
@@ -2206,6 +2246,20 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
       rec(6);
       if (timed && split) timed_rest_cursor_++;
     }
+  }
+}
+
+// (tracing) when the nine stage marks of the timed decode recorded last were reached, in ms after `ref_event`: LF start, LF end, LF post end, HF end, IDCT end,
+// filters end, output end, HF start, IDCT start; -1 = not recorded
+void Batch::DebugTimeline(void* ref_event, float out[9]) {
+  for (int i = 0; i < 9; i++) out[i] = -1;
+  if (timed_events_.empty()) return;
+  auto& evs = timed_events_.back();
+  for (int i = 0; i < 9 && i < (int)evs.size(); i++) {
+    if (!evs[(size_t)i]) continue;
+    if (hipEventSynchronize((hipEvent_t)evs[(size_t)i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)ref_event, (hipEvent_t)evs[(size_t)i]) == hipSuccess) out[i] = ms; else (void)hipGetLastError();
   }
 }
 

@@ -68,10 +68,12 @@ class HostStage {
   const uint8_t* data() const { return p_; }
   void clear() { n_ = 0; }
   void Resize(size_t n);
+  void Reserve(size_t n);      // capacity only
   bool pinned() const { return pinned_; }
  private:
   void Release();
   uint8_t* p_ = nullptr; size_t n_ = 0, cap_ = 0; bool pinned_ = false;
+  std::vector<std::pair<uint8_t*, bool>> retired_;     // outgrown blocks, freed with the object
 };
 
 // Coefficient / pixel planes that belong to somebody else (a Pipeline): a batch whose layout fits uses them instead of arenas of its own (Batch::UseSharedPlanes).
@@ -112,7 +114,8 @@ class Batch {
   const ImageEntry& frame(int i, int k) const { return *images_[pub_[i].first_unit + k]; }
   void SetOutput(int i, const OutputSpec& o);
   // Allocates device memory, uploads streams + tables (inputs become HBM-resident).  stream: hipStream_t.
-  void Prepare(void* stream);
+  // wait_upload = false: returns with the upload still in flight on `stream` (the caller enqueues the first stage of the decode on that same stream)
+  void Prepare(void* stream, bool wait_upload = true);
   // Enqueues the whole decode of every frame of the batch.  No host synchronisation inside.
   void Run(void* stream);
   // Waits, checks device status words; throws ParseError on stream errors.
@@ -134,6 +137,7 @@ class Batch {
   void RunTimed(void* stream);
   void RunPart(void* stream, int part, bool timed);
   StageTimes CollectTimes(int* runs);
+  void DebugTimeline(void* ref_event, float out[9]);
   // ALGORITHMIC bytes per stage for one Run of the batch: 0 lf, 1 lfpost, 2 hf, 3 idct, 4 filters, 5 out
   void StageBytes(uint64_t out[6]) const;
   LaunchCfg cfg;
@@ -261,6 +265,6 @@ class Batch {
 size_t DeviceArenaPoolTrim();      // gives every pooled block back to the runtime; returns the bytes released
 size_t DeviceArenaPoolHeld();
 void* DeviceArenaTake(size_t want, size_t* cap, int device);
-void DeviceArenaGive(void* p, size_t cap, int device);
+void DeviceArenaGive(void* p, size_t cap, int device, bool idle = false);   // idle: nothing on the device refers to the block (no device-wide wait)
 
 }  // namespace jxlhip

@@ -35,7 +35,7 @@ size_t Align256(size_t v) { return (v + 255) / 256 * 256; }
 Pipeline::Pipeline(int device, const PipelineOptions& opt) : device_(device), opt_(opt) {
   HIP_CHECK(hipSetDevice(device_));
   opt_.in_flight = std::max(1, std::min(opt_.in_flight, 64));
-  opt_.hf_streams = std::max(1, std::min(opt_.hf_streams, 4));
+  opt_.hf_streams = std::max(1, std::min(opt_.hf_streams, 12));
   opt_.lf_streams = std::max(1, std::min(opt_.lf_streams, 32));
   opt_.prepare_threads = std::max(1, std::min(opt_.prepare_threads, 16));
   opt_.parse_threads = std::max(1, std::min(opt_.parse_threads, 64));
@@ -43,13 +43,14 @@ Pipeline::Pipeline(int device, const PipelineOptions& opt) : device_(device), op
   // batch objects: the jobs in flight on the GPU + the ones the prepare threads are filling (+ one: a worker waits for its slot's previous job to leave the GPU)
   nbuf_ = opt_.in_flight + 2 + 1;
   if (nbuf_ % ncoef_) nbuf_ += ncoef_ - nbuf_ % ncoef_;     // (job k always meets coefficient set k % ncoef and slot k % nbuf)
-  int prio_low = 0, prio_high = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);     // (numerically lower = higher priority)
-  main_ = NewStream(prio_low);
-  d2h_ = NewStream(prio_low);
+  // the few long wavefronts of the entropy stages on high-priority streams, everything else at the default priority (0; the range's other end would be "low")
+  int prio_least = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_high);   // (numerically lower = higher priority)
+  prio_high = std::min(prio_high, 0);
+  main_ = NewStream(0);
+  d2h_ = NewStream(0);
   for (int i = 0; i < opt_.lf_streams; i++) lf_side_.push_back(NewStream(prio_high));
   for (int i = 0; i < opt_.hf_streams; i++) hf_side_.push_back(NewStream(prio_high));
-  for (int i = 0; i < opt_.prepare_threads; i++) copy_.push_back(NewStream(prio_low));
   clock_event_ = NewEvent(true);
   Record(clock_event_, main_);
   coef_.assign((size_t)ncoef_, SharedPlanes());
@@ -94,7 +95,6 @@ Pipeline::~Pipeline() {
   if (clock_event_) (void)hipEventDestroy((hipEvent_t)clock_event_);
   for (void* s : lf_side_) (void)hipStreamDestroy((hipStream_t)s);
   for (void* s : hf_side_) (void)hipStreamDestroy((hipStream_t)s);
-  for (void* s : copy_) (void)hipStreamDestroy((hipStream_t)s);
   (void)hipStreamDestroy((hipStream_t)main_);
   (void)hipStreamDestroy((hipStream_t)d2h_);
 }
@@ -102,7 +102,7 @@ Pipeline::~Pipeline() {
 // (device idle as far as these planes go) makes sp a block of at least `bytes`: from the arena pool, else from the runtime
 void Pipeline::ReservePlanes(SharedPlanes* sp, size_t bytes) {
   if (sp->p && sp->cap >= bytes) return;
-  if (sp->p) { DeviceArenaGive(sp->p, sp->cap, device_); sp->p = nullptr; sp->cap = 0; }
+  if (sp->p) { DeviceArenaGive(sp->p, sp->cap, device_, /*idle=*/true); sp->p = nullptr; sp->cap = 0; }
   if (!bytes) return;
   const size_t want = bytes + bytes / 16;
   size_t cap = 0;
@@ -202,6 +202,7 @@ void Pipeline::PrepareWorker(int worker) {
 
 void Pipeline::PrepareJob(Job* j, int worker) {
   const auto t0 = std::chrono::steady_clock::now();
+  auto t_parse = t0, t_prep = t0;
   Slot& s = *slots_[(size_t)(j->ticket % nbuf_)];
   Batch& bt = *s.batch;
   const int n = (int)j->datas.size();
@@ -211,6 +212,7 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     vec<int> index;
     std::vector<std::string> errors;
     bt.AddImagesTolerant(j->datas.data(), j->sizes.data(), n, opt_.parse_threads, &index, &errors);
+    t_parse = std::chrono::steady_clock::now();
     j->batch_index.assign(index.begin(), index.end());
     bool any = false;
     for (int i = 0; i < n; i++) {
@@ -231,9 +233,13 @@ void Pipeline::PrepareJob(Job* j, int worker) {
       bt.SetOutput(index[(size_t)i], o);
     }
     if (!any) { j->job_error = "no image of the job could be parsed"; return; }
-    bt.cfg.lane_stride_lf = opt_.lane_stride_lf; bt.cfg.lane_stride_hf = opt_.lane_stride_hf;
+    bt.cfg.lane_stride_lf = opt_.lane_stride_lf; bt.cfg.lane_stride_hf = opt_.lane_stride_hf; bt.cfg.no_flag_wait = opt_.no_flag_wait;
     bt.UseSharedPlanes(&big_, &coef_[(size_t)(j->ticket % ncoef_)]);
-    bt.Prepare(copy_[(size_t)worker % copy_.size()]);              // (returns when the upload has completed)
+    // tables + upload go to the stream the job's LF stage runs on, which follows without a host-side wait (an upload stream of its own was seen waiting tens of
+    // milliseconds behind other streams' entropy kernels)
+    void* side = lf_side_[(size_t)(j->ticket % (int64_t)lf_side_.size())];
+    bt.Prepare(side, /*wait_upload=*/false);
+    t_prep = std::chrono::steady_clock::now();
     {
       std::lock_guard<std::mutex> lock(mu_);
       want_big_ = std::max(want_big_, bt.big_bytes_wanted()); want_coef_ = std::max(want_coef_, bt.coef_bytes_wanted());
@@ -245,7 +251,6 @@ void Pipeline::PrepareJob(Job* j, int worker) {
       last_info_["frames"] = (int64_t)bt.size();
     }
     // the LF stage goes out right away, from this thread: the earlier it starts the better
-    void* side = lf_side_[(size_t)(j->ticket % (int64_t)lf_side_.size())];
     if (j->cold_wide && opt_.lane_stride_lf < 64) bt.cfg.lf_wide_once = 1;
     bt.RunPart(side, 5, opt_.timed != 0);           // LF decode + varblock placement: all the HF stage waits for
     Record(s.lf_done, side);
@@ -256,6 +261,9 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     if (j->job_error.empty()) j->job_error = "prepare failed";
   }
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  static const bool trace = getenv("JXL_HIP_SCHED_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[pipe %.1f] job %lld (%d images, slot %d): prepare + LF enqueue %.1f ms (parse %.1f, prepare %.1f)%s%s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(),
+                     (long long)j->ticket, n, (int)(j->ticket % nbuf_), dt * 1e3, std::chrono::duration<double, std::milli>(t_parse - t0).count(), std::chrono::duration<double, std::milli>(t_prep - t_parse).count(), j->job_error.empty() ? "" : " ERROR ", j->job_error.c_str());
   std::lock_guard<std::mutex> lock(mu_);
   prepare_s_total_ += dt; prepared_jobs_++;
 }
@@ -367,6 +375,17 @@ void Pipeline::Harvest(Job* j) {
       j->result.status[i] = 1;
       j->result.error[i] = (bad & kErrUnsupported) ? "unsupported: stream feature on the device path" : "corrupt stream (device status " + std::to_string(bad) + ")";
     } else j->result.status[i] = 0;
+  }
+  static const bool trace = getenv("JXL_HIP_SCHED_TRACE") != nullptr;
+  if (trace && opt_.timed && readback_ok) {
+    float tl[9];
+    bt.DebugTimeline(clock_event_, tl);
+    fprintf(stderr, "[pipe] job %lld timeline (ms): LF %.1f .. %.1f, LF post end %.1f, HF %.1f .. %.1f, IDCT %.1f .. %.1f, filters end %.1f, out end %.1f\n", (long long)j->ticket, tl[0], tl[1], tl[2], tl[7], tl[3],
+            tl[8], tl[4], tl[5], tl[6]);
+    int runs = 0;
+    const StageTimes t = bt.CollectTimes(&runs);
+    fprintf(stderr, "[pipe] job %lld (%zu images) on the GPU: lf %.1f lfpost %.1f hf %.1f idct %.1f filters %.1f out %.1f, first kernel to last %.1f ms; done at %.1f ms\n", (long long)j->ticket, n, t.lf_ms, t.lfpost_ms,
+            t.hf_ms, t.idct_ms, t.filter_ms, t.out_ms, t.total_ms, j->result.end_ms);
   }
   {
     std::lock_guard<std::mutex> lock(mu_);

@@ -34,6 +34,7 @@ struct PipelineOptions {
   int lane_stride_lf = 8, lane_stride_hf = 1;
   int wide_first = 4;        // LF stages at the start of a cold pipeline that take the one-wavefront-per-stream kernel (shorter latency on an idle GPU)
   int small_job_frames = 0;  // jobs of at most this many frames always take it (latency mode: DeviceScheduler)
+  int no_flag_wait = 0;      // the issuing thread never waits for a job's LF stage (placement flags): every IDCT kernel variant is launched instead — latency mode
   int timed = 0;             // bracket the stages with HIP events (CollectTimes)
   // shared coefficient sets / pixel planes are sized for jobs of this shape at creation (0: nothing is reserved; jobs run on arenas of their own until the
   // pipeline is idle, then the shared planes grow to the largest job seen)
@@ -103,7 +104,7 @@ class Pipeline {
   std::vector<SharedPlanes> coef_;
   size_t want_big_ = 0, want_coef_ = 0;        // the largest layouts seen: what the shared planes grow to when the pipeline is idle
   void* main_ = nullptr; void* d2h_ = nullptr;
-  std::vector<void*> lf_side_, hf_side_, copy_;
+  std::vector<void*> lf_side_, hf_side_;
   void* clock_event_ = nullptr;
   std::mutex mu_;
   std::condition_variable cv_;

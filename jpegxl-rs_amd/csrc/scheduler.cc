@@ -8,6 +8,7 @@
 #include "pipeline.h"
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -29,22 +30,34 @@ bool SameSpec(const OutputSpec& a, const OutputSpec& b) {
 }
 
 int EnvInt(const char* name, int def) { const char* e = getenv(name); return e && *e ? atoi(e) : def; }
+double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool Trace() { static const bool on = getenv("JXL_HIP_SCHED_TRACE") != nullptr; return on; }
 
 class DeviceScheduler {
  public:
   explicit DeviceScheduler(int device) : device_(device) {
     PipelineOptions o;
     // latency mode: a handful of small jobs in flight; small jobs take the one-wavefront-per-stream LF kernel (a third of the SIMT kernel's latency on a GPU that has room)
-    o.in_flight = EnvInt("JXL_HIP_SCHED_IN_FLIGHT", 6);
-    o.lf_streams = EnvInt("JXL_HIP_SCHED_LF_STREAMS", 6);
-    o.hf_streams = 1;
+    o.in_flight = EnvInt("JXL_HIP_SCHED_IN_FLIGHT", 4);      // (few slots: their arenas settle after a handful of jobs — hipMalloc under a busy GPU takes hundreds of milliseconds)
+    o.lf_streams = EnvInt("JXL_HIP_SCHED_LF_STREAMS", 4);     // (with the HF, main, copy and upload streams: 13 of the 16 hardware queues — streams that share one serialise)
+    // (the HF stage of a small job is a latency chain of its own, ~35 ms for one 4K frame: several in flight, a coefficient set each)
+    o.hf_streams = EnvInt("JXL_HIP_SCHED_HF_STREAMS", 3);
+    o.no_flag_wait = 1;
     o.prepare_threads = EnvInt("JXL_HIP_SCHED_PREPARE_THREADS", 3);
     o.parse_threads = EnvInt("JXL_HIP_SCHED_PARSE_THREADS", 8);
+    // latency over occupancy: every LF-group stream gets a wavefront of its own (100 ms per launch instead of the 250-300 ms of the SIMT form, which packs eight streams
+    // into a wavefront for the deep throughput pipeline)
+    o.lane_stride_lf = EnvInt("JXL_HIP_SCHED_LANE_STRIDE_LF", 64);
+    o.timed = Trace() ? 1 : 0;
     o.wide_first = 0;
-    o.small_job_frames = EnvInt("JXL_HIP_SCHED_WIDE_BELOW", 48);
-    o.reserve_frames = EnvInt("JXL_HIP_SCHED_RESERVE_FRAMES", 16); o.reserve_width = 3840; o.reserve_height = 2160;
+    o.small_job_frames = EnvInt("JXL_HIP_SCHED_WIDE_BELOW", 0);
     max_job_ = std::max(1, EnvInt("JXL_HIP_SCHED_MAX_JOB", 64));
-    coalesce_us_ = std::max(0, EnvInt("JXL_HIP_COALESCE_US", 150));
+    // shared planes for a few 4K frames to start with (a process that decodes one picture must not pay for gigabytes); they grow to the largest job seen whenever the pipeline
+    // idles, jobs that do not fit run on arenas of their own
+    o.reserve_frames = EnvInt("JXL_HIP_SCHED_RESERVE_FRAMES", 4); o.reserve_width = 3840; o.reserve_height = 2160;
+    max_jobs_ = std::max(1, EnvInt("JXL_HIP_SCHED_JOBS", 3));
+    return_us_ = std::max(0, EnvInt("JXL_HIP_SCHED_RETURN_US", 25000));
+    quiet_us_ = std::max(0, EnvInt("JXL_HIP_SCHED_QUIET_US", 1000)); max_wait_us_ = std::max(0, EnvInt("JXL_HIP_SCHED_MAX_WAIT_US", 8000));
     pipe_.reset(new Pipeline(device, o));
     collector_ = std::thread([this] { CollectorLoop(); });
     completer_ = std::thread([this] { CompleterLoop(); });
@@ -62,6 +75,7 @@ class DeviceScheduler {
   int Decode(const uint8_t* data, size_t size, const OutputSpec& spec, void* dst, size_t dst_size, std::string* error) {
     Request r;
     r.data = data; r.size = size; r.spec = spec; r.spec.device_ptr = nullptr; r.dst = dst; r.dst_size = dst_size;
+    const double t_in = Trace() ? NowMs() : 0;
     {
       std::unique_lock<std::mutex> lock(mu_);
       if (shutdown_) { if (error) *error = "scheduler shut down"; return 1; }
@@ -70,7 +84,9 @@ class DeviceScheduler {
       r.cv.wait(lock, [&] { return r.done; });
     }
     int rc = r.status == 0 ? 0 : 1;
+    const double t_woke = Trace() ? NowMs() : 0;
     if (rc == 0 && r.staging) memcpy(dst, r.staging, dst_size);     // every caller copies its own pixels: T threads, T copies at once
+    if (Trace()) fprintf(stderr, "[req %.1f] waited %.1f ms, copy-out %.1f ms\n", NowMs(), t_woke - t_in, NowMs() - t_woke);
     if (r.staging) { std::lock_guard<std::mutex> lock(mu_); ReleaseStaging(r.staging, r.staging_cap); }
     if (rc && error) *error = r.error.empty() ? "decode failed" : r.error;
     return rc;
@@ -100,6 +116,7 @@ class DeviceScheduler {
   }
 
   void SubmitJob(std::vector<Request*>& reqs) {
+    const double t_stage = NowMs();
     // staging for every request (pinned: the copy engine writes it while later jobs decode)
     std::vector<const uint8_t*> datas; std::vector<size_t> sizes, caps; std::vector<void*> outs;
     for (Request* r : reqs) {
@@ -117,11 +134,14 @@ class DeviceScheduler {
     }
     int64_t ticket = -1;
     std::string err;
+    const double t_sub = t_stage;
     try { ticket = pipe_->Submit(datas.data(), sizes.data(), (int)reqs.size(), reqs[0]->spec, nullptr, outs.data(), caps.data()); }
     catch (const std::exception& e) { err = e.what(); }
     std::lock_guard<std::mutex> lock(mu_);
     if (ticket < 0) { for (Request* r : reqs) Finish(r, 1, err); return; }
+    if (Trace()) fprintf(stderr, "[sched %.1f] job %lld: %zu images submitted (staging + submit %.1f ms)\n", NowMs(), (long long)ticket, reqs.size(), NowMs() - t_sub);
     jobs_++; images_ += (int64_t)reqs.size();
+    inflight_count_++;
     inflight_.push_back(InFlight{ticket, reqs});
     done_cv_.notify_all();
   }
@@ -132,17 +152,27 @@ class DeviceScheduler {
       std::vector<Request*> reqs;
       {
         std::unique_lock<std::mutex> lock(mu_);
-        cv_.wait(lock, [&] { return shutdown_ || !pending_.empty(); });
+        // At most max_jobs_ jobs on their way: what arrives meanwhile waits and rides together.  A job's cost on the GPU hardly depends on its size (the entropy stages
+        // are latency chains per stream), so a few large jobs in flight beat many small ones — measured with 64 callers: 0.9 Gpixel/s with a job per arrival.
+        cv_.wait(lock, [&] { return shutdown_ || (!pending_.empty() && (int)inflight_count_ < max_jobs_); });
         if (shutdown_) { for (Request* r : pending_) Finish(r, 1, "scheduler shut down"); pending_.clear(); return; }
-        // a short window for company: threads that were released together by the job before come back together
-        if (coalesce_us_ > 0 && (int)pending_.size() < max_job_) {
-          const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(coalesce_us_);
+        // A window for company: threads that were released together by a job come back together, a few milliseconds apart (each copies its pixels out first), and one job
+        // of 64 frames costs the GPU little more than one of a single frame (the entropy stages are latency chains per stream).  The job goes out when nothing new has
+        // arrived for quiet_us, after max_wait_us at the latest, or when it is full.
+        if ((int)pending_.size() < max_job_ && max_wait_us_ > 0) {
+          const auto t_first = std::chrono::steady_clock::now();
+          auto t_last = t_first;
           size_t seen = pending_.size();
           while (!shutdown_ && (int)pending_.size() < max_job_) {
-            if (cv_.wait_until(lock, until) == std::cv_status::timeout) break;
-            if (pending_.size() == seen) continue;
-            seen = pending_.size();
+            const auto now = std::chrono::steady_clock::now();
+            auto deadline = std::min(t_first + std::chrono::microseconds(max_wait_us_), t_last + std::chrono::microseconds(quiet_us_));
+            // the callers of a job that has just completed are on their way back (each copies its pixels out first): the first of them does not leave alone
+            if (pending_.size() * 4 < expected_back_ * 3 && now < expected_until_) deadline = std::max(deadline, std::min(expected_until_, t_first + std::chrono::microseconds(5 * max_wait_us_)));
+            if (now >= deadline) break;
+            cv_.wait_until(lock, deadline);
+            if (pending_.size() != seen) { seen = pending_.size(); t_last = std::chrono::steady_clock::now(); }
           }
+          expected_back_ = 0;
         }
         // the requests that share the first one's output format, in arrival order
         const OutputSpec spec = pending_.front()->spec;
@@ -167,9 +197,13 @@ class DeviceScheduler {
       PipelineJobResult res;
       std::string err;
       try { pipe_->Wait(job.ticket, &res); } catch (const std::exception& e) { err = e.what(); }
+      if (Trace()) fprintf(stderr, "[sched %.1f] job %lld done\n", NowMs(), (long long)job.ticket);
       std::vector<Request*> retry;
       {
         std::lock_guard<std::mutex> lock(mu_);
+        inflight_count_--;
+        if (job.reqs.size() >= 4) { expected_back_ = job.reqs.size(); expected_until_ = std::chrono::steady_clock::now() + std::chrono::microseconds(return_us_); }
+        cv_.notify_all();
         for (size_t i = 0; i < job.reqs.size(); i++) {
           Request* r = job.reqs[i];
           if (!err.empty()) { Finish(r, 1, err); continue; }
@@ -191,7 +225,9 @@ class DeviceScheduler {
   std::deque<InFlight> inflight_;
   std::vector<std::pair<void*, size_t>> free_staging_;
   size_t staging_held_ = 0;
-  int max_job_ = 64, coalesce_us_ = 150;
+  int max_job_ = 64, quiet_us_ = 1000, max_wait_us_ = 8000, max_jobs_ = 4;
+  int inflight_count_ = 0;
+  size_t expected_back_ = 0; std::chrono::steady_clock::time_point expected_until_{}; int return_us_ = 25000;
   int64_t jobs_ = 0, images_ = 0;
   bool shutdown_ = false;
   std::thread collector_, completer_;

@@ -191,7 +191,7 @@ def test_concurrent_decoders_on_their_own_streams(jx):
     """What does not go through the shared pipeline runs as a batch of one on the decoder's own non-blocking stream (SURVEY 8b "Threading"): eight threads reconstruct
     the JPEG of sample_jpg.jxl (entropy stages on the GPU, Huffman writer on the host) while others decode the 16-bit RGBA fixture through the shared pipeline."""
     jpg_jxl, jpg = fixture_bytes("sample_jpg.jxl"), fixture_bytes("sample.jpg")
-    rgba = O.decode(fixture_bytes("sample.jxl")).pixels("u16", 4)
+    rgba = O.decode(fixture_bytes("sample.jxl")).pixels("u16", 4).view(np.uint16)
     def work(i):
         if i % 2 == 0:
             meta, (kind, data) = jx.decoder_builder().reconstruct(jpg_jxl)

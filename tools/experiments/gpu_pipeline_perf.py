@@ -11,6 +11,9 @@ streams = bench.make_streams(distinct, 3840, 2160, 1)
 import numpy as np, torch
 import jpegxl_rs_amd as jx
 W, H = 3840, 2160
+SKIP = os.environ.get('SKIP_PIPE') == '1'
+if not SKIP:
+  exec('''
 p = jx.Pipeline(0, timed=1, reserve_frames=B, reserve_width=W, reserve_height=H)
 outs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
 def frames_of(k):
@@ -39,20 +42,24 @@ for fi in (0, B // 2, B - 1):
     ok = ok and bool(np.array_equal(outs[k % 2][fi].cpu().numpy().reshape(-1), O.decode(frames_of(k)[fi]).pixels("u8", 3)))
 print("verified", ok)
 p.close(); del outs; torch.cuda.empty_cache()
+''')
 # concurrent decode_with callers
 import concurrent.futures as cf, threading
-for T in (1, 8, 64):
-    n = max(T * 3, 6)
+for T in [int(x) for x in os.environ.get('THREADS', '1,8,64').split(',')]:
+    n = max(T * int(os.environ.get("PER_THREAD", "6")), 6)
     barrier = threading.Barrier(T)
+    lat = []
     def work(i):
         dec = jx.decoder_builder(pixel_format=jx.PixelFormat(num_channels=3))
         barrier.wait()
         for k in range(i, n, T):
+            t0 = time.perf_counter()
             dec.decode_with(streams[k % len(streams)], np.uint8)
+            lat.append(time.perf_counter() - t0)
     with cf.ThreadPoolExecutor(T) as ex:
         list(ex.map(work, range(T)))          # warm-up round
         barrier.reset()
         t0 = time.perf_counter()
         list(ex.map(work, range(T)))
         dt = time.perf_counter() - t0
-    print(json.dumps({"threads": T, "frames": n, "s": round(dt, 3), "mpixel_per_s": round(n * W * H / 1e6 / dt, 1), "ms_per_frame_per_thread": round(dt / (n / T) * 1e3, 1)}))
+    print(json.dumps({"threads": T, "frames": n, "s": round(dt, 3), "mpixel_per_s": round(n * W * H / 1e6 / dt, 1), "ms_per_frame_per_thread": round(dt / (n / T) * 1e3, 1), "decode_with_ms_mean": round(1e3 * sum(lat[-n:]) / n, 1)}))
