@@ -1,27 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — Mpixel/s of JPEG XL VarDCT (d1) decode of 3840x2160 frames on MI355X (BASELINE.json metric).
 
-A "step" decodes one batch of B synthetic 4K VarDCT frames per GPU (u8 RGB out) through the C-ABI batch API
-(include/jxl_hip.h); decoded pixels stay in HBM (a torch tensor).  Two modes, both run by default:
+A "step" decodes one job of B fresh synthetic 4K VarDCT frames per GPU (u8 RGB out) through the library's streaming pipeline (include/jxl_hip.h
+JxlHipPipeline*: the ring of batch objects, the LF / HF / tail streams, the prepare threads and the coefficient-set rotation live in csrc/pipeline.cc —
+this file only submits jobs and waits for them).  Every step's compressed frames come from host memory and are parsed, prepared and uploaded inside
+the timed region; decoded pixels stay in HBM (a torch tensor).  `workload_realistic` repeats that on frames with photograph-like texture
+(1.5 - 2.5 bits per pixel), `workload_cjxl_shape` on frames whose LF-group MA trees have the shape a default-effort cjxl writes (weighted predictor).
+With N > 1 ranks every rank decodes its own shard (weak scaling, no data-path collective) and the decoded pixels are gathered to rank 0 over RCCL
+(BASELINE.json north_star); `decode_only_mpixel_per_s` / `gather_ms` split the two; `per_rank_consumers` is the same job consumed where it was decoded.
+--scaling strong --total-frames T fixes the job instead (BASELINE config 3: 1024 frames over the node).
 
-  streaming (the headline `value`): every step decodes a batch of FRESH inputs.  Prepare workers refill a ring of batch objects
-      (JxlHipBatchReset / AddImages: parse on host threads into pinned staging; Prepare: tables + upload on a copy stream) and
-      enqueue the latency-bound LF stage on side streams, ten or so batches ahead; the main thread issues HF decode, IDCT and the
-      filter / write stages of step k.  The host never holds a decoded stream longer than the ring.
-  resident (`resident_mpixel_per_s`): the same pipeline over batch objects prepared before the timed region — compressed streams
-      and tables are in HBM when the clock starts (the configuration round 2's number was quoted on).
-
-`workload_realistic` repeats the headline mode on frames with photograph-like texture (1.5 - 2.5 bits per pixel).
-With N > 1 ranks every rank decodes its own shard of the batch (weak scaling, no data-path collective) and the decoded pixels are
-gathered to rank 0 over RCCL (BASELINE.json north_star); `decode_only_mpixel_per_s` / `gather_ms` split the two.
---scaling strong --total-frames T fixes the job instead (BASELINE config 3: 1024 frames over the node): every rank decodes
-T / N frames per step, in chunks of at most --batch.
-
-Besides the headline the N = 1 line reports what a caller of the drop-in API sees: single_frame_ms (config 2: one 4K frame through
-decode_with, host to host), one_pass (config-3 shape: a fresh batch of 128 frames decoded once, cold, no pipelining, with and
-without the host-side parse + upload), pcie_inclusive (the same pass plus the copy of the pixels back to host memory),
-step_end_ms / steady_state_ms_per_step (the pipeline fill is inside the K timed steps) and verified_vs_oracle (pixels of the
-timed batches against the CPU oracle).
+Besides the headline the N = 1 line reports what callers of the drop-in API see — api_concurrent: the reference crate's call sequence against the libjxl C ABI
+from 1 / 8 / 64 host threads (tools/api_concurrent.cc, host bytes in, host pixels out; the shared per-device scheduler coalesces the callers); single_frame_ms:
+one 4K frame through decode_with (gradient LF tree, cjxl-shaped tree) and the reference's own criterion input bench.jxl; streaming_host_out: the pipeline with
+pinned host destinations beside the measured PCIe ceiling; one_pass_128 / pcie_inclusive: a cold batch of 128 frames; the 8K workloads of BASELINE configs 4 and 5
+(f32 HDR EPF 3; lossless Modular Squeeze u16) with the rooflines of their own kernels; step_end_ms / steady_state_ms_per_step; verified_vs_oracle.
 
 Contract: python bench.py --gpus N --steps K --warmup W  → rank 0 prints ONE JSON line.
 """
@@ -170,18 +163,237 @@ def cpu_baseline(streams, width, height, target_seconds=15.0):
                       f"single-core rate {width * height / 1e6 / dt:.2f} Mpixel/s"}
 
 
-def extras(jx, torch, streams, W, H, device):
-    """What a caller of the drop-in API sees, measured after the timed region (N = 1): see the module docstring."""
+
+
+def _make_8k_hdr(seed):
+    """BASELINE config 5: 7680x4320 f32 HDR VarDCT (linear light, values up to 4.0, intensity target 1000), gaborish + EPF 3."""
     import numpy as np
+    import synth_lib as S
+    lin = ((S.synthetic_image(seed, 7680, 4320).astype(np.float32) / 255.0) ** 2.2) * 4.0
+    return S.encode_vardct(lin, seed=seed, strategy_mix=1, epf_iters=3, gab=1, out_bits=32, hdr=1)
+
+
+def _make_8k_modular(seed):
+    """BASELINE config 4: lossless Modular 8192x8192 u16 (one channel) under the default Squeeze chain."""
+    import numpy as np
+    import synth_lib as S
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:8192, 0:8192].astype(np.float32)
+    base = ((np.sin(xx / (37.0 + seed % 5)) + np.cos(yy / 23.0)) * 0.25 + 0.5) * 65535
+    img = np.clip(base[..., None] + rng.normal(0, 64.0, (8192, 8192, 1)).astype(np.float32), 0, 65535).astype(np.int32)
+    return S.encode_modular(img, 16, False, 1)
+
+
+def _pool_map(fn, jobs):
+    import multiprocessing as mp
+    workers = max(1, min(len(jobs), int(os.environ.get("JXL_BENCH_SYNTH_WORKERS", "0")) or (os.cpu_count() or 1), 64))
+    if workers == 1 or len(jobs) <= 1:
+        return [fn(j) for j in jobs]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(fn, jobs)
+
+
+class Run:
+    """One measured workload: a library pipeline (jx.Pipeline = JxlHipPipeline*), a ring of output tensors, the job loop of one rank.
+    consumer: "none" (pixels stay where they were decoded), "gather" (RCCL point-to-point gather to rank 0, north_star's mode), "per_rank" (a reduction over the decoded
+    pixels on a side stream stands in for a consumer on every rank; the ranks exchange the 8-byte checksums at the end)."""
+
+    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, W, H, dtype="uint8", nch=3, consumer="none", in_flight=None, lf_streams=None, host_out=False):
+        import numpy as np
+        self.args, self.jx, self.torch, self.dist, self.streams = args, jx, torch, dist, streams
+        self.dev, self.rank, self.world, self.B, self.inner, self.W, self.H, self.dtype, self.nch = dev, rank, world, B, inner, W, H, dtype, nch
+        self.consumer = consumer if (world > 1 or consumer == "per_rank") else "none"
+        if consumer == "gather" and (world == 1 or args.no_gather):
+            self.consumer = "none"
+        self.frame_bytes = W * H * nch * np.dtype(dtype).itemsize
+        self.host_out = host_out
+        if self.consumer != "none" and not in_flight:
+            in_flight = min(args.in_flight, 7)    # (a consumer needs one output buffer per batch object + 1 — 6.4 GB each at 256 frames —, beside rank 0's job buffer)
+        self.p = jx.Pipeline(local_rank, timed=1, jobs_in_flight=in_flight or args.in_flight, lf_streams=lf_streams or args.lf_streams, hf_streams=args.hf_streams,
+                             prepare_threads=args.prepare_threads, parse_threads=args.parse_threads, lane_stride_lf=args.lane_stride_lf, lane_stride_hf=args.lane_stride_hf,
+                             wide_first=args.wide_first, reserve_frames=B, reserve_width=W, reserve_height=H)
+        self.slots = self.p.info("slots")
+        # output buffers: two when nobody reads them; with a consumer (gather / reduction on a side stream) one more than the jobs the pipeline can hold, so that a job never
+        # writes where the consumer of an earlier one may still be reading
+        self.nout = 2 if self.consumer == "none" and not host_out else self.slots + 1
+        tdt = {"uint8": torch.uint8, "uint16": torch.uint16 if hasattr(torch, "uint16") else torch.int16, "float32": torch.float32}[np.dtype(dtype).name]
+        if host_out:
+            self.pinned = [jx.PinnedBuffer(B * self.frame_bytes) for _ in range(self.nout)]
+            self.outs = None
+        else:
+            self.outs = [torch.empty((B, H, W, nch), dtype=tdt, device=dev) for _ in range(self.nout)]
+        self.comm = torch.cuda.Stream(device=dev) if self.consumer != "none" else None
+        self.out_free = [torch.cuda.Event() for _ in range(self.nout)]
+        self.checksum = torch.zeros((), dtype=torch.int64, device=dev)
+        self.gathered = torch.empty((world, inner * B, H, W, nch), dtype=tdt, device=dev) if self.consumer == "gather" and rank == 0 else None
+        self.lag = max(0, self.slots - 2)                    # jobs between a submit and the wait for an earlier one (the pipeline's own back-pressure is slots - 1)
+        self.step_offset = 0
+
+    def frames_of(self, k):
+        n = len(self.streams)
+        off = (k * 37) % n                                   # a different rotation of the distinct frames every step
+        return [self.streams[(off + i) % n] for i in range(self.B)]
+
+    def _dest(self, k):
+        if self.host_out:
+            base = self.pinned[k % self.nout].ptr
+            return dict(host_ptrs=[base + i * self.frame_bytes for i in range(self.B)])
+        base = self.outs[k % self.nout].data_ptr()
+        return dict(device_ptrs=[base + i * self.frame_bytes for i in range(self.B)])
+
+    def _consume(self, k):
+        """job k's pixels are in outs[k % nout]: hand them to the consumer on the side stream"""
+        torch = self.torch
+        if self.consumer == "per_rank":
+            with torch.cuda.stream(self.comm):
+                self.checksum += self.outs[k % self.nout].view(-1).view(torch.int32).sum(dtype=torch.int64)     # every decoded byte is read once, where it was written
+                self.out_free[k % self.nout].record(self.comm)
+        elif self.consumer == "gather":
+            from jpegxl_rs_amd.sharding import gather_frames_chunked
+            with torch.cuda.stream(self.comm):
+                j = k % self.inner
+                gather_frames_chunked(self.outs[k % self.nout], self.gathered[:, j * self.B:(j + 1) * self.B] if self.rank == 0 else None, dst=0, chunk_frames=self.args.gather_chunk)
+                self.out_free[k % self.nout].record(self.comm)
+
+    def run(self, njobs):
+        """njobs jobs from an idle pipeline; returns (seconds, per-job end times in ms of the GPU clock, seconds until this rank's own decode work was done)"""
+        torch, dist, p = self.torch, self.dist, self.p
+        self.checksum.zero_()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        p.reset_clock()
+        cpu0 = time.process_time()
+        tickets, ends = [], []
+        t0 = time.perf_counter()
+        for k in range(njobs):
+            if self.consumer != "none" and k >= self.nout:
+                self.out_free[k % self.nout].synchronize()       # the consumer of the job that used this buffer last has read it (long since)
+            tickets.append(p.submit(self.frames_of(self.step_offset + k), self.dtype, self.nch, **self._dest(k)))
+            if k >= self.lag:
+                ends.append(p.wait(tickets[k - self.lag])[1])
+                self._consume(k - self.lag)
+        for k in range(max(0, njobs - self.lag), njobs):
+            ends.append(p.wait(tickets[k])[1])
+            self._consume(k)
+        t_decode = time.perf_counter() - t0
+        if self.consumer == "per_rank" and self.world > 1:
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(self.checksum)                   # checksum of checksums: the only bytes that cross xGMI in this mode
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        self.cpu_s = time.process_time() - cpu0
+        self.last_first = self.step_offset
+        self.step_offset += njobs
+        return elapsed, [round(e, 1) for e in ends], t_decode
+
+    def verify(self, njobs, O, np, kind="u8"):
+        """decoded frames of the output buffers the last jobs wrote, against the CPU oracle"""
+        ok, checked = True, []
+        for oj in range(min(self.nout, njobs, 2)):
+            k = njobs - 1 - oj
+            frames = self.frames_of(self.last_first + k)
+            for fi in sorted({0, self.B // 2, self.B - 1}):
+                if self.host_out:
+                    got = np.array(self.pinned[k % self.nout].array[fi * self.frame_bytes:(fi + 1) * self.frame_bytes])
+                else:
+                    got = self.outs[k % self.nout][fi].cpu().numpy().reshape(-1).view(np.uint8)
+                ref = O.decode(frames[fi]).pixels(kind, self.nch)
+                ok = ok and bool(np.array_equal(got.view(np.uint8).reshape(-1), np.asarray(ref).view(np.uint8).reshape(-1)))
+                checked.append(f"{k}:{fi}")
+        if self.gathered is not None and self.rank == 0:
+            # what the consumer rank holds of the other ranks' shards after the last job's gather (their frames are regenerated here: seeds are per rank)
+            self.torch.cuda.synchronize()
+            k = njobs - 1
+            n, B = len(self.streams), self.B
+            off = ((self.last_first + k) * 37) % n
+            for r in range(1, self.world):
+                for fi in sorted({0, B - 1}):
+                    data = _make_stream((1000 + 1000 * r + (off + fi) % n, self.W, self.H, self.args.epf, self.stream_texture, self.stream_tree_shape))
+                    got = self.gathered[r][(k % self.inner) * B + fi].cpu().numpy().reshape(-1)
+                    ok = ok and bool(np.array_equal(got, O.decode(data).pixels("u8", 3)))
+                    checked.append(f"rank{r}:{k}:{fi}")
+        return ok, checked
+
+    def close(self):
+        self.p.close()
+        self.outs = None; self.pinned = None; self.gathered = None
+        self.torch.cuda.empty_cache()
+
+
+def _steady(e):
+    n = len(e)
+    return round((e[n * 2 // 3] - e[n // 5]) / max(1, n * 2 // 3 - n // 5), 2) if n >= 10 else None
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def api_concurrent(streams, O, np, threads=(1, 8, 64), per_thread=8):
+    """tools/api_concurrent: the reference crate's call sequence (decode.rs:207-325) against the libjxl C ABI from T pthreads, host bytes in, host pixels out —
+    what the unchanged Rust crate gets when its callers decode on many threads (decoders are Send, decode.rs:523-532).  In a subprocess (its own HIP runtime)."""
+    import subprocess
+    import tempfile
+    import zlib
+    exe = os.path.join(ROOT, "tools", "_build", "api_concurrent")
+    lib = os.path.join(ROOT, "jpegxl-rs_amd", "lib", "libjxl.so")
+    if not os.path.exists(exe):
+        return {"error": "tools/_build/api_concurrent not built"}
+    with tempfile.TemporaryDirectory() as d:
+        for i, s in enumerate(streams[:64]):
+            with open(os.path.join(d, f"f{i:03d}.jxl"), "wb") as fh:
+                fh.write(s)
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+        try:
+            out = subprocess.run([exe, lib, d, ",".join(str(t) for t in threads), str(per_thread), "3", "verify"], env=env, capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired:
+            return {"error": "timeout"}
+    if out.returncode != 0:
+        return {"error": out.stderr[-400:]}
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    crcs = next((l["crc32"] for l in lines if "crc32" in l), {})
+    ok = True
+    for i in (0, min(len(streams), 64) // 2, min(len(streams), 64) - 1):
+        ok = ok and crcs.get(f"f{i:03d}.jxl") == (zlib.crc32(np.asarray(O.decode(streams[i]).pixels("u8", 3)).tobytes()) & 0xFFFFFFFF)
+    legs = {f"threads_{l['threads']}": {k: l[k] for k in ("mpixel_per_s", "latency_ms_median", "latency_ms_p90", "decodes", "failures")} for l in lines if "threads" in l}
+    return {"what": "tools/api_concurrent.cc: every thread owns a JxlDecoder and runs jpegxl-rs' decode_internal loop (SubscribeEvents, SetInput, CloseInput, ProcessInput ..., zero-filled Vec per image) over "
+                    "distinct 3840x2160 frames: host bytes in, host pixels out through the libjxl C ABI; callers that decode at the same time are coalesced into jobs of one shared pipeline per device "
+                    "(csrc/scheduler.cc); one warm-up round, then the timed one", "verified_vs_oracle_crc32": ok, **legs}
+
+
+def extras(jx, torch, streams, cjxl_streams, W, H, device, O, np):
+    """What a caller of the drop-in API sees, measured after the timed region (N = 1): see the module docstring."""
     out = {}
     dec = jx.decoder_builder()
-    ts = []
-    for i in range(6):
-        t0 = time.perf_counter()
-        dec.decode_with(streams[i % len(streams)], np.uint8)
-        ts.append((time.perf_counter() - t0) * 1e3)
-    out["single_frame_ms"] = {"value": round(sorted(ts[1:])[len(ts[1:]) // 2], 3), "what": f"one {W}x{H} frame through decoder_builder().decode_with(u8): host bytes in, host pixels out "
-                              "(parse, device allocation, upload, decode, copy back); median of 5 after one warm-up", "mpixel_per_s": round(W * H / 1e6 / (sorted(ts[1:])[2] * 1e-3), 1)}
+
+    def latency(data, dtype=np.uint8, reps=5):
+        ts = []
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            dec.decode_with(data, dtype)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return round(_median(ts[1:]), 3)
+    one = latency(streams[0])
+    out["single_frame_ms"] = {"value": one, "what": f"one {W}x{H} frame through decoder_builder().decode_with(u8): host bytes in, host pixels out (parse, upload, decode, copy back); median of 5 after one "
+                              "warm-up; through the shared per-device pipeline, on streams of its own", "mpixel_per_s": round(W * H / 1e6 / (one * 1e-3), 1)}
+    if cjxl_streams:
+        c = latency(cjxl_streams[0])
+        out["single_frame_ms"]["cjxl_shape_ms"] = c
+    try:
+        bj = open(os.path.join(ROOT, "tests", "fixtures", "bench.jxl"), "rb").read()
+        t_or = time.perf_counter(); O.decode(bj); t_or = (time.perf_counter() - t_or) * 1e3
+        out["single_frame_ms"]["bench_jxl_ms"] = latency(bj, np.uint8, 3)
+        out["single_frame_ms"]["bench_jxl_oracle_1_thread_ms"] = round(t_or, 1)
+        out["single_frame_ms"]["bench_jxl_what"] = "samples/bench.jxl, the input of the reference's criterion bench (benches/decode.rs:10): lossless Modular 2122x1433 RGBA"
+    except Exception as e:
+        out["single_frame_ms"]["bench_jxl_error"] = repr(e)
+    t_or = time.perf_counter(); O.decode(streams[0]); out["single_frame_ms"]["oracle_1_thread_ms"] = round((time.perf_counter() - t_or) * 1e3, 1)
     # BASELINE config 3 per-GPU shape: 128 frames, one pass, nothing resident beforehand, no pipelining
     n = 128
     torch.cuda.synchronize()
@@ -205,315 +417,13 @@ def extras(jx, torch, streams, W, H, device):
     mpx = n * W * H / 1e6
     out["one_pass_128"] = {"decode_ms": round((t2 - t1) * 1e3, 2), "prepare_ms": round((t1 - t0) * 1e3, 2), "mpixel_per_s_decode_only": round(mpx / (t2 - t1), 1),
                            "mpixel_per_s_with_prepare": round(mpx / (t2 - t0), 1),
-                           "what": "fresh batch of 128 frames (BASELINE config 3 per-GPU share), decoded once: prepare = host parse of headers / TOC / entropy tables + device "
+                           "what": "fresh batch of 128 frames (BASELINE config 3 per-GPU share) through JxlHipBatch*, decoded once: prepare = host parse of headers / TOC / entropy tables + device "
                                    "allocation + upload of the compressed streams; decode = every kernel, no overlap between batches"}
     out["pcie_inclusive"] = {"mpixel_per_s": round(mpx / (t3 - t0), 1), "d2h_ms": round((t3 - t2) * 1e3, 2), "d2h_gbs": round(n * W * H * 3 / 1e9 / (t3 - t2), 1),
-                             "what": "the same pass plus the copy of the decoded pixels to pinned host memory (compressed input up, 24.9 MB per frame down)"}
-    del b
+                             "what": "the same pass plus the copy of the decoded pixels to pinned host memory (compressed input up, 24.9 MB per frame down), nothing overlapped"}
+    del b, dst, host
+    torch.cuda.empty_cache()
     return out
-
-
-def _cu_mask(spec, ncu=256):
-    """CU mask of an experiment stream: 'first:N' (mask bits 0 .. N-1; the driver deals mask bits round-robin over the XCDs, so this is N / 8
-    CUs of every XCD), 'last:N', 'stride:K' (every K-th bit), 'not-first:N', or comma-separated 32-bit hex words.  '' = no mask."""
-    if not spec:
-        return None
-    kind, _, val = spec.partition(":")
-    if kind == "first":
-        bits = [i < int(val) for i in range(ncu)]
-    elif kind == "last":
-        bits = [i >= ncu - int(val) for i in range(ncu)]
-    elif kind == "not-first":
-        bits = [i >= int(val) for i in range(ncu)]
-    elif kind == "stride":
-        bits = [i % int(val) == 0 for i in range(ncu)]
-    else:
-        return [int(w, 16) for w in spec.split(",")]
-    return [sum(1 << b for b in range(32) if bits[w * 32 + b]) for w in range(ncu // 32)]
-
-
-def _masked_stream(torch, dev, mask):
-    """hipExtStreamCreateWithCUMask through the HIP runtime torch has loaded, wrapped as a torch stream (lives as long as the process)."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (ctypes.c_uint32 * len(mask))(*mask)
-    st = ctypes.c_void_p()
-    with torch.cuda.device(dev):
-        err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(mask)), words)
-    if err != 0 or not st.value:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {err}")
-    return torch.cuda.ExternalStream(st.value, device=dev)
-
-
-class Pipeline:
-    """The decode pipeline of one GPU.  A decode is LF (entropy decode of the LF groups: a serial chain per stream, ~230 ms per
-    launch whatever the batch size, a few dozen wavefronts in the SIMT form) -> varblock placement + LF post-processing -> HF (entropy decode of
-    the coefficients, ~40 ms, one sparse workgroup per frame) -> IDCT -> filters + write (the HBM-bound part).  Throughput comes from batches in
-    flight: step k runs the tail of batch k on the main stream, the HF stage of batch k + 1 on a stream of its own ("deep"), the LF stages of
-    batches k + 1 .. k + ahead on side streams and — in streaming mode — parses, prepares and uploads the batches after that on host threads.
-    A batch object (its LF outputs: 14 MB per 4K frame) is busy from its preparation to its tail; the coefficient planes (106 MB per frame)
-    exist once per HF stage in flight + 1, the pixel planes once, the outputs as often as --out-buffers says.
-
-    streaming: every step decodes a batch of compressed frames that has not been seen before: the batch object is reset, its frames are
-    parsed (JxlHipBatchAddImages, --parse-threads host threads), the tables built and uploaded from pinned memory (JxlHipBatchPrepare, on a copy
-    stream) by one of --prepare-threads worker threads, overlapped with the GPU's work on earlier batches.
-    resident: the batch objects are prepared once before the timed region and decoded again and again (inputs resident in HBM)."""
-
-    _streams = {}
-
-    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer="gather", depth=None):
-        self.args, self.jx, self.torch, self.dist, self.streams = args, jx, torch, dist, streams
-        # who consumes the decoded pixels: "gather" = rank 0 (RCCL point-to-point gather, north_star's mode); "per_rank" = every rank its own frames, in place
-        # in HBM (a reduction over the pixels stands in for the consumer; the ranks only exchange the 8-byte checksums at the end of the run)
-        self.consumer = consumer
-        self.dev, self.local_rank, self.rank, self.world, self.B, self.inner, self.streaming = dev, local_rank, rank, world, B, inner, streaming
-        self.stream_texture, self.stream_tree_shape = args.main_texture, args.main_tree_shape    # how `streams` were made (verify() regenerates other ranks' frames)
-        W, H = args.width, args.height
-        self.frame_bytes = W * H * 3
-        self.pipeline = not args.no_pipeline
-        self.deep = self.pipeline and os.environ.get("JXL_BENCH_DEEP", "1") == "1"
-        # depth = (batches in flight, LF side streams): as many LF stages in flight as it takes to cover one LF launch with steps (weighted-predictor LF streams
-        # take ~2x the time per launch of gradient-tree ones: their pipeline is deeper)
-        in_flight, lf_streams = depth if depth else (args.in_flight, args.lf_streams)
-        nbuf = int(os.environ.get("JXL_BENCH_NBUF", str(in_flight))) if self.pipeline else 1
-        self.nhf = max(1, args.hf_streams) if self.deep else 0        # HF stages in flight beside the tail of the step (each on its own stream)
-        self.ncoef = self.nhf + 1                                      # coefficient sets: one per HF stage in flight + the one the tail is consuming
-        self.ahead = nbuf - 1 if self.pipeline else 0                  # LF stages issued ahead of the step being finished
-        self.prep_ahead = self.ahead + 2 if streaming else 0           # streaming: batches whose preparation has been handed to the host threads
-        if streaming:
-            nbuf = self.prep_ahead + 1
-        if self.deep and nbuf % self.ncoef:
-            nbuf += self.ncoef - nbuf % self.ncoef                     # (coefficient sets rotate with k: batch object k % nbuf must always meet set k % ncoef)
-        self.nbuf = nbuf
-        # tails in flight: 1 = IDCT and filters of consecutive batches one after the other on the main stream; 2 = the filter stage on a stream of
-        # its own beside the IDCT of the next batch (two sets of pixel planes)
-        self.ntail = max(1, min(2, args.tail_streams)) if self.deep else 1
-        if self.ntail > 1 and nbuf % (self.ncoef * self.ntail):
-            nbuf += self.ncoef * self.ntail - nbuf % (self.ncoef * self.ntail)
-            self.nbuf = nbuf
-        self.nout = min(nbuf, max(1, args.out_buffers))
-        if os.environ.get("JXL_BENCH_CUMASK_MAIN") and "main" not in Pipeline._streams:          # experiment: the tail's kernels on a CU-masked stream
-            Pipeline._streams["main"] = _masked_stream(torch, dev, _cu_mask(os.environ["JXL_BENCH_CUMASK_MAIN"]))
-            torch.cuda.set_stream(Pipeline._streams["main"])
-        self.main = torch.cuda.current_stream()
-        self.stream = self.main.cuda_stream
-        self.outs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(self.nout)]
-        self.batches = []
-        for b in range(nbuf):
-            bt = jx.BatchDecoder(local_rank)
-            self.fill(bt, b)
-            if b >= self.ntail:
-                bt.share_buffers(self.batches[b % self.ntail])     # one set of pixel planes per tail in flight (1: the tails run one after the other on the main stream)
-            if b >= self.ncoef:
-                bt.share_coefficients(self.batches[b % self.ncoef])
-            bt.prepare(self.stream)
-            self.batches.append(bt)
-        self.do_gather = world > 1 and not args.no_gather and consumer == "gather"
-        self.consume_local = consumer == "per_rank"
-        self.checksum = torch.zeros((), dtype=torch.int64, device=dev)
-        self.gathered = torch.empty((world, inner * B, H, W, 3), dtype=torch.uint8, device=dev) if self.do_gather and rank == 0 else None
-        E = torch.cuda.Event
-        # (HIP streams are made once per process and handed to every pipeline: the runtime spreads streams over GPU_MAX_HW_QUEUES hardware
-        # queues, and kernels of two streams that share a queue serialise — an LF stage in front of a tail kernel stalls the step)
-        def S(kind, i, priority=0):
-            key = (kind, i)
-            if key not in Pipeline._streams:
-                mask = _cu_mask(os.environ.get("JXL_BENCH_CUMASK_" + kind.upper(), ""))    # experiment: confine the kernels of one kind of stream to a set of CUs
-                Pipeline._streams[key] = _masked_stream(torch, dev, mask) if mask else torch.cuda.Stream(device=dev, priority=priority)
-            return Pipeline._streams[key]
-        lf_prio = (lambda i: -1 if i == 0 else 0) if os.environ.get("JXL_BENCH_LF_PRIO") == "first" else (lambda i: -1)   # experiment: only the stream of the first cold LF stage is a high-priority one
-        self.sides = [S("lf", i, lf_prio(i)) for i in range(max(1, min(self.ahead, lf_streams)))] if self.pipeline else []
-        self.comm = S("comm", 0) if (self.do_gather or self.consume_local) else None            # RCCL gather / local consumer overlaps the next step's decode
-        self.hf_streams = [S("hf", i, -1) for i in range(self.nhf)]
-        self.filter_stream = S("filter", 0) if self.ntail > 1 else None
-        self.copy_streams = [S("copy", i) for i in range(max(1, args.prepare_threads))] if streaming else []
-        self.hf_done, self.front_done, self.lf_done, self.rest_done, self.idct_done = ([E() for _ in range(nbuf)] for _ in range(5))
-        self.out_free = [E() for _ in range(self.nout)]               # the gather of the step that used this output buffer last has read it
-        self.pool = None
-        if streaming:
-            import concurrent.futures as cf
-            self.pool = cf.ThreadPoolExecutor(max(1, args.prepare_threads))
-        self.prepare_s = []
-
-    def frames_of(self, k):
-        """compressed frames of step k (streaming: a different rotation of the distinct frames every step; resident: of batch object k)"""
-        n, B = len(self.streams), self.B
-        off = (k * 37 if self.streaming else k * B) % n
-        return [self.streams[(off + i) % n] for i in range(B)]
-
-    def fill(self, bt, k):
-        out = self.outs[k % self.nout]
-        ptrs = [out.data_ptr() + i * self.frame_bytes for i in range(self.B)]
-        bt.add_many(self.frames_of(k), "uint8", 3, device_ptrs=ptrs, threads=max(1, self.args.parse_threads))
-        bt.set_lane_stride(self.args.lane_stride_lf, self.args.lane_stride_hf)
-        if os.environ.get("JXL_BENCH_LDS_BUDGET"):
-            bt.set_option("lds_code_budget", int(os.environ["JXL_BENCH_LDS_BUDGET"]))   # experiment: entropy-code tables of the HF stage through the L2
-
-    def prepare_job(self, k, slot, timed=False):
-        """host side of step k (a worker thread): wait until the batch object's previous decode has left the GPU, parse, build, upload"""
-        b = k % self.nbuf
-        if k >= self.nbuf:
-            self.rest_done[b].synchronize()
-        t0 = time.perf_counter()
-        bt = self.batches[b]
-        bt.reset()
-        self.fill(bt, k)
-        bt.prepare(self.copy_streams[slot % len(self.copy_streams)].cuda_stream)     # (returns when the upload has completed)
-        self.prepare_s.append(time.perf_counter() - t0)
-        if self.pipeline:
-            self.issue_front(k, timed)          # the batch's LF stage goes out right away, from this thread: the earlier it starts the better
-
-    def issue_front(self, k, timed):
-        b = k % self.nbuf
-        side = self.sides[k % len(self.sides)]
-        torch = self.torch
-        with torch.cuda.stream(side):
-            if k >= self.nbuf and not self.streaming:
-                side.wait_event(self.rest_done[b])                  # the batch object's previous decode is complete (streaming: its preparation waited)
-            if k < self.args.wide_first and self.args.lane_stride_lf < 64:
-                self.batches[b].set_option("lf_wide_once", 1)       # cold pipeline, idle GPU: the wide LF kernel (100 instead of 250 ms until step 0 can go on)
-            self.batches[b].decode_part(5, side.cuda_stream, timed)  # LF decode + varblock placement: all the HF stage waits for
-            self.lf_done[b].record(side)
-            self.batches[b].decode_part(6, side.cuda_stream, timed)  # LF post-processing: needed by the IDCT only
-            self.front_done[b].record(side)
-
-    def issue_hf(self, k, timed):
-        b = k % self.nbuf
-        s_ = self.hf_streams[k % self.nhf] if self.deep else self.main
-        with self.torch.cuda.stream(s_):
-            s_.wait_event(self.lf_done[b])
-            if self.deep and k >= self.ncoef:
-                s_.wait_event(self.idct_done[(k - self.ncoef) % self.nbuf])   # the coefficient set's previous user has consumed (and zeroed) it
-            self.batches[b].decode_part(3, s_.cuda_stream, timed)
-            self.hf_done[b].record(s_)
-
-    def step(self, k, timed, st):
-        b = k % self.nbuf
-        main, torch = self.main, self.torch
-        if not self.pipeline:
-            if self.streaming:
-                self.prepare_job(k, 0, timed)
-            (self.batches[b].decode_timed if timed else self.batches[b].decode)(self.stream)
-            self.rest_done[b].record(main)
-        else:
-            if self.streaming:
-                for j in range(0, self.prep_ahead + 1):
-                    if k + j < st["limit"] and st["prep_submitted"] <= k + j:
-                        st["futures"][k + j] = self.pool.submit(self.prepare_job, k + j, k + j, timed); st["prep_submitted"] = k + j + 1
-                # (the worker that prepared a batch has enqueued its LF stage as well) step k's own batch: wait for it — normally long since on the GPU
-                while st["front_issued"] < st["limit"] and st["front_issued"] <= k + self.ahead and (st["front_issued"] <= k or st["futures"][st["front_issued"]].done()):
-                    st["futures"].pop(st["front_issued"]).result(); st["front_issued"] += 1
-            for j in range(0, self.ahead + 1):
-                if not self.streaming and k + j < st["limit"] and st["front_issued"] <= k + j:
-                    self.issue_front(k + j, timed); st["front_issued"] = k + j + 1
-            for j in range(0, self.nhf + 1 if self.deep else 1):
-                if st["front_issued"] <= k + j:
-                    break                                          # (its LF stage is not enqueued yet: the events it would wait for are a previous decode's)
-                if k + j < st["limit"] and st["hf_issued"] <= k + j:
-                    self.issue_hf(k + j, timed); st["hf_issued"] = k + j + 1
-            if self.deep:
-                main.wait_event(self.hf_done[b])
-            main.wait_event(self.front_done[b])
-            if (self.do_gather or self.consume_local) and st["gathers"] >= self.nout:
-                main.wait_event(self.out_free[k % self.nout])   # the previous gather of this output buffer must have read the pixels
-            if self.ntail > 1 and k >= self.ntail:
-                main.wait_event(self.rest_done[(k - self.ntail) % self.nbuf])   # the plane set's previous user has written its pixels
-            self.batches[b].decode_part(7, self.stream, timed)     # IDCT
-            self.idct_done[b].record(main)
-            if self.ntail > 1:
-                fs = self.filter_stream
-                with torch.cuda.stream(fs):
-                    fs.wait_event(self.idct_done[b])
-                    if (self.do_gather or self.consume_local) and st["gathers"] >= self.nout:
-                        fs.wait_event(self.out_free[k % self.nout])
-                    self.batches[b].decode_part(8, fs.cuda_stream, timed)
-                    self.rest_done[b].record(fs)
-            else:
-                self.batches[b].decode_part(8, self.stream, timed)     # restoration filters, colour, write
-                self.rest_done[b].record(main)
-        if self.consume_local:
-            with torch.cuda.stream(self.comm):
-                self.comm.wait_event(self.rest_done[b])
-                self.checksum += self.outs[k % self.nout].view(-1).view(torch.int32).sum(dtype=torch.int64)     # every decoded byte is read once, where it was written
-                self.out_free[k % self.nout].record(self.comm)
-            st["gathers"] += 1
-            if not self.pipeline:
-                main.wait_event(self.out_free[k % self.nout])
-        if self.do_gather:
-            from jpegxl_rs_amd.sharding import gather_frames_chunked
-            with torch.cuda.stream(self.comm):
-                self.comm.wait_event(self.rest_done[b])
-                # per-chunk point-to-point transfers straight into their final place (all peers at once, one xGMI link each)
-                j = k % self.inner
-                gather_frames_chunked(self.outs[k % self.nout], self.gathered[:, j * self.B:(j + 1) * self.B] if self.rank == 0 else None, dst=0, chunk_frames=self.args.gather_chunk)
-                self.out_free[k % self.nout].record(self.comm)
-            st["gathers"] += 1
-            if not self.pipeline:
-                main.wait_event(self.out_free[k % self.nout])
-
-    def run(self, nsteps, timed):
-        """nsteps steps from an empty pipeline; returns (seconds, per-step end times in ms, seconds of the gather tail)"""
-        torch, dist = self.torch, self.dist
-        st = {"front_issued": 0, "hf_issued": 0, "prep_submitted": 0, "limit": nsteps, "gathers": 0, "futures": {}}
-        self.prepare_s = []
-        self.checksum.zero_()
-        torch.cuda.synchronize()
-        if self.world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        cpu0 = time.process_time()
-        t_start = torch.cuda.Event(enable_timing=True); t_start.record(self.main)
-        marks = []
-        t0 = time.perf_counter()
-        for k in range(nsteps):
-            self.step(k, timed, st)
-            ev = torch.cuda.Event(enable_timing=True); ev.record(self.filter_stream if self.filter_stream is not None else self.main); marks.append(ev)
-        self.main.synchronize()
-        if self.filter_stream is not None:
-            self.filter_stream.synchronize()
-        t_decode = time.perf_counter() - t0          # every rank's own decode work is done (the gather may still be running)
-        if self.consume_local and self.world > 1:
-            with torch.cuda.stream(self.comm):
-                dist.all_reduce(self.checksum)         # checksum of checksums: the only bytes that cross xGMI in this mode
-        torch.cuda.synchronize()
-        if self.world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        self.cpu_s = time.process_time() - cpu0       # host CPU seconds of this rank's process over the run (all threads: parse, prepare, enqueue)
-        return elapsed, [round(t_start.elapsed_time(e), 1) for e in marks], t_decode
-
-    def verify(self, nsteps, O, np):
-        """decoded frames of the output buffers the last steps wrote, against the CPU oracle"""
-        ok, checked = True, []
-        for oj in range(len(self.outs)):
-            ks = [k for k in range(nsteps) if k % self.nout == oj]
-            if not ks:
-                continue
-            frames = self.frames_of(ks[-1])
-            for fi in sorted({0, self.B // 2, self.B - 1}):
-                got = self.outs[oj][fi].cpu().numpy().reshape(-1)
-                ok = ok and bool(np.array_equal(got, O.decode(frames[fi]).pixels("u8", 3)))
-                checked.append(f"{ks[-1]}:{fi}")
-        if self.gathered is not None and self.rank == 0:
-            # what the consumer rank holds of the other ranks' shards after the last step's gather (their frames are regenerated here: seeds are per rank)
-            self.torch.cuda.synchronize()
-            k = nsteps - 1
-            n, B = len(self.streams), self.B
-            off = (k * 37 if self.streaming else k * B) % n
-            for r in range(1, self.world):
-                for fi in sorted({0, B - 1}):
-                    data = _make_stream((1000 + 1000 * r + (off + fi) % n, self.args.width, self.args.height, self.args.epf, self.stream_texture, self.stream_tree_shape))
-                    got = self.gathered[r][(k % self.inner) * B + fi].cpu().numpy().reshape(-1)
-                    ok = ok and bool(np.array_equal(got, O.decode(data).pixels("u8", 3)))
-                    checked.append(f"rank{r}:{k}:{fi}")
-        return ok, checked
-
-    def close(self):
-        if self.pool:
-            self.pool.shutdown(wait=True)
-        self.batches.clear(); self.outs.clear(); self.gathered = None
-        self.torch.cuda.empty_cache()
 
 
 def main():
@@ -522,14 +432,12 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXL_BENCH_BATCH", "256")), help="frames per GPU per step")
-    ap.add_argument("--distinct", type=int, default=int(os.environ.get("JXL_BENCH_DISTINCT", "0")), help="distinct synthetic frames per GPU (cycled to fill the batches); default 256, 64 per GPU when N > 1 "
+    ap.add_argument("--distinct", type=int, default=int(os.environ.get("JXL_BENCH_DISTINCT", "0")), help="distinct synthetic frames per GPU (cycled to fill the jobs); default 256, 64 per GPU when N > 1 "
                     "(the ranks of a node share its host cores for the synthesis: 4.6 s per frame)")
-    ap.add_argument("--mode", choices=["streaming", "resident", "both"], default=os.environ.get("JXL_BENCH_MODE", "both"),
-                    help="streaming (the headline): every step parses, prepares, uploads and decodes a fresh batch of compressed frames; resident: prepared "
-                         "batches decoded again and again; both: streaming timed first, the resident figure reported beside it")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: --batch frames per GPU per step; strong: --total-frames per step over all GPUs")
     ap.add_argument("--total-frames", type=int, default=1024, help="frames per step of the whole job with --scaling strong (BASELINE config 3)")
-    ap.add_argument("--no-extras", action="store_true", help="skip single_frame_ms / one_pass / pcie_inclusive (N = 1 only anyway)")
+    ap.add_argument("--no-extras", action="store_true", help="skip api_concurrent / single_frame_ms / one_pass / streaming_host_out / the 8K workloads (N = 1 only anyway)")
+    ap.add_argument("--no-8k", action="store_true", help="skip the 8K workloads (BASELINE configs 4 and 5)")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison of decoded frames with the CPU oracle after the run")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -541,20 +449,15 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
     ap.add_argument("--per-rank-consumers", action="store_true", help="N = 1: also run the per-rank-consumer leg that N > 1 runs beside the gather (a reduction over the decoded pixels per step)")
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
-    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the stages of different batches")
-    ap.add_argument("--in-flight", type=int, default=11, help="batches in flight on the GPU (pipelined): LF stages run this many steps ahead, minus one")
-    ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the batches ahead are spread over")
-    ap.add_argument("--wp-in-flight", type=int, default=11, help="batches in flight for workloads whose LF streams use the weighted predictor (LF stage ~700 ms per launch instead of ~370)")
-    ap.add_argument("--wp-lf-streams", type=int, default=7, help="LF side streams for those workloads")
-    ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current step (deep pipeline), one stream and one coefficient set each")
-    ap.add_argument("--tail-streams", type=int, default=int(os.environ.get("JXL_BENCH_TAIL_STREAMS", "1")), help="2: the filter stage of a batch on its own stream beside the IDCT of the next (two sets of pixel planes)")
-    ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of the (cold) pipeline that take the one-wavefront-per-stream kernel")
-    ap.add_argument("--out-buffers", type=int, default=2, help="output buffer sets the batches in flight cycle through")
-    ap.add_argument("--prepare-threads", type=int, default=int(os.environ.get("JXL_BENCH_PREPARE_THREADS", "3")), help="streaming: host threads that each parse + prepare + upload one batch at a time")
-    ap.add_argument("--parse-threads", type=int, default=int(os.environ.get("JXL_BENCH_PARSE_THREADS", "8")), help="host threads JxlHipBatchAddImages parses the frames of one batch on")
+    ap.add_argument("--in-flight", type=int, default=11, help="jobs in flight in the library pipeline (JxlHipPipelineOptions.jobs_in_flight): LF stages run this many jobs ahead of the tail")
+    ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the jobs ahead are spread over")
+    ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current job, one stream and one coefficient set each")
+    ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of a cold pipeline that take the one-wavefront-per-stream kernel")
+    ap.add_argument("--prepare-threads", type=int, default=int(os.environ.get("JXL_BENCH_PREPARE_THREADS", "3")), help="host threads of the pipeline that each parse + prepare + upload one job at a time")
+    ap.add_argument("--parse-threads", type=int, default=int(os.environ.get("JXL_BENCH_PARSE_THREADS", "8")), help="host threads one job's frames are parsed on")
     ap.add_argument("--texture", type=float, default=5.0, help="strength (sRGB levels) of the texture of the realistic-bit-rate workload (0: skip it)")
     ap.add_argument("--realistic-distinct", type=int, default=64, help="distinct frames of the realistic-bit-rate workload")
-    ap.add_argument("--no-realistic", action="store_true", help="skip the second workload (textured frames, ~2 bpp)")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the second and third workload (textured frames, ~2 bpp; cjxl-shaped LF trees)")
     ap.add_argument("--cjxl-distinct", type=int, default=32, help="distinct frames of the cjxl-shaped workload (textured frames whose LF-group streams use the MA-tree shape of a default-effort "
                     "cjxl encode: weighted predictor); 0: skip it")
     ap.add_argument("--main-tree-shape", type=int, default=0, help="experiments: LF tree shape of the headline workload's frames (1: the cjxl default-effort shape)")
@@ -571,22 +474,26 @@ def main():
     if world > 1:
         args.realistic_distinct = min(args.realistic_distinct, 16)
         os.environ.setdefault("JXL_BENCH_SYNTH_WORKERS", str(max(1, (os.cpu_count() or 1) // int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))))
+    do_extras = world == 1 and not args.no_extras
 
     streams = make_streams(args.distinct, W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.main_texture, tree_shape=args.main_tree_shape)
     # the same frames with photograph-like texture: ~2 bpp at distance 1 instead of 0.8 (second workload of the line, fewer distinct frames)
     realistic_streams = make_streams(min(args.distinct, args.realistic_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture) if args.texture > 0 and not args.no_realistic else None
     cjxl_streams = make_streams(min(args.distinct, args.cjxl_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture, tree_shape=1) if args.cjxl_distinct > 0 and not args.no_realistic else None
+    hdr_streams = _pool_map(_make_8k_hdr, [6 + i for i in range(8)]) if do_extras and not args.no_8k else None
+    mod_streams = _pool_map(_make_8k_modular, [5 + i for i in range(4)]) if do_extras and not args.no_8k else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(streams, W, H)   # before any GPU runtime is initialised in this process (fork safety)
 
-    # the pipeline keeps ~15 HIP streams busy at once (main, HF, LF side streams, copy streams, gather); the runtime maps streams onto 4
-    # hardware queues by default and kernels of streams that share a queue serialise
+    # the pipeline keeps ~12 HIP streams busy at once (main, HF, LF side streams, copies); the runtime maps streams onto 4 hardware queues by default and kernels of
+    # streams that share a queue serialise (the library sets the same default when it is loaded first)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
     import torch.distributed as dist
     import jpegxl_rs_amd as jx
+    import oracle_lib as O
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path is HIP-only (no CPU fallback)")
     # JXL_BENCH_SHARE_GPU=1 + JXL_BENCH_BACKEND=gloo: several ranks on one GPU — a functional check of the N > 1 control flow on a
@@ -603,25 +510,23 @@ def main():
             dist.init_process_group(backend=backend)
 
     B = args.batch
-    inner = 1                       # pipeline iterations per step
+    inner = 1                       # jobs per step
     if args.scaling == "strong":
         per_rank = max(1, args.total_frames // world)
         B = min(args.batch, per_rank)
         inner = max(1, per_rank // B)
 
-    def measure(streaming, streams=streams, texture=args.main_texture, tree_shape=args.main_tree_shape, consumer="gather"):
-        """one mode: W untimed warm-up steps, then exactly K timed steps from an empty pipeline, bracketed by barrier + synchronize"""
-        depth = (args.wp_in_flight, args.wp_lf_streams) if tree_shape == 1 and not args.no_pipeline else None
-        p = Pipeline(args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, streaming, consumer, depth)
-        p.stream_texture, p.stream_tree_shape = texture, tree_shape
-        p.run(args.warmup * inner, False)
-        for bt in p.batches:
-            bt.finish(p.stream)
-            bt.collect_times()
-        elapsed, step_end, t_decode = p.run(args.steps * inner, True)
-        for bt in p.batches:
-            bt.finish(p.stream)
-        cpu_s = p.cpu_s
+    def measure(streams=streams, texture=args.main_texture, tree_shape=args.main_tree_shape, consumer="gather", **kw):
+        """one workload: the pipeline's batch objects are filled once (what constructing it costs: device arenas, pinned staging), W untimed warm-up steps, then exactly K timed
+        steps from an idle pipeline, bracketed by barrier + synchronize"""
+        steps, warmup = kw.pop("steps", args.steps), args.warmup
+        r = Run(args, jx, torch, dist, streams, dev, local_rank, rank, world, kw.pop("B", B), inner, kw.pop("W", W), kw.pop("H", H), consumer=consumer, **kw)
+        r.stream_texture, r.stream_tree_shape = texture, tree_shape
+        r.run(r.slots)                        # every batch object of the ring allocates its arenas (untimed set-up)
+        r.run(warmup * inner)
+        r.p.collect_times()
+        elapsed, ends, t_decode = r.run(steps * inner)
+        cpu_s = r.cpu_s
         if world > 1:
             t = torch.tensor([elapsed, t_decode], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -629,34 +534,25 @@ def main():
             c = torch.tensor([cpu_s], dtype=torch.float64, device=dev)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)       # host CPU seconds of all ranks (they share one host)
             cpu_s = float(c[0].item())
-        times, runs = {}, 0
-        for bt in p.batches:
-            t_, r_ = bt.collect_times()
-            runs += r_
-            for kk, vv in t_.items():
-                times[kk] = times.get(kk, 0.0) + vv
-        r = {"elapsed": elapsed, "t_decode": t_decode, "step_end": step_end, "stage_ms": {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"},
-             "stage_bytes": p.batches[0].stage_bytes, "device_bytes": sum(bt.device_bytes for bt in p.batches), "compressed": int(p.batches[0].compressed_bytes // B),
-             "nbuf": p.nbuf, "prepare_s": list(p.prepare_s), "gather": bool(p.do_gather), "pipelined": bool(p.pipeline), "cpu_s": cpu_s, "checksum": int(p.checksum.item()),
-             "nonzeros": p.batches[0].info_value("hf_nonzeros") // B,
-             "lf_simt": [p.batches[0].info_value(k) for k in ("lf_simt_frames", "lf_legacy_frames", "lf_simt_wp")]}
+        times, runs = r.p.collect_times()
+        p = r.p
+        res = {"elapsed": elapsed, "t_decode": t_decode, "step_end": ends[inner - 1::inner], "stage_ms": {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"},
+               "stage_bytes": p.stage_bytes, "device_bytes": p.info("device_bytes"), "compressed": int(p.info("compressed_bytes") // max(1, p.info("frames"))), "slots": r.slots,
+               "prepare_ms_per_job": p.info("prepare_us_total") / 1e3 / max(1, p.info("prepared_jobs")), "gather": r.consumer == "gather", "cpu_s": cpu_s, "checksum": int(r.checksum.item()),
+               "nonzeros": p.info("hf_nonzeros") // max(1, p.info("frames")), "lf_simt": [p.info(k) for k in ("lf_simt_frames", "lf_legacy_frames", "lf_simt_wp")],
+               "private_plane_jobs": p.info("private_plane_jobs"), "B": r.B, "steps": steps}
         if not args.no_verify and rank == 0:
-            import oracle_lib as O
-            r["verified"], r["verified_frames"] = p.verify(args.steps * inner, O, np)
-        p.close()
-        del p
+            res["verified"], res["verified_frames"] = r.verify(steps * inner, O, np, {"uint8": "u8", "uint16": "u16", "float32": "f32"}[np.dtype(r.dtype).name])
+        r.close()
+        del r
         torch.cuda.empty_cache()
-        return r
+        return res
 
-    modes = ["streaming", "resident"] if args.mode == "both" else [args.mode]
-    res = {m: measure(m == "streaming") for m in modes}
-    head = res[modes[0]]
-    realistic = None
-    if args.texture > 0 and not args.no_realistic and realistic_streams:
-        realistic = measure(modes[0] == "streaming", realistic_streams, args.texture, 0)
-    cjxl = measure(modes[0] == "streaming", cjxl_streams, args.texture, 1) if cjxl_streams else None
+    head = measure()
+    realistic = measure(realistic_streams, args.texture, 0) if args.texture > 0 and not args.no_realistic and realistic_streams else None
+    cjxl = measure(cjxl_streams, args.texture, 1) if cjxl_streams else None
     # N > 1: the same job with per-rank consumers beside the gather to rank 0 (7 peers x ~80 GB/s of pixels into one GPU's xGMI links bound the gather)
-    local_leg = measure(modes[0] == "streaming", consumer="per_rank") if (world > 1 or args.per_rank_consumers) and not args.no_gather else None
+    local_leg = measure(consumer="per_rank") if (world > 1 or args.per_rank_consumers) and not args.no_gather else None
     if rank == 0:
         total_px = world * B * inner * W * H * args.steps
         rate = lambda r: total_px / r["elapsed"] / 1e6
@@ -677,19 +573,17 @@ def main():
             except Exception:
                 traffic = None
         e = head["step_end"]
-        n_e = len(e)
-        steady = round((e[n_e * 2 // 3] - e[n_e // 5]) / max(1, n_e * 2 // 3 - n_e // 5), 2) if n_e >= 10 else None
+        steady = _steady(e)
         result = {
             "metric": "Mpixel/s decode (4K VarDCT d1)", "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(head["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": f"synthetic ({args.distinct} distinct seeded frames per GPU, tools/jxlsynth; own synthesiser, 0.8 bpp — real d1 photographs run 1.5-2.5 bpp: config.workload_realistic; the LF-group MA tree is the gradient tree the SIMT LF kernel is eligible for by "
                                                         f"construction — a default-effort cjxl encode writes weighted-predictor trees: config.workload_cjxl_shape; cpu_baseline kind 'port' is the scalar oracle, not libjxl)",
-            "config": {"workload": f"batch of {B} x {W}x{H} VarDCT d1 frames per GPU per step (XYB, ANS, var-block DCT8..32 mix, gaborish, EPF {args.epf}), u8 RGB out; "
-                                   + ("streaming: every step's compressed frames come from host memory and are parsed, prepared and uploaded inside the timed region, outputs stay in HBM"
-                                      if modes[0] == "streaming" else "inputs and outputs resident in HBM"),
-                       "mode": modes[0], "frames_per_gpu": B * inner, "frames_per_launch": B, "width": W, "height": H, "compressed_bytes_per_frame": head["compressed"],
-                       "lane_stride_lf": args.lane_stride_lf, "lane_stride_hf": args.lane_stride_hf, "batches_in_flight": head["nbuf"],
-                       "gather": head["gather"], "pipelined_steps": head["pipelined"], "parallelism": f"frame-sharded x{world}"},
+            "config": {"workload": f"job of {B} x {W}x{H} VarDCT d1 frames per GPU per step (XYB, ANS, var-block DCT8..32 mix, gaborish, EPF {args.epf}), u8 RGB out, through the library's streaming pipeline "
+                                   "(JxlHipPipelineSubmit / Wait): every step's compressed frames come from host memory and are parsed, prepared and uploaded inside the timed region, outputs stay in HBM",
+                       "mode": "streaming", "frames_per_gpu": B * inner, "frames_per_launch": B, "width": W, "height": H, "compressed_bytes_per_frame": head["compressed"],
+                       "lane_stride_lf": args.lane_stride_lf, "lane_stride_hf": args.lane_stride_hf, "jobs_in_flight": args.in_flight, "batch_objects": head["slots"],
+                       "gather": head["gather"], "pipeline": "library (csrc/pipeline.cc)", "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_ms": round(stage_ms[dom], 4)},
@@ -703,44 +597,32 @@ def main():
             # step (SQ_INSTS_VALU, profiles/sq_valu.json) against 256 CUs x 4 SIMDs issuing one wave64 FP32 instruction per 4 cycles at 2.4 GHz
             "valu_issue": _valu_issue(B, head["elapsed"] / args.steps, steady),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            # when the tail of every timed step had completed (ms after the start of the timed region): pipeline fill, then the steady state
+            # when every timed step's last byte had been written (ms after the start of the timed region, GPU clock): pipeline fill, then the steady state
             "step_end_ms": e, "steady_state_ms_per_step": steady,
             "stage_gbs": {k: round(stage_bytes[k] / (stage_ms[k] * 1e-3) / 1e9, 2) if stage_ms[k] > 0 else None for k in stage_ms},
             "device_bytes": head["device_bytes"],
+            "streaming": {"prepare_threads": args.prepare_threads, "parse_threads_per_job": args.parse_threads, "distinct_frames": args.distinct,
+                          "prepare_ms_per_job": round(head["prepare_ms_per_job"], 2), "prepare_ms_per_frame": round(head["prepare_ms_per_job"] / B, 4),
+                          "what": "prepare = parse on the parse threads + tables into pinned staging + upload and LF stage enqueued on a side stream, wall time of one worker thread of the pipeline per job"},
         }
-        if modes[0] == "streaming":
-            ps = head["prepare_s"]
-            result["streaming"] = {"prepare_threads": args.prepare_threads, "parse_threads_per_batch": args.parse_threads, "distinct_frames": args.distinct,
-                                   "prepare_ms_per_batch": round(1e3 * sum(ps) / max(1, len(ps)), 2), "prepare_ms_per_frame": round(1e3 * sum(ps) / max(1, len(ps)) / B, 4),
-                                   "what": "prepare = JxlHipBatchReset + JxlHipBatchAddImages (parse on the parse threads) + JxlHipBatchPrepare (tables, pinned staging, upload on a copy stream), wall time of one worker thread per batch"}
-        if "resident" in res and modes[0] != "resident":
-            rr = res["resident"]
-            result["resident_mpixel_per_s"] = round(rate(rr), 2)
-            result["resident"] = {"ms_per_step": round(rr["elapsed"] / args.steps * 1e3, 3), "stage_ms": {k: round(v, 4) for k, v in rr["stage_ms"].items()}, "step_end_ms": rr["step_end"],
-                                  "verified_vs_oracle": rr.get("verified"), "streaming_over_resident": round(rate(head) / rate(rr), 4)}
         result["config"]["nonzero_coefficients_per_frame"] = head["nonzeros"]
         result["config"]["bits_per_pixel"] = round(head["compressed"] * 8 / (W * H), 3)
+
+        def leg(r, what, extra=None):
+            d = {"what": what, "value": round(rate(r), 2), "unit": "Mpixel/s", "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3), "steady_state_ms_per_step": _steady(r["step_end"]),
+                 "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()}, "compressed_bytes_per_frame": r["compressed"], "bits_per_pixel": round(r["compressed"] * 8 / (W * H), 3),
+                 "nonzero_coefficients_per_frame": r["nonzeros"], "verified_vs_oracle": r.get("verified")}
+            d.update(extra or {})
+            return d
         if realistic is not None:
-            re_ = realistic["step_end"]; n_r = len(re_)
-            result["config"]["workload_realistic"] = {
-                "what": f"the same pipeline and mode on frames with photograph-like texture (bench.py _textured, {args.texture:g} sRGB levels): the bit rate of real cjxl -d 1 photographs",
-                "value": round(rate(realistic), 2), "unit": "Mpixel/s", "ms_per_step": round(realistic["elapsed"] / args.steps * 1e3, 3),
-                "steady_state_ms_per_step": round((re_[n_r * 2 // 3] - re_[n_r // 5]) / max(1, n_r * 2 // 3 - n_r // 5), 2) if n_r >= 10 else None,
-                "stage_ms": {k: round(v, 4) for k, v in realistic["stage_ms"].items()}, "compressed_bytes_per_frame": realistic["compressed"],
-                "bits_per_pixel": round(realistic["compressed"] * 8 / (W * H), 3), "nonzero_coefficients_per_frame": realistic["nonzeros"],
-                "distinct_frames": len(realistic_streams), "verified_vs_oracle": realistic.get("verified")}
+            result["config"]["workload_realistic"] = leg(realistic, f"the same pipeline on frames with photograph-like texture (bench.py _textured, {args.texture:g} sRGB levels): the bit rate of real cjxl -d 1 photographs",
+                                                         {"distinct_frames": len(realistic_streams)})
         if cjxl is not None:
-            ce_ = cjxl["step_end"]; n_c = len(ce_)
-            result["config"]["workload_cjxl_shape"] = {
-                "what": "the realistic-bit-rate frames with LF-group streams under the MA-tree shape of a default-effort cjxl encode (enc_modular.cc tree kinds 'WP fixed DC' + 'AC meta': "
-                        "weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients; row / N / W splits for the HF metadata) — the headline's and the realistic "
-                        "workload's LF trees are the gradient tree `cjxl --faster_decoding` picks, which the plain SIMT LF kernel was built around",
-                "value": round(rate(cjxl), 2), "unit": "Mpixel/s", "ms_per_step": round(cjxl["elapsed"] / args.steps * 1e3, 3),
-                "steady_state_ms_per_step": round((ce_[n_c * 2 // 3] - ce_[n_c // 5]) / max(1, n_c * 2 // 3 - n_c // 5), 2) if n_c >= 10 else None,
-                "stage_ms": {k: round(v, 4) for k, v in cjxl["stage_ms"].items()}, "compressed_bytes_per_frame": cjxl["compressed"],
-                "bits_per_pixel": round(cjxl["compressed"] * 8 / (W * H), 3), "lf_simt_frames": cjxl["lf_simt"][0], "lf_legacy_frames": cjxl["lf_simt"][1],
-                "lf_simt_weighted_predictor_kernel": bool(cjxl["lf_simt"][2]), "distinct_frames": len(cjxl_streams), "verified_vs_oracle": cjxl.get("verified"),
-                "batches_in_flight": cjxl["nbuf"], "lf_streams": args.wp_lf_streams}
+            result["config"]["workload_cjxl_shape"] = leg(cjxl, "the realistic-bit-rate frames with LF-group streams under the MA-tree shape of a default-effort cjxl encode (enc_modular.cc tree kinds 'WP fixed DC' + 'AC meta': "
+                                                          "weighted-predictor leaves under a fixed tree over property 15 for the LF coefficients; row / N / W splits for the HF metadata) — the headline's and the realistic "
+                                                          "workload's LF trees are the gradient tree `cjxl --faster_decoding` picks, which the plain SIMT LF kernel was built around",
+                                                          {"lf_simt_frames": cjxl["lf_simt"][0], "lf_legacy_frames": cjxl["lf_simt"][1], "lf_simt_weighted_predictor_kernel": bool(cjxl["lf_simt"][2]),
+                                                           "distinct_frames": len(cjxl_streams)})
         frames_total = world * B * inner * args.steps
         result["host_cpu"] = {"cpu_s_per_frame": round(head["cpu_s"] / frames_total, 6), "cores_busy": round(head["cpu_s"] / head["elapsed"], 2),
                               "what": "process CPU time of all ranks over the timed steps (parse + prepare + upload + enqueue threads) per decoded frame; cores_busy = CPU seconds per wall second: "
@@ -770,9 +652,71 @@ def main():
         if "verified" in head:
             result["verified_vs_oracle"] = head["verified"]
             result["verified_frames"] = head["verified_frames"]
-        if world == 1 and not args.no_extras:
+        if do_extras:
             torch.cuda.empty_cache()
-            result.update(extras(jx, torch, streams, W, H, local_rank))
+            jx.arena_pool_trim()
+            # ---- host pixels out: the API's contract is a host buffer (decode.rs:417-430) — the pipeline with pinned host destinations, copies overlapped with later jobs
+            try:
+                hb = max(8, min(64, B))
+                ho = measure(B=hb, host_out=True, in_flight=6, steps=max(10, min(args.steps, 30)))
+                px = hb * W * H * ho["steps"]
+                t = torch.empty(1 << 30, dtype=torch.uint8, device=dev); hbuf = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+                hbuf.copy_(t); torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(4):
+                    hbuf.copy_(t, non_blocking=True)
+                torch.cuda.synchronize(); d2h = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+                del t, hbuf
+                result["streaming_host_out"] = {"value": round(px / ho["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "frames_per_job": hb, "ms_per_job": round(ho["elapsed"] / ho["steps"] * 1e3, 3),
+                                                "d2h_gbs_measured": round(d2h, 1), "pcie_ceiling_mpixel_per_s": round(d2h * 1e9 / 3 / 1e6, 1),
+                                                "fraction_of_pcie_ceiling": round(px / ho["elapsed"] * 3 / (d2h * 1e9), 3), "verified_vs_oracle": ho.get("verified"),
+                                                "what": "the library pipeline with pinned host destinations (JxlHipPipelineSubmit host_out): host bytes in, host pixels out, the copy of job k under the decode of the jobs behind it"}
+            except Exception as ex:
+                result["streaming_host_out"] = {"error": repr(ex)}
+            torch.cuda.empty_cache(); jx.arena_pool_trim()
+            # ---- BASELINE configs 5 and 4 at full size: batch throughput through the pipeline + single image through decode_with, with their own stage times
+            if hdr_streams:
+                try:
+                    r5 = measure(hdr_streams, B=16, W=7680, H=4320, dtype="float32", in_flight=4, lf_streams=3, steps=max(6, min(args.steps, 12)))
+                    px = 16 * 7680 * 4320 * r5["steps"]
+                    sm, sb = r5["stage_ms"], r5["stage_bytes"]
+                    d5 = jx.decoder_builder()
+                    ts = []
+                    for _ in range(3):
+                        t0 = time.perf_counter(); d5.decode_with(hdr_streams[0], np.float32); ts.append((time.perf_counter() - t0) * 1e3)
+                    result["config"]["workload_8k_hdr_f32_epf3"] = {
+                        "what": "BASELINE config 5: 7680x4320 VarDCT frames, linear-light HDR (values up to 4.0, intensity target 1000), gaborish + EPF 3 iterations, f32 RGB out (398 MB per frame); jobs of 16 through the pipeline",
+                        "value": round(px / r5["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "ms_per_job": round(r5["elapsed"] / r5["steps"] * 1e3, 3), "single_image_ms": round(_median(ts), 2),
+                        "stage_ms": {k: round(v, 4) for k, v in sm.items()}, "stage_gbs": {k: round(sb[k] / (sm[k] * 1e-3) / 1e9, 2) if sm[k] > 0 else None for k in sm},
+                        "roofline_filter_stage": {"bound": "hbm", "kernel": "GaborishKernel + EpfKernel<0,1,2> + OutputKernel (stage by stage)", "achieved": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9, 2) if sm["filter"] > 0 else None,
+                                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sm["filter"] > 0 else None,
+                                                  "algorithmic_bytes_per_launch": sb["filter"], "avg_launch_ms": round(sm["filter"], 3)},
+                        "compressed_bytes_per_frame": r5["compressed"], "verified_vs_oracle_bit_exact": r5.get("verified"), "private_plane_jobs": r5["private_plane_jobs"]}
+                except Exception as ex:
+                    result["config"]["workload_8k_hdr_f32_epf3"] = {"error": repr(ex)}
+                torch.cuda.empty_cache(); jx.arena_pool_trim()
+            if mod_streams:
+                try:
+                    r4 = measure(mod_streams, B=8, W=8192, H=8192, dtype="uint16", nch=1, in_flight=3, lf_streams=2, steps=max(6, min(args.steps, 10)))
+                    px = 8 * 8192 * 8192 * r4["steps"]
+                    sm, sb = r4["stage_ms"], r4["stage_bytes"]
+                    d4 = jx.decoder_builder()
+                    ts = []
+                    for _ in range(3):
+                        t0 = time.perf_counter(); d4.decode_with(mod_streams[0], np.uint16); ts.append((time.perf_counter() - t0) * 1e3)
+                    result["config"]["workload_8k_modular_squeeze_u16"] = {
+                        "what": "BASELINE config 4: lossless Modular 8192x8192 u16 (one channel), default Squeeze chain, 1024 groups + 16 LF groups of residual channels; jobs of 8 through the pipeline; stage 'lf' = global "
+                                "Modular stream (ModularGlobalFastKernel), 'out' = group sub-streams (ModularGroupFastKernel), inverse Squeeze and the write stage",
+                        "value": round(px / r4["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "ms_per_job": round(r4["elapsed"] / r4["steps"] * 1e3, 3), "single_image_ms": round(_median(ts), 2),
+                        "stage_ms": {k: round(v, 4) for k, v in sm.items()}, "compressed_bytes_per_frame": r4["compressed"], "verified_vs_oracle": r4.get("verified")}
+                except Exception as ex:
+                    result["config"]["workload_8k_modular_squeeze_u16"] = {"error": repr(ex)}
+                torch.cuda.empty_cache(); jx.arena_pool_trim()
+            try:
+                result.update(extras(jx, torch, streams, cjxl_streams, W, H, local_rank, O, np))
+            except Exception as ex:
+                result["extras_error"] = repr(ex)
+            torch.cuda.empty_cache(); jx.arena_pool_trim()
+            result["api_concurrent"] = api_concurrent(streams, O, np)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
