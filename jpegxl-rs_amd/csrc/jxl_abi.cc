@@ -506,9 +506,8 @@ JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* d, const JxlBitDepth*
 }
 
 // ---- decode.rs:1326-1470: container boxes
-static void ScanBoxes(JxlDecoder* d) {
-  d->boxes.clear(); d->box_next = 0; d->box_split = 0; d->box_current = -1;
-  const uint8_t* data = d->container.data(); const size_t size = d->container.size();
+static void ScanBoxesOf(const uint8_t* data, size_t size, vec<JxlDecoderStruct::BoxRec>* boxes, size_t* split) {
+  boxes->clear(); *split = 0;
   size_t pos = 0; bool seen_cs = false;
   while (pos + 8 <= size) {
     uint64_t bs = ((uint64_t)data[pos] << 24) | ((uint64_t)data[pos + 1] << 16) | ((uint64_t)data[pos + 2] << 8) | data[pos + 3];
@@ -521,11 +520,15 @@ static void ScanBoxes(JxlDecoder* d) {
     b.raw_size = bs; b.body = pos + hdr; b.body_size = end - (pos + hdr);
     b.brob = !memcmp(b.type, "brob", 4) && b.body_size >= 4;
     if (b.brob) memcpy(b.real, data + b.body, 4);
-    d->boxes.push_back(b);
-    if (!seen_cs && (!memcmp(b.type, "jxlc", 4) || !memcmp(b.type, "jxlp", 4))) { seen_cs = true; d->box_split = d->boxes.size(); }
+    boxes->push_back(b);
+    if (!seen_cs && (!memcmp(b.type, "jxlc", 4) || !memcmp(b.type, "jxlp", 4))) { seen_cs = true; *split = boxes->size(); }
     pos = end;
   }
-  if (!seen_cs) d->box_split = d->boxes.size();
+  if (!seen_cs) *split = boxes->size();
+}
+static void ScanBoxes(JxlDecoder* d) {
+  d->box_next = 0; d->box_current = -1;
+  ScanBoxesOf(d->container.data(), d->container.size(), &d->boxes, &d->box_split);
 }
 // content of the current box as the caller gets it: the payload, or — `brob` box with decompression on — the decompressed payload behind the 4-byte type
 static bool BoxContent(JxlDecoder* d, const uint8_t** src, size_t* n) {
@@ -1058,6 +1061,15 @@ int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap)
       std::string why;
       const bool ok = b.CanReconstructJpeg(0, &why);
       s += ok ? std::string("jpeg_reconstruction=1\n") : "jpeg_reconstruction=0 reason: " + why + "\n";
+    }
+    if (b.image(0).ih.have_container) {
+      // the box walk of the decoder's box API (ScanBoxes), on the same bytes
+      vec<JxlDecoderStruct::BoxRec> boxes; size_t split = 0;
+      ScanBoxesOf(data, size, &boxes, &split);
+      snprintf(line, sizeof line, "boxes=%zu before_codestream=%zu:", boxes.size(), split);
+      s += line;
+      for (auto& bx : boxes) { snprintf(line, sizeof line, " %.4s(%zu)", bx.type, bx.body_size); s += line; }
+      s += "\n";
     }
     if (out && cap) { const size_t n = std::min(cap - 1, s.size()); memcpy(out, s.data(), n); out[n] = 0; }
     return 0;

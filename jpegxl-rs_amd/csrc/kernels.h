@@ -1,6 +1,11 @@
 // jxl-hip: device-side frame descriptor + kernel launch interface (implemented in kernels.hip).
 #pragma once
 #include "jxl_dev.h"
+#if !defined(__HIPCC__)
+// host-only builds of the library's host sources (the sanitizer build, tests/test_sanitizers.py): the runtime API and the vector types, no device code
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#endif
 
 namespace jxlhip {
 
