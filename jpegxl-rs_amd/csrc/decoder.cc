@@ -2134,7 +2134,13 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
   // event between them (bench.py starts the LF stage of a later batch when an HF stage has ended, not when it starts).
   hipStream_t stream = (hipStream_t)stream_v;
   if (!prepared_) Prepare(stream_v);
-  (void)hipGetLastError();          // (whatever an earlier runtime call of this thread left unread is not this decode's)
+  // (whatever an earlier runtime call of this thread left unread is not this decode's — it is named on stderr once, not silently dropped, and then cleared so that
+  // the checks behind this part's launches report this part's launches only)
+  if (const hipError_t stale = hipPeekAtLastError()) {
+    static std::atomic<bool> told{false};
+    if (!told.exchange(true)) fprintf(stderr, "[jxl-hip] a HIP error left pending by an earlier call on this thread (not by this decode) is being cleared: %s\n", hipGetErrorString(stale));
+    (void)hipGetLastError();
+  }
   const int n = (int)images_.size();
   if (any_vardct_) CheckFilterBuffers();
   // The front, too, comes in two pieces: 5 = LF decode (what the HF stage needs: block info, varblock lists, coefficient offsets),

@@ -45,7 +45,7 @@ struct JxlDecoderStruct {
   vec<uint8_t> container; vec<BoxRec> boxes;
   size_t box_next, box_split; int box_current; bool box_complete_pending;
   vec<uint8_t> box_plain; bool box_plain_ready; size_t box_written;
-  uint8_t* box_buffer; size_t box_size, box_buffer_written; bool box_set;
+  uint8_t* box_buffer; size_t box_size, box_buffer_written; bool box_set; int box_buffer_for;
   // progress
   enum Stage { kInit, kHeaders, kFrame, kDone } stage;
   int events_emitted;
@@ -98,7 +98,7 @@ static void ClearState(JxlDecoder* d) {
   d->mt_init = nullptr; d->mt_run = nullptr; d->mt_destroy = nullptr; d->mt_opaque = nullptr;
   d->ec_buffers.clear(); d->progressive_detail = 0; d->out_int_bits = 0;
   d->decompress_boxes = false; d->container.clear(); d->boxes.clear(); d->box_next = d->box_split = 0; d->box_current = -1; d->box_complete_pending = false;
-  d->box_plain.clear(); d->box_plain_ready = false; d->box_written = 0; d->box_buffer = nullptr; d->box_size = d->box_buffer_written = 0; d->box_set = false;
+  d->box_plain.clear(); d->box_plain_ready = false; d->box_written = 0; d->box_buffer = nullptr; d->box_size = d->box_buffer_written = 0; d->box_set = false; d->box_buffer_for = -1;
   DeleteBatch(d->batch); d->batch = nullptr;
 }
 // frames JXL_DEC_FRAME / JXL_DEC_FULL_IMAGE are reported for
@@ -546,7 +546,7 @@ static JxlDecoderStatus PumpBoxes(JxlDecoder* d, size_t upto) {
   if (!(d->events_wanted & (JXL_DEC_BOX | JXL_DEC_BOX_COMPLETE))) return JXL_DEC_SUCCESS;
   for (;;) {
     if (d->box_current >= 0) {
-      if (d->box_set) {
+      if (d->box_set && d->box_buffer_for == d->box_current) {      // (libjxl writes a buffer with the box it was set for only: one that is still set when the next box is announced is left alone)
         const uint8_t* src; size_t n;
         if (!BoxContent(d, &src, &n)) return JXL_DEC_ERROR;
         const size_t k = std::min(n - d->box_written, d->box_size - d->box_buffer_written);
@@ -564,7 +564,8 @@ static JxlDecoderStatus PumpBoxes(JxlDecoder* d, size_t upto) {
 }
 JxlDecoderStatus JxlDecoderSetBoxBuffer(JxlDecoder* d, uint8_t* data, size_t size) {
   if (!d || d->box_set) { SetLastError("a box buffer is already set: JxlDecoderReleaseBoxBuffer first"); return JXL_DEC_ERROR; }
-  d->box_buffer = data; d->box_size = size; d->box_buffer_written = 0; d->box_set = true;
+  if (d->box_current < 0) { SetLastError("no box is current: JxlDecoderSetBoxBuffer follows a JXL_DEC_BOX event"); return JXL_DEC_ERROR; }
+  d->box_buffer = data; d->box_size = size; d->box_buffer_written = 0; d->box_set = true; d->box_buffer_for = d->box_current;
   return JXL_DEC_SUCCESS;
 }
 size_t JxlDecoderReleaseBoxBuffer(JxlDecoder* d) {
@@ -598,7 +599,7 @@ JxlDecoderStatus JxlDecoderGetBoxSizeRaw(JxlDecoder* d, uint64_t* size) {
 JxlDecoderStatus JxlDecoderGetBoxSizeContents(JxlDecoder* d, uint64_t* size) {
   if (!d || !size || d->box_current < 0) return JXL_DEC_ERROR;
   const JxlDecoderStruct::BoxRec& b = d->boxes[(size_t)d->box_current];
-  *size = b.raw_size == 0 ? 0 : b.body_size;               // (libjxl: 0 for a box of unbounded size)
+  *size = b.raw_size == 0 ? 0 : b.body_size;               // (libjxl: 0 for a box of unbounded size; a brob box's 4-byte inner type is part of what is handed out undecompressed, so it counts)
   return JXL_DEC_SUCCESS;
 }
 
@@ -1068,7 +1069,11 @@ int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap)
       ScanBoxesOf(data, size, &boxes, &split);
       snprintf(line, sizeof line, "boxes=%zu before_codestream=%zu:", boxes.size(), split);
       s += line;
-      for (auto& bx : boxes) { snprintf(line, sizeof line, " %.4s(%zu)", bx.type, bx.body_size); s += line; }
+      for (auto& bx : boxes) {
+        char t[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < 4; k++) t[k] = (bx.type[k] >= 0x20 && bx.type[k] < 0x7F) ? bx.type[k] : '?';      // (damaged files: keep the text printable)
+        snprintf(line, sizeof line, " %s(%zu)", t, bx.body_size); s += line;
+      }
       s += "\n";
     }
     if (out && cap) { const size_t n = std::min(cap - 1, s.size()); memcpy(out, s.data(), n); out[n] = 0; }

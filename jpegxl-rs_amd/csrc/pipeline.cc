@@ -234,6 +234,8 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     }
     if (!any) { j->job_error = "no image of the job could be parsed"; return; }
     bt.cfg.lane_stride_lf = opt_.lane_stride_lf; bt.cfg.lane_stride_hf = opt_.lane_stride_hf; bt.cfg.no_flag_wait = opt_.no_flag_wait;
+    // a handful of frames: one group stream per wavefront in the HF stage, too (33 instead of 41 ms for one 4K frame; from a few dozen frames on the SIMT form wins)
+    if (opt_.hf_wave_below > 0 && n <= opt_.hf_wave_below) bt.cfg.lane_stride_hf = 64;
     bt.UseSharedPlanes(&big_, &coef_[(size_t)(j->ticket % ncoef_)]);
     // tables + upload go to the stream the job's LF stage runs on, which follows without a host-side wait (an upload stream of its own was seen waiting tens of
     // milliseconds behind other streams' entropy kernels)
