@@ -41,12 +41,12 @@ def _pmc_bytes(kernels, frames):
 
 
 def _valu_issue(frames, s_per_step, steady_ms):
-    """VALU issue rate of a step: wavefront-instructions per second over the chip's peak (1024 SIMDs, one wave64 FP32 instruction per 4 cycles, 2.4 GHz) — a lower bound of
+    """VALU issue rate of a step: wavefront-instructions per second over the chip's measured peak (tools/microbench/valu_issue.hip: 8.96e11 per second, one wave64 FP32 instruction per 2.7 cycles of the nominal 2.4 GHz per SIMD) — a lower bound of
     how busy the vector ALUs are (transcendental and 64-bit operations take longer than 4 cycles).  Counts from the SQ counter passes of the round (profiles/sq_valu.json)."""
     try:
         per = json.load(open(os.path.join(ROOT, "profiles", "sq_valu.json")))["per_kernel"]
         instr = sum(v["valu_wave_instr_per_frame"] for v in per.values() if v["calls"] == 2) * frames
-        peak = 256 * 4 * 2.4e9 / 4
+        peak = 8.96e11          # measured: tools/microbench/valu_issue.hip, 8 wavefronts per SIMD of independent v_fma_f32 (profiles/r05_notes.md; rounds 3-4 assumed 6.14e11 = 4 cycles per instruction)
         out = {"wave_instr_per_step": int(instr), "peak_wave_instr_per_s": peak, "frac": round(instr / s_per_step / peak, 4)}
         if steady_ms:
             out["frac_steady_state"] = round(instr / (steady_ms * 1e-3) / peak, 4)
@@ -594,7 +594,7 @@ def main():
                                                      "traffic": pf, "algorithmic_bytes_per_launch": by, "avg_launch_ms": round(ms, 4)})(
                 stage_ms.get("idct", 0.0), stage_bytes.get("idct", 0), _pmc_bytes(("IdctTileKernel<4, true>", "IdctRareSpecialKernel"), B)),
             # what the step as a whole runs into is neither HBM nor MFMA but vector-ALU issue (profiles/r03_notes.md): VALU wavefront-instructions of all kernels of a
-            # step (SQ_INSTS_VALU, profiles/sq_valu.json) against 256 CUs x 4 SIMDs issuing one wave64 FP32 instruction per 4 cycles at 2.4 GHz
+            # step (SQ_INSTS_VALU, profiles/sq_valu.json) against the measured issue peak of the chip (tools/microbench/valu_issue.hip)
             "valu_issue": _valu_issue(B, head["elapsed"] / args.steps, steady),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             # when every timed step's last byte had been written (ms after the start of the timed region, GPU clock): pipeline fill, then the steady state
@@ -676,18 +676,18 @@ def main():
             # ---- BASELINE configs 5 and 4 at full size: batch throughput through the pipeline + single image through decode_with, with their own stage times
             if hdr_streams:
                 try:
-                    r5 = measure(hdr_streams, B=16, W=7680, H=4320, dtype="float32", in_flight=4, lf_streams=3, steps=max(6, min(args.steps, 12)))
-                    px = 16 * 7680 * 4320 * r5["steps"]
+                    r5 = measure(hdr_streams, B=32, W=7680, H=4320, dtype="float32", in_flight=4, lf_streams=3, steps=max(6, min(args.steps, 12)))
+                    px = 32 * 7680 * 4320 * r5["steps"]
                     sm, sb = r5["stage_ms"], r5["stage_bytes"]
                     d5 = jx.decoder_builder()
                     ts = []
                     for _ in range(3):
                         t0 = time.perf_counter(); d5.decode_with(hdr_streams[0], np.float32); ts.append((time.perf_counter() - t0) * 1e3)
                     result["config"]["workload_8k_hdr_f32_epf3"] = {
-                        "what": "BASELINE config 5: 7680x4320 VarDCT frames, linear-light HDR (values up to 4.0, intensity target 1000), gaborish + EPF 3 iterations, f32 RGB out (398 MB per frame); jobs of 16 through the pipeline",
+                        "what": "BASELINE config 5: 7680x4320 VarDCT frames, linear-light HDR (values up to 4.0, intensity target 1000), gaborish + EPF 3 iterations, f32 RGB out (398 MB per frame); jobs of 32 through the pipeline",
                         "value": round(px / r5["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "ms_per_job": round(r5["elapsed"] / r5["steps"] * 1e3, 3), "single_image_ms": round(_median(ts), 2),
                         "stage_ms": {k: round(v, 4) for k, v in sm.items()}, "stage_gbs": {k: round(sb[k] / (sm[k] * 1e-3) / 1e9, 2) if sm[k] > 0 else None for k in sm},
-                        "roofline_filter_stage": {"bound": "hbm", "kernel": "GaborishKernel + EpfKernel<0,1,2> + OutputKernel (stage by stage)", "achieved": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9, 2) if sm["filter"] > 0 else None,
+                        "roofline_filter_stage": {"bound": "hbm", "kernel": "GaborishKernel + EpfTileKernel<0> + <1> + <2> (LDS tiles; the last pass writes the pixels)", "achieved": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9, 2) if sm["filter"] > 0 else None,
                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sm["filter"] > 0 else None,
                                                   "algorithmic_bytes_per_launch": sb["filter"], "avg_launch_ms": round(sm["filter"], 3)},
                         "compressed_bytes_per_frame": r5["compressed"], "verified_vs_oracle_bit_exact": r5.get("verified"), "private_plane_jobs": r5["private_plane_jobs"]}

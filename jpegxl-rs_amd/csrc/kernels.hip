@@ -3755,24 +3755,10 @@ __global__ void UpsampleKernel(const FrameDev* __restrict__ frames) {
   }
 }
 
-__global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
-  const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular || f.post_mode || FusedEligible(f, unfused)) return;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= (int)f.img_w || y >= (int)f.img_h) return;
-  float X, Y, B, A = 1.0f;
-  if (f.upsampling > 1) {
-    const size_t o = (size_t)y * f.img_w + x;
-    X = f.up_plane[0][o]; Y = f.up_plane[1][o]; B = f.up_plane[2][o];
-    if (f.alpha_plane) A = f.up_plane[3][o];
-  } else {
-    const bool src_is_a = (FilterStagesBefore(f, 4) & 1) == 0;
-    const size_t o = (size_t)y * f.plane_stride + x;
-    X = (src_is_a ? f.plane_a[0] : f.plane_b[0])[o];
-    Y = (src_is_a ? f.plane_a[1] : f.plane_b[1])[o];
-    B = (src_is_a ? f.plane_a[2] : f.plane_b[2])[o];
-    if (f.alpha_plane) A = (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor;
-  }
+__device__ __forceinline__ uint32_t XcdContiguous(uint32_t bid, uint32_t nwg);
+// XYB (or YCbCr / RGB) sample of image position (x, y) -> colour transform -> transfer function -> the caller's layout: the tail of OutputKernel, shared with the last
+// EPF pass of the tiled filter path (EpfTileKernel), which hands its results over in registers instead of through a plane
+__device__ __forceinline__ void ColorAndStore(const FrameDev& f, int x, int y, float X, float Y, float B, float A) {
   float r, g, b;
   if (f.color_mode <= 1 || f.color_mode >= 4) {
     const float gr = (Y + X) - f.neg_bias_cbrt[0];
@@ -3801,6 +3787,122 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused) {
   } else { r = X; g = Y; b = B; }
   if (f.is_gray) r = g;
   StorePixel(f, x, y, r, g, b, A);
+}
+// frames whose last EPF pass writes the pixels itself (EpfTileKernel; fuse_out = 0: a test stops the tail between the stages)
+__device__ __forceinline__ bool EpfWritesOutput(const FrameDev& f, int unfused, int fuse_out) {
+  return fuse_out && !FusedEligible(f, unfused) && f.epf_iters >= 1 && f.upsampling == 1 && f.post_mode == 0;
+}
+
+__global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused, int fuse_out) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular || f.post_mode || FusedEligible(f, unfused) || EpfWritesOutput(f, unfused, fuse_out)) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= (int)f.img_w || y >= (int)f.img_h) return;
+  float X, Y, B, A = 1.0f;
+  if (f.upsampling > 1) {
+    const size_t o = (size_t)y * f.img_w + x;
+    X = f.up_plane[0][o]; Y = f.up_plane[1][o]; B = f.up_plane[2][o];
+    if (f.alpha_plane) A = f.up_plane[3][o];
+  } else {
+    const bool src_is_a = (FilterStagesBefore(f, 4) & 1) == 0;
+    const size_t o = (size_t)y * f.plane_stride + x;
+    X = (src_is_a ? f.plane_a[0] : f.plane_b[0])[o];
+    Y = (src_is_a ? f.plane_a[1] : f.plane_b[1])[o];
+    B = (src_is_a ? f.plane_a[2] : f.plane_b[2])[o];
+    if (f.alpha_plane) A = (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor;
+  }
+  ColorAndStore(f, x, y, X, Y, B, A);
+}
+
+// =====================================================================================================================
+// EPF pass on 32x32 pixel tiles out of LDS (frames the fused gaborish + EPF 1 kernel does not take: two or three EPF iterations, other transfer functions,
+// no gaborish ...).  The stage-by-stage kernel this replaces read every tap from global memory with mirrored coordinates worked out per tap — pass 0 is 12 taps x 3
+// channels x 5-sample plus shapes x 2 = 360 loads per pixel — and spilled 90 registers.  Here a workgroup loads the tile with a halo of 3 / 2 / 1 samples (the
+// stage's reach: taps + plus shape) once, mirrored at the image border like every stage of libjxl's pipeline mirrors its own input, and every thread works four
+// pixels out of LDS with the arithmetic and operation order of stage_epf.cc (= EpfKernel): results are bit-identical.  The last active pass hands its pixels
+// straight to the colour transform and the write stage (no plane in between) unless something else follows (upsampling, the frame tail of complex images).
+// =====================================================================================================================
+constexpr int kEtT = 32;                                   // tile edge
+template <int PASS> struct EpfTileGeom { static constexpr int kHalo = PASS == 0 ? 3 : PASS == 1 ? 2 : 1, kR = kEtT + 2 * kHalo, kP = kR + 1; };
+template <int PASS> __global__ __launch_bounds__(256) void EpfTileKernel(const FrameDev* __restrict__ frames, int unfused, int tiles_x, int fuse_out) {
+  const FrameDev& f = frames[blockIdx.z];
+  constexpr int stage = PASS + 1;
+  if (f.is_modular || !FilterStageActive(f, stage) || FusedEligible(f, unfused)) return;
+  const int w = (int)f.width, h = (int)f.height;
+  const uint32_t tile = XcdContiguous(blockIdx.x, gridDim.x);
+  const int x0 = (int)(tile % (uint32_t)tiles_x) * kEtT, y0 = (int)(tile / (uint32_t)tiles_x) * kEtT;
+  if (x0 >= w || y0 >= h) return;
+  constexpr int H = EpfTileGeom<PASS>::kHalo, R = EpfTileGeom<PASS>::kR, P = EpfTileGeom<PASS>::kP;
+  __shared__ float s_t[3 * R * P];
+  const bool src_is_a = (FilterStagesBefore(f, stage) & 1) == 0;
+  const size_t stride = f.plane_stride;
+  const float* src[3]; float* dst[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) { src[c] = src_is_a ? f.plane_a[c] : f.plane_b[c]; dst[c] = src_is_a ? f.plane_b[c] : f.plane_a[c]; }
+  for (int i = threadIdx.x; i < R * R; i += 256) {
+    const int ly = i / R, lx = i - ly * R;
+    const size_t o = (size_t)MirrorD(y0 + ly - H, h) * stride + MirrorD(x0 + lx - H, w);
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_t[(c * R + ly) * P + lx] = LdG(src[c] + o);
+  }
+  __syncthreads();
+  const bool last = PASS == 2 || (PASS == 1 && f.epf_iters == 1);
+  const bool write_out = last && EpfWritesOutput(f, unfused, fuse_out);
+  const float cs0 = f.epf_channel_scale[0], cs1 = f.epf_channel_scale[1], cs2 = f.epf_channel_scale[2];
+  constexpr int ntaps = PASS == 0 ? 12 : 4;
+  constexpr int taps0[12][2] = {{0, -2}, {-1, -1}, {0, -1}, {1, -1}, {-2, 0}, {-1, 0}, {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {0, 2}};
+  constexpr int taps1[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  constexpr int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    const int lx = threadIdx.x & 31, ly = (threadIdx.x >> 5) + 8 * q;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) continue;
+    const float* t0 = s_t + (ly + H) * P + (lx + H);        // centre sample of channel 0
+    auto px = [&](int c, int dx, int dy) -> float { return t0[c * R * P + dy * P + dx]; };
+    float out[3];
+    const float is = f.inv_sigma[(size_t)(y / 8) * f.bw + x / 8];
+    if (is < -3.90524291751269967465540850526868f) { out[0] = px(0, 0, 0); out[1] = px(1, 0, 0); out[2] = px(2, 0, 0); }
+    else {
+      const bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
+      const float vmul = is * (border ? f.epf_bsm[PASS] : f.epf_sm[PASS]);
+      float wsum = 1.0f;
+      float acc[3] = {px(0, 0, 0), px(1, 0, 0), px(2, 0, 0)};
+#pragma unroll
+      for (int t = 0; t < ntaps; t++) {
+        const int dx = PASS == 0 ? taps0[t][0] : taps1[t][0], dy = PASS == 0 ? taps0[t][1] : taps1[t][1];
+        float sad = 0.f;
+        if (PASS == 2) {
+          sad = fmaf(fabsf(px(0, dx, dy) - px(0, 0, 0)), cs0, sad);
+          sad = fmaf(fabsf(px(1, dx, dy) - px(1, 0, 0)), cs1, sad);
+          sad = fmaf(fabsf(px(2, dx, dy) - px(2, 0, 0)), cs2, sad);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; k++) s += fabsf(px(c, dx + plus[k][0], dy + plus[k][1]) - px(c, plus[k][0], plus[k][1]));
+            sad = fmaf(s, c == 0 ? cs0 : c == 1 ? cs1 : cs2, sad);
+          }
+        }
+        const float wgt = fmaxf(0.0f, fmaf(sad, vmul, 1.0f));
+        wsum += wgt;
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] = fmaf(wgt, px(c, dx, dy), acc[c]);
+      }
+      const float inv = 1.0f / wsum;
+#pragma unroll
+      for (int c = 0; c < 3; c++) out[c] = acc[c] * inv;
+    }
+    if (write_out) {
+      const float A = f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f;
+      ColorAndStore(f, x, y, out[0], out[1], out[2], A);
+    } else {
+      const size_t o = (size_t)y * stride + x;
+#pragma unroll
+      for (int c = 0; c < 3; c++) dst[c][o] = out[c];
+    }
+  }
 }
 
 // =====================================================================================================================
@@ -4647,7 +4749,10 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     // lanes per workgroup: the groups of a frame spread evenly over as few workgroups as possible, whole wavefronts (a
     // 3840x2160 frame has 135 groups: 192 threads, 136 lane regions, 80 KB of LDS instead of 99 KB — which is what lets two
     // LF workgroups share the CU with it)
-    const int nblk = DivUp(max_groups, (int)kSimtMaxThreads);
+    // (at most ~136 group streams per workgroup — a 4K frame's 135 in one —: an 8K frame's 510 spread over four workgroups of 128 lanes, 32 per wavefront, decode in a
+    // third of the time two workgroups of 255 took — 64 streams per wavefront run every path of the lock-step loop in every iteration)
+    static const int lanes_cap = getenv("JXL_HIP_HF_LANES_PER_WG") ? std::max(16, std::min((int)kSimtMaxThreads, atoi(getenv("JXL_HIP_HF_LANES_PER_WG")))) : 136;
+    const int nblk = DivUp(max_groups, lanes_cap);
     const uint32_t lanes = (uint32_t)DivUp(max_groups, nblk);
     static const int lpw_env = getenv("JXL_HIP_HF_LANES") ? atoi(getenv("JXL_HIP_HF_LANES")) : 0;
     // streams per wavefront: four wavefronts per workgroup, one per SIMD (two of these on one SIMD slow each other down
@@ -4749,16 +4854,28 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
   // (cfg.debug_stop_after, testing: 2 = stop after gaborish, 3 / 4 / 5 = after EPF pass 0 / 1 / 2 — the planes are then read back, JxlHipBatchDebugRead)
   const int stop = cfg.debug_stop_after ? cfg.debug_stop_after : 99;
   if (fp.any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames, unfused);
-  if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames, unfused);
-  if (fp.max_epf >= 1 && stop >= 4) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames, unfused);
-  if (fp.max_epf >= 2 && stop >= 5) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  // the EPF passes on LDS tiles (JXL_HIP_EPF_STAGED=1: the per-pixel kernels they replaced — same results, an A/B knob)
+  static const bool staged = getenv("JXL_HIP_EPF_STAGED") != nullptr;
+  const int fuse_out = cfg.debug_stop_after ? 0 : 1;
+  if (staged) {
+    if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+    if (fp.max_epf >= 1 && stop >= 4) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+    if (fp.max_epf >= 2 && stop >= 5) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames, unfused);
+    return;
+  }
+  const int etx = DivUp(max_w, kEtT);
+  const dim3 tgrid(etx * DivUp(max_h, kEtT), 1, nframes);
+  if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfTileKernel<0>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
+  if (fp.max_epf >= 1 && stop >= 4) hipLaunchKernelGGL(EpfTileKernel<1>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
+  if (fp.max_epf >= 2 && stop >= 5) hipLaunchKernelGGL(EpfTileKernel<2>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
 }
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   if (!fp.any_unfused && !cfg.force_unfused_filters) return;
   const int ow = std::max(max_w, fp.max_out_w), oh = std::max(max_h, fp.max_out_h);   // upsampled frames write more pixels than they code
   dim3 block(64, 4), grid(DivUp(ow, 64), DivUp(oh, 4), nframes);
   if (fp.any_upsampled) hipLaunchKernelGGL(UpsampleKernel, grid, block, 0, (hipStream_t)stream, frames);
-  hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters);
+  static const bool staged = getenv("JXL_HIP_EPF_STAGED") != nullptr;
+  hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters, (cfg.debug_stop_after || staged) ? 0 : 1);
 }
 void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream);
 // LDS plan of the Modular kernels: per-wavefront regions, tree region (whole tree or pruned per-wavefront slices), the
