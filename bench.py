@@ -198,7 +198,7 @@ class Run:
     consumer: "none" (pixels stay where they were decoded), "gather" (RCCL point-to-point gather to rank 0, north_star's mode), "per_rank" (a reduction over the decoded
     pixels on a side stream stands in for a consumer on every rank; the ranks exchange the 8-byte checksums at the end)."""
 
-    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, W, H, dtype="uint8", nch=3, consumer="none", in_flight=None, lf_streams=None, host_out=False):
+    def __init__(self, args, jx, torch, dist, streams, dev, local_rank, rank, world, B, inner, W, H, dtype="uint8", nch=3, consumer="none", in_flight=None, lf_streams=None, host_out=False, plane_sets=1):
         import numpy as np
         self.args, self.jx, self.torch, self.dist, self.streams = args, jx, torch, dist, streams
         self.dev, self.rank, self.world, self.B, self.inner, self.W, self.H, self.dtype, self.nch = dev, rank, world, B, inner, W, H, dtype, nch
@@ -211,7 +211,7 @@ class Run:
             in_flight = min(args.in_flight, 7)    # (a consumer needs one output buffer per batch object + 1 — 6.4 GB each at 256 frames —, beside rank 0's job buffer)
         self.p = jx.Pipeline(local_rank, timed=1, jobs_in_flight=in_flight or args.in_flight, lf_streams=lf_streams or args.lf_streams, hf_streams=args.hf_streams,
                              prepare_threads=args.prepare_threads, parse_threads=args.parse_threads, lane_stride_lf=args.lane_stride_lf, lane_stride_hf=args.lane_stride_hf,
-                             wide_first=args.wide_first, reserve_frames=B, reserve_width=W, reserve_height=H)
+                             wide_first=args.wide_first, reserve_frames=B, reserve_width=W, reserve_height=H, reserve_plane_sets=plane_sets)
         self.slots = self.p.info("slots")
         # output buffers: two when nobody reads them; with a consumer (gather / reduction on a side stream) one more than the jobs the pipeline can hold, so that a job never
         # writes where the consumer of an earlier one may still be reading
@@ -522,6 +522,7 @@ def main():
         steps, warmup = kw.pop("steps", args.steps), args.warmup
         r = Run(args, jx, torch, dist, streams, dev, local_rank, rank, world, kw.pop("B", B), inner, kw.pop("W", W), kw.pop("H", H), consumer=consumer, **kw)
         r.stream_texture, r.stream_tree_shape = texture, tree_shape
+        r.run(1)                              # (a first job alone: should the shared planes be too small for this shape they grow before the ring fills)
         r.run(r.slots)                        # every batch object of the ring allocates its arenas (untimed set-up)
         r.run(warmup * inner)
         r.p.collect_times()
@@ -676,7 +677,7 @@ def main():
             # ---- BASELINE configs 5 and 4 at full size: batch throughput through the pipeline + single image through decode_with, with their own stage times
             if hdr_streams:
                 try:
-                    r5 = measure(hdr_streams, B=32, W=7680, H=4320, dtype="float32", in_flight=4, lf_streams=3, steps=max(6, min(args.steps, 12)))
+                    r5 = measure(hdr_streams, B=32, W=7680, H=4320, dtype="float32", in_flight=4, lf_streams=3, plane_sets=2, steps=max(6, min(args.steps, 12)))
                     px = 32 * 7680 * 4320 * r5["steps"]
                     sm, sb = r5["stage_ms"], r5["stage_bytes"]
                     d5 = jx.decoder_builder()

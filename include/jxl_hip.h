@@ -305,6 +305,7 @@ typedef struct {
   int32_t small_job_frames;  /* jobs of at most this many frames always take it (latency over occupancy); 0 = never */
   int32_t timed;             /* bracket the stages with HIP events: JxlHipPipelineCollectTimes */
   int32_t reserve_frames, reserve_width, reserve_height;   /* size the shared planes for jobs of this shape at creation (0: grown when the pipeline is idle) */
+  int32_t reserve_plane_sets; /* 2: the frames take the stage-by-stage restoration filters (anything but gaborish + one EPF pass) and need a second set of pixel planes */
 } JxlHipPipelineOptions;
 JxlHipPipeline* JxlHipPipelineCreate(int device, const JxlHipPipelineOptions* options /* NULL = defaults */);
 void JxlHipPipelineDestroy(JxlHipPipeline* pipeline);

@@ -91,7 +91,7 @@ class JxlHipStageTimes(C.Structure):
 class JxlHipPipelineOptions(C.Structure):
     """include/jxl_hip.h JxlHipPipelineOptions (0 / negative = the library's default)"""
     _fields_ = [(n, C.c_int32) for n in ("jobs_in_flight", "lf_streams", "hf_streams", "prepare_threads", "parse_threads", "lane_stride_lf", "lane_stride_hf", "wide_first",
-                                         "small_job_frames", "timed", "reserve_frames", "reserve_width", "reserve_height")]
+                                         "small_job_frames", "timed", "reserve_frames", "reserve_width", "reserve_height", "reserve_plane_sets")]
 
 
 assert C.sizeof(JxlBasicInfo) == 204 and C.sizeof(JxlPixelFormat) == 24 and C.sizeof(JxlMemoryManager) == 24

@@ -911,7 +911,7 @@ JxlHipPipeline* JxlHipPipelineCreate(int device, const JxlHipPipelineOptions* o)
       po.lane_stride_lf = pick(o->lane_stride_lf, po.lane_stride_lf); po.lane_stride_hf = pick(o->lane_stride_hf, po.lane_stride_hf);
       po.wide_first = o->wide_first >= 0 ? o->wide_first : po.wide_first; po.small_job_frames = o->small_job_frames > 0 ? o->small_job_frames : 0;
       po.timed = o->timed != 0;
-      po.reserve_frames = o->reserve_frames; po.reserve_width = o->reserve_width; po.reserve_height = o->reserve_height;
+      po.reserve_frames = o->reserve_frames; po.reserve_width = o->reserve_width; po.reserve_height = o->reserve_height; po.reserve_plane_sets = o->reserve_plane_sets > 1 ? 2 : 1;
     }
     auto ok = [](int v) { return v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
     if (!ok(po.lane_stride_lf) || !ok(po.lane_stride_hf)) { SetLastError("lane strides must be powers of two up to 64"); return nullptr; }

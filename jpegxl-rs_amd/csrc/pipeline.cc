@@ -48,7 +48,7 @@ Pipeline::Pipeline(int device, const PipelineOptions& opt) : device_(device), op
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_high);   // (numerically lower = higher priority)
   prio_high = std::min(prio_high, 0);
   main_ = NewStream(0);
-  d2h_ = NewStream(0);
+  d2h_[0] = NewStream(0); d2h_[1] = NewStream(0);
   for (int i = 0; i < opt_.lf_streams; i++) lf_side_.push_back(NewStream(prio_high));
   for (int i = 0; i < opt_.hf_streams; i++) hf_side_.push_back(NewStream(prio_high));
   clock_event_ = NewEvent(true);
@@ -65,7 +65,7 @@ Pipeline::Pipeline(int device, const PipelineOptions& opt) : device_(device), op
     const size_t ng = (size_t)((opt_.reserve_width + 255) / 256) * ((opt_.reserve_height + 255) / 256);
     const size_t bw = (size_t)(opt_.reserve_width + 7) / 8, bh = (size_t)(opt_.reserve_height + 7) / 8;
     want_coef_ = (size_t)opt_.reserve_frames * 3 * ng * 65536 * 4;
-    want_big_ = (size_t)opt_.reserve_frames * 3 * Align256(bw * 8 * bh * 8 * 4);
+    want_big_ = (size_t)opt_.reserve_frames * 3 * Align256(bw * 8 * bh * 8 * 4) * (size_t)std::max(1, std::min(opt_.reserve_plane_sets, 2));
     ReservePlanes(&big_, want_big_);
     for (auto& c : coef_) ReservePlanes(&c, want_coef_);
   }
@@ -82,7 +82,7 @@ Pipeline::~Pipeline() {
   for (void* s : lf_side_) (void)hipStreamSynchronize((hipStream_t)s);
   for (void* s : hf_side_) (void)hipStreamSynchronize((hipStream_t)s);
   (void)hipStreamSynchronize((hipStream_t)main_);
-  (void)hipStreamSynchronize((hipStream_t)d2h_);
+  for (void* s : d2h_) (void)hipStreamSynchronize((hipStream_t)s);
   for (auto& kv : jobs_) if (kv.second->done_event) (void)hipEventDestroy((hipEvent_t)kv.second->done_event);
   jobs_.clear();
   for (auto& s : slots_) {
@@ -96,7 +96,7 @@ Pipeline::~Pipeline() {
   for (void* s : lf_side_) (void)hipStreamDestroy((hipStream_t)s);
   for (void* s : hf_side_) (void)hipStreamDestroy((hipStream_t)s);
   (void)hipStreamDestroy((hipStream_t)main_);
-  (void)hipStreamDestroy((hipStream_t)d2h_);
+  for (void* s : d2h_) (void)hipStreamDestroy((hipStream_t)s);
 }
 
 // (device idle as far as these planes go) makes sp a block of at least `bytes`: from the arena pool, else from the runtime
@@ -296,15 +296,16 @@ void Pipeline::IssueTail(Job* j) {
       Record(s.idct_done, main_);
       bt.RunPart(main_, 8, opt_.timed != 0);      // restoration filters, colour, write
       Record(s.rest_done, main_);
-      StreamWait(d2h_, s.rest_done);
+      void* d2h = d2h_[j->ticket & 1];
+      StreamWait(d2h, s.rest_done);
       if (!j->host_out.empty()) {
         for (size_t i = 0; i < j->host_out.size(); i++) {
           const int bi = j->batch_index[i];
           if (bi < 0) continue;
-          HIP_CHECK(hipMemcpyAsync(j->host_out[i], bt.device_output(bi), bt.image(bi).out_size, hipMemcpyDeviceToHost, (hipStream_t)d2h_));
+          HIP_CHECK(hipMemcpyAsync(j->host_out[i], bt.device_output(bi), bt.image(bi).out_size, hipMemcpyDeviceToHost, (hipStream_t)d2h));
         }
       }
-      bt.EnqueueStatusReadback(d2h_);
+      bt.EnqueueStatusReadback(d2h);
     } catch (const std::exception& e) {
       j->job_error = e.what();
       // whatever was enqueued keeps the slot busy: Harvest drains the streams before the batch object is touched again
@@ -315,7 +316,7 @@ void Pipeline::IssueTail(Job* j) {
   }
   try {
     if (!j->done_event) j->done_event = NewEvent(true);
-    Record(j->done_event, d2h_);
+    Record(j->done_event, d2h_[j->ticket & 1]);
   } catch (const std::exception& e) { if (j->job_error.empty()) j->job_error = e.what(); }
 }
 
@@ -365,7 +366,7 @@ void Pipeline::Harvest(Job* j) {
     (void)hipStreamSynchronize((hipStream_t)main_);
     for (void* x : lf_side_) (void)hipStreamSynchronize((hipStream_t)x);
     for (void* x : hf_side_) (void)hipStreamSynchronize((hipStream_t)x);
-    (void)hipStreamSynchronize((hipStream_t)d2h_);
+    for (void* x : d2h_) (void)hipStreamSynchronize((hipStream_t)x);
   }
   for (size_t i = 0; i < n; i++) {
     const int bi = i < j->batch_index.size() ? j->batch_index[i] : -1;

@@ -40,6 +40,7 @@ struct PipelineOptions {
   // shared coefficient sets / pixel planes are sized for jobs of this shape at creation (0: nothing is reserved; jobs run on arenas of their own until the
   // pipeline is idle, then the shared planes grow to the largest job seen)
   int reserve_frames = 0, reserve_width = 0, reserve_height = 0;
+  int reserve_plane_sets = 1;   // 2: frames that take the stage-by-stage filters (anything but gaborish + one EPF pass) need a second set of pixel planes
 };
 
 struct PipelineJobResult {
@@ -104,7 +105,7 @@ class Pipeline {
   SharedPlanes big_;
   std::vector<SharedPlanes> coef_;
   size_t want_big_ = 0, want_coef_ = 0;        // the largest layouts seen: what the shared planes grow to when the pipeline is idle
-  void* main_ = nullptr; void* d2h_ = nullptr;
+  void* main_ = nullptr; void* d2h_[2] = {nullptr, nullptr};     // copies of consecutive jobs alternate between two streams (two copy engines)
   std::vector<void*> lf_side_, hf_side_;
   void* clock_event_ = nullptr;
   std::mutex mu_;

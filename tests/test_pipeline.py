@@ -40,7 +40,7 @@ def test_pipeline_symbols_exported(jxh):
         assert hasattr(L, name), name
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "jxl_hip.h")).read()
     assert "JxlHipPipelineSubmit" in header and "JxlHipPipelineOptions" in header
-    assert C.sizeof(jxh.JxlHipPipelineOptions) == 13 * 4
+    assert C.sizeof(jxh.JxlHipPipelineOptions) == 14 * 4
 
 
 def test_image_out_size_is_host_only(jxh):
