@@ -658,8 +658,8 @@ def main():
             jx.arena_pool_trim()
             # ---- host pixels out: the API's contract is a host buffer (decode.rs:417-430) — the pipeline with pinned host destinations, copies overlapped with later jobs
             try:
-                hb = max(8, min(128, B))
-                ho = measure(B=hb, host_out=True, in_flight=6, steps=max(10, min(args.steps, 30)))
+                hb = max(8, min(256, B))
+                ho = measure(B=hb, host_out=True, in_flight=4, steps=max(10, min(args.steps, 20)))      # (a ring of 9 pinned buffers of hb frames: 57 GB of host memory at 256)
                 px = hb * W * H * ho["steps"]
                 t = torch.empty(1 << 30, dtype=torch.uint8, device=dev); hbuf = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
                 hbuf.copy_(t); torch.cuda.synchronize(); t0 = time.perf_counter()

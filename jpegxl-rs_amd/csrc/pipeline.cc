@@ -296,13 +296,31 @@ void Pipeline::IssueTail(Job* j) {
       Record(s.idct_done, main_);
       bt.RunPart(main_, 8, opt_.timed != 0);      // restoration filters, colour, write
       Record(s.rest_done, main_);
-      void* d2h = d2h_[j->ticket & 1];
+      void* d2h = d2h_[0];
       StreamWait(d2h, s.rest_done);
       if (!j->host_out.empty()) {
-        for (size_t i = 0; i < j->host_out.size(); i++) {
+        // equally sized images at equal distances on both sides (a job of same-shaped frames into one host buffer): one pitched copy instead of one per image
+        bool pitched = j->host_out.size() >= 2;
+        ptrdiff_t hp = 0, dp = 0;
+        size_t osz = 0;
+        for (size_t i = 0; i < j->host_out.size() && pitched; i++) {
           const int bi = j->batch_index[i];
-          if (bi < 0) continue;
-          HIP_CHECK(hipMemcpyAsync(j->host_out[i], bt.device_output(bi), bt.image(bi).out_size, hipMemcpyDeviceToHost, (hipStream_t)d2h));
+          if (bi < 0) { pitched = false; break; }
+          if (i == 0) { osz = bt.image(bi).out_size; continue; }
+          const ptrdiff_t h = (const uint8_t*)j->host_out[i] - (const uint8_t*)j->host_out[i - 1];
+          const ptrdiff_t d = (const uint8_t*)bt.device_output(bi) - (const uint8_t*)bt.device_output(j->batch_index[i - 1]);
+          if (i == 1) { hp = h; dp = d; }
+          if (h != hp || d != dp || bt.image(bi).out_size != osz || hp < (ptrdiff_t)osz || dp < (ptrdiff_t)osz) pitched = false;
+        }
+        static const bool no_pitched = getenv("JXL_HIP_NO_PITCHED_D2H") != nullptr;
+        if (pitched && !no_pitched) {
+          HIP_CHECK(hipMemcpy2DAsync(j->host_out[0], (size_t)hp, bt.device_output(j->batch_index[0]), (size_t)dp, osz, j->host_out.size(), hipMemcpyDeviceToHost, (hipStream_t)d2h));
+        } else {
+          for (size_t i = 0; i < j->host_out.size(); i++) {
+            const int bi = j->batch_index[i];
+            if (bi < 0) continue;
+            HIP_CHECK(hipMemcpyAsync(j->host_out[i], bt.device_output(bi), bt.image(bi).out_size, hipMemcpyDeviceToHost, (hipStream_t)d2h));
+          }
         }
       }
       bt.EnqueueStatusReadback(d2h);
@@ -316,7 +334,7 @@ void Pipeline::IssueTail(Job* j) {
   }
   try {
     if (!j->done_event) j->done_event = NewEvent(true);
-    Record(j->done_event, d2h_[j->ticket & 1]);
+    Record(j->done_event, d2h_[0]);
   } catch (const std::exception& e) { if (j->job_error.empty()) j->job_error = e.what(); }
 }
 

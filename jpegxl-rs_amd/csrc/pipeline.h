@@ -105,7 +105,7 @@ class Pipeline {
   SharedPlanes big_;
   std::vector<SharedPlanes> coef_;
   size_t want_big_ = 0, want_coef_ = 0;        // the largest layouts seen: what the shared planes grow to when the pipeline is idle
-  void* main_ = nullptr; void* d2h_[2] = {nullptr, nullptr};     // copies of consecutive jobs alternate between two streams (two copy engines)
+  void* main_ = nullptr; void* d2h_[2] = {nullptr, nullptr};     // [0]: copies to host + status words of every job, in job order ([1] spare: two streams taking turns measured slower)
   std::vector<void*> lf_side_, hf_side_;
   void* clock_event_ = nullptr;
   std::mutex mu_;
