@@ -519,7 +519,7 @@ void Batch::Reset() {
   // (stage timings recorded so far stay: CollectTimes sums over the object's life)
   any_complex_ = false; any_gab_ = any_vardct_ = any_modular_ = any_modchan_ = any_multipass_ = false;
   prepared_ = false; ran_once_ = false; flags_pending_ = false; decodes_since_finish_ = 0;
-  cfg.idct_flags_known = 0;
+  cfg.idct_flags_known = 0; cfg.skip_hf = 0;
   lf_simt_ = LfSimtPlan();
   if (lf_batch_) lf_batch_->Reset();     // (kept for its arenas; Prepare drops it when no unit refers to an LF frame)
 }
@@ -554,7 +554,7 @@ int Batch::AddImagesImpl(const uint8_t* const* datas, const size_t* sizes, int n
     for (;;) {
       const int i = next.fetch_add(1);
       if (i >= n) break;
-      try { ParseImage(datas[i], sizes[i], &parsed[i]); } catch (...) { errors[i] = std::current_exception(); }
+      try { ParseImage(datas[i], sizes[i], &parsed[i], false); } catch (...) { errors[i] = std::current_exception(); }
     }
   };
   if (nt == 1) work();
@@ -576,11 +576,12 @@ int Batch::AddImagesImpl(const uint8_t* const* datas, const size_t* sizes, int n
   return first;
 }
 
-int Batch::AddImage(const uint8_t* data, size_t size) {
+int Batch::AddImage(const uint8_t* data, size_t size, bool allow_partial) {
   ParsedImage pi;
-  ParseImage(data, size, &pi);
+  ParseImage(data, size, &pi, allow_partial);
   return Append(std::move(pi));
 }
+bool Batch::is_partial(int i) const { return images_[pub_[i].first_unit]->plan.partial; }
 
 int Batch::Append(ParsedImage&& im) {
   PubImage pi; pi.first_unit = (int)images_.size(); pi.num_units = (int)im.units.size(); pi.complex = im.complex;
@@ -650,10 +651,10 @@ void Batch::DecodePreview(int i, const OutputSpec& o, void* dst, size_t cap, voi
   tmp.CopyOutputToHost(0, dst, tmp.image(0).out_size, stream_v);
 }
 
-void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
+void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out, bool allow_partial) {
   std::shared_ptr<ImageShared> sh(new ImageShared());
   bool have_container = false, has_jbrd = false;
-  if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, &sh->boxes)) throw ParseError("truncated", false);
+  if (!ExtractCodestream(data, size, &sh->cs, &have_container, &has_jbrd, &sh->boxes) && !allow_partial) throw ParseError("truncated", false);
   uint64_t bitpos = 0, preview_bitpos = 0;
   ParseImageHeader(sh->cs, &sh->ih, &bitpos);
   sh->ih.have_container = have_container;
@@ -685,8 +686,10 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out) {
     e->frame_bitpos = bitpos;
     e->frame_index = (int)units.size();   // (position among the units of the image: LF frames are none)
     e->pub_index = 0;                     // (set when the image is appended)
-    ParseFrameStart(sh->cs, ih, bitpos, &e->plan);
+    // (allow_partial: a single-frame image cut off inside its PassGroup sections parses as far as its LF part — what a progressive flush shows)
+    ParseFrameStart(sh->cs, ih, bitpos, &e->plan, /*header_and_toc_only=*/false, /*allow_partial=*/allow_partial && units.empty());
     const FramePlan& p = e->plan;
+    if (p.partial && !(p.frame_type == 0 && p.is_last && !p.have_crop)) throw ParseError("truncated", false);
     if (p.frame_type == 0 || p.frame_type == 3) { visible++; nonvisible = 0; } else nonvisible++;
     e->visible_frame_index = visible; e->nonvisible_frame_index = nonvisible;
     if (p.use_lf_frame) {
@@ -1624,6 +1627,7 @@ void Batch::Prepare(void* stream_v, bool wait_upload) {
       lf_batch_->Prepare(stream_v, wait_upload);
     }
   }
+  for (int i = 0; i < n; i++) if (images_[i]->plan.partial) cfg.skip_hf = 1;     // (a frame cut off inside its AC groups: LF part only)
   cfg.any_multipass = any_multipass_ ? 1 : 0;
   if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
   if (cfg.any_subsampled) cfg.lane_stride_hf = 1;   // so do chroma-subsampled frames (per-channel block grids)
@@ -2220,7 +2224,8 @@ void Batch::RunPart(void* stream_v, int part, bool timed) {
     // halves are timed separately)
     ClearCoefficientsBeforeHf(stream_v);
     rec(split ? 7 : 2);
-    LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
+    // (progressive flush at the kDC step: no AC group is decoded — the planes stay zero, the IDCT sees the LF part only)
+    if (!cfg.skip_hf) LaunchHfDecode(dframes_, n, max_groups_, cfg, stream_v);
     DebugSync("HF decode", stream_v);
     if (any_modchan_) EnqueueModularTail(stream_v);   // (the PassGroup Modular parts start where the HF streams ended)
     LaunchZeroFailedCoefficients(dframes_, n, stream_v);   // (frames that failed up to here are skipped by the IDCT kernels: their planes are zeroed now)

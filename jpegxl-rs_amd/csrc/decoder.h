@@ -87,7 +87,10 @@ class Batch {
   explicit Batch(int device);
   ~Batch();
   // Parses headers (container, image header, frame header, TOC, global sections).  Throws ParseError.
-  int AddImage(const uint8_t* data, size_t size);
+  // allow_partial: a single-frame VarDCT image whose bytes end inside its PassGroup sections is accepted as far as its LF part (LfGlobal, LfGroups, HfGlobal complete):
+  // it decodes with every AC coefficient zero — what JxlDecoderFlushImage shows at the kDC progression step
+  int AddImage(const uint8_t* data, size_t size, bool allow_partial = false);
+  bool is_partial(int i) const;
   // The same for n images, parsed on `threads` host threads and appended in order; returns the index of the first.
   int AddImages(const uint8_t* const* datas, const size_t* sizes, int n, int threads);
   // Same, but an image that does not parse is left out instead of failing the call: (*index)[i] = its index in the batch or -1, (*errors)[i] = what it threw.
@@ -193,7 +196,7 @@ class Batch {
   vec<FrameDev> frames_host_;
   HostStage hconst_;
   struct ParsedImage { vec<std::unique_ptr<ImageEntry>> units; bool complex = false; };
-  static void ParseImage(const uint8_t* data, size_t size, ParsedImage* out);
+  static void ParseImage(const uint8_t* data, size_t size, ParsedImage* out, bool allow_partial = false);
   int AddImagesImpl(const uint8_t* const* datas, const size_t* sizes, int n, int threads, bool tolerant, vec<int>* index, std::vector<std::string>* errors);
   int Append(ParsedImage&& im);
   bool DevReserve(void** ptr, size_t* cap, size_t bytes);

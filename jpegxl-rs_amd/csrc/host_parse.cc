@@ -773,7 +773,7 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
 static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p);
 static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p);
 
-void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* p, bool header_and_toc_only) {
+void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* p, bool header_and_toc_only, bool allow_partial) {
   const bool skip = header_and_toc_only;
   Reader r(cs, frame_bitpos);
   const size_t num_extra = ih.extra.size();
@@ -927,7 +927,14 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   for (size_t i = 0; i < n; i++) { phys[i] = {off, sizes[i]}; off += sizes[i]; }
   p->sections.resize(n);
   for (size_t i = 0; i < n; i++) p->sections[i] = perm.empty() ? phys[i] : phys[perm[i]];
-  if (off > cs.size) throw ParseError("truncated", false);
+  if (off > cs.size) {
+    // the stream ends inside this frame.  A VarDCT frame whose LfGlobal, LfGroup and HfGlobal sections are all there can be shown without its AC groups (the kDC step of
+    // progressive decoding, JxlDecoderFlushImage): only for the plain case — sections in file order, no Modular extra channels riding in the PassGroups, no LF frame
+    const size_t lf_last = 1 + p->num_lf_groups;
+    const bool lf_complete = !p->single_section && !p->modular && perm.empty() && n > lf_last && phys[lf_last].offset + phys[lf_last].size <= cs.size;
+    if (!(allow_partial && !skip && lf_complete && ih.extra.empty() && !p->use_lf_frame)) throw ParseError("truncated", false);
+    p->partial = true;
+  }
   p->frame_end_bitpos = off * 8;
   if (skip) return;
   // ---- LfGlobal

@@ -139,6 +139,7 @@ struct FramePlan {
   float sigma_for_modular = 1.0f;
   FrameFeatures feat;
   uint64_t frame_end_bitpos = 0;           // first bit after the frame's last section (= next frame header)
+  bool partial = false;                    // the codestream ends inside the frame's PassGroup sections: LF part complete, no AC group is decoded (progressive flush)
   // geometry
   uint32_t width = 0, height = 0, group_dim = 256;
   uint32_t xgroups = 0, ygroups = 0, num_groups = 0, xlfgroups = 0, ylfgroups = 0, num_lf_groups = 0;
@@ -208,7 +209,7 @@ void ParseImageHeader(const Codestream& cs, ImageHeader* ih, uint64_t* frame_bit
 // frames, HfGlobal has been parsed too.  For single-section frames HfGlobal must be parsed later with ParseHfGlobal
 // at the bit position where the device-decoded LfGroup streams end.
 // header_and_toc_only: the frame is only stepped over (the preview frame): frame header and TOC give plan->frame_end_bitpos, nothing else is looked at
-void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* plan, bool header_and_toc_only = false);
+void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame_bitpos, FramePlan* plan, bool header_and_toc_only = false, bool allow_partial = false);
 void ParseHfGlobal(const Codestream& cs, const ImageHeader& ih, uint64_t bitpos, FramePlan* plan);
 
 // Dequantisation table (1/weight) of quant kind `kind`, channel c; natural coefficient order of a strategy.

@@ -54,6 +54,8 @@ struct JxlDecoderStruct {
   vec<int> frames; size_t frame_cursor, skip_frames; bool frame_announced;
   // coalesced animation decoded once: the canvases after every shown frame wait in device memory, in the format of the first buffer the caller set
   bool anim_cached, anim_cache_failed; JxlPixelFormat anim_format; bool anim_keep_orientation, anim_unpremul, anim_spot; uint32_t anim_int_bits;
+  bool partial;        // the batch was parsed from a stream that ends inside its frame's AC groups (Batch::AddImage allow_partial): headers and JxlDecoderFlushImage work, the decode waits for more input
+  bool progression_emitted;   // JXL_DEC_FRAME_PROGRESSION (kDC step) has been returned for the current frame
   bool frame_done;     // JXL_DEC_FULL_IMAGE of frames[frame_cursor] has been returned: its header stays readable until the next JxlDecoderProcessInput moves on
   Batch* batch;
   int device;
@@ -94,9 +96,9 @@ static void ClearState(JxlDecoder* d) {
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
   d->frames.clear(); d->frame_cursor = 0; d->skip_frames = 0; d->frame_announced = false; d->frame_done = false;
-  d->anim_cached = d->anim_cache_failed = false;
+  d->anim_cached = d->anim_cache_failed = false; d->partial = false; d->progression_emitted = false;
   d->mt_init = nullptr; d->mt_run = nullptr; d->mt_destroy = nullptr; d->mt_opaque = nullptr;
-  d->ec_buffers.clear(); d->progressive_detail = 0; d->out_int_bits = 0;
+  d->ec_buffers.clear(); d->progressive_detail = 1 /* kDC, libjxl's default */; d->out_int_bits = 0;
   d->decompress_boxes = false; d->container.clear(); d->boxes.clear(); d->box_next = d->box_split = 0; d->box_current = -1; d->box_complete_pending = false;
   d->box_plain.clear(); d->box_plain_ready = false; d->box_written = 0; d->box_buffer = nullptr; d->box_size = d->box_buffer_written = 0; d->box_set = false; d->box_buffer_for = -1;
   DeleteBatch(d->batch); d->batch = nullptr;
@@ -277,6 +279,7 @@ static bool NeedsToneMapping(const JxlDecoder* d) {
 JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t size) {
   if (d->input_set) return JXL_DEC_ERROR;  // libjxl: "already set input, use JxlDecoderReleaseInput first"
   d->input = data; d->input_size = size; d->input_set = true;
+  if (d->partial) { d->stage = JxlDecoderStruct::kInit; d->partial = false; }    // (more bytes after a partial parse: parsed again from the start; what has been announced stays announced)
   return JXL_DEC_SUCCESS;
 }
 void JxlDecoderCloseInput(JxlDecoder* d) { d->input_closed = true; }
@@ -285,7 +288,7 @@ size_t JxlDecoderReleaseInput(JxlDecoder* d) {
   // Until the headers and the frame index could be parsed nothing counts as consumed (the caller provides the stream again
   // from its start); after that the decoder works from its own copy of the codestream.
   if (!d->input_set) return 0;
-  const size_t unconsumed = d->stage == JxlDecoderStruct::kInit ? d->input_size : 0;
+  const size_t unconsumed = (d->stage == JxlDecoderStruct::kInit || d->partial) ? d->input_size : 0;     // (a partial parse consumed nothing: the stream comes again from its start, longer)
   d->input = nullptr; d->input_size = 0; d->input_set = false;
   return unconsumed;
 }
@@ -479,13 +482,41 @@ JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* d, const JxlPixelFo
 // ---- decode.rs:1482 / :1513 / :1528
 JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* d, int detail) {
   if (!d || detail < 0 || detail > 3) { SetLastError("unsupported progressive detail (kFrames, kDC, kLastPasses, kPasses are accepted)"); return JXL_DEC_ERROR; }
-  d->progressive_detail = detail;        // (no JXL_DEC_FRAME_PROGRESSION is ever emitted: a frame is decoded whole once its bytes are there)
+  // kDC (1) and above: JXL_DEC_FRAME_PROGRESSION is returned once per frame, when the frame's LF image is decodable — before its AC groups are looked at — and
+  // JxlDecoderFlushImage then shows that step (a frame is decoded whole on the device, so the pass-by-pass steps of kLastPasses / kPasses coincide with the full image)
+  d->progressive_detail = detail;
   return JXL_DEC_SUCCESS;
 }
+// decode.rs:1513.  Writes the image as far as it can be shown into the buffer set with JxlDecoderSetImageOutBuffer: after JXL_DEC_FRAME_PROGRESSION, or after
+// JXL_DEC_NEED_MORE_INPUT on a stream that ends inside its frame's AC groups, that is the kDC step — the LF image and the HF metadata decoded, every AC coefficient zero,
+// through the regular IDCT / restoration / colour stages (dec_frame.cc Flush: groups that have not arrived are drawn from their LF part).  Single-frame VarDCT images
+// without extra channels whose sections come in file order; anything else answers JXL_DEC_ERROR ("no flush was done"), as libjxl does when nothing new can be shown.
 JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* d) {
-  (void)d;
-  SetLastError("nothing to flush: frames are decoded whole on the device once their bytes are available");
-  return JXL_DEC_ERROR;                  // libjxl's answer when no new image data could be flushed
+  JXL_MM_SCOPE(d);
+  if (!d || !d->batch || d->stage < JxlDecoderStruct::kHeaders || !d->out_set || !d->out_buffer || d->out_callback || d->mt_run) { SetLastError("nothing to flush: no frame in progress or no image out buffer set"); return JXL_DEC_ERROR; }
+  if (!d->input_set) { SetLastError("nothing to flush: the input has been released"); return JXL_DEC_ERROR; }
+  try {
+    if (hipSetDevice(d->device) != hipSuccess) { (void)hipGetLastError(); SetLastError("no usable HIP device"); return JXL_DEC_ERROR; }
+    struct Holder { Batch* b; ~Holder() { DeleteBatch(b); } } hold{NewBatch(d->device)};
+    hold.b->AddImage(d->input, d->input_size, /*allow_partial=*/true);
+    if (hold.b->num_frames(0) != 1) throw ParseError("unsupported: progressive flush of an image with several frames", true);
+    const ImageEntry& e = hold.b->frame(0, 0);
+    if (e.plan.modular || e.plan.single_section || !e.ih.extra.empty() || e.plan.use_lf_frame || e.complex) throw ParseError("unsupported: progressive flush of this kind of frame", true);
+    OutputSpec o;
+    FormatToSpec(&d->out_format, &o);
+    o.keep_orientation = d->keep_orientation; o.int_bits = d->out_int_bits;
+    hold.b->SetOutput(0, o);
+    if (hold.b->image(0).out_size > d->out_size) throw ParseError("output buffer too small for this frame", false);
+    hold.b->cfg.skip_hf = 1;
+    hold.b->Prepare(DecoderStream(d));
+    hold.b->Run(DecoderStream(d));       // ══► the HIP hot path without its HF stage
+    hold.b->Finish(DecoderStream(d));
+    hold.b->CopyOutputToHost(0, d->out_buffer, hold.b->image(0).out_size, DecoderStream(d));
+    return JXL_DEC_SUCCESS;
+  } catch (const std::exception& e) {
+    SetLastError(std::string("no flush was done: ") + e.what());
+    return JXL_DEC_ERROR;
+  }
 }
 JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* d, const JxlBitDepth* bd) {
   if (!d || !bd || !d->out_set) { SetLastError("JxlDecoderSetImageOutBitDepth: no image out buffer is set"); return JXL_DEC_ERROR; }
@@ -620,7 +651,16 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
       if (sig == JXL_SIG_NOT_ENOUGH_BYTES) return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
       if (hipSetDevice(d->device) != hipSuccess) { SetLastError("no usable HIP device: the JPEG XL decode path requires an MI355X-class GPU (no CPU fallback)"); return JXL_DEC_ERROR; }
       struct Holder { Batch* b; ~Holder() { DeleteBatch(b); } } hold{NewBatch(d->device)};
-      hold.b->AddImage(d->input, d->input_size);      // (throws "truncated" while the frame index is incomplete: nothing is kept)
+      try {
+        hold.b->AddImage(d->input, d->input_size);      // (throws "truncated" while the frame index is incomplete)
+      } catch (const ParseError& e) {
+        // a stream that ends inside its frame's AC groups: the headers are there (the events up to JXL_DEC_NEED_IMAGE_OUT_BUFFER follow), JxlDecoderFlushImage can show the LF
+        // part, the decode itself waits for the rest (JXL_DEC_NEED_MORE_INPUT at that point)
+        if (strcmp(e.what(), "truncated") != 0) throw;
+        DeleteBatch(hold.b); hold.b = nullptr; hold.b = NewBatch(d->device);
+        hold.b->AddImage(d->input, d->input_size, /*allow_partial=*/true);     // (throws "truncated" again when not even the LF part is complete)
+        d->partial = true;
+      }
       DeleteBatch(d->batch);
       d->batch = hold.b; hold.b = nullptr;
       d->stage = JxlDecoderStruct::kHeaders;
@@ -653,7 +693,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
     }
     while (d->stage == JxlDecoderStruct::kFrame) {
       // one round per frame the caller sees: the composite (coalescing, one round) or every regular frame as coded
-      if (d->frame_done) { d->frame_cursor++; d->frame_announced = false; d->frame_done = false; }     // (the frame reported last stayed current until now)
+      if (d->frame_done) { d->frame_cursor++; d->frame_announced = false; d->frame_done = false; d->progression_emitted = false; }     // (the frame reported last stayed current until now)
       while (d->skip_frames > 0 && d->frame_cursor < d->frames.size() && !d->frame_announced) { d->frame_cursor++; d->skip_frames--; }
       if (d->frame_cursor >= d->frames.size()) { d->stage = JxlDecoderStruct::kDone; break; }
       if ((d->events_wanted & JXL_DEC_FRAME) && !d->frame_announced) { d->frame_announced = true; d->events_emitted |= JXL_DEC_FRAME; return JXL_DEC_FRAME; }
@@ -688,6 +728,14 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         }
       }
       if (!d->out_set) return JXL_DEC_NEED_IMAGE_OUT_BUFFER;
+      if (d->partial) {       // the frame's AC groups are not all there yet (JxlDecoderFlushImage shows the LF part meanwhile)
+        SetLastError("the stream ends inside the frame");
+        return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
+      }
+      if ((d->events_wanted & JXL_DEC_FRAME_PROGRESSION) && d->progressive_detail >= 1 && !d->progression_emitted && d->coalescing && d->frames.size() == 1 && d->batch->num_frames(0) == 1) {
+        const ImageEntry& e0 = d->batch->frame(0, 0);
+        if (!e0.plan.modular && !e0.plan.single_section && e0.ih.extra.empty() && !e0.plan.use_lf_frame && !e0.complex) { d->progression_emitted = true; return JXL_DEC_FRAME_PROGRESSION; }
+      }
       if (NeedsToneMapping(d)) throw ParseError("unsupported: desired_intensity_target below the intensity target of a PQ image asks for libjxl's tone mapping stage, which this decoder does not have (leave the target at 0 to get the untouched PQ pixels)", true);
       OutputSpec o;
       FormatToSpec(&d->out_format, &o);

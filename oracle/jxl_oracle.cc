@@ -56,11 +56,16 @@ void InitFrame(Frame& f, const ImageMetadata& m) {
   }
 }
 
+// Progressive preview (decode.cc JxlDecoderFlushImage at the kDC step: the frame as it stands when the LF image and the HF metadata are there and no AC group has
+// been decoded — every AC coefficient still zero): set for the decodes started afterwards on this thread; the PassGroup sections are not looked at (they may be cut off).
+static thread_local bool g_dc_only = false;
 void DecodeFrameSections(const uint8_t* data, size_t size, BitReader& br, Frame& f) {
   size_t n = f.fh.toc_entries();
   std::vector<Section> sec;
   ReadTOC(br, n, sec);
-  if (sec.back().offset > size) JXLO_FAIL("truncated frame");
+  if (g_dc_only && n > 1 && !f.fh.modular) {
+    if (sec[1 + f.fh.num_lf_groups].offset + sec[1 + f.fh.num_lf_groups].size > size) JXLO_FAIL("truncated frame (LF part incomplete)");
+  } else if (sec.back().offset > size) JXLO_FAIL("truncated frame");
   auto reader = [&](size_t i) { BitReader r(data + sec[i].offset, sec[i].size); return r; };
   if (n == 1) {
     BitReader r = reader(0);
@@ -73,7 +78,7 @@ void DecodeFrameSections(const uint8_t* data, size_t size, BitReader& br, Frame&
     { BitReader r = reader(0); ReadLfGlobal(r, f); if (r.pos > r.size * 8) JXLO_FAIL("LfGlobal overrun"); }
     for (uint32_t g = 0; g < f.fh.num_lf_groups; g++) { BitReader r = reader(1 + g); ReadLfGroup(r, f, g); if (r.pos > r.size * 8) JXLO_FAIL("LfGroup overrun"); }
     if (!f.fh.modular) { BitReader r = reader(1 + f.fh.num_lf_groups); ReadHfGlobal(r, f); if (r.pos > r.size * 8) JXLO_FAIL("HfGlobal overrun"); }
-    for (uint32_t p = 0; p < f.fh.passes.num_passes; p++)
+    for (uint32_t p = 0; p < f.fh.passes.num_passes && !(g_dc_only && !f.fh.modular); p++)
       for (uint32_t g = 0; g < f.fh.num_groups; g++) {
         BitReader r = reader(2 + f.fh.num_lf_groups + p * f.fh.num_groups + g);
         ReadPassGroup(r, f, p, g);
@@ -573,6 +578,7 @@ const char* jxlo_error(jxlo_handle* h) { return h->err.empty() ? nullptr : h->er
 void jxlo_free(jxlo_handle* h) { delete h; }
 void jxlo_set_unpremultiply_alpha(jxlo_handle* h, int v) { h->unpremul = v != 0; }
 void jxlo_set_render_spotcolors(int v) { g_render_spot = v != 0; }   // applies to the decodes started afterwards on this thread
+void jxlo_set_dc_only(int v) { g_dc_only = v != 0; }                  // likewise: JxlDecoderFlushImage at the kDC step (no AC group decoded)
 // embedded ICC profile of the image (empty when the colour encoding is enumerated)
 size_t jxlo_icc(jxlo_handle* h, uint8_t* out, size_t cap) { const auto& v = h->d.meta.icc; if (out && cap >= v.size() && !v.empty()) memcpy(out, v.data(), v.size()); return v.size(); }
 void jxlo_get_info(jxlo_handle* h, jxlo_info* i) {

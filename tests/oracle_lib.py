@@ -120,7 +120,17 @@ class Decoded:
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
 
 
-def decode(data: bytes, dump=False) -> Decoded:
+def decode(data: bytes, dump=False, dc_only=False) -> Decoded:
+    """dc_only: the image as JxlDecoderFlushImage shows it at the kDC progression step — LF image + HF metadata decoded, every AC coefficient zero; the
+    PassGroup sections are not read (the input may end in them)."""
+    if dc_only:
+        L = lib()
+        L.jxlo_set_dc_only.argtypes = [C.c_int]
+        L.jxlo_set_dc_only(1)
+        try:
+            return Decoded(data, dump)
+        finally:
+            L.jxlo_set_dc_only(0)
     return Decoded(data, dump)
 
 
