@@ -137,7 +137,7 @@ def libjxl():
             "JxlDecoderGetIntendedDownsamplingRatio": (sz, [vp]),
             "JxlDecoderPreviewOutBufferSize": (C.c_int, [vp, C.POINTER(JxlPixelFormat), C.POINTER(sz)]),
             "JxlDecoderSetPreviewOutBuffer": (C.c_int, [vp, C.POINTER(JxlPixelFormat), vp, sz]),
-            "JxlDecoderSetJPEGBuffer": (C.c_int, [vp, vp, sz]), "JxlDecoderReleaseJPEGBuffer": (sz, [vp]),
+            "JxlDecoderReleaseInput": (sz, [vp]), "JxlDecoderSetJPEGBuffer": (C.c_int, [vp, vp, sz]), "JxlDecoderReleaseJPEGBuffer": (sz, [vp]),
             "JxlDecoderGetFrameHeader": (C.c_int, [vp, C.POINTER(JxlFrameHeader)]), "JxlDecoderGetFrameName": (C.c_int, [vp, C.c_char_p, sz]),
             "JxlDecoderGetExtraChannelBlendInfo": (C.c_int, [vp, sz, C.POINTER(JxlBlendInfo)]), "JxlDecoderSkipFrames": (None, [vp, sz]),
             "JxlDecoderSkipCurrentFrame": (C.c_int, [vp]), "JxlDecoderRewind": (None, [vp]),

@@ -1077,8 +1077,14 @@ int JxlHipDebugWriteJpeg(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, 
 int JxlHipDebugDescribe(const uint8_t* data, size_t size, char* out, size_t cap) {
   try {
     Batch b(-1);
-    b.AddImage(data, size);
     std::string s;
+    try { b.AddImage(data, size); }
+    catch (const ParseError& e) {
+      // a stream that ends inside its frame's AC groups is still described as far as a progressive flush could show it (Batch::AddImage allow_partial)
+      if (strcmp(e.what(), "truncated") != 0) throw;
+      b.AddImage(data, size, /*allow_partial=*/true);
+      s += "partial: the stream ends inside the frame's AC groups\n";
+    }
     char line[512];
     const ImageHeader& ih = b.image(0).ih;
     snprintf(line, sizeof line, "image %ux%u bits=%u extra=%zu xyb=%d gray=%d icc=%zu frames=%d\n", ih.xsize, ih.ysize, ih.depth.bits, ih.extra.size(), (int)ih.xyb_encoded,
