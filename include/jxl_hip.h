@@ -342,6 +342,25 @@ size_t JxlHipArenaPoolHeld(void);
 void JxlHipSchedulerStats(int device, int64_t* jobs, int64_t* images);
 void JxlHipSchedulerShutdown(void);
 
+/* ---- extension: the gather of decoded pixels over RCCL / xGMI (csrc/gather.cc) --------------------------------------------------
+ * The multi-GPU path shards independent frames over one process per GPU and has ONE exchange step: the decoded pixels go to the consumer rank.  These
+ * calls put it behind the C ABI so that a caller needs no PyTorch: rank 0 makes an id, the job hands it to the other ranks (file, environment, MPI ...), every rank
+ * creates its communicator (world = 1 needs no id exchange and no RCCL).  librccl.so is loaded on first use.  All calls return 0 on success (JxlHipLastError). */
+#define JXL_HIP_COMM_ID_BYTES 128
+typedef struct JxlHipCommStruct JxlHipComm;
+int JxlHipCommGetUniqueId(uint8_t id[JXL_HIP_COMM_ID_BYTES]);
+JxlHipComm* JxlHipCommCreate(int device, int rank, int world, const uint8_t id[JXL_HIP_COMM_ID_BYTES]);
+void JxlHipCommDestroy(JxlHipComm* comm);
+/* Every rank holds `frames` decoded frames of frame_bytes each at `send` (device memory); `root` receives them at recv[rank][frame] (device memory, world x frames x
+ * frame_bytes; ignored elsewhere) as point-to-point messages of chunk_frames frames, all peers of a chunk in one group — each over its own xGMI link — enqueued on
+ * hip_stream.  The root's own shard is a device copy (skipped when send already points into recv). */
+int JxlHipGatherFrames(JxlHipComm* comm, const void* send, size_t frame_bytes, int frames, void* recv, int root, int chunk_frames, void* hip_stream);
+/* Shards of unequal length (1024 frames over 3, 5, 6, 7 GPUs): rank r holds frames_per_rank[r] frames, the root receives them in rank order (the frame order of the
+ * unsharded job). */
+int JxlHipGatherFramesRagged(JxlHipComm* comm, const void* send, size_t frame_bytes, const int* frames_per_rank, void* recv, int root, int chunk_frames, void* hip_stream);
+/* Sum over the ranks, in place (per-rank consumers exchange checksums, not pixels). */
+int JxlHipAllReduceSumI64(JxlHipComm* comm, int64_t* device_values, size_t count, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,6 +174,10 @@ def libjxl():
             "JxlHipHostAlloc": (vp, [sz]), "JxlHipHostFree": (None, [vp]),
             "JxlHipImageOutSize": (C.c_int, [vp, sz, C.POINTER(JxlPixelFormat), C.POINTER(JxlBasicInfo), C.POINTER(sz)]),
             "JxlHipArenaPoolTrim": (sz, []), "JxlHipArenaPoolHeld": (sz, []),
+            "JxlHipCommGetUniqueId": (C.c_int, [vp]), "JxlHipCommCreate": (vp, [C.c_int, C.c_int, C.c_int, vp]), "JxlHipCommDestroy": (None, [vp]),
+            "JxlHipGatherFrames": (C.c_int, [vp, vp, sz, C.c_int, vp, C.c_int, C.c_int, vp]),
+            "JxlHipGatherFramesRagged": (C.c_int, [vp, vp, sz, C.POINTER(C.c_int), vp, C.c_int, C.c_int, vp]),
+            "JxlHipAllReduceSumI64": (C.c_int, [vp, vp, sz, vp]),
             "JxlHipSchedulerStats": (None, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]), "JxlHipSchedulerShutdown": (None, []),
         }
         for name, (res, args) in sig.items():

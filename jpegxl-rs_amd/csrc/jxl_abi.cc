@@ -16,6 +16,7 @@ using namespace jxlhip;
 
 static thread_local std::string g_last_error;
 static void SetLastError(const std::string& s) { g_last_error = s; }
+namespace jxlhip { void SetLastErrorText(const std::string& s) { g_last_error = s; } }     // (gather.cc)
 
 struct JxlDecoderStruct {
   JxlMemoryManager mm;
