@@ -226,6 +226,22 @@ class Run:
         self.out_free = [torch.cuda.Event() for _ in range(self.nout)]
         self.checksum = torch.zeros((), dtype=torch.int64, device=dev)
         self.gathered = torch.empty((world, inner * B, H, W, nch), dtype=tdt, device=dev) if self.consumer == "gather" and rank == 0 else None
+        self.ccomm = None
+        if self.consumer == "gather" and args.gather_impl == "c" and inner == 1:
+            # the gather behind the C ABI (csrc/gather.cc, RCCL loaded by the library): rank 0's communicator id travels through the process group that exists anyway
+            import ctypes as C
+            L = jx.libjxl()
+            uid = (C.c_uint8 * 128)()
+            box = [bytes(uid)]
+            if rank == 0:
+                if L.JxlHipCommGetUniqueId(uid) != 0:
+                    raise RuntimeError(jx.last_error())
+                box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            self.ccomm = L.JxlHipCommCreate(local_rank, rank, world, uid)
+            if not self.ccomm:
+                raise RuntimeError(jx.last_error())
         self.lag = max(0, self.slots - 2)                    # jobs between a submit and the wait for an earlier one (the pipeline's own back-pressure is slots - 1)
         self.step_offset = 0
 
@@ -250,6 +266,14 @@ class Run:
                 self.out_free[k % self.nout].record(self.comm)
         elif self.consumer == "gather":
             from jpegxl_rs_amd.sharding import gather_frames_chunked
+            if self.ccomm:
+                with torch.cuda.stream(self.comm):
+                    rc = self.jx.libjxl().JxlHipGatherFrames(self.ccomm, self.outs[k % self.nout].data_ptr(), self.frame_bytes, self.B, self.gathered.data_ptr() if self.rank == 0 else None, 0,
+                                                             self.args.gather_chunk, self.comm.cuda_stream)
+                    if rc != 0:
+                        raise RuntimeError(self.jx.last_error())
+                    self.out_free[k % self.nout].record(self.comm)
+                return
             with torch.cuda.stream(self.comm):
                 j = k % self.inner
                 gather_frames_chunked(self.outs[k % self.nout], self.gathered[:, j * self.B:(j + 1) * self.B] if self.rank == 0 else None, dst=0, chunk_frames=self.args.gather_chunk)
@@ -320,6 +344,10 @@ class Run:
         return ok, checked
 
     def close(self):
+        if self.ccomm:
+            self.torch.cuda.synchronize()
+            self.jx.libjxl().JxlHipCommDestroy(self.ccomm)
+            self.ccomm = None
         self.p.close()
         self.outs = None; self.pinned = None; self.gathered = None
         self.torch.cuda.empty_cache()
@@ -448,6 +476,8 @@ def main():
                     help="1 = SIMT HF decode (one group stream per lane), 64 = one stream per wavefront")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of decoded pixels (N > 1)")
     ap.add_argument("--per-rank-consumers", action="store_true", help="N = 1: also run the per-rank-consumer leg that N > 1 runs beside the gather (a reduction over the decoded pixels per step)")
+    ap.add_argument("--gather-impl", choices=["torch", "c"], default=os.environ.get("JXL_BENCH_GATHER_IMPL", "torch"), help="N > 1: the pixel gather through torch.distributed point-to-point "
+                    "operations (default) or through the library's own C entry points over RCCL (JxlHipGatherFrames, csrc/gather.cc; weak scaling only)")
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
     ap.add_argument("--in-flight", type=int, default=11, help="jobs in flight in the library pipeline (JxlHipPipelineOptions.jobs_in_flight): LF stages run this many jobs ahead of the tail")
     ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the jobs ahead are spread over")
