@@ -9,6 +9,7 @@ import csv, glob, json, os, re, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stats_dir, fetch_dir, write_dir, log = sys.argv[1:6]
 frames = int(sys.argv[6]) if len(sys.argv) > 6 else 32
+write_json = not (len(sys.argv) > 7 and sys.argv[7] == "no-json")     # (the tables of the 8K workloads: pmc_traffic.json stays the 4K one bench.py reads)
 
 def pmc(d):
     out = {}
@@ -31,7 +32,8 @@ for k in list(per):          # template instantiations also under their plain na
     if "<" in k:
         base = k.split("<")[0]
         per[base] = max(per.get(base, 0), per[k])
-json.dump({"unit": "bytes per frame per launch (3840x2160 VarDCT d1, u8 RGB out)", "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / frames; separate --pmc passes",
+if write_json:
+  json.dump({"unit": "bytes per frame per launch (3840x2160 VarDCT d1, u8 RGB out)", "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / frames; separate --pmc passes",
            "frames_in_profiled_launch": frames, "per_kernel": per}, open(os.path.join(R, "profiles", "pmc_traffic.json"), "w"), indent=1)
 md = "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB / frame |\n|---|---|---|---|\n" + "".join("| %s | %d | %d | %.2f |\n" % r for r in rows)
 open(os.path.join(R, "profiles", tag + "_pmc_table.md"), "w").write(md)
