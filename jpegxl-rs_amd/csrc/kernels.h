@@ -148,6 +148,7 @@ struct LaunchCfg {
   int lf_wp_narrow_test = 0;         // testing: the SIMT LF kernel's weighted-predictor lanes hand a stream back at |sample| > 16 instead of 2^20
   int lf_head_start = 0;             // the LF launch waits until the next HF launch is resident (set for pipelined front-only calls)
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
+  int hf_lanes_per_wave = 0, hf_lanes_per_wg = 0;   // SIMT HF decode: group streams per wavefront / per workgroup (0: the throughput defaults — a frame's streams on four wavefronts of one workgroup)
   int skip_hf = 0;                   // the HF stage is left out: every AC coefficient stays zero (progressive flush at the kDC step, decoder.h AddImage allow_partial)
   int no_flag_wait = 0;              // latency mode (pipeline.h small-job scheduler): the tail never waits on the host for the placement flags of the LF stage, every IDCT kernel variant is launched
   int need_tile4_plain = 1, need_tile4_special = 1, need_tile8_plain = 1, need_tile8_special = 1;   // IdctTileKernel<TB, SPECIAL> variants some frame takes

@@ -4752,12 +4752,14 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     // (at most ~136 group streams per workgroup — a 4K frame's 135 in one —: an 8K frame's 510 spread over four workgroups of 128 lanes, 32 per wavefront, decode in a
     // third of the time two workgroups of 255 took — 64 streams per wavefront run every path of the lock-step loop in every iteration)
     static const int lanes_cap = getenv("JXL_HIP_HF_LANES_PER_WG") ? std::max(16, std::min((int)kSimtMaxThreads, atoi(getenv("JXL_HIP_HF_LANES_PER_WG")))) : 136;
-    const int nblk = DivUp(max_groups, lanes_cap);
+    const int nblk = DivUp(max_groups, cfg.hf_lanes_per_wg > 0 ? std::max(16, std::min((int)kSimtMaxThreads, cfg.hf_lanes_per_wg)) : lanes_cap);
     const uint32_t lanes = (uint32_t)DivUp(max_groups, nblk);
     static const int lpw_env = getenv("JXL_HIP_HF_LANES") ? atoi(getenv("JXL_HIP_HF_LANES")) : 0;
     // streams per wavefront: four wavefronts per workgroup, one per SIMD (two of these on one SIMD slow each other down
     // more than the sparser lanes gain: 5 wavefronts 64 ms, 4: 49 ms, 3: 53 ms per 256 4K frames)
-    uint32_t lpw = lpw_env >= 1 && lpw_env <= 64 ? (uint32_t)lpw_env : (uint32_t)DivUp((int)lanes, 4);
+    // (latency mode, cfg.hf_lanes_per_wave: a few dozen frames at most — one to four streams per wavefront: a lane that has its wavefront nearly to itself skips the paths
+    // the other lanes of a dense wavefront drag it through: 26 ms for one 4K frame at 1 stream per wavefront, 29.5 ms for 64 frames at 4, against 40-41 ms at the dense packing)
+    uint32_t lpw = cfg.hf_lanes_per_wave > 0 ? (uint32_t)std::min(64, cfg.hf_lanes_per_wave) : lpw_env >= 1 && lpw_env <= 64 ? (uint32_t)lpw_env : (uint32_t)DivUp((int)lanes, 4);
     lpw = std::max(lpw, (uint32_t)DivUp((int)lanes, 16));                        // at most 16 wavefronts per workgroup
     const uint32_t threads = (uint32_t)DivUp((int)lanes, (int)lpw) * 64;
     const uint32_t lds = kSimtCodeOff + (uint32_t)(all_lds ? code_lds : std::min(cfg.lds_code_budget, cfg.ac_code_bytes)) + (lanes + 1) * kSimtLaneBytes;

@@ -234,8 +234,12 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     }
     if (!any) { j->job_error = "no image of the job could be parsed"; return; }
     bt.cfg.lane_stride_lf = opt_.lane_stride_lf; bt.cfg.lane_stride_hf = opt_.lane_stride_hf; bt.cfg.no_flag_wait = opt_.no_flag_wait;
-    // a handful of frames: one group stream per wavefront in the HF stage, too (33 instead of 41 ms for one 4K frame; from a few dozen frames on the SIMT form wins)
-    if (opt_.hf_wave_below > 0 && n <= opt_.hf_wave_below) bt.cfg.lane_stride_hf = 64;
+    // latency mode: sparse wavefronts in the SIMT HF stage — one group stream per wavefront for a handful of frames, four up to a hundred (kernels.hip LaunchHfDecode)
+    bt.cfg.hf_lanes_per_wave = bt.cfg.hf_lanes_per_wg = 0;
+    if (opt_.hf_sparse) {
+      if (n <= 8) { bt.cfg.hf_lanes_per_wave = 1; bt.cfg.hf_lanes_per_wg = 16; }
+      else if (n <= 96) { bt.cfg.hf_lanes_per_wave = 4; bt.cfg.hf_lanes_per_wg = 64; }
+    }
     bt.UseSharedPlanes(&big_, &coef_[(size_t)(j->ticket % ncoef_)]);
     // tables + upload go to the stream the job's LF stage runs on, which follows without a host-side wait (an upload stream of its own was seen waiting tens of
     // milliseconds behind other streams' entropy kernels)

@@ -33,7 +33,7 @@ struct PipelineOptions {
   int parse_threads = 8;     // host threads one job's images are parsed on
   int lane_stride_lf = 8, lane_stride_hf = 1;
   int wide_first = 4;        // LF stages at the start of a cold pipeline that take the one-wavefront-per-stream kernel (shorter latency on an idle GPU)
-  int hf_wave_below = 0;     // jobs of at most this many frames decode their HF group streams one per wavefront (latency mode)
+  int hf_sparse = 0;         // latency mode: small jobs spread their HF group streams over many sparse wavefronts (1 per wavefront up to 8 frames, 4 up to 96)
   int small_job_frames = 0;  // jobs of at most this many frames always take it (latency mode: DeviceScheduler)
   int no_flag_wait = 0;      // the issuing thread never waits for a job's LF stage (placement flags): every IDCT kernel variant is launched instead — latency mode
   int timed = 0;             // bracket the stages with HIP events (CollectTimes)

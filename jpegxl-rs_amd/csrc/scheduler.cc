@@ -43,7 +43,7 @@ class DeviceScheduler {
     // (the HF stage of a small job is a latency chain of its own, ~35 ms for one 4K frame: several in flight, a coefficient set each)
     o.hf_streams = EnvInt("JXL_HIP_SCHED_HF_STREAMS", 3);
     o.no_flag_wait = 1;
-    o.hf_wave_below = EnvInt("JXL_HIP_SCHED_HF_WAVE_BELOW", 12);
+    o.hf_sparse = EnvInt("JXL_HIP_SCHED_HF_SPARSE", 1);
     o.prepare_threads = EnvInt("JXL_HIP_SCHED_PREPARE_THREADS", 3);
     o.parse_threads = EnvInt("JXL_HIP_SCHED_PARSE_THREADS", 8);
     // latency over occupancy: every LF-group stream gets a wavefront of its own (100 ms per launch instead of the 250-300 ms of the SIMT form, which packs eight streams
