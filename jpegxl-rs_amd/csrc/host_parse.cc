@@ -901,6 +901,9 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
   // ---- TOC
   p->single_section = p->num_groups == 1 && p->num_passes == 1;
   size_t n = p->single_section ? 1 : 1 + p->num_lf_groups + 1 + (size_t)p->num_groups * p->num_passes;
+  // (every TOC entry takes at least 12 bits: a header that announces more sections than the rest of the stream could list is cut off or damaged — said before
+  // anything of that size is allocated)
+  if (n > ((uint64_t)cs.size * 8 - std::min<uint64_t>(r.pos(), (uint64_t)cs.size * 8)) / 12 + 1) throw ParseError("truncated", false);
   // toc.cc ReadToc: an optional Lehmer-coded permutation says where logical section i is stored
   vec<uint32_t> perm;
   if (r.b()) {
@@ -914,9 +917,19 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     uint32_t last = 0;
     for (size_t i = 0; i < end; i++) { lehmer[i] = sr.Read(ctxof(last)); last = lehmer[i]; if (lehmer[i] >= n - i) Fail("TOC lehmer code"); }
     sr.CheckFinal();
-    for (size_t i = 0; i < n; i++) temp[i] = (uint32_t)i;
+    // perm[i] = the lehmer[i]-th element still unused, in O(n log n): a Fenwick tree over "unused" flags, descended from the top bit (erasing from a vector is quadratic —
+    // a damaged header that claims millions of groups made the parser spin for an hour; found by tests/fuzz/fuzz_host.cc)
+    size_t top = 1;
+    while (top * 2 <= n) top *= 2;
+    for (size_t i = 0; i < n; i++) temp[i] = (uint32_t)((i + 1) & (~(i + 1) + 1));      // tree of all ones: node i (1-based) covers lowbit(i) elements
     perm.resize(n);
-    for (size_t i = 0; i < n; i++) { perm[i] = temp[lehmer[i]]; temp.erase(temp.begin() + lehmer[i]); }
+    for (size_t i = 0; i < n; i++) {
+      size_t pos = 0, rem = lehmer[i];                      // the element with exactly `rem` unused elements in front of it
+      for (size_t step = top; step; step >>= 1)
+        if (pos + step <= n && temp[pos + step - 1] <= rem) { pos += step; rem -= temp[pos - 1]; }
+      perm[i] = (uint32_t)pos;                               // 0-based index of that element
+      for (size_t k = pos + 1; k <= n; k += k & (~k + 1)) temp[k - 1]--;
+    }
   }
   r.align();
   vec<uint64_t> sizes(n);

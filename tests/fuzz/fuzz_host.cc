@@ -10,6 +10,9 @@
 // Every trial takes a corpus file, applies 1..8 mutations (bit flips, byte stores, truncation, splices, length-field edits) and feeds it through the
 // entry points.  A sanitizer report aborts the process (non-zero exit); the summary line says how many inputs were accepted / rejected.
 #include <dirent.h>
+#include <signal.h>
+#include <unistd.h>
+#include <fcntl.h>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -22,6 +25,18 @@
 
 static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
 static uint64_t Rng() { g_rng ^= g_rng << 13; g_rng ^= g_rng >> 7; g_rng ^= g_rng << 17; return g_rng; }
+
+// a trial that runs longer than 20 s is a finding, too (an input that makes the parser spin): the input is written to slow_input.jxl and the process fails
+extern "C" void __sanitizer_print_stack_trace(void);      // (where the trial was when its time ran out)
+static const uint8_t* g_cur = nullptr; static size_t g_cur_size = 0;
+static void OnAlarm(int) {
+  __sanitizer_print_stack_trace();
+  const int fd = open("slow_input.jxl", O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd >= 0) { size_t off = 0; while (off < g_cur_size) { const ssize_t k = write(fd, g_cur + off, g_cur_size - off); if (k <= 0) break; off += (size_t)k; } close(fd); }
+  static const char msg[] = "fuzz_host: a trial exceeded its time budget (input saved as slow_input.jxl)\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  _exit(3);
+}
 
 static void Mutate(std::vector<uint8_t>& b, const std::vector<std::vector<uint8_t>>& corpus) {
   const int n = 1 + (int)(Rng() % 8);
@@ -68,6 +83,7 @@ int main(int argc, char** argv) {
   const long trials = atol(argv[2]);
   const double seconds = atof(argv[3]);
   if (argc > 4) g_rng ^= strtoull(argv[4], nullptr, 0) * 0xD1342543DE82EF95ull + 1;
+  signal(SIGALRM, OnAlarm);
   const auto t0 = std::chrono::steady_clock::now();
   long done = 0, accepted = 0, rejected = 0, sized = 0, icc_ok = 0;
   std::vector<char> text(1 << 16);
@@ -79,6 +95,8 @@ int main(int argc, char** argv) {
     // exact-size heap copy: an over-read of the input is an ASan report, not a read of vector slack
     uint8_t* data = (uint8_t*)malloc(b.size() ? b.size() : 1);
     memcpy(data, b.data(), b.size());
+    g_cur = data; g_cur_size = b.size();
+    alarm(20);
     (void)JxlSignatureCheck(data, b.size());
     if (JxlHipDebugDescribe(data, b.size(), text.data(), text.size()) == 0) accepted++; else rejected++;
     JxlPixelFormat fmt = {(uint32_t)(Rng() % 5), (Rng() & 1) ? JXL_TYPE_UINT8 : JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN, (size_t)(Rng() % 3 == 0 ? 16 : 0)};
@@ -96,6 +114,7 @@ int main(int argc, char** argv) {
       }
       JxlDecoderDestroy(dec);
     }
+    alarm(0);
     free(data);
   }
   printf("{\"trials\": %ld, \"accepted\": %ld, \"rejected\": %ld, \"sized\": %ld, \"icc\": %ld, \"corpus\": %zu, \"seconds\": %.1f}\n", done, accepted, rejected, sized, icc_ok, corpus.size(),
