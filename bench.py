@@ -551,30 +551,32 @@ def main():
         steps from an idle pipeline, bracketed by barrier + synchronize"""
         steps, warmup = kw.pop("steps", args.steps), args.warmup
         r = Run(args, jx, torch, dist, streams, dev, local_rank, rank, world, kw.pop("B", B), inner, kw.pop("W", W), kw.pop("H", H), consumer=consumer, **kw)
-        r.stream_texture, r.stream_tree_shape = texture, tree_shape
-        r.run(1)                              # (a first job alone: should the shared planes be too small for this shape they grow before the ring fills)
-        r.run(r.slots)                        # every batch object of the ring allocates its arenas (untimed set-up)
-        r.run(warmup * inner)
-        r.p.collect_times()
-        elapsed, ends, t_decode = r.run(steps * inner)
-        cpu_s = r.cpu_s
-        if world > 1:
-            t = torch.tensor([elapsed, t_decode], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed, t_decode = float(t[0].item()), float(t[1].item())
-            c = torch.tensor([cpu_s], dtype=torch.float64, device=dev)
-            dist.all_reduce(c, op=dist.ReduceOp.SUM)       # host CPU seconds of all ranks (they share one host)
-            cpu_s = float(c[0].item())
-        times, runs = r.p.collect_times()
-        p = r.p
-        res = {"elapsed": elapsed, "t_decode": t_decode, "step_end": ends[inner - 1::inner], "stage_ms": {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"},
-               "stage_bytes": p.stage_bytes, "device_bytes": p.info("device_bytes"), "compressed": int(p.info("compressed_bytes") // max(1, p.info("frames"))), "slots": r.slots,
-               "prepare_ms_per_job": p.info("prepare_us_total") / 1e3 / max(1, p.info("prepared_jobs")), "gather": r.consumer == "gather", "cpu_s": cpu_s, "checksum": int(r.checksum.item()),
-               "nonzeros": p.info("hf_nonzeros") // max(1, p.info("frames")), "lf_simt": [p.info(k) for k in ("lf_simt_frames", "lf_legacy_frames", "lf_simt_wp")],
-               "private_plane_jobs": p.info("private_plane_jobs"), "B": r.B, "steps": steps}
-        if not args.no_verify and rank == 0:
-            res["verified"], res["verified_frames"] = r.verify(steps * inner, O, np, {"uint8": "u8", "uint16": "u16", "float32": "f32"}[np.dtype(r.dtype).name])
-        r.close()
+        try:
+            r.stream_texture, r.stream_tree_shape = texture, tree_shape
+            r.run(1)                              # (a first job alone: should the shared planes be too small for this shape they grow before the ring fills)
+            r.run(r.slots)                        # every batch object of the ring allocates its arenas (untimed set-up)
+            r.run(warmup * inner)
+            r.p.collect_times()
+            elapsed, ends, t_decode = r.run(steps * inner)
+            cpu_s = r.cpu_s
+            if world > 1:
+                t = torch.tensor([elapsed, t_decode], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed, t_decode = float(t[0].item()), float(t[1].item())
+                c = torch.tensor([cpu_s], dtype=torch.float64, device=dev)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)       # host CPU seconds of all ranks (they share one host)
+                cpu_s = float(c[0].item())
+            times, runs = r.p.collect_times()
+            p = r.p
+            res = {"elapsed": elapsed, "t_decode": t_decode, "step_end": ends[inner - 1::inner], "stage_ms": {k[:-3]: v / max(runs, 1) for k, v in times.items() if k != "total_ms"},
+                   "stage_bytes": p.stage_bytes, "device_bytes": p.info("device_bytes"), "compressed": int(p.info("compressed_bytes") // max(1, p.info("frames"))), "slots": r.slots,
+                   "prepare_ms_per_job": p.info("prepare_us_total") / 1e3 / max(1, p.info("prepared_jobs")), "gather": r.consumer == "gather", "cpu_s": cpu_s, "checksum": int(r.checksum.item()),
+                   "nonzeros": p.info("hf_nonzeros") // max(1, p.info("frames")), "lf_simt": [p.info(k) for k in ("lf_simt_frames", "lf_legacy_frames", "lf_simt_wp")],
+                   "private_plane_jobs": p.info("private_plane_jobs"), "B": r.B, "steps": steps}
+            if not args.no_verify and rank == 0:
+                res["verified"], res["verified_frames"] = r.verify(steps * inner, O, np, {"uint8": "u8", "uint16": "u16", "float32": "f32"}[np.dtype(r.dtype).name])
+        finally:
+            r.close()
         del r
         torch.cuda.empty_cache()
         return res
@@ -727,18 +729,26 @@ def main():
                 torch.cuda.empty_cache(); jx.arena_pool_trim()
             if mod_streams:
                 try:
-                    r4 = measure(mod_streams, B=2, W=8192, H=8192, dtype="uint16", nch=1, in_flight=2, lf_streams=2, steps=max(6, min(args.steps, 10)))     # (8 GB of device memory per frame in flight: mostly per-group scratch)
-                    px = 2 * 8192 * 8192 * r4["steps"]
+                    r4, bm = None, 2
+                    for bm, infl in ((4, 1), (2, 2)):        # (8 GB of device memory per frame in flight — mostly per-group scratch for local transforms —: jobs of 4 if they fit, else of 2)
+                        try:
+                            r4 = measure(mod_streams, B=bm, W=8192, H=8192, dtype="uint16", nch=1, in_flight=infl, lf_streams=2, steps=max(6, min(args.steps, 10)))
+                            break
+                        except Exception:
+                            torch.cuda.empty_cache(); jx.arena_pool_trim()
+                            if bm == 2:
+                                raise
+                    px = bm * 8192 * 8192 * r4["steps"]
                     sm, sb = r4["stage_ms"], r4["stage_bytes"]
                     d4 = jx.decoder_builder()
                     ts = []
                     for _ in range(3):
                         t0 = time.perf_counter(); d4.decode_with(mod_streams[0], np.uint16); ts.append((time.perf_counter() - t0) * 1e3)
                     result["config"]["workload_8k_modular_squeeze_u16"] = {
-                        "what": "BASELINE config 4: lossless Modular 8192x8192 u16 (one channel), default Squeeze chain, 1024 groups + 16 LF groups of residual channels; jobs of 2 through the pipeline; stage 'lf' = global "
+                        "what": "BASELINE config 4: lossless Modular 8192x8192 u16 (one channel), default Squeeze chain, 1024 groups + 16 LF groups of residual channels; jobs of 2 or 4 (frames_per_job) through the pipeline; stage 'lf' = global "
                                 "Modular stream (ModularGlobalFastKernel), 'out' = group sub-streams (ModularGroupFastKernel), inverse Squeeze and the write stage",
-                        "value": round(px / r4["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "ms_per_job": round(r4["elapsed"] / r4["steps"] * 1e3, 3), "single_image_ms": round(_median(ts), 2),
-                        "stage_ms": {k: round(v, 4) for k, v in sm.items()}, "compressed_bytes_per_frame": r4["compressed"], "verified_vs_oracle": r4.get("verified")}
+                        "value": round(px / r4["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "frames_per_job": bm, "ms_per_job": round(r4["elapsed"] / r4["steps"] * 1e3, 3), "single_image_ms": round(_median(ts), 2),
+                        "stage_ms": {k: round(v, 4) for k, v in sm.items() if k in ("lf", "out")}, "compressed_bytes_per_frame": r4["compressed"], "verified_vs_oracle": r4.get("verified")}
                 except Exception as ex:
                     result["config"]["workload_8k_modular_squeeze_u16"] = {"error": repr(ex)}
                 torch.cuda.empty_cache(); jx.arena_pool_trim()
