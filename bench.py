@@ -480,7 +480,7 @@ def main():
                     "operations (default) or through the library's own C entry points over RCCL (JxlHipGatherFrames, csrc/gather.cc; weak scaling only)")
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
     ap.add_argument("--in-flight", type=int, default=11, help="jobs in flight in the library pipeline (JxlHipPipelineOptions.jobs_in_flight): LF stages run this many jobs ahead of the tail")
-    ap.add_argument("--lf-streams", type=int, default=7, help="side streams the LF stages of the jobs ahead are spread over")
+    ap.add_argument("--lf-streams", type=int, default=11, help="side streams the LF stages of the jobs ahead are spread over")
     ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current job, one stream and one coefficient set each")
     ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of a cold pipeline that take the one-wavefront-per-stream kernel")
     ap.add_argument("--prepare-threads", type=int, default=int(os.environ.get("JXL_BENCH_PREPARE_THREADS", "3")), help="host threads of the pipeline that each parse + prepare + upload one job at a time")
@@ -621,11 +621,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": stage_bytes[dom], "avg_launch_ms": round(stage_ms[dom], 4)},
             # the entropy stages above are serial chains (HBM fraction ~ 0 by construction); the stage that IS bound by HBM is the IDCT:
-            # the same figures for it (stage = IdctTileKernel + IdctRareSpecialKernel, measured while the other stages of the pipeline run beside it)
-            "roofline_hbm_stage": (lambda ms, by, pf: {"bound": "hbm", "kernel": "IdctTileKernel (+ IdctRareSpecialKernel)", "achieved": round(by / (ms * 1e-3) / 1e9, 3) if ms > 0 else None,
+            # the same figures for it (stage = IdctTileKernel, measured while the other stages of the pipeline run beside it)
+            "roofline_hbm_stage": (lambda ms, by, pf: {"bound": "hbm", "kernel": "IdctTileKernel<4, true>", "achieved": round(by / (ms * 1e-3) / 1e9, 3) if ms > 0 else None,
                                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
                                                      "traffic": pf, "algorithmic_bytes_per_launch": by, "avg_launch_ms": round(ms, 4)})(
-                stage_ms.get("idct", 0.0), stage_bytes.get("idct", 0), _pmc_bytes(("IdctTileKernel<4, true>", "IdctRareSpecialKernel"), B)),
+                stage_ms.get("idct", 0.0), stage_bytes.get("idct", 0), _pmc_bytes(("IdctTileKernel<4, true>",), B)),
             # what the step as a whole runs into is neither HBM nor MFMA but vector-ALU issue (profiles/r03_notes.md): VALU wavefront-instructions of all kernels of a
             # step (SQ_INSTS_VALU, profiles/sq_valu.json) against the measured issue peak of the chip (tools/microbench/valu_issue.hip)
             "valu_issue": _valu_issue(B, head["elapsed"] / args.steps, steady),

@@ -519,7 +519,7 @@ void Batch::Reset() {
   // (stage timings recorded so far stay: CollectTimes sums over the object's life)
   any_complex_ = false; any_gab_ = any_vardct_ = any_modular_ = any_modchan_ = any_multipass_ = false;
   prepared_ = false; ran_once_ = false; flags_pending_ = false; decodes_since_finish_ = 0;
-  cfg.idct_flags_known = 0; cfg.skip_hf = 0;
+  cfg.idct_flags_known = 0; cfg.skip_hf = 0; cfg.max_passes = 0;
   lf_simt_ = LfSimtPlan();
   if (lf_batch_) lf_batch_->Reset();     // (kept for its arenas; Prepare drops it when no unit refers to an LF frame)
 }
@@ -1295,7 +1295,7 @@ void Batch::Prepare(void* stream_v, bool wait_upload) {
       f.lf_scratch = (int32_t*)(dwork_ + o.lf_scratch); f.lf_scratch_stride = o.lf_scratch_stride;
       // HfGlobal-derived fields (present once parsed)
       if (!p.ac_code.empty()) {
-        f.num_passes = p.num_passes;
+        f.num_passes = cfg.max_passes > 0 ? std::min<uint32_t>(p.num_passes, (uint32_t)cfg.max_passes) : p.num_passes;     // (a progressive flush shows the first passes only; the later ones' sections stay unread)
         f.passes = dpasses_ + pass_first_[i];
         for (uint32_t ps = 0; ps < p.num_passes; ps++) {
           const ConstOffsets::Pass& cp = c.pass[ps];
@@ -1627,7 +1627,8 @@ void Batch::Prepare(void* stream_v, bool wait_upload) {
       lf_batch_->Prepare(stream_v, wait_upload);
     }
   }
-  for (int i = 0; i < n; i++) if (images_[i]->plan.partial) cfg.skip_hf = 1;     // (a frame cut off inside its AC groups: LF part only)
+  // (a frame cut off inside its AC groups, FramePlan::partial: the HF kernels leave out the group streams that are not completely there; nothing to do when none is)
+  for (int i = 0; i < n; i++) if (images_[i]->plan.partial && images_[i]->plan.partial_ac_sections == 0) cfg.skip_hf = 1;
   cfg.any_multipass = any_multipass_ ? 1 : 0;
   if (any_multipass_) cfg.lane_stride_hf = 1;   // progressive frames: only the SIMT HF kernel walks the passes
   if (cfg.any_subsampled) cfg.lane_stride_hf = 1;   // so do chroma-subsampled frames (per-channel block grids)
@@ -2326,13 +2327,12 @@ void Batch::Finish(void* stream_v) {
 void Batch::ApplyIdctFlags(const uint32_t* flags) {
   const int n = (int)images_.size();
   cfg.any_irregular_blocks = cfg.any_big_blocks = 0;
-  cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = cfg.need_rare_special = 0;
+  cfg.need_tile4_plain = cfg.need_tile4_special = cfg.need_tile8_plain = cfg.need_tile8_special = 0;
   for (int i = 0; i < n; i++) {
     if (images_[i]->plan.modular) continue;
     const uint32_t v = flags[i];
     cfg.any_irregular_blocks |= (v & 1) != 0; cfg.any_big_blocks |= (v & 2) != 0;
     if (v & 1) continue;                                  // generic IdctKernel frame
-    if (v & 16) cfg.need_rare_special = 1;
     if (v & 4) { if (v & 8) cfg.need_tile8_special = 1; else cfg.need_tile8_plain = 1; }
     else { if (v & 8) cfg.need_tile4_special = 1; else cfg.need_tile4_plain = 1; }
   }

@@ -947,6 +947,7 @@ void ParseFrameStart(const Codestream& cs, const ImageHeader& ih, uint64_t frame
     const bool lf_complete = !p->single_section && !p->modular && perm.empty() && n > lf_last && phys[lf_last].offset + phys[lf_last].size <= cs.size;
     if (!(allow_partial && !skip && lf_complete && ih.extra.empty() && !p->use_lf_frame)) throw ParseError("truncated", false);
     p->partial = true;
+    for (size_t i = lf_last + 1; i < n; i++) p->partial_ac_sections += phys[i].offset + phys[i].size <= cs.size;
   }
   p->frame_end_bitpos = off * 8;
   if (skip) return;

@@ -139,7 +139,8 @@ struct FramePlan {
   float sigma_for_modular = 1.0f;
   FrameFeatures feat;
   uint64_t frame_end_bitpos = 0;           // first bit after the frame's last section (= next frame header)
-  bool partial = false;                    // the codestream ends inside the frame's PassGroup sections: LF part complete, no AC group is decoded (progressive flush)
+  bool partial = false;                    // the codestream ends inside the frame's PassGroup sections: LF part complete; the AC groups that are completely there are decoded (progressive flush)
+  uint32_t partial_ac_sections = 0;        // (partial) PassGroup sections that are completely there
   // geometry
   uint32_t width = 0, height = 0, group_dim = 256;
   uint32_t xgroups = 0, ygroups = 0, num_groups = 0, xlfgroups = 0, ylfgroups = 0, num_lf_groups = 0;

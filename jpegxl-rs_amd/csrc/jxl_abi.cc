@@ -57,6 +57,8 @@ struct JxlDecoderStruct {
   bool anim_cached, anim_cache_failed; JxlPixelFormat anim_format; bool anim_keep_orientation, anim_unpremul, anim_spot; uint32_t anim_int_bits;
   bool partial;        // the batch was parsed from a stream that ends inside its frame's AC groups (Batch::AddImage allow_partial): headers and JxlDecoderFlushImage work, the decode waits for more input
   bool progression_emitted;   // JXL_DEC_FRAME_PROGRESSION (kDC step) has been returned for the current frame
+  int progression_passes;     // passes of every group the latest progression step of the current frame shows (0: the kDC step) — what JxlDecoderFlushImage draws
+  size_t downsampling_target; // JxlDecoderGetIntendedDownsamplingRatio: 8 at the kDC step, the frame header's ratio for the passes shown after that, 1 for the full image
   bool frame_done;     // JXL_DEC_FULL_IMAGE of frames[frame_cursor] has been returned: its header stays readable until the next JxlDecoderProcessInput moves on
   Batch* batch;
   int device;
@@ -97,7 +99,7 @@ static void ClearState(JxlDecoder* d) {
   d->jpeg_available = false; d->jpeg_written = 0; d->jpeg_bytes.clear();
   d->stage = JxlDecoderStruct::kInit; d->events_emitted = 0; d->started = false; d->need_out_reported = false;
   d->frames.clear(); d->frame_cursor = 0; d->skip_frames = 0; d->frame_announced = false; d->frame_done = false;
-  d->anim_cached = d->anim_cache_failed = false; d->partial = false; d->progression_emitted = false;
+  d->anim_cached = d->anim_cache_failed = false; d->partial = false; d->progression_emitted = false; d->progression_passes = 0; d->downsampling_target = 1;
   d->mt_init = nullptr; d->mt_run = nullptr; d->mt_destroy = nullptr; d->mt_opaque = nullptr;
   d->ec_buffers.clear(); d->progressive_detail = 1 /* kDC, libjxl's default */; d->out_int_bits = 0;
   d->decompress_boxes = false; d->container.clear(); d->boxes.clear(); d->box_next = d->box_split = 0; d->box_current = -1; d->box_complete_pending = false;
@@ -248,7 +250,7 @@ JxlDecoderStatus JxlDecoderGetExtraChannelName(const JxlDecoder* d, size_t index
   return JXL_DEC_SUCCESS;
 }
 size_t JxlDecoderSizeHintBasicInfo(const JxlDecoder* d) { return d->batch ? 0 : 98; }      // (decode.cc InitialBasicInfoSizeHint: container signature + box headers + the largest fixed headers)
-size_t JxlDecoderGetIntendedDownsamplingRatio(const JxlDecoder*) { return 1; }
+size_t JxlDecoderGetIntendedDownsamplingRatio(const JxlDecoder* d) { return d ? d->downsampling_target : 1; }      // decode.rs:1495
 JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* d, char* name, size_t size) {
   const int k = CurrentFrame(d);
   if (k < 0 || d->stage != JxlDecoderStruct::kFrame || !name) return JXL_DEC_ERROR;
@@ -483,15 +485,17 @@ JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* d, const JxlPixelFo
 // ---- decode.rs:1482 / :1513 / :1528
 JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* d, int detail) {
   if (!d || detail < 0 || detail > 3) { SetLastError("unsupported progressive detail (kFrames, kDC, kLastPasses, kPasses are accepted)"); return JXL_DEC_ERROR; }
-  // kDC (1) and above: JXL_DEC_FRAME_PROGRESSION is returned once per frame, when the frame's LF image is decodable — before its AC groups are looked at — and
-  // JxlDecoderFlushImage then shows that step (a frame is decoded whole on the device, so the pass-by-pass steps of kLastPasses / kPasses coincide with the full image)
+  // kDC (1) and above: JXL_DEC_FRAME_PROGRESSION is returned when the frame's LF image is decodable — before its AC groups are looked at; kLastPasses (2): again after
+  // every pass the frame header names as the last one of a downsampling ratio; kPasses (3): after every pass but the last.  JxlDecoderFlushImage then shows that step
+  // (one more decode of the frame on the device with its HF stage cut down to the step's passes), JxlDecoderGetIntendedDownsamplingRatio names its ratio.
   d->progressive_detail = detail;
   return JXL_DEC_SUCCESS;
 }
-// decode.rs:1513.  Writes the image as far as it can be shown into the buffer set with JxlDecoderSetImageOutBuffer: after JXL_DEC_FRAME_PROGRESSION, or after
-// JXL_DEC_NEED_MORE_INPUT on a stream that ends inside its frame's AC groups, that is the kDC step — the LF image and the HF metadata decoded, every AC coefficient zero,
-// through the regular IDCT / restoration / colour stages (dec_frame.cc Flush: groups that have not arrived are drawn from their LF part).  Single-frame VarDCT images
-// without extra channels whose sections come in file order; anything else answers JXL_DEC_ERROR ("no flush was done"), as libjxl does when nothing new can be shown.
+// decode.rs:1513.  Writes the image as far as it can be shown into the buffer set with JxlDecoderSetImageOutBuffer.  After JXL_DEC_FRAME_PROGRESSION: that step — the
+// kDC step is the LF image and the HF metadata decoded, every AC coefficient zero; a pass step adds the first passes of every group — through the regular IDCT /
+// restoration / colour stages.  After JXL_DEC_NEED_MORE_INPUT on a stream that ends inside its frame's AC groups: every group with the passes that have completely
+// arrived, the others from their LF part (dec_frame.cc Flush).  Single-frame VarDCT images without extra channels whose sections come in file order; anything else
+// answers JXL_DEC_ERROR ("no flush was done"), as libjxl does when nothing new can be shown.
 JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* d) {
   JXL_MM_SCOPE(d);
   if (!d || !d->batch || d->stage < JxlDecoderStruct::kHeaders || !d->out_set || !d->out_buffer || d->out_callback || d->mt_run) { SetLastError("nothing to flush: no frame in progress or no image out buffer set"); return JXL_DEC_ERROR; }
@@ -508,9 +512,14 @@ JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* d) {
     o.keep_orientation = d->keep_orientation; o.int_bits = d->out_int_bits;
     hold.b->SetOutput(0, o);
     if (hold.b->image(0).out_size > d->out_size) throw ParseError("output buffer too small for this frame", false);
-    hold.b->cfg.skip_hf = 1;
+    // what is shown: input that ends inside the frame — every group with the passes that have completely arrived (the HF kernels leave the others out); after a
+    // JXL_DEC_FRAME_PROGRESSION event on complete input — that step: the LF image alone (kDC), or the first passes of every group (kLastPasses / kPasses)
+    if (!e.plan.partial) {
+      if (d->progression_passes <= 0) hold.b->cfg.skip_hf = 1;
+      else if ((uint32_t)d->progression_passes < e.plan.num_passes) hold.b->cfg.max_passes = d->progression_passes;
+    }
     hold.b->Prepare(DecoderStream(d));
-    hold.b->Run(DecoderStream(d));       // ══► the HIP hot path without its HF stage
+    hold.b->Run(DecoderStream(d));       // ══► the HIP hot path, its HF stage cut down to what the step shows
     hold.b->Finish(DecoderStream(d));
     hold.b->CopyOutputToHost(0, d->out_buffer, hold.b->image(0).out_size, DecoderStream(d));
     return JXL_DEC_SUCCESS;
@@ -694,7 +703,7 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
     }
     while (d->stage == JxlDecoderStruct::kFrame) {
       // one round per frame the caller sees: the composite (coalescing, one round) or every regular frame as coded
-      if (d->frame_done) { d->frame_cursor++; d->frame_announced = false; d->frame_done = false; d->progression_emitted = false; }     // (the frame reported last stayed current until now)
+      if (d->frame_done) { d->frame_cursor++; d->frame_announced = false; d->frame_done = false; d->progression_emitted = false; d->progression_passes = 0; d->downsampling_target = 1; }     // (the frame reported last stayed current until now)
       while (d->skip_frames > 0 && d->frame_cursor < d->frames.size() && !d->frame_announced) { d->frame_cursor++; d->skip_frames--; }
       if (d->frame_cursor >= d->frames.size()) { d->stage = JxlDecoderStruct::kDone; break; }
       if ((d->events_wanted & JXL_DEC_FRAME) && !d->frame_announced) { d->frame_announced = true; d->events_emitted |= JXL_DEC_FRAME; return JXL_DEC_FRAME; }
@@ -733,9 +742,26 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
         SetLastError("the stream ends inside the frame");
         return d->input_closed ? JXL_DEC_ERROR : JXL_DEC_NEED_MORE_INPUT;
       }
-      if ((d->events_wanted & JXL_DEC_FRAME_PROGRESSION) && d->progressive_detail >= 1 && !d->progression_emitted && d->coalescing && d->frames.size() == 1 && d->batch->num_frames(0) == 1) {
+      if ((d->events_wanted & JXL_DEC_FRAME_PROGRESSION) && d->progressive_detail >= 1 && d->coalescing && d->frames.size() == 1 && d->batch->num_frames(0) == 1) {
         const ImageEntry& e0 = d->batch->frame(0, 0);
-        if (!e0.plan.modular && !e0.plan.single_section && e0.ih.extra.empty() && !e0.plan.use_lf_frame && !e0.complex) { d->progression_emitted = true; return JXL_DEC_FRAME_PROGRESSION; }
+        const FramePlan& p0 = e0.plan;
+        if (!p0.modular && !p0.single_section && e0.ih.extra.empty() && !p0.use_lf_frame && !e0.complex) {
+          // frame_header.h Passes::GetDownsamplingTargetForCompletedPasses
+          auto target = [&](uint32_t done) -> size_t {
+            if (done >= p0.num_passes) return 1;
+            uint32_t r = 8;
+            for (uint32_t i = 0; i < p0.num_ds; i++) if (done > p0.ds_last_pass[i]) r = std::min(r, p0.downsample[i]);
+            return r;
+          };
+          if (!d->progression_emitted) { d->progression_emitted = true; d->progression_passes = 0; d->downsampling_target = 8; return JXL_DEC_FRAME_PROGRESSION; }      // the kDC step
+          // kLastPasses: a step after every pass the frame header names as the last one of a downsampling ratio; kPasses: after every pass (the last pass is the full image)
+          for (uint32_t done = (uint32_t)d->progression_passes + 1; d->progressive_detail >= 2 && done < p0.num_passes; done++) {
+            bool step = d->progressive_detail >= 3;
+            for (uint32_t i = 0; i < p0.num_ds; i++) step |= p0.ds_last_pass[i] + 1 == done;
+            if (step) { d->progression_passes = (int)done; d->downsampling_target = target(done); return JXL_DEC_FRAME_PROGRESSION; }
+          }
+          d->progression_passes = (int)p0.num_passes; d->downsampling_target = 1;
+        }
       }
       if (NeedsToneMapping(d)) throw ParseError("unsupported: desired_intensity_target below the intensity target of a PQ image asks for libjxl's tone mapping stage, which this decoder does not have (leave the target at 0 to get the untouched PQ pixels)", true);
       OutputSpec o;

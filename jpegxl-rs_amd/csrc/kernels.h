@@ -150,9 +150,9 @@ struct LaunchCfg {
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
   int hf_lanes_per_wave = 0, hf_lanes_per_wg = 0;   // SIMT HF decode: group streams per wavefront / per workgroup (0: the throughput defaults — a frame's streams on four wavefronts of one workgroup)
   int skip_hf = 0;                   // the HF stage is left out: every AC coefficient stays zero (progressive flush at the kDC step, decoder.h AddImage allow_partial)
+  int max_passes = 0;                // > 0: at most this many passes of every group are decoded (progressive flush at a kLastPasses / kPasses step)
   int no_flag_wait = 0;              // latency mode (pipeline.h small-job scheduler): the tail never waits on the host for the placement flags of the LF stage, every IDCT kernel variant is launched
   int need_tile4_plain = 1, need_tile4_special = 1, need_tile8_plain = 1, need_tile8_special = 1;   // IdctTileKernel<TB, SPECIAL> variants some frame takes
-  int need_rare_special = 1;         // some tile-kernel frame has IDENTITY / DCT2X2 blocks (IdctRareSpecialKernel)
   int debug_stop_after = 0;          // testing: the tail of a decode stops after 1 = IDCT, 2 = gaborish, 3 / 4 / 5 = EPF pass 0 / 1 / 2 (stage-by-stage filters only)
   int force_unfused_filters = 0;     // testing: stage-by-stage gaborish / EPF / output kernels even for fusable frames        // testing: run the generic (non-tiled) IDCT kernel even for tile-regular frames
   int hf_block_threads = 512;        // threads per HF-decode block (streams per block = threads / lane_stride_hf)

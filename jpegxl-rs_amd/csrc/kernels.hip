@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(64) void LfPlaceSimtKernel(const FrameDev* __restri
     if (clash) { err = kErrVarblock; break; }
     if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;      // not inside one 32x32 tile: the IDCT uses 64x64 tiles
     if (s == 1 || s == 2 || s == 3 || (s >= 12 && s <= 17)) flags_acc |= 8u;  // IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4 / AFV0-3: the tile kernel variant that carries them
-    if (s == 1 || s == 2 || (s >= 14 && s <= 17)) flags_acc |= 16u;           // IDENTITY / DCT2X2 / AFV: redone by IdctRareSpecialKernel after the tile kernel
+    if (s == 1 || s == 2 || (s >= 14 && s <= 17)) flags_acc |= 16u;           // IDENTITY / DCT2X2 / AFV (statistics; until round 5 a second kernel redid these blocks after the tile kernel)
     if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;   // DCT128/256 family: BigIdctKernel (+ generic path if unaligned)
     else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;  // varblock not contained in a 64x64 tile: generic IDCT
     const uint32_t go = goff[wi], gc = gcnt[wi];
@@ -1736,7 +1736,7 @@ struct WpLane {
 };
 
 // One LF-group stream per lane, `lanes_per_wave` lanes per wavefront.  Instantiations: <false, false> the lean one — a context per row or a table
-// over W + N - NW, predictors zero / W / clamped gradient (the gradient trees of `cjxl --faster_decoding`, the synthesiser's default): 64 VGPRs;
+// over W + N - NW, predictors zero / W / clamped gradient (the gradient trees of `cjxl --faster_decoding`, the synthesiser's default): 72 VGPRs (under a 64-register cap the row-change path spilled six);
 // <false, true> adds tables over W / N and pairs of properties and the rarer predictors; <true, true> weighted-predictor state on top (any channel
 // class with kLfSimtWpLive): a 256-byte division table and ~50 VGPRs more.
 // No LDS in any of them (kernels.h: LF workgroups stay for hundreds of milliseconds and would fragment what the HF workgroups need): the
@@ -1750,7 +1750,7 @@ __device__ __forceinline__ int32_t QuadSum(int32_t v) {
   v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
   return v;
 }
-template <bool WP, bool GEN, bool QUAD = false> __global__ __launch_bounds__(256, WP ? 4 : 8) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
+template <bool WP, bool GEN, bool QUAD = false> __global__ __launch_bounds__(256, WP ? 4 : (GEN ? 6 : 7)) void LfDecodeSimtKernel(const FrameDev* __restrict__ frames, const LfSimtStream* __restrict__ streams, const LfSimtLane* __restrict__ lanes,
                                                           const uint8_t* __restrict__ luts, uint32_t num_lanes, uint32_t lanes_per_wave, int high_priority, const uint32_t* __restrict__ s_div) {
   static_assert(!QUAD || WP, "quads only pay for the weighted predictor");
   const uint32_t lane_in_wave = QUAD ? (threadIdx.x & 63) >> 2 : (threadIdx.x & 63);
@@ -2271,7 +2271,11 @@ __global__ __launch_bounds__(512) void HfDecodeKernel(const FrameDev* __restrict
   BitReaderP br;
   uint64_t limit;
   if (f.single_section) { br.Init(f.cs, f.hf_start_bitpos, f.cs_size); limit = f.cs_size * 8; }
-  else { const uint32_t si = 2 + f.num_lf_groups + g; const uint64_t off = f.sec_off[si]; br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8; }
+  else {
+    const uint32_t si = 2 + f.num_lf_groups + g; const uint64_t off = f.sec_off[si];
+    if (off + f.sec_size[si] > f.cs_size) return;      // input that ends inside the frame (progressive flush): this group's stream is not there yet, the group is drawn from its LF part
+    br.Init(f.cs, off * 8, off + f.sec_size[si]); limit = (off + f.sec_size[si]) * 8;
+  }
   if (f.num_passes != 1) { SetError(f, kErrUnsupported); return; }   // progressive frames go through the SIMT kernel (the host forces it)
   const BlockCtxDev& bcm = *f.bcm;
   const uint32_t nctx = bcm.num_ctxs;
@@ -2521,6 +2525,9 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   uint64_t bit0, byte_end;
   if (f.single_section) { bit0 = f.hf_start_bitpos; byte_end = f.cs_size; }
   else { const uint32_t si = 2 + f.num_lf_groups + pass * f.num_groups + gsafe; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); bit0 = off * 8; byte_end = off + sz; }
+  // input that ends inside the frame (progressive flush, host_parse.cc FramePlan::partial): a group stream that is not completely there is left out, and with it the
+  // group's later passes — the group is drawn from what has arrived (dec_frame.cc Flush).  Complete frames never get here: their sections lie inside the codestream.
+  if (!done && byte_end > f.cs_size) { done = true; dead = true; bit0 = 0; }
   const uint64_t limit = byte_end * 8;
   const uint32_t* words = reinterpret_cast<const uint32_t*>(f.cs);
   BitReaderRing br;
@@ -2862,20 +2869,104 @@ __device__ void SpecialTransform(uint32_t s, const float* cf, float* out, size_t
   }
 }
 
-// DCT4X4 / DCT4X8 / DCT8X4 on an 8x8 block that sits in an LDS tile in stored order, one HALF per lane (two adjacent lanes of
-// a wavefront per block and channel): half h needs the stored rows h, h + 2, h + 4, h + 6 (plus the two or four DC-mix
-// inputs of rows 0 / 1) and produces rows 4h..4h+3 (DCT4X4, DCT4X8) or columns 4h..4h+3 (DCT8X4).  Outputs overwrite the
-// partner's inputs, so every lane reads first and all lanes write afterwards (lock-step inside the wavefront + a wave
-// fence).  Same arithmetic as SpecialTransform, 32 instead of 64 live coefficients per lane.
+// The 8x8 "special" transforms on a block that sits in an LDS tile in stored order, one HALF per lane (two adjacent lanes of a
+// wavefront per block and channel).  Half h needs four stored rows — h, h + 2, h + 4, h + 6 (DCT2X2: 2h, 2h + 1, 2h + 4, 2h + 5)
+// — plus the DC-mix inputs of rows 0 / 1, and produces rows 4h..4h+3 (DCT8X4: columns 4h..4h+3; AFV: half 0 = the AFV corner and
+// the 4x4 DCT beside it from the even rows, half 1 = the 4x8 DCT from the odd rows).  Outputs overwrite the partner's inputs,
+// so every lane reads first and all lanes write afterwards (lock-step inside the wavefront + a wave fence).  Same arithmetic,
+// same operation order as SpecialTransform; 32 instead of 64 live coefficients per lane.
+// SmallIdct2D with the intermediate (row-transformed) block parked at its destination in LDS instead of in registers: the same operations in
+// the same order, half the live registers (the half transforms run beside 36 registers of loaded inputs under the tile kernel's 96-VGPR budget)
+template <int R, int C, int PITCH> __device__ __forceinline__ void SmallIdct2DLds(const float* sem, float* out) {
+#pragma unroll
+  for (int v = 0; v < R; v++) {
+    float row[C];
+#pragma unroll
+    for (int u = 0; u < C; u++) row[u] = sem[v * C + u];
+    IDct1D<C>(row);
+#pragma unroll
+    for (int u = 0; u < C; u++) out[v * PITCH + u] = row[u];
+  }
+  __asm__ volatile("" ::: "memory");     // (keeps the compiler from forwarding the stores above into the loads below: that would be the register version again)
+#pragma unroll
+  for (int x = 0; x < C; x++) {
+    float col[R];
+#pragma unroll
+    for (int v = 0; v < R; v++) col[v] = out[v * PITCH + x];
+    IDct1D<R>(col);
+#pragma unroll
+    for (int y = 0; y < R; y++) out[y * PITCH + x] = col[y];
+  }
+}
+__device__ __forceinline__ uint32_t SpecialHalfRow(uint32_t s, uint32_t h, int iy) { return s == 2 ? 2 * h + (uint32_t)(iy & 1) + (uint32_t)(iy >> 1) * 4 : h + (uint32_t)iy * 2; }
+// DCT2X2: the first two levels only touch the stored 4x4 corner; one lane runs them in place before the halves are read
+template <int PITCH> __device__ __forceinline__ void Dct2x2Corner(float* blk) {
+  float a[16], b[16];
+#pragma unroll
+  for (int y = 0; y < 4; y++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) a[y * 4 + x] = blk[y * PITCH + x];
+  {
+    const float c00 = a[0], c01 = a[1], c10 = a[4], c11 = a[5];
+    a[0] = c00 + c01 + c10 + c11; a[1] = c00 + c01 - c10 - c11; a[4] = c00 - c01 + c10 - c11; a[5] = c00 - c01 - c10 + c11;
+  }
+#pragma unroll
+  for (int y = 0; y < 2; y++)
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      const float c00 = a[y * 4 + x], c01 = a[y * 4 + 2 + x], c10 = a[(y + 2) * 4 + x], c11 = a[(y + 2) * 4 + 2 + x];
+      b[y * 2 * 4 + x * 2] = c00 + c01 + c10 + c11; b[y * 2 * 4 + x * 2 + 1] = c00 + c01 - c10 - c11;
+      b[(y * 2 + 1) * 4 + x * 2] = c00 - c01 + c10 - c11; b[(y * 2 + 1) * 4 + x * 2 + 1] = c00 - c01 - c10 + c11;
+    }
+#pragma unroll
+  for (int y = 0; y < 4; y++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) blk[y * PITCH + x] = b[y * 4 + x];
+}
 template <int PITCH> __device__ __forceinline__ void SpecialHalfLoad(uint32_t s, const float* blk, uint32_t h, float (&in)[32], float (&dc)[4]) {
 #pragma unroll
-  for (int iy = 0; iy < 4; iy++)
+  for (int iy = 0; iy < 4; iy++) {
+    const float* row = blk + SpecialHalfRow(s, h, iy) * PITCH;
 #pragma unroll
-    for (int ix = 0; ix < 8; ix++) in[iy * 8 + ix] = blk[(h + iy * 2) * PITCH + ix];
+    for (int ix = 0; ix < 8; ix++) in[iy * 8 + ix] = row[ix];
+  }
   dc[0] = blk[0]; dc[1] = blk[1]; dc[2] = blk[PITCH]; dc[3] = blk[PITCH + 1];   // stored (0,0), (0,1), (1,0), (1,1)
 }
 template <int PITCH> __device__ __forceinline__ void SpecialHalfStore(uint32_t s, float* blk, uint32_t h, const float (&in)[32], const float (&dc)[4]) {
-  if (s == 3) {  // DCT4X4: quadrants (y = h, x = 0, 1)
+  if (s == 1) {  // IDENTITY: quadrants (y = h, x = 0, 1); in[iy * 8 + j] = stored (h + 2 iy, j)
+    const float b00 = dc[0], b01 = dc[1], b10 = dc[2], b11 = dc[3];
+    float dcs[4];
+    dcs[0] = b00 + b01 + b10 + b11; dcs[1] = b00 + b01 - b10 - b11; dcs[2] = b00 - b01 + b10 - b11; dcs[3] = b00 - b01 - b10 + b11;
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      const float block_dc = h == 0 ? dcs[x] : dcs[2 + x];
+      float residual_sum = 0;
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++) { if (ix == 0 && iy == 0) continue; residual_sum += in[iy * 8 + x + ix * 2]; }
+      const float p11 = block_dc - residual_sum * (1.0f / 16);
+      float* out = blk + (h * 4) * PITCH + x * 4;
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++) {
+          if (ix == 1 && iy == 1) out[PITCH + 1] = p11;
+          else if (ix == 0 && iy == 0) out[0] = in[8 + x + 2] + p11;      // the corner takes the value stored at (1, 1) of the quadrant
+          else out[iy * PITCH + ix] = in[iy * 8 + x + ix * 2] + p11;
+        }
+    }
+  } else if (s == 2) {  // DCT2X2, last level: in[] = rows 2h, 2h + 1, 2h + 4, 2h + 5 after Dct2x2Corner; outputs rows 4h .. 4h + 3
+#pragma unroll
+    for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const float c00 = in[yy * 8 + x], c01 = in[yy * 8 + 4 + x], c10 = in[(2 + yy) * 8 + x], c11 = in[(2 + yy) * 8 + 4 + x];
+        float* out = blk + (h * 4 + yy * 2) * PITCH + x * 2;
+        out[0] = c00 + c01 + c10 + c11; out[1] = c00 + c01 - c10 - c11;
+        out[PITCH] = c00 - c01 + c10 - c11; out[PITCH + 1] = c00 - c01 - c10 + c11;
+      }
+  } else if (s == 3) {  // DCT4X4: quadrants (y = h, x = 0, 1)
     const float b00 = dc[0], b01 = dc[1], b10 = dc[2], b11 = dc[3];
     float dcs[4];
     dcs[0] = b00 + b01 + b10 + b11; dcs[1] = b00 + b01 - b10 - b11; dcs[2] = b00 - b01 + b10 - b11; dcs[3] = b00 - b01 - b10 + b11;
@@ -2886,7 +2977,7 @@ template <int PITCH> __device__ __forceinline__ void SpecialHalfStore(uint32_t s
       for (int iy = 0; iy < 4; iy++)
 #pragma unroll
         for (int ix = 0; ix < 4; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? (h == 0 ? dcs[x] : dcs[2 + x]) : in[iy * 8 + x + ix * 2];
-      SmallIdct2D<4, 4>(sem, blk + (h * 4) * PITCH + x * 4, PITCH);
+      SmallIdct2DLds<4, 4, PITCH>(sem, blk + (h * 4) * PITCH + x * 4);
     }
   } else if (s == 12) {  // DCT4X8: half y = h
     const float b0 = dc[0], b1 = dc[2];
@@ -2895,20 +2986,70 @@ template <int PITCH> __device__ __forceinline__ void SpecialHalfStore(uint32_t s
     for (int iy = 0; iy < 4; iy++)
 #pragma unroll
       for (int ix = 0; ix < 8; ix++) sem[iy * 8 + ix] = (iy == 0 && ix == 0) ? (h == 0 ? b0 + b1 : b0 - b1) : in[iy * 8 + ix];
-    SmallIdct2D<4, 8>(sem, blk + (h * 4) * PITCH, PITCH);
-  } else {  // s == 13, DCT8X4: half x = h
+    SmallIdct2DLds<4, 8, PITCH>(sem, blk + (h * 4) * PITCH);
+  } else if (s == 13) {  // DCT8X4: half x = h
     const float b0 = dc[0], b1 = dc[2];
     float sem[32];  // sem[v*4+u] = stored[u*8+v]
 #pragma unroll
     for (int iy = 0; iy < 4; iy++)
 #pragma unroll
       for (int ix = 0; ix < 8; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? (h == 0 ? b0 + b1 : b0 - b1) : in[iy * 8 + ix];
-    SmallIdct2D<8, 4>(sem, blk + h * 4, PITCH);
+    SmallIdct2DLds<8, 4, PITCH>(sem, blk + h * 4);
+  } else {  // s == 14..17, AFV0-3: half 0 = even stored rows (AFV corner + the 4x4 DCT beside it), half 1 = odd rows (the 4x8 DCT of the other half)
+    const uint32_t afv_x = (s - 14) & 1, afv_y = (s - 14) >> 1;
+    const float b00 = dc[0], b01 = dc[1], b10 = dc[2];
+    if (h == 0) {
+      {
+        float coeff[16];
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+          for (int ix = 0; ix < 4; ix++) coeff[iy * 4 + ix] = (iy == 0 && ix == 0) ? (b00 + b10 + b01) * 4.0f : in[iy * 8 + ix * 2];
+        for (int iy = 0; iy < 4; iy++)
+          for (int ix = 0; ix < 4; ix++) {
+            const int i = (afv_y == 1 ? 3 - iy : iy) * 4 + (afv_x == 1 ? 3 - ix : ix);
+            float px = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) px = fmaf(coeff[j], d_afv_basis[j][i], px);
+            blk[(iy + afv_y * 4) * PITCH + afv_x * 4 + ix] = px;
+          }
+      }
+      {
+        float sem[16];  // sem[v*4+u] = stored[u*4+v]
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+          for (int ix = 0; ix < 4; ix++) sem[ix * 4 + iy] = (iy == 0 && ix == 0) ? (b00 + b10 - b01) : in[iy * 8 + ix * 2 + 1];
+        SmallIdct2DLds<4, 4, PITCH>(sem, blk + (afv_y * 4) * PITCH + (afv_x == 1 ? 0 : 4));
+      }
+    } else {
+      float sem[32];
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++) sem[iy * 8 + ix] = (iy == 0 && ix == 0) ? b00 - b10 : in[iy * 8 + ix];
+      SmallIdct2DLds<4, 8, PITCH>(sem, blk + (afv_y == 1 ? 0 : 4) * PITCH);
+    }
   }
 }
 
+// One kind of special transform, both phases: the lanes of a wavefront that hold blocks of this kind read their halves, then write them.  The read-before-write
+// hazard is between the two halves of ONE block — adjacent lanes with the same kind — so every kind can run as a branch of its own: each loads its inputs in the
+// arrangement its transform wants (one generic load ahead of a seven-way branch made the compiler shuffle 32 registers per kind into packed-math pairs, and spill).
+// KIND = the strategy (14 stands for AFV0-3: `s` tells which).
+template <int PITCH, uint32_t KIND> __device__ __forceinline__ void SpecialHalfRun(uint32_t s, float* blk, uint32_t h) {
+  __asm__ volatile("; special transform %0" :: "n"(KIND) : "memory");      // (distinct per kind: keeps the identical leading loads of the branches from being merged ahead of them)
+  if (KIND == 2) {
+    if (h == 0) Dct2x2Corner<PITCH>(blk);                                  // DCT2X2: the levels below the last one, in place, before either half is read
+    WaveSync();
+  }
+  float in[32], dc[4];
+  SpecialHalfLoad<PITCH>(KIND, blk, h, in, dc);
+  WaveSync();                                                              // every lane has read its inputs before any lane writes
+  SpecialHalfStore<PITCH>(KIND == 14 ? s : KIND, blk, h, in, dc);
+}
+
 __device__ __forceinline__ bool IsSpecial(uint32_t s) { return s == 1 || s == 2 || s == 3 || (s >= 12 && s <= 17); }
-__device__ __forceinline__ bool IsRareSpecial(uint32_t s) { return s == 1 || s == 2 || (s >= 14 && s <= 17); }   // IDENTITY, DCT2X2, AFV0-3
 __device__ __forceinline__ bool IsBig(uint32_t s) { return s >= 21; }
 __device__ __forceinline__ uint32_t Log2Cov8(uint32_t n) { return n == 1 ? 0u : n == 2 ? 1u : n == 4 ? 2u : 3u; }   // covered blocks 1, 2, 4, 8   // DCT128x128 ... DCT128x256: larger than a 64x64 tile
 
@@ -3171,59 +3312,6 @@ __global__ __launch_bounds__(256) void IdctSubsampledKernel(const FrameDev* __re
   }
 }
 
-// ---- IDENTITY, DCT2X2 and AFV blocks (64 live coefficients per lane) of frames that take the tile kernels: the tile
-// kernel leaves them alone and this kernel, launched after it for the frames the LF stage flagged, writes their pixels.
-// The group's blocks are compacted first so that every lane has a (block, channel) of its own.  Same arithmetic as
-// IdctKernel's special path (DequantCoef + SpecialTransform).
-__global__ __launch_bounds__(256) void IdctRareSpecialKernel(const FrameDev* __restrict__ frames, int force_generic) {
-  const FrameDev& f = frames[blockIdx.y];
-  if (f.is_modular || f.subsampled || force_generic || FrameFailed(f)) return;
-  const uint32_t flags = *f.frame_flags;
-  if ((flags & 1) != 0 || (flags & 16) == 0) return;    // generic frames do their own; no such block in this frame
-  const uint32_t g = blockIdx.x;
-  if (g >= f.num_groups) return;
-  const uint32_t gx = g % f.xgroups, gy = g / f.xgroups;
-  const uint32_t bx0 = gx * 32, by0 = gy * 32;
-  const uint32_t gbw = min(32u, f.bw - bx0), gbh = min(32u, f.bh - by0);
-  const size_t stride = f.plane_stride;
-  __shared__ uint16_t s_list[1024];
-  __shared__ uint32_t s_n;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  for (uint32_t t = threadIdx.x; t < gbw * gbh; t += blockDim.x) {
-    const uint32_t st = BI_Strategy(LdG(f.blk_info + (size_t)(by0 + t / gbw) * f.bw + bx0 + t % gbw));
-    if (IsRareSpecial(st)) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)t;
-  }
-  __syncthreads();
-  const uint32_t n = s_n;
-  for (uint32_t task = threadIdx.x; task < n * 3; task += blockDim.x) {
-    const uint32_t c = task / n, t = s_list[task - c * n];
-    const uint32_t bx = t % gbw, by = t / gbw;
-    const size_t o = (size_t)(by0 + by) * f.bw + bx0 + bx;
-    const uint32_t info = LdG(f.blk_info + o), s = BI_Strategy(info), kind = QuantKind(s);
-    BlockDequant d;
-    const uint32_t coff = LdG(f.coef_off + o);
-    for (int k = 0; k < 3; k++) { d.q[k] = f.coeff[k] + (size_t)g * 65536 + coff; d.table[k] = f.qtable[kind * 3 + k]; }
-    const float sd = f.inv_global_scale / (float)BI_HfMul(info);
-    d.sdc[0] = sd * f.x_dm; d.sdc[1] = sd; d.sdc[2] = sd * f.b_dm;
-    const size_t tile = (size_t)((by0 + by) / 8) * f.cw + (bx0 + bx) / 8;
-    d.kx = f.base_x + (float)f.ytox[tile] * f.color_scale;
-    d.kb = f.base_b + (float)f.ytob[tile] * f.color_scale;
-    for (int i = 0; i < 4; i++) d.bias[i] = f.quant_bias[i];
-    float cf[64];
-    for (uint32_t k = 0; k < 64; k++) cf[k] = DequantCoef(d, (int)c, k);
-    cf[0] = LdG(f.llf[c] + o);
-    SpecialTransform(s, cf, f.plane_a[c] + (size_t)(by0 + by) * 8 * stride + (bx0 + bx) * 8, stride);
-  }
-  __syncthreads();
-  // these blocks' coefficients have been consumed: zero them for the batch's next decode (see IdctTileKernel pass 0)
-  for (uint32_t i = threadIdx.x; i < n * 192; i += blockDim.x) {
-    const uint32_t t = s_list[i / 192], r = i % 192;
-    const size_t o = (size_t)(by0 + t / gbw) * f.bw + bx0 + t % gbw;
-    f.coeff[r / 64][(size_t)g * 65536 + LdG(f.coef_off + o) + r % 64] = 0;
-  }
-}
-
 // ---- fast path: one 256-thread workgroup per 64x64-pixel tile (8x8 blocks), all three channels staged in LDS ----------
 // Requires every varblock to lie inside one tile (true for naturally aligned blocks, i.e. everything encoders emit);
 // frames violating that are flagged by the LF stage and use IdctKernel above.  Same arithmetic, same operation order.
@@ -3332,8 +3420,10 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL
   __shared__ uint32_t s_ccur[4];
   if (threadIdx.x == 0) { uint32_t a = 0; for (int k = 0; k < 4; k++) { s_ccur[k] = a; a += s_cnt[5 + k]; } }
   __syncthreads();
-  const uint32_t r_begin[6] = {s_cnt[9], s_cnt[10], s_cnt[11], s_cnt[12], s_cnt[13], s_cnt[13] + s_cnt[4]};
-  const uint32_t c_begin[5] = {s_ccur[0], s_ccur[1], s_ccur[2], s_ccur[3], s_ccur[3] + s_cnt[8]};
+  // (the same for every lane: kept in scalar registers — eleven VGPRs that the special transforms' 36 loaded inputs need under the 96-register budget)
+  auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  const uint32_t r_begin[6] = {uni(s_cnt[9]), uni(s_cnt[10]), uni(s_cnt[11]), uni(s_cnt[12]), uni(s_cnt[13]), uni(s_cnt[13] + s_cnt[4])};
+  const uint32_t c_begin[5] = {uni(s_ccur[0]), uni(s_ccur[1]), uni(s_ccur[2]), uni(s_ccur[3]), uni(s_ccur[3] + s_cnt[8])};
   __syncthreads();
   for (int q = 0; q < kQ; q++) {
     const uint32_t tt = threadIdx.x + q * blockDim.x;
@@ -3375,8 +3465,8 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL
     }
     // The HF stage only writes non-zero coefficients, so the planes must be zero again before the batch's next decode: every
     // kernel that consumes a block's coefficients for good puts zeros back where it found something else (a few MB per frame
-    // instead of a 100 MB memset; IDENTITY / DCT2X2 / AFV blocks are read again, and cleared, by IdctRareSpecialKernel).
-    if (!(SPECIAL && IsRareSpecial(s))) {
+    // instead of a 100 MB memset).
+    {
       const int4 z = make_int4(0, 0, 0, 0);
       if (p.qy.x | p.qy.y | p.qy.z | p.qy.w) StG(reinterpret_cast<int4*>(cq[1] + base), z);
       if (p.qx.x | p.qx.y | p.qx.z | p.qx.w) StG(reinterpret_cast<int4*>(cq[0] + base), z);
@@ -3450,17 +3540,22 @@ template <int TB, bool SPECIAL> __global__ __launch_bounds__(TB == 8 ? 256 : JXL
       const uint32_t n4 = r_begin[5] - r_begin[4];
       if (n4 && wave == nwaves - 1) {
         for (uint32_t t0 = 0; t0 < n4 * 6; t0 += 64) {     // (block, channel, half) per lane; both halves in adjacent lanes
-          const uint32_t t = t0 + lane;
+          uint32_t ln = lane;
+          __asm__ volatile("" : "+v"(ln));                   // (opaque: what derives from the lane is computed in here, not ahead of the loop and then spilled)
+          const uint32_t t = t0 + ln;
           const bool live = t < n4 * 6;
           const uint32_t task = live ? t >> 1 : 0, h = t & 1;
-          const uint32_t c = task / n4, tt = s_rtask[r_begin[4] + (task - c * n4)];
+          const uint32_t c = (task >= n4 ? 1u : 0u) + (task >= 2 * n4 ? 1u : 0u), tt = s_rtask[r_begin[4] + (task - c * n4)];
           uint32_t s, iy; size_t o_first;
           float* blk0 = block_of(tt, c, s, iy, o_first);
-          const bool mine = live && !IsRareSpecial(s);       // IDENTITY / DCT2X2 / AFV are left to IdctRareSpecialKernel
-          float in[32], dc[4];
-          if (mine) SpecialHalfLoad<kTilePitch>(s, blk0, h, in, dc);
-          WaveSync();                                        // every lane has read its inputs before any lane writes
-          if (mine) SpecialHalfStore<kTilePitch>(s, blk0, h, in, dc);
+          if (live) {
+            if (s == 3) SpecialHalfRun<kTilePitch, 3>(s, blk0, h);
+            else if (s == 12) SpecialHalfRun<kTilePitch, 12>(s, blk0, h);
+            else if (s == 13) SpecialHalfRun<kTilePitch, 13>(s, blk0, h);
+            else if (s == 1) SpecialHalfRun<kTilePitch, 1>(s, blk0, h);
+            else if (s == 2) SpecialHalfRun<kTilePitch, 2>(s, blk0, h);
+            else SpecialHalfRun<kTilePitch, 14>(s, blk0, h);
+          }
         }
       }
     }
@@ -4709,7 +4804,7 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     if (uint32_t* sync = HfSyncWords(&dev))
       hipLaunchKernelGGL(HeadStartKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sync, g_hf_enqueued[dev] + 1, (uint64_t)200000);   // the next HF launch, or 2 ms
   }
-  if (big) {
+  if (big && !wide) {     // (the register cap buys room for the wavefronts of other stages beside this one; the first launches of a cold pipeline have the GPU to themselves: no cap, no spills)
     hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_tables, simt_mode, wp_base);
   } else {
     hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_tables, simt_mode, wp_base);
@@ -4830,10 +4925,7 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     DebugLaunch("IdctTileKernel<4>");
   }
   if (cfg.any_subsampled) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
-  // one wavefront per group: a group holds a few dozen of these blocks (x 3 channels, one lane each), three more wavefronts per workgroup
-  // only occupied slots (256 threads: 26.4 ms for the IDCT stage of the bench batch, 64 or 128 threads: 25.0 ms)
-  if (all || cfg.need_rare_special) hipLaunchKernelGGL(IdctRareSpecialKernel, dim3(max_groups, nframes), dim3(64), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);
-  DebugLaunch("IdctSubsampledKernel / IdctRareSpecialKernel");
+  DebugLaunch("IdctSubsampledKernel");
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only
   if (!cfg.idct_flags_known || cfg.any_big_blocks)

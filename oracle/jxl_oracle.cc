@@ -59,11 +59,15 @@ void InitFrame(Frame& f, const ImageMetadata& m) {
 // Progressive preview (decode.cc JxlDecoderFlushImage at the kDC step: the frame as it stands when the LF image and the HF metadata are there and no AC group has
 // been decoded — every AC coefficient still zero): set for the decodes started afterwards on this thread; the PassGroup sections are not looked at (they may be cut off).
 static thread_local bool g_dc_only = false;
+// Later progression steps (kLastPasses / kPasses) and truncated input: at most g_max_passes passes of every group are decoded (-1: all), and with g_allow_truncated a
+// PassGroup section that is not completely there — and every later pass of that group — is left out: dec_frame.cc Flush draws each group with the passes that have arrived.
+static thread_local int g_max_passes = -1;
+static thread_local bool g_allow_truncated = false;
 void DecodeFrameSections(const uint8_t* data, size_t size, BitReader& br, Frame& f) {
   size_t n = f.fh.toc_entries();
   std::vector<Section> sec;
   ReadTOC(br, n, sec);
-  if (g_dc_only && n > 1 && !f.fh.modular) {
+  if ((g_dc_only || g_allow_truncated) && n > 1 && !f.fh.modular) {
     if (sec[1 + f.fh.num_lf_groups].offset + sec[1 + f.fh.num_lf_groups].size > size) JXLO_FAIL("truncated frame (LF part incomplete)");
   } else if (sec.back().offset > size) JXLO_FAIL("truncated frame");
   auto reader = [&](size_t i) { BitReader r(data + sec[i].offset, sec[i].size); return r; };
@@ -78,9 +82,13 @@ void DecodeFrameSections(const uint8_t* data, size_t size, BitReader& br, Frame&
     { BitReader r = reader(0); ReadLfGlobal(r, f); if (r.pos > r.size * 8) JXLO_FAIL("LfGlobal overrun"); }
     for (uint32_t g = 0; g < f.fh.num_lf_groups; g++) { BitReader r = reader(1 + g); ReadLfGroup(r, f, g); if (r.pos > r.size * 8) JXLO_FAIL("LfGroup overrun"); }
     if (!f.fh.modular) { BitReader r = reader(1 + f.fh.num_lf_groups); ReadHfGlobal(r, f); if (r.pos > r.size * 8) JXLO_FAIL("HfGlobal overrun"); }
+    std::vector<uint8_t> gone(f.fh.num_groups, 0);       // (truncated input) the group's stream of an earlier pass was not there
     for (uint32_t p = 0; p < f.fh.passes.num_passes && !(g_dc_only && !f.fh.modular); p++)
       for (uint32_t g = 0; g < f.fh.num_groups; g++) {
-        BitReader r = reader(2 + f.fh.num_lf_groups + p * f.fh.num_groups + g);
+        if (!f.fh.modular && g_max_passes >= 0 && (int)p >= g_max_passes) continue;
+        const size_t si = 2 + f.fh.num_lf_groups + p * f.fh.num_groups + g;
+        if (g_allow_truncated && !f.fh.modular && (gone[g] || sec[si].offset + sec[si].size > size)) { gone[g] = 1; continue; }
+        BitReader r = reader(si);
         ReadPassGroup(r, f, p, g);
         if (r.pos > r.size * 8) JXLO_FAIL("PassGroup overrun");
       }
@@ -578,6 +586,7 @@ const char* jxlo_error(jxlo_handle* h) { return h->err.empty() ? nullptr : h->er
 void jxlo_free(jxlo_handle* h) { delete h; }
 void jxlo_set_unpremultiply_alpha(jxlo_handle* h, int v) { h->unpremul = v != 0; }
 void jxlo_set_render_spotcolors(int v) { g_render_spot = v != 0; }   // applies to the decodes started afterwards on this thread
+void jxlo_set_progress(int max_passes, int allow_truncated) { g_max_passes = max_passes; g_allow_truncated = allow_truncated != 0; }   // later progression steps / input cut off inside the AC groups
 void jxlo_set_dc_only(int v) { g_dc_only = v != 0; }                  // likewise: JxlDecoderFlushImage at the kDC step (no AC group decoded)
 // embedded ICC profile of the image (empty when the colour encoding is enumerated)
 size_t jxlo_icc(jxlo_handle* h, uint8_t* out, size_t cap) { const auto& v = h->d.meta.icc; if (out && cap >= v.size() && !v.empty()) memcpy(out, v.data(), v.size()); return v.size(); }

@@ -120,9 +120,18 @@ class Decoded:
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
 
 
-def decode(data: bytes, dump=False, dc_only=False) -> Decoded:
+def decode(data: bytes, dump=False, dc_only=False, max_passes=-1, allow_truncated=False) -> Decoded:
     """dc_only: the image as JxlDecoderFlushImage shows it at the kDC progression step — LF image + HF metadata decoded, every AC coefficient zero; the
-    PassGroup sections are not read (the input may end in them)."""
+    PassGroup sections are not read (the input may end in them).  max_passes: a later progression step — only that many passes of every group.
+    allow_truncated: `data` may end inside the frame's PassGroup sections; groups are drawn with the passes that are completely there."""
+    if max_passes >= 0 or allow_truncated:
+        L = lib()
+        L.jxlo_set_progress.argtypes = [C.c_int, C.c_int]
+        L.jxlo_set_progress(max_passes, 1 if allow_truncated else 0)
+        try:
+            return Decoded(data, dump)
+        finally:
+            L.jxlo_set_progress(-1, 0)
     if dc_only:
         L = lib()
         L.jxlo_set_dc_only.argtypes = [C.c_int]

@@ -13,7 +13,7 @@ class Params(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("distance", C.c_float), ("epf_iters", C.c_int32), ("gab", C.c_int32),
                 ("strategy_mix", C.c_int32), ("out_bits", C.c_int32), ("hdr", C.c_int32), ("skip_lf_smoothing", C.c_int32),
                 ("custom_orders", C.c_int32), ("orientation", C.c_int32), ("upsampling", C.c_int32), ("custom_up_weights", C.c_int32),
-                ("num_passes", C.c_int32), ("permute_toc", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("num_passes", C.c_int32), ("permute_toc", C.c_int32), ("pass_ds", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Frame(C.Structure):
@@ -74,13 +74,13 @@ def _take(out, n):
     return data
 
 
-def encode_vardct(rgb, seed=1, distance=1.0, epf_iters=1, gab=1, strategy_mix=1, out_bits=8, hdr=0, skip_lf_smoothing=0, orientation=1, alpha=None, upsampling=1, custom_up_weights=0, num_passes=1, permute_toc=0):
+def encode_vardct(rgb, seed=1, distance=1.0, epf_iters=1, gab=1, strategy_mix=1, out_bits=8, hdr=0, skip_lf_smoothing=0, orientation=1, alpha=None, upsampling=1, custom_up_weights=0, num_passes=1, permute_toc=0, pass_ds=0):
     """rgb: (h,w,3) uint8 sRGB, or float32 linear when hdr=1; alpha: optional (h,w) uint8 plane carried as a lossless
     extra channel.  Returns codestream bytes."""
     L = lib()
     h, w = rgb.shape[:2]
     p = Params(seed=seed, distance=distance, epf_iters=epf_iters, gab=gab, strategy_mix=strategy_mix, out_bits=out_bits,
-               hdr=hdr, skip_lf_smoothing=skip_lf_smoothing, orientation=orientation, upsampling=upsampling, custom_up_weights=custom_up_weights, num_passes=num_passes, permute_toc=permute_toc)
+               hdr=hdr, skip_lf_smoothing=skip_lf_smoothing, orientation=orientation, upsampling=upsampling, custom_up_weights=custom_up_weights, num_passes=num_passes, permute_toc=permute_toc, pass_ds=pass_ds)
     out = C.c_void_p(); n = C.c_size_t()
     alpha_arr = None if alpha is None else np.ascontiguousarray(alpha, dtype=np.uint8)
     al = None if alpha_arr is None else alpha_arr.ctypes.data

@@ -1778,14 +1778,14 @@ def test_free_running_modular_streams(jx, name):
 def test_repeated_decodes_leave_clean_coefficient_planes(jx):
     """The HF stage writes only non-zero coefficients and the IDCT kernels zero what they consumed (no dense clear between the
     decodes of a resident batch): every kernel family that reads coefficients — 32x32 and 64x64 tiles, the special 8x8 transforms,
-    IDENTITY / DCT2X2 / AFV (IdctRareSpecialKernel), DCT128/256 (BigIdctKernel), unaligned varblocks and the forced generic
+    IDENTITY / DCT2X2 / AFV (halves of a block per lane inside the tile kernel since round 5), DCT128/256 (BigIdctKernel), unaligned varblocks and the forced generic
     kernel, progressive passes (accumulating) — must leave the planes such that a second and a third decode give the same
     pixels."""
     img = S.synthetic_image(21, 520, 300)
     al = (np.add.outer(np.arange(300), np.arange(520)) % 256).astype(np.uint8)
     families = {
         "tiles_plain": [S.encode_vardct(img, seed=3, strategy_mix=0), S.encode_vardct(S.synthetic_image(22, 300, 200), seed=4, strategy_mix=1, epf_iters=2)],
-        "special_and_rare": [S.encode_vardct(img, seed=5, strategy_mix=2, epf_iters=1, gab=1)] + [S.encode_vardct(S.synthetic_image(40 + s, 96, 80), seed=s, strategy_mix=100 + s) for s in (1, 2, 3, 12, 14, 17)],
+        "special_and_rare": [S.encode_vardct(img, seed=5, strategy_mix=2, epf_iters=1, gab=1)] + [S.encode_vardct(S.synthetic_image(40 + s, 96, 80), seed=s, strategy_mix=100 + s) for s in (1, 2, 3, 12, 13, 14, 15, 16, 17)],
         "unaligned_generic": [S.encode_vardct(img, seed=8, strategy_mix=3, epf_iters=1, gab=1)],
         "big": [S.encode_vardct(img, seed=9, strategy_mix=4), S.encode_vardct(img, seed=10, strategy_mix=5, epf_iters=3, gab=1)],
         "passes": [S.encode_vardct(img, seed=11, strategy_mix=2, num_passes=3, alpha=al), S.encode_vardct(img, seed=12, strategy_mix=1, num_passes=2)],

@@ -1,7 +1,9 @@
-"""Progressive output through the libjxl ABI (-m gpu): JXL_DEC_FRAME_PROGRESSION at the kDC step and JxlDecoderFlushImage (jpegxl-sys/src/decode.rs:243, :1482, :1513).
-A frame's LF image and HF metadata are decodable before any AC group: the flush shows the frame with every AC coefficient zero through the regular IDCT / restoration /
-colour stages — compared bit for bit with the oracle's dc_only render —, on complete streams (event, flush, then the full image) and on streams cut off inside their AC groups
-(JXL_DEC_NEED_MORE_INPUT, flush, more input, full image)."""
+"""Progressive output through the libjxl ABI (-m gpu): JXL_DEC_FRAME_PROGRESSION at the kDC / kLastPasses / kPasses steps, JxlDecoderFlushImage and
+JxlDecoderGetIntendedDownsamplingRatio (jpegxl-sys/src/decode.rs:243, :1482, :1495, :1513).
+A frame's LF image and HF metadata are decodable before any AC group: the flush at the kDC step shows the frame with every AC coefficient zero through the regular IDCT /
+restoration / colour stages; the later steps add the first passes of every group — each compared bit for bit with the oracle's render of that step —, on complete streams
+(events, flushes, then the full image) and on streams cut off inside their AC groups (JXL_DEC_NEED_MORE_INPUT, flush — the groups that have arrived in full, the others from
+their LF part —, more input, full image)."""
 import ctypes as C
 
 import numpy as np
@@ -50,7 +52,8 @@ def _run(jx, data, cut=None, detail=None, events=None):
             assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), px.ctypes.data, px.size) == 0
         elif st == jx.JXL_DEC_FRAME_PROGRESSION:
             assert L.JxlDecoderFlushImage(dec) == 0, jx.last_error()
-            shots["progression"] = px.copy()
+            shots.setdefault("progression", px.copy())             # the first step (kDC)
+            shots.setdefault("steps", []).append((int(L.JxlDecoderGetIntendedDownsamplingRatio(dec)), px.copy()))
         elif st == jx.JXL_DEC_NEED_MORE_INPUT:
             if px is not None:
                 rc = L.JxlDecoderFlushImage(dec)
@@ -97,8 +100,11 @@ def test_flush_on_a_truncated_stream_then_more_input(jx, frac):
     seen, shots = _run(jx, data, cut=cut)
     assert seen[:3] == [jx.JXL_DEC_BASIC_INFO, jx.JXL_DEC_NEED_IMAGE_OUT_BUFFER, jx.JXL_DEC_NEED_MORE_INPUT]
     assert shots["flush_rc"] == 0
-    assert np.array_equal(shots["truncated"], O.decode(data[:cut], dc_only=True).pixels("u8", 3))
-    assert np.array_equal(shots["truncated"], O.decode(data, dc_only=True).pixels("u8", 3))       # (the LF part does not depend on where the stream was cut)
+    # every group whose stream is completely there is drawn in full, the others from their LF part
+    part = O.decode(data[:cut], allow_truncated=True).pixels("u8", 3)
+    assert np.array_equal(shots["truncated"], part)
+    dc, full = O.decode(data, dc_only=True).pixels("u8", 3), O.decode(data).pixels("u8", 3)
+    assert not np.array_equal(part, dc) and not np.array_equal(part, full)
     assert seen[-2:] == [jx.JXL_DEC_FULL_IMAGE, jx.JXL_DEC_SUCCESS] and np.array_equal(shots["full"], O.decode(data).pixels("u8", 3))
 
 
@@ -124,3 +130,35 @@ def test_no_flush_without_the_lf_part_or_for_other_frame_kinds(jx):
     assert L.JxlDecoderFlushImage(dec) == 1 and "no flush was done" in jx.last_error()
     assert L.JxlDecoderProcessInput(dec) == jx.JXL_DEC_FULL_IMAGE
     L.JxlDecoderDestroy(dec)
+
+
+@pytest.mark.parametrize("num_passes,pass_ds", [(3, 1), (3, 0), (2, 1)])
+def test_pass_steps_of_a_progressive_frame(jx, num_passes, pass_ds):
+    """kPasses: a step after every pass but the last; kLastPasses: after the passes the frame header names as the last ones of a downsampling ratio (none without such
+    entries); kDC: the LF step alone.  Every flush equals the oracle's render with that many passes of every group; the ratio is the frame header's."""
+    img = S.synthetic_image(31, 1030, 520)
+    data = S.encode_vardct(img, seed=31, strategy_mix=2, epf_iters=1, gab=1, num_passes=num_passes, pass_ds=pass_ds)
+    full = O.decode(data).pixels("u8", 3)
+    renders = [O.decode(data, dc_only=True).pixels("u8", 3)] + [O.decode(data, max_passes=k).pixels("u8", 3) for k in range(1, num_passes)]
+    for a, b in zip(renders, renders[1:] + [full]):
+        assert not np.array_equal(a, b)                                          # every step adds something
+    ratios = [8] + ([4, 2][-(num_passes - 1):] if pass_ds else [8] * (num_passes - 1))
+    for detail, want in ((3, list(range(num_passes))), (2, list(range(num_passes)) if pass_ds else [0]), (1, [0])):
+        seen, shots = _run(jx, data, detail=detail)
+        assert seen.count(jx.JXL_DEC_FRAME_PROGRESSION) == len(want) and seen[-2:] == [jx.JXL_DEC_FULL_IMAGE, jx.JXL_DEC_SUCCESS]
+        for (ratio, px), k in zip(shots["steps"], want):
+            assert np.array_equal(px, renders[k]), (detail, k)
+            assert ratio == ratios[k], (detail, k, ratio)
+        assert np.array_equal(shots["full"], full)
+
+
+@pytest.mark.parametrize("frac", [0.45, 0.7, 0.95])
+def test_flush_on_a_truncated_progressive_stream(jx, frac):
+    """Three passes, cut inside one of them: groups show as many passes as have arrived in full."""
+    img = S.synthetic_image(32, 1500, 700)
+    data = S.encode_vardct(img, seed=32, strategy_mix=1, epf_iters=1, gab=1, num_passes=3)
+    cut = int(len(data) * frac)
+    seen, shots = _run(jx, data, cut=cut)
+    assert jx.JXL_DEC_NEED_MORE_INPUT in seen and shots["flush_rc"] == 0
+    assert np.array_equal(shots["truncated"], O.decode(data[:cut], allow_truncated=True).pixels("u8", 3))
+    assert np.array_equal(shots["full"], O.decode(data).pixels("u8", 3))

@@ -4,7 +4,7 @@ TAG=${TAG:-cjxl_depth}
 export JXL_BENCH_STREAM_CACHE=/tmp/sc
 mkdir -p gpurun_out/$TAG
 COMMON="--steps ${STEPS:-20} --warmup 5 --main-tree-shape 1 --main-texture 5 --no-extras --no-realistic --no-cpu-baseline --no-verify"
-for cfg in ${CFGS:-"11:7 14:10 16:12 20:14"}; do
+for cfg in ${CFGS:-11:7 14:10 16:12 20:14}; do
   inf=${cfg%%:*}; lfs=${cfg##*:}
   timeout 600 python bench.py $COMMON --in-flight $inf --lf-streams $lfs > gpurun_out/$TAG/line_${inf}_${lfs}.json 2> gpurun_out/$TAG/err_${inf}_${lfs}.log
   python - <<PY

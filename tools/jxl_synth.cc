@@ -84,6 +84,7 @@ struct Params {
   int upsampling = 1;     // 1 | 2 | 4 | 8: the frame is coded at 1/upsampling of the image size
   int custom_up_weights = 0;  // 1: the image header carries explicit upsampling weights (required for 4x / 8x here)
   int num_passes = 1;     // 1..3: coefficients split into bit planes (pass p carries value >> shift[p], the last pass the remainder)
+  int pass_ds = 0;        // VarDCT, num_passes > 1: the frame header lists every pass but the last as the last pass of a downsampling ratio (4, 2 / 2): the kLastPasses progression steps
   int permute_toc = 0;    // != 0: sections stored in a shuffled order (seed), TOC carries the permutation
   int reserved[3] = {0};
   // ---- frame control (multi-frame streams are assembled by concatenating the pieces): noise, frame type, crop, blending, slots
@@ -735,7 +736,7 @@ static void WriteFrameHeader(BitWriter& w, const Params& p, bool modular, bool x
     const int np = modular ? p.mod_passes : p.num_passes;
     w.put((uint32_t)(np - 1), 2);  // num_passes (1, 2, 3)
     if (np != 1) {
-      const int nds = modular && p.mod_ds ? np - 1 : 0;
+      const int nds = (modular ? p.mod_ds : p.pass_ds) ? np - 1 : 0;
       w.put((uint32_t)nds, 2);                             // num_downsample (0 .. 2)
       for (int i = 0; i + 1 < np; i++) w.put(modular ? 0u : (uint32_t)PassShift(np, i), 2);   // shift of every pass but the last
       // entry i: "pass i completes the image at 1 / (2 << (nds - 1 - i))" -> downsample 4, 2 (np = 3) or 2 (np = 2); U32(Val 1, 2, 4, 8)
@@ -1605,7 +1606,7 @@ static std::vector<uint8_t> EncodeModular(const int32_t* const* planes, int ncha
 // ---- C API ---------------------------------------------------------------------------------------------------------
 extern "C" {
 struct jxlsynth_params {
-  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation, upsampling, custom_up_weights, num_passes, permute_toc; int32_t reserved[3];
+  uint32_t seed; float distance; int32_t epf_iters, gab, strategy_mix, out_bits, hdr, skip_lf_smoothing, custom_orders, orientation, upsampling, custom_up_weights, num_passes, permute_toc, pass_ds; int32_t reserved[2];
 };
 static thread_local std::string g_err;
 const char* jxlsynth_last_error() { return g_err.c_str(); }
@@ -1667,7 +1668,7 @@ int jxlsynth_vardct2(const uint8_t* rgb8, const float* rgb_lin, const uint8_t* a
     p.upsampling = (pp->upsampling == 2 || pp->upsampling == 4 || pp->upsampling == 8) ? pp->upsampling : 1;
     p.custom_up_weights = pp->custom_up_weights;
     p.num_passes = pp->num_passes >= 1 && pp->num_passes <= 3 ? pp->num_passes : 1;
-    p.permute_toc = pp->permute_toc;
+    p.permute_toc = pp->permute_toc; p.pass_ds = pp->pass_ds;
     std::vector<float> pl[3];
     for (auto& v : pl) v.resize((size_t)w * h);
     const float scale = p.hdr ? 255.0f / 1000.0f : 1.0f;  // intensity_target 1000: linear 1.0 == 1000 nits
