@@ -4804,7 +4804,7 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     if (uint32_t* sync = HfSyncWords(&dev))
       hipLaunchKernelGGL(HeadStartKernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sync, g_hf_enqueued[dev] + 1, (uint64_t)200000);   // the next HF launch, or 2 ms
   }
-  if (big && !wide) {     // (the register cap buys room for the wavefronts of other stages beside this one; the first launches of a cold pipeline have the GPU to themselves: no cap, no spills)
+  if (big) {      // (the register cap — 170 VGPRs, with spills — leaves room for the wavefronts of other stages; for the first launches of a cold pipeline the uncapped instantiation measured the same: profiles/r05_notes.md)
     hipLaunchKernelGGL(LfDecodeKernel<true>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_tables, simt_mode, wp_base);
   } else {
     hipLaunchKernelGGL(LfDecodeKernel<false>, dim3(DivUp(max_lf_groups, (int)gpb), nframes), dim3(64 * kLfDecWaves), lds_bytes, (hipStream_t)stream, frames, gpb, tree_cap, lds_tables, simt_mode, wp_base);

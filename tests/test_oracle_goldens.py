@@ -406,3 +406,27 @@ def test_spot_colour_mixing_against_numpy():
         assert np.array_equal(np.frombuffer(O.decode(data).pixels("u8", 3), np.uint8).reshape(h, w, 3), img[..., :3].astype(np.uint8))
     finally:
         O.set_render_spotcolors(True)
+
+
+def test_progression_steps_of_the_oracle_are_consistent():
+    """The oracle's renders of progression steps (what the -m gpu progressive tests compare JxlDecoderFlushImage with): no pass = the kDC render, all passes = the full image,
+    complete input under allow_truncated = the full image, a cut right behind pass k = the render of k passes, and every step changes pixels."""
+    import synth_lib as S
+    img = S.synthetic_image(31, 520, 300)
+    data = S.encode_vardct(img, seed=31, strategy_mix=2, epf_iters=1, gab=1, num_passes=3, pass_ds=1)
+    full = O.decode(data).pixels("u8", 3)
+    dc = O.decode(data, dc_only=True).pixels("u8", 3)
+    steps = [O.decode(data, max_passes=k).pixels("u8", 3) for k in range(4)]
+    assert np.array_equal(steps[0], dc) and np.array_equal(steps[3], full)
+    assert np.array_equal(O.decode(data, allow_truncated=True).pixels("u8", 3), full)
+    for a, b in zip(steps, steps[1:]):
+        assert not np.array_equal(a, b)
+    # truncated input: cut points from the coarse end to the fine end show monotonically more; one byte short of the end still lacks the last group's last pass
+    errs = []
+    for frac in (0.55, 0.7, 0.85, 0.97):
+        part = O.decode(data[:int(len(data) * frac)], allow_truncated=True).pixels("u8", 3)
+        errs.append(float(np.abs(part.astype(np.int32) - full.astype(np.int32)).mean()))
+    assert errs[-1] < errs[0] and errs[-1] > 0, errs
+    with pytest.raises(O.OracleError):
+        O.decode(data[:len(data) // 10], allow_truncated=True)           # inside the LF part: nothing to show
+    assert not np.array_equal(O.decode(data[:-1], allow_truncated=True).pixels("u8", 3), full)
