@@ -481,7 +481,7 @@ def main():
     ap.add_argument("--gather-chunk", type=int, default=32, help="frames per point-to-point transfer of the pixel gather (N > 1)")
     ap.add_argument("--in-flight", type=int, default=11, help="jobs in flight in the library pipeline (JxlHipPipelineOptions.jobs_in_flight): LF stages run this many jobs ahead of the tail")
     ap.add_argument("--lf-streams", type=int, default=11, help="side streams the LF stages of the jobs ahead are spread over")
-    ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "1")), help="HF stages in flight beside the tail of the current job, one stream and one coefficient set each")
+    ap.add_argument("--hf-streams", type=int, default=int(os.environ.get("JXL_BENCH_HF_STREAMS", "2")), help="HF stages in flight beside the tail of the current job, one stream and one coefficient set each")
     ap.add_argument("--wide-first", type=int, default=int(os.environ.get("JXL_BENCH_WIDE_FIRST", "4")), help="LF stages at the start of a cold pipeline that take the one-wavefront-per-stream kernel")
     ap.add_argument("--prepare-threads", type=int, default=int(os.environ.get("JXL_BENCH_PREPARE_THREADS", "3")), help="host threads of the pipeline that each parse + prepare + upload one job at a time")
     ap.add_argument("--parse-threads", type=int, default=int(os.environ.get("JXL_BENCH_PARSE_THREADS", "8")), help="host threads one job's frames are parsed on")

@@ -297,7 +297,7 @@ typedef struct JxlHipPipelineStruct JxlHipPipeline;
 typedef struct {
   int32_t jobs_in_flight;    /* jobs in flight on the GPU; 0 = default (11) */
   int32_t lf_streams;        /* side streams for the LF stages; 0 = default (11) */
-  int32_t hf_streams;        /* HF stages in flight beside the tail, one coefficient set each + one; 0 = default (1) */
+  int32_t hf_streams;        /* HF stages in flight beside the tail, one coefficient set each + one; 0 = default (2) */
   int32_t prepare_threads;   /* host threads that each prepare one job at a time; 0 = default (3) */
   int32_t parse_threads;     /* host threads one job's images are parsed on; 0 = default (8) */
   int32_t lane_stride_lf, lane_stride_hf;   /* see JxlHipBatchSetLaneStride; 0 = defaults (8, 1) */

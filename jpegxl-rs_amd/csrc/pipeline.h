@@ -28,7 +28,7 @@ namespace jxlhip {
 struct PipelineOptions {
   int in_flight = 11;        // jobs in flight on the GPU (LF stages run this many jobs ahead of the tail, minus one)
   int lf_streams = 11;       // side streams the LF stages are spread over (one per job in flight: weighted-predictor LF stages take ~590 ms per launch against steps of ~75 ms, seven streams bound such frames at 84 ms per step)
-  int hf_streams = 1;        // HF stages in flight beside the tail (one stream and one coefficient set each, + the set the tail consumes)
+  int hf_streams = 2;        // HF stages in flight beside the tail (one stream and one coefficient set each, + the set the tail consumes)
   int prepare_threads = 3;   // host threads that each parse + prepare + upload one job at a time and enqueue its LF stage
   int parse_threads = 8;     // host threads one job's images are parsed on
   int lane_stride_lf = 8, lane_stride_hf = 1;
