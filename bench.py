@@ -730,7 +730,7 @@ def main():
             if mod_streams:
                 try:
                     r4, bm = None, 2
-                    for bm, infl in ((4, 1), (2, 2)):        # (8 GB of device memory per frame in flight — mostly per-group scratch for local transforms —: jobs of 4 if they fit, else of 2)
+                    for bm, infl in ((8, 2), (4, 2), (2, 2)):        # (1.6 GB of device memory per frame in flight since the per-unit scratch is sized by the unit headers — 8 GB before —: jobs of 8 = 65 GB over the five batch objects, else smaller ones)
                         try:
                             r4 = measure(mod_streams, B=bm, W=8192, H=8192, dtype="uint16", nch=1, in_flight=infl, lf_streams=2, steps=max(6, min(args.steps, 10)))
                             break

@@ -1114,9 +1114,14 @@ void Batch::Prepare(void* stream_v, bool wait_upload) {
       for (size_t k = 0; k < p.gchannels.size(); k++) table.push_back(ModChanDev{mp[k], p.gchannels[k].w, p.gchannels[k].h, p.gchannels[k].hshift, p.gchannels[k].vshift});
       co[i].mod_chan = arena.Put(table.data(), table.size() * sizeof(ModChanDev));
       const size_t gd = p.group_dim;
-      o.mod_scratch_stride = (8 + 4) * gd * gd + 4 * 65536;
+      // per-unit scratch: channels of units with transforms of their own are decoded there (worst case 12 planes of a group + palettes: 4 MB per unit, 4.3 GB for the 1040
+      // units of an 8192x8192 frame) — the host has read every unit's header: frames without such units get none; weighted-predictor rows: two rows x five arrays of the widest channel
+      const bool tight = p.mod_units_scanned && !p.mod_local_transforms;
+      o.mod_scratch_stride = tight ? 64 : (8 + 4) * gd * gd + 4 * 65536;
       o.mod_scratch = take(o.mod_scratch_stride * 4 * p.NumModUnits());
-      o.wp_scratch_stride = p.tree.uses_wp ? 10 * (65536 + 2) : 16;
+      size_t widest = gd;
+      for (auto& ch : p.gchannels) widest = std::max<size_t>(widest, ch.w);
+      o.wp_scratch_stride = (p.tree.uses_wp || p.mod_local_wp) ? (tight ? 10 * (widest + 2) : 10 * (65536 + 2)) : 16;
       o.wp_scratch = take(o.wp_scratch_stride * 4 * (1 + p.NumModUnits()));
       if (e.complex) for (int c = 0; c < 3; c++) { o.plane_a[c] = take_big((size_t)p.bw * 8 * p.bh * 8 * 4); o.plane_b[c] = (size_t)-1; }
     }

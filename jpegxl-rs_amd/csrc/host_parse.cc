@@ -1171,7 +1171,9 @@ static void ParseLfGlobal(Reader& r, const ImageHeader& ih, FramePlan* p) {
 // holds channels and, where it says use_global_tree = 0, the stream's own tree and code (dec_modular.cc DecodeGroup,
 // encoding.cc ModularDecode).  VarDCT frames keep such streams behind data only the device decodes: not parsed here.
 static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p) {
-  if (!p->modular || p->single_section || p->global_decodable >= p->gchannels.size()) return;
+  if (!p->modular || p->single_section) return;
+  p->mod_units_scanned = true;
+  if (p->global_decodable >= p->gchannels.size()) return;
   const uint32_t total = p->NumModUnits();
   for (uint32_t unit = 0; unit < total; unit++) {
     const bool is_lf = unit < p->num_lf_groups;
@@ -1194,15 +1196,19 @@ static void ParseLocalModularStreams(const Codestream& cs, FramePlan* p) {
     const Section& sec = p->sections[is_lf ? 1 + g : 2 + p->num_lf_groups + pass * p->num_groups + g];
     Reader r(cs, sec.offset * 8);
     r.limit_bits = (sec.offset + sec.size) * 8;
-    if (r.b()) { if (!p->has_global_tree) Fail("global tree missing"); continue; }
+    const bool global_tree = r.b();
+    if (global_tree && !p->has_global_tree) Fail("global tree missing");
     if (!r.b()) { r.u(5); r.u(5); for (int i = 0; i < 5; i++) r.u(5); for (int i = 0; i < 4; i++) r.u(4); }   // WPHeader (read again on the device)
     const uint32_t nt = r.U32({0, 0}, {0, 1}, {4, 2}, {8, 18});
+    if (nt) p->mod_local_transforms = true;          // (the unit decodes into scratch of its own: decoder.cc sizes that by this)
+    if (global_tree) continue;
     for (uint32_t i = 0; i < nt; i++) { TransformDesc t; ReadTransform(r, &t); }
     FramePlan::LocalStream ls;
     ReadTree(r, &ls.tree, std::min<size_t>(1u << 20, 1024 + pixels));
     ReadEntropyCode(r, ls.tree.num_leaves, &ls.code);
     ls.unit = 1 + unit;
     ls.data_bitpos = r.pos();
+    if (ls.tree.uses_wp) p->mod_local_wp = true;
     p->max_prop = std::max(p->max_prop, ls.tree.max_prop);
     p->local_streams.push_back(std::move(ls));
   }

@@ -141,6 +141,9 @@ struct FramePlan {
   uint64_t frame_end_bitpos = 0;           // first bit after the frame's last section (= next frame header)
   bool partial = false;                    // the codestream ends inside the frame's PassGroup sections: LF part complete; the AC groups that are completely there are decoded (progressive flush)
   uint32_t partial_ac_sections = 0;        // (partial) PassGroup sections that are completely there
+  // Modular frames: every unit's group header has been looked at (ParseLocalModularStreams) — whether any unit carries transforms of its own (then it decodes into per-unit
+  // scratch) or a local tree with the weighted predictor: what decoder.cc sizes the per-unit scratch by (an 8192x8192 frame has 1040 units)
+  bool mod_units_scanned = false, mod_local_transforms = false, mod_local_wp = false;
   // geometry
   uint32_t width = 0, height = 0, group_dim = 256;
   uint32_t xgroups = 0, ygroups = 0, num_groups = 0, xlfgroups = 0, ylfgroups = 0, num_lf_groups = 0;

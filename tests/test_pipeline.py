@@ -79,8 +79,8 @@ def test_pipeline_jobs_device_and_host_out(jx):
     streams = _small_streams()
     extra = [fixture_bytes("sample.jxl"), fixture_bytes("sample_grey.jxl")]
     refs = {id(d): O.decode(d).pixels("u8", 3) for d in streams + extra}
-    p = jx.Pipeline(0, jobs_in_flight=3, lf_streams=2, prepare_threads=2, parse_threads=2, timed=1, reserve_frames=4, reserve_width=1024, reserve_height=640)
-    assert p.info("coefficient_sets") == 2 and p.info("slots") >= 5
+    p = jx.Pipeline(0, jobs_in_flight=3, lf_streams=2, hf_streams=1, prepare_threads=2, parse_threads=2, timed=1, reserve_frames=4, reserve_width=1024, reserve_height=640)
+    assert p.info("coefficient_sets") == 2 and p.info("slots") >= 5           # (hf_streams + 1 sets; the default is two HF stages in flight = three sets)
     jobs = []
     for rnd in range(6):
         datas = [streams[(rnd + k) % len(streams)] for k in range(3)] if rnd % 3 != 2 else [extra[0], streams[rnd % len(streams)], extra[1]]
