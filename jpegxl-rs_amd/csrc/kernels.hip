@@ -384,7 +384,8 @@ constexpr uint32_t kChunkOff = kRowOff + 2 * kRowMax * 4;             // 256-sam
 constexpr uint32_t kWaveLds = 8448;                                   // >= kChunkOff + 1024 and >= the 8 KiB placement bitmap
 static_assert(kChunkOff + 1024 <= kWaveLds, "per-wave LDS layout");
 #ifndef JXL_LF_MINW
-#define JXL_LF_MINW 3      // LfDecodeKernel<true>: VGPR budget 512 / JXL_LF_MINW per lane (170: three IDCT or six filter wavefronts fit beside it)
+#define JXL_LF_MINW 2      // LfDecodeKernel<true>: VGPR budget 512 / JXL_LF_MINW per lane (256: no spills.  Rounds 3-5 ran it at 3 = 170 registers with 210 spilled, for the wavefronts of other stages
+                           // beside it; since the SIMT kernel took over the LF streams of resident pipelines this one runs at cold starts and for handed-back streams, and measured the same either way)
 #endif
 #ifndef JXL_IDCT_T4
 #define JXL_IDCT_T4 128   // threads of an IdctTileKernel<4> workgroup (A/B knob: 256 = four wavefronts share the 14 KB tile)
@@ -3649,53 +3650,6 @@ __global__ void GaborishKernel(const FrameDev* __restrict__ frames, int unfused)
   }
 }
 
-template <int PASS> __global__ void EpfKernel(const FrameDev* __restrict__ frames, int unfused) {
-  const FrameDev& f = frames[blockIdx.z];
-  constexpr int stage = PASS + 1;
-  if (f.is_modular || !FilterStageActive(f, stage) || FusedEligible(f, unfused)) return;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  const int w = (int)f.width, h = (int)f.height;
-  if (x >= w || y >= h) return;
-  const bool src_is_a = (FilterStagesBefore(f, stage) & 1) == 0;
-  const size_t stride = f.plane_stride;
-  const float* src[3]; float* dst[3];
-  for (int c = 0; c < 3; c++) { src[c] = src_is_a ? f.plane_a[c] : f.plane_b[c]; dst[c] = src_is_a ? f.plane_b[c] : f.plane_a[c]; }
-  const size_t o = (size_t)y * stride + x;
-  const float is = f.inv_sigma[(size_t)(y / 8) * f.bw + x / 8];
-  if (is < -3.90524291751269967465540850526868f) { for (int c = 0; c < 3; c++) dst[c][o] = src[c][o]; return; }
-  const bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
-  const float vmul = is * (border ? f.epf_bsm[PASS] : f.epf_sm[PASS]);
-  auto px = [&](int c, int xx, int yy) -> float { return src[c][(size_t)MirrorD(yy, h) * stride + MirrorD(xx, w)]; };
-  float wsum = 1.0f;
-  float acc[3] = {src[0][o], src[1][o], src[2][o]};
-  constexpr int ntaps = PASS == 0 ? 12 : 4;
-  const int taps0[12][2] = {{0, -2}, {-1, -1}, {0, -1}, {1, -1}, {-2, 0}, {-1, 0}, {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {0, 2}};
-  const int taps1[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
-  const int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
-#pragma unroll
-  for (int t = 0; t < ntaps; t++) {
-    const int dx = PASS == 0 ? taps0[t][0] : taps1[t][0], dy = PASS == 0 ? taps0[t][1] : taps1[t][1];
-    float sad = 0.f;
-    if (PASS == 2) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) sad = fmaf(fabsf(px(c, x + dx, y + dy) - src[c][o]), f.epf_channel_scale[c], sad);
-    } else {
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 5; k++) s += fabsf(px(c, x + dx + plus[k][0], y + dy + plus[k][1]) - px(c, x + plus[k][0], y + plus[k][1]));
-        sad = fmaf(s, f.epf_channel_scale[c], sad);
-      }
-    }
-    const float wgt = fmaxf(0.0f, fmaf(sad, vmul, 1.0f));
-    wsum += wgt;
-#pragma unroll
-    for (int c = 0; c < 3; c++) acc[c] = fmaf(wgt, px(c, x + dx, y + dy), acc[c]);
-  }
-  const float inv = 1.0f / wsum;
-  for (int c = 0; c < 3; c++) dst[c][o] = acc[c] * inv;
-}
 
 // =====================================================================================================================
 // K_out: XYB -> linear -> sRGB -> clamp/scale/round -> interleaved caller layout (stage_xyb/from_linear/write)
@@ -4720,7 +4674,7 @@ __global__ void ModularOutputKernel(const FrameDev* __restrict__ frames, int fid
 // launchers
 // =====================================================================================================================
 const char* const kKernelNames[] = {"LfDecodeKernel", "LfDequantKernel", "LfSmoothKernel", "LlfSigmaKernel", "HfDecodeKernel", "IdctKernel",
-                                    "GaborishKernel", "EpfKernel", "OutputKernel", "ModularGlobalFastKernel", "ModularGroupFastKernel", nullptr};
+                                    "GaborishKernel", "EpfTileKernel", "OutputKernel", "ModularGlobalFastKernel", "ModularGroupFastKernel", nullptr};
 
 // (per device, once; decoders of several host threads may get here at the same time)
 static std::mutex g_tables_mu;
@@ -4999,15 +4953,8 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
   // (cfg.debug_stop_after, testing: 2 = stop after gaborish, 3 / 4 / 5 = after EPF pass 0 / 1 / 2 — the planes are then read back, JxlHipBatchDebugRead)
   const int stop = cfg.debug_stop_after ? cfg.debug_stop_after : 99;
   if (fp.any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames, unfused);
-  // the EPF passes on LDS tiles (JXL_HIP_EPF_STAGED=1: the per-pixel kernels they replaced — same results, an A/B knob)
-  static const bool staged = getenv("JXL_HIP_EPF_STAGED") != nullptr;
+  // the EPF passes on LDS tiles (the per-pixel kernels they replaced in round 5 — EpfKernel<PASS>, 90 spilled registers in the first pass — are in the history)
   const int fuse_out = cfg.debug_stop_after ? 0 : 1;
-  if (staged) {
-    if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfKernel<0>, grid, block, 0, (hipStream_t)stream, frames, unfused);
-    if (fp.max_epf >= 1 && stop >= 4) hipLaunchKernelGGL(EpfKernel<1>, grid, block, 0, (hipStream_t)stream, frames, unfused);
-    if (fp.max_epf >= 2 && stop >= 5) hipLaunchKernelGGL(EpfKernel<2>, grid, block, 0, (hipStream_t)stream, frames, unfused);
-    return;
-  }
   const int etx = DivUp(max_w, kEtT);
   const dim3 tgrid(etx * DivUp(max_h, kEtT), 1, nframes);
   if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfTileKernel<0>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
@@ -5019,8 +4966,7 @@ void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, con
   const int ow = std::max(max_w, fp.max_out_w), oh = std::max(max_h, fp.max_out_h);   // upsampled frames write more pixels than they code
   dim3 block(64, 4), grid(DivUp(ow, 64), DivUp(oh, 4), nframes);
   if (fp.any_upsampled) hipLaunchKernelGGL(UpsampleKernel, grid, block, 0, (hipStream_t)stream, frames);
-  static const bool staged = getenv("JXL_HIP_EPF_STAGED") != nullptr;
-  hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters, (cfg.debug_stop_after || staged) ? 0 : 1);
+  hipLaunchKernelGGL(OutputKernel, grid, block, 0, (hipStream_t)stream, frames, cfg.force_unfused_filters, cfg.debug_stop_after ? 0 : 1);
 }
 void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& cfg, void* stream);
 // LDS plan of the Modular kernels: per-wavefront regions, tree region (whole tree or pruned per-wavefront slices), the
