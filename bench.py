@@ -709,7 +709,7 @@ def main():
             # ---- BASELINE configs 5 and 4 at full size: batch throughput through the pipeline + single image through decode_with, with their own stage times
             if hdr_streams:
                 try:
-                    r5 = measure(hdr_streams, B=32, W=7680, H=4320, dtype="float32", in_flight=4, lf_streams=3, plane_sets=2, steps=max(6, min(args.steps, 12)))
+                    r5 = measure(hdr_streams, B=32, W=7680, H=4320, dtype="float32", plane_sets=2, steps=max(6, min(args.steps, 12)))      # (the pipeline's defaults: 11 jobs in flight — 92 GB of device memory; four in flight, as until r05i, left the LF stage short of streams: 9.5 against 11.7 Gpixel/s)
                     px = 32 * 7680 * 4320 * r5["steps"]
                     sm, sb = r5["stage_ms"], r5["stage_bytes"]
                     d5 = jx.decoder_builder()
