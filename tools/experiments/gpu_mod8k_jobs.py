@@ -15,7 +15,7 @@ W = H = 8192
 for cfg in sys.argv[1:]:
     B, infl = map(int, cfg.split(":"))
     try:
-        p = jx.Pipeline(0, timed=1, jobs_in_flight=infl, lf_streams=max(1, infl), prepare_threads=2, parse_threads=8, reserve_frames=B, reserve_width=W, reserve_height=H)
+        p = jx.Pipeline(0, timed=1, jobs_in_flight=infl, lf_streams=max(1, infl), prepare_threads=3, parse_threads=8, reserve_frames=B, reserve_width=W, reserve_height=H)
         outs = [torch.empty((B, H, W), dtype=torch.int16, device="cuda:0") for _ in range(infl + 2)]
         job = [streams[i % 2] for i in range(B)]
         def run(n):
