@@ -12,11 +12,11 @@ cd /tmp && export TMPDIR=/tmp
 for W in "4k 256 2" "hdr8k 8 2" "mod8k 2 2"; do
   set -- $W
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/${1}_$C -o p -- python $R/tools/experiments/one_batch_decode.py $1 $2 $3 > $R/gpurun_out/$TAG/${1}_$C.log 2>&1 < /dev/null
+    timeout 420 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/${1}_$C -o p -- python $R/tools/experiments/one_batch_decode.py $1 $2 $3 > $R/gpurun_out/$TAG/${1}_$C.log 2>&1 < /dev/null
   done
 done
 # VALU instruction counts of the 4K kernels (SQ_INSTS_VALU: the bench line's valu_issue)
-timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/4k_SQ -o p -- python $R/tools/experiments/one_batch_decode.py 4k 256 2 > $R/gpurun_out/$TAG/4k_SQ.log 2>&1 < /dev/null
+timeout 420 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/$TAG/4k_SQ -o p -- python $R/tools/experiments/one_batch_decode.py 4k 256 2 > $R/gpurun_out/$TAG/4k_SQ.log 2>&1 < /dev/null
 find $R/gpurun_out/$TAG -name "*kernel_trace.csv" -size +20M -delete
 find $R/gpurun_out/$TAG -name "*counter_collection.csv" -size +30M -delete
 find $R/gpurun_out/$TAG -name "*agent_info.csv" -delete
