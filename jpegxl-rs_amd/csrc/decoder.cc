@@ -109,26 +109,13 @@ struct ConstOffsets {
   bool has_qtable[17] = {false};
 };
 
-// copy into pinned staging; large blocks (the codestream of a lossless 8192x8192 frame is 70 MB, a job of eight 580 MB) on four threads
-static void StageCopy(uint8_t* dst, const uint8_t* src, size_t n) {
-  constexpr size_t kBig = (size_t)8 << 20;
-  if (n < kBig) { memcpy(dst, src, n); return; }
-  constexpr int kThreads = 4;
-  const size_t chunk = ((n + kThreads - 1) / kThreads + 4095) & ~(size_t)4095;
-  std::thread th[kThreads - 1];
-  int started = 0;
-  for (int t = 1; t < kThreads && (size_t)t * chunk < n; t++, started++)
-    th[t - 1] = std::thread([=] { memcpy(dst + (size_t)t * chunk, src + (size_t)t * chunk, std::min(chunk, n - (size_t)t * chunk)); });
-  memcpy(dst, src, std::min(chunk, n));
-  for (int t = 0; t < started; t++) th[t].join();
-}
 struct Arena {
   HostStage& buf;
   explicit Arena(HostStage& b) : buf(b) {}
   size_t Put(const void* src, size_t n, size_t align = 256) {
     const size_t off = Align(buf.size(), align), end = off + std::max<size_t>(n, 4);
     buf.Resize(end);                                   // (the gap before `off` and a short tail are zeroed)
-    if (n) StageCopy(buf.data() + off, (const uint8_t*)src, n);
+    if (n) memcpy(buf.data() + off, src, n);
     return off;
   }
 };
