@@ -3616,9 +3616,9 @@ __device__ __forceinline__ int MirrorD(int x, int size) {
   while (x < 0 || x >= size) x = x < 0 ? -x - 1 : 2 * size - 1 - x;
   return x;
 }
-__device__ __forceinline__ int FilterStagesBefore(const FrameDev& f, int stage) {  // stage: 0 gab, 1 epf0, 2 epf1, 3 epf2
+__device__ __forceinline__ int FilterStagesBefore(const FrameDev& f, int stage, bool gab_folded = false) {  // stage: 0 gab, 1 epf0, 2 epf1, 3 epf2; gab_folded: gaborish runs inside the first EPF pass (no plane of its own)
   int n = 0;
-  if (stage > 0 && f.gab) n++;
+  if (stage > 0 && f.gab && !gab_folded) n++;
   if (stage > 1 && f.epf_iters >= 3) n++;
   if (stage > 2 && f.epf_iters >= 1) n++;
   if (stage > 3 && f.epf_iters >= 2) n++;
@@ -3632,9 +3632,17 @@ __device__ __forceinline__ bool FilterStageActive(const FrameDev& f, int stage) 
 // FusedGabEpf1OutKernel; everything else runs the stage-by-stage kernels.
 __device__ __forceinline__ bool FusedEligible(const FrameDev& f, int unfused) { return !unfused && f.gab && f.epf_iters == 1 && f.color_mode <= 1 && f.upsampling == 1 && f.post_mode == 0; }
 
-__global__ void GaborishKernel(const FrameDev* __restrict__ frames, int unfused) {
+// frames whose last EPF pass writes the pixels itself (EpfTileKernel; fuse_out bit 0 clear: a test stops the tail between the stages)
+__device__ __forceinline__ bool EpfWritesOutput(const FrameDev& f, int unfused, int fuse_out) {
+  return (fuse_out & 1) && !FusedEligible(f, unfused) && f.epf_iters >= 1 && f.upsampling == 1 && f.post_mode == 0;
+}
+// ... and whose first EPF pass applies gaborish to its own tile while loading it (fuse_out bit 1; nothing but the EPF kernels looks at such a frame's planes afterwards,
+// so the plane the separate gaborish pass would have filled is never missed)
+__device__ __forceinline__ bool GabFolded(const FrameDev& f, int unfused, int fuse_out) { return (fuse_out & 2) && f.gab && EpfWritesOutput(f, unfused, fuse_out); }
+
+__global__ void GaborishKernel(const FrameDev* __restrict__ frames, int unfused, int fuse_out) {
   const FrameDev& f = frames[blockIdx.z];
-  if (f.is_modular || !f.gab || FusedEligible(f, unfused)) return;
+  if (f.is_modular || !f.gab || FusedEligible(f, unfused) || GabFolded(f, unfused, fuse_out)) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   const int w = (int)f.width, h = (int)f.height;
   if (x >= w || y >= h) return;
@@ -3837,11 +3845,6 @@ __device__ __forceinline__ void ColorAndStore(const FrameDev& f, int x, int y, f
   if (f.is_gray) r = g;
   StorePixel(f, x, y, r, g, b, A);
 }
-// frames whose last EPF pass writes the pixels itself (EpfTileKernel; fuse_out = 0: a test stops the tail between the stages)
-__device__ __forceinline__ bool EpfWritesOutput(const FrameDev& f, int unfused, int fuse_out) {
-  return fuse_out && !FusedEligible(f, unfused) && f.epf_iters >= 1 && f.upsampling == 1 && f.post_mode == 0;
-}
-
 __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused, int fuse_out) {
   const FrameDev& f = frames[blockIdx.z];
   if (f.is_modular || f.post_mode || FusedEligible(f, unfused) || EpfWritesOutput(f, unfused, fuse_out)) return;
@@ -3883,16 +3886,56 @@ template <int PASS> __global__ __launch_bounds__(256) void EpfTileKernel(const F
   if (x0 >= w || y0 >= h) return;
   constexpr int H = EpfTileGeom<PASS>::kHalo, R = EpfTileGeom<PASS>::kR, P = EpfTileGeom<PASS>::kP;
   __shared__ float s_t[3 * R * P];
-  const bool src_is_a = (FilterStagesBefore(f, stage) & 1) == 0;
+  const bool folded = GabFolded(f, unfused, fuse_out);
+  const bool src_is_a = (FilterStagesBefore(f, stage, folded) & 1) == 0;
   const size_t stride = f.plane_stride;
   const float* src[3]; float* dst[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) { src[c] = src_is_a ? f.plane_a[c] : f.plane_b[c]; dst[c] = src_is_a ? f.plane_b[c] : f.plane_a[c]; }
-  for (int i = threadIdx.x; i < R * R; i += 256) {
-    const int ly = i / R, lx = i - ly * R;
-    const size_t o = (size_t)MirrorD(y0 + ly - H, h) * stride + MirrorD(x0 + lx - H, w);
+  // the frame's first EPF pass of a frame with folded gaborish: the tile is loaded with one more sample of halo, gaborish (GaborishKernel's arithmetic) fills the EPF tile
+  // for the positions inside the image, and the positions outside it take the value of their mirror image — what this pass would have read from a gaborish plane
+  constexpr bool kCanFold = PASS < 2;                      // (pass 2 is never the first one)
+  constexpr int RG = R + 2, PG = RG + 1;
+  __shared__ float s_raw[kCanFold ? 3 * RG * PG : 1];
+  const bool fold_here = kCanFold && folded && (PASS == 0 || f.epf_iters < 3);
+  if (fold_here) {
+    for (int i = threadIdx.x; i < RG * RG; i += 256) {
+      const int ry = i / RG, rx = i - ry * RG;
+      const size_t o = (size_t)MirrorD(y0 + ry - H - 1, h) * stride + MirrorD(x0 + rx - H - 1, w);
 #pragma unroll
-    for (int c = 0; c < 3; c++) s_t[(c * R + ly) * P + lx] = LdG(src[c] + o);
+      for (int c = 0; c < 3; c++) s_raw[(c * RG + ry) * PG + rx] = LdG(f.plane_a[c] + o);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * R; i += 256) {
+      const int ly = i / R, lx = i - ly * R;
+      const int Y = y0 + ly - H, X = x0 + lx - H;
+      if (Y < 0 || Y >= h || X < 0 || X >= w) continue;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float* t = s_raw + (c * RG + ly) * PG + lx; const float* m = t + PG; const float* b = m + PG;      // rows Y - 1, Y, Y + 1 from column X - 1
+        const float sum0 = m[1];
+        const float sum1 = (m[0] + m[2]) + (t[1] + b[1]);
+        const float sum2 = (t[0] + t[2]) + (b[0] + b[2]);
+        s_t[(c * R + ly) * P + lx] = fmaf(sum2, f.gab_w[c * 3 + 2], fmaf(sum1, f.gab_w[c * 3 + 1], sum0 * f.gab_w[c * 3 + 0]));
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * R; i += 256) {
+      const int ly = i / R, lx = i - ly * R;
+      const int Y = y0 + ly - H, X = x0 + lx - H;
+      if (Y >= 0 && Y < h && X >= 0 && X < w) continue;
+      const int my = MirrorD(Y, h) - y0 + H, mx = MirrorD(X, w) - x0 + H;
+      if (my < 0 || my >= R || mx < 0 || mx >= R) continue;                     // (farther out than any pixel of the image reaches)
+#pragma unroll
+      for (int c = 0; c < 3; c++) s_t[(c * R + ly) * P + lx] = s_t[(c * R + my) * P + mx];
+    }
+  } else {
+    for (int i = threadIdx.x; i < R * R; i += 256) {
+      const int ly = i / R, lx = i - ly * R;
+      const size_t o = (size_t)MirrorD(y0 + ly - H, h) * stride + MirrorD(x0 + lx - H, w);
+#pragma unroll
+      for (int c = 0; c < 3; c++) s_t[(c * R + ly) * P + lx] = LdG(src[c] + o);
+    }
   }
   __syncthreads();
   const bool last = PASS == 2 || (PASS == 1 && f.epf_iters == 1);
@@ -4952,9 +4995,11 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
   if (!fp.any_unfused && !unfused) return;
   // (cfg.debug_stop_after, testing: 2 = stop after gaborish, 3 / 4 / 5 = after EPF pass 0 / 1 / 2 — the planes are then read back, JxlHipBatchDebugRead)
   const int stop = cfg.debug_stop_after ? cfg.debug_stop_after : 99;
-  if (fp.any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames, unfused);
+  // (fuse_out bit 0: the last EPF pass writes the pixels; bit 1: gaborish inside the first EPF pass of those frames — JXL_HIP_NO_GAB_FOLD: the separate pass, an A/B knob)
+  static const bool no_gab_fold = getenv("JXL_HIP_NO_GAB_FOLD") != nullptr;
+  const int fuse_out = cfg.debug_stop_after ? 0 : (no_gab_fold ? 1 : 3);
+  if (fp.any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames, unfused, fuse_out);
   // the EPF passes on LDS tiles (the per-pixel kernels they replaced in round 5 — EpfKernel<PASS>, 90 spilled registers in the first pass — are in the history)
-  const int fuse_out = cfg.debug_stop_after ? 0 : 1;
   const int etx = DivUp(max_w, kEtT);
   const dim3 tgrid(etx * DivUp(max_h, kEtT), 1, nframes);
   if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfTileKernel<0>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
