@@ -3876,10 +3876,54 @@ __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused, i
 // =====================================================================================================================
 constexpr int kEtT = 32;                                   // tile edge
 template <int PASS> struct EpfTileGeom { static constexpr int kHalo = PASS == 0 ? 3 : PASS == 1 ? 2 : 1, kR = kEtT + 2 * kHalo, kP = kR + 1; };
+// One pixel of EPF pass PASS out of an LDS tile: t0 = the pixel's sample of channel 0, `plane` floats between the channels, row pitch P (stage_epf.cc's arithmetic and operation order)
+template <int PASS> __device__ __forceinline__ void EpfPixel(const FrameDev& f, const float* t0, int plane, int P, int x, int y, float cs0, float cs1, float cs2, float (&out)[3]) {
+  constexpr int ntaps = PASS == 0 ? 12 : 4;
+  constexpr int taps0[12][2] = {{0, -2}, {-1, -1}, {0, -1}, {1, -1}, {-2, 0}, {-1, 0}, {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {0, 2}};
+  constexpr int taps1[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  constexpr int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  auto px = [&](int c, int dx, int dy) -> float { return t0[c * plane + dy * P + dx]; };
+  const float is = f.inv_sigma[(size_t)(y / 8) * f.bw + x / 8];
+  if (is < -3.90524291751269967465540850526868f) { out[0] = px(0, 0, 0); out[1] = px(1, 0, 0); out[2] = px(2, 0, 0); return; }
+  const bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
+  const float vmul = is * (border ? f.epf_bsm[PASS] : f.epf_sm[PASS]);
+  float wsum = 1.0f;
+  float acc[3] = {px(0, 0, 0), px(1, 0, 0), px(2, 0, 0)};
+#pragma unroll
+  for (int t = 0; t < ntaps; t++) {
+    const int dx = PASS == 0 ? taps0[t][0] : taps1[t][0], dy = PASS == 0 ? taps0[t][1] : taps1[t][1];
+    float sad = 0.f;
+    if (PASS == 2) {
+      sad = fmaf(fabsf(px(0, dx, dy) - px(0, 0, 0)), cs0, sad);
+      sad = fmaf(fabsf(px(1, dx, dy) - px(1, 0, 0)), cs1, sad);
+      sad = fmaf(fabsf(px(2, dx, dy) - px(2, 0, 0)), cs2, sad);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) sacc += fabsf(px(c, dx + plus[k][0], dy + plus[k][1]) - px(c, plus[k][0], plus[k][1]));
+        sad = fmaf(sacc, c == 0 ? cs0 : c == 1 ? cs1 : cs2, sad);
+      }
+    }
+    const float wgt = fmaxf(0.0f, fmaf(sad, vmul, 1.0f));
+    wsum += wgt;
+#pragma unroll
+    for (int c = 0; c < 3; c++) acc[c] = fmaf(wgt, px(c, dx, dy), acc[c]);
+  }
+  const float inv = 1.0f / wsum;
+#pragma unroll
+  for (int c = 0; c < 3; c++) out[c] = acc[c] * inv;
+}
+// frames whose passes 1 and 2 run in ONE kernel (EpfTile12Kernel; fuse_out bit 2): the last pass writes the pixels, and pass 1 is not the pass that carries a folded gaborish
+__device__ __forceinline__ bool EpfPasses12Fused(const FrameDev& f, int unfused, int fuse_out) {
+  return (fuse_out & 4) && f.epf_iters >= 2 && EpfWritesOutput(f, unfused, fuse_out) && !(GabFolded(f, unfused, fuse_out) && f.epf_iters < 3);
+}
 template <int PASS> __global__ __launch_bounds__(256) void EpfTileKernel(const FrameDev* __restrict__ frames, int unfused, int tiles_x, int fuse_out) {
   const FrameDev& f = frames[blockIdx.z];
   constexpr int stage = PASS + 1;
   if (f.is_modular || !FilterStageActive(f, stage) || FusedEligible(f, unfused)) return;
+  if (PASS >= 1 && EpfPasses12Fused(f, unfused, fuse_out)) return;          // EpfTile12Kernel
   const int w = (int)f.width, h = (int)f.height;
   const uint32_t tile = XcdContiguous(blockIdx.x, gridDim.x);
   const int x0 = (int)(tile % (uint32_t)tiles_x) * kEtT, y0 = (int)(tile / (uint32_t)tiles_x) * kEtT;
@@ -3941,51 +3985,13 @@ template <int PASS> __global__ __launch_bounds__(256) void EpfTileKernel(const F
   const bool last = PASS == 2 || (PASS == 1 && f.epf_iters == 1);
   const bool write_out = last && EpfWritesOutput(f, unfused, fuse_out);
   const float cs0 = f.epf_channel_scale[0], cs1 = f.epf_channel_scale[1], cs2 = f.epf_channel_scale[2];
-  constexpr int ntaps = PASS == 0 ? 12 : 4;
-  constexpr int taps0[12][2] = {{0, -2}, {-1, -1}, {0, -1}, {1, -1}, {-2, 0}, {-1, 0}, {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {0, 2}};
-  constexpr int taps1[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
-  constexpr int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const int lx = threadIdx.x & 31, ly = (threadIdx.x >> 5) + 8 * q;
     const int x = x0 + lx, y = y0 + ly;
     if (x >= w || y >= h) continue;
-    const float* t0 = s_t + (ly + H) * P + (lx + H);        // centre sample of channel 0
-    auto px = [&](int c, int dx, int dy) -> float { return t0[c * R * P + dy * P + dx]; };
     float out[3];
-    const float is = f.inv_sigma[(size_t)(y / 8) * f.bw + x / 8];
-    if (is < -3.90524291751269967465540850526868f) { out[0] = px(0, 0, 0); out[1] = px(1, 0, 0); out[2] = px(2, 0, 0); }
-    else {
-      const bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
-      const float vmul = is * (border ? f.epf_bsm[PASS] : f.epf_sm[PASS]);
-      float wsum = 1.0f;
-      float acc[3] = {px(0, 0, 0), px(1, 0, 0), px(2, 0, 0)};
-#pragma unroll
-      for (int t = 0; t < ntaps; t++) {
-        const int dx = PASS == 0 ? taps0[t][0] : taps1[t][0], dy = PASS == 0 ? taps0[t][1] : taps1[t][1];
-        float sad = 0.f;
-        if (PASS == 2) {
-          sad = fmaf(fabsf(px(0, dx, dy) - px(0, 0, 0)), cs0, sad);
-          sad = fmaf(fabsf(px(1, dx, dy) - px(1, 0, 0)), cs1, sad);
-          sad = fmaf(fabsf(px(2, dx, dy) - px(2, 0, 0)), cs2, sad);
-        } else {
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < 5; k++) s += fabsf(px(c, dx + plus[k][0], dy + plus[k][1]) - px(c, plus[k][0], plus[k][1]));
-            sad = fmaf(s, c == 0 ? cs0 : c == 1 ? cs1 : cs2, sad);
-          }
-        }
-        const float wgt = fmaxf(0.0f, fmaf(sad, vmul, 1.0f));
-        wsum += wgt;
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc[c] = fmaf(wgt, px(c, dx, dy), acc[c]);
-      }
-      const float inv = 1.0f / wsum;
-#pragma unroll
-      for (int c = 0; c < 3; c++) out[c] = acc[c] * inv;
-    }
+    EpfPixel<PASS>(f, s_t + (ly + H) * P + (lx + H), R * P, P, x, y, cs0, cs1, cs2, out);
     if (write_out) {
       const float A = f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f;
       ColorAndStore(f, x, y, out[0], out[1], out[2], A);
@@ -3994,6 +4000,62 @@ template <int PASS> __global__ __launch_bounds__(256) void EpfTileKernel(const F
 #pragma unroll
       for (int c = 0; c < 3; c++) dst[c][o] = out[c];
     }
+  }
+}
+
+// EPF passes 1 and 2 in one kernel (frames with two or three EPF iterations whose last pass writes the pixels): the tile is loaded with the halo of both passes (3), pass 1 is
+// computed for the 34x34 positions pass 2 reads — inside the image; positions outside it take the value of their mirror image, what pass 2 would have read from pass 1's plane —
+// into a second LDS tile, and pass 2 runs out of that.  One pass over the planes less; per pixel the arithmetic of the two separate passes (EpfPixel).
+__global__ __launch_bounds__(256) void EpfTile12Kernel(const FrameDev* __restrict__ frames, int unfused, int tiles_x, int fuse_out) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular || FusedEligible(f, unfused) || !EpfPasses12Fused(f, unfused, fuse_out)) return;
+  const int w = (int)f.width, h = (int)f.height;
+  const uint32_t tile = XcdContiguous(blockIdx.x, gridDim.x);
+  const int x0 = (int)(tile % (uint32_t)tiles_x) * kEtT, y0 = (int)(tile / (uint32_t)tiles_x) * kEtT;
+  if (x0 >= w || y0 >= h) return;
+  constexpr int R0 = kEtT + 6, P0 = R0 + 1, R1 = kEtT + 2, P1 = R1 + 1;
+  __shared__ float s_in[3 * R0 * P0];
+  __shared__ float s_p1[3 * R1 * P1];
+  const bool src_is_a = (FilterStagesBefore(f, 2, GabFolded(f, unfused, fuse_out)) & 1) == 0;
+  const size_t stride = f.plane_stride;
+  for (int i = threadIdx.x; i < R0 * R0; i += 256) {
+    const int ly = i / R0, lx = i - ly * R0;
+    const size_t o = (size_t)MirrorD(y0 + ly - 3, h) * stride + MirrorD(x0 + lx - 3, w);
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_in[(c * R0 + ly) * P0 + lx] = LdG((src_is_a ? f.plane_a[c] : f.plane_b[c]) + o);
+  }
+  __syncthreads();
+  const float cs0 = f.epf_channel_scale[0], cs1 = f.epf_channel_scale[1], cs2 = f.epf_channel_scale[2];
+#pragma unroll 1
+  for (int i = threadIdx.x; i < R1 * R1; i += 256) {
+    const int ly = i / R1, lx = i - ly * R1;
+    const int y = y0 + ly - 1, x = x0 + lx - 1;
+    if (y < 0 || y >= h || x < 0 || x >= w) continue;
+    float out[3];
+    EpfPixel<1>(f, s_in + (ly + 2) * P0 + (lx + 2), R0 * P0, P0, x, y, cs0, cs1, cs2, out);
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_p1[(c * R1 + ly) * P1 + lx] = out[c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R1 * R1; i += 256) {
+    const int ly = i / R1, lx = i - ly * R1;
+    const int y = y0 + ly - 1, x = x0 + lx - 1;
+    if (y >= 0 && y < h && x >= 0 && x < w) continue;
+    const int my = MirrorD(y, h) - y0 + 1, mx = MirrorD(x, w) - x0 + 1;
+    if (my < 0 || my >= R1 || mx < 0 || mx >= R1) continue;                     // (farther out than any pixel of the image reaches)
+#pragma unroll
+    for (int c = 0; c < 3; c++) s_p1[(c * R1 + ly) * P1 + lx] = s_p1[(c * R1 + my) * P1 + mx];
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    const int lx = threadIdx.x & 31, ly = (threadIdx.x >> 5) + 8 * q;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) continue;
+    float out[3];
+    EpfPixel<2>(f, s_p1 + (ly + 1) * P1 + (lx + 1), R1 * P1, P1, x, y, cs0, cs1, cs2, out);
+    const float A = f.alpha_plane ? (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor : 1.0f;
+    ColorAndStore(f, x, y, out[0], out[1], out[2], A);
   }
 }
 
@@ -4997,7 +5059,8 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
   const int stop = cfg.debug_stop_after ? cfg.debug_stop_after : 99;
   // (fuse_out bit 0: the last EPF pass writes the pixels; bit 1: gaborish inside the first EPF pass of those frames — JXL_HIP_NO_GAB_FOLD: the separate pass, an A/B knob)
   static const bool no_gab_fold = getenv("JXL_HIP_NO_GAB_FOLD") != nullptr;
-  const int fuse_out = cfg.debug_stop_after ? 0 : (no_gab_fold ? 1 : 3);
+  static const bool no_p12 = getenv("JXL_HIP_NO_EPF12") != nullptr;           // (A/B knob: passes 1 and 2 as kernels of their own)
+  const int fuse_out = cfg.debug_stop_after ? 0 : ((no_gab_fold ? 1 : 3) | (no_p12 ? 0 : 4));
   if (fp.any_gab) hipLaunchKernelGGL(GaborishKernel, grid, block, 0, (hipStream_t)stream, frames, unfused, fuse_out);
   // the EPF passes on LDS tiles (the per-pixel kernels they replaced in round 5 — EpfKernel<PASS>, 90 spilled registers in the first pass — are in the history)
   const int etx = DivUp(max_w, kEtT);
@@ -5005,6 +5068,7 @@ void LaunchFilters(const FrameDev* frames, int nframes, int max_w, int max_h, co
   if (fp.max_epf >= 3 && stop >= 3) hipLaunchKernelGGL(EpfTileKernel<0>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
   if (fp.max_epf >= 1 && stop >= 4) hipLaunchKernelGGL(EpfTileKernel<1>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
   if (fp.max_epf >= 2 && stop >= 5) hipLaunchKernelGGL(EpfTileKernel<2>, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
+  if (fp.max_epf >= 2 && (fuse_out & 4)) hipLaunchKernelGGL(EpfTile12Kernel, tgrid, dim3(256), 0, (hipStream_t)stream, frames, unfused, etx, fuse_out);
 }
 void LaunchOutput(const FrameDev* frames, int nframes, int max_w, int max_h, const FilterPlan& fp, const LaunchCfg& cfg, void* stream) {
   if (!fp.any_unfused && !cfg.force_unfused_filters) return;
