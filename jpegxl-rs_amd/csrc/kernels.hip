@@ -202,6 +202,7 @@ struct FastCode {
   const uint64_t* alias_g;
   uint32_t ctx_map_off, cfg_off, alias_off;   // kNotInLds if the table stayed in global memory
   uint32_t freq_off;                          // StageCodeCompact: per-symbol frequencies (u16) behind the 4-byte alias slots
+  uint32_t wide_off, cut_off;                 // StageCode(with_wide): the alias table once more in the form the wave-wide decoder reads (below); kNotInLds if not staged
   uint32_t log_alpha;
   uint32_t cfg_uniform;                       // the hybrid-uint config shared by every cluster, or 0xFFFFFFFF
   __device__ __forceinline__ uint32_t Cluster(uint32_t ctx) const { return ctx_map_off != kNotInLds ? LdS<uint8_t>(ctx_map_off + ctx) : LdG(ctx_map_g + ctx); }
@@ -300,11 +301,21 @@ struct BitReaderW {      // reads 32-bit words from an LDS window at win_off hol
 };
 // Cooperative copy of an entropy code into LDS (all threads of the block) starting at byte offset `base`; tables
 // that do not fit in [base, base + budget) stay in global memory.  Returns the bytes used.
-__device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget, bool with_ctx_map) {
+// with_wide: when budget is left, the alias table is staged a second time in the layout of the wave-wide decoder (DecodeChannelWave): per slot one 64-bit
+// pair of ready-made candidates — low word: the slot's own symbol, high word: the aliased one, each {frequency - 1 [0:12), offset [12:24), value [24:32)} where
+// value is the symbol's UnpackSigned() as a signed byte when the symbol is a complete hybrid-uint token of its cluster's configuration, -128 (kWideEscape)
+// when extra bits follow — and one u16 {cutoff [0:8), aliased symbol [8:16)}.  10 bytes per slot instead of 8.
+constexpr int32_t kWideEscape = -128;
+__device__ __forceinline__ uint32_t WideValue(uint32_t tok, uint32_t cfg) {
+  const uint32_t split = 1u << (cfg & 0xFF);
+  return (tok < split && tok < 255u) ? ((uint32_t)UnpackSigned(tok) & 0xFFu) : ((uint32_t)kWideEscape & 0xFFu);
+}
+__device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget, bool with_ctx_map, bool with_wide = false) {
   uint32_t used = 0;
   fc.log_alpha = g.log_alpha;
   fc.ctx_map_g = g.ctx_map; fc.cfg_g = g.cfg; fc.alias_g = g.alias;
   fc.ctx_map_off = fc.cfg_off = fc.alias_off = kNotInLds;
+  fc.wide_off = fc.cut_off = kNotInLds;
   {
     const uint32_t c0 = LdG(g.cfg);
     bool same = true;
@@ -327,6 +338,21 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
   if (used + n_alias * 8 <= budget) {
     for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) StS<uint64_t>(base + used + i * 8, LdG(g.alias + i));
     fc.alias_off = base + used; used += n_alias * 8;
+    const uint32_t wide_bytes = n_alias * 8 + ((n_alias * 2 + 15) & ~15u);
+    if (with_wide && fc.cfg_off != kNotInLds && used + wide_bytes <= budget) {
+      const uint32_t wo = base + used, co = wo + n_alias * 8;
+      for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) {
+        const uint64_t e = LdG(g.alias + i);
+        const uint32_t cfg = LdG(g.cfg + (i >> g.log_alpha)), slot = i & ((1u << g.log_alpha) - 1);
+        const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
+        const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
+        const uint32_t lo = (max(freq0, 1u) - 1) | (WideValue(slot, cfg) << 24);
+        const uint32_t hi = (max(freq1, 1u) - 1) | ((offs1 & 0xFFFu) << 12) | (WideValue(right, cfg) << 24);
+        StS<uint64_t>(wo + i * 8, (uint64_t)lo | ((uint64_t)hi << 32));
+        StS<uint16_t>(co + i * 2, (uint16_t)(cutoff | (right << 8)));
+      }
+      fc.wide_off = wo; fc.cut_off = co; used += wide_bytes;
+    }
   }
   return used;
 }
@@ -339,7 +365,7 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
 __device__ uint32_t StageCodeCompact(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget) {
   fc.log_alpha = g.log_alpha;
   fc.ctx_map_g = g.ctx_map; fc.cfg_g = g.cfg; fc.alias_g = g.alias;
-  fc.ctx_map_off = fc.cfg_off = fc.alias_off = fc.freq_off = kNotInLds;
+  fc.ctx_map_off = fc.cfg_off = fc.alias_off = fc.freq_off = fc.wide_off = fc.cut_off = kNotInLds;
   {
     const uint32_t c0 = LdG(g.cfg);
     bool same = true;
@@ -816,6 +842,178 @@ __device__ __forceinline__ void DecodeRowsBallot(BitReaderP& br, uint32_t& state
   WaveSync();
 }
 
+// ---- wave-wide decode of a channel under a single-property tree (round 6) -------------------------------------------------------------------
+// The serial fast path above runs the chain on lane 0: per sample two dependent LDS round trips (property -> cluster table, cluster -> alias slot)
+// and ~50 instructions, 0.25 us.  A lone wavefront issues a dependent instruction every ~4 ns whatever the number of active lanes
+// (tools/microbench/chain_ops.hip), so here ALL lanes run the chain and the lanes are spent on speculation instead:
+//  * the channel's subtree tests one property (W + N - NW) against at most 63 constants: lane j keeps constant j, one compare + ballot + popcount gives
+//    the index k of the interval the property value falls in — no table read;
+//  * lane k owns interval k: as soon as the ANS state of the sample is known it reads the alias slot OF ITS INTERVAL'S CLUSTER (StageCode's wide layout:
+//    both candidates ready-made, the signed value of a complete token precomputed) — every cluster's slot in one LDS round trip, while the scalar
+//    unit works out k from the sample before; `v_readlane` with k picks the winner;
+//  * everything that is the same for all lanes (ANS state, bit buffer, neighbours, prediction) stays in scalar registers; the bit stream sits in a
+//    VGPR, one 32-bit word per lane (a 2048-bit window, the next one already loaded), the row above and the row being decoded in VGPRs, one sample
+//    per lane (`v_readlane` / `v_writelane`): no LDS or memory access on the chain but the alias read, rows leave as coalesced 256-byte stores.
+// Semantics: DecodeChunkLds / jxl_dev.h DecodeModularChannel.  Channels: leaves (predictor zero / W / clamped gradient, offset 0, multiplier 1), no
+// property or the row (one cluster per row) or W + N - NW; rows up to 256 samples when the row above is needed, any width otherwise.
+struct WaveBits {           // uniform state; `win`: this lane's word of the current 64-word window
+  const uint32_t* words;
+  uint32_t wend, wbase, widx;      // window = words [wbase, wbase + 64); widx: the next word to take, relative to wbase
+  uint32_t win;                    // (no second window in flight: a load pending across the sample loop puts an s_waitcnt vmcnt(0) — which also waits for the row stores — into every
+                                   // iteration; the switch waits for its own load instead, ~1 us per 2048 bits)
+  uint64_t buf;
+  int avail;
+  __device__ __forceinline__ uint32_t Load(uint32_t i) const { return i < wend ? LdG(words + i) : 0u; }
+  __device__ __forceinline__ void Start(const uint32_t* w, uint32_t wend_, uint64_t bit_pos, uint32_t lane) {
+    words = w; wend = wend_; wbase = (uint32_t)(bit_pos >> 5); widx = 0;
+    win = Load(wbase + lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    buf = 0; avail = 0;
+    Refill();
+    const int skip = (int)(bit_pos & 31);
+    buf >>= skip; avail -= skip;
+    Refill();
+  }
+  __device__ __forceinline__ void Refill() {
+    if (avail <= 32) {
+      if (__builtin_expect(widx == 64, 0)) { const uint32_t lane = threadIdx.x & 63; wbase += 64; widx = 0; win = Load(wbase + lane); __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) here, so that none is needed in the loop */ }
+      const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)widx);
+      buf |= (uint64_t)w << avail;
+      avail += 32;
+      widx++;
+    }
+  }
+  __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)(wbase + widx) * 32 - (uint64_t)avail; }
+};
+struct WaveChan {           // per channel (uniform unless noted)
+  int32_t thr;              // per lane: split constant of this lane's inner node (INT_MAX beyond the last)
+  uint32_t abase, cbase;    // per lane: LDS byte offsets of the wide table / cutoff table of this lane's interval's cluster
+  uint32_t cluster;         // per lane: that cluster
+  uint32_t la, cfg_off, cfg_uniform;
+};
+template <bool NEEDN, bool PROP9, int UPRED>
+__device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int32_t& left, int32_t& nw, const int32_t prevv, int32_t& curv, const int n, const WaveChan& wc) {
+  const uint32_t la = wc.la, pmask = (1u << (12 - la)) - 1, lane = threadIdx.x & 63;
+  int32_t cur = curv;
+  for (int xl = 0; xl < n; xl++) {
+    const int32_t W = left;
+    int32_t N = W, NW = W;
+    if (NEEDN) { N = __builtin_amdgcn_readlane(prevv, xl); NW = nw; nw = N; }
+    const int32_t v0 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+    int k = 0;
+    if (PROP9) k = __builtin_popcountll(__ballot(v0 > wc.thr));
+    int32_t guess;
+    if (UPRED == 0) guess = 0;
+    else if (UPRED == 1) guess = W;
+    else { const int32_t m = min(N, W), M = max(N, W); guess = max(m, min(M, v0)); }   // clamped gradient = median(N, W, N + W - NW)
+    // --- ANS: every lane reads the slot of its own interval's cluster
+    const uint32_t slot = (state & 0xFFF) >> (12 - la), pos = state & pmask, hi = state >> 12;
+    const uint2 e = LdS<uint2>(wc.abase + slot * 8);
+    const uint32_t cr = LdS<uint16_t>(wc.cbase + slot * 2);
+    const bool hit = pos >= (cr & 0xFFu);
+    const uint32_t cand = hit ? e.y : e.x;
+    const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)cand, k);
+    state = (sw & 0xFFFu) * hi + (hi + pos) + ((sw >> 12) & 0xFFFu);
+    int32_t v = (int32_t)sw >> 24;
+    if (state < (1u << 16)) { asm volatile("" ::: "memory"); /* (keeps this a branch: as selects it costs 13 scalar instructions on every sample) */ state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; }
+    if (__builtin_expect(v == kWideEscape, 0)) {
+      // the token carries extra bits (or is too large for the table's byte): the symbol again from this lane's {cutoff, aliased symbol}, then dec_ans.h's hybrid integer
+      const uint32_t crk = (uint32_t)__builtin_amdgcn_readlane((int)cr, k);
+      uint32_t tok = pos >= (crk & 0xFFu) ? (crk >> 8) : slot;
+      uint32_t cfg = wc.cfg_uniform;
+      if (cfg == 0xFFFFFFFFu) cfg = Uniform(LdS<uint32_t>(wc.cfg_off + 4 * (uint32_t)__builtin_amdgcn_readlane((int)wc.cluster, k)));
+      const uint32_t split_exp = cfg & 0xFF, split = 1u << split_exp;
+      if (tok >= split) {
+        const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+        const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb))) & 31;
+        const uint32_t low = tok & ((1u << lsb) - 1);
+        tok >>= lsb;
+        if ((int)nbits > bits.avail) bits.Refill();
+        const uint32_t xb = (uint32_t)(bits.buf & ((1ull << nbits) - 1));
+        bits.buf >>= nbits; bits.avail -= (int)nbits;
+        const uint32_t hb = (1u << msb) | (tok & ((1u << msb) - 1));
+        tok = (((hb << nbits) | xb) << lsb) | low;
+      }
+      v = UnpackSigned(tok);
+    }
+    const int32_t val = (int32_t)((uint32_t)v + (uint32_t)guess);
+    cur = (int)lane == xl ? val : cur;      // (v_writelane would need its value in a scalar register and its lane select in M0 on gfx9: three instructions against these two)
+    left = val;
+    bits.Refill();
+  }
+  curv = cur;
+}
+// All 64 lanes.  `upred`, `prop`, `subroot` as DecodeChannelCoop found them; ni inner nodes of the channel's subtree, their constants at thr_off.
+__device__ __forceinline__ void DecodeChannelWave(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, int upred_in, int prop_in, uint32_t subroot_in, uint32_t ni_in, uint32_t thr_off_in) {
+  const uint32_t lane = threadIdx.x & 63;
+  // (everything that steers control flow into scalar registers: the compiler has to see the loops below as uniform to keep the chain there)
+  const int w = (int)Uniform((uint32_t)ch.w), h = (int)Uniform((uint32_t)ch.h);
+  const int upred = (int)Uniform((uint32_t)upred_in), prop = (int)Uniform((uint32_t)prop_in);
+  const uint32_t subroot = Uniform(subroot_in), ni = Uniform(ni_in), thr_off = Uniform(thr_off_in);
+  WaveChan wc;
+  wc.la = Uniform(T.code.log_alpha); wc.cfg_off = Uniform(T.code.cfg_off); wc.cfg_uniform = Uniform(T.code.cfg_uniform);
+  const uint32_t wide_off = Uniform(T.code.wide_off), cut_off = Uniform(T.code.cut_off);
+  wc.thr = 0x7FFFFFFF; wc.cluster = 0;
+  if (prop == 9) {
+    // interval k = (number of constants below the value): lane k walks the subtree once with a value of its interval
+    const int32_t t = lane < ni ? LdS<int32_t>(thr_off + 4 * lane) : 0x7FFFFFFF;
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < ni; i++) { const int32_t ti = __builtin_amdgcn_readlane(t, (int)i); rank += (ti < t || (ti == t && i < lane)) ? 1u : 0u; }
+    const uint32_t sorted_off = thr_off + 256;
+    if (lane < ni) StS<int32_t>(sorted_off + 4 * rank, t);
+    WaveSync();
+    const uint32_t kk = min(lane, ni);
+    const int32_t rep = ni == 0 ? 0 : (kk == 0 ? LdS<int32_t>(sorted_off) : (int32_t)((uint32_t)LdS<int32_t>(sorted_off + 4 * (kk - 1)) + 1u));
+    wc.cluster = WalkCluster(T.node_base, subroot, rep);
+    wc.thr = t;
+    WaveSync();
+  }
+  state_io = Uniform(state_io);
+  uint32_t state = state_io;
+  const uint64_t bp = br.BitPos();
+  const uint64_t bp0 = ((uint64_t)Uniform((uint32_t)(bp >> 32)) << 32) | Uniform((uint32_t)bp);
+  WaveBits bits;
+  bits.Start(br.words, Uniform(br.wend), bp0, lane);
+  const bool need_n = upred == 5 || prop == 9;
+  int32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;      // the row above, 64 samples per register (rows of up to 256 samples; only when need_n)
+  int32_t first = 0;                            // first sample of the row above (W of a row's first sample when the row above is not kept)
+  for (int y = 0; y < h; y++) {
+    int32_t* p = ch.data + (size_t)y * ch.stride;
+    if (prop != 9) {
+      wc.cluster = WalkCluster(T.node_base, subroot, prop == 2 ? y : 0);
+    }
+    wc.abase = wide_off + ((wc.cluster << wc.la) << 3); wc.cbase = cut_off + ((wc.cluster << wc.la) << 1);
+    const bool rows = need_n && y > 0;
+    int32_t left = 0, nw = 0;
+    if (y > 0) { left = rows ? __builtin_amdgcn_readlane(p0, 0) : first; nw = left; }
+    int32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int x0 = 0; x0 < w; x0 += 64) {
+      const int n = min(64, w - x0), seg = (x0 >> 6) & 3;
+      const int32_t prevv = seg == 0 ? p0 : seg == 1 ? p1 : seg == 2 ? p2 : p3;
+      int32_t curv = 0;
+#define JXL_WSEG(NN, P9, UP) WaveSegment<NN, P9, UP>(bits, state, left, nw, prevv, curv, n, wc)
+      if (prop == 9) {
+        if (upred == 5) { if (rows) JXL_WSEG(true, true, 5); else JXL_WSEG(false, true, 5); }
+        else if (upred == 1) { if (rows) JXL_WSEG(true, true, 1); else JXL_WSEG(false, true, 1); }
+        else { if (rows) JXL_WSEG(true, true, 0); else JXL_WSEG(false, true, 0); }
+      } else {
+        if (upred == 5) { if (rows) JXL_WSEG(true, false, 5); else JXL_WSEG(false, false, 5); }
+        else if (upred == 1) JXL_WSEG(false, false, 1);
+        else JXL_WSEG(false, false, 0);
+      }
+#undef JXL_WSEG
+      if ((int)lane < n) StG(p + x0 + (int)lane, curv);
+      if (x0 == 0) first = __builtin_amdgcn_readlane(curv, 0);
+      if (seg == 0) c0 = curv; else if (seg == 1) c1 = curv; else if (seg == 2) c2 = curv; else c3 = curv;
+    }
+    p0 = c0; p1 = c1; p2 = c2; p3 = c3;
+  }
+  state_io = state;
+  const uint64_t endpos = bits.BitPos();
+  br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
+  WaveSync();
+}
+
 // BALLOT: general trees are evaluated by the whole wavefront (see the "ballot" path below) — the Modular kernels; the LF kernel
 // of the VarDCT path keeps the single-lane loops (register budget).
 template <bool BALLOT = false>
@@ -870,6 +1068,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       n = T.Node(pos);
     }
     int mode = 1, prop = -1, count = 0, wide = 0;
+    uint32_t ni = 0;  // inner nodes seen; the first 64 constants go to the (not yet built) LUT region for the wave-wide decoder
     int upred = -1;   // predictor shared by all leaves with offset 0 / multiplier 1 (-2: not uniform / not simple)
     int sp = 0;       // iterative DFS with a bounded stack at kWorkOff + 64
     StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)pos);
@@ -887,6 +1086,8 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       if (prop < 0) prop = m.prop; else if (prop != m.prop) { mode = 0; break; }
       if (sp + 2 > 200) { mode = 0; break; }
       if (m.val < -512 || m.val > 510) wide = 1;      // split outside the LUT's range: such property values walk the subtree
+      if (ni < 64) StS<int32_t>(wb + kLutOff + 4 * ni, m.val);
+      ni++;
       StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.a); StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.b);
     }
     if (!T.tree_in_lds) mode = 0;
@@ -911,6 +1112,7 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     StS<int>(wb + kWorkOff + 56, sub_wp);
     StS<int>(wb + kWorkOff + 0, mode); StS<int>(wb + kWorkOff + 4, prop); StS<int>(wb + kWorkOff + 8, (int)pos); StS<int>(wb + kWorkOff + 12, upred);
     StS<int>(wb + kWorkOff + 20, wide);
+    StS<uint32_t>(wb + kWorkOff + 60, ni);
   }
   WaveSync();
   const int mode = mc.slow ? 0 : LdS<int>(wb + kWorkOff + 0), prop = LdS<int>(wb + kWorkOff + 4);   // prefix / LZ77 streams: general loop only
@@ -922,6 +1124,12 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
   const bool need_n = upred == 5 || prop == 9;    // previous row needed
   const bool fast = mode == 1 && (upred == 0 || upred == 1 || upred == 5) && (prop < 0 || prop == 2 || prop == 9) &&
                     T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && ((uint32_t)ch.w <= kRowMax || !need_n);
+#ifndef JXL_NO_WAVE_LF
+  if (fast && T.code.wide_off != kNotInLds && (prop != 9 || LdS<uint32_t>(wb + kWorkOff + 60) <= 63u)) {
+    DecodeChannelWave(br, state, T, ch, upred, prop, subroot, LdS<uint32_t>(wb + kWorkOff + 60), wb + kLutOff);
+    return;
+  }
+#endif
   if (mode == 1) {
     for (int i = (int)lane; i < 1024; i += 64) {
       const int32_t v = i - 512;
@@ -1256,7 +1464,7 @@ __device__ void StageModular(const TreeNode* tree, uint32_t num_tree_nodes, cons
   const uint32_t tree_off = (blockDim.x >> 6) * kWaveLds;   // shared part starts after the per-wavefront regions
   const uint32_t code_base = tree_off + tree_cap * 16;
   const uint32_t budget = lds_bytes > code_base ? lds_bytes - code_base : 0;
-  StageCode(code, T.code, code_base, budget, /*with_ctx_map=*/false);
+  StageCode(code, T.code, code_base, budget, /*with_ctx_map=*/false, /*with_wide=*/true);
   T.tree_g = tree;
   T.tree_cap = tree_cap;
   T.tree_in_lds = num_tree_nodes <= tree_cap;
@@ -4895,7 +5103,10 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   // (the pass that only takes the streams the weighted-predictor SIMT lanes handed back — normally none — keeps the entropy code out of the LDS: its 256 workgroups
   // have to find room on CUs that the HF stage and the pixel kernels fill, and the launch holds up the placement kernels behind it until the last one has been dispatched)
   const bool redo_only_launch = simt_mode == 2 && simt && !simt->any_legacy;
-  const uint32_t lds_tables = kLfDecWaves * kWaveLds + tree_cap * 16 + (redo_only_launch ? 0u : (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes));
+  // (+ the wave-wide decoder's second copy of the alias tables, StageCode(with_wide): 10 bytes per slot — when the plain tables fit their budget and the two together 96 KB)
+  static const bool no_wide = getenv("JXL_HIP_NO_WAVE_LF") != nullptr;     // A/B: the lane-0 serial fast path
+  const uint32_t wide_bytes = (!no_wide && !redo_only_launch && cfg.mod_code_bytes <= cfg.lds_code_budget && cfg.mod_code_bytes * 9 / 4 + 64 <= 96 * 1024) ? (uint32_t)cfg.mod_code_bytes * 5 / 4 + 48 : 0u;
+  const uint32_t lds_tables = kLfDecWaves * kWaveLds + tree_cap * 16 + (redo_only_launch ? 0u : (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes)) + wide_bytes;
   // trees with the weighted predictor: its state rows (channels up to 256 wide — all but the block-info rows) in LDS, one slot per wavefront
   const uint32_t wp_base = cfg.any_wp ? (lds_tables + 15) & ~15u : 0u;
   const uint32_t lds_bytes = wp_base ? wp_base + kLfDecWaves * kWpLdsBytes : lds_tables;
