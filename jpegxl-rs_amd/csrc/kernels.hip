@@ -891,33 +891,54 @@ struct WaveChan {           // per channel (uniform unless noted)
   uint32_t cluster;         // per lane: that cluster
   uint32_t la, cfg_off, cfg_uniform;
 };
+#define SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ int32_t WaveShr1(int32_t v, int32_t lane0) {     // lane i <- lane i - 1 of v; lane 0 <- lane0 (DPP wave_shr:1)
+  return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xF, 0xF, false);
+}
+// The source is written in the order the chain should issue and pinned there (scheduling barriers, empty asm): the alias reads go out first; the
+// context of the sample (k, prediction) and the store of the sample BEFORE are computed in their shadow; the bit buffer is topped up only after
+// bits were taken; N - NW of a whole segment comes from one DPP shift.  tools/microbench/wave_ans.hip times variants of this loop: 148 -> 126 ns
+// per sample against the plain formulation (a lone wavefront issues one instruction per ~2.7 ns, a dependent one per ~4.1 ns: ~38 instructions).
 template <bool NEEDN, bool PROP9, int UPRED>
 __device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int32_t& left, int32_t& nw, const int32_t prevv, int32_t& curv, const int n, const WaveChan& wc) {
   const uint32_t la = wc.la, pmask = (1u << (12 - la)) - 1, lane = threadIdx.x & 63;
+  const uint32_t sh = 12 - la;
   int32_t cur = curv;
+  int32_t dvec = 0;
+  if (NEEDN) { dvec = prevv - WaveShr1(prevv, nw); nw = __builtin_amdgcn_readlane(prevv, 63); }
+  int32_t val_prev = 0; int xl_prev = -1;
   for (int xl = 0; xl < n; xl++) {
+    // [A] alias reads
+    const uint32_t slot = (state & 0xFFF) >> sh;
+    const uint2 e = LdS<uint2>(wc.abase + slot * 8);
+    const uint32_t cr = LdS<uint16_t>(wc.cbase + slot * 2);
+    SB();
+    const uint32_t pos = state & pmask, hi = state >> 12, hp = hi + pos;
+    SB();
+    // [C] the sample before goes to its lane
+    cur = (int)lane == xl_prev ? val_prev : cur;
+    asm volatile("" : "+v"(cur));
+    SB();
+    // [B] context
     const int32_t W = left;
-    int32_t N = W, NW = W;
-    if (NEEDN) { N = __builtin_amdgcn_readlane(prevv, xl); NW = nw; nw = N; }
-    const int32_t v0 = (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW);
+    int32_t N = W, v0 = W;
+    if (NEEDN) { N = __builtin_amdgcn_readlane(prevv, xl); v0 = (int32_t)((uint32_t)W + (uint32_t)__builtin_amdgcn_readlane(dvec, xl)); }
     int k = 0;
     if (PROP9) k = __builtin_popcountll(__ballot(v0 > wc.thr));
     int32_t guess;
     if (UPRED == 0) guess = 0;
     else if (UPRED == 1) guess = W;
-    else { const int32_t m = min(N, W), M = max(N, W); guess = max(m, min(M, v0)); }   // clamped gradient = median(N, W, N + W - NW)
-    // --- ANS: every lane reads the slot of its own interval's cluster
-    const uint32_t slot = (state & 0xFFF) >> (12 - la), pos = state & pmask, hi = state >> 12;
-    const uint2 e = LdS<uint2>(wc.abase + slot * 8);
-    const uint32_t cr = LdS<uint16_t>(wc.cbase + slot * 2);
+    else { const int32_t m = min(N, W), M = max(N, W); guess = max(m, min(M, v0)); }
+    asm volatile("" : "+v"(guess), "+s"(k));
+    SB();
     const bool hit = pos >= (cr & 0xFFu);
     const uint32_t cand = hit ? e.y : e.x;
     const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)cand, k);
-    state = (sw & 0xFFFu) * hi + (hi + pos) + ((sw >> 12) & 0xFFFu);
+    state = (sw & 0xFFFu) * hi + hp + ((sw >> 12) & 0xFFFu);
     int32_t v = (int32_t)sw >> 24;
-    if (state < (1u << 16)) { asm volatile("" ::: "memory"); /* (keeps this a branch: as selects it costs 13 scalar instructions on every sample) */ state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; }
+    SB();
+    if (state < (1u << 16)) { asm volatile("" ::: "memory"); state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
     if (__builtin_expect(v == kWideEscape, 0)) {
-      // the token carries extra bits (or is too large for the table's byte): the symbol again from this lane's {cutoff, aliased symbol}, then dec_ans.h's hybrid integer
       const uint32_t crk = (uint32_t)__builtin_amdgcn_readlane((int)cr, k);
       uint32_t tok = pos >= (crk & 0xFFu) ? (crk >> 8) : slot;
       uint32_t cfg = wc.cfg_uniform;
@@ -933,16 +954,17 @@ __device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int
         bits.buf >>= nbits; bits.avail -= (int)nbits;
         const uint32_t hb = (1u << msb) | (tok & ((1u << msb) - 1));
         tok = (((hb << nbits) | xb) << lsb) | low;
+        bits.Refill();
       }
       v = UnpackSigned(tok);
     }
     const int32_t val = (int32_t)((uint32_t)v + (uint32_t)guess);
-    cur = (int)lane == xl ? val : cur;      // (v_writelane would need its value in a scalar register and its lane select in M0 on gfx9: three instructions against these two)
-    left = val;
-    bits.Refill();
+    left = val; val_prev = val; xl_prev = xl;
   }
+  cur = (int)lane == xl_prev ? val_prev : cur;
   curv = cur;
 }
+#undef SB
 // All 64 lanes.  `upred`, `prop`, `subroot` as DecodeChannelCoop found them; ni inner nodes of the channel's subtree, their constants at thr_off.
 __device__ __forceinline__ void DecodeChannelWave(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, int upred_in, int prop_in, uint32_t subroot_in, uint32_t ni_in, uint32_t thr_off_in) {
   const uint32_t lane = threadIdx.x & 63;
