@@ -1036,10 +1036,208 @@ __device__ __forceinline__ void DecodeChannelWave(BitReaderP& br, uint32_t& stat
   WaveSync();
 }
 
+// ---- wave-wide decode of a channel under a weighted-predictor tree (round 6): the MA-tree shape of a default-effort cjxl encode's LF coefficients (enc_modular.cc
+// "WP fixed DC": every split tests property 15 — the largest neighbouring error of the weighted predictor —, every leaf predicts with it).  The entropy chain is
+// DecodeChannelWave's (lanes = intervals of the property, alias slots of all clusters in one LDS round trip); the predictor (context_predict.h weighted::State,
+// jxl_dev.h WPState) is spread over the lanes of every quad: lane q of a quad owns sub-predictor q — its error sums (one LDS read per sample: the stored error at
+// x + 1 of the row above; the additions of the reference's "+= error at x + 1" live in register carries), its weight (division table in LDS), its prediction (a
+// per-lane linear form of the neighbours and true errors) — and the sums over the four are DPP quad permutes.  True errors and samples of the rows above sit in
+// VGPRs, one per lane, like DecodeChannelWave's rows.  32-bit arithmetic (exact while |sample| <= 4095, as WPStateLds::PredictT<int32_t>): the first larger sample
+// ends the attempt and the caller decodes the channel again the general way.  Rows up to 256 samples.
+struct WaveWpLane { int32_t kW, kNE, kN, cW, cN, cNE, cNW, cNN, cNWW; uint32_t wmax; };
+__device__ __forceinline__ int32_t QuadSumI(int32_t v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+  return v;
+}
+__device__ __forceinline__ int32_t WaveShl1(int32_t v, int32_t lane63) {    // lane i <- lane i + 1 of v; lane 63 <- lane63 (DPP wave_shl:1)
+  return __builtin_amdgcn_update_dpp(lane63, v, 0x130, 0xF, 0xF, false);
+}
+struct WaveWpRow {          // carries of one row (uniform unless noted)
+  int32_t left, Nprev, teW, teNprev;
+  int32_t e0prev, aprev, e1x;          // per lane (sub-predictor lane & 3): error of the sample before, A of the sample before, stored error of the row above at x
+  int32_t toobig;
+};
+template <bool ROW0, bool LAST>
+__device__ __forceinline__ void WaveWpSample(WaveBits& bits, uint32_t& state, WaveWpRow& r, const int xl, const uint32_t x, const int32_t p1v, const int32_t p1s, const int32_t p2v, const int32_t te1v, const int32_t te1s,
+                                            int32_t& curv, int32_t& tecur, const uint32_t e1, const uint32_t e0, const uint32_t div_off, const WaveWpLane& L, const WaveChan& wc) {
+  const uint32_t la = wc.la, pmask = (1u << (12 - la)) - 1, lane = threadIdx.x & 63;
+  // --- alias reads
+  const uint32_t slot = (state & 0xFFF) >> (12 - la);
+  const uint2 e = LdS<uint2>(wc.abase + slot * 8);
+  const uint32_t cr = LdS<uint16_t>(wc.cbase + slot * 2);
+  const uint32_t pos = state & pmask, hi = state >> 12, hp = hi + pos;
+  // --- neighbours and true errors
+  const int32_t W = r.left;
+  int32_t N = W, NE = W, NW = W, NN = W, teN = 0, teNE = 0, teNW = 0;
+  if (!ROW0) {
+    N = __builtin_amdgcn_readlane(p1v, xl); NE = LAST ? N : __builtin_amdgcn_readlane(p1s, xl); NW = r.Nprev; NN = __builtin_amdgcn_readlane(p2v, xl);
+    teN = __builtin_amdgcn_readlane(te1v, xl); teNE = LAST ? teN : __builtin_amdgcn_readlane(te1s, xl); teNW = r.teNprev;
+  }
+  const int32_t teW = r.teW;
+  const int32_t W8 = W * 8, N8 = N * 8, NE8 = NE * 8, NW8 = NW * 8, NN8 = NN * 8;
+  // --- error sums of this lane's sub-predictor: A (at N, includes the error of W), B (at NW = the A of the sample before), C (at NE)
+  const int32_t A = r.e1x + r.e0prev;
+  const int32_t C = LAST ? A : LdS<int32_t>(e1 + 4 * (x + 1));
+  const uint32_t sum = (uint32_t)A + (uint32_t)r.aprev + (uint32_t)C;
+  int shift = 26 - __clz((int)(sum + 1));          // floor(log2(sum + 1)) - 5
+  if (shift < 0) shift = 0;
+  const uint32_t quot = LdS<uint32_t>(div_off + 4 * (sum >> shift));
+  uint32_t wgt = 4 + ((L.wmax * quot) >> shift);
+  const uint32_t wsum = (uint32_t)QuadSumI((int32_t)wgt);
+  wgt >>= (27 - __clz((int)wsum));                 // floor(log2(wsum)) - 4
+  const uint32_t wsum2 = (uint32_t)QuadSumI((int32_t)wgt);
+  const uint32_t inv = LdS<uint32_t>(div_off + 4 * (wsum2 - 1));
+  // --- this lane's sub-prediction
+  const int32_t lin = L.cW * teW + L.cN * teN + L.cNE * teNE + L.cNW * teNW + L.cNN * (NN8 - N8) + L.cNWW * (NW8 - W8);
+  const int32_t predi = L.kW * W8 + L.kNE * NE8 + L.kN * N8 - (lin >> 5);
+  const int32_t sump = QuadSumI(predi * (int32_t)wgt) + (int32_t)(wsum2 >> 1) - 1;
+  int32_t pred = (int32_t)(((int64_t)sump * (int64_t)inv) >> 24);
+  if (!(((teN ^ teW) | (teN ^ teNW)) > 0)) {
+    const int32_t mx = max(W8, max(NE8, N8)), mn = min(W8, min(NE8, N8));
+    pred = max(mn, min(mx, pred));
+  }
+  // --- property 15: the true error of largest magnitude among W, N, NW, NE (the first of equals)
+  int32_t perr = teW;
+  if (abs(teN) > abs(perr)) perr = teN;
+  if (abs(teNW) > abs(perr)) perr = teNW;
+  if (abs(teNE) > abs(perr)) perr = teNE;
+  const int k = __builtin_popcountll(__ballot(perr > wc.thr));
+  const int32_t guess = (pred + 3) >> 3;
+  // --- ANS symbol
+  const bool hit = pos >= (cr & 0xFFu);
+  const uint32_t cand = hit ? e.y : e.x;
+  const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)cand, k);
+  state = (sw & 0xFFFu) * hi + hp + ((sw >> 12) & 0xFFFu);
+  int32_t v = (int32_t)sw >> 24;
+  if (state < (1u << 16)) { asm volatile("" ::: "memory"); state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
+  if (__builtin_expect(v == kWideEscape, 0)) {
+    const uint32_t crk = (uint32_t)__builtin_amdgcn_readlane((int)cr, k);
+    uint32_t tok = pos >= (crk & 0xFFu) ? (crk >> 8) : slot;
+    uint32_t cfg = wc.cfg_uniform;
+    if (cfg == 0xFFFFFFFFu) cfg = Uniform(LdS<uint32_t>(wc.cfg_off + 4 * (uint32_t)__builtin_amdgcn_readlane((int)wc.cluster, k)));
+    const uint32_t split_exp = cfg & 0xFF, split = 1u << split_exp;
+    if (tok >= split) {
+      const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+      const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb))) & 31;
+      const uint32_t low = tok & ((1u << lsb) - 1);
+      tok >>= lsb;
+      if ((int)nbits > bits.avail) bits.Refill();
+      const uint32_t xb = (uint32_t)(bits.buf & ((1ull << nbits) - 1));
+      bits.buf >>= nbits; bits.avail -= (int)nbits;
+      const uint32_t hb = (1u << msb) | (tok & ((1u << msb) - 1));
+      tok = (((hb << nbits) | xb) << lsb) | low;
+      bits.Refill();
+    }
+    v = UnpackSigned(tok);
+  }
+  const int32_t val = (int32_t)((uint32_t)v + (uint32_t)guess);
+  if ((uint32_t)(val + 4095) > 8190u) r.toobig = 1;
+  // --- the sample's errors: magnitudes per sub-predictor (stored for the row below, carried for the sample to the right), true error
+  const int32_t v8 = val * 8;
+  const int32_t err = (abs(predi - v8) + 3) >> 3;
+  StS<int32_t>(e0 + 4 * x, err);
+  const int32_t te = pred - v8;
+  curv = (int)lane == xl ? val : curv;
+  tecur = (int)lane == xl ? te : tecur;
+  r.left = val; r.Nprev = N; r.teW = te; r.teNprev = teN; r.e0prev = err; r.aprev = A; r.e1x = C;
+}
+// All 64 lanes.  false: a sample beyond +-4095 (nothing of `br` / `state_io` was touched: the caller decodes the channel again the general way).
+__device__ __forceinline__ bool DecodeChannelWaveWp(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, const WPHeader& hdr, uint32_t subroot_in, uint32_t ni_in, uint32_t thr_off_in) {
+  const uint32_t lane = threadIdx.x & 63;
+  const int w = (int)Uniform((uint32_t)ch.w), h = (int)Uniform((uint32_t)ch.h);
+  const uint32_t subroot = Uniform(subroot_in), ni = Uniform(ni_in), thr_off = Uniform(thr_off_in);
+  WaveChan wc;
+  wc.la = Uniform(T.code.log_alpha); wc.cfg_off = Uniform(T.code.cfg_off); wc.cfg_uniform = Uniform(T.code.cfg_uniform);
+  const uint32_t wide_off = Uniform(T.code.wide_off), cut_off = Uniform(T.code.cut_off);
+  {
+    const int32_t t = lane < ni ? LdS<int32_t>(thr_off + 4 * lane) : 0x7FFFFFFF;
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < ni; i++) { const int32_t ti = __builtin_amdgcn_readlane(t, (int)i); rank += (ti < t || (ti == t && i < lane)) ? 1u : 0u; }
+    const uint32_t sorted_off = thr_off + 256;
+    if (lane < ni) StS<int32_t>(sorted_off + 4 * rank, t);
+    WaveSync();
+    const uint32_t kk = min(lane, ni);
+    const int32_t rep = ni == 0 ? 0 : (kk == 0 ? LdS<int32_t>(sorted_off) : (int32_t)((uint32_t)LdS<int32_t>(sorted_off + 4 * (kk - 1)) + 1u));
+    wc.cluster = WalkCluster(T.node_base, subroot, rep);
+    wc.thr = t;
+    WaveSync();
+  }
+  wc.abase = wide_off + ((wc.cluster << wc.la) << 3); wc.cbase = cut_off + ((wc.cluster << wc.la) << 1);
+  // weighted-predictor state: WPStateLds' layout (error rows of sub-predictor i at array 1 + i, two rows of w + 2 ints each), zeroed; the division table behind it
+  const uint32_t wp_base = Uniform(T.wp_off), div_off = wp_base + kWpLdsBytes - 256;
+  for (uint32_t i = lane; i < WPStateLds::Bytes(w) / 4; i += 64) StS<int32_t>(wp_base + i * 4, 0);
+  StS<uint32_t>(div_off + lane * 4, (1u << 24) / (lane + 1));
+  WaveSync();
+  const uint32_t q = lane & 3, rowb = (uint32_t)(w + 2) * 4;
+  const uint32_t erows = wp_base + (1 + q) * rowb * 2;
+  WaveWpLane L;
+  {
+    const int32_t p1 = hdr.p1, p2 = hdr.p2;
+    L.kW = q == 0 || q == 2 ? 1 : 0; L.kNE = q == 0 ? 1 : 0; L.kN = q == 0 ? -1 : (q == 2 ? 0 : 1);
+    L.cW = q == 1 ? p1 : (q == 2 ? p2 : 0);
+    L.cN = q == 1 ? p1 : (q == 2 ? p2 : (q == 3 ? hdr.p3[1] : 0));
+    L.cNE = q == 1 ? p1 : (q == 3 ? hdr.p3[2] : 0);
+    L.cNW = q == 2 ? p2 : (q == 3 ? hdr.p3[0] : 0);
+    L.cNN = q == 3 ? hdr.p3[3] : 0;
+    L.cNWW = q == 3 ? hdr.p3[4] : 0;
+    L.wmax = (uint32_t)hdr.w[q];
+  }
+  uint32_t state = Uniform(state_io);
+  const uint64_t bp = br.BitPos();
+  const uint64_t bp0 = ((uint64_t)Uniform((uint32_t)(bp >> 32)) << 32) | Uniform((uint32_t)bp);
+  WaveBits bits;
+  bits.Start(br.words, Uniform(br.wend), bp0, lane);
+  int32_t p1r[4] = {0, 0, 0, 0}, p2r[4] = {0, 0, 0, 0}, t1r[4] = {0, 0, 0, 0};     // samples of the row above / two above, true errors of the row above
+  WaveWpRow r;
+  r.toobig = 0;
+  const int nseg = (w + 63) >> 6;
+  for (int y = 0; y < h && !r.toobig; y++) {
+    int32_t* p = ch.data + (size_t)y * ch.stride;
+    const uint32_t e0 = erows + (uint32_t)(y & 1) * rowb, e1 = erows + (uint32_t)((y & 1) ^ 1) * rowb;
+    r.left = y ? __builtin_amdgcn_readlane(p1r[0], 0) : 0;
+    r.Nprev = r.left; r.teW = 0; r.teNprev = y ? __builtin_amdgcn_readlane(t1r[0], 0) : 0;
+    r.e0prev = 0; r.e1x = LdS<int32_t>(e1); r.aprev = r.e1x;
+    int32_t c[4] = {0, 0, 0, 0}, tc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int seg = 0; seg < 4; seg++) {
+      if (seg < nseg) {
+        const int x0 = seg * 64, n = min(64, w - x0);
+        const bool last_seg = seg == nseg - 1;
+        const int32_t nextp = seg < 3 ? __builtin_amdgcn_readlane(p1r[seg < 3 ? seg + 1 : 3], 0) : 0, nextt = seg < 3 ? __builtin_amdgcn_readlane(t1r[seg < 3 ? seg + 1 : 3], 0) : 0;
+        const int32_t p1s = WaveShl1(p1r[seg], nextp), te1s = WaveShl1(t1r[seg], nextt);
+        int32_t curv = 0, tecur = 0;
+        const int nn = last_seg ? n - 1 : n;
+        if (y == 0) {
+          for (int xl = 0; xl < nn; xl++) WaveWpSample<true, false>(bits, state, r, xl, (uint32_t)(x0 + xl), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
+          if (last_seg) WaveWpSample<true, true>(bits, state, r, nn, (uint32_t)(x0 + nn), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
+        } else {
+          for (int xl = 0; xl < nn; xl++) WaveWpSample<false, false>(bits, state, r, xl, (uint32_t)(x0 + xl), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
+          if (last_seg) WaveWpSample<false, true>(bits, state, r, nn, (uint32_t)(x0 + nn), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
+        }
+        if ((int)lane < n) StG(p + x0 + (int)lane, curv);
+        c[seg] = curv; tc[seg] = tecur;
+      }
+    }
+#pragma unroll
+    for (int seg = 0; seg < 4; seg++) { p2r[seg] = y == 0 ? c[seg] : p1r[seg]; p1r[seg] = c[seg]; t1r[seg] = tc[seg]; }
+    WaveSync();      // (this row's error stores before the next row's reads)
+  }
+  if (r.toobig) { WaveSync(); return false; }
+  state_io = state;
+  const uint64_t endpos = bits.BitPos();
+  br.Init(reinterpret_cast<const uint8_t*>(br.words), endpos, (uint64_t)br.wend * 4);
+  WaveSync();
+  return true;
+}
+
 // BALLOT: general trees are evaluated by the whole wavefront (see the "ballot" path below) — the Modular kernels; the LF kernel
 // of the VarDCT path keeps the single-lane loops (register budget).
 template <bool BALLOT = false>
-__device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T_in, const ModularCtx& mc, const ChannelDesc& ch, int chan) {
+__device__ __noinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T_in, const ModularCtx& mc_in, const ChannelDesc& ch_in, int chan) {
+  // (a real call since round 6 — inlined six times over, LfDecodeKernel was 85 000 instructions and three minutes of compile time: the arguments into registers once)
+  const ModularCtx mc = mc_in;
+  const ChannelDesc ch = ch_in;
   if (ch.w == 0 || ch.h == 0) return;
   const uint32_t lane = threadIdx.x & 63, wb = T_in.wb;
   ModTables T = T_in;
@@ -1132,6 +1330,25 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
       }
     }
     StS<int>(wb + kWorkOff + 56, sub_wp);
+    // the wave-wide weighted-predictor decoder's tree shape: every split on property 15, every leaf (predictor 6, offset 0, multiplier 1), at most 63 splits
+    int wpw = 0;
+    uint32_t wni = 0;
+    if (mc.uses_wp && mode == 0 && sub_wp) {
+      int visited = 0;
+      wpw = 1; sp = 0;
+      StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)pos);
+      while (sp > 0 && wpw) {
+        const TreeNode m = T.Node((uint32_t)LdS<int>(wb + kWorkOff + 64 + 4 * --sp));
+        if (++visited > 130) { wpw = 0; break; }
+        if (m.prop < 0) { if ((m.a & 0xFF) != 6 || m.val != 0 || m.b != 1) wpw = 0; continue; }
+        if (m.prop != 15 || sp + 2 > 200) { wpw = 0; break; }
+        if (wni < 64) StS<int32_t>(wb + kLutOff + 4 * wni, m.val);
+        wni++;
+        StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.a); StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.b);
+      }
+      if (wni > 63) wpw = 0;
+    }
+    StS<int>(wb + kLutOff + 512, wpw); StS<uint32_t>(wb + kLutOff + 516, wni);
     StS<int>(wb + kWorkOff + 0, mode); StS<int>(wb + kWorkOff + 4, prop); StS<int>(wb + kWorkOff + 8, (int)pos); StS<int>(wb + kWorkOff + 12, upred);
     StS<int>(wb + kWorkOff + 20, wide);
     StS<uint32_t>(wb + kWorkOff + 60, ni);
@@ -1252,6 +1469,11 @@ __device__ __forceinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& stat
     return;
   }
   WPStateLds wpl;
+#ifndef JXL_NO_WAVE_LF
+  if (wp_in_lds && !mc.slow && T.tree_in_lds && T.code.wide_off != kNotInLds && LdS<int>(wb + kLutOff + 512)) {
+    if (DecodeChannelWaveWp(br, state, T, ch, mc.wp, subroot, LdS<uint32_t>(wb + kLutOff + 516), wb + kLutOff)) return;
+  }
+#endif
   if (wp_in_lds) { wpl.Init(T.wp_off, T.wp_off + kWpLdsBytes - 256, ch.w, lane, mc.narrow_wp != 0); WaveSync(); }
   // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
   // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
