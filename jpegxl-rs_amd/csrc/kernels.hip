@@ -842,20 +842,22 @@ __device__ __forceinline__ void DecodeRowsBallot(BitReaderP& br, uint32_t& state
   WaveSync();
 }
 
-// ---- wave-wide decode of a channel under a single-property tree (round 6) -------------------------------------------------------------------
+// ---- wave-wide decode of a channel under a small MA tree (round 6) ---------------------------------------------------------------------------
 // The serial fast path above runs the chain on lane 0: per sample two dependent LDS round trips (property -> cluster table, cluster -> alias slot)
 // and ~50 instructions, 0.25 us.  A lone wavefront issues a dependent instruction every ~4 ns whatever the number of active lanes
 // (tools/microbench/chain_ops.hip), so here ALL lanes run the chain and the lanes are spent on speculation instead:
-//  * the channel's subtree tests one property (W + N - NW) against at most 63 constants: lane j keeps constant j, one compare + ballot + popcount gives
-//    the index k of the interval the property value falls in — no table read;
-//  * lane k owns interval k: as soon as the ANS state of the sample is known it reads the alias slot OF ITS INTERVAL'S CLUSTER (StageCode's wide layout:
+//  * lane j keeps the constant of inner node j of the channel's subtree (static splits — channel, stream, and per row the row index — resolved):
+//    one compare + ballot gives every decision of the tree; with one property under test the leaf is the number of constants below the value
+//    (popcount), with two the leaf lane whose path agrees with the decisions (one AND + compare per lane, ballot, find-first) — no table read;
+//  * lane k owns leaf k: as soon as the ANS state of the sample is known it reads the alias slot OF ITS LEAF'S CLUSTER (StageCode's wide layout:
 //    both candidates ready-made, the signed value of a complete token precomputed) — every cluster's slot in one LDS round trip, while the scalar
 //    unit works out k from the sample before; `v_readlane` with k picks the winner;
 //  * everything that is the same for all lanes (ANS state, bit buffer, neighbours, prediction) stays in scalar registers; the bit stream sits in a
-//    VGPR, one 32-bit word per lane (a 2048-bit window, the next one already loaded), the row above and the row being decoded in VGPRs, one sample
-//    per lane (`v_readlane` / `v_writelane`): no LDS or memory access on the chain but the alias read, rows leave as coalesced 256-byte stores.
-// Semantics: DecodeChunkLds / jxl_dev.h DecodeModularChannel.  Channels: leaves (predictor zero / W / clamped gradient, offset 0, multiplier 1), no
-// property or the row (one cluster per row) or W + N - NW; rows up to 256 samples when the row above is needed, any width otherwise.
+//    VGPR, one 32-bit word per lane (a 2048-bit window), the row above and the row being decoded in VGPRs, one sample per lane (`v_readlane`,
+//    a compare + select for the store): no LDS or memory access on the chain but the alias read, rows leave as coalesced 256-byte stores.
+// Semantics: DecodeChunkLds / jxl_dev.h DecodeModularChannel.  Channels: leaves (predictor zero / W / clamped gradient, offset 0, multiplier 1), splits
+// on the row (static per row) and on at most two of {x, N, W, W + N - NW, W - NW, NW - N}; rows up to 256 samples when the row above is needed, any
+// width otherwise; at most 63 splits per row (32 with two properties), 64 leaves.
 struct WaveBits {           // uniform state; `win`: this lane's word of the current 64-word window
   const uint32_t* words;
   uint32_t wend, wbase, widx;      // window = words [wbase, wbase + 64); widx: the next word to take, relative to wbase
@@ -885,27 +887,33 @@ struct WaveBits {           // uniform state; `win`: this lane's word of the cur
   }
   __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)(wbase + widx) * 32 - (uint64_t)avail; }
 };
-struct WaveChan {           // per channel (uniform unless noted)
+struct WaveChan {           // per row class (uniform unless noted)
   int32_t thr;              // per lane: split constant of this lane's inner node (INT_MAX beyond the last)
-  uint32_t abase, cbase;    // per lane: LDS byte offsets of the wide table / cutoff table of this lane's interval's cluster
+  bool psel;                // per lane: that node tests the second property
+  uint32_t lmask, lwant;    // per lane (two properties): the inner nodes on the path to this lane's leaf / the decisions taken there
+  uint32_t abase, cbase;    // per lane: LDS byte offsets of the wide table / cutoff table of this lane's leaf's cluster
   uint32_t cluster;         // per lane: that cluster
+  bool is1, is5;            // per lane: this lane's leaf predicts with W / with the clamped gradient (UPRED -2)
+  int32_t am0, am1;         // property value = (W & am) + this segment's vector at x
   uint32_t la, cfg_off, cfg_uniform;
 };
 #define SB() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ int32_t WaveShr1(int32_t v, int32_t lane0) {     // lane i <- lane i - 1 of v; lane 0 <- lane0 (DPP wave_shr:1)
   return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xF, 0xF, false);
 }
+// MODE 0: one leaf; 1: one property (leaf = number of constants below the value); 2: two properties (leaf = the lane whose path matches).  UPRED: the
+// predictor of every leaf (0 zero, 1 W, 5 clamped gradient) or -2: per leaf.  NEEDN: the row above exists (else N = NW = W).  vec0 / vec1: the part of
+// the property values that does not depend on W, for the 64 samples of this segment; dvec: N - NW likewise; V0GRAD: vec0 is dvec and am0 all ones (the
+// property is W + N - NW: the gradient predictor reuses it).
 // The source is written in the order the chain should issue and pinned there (scheduling barriers, empty asm): the alias reads go out first; the
-// context of the sample (k, prediction) and the store of the sample BEFORE are computed in their shadow; the bit buffer is topped up only after
-// bits were taken; N - NW of a whole segment comes from one DPP shift.  tools/microbench/wave_ans.hip times variants of this loop: 148 -> 126 ns
-// per sample against the plain formulation (a lone wavefront issues one instruction per ~2.7 ns, a dependent one per ~4.1 ns: ~38 instructions).
-template <bool NEEDN, bool PROP9, int UPRED>
-__device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int32_t& left, int32_t& nw, const int32_t prevv, int32_t& curv, const int n, const WaveChan& wc) {
+// context of the sample (leaf, prediction) and the store of the sample BEFORE are computed in their shadow; the bit buffer is topped up only after
+// bits were taken.  tools/microbench/wave_ans.hip times variants of this loop: 148 -> 126 ns per sample against the plain formulation (a lone
+// wavefront issues one instruction per ~2.7 ns, a dependent one per ~4.1 ns: ~38 instructions).
+template <int MODE, bool NEEDN, int UPRED, bool V0GRAD>
+__device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int32_t& left, const int32_t prevv, const int32_t dvec, const int32_t vec0, const int32_t vec1, int32_t& curv, const int n, const WaveChan& wc) {
   const uint32_t la = wc.la, pmask = (1u << (12 - la)) - 1, lane = threadIdx.x & 63;
   const uint32_t sh = 12 - la;
   int32_t cur = curv;
-  int32_t dvec = 0;
-  if (NEEDN) { dvec = prevv - WaveShr1(prevv, nw); nw = __builtin_amdgcn_readlane(prevv, 63); }
   int32_t val_prev = 0; int xl_prev = -1;
   for (int xl = 0; xl < n; xl++) {
     // [A] alias reads
@@ -921,15 +929,29 @@ __device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int
     SB();
     // [B] context
     const int32_t W = left;
-    int32_t N = W, v0 = W;
-    if (NEEDN) { N = __builtin_amdgcn_readlane(prevv, xl); v0 = (int32_t)((uint32_t)W + (uint32_t)__builtin_amdgcn_readlane(dvec, xl)); }
     int k = 0;
-    if (PROP9) k = __builtin_popcountll(__ballot(v0 > wc.thr));
+    int32_t v0 = 0;
+    if (MODE >= 1) v0 = V0GRAD ? (int32_t)((uint32_t)W + (uint32_t)__builtin_amdgcn_readlane(vec0, xl)) : (int32_t)((uint32_t)(W & wc.am0) + (uint32_t)__builtin_amdgcn_readlane(vec0, xl));
+    if (MODE == 1) k = __builtin_popcountll(__ballot(v0 > wc.thr));
+    if (MODE == 2) {
+      const int32_t v1 = (int32_t)((uint32_t)(W & wc.am1) + (uint32_t)__builtin_amdgcn_readlane(vec1, xl));
+      const uint32_t d = (uint32_t)__ballot((wc.psel ? v1 : v0) > wc.thr);
+      k = __builtin_ctzll(__ballot((d & wc.lmask) == wc.lwant) | (1ull << 63));
+    }
+    int32_t grad = W;
+    if (NEEDN && (UPRED == 5 || UPRED == -2)) {      // clamped gradient = median(N, W, W + N - NW)
+      const int32_t N = __builtin_amdgcn_readlane(prevv, xl);
+      const int32_t g0 = V0GRAD ? v0 : (int32_t)((uint32_t)W + (uint32_t)__builtin_amdgcn_readlane(dvec, xl));
+      const int32_t m = min(N, W), M = max(N, W);
+      grad = max(m, min(M, g0));
+    }
     int32_t guess;
     if (UPRED == 0) guess = 0;
     else if (UPRED == 1) guess = W;
-    else { const int32_t m = min(N, W), M = max(N, W); guess = max(m, min(M, v0)); }
-    asm volatile("" : "+v"(guess), "+s"(k));
+    else if (UPRED == 5) guess = grad;
+    else guess = __builtin_amdgcn_readlane(wc.is1 ? W : (wc.is5 ? grad : 0), k);
+    if (UPRED == -2) asm volatile("" : "+s"(guess)); else if (UPRED != 0) asm volatile("" : "+v"(guess));
+    if (MODE >= 1) asm volatile("" : "+s"(k));
     SB();
     const bool hit = pos >= (cr & 0xFFu);
     const uint32_t cand = hit ? e.y : e.x;
@@ -937,8 +959,9 @@ __device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int
     state = (sw & 0xFFFu) * hi + hp + ((sw >> 12) & 0xFFFu);
     int32_t v = (int32_t)sw >> 24;
     SB();
-    if (state < (1u << 16)) { asm volatile("" ::: "memory"); state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
+    if (state < (1u << 16)) { asm volatile("" ::: "memory"); /* (keeps this a branch: as selects it costs 13 scalar instructions on every sample) */ state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
     if (__builtin_expect(v == kWideEscape, 0)) {
+      // the token carries extra bits (or is too large for the table's byte): the symbol again from this lane's {cutoff, aliased symbol}, then dec_ans.h's hybrid integer
       const uint32_t crk = (uint32_t)__builtin_amdgcn_readlane((int)cr, k);
       uint32_t tok = pos >= (crk & 0xFFu) ? (crk >> 8) : slot;
       uint32_t cfg = wc.cfg_uniform;
@@ -965,64 +988,155 @@ __device__ __forceinline__ void WaveSegment(WaveBits& bits, uint32_t& state, int
   curv = cur;
 }
 #undef SB
-// All 64 lanes.  `upred`, `prop`, `subroot` as DecodeChannelCoop found them; ni inner nodes of the channel's subtree, their constants at thr_off.
-__device__ __forceinline__ void DecodeChannelWave(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, int upred_in, int prop_in, uint32_t subroot_in, uint32_t ni_in, uint32_t thr_off_in) {
-  const uint32_t lane = threadIdx.x & 63;
+// The channel's subtree as the wave-wide decoder wants it.  Lane 0 walks it depth first from `subroot` with the static properties resolved — channel (0), stream (1) and,
+// unless `explore`, the row (2) — and writes into the wavefront's LUT region: per inner node its constant and which of the (at most two) dynamic properties it tests, per
+// leaf the nodes on its path, the decisions taken there and the leaf's {predictor, cluster} word; then the header.  explore: both sides of every row split are visited and
+// nothing is recorded but the header — an upper bound for every row, used once per channel to decide whether the wave-wide decoder takes it at all.
+constexpr uint32_t kWaThr = 0, kWaSorted = 256, kWaPsel = 512, kWaMask = 768, kWaWant = 1024, kWaLeaf = 1280, kWaHdr = 1536;   // byte offsets in the LUT region; header: ok, ni, nl, nprops, prop0, prop1, has_y, upred, need_n
+__device__ __forceinline__ bool WaveDynProp(int p) { return p == 3 || p == 6 || p == 7 || p == 9 || p == 10 || p == 11; }
+__device__ void WaveAnalyse(const ModTables& T, uint32_t subroot, int chan, int32_t stream_id, int y, bool explore) {
+  const uint32_t wb = T.wb, L = wb + kLutOff, stack = wb + kWorkOff + 64;
+  int ok = 1, has_y = 0, upred = -1, need_n = 0, props[2] = {-1, -1};
+  uint32_t ni = 0, nl = 0, np = 0, visited = 0;
+  int sp = 0;
+  StS<uint32_t>(stack, subroot); StS<uint32_t>(stack + 4, 0u); StS<uint32_t>(stack + 8, 0u); sp = 1;
+  while (sp > 0 && ok) {
+    sp--;
+    uint32_t pos = LdS<uint32_t>(stack + 12 * sp);
+    const uint32_t mask = LdS<uint32_t>(stack + 12 * sp + 4), want = LdS<uint32_t>(stack + 12 * sp + 8);
+    TreeNode n = T.Node(pos);
+    bool fork_y = false;
+    while (n.prop == 0 || n.prop == 1 || n.prop == 2) {
+      if (++visited > 400) { ok = 0; break; }
+      if (n.prop == 2) { has_y = 1; if (explore) { fork_y = true; break; } }
+      const int32_t v = n.prop == 0 ? chan : (n.prop == 1 ? stream_id : y);
+      pos = v > n.val ? n.a : n.b;
+      n = T.Node(pos);
+    }
+    if (!ok || ++visited > 400) { ok = 0; break; }
+    if (fork_y) {
+      if (sp + 2 > 60) { ok = 0; break; }
+      StS<uint32_t>(stack + 12 * sp, n.a); StS<uint32_t>(stack + 12 * sp + 4, mask); StS<uint32_t>(stack + 12 * sp + 8, want); sp++;
+      StS<uint32_t>(stack + 12 * sp, n.b); StS<uint32_t>(stack + 12 * sp + 4, mask); StS<uint32_t>(stack + 12 * sp + 8, want); sp++;
+      continue;
+    }
+    if (n.prop < 0) {
+      const int pr = (int)(n.a & 0xFF);
+      if ((pr != 0 && pr != 1 && pr != 5) || n.val != 0 || n.b != 1 || nl >= 64) { ok = 0; break; }
+      if (pr == 5) need_n = 1;
+      if (upred == -1) upred = pr; else if (upred != pr) upred = -2;
+      if (!explore) { StS<uint32_t>(L + kWaMask + 4 * nl, mask); StS<uint32_t>(L + kWaWant + 4 * nl, want); StS<uint32_t>(L + kWaLeaf + 4 * nl, n.a); }
+      nl++;
+      continue;
+    }
+    if (!WaveDynProp(n.prop) || ni >= 63 || sp + 2 > 60) { ok = 0; break; }
+    if (n.prop != 3 && n.prop != 7) need_n = 1;
+    uint32_t sel = 0;
+    if (props[0] == n.prop || props[0] < 0) { props[0] = n.prop; sel = 0; if (np < 1) np = 1; }
+    else if (props[1] == n.prop || props[1] < 0) { props[1] = n.prop; sel = 1; np = 2; }
+    else { ok = 0; break; }
+    const uint32_t j = ni++;
+    if (!explore) { StS<int32_t>(L + kWaThr + 4 * j, n.val); StS<uint32_t>(L + kWaPsel + 4 * j, sel); }
+    const uint32_t bit = j < 32 ? 1u << j : 0u;
+    StS<uint32_t>(stack + 12 * sp, n.b); StS<uint32_t>(stack + 12 * sp + 4, mask | bit); StS<uint32_t>(stack + 12 * sp + 8, want); sp++;
+    StS<uint32_t>(stack + 12 * sp, n.a); StS<uint32_t>(stack + 12 * sp + 4, mask | bit); StS<uint32_t>(stack + 12 * sp + 8, want | bit); sp++;
+  }
+  if (np == 2 && ni > 32) ok = 0;
+  StS<int>(L + kWaHdr + 0, ok); StS<uint32_t>(L + kWaHdr + 4, ni); StS<uint32_t>(L + kWaHdr + 8, nl); StS<uint32_t>(L + kWaHdr + 12, np);
+  StS<int>(L + kWaHdr + 16, props[0]); StS<int>(L + kWaHdr + 20, props[1]); StS<int>(L + kWaHdr + 24, has_y); StS<int>(L + kWaHdr + 28, upred); StS<int>(L + kWaHdr + 32, need_n);
+}
+// the leaf word {predictor, cluster << 8} that property value v reaches in a one-property subtree (static properties resolved on the way)
+__device__ __forceinline__ uint32_t WaveWalkLeaf(const ModTables& T, uint32_t pos, int chan, int32_t stream_id, int y, int32_t v) {
+  TreeNode n = T.Node(pos);
+  for (int guard = 0; n.prop >= 0 && guard < 400; guard++) {
+    const int32_t pv = n.prop == 0 ? chan : (n.prop == 1 ? stream_id : (n.prop == 2 ? y : v));
+    n = T.Node(pv > n.val ? n.a : n.b);
+  }
+  return n.a;
+}
+// the part of property p that does not depend on W, for the 64 samples of a segment (lane = sample), and the mask W enters with; rows: the row above exists
+__device__ __forceinline__ int32_t WavePropVec(int p, bool rows, int x0, uint32_t lane, int32_t prevv, int32_t shv, int32_t dvec, int32_t* am) {
+  *am = (p == 7 || p == 9 || (p == 10 && rows) || (p == 6 && !rows)) ? -1 : 0;
+  if (p == 3) return x0 + (int)lane;
+  if (!rows) return 0;
+  return p == 6 ? prevv : p == 9 ? dvec : p == 10 ? (int32_t)(0u - (uint32_t)shv) : p == 11 ? (int32_t)(0u - (uint32_t)dvec) : 0;
+}
+// All 64 lanes; WaveAnalyse(explore) said yes.  need_n: some row needs the row above (the caller checked the width).
+__device__ void DecodeChannelWave(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, uint32_t subroot_in, int chan_in, int32_t stream_in, bool has_y_in) {
+  const uint32_t lane = threadIdx.x & 63, wb = T.wb, L = wb + kLutOff;
   // (everything that steers control flow into scalar registers: the compiler has to see the loops below as uniform to keep the chain there)
-  const int w = (int)Uniform((uint32_t)ch.w), h = (int)Uniform((uint32_t)ch.h);
-  const int upred = (int)Uniform((uint32_t)upred_in), prop = (int)Uniform((uint32_t)prop_in);
-  const uint32_t subroot = Uniform(subroot_in), ni = Uniform(ni_in), thr_off = Uniform(thr_off_in);
+  const int w = (int)Uniform((uint32_t)ch.w), h = (int)Uniform((uint32_t)ch.h), chan = (int)Uniform((uint32_t)chan_in);
+  const int32_t stream_id = (int32_t)Uniform((uint32_t)stream_in);
+  const uint32_t subroot = Uniform(subroot_in);
+  const bool has_y = Uniform(has_y_in ? 1u : 0u) != 0;
   WaveChan wc;
   wc.la = Uniform(T.code.log_alpha); wc.cfg_off = Uniform(T.code.cfg_off); wc.cfg_uniform = Uniform(T.code.cfg_uniform);
   const uint32_t wide_off = Uniform(T.code.wide_off), cut_off = Uniform(T.code.cut_off);
-  wc.thr = 0x7FFFFFFF; wc.cluster = 0;
-  if (prop == 9) {
-    // interval k = (number of constants below the value): lane k walks the subtree once with a value of its interval
-    const int32_t t = lane < ni ? LdS<int32_t>(thr_off + 4 * lane) : 0x7FFFFFFF;
-    uint32_t rank = 0;
-    for (uint32_t i = 0; i < ni; i++) { const int32_t ti = __builtin_amdgcn_readlane(t, (int)i); rank += (ti < t || (ti == t && i < lane)) ? 1u : 0u; }
-    const uint32_t sorted_off = thr_off + 256;
-    if (lane < ni) StS<int32_t>(sorted_off + 4 * rank, t);
-    WaveSync();
-    const uint32_t kk = min(lane, ni);
-    const int32_t rep = ni == 0 ? 0 : (kk == 0 ? LdS<int32_t>(sorted_off) : (int32_t)((uint32_t)LdS<int32_t>(sorted_off + 4 * (kk - 1)) + 1u));
-    wc.cluster = WalkCluster(T.node_base, subroot, rep);
-    wc.thr = t;
-    WaveSync();
-  }
-  state_io = Uniform(state_io);
-  uint32_t state = state_io;
+  wc.thr = 0x7FFFFFFF; wc.cluster = 0; wc.psel = false; wc.lmask = 0; wc.lwant = 1; wc.is1 = false; wc.is5 = false; wc.am0 = 0; wc.am1 = 0; wc.abase = wide_off; wc.cbase = cut_off;
+  uint32_t state = Uniform(state_io);
   const uint64_t bp = br.BitPos();
   const uint64_t bp0 = ((uint64_t)Uniform((uint32_t)(bp >> 32)) << 32) | Uniform((uint32_t)bp);
   WaveBits bits;
   bits.Start(br.words, Uniform(br.wend), bp0, lane);
-  const bool need_n = upred == 5 || prop == 9;
-  int32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;      // the row above, 64 samples per register (rows of up to 256 samples; only when need_n)
-  int32_t first = 0;                            // first sample of the row above (W of a row's first sample when the row above is not kept)
+  int mode = 0, upred = 0, prop0 = -1, prop1 = -1;
+  int32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;      // the row above, 64 samples per register (rows of up to 256 samples)
+  int32_t first = 0;                            // first sample of the row above
   for (int y = 0; y < h; y++) {
     int32_t* p = ch.data + (size_t)y * ch.stride;
-    if (prop != 9) {
-      wc.cluster = WalkCluster(T.node_base, subroot, prop == 2 ? y : 0);
+    if (y == 0 || has_y) {
+      // ---- this row's subtree: constants and leaves into the lanes
+      WaveSync();
+      if (lane == 0) WaveAnalyse(T, subroot, chan, stream_id, y, false);
+      WaveSync();
+      const uint32_t ni = Uniform(LdS<uint32_t>(L + kWaHdr + 4)), np = Uniform(LdS<uint32_t>(L + kWaHdr + 12));
+      prop0 = (int)Uniform((uint32_t)LdS<int>(L + kWaHdr + 16)); prop1 = (int)Uniform((uint32_t)LdS<int>(L + kWaHdr + 20));
+      upred = (int)Uniform((uint32_t)LdS<int>(L + kWaHdr + 28));
+      mode = (int)np;
+      uint32_t leaf = 0;
+      wc.thr = lane < ni ? LdS<int32_t>(L + kWaThr + 4 * lane) : 0x7FFFFFFF;
+      if (mode == 2) {
+        const uint32_t nl = Uniform(LdS<uint32_t>(L + kWaHdr + 8));
+        wc.psel = lane < ni && LdS<uint32_t>(L + kWaPsel + 4 * lane) != 0;
+        wc.lmask = lane < nl ? LdS<uint32_t>(L + kWaMask + 4 * lane) : 0u;
+        wc.lwant = lane < nl ? LdS<uint32_t>(L + kWaWant + 4 * lane) : 1u;
+        leaf = LdS<uint32_t>(L + kWaLeaf + 4 * min(lane, nl - 1));
+      } else if (mode == 1) {
+        // interval k = (number of constants below the value): lane k walks the subtree once with a value of its interval
+        const int32_t t = wc.thr;
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < ni; i++) { const int32_t ti = __builtin_amdgcn_readlane(t, (int)i); rank += (ti < t || (ti == t && i < lane)) ? 1u : 0u; }
+        if (lane < ni) StS<int32_t>(L + kWaSorted + 4 * rank, t);
+        WaveSync();
+        const uint32_t kk = min(lane, ni);
+        const int32_t rep = kk == 0 ? LdS<int32_t>(L + kWaSorted) : (int32_t)((uint32_t)LdS<int32_t>(L + kWaSorted + 4 * (kk - 1)) + 1u);
+        leaf = WaveWalkLeaf(T, subroot, chan, stream_id, y, rep);
+      } else leaf = LdS<uint32_t>(L + kWaLeaf);
+      wc.cluster = leaf >> 8;
+      wc.is1 = (leaf & 0xFF) == 1; wc.is5 = (leaf & 0xFF) == 5;
+      wc.abase = wide_off + ((wc.cluster << wc.la) << 3); wc.cbase = cut_off + ((wc.cluster << wc.la) << 1);
     }
-    wc.abase = wide_off + ((wc.cluster << wc.la) << 3); wc.cbase = cut_off + ((wc.cluster << wc.la) << 1);
-    const bool rows = need_n && y > 0;
-    int32_t left = 0, nw = 0;
-    if (y > 0) { left = rows ? __builtin_amdgcn_readlane(p0, 0) : first; nw = left; }
+    const bool rows = y > 0;
+    int32_t left = 0;
+    if (y > 0) left = w <= 256 ? __builtin_amdgcn_readlane(p0, 0) : first;       // W of the first sample = N (rows wider than 256 samples only get here when no row needs N but this)
     int32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int32_t nw_in = left;
     for (int x0 = 0; x0 < w; x0 += 64) {
       const int n = min(64, w - x0), seg = (x0 >> 6) & 3;
       const int32_t prevv = seg == 0 ? p0 : seg == 1 ? p1 : seg == 2 ? p2 : p3;
+      const int32_t shv = WaveShr1(prevv, nw_in), dvec = prevv - shv;
+      nw_in = __builtin_amdgcn_readlane(prevv, 63);
+      int32_t am0 = 0, am1 = 0;
+      const int32_t vec0 = WavePropVec(prop0, rows, x0, lane, prevv, shv, dvec, &am0), vec1 = WavePropVec(prop1, rows, x0, lane, prevv, shv, dvec, &am1);
+      wc.am0 = (int32_t)Uniform((uint32_t)am0); wc.am1 = (int32_t)Uniform((uint32_t)am1);
       int32_t curv = 0;
-#define JXL_WSEG(NN, P9, UP) WaveSegment<NN, P9, UP>(bits, state, left, nw, prevv, curv, n, wc)
-      if (prop == 9) {
-        if (upred == 5) { if (rows) JXL_WSEG(true, true, 5); else JXL_WSEG(false, true, 5); }
-        else if (upred == 1) { if (rows) JXL_WSEG(true, true, 1); else JXL_WSEG(false, true, 1); }
-        else { if (rows) JXL_WSEG(true, true, 0); else JXL_WSEG(false, true, 0); }
-      } else {
-        if (upred == 5) { if (rows) JXL_WSEG(true, false, 5); else JXL_WSEG(false, false, 5); }
-        else if (upred == 1) JXL_WSEG(false, false, 1);
-        else JXL_WSEG(false, false, 0);
-      }
+#define JXL_WSEG(M, NN, UP, VG) WaveSegment<M, NN, UP, VG>(bits, state, left, prevv, dvec, vec0, vec1, curv, n, wc)
+#define JXL_WSEG_UP(M, NN, VG) do { if (upred == 0) JXL_WSEG(M, NN, 0, VG); else if (upred == 1) JXL_WSEG(M, NN, 1, VG); else if (upred == 5) JXL_WSEG(M, NN, 5, VG); else JXL_WSEG(M, NN, -2, VG); } while (0)
+      if (mode == 0) { if (rows) JXL_WSEG_UP(0, true, false); else JXL_WSEG_UP(0, false, false); }
+      else if (mode == 1) {
+        if (rows) { if (prop0 == 9) JXL_WSEG_UP(1, true, true); else JXL_WSEG_UP(1, true, false); }
+        else JXL_WSEG_UP(1, false, false);
+      } else { if (rows) JXL_WSEG_UP(2, true, false); else JXL_WSEG_UP(2, false, false); }
+#undef JXL_WSEG_UP
 #undef JXL_WSEG
       if ((int)lane < n) StG(p + x0 + (int)lane, curv);
       if (x0 == 0) first = __builtin_amdgcn_readlane(curv, 0);
@@ -1278,6 +1392,16 @@ __device__ __noinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, 
     if (LdS<int>(wb + kWorkOff + 28)) { T.tree_in_lds = true; T.node_base = T.prune_off; }
     WaveSync();
   }
+#ifndef JXL_NO_WAVE_LF
+  // ---- small trees over cheap properties with simple leaves: the wave-wide decoder (every row of the channel, or none)
+  if (T.tree_in_lds && !mc.slow && T.code.wide_off != kNotInLds && T.code.cfg_off != kNotInLds) {
+    if (lane == 0) WaveAnalyse(T, 0, chan, (int32_t)mc.stream_id, 0, /*explore=*/true);
+    WaveSync();
+    const int wave_ok = LdS<int>(wb + kLutOff + kWaHdr), wave_has_y = LdS<int>(wb + kLutOff + kWaHdr + 24), wave_need_n = LdS<int>(wb + kLutOff + kWaHdr + 32);
+    WaveSync();
+    if (wave_ok && (!wave_need_n || ch.w <= 256)) { DecodeChannelWave(br, state, T, ch, 0, chan, (int32_t)mc.stream_id, wave_has_y != 0); return; }
+  }
+#endif
   // ---- lane 0: resolve static properties (channel, stream id) and analyse the remaining subtree
   if (lane == 0) {
     uint32_t pos = 0;
@@ -1363,12 +1487,6 @@ __device__ __noinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, 
   const bool need_n = upred == 5 || prop == 9;    // previous row needed
   const bool fast = mode == 1 && (upred == 0 || upred == 1 || upred == 5) && (prop < 0 || prop == 2 || prop == 9) &&
                     T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && ((uint32_t)ch.w <= kRowMax || !need_n);
-#ifndef JXL_NO_WAVE_LF
-  if (fast && T.code.wide_off != kNotInLds && (prop != 9 || LdS<uint32_t>(wb + kWorkOff + 60) <= 63u)) {
-    DecodeChannelWave(br, state, T, ch, upred, prop, subroot, LdS<uint32_t>(wb + kWorkOff + 60), wb + kLutOff);
-    return;
-  }
-#endif
   if (mode == 1) {
     for (int i = (int)lane; i < 1024; i += 64) {
       const int32_t v = i - 512;
