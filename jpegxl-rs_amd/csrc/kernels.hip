@@ -338,6 +338,9 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
   if (used + n_alias * 8 <= budget) {
     for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) StS<uint64_t>(base + used + i * 8, LdG(g.alias + i));
     fc.alias_off = base + used; used += n_alias * 8;
+  }
+  {
+    // the wide layout behind the plain one, when both fit
     const uint32_t wide_bytes = n_alias * 8 + ((n_alias * 2 + 15) & ~15u);
     if (with_wide && fc.cfg_off != kNotInLds && used + wide_bytes <= budget) {
       const uint32_t wo = base + used, co = wo + n_alias * 8;
@@ -1150,15 +1153,26 @@ __device__ void DecodeChannelWave(BitReaderP& br, uint32_t& state_io, const ModT
   WaveSync();
 }
 
-// ---- wave-wide decode of a channel under a weighted-predictor tree (round 6): the MA-tree shape of a default-effort cjxl encode's LF coefficients (enc_modular.cc
-// "WP fixed DC": every split tests property 15 — the largest neighbouring error of the weighted predictor —, every leaf predicts with it).  The entropy chain is
-// DecodeChannelWave's (lanes = intervals of the property, alias slots of all clusters in one LDS round trip); the predictor (context_predict.h weighted::State,
-// jxl_dev.h WPState) is spread over the lanes of every quad: lane q of a quad owns sub-predictor q — its error sums (one LDS read per sample: the stored error at
-// x + 1 of the row above; the additions of the reference's "+= error at x + 1" live in register carries), its weight (division table in LDS), its prediction (a
-// per-lane linear form of the neighbours and true errors) — and the sums over the four are DPP quad permutes.  True errors and samples of the rows above sit in
-// VGPRs, one per lane, like DecodeChannelWave's rows.  32-bit arithmetic (exact while |sample| <= 4095, as WPStateLds::PredictT<int32_t>): the first larger sample
-// ends the attempt and the caller decodes the channel again the general way.  Rows up to 256 samples.
+// ---- wave-wide decode of a channel under a general MA tree, with or without the weighted predictor (round 6) ---------------------------------------------------
+// Two tree shapes.  THRESH: every split tests property 15 — the largest neighbouring error of the weighted predictor — and every leaf predicts with it: the LF
+// coefficients of a default-effort cjxl encode (enc_modular.cc "WP fixed DC"); the leaf is a popcount as in DecodeChannelWave.  GEN: what cjxl's lossless modes
+// write — up to 63 splits on any of {x, N, W, W+N-NW, W-NW, NW-N, N-NE, N-NN, weighted-predictor error} (row / channel / stream splits resolved per row), leaves
+// predicting with zero / W / clamped gradient / weighted predictor: lane j evaluates ITS node's property as a per-lane linear form of the (uniform) neighbours —
+// six multiply-adds for all 64 nodes at once, whatever the mix of properties —, one compare + ballot yields every decision, the leaf lane whose path agrees is
+// found with one AND + compare per lane, ballot and find-first; the prediction is the leaf lane's pick of the candidates.
+// The entropy chain is DecodeChannelWave's (lanes = leaves, alias slots of all clusters in one LDS round trip).  The weighted predictor (context_predict.h
+// weighted::State, jxl_dev.h WPState) is spread over the lanes of every quad: lane q of a quad owns sub-predictor q — its error sums (one LDS read per sample: the
+// stored error at x + 1 of the row above; the additions of the reference's "+= error at x + 1" live in register carries), its weight (division table in LDS), its
+// prediction (a per-lane linear form of the neighbours and true errors) — and the sums over the four are DPP quad permutes.  True errors and samples of the rows
+// above sit in VGPRs, one per lane, like DecodeChannelWave's rows.  32-bit arithmetic (exact while |sample| <= 4095, as WPStateLds::PredictT<int32_t>; without the
+// predictor while |sample| < 2^22: the 24-bit multiply-adds): the first larger sample ends the attempt and the caller decodes the channel again the general way.
+// Rows up to 256 samples.
 struct WaveWpLane { int32_t kW, kNE, kN, cW, cN, cNE, cNW, cNN, cNWW; uint32_t wmax; };
+struct WaveGenLane {        // per lane: the linear form of this lane's inner node's property, this lane's leaf
+  int32_t aW, aN, aNW, aNE, aNN, aE, aX, c0, thr;
+  uint32_t mlo, mhi, wlo, whi;
+  bool is1, is5, is6;
+};
 __device__ __forceinline__ int32_t QuadSumI(int32_t v) {
   v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
   v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
@@ -1172,9 +1186,9 @@ struct WaveWpRow {          // carries of one row (uniform unless noted)
   int32_t e0prev, aprev, e1x;          // per lane (sub-predictor lane & 3): error of the sample before, A of the sample before, stored error of the row above at x
   int32_t toobig;
 };
-template <bool ROW0, bool LAST>
-__device__ __forceinline__ void WaveWpSample(WaveBits& bits, uint32_t& state, WaveWpRow& r, const int xl, const uint32_t x, const int32_t p1v, const int32_t p1s, const int32_t p2v, const int32_t te1v, const int32_t te1s,
-                                            int32_t& curv, int32_t& tecur, const uint32_t e1, const uint32_t e0, const uint32_t div_off, const WaveWpLane& L, const WaveChan& wc) {
+template <bool ROW0, bool LAST, bool USE_WP, bool GEN>
+__device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, WaveWpRow& r, const int xl, const uint32_t x, const int32_t p1v, const int32_t p1s, const int32_t p2v, const int32_t te1v, const int32_t te1s,
+                                             int32_t& curv, int32_t& tecur, const uint32_t e1, const uint32_t e0, const uint32_t div_off, const WaveWpLane& L, const WaveGenLane& G, const WaveChan& wc) {
   const uint32_t la = wc.la, pmask = (1u << (12 - la)) - 1, lane = threadIdx.x & 63;
   // --- alias reads
   const uint32_t slot = (state & 0xFFF) >> (12 - la);
@@ -1186,38 +1200,59 @@ __device__ __forceinline__ void WaveWpSample(WaveBits& bits, uint32_t& state, Wa
   int32_t N = W, NE = W, NW = W, NN = W, teN = 0, teNE = 0, teNW = 0;
   if (!ROW0) {
     N = __builtin_amdgcn_readlane(p1v, xl); NE = LAST ? N : __builtin_amdgcn_readlane(p1s, xl); NW = r.Nprev; NN = __builtin_amdgcn_readlane(p2v, xl);
-    teN = __builtin_amdgcn_readlane(te1v, xl); teNE = LAST ? teN : __builtin_amdgcn_readlane(te1s, xl); teNW = r.teNprev;
+    if (USE_WP) { teN = __builtin_amdgcn_readlane(te1v, xl); teNE = LAST ? teN : __builtin_amdgcn_readlane(te1s, xl); teNW = r.teNprev; }
   }
-  const int32_t teW = r.teW;
-  const int32_t W8 = W * 8, N8 = N * 8, NE8 = NE * 8, NW8 = NW * 8, NN8 = NN * 8;
-  // --- error sums of this lane's sub-predictor: A (at N, includes the error of W), B (at NW = the A of the sample before), C (at NE)
-  const int32_t A = r.e1x + r.e0prev;
-  const int32_t C = LAST ? A : LdS<int32_t>(e1 + 4 * (x + 1));
-  const uint32_t sum = (uint32_t)A + (uint32_t)r.aprev + (uint32_t)C;
-  int shift = 26 - __clz((int)(sum + 1));          // floor(log2(sum + 1)) - 5
-  if (shift < 0) shift = 0;
-  const uint32_t quot = LdS<uint32_t>(div_off + 4 * (sum >> shift));
-  uint32_t wgt = 4 + ((L.wmax * quot) >> shift);
-  const uint32_t wsum = (uint32_t)QuadSumI((int32_t)wgt);
-  wgt >>= (27 - __clz((int)wsum));                 // floor(log2(wsum)) - 4
-  const uint32_t wsum2 = (uint32_t)QuadSumI((int32_t)wgt);
-  const uint32_t inv = LdS<uint32_t>(div_off + 4 * (wsum2 - 1));
-  // --- this lane's sub-prediction
-  const int32_t lin = L.cW * teW + L.cN * teN + L.cNE * teNE + L.cNW * teNW + L.cNN * (NN8 - N8) + L.cNWW * (NW8 - W8);
-  const int32_t predi = L.kW * W8 + L.kNE * NE8 + L.kN * N8 - (lin >> 5);
-  const int32_t sump = QuadSumI(predi * (int32_t)wgt) + (int32_t)(wsum2 >> 1) - 1;
-  int32_t pred = (int32_t)(((int64_t)sump * (int64_t)inv) >> 24);
-  if (!(((teN ^ teW) | (teN ^ teNW)) > 0)) {
-    const int32_t mx = max(W8, max(NE8, N8)), mn = min(W8, min(NE8, N8));
-    pred = max(mn, min(mx, pred));
+  int32_t pred = 0, perr = 0, predi = 0;
+  if (USE_WP) {
+    const int32_t teW = r.teW;
+    const int32_t W8 = W * 8, N8 = N * 8, NE8 = NE * 8, NW8 = NW * 8, NN8 = NN * 8;
+    // --- error sums of this lane's sub-predictor: A (at N, includes the error of W), B (at NW = the A of the sample before), C (at NE)
+    const int32_t A = r.e1x + r.e0prev;
+    const int32_t C = LAST ? A : LdS<int32_t>(e1 + 4 * (x + 1));
+    const uint32_t sum = (uint32_t)A + (uint32_t)r.aprev + (uint32_t)C;
+    int shift = 26 - __clz((int)(sum + 1));          // floor(log2(sum + 1)) - 5
+    if (shift < 0) shift = 0;
+    const uint32_t quot = LdS<uint32_t>(div_off + 4 * (sum >> shift));
+    uint32_t wgt = 4 + ((L.wmax * quot) >> shift);
+    const uint32_t wsum = (uint32_t)QuadSumI((int32_t)wgt);
+    wgt >>= (27 - __clz((int)wsum));                 // floor(log2(wsum)) - 4
+    const uint32_t wsum2 = (uint32_t)QuadSumI((int32_t)wgt);
+    const uint32_t inv = LdS<uint32_t>(div_off + 4 * (wsum2 - 1));
+    // --- this lane's sub-prediction
+    const int32_t lin = L.cW * teW + L.cN * teN + L.cNE * teNE + L.cNW * teNW + L.cNN * (NN8 - N8) + L.cNWW * (NW8 - W8);
+    predi = L.kW * W8 + L.kNE * NE8 + L.kN * N8 - (lin >> 5);
+    const int32_t sump = QuadSumI(predi * (int32_t)wgt) + (int32_t)(wsum2 >> 1) - 1;
+    pred = (int32_t)(((int64_t)sump * (int64_t)inv) >> 24);
+    if (!(((teN ^ teW) | (teN ^ teNW)) > 0)) {
+      const int32_t mx = max(W8, max(NE8, N8)), mn = min(W8, min(NE8, N8));
+      pred = max(mn, min(mx, pred));
+    }
+    // --- property 15: the true error of largest magnitude among W, N, NW, NE (the first of equals)
+    perr = teW;
+    if (abs(teN) > abs(perr)) perr = teN;
+    if (abs(teNW) > abs(perr)) perr = teNW;
+    if (abs(teNE) > abs(perr)) perr = teNE;
+    r.aprev = A; r.e1x = C;
   }
-  // --- property 15: the true error of largest magnitude among W, N, NW, NE (the first of equals)
-  int32_t perr = teW;
-  if (abs(teN) > abs(perr)) perr = teN;
-  if (abs(teNW) > abs(perr)) perr = teNW;
-  if (abs(teNE) > abs(perr)) perr = teNE;
-  const int k = __builtin_popcountll(__ballot(perr > wc.thr));
-  const int32_t guess = (pred + 3) >> 3;
+  int k;
+  int32_t guess;
+  const int32_t wpguess = (pred + 3) >> 3;
+  if (!GEN) {
+    k = __builtin_popcountll(__ballot(perr > wc.thr));
+    guess = wpguess;
+  } else {
+    // every inner node's property value in its lane (24-bit multiply-adds: the samples are checked below), all decisions, the leaf whose path agrees
+    int32_t pv = G.c0 + __mul24(G.aX, (int32_t)x);
+    pv += __mul24(G.aN, N); pv += __mul24(G.aNW, NW); pv += __mul24(G.aNE, NE); pv += __mul24(G.aNN, NN);
+    if (USE_WP) pv += __mul24(G.aE, perr);
+    pv += __mul24(G.aW, W);
+    const uint64_t d = __ballot(pv > G.thr);
+    const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
+    k = __builtin_ctzll(__ballot((dlo & G.mlo) == G.wlo && (dhi & G.mhi) == G.whi) | (1ull << 63));
+    const int32_t m = min(N, W), M = max(N, W);
+    const int32_t grad = max(m, min(M, (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW)));
+    guess = __builtin_amdgcn_readlane(G.is6 ? wpguess : (G.is5 ? grad : (G.is1 ? W : 0)), k);
+  }
   // --- ANS symbol
   const bool hit = pos >= (cr & 0xFFu);
   const uint32_t cand = hit ? e.y : e.x;
@@ -1246,47 +1281,94 @@ __device__ __forceinline__ void WaveWpSample(WaveBits& bits, uint32_t& state, Wa
     v = UnpackSigned(tok);
   }
   const int32_t val = (int32_t)((uint32_t)v + (uint32_t)guess);
-  if ((uint32_t)(val + 4095) > 8190u) r.toobig = 1;
-  // --- the sample's errors: magnitudes per sub-predictor (stored for the row below, carried for the sample to the right), true error
-  const int32_t v8 = val * 8;
-  const int32_t err = (abs(predi - v8) + 3) >> 3;
-  StS<int32_t>(e0 + 4 * x, err);
-  const int32_t te = pred - v8;
+  if (USE_WP) { if ((uint32_t)(val + 4095) > 8190u) r.toobig = 1; }
+  else if ((uint32_t)(val + (1 << 22)) > (1u << 23)) r.toobig = 1;
   curv = (int)lane == xl ? val : curv;
-  tecur = (int)lane == xl ? te : tecur;
-  r.left = val; r.Nprev = N; r.teW = te; r.teNprev = teN; r.e0prev = err; r.aprev = A; r.e1x = C;
+  if (USE_WP) {
+    // --- the sample's errors: magnitudes per sub-predictor (stored for the row below, carried for the sample to the right), true error
+    const int32_t v8 = val * 8;
+    const int32_t err = (abs(predi - v8) + 3) >> 3;
+    StS<int32_t>(e0 + 4 * x, err);
+    const int32_t te = pred - v8;
+    tecur = (int)lane == xl ? te : tecur;
+    r.teW = te; r.teNprev = teN; r.e0prev = err;
+  }
+  r.left = val; r.Nprev = N;
 }
-// All 64 lanes.  false: a sample beyond +-4095 (nothing of `br` / `state_io` was touched: the caller decodes the channel again the general way).
-__device__ __forceinline__ bool DecodeChannelWaveWp(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, const WPHeader& hdr, uint32_t subroot_in, uint32_t ni_in, uint32_t thr_off_in) {
-  const uint32_t lane = threadIdx.x & 63;
-  const int w = (int)Uniform((uint32_t)ch.w), h = (int)Uniform((uint32_t)ch.h);
-  const uint32_t subroot = Uniform(subroot_in), ni = Uniform(ni_in), thr_off = Uniform(thr_off_in);
+// The general shape's analysis (lane 0): as WaveAnalyse, for the wider property / predictor sets and 64-bit paths.  Per inner node j: property and constant; per leaf:
+// path mask / decisions (two words each) and the {predictor, cluster} word.  Header: ok, ni, nl, has_y, uses_wp, thresh (every split on property 15, every leaf the
+// weighted predictor: the popcount form).
+constexpr uint32_t kWgProp = kWaPsel, kWgMaskHi = kWaSorted, kWgWantHi = 1600;
+__device__ __forceinline__ bool WaveGenProp(int p) { return p == 3 || p == 6 || p == 7 || (p >= 9 && p <= 13) || p == 15; }
+__device__ void WaveAnalyseGen(const ModTables& T, uint32_t subroot, int chan, int32_t stream_id, int y, bool explore) {
+  const uint32_t wb = T.wb, L = wb + kLutOff, stack = wb + kWorkOff + 64;    // stack entries: node, mask lo, mask hi, want lo, want hi
+  int ok = 1, has_y = 0, uses_wp = 0, thresh = 1;
+  uint32_t ni = 0, nl = 0, visited = 0;
+  int sp = 0;
+  StS<uint32_t>(stack, subroot); StS<uint32_t>(stack + 4, 0u); StS<uint32_t>(stack + 8, 0u); StS<uint32_t>(stack + 12, 0u); StS<uint32_t>(stack + 16, 0u); sp = 1;
+  while (sp > 0 && ok) {
+    sp--;
+    uint32_t pos = LdS<uint32_t>(stack + 20 * sp);
+    const uint32_t mlo = LdS<uint32_t>(stack + 20 * sp + 4), mhi = LdS<uint32_t>(stack + 20 * sp + 8), wlo = LdS<uint32_t>(stack + 20 * sp + 12), whi = LdS<uint32_t>(stack + 20 * sp + 16);
+    TreeNode n = T.Node(pos);
+    bool fork_y = false;
+    while (n.prop == 0 || n.prop == 1 || n.prop == 2) {
+      if (++visited > 600) { ok = 0; break; }
+      if (n.prop == 2) { has_y = 1; if (explore) { fork_y = true; break; } }
+      const int32_t v = n.prop == 0 ? chan : (n.prop == 1 ? stream_id : y);
+      pos = v > n.val ? n.a : n.b;
+      n = T.Node(pos);
+    }
+    if (!ok || ++visited > 600) { ok = 0; break; }
+    auto push = [&](uint32_t node, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+      StS<uint32_t>(stack + 20 * sp, node); StS<uint32_t>(stack + 20 * sp + 4, a0); StS<uint32_t>(stack + 20 * sp + 8, a1); StS<uint32_t>(stack + 20 * sp + 12, b0); StS<uint32_t>(stack + 20 * sp + 16, b1); sp++;
+    };
+    if (fork_y) {
+      if (sp + 2 > 38) { ok = 0; break; }
+      push(n.a, mlo, mhi, wlo, whi); push(n.b, mlo, mhi, wlo, whi);
+      continue;
+    }
+    if (n.prop < 0) {
+      const int pr = (int)(n.a & 0xFF);
+      if ((pr != 0 && pr != 1 && pr != 5 && pr != 6) || n.val != 0 || n.b != 1 || nl >= 64) { ok = 0; break; }
+      if (pr == 6) uses_wp = 1; else thresh = 0;
+      if (!explore) { StS<uint32_t>(L + kWaMask + 4 * nl, mlo); StS<uint32_t>(L + kWgMaskHi + 4 * nl, mhi); StS<uint32_t>(L + kWaWant + 4 * nl, wlo); StS<uint32_t>(L + kWgWantHi + 4 * nl, whi); StS<uint32_t>(L + kWaLeaf + 4 * nl, n.a); }
+      nl++;
+      continue;
+    }
+    if (!WaveGenProp(n.prop) || ni >= 63 || sp + 2 > 38) { ok = 0; break; }
+    if (n.prop == 15) uses_wp = 1; else thresh = 0;
+    const uint32_t j = ni++;
+    if (!explore) { StS<int32_t>(L + kWaThr + 4 * j, n.val); StS<uint32_t>(L + kWgProp + 4 * j, (uint32_t)n.prop); }
+    const uint32_t blo = j < 32 ? 1u << j : 0u, bhi = j >= 32 ? 1u << (j - 32) : 0u;
+    push(n.b, mlo | blo, mhi | bhi, wlo, whi);
+    push(n.a, mlo | blo, mhi | bhi, wlo | blo, whi | bhi);
+  }
+  StS<int>(L + kWaHdr + 0, ok); StS<uint32_t>(L + kWaHdr + 4, ni); StS<uint32_t>(L + kWaHdr + 8, nl); StS<int>(L + kWaHdr + 24, has_y); StS<int>(L + kWaHdr + 36, uses_wp); StS<int>(L + kWaHdr + 40, thresh);
+}
+// All 64 lanes; WaveAnalyseGen(explore) said yes.  false: a sample beyond the range of the 32-bit arithmetic (nothing of `br` / `state_io` was touched: the caller
+// decodes the channel again the general way).
+template <bool USE_WP>
+__device__ bool DecodeChannelWaveGen(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, const WPHeader& hdr, int chan_in, int32_t stream_in, bool has_y_in) {
+  const uint32_t lane = threadIdx.x & 63, wb = T.wb, LR = wb + kLutOff;
+  const int w = (int)Uniform((uint32_t)ch.w), h = (int)Uniform((uint32_t)ch.h), chan = (int)Uniform((uint32_t)chan_in);
+  const int32_t stream_id = (int32_t)Uniform((uint32_t)stream_in);
+  const bool has_y = Uniform(has_y_in ? 1u : 0u) != 0;
   WaveChan wc;
   wc.la = Uniform(T.code.log_alpha); wc.cfg_off = Uniform(T.code.cfg_off); wc.cfg_uniform = Uniform(T.code.cfg_uniform);
   const uint32_t wide_off = Uniform(T.code.wide_off), cut_off = Uniform(T.code.cut_off);
-  {
-    const int32_t t = lane < ni ? LdS<int32_t>(thr_off + 4 * lane) : 0x7FFFFFFF;
-    uint32_t rank = 0;
-    for (uint32_t i = 0; i < ni; i++) { const int32_t ti = __builtin_amdgcn_readlane(t, (int)i); rank += (ti < t || (ti == t && i < lane)) ? 1u : 0u; }
-    const uint32_t sorted_off = thr_off + 256;
-    if (lane < ni) StS<int32_t>(sorted_off + 4 * rank, t);
-    WaveSync();
-    const uint32_t kk = min(lane, ni);
-    const int32_t rep = ni == 0 ? 0 : (kk == 0 ? LdS<int32_t>(sorted_off) : (int32_t)((uint32_t)LdS<int32_t>(sorted_off + 4 * (kk - 1)) + 1u));
-    wc.cluster = WalkCluster(T.node_base, subroot, rep);
-    wc.thr = t;
-    WaveSync();
-  }
-  wc.abase = wide_off + ((wc.cluster << wc.la) << 3); wc.cbase = cut_off + ((wc.cluster << wc.la) << 1);
+  wc.thr = 0x7FFFFFFF; wc.cluster = 0; wc.abase = wide_off; wc.cbase = cut_off;
+  WaveGenLane G;
+  G.aW = G.aN = G.aNW = G.aNE = G.aNN = G.aE = G.aX = G.c0 = 0; G.thr = 0x7FFFFFFF; G.mlo = G.mhi = 0; G.wlo = 1; G.whi = 0; G.is1 = G.is5 = G.is6 = false;
   // weighted-predictor state: WPStateLds' layout (error rows of sub-predictor i at array 1 + i, two rows of w + 2 ints each), zeroed; the division table behind it
-  const uint32_t wp_base = Uniform(T.wp_off), div_off = wp_base + kWpLdsBytes - 256;
-  for (uint32_t i = lane; i < WPStateLds::Bytes(w) / 4; i += 64) StS<int32_t>(wp_base + i * 4, 0);
-  StS<uint32_t>(div_off + lane * 4, (1u << 24) / (lane + 1));
-  WaveSync();
+  const uint32_t wp_base = USE_WP ? Uniform(T.wp_off) : 0u, div_off = wp_base + kWpLdsBytes - 256;
   const uint32_t q = lane & 3, rowb = (uint32_t)(w + 2) * 4;
   const uint32_t erows = wp_base + (1 + q) * rowb * 2;
   WaveWpLane L;
-  {
+  L.kW = L.kNE = L.kN = L.cW = L.cN = L.cNE = L.cNW = L.cNN = L.cNWW = 0; L.wmax = 0;
+  if (USE_WP) {
+    for (uint32_t i = lane; i < WPStateLds::Bytes(w) / 4; i += 64) StS<int32_t>(wp_base + i * 4, 0);
+    StS<uint32_t>(div_off + lane * 4, (1u << 24) / (lane + 1));
     const int32_t p1 = hdr.p1, p2 = hdr.p2;
     L.kW = q == 0 || q == 2 ? 1 : 0; L.kNE = q == 0 ? 1 : 0; L.kN = q == 0 ? -1 : (q == 2 ? 0 : 1);
     L.cW = q == 1 ? p1 : (q == 2 ? p2 : 0);
@@ -1304,14 +1386,53 @@ __device__ __forceinline__ bool DecodeChannelWaveWp(BitReaderP& br, uint32_t& st
   bits.Start(br.words, Uniform(br.wend), bp0, lane);
   int32_t p1r[4] = {0, 0, 0, 0}, p2r[4] = {0, 0, 0, 0}, t1r[4] = {0, 0, 0, 0};     // samples of the row above / two above, true errors of the row above
   WaveWpRow r;
-  r.toobig = 0;
+  r.toobig = 0; r.teW = 0; r.teNprev = 0; r.e0prev = 0; r.aprev = 0; r.e1x = 0;
   const int nseg = (w + 63) >> 6;
+  bool thresh = false;
   for (int y = 0; y < h && !r.toobig; y++) {
     int32_t* p = ch.data + (size_t)y * ch.stride;
+    if (y == 0 || has_y) {
+      // ---- this row's subtree: linear forms, constants and leaves into the lanes
+      WaveSync();
+      if (lane == 0) WaveAnalyseGen(T, 0, chan, stream_id, y, false);
+      WaveSync();
+      const uint32_t ni = Uniform(LdS<uint32_t>(LR + kWaHdr + 4)), nl = Uniform(LdS<uint32_t>(LR + kWaHdr + 8));
+      thresh = USE_WP && Uniform((uint32_t)LdS<int>(LR + kWaHdr + 40)) != 0;
+      const int32_t t = lane < ni ? LdS<int32_t>(LR + kWaThr + 4 * lane) : 0x7FFFFFFF;
+      uint32_t leaf;
+      if (thresh) {
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < ni; i++) { const int32_t ti = __builtin_amdgcn_readlane(t, (int)i); rank += (ti < t || (ti == t && i < lane)) ? 1u : 0u; }
+        if (lane < ni) StS<int32_t>(LR + kWaSorted + 4 * rank, t);       // (the region doubles as the high mask words of the general shape)
+        WaveSync();
+        const uint32_t kk = min(lane, ni);
+        const int32_t rep = ni == 0 ? 0 : (kk == 0 ? LdS<int32_t>(LR + kWaSorted) : (int32_t)((uint32_t)LdS<int32_t>(LR + kWaSorted + 4 * (kk - 1)) + 1u));
+        leaf = WaveWalkLeaf(T, 0, chan, stream_id, y, rep);
+        wc.thr = t;
+      } else {
+        const int pr = lane < ni ? (int)LdS<uint32_t>(LR + kWgProp + 4 * lane) : -1;
+        G.thr = t;
+        G.aW = pr == 7 || pr == 9 || pr == 10 ? 1 : 0;
+        G.aN = pr == 6 || pr == 9 || pr == 12 || pr == 13 ? 1 : (pr == 11 ? -1 : 0);
+        G.aNW = pr == 9 || pr == 10 ? -1 : (pr == 11 ? 1 : 0);
+        G.aNE = pr == 12 ? -1 : 0;
+        G.aNN = pr == 13 ? -1 : 0;
+        G.aE = pr == 15 ? 1 : 0;
+        G.aX = pr == 3 ? 1 : 0;
+        G.c0 = 0;
+        G.mlo = lane < nl ? LdS<uint32_t>(LR + kWaMask + 4 * lane) : 0u; G.mhi = lane < nl ? LdS<uint32_t>(LR + kWgMaskHi + 4 * lane) : 0u;
+        G.wlo = lane < nl ? LdS<uint32_t>(LR + kWaWant + 4 * lane) : 1u; G.whi = lane < nl ? LdS<uint32_t>(LR + kWgWantHi + 4 * lane) : 0u;
+        leaf = LdS<uint32_t>(LR + kWaLeaf + 4 * min(lane, nl - 1));
+        G.is1 = (leaf & 0xFF) == 1; G.is5 = (leaf & 0xFF) == 5; G.is6 = (leaf & 0xFF) == 6;
+      }
+      wc.cluster = leaf >> 8;
+      wc.abase = wide_off + ((wc.cluster << wc.la) << 3); wc.cbase = cut_off + ((wc.cluster << wc.la) << 1);
+      WaveSync();
+    }
     const uint32_t e0 = erows + (uint32_t)(y & 1) * rowb, e1 = erows + (uint32_t)((y & 1) ^ 1) * rowb;
     r.left = y ? __builtin_amdgcn_readlane(p1r[0], 0) : 0;
-    r.Nprev = r.left; r.teW = 0; r.teNprev = y ? __builtin_amdgcn_readlane(t1r[0], 0) : 0;
-    r.e0prev = 0; r.e1x = LdS<int32_t>(e1); r.aprev = r.e1x;
+    r.Nprev = r.left;
+    if (USE_WP) { r.teW = 0; r.teNprev = y ? __builtin_amdgcn_readlane(t1r[0], 0) : 0; r.e0prev = 0; r.e1x = LdS<int32_t>(e1); r.aprev = r.e1x; }
     int32_t c[4] = {0, 0, 0, 0}, tc[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int seg = 0; seg < 4; seg++) {
@@ -1322,20 +1443,19 @@ __device__ __forceinline__ bool DecodeChannelWaveWp(BitReaderP& br, uint32_t& st
         const int32_t p1s = WaveShl1(p1r[seg], nextp), te1s = WaveShl1(t1r[seg], nextt);
         int32_t curv = 0, tecur = 0;
         const int nn = last_seg ? n - 1 : n;
-        if (y == 0) {
-          for (int xl = 0; xl < nn; xl++) WaveWpSample<true, false>(bits, state, r, xl, (uint32_t)(x0 + xl), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
-          if (last_seg) WaveWpSample<true, true>(bits, state, r, nn, (uint32_t)(x0 + nn), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
-        } else {
-          for (int xl = 0; xl < nn; xl++) WaveWpSample<false, false>(bits, state, r, xl, (uint32_t)(x0 + xl), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
-          if (last_seg) WaveWpSample<false, true>(bits, state, r, nn, (uint32_t)(x0 + nn), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, wc);
-        }
+#define JXL_GSAMPLE(R0, LA, GE, XL) WaveGenSample<R0, LA, USE_WP, GE>(bits, state, r, XL, (uint32_t)(x0 + (XL)), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, G, wc)
+#define JXL_GROW(R0, GE) do { for (int xl = 0; xl < nn; xl++) JXL_GSAMPLE(R0, false, GE, xl); if (last_seg) JXL_GSAMPLE(R0, true, GE, nn); } while (0)
+        if (USE_WP && thresh) { if (y == 0) JXL_GROW(true, false); else JXL_GROW(false, false); }
+        else { if (y == 0) JXL_GROW(true, true); else JXL_GROW(false, true); }
+#undef JXL_GROW
+#undef JXL_GSAMPLE
         if ((int)lane < n) StG(p + x0 + (int)lane, curv);
         c[seg] = curv; tc[seg] = tecur;
       }
     }
 #pragma unroll
     for (int seg = 0; seg < 4; seg++) { p2r[seg] = y == 0 ? c[seg] : p1r[seg]; p1r[seg] = c[seg]; t1r[seg] = tc[seg]; }
-    WaveSync();      // (this row's error stores before the next row's reads)
+    if (USE_WP) WaveSync();      // (this row's error stores before the next row's reads)
   }
   if (r.toobig) { WaveSync(); return false; }
   state_io = state;
@@ -1400,6 +1520,20 @@ __device__ __noinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, 
     const int wave_ok = LdS<int>(wb + kLutOff + kWaHdr), wave_has_y = LdS<int>(wb + kLutOff + kWaHdr + 24), wave_need_n = LdS<int>(wb + kLutOff + kWaHdr + 32);
     WaveSync();
     if (wave_ok && (!wave_need_n || ch.w <= 256)) { DecodeChannelWave(br, state, T, ch, 0, chan, (int32_t)mc.stream_id, wave_has_y != 0); return; }
+    // ---- general trees (cjxl's lossless property set, weighted predictor): the wave-wide decoder's general form, rows up to 256 samples
+    if (ch.w <= 256) {
+      if (lane == 0) WaveAnalyseGen(T, 0, chan, (int32_t)mc.stream_id, 0, /*explore=*/true);
+      WaveSync();
+      const int gen_ok = LdS<int>(wb + kLutOff + kWaHdr), gen_has_y = LdS<int>(wb + kLutOff + kWaHdr + 24), gen_wp = LdS<int>(wb + kLutOff + kWaHdr + 36);
+      WaveSync();
+#ifdef JXL_WAVE_DEBUG
+      if (lane == 0) printf("wave gen: stream %u chan %d w %d h %d ok %d ni %u nl %u wp %d wp_off %x simple_ok %d\n", mc.stream_id, chan, ch.w, ch.h, gen_ok, LdS<uint32_t>(wb + kLutOff + kWaHdr + 4), LdS<uint32_t>(wb + kLutOff + kWaHdr + 8), gen_wp, T.wp_off, wave_ok);
+#endif
+      if (gen_ok) {
+        if (!gen_wp) { if (DecodeChannelWaveGen<false>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, gen_has_y != 0)) return; }
+        else if (T.wp_off != 0xFFFFFFFFu) { if (DecodeChannelWaveGen<true>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, gen_has_y != 0)) return; }
+      }
+    }
   }
 #endif
   // ---- lane 0: resolve static properties (channel, stream id) and analyse the remaining subtree
@@ -1454,25 +1588,6 @@ __device__ __noinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, 
       }
     }
     StS<int>(wb + kWorkOff + 56, sub_wp);
-    // the wave-wide weighted-predictor decoder's tree shape: every split on property 15, every leaf (predictor 6, offset 0, multiplier 1), at most 63 splits
-    int wpw = 0;
-    uint32_t wni = 0;
-    if (mc.uses_wp && mode == 0 && sub_wp) {
-      int visited = 0;
-      wpw = 1; sp = 0;
-      StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)pos);
-      while (sp > 0 && wpw) {
-        const TreeNode m = T.Node((uint32_t)LdS<int>(wb + kWorkOff + 64 + 4 * --sp));
-        if (++visited > 130) { wpw = 0; break; }
-        if (m.prop < 0) { if ((m.a & 0xFF) != 6 || m.val != 0 || m.b != 1) wpw = 0; continue; }
-        if (m.prop != 15 || sp + 2 > 200) { wpw = 0; break; }
-        if (wni < 64) StS<int32_t>(wb + kLutOff + 4 * wni, m.val);
-        wni++;
-        StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.a); StS<int>(wb + kWorkOff + 64 + 4 * sp++, (int)m.b);
-      }
-      if (wni > 63) wpw = 0;
-    }
-    StS<int>(wb + kLutOff + 512, wpw); StS<uint32_t>(wb + kLutOff + 516, wni);
     StS<int>(wb + kWorkOff + 0, mode); StS<int>(wb + kWorkOff + 4, prop); StS<int>(wb + kWorkOff + 8, (int)pos); StS<int>(wb + kWorkOff + 12, upred);
     StS<int>(wb + kWorkOff + 20, wide);
     StS<uint32_t>(wb + kWorkOff + 60, ni);
@@ -1587,11 +1702,6 @@ __device__ __noinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, 
     return;
   }
   WPStateLds wpl;
-#ifndef JXL_NO_WAVE_LF
-  if (wp_in_lds && !mc.slow && T.tree_in_lds && T.code.wide_off != kNotInLds && LdS<int>(wb + kLutOff + 512)) {
-    if (DecodeChannelWaveWp(br, state, T, ch, mc.wp, subroot, LdS<uint32_t>(wb + kLutOff + 516), wb + kLutOff)) return;
-  }
-#endif
   if (wp_in_lds) { wpl.Init(T.wp_off, T.wp_off + kWpLdsBytes - 256, ch.w, lane, mc.narrow_wp != 0); WaveSync(); }
   // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
   // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
@@ -5668,6 +5778,13 @@ static void PlanModularLds(const LaunchCfg& cfg, uint32_t* nwaves_io, uint32_t* 
   auto total = [&]() { return nwaves * kWaveLds + cap * 16 + code + 16 + wp(); };
   while (total() > limit && pruned && cap > 512) cap /= 2;
   if (total() > limit) code = (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes);
+  // the wave-wide decoders' second copy of the alias tables (StageCode with_wide: 10 bytes per slot), when the plain tables are staged whole and both fit
+  static const bool no_wide = getenv("JXL_HIP_NO_WAVE_LF") != nullptr;
+  if (!no_wide && code == (uint32_t)cfg.mod_code_bytes) {
+    const uint32_t wide = code * 5 / 4 + 64;
+    if (total() + wide <= limit) code += wide;               // both layouts, or the plain one as before (the paths that take the channels the wave-wide decoders turn down — trees of hundreds of
+                                                             // nodes per stream: bench.jxl — need it in LDS; the wide one alone made that file 1.7x slower)
+  }
   *nwaves_io = nwaves;
   *tree_cap = cap;
   *lds_tables = nwaves * kWaveLds + cap * 16 + code;
