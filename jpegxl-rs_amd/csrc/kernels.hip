@@ -310,7 +310,7 @@ __device__ __forceinline__ uint32_t WideValue(uint32_t tok, uint32_t cfg) {
   const uint32_t split = 1u << (cfg & 0xFF);
   return (tok < split && tok < 255u) ? ((uint32_t)UnpackSigned(tok) & 0xFFu) : ((uint32_t)kWideEscape & 0xFFu);
 }
-__device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget, bool with_ctx_map, bool with_wide = false) {
+__device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uint32_t budget, bool with_ctx_map, bool with_wide = false, bool with_plain = true) {
   uint32_t used = 0;
   fc.log_alpha = g.log_alpha;
   fc.ctx_map_g = g.ctx_map; fc.cfg_g = g.cfg; fc.alias_g = g.alias;
@@ -335,12 +335,12 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
     }
   }
   const uint32_t n_alias = g.num_clusters << g.log_alpha;
-  if (used + n_alias * 8 <= budget) {
+  if (with_plain && used + n_alias * 8 <= budget) {
     for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) StS<uint64_t>(base + used + i * 8, LdG(g.alias + i));
     fc.alias_off = base + used; used += n_alias * 8;
   }
   {
-    // the wide layout behind the plain one, when both fit
+    // the wide layout behind the plain one, when both fit (with_plain = false: a kernel that only reads the wide one)
     const uint32_t wide_bytes = n_alias * 8 + ((n_alias * 2 + 15) & ~15u);
     if (with_wide && fc.cfg_off != kNotInLds && used + wide_bytes <= budget) {
       const uint32_t wo = base + used, co = wo + n_alias * 8;
@@ -887,6 +887,12 @@ struct WaveBits {           // uniform state; `win`: this lane's word of the cur
       avail += 32;
       widx++;
     }
+  }
+  __device__ __forceinline__ uint32_t Read(int n) {      // n <= 32; at least 33 bits are buffered before and after
+    const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
+    buf >>= n; avail -= n;
+    Refill();
+    return v;
   }
   __device__ __forceinline__ uint64_t BitPos() const { return (uint64_t)(wbase + widx) * 32 - (uint64_t)avail; }
 };
@@ -3369,6 +3375,202 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
   }  // passes
 }
 
+// ---- wave-wide variant (round 6): ONE group stream per wavefront, every lane running the chain — what a single image (or a handful) needs: 135 streams of a 4K frame
+// on 135 wavefronts.  The sparse SIMT form above spends ~220 instructions and several dependent LDS round trips per token on one busy lane (1.4 us per token with the
+// block bookkeeping); here the state of the stream (ANS state, bit buffer, position in the block, counts) sits in scalar registers, the bit stream in a VGPR (one word
+// per lane, WaveBits), the "non-zeros above" rows in three VGPRs (one block column per lane), the varblock list 64 entries at a time in two, the first 64 entries of
+// every coefficient order in LDS (the head of an order table is where most blocks end).  The context of a coefficient token depends on the token before it only through
+// "was it zero" and the count of non-zeros left — two outcomes: the even / odd lanes work out the context, its cluster and the cluster's alias-table base for both while
+// the token before is still being decoded, and the alias read of the next token goes out with per-lane addresses the moment the ANS state is known; `v_readlane` with the
+// outcome picks the winner (StageCode's wide layout, as DecodeChannelWave).  Single-pass ANS-coded frames without chroma subsampling; the host sends everything else
+// to the SIMT kernel.
+constexpr uint32_t kHwOrdOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;   // 39 x 64 u16: heads of the order tables
+constexpr uint32_t kHwCodeOff = kHwOrdOff + 39 * 128;
+constexpr uint32_t kHwWaves = 4;
+struct WaveTok { uint32_t u; int32_t v; };      // a decoded hybrid integer and its UnpackSigned()
+// one token under a known (uniform) cluster base: the non-speculative form (the "number of non-zeros" token of a block)
+__device__ __forceinline__ WaveTok WaveTokenAt(WaveBits& bits, uint32_t& state, uint32_t abase, uint32_t cbase, uint32_t cfg, uint32_t la) {
+  const uint32_t pmask = (1u << (12 - la)) - 1;
+  const uint32_t slot = (state & 0xFFF) >> (12 - la), pos = state & pmask, hi = state >> 12;
+  const uint2 e = LdS<uint2>(abase + slot * 8);
+  const uint32_t cr = Uniform(LdS<uint16_t>(cbase + slot * 2));
+  const bool hit = pos >= (cr & 0xFFu);
+  const uint32_t sw = Uniform(hit ? e.y : e.x);
+  state = (sw & 0xFFFu) * hi + hi + pos + ((sw >> 12) & 0xFFFu);
+  int32_t v = (int32_t)sw >> 24;
+  if (state < (1u << 16)) { state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
+  WaveTok t;
+  if (v != kWideEscape) { t.v = v; t.u = (uint32_t)((v << 1) ^ (v >> 31)); return t; }
+  uint32_t tok = hit ? (cr >> 8) : slot;
+  const uint32_t split_exp = cfg & 0xFF, split = 1u << split_exp;
+  if (tok >= split) {
+    const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+    const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb))) & 31;
+    const uint32_t low = tok & ((1u << lsb) - 1);
+    tok >>= lsb;
+    if ((int)nbits > bits.avail) bits.Refill();
+    const uint32_t xb = (uint32_t)(bits.buf & ((1ull << nbits) - 1));
+    bits.buf >>= nbits; bits.avail -= (int)nbits;
+    const uint32_t hb = (1u << msb) | (tok & ((1u << msb) - 1));
+    tok = (((hb << nbits) | xb) << lsb) | low;
+    bits.Refill();
+  }
+  t.u = tok; t.v = UnpackSigned(tok);
+  return t;
+}
+__global__ __launch_bounds__(64 * kHwWaves) void HfDecodeWaveKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes) {
+  const FrameDev& f = frames[blockIdx.y];
+  if (f.is_modular || FrameFailed(f)) return;
+  if (blockIdx.x * kHwWaves >= f.num_groups) return;
+  const PassDev& pd = f.passes[0];
+  FastCode code;
+  if (threadIdx.x < 64) { StS<uint8_t>(threadIdx.x, kNzCtx[threadIdx.x]); StS<uint8_t>(64 + threadIdx.x, kFreqCtx[threadIdx.x]); }
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(f.bcm);
+    for (uint32_t i = threadIdx.x; i < sizeof(BlockCtxDev) / 4; i += blockDim.x) StS<uint32_t>(kSimtBcmOff + i * 4, LdG(src + i));
+  }
+  for (uint32_t i = threadIdx.x; i < 39 * 64; i += blockDim.x) StS<uint16_t>(kHwOrdOff + i * 2, LdG(pd.orders[i >> 6] + (i & 63)));
+  StageCode(pd.code, code, kHwCodeOff, lds_bytes > kHwCodeOff ? lds_bytes - kHwCodeOff : 0, /*with_ctx_map=*/true, /*with_wide=*/true, /*with_plain=*/false);
+  __syncthreads();
+  if (code.wide_off == kNotInLds || code.ctx_map_off == kNotInLds || code.cfg_off == kNotInLds) { if (threadIdx.x == 0) SetError(f, kErrUnsupported); return; }
+  const uint32_t lane = threadIdx.x & 63, g = blockIdx.x * kHwWaves + (threadIdx.x >> 6);
+  if (g >= f.num_groups) return;
+  __builtin_amdgcn_s_setprio(3);
+  constexpr uint32_t oMap = kSimtBcmOff + offsetof(BlockCtxDev, ctx_map);
+  const uint32_t n_qf = Uniform(LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, n_qf_thr)));
+  const uint32_t num_lf_ctxs = Uniform(LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, num_lf_ctxs)));
+  const uint32_t nctx = Uniform(LdS<uint32_t>(kSimtBcmOff + offsetof(BlockCtxDev, num_ctxs)));
+  const uint32_t qlf_stride = (n_qf + 1) * num_lf_ctxs, bctx_step = 13u * qlf_stride;
+  const uint32_t la = Uniform(code.log_alpha), cfg_off = Uniform(code.cfg_off), cfg_uniform = Uniform(code.cfg_uniform), map_off = Uniform(code.ctx_map_off);
+  const uint32_t wide_off = Uniform(code.wide_off), cut_off = Uniform(code.cut_off);
+  uint64_t bit0, byte_end;
+  if (f.single_section) { bit0 = f.hf_start_bitpos; byte_end = f.cs_size; }
+  else { const uint32_t si = 2 + f.num_lf_groups + g; const uint64_t off = LdG(f.sec_off + si), sz = LdG(f.sec_size + si); bit0 = off * 8; byte_end = off + sz; }
+  if (byte_end > f.cs_size) return;      // input that ends inside the frame (progressive flush): the group is drawn from its LF part
+  const uint64_t limit = byte_end * 8;
+  WaveBits bits;
+  bits.Start(reinterpret_cast<const uint32_t*>(f.cs), (uint32_t)((f.cs_size + 3) >> 2) + 16u, ((uint64_t)Uniform((uint32_t)(bit0 >> 32)) << 32) | Uniform((uint32_t)bit0), lane);   // (80 zero bytes follow the codestream)
+  const uint32_t preset = f.preset_bits ? bits.Read((int)f.preset_bits) : 0;
+  uint32_t err = 0;
+  if (preset >= f.num_hf_presets) err = kErrBadValue;
+  const uint32_t ctx_offset = 495u * nctx * preset;
+  uint32_t state = bits.Read(32);
+  const uint2* vbl = f.vb_list + (size_t)g * 1024;
+  const uint32_t nvb = err ? 0u : Uniform(LdG(f.vb_count + g));
+  const uint32_t gbase = g * 65536u;
+  int32_t* const cb0 = f.coeff[0]; int32_t* const cb1 = f.coeff[1]; int32_t* const cb2 = f.coeff[2];
+  uint32_t nzr0 = 0, nzr1 = 0, nzr2 = 0;        // "non-zeros" of the blocks above, per channel: lane = block column
+  uint32_t entx = 0, enty = 0;
+  uint32_t nz_total = 0;
+  for (uint32_t vi = 0; vi < nvb && !err; vi++) {
+    if ((vi & 63) == 0) {
+      const uint2 ent = vi + lane < nvb ? LdG(vbl + vi + lane) : make_uint2(0, 0);
+      entx = ent.x; enty = ent.y;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    const uint32_t ex = (uint32_t)__builtin_amdgcn_readlane((int)entx, (int)(vi & 63)), ey = (uint32_t)__builtin_amdgcn_readlane((int)enty, (int)(vi & 63));
+    const uint32_t bx = (ex >> 16) & 31, by = (ex >> 21) & 31, qlf = ex >> 26, lcx = (ex >> 5) & 7, l2 = (ex >> 8) & 15, ord = (ex >> 12) & 15;
+    const uint32_t covered = 1u << l2, size = covered * 64, coff = gbase + ey;
+    const uint32_t bctx_idx = ord * qlf_stride + qlf;
+    const bool in_cols = lane >= bx && lane < bx + (1u << lcx);
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      if (err) break;
+      const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;       // Y, X, B
+      const uint32_t nzr = c == 0 ? nzr0 : c == 1 ? nzr1 : nzr2;
+      const uint32_t block_ctx = Uniform(LdS<uint8_t>(oMap + bctx_idx + (uint32_t)ci * bctx_step));
+      const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)nzr, (int)bx), left = bx ? (uint32_t)__builtin_amdgcn_readlane((int)nzr, (int)(bx - 1)) : 0u;
+      const uint32_t pred = bx == 0 ? (by == 0 ? 32u : top) : by == 0 ? left : (top + left + 1) / 2;
+      const uint32_t pc = pred > 64 ? 64 : pred;
+      const uint32_t nz_ctx = ctx_offset + (pc < 8 ? block_ctx + nctx * pc : block_ctx + nctx * (4 + pc / 2));
+      const uint32_t histo = ctx_offset + 37 * nctx + 458 * block_ctx;
+      uint32_t nzeros;
+      {
+        const uint32_t cl = Uniform(LdS<uint8_t>(map_off + nz_ctx));
+        const uint32_t cfg = cfg_uniform != 0xFFFFFFFFu ? cfg_uniform : Uniform(LdS<uint32_t>(cfg_off + 4 * cl));
+        nzeros = WaveTokenAt(bits, state, wide_off + ((cl << la) << 3), cut_off + ((cl << la) << 1), cfg, la).u;
+      }
+      if (nzeros + covered > size) { err = kErrNzeros; break; }
+      nz_total += nzeros;
+      const uint32_t nzm = (nzeros + covered - 1) >> l2;
+      if (c == 0) nzr0 = in_cols ? nzm : nzr0; else if (c == 1) nzr1 = in_cols ? nzm : nzr1; else nzr2 = in_cols ? nzm : nzr2;
+      if (nzeros == 0) continue;
+      // ---- coefficient tokens
+      int32_t* const blk = (c == 0 ? cb0 : c == 1 ? cb1 : cb2) + coff;
+      const uint16_t* order = pd.orders[ord * 3 + c];
+      uint32_t ordv = LdS<uint16_t>(kHwOrdOff + (ord * 3 + (uint32_t)c) * 128 + lane * 2), kbase = 0;
+      uint32_t k = covered;
+      uint32_t sel = nzeros > size / 16 ? 0u : 1u;
+      const uint32_t par = lane & 1;
+      // candidates of the first token: the context for "previous was zero" (even lanes) / "was not" (odd lanes) — no count has changed yet
+      uint32_t abase, cbase, clus;
+      {
+        const uint32_t ctx0 = histo + ((uint32_t)LdS<uint8_t>((nzeros + covered - 1) >> l2) + LdS<uint8_t>(64 + (k >> l2))) * 2 + par;
+        clus = LdS<uint8_t>(map_off + ctx0);
+        abase = wide_off + ((clus << la) << 3); cbase = cut_off + ((clus << la) << 1);
+      }
+      const uint32_t pmask = (1u << (12 - la)) - 1;
+      for (;;) {
+        // [A] alias reads, per-lane cluster
+        const uint32_t slot = (state & 0xFFF) >> (12 - la), pos = state & pmask, hi = state >> 12, hp = hi + pos;
+        const uint2 e = LdS<uint2>(abase + slot * 8);
+        const uint32_t cr = LdS<uint16_t>(cbase + slot * 2);
+        // [B] candidates of the token after this one: count of non-zeros left if this one is zero (even lanes) / is not (odd lanes)
+        const uint32_t nzl = (nzeros - par + covered - 1) >> l2;
+        const uint32_t ctxn = histo + ((uint32_t)LdS<uint8_t>(nzl) + LdS<uint8_t>(64 + ((k + 1) >> l2))) * 2 + par;
+        const uint32_t clus_n = LdS<uint8_t>(map_off + ctxn);
+        // position of this coefficient
+        if (__builtin_expect(k >= kbase + 64, 0)) { kbase = k & ~63u; ordv = LdG(order + kbase + lane); __builtin_amdgcn_s_waitcnt(0x0F70); }
+        const uint32_t cpos = (uint32_t)__builtin_amdgcn_readlane((int)ordv, (int)(k - kbase));
+        // [C] the symbol
+        const bool hit = pos >= (cr & 0xFFu);
+        const uint32_t cand = hit ? e.y : e.x;
+        const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)sel);
+        state = (sw & 0xFFFu) * hi + hp + ((sw >> 12) & 0xFFFu);
+        int32_t v = (int32_t)sw >> 24;
+        if (state < (1u << 16)) { asm volatile("" ::: "memory"); state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
+        if (__builtin_expect(v == kWideEscape, 0)) {
+          const uint32_t crk = (uint32_t)__builtin_amdgcn_readlane((int)cr, (int)sel);
+          uint32_t tok = pos >= (crk & 0xFFu) ? (crk >> 8) : slot;
+          uint32_t cfg = cfg_uniform;
+          if (cfg == 0xFFFFFFFFu) cfg = Uniform(LdS<uint32_t>(cfg_off + 4 * (uint32_t)__builtin_amdgcn_readlane((int)clus, (int)sel)));
+          const uint32_t split_exp = cfg & 0xFF, split = 1u << split_exp;
+          if (tok >= split) {
+            const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+            const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb))) & 31;
+            const uint32_t low = tok & ((1u << lsb) - 1);
+            tok >>= lsb;
+            if ((int)nbits > bits.avail) bits.Refill();
+            const uint32_t xb = (uint32_t)(bits.buf & ((1ull << nbits) - 1));
+            bits.buf >>= nbits; bits.avail -= (int)nbits;
+            const uint32_t hb = (1u << msb) | (tok & ((1u << msb) - 1));
+            tok = (((hb << nbits) | xb) << lsb) | low;
+            bits.Refill();
+          }
+          v = UnpackSigned(tok);
+          if (tok == 0) v = 0;
+        }
+        sel = v != 0 ? 1u : 0u;
+        if (sel && lane == 0) StG(blk + cpos, v);
+        nzeros -= sel;
+        k++;
+        if (nzeros == 0) break;
+        if (k >= size) { err = kErrNzeros; break; }
+        clus = clus_n;
+        abase = wide_off + ((clus_n << la) << 3); cbase = cut_off + ((clus_n << la) << 1);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (!err) { if (state != 0x130000u) err = kErrAnsFinalState; else if (bits.BitPos() > limit) err = kErrOverrun; }
+    if (err) SetError(f, err);
+    else {
+      if (f.hf_end_bitpos && f.mod_pass == 0) f.hf_end_bitpos[g] = bits.BitPos();
+      if (nz_total) atomicAdd(f.hf_written, nz_total);
+    }
+  }
+}
+
 // =====================================================================================================================
 // K_idct: dequant + chroma-from-luma + LLF + inverse transforms.  One 256-thread workgroup per 256x256 group.
 // Pass 1 (rows): horizontal 1-D IDCT of every coefficient row, written into the pixel plane as an intermediate;
@@ -5627,6 +5829,18 @@ void LaunchZeroFailedCoefficients(const FrameDev* frames, int nframes, void* str
   if (nframes > 0) hipLaunchKernelGGL(ZeroFailedCoefKernel, dim3(32, nframes), dim3(256), 0, (hipStream_t)stream, frames);
 }
 void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const LaunchCfg& cfg, void* stream) {
+  // latency mode (one stream per wavefront asked for) with plain frames whose AC code fits the LDS in the wide layout: the wave-wide kernel
+  static const bool no_wave_hf = getenv("JXL_HIP_NO_WAVE_HF") != nullptr;
+  if (!no_wave_hf && cfg.lane_stride_hf == 1 && cfg.hf_lanes_per_wave == 1 && !cfg.any_subsampled && !cfg.any_multipass && !cfg.any_prefix_ac && !cfg.skip_hf && cfg.max_passes == 0) {
+    const uint32_t code_bytes = (uint32_t)cfg.ac_code_bytes * 5 / 4 + 64;      // cfg + context map + 10 bytes per alias slot (ac_code_bytes counts 8)
+    const uint32_t lds = kHwCodeOff + code_bytes;
+    if (lds <= 150 * 1024) {
+      static bool attr = false;
+      if (!attr) { SetMaxDynamicLds((const void*)HfDecodeWaveKernel, 160 * 1024 - 2048, "HfDecodeWaveKernel"); attr = true; }
+      hipLaunchKernelGGL(HfDecodeWaveKernel, dim3(DivUp(max_groups, (int)kHwWaves), nframes), dim3(64 * kHwWaves), lds, (hipStream_t)stream, frames, lds);
+      return;
+    }
+  }
   if (cfg.lane_stride_hf == 1) {   // SIMT: one group stream per lane
 #ifndef JXL_HF_WIDE_ALIAS
     const int code_lds = cfg.ac_code_bytes_compact;                    // the all-in-LDS instantiations stage the compact form (StageCodeCompact)

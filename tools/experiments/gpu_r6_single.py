@@ -12,7 +12,8 @@ for tree_shape in (0, 1):
     for n in (1, 4):
         b = jx.BatchDecoder(0)
         b.add_many([streams[i % len(streams)] for i in range(n)], "uint8", 3, threads=8)
-        b.set_lane_stride(64, 1 if n <= 12 else 64)
+        b.set_lane_stride(64, 1)
+        if n <= 8 and not os.environ.get('NO_SPARSE'): b.set_option('hf_lanes_per_wave', 1)
         b.prepare()
         b.decode(); b.finish()
         b.collect_times()
