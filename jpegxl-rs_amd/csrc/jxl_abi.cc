@@ -953,6 +953,7 @@ void JxlHipBatchSetOption(JxlHipBatch* h, const char* name, int value) {
   else if (n == "keep_orientation") h->keep_orientation = value != 0;   // applies to outputs set afterwards
   else if (n == "hf_block_threads" && value >= 64 && value <= 1024 && value % 64 == 0) h->b->cfg.hf_block_threads = value;
   else if (n == "lds_code_budget" && value >= 0 && value <= 128 * 1024) h->b->cfg.lds_code_budget = value;
+  else if (n == "lf_force_big" && value >= -1 && value <= 2) h->b->cfg.lf_force_big = value;
   else if (n == "hf_lanes_per_wave" && value >= 0 && value <= 64) h->b->cfg.hf_lanes_per_wave = value;   // SIMT HF stage: group streams per wavefront (1: the wave-wide kernel where it applies); 0: the throughput packing
 }
 size_t JxlHipBatchDebugRead(JxlHipBatch* h, int index, const char* name, int channel, void* dst, size_t cap, void* s) {

@@ -146,6 +146,7 @@ struct LaunchCfg {
   int lf_wide_once = 0;              // the next LF launch takes the one-wavefront-per-stream kernel for every frame, SIMT-eligible or not (a pipeline that starts
                                      // on an idle GPU: 100 instead of 250 ms until the first batch can go on); reset by the launch
   int lf_wp_narrow_test = 0;         // testing: the SIMT LF kernel's weighted-predictor lanes hand a stream back at |sample| > 16 instead of 2^20
+  int lf_force_big = 0;              // testing: the launch shape of LfDecodeKernel (kernels.hip LaunchLfDecode)
   int lf_head_start = 0;             // the LF launch waits until the next HF launch is resident (set for pipelined front-only calls)
   int idct_flags_known = 0, any_irregular_blocks = 1, any_big_blocks = 1;
   int hf_lanes_per_wave = 0, hf_lanes_per_wg = 0;   // SIMT HF decode: group streams per wavefront / per workgroup (0: the throughput defaults — a frame's streams on four wavefronts of one workgroup)

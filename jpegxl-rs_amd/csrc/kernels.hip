@@ -1474,10 +1474,16 @@ __device__ bool DecodeChannelWaveGen(BitReaderP& br, uint32_t& state_io, const M
 // BALLOT: general trees are evaluated by the whole wavefront (see the "ballot" path below) — the Modular kernels; the LF kernel
 // of the VarDCT path keeps the single-lane loops (register budget).
 template <bool BALLOT = false>
-__device__ __noinline__ void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T_in, const ModularCtx& mc_in, const ChannelDesc& ch_in, int chan) {
-  // (a real call since round 6 — inlined six times over, LfDecodeKernel was 85 000 instructions and three minutes of compile time: the arguments into registers once)
-  const ModularCtx mc = mc_in;
-  const ChannelDesc ch = ch_in;
+// (inlined: as a real call — tried in round 6 for the build time, LfDecodeKernel is 85 000 instructions with six copies of this — the second LF group of a wavefront
+// failed with four groups per workgroup: JXL_COOP_NOINLINE keeps the experiment)
+#ifdef JXL_COOP_NOINLINE
+#define JXL_COOP_ATTR __noinline__
+#else
+#define JXL_COOP_ATTR __forceinline__
+#endif
+__device__ JXL_COOP_ATTR void DecodeChannelCoop(BitReaderP& br, uint32_t& state, const ModTables& T_in, const ModularCtx& mc_in, const ChannelDesc& ch_in, int chan) {
+  const ModularCtx& mc = mc_in;
+  const ChannelDesc& ch = ch_in;
   if (ch.w == 0 || ch.h == 0) return;
   const uint32_t lane = threadIdx.x & 63, wb = T_in.wb;
   ModTables T = T_in;
@@ -2117,11 +2123,14 @@ __device__ __forceinline__ void LfDecodeGroup(const FrameDev& f, const uint32_t 
   int32_t* m_blk = m_ytob + mcw * mch;
   int32_t* m_sharp = m_blk + 2 * nb_blocks;
   mc.wp = s_gh.wp; mc.stream_id = 1 + 2 * f.num_lf_groups + g;
-  ChannelDesc ch;
-  ch.data = m_ytox; ch.w = (int)mcw; ch.h = (int)mch; ch.stride = (int)mcw; before_channel(ch, 0); DecodeChannelCoop(br, state, T, mc, ch, 0);
-  ch.data = m_ytob; before_channel(ch, 1); DecodeChannelCoop(br, state, T, mc, ch, 1);
-  ch.data = m_blk; ch.w = (int)nb_blocks; ch.h = 2; ch.stride = (int)nb_blocks; before_channel(ch, 2); DecodeChannelCoop(br, state, T, mc, ch, 2);
-  ch.data = m_sharp; ch.w = (int)gbw; ch.h = (int)gbh; ch.stride = (int)gbw; before_channel(ch, 3); DecodeChannelCoop(br, state, T, mc, ch, 3);
+  for (int k = 0; k < 4; k++) {       // (one call site: DecodeChannelCoop is inlined)
+    ChannelDesc ch;
+    ch.data = k == 0 ? m_ytox : k == 1 ? m_ytob : k == 2 ? m_blk : m_sharp;
+    ch.w = k < 2 ? (int)mcw : k == 2 ? (int)nb_blocks : (int)gbw; ch.h = k < 2 ? (int)mch : k == 2 ? 2 : (int)gbh; ch.stride = ch.w;
+    ch.hs = 0; ch.vs = 0;
+    before_channel(ch, k);
+    DecodeChannelCoop(br, state, T, mc, ch, k);
+  }
   if (lane == 0) {
     if (state != 0x130000u) SetError(f, kErrAnsFinalState);
     else if (br.BitPos() > limit) SetError(f, kErrOverrun);
@@ -5791,8 +5800,10 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     attr_set = true;
   }
   // batches that fill the GPU: four groups per workgroup (two per wavefront, paired large + small); otherwise one per wavefront
-  const bool big = (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128;
-  const uint32_t gpb = big ? kLfDecGroups : kLfDecWaves;
+  // (cfg.lf_force_big — tests: 1 the four-groups-per-workgroup shape whatever the batch size, 2 the same under the uncapped instantiation, -1 never)
+  const bool big4 = cfg.lf_force_big > 0 || (cfg.lf_force_big == 0 && (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128);
+  const bool big = big4 && cfg.lf_force_big != 2;
+  const uint32_t gpb = big4 ? kLfDecGroups : kLfDecWaves;
   if (big && cfg.lf_head_start) {
     std::lock_guard<std::mutex> lock(g_hf_sync_mu);
     int dev;

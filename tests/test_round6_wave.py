@@ -1,0 +1,91 @@
+"""GPU parity tests (-m gpu) of round 6's wave-wide entropy decoders (kernels.hip DecodeChannelWave / DecodeChannelWaveGen / HfDecodeWaveKernel) in the launch shapes
+the other tests do not reach: LfDecodeKernel with four LF groups per workgroup (what a cold pipeline of 256 frames launches — a variant of this round that made
+DecodeChannelCoop a real call passed every other test and failed there), the wave-wide HF kernel asked for explicitly on a batch, the decoders' fall-back on samples
+beyond their 32-bit arithmetic, and trees at the limits of the shapes they take.  Expected values: the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth_lib as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def jx(built):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import jpegxl_rs_amd as jx
+    return jx
+
+
+def batch_decode(jx, streams, lf_stride, hf_stride, options):
+    b = jx.BatchDecoder(0)
+    b.add_many(streams, "uint8", 3, threads=4)
+    b.set_lane_stride(lf_stride, hf_stride)
+    b.prepare()
+    for k, v in options.items():
+        b.set_option(k, v)
+    b.decode(); b.finish()
+    return [b.output(i) for i in range(len(streams))]
+
+
+@pytest.fixture(scope="module")
+def six_lf_groups():
+    """a frame of 3 x 2 LF groups (4200 x 2100) under the gradient LF tree and under the weighted-predictor (cjxl default-effort) one, with the oracle's pixels"""
+    img = S.synthetic_image(61, 4200, 2100)
+    out = []
+    for shape in (0, 1):
+        S.set_lf_tree_shape(shape)
+        try:
+            d = S.encode_vardct(img, seed=7 + shape, strategy_mix=2, epf_iters=1, gab=1)
+        finally:
+            S.set_lf_tree_shape(0)
+        out.append((d, O.decode(d).pixels("u8", 3)))
+    return out
+
+
+@pytest.mark.parametrize("force_big", [1, 2, -1])
+def test_lf_kernel_launch_shapes(jx, six_lf_groups, force_big):
+    """LfDecodeKernel: four groups per workgroup (a wavefront decodes two LF groups one after the other) under the register-capped and the uncapped instantiation, and
+    one group per wavefront — same pixels"""
+    streams = [d for d, _ in six_lf_groups]
+    got = batch_decode(jx, streams, 64, 1, {"lf_force_big": force_big})
+    for (d, ref), px in zip(six_lf_groups, got):
+        assert np.array_equal(px.reshape(ref.shape), ref), f"lf_force_big {force_big}: {int((px.reshape(ref.shape) != ref).sum())} samples differ"
+
+
+@pytest.mark.parametrize("lanes_per_wave", [1, 4, 0])
+def test_hf_kernels_agree(jx, six_lf_groups, lanes_per_wave):
+    """the wave-wide HF kernel (one group stream per wavefront), the sparse and the dense SIMT packing: same coefficients"""
+    streams = [d for d, _ in six_lf_groups]
+    got = batch_decode(jx, streams, 64, 1, {"hf_lanes_per_wave": lanes_per_wave})
+    for (d, ref), px in zip(six_lf_groups, got):
+        assert np.array_equal(px.reshape(ref.shape), ref), f"hf_lanes_per_wave {lanes_per_wave}"
+
+
+def test_wave_hf_strategies_and_bit_rates(jx):
+    """every transform mix of the synthesiser, EPF 0-3, low and high bit rates through the wave-wide HF kernel (tokens with extra bits, blocks whose order table goes
+    beyond its 64-entry head, empty blocks)"""
+    cases = []
+    for seed, (w, h, mix, epf, dist) in enumerate([(530, 400, 0, 0, 1.0), (640, 300, 1, 1, 0.3), (300, 620, 2, 2, 3.0), (1030, 520, 3, 3, 1.0), (260, 260, 2, 1, 8.0), (1300, 300, 1, 1, 0.1)]):
+        img = S.synthetic_image(100 + seed, w, h)
+        cases.append(S.encode_vardct(img, seed=seed + 1, strategy_mix=mix, epf_iters=epf, gab=1, distance=dist))
+    got = batch_decode(jx, cases, 64, 1, {"hf_lanes_per_wave": 1})
+    for d, px in zip(cases, got):
+        ref = O.decode(d).pixels("u8", 3)
+        assert np.array_equal(px.reshape(ref.shape), ref)
+
+
+def test_wave_lf_falls_back_on_large_samples(jx):
+    """quantised LF values beyond +-4095 under a weighted-predictor tree: the wave-wide decoder's 32-bit arithmetic gives the channel back to the general path (quant_lf at
+    its finest step makes the LF samples large)"""
+    img = S.synthetic_image(77, 520, 300)
+    S.set_quant_lf(5000); S.set_lf_tree_shape(1)
+    try:
+        d = S.encode_vardct(img, seed=3, strategy_mix=2, epf_iters=1, gab=1)
+    finally:
+        S.set_quant_lf(); S.set_lf_tree_shape(0)
+    ref = O.decode(d).pixels("u8", 3)
+    meta, px = jx.decoder_builder().decode_with(d, np.uint8)
+    assert np.array_equal(px.reshape(ref.shape), ref)
