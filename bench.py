@@ -720,7 +720,7 @@ def main():
                         "what": "BASELINE config 5: 7680x4320 VarDCT frames, linear-light HDR (values up to 4.0, intensity target 1000), gaborish + EPF 3 iterations, f32 RGB out (398 MB per frame); jobs of 32 through the pipeline",
                         "value": round(px / r5["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "ms_per_job": round(r5["elapsed"] / r5["steps"] * 1e3, 3), "single_image_ms": round(_median(ts), 2),
                         "stage_ms": {k: round(v, 4) for k, v in sm.items()}, "stage_gbs": {k: round(sb[k] / (sm[k] * 1e-3) / 1e9, 2) if sm[k] > 0 else None for k in sm},
-                        "roofline_filter_stage": {"bound": "hbm", "kernel": "GaborishKernel + EpfTileKernel<0> + <1> + <2> (LDS tiles; the last pass writes the pixels)", "achieved": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9, 2) if sm["filter"] > 0 else None,
+                        "roofline_filter_stage": {"bound": "hbm", "kernel": "EpfTileKernel<0> (gaborish applied to its own tile) + EpfTile12Kernel (passes 1 and 2, colour transform, writes the pixels); algorithmic bytes 12 B/px in + 12 B/px out, once (Batch::StageBytes)", "achieved": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9, 2) if sm["filter"] > 0 else None,
                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sb["filter"] / (sm["filter"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sm["filter"] > 0 else None,
                                                   "algorithmic_bytes_per_launch": sb["filter"], "avg_launch_ms": round(sm["filter"], 3)},
                         "compressed_bytes_per_frame": r5["compressed"], "verified_vs_oracle_bit_exact": r5.get("verified"), "private_plane_jobs": r5["private_plane_jobs"]}
@@ -748,7 +748,14 @@ def main():
                         "what": "BASELINE config 4: lossless Modular 8192x8192 u16 (one channel), default Squeeze chain, 1024 groups + 16 LF groups of residual channels; jobs of 2 or 4 (frames_per_job) through the pipeline; stage 'lf' = global "
                                 "Modular stream (ModularGlobalFastKernel), 'out' = group sub-streams (ModularGroupFastKernel), inverse Squeeze and the write stage",
                         "value": round(px / r4["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "frames_per_job": bm, "ms_per_job": round(r4["elapsed"] / r4["steps"] * 1e3, 3), "single_image_ms": round(_median(ts), 2),
-                        "stage_ms": {k: round(v, 4) for k, v in sm.items() if k in ("lf", "out")}, "compressed_bytes_per_frame": r4["compressed"], "verified_vs_oracle": r4.get("verified")}
+                        "stage_ms": {k: round(v, 4) for k, v in sm.items() if k in ("lf", "out")}, "compressed_bytes_per_frame": r4["compressed"], "verified_vs_oracle": r4.get("verified"),
+                        # the two stages of a Modular job against their own bounds: the entropy chains by samples per second (a serial chain per sub-stream: its HBM fraction is ~0 by
+                        # construction), the group stage (sub-streams, inverse Squeeze, write) also by its compulsory bytes — compressed sections in, u16 pixels out, once
+                        "roofline_global_stream": {"bound": "latency", "kernel": "ModularGlobalFastKernel (one sub-stream per frame)", "samples_per_s": None, "avg_launch_ms": round(sm["lf"], 3)},
+                        "roofline_group_stage": (lambda algo: {"bound": "hbm", "kernel": "ModularGroupFastKernel + ModInvSqueezeH/VKernel + ModularOutputKernel", "achieved": round(algo / (sm["out"] * 1e-3) / 1e9, 2) if sm["out"] > 0 else None,
+                                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (sm["out"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if sm["out"] > 0 else None,
+                                                               "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(sm["out"], 3),
+                                                               "samples_per_s": round(bm * 8192 * 8192 / (sm["out"] * 1e-3)) if sm["out"] > 0 else None})(bm * (r4["compressed"] + 8192 * 8192 * 2))}
                 except Exception as ex:
                     result["config"]["workload_8k_modular_squeeze_u16"] = {"error": repr(ex)}
                 torch.cuda.empty_cache(); jx.arena_pool_trim()

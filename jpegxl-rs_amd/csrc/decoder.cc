@@ -796,8 +796,10 @@ void Batch::StageBytes(uint64_t out[6]) const {
   //  lfpost LF dequantisation, smoothing, LLF, EPF sigma: 76 B per block
   //  hf     PassGroup sections -> the non-zero coefficients (i32 each; counted by the kernel, known after the first Finish)
   //  idct   coefficient planes as stored (dense i32: 12 B/px) -> 3 f32 planes (12 B/px)
-  //  filter fused gaborish + EPF + colour + write: 12 B/px in, C x bytes out.  Stage-by-stage: 24 B/px per filter pass
-  //  out    stage-by-stage frames only: 12 B/px in, C x bytes out (the fused kernel has written the pixels already)
+  //  filter gaborish + EPF (+ colour + write when the stage's last kernel writes the pixels — the fused kernel of the headline, the tiled EPF passes of every other
+  //         plain frame): 12 B/px in, C x bytes out — ONCE, however many kernels the stage is split into (their intermediate planes are traffic, not algorithmic
+  //         bytes: SURVEY.md 8(d)).  Frames whose filters end in the planes (upsampling, the frame tail of complex images): 12 B/px in, 12 B/px out
+  //  out    those frames only: 12 B/px in, C x bytes out
   for (int i = 0; i < 6; i++) out[i] = 0;
   for (size_t u = 0; u < images_.size(); u++) {
     const ImageEntry& e = *images_[u];
@@ -818,10 +820,11 @@ void Batch::StageBytes(uint64_t out[6]) const {
     out[2] += hf_sec + (u < hf_written_.size() ? (uint64_t)hf_written_[u] * 4 : 0);
     out[3] += npx * (12 + 12);
     const bool fused = p.lf.gab && p.lf.epf_iters == 1 && e.ih.xyb_encoded && SimpleTransfer(e.ih) && p.upsampling == 1 && !e.complex && !cfg.force_unfused_filters;
-    if (fused) out[4] += npx * (12 + out_px);
+    const bool any_filter = p.lf.gab || p.lf.epf_iters > 0;
+    const bool epf_writes = !fused && p.lf.epf_iters >= 1 && p.upsampling == 1 && !e.complex && cfg.debug_stop_after == 0;    // kernels.hip EpfWritesOutput
+    if (fused || epf_writes) out[4] += npx * (12 + out_px);
     else {
-      const uint32_t nstages = (p.lf.gab ? 1 : 0) + (p.lf.epf_iters >= 3 ? 3 : p.lf.epf_iters);
-      out[4] += npx * 24 * nstages;
+      if (any_filter) out[4] += npx * 24;
       out[5] += npx * (12 + out_px);
     }
   }

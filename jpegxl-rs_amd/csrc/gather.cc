@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <vector>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -72,7 +73,7 @@ int JxlHipCommGetUniqueId(uint8_t id[JXL_HIP_COMM_ID_BYTES]) {
 }
 
 JxlHipComm* JxlHipCommCreate(int device, int rank, int world, const uint8_t id[JXL_HIP_COMM_ID_BYTES]) {
-  if (world < 1 || rank < 0 || rank >= world || !id) { Fail("JxlHipCommCreate: bad rank / world / id"); return nullptr; }
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) { Fail("JxlHipCommCreate: bad rank / world / id"); return nullptr; }    // (a single rank needs no id exchange and no RCCL: jxl_hip.h)
   if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); Fail("JxlHipCommCreate: no such HIP device"); return nullptr; }
   JxlHipComm* c = new JxlHipCommStruct();
   c->rank = rank; c->world = world; c->device = device;
@@ -95,12 +96,12 @@ void JxlHipCommDestroy(JxlHipComm* c) {
 
 int JxlHipGatherFramesRagged(JxlHipComm* c, const void* send, size_t frame_bytes, const int* frames_per_rank, void* recv, int root, int chunk_frames, void* hip_stream) {
   if (!c || !frames_per_rank || root < 0 || root >= c->world || frame_bytes == 0) { Fail("JxlHipGatherFrames: bad arguments"); return 1; }
+  if (c->world > 1024) { Fail("JxlHipGatherFrames: more than 1024 ranks"); return 1; }
   hipStream_t s = (hipStream_t)hip_stream;
   const int mine = frames_per_rank[c->rank];
   if (mine < 0 || (mine > 0 && !send) || (c->rank == root && !recv)) { Fail("JxlHipGatherFrames: missing buffer"); return 1; }
   if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); Fail("JxlHipGatherFrames: no such HIP device"); return 1; }
-  size_t off[1025];
-  if (c->world > 1024) { Fail("JxlHipGatherFrames: more than 1024 ranks"); return 1; }
+  std::vector<size_t> off((size_t)c->world + 1);      // (first frame of every rank's shard in the consumer's buffer; off the stack: ADVICE r5)
   int longest = 0;
   off[0] = 0;
   for (int r = 0; r < c->world; r++) { if (frames_per_rank[r] < 0) { Fail("JxlHipGatherFrames: negative shard length"); return 1; } off[r + 1] = off[r] + (size_t)frames_per_rank[r]; longest = std::max(longest, frames_per_rank[r]); }
@@ -131,9 +132,8 @@ int JxlHipGatherFramesRagged(JxlHipComm* c, const void* send, size_t frame_bytes
 
 int JxlHipGatherFrames(JxlHipComm* c, const void* send, size_t frame_bytes, int frames, void* recv, int root, int chunk_frames, void* hip_stream) {
   if (!c || frames < 0 || c->world > 1024) { Fail("JxlHipGatherFrames: bad arguments"); return 1; }
-  int per[1024];
-  for (int r = 0; r < c->world; r++) per[r] = frames;
-  return JxlHipGatherFramesRagged(c, send, frame_bytes, per, recv, root, chunk_frames, hip_stream);
+  std::vector<int> per((size_t)c->world, frames);
+  return JxlHipGatherFramesRagged(c, send, frame_bytes, per.data(), recv, root, chunk_frames, hip_stream);
 }
 
 int JxlHipAllReduceSumI64(JxlHipComm* c, int64_t* device_values, size_t count, void* hip_stream) {

@@ -1062,8 +1062,9 @@ JxlDecoderStatus JxlHipImageOutSize(const uint8_t* data, size_t size, const JxlP
 }
 
 // the pipelines keep ~15 HIP streams busy at once; the runtime maps streams onto 4 hardware queues by default and kernels of streams that share a queue serialise.
-// Set (unless the caller chose a value) before the HIP runtime reads it, i.e. when this library is loaded.
-__attribute__((constructor)) static void JxlHipDefaultHwQueues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// Set (unless the caller chose a value) before the HIP runtime reads it, i.e. when this library is loaded — the runtime reads the variable once, when it initialises, so
+// the first pipeline would be too late.  A process-wide side effect of loading the library: JXL_HIP_KEEP_HW_QUEUES=1 leaves the variable alone.
+__attribute__((constructor)) static void JxlHipDefaultHwQueues() { if (!getenv("JXL_HIP_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 int JxlHipDebugWriteJpegSampled(const uint8_t* jbrd, size_t jbrd_size, uint32_t width, uint32_t height, const uint32_t* sampling, const int16_t* coefficients,
                                 const int32_t* quant_tables, uint8_t* out, size_t* out_size) {

@@ -1159,6 +1159,38 @@ __device__ void DecodeChannelWave(BitReaderP& br, uint32_t& state_io, const ModT
   WaveSync();
 }
 
+// ---- one token of a wave-wide decoder without speculation (the cluster is known): HfDecodeWaveKernel's count tokens, the big-tree form of DecodeChannelWaveGen
+struct WaveTok { uint32_t u; int32_t v; };      // a decoded hybrid integer and its UnpackSigned()
+// one token under a known (uniform) cluster base: the non-speculative form (the "number of non-zeros" token of a block)
+__device__ __forceinline__ WaveTok WaveTokenAt(WaveBits& bits, uint32_t& state, uint32_t abase, uint32_t cbase, uint32_t cfg, uint32_t la) {
+  const uint32_t pmask = (1u << (12 - la)) - 1;
+  const uint32_t slot = (state & 0xFFF) >> (12 - la), pos = state & pmask, hi = state >> 12;
+  const uint2 e = LdS<uint2>(abase + slot * 8);
+  const uint32_t cr = Uniform(LdS<uint16_t>(cbase + slot * 2));
+  const bool hit = pos >= (cr & 0xFFu);
+  const uint32_t sw = Uniform(hit ? e.y : e.x);
+  state = (sw & 0xFFFu) * hi + hi + pos + ((sw >> 12) & 0xFFFu);
+  int32_t v = (int32_t)sw >> 24;
+  if (state < (1u << 16)) { state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
+  WaveTok t;
+  if (v != kWideEscape) { t.v = v; t.u = (uint32_t)((v << 1) ^ (v >> 31)); return t; }
+  uint32_t tok = hit ? (cr >> 8) : slot;
+  const uint32_t split_exp = cfg & 0xFF, split = 1u << split_exp;
+  if (tok >= split) {
+    const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+    const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb))) & 31;
+    const uint32_t low = tok & ((1u << lsb) - 1);
+    tok >>= lsb;
+    if ((int)nbits > bits.avail) bits.Refill();
+    const uint32_t xb = (uint32_t)(bits.buf & ((1ull << nbits) - 1));
+    bits.buf >>= nbits; bits.avail -= (int)nbits;
+    const uint32_t hb = (1u << msb) | (tok & ((1u << msb) - 1));
+    tok = (((hb << nbits) | xb) << lsb) | low;
+    bits.Refill();
+  }
+  t.u = tok; t.v = UnpackSigned(tok);
+  return t;
+}
 // ---- wave-wide decode of a channel under a general MA tree, with or without the weighted predictor (round 6) ---------------------------------------------------
 // Two tree shapes.  THRESH: every split tests property 15 — the largest neighbouring error of the weighted predictor — and every leaf predicts with it: the LF
 // coefficients of a default-effort cjxl encode (enc_modular.cc "WP fixed DC"); the leaf is a popcount as in DecodeChannelWave.  GEN: what cjxl's lossless modes
@@ -1192,14 +1224,22 @@ struct WaveWpRow {          // carries of one row (uniform unless noted)
   int32_t e0prev, aprev, e1x;          // per lane (sub-predictor lane & 3): error of the sample before, A of the sample before, stored error of the row above at x
   int32_t toobig;
 };
-template <bool ROW0, bool LAST, bool USE_WP, bool GEN>
+// TREE 0: thresholds on property 15 (popcount); 1: general, up to 63 splits (linear forms, path match); 2: big — up to 128 splits per property of cjxl's lossless set
+// {W+N-NW, W-NW, NW-N, N-NE, N-NN, weighted-predictor error}, hundreds per subtree: the lanes hold the nodes grouped by property (two register rows of 64 per property), a
+// compare per row yields every decision, every node lane writes its chosen child into a next-pointer table in LDS, and the walk from the root is a chain of 16 dependent LDS
+// reads (leaves point at themselves) that the compiler interleaves with the weighted predictor's arithmetic; the entropy symbol follows without speculation.
+constexpr int kBigRows = 12;
+struct WaveBigLane { int32_t thr[kBigRows]; uint32_t a[kBigRows], b[kBigRows], addr[kBigRows]; uint32_t next_off, root, node_base, wide_off, cut_off, nrows; };
+template <bool ROW0, bool LAST, bool USE_WP, int TREE>
 __device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, WaveWpRow& r, const int xl, const uint32_t x, const int32_t p1v, const int32_t p1s, const int32_t p2v, const int32_t te1v, const int32_t te1s,
-                                             int32_t& curv, int32_t& tecur, const uint32_t e1, const uint32_t e0, const uint32_t div_off, const WaveWpLane& L, const WaveGenLane& G, const WaveChan& wc) {
+                                             int32_t& curv, int32_t& tecur, const uint32_t e1, const uint32_t e0, const uint32_t div_off, const WaveWpLane& L, const WaveGenLane& G, const WaveBigLane& BG, const WaveChan& wc) {
+  constexpr bool GEN = TREE == 1;
   const uint32_t la = wc.la, pmask = (1u << (12 - la)) - 1, lane = threadIdx.x & 63;
-  // --- alias reads
+  // --- alias reads (the speculative forms: every leaf's cluster at once)
   const uint32_t slot = (state & 0xFFF) >> (12 - la);
-  const uint2 e = LdS<uint2>(wc.abase + slot * 8);
-  const uint32_t cr = LdS<uint16_t>(wc.cbase + slot * 2);
+  uint2 e = make_uint2(0, 0);
+  uint32_t cr = 0;
+  if (TREE != 2) { e = LdS<uint2>(wc.abase + slot * 8); cr = LdS<uint16_t>(wc.cbase + slot * 2); }
   const uint32_t pos = state & pmask, hi = state >> 12, hp = hi + pos;
   // --- neighbours and true errors
   const int32_t W = r.left;
@@ -1240,10 +1280,29 @@ __device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, W
     if (abs(teNE) > abs(perr)) perr = teNE;
     r.aprev = A; r.e1x = C;
   }
-  int k;
+  int k = 0;
   int32_t guess;
   const int32_t wpguess = (pred + 3) >> 3;
-  if (!GEN) {
+  int32_t v = 0;
+  if (TREE == 2) {
+    // every node's decision, its chosen child into the next-pointer table, the walk
+    const int32_t pv[6] = {(int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW), (int32_t)((uint32_t)W - (uint32_t)NW), (int32_t)((uint32_t)NW - (uint32_t)N),
+                           (int32_t)((uint32_t)N - (uint32_t)NE), (int32_t)((uint32_t)N - (uint32_t)NN), perr};
+#pragma unroll
+    for (int rr = 0; rr < kBigRows; rr++)
+      if ((rr & 1) == 0 || (BG.nrows >> (rr >> 1)) & 1u) StS<uint32_t>(BG.addr[rr], pv[rr >> 1] > BG.thr[rr] ? BG.a[rr] : BG.b[rr]);
+    uint32_t at = BG.root;
+#pragma unroll
+    for (int i = 0; i < 16; i++) at = LdS<uint32_t>(BG.next_off + at * 4);
+    uint4 nd = LdS<uint4>(BG.node_base + at * 16);
+    while ((int32_t)Uniform(nd.x) >= 0) { at = LdS<uint32_t>(BG.next_off + at * 4); nd = LdS<uint4>(BG.node_base + at * 16); }      // (paths longer than 16)
+    const uint32_t leaf = Uniform(nd.z), pk = leaf & 0xFF, cl = leaf >> 8;
+    const int32_t m = min(N, W), M = max(N, W);
+    const int32_t grad = max(m, min(M, pv[0]));
+    guess = pk == 6 ? wpguess : (pk == 5 ? grad : (pk == 1 ? W : 0));
+    const uint32_t cfg = wc.cfg_uniform != 0xFFFFFFFFu ? wc.cfg_uniform : Uniform(LdS<uint32_t>(wc.cfg_off + 4 * cl));
+    v = WaveTokenAt(bits, state, BG.wide_off + ((cl << la) << 3), BG.cut_off + ((cl << la) << 1), cfg, la).v;
+  } else if (!GEN) {
     k = __builtin_popcountll(__ballot(perr > wc.thr));
     guess = wpguess;
   } else {
@@ -1260,11 +1319,12 @@ __device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, W
     guess = __builtin_amdgcn_readlane(G.is6 ? wpguess : (G.is5 ? grad : (G.is1 ? W : 0)), k);
   }
   // --- ANS symbol
+  if (TREE != 2) {
   const bool hit = pos >= (cr & 0xFFu);
   const uint32_t cand = hit ? e.y : e.x;
   const uint32_t sw = (uint32_t)__builtin_amdgcn_readlane((int)cand, k);
   state = (sw & 0xFFFu) * hi + hp + ((sw >> 12) & 0xFFFu);
-  int32_t v = (int32_t)sw >> 24;
+  v = (int32_t)sw >> 24;
   if (state < (1u << 16)) { asm volatile("" ::: "memory"); state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
   if (__builtin_expect(v == kWideEscape, 0)) {
     const uint32_t crk = (uint32_t)__builtin_amdgcn_readlane((int)cr, k);
@@ -1285,6 +1345,7 @@ __device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, W
       bits.Refill();
     }
     v = UnpackSigned(tok);
+  }
   }
   const int32_t val = (int32_t)((uint32_t)v + (uint32_t)guess);
   if (USE_WP) { if ((uint32_t)(val + 4095) > 8190u) r.toobig = 1; }
@@ -1351,6 +1412,47 @@ __device__ void WaveAnalyseGen(const ModTables& T, uint32_t subroot, int chan, i
     push(n.a, mlo | blo, mhi | bhi, wlo | blo, whi | bhi);
   }
   StS<int>(L + kWaHdr + 0, ok); StS<uint32_t>(L + kWaHdr + 4, ni); StS<uint32_t>(L + kWaHdr + 8, nl); StS<int>(L + kWaHdr + 24, has_y); StS<int>(L + kWaHdr + 36, uses_wp); StS<int>(L + kWaHdr + 40, thresh);
+}
+// The big shape's analysis (lane 0): the subtree's dynamic nodes grouped by property — node indices, up to 128 per property, at the start of the LUT region —, the
+// next-pointer entries that never change (leaves point at themselves, static splits at the child their property picks).  Header: ok, has_y, uses_wp, counts per property.
+constexpr uint32_t kWbList = 0, kWbCnt = kWaHdr + 48, kWbNextEntries = 1025;       // (entry 1024: where the unused node lanes write)
+__device__ __forceinline__ int WaveBigProp(int p) { return p >= 9 && p <= 13 ? p - 9 : (p == 15 ? 5 : -1); }
+__device__ void WaveAnalyseBig(const ModTables& T, uint32_t next_off, int chan, int32_t stream_id, int y, bool explore) {
+  const uint32_t wb = T.wb, L = wb + kLutOff, stack = wb + kWorkOff + 64;
+  int ok = 1, has_y = 0, uses_wp = 0;
+  uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, visited = 0;
+  int sp = 0;
+  StS<uint32_t>(stack, 0u); sp = 1;
+  while (sp > 0 && ok) {
+    const uint32_t pos = LdS<uint32_t>(stack + 4 * --sp);
+    if (pos >= 1024 || ++visited > 2048) { ok = 0; break; }
+    const TreeNode n = T.Node(pos);
+    if (n.prop < 0) {
+      const int pr = (int)(n.a & 0xFF);
+      if ((pr != 0 && pr != 1 && pr != 5 && pr != 6) || n.val != 0 || n.b != 1) { ok = 0; break; }
+      if (pr == 6) uses_wp = 1;
+      if (!explore) StS<uint32_t>(next_off + 4 * pos, pos);
+      continue;
+    }
+    if (sp + 2 > 190) { ok = 0; break; }
+    if (n.prop == 0 || n.prop == 1 || n.prop == 2) {
+      if (n.prop == 2) has_y = 1;
+      if (n.prop == 2 && explore) { StS<uint32_t>(stack + 4 * sp++, n.a); StS<uint32_t>(stack + 4 * sp++, n.b); continue; }
+      const int32_t v = n.prop == 0 ? chan : (n.prop == 1 ? stream_id : y);
+      const uint32_t child = v > n.val ? n.a : n.b;
+      if (!explore) StS<uint32_t>(next_off + 4 * pos, child);
+      StS<uint32_t>(stack + 4 * sp++, child);
+      continue;
+    }
+    const int pi = WaveBigProp(n.prop);
+    if (pi < 0 || cnt[pi] >= 128) { ok = 0; break; }
+    if (pi == 5) uses_wp = 1;
+    if (!explore) StS<uint16_t>(L + kWbList + 2 * ((uint32_t)pi * 128 + cnt[pi]), (uint16_t)pos);
+    cnt[pi]++;
+    StS<uint32_t>(stack + 4 * sp++, n.a); StS<uint32_t>(stack + 4 * sp++, n.b);
+  }
+  StS<int>(L + kWaHdr + 0, ok); StS<int>(L + kWaHdr + 24, has_y); StS<int>(L + kWaHdr + 36, uses_wp);
+  for (int i = 0; i < 6; i++) StS<uint32_t>(L + kWbCnt + 4 * i, cnt[i]);
 }
 // All 64 lanes; WaveAnalyseGen(explore) said yes.  false: a sample beyond the range of the 32-bit arithmetic (nothing of `br` / `state_io` was touched: the caller
 // decodes the channel again the general way).
@@ -3153,7 +3255,9 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
                                                                                  uint32_t* __restrict__ sync, uint32_t epoch, int prio) {
   // sync[0]: workgroups of this launch that have started, sync[1]: number of the last HF launch whose workgroups all have
   // (the LF stage of a later batch waits for that before its own workgroups are dispatched, see HeadStartKernel)
-  if (sync && threadIdx.x == 0 && atomicAdd(sync, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(sync, 0u); __threadfence(); atomicMax(sync + 1, epoch); }
+  // (a counter per launch — slot 2 + epoch % 16 —: up to three HF launches of different sizes run at the same time, and one shared counter could pass both targets
+  // without matching either, never reset, and every later LF head start would run into its 2 ms timeout: ADVICE r5)
+  if (sync && threadIdx.x == 0) { uint32_t* ctr = sync + 2 + (epoch & 15u); if (atomicAdd(ctr, 1u) + 1 == gridDim.x * gridDim.y) { atomicExch(ctr, 0u); __threadfence(); atomicMax(sync + 1, epoch); } }
   const FrameDev& f = frames[blockIdx.y];
   // (the status word is read once per workgroup — another workgroup of the launch may set it at any time, and wavefronts that disagreed about it
   // would part ways in front of the barriers below; the 8 spare bytes behind the 39 order pointers carry it)
@@ -3396,37 +3500,6 @@ template <bool ALL_LDS, bool SUB, bool MULTI> __global__ __launch_bounds__(1024)
 constexpr uint32_t kHwOrdOff = (kSimtBcmOff + (uint32_t)sizeof(BlockCtxDev) + 15) & ~15u;   // 39 x 64 u16: heads of the order tables
 constexpr uint32_t kHwCodeOff = kHwOrdOff + 39 * 128;
 constexpr uint32_t kHwWaves = 4;
-struct WaveTok { uint32_t u; int32_t v; };      // a decoded hybrid integer and its UnpackSigned()
-// one token under a known (uniform) cluster base: the non-speculative form (the "number of non-zeros" token of a block)
-__device__ __forceinline__ WaveTok WaveTokenAt(WaveBits& bits, uint32_t& state, uint32_t abase, uint32_t cbase, uint32_t cfg, uint32_t la) {
-  const uint32_t pmask = (1u << (12 - la)) - 1;
-  const uint32_t slot = (state & 0xFFF) >> (12 - la), pos = state & pmask, hi = state >> 12;
-  const uint2 e = LdS<uint2>(abase + slot * 8);
-  const uint32_t cr = Uniform(LdS<uint16_t>(cbase + slot * 2));
-  const bool hit = pos >= (cr & 0xFFu);
-  const uint32_t sw = Uniform(hit ? e.y : e.x);
-  state = (sw & 0xFFFu) * hi + hi + pos + ((sw >> 12) & 0xFFFu);
-  int32_t v = (int32_t)sw >> 24;
-  if (state < (1u << 16)) { state = (state << 16) | (uint32_t)(bits.buf & 0xFFFFu); bits.buf >>= 16; bits.avail -= 16; bits.Refill(); }
-  WaveTok t;
-  if (v != kWideEscape) { t.v = v; t.u = (uint32_t)((v << 1) ^ (v >> 31)); return t; }
-  uint32_t tok = hit ? (cr >> 8) : slot;
-  const uint32_t split_exp = cfg & 0xFF, split = 1u << split_exp;
-  if (tok >= split) {
-    const uint32_t msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
-    const uint32_t nbits = (split_exp - (msb + lsb) + ((tok - split) >> (msb + lsb))) & 31;
-    const uint32_t low = tok & ((1u << lsb) - 1);
-    tok >>= lsb;
-    if ((int)nbits > bits.avail) bits.Refill();
-    const uint32_t xb = (uint32_t)(bits.buf & ((1ull << nbits) - 1));
-    bits.buf >>= nbits; bits.avail -= (int)nbits;
-    const uint32_t hb = (1u << msb) | (tok & ((1u << msb) - 1));
-    tok = (((hb << nbits) | xb) << lsb) | low;
-    bits.Refill();
-  }
-  t.u = tok; t.v = UnpackSigned(tok);
-  return t;
-}
 __global__ __launch_bounds__(64 * kHwWaves) void HfDecodeWaveKernel(const FrameDev* __restrict__ frames, uint32_t lds_bytes) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.is_modular || FrameFailed(f)) return;
@@ -5714,8 +5787,8 @@ static uint32_t* HfSyncWords(int* dev_out) {
   if (dev < 0 || dev >= 64) dev = 0;
   *dev_out = dev;
   if (!g_hf_sync[dev]) {
-    if (hipMalloc((void**)&g_hf_sync[dev], 2 * sizeof(uint32_t)) != hipSuccess) return nullptr;
-    (void)hipMemset(g_hf_sync[dev], 0, 2 * sizeof(uint32_t));
+    if (hipMalloc((void**)&g_hf_sync[dev], 18 * sizeof(uint32_t)) != hipSuccess) return nullptr;      // [0] unused, [1] last HF launch whose workgroups have all started, [2, 18) a start counter per launch in flight
+    (void)hipMemset(g_hf_sync[dev], 0, 18 * sizeof(uint32_t));
   }
   return g_hf_sync[dev];
 }

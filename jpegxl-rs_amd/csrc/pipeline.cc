@@ -32,8 +32,18 @@ void StreamWait(void* stream, void* ev) { HIP_CHECK(hipStreamWaitEvent((hipStrea
 size_t Align256(size_t v) { return (v + 255) / 256 * 256; }
 }  // namespace
 
+// The caller's current device comes back at the end of every public entry point (a thread that drives pipelines on several GPUs, or mixes its own HIP code
+// with the pipeline, must not find its device changed after a Submit or a Wait).  The pipeline's own threads stay on their device.
+namespace {
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(int device) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != device) (void)hipSetDevice(device); else prev = -1; }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
 Pipeline::Pipeline(int device, const PipelineOptions& opt) : device_(device), opt_(opt) {
-  HIP_CHECK(hipSetDevice(device_));
+  DeviceScope scope(device_);
   opt_.in_flight = std::max(1, std::min(opt_.in_flight, 64));
   opt_.hf_streams = std::max(1, std::min(opt_.hf_streams, 12));
   opt_.lf_streams = std::max(1, std::min(opt_.lf_streams, 32));
@@ -78,7 +88,7 @@ Pipeline::~Pipeline() {
   cv_.notify_all();
   for (auto& t : workers_) t.join();
   if (issuer_.joinable()) issuer_.join();
-  (void)hipSetDevice(device_);
+  DeviceScope scope(device_);
   for (void* s : lf_side_) (void)hipStreamSynchronize((hipStream_t)s);
   for (void* s : hf_side_) (void)hipStreamSynchronize((hipStream_t)s);
   (void)hipStreamSynchronize((hipStream_t)main_);
@@ -147,7 +157,7 @@ int64_t Pipeline::Submit(const uint8_t* const* datas, const size_t* sizes, int n
   bool idle = next_issue_ == next_ticket_;
   if (idle) for (auto& kv : jobs_) if (kv.second->state != kHarvested) { idle = false; break; }
   if (idle) {
-    HIP_CHECK(hipSetDevice(device_));
+    DeviceScope scope(device_);
     GrowSharedWhenIdle();
     cold_count_ = 0;
   }
@@ -370,7 +380,7 @@ void Pipeline::Harvest(Job* j) {
   Slot& s = *slots_[(size_t)(j->ticket % nbuf_)];
   std::lock_guard<std::mutex> slot_lock(s.mu);
   { std::lock_guard<std::mutex> lock(mu_); if (j->state >= kHarvested) return; }
-  (void)hipSetDevice(device_);
+  DeviceScope scope(device_);
   Batch& bt = *s.batch;
   const size_t n = j->datas.size();
   bool readback_ok = false;
@@ -456,7 +466,7 @@ void Pipeline::WaitAll() {
 void Pipeline::ResetClock() {
   WaitAll();
   std::lock_guard<std::mutex> lock(mu_);
-  (void)hipSetDevice(device_);
+  DeviceScope scope(device_);
   (void)hipStreamSynchronize((hipStream_t)main_);
   Record(clock_event_, main_);
   (void)hipStreamSynchronize((hipStream_t)main_);
@@ -465,7 +475,7 @@ void Pipeline::ResetClock() {
 
 StageTimes Pipeline::CollectTimes(int* runs) {
   WaitAll();
-  (void)hipSetDevice(device_);
+  DeviceScope scope(device_);
   StageTimes t; int total = 0;
   for (auto& s : slots_) {
     int r = 0;

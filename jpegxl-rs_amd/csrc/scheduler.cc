@@ -63,15 +63,24 @@ class DeviceScheduler {
     collector_ = std::thread([this] { CollectorLoop(); });
     completer_ = std::thread([this] { CompleterLoop(); });
   }
+  // Shutdown order: the collector first — it may be inside SubmitJob and push one more job —, then the completer, which only leaves once the collector has and
+  // nothing is in flight (every request gets its Finish), then the callers that are still inside Decode (copying their pixels out of the staging buffers freed below).
   ~DeviceScheduler() {
     { std::lock_guard<std::mutex> lock(mu_); shutdown_ = true; }
     cv_.notify_all(); done_cv_.notify_all();
     if (collector_.joinable()) collector_.join();
+    { std::lock_guard<std::mutex> lock(mu_); collector_done_ = true; }
+    done_cv_.notify_all();
     if (completer_.joinable()) completer_.join();
+    { std::unique_lock<std::mutex> lock(mu_); idle_cv_.wait(lock, [&] { return callers_ == 0; }); }
     pipe_.reset();
     (void)hipSetDevice(device_);
     for (auto& b : free_staging_) (void)hipHostFree(b.first);
   }
+
+  // Enter / Leave bracket a caller's stay (SchedulerDecode takes Enter under the table lock, so that SchedulerShutdown never deletes a scheduler somebody is about to use)
+  void Enter() { std::lock_guard<std::mutex> lock(mu_); callers_++; }
+  void Leave() { std::lock_guard<std::mutex> lock(mu_); if (--callers_ == 0) idle_cv_.notify_all(); }
 
   int Decode(const uint8_t* data, size_t size, const OutputSpec& spec, void* dst, size_t dst_size, std::string* error) {
     Request r;
@@ -160,7 +169,9 @@ class DeviceScheduler {
         // A window for company: threads that were released together by a job come back together, a few milliseconds apart (each copies its pixels out first), and one job
         // of 64 frames costs the GPU little more than one of a single frame (the entropy stages are latency chains per stream).  The job goes out when nothing new has
         // arrived for quiet_us, after max_wait_us at the latest, or when it is full.
-        if ((int)pending_.size() < max_job_ && max_wait_us_ > 0) {
+        // (a lone caller — nobody else inside Decode, nothing in flight whose callers could come back — does not wait for company that cannot come)
+        const bool alone = callers_ <= 1 && inflight_count_ == 0;
+        if ((int)pending_.size() < max_job_ && max_wait_us_ > 0 && !alone) {
           const auto t_first = std::chrono::steady_clock::now();
           auto t_last = t_first;
           size_t seen = pending_.size();
@@ -191,8 +202,8 @@ class DeviceScheduler {
       InFlight job;
       {
         std::unique_lock<std::mutex> lock(mu_);
-        done_cv_.wait(lock, [&] { return shutdown_ || !inflight_.empty(); });
-        if (inflight_.empty()) { if (shutdown_) return; continue; }
+        done_cv_.wait(lock, [&] { return (shutdown_ && collector_done_) || !inflight_.empty(); });
+        if (inflight_.empty()) { if (shutdown_ && collector_done_) return; continue; }
         job = inflight_.front(); inflight_.pop_front();
       }
       PipelineJobResult res;
@@ -230,27 +241,31 @@ class DeviceScheduler {
   int inflight_count_ = 0;
   size_t expected_back_ = 0; std::chrono::steady_clock::time_point expected_until_{}; int return_us_ = 25000;
   int64_t jobs_ = 0, images_ = 0;
-  bool shutdown_ = false;
+  bool shutdown_ = false, collector_done_ = false;
+  int callers_ = 0;                       // threads between Enter and Leave
+  std::condition_variable idle_cv_;
   std::thread collector_, completer_;
 };
 
 std::mutex g_sched_mu;
 DeviceScheduler* g_sched[64] = {nullptr};       // (never destroyed at exit: the HIP runtime may be gone by then; SchedulerShutdown for tests)
 
-DeviceScheduler* For(int device) {
-  if (device < 0 || device >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(g_sched_mu);
-  if (!g_sched[device]) g_sched[device] = new DeviceScheduler(device);
-  return g_sched[device];
-}
-
 }  // namespace
 
 int SchedulerDecode(int device, const uint8_t* data, size_t size, const OutputSpec& spec, void* dst, size_t dst_size, std::string* error) {
   DeviceScheduler* s = nullptr;
-  try { s = For(device); } catch (const std::exception& e) { if (error) *error = e.what(); return 1; }
+  try {
+    if (device >= 0 && device < 64) {
+      std::lock_guard<std::mutex> lock(g_sched_mu);
+      if (!g_sched[device]) g_sched[device] = new DeviceScheduler(device);
+      s = g_sched[device];
+      s->Enter();
+    }
+  } catch (const std::exception& e) { if (error) *error = e.what(); return 1; }
   if (!s) { if (error) *error = "no scheduler for this device"; return 1; }
-  return s->Decode(data, size, spec, dst, dst_size, error);
+  const int rc = s->Decode(data, size, spec, dst, dst_size, error);
+  s->Leave();
+  return rc;
 }
 
 void SchedulerStats(int device, int64_t* jobs, int64_t* images) {
@@ -260,7 +275,7 @@ void SchedulerStats(int device, int64_t* jobs, int64_t* images) {
   if (device >= 0 && device < 64 && g_sched[device]) g_sched[device]->Stats(jobs, images);
 }
 
-void SchedulerShutdown() {
+void SchedulerShutdown() {     // legal at any time: requests that have not been submitted fail ("scheduler shut down"), the ones in flight complete, their callers leave, then the schedulers go
   std::lock_guard<std::mutex> lock(g_sched_mu);
   for (auto& s : g_sched) { delete s; s = nullptr; }
 }
