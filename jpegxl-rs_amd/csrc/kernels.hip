@@ -208,11 +208,23 @@ struct FastCode {
   __device__ __forceinline__ uint32_t Cluster(uint32_t ctx) const { return ctx_map_off != kNotInLds ? LdS<uint8_t>(ctx_map_off + ctx) : LdG(ctx_map_g + ctx); }
   __device__ __forceinline__ uint32_t Cfg(uint32_t cl) const { return cfg_off != kNotInLds ? LdS<uint32_t>(cfg_off + cl * 4) : LdG(cfg_g + cl); }
   __device__ __forceinline__ uint64_t Alias(uint32_t cluster, uint32_t slot) const {
-    if (alias_off == kNotInLds) return LdG(alias_g + (cluster << log_alpha) + slot);
-    return LdS<uint64_t>(alias_off + (((cluster << log_alpha) + slot) << 3));
+    if (alias_off == kNotInLds && wide_off == kNotInLds) return LdG(alias_g + (cluster << log_alpha) + slot);
+    if (alias_off != kNotInLds) return LdS<uint64_t>(alias_off + (((cluster << log_alpha) + slot) << 3));
+    const uint32_t idx = (cluster << log_alpha) + slot;      // (LdAliasAt: defined below)
+    const uint2 w = LdS<uint2>(wide_off + (idx << 3));
+    const uint32_t cr = LdS<uint16_t>(cut_off + (idx << 1));
+    return PackAlias(cr & 0xFFu, cr >> 8, (w.x & 0xFFFu) + 1, (w.y >> 12) & 0xFFFu, (w.y & 0xFFFu) + 1);
   }
 };
 
+// alias entry `idx` (= cluster << log_alpha | slot) out of LDS: the plain 8-byte table, or — a code too large for both layouts keeps only the wide one (StageCode) — put
+// together again from the wide pair and the {cutoff, aliased symbol} word (the paths that take the channels the wave-wide decoders turn down)
+__device__ __forceinline__ uint64_t LdAliasAt(uint32_t alias_off, uint32_t wide_off, uint32_t cut_off, uint32_t idx) {
+  if (alias_off != kNotInLds) return LdS<uint64_t>(alias_off + (idx << 3));
+  const uint2 w = LdS<uint2>(wide_off + (idx << 3));
+  const uint32_t cr = LdS<uint16_t>(cut_off + (idx << 1));
+  return PackAlias(cr & 0xFFu, cr >> 8, (w.x & 0xFFFu) + 1, (w.y >> 12) & 0xFFFu, (w.y & 0xFFFu) + 1);
+}
 __device__ __forceinline__ uint32_t FastSymbol(BitReaderP& br, uint32_t& state, const FastCode& c, uint32_t cluster) {
   const uint32_t la = c.log_alpha;
   const uint32_t res = state & 0xFFF;
@@ -335,13 +347,18 @@ __device__ uint32_t StageCode(const DevCode& g, FastCode& fc, uint32_t base, uin
     }
   }
   const uint32_t n_alias = g.num_clusters << g.log_alpha;
-  if (with_plain && used + n_alias * 8 <= budget) {
+  const uint32_t wide_bytes = n_alias * 8 + ((n_alias * 2 + 15) & ~15u);
+  // both layouts when they fit; the wide one alone when only it does and the caller reads it (its readers are the fast ones; the others put the plain entry together
+  // again: LdAliasAt); else the plain one as before
+  const bool wide_ok = with_wide && fc.cfg_off != kNotInLds && used + wide_bytes <= budget;
+  if (with_plain && used + n_alias * 8 + (wide_ok ? wide_bytes : 0) <= budget) {
+    for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) StS<uint64_t>(base + used + i * 8, LdG(g.alias + i));
+    fc.alias_off = base + used; used += n_alias * 8;
+  } else if (with_plain && !wide_ok && used + n_alias * 8 <= budget) {
     for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) StS<uint64_t>(base + used + i * 8, LdG(g.alias + i));
     fc.alias_off = base + used; used += n_alias * 8;
   }
   {
-    // the wide layout behind the plain one, when both fit (with_plain = false: a kernel that only reads the wide one)
-    const uint32_t wide_bytes = n_alias * 8 + ((n_alias * 2 + 15) & ~15u);
     if (with_wide && fc.cfg_off != kNotInLds && used + wide_bytes <= budget) {
       const uint32_t wo = base + used, co = wo + n_alias * 8;
       for (uint32_t i = threadIdx.x; i < n_alias; i += blockDim.x) {
@@ -812,7 +829,7 @@ __device__ __forceinline__ void DecodeRowsBallot(BitReaderP& br, uint32_t& state
       // ANS symbol + hybrid integer out of LDS (all lanes read the same addresses: broadcasts)
       const uint32_t res = state & 0xFFF;
       const uint32_t i = res >> (12 - la), pos_ = res & ((1u << (12 - la)) - 1);
-      const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
+      const uint64_t e = LdAliasAt(alias_off, T.code.wide_off, T.code.cut_off, (cluster << la) + i);
       const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
       const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
       const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
@@ -1224,11 +1241,12 @@ struct WaveWpRow {          // carries of one row (uniform unless noted)
   int32_t e0prev, aprev, e1x;          // per lane (sub-predictor lane & 3): error of the sample before, A of the sample before, stored error of the row above at x
   int32_t toobig;
 };
-// TREE 0: thresholds on property 15 (popcount); 1: general, up to 63 splits (linear forms, path match); 2: big — up to 128 splits per property of cjxl's lossless set
-// {W+N-NW, W-NW, NW-N, N-NE, N-NN, weighted-predictor error}, hundreds per subtree: the lanes hold the nodes grouped by property (two register rows of 64 per property), a
+// TREE 0: thresholds on property 15 (popcount); 1: general, up to 63 splits (linear forms, path match); 2: big — up to 192 splits per property (768 in all) of cjxl's lossless set
+// {W+N-NW, W-NW, NW-N, N-NE, N-NN, weighted-predictor error}, hundreds per subtree: the lanes hold the nodes grouped by property (three register rows of 64 per property), a
 // compare per row yields every decision, every node lane writes its chosen child into a next-pointer table in LDS, and the walk from the root is a chain of 16 dependent LDS
 // reads (leaves point at themselves) that the compiler interleaves with the weighted predictor's arithmetic; the entropy symbol follows without speculation.
-constexpr int kBigRows = 12;
+constexpr int kBigTreeNodes = 160;      // frames with larger MA trees take the Modular group kernel's big-tree instantiation
+constexpr int kBigRows = 18, kBigRowsPerProp = 3, kBigPerProp = 64 * kBigRowsPerProp, kBigNodes = 768;
 struct WaveBigLane { int32_t thr[kBigRows]; uint32_t a[kBigRows], b[kBigRows], addr[kBigRows]; uint32_t next_off, root, node_base, wide_off, cut_off, nrows; };
 template <bool ROW0, bool LAST, bool USE_WP, int TREE>
 __device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, WaveWpRow& r, const int xl, const uint32_t x, const int32_t p1v, const int32_t p1s, const int32_t p2v, const int32_t te1v, const int32_t te1s,
@@ -1289,8 +1307,7 @@ __device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, W
     const int32_t pv[6] = {(int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW), (int32_t)((uint32_t)W - (uint32_t)NW), (int32_t)((uint32_t)NW - (uint32_t)N),
                            (int32_t)((uint32_t)N - (uint32_t)NE), (int32_t)((uint32_t)N - (uint32_t)NN), perr};
 #pragma unroll
-    for (int rr = 0; rr < kBigRows; rr++)
-      if ((rr & 1) == 0 || (BG.nrows >> (rr >> 1)) & 1u) StS<uint32_t>(BG.addr[rr], pv[rr >> 1] > BG.thr[rr] ? BG.a[rr] : BG.b[rr]);
+    for (int rr = 0; rr < kBigRows; rr++) StS<uint32_t>(BG.addr[rr], pv[rr / kBigRowsPerProp] > BG.thr[rr] ? BG.a[rr] : BG.b[rr]);      // (unused node lanes write the spare entry)
     uint32_t at = BG.root;
 #pragma unroll
     for (int i = 0; i < 16; i++) at = LdS<uint32_t>(BG.next_off + at * 4);
@@ -1415,50 +1432,66 @@ __device__ void WaveAnalyseGen(const ModTables& T, uint32_t subroot, int chan, i
 }
 // The big shape's analysis (lane 0): the subtree's dynamic nodes grouped by property — node indices, up to 128 per property, at the start of the LUT region —, the
 // next-pointer entries that never change (leaves point at themselves, static splits at the child their property picks).  Header: ok, has_y, uses_wp, counts per property.
-constexpr uint32_t kWbList = 0, kWbCnt = kWaHdr + 48, kWbNextEntries = 1025;       // (entry 1024: where the unused node lanes write)
+constexpr uint32_t kWbList = 0, kWbCnt = kWaHdr + 48, kWbOff = kWaHdr + 72, kWbNextEntries = 1025;       // (entry 1024: where the unused node lanes write)
+static_assert(kWbList + 2 * kBigNodes <= kWaHdr, "node list in front of the header");
 __device__ __forceinline__ int WaveBigProp(int p) { return p >= 9 && p <= 13 ? p - 9 : (p == 15 ? 5 : -1); }
 __device__ void WaveAnalyseBig(const ModTables& T, uint32_t next_off, int chan, int32_t stream_id, int y, bool explore) {
   const uint32_t wb = T.wb, L = wb + kLutOff, stack = wb + kWorkOff + 64;
   int ok = 1, has_y = 0, uses_wp = 0;
-  uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, visited = 0;
-  int sp = 0;
-  StS<uint32_t>(stack, 0u); sp = 1;
-  while (sp > 0 && ok) {
-    const uint32_t pos = LdS<uint32_t>(stack + 4 * --sp);
-    if (pos >= 1024 || ++visited > 2048) { ok = 0; break; }
-    const TreeNode n = T.Node(pos);
-    if (n.prop < 0) {
-      const int pr = (int)(n.a & 0xFF);
-      if ((pr != 0 && pr != 1 && pr != 5 && pr != 6) || n.val != 0 || n.b != 1) { ok = 0; break; }
-      if (pr == 6) uses_wp = 1;
-      if (!explore) StS<uint32_t>(next_off + 4 * pos, pos);
-      continue;
+  uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, off[6] = {0, 0, 0, 0, 0, 0};
+  // two walks: the first counts the nodes per property (and fills the constant next-pointer entries), the second puts the node indices into their property's stretch of the list
+  for (int pass = 0; pass < (explore ? 1 : 2) && ok; pass++) {
+    uint32_t visited = 0, placed[6] = {0, 0, 0, 0, 0, 0};
+    int sp = 0;
+    StS<uint32_t>(stack, 0u); sp = 1;
+    while (sp > 0 && ok) {
+      const uint32_t pos = LdS<uint32_t>(stack + 4 * --sp);
+      if (pos >= 1024 || ++visited > 2048) { ok = 0; break; }
+      const TreeNode n = T.Node(pos);
+      if (n.prop < 0) {
+        const int pr = (int)(n.a & 0xFF);
+        if ((pr != 0 && pr != 1 && pr != 5 && pr != 6) || n.val != 0 || n.b != 1) { ok = 0; break; }
+        if (pr == 6) uses_wp = 1;
+        if (!explore && pass == 0) StS<uint32_t>(next_off + 4 * pos, pos);
+        continue;
+      }
+      if (sp + 2 > 190) { ok = 0; break; }
+      if (n.prop == 0 || n.prop == 1 || n.prop == 2) {
+        if (n.prop == 2) has_y = 1;
+        if (n.prop == 2 && explore) { StS<uint32_t>(stack + 4 * sp++, n.a); StS<uint32_t>(stack + 4 * sp++, n.b); continue; }
+        const int32_t v = n.prop == 0 ? chan : (n.prop == 1 ? stream_id : y);
+        const uint32_t child = v > n.val ? n.a : n.b;
+        if (!explore && pass == 0) StS<uint32_t>(next_off + 4 * pos, child);
+        StS<uint32_t>(stack + 4 * sp++, child);
+        continue;
+      }
+      const int pi = WaveBigProp(n.prop);
+      if (pi < 0) { ok = 0; break; }
+      if (pi == 5) uses_wp = 1;
+      if (pass == 0) { if (++cnt[pi] > (uint32_t)kBigPerProp) { ok = 0; break; } }
+      else StS<uint16_t>(L + kWbList + 2 * (off[pi] + placed[pi]++), (uint16_t)pos);
+      StS<uint32_t>(stack + 4 * sp++, n.a); StS<uint32_t>(stack + 4 * sp++, n.b);
     }
-    if (sp + 2 > 190) { ok = 0; break; }
-    if (n.prop == 0 || n.prop == 1 || n.prop == 2) {
-      if (n.prop == 2) has_y = 1;
-      if (n.prop == 2 && explore) { StS<uint32_t>(stack + 4 * sp++, n.a); StS<uint32_t>(stack + 4 * sp++, n.b); continue; }
-      const int32_t v = n.prop == 0 ? chan : (n.prop == 1 ? stream_id : y);
-      const uint32_t child = v > n.val ? n.a : n.b;
-      if (!explore) StS<uint32_t>(next_off + 4 * pos, child);
-      StS<uint32_t>(stack + 4 * sp++, child);
-      continue;
+    if (pass == 0) {
+      uint32_t total = 0;
+      for (int i = 0; i < 6; i++) { off[i] = total; total += cnt[i]; }
+      if (total > (uint32_t)kBigNodes) ok = 0;
     }
-    const int pi = WaveBigProp(n.prop);
-    if (pi < 0 || cnt[pi] >= 128) { ok = 0; break; }
-    if (pi == 5) uses_wp = 1;
-    if (!explore) StS<uint16_t>(L + kWbList + 2 * ((uint32_t)pi * 128 + cnt[pi]), (uint16_t)pos);
-    cnt[pi]++;
-    StS<uint32_t>(stack + 4 * sp++, n.a); StS<uint32_t>(stack + 4 * sp++, n.b);
   }
   StS<int>(L + kWaHdr + 0, ok); StS<int>(L + kWaHdr + 24, has_y); StS<int>(L + kWaHdr + 36, uses_wp);
-  for (int i = 0; i < 6; i++) StS<uint32_t>(L + kWbCnt + 4 * i, cnt[i]);
+  for (int i = 0; i < 6; i++) { StS<uint32_t>(L + kWbCnt + 4 * i, cnt[i]); StS<uint32_t>(L + kWbOff + 4 * i, off[i]); }
 }
 // All 64 lanes; WaveAnalyseGen(explore) said yes.  false: a sample beyond the range of the 32-bit arithmetic (nothing of `br` / `state_io` was touched: the caller
 // decodes the channel again the general way).
-template <bool USE_WP>
+// BIG: the big-tree form (WaveAnalyseBig said yes; the next-pointer table takes the wavefront's bit-stream window / row buffers, which this decoder does not use)
+template <bool USE_WP, bool BIG>
 __device__ bool DecodeChannelWaveGen(BitReaderP& br, uint32_t& state_io, const ModTables& T, const ChannelDesc& ch, const WPHeader& hdr, int chan_in, int32_t stream_in, bool has_y_in) {
   const uint32_t lane = threadIdx.x & 63, wb = T.wb, LR = wb + kLutOff;
+  static_assert(kWinOff + kWbNextEntries * 4 <= kWaveLds, "next-pointer table in the per-wavefront LDS region");
+  WaveBigLane BG;
+  BG.next_off = wb + kWinOff; BG.root = 0; BG.node_base = Uniform(T.node_base); BG.wide_off = Uniform(T.code.wide_off); BG.cut_off = Uniform(T.code.cut_off); BG.nrows = 0;
+#pragma unroll
+  for (int rr = 0; rr < kBigRows; rr++) { BG.thr[rr] = 0x7FFFFFFF; BG.a[rr] = 0; BG.b[rr] = 0; BG.addr[rr] = BG.next_off + 1024 * 4; }
   const int w = (int)Uniform((uint32_t)ch.w), h = (int)Uniform((uint32_t)ch.h), chan = (int)Uniform((uint32_t)chan_in);
   const int32_t stream_id = (int32_t)Uniform((uint32_t)stream_in);
   const bool has_y = Uniform(has_y_in ? 1u : 0u) != 0;
@@ -1499,7 +1532,25 @@ __device__ bool DecodeChannelWaveGen(BitReaderP& br, uint32_t& state_io, const M
   bool thresh = false;
   for (int y = 0; y < h && !r.toobig; y++) {
     int32_t* p = ch.data + (size_t)y * ch.stride;
-    if (y == 0 || has_y) {
+    if (BIG && (y == 0 || has_y)) {
+      // ---- this row's subtree: nodes grouped by property into the lanes, the constant entries of the next-pointer table
+      WaveSync();
+      if (lane == 0) WaveAnalyseBig(T, BG.next_off, chan, stream_id, y, false);
+      WaveSync();
+#pragma unroll
+      for (int rr = 0; rr < kBigRows; rr++) {
+        const uint32_t pi = (uint32_t)rr / kBigRowsPerProp, slot = (uint32_t)(rr % kBigRowsPerProp) * 64 + lane;
+        const uint32_t cnt = Uniform(LdS<uint32_t>(LR + kWbCnt + 4 * pi)), first = Uniform(LdS<uint32_t>(LR + kWbOff + 4 * pi));
+        BG.thr[rr] = 0x7FFFFFFF; BG.a[rr] = 0; BG.b[rr] = 0; BG.addr[rr] = BG.next_off + 1024 * 4;
+        if (slot < cnt) {
+          const uint32_t j = LdS<uint16_t>(LR + kWbList + 2 * (first + slot));
+          const TreeNode n = T.Node(j);
+          BG.thr[rr] = n.val; BG.a[rr] = n.a; BG.b[rr] = n.b; BG.addr[rr] = BG.next_off + j * 4;
+        }
+      }
+      WaveSync();
+    }
+    if (!BIG && (y == 0 || has_y)) {
       // ---- this row's subtree: linear forms, constants and leaves into the lanes
       WaveSync();
       if (lane == 0) WaveAnalyseGen(T, 0, chan, stream_id, y, false);
@@ -1551,10 +1602,11 @@ __device__ bool DecodeChannelWaveGen(BitReaderP& br, uint32_t& state_io, const M
         const int32_t p1s = WaveShl1(p1r[seg], nextp), te1s = WaveShl1(t1r[seg], nextt);
         int32_t curv = 0, tecur = 0;
         const int nn = last_seg ? n - 1 : n;
-#define JXL_GSAMPLE(R0, LA, GE, XL) WaveGenSample<R0, LA, USE_WP, GE>(bits, state, r, XL, (uint32_t)(x0 + (XL)), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, G, wc)
+#define JXL_GSAMPLE(R0, LA, GE, XL) WaveGenSample<R0, LA, USE_WP, GE>(bits, state, r, XL, (uint32_t)(x0 + (XL)), p1r[seg], p1s, p2r[seg], t1r[seg], te1s, curv, tecur, e1, e0, div_off, L, G, BG, wc)
 #define JXL_GROW(R0, GE) do { for (int xl = 0; xl < nn; xl++) JXL_GSAMPLE(R0, false, GE, xl); if (last_seg) JXL_GSAMPLE(R0, true, GE, nn); } while (0)
-        if (USE_WP && thresh) { if (y == 0) JXL_GROW(true, false); else JXL_GROW(false, false); }
-        else { if (y == 0) JXL_GROW(true, true); else JXL_GROW(false, true); }
+        if (BIG) { if (y == 0) JXL_GROW(true, 2); else JXL_GROW(false, 2); }
+        else if (USE_WP && thresh) { if (y == 0) JXL_GROW(true, 0); else JXL_GROW(false, 0); }
+        else { if (y == 0) JXL_GROW(true, 1); else JXL_GROW(false, 1); }
 #undef JXL_GROW
 #undef JXL_GSAMPLE
         if ((int)lane < n) StG(p + x0 + (int)lane, curv);
@@ -1575,7 +1627,8 @@ __device__ bool DecodeChannelWaveGen(BitReaderP& br, uint32_t& state_io, const M
 
 // BALLOT: general trees are evaluated by the whole wavefront (see the "ballot" path below) — the Modular kernels; the LF kernel
 // of the VarDCT path keeps the single-lane loops (register budget).
-template <bool BALLOT = false>
+// BALLOT 0: the LF kernel of the VarDCT path; 1: the Modular kernels; 2: the Modular kernels' big-tree instantiations (DecodeChannelWaveGen<.., BIG>: 72 more registers)
+template <int BALLOT = 0>
 // (inlined: as a real call — tried in round 6 for the build time, LfDecodeKernel is 85 000 instructions with six copies of this — the second LF group of a wavefront
 // failed with four groups per workgroup: JXL_COOP_NOINLINE keeps the experiment)
 #ifdef JXL_COOP_NOINLINE
@@ -1644,8 +1697,22 @@ __device__ JXL_COOP_ATTR void DecodeChannelCoop(BitReaderP& br, uint32_t& state,
       if (lane == 0) printf("wave gen: stream %u chan %d w %d h %d ok %d ni %u nl %u wp %d wp_off %x simple_ok %d\n", mc.stream_id, chan, ch.w, ch.h, gen_ok, LdS<uint32_t>(wb + kLutOff + kWaHdr + 4), LdS<uint32_t>(wb + kLutOff + kWaHdr + 8), gen_wp, T.wp_off, wave_ok);
 #endif
       if (gen_ok) {
-        if (!gen_wp) { if (DecodeChannelWaveGen<false>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, gen_has_y != 0)) return; }
-        else if (T.wp_off != 0xFFFFFFFFu) { if (DecodeChannelWaveGen<true>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, gen_has_y != 0)) return; }
+        if (!gen_wp) { if (DecodeChannelWaveGen<false, false>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, gen_has_y != 0)) return; }
+        else if (T.wp_off != 0xFFFFFFFFu) { if (DecodeChannelWaveGen<true, false>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, gen_has_y != 0)) return; }
+      } else if (BALLOT == 2) {
+        // ---- trees of hundreds of splits per stream (cjxl's lossless modes): the big-tree form — the Modular kernels only
+        if (lane == 0) WaveAnalyseBig(T, wb + kWinOff, chan, (int32_t)mc.stream_id, 0, /*explore=*/true);
+        WaveSync();
+        const int big_ok = LdS<int>(wb + kLutOff + kWaHdr), big_has_y = LdS<int>(wb + kLutOff + kWaHdr + 24), big_wp = LdS<int>(wb + kLutOff + kWaHdr + 36);
+        WaveSync();
+#ifdef JXL_WAVE_DEBUG
+        if (lane == 0) printf("wave big: stream %u chan %d w %d h %d ok %d wp %d cnt %u %u %u %u %u %u\n", mc.stream_id, chan, ch.w, ch.h, big_ok, big_wp, LdS<uint32_t>(wb + kLutOff + kWbCnt), LdS<uint32_t>(wb + kLutOff + kWbCnt + 4),
+                              LdS<uint32_t>(wb + kLutOff + kWbCnt + 8), LdS<uint32_t>(wb + kLutOff + kWbCnt + 12), LdS<uint32_t>(wb + kLutOff + kWbCnt + 16), LdS<uint32_t>(wb + kLutOff + kWbCnt + 20));
+#endif
+        if (big_ok) {
+          if (!big_wp) { if (DecodeChannelWaveGen<false, true>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, big_has_y != 0)) return; }
+          else if (T.wp_off != 0xFFFFFFFFu) { if (DecodeChannelWaveGen<true, true>(br, state, T, ch, mc.wp, chan, (int32_t)mc.stream_id, big_has_y != 0)) return; }
+        }
       }
     }
   }
@@ -1820,7 +1887,7 @@ __device__ JXL_COOP_ATTR void DecodeChannelCoop(BitReaderP& br, uint32_t& state,
   // ---- general trees / predictors with everything the sample loop touches in LDS (no vector-memory instruction, hence no
   // vmcnt wait, per sample): tree (whole or pruned), alias tables, bit-stream window, the three sample rows the properties
   // and predictors read, the WP state.  Rows up to kRowMax samples; wider channels take the loop below.
-  const bool lds_generic = !mc.slow && mc.max_prop < 16 && T.tree_in_lds && T.code.cfg_off != kNotInLds && T.code.alias_off != kNotInLds && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
+  const bool lds_generic = !mc.slow && mc.max_prop < 16 && T.tree_in_lds && T.code.cfg_off != kNotInLds && (T.code.alias_off != kNotInLds || T.code.wide_off != kNotInLds) && (uint32_t)ch.w <= kRowMax && (!use_wp || wp_in_lds);
   // ---- "ballot" path: the whole wavefront decodes the channel together.  Every value of the serial chain (neighbours, ANS state,
   // bit buffer, weighted-predictor arithmetic) is computed redundantly by all 64 lanes — that costs nothing, a wavefront
   // instruction takes the same time for one active lane as for 64 — and the part that used to be a pointer chase through LDS is
@@ -1938,7 +2005,7 @@ __device__ JXL_COOP_ATTR void DecodeChannelCoop(BitReaderP& br, uint32_t& state,
           // ANS symbol + hybrid integer out of LDS (same as DecodeChunkLds)
           const uint32_t res = state & 0xFFF;
           const uint32_t i = res >> (12 - la), pos_ = res & ((1u << (12 - la)) - 1);
-          const uint64_t e = LdS<uint64_t>(alias_off + (((cluster << la) + i) << 3));
+          const uint64_t e = LdAliasAt(alias_off, T.code.wide_off, T.code.cut_off, (cluster << la) + i);
           const uint32_t cfg = LdS<uint32_t>(cfg_off + cluster * 4);
           const uint32_t cutoff = (uint32_t)(e & 0xFF), right = (uint32_t)((e >> 8) & 0xFF);
           const uint32_t freq0 = (uint32_t)((e >> 16) & 0x1FFF), offs1 = (uint32_t)((e >> 29) & 0x1FFF), freq1 = (uint32_t)((e >> 42) & 0x1FFF);
@@ -5317,7 +5384,7 @@ __global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __
       }
       WaveSync();
     }
-    DecodeChannelCoop<true>(br, state, T, mc, ch, (int)c);
+    DecodeChannelCoop<2>(br, state, T, mc, ch, (int)c);
   }
   if (lane == 0) {
     if (state != 0x130000u) SetError(f, kErrAnsFinalState);
@@ -5344,7 +5411,9 @@ struct ModUnitShared {
 #ifndef JXL_MODGROUP_MINW
 #define JXL_MODGROUP_MINW 2     // wavefronts per SIMD the register budget of ModularGroupFastKernel allows (one serial chain per wavefront: residency is throughput)
 #endif
-__global__ __launch_bounds__(256, JXL_MODGROUP_MINW) void ModularGroupFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base, uint32_t local_pass) {
+// BIGTREE: the instantiation for frames whose MA tree has more than kBigTreeNodes nodes (subtrees of hundreds of splits per stream: the wave-wide decoder's big-tree form, at one
+// wavefront per SIMD — such trees are copied per wavefront, two wavefronts per workgroup, and the LDS admits no more anyway)
+template <bool BIGTREE> __global__ __launch_bounds__(256, BIGTREE ? 1 : JXL_MODGROUP_MINW) void ModularGroupFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base, uint32_t local_pass) {
   const FrameDev& f = frames[blockIdx.y];
   if (f.mod_nchan == 0 || f.single_section) return;
   if (local_pass ? !f.mod_local : !f.tree) return;   // (a frame without a global tree: every unit is decoded by the local pass)
@@ -5466,7 +5535,7 @@ __global__ __launch_bounds__(256, JXL_MODGROUP_MINW) void ModularGroupFastKernel
         }
         WaveSync();
       }
-      DecodeChannelCoop<true>(br, state, T, mc, d, k++);
+      DecodeChannelCoop<BIGTREE ? 2 : 1>(br, state, T, mc, d, k++);
     }
   } else {
     const int nch = U.nch;
@@ -5484,7 +5553,7 @@ __global__ __launch_bounds__(256, JXL_MODGROUP_MINW) void ModularGroupFastKernel
         }
         WaveSync();
       }
-      DecodeChannelCoop<true>(br, state, T, mc, cd, c);
+      DecodeChannelCoop<BIGTREE ? 2 : 1>(br, state, T, mc, cd, c);
     }
   }
   int fail = 0;
@@ -6080,8 +6149,8 @@ static void PlanModularLds(const LaunchCfg& cfg, uint32_t* nwaves_io, uint32_t* 
   static const bool no_wide = getenv("JXL_HIP_NO_WAVE_LF") != nullptr;
   if (!no_wide && code == (uint32_t)cfg.mod_code_bytes) {
     const uint32_t wide = code * 5 / 4 + 64;
-    if (total() + wide <= limit) code += wide;               // both layouts, or the plain one as before (the paths that take the channels the wave-wide decoders turn down — trees of hundreds of
-                                                             // nodes per stream: bench.jxl — need it in LDS; the wide one alone made that file 1.7x slower)
+    if (total() + wide <= limit) code += wide;               // both layouts
+    else { const uint32_t plain = code; code = wide; if (total() > limit) code = plain; }     // the wide one alone (bench.jxl: 66 KB of plain tables), or the plain one as before
   }
   *nwaves_io = nwaves;
   *tree_cap = cap;
@@ -6094,14 +6163,17 @@ void LaunchModularGroups(const FrameDev* frames, int nframes, int max_units, con
   uint32_t nwaves = kLfWaves, tree_cap, lds_tables, wp_base, lds_bytes;
   PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
   static bool attr_set = false;
-  if (!attr_set) { SetMaxDynamicLds((const void*)ModularGroupFastKernel, 160 * 1024 - 8192, "ModularGroupFastKernel"); attr_set = true; }
-  hipLaunchKernelGGL(ModularGroupFastKernel, dim3(DivUp(max_lf_groups + max_groups, (int)nwaves), nframes), dim3(64 * nwaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 0u);
+  if (!attr_set) { SetMaxDynamicLds((const void*)ModularGroupFastKernel<false>, 160 * 1024 - 8192, "ModularGroupFastKernel<false>"); SetMaxDynamicLds((const void*)ModularGroupFastKernel<true>, 160 * 1024 - 8192, "ModularGroupFastKernel<true>"); attr_set = true; }
+  const bool bigtree = cfg.max_tree_nodes > kBigTreeNodes;
+  if (bigtree) hipLaunchKernelGGL(ModularGroupFastKernel<true>, dim3(DivUp(max_lf_groups + max_groups, (int)nwaves), nframes), dim3(64 * nwaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 0u);
+  else hipLaunchKernelGGL(ModularGroupFastKernel<false>, dim3(DivUp(max_lf_groups + max_groups, (int)nwaves), nframes), dim3(64 * nwaves), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 0u);
   if (getenv("JXL_HIP_DEBUG_SYNC")) fprintf(stderr, "[jxl-hip] ModularGroupFastKernel: grid %d x %d, %u threads, %u B of dynamic LDS (tree cap %u, tables %u, wp base %u; max nodes %d, code %d B, any_wp %d)\n",
                                             DivUp(max_lf_groups + max_groups, (int)nwaves), nframes, 64 * nwaves, lds_bytes, tree_cap, lds_tables, wp_base, cfg.max_tree_nodes, cfg.mod_code_bytes, cfg.any_wp);
   if (cfg.any_local_trees) {   // units with a tree / code of their own: one wavefront per workgroup, each staging its own tables
     nwaves = 1;
     PlanModularLds(cfg, &nwaves, &tree_cap, &lds_tables, &wp_base, &lds_bytes);
-    hipLaunchKernelGGL(ModularGroupFastKernel, dim3(max_lf_groups + max_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 1u);
+    if (bigtree) hipLaunchKernelGGL(ModularGroupFastKernel<true>, dim3(max_lf_groups + max_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 1u);
+    else hipLaunchKernelGGL(ModularGroupFastKernel<false>, dim3(max_lf_groups + max_groups, nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base, 1u);
   }
 }
 uint32_t ModularGroupLdsBytes(const LaunchCfg& cfg) {   // dynamic LDS of the shared-tree launch of ModularGroupFastKernel (tests: plans above the 64 KB default)
