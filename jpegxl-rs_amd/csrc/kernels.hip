@@ -1308,11 +1308,12 @@ __device__ __forceinline__ void WaveGenSample(WaveBits& bits, uint32_t& state, W
                            (int32_t)((uint32_t)N - (uint32_t)NE), (int32_t)((uint32_t)N - (uint32_t)NN), perr};
 #pragma unroll
     for (int rr = 0; rr < kBigRows; rr++) StS<uint32_t>(BG.addr[rr], pv[rr / kBigRowsPerProp] > BG.thr[rr] ? BG.a[rr] : BG.b[rr]);      // (unused node lanes write the spare entry)
-    uint32_t at = BG.root;
+    // (the table holds ADDRESSES of entries — a hop is one LDS read with nothing to compute in between)
+    uint32_t at = BG.next_off + BG.root * 4;
 #pragma unroll
-    for (int i = 0; i < 16; i++) at = LdS<uint32_t>(BG.next_off + at * 4);
-    uint4 nd = LdS<uint4>(BG.node_base + at * 16);
-    while ((int32_t)Uniform(nd.x) >= 0) { at = LdS<uint32_t>(BG.next_off + at * 4); nd = LdS<uint4>(BG.node_base + at * 16); }      // (paths longer than 16)
+    for (int i = 0; i < 12; i++) at = LdS<uint32_t>(at);
+    uint4 nd = LdS<uint4>(BG.node_base + (at - BG.next_off) * 4);
+    while ((int32_t)Uniform(nd.x) >= 0) { at = LdS<uint32_t>(at); nd = LdS<uint4>(BG.node_base + (at - BG.next_off) * 4); }      // (paths longer than 12)
     const uint32_t leaf = Uniform(nd.z), pk = leaf & 0xFF, cl = leaf >> 8;
     const int32_t m = min(N, W), M = max(N, W);
     const int32_t grad = max(m, min(M, pv[0]));
@@ -1452,7 +1453,7 @@ __device__ void WaveAnalyseBig(const ModTables& T, uint32_t next_off, int chan, 
         const int pr = (int)(n.a & 0xFF);
         if ((pr != 0 && pr != 1 && pr != 5 && pr != 6) || n.val != 0 || n.b != 1) { ok = 0; break; }
         if (pr == 6) uses_wp = 1;
-        if (!explore && pass == 0) StS<uint32_t>(next_off + 4 * pos, pos);
+        if (!explore && pass == 0) StS<uint32_t>(next_off + 4 * pos, next_off + 4 * pos);
         continue;
       }
       if (sp + 2 > 190) { ok = 0; break; }
@@ -1461,7 +1462,7 @@ __device__ void WaveAnalyseBig(const ModTables& T, uint32_t next_off, int chan, 
         if (n.prop == 2 && explore) { StS<uint32_t>(stack + 4 * sp++, n.a); StS<uint32_t>(stack + 4 * sp++, n.b); continue; }
         const int32_t v = n.prop == 0 ? chan : (n.prop == 1 ? stream_id : y);
         const uint32_t child = v > n.val ? n.a : n.b;
-        if (!explore && pass == 0) StS<uint32_t>(next_off + 4 * pos, child);
+        if (!explore && pass == 0) StS<uint32_t>(next_off + 4 * pos, next_off + 4 * child);
         StS<uint32_t>(stack + 4 * sp++, child);
         continue;
       }
@@ -1545,7 +1546,7 @@ __device__ bool DecodeChannelWaveGen(BitReaderP& br, uint32_t& state_io, const M
         if (slot < cnt) {
           const uint32_t j = LdS<uint16_t>(LR + kWbList + 2 * (first + slot));
           const TreeNode n = T.Node(j);
-          BG.thr[rr] = n.val; BG.a[rr] = n.a; BG.b[rr] = n.b; BG.addr[rr] = BG.next_off + j * 4;
+          BG.thr[rr] = n.val; BG.a[rr] = BG.next_off + n.a * 4; BG.b[rr] = BG.next_off + n.b * 4; BG.addr[rr] = BG.next_off + j * 4;
         }
       }
       WaveSync();

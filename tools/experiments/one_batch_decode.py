@@ -11,7 +11,7 @@ def cached(name, fn, seed):
     if os.path.exists(p): return open(p, "rb").read()
     d = fn(seed); open(p, "wb").write(d); return d
 if kind == "4k":
-    streams, dtype, nch = bench.make_streams(min(n, 32), 3840, 2160, 1), "uint8", 3
+    streams, dtype, nch = bench.make_streams(min(n, 32), 3840, 2160, 1, tree_shape=int(os.environ.get("TREE_SHAPE", "0"))), "uint8", 3
 elif kind == "hdr8k":
     streams, dtype, nch = [cached("hdr8k", bench._make_8k_hdr, 6 + i) for i in range(min(n, 4))], "float32", 3
 else:
@@ -21,6 +21,7 @@ b = jx.BatchDecoder(0)
 b.add_many([streams[i % len(streams)] for i in range(n)], dtype, nch, threads=8)
 b.set_lane_stride(int(os.environ.get("LF_STRIDE", "8")), 1)
 b.prepare()
+if os.environ.get("HF_LPW"): b.set_option("hf_lanes_per_wave", int(os.environ["HF_LPW"]))      # (1: the wave-wide HF kernel — latency mode)
 for _ in range(reps):
     b.decode(); b.finish()
 print("decoded", n, "frames x", reps)
