@@ -2432,6 +2432,75 @@ __global__ __launch_bounds__(64) void LfPlaceSimtKernel(const FrameDev* __restri
   for (uint32_t i = 0; i < 8; i++) if (i * 32 < bg.gbw) StG(f.vb_count + (bg.gy * 8 + band) * f.xgroups + bg.gx * 8 + i, err ? 0u : gcnt[i]);
 }
 
+// The same walk with one band per WAVEFRONT (round 6, latency mode: a handful of frames).  The lane-per-band form above waits for a global load per varblock (the next list entry
+// is requested one step ahead; the walk of a band of a 4K frame — up to 8192 blocks — took 7 ms, a tenth of a single image's decode).  Here every lane runs the walk (scalar
+// registers), the (strategy, quantiser) list sits in two VGPRs 64 entries at a time, the coverage ring in LDS, the running offsets / counts of the band's eight groups in two VGPRs
+// (lane = group column).  Records, counts, flags and errors exactly as LfPlaceSimtKernel.
+__global__ __launch_bounds__(64) void LfPlaceWaveKernel(const FrameDev* __restrict__ frames, const uint2* __restrict__ units, uint32_t num_units) {
+  __shared__ uint32_t ring[256];
+  const uint32_t u = blockIdx.x, lane = threadIdx.x;
+  if (u >= num_units) return;
+  const uint2 unit = LdG(units + u);
+  const FrameDev& f = frames[unit.x];
+  const uint32_t g = unit.y & 0xFFFF, band = unit.y >> 16;
+  const BandGeom bg = BandGeometry(f, g, band);
+  uint32_t* cnt_out = f.place_cnt + g * 8 + band;
+  uint32_t k = Uniform(LdG(f.band_start + g * 8 + band));
+  if (k == 0xFFFFFFFFu) { if (lane == 0) { if (LdG(f.status) == 0) SetError(f, kErrVarblock); StG(cnt_out, 0u); } return; }
+  int32_t* scratch = f.lf_scratch + (uint64_t)g * f.lf_scratch_stride;
+  const uint32_t nb_blocks = Uniform((uint32_t)LdG(scratch + 1));
+  const uint32_t gbw = Uniform(bg.gbw), gbh = Uniform(bg.gbh), y_end = Uniform(bg.y_end);
+  const uint32_t mcw = (gbw + 7) / 8, mch = (gbh + 7) / 8;
+  const int32_t* m_blk = scratch + 16 + 2 * mcw * mch;
+  uint4* rec = f.place_rec + BandRecordBase(f, bg);
+  for (uint32_t i = lane; i < 256; i += 64) { const uint32_t wi = i & 7; ring[i] = wi * 32 >= gbw ? ~0u : (gbw - wi * 32 < 32 ? ~0u << (gbw - wi * 32) : 0u); }   // bits outside the group are pre-set
+  __syncthreads();
+  uint32_t goffv = 0, gcntv = 0;          // lane = group column of the band
+  uint32_t y = Uniform(bg.y_begin), wi = 0, count = 0, flags_acc = 0, err = 0;
+  uint32_t kbase = k & ~63u;
+  int32_t sv = kbase + lane < nb_blocks ? LdG(m_blk + kbase + lane) : -1, qv = kbase + lane < nb_blocks ? LdG(m_blk + nb_blocks + kbase + lane) : -1;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  const bool subsampled = f.subsampled != 0;
+  while (y < y_end) {
+    const uint32_t row = (y & 31) * 8;
+    const uint32_t cov = Uniform(ring[row + wi]);
+    if (cov == ~0u) { if (++wi == 8) { wi = 0; y++; } continue; }     // the first uncovered block of a row only moves right
+    const uint32_t xb = (uint32_t)__ffs((int)~cov) - 1, x = wi * 32 + xb;
+    if (k >= nb_blocks) { err = kErrVarblock; break; }
+    if (k >= kbase + 64) {
+      kbase = k & ~63u;
+      sv = kbase + lane < nb_blocks ? LdG(m_blk + kbase + lane) : -1; qv = kbase + lane < nb_blocks ? LdG(m_blk + nb_blocks + kbase + lane) : -1;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    const uint32_t s = (uint32_t)__builtin_amdgcn_readlane(sv, (int)(k - kbase)), q = (uint32_t)__builtin_amdgcn_readlane(qv, (int)(k - kbase));
+    k++;
+    if (s >= 27 || q > 255) { err = kErrBadValue; break; }           // (negative values wrap to large ones)
+    if (subsampled && s != 0) { err = kErrUnsupported; break; }      // chroma-subsampled frames: 8x8 DCT only
+    const uint32_t geo = StrategyGeo(s), cx = geo & 0xFF, cy = (geo >> 8) & 0xFF;
+    if (x + cx > gbw || y + cy > gbh || xb + cx > 32 || (y % 32) + cy > 32) { err = kErrVarblock; break; }
+    const uint32_t bits = (cx == 32 ? ~0u : (1u << cx) - 1u) << xb;
+    uint32_t clash = 0;
+    for (uint32_t iy = 0; iy < cy; iy++) { const uint32_t o = ((y + iy) & 31) * 8 + wi; const uint32_t wv = Uniform(ring[o]); clash |= wv & bits; if (lane == 0) ring[o] = wv | bits; }
+    if (clash) { err = kErrVarblock; break; }
+    if ((x % 4) + cx > 4 || (y % 4) + cy > 4) flags_acc |= 4u;
+    if (s == 1 || s == 2 || s == 3 || (s >= 12 && s <= 17)) flags_acc |= 8u;
+    if (s == 1 || s == 2 || (s >= 14 && s <= 17)) flags_acc |= 16u;
+    if (cx > 8 || cy > 8) flags_acc |= (x % 8) || (y % 8) ? 3u : 2u;
+    else if ((x % 8) + cx > 8 || (y % 8) + cy > 8) flags_acc |= 1u;
+    const uint32_t go = (uint32_t)__builtin_amdgcn_readlane((int)goffv, (int)wi), gc = (uint32_t)__builtin_amdgcn_readlane((int)gcntv, (int)wi);
+    goffv = lane == wi ? go + cx * cy * 64 : goffv;
+    gcntv = lane == wi ? gc + 1 : gcntv;
+    if (lane == 0) StG(rec + count, make_uint4(x | (y << 8) | (s << 16) | (q << 24), go, gc, geo));
+    count++;
+  }
+  if (lane == 0) {
+    if (err) { SetError(f, err); count = 0; }
+    if (flags_acc) atomicOr(f.frame_flags, flags_acc);
+    StG(cnt_out, count);
+  }
+  if (lane < 8 && lane * 32 < gbw) StG(f.vb_count + (bg.gy * 8 + band) * f.xgroups + bg.gx * 8 + lane, err ? 0u : gcntv);
+}
+
 __global__ __launch_bounds__(256) void LfPlaceExpandKernel(const FrameDev* __restrict__ frames, const uint2* __restrict__ units, uint32_t num_units) {
   const uint2 unit = LdG(units + blockIdx.x);
   const FrameDev& f = frames[unit.x];
@@ -5887,7 +5956,10 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
     if (time_it) (void)hipEventRecord(ev[1], (hipStream_t)stream);
     hipLaunchKernelGGL(LfBandStartKernel, dim3(DivUp(max_lf_groups, 4), nframes), dim3(256), 0, (hipStream_t)stream, frames);
     if (simt && simt->num_units) {
-      hipLaunchKernelGGL(LfPlaceSimtKernel, dim3(DivUp((int)simt->num_units, (int)kPlaceLanes)), dim3(64), 0, (hipStream_t)stream, frames, simt->units, simt->num_units);
+      // (a handful of frames: one band per wavefront — the lane-per-band walk waits for a global load per varblock, 7 ms for a 4K frame against 1)
+      static const bool no_wave_place = getenv("JXL_HIP_NO_WAVE_PLACE") != nullptr;
+      if (simt->num_units <= 512 && !no_wave_place) hipLaunchKernelGGL(LfPlaceWaveKernel, dim3(simt->num_units), dim3(64), 0, (hipStream_t)stream, frames, simt->units, simt->num_units);
+      else hipLaunchKernelGGL(LfPlaceSimtKernel, dim3(DivUp((int)simt->num_units, (int)kPlaceLanes)), dim3(64), 0, (hipStream_t)stream, frames, simt->units, simt->num_units);
       hipLaunchKernelGGL(LfPlaceExpandKernel, dim3(simt->num_units), dim3(256), 0, (hipStream_t)stream, frames, simt->units, simt->num_units);
     }
     if (time_it) {
