@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <vector>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -41,7 +42,11 @@ Rccl& Lib() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // JXL_HIP_RCCL_LIB: the library to bind instead (a test double that runs several ranks on one GPU: tests/fake_rccl)
+    const char* named = getenv("JXL_HIP_RCCL_LIB");
+    void* h = named && *named ? dlopen(named, RTLD_NOW | RTLD_LOCAL) : nullptr;
+    if (named && *named && !h) return;
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return;
