@@ -184,6 +184,13 @@ def _make_8k_modular(seed):
     return S.encode_modular(img, 16, False, 1)
 
 
+def _make_ycbcr420(seed):
+    """a 3840x2160 frame shaped like a lossless JPEG transcode: YCbCr, 4:2:0 chroma subsampling, 8x8 DCT only, no gaborish / EPF (tools/synth_ycbcr.h) — the frames `cjxl photo.jpg` writes,
+    minus the jbrd box"""
+    import synth_lib as S
+    return S.encode_ycbcr(S.synthetic_image(seed, 3840, 2160), "420", seed=seed)
+
+
 def _pool_map(fn, jobs):
     import multiprocessing as mp
     workers = max(1, min(len(jobs), int(os.environ.get("JXL_BENCH_SYNTH_WORKERS", "0")) or (os.cpu_count() or 1), 64))
@@ -512,6 +519,7 @@ def main():
     cjxl_streams = make_streams(min(args.distinct, args.cjxl_distinct), W, H, args.epf, seed0=1000 + 1000 * rank, texture=args.texture, tree_shape=1) if args.cjxl_distinct > 0 and not args.no_realistic else None
     hdr_streams = _pool_map(_make_8k_hdr, [6 + i for i in range(8)]) if do_extras and not args.no_8k else None
     mod_streams = _pool_map(_make_8k_modular, [5 + i for i in range(4)]) if do_extras and not args.no_8k else None
+    ycbcr_streams = _pool_map(_make_ycbcr420, [700 + i for i in range(16)]) if do_extras and not args.no_8k else None
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(streams, W, H)   # before any GPU runtime is initialised in this process (fork safety)
@@ -758,6 +766,17 @@ def main():
                                                                "samples_per_s": round(bm * 8192 * 8192 / (sm["out"] * 1e-3)) if sm["out"] > 0 else None})(bm * (r4["compressed"] + 8192 * 8192 * 2))}
                 except Exception as ex:
                     result["config"]["workload_8k_modular_squeeze_u16"] = {"error": repr(ex)}
+                torch.cuda.empty_cache(); jx.arena_pool_trim()
+            if ycbcr_streams:
+                # ---- JPEG-transcode-shaped frames: chroma-subsampled YCbCr takes IdctSubsampledKernel + ChromaUpsampleKernel and the general SIMT HF instantiation
+                try:
+                    rj = measure(ycbcr_streams, B=64, in_flight=4, lf_streams=4, consumer="none", steps=max(6, min(args.steps, 12)))       # (jobs of 256 with 11 in flight do not fit beside what the other legs keep pooled)
+                    result["config"]["workload_jpeg_transcode_420"] = {
+                        "what": "3840x2160 frames shaped like lossless JPEG transcodes (YCbCr 4:2:0, 8x8 DCT, no restoration filters; tools/synth_ycbcr.h), jobs of 64 (four in flight) through the pipeline, u8 RGB out",
+                        "value": round(rj["B"] * W * H * rj["steps"] / rj["elapsed"] / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(rj["elapsed"] / rj["steps"] * 1e3, 3),
+                        "stage_ms": {k: round(v, 4) for k, v in rj["stage_ms"].items()}, "compressed_bytes_per_frame": rj["compressed"], "verified_vs_oracle": rj.get("verified"), "distinct_frames": len(ycbcr_streams)}
+                except Exception as ex:
+                    result["config"]["workload_jpeg_transcode_420"] = {"error": repr(ex)}
                 torch.cuda.empty_cache(); jx.arena_pool_trim()
             try:
                 result.update(extras(jx, torch, streams, cjxl_streams, W, H, local_rank, O, np))
