@@ -25,6 +25,17 @@ def test_gather_symbols_exported_and_declared(jx):
     assert "JXL_HIP_COMM_ID_BYTES 128" in header
 
 
+def test_fake_rccl_double_exports_what_gather_cc_binds(built):
+    """the shared-memory double of librccl (tests/fake_rccl, built by tools/Makefile) carries every entry point csrc/gather.cc looks up"""
+    fake = os.path.join(ROOT, "tools", "_build", "libfake_rccl.so")
+    assert os.path.exists(fake), "make -C tools"
+    L = C.CDLL(fake)
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclAllReduce", "ncclGetErrorString"):
+        assert hasattr(L, name), name
+    uid = (C.c_uint8 * 128)()
+    assert L.ncclGetUniqueId(uid) == 0 and bytes(uid).startswith(b"fake_rccl_")
+
+
 @pytest.mark.gpu
 def test_gather_world_of_one_and_rccl_loads(jx):
     import torch
