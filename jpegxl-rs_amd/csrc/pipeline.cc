@@ -162,7 +162,15 @@ int64_t Pipeline::Submit(const uint8_t* const* datas, const size_t* sizes, int n
     cold_count_ = 0;
   }
   job->ticket = next_ticket_++;
-  job->cold_wide = cold_count_++ < opt_.wide_first || n <= opt_.small_job_frames;
+  {
+    // the first jobs of a cold pipeline take the one-wavefront-per-stream LF kernel — one after the other: job k's LF stage waits for job k - 1's (on the device), so that the first
+    // job's front is done after one kernel time instead of all of them after four (small jobs — latency mode — are wide too, but never chained: they overlap)
+    const bool cold = cold_count_ < opt_.wide_first && n > opt_.small_job_frames;
+    static const bool no_chain = getenv("JXL_HIP_NO_WIDE_CHAIN") != nullptr;
+    job->wide_chain = cold && !no_chain;
+    job->wide_after = job->wide_chain && cold_count_ > 0 ? job->ticket - 1 : -1;
+    job->cold_wide = cold_count_++ < opt_.wide_first || n <= opt_.small_job_frames;
+  }
   // results nobody collects: keep a bounded history
   while (jobs_.size() > (size_t)(8 * nbuf_ + 64)) {
     auto it = jobs_.begin();
@@ -205,7 +213,7 @@ void Pipeline::PrepareWorker(int worker) {
       }
     }
     PrepareJob(job.get(), worker);
-    { std::lock_guard<std::mutex> lock(mu_); job->state = kFrontIssued; }
+    { std::lock_guard<std::mutex> lock(mu_); job->state = kFrontIssued; if (job->wide_chain) wide_enqueued_ = std::max(wide_enqueued_, job->ticket); /* (also when its prepare failed: the job behind it must not wait for ever) */ }
     cv_.notify_all();
   }
 }
@@ -268,8 +276,18 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     }
     // the LF stage goes out right away, from this thread: the earlier it starts the better
     if (j->cold_wide && opt_.lane_stride_lf < 64) bt.cfg.lf_wide_once = 1;
+    if (j->wide_after >= 0) {
+      // behind the cold-start job before it: wait (host) until that job's LF stage is in its stream, then make ours wait for it (device)
+      std::unique_lock<std::mutex> lock(mu_);
+      cv_.wait(lock, [&] { return shutdown_ || wide_enqueued_ >= j->wide_after; });
+      auto it = jobs_.find(j->wide_after);
+      const bool chained = it != jobs_.end() && it->second->job_error.empty() && it->second->state < kHarvested;
+      lock.unlock();
+      if (chained) StreamWait(side, slots_[(size_t)(j->wide_after % nbuf_)]->lf_done);
+    }
     bt.RunPart(side, 5, opt_.timed != 0);           // LF decode + varblock placement: all the HF stage waits for
     Record(s.lf_done, side);
+    if (j->wide_chain) { { std::lock_guard<std::mutex> lock(mu_); wide_enqueued_ = std::max(wide_enqueued_, j->ticket); } cv_.notify_all(); }
     bt.RunPart(side, 6, opt_.timed != 0);           // LF post-processing: needed by the IDCT only
     Record(s.front_done, side);
   } catch (const std::exception& e) {

@@ -81,6 +81,8 @@ class Pipeline {
     std::string job_error;                     // the whole job failed (Prepare threw)
     State state = kQueued;
     bool hf_issued = false, waited = false, cold_wide = false;
+    bool wide_chain = false;     // one of the chained cold-start jobs
+    int64_t wide_after = -1;     // cold-start job (one-wavefront-per-stream LF kernel) behind another one: its LF stage waits for that job's (round 6: four at once took 95-120 ms each, one after the other 55)
     void* done_event = nullptr;                // (timing enabled) recorded behind the job's last copy
   };
   struct Slot {
@@ -114,6 +116,7 @@ class Pipeline {
   std::deque<std::shared_ptr<Job>> prep_queue_;
   int64_t next_ticket_ = 0, next_issue_ = 0, completed_upto_ = 0;   // completed_upto_: every ticket below has state >= kHarvested or has been dropped
   int64_t cold_count_ = 0;
+  int64_t wide_enqueued_ = -1;    // ticket of the last chained cold-start job whose LF stage has been enqueued (or given up)
   int64_t private_plane_jobs_ = 0;
   bool shutdown_ = false;
   std::vector<std::thread> workers_;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: how many LF stages of a cold pipeline should take the wave-wide kernel (it is 2x faster per stream now) — K = 20 value and the time the first step is done
-for wf in 0 1 2 3 4 6; do
+for wf in ${WF_LIST:-0 1 2 3 4 6}; do
   python bench.py --gpus 1 --steps 20 --warmup 5 --no-realistic --no-extras --no-cpu-baseline --wide-first $wf 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
