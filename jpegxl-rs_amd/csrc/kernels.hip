@@ -5972,7 +5972,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   // this launch: one wavefront per stream for every frame (shorter latency, the whole GPU's SIMDs) — not for batches whose SIMT launch is the weighted-predictor
   // instantiation: per stream the lane-serial form is the faster one there (1.5 against 2.8 us per sample), four of these wide launches at the start of a cold
   // pipeline took 1.0-2.3 s each (profiles/r04_notes.md)
-  const int wide = cfg.lf_wide_once && !(simt && simt->num_lanes && simt->any_wp);
+  static const bool wide_wp = getenv("JXL_HIP_WIDE_WP") != nullptr;       // experiments
+  static const int force_big_env = getenv("JXL_HIP_LF_FORCE_BIG") ? atoi(getenv("JXL_HIP_LF_FORCE_BIG")) : 0;
+  const int wide = cfg.lf_wide_once && (wide_wp || !(simt && simt->num_lanes && simt->any_wp));
   int simt_mode = wide ? 1 : 0;           // LfDecodeKernel's take_simt_frames: 0 legacy frames only, 1 every frame, 2 legacy frames + the streams the SIMT kernel handed back
   if (simt && simt->num_lanes && !wide) {
     // SIMT frames: the entropy decode on a handful of wavefronts (one stream per lane)
@@ -6016,8 +6018,9 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   }
   // batches that fill the GPU: four groups per workgroup (two per wavefront, paired large + small); otherwise one per wavefront
   // (cfg.lf_force_big — tests: 1 the four-groups-per-workgroup shape whatever the batch size, 2 the same under the uncapped instantiation, -1 never)
-  const bool big4 = cfg.lf_force_big > 0 || (cfg.lf_force_big == 0 && (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128);
-  const bool big = big4 && cfg.lf_force_big != 2;
+  const int force_big = cfg.lf_force_big ? cfg.lf_force_big : (wide ? force_big_env : 0);
+  const bool big4 = force_big > 0 || (force_big == 0 && (size_t)nframes * DivUp(max_lf_groups, (int)kLfDecGroups) >= 128);
+  const bool big = big4 && force_big != 2;
   const uint32_t gpb = big4 ? kLfDecGroups : kLfDecWaves;
   if (big && cfg.lf_head_start) {
     std::lock_guard<std::mutex> lock(g_hf_sync_mu);

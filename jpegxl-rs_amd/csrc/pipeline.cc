@@ -276,12 +276,15 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     }
     // the LF stage goes out right away, from this thread: the earlier it starts the better
     if (j->cold_wide && opt_.lane_stride_lf < 64) bt.cfg.lf_wide_once = 1;
-    if (j->wide_after >= 0) {
+    // (jobs whose LF trees use the weighted predictor keep the SIMT kernel whatever lf_wide_once says — LaunchLfDecode —: 420 ms a launch, nothing to chain)
+    const bool lf_wide = bt.cfg.lf_wide_once && !bt.Info("lf_simt_wp");
+    if (j->wide_chain) { std::lock_guard<std::mutex> lock(mu_); j->lf_wide = lf_wide; }
+    if (j->wide_after >= 0 && lf_wide) {
       // behind the cold-start job before it: wait (host) until that job's LF stage is in its stream, then make ours wait for it (device)
       std::unique_lock<std::mutex> lock(mu_);
       cv_.wait(lock, [&] { return shutdown_ || wide_enqueued_ >= j->wide_after; });
       auto it = jobs_.find(j->wide_after);
-      const bool chained = it != jobs_.end() && it->second->job_error.empty() && it->second->state < kHarvested;
+      const bool chained = it != jobs_.end() && it->second->job_error.empty() && it->second->state < kHarvested && it->second->lf_wide;
       lock.unlock();
       if (chained) StreamWait(side, slots_[(size_t)(j->wide_after % nbuf_)]->lf_done);
     }

@@ -82,6 +82,7 @@ class Pipeline {
     State state = kQueued;
     bool hf_issued = false, waited = false, cold_wide = false;
     bool wide_chain = false;     // one of the chained cold-start jobs
+    bool lf_wide = false;        // ... whose LF stage really is the one-wavefront-per-stream launch (set before wide_enqueued_ reaches its ticket)
     int64_t wide_after = -1;     // cold-start job (one-wavefront-per-stream LF kernel) behind another one: its LF stage waits for that job's (round 6: four at once took 95-120 ms each, one after the other 55)
     void* done_event = nullptr;                // (timing enabled) recorded behind the job's last copy
   };
