@@ -456,7 +456,28 @@ def extras(jx, torch, streams, cjxl_streams, W, H, device, O, np):
                                    "allocation + upload of the compressed streams; decode = every kernel, no overlap between batches"}
     out["pcie_inclusive"] = {"mpixel_per_s": round(mpx / (t3 - t0), 1), "d2h_ms": round((t3 - t2) * 1e3, 2), "d2h_gbs": round(n * W * H * 3 / 1e9 / (t3 - t2), 1),
                              "what": "the same pass plus the copy of the decoded pixels to pinned host memory (compressed input up, 24.9 MB per frame down), nothing overlapped"}
-    del b, dst, host
+    del b, host
+    # the same 128 frames as two jobs of 64 through a library pipeline in latency mode (small_job_frames: wave-wide LF kernel, sparse HF wavefronts): the host parse of the second job runs
+    # beside the first one's LF stage.  The pipeline object (streams, threads, shared planes) exists beforehand — a service would keep it —, the compressed bytes are host memory until submit
+    try:
+        p = jx.Pipeline(device, jobs_in_flight=4, lf_streams=4, hf_streams=2, prepare_threads=3, parse_threads=8, small_job_frames=64, reserve_frames=64, reserve_width=W, reserve_height=H)
+        frames = [streams[i % len(streams)] for i in range(n)]
+        fb = W * H * 3
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tk = [p.submit(frames[k:k + 64], "uint8", 3, device_ptrs=[dst.data_ptr() + i * fb for i in range(k, k + 64)]) for k in (0, 64)]
+            for t in tk:
+                p.wait(t)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        p.close()
+        out["one_pass_128"]["pipelined_2x64"] = {"ms": round(_median(ts[1:]), 2), "mpixel_per_s_with_prepare": round(mpx / (_median(ts[1:]) * 1e-3), 1),
+                                                 "what": "two jobs of 64 through JxlHipPipeline* with small_job_frames = 64 (parse, upload and every kernel inside the timed span; median of 3 after one warm-up pass)"}
+    except Exception as e:
+        out["one_pass_128"]["pipelined_2x64"] = {"error": repr(e)}
+    del dst
     torch.cuda.empty_cache()
     return out
 

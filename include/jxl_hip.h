@@ -302,7 +302,7 @@ typedef struct {
   int32_t parse_threads;     /* host threads one job's images are parsed on; 0 = default (8) */
   int32_t lane_stride_lf, lane_stride_hf;   /* see JxlHipBatchSetLaneStride; 0 = defaults (8, 1) */
   int32_t wide_first;        /* LF stages at the start of a cold pipeline that take the one-wavefront-per-stream kernel; < 0 = default (4) */
-  int32_t small_job_frames;  /* jobs of at most this many frames always take it (latency over occupancy); 0 = never */
+  int32_t small_job_frames;  /* jobs of at most this many frames always take it, and sparse wavefronts in the HF stage (latency over occupancy); 0 = never */
   int32_t timed;             /* bracket the stages with HIP events: JxlHipPipelineCollectTimes */
   int32_t reserve_frames, reserve_width, reserve_height;   /* size the shared planes for jobs of this shape at creation (0: grown when the pipeline is idle) */
   int32_t reserve_plane_sets; /* 2: the frames take the stage-by-stage restoration filters (anything but gaborish + one EPF pass) and need a second set of pixel planes */

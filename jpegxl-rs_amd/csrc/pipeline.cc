@@ -254,7 +254,7 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     bt.cfg.lane_stride_lf = opt_.lane_stride_lf; bt.cfg.lane_stride_hf = opt_.lane_stride_hf; bt.cfg.no_flag_wait = opt_.no_flag_wait;
     // latency mode: sparse wavefronts in the SIMT HF stage — one group stream per wavefront for a handful of frames, four up to a hundred (kernels.hip LaunchHfDecode)
     bt.cfg.hf_lanes_per_wave = bt.cfg.hf_lanes_per_wg = 0;
-    if (opt_.hf_sparse) {
+    if (opt_.hf_sparse || n <= opt_.small_job_frames) {
       if (n <= 8) { bt.cfg.hf_lanes_per_wave = 1; bt.cfg.hf_lanes_per_wg = 16; }
       else if (n <= 96) { bt.cfg.hf_lanes_per_wave = 4; bt.cfg.hf_lanes_per_wg = 64; }
     }
@@ -277,7 +277,8 @@ void Pipeline::PrepareJob(Job* j, int worker) {
     // the LF stage goes out right away, from this thread: the earlier it starts the better
     if (j->cold_wide && opt_.lane_stride_lf < 64) bt.cfg.lf_wide_once = 1;
     // (jobs whose LF trees use the weighted predictor keep the SIMT kernel whatever lf_wide_once says — LaunchLfDecode —: 420 ms a launch, nothing to chain)
-    const bool lf_wide = bt.cfg.lf_wide_once && !bt.Info("lf_simt_wp");
+    static const bool wide_wp = getenv("JXL_HIP_WIDE_WP") != nullptr;       // experiments (kernels.hip LaunchLfDecode)
+    const bool lf_wide = bt.cfg.lf_wide_once && (wide_wp || !bt.Info("lf_simt_wp"));
     if (j->wide_chain) { std::lock_guard<std::mutex> lock(mu_); j->lf_wide = lf_wide; }
     if (j->wide_after >= 0 && lf_wide) {
       // behind the cold-start job before it: wait (host) until that job's LF stage is in its stream, then make ours wait for it (device)

@@ -89,3 +89,40 @@ def test_wave_lf_falls_back_on_large_samples(jx):
     ref = O.decode(d).pixels("u8", 3)
     meta, px = jx.decoder_builder().decode_with(d, np.uint8)
     assert np.array_equal(px.reshape(ref.shape), ref)
+
+
+def test_corrupted_round6_streams_fail_cleanly_or_decode(jx):
+    """Robustness of the wave-wide decoders: random byte corruption / truncation of streams that take them — a weighted-predictor (cjxl-shaped) LF tree, the reference's bench.jxl
+    (big MA tree: the register-row tree walk), free-running Modular streams with deep trees — ends in a DecodeError or a decode of the right size, never a crash or a hang
+    (every walk is bounded by the tree's node count, every sample loop by the channel geometry; reads past a section's end give zeros)."""
+    from conftest import fixture_bytes
+    rng = np.random.default_rng(606)
+    img = S.synthetic_image(78, 520, 300)
+    S.set_lf_tree_shape(1)
+    try:
+        wp = S.encode_vardct(img, seed=5, strategy_mix=2, epf_iters=1, gab=1)
+    finally:
+        S.set_lf_tree_shape(0)
+    streams = [(wp, 24), (fixture_bytes("bench.jxl"), 12),
+               (S.encode_modular_free(seed=41, w=300, h=260, nchan=3, bits=8, tree_flags=S.TREE_WP | S.TREE_PREV_CHANNELS, tree_depth=9), 16),
+               (S.encode_modular_free(seed=42, w=300, h=260, nchan=3, bits=12, tree_flags=31, tree_depth=7), 16)]
+    outcomes = {"error": 0, "decoded": 0}
+    total = 0
+    for data, trials in streams:
+        for trial in range(trials):
+            bad = bytearray(data)
+            for pos in rng.integers(len(bad) // 8, len(bad), 1 + trial % 4):        # (past the headers: the decode reaches the GPU)
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            if trial % 6 == 5:
+                bad = bad[: int(rng.integers(len(bad) // 2, len(bad)))]
+            total += 1
+            try:
+                meta, px = jx.decoder_builder().decode_with(bytes(bad), np.uint8)
+                assert len(px) == meta.width * meta.height * (4 if meta.has_alpha_channel else 3)
+                outcomes["decoded"] += 1
+            except jx.DecodeError:
+                outcomes["error"] += 1
+    assert outcomes["error"] > 0 and outcomes["error"] + outcomes["decoded"] == total
+    ref = O.decode(wp).pixels("u8", 3)                                       # the decoder is still healthy afterwards
+    meta, px = jx.decoder_builder().decode_with(wp, np.uint8)
+    assert np.array_equal(px.reshape(ref.shape), ref)
