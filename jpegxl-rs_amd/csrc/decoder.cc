@@ -719,7 +719,7 @@ void Batch::ParseImage(const uint8_t* data, size_t size, ParsedImage* out, bool 
     if ((p.flags & (1 | 2 | 16)) || p.have_crop || !replace_all || p.frame_type != 0) complex = true;
     if (p.modular && ih.xyb_encoded) complex = true;      // XYB Modular frames go through the float planes
     if (p.modular && p.upsampling != 1) complex = true;
-    if (p.subsampled) complex = true;                     // chroma planes are upsampled in the frame tail
+    // (chroma-subsampled frames without anything else: OutputKernel upsamples the chroma planes as it reads them; in the frame tail of complex images ChromaUpsampleKernel does)
   }
   for (auto& x : ih.extra) if (x.depth.is_float) complex = true;   // float extra channels are converted in the frame tail (IntToFloatSample)
   if (complex && ih.extra.size() > 4) throw ParseError("unsupported: more than 4 extra channels in a multi-frame / feature image", true);

@@ -4946,13 +4946,39 @@ __device__ __forceinline__ void ColorAndStore(const FrameDev& f, int x, int y, f
   if (f.is_gray) r = g;
   StorePixel(f, x, y, r, g, b, A);
 }
+// Sample (x, y) of channel c of a chroma-subsampled frame at full resolution (stage_chroma_upsampling.cc: horizontal, then vertical, each with the (1/4, 3/4) kernel — out[2x] = 0.25 in[x-1]
+// + 0.75 in[x], out[2x+1] = 0.25 in[x+1] + 0.75 in[x] —, neighbours clamped at the channel's own edges; the channel sits packed in the top-left corner of its plane).  The arithmetic and
+// its order are ChromaUpsampleKernel's (kernels_features.hip: the frame tail of images with features): the vertical step works on horizontally upsampled rows, exactly as two stages would.
+__device__ __forceinline__ float SubsampledAt(const FrameDev& f, const float* __restrict__ plane, int c, uint32_t x, uint32_t y) {
+  const uint32_t hs = f.hs[c], vs = f.vs[c];
+  if (!(hs | vs)) return plane[(size_t)y * f.plane_stride + x];
+  const uint32_t cw = (f.width + (1u << hs) - 1) >> hs, ch = (f.height + (1u << vs) - 1) >> vs;
+  const uint32_t sx = x >> hs, sy = y >> vs;
+  auto hval = [&](uint32_t row) -> float {
+    const float* in = plane + (size_t)row * f.plane_stride;
+    if (!hs) return in[x];
+    const float mid = in[sx] * 0.75f;
+    const uint32_t nb = (x & 1) ? min(sx + 1, cw - 1) : (sx ? sx - 1 : 0);
+    return fmaf(0.25f, in[nb], mid);
+  };
+  if (!vs) return hval(sy);
+  const float mid = hval(sy) * 0.75f;
+  const uint32_t nb = (y & 1) ? min(sy + 1, ch - 1) : (sy ? sy - 1 : 0);
+  return fmaf(0.25f, hval(nb), mid);
+}
 __global__ void OutputKernel(const FrameDev* __restrict__ frames, int unfused, int fuse_out) {
   const FrameDev& f = frames[blockIdx.z];
   if (f.is_modular || f.post_mode || FusedEligible(f, unfused) || EpfWritesOutput(f, unfused, fuse_out)) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= (int)f.img_w || y >= (int)f.img_h) return;
   float X, Y, B, A = 1.0f;
-  if (f.upsampling > 1) {
+  if (f.subsampled) {
+    // JPEG transcodes with subsampled chroma (no restoration filters, no upsampling — the host rejects those combinations): chroma upsampling, YCbCr -> RGB and the write in one pass
+    X = SubsampledAt(f, f.plane_a[0], 0, (uint32_t)x, (uint32_t)y);
+    Y = SubsampledAt(f, f.plane_a[1], 1, (uint32_t)x, (uint32_t)y);
+    B = SubsampledAt(f, f.plane_a[2], 2, (uint32_t)x, (uint32_t)y);
+    if (f.alpha_plane) A = (float)f.alpha_plane[(size_t)y * f.width + x] * f.alpha_factor;
+  } else if (f.upsampling > 1) {
     const size_t o = (size_t)y * f.img_w + x;
     X = f.up_plane[0][o]; Y = f.up_plane[1][o]; B = f.up_plane[2][o];
     if (f.alpha_plane) A = f.up_plane[3][o];
