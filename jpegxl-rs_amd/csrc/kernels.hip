@@ -4414,6 +4414,91 @@ __global__ __launch_bounds__(256) void IdctSubsampledKernel(const FrameDev* __re
   }
 }
 
+// The same on tiles (round 6): a 256-thread workgroup takes 8 x 4 blocks of ONE channel (64 x 32 samples of its packed plane) through LDS — the thread-per-block form above reads
+// its 64 coefficients 256 bytes apart from its neighbours' and writes 8-sample rows with the plane's stride between lanes (30 ms per 256 4K frames, 272 bytes of scratch).
+//  pass 0: coalesced read of the tile's 2048 quantised coefficients (consecutive lanes = consecutive coefficients of a block), dequantisation, the LF sample in slot 0,
+//          into the block's 8 x 8 cell in LDS at the coefficient's (v, u) position; zeros back where something was read
+//  pass 1: one row per thread (IDct1D<8>)      pass 2: one column per thread      pass 3: coalesced write of the 64 x 32 samples
+// Arithmetic and operation order: SmallIdct2D<8, 8> (rows, then columns) on the values IdctSubsampledKernel computes.
+constexpr int kSubTileBx = 8, kSubTileBy = 4, kSubCell = 73;            // (cells of 8 rows x 9 floats + 1: rows and columns of neighbouring blocks fall on different banks)
+__global__ __launch_bounds__(256) void IdctSubsampledTileKernel(const FrameDev* __restrict__ frames) {
+  const FrameDev& f = frames[blockIdx.z];
+  if (f.is_modular || !f.subsampled || FrameFailed(f)) return;
+  const uint32_t c = blockIdx.y, hs = f.hs[c], vs = f.vs[c];
+  const uint32_t cbw = f.bw >> hs, cbh = f.bh >> vs;                     // the channel's own block grid (bw, bh are multiples of the largest cell)
+  const uint32_t tiles_x = (cbw + kSubTileBx - 1) / kSubTileBx, tiles_y = (cbh + kSubTileBy - 1) / kSubTileBy;
+  if (blockIdx.x >= tiles_x * tiles_y) return;
+  const uint32_t sx0 = (blockIdx.x % tiles_x) * kSubTileBx, sy0 = (blockIdx.x / tiles_x) * kSubTileBy;
+  __shared__ float s_px[kSubTileBx * kSubTileBy * kSubCell];
+  __shared__ int32_t* s_q[kSubTileBx * kSubTileBy];
+  __shared__ float s_mul[kSubTileBx * kSubTileBy], s_lf[kSubTileBx * kSubTileBy];
+  const uint32_t t = threadIdx.x;
+  if (t < kSubTileBx * kSubTileBy) {
+    const uint32_t sx = sx0 + t % kSubTileBx, sy = sy0 + t / kSubTileBx;
+    int32_t* q = nullptr; float mul = 0.f, lf = 0.f;
+    if (sx < cbw && sy < cbh) {
+      const uint32_t X = sx << hs, Y = sy << vs;
+      const size_t o = (size_t)Y * f.bw + X;
+      const uint32_t info = LdG(f.blk_info + o);
+      if (BI_Strategy(info) == 0) {                                      // (anything else was rejected by the LF stage)
+        const uint32_t g = (Y / 32) * f.xgroups + X / 32;
+        q = f.coeff[c] + (size_t)g * 65536 + LdG(f.coef_off + o);
+        const float sd = f.inv_global_scale / (float)BI_HfMul(info);
+        mul = c == 0 ? sd * f.x_dm : c == 2 ? sd * f.b_dm : sd;
+        lf = LdG(f.lf[c] + (size_t)sy * f.bw + sx);                      // the lowest frequency of an 8x8 DCT is the LF sample
+      }
+    }
+    s_q[t] = q; s_mul[t] = mul; s_lf[t] = lf;
+  }
+  __syncthreads();
+  const float* table = f.qtable[c];                                      // kind 0 (DCT8), channel c
+  const float bias_c = f.quant_bias[c], bias3 = f.quant_bias[3];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t i = t + 256u * (uint32_t)j, b = i >> 6, k = i & 63;
+    int32_t* q = s_q[b];
+    float v = 0.f;
+    if (q) {
+      const int32_t qv = LdG(q + k);
+      if (qv) StG(q + k, 0);                                             // consumed: the planes stay clean for the next decode
+      v = k == 0 ? s_lf[b] : AdjustQuantBias(qv, bias_c, bias3) * (LdG(table + k) * s_mul[b]);
+    }
+    s_px[b * kSubCell + (k & 7) * 9 + (k >> 3)] = v;                     // stored layout is the transpose of (v, u)
+  }
+  __syncthreads();
+  {
+    const uint32_t b = t >> 3, r = t & 7;
+    float* row = s_px + b * kSubCell + r * 9;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = row[u];
+    IDct1D<8>(v);
+#pragma unroll
+    for (int u = 0; u < 8; u++) row[u] = v[u];
+  }
+  __syncthreads();
+  {
+    const uint32_t b = t >> 3, x = t & 7;
+    float* col = s_px + b * kSubCell + x;
+    float v[8];
+#pragma unroll
+    for (int y = 0; y < 8; y++) v[y] = col[y * 9];
+    IDct1D<8>(v);
+#pragma unroll
+    for (int y = 0; y < 8; y++) col[y * 9] = v[y];
+  }
+  __syncthreads();
+  const size_t stride = f.plane_stride;
+  float* out = f.plane_a[c];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t i = t + 256u * (uint32_t)j, px = i & 63, py = i >> 6;  // sample (px, py) of the 64 x 32 tile
+    const uint32_t b = (py >> 3) * kSubTileBx + (px >> 3);
+    if (!s_q[b]) continue;
+    out[(size_t)(sy0 * 8 + py) * stride + sx0 * 8 + px] = s_px[b * kSubCell + (py & 7) * 9 + (px & 7)];
+  }
+}
+
 // ---- fast path: one 256-thread workgroup per 64x64-pixel tile (8x8 blocks), all three channels staged in LDS ----------
 // Requires every varblock to lie inside one tile (true for naturally aligned blocks, i.e. everything encoders emit);
 // frames violating that are flagged by the LF stage and use IdctKernel above.  Same arithmetic, same operation order.
@@ -6186,7 +6271,11 @@ void LaunchIdct(const FrameDev* frames, int nframes, int max_groups, int max_bw,
     if (all || cfg.need_tile4_special) hipLaunchKernelGGL((IdctTileKernel<4, true>), grid, dim3(JXL_IDCT_T4), lds, (hipStream_t)stream, frames, tiles_x, cfg.force_generic_idct | nocoef);
     DebugLaunch("IdctTileKernel<4>");
   }
-  if (cfg.any_subsampled) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
+  if (cfg.any_subsampled) {
+    static const bool per_block = getenv("JXL_HIP_SUBSAMPLED_IDCT_PER_BLOCK") != nullptr;     // A/B: the thread-per-block form
+    if (per_block) hipLaunchKernelGGL(IdctSubsampledKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames);
+    else hipLaunchKernelGGL(IdctSubsampledTileKernel, dim3(DivUp(max_bw, kSubTileBx) * DivUp(max_bh, kSubTileBy), 3, nframes), dim3(256), 0, (hipStream_t)stream, frames);
+  }
   DebugLaunch("IdctSubsampledKernel");
   if (cfg.force_generic_idct || !cfg.idct_flags_known || cfg.any_irregular_blocks)
     hipLaunchKernelGGL(IdctKernel, dim3(max_groups, nframes), dim3(256), 0, (hipStream_t)stream, frames, cfg.force_generic_idct);   // irregular frames only

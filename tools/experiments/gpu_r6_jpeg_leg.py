@@ -6,7 +6,7 @@ import bench, numpy as np, torch
 import jpegxl_rs_amd as jx, oracle_lib as O
 streams = bench._pool_map(bench._make_ycbcr420, [700 + i for i in range(8)])
 W, H = 3840, 2160
-for B, infl in ((64, 4), (128, 6), (256, 6), (256, 11)):
+for B, infl in (((256, 11),) if os.environ.get("JPEG_LEG_ONLY_FIRST") else ((64, 4), (128, 6), (256, 6), (256, 11))):
     try:
         p = jx.Pipeline(0, timed=1, jobs_in_flight=infl, lf_streams=infl, prepare_threads=3, parse_threads=8, reserve_frames=B, reserve_width=W, reserve_height=H)
         outs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda:0") for _ in range(2)]
