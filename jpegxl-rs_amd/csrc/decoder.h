@@ -211,6 +211,7 @@ class Batch {
   // runs under the next batch's latency-bound HF stage.  The next decode of this batch only waits for that event.
   uint8_t* dcoef_ = nullptr;
   void* clear_stream_ = nullptr; void* clear_event_ = nullptr; void* idct_event_ = nullptr;
+  vec<void*> mod_streams_, mod_join_events_; void* mod_fork_event_ = nullptr;   // side streams of the Modular tail (EnqueueModularTail): one inverse-transform chain per image
   bool clear_pending_ = false, coef_dirty_ = true;
   Batch* coef_owner_ = nullptr;
   size_t coef_clean_extent_ = 0;   // bytes of this object's own coefficient planes known to be zero after a completed decode

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 namespace jxlhip {
 
@@ -634,6 +635,40 @@ SigResult CheckSignature(const uint8_t* buf, size_t len) {
   return len < 12 ? kSigNotEnoughBytes : kSigContainer;
 }
 
+// ---- free list of large codestream copies (Codestream::~Codestream) ----
+namespace {
+struct CsPool { std::mutex mu; std::vector<vec<uint32_t>> free; size_t bytes = 0; };
+CsPool& CodestreamPool() { static CsPool* p = new CsPool; return *p; }                 // (never destroyed: decoders may outlive static destructors)
+constexpr size_t kCsPoolMinWords = ((size_t)1 << 20) / 4;
+size_t CsPoolMaxBytes() { static const size_t v = getenv("JXL_HIP_CODESTREAM_POOL_MB") ? (size_t)atoll(getenv("JXL_HIP_CODESTREAM_POOL_MB")) << 20 : (size_t)4 << 30; return v; }
+bool PlainMalloc(const vec<uint32_t>& v) {        // the block did not come from a caller's memory manager (mm_alloc.h MmHeader)
+  if (!v.data()) return false;
+  const MmHeader* hd = reinterpret_cast<const MmHeader*>(reinterpret_cast<uintptr_t>(v.data()) - sizeof(MmHeader));
+  return hd->free == nullptr;
+}
+vec<uint32_t> TakeCodestreamStorage(size_t words) {
+  vec<uint32_t> out;
+  if (words < kCsPoolMinWords || MmCurrent()) return out;
+  CsPool& p = CodestreamPool();
+  std::lock_guard<std::mutex> lock(p.mu);
+  size_t best = (size_t)-1;
+  for (size_t i = 0; i < p.free.size(); i++) {
+    const size_t cap = p.free[i].capacity();
+    if (cap >= words && cap <= words + words / 2 + 1024 && (best == (size_t)-1 || cap < p.free[best].capacity())) best = i;
+  }
+  if (best != (size_t)-1) { out = std::move(p.free[best]); p.bytes -= out.capacity() * 4; p.free.erase(p.free.begin() + (ptrdiff_t)best); }
+  return out;
+}
+}  // namespace
+Codestream::~Codestream() {
+  if (storage.capacity() < kCsPoolMinWords || !PlainMalloc(storage)) return;
+  CsPool& p = CodestreamPool();
+  std::lock_guard<std::mutex> lock(p.mu);
+  if (p.bytes + storage.capacity() * 4 > CsPoolMaxBytes()) return;
+  p.bytes += storage.capacity() * 4;
+  p.free.push_back(std::move(storage));
+}
+
 bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* have_container, bool* has_jbrd, MetadataBoxes* boxes) {
   *have_container = false; *has_jbrd = false;
   vec<uint8_t> tmp;
@@ -680,8 +715,12 @@ bool ExtractCodestream(const uint8_t* data, size_t size, Codestream* cs, bool* h
     src = tmp.data(); n = tmp.size();
   }
   cs->size = n;
-  cs->storage.assign((n + 3) / 4 + 20, 0);     // 80 zero bytes after the stream: the HF kernel's bit-stream ring prefetches up to 64 bytes ahead
+  const size_t words = (n + 3) / 4 + 20;       // 80 zero bytes after the stream: the HF kernel's bit-stream ring prefetches up to 64 bytes ahead
+  cs->storage = TakeCodestreamStorage(words);
+  if (cs->storage.capacity() >= words) cs->storage.resize(words);      // (a recycled block: only what lies beyond its old size is zero-filled)
+  else cs->storage.assign(words, 0);
   if (n) memcpy(cs->data(), src, n);
+  memset(cs->data() + n, 0, words * 4 - n);
   return complete;
 }
 

@@ -192,6 +192,14 @@ struct FramePlan {
 struct Codestream {
   vec<uint32_t> storage;
   size_t size = 0;
+  Codestream() = default;
+  Codestream(const Codestream&) = default;
+  Codestream(Codestream&&) = default;
+  Codestream& operator=(const Codestream&) = default;
+  Codestream& operator=(Codestream&&) = default;
+  // large copies (>= 1 MB, plain malloc) go back to a process-wide free list instead of the C library: a 73 MB codestream is mapped, page-faulted in and unmapped again
+  // per decode otherwise — with three prepare workers x eight parse threads faulting at once, 100-190 ms per job of eight such frames (host_parse.cc TakeCodestreamStorage)
+  ~Codestream();
   const uint8_t* data() const { return reinterpret_cast<const uint8_t*>(storage.data()); }
   uint8_t* data() { return reinterpret_cast<uint8_t*>(storage.data()); }
   size_t padded_size() const { return storage.size() * 4; }

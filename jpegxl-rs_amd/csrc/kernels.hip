@@ -5518,7 +5518,7 @@ __device__ __forceinline__ int32_t PaletteValue(const int32_t* pal, int pal_w, i
 
 // The global stream (meta channels + every channel that fits one group) with the same cooperative decoder: one wavefront
 // per frame.  Replaces the one-thread ModularGlobalKernel whenever the stream uses the global tree.
-__global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base) {
+__global__ __launch_bounds__(64, 3) void ModularGlobalFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base) {
   const FrameDev& f = frames[blockIdx.x];
   if (f.mod_nchan == 0) return;
   ModTables T;
