@@ -408,7 +408,6 @@ Batch::~Batch() {
   if (device_ >= 0 && cur != device_) (void)hipSetDevice(device_);
   if (clear_stream_) { (void)hipStreamSynchronize((hipStream_t)clear_stream_); (void)hipStreamDestroy((hipStream_t)clear_stream_); }
   if (clear_event_) (void)hipEventDestroy((hipEvent_t)clear_event_);
-  for (void* st : mod_streams_) { (void)hipStreamSynchronize((hipStream_t)st); (void)hipStreamDestroy((hipStream_t)st); }
   for (void* ev : mod_join_events_) (void)hipEventDestroy((hipEvent_t)ev);
   if (mod_fork_event_) (void)hipEventDestroy((hipEvent_t)mod_fork_event_);
   if (idct_event_) (void)hipEventDestroy((hipEvent_t)idct_event_);
@@ -1669,27 +1668,29 @@ void Batch::EnqueueModularTail(void* stream_v) {
   LaunchModularGroups(dframes_, n, max_units, cfg, stream_v);
   check("ModularGroupFastKernel", max_units);
   // The inverse transforms of different images are independent chains of latency-bound kernels (an inverse Squeeze step is one thread per row / column walking a recurrence:
-  // 32 workgroups for the last step of an 8192 x 8192 channel, ~40 launches per channel): with several images in the batch the chains go to a few side streams that fork from
-  // and join `stream_v` (JXL_HIP_MOD_TAIL_STREAMS, default 8; 1 = one after the other on stream_v)
-  static const int tail_streams = getenv("JXL_HIP_MOD_TAIL_STREAMS") ? std::max(1, std::min(16, atoi(getenv("JXL_HIP_MOD_TAIL_STREAMS")))) : 8;
+  // 32 workgroups for the last step of an 8192 x 8192 channel, ~40 launches per channel): with several images in the batch the chains go to the side streams the batch's
+  // owner lends it (SetTailStreams: a pipeline's four; a batch on its own runs them one after the other on stream_v), which fork from and join `stream_v`.
+  // (Streams of the batch's own — eight per batch object, ~50 per pipeline — made every later latency-bound decode of the PROCESS 1.6x slower, even after they were destroyed:
+  // profiles/r06_notes.md section 12.)
   int with_ops = 0;
   for (int i = 0; i < n; i++) with_ops += !mod_ops_[i].empty();
-  const int nside = with_ops >= 2 ? std::min(with_ops, tail_streams) : 1;
+  int nside = 1;
+  vec<void*> side;
+  if (with_ops >= 2 && tail_streams_) {
+    for (int k = 0; k < std::min(with_ops, 16); k++) { void* st = tail_streams_(k); if (!st) break; side.push_back(st); }
+    if (side.size() >= 2) nside = (int)side.size();
+  }
   if (nside > 1) {
-    while ((int)mod_streams_.size() < nside) {
-      hipStream_t st; hipEvent_t ev;
-      HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); mod_streams_.push_back(st);
-      HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); mod_join_events_.push_back(ev);
-    }
+    while ((int)mod_join_events_.size() < nside) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); mod_join_events_.push_back(ev); }
     if (!mod_fork_event_) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); mod_fork_event_ = ev; }
     HIP_CHECK(hipEventRecord((hipEvent_t)mod_fork_event_, (hipStream_t)stream_v));
-    for (int k = 0; k < nside; k++) HIP_CHECK(hipStreamWaitEvent((hipStream_t)mod_streams_[(size_t)k], (hipEvent_t)mod_fork_event_, 0));
+    for (int k = 0; k < nside; k++) HIP_CHECK(hipStreamWaitEvent((hipStream_t)side[(size_t)k], (hipEvent_t)mod_fork_event_, 0));
   }
   void* const main_stream = stream_v;
   int chain = 0;
   for (int i = 0; i < n; i++) {
     if (mod_ops_[i].empty()) continue;
-    stream_v = nside > 1 ? mod_streams_[(size_t)(chain++ % nside)] : main_stream;
+    stream_v = nside > 1 ? side[(size_t)(chain++ % nside)] : main_stream;
     for (const ModOp& op : mod_ops_[i]) {
       check("Modular tail op before", (int)op.kind);
       auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
@@ -1719,7 +1720,7 @@ void Batch::EnqueueModularTail(void* stream_v) {
   }
   if (nside > 1) {
     for (int k = 0; k < nside; k++) {
-      HIP_CHECK(hipEventRecord((hipEvent_t)mod_join_events_[(size_t)k], (hipStream_t)mod_streams_[(size_t)k]));
+      HIP_CHECK(hipEventRecord((hipEvent_t)mod_join_events_[(size_t)k], (hipStream_t)side[(size_t)k]));
       HIP_CHECK(hipStreamWaitEvent((hipStream_t)main_stream, (hipEvent_t)mod_join_events_[(size_t)k], 0));
     }
   }

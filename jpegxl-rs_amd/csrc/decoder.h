@@ -151,6 +151,8 @@ class Batch {
   // Planes owned by the caller (pipeline.cc): used by the next Prepare when they are large enough for the batch's layout, otherwise the batch falls back to arenas of
   // its own (big_bytes_wanted / coef_bytes_wanted say what it would have taken).  nullptr = back to own arenas.  The caller orders the decodes that share a set.
   void UseSharedPlanes(SharedPlanes* big, SharedPlanes* coef);
+  // Side streams (hipStream_t, owned by the caller, alive as long as the batch decodes) for the independent inverse-transform chains of a batch's Modular images; without them the chains run one after the other.
+  void SetTailStreams(std::function<void*(int)> provider) { tail_streams_ = std::move(provider); }
   size_t big_bytes_wanted() const { return big_size_; }
   size_t coef_bytes_wanted() const { return coeff_bytes_; }
   bool uses_shared_big() const { return big_is_ext_; }
@@ -211,7 +213,8 @@ class Batch {
   // runs under the next batch's latency-bound HF stage.  The next decode of this batch only waits for that event.
   uint8_t* dcoef_ = nullptr;
   void* clear_stream_ = nullptr; void* clear_event_ = nullptr; void* idct_event_ = nullptr;
-  vec<void*> mod_streams_, mod_join_events_; void* mod_fork_event_ = nullptr;   // side streams of the Modular tail (EnqueueModularTail): one inverse-transform chain per image
+  vec<void*> mod_join_events_; void* mod_fork_event_ = nullptr;   // fork / join of the Modular tail's side streams (EnqueueModularTail): one inverse-transform chain per image
+  std::function<void*(int)> tail_streams_;                        // k -> the owner's k-th side stream for those chains (nullptr: no more)
   bool clear_pending_ = false, coef_dirty_ = true;
   Batch* coef_owner_ = nullptr;
   size_t coef_clean_extent_ = 0;   // bytes of this object's own coefficient planes known to be zero after a completed decode

@@ -22,6 +22,17 @@ void* NewStream(int priority) {
   HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
   return s;
 }
+}  // namespace
+// The k-th of the pipeline's (at most four) side streams for the inverse-transform chains of a job's Modular images (Batch::EnqueueModularTail), made when first asked for:
+// pipelines that never see such jobs — the one behind the libjxl API decodes single images — keep the process's stream count where it was.
+void* Pipeline::TailStream(int k) {
+  static const int cap = getenv("JXL_HIP_MOD_TAIL_STREAMS") ? std::max(1, std::min(16, atoi(getenv("JXL_HIP_MOD_TAIL_STREAMS")))) : 4;
+  if (k < 0 || k >= cap || cap < 2) return nullptr;
+  std::lock_guard<std::mutex> lock(tail_mu_);
+  while ((int)tail_side_.size() <= k) tail_side_.push_back(NewStream(0));
+  return tail_side_[(size_t)k];
+}
+namespace {
 void* NewEvent(bool timing = false) {
   hipEvent_t e = nullptr;
   HIP_CHECK(hipEventCreateWithFlags(&e, timing ? hipEventDefault : hipEventDisableTiming));
@@ -67,6 +78,7 @@ Pipeline::Pipeline(int device, const PipelineOptions& opt) : device_(device), op
   for (int b = 0; b < nbuf_; b++) {
     std::unique_ptr<Slot> s(new Slot());
     s->batch.reset(new Batch(device_));
+    s->batch->SetTailStreams([this](int k) -> void* { return TailStream(k); });
     s->lf_done = NewEvent(); s->front_done = NewEvent(); s->hf_done = NewEvent(); s->idct_done = NewEvent(); s->rest_done = NewEvent();
     slots_.push_back(std::move(s));
   }
@@ -105,6 +117,7 @@ Pipeline::~Pipeline() {
   if (clock_event_) (void)hipEventDestroy((hipEvent_t)clock_event_);
   for (void* s : lf_side_) (void)hipStreamDestroy((hipStream_t)s);
   for (void* s : hf_side_) (void)hipStreamDestroy((hipStream_t)s);
+  for (void* s : tail_side_) { (void)hipStreamSynchronize((hipStream_t)s); (void)hipStreamDestroy((hipStream_t)s); }
   (void)hipStreamDestroy((hipStream_t)main_);
   for (void* s : d2h_) (void)hipStreamDestroy((hipStream_t)s);
 }

@@ -110,6 +110,8 @@ class Pipeline {
   size_t want_big_ = 0, want_coef_ = 0;        // the largest layouts seen: what the shared planes grow to when the pipeline is idle
   void* main_ = nullptr; void* d2h_[2] = {nullptr, nullptr};     // [0]: copies to host + status words of every job, in job order ([1] spare: two streams taking turns measured slower)
   std::vector<void*> lf_side_, hf_side_;
+  std::vector<void*> tail_side_; std::mutex tail_mu_;   // TailStream()
+  void* TailStream(int k);
   void* clock_event_ = nullptr;
   std::mutex mu_;
   std::condition_variable cv_;
