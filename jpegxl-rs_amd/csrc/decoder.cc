@@ -1668,60 +1668,80 @@ void Batch::EnqueueModularTail(void* stream_v) {
   LaunchModularGroups(dframes_, n, max_units, cfg, stream_v);
   check("ModularGroupFastKernel", max_units);
   // The inverse transforms of different images are independent chains of latency-bound kernels (an inverse Squeeze step is one thread per row / column walking a recurrence:
-  // 32 workgroups for the last step of an 8192 x 8192 channel, ~40 launches per channel): with several images in the batch the chains go to the side streams the batch's
-  // owner lends it (SetTailStreams: a pipeline's four; a batch on its own runs them one after the other on stream_v), which fork from and join `stream_v`.
-  // (Streams of the batch's own — eight per batch object, ~50 per pipeline — made every later latency-bound decode of the PROCESS 1.6x slower, even after they were destroyed:
-  // profiles/r06_notes.md section 12.)
-  int with_ops = 0;
-  for (int i = 0; i < n; i++) with_ops += !mod_ops_[i].empty();
-  int nside = 1;
-  vec<void*> side;
-  if (with_ops >= 2 && tail_streams_) {
-    for (int k = 0; k < std::min(with_ops, 16); k++) { void* st = tail_streams_(k); if (!st) break; side.push_back(st); }
-    if (side.size() >= 2) nside = (int)side.size();
-  }
-  if (nside > 1) {
-    while ((int)mod_join_events_.size() < nside) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); mod_join_events_.push_back(ev); }
-    if (!mod_fork_event_) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); mod_fork_event_ = ev; }
-    HIP_CHECK(hipEventRecord((hipEvent_t)mod_fork_event_, (hipStream_t)stream_v));
-    for (int k = 0; k < nside; k++) HIP_CHECK(hipStreamWaitEvent((hipStream_t)side[(size_t)k], (hipEvent_t)mod_fork_event_, 0));
-  }
-  void* const main_stream = stream_v;
-  int chain = 0;
-  for (int i = 0; i < n; i++) {
-    if (mod_ops_[i].empty()) continue;
-    stream_v = nside > 1 ? side[(size_t)(chain++ % nside)] : main_stream;
-    for (const ModOp& op : mod_ops_[i]) {
-      check("Modular tail op before", (int)op.kind);
-      auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
-      switch (op.kind) {
-        case ModOp::kRct: LaunchModRct(P(op.in[0]), P(op.in[1]), P(op.in[2]), op.n, op.param, stream_v); break;
-        case ModOp::kPalette: {
-          int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
-          for (uint32_t c = 0; c < op.num_c; c++) outs[c] = P(op.out[c]);
-          if (op.nb_deltas == 0 && op.predictor == 0) LaunchModPalette(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.n, stream_v);
-          else LaunchModPaletteDelta(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.nb_deltas, op.predictor, op.aw, op.ah, images_[i]->plan.gwp,
-                                     op.predictor == 6 ? P(op.wp_scratch) : nullptr, op.wp_stride, stream_v);
-          break;
-        }
-        case ModOp::kSqueeze: LaunchModInvSqueeze(P(op.in[0]), P(op.in[1]), P(op.out[0]), op.param, op.aw, op.ah, op.rw, op.rh, stream_v); break;
-        case ModOp::kOutput: {
-          ModOutputArgs a;
-          memset(&a, 0, sizeof(a));
-          a.ncolor = op.num_c;
-          for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = P(op.in[c]);
-          a.color_factor = op.color_factor; a.float_bits = op.float_bits; a.float_exp_bits = op.float_exp_bits;
-          a.alpha = op.has_alpha ? P(op.in[3]) : nullptr; a.alpha_factor = op.alpha_factor;
-          LaunchModOutput(dframes_, i, a, images_[i]->plan.width, images_[i]->plan.height, stream_v);
-          break;
-        }
+  // 32 workgroups for the last step of an 8192 x 8192 channel, ~40 launches per channel).  Images whose chains have the same shape — the frames of a job usually do — go through
+  // them together: step k of up to kSqueezeBatch images is ONE launch (blockIdx.y = image).  Side streams per image gave the same overlap and made every later latency-bound
+  // decode of the process 1.3-1.6x slower (profiles/r06_notes.md section 12); the owner's streams (SetTailStreams) are only used when JXL_HIP_MOD_TAIL_STREAMS asks for them.
+  auto P = [&](size_t off) { return (int32_t*)(dwork_ + off); };
+  auto run_op = [&](int i, const ModOp& op, void* st) {
+    check("Modular tail op before", (int)op.kind);
+    switch (op.kind) {
+      case ModOp::kRct: LaunchModRct(P(op.in[0]), P(op.in[1]), P(op.in[2]), op.n, op.param, st); break;
+      case ModOp::kPalette: {
+        int32_t* outs[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (uint32_t c = 0; c < op.num_c; c++) outs[c] = P(op.out[c]);
+        if (op.nb_deltas == 0 && op.predictor == 0) LaunchModPalette(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.n, st);
+        else LaunchModPaletteDelta(P(op.in[0]), outs, op.param, op.num_c, op.bits, op.nb_deltas, op.predictor, op.aw, op.ah, images_[i]->plan.gwp,
+                                   op.predictor == 6 ? P(op.wp_scratch) : nullptr, op.wp_stride, st);
+        break;
+      }
+      case ModOp::kSqueeze: LaunchModInvSqueeze(P(op.in[0]), P(op.in[1]), P(op.out[0]), op.param, op.aw, op.ah, op.rw, op.rh, st); break;
+      case ModOp::kOutput: {
+        ModOutputArgs a;
+        memset(&a, 0, sizeof(a));
+        a.ncolor = op.num_c;
+        for (uint32_t c = 0; c < a.ncolor; c++) a.color[c] = P(op.in[c]);
+        a.color_factor = op.color_factor; a.float_bits = op.float_bits; a.float_exp_bits = op.float_exp_bits;
+        a.alpha = op.has_alpha ? P(op.in[3]) : nullptr; a.alpha_factor = op.alpha_factor;
+        LaunchModOutput(dframes_, i, a, images_[i]->plan.width, images_[i]->plan.height, st);
+        break;
       }
     }
+  };
+  static const int tail_streams = getenv("JXL_HIP_MOD_TAIL_STREAMS") ? atoi(getenv("JXL_HIP_MOD_TAIL_STREAMS")) : 0;
+  static const bool no_batch = getenv("JXL_HIP_NO_SQUEEZE_BATCH") != nullptr;      // A/B: every image's chain on its own
+  vec<int> with_ops;
+  for (int i = 0; i < n; i++) if (!mod_ops_[i].empty()) with_ops.push_back(i);
+  if (tail_streams >= 2 && with_ops.size() >= 2 && tail_streams_) {
+    // (experiments) one chain per side stream of the owner, forked from and joined to stream_v
+    vec<void*> side;
+    for (int k = 0; k < std::min<int>((int)with_ops.size(), tail_streams); k++) { void* st = tail_streams_(k); if (!st) break; side.push_back(st); }
+    if (side.size() >= 2) {
+      while (mod_join_events_.size() < side.size()) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); mod_join_events_.push_back(ev); }
+      if (!mod_fork_event_) { hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); mod_fork_event_ = ev; }
+      HIP_CHECK(hipEventRecord((hipEvent_t)mod_fork_event_, (hipStream_t)stream_v));
+      for (void* st : side) HIP_CHECK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)mod_fork_event_, 0));
+      for (size_t k = 0; k < with_ops.size(); k++) for (const ModOp& op : mod_ops_[with_ops[k]]) run_op(with_ops[k], op, side[k % side.size()]);
+      for (size_t k = 0; k < side.size(); k++) {
+        HIP_CHECK(hipEventRecord((hipEvent_t)mod_join_events_[k], (hipStream_t)side[k]));
+        HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream_v, (hipEvent_t)mod_join_events_[k], 0));
+      }
+      return;
+    }
   }
-  if (nside > 1) {
-    for (int k = 0; k < nside; k++) {
-      HIP_CHECK(hipEventRecord((hipEvent_t)mod_join_events_[(size_t)k], (hipStream_t)side[(size_t)k]));
-      HIP_CHECK(hipStreamWaitEvent((hipStream_t)main_stream, (hipEvent_t)mod_join_events_[(size_t)k], 0));
+  // groups of images whose chains have the same shape (kind and geometry of every step)
+  auto same_shape = [&](int a, int b) {
+    const vec<ModOp>& x = mod_ops_[a]; const vec<ModOp>& y = mod_ops_[b];
+    if (x.size() != y.size()) return false;
+    for (size_t k = 0; k < x.size(); k++)
+      if (x[k].kind != y[k].kind || x[k].param != y[k].param || x[k].aw != y[k].aw || x[k].ah != y[k].ah || x[k].rw != y[k].rw || x[k].rh != y[k].rh) return false;
+    return true;
+  };
+  vec<char> done((size_t)n, 0);
+  for (int lead : with_ops) {
+    if (done[(size_t)lead]) continue;
+    vec<int> grp;
+    for (int i : with_ops) if (!done[(size_t)i] && (int)grp.size() < kSqueezeBatch && (i == lead || (!no_batch && same_shape(lead, i)))) { grp.push_back(i); done[(size_t)i] = 1; }
+    const vec<ModOp>& ops = mod_ops_[lead];
+    for (size_t k = 0; k < ops.size(); k++) {
+      if (ops[k].kind == ModOp::kSqueeze && grp.size() > 1) {
+        check("Modular tail op before", (int)ops[k].kind);
+        SqueezeBatch b;
+        memset(&b, 0, sizeof(b));
+        for (size_t g = 0; g < grp.size(); g++) { const ModOp& o = mod_ops_[grp[g]][k]; b.avg[g] = P(o.in[0]); b.res[g] = P(o.in[1]); b.out[g] = P(o.out[0]); }
+        LaunchModInvSqueezeBatch(b, (int)grp.size(), ops[k].param, ops[k].aw, ops[k].ah, ops[k].rw, ops[k].rh, stream_v);
+      } else {
+        for (int i : grp) run_op(i, mod_ops_[i][k], stream_v);
+      }
     }
   }
 }

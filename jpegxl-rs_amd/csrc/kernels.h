@@ -208,6 +208,10 @@ uint32_t ModularGroupLdsBytes(const LaunchCfg& cfg);
 void LaunchModularGroups(const FrameDev* frames, int nframes, int max_units, const LaunchCfg& cfg, void* stream);   // max_units: most LF groups + groups x passes of a frame
 // inverse Squeeze of one channel: (avg, res) -> out; horizontal: avg aw x h, res rw x h, out (aw+rw) x h; vertical: avg w x ah, res w x rh
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);
+// the same step of n <= kSqueezeBatch equally shaped, independent channels (one per image of a batch) in one launch
+constexpr int kSqueezeBatch = 16;
+struct SqueezeBatch { const int32_t* avg[kSqueezeBatch]; const int32_t* res[kSqueezeBatch]; int32_t* out[kSqueezeBatch]; };
+void LaunchModInvSqueezeBatch(const SqueezeBatch& b, int n, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream);
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream);
 void LaunchModPalette(const int32_t* pal, int32_t* const* out, uint32_t nb_colors, uint32_t num_c, uint32_t bit_depth, size_t n, void* stream);
 void LaunchChromaUpsample(const float* src, uint32_t src_stride, float* dst, uint32_t dst_stride, uint32_t cw, uint32_t ch, uint32_t hs, uint32_t vs, uint32_t out_w, uint32_t out_h, void* stream);

@@ -5518,7 +5518,7 @@ __device__ __forceinline__ int32_t PaletteValue(const int32_t* pal, int pal_w, i
 
 // The global stream (meta channels + every channel that fits one group) with the same cooperative decoder: one wavefront
 // per frame.  Replaces the one-thread ModularGlobalKernel whenever the stream uses the global tree.
-__global__ __launch_bounds__(64, 3) void ModularGlobalFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base) {
+__global__ __launch_bounds__(64) void ModularGlobalFastKernel(const FrameDev* __restrict__ frames, uint32_t tree_cap, uint32_t lds_bytes, uint32_t wp_base) {
   const FrameDev& f = frames[blockIdx.x];
   if (f.mod_nchan == 0) return;
   ModTables T;
@@ -5841,10 +5841,11 @@ __device__ __forceinline__ void SqueezePairFast(int32_t prev, int32_t a, int32_t
 // horizontal: the recurrence runs along x, so one thread owns one row.  The averages and residuals of the next eight pairs do not depend on the recurrence: they are loaded
 // ahead of it (round 5: one dependent memory round trip per pair before — 0.84 us per pair, 20 ms of inverse Squeeze per two 8192x8192 frames)
 constexpr int kSqueezeAhead = 8;
-__global__ __launch_bounds__(64) void ModInvSqueezeHKernel(const int32_t* __restrict__ avg, const int32_t* __restrict__ res, int32_t* __restrict__ out,
-                                                           uint32_t aw, uint32_t rw, uint32_t h) {
+// (blockIdx.y = the image: the same step of up to kSqueezeBatch equally shaped images in one launch — a step is one thread per row / column, 32 workgroups for the last one of an 8192 x 8192 channel)
+__global__ __launch_bounds__(64) void ModInvSqueezeHKernel(const SqueezeBatch b, uint32_t aw, uint32_t rw, uint32_t h) {
   const uint32_t y = blockIdx.x * blockDim.x + threadIdx.x;
   if (y >= h) return;
+  const int32_t* __restrict__ avg = b.avg[blockIdx.y]; const int32_t* __restrict__ res = b.res[blockIdx.y]; int32_t* __restrict__ out = b.out[blockIdx.y];
   const int32_t* pa = avg + (size_t)y * aw;
   const int32_t* pr = res + (size_t)y * rw;
   int32_t* po = out + (size_t)y * (aw + rw);
@@ -5872,10 +5873,10 @@ __global__ __launch_bounds__(64) void ModInvSqueezeHKernel(const int32_t* __rest
   if (aw > rw) po[2 * rw] = pa[rw];
 }
 // vertical: one thread per column, rows top to bottom (coalesced across the wave), eight rows loaded ahead of the recurrence
-__global__ __launch_bounds__(256) void ModInvSqueezeVKernel(const int32_t* __restrict__ avg, const int32_t* __restrict__ res, int32_t* __restrict__ out,
-                                                            uint32_t w, uint32_t ah, uint32_t rh) {
+__global__ __launch_bounds__(256) void ModInvSqueezeVKernel(const SqueezeBatch b, uint32_t w, uint32_t ah, uint32_t rh) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= w) return;
+  const int32_t* __restrict__ avg = b.avg[blockIdx.y]; const int32_t* __restrict__ res = b.res[blockIdx.y]; int32_t* __restrict__ out = b.out[blockIdx.y];
   int32_t a = ah ? avg[x] : 0, top = a;
   uint32_t y = 0;
   for (; y + kSqueezeAhead < rh; y += kSqueezeAhead) {        // (y + k + 1 <= rh - 1 < ah for every k)
@@ -6379,9 +6380,16 @@ void LaunchModularGlobal(const FrameDev* frames, int nframes, const LaunchCfg& c
   if (!attr_set) { SetMaxDynamicLds((const void*)ModularGlobalFastKernel, 160 * 1024 - 8192, "ModularGlobalFastKernel"); attr_set = true; }
   hipLaunchKernelGGL(ModularGlobalFastKernel, dim3(nframes), dim3(64), lds_bytes, (hipStream_t)stream, frames, tree_cap, lds_tables, wp_base);
 }
+void LaunchModInvSqueezeBatch(const SqueezeBatch& b, int n, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream) {
+  if (n <= 0) return;
+  if (horizontal) { if (ah) hipLaunchKernelGGL(ModInvSqueezeHKernel, dim3((ah + 63) / 64, n), dim3(64), 0, (hipStream_t)stream, b, aw, rw, ah); }
+  else if (aw) hipLaunchKernelGGL(ModInvSqueezeVKernel, dim3((aw + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b, aw, ah, rh);
+}
 void LaunchModInvSqueeze(const int32_t* avg, const int32_t* res, int32_t* out, int horizontal, uint32_t aw, uint32_t ah, uint32_t rw, uint32_t rh, void* stream) {
-  if (horizontal) { if (ah) hipLaunchKernelGGL(ModInvSqueezeHKernel, dim3((ah + 63) / 64), dim3(64), 0, (hipStream_t)stream, avg, res, out, aw, rw, ah); }
-  else if (aw) hipLaunchKernelGGL(ModInvSqueezeVKernel, dim3((aw + 255) / 256), dim3(256), 0, (hipStream_t)stream, avg, res, out, aw, ah, rh);
+  SqueezeBatch b;
+  memset(&b, 0, sizeof(b));
+  b.avg[0] = avg; b.res[0] = res; b.out[0] = out;
+  LaunchModInvSqueezeBatch(b, 1, horizontal, aw, ah, rw, rh, stream);
 }
 void LaunchModRct(int32_t* a, int32_t* b, int32_t* c, size_t n, uint32_t rct_type, void* stream) {
   hipLaunchKernelGGL(ModRctKernel, dim3((unsigned)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n, rct_type);

@@ -34,10 +34,10 @@ for w in which:
         run_leg([s[i % 2] for i in range(8)], "uint16", 1, 8, 2, (8192, 8192), torch.int16)
     elif w == "jpeg":
         s = bench._pool_map(bench._make_ycbcr420, [700 + i for i in range(4)])
-        run_leg([s[i % 4] for i in range(256)], "uint8", 3, 256, 6, (H, W, 3), torch.uint8)
+        run_leg([s[i % 4] for i in range(128)], "uint8", 3, 128, 6, (H, W, 3), torch.uint8)
     elif w == "hdr8k":
         s = [bench._make_8k_hdr(6), bench._make_8k_hdr(7)]
         run_leg([s[i % 2] for i in range(32)], "float32", 3, 32, 6, (4320, 7680, 3), torch.float32, reserve_plane_sets=2)
     elif w == "4k":
-        run_leg([streams[i % 4] for i in range(256)], "uint8", 3, 256, 6, (H, W, 3), torch.uint8)
+        run_leg([streams[i % 4] for i in range(128)], "uint8", 3, 128, 11, (H, W, 3), torch.uint8, n=14)
     lat(w)
