@@ -793,7 +793,7 @@ def main():
                 # subsampled branch (chroma upsampling + YCbCr -> RGB + write in one pass); jobs of the headline's shape
                 try:
                     rj = None
-                    for jb, jf in ((args.batch, args.in_flight), (args.batch, 6), (64, 4)):
+                    for jb, jf in ((args.batch, 6), (64, 4)):      # (eleven jobs of 256 in flight need 183 GB: they fit a fresh process, not always this one after the 8K legs; six measured the same or better)
                         try:
                             rj = measure(ycbcr_streams, B=jb, in_flight=jf, lf_streams=jf, consumer="none", steps=max(6, min(args.steps, 12)))
                             break
