@@ -126,3 +126,42 @@ def test_corrupted_round6_streams_fail_cleanly_or_decode(jx):
     ref = O.decode(wp).pixels("u8", 3)                                       # the decoder is still healthy afterwards
     meta, px = jx.decoder_builder().decode_with(wp, np.uint8)
     assert np.array_equal(px.reshape(ref.shape), ref)
+
+
+def _smooth(seed, h, w, c, bits):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = ((np.sin(xx / 37.0) + np.cos(yy / 23.0)) * 0.25 + 0.5) * ((1 << bits) - 1)
+    return np.clip(base[..., None] + rng.normal(0, (1 << bits) / 1024.0, (h, w, c)).astype(np.float32), 0, (1 << bits) - 1).astype(np.int32)
+
+
+def test_inverse_squeeze_steps_of_several_images_in_one_launch(jx):
+    """Batch::EnqueueModularTail: images whose inverse-transform chains have the same shape go through them together (SqueezeBatch: step k of up to 16 images in one launch),
+    others on their own — 18 squeezed Modular images of one size (two launches' worth), three of other sizes / channel counts and one without Squeeze in one batch: every
+    image as the oracle decodes it"""
+    imgs = [(_smooth(200 + i, 300, 520, 1, 16), 16, False, 1) for i in range(18)]
+    imgs += [(_smooth(300, 200, 136, 1, 16), 16, False, 1), (_smooth(301, 300, 520, 3, 8), 8, True, 1), (_smooth(302, 300, 520, 1, 16), 16, False, 2), (_smooth(303, 300, 520, 1, 16), 16, False, 0)]
+    streams = [S.encode_modular(a, bits, rct, sq) for a, bits, rct, sq in imgs]
+    b = jx.BatchDecoder(0)
+    b.add_many(streams, "uint16", 0, threads=4)
+    b.prepare(); b.decode(); b.finish()
+    for i, d in enumerate(streams):
+        ref = O.decode(d)
+        nch = 3 if imgs[i][0].shape[2] == 3 else 1
+        assert np.array_equal(b.output(i).view(np.uint16).reshape(-1), ref.pixels("u16", nch).view(np.uint16).reshape(-1)), f"image {i}"
+
+
+def test_chroma_subsampled_frames_in_one_job(jx):
+    """chroma-subsampled YCbCr frames take the plain path since round 6 (IdctSubsampledTileKernel, OutputKernel's upsampling branch): a job that mixes the subsampling modes,
+    odd sizes and a plain XYB frame on shared planes, u8 and f32 — every frame as the oracle decodes it"""
+    cases = [("420", 530, 300), ("422", 203, 139), ("440", 200, 136), ("mixed", 300, 260), ("444", 260, 300), ("420", 2100, 270), ("420", 64, 48)]
+    streams = [S.encode_ycbcr(S.synthetic_image(80 + i, w, h), sub, seed=w + h, distance=0.7) for i, (sub, w, h) in enumerate(cases)]
+    streams.append(S.encode_vardct(S.synthetic_image(99, 520, 300), seed=3, strategy_mix=2, epf_iters=1, gab=1))
+    for dtype, kind in ((np.uint8, "u8"), (np.float32, "f32")):
+        b = jx.BatchDecoder(0)
+        b.add_many(streams, np.dtype(dtype).name, 3, threads=4)
+        b.prepare(); b.decode(); b.finish()
+        for i, d in enumerate(streams):
+            ref = O.decode(d).pixels(kind, 3)
+            got = b.output(i).view(dtype).reshape(-1)
+            assert np.array_equal(got.view(np.uint8), np.ascontiguousarray(ref).reshape(-1).view(np.uint8)), f"frame {i} ({kind})"
