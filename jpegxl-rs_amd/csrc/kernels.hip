@@ -6118,7 +6118,12 @@ void LaunchLfDecode(const FrameDev* frames, int nframes, int max_lf_groups, cons
   // (+ the wave-wide decoder's second copy of the alias tables, StageCode(with_wide): 10 bytes per slot — when the plain tables fit their budget and the two together 96 KB)
   static const bool no_wide = getenv("JXL_HIP_NO_WAVE_LF") != nullptr;     // A/B: the lane-0 serial fast path
   const uint32_t wide_bytes = (!no_wide && !redo_only_launch && cfg.mod_code_bytes <= cfg.lds_code_budget && cfg.mod_code_bytes * 9 / 4 + 64 <= 96 * 1024) ? (uint32_t)cfg.mod_code_bytes * 5 / 4 + 48 : 0u;
-  const uint32_t lds_tables = kLfDecWaves * kWaveLds + tree_cap * 16 + (redo_only_launch ? 0u : (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes)) + wide_bytes;
+  // (the one-wavefront-per-stream launches of a cold pipeline / of small jobs: the wide layout alone — StageCode stages what the budget admits, the few readers of the plain layout put the
+  // entry together again (LdAliasAt).  These launches run beside the HF stage (80 KB of LDS a workgroup) and the pixel kernels of the jobs before: 40 instead of 57 KB per CU is the
+  // difference between one and three IDCT / filter workgroups next to them.  JXL_HIP_LF_WIDE_BOTH: both layouts, as the launches that also serve SIMT hand-backs keep)
+  static const bool wide_both = getenv("JXL_HIP_LF_WIDE_BOTH") != nullptr;
+  const bool wide_only = wide && wide_bytes && !wide_both;
+  const uint32_t lds_tables = kLfDecWaves * kWaveLds + tree_cap * 16 + (redo_only_launch || wide_only ? 0u : (uint32_t)std::min(cfg.lds_code_budget, cfg.mod_code_bytes)) + wide_bytes;
   // trees with the weighted predictor: its state rows (channels up to 256 wide — all but the block-info rows) in LDS, one slot per wavefront
   const uint32_t wp_base = cfg.any_wp ? (lds_tables + 15) & ~15u : 0u;
   const uint32_t lds_bytes = wp_base ? wp_base + kLfDecWaves * kWpLdsBytes : lds_tables;
@@ -6205,7 +6210,10 @@ void LaunchHfDecode(const FrameDev* frames, int nframes, int max_groups, const L
     uint32_t lpw = cfg.hf_lanes_per_wave > 0 ? (uint32_t)std::min(64, cfg.hf_lanes_per_wave) : lpw_env >= 1 && lpw_env <= 64 ? (uint32_t)lpw_env : (uint32_t)DivUp((int)lanes, 4);
     lpw = std::max(lpw, (uint32_t)DivUp((int)lanes, 16));                        // at most 16 wavefronts per workgroup
     const uint32_t threads = (uint32_t)DivUp((int)lanes, (int)lpw) * 64;
-    const uint32_t lds = kSimtCodeOff + (uint32_t)(all_lds ? code_lds : std::min(cfg.lds_code_budget, cfg.ac_code_bytes)) + (lanes + 1) * kSimtLaneBytes;
+    const uint32_t lds_need = kSimtCodeOff + (uint32_t)(all_lds ? code_lds : std::min(cfg.lds_code_budget, cfg.ac_code_bytes)) + (lanes + 1) * kSimtLaneBytes;
+    // (JXL_HIP_HF_LDS_MIN, experiments: a floor under the request — above half the CU's 160 KB no two HF workgroups share a CU)
+    static const uint32_t lds_floor = getenv("JXL_HIP_HF_LDS_MIN") ? (uint32_t)atoi(getenv("JXL_HIP_HF_LDS_MIN")) : 0u;
+    const uint32_t lds = std::min(std::max(lds_need, lds_floor), 160u * 1024 - 2048);
     static bool attr = false;
     if (!attr) {
       SetMaxDynamicLds((const void*)HfDecodeSimtKernel<true, false, false>, 160 * 1024 - 2048, "HfDecodeSimtKernel<true, false, false>");
