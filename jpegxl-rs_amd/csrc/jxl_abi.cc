@@ -146,11 +146,13 @@ JxlDecoder* JxlDecoderCreate(const JxlMemoryManager* mm) {
   d->mm = copy; d->has_mm = has; d->batch = nullptr; d->device = DefaultDevice(); d->stream = nullptr;
   d->hooks.opaque = copy.opaque; d->hooks.alloc = copy.alloc; d->hooks.free = copy.free;
   ClearState(d);
+  SchedulerNoteDecoder(+1);
   return d;
 }
 void JxlDecoderReset(JxlDecoder* d) { if (d) ClearState(d); }
 void JxlDecoderDestroy(JxlDecoder* d) {
   if (!d) return;
+  SchedulerNoteDecoder(-1);
   ClearState(d);
   if (d->stream) { (void)hipStreamSynchronize((hipStream_t)d->stream); (void)hipStreamDestroy((hipStream_t)d->stream); d->stream = nullptr; }
   JxlMemoryManager mm = d->mm; bool has = d->has_mm;

@@ -137,6 +137,7 @@ class Pipeline {
 int SchedulerDecode(int device, const uint8_t* data, size_t size, const OutputSpec& spec, void* dst, size_t dst_size, std::string* error);
 // statistics of the device's scheduler since the process started: jobs submitted, images decoded (nullptr-safe)
 void SchedulerStats(int device, int64_t* jobs, int64_t* images);
+void SchedulerNoteDecoder(int delta);   // a JxlDecoder was created (+1) / destroyed (-1): the scheduler sizes its jobs by the decoders that exist (one per calling thread in the reference crate)
 void SchedulerShutdown();      // joins the scheduler threads and frees their pipelines (tests; atexit)
 
 }  // namespace jxlhip

@@ -7,6 +7,7 @@
 // into its own buffer.  A single caller sees the latency of a one-image job on streams of the pipeline's own (never the NULL stream).
 #include "pipeline.h"
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,7 @@ bool SameSpec(const OutputSpec& a, const OutputSpec& b) {
          a.int_bits == b.int_bits && a.render_spotcolors == b.render_spotcolors;
 }
 
+std::atomic<int> g_live_decoders{0};      // JxlDecoderCreate / Destroy (SchedulerNoteDecoder)
 int EnvInt(const char* name, int def) { const char* e = getenv(name); return e && *e ? atoi(e) : def; }
 double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 bool Trace() { static const bool on = getenv("JXL_HIP_SCHED_TRACE") != nullptr; return on; }
@@ -52,11 +54,11 @@ class DeviceScheduler {
     o.timed = Trace() ? 1 : 0;
     o.wide_first = 0;
     o.small_job_frames = EnvInt("JXL_HIP_SCHED_WIDE_BELOW", 0);
-    max_job_ = std::max(1, EnvInt("JXL_HIP_SCHED_MAX_JOB", 64));
+    max_job_ = std::max(1, EnvInt("JXL_HIP_SCHED_MAX_JOB", 64)); max_job_fixed_ = getenv("JXL_HIP_SCHED_MAX_JOB") != nullptr;
     // shared planes for a few 4K frames to start with (a process that decodes one picture must not pay for gigabytes); they grow to the largest job seen whenever the pipeline
     // idles, jobs that do not fit run on arenas of their own
     o.reserve_frames = EnvInt("JXL_HIP_SCHED_RESERVE_FRAMES", 4); o.reserve_width = 3840; o.reserve_height = 2160;
-    max_jobs_ = std::max(1, EnvInt("JXL_HIP_SCHED_JOBS", 3));
+    max_jobs_ = std::max(1, EnvInt("JXL_HIP_SCHED_JOBS", 4));
     return_us_ = std::max(0, EnvInt("JXL_HIP_SCHED_RETURN_US", 25000));
     quiet_us_ = std::max(0, EnvInt("JXL_HIP_SCHED_QUIET_US", 1000)); max_wait_us_ = std::max(0, EnvInt("JXL_HIP_SCHED_MAX_WAIT_US", 8000));
     pipe_.reset(new Pipeline(device, o));
@@ -171,11 +173,17 @@ class DeviceScheduler {
         // arrived for quiet_us, after max_wait_us at the latest, or when it is full.
         // (a lone caller — nobody else inside Decode, nothing in flight whose callers could come back — does not wait for company that cannot come)
         const bool alone = callers_ <= 1 && inflight_count_ == 0;
-        if ((int)pending_.size() < max_job_ && max_wait_us_ > 0 && !alone) {
+        // Largest job: a third of the callers inside Decode right now (at least 8, at most max_job_).  Callers are synchronous — each waits for its image —, so C callers are
+        // C images in flight at most: as ONE job they pay a job's whole latency (LF, HF, pixels: ~140 ms at 64) per round; as three jobs a third apart the stages of one overlap
+        // the next one's (64 callers: 3.0-3.3 Gpixel/s with jobs of up to 64, 3.8-4.3 with jobs of up to 22, four in flight: profiles/r06_notes.md section 15).
+        // (the callers that exist = the decoders that exist: the reference crate's JxlDecoder owns one and is not shared between threads; the count of threads inside Decode
+        // dips while they copy their pixels out and allocate the next buffer — a cap that followed it measured 2.7-3.8 against 4.1-4.3 Gpixel/s for the fixed 22)
+        const int job_cap = max_job_fixed_ ? max_job_ : std::min(max_job_, std::max(8, (std::max(g_live_decoders.load(), callers_) + 2) / 3));
+        if ((int)pending_.size() < job_cap && max_wait_us_ > 0 && !alone) {
           const auto t_first = std::chrono::steady_clock::now();
           auto t_last = t_first;
           size_t seen = pending_.size();
-          while (!shutdown_ && (int)pending_.size() < max_job_) {
+          while (!shutdown_ && (int)pending_.size() < job_cap) {
             const auto now = std::chrono::steady_clock::now();
             auto deadline = std::min(t_first + std::chrono::microseconds(max_wait_us_), t_last + std::chrono::microseconds(quiet_us_));
             // the callers of a job that has just completed are on their way back (each copies its pixels out first): the first of them does not leave alone
@@ -188,7 +196,7 @@ class DeviceScheduler {
         }
         // the requests that share the first one's output format, in arrival order
         const OutputSpec spec = pending_.front()->spec;
-        for (auto it = pending_.begin(); it != pending_.end() && (int)reqs.size() < max_job_;) {
+        for (auto it = pending_.begin(); it != pending_.end() && (int)reqs.size() < job_cap;) {
           if (SameSpec((*it)->spec, spec)) { reqs.push_back(*it); it = pending_.erase(it); } else ++it;
         }
       }
@@ -238,6 +246,7 @@ class DeviceScheduler {
   std::vector<std::pair<void*, size_t>> free_staging_;
   size_t staging_held_ = 0;
   int max_job_ = 64, quiet_us_ = 1000, max_wait_us_ = 8000, max_jobs_ = 4;
+  bool max_job_fixed_ = false;            // JXL_HIP_SCHED_MAX_JOB given: no cap by the number of callers
   int inflight_count_ = 0;
   size_t expected_back_ = 0; std::chrono::steady_clock::time_point expected_until_{}; int return_us_ = 25000;
   int64_t jobs_ = 0, images_ = 0;
@@ -275,6 +284,7 @@ void SchedulerStats(int device, int64_t* jobs, int64_t* images) {
   if (device >= 0 && device < 64 && g_sched[device]) g_sched[device]->Stats(jobs, images);
 }
 
+void SchedulerNoteDecoder(int delta) { g_live_decoders.fetch_add(delta); }
 void SchedulerShutdown() {     // legal at any time: requests that have not been submitted fail ("scheduler shut down"), the ones in flight complete, their callers leave, then the schedulers go
   std::lock_guard<std::mutex> lock(g_sched_mu);
   for (auto& s : g_sched) { delete s; s = nullptr; }
