@@ -1,5 +1,5 @@
 """One prepared batch decoded a few times with nothing else on the GPU — what the PMC passes of a round profile (tools/scripts/profile_round5.sh).
-usage: one_batch_decode.py <4k|hdr8k|mod8k> <frames> <decodes>"""
+usage: one_batch_decode.py <4k|jpeg|hdr8k|mod8k> <frames> <decodes>"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,8 @@ def cached(name, fn, seed):
     d = fn(seed); open(p, "wb").write(d); return d
 if kind == "4k":
     streams, dtype, nch = bench.make_streams(min(n, 32), 3840, 2160, 1, tree_shape=int(os.environ.get("TREE_SHAPE", "0"))), "uint8", 3
+elif kind == "jpeg":
+    streams, dtype, nch = bench._pool_map(bench._make_ycbcr420, [700 + i for i in range(min(n, 8))]), "uint8", 3
 elif kind == "hdr8k":
     streams, dtype, nch = [cached("hdr8k", bench._make_8k_hdr, 6 + i) for i in range(min(n, 4))], "float32", 3
 else:
